@@ -1,0 +1,217 @@
+/*
+ * bjx.h — C ABI of libbjx_hip.so: the MI355X (gfx950) implementation of Bijectors.jl's
+ * batched transform + log-abs-det-Jacobian hot path.
+ *
+ * The reference (Bijectors.jl v0.16.2) has no FFI: its extension point is Julia multiple
+ * dispatch on `transform / logabsdetjac / with_logabsdet_jacobian / inverse`
+ * (src/interface.jl:156-218, :265-281).  Every entry below is what a Julia method
+ *     with_logabsdet_jacobian(b::<Bijector>, x::ROCArray)
+ * would `ccall`; the reference function each entry replaces is cited on the entry.
+ * The Julia-side binding is shown in INTEGRATION.md and julia/BijectorsBJX.jl.
+ *
+ * Conventions (all entries)
+ *  - Arrays are Julia column-major X[dim, batch]: `dim` is the contiguous axis, one sample
+ *    (column) = `dim` consecutive elements, leading dimension == dim.  batch may be 1 (a
+ *    Julia Vector).  All array pointers are DEVICE pointers owned by the caller; the
+ *    library never allocates or frees caller memory and allocates nothing per call (a small
+ *    scratch for reduction partials lives inside the context).
+ *  - `dt` selects Float32 / Float64 for every `void*` data/parameter pointer of the call.
+ *  - `ladj_ps`  : optional T[batch] per-sample (per-column) log|det J|   (may be NULL)
+ *    `ladj_sum` : optional double[1] sum over the batch of the above      (may be NULL)
+ *    With BJX_ACCUMULATE both are added to instead of overwritten — this is the
+ *    `with_logabsdet_jacobian!(b, x, y, logjac)` contract (src/interface.jl:212-218).
+ *    The reference's per-bijector return shape (scalar vs per-column vector,
+ *    SURVEY.md §8a') is rebuilt by the host wrapper from these two outputs.
+ *  - Calls are asynchronous on the context's HIP stream.  A context is not thread-safe;
+ *    distinct contexts are independent.  No exception crosses the ABI.
+ *  - Return value: 0 ok; <0 argument/shape error (mirrors the reference's precondition
+ *    checks: simplex.jl:30, normalise.jl:43-45, corr.jl:215-219, rational_quadratic_spline.jl:84-85);
+ *    >0 a hipError_t (or 1000+ncclResult_t).  bjx_last_error(ctx) gives the message.
+ */
+#ifndef BJX_H
+#define BJX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BJX_VERSION 100
+
+typedef struct bjx_ctx bjx_ctx;
+
+typedef enum { BJX_F32 = 0, BJX_F64 = 1 } bjx_dtype;
+
+/* error codes (<0) */
+enum {
+  BJX_OK = 0,
+  BJX_ERR_ARG = -1,       /* NULL / negative size / bad enum  (Julia: ArgumentError)      */
+  BJX_ERR_SHAPE = -2,     /* size mismatch                    (Julia: DimensionMismatch)  */
+  BJX_ERR_UNSUPPORTED = -3,
+  BJX_ERR_NOCOMM = -4     /* collective requested without bjx_comm_init                  */
+};
+
+/* flags */
+enum {
+  BJX_ACCUMULATE = 1u << 0,          /* add into ladj_ps / ladj_sum instead of overwriting   */
+  /* scale.jl:31-32: for a VECTOR-parameter Scale applied to a d x N matrix the reference
+   * returns sum_i log|a_i| (NOT multiplied by N).  With this flag the chain's `ladj_sum`
+   * reproduces that value; without it the mathematically consistent N * sum_i log|a_i| is
+   * returned.  `ladj_ps` is always the true per-sample value. */
+  BJX_REF_VECTOR_SCALE_LADJ = 1u << 1
+};
+
+/* ---------------------------------------------------------------- context */
+/* `hip_stream` is a hipStream_t (NULL = default stream).  AMDGPU.jl: AMDGPU.stream().stream  */
+int bjx_create(int device, void* hip_stream, bjx_ctx** out);
+int bjx_destroy(bjx_ctx* ctx);
+int bjx_set_stream(bjx_ctx* ctx, void* hip_stream);
+const char* bjx_last_error(bjx_ctx* ctx);
+int bjx_version(void);
+/* bytes of scratch a context holds (informational; SURVEY.md §8b "bjx_workspace_bytes") */
+size_t bjx_workspace_bytes(bjx_ctx* ctx);
+int bjx_synchronize(bjx_ctx* ctx);
+
+/* ------------------------------------------- F1: fused elementwise chains */
+/* One entry of a `ComposedFunction` chain (src/bijectors/composed.jl:4-25) after the host has
+ * walked `outer ∘ inner` into application order (ops[0] is applied first).
+ * Inverse bijectors are their own op kinds (the host maps inverse(b) -> kind). */
+typedef enum {
+  BJX_OP_EXP = 1,            /* elementwise(exp)        interface.jl:6,33; exp_log.jl:5-6     */
+  BJX_OP_LOG = 2,            /* elementwise(log)        exp_log.jl:8-9                        */
+  BJX_OP_SHIFT = 3,          /* Shift(a): a .+ x        shift.jl:14,21   (inverse: a := -a)   */
+  BJX_OP_SCALE = 4,          /* Scale(a): a .* x        scale.jl:13,26-32                     */
+  BJX_OP_SCALE_INV = 5,      /* Inverse{Scale}: inv(a) .* y          scale.jl:15-16           */
+  BJX_OP_LOGIT = 6,          /* Logit(a,b)              logit.jl:15,24-30                     */
+  BJX_OP_LOGIT_INV = 7,      /* Inverse{Logit}          logit.jl:19-21 + interface.jl:276-281 */
+  BJX_OP_LEAKY_RELU = 8,     /* LeakyReLU(alpha)        leaky_relu.jl:18-29 (inverse: 1/alpha)*/
+  BJX_OP_TRUNCATED = 9,      /* TruncatedBijector(lb,ub)          truncated.jl:15-31,51-67    */
+  BJX_OP_TRUNCATED_INV = 10, /* Inverse{TruncatedBijector}        truncated.jl:33-49,71-91    */
+  BJX_OP_SIGNFLIP = 11,      /* SignFlip                ordered.jl:3                          */
+  BJX_OP_IDENTITY = 12
+} bjx_op_kind;
+
+typedef struct {
+  int32_t kind;      /* bjx_op_kind                                                          */
+  int32_t param_len; /* 0: no parameter; 1: scalar; ==dim: one value per row                 */
+  double p0, p1;     /* host scalars used when v0/v1 == NULL (a | a,b | alpha | lb,ub)       */
+  const void* v0;    /* device T[param_len] (overrides p0) or NULL                           */
+  const void* v1;    /* device T[param_len] (overrides p1) or NULL                           */
+} bjx_op;
+
+#define BJX_MAX_OPS 8
+
+/* y = (ops[n-1] ∘ ... ∘ ops[0])(x) and the summed log|det J| in ONE pass over x.
+ * Replaces the 3+ allocating passes of SURVEY.md §3.1.  y may alias x (transform!). */
+int bjx_chain(bjx_ctx* ctx, bjx_dtype dt, const bjx_op* ops, int n_ops,
+              const void* x, void* y, void* ladj_ps, double* ladj_sum,
+              int64_t dim, int64_t batch, uint32_t flags);
+
+/* --------------------------------- F3: sequential / prefix along `dim`    */
+/* OrderedBijector, ordered.jl:24-80.  inverse=0: x1=y1, xi=x(i-1)+exp(yi); ladj[n]=sum_{i>=2} y[i,n].
+ * inverse=1: y1=x1, yi=log(xi-x(i-1)); ladj = -sum_{i>=2} y_out[i,n] (interface.jl:276-281). */
+int bjx_ordered(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out,
+                void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
+
+/* SimplexBijector, simplex.jl:28-143.  K = rows of the simplex side.
+ * inverse=0: in  X[K,N]   -> out Y[K-1,N], ladj = logabsdetjac(b, X)      (:122-143)
+ * inverse=1: in  Y[K-1,N] -> out X[K,N],   ladj = -logabsdetjac(b, X_out) (interface.jl:276-281)
+ * `out` may be NULL to compute only the log-det (logabsdetjac(b, x)); K < 2 -> BJX_ERR_SHAPE. */
+int bjx_simplex(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out,
+                void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags);
+
+/* VecCholeskyBijector, corr.jl:227-254 (+ :314-337, :370-399, :485-501), batched over samples.
+ * K x K Cholesky factor of a correlation matrix <-> vector of n = K(K-1)/2 unconstrained reals.
+ * uplo = 'U' or 'L' (corr.jl:215-219, anything else -> BJX_ERR_ARG).
+ * inverse=1: in y[n,N] -> out W[K,K,N] dense column-major factor (upper filled, lower zero for
+ *            'U'; transposed for 'L'), ladj = logJ of _inv_link_chol_lkj.
+ * inverse=0: in W[K,K,N] -> out y[n,N], ladj = -_logabsdetjac_inv_chol(y) (corr.jl:235-237).
+ * `out` may be NULL with inverse=1 to compute only logabsdetjac(inverse(b), y) (:252-254). */
+int bjx_vec_cholesky(bjx_ctx* ctx, bjx_dtype dt, int inverse, int uplo, const void* in, void* out,
+                     void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags);
+
+/* ------------------------------- F2: per-sample reduce + broadcast        */
+/* PlanarLayer, planar_layer.jl:65-127,160-185; `n_layers` stacked layers (composition
+ * layer[n_layers-1] ∘ ... ∘ layer[0]) are fused into one pass over Z.
+ * w,u: device T[dim*n_layers] (layer-major), b: device T[n_layers].
+ * inverse=0: z' = z + û tanh(wᵀz+b), ladj[n] = Σ_layers log1p(wᵀû sech²(wᵀz+b)).
+ * inverse=1: layers are undone last-to-first with find_alpha; ladj = -(forward ladj at the result). */
+int bjx_planar(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* w, const void* u,
+               const void* b, int n_layers, const void* in, void* out,
+               void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
+
+/* RadialLayer, radial_layer.jl:43-129.  alpha_, beta: device T[1]; z0: device T[dim]. */
+int bjx_radial(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* alpha_, const void* beta,
+               const void* z0, const void* in, void* out,
+               void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
+
+/* InvertibleBatchNorm in eval mode (istraining() == false), normalise.jl:41-88.
+ * b, logs, m, v: device T[dim] (channels = dim for 2-D input, :43-47). */
+int bjx_batchnorm(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* b, const void* logs,
+                  const void* m, const void* v, double eps, const void* in, void* out,
+                  void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
+
+/* ------------------------------- F4: table lookup                         */
+/* RationalQuadraticSpline with matrix parameters, rational_quadratic_spline.jl:128-367,
+ * applied to every column of X[dim,batch].  widths/heights/derivs: device T[dim, n_knots]
+ * column-major (row i of the Julia matrices = knots of dimension i).
+ * inverse=0: y = rqs_univariate, ladj[n] = Σ_i rqs_logabsdetjac (fused like rqs_forward :317-357)
+ * inverse=1: x = rqs_univariate_inverse, ladj = -(forward ladj at x). */
+int bjx_rqs(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* widths, const void* heights,
+            const void* derivs, int n_knots, const void* in, void* out,
+            void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
+
+/* The `B` constructor, rational_quadratic_spline.jl:109-123: raw_w, raw_h: T[dim,K];
+ * raw_d: T[dim,K-1]  ->  widths, heights, derivs: T[dim,K+1]. */
+int bjx_rqs_params(bjx_ctx* ctx, bjx_dtype dt, const void* raw_w, const void* raw_h,
+                   const void* raw_d, int K, int64_t dim, double B,
+                   void* widths, void* heights, void* derivs);
+
+/* ------------------------------- F5: gather / scatter wrappers            */
+/* Permute, permute.jl:152-157: out[i,n] = in[src[i],n]  (src = column index of the nonzero in
+ * row i of the permutation matrix A; 0-based).  Bit-exact data movement; log-det is 0. */
+int bjx_permute(bjx_ctx* ctx, bjx_dtype dt, const int32_t* src, const void* in, void* out,
+                int64_t dim, int64_t batch);
+
+/* Coupling with a PartitionMask, coupling.jl:125-134,206-259, for coupling laws whose
+ * parameters the Julia side has already evaluated (θ(x₂) is an arbitrary closure and cannot
+ * cross a C ABI).  idx1: int32[n1] rows that are transformed (0-based); all other rows copy
+ * through.  Affine law  y₁ = shift + scale·x₁  (θ ↦ Shift ∘ Scale):
+ * scale, shift: device T[n1, batch] (NULL = 1 / 0).  inverse=1 undoes it. */
+int bjx_coupling_affine(bjx_ctx* ctx, bjx_dtype dt, int inverse, const int32_t* idx1, int64_t n1,
+                        const void* scale, const void* shift, const void* in, void* out,
+                        void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch,
+                        uint32_t flags);
+/* Spline law (θ ↦ RationalQuadraticSpline(w,h,d)): knots T[n1, n_knots] shared over the batch. */
+int bjx_coupling_rqs(bjx_ctx* ctx, bjx_dtype dt, int inverse, const int32_t* idx1, int64_t n1,
+                     const void* widths, const void* heights, const void* derivs, int n_knots,
+                     const void* in, void* out, void* ladj_ps, double* ladj_sum,
+                     int64_t dim, int64_t batch, uint32_t flags);
+
+/* ------------------------------- multi-GPU                */
+/* RCCL communicator owned by the context (one process per GPU).  `unique_id` is the 128-byte
+ * ncclUniqueId made by bjx_comm_unique_id on rank 0 and broadcast by the host (Julia: MPI.jl
+ * or a file; Python: the torch.distributed store). */
+int bjx_comm_unique_id(void* out128);
+int bjx_comm_init(bjx_ctx* ctx, int nranks, int rank, const void* unique_id128);
+int bjx_comm_destroy(bjx_ctx* ctx);
+/* The single collective of the path: in-place sum all-reduce of the partial Σ logabsdetjac. */
+int bjx_allreduce_sum_f64(bjx_ctx* ctx, double* ptr, int64_t n);
+
+/* ------------------------------- measurement helpers                      */
+/* Counter-based (Philox4x32-10) standard-normal fill, keyed by (seed, global element index)
+ * so synthetic batches are identical for any shard count.
+ * `col0` is the global index of this shard's first column. */
+int bjx_fill_normal(bjx_ctx* ctx, bjx_dtype dt, void* out, int64_t dim, int64_t batch,
+                    int64_t col0, uint64_t seed, double mean, double std);
+/* Launch `bjx_chain` `iters` times bracketed by hipEvents on the context stream and return
+ * the average milliseconds per launch (used by bench.py for roofline.achieved). */
+int bjx_time_begin(bjx_ctx* ctx);
+int bjx_time_end(bjx_ctx* ctx, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BJX_H */

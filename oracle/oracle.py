@@ -1,0 +1,289 @@
+"""ctypes front-end of the CPU oracle (oracle/bjx_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY — see the header of bjx_oracle.cpp.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+
+Arrays use the reference's orientation: numpy arrays of shape (dim, batch) in Fortran
+(column-major) order, i.e. exactly a Julia Matrix; 1-D arrays are Julia Vectors (one sample).
+Every function returns what the corresponding reference method returns (SURVEY.md §8a').
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libbjx_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "bjx_oracle.cpp")
+    if force or not os.path.exists(_SO) or (
+        os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO)
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class Op(C.Structure):
+    """Mirror of `bjx_op` (include/bjx.h); v0/v1 are HOST pointers for the oracle."""
+
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("param_len", C.c_int32),
+        ("p0", C.c_double),
+        ("p1", C.c_double),
+        ("v0", C.c_void_p),
+        ("v1", C.c_void_p),
+    ]
+
+
+OP_EXP, OP_LOG, OP_SHIFT, OP_SCALE, OP_SCALE_INV, OP_LOGIT, OP_LOGIT_INV = 1, 2, 3, 4, 5, 6, 7
+OP_LEAKY_RELU, OP_TRUNCATED, OP_TRUNCATED_INV, OP_SIGNFLIP, OP_IDENTITY = 8, 9, 10, 11, 12
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        for suf in ("f32", "f64"):
+            for name in ("chain", "chain_fused", "find_alpha", "logistic", "log1pexp", "logcosh"):
+                getattr(_lib, f"bjo_{name}_{suf}").restype = C.c_double
+        _lib.bjo_triu1_dim_from_length.restype = C.c_int64
+        _lib.bjo_triu1_dim_from_length.argtypes = [C.c_int64]
+    return _lib
+
+
+def _suf(dt):
+    dt = np.dtype(dt)
+    if dt == np.float32:
+        return "f32", C.c_float
+    if dt == np.float64:
+        return "f64", C.c_double
+    raise TypeError(f"oracle supports float32/float64, got {dt}")
+
+
+def _f(x, dtype=None):
+    a = np.asfortranarray(np.asarray(x, dtype=dtype))
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _dims(x):
+    if x.ndim == 1:
+        return x.shape[0], 1
+    if x.ndim == 2:
+        return x.shape[0], x.shape[1]
+    raise ValueError("expected a vector or a (dim, batch) matrix")
+
+
+def make_ops(ops, dtype, keep):
+    """ops: list of (kind, p0, p1) where p0/p1 are floats or 1-D arrays (per-row)."""
+    arr = (Op * len(ops))()
+    for i, (kind, p0, p1) in enumerate(ops):
+        o = arr[i]
+        o.kind = kind
+        o.param_len = 0
+        o.p0 = 0.0
+        o.p1 = 0.0
+        o.v0 = None
+        o.v1 = None
+        for j, p in enumerate((p0, p1)):
+            if p is None:
+                continue
+            if np.ndim(p) == 0:
+                o.param_len = max(o.param_len, 1)
+                setattr(o, f"p{j}", float(p))
+            else:
+                v = np.ascontiguousarray(np.asarray(p, dtype=dtype))
+                keep.append(v)
+                o.param_len = v.shape[0]
+                setattr(o, f"v{j}", v.ctypes.data)
+        # mixed scalar/vector bounds: broadcast the scalar side
+        if o.param_len > 1:
+            for j, p in enumerate((p0, p1)):
+                if p is not None and np.ndim(p) == 0:
+                    v = np.full(o.param_len, float(p), dtype=dtype)
+                    keep.append(v)
+                    setattr(o, f"v{j}", v.ctypes.data)
+    return arr
+
+
+def chain(ops, x, fused=False):
+    """with_logabsdet_jacobian of a ComposedFunction chain (application order).  -> (y, ladj scalar)."""
+    x = _f(x)
+    suf, _ = _suf(x.dtype)
+    dim, batch = _dims(x)
+    keep = []
+    arr = make_ops(ops, x.dtype, keep)
+    y = np.empty_like(x, order="F")
+    fn = getattr(lib(), f"bjo_chain_fused_{suf}" if fused else f"bjo_chain_{suf}")
+    l = fn(arr, C.c_int(len(ops)), _p(x), _p(y), C.c_int64(dim), C.c_int64(batch))
+    return y, x.dtype.type(l) if not fused else l
+
+
+def ordered(x, inverse=False):
+    x = _f(x)
+    suf, _ = _suf(x.dtype)
+    dim, batch = _dims(x)
+    out = np.empty_like(x, order="F")
+    ladj = np.empty(batch, dtype=x.dtype)
+    getattr(lib(), f"bjo_ordered_{suf}")(C.c_int(int(inverse)), _p(x), _p(out), C.c_int64(dim), C.c_int64(batch), _p(ladj))
+    return out, (ladj if x.ndim == 2 else ladj[0])
+
+
+def simplex(x, inverse=False, transform=True):
+    """-> (out, per-column ladj).  The reference returns the SUM over columns (simplex.jl:141-143)."""
+    x = _f(x)
+    suf, _ = _suf(x.dtype)
+    rows, batch = _dims(x)
+    K = rows + 1 if inverse else rows
+    orow = K if inverse else K - 1
+    out = np.empty((orow, batch) if x.ndim == 2 else (orow,), dtype=x.dtype, order="F") if transform else None
+    ladj = np.empty(batch, dtype=x.dtype)
+    getattr(lib(), f"bjo_simplex_{suf}")(C.c_int(int(inverse)), _p(x), _p(out), C.c_int64(K), C.c_int64(batch), _p(ladj))
+    return out, ladj
+
+
+def vec_cholesky(x, inverse=False, uplo="U", transform=True):
+    """inverse: y[n(,N)] -> W[K,K(,N)], logJ;  forward: W -> y, ladj.  Per-sample ladj vector."""
+    x = _f(x)
+    suf, _ = _suf(x.dtype)
+    if inverse:
+        nv = x.shape[0]
+        batch = 1 if x.ndim == 1 else x.shape[1]
+        K = int(lib().bjo_triu1_dim_from_length(nv))
+        out = np.empty((K, K, batch) if x.ndim == 2 else (K, K), dtype=x.dtype, order="F") if transform else None
+    else:
+        K = x.shape[0]
+        batch = 1 if x.ndim == 2 else x.shape[2]
+        nv = K * (K - 1) // 2
+        out = np.empty((nv, batch) if x.ndim == 3 else (nv,), dtype=x.dtype, order="F")
+    ladj = np.empty(batch, dtype=x.dtype)
+    getattr(lib(), f"bjo_vec_cholesky_{suf}")(C.c_int(int(inverse)), C.c_int(ord(uplo)), _p(x), _p(out), C.c_int64(K), C.c_int64(batch), _p(ladj))
+    return out, ladj
+
+
+def planar(w, u, b, x, inverse=False):
+    """w,u: (dim, n_layers) or (dim,), b: (n_layers,) or scalar.  -> (out, per-column ladj)."""
+    x = _f(x)
+    suf, ct = _suf(x.dtype)
+    dim, batch = _dims(x)
+    w = _f(np.asarray(w, dtype=x.dtype).reshape(dim, -1))
+    u = _f(np.asarray(u, dtype=x.dtype).reshape(dim, -1))
+    b = np.ascontiguousarray(np.asarray(b, dtype=x.dtype).reshape(-1))
+    nl = w.shape[1]
+    out = np.empty_like(x, order="F")
+    ladj = np.empty(batch, dtype=x.dtype)
+    getattr(lib(), f"bjo_planar_{suf}")(C.c_int(int(inverse)), _p(w), _p(u), _p(b), C.c_int(nl), _p(x), _p(out), C.c_int64(dim), C.c_int64(batch), _p(ladj))
+    return out, ladj
+
+
+def find_alpha(wt_y, wt_u_hat, b, dtype=np.float64):
+    suf, ct = _suf(dtype)
+    return getattr(lib(), f"bjo_find_alpha_{suf}")(ct(wt_y), ct(wt_u_hat), ct(b))
+
+
+def radial(alpha_, beta, z0, x, inverse=False):
+    x = _f(x)
+    suf, ct = _suf(x.dtype)
+    dim, batch = _dims(x)
+    z0 = np.ascontiguousarray(np.asarray(z0, dtype=x.dtype))
+    out = np.empty_like(x, order="F")
+    ladj = np.empty(batch, dtype=x.dtype)
+    getattr(lib(), f"bjo_radial_{suf}")(C.c_int(int(inverse)), ct(float(alpha_)), ct(float(beta)), _p(z0), _p(x), _p(out), C.c_int64(dim), C.c_int64(batch), _p(ladj))
+    return out, ladj
+
+
+def batchnorm(b, logs, m, v, eps, x, inverse=False):
+    x = _f(x)
+    suf, ct = _suf(x.dtype)
+    dim, batch = _dims(x)
+    ps = [np.ascontiguousarray(np.asarray(p, dtype=x.dtype)) for p in (b, logs, m, v)]
+    out = np.empty_like(x, order="F")
+    ladj = np.empty(batch, dtype=x.dtype)
+    getattr(lib(), f"bjo_batchnorm_{suf}")(C.c_int(int(inverse)), *[_p(p) for p in ps], ct(float(eps)), _p(x), _p(out), C.c_int64(dim), C.c_int64(batch), _p(ladj))
+    return out, ladj
+
+
+def rqs(widths, heights, derivs, x, inverse=False):
+    """knot matrices (dim, K+1) Fortran order; x (dim, batch) or (dim,).  -> (out, per-column ladj)."""
+    x = _f(x)
+    suf, _ = _suf(x.dtype)
+    dim, batch = _dims(x)
+    w, h, d = (_f(np.asarray(a, dtype=x.dtype).reshape(dim, -1)) for a in (widths, heights, derivs))
+    out = np.empty_like(x, order="F")
+    ladj = np.empty(batch, dtype=x.dtype)
+    getattr(lib(), f"bjo_rqs_{suf}")(C.c_int(int(inverse)), _p(w), _p(h), _p(d), C.c_int64(w.shape[1]), _p(x), _p(out), C.c_int64(dim), C.c_int64(batch), _p(ladj))
+    return out, ladj
+
+
+def rqs_params(raw_w, raw_h, raw_d, B):
+    raw_w = _f(raw_w)
+    suf, ct = _suf(raw_w.dtype)
+    dim, K = raw_w.shape
+    raw_h = _f(np.asarray(raw_h, dtype=raw_w.dtype))
+    raw_d = _f(np.asarray(raw_d, dtype=raw_w.dtype))
+    w, h, d = (np.empty((dim, K + 1), dtype=raw_w.dtype, order="F") for _ in range(3))
+    getattr(lib(), f"bjo_rqs_params_{suf}")(_p(raw_w), _p(raw_h), _p(raw_d), C.c_int64(K), C.c_int64(dim), ct(float(B)), _p(w), _p(h), _p(d))
+    return w, h, d
+
+
+def permute(src, x):
+    x = _f(x)
+    suf, _ = _suf(x.dtype)
+    dim, batch = _dims(x)
+    src = np.ascontiguousarray(np.asarray(src, dtype=np.int32))
+    out = np.empty_like(x, order="F")
+    getattr(lib(), f"bjo_permute_{suf}")(_p(src), _p(x), _p(out), C.c_int64(dim), C.c_int64(batch))
+    return out
+
+
+def coupling_affine(idx1, scale, shift, x, inverse=False):
+    x = _f(x)
+    suf, _ = _suf(x.dtype)
+    dim, batch = _dims(x)
+    idx1 = np.ascontiguousarray(np.asarray(idx1, dtype=np.int32))
+    s = _f(np.asarray(scale, dtype=x.dtype)) if scale is not None else None
+    t = _f(np.asarray(shift, dtype=x.dtype)) if shift is not None else None
+    out = np.empty_like(x, order="F")
+    ladj = np.empty(batch, dtype=x.dtype)
+    getattr(lib(), f"bjo_coupling_affine_{suf}")(C.c_int(int(inverse)), _p(idx1), C.c_int64(len(idx1)), _p(s), _p(t), _p(x), _p(out), C.c_int64(dim), C.c_int64(batch), _p(ladj))
+    return out, ladj
+
+
+def coupling_rqs(idx1, widths, heights, derivs, x, inverse=False):
+    x = _f(x)
+    suf, _ = _suf(x.dtype)
+    dim, batch = _dims(x)
+    idx1 = np.ascontiguousarray(np.asarray(idx1, dtype=np.int32))
+    n1 = len(idx1)
+    w, h, d = (_f(np.asarray(a, dtype=x.dtype).reshape(n1, -1)) for a in (widths, heights, derivs))
+    out = np.empty_like(x, order="F")
+    ladj = np.empty(batch, dtype=x.dtype)
+    getattr(lib(), f"bjo_coupling_rqs_{suf}")(C.c_int(int(inverse)), _p(idx1), C.c_int64(n1), _p(w), _p(h), _p(d), C.c_int64(w.shape[1]), _p(x), _p(out), C.c_int64(dim), C.c_int64(batch), _p(ladj))
+    return out, ladj
+
+
+def logistic(x, dtype=np.float64):
+    suf, ct = _suf(dtype)
+    return getattr(lib(), f"bjo_logistic_{suf}")(ct(x))
+
+
+def log1pexp(x, dtype=np.float64):
+    suf, ct = _suf(dtype)
+    return getattr(lib(), f"bjo_log1pexp_{suf}")(ct(x))
+
+
+def logcosh(x, dtype=np.float64):
+    suf, ct = _suf(dtype)
+    return getattr(lib(), f"bjo_logcosh_{suf}")(ct(x))

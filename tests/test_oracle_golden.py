@@ -1,0 +1,362 @@
+"""Pins the CPU oracle against the reference's own golden vectors and property tests.
+
+Sources (paths relative to /root/reference, Bijectors.jl v0.16.2; table in SURVEY.md §8c).
+The reference is pure Julia and cannot run in this image; these are the values its docstrings
+and tests hold for the hot path, plus its generic `test_bijector` properties
+(test/bijectors/utils.jl:7-91) re-expressed with finite-difference Jacobians.
+"""
+import itertools
+import math
+
+import numpy as np
+import pytest
+
+E = math.e
+
+
+def _jac_logabsdet(f, x, h=1e-6):
+    """log|det J| of f at x by central differences (square Jacobian), float64."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.size
+    J = np.zeros((f(x).size, n))
+    for i in range(n):
+        d = np.zeros(n)
+        d[i] = h
+        J[:, i] = (f(x + d) - f(x - d)) / (2 * h)
+    return np.linalg.slogdet(J)[1]
+
+
+# ------------------------------------------------------------------ golden values
+def test_elementwise_exp_docstring(orc):
+    # src/interface.jl:29-30
+    y, l = orc.chain([(orc.OP_EXP, None, None)], np.array([1.0, 2.0, 3.0]))
+    assert y.tolist() == [2.718281828459045, 7.38905609893065, 20.085536923187668]
+    assert l == 6.0
+
+
+def test_elementwise_log_lognormal(orc):
+    # README.md:17-28 ; src/Bijectors.jl:244-246
+    y, l = orc.chain([(orc.OP_LOG, None, None)], np.array([0.6471106974390148]))
+    assert y[0] == pytest.approx(-0.43523790570180304, abs=1e-15)
+    assert l == pytest.approx(0.43523790570180304, abs=1e-15)
+    _, l = orc.chain([(orc.OP_LOG, None, None)], np.array([E]))
+    assert l == pytest.approx(-1.0, abs=1e-15)
+
+
+def test_named_stacked_log_values(orc):
+    # src/bijectors/named_stacked.jl:33-36 (log on a=1.0, b=2.0)
+    y, l = orc.chain([(orc.OP_LOG, None, None)], np.array([1.0, 2.0]))
+    assert y.tolist() == [0.0, 0.6931471805599453]
+    assert l == -0.6931471805599453
+
+
+def test_truncate_untruncate_docstrings(orc):
+    # src/vector/interface.jl:98-101: Truncate(0,1) (inverse link) at 1.0
+    x, l = orc.chain([(orc.OP_TRUNCATED_INV, 0.0, 1.0)], np.array([1.0]))
+    assert x[0] == pytest.approx(0.7310585786300049, abs=1e-15)
+    assert l == pytest.approx(-1.6265233750364456, abs=1e-15)
+    # src/vector/interface.jl:129: Untruncate(0,1) at 0.5
+    y, l = orc.chain([(orc.OP_TRUNCATED, 0.0, 1.0)], np.array([0.5]))
+    assert y[0] == 0.0
+    assert l == pytest.approx(1.3862943611198906, abs=1e-15)
+
+
+def test_simplex_invlink_saturation(orc):
+    # test/legacy_interface.jl:285 (needs the guarded logistic)
+    x, _ = orc.simplex(np.array([-1000.0, -1000.0]), inverse=True)
+    np.testing.assert_allclose(x, [0.0, 0.0, 1.0], atol=1e-9)
+
+
+def test_simplex_logpdf_with_trans_value(orc):
+    # test/legacy_interface.jl:289: logpdf_with_trans(Dirichlet(1,1,1), invlink(d,[-1,-2]), true)
+    x, l = orc.simplex(np.array([-1.0, -2.0]), inverse=True)
+    np.testing.assert_allclose(x, [0.15536240349696342, 0.1006832695529001, 0.7439543269501365], atol=1e-15)
+    _, lf = orc.simplex(x)
+    assert lf[0] == pytest.approx(4.45354607314081, abs=1e-12)
+    assert l[0] == pytest.approx(-4.45354607314081, abs=1e-12)
+    # Dirichlet(1,1,1) logpdf = log Γ(3) = log 2 ; with_trans subtracts the forward ladj
+    assert math.log(2.0) - lf[0] == pytest.approx(-3.760398892580863, abs=1e-9)
+
+
+def test_simplex_matrix_columns_sum_to_one(orc):
+    # test/legacy_interface.jl:275-279
+    x = np.array([[-2.72689, -2.92751, 1.63114, -1.62054, 0.0], [-1.24249, 2.58902, -3.73043, -3.53685, 0.0]]).T
+    X, _ = orc.simplex(np.asfortranarray(x), inverse=True)
+    assert X.shape == (6, 2)
+    assert np.all(X.sum(axis=0) == 1.0)
+
+
+def test_veccorr_docstring_pins_link_chol(orc):
+    # src/bijectors/corr.jl:113-122 (input printed with 6 digits -> 6e-7)
+    X = np.array([[1.0, -0.705273, -0.348638], [-0.705273, 1.0, 0.0534538], [-0.348638, 0.0534538, 1.0]])
+    U = np.linalg.cholesky(X).T
+    y, _ = orc.vec_cholesky(U, inverse=False, uplo="U")
+    np.testing.assert_allclose(y, [-0.8777149781928181, -0.3638927608636788, -0.29813769428942216], atol=2e-6)
+    # 'L' mode goes through transpose_eager (corr.jl:337)
+    yl, _ = orc.vec_cholesky(np.ascontiguousarray(U.T), inverse=False, uplo="L")
+    np.testing.assert_array_equal(y, yl)
+
+
+def test_vec_cholesky_consistency_and_roundtrip(orc):
+    # corr.jl:370-399 vs :485-501 ; roundtrip test/bijectors/corr.jl:46-64
+    rng = np.random.default_rng(3)
+    for K in (2, 3, 5, 8):
+        y = rng.normal(size=K * (K - 1) // 2) * 0.7
+        W, lj = orc.vec_cholesky(y, inverse=True)
+        _, lj2 = orc.vec_cholesky(y, inverse=True, transform=False)
+        assert lj[0] == pytest.approx(lj2[0], rel=1e-13)
+        np.testing.assert_allclose(np.linalg.norm(W, axis=0), 1.0, atol=1e-14)
+        assert np.all(np.tril(W, -1) == 0)
+        y2, lf = orc.vec_cholesky(W, inverse=False)
+        np.testing.assert_allclose(y2, y, atol=1e-12)
+        assert lf[0] == pytest.approx(-lj[0], rel=1e-10)
+        WL, _ = orc.vec_cholesky(y, inverse=True, uplo="L")
+        np.testing.assert_array_equal(WL, W.T)
+
+
+def test_vec_cholesky_logjac_vs_numeric_jacobian(orc):
+    # free parameters of a K=4 factor: strict upper triangle of W (unit-norm columns)
+    K = 4
+    rng = np.random.default_rng(5)
+    y = rng.normal(size=6) * 0.5
+    iu = np.triu_indices(K, 1)
+
+    def f(v):
+        W, _ = orc.vec_cholesky(v, inverse=True)
+        return W[iu]
+
+    _, lj = orc.vec_cholesky(y, inverse=True)
+    assert _jac_logabsdet(f, y) == pytest.approx(lj[0], abs=1e-7)
+
+
+def test_find_alpha_sweep_and_value(orc):
+    # test/normalising_flows.jl:47-70
+    for wt_y, wu, b in itertools.product(
+        (-20.3, -3, -1.5, 0.0, 5, 7.25, 12.3), (-1, -0.5, -1e-20, 0, 1e-20, 3, 11 / 3, 17.2), (-19.3, -8 / 3, -1, 0.0, 0.5, 3, 4.3)
+    ):
+        a = orc.find_alpha(wt_y, wu, b)
+        res = a + wu * math.tanh(a + b)
+        if wt_y == 0.0:
+            assert abs(res - wt_y) <= 1e-14
+        else:
+            assert res == pytest.approx(wt_y, rel=1.5e-8)
+    a = orc.find_alpha(0.8845640339582252, 0.8296950433716855, -1e8)
+    assert a == pytest.approx(0.8845640339582252 + 0.8296950433716855, rel=1.5e-8)
+
+
+def test_coupling_golden(orc):
+    # src/bijectors/coupling.jl:147-172 ; test/bijectors/coupling.jl:18-56  (mask(3,[1],[2]))
+    x = np.array([1.0, 2.0, 3.0])
+    y, l = orc.coupling_affine([0], None, np.array([[x[1]]]), x)  # θ = x2 -> Shift(x2[1])
+    assert y.tolist() == [3.0, 2.0, 3.0] and l[0] == 0.0
+    xb, lb = orc.coupling_affine([0], None, np.array([[x[1]]]), y, inverse=True)
+    assert xb.tolist() == x.tolist() and lb[0] == 0.0
+    for x, yy in (([-1.0, -2.0, -3.0], [2.0, -2.0, -3.0]), ([1.0, 2.0, 3.0], [2.0, 2.0, 3.0])):
+        x = np.array(x)
+        y, l = orc.coupling_affine([0], np.array([[x[1]]]), None, x)  # θ -> Scale(x2[1])
+        assert y.tolist() == yy
+        assert l[0] == pytest.approx(math.log(2.0), abs=1e-15)
+
+
+def test_stacked_values_via_chains(orc):
+    # test/bijectors/stacked.jl:100-108: Stacked(exp, log, Shift(5)) on ones(3) -> [e, 0, 6]
+    assert orc.chain([(orc.OP_EXP, None, None)], np.ones(1))[0][0] == E
+    assert orc.chain([(orc.OP_LOG, None, None)], np.ones(1))[0][0] == 0.0
+    assert orc.chain([(orc.OP_SHIFT, 5.0, None)], np.ones(1))[0][0] == 6.0
+
+
+def test_permute_exact(orc):
+    # test/bijectors/permute.jl:23-64: Permute([2,1,3]) maps [1,2,3] -> [2,1,3]; exact round trip
+    src = [1, 0, 2]
+    x = np.array([1.0, 2.0, 3.0])
+    y = orc.permute(src, x)
+    assert y.tolist() == [2.0, 1.0, 3.0]
+    assert orc.permute(np.argsort(src), y).tolist() == x.tolist()
+
+
+def test_rqs_identity_outside_and_knot_ends(orc):
+    # test/bijectors/rational_quadratic_spline.jl:17-35,47-61
+    rng = np.random.default_rng(0)
+    d, K, B = 2, 3, 2.0
+    w, h, dv = orc.rqs_params(rng.normal(size=(d, K)), rng.normal(size=(d, K)), rng.normal(size=(d, K - 1)), B)
+    np.testing.assert_allclose(w[:, 0], -B)
+    np.testing.assert_allclose(w[:, -1], B, atol=1e-15)
+    assert np.all(dv[:, 0] == 1.0) and np.all(dv[:, -1] == 1.0)
+    for xv in (5.0, -5.0):
+        x = np.full(d, xv)
+        y, l = orc.rqs(w, h, dv, x)
+        assert y.tolist() == x.tolist() and l[0] == 0.0
+        xi, li = orc.rqs(w, h, dv, x, inverse=True)
+        assert xi.tolist() == x.tolist() and li[0] == 0.0
+
+
+def test_logexpfunctions_guards(orc):
+    assert orc.logistic(-1000.0) == 0.0 and orc.logistic(40.0) == 1.0
+    assert orc.logistic(-110.0, np.float32) == 0.0 and orc.logistic(17.0, np.float32) == 1.0
+    for x in (-50.0, -5.0, 0.3, 10.0, 20.0, 40.0):
+        assert orc.log1pexp(x) == pytest.approx(np.logaddexp(0.0, x), rel=1e-15)
+        assert orc.logcosh(x) == pytest.approx(abs(x) + math.log1p(math.exp(-2 * abs(x))) - math.log(2), rel=1e-14, abs=1e-16)
+
+
+# ------------------------------------------------------------------ test_bijector properties
+def _check_props(fwd, inv, x, dense_jac=True, tol=1e-7):
+    """test/bijectors/utils.jl:43-62: roundtrip, ladj vs Jacobian, ladj(inv) == -ladj(fwd)."""
+    y, l = fwd(x)
+    xb, lb = inv(y)
+    np.testing.assert_allclose(xb, x, rtol=1e-9, atol=1e-10)
+    assert np.sum(lb) == pytest.approx(-np.sum(l), rel=1e-9, abs=1e-10)
+    if dense_jac:
+        assert _jac_logabsdet(lambda v: fwd(v)[0], x) == pytest.approx(float(np.sum(l)), abs=tol)
+
+
+@pytest.mark.parametrize(
+    "ops_f,ops_i,gen",
+    [
+        ("exp", "log", lambda r: r.normal(size=4)),
+        ("logit", "logit_inv", lambda r: r.uniform(-0.9, 1.9, size=4)),
+        ("leaky", "leaky_inv", lambda r: r.normal(size=5)),
+        ("trunc_both", "trunc_both_inv", lambda r: r.uniform(0.1, 1.9, size=4)),
+        ("trunc_lo", "trunc_lo_inv", lambda r: r.uniform(0.1, 4.0, size=4)),
+        ("trunc_up", "trunc_up_inv", lambda r: r.uniform(-4, 1.9, size=4)),
+        ("affexp", "affexp_inv", lambda r: r.normal(size=4)),
+    ],
+)
+def test_elementwise_properties(orc, ops_f, ops_i, gen):
+    o = orc
+    a_vec = np.array([0.5, 1.5, -2.0, 0.7])
+    table = {
+        "exp": [(o.OP_EXP, None, None)], "log": [(o.OP_LOG, None, None)],
+        "logit": [(o.OP_LOGIT, -1.0, 2.0)], "logit_inv": [(o.OP_LOGIT_INV, -1.0, 2.0)],
+        "leaky": [(o.OP_LEAKY_RELU, 0.1, None)], "leaky_inv": [(o.OP_LEAKY_RELU, 1 / 0.1, None)],
+        "trunc_both": [(o.OP_TRUNCATED, 0.0, 2.0)], "trunc_both_inv": [(o.OP_TRUNCATED_INV, 0.0, 2.0)],
+        "trunc_lo": [(o.OP_TRUNCATED, 0.0, np.inf)], "trunc_lo_inv": [(o.OP_TRUNCATED_INV, 0.0, np.inf)],
+        "trunc_up": [(o.OP_TRUNCATED, -np.inf, 2.0)], "trunc_up_inv": [(o.OP_TRUNCATED_INV, -np.inf, 2.0)],
+        # exp ∘ Shift(b) ∘ Scale(a): application order Scale, Shift, Exp
+        "affexp": [(o.OP_SCALE, a_vec, None), (o.OP_SHIFT, 0.1, None), (o.OP_EXP, None, None)],
+        "affexp_inv": [(o.OP_LOG, None, None), (o.OP_SHIFT, -0.1, None), (o.OP_SCALE_INV, a_vec, None)],
+    }
+    x = gen(np.random.default_rng(1))
+    _check_props(lambda v: o.chain(table[ops_f], v), lambda v: o.chain(table[ops_i], v), x)
+
+
+def test_scale_ladj_quirk(orc):
+    # scale.jl:26-32: scalar a -> log|a| * length(x); vector a -> sum(log|a_i|) even for a matrix
+    x = np.asfortranarray(np.random.default_rng(0).normal(size=(3, 5)))
+    _, l = orc.chain([(orc.OP_SCALE, -2.0, None)], x)
+    assert l == pytest.approx(math.log(2.0) * 15)
+    a = np.array([0.5, -3.0, 2.0])
+    _, l = orc.chain([(orc.OP_SCALE, a, None)], x)
+    assert l == pytest.approx(np.sum(np.log(np.abs(a))))
+    _, l = orc.chain([(orc.OP_SHIFT, a, None)], x)
+    assert l == 0.0
+
+
+def test_leaky_relu_values(orc):
+    # test/bijectors/leaky_relu.jl:6-50
+    for dt in (np.float32, np.float64):
+        y, l = orc.chain([(orc.OP_LEAKY_RELU, 0.1, None)], np.array([-1.0, 1.0], dtype=dt))
+        assert y.dtype == dt
+        np.testing.assert_allclose(y, [-0.1, 1.0], rtol=1e-7)
+        assert l == pytest.approx(math.log(0.1), rel=1e-6)
+
+
+def test_ordered_properties(orc):
+    # test/bijectors/ordered.jl:25-38
+    rng = np.random.default_rng(2)
+    y = np.asfortranarray(rng.normal(size=(5, 4)))
+    x, l = orc.ordered(y)
+    assert np.all(np.diff(x, axis=0) > 0)
+    np.testing.assert_allclose(l, y[1:].sum(axis=0), rtol=1e-14)
+    yb, lb = orc.ordered(x, inverse=True)
+    np.testing.assert_allclose(yb, y, atol=1e-12)
+    np.testing.assert_allclose(lb, -l, atol=1e-12)
+    v = y[:, 0].copy()
+    assert _jac_logabsdet(lambda t: orc.ordered(t)[0], v) == pytest.approx(float(orc.ordered(v)[1]), abs=1e-7)
+    one = np.array([0.3])
+    assert orc.ordered(one)[0].tolist() == [0.3]
+
+
+def test_simplex_properties(orc):
+    # test/bijectors/simplex.jl:1-11, legacy_interface.jl:300-319 (Jacobian consistency)
+    rng = np.random.default_rng(4)
+    K = 5
+    x = rng.dirichlet(np.ones(K))
+    y, l = orc.simplex(x)
+    xb, lb = orc.simplex(y, inverse=True)
+    np.testing.assert_allclose(xb, x, atol=1e-12)
+    assert lb[0] == pytest.approx(-l[0], rel=1e-10)
+    # square Jacobian on the first K-1 coordinates (x_K = 1 - sum)
+    def f(v):
+        full = np.append(v, 1.0 - v.sum())
+        return orc.simplex(full)[0]
+    assert _jac_logabsdet(f, x[:-1], h=1e-7) == pytest.approx(l[0], abs=1e-5)
+
+
+def test_flow_layers_logdet_vs_jacobian(orc):
+    # test/normalising_flows.jl:7-35,74-84 (2 x 20 batches, per-column Jacobians)
+    rng = np.random.default_rng(6)
+    d = 2
+    Z = np.asfortranarray(rng.normal(size=(d, 20)))
+    w, u, b = rng.normal(size=d), rng.normal(size=d), rng.normal()
+    out, l = orc.planar(w, u, [b], Z)
+    for n in range(20):
+        z = Z[:, n].copy()
+        assert _jac_logabsdet(lambda t: orc.planar(w, u, [b], t)[0], z) == pytest.approx(l[n], abs=1e-7)
+    a_, be, z0 = rng.normal(), rng.normal(), rng.normal(size=d)
+    out, l = orc.radial(a_, be, z0, Z)
+    for n in range(20):
+        z = Z[:, n].copy()
+        assert _jac_logabsdet(lambda t: orc.radial(a_, be, z0, t)[0], z) == pytest.approx(l[n], abs=1e-7)
+    bb, logs, m, v = rng.normal(size=d), rng.normal(size=d) * 0.3, rng.normal(size=d), rng.uniform(0.5, 2, size=d)
+    out, l = orc.batchnorm(bb, logs, m, v, 1e-5, Z)
+    for n in range(3):
+        z = Z[:, n].copy()
+        assert _jac_logabsdet(lambda t: orc.batchnorm(bb, logs, m, v, 1e-5, t)[0], z) == pytest.approx(l[n], abs=1e-7)
+    xb, lb = orc.batchnorm(bb, logs, m, v, 1e-5, out, inverse=True)
+    np.testing.assert_allclose(xb, Z, atol=1e-12)
+    np.testing.assert_allclose(lb, -l, atol=1e-13)
+
+
+def test_flow_layers_inverse_roundtrip(orc):
+    # test/normalising_flows.jl:37-42,86-91 (10 x 100)
+    rng = np.random.default_rng(7)
+    d = 10
+    Z = np.asfortranarray(np.ones((d, 100)) + 0.1 * rng.normal(size=(d, 100)))
+    w, u, b = rng.normal(size=(d, 3)), rng.normal(size=(d, 3)), rng.normal(size=3)
+    Y, l = orc.planar(w, u, b, Z)
+    Zb, lb = orc.planar(w, u, b, Y, inverse=True)
+    np.testing.assert_allclose(Zb, Z, atol=1e-9)
+    np.testing.assert_allclose(lb, -l, atol=1e-9)
+    a_, be, z0 = rng.normal(), rng.normal(), rng.normal(size=d)
+    Y, l = orc.radial(a_, be, z0, Z)
+    Zb, lb = orc.radial(a_, be, z0, Y, inverse=True)
+    np.testing.assert_allclose(Zb, Z, atol=1e-9)
+    np.testing.assert_allclose(lb, -l, atol=1e-9)
+
+
+def test_rqs_properties(orc):
+    # test/bijectors/rational_quadratic_spline.jl:17-104
+    rng = np.random.default_rng(8)
+    d, K, B = 3, 8, 3.0
+    w, h, dv = orc.rqs_params(rng.normal(size=(d, K)), rng.normal(size=(d, K)), rng.normal(size=(d, K - 1)), B)
+    assert np.all(np.diff(w, axis=1) > 0) and np.all(np.diff(h, axis=1) > 0)
+    X = np.asfortranarray(rng.uniform(-2.9, 2.9, size=(d, 50)))
+    Y, l = orc.rqs(w, h, dv, X)
+    Xb, lb = orc.rqs(w, h, dv, Y, inverse=True)
+    np.testing.assert_allclose(Xb, X, atol=1e-10)
+    np.testing.assert_allclose(lb, -l, atol=1e-9)
+    assert np.all(np.abs(Y) < B)
+    x = X[:, 0].copy()
+    assert _jac_logabsdet(lambda t: orc.rqs(w, h, dv, t)[0], x, h=1e-7) == pytest.approx(l[0], abs=1e-5)
+    # monotone
+    xs = np.linspace(-3.5, 3.5, 200)
+    ys = np.array([orc.rqs(w, h, dv, np.full(d, t))[0] for t in xs])
+    assert np.all(np.diff(ys, axis=0) > 0)
+
+
+def test_float32_type_preservation(orc):
+    # test/bijectors/utils.jl:85-90
+    x = np.random.default_rng(9).normal(size=(4, 3)).astype(np.float32, order="F")
+    for ops in ([(orc.OP_EXP, None, None)], [(orc.OP_SCALE, 0.5, None), (orc.OP_SHIFT, 0.1, None), (orc.OP_EXP, None, None)]):
+        y, l = orc.chain(ops, x)
+        assert y.dtype == np.float32 and isinstance(l, np.float32)
