@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the batched transform + log-abs-det-Jacobian hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5a|c5b]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = ONE pass of the hot path over one batch of synthetic input that is already resident in
+HBM.  Default workload = BASELINE.json configs[1] ("c2"): with_logabsdet_jacobian of
+exp ∘ Shift(b) ∘ Scale(a), Float32, dim = 64, batch = 2^24 PER GPU (weak scaling: every rank
+owns an independent column block; the only collective is the 8-byte all-reduce of Σ logabsdetjac).
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (algorithmic
+bytes / HIP-event time of the dominant kernel vs the 8 TB/s HBM peak) and `cpu_baseline`
+(the CPU oracle = a port of the reference algorithm, timed on the host cores of the same box on a
+bounded sample of the same workload).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md:35)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--workload", default="c2", choices=["c2", "c2v", "c3", "c4", "c5a", "c5b"])
+    p.add_argument("--log2-batch", type=int, default=None, help="override the per-GPU batch (testing)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-log2-batch", type=int, default=None)
+    return p.parse_args()
+
+
+def colmajor_empty(torch, rows, batch, dtype, device):
+    return torch.empty((batch, rows), dtype=dtype, device=device).T
+
+
+def fill_normal(bj, torch, t, col0, seed, mean=0.0, std=1.0):
+    """Counter-based N(mean, std) fill keyed by the GLOBAL element index -> shard-count invariant."""
+    L = bj._lib
+    ctx = bj.context(t.device)
+    rows, batch = (t.shape[0], t.shape[1]) if t.dim() == 2 else (t.shape[0], 1)
+    dt = L.BJX_F32 if t.dtype == torch.float32 else L.BJX_F64
+    rc = L.load().bjx_fill_normal(ctx.h, dt, t.data_ptr(), rows, batch, col0, seed, mean, std)
+    L.check(ctx.h, rc, "bjx_fill_normal")
+
+
+# ---------------------------------------------------------------------------------- workloads
+def make_workload(name, bj, torch, device, rank, world, log2_batch):
+    """-> dict(step=callable, samples=int per rank, bytes_per_sample=float, label=str, kernel=str, dtype=str, cfg=dict)"""
+    f32 = torch.float32
+    if name in ("c2", "c2v"):
+        dim, lb = 64, (24 if log2_batch is None else log2_batch)
+        N = 1 << lb
+        x = colmajor_empty(torch, dim, N, f32, device)
+        y = colmajor_empty(torch, dim, N, f32, device)
+        fill_normal(bj, torch, x, rank * N, seed=0)
+        if name == "c2":
+            b = bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5)
+        else:  # per-row vector parameters
+            b = bj.elementwise(bj.exp) @ bj.Shift(torch.full((dim,), 0.1, device=device)) @ bj.Scale(torch.linspace(0.5, 1.5, dim, device=device))
+
+        def step():
+            return bj.shard.with_logabsdet_jacobian_sharded(b, x, out=y, per_sample=False)[2]
+
+        return dict(step=step, samples=N, bytes_per_sample=2 * dim * 4, kernel="chain_flat_kernel", dtype="f32",
+                    label=f"with_logabsdet_jacobian(exp∘Shift∘Scale) Float32 dim={dim} batch=2^{lb}/GPU",
+                    cfg={"workload": "Composed(Shift,Scale,Exp) fused fwd+logabsdetjac (BASELINE configs[1])", "dim": dim,
+                         "batch_per_gpu": N, "params": "scalar" if name == "c2" else "per-row vectors"})
+    if name == "c3":
+        dim, K, lb = 32, 16, (22 if log2_batch is None else log2_batch)
+        N = 1 << lb
+        x = colmajor_empty(torch, dim, N, f32, device)
+        y = colmajor_empty(torch, dim, N, f32, device)
+        xb = colmajor_empty(torch, dim, N, f32, device)
+        fill_normal(bj, torch, x, rank * N, seed=0)
+        raw = [colmajor_empty(torch, dim, k, f32, device) for k in (K, K, K - 1)]
+        for i, r in enumerate(raw):
+            fill_normal(bj, torch, r, 0, seed=100 + i)
+        b = bj.RationalQuadraticSpline(raw[0], raw[1], raw[2], 3.0)
+        ib = bj.inverse(b)
+
+        def step():
+            y_, _, s1 = bj.shard.with_logabsdet_jacobian_sharded(b, x, out=y)
+            _, _, s2 = bj.shard.with_logabsdet_jacobian_sharded(ib, y_, out=xb)
+            return s1
+
+        return dict(step=step, samples=N, bytes_per_sample=(2 * dim * 4 + 4) * 2, kernel="colgroup_kernel<RqsF>", dtype="f32",
+                    label=f"RationalQuadraticSpline K=16 fwd+inverse+logabsdetjac Float32 dim={dim} batch=2^{lb}/GPU",
+                    cfg={"workload": "RationalQuadraticSpline K=16 fwd+inv+logabsdetjac (BASELINE configs[2])", "dim": dim, "batch_per_gpu": N})
+    if name == "c4":
+        dim, nl, lb = 128, 8, (22 if log2_batch is None else log2_batch)
+        N = 1 << lb
+        x = colmajor_empty(torch, dim, N, f32, device)
+        y = colmajor_empty(torch, dim, N, f32, device)
+        fill_normal(bj, torch, x, rank * N, seed=0)
+        w = colmajor_empty(torch, dim, nl, f32, device)
+        u = colmajor_empty(torch, dim, nl, f32, device)
+        bb = torch.empty(nl, dtype=f32, device=device)
+        fill_normal(bj, torch, w, 0, seed=200, std=1.0 / math.sqrt(dim))
+        fill_normal(bj, torch, u, 0, seed=201, std=1.0 / math.sqrt(dim))
+        fill_normal(bj, torch, bb, 0, seed=202)
+        flow = bj.PlanarLayer(w, u, bb)
+
+        def step():
+            return bj.shard.with_logabsdet_jacobian_sharded(flow, x, out=y)[2]
+
+        return dict(step=step, samples=N, bytes_per_sample=2 * dim * 4 + 4, kernel="planar_kernel", dtype="f32",
+                    label=f"8-layer PlanarLayer flow fused fwd+logabsdetjac Float32 dim={dim} batch=2^{lb}/GPU",
+                    cfg={"workload": "8x PlanarLayer fused (BASELINE configs[3])", "dim": dim, "layers": nl, "batch_per_gpu": N})
+    if name == "c5a":
+        K, lb = 64, (20 if log2_batch is None else log2_batch)
+        N = 1 << lb
+        x = colmajor_empty(torch, K, N, f32, device)
+        fill_normal(bj, torch, x, rank * N, seed=0)
+        x = torch.softmax(x.T, dim=1).T  # synthetic-input preparation (outside the timed region)
+        b = bj.SimplexBijector()
+
+        def step():
+            return bj.shard.with_logabsdet_jacobian_sharded(b, x)[2]
+
+        return dict(step=step, samples=N, bytes_per_sample=K * 4 + (K - 1) * 4 + 4, kernel="seq_kernel<SimplexFwd>", dtype="f32",
+                    label=f"SimplexBijector fwd+logabsdetjac Float32 K={K} batch=2^{lb}/GPU",
+                    cfg={"workload": "SimplexBijector (BASELINE configs[4], first half)", "K": K, "batch_per_gpu": N})
+    if name == "c5b":
+        K, lb = 64, (16 if log2_batch is None else log2_batch)
+        N = 1 << lb
+        n = K * (K - 1) // 2
+        yv = colmajor_empty(torch, n, N, f32, device)
+        fill_normal(bj, torch, yv, rank * N, seed=0, std=0.5)
+        ib = bj.inverse(bj.VecCholeskyBijector("U"))
+
+        def step():
+            return bj.shard.with_logabsdet_jacobian_sharded(ib, yv)[2]
+
+        return dict(step=step, samples=N, bytes_per_sample=n * 4 + K * K * 4 + 4, kernel="chol_inv_kernel", dtype="f32",
+                    label=f"inverse VecCholeskyBijector (y->W dense + logJ) Float32 K={K} batch=2^{lb}/GPU",
+                    cfg={"workload": "VecCholeskyBijector inverse, dense W (BASELINE configs[4], second half)", "K": K, "batch_per_gpu": N})
+    raise ValueError(name)
+
+
+# ---------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(name, log2_batch):
+    """The oracle (a C++ port of the reference algorithm, reference-structured: one allocating pass
+    per composed stage, single thread — the reference is single-threaded) on a bounded sample."""
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(0)
+    if name in ("c2", "c2v"):
+        lb = 20 if log2_batch is None else log2_batch
+        N, dim = 1 << lb, 64
+        x = np.asfortranarray(rng.standard_normal((dim, N), dtype=np.float32))
+        if name == "c2":
+            ops = [(orc.OP_SCALE, 0.5, None), (orc.OP_SHIFT, 0.1, None), (orc.OP_EXP, None, None)]
+        else:
+            ops = [(orc.OP_SCALE, np.linspace(0.5, 1.5, dim), None), (orc.OP_SHIFT, np.full(dim, 0.1), None), (orc.OP_EXP, None, None)]
+        fn = lambda: orc.chain(ops, x)
+        sample = f"oracle chain (3 allocating passes, 1 thread) on Float32 64 x 2^{lb}"
+    elif name == "c3":
+        lb = 16 if log2_batch is None else log2_batch
+        N, dim, K = 1 << lb, 32, 16
+        w, h, d = orc.rqs_params(rng.standard_normal((dim, K), dtype=np.float32), rng.standard_normal((dim, K), dtype=np.float32), rng.standard_normal((dim, K - 1), dtype=np.float32), 3.0)
+        x = np.asfortranarray(rng.standard_normal((dim, N), dtype=np.float32))
+
+        def fn():
+            y, _ = orc.rqs(w, h, d, x)
+            orc.rqs(w, h, d, y, inverse=True)
+
+        sample = f"oracle RQS fwd+inv (per-element knot search, 1 thread) on Float32 32 x 2^{lb}"
+    elif name == "c4":
+        lb = 16 if log2_batch is None else log2_batch
+        N, dim, nl = 1 << lb, 128, 8
+        w = (rng.standard_normal((dim, nl)) / math.sqrt(dim)).astype(np.float32)
+        u = (rng.standard_normal((dim, nl)) / math.sqrt(dim)).astype(np.float32)
+        b = rng.standard_normal(nl).astype(np.float32)
+        x = np.asfortranarray(rng.standard_normal((dim, N), dtype=np.float32))
+        fn = lambda: orc.planar(w, u, b, x)
+        sample = f"oracle 8 Planar layers (layer-by-layer passes, 1 thread) on Float32 128 x 2^{lb}"
+    elif name == "c5a":
+        lb = 18 if log2_batch is None else log2_batch
+        N, K = 1 << lb, 64
+        x = np.asfortranarray(rng.dirichlet(np.ones(K), size=N).T.astype(np.float32))
+        fn = lambda: orc.simplex(x)
+        sample = f"oracle Simplex transform + logabsdetjac (2 passes, 1 thread) on Float32 64 x 2^{lb}"
+    else:
+        lb = 11 if log2_batch is None else log2_batch
+        N, K = 1 << lb, 64
+        y = np.asfortranarray((0.5 * rng.standard_normal((K * (K - 1) // 2, N))).astype(np.float32))
+        fn = lambda: orc.vec_cholesky(y, inverse=True)
+        sample = f"oracle _inv_link_chol_lkj per sample (1 thread) on Float32 2016 x 2^{lb}"
+    fn()  # warm (page faults, libm init)
+    best, reps, t_all = float("inf"), 0, time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t_all < 8.0 and reps < 10):
+        t0 = time.perf_counter()
+        fn()
+        best = min(best, time.perf_counter() - t0)
+        reps += 1
+    return {"value": N / best / 1e6, "unit": "M samples/s", "cores": 1, "kind": "port",
+            "sample": f"{sample}; best of {reps} runs, {best * 1e3:.1f} ms each; host has {os.cpu_count()} cores"}
+
+
+def traffic_from_profiles(workload):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE), stored by the profiling recipe in profiles/; None when not collected."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    a = parse()
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+        dist = None
+    if a.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    import bijectors_amd as bj
+
+    wl = make_workload(a.workload, bj, torch, device, rank, world, a.log2_batch)
+    ctx = bj.context(device)
+    lib = bj._lib.load()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    last = None
+    for _ in range(a.warmup):
+        last = wl["step"]()
+    barrier()
+    import ctypes as C
+
+    lib.bjx_time_begin(ctx.h)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = wl["step"]()
+    ev_ms = C.c_float(0.0)
+    lib.bjx_time_end(ctx.h, C.byref(ev_ms))   # hipEvent pair on the stream the kernels run on
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt, ev_ms.value], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, ev = float(tt[0]), float(tt[1])
+    else:
+        ev = ev_ms.value
+    ladj_total = float(last[0]) if last is not None else float("nan")
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        total_samples = wl["samples"] * world
+        value = total_samples / (dt / a.steps) / 1e6
+        kern_ms = ev / a.steps
+        alg_bytes = wl["samples"] * wl["bytes_per_sample"]       # per launch, one GPU
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = traffic_from_profiles(a.workload)
+        out = {
+            "metric": "M samples/sec for with_logabsdet_jacobian (named bijector, dim×batch); % HBM roofline",
+            "value": value, "unit": "M samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": wl["dtype"], "data": "synthetic (Philox N(0,1), shard-invariant)",
+            "config": dict(wl["cfg"], parallelism=f"batch-sharded x{world}, one f64 all-reduce of Σlogabsdetjac"),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": wl["kernel"], "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
+            "sum_logabsdetjac": ladj_total,
+            "label": wl["label"],
+        }
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_log2_batch)
+            except Exception as e:  # the baseline is informational; never lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "M samples/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""ctypes binding of libbjx_hip.so (include/bjx.h).  No torch types cross this boundary.
+
+The library is the product: if it is missing or fails to load this module raises — there is
+no CPU or PyTorch fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbjx_hip.so")
+
+BJX_F32, BJX_F64 = 0, 1
+BJX_ACCUMULATE = 1 << 0
+BJX_REF_VECTOR_SCALE_LADJ = 1 << 1
+BJX_MAX_OPS = 8
+
+(OP_EXP, OP_LOG, OP_SHIFT, OP_SCALE, OP_SCALE_INV, OP_LOGIT, OP_LOGIT_INV, OP_LEAKY_RELU,
+ OP_TRUNCATED, OP_TRUNCATED_INV, OP_SIGNFLIP, OP_IDENTITY) = range(1, 13)
+
+ERR_ARG, ERR_SHAPE, ERR_UNSUPPORTED, ERR_NOCOMM = -1, -2, -3, -4
+
+
+class BjxOp(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("param_len", C.c_int32),
+        ("p0", C.c_double),
+        ("p1", C.c_double),
+        ("v0", C.c_void_p),
+        ("v1", C.c_void_p),
+    ]
+
+
+_vp, _i, _i64, _u32, _u64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
+_tail = [_vp, _vp, _i64, _i64, _u32]  # ladj_ps, ladj_sum, dim/K, batch, flags
+
+# name -> (restype, argtypes); mirrors include/bjx.h line by line
+SIGNATURES = {
+    "bjx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "bjx_destroy": (_i, [_vp]),
+    "bjx_set_stream": (_i, [_vp, _vp]),
+    "bjx_last_error": (C.c_char_p, [_vp]),
+    "bjx_version": (_i, []),
+    "bjx_workspace_bytes": (C.c_size_t, [_vp]),
+    "bjx_synchronize": (_i, [_vp]),
+    "bjx_chain": (_i, [_vp, _i, C.POINTER(BjxOp), _i, _vp, _vp] + _tail),
+    "bjx_ordered": (_i, [_vp, _i, _i, _vp, _vp] + _tail),
+    "bjx_simplex": (_i, [_vp, _i, _i, _vp, _vp] + _tail),
+    "bjx_vec_cholesky": (_i, [_vp, _i, _i, _i, _vp, _vp] + _tail),
+    "bjx_planar": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp] + _tail),
+    "bjx_radial": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp] + _tail),
+    "bjx_batchnorm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _d, _vp, _vp] + _tail),
+    "bjx_rqs": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp] + _tail),
+    "bjx_rqs_params": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i64, _d, _vp, _vp, _vp]),
+    "bjx_permute": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _i64]),
+    "bjx_coupling_affine": (_i, [_vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp] + _tail),
+    "bjx_coupling_rqs": (_i, [_vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _i, _vp, _vp] + _tail),
+    "bjx_comm_unique_id": (_i, [_vp]),
+    "bjx_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "bjx_comm_destroy": (_i, [_vp]),
+    "bjx_allreduce_sum_f64": (_i, [_vp, _vp, _i64]),
+    "bjx_fill_normal": (_i, [_vp, _i, _vp, _i64, _i64, _i64, _u64, _d, _d]),
+    "bjx_time_begin": (_i, [_vp]),
+    "bjx_time_end": (_i, [_vp, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libbjx_hip.so; raises (never falls back) when the HIP extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    missing = [n for n in SIGNATURES if not hasattr(lib, n)]
+    if missing:  # an incomplete ABI is a build error, not something to paper over
+        raise ImportError(f"{LIB_PATH} does not export {missing}; rebuild it")
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class BjxError(RuntimeError):
+    """hipError_t / ncclResult_t surfaced by the library (Julia: ErrorException)."""
+
+
+def check(ctx, code: int, what: str):
+    """Map ABI status codes onto the exception classes the reference raises."""
+    if code == 0:
+        return
+    msg = load().bjx_last_error(ctx)
+    msg = msg.decode() if msg else ""
+    if code == ERR_ARG:
+        raise ValueError(f"{what}: {msg}")  # Julia ArgumentError
+    if code == ERR_SHAPE:
+        raise ValueError(f"{what}: DimensionMismatch: {msg}")
+    if code == ERR_UNSUPPORTED:
+        raise NotImplementedError(f"{what}: {msg}")
+    raise BjxError(f"{what}: status {code}: {msg}")

@@ -1,0 +1,256 @@
+// bjx_ctx.hip — context, deterministic log-det reduction, timing and synthetic-data helpers.
+#include <dlfcn.h>
+
+#include <new>
+
+#include "bjx_internal.h"
+
+// ------------------------------------------------------------------ finalize
+// One 256-thread block sums the per-block partials in a fixed order (thread t takes
+// t, t+256, ...; then a fixed tree) so the result does not depend on dispatch order.
+__global__ __launch_bounds__(256) void bjx_finalize_kernel(const double* __restrict__ partials, int n,
+                                                            double* __restrict__ out, double host_const,
+                                                            const double* __restrict__ dev_const, int accumulate) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+  s = bjx::group_sum<64>(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = ((red[0] + red[1]) + (red[2] + red[3])) + host_const;
+    if (dev_const) t += *dev_const;
+    *out = accumulate ? (*out + t) : t;
+  }
+}
+
+int bjx_launch_finalize(bjx_ctx* ctx, int n_partials, double* ladj_sum, double host_const,
+                        int use_dev_const, double /*unused*/, uint32_t flags) {
+  hipLaunchKernelGGL(bjx_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, n_partials,
+                     ladj_sum, host_const, use_dev_const ? ctx->consts + 1 : nullptr,
+                     (flags & BJX_ACCUMULATE) ? 1 : 0);
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+
+// ------------------------------------------------------------------ context
+BJX_API int bjx_version(void) { return BJX_VERSION; }
+
+BJX_API int bjx_create(int device, void* hip_stream, bjx_ctx** out) {
+  if (!out) return BJX_ERR_ARG;
+  *out = nullptr;
+  bjx_ctx* ctx = new (std::nothrow) bjx_ctx();
+  if (!ctx) return BJX_ERR_ARG;
+  ctx->device = device;
+  ctx->stream = static_cast<hipStream_t>(hip_stream);
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMalloc(&ctx->partials, sizeof(double) * BJX_MAX_BLOCKS);
+  if (e == hipSuccess) e = hipMalloc(&ctx->consts, sizeof(double) * BJX_CONSTS);
+  if (e == hipSuccess) e = hipMalloc(&ctx->scratch, BJX_SCRATCH_BYTES);
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+  if (e == hipSuccess) {
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  if (e != hipSuccess) {
+    int code = (int)e;
+    bjx_destroy(ctx);
+    return code;
+  }
+  *out = ctx;
+  return BJX_OK;
+}
+
+BJX_API int bjx_destroy(bjx_ctx* ctx) {
+  if (!ctx) return BJX_OK;
+  bjx_comm_destroy(ctx);
+  if (ctx->partials) (void)hipFree(ctx->partials);
+  if (ctx->consts) (void)hipFree(ctx->consts);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  delete ctx;
+  return BJX_OK;
+}
+
+BJX_API int bjx_set_stream(bjx_ctx* ctx, void* hip_stream) {
+  if (!ctx) return BJX_ERR_ARG;
+  ctx->stream = static_cast<hipStream_t>(hip_stream);
+  return BJX_OK;
+}
+
+BJX_API const char* bjx_last_error(bjx_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+BJX_API size_t bjx_workspace_bytes(bjx_ctx* ctx) {
+  (void)ctx;
+  return sizeof(double) * (BJX_MAX_BLOCKS + BJX_CONSTS) + BJX_SCRATCH_BYTES;
+}
+
+BJX_API int bjx_synchronize(bjx_ctx* ctx) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return BJX_OK;
+}
+
+BJX_API int bjx_time_begin(bjx_ctx* ctx) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return BJX_OK;
+}
+
+BJX_API int bjx_time_end(bjx_ctx* ctx, float* ms_out) {
+  if (!ctx || !ms_out) return BJX_ERR_ARG;
+  BJX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  BJX_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  BJX_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+  return BJX_OK;
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 normal fill
+// Counter = global element index / 4, key = seed; 4 x u32 -> 2 Box-Muller pairs -> 4 normals.
+// Element e of the GLOBAL array (col0*dim + local index) always gets the same value, so a batch
+// is identical for any shard count.
+namespace {
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t* out) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void fill_normal_kernel(T* __restrict__ out, int64_t n_local, int64_t e0,
+                                                           uint64_t seed, double mean, double std) {
+  // each thread produces the 4 normals of one Philox counter; counters are aligned to GLOBAL index/4
+  const int64_t c_first = e0 >> 2, c_last = (e0 + n_local - 1) >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t c = c_first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c <= c_last; c += stride) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    double z[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      // u1 in (0,1], u2 in [0,1)
+      double u1 = ((double)r[2 * p] + 1.0) * (1.0 / 4294967296.0);
+      double u2 = (double)r[2 * p + 1] * (1.0 / 4294967296.0);
+      double rad = sqrt(-2.0 * log(u1));
+      double s, co;
+      sincospi(2.0 * u2, &s, &co);
+      z[2 * p] = rad * co;
+      z[2 * p + 1] = rad * s;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int64_t e = (c << 2) + j - e0;
+      if (e >= 0 && e < n_local) out[e] = (T)(mean + std * z[j]);
+    }
+  }
+}
+}  // namespace
+
+BJX_API int bjx_fill_normal(bjx_ctx* ctx, bjx_dtype dt, void* out, int64_t dim, int64_t batch, int64_t col0,
+                            uint64_t seed, double mean, double std) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, out && dim >= 0 && batch >= 0 && col0 >= 0, BJX_ERR_ARG, "bjx_fill_normal: bad argument");
+  int64_t n = dim * batch;
+  if (n == 0) return BJX_OK;
+  int grid = bjx_stream_grid(ctx, (n + 3) / 4, 256);
+  if (dt == BJX_F32)
+    hipLaunchKernelGGL(fill_normal_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (float*)out, n, col0 * dim, seed, mean, std);
+  else if (dt == BJX_F64)
+    hipLaunchKernelGGL(fill_normal_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (double*)out, n, col0 * dim, seed, mean, std);
+  else
+    return bjx_fail(ctx, BJX_ERR_ARG, "bjx_fill_normal: bad dtype %d", (int)dt);
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+
+// ------------------------------------------------------------------ RCCL (lazy)
+// RCCL is dlopen'ed on first use so the library loads (and single-GPU use works) in processes
+// that never touch a communicator, and so it shares the RCCL already mapped by the host
+// runtime if there is one.
+namespace {
+typedef struct { char internal[128]; } nccl_uid;
+typedef int (*fn_uid)(nccl_uid*);
+typedef int (*fn_init)(void**, int, nccl_uid, int);
+typedef int (*fn_destroy)(void*);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0;
+
+void* rccl_open() {
+  static void* h = nullptr;
+  if (h) return h;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    if (h) return h;
+  }
+  for (const char* n : names) {
+    h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (h) return h;
+  }
+  return nullptr;
+}
+}  // namespace
+
+BJX_API int bjx_comm_unique_id(void* out128) {
+  if (!out128) return BJX_ERR_ARG;
+  void* h = rccl_open();
+  if (!h) return BJX_ERR_NOCOMM;
+  fn_uid f = (fn_uid)dlsym(h, "ncclGetUniqueId");
+  if (!f) return BJX_ERR_NOCOMM;
+  nccl_uid id;
+  int r = f(&id);
+  if (r != 0) return 1000 + r;
+  memcpy(out128, &id, sizeof(id));
+  return BJX_OK;
+}
+
+BJX_API int bjx_comm_init(bjx_ctx* ctx, int nranks, int rank, const void* unique_id128) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, nranks >= 1 && rank >= 0 && rank < nranks && unique_id128, BJX_ERR_ARG, "bjx_comm_init: bad argument");
+  void* h = rccl_open();
+  BJX_REQUIRE(ctx, h, BJX_ERR_NOCOMM, "bjx_comm_init: cannot dlopen librccl.so: %s", dlerror());
+  fn_init f = (fn_init)dlsym(h, "ncclCommInitRank");
+  BJX_REQUIRE(ctx, f, BJX_ERR_NOCOMM, "bjx_comm_init: ncclCommInitRank not found");
+  BJX_HIP(ctx, hipSetDevice(ctx->device));
+  nccl_uid id;
+  memcpy(&id, unique_id128, sizeof(id));
+  void* comm = nullptr;
+  int r = f(&comm, nranks, id, rank);
+  if (r != 0) return bjx_fail(ctx, 1000 + r, "ncclCommInitRank failed: %d", r);
+  ctx->rccl_handle = h;
+  ctx->comm = comm;
+  ctx->nranks = nranks;
+  ctx->rank = rank;
+  return BJX_OK;
+}
+
+BJX_API int bjx_comm_destroy(bjx_ctx* ctx) {
+  if (!ctx || !ctx->comm) return BJX_OK;
+  fn_destroy f = (fn_destroy)dlsym(ctx->rccl_handle, "ncclCommDestroy");
+  if (f) f(ctx->comm);
+  ctx->comm = nullptr;
+  return BJX_OK;
+}
+
+BJX_API int bjx_allreduce_sum_f64(bjx_ctx* ctx, double* ptr, int64_t n) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, ptr && n >= 0, BJX_ERR_ARG, "bjx_allreduce_sum_f64: bad argument");
+  if (ctx->nranks == 1 && !ctx->comm) return BJX_OK;  // single shard: the sum is already global
+  BJX_REQUIRE(ctx, ctx->comm, BJX_ERR_NOCOMM, "bjx_allreduce_sum_f64: call bjx_comm_init first");
+  fn_allreduce f = (fn_allreduce)dlsym(ctx->rccl_handle, "ncclAllReduce");
+  BJX_REQUIRE(ctx, f, BJX_ERR_NOCOMM, "ncclAllReduce not found");
+  int r = f(ptr, ptr, (size_t)n, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->stream);
+  if (r != 0) return bjx_fail(ctx, 1000 + r, "ncclAllReduce failed: %d", r);
+  return BJX_OK;
+}

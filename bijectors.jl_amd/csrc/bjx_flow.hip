@@ -1,0 +1,338 @@
+// bjx_flow.hip — F2: per-sample reduce + broadcast flow layers.
+//   PlanarLayer  planar_layer.jl:65-127,160-185   (n_layers fused in one pass)
+//   RadialLayer  radial_layer.jl:43-129
+//
+// Mapping: G consecutive lanes own one column and keep it in registers (R 16-byte packs per lane),
+// so every element is read from HBM once and written once even for an 8-layer stack: the
+// reference's GEMV pass + rank-1 update pass + sech/log1p pass per layer become
+// in-register dot products reduced with wave shuffles inside the G-lane group.
+#include "bjx_internal.h"
+
+namespace {
+using namespace bjx;
+
+// planar_layer.jl:65-70: û = u + ((log1pexp(-wᵀu) - 1)/‖w‖²) w ;  wᵀû = log1pexp(wᵀu) - 1.
+// One block per layer; writes û[l,:] and wᵀû[l] to scratch.
+template <class T>
+__global__ __launch_bounds__(256) void planar_prep_kernel(const T* w, const T* u, int64_t dim, T* u_hat, T* wtu_hat) {
+  __shared__ double red[8];
+  const int l = blockIdx.x;
+  const T* wl = w + (int64_t)l * dim;
+  const T* ul = u + (int64_t)l * dim;
+  double dot = 0.0, w2 = 0.0;   // accumulated in f64, rounded to T once (reference: T dot / sum)
+  for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) { dot += (double)wl[i] * (double)ul[i]; w2 += (double)wl[i] * (double)wl[i]; }
+  dot = group_sum<64>(dot);
+  w2 = group_sum<64>(w2);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = dot; red[4 + (threadIdx.x >> 6)] = w2; }
+  __syncthreads();
+  T wT_u = (T)((red[0] + red[1]) + (red[2] + red[3]));
+  T ww = (T)((red[4] + red[5]) + (red[6] + red[7]));
+  T c = (d_log1pexp(-wT_u) - T(1)) / ww;
+  for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) u_hat[(int64_t)l * dim + i] = ul[i] + c * wl[i];
+  if (threadIdx.x == 0) wtu_hat[l] = d_log1pexp(wT_u) - T(1);
+}
+
+// planar_layer.jl:160-185 (find_alpha): solve α + c·tanh(α+b) = wy inside [wy-2|c|, wy+2|c|].
+// Roots.A42 is replaced by a safeguarded Newton iteration on the same bracket (the function is
+// strictly increasing because c = wᵀû > -1); terminates when the step is below 1 ulp or the
+// bracket collapses.  Parity with the reference is residual-pinned (test/normalising_flows.jl:47-70).
+template <class T> __device__ __forceinline__ T find_alpha_dev(T wy, T c, T b) {
+  const T delta = T(2) * d_abs(c);
+  T lo = wy - delta, hi = wy + delta;
+  if (lo == hi) return lo;                       // :171-173
+  T a = wy - c * d_tanh(wy + b);                 // one fixed-point step as the start
+  a = a < lo ? lo : (a > hi ? hi : a);
+  const int max_it = sizeof(T) == 4 ? 40 : 80;
+  for (int it = 0; it < max_it; ++it) {
+    T t = d_tanh(a + b);
+    T f = a + c * t - wy;
+    if (f == T(0)) break;
+    if (f < T(0)) lo = a; else hi = a;
+    T fp = T(1) + c * (T(1) - t * t);
+    T an = a - f / fp;
+    if (!(an > lo && an < hi)) an = lo + (hi - lo) / T(2);     // safeguard: bisect
+    if (an == a || !(an > lo && an < hi)) break;               // bracket is adjacent floats
+    T step = d_abs(an - a);
+    a = an;
+    if (step <= Num<T>::eps * d_abs(a)) {
+      // one more residual check would not change the float; done
+      break;
+    }
+  }
+  return a;
+}
+
+template <class T> struct PlanarArgs {
+  const T *w, *u_hat, *wtu_hat, *b;
+  int n_layers;
+  int in_lds;
+};
+
+template <class T, int V, int R, bool INV>
+__global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, const T* x, T* y, T* ladj_ps, int64_t dim,
+                                                     int64_t batch, int G, int accumulate, double* partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);
+  T* tab = reinterpret_cast<T*>(smem + 32);
+  const int64_t nld = (int64_t)A.n_layers * dim;
+  if (A.in_lds) {
+    for (int64_t i = threadIdx.x; i < nld; i += blockDim.x) { tab[i] = A.w[i]; tab[nld + i] = A.u_hat[i]; }
+    __syncthreads();
+  }
+  const T* W = A.in_lds ? tab : A.w;
+  const T* UH = A.in_lds ? tab + nld : A.u_hat;
+
+  const int gl = threadIdx.x & (G - 1);
+  const int cols_per_block = blockDim.x / G;
+  const int64_t col_stride = (int64_t)gridDim.x * cols_per_block;
+  const int64_t nvc = dim / V;
+  double acc = 0.0;
+  for (int64_t col = (int64_t)blockIdx.x * cols_per_block + threadIdx.x / G; col < batch; col += col_stride) {
+    const T* xc = x + col * dim;
+    T* yc = y + col * dim;
+    Pack<T, V> z[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int64_t v = gl + (int64_t)r * G;
+      if (v < nvc) z[r] = load_pack<T, V, false>(xc + v * V);
+      else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) z[r].v[j] = T(0);
+      }
+    }
+    T ladj = T(0);
+    for (int li = 0; li < A.n_layers; ++li) {
+      const int l = INV ? A.n_layers - 1 - li : li;
+      const T* wl = W + (int64_t)l * dim;
+      const T* ul = UH + (int64_t)l * dim;
+      T s = T(0);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int64_t v = gl + (int64_t)r * G;
+        if (v < nvc) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) s += wl[v * V + j] * z[r].v[j];
+        }
+      }
+      s = group_sum_rt(s, G);                 // wᵀz   (src/utils.jl:2)
+      const T bl = A.b[l], c = A.wtu_hat[l];
+      T arg;
+      if (!INV) arg = s + bl;
+      else arg = find_alpha_dev<T>(s, c, bl) + bl;
+      const T t = d_tanh(arg);
+      const T sech = T(1) / d_cosh(arg);
+      const T ld = d_log1p(c * (sech * sech));  // planar_layer.jl:107
+      ladj += INV ? -ld : ld;
+      const T tt = INV ? -t : t;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int64_t v = gl + (int64_t)r * G;
+        if (v < nvc) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) z[r].v[j] += ul[v * V + j] * tt;   // z ± û tanh(·)
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int64_t v = gl + (int64_t)r * G;
+      if (v < nvc) store_pack<T, V, false>(yc + v * V, z[r]);
+    }
+    if (gl == 0) {
+      if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + ladj : ladj;
+      acc += (double)ladj;
+    }
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
+template <class T> struct RadialArgs {
+  const T *alpha_, *beta, *z0;
+  int in_lds;
+};
+
+// radial_layer.jl:43-72 (forward) and :88-129 (inverse)
+template <class T, int V, int R, bool INV>
+__global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, const T* x, T* y, T* ladj_ps, int64_t dim,
+                                                     int64_t batch, int G, int accumulate, double* partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);
+  T* tab = reinterpret_cast<T*>(smem + 32);
+  if (A.in_lds) {
+    for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) tab[i] = A.z0[i];
+    __syncthreads();
+  }
+  const T* Z0 = A.in_lds ? tab : A.z0;
+  const T alpha = d_log1pexp(A.alpha_[0]);          // :44
+  const T apb = d_log1pexp(A.beta[0]);              // α + β̂
+  const T beta_hat = -alpha + apb;                  // :45
+
+  const int gl = threadIdx.x & (G - 1);
+  const int cols_per_block = blockDim.x / G;
+  const int64_t col_stride = (int64_t)gridDim.x * cols_per_block;
+  const int64_t nvc = dim / V;
+  double acc = 0.0;
+  for (int64_t col = (int64_t)blockIdx.x * cols_per_block + threadIdx.x / G; col < batch; col += col_stride) {
+    const T* xc = x + col * dim;
+    T* yc = y + col * dim;
+    Pack<T, V> zz[R];
+    T ss = T(0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int64_t v = gl + (int64_t)r * G;
+      if (v < nvc) {
+        zz[r] = load_pack<T, V, false>(xc + v * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { T dlt = zz[r].v[j] - Z0[v * V + j]; ss += dlt * dlt; }
+      }
+    }
+    ss = group_sum_rt(ss, G);
+    T r_fwd, gain;   // out = z0 + gain * dz ; r_fwd = ‖z_fwd_input − z0‖ used by the log-det
+    if (!INV) {
+      r_fwd = d_sqrt(ss);
+      gain = T(1) + beta_hat / (alpha + r_fwd);     // z + β̂/(α+r)(z−z0) = z0 + (1+β̂h)(z−z0)
+    } else {
+      const T gam = d_sqrt(ss);                     // compute_r :124-129
+      const T a = apb - gam;
+      const T rr = (d_sqrt(a * a + 4 * alpha * gam) - a) / 2;
+      gain = (alpha + rr) / (apb + rr);             // γ :96-101
+      r_fwd = gain * gam;                           // ‖z − z0‖ of the result
+    }
+    const T h_ = T(1) / (alpha + r_fwd);
+    T ld = T(dim - 1) * d_log(T(1) + beta_hat * h_) + d_log(T(1) + beta_hat * h_ + beta_hat * (-(h_ * h_)) * r_fwd);   // :68-70
+    if (INV) ld = -ld;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int64_t v = gl + (int64_t)r * G;
+      if (v < nvc) {
+        Pack<T, V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const T z0j = Z0[v * V + j];
+          const T dlt = zz[r].v[j] - z0j;
+          if (!INV) o.v[j] = zz[r].v[j] + beta_hat / (alpha + r_fwd) * dlt;   // :52
+          else o.v[j] = z0j + gain * dlt;                                     // :101
+        }
+        store_pack<T, V, false>(yc + v * V, o);
+      }
+    }
+    if (gl == 0) {
+      if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + ld : ld;
+      acc += (double)ld;
+    }
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
+struct FlowCfg { int V, G, R, grid; };
+
+template <class T> bool flow_cfg(const bjx_ctx* ctx, const void* x, const void* y, int64_t dim, int64_t batch, FlowCfg* c) {
+  constexpr int VW = Vec16<T>::N;
+  const bool v_ok = bjx_aligned16(x) && bjx_aligned16(y) && dim % VW == 0;
+  c->V = v_ok ? VW : 1;
+  const int64_t packs = dim / c->V;
+  int G = 1;
+  while (G < 64 && G < packs) G <<= 1;
+  // prefer fewer lanes per column with 2 packs each when that keeps >= 16-lane groups (more ILP)
+  int64_t need = (packs + G - 1) / G;
+  int R = 1;
+  while (R < need) R <<= 1;
+  if (R > 32) return false;
+  c->G = G;
+  c->R = R;
+  c->grid = bjx_stream_grid(ctx, batch, 256 / G);
+  return true;
+}
+
+#define FLOW_SWITCH_R(KERNEL, TT, VV, INVV, ...)                                                                         \
+  switch (c.R) {                                                                                                        \
+    case 1: hipLaunchKernelGGL((KERNEL<TT, VV, 1, INVV>), dim3(c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
+    case 2: hipLaunchKernelGGL((KERNEL<TT, VV, 2, INVV>), dim3(c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
+    case 4: hipLaunchKernelGGL((KERNEL<TT, VV, 4, INVV>), dim3(c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
+    case 8: hipLaunchKernelGGL((KERNEL<TT, VV, 8, INVV>), dim3(c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
+    case 16: hipLaunchKernelGGL((KERNEL<TT, VV, 16, INVV>), dim3(c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL((KERNEL<TT, VV, 32, INVV>), dim3(c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break; \
+  }
+
+template <class T>
+int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, int nl, const T* in, T* out, T* ladj_ps,
+                double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
+  const size_t need = ((size_t)nl * dim + nl) * sizeof(T);
+  BJX_REQUIRE(ctx, need <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_planar: n_layers*dim = %lld exceeds the context scratch", (long long)nl * dim);
+  T* u_hat = static_cast<T*>(ctx->scratch);
+  T* wtu = u_hat + (size_t)nl * dim;
+  hipLaunchKernelGGL(planar_prep_kernel<T>, dim3(nl), dim3(256), 0, ctx->stream, w, u, dim, u_hat, wtu);
+  BJX_CHECK_LAUNCH(ctx);
+  if (batch == 0) {
+    if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
+    return BJX_OK;
+  }
+  FlowCfg c;
+  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, out, dim, batch, &c), BJX_ERR_UNSUPPORTED, "bjx_planar: dim %lld too large for the register-resident kernel", (long long)dim);
+  const size_t tab_bytes = (size_t)2 * nl * dim * sizeof(T);
+  const bool lds = tab_bytes <= 60 * 1024;
+  PlanarArgs<T> A{w, u_hat, wtu, b, nl, lds ? 1 : 0};
+  const size_t smem = 32 + (lds ? tab_bytes : 0);
+  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  double* partials = ladj_sum ? ctx->partials : nullptr;
+  constexpr int VW = Vec16<T>::N;
+  if (c.V == VW) {
+    if (!inverse) { FLOW_SWITCH_R(planar_kernel, T, VW, false, A, in, out, ladj_ps, dim, batch, c.G, accum, partials) }
+    else { FLOW_SWITCH_R(planar_kernel, T, VW, true, A, in, out, ladj_ps, dim, batch, c.G, accum, partials) }
+  } else {
+    if (!inverse) { FLOW_SWITCH_R(planar_kernel, T, 1, false, A, in, out, ladj_ps, dim, batch, c.G, accum, partials) }
+    else { FLOW_SWITCH_R(planar_kernel, T, 1, true, A, in, out, ladj_ps, dim, batch, c.G, accum, partials) }
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  if (ladj_sum) return bjx_launch_finalize(ctx, c.grid, ladj_sum, 0.0, 0, 0.0, flags);
+  return BJX_OK;
+}
+
+template <class T>
+int radial_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const T* z0, const T* in, T* out, T* ladj_ps,
+                double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
+  if (batch == 0) {
+    if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
+    return BJX_OK;
+  }
+  FlowCfg c;
+  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, out, dim, batch, &c), BJX_ERR_UNSUPPORTED, "bjx_radial: dim %lld too large for the register-resident kernel", (long long)dim);
+  const size_t tab_bytes = (size_t)dim * sizeof(T);
+  const bool lds = tab_bytes <= 60 * 1024;
+  RadialArgs<T> A{alpha_, beta, z0, lds ? 1 : 0};
+  const size_t smem = 32 + (lds ? tab_bytes : 0);
+  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  double* partials = ladj_sum ? ctx->partials : nullptr;
+  constexpr int VW = Vec16<T>::N;
+  if (c.V == VW) {
+    if (!inverse) { FLOW_SWITCH_R(radial_kernel, T, VW, false, A, in, out, ladj_ps, dim, batch, c.G, accum, partials) }
+    else { FLOW_SWITCH_R(radial_kernel, T, VW, true, A, in, out, ladj_ps, dim, batch, c.G, accum, partials) }
+  } else {
+    if (!inverse) { FLOW_SWITCH_R(radial_kernel, T, 1, false, A, in, out, ladj_ps, dim, batch, c.G, accum, partials) }
+    else { FLOW_SWITCH_R(radial_kernel, T, 1, true, A, in, out, ladj_ps, dim, batch, c.G, accum, partials) }
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  if (ladj_sum) return bjx_launch_finalize(ctx, c.grid, ladj_sum, 0.0, 0, 0.0, flags);
+  return BJX_OK;
+}
+}  // namespace
+
+BJX_API int bjx_planar(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* w, const void* u, const void* b, int n_layers,
+                       const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0 && n_layers >= 1, BJX_ERR_SHAPE, "bjx_planar: bad size (dim=%lld, n_layers=%d)", (long long)dim, n_layers);
+  BJX_REQUIRE(ctx, w && u && b && ((in && out) || batch == 0), BJX_ERR_ARG, "bjx_planar: null pointer");
+  if (dt == BJX_F32) return planar_impl<float>(ctx, inverse, (const float*)w, (const float*)u, (const float*)b, n_layers, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, batch, flags);
+  if (dt == BJX_F64) return planar_impl<double>(ctx, inverse, (const double*)w, (const double*)u, (const double*)b, n_layers, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, batch, flags);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_planar: bad dtype %d", (int)dt);
+}
+
+BJX_API int bjx_radial(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* alpha_, const void* beta, const void* z0,
+                       const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_radial: bad size");
+  BJX_REQUIRE(ctx, alpha_ && beta && z0 && ((in && out) || batch == 0), BJX_ERR_ARG, "bjx_radial: null pointer");
+  if (dt == BJX_F32) return radial_impl<float>(ctx, inverse, (const float*)alpha_, (const float*)beta, (const float*)z0, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, batch, flags);
+  if (dt == BJX_F64) return radial_impl<double>(ctx, inverse, (const double*)alpha_, (const double*)beta, (const double*)z0, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, batch, flags);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_radial: bad dtype %d", (int)dt);
+}

@@ -1,0 +1,198 @@
+// bjx_internal.h — shared host/device helpers of libbjx_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+
+#include "../../include/bjx.h"
+
+#define BJX_API extern "C" __attribute__((visibility("default")))
+
+// ------------------------------------------------------------------ context
+constexpr int BJX_MAX_BLOCKS = 4096;        // upper bound on blocks that publish a partial
+constexpr int BJX_CONSTS = 8;               // device doubles for parameter-only log-det terms
+constexpr size_t BJX_SCRATCH_BYTES = 1 << 20;  // û tables, small parameter staging
+
+struct bjx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  double* partials = nullptr;   // [BJX_MAX_BLOCKS]
+  double* consts = nullptr;     // [BJX_CONSTS]
+  void* scratch = nullptr;      // [BJX_SCRATCH_BYTES]
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int num_cu = 256;
+  // RCCL (lazily dlopen'ed)
+  void* rccl_handle = nullptr;
+  void* comm = nullptr;
+  int nranks = 1, rank = 0;
+  char err[512] = {0};
+};
+
+inline int bjx_fail(bjx_ctx* ctx, int code, const char* fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define BJX_HIP(ctx, expr)                                                              \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return bjx_fail((ctx), (int)e_, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+  } while (0)
+
+#define BJX_CHECK_LAUNCH(ctx) BJX_HIP(ctx, hipGetLastError())
+
+#define BJX_REQUIRE(ctx, cond, code, ...)                    \
+  do {                                                       \
+    if (!(cond)) return bjx_fail((ctx), (code), __VA_ARGS__); \
+  } while (0)
+
+// host side: launch the fixed-order reduction of per-block partials (+ constant term)
+int bjx_launch_finalize(bjx_ctx* ctx, int n_partials, double* ladj_sum, double host_const,
+                        int use_dev_const, double dev_const_mult, uint32_t flags);
+
+// ------------------------------------------------------------------ device math
+// Same definitions as the reference's third-party scalar functions (LogExpFunctions), see
+// oracle/bjx_oracle.cpp for the citations; thresholds are identical to the CPU restatement.
+namespace bjx {
+
+template <class T> struct Num;
+template <> struct Num<float> {
+  static constexpr float eps = 1.1920928955078125e-07f;
+  static constexpr float logistic_lo = -103.27893f, logistic_hi = 16.635532f;
+  static constexpr float l1pe0 = -16.635532f, l1pe1 = 7.9711924f, l1pe2 = 13.993f;
+  static constexpr float log2 = 0.69314718055994530942f;
+  static constexpr float inf = __builtin_huge_valf();
+};
+template <> struct Num<double> {
+  static constexpr double eps = 2.220446049250313e-16;
+  static constexpr double logistic_lo = -744.4400719213812, logistic_hi = 36.7368005696771;
+  static constexpr double l1pe0 = -36.7368005696771, l1pe1 = 18.021826694558577, l1pe2 = 33.23111882352963;
+  static constexpr double log2 = 0.69314718055994530942;
+  static constexpr double inf = __builtin_huge_val();
+};
+
+__device__ __forceinline__ float d_exp(float x) { return expf(x); }
+__device__ __forceinline__ double d_exp(double x) { return exp(x); }
+__device__ __forceinline__ float d_log(float x) { return logf(x); }
+__device__ __forceinline__ double d_log(double x) { return log(x); }
+__device__ __forceinline__ float d_log1p(float x) { return log1pf(x); }
+__device__ __forceinline__ double d_log1p(double x) { return log1p(x); }
+__device__ __forceinline__ float d_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ double d_tanh(double x) { return tanh(x); }
+__device__ __forceinline__ float d_cosh(float x) { return coshf(x); }
+__device__ __forceinline__ double d_cosh(double x) { return cosh(x); }
+__device__ __forceinline__ float d_atanh(float x) { return atanhf(x); }
+__device__ __forceinline__ double d_atanh(double x) { return atanh(x); }
+__device__ __forceinline__ float d_asinh(float x) { return asinhf(x); }
+__device__ __forceinline__ double d_asinh(double x) { return asinh(x); }
+__device__ __forceinline__ float d_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double d_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float d_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double d_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float d_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double d_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ bool d_isfinite(float x) { return fabsf(x) < Num<float>::inf; }
+__device__ __forceinline__ bool d_isfinite(double x) { return fabs(x) < Num<double>::inf; }
+
+// src/Bijectors.jl:95-100
+template <class T> __device__ __forceinline__ T d_clamp(T x, T a, T b) { return x < a ? a : (x > b ? b : x); }
+template <class T> __device__ __forceinline__ T d_logit(T x) { return d_log(x / (T(1) - x)); }
+template <class T> __device__ __forceinline__ T d_logistic(T x) {
+  T e = d_exp(x);
+  return x < Num<T>::logistic_lo ? T(0) : (x > Num<T>::logistic_hi ? T(1) : e / (T(1) + e));
+}
+template <class T> __device__ __forceinline__ T d_log1pexp(T x) {
+  if (x < Num<T>::l1pe0) return d_exp(x);
+  if (x < Num<T>::l1pe1) return d_log1p(d_exp(x));
+  if (x < Num<T>::l1pe2) return x + d_exp(-x);
+  return x;
+}
+template <class T> __device__ __forceinline__ T d_logcosh(T x) {
+  T ax = d_abs(x);
+  return ax + d_log1pexp(T(-2) * ax) - Num<T>::log2;
+}
+
+// ------------------------------------------------------------------ reductions (wave = 64)
+template <class T> __device__ __forceinline__ T shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
+
+// sum over aligned groups of G consecutive lanes (G power of two <= 64); every lane gets the sum
+template <int G, class T> __device__ __forceinline__ T group_sum(T v) {
+#pragma unroll
+  for (int m = G >> 1; m >= 1; m >>= 1) v += shfl_xor(v, m);
+  return v;
+}
+template <class T> __device__ __forceinline__ T group_sum_rt(T v, int G) {
+  for (int m = G >> 1; m >= 1; m >>= 1) v += shfl_xor(v, m);
+  return v;
+}
+
+// Block-wide sum of one double per thread -> partials[blockIdx.x] (fixed order, deterministic).
+// `red` is an LDS array of >= blockDim.x/64 doubles.
+__device__ __forceinline__ void block_publish_partial(double acc, double* red, double* partials) {
+  acc = group_sum<64>(acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < nw; ++w) s += red[w];
+    partials[blockIdx.x] = s;
+  }
+}
+
+// 16-byte vector types per element type
+template <class T> struct Vec16;
+typedef float bjx_f32x4 __attribute__((ext_vector_type(4)));
+typedef double bjx_f64x2 __attribute__((ext_vector_type(2)));
+template <> struct Vec16<float> { using type = bjx_f32x4; static constexpr int N = 4; };
+template <> struct Vec16<double> { using type = bjx_f64x2; static constexpr int N = 2; };
+
+template <class T, int V> struct Pack { T v[V]; };
+
+template <class T, int V, bool NT> __device__ __forceinline__ Pack<T, V> load_pack(const T* p) {
+  Pack<T, V> r;
+  if constexpr (V == 1) {
+    r.v[0] = NT ? __builtin_nontemporal_load(p) : *p;
+  } else {
+    using VT = typename Vec16<T>::type;
+    static_assert(V == Vec16<T>::N, "pack width");
+    VT t = NT ? __builtin_nontemporal_load(reinterpret_cast<const VT*>(p)) : *reinterpret_cast<const VT*>(p);
+    __builtin_memcpy(&r, &t, sizeof(t));
+  }
+  return r;
+}
+template <class T, int V, bool NT> __device__ __forceinline__ void store_pack(T* p, const Pack<T, V>& r) {
+  if constexpr (V == 1) {
+    if (NT) __builtin_nontemporal_store(r.v[0], p); else *p = r.v[0];
+  } else {
+    using VT = typename Vec16<T>::type;
+    VT t;
+    __builtin_memcpy(&t, &r, sizeof(t));
+    if (NT) __builtin_nontemporal_store(t, reinterpret_cast<VT*>(p)); else *reinterpret_cast<VT*>(p) = t;
+  }
+}
+
+}  // namespace bjx
+
+// grid sizing for streaming kernels: enough blocks to fill 256 CUs x 8 resident blocks
+inline int bjx_stream_grid(const bjx_ctx* ctx, int64_t work_items, int per_block) {
+  int64_t need = (work_items + per_block - 1) / per_block;
+  int64_t cap = (int64_t)ctx->num_cu * 8;
+  if (cap > BJX_MAX_BLOCKS) cap = BJX_MAX_BLOCKS;
+  if (need < 1) need = 1;
+  return (int)(need < cap ? need : cap);
+}
+
+inline bool bjx_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -1,0 +1,400 @@
+// bjx_seq.hip — F3: bijectors with a sequential / prefix dependency along `dim`
+// (SURVEY.md §8a rows a9-a14).
+//   OrderedBijector      ordered.jl:24-80
+//   SimplexBijector      simplex.jl:28-143
+//   VecCholeskyBijector  corr.jl:227-254, 314-337, 370-399, 485-501
+//
+// Ordered / Simplex: the block stages a [256 columns x C rows] tile through padded LDS with
+// coalesced global accesses (a lane pair of 128 B per column chunk), then ONE LANE PER SAMPLE walks
+// its column in ascending row order — exactly the reference's summation order — writing results
+// back into the same tile, which is then stored coalesced.  LDS pitch C+1 makes the column walk
+// bank-conflict free (lane t reads tile[t*(C+1)+i]).
+//
+// VecCholesky: one WAVE per sample walks the packed strict-upper vector 64 entries at a time; the
+// per-column running sums (Σ logcosh for the inverse, Σ w² for the forward link) are segmented
+// wave scans built from one inclusive shuffle scan + one bpermute gather.
+#include "bjx_internal.h"
+
+namespace {
+using namespace bjx;
+
+template <class T> struct SeqCfg { static constexpr int C = 128 / sizeof(T); static constexpr int NT = 256; };
+
+// ---- per-column walkers.  step(i, have_in, v) is called for i = 0..rows-1 in ascending order and
+// returns the output of row i (ignored when i >= rows_out).
+template <class T> struct OrderedFwd {   // ordered.jl:36-49, :80
+  T prev, ladj;
+  __device__ void init() { prev = T(0); ladj = T(0); }
+  __device__ T step(int64_t i, T v, const T*) {
+    T o;
+    if (i == 0) o = v; else { o = prev + d_exp(v); ladj += v; }
+    prev = o;
+    return o;
+  }
+  __device__ T result() const { return ladj; }
+};
+template <class T> struct OrderedInv {   // ordered.jl:63-77 ; interface.jl:276-281
+  T prev, ladj;
+  __device__ void init() { prev = T(0); ladj = T(0); }
+  __device__ T step(int64_t i, T v, const T*) {
+    T o;
+    if (i == 0) o = v; else { o = d_log(v - prev); ladj -= o; }
+    prev = v;
+    return o;
+  }
+  __device__ T result() const { return ladj; }
+};
+// simplex.jl:47-64 (transform) fused with :122-138 (logabsdetjac); logk[i] = log(T(K-1-i))
+template <class T, bool LADJ> struct SimplexFwd {
+  int64_t K;
+  T sum_tmp, prev_x, lp;
+  __device__ void init() { sum_tmp = T(0); prev_x = T(0); lp = T(0); }
+  __device__ T step(int64_t i, T x, const T* logk) {
+    const T e = Num<T>::eps;
+    T o = T(0);
+    if (i == 0) {
+      T z = x * (T(1) - 2 * e) + e;
+      o = d_logit(z) + logk[0];
+      if (LADJ) lp += d_log(d_max(x, e)) + d_log(d_max(T(1) - x, e));
+    } else if (i < K - 1) {
+      sum_tmp += prev_x;
+      T z = (x + e) * (T(1) - 2 * e) / ((T(1) + e) - sum_tmp);
+      o = d_logit(z) + logk[i];
+      if (LADJ) {
+        T zl = x / d_max(T(1) - sum_tmp, e);
+        lp += d_log(d_max(zl, e)) + d_log(d_max(T(1) - zl, e)) + d_log(d_max(T(1) - sum_tmp, e));
+      }
+    }
+    prev_x = x;
+    return o;
+  }
+  __device__ T result() const { return -lp; }
+};
+// simplex.jl:102-120 ; log-det = -logabsdetjac(b, x_out)
+template <class T, bool LADJ> struct SimplexInv {
+  int64_t K;
+  T sum_tmp, prev_x, lp;
+  __device__ void init() { sum_tmp = T(0); prev_x = T(0); lp = T(0); }
+  __device__ T step(int64_t i, T y, const T* logk) {
+    const T e = Num<T>::eps;
+    T x;
+    if (i == 0) {
+      T z = d_logistic(y - logk[0]);
+      x = d_clamp((z - e) / (T(1) - 2 * e), T(0), T(1));
+      if (LADJ) lp += d_log(d_max(x, e)) + d_log(d_max(T(1) - x, e));
+    } else if (i < K - 1) {
+      T z = d_logistic(y - logk[i]);
+      sum_tmp += prev_x;
+      x = d_clamp(((T(1) + e) - sum_tmp) / (T(1) - 2 * e) * z - e, T(0), T(1));
+      if (LADJ) {
+        T zl = x / d_max(T(1) - sum_tmp, e);
+        lp += d_log(d_max(zl, e)) + d_log(d_max(T(1) - zl, e)) + d_log(d_max(T(1) - sum_tmp, e));
+      }
+    } else {
+      sum_tmp += prev_x;
+      x = d_clamp(T(1) - sum_tmp, T(0), T(1));
+    }
+    prev_x = x;
+    return x;
+  }
+  __device__ T result() const { return lp; }
+};
+
+template <class T, class Op>
+__global__ __launch_bounds__(256) void seq_kernel(Op op0, const T* in, T* out, T* ladj_ps, int64_t rows_in, int64_t rows_out,
+                                                  int64_t batch, int n_logk, int accumulate, double* partials) {
+  constexpr int C = SeqCfg<T>::C, NT = SeqCfg<T>::NT, P = C + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);
+  T* tile = reinterpret_cast<T*>(smem + 32);
+  T* logk = tile + (size_t)NT * P;
+  // log(T(K-1-i)) table (simplex.jl:35,41); broadcast LDS reads in the walk
+  for (int i = threadIdx.x; i < n_logk; i += NT) logk[i] = d_log(T(n_logk - i));
+  const int64_t rows = rows_in > rows_out ? rows_in : rows_out;
+  const int li = threadIdx.x & (C - 1);       // row inside a chunk handled by this lane in load/store
+  const int lc0 = threadIdx.x / C;            // first column handled by this lane in load/store
+  double acc = 0.0;
+  for (int64_t col0 = (int64_t)blockIdx.x * NT; col0 < batch; col0 += (int64_t)gridDim.x * NT) {
+    const int ncols = (int)((batch - col0) < NT ? (batch - col0) : NT);
+    Op op = op0;
+    op.init();
+    for (int64_t c0 = 0; c0 < rows; c0 += C) {
+      __syncthreads();   // previous chunk's stores / logk staging are done
+      if (c0 + li < rows_in) {
+        for (int c = lc0; c < ncols; c += NT / C) tile[c * P + li] = in[(col0 + c) * rows_in + c0 + li];
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < ncols) {
+        T* mine = tile + threadIdx.x * P;
+        const int nr = (int)((rows - c0) < C ? (rows - c0) : C);
+#pragma unroll 4
+        for (int i = 0; i < nr; ++i) mine[i] = op.step(c0 + i, mine[i], logk);
+      }
+      __syncthreads();
+      if (out && c0 + li < rows_out) {
+        for (int c = lc0; c < ncols; c += NT / C) out[(col0 + c) * rows_out + c0 + li] = tile[c * P + li];
+      }
+    }
+    if ((int)threadIdx.x < ncols) {
+      T l = op.result();
+      if (ladj_ps) ladj_ps[col0 + threadIdx.x] = accumulate ? ladj_ps[col0 + threadIdx.x] + l : l;
+      acc += (double)l;
+    }
+  }
+  __syncthreads();
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
+template <class T, class Op>
+int launch_seq(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t rows_in, int64_t rows_out,
+               int64_t batch, int n_logk, uint32_t flags) {
+  if (batch == 0) {
+    if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
+    return BJX_OK;
+  }
+  constexpr int C = SeqCfg<T>::C, NT = SeqCfg<T>::NT;
+  const size_t smem = 32 + ((size_t)NT * (C + 1) + (size_t)n_logk) * sizeof(T);
+  BJX_REQUIRE(ctx, smem <= 64 * 1024, BJX_ERR_UNSUPPORTED, "simplex: K = %d too large for the LDS log-table", n_logk + 1);
+  const int grid = bjx_stream_grid(ctx, batch, NT);
+  double* partials = ladj_sum ? ctx->partials : nullptr;
+  hipLaunchKernelGGL((seq_kernel<T, Op>), dim3(grid), dim3(NT), smem, ctx->stream, op, in, out, ladj_ps, rows_in, rows_out, batch, n_logk,
+                     (flags & BJX_ACCUMULATE) ? 1 : 0, partials);
+  BJX_CHECK_LAUNCH(ctx);
+  if (ladj_sum) return bjx_launch_finalize(ctx, grid, ladj_sum, 0.0, 0, 0.0, flags);
+  return BJX_OK;
+}
+
+// ------------------------------------------------------------------ VecCholesky (wave per sample)
+template <class T> __device__ __forceinline__ T wave_incl_scan(T v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+// packed strict-upper index e (column-major, 0-based) -> column c (1..K-1) and row i0 (0..c-1)
+__device__ __forceinline__ void triu1_decode(int64_t e, int& c, int& i0) {
+  int cc = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);
+  while ((int64_t)cc * (cc - 1) / 2 > e) --cc;
+  while ((int64_t)(cc + 1) * cc / 2 <= e) ++cc;
+  c = cc;
+  i0 = (int)(e - (int64_t)cc * (cc - 1) / 2);
+}
+
+// Σ over the entries of this lane's column that are at or before this lane (ascending order),
+// including the part carried over from earlier 64-entry steps.
+template <class T> __device__ __forceinline__ T seg_prefix_incl(T v, int i0, T carry) {
+  const int lane = threadIdx.x & 63;
+  T S = wave_incl_scan(v);
+  int head = lane - i0;                       // lane of my column's first entry (may be < 0)
+  T base = __shfl(S, head > 0 ? head - 1 : 0, 64);
+  return S - (head > 0 ? base : T(0)) + (head < 0 ? carry : T(0));
+}
+
+// corr.jl:370-399 (_inv_link_chol_lkj, vector form) and :485-501 (_logabsdetjac_inv_chol)
+template <class T, bool WRITE_W>
+__global__ __launch_bounds__(256) void chol_inv_kernel(const T* y, T* W, T* ladj_ps, int64_t K, int64_t batch, int lower,
+                                                       int accumulate, double* partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* diag = reinterpret_cast<T*>(smem + 32) + (size_t)wave * K;
+  const int64_t nv = K * (K - 1) / 2;
+  double acc = 0.0;
+  for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < batch; s += (int64_t)gridDim.x * 4) {
+    const T* ys = y + s * nv;
+    T* Ws = W + s * K * K;
+    T carry = T(0), lj = T(0);
+    for (int64_t e0 = 0; e0 < nv; e0 += 64) {
+      const int64_t e = e0 + lane;
+      const bool valid = e < nv;
+      int c = 1, i0 = 0;
+      if (valid) triu1_decode(e, c, i0);
+      const T yv = valid ? ys[e] : T(0);
+      const T lc = valid ? d_logcosh(yv) : T(0);
+      const T incl = seg_prefix_incl<T>(lc, valid ? i0 : 0, carry);   // Σ_{k<=i} logcosh  => log_remainder_after = -incl
+      const bool last = valid && (i0 == c - 1);
+      if (valid) {
+        lj += last ? T(-2) * incl : -incl;        // logJ += log_remainder (each entry) + once more per column (:385-389)
+        if (WRITE_W) {
+          const T wv = d_tanh(yv) * d_exp(-(incl - lc));   // z * exp(log_remainder_before) (:383)
+          if (!lower) Ws[(int64_t)c * K + i0] = wv; else Ws[(int64_t)i0 * K + c] = wv;
+          if (last) diag[c] = d_exp(-incl);       // W[j,j] = exp(log_remainder) (:390)
+        }
+      }
+      const T incl63 = __shfl(incl, 63, 64);
+      const int last63 = __shfl((int)last, 63, 64);
+      carry = last63 ? T(0) : incl63;
+    }
+    if (WRITE_W) {
+      if (lane == 0) diag[0] = T(1);
+      // diagonal + zero fill of the other triangle (:391-395); column-major, rows c..K-1 of column c
+      for (int c = 0; c < K; ++c) {
+        for (int r = c + lane; r < K; r += 64) {
+          const T v = (r == c) ? diag[c] : T(0);
+          if (!lower) Ws[(int64_t)c * K + r] = v; else Ws[(int64_t)r * K + c] = v;
+        }
+      }
+    }
+    lj = group_sum<64>(lj);
+    if (lane == 0) {
+      if (ladj_ps) ladj_ps[s] = accumulate ? ladj_ps[s] + lj : lj;
+      acc += (double)lj;
+    }
+  }
+  __syncthreads();
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
+// corr.jl:314-337 (_link_chol_lkj_from_upper / _from_lower) ; log-det = -_logabsdetjac_inv_chol(y) (:235-237)
+template <class T>
+__global__ __launch_bounds__(256) void chol_fwd_kernel(const T* W, T* y, T* ladj_ps, int64_t K, int64_t batch, int lower,
+                                                       int accumulate, int want_ladj, double* partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t nv = K * (K - 1) / 2;
+  double acc = 0.0;
+  for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < batch; s += (int64_t)gridDim.x * 4) {
+    const T* Ws = W + s * K * K;
+    T* ys = y + s * nv;
+    // pass A, descending: remainder_sq = W[j,j]^2 + Σ_{k>i} W[k,j]^2 (suffix sum inside the column)
+    T carry = T(0);   // Σ w² of the straddling column's entries that live in higher steps
+    const int64_t steps = (nv + 63) / 64;
+    for (int64_t st = steps - 1; st >= 0; --st) {
+      const int64_t e = st * 64 + lane;
+      const bool valid = e < nv;
+      int c = 1, i0 = 0;
+      if (valid) triu1_decode(e, c, i0);
+      const T w = valid ? (!lower ? Ws[(int64_t)c * K + i0] : Ws[(int64_t)i0 * K + c]) : T(0);
+      const T dg = valid ? Ws[(int64_t)c * K + c] : T(1);
+      const T S = wave_incl_scan(w * w);
+      const int nvalid = (int)((nv - st * 64) < 64 ? (nv - st * 64) : 64);
+      int tail = lane + (c - 1 - i0);                 // lane of my column's last entry (may be > last valid lane)
+      const bool in_step = tail <= nvalid - 1;
+      const T Stail = __shfl(S, in_step ? tail : nvalid - 1, 64);
+      const T suffix = Stail - S + (in_step ? T(0) : carry);   // Σ_{k>i0} w_k²
+      if (valid) {
+        T yv;
+        if (i0 == 0) yv = d_atanh(w);                            // :322
+        else yv = d_asinh(w / d_sqrt(dg * dg + suffix));         // :327-329
+        ys[e] = yv;
+      }
+      // carry for the next (lower) step: Σ w² of lane 0's column inside this step (+ old carry if it runs past)
+      int c0, i00;
+      triu1_decode(st * 64, c0, i00);
+      int tail0 = (c0 - 1 - i00);
+      const bool in0 = tail0 <= nvalid - 1;
+      const T S0 = __shfl(S, in0 ? tail0 : nvalid - 1, 64);
+      carry = (i00 == 0) ? T(0) : (S0 + (in0 ? T(0) : carry));
+    }
+    if (want_ladj) {
+      // pass B, ascending over the y just written (same wave, same lanes -> program order)
+      T cr = T(0), lj = T(0);
+      for (int64_t e0 = 0; e0 < nv; e0 += 64) {
+        const int64_t e = e0 + lane;
+        const bool valid = e < nv;
+        int c = 1, i0 = 0;
+        if (valid) triu1_decode(e, c, i0);
+        const T lc = valid ? d_logcosh(ys[e]) : T(0);
+        const T incl = seg_prefix_incl<T>(lc, valid ? i0 : 0, cr);
+        const bool last = valid && (i0 == c - 1);
+        if (valid) lj += last ? T(-2) * incl : -incl;
+        const T incl63 = __shfl(incl, 63, 64);
+        const int last63 = __shfl((int)last, 63, 64);
+        cr = last63 ? T(0) : incl63;
+      }
+      lj = -group_sum<64>(lj);
+      if (lane == 0) {
+        if (ladj_ps) ladj_ps[s] = accumulate ? ladj_ps[s] + lj : lj;
+        acc += (double)lj;
+      }
+    }
+  }
+  __syncthreads();
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
+template <class T>
+int chol_impl(bjx_ctx* ctx, int inverse, int uplo, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t K, int64_t batch,
+              uint32_t flags) {
+  if (batch == 0) {
+    if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
+    return BJX_OK;
+  }
+  const int lower = (uplo == 'L') ? 1 : 0;
+  const int grid = bjx_stream_grid(ctx, batch, 4);
+  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  double* partials = ladj_sum ? ctx->partials : nullptr;
+  if (inverse) {
+    const size_t smem = 32 + (size_t)4 * K * sizeof(T);
+    BJX_REQUIRE(ctx, smem <= 64 * 1024, BJX_ERR_UNSUPPORTED, "bjx_vec_cholesky: K = %lld too large", (long long)K);
+    if (out) hipLaunchKernelGGL((chol_inv_kernel<T, true>), dim3(grid), dim3(256), smem, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, partials);
+    else hipLaunchKernelGGL((chol_inv_kernel<T, false>), dim3(grid), dim3(256), smem, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, partials);
+  } else {
+    const int want = (ladj_ps || ladj_sum) ? 1 : 0;
+    hipLaunchKernelGGL((chol_fwd_kernel<T>), dim3(grid), dim3(256), 32, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, want, partials);
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  if (ladj_sum) return bjx_launch_finalize(ctx, grid, ladj_sum, 0.0, 0, 0.0, flags);
+  return BJX_OK;
+}
+}  // namespace
+
+BJX_API int bjx_ordered(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out, void* ladj_ps, double* ladj_sum,
+                        int64_t dim, int64_t batch, uint32_t flags) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_ordered: input must not be empty (ordered.jl:26)");
+  BJX_REQUIRE(ctx, (in && out) || batch == 0, BJX_ERR_ARG, "bjx_ordered: null pointer");
+  if (dt == BJX_F32) {
+    if (!inverse) return launch_seq<float>(ctx, OrderedFwd<float>{}, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, dim, batch, 0, flags);
+    return launch_seq<float>(ctx, OrderedInv<float>{}, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, dim, batch, 0, flags);
+  }
+  if (dt == BJX_F64) {
+    if (!inverse) return launch_seq<double>(ctx, OrderedFwd<double>{}, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, dim, batch, 0, flags);
+    return launch_seq<double>(ctx, OrderedInv<double>{}, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, dim, batch, 0, flags);
+  }
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_ordered: bad dtype %d", (int)dt);
+}
+
+namespace {
+template <class T>
+int simplex_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags) {
+  const bool want = ladj_ps || ladj_sum;
+  const int nlk = (int)(K - 1);
+  if (!inverse) {
+    if (want) { SimplexFwd<T, true> op; op.K = K; return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K, K - 1, batch, nlk, flags); }
+    SimplexFwd<T, false> op; op.K = K;
+    return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K, K - 1, batch, nlk, flags);
+  }
+  if (want) { SimplexInv<T, true> op; op.K = K; return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K - 1, K, batch, nlk, flags); }
+  SimplexInv<T, false> op; op.K = K;
+  return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K - 1, K, batch, nlk, flags);
+}
+}  // namespace
+
+BJX_API int bjx_simplex(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out, void* ladj_ps, double* ladj_sum,
+                        int64_t K, int64_t batch, uint32_t flags) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, K > 1, BJX_ERR_SHAPE, "bjx_simplex: x needs to be of length greater than 1 (simplex.jl:30), got K=%lld", (long long)K);
+  BJX_REQUIRE(ctx, batch >= 0, BJX_ERR_SHAPE, "bjx_simplex: negative batch");
+  BJX_REQUIRE(ctx, in || batch == 0, BJX_ERR_ARG, "bjx_simplex: null input");
+  BJX_REQUIRE(ctx, out || !inverse, BJX_ERR_ARG, "bjx_simplex: the inverse needs an output buffer");
+  if (dt == BJX_F32) return simplex_impl<float>(ctx, inverse, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, K, batch, flags);
+  if (dt == BJX_F64) return simplex_impl<double>(ctx, inverse, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, K, batch, flags);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_simplex: bad dtype %d", (int)dt);
+}
+
+BJX_API int bjx_vec_cholesky(bjx_ctx* ctx, bjx_dtype dt, int inverse, int uplo, const void* in, void* out, void* ladj_ps,
+                             double* ladj_sum, int64_t K, int64_t batch, uint32_t flags) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, uplo == 'U' || uplo == 'L', BJX_ERR_ARG, "mode must be either :U (upper triangular) or :L (lower triangular)");  // corr.jl:215-219
+  BJX_REQUIRE(ctx, K >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_vec_cholesky: bad size");
+  BJX_REQUIRE(ctx, in || batch == 0 || K == 1, BJX_ERR_ARG, "bjx_vec_cholesky: null input");
+  BJX_REQUIRE(ctx, out || inverse || batch == 0, BJX_ERR_ARG, "bjx_vec_cholesky: the forward link needs an output buffer");
+  if (dt == BJX_F32) return chol_impl<float>(ctx, inverse, uplo, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, K, batch, flags);
+  if (dt == BJX_F64) return chol_impl<double>(ctx, inverse, uplo, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, K, batch, flags);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_vec_cholesky: bad dtype %d", (int)dt);
+}

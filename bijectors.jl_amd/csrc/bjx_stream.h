@@ -1,0 +1,107 @@
+// bjx_stream.h — column-group streaming skeleton shared by the per-element bijectors that need
+// a per-sample log-det (RQS, BatchNorm, Coupling) and by Permute.
+//
+// Mapping (SURVEY.md §7 family F2/F4): a column (sample) is `dim` contiguous elements, so G
+// consecutive lanes own one column and read it as 16-byte packs -> every wave instruction covers a
+// contiguous 1 KiB run of HBM.  The functor F transforms a pack in registers and returns the pack's
+// log-det contribution; the G lanes are summed with a butterfly of wave shuffles, lane 0 of the
+// group writes ladj_ps[col], and the block publishes one f64 partial for the global sum.
+#pragma once
+#include "bjx_internal.h"
+
+namespace bjx {
+
+constexpr int STREAM_U = 4;
+
+// F interface:
+//   __device__ void stage(char* smem) const;                       // cooperative LDS staging (+sync)
+//   template <int V> __device__ T apply(const char* smem, Pack<T,V>& p, const T* xcol, int64_t row, int64_t col) const;
+//       row = index of p.v[0] inside the column; xcol = start of the input column (for gathers)
+//   static constexpr bool kLoadInput   (false: apply() gathers from xcol itself, e.g. Permute)
+//   double per_sample_const            (host-known constant added to every ladj_ps entry)
+//   const double* per_sample_dev       (device constant added likewise, or null)
+template <class T, int V, bool NT, class F>
+__global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T* y, T* ladj_ps, int64_t dim,
+                                                       int64_t batch, int G, int accumulate, double* partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);   // first 32 bytes
+  char* fsm = smem + 32;
+  f.stage(fsm);
+  const int gl = threadIdx.x & (G - 1);
+  const int cols_per_block = blockDim.x / G;
+  const int64_t col_stride = (int64_t)gridDim.x * cols_per_block;
+  const int64_t nvc = dim / V;
+  double acc = 0.0;
+  for (int64_t col = (int64_t)blockIdx.x * cols_per_block + threadIdx.x / G; col < batch; col += col_stride) {
+    const T* xc = x + col * dim;
+    T* yc = y + col * dim;
+    T l = T(0);
+    for (int64_t v0 = 0; v0 < nvc; v0 += (int64_t)G * STREAM_U) {
+      Pack<T, V> p[STREAM_U];
+#pragma unroll
+      for (int u = 0; u < STREAM_U; ++u) {
+        int64_t v = v0 + (int64_t)u * G + gl;
+        if (F::kLoadInput && v < nvc) p[u] = load_pack<T, V, NT>(xc + v * V);
+      }
+#pragma unroll
+      for (int u = 0; u < STREAM_U; ++u) {
+        int64_t v = v0 + (int64_t)u * G + gl;
+        if (v < nvc) {
+          l += f.template apply<V>(fsm, p[u], xc, v * V, col);
+          store_pack<T, V, NT>(yc + v * V, p[u]);
+        }
+      }
+    }
+    l = group_sum_rt(l, G);
+    if (gl == 0) {
+      if (ladj_ps) {
+        T out = l + (T)(f.per_sample_const + (f.per_sample_dev ? *f.per_sample_dev : 0.0));
+        if (accumulate) out += ladj_ps[col];
+        ladj_ps[col] = out;
+      }
+      acc += (double)l;
+    }
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
+struct ColLaunch {
+  int V, G, grid;
+};
+
+// choose pack width / lanes per column / grid for a [dim, batch] problem
+template <class T> inline ColLaunch col_launch_cfg(const bjx_ctx* ctx, const void* x, const void* y, int64_t dim, int64_t batch) {
+  ColLaunch c;
+  constexpr int VW = Vec16<T>::N;
+  const bool v_ok = bjx_aligned16(x) && bjx_aligned16(y) && dim % VW == 0;
+  c.V = v_ok ? VW : 1;
+  const int64_t packs = dim / c.V;
+  int G = 1;
+  while (G < 64 && G < packs) G <<= 1;
+  c.G = G;
+  c.grid = bjx_stream_grid(ctx, batch, 256 / G);
+  return c;
+}
+
+template <class T, class F>
+inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, T* y, T* ladj_ps, double* ladj_sum,
+                           int64_t dim, int64_t batch, uint32_t flags, double sum_const) {
+  if (dim * batch == 0) {
+    if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
+    return BJX_OK;
+  }
+  ColLaunch c = col_launch_cfg<T>(ctx, x, y, dim, batch);
+  constexpr int VW = Vec16<T>::N;
+  const size_t smem = 32 + f_smem;
+  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  double* partials = ladj_sum ? ctx->partials : nullptr;
+  if (c.V == VW)
+    hipLaunchKernelGGL((colgroup_kernel<T, VW, false, F>), dim3(c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, partials);
+  else
+    hipLaunchKernelGGL((colgroup_kernel<T, 1, false, F>), dim3(c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, partials);
+  BJX_CHECK_LAUNCH(ctx);
+  if (ladj_sum) return bjx_launch_finalize(ctx, c.grid, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, 0.0, flags);
+  return BJX_OK;
+}
+
+}  // namespace bjx

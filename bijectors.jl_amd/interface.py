@@ -1,0 +1,954 @@
+"""Host-side mirror of the reference's Bijector interface for the hot path.
+
+Same names, argument meaning and error behaviour as Bijectors.jl v0.16.2
+(src/interface.jl:133-281 and the per-bijector files under src/bijectors/), so the parity tests
+read like the reference's own tests.  All array math happens in libbjx_hip.so through the C ABI
+(include/bjx.h); PyTorch is used only for device memory and the HIP stream handle.
+
+Array orientation is the reference's: a batch is a 2-D tensor of shape ``(dim, batch)`` stored
+column-major (``x.stride() == (1, dim)``, i.e. ``torch.empty(batch, dim).T``), a single sample is
+a 1-D tensor.  `colmajor(t)` converts.  Outputs use the same convention.
+
+Return shapes follow the reference bijector by bijector (SURVEY.md §8a'): elementwise bijectors,
+Simplex and chains return ONE scalar log-det for a matrix input; Ordered / Planar / Radial /
+InvertibleBatchNorm return a per-column vector; Planar returns a namedtuple
+``(result, logabsdetjac)``.  Every bijector additionally accepts ``per_sample=True`` in
+`with_logabsdet_jacobian` to get the per-column vector (what a density evaluation needs,
+SURVEY.md §8a'' row 2).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import namedtuple
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+__all__ = [
+    "Transform", "Bijector", "Inverse", "ComposedFunction", "Elementwise", "elementwise", "exp", "log", "identity",
+    "Shift", "Scale", "Logit", "LeakyReLU", "TruncatedBijector", "SignFlip", "OrderedBijector", "SimplexBijector",
+    "VecCholeskyBijector", "Permute", "PlanarLayer", "RadialLayer", "InvertibleBatchNorm", "RationalQuadraticSpline",
+    "PartitionMask", "Coupling", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
+    "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
+    "PlanarResult",
+]
+
+PlanarResult = namedtuple("PlanarResult", ["result", "logabsdetjac"])  # planar_layer.jl:109
+
+# ------------------------------------------------------------------ device plumbing
+_ctx_cache: dict = {}
+
+
+class _Ctx:
+    """One bjx_ctx per (device, stream)."""
+
+    def __init__(self, device: int, stream_ptr: int):
+        lib = L.load()
+        h = C.c_void_p()
+        rc = lib.bjx_create(device, C.c_void_p(stream_ptr), C.byref(h))
+        if rc != 0:
+            raise L.BjxError(f"bjx_create(device={device}) failed with status {rc}")
+        self.h = h
+        self.device = device
+
+    def __del__(self):
+        try:
+            L.load().bjx_destroy(self.h)
+        except Exception:
+            pass
+
+
+def context(device: Optional[torch.device] = None) -> _Ctx:
+    if not torch.cuda.is_available():
+        raise RuntimeError("bijectors_amd needs a ROCm GPU; there is no CPU fallback")
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev, stream)
+    c = _ctx_cache.get(key)
+    if c is None:
+        c = _Ctx(dev, stream)
+        _ctx_cache[key] = c
+    return c
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.BJX_F32
+    if t.dtype == torch.float64:
+        return L.BJX_F64
+    raise TypeError(f"only Float32/Float64 arrays are supported, got {t.dtype}")
+
+
+def colmajor(t: torch.Tensor) -> torch.Tensor:
+    """Return `t` (shape (dim, batch)) with Julia's column-major memory layout."""
+    if t.dim() != 2:
+        return t.contiguous()
+    if t.stride(0) == 1 and t.stride(1) == max(t.shape[0], 1) or t.shape[1] <= 1 and t.stride(0) == 1:
+        return t
+    return t.T.contiguous().T
+
+
+def _check_dev(x: torch.Tensor):
+    if not isinstance(x, torch.Tensor):
+        raise TypeError("expected a torch.Tensor on a ROCm device")
+    if not x.is_cuda:
+        raise RuntimeError("bijectors_amd operates on ROCm device tensors only (no CPU fallback)")
+
+
+def _prep(x: torch.Tensor):
+    """-> (x column-major, dim, batch, is_vector)"""
+    _check_dev(x)
+    if x.dim() == 1:
+        return x.contiguous(), x.shape[0], 1, True
+    if x.dim() == 2:
+        xc = colmajor(x)
+        return xc, x.shape[0], x.shape[1], False
+    raise ValueError("expected a vector or a (dim, batch) matrix")
+
+
+def _empty(rows: int, batch: int, like: torch.Tensor, vec: bool) -> torch.Tensor:
+    if vec:
+        return torch.empty(rows, dtype=like.dtype, device=like.device)
+    return torch.empty((batch, rows), dtype=like.dtype, device=like.device).T
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _Out:
+    """Allocates the optional log-det outputs of one ABI call."""
+
+    def __init__(self, x: torch.Tensor, batch: int, per_sample, want_ladj: bool = True, ret_vector: bool = False):
+        """per_sample: False (reference shape), True (per-column vector) or "both"
+        (per-column vector AND the float64 global sum, used by the sharded path)."""
+        self.both = per_sample == "both"
+        self.sum64 = per_sample == "sum64"          # only the float64 global sum (sharded scalar path)
+        want_ps = want_ladj and not self.sum64 and (bool(per_sample) or ret_vector)
+        want_sum = want_ladj and (self.both or self.sum64 or not want_ps)
+        self.ps = torch.empty(batch, dtype=x.dtype, device=x.device) if want_ps else None
+        self.sum = torch.empty(1, dtype=torch.float64, device=x.device) if want_sum else None
+        self.dtype = x.dtype
+
+    def scalar(self) -> torch.Tensor:
+        return self.sum[0].to(self.dtype)
+
+    def result(self, vec_scalar: bool = False):
+        if self.both:
+            return self.ps, self.sum
+        if self.sum64:
+            return self.sum
+        if self.ps is not None:
+            return self.ps[0] if vec_scalar else self.ps
+        return self.scalar()
+
+
+def _param(p, like: torch.Tensor) -> torch.Tensor:
+    """device tensor for a parameter (python number / sequence / tensor)."""
+    if isinstance(p, torch.Tensor):
+        return p.to(device=like.device, dtype=like.dtype).contiguous()
+    return torch.as_tensor(p, dtype=like.dtype, device=like.device).contiguous()
+
+
+# ------------------------------------------------------------------ interface (src/interface.jl)
+class Transform:
+    """src/interface.jl:133-135"""
+
+    def __call__(self, x):
+        return transform(self, x)
+
+    def __matmul__(self, inner):  # `outer @ inner` plays the role of Julia's `outer ∘ inner`
+        return ComposedFunction(self, inner)
+
+    def __eq__(self, other):
+        return type(self) is type(other) and self._key() == other._key()
+
+    def __hash__(self):
+        return hash((type(self).__name__,))
+
+    def _key(self):
+        return ()
+
+    # defaults: subclasses implement _wlj(x, per_sample) -> (y, ladj)
+    def _wlj(self, x, per_sample: bool, want_ladj: bool = True):
+        raise NotImplementedError(f"`with_logabsdet_jacobian` not implemented for {type(self).__name__}")
+
+
+class Bijector(Transform):
+    """src/interface.jl:271"""
+
+
+def isinvertible(t) -> bool:  # interface.jl:238,273
+    return isinstance(t, (Bijector, Inverse, Elementwise)) or (isinstance(t, ComposedFunction) and isinvertible(t.inner) and isinvertible(t.outer))
+
+
+def isclosedform(t) -> bool:  # interface.jl:231 ; planar_layer.jl:188 ; composed.jl:2
+    if isinstance(t, ComposedFunction):
+        return isclosedform(t.inner) and isclosedform(t.outer)
+    if isinstance(t, Inverse) and isinstance(t.orig, PlanarLayer):
+        return False
+    return True
+
+
+class Inverse(Transform):
+    """src/interface.jl:246-256"""
+
+    def __init__(self, orig: Transform):
+        if not isinvertible(orig):
+            raise ValueError(f"{orig} is not invertible")
+        self.orig = orig
+
+    def _key(self):
+        return (self.orig,)
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        return self.orig._wlj_inv(x, per_sample, want_ladj)
+
+
+def inverse(t):
+    """src/interface.jl:265-266 (+ shift.jl:12, leaky_relu.jl:16, composed inverse)"""
+    if isinstance(t, Inverse):
+        return t.orig
+    if isinstance(t, ComposedFunction):
+        return ComposedFunction(inverse(t.inner), inverse(t.outer))
+    if isinstance(t, Elementwise):
+        if t.f is exp:
+            return Elementwise(log)
+        if t.f is log:
+            return Elementwise(exp)
+        return t
+    if isinstance(t, Shift):
+        return Shift(-t.a if not isinstance(t.a, (list, tuple)) else [-v for v in t.a])
+    if isinstance(t, LeakyReLU):
+        return LeakyReLU(1.0 / t.alpha)
+    if isinstance(t, SignFlip):
+        return SignFlip()
+    if isinstance(t, Permute):
+        inv = [0] * len(t.src)
+        for i, s in enumerate(t.src):
+            inv[s] = i
+        return Permute._from_src(inv)
+    if isinstance(t, Transform):
+        return Inverse(t)
+    raise TypeError(f"cannot invert {t!r}")
+
+
+def transform(b, x):
+    """src/interface.jl:156-166"""
+    return b._wlj(x, per_sample=False, want_ladj=False)[0]
+
+
+def logabsdetjac(b, x):
+    """src/interface.jl:183-192"""
+    return _shape_result(b, *b._wlj(x, per_sample=False))[1]
+
+
+def with_logabsdet_jacobian(b, x, per_sample: bool = False):
+    """ChangesOfVariables.with_logabsdet_jacobian for the hot-path bijectors.
+
+    per_sample=False reproduces the reference's return shape; per_sample=True always returns the
+    per-column log-det vector."""
+    y, l = b._wlj(x, per_sample=per_sample)
+    if per_sample:
+        return y, l
+    return _shape_result(b, y, l)
+
+
+def _shape_result(b, y, l):
+    if isinstance(b, PlanarLayer):
+        return PlanarResult(y, l)  # planar_layer.jl:109 returns a NamedTuple
+    return y, l
+
+
+def _fused_ops(b):
+    """Op list when `b` is ONE fusable elementwise chain, else None."""
+    if isinstance(b, ComposedFunction):
+        ops = []
+        for s in b._stages():
+            o = _stage_ops(s)
+            if o is None:
+                return None
+            ops.extend(o)
+        return ops if len(ops) <= L.BJX_MAX_OPS else None
+    return _stage_ops(b)
+
+
+def transform_(b, x, y=None):
+    """transform!(b, x[, y]) — src/interface.jl:175-176 (composed.jl:7-10 for chains)"""
+    tgt = x if y is None else y
+    ops = _fused_ops(b)
+    if ops is not None:
+        _run_chain(ops, x, False, False, out_y=tgt)
+        return tgt
+    tgt.copy_(transform(b, x))
+    return tgt
+
+
+def with_logabsdet_jacobian_(b, x, y=None, logjac=0.0):
+    """with_logabsdet_jacobian!(b, x[, y, logjac]) — src/interface.jl:212-218: (y, logjac + new).
+    Elementwise chains write directly into `y` in one launch (composed.jl:22-25)."""
+    tgt = x if y is None else y
+    ops = _fused_ops(b)
+    if ops is not None:
+        _, l = _run_chain(ops, x, False, True, out_y=tgt)
+        return tgt, (l if isinstance(logjac, float) and logjac == 0.0 else logjac + l)
+    out, l = with_logabsdet_jacobian(b, x)
+    tgt.copy_(out)
+    return tgt, logjac + l
+
+
+def output_size(b, sz):
+    """src/interface.jl:85-86 and the per-bijector overloads"""
+    sz = tuple(sz)
+    if isinstance(b, ComposedFunction):
+        return output_size(b.outer, output_size(b.inner, sz))
+    if isinstance(b, SimplexBijector):  # simplex.jl:6-12
+        return (sz[0] - 1,) + sz[1:]
+    if isinstance(b, Inverse) and isinstance(b.orig, SimplexBijector):
+        return (sz[0] + 1,) + sz[1:]
+    if isinstance(b, VecCholeskyBijector):  # corr.jl:256-259
+        n = sz[0]
+        return (n * (n - 1) // 2,)
+    if isinstance(b, Inverse) and isinstance(b.orig, VecCholeskyBijector):
+        n = _triu1_dim_from_length(sz[0])
+        return (n, n)
+    return sz
+
+
+def _triu1_dim_from_length(d: int) -> int:  # src/utils.jl:99
+    return (1 + math.isqrt(1 + 8 * d)) // 2
+
+
+# ------------------------------------------------------------------ elementwise chain (F1)
+def exp(x):  # scalar functions, used as tags by `elementwise`
+    return math.exp(x)
+
+
+def log(x):
+    return math.log(x)
+
+
+def identity(x):
+    return x
+
+
+class Elementwise(Transform):
+    """`Base.Fix1(broadcast, f)` — src/interface.jl:6,33"""
+
+    def __init__(self, f):
+        if f not in (exp, log):
+            raise NotImplementedError("only elementwise(exp) / elementwise(log) are device kernels (SURVEY.md §8b)")
+        self.f = f
+
+    def _key(self):
+        return (self.f,)
+
+    def _ops(self, inv=False):
+        kind = L.OP_EXP if (self.f is exp) != inv else L.OP_LOG
+        return [(kind, None, None)]
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        return _run_chain(self._ops(), x, per_sample, want_ladj)
+
+
+def elementwise(f):
+    """src/interface.jl:33-39"""
+    if f is identity:
+        return identity
+    if isinstance(f, ComposedFunction):
+        return ComposedFunction(elementwise(f.outer), elementwise(f.inner))
+    return Elementwise(f)
+
+
+class _ChainOp(Bijector):
+    """Bijectors that are single ops of the fused chain kernel."""
+
+    def _ops(self, inv=False):
+        raise NotImplementedError
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        return _run_chain(self._ops(False), x, per_sample, want_ladj)
+
+    def _wlj_inv(self, x, per_sample, want_ladj=True):
+        return _run_chain(self._ops(True), x, per_sample, want_ladj)
+
+
+def _is_seq(p):
+    return isinstance(p, (list, tuple)) or (isinstance(p, torch.Tensor) and p.dim() >= 1)
+
+
+class Shift(_ChainOp):
+    """shift.jl:4-24"""
+
+    def __init__(self, a):
+        self.a = a
+
+    def _key(self):
+        return (_keyify(self.a),)
+
+    def _ops(self, inv=False):
+        a = self.a
+        if inv:
+            a = -a if not isinstance(a, (list, tuple)) else [-v for v in a]
+        return [(L.OP_SHIFT, a, None)]
+
+
+class Scale(_ChainOp):
+    """scale.jl:1-36 (scalar and vector `a`; matrix `a` is out of scope)"""
+
+    def __init__(self, a):
+        if isinstance(a, torch.Tensor) and a.dim() > 1:
+            raise NotImplementedError("Scale with a matrix parameter is not on the hot path (SURVEY.md §8f-4)")
+        self.a = a
+
+    def _key(self):
+        return (_keyify(self.a),)
+
+    def _ops(self, inv=False):
+        return [(L.OP_SCALE_INV if inv else L.OP_SCALE, self.a, None)]
+
+
+class Logit(_ChainOp):
+    """logit.jl:4-30"""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    def _key(self):
+        return (self.a, self.b)
+
+    def _ops(self, inv=False):
+        return [(L.OP_LOGIT_INV if inv else L.OP_LOGIT, self.a, self.b)]
+
+
+class LeakyReLU(_ChainOp):
+    """leaky_relu.jl:10-29"""
+
+    def __init__(self, alpha):
+        self.alpha = alpha
+
+    def _key(self):
+        return (self.alpha,)
+
+    def _ops(self, inv=False):
+        return [(L.OP_LEAKY_RELU, 1.0 / self.alpha if inv else self.alpha, None)]
+
+
+class TruncatedBijector(_ChainOp):
+    """truncated.jl:4-91"""
+
+    def __init__(self, lb, ub):
+        self.lb, self.ub = lb, ub
+
+    def _key(self):
+        return (_keyify(self.lb), _keyify(self.ub))
+
+    def _ops(self, inv=False):
+        return [(L.OP_TRUNCATED_INV if inv else L.OP_TRUNCATED, self.lb, self.ub)]
+
+
+class SignFlip(_ChainOp):
+    """ordered.jl:1-7"""
+
+    def _ops(self, inv=False):
+        return [(L.OP_SIGNFLIP, None, None)]
+
+
+def _keyify(p):
+    if isinstance(p, torch.Tensor):
+        return tuple(p.detach().cpu().reshape(-1).tolist())
+    if isinstance(p, (list, tuple)):
+        return tuple(p)
+    return p
+
+
+class ComposedFunction(Transform):
+    """Base.ComposedFunction: `outer ∘ inner` — src/bijectors/composed.jl:1-25"""
+
+    def __init__(self, outer, inner):
+        self.outer, self.inner = outer, inner
+
+    def _key(self):
+        return (self.outer, self.inner)
+
+    def _stages(self):
+        """Application order (inner first)."""
+        out = []
+        for part in (self.inner, self.outer):
+            if isinstance(part, ComposedFunction):
+                out.extend(part._stages())
+            elif part is identity:
+                continue
+            else:
+                out.append(part)
+        return out
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        # Walk the chain; maximal runs of fusable elementwise stages become ONE kernel launch.
+        stages = self._stages()
+        y = x
+        total = None
+        run: list = []
+
+        def flush(y, total):
+            if not run:
+                return y, total
+            y2, l = _run_chain(list(run), y, per_sample, want_ladj)
+            run.clear()
+            return y2, _add_ladj(total, l)
+
+        for s in stages:
+            ops = _stage_ops(s)
+            if ops is not None and len(run) + len(ops) <= L.BJX_MAX_OPS:
+                run.extend(ops)
+                continue
+            y, total = flush(y, total)
+            if ops is not None:
+                run.extend(ops)
+            else:
+                y, l = s._wlj(y, per_sample, want_ladj)
+                total = _add_ladj(total, l)
+        y, total = flush(y, total)
+        return y, total
+
+
+def _add_ladj(a, b):
+    if a is None:
+        return b
+    if b is None:
+        return a
+    if isinstance(a, tuple):  # per_sample="both": (per-column vector, float64 sum)
+        return (a[0] + b[0], a[1] + b[1])
+    return a + b  # scalar + per-column vector broadcasts exactly like Julia's `+` in composed.jl:13
+
+
+def _stage_ops(s):
+    if isinstance(s, Elementwise):
+        return s._ops()
+    if isinstance(s, _ChainOp):
+        return s._ops(False)
+    if isinstance(s, Inverse) and isinstance(s.orig, _ChainOp):
+        return s.orig._ops(True)
+    return None
+
+
+def _run_chain(ops: Sequence, x: torch.Tensor, per_sample: bool, want_ladj: bool = True, out_y: Optional[torch.Tensor] = None):
+    """One bjx_chain launch.  ops: [(kind, p0, p1)] in application order."""
+    xc, dim, batch, vec = _prep(x)
+    ctx = context(xc.device)
+    arr = (L.BjxOp * max(len(ops), 1))()
+    keep = []
+    for i, (kind, p0, p1) in enumerate(ops):
+        o = arr[i]
+        o.kind, o.param_len, o.p0, o.p1, o.v0, o.v1 = kind, 0, 0.0, 0.0, None, None
+        seq = any(_is_seq(p) for p in (p0, p1) if p is not None)
+        for j, p in enumerate((p0, p1)):
+            if p is None:
+                continue
+            if seq:
+                t = _param(p, xc).reshape(-1) if _is_seq(p) else torch.full((dim,), float(p), dtype=xc.dtype, device=xc.device)
+                if t.numel() != dim:
+                    raise ValueError(f"DimensionMismatch: parameter of length {t.numel()} for input with {dim} rows")
+                keep.append(t)
+                o.param_len = dim
+                setattr(o, f"v{j}", t.data_ptr())
+            else:
+                o.param_len = 1
+                setattr(o, f"p{j}", float(p))
+    if out_y is None:
+        y = _empty(dim, batch, xc, vec)
+    else:  # transform!/with_logabsdet_jacobian!: write straight into the caller's buffer (may alias x)
+        y = out_y
+        if y.shape != x.shape or y.dtype != xc.dtype or y.device != xc.device or (y.dim() == 2 and colmajor(y) is not y):
+            raise ValueError("DimensionMismatch: output buffer must match the input's shape, dtype and column-major layout")
+    out = _Out(xc, batch, per_sample, want_ladj)
+    flags = L.BJX_REF_VECTOR_SCALE_LADJ  # reproduce scale.jl:31-32 in the scalar the reference returns
+    rc = L.load().bjx_chain(ctx.h, _dt(xc), arr, len(ops), _ptr(xc), _ptr(y), _ptr(out.ps), _ptr(out.sum), dim, batch, flags)
+    L.check(ctx.h, rc, "bjx_chain")
+    del keep
+    if not want_ladj:
+        return y, None
+    return y, out.result()
+
+
+# ------------------------------------------------------------------ structured bijectors
+def _call_struct(fn_name: str, x, rows_out: int, per_sample_ret: bool, per_sample: bool, want_ladj: bool, pre_args, post_dims):
+    """Shared launcher: fn(ctx, dt, *pre_args, in, out, ladj_ps, ladj_sum, *post_dims, flags)."""
+    xc, dim, batch, vec = _prep(x)
+    ctx = context(xc.device)
+    y = _empty(rows_out, batch, xc, vec)
+    out = _Out(xc, batch, per_sample, want_ladj, ret_vector=per_sample_ret)
+    fn = getattr(L.load(), fn_name)
+    rc = fn(ctx.h, _dt(xc), *pre_args, _ptr(xc), _ptr(y), _ptr(out.ps), _ptr(out.sum), *post_dims, batch, 0)
+    L.check(ctx.h, rc, fn_name)
+    if not want_ladj:
+        return y, None
+    return y, out.result(vec_scalar=vec and not per_sample)
+
+
+class OrderedBijector(Bijector):
+    """ordered.jl:9-80.  Matrix input -> per-column log-det vector (:80)."""
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        return _call_struct("bjx_ordered", x, x.shape[0], True, per_sample, want_ladj, (0,), (x.shape[0],))
+
+    def _wlj_inv(self, x, per_sample, want_ladj=True):
+        return _call_struct("bjx_ordered", x, x.shape[0], True, per_sample, want_ladj, (1,), (x.shape[0],))
+
+
+class SimplexBijector(Bijector):
+    """simplex.jl:4-143.  Matrix input -> scalar sum over columns (:141-143)."""
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        K = x.shape[0]
+        return _call_struct("bjx_simplex", x, K - 1, False, per_sample, want_ladj, (0,), (K,))
+
+    def _wlj_inv(self, y, per_sample, want_ladj=True):
+        K = y.shape[0] + 1
+        return _call_struct("bjx_simplex", y, K, False, per_sample, want_ladj, (1,), (K,))
+
+
+class VecCholeskyBijector(Bijector):
+    """corr.jl:164-259, batched: W is (K, K) or (K, K, batch) column-major; y is (n,) or (n, batch)."""
+
+    def __init__(self, mode="U"):
+        s = str(mode).lstrip(":")
+        if s not in ("U", "L"):
+            raise ValueError("mode must be either :U (upper triangular) or :L (lower triangular)")  # corr.jl:215-219
+        self.mode = s
+
+    def _key(self):
+        return (self.mode,)
+
+    def _wlj(self, W, per_sample, want_ladj=True):
+        _check_dev(W)
+        if W.dim() not in (2, 3) or W.shape[0] != W.shape[1]:
+            raise ValueError("DimensionMismatch: expected a square (K, K[, batch]) factor")
+        K = W.shape[0]
+        vec = W.dim() == 2
+        batch = 1 if vec else W.shape[2]
+        Wc = W if vec else W.permute(2, 1, 0).contiguous().permute(2, 1, 0)  # [K,K,batch] column-major
+        Wc = Wc.T.contiguous().T if vec else Wc
+        ctx = context(W.device)
+        n = K * (K - 1) // 2
+        y = _empty(n, batch, W, vec)
+        out = _Out(W, batch, per_sample, want_ladj)
+        rc = L.load().bjx_vec_cholesky(ctx.h, _dt(W), 0, ord(self.mode), _ptr(Wc), _ptr(y), _ptr(out.ps), _ptr(out.sum), K, batch, 0)
+        L.check(ctx.h, rc, "bjx_vec_cholesky")
+        if not want_ladj:
+            return y, None
+        return y, out.result()
+
+    def _wlj_inv(self, y, per_sample, want_ladj=True):
+        yc, n, batch, vec = _prep(y)
+        K = _triu1_dim_from_length(n)
+        if K * (K - 1) // 2 != n:
+            raise ValueError(f"DimensionMismatch: {n} is not a triangular number K(K-1)/2")
+        ctx = context(yc.device)
+        if vec:
+            W = torch.empty((K, K), dtype=yc.dtype, device=yc.device).T
+        else:
+            W = torch.empty((batch, K, K), dtype=yc.dtype, device=yc.device).permute(2, 1, 0)
+        out = _Out(yc, batch, per_sample, want_ladj)
+        rc = L.load().bjx_vec_cholesky(ctx.h, _dt(yc), 1, ord(self.mode), _ptr(yc), _ptr(W), _ptr(out.ps), _ptr(out.sum), K, batch, 0)
+        L.check(ctx.h, rc, "bjx_vec_cholesky")
+        if not want_ladj:
+            return W, None
+        return W, out.result()
+
+
+class Permute(Bijector):
+    """permute.jl:85-157.  Built from an index vector, pairs or a permutation matrix (1-based like Julia)."""
+
+    def __init__(self, arg, *pairs):
+        if isinstance(arg, int) and pairs:  # Permute(n, src => dst, ...) : permute.jl:102-150
+            n = arg
+            dst_of = list(range(n))
+            dests, sources = set(), set()
+            for src, dst in pairs:
+                srcs = src if isinstance(src, (list, tuple)) else [src]
+                dsts = dst if isinstance(dst, (list, tuple)) else [dst]
+                if len(srcs) != len(dsts):
+                    raise ValueError(f"{srcs} => {dsts} is not bijective")
+                for s_, d_ in zip(srcs, dsts):
+                    if d_ in dests or s_ in sources:
+                        raise ValueError(f"{s_} => {d_}: index used more than once")
+                    dests.add(d_)
+                    sources.add(s_)
+                    dst_of[s_ - 1] = d_ - 1
+            if dests != sources:
+                raise ValueError(f"{sources} ∩ {dests} ≠ {sources} ∪ {dests}")
+            src_of = [0] * n
+            for s_, d_ in enumerate(dst_of):
+                src_of[d_] = s_
+            self.src = src_of
+        elif isinstance(arg, (list, tuple)) and arg and isinstance(arg[0], (list, tuple)):  # matrix A: y = A x
+            self.src = [row.index(1) for row in [list(map(int, r)) for r in arg]]
+        else:  # Permute(indices): A[idx, i] = 1  =>  y[idx_i] = x[i]   (permute.jl:90-100)
+            idx = [int(i) - 1 for i in arg]
+            src = [0] * len(idx)
+            for i, d_ in enumerate(idx):
+                src[d_] = i
+            self.src = src
+        if sorted(self.src) != list(range(len(self.src))):
+            raise ValueError("not a permutation")
+        self._dev = {}
+
+    @classmethod
+    def _from_src(cls, src):
+        p = cls.__new__(cls)
+        p.src = list(src)
+        p._dev = {}
+        return p
+
+    def _key(self):
+        return (tuple(self.src),)
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        xc, dim, batch, vec = _prep(x)
+        if dim != len(self.src):
+            raise ValueError(f"DimensionMismatch: permutation of {len(self.src)} rows applied to {dim} rows")
+        ctx = context(xc.device)
+        src = self._dev.get(xc.device)
+        if src is None:
+            src = torch.tensor(self.src, dtype=torch.int32, device=xc.device)
+            self._dev[xc.device] = src
+        y = _empty(dim, batch, xc, vec)
+        rc = L.load().bjx_permute(ctx.h, _dt(xc), _ptr(src), _ptr(xc), _ptr(y), dim, batch)
+        L.check(ctx.h, rc, "bjx_permute")
+        if not want_ladj:
+            return y, None
+        if per_sample == "both":
+            return y, (torch.zeros(batch, dtype=xc.dtype, device=xc.device), torch.zeros(1, dtype=torch.float64, device=xc.device))
+        if per_sample == "sum64":
+            return y, torch.zeros(1, dtype=torch.float64, device=xc.device)
+        z = torch.zeros(batch if per_sample else (), dtype=xc.dtype, device=xc.device)  # permute.jl:155
+        return y, z
+
+
+class PlanarLayer(Bijector):
+    """planar_layer.jl:12-188.  `w`, `u`: (dim,) tensors, `b`: 1-element tensor.
+    Several layers may be stacked into one fused launch with `PlanarLayer.stack([...])`."""
+
+    def __init__(self, w, u, b):
+        self.w = torch.as_tensor(w)
+        self.u = torch.as_tensor(u)
+        self.b = torch.as_tensor(b).reshape(-1)
+        self.n_layers = 1 if self.w.dim() == 1 else self.w.shape[1]
+
+    @classmethod
+    def stack(cls, layers):
+        """layer[-1] ∘ ... ∘ layer[0] evaluated by ONE kernel."""
+        w = torch.stack([l.w.reshape(-1) for l in layers], dim=1)
+        u = torch.stack([l.u.reshape(-1) for l in layers], dim=1)
+        b = torch.cat([l.b.reshape(-1)[:1] for l in layers])
+        return cls(w, u, b)
+
+    def _key(self):
+        return (_keyify(self.w), _keyify(self.u), _keyify(self.b))
+
+    def _run(self, x, inv, per_sample, want_ladj):
+        xc, dim, batch, vec = _prep(x)
+        w = _param(self.w, xc)
+        u = _param(self.u, xc)
+        if w.dim() == 2:  # (dim, n_layers) -> layer-major contiguous
+            w, u = w.T.contiguous(), u.T.contiguous()
+        if w.numel() != dim * self.n_layers:
+            raise ValueError(f"DimensionMismatch: PlanarLayer of dimension {w.numel() // self.n_layers} applied to {dim} rows")
+        b = _param(self.b, xc)
+        return _call_struct("bjx_planar", x, dim, True, per_sample, want_ladj,
+                            (int(inv), _ptr(w), _ptr(u), _ptr(b), self.n_layers), (dim,))
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        return self._run(x, False, per_sample, want_ladj)
+
+    def _wlj_inv(self, x, per_sample, want_ladj=True):
+        return self._run(x, True, per_sample, want_ladj)
+
+
+class RadialLayer(Bijector):
+    """radial_layer.jl:11-133"""
+
+    def __init__(self, alpha_, beta, z_0):
+        self.alpha_ = torch.as_tensor(alpha_).reshape(-1)
+        self.beta = torch.as_tensor(beta).reshape(-1)
+        self.z_0 = torch.as_tensor(z_0)
+
+    def _key(self):
+        return (_keyify(self.alpha_), _keyify(self.beta), _keyify(self.z_0))
+
+    def _run(self, x, inv, per_sample, want_ladj):
+        xc, dim, batch, vec = _prep(x)
+        z0 = _param(self.z_0, xc)
+        if z0.numel() != dim:
+            raise ValueError(f"DimensionMismatch: RadialLayer of dimension {z0.numel()} applied to {dim} rows")
+        a, be = _param(self.alpha_, xc), _param(self.beta, xc)
+        return _call_struct("bjx_radial", x, dim, True, per_sample, want_ladj, (int(inv), _ptr(a), _ptr(be), _ptr(z0)), (dim,))
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        return self._run(x, False, per_sample, want_ladj)
+
+    def _wlj_inv(self, x, per_sample, want_ladj=True):
+        return self._run(x, True, per_sample, want_ladj)
+
+
+class InvertibleBatchNorm(Bijector):
+    """normalise.jl:9-92, eval mode (`istraining() == false`, :7)."""
+
+    def __init__(self, chs_or_b, logs=None, m=None, v=None, eps=1e-5, mtm=0.1, dtype=torch.float32):
+        if isinstance(chs_or_b, int):  # normalise.jl:26-37
+            c = chs_or_b
+            self.b, self.logs = torch.zeros(c, dtype=dtype), torch.zeros(c, dtype=dtype)
+            self.m, self.v = torch.zeros(c, dtype=dtype), torch.ones(c, dtype=dtype)
+        else:
+            self.b, self.logs, self.m, self.v = (torch.as_tensor(t) for t in (chs_or_b, logs, m, v))
+        self.eps, self.mtm = float(eps), float(mtm)
+
+    def _key(self):
+        return tuple(_keyify(t) for t in (self.b, self.logs, self.m, self.v)) + (self.eps, self.mtm)
+
+    def _run(self, x, inv, per_sample, want_ladj):
+        _check_dev(x)
+        if x.dim() < 2:
+            raise ValueError("InvertibleBatchNorm needs an input with at least 2 dimensions")
+        if x.shape[-2] != self.b.numel():  # normalise.jl:43-45
+            raise RuntimeError(f"InvertibleBatchNorm expected {self.b.numel()} channels, got {x.shape[-2]}")
+        ps = [_param(t, x) for t in (self.b, self.logs, self.m, self.v)]
+        dim = x.shape[0]
+        return _call_struct("bjx_batchnorm", x, dim, True, per_sample, want_ladj,
+                            (int(inv), *[_ptr(p) for p in ps], self.eps), (dim,))
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        return self._run(x, False, per_sample, want_ladj)
+
+    def _wlj_inv(self, x, per_sample, want_ladj=True):
+        return self._run(x, True, per_sample, want_ladj)
+
+
+class RationalQuadraticSpline(Bijector):
+    """rational_quadratic_spline.jl:75-367 with matrix parameters (dim, K+1), batched over columns.
+
+    RationalQuadraticSpline(widths, heights, derivatives)          — knot arrays as in :79-97
+    RationalQuadraticSpline(widths, heights, derivatives, B)       — raw (dim,K),(dim,K),(dim,K-1) via :109-123
+    """
+
+    def __init__(self, widths, heights, derivatives, B=None):
+        w, h, d = (torch.as_tensor(t) for t in (widths, heights, derivatives))
+        if w.dim() == 1:
+            w, h, d = w[None, :], h[None, :], d[None, :]
+        if B is not None:
+            if not w.is_cuda:
+                raise RuntimeError("the B-constructor runs on the device: pass ROCm tensors")
+            K = w.shape[1]
+            if h.shape != w.shape or d.shape != (w.shape[0], K - 1):
+                raise ValueError("DimensionMismatch: expected widths/heights (dim,K) and derivatives (dim,K-1)")
+            dim = w.shape[0]
+            ctx = context(w.device)
+            rw, rh, rd = (colmajor(t) for t in (w, h, d.to(w.dtype)))
+            outs = [torch.empty((K + 1, dim), dtype=w.dtype, device=w.device).T for _ in range(3)]
+            rc = L.load().bjx_rqs_params(ctx.h, _dt(w), _ptr(rw), _ptr(rh), _ptr(rd), K, dim, float(B), *[_ptr(o) for o in outs])
+            L.check(ctx.h, rc, "bjx_rqs_params")
+            w, h, d = outs
+        else:
+            if not (w.shape[1] == h.shape[1] == d.shape[1]):  # :93
+                raise AssertionError("widths, heights and derivatives need the same number of knots")
+            if not bool((d > 0).all()):  # :94
+                raise AssertionError("derivatives need to be positive")
+        self.widths, self.heights, self.derivatives = w, h, d
+
+    def _key(self):
+        return tuple(_keyify(t) for t in (self.widths, self.heights, self.derivatives))
+
+    def _run(self, x, inv, per_sample, want_ladj):
+        xc, dim, batch, vec = _prep(x)
+        if dim != self.widths.shape[0]:
+            raise ValueError(f"DimensionMismatch: spline with {self.widths.shape[0]} rows applied to {dim} rows")
+        w, h, d = (colmajor(_param(t, xc)) for t in (self.widths, self.heights, self.derivatives))
+        return _call_struct("bjx_rqs", x, dim, False, per_sample, want_ladj,
+                            (int(inv), _ptr(w), _ptr(h), _ptr(d), int(self.widths.shape[1])), (dim,))
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        return self._run(x, False, per_sample, want_ladj)
+
+    def _wlj_inv(self, x, per_sample, want_ladj=True):
+        return self._run(x, True, per_sample, want_ladj)
+
+
+class PartitionMask:
+    """coupling.jl:51-118 with index lists instead of one-hot sparse matrices (1-based indices)."""
+
+    def __init__(self, n: int, indices_1, indices_2=None, indices_3=None):
+        i1 = [int(i) for i in indices_1]
+        if indices_2 is None and indices_3 is None:  # :105-113: split, x_3 empty
+            i2 = [i for i in range(1, n + 1) if i not in set(i1)]
+            i3 = []
+        elif indices_3 is None:  # :83-90
+            i2 = [int(i) for i in indices_2]
+            i3 = [i for i in range(1, n + 1) if i not in set(i1) | set(i2)]
+        elif indices_2 is None:  # :92-99
+            i3 = [int(i) for i in indices_3]
+            i2 = [i for i in range(1, n + 1) if i not in set(i1) | set(i3)]
+        else:
+            i2, i3 = [int(i) for i in indices_2], [int(i) for i in indices_3]
+        self.n, self.indices_1, self.indices_2, self.indices_3 = n, i1, i2, i3
+
+    def partition(self, x):  # coupling.jl:132-134
+        idx = lambda l: torch.tensor([i - 1 for i in l], dtype=torch.long, device=x.device)
+        return x[idx(self.indices_1)], x[idx(self.indices_2)], x[idx(self.indices_3)]
+
+
+class Coupling(Bijector):
+    """coupling.jl:174-259.  θ maps x₂ (rows of partition 2, shape (n2[, batch])) to a bijector for x₁.
+    θ runs on the host side (it is an arbitrary closure, SURVEY.md §8b last row); the laws it may
+    return that have device kernels are `Shift`, `Scale`, `Shift @ Scale` with parameters of shape
+    (n1[, batch]) and `RationalQuadraticSpline` with (n1, K+1) knots."""
+
+    def __init__(self, theta, mask):
+        if isinstance(mask, int):  # coupling.jl:183-186
+            mask = PartitionMask(mask, list(range(1, mask // 2 + 1)))
+        self.theta, self.mask = theta, mask
+
+    def _run(self, x, inv, per_sample, want_ladj):
+        xc, dim, batch, vec = _prep(x)
+        if dim != self.mask.n:
+            raise ValueError(f"DimensionMismatch: mask for {self.mask.n} rows applied to {dim} rows")
+        x1, x2, x3 = self.mask.partition(xc)
+        law = self.theta(x2)
+        idx1 = torch.tensor([i - 1 for i in self.mask.indices_1], dtype=torch.int32, device=xc.device)
+        n1 = idx1.numel()
+        if isinstance(law, RationalQuadraticSpline):
+            w, h, d = (colmajor(_param(t, xc)) for t in (law.widths, law.heights, law.derivatives))
+            return _call_struct("bjx_coupling_rqs", x, dim, False, per_sample, want_ladj,
+                                (int(inv), _ptr(idx1), n1, _ptr(w), _ptr(h), _ptr(d), int(law.widths.shape[1])), (dim,))
+        scale = shift = None
+        stages = law._stages() if isinstance(law, ComposedFunction) else [law]
+        for s in stages:
+            if isinstance(s, Scale) and scale is None and shift is None:
+                scale = s.a
+            elif isinstance(s, Shift) and shift is None:
+                shift = s.a
+            else:
+                raise NotImplementedError(f"coupling law {law!r} has no device kernel (supported: Shift, Scale, Shift∘Scale, RQS)")
+
+        def full(p):
+            if p is None:
+                return None
+            t = _param(p, xc)
+            if t.dim() == 0:
+                t = t.expand(n1)
+            if t.dim() == 1 and not vec:
+                t = t[:, None].expand(n1, batch)
+            return colmajor(t.contiguous() if t.dim() == 1 else t)
+
+        s_t, t_t = full(scale), full(shift)
+        return _call_struct("bjx_coupling_affine", x, dim, False, per_sample, want_ladj,
+                            (int(inv), _ptr(idx1), n1, _ptr(s_t), _ptr(t_t)), (dim,))
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        return self._run(x, False, per_sample, want_ladj)
+
+    def _wlj_inv(self, x, per_sample, want_ladj=True):
+        return self._run(x, True, per_sample, want_ladj)

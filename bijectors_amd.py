@@ -1,0 +1,13 @@
+"""Import shim: the package directory is named `bijectors.jl_amd/` (not a valid Python identifier),
+so `import bijectors_amd` loads it from that directory under this name."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bijectors.jl_amd")
+_spec = importlib.util.spec_from_file_location(
+    "bijectors_amd", os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir]
+)
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["bijectors_amd"] = _mod
+_spec.loader.exec_module(_mod)
