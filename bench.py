@@ -33,7 +33,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--workload", default="c2", choices=["c2", "c2v", "c3", "c4", "c5a", "c5b"])
+    p.add_argument("--workload", default="c2", choices=["c2", "c2v", "copy", "c3", "c4", "c5a", "c5b"])
     p.add_argument("--log2-batch", type=int, default=None, help="override the per-GPU batch (testing)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-log2-batch", type=int, default=None)
@@ -58,7 +58,7 @@ def fill_normal(bj, torch, t, col0, seed, mean=0.0, std=1.0):
 def make_workload(name, bj, torch, device, rank, world, log2_batch):
     """-> dict(step=callable, samples=int per rank, bytes_per_sample=float, label=str, kernel=str, dtype=str, cfg=dict)"""
     f32 = torch.float32
-    if name in ("c2", "c2v"):
+    if name in ("c2", "c2v", "copy"):
         dim, lb = 64, (24 if log2_batch is None else log2_batch)
         N = 1 << lb
         x = colmajor_empty(torch, dim, N, f32, device)
@@ -66,6 +66,8 @@ def make_workload(name, bj, torch, device, rank, world, log2_batch):
         fill_normal(bj, torch, x, rank * N, seed=0)
         if name == "c2":
             b = bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5)
+        elif name == "copy":  # streaming ceiling of the same kernel skeleton (one trivial stage)
+            b = bj.Shift(0.0)
         else:  # per-row vector parameters
             b = bj.elementwise(bj.exp) @ bj.Shift(torch.full((dim,), 0.1, device=device)) @ bj.Scale(torch.linspace(0.5, 1.5, dim, device=device))
 
@@ -157,6 +159,8 @@ def cpu_baseline(name, log2_batch):
     from oracle import oracle as orc
 
     rng = np.random.default_rng(0)
+    if name == "copy":
+        name = "c2"
     if name in ("c2", "c2v"):
         lb = 20 if log2_batch is None else log2_batch
         N, dim = 1 << lb, 64

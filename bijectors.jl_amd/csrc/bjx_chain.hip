@@ -24,6 +24,8 @@ template <class T> struct DevOp {
   const T* v1;
   int off0, off1;      // element offsets into the LDS table (per-row params)
 };
+constexpr int CHAIN_U = 4;  // independent 16-B loads in flight per lane
+
 template <class T> struct ChainArgs {
   DevOp<T> ops[BJX_MAX_OPS];
   int n_ops;
@@ -74,89 +76,85 @@ __device__ __forceinline__ void load_params(const DevOp<T>& op, const T* tab, in
   }
 }
 
-// Applies every stage of the chain to one pack of V consecutive elements; returns Σ of the
-// data-dependent log-det contributions of these V elements (Scale's parameter-only term is
-// added by the caller / finalize).
-template <class T, int V, int ROWMODE>
-__device__ __forceinline__ T apply_chain(const ChainArgs<T>& A, const T* tab, Pack<T, V>& p, int64_t r, int64_t dim) {
+// Applies every stage of the chain to U packs of V consecutive elements each.  The op loop is the
+// OUTER loop: one wave-uniform `switch` per stage handles all U*V elements of the lane, so the
+// interpreter's scalar overhead is amortised over 16-32 elements and every case is a straight run
+// of independent VALU work.  Returns Σ of the data-dependent log-det contributions (Scale's
+// parameter-only term is added by the caller / finalize).
+#define BJX_FOR_UJ _Pragma("unroll") for (int u = 0; u < U; ++u) _Pragma("unroll") for (int j = 0; j < V; ++j)
+template <class T, int V, int U, int ROWMODE>
+__device__ __forceinline__ T apply_chain(const ChainArgs<T>& A, const T* tab, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim) {
   T l = T(0);
   for (int k = 0; k < A.n_ops; ++k) {
     const DevOp<T>& op = A.ops[k];
-    T a[V], b[V];
-    load_params<T, V, ROWMODE>(op, tab, r, dim, a, b);
-    switch (op.kind) {
-      case BJX_OP_EXP:  // exp_log.jl:5-6: ladj = sum(x)
+    const int kind = op.kind;
+    T a[U][V], b[U][V];
+    if (kind != BJX_OP_EXP && kind != BJX_OP_LOG && kind != BJX_OP_SIGNFLIP) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) { l += p.v[j]; p.v[j] = d_exp(p.v[j]); }
+      for (int u = 0; u < U; ++u) load_params<T, V, ROWMODE>(op, tab, r[u], dim, a[u], b[u]);
+    }
+    switch (kind) {
+      case BJX_OP_EXP:  // exp_log.jl:5-6: ladj = sum(x)
+        BJX_FOR_UJ { l += p[u].v[j]; p[u].v[j] = d_exp(p[u].v[j]); }
         break;
       case BJX_OP_LOG:  // exp_log.jl:8-9: ladj = -sum(log, x)
-#pragma unroll
-        for (int j = 0; j < V; ++j) { T t = d_log(p.v[j]); l -= t; p.v[j] = t; }
+        BJX_FOR_UJ { T t = d_log(p[u].v[j]); l -= t; p[u].v[j] = t; }
         break;
       case BJX_OP_SHIFT:  // shift.jl:14
-#pragma unroll
-        for (int j = 0; j < V; ++j) p.v[j] = a[j] + p.v[j];
+        BJX_FOR_UJ p[u].v[j] = a[u][j] + p[u].v[j];
         break;
       case BJX_OP_SCALE:  // scale.jl:13
-#pragma unroll
-        for (int j = 0; j < V; ++j) p.v[j] = a[j] * p.v[j];
+        BJX_FOR_UJ p[u].v[j] = a[u][j] * p[u].v[j];
         break;
       case BJX_OP_SCALE_INV:  // scale.jl:15-16: Scale(inv(a))
-#pragma unroll
-        for (int j = 0; j < V; ++j) p.v[j] = (T(1) / a[j]) * p.v[j];
+        BJX_FOR_UJ p[u].v[j] = (T(1) / a[u][j]) * p[u].v[j];
         break;
       case BJX_OP_LOGIT:  // logit.jl:15,24
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-          T x = p.v[j];
-          l += -d_log((x - a[j]) * (b[j] - x) / (b[j] - a[j]));
-          p.v[j] = d_logit((x - a[j]) / (b[j] - a[j]));
+        BJX_FOR_UJ {
+          T x = p[u].v[j];
+          l += -d_log((x - a[u][j]) * (b[u][j] - x) / (b[u][j] - a[u][j]));
+          p[u].v[j] = d_logit((x - a[u][j]) / (b[u][j] - a[u][j]));
         }
         break;
       case BJX_OP_LOGIT_INV:  // logit.jl:19 ; interface.jl:276-281
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-          T x = (b[j] - a[j]) * d_logistic(p.v[j]) + a[j];
-          l += d_log((x - a[j]) * (b[j] - x) / (b[j] - a[j]));
-          p.v[j] = x;
+        BJX_FOR_UJ {
+          T x = (b[u][j] - a[u][j]) * d_logistic(p[u].v[j]) + a[u][j];
+          l += d_log((x - a[u][j]) * (b[u][j] - x) / (b[u][j] - a[u][j]));
+          p[u].v[j] = x;
         }
         break;
       case BJX_OP_LEAKY_RELU:  // leaky_relu.jl:25-29
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-          T J = p.v[j] < T(0) ? a[j] : T(1);
+        BJX_FOR_UJ {
+          T J = p[u].v[j] < T(0) ? a[u][j] : T(1);
           l += d_log(d_abs(J));
-          p.v[j] = J * p.v[j];
+          p[u].v[j] = J * p[u].v[j];
         }
         break;
       case BJX_OP_TRUNCATED:  // truncated.jl:15-31,51-67
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-          T lo = a[j], up = b[j];
-          T x = d_clamp(p.v[j], lo, up);
+        BJX_FOR_UJ {
+          T lo = a[u][j], up = b[u][j];
+          T x = d_clamp(p[u].v[j], lo, up);
           bool lb = d_isfinite(lo), ub = d_isfinite(up);
-          if (lb && ub) { l += -d_log((x - lo) * (up - x) / (up - lo)); p.v[j] = d_logit((x - lo) / (up - lo)); }
-          else if (lb) { T t = d_log(x - lo); l -= t; p.v[j] = t; }
-          else if (ub) { T t = d_log(up - x); l -= t; p.v[j] = t; }
-          else p.v[j] = x;
+          if (lb && ub) { l += -d_log((x - lo) * (up - x) / (up - lo)); p[u].v[j] = d_logit((x - lo) / (up - lo)); }
+          else if (lb) { T t = d_log(x - lo); l -= t; p[u].v[j] = t; }
+          else if (ub) { T t = d_log(up - x); l -= t; p[u].v[j] = t; }
+          else p[u].v[j] = x;
         }
         break;
       case BJX_OP_TRUNCATED_INV:  // truncated.jl:33-49,71-91
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-          T lo = a[j], up = b[j], yv = p.v[j];
+        BJX_FOR_UJ {
+          T lo = a[u][j], up = b[u][j], yv = p[u].v[j];
           bool lb = d_isfinite(lo), ub = d_isfinite(up);
           T x;
           if (lb && ub) { T ay = d_abs(yv); l += d_log(up - lo) - ay - T(2) * d_log1pexp(-ay); x = (up - lo) * d_logistic(yv) + lo; }
           else if (lb) { l += yv; x = d_exp(yv) + lo; }
           else if (ub) { l += yv; x = up - d_exp(yv); }
           else x = yv;
-          p.v[j] = d_clamp(x, lo, up);
+          p[u].v[j] = d_clamp(x, lo, up);
         }
         break;
       case BJX_OP_SIGNFLIP:  // ordered.jl:3
-#pragma unroll
-        for (int j = 0; j < V; ++j) p.v[j] = -p.v[j];
+        BJX_FOR_UJ p[u].v[j] = -p[u].v[j];
         break;
       default: break;
     }
@@ -180,9 +178,7 @@ __device__ __forceinline__ void stage_table(const ChainArgs<T>& A, T* tab) {
   }
 }
 
-constexpr int CHAIN_U = 4;  // independent 16-B loads in flight per lane
-
-template <class T, int V, int ROWMODE, bool NT>
+template <class T, int V, int U, int ROWMODE, bool NT>
 __global__ __launch_bounds__(256) void chain_flat_kernel(const ChainArgs<T> A, const T* x, T* y, int64_t n,
                                                          int64_t dim, int64_t row_step, double* partials) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -193,37 +189,45 @@ __global__ __launch_bounds__(256) void chain_flat_kernel(const ChainArgs<T> A, c
   const int64_t nv = n / V;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t r = 0;
-  if constexpr (ROWMODE != 0) r = (i * V) % dim;
+  int64_t r0 = 0;
+  if constexpr (ROWMODE != 0) r0 = (i * V) % dim;
   double acc = 0.0;
-  for (; i < nv; i += stride * CHAIN_U) {
-    Pack<T, V> p[CHAIN_U];
+  // full iterations: U independent 16-byte loads in flight per lane
+  for (; i + (U - 1) * stride < nv; i += stride * U) {
+    Pack<T, V> p[U];
+    int64_t r[U];
 #pragma unroll
-    for (int u = 0; u < CHAIN_U; ++u) {
-      int64_t idx = i + u * stride;
-      if (idx < nv) p[u] = load_pack<T, V, NT>(x + idx * V);
+    for (int u = 0; u < U; ++u) {
+      p[u] = load_pack<T, V, NT>(x + (i + u * stride) * V);
+      r[u] = r0;
+      if constexpr (ROWMODE != 0) { r0 += row_step; if (r0 >= dim) r0 -= dim; }
     }
+    T l = apply_chain<T, V, U, ROWMODE>(A, tab, p, r, dim);
 #pragma unroll
-    for (int u = 0; u < CHAIN_U; ++u) {
-      int64_t idx = i + u * stride;
-      if (idx < nv) {
-        T l = apply_chain<T, V, ROWMODE>(A, tab, p[u], r, dim);
-        store_pack<T, V, NT>(y + idx * V, p[u]);
-        acc += (double)l;
-      }
-      if constexpr (ROWMODE != 0) { r += row_step; if (r >= dim) r -= dim; }
-    }
+    for (int u = 0; u < U; ++u) store_pack<T, V, NT>(y + (i + u * stride) * V, p[u]);
+    acc += (double)l;
+  }
+  // remainder packs, one at a time
+  for (; i < nv; i += stride) {
+    Pack<T, V> p[1];
+    int64_t r[1] = {r0};
+    p[0] = load_pack<T, V, NT>(x + i * V);
+    T l = apply_chain<T, V, 1, ROWMODE>(A, tab, p, r, dim);
+    store_pack<T, V, NT>(y + i * V, p[0]);
+    acc += (double)l;
+    if constexpr (ROWMODE != 0) { r0 += row_step; if (r0 >= dim) r0 -= dim; }
   }
   // tail elements (n % V) by one lane
   if (V > 1 && blockIdx.x == 0 && threadIdx.x == 0) {
     for (int64_t e = nv * V; e < n; ++e) {
-      Pack<T, 1> q;
-      q.v[0] = x[e];
+      Pack<T, 1> q[1];
+      q[0].v[0] = x[e];
+      int64_t r[1] = {ROWMODE == 0 ? 0 : e % dim};
       T l;
-      if constexpr (ROWMODE == 0) l = apply_chain<T, 1, 0>(A, tab, q, 0, dim);
-      else if constexpr (ROWMODE == 3) l = apply_chain<T, 1, 3>(A, tab, q, e % dim, dim);
-      else l = apply_chain<T, 1, 2>(A, tab, q, e % dim, dim);
-      y[e] = q.v[0];
+      if constexpr (ROWMODE == 0) l = apply_chain<T, 1, 1, 0>(A, tab, q, r, dim);
+      else if constexpr (ROWMODE == 3) l = apply_chain<T, 1, 1, 3>(A, tab, q, r, dim);
+      else l = apply_chain<T, 1, 1, 2>(A, tab, q, r, dim);
+      y[e] = q[0].v[0];
       acc += (double)l;
     }
   }
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256) void chain_flat_kernel(const ChainArgs<T> A, c
 // Per-sample variant: G consecutive lanes own one column (G*V elements per step, coalesced because
 // a column is contiguous); 256/G columns per block step.  Writes ladj_ps[col] (+ per-sample
 // constant) and the block partial of the sum.
-template <class T, int V, int ROWMODE, bool NT>
+template <class T, int V, int U, int ROWMODE, bool NT>
 __global__ __launch_bounds__(256) void chain_colgroup_kernel(const ChainArgs<T> A, const T* x, T* y, T* ladj_ps,
                                                              int64_t dim, int64_t batch, int G, double c_ps_host,
                                                              const double* c_ps_dev, int accumulate,
@@ -253,21 +257,22 @@ __global__ __launch_bounds__(256) void chain_colgroup_kernel(const ChainArgs<T> 
     const T* xc = x + col * dim;
     T* yc = y + col * dim;
     T l = T(0);
-    for (int64_t v0 = 0; v0 < nvc; v0 += (int64_t)G * CHAIN_U) {
-      Pack<T, V> p[CHAIN_U];
+    int64_t v = gl;
+    for (; v + (int64_t)(U - 1) * G < nvc; v += (int64_t)G * U) {
+      Pack<T, V> p[U];
+      int64_t r[U];
 #pragma unroll
-      for (int u = 0; u < CHAIN_U; ++u) {
-        int64_t v = v0 + (int64_t)u * G + gl;
-        if (v < nvc) p[u] = load_pack<T, V, NT>(xc + v * V);
-      }
+      for (int u = 0; u < U; ++u) { p[u] = load_pack<T, V, NT>(xc + (v + (int64_t)u * G) * V); r[u] = (v + (int64_t)u * G) * V; }
+      l += apply_chain<T, V, U, ROWMODE>(A, tab, p, r, dim);
 #pragma unroll
-      for (int u = 0; u < CHAIN_U; ++u) {
-        int64_t v = v0 + (int64_t)u * G + gl;
-        if (v < nvc) {
-          l += apply_chain<T, V, ROWMODE>(A, tab, p[u], v * V, dim);
-          store_pack<T, V, NT>(yc + v * V, p[u]);
-        }
-      }
+      for (int u = 0; u < U; ++u) store_pack<T, V, NT>(yc + (v + (int64_t)u * G) * V, p[u]);
+    }
+    for (; v < nvc; v += G) {
+      Pack<T, V> p[1];
+      int64_t r[1] = {v * V};
+      p[0] = load_pack<T, V, NT>(xc + v * V);
+      l += apply_chain<T, V, 1, ROWMODE>(A, tab, p, r, dim);
+      store_pack<T, V, NT>(yc + v * V, p[0]);
     }
     l = group_sum_rt(l, G);
     if (gl == 0) {
@@ -306,6 +311,10 @@ __global__ __launch_bounds__(256) void chain_consts_kernel(const ChainArgs<T> A,
   if (threadIdx.x == 0) { consts[0] = c_ps; consts[1] = c_sum; }
 }
 
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 bool env_nt() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("BJX_NT"); v = e ? atoi(e) : 0; }
@@ -368,18 +377,25 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
   double* partials = ladj_sum ? ctx->partials : nullptr;
   int grid = 1;
 
-#define LAUNCH_FLAT(V_, RM_)                                                                                  \
+  static const int bpc = env_int("BJX_BPC", 8);   // resident 256-thread blocks per CU the grid is sized for
+  static const int uu = env_int("BJX_U", CHAIN_U); // packs in flight per lane (tuning knob: 4 or 8)
+#define LAUNCH_FLAT_U(V_, RM_, U_)                                                                            \
   do {                                                                                                        \
-    grid = bjx_stream_grid(ctx, (n / V_ + CHAIN_U - 1) / CHAIN_U, 256);                                       \
-    int64_t row_step = any_row ? (((int64_t)grid * 256 * V_) % dim) : 0;                            \
-    if (nt) hipLaunchKernelGGL((chain_flat_kernel<T, V_, RM_, true>), dim3(grid), dim3(256), smem, ctx->stream, A, x, y, n, dim, row_step, partials); \
-    else hipLaunchKernelGGL((chain_flat_kernel<T, V_, RM_, false>), dim3(grid), dim3(256), smem, ctx->stream, A, x, y, n, dim, row_step, partials);  \
+    int64_t need_ = (n / V_ + U_ * 256 - 1) / (U_ * 256);                                                     \
+    int64_t cap_ = (int64_t)ctx->num_cu * bpc;                                                                \
+    if (cap_ > BJX_MAX_BLOCKS) cap_ = BJX_MAX_BLOCKS;                                                         \
+    grid = (int)(need_ < 1 ? 1 : (need_ < cap_ ? need_ : cap_));                                              \
+    int64_t row_step = any_row ? (((int64_t)grid * 256 * V_) % dim) : 0;                                      \
+    if (nt) hipLaunchKernelGGL((chain_flat_kernel<T, V_, U_, RM_, true>), dim3(grid), dim3(256), smem, ctx->stream, A, x, y, n, dim, row_step, partials); \
+    else hipLaunchKernelGGL((chain_flat_kernel<T, V_, U_, RM_, false>), dim3(grid), dim3(256), smem, ctx->stream, A, x, y, n, dim, row_step, partials);  \
   } while (0)
+#define LAUNCH_FLAT(V_, RM_) LAUNCH_FLAT_U(V_, RM_, CHAIN_U)
+#define LAUNCH_FLAT_TUNED(V_, RM_) do { if (uu == 8) LAUNCH_FLAT_U(V_, RM_, 8); else if (uu == 2) LAUNCH_FLAT_U(V_, RM_, 2); else LAUNCH_FLAT_U(V_, RM_, CHAIN_U); } while (0)
 
   if (!ladj_ps) {
-    if (!any_row) { if (vec_ok) LAUNCH_FLAT(VW, 0); else LAUNCH_FLAT(1, 0); }
+    if (!any_row) { if (vec_ok) LAUNCH_FLAT_TUNED(VW, 0); else LAUNCH_FLAT(1, 0); }
     else if (!tab_lds) { if (vec_ok) LAUNCH_FLAT(VW, 3); else LAUNCH_FLAT(1, 3); }
-    else if (vec_ok && dim % VW == 0) LAUNCH_FLAT(VW, 1);
+    else if (vec_ok && dim % VW == 0) LAUNCH_FLAT_TUNED(VW, 1);
     else if (vec_ok) LAUNCH_FLAT(VW, 2);
     else LAUNCH_FLAT(1, 2);
   } else {
@@ -394,8 +410,8 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
     const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
 #define LAUNCH_COL(V_, RM_)                                                                                                 \
   do {                                                                                                                      \
-    if (nt) hipLaunchKernelGGL((chain_colgroup_kernel<T, V_, RM_, true>), dim3(grid), dim3(256), smem, ctx->stream, A, x, y, ladj_ps, dim, batch, G, c_ps_host, cdev, accum, partials);  \
-    else hipLaunchKernelGGL((chain_colgroup_kernel<T, V_, RM_, false>), dim3(grid), dim3(256), smem, ctx->stream, A, x, y, ladj_ps, dim, batch, G, c_ps_host, cdev, accum, partials);   \
+    if (nt) hipLaunchKernelGGL((chain_colgroup_kernel<T, V_, CHAIN_U, RM_, true>), dim3(grid), dim3(256), smem, ctx->stream, A, x, y, ladj_ps, dim, batch, G, c_ps_host, cdev, accum, partials);  \
+    else hipLaunchKernelGGL((chain_colgroup_kernel<T, V_, CHAIN_U, RM_, false>), dim3(grid), dim3(256), smem, ctx->stream, A, x, y, ladj_ps, dim, batch, G, c_ps_host, cdev, accum, partials);   \
   } while (0)
     if (!any_row) { if (v_ok) LAUNCH_COL(VW, 0); else LAUNCH_COL(1, 0); }
     else if (!tab_lds) { if (v_ok) LAUNCH_COL(VW, 3); else LAUNCH_COL(1, 3); }
@@ -404,6 +420,8 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
 #undef LAUNCH_COL
   }
 #undef LAUNCH_FLAT
+#undef LAUNCH_FLAT_U
+#undef LAUNCH_FLAT_TUNED
   BJX_CHECK_LAUNCH(ctx);
   if (ladj_sum) return bjx_launch_finalize(ctx, grid, ladj_sum, c_sum_host, any_dev_scale ? 1 : 0, 0.0, flags);
   return BJX_OK;

@@ -183,14 +183,18 @@ __device__ __forceinline__ void triu1_decode(int64_t e, int& c, int& i0) {
   i0 = (int)(e - (int64_t)cc * (cc - 1) / 2);
 }
 
-// Σ over the entries of this lane's column that are at or before this lane (ascending order),
-// including the part carried over from earlier 64-entry steps.
-template <class T> __device__ __forceinline__ T seg_prefix_incl(T v, int i0, T carry) {
+// Inclusive segmented PREFIX sum inside this lane's column (ascending order), including the part
+// carried over from earlier 64-entry steps.  `head` marks the first entry of a column.
+template <class T> __device__ __forceinline__ T seg_prefix_incl(T v, bool head, T carry) {
   const int lane = threadIdx.x & 63;
-  T S = wave_incl_scan(v);
-  int head = lane - i0;                       // lane of my column's first entry (may be < 0)
-  T base = __shfl(S, head > 0 ? head - 1 : 0, 64);
-  return S - (head > 0 ? base : T(0)) + (head < 0 ? carry : T(0));
+  int f = head ? 1 : 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const T vo = __shfl_up(v, d, 64);
+    const int fo = __shfl_up(f, d, 64);
+    if (lane >= d && !f) { v += vo; f |= fo; }
+  }
+  return v + (f ? T(0) : carry);
 }
 
 // corr.jl:370-399 (_inv_link_chol_lkj, vector form) and :485-501 (_logabsdetjac_inv_chol)
@@ -214,12 +218,14 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const T* y, T* W, T* ladj
       if (valid) triu1_decode(e, c, i0);
       const T yv = valid ? ys[e] : T(0);
       const T lc = valid ? d_logcosh(yv) : T(0);
-      const T incl = seg_prefix_incl<T>(lc, valid ? i0 : 0, carry);   // Σ_{k<=i} logcosh  => log_remainder_after = -incl
+      const T incl = seg_prefix_incl<T>(lc, !valid || i0 == 0, carry);   // Σ_{k<=i} logcosh  => log_remainder_after = -incl
       const bool last = valid && (i0 == c - 1);
+      const T prev_incl = __shfl_up(incl, 1, 64);
+      const T excl = (i0 == 0) ? T(0) : (lane == 0 ? carry : prev_incl);   // Σ_{k<i} logcosh
       if (valid) {
         lj += last ? T(-2) * incl : -incl;        // logJ += log_remainder (each entry) + once more per column (:385-389)
         if (WRITE_W) {
-          const T wv = d_tanh(yv) * d_exp(-(incl - lc));   // z * exp(log_remainder_before) (:383)
+          const T wv = d_tanh(yv) * d_exp(-excl);          // z * exp(log_remainder_before) (:383)
           if (!lower) Ws[(int64_t)c * K + i0] = wv; else Ws[(int64_t)i0 * K + c] = wv;
           if (last) diag[c] = d_exp(-incl);       // W[j,j] = exp(log_remainder) (:390)
         }
@@ -270,25 +276,31 @@ __global__ __launch_bounds__(256) void chol_fwd_kernel(const T* W, T* y, T* ladj
       if (valid) triu1_decode(e, c, i0);
       const T w = valid ? (!lower ? Ws[(int64_t)c * K + i0] : Ws[(int64_t)i0 * K + c]) : T(0);
       const T dg = valid ? Ws[(int64_t)c * K + c] : T(1);
-      const T S = wave_incl_scan(w * w);
-      const int nvalid = (int)((nv - st * 64) < 64 ? (nv - st * 64) : 64);
-      int tail = lane + (c - 1 - i0);                 // lane of my column's last entry (may be > last valid lane)
-      const bool in_step = tail <= nvalid - 1;
-      const T Stail = __shfl(S, in_step ? tail : nvalid - 1, 64);
-      const T suffix = Stail - S + (in_step ? T(0) : carry);   // Σ_{k>i0} w_k²
+      // inclusive segmented SUFFIX scan of w² (a prefix-difference would cancel catastrophically:
+      // deep entries are ~1e-7 next to O(1) neighbours).  Flags mark column tails.
+      const bool is_tail = valid && (i0 == c - 1);
+      T v = w * w;
+      int f = (is_tail || !valid) ? 1 : 0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const T vo = __shfl_down(v, d, 64);
+        const int fo = __shfl_down(f, d, 64);
+        if (lane + d < 64 && !f) { v += vo; f |= fo; }
+      }
+      const T incl = v + (f ? T(0) : carry);          // Σ_{k>=i0} w_k² over my column
+      const T nxt = __shfl_down(incl, 1, 64);
+      const T suffix = is_tail ? T(0) : (lane == 63 ? carry : nxt);   // Σ_{k>i0} w_k²
       if (valid) {
         T yv;
         if (i0 == 0) yv = d_atanh(w);                            // :322
         else yv = d_asinh(w / d_sqrt(dg * dg + suffix));         // :327-329
         ys[e] = yv;
       }
-      // carry for the next (lower) step: Σ w² of lane 0's column inside this step (+ old carry if it runs past)
+      // carry for the next (lower) step: the part of lane 0's column that lives in this and higher steps
       int c0, i00;
       triu1_decode(st * 64, c0, i00);
-      int tail0 = (c0 - 1 - i00);
-      const bool in0 = tail0 <= nvalid - 1;
-      const T S0 = __shfl(S, in0 ? tail0 : nvalid - 1, 64);
-      carry = (i00 == 0) ? T(0) : (S0 + (in0 ? T(0) : carry));
+      const T incl0 = __shfl(incl, 0, 64);
+      carry = (i00 == 0) ? T(0) : incl0;
     }
     if (want_ladj) {
       // pass B, ascending over the y just written (same wave, same lanes -> program order)
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(256) void chol_fwd_kernel(const T* W, T* y, T* ladj
         int c = 1, i0 = 0;
         if (valid) triu1_decode(e, c, i0);
         const T lc = valid ? d_logcosh(ys[e]) : T(0);
-        const T incl = seg_prefix_incl<T>(lc, valid ? i0 : 0, cr);
+        const T incl = seg_prefix_incl<T>(lc, !valid || i0 == 0, cr);
         const bool last = valid && (i0 == c - 1);
         if (valid) lj += last ? T(-2) * incl : -incl;
         const T incl63 = __shfl(incl, 63, 64);

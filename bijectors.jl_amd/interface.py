@@ -399,8 +399,11 @@ class Shift(_ChainOp):
 class Scale(_ChainOp):
     """scale.jl:1-36 (scalar and vector `a`; matrix `a` is out of scope)"""
 
-    def __init__(self, a):
-        if isinstance(a, torch.Tensor) and a.dim() > 1:
+    def __init__(self, a, batched: bool = False):
+        # `batched=True`: `a` has shape (rows, batch) and scales element-wise — only meaningful as the
+        # law returned by a Coupling's θ for a batch of columns.  A plain matrix `a` means `a * x`
+        # in the reference (scale.jl:14), which is not on the hot path.
+        if isinstance(a, torch.Tensor) and a.dim() > 1 and not batched:
             raise NotImplementedError("Scale with a matrix parameter is not on the hot path (SURVEY.md §8f-4)")
         self.a = a
 

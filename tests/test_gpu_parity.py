@@ -431,7 +431,7 @@ def test_coupling_batched(bj, orc, dt):
     X = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
     s = np.asfortranarray(np.exp(0.3 * r.normal(size=(len(idx1), N))).astype(dt))
     t = np.asfortranarray(r.normal(size=(len(idx1), N)).astype(dt))
-    cl = bj.Coupling(lambda th: bj.Shift(dev(t)) @ bj.Scale(dev(s)), m)
+    cl = bj.Coupling(lambda th: bj.Shift(dev(t)) @ bj.Scale(dev(s), batched=True), m)
     i0 = [i - 1 for i in idx1]
     Y_ref, l_ref = orc.coupling_affine(i0, s, t, X)
     Y, l = bj.with_logabsdet_jacobian(cl, dev(X), per_sample=True)
