@@ -24,9 +24,45 @@ __global__ __launch_bounds__(256) void bjx_finalize_kernel(const double* __restr
   }
 }
 
+// Stage 1 for large grids (one-pack-per-thread kernels publish up to millions of partials): block b
+// sums the contiguous slice [b*per, (b+1)*per) in a fixed order -> out[b].
+__global__ __launch_bounds__(256) void bjx_reduce_slices_kernel(const double* __restrict__ partials, long n, long per,
+                                                                 double* __restrict__ out) {
+  __shared__ double red[4];
+  const long lo = (long)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double s = 0.0;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) s += partials[i];
+  s = bjx::group_sum<64>(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+int bjx_ensure_partials(bjx_ctx* ctx, size_t n) {
+  if (n <= ctx->partials_cap) return BJX_OK;
+  size_t cap = ctx->partials_cap ? ctx->partials_cap : (size_t)BJX_MAX_BLOCKS;
+  while (cap < n) cap *= 2;
+  if (ctx->partials) BJX_HIP(ctx, hipFree(ctx->partials));   // synchronises: earlier launches are done with it
+  ctx->partials = nullptr;
+  ctx->partials_cap = 0;
+  BJX_HIP(ctx, hipMalloc(&ctx->partials, cap * sizeof(double)));
+  ctx->partials_cap = cap;
+  return BJX_OK;
+}
+
 int bjx_launch_finalize(bjx_ctx* ctx, int n_partials, double* ladj_sum, double host_const,
                         int use_dev_const, double /*unused*/, uint32_t flags) {
-  hipLaunchKernelGGL(bjx_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, n_partials,
+  const double* src = ctx->partials;
+  int n = n_partials;
+  if (n > BJX_MAX_BLOCKS) {
+    const long per = ((long)n + BJX_MAX_BLOCKS - 1) / BJX_MAX_BLOCKS;
+    const int nb = (int)(((long)n + per - 1) / per);
+    hipLaunchKernelGGL(bjx_reduce_slices_kernel, dim3(nb), dim3(256), 0, ctx->stream, ctx->partials, (long)n, per, ctx->partials2);
+    BJX_CHECK_LAUNCH(ctx);
+    src = ctx->partials2;
+    n = nb;
+  }
+  hipLaunchKernelGGL(bjx_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, src, n,
                      ladj_sum, host_const, use_dev_const ? ctx->consts + 1 : nullptr,
                      (flags & BJX_ACCUMULATE) ? 1 : 0);
   BJX_CHECK_LAUNCH(ctx);
@@ -45,6 +81,8 @@ BJX_API int bjx_create(int device, void* hip_stream, bjx_ctx** out) {
   ctx->stream = static_cast<hipStream_t>(hip_stream);
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMalloc(&ctx->partials, sizeof(double) * BJX_MAX_BLOCKS);
+  if (e == hipSuccess) ctx->partials_cap = BJX_MAX_BLOCKS;
+  if (e == hipSuccess) e = hipMalloc(&ctx->partials2, sizeof(double) * BJX_MAX_BLOCKS);
   if (e == hipSuccess) e = hipMalloc(&ctx->consts, sizeof(double) * BJX_CONSTS);
   if (e == hipSuccess) e = hipMalloc(&ctx->scratch, BJX_SCRATCH_BYTES);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
@@ -67,6 +105,7 @@ BJX_API int bjx_destroy(bjx_ctx* ctx) {
   if (!ctx) return BJX_OK;
   bjx_comm_destroy(ctx);
   if (ctx->partials) (void)hipFree(ctx->partials);
+  if (ctx->partials2) (void)hipFree(ctx->partials2);
   if (ctx->consts) (void)hipFree(ctx->consts);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -85,7 +124,7 @@ BJX_API const char* bjx_last_error(bjx_ctx* ctx) { return ctx ? ctx->err : "null
 
 BJX_API size_t bjx_workspace_bytes(bjx_ctx* ctx) {
   (void)ctx;
-  return sizeof(double) * (BJX_MAX_BLOCKS + BJX_CONSTS) + BJX_SCRATCH_BYTES;
+  return sizeof(double) * ((ctx ? ctx->partials_cap : (size_t)BJX_MAX_BLOCKS) + BJX_MAX_BLOCKS + BJX_CONSTS) + BJX_SCRATCH_BYTES;
 }
 
 BJX_API int bjx_synchronize(bjx_ctx* ctx) {

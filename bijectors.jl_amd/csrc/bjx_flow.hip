@@ -84,17 +84,21 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
 
   const int gl = threadIdx.x & (G - 1);
   const int cols_per_block = blockDim.x / G;
-  const int64_t col_stride = (int64_t)gridDim.x * cols_per_block;
   const int64_t nvc = dim / V;
   double acc = 0.0;
-  for (int64_t col = (int64_t)blockIdx.x * cols_per_block + threadIdx.x / G; col < batch; col += col_stride) {
+  // non-persistent grid: one column per G-lane group.  Lanes of a group past the batch keep
+  // running (on column batch-1, results discarded) so the group shuffles stay convergent.
+  const int64_t col_raw = (int64_t)blockIdx.x * cols_per_block + threadIdx.x / G;
+  const bool col_ok = col_raw < batch;
+  {
+    const int64_t col = col_ok ? col_raw : batch - 1;
     const T* xc = x + col * dim;
     T* yc = y + col * dim;
     Pack<T, V> z[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       int64_t v = gl + (int64_t)r * G;
-      if (v < nvc) z[r] = load_pack<T, V, false>(xc + v * V);
+      if (v < nvc) z[r] = load_pack<T, V, true>(xc + v * V);
       else {
 #pragma unroll
         for (int j = 0; j < V; ++j) z[r].v[j] = T(0);
@@ -136,9 +140,9 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       int64_t v = gl + (int64_t)r * G;
-      if (v < nvc) store_pack<T, V, false>(yc + v * V, z[r]);
+      if (col_ok && v < nvc) store_pack<T, V, true>(yc + v * V, z[r]);
     }
-    if (gl == 0) {
+    if (col_ok && gl == 0) {
       if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + ladj : ladj;
       acc += (double)ladj;
     }
@@ -169,10 +173,14 @@ __global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, cons
 
   const int gl = threadIdx.x & (G - 1);
   const int cols_per_block = blockDim.x / G;
-  const int64_t col_stride = (int64_t)gridDim.x * cols_per_block;
   const int64_t nvc = dim / V;
   double acc = 0.0;
-  for (int64_t col = (int64_t)blockIdx.x * cols_per_block + threadIdx.x / G; col < batch; col += col_stride) {
+  // non-persistent grid: one column per G-lane group.  Lanes of a group past the batch keep
+  // running (on column batch-1, results discarded) so the group shuffles stay convergent.
+  const int64_t col_raw = (int64_t)blockIdx.x * cols_per_block + threadIdx.x / G;
+  const bool col_ok = col_raw < batch;
+  {
+    const int64_t col = col_ok ? col_raw : batch - 1;
     const T* xc = x + col * dim;
     T* yc = y + col * dim;
     Pack<T, V> zz[R];
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, cons
     for (int r = 0; r < R; ++r) {
       int64_t v = gl + (int64_t)r * G;
       if (v < nvc) {
-        zz[r] = load_pack<T, V, false>(xc + v * V);
+        zz[r] = load_pack<T, V, true>(xc + v * V);
 #pragma unroll
         for (int j = 0; j < V; ++j) { T dlt = zz[r].v[j] - Z0[v * V + j]; ss += dlt * dlt; }
       }
@@ -213,10 +221,10 @@ __global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, cons
           if (!INV) o.v[j] = zz[r].v[j] + beta_hat / (alpha + r_fwd) * dlt;   // :52
           else o.v[j] = z0j + gain * dlt;                                     // :101
         }
-        store_pack<T, V, false>(yc + v * V, o);
+        if (col_ok) store_pack<T, V, true>(yc + v * V, o);
       }
     }
-    if (gl == 0) {
+    if (col_ok && gl == 0) {
       if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + ld : ld;
       acc += (double)ld;
     }
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, cons
   if (partials) block_publish_partial(acc, red, partials);
 }
 
-struct FlowCfg { int V, G, R, grid; };
+struct FlowCfg { int V, G, R; int64_t grid; };
 
 template <class T> bool flow_cfg(const bjx_ctx* ctx, const void* x, const void* y, int64_t dim, int64_t batch, FlowCfg* c) {
   constexpr int VW = Vec16<T>::N;
@@ -240,18 +248,19 @@ template <class T> bool flow_cfg(const bjx_ctx* ctx, const void* x, const void* 
   if (R > 32) return false;
   c->G = G;
   c->R = R;
-  c->grid = bjx_stream_grid(ctx, batch, 256 / G);
-  return true;
+  (void)ctx;
+  c->grid = (batch + (256 / G) - 1) / (256 / G);
+  return c->grid < ((int64_t)1 << 31);
 }
 
 #define FLOW_SWITCH_R(KERNEL, TT, VV, INVV, ...)                                                                         \
   switch (c.R) {                                                                                                        \
-    case 1: hipLaunchKernelGGL((KERNEL<TT, VV, 1, INVV>), dim3(c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
-    case 2: hipLaunchKernelGGL((KERNEL<TT, VV, 2, INVV>), dim3(c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
-    case 4: hipLaunchKernelGGL((KERNEL<TT, VV, 4, INVV>), dim3(c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
-    case 8: hipLaunchKernelGGL((KERNEL<TT, VV, 8, INVV>), dim3(c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
-    case 16: hipLaunchKernelGGL((KERNEL<TT, VV, 16, INVV>), dim3(c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break; \
-    default: hipLaunchKernelGGL((KERNEL<TT, VV, 32, INVV>), dim3(c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break; \
+    case 1: hipLaunchKernelGGL((KERNEL<TT, VV, 1, INVV>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
+    case 2: hipLaunchKernelGGL((KERNEL<TT, VV, 2, INVV>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
+    case 4: hipLaunchKernelGGL((KERNEL<TT, VV, 4, INVV>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
+    case 8: hipLaunchKernelGGL((KERNEL<TT, VV, 8, INVV>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
+    case 16: hipLaunchKernelGGL((KERNEL<TT, VV, 16, INVV>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL((KERNEL<TT, VV, 32, INVV>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break; \
   }
 
 template <class T>
@@ -274,6 +283,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
   PlanarArgs<T> A{w, u_hat, wtu, b, nl, lds ? 1 : 0};
   const size_t smem = 32 + (lds ? tab_bytes : 0);
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)c.grid); if (rc) return rc; }
   double* partials = ladj_sum ? ctx->partials : nullptr;
   constexpr int VW = Vec16<T>::N;
   if (c.V == VW) {
@@ -284,7 +294,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
     else { FLOW_SWITCH_R(planar_kernel, T, 1, true, A, in, out, ladj_ps, dim, batch, c.G, accum, partials) }
   }
   BJX_CHECK_LAUNCH(ctx);
-  if (ladj_sum) return bjx_launch_finalize(ctx, c.grid, ladj_sum, 0.0, 0, 0.0, flags);
+  if (ladj_sum) return bjx_launch_finalize(ctx, (int)c.grid, ladj_sum, 0.0, 0, 0.0, flags);
   return BJX_OK;
 }
 
@@ -302,6 +312,7 @@ int radial_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const
   RadialArgs<T> A{alpha_, beta, z0, lds ? 1 : 0};
   const size_t smem = 32 + (lds ? tab_bytes : 0);
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)c.grid); if (rc) return rc; }
   double* partials = ladj_sum ? ctx->partials : nullptr;
   constexpr int VW = Vec16<T>::N;
   if (c.V == VW) {
@@ -312,7 +323,7 @@ int radial_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const
     else { FLOW_SWITCH_R(radial_kernel, T, 1, true, A, in, out, ladj_ps, dim, batch, c.G, accum, partials) }
   }
   BJX_CHECK_LAUNCH(ctx);
-  if (ladj_sum) return bjx_launch_finalize(ctx, c.grid, ladj_sum, 0.0, 0, 0.0, flags);
+  if (ladj_sum) return bjx_launch_finalize(ctx, (int)c.grid, ladj_sum, 0.0, 0, 0.0, flags);
   return BJX_OK;
 }
 }  // namespace

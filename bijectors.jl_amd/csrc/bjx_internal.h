@@ -14,14 +14,16 @@
 #define BJX_API extern "C" __attribute__((visibility("default")))
 
 // ------------------------------------------------------------------ context
-constexpr int BJX_MAX_BLOCKS = 4096;        // upper bound on blocks that publish a partial
+constexpr int BJX_MAX_BLOCKS = 4096;        // persistent-grid cap AND size of the 2nd-stage partial buffer
 constexpr int BJX_CONSTS = 8;               // device doubles for parameter-only log-det terms
 constexpr size_t BJX_SCRATCH_BYTES = 1 << 20;  // û tables, small parameter staging
 
 struct bjx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  double* partials = nullptr;   // [BJX_MAX_BLOCKS]
+  double* partials = nullptr;   // [partials_cap] one f64 per publishing block (grown on demand, cached)
+  size_t partials_cap = 0;
+  double* partials2 = nullptr;  // [BJX_MAX_BLOCKS] second reduction stage
   double* consts = nullptr;     // [BJX_CONSTS]
   void* scratch = nullptr;      // [BJX_SCRATCH_BYTES]
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -57,6 +59,8 @@ inline int bjx_fail(bjx_ctx* ctx, int code, const char* fmt, ...) {
     if (!(cond)) return bjx_fail((ctx), (code), __VA_ARGS__); \
   } while (0)
 
+// host side: make sure ctx->partials can hold n doubles (cached; reallocation synchronises the device)
+int bjx_ensure_partials(bjx_ctx* ctx, size_t n);
 // host side: launch the fixed-order reduction of per-block partials (+ constant term)
 int bjx_launch_finalize(bjx_ctx* ctx, int n_partials, double* ladj_sum, double host_const,
                         int use_dev_const, double dev_const_mult, uint32_t flags);

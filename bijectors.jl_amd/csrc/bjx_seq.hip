@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void seq_kernel(Op op0, const T* in, T* out, T
   const int li = threadIdx.x & (C - 1);       // row inside a chunk handled by this lane in load/store
   const int lc0 = threadIdx.x / C;            // first column handled by this lane in load/store
   double acc = 0.0;
-  for (int64_t col0 = (int64_t)blockIdx.x * NT; col0 < batch; col0 += (int64_t)gridDim.x * NT) {
+  {  // non-persistent: block b owns columns [b*NT, (b+1)*NT)
+    const int64_t col0 = (int64_t)blockIdx.x * NT;
     const int ncols = (int)((batch - col0) < NT ? (batch - col0) : NT);
     Op op = op0;
     op.init();
@@ -155,12 +156,14 @@ int launch_seq(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, doub
   constexpr int C = SeqCfg<T>::C, NT = SeqCfg<T>::NT;
   const size_t smem = 32 + ((size_t)NT * (C + 1) + (size_t)n_logk) * sizeof(T);
   BJX_REQUIRE(ctx, smem <= 64 * 1024, BJX_ERR_UNSUPPORTED, "simplex: K = %d too large for the LDS log-table", n_logk + 1);
-  const int grid = bjx_stream_grid(ctx, batch, NT);
+  const int64_t grid = (batch + NT - 1) / NT;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+  if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
   double* partials = ladj_sum ? ctx->partials : nullptr;
-  hipLaunchKernelGGL((seq_kernel<T, Op>), dim3(grid), dim3(NT), smem, ctx->stream, op, in, out, ladj_ps, rows_in, rows_out, batch, n_logk,
+  hipLaunchKernelGGL((seq_kernel<T, Op>), dim3((unsigned)grid), dim3(NT), smem, ctx->stream, op, in, out, ladj_ps, rows_in, rows_out, batch, n_logk,
                      (flags & BJX_ACCUMULATE) ? 1 : 0, partials);
   BJX_CHECK_LAUNCH(ctx);
-  if (ladj_sum) return bjx_launch_finalize(ctx, grid, ladj_sum, 0.0, 0, 0.0, flags);
+  if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
   return BJX_OK;
 }
 
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const T* y, T* W, T* ladj
   T* diag = reinterpret_cast<T*>(smem + 32) + (size_t)wave * K;
   const int64_t nv = K * (K - 1) / 2;
   double acc = 0.0;
-  for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < batch; s += (int64_t)gridDim.x * 4) {
+  for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < batch; s += (int64_t)gridDim.x * 4) {   // grid = batch/4: one trip
     const T* ys = y + s * nv;
     T* Ws = W + s * K * K;
     T carry = T(0), lj = T(0);
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256) void chol_fwd_kernel(const T* W, T* y, T* ladj
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nv = K * (K - 1) / 2;
   double acc = 0.0;
-  for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < batch; s += (int64_t)gridDim.x * 4) {
+  for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < batch; s += (int64_t)gridDim.x * 4) {   // grid = batch/4: one trip
     const T* Ws = W + s * K * K;
     T* ys = y + s * nv;
     // pass A, descending: remainder_sq = W[j,j]^2 + Σ_{k>i} W[k,j]^2 (suffix sum inside the column)
@@ -337,20 +340,22 @@ int chol_impl(bjx_ctx* ctx, int inverse, int uplo, const T* in, T* out, T* ladj_
     return BJX_OK;
   }
   const int lower = (uplo == 'L') ? 1 : 0;
-  const int grid = bjx_stream_grid(ctx, batch, 4);
+  const int64_t grid = (batch + 3) / 4;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
   double* partials = ladj_sum ? ctx->partials : nullptr;
   if (inverse) {
     const size_t smem = 32 + (size_t)4 * K * sizeof(T);
     BJX_REQUIRE(ctx, smem <= 64 * 1024, BJX_ERR_UNSUPPORTED, "bjx_vec_cholesky: K = %lld too large", (long long)K);
-    if (out) hipLaunchKernelGGL((chol_inv_kernel<T, true>), dim3(grid), dim3(256), smem, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, partials);
-    else hipLaunchKernelGGL((chol_inv_kernel<T, false>), dim3(grid), dim3(256), smem, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, partials);
+    if (out) hipLaunchKernelGGL((chol_inv_kernel<T, true>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, partials);
+    else hipLaunchKernelGGL((chol_inv_kernel<T, false>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, partials);
   } else {
     const int want = (ladj_ps || ladj_sum) ? 1 : 0;
-    hipLaunchKernelGGL((chol_fwd_kernel<T>), dim3(grid), dim3(256), 32, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, want, partials);
+    hipLaunchKernelGGL((chol_fwd_kernel<T>), dim3((unsigned)grid), dim3(256), 32, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, want, partials);
   }
   BJX_CHECK_LAUNCH(ctx);
-  if (ladj_sum) return bjx_launch_finalize(ctx, grid, ladj_sum, 0.0, 0, 0.0, flags);
+  if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
   return BJX_OK;
 }
 }  // namespace

@@ -29,13 +29,15 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
   f.stage(fsm);
   const int gl = threadIdx.x & (G - 1);
   const int cols_per_block = blockDim.x / G;
-  const int64_t col_stride = (int64_t)gridDim.x * cols_per_block;
   const int64_t nvc = dim / V;
   double acc = 0.0;
-  for (int64_t col = (int64_t)blockIdx.x * cols_per_block + threadIdx.x / G; col < batch; col += col_stride) {
+  // non-persistent: one column per G-lane group (scripts/membench.hip: in-order short blocks stream
+  // ~30 % faster than grid-stride loops on MI355X)
+  const int64_t col = (int64_t)blockIdx.x * cols_per_block + threadIdx.x / G;
+  T l = T(0);
+  if (col < batch) {
     const T* xc = x + col * dim;
     T* yc = y + col * dim;
-    T l = T(0);
     for (int64_t v0 = 0; v0 < nvc; v0 += (int64_t)G * STREAM_U) {
       Pack<T, V> p[STREAM_U];
 #pragma unroll
@@ -52,21 +54,22 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
         }
       }
     }
-    l = group_sum_rt(l, G);
-    if (gl == 0) {
-      if (ladj_ps) {
-        T out = l + (T)(f.per_sample_const + (f.per_sample_dev ? *f.per_sample_dev : 0.0));
-        if (accumulate) out += ladj_ps[col];
-        ladj_ps[col] = out;
-      }
-      acc += (double)l;
+  }
+  l = group_sum_rt(l, G);
+  if (col < batch && gl == 0) {
+    if (ladj_ps) {
+      T out = l + (T)(f.per_sample_const + (f.per_sample_dev ? *f.per_sample_dev : 0.0));
+      if (accumulate) out += ladj_ps[col];
+      ladj_ps[col] = out;
     }
+    acc = (double)l;
   }
   if (partials) block_publish_partial(acc, red, partials);
 }
 
 struct ColLaunch {
-  int V, G, grid;
+  int V, G;
+  int64_t grid;
 };
 
 // choose pack width / lanes per column / grid for a [dim, batch] problem
@@ -79,7 +82,8 @@ template <class T> inline ColLaunch col_launch_cfg(const bjx_ctx* ctx, const voi
   int G = 1;
   while (G < 64 && G < packs) G <<= 1;
   c.G = G;
-  c.grid = bjx_stream_grid(ctx, batch, 256 / G);
+  (void)ctx;
+  c.grid = (batch + (256 / G) - 1) / (256 / G);
   return c;
 }
 
@@ -94,13 +98,15 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
   constexpr int VW = Vec16<T>::N;
   const size_t smem = 32 + f_smem;
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  BJX_REQUIRE(ctx, c.grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+  if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)c.grid); if (rc) return rc; }
   double* partials = ladj_sum ? ctx->partials : nullptr;
   if (c.V == VW)
-    hipLaunchKernelGGL((colgroup_kernel<T, VW, false, F>), dim3(c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, partials);
+    hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, partials);
   else
-    hipLaunchKernelGGL((colgroup_kernel<T, 1, false, F>), dim3(c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, partials);
+    hipLaunchKernelGGL((colgroup_kernel<T, 1, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, partials);
   BJX_CHECK_LAUNCH(ctx);
-  if (ladj_sum) return bjx_launch_finalize(ctx, c.grid, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, 0.0, flags);
+  if (ladj_sum) return bjx_launch_finalize(ctx, (int)c.grid, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, 0.0, flags);
   return BJX_OK;
 }
 
