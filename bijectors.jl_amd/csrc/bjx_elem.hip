@@ -124,6 +124,136 @@ __global__ __launch_bounds__(256) void rqs_params_kernel(const T* rw, const T* r
   }
 }
 
+// ------------------------------------------------------------------ RQS, table kernel
+// The functor path above costs 178 (fwd) / 295 (inv) VALU instructions per element and suffers
+// 8-way LDS bank conflicts on the [rows, K] column-major knot tables (PMC: SQ_LDS_BANK_CONFLICT =
+// 63 % of LDS cycles), i.e. it is VALU/LDS-bound at 13 % of the HBM roofline.  This kernel
+//  * precomputes, once per call, a per-(row, bin) record {w_k, 1/w, h_k, Δy | s, d_k, d_k+1, w}
+//    (two 16-byte LDS reads replace six 4-byte reads and two divisions per element),
+//  * stores search keys and records row-major ([row][bin]) so that lanes that share a row but fall
+//    into different bins hit different banks,
+//  * uses one hardware log + one reciprocal per element in Float32 (log(num/den²)),
+//  * reuses the inverse's ξ for its log-det instead of a second search + forward evaluation, and
+//  * lets one block walk ITER column groups so the 20 KiB table staging is amortised.
+// Bin selection is exact (same Float32/Float64 knot values and comparisons as the oracle).
+template <class T> struct RqsRec { T a[4]; T b[4]; };   // a = {w_k, 1/w, h_k, dy}, b = {s, d_k, d_k1, w}
+
+// rational_quadratic_spline.jl:139-156: bin k in 0..K-1 spans knots k..k+1 (knot 0 = -knot K mirrored)
+template <class T>
+__global__ __launch_bounds__(256) void rqs_prep_kernel(const T* w, const T* h, const T* d, int K, int64_t rows,
+                                                       T* keyW, T* keyH, RqsRec<T>* rec) {
+  const int64_t n = rows * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / K;
+    const int k = (int)(i % K);
+    auto W = [&](int j) { return w[(int64_t)(j - 1) * rows + r]; };   // 1-based knot j of row r
+    auto H = [&](int j) { return h[(int64_t)(j - 1) * rows + r]; };
+    auto D = [&](int j) { return d[(int64_t)(j - 1) * rows + r]; };
+    keyW[i] = W(k + 1);
+    keyH[i] = H(k + 1);
+    const T w_k = (k == 0) ? -W(K) : W(k);
+    const T wd = W(k + 1) - w_k;
+    const T h_k = (k == 0) ? -H(K) : H(k);
+    const T dy = H(k + 1) - h_k;
+    RqsRec<T> q;
+    q.a[0] = w_k; q.a[1] = T(1) / wd; q.a[2] = h_k; q.a[3] = dy;
+    q.b[0] = dy / wd;                                  // s
+    q.b[1] = (k == 0) ? T(1) : D(k);                   // d_k
+    q.b[2] = (k == K - 1) ? T(1) : D(k + 1);           // d_{k+1}
+    q.b[3] = wd;
+    rec[i] = q;
+  }
+}
+
+// number of keys (ascending, length K) strictly below x == searchsortedfirst(keys, x) - 1
+template <class T> __device__ __forceinline__ int count_below(const T* keys, int K, int top, T x) {
+  int pos = 0;
+  for (int step = top; step >= 1; step >>= 1) {
+    const int nx = pos + step;
+    if (nx <= K && keys[nx - 1] < x) pos = nx;
+  }
+  return pos;
+}
+
+template <class T, bool INV>
+__device__ __forceinline__ T rqs_table_elem(const T* keys, const RqsRec<T>* rec, int K, int top, T& v) {
+  using F = Fast<T>;
+  const T lim = keys[K - 1];
+  const T x = v;
+  if ((x <= -lim) || (x >= lim)) return T(0);        // identity outside [-B, B], log-det 0 (:132, :186)
+  const int k = count_below<T>(keys, K, top, x);
+  const RqsRec<T> q = rec[k];
+  const T s = q.b[0], d_k = q.b[1], d_k1 = q.b[2];
+  T xi;
+  if (!INV) {
+    xi = (x - q.a[0]) * q.a[1];                                             // ξ
+  } else {
+    const T yh = x - q.a[2];
+    const T ds = d_k1 + d_k - 2 * s;
+    const T a1 = q.a[3] * (s - d_k) + yh * ds;                              // Eq. (25)
+    const T a2 = q.a[3] * d_k - yh * ds;                                    // Eq. (26)
+    const T a3 = -s * yh;                                                   // Eq. (27)
+    xi = F::div(-2 * a3, a2 + F::sqrt(a2 * a2 - 4 * a1 * a3));              // Eq. (24)
+  }
+  const T om = T(1) - xi;
+  const T xo = xi * om;
+  const T den = s + (d_k1 + d_k - 2 * s) * xo;
+  const T rden = F::rcp(den);
+  const T num_jl = s * s * (d_k1 * (xi * xi) + 2 * s * xo + d_k * (om * om));
+  const T lj = F::log(num_jl * rden * rden);                                // log(num) - 2 log(den)
+  if (!INV) { v = q.a[2] + q.a[3] * (s * (xi * xi) + d_k * xo) * rden; return lj; }
+  v = xi * q.b[3] + q.a[0];
+  return -lj;                                                               // interface.jl:276-281
+}
+
+template <class T, int V, bool INV>
+__global__ __launch_bounds__(256) void rqs_table_kernel(const T* keys_g, const RqsRec<T>* rec_g, int K, int top, int in_lds,
+                                                        const T* x, T* y, T* ladj_ps, int64_t dim, int64_t batch, int G,
+                                                        int iters, int accumulate, double* partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[4];
+  const int64_t nrec = dim * K;
+  RqsRec<T>* rec_l = reinterpret_cast<RqsRec<T>*>(smem);
+  T* keys_l = reinterpret_cast<T*>(smem + (size_t)nrec * sizeof(RqsRec<T>));
+  if (in_lds) {
+    const int npk = (int)(nrec * (sizeof(RqsRec<T>) / 16));
+    const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(rec_g);
+    bjx_f32x4* dst = reinterpret_cast<bjx_f32x4*>(rec_l);
+    for (int i = threadIdx.x; i < npk; i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < nrec; i += 256) keys_l[i] = keys_g[i];
+    __syncthreads();
+  }
+  const RqsRec<T>* rec = in_lds ? rec_l : rec_g;
+  const T* keys = in_lds ? keys_l : keys_g;
+  const int gl = threadIdx.x & (G - 1);
+  const int cols_per_block = 256 / G;
+  const int64_t nvc = dim / V;
+  double acc = 0.0;
+  for (int it = 0; it < iters; ++it) {
+    const int64_t col = ((int64_t)blockIdx.x * iters + it) * cols_per_block + threadIdx.x / G;
+    T l = T(0);
+    if (col < batch) {
+      const T* xc = x + col * dim;
+      T* yc = y + col * dim;
+      for (int64_t v = gl; v < nvc; v += G) {
+        Pack<T, V> p = load_pack<T, V, true>(xc + v * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const int64_t r = v * V + j;
+          l += rqs_table_elem<T, INV>(keys + r * K, rec + r * K, K, top, p.v[j]);
+        }
+        store_pack<T, V, true>(yc + v * V, p);
+      }
+    }
+    l = group_sum_rt(l, G);
+    if (col < batch && gl == 0) {
+      if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + l : l;
+      acc += (double)l;
+    }
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
 // ------------------------------------------------------------------ BatchNorm (eval)
 // normalise.jl:41-88.  LDS rows: s = exp(logs), m, q = sqrt(v + eps), b.
 template <class T, bool INV> struct BnF {
@@ -255,11 +385,56 @@ template <class T> bool knots_fit_lds(int64_t rows, int K1) { return (size_t)row
 template <class T>
 int rqs_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int K1, const T* in, T* out, T* ladj_ps,
              double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
-  const bool lds = knots_fit_lds<T>(dim, K1);
-  const size_t fsm = lds ? (size_t)dim * K1 * 3 * sizeof(T) : 0;
-  if (!inverse) { RqsF<T, false> f{w, h, d, K1, dim, lds ? 1 : 0, 0.0, nullptr}; return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0); }
-  RqsF<T, true> f{w, h, d, K1, dim, lds ? 1 : 0, 0.0, nullptr};
-  return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0);
+  const size_t nrec = (size_t)dim * K1;
+  const size_t tab_bytes = nrec * (sizeof(RqsRec<T>) + 2 * sizeof(T));
+  if (tab_bytes + 64 > BJX_SCRATCH_BYTES) {   // huge knot tables: generic functor path, tables from global memory
+    const bool lds = knots_fit_lds<T>(dim, K1);
+    const size_t fsm = lds ? (size_t)dim * K1 * 3 * sizeof(T) : 0;
+    if (!inverse) { RqsF<T, false> f{w, h, d, K1, dim, lds ? 1 : 0, 0.0, nullptr}; return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0); }
+    RqsF<T, true> f{w, h, d, K1, dim, lds ? 1 : 0, 0.0, nullptr};
+    return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0);
+  }
+  if (dim * batch == 0) {
+    if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
+    return BJX_OK;
+  }
+  RqsRec<T>* rec = static_cast<RqsRec<T>*>(ctx->scratch);
+  T* keyW = reinterpret_cast<T*>(rec + nrec);
+  T* keyH = keyW + nrec;
+  int pg = (int)((nrec + 255) / 256);
+  if (pg > 256) pg = 256;
+  hipLaunchKernelGGL(rqs_prep_kernel<T>, dim3(pg), dim3(256), 0, ctx->stream, w, h, d, K1, dim, keyW, keyH, rec);
+  BJX_CHECK_LAUNCH(ctx);
+  ColLaunch c = col_launch_cfg<T>(ctx, in, out, dim, batch);
+  const size_t lds_bytes = nrec * (sizeof(RqsRec<T>) + sizeof(T));
+  const int in_lds = lds_bytes <= 60 * 1024 ? 1 : 0;
+  const int cols_per_block = 256 / c.G;
+  // amortise the table staging: each block walks `iters` column groups (>= ~64 KiB of data)
+  int iters = 1;
+  if (in_lds) {
+    const int64_t bytes_per_group = (int64_t)cols_per_block * dim * sizeof(T);
+    iters = (int)((4 * (int64_t)lds_bytes + bytes_per_group - 1) / bytes_per_group);
+    if (iters < 1) iters = 1;
+    if (iters > 64) iters = 64;
+  }
+  const int64_t groups = (batch + cols_per_block - 1) / cols_per_block;
+  const int64_t grid = (groups + iters - 1) / iters;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_rqs: batch too large for one launch");
+  if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
+  double* partials = ladj_sum ? ctx->partials : nullptr;
+  int top = 1;
+  while (top * 2 <= K1) top *= 2;
+  const T* keys = inverse ? keyH : keyW;
+  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  const size_t smem = in_lds ? lds_bytes : 0;
+  constexpr int VW = Vec16<T>::N;
+#define LAUNCH_RQS(V_, INV_) hipLaunchKernelGGL((rqs_table_kernel<T, V_, INV_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, keys, rec, K1, top, in_lds, in, out, ladj_ps, dim, batch, c.G, iters, accum, partials)
+  if (c.V == VW) { if (inverse) LAUNCH_RQS(VW, true); else LAUNCH_RQS(VW, false); }
+  else { if (inverse) LAUNCH_RQS(1, true); else LAUNCH_RQS(1, false); }
+#undef LAUNCH_RQS
+  BJX_CHECK_LAUNCH(ctx);
+  if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+  return BJX_OK;
 }
 
 template <class T>

@@ -150,6 +150,170 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
   if (partials) block_publish_partial(acc, red, partials);
 }
 
+// ------------------------------------------------------------------ Planar, tile kernel
+// One WAVE owns 64 columns.  The lanes-along-dim kernel above evaluates tanh/cosh/log1p for only
+// 2-4 distinct samples per wave instruction, which makes an 8-layer stack ALU-bound at 8 % of the
+// HBM roofline (profiles/r01_bench_lines_first_pass.jsonl).  Here the 64 x dim tile is staged
+// through LDS (coalesced 16-byte global accesses; XOR-swizzled so both the pack-wise stores and the
+// lane-per-column reads are bank-conflict free) and then LANE = COLUMN: all 64 lanes run the
+// per-sample scalar recurrence on different samples.
+//
+// Algebra: with t_k = tanh(a_k + b_k), a_k = w_kᵀ z_{k-1} and z_k = z_{k-1} + û_k t_k,
+//   a_k = w_kᵀ z_0 + Σ_{j<k} (w_kᵀ û_j) t_j ,   z_K = z_0 + Σ_k û_k t_k
+// so the K dot products against z_0 are independent (one pass over the tile), the layer-to-layer
+// dependency is an K-step scalar recurrence with the K x K table G[k][j] = w_kᵀ û_j, and the update
+// is one more pass.  This re-associates the reference's sums (planar_layer.jl:73-80); differences
+// are O(eps·‖w‖‖z‖), inside the 1e-3 / 1e-6 parity bars (tests/test_gpu_parity.py::test_planar).
+// Layers are processed in groups of NLMAX; the tile in LDS is updated between groups.
+constexpr int PLANAR_NLMAX = 8;
+
+template <class T>
+__global__ __launch_bounds__(256) void planar_prep2_kernel(const T* w, const T* u_hat, int64_t dim, int nl, T* G, T* wT, T* uT) {
+  // block (k, j): G[k*nl + j] = w_kᵀ û_j ; block row 0 also writes the [row][layer] transposes
+  __shared__ double red[4];
+  const int k = blockIdx.x / nl, j = blockIdx.x % nl;
+  double dot = 0.0;
+  for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) dot += (double)w[(int64_t)k * dim + i] * (double)u_hat[(int64_t)j * dim + i];
+  dot = group_sum<64>(dot);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) G[k * nl + j] = (T)((red[0] + red[1]) + (red[2] + red[3]));
+  if (j == 0) {
+    for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) { wT[i * nl + k] = w[(int64_t)k * dim + i]; uT[i * nl + k] = u_hat[(int64_t)k * dim + i]; }
+  }
+}
+
+template <class T> struct PlanarTileArgs {
+  const T *wT, *uT;      // [dim][nl]
+  const T *G;            // [nl][nl]
+  const T *wtu_hat, *b;  // [nl]
+  int nl;
+};
+
+__device__ __forceinline__ int tile_addr(int row, int c) { return row * 64 + (c ^ ((row >> 2) & 31)); }
+
+// One group of ng <= NLMAX layers applied to this lane's column of the LDS tile; returns the
+// group's log-det contribution.  FULL = (ng == NLMAX): no per-layer guards in the hot loops.
+template <class T, bool INV, bool FULL>
+__device__ __forceinline__ T planar_tile_group(const PlanarTileArgs<T>& A, T* tile, int dim, int lane, int l0, int ng) {
+  constexpr int NL = PLANAR_NLMAX;
+  // ---- dot products of the column against the group's w rows (wave-uniform -> scalar loads)
+  T s[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) s[l] = T(0);
+#pragma unroll 4
+  for (int r = 0; r < dim; ++r) {
+    const T z = tile[tile_addr(r, lane)];
+    const T* wr = A.wT + (int64_t)r * A.nl + l0;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) if (FULL || l < ng) s[l] += wr[l] * z;
+  }
+  // ---- scalar recurrence, one sample per lane
+  T t[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) t[l] = T(0);
+  T ladj = T(0);
+#pragma unroll
+  for (int kk = 0; kk < NL; ++kk) {
+    const int k = INV ? (NL - 1 - kk) : kk;     // the inverse undoes the group's layers last-to-first
+    if (FULL || k < ng) {
+      const T* Gk = A.G + (int64_t)(l0 + k) * A.nl + l0;
+      T a = s[k];
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        if (!INV) { if (j < k) a += Gk[j] * t[j]; }
+        else { if (j > k && (FULL || j < ng)) a -= Gk[j] * t[j]; }
+      }
+      const T bl = A.b[l0 + k], c = A.wtu_hat[l0 + k];
+      const T arg = INV ? find_alpha_dev<T>(a, c, bl) + bl : a + bl;
+      const T th = d_tanh(arg);
+      const T sech = T(1) / d_cosh(arg);
+      const T ld = d_log1p(c * (sech * sech));            // planar_layer.jl:107
+      ladj += INV ? -ld : ld;
+      t[k] = th;
+    }
+  }
+  // ---- rank-ng update of the lane's column in LDS
+#pragma unroll 4
+  for (int r = 0; r < dim; ++r) {
+    const T* ur = A.uT + (int64_t)r * A.nl + l0;
+    T d = T(0);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) if (FULL || l < ng) d += ur[l] * t[l];
+    const int ad = tile_addr(r, lane);
+    tile[ad] = INV ? tile[ad] - d : tile[ad] + d;
+  }
+  return ladj;
+}
+
+template <class T, int V, bool INV>
+__global__ __launch_bounds__(64) void planar_tile_kernel(const PlanarTileArgs<T> A, const T* x, T* y, T* ladj_ps, int dim,
+                                                        int64_t batch, int accumulate, double* partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tile = reinterpret_cast<T*>(smem);
+  const int lane = threadIdx.x;
+  const int64_t col0 = (int64_t)blockIdx.x * 64;
+  const int ncols = (int)((batch - col0) < 64 ? (batch - col0) : 64);
+  const int nelem = ncols * dim;
+  const T* xt = x + col0 * dim;
+  T* yt = y + col0 * dim;
+  const int npk = (64 * dim) / V;
+  // (column, row) of this lane's first pack; every step advances by 64 packs = 64*V elements
+  const int c_first = (lane * V) / dim, r_first = (lane * V) % dim;
+  // ---- stage in: coalesced packs -> swizzled [row][col] tile
+  {
+    int c = c_first, r = r_first;
+#pragma unroll 8
+    for (int q = lane; q < npk; q += 64) {
+      const int e = q * V;
+      Pack<T, V> p;
+      if (e < nelem) p = load_pack<T, V, true>(xt + e);
+      else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) p.v[j] = T(0);
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) tile[tile_addr(r + j, c)] = p.v[j];
+      r += 64 * V;
+      while (r >= dim) { r -= dim; ++c; }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();   // single-wave block: LDS is in order per wave, only stop compiler motion
+
+  T ladj = T(0);
+  const int ngroups = (A.nl + PLANAR_NLMAX - 1) / PLANAR_NLMAX;
+  for (int gi = 0; gi < ngroups; ++gi) {
+    const int g = INV ? ngroups - 1 - gi : gi;      // the inverse undoes the LAST group first
+    const int l0 = g * PLANAR_NLMAX;
+    const int ng = (A.nl - l0) < PLANAR_NLMAX ? (A.nl - l0) : PLANAR_NLMAX;
+    if (ng == PLANAR_NLMAX) ladj += planar_tile_group<T, INV, true>(A, tile, dim, lane, l0, ng);
+    else ladj += planar_tile_group<T, INV, false>(A, tile, dim, lane, l0, ng);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- stage out: swizzled tile -> coalesced packs
+  {
+    int c = c_first, r = r_first;
+#pragma unroll 8
+    for (int q = lane; q < npk; q += 64) {
+      const int e = q * V;
+      if (e < nelem) {
+        Pack<T, V> p;
+#pragma unroll
+        for (int j = 0; j < V; ++j) p.v[j] = tile[tile_addr(r + j, c)];
+        store_pack<T, V, true>(yt + e, p);
+      }
+      r += 64 * V;
+      while (r >= dim) { r -= dim; ++c; }
+    }
+  }
+  const bool ok = lane < ncols;
+  if (ok && ladj_ps) ladj_ps[col0 + lane] = accumulate ? ladj_ps[col0 + lane] + ladj : ladj;
+  if (partials) {
+    double acc = group_sum<64>(ok ? (double)ladj : 0.0);
+    if (lane == 0) partials[blockIdx.x] = acc;
+  }
+}
+
 template <class T> struct RadialArgs {
   const T *alpha_, *beta, *z0;
   int in_lds;
@@ -274,6 +438,32 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
   BJX_CHECK_LAUNCH(ctx);
   if (batch == 0) {
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
+    return BJX_OK;
+  }
+  // tile kernel: lane = column (full-lane scalar recurrence); needs the 64 x dim tile in LDS
+  static const int use_tile = getenv("BJX_PLANAR_TILE") ? atoi(getenv("BJX_PLANAR_TILE")) : 1;
+  const size_t tile_bytes = (size_t)64 * dim * sizeof(T);
+  const size_t need2 = need + ((size_t)nl * nl + 2 * (size_t)nl * dim) * sizeof(T);
+  if (use_tile && tile_bytes <= 64 * 1024 && need2 <= BJX_SCRATCH_BYTES && dim < (1 << 20)) {
+    T* G = wtu + nl;
+    T* wT = G + (size_t)nl * nl;
+    T* uT = wT + (size_t)nl * dim;
+    hipLaunchKernelGGL(planar_prep2_kernel<T>, dim3(nl * nl), dim3(256), 0, ctx->stream, w, u_hat, dim, nl, G, wT, uT);
+    BJX_CHECK_LAUNCH(ctx);
+    const int64_t grid = (batch + 63) / 64;
+    BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar: batch too large for one launch");
+    if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
+    double* partials = ladj_sum ? ctx->partials : nullptr;
+    PlanarTileArgs<T> TA{wT, uT, G, wtu, b, nl};
+    const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+    constexpr int VW = Vec16<T>::N;
+    const bool v_ok = bjx_aligned16(in) && bjx_aligned16(out) && dim % VW == 0;
+#define LAUNCH_TILE(V_, INV_) hipLaunchKernelGGL((planar_tile_kernel<T, V_, INV_>), dim3((unsigned)grid), dim3(64), tile_bytes, ctx->stream, TA, in, out, ladj_ps, (int)dim, batch, accum, partials)
+    if (v_ok) { if (inverse) LAUNCH_TILE(VW, true); else LAUNCH_TILE(VW, false); }
+    else { if (inverse) LAUNCH_TILE(1, true); else LAUNCH_TILE(1, false); }
+#undef LAUNCH_TILE
+    BJX_CHECK_LAUNCH(ctx);
+    if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
     return BJX_OK;
   }
   FlowCfg c;

@@ -127,6 +127,34 @@ template <class T> __device__ __forceinline__ T d_logcosh(T x) {
   return ax + d_log1pexp(T(-2) * ax) - Num<T>::log2;
 }
 
+// ------------------------------------------------------------------ fast math for ALU-bound kernels
+// Float32: hardware transcendental units (v_log_f32 / v_exp_f32 / v_rcp_f32, ~1 ulp each, relative
+// error of the composite <= ~1e-6) — used only in kernels that are VALU-bound with the OCML
+// routines (Simplex, RQS, VecCholesky, Planar recurrence; PMC evidence in profiles/).  The Float32
+// parity bar is 1e-3.  Float64 always uses the exact OCML functions (parity bar 1e-6).
+template <class T> struct Fast;
+template <> struct Fast<float> {
+  static __device__ __forceinline__ float log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+  static __device__ __forceinline__ float exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+  static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+  static __device__ __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+  static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+  static __device__ __forceinline__ float log1p(float x) {
+    // log1p via the compensated log(1+x) * x / ((1+x) - 1) form (exact when 1+x rounds to 1)
+    const float u = 1.0f + x;
+    const float d = u - 1.0f;
+    return d == 0.0f ? x : log(u) * (x * __builtin_amdgcn_rcpf(d));
+  }
+};
+template <> struct Fast<double> {
+  static __device__ __forceinline__ double log(double x) { return ::log(x); }
+  static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+  static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+  static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+  static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+  static __device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
+};
+
 // ------------------------------------------------------------------ reductions (wave = 64)
 template <class T> __device__ __forceinline__ T shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
 

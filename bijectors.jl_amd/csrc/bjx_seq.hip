@@ -44,25 +44,30 @@ template <class T> struct OrderedInv {   // ordered.jl:63-77 ; interface.jl:276-
   }
   __device__ T result() const { return ladj; }
 };
-// simplex.jl:47-64 (transform) fused with :122-138 (logabsdetjac); logk[i] = log(T(K-1-i))
+// simplex.jl:47-64 (transform) fused with :122-138 (logabsdetjac); logk[i] = log(T(K-1-i)).
+// The kernel is VALU-bound with exact OCML logs/divisions (118 VALU per element, PMC in
+// profiles/r01_pmc_notes.md), so Float32 uses the hardware log/rcp units (Fast<T>) and the three
+// logs of one log-det term are merged into the log of their product (>= eps^3, no underflow).
 template <class T, bool LADJ> struct SimplexFwd {
   int64_t K;
   T sum_tmp, prev_x, lp;
   __device__ void init() { sum_tmp = T(0); prev_x = T(0); lp = T(0); }
   __device__ T step(int64_t i, T x, const T* logk) {
+    using F = Fast<T>;
     const T e = Num<T>::eps;
     T o = T(0);
     if (i == 0) {
-      T z = x * (T(1) - 2 * e) + e;
-      o = d_logit(z) + logk[0];
-      if (LADJ) lp += d_log(d_max(x, e)) + d_log(d_max(T(1) - x, e));
+      T z = x * (T(1) - 2 * e) + e;                                        // :53
+      o = F::log(z * F::rcp(T(1) - z)) + logk[0];                          // logit(z) + log(K-1)
+      if (LADJ) lp += F::log(d_max(x, e) * d_max(T(1) - x, e));            // :130-131
     } else if (i < K - 1) {
       sum_tmp += prev_x;
-      T z = (x + e) * (T(1) - 2 * e) / ((T(1) + e) - sum_tmp);
-      o = d_logit(z) + logk[i];
+      T z = (x + e) * (T(1) - 2 * e) * F::rcp((T(1) + e) - sum_tmp);       // :58
+      o = F::log(z * F::rcp(T(1) - z)) + logk[i];
       if (LADJ) {
-        T zl = x / d_max(T(1) - sum_tmp, e);
-        lp += d_log(d_max(zl, e)) + d_log(d_max(T(1) - zl, e)) + d_log(d_max(T(1) - sum_tmp, e));
+        T m = d_max(T(1) - sum_tmp, e);
+        T zl = x * F::rcp(m);                                              // :134
+        lp += F::log(d_max(zl, e) * d_max(T(1) - zl, e) * m);              // :135
       }
     }
     prev_x = x;
@@ -75,24 +80,32 @@ template <class T, bool LADJ> struct SimplexInv {
   int64_t K;
   T sum_tmp, prev_x, lp;
   __device__ void init() { sum_tmp = T(0); prev_x = T(0); lp = T(0); }
+  static __device__ __forceinline__ T logistic(T v) {   // LogExpFunctions.logistic with its exact 0/1 saturation
+    using F = Fast<T>;
+    const T ex = F::exp(v);
+    return v < Num<T>::logistic_lo ? T(0) : (v > Num<T>::logistic_hi ? T(1) : ex * F::rcp(T(1) + ex));
+  }
   __device__ T step(int64_t i, T y, const T* logk) {
+    using F = Fast<T>;
     const T e = Num<T>::eps;
+    const T inv12e = T(1) / (T(1) - 2 * e);
     T x;
     if (i == 0) {
-      T z = d_logistic(y - logk[0]);
-      x = d_clamp((z - e) / (T(1) - 2 * e), T(0), T(1));
-      if (LADJ) lp += d_log(d_max(x, e)) + d_log(d_max(T(1) - x, e));
+      T z = logistic(y - logk[0]);
+      x = d_clamp((z - e) * inv12e, T(0), T(1));                           // :109
+      if (LADJ) lp += F::log(d_max(x, e) * d_max(T(1) - x, e));
     } else if (i < K - 1) {
-      T z = d_logistic(y - logk[i]);
+      T z = logistic(y - logk[i]);
       sum_tmp += prev_x;
-      x = d_clamp(((T(1) + e) - sum_tmp) / (T(1) - 2 * e) * z - e, T(0), T(1));
+      x = d_clamp(((T(1) + e) - sum_tmp) * inv12e * z - e, T(0), T(1));    // :113
       if (LADJ) {
-        T zl = x / d_max(T(1) - sum_tmp, e);
-        lp += d_log(d_max(zl, e)) + d_log(d_max(T(1) - zl, e)) + d_log(d_max(T(1) - sum_tmp, e));
+        T m = d_max(T(1) - sum_tmp, e);
+        T zl = x * F::rcp(m);
+        lp += F::log(d_max(zl, e) * d_max(T(1) - zl, e) * m);
       }
     } else {
       sum_tmp += prev_x;
-      x = d_clamp(T(1) - sum_tmp, T(0), T(1));
+      x = d_clamp(T(1) - sum_tmp, T(0), T(1));                             // :116
     }
     prev_x = x;
     return x;
@@ -200,50 +213,83 @@ template <class T> __device__ __forceinline__ T seg_prefix_incl(T v, bool head, 
   return v + (f ? T(0) : carry);
 }
 
-// corr.jl:370-399 (_inv_link_chol_lkj, vector form) and :485-501 (_logabsdetjac_inv_chol)
+// Wave-wide inclusive prefix sum with DPP (row_shr 1,2,4,8 inside the 16-lane rows, then the GFX9
+// row_bcast:15 / row_bcast:31 steps): 6 fused v_add_dpp instead of 6 x (ds_bpermute + select + add).
+__device__ __forceinline__ float wave_incl_scan_dpp(float v) {
+#define BJX_DPP_ADD(ctrl, rmask)                                                                         \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, true))
+  BJX_DPP_ADD(0x111, 0xF);   // row_shr:1
+  BJX_DPP_ADD(0x112, 0xF);   // row_shr:2
+  BJX_DPP_ADD(0x114, 0xF);   // row_shr:4
+  BJX_DPP_ADD(0x118, 0xF);   // row_shr:8
+  BJX_DPP_ADD(0x142, 0xA);   // row_bcast:15 -> rows 1 and 3
+  BJX_DPP_ADD(0x143, 0xC);   // row_bcast:31 -> rows 2 and 3
+#undef BJX_DPP_ADD
+  return v;
+}
+__device__ __forceinline__ double wave_incl_scan_dpp(double v) { return wave_incl_scan(v); }
+
+// corr.jl:370-399 (_inv_link_chol_lkj, vector form) and :485-501 (_logabsdetjac_inv_chol).
+// VALU-bound with the first version (340 VALU / entry, PMC in profiles/r01_pmc_notes.md); now:
+//  * (column, row) of a lane's entry is advanced incrementally (+64 entries per step) instead of an
+//    isqrt-style decode per entry;
+//  * tanh and logcosh share one exp(-2|y|) (tanh = (1-t)/(1+t), logcosh = |y| + log1p(t) - log 2);
+//    Float32 uses the hardware exp/log/rcp units;
+//  * the per-column running Σ logcosh is a DPP wave scan minus the scan value just before the
+//    column head (all terms are >= 0 and O(0.1), so the difference loses < 1e-6 absolute).
 template <class T, bool WRITE_W>
 __global__ __launch_bounds__(256) void chol_inv_kernel(const T* y, T* W, T* ladj_ps, int64_t K, int64_t batch, int lower,
                                                        int accumulate, double* partials) {
+  using F = Fast<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* red = reinterpret_cast<double*>(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T* diag = reinterpret_cast<T*>(smem + 32) + (size_t)wave * K;
   const int64_t nv = K * (K - 1) / 2;
   double acc = 0.0;
-  for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < batch; s += (int64_t)gridDim.x * 4) {   // grid = batch/4: one trip
+  int c_lane0, i0_lane0;
+  triu1_decode(lane, c_lane0, i0_lane0);
+  const int64_t s = (int64_t)blockIdx.x * 4 + wave;
+  if (s < batch) {
     const T* ys = y + s * nv;
     T* Ws = W + s * K * K;
     T carry = T(0), lj = T(0);
+    int c = c_lane0, i0 = i0_lane0;      // entry e = e0 + lane sits in column c (1..K-1), row i0 (0..c-1)
     for (int64_t e0 = 0; e0 < nv; e0 += 64) {
       const int64_t e = e0 + lane;
       const bool valid = e < nv;
-      int c = 1, i0 = 0;
-      if (valid) triu1_decode(e, c, i0);
       const T yv = valid ? ys[e] : T(0);
-      const T lc = valid ? d_logcosh(yv) : T(0);
-      const T incl = seg_prefix_incl<T>(lc, !valid || i0 == 0, carry);   // Σ_{k<=i} logcosh  => log_remainder_after = -incl
+      const T ay = d_abs(yv);
+      const T t = F::exp(T(-2) * ay);
+      const T lc = valid ? ay + F::log1p(t) - Num<T>::log2 : T(0);          // LogExpFunctions.logcosh
+      // inclusive Σ logcosh over my column: wave prefix minus the prefix just before the column head
+      const T S = wave_incl_scan_dpp(lc);
+      const int head = lane - i0;                                             // lane of the column's first entry (< 0: earlier step)
+      const T base = __shfl(S, head > 0 ? head - 1 : 0, 64);
+      const T incl = S - (head > 0 ? base : T(0)) + (head < 0 ? carry : T(0));
       const bool last = valid && (i0 == c - 1);
-      const T prev_incl = __shfl_up(incl, 1, 64);
-      const T excl = (i0 == 0) ? T(0) : (lane == 0 ? carry : prev_incl);   // Σ_{k<i} logcosh
       if (valid) {
         lj += last ? T(-2) * incl : -incl;        // logJ += log_remainder (each entry) + once more per column (:385-389)
         if (WRITE_W) {
-          const T wv = d_tanh(yv) * d_exp(-excl);          // z * exp(log_remainder_before) (:383)
+          const T th = (T(1) - t) * F::rcp(T(1) + t);                         // tanh|y|
+          const T wv = (yv < T(0) ? -th : th) * F::exp(-(incl - lc));         // z * exp(log_remainder_before) (:383)
           if (!lower) Ws[(int64_t)c * K + i0] = wv; else Ws[(int64_t)i0 * K + c] = wv;
-          if (last) diag[c] = d_exp(-incl);       // W[j,j] = exp(log_remainder) (:390)
+          if (last) diag[c] = F::exp(-incl);       // W[j,j] = exp(log_remainder) (:390)
         }
       }
       const T incl63 = __shfl(incl, 63, 64);
       const int last63 = __shfl((int)last, 63, 64);
       carry = last63 ? T(0) : incl63;
+      i0 += 64;
+      while (i0 >= c) { i0 -= c; ++c; }
     }
     if (WRITE_W) {
       if (lane == 0) diag[0] = T(1);
       // diagonal + zero fill of the other triangle (:391-395); column-major, rows c..K-1 of column c
-      for (int c = 0; c < K; ++c) {
-        for (int r = c + lane; r < K; r += 64) {
-          const T v = (r == c) ? diag[c] : T(0);
-          if (!lower) Ws[(int64_t)c * K + r] = v; else Ws[(int64_t)r * K + c] = v;
+      for (int cc = 0; cc < K; ++cc) {
+        for (int r = cc + lane; r < K; r += 64) {
+          const T v = (r == cc) ? diag[cc] : T(0);
+          if (!lower) Ws[(int64_t)cc * K + r] = v; else Ws[(int64_t)r * K + cc] = v;
         }
       }
     }

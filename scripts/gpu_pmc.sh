@@ -1,0 +1,21 @@
+#!/bin/bash
+# usage: gpu_pmc.sh <workload> <kernel-substring> "<counters...>"
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+R=$PWD; WL=$1; KS=$2; shift 2
+i=0
+for set in "$@"; do
+  i=$((i+1))
+  ( cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${WL}_$i -o p -- python $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_${WL}_$i.log 2>&1 )
+  f=$(ls gpurun_out/pmc_${WL}_$i/*counter_collection.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && python - "$f" "$KS" <<'PY'
+import csv, sys, collections
+rows=[r for r in csv.DictReader(open(sys.argv[1])) if sys.argv[2] in r['Kernel_Name']]
+agg=collections.defaultdict(list)
+for r in rows: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+if rows: print('kernel:', rows[0]['Kernel_Name'][:90], 'VGPR', rows[0]['VGPR_Count'], 'SGPR', rows[0]['SGPR_Count'], 'LDS', rows[0]['LDS_Block_Size'], 'grid', rows[0]['Grid_Size'], 'wg', rows[0]['Workgroup_Size'])
+for k,v in agg.items(): print('  %-28s %16.1f  (n=%d)' % (k, sum(v)/len(v), len(v)))
+PY
+done
+exit 0

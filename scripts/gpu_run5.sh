@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests -m gpu -q --maxfail=25 -p no:cacheprovider -k "planar or radial" > gpurun_out/pytest_gpu_flow.txt 2>&1; tail -3 gpurun_out/pytest_gpu_flow.txt
+grep -E "Mismatched|Max absolute|Max relative|^E  " gpurun_out/pytest_gpu_flow.txt | head -20
+b() { python bench.py --no-cpu-baseline --steps 10 --warmup 3 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%8.1f Msamp/s  %7.1f GB/s  frac %.3f  kernel_ms %.4f' % (d['value'], d['roofline']['achieved'], d['roofline']['frac'], d['roofline']['kernel_ms']))"; }
+for t in 1 0; do echo -n "c4 tile=$t : "; BJX_PLANAR_TILE=$t b --workload c4; done
+exit 0
