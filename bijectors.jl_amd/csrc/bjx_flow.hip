@@ -314,6 +314,247 @@ __global__ __launch_bounds__(64) void planar_tile_kernel(const PlanarTileArgs<T>
   }
 }
 
+// ------------------------------------------------------------------ Planar, register kernel (Float32)
+// The LDS tile kernel above needs 32 KiB of LDS per wave at dim = 128, i.e. 5 waves per CU with no
+// overlap of loads and arithmetic (15 % of the HBM roofline, profiles/r01_*).  Here the 64 x dim
+// tile of a wave stays in REGISTERS in the coalesced layout the loads deliver (G = dim/4 lanes own
+// one column as 16-byte packs, 64/G columns per wave instruction, G instructions in flight), and
+// only the tiny [64 columns x NL layers] matrices of dot products / tanh values cross lanes:
+//   1. p[k] = w_k[4gl..4gl+3] · z-pack                    (4 FMA per layer, lanes-along-dim)
+//   2. transposed reduction over the G lanes of a column: v_permlane16_swap halves the number of
+//      live values while it folds lane i+16 onto lane i, then DPP butterflies (quad_perm,
+//      row_half_mirror, row_mirror) finish inside the 16-lane row; one lane per row stores the sums
+//      to S[column][layer] in LDS (2 KiB per wave)
+//   3. LANE = COLUMN: all 64 lanes run the NL-step scalar recurrence (same algebra as the tile
+//      kernel) with hardware exp/log/rcp, and write t[column][layer] back to the same 2 KiB
+//   4. z-pack += Σ_k û_k[4gl..4gl+3] t[column][k]          (4 FMA per layer), stored straight from
+//      registers.
+// 128 + 32 VGPRs at dim = 128 -> 2 waves per SIMD, every load of a wave in flight at once.
+
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) {
+  // a' rows = [a0, b0, a2, b2], b' rows = [a1, b1, a3, b3] (row = 16 lanes; scripts/probe_lane_ops.hip).
+  // inline asm: __builtin_amdgcn_permlane16_swap miscompiles in this ROCm (both results read vdst).
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+// One butterfly stage (v += v[partner]) on NV independent values with the DPP modifier fused into
+// the add.  GFX9 hazard: a VALU write needs 2 wait states before a DPP read of the same VGPR.  The
+// NV adds of a stage are independent, so from the second stage on NV >= 4 needs no padding; the
+// first stage (inputs written by compiler-scheduled VALU code) and short stages get an s_nop 1.
+#define BJX_DPP1(i, CTRL) "v_add_f32_dpp %" #i ", %" #i ", %" #i " " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+#define BJX_DPP_STAGE(NOP, CTRL)                                                                                       \
+  if constexpr (NV == 1) asm volatile("s_nop 1\n\t" BJX_DPP1(0, CTRL) : "+v"(q[0]));                                    \
+  else if constexpr (NV == 2) asm volatile("s_nop 1\n\t" BJX_DPP1(0, CTRL) BJX_DPP1(1, CTRL) : "+v"(q[0]), "+v"(q[1])); \
+  else if constexpr (NV == 4) asm volatile(NOP BJX_DPP1(0, CTRL) BJX_DPP1(1, CTRL) BJX_DPP1(2, CTRL) BJX_DPP1(3, CTRL) \
+                                           : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));                           \
+  else asm volatile(NOP BJX_DPP1(0, CTRL) BJX_DPP1(1, CTRL) BJX_DPP1(2, CTRL) BJX_DPP1(3, CTRL)                         \
+                    BJX_DPP1(4, CTRL) BJX_DPP1(5, CTRL) BJX_DPP1(6, CTRL) BJX_DPP1(7, CTRL)                             \
+                    : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]));
+// all-lanes sum over aligned groups of W <= 16 consecutive lanes, NV values at once
+template <int W, int NV> __device__ __forceinline__ void row_allsum(float (&q)[NV]) {
+  static_assert(NV == 1 || NV == 2 || NV == 4 || NV == 8, "NV");
+  if constexpr (W >= 2) { BJX_DPP_STAGE("s_nop 1\n\t", "quad_perm:[1,0,3,2]") }
+  if constexpr (W >= 4) { BJX_DPP_STAGE("", "quad_perm:[2,3,0,1]") }
+  if constexpr (W >= 8) { BJX_DPP_STAGE("", "row_half_mirror") }
+  if constexpr (W >= 16) { BJX_DPP_STAGE("", "row_mirror") }
+}
+#undef BJX_DPP_STAGE
+// q[k] = fold(p[k], p[k+NV]) for k < NV: v_permlane16_swap puts lanes i / i+16 of p[k] side by side
+// in the even rows and those of p[k+NV] in the odd rows (see permlane16_swap), then one add.
+template <int NV> __device__ __forceinline__ void swap_fold(float* p, float (&q)[NV]) {
+  if constexpr (NV == 4)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                 "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                 : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
+  else if constexpr (NV == 2)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1"
+                 : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));
+  else
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(p[0]), "+v"(p[1]));
+#pragma unroll
+  for (int k = 0; k < NV; ++k) q[k] = p[k] + p[k + NV];
+}
+
+struct PlanarRegArgs {
+  const float *w, *u_hat;   // [nl_pad][dim] (layers beyond n_layers are zero)
+  const float *G;           // [nl_pad][nl_pad], G[k][j] = w_k . u_hat_j
+  const float *wtu_hat, *b; // [nl_pad]
+  int nl_pad;
+};
+
+// tanh / sech^2 / log1p from one exp (|rel err| ~ 1e-6, Float32 parity bar 1e-3)
+__device__ __forceinline__ void planar_act(float arg, float c, float& th, float& ld) {
+  using F = Fast<float>;
+  const float e = F::exp(-2.0f * fabsf(arg));
+  const float r = F::rcp(1.0f + e);
+  const float t = (1.0f - e) * r;
+  th = arg < 0.0f ? -t : t;
+  ld = F::log1p(c * (4.0f * e * r * r));     // planar_layer.jl:107, sech² = 4e/(1+e)²
+}
+
+template <int G, int NL, bool INV>
+__global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, const float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate,
+                                                         double* partials) {
+  constexpr int CPS = 64 / G;                       // columns per wave instruction
+  constexpr int NS = G;                             // pack steps for 64 columns
+  constexpr bool SWAP = (G == 32) && (NL >= 2);     // fold lane i+16 onto i with a transposed halving
+  constexpr int NV = SWAP ? NL / 2 : NL;            // live values per lane after the fold
+  constexpr int RW = G < 16 ? G : 16;               // lanes of a row that still have to be summed
+  constexpr int NP = NL >= 2 ? NL / 2 : 1;          // layer pairs (packed-FP32 math)
+  __shared__ __attribute__((aligned(16))) float st_all[4][64 * NL];
+  __shared__ double red[4];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* st = st_all[wave];
+  const int gl = lane & (G - 1);
+  const int cg = lane / G;                          // column inside a wave instruction
+  const bool row_ok = 4 * gl < dim;
+  const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  const int64_t left = batch - col0;
+  const int nvalid = left >= 64 ? 64 : (left > 0 ? (int)left : 0);
+  const int64_t step_elems = (int64_t)CPS * dim;
+
+  f4 z[NS];
+  {
+    const float* px = x + (col0 + cg) * dim + 4 * gl;
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+      if (row_ok && r * CPS + cg < nvalid) z[r] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(px));
+      else z[r] = f4{0.f, 0.f, 0.f, 0.f};
+      px += step_elems;
+    }
+  }
+  float ladj = 0.f;
+  const int ngroups = A.nl_pad / NL;
+  for (int gi = 0; gi < ngroups; ++gi) {
+    const int l0 = (INV ? ngroups - 1 - gi : gi) * NL;   // the inverse undoes the LAST group first
+    // ---- 1+2: dot products against the group's w rows, reduced over the G lanes of each column
+    {
+      // wq[kp][j] = (w_{2kp}[4gl+j], w_{2kp+1}[4gl+j]): two layers per packed-FP32 instruction
+      f2 wq[NP][4];
+#pragma unroll
+      for (int kp = 0; kp < NP; ++kp) {
+        f4 a = f4{0.f, 0.f, 0.f, 0.f}, b = a;
+        if (row_ok) {
+          a = *reinterpret_cast<const f4*>(A.w + (int64_t)(l0 + 2 * kp) * dim + 4 * gl);
+          if (NL >= 2) b = *reinterpret_cast<const f4*>(A.w + (int64_t)(l0 + 2 * kp + 1) * dim + 4 * gl);
+        }
+        wq[kp][0] = f2{a.x, b.x}; wq[kp][1] = f2{a.y, b.y}; wq[kp][2] = f2{a.z, b.z}; wq[kp][3] = f2{a.w, b.w};
+      }
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        float p[NL >= 2 ? NL : 2];
+#pragma unroll
+        for (int kp = 0; kp < NP; ++kp) {
+          f2 acc = wq[kp][0] * z[r].x;
+          acc += wq[kp][1] * z[r].y;
+          acc += wq[kp][2] * z[r].z;
+          acc += wq[kp][3] * z[r].w;
+          p[2 * kp] = acc.x; p[2 * kp + 1] = acc.y;
+        }
+        float q[NV];
+        if constexpr (SWAP) {
+          swap_fold<NV>(p, q);
+        } else if constexpr (G == 32) {   // NL == 1: plain fold of lane i+16 onto lane i
+          p[1] = p[0];
+          swap_fold<1>(p, q);
+        } else {
+#pragma unroll
+          for (int k = 0; k < NV; ++k) q[k] = p[k];
+        }
+        row_allsum<RW, NV>(q);
+        // rows (16 lanes): G=32 -> row 0/1 = layers lo/hi of column A, row 2/3 = of column B
+        if ((lane & (RW - 1)) == 0) {
+          int cl, lo;
+          if (G == 32) { cl = r * CPS + (lane >> 5); lo = SWAP ? ((lane >> 4) & 1) * NV : 0; }
+          else { cl = r * CPS + cg; lo = 0; }
+          if (!(G == 32 && !SWAP && ((lane >> 4) & 1))) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) st[cl * NL + lo + k] = q[k];
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- 3: scalar recurrence, one sample per lane
+    {
+      float s[NL], t[NL];
+#pragma unroll
+      for (int k = 0; k < NL; ++k) { s[k] = st[lane * NL + k]; t[k] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < NL; ++kk) {
+        const int k = INV ? NL - 1 - kk : kk;
+        const float* Gk = A.G + (int64_t)(l0 + k) * A.nl_pad + l0;
+        float a = s[k];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+          if (!INV) { if (j < k) a += Gk[j] * t[j]; }
+          else { if (j > k) a += Gk[j] * t[j]; }        // t holds -tanh for the inverse
+        }
+        const float bl = A.b[l0 + k], c = A.wtu_hat[l0 + k];
+        const float arg = INV ? find_alpha_dev<float>(a, c, bl) + bl : a + bl;
+        float th, ld;
+        planar_act(arg, c, th, ld);
+        ladj += INV ? -ld : ld;
+        t[k] = INV ? -th : th;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < NL; ++k) st[lane * NL + k] = t[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- 4: rank-NL update of the register tile
+    {
+      f4 uv[NL];
+#pragma unroll
+      for (int k = 0; k < NL; ++k)
+        uv[k] = row_ok ? *reinterpret_cast<const f4*>(A.u_hat + (int64_t)(l0 + k) * dim + 4 * gl) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        const float* tc = st + (r * CPS + cg) * NL;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) { const float tk = tc[k]; z[r] += uv[k] * tk; }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  {
+    float* py = y + (col0 + cg) * dim + 4 * gl;
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+      if (row_ok && r * CPS + cg < nvalid) __builtin_nontemporal_store(z[r], reinterpret_cast<f4*>(py));
+      py += step_elems;
+    }
+  }
+  const bool ok = lane < nvalid;
+  if (ok && ladj_ps) ladj_ps[col0 + lane] = accumulate ? ladj_ps[col0 + lane] + ladj : ladj;
+  if (partials) block_publish_partial(ok ? (double)ladj : 0.0, red, partials);
+}
+
+// zero-padded parameter tables for the register kernel: w, û -> [nl_pad][dim]; b, wᵀû -> [nl_pad];
+// G[k][j] = w_k . û_j -> [nl_pad][nl_pad].  grid = nl_pad * nl_pad blocks.
+__global__ __launch_bounds__(256) void planar_prep_reg_kernel(const float* w, const float* u_hat, const float* wtu_hat, const float* b,
+                                                              int64_t dim, int nl, int nl_pad, float* wp, float* up, float* Gp,
+                                                              float* cp, float* bp) {
+  __shared__ double red[4];
+  const int k = blockIdx.x / nl_pad, j = blockIdx.x % nl_pad;
+  const bool live = k < nl && j < nl;
+  double dot = 0.0;
+  if (live) for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) dot += (double)w[(int64_t)k * dim + i] * (double)u_hat[(int64_t)j * dim + i];
+  dot = group_sum<64>(dot);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) Gp[k * nl_pad + j] = live ? (float)((red[0] + red[1]) + (red[2] + red[3])) : 0.f;
+  if (j == 0) {
+    for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) {
+      wp[(int64_t)k * dim + i] = k < nl ? w[(int64_t)k * dim + i] : 0.f;
+      up[(int64_t)k * dim + i] = k < nl ? u_hat[(int64_t)k * dim + i] : 0.f;
+    }
+    if (threadIdx.x == 0) { cp[k] = k < nl ? wtu_hat[k] : 0.f; bp[k] = k < nl ? b[k] : 0.f; }
+  }
+}
+
 template <class T> struct RadialArgs {
   const T *alpha_, *beta, *z0;
   int in_lds;
@@ -439,6 +680,44 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
   if (batch == 0) {
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
     return BJX_OK;
+  }
+  // register kernel (Float32, 16-byte packs, 20 <= dim <= 128): see planar_reg_kernel
+  static const int use_reg = getenv("BJX_PLANAR_REG") ? atoi(getenv("BJX_PLANAR_REG")) : 1;
+  if constexpr (sizeof(T) == 4) {
+    if (use_reg && dim % 4 == 0 && dim > 16 && dim <= 128 && bjx_aligned16(in) && bjx_aligned16(out)) {
+      const int NL = nl >= 8 ? 8 : (nl > 2 ? 4 : nl);
+      const int nl_pad = (nl + NL - 1) / NL * NL;
+      const size_t off0 = ((size_t)nl * dim + nl + 3) / 4 * 4;   // floats, keeps the padded tables 16-byte aligned
+      const size_t need_reg = (off0 + (size_t)2 * nl_pad * dim + (size_t)nl_pad * nl_pad + 2 * (size_t)nl_pad) * sizeof(float);
+      if (need_reg <= BJX_SCRATCH_BYTES) {
+        float* base = reinterpret_cast<float*>(ctx->scratch);
+        float* wp = base + off0;
+        float* up = wp + (size_t)nl_pad * dim;
+        float* Gp = up + (size_t)nl_pad * dim;
+        float* cp = Gp + (size_t)nl_pad * nl_pad;
+        float* bp = cp + nl_pad;
+        hipLaunchKernelGGL(planar_prep_reg_kernel, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, (const float*)w, (const float*)u_hat,
+                           (const float*)wtu, (const float*)b, dim, nl, nl_pad, wp, up, Gp, cp, bp);
+        BJX_CHECK_LAUNCH(ctx);
+        const int64_t grid = (batch + 255) / 256;
+        BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar: batch too large for one launch");
+        if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
+        double* partials = ladj_sum ? ctx->partials : nullptr;
+        PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad};
+        const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+        const int G = dim > 64 ? 32 : (dim > 32 ? 16 : 8);
+#define LAUNCH_REG(G_, NL_, INV_) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, partials)
+#define LAUNCH_REG_NL(G_, INV_) switch (NL) { case 1: LAUNCH_REG(G_, 1, INV_); break; case 2: LAUNCH_REG(G_, 2, INV_); break; case 4: LAUNCH_REG(G_, 4, INV_); break; default: LAUNCH_REG(G_, 8, INV_); break; }
+#define LAUNCH_REG_G(INV_) switch (G) { case 8: LAUNCH_REG_NL(8, INV_) break; case 16: LAUNCH_REG_NL(16, INV_) break; default: LAUNCH_REG_NL(32, INV_) break; }
+        if (inverse) { LAUNCH_REG_G(true) } else { LAUNCH_REG_G(false) }
+#undef LAUNCH_REG_G
+#undef LAUNCH_REG_NL
+#undef LAUNCH_REG
+        BJX_CHECK_LAUNCH(ctx);
+        if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+        return BJX_OK;
+      }
+    }
   }
   // tile kernel: lane = column (full-lane scalar recurrence); needs the 64 x dim tile in LDS
   static const int use_tile = getenv("BJX_PLANAR_TILE") ? atoi(getenv("BJX_PLANAR_TILE")) : 1;

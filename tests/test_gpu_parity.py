@@ -273,7 +273,8 @@ def test_vec_cholesky_mode_check(bj):
 
 # ------------------------------------------------------------------ F2 flows
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("dim,N,nl", [(2, 20, 1), (10, 100, 1), (128, 500, 8), (130, 33, 3), (7, 1, 2), (600, 9, 2)])
+@pytest.mark.parametrize("dim,N,nl", [(2, 20, 1), (10, 100, 1), (128, 500, 8), (130, 33, 3), (7, 1, 2), (600, 9, 2),
+                                       (128, 67, 1), (100, 300, 2), (64, 257, 5), (32, 1000, 4), (24, 65, 16), (128, 129, 11), (60, 64, 8)])
 def test_planar(bj, orc, dim, N, nl, dt):
     r = rng(7)
     w = (r.normal(size=(dim, nl)) / math.sqrt(dim)).astype(dt)
