@@ -109,7 +109,37 @@ def _prep(x: torch.Tensor):
     raise ValueError("expected a vector or a (dim, batch) matrix")
 
 
+_OUT_HINT: list = []  # caller-owned output buffer for the next structured launch (the `!` methods)
+
+
+class _into:
+    """`with _into(y):` — the next `_empty` of y's shape/dtype/layout returns `y` itself, so the
+    kernel writes straight into the caller's buffer (transform!/with_logabsdet_jacobian!,
+    src/interface.jl:175-218) instead of into a temporary that is copied afterwards."""
+
+    def __init__(self, y: Optional[torch.Tensor]):
+        self.y = y
+
+    def __enter__(self):
+        _OUT_HINT.append(self.y)
+        return self
+
+    def __exit__(self, *exc):
+        _OUT_HINT.pop()
+        return False
+
+
+def _colmajor_dense(t: torch.Tensor) -> bool:
+    return t.dim() == 1 and t.is_contiguous() or t.dim() == 2 and t.T.is_contiguous()
+
+
 def _empty(rows: int, batch: int, like: torch.Tensor, vec: bool) -> torch.Tensor:
+    if _OUT_HINT and _OUT_HINT[-1] is not None:
+        h = _OUT_HINT[-1]
+        want = (rows,) if vec else (rows, batch)
+        if tuple(h.shape) == want and h.dtype == like.dtype and h.device == like.device and _colmajor_dense(h):
+            _OUT_HINT[-1] = None  # one use per scope
+            return h
     if vec:
         return torch.empty(rows, dtype=like.dtype, device=like.device)
     return torch.empty((batch, rows), dtype=like.dtype, device=like.device).T
@@ -283,7 +313,10 @@ def transform_(b, x, y=None):
     if ops is not None:
         _run_chain(ops, x, False, False, out_y=tgt)
         return tgt
-    tgt.copy_(transform(b, x))
+    with _into(tgt if tgt is not x else None):
+        out = transform(b, x)
+    if out.data_ptr() != tgt.data_ptr():
+        tgt.copy_(out)
     return tgt
 
 
@@ -295,8 +328,10 @@ def with_logabsdet_jacobian_(b, x, y=None, logjac=0.0):
     if ops is not None:
         _, l = _run_chain(ops, x, False, True, out_y=tgt)
         return tgt, (l if isinstance(logjac, float) and logjac == 0.0 else logjac + l)
-    out, l = with_logabsdet_jacobian(b, x)
-    tgt.copy_(out)
+    with _into(tgt if tgt is not x else None):
+        out, l = with_logabsdet_jacobian(b, x)
+    if out.data_ptr() != tgt.data_ptr():
+        tgt.copy_(out)
     return tgt, logjac + l
 
 

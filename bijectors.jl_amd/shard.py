@@ -43,8 +43,9 @@ def with_logabsdet_jacobian_sharded(b, x_shard: torch.Tensor, group=None, out: O
     if ops is not None:
         y, l = I._run_chain(ops, x_shard, mode, True, out_y=out)
     else:
-        y, l = b._wlj(x_shard, per_sample=mode)
-        if out is not None:
+        with I._into(out):
+            y, l = b._wlj(x_shard, per_sample=mode)
+        if out is not None and y.data_ptr() != out.data_ptr():
             out.copy_(y)
             y = out
     lps, lsum = l if per_sample else (None, l)

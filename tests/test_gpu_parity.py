@@ -474,3 +474,28 @@ def test_shard_emulation_sum_is_invariant(bj):
     # same call twice: bitwise identical (fixed-order reduction, no atomics)
     _, l2 = bj.with_logabsdet_jacobian(b, x)
     assert float(l1) == float(l2)
+
+
+def test_inplace_methods_write_into_the_callers_buffer(bj, orc):
+    """transform!(b, x, y) / with_logabsdet_jacobian!(b, x, y, logjac) (src/interface.jl:175-218):
+    structured bijectors launch straight into `y` (no temporary + copy) and add onto `logjac`."""
+    r = rng(21)
+    d, N = 64, 300
+    w, u, b0 = r.normal(size=(d, 2)) / 8, r.normal(size=(d, 2)) / 8, r.normal(size=2)
+    Z = np.asfortranarray(r.normal(size=(d, N)))
+    layer = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(b0))
+    Y_ref, l_ref = orc.planar(w, u, b0, Z)
+    zd = dev(Z)
+    y = torch.empty((N, d), dtype=zd.dtype, device=zd.device).T
+    ptr = y.data_ptr()
+    got, l = bj.with_logabsdet_jacobian_(layer, zd, y, 0.0)
+    assert got.data_ptr() == ptr
+    close(host(y), Y_ref, np.float64)
+    close(host(l), l_ref, np.float64, scale=2)
+    y2 = torch.empty((N, d), dtype=zd.dtype, device=zd.device).T
+    assert bj.transform_(layer, zd, y2).data_ptr() == y2.data_ptr()
+    close(host(y2), Y_ref, np.float64)
+    # x itself as the target (transform!(b, x)): result lands in x
+    x_inplace = zd.clone()
+    bj.transform_(layer, x_inplace)
+    close(host(x_inplace), Y_ref, np.float64)
