@@ -124,132 +124,256 @@ __global__ __launch_bounds__(256) void rqs_params_kernel(const T* rw, const T* r
   }
 }
 
-// ------------------------------------------------------------------ RQS, table kernel
+// ------------------------------------------------------------------ RQS, LDS table kernel
 // The functor path above costs 178 (fwd) / 295 (inv) VALU instructions per element and suffers
 // 8-way LDS bank conflicts on the [rows, K] column-major knot tables (PMC: SQ_LDS_BANK_CONFLICT =
-// 63 % of LDS cycles), i.e. it is VALU/LDS-bound at 13 % of the HBM roofline.  This kernel
-//  * precomputes, once per call, a per-(row, bin) record {w_k, 1/w, h_k, Δy | s, d_k, d_k+1, w}
-//    (two 16-byte LDS reads replace six 4-byte reads and two divisions per element),
-//  * stores search keys and records row-major ([row][bin]) so that lanes that share a row but fall
-//    into different bins hit different banks,
-//  * uses one hardware log + one reciprocal per element in Float32 (log(num/den²)),
-//  * reuses the inverse's ξ for its log-det instead of a second search + forward evaluation, and
-//  * lets one block walk ITER column groups so the 20 KiB table staging is amortised.
-// Bin selection is exact (same Float32/Float64 knot values and comparisons as the oracle).
-template <class T> struct RqsRec { T a[4]; T b[4]; };   // a = {w_k, 1/w, h_k, dy}, b = {s, d_k, d_k1, w}
-
-// rational_quadratic_spline.jl:139-156: bin k in 0..K-1 spans knots k..k+1 (knot 0 = -knot K mirrored)
-template <class T>
-__global__ __launch_bounds__(256) void rqs_prep_kernel(const T* w, const T* h, const T* d, int K, int64_t rows,
-                                                       T* keyW, T* keyH, RqsRec<T>* rec) {
-  const int64_t n = rows * K;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / K;
-    const int k = (int)(i % K);
-    auto W = [&](int j) { return w[(int64_t)(j - 1) * rows + r]; };   // 1-based knot j of row r
-    auto H = [&](int j) { return h[(int64_t)(j - 1) * rows + r]; };
-    auto D = [&](int j) { return d[(int64_t)(j - 1) * rows + r]; };
-    keyW[i] = W(k + 1);
-    keyH[i] = H(k + 1);
-    const T w_k = (k == 0) ? -W(K) : W(k);
-    const T wd = W(k + 1) - w_k;
-    const T h_k = (k == 0) ? -H(K) : H(k);
-    const T dy = H(k + 1) - h_k;
-    RqsRec<T> q;
-    q.a[0] = w_k; q.a[1] = T(1) / wd; q.a[2] = h_k; q.a[3] = dy;
-    q.b[0] = dy / wd;                                  // s
-    q.b[1] = (k == 0) ? T(1) : D(k);                   // d_k
-    q.b[2] = (k == K - 1) ? T(1) : D(k + 1);           // d_{k+1}
-    q.b[3] = wd;
-    rec[i] = q;
-  }
+// 63 % of LDS cycles), i.e. it is VALU/LDS-bound at 13 % of the HBM roofline.  This kernel keeps the
+// reference's arithmetic (rational_quadratic_spline.jl:128-164,183-220,266-357) but
+//  * precomputes, once per call, a per-(row, bin) record {w_k, 1/w, h_k, Δy | s, d_k, d_k+1, Σd-2s}
+//    (two 16-byte LDS reads replace six 4-byte reads and two divisions per element);
+//  * stores the searched knots as an implicit binary tree, LEVEL BY LEVEL, with the rows permuted so
+//    that the rows touched by one wave instruction are adjacent: level l of the 8 rows a wave
+//    instruction touches at dim = 32 is 8·2^(l-1) consecutive words -> levels 1-3 are bank-conflict
+//    free, level 4 at most 2-way (the old [row][bin] layout put every row on the same 16 banks);
+//  * keeps each lane's level-1/2 keys and range limit in registers (a lane owns the same rows of
+//    every column), so only levels >= 3 are read from LDS per element;
+//  * is branch-free per element (outside [-B, B] is a select), searches the 4 elements of a pack
+//    in lock step, and uses one hardware log + one reciprocal per element in Float32;
+//  * reuses the inverse's ξ for its log-det instead of a second search + forward evaluation;
+//  * drops the empty bin 0 (knot 1 = -knot K for the `B` constructor, :109-123) when every row has
+//    it, which saves one search level for K+1 = 2^m + 1 knots (flag computed on the device);
+//  * lets one block walk ITER column groups so the table staging is amortised.
+// Bin selection is exact (same knot values and comparisons as the oracle).
+//
+// LDS blob, in units of T (built by rqs_blob_kernel in the context scratch, copied verbatim):
+//   [0, dimp)                         lim[rp]          = knot K (range limit) of permuted row rp
+//   [dimp·2^(l-1), dimp·2^l)          level l keys     [rp][2^(l-1)],  l = 1..NSTEP
+//   [dimp·2^NSTEP, +4·dimp·RS)        record half A    [rp][RS] x 4    {w_k, 1/w, h_k, Δy}  (inverse: {h_k, Δy, w_k, w})
+//   [.. , +4·dimp·RS)                 record half B    [rp][RS] x 4    {s, d_k, d_k+1, d_k+1 + d_k - 2s}
+// rp = j·nvc + v for row v·V + j (V = pack width, nvc = packs per column); RS = nslots + 1 (skew).
+struct RqsGeom {
+  int K1;       // knots per row
+  int nvc;      // packs per column (dim / V)
+  int V;
+  int dimp;     // rows, padded to a multiple of 4
+  int nstep;    // search levels
+  int kbase;    // 1: bin 0 dropped
+  int nslots;   // bins kept = K1 - kbase
+  int RS;       // record row stride (records)
+};
+__host__ __device__ inline RqsGeom rqs_geom(int K1, int64_t dim, int V, int skip0, int nstep_hi) {
+  RqsGeom g;
+  g.K1 = K1; g.V = V; g.nvc = (int)(dim / V); g.dimp = (int)((dim + 3) / 4 * 4);
+  g.kbase = skip0 ? 1 : 0;
+  g.nstep = nstep_hi - g.kbase;
+  g.nslots = K1 - g.kbase;
+  g.RS = g.nslots + 1;
+  return g;
 }
+__host__ __device__ inline size_t rqs_blob_words(const RqsGeom& g) { return (size_t)g.dimp * (1u << g.nstep) + 8 * (size_t)g.dimp * g.RS; }
 
-// number of keys (ascending, length K) strictly below x == searchsortedfirst(keys, x) - 1
-template <class T> __device__ __forceinline__ int count_below(const T* keys, int K, int top, T x) {
-  int pos = 0;
-  for (int step = top; step >= 1; step >>= 1) {
-    const int nx = pos + step;
-    if (nx <= K && keys[nx - 1] < x) pos = nx;
-  }
-  return pos;
+// flag[0] = 1 iff knot 1 <= -knot K for widths and heights of every row (bin 0 unreachable)
+template <class T>
+__global__ __launch_bounds__(256) void rqs_flag_kernel(const T* w, const T* h, int K1, int64_t rows, int* flag) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  for (int64_t r = threadIdx.x; r < rows; r += blockDim.x)
+    if (!(w[r] <= -w[(int64_t)(K1 - 1) * rows + r]) || !(h[r] <= -h[(int64_t)(K1 - 1) * rows + r])) bad = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) flag[0] = bad ? 0 : 1;
 }
 
 template <class T, bool INV>
-__device__ __forceinline__ T rqs_table_elem(const T* keys, const RqsRec<T>* rec, int K, int top, T& v) {
-  using F = Fast<T>;
-  const T lim = keys[K - 1];
-  const T x = v;
-  if ((x <= -lim) || (x >= lim)) return T(0);        // identity outside [-B, B], log-det 0 (:132, :186)
-  const int k = count_below<T>(keys, K, top, x);
-  const RqsRec<T> q = rec[k];
-  const T s = q.b[0], d_k = q.b[1], d_k1 = q.b[2];
-  T xi;
-  if (!INV) {
-    xi = (x - q.a[0]) * q.a[1];                                             // ξ
+__global__ __launch_bounds__(256) void rqs_blob_kernel(const T* w, const T* h, const T* d, int K1, int64_t rows, int V, int nstep_hi,
+                                                       int dual, const int* flag, T* blob) {
+  const RqsGeom g = rqs_geom(K1, rows, V, dual ? flag[0] : 0, nstep_hi);
+  const int nkeys = (1 << g.nstep) - 1;
+  const int per_row = nkeys > g.nslots ? nkeys : g.nslots;
+  const int64_t total = (int64_t)g.dimp * per_row;
+  T* recA = blob + (size_t)g.dimp * (1u << g.nstep);
+  T* recB = recA + 4 * (size_t)g.dimp * g.RS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int rp = (int)(i / per_row), s = (int)(i % per_row);
+    const int64_t r = (int64_t)(rp % g.nvc) * g.V + rp / g.nvc;   // actual row
+    const bool live = rp < g.V * g.nvc && r < rows;
+    auto W = [&](int j) { return w[(int64_t)(j - 1) * rows + r]; };   // 1-based knot j of row r
+    auto H = [&](int j) { return h[(int64_t)(j - 1) * rows + r]; };
+    auto D = [&](int j) { return d[(int64_t)(j - 1) * rows + r]; };
+    if (s == 0) blob[rp] = live ? (INV ? H(K1) : W(K1)) : T(0);
+    if (s < nkeys) {
+      // sorted searched key s (0-based) = knot kbase + s + 1, padded with +inf; tree position:
+      const int t = __builtin_ctz(s + 1);
+      const int lvl = g.nstep - t, path = (s + 1) >> (t + 1);
+      T kv = Num<T>::inf;
+      if (live && s < g.nslots - 1) kv = INV ? H(g.kbase + s + 1) : W(g.kbase + s + 1);
+      blob[(size_t)g.dimp * (1u << (lvl - 1)) + (size_t)rp * (1u << (lvl - 1)) + path] = kv;
+    }
+    if (s < g.nslots) {
+      T a[4] = {T(0), T(1), T(0), T(0)}, b[4] = {T(1), T(1), T(1), T(0)};
+      if (live) {
+        const int k = s + g.kbase;                                   // bin k spans knots k..k+1 (knot 0 = -knot K)
+        const T w_k = (k == 0) ? -W(K1) : W(k);                      // :140,:192
+        const T wd = W(k + 1) - w_k;
+        const T h_k = (k == 0) ? -H(K1) : H(k);
+        const T dy = H(k + 1) - h_k;
+        const T sl = dy / wd;                                        // s = Δy/w
+        const T d_k = (k == 0) ? T(1) : D(k);
+        const T d_k1 = (k == K1 - 1) ? T(1) : D(k + 1);
+        if (!INV) { a[0] = w_k; a[1] = T(1) / wd; a[2] = h_k; a[3] = dy; }
+        else { a[0] = h_k; a[1] = dy; a[2] = w_k; a[3] = wd; }
+        b[0] = sl; b[1] = d_k; b[2] = d_k1; b[3] = d_k1 + d_k - 2 * sl;
+      }
+      T* pa = recA + 4 * ((size_t)rp * g.RS + s);
+      T* pb = recB + 4 * ((size_t)rp * g.RS + s);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { pa[q] = a[q]; pb[q] = b[q]; }
+    }
+  }
+}
+
+template <class T> struct Rec4 { T v[4]; };
+template <class T> __device__ __forceinline__ Rec4<T> lds_rec(const T* p) {
+  Rec4<T> r;
+  if constexpr (sizeof(T) == 4) {
+    bjx_f32x4 t = *reinterpret_cast<const bjx_f32x4*>(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
   } else {
-    const T yh = x - q.a[2];
-    const T ds = d_k1 + d_k - 2 * s;
-    const T a1 = q.a[3] * (s - d_k) + yh * ds;                              // Eq. (25)
-    const T a2 = q.a[3] * d_k - yh * ds;                                    // Eq. (26)
+    bjx_f64x2 t0 = *reinterpret_cast<const bjx_f64x2*>(p), t1 = *reinterpret_cast<const bjx_f64x2*>(p + 2);
+    r.v[0] = t0.x; r.v[1] = t0.y; r.v[2] = t1.x; r.v[3] = t1.y;
+  }
+  return r;
+}
+
+// value + log-det of one element given its bin records; x is replaced by the result.
+// Forward: rational_quadratic_spline.jl:317-357.  Inverse: :183-220 + the forward log-det at the
+// recovered ξ, negated (interface.jl:276-281).
+template <class T, bool INV>
+__device__ __forceinline__ T rqs_eval(const Rec4<T>& A, const Rec4<T>& B, T lim, T& x) {
+  using F = Fast<T>;
+  const T s = B.v[0], d_k = B.v[1], d_k1 = B.v[2], ds = B.v[3];
+  const T xin = x;
+  T xi, res;
+  if (!INV) {
+    xi = (xin - A.v[0]) * A.v[1];                                           // ξ = (x - w_k)/w
+  } else {
+    const T yh = xin - A.v[0];
+    const T t = yh * ds;
+    const T a1 = A.v[1] * (s - d_k) + t;                                    // Eq. (25)
+    const T a2 = A.v[1] * d_k - t;                                          // Eq. (26)
     const T a3 = -s * yh;                                                   // Eq. (27)
     xi = F::div(-2 * a3, a2 + F::sqrt(a2 * a2 - 4 * a1 * a3));              // Eq. (24)
   }
   const T om = T(1) - xi;
   const T xo = xi * om;
-  const T den = s + (d_k1 + d_k - 2 * s) * xo;
+  const T xi2 = xi * xi;
+  const T den = s + ds * xo;
   const T rden = F::rcp(den);
-  const T num_jl = s * s * (d_k1 * (xi * xi) + 2 * s * xo + d_k * (om * om));
-  const T lj = F::log(num_jl * rden * rden);                                // log(num) - 2 log(den)
-  if (!INV) { v = q.a[2] + q.a[3] * (s * (xi * xi) + d_k * xo) * rden; return lj; }
-  v = xi * q.b[3] + q.a[0];
-  return -lj;                                                               // interface.jl:276-281
+  const T nj = d_k1 * xi2 + (2 * s) * xo + d_k * (om * om);
+  const T sr = s * rden;
+  T lj = F::log(nj * (sr * sr));                                            // log(s²·nj) - 2 log(den)
+  if (!INV) res = A.v[2] + A.v[3] * (s * xi2 + d_k * xo) * rden;
+  else { res = xi * A.v[3] + A.v[2]; lj = -lj; }
+  // identity outside [-B, B] (:132, :186): (x <= -lim || x >= lim) == !(|x| < lim), NaN included
+  const bool inside = d_abs(xin) < lim;
+  x = inside ? res : xin;
+  return inside ? lj : T(0);
 }
 
-template <class T, int V, bool INV>
-__global__ __launch_bounds__(256) void rqs_table_kernel(const T* keys_g, const RqsRec<T>* rec_g, int K, int top, int in_lds,
-                                                        const T* x, T* y, T* ladj_ps, int64_t dim, int64_t batch, int G,
-                                                        int iters, int accumulate, double* partials) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double red[4];
-  const int64_t nrec = dim * K;
-  RqsRec<T>* rec_l = reinterpret_cast<RqsRec<T>*>(smem);
-  T* keys_l = reinterpret_cast<T*>(smem + (size_t)nrec * sizeof(RqsRec<T>));
-  if (in_lds) {
-    const int npk = (int)(nrec * (sizeof(RqsRec<T>) / 16));
-    const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(rec_g);
-    bjx_f32x4* dst = reinterpret_cast<bjx_f32x4*>(rec_l);
-    for (int i = threadIdx.x; i < npk; i += 256) dst[i] = src[i];
-    for (int i = threadIdx.x; i < nrec; i += 256) keys_l[i] = keys_g[i];
-    __syncthreads();
-  }
-  const RqsRec<T>* rec = in_lds ? rec_l : rec_g;
-  const T* keys = in_lds ? keys_l : keys_g;
+// pos = 2*pos + (key < x): one compare + one add-with-carry (the compiler's own lowering of this
+// line is compare + cndmask + shift-or).
+__device__ __forceinline__ void search_step(int& pos, float key, float x) {
+  asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(pos) : "v"(key), "v"(x) : "vcc");
+}
+__device__ __forceinline__ void search_step(int& pos, double key, double x) {
+  asm("v_cmp_lt_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(pos) : "v"(key), "v"(x) : "vcc");
+}
+
+template <class T, int V, int NSTEP, bool INV>
+__device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const RqsGeom g, const T* __restrict__ x, T* __restrict__ y,
+                                         T* __restrict__ ladj_ps, int64_t dim, int64_t batch, int G, int iters, int accumulate,
+                                         double& acc) {
   const int gl = threadIdx.x & (G - 1);
   const int cols_per_block = 256 / G;
-  const int64_t nvc = dim / V;
-  double acc = 0.0;
+  const bool lane_ok = gl < g.nvc;
+  const int glc = lane_ok ? gl : 0;
+  const char* base = reinterpret_cast<const char*>(blob_l);
+  // per-lane constants: a lane owns rows glc*V + j of every column.  lb[l][j] / ra / rb are LDS BYTE
+  // offsets so the per-element address is one v_lshl_add_u32 of the search position.
+  T lim[V], k1[V], k2a[V], k2b[V];
+  int lb[NSTEP > 2 ? NSTEP - 2 : 1][V], ra[V], rb[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int rp = j * g.nvc + glc;
+    lim[j] = blob_l[rp];
+    k1[j] = blob_l[g.dimp + rp];
+    if (NSTEP >= 2) { k2a[j] = blob_l[2 * g.dimp + 2 * rp]; k2b[j] = blob_l[2 * g.dimp + 2 * rp + 1]; }
+    else { k2a[j] = k2b[j] = T(0); }
+#pragma unroll
+    for (int lvl = 3; lvl <= NSTEP; ++lvl) lb[lvl - 3][j] = (int)sizeof(T) * ((g.dimp + rp) << (lvl - 1));
+    ra[j] = (int)sizeof(T) * ((g.dimp << NSTEP) + 4 * rp * g.RS);
+    rb[j] = ra[j] + (int)sizeof(T) * 4 * g.dimp * g.RS;
+  }
+  constexpr int SH = sizeof(T) == 4 ? 2 : 3;
   for (int it = 0; it < iters; ++it) {
     const int64_t col = ((int64_t)blockIdx.x * iters + it) * cols_per_block + threadIdx.x / G;
     T l = T(0);
-    if (col < batch) {
-      const T* xc = x + col * dim;
-      T* yc = y + col * dim;
-      for (int64_t v = gl; v < nvc; v += G) {
-        Pack<T, V> p = load_pack<T, V, true>(xc + v * V);
+    if (col < batch && lane_ok) {
+      Pack<T, V> p = load_pack<T, V, true>(x + col * dim + (int64_t)gl * V);
+      int pos[V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          const int64_t r = v * V + j;
-          l += rqs_table_elem<T, INV>(keys + r * K, rec + r * K, K, top, p.v[j]);
-        }
-        store_pack<T, V, true>(yc + v * V, p);
+      for (int j = 0; j < V; ++j) {
+        pos[j] = (k1[j] < p.v[j]) ? 1 : 0;
+        if (NSTEP >= 2) { const T kk = pos[j] ? k2b[j] : k2a[j]; search_step(pos[j], kk, p.v[j]); }
       }
+#pragma unroll
+      for (int lvl = 3; lvl <= NSTEP; ++lvl) {
+        T kv[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) kv[j] = *reinterpret_cast<const T*>(base + ((pos[j] << SH) + lb[lvl - 3][j]));
+#pragma unroll
+        for (int j = 0; j < V; ++j) search_step(pos[j], kv[j], p.v[j]);
+      }
+      Rec4<T> A[V], B[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        A[j] = lds_rec<T>(reinterpret_cast<const T*>(base + ((pos[j] << (SH + 2)) + ra[j])));
+        B[j] = lds_rec<T>(reinterpret_cast<const T*>(base + ((pos[j] << (SH + 2)) + rb[j])));
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) l += rqs_eval<T, INV>(A[j], B[j], lim[j], p.v[j]);
+      store_pack<T, V, true>(y + col * dim + (int64_t)gl * V, p);
     }
     l = group_sum_rt(l, G);
     if (col < batch && gl == 0) {
       if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + l : l;
       acc += (double)l;
     }
+  }
+}
+
+template <class T, int V, int NSTEP_HI, bool DUAL, bool INV>
+__global__ __launch_bounds__(256) void rqs_lds_kernel(const T* __restrict__ blob, const int* __restrict__ flag, int K1,
+                                                      const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t dim,
+                                                      int64_t batch, int G, int iters, int accumulate, double* partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[4];
+  T* blob_l = reinterpret_cast<T*>(smem);
+  const int skip0 = DUAL ? flag[0] : 0;
+  const RqsGeom g = rqs_geom(K1, dim, V, skip0, NSTEP_HI);
+  {
+    const int n16 = (int)(rqs_blob_words(g) * sizeof(T) / 16);
+    const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(blob);
+    bjx_f32x4* dst = reinterpret_cast<bjx_f32x4*>(blob_l);
+    for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+    __syncthreads();
+  }
+  double acc = 0.0;
+  if constexpr (DUAL) {
+    if (skip0) rqs_body<T, V, NSTEP_HI - 1, INV>(blob_l, g, x, y, ladj_ps, dim, batch, G, iters, accumulate, acc);
+    else rqs_body<T, V, NSTEP_HI, INV>(blob_l, g, x, y, ladj_ps, dim, batch, G, iters, accumulate, acc);
+  } else {
+    rqs_body<T, V, NSTEP_HI, INV>(blob_l, g, x, y, ladj_ps, dim, batch, G, iters, accumulate, acc);
   }
   if (partials) block_publish_partial(acc, red, partials);
 }
@@ -382,57 +506,79 @@ template <class T> struct PermuteF {
 
 template <class T> bool knots_fit_lds(int64_t rows, int K1) { return (size_t)rows * K1 * 3 * sizeof(T) <= 60 * 1024; }
 
+inline int ceil_log2(int n) { int s = 0; while ((1 << s) < n) ++s; return s; }
+
+template <class T, int V, bool INV>
+int rqs_launch_lds(bjx_ctx* ctx, int nstep_hi, int dual, const T* blob, const int* flag, int K1, size_t smem, int64_t grid, const T* in,
+                   T* out, T* ladj_ps, int64_t dim, int64_t batch, int G, int iters, int accum, double* partials) {
+#define RQS_L(NS_, DUAL_) hipLaunchKernelGGL((rqs_lds_kernel<T, V, NS_, DUAL_, INV>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, blob, flag, K1, in, out, ladj_ps, dim, batch, G, iters, accum, partials)
+  switch (nstep_hi * 2 + (dual ? 1 : 0)) {
+    case 2: RQS_L(1, false); break;
+    case 4: RQS_L(2, false); break;  case 5: RQS_L(2, true); break;
+    case 6: RQS_L(3, false); break;  case 7: RQS_L(3, true); break;
+    case 8: RQS_L(4, false); break;  case 9: RQS_L(4, true); break;
+    case 10: RQS_L(5, false); break; case 11: RQS_L(5, true); break;
+    case 12: RQS_L(6, false); break; case 13: RQS_L(6, true); break;
+    default: return bjx_fail(ctx, BJX_ERR_UNSUPPORTED, "bjx_rqs: unsupported search depth %d", nstep_hi);
+  }
+#undef RQS_L
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+
 template <class T>
 int rqs_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int K1, const T* in, T* out, T* ladj_ps,
              double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
-  const size_t nrec = (size_t)dim * K1;
-  const size_t tab_bytes = nrec * (sizeof(RqsRec<T>) + 2 * sizeof(T));
-  if (tab_bytes + 64 > BJX_SCRATCH_BYTES) {   // huge knot tables: generic functor path, tables from global memory
+  if (dim * batch == 0) {
+    if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
+    return BJX_OK;
+  }
+  ColLaunch c = col_launch_cfg<T>(ctx, in, out, dim, batch);
+  const int nstep_hi = ceil_log2(K1 < 2 ? 2 : K1);
+  const int dual = (K1 >= 3 && ceil_log2(K1 - 1) < nstep_hi) ? 1 : 0;
+  const RqsGeom g_hi = rqs_geom(K1, dim, c.V, 0, nstep_hi);
+  const size_t blob_bytes = rqs_blob_words(g_hi) * sizeof(T);      // the no-skip layout is the larger one
+  const bool lds_path = nstep_hi <= 6 && dim / c.V <= 64 && dim < (1 << 20) && blob_bytes <= 64 * 1024 && blob_bytes + 64 <= BJX_SCRATCH_BYTES;
+  if (!lds_path) {   // huge knot tables / very wide columns: generic functor path
     const bool lds = knots_fit_lds<T>(dim, K1);
     const size_t fsm = lds ? (size_t)dim * K1 * 3 * sizeof(T) : 0;
     if (!inverse) { RqsF<T, false> f{w, h, d, K1, dim, lds ? 1 : 0, 0.0, nullptr}; return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0); }
     RqsF<T, true> f{w, h, d, K1, dim, lds ? 1 : 0, 0.0, nullptr};
     return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0);
   }
-  if (dim * batch == 0) {
-    if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
-    return BJX_OK;
+  int* flag = reinterpret_cast<int*>(ctx->scratch);
+  T* blob = reinterpret_cast<T*>(static_cast<char*>(ctx->scratch) + 64);
+  if (dual) {
+    hipLaunchKernelGGL(rqs_flag_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, w, h, K1, dim, flag);
+    BJX_CHECK_LAUNCH(ctx);
   }
-  RqsRec<T>* rec = static_cast<RqsRec<T>*>(ctx->scratch);
-  T* keyW = reinterpret_cast<T*>(rec + nrec);
-  T* keyH = keyW + nrec;
-  int pg = (int)((nrec + 255) / 256);
-  if (pg > 256) pg = 256;
-  hipLaunchKernelGGL(rqs_prep_kernel<T>, dim3(pg), dim3(256), 0, ctx->stream, w, h, d, K1, dim, keyW, keyH, rec);
-  BJX_CHECK_LAUNCH(ctx);
-  ColLaunch c = col_launch_cfg<T>(ctx, in, out, dim, batch);
-  const size_t lds_bytes = nrec * (sizeof(RqsRec<T>) + sizeof(T));
-  const int in_lds = lds_bytes <= 60 * 1024 ? 1 : 0;
+  {
+    const int64_t total = (int64_t)g_hi.dimp * (1 << nstep_hi);
+    int pg = (int)((total + 255) / 256);
+    if (pg > 256) pg = 256;
+    if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(pg), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, flag, blob);
+    else hipLaunchKernelGGL((rqs_blob_kernel<T, false>), dim3(pg), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, flag, blob);
+    BJX_CHECK_LAUNCH(ctx);
+  }
   const int cols_per_block = 256 / c.G;
-  // amortise the table staging: each block walks `iters` column groups (>= ~64 KiB of data)
-  int iters = 1;
-  if (in_lds) {
-    const int64_t bytes_per_group = (int64_t)cols_per_block * dim * sizeof(T);
-    iters = (int)((4 * (int64_t)lds_bytes + bytes_per_group - 1) / bytes_per_group);
-    if (iters < 1) iters = 1;
-    if (iters > 64) iters = 64;
-  }
+  // amortise the table staging: each block walks `iters` column groups (>= ~4x the table bytes of data)
+  const int64_t bytes_per_group = (int64_t)cols_per_block * dim * sizeof(T);
+  int iters = (int)((4 * (int64_t)blob_bytes + bytes_per_group - 1) / bytes_per_group);
+  if (iters < 1) iters = 1;
+  if (iters > 64) iters = 64;
   const int64_t groups = (batch + cols_per_block - 1) / cols_per_block;
   const int64_t grid = (groups + iters - 1) / iters;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_rqs: batch too large for one launch");
   if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
   double* partials = ladj_sum ? ctx->partials : nullptr;
-  int top = 1;
-  while (top * 2 <= K1) top *= 2;
-  const T* keys = inverse ? keyH : keyW;
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
-  const size_t smem = in_lds ? lds_bytes : 0;
   constexpr int VW = Vec16<T>::N;
-#define LAUNCH_RQS(V_, INV_) hipLaunchKernelGGL((rqs_table_kernel<T, V_, INV_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, keys, rec, K1, top, in_lds, in, out, ladj_ps, dim, batch, c.G, iters, accum, partials)
-  if (c.V == VW) { if (inverse) LAUNCH_RQS(VW, true); else LAUNCH_RQS(VW, false); }
-  else { if (inverse) LAUNCH_RQS(1, true); else LAUNCH_RQS(1, false); }
-#undef LAUNCH_RQS
-  BJX_CHECK_LAUNCH(ctx);
+  int rc;
+  if (c.V == VW) rc = inverse ? rqs_launch_lds<T, VW, true>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, partials)
+                              : rqs_launch_lds<T, VW, false>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, partials);
+  else rc = inverse ? rqs_launch_lds<T, 1, true>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, partials)
+                    : rqs_launch_lds<T, 1, false>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, partials);
+  if (rc) return rc;
   if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
   return BJX_OK;
 }

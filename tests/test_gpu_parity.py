@@ -347,7 +347,8 @@ def test_batchnorm_eval(bj, orc, dim, N, dt):
 
 # ------------------------------------------------------------------ F4 RQS
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("dim,K,N", [(32, 16, 500), (3, 8, 50), (1, 4, 10), (130, 5, 20)])
+@pytest.mark.parametrize("dim,K,N", [(32, 16, 500), (3, 8, 50), (1, 4, 10), (130, 5, 20), (64, 16, 300), (32, 7, 200), (256, 4, 70),
+                                     (40, 32, 100), (8, 1, 33), (12, 2, 40), (300, 3, 9)])
 def test_rqs(bj, orc, dim, K, N, dt):
     r = rng(12)
     raw = [r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K - 1)).astype(dt)]
@@ -372,6 +373,26 @@ def test_rqs(bj, orc, dim, K, N, dt):
     close(host(lb), lb_ref, dt, scale=dim * 10, what="rqs inv ladj")
     outside = np.abs(X) >= B
     assert np.array_equal(host(Y)[outside], X[outside])      # identity outside [-B, B] (rqs.jl:132)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_rqs_general_knots_without_the_mirrored_first_knot(bj, orc, dt):
+    """3-argument constructor (rational_quadratic_spline.jl:76-96) with knot 1 > -knot K: bin 0
+    ([-w_K, w_1], left derivative 1, :140-156) is a real bin, so the device may not drop it."""
+    r = rng(31)
+    dim, K, N = 32, 16, 400
+    w, h, d = orc.rqs_params(r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K - 1)).astype(dt), 3.0)
+    w, h, d = np.ascontiguousarray(w[:, 1:]), np.ascontiguousarray(h[:, 1:]), np.ascontiguousarray(d[:, 1:])   # 16 knots, first != -last
+    b = bj.RationalQuadraticSpline(dev(w), dev(h), dev(d))
+    X = np.asfortranarray((r.normal(size=(dim, N)) * 1.6).astype(dt))
+    Y_ref, l_ref = orc.rqs(w, h, d, X)
+    Y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+    close(host(Y), Y_ref, dt, what="rqs general fwd")
+    close(host(l), l_ref, dt, scale=dim, what="rqs general ladj")
+    Xb_ref, lb_ref = orc.rqs(w, h, d, Y_ref, inverse=True)
+    Xb, lb = bj.with_logabsdet_jacobian(bj.inverse(b), dev(Y_ref), per_sample=True)
+    close(host(Xb), Xb_ref, dt, scale=10, what="rqs general inv")
+    close(host(lb), lb_ref, dt, scale=dim * 10, what="rqs general inv ladj")
 
 
 # ------------------------------------------------------------------ F5 Permute / Coupling
