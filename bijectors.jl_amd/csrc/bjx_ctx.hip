@@ -1,6 +1,8 @@
 // bjx_ctx.hip — context, deterministic log-det reduction, timing and synthetic-data helpers.
 #include <dlfcn.h>
 
+#include <cstdlib>
+
 #include <new>
 
 #include "bjx_internal.h"
@@ -69,6 +71,27 @@ int bjx_launch_finalize(bjx_ctx* ctx, int n_partials, double* ladj_sum, double h
   return BJX_OK;
 }
 
+int bjx_make_fin(bjx_ctx* ctx, int64_t grid, double* ladj_sum, double host_const, int use_dev_const, uint32_t flags,
+                 BjxFin* fin, bool* second_pass) {
+  *fin = BjxFin{};
+  *second_pass = false;
+  if (!ladj_sum) return BJX_OK;
+  int rc = bjx_ensure_partials(ctx, (size_t)grid);
+  if (rc) return rc;
+  fin->partials = ctx->partials;
+  static const int inkernel = getenv("BJX_INKERNEL_FIN") ? atoi(getenv("BJX_INKERNEL_FIN")) : 1;
+  if (inkernel && grid <= BJX_INKERNEL_FIN_MAX) {
+    fin->counter = ctx->fin_counter;
+    fin->out = ladj_sum;
+    fin->host_const = host_const;
+    fin->dev_const = use_dev_const ? ctx->consts + 1 : nullptr;
+    fin->accumulate = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  } else {
+    *second_pass = true;
+  }
+  return BJX_OK;
+}
+
 // ------------------------------------------------------------------ context
 BJX_API int bjx_version(void) { return BJX_VERSION; }
 
@@ -84,6 +107,8 @@ BJX_API int bjx_create(int device, void* hip_stream, bjx_ctx** out) {
   if (e == hipSuccess) ctx->partials_cap = BJX_MAX_BLOCKS;
   if (e == hipSuccess) e = hipMalloc(&ctx->partials2, sizeof(double) * BJX_MAX_BLOCKS);
   if (e == hipSuccess) e = hipMalloc(&ctx->consts, sizeof(double) * BJX_CONSTS);
+  if (e == hipSuccess) e = hipMalloc(&ctx->fin_counter, 64);
+  if (e == hipSuccess) e = hipMemset(ctx->fin_counter, 0, 64);
   if (e == hipSuccess) e = hipMalloc(&ctx->scratch, BJX_SCRATCH_BYTES);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
@@ -107,6 +132,7 @@ BJX_API int bjx_destroy(bjx_ctx* ctx) {
   if (ctx->partials) (void)hipFree(ctx->partials);
   if (ctx->partials2) (void)hipFree(ctx->partials2);
   if (ctx->consts) (void)hipFree(ctx->consts);
+  if (ctx->fin_counter) (void)hipFree(ctx->fin_counter);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

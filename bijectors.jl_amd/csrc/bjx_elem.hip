@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void rqs_params_kernel(const T* rw, const T* r
 //   [0, dimp)                         lim[rp]          = knot K (range limit) of permuted row rp
 //   [dimp·2^(l-1), dimp·2^l)          level l keys     [rp][2^(l-1)],  l = 1..NSTEP
 //   [dimp·2^NSTEP, +4·dimp·RS)        record half A    [rp][RS] x 4    {w_k, 1/w, h_k, Δy}  (inverse: {h_k, Δy, w_k, w})
-//   [.. , +4·dimp·RS)                 record half B    [rp][RS] x 4    {s, d_k, d_k+1, d_k+1 + d_k - 2s}
+//   [.. , +4·dimp·RS)                 record half B    [rp][RS] x 4    {s, d_k, d_k+1 + d_k - 2s, d_k+1 - d_k}
 // rp = j·nvc + v for row v·V + j (V = pack width, nvc = packs per column); RS = nslots + 1 (skew).
 struct RqsGeom {
   int K1;       // knots per row
@@ -172,28 +172,28 @@ __host__ __device__ inline RqsGeom rqs_geom(int K1, int64_t dim, int V, int skip
 }
 __host__ __device__ inline size_t rqs_blob_words(const RqsGeom& g) { return (size_t)g.dimp * (1u << g.nstep) + 8 * (size_t)g.dimp * g.RS; }
 
-// flag[0] = 1 iff knot 1 <= -knot K for widths and heights of every row (bin 0 unreachable)
-template <class T>
-__global__ __launch_bounds__(256) void rqs_flag_kernel(const T* w, const T* h, int K1, int64_t rows, int* flag) {
+// One block: (i) flag[0] = 1 iff knot 1 <= -knot K for widths and heights of every row (bin 0
+// unreachable, only evaluated when `dual`), (ii) the LDS blob in the layout above.
+template <class T, bool INV>
+__global__ __launch_bounds__(256) void rqs_blob_kernel(const T* w, const T* h, const T* d, int K1, int64_t rows, int V, int nstep_hi,
+                                                       int dual, int* flag, T* blob) {
   __shared__ int bad;
   if (threadIdx.x == 0) bad = 0;
   __syncthreads();
-  for (int64_t r = threadIdx.x; r < rows; r += blockDim.x)
-    if (!(w[r] <= -w[(int64_t)(K1 - 1) * rows + r]) || !(h[r] <= -h[(int64_t)(K1 - 1) * rows + r])) bad = 1;
+  if (dual) {
+    for (int64_t r = threadIdx.x; r < rows; r += blockDim.x)
+      if (!(w[r] <= -w[(int64_t)(K1 - 1) * rows + r]) || !(h[r] <= -h[(int64_t)(K1 - 1) * rows + r])) bad = 1;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) flag[0] = bad ? 0 : 1;
-}
-
-template <class T, bool INV>
-__global__ __launch_bounds__(256) void rqs_blob_kernel(const T* w, const T* h, const T* d, int K1, int64_t rows, int V, int nstep_hi,
-                                                       int dual, const int* flag, T* blob) {
-  const RqsGeom g = rqs_geom(K1, rows, V, dual ? flag[0] : 0, nstep_hi);
+  const int skip0 = (dual && !bad) ? 1 : 0;
+  if (threadIdx.x == 0) flag[0] = skip0;
+  const RqsGeom g = rqs_geom(K1, rows, V, skip0, nstep_hi);
   const int nkeys = (1 << g.nstep) - 1;
   const int per_row = nkeys > g.nslots ? nkeys : g.nslots;
   const int64_t total = (int64_t)g.dimp * per_row;
   T* recA = blob + (size_t)g.dimp * (1u << g.nstep);
   T* recB = recA + 4 * (size_t)g.dimp * g.RS;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
     const int rp = (int)(i / per_row), s = (int)(i % per_row);
     const int64_t r = (int64_t)(rp % g.nvc) * g.V + rp / g.nvc;   // actual row
     const bool live = rp < g.V * g.nvc && r < rows;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void rqs_blob_kernel(const T* w, const T* h, c
       blob[(size_t)g.dimp * (1u << (lvl - 1)) + (size_t)rp * (1u << (lvl - 1)) + path] = kv;
     }
     if (s < g.nslots) {
-      T a[4] = {T(0), T(1), T(0), T(0)}, b[4] = {T(1), T(1), T(1), T(0)};
+      T a[4] = {T(0), T(1), T(0), T(0)}, b[4] = {T(1), T(1), T(0), T(0)};
       if (live) {
         const int k = s + g.kbase;                                   // bin k spans knots k..k+1 (knot 0 = -knot K)
         const T w_k = (k == 0) ? -W(K1) : W(k);                      // :140,:192
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void rqs_blob_kernel(const T* w, const T* h, c
         const T d_k1 = (k == K1 - 1) ? T(1) : D(k + 1);
         if (!INV) { a[0] = w_k; a[1] = T(1) / wd; a[2] = h_k; a[3] = dy; }
         else { a[0] = h_k; a[1] = dy; a[2] = w_k; a[3] = wd; }
-        b[0] = sl; b[1] = d_k; b[2] = d_k1; b[3] = d_k1 + d_k - 2 * sl;
+        b[0] = sl; b[1] = d_k; b[2] = d_k1 + d_k - 2 * sl; b[3] = d_k1 - d_k;
       }
       T* pa = recA + 4 * ((size_t)rp * g.RS + s);
       T* pb = recB + 4 * ((size_t)rp * g.RS + s);
@@ -245,13 +245,19 @@ template <class T> __device__ __forceinline__ Rec4<T> lds_rec(const T* p) {
   return r;
 }
 
-// value + log-det of one element given its bin records; x is replaced by the result.
+// value + log2-det of one element given its bin records; x is replaced by the result.
 // Forward: rational_quadratic_spline.jl:317-357.  Inverse: :183-220 + the forward log-det at the
-// recovered ξ, negated (interface.jl:276-281).
+// recovered ξ, negated (interface.jl:276-281).  With p = ξ(1-ξ) (one fma: ξ - ξ²), ξ² = ξ - p and
+// (1-ξ)² = (1-ξ) - p, the reference's three quadratics are LINEAR in (ξ, p):
+//   denominator      s + (d_{k+1} + d_k - 2s) ξ(1-ξ)                       = s + ds·p
+//   numerator of y   s ξ² + d_k ξ(1-ξ)                                     = ξ (d_k + (s - d_k) ξ)
+//   numerator of J   d_{k+1} ξ² + 2s ξ(1-ξ) + d_k (1-ξ)²                   = d_k + (d_{k+1} - d_k) ξ - ds·p
+// (the last is a convex interpolation minus a term of at most the same size: cancellation <= ~2x).
+// Returns log2|J| (the caller multiplies the per-column sum by ln 2 once).
 template <class T, bool INV>
 __device__ __forceinline__ T rqs_eval(const Rec4<T>& A, const Rec4<T>& B, T lim, T& x) {
   using F = Fast<T>;
-  const T s = B.v[0], d_k = B.v[1], d_k1 = B.v[2], ds = B.v[3];
+  const T s = B.v[0], d_k = B.v[1], ds = B.v[2], dd = B.v[3];
   const T xin = x;
   T xi, res;
   if (!INV) {
@@ -261,18 +267,16 @@ __device__ __forceinline__ T rqs_eval(const Rec4<T>& A, const Rec4<T>& B, T lim,
     const T t = yh * ds;
     const T a1 = A.v[1] * (s - d_k) + t;                                    // Eq. (25)
     const T a2 = A.v[1] * d_k - t;                                          // Eq. (26)
-    const T a3 = -s * yh;                                                   // Eq. (27)
-    xi = F::div(-2 * a3, a2 + F::sqrt(a2 * a2 - 4 * a1 * a3));              // Eq. (24)
+    const T q = s * yh;                                                     // -a3, Eq. (27)
+    xi = F::div(q + q, a2 + F::sqrt(a2 * a2 + 4 * (a1 * q)));               // Eq. (24)
   }
-  const T om = T(1) - xi;
-  const T xo = xi * om;
-  const T xi2 = xi * xi;
-  const T den = s + ds * xo;
+  const T p = xi - xi * xi;                                                 // contracts to fma(-ξ, ξ, ξ)
+  const T den = s + ds * p;
   const T rden = F::rcp(den);
-  const T nj = d_k1 * xi2 + (2 * s) * xo + d_k * (om * om);
+  const T nj = (d_k + dd * xi) - ds * p;
   const T sr = s * rden;
-  T lj = F::log(nj * (sr * sr));                                            // log(s²·nj) - 2 log(den)
-  if (!INV) res = A.v[2] + A.v[3] * (s * xi2 + d_k * xo) * rden;
+  T lj = F::log2(nj * (sr * sr));                                           // log(s²·nj) - 2 log(den)
+  if (!INV) res = A.v[2] + (A.v[3] * (xi * (d_k + (s - d_k) * xi))) * rden;
   else { res = xi * A.v[3] + A.v[2]; lj = -lj; }
   // identity outside [-B, B] (:132, :186): (x <= -lim || x >= lim) == !(|x| < lim), NaN included
   const bool inside = d_abs(xin) < lim;
@@ -313,6 +317,8 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
     for (int lvl = 3; lvl <= NSTEP; ++lvl) lb[lvl - 3][j] = (int)sizeof(T) * ((g.dimp + rp) << (lvl - 1));
     ra[j] = (int)sizeof(T) * ((g.dimp << NSTEP) + 4 * rp * g.RS);
     rb[j] = ra[j] + (int)sizeof(T) * 4 * g.dimp * g.RS;
+    // opaque to the optimiser: otherwise the constants are re-read from LDS inside the column loop
+    asm volatile("" : "+v"(lim[j]), "+v"(k1[j]), "+v"(k2a[j]), "+v"(k2b[j]));
   }
   constexpr int SH = sizeof(T) == 4 ? 2 : 3;
   for (int it = 0; it < iters; ++it) {
@@ -344,7 +350,7 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
       for (int j = 0; j < V; ++j) l += rqs_eval<T, INV>(A[j], B[j], lim[j], p.v[j]);
       store_pack<T, V, true>(y + col * dim + (int64_t)gl * V, p);
     }
-    l = group_sum_rt(l, G);
+    l = group_sum_rt(l, G) * Num<T>::log2;          // log2 -> natural log, once per column
     if (col < batch && gl == 0) {
       if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + l : l;
       acc += (double)l;
@@ -355,7 +361,7 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
 template <class T, int V, int NSTEP_HI, bool DUAL, bool INV>
 __global__ __launch_bounds__(256) void rqs_lds_kernel(const T* __restrict__ blob, const int* __restrict__ flag, int K1,
                                                       const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t dim,
-                                                      int64_t batch, int G, int iters, int accumulate, double* partials) {
+                                                      int64_t batch, int G, int iters, int accumulate, const BjxFin fin) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double red[4];
   T* blob_l = reinterpret_cast<T*>(smem);
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(256) void rqs_lds_kernel(const T* __restrict__ blob
   } else {
     rqs_body<T, V, NSTEP_HI, INV>(blob_l, g, x, y, ladj_ps, dim, batch, G, iters, accumulate, acc);
   }
-  if (partials) block_publish_partial(acc, red, partials);
+  block_publish_partial(acc, red, fin);
 }
 
 // ------------------------------------------------------------------ BatchNorm (eval)
@@ -510,8 +516,8 @@ inline int ceil_log2(int n) { int s = 0; while ((1 << s) < n) ++s; return s; }
 
 template <class T, int V, bool INV>
 int rqs_launch_lds(bjx_ctx* ctx, int nstep_hi, int dual, const T* blob, const int* flag, int K1, size_t smem, int64_t grid, const T* in,
-                   T* out, T* ladj_ps, int64_t dim, int64_t batch, int G, int iters, int accum, double* partials) {
-#define RQS_L(NS_, DUAL_) hipLaunchKernelGGL((rqs_lds_kernel<T, V, NS_, DUAL_, INV>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, blob, flag, K1, in, out, ladj_ps, dim, batch, G, iters, accum, partials)
+                   T* out, T* ladj_ps, int64_t dim, int64_t batch, int G, int iters, int accum, const BjxFin& fin) {
+#define RQS_L(NS_, DUAL_) hipLaunchKernelGGL((rqs_lds_kernel<T, V, NS_, DUAL_, INV>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, blob, flag, K1, in, out, ladj_ps, dim, batch, G, iters, accum, fin)
   switch (nstep_hi * 2 + (dual ? 1 : 0)) {
     case 2: RQS_L(1, false); break;
     case 4: RQS_L(2, false); break;  case 5: RQS_L(2, true); break;
@@ -548,18 +554,9 @@ int rqs_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int 
   }
   int* flag = reinterpret_cast<int*>(ctx->scratch);
   T* blob = reinterpret_cast<T*>(static_cast<char*>(ctx->scratch) + 64);
-  if (dual) {
-    hipLaunchKernelGGL(rqs_flag_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, w, h, K1, dim, flag);
-    BJX_CHECK_LAUNCH(ctx);
-  }
-  {
-    const int64_t total = (int64_t)g_hi.dimp * (1 << nstep_hi);
-    int pg = (int)((total + 255) / 256);
-    if (pg > 256) pg = 256;
-    if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(pg), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, flag, blob);
-    else hipLaunchKernelGGL((rqs_blob_kernel<T, false>), dim3(pg), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, flag, blob);
-    BJX_CHECK_LAUNCH(ctx);
-  }
+  if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, flag, blob);
+  else hipLaunchKernelGGL((rqs_blob_kernel<T, false>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, flag, blob);
+  BJX_CHECK_LAUNCH(ctx);
   const int cols_per_block = 256 / c.G;
   // amortise the table staging: each block walks `iters` column groups (>= ~4x the table bytes of data)
   const int64_t bytes_per_group = (int64_t)cols_per_block * dim * sizeof(T);
@@ -569,17 +566,18 @@ int rqs_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int 
   const int64_t groups = (batch + cols_per_block - 1) / cols_per_block;
   const int64_t grid = (groups + iters - 1) / iters;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_rqs: batch too large for one launch");
-  if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
-  double* partials = ladj_sum ? ctx->partials : nullptr;
+  BjxFin fin;
+  bool second = false;
+  { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
   constexpr int VW = Vec16<T>::N;
   int rc;
-  if (c.V == VW) rc = inverse ? rqs_launch_lds<T, VW, true>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, partials)
-                              : rqs_launch_lds<T, VW, false>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, partials);
-  else rc = inverse ? rqs_launch_lds<T, 1, true>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, partials)
-                    : rqs_launch_lds<T, 1, false>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, partials);
+  if (c.V == VW) rc = inverse ? rqs_launch_lds<T, VW, true>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, fin)
+                              : rqs_launch_lds<T, VW, false>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, fin);
+  else rc = inverse ? rqs_launch_lds<T, 1, true>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, fin)
+                    : rqs_launch_lds<T, 1, false>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, fin);
   if (rc) return rc;
-  if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+  if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
   return BJX_OK;
 }
 

@@ -394,7 +394,7 @@ __device__ __forceinline__ void planar_act(float arg, float c, float& th, float&
 template <int G, int NL, bool INV>
 __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, const float* __restrict__ x, float* __restrict__ y,
                                                          float* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate,
-                                                         double* partials) {
+                                                         const BjxFin fin) {
   constexpr int CPS = 64 / G;                       // columns per wave instruction
   constexpr int NS = G;                             // pack steps for 64 columns
   constexpr bool SWAP = (G == 32) && (NL >= 2);     // fold lane i+16 onto i with a transposed halving
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
   }
   const bool ok = lane < nvalid;
   if (ok && ladj_ps) ladj_ps[col0 + lane] = accumulate ? ladj_ps[col0 + lane] + ladj : ladj;
-  if (partials) block_publish_partial(ok ? (double)ladj : 0.0, red, partials);
+  block_publish_partial(ok ? (double)ladj : 0.0, red, fin);
 }
 
 // zero-padded parameter tables for the register kernel: w, û -> [nl_pad][dim]; b, wᵀû -> [nl_pad];
@@ -701,12 +701,13 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         BJX_CHECK_LAUNCH(ctx);
         const int64_t grid = (batch + 255) / 256;
         BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar: batch too large for one launch");
-        if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
-        double* partials = ladj_sum ? ctx->partials : nullptr;
+        BjxFin fin;
+        bool second = false;
+        { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
         PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad};
         const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
         const int G = dim > 64 ? 32 : (dim > 32 ? 16 : 8);
-#define LAUNCH_REG(G_, NL_, INV_) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, partials)
+#define LAUNCH_REG(G_, NL_, INV_) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
 #define LAUNCH_REG_NL(G_, INV_) switch (NL) { case 1: LAUNCH_REG(G_, 1, INV_); break; case 2: LAUNCH_REG(G_, 2, INV_); break; case 4: LAUNCH_REG(G_, 4, INV_); break; default: LAUNCH_REG(G_, 8, INV_); break; }
 #define LAUNCH_REG_G(INV_) switch (G) { case 8: LAUNCH_REG_NL(8, INV_) break; case 16: LAUNCH_REG_NL(16, INV_) break; default: LAUNCH_REG_NL(32, INV_) break; }
         if (inverse) { LAUNCH_REG_G(true) } else { LAUNCH_REG_G(false) }
@@ -714,7 +715,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
 #undef LAUNCH_REG_NL
 #undef LAUNCH_REG
         BJX_CHECK_LAUNCH(ctx);
-        if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+        if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
         return BJX_OK;
       }
     }

@@ -24,6 +24,7 @@ struct bjx_ctx {
   double* partials = nullptr;   // [partials_cap] one f64 per publishing block (grown on demand, cached)
   size_t partials_cap = 0;
   double* partials2 = nullptr;  // [BJX_MAX_BLOCKS] second reduction stage
+  unsigned* fin_counter = nullptr;  // arrival counter of the in-kernel finalize (zero between launches)
   double* consts = nullptr;     // [BJX_CONSTS]
   void* scratch = nullptr;      // [BJX_SCRATCH_BYTES]
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -58,6 +59,22 @@ inline int bjx_fail(bjx_ctx* ctx, int code, const char* fmt, ...) {
   do {                                                       \
     if (!(cond)) return bjx_fail((ctx), (code), __VA_ARGS__); \
   } while (0)
+
+// Σ log|det J| epilogue descriptor, passed BY VALUE to the hot kernels.  With `counter` set the
+// last block to arrive reduces all partials in the fixed order of bjx_finalize_kernel inside the same
+// launch (no extra dispatch, ~5 us each on MI355X); otherwise the host launches the two-pass finalize.
+struct BjxFin {
+  double* partials = nullptr;       // null: no sum requested
+  unsigned* counter = nullptr;      // null: host-launched finalize
+  double* out = nullptr;
+  double host_const = 0.0;
+  const double* dev_const = nullptr;
+  int accumulate = 0;
+};
+constexpr int BJX_INKERNEL_FIN_MAX = 32768;   // partials one block may reduce in-kernel
+// host side: builds the descriptor for a launch of `grid` blocks; *second_pass = launch bjx_launch_finalize afterwards
+int bjx_make_fin(bjx_ctx* ctx, int64_t grid, double* ladj_sum, double host_const, int use_dev_const, uint32_t flags,
+                 BjxFin* fin, bool* second_pass);
 
 // host side: make sure ctx->partials can hold n doubles (cached; reallocation synchronises the device)
 int bjx_ensure_partials(bjx_ctx* ctx, size_t n);
@@ -135,6 +152,7 @@ template <class T> __device__ __forceinline__ T d_logcosh(T x) {
 template <class T> struct Fast;
 template <> struct Fast<float> {
   static __device__ __forceinline__ float log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+  static __device__ __forceinline__ float log2(float x) { return __builtin_amdgcn_logf(x); }
   static __device__ __forceinline__ float exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
   static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
   static __device__ __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
@@ -148,6 +166,7 @@ template <> struct Fast<float> {
 };
 template <> struct Fast<double> {
   static __device__ __forceinline__ double log(double x) { return ::log(x); }
+  static __device__ __forceinline__ double log2(double x) { return ::log2(x); }
   static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
   static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
   static __device__ __forceinline__ double div(double a, double b) { return a / b; }
@@ -181,6 +200,52 @@ __device__ __forceinline__ void block_publish_partial(double acc, double* red, d
     double s = 0.0;
     for (int w = 0; w < nw; ++w) s += red[w];
     partials[blockIdx.x] = s;
+  }
+}
+
+// Same block sum; when f.counter is set, the LAST block to arrive finishes the global reduction
+// (thread t sums partials t, t+256, ... then the fixed tree of bjx_finalize_kernel -> the result is
+// independent of the arrival order).  Hand-off without agent-scope fences (an agent-scope release
+// writes the XCD's dirty L2 lines back on EVERY block: measured +0.4..0.8 ms per launch): the partial
+// is stored and re-loaded with agent-scope (sc1) atomics, which are served at the device-coherent
+// level, the store is waited for (vmcnt) before the arrival counter is bumped, and the last block
+// reads the partials with sc1 loads (MI355X_MICROARCH.md G16: "sc1 stores AND sc1 loads").
+// tests/test_gpu_parity.py::test_inkernel_finalize_is_bit_identical_to_two_pass stresses it.
+__device__ __forceinline__ void block_publish_partial(double acc, double* red, const BjxFin& f) {
+  if (!f.partials) return;
+  if (!f.counter) { block_publish_partial(acc, red, f.partials); return; }
+  __shared__ int is_last;
+  acc = group_sum<64>(acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < nw; ++w) s += red[w];
+    __hip_atomic_store(&f.partials[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // s_waitcnt vmcnt(0): the store is acknowledged
+    const unsigned prev = __hip_atomic_fetch_add(f.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (prev == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  double s = 0.0;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x)
+    s += __hip_atomic_load(&f.partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // blockDim.x == 256 for every kernel that uses the in-kernel finalize (fixed tree of 4 waves)
+  s = group_sum<64>(s);
+  __syncthreads();
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    if (nw == 4) t = (red[0] + red[1]) + (red[2] + red[3]);
+    else for (int w = 0; w < nw; ++w) t += red[w];
+    t += f.host_const;
+    if (f.dev_const) t += *f.dev_const;
+    *f.out = f.accumulate ? (*f.out + t) : t;
+    __hip_atomic_store(f.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -22,7 +22,7 @@ constexpr int STREAM_U = 4;
 //   const double* per_sample_dev       (device constant added likewise, or null)
 template <class T, int V, bool NT, class F>
 __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T* y, T* ladj_ps, int64_t dim,
-                                                       int64_t batch, int G, int accumulate, double* partials) {
+                                                       int64_t batch, int G, int accumulate, const BjxFin fin) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* red = reinterpret_cast<double*>(smem);   // first 32 bytes
   char* fsm = smem + 32;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
     }
     acc = (double)l;
   }
-  if (partials) block_publish_partial(acc, red, partials);
+  block_publish_partial(acc, red, fin);
 }
 
 struct ColLaunch {
@@ -99,14 +99,15 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
   const size_t smem = 32 + f_smem;
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
   BJX_REQUIRE(ctx, c.grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
-  if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)c.grid); if (rc) return rc; }
-  double* partials = ladj_sum ? ctx->partials : nullptr;
+  BjxFin fin;
+  bool second = false;
+  { int rc = bjx_make_fin(ctx, c.grid, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, flags, &fin, &second); if (rc) return rc; }
   if (c.V == VW)
-    hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, partials);
+    hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin);
   else
-    hipLaunchKernelGGL((colgroup_kernel<T, 1, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, partials);
+    hipLaunchKernelGGL((colgroup_kernel<T, 1, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin);
   BJX_CHECK_LAUNCH(ctx);
-  if (ladj_sum) return bjx_launch_finalize(ctx, (int)c.grid, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, 0.0, flags);
+  if (second) return bjx_launch_finalize(ctx, (int)c.grid, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, 0.0, flags);
   return BJX_OK;
 }
 

@@ -178,9 +178,12 @@ class _Out:
 
 def _param(p, like: torch.Tensor) -> torch.Tensor:
     """device tensor for a parameter (python number / sequence / tensor)."""
-    if isinstance(p, torch.Tensor):
-        return p.to(device=like.device, dtype=like.dtype).contiguous()
-    return torch.as_tensor(p, dtype=like.dtype, device=like.device).contiguous()
+    if not isinstance(p, torch.Tensor):
+        p = torch.as_tensor(p, dtype=like.dtype, device=like.device)
+    p = p.to(device=like.device, dtype=like.dtype)
+    if p.dim() == 2 and _colmajor_dense(p):
+        return p  # already Julia-layout: no row-major round trip (2 copy kernels per call)
+    return p.contiguous()
 
 
 # ------------------------------------------------------------------ interface (src/interface.jl)

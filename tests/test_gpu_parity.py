@@ -520,3 +520,28 @@ def test_inplace_methods_write_into_the_callers_buffer(bj, orc):
     x_inplace = zd.clone()
     bj.transform_(layer, x_inplace)
     close(host(x_inplace), Y_ref, np.float64)
+
+
+def test_inkernel_finalize_is_bit_identical_to_two_pass(bj):
+    """Σ log|det J| is finished by the last block to arrive inside the hot kernel (no extra launch).
+    The hand-off uses device-coherent (sc1) stores/loads instead of fences; a stale or missing
+    per-block partial would show up as a run-to-run difference when the input alternates, so the
+    float64 sum must be BIT-identical over hundreds of launches for each input."""
+    r = rng(33)
+    d, N = 32, 1 << 17                     # 512 blocks of the planar register kernel
+    layer = bj.PlanarLayer(torch.tensor(r.normal(size=(d, 4)) / 6).float(), torch.tensor(r.normal(size=(d, 4)) / 6).float(),
+                           torch.tensor(r.normal(size=4)).float())
+    xs = [torch.randn((N, d), device="cuda", dtype=torch.float32, generator=torch.Generator("cuda").manual_seed(s)).T for s in (1, 2)]
+    y = torch.empty((N, d), device="cuda", dtype=torch.float32).T
+    first = [None, None]
+    for it in range(400):
+        k = it & 1
+        _, lps, lsum = bj.shard.with_logabsdet_jacobian_sharded(layer, xs[k], out=y)
+        v = lsum.clone()
+        if first[k] is None:
+            first[k] = v
+            # and it equals the float64 sum of the per-sample values up to summation order
+            assert abs(float(v) - float(lps.double().sum())) <= 1e-9 * max(1.0, abs(float(v)))
+        else:
+            assert torch.equal(v, first[k]), f"launch {it}: {float(v)!r} != {float(first[k])!r}"
+    assert not torch.equal(first[0], first[1])
