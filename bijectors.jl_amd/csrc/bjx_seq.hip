@@ -13,6 +13,8 @@
 // VecCholesky: one WAVE per sample walks the packed strict-upper vector 64 entries at a time; the
 // per-column running sums (Σ logcosh for the inverse, Σ w² for the forward link) are segmented
 // wave scans built from one inclusive shuffle scan + one bpermute gather.
+#include <cstdlib>
+
 #include "bjx_internal.h"
 
 namespace {
@@ -20,97 +22,110 @@ using namespace bjx;
 
 template <class T> struct SeqCfg { static constexpr int C = 128 / sizeof(T); static constexpr int NT = 256; };
 
-// ---- per-column walkers.  step(i, have_in, v) is called for i = 0..rows-1 in ascending order and
-// returns the output of row i (ignored when i >= rows_out).
+// ---- per-column walkers.  A column is walked in ascending row order: first(v) for row 0,
+// mid(i, v, log(K-1-i)) for the interior rows, last(v) for the final row when the op has a special
+// one (HAS_LAST).  The split keeps the interior loop free of row-index branches, so four rows are
+// in flight per lane (the only carried dependency is the running sum).  step() is the generic form
+// used by the chunked kernel.
+template <class T, class Op> __device__ __forceinline__ T seq_step(Op& op, int64_t i, int64_t rows, T v, const T* logk) {
+  if (i == 0) return op.first(v, logk);
+  if (Op::HAS_LAST && i == rows - 1) return op.last(v);
+  return op.mid((int)i, v, Op::USES_LOGK ? logk[i] : T(0));
+}
 template <class T> struct OrderedFwd {   // ordered.jl:36-49, :80
+  static constexpr bool HAS_LAST = false, USES_LOGK = false;
   T prev, ladj;
   __device__ void init() { prev = T(0); ladj = T(0); }
-  __device__ T step(int64_t i, T v, const T*) {
-    T o;
-    if (i == 0) o = v; else { o = prev + d_exp(v); ladj += v; }
-    prev = o;
-    return o;
-  }
+  __device__ T first(T v, const T*) { prev = v; return v; }
+  __device__ T mid(int, T v, T) { const T o = prev + d_exp(v); ladj += v; prev = o; return o; }
+  __device__ T last(T v) { return v; }
   __device__ T result() const { return ladj; }
 };
 template <class T> struct OrderedInv {   // ordered.jl:63-77 ; interface.jl:276-281
+  static constexpr bool HAS_LAST = false, USES_LOGK = false;
   T prev, ladj;
   __device__ void init() { prev = T(0); ladj = T(0); }
-  __device__ T step(int64_t i, T v, const T*) {
-    T o;
-    if (i == 0) o = v; else { o = d_log(v - prev); ladj -= o; }
-    prev = v;
-    return o;
-  }
+  __device__ T first(T v, const T*) { prev = v; return v; }
+  __device__ T mid(int, T v, T) { const T o = d_log(v - prev); ladj -= o; prev = v; return o; }
+  __device__ T last(T v) { return v; }
   __device__ T result() const { return ladj; }
 };
-// simplex.jl:47-64 (transform) fused with :122-138 (logabsdetjac); logk[i] = log(T(K-1-i)).
+// simplex.jl:47-64 (transform) fused with :122-138 (logabsdetjac); lk = log(T(K-1-i)).
 // The kernel is VALU-bound with exact OCML logs/divisions (118 VALU per element, PMC in
-// profiles/r01_pmc_notes.md), so Float32 uses the hardware log/rcp units (Fast<T>) and the three
-// logs of one log-det term are merged into the log of their product (>= eps^3, no underflow).
+// profiles/), so Float32 uses the hardware log/rcp units (Fast<T>), logit(z) = log(a/(d-a)) for
+// z = a/d needs one reciprocal instead of two, the three logs of one log-det term are merged into
+// the log of their product (>= eps^3, no underflow) and log2 values are summed (x ln 2 once).
 template <class T, bool LADJ> struct SimplexFwd {
+  static constexpr bool HAS_LAST = true, USES_LOGK = true;
   int64_t K;
-  T sum_tmp, prev_x, lp;
-  __device__ void init() { sum_tmp = T(0); prev_x = T(0); lp = T(0); }
-  __device__ T step(int64_t i, T x, const T* logk) {
+  T sum_tmp, lp;   // lp accumulates log2 terms
+  __device__ void init() { sum_tmp = T(0); lp = T(0); }
+  __device__ T first(T x, const T* logk) {
     using F = Fast<T>;
     const T e = Num<T>::eps;
-    T o = T(0);
-    if (i == 0) {
-      T z = x * (T(1) - 2 * e) + e;                                        // :53
-      o = F::log(z * F::rcp(T(1) - z)) + logk[0];                          // logit(z) + log(K-1)
-      if (LADJ) lp += F::log(d_max(x, e) * d_max(T(1) - x, e));            // :130-131
-    } else if (i < K - 1) {
-      sum_tmp += prev_x;
-      T z = (x + e) * (T(1) - 2 * e) * F::rcp((T(1) + e) - sum_tmp);       // :58
-      o = F::log(z * F::rcp(T(1) - z)) + logk[i];
-      if (LADJ) {
-        T m = d_max(T(1) - sum_tmp, e);
-        T zl = x * F::rcp(m);                                              // :134
-        lp += F::log(d_max(zl, e) * d_max(T(1) - zl, e) * m);              // :135
-      }
+    sum_tmp = x;                                                            // Σ_{j<1} x_j for the next row
+    if (K < 2) return T(0);
+    const T z = x * (T(1) - 2 * e) + e;                                     // :53
+    if (LADJ) lp += F::log2(d_max(x, e) * d_max(T(1) - x, e));              // :130-131
+    return F::log2(z * F::rcp(T(1) - z)) * Num<T>::log2 + logk[0];          // logit(z) + log(K-1)
+  }
+  __device__ T mid(int, T x, T lk) {
+    using F = Fast<T>;
+    const T e = Num<T>::eps;
+    const T s = sum_tmp;
+    sum_tmp = s + x;
+    const T a = (x + e) * (T(1) - 2 * e);                                   // z = a / ((1+ε) - Σ)   (:58)
+    const T dn = (T(1) + e) - s;
+    const T o = F::log2(a * F::rcp(dn - a)) * Num<T>::log2 + lk;            // logit(z) + log(K-1-i)
+    if (LADJ) {
+      const T m = d_max(T(1) - s, e);                                       // :133
+      const T zl = x * F::rcp(m);                                           // :134
+      lp += F::log2(d_max(zl, e) * d_max(T(1) - zl, e) * m);                // :135
     }
-    prev_x = x;
     return o;
   }
-  __device__ T result() const { return -lp; }
+  __device__ T last(T) { return T(0); }                                     // row K has no output
+  __device__ T result() const { return -lp * Num<T>::log2; }
 };
 // simplex.jl:102-120 ; log-det = -logabsdetjac(b, x_out)
 template <class T, bool LADJ> struct SimplexInv {
+  static constexpr bool HAS_LAST = true, USES_LOGK = true;
   int64_t K;
-  T sum_tmp, prev_x, lp;
-  __device__ void init() { sum_tmp = T(0); prev_x = T(0); lp = T(0); }
+  T sum_tmp, lp;
+  __device__ void init() { sum_tmp = T(0); lp = T(0); }
   static __device__ __forceinline__ T logistic(T v) {   // LogExpFunctions.logistic with its exact 0/1 saturation
     using F = Fast<T>;
     const T ex = F::exp(v);
     return v < Num<T>::logistic_lo ? T(0) : (v > Num<T>::logistic_hi ? T(1) : ex * F::rcp(T(1) + ex));
   }
-  __device__ T step(int64_t i, T y, const T* logk) {
+  __device__ T first(T y, const T* logk) {
+    using F = Fast<T>;
+    const T e = Num<T>::eps;
+    if (K < 2) return T(1);
+    const T inv12e = T(1) / (T(1) - 2 * e);
+    const T z = logistic(y - logk[0]);
+    const T x = d_clamp((z - e) * inv12e, T(0), T(1));                      // :109
+    if (LADJ) lp += F::log2(d_max(x, e) * d_max(T(1) - x, e));
+    sum_tmp = x;
+    return x;
+  }
+  __device__ T mid(int, T y, T lk) {
     using F = Fast<T>;
     const T e = Num<T>::eps;
     const T inv12e = T(1) / (T(1) - 2 * e);
-    T x;
-    if (i == 0) {
-      T z = logistic(y - logk[0]);
-      x = d_clamp((z - e) * inv12e, T(0), T(1));                           // :109
-      if (LADJ) lp += F::log(d_max(x, e) * d_max(T(1) - x, e));
-    } else if (i < K - 1) {
-      T z = logistic(y - logk[i]);
-      sum_tmp += prev_x;
-      x = d_clamp(((T(1) + e) - sum_tmp) * inv12e * z - e, T(0), T(1));    // :113
-      if (LADJ) {
-        T m = d_max(T(1) - sum_tmp, e);
-        T zl = x * F::rcp(m);
-        lp += F::log(d_max(zl, e) * d_max(T(1) - zl, e) * m);
-      }
-    } else {
-      sum_tmp += prev_x;
-      x = d_clamp(T(1) - sum_tmp, T(0), T(1));                             // :116
+    const T z = logistic(y - lk);
+    const T s = sum_tmp;
+    const T x = d_clamp(((T(1) + e) - s) * inv12e * z - e, T(0), T(1));     // :113
+    sum_tmp = s + x;
+    if (LADJ) {
+      const T m = d_max(T(1) - s, e);
+      const T zl = x * F::rcp(m);
+      lp += F::log2(d_max(zl, e) * d_max(T(1) - zl, e) * m);
     }
-    prev_x = x;
     return x;
   }
-  __device__ T result() const { return lp; }
+  __device__ T last(T) { return d_clamp(T(1) - sum_tmp, T(0), T(1)); }      // :116
+  __device__ T result() const { return lp * Num<T>::log2; }
 };
 
 template <class T, class Op>
@@ -142,7 +157,7 @@ __global__ __launch_bounds__(256) void seq_kernel(Op op0, const T* in, T* out, T
         T* mine = tile + threadIdx.x * P;
         const int nr = (int)((rows - c0) < C ? (rows - c0) : C);
 #pragma unroll 4
-        for (int i = 0; i < nr; ++i) mine[i] = op.step(c0 + i, mine[i], logk);
+        for (int i = 0; i < nr; ++i) mine[i] = seq_step<T, Op>(op, c0 + i, rows, mine[i], logk);
       }
       __syncthreads();
       if (out && c0 + li < rows_out) {
@@ -159,12 +174,156 @@ __global__ __launch_bounds__(256) void seq_kernel(Op op0, const T* in, T* out, T
   if (partials) block_publish_partial(acc, red, partials);
 }
 
+// Wave-private variant (whole columns in LDS): ONE WAVE owns 64 consecutive columns, i.e. one
+// CONTIGUOUS run of 64*rows elements of the input and of the output.  The run is moved with
+// 16-byte flat accesses (no per-column alignment requirement: K-1 = 63 rows are fine), transposed
+// through a [64][P] LDS tile with odd pitch P (the column walk of lane t reads tile[t*P+i]: 32
+// distinct banks per 32-lane group), walked by one lane per column in ascending row order (the
+// reference's summation order) and written back the same way.  No block barrier anywhere; blocks
+// are single waves, so a CU holds ~9 independent tiles at K = 64 and loads, transcendental math and
+// stores of different waves overlap.  (The chunked block kernel above did 3 barriers per 32 rows
+// with 4-byte global accesses: 32 % of the HBM roofline at C5a.)
+template <class T, class Op, int V>
+__global__ __launch_bounds__(64) void seq_wave_kernel(Op op0, const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps,
+                                                     int rows_in, int rows_out, int P, int64_t batch, int n_logk, int accumulate,
+                                                     const BjxFin fin) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[1];
+  T* tile = reinterpret_cast<T*>(smem);
+  T* logk = tile + (size_t)64 * P;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < n_logk; i += 64) logk[i] = d_log(T(n_logk - i));      // log(K-1-i), simplex.jl:35,41
+  const int64_t col0 = (int64_t)blockIdx.x * 64;
+  const int ncols = (int)((batch - col0) < 64 ? (batch - col0) : 64);
+  // ---- stage in: SU independent 16-byte loads in flight per lane, then the LDS scatter.
+  // A full tile (64 columns) is a whole number of packs (64*rows*sizeof(T) % 16 == 0); the ragged
+  // last wave of the batch takes the element-wise path.
+  if (ncols == 64) {
+    constexpr int SU = 8;
+    const T* src = in + col0 * rows_in;
+    const int ne = 64 * rows_in;
+    const int dc = (64 * V) / rows_in, dr = (64 * V) % rows_in;
+    int e = lane * V, c = e / rows_in, r = e % rows_in;
+    for (; e < ne; e += SU * 64 * V) {
+      Pack<T, V> p[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (e + u * 64 * V < ne) p[u] = load_pack<T, V, true>(src + e + u * 64 * V);
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (e + u * 64 * V < ne) {
+          int cc = c, rr = r;
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            tile[cc * P + rr] = p[u].v[j];
+            if (++rr == rows_in) { rr = 0; ++cc; }
+          }
+        }
+        c += dc; r += dr;
+        if (r >= rows_in) { r -= rows_in; ++c; }
+      }
+    }
+  } else {
+    const T* src = in + col0 * rows_in;
+    const int ne = ncols * rows_in;
+    for (int e = lane; e < ne; e += 64) tile[(e / rows_in) * P + e % rows_in] = src[e];
+  }
+  asm volatile("" ::: "memory");   // single-wave block: the LDS queue is in order, only pin the compiler
+  __builtin_amdgcn_wave_barrier();
+  // ---- walk: lane = column
+  T lres = T(0);
+  if (lane < ncols) {
+    Op op = op0;
+    op.init();
+    T* mine = tile + lane * P;
+    const int rows = rows_in > rows_out ? rows_in : rows_out;
+    const int mid_end = (Op::HAS_LAST && rows > 1) ? rows - 1 : rows;       // interior rows are [1, mid_end)
+    mine[0] = op.first(mine[0], logk);
+    int i = 1;
+    for (; i + 4 <= mid_end; i += 4) {
+      T v[4], lk[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = mine[i + j]; lk[j] = Op::USES_LOGK ? logk[i + j] : T(0); }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = op.mid(i + j, v[j], lk[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mine[i + j] = v[j];
+    }
+    for (; i < mid_end; ++i) mine[i] = op.mid(i, mine[i], Op::USES_LOGK ? logk[i] : T(0));
+    if (Op::HAS_LAST && rows > 1) mine[rows - 1] = op.last(mine[rows - 1]);
+    lres = op.result();
+    if (ladj_ps) ladj_ps[col0 + lane] = accumulate ? ladj_ps[col0 + lane] + lres : lres;
+  }
+  asm volatile("" ::: "memory");   // single-wave block: the LDS queue is in order, only pin the compiler
+  __builtin_amdgcn_wave_barrier();
+  // ---- stage out
+  if (out && ncols == 64) {
+    constexpr int SU = 4;
+    T* dst = out + col0 * rows_out;
+    const int ne = 64 * rows_out;
+    const int dc = (64 * V) / rows_out, dr = (64 * V) % rows_out;
+    int e = lane * V, c = e / rows_out, r = e % rows_out;
+    for (; e < ne; e += SU * 64 * V) {
+      Pack<T, V> p[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        int cc = c, rr = r;
+        if (e + u * 64 * V < ne) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            p[u].v[j] = tile[cc * P + rr];
+            if (++rr == rows_out) { rr = 0; ++cc; }
+          }
+        }
+        c += dc; r += dr;
+        if (r >= rows_out) { r -= rows_out; ++c; }
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (e + u * 64 * V < ne) store_pack<T, V, true>(dst + e + u * 64 * V, p[u]);
+      }
+    }
+  } else if (out) {
+    T* dst = out + col0 * rows_out;
+    const int ne = ncols * rows_out;
+    for (int e = lane; e < ne; e += 64) dst[e] = tile[(e / rows_out) * P + e % rows_out];
+  }
+  block_publish_partial(lane < ncols ? (double)lres : 0.0, red, fin);
+}
+
 template <class T, class Op>
 int launch_seq(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t rows_in, int64_t rows_out,
                int64_t batch, int n_logk, uint32_t flags) {
   if (batch == 0) {
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
     return BJX_OK;
+  }
+  // wave-private tiles when a [64][rows] tile (+ log table) fits in 64 KiB of LDS
+  {
+    const int64_t rows = rows_in > rows_out ? rows_in : rows_out;
+    const int64_t P = rows | 1;
+    const size_t smem_w = ((size_t)64 * P + (size_t)n_logk) * sizeof(T);
+    static const int use_wave = getenv("BJX_SEQ_WAVE") ? atoi(getenv("BJX_SEQ_WAVE")) : 1;
+    if (use_wave && smem_w <= 64 * 1024 && rows_in >= 1 && rows_out >= 1) {
+      const int64_t grid = (batch + 63) / 64;
+      BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+      BjxFin fin;
+      bool second = false;
+      { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
+      // single-wave blocks: the in-kernel finalize would make EVERY wave wait for its own tile stores
+      // (vmcnt(0) before the arrival atomic) -> 2x slower (measured 0.27 vs 0.13 ms at C5a); use the
+      // two-pass finalize here.
+      if (fin.counter) { fin.counter = nullptr; second = true; }
+      constexpr int VW = Vec16<T>::N;
+      const bool v_ok = bjx_aligned16(in) && (!out || bjx_aligned16(out));
+      const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+      if (v_ok) hipLaunchKernelGGL((seq_wave_kernel<T, Op, VW>), dim3((unsigned)grid), dim3(64), smem_w, ctx->stream, op, in, out, ladj_ps, (int)rows_in, (int)rows_out, (int)P, batch, n_logk, accum, fin);
+      else hipLaunchKernelGGL((seq_wave_kernel<T, Op, 1>), dim3((unsigned)grid), dim3(64), smem_w, ctx->stream, op, in, out, ladj_ps, (int)rows_in, (int)rows_out, (int)P, batch, n_logk, accum, fin);
+      BJX_CHECK_LAUNCH(ctx);
+      if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+      return BJX_OK;
+    }
   }
   constexpr int C = SeqCfg<T>::C, NT = SeqCfg<T>::NT;
   const size_t smem = 32 + ((size_t)NT * (C + 1) + (size_t)n_logk) * sizeof(T);
