@@ -36,6 +36,8 @@ class BjxOp(C.Structure):
 _vp, _i, _i64, _u32, _u64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
 _tail = [_vp, _vp, _i64, _i64, _u32]  # ladj_ps, ladj_sum, dim/K, batch, flags
 
+BJX_OPT_INKERNEL_FINALIZE = 1
+
 # name -> (restype, argtypes); mirrors include/bjx.h line by line
 SIGNATURES = {
     "bjx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
@@ -45,6 +47,7 @@ SIGNATURES = {
     "bjx_version": (_i, []),
     "bjx_workspace_bytes": (C.c_size_t, [_vp]),
     "bjx_synchronize": (_i, [_vp]),
+    "bjx_set_option": (_i, [_vp, _i, _i]),
     "bjx_chain": (_i, [_vp, _i, C.POINTER(BjxOp), _i, _vp, _vp] + _tail),
     "bjx_ordered": (_i, [_vp, _i, _i, _vp, _vp] + _tail),
     "bjx_simplex": (_i, [_vp, _i, _i, _vp, _vp] + _tail),

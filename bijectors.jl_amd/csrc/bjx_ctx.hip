@@ -79,8 +79,7 @@ int bjx_make_fin(bjx_ctx* ctx, int64_t grid, double* ladj_sum, double host_const
   int rc = bjx_ensure_partials(ctx, (size_t)grid);
   if (rc) return rc;
   fin->partials = ctx->partials;
-  static const int inkernel = getenv("BJX_INKERNEL_FIN") ? atoi(getenv("BJX_INKERNEL_FIN")) : 1;
-  if (inkernel && grid <= BJX_INKERNEL_FIN_MAX) {
+  if (ctx->opt_inkernel_fin && grid <= BJX_INKERNEL_FIN_MAX) {
     fin->counter = ctx->fin_counter;
     fin->out = ladj_sum;
     fin->host_const = host_const;
@@ -112,6 +111,7 @@ BJX_API int bjx_create(int device, void* hip_stream, bjx_ctx** out) {
   if (e == hipSuccess) e = hipMalloc(&ctx->scratch, BJX_SCRATCH_BYTES);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+  if (e == hipSuccess && getenv("BJX_INKERNEL_FIN")) ctx->opt_inkernel_fin = atoi(getenv("BJX_INKERNEL_FIN")) ? 1 : 0;
   if (e == hipSuccess) {
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, device);
@@ -151,6 +151,12 @@ BJX_API const char* bjx_last_error(bjx_ctx* ctx) { return ctx ? ctx->err : "null
 BJX_API size_t bjx_workspace_bytes(bjx_ctx* ctx) {
   (void)ctx;
   return sizeof(double) * ((ctx ? ctx->partials_cap : (size_t)BJX_MAX_BLOCKS) + BJX_MAX_BLOCKS + BJX_CONSTS) + BJX_SCRATCH_BYTES;
+}
+
+BJX_API int bjx_set_option(bjx_ctx* ctx, int option, int value) {
+  if (!ctx) return BJX_ERR_ARG;
+  if (option == BJX_OPT_INKERNEL_FINALIZE) { ctx->opt_inkernel_fin = value ? 1 : 0; return BJX_OK; }
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_set_option: unknown option %d", option);
 }
 
 BJX_API int bjx_synchronize(bjx_ctx* ctx) {

@@ -29,6 +29,7 @@ struct bjx_ctx {
   void* scratch = nullptr;      // [BJX_SCRATCH_BYTES]
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cu = 256;
+  int opt_inkernel_fin = 0;     // BJX_OPT_INKERNEL_FINALIZE
   // RCCL (lazily dlopen'ed)
   void* rccl_handle = nullptr;
   void* comm = nullptr;
@@ -293,3 +294,4 @@ inline int bjx_stream_grid(const bjx_ctx* ctx, int64_t work_items, int per_block
 }
 
 inline bool bjx_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__device__ __forceinline__ bool bjx_aligned16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -462,6 +462,136 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const T* y, T* W, T* ladj
   if (partials) block_publish_partial(acc, red, partials);
 }
 
+// ------------------------------------------------------------------ VecCholesky inverse, chunk kernel
+// The kernel above handles one packed entry per lane per step: 4-byte loads, a 4-byte scattered
+// global store per entry plus K partial-row stores for the diagonal and the zero triangle (96 store
+// instructions for a 16 KiB sample at K = 64) — 33 % of the HBM roofline, bound by the store path.
+// Here ONE WAVE still owns one sample, but
+//  * LANE L OWNS THE CONTIGUOUS CHUNK [L*CH, (L+1)*CH) of the packed vector (CH = 32 entries = one
+//    128-byte line at K = 64, read with 16-byte loads) and walks it serially with 100 % lane
+//    utilisation; the only cross-lane step is ONE segmented scan per sample that hands each lane the
+//    Σ logcosh of the part of its first column that lives in earlier lanes (a column spans <= 3 lanes);
+//  * the K x K factor is assembled in a zero-initialised LDS tile (scattered 4-byte LDS writes) and
+//    leaves as 16 fully coalesced 16-byte stores per lane (the dense column-major W of corr.jl:391-395
+//    IS the tile);
+//  * pass 1 evaluates t = exp(-2|y|) and logcosh = |y| + log(1+t) - log 2 once per entry, pass 2
+//    needs one more exp per entry: w = tanh(y)·exp(-Σ_before logcosh) (:383), tanh = ±(1-t)/(1+t).
+// corr.jl:370-399 (_inv_link_chol_lkj) and :485-501 (_logabsdetjac_inv_chol when W is not wanted).
+constexpr int CHOL_WPB = 2;   // waves (= samples) per block: 2 x 16 KiB tiles at K = 64, ~4 blocks per CU
+template <class T, int V, int CHV, bool WRITE_W>
+__global__ __launch_bounds__(64 * CHOL_WPB) void chol_inv_chunk_kernel(const T* __restrict__ y, T* __restrict__ W, T* __restrict__ ladj_ps, int K,
+                                                             int64_t batch, int lower, int accumulate, double* partials) {
+  using F = Fast<T>;
+  constexpr int CH = CHV * V;                      // entries per lane
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* tile = reinterpret_cast<T*>(smem) + (size_t)wave * K * K;
+  const int nv = K * (K - 1) / 2;
+  const int64_t s = (int64_t)blockIdx.x * CHOL_WPB + wave;
+  double acc = 0.0;
+  if (s < batch) {
+    const T* ys = y + s * nv;
+    const int e0 = lane * CH;
+    // ---- loads first (all in flight), tile zeroing underneath
+    Pack<T, V> yp[CHV];
+#pragma unroll
+    for (int q = 0; q < CHV; ++q) {
+      const int e = e0 + q * V;
+      if (V > 1 && e + V <= nv) yp[q] = load_pack<T, V, false>(ys + e);
+      else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) yp[q].v[j] = (e + j < nv) ? ys[e + j] : T(0);
+      }
+    }
+    if (WRITE_W) {
+      constexpr int ZV = 16 / sizeof(T);
+      const int nz = K * K / ZV;
+      typename Vec16<T>::type zero = {};
+      for (int i = lane; i < nz; i += 64) reinterpret_cast<typename Vec16<T>::type*>(tile)[i] = zero;
+      for (int i = nz * ZV + lane; i < K * K; i += 64) tile[i] = T(0);
+    }
+    // (column, row) of my first entry; then incrementally
+    int c0, i00;
+    triu1_decode(e0 < nv ? e0 : 0, c0, i00);
+    // ---- pass 1: t, logcosh per entry; tail sum of my last (open) column segment
+    T lc[CH], tt[CH];
+    T tail = T(0);
+    bool has_head = false;
+    {
+      int c = c0, i0 = i00;
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const T yv = yp[k / V].v[k % V];
+        const T ay = d_abs(yv);
+        const T t = F::exp(T(-2) * ay);
+        const bool valid = e0 + k < nv;
+        lc[k] = valid ? (ay - Num<T>::log2) + F::log2(T(1) + t) * Num<T>::log2 : T(0);   // LogExpFunctions.logcosh
+        tt[k] = t;
+        if (valid && i0 == 0) { has_head = true; tail = T(0); }
+        tail += lc[k];
+        if (++i0 == c) { i0 = 0; ++c; }
+      }
+    }
+    // ---- carry-in: Σ logcosh of my first column's entries held by earlier lanes (segmented scan, once per sample)
+    T carry;
+    {
+      const T incl = seg_prefix_incl<T>(tail, has_head, T(0));
+      const T up = __shfl_up(incl, 1, 64);
+      carry = lane == 0 ? T(0) : up;
+    }
+    __builtin_amdgcn_wave_barrier();   // tile zeroing (same wave, in-order LDS queue) precedes the scatter
+    // ---- pass 2
+    T lj = T(0);
+    {
+      int c = c0, i0 = i00;
+      T run = carry;
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const bool valid = e0 + k < nv;
+        if (i0 == 0) run = T(0);
+        const T excl = run;                                  // log_remainder before this entry = -excl
+        run += lc[k];
+        const bool last = (i0 == c - 1);
+        if (valid) {
+          lj -= last ? run + run : run;                      // logJ += log_remainder per entry, once more per column (:385-389)
+          if (WRITE_W) {
+            const T yv = yp[k / V].v[k % V];
+            const T t = tt[k];
+            const T th = (T(1) - t) * F::rcp(T(1) + t);      // tanh|y|
+            const T wv = (yv < T(0) ? -th : th) * F::exp(-excl);   // z * exp(log_remainder) (:383)
+            tile[lower ? i0 * K + c : c * K + i0] = wv;
+            if (last) tile[c * K + c] = F::exp(-run);        // W[j,j] = exp(log_remainder) (:390)
+          }
+        }
+        if (++i0 == c) { i0 = 0; ++c; }
+      }
+    }
+    if (WRITE_W && lane == 0) tile[0] = T(1);                // W[1,1] = 1 (:376)
+    lj = group_sum<64>(lj);
+    if (lane == 0) {
+      if (ladj_ps) ladj_ps[s] = accumulate ? ladj_ps[s] + lj : lj;
+      acc = (double)lj;
+    }
+    if (WRITE_W) {
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      T* Ws = W + s * (int64_t)K * K;
+      constexpr int ZV = 16 / sizeof(T);
+      const int nz = K * K / ZV;
+      if (bjx_aligned16_dev(Ws)) {
+        for (int i = lane; i < nz; i += 64)
+          __builtin_nontemporal_store(reinterpret_cast<const typename Vec16<T>::type*>(tile)[i], reinterpret_cast<typename Vec16<T>::type*>(Ws) + i);
+        for (int i = nz * ZV + lane; i < K * K; i += 64) Ws[i] = tile[i];
+      } else {
+        for (int i = lane; i < K * K; i += 64) Ws[i] = tile[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
 // corr.jl:314-337 (_link_chol_lkj_from_upper / _from_lower) ; log-det = -_logabsdetjac_inv_chol(y) (:235-237)
 template <class T>
 __global__ __launch_bounds__(256) void chol_fwd_kernel(const T* W, T* y, T* ladj_ps, int64_t K, int64_t batch, int lower,
@@ -551,6 +681,33 @@ int chol_impl(bjx_ctx* ctx, int inverse, int uplo, const T* in, T* out, T* ladj_
   if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
   double* partials = ladj_sum ? ctx->partials : nullptr;
   if (inverse) {
+    // chunk kernel: lane = contiguous chunk of <= 32 packed entries, W tile in LDS (K <= 64 for Float32)
+    static const int use_chunk = getenv("BJX_CHOL_CHUNK") ? atoi(getenv("BJX_CHOL_CHUNK")) : 1;
+    const int64_t nv = K * (K - 1) / 2;
+    const size_t tile_bytes = out ? (size_t)CHOL_WPB * K * K * sizeof(T) : 0;
+    if (use_chunk && K >= 2 && nv <= 64 * 32 && tile_bytes <= 60 * 1024) {
+      const int64_t grid = (batch + CHOL_WPB - 1) / CHOL_WPB;
+      BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+      if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
+      double* partials = ladj_sum ? ctx->partials : nullptr;
+      constexpr int VW = Vec16<T>::N;
+      const bool v_ok = bjx_aligned16(in) && nv % VW == 0;
+      const int ch = (int)((nv + 63) / 64);                       // entries per lane
+#define CHOL_L(V_, CHV_) do { if (out) hipLaunchKernelGGL((chol_inv_chunk_kernel<T, V_, CHV_, true>), dim3((unsigned)grid), dim3(64 * CHOL_WPB), tile_bytes, ctx->stream, in, out, ladj_ps, (int)K, batch, lower, accum, partials); \
+                              else hipLaunchKernelGGL((chol_inv_chunk_kernel<T, V_, CHV_, false>), dim3((unsigned)grid), dim3(64 * CHOL_WPB), 0, ctx->stream, in, out, ladj_ps, (int)K, batch, lower, accum, partials); } while (0)
+      if (v_ok) {
+        const int chv = (ch + VW - 1) / VW;
+        if (chv <= 1) CHOL_L(VW, 1); else if (chv <= 2) CHOL_L(VW, 2); else if (chv <= 4) CHOL_L(VW, 4);
+        else if (chv * VW <= 32 && chv <= 8) CHOL_L(VW, 8); else if (VW == 2 && chv <= 16) CHOL_L(VW, 16);
+        else return bjx_fail(ctx, BJX_ERR_UNSUPPORTED, "bjx_vec_cholesky: internal chunk size");
+      } else {
+        if (ch <= 2) CHOL_L(1, 2); else if (ch <= 8) CHOL_L(1, 8); else if (ch <= 16) CHOL_L(1, 16); else CHOL_L(1, 32);
+      }
+#undef CHOL_L
+      BJX_CHECK_LAUNCH(ctx);
+      if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+      return BJX_OK;
+    }
     const size_t smem = 32 + (size_t)4 * K * sizeof(T);
     BJX_REQUIRE(ctx, smem <= 64 * 1024, BJX_ERR_UNSUPPORTED, "bjx_vec_cholesky: K = %lld too large", (long long)K);
     if (out) hipLaunchKernelGGL((chol_inv_kernel<T, true>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, partials);

@@ -73,6 +73,13 @@ int bjx_version(void);
 /* bytes of scratch a context holds (informational; SURVEY.md §8b "bjx_workspace_bytes") */
 size_t bjx_workspace_bytes(bjx_ctx* ctx);
 int bjx_synchronize(bjx_ctx* ctx);
+/* Tuning switches (per context).  BJX_OPT_INKERNEL_FINALIZE: 1 = the last block to arrive finishes
+ * the deterministic sum of `ladj_sum` inside the hot kernel (one launch per call) instead of the
+ * default two small follow-up launches; same bits either way (tests/test_gpu_parity.py).  Default 0:
+ * on MI355X the arrival atomic makes every block wait for its own output stores, which costs more
+ * than the ~10 us of extra launches (profiles/r01_finalize_variants.txt). */
+enum { BJX_OPT_INKERNEL_FINALIZE = 1 };
+int bjx_set_option(bjx_ctx* ctx, int option, int value);
 
 /* ------------------------------------------- F1: fused elementwise chains */
 /* One entry of a `ComposedFunction` chain (src/bijectors/composed.jl:4-25) after the host has

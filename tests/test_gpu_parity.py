@@ -523,7 +523,7 @@ def test_inplace_methods_write_into_the_callers_buffer(bj, orc):
 
 
 def test_inkernel_finalize_is_bit_identical_to_two_pass(bj):
-    """Σ log|det J| is finished by the last block to arrive inside the hot kernel (no extra launch).
+    """BJX_OPT_INKERNEL_FINALIZE: Σ log|det J| is finished by the last block to arrive inside the hot kernel.
     The hand-off uses device-coherent (sc1) stores/loads instead of fences; a stale or missing
     per-block partial would show up as a run-to-run difference when the input alternates, so the
     float64 sum must be BIT-identical over hundreds of launches for each input."""
@@ -533,15 +533,16 @@ def test_inkernel_finalize_is_bit_identical_to_two_pass(bj):
                            torch.tensor(r.normal(size=4)).float())
     xs = [torch.randn((N, d), device="cuda", dtype=torch.float32, generator=torch.Generator("cuda").manual_seed(s)).T for s in (1, 2)]
     y = torch.empty((N, d), device="cuda", dtype=torch.float32).T
-    first = [None, None]
-    for it in range(400):
-        k = it & 1
-        _, lps, lsum = bj.shard.with_logabsdet_jacobian_sharded(layer, xs[k], out=y)
-        v = lsum.clone()
-        if first[k] is None:
-            first[k] = v
-            # and it equals the float64 sum of the per-sample values up to summation order
-            assert abs(float(v) - float(lps.double().sum())) <= 1e-9 * max(1.0, abs(float(v)))
-        else:
-            assert torch.equal(v, first[k]), f"launch {it}: {float(v)!r} != {float(first[k])!r}"
-    assert not torch.equal(first[0], first[1])
+    L, ctx = bj._lib, bj.context(y.device)
+    two_pass = [bj.shard.with_logabsdet_jacobian_sharded(layer, xs[k], out=y)[2].clone() for k in (0, 1)]   # default path
+    L.check(ctx.h, L.load().bjx_set_option(ctx.h, L.BJX_OPT_INKERNEL_FINALIZE, 1), "bjx_set_option")
+    try:
+        for it in range(400):
+            k = it & 1
+            _, lps, lsum = bj.shard.with_logabsdet_jacobian_sharded(layer, xs[k], out=y)
+            assert torch.equal(lsum, two_pass[k]), f"launch {it}: {float(lsum)!r} != {float(two_pass[k])!r}"
+    finally:
+        L.check(ctx.h, L.load().bjx_set_option(ctx.h, L.BJX_OPT_INKERNEL_FINALIZE, 0), "bjx_set_option")
+    _, lps0, _ = bj.shard.with_logabsdet_jacobian_sharded(layer, xs[0], out=y)
+    assert abs(float(two_pass[0]) - float(lps0.double().sum())) <= 1e-9 * max(1.0, abs(float(two_pass[0])))
+    assert not torch.equal(two_pass[0], two_pass[1])
