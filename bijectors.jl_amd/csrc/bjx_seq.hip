@@ -477,16 +477,25 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const T* y, T* W, T* ladj
 //  * pass 1 evaluates t = exp(-2|y|) and logcosh = |y| + log(1+t) - log 2 once per entry, pass 2
 //    needs one more exp per entry: w = tanh(y)·exp(-Σ_before logcosh) (:383), tanh = ±(1-t)/(1+t).
 // corr.jl:370-399 (_inv_link_chol_lkj) and :485-501 (_logabsdetjac_inv_chol when W is not wanted).
-constexpr int CHOL_WPB = 2;   // waves (= samples) per block: 2 x 16 KiB tiles at K = 64, ~4 blocks per CU
-template <class T, int V, int CHV, bool WRITE_W>
+constexpr int CHOL_WPB = 2;   // waves (= samples) per block: 2 x ~17 KiB tiles at K = 64, 4 blocks per CU
+// Column bookkeeping without divisions or per-entry branches: `d` = entries left in the current
+// column (counts down), `len` = its length (= column index c), wrap = "this entry is the last of its
+// column" = "the next entry is a column head".  Pass 1 shifts the wrap bits into a per-lane mask so
+// pass 2 only tests a bit.  Entries past the end of the vector (only in the last lanes; loaded as 0)
+// form phantom columns c >= K whose logcosh is EXACTLY 0 (t = 1, log2(2) = 1), so they add nothing to
+// the log-det and need no predicate; their tile writes land in the padding columns behind the K x K
+// factor ('U') or are redirected to a dummy word ('L').
+template <class T, int V, int CHV, bool WRITE_W, bool LOWER>
 __global__ __launch_bounds__(64 * CHOL_WPB) void chol_inv_chunk_kernel(const T* __restrict__ y, T* __restrict__ W, T* __restrict__ ladj_ps, int K,
-                                                             int64_t batch, int lower, int accumulate, double* partials) {
+                                                             int tile_words, int64_t batch, int accumulate, double* partials) {
   using F = Fast<T>;
   constexpr int CH = CHV * V;                      // entries per lane
+  static_assert(CH <= 32, "wrap mask is 32 bits");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double red[4];
+  __shared__ double red[CHOL_WPB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  T* tile = reinterpret_cast<T*>(smem) + (size_t)wave * K * K;
+  T* tile = reinterpret_cast<T*>(smem) + (size_t)wave * tile_words;   // [K + pad columns][K] + 1 dummy word
+  const int dummy = tile_words - 1;
   const int nv = K * (K - 1) / 2;
   const int64_t s = (int64_t)blockIdx.x * CHOL_WPB + wave;
   double acc = 0.0;
@@ -498,10 +507,14 @@ __global__ __launch_bounds__(64 * CHOL_WPB) void chol_inv_chunk_kernel(const T* 
 #pragma unroll
     for (int q = 0; q < CHV; ++q) {
       const int e = e0 + q * V;
-      if (V > 1 && e + V <= nv) yp[q] = load_pack<T, V, false>(ys + e);
-      else {
+      if (V > 1) {
+        if (e + V <= nv) yp[q] = load_pack<T, V, false>(ys + e);      // nv % V == 0 on this path: whole packs only
+        else {
 #pragma unroll
-        for (int j = 0; j < V; ++j) yp[q].v[j] = (e + j < nv) ? ys[e + j] : T(0);
+          for (int j = 0; j < V; ++j) yp[q].v[j] = T(0);
+        }
+      } else {
+        yp[q].v[0] = (e < nv) ? ys[e] : T(0);
       }
     }
     if (WRITE_W) {
@@ -511,29 +524,33 @@ __global__ __launch_bounds__(64 * CHOL_WPB) void chol_inv_chunk_kernel(const T* 
       for (int i = lane; i < nz; i += 64) reinterpret_cast<typename Vec16<T>::type*>(tile)[i] = zero;
       for (int i = nz * ZV + lane; i < K * K; i += 64) tile[i] = T(0);
     }
-    // (column, row) of my first entry; then incrementally
     int c0, i00;
-    triu1_decode(e0 < nv ? e0 : 0, c0, i00);
-    // ---- pass 1: t, logcosh per entry; tail sum of my last (open) column segment
+    triu1_decode(e0, c0, i00);                     // column (1-based count = its length) and row of my first entry
+    // ---- pass 1: t, logcosh per entry; wrap mask; Σ logcosh of my last (open) column segment
     T lc[CH], tt[CH];
+    unsigned wmask = 0;
     T tail = T(0);
-    bool has_head = false;
+    bool has_head = (i00 == 0);
     {
-      int c = c0, i0 = i00;
+      int d = c0 - i00, len = c0;
+      bool prev_wrap = false;
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
-        const T yv = yp[k / V].v[k % V];
-        const T ay = d_abs(yv);
+        const T ay = d_abs(yp[k / V].v[k % V]);
         const T t = F::exp(T(-2) * ay);
-        const bool valid = e0 + k < nv;
-        lc[k] = valid ? (ay - Num<T>::log2) + F::log2(T(1) + t) * Num<T>::log2 : T(0);   // LogExpFunctions.logcosh
+        lc[k] = F::log2(T(1) + t) * Num<T>::log2 + (ay - Num<T>::log2);    // LogExpFunctions.logcosh (exactly 0 at y = 0)
         tt[k] = t;
-        if (valid && i0 == 0) { has_head = true; tail = T(0); }
-        tail += lc[k];
-        if (++i0 == c) { i0 = 0; ++c; }
+        tail = (prev_wrap ? T(0) : tail) + lc[k];
+        has_head |= prev_wrap;
+        d -= 1;
+        const bool wrap = (d == 0);
+        len += wrap ? 1 : 0;
+        d = wrap ? len : d;
+        wmask = (wmask << 1) | (wrap ? 1u : 0u);
+        prev_wrap = wrap;
       }
     }
-    // ---- carry-in: Σ logcosh of my first column's entries held by earlier lanes (segmented scan, once per sample)
+    // ---- carry-in: Σ logcosh of my first column's entries held by earlier lanes (one segmented scan per sample)
     T carry;
     {
       const T incl = seg_prefix_incl<T>(tail, has_head, T(0));
@@ -544,30 +561,40 @@ __global__ __launch_bounds__(64 * CHOL_WPB) void chol_inv_chunk_kernel(const T* 
     // ---- pass 2
     T lj = T(0);
     {
-      int c = c0, i0 = i00;
-      T run = carry;
+      T run = (i00 == 0) ? T(0) : carry;
+      int len = c0;
+      int addr = LOWER ? i00 * K + c0 : c0 * K + i00;       // word index of my first entry in the tile
+      bool prev_wrap = false;
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
-        const bool valid = e0 + k < nv;
-        if (i0 == 0) run = T(0);
+        const bool wrap = (wmask >> (CH - 1 - k)) & 1u;      // last entry of its column
+        run = prev_wrap ? T(0) : run;
         const T excl = run;                                  // log_remainder before this entry = -excl
         run += lc[k];
-        const bool last = (i0 == c - 1);
-        if (valid) {
-          lj -= last ? run + run : run;                      // logJ += log_remainder per entry, once more per column (:385-389)
-          if (WRITE_W) {
-            const T yv = yp[k / V].v[k % V];
-            const T t = tt[k];
-            const T th = (T(1) - t) * F::rcp(T(1) + t);      // tanh|y|
-            const T wv = (yv < T(0) ? -th : th) * F::exp(-excl);   // z * exp(log_remainder) (:383)
-            tile[lower ? i0 * K + c : c * K + i0] = wv;
-            if (last) tile[c * K + c] = F::exp(-run);        // W[j,j] = exp(log_remainder) (:390)
+        lj -= run;                                           // logJ += log_remainder after the entry (:385-387)
+        lj -= wrap ? run : T(0);                             // ... and once more at the end of a column (:389)
+        if (WRITE_W) {
+          const T yv = yp[k / V].v[k % V];
+          const T t = tt[k];
+          const T th = (T(1) - t) * F::rcp(T(1) + t);        // tanh|y|
+          const T wv = __builtin_copysign(th, yv) * F::exp(-excl);   // z * exp(log_remainder) (:383)
+          int wa = addr, da;
+          if (LOWER) {
+            const bool real = len < K;
+            wa = real ? addr : dummy;
+            da = (wrap && real) ? addr + K : dummy;          // (c-1)*K + c  ->  c*K + c
+          } else {
+            da = wrap ? addr + 1 : dummy;                    // c*K + c-1    ->  c*K + c
           }
+          tile[wa] = wv;
+          tile[da] = run;                                    // Σ logcosh of the whole column, exponentiated below
+          if (LOWER) addr = wrap ? len + 1 : addr + K;
+          else addr += wrap ? K + 1 - len : 1;
+          len += wrap ? 1 : 0;
         }
-        if (++i0 == c) { i0 = 0; ++c; }
+        prev_wrap = wrap;
       }
     }
-    if (WRITE_W && lane == 0) tile[0] = T(1);                // W[1,1] = 1 (:376)
     lj = group_sum<64>(lj);
     if (lane == 0) {
       if (ladj_ps) ladj_ps[s] = accumulate ? ladj_ps[s] + lj : lj;
@@ -575,7 +602,12 @@ __global__ __launch_bounds__(64 * CHOL_WPB) void chol_inv_chunk_kernel(const T* 
     }
     if (WRITE_W) {
       __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // diagonal: W[j,j] = exp(log_remainder at the end of column j) (:390); W[1,1] = 1 (:376)
+      for (int c = lane; c < K; c += 64) {
+        const T r = tile[c * K + c];
+        tile[c * K + c] = c == 0 ? T(1) : F::exp(-r);
+      }
+      __builtin_amdgcn_wave_barrier();
       T* Ws = W + s * (int64_t)K * K;
       constexpr int ZV = 16 / sizeof(T);
       const int nz = K * K / ZV;
@@ -684,26 +716,36 @@ int chol_impl(bjx_ctx* ctx, int inverse, int uplo, const T* in, T* out, T* ladj_
     // chunk kernel: lane = contiguous chunk of <= 32 packed entries, W tile in LDS (K <= 64 for Float32)
     static const int use_chunk = getenv("BJX_CHOL_CHUNK") ? atoi(getenv("BJX_CHOL_CHUNK")) : 1;
     const int64_t nv = K * (K - 1) / 2;
-    const size_t tile_bytes = out ? (size_t)CHOL_WPB * K * K * sizeof(T) : 0;
-    if (use_chunk && K >= 2 && nv <= 64 * 32 && tile_bytes <= 60 * 1024) {
+    constexpr int VW = Vec16<T>::N;
+    const bool v_ok = bjx_aligned16(in) && nv % VW == 0;
+    const int ch = (int)((nv + 63) / 64);                         // entries per lane
+    int chv, vv;                                                  // template CHV, V
+    if (v_ok) { vv = VW; const int need = (ch + VW - 1) / VW; chv = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16; }
+    else { vv = 1; chv = ch <= 2 ? 2 : ch <= 8 ? 8 : ch <= 16 ? 16 : 32; }
+    const int CHn = chv * vv;
+    // phantom entries (< 64*CH) reach column cmax: pad the tile so their 'U' writes stay inside it
+    int64_t cmax = K;
+    while (cmax * (cmax + 1) / 2 <= (int64_t)64 * CHn - 1) ++cmax;
+    int64_t tile_words = cmax * (K + 1) + 1;                      // highest phantom write: [cmax][cmax-1] and its diagonal slot
+    if (tile_words < K * K) tile_words = K * K;
+    tile_words = (tile_words + 1 + 3) / 4 * 4;                    // + dummy word, 16-byte multiple
+    const size_t tile_bytes = out ? (size_t)CHOL_WPB * tile_words * sizeof(T) : 0;
+    if (use_chunk && K >= 2 && CHn <= 32 && nv <= 64 * 32 && tile_bytes <= 60 * 1024) {
       const int64_t grid = (batch + CHOL_WPB - 1) / CHOL_WPB;
       BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
       if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
       double* partials = ladj_sum ? ctx->partials : nullptr;
-      constexpr int VW = Vec16<T>::N;
-      const bool v_ok = bjx_aligned16(in) && nv % VW == 0;
-      const int ch = (int)((nv + 63) / 64);                       // entries per lane
-#define CHOL_L(V_, CHV_) do { if (out) hipLaunchKernelGGL((chol_inv_chunk_kernel<T, V_, CHV_, true>), dim3((unsigned)grid), dim3(64 * CHOL_WPB), tile_bytes, ctx->stream, in, out, ladj_ps, (int)K, batch, lower, accum, partials); \
-                              else hipLaunchKernelGGL((chol_inv_chunk_kernel<T, V_, CHV_, false>), dim3((unsigned)grid), dim3(64 * CHOL_WPB), 0, ctx->stream, in, out, ladj_ps, (int)K, batch, lower, accum, partials); } while (0)
-      if (v_ok) {
-        const int chv = (ch + VW - 1) / VW;
-        if (chv <= 1) CHOL_L(VW, 1); else if (chv <= 2) CHOL_L(VW, 2); else if (chv <= 4) CHOL_L(VW, 4);
-        else if (chv * VW <= 32 && chv <= 8) CHOL_L(VW, 8); else if (VW == 2 && chv <= 16) CHOL_L(VW, 16);
-        else return bjx_fail(ctx, BJX_ERR_UNSUPPORTED, "bjx_vec_cholesky: internal chunk size");
+#define CHOL_K(V_, CHV_, W_, L_) hipLaunchKernelGGL((chol_inv_chunk_kernel<T, V_, CHV_, W_, L_>), dim3((unsigned)grid), dim3(64 * CHOL_WPB), tile_bytes, ctx->stream, in, out, ladj_ps, (int)K, (int)tile_words, batch, accum, partials)
+#define CHOL_L(V_, CHV_) do { if (!out) CHOL_K(V_, CHV_, false, false); else if (lower) CHOL_K(V_, CHV_, true, true); else CHOL_K(V_, CHV_, true, false); } while (0)
+      if (vv == VW) {
+        if (chv == 1) CHOL_L(VW, 1); else if (chv == 2) CHOL_L(VW, 2); else if (chv == 4) CHOL_L(VW, 4);
+        else if (chv == 8 && VW * 8 <= 32) CHOL_L(VW, (VW * 8 <= 32 ? 8 : 1));
+        else if (VW == 2 && chv == 8) CHOL_L(VW, 8); else CHOL_L(VW, (VW == 2 ? 16 : 1));
       } else {
-        if (ch <= 2) CHOL_L(1, 2); else if (ch <= 8) CHOL_L(1, 8); else if (ch <= 16) CHOL_L(1, 16); else CHOL_L(1, 32);
+        if (chv == 2) CHOL_L(1, 2); else if (chv == 8) CHOL_L(1, 8); else if (chv == 16) CHOL_L(1, 16); else CHOL_L(1, 32);
       }
 #undef CHOL_L
+#undef CHOL_K
       BJX_CHECK_LAUNCH(ctx);
       if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
       return BJX_OK;
