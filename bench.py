@@ -96,7 +96,7 @@ def make_workload(name, bj, torch, device, rank, world, log2_batch):
             _, _, s2 = bj.shard.with_logabsdet_jacobian_sharded(ib, y_, out=xb)
             return s1
 
-        return dict(step=step, samples=N, bytes_per_sample=(2 * dim * 4 + 4) * 2, kernel="colgroup_kernel<RqsF>", dtype="f32",
+        return dict(step=step, samples=N, bytes_per_sample=(2 * dim * 4 + 4) * 2, kernel="rqs_lds_kernel (forward + inverse launch)", dtype="f32",
                     label=f"RationalQuadraticSpline K=16 fwd+inverse+logabsdetjac Float32 dim={dim} batch=2^{lb}/GPU",
                     cfg={"workload": "RationalQuadraticSpline K=16 fwd+inv+logabsdetjac (BASELINE configs[2])", "dim": dim, "batch_per_gpu": N})
     if name == "c4":
@@ -116,7 +116,7 @@ def make_workload(name, bj, torch, device, rank, world, log2_batch):
         def step():
             return bj.shard.with_logabsdet_jacobian_sharded(flow, x, out=y)[2]
 
-        return dict(step=step, samples=N, bytes_per_sample=2 * dim * 4 + 4, kernel="planar_kernel", dtype="f32",
+        return dict(step=step, samples=N, bytes_per_sample=2 * dim * 4 + 4, kernel="planar_reg_kernel", dtype="f32",
                     label=f"8-layer PlanarLayer flow fused fwd+logabsdetjac Float32 dim={dim} batch=2^{lb}/GPU",
                     cfg={"workload": "8x PlanarLayer fused (BASELINE configs[3])", "dim": dim, "layers": nl, "batch_per_gpu": N})
     if name == "c5a":
@@ -130,7 +130,7 @@ def make_workload(name, bj, torch, device, rank, world, log2_batch):
         def step():
             return bj.shard.with_logabsdet_jacobian_sharded(b, x)[2]
 
-        return dict(step=step, samples=N, bytes_per_sample=K * 4 + (K - 1) * 4 + 4, kernel="seq_kernel<SimplexFwd>", dtype="f32",
+        return dict(step=step, samples=N, bytes_per_sample=K * 4 + (K - 1) * 4 + 4, kernel="seq_wave_kernel<SimplexFwd>", dtype="f32",
                     label=f"SimplexBijector fwd+logabsdetjac Float32 K={K} batch=2^{lb}/GPU",
                     cfg={"workload": "SimplexBijector (BASELINE configs[4], first half)", "K": K, "batch_per_gpu": N})
     if name == "c5b":
@@ -144,7 +144,7 @@ def make_workload(name, bj, torch, device, rank, world, log2_batch):
         def step():
             return bj.shard.with_logabsdet_jacobian_sharded(ib, yv)[2]
 
-        return dict(step=step, samples=N, bytes_per_sample=n * 4 + K * K * 4 + 4, kernel="chol_inv_kernel", dtype="f32",
+        return dict(step=step, samples=N, bytes_per_sample=n * 4 + K * K * 4 + 4, kernel="chol_inv_chunk_kernel", dtype="f32",
                     label=f"inverse VecCholeskyBijector (y->W dense + logJ) Float32 K={K} batch=2^{lb}/GPU",
                     cfg={"workload": "VecCholeskyBijector inverse, dense W (BASELINE configs[4], second half)", "K": K, "batch_per_gpu": N})
     raise ValueError(name)
@@ -264,28 +264,34 @@ def main():
     barrier()
     import ctypes as C
 
+    lib.bjx_kernel_time_begin(ctx.h)          # one hipEvent pair around every dominant-kernel launch (context stream)
     lib.bjx_time_begin(ctx.h)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         last = wl["step"]()
     ev_ms = C.c_float(0.0)
-    lib.bjx_time_end(ctx.h, C.byref(ev_ms))   # hipEvent pair on the stream the kernels run on
+    lib.bjx_time_end(ctx.h, C.byref(ev_ms))   # hipEvent pair around the whole timed region (helpers + gaps included)
     barrier()
     dt = time.perf_counter() - t0
+    k_ms, k_n = C.c_float(0.0), C.c_int(0)
+    bj._lib.check(ctx.h, lib.bjx_kernel_time_end(ctx.h, C.byref(k_ms), C.byref(k_n)), "bjx_kernel_time_end")
     if dist is not None:
-        tt = torch.tensor([dt, ev_ms.value], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt, ev_ms.value, k_ms.value], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, ev = float(tt[0]), float(tt[1])
+        dt, ev, kern_total = float(tt[0]), float(tt[1]), float(tt[2])
     else:
-        ev = ev_ms.value
+        ev, kern_total = ev_ms.value, k_ms.value
     ladj_total = float(last[0]) if last is not None else float("nan")
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         total_samples = wl["samples"] * world
         value = total_samples / (dt / a.steps) / 1e6
-        kern_ms = ev / a.steps
-        alg_bytes = wl["samples"] * wl["bytes_per_sample"]       # per launch, one GPU
+        # dominant kernel(s) of ONE step: per-launch hipEvent pairs summed, / steps (a step of c3 has two
+        # launches, forward + inverse, and `bytes_per_sample` counts both)
+        kern_ms = kern_total / a.steps
+        region_ms = ev / a.steps                                 # incl. parameter-prep / finalize helpers and gaps
+        alg_bytes = wl["samples"] * wl["bytes_per_sample"]       # per step, one GPU
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = traffic_from_profiles(a.workload)
         out = {
@@ -295,7 +301,8 @@ def main():
             "dtype": wl["dtype"], "data": "synthetic (Philox N(0,1), shard-invariant)",
             "config": dict(wl["cfg"], parallelism=f"batch-sharded x{world}, one f64 all-reduce of Σlogabsdetjac"),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": wl["kernel"], "kernel_ms": kern_ms,
+                         "traffic": traffic, "kernel": wl["kernel"], "kernel_ms": kern_ms, "kernel_launches_per_step": k_n.value / max(a.steps, 1),
+                         "stream_region_ms_per_step": region_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
             "sum_logabsdetjac": ladj_total,
             "label": wl["label"],

@@ -67,6 +67,8 @@ SIGNATURES = {
     "bjx_fill_normal": (_i, [_vp, _i, _vp, _i64, _i64, _i64, _u64, _d, _d]),
     "bjx_time_begin": (_i, [_vp]),
     "bjx_time_end": (_i, [_vp, C.POINTER(C.c_float)]),
+    "bjx_kernel_time_begin": (_i, [_vp]),
+    "bjx_kernel_time_end": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 }
 
 _lib = None

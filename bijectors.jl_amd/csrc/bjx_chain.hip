@@ -357,6 +357,7 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
     BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_chain: input too large for one launch"); \
     if (ladj_sum) { int rc_ = bjx_ensure_partials(ctx, (size_t)grid); if (rc_) return rc_; }                  \
     double* partials = ladj_sum ? ctx->partials : nullptr;                                                    \
+    BjxProf prof_(ctx);                                                                                       \
     if (nt) hipLaunchKernelGGL((chain_flat_kernel<T, V_, RM_, true, U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, x, y, n, dim, dim_pow2, partials); \
     else hipLaunchKernelGGL((chain_flat_kernel<T, V_, RM_, false, U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, x, y, n, dim, dim_pow2, partials);  \
   } while (0)
@@ -388,6 +389,7 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
     const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
 #define LAUNCH_COL(V_, RM_)                                                                                                 \
   do {                                                                                                                      \
+    BjxProf prof_(ctx);                                                                                                     \
     if (nt) hipLaunchKernelGGL((chain_colgroup_kernel<T, V_, RM_, true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, x, y, ladj_ps, dim, batch, G, c_ps_host, cdev, accum, partials);  \
     else hipLaunchKernelGGL((chain_colgroup_kernel<T, V_, RM_, false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, x, y, ladj_ps, dim, batch, G, c_ps_host, cdev, accum, partials);   \
   } while (0)

@@ -136,6 +136,10 @@ BJX_API int bjx_destroy(bjx_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->prof_ev) {
+    for (int i = 0; i < 2 * bjx_ctx::PROF_MAX; ++i) if (ctx->prof_ev[i]) (void)hipEventDestroy(ctx->prof_ev[i]);
+    delete[] ctx->prof_ev;
+  }
   delete ctx;
   return BJX_OK;
 }
@@ -176,6 +180,35 @@ BJX_API int bjx_time_end(bjx_ctx* ctx, float* ms_out) {
   BJX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   BJX_HIP(ctx, hipEventSynchronize(ctx->ev1));
   BJX_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+  return BJX_OK;
+}
+
+BJX_API int bjx_kernel_time_begin(bjx_ctx* ctx) {
+  if (!ctx) return BJX_ERR_ARG;
+  if (!ctx->prof_ev) {
+    ctx->prof_ev = new (std::nothrow) hipEvent_t[2 * bjx_ctx::PROF_MAX]();
+    if (!ctx->prof_ev) return bjx_fail(ctx, BJX_ERR_ARG, "out of host memory");
+    for (int i = 0; i < 2 * bjx_ctx::PROF_MAX; ++i) BJX_HIP(ctx, hipEventCreate(&ctx->prof_ev[i]));
+  }
+  ctx->prof_n = 0;
+  ctx->prof_dropped = 0;
+  ctx->prof_on = 1;
+  return BJX_OK;
+}
+
+BJX_API int bjx_kernel_time_end(bjx_ctx* ctx, float* total_ms, int* launches) {
+  if (!ctx || !total_ms || !launches) return BJX_ERR_ARG;
+  ctx->prof_on = 0;
+  BJX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0.0;
+  for (int i = 0; i < ctx->prof_n; ++i) {
+    float ms = 0.f;
+    BJX_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+    tot += ms;
+  }
+  *total_ms = (float)tot;
+  *launches = ctx->prof_n;
+  if (ctx->prof_dropped) return bjx_fail(ctx, BJX_ERR_UNSUPPORTED, "bjx_kernel_time_end: %d launches not recorded (more than %d in the region)", ctx->prof_dropped, bjx_ctx::PROF_MAX);
   return BJX_OK;
 }
 

@@ -517,6 +517,7 @@ inline int ceil_log2(int n) { int s = 0; while ((1 << s) < n) ++s; return s; }
 template <class T, int V, bool INV>
 int rqs_launch_lds(bjx_ctx* ctx, int nstep_hi, int dual, const T* blob, const int* flag, int K1, size_t smem, int64_t grid, const T* in,
                    T* out, T* ladj_ps, int64_t dim, int64_t batch, int G, int iters, int accum, const BjxFin& fin) {
+  BjxProf prof_(ctx);
 #define RQS_L(NS_, DUAL_) hipLaunchKernelGGL((rqs_lds_kernel<T, V, NS_, DUAL_, INV>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, blob, flag, K1, in, out, ladj_ps, dim, batch, G, iters, accum, fin)
   switch (nstep_hi * 2 + (dual ? 1 : 0)) {
     case 2: RQS_L(1, false); break;

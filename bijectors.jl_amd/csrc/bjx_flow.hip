@@ -710,7 +710,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
 #define LAUNCH_REG(G_, NL_, INV_) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
 #define LAUNCH_REG_NL(G_, INV_) switch (NL) { case 1: LAUNCH_REG(G_, 1, INV_); break; case 2: LAUNCH_REG(G_, 2, INV_); break; case 4: LAUNCH_REG(G_, 4, INV_); break; default: LAUNCH_REG(G_, 8, INV_); break; }
 #define LAUNCH_REG_G(INV_) switch (G) { case 8: LAUNCH_REG_NL(8, INV_) break; case 16: LAUNCH_REG_NL(16, INV_) break; default: LAUNCH_REG_NL(32, INV_) break; }
-        if (inverse) { LAUNCH_REG_G(true) } else { LAUNCH_REG_G(false) }
+        { BjxProf prof_(ctx); if (inverse) { LAUNCH_REG_G(true) } else { LAUNCH_REG_G(false) } }
 #undef LAUNCH_REG_G
 #undef LAUNCH_REG_NL
 #undef LAUNCH_REG
@@ -739,8 +739,9 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
     constexpr int VW = Vec16<T>::N;
     const bool v_ok = bjx_aligned16(in) && bjx_aligned16(out) && dim % VW == 0;
 #define LAUNCH_TILE(V_, INV_) hipLaunchKernelGGL((planar_tile_kernel<T, V_, INV_>), dim3((unsigned)grid), dim3(64), tile_bytes, ctx->stream, TA, in, out, ladj_ps, (int)dim, batch, accum, partials)
+    { BjxProf prof_(ctx);
     if (v_ok) { if (inverse) LAUNCH_TILE(VW, true); else LAUNCH_TILE(VW, false); }
-    else { if (inverse) LAUNCH_TILE(1, true); else LAUNCH_TILE(1, false); }
+    else { if (inverse) LAUNCH_TILE(1, true); else LAUNCH_TILE(1, false); } }
 #undef LAUNCH_TILE
     BJX_CHECK_LAUNCH(ctx);
     if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
@@ -756,6 +757,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
   if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)c.grid); if (rc) return rc; }
   double* partials = ladj_sum ? ctx->partials : nullptr;
   constexpr int VW = Vec16<T>::N;
+  BjxProf prof_(ctx);
   if (c.V == VW) {
     if (!inverse) { FLOW_SWITCH_R(planar_kernel, T, VW, false, A, in, out, ladj_ps, dim, batch, c.G, accum, partials) }
     else { FLOW_SWITCH_R(planar_kernel, T, VW, true, A, in, out, ladj_ps, dim, batch, c.G, accum, partials) }
@@ -785,6 +787,7 @@ int radial_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const
   if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)c.grid); if (rc) return rc; }
   double* partials = ladj_sum ? ctx->partials : nullptr;
   constexpr int VW = Vec16<T>::N;
+  BjxProf prof_(ctx);
   if (c.V == VW) {
     if (!inverse) { FLOW_SWITCH_R(radial_kernel, T, VW, false, A, in, out, ladj_ps, dim, batch, c.G, accum, partials) }
     else { FLOW_SWITCH_R(radial_kernel, T, VW, true, A, in, out, ladj_ps, dim, batch, c.G, accum, partials) }

@@ -30,6 +30,11 @@ struct bjx_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cu = 256;
   int opt_inkernel_fin = 0;     // BJX_OPT_INKERNEL_FINALIZE
+  // per-launch timing of the DOMINANT kernel of each call (bjx_kernel_time_begin/_end): event pairs
+  // recorded right around the hot kernel, so helper launches and host gaps are excluded
+  static constexpr int PROF_MAX = 1024;
+  hipEvent_t* prof_ev = nullptr;   // [2 * PROF_MAX], created lazily
+  int prof_on = 0, prof_n = 0, prof_dropped = 0;
   // RCCL (lazily dlopen'ed)
   void* rccl_handle = nullptr;
   void* comm = nullptr;
@@ -55,6 +60,21 @@ inline int bjx_fail(bjx_ctx* ctx, int code, const char* fmt, ...) {
   } while (0)
 
 #define BJX_CHECK_LAUNCH(ctx) BJX_HIP(ctx, hipGetLastError())
+
+// RAII event pair around the hot kernel launch of an entry point (no-op unless profiling is on)
+struct BjxProf {
+  bjx_ctx* c;
+  int slot;
+  explicit BjxProf(bjx_ctx* ctx) : c(ctx), slot(-1) {
+    if (c->prof_on) {
+      if (c->prof_n < bjx_ctx::PROF_MAX) { slot = c->prof_n++; (void)hipEventRecord(c->prof_ev[2 * slot], c->stream); }
+      else ++c->prof_dropped;
+    }
+  }
+  ~BjxProf() { if (slot >= 0) (void)hipEventRecord(c->prof_ev[2 * slot + 1], c->stream); }
+  BjxProf(const BjxProf&) = delete;
+  BjxProf& operator=(const BjxProf&) = delete;
+};
 
 #define BJX_REQUIRE(ctx, cond, code, ...)                    \
   do {                                                       \

@@ -318,8 +318,9 @@ int launch_seq(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, doub
       constexpr int VW = Vec16<T>::N;
       const bool v_ok = bjx_aligned16(in) && (!out || bjx_aligned16(out));
       const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+      { BjxProf prof_(ctx);
       if (v_ok) hipLaunchKernelGGL((seq_wave_kernel<T, Op, VW>), dim3((unsigned)grid), dim3(64), smem_w, ctx->stream, op, in, out, ladj_ps, (int)rows_in, (int)rows_out, (int)P, batch, n_logk, accum, fin);
-      else hipLaunchKernelGGL((seq_wave_kernel<T, Op, 1>), dim3((unsigned)grid), dim3(64), smem_w, ctx->stream, op, in, out, ladj_ps, (int)rows_in, (int)rows_out, (int)P, batch, n_logk, accum, fin);
+      else hipLaunchKernelGGL((seq_wave_kernel<T, Op, 1>), dim3((unsigned)grid), dim3(64), smem_w, ctx->stream, op, in, out, ladj_ps, (int)rows_in, (int)rows_out, (int)P, batch, n_logk, accum, fin); }
       BJX_CHECK_LAUNCH(ctx);
       if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
       return BJX_OK;
@@ -332,8 +333,9 @@ int launch_seq(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, doub
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
   if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
   double* partials = ladj_sum ? ctx->partials : nullptr;
+  { BjxProf prof_(ctx);
   hipLaunchKernelGGL((seq_kernel<T, Op>), dim3((unsigned)grid), dim3(NT), smem, ctx->stream, op, in, out, ladj_ps, rows_in, rows_out, batch, n_logk,
-                     (flags & BJX_ACCUMULATE) ? 1 : 0, partials);
+                     (flags & BJX_ACCUMULATE) ? 1 : 0, partials); }
   BJX_CHECK_LAUNCH(ctx);
   if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
   return BJX_OK;
@@ -737,13 +739,14 @@ int chol_impl(bjx_ctx* ctx, int inverse, int uplo, const T* in, T* out, T* ladj_
       double* partials = ladj_sum ? ctx->partials : nullptr;
 #define CHOL_K(V_, CHV_, W_, L_) hipLaunchKernelGGL((chol_inv_chunk_kernel<T, V_, CHV_, W_, L_>), dim3((unsigned)grid), dim3(64 * CHOL_WPB), tile_bytes, ctx->stream, in, out, ladj_ps, (int)K, (int)tile_words, batch, accum, partials)
 #define CHOL_L(V_, CHV_) do { if (!out) CHOL_K(V_, CHV_, false, false); else if (lower) CHOL_K(V_, CHV_, true, true); else CHOL_K(V_, CHV_, true, false); } while (0)
+      { BjxProf prof_(ctx);
       if (vv == VW) {
         if (chv == 1) CHOL_L(VW, 1); else if (chv == 2) CHOL_L(VW, 2); else if (chv == 4) CHOL_L(VW, 4);
         else if (chv == 8 && VW * 8 <= 32) CHOL_L(VW, (VW * 8 <= 32 ? 8 : 1));
         else if (VW == 2 && chv == 8) CHOL_L(VW, 8); else CHOL_L(VW, (VW == 2 ? 16 : 1));
       } else {
         if (chv == 2) CHOL_L(1, 2); else if (chv == 8) CHOL_L(1, 8); else if (chv == 16) CHOL_L(1, 16); else CHOL_L(1, 32);
-      }
+      } }
 #undef CHOL_L
 #undef CHOL_K
       BJX_CHECK_LAUNCH(ctx);
@@ -752,10 +755,12 @@ int chol_impl(bjx_ctx* ctx, int inverse, int uplo, const T* in, T* out, T* ladj_
     }
     const size_t smem = 32 + (size_t)4 * K * sizeof(T);
     BJX_REQUIRE(ctx, smem <= 64 * 1024, BJX_ERR_UNSUPPORTED, "bjx_vec_cholesky: K = %lld too large", (long long)K);
+    BjxProf prof_(ctx);
     if (out) hipLaunchKernelGGL((chol_inv_kernel<T, true>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, partials);
     else hipLaunchKernelGGL((chol_inv_kernel<T, false>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, partials);
   } else {
     const int want = (ladj_ps || ladj_sum) ? 1 : 0;
+    BjxProf prof_(ctx);
     hipLaunchKernelGGL((chol_fwd_kernel<T>), dim3((unsigned)grid), dim3(256), 32, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, want, partials);
   }
   BJX_CHECK_LAUNCH(ctx);

@@ -102,10 +102,13 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
   BjxFin fin;
   bool second = false;
   { int rc = bjx_make_fin(ctx, c.grid, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, flags, &fin, &second); if (rc) return rc; }
+  {
+  BjxProf prof_(ctx);
   if (c.V == VW)
     hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin);
   else
     hipLaunchKernelGGL((colgroup_kernel<T, 1, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin);
+  }
   BJX_CHECK_LAUNCH(ctx);
   if (second) return bjx_launch_finalize(ctx, (int)c.grid, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, 0.0, flags);
   return BJX_OK;

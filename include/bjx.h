@@ -217,6 +217,12 @@ int bjx_fill_normal(bjx_ctx* ctx, bjx_dtype dt, void* out, int64_t dim, int64_t 
  * the average milliseconds per launch (used by bench.py for roofline.achieved). */
 int bjx_time_begin(bjx_ctx* ctx);
 int bjx_time_end(bjx_ctx* ctx, float* ms_out);
+/* Between _begin and _end every entry point brackets its DOMINANT kernel launch (not the
+ * parameter-prep / finalize helpers) with its own hipEvent pair on the context stream; _end
+ * synchronises and returns the summed kernel milliseconds and the number of launches recorded
+ * (at most 1024 per region).  bench.py's roofline.achieved is computed from this. */
+int bjx_kernel_time_begin(bjx_ctx* ctx);
+int bjx_kernel_time_end(bjx_ctx* ctx, float* total_ms, int* launches);
 
 #ifdef __cplusplus
 }
