@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/<TAG>/ (written by scripts/gpu_profile.sh on the GPU box) into the tracked
+evidence under profiles/: <TAG>_bench_lines.jsonl, <TAG>_<wl>_kernel_stats.csv (top rows),
+<TAG>_<wl>_pmc_{FETCH,WRITE}_SIZE.csv (dominant-kernel rows) and profiles/traffic.json.
+
+HBM bytes per step = (2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024 summed over the dominant kernel
+launches of one step — the x2 is the gfx950 FETCH_SIZE half-count of wide coalesced reads
+(MI355X_MICROARCH.md, HBM section); it is exact for the 16-byte streaming loads these kernels use."""
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DOMINANT = {"c2": ["chain_flat_kernel"], "c2v": ["chain_flat_kernel"], "c3": ["rqs_lds_kernel"], "c4": ["planar_reg_kernel"],
+            "c5a": ["seq_wave_kernel"], "c5b": ["chol_inv_chunk_kernel"]}
+
+
+def main(tag):
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    traffic_path = os.path.join(dst, "traffic.json")
+    try:
+        traffic = json.load(open(traffic_path))
+    except Exception:
+        traffic = {}
+    traffic["_how"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), KiB per dispatch of the dominant "
+                       "kernel(s); HBM bytes per step = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the dominant launches of one step — the x2 is the "
+                       "gfx950 FETCH_SIZE half-count correction of MI355X_MICROARCH.md (HBM section); raw rows in profiles/<tag>_<wl>_pmc_*.csv")
+    lines = []
+    for wl, subs in DOMINANT.items():
+        bj = os.path.join(src, f"bench_{wl}.json")
+        if os.path.exists(bj) and os.path.getsize(bj) > 2:
+            lines.append(open(bj).read().strip())
+        ks = os.path.join(src, f"{wl}_kernel_stats.csv")
+        if os.path.exists(ks):
+            rows = list(csv.reader(open(ks)))
+            with open(os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv"), "w", newline="") as f:
+                csv.writer(f).writerows(rows[:12])
+        per = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            p = os.path.join(src, f"{wl}_pmc_{c}.csv")
+            if not os.path.exists(p):
+                continue
+            rows = [r for r in csv.DictReader(open(p)) if any(s in r["Kernel_Name"] for s in subs)]
+            if not rows:
+                continue
+            with open(os.path.join(dst, f"{tag}_{wl}_pmc_{c}.csv"), "w", newline="") as f:
+                w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+                w.writeheader()
+                w.writerows(rows)
+            by = defaultdict(list)
+            for r in rows:
+                by[r["Kernel_Name"].split("(")[0] + "|" + r["Kernel_Name"][:160]].append(float(r["Counter_Value"]))
+            # one launch of every distinct dominant kernel per step (c3: forward + inverse)
+            per[c] = {k: sum(v) / len(v) for k, v in by.items()}
+        if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
+            f_kib = sum(per["FETCH_SIZE"].values())
+            w_kib = sum(per["WRITE_SIZE"].values())
+            entry = {"tag": tag, "kernels": sorted(k.split("|")[1] for k in per["FETCH_SIZE"]), "FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib,
+                     "hbm_bytes_per_launch": (2 * f_kib + w_kib) * 1024.0}
+            for ln in lines[-1:]:
+                try:
+                    d = json.loads(ln)
+                    entry["algorithmic_bytes_per_launch"] = d["roofline"]["algorithmic_bytes_per_launch"]
+                except Exception:
+                    pass
+            traffic[wl] = entry
+    if lines:
+        with open(os.path.join(dst, f"{tag}_bench_lines.jsonl"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    json.dump(traffic, open(traffic_path, "w"), indent=1)
+    pt = os.path.join(src, "pytest_gpu.txt")
+    if os.path.exists(pt):
+        open(os.path.join(dst, f"{tag}_pytest_gpu_tail.txt"), "w").write("".join(open(pt).readlines()[-5:]))
+    print(json.dumps({k: v for k, v in traffic.items() if k != "_how"}, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
