@@ -72,8 +72,7 @@ __device__ __forceinline__ void load_params(const DevOp<T>& op, int64_t r, int64
 // data-dependent log-det contribution (Scale's parameter-only term is added by finalize).
 #define BJX_FOR_UJ _Pragma("unroll") for (int u = 0; u < U; ++u) _Pragma("unroll") for (int j = 0; j < V; ++j)
 template <class T, int V, int U, int ROWMODE>
-__device__ __forceinline__ T apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim) {
-  T l = T(0);
+__device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim, T (&l)[U]) {
   const int kind = op.kind;
   T a[U][V], b[U][V];
   if (kind != BJX_OP_EXP && kind != BJX_OP_LOG && kind != BJX_OP_SIGNFLIP) {
@@ -82,10 +81,10 @@ __device__ __forceinline__ T apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U], co
   }
   switch (kind) {
     case BJX_OP_EXP:  // exp_log.jl:5-6: ladj = sum(x)
-      BJX_FOR_UJ { l += p[u].v[j]; p[u].v[j] = d_exp(p[u].v[j]); }
+      BJX_FOR_UJ { l[u] += p[u].v[j]; p[u].v[j] = d_exp(p[u].v[j]); }
       break;
     case BJX_OP_LOG:  // exp_log.jl:8-9: ladj = -sum(log, x)
-      BJX_FOR_UJ { T t = d_log(p[u].v[j]); l -= t; p[u].v[j] = t; }
+      BJX_FOR_UJ { T t = d_log(p[u].v[j]); l[u] -= t; p[u].v[j] = t; }
       break;
     case BJX_OP_SHIFT:  // shift.jl:14
       BJX_FOR_UJ p[u].v[j] = a[u][j] + p[u].v[j];
@@ -99,21 +98,21 @@ __device__ __forceinline__ T apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U], co
     case BJX_OP_LOGIT:  // logit.jl:15,24
       BJX_FOR_UJ {
         T x = p[u].v[j];
-        l += -d_log((x - a[u][j]) * (b[u][j] - x) / (b[u][j] - a[u][j]));
+        l[u] += -d_log((x - a[u][j]) * (b[u][j] - x) / (b[u][j] - a[u][j]));
         p[u].v[j] = d_logit((x - a[u][j]) / (b[u][j] - a[u][j]));
       }
       break;
     case BJX_OP_LOGIT_INV:  // logit.jl:19 ; interface.jl:276-281
       BJX_FOR_UJ {
         T x = (b[u][j] - a[u][j]) * d_logistic(p[u].v[j]) + a[u][j];
-        l += d_log((x - a[u][j]) * (b[u][j] - x) / (b[u][j] - a[u][j]));
+        l[u] += d_log((x - a[u][j]) * (b[u][j] - x) / (b[u][j] - a[u][j]));
         p[u].v[j] = x;
       }
       break;
     case BJX_OP_LEAKY_RELU:  // leaky_relu.jl:25-29
       BJX_FOR_UJ {
         T J = p[u].v[j] < T(0) ? a[u][j] : T(1);
-        l += d_log(d_abs(J));
+        l[u] += d_log(d_abs(J));
         p[u].v[j] = J * p[u].v[j];
       }
       break;
@@ -122,9 +121,9 @@ __device__ __forceinline__ T apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U], co
         T lo = a[u][j], up = b[u][j];
         T x = d_clamp(p[u].v[j], lo, up);
         bool lb = d_isfinite(lo), ub = d_isfinite(up);
-        if (lb && ub) { l += -d_log((x - lo) * (up - x) / (up - lo)); p[u].v[j] = d_logit((x - lo) / (up - lo)); }
-        else if (lb) { T t = d_log(x - lo); l -= t; p[u].v[j] = t; }
-        else if (ub) { T t = d_log(up - x); l -= t; p[u].v[j] = t; }
+        if (lb && ub) { l[u] += -d_log((x - lo) * (up - x) / (up - lo)); p[u].v[j] = d_logit((x - lo) / (up - lo)); }
+        else if (lb) { T t = d_log(x - lo); l[u] -= t; p[u].v[j] = t; }
+        else if (ub) { T t = d_log(up - x); l[u] -= t; p[u].v[j] = t; }
         else p[u].v[j] = x;
       }
       break;
@@ -133,9 +132,9 @@ __device__ __forceinline__ T apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U], co
         T lo = a[u][j], up = b[u][j], yv = p[u].v[j];
         bool lb = d_isfinite(lo), ub = d_isfinite(up);
         T x;
-        if (lb && ub) { T ay = d_abs(yv); l += d_log(up - lo) - ay - T(2) * d_log1pexp(-ay); x = (up - lo) * d_logistic(yv) + lo; }
-        else if (lb) { l += yv; x = d_exp(yv) + lo; }
-        else if (ub) { l += yv; x = up - d_exp(yv); }
+        if (lb && ub) { T ay = d_abs(yv); l[u] += d_log(up - lo) - ay - T(2) * d_log1pexp(-ay); x = (up - lo) * d_logistic(yv) + lo; }
+        else if (lb) { l[u] += yv; x = d_exp(yv) + lo; }
+        else if (ub) { l[u] += yv; x = up - d_exp(yv); }
         else x = yv;
         p[u].v[j] = d_clamp(x, lo, up);
       }
@@ -145,13 +144,22 @@ __device__ __forceinline__ T apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U], co
       break;
     default: break;
   }
-  return l;
 }
 
+// per-pack log-det contributions lu[u] (the per-sample kernel reduces each pack's column separately)
+template <class T, int V, int U, int ROWMODE>
+__device__ __forceinline__ void apply_chain_u(const ChainArgs<T>& A, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim, T (&lu)[U]) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) lu[u] = T(0);
+  for (int k = 0; k < A.n_ops; ++k) apply_op<T, V, U, ROWMODE>(A.ops[k], p, r, dim, lu);
+}
 template <class T, int V, int U, int ROWMODE>
 __device__ __forceinline__ T apply_chain(const ChainArgs<T>& A, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim) {
-  T l = T(0);
-  for (int k = 0; k < A.n_ops; ++k) l += apply_op<T, V, U, ROWMODE>(A.ops[k], p, r, dim);
+  T lu[U];
+  apply_chain_u<T, V, U, ROWMODE>(A, p, r, dim, lu);
+  T l = lu[0];
+#pragma unroll
+  for (int u = 1; u < U; ++u) l += lu[u];
   return l;
 }
 
@@ -201,6 +209,52 @@ __global__ __launch_bounds__(256) void chain_flat_kernel(const ChainArgs<T> A, c
           acc += (double)l;
         }
       }
+    }
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
+// Per-sample log-det with the FLAT geometry (U packs in flight per lane, 16 KiB per block) when a
+// column is G = dim/V packs with G a power of two <= 64: the G lanes of an aligned group hold one
+// column of each of their U packs, so U butterflies over G lanes give the U per-column sums.
+// (chain_colgroup_kernel below keeps one pack per lane in flight for such shapes: 36 % of the HBM
+// roofline at dim = 64 against 79 % for the flat kernel, profiles/r01b_rows.md.)
+template <class T, int V, int ROWMODE, bool NT, int U, int G>
+__global__ __launch_bounds__(256) void chain_flatcol_kernel(const ChainArgs<T> A, const T* x, T* y, T* ladj_ps, int64_t n, int64_t dim,
+                                                            double c_ps_host, const double* c_ps_dev, int accumulate, double* partials) {
+  __shared__ double red[4];
+  const int64_t nv = n / V;                         // dim % V == 0 here: no element tail
+  const int64_t i0 = (int64_t)blockIdx.x * (256 * U) + threadIdx.x;
+  const int gl = threadIdx.x & (G - 1);
+  double acc = 0.0;
+  Pack<T, V> p[U];
+  int64_t r[U];
+  const bool full = i0 + (U - 1) * 256 < nv;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = i0 + u * 256;
+    if (full || i < nv) p[u] = load_pack<T, V, NT>(x + i * V);
+    else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) p[u].v[j] = T(1);   // harmless input for every op; results discarded
+    }
+    r[u] = (int64_t)gl * V;                         // row of the pack inside its column
+  }
+  T lu[U];
+  apply_chain_u<T, V, U, ROWMODE>(A, p, r, dim, lu);
+  const double c_ps = c_ps_host + (c_ps_dev ? *c_ps_dev : 0.0);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = i0 + u * 256;
+    const bool ok = full || i < nv;
+    if (ok) store_pack<T, V, NT>(y + i * V, p[u]);
+    const T l = group_sum<G>(ok ? lu[u] : T(0));
+    if (ok && gl == 0) {
+      const int64_t col = i / G;
+      T out = l + (T)c_ps;
+      if (accumulate) out += ladj_ps[col];
+      ladj_ps[col] = out;
+      acc += (double)l;
     }
   }
   if (partials) block_publish_partial(acc, red, partials);
@@ -380,13 +434,36 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
     const int64_t packs = v_ok ? dim / VW : dim;
     int G = 1;
     while (G < 64 && G < packs) G <<= 1;
+    const double* cdev = any_dev_scale ? ctx->consts : nullptr;
+    const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+    // flat geometry with per-column butterflies: packs per column a power of two <= 64, parameters per row
+    // either absent or readable as aligned packs
+    static const int use_flatcol = env_int("BJX_CHAIN_FLATCOL", 1);
+    if (use_flatcol && v_ok && packs == G && (!any_row || rows_vec)) {
+      constexpr int UF = 4;
+      grid = (n / VW + 256 * UF - 1) / (256 * UF);
+      BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_chain: input too large for one launch");
+      if (ladj_sum) { int rc_ = bjx_ensure_partials(ctx, (size_t)grid); if (rc_) return rc_; }
+      double* partials = ladj_sum ? ctx->partials : nullptr;
+#define LAUNCH_FC2(RM_, NT_, G_) hipLaunchKernelGGL((chain_flatcol_kernel<T, VW, RM_, NT_, UF, G_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, x, y, ladj_ps, n, dim, c_ps_host, cdev, accum, partials)
+#define LAUNCH_FC1(RM_, NT_) switch (G) { case 1: LAUNCH_FC2(RM_, NT_, 1); break; case 2: LAUNCH_FC2(RM_, NT_, 2); break; case 4: LAUNCH_FC2(RM_, NT_, 4); break; case 8: LAUNCH_FC2(RM_, NT_, 8); break; \
+                                           case 16: LAUNCH_FC2(RM_, NT_, 16); break; case 32: LAUNCH_FC2(RM_, NT_, 32); break; default: LAUNCH_FC2(RM_, NT_, 64); break; }
+      {
+        BjxProf prof_(ctx);
+        if (!any_row) { if (nt) { LAUNCH_FC1(0, true) } else { LAUNCH_FC1(0, false) } }
+        else { if (nt) { LAUNCH_FC1(1, true) } else { LAUNCH_FC1(1, false) } }
+      }
+#undef LAUNCH_FC1
+#undef LAUNCH_FC2
+      BJX_CHECK_LAUNCH(ctx);
+      if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, c_sum_host, any_dev_scale ? 1 : 0, 0.0, flags);
+      return BJX_OK;
+    }
     const int cols_per_block = 256 / G;
     grid = (batch + cols_per_block - 1) / cols_per_block;
     BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_chain: input too large for one launch");
     if (ladj_sum) { int rc_ = bjx_ensure_partials(ctx, (size_t)grid); if (rc_) return rc_; }
     double* partials = ladj_sum ? ctx->partials : nullptr;
-    const double* cdev = any_dev_scale ? ctx->consts : nullptr;
-    const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
 #define LAUNCH_COL(V_, RM_)                                                                                                 \
   do {                                                                                                                      \
     BjxProf prof_(ctx);                                                                                                     \

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""One measured line per SURVEY.md §8(a) row (forward and inverse where the row has both): dominant
+kernel time from per-launch hipEvent pairs (bjx_kernel_time_begin/_end), algorithmic bytes
+(read input once + write output once + 4 B/sample when a per-sample log-det is written) and the
+fraction of the 8 TB/s HBM peak.  Float32, inputs resident in HBM.  Output: a markdown table.
+
+    python scripts/bench_rows.py [--log2-batch 22] [--steps 10] [--only name,...]
+"""
+import argparse
+import ctypes as C
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bijectors_amd as bj  # noqa: E402
+
+PEAK = 8000.0
+
+
+def cm(rows, batch, dev, dt=torch.float32):
+    return torch.empty((batch, rows), dtype=dt, device=dev).T
+
+
+def randn(rows, batch, dev, seed, std=1.0, mean=0.0):
+    t = cm(rows, batch, dev)
+    L, ctx = bj._lib, bj.context(dev)
+    L.check(ctx.h, L.load().bjx_fill_normal(ctx.h, L.BJX_F32, t.data_ptr(), rows, batch, 0, seed, mean, std), "fill")
+    return t
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log2-batch", type=int, default=22)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    N = 1 << a.log2_batch
+    d = 64
+    f32 = torch.float32
+    x = randn(d, N, dev, 0)
+    xpos = torch.exp(0.5 * x.T).T
+    xunit = torch.sigmoid(x.T).T
+    rows = []  # (name, reference, callable, bytes_per_sample, samples)
+
+    def add(name, ref, b, inp, out_rows=None, per_sample=True, samples=None):
+        n = inp.shape[-1] if samples is None else samples
+        in_rows = inp.numel() // n
+        orows = in_rows if out_rows is None else out_rows
+        y = cm(orows, n, dev) if inp.dim() == 2 and orows * n < (1 << 34) else None
+        bps = 4 * (in_rows + orows) + (4 if per_sample else 0)
+
+        def step():
+            return bj.shard.with_logabsdet_jacobian_sharded(b, inp, out=y, per_sample=per_sample)
+
+        rows.append((name, ref, step, bps, n))
+
+    e = bj.elementwise
+    add("exp∘Shift∘Scale (sum)", "a1,a3,a4,a5", e(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5), x, per_sample=False)
+    add("exp∘Shift∘Scale (per-sample ladj)", "a1,a3,a4,a5", e(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5), x)
+    add("elementwise(log)", "a2", e(bj.log), xpos, per_sample=False)
+    add("Logit(0,1)", "a6", bj.Logit(0.0, 1.0), xunit, per_sample=False)
+    add("inverse(Logit(0,1))", "a6", bj.inverse(bj.Logit(0.0, 1.0)), x, per_sample=False)
+    add("LeakyReLU(0.1)", "a7", bj.LeakyReLU(0.1), x, per_sample=False)
+    add("TruncatedBijector(0,1)", "a8", bj.TruncatedBijector(0.0, 1.0), xunit, per_sample=False)
+    add("inverse(TruncatedBijector(0,1))", "a8", bj.inverse(bj.TruncatedBijector(0.0, 1.0)), x, per_sample=False)
+    add("OrderedBijector", "a9", bj.OrderedBijector(), x)
+    xo = bj.transform(bj.OrderedBijector(), x)
+    add("inverse(OrderedBijector)", "a9", bj.inverse(bj.OrderedBijector()), xo)
+    Ns = 1 << min(a.log2_batch, 22)
+    xs = torch.softmax(randn(d, Ns, dev, 1).T, dim=1).T
+    add("SimplexBijector K=64", "a10,a12", bj.SimplexBijector(), xs, out_rows=d - 1)
+    ys = randn(d - 1, Ns, dev, 2)
+    add("inverse(SimplexBijector) K=64", "a11", bj.inverse(bj.SimplexBijector()), ys, out_rows=d)
+    K = 64
+    Nc = 1 << min(a.log2_batch, 16)
+    n = K * (K - 1) // 2
+    yv = randn(n, Nc, dev, 3, std=0.5)
+    icb = bj.inverse(bj.VecCholeskyBijector("U"))
+    rows.append(("inverse(VecCholesky) K=64", "a14", lambda: bj.shard.with_logabsdet_jacobian_sharded(icb, yv), 4 * (n + K * K) + 4, Nc))
+    Wd, _, _ = bj.shard.with_logabsdet_jacobian_sharded(icb, yv)
+    cb = bj.VecCholeskyBijector("U")
+    rows.append(("VecCholesky K=64 (W→y)", "a13", lambda: bj.shard.with_logabsdet_jacobian_sharded(cb, Wd), 4 * (n + K * K) + 4, Nc))
+    dp, nl = 128, 8
+    Np = 1 << min(a.log2_batch, 22)
+    z = randn(dp, Np, dev, 4)
+    w = randn(dp, nl, dev, 5, std=1 / math.sqrt(dp))
+    u = randn(dp, nl, dev, 6, std=1 / math.sqrt(dp))
+    bb = randn(nl, 1, dev, 7).reshape(-1).contiguous()
+    flow = bj.PlanarLayer(w, u, bb)
+    add("8×PlanarLayer d=128", "a15", flow, z)
+    zf = bj.transform(flow, z)
+    add("inverse(8×PlanarLayer) d=128", "a16", bj.inverse(flow), zf)
+    one = bj.PlanarLayer(w[:, 0].contiguous(), u[:, 0].contiguous(), bb[:1].contiguous())
+    add("1×PlanarLayer d=128", "a15", one, z)
+    rad = bj.RadialLayer(torch.tensor([0.3], device=dev), torch.tensor([0.5], device=dev), randn(dp, 1, dev, 8).reshape(-1).contiguous())
+    add("RadialLayer d=128", "a17", rad, z)
+    add("inverse(RadialLayer) d=128", "a17", bj.inverse(rad), z)
+    bn = bj.InvertibleBatchNorm(torch.zeros(d, device=dev), torch.zeros(d, device=dev), torch.zeros(d, device=dev), torch.ones(d, device=dev))
+    add("InvertibleBatchNorm (eval) d=64", "a18", bn, x)
+    dr, Kb = 32, 16
+    raw = [randn(dr, k, dev, 100 + i) for i, k in enumerate((Kb, Kb, Kb - 1))]
+    rqs = bj.RationalQuadraticSpline(raw[0], raw[1], raw[2], 3.0)
+    xr = randn(dr, N, dev, 9)
+    add("RQS K=16 d=32 forward", "a19", rqs, xr)
+    yr = bj.transform(rqs, xr)
+    add("RQS K=16 d=32 inverse", "a19", bj.inverse(rqs), yr)
+    perm = bj.Permute(list(torch.randperm(d, generator=torch.Generator().manual_seed(0)).add(1).tolist()))
+    add("Permute d=64", "a21", perm, x, per_sample=False)
+    mask = bj.PartitionMask(d, list(range(1, d // 2 + 1)), list(range(d // 2 + 1, d + 1)))
+    sc = torch.full((d // 2,), 1.5, device=dev)
+    cpl = bj.Coupling(lambda x2: bj.Shift(0.25) @ bj.Scale(sc), mask)
+    add("Coupling(Shift∘Scale) d=64", "a20", cpl, x)
+
+    only = [s for s in a.only.split(",") if s]
+    L, ctx = bj._lib, bj.context(dev)
+    lib = L.load()
+    print("| row | §8(a) | kernel ms | samples | alg. B/sample | GB/s | % of 8 TB/s |")
+    print("|---|---|---|---|---|---|---|")
+    for name, ref, step, bps, n in rows:
+        if only and not any(o in name for o in only):
+            continue
+        try:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            lib.bjx_kernel_time_begin(ctx.h)
+            for _ in range(a.steps):
+                step()
+            ms, cnt = C.c_float(0), C.c_int(0)
+            L.check(ctx.h, lib.bjx_kernel_time_end(ctx.h, C.byref(ms), C.byref(cnt)), "time_end")
+            k = ms.value / a.steps
+            gbs = bps * n / (k * 1e-3) / 1e9
+            print(f"| {name} | {ref} | {k:.4f} | 2^{int(math.log2(n))} | {bps} | {gbs:.0f} | {100 * gbs / PEAK:.1f} |", flush=True)
+        except Exception as ex:  # keep the table going
+            print(f"| {name} | {ref} | failed: {ex!r} | | | | |", flush=True)
+
+
+if __name__ == "__main__":
+    main()
