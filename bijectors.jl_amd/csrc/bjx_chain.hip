@@ -73,6 +73,7 @@ __device__ __forceinline__ void load_params(const DevOp<T>& op, int64_t r, int64
 #define BJX_FOR_UJ _Pragma("unroll") for (int u = 0; u < U; ++u) _Pragma("unroll") for (int j = 0; j < V; ++j)
 template <class T, int V, int U, int ROWMODE>
 __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim, T (&l)[U]) {
+  using F = Fast<T>;
   const int kind = op.kind;
   T a[U][V], b[U][V];
   if (kind != BJX_OP_EXP && kind != BJX_OP_LOG && kind != BJX_OP_SIGNFLIP) {
@@ -95,17 +96,21 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
     case BJX_OP_SCALE_INV:  // scale.jl:15-16: Scale(inv(a))
       BJX_FOR_UJ p[u].v[j] = (T(1) / a[u][j]) * p[u].v[j];
       break;
-    case BJX_OP_LOGIT:  // logit.jl:15,24
+    case BJX_OP_LOGIT:  // logit.jl:15,24.  Float32: hardware log/rcp (the OCML versions make this op VALU-bound at 50 % of the roofline)
       BJX_FOR_UJ {
-        T x = p[u].v[j];
-        l[u] += -d_log((x - a[u][j]) * (b[u][j] - x) / (b[u][j] - a[u][j]));
-        p[u].v[j] = d_logit((x - a[u][j]) / (b[u][j] - a[u][j]));
+        const T x = p[u].v[j];
+        const T inv = F::rcp(b[u][j] - a[u][j]);
+        const T xa = x - a[u][j];
+        l[u] -= F::log(xa * (b[u][j] - x) * inv);
+        const T z = xa * inv;
+        p[u].v[j] = F::log(z * F::rcp(T(1) - z));               // LogExpFunctions.logit
       }
       break;
     case BJX_OP_LOGIT_INV:  // logit.jl:19 ; interface.jl:276-281
       BJX_FOR_UJ {
-        T x = (b[u][j] - a[u][j]) * d_logistic(p[u].v[j]) + a[u][j];
-        l[u] += d_log((x - a[u][j]) * (b[u][j] - x) / (b[u][j] - a[u][j]));
+        const T w = b[u][j] - a[u][j];
+        const T x = w * f_logistic(p[u].v[j]) + a[u][j];
+        l[u] += F::log((x - a[u][j]) * (b[u][j] - x) * F::rcp(w));
         p[u].v[j] = x;
       }
       break;
@@ -121,9 +126,14 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
         T lo = a[u][j], up = b[u][j];
         T x = d_clamp(p[u].v[j], lo, up);
         bool lb = d_isfinite(lo), ub = d_isfinite(up);
-        if (lb && ub) { l[u] += -d_log((x - lo) * (up - x) / (up - lo)); p[u].v[j] = d_logit((x - lo) / (up - lo)); }
-        else if (lb) { T t = d_log(x - lo); l[u] -= t; p[u].v[j] = t; }
-        else if (ub) { T t = d_log(up - x); l[u] -= t; p[u].v[j] = t; }
+        if (lb && ub) {
+          const T inv = F::rcp(up - lo), xa = x - lo;
+          l[u] -= F::log(xa * (up - x) * inv);
+          const T z = xa * inv;
+          p[u].v[j] = F::log(z * F::rcp(T(1) - z));
+        }
+        else if (lb) { T t = F::log(x - lo); l[u] -= t; p[u].v[j] = t; }
+        else if (ub) { T t = F::log(up - x); l[u] -= t; p[u].v[j] = t; }
         else p[u].v[j] = x;
       }
       break;
@@ -132,9 +142,9 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
         T lo = a[u][j], up = b[u][j], yv = p[u].v[j];
         bool lb = d_isfinite(lo), ub = d_isfinite(up);
         T x;
-        if (lb && ub) { T ay = d_abs(yv); l[u] += d_log(up - lo) - ay - T(2) * d_log1pexp(-ay); x = (up - lo) * d_logistic(yv) + lo; }
-        else if (lb) { l[u] += yv; x = d_exp(yv) + lo; }
-        else if (ub) { l[u] += yv; x = up - d_exp(yv); }
+        if (lb && ub) { T ay = d_abs(yv); l[u] += F::log(up - lo) - ay - T(2) * f_log1pexp(-ay); x = (up - lo) * f_logistic(yv) + lo; }
+        else if (lb) { l[u] += yv; x = F::exp(yv) + lo; }
+        else if (ub) { l[u] += yv; x = up - F::exp(yv); }
         else x = yv;
         p[u].v[j] = d_clamp(x, lo, up);
       }

@@ -560,10 +560,13 @@ template <class T> struct RadialArgs {
   int in_lds;
 };
 
-// radial_layer.jl:43-72 (forward) and :88-129 (inverse)
+// radial_layer.jl:43-72 (forward) and :88-129 (inverse).  UC = 4/R columns per lane group are in
+// flight at once (one 16-byte pack per lane and column is latency-bound: 39 % of the HBM roofline).
+template <int R> struct RadialUC { static constexpr int value = R == 1 ? 4 : (R == 2 ? 2 : 1); };
 template <class T, int V, int R, bool INV>
 __global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, const T* x, T* y, T* ladj_ps, int64_t dim,
                                                      int64_t batch, int G, int accumulate, double* partials) {
+  constexpr int UC = RadialUC<R>::value;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* red = reinterpret_cast<double*>(smem);
   T* tab = reinterpret_cast<T*>(smem + 32);
@@ -580,23 +583,40 @@ __global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, cons
   const int cols_per_block = blockDim.x / G;
   const int64_t nvc = dim / V;
   double acc = 0.0;
-  // non-persistent grid: one column per G-lane group.  Lanes of a group past the batch keep
+  // non-persistent grid: UC columns per G-lane group.  Lanes of a group past the batch keep
   // running (on column batch-1, results discarded) so the group shuffles stay convergent.
-  const int64_t col_raw = (int64_t)blockIdx.x * cols_per_block + threadIdx.x / G;
-  const bool col_ok = col_raw < batch;
-  {
+  const int64_t col_first = (int64_t)blockIdx.x * cols_per_block * UC + threadIdx.x / G;
+  Pack<T, V> zz[UC][R];
+  T z0r[R][V];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t v = gl + (int64_t)r * G;
+#pragma unroll
+    for (int j = 0; j < V; ++j) z0r[r][j] = v < nvc ? Z0[v * V + j] : T(0);
+  }
+#pragma unroll
+  for (int u = 0; u < UC; ++u) {
+    const int64_t col_raw = col_first + (int64_t)u * cols_per_block;
+    const int64_t col = col_raw < batch ? col_raw : batch - 1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t v = gl + (int64_t)r * G;
+      if (v < nvc) zz[u][r] = load_pack<T, V, true>(x + col * dim + v * V);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < UC; ++u) {
+    const int64_t col_raw = col_first + (int64_t)u * cols_per_block;
+    const bool col_ok = col_raw < batch;
     const int64_t col = col_ok ? col_raw : batch - 1;
-    const T* xc = x + col * dim;
     T* yc = y + col * dim;
-    Pack<T, V> zz[R];
     T ss = T(0);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      int64_t v = gl + (int64_t)r * G;
+      const int64_t v = gl + (int64_t)r * G;
       if (v < nvc) {
-        zz[r] = load_pack<T, V, true>(xc + v * V);
 #pragma unroll
-        for (int j = 0; j < V; ++j) { T dlt = zz[r].v[j] - Z0[v * V + j]; ss += dlt * dlt; }
+        for (int j = 0; j < V; ++j) { const T dlt = zz[u][r].v[j] - z0r[r][j]; ss += dlt * dlt; }
       }
     }
     ss = group_sum_rt(ss, G);
@@ -614,17 +634,17 @@ __global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, cons
     const T h_ = T(1) / (alpha + r_fwd);
     T ld = T(dim - 1) * d_log(T(1) + beta_hat * h_) + d_log(T(1) + beta_hat * h_ + beta_hat * (-(h_ * h_)) * r_fwd);   // :68-70
     if (INV) ld = -ld;
+    const T fwd_gain = beta_hat / (alpha + r_fwd);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      int64_t v = gl + (int64_t)r * G;
+      const int64_t v = gl + (int64_t)r * G;
       if (v < nvc) {
         Pack<T, V> o;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-          const T z0j = Z0[v * V + j];
-          const T dlt = zz[r].v[j] - z0j;
-          if (!INV) o.v[j] = zz[r].v[j] + beta_hat / (alpha + r_fwd) * dlt;   // :52
-          else o.v[j] = z0j + gain * dlt;                                     // :101
+          const T dlt = zz[u][r].v[j] - z0r[r][j];
+          if (!INV) o.v[j] = zz[u][r].v[j] + fwd_gain * dlt;                  // :52
+          else o.v[j] = z0r[r][j] + gain * dlt;                              // :101
         }
         if (col_ok) store_pack<T, V, true>(yc + v * V, o);
       }
@@ -779,6 +799,11 @@ int radial_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const
   }
   FlowCfg c;
   BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, out, dim, batch, &c), BJX_ERR_UNSUPPORTED, "bjx_radial: dim %lld too large for the register-resident kernel", (long long)dim);
+  {
+    const int uc = c.R == 1 ? 4 : (c.R == 2 ? 2 : 1);          // RadialUC<R>
+    const int64_t cpb = (int64_t)(256 / c.G) * uc;
+    c.grid = (batch + cpb - 1) / cpb;
+  }
   const size_t tab_bytes = (size_t)dim * sizeof(T);
   const bool lds = tab_bytes <= 60 * 1024;
   RadialArgs<T> A{alpha_, beta, z0, lds ? 1 : 0};

@@ -195,6 +195,19 @@ template <> struct Fast<double> {
   static __device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
 };
 
+// LogExpFunctions.logistic / log1pexp on the fast units (same saturation / branch thresholds as above)
+template <class T> __device__ __forceinline__ T f_logistic(T x) {
+  const T e = Fast<T>::exp(x);
+  return x < Num<T>::logistic_lo ? T(0) : (x > Num<T>::logistic_hi ? T(1) : e * Fast<T>::rcp(T(1) + e));
+}
+template <class T> __device__ __forceinline__ T f_log1pexp(T x) {
+  const T e = Fast<T>::exp(x < Num<T>::l1pe1 ? x : -x);
+  if (x < Num<T>::l1pe0) return e;
+  if (x < Num<T>::l1pe1) return Fast<T>::log1p(e);
+  if (x < Num<T>::l1pe2) return x + e;
+  return x;
+}
+
 // ------------------------------------------------------------------ reductions (wave = 64)
 template <class T> __device__ __forceinline__ T shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
 

@@ -20,6 +20,8 @@ constexpr int STREAM_U = 4;
 //   static constexpr bool kLoadInput   (false: apply() gathers from xcol itself, e.g. Permute)
 //   double per_sample_const            (host-known constant added to every ladj_ps entry)
 //   const double* per_sample_dev       (device constant added likewise, or null)
+constexpr int COL_UC = 4;   // columns in flight per lane group (one 16-byte pack each) when a column fits in G packs
+
 template <class T, int V, bool NT, class F>
 __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T* y, T* ladj_ps, int64_t dim,
                                                        int64_t batch, int G, int accumulate, const BjxFin fin) {
@@ -31,38 +33,70 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
   const int cols_per_block = blockDim.x / G;
   const int64_t nvc = dim / V;
   double acc = 0.0;
-  // non-persistent: one column per G-lane group (scripts/membench.hip: in-order short blocks stream
-  // ~30 % faster than grid-stride loops on MI355X)
-  const int64_t col = (int64_t)blockIdx.x * cols_per_block + threadIdx.x / G;
-  T l = T(0);
-  if (col < batch) {
-    const T* xc = x + col * dim;
-    T* yc = y + col * dim;
-    for (int64_t v0 = 0; v0 < nvc; v0 += (int64_t)G * STREAM_U) {
-      Pack<T, V> p[STREAM_U];
+  // non-persistent: COL_UC columns per G-lane group (scripts/membench.hip: in-order short blocks stream
+  // ~30 % faster than grid-stride loops on MI355X; one pack per lane in flight is latency-bound)
+  const int64_t col0 = (int64_t)blockIdx.x * cols_per_block * COL_UC + threadIdx.x / G;
+  const double psc = f.per_sample_const + (f.per_sample_dev ? *f.per_sample_dev : 0.0);
+  if (nvc <= G) {
+    Pack<T, V> p[COL_UC];
+    const bool lane_ok = gl < nvc;
 #pragma unroll
-      for (int u = 0; u < STREAM_U; ++u) {
-        int64_t v = v0 + (int64_t)u * G + gl;
-        if (F::kLoadInput && v < nvc) p[u] = load_pack<T, V, NT>(xc + v * V);
+    for (int u = 0; u < COL_UC; ++u) {
+      const int64_t col = col0 + (int64_t)u * cols_per_block;
+      if (F::kLoadInput && lane_ok && col < batch) p[u] = load_pack<T, V, NT>(x + col * dim + (int64_t)gl * V);
+    }
+#pragma unroll
+    for (int u = 0; u < COL_UC; ++u) {
+      const int64_t col = col0 + (int64_t)u * cols_per_block;
+      T l = T(0);
+      if (lane_ok && col < batch) {
+        l = f.template apply<V>(fsm, p[u], x + col * dim, (int64_t)gl * V, col);
+        store_pack<T, V, NT>(y + col * dim + (int64_t)gl * V, p[u]);
       }
+      l = group_sum_rt(l, G);
+      if (col < batch && gl == 0) {
+        if (ladj_ps) {
+          T out = l + (T)psc;
+          if (accumulate) out += ladj_ps[col];
+          ladj_ps[col] = out;
+        }
+        acc += (double)l;
+      }
+    }
+  } else {
+    for (int uc = 0; uc < COL_UC; ++uc) {
+      const int64_t col = col0 + (int64_t)uc * cols_per_block;
+      T l = T(0);
+      if (col < batch) {
+        const T* xc = x + col * dim;
+        T* yc = y + col * dim;
+        for (int64_t v0 = 0; v0 < nvc; v0 += (int64_t)G * STREAM_U) {
+          Pack<T, V> p[STREAM_U];
 #pragma unroll
-      for (int u = 0; u < STREAM_U; ++u) {
-        int64_t v = v0 + (int64_t)u * G + gl;
-        if (v < nvc) {
-          l += f.template apply<V>(fsm, p[u], xc, v * V, col);
-          store_pack<T, V, NT>(yc + v * V, p[u]);
+          for (int u = 0; u < STREAM_U; ++u) {
+            int64_t v = v0 + (int64_t)u * G + gl;
+            if (F::kLoadInput && v < nvc) p[u] = load_pack<T, V, NT>(xc + v * V);
+          }
+#pragma unroll
+          for (int u = 0; u < STREAM_U; ++u) {
+            int64_t v = v0 + (int64_t)u * G + gl;
+            if (v < nvc) {
+              l += f.template apply<V>(fsm, p[u], xc, v * V, col);
+              store_pack<T, V, NT>(yc + v * V, p[u]);
+            }
+          }
         }
       }
+      l = group_sum_rt(l, G);
+      if (col < batch && gl == 0) {
+        if (ladj_ps) {
+          T out = l + (T)psc;
+          if (accumulate) out += ladj_ps[col];
+          ladj_ps[col] = out;
+        }
+        acc += (double)l;
+      }
     }
-  }
-  l = group_sum_rt(l, G);
-  if (col < batch && gl == 0) {
-    if (ladj_ps) {
-      T out = l + (T)(f.per_sample_const + (f.per_sample_dev ? *f.per_sample_dev : 0.0));
-      if (accumulate) out += ladj_ps[col];
-      ladj_ps[col] = out;
-    }
-    acc = (double)l;
   }
   block_publish_partial(acc, red, fin);
 }
@@ -83,7 +117,8 @@ template <class T> inline ColLaunch col_launch_cfg(const bjx_ctx* ctx, const voi
   while (G < 64 && G < packs) G <<= 1;
   c.G = G;
   (void)ctx;
-  c.grid = (batch + (256 / G) - 1) / (256 / G);
+  const int64_t cpb = (int64_t)(256 / G) * COL_UC;   // columns per block
+  c.grid = (batch + cpb - 1) / cpb;
   return c;
 }
 

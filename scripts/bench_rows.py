@@ -115,7 +115,7 @@ def main():
     mask = bj.PartitionMask(d, list(range(1, d // 2 + 1)), list(range(d // 2 + 1, d + 1)))
     sc = torch.full((d // 2,), 1.5, device=dev)
     cpl = bj.Coupling(lambda x2: bj.Shift(0.25) @ bj.Scale(sc), mask)
-    add("Coupling(Shift∘Scale) d=64", "a20", cpl, x)
+    add("Coupling(Shift∘Scale) d=64 (wrapper expands θ to [n1,batch] per call)", "a20", cpl, x)
 
     only = [s for s in a.only.split(",") if s]
     L, ctx = bj._lib, bj.context(dev)
