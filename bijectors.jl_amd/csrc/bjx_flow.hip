@@ -381,6 +381,37 @@ struct PlanarRegArgs {
   int nl_pad;
 };
 
+// find_alpha for the register kernel: same safeguarded Newton on the reference's bracket
+// (planar_layer.jl:160-185) with tanh from one hardware exp (the OCML tanhf made the inverse flow
+// VALU-bound at 39 % of the HBM roofline); lanes leave the loop individually, the wave runs
+// max-over-lanes iterations (typically 3-5).
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = Fast<float>::exp(-2.0f * fabsf(x));
+  const float t = (1.0f - e) * Fast<float>::rcp(1.0f + e);
+  return x < 0.0f ? -t : t;
+}
+__device__ __forceinline__ float find_alpha_fast(float wy, float c, float b) {
+  const float delta = 2.0f * fabsf(c);
+  float lo = wy - delta, hi = wy + delta;
+  if (lo == hi) return lo;                       // :171-173
+  float a = wy - c * fast_tanh(wy + b);          // one fixed-point step as the start
+  a = a < lo ? lo : (a > hi ? hi : a);
+  for (int it = 0; it < 40; ++it) {
+    const float t = fast_tanh(a + b);
+    const float f = a + c * t - wy;
+    if (f == 0.0f) break;
+    if (f < 0.0f) lo = a; else hi = a;
+    const float fp = 1.0f + c * (1.0f - t * t);
+    float an = a - f * Fast<float>::rcp(fp);
+    if (!(an > lo && an < hi)) an = lo + (hi - lo) * 0.5f;     // safeguard: bisect
+    if (an == a || !(an > lo && an < hi)) break;               // bracket is adjacent floats
+    const float step = fabsf(an - a);
+    a = an;
+    if (step <= Num<float>::eps * fabsf(a)) break;
+  }
+  return a;
+}
+
 // tanh / sech^2 / log1p from one exp (|rel err| ~ 1e-6, Float32 parity bar 1e-3)
 __device__ __forceinline__ void planar_act(float arg, float c, float& th, float& ld) {
   using F = Fast<float>;
@@ -493,7 +524,7 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
           else { if (j > k) a += Gk[j] * t[j]; }        // t holds -tanh for the inverse
         }
         const float bl = A.b[l0 + k], c = A.wtu_hat[l0 + k];
-        const float arg = INV ? find_alpha_dev<float>(a, c, bl) + bl : a + bl;
+        const float arg = INV ? find_alpha_fast(a, c, bl) + bl : a + bl;
         float th, ld;
         planar_act(arg, c, th, ld);
         ladj += INV ? -ld : ld;
