@@ -144,6 +144,8 @@ __device__ __forceinline__ float d_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double d_abs(double x) { return fabs(x); }
 __device__ __forceinline__ float d_max(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ double d_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float d_copysign(float m, float s) { return __builtin_copysignf(m, s); }
+__device__ __forceinline__ double d_copysign(double m, double s) { return __builtin_copysign(m, s); }
 __device__ __forceinline__ bool d_isfinite(float x) { return fabsf(x) < Num<float>::inf; }
 __device__ __forceinline__ bool d_isfinite(double x) { return fabs(x) < Num<double>::inf; }
 
@@ -178,6 +180,7 @@ template <> struct Fast<float> {
   static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
   static __device__ __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
   static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+  static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
   static __device__ __forceinline__ float log1p(float x) {
     // log1p via the compensated log(1+x) * x / ((1+x) - 1) form (exact when 1+x rounds to 1)
     const float u = 1.0f + x;
@@ -192,6 +195,7 @@ template <> struct Fast<double> {
   static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
   static __device__ __forceinline__ double div(double a, double b) { return a / b; }
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+  static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
   static __device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
 };
 

@@ -504,19 +504,58 @@ __global__ __launch_bounds__(64 * CHOL_WPB) void chol_inv_chunk_kernel(const T* 
   if (s < batch) {
     const T* ys = y + s * nv;
     const int e0 = lane * CH;
-    // ---- loads first (all in flight), tile zeroing underneath
+    // ---- the packed vector arrives with COALESCED flat 16-byte loads (pack p = lane + 64 i) and is
+    //      re-dealt through LDS so that lane L holds the contiguous chunk [L*CH, (L+1)*CH).  (Loading the
+    //      chunks directly makes every wave instruction touch 64 different 128-byte lines: the kernel then
+    //      runs at the same 0.29 ms whether or not W is written.)  Chunk pitch CH + V words: the 16-byte
+    //      LDS accesses of both phases are bank-conflict free.  Without WRITE_W there is no LDS tile and the
+    //      chunk is loaded directly.
     Pack<T, V> yp[CHV];
+    if (WRITE_W) {
+      constexpr int S = CH + V;
 #pragma unroll
-    for (int q = 0; q < CHV; ++q) {
-      const int e = e0 + q * V;
-      if (V > 1) {
-        if (e + V <= nv) yp[q] = load_pack<T, V, false>(ys + e);      // nv % V == 0 on this path: whole packs only
-        else {
+      for (int i = 0; i < CHV; ++i) {
+        const int e = (lane + 64 * i) * V;                              // flat element index of this pack
+        Pack<T, V> t;
+        if (V > 1) {
+          if (e + V <= nv) t = load_pack<T, V, true>(ys + e);           // nv % V == 0 on this path: whole packs only
+          else {
 #pragma unroll
-          for (int j = 0; j < V; ++j) yp[q].v[j] = T(0);
+            for (int j = 0; j < V; ++j) t.v[j] = T(0);
+          }
+        } else {
+          t.v[0] = (e < nv) ? ys[e] : T(0);
         }
-      } else {
-        yp[q].v[0] = (e < nv) ? ys[e] : T(0);
+        yp[i] = t;
+      }
+#pragma unroll
+      for (int i = 0; i < CHV; ++i) {
+        const int e = (lane + 64 * i) * V;
+        T* dst = tile + (e / CH) * S + e % CH;
+        if (V > 1) *reinterpret_cast<typename Vec16<T>::type*>(dst) = *reinterpret_cast<const typename Vec16<T>::type*>(&yp[i]);
+        else dst[0] = yp[i].v[0];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < CHV; ++q) {
+        const T* src = tile + lane * S + q * V;
+        if (V > 1) *reinterpret_cast<typename Vec16<T>::type*>(&yp[q]) = *reinterpret_cast<const typename Vec16<T>::type*>(src);
+        else yp[q].v[0] = src[0];
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int q = 0; q < CHV; ++q) {
+        const int e = e0 + q * V;
+        if (V > 1) {
+          if (e + V <= nv) yp[q] = load_pack<T, V, false>(ys + e);
+          else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) yp[q].v[j] = T(0);
+          }
+        } else {
+          yp[q].v[0] = (e < nv) ? ys[e] : T(0);
+        }
       }
     }
     if (WRITE_W) {
@@ -579,7 +618,7 @@ __global__ __launch_bounds__(64 * CHOL_WPB) void chol_inv_chunk_kernel(const T* 
           const T yv = yp[k / V].v[k % V];
           const T t = tt[k];
           const T th = (T(1) - t) * F::rcp(T(1) + t);        // tanh|y|
-          const T wv = __builtin_copysign(th, yv) * F::exp(-excl);   // z * exp(log_remainder) (:383)
+          const T wv = d_copysign(th, yv) * F::exp(-excl);   // z * exp(log_remainder) (:383)
           int wa = addr, da;
           if (LOWER) {
             const bool real = len < K;
@@ -619,6 +658,187 @@ __global__ __launch_bounds__(64 * CHOL_WPB) void chol_inv_chunk_kernel(const T* 
         for (int i = nz * ZV + lane; i < K * K; i += 64) Ws[i] = tile[i];
       } else {
         for (int i = lane; i < K * K; i += 64) Ws[i] = tile[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
+// ------------------------------------------------------------------ VecCholesky forward link, chunk kernel
+// corr.jl:314-337 (_link_chol_lkj_from_upper / _from_lower) with the same decomposition as the
+// inverse chunk kernel: the K x K factor is staged into LDS with coalesced 16-byte loads (the tile IS
+// the input layout), lane L owns packed entries [L*CH, (L+1)*CH) of the OUTPUT vector and gathers
+// its W[i,j] from the tile.  remainder_sq = W[j,j]² + Σ_{k>i} W[k,j]² is a true SUFFIX sum inside a
+// column (a prefix difference would cancel catastrophically: deep entries are ~1e-7 next to O(1)
+// neighbours): each lane walks its chunk in DESCENDING order, and one reversed segmented scan per
+// sample hands it the part of its last column that lives in later lanes.  asinh(w/√rem) =
+// log((|w| + √(w²+rem))/√rem); the first row's atanh(w) (:322) is the same expression with
+// rem := 1 - w² (atanh w = asinh(w/√(1-w²))), so every entry costs one rsq, one sqrt and one log.
+// The log-det -_logabsdetjac_inv_chol(y) (:235-237) reuses the inverse kernel's ascending machinery.
+template <class T> __device__ __forceinline__ T seg_suffix_excl(T v, bool stop, T /*unused*/) {
+  // R(L) = v(L) + (stop(L) ? 0 : R(L+1)); returns R(L+1) (0 for lane 63)
+  const int lane = threadIdx.x & 63;
+  int f = stop ? 1 : 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const T vo = __shfl_down(v, d, 64);
+    const int fo = __shfl_down(f, d, 64);
+    if (lane + d < 64 && !f) { v += vo; f |= fo; }
+  }
+  const T nxt = __shfl_down(v, 1, 64);
+  return lane == 63 ? T(0) : nxt;
+}
+
+template <class T, int V, int CHV, bool LOWER, bool LADJ>
+__global__ __launch_bounds__(64 * CHOL_WPB) void chol_fwd_chunk_kernel(const T* __restrict__ W, T* __restrict__ y, T* __restrict__ ladj_ps, int K,
+                                                             int tile_words, int64_t batch, int accumulate, double* partials) {
+  using F = Fast<T>;
+  constexpr int CH = CHV * V;
+  static_assert(CH <= 32, "wrap mask is 32 bits");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[CHOL_WPB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* tile = reinterpret_cast<T*>(smem) + (size_t)wave * tile_words;
+  const int nv = K * (K - 1) / 2;
+  const int64_t s = (int64_t)blockIdx.x * CHOL_WPB + wave;
+  double acc = 0.0;
+  if (s < batch) {
+    // ---- stage W into the tile (flat copy)
+    {
+      const T* Ws = W + s * (int64_t)K * K;
+      constexpr int ZV = 16 / sizeof(T);
+      const int nz = K * K / ZV;
+      if (bjx_aligned16_dev(Ws)) {
+        constexpr int SU = 8;
+        for (int i0 = lane; i0 < nz; i0 += 64 * SU) {
+          typename Vec16<T>::type t[SU];
+#pragma unroll
+          for (int u = 0; u < SU; ++u) if (i0 + u * 64 < nz) t[u] = __builtin_nontemporal_load(reinterpret_cast<const typename Vec16<T>::type*>(Ws) + i0 + u * 64);
+#pragma unroll
+          for (int u = 0; u < SU; ++u) if (i0 + u * 64 < nz) reinterpret_cast<typename Vec16<T>::type*>(tile)[i0 + u * 64] = t[u];
+        }
+        for (int i = nz * ZV + lane; i < K * K; i += 64) tile[i] = Ws[i];
+      } else {
+        for (int i = lane; i < K * K; i += 64) tile[i] = Ws[i];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int e0 = lane * CH;
+    int c0, i00;
+    triu1_decode(e0, c0, i00);
+    // ---- ascending pass: gather w (and the diagonal at column ends), wrap mask, my contribution to
+    //      earlier lanes' suffixes: pre = Σ w² up to and including my first column end (+ its diagonal²)
+    T wv[CH], aux[CH];     // aux: diagonal (pass 1/2) then logcosh (pass 3/4)
+    unsigned wmask = 0;
+    T pre = T(0);
+    bool seen_wrap = false;
+    {
+      int d = c0 - i00, len = c0;
+      int addr = LOWER ? i00 * K + c0 : c0 * K + i00;
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int ra = addr < tile_words ? addr : 0;                   // phantom entries: any in-bounds word
+        const int da = LOWER ? addr + K : addr + 1;
+        const T w = tile[ra];
+        const T dg = tile[da < tile_words ? da : 0];
+        wv[k] = w; aux[k] = dg;
+        d -= 1;
+        const bool wrap = (d == 0);
+        pre += seen_wrap ? T(0) : w * w + (wrap ? dg * dg : T(0));
+        seen_wrap |= wrap;
+        if (LOWER) addr = wrap ? len + 1 : addr + K;
+        else addr += wrap ? K + 1 - len : 1;
+        len += wrap ? 1 : 0;
+        d = wrap ? len : d;
+        wmask = (wmask << 1) | (wrap ? 1u : 0u);
+      }
+    }
+    const T carry_sfx = seg_suffix_excl<T>(pre, seen_wrap, T(0));
+    // ---- descending pass: suffix of w² inside the column, y
+    {
+      T sfx = carry_sfx;
+#pragma unroll
+      for (int k = CH - 1; k >= 0; --k) {
+        const bool wrap = (wmask >> (CH - 1 - k)) & 1u;
+        const bool head = k == 0 ? (i00 == 0) : ((wmask >> (CH - k)) & 1u);
+        const T w = wv[k];
+        const T w2 = w * w;
+        sfx = wrap ? aux[k] * aux[k] : sfx;                            // remainder_sq starts at W[j,j]² (:318)
+        const T rem = head ? T(1) - w2 : sfx;                          // first row: atanh(w) (:322)
+        const T rs = F::rsqrt(rem);
+        const T q = (d_abs(w) + F::sqrt(w2 + rem)) * rs;
+        wv[k] = d_copysign(F::log(q), w);                      // asinh(w / sqrt(remainder_sq)) (:327-329)
+        sfx += w2;
+      }
+    }
+    // ---- store y: my chunk goes to LDS (pitch CH + V: conflict-free 16-byte accesses; the W tile is dead
+    //      by now) and leaves as COALESCED flat 16-byte stores (pack p = lane + 64 i).  Storing the chunks
+    //      directly makes every wave instruction write 64 partial lines: 14 % of the HBM roofline.
+    {
+      constexpr int S = CH + V;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < CHV; ++q) {
+        T* dst = tile + lane * S + q * V;
+        if (V > 1) {
+          Pack<T, V> p;
+#pragma unroll
+          for (int j = 0; j < V; ++j) p.v[j] = wv[q * V + j];
+          *reinterpret_cast<typename Vec16<T>::type*>(dst) = *reinterpret_cast<const typename Vec16<T>::type*>(&p);
+        } else dst[0] = wv[q];
+      }
+      __builtin_amdgcn_wave_barrier();
+      T* ys = y + s * nv;
+#pragma unroll
+      for (int i = 0; i < CHV; ++i) {
+        const int e = (lane + 64 * i) * V;
+        const T* src = tile + (e / CH) * S + e % CH;
+        if (V > 1) {
+          if (e + V <= nv) {
+            Pack<T, V> p;
+            *reinterpret_cast<typename Vec16<T>::type*>(&p) = *reinterpret_cast<const typename Vec16<T>::type*>(src);
+            store_pack<T, V, true>(ys + e, p);
+          }
+        } else if (e < nv) ys[e] = src[0];
+      }
+    }
+    if (LADJ) {
+      // ---- log-det = -_logabsdetjac_inv_chol(y): Σ_entries incl + Σ_columns incl(last)
+      T tail = T(0);
+      bool has_head = (i00 == 0);
+      {
+        bool prev_wrap = false;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const T ay = d_abs(wv[k]);
+          const T t = F::exp(T(-2) * ay);
+          const T lcv = F::log2(T(1) + t) * Num<T>::log2 + (ay - Num<T>::log2);
+          aux[k] = (e0 + k < nv) ? lcv : T(0);
+          tail = (prev_wrap ? T(0) : tail) + aux[k];
+          has_head |= prev_wrap;
+          prev_wrap = (wmask >> (CH - 1 - k)) & 1u;
+        }
+      }
+      const T incl = seg_prefix_incl<T>(tail, has_head, T(0));
+      const T up = __shfl_up(incl, 1, 64);
+      T run = (i00 == 0 || lane == 0) ? T(0) : up;
+      T lj = T(0);
+      {
+        bool prev_wrap = false;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const bool wrap = (wmask >> (CH - 1 - k)) & 1u;
+          run = (prev_wrap ? T(0) : run) + aux[k];
+          lj += run;
+          lj += wrap ? run : T(0);
+          prev_wrap = wrap;
+        }
+      }
+      lj = group_sum<64>(lj);
+      if (lane == 0) {
+        if (ladj_ps) ladj_ps[s] = accumulate ? ladj_ps[s] + lj : lj;
+        acc = (double)lj;
       }
     }
   }
@@ -730,6 +950,7 @@ int chol_impl(bjx_ctx* ctx, int inverse, int uplo, const T* in, T* out, T* ladj_
     while (cmax * (cmax + 1) / 2 <= (int64_t)64 * CHn - 1) ++cmax;
     int64_t tile_words = cmax * (K + 1) + 1;                      // highest phantom write: [cmax][cmax-1] and its diagonal slot
     if (tile_words < K * K) tile_words = K * K;
+    if (tile_words < (int64_t)64 * (CHn + vv)) tile_words = (int64_t)64 * (CHn + vv);   // staging of the packed vector
     tile_words = (tile_words + 1 + 3) / 4 * 4;                    // + dummy word, 16-byte multiple
     const size_t tile_bytes = out ? (size_t)CHOL_WPB * tile_words * sizeof(T) : 0;
     if (use_chunk && K >= 2 && CHn <= 32 && nv <= 64 * 32 && tile_bytes <= 60 * 1024) {
@@ -760,6 +981,41 @@ int chol_impl(bjx_ctx* ctx, int inverse, int uplo, const T* in, T* out, T* ladj_
     else hipLaunchKernelGGL((chol_inv_kernel<T, false>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, partials);
   } else {
     const int want = (ladj_ps || ladj_sum) ? 1 : 0;
+    {
+      static const int use_chunk = getenv("BJX_CHOL_CHUNK") ? atoi(getenv("BJX_CHOL_CHUNK")) : 1;
+      const int64_t nv = K * (K - 1) / 2;
+      constexpr int VW = Vec16<T>::N;
+      const bool v_ok = bjx_aligned16(out) && nv % VW == 0;
+      const int ch = (int)((nv + 63) / 64);
+      int chv, vv;
+      if (v_ok) { vv = VW; const int need = (ch + VW - 1) / VW; chv = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16; }
+      else { vv = 1; chv = ch <= 2 ? 2 : ch <= 8 ? 8 : ch <= 16 ? 16 : 32; }
+      const int CHn = chv * vv;
+      int64_t tile_words = (K * K + 3) / 4 * 4;
+      if (tile_words < (int64_t)64 * (CHn + vv)) tile_words = (int64_t)64 * (CHn + vv);   // staging of the packed vector
+      const size_t tile_bytes = (size_t)CHOL_WPB * tile_words * sizeof(T);
+      if (use_chunk && K >= 2 && CHn <= 32 && nv <= 64 * 32 && tile_bytes <= 60 * 1024) {
+        const int64_t grid = (batch + CHOL_WPB - 1) / CHOL_WPB;
+        BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+        if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
+        double* partials = ladj_sum ? ctx->partials : nullptr;
+#define CHOLF_K(V_, CHV_, L_, J_) hipLaunchKernelGGL((chol_fwd_chunk_kernel<T, V_, CHV_, L_, J_>), dim3((unsigned)grid), dim3(64 * CHOL_WPB), tile_bytes, ctx->stream, in, out, ladj_ps, (int)K, (int)tile_words, batch, accum, partials)
+#define CHOLF_L(V_, CHV_) do { if (lower) { if (want) CHOLF_K(V_, CHV_, true, true); else CHOLF_K(V_, CHV_, true, false); } else { if (want) CHOLF_K(V_, CHV_, false, true); else CHOLF_K(V_, CHV_, false, false); } } while (0)
+        { BjxProf prof_(ctx);
+        if (vv == VW) {
+          if (chv == 1) CHOLF_L(VW, 1); else if (chv == 2) CHOLF_L(VW, 2); else if (chv == 4) CHOLF_L(VW, 4);
+          else if (chv == 8 && VW * 8 <= 32) CHOLF_L(VW, (VW * 8 <= 32 ? 8 : 1));
+          else if (VW == 2 && chv == 8) CHOLF_L(VW, 8); else CHOLF_L(VW, (VW == 2 ? 16 : 1));
+        } else {
+          if (chv == 2) CHOLF_L(1, 2); else if (chv == 8) CHOLF_L(1, 8); else if (chv == 16) CHOLF_L(1, 16); else CHOLF_L(1, 32);
+        } }
+#undef CHOLF_L
+#undef CHOLF_K
+        BJX_CHECK_LAUNCH(ctx);
+        if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+        return BJX_OK;
+      }
+    }
     BjxProf prof_(ctx);
     hipLaunchKernelGGL((chol_fwd_kernel<T>), dim3((unsigned)grid), dim3(256), 32, ctx->stream, in, out, ladj_ps, K, batch, lower, accum, want, partials);
   }
