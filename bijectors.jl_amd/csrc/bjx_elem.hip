@@ -321,11 +321,21 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
     asm volatile("" : "+v"(lim[j]), "+v"(k1[j]), "+v"(k2a[j]), "+v"(k2b[j]));
   }
   constexpr int SH = sizeof(T) == 4 ? 2 : 3;
+  // uniform block base + 32-bit lane offset: the per-iteration address is one scalar add
+  const int64_t bcol0 = (int64_t)blockIdx.x * iters * cols_per_block;
+  const T* xb = x + bcol0 * dim;
+  T* yb = y + bcol0 * dim;
+  T* lb_ps = ladj_ps ? ladj_ps + bcol0 : nullptr;
+  const int cg = threadIdx.x / G;
+  const int loff = cg * (int)dim + gl * V;                 // < 2^31: a block spans iters*cols_per_block*dim elements
+  const int64_t left = batch - bcol0 - cg;                 // my columns: it*cols_per_block < left
+  const int my_cols = left > (int64_t)iters * cols_per_block ? iters * cols_per_block : (left > 0 ? (int)left : 0);
+  const int64_t it_stride = (int64_t)cols_per_block * dim;
   for (int it = 0; it < iters; ++it) {
-    const int64_t col = ((int64_t)blockIdx.x * iters + it) * cols_per_block + threadIdx.x / G;
+    const bool col_ok = it * cols_per_block < my_cols;
     T l = T(0);
-    if (col < batch && lane_ok) {
-      Pack<T, V> p = load_pack<T, V, true>(x + col * dim + (int64_t)gl * V);
+    if (col_ok && lane_ok) {
+      Pack<T, V> p = load_pack<T, V, true>(xb + loff);
       int pos[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) {
@@ -348,13 +358,16 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
       }
 #pragma unroll
       for (int j = 0; j < V; ++j) l += rqs_eval<T, INV>(A[j], B[j], lim[j], p.v[j]);
-      store_pack<T, V, true>(y + col * dim + (int64_t)gl * V, p);
+      store_pack<T, V, true>(yb + loff, p);
     }
     l = group_sum_rt(l, G) * Num<T>::log2;          // log2 -> natural log, once per column
-    if (col < batch && gl == 0) {
-      if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + l : l;
+    if (col_ok && gl == 0) {
+      if (lb_ps) lb_ps[cg] = accumulate ? lb_ps[cg] + l : l;
       acc += (double)l;
     }
+    xb += it_stride;
+    yb += it_stride;
+    if (lb_ps) lb_ps += cols_per_block;
   }
 }
 

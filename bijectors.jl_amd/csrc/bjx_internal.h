@@ -225,6 +225,21 @@ template <class T> __device__ __forceinline__ T group_sum_rt(T v, int G) {
   for (int m = G >> 1; m >= 1; m >>= 1) v += shfl_xor(v, m);
   return v;
 }
+// Float32: the four in-row stages as DPP butterflies (one v_add_f32 with a DPP operand each, no LDS
+// crossbar traffic, no per-stage address arithmetic: a ds_bpermute stage costs ~6 VALU + 1 LDS op);
+// the two cross-row stages stay shuffles.  G is wave-uniform, so the branches are scalar.
+template <int CTRL> __device__ __forceinline__ float dpp_xadd(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <> __device__ __forceinline__ float group_sum_rt<float>(float v, int G) {
+  if (G >= 2) v = dpp_xadd<0xB1>(v);     // quad_perm [1,0,3,2]
+  if (G >= 4) v = dpp_xadd<0x4E>(v);     // quad_perm [2,3,0,1]
+  if (G >= 8) v = dpp_xadd<0x141>(v);    // row_half_mirror (quads already uniform)
+  if (G >= 16) v = dpp_xadd<0x140>(v);   // row_mirror (halves already uniform)
+  if (G >= 32) v += shfl_xor(v, 16);
+  if (G >= 64) v += shfl_xor(v, 32);
+  return v;
+}
 
 // Block-wide sum of one double per thread -> partials[blockIdx.x] (fixed order, deterministic).
 // `red` is an LDS array of >= blockDim.x/64 doubles.
