@@ -331,11 +331,15 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
   const int64_t left = batch - bcol0 - cg;                 // my columns: it*cols_per_block < left
   const int my_cols = left > (int64_t)iters * cols_per_block ? iters * cols_per_block : (left > 0 ? (int)left : 0);
   const int64_t it_stride = (int64_t)cols_per_block * dim;
+  // one pack of look-ahead: the next column's load is in flight while this one is evaluated
+  Pack<T, V> pnext;
+  if (0 < my_cols && lane_ok) pnext = load_pack<T, V, true>(xb + loff);
   for (int it = 0; it < iters; ++it) {
     const bool col_ok = it * cols_per_block < my_cols;
     T l = T(0);
+    Pack<T, V> p = pnext;
+    if ((it + 1) * cols_per_block < my_cols && lane_ok) pnext = load_pack<T, V, true>(xb + it_stride + loff);
     if (col_ok && lane_ok) {
-      Pack<T, V> p = load_pack<T, V, true>(xb + loff);
       int pos[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) {
