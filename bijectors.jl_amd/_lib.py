@@ -33,6 +33,14 @@ class BjxOp(C.Structure):
     ]
 
 
+BJX_MAX_SEG_OPS = 4
+
+
+class BjxSegment(C.Structure):
+    _fields_ = [("in_lo", C.c_int64), ("out_lo", C.c_int64), ("len", C.c_int64), ("n_ops", C.c_int32), ("reserved", C.c_int32),
+                ("ops", BjxOp * BJX_MAX_SEG_OPS)]
+
+
 _vp, _i, _i64, _u32, _u64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
 _tail = [_vp, _vp, _i64, _i64, _u32]  # ladj_ps, ladj_sum, dim/K, batch, flags
 
@@ -47,6 +55,7 @@ SIGNATURES = {
     "bjx_version": (_i, []),
     "bjx_workspace_bytes": (C.c_size_t, [_vp]),
     "bjx_synchronize": (_i, [_vp]),
+    "bjx_stacked": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _vp, _vp, _vp, _i64, _i64, _u32]),
     "bjx_set_option": (_i, [_vp, _i, _i]),
     "bjx_chain": (_i, [_vp, _i, C.POINTER(BjxOp), _i, _vp, _vp] + _tail),
     "bjx_ordered": (_i, [_vp, _i, _i, _vp, _vp] + _tail),

@@ -31,7 +31,7 @@ __all__ = [
     "Transform", "Bijector", "Inverse", "ComposedFunction", "Elementwise", "elementwise", "exp", "log", "identity",
     "Shift", "Scale", "Logit", "LeakyReLU", "TruncatedBijector", "SignFlip", "OrderedBijector", "SimplexBijector",
     "VecCholeskyBijector", "Permute", "PlanarLayer", "RadialLayer", "InvertibleBatchNorm", "RationalQuadraticSpline",
-    "PartitionMask", "Coupling", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
+    "PartitionMask", "Coupling", "Stacked", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
     "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
     "PlanarResult",
 ]
@@ -242,7 +242,9 @@ class Inverse(Transform):
 
 
 def inverse(t):
-    """src/interface.jl:265-266 (+ shift.jl:12, leaky_relu.jl:16, composed inverse)"""
+    """src/interface.jl:265-266 (+ shift.jl:12, leaky_relu.jl:16, composed inverse, stacked.jl:113-118)"""
+    if type(t).__name__ == "Stacked":
+        return t._inverse()
     if isinstance(t, Inverse):
         return t.orig
     if isinstance(t, ComposedFunction):
@@ -343,6 +345,8 @@ def output_size(b, sz):
     sz = tuple(sz)
     if isinstance(b, ComposedFunction):
         return output_size(b.outer, output_size(b.inner, sz))
+    if type(b).__name__ == "Stacked":  # stacked.jl:127
+        return (b.length_out,) + sz[1:]
     if isinstance(b, SimplexBijector):  # simplex.jl:6-12
         return (sz[0] - 1,) + sz[1:]
     if isinstance(b, Inverse) and isinstance(b.orig, SimplexBijector):
@@ -993,3 +997,107 @@ class Coupling(Bijector):
 
     def _wlj_inv(self, x, per_sample, want_ladj=True):
         return self._run(x, True, per_sample, want_ladj)
+
+
+# ------------------------------------------------------------------ Stacked (SURVEY.md §8f, f-4)
+def _elementwise_ops(b):
+    """[(kind, p0, p1)] in application order if `b` is a (chain of) elementwise bijector(s), else None."""
+    if b is identity:          # `identity` is its own bijector in the reference (stacked.jl:21-23 example)
+        return []
+    return _fused_ops(b)
+
+
+class Stacked(Transform):
+    """src/bijectors/stacked.jl:27-252.  `Stacked(bs)` applies bs[i] to row i; `Stacked(bs, ranges)` applies
+    bs[i] to x[ranges[i]] where ranges[i] = (lo, hi) is Julia's lo:hi (1-based, inclusive).  The output is
+    the concatenation of the pieces in the order of `bs` (ranges_out are cumulative, :50-57).
+
+    Every segment whose bijector is a chain of at most 4 elementwise ops is evaluated by ONE fused launch
+    (bjx_stacked) over all columns; a structured segment (Simplex, Ordered, ...) is sliced out, sent through
+    its own entry point and written back."""
+
+    def __init__(self, bs, ranges=None):
+        self.bs = list(bs) if isinstance(bs, (list, tuple)) else [bs]
+        if ranges is None:
+            ranges = [(i + 1, i + 1) for i in range(len(self.bs))]                    # :46-48
+        self.ranges_in = [(int(lo), int(hi)) for lo, hi in ranges]
+        if len(self.ranges_in) != len(self.bs):
+            raise ValueError("length(bs) == length(ranges) needs to be true")           # :14
+        self.ranges_out, off = [], 0
+        for b, (lo, hi) in zip(self.bs, self.ranges_in):                                # determine_output_ranges :50-57
+            n_out = (hi - lo + 1) if b is identity else output_size(b, (hi - lo + 1,))[0]
+            self.ranges_out.append((off + 1, off + n_out))
+            off += n_out
+        self.length_in = sum(hi - lo + 1 for lo, hi in self.ranges_in)
+        self.length_out = off
+
+    def _key(self):
+        return (tuple(self.bs), tuple(self.ranges_in))
+
+    def _inverse(self):                                                                  # :113-118
+        inv = Stacked.__new__(Stacked)
+        inv.bs = [b if b is identity else inverse(b) for b in self.bs]
+        inv.ranges_in, inv.ranges_out = list(self.ranges_out), list(self.ranges_in)
+        inv.length_in, inv.length_out = self.length_out, self.length_in
+        return inv
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        xc, dim, batch, vec = _prep(x)
+        if dim != self.length_in:
+            raise ValueError(f"input length mismatch ({self.length_in} != {dim})")       # :157
+        segs_ops = [_elementwise_ops(b) for b in self.bs]
+        fused = [i for i, o in enumerate(segs_ops) if o is not None and len(o) <= L.BJX_MAX_SEG_OPS]
+        rest = [i for i in range(len(self.bs)) if i not in fused]
+        ctx = context(xc.device)
+        y = _empty(self.length_out, batch, xc, vec)
+        out = _Out(xc, batch, per_sample, want_ladj)
+        if not rest and self.length_out == dim:
+            arr = (L.BjxSegment * max(len(self.bs), 1))()
+            keep = []
+            for si, i in enumerate(fused):
+                (lo, hi), (olo, _) = self.ranges_in[i], self.ranges_out[i]
+                sg = arr[si]
+                sg.in_lo, sg.out_lo, sg.len, sg.n_ops = lo - 1, olo - 1, hi - lo + 1, len(segs_ops[i])
+                for k, (kind, p0, p1) in enumerate(segs_ops[i]):
+                    o = sg.ops[k]
+                    o.kind, o.param_len, o.p0, o.p1, o.v0, o.v1 = kind, 0, 0.0, 0.0, None, None
+                    seq = any(_is_seq(p) for p in (p0, p1) if p is not None)
+                    for j, p in enumerate((p0, p1)):
+                        if p is None:
+                            continue
+                        if seq:
+                            t = _param(p, xc).reshape(-1) if _is_seq(p) else torch.full((sg.len,), float(p), dtype=xc.dtype, device=xc.device)
+                            if t.numel() != sg.len:
+                                raise ValueError(f"DimensionMismatch: parameter of length {t.numel()} for a segment of {sg.len} rows")
+                            keep.append(t)
+                            o.param_len = sg.len
+                            setattr(o, f"v{j}", t.data_ptr())
+                        else:
+                            o.param_len = 1
+                            setattr(o, f"p{j}", float(p))
+            rc = L.load().bjx_stacked(ctx.h, _dt(xc), arr, len(fused), _ptr(xc), _ptr(y), _ptr(out.ps), _ptr(out.sum), dim, batch, 0)
+            L.check(ctx.h, rc, "bjx_stacked")
+            del keep
+            return (y, out.result(vec_scalar=vec and bool(per_sample) and per_sample is True)) if want_ladj else (y, None)
+        # general case: per-segment launches on row slices (copies); log-dets are summed like :236-244
+        total = None
+        x2 = xc if not vec else xc[:, None]
+        y2 = y if not vec else y[:, None]
+        for b, (lo, hi), (olo, ohi) in zip(self.bs, self.ranges_in, self.ranges_out):
+            piece = colmajor(x2[lo - 1:hi, :])
+            if b is identity:
+                b = Shift(0.0)
+            yp, lp = b._wlj(piece, per_sample="both" if want_ladj else False, want_ladj=want_ladj)
+            y2[olo - 1:ohi, :] = yp
+            if want_ladj:
+                total = lp if total is None else (total[0] + lp[0], total[1] + lp[1])
+        if not want_ladj:
+            return y, None
+        ps, sm = total
+        if out.both:
+            return y, (ps, sm)
+        if out.sum64:
+            return y, sm
+        if per_sample:
+            return y, (ps[0] if vec else ps)
+        return y, sm[0].to(xc.dtype)

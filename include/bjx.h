@@ -197,6 +197,26 @@ int bjx_coupling_rqs(bjx_ctx* ctx, bjx_dtype dt, int inverse, const int32_t* idx
                      const void* in, void* out, void* ladj_ps, double* ladj_sum,
                      int64_t dim, int64_t batch, uint32_t flags);
 
+/* ------------------------------- Stacked with elementwise segments   */
+/* Stacked(bs, ranges), src/bijectors/stacked.jl:27-252: y = vcat(bs[i](x[ranges_in[i]])...) and
+ * logabsdetjac = Σ_i sum(logabsdetjac(bs[i], x[ranges_in[i]])) (:172-196), applied to every column
+ * of X[dim, batch] in ONE launch.  Segment i reads rows [in_lo, in_lo+len) and writes rows
+ * [out_lo, out_lo+len) (0-based; `ranges_out` are the cumulative output ranges of :50-57); its
+ * bijector is a chain of <= BJX_MAX_SEG_OPS elementwise ops (bjx_op, parameters scalar or one
+ * device value per row of the segment).  The segments must use every row exactly once
+ * ("input length mismatch", :157).  `segs` is HOST memory; the call copies it.
+ * Segments whose bijector is not elementwise (Simplex, Ordered, ...) are the host wrapper's job
+ * (slice -> structured entry point -> write back). */
+#define BJX_MAX_SEG_OPS 4
+typedef struct {
+  int64_t in_lo, out_lo, len;
+  int32_t n_ops;      /* 0 = identity */
+  int32_t reserved;
+  bjx_op ops[BJX_MAX_SEG_OPS];
+} bjx_segment;
+int bjx_stacked(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const void* x, void* y,
+                void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
+
 /* ------------------------------- multi-GPU                */
 /* RCCL communicator owned by the context (one process per GPU).  `unique_id` is the 128-byte
  * ncclUniqueId made by bjx_comm_unique_id on rank 0 and broadcast by the host (Julia: MPI.jl

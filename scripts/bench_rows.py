@@ -117,6 +117,11 @@ def main():
     cpl = bj.Coupling(lambda x2: bj.Shift(0.25) @ bj.Scale(sc), mask)
     add("Coupling(Shift∘Scale) d=64 (wrapper expands θ to [n1,batch] per call)", "a20", cpl, x)
 
+    stk = bj.Stacked([e(bj.exp), bj.Logit(0.0, 1.0), bj.identity, e(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5)], [(1, 16), (17, 32), (33, 48), (49, 64)])
+    xst = x.clone()
+    xst[16:32] = xunit[16:32]
+    add("Stacked(exp|Logit|identity|exp∘Shift∘Scale) d=64", "f-4", stk, xst)
+
     only = [s for s in a.only.split(",") if s]
     L, ctx = bj._lib, bj.context(dev)
     lib = L.load()

@@ -546,3 +546,84 @@ def test_inkernel_finalize_is_bit_identical_to_two_pass(bj):
     _, lps0, _ = bj.shard.with_logabsdet_jacobian_sharded(layer, xs[0], out=y)
     assert abs(float(two_pass[0]) - float(lps0.double().sum())) <= 1e-9 * max(1.0, abs(float(two_pass[0])))
     assert not torch.equal(two_pass[0], two_pass[1])
+
+
+# ------------------------------------------------------------------ §8(f) f-4: Stacked
+def _stacked_oracle(orc, segs, X):
+    """vcat of the per-segment chain results + summed log-dets (stacked.jl:142-165, :236-244)."""
+    ys, l = [], np.zeros(X.shape[1])
+    for ops, (lo, hi) in segs:
+        piece = np.asfortranarray(X[lo - 1:hi, :])
+        if ops:
+            y, _ = orc.chain(ops, piece)
+            lp = np.array([float(orc.chain(ops, np.asfortranarray(piece[:, [c]]))[1]) for c in range(X.shape[1])])
+        else:
+            y, lp = piece.copy(), np.zeros(X.shape[1])
+        ys.append(y)
+        l += lp
+    return np.vstack(ys), l
+
+
+def test_stacked_reference_examples(bj):
+    # test/bijectors/stacked.jl:100-108: Stacked(exp, log, Shift(5))(ones(3)) == [e, 0, 6], ladj = sum of parts
+    b = bj.Stacked([bj.elementwise(bj.exp), bj.elementwise(bj.log), bj.Shift(5.0)])
+    y, l = bj.with_logabsdet_jacobian(b, torch.ones(3, dtype=torch.float64, device="cuda"))
+    np.testing.assert_allclose(host(y), [math.e, 0.0, 6.0], rtol=1e-15)
+    assert abs(float(l) - (1.0 - 0.0 + 0.0)) < 1e-15
+    # docstring stacked.jl:17-24: Stacked(Logit(0,1), identity)([0.0, 1.0]) == [logit(0.0), 1.0]
+    b2 = bj.Stacked([bj.Logit(0.0, 1.0), bj.identity])
+    y2 = bj.transform(b2, torch.tensor([0.25, 1.0], dtype=torch.float64, device="cuda"))
+    np.testing.assert_allclose(host(y2), [math.log(0.25 / 0.75), 1.0], rtol=1e-12)
+    with pytest.raises(ValueError, match="input length mismatch"):                   # stacked.jl:157
+        bj.transform(b2, torch.ones(3, dtype=torch.float64, device="cuda"))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("N", [1, 257])
+def test_stacked_elementwise_segments_one_launch(bj, orc, dt, N):
+    r = rng(41)
+    a_vec = np.linspace(0.5, 2.0, 7)
+    segs = [  # (mirror bijector, oracle ops, (lo, hi) 1-based inclusive)
+        (bj.elementwise(bj.exp), [(orc.OP_EXP, None, None)], (1, 5)),
+        (bj.identity, [], (6, 6)),
+        (bj.Logit(-1.0, 2.0), [(orc.OP_LOGIT, -1.0, 2.0)], (7, 19)),
+        (bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(torch.tensor(a_vec)), [(orc.OP_SCALE, a_vec, None), (orc.OP_SHIFT, 0.1, None), (orc.OP_EXP, None, None)], (20, 26)),
+        (bj.inverse(bj.TruncatedBijector(0.0, 3.0)), [(orc.OP_TRUNCATED_INV, 0.0, 3.0)], (27, 40)),
+        (bj.elementwise(bj.log), [(orc.OP_LOG, None, None)], (41, 41)),
+    ]
+    dim = 41
+    X = r.normal(size=(dim, N))
+    X[6:19] = r.uniform(-0.9, 1.9, size=(13, N))
+    X[40] = r.uniform(0.1, 3.0, size=N)
+    X = np.asfortranarray(X.astype(dt))
+    b = bj.Stacked([s[0] for s in segs], [s[2] for s in segs])
+    Y_ref, l_ref = _stacked_oracle(orc, [(s[1], s[2]) for s in segs], X)
+    Y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+    close(host(Y), Y_ref, dt, what="stacked y")
+    close(host(l), l_ref, dt, scale=dim, what="stacked ladj")
+    _, lsum = bj.with_logabsdet_jacobian(b, dev(X))
+    sum_close(host(lsum), l_ref.sum(), dt, dim * N)
+    # inverse(Stacked) undoes it and negates the log-det (stacked.jl:113-118)
+    Xb, lb = bj.with_logabsdet_jacobian(bj.inverse(b), dev(Y_ref), per_sample=True)
+    close(host(Xb), X, dt, scale=10, what="stacked inverse")
+    close(host(lb), -l_ref, dt, scale=dim * 10, what="stacked inverse ladj")
+
+
+def test_stacked_permuted_ranges_and_structured_segments(bj, orc):
+    r = rng(42)
+    N = 50
+    # ranges_in out of order: the output is the concatenation in the order of `bs` (stacked.jl:50-57)
+    b = bj.Stacked([bj.elementwise(bj.exp), bj.Scale(2.0)], [(4, 6), (1, 3)])
+    X = np.asfortranarray(r.normal(size=(6, N)))
+    Y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+    np.testing.assert_allclose(host(Y), np.vstack([np.exp(X[3:6]), 2.0 * X[0:3]]), rtol=1e-12)
+    np.testing.assert_allclose(host(l), X[3:6].sum(axis=0) + 3 * math.log(2.0), rtol=1e-12)
+    # a structured segment (Simplex: 5 rows -> 4) next to an elementwise one: per-segment launches
+    P = np.asfortranarray(r.dirichlet(np.ones(5), size=N).T)
+    X2 = np.asfortranarray(np.vstack([P, r.normal(size=(2, N))]))
+    b2 = bj.Stacked([bj.SimplexBijector(), bj.elementwise(bj.exp)], [(1, 5), (6, 7)])
+    assert bj.output_size(b2, (7,)) == (6,)
+    Y2, l2 = bj.with_logabsdet_jacobian(b2, dev(X2), per_sample=True)
+    ys_ref, ls_ref = orc.simplex(P)
+    np.testing.assert_allclose(host(Y2), np.vstack([ys_ref, np.exp(X2[5:7])]), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(host(l2), ls_ref + X2[5:7].sum(axis=0), rtol=1e-9, atol=1e-12)
