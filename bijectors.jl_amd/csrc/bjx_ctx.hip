@@ -133,6 +133,8 @@ BJX_API int bjx_destroy(bjx_ctx* ctx) {
   if (ctx->partials2) (void)hipFree(ctx->partials2);
   if (ctx->consts) (void)hipFree(ctx->consts);
   if (ctx->fin_counter) (void)hipFree(ctx->fin_counter);
+  if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
+  if (ctx->stage_ev) (void)hipEventDestroy(ctx->stage_ev);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

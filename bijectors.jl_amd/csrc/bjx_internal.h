@@ -17,6 +17,7 @@
 constexpr int BJX_MAX_BLOCKS = 4096;        // persistent-grid cap AND size of the 2nd-stage partial buffer
 constexpr int BJX_CONSTS = 8;               // device doubles for parameter-only log-det terms
 constexpr size_t BJX_SCRATCH_BYTES = 1 << 20;  // û tables, small parameter staging
+constexpr size_t BJX_HOST_STAGE_BYTES = 256 << 10;  // pinned host staging for descriptor lists (bjx_stacked)
 
 struct bjx_ctx {
   int device = 0;
@@ -24,6 +25,8 @@ struct bjx_ctx {
   double* partials = nullptr;   // [partials_cap] one f64 per publishing block (grown on demand, cached)
   size_t partials_cap = 0;
   double* partials2 = nullptr;  // [BJX_MAX_BLOCKS] second reduction stage
+  void* host_stage = nullptr;      // pinned, BJX_HOST_STAGE_BYTES, created on first use
+  hipEvent_t stage_ev = nullptr;   // recorded after the last copy out of host_stage
   unsigned* fin_counter = nullptr;  // arrival counter of the in-kernel finalize (zero between launches)
   double* consts = nullptr;     // [BJX_CONSTS]
   void* scratch = nullptr;      // [BJX_SCRATCH_BYTES]
@@ -151,6 +154,9 @@ __device__ __forceinline__ bool d_isfinite(double x) { return fabs(x) < Num<doub
 
 // src/Bijectors.jl:95-100
 template <class T> __device__ __forceinline__ T d_clamp(T x, T a, T b) { return x < a ? a : (x > b ? b : x); }
+// clamp in one instruction (v_med3_f32); bounds may be +-inf
+__device__ __forceinline__ float d_med3(float x, float a, float b) { return __builtin_amdgcn_fmed3f(x, a, b); }
+__device__ __forceinline__ double d_med3(double x, double a, double b) { return fmin(fmax(x, a), b); }
 template <class T> __device__ __forceinline__ T d_logit(T x) { return d_log(x / (T(1) - x)); }
 template <class T> __device__ __forceinline__ T d_logistic(T x) {
   T e = d_exp(x);

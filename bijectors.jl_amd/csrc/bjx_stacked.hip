@@ -15,11 +15,30 @@
 namespace {
 using namespace bjx;
 
-template <class T> struct StackedRow {
-  int32_t src;                       // input row feeding this output row
-  uint32_t kinds;                    // op kinds, 8 bits each, applied from the low byte up (0 = end)
-  T p0[BJX_MAX_SEG_OPS];
-  T p1[BJX_MAX_SEG_OPS];             // SCALE / SCALE_INV: ± log|a| (the parameter-only log-det term)
+// ---- canonical slot: every chain of elementwise bijectors is (a composition of at most two of)
+//        y = clamp_post( a2 · N( a1 · clamp_pre(x) + b1 ) + b2 ),   N ∈ {id, exp, log, logit, logistic, leaky}
+//      log|J| = ladj_N(a1·x+b1) + log|a1| + log|a2|
+//   exp ∘ Shift(b) ∘ Scale(a)      -> N = exp, a1 = a, b1 = b                        (one slot instead of three ops)
+//   Logit(lo, hi)                  -> N = logit, a1 = 1/(hi-lo), b1 = -lo/(hi-lo)    (logit.jl:15,24)
+//   inverse(Logit(lo, hi))         -> N = logistic, a2 = hi-lo, b2 = lo              (logit.jl:19)
+//   TruncatedBijector(lo, hi)      -> clamp_pre + logit / log(x-lo) / log(hi-x) / id (truncated.jl:15-31,51-67)
+//   inverse(TruncatedBijector)     -> logistic / exp with a2, b2 and clamp_post      (truncated.jl:33-49,71-91)
+// The per-row compile runs on the device (one thread per output row walks its op list), so per-row
+// vector parameters fold exactly like scalars.  The streaming kernel then has a 6-way switch per slot
+// instead of the 12-way op switch per op (which, unrolled over 16 elements x 3 ops, produced a 120 KB
+// kernel that thrashed the instruction cache: 19 % of the HBM roofline).
+enum { SK_END = 0, SK_ID = 1, SK_EXP = 2, SK_LOG = 3, SK_LOGIT = 4, SK_LOGISTIC = 5, SK_LEAKY = 6 };
+constexpr int STACKED_SLOTS = 2;
+
+template <class T> struct alignas(16) Slot {      // 12 words (Float32), 16-byte aligned so a slot is read with vector loads
+  T clo, chi;      // pre-clamp  (-inf, +inf when absent)
+  T a1, b1;
+  T a2, b2;
+  T plo, phi;      // post-clamp
+  T alpha;         // LeakyReLU slope
+  T c;             // log|a1| + log|a2| (+ log|hi-lo| terms)
+  int32_t kind;
+  int32_t src;     // slot 0 only: input row feeding this output row
 };
 
 struct SegDev {                      // device copy of one bjx_segment (pointers are device pointers)
@@ -31,90 +50,132 @@ struct SegDev {                      // device copy of one bjx_segment (pointers
   const void* v1[BJX_MAX_SEG_OPS];
 };
 
-// flag[0] |= 1 if some output row is not the identity source (then the main kernel gathers)
+// Table layout: one entry of STACKED_SLOTS slots per OUTPUT row, padded to an ODD number of 16-byte units
+// (7 for Float32, 11 for Float64) and indexed by the PERMUTED row rp = (row % V)·nvc + row / V, so that
+// the rows one wave instruction touches (same element of consecutive packs) are adjacent: their 16-byte
+// LDS reads then fall into different bank groups.  (Unpermuted, a 96-byte entry put 16 lanes on 2 bank
+// groups: SQ_LDS_BANK_CONFLICT = 89 % of the LDS cycles and 23 % of the HBM roofline.)
+template <class T> __host__ __device__ constexpr size_t stacked_row_bytes() {
+  return ((STACKED_SLOTS * sizeof(Slot<T>) + 15) / 16) % 2 == 1 ? (STACKED_SLOTS * sizeof(Slot<T>) + 15) / 16 * 16
+                                                                : (STACKED_SLOTS * sizeof(Slot<T>) + 15) / 16 * 16 + 16;
+}
+__host__ __device__ inline int64_t stacked_row_index(int64_t row, int V, int64_t nvc) { return V > 1 ? (row % V) * nvc + row / V : row; }
+
+template <class T> __device__ __forceinline__ void slot_reset(Slot<T>& s) {
+  s.clo = -Num<T>::inf; s.chi = Num<T>::inf; s.a1 = T(1); s.b1 = T(0); s.a2 = T(1); s.b2 = T(0);
+  s.plo = -Num<T>::inf; s.phi = Num<T>::inf; s.alpha = T(1); s.c = T(0); s.kind = SK_ID; s.src = 0;
+}
+
+// flag[0] |= 1: some row is not its own source (gather); flag[0] |= 2: a chain needs more than two slots
 template <class T>
-__global__ __launch_bounds__(256) void stacked_table_kernel(const SegDev* segs, int n_segs, int64_t dim, StackedRow<T>* tab, int* flag) {
-  for (int64_t r = threadIdx.x; r < dim; r += blockDim.x) { tab[r].src = -1; tab[r].kinds = 0; }
-  __syncthreads();
-  int gather = 0;
-  for (int s = 0; s < n_segs; ++s) {
-    const SegDev& g = segs[s];
+__global__ __launch_bounds__(256) void stacked_table_kernel(const SegDev* segs, int n_segs, int64_t dim, int V, char* tab, int* flag) {
+  const int64_t nvc = dim / V;
+  int bits = 0;
+  for (int sidx = 0; sidx < n_segs; ++sidx) {
+    const SegDev& g = segs[sidx];
+    if (g.in_lo != g.out_lo) bits |= 1;
     for (int64_t i = threadIdx.x; i < g.len; i += blockDim.x) {
-      StackedRow<T> row;
-      row.src = (int32_t)(g.in_lo + i);
-      row.kinds = 0;
-      if (g.in_lo != g.out_lo) gather = 1;
-      for (int k = 0; k < BJX_MAX_SEG_OPS; ++k) {
-        row.p0[k] = T(0); row.p1[k] = T(0);
-        if (k < g.n_ops) {
-          const int kind = g.kind[k];
-          row.kinds |= (uint32_t)kind << (8 * k);
-          T a = g.plen[k] > 1 ? reinterpret_cast<const T*>(g.v0[k])[i] : (g.plen[k] == 1 && g.v0[k] ? reinterpret_cast<const T*>(g.v0[k])[0] : (T)g.s0[k]);
-          T b = (g.plen[k] > 1 && g.v1[k]) ? reinterpret_cast<const T*>(g.v1[k])[i] : (g.plen[k] == 1 && g.v1[k] ? reinterpret_cast<const T*>(g.v1[k])[0] : (T)g.s1[k]);
-          if (kind == BJX_OP_SCALE) b = d_log(d_abs(a));                          // scale.jl:26-32
-          if (kind == BJX_OP_SCALE_INV) { b = -d_log(d_abs(a)); a = T(1) / a; }     // Scale(inv(a)), scale.jl:15-16
-          row.p0[k] = a; row.p1[k] = b;
+      Slot<T> sl[STACKED_SLOTS];
+      int cur = 0;
+      bool has_n = false;        // the current slot already has its nonlinearity
+      bool seen_affine = false;  // ... or a folded affine op (value-independent: the host counts slots the same way)
+      bool post_clamped = false;
+      bool overflow = false;
+      slot_reset(sl[0]);
+      for (int k = 0; k < g.n_ops; ++k) {
+        const int kind = g.kind[k];
+        const T a = g.plen[k] > 1 ? reinterpret_cast<const T*>(g.v0[k])[i] : (g.plen[k] == 1 && g.v0[k] ? reinterpret_cast<const T*>(g.v0[k])[0] : (T)g.s0[k]);
+        const T b = (g.plen[k] > 1 && g.v1[k]) ? reinterpret_cast<const T*>(g.v1[k])[i] : (g.plen[k] == 1 && g.v1[k] ? reinterpret_cast<const T*>(g.v1[k])[0] : (T)g.s1[k]);
+        const bool affine = kind == BJX_OP_SHIFT || kind == BJX_OP_SCALE || kind == BJX_OP_SCALE_INV || kind == BJX_OP_SIGNFLIP || kind == BJX_OP_IDENTITY;
+        Slot<T>* s = &sl[cur];
+        if (affine) {
+          T m = T(1), t = T(0);
+          if (kind == BJX_OP_SHIFT) t = a;                        // shift.jl:14
+          else if (kind == BJX_OP_SCALE) m = a;                   // scale.jl:13
+          else if (kind == BJX_OP_SCALE_INV) m = T(1) / a;        // scale.jl:15-16
+          else if (kind == BJX_OP_SIGNFLIP) m = T(-1);            // ordered.jl:3
+          if (has_n && post_clamped) {
+            if (cur + 1 < STACKED_SLOTS) { ++cur; s = &sl[cur]; slot_reset(*s); has_n = false; post_clamped = false; seen_affine = false; }
+            else { overflow = true; continue; }
+          }
+          seen_affine = true;
+          if (!has_n) { s->a1 *= m; s->b1 = s->b1 * m + t; } else { s->a2 *= m; s->b2 = s->b2 * m + t; }
+          s->c += d_log(d_abs(m));                                // scale.jl:26-32 (0 for Shift)
+          continue;
+        }
+        // a nonlinearity: needs a slot without one (and, for the clamping ones, a fresh slot)
+        const bool clamps = kind == BJX_OP_TRUNCATED;
+        if (has_n || (clamps && seen_affine)) {
+          if (cur + 1 < STACKED_SLOTS) { ++cur; s = &sl[cur]; slot_reset(*s); post_clamped = false; seen_affine = false; } else { overflow = true; continue; }
+        }
+        has_n = true;
+        if (kind == BJX_OP_TRUNCATED_INV) post_clamped = true;
+        const T lo = a, hi = b;
+        const bool lb = d_isfinite(lo), ub = d_isfinite(hi);
+        switch (kind) {
+          case BJX_OP_EXP: s->kind = SK_EXP; break;
+          case BJX_OP_LOG: s->kind = SK_LOG; break;
+          case BJX_OP_LOGIT: { const T w = hi - lo; s->a1 = s->a1 / w; s->b1 = (s->b1 - lo) / w; s->c -= d_log(w); s->kind = SK_LOGIT; } break;
+          case BJX_OP_LOGIT_INV: { const T w = hi - lo; s->a2 = w; s->b2 = lo; s->c += d_log(w); s->kind = SK_LOGISTIC; } break;
+          case BJX_OP_LEAKY_RELU: s->kind = SK_LEAKY; s->alpha = a; break;
+          case BJX_OP_TRUNCATED:
+            s->clo = lo; s->chi = hi;
+            if (lb && ub) { const T w = hi - lo; s->a1 = T(1) / w; s->b1 = -lo / w; s->c -= d_log(w); s->kind = SK_LOGIT; }
+            else if (lb) { s->b1 = -lo; s->kind = SK_LOG; }
+            else if (ub) { s->a1 = T(-1); s->b1 = hi; s->kind = SK_LOG; }
+            else s->kind = SK_ID;
+            break;
+          case BJX_OP_TRUNCATED_INV:
+            s->plo = lo; s->phi = hi;
+            if (lb && ub) { const T w = hi - lo; s->a2 = w; s->b2 = lo; s->c += d_log(w); s->kind = SK_LOGISTIC; }
+            else if (lb) { s->b2 = lo; s->kind = SK_EXP; }
+            else if (ub) { s->a2 = T(-1); s->b2 = hi; s->kind = SK_EXP; }
+            else s->kind = SK_ID;
+            break;
+          default: break;
         }
       }
-      tab[g.out_lo + i] = row;
+      if (overflow) bits |= 2;
+      sl[0].src = (int32_t)(g.in_lo + i);
+      for (int q = cur + 1; q < STACKED_SLOTS; ++q) { slot_reset(sl[q]); sl[q].kind = SK_END; }
+      {
+        const int64_t r = g.out_lo + i;
+        Slot<T>* dst = reinterpret_cast<Slot<T>*>(tab + stacked_row_index(r, V, nvc) * stacked_row_bytes<T>());
+        for (int q = 0; q < STACKED_SLOTS; ++q) dst[q] = sl[q];
+      }
     }
   }
-  if (gather) atomicOr(flag, 1);
+  if (bits) atomicOr(flag, bits);
 }
 
-// one op on one element (the scalar form of apply_op in bjx_chain.hip; same reference lines)
-template <class T> __device__ __forceinline__ void stacked_op(int kind, T a, T b, T& x, T& l) {
+// one slot on one element; returns the log-det contribution
+template <class T> __device__ __forceinline__ T slot_eval(const Slot<T>& s, T& x) {
   using F = Fast<T>;
-  switch (kind) {
-    case BJX_OP_EXP: l += x; x = d_exp(x); break;                                   // exp_log.jl:5-6
-    case BJX_OP_LOG: { const T t = d_log(x); l -= t; x = t; } break;                // exp_log.jl:8-9
-    case BJX_OP_SHIFT: x = a + x; break;                                            // shift.jl:14
-    case BJX_OP_SCALE:
-    case BJX_OP_SCALE_INV: x = a * x; l += b; break;                                // scale.jl:13,26-32
-    case BJX_OP_LOGIT: {                                                            // logit.jl:15,24
-      const T inv = F::rcp(b - a), xa = x - a;
-      l -= F::log(xa * (b - x) * inv);
-      const T z = xa * inv;
-      x = F::log(z * F::rcp(T(1) - z));
-    } break;
-    case BJX_OP_LOGIT_INV: {                                                        // logit.jl:19
-      const T w = b - a, xx = w * f_logistic(x) + a;
-      l += F::log((xx - a) * (b - xx) * F::rcp(w));
-      x = xx;
-    } break;
-    case BJX_OP_LEAKY_RELU: { const T J = x < T(0) ? a : T(1); l += d_log(d_abs(J)); x = J * x; } break;   // leaky_relu.jl:25-29
-    case BJX_OP_TRUNCATED: {                                                        // truncated.jl:15-31,51-67
-      const T xc = d_clamp(x, a, b);
-      const bool lb = d_isfinite(a), ub = d_isfinite(b);
-      if (lb && ub) { const T inv = F::rcp(b - a), xa = xc - a; l -= F::log(xa * (b - xc) * inv); const T z = xa * inv; x = F::log(z * F::rcp(T(1) - z)); }
-      else if (lb) { const T t = F::log(xc - a); l -= t; x = t; }
-      else if (ub) { const T t = F::log(b - xc); l -= t; x = t; }
-      else x = xc;
-    } break;
-    case BJX_OP_TRUNCATED_INV: {                                                    // truncated.jl:33-49,71-91
-      const bool lb = d_isfinite(a), ub = d_isfinite(b);
-      T xx;
-      if (lb && ub) { const T ay = d_abs(x); l += F::log(b - a) - ay - T(2) * f_log1pexp(-ay); xx = (b - a) * f_logistic(x) + a; }
-      else if (lb) { l += x; xx = F::exp(x) + a; }
-      else if (ub) { l += x; xx = b - F::exp(x); }
-      else xx = x;
-      x = d_clamp(xx, a, b);
-    } break;
-    case BJX_OP_SIGNFLIP: x = -x; break;                                            // ordered.jl:3
-    default: break;                                                                 // identity
+  const T xc = d_med3(x, s.clo, s.chi);
+  const T u = s.a1 * xc + s.b1;
+  T v = u, l = s.c;
+  switch (s.kind) {
+    case SK_EXP: v = F::exp(u); l += u; break;                                                        // exp_log.jl:5-6
+    case SK_LOG: v = F::log(u); l -= v; break;                                                        // exp_log.jl:8-9
+    case SK_LOGIT: { l -= F::log(u * (T(1) - u)); v = F::log(u * F::rcp(T(1) - u)); } break;         // logit.jl:15,24
+    case SK_LOGISTIC: { const T au = d_abs(u); v = f_logistic(u); l += -au - T(2) * f_log1pexp(-au); } break;   // logit.jl:19, truncated.jl:71-82
+    case SK_LEAKY: { const T J = u < T(0) ? s.alpha : T(1); v = J * u; l += d_log(d_abs(J)); } break; // leaky_relu.jl:25-29
+    default: break;
   }
+  x = d_med3(s.a2 * v + s.b2, s.plo, s.phi);
+  return l;
 }
 
-template <class T, bool GATHER> struct StackedF {
+template <class T, bool GATHER, bool IN_LDS> struct StackedF {
   static constexpr bool kLoadInput = !GATHER;
-  const StackedRow<T>* tab;
+  const char* tab;
   int64_t dim;
-  int in_lds, max_ops;
+  int two_slots;
   double per_sample_const;
   const double* per_sample_dev;
   __device__ void stage(char* smem) const {
-    if (in_lds) {
-      const int n16 = (int)(dim * sizeof(StackedRow<T>) / 16);
+    if (IN_LDS) {
+      const int n16 = (int)(dim * stacked_row_bytes<T>() / 16);
       const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(tab);
       bjx_f32x4* dst = reinterpret_cast<bjx_f32x4*>(smem);
       for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
@@ -122,18 +183,30 @@ template <class T, bool GATHER> struct StackedF {
     }
   }
   template <int V> __device__ T apply(const char* smem, Pack<T, V>& p, const T* xcol, int64_t row, int64_t) const {
-    const StackedRow<T>* t = in_lds ? reinterpret_cast<const StackedRow<T>*>(smem) : tab;
+    const char* t = IN_LDS ? smem : tab;          // two instantiations: never a generic (flat) pointer
+    const int64_t nvc = dim / V;
     T l = T(0);
-#pragma unroll
+    // NOT unrolled: slot_eval is ~200 instructions; 4 elements x 2 slots x the skeleton's own unrolling made
+    // a 15k-instruction kernel
+#pragma unroll 1
     for (int j = 0; j < V; ++j) {
-      const StackedRow<T>& e = t[row + j];
-      T x = GATHER ? xcol[e.src] : p.v[j];
-      uint32_t kinds = e.kinds;
-      for (int k = 0; k < max_ops; ++k) {
-        stacked_op<T>((int)(kinds & 0xFFu), e.p0[k], e.p1[k], x, l);
-        kinds >>= 8;
+      const Slot<T>* e = reinterpret_cast<const Slot<T>*>(t + (V > 1 ? j * nvc + row / V : row) * stacked_row_bytes<T>());
+      T x = p.v[0];
+      if (V > 1) x = j == 1 ? p.v[1 % V] : (j == 2 ? p.v[2 % V] : (j == 3 ? p.v[3 % V] : x));
+      if (GATHER) x = xcol[e[0].src];
+#pragma unroll 1
+      for (int q = 0; q < (two_slots ? STACKED_SLOTS : 1); ++q) {
+        const Slot<T> sq = e[q];                  // 16-byte aligned: whole-slot vector reads
+        if (sq.kind == SK_END) break;
+        l += slot_eval<T>(sq, x);
       }
-      p.v[j] = x;
+      if (V == 1) p.v[0] = x;
+      else {
+        p.v[0] = j == 0 ? x : p.v[0];
+        p.v[1 % V] = j == 1 ? x : p.v[1 % V];
+        p.v[2 % V] = j == 2 ? x : p.v[2 % V];
+        p.v[3 % V] = j == 3 ? x : p.v[3 % V];
+      }
     }
     return l;
   }
@@ -164,12 +237,37 @@ int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, 
   }
   BJX_REQUIRE(ctx, total == dim, BJX_ERR_SHAPE, "input length mismatch (%lld != %lld)", (long long)total, (long long)dim);   // stacked.jl:157
   const size_t seg_bytes = ((size_t)n_segs * sizeof(SegDev) + 63) / 64 * 64;
-  const size_t tab_bytes = (size_t)dim * sizeof(StackedRow<T>);
+  const size_t tab_bytes = (size_t)dim * stacked_row_bytes<T>();
   BJX_REQUIRE(ctx, 64 + seg_bytes + tab_bytes <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_stacked: %d segments / %lld rows exceed the context scratch", n_segs, (long long)dim);
   BJX_REQUIRE(ctx, !gather || x != y, BJX_ERR_ARG, "bjx_stacked: in-place is only supported when every segment keeps its rows (ranges_in == ranges_out)");
-  // segment list -> device (host staging copy: the caller's array may be reused right after the call)
-  SegDev* hseg = static_cast<SegDev*>(malloc(seg_bytes ? seg_bytes : 64));
-  BJX_REQUIRE(ctx, hseg, BJX_ERR_ARG, "out of host memory");
+  // value-independent slot count per segment (same rules as stacked_table_kernel)
+  for (int sg = 0; sg < n_segs; ++sg) {
+    int cur = 0;
+    bool has_n = false, seen_affine = false, post_clamped = false;
+    for (int k = 0; k < segs[sg].n_ops; ++k) {
+      const int kind = segs[sg].ops[k].kind;
+      const bool affine = kind == BJX_OP_SHIFT || kind == BJX_OP_SCALE || kind == BJX_OP_SCALE_INV || kind == BJX_OP_SIGNFLIP || kind == BJX_OP_IDENTITY;
+      if (affine) {
+        if (has_n && post_clamped) { ++cur; has_n = false; post_clamped = false; seen_affine = false; }
+        seen_affine = true;
+      } else {
+        BJX_REQUIRE(ctx, kind >= BJX_OP_EXP && kind <= BJX_OP_IDENTITY, BJX_ERR_ARG, "bjx_stacked: segment %d op %d: bad kind %d", sg, k, kind);
+        if (has_n || (kind == BJX_OP_TRUNCATED && seen_affine)) { ++cur; post_clamped = false; seen_affine = false; }
+        has_n = true;
+        if (kind == BJX_OP_TRUNCATED_INV) post_clamped = true;
+      }
+    }
+    BJX_REQUIRE(ctx, cur < STACKED_SLOTS, BJX_ERR_UNSUPPORTED, "bjx_stacked: the chain of segment %d needs more than %d nonlinear stages", sg, STACKED_SLOTS);
+  }
+  // segment list -> device through the context's pinned staging buffer (asynchronous; the event guards its reuse)
+  BJX_REQUIRE(ctx, seg_bytes <= BJX_HOST_STAGE_BYTES, BJX_ERR_UNSUPPORTED, "bjx_stacked: too many segments (%d)", n_segs);
+  if (!ctx->host_stage) {
+    BJX_HIP(ctx, hipHostMalloc(&ctx->host_stage, BJX_HOST_STAGE_BYTES, hipHostMallocDefault));
+    BJX_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev, hipEventDisableTiming));
+  } else {
+    BJX_HIP(ctx, hipEventSynchronize(ctx->stage_ev));      // the previous call's copy has left the buffer
+  }
+  SegDev* hseg = static_cast<SegDev*>(ctx->host_stage);
   for (int s = 0; s < n_segs; ++s) {
     SegDev d{};
     d.in_lo = segs[s].in_lo; d.out_lo = segs[s].out_lo; d.len = segs[s].len; d.n_ops = segs[s].n_ops;
@@ -182,19 +280,22 @@ int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, 
   char* sc = static_cast<char*>(ctx->scratch);
   int* flag = reinterpret_cast<int*>(sc);
   SegDev* dseg = reinterpret_cast<SegDev*>(sc + 64);
-  StackedRow<T>* tab = reinterpret_cast<StackedRow<T>*>(sc + 64 + seg_bytes);
-  hipError_t e = hipMemsetAsync(flag, 0, 64, ctx->stream);
-  if (e == hipSuccess && n_segs) e = hipMemcpyAsync(dseg, hseg, (size_t)n_segs * sizeof(SegDev), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // pageable staging buffer: must outlive the copy
-  free(hseg);
-  BJX_HIP(ctx, e);
-  hipLaunchKernelGGL(stacked_table_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, dseg, n_segs, dim, tab, flag);
+  char* tab = sc + 64 + seg_bytes;
+  BJX_HIP(ctx, hipMemsetAsync(flag, 0, 64, ctx->stream));
+  if (n_segs) BJX_HIP(ctx, hipMemcpyAsync(dseg, hseg, (size_t)n_segs * sizeof(SegDev), hipMemcpyHostToDevice, ctx->stream));
+  BJX_HIP(ctx, hipEventRecord(ctx->stage_ev, ctx->stream));
+  // the main kernel's pack width decides the row permutation of the table (same rule as col_launch_cfg)
+  const ColLaunch cl = col_launch_cfg<T>(ctx, x, y, dim, batch);
+  hipLaunchKernelGGL(stacked_table_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, dseg, n_segs, dim, cl.V, tab, flag);
   BJX_CHECK_LAUNCH(ctx);
-  const int lds = tab_bytes <= 48 * 1024 && tab_bytes % 16 == 0 ? 1 : 0;
+  const int two = max_ops > 1 ? 1 : 0;
+  const bool lds = tab_bytes <= 48 * 1024;
   const size_t fsm = lds ? tab_bytes : 0;
-  if (gather) { StackedF<T, true> f{tab, dim, lds, max_ops, 0.0, nullptr}; return launch_colgroup<T>(ctx, f, fsm, x, y, ladj_ps, ladj_sum, dim, batch, flags, 0.0); }
-  StackedF<T, false> f{tab, dim, lds, max_ops, 0.0, nullptr};
-  return launch_colgroup<T>(ctx, f, fsm, x, y, ladj_ps, ladj_sum, dim, batch, flags, 0.0);
+#define STK_LAUNCH(G_, L_) do { StackedF<T, G_, L_> f{tab, dim, two, 0.0, nullptr}; return launch_colgroup<T>(ctx, f, fsm, x, y, ladj_ps, ladj_sum, dim, batch, flags, 0.0); } while (0)
+  if (gather) { if (lds) STK_LAUNCH(true, true); else STK_LAUNCH(true, false); }
+  if (lds) STK_LAUNCH(false, true);
+  STK_LAUNCH(false, false);
+#undef STK_LAUNCH
 }
 }  // namespace
 

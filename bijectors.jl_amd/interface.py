@@ -1076,9 +1076,10 @@ class Stacked(Transform):
                             o.param_len = 1
                             setattr(o, f"p{j}", float(p))
             rc = L.load().bjx_stacked(ctx.h, _dt(xc), arr, len(fused), _ptr(xc), _ptr(y), _ptr(out.ps), _ptr(out.sum), dim, batch, 0)
-            L.check(ctx.h, rc, "bjx_stacked")
             del keep
-            return (y, out.result(vec_scalar=vec and bool(per_sample) and per_sample is True)) if want_ladj else (y, None)
+            if rc != L.ERR_UNSUPPORTED:   # a chain with > 2 nonlinear stages is evaluated per segment below
+                L.check(ctx.h, rc, "bjx_stacked")
+                return (y, out.result(vec_scalar=vec and bool(per_sample) and per_sample is True)) if want_ladj else (y, None)
         # general case: per-segment launches on row slices (copies); log-dets are summed like :236-244
         total = None
         x2 = xc if not vec else xc[:, None]

@@ -609,6 +609,17 @@ def test_stacked_elementwise_segments_one_launch(bj, orc, dt, N):
     close(host(lb), -l_ref, dt, scale=dim * 10, what="stacked inverse ladj")
 
 
+def test_stacked_chain_with_three_nonlinear_stages_falls_back(bj, orc):
+    """exp ∘ log ∘ exp needs three canonical slots: bjx_stacked refuses, the wrapper evaluates per segment."""
+    r = rng(43)
+    X = np.asfortranarray(r.normal(size=(4, 30)))
+    ch = bj.elementwise(bj.exp) @ bj.elementwise(bj.log) @ bj.elementwise(bj.exp)
+    b = bj.Stacked([ch, bj.identity], [(1, 3), (4, 4)])
+    Y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+    np.testing.assert_allclose(host(Y), np.vstack([np.exp(X[:3]), X[3:]]), rtol=1e-12)
+    np.testing.assert_allclose(host(l), X[:3].sum(axis=0), rtol=1e-10, atol=1e-12)
+
+
 def test_stacked_permuted_ranges_and_structured_segments(bj, orc):
     r = rng(42)
     N = 50
