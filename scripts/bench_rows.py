@@ -115,7 +115,8 @@ def main():
     mask = bj.PartitionMask(d, list(range(1, d // 2 + 1)), list(range(d // 2 + 1, d + 1)))
     sc = torch.full((d // 2,), 1.5, device=dev)
     cpl = bj.Coupling(lambda x2: bj.Shift(0.25) @ bj.Scale(sc), mask)
-    add("Coupling(Shift∘Scale) d=64 (wrapper expands θ to [n1,batch] per call)", "a20", cpl, x)
+    add("Coupling(Shift∘Scale) d=64, θ = [n1,batch] scale + shift arrays", "a20", cpl, x)
+    rows[-1] = rows[-1][:3] + (rows[-1][3] + 2 * (d // 2) * 4,) + rows[-1][4:]     # the per-sample θ arrays are read too
 
     stk = bj.Stacked([e(bj.exp), bj.Logit(0.0, 1.0), bj.identity, e(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5)], [(1, 16), (17, 32), (33, 48), (49, 64)])
     xst = x.clone()
