@@ -174,6 +174,76 @@ __global__ __launch_bounds__(256) void seq_kernel(Op op0, const T* in, T* out, T
   if (partials) block_publish_partial(acc, red, partials);
 }
 
+// ---- wave-private [64][P] tile staging (single-wave blocks; shared by seq_wave_kernel and the VJP kernels)
+// A full tile (64 columns) is a whole number of 16-byte packs (64*rows*sizeof(T) % 16 == 0); the ragged
+// last wave of the batch takes the element-wise path.  SU independent 16-byte loads are in flight per lane.
+template <class T, int V>
+__device__ __forceinline__ void tile_stage_in(T* tile, const T* __restrict__ src, int rows, int P, int ncols, int lane) {
+  if (ncols == 64) {
+    constexpr int SU = 8;
+    const int ne = 64 * rows;
+    const int dc = (64 * V) / rows, dr = (64 * V) % rows;
+    int e = lane * V, c = e / rows, r = e % rows;
+    for (; e < ne; e += SU * 64 * V) {
+      Pack<T, V> p[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (e + u * 64 * V < ne) p[u] = load_pack<T, V, true>(src + e + u * 64 * V);
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (e + u * 64 * V < ne) {
+          int cc = c, rr = r;
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            tile[cc * P + rr] = p[u].v[j];
+            if (++rr == rows) { rr = 0; ++cc; }
+          }
+        }
+        c += dc; r += dr;
+        if (r >= rows) { r -= rows; ++c; }
+      }
+    }
+  } else {
+    const int ne = ncols * rows;
+    for (int e = lane; e < ne; e += 64) tile[(e / rows) * P + e % rows] = src[e];
+  }
+}
+template <class T, int V>
+__device__ __forceinline__ void tile_stage_out(const T* tile, T* __restrict__ dst, int rows, int P, int ncols, int lane) {
+  if (ncols == 64) {
+    constexpr int SU = 4;
+    const int ne = 64 * rows;
+    const int dc = (64 * V) / rows, dr = (64 * V) % rows;
+    int e = lane * V, c = e / rows, r = e % rows;
+    for (; e < ne; e += SU * 64 * V) {
+      Pack<T, V> p[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        int cc = c, rr = r;
+        if (e + u * 64 * V < ne) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            p[u].v[j] = tile[cc * P + rr];
+            if (++rr == rows) { rr = 0; ++cc; }
+          }
+        }
+        c += dc; r += dr;
+        if (r >= rows) { r -= rows; ++c; }
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (e + u * 64 * V < ne) store_pack<T, V, true>(dst + e + u * 64 * V, p[u]);
+      }
+    }
+  } else {
+    const int ne = ncols * rows;
+    for (int e = lane; e < ne; e += 64) dst[e] = tile[(e / rows) * P + e % rows];
+  }
+}
+// single-wave block: the LDS queue is in order, only pin the compiler
+__device__ __forceinline__ void tile_sync() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
 // Wave-private variant (whole columns in LDS): ONE WAVE owns 64 consecutive columns, i.e. one
 // CONTIGUOUS run of 64*rows elements of the input and of the output.  The run is moved with
 // 16-byte flat accesses (no per-column alignment requirement: K-1 = 63 rows are fine), transposed
@@ -195,42 +265,8 @@ __global__ __launch_bounds__(64) void seq_wave_kernel(Op op0, const T* __restric
   for (int i = lane; i < n_logk; i += 64) logk[i] = d_log(T(n_logk - i));      // log(K-1-i), simplex.jl:35,41
   const int64_t col0 = (int64_t)blockIdx.x * 64;
   const int ncols = (int)((batch - col0) < 64 ? (batch - col0) : 64);
-  // ---- stage in: SU independent 16-byte loads in flight per lane, then the LDS scatter.
-  // A full tile (64 columns) is a whole number of packs (64*rows*sizeof(T) % 16 == 0); the ragged
-  // last wave of the batch takes the element-wise path.
-  if (ncols == 64) {
-    constexpr int SU = 8;
-    const T* src = in + col0 * rows_in;
-    const int ne = 64 * rows_in;
-    const int dc = (64 * V) / rows_in, dr = (64 * V) % rows_in;
-    int e = lane * V, c = e / rows_in, r = e % rows_in;
-    for (; e < ne; e += SU * 64 * V) {
-      Pack<T, V> p[SU];
-#pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        if (e + u * 64 * V < ne) p[u] = load_pack<T, V, true>(src + e + u * 64 * V);
-      }
-#pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        if (e + u * 64 * V < ne) {
-          int cc = c, rr = r;
-#pragma unroll
-          for (int j = 0; j < V; ++j) {
-            tile[cc * P + rr] = p[u].v[j];
-            if (++rr == rows_in) { rr = 0; ++cc; }
-          }
-        }
-        c += dc; r += dr;
-        if (r >= rows_in) { r -= rows_in; ++c; }
-      }
-    }
-  } else {
-    const T* src = in + col0 * rows_in;
-    const int ne = ncols * rows_in;
-    for (int e = lane; e < ne; e += 64) tile[(e / rows_in) * P + e % rows_in] = src[e];
-  }
-  asm volatile("" ::: "memory");   // single-wave block: the LDS queue is in order, only pin the compiler
-  __builtin_amdgcn_wave_barrier();
+  tile_stage_in<T, V>(tile, in + col0 * rows_in, rows_in, P, ncols, lane);
+  tile_sync();
   // ---- walk: lane = column
   T lres = T(0);
   if (lane < ncols) {
@@ -255,40 +291,8 @@ __global__ __launch_bounds__(64) void seq_wave_kernel(Op op0, const T* __restric
     lres = op.result();
     if (ladj_ps) ladj_ps[col0 + lane] = accumulate ? ladj_ps[col0 + lane] + lres : lres;
   }
-  asm volatile("" ::: "memory");   // single-wave block: the LDS queue is in order, only pin the compiler
-  __builtin_amdgcn_wave_barrier();
-  // ---- stage out
-  if (out && ncols == 64) {
-    constexpr int SU = 4;
-    T* dst = out + col0 * rows_out;
-    const int ne = 64 * rows_out;
-    const int dc = (64 * V) / rows_out, dr = (64 * V) % rows_out;
-    int e = lane * V, c = e / rows_out, r = e % rows_out;
-    for (; e < ne; e += SU * 64 * V) {
-      Pack<T, V> p[SU];
-#pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        int cc = c, rr = r;
-        if (e + u * 64 * V < ne) {
-#pragma unroll
-          for (int j = 0; j < V; ++j) {
-            p[u].v[j] = tile[cc * P + rr];
-            if (++rr == rows_out) { rr = 0; ++cc; }
-          }
-        }
-        c += dc; r += dr;
-        if (r >= rows_out) { r -= rows_out; ++c; }
-      }
-#pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        if (e + u * 64 * V < ne) store_pack<T, V, true>(dst + e + u * 64 * V, p[u]);
-      }
-    }
-  } else if (out) {
-    T* dst = out + col0 * rows_out;
-    const int ne = ncols * rows_out;
-    for (int e = lane; e < ne; e += 64) dst[e] = tile[(e / rows_out) * P + e % rows_out];
-  }
+  tile_sync();
+  if (out) tile_stage_out<T, V>(tile, out + col0 * rows_out, rows_out, P, ncols, lane);
   block_publish_partial(lane < ncols ? (double)lres : 0.0, red, fin);
 }
 
@@ -1023,6 +1027,121 @@ int chol_impl(bjx_ctx* ctx, int inverse, int uplo, const T* in, T* out, T* ladj_
   if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
   return BJX_OK;
 }
+}  // namespace
+
+namespace {
+// ------------------------------------------------------------------ OrderedBijector pullbacks
+// ext/BijectorsChainRulesCoreExt.jl:65-197 (rrules of _transform_ordered / _transform_inverse_ordered,
+// matrix methods), extended by the log-det cotangent so that ONE call is the pullback of
+// with_logabsdet_jacobian:   in_bar = J(in)ᵀ · out_bar + ladj_bar · ∇_in logabsdetjac.
+//   forward  x = b(y): x_1 = y_1, x_i = x_{i-1} + exp(y_i), ladj = Σ_{i>=2} y_i
+//            y_bar[1] = Σ_k x_bar[k];  y_bar[i] = (Σ_{k>=i} x_bar[k]) · exp(y_i) + ladj_bar       (:74-88)
+//   inverse  y = b⁻¹(x): r_1 = 1, r_i = x_i - x_{i-1}, y_i = log r_i, ladj = -Σ_{i>=2} y_i
+//            with Δ_1 = y_bar[1], Δ_i = y_bar[i] - ladj_bar:  x_bar[j] = Δ_j / r_j - Δ_{j+1} / r_{j+1}  (:136-147)
+// Same wave-private tiles as the forward kernels: two [64][P] tiles (primal input, output cotangent),
+// one lane per column; the suffix sum runs from the last row up.
+template <class T, int V, bool INV>
+__global__ __launch_bounds__(64) void ordered_vjp_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
+                                                        T* __restrict__ in_bar, int rows, int P, int64_t batch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tin = reinterpret_cast<T*>(smem);
+  T* tg = tin + (size_t)64 * P;
+  const int lane = threadIdx.x;
+  const int64_t col0 = (int64_t)blockIdx.x * 64;
+  const int ncols = (int)((batch - col0) < 64 ? (batch - col0) : 64);
+  tile_stage_in<T, V>(tin, in + col0 * rows, rows, P, ncols, lane);
+  tile_stage_in<T, V>(tg, out_bar + col0 * rows, rows, P, ncols, lane);
+  tile_sync();
+  if (lane < ncols) {
+    const T lb = ladj_bar ? ladj_bar[col0 + lane] : T(0);
+    const T* a = tin + lane * P;
+    T* g = tg + lane * P;
+    if (!INV) {
+      T sfx = T(0);
+      for (int i = rows - 1; i >= 1; --i) { sfx += g[i]; g[i] = sfx * d_exp(a[i]) + lb; }
+      g[0] = sfx + g[0];
+    } else {
+      // walk up keeping Δ_{i+1}/r_{i+1}
+      T nxt = T(0);
+      for (int i = rows - 1; i >= 1; --i) {
+        const T q = (g[i] - lb) / (a[i] - a[i - 1]);
+        g[i] = q - nxt;
+        nxt = q;
+      }
+      g[0] = g[0] - nxt;
+    }
+  }
+  tile_sync();
+  tile_stage_out<T, V>(tg, in_bar + col0 * rows, rows, P, ncols, lane);
+}
+
+// fallback for columns too long for two LDS tiles: one thread per column, straight from global memory
+template <class T, bool INV>
+__global__ __launch_bounds__(256) void ordered_vjp_column_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
+                                                                 T* __restrict__ in_bar, int64_t rows, int64_t batch) {
+  const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= batch) return;
+  const T lb = ladj_bar ? ladj_bar[col] : T(0);
+  const T* a = in + col * rows;
+  const T* g = out_bar + col * rows;
+  T* o = in_bar + col * rows;
+  if (!INV) {
+    T sfx = T(0);
+    for (int64_t i = rows - 1; i >= 1; --i) { sfx += g[i]; o[i] = sfx * d_exp(a[i]) + lb; }
+    o[0] = sfx + g[0];
+  } else {
+    T nxt = T(0);
+    for (int64_t i = rows - 1; i >= 1; --i) {
+      const T q = (g[i] - lb) / (a[i] - a[i - 1]);
+      o[i] = q - nxt;
+      nxt = q;
+    }
+    o[0] = g[0] - nxt;
+  }
+}
+
+template <class T>
+int ordered_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t dim, int64_t batch) {
+  if (batch == 0) return BJX_OK;
+  const int64_t P = dim | 1;
+  const size_t smem = (size_t)2 * 64 * P * sizeof(T);
+  if (smem > 64 * 1024) {
+    BJX_REQUIRE(ctx, in_bar != out_bar, BJX_ERR_ARG, "bjx_ordered_vjp: in_bar may not alias out_bar for dim = %lld", (long long)dim);
+    const int64_t g2 = (batch + 255) / 256;
+    BJX_REQUIRE(ctx, g2 < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+    BjxProf prof_(ctx);
+    if (inverse) hipLaunchKernelGGL((ordered_vjp_column_kernel<T, true>), dim3((unsigned)g2), dim3(256), 0, ctx->stream, in, out_bar, ladj_bar, in_bar, dim, batch);
+    else hipLaunchKernelGGL((ordered_vjp_column_kernel<T, false>), dim3((unsigned)g2), dim3(256), 0, ctx->stream, in, out_bar, ladj_bar, in_bar, dim, batch);
+    BJX_CHECK_LAUNCH(ctx);
+    return BJX_OK;
+  }
+  const int64_t grid = (batch + 63) / 64;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+  constexpr int VW = Vec16<T>::N;
+  const bool v_ok = bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
+  {
+    BjxProf prof_(ctx);
+#define OVJP(V_, I_) hipLaunchKernelGGL((ordered_vjp_kernel<T, V_, I_>), dim3((unsigned)grid), dim3(64), smem, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)dim, (int)P, batch)
+    if (v_ok) { if (inverse) OVJP(VW, true); else OVJP(VW, false); }
+    else { if (inverse) OVJP(1, true); else OVJP(1, false); }
+#undef OVJP
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+}  // namespace
+
+BJX_API int bjx_ordered_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar, const void* ladj_bar,
+                            void* in_bar, int64_t dim, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_ordered_vjp: bad size");
+  BJX_REQUIRE(ctx, (in && out_bar && in_bar) || batch == 0, BJX_ERR_ARG, "bjx_ordered_vjp: null pointer");
+  if (dt == BJX_F32) return ordered_vjp_impl<float>(ctx, inverse, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, dim, batch);
+  if (dt == BJX_F64) return ordered_vjp_impl<double>(ctx, inverse, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, dim, batch);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_ordered_vjp: bad dtype %d", (int)dt);
+}
+
+namespace {
 }  // namespace
 
 BJX_API int bjx_ordered(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out, void* ladj_ps, double* ladj_sum,

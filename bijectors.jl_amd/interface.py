@@ -31,7 +31,7 @@ __all__ = [
     "Transform", "Bijector", "Inverse", "ComposedFunction", "Elementwise", "elementwise", "exp", "log", "identity",
     "Shift", "Scale", "Logit", "LeakyReLU", "TruncatedBijector", "SignFlip", "OrderedBijector", "SimplexBijector",
     "VecCholeskyBijector", "Permute", "PlanarLayer", "RadialLayer", "InvertibleBatchNorm", "RationalQuadraticSpline",
-    "PartitionMask", "Coupling", "Stacked", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
+    "PartitionMask", "Coupling", "Stacked", "vjp", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
     "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
     "PlanarResult",
 ]
@@ -1102,3 +1102,33 @@ class Stacked(Transform):
         if per_sample:
             return y, (ps[0] if vec else ps)
         return y, sm[0].to(xc.dtype)
+
+
+# ------------------------------------------------------------------ reverse-mode pullbacks
+def vjp(b, x, out_bar, ladj_bar=None):
+    """Pullback of `with_logabsdet_jacobian(b, x)`: returns x_bar = J(x)^T out_bar + ladj_bar * grad_x logabsdetjac.
+
+    `out_bar` has the shape of b(x); `ladj_bar` is the cotangent of the PER-COLUMN log-det (a (batch,) tensor,
+    a python number broadcast over the batch, or None = 0).  Device kernels exist for the bijectors whose
+    rrules the reference ships (ext/BijectorsChainRulesCoreExt.jl): OrderedBijector and its inverse (:65-197)."""
+    inv = isinstance(b, Inverse)
+    base = b.orig if inv else b
+    if not isinstance(base, OrderedBijector):
+        raise NotImplementedError(f"no device pullback for {b!r} yet (SURVEY.md §8f f-1)")
+    xc, dim, batch, vec = _prep(x)
+    gc, gdim, gbatch, _ = _prep(out_bar)
+    if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:
+        raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
+    lb = None
+    if ladj_bar is not None:
+        lb = ladj_bar if isinstance(ladj_bar, torch.Tensor) else torch.full((batch,), float(ladj_bar), dtype=xc.dtype, device=xc.device)
+        lb = lb.to(device=xc.device, dtype=xc.dtype).reshape(-1).contiguous()
+        if lb.numel() == 1 and batch != 1:
+            lb = lb.expand(batch).contiguous()
+        if lb.numel() != batch:
+            raise ValueError("DimensionMismatch: ladj_bar needs one entry per column")
+    ctx = context(xc.device)
+    xb = _empty(dim, batch, xc, vec)
+    rc = L.load().bjx_ordered_vjp(ctx.h, _dt(xc), int(inv), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
+    L.check(ctx.h, rc, "bjx_ordered_vjp")
+    return xb

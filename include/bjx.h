@@ -217,6 +217,17 @@ typedef struct {
 int bjx_stacked(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const void* x, void* y,
                 void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
 
+/* ------------------------------- reverse-mode pullbacks (first rows)  */
+/* Pullback of with_logabsdet_jacobian for one launch over the batch:
+ *     in_bar = J(in)^T * out_bar + ladj_bar * grad_in logabsdetjac
+ * `in` is the PRIMAL INPUT of the direction being differentiated, `out_bar` the cotangent of its
+ * output (same shape), `ladj_bar` the cotangent of the per-sample log-det (T[batch], may be NULL = 0),
+ * `in_bar` the result (may not alias `in`; may alias `out_bar`).
+ * OrderedBijector: ext/BijectorsChainRulesCoreExt.jl:65-197 (rrules of _transform_ordered and
+ * _transform_inverse_ordered, matrix methods). */
+int bjx_ordered_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar,
+                    const void* ladj_bar, void* in_bar, int64_t dim, int64_t batch);
+
 /* ------------------------------- multi-GPU                */
 /* RCCL communicator owned by the context (one process per GPU).  `unique_id` is the 128-byte
  * ncclUniqueId made by bjx_comm_unique_id on rank 0 and broadcast by the host (Julia: MPI.jl

@@ -287,3 +287,32 @@ def log1pexp(x, dtype=np.float64):
 def logcosh(x, dtype=np.float64):
     suf, ct = _suf(dtype)
     return getattr(lib(), f"bjo_logcosh_{suf}")(ct(x))
+
+
+# ------------------------------------------------------------------ reverse-mode pullbacks
+def ordered_vjp(inp, out_bar, ladj_bar=None, inverse=False):
+    """Pullback of with_logabsdet_jacobian(OrderedBijector() or its inverse, inp) for a (dim, batch) matrix:
+    ext/BijectorsChainRulesCoreExt.jl:90-112 (_transform_ordered, matrix) and :149-197
+    (_transform_inverse_ordered, matrix), with the log-det cotangent added (ordered.jl:79-80:
+    logabsdetjac = sum(y[2:end, :]; dims=1), and its negative for the inverse, interface.jl:276-281).
+    numpy restatement, row loop in the reference's order, vectorised over the batch."""
+    a = np.asarray(inp)
+    g = np.asarray(out_bar, dtype=a.dtype)
+    n, N = a.shape
+    lb = np.zeros(N, dtype=a.dtype) if ladj_bar is None else np.broadcast_to(np.asarray(ladj_bar, dtype=a.dtype), (N,))
+    res = np.empty_like(a)
+    if not inverse:
+        s = g.sum(axis=0)                      # :99
+        res[0] = s                             # :100
+        for i in range(1, n):                  # :101-108
+            s = s - g[i - 1]
+            res[i] = s * np.exp(a[i]) + lb
+        return res
+    r = np.ones_like(a)                       # :153-160
+    r[1:] = a[1:] - a[:-1]
+    d = g.copy()
+    d[1:] -= lb                                # cotangent of -sum(log r_i, i >= 2)
+    for i in range(n - 1):                     # :168-170
+        res[i] = d[i] / r[i] - d[i + 1] / r[i + 1]
+    res[n - 1] = d[n - 1] / r[n - 1]           # :172-174
+    return res

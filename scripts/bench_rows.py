@@ -123,6 +123,13 @@ def main():
     xst[16:32] = xunit[16:32]
     add("Stacked(exp|Logit|identity|exp∘Shift∘Scale) d=64", "f-4", stk, xst)
 
+    gb = randn(d, N, dev, 11)
+    lbar = randn(N, 1, dev, 12).reshape(-1).contiguous()
+    ob = bj.OrderedBijector()
+    # pullbacks read the primal input + the output cotangent (+ 4 B/sample of log-det cotangent) and write the input cotangent
+    rows.append(("vjp(OrderedBijector) d=64", "f-1", lambda: bj.vjp(ob, x, gb, lbar), 3 * d * 4 + 4, N))
+    rows.append(("vjp(inverse(OrderedBijector)) d=64", "f-1", lambda: bj.vjp(bj.inverse(ob), xo, gb, lbar), 3 * d * 4 + 4, N))
+
     only = [s for s in a.only.split(",") if s]
     L, ctx = bj._lib, bj.context(dev)
     lib = L.load()

@@ -638,3 +638,26 @@ def test_stacked_permuted_ranges_and_structured_segments(bj, orc):
     ys_ref, ls_ref = orc.simplex(P)
     np.testing.assert_allclose(host(Y2), np.vstack([ys_ref, np.exp(X2[5:7])]), rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(host(l2), ls_ref + X2[5:7].sum(axis=0), rtol=1e-9, atol=1e-12)
+
+
+# ------------------------------------------------------------------ §8(f) f-1: pullbacks
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(1, 5), (2, 64), (7, 300), (64, 129), (100, 33)])
+def test_ordered_vjp(bj, orc, shape, dt):
+    r = rng(51)
+    n, N = shape
+    y = np.asfortranarray((0.7 * r.normal(size=shape)).astype(dt))
+    gbar = np.asfortranarray(r.normal(size=shape).astype(dt))
+    lbar = r.normal(size=N).astype(dt)
+    b = bj.OrderedBijector()
+    ref = orc.ordered_vjp(y.astype(np.float64), gbar.astype(np.float64), lbar.astype(np.float64))
+    got = bj.vjp(b, dev(y), dev(gbar), torch.from_numpy(lbar).cuda())
+    close(host(got), ref, dt, scale=10 * n, what="ordered vjp")
+    x, _ = orc.ordered(y.astype(np.float64))
+    x = np.asfortranarray(x.astype(dt))
+    ref_i = orc.ordered_vjp(x.astype(np.float64), gbar.astype(np.float64), lbar.astype(np.float64), inverse=True)
+    got_i = bj.vjp(bj.inverse(b), dev(x), dev(gbar), torch.from_numpy(lbar).cuda())
+    np.testing.assert_allclose(host(got_i), ref_i, rtol=RTOL[dt] * 50, atol=ATOL[dt] * 100 * max(1.0, float(np.abs(ref_i).max())))
+    # no log-det cotangent, vector input
+    g1 = bj.vjp(b, dev(y[:, 0].copy()), dev(gbar[:, 0].copy()))
+    close(host(g1), orc.ordered_vjp(y[:, :1].astype(np.float64), gbar[:, :1].astype(np.float64))[:, 0], dt, scale=10 * n)
