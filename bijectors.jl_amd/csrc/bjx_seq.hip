@@ -850,6 +850,191 @@ __global__ __launch_bounds__(64 * CHOL_WPB) void chol_fwd_chunk_kernel(const T* 
   if (partials) block_publish_partial(acc, red, partials);
 }
 
+// ------------------------------------------------------------------ pullback of _inv_link_chol_lkj
+// corr.jl:402-451 (_inv_link_chol_lkj_rrule, the rule behind ext/BijectorsChainRulesCoreExt.jl:311-320):
+// given y, ΔW (K x K, dense) and ΔlogJ,
+//   for j = K..2:  Δlr = W[j,j] ΔW[j,j] + 2 ΔlogJ
+//     for i = j-1..1:  Δy[idx] = (1/z - z) W[i,j] ΔW[i,j] - z Δlr ;  Δlr += ΔlogJ + W[i,j] ΔW[i,j]
+// with z = tanh y, W[i,j] = z exp(lr_before), W[j,j] = exp(lr_end).  Same chunk decomposition as the
+// forward kernels: pass 1 (ascending) rebuilds lr_before from Σ logcosh (one forward segmented scan),
+// e = exp(lr_before) ΔW[i,j] is gathered from the staged ΔW tile, and Δlr — a SUFFIX sum inside the
+// column seeded by the diagonal term — comes from a descending walk plus one reversed segmented scan.
+// (1/z - z) W[i,j] is evaluated as (1 - z²) exp(lr_before): no 0·inf at y = 0.
+template <class T, int V, int CHV, bool LOWER>
+__global__ __launch_bounds__(64 * CHOL_WPB) void chol_inv_vjp_kernel(const T* __restrict__ y, const T* __restrict__ Wbar, const T* __restrict__ lbar,
+                                                           T* __restrict__ ybar, int K, int tile_words, int64_t batch) {
+  using F = Fast<T>;
+  constexpr int CH = CHV * V;
+  static_assert(CH <= 32, "wrap mask is 32 bits");
+  constexpr int S = CH + V;                          // chunk pitch of the packed-vector staging
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* tile = reinterpret_cast<T*>(smem) + (size_t)wave * tile_words;
+  const int nv = K * (K - 1) / 2;
+  const int64_t s = (int64_t)blockIdx.x * CHOL_WPB + wave;
+  if (s >= batch) return;
+  const T dl = lbar ? lbar[s] : T(0);
+  const int e0 = lane * CH;
+  // ---- y: coalesced flat loads -> LDS -> my contiguous chunk
+  Pack<T, V> yp[CHV];
+  {
+    const T* ys = y + s * nv;
+#pragma unroll
+    for (int i = 0; i < CHV; ++i) {
+      const int e = (lane + 64 * i) * V;
+      Pack<T, V> t;
+      if (V > 1) {
+        if (e + V <= nv) t = load_pack<T, V, true>(ys + e);
+        else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) t.v[j] = T(0);
+        }
+      } else t.v[0] = (e < nv) ? ys[e] : T(0);
+      T* dst = tile + (e / CH) * S + e % CH;
+      if (V > 1) *reinterpret_cast<typename Vec16<T>::type*>(dst) = *reinterpret_cast<const typename Vec16<T>::type*>(&t);
+      else dst[0] = t.v[0];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < CHV; ++q) {
+      const T* src = tile + lane * S + q * V;
+      if (V > 1) *reinterpret_cast<typename Vec16<T>::type*>(&yp[q]) = *reinterpret_cast<const typename Vec16<T>::type*>(src);
+      else yp[q].v[0] = src[0];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- ΔW -> tile (flat copy: the tile is ΔW's own layout)
+  {
+    const T* Ws = Wbar + s * (int64_t)K * K;
+    constexpr int ZV = 16 / sizeof(T);
+    const int nz = K * K / ZV;
+    if (bjx_aligned16_dev(Ws)) {
+      constexpr int SU = 8;
+      for (int i0 = lane; i0 < nz; i0 += 64 * SU) {
+        typename Vec16<T>::type t[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) if (i0 + u * 64 < nz) t[u] = __builtin_nontemporal_load(reinterpret_cast<const typename Vec16<T>::type*>(Ws) + i0 + u * 64);
+#pragma unroll
+        for (int u = 0; u < SU; ++u) if (i0 + u * 64 < nz) reinterpret_cast<typename Vec16<T>::type*>(tile)[i0 + u * 64] = t[u];
+      }
+      for (int i = nz * ZV + lane; i < K * K; i += 64) tile[i] = Ws[i];
+    } else {
+      for (int i = lane; i < K * K; i += 64) tile[i] = Ws[i];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  int c0, i00;
+  triu1_decode(e0, c0, i00);
+  // ---- pass 1 (ascending): signed t, logcosh, wrap mask, tail of my open column; gather ΔW[i,j] and ΔW[j,j]
+  T ts[CH], ed[CH], aux[CH];      // ts = copysign(exp(-2|y|), y); ed = ΔW[i,j] (then exp(lr_before) ΔW[i,j]); aux = logcosh, then D at column ends
+  unsigned wmask = 0;
+  T tail = T(0);
+  bool has_head = (i00 == 0);
+  {
+    int d = c0 - i00, len = c0;
+    int addr = LOWER ? i00 * K + c0 : c0 * K + i00;
+    bool prev_wrap = false;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const T yv = yp[k / V].v[k % V];
+      const T ay = d_abs(yv);
+      const T t = F::exp(T(-2) * ay);
+      aux[k] = F::log2(T(1) + t) * Num<T>::log2 + (ay - Num<T>::log2);      // logcosh (exactly 0 for the zero padding)
+      ts[k] = d_copysign(t, yv);
+      tail = (prev_wrap ? T(0) : tail) + aux[k];
+      has_head |= prev_wrap;
+      const bool real = len < K;                                             // phantom columns read word 0
+      ed[k] = tile[real ? addr : 0];
+      d -= 1;
+      const bool wrap = (d == 0);
+      if (LOWER) addr = wrap ? len + 1 : addr + K;
+      else addr += wrap ? K + 1 - len : 1;
+      len += wrap ? 1 : 0;
+      d = wrap ? len : d;
+      wmask = (wmask << 1) | (wrap ? 1u : 0u);
+      prev_wrap = wrap;
+    }
+  }
+  T carry;
+  {
+    const T incl = seg_prefix_incl<T>(tail, has_head, T(0));
+    const T up = __shfl_up(incl, 1, 64);
+    carry = lane == 0 ? T(0) : up;
+  }
+  // ---- pass 2 (ascending): e = exp(lr_before) ΔW[i,j]; s_k = ΔlogJ + z e; D = exp(lr_end) ΔW[j,j] + 2 ΔlogJ at column ends;
+  //      my contribution to earlier lanes' suffixes
+  T pre = T(0);
+  bool seen_wrap = false;
+  {
+    T run = (i00 == 0) ? T(0) : carry;
+    T Eb = F::exp(-run);                               // exp(lr_before) of the current entry; one exp per entry below
+    int len = c0;
+    bool prev_wrap = false;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const bool wrap = (wmask >> (CH - 1 - k)) & 1u;
+      run = prev_wrap ? T(0) : run;
+      Eb = prev_wrap ? T(1) : Eb;
+      const T e = Eb * ed[k];
+      run += aux[k];
+      const T Ea = F::exp(-run);                       // exp(lr_after): W[j,j] at a column end, exp(lr_before) of the next entry
+      const T t = d_abs(ts[k]);
+      const T z = d_copysign((T(1) - t) * F::rcp(T(1) + t), ts[k]);
+      const T sk = dl + z * e;
+      const T dgbar = tile[len < K ? len * K + len : 0];
+      const T D = wrap ? Ea * dgbar + 2 * dl : T(0);   // W[j,j] ΔW[j,j] + 2 ΔlogJ
+      ed[k] = e;
+      aux[k] = D;
+      pre += seen_wrap ? T(0) : sk + D;
+      seen_wrap |= wrap;
+      len += wrap ? 1 : 0;
+      Eb = Ea;
+      prev_wrap = wrap;
+    }
+  }
+  const T carry_sfx = seg_suffix_excl<T>(pre, seen_wrap, T(0));
+  // ---- pass 3 (descending): Δlr and Δy
+  {
+    T sfx = carry_sfx;
+#pragma unroll
+    for (int k = CH - 1; k >= 0; --k) {
+      const bool wrap = (wmask >> (CH - 1 - k)) & 1u;
+      sfx = wrap ? aux[k] : sfx;
+      const T t = d_abs(ts[k]);
+      const T z = d_copysign((T(1) - t) * F::rcp(T(1) + t), ts[k]);
+      const T e = ed[k];
+      ed[k] = (T(1) - z * z) * e - z * sfx;                                  // Δy
+      sfx += dl + z * e;
+    }
+  }
+  // ---- Δy: chunk -> LDS -> coalesced flat stores
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < CHV; ++q) {
+    T* dst = tile + lane * S + q * V;
+    if (V > 1) {
+      Pack<T, V> p;
+#pragma unroll
+      for (int j = 0; j < V; ++j) p.v[j] = ed[q * V + j];
+      *reinterpret_cast<typename Vec16<T>::type*>(dst) = *reinterpret_cast<const typename Vec16<T>::type*>(&p);
+    } else dst[0] = ed[q];
+  }
+  __builtin_amdgcn_wave_barrier();
+  T* ybs = ybar + s * nv;
+#pragma unroll
+  for (int i = 0; i < CHV; ++i) {
+    const int e = (lane + 64 * i) * V;
+    const T* src = tile + (e / CH) * S + e % CH;
+    if (V > 1) {
+      if (e + V <= nv) {
+        Pack<T, V> p;
+        *reinterpret_cast<typename Vec16<T>::type*>(&p) = *reinterpret_cast<const typename Vec16<T>::type*>(src);
+        store_pack<T, V, true>(ybs + e, p);
+      }
+    } else if (e < nv) ybs[e] = src[0];
+  }
+}
+
 // corr.jl:314-337 (_link_chol_lkj_from_upper / _from_lower) ; log-det = -_logabsdetjac_inv_chol(y) (:235-237)
 template <class T>
 __global__ __launch_bounds__(256) void chol_fwd_kernel(const T* W, T* y, T* ladj_ps, int64_t K, int64_t batch, int lower,
@@ -1186,6 +1371,56 @@ BJX_API int bjx_simplex(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in,
   if (dt == BJX_F32) return simplex_impl<float>(ctx, inverse, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, K, batch, flags);
   if (dt == BJX_F64) return simplex_impl<double>(ctx, inverse, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, K, batch, flags);
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_simplex: bad dtype %d", (int)dt);
+}
+
+namespace {
+template <class T>
+int chol_inv_vjp_impl(bjx_ctx* ctx, int uplo, const T* y, const T* Wbar, const T* lbar, T* ybar, int64_t K, int64_t batch) {
+  if (batch == 0 || K < 2) return BJX_OK;
+  const int lower = (uplo == 'L') ? 1 : 0;
+  const int64_t nv = K * (K - 1) / 2;
+  constexpr int VW = Vec16<T>::N;
+  const bool v_ok = bjx_aligned16(y) && bjx_aligned16(ybar) && nv % VW == 0;
+  const int ch = (int)((nv + 63) / 64);
+  int chv, vv;
+  if (v_ok) { vv = VW; const int need = (ch + VW - 1) / VW; chv = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16; }
+  else { vv = 1; chv = ch <= 2 ? 2 : ch <= 8 ? 8 : ch <= 16 ? 16 : 32; }
+  const int CHn = chv * vv;
+  int64_t tile_words = (K * K + 3) / 4 * 4;
+  if (tile_words < (int64_t)64 * (CHn + vv)) tile_words = (int64_t)64 * (CHn + vv);
+  const size_t tile_bytes = (size_t)CHOL_WPB * tile_words * sizeof(T);
+  BJX_REQUIRE(ctx, CHn <= 32 && nv <= 64 * 32 && tile_bytes <= 60 * 1024, BJX_ERR_UNSUPPORTED,
+              "bjx_vec_cholesky_inv_vjp: K = %lld is too large for the LDS tile kernel", (long long)K);
+  const int64_t grid = (batch + CHOL_WPB - 1) / CHOL_WPB;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+#define CVJP_K(V_, CHV_, L_) hipLaunchKernelGGL((chol_inv_vjp_kernel<T, V_, CHV_, L_>), dim3((unsigned)grid), dim3(64 * CHOL_WPB), tile_bytes, ctx->stream, y, Wbar, lbar, ybar, (int)K, (int)tile_words, batch)
+#define CVJP_L(V_, CHV_) do { if (lower) CVJP_K(V_, CHV_, true); else CVJP_K(V_, CHV_, false); } while (0)
+  {
+    BjxProf prof_(ctx);
+    if (vv == VW) {
+      if (chv == 1) CVJP_L(VW, 1); else if (chv == 2) CVJP_L(VW, 2); else if (chv == 4) CVJP_L(VW, 4);
+      else if (chv == 8 && VW * 8 <= 32) CVJP_L(VW, (VW * 8 <= 32 ? 8 : 1));
+      else if (VW == 2 && chv == 8) CVJP_L(VW, 8); else CVJP_L(VW, (VW == 2 ? 16 : 1));
+    } else {
+      if (chv == 2) CVJP_L(1, 2); else if (chv == 8) CVJP_L(1, 8); else if (chv == 16) CVJP_L(1, 16); else CVJP_L(1, 32);
+    }
+  }
+#undef CVJP_L
+#undef CVJP_K
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+}  // namespace
+
+BJX_API int bjx_vec_cholesky_inv_vjp(bjx_ctx* ctx, bjx_dtype dt, int uplo, const void* y, const void* W_bar, const void* logJ_bar,
+                                     void* y_bar, int64_t K, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, uplo == 'U' || uplo == 'L', BJX_ERR_ARG, "mode must be either :U (upper triangular) or :L (lower triangular)");
+  BJX_REQUIRE(ctx, K >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_vec_cholesky_inv_vjp: bad size");
+  BJX_REQUIRE(ctx, (y && W_bar && y_bar) || batch == 0 || K == 1, BJX_ERR_ARG, "bjx_vec_cholesky_inv_vjp: null pointer");
+  if (dt == BJX_F32) return chol_inv_vjp_impl<float>(ctx, uplo, (const float*)y, (const float*)W_bar, (const float*)logJ_bar, (float*)y_bar, K, batch);
+  if (dt == BJX_F64) return chol_inv_vjp_impl<double>(ctx, uplo, (const double*)y, (const double*)W_bar, (const double*)logJ_bar, (double*)y_bar, K, batch);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_vec_cholesky_inv_vjp: bad dtype %d", (int)dt);
 }
 
 BJX_API int bjx_vec_cholesky(bjx_ctx* ctx, bjx_dtype dt, int inverse, int uplo, const void* in, void* out, void* ladj_ps,

@@ -1105,12 +1105,43 @@ class Stacked(Transform):
 
 
 # ------------------------------------------------------------------ reverse-mode pullbacks
+def _ladj_bar(ladj_bar, batch, like):
+    if ladj_bar is None:
+        return None
+    lb = ladj_bar if isinstance(ladj_bar, torch.Tensor) else torch.full((batch,), float(ladj_bar), dtype=like.dtype, device=like.device)
+    lb = lb.to(device=like.device, dtype=like.dtype).reshape(-1).contiguous()
+    if lb.numel() == 1 and batch != 1:
+        lb = lb.expand(batch).contiguous()
+    if lb.numel() != batch:
+        raise ValueError("DimensionMismatch: ladj_bar needs one entry per column")
+    return lb
+
+
 def vjp(b, x, out_bar, ladj_bar=None):
     """Pullback of `with_logabsdet_jacobian(b, x)`: returns x_bar = J(x)^T out_bar + ladj_bar * grad_x logabsdetjac.
 
     `out_bar` has the shape of b(x); `ladj_bar` is the cotangent of the PER-COLUMN log-det (a (batch,) tensor,
     a python number broadcast over the batch, or None = 0).  Device kernels exist for the bijectors whose
-    rrules the reference ships (ext/BijectorsChainRulesCoreExt.jl): OrderedBijector and its inverse (:65-197)."""
+    rrules the reference ships (ext/BijectorsChainRulesCoreExt.jl): OrderedBijector and its inverse (:65-197)
+    and inverse(VecCholeskyBijector) (:311-320, src/bijectors/corr.jl:402-451)."""
+    inv = isinstance(b, Inverse)
+    base = b.orig if inv else b
+    if inv and isinstance(base, VecCholeskyBijector):
+        # inverse(VecCholeskyBijector): y (n[, batch]) -> W (K, K[, batch]); corr.jl:402-451
+        yc, n, batch, vec = _prep(x)
+        K = _triu1_dim_from_length(n)
+        if K * (K - 1) // 2 != n:
+            raise ValueError(f"DimensionMismatch: {n} is not a triangular number K(K-1)/2")
+        Wb = out_bar
+        if tuple(Wb.shape) != ((K, K) if vec else (K, K, batch)) or Wb.dtype != yc.dtype:
+            raise ValueError("DimensionMismatch: out_bar must be (K, K[, batch]) with the dtype of y")
+        Wc = Wb.T.contiguous().T if vec else Wb.permute(2, 1, 0).contiguous().permute(2, 1, 0)   # column-major per sample
+        lb = _ladj_bar(ladj_bar, batch, yc)
+        ctx = context(yc.device)
+        yb = _empty(n, batch, yc, vec)
+        rc = L.load().bjx_vec_cholesky_inv_vjp(ctx.h, _dt(yc), ord(base.mode), _ptr(yc), _ptr(Wc), _ptr(lb), _ptr(yb), K, batch)
+        L.check(ctx.h, rc, "bjx_vec_cholesky_inv_vjp")
+        return yb
     inv = isinstance(b, Inverse)
     base = b.orig if inv else b
     if not isinstance(base, OrderedBijector):
@@ -1119,14 +1150,7 @@ def vjp(b, x, out_bar, ladj_bar=None):
     gc, gdim, gbatch, _ = _prep(out_bar)
     if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:
         raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
-    lb = None
-    if ladj_bar is not None:
-        lb = ladj_bar if isinstance(ladj_bar, torch.Tensor) else torch.full((batch,), float(ladj_bar), dtype=xc.dtype, device=xc.device)
-        lb = lb.to(device=xc.device, dtype=xc.dtype).reshape(-1).contiguous()
-        if lb.numel() == 1 and batch != 1:
-            lb = lb.expand(batch).contiguous()
-        if lb.numel() != batch:
-            raise ValueError("DimensionMismatch: ladj_bar needs one entry per column")
+    lb = _ladj_bar(ladj_bar, batch, xc)
     ctx = context(xc.device)
     xb = _empty(dim, batch, xc, vec)
     rc = L.load().bjx_ordered_vjp(ctx.h, _dt(xc), int(inv), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)

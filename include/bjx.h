@@ -227,6 +227,12 @@ int bjx_stacked(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs,
  * _transform_inverse_ordered, matrix methods). */
 int bjx_ordered_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar,
                     const void* ladj_bar, void* in_bar, int64_t dim, int64_t batch);
+/* inverse(VecCholeskyBijector): y[n,batch] -> (W[K,K,batch], logJ[batch]); pullback
+ * src/bijectors/corr.jl:402-451 (_inv_link_chol_lkj_rrule; ext/BijectorsChainRulesCoreExt.jl:311-320).
+ * W_bar: dense K x K per sample (entries outside the stored triangle are ignored), logJ_bar: T[batch]
+ * or NULL, y_bar: T[n,batch]. */
+int bjx_vec_cholesky_inv_vjp(bjx_ctx* ctx, bjx_dtype dt, int uplo, const void* y, const void* W_bar,
+                             const void* logJ_bar, void* y_bar, int64_t K, int64_t batch);
 
 /* ------------------------------- multi-GPU                */
 /* RCCL communicator owned by the context (one process per GPU).  `unique_id` is the 128-byte

@@ -316,3 +316,45 @@ def ordered_vjp(inp, out_bar, ladj_bar=None, inverse=False):
         res[i] = d[i] / r[i] - d[i + 1] / r[i + 1]
     res[n - 1] = d[n - 1] / r[n - 1]           # :172-174
     return res
+
+
+def vec_cholesky_inv_vjp(y, W_bar, logJ_bar=None, uplo="U"):
+    """Pullback of _inv_link_chol_lkj for y (n, batch), W_bar (K, K, batch), logJ_bar (batch,):
+    src/bijectors/corr.jl:402-451 (_inv_link_chol_lkj_rrule), loops in the reference's order,
+    vectorised over the batch.  uplo="L": W is the transposed (lower) factor, so ΔW is read transposed.
+    At z == 0 exactly the reference's (inv(z) - z) * W[i,j] * ΔW[i,j] is Inf * 0; its limit
+    (1 - z²) exp(log_remainder) ΔW[i,j] is used there."""
+    y = np.asarray(y)
+    n, N = y.shape
+    K = (1 + int(round(np.sqrt(1 + 8 * n)))) // 2
+    dW = np.asarray(W_bar, dtype=y.dtype)
+    if uplo == "L":
+        dW = np.transpose(dW, (1, 0, 2))
+    dl = np.zeros(N, dtype=y.dtype) if logJ_bar is None else np.broadcast_to(np.asarray(logJ_bar, dtype=y.dtype), (N,))
+    z_vec = np.tanh(y)                                                        # :411
+    lc_vec = np.abs(y) + np.log1p(np.exp(-2 * np.abs(y))) - np.log(2.0)       # :412 LogExpFunctions.logcosh
+    W = np.zeros((K, K, N), dtype=y.dtype)
+    E = np.empty_like(y)                                                      # exp(log_remainder) before each entry
+    W[0, 0] = 1
+    idx = 0
+    for j in range(1, K):                                                     # :416-431 (primal)
+        lr = np.zeros(N, dtype=y.dtype)
+        for i in range(j):
+            E[idx] = np.exp(lr)
+            W[i, j] = z_vec[idx] * E[idx]
+            lr = lr - lc_vec[idx]
+            idx += 1
+        W[j, j] = np.exp(lr)
+    dy = np.empty_like(y)
+    idx = n - 1
+    for j in range(K - 1, 0, -1):                                             # :437-447
+        dlr = W[j, j] * dW[j, j] + 2 * dl
+        for i in range(j - 1, -1, -1):
+            W_dW = W[i, j] * dW[i, j]
+            z = z_vec[idx]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                first = np.where(z == 0, E[idx] * dW[i, j], (1 / z - z) * W_dW)
+            dy[idx] = first - z * dlr
+            idx -= 1
+            dlr = dlr + dl + W_dW
+    return dy

@@ -661,3 +661,23 @@ def test_ordered_vjp(bj, orc, shape, dt):
     # no log-det cotangent, vector input
     g1 = bj.vjp(b, dev(y[:, 0].copy()), dev(gbar[:, 0].copy()))
     close(host(g1), orc.ordered_vjp(y[:, :1].astype(np.float64), gbar[:, :1].astype(np.float64))[:, 0], dt, scale=10 * n)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("K,N", [(2, 5), (3, 33), (5, 100), (12, 64), (33, 21), (64, 40)])
+@pytest.mark.parametrize("uplo", ["U", "L"])
+def test_vec_cholesky_inverse_vjp(bj, orc, K, N, uplo, dt):
+    if dt == np.float64 and K == 64:
+        pytest.skip("Float64 K = 64 needs a 64 KiB tile per wave: not covered by the LDS tile kernel")
+    r = rng(52)
+    n = K * (K - 1) // 2
+    y = np.asfortranarray((0.5 * r.normal(size=(n, N))).astype(dt))
+    Wbar = r.normal(size=(K, K, N)).astype(dt)
+    lbar = r.normal(size=N).astype(dt)
+    ref = orc.vec_cholesky_inv_vjp(y.astype(np.float64), Wbar.astype(np.float64), lbar.astype(np.float64), uplo=uplo)
+    b = bj.inverse(bj.VecCholeskyBijector(uplo))
+    got = bj.vjp(b, dev(y), dev(Wbar), torch.from_numpy(lbar).cuda())
+    np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())))
+    g0 = bj.vjp(b, dev(y), dev(Wbar))                                    # no log-det cotangent
+    ref0 = orc.vec_cholesky_inv_vjp(y.astype(np.float64), Wbar.astype(np.float64), None, uplo=uplo)
+    np.testing.assert_allclose(host(g0), ref0, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref0).max())))

@@ -395,3 +395,25 @@ def test_ordered_pullbacks_match_finite_differences(orc):
     # pullback(inverse) at b(y) is the inverse-transpose of pullback(forward) at y (ladj terms off)
     back = orc.ordered_vjp(x, orc.ordered_vjp(y, gbar), inverse=True)
     np.testing.assert_allclose(back, gbar, rtol=1e-10, atol=1e-12)
+
+
+def test_vec_cholesky_inverse_pullback_matches_finite_differences(orc):
+    """corr.jl:402-451 restated; pinned like the reference pins it (finite differences, test/ad/chainrules.jl)."""
+    r = np.random.default_rng(6)
+    K, N = 5, 3
+    n = K * (K - 1) // 2
+    y = np.asfortranarray(0.6 * r.normal(size=(n, N)))
+    Wbar = r.normal(size=(K, K, N))
+    lbar = r.normal(size=N)
+    for uplo in ("U", "L"):
+        got = orc.vec_cholesky_inv_vjp(y, Wbar, lbar, uplo=uplo)
+        fd = np.zeros_like(y)
+        h = 1e-6
+        for i in range(n):
+            yp, ym = y.copy(), y.copy()
+            yp[i] += h
+            ym[i] -= h
+            Wp, lp = orc.vec_cholesky(np.asfortranarray(yp), inverse=True, uplo=uplo)
+            Wm, lm = orc.vec_cholesky(np.asfortranarray(ym), inverse=True, uplo=uplo)
+            fd[i] = ((Wp - Wm) * Wbar).sum(axis=(0, 1)) / (2 * h) + lbar * (lp - lm) / (2 * h)
+        np.testing.assert_allclose(got, fd, rtol=1e-6, atol=1e-7, err_msg=uplo)
