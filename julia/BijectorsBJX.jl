@@ -13,7 +13,9 @@ using AMDGPU: AMDGPU, ROCArray, ROCVector, ROCMatrix
 using Bijectors
 using Bijectors: Elementwise, Inverse, Shift, Scale, Logit, LeakyReLU, TruncatedBijector, OrderedBijector,
     SimplexBijector, VecCholeskyBijector, Permute, PlanarLayer, RadialLayer, InvertibleBatchNorm,
-    RationalQuadraticSpline
+    RationalQuadraticSpline, Stacked
+using ChainRulesCore: ChainRulesCore
+const ROCVecOrMat{T} = Union{ROCVector{T},ROCMatrix{T}}
 import Bijectors: transform, logabsdetjac, with_logabsdet_jacobian, with_logabsdet_jacobian!
 
 const libbjx = get(ENV, "BJX_LIBRARY", "libbjx_hip.so")
@@ -191,6 +193,65 @@ function with_logabsdet_jacobian(b::RationalQuadraticSpline{<:ROCMatrix{T}}, x::
 end
 # VecCholeskyBijector, Permute, Coupling and the Inverse{…} flow methods follow the same pattern
 # (bjx_vec_cholesky / bjx_permute / bjx_coupling_* / inverse = Cint(1)); see INTEGRATION.md.
+
+# ---------------------------------------------------------------- Stacked (SURVEY.md §8f f-4)
+# stacked.jl:27-252: every segment whose bijector is a fusable elementwise chain goes into ONE launch.
+struct BjxSegment
+    in_lo::Int64; out_lo::Int64; len::Int64; n_ops::Int32; reserved::Int32
+    ops::NTuple{4,BjxOp}
+end
+const NOOP = BjxOp(Int32(OP_IDENTITY), 0, 0, 0, C_NULL, C_NULL)
+function with_logabsdet_jacobian(sb::Stacked, x::ROCVecOrMat{T}) where {T<:Union{Float32,Float64}}
+    d, n = dims(x)
+    sb.length_in == d || error("input length mismatch ($(sb.length_in) != $d)")          # stacked.jl:157
+    keep = Any[]
+    segs = BjxSegment[]
+    for (b, rin, rout) in zip(sb.bs, sb.ranges_in, sb.ranges_out)
+        o = b === identity ? BjxOp[] : ops(b, T, keep)
+        (o === nothing || length(o) > 4 || length(rin) != length(rout)) &&
+            return invoke(with_logabsdet_jacobian, Tuple{Stacked,AbstractVector}, sb, x)   # structured segment: generic method
+        push!(segs, BjxSegment(first(rin) - 1, first(rout) - 1, length(rin), length(o), 0,
+                               ntuple(k -> k <= length(o) ? o[k] : NOOP, 4)))
+    end
+    y = similar(x)
+    lsum = AMDGPU.zeros(Float64, 1)
+    GC.@preserve keep x y lsum begin
+        rc = ccall((:bjx_stacked, libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+            ctx().h, dtype(T), segs, length(segs), devptr(x), devptr(y), C_NULL, devptr(lsum), d, n, 0)
+        check(rc, "bjx_stacked")
+    end
+    return y, T(Array(lsum)[1])
+end
+
+# ---------------------------------------------------------------- reverse-mode pullbacks (SURVEY.md §8f f-1)
+# The reference's own rrules (ext/BijectorsChainRulesCoreExt.jl:65-197, :311-320) for ROCArray primals:
+# the pullback closure calls the `_vjp` entry with the saved primal input.
+function ChainRulesCore.rrule(::typeof(Bijectors._transform_ordered), y::ROCMatrix{T}) where {T}
+    x = first(with_logabsdet_jacobian(OrderedBijector(), y))
+    function _transform_ordered_adjoint(Δ)
+        ȳ = similar(y)
+        Δc = ROCArray{T}(ChainRulesCore.unthunk(Δ))
+        GC.@preserve y Δc ȳ check(ccall((:bjx_ordered_vjp, libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+            ctx().h, dtype(T), 0, devptr(y), devptr(Δc), C_NULL, devptr(ȳ), size(y, 1), size(y, 2)), "bjx_ordered_vjp")
+        return ChainRulesCore.NoTangent(), ȳ
+    end
+    return x, _transform_ordered_adjoint
+end
+function ChainRulesCore.rrule(::typeof(Bijectors._inv_link_chol_lkj), y::ROCMatrix{T}) where {T}   # columns = samples
+    K = Bijectors._triu1_dim_from_length(size(y, 1)); n = size(y, 2)
+    W = similar(y, K, K, n); logJ = similar(y, n)
+    # primal: bjx_vec_cholesky(inverse = 1, uplo = 'U'); pullback:
+    function pullback_inv_link_chol_lkj((ΔW, ΔlogJ))
+        Δy = similar(y)
+        GC.@preserve y ΔW ΔlogJ Δy check(ccall((:bjx_vec_cholesky_inv_vjp, libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+            ctx().h, dtype(T), Cint('U'), devptr(y), devptr(ΔW), devptr(ΔlogJ), devptr(Δy), K, n), "bjx_vec_cholesky_inv_vjp")
+        return ChainRulesCore.NoTangent(), Δy
+    end
+    return (W, logJ), pullback_inv_link_chol_lkj
+end
 
 # ---------------------------------------------------------------- multi-GPU (one process per GPU)
 comm_unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:bjx_comm_unique_id, libbjx), Cint, (Ptr{UInt8},), id), "bjx_comm_unique_id"); id)
