@@ -212,13 +212,12 @@ template <class T, bool GATHER, bool IN_LDS> struct StackedF {
   }
 };
 
+struct StackedPlan { char* tab; size_t tab_bytes; bool gather; int two; int V; };
+
+// validates the segment list, uploads it and launches the table build; `x`/`y` only decide the pack width
 template <class T>
-int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, T* y, T* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch,
-                 uint32_t flags) {
-  if (dim * batch == 0) {
-    if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
-    return BJX_OK;
-  }
+int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const void* x, const void* y, int64_t dim, int64_t batch, bool inplace_check,
+                    StackedPlan* plan) {
   // validate on the host: every output row and every input row exactly once (stacked.jl:156-165 checks the lengths)
   int64_t total = 0;
   int max_ops = 0;
@@ -239,7 +238,7 @@ int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, 
   const size_t seg_bytes = ((size_t)n_segs * sizeof(SegDev) + 63) / 64 * 64;
   const size_t tab_bytes = (size_t)dim * stacked_row_bytes<T>();
   BJX_REQUIRE(ctx, 64 + seg_bytes + tab_bytes <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_stacked: %d segments / %lld rows exceed the context scratch", n_segs, (long long)dim);
-  BJX_REQUIRE(ctx, !gather || x != y, BJX_ERR_ARG, "bjx_stacked: in-place is only supported when every segment keeps its rows (ranges_in == ranges_out)");
+  BJX_REQUIRE(ctx, !inplace_check || !gather || x != y, BJX_ERR_ARG, "bjx_stacked: in-place is only supported when every segment keeps its rows (ranges_in == ranges_out)");
   // value-independent slot count per segment (same rules as stacked_table_kernel)
   for (int sg = 0; sg < n_segs; ++sg) {
     int cur = 0;
@@ -288,14 +287,144 @@ int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, 
   const ColLaunch cl = col_launch_cfg<T>(ctx, x, y, dim, batch);
   hipLaunchKernelGGL(stacked_table_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, dseg, n_segs, dim, cl.V, tab, flag);
   BJX_CHECK_LAUNCH(ctx);
-  const int two = max_ops > 1 ? 1 : 0;
-  const bool lds = tab_bytes <= 48 * 1024;
-  const size_t fsm = lds ? tab_bytes : 0;
+  plan->tab = tab; plan->tab_bytes = tab_bytes; plan->gather = gather; plan->two = max_ops > 1 ? 1 : 0; plan->V = cl.V;
+  return BJX_OK;
+}
+
+template <class T>
+int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, T* y, T* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch,
+                 uint32_t flags) {
+  if (dim * batch == 0) {
+    if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
+    return BJX_OK;
+  }
+  StackedPlan pl;
+  { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, y, dim, batch, true, &pl); if (rc) return rc; }
+  char* tab = pl.tab;
+  const int two = pl.two;
+  const bool lds = pl.tab_bytes <= 48 * 1024;
+  const size_t fsm = lds ? pl.tab_bytes : 0;
 #define STK_LAUNCH(G_, L_) do { StackedF<T, G_, L_> f{tab, dim, two, 0.0, nullptr}; return launch_colgroup<T>(ctx, f, fsm, x, y, ladj_ps, ladj_sum, dim, batch, flags, 0.0); } while (0)
-  if (gather) { if (lds) STK_LAUNCH(true, true); else STK_LAUNCH(true, false); }
+  if (pl.gather) { if (lds) STK_LAUNCH(true, true); else STK_LAUNCH(true, false); }
   if (lds) STK_LAUNCH(false, true);
   STK_LAUNCH(false, false);
 #undef STK_LAUNCH
+}
+
+// ------------------------------------------------------------------ pullback (elementwise part)
+// x_bar = (dy/dx) y_bar + ladj_bar (d ladj / dx), element by element through the same canonical slots:
+//   u = a1 clamp(x) + b1,  v = N(u),  y = clamp(a2 v + b2):   dy/dx = a2 N'(u) a1 (0 where a clamp is active),
+//   d ladj/dx = l_N'(u) a1.   N: exp (v, 1) | log (1/u, -1/u) | logit (1/(u(1-u)), -(1-2u)/(u(1-u))) |
+//   logistic (s(1-s), 1-2s) | leaky (J, 0) | id (1, 0).   Two slots chain: x -> x1 -> y.
+template <class T> __device__ __forceinline__ void slot_grad(const Slot<T>& s, T x, T& y, T& dy, T& dl) {
+  using F = Fast<T>;
+  const bool pre_active = x < s.clo || x > s.chi;
+  const T xc = d_med3(x, s.clo, s.chi);
+  const T u = s.a1 * xc + s.b1;
+  T v = u, np = T(1), lp = T(0);
+  switch (s.kind) {
+    case SK_EXP: v = F::exp(u); np = v; lp = T(1); break;
+    case SK_LOG: { const T r = F::rcp(u); v = F::log(u); np = r; lp = -r; } break;
+    case SK_LOGIT: { const T r = F::rcp(u * (T(1) - u)); v = F::log(u * F::rcp(T(1) - u)); np = r; lp = -(T(1) - 2 * u) * r; } break;
+    case SK_LOGISTIC: { v = f_logistic(u); np = v * (T(1) - v); lp = T(1) - 2 * v; } break;
+    case SK_LEAKY: { const T J = u < T(0) ? s.alpha : T(1); v = J * u; np = J; } break;
+    default: break;
+  }
+  const T yr = s.a2 * v + s.b2;
+  const bool post_active = yr < s.plo || yr > s.phi;
+  y = d_med3(yr, s.plo, s.phi);
+  const T m = pre_active ? T(0) : s.a1;
+  dy = post_active ? T(0) : s.a2 * np * m;
+  dl = lp * m;
+}
+
+template <class T, int V, bool GATHER, bool IN_LDS>
+__global__ __launch_bounds__(256) void stacked_vjp_kernel(const char* __restrict__ tab_g, int two_slots, const T* __restrict__ x, const T* __restrict__ ybar,
+                                                          const T* __restrict__ lbar, T* __restrict__ xbar, int64_t dim, int64_t batch, int G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (IN_LDS) {
+    const int n16 = (int)(dim * stacked_row_bytes<T>() / 16);
+    const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(tab_g);
+    bjx_f32x4* dst = reinterpret_cast<bjx_f32x4*>(smem);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+  }
+  const char* t = IN_LDS ? smem : tab_g;
+  const int gl = threadIdx.x & (G - 1);
+  const int cols_per_block = blockDim.x / G;
+  const int64_t nvc = dim / V;
+  for (int uc = 0; uc < COL_UC; ++uc) {
+    const int64_t col = ((int64_t)blockIdx.x * COL_UC + uc) * cols_per_block + threadIdx.x / G;
+    if (col >= batch) continue;
+    const T lb = lbar ? lbar[col] : T(0);
+    const T* xc = x + col * dim;
+    const T* gc = ybar + col * dim;
+    T* oc = xbar + col * dim;
+    for (int64_t v = gl; v < nvc; v += G) {
+      Pack<T, V> px, pg;
+      if (!GATHER) px = load_pack<T, V, true>(xc + v * V);
+      pg = load_pack<T, V, true>(gc + v * V);
+#pragma unroll 1
+      for (int j = 0; j < V; ++j) {
+        const Slot<T>* e = reinterpret_cast<const Slot<T>*>(t + (V > 1 ? j * nvc + v : v) * stacked_row_bytes<T>());
+        const Slot<T> s0 = e[0];
+        T xv = px.v[0], gv = pg.v[0];
+        if (V > 1) {
+          xv = j == 1 ? px.v[1 % V] : (j == 2 ? px.v[2 % V] : (j == 3 ? px.v[3 % V] : xv));
+          gv = j == 1 ? pg.v[1 % V] : (j == 2 ? pg.v[2 % V] : (j == 3 ? pg.v[3 % V] : gv));
+        }
+        if (GATHER) xv = xc[s0.src];
+        T x1, dy0, dl0;
+        slot_grad<T>(s0, xv, x1, dy0, dl0);
+        T g = gv;                                     // cotangent of the value entering the remaining slots
+        if (two_slots) {
+          const Slot<T> s1 = e[1];
+          if (s1.kind != SK_END) {
+            T y2, dy1, dl1;
+            slot_grad<T>(s1, x1, y2, dy1, dl1);
+            g = gv * dy1 + lb * dl1;
+          }
+        }
+        const T res = g * dy0 + lb * dl0;
+        if (GATHER) oc[s0.src] = res;
+        else if (V == 1) px.v[0] = res;
+        else {
+          px.v[0] = j == 0 ? res : px.v[0];
+          px.v[1 % V] = j == 1 ? res : px.v[1 % V];
+          px.v[2 % V] = j == 2 ? res : px.v[2 % V];
+          px.v[3 % V] = j == 3 ? res : px.v[3 % V];
+        }
+      }
+      if (!GATHER) store_pack<T, V, true>(oc + v * V, px);
+    }
+  }
+}
+
+template <class T>
+int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, const T* ybar, const T* lbar, T* xbar, int64_t dim, int64_t batch) {
+  if (dim * batch == 0) return BJX_OK;
+  StackedPlan pl;
+  const bool al = bjx_aligned16(x) && bjx_aligned16(ybar) && bjx_aligned16(xbar);
+  { int rc = stacked_prepare<T>(ctx, segs, n_segs, al ? (const void*)x : (const void*)(reinterpret_cast<const char*>(x) + 4), xbar, dim, batch, false, &pl); if (rc) return rc; }
+  const bool lds = pl.tab_bytes <= 48 * 1024;
+  const size_t smem = lds ? pl.tab_bytes : 0;
+  const int64_t packs = dim / pl.V;
+  int G = 1;
+  while (G < 64 && G < packs) G <<= 1;
+  const int64_t cpb = (int64_t)(256 / G) * COL_UC;
+  const int64_t grid = (batch + cpb - 1) / cpb;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_stacked_vjp: batch too large for one launch");
+  constexpr int VW = Vec16<T>::N;
+#define SVJP(V_, G_, L_) hipLaunchKernelGGL((stacked_vjp_kernel<T, V_, G_, L_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, pl.tab, pl.two, x, ybar, lbar, xbar, dim, batch, G)
+#define SVJP_V(V_) do { if (pl.gather) { if (lds) SVJP(V_, true, true); else SVJP(V_, true, false); } else { if (lds) SVJP(V_, false, true); else SVJP(V_, false, false); } } while (0)
+  {
+    BjxProf prof_(ctx);
+    if (pl.V == VW) SVJP_V(VW); else SVJP_V(1);
+  }
+#undef SVJP_V
+#undef SVJP
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
 }
 }  // namespace
 
@@ -308,4 +437,16 @@ BJX_API int bjx_stacked(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int
   if (dt == BJX_F32) return stacked_impl<float>(ctx, segs, n_segs, (const float*)x, (float*)y, (float*)ladj_ps, ladj_sum, dim, batch, flags);
   if (dt == BJX_F64) return stacked_impl<double>(ctx, segs, n_segs, (const double*)x, (double*)y, (double*)ladj_ps, ladj_sum, dim, batch, flags);
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_stacked: bad dtype %d", (int)dt);
+}
+
+BJX_API int bjx_stacked_vjp(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const void* x, const void* y_bar,
+                            const void* ladj_bar, void* x_bar, int64_t dim, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 0 && batch >= 0 && n_segs >= 0, BJX_ERR_SHAPE, "bjx_stacked_vjp: negative size");
+  BJX_REQUIRE(ctx, (segs || n_segs == 0) && ((x && y_bar && x_bar) || dim * batch == 0), BJX_ERR_ARG, "bjx_stacked_vjp: null pointer");
+  BJX_REQUIRE(ctx, x_bar != x, BJX_ERR_ARG, "bjx_stacked_vjp: x_bar may not alias x");
+  BJX_REQUIRE(ctx, dim < ((int64_t)1 << 31), BJX_ERR_UNSUPPORTED, "bjx_stacked_vjp: too many rows");
+  if (dt == BJX_F32) return stacked_vjp_impl<float>(ctx, segs, n_segs, (const float*)x, (const float*)y_bar, (const float*)ladj_bar, (float*)x_bar, dim, batch);
+  if (dt == BJX_F64) return stacked_vjp_impl<double>(ctx, segs, n_segs, (const double*)x, (const double*)y_bar, (const double*)ladj_bar, (double*)x_bar, dim, batch);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_stacked_vjp: bad dtype %d", (int)dt);
 }

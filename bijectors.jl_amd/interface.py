@@ -1041,6 +1041,52 @@ class Stacked(Transform):
         inv.length_in, inv.length_out = self.length_out, self.length_in
         return inv
 
+    def _segments(self, segs_ops, fused, xc):
+        """bjx_segment[] for the fusable segments (+ the parameter tensors that must stay alive)"""
+        arr = (L.BjxSegment * max(len(self.bs), 1))()
+        keep = []
+        for si, i in enumerate(fused):
+            (lo, hi), (olo, _) = self.ranges_in[i], self.ranges_out[i]
+            sg = arr[si]
+            sg.in_lo, sg.out_lo, sg.len, sg.n_ops = lo - 1, olo - 1, hi - lo + 1, len(segs_ops[i])
+            for k, (kind, p0, p1) in enumerate(segs_ops[i]):
+                o = sg.ops[k]
+                o.kind, o.param_len, o.p0, o.p1, o.v0, o.v1 = kind, 0, 0.0, 0.0, None, None
+                seq = any(_is_seq(p) for p in (p0, p1) if p is not None)
+                for j, p in enumerate((p0, p1)):
+                    if p is None:
+                        continue
+                    if seq:
+                        t = _param(p, xc).reshape(-1) if _is_seq(p) else torch.full((sg.len,), float(p), dtype=xc.dtype, device=xc.device)
+                        if t.numel() != sg.len:
+                            raise ValueError(f"DimensionMismatch: parameter of length {t.numel()} for a segment of {sg.len} rows")
+                        keep.append(t)
+                        o.param_len = sg.len
+                        setattr(o, f"v{j}", t.data_ptr())
+                    else:
+                        o.param_len = 1
+                        setattr(o, f"p{j}", float(p))
+        return arr, keep
+
+    def _vjp(self, x, out_bar, ladj_bar):
+        xc, dim, batch, vec = _prep(x)
+        gc, gdim, gbatch, _ = _prep(out_bar)
+        if dim != self.length_in:
+            raise ValueError(f"input length mismatch ({self.length_in} != {dim})")
+        if (gdim, gbatch) != (self.length_out, batch) or gc.dtype != xc.dtype:
+            raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
+        segs_ops = [_elementwise_ops(b) for b in self.bs]
+        if any(o is None or len(o) > L.BJX_MAX_SEG_OPS for o in segs_ops) or self.length_out != dim:
+            raise NotImplementedError("device pullback of Stacked needs every segment to be a chain of <= 4 elementwise bijectors")
+        arr, keep = self._segments(segs_ops, list(range(len(self.bs))), xc)
+        lb = _ladj_bar(ladj_bar, batch, xc)
+        ctx = context(xc.device)
+        xb = _empty(dim, batch, xc, vec)
+        rc = L.load().bjx_stacked_vjp(ctx.h, _dt(xc), arr, len(self.bs), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
+        del keep
+        L.check(ctx.h, rc, "bjx_stacked_vjp")
+        return xb
+
     def _wlj(self, x, per_sample, want_ladj=True):
         xc, dim, batch, vec = _prep(x)
         if dim != self.length_in:
@@ -1052,29 +1098,7 @@ class Stacked(Transform):
         y = _empty(self.length_out, batch, xc, vec)
         out = _Out(xc, batch, per_sample, want_ladj)
         if not rest and self.length_out == dim:
-            arr = (L.BjxSegment * max(len(self.bs), 1))()
-            keep = []
-            for si, i in enumerate(fused):
-                (lo, hi), (olo, _) = self.ranges_in[i], self.ranges_out[i]
-                sg = arr[si]
-                sg.in_lo, sg.out_lo, sg.len, sg.n_ops = lo - 1, olo - 1, hi - lo + 1, len(segs_ops[i])
-                for k, (kind, p0, p1) in enumerate(segs_ops[i]):
-                    o = sg.ops[k]
-                    o.kind, o.param_len, o.p0, o.p1, o.v0, o.v1 = kind, 0, 0.0, 0.0, None, None
-                    seq = any(_is_seq(p) for p in (p0, p1) if p is not None)
-                    for j, p in enumerate((p0, p1)):
-                        if p is None:
-                            continue
-                        if seq:
-                            t = _param(p, xc).reshape(-1) if _is_seq(p) else torch.full((sg.len,), float(p), dtype=xc.dtype, device=xc.device)
-                            if t.numel() != sg.len:
-                                raise ValueError(f"DimensionMismatch: parameter of length {t.numel()} for a segment of {sg.len} rows")
-                            keep.append(t)
-                            o.param_len = sg.len
-                            setattr(o, f"v{j}", t.data_ptr())
-                        else:
-                            o.param_len = 1
-                            setattr(o, f"p{j}", float(p))
+            arr, keep = self._segments(segs_ops, fused, xc)
             rc = L.load().bjx_stacked(ctx.h, _dt(xc), arr, len(fused), _ptr(xc), _ptr(y), _ptr(out.ps), _ptr(out.sum), dim, batch, 0)
             del keep
             if rc != L.ERR_UNSUPPORTED:   # a chain with > 2 nonlinear stages is evaluated per segment below
@@ -1121,9 +1145,15 @@ def vjp(b, x, out_bar, ladj_bar=None):
     """Pullback of `with_logabsdet_jacobian(b, x)`: returns x_bar = J(x)^T out_bar + ladj_bar * grad_x logabsdetjac.
 
     `out_bar` has the shape of b(x); `ladj_bar` is the cotangent of the PER-COLUMN log-det (a (batch,) tensor,
-    a python number broadcast over the batch, or None = 0).  Device kernels exist for the bijectors whose
+    a python number broadcast over the batch, or None = 0).  Elementwise chains and `Stacked`s of them go through
+    bjx_stacked_vjp (input gradient only, not the bijectors' parameters); device kernels also exist for the bijectors whose
     rrules the reference ships (ext/BijectorsChainRulesCoreExt.jl): OrderedBijector and its inverse (:65-197)
     and inverse(VecCholeskyBijector) (:311-320, src/bijectors/corr.jl:402-451)."""
+    if isinstance(b, Stacked):
+        return b._vjp(x, out_bar, ladj_bar)
+    if _elementwise_ops(b) is not None:                 # any chain of elementwise bijectors = one segment over all rows
+        dim = x.shape[0]
+        return Stacked([b], [(1, dim)])._vjp(x, out_bar, ladj_bar)
     inv = isinstance(b, Inverse)
     base = b.orig if inv else b
     if inv and isinstance(base, VecCholeskyBijector):

@@ -225,6 +225,11 @@ int bjx_stacked(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs,
  * `in_bar` the result (may not alias `in`; may alias `out_bar`).
  * OrderedBijector: ext/BijectorsChainRulesCoreExt.jl:65-197 (rrules of _transform_ordered and
  * _transform_inverse_ordered, matrix methods). */
+/* Stacked / any chain of elementwise bijectors (same segment list as bjx_stacked): x_bar[src row] =
+ * (dy/dx) y_bar[out row] + ladj_bar (d logabsdetjac / dx), element by element (the Jacobian is diagonal up
+ * to the row mapping).  Gradients with respect to the bijectors' PARAMETERS are not produced. */
+int bjx_stacked_vjp(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const void* x,
+                    const void* y_bar, const void* ladj_bar, void* x_bar, int64_t dim, int64_t batch);
 int bjx_ordered_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar,
                     const void* ladj_bar, void* in_bar, int64_t dim, int64_t batch);
 /* inverse(VecCholeskyBijector): y[n,batch] -> (W[K,K,batch], logJ[batch]); pullback

@@ -358,3 +358,75 @@ def vec_cholesky_inv_vjp(y, W_bar, logJ_bar=None, uplo="U"):
             idx -= 1
             dlr = dlr + dl + W_dW
     return dy
+
+
+def chain_vjp(ops, x, y_bar, ladj_bar=None):
+    """Input pullback of with_logabsdet_jacobian for a chain of elementwise bijectors, (dim, batch) input:
+    x_bar = (dy/dx) y_bar + ladj_bar (d ladj/dx) with ladj the PER-COLUMN log-det.  Closed-form derivatives of
+    the reference's scalar maps (exp_log.jl:5-9, shift.jl:14, scale.jl:13, logit.jl:15-30,
+    leaky_relu.jl:25-29, truncated.jl:15-91), applied in reverse over the stages; numpy, float64."""
+    x = np.asarray(x, dtype=np.float64)
+    dim, N = x.shape
+    lb = np.zeros(N) if ladj_bar is None else np.broadcast_to(np.asarray(ladj_bar, dtype=np.float64), (N,))
+    col = lambda p: np.broadcast_to(np.asarray(p, dtype=np.float64).reshape(-1, 1), (dim, 1)) if np.ndim(p) else float(p)
+    stages = []            # (dy/dx, dl/dx) of every stage at its own input
+    v = x
+    for kind, p0, p1 in ops:
+        a = None if p0 is None else col(p0)
+        b = None if p1 is None else col(p1)
+        one, zero = np.ones_like(v), np.zeros_like(v)
+        if kind == OP_EXP:
+            out, dy, dl = np.exp(v), np.exp(v), one
+        elif kind == OP_LOG:
+            out, dy, dl = np.log(v), 1 / v, -1 / v
+        elif kind == OP_SHIFT:
+            out, dy, dl = v + a, one, zero
+        elif kind == OP_SCALE:
+            out, dy, dl = v * a, one * a, zero
+        elif kind == OP_SCALE_INV:
+            out, dy, dl = v / a, one / a, zero
+        elif kind == OP_SIGNFLIP:
+            out, dy, dl = -v, -one, zero
+        elif kind == OP_LOGIT:
+            w = b - a
+            z = (v - a) / w
+            out, dy = np.log(z / (1 - z)), 1 / (w * z * (1 - z))
+            dl = -(1 - 2 * z) / (w * z * (1 - z))                 # d/dx of -log((x-a)(b-x)/(b-a))
+        elif kind == OP_LOGIT_INV:
+            w = b - a
+            sg = 1 / (1 + np.exp(-v))
+            out, dy, dl = w * sg + a, w * sg * (1 - sg), 1 - 2 * sg   # ladj = log(s(1-s)) + log(b-a)
+        elif kind == OP_LEAKY_RELU:
+            J = np.where(v < 0, a, 1.0)
+            out, dy, dl = J * v, J * one, zero
+        elif kind in (OP_TRUNCATED, OP_TRUNCATED_INV):
+            lo, hi = a * one, b * one
+            lbm, ubm = np.isfinite(lo), np.isfinite(hi)
+            if kind == OP_TRUNCATED:
+                inside = (v >= lo) & (v <= hi)
+                xc = np.clip(v, lo, hi)
+                with np.errstate(all="ignore"):
+                    w = hi - lo
+                    z = (xc - lo) / w
+                    out = np.where(lbm & ubm, np.log(z / (1 - z)), np.where(lbm, np.log(xc - lo), np.where(ubm, np.log(hi - xc), xc)))
+                    dy = np.where(lbm & ubm, 1 / (w * z * (1 - z)), np.where(lbm, 1 / (xc - lo), np.where(ubm, -1 / (hi - xc), 1.0)))
+                    dl = np.where(lbm & ubm, -(1 - 2 * z) / (w * z * (1 - z)), np.where(lbm, -1 / (xc - lo), np.where(ubm, 1 / (hi - xc), 0.0)))
+                dy, dl = np.where(inside, dy, 0.0), np.where(inside, dl, 0.0)
+            else:
+                with np.errstate(all="ignore"):
+                    w = hi - lo
+                    sg = 1 / (1 + np.exp(-v))
+                    ev = np.exp(v)
+                    raw = np.where(lbm & ubm, w * sg + lo, np.where(lbm, ev + lo, np.where(ubm, hi - ev, v)))
+                    dy = np.where(lbm & ubm, w * sg * (1 - sg), np.where(lbm, ev, np.where(ubm, -ev, 1.0)))
+                    dl = np.where(lbm & ubm, 1 - 2 * sg, np.where(lbm | ubm, 1.0, 0.0))
+                out = np.clip(raw, lo, hi)
+                dy = np.where((raw >= lo) & (raw <= hi), dy, 0.0)
+        else:
+            raise ValueError(kind)
+        stages.append((dy, dl))
+        v = out
+    g = np.asarray(y_bar, dtype=np.float64)
+    for dy, dl in reversed(stages):
+        g = g * dy + lb * dl
+    return g

@@ -134,6 +134,8 @@ def main():
     lb2 = randn(Nc, 1, dev, 14).reshape(-1).contiguous()
     rows.append(("vjp(inverse(VecCholesky)) K=64", "f-1", lambda: bj.vjp(icb, yv, Wb, lb2), 4 * (2 * n + K * K) + 4, Nc))
 
+    rows.append(("vjp(Stacked(exp|Logit|identity|exp∘Shift∘Scale)) d=64", "f-1", lambda: bj.vjp(stk, xst, gb, lbar), 3 * d * 4 + 4, N))
+
     only = [s for s in a.only.split(",") if s]
     L, ctx = bj._lib, bj.context(dev)
     lib = L.load()

@@ -681,3 +681,47 @@ def test_vec_cholesky_inverse_vjp(bj, orc, K, N, uplo, dt):
     g0 = bj.vjp(b, dev(y), dev(Wbar))                                    # no log-det cotangent
     ref0 = orc.vec_cholesky_inv_vjp(y.astype(np.float64), Wbar.astype(np.float64), None, uplo=uplo)
     np.testing.assert_allclose(host(g0), ref0, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref0).max())))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_stacked_and_chain_vjp(bj, orc, dt):
+    r = rng(53)
+    N = 130
+    a_vec = np.linspace(0.5, 2.0, 7)
+    segs = [
+        (bj.elementwise(bj.exp), [(orc.OP_EXP, None, None)], (1, 5)),
+        (bj.identity, [], (6, 6)),
+        (bj.Logit(-1.0, 2.0), [(orc.OP_LOGIT, -1.0, 2.0)], (7, 19)),
+        (bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(torch.tensor(a_vec)), [(orc.OP_SCALE, a_vec, None), (orc.OP_SHIFT, 0.1, None), (orc.OP_EXP, None, None)], (20, 26)),
+        (bj.inverse(bj.TruncatedBijector(0.0, 3.0)), [(orc.OP_TRUNCATED_INV, 0.0, 3.0)], (27, 40)),
+        (bj.elementwise(bj.log), [(orc.OP_LOG, None, None)], (41, 41)),
+    ]
+    dim = 41
+    X = r.normal(size=(dim, N))
+    X[6:19] = r.uniform(-0.8, 1.8, size=(13, N))
+    X[40] = r.uniform(0.2, 3.0, size=N)
+    X = np.asfortranarray(X.astype(dt))
+    gbar = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    lbar = r.normal(size=N).astype(dt)
+    ref = np.vstack([orc.chain_vjp(ops, X[lo - 1:hi].astype(np.float64), gbar[lo - 1:hi].astype(np.float64), lbar.astype(np.float64)) if ops
+                     else gbar[lo - 1:hi].astype(np.float64) for _, ops, (lo, hi) in segs])
+    b = bj.Stacked([s[0] for s in segs], [s[2] for s in segs])
+    got = bj.vjp(b, dev(X), dev(gbar), torch.from_numpy(lbar).cuda())
+    np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())))
+    # a plain chain (one segment over all rows), vector parameters, dim % 4 != 0 and == 0
+    for d2 in (7, 64):
+        av = np.linspace(0.5, 1.5, d2)
+        ch = bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(torch.tensor(av))
+        ops = [(orc.OP_SCALE, av, None), (orc.OP_SHIFT, 0.1, None), (orc.OP_EXP, None, None)]
+        X2 = np.asfortranarray(r.normal(size=(d2, N)).astype(dt))
+        g2 = np.asfortranarray(r.normal(size=(d2, N)).astype(dt))
+        ref2 = orc.chain_vjp(ops, X2.astype(np.float64), g2.astype(np.float64), lbar.astype(np.float64))
+        got2 = bj.vjp(ch, dev(X2), dev(g2), torch.from_numpy(lbar).cuda())
+        np.testing.assert_allclose(host(got2), ref2, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref2).max())))
+    # permuted ranges: x_bar lands on the SOURCE rows
+    bp = bj.Stacked([bj.elementwise(bj.exp), bj.Scale(2.0)], [(4, 6), (1, 3)])
+    X3 = np.asfortranarray(r.normal(size=(6, N)).astype(dt))
+    g3 = np.asfortranarray(r.normal(size=(6, N)).astype(dt))
+    got3 = host(bj.vjp(bp, dev(X3), dev(g3), torch.from_numpy(lbar).cuda()))
+    ref3 = np.vstack([2.0 * g3[3:6].astype(np.float64), np.exp(X3[3:6].astype(np.float64)) * g3[0:3] + lbar.astype(np.float64)])
+    np.testing.assert_allclose(got3, ref3, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10)

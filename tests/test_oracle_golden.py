@@ -417,3 +417,33 @@ def test_vec_cholesky_inverse_pullback_matches_finite_differences(orc):
             Wm, lm = orc.vec_cholesky(np.asfortranarray(ym), inverse=True, uplo=uplo)
             fd[i] = ((Wp - Wm) * Wbar).sum(axis=(0, 1)) / (2 * h) + lbar * (lp - lm) / (2 * h)
         np.testing.assert_allclose(got, fd, rtol=1e-6, atol=1e-7, err_msg=uplo)
+
+
+def test_elementwise_chain_pullback_matches_finite_differences(orc):
+    r = np.random.default_rng(7)
+    dim, N = 5, 4
+    a_vec = np.linspace(0.5, 1.5, dim)
+    cases = [
+        ([(orc.OP_SCALE, a_vec, None), (orc.OP_SHIFT, 0.1, None), (orc.OP_EXP, None, None)], lambda: r.normal(size=(dim, N))),
+        ([(orc.OP_LOGIT, -1.0, 2.0)], lambda: r.uniform(-0.8, 1.8, size=(dim, N))),
+        ([(orc.OP_LOGIT_INV, -1.0, 2.0)], lambda: r.normal(size=(dim, N))),
+        ([(orc.OP_LOG, None, None), (orc.OP_SIGNFLIP, None, None)], lambda: r.uniform(0.2, 3.0, size=(dim, N))),
+        ([(orc.OP_LEAKY_RELU, 0.1, None)], lambda: r.normal(size=(dim, N))),
+        ([(orc.OP_TRUNCATED, 0.0, 3.0)], lambda: r.uniform(0.2, 2.8, size=(dim, N))),
+        ([(orc.OP_TRUNCATED_INV, 0.0, np.inf), (orc.OP_SCALE_INV, 2.0, None)], lambda: r.normal(size=(dim, N))),
+    ]
+    h = 1e-6
+    for ops, gen in cases:
+        x = np.asfortranarray(gen())
+        ybar, lbar = r.normal(size=(dim, N)), r.normal(size=N)
+        got = orc.chain_vjp(ops, x, ybar, lbar)
+        fd = np.zeros_like(x)
+        for i in range(dim):                      # the Jacobian is diagonal: perturb one row at a time
+            xp, xm = x.copy(), x.copy()
+            xp[i] += h
+            xm[i] -= h
+            lp = np.array([float(orc.chain(ops, np.asfortranarray(xp[:, [c]]))[1]) for c in range(N)])
+            lm = np.array([float(orc.chain(ops, np.asfortranarray(xm[:, [c]]))[1]) for c in range(N)])
+            yp, ym = orc.chain(ops, np.asfortranarray(xp))[0], orc.chain(ops, np.asfortranarray(xm))[0]
+            fd[i] = (yp[i] - ym[i]) / (2 * h) * ybar[i] + lbar * (lp - lm) / (2 * h)
+        np.testing.assert_allclose(got, fd, rtol=2e-6, atol=2e-6, err_msg=str(ops))
