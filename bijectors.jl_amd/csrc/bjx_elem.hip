@@ -331,47 +331,57 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
   const int64_t left = batch - bcol0 - cg;                 // my columns: it*cols_per_block < left
   const int my_cols = left > (int64_t)iters * cols_per_block ? iters * cols_per_block : (left > 0 ? (int)left : 0);
   const int64_t it_stride = (int64_t)cols_per_block * dim;
-  // one pack of look-ahead: the next column's load is in flight while this one is evaluated
-  Pack<T, V> pnext;
-  if (0 < my_cols && lane_ok) pnext = load_pack<T, V, true>(xb + loff);
-  for (int it = 0; it < iters; ++it) {
-    const bool col_ok = it * cols_per_block < my_cols;
+  // TWO columns per trip (the per-column epilogue — G-lane butterfly behind wave-uniform branches, log-det
+  // store, loop control — costs ~40 VALU, a quarter of a 4-element pack's evaluation) and one trip of
+  // look-ahead: the next two loads are in flight while these are evaluated.
+  auto eval_pack = [&](Pack<T, V>& p) -> T {
+    int pos[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      pos[j] = (k1[j] < p.v[j]) ? 1 : 0;
+      if (NSTEP >= 2) { const T kk = pos[j] ? k2b[j] : k2a[j]; search_step(pos[j], kk, p.v[j]); }
+    }
+#pragma unroll
+    for (int lvl = 3; lvl <= NSTEP; ++lvl) {
+      T kv[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) kv[j] = *reinterpret_cast<const T*>(base + ((pos[j] << SH) + lb[lvl - 3][j]));
+#pragma unroll
+      for (int j = 0; j < V; ++j) search_step(pos[j], kv[j], p.v[j]);
+    }
+    Rec4<T> A[V], B[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      A[j] = lds_rec<T>(reinterpret_cast<const T*>(base + ((pos[j] << (SH + 2)) + ra[j])));
+      B[j] = lds_rec<T>(reinterpret_cast<const T*>(base + ((pos[j] << (SH + 2)) + rb[j])));
+    }
     T l = T(0);
-    Pack<T, V> p = pnext;
-    if ((it + 1) * cols_per_block < my_cols && lane_ok) pnext = load_pack<T, V, true>(xb + it_stride + loff);
-    if (col_ok && lane_ok) {
-      int pos[V];
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        pos[j] = (k1[j] < p.v[j]) ? 1 : 0;
-        if (NSTEP >= 2) { const T kk = pos[j] ? k2b[j] : k2a[j]; search_step(pos[j], kk, p.v[j]); }
-      }
-#pragma unroll
-      for (int lvl = 3; lvl <= NSTEP; ++lvl) {
-        T kv[V];
-#pragma unroll
-        for (int j = 0; j < V; ++j) kv[j] = *reinterpret_cast<const T*>(base + ((pos[j] << SH) + lb[lvl - 3][j]));
-#pragma unroll
-        for (int j = 0; j < V; ++j) search_step(pos[j], kv[j], p.v[j]);
-      }
-      Rec4<T> A[V], B[V];
-#pragma unroll
-      for (int j = 0; j < V; ++j) {
-        A[j] = lds_rec<T>(reinterpret_cast<const T*>(base + ((pos[j] << (SH + 2)) + ra[j])));
-        B[j] = lds_rec<T>(reinterpret_cast<const T*>(base + ((pos[j] << (SH + 2)) + rb[j])));
-      }
-#pragma unroll
-      for (int j = 0; j < V; ++j) l += rqs_eval<T, INV>(A[j], B[j], lim[j], p.v[j]);
-      store_pack<T, V, true>(yb + loff, p);
+    for (int j = 0; j < V; ++j) l += rqs_eval<T, INV>(A[j], B[j], lim[j], p.v[j]);
+    return l;
+  };
+  Pack<T, V> pn0, pn1;
+  if (0 < my_cols && lane_ok) pn0 = load_pack<T, V, true>(xb + loff);
+  if (cols_per_block < my_cols && lane_ok) pn1 = load_pack<T, V, true>(xb + it_stride + loff);
+  for (int it = 0; it < iters; it += 2) {
+    const bool ok0 = it * cols_per_block < my_cols && lane_ok;
+    const bool ok1 = (it + 1) * cols_per_block < my_cols && lane_ok && it + 1 < iters;
+    Pack<T, V> p0 = pn0, p1 = pn1;
+    if ((it + 2) * cols_per_block < my_cols && lane_ok) pn0 = load_pack<T, V, true>(xb + 2 * it_stride + loff);
+    if ((it + 3) * cols_per_block < my_cols && lane_ok) pn1 = load_pack<T, V, true>(xb + 3 * it_stride + loff);
+    T l0 = T(0), l1 = T(0);
+    if (ok0) { l0 = eval_pack(p0); store_pack<T, V, true>(yb + loff, p0); }
+    if (ok1) { l1 = eval_pack(p1); store_pack<T, V, true>(yb + it_stride + loff, p1); }
+    group_sum2_rt(l0, l1, G);
+    l0 *= Num<T>::log2;                               // log2 -> natural log, once per column
+    l1 *= Num<T>::log2;
+    if (gl == 0) {
+      if (ok0) { if (lb_ps) lb_ps[cg] = accumulate ? lb_ps[cg] + l0 : l0; acc += (double)l0; }
+      if (ok1) { if (lb_ps) lb_ps[cols_per_block + cg] = accumulate ? lb_ps[cols_per_block + cg] + l1 : l1; acc += (double)l1; }
     }
-    l = group_sum_rt(l, G) * Num<T>::log2;          // log2 -> natural log, once per column
-    if (col_ok && gl == 0) {
-      if (lb_ps) lb_ps[cg] = accumulate ? lb_ps[cg] + l : l;
-      acc += (double)l;
-    }
-    xb += it_stride;
-    yb += it_stride;
-    if (lb_ps) lb_ps += cols_per_block;
+    xb += 2 * it_stride;
+    yb += 2 * it_stride;
+    if (lb_ps) lb_ps += 2 * cols_per_block;
   }
 }
 

@@ -308,6 +308,17 @@ __device__ __forceinline__ void block_publish_partial(double acc, double* red, c
   }
 }
 
+// two values through one butterfly (shares the wave-uniform branches)
+template <class T> __device__ __forceinline__ void group_sum2_rt(T& a, T& b, int G) { a = group_sum_rt(a, G); b = group_sum_rt(b, G); }
+template <> __device__ __forceinline__ void group_sum2_rt<float>(float& a, float& b, int G) {
+  if (G >= 2) { a = dpp_xadd<0xB1>(a); b = dpp_xadd<0xB1>(b); }
+  if (G >= 4) { a = dpp_xadd<0x4E>(a); b = dpp_xadd<0x4E>(b); }
+  if (G >= 8) { a = dpp_xadd<0x141>(a); b = dpp_xadd<0x141>(b); }
+  if (G >= 16) { a = dpp_xadd<0x140>(a); b = dpp_xadd<0x140>(b); }
+  if (G >= 32) { a += shfl_xor(a, 16); b += shfl_xor(b, 16); }
+  if (G >= 64) { a += shfl_xor(a, 32); b += shfl_xor(b, 32); }
+}
+
 // 16-byte vector types per element type
 template <class T> struct Vec16;
 typedef float bjx_f32x4 __attribute__((ext_vector_type(4)));
