@@ -31,7 +31,7 @@ __all__ = [
     "Transform", "Bijector", "Inverse", "ComposedFunction", "Elementwise", "elementwise", "exp", "log", "identity",
     "Shift", "Scale", "Logit", "LeakyReLU", "TruncatedBijector", "SignFlip", "OrderedBijector", "SimplexBijector",
     "VecCholeskyBijector", "Permute", "PlanarLayer", "RadialLayer", "InvertibleBatchNorm", "RationalQuadraticSpline",
-    "PartitionMask", "Coupling", "Stacked", "vjp", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
+    "PartitionMask", "Coupling", "Stacked", "Columnwise", "columnwise", "vjp", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
     "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
     "PlanarResult",
 ]
@@ -245,6 +245,8 @@ def inverse(t):
     """src/interface.jl:265-266 (+ shift.jl:12, leaky_relu.jl:16, composed inverse, stacked.jl:113-118)"""
     if type(t).__name__ == "Stacked":
         return t._inverse()
+    if type(t).__name__ == "Columnwise":                  # interface.jl:71
+        return Columnwise(inverse(t.x))
     if isinstance(t, Inverse):
         return t.orig
     if isinstance(t, ComposedFunction):
@@ -1186,3 +1188,34 @@ def vjp(b, x, out_bar, ladj_bar=None):
     rc = L.load().bjx_ordered_vjp(ctx.h, _dt(xc), int(inv), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
     L.check(ctx.h, rc, "bjx_ordered_vjp")
     return xb
+
+
+# ------------------------------------------------------------------ columnwise (src/interface.jl:41-78)
+class Columnwise(Transform):
+    """`columnwise(f)` = Base.Fix1(eachcolmaphcat, f): `f` applied to every column, log-det = the SUM over the
+    columns (src/interface.jl:71-78).  Every device kernel here is already batched over columns, so this is
+    the same launch with the reference's scalar return shape; it is how the reference batches the bijectors
+    that only have vector methods (RQS with matrix parameters, Coupling, VecCholesky, Stacked)."""
+
+    def __init__(self, f):
+        self.x = f        # the reference's field name (Base.Fix1.x)
+
+    def _key(self):
+        return (self.x,)
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        if x.dim() != 2 and not isinstance(self.x, (VecCholeskyBijector,)):
+            raise ValueError("columnwise(f) applies to a matrix (one sample per column)")
+        if not want_ladj:
+            return self.x._wlj(x, per_sample=False, want_ladj=False)
+        if per_sample is True:
+            return self.x._wlj(x, per_sample=True)
+        if per_sample in ("both", "sum64"):
+            return self.x._wlj(x, per_sample=per_sample)
+        y, (ps, sm) = self.x._wlj(x, per_sample="both")
+        return y, sm[0].to(ps.dtype)          # interface.jl:75-77: one scalar, summed over the columns (float64 accumulation)
+
+
+def columnwise(f):
+    """src/interface.jl:70"""
+    return Columnwise(f)
