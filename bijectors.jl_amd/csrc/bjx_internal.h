@@ -362,5 +362,11 @@ inline int bjx_stream_grid(const bjx_ctx* ctx, int64_t work_items, int per_block
   return (int)(need < cap ? need : cap);
 }
 
+// MI355X: a workgroup may use all 160 KiB of a CU's LDS; dynamic allocations above 64 KiB are opted into per kernel
+constexpr size_t BJX_LDS_MAX = 160 * 1024;
+template <class K> inline void bjx_allow_big_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 inline bool bjx_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 __device__ __forceinline__ bool bjx_aligned16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -309,7 +309,7 @@ int launch_seq(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, doub
     const int64_t P = rows | 1;
     const size_t smem_w = ((size_t)64 * P + (size_t)n_logk) * sizeof(T);
     static const int use_wave = getenv("BJX_SEQ_WAVE") ? atoi(getenv("BJX_SEQ_WAVE")) : 1;
-    if (use_wave && smem_w <= 64 * 1024 && rows_in >= 1 && rows_out >= 1) {
+    if (use_wave && smem_w <= 64 * 1024 && rows_in >= 1 && rows_out >= 1) {   // larger columns: the chunked block kernel below
       const int64_t grid = (batch + 63) / 64;
       BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
       BjxFin fin;
@@ -1290,7 +1290,7 @@ int ordered_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, c
   if (batch == 0) return BJX_OK;
   const int64_t P = dim | 1;
   const size_t smem = (size_t)2 * 64 * P * sizeof(T);
-  if (smem > 64 * 1024) {
+  if (smem > BJX_LDS_MAX) {
     BJX_REQUIRE(ctx, in_bar != out_bar, BJX_ERR_ARG, "bjx_ordered_vjp: in_bar may not alias out_bar for dim = %lld", (long long)dim);
     const int64_t g2 = (batch + 255) / 256;
     BJX_REQUIRE(ctx, g2 < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
@@ -1306,15 +1306,159 @@ int ordered_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, c
   const bool v_ok = bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
   {
     BjxProf prof_(ctx);
-#define OVJP(V_, I_) hipLaunchKernelGGL((ordered_vjp_kernel<T, V_, I_>), dim3((unsigned)grid), dim3(64), smem, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)dim, (int)P, batch)
-    if (v_ok) { if (inverse) OVJP(VW, true); else OVJP(VW, false); }
-    else { if (inverse) OVJP(1, true); else OVJP(1, false); }
+#define OVJP(V_, I_) bjx_allow_big_lds(ordered_vjp_kernel<T, V_, I_>, smem); hipLaunchKernelGGL((ordered_vjp_kernel<T, V_, I_>), dim3((unsigned)grid), dim3(64), smem, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)dim, (int)P, batch)
+    if (v_ok) { if (inverse) { OVJP(VW, true); } else { OVJP(VW, false); } }
+    else { if (inverse) { OVJP(1, true); } else { OVJP(1, false); } }
 #undef OVJP
   }
   BJX_CHECK_LAUNCH(ctx);
   return BJX_OK;
 }
+// ------------------------------------------------------------------ SimplexBijector pullbacks
+// Reverse sweeps of the stick-breaking recurrences (simplex.jl:47-64 forward, :102-120 inverse) and of the
+// log-det terms (:122-138); the reference's own adjoints are simplex.jl:145-215 (log-det gradient, O(K²)),
+// :248-308 (link) and :358-470 (invlink).  Conventions as there: a clamped value has zero derivative and
+// max(v, ε) has derivative 1 only where v > ε.  One call = pullback of with_logabsdet_jacobian:
+//   inverse (y[K-1] -> x[K], ladj = +Σ t_k):  in = y, out_bar = x_bar[K], in_bar = y_bar[K-1]
+//   forward (x[K] -> y[K-1], ladj = -Σ t_k):  in = x, out_bar = y_bar[K-1], in_bar = x_bar[K]
+// Two wave-private [64][P] tiles (primal, cotangent), lane = column.  The inverse first re-runs the forward
+// recurrence (ascending) leaving x_k in the primal tile; the backward sweep recovers s_k = s_{k+1} - x_k and,
+// where x_k is not clamped, z_k = (x_k + ε)/((1+ε-s_k)/(1-2ε)) — a clamped x_k has zero derivative anyway.
+template <class T> __device__ __forceinline__ void simplex_t_partials(T xk, T sk, bool first, T& dtdx, T& dtds) {
+  using F = Fast<T>;
+  const T e = Num<T>::eps;
+  if (first) {
+    dtdx = (xk > e ? F::rcp(xk) : T(0)) - (T(1) - xk > e ? F::rcp(T(1) - xk) : T(0));
+    dtds = T(0);
+    return;
+  }
+  const T M = d_max(T(1) - sk, e);
+  const T rM = F::rcp(M);
+  const T zl = xk * rM;
+  const T dtdzl = (zl > e ? F::rcp(zl) : T(0)) - (T(1) - zl > e ? F::rcp(T(1) - zl) : T(0));
+  dtdx = dtdzl * rM;
+  const T dtdM = rM - dtdzl * zl * rM;                 // d/dM [log max(zl) + log max(1-zl) + log M], zl = x/M
+  dtds = (T(1) - sk > e) ? -dtdM : T(0);
+}
+
+template <class T, int V, bool INV>
+__global__ __launch_bounds__(64) void simplex_vjp_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
+                                                        T* __restrict__ in_bar, int K, int P, int64_t batch) {
+  using F = Fast<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* ta = reinterpret_cast<T*>(smem);
+  T* tb = ta + (size_t)64 * P;
+  T* logk = tb + (size_t)64 * P;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < K - 1; i += 64) logk[i] = d_log(T(K - 1 - i));
+  const int rows_in = INV ? K - 1 : K, rows_g = INV ? K : K - 1;
+  const int64_t col0 = (int64_t)blockIdx.x * 64;
+  const int ncols = (int)((batch - col0) < 64 ? (batch - col0) : 64);
+  tile_stage_in<T, V>(ta, in + col0 * rows_in, rows_in, P, ncols, lane);
+  tile_stage_in<T, V>(tb, out_bar + col0 * rows_g, rows_g, P, ncols, lane);
+  tile_sync();
+  if (lane < ncols) {
+    const T e = Num<T>::eps;
+    const T c = T(1) / (T(1) - 2 * e), E = T(1) + e, c2 = T(1) - 2 * e;
+    const T lb = ladj_bar ? ladj_bar[col0 + lane] : T(0);
+    T* a = ta + lane * P;
+    T* g = tb + lane * P;
+    if (INV) {
+      // forward recurrence: a[k] <- x_k, s = Σ x
+      T s = T(0);
+      for (int k = 0; k < K - 1; ++k) {
+        const T yk = a[k] - logk[k];
+        const T ex = F::exp(yk);
+        const T z = yk < Num<T>::logistic_lo ? T(0) : (yk > Num<T>::logistic_hi ? T(1) : ex * F::rcp(T(1) + ex));
+        const T u = k == 0 ? (z - e) * c : (E - s) * c * z - e;
+        const T xk = d_clamp(u, T(0), T(1));
+        a[k] = xk;
+        s += xk;
+      }
+      const T last = T(1) - s;
+      T sb = (last > T(0) && last < T(1)) ? -g[K - 1] : T(0);
+      for (int k = K - 2; k >= 0; --k) {
+        const T xk = a[k];
+        const T sk = s - xk;
+        T dtdx, dtds;
+        simplex_t_partials<T>(xk, sk, k == 0, dtdx, dtds);
+        const T xb = g[k] + sb + lb * dtdx;
+        sb += lb * dtds;
+        const T ub = (xk > T(0) && xk < T(1)) ? xb : T(0);
+        T zb, z;
+        if (k == 0) { zb = ub * c; z = xk * c2 + e; }
+        else { const T rc = (E - sk) * c; zb = ub * rc; z = (xk + e) * F::rcp(rc); sb -= ub * c * z; }
+        g[k] = zb * z * (T(1) - z);
+        s = sk;
+      }
+    } else {
+      T s = T(0);
+      for (int k = 0; k < K - 1; ++k) s += a[k];                       // s_{K-1} = Σ_{j<K-1} x_j
+      T sbn = T(0);
+      g[K - 1] = T(0);                                                  // row K enters neither y nor the log-det
+      for (int k = K - 2; k >= 0; --k) {
+        const T xk = a[k];
+        const T sk = s - xk;
+        const T gy = g[k];
+        T xb = sbn, sb = sbn;
+        if (k == 0) {
+          const T zf = xk * c2 + e;
+          const T zfb = gy * F::rcp(zf * (T(1) - zf));
+          xb += zfb * c2;
+        } else {
+          const T rd = F::rcp(E - sk);
+          const T an = (xk + e) * c2;
+          const T zf = an * rd;
+          const T zfb = gy * F::rcp(zf * (T(1) - zf));
+          xb += zfb * c2 * rd;
+          sb += zfb * an * rd * rd;
+        }
+        T dtdx, dtds;
+        simplex_t_partials<T>(xk, sk, k == 0, dtdx, dtds);
+        xb -= lb * dtdx;
+        sb -= lb * dtds;
+        g[k] = xb;
+        sbn = sb;
+        s = sk;
+      }
+    }
+  }
+  tile_sync();
+  tile_stage_out<T, V>(tb, in_bar + col0 * rows_in, rows_in, P, ncols, lane);
+}
+
+template <class T>
+int simplex_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
+  if (batch == 0) return BJX_OK;
+  const int64_t P = K | 1;
+  const size_t smem = ((size_t)2 * 64 * P + (size_t)K) * sizeof(T);
+  BJX_REQUIRE(ctx, smem <= BJX_LDS_MAX, BJX_ERR_UNSUPPORTED, "bjx_simplex_vjp: K = %lld too large for the LDS tiles", (long long)K);
+  const int64_t grid = (batch + 63) / 64;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+  constexpr int VW = Vec16<T>::N;
+  const bool v_ok = bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
+  {
+    BjxProf prof_(ctx);
+#define SVJPK(V_, I_) bjx_allow_big_lds(simplex_vjp_kernel<T, V_, I_>, smem); hipLaunchKernelGGL((simplex_vjp_kernel<T, V_, I_>), dim3((unsigned)grid), dim3(64), smem, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)K, (int)P, batch)
+    if (v_ok) { if (inverse) { SVJPK(VW, true); } else { SVJPK(VW, false); } }
+    else { if (inverse) { SVJPK(1, true); } else { SVJPK(1, false); } }
+#undef SVJPK
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
 }  // namespace
+
+BJX_API int bjx_simplex_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar, const void* ladj_bar,
+                            void* in_bar, int64_t K, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, K > 1, BJX_ERR_SHAPE, "bjx_simplex_vjp: x needs to be of length greater than 1 (simplex.jl:30), got K=%lld", (long long)K);
+  BJX_REQUIRE(ctx, batch >= 0, BJX_ERR_SHAPE, "bjx_simplex_vjp: negative batch");
+  BJX_REQUIRE(ctx, (in && out_bar && in_bar) || batch == 0, BJX_ERR_ARG, "bjx_simplex_vjp: null pointer");
+  if (dt == BJX_F32) return simplex_vjp_impl<float>(ctx, inverse, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, K, batch);
+  if (dt == BJX_F64) return simplex_vjp_impl<double>(ctx, inverse, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, K, batch);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_simplex_vjp: bad dtype %d", (int)dt);
+}
 
 BJX_API int bjx_ordered_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar, const void* ladj_bar,
                             void* in_bar, int64_t dim, int64_t batch) {

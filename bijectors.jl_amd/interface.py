@@ -1176,6 +1176,18 @@ def vjp(b, x, out_bar, ladj_bar=None):
         return yb
     inv = isinstance(b, Inverse)
     base = b.orig if inv else b
+    if isinstance(base, SimplexBijector):
+        xc, rows, batch, vec = _prep(x)
+        gc, grows, gbatch, _ = _prep(out_bar)
+        K = rows + 1 if inv else rows
+        if (grows, gbatch) != ((K if inv else K - 1), batch) or gc.dtype != xc.dtype:
+            raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
+        lb = _ladj_bar(ladj_bar, batch, xc)
+        ctx = context(xc.device)
+        xb = _empty(rows, batch, xc, vec)
+        rc = L.load().bjx_simplex_vjp(ctx.h, _dt(xc), int(inv), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), K, batch)
+        L.check(ctx.h, rc, "bjx_simplex_vjp")
+        return xb
     if not isinstance(base, OrderedBijector):
         raise NotImplementedError(f"no device pullback for {b!r} yet (SURVEY.md §8f f-1)")
     xc, dim, batch, vec = _prep(x)

@@ -232,6 +232,12 @@ int bjx_stacked_vjp(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_s
                     const void* y_bar, const void* ladj_bar, void* x_bar, int64_t dim, int64_t batch);
 int bjx_ordered_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar,
                     const void* ladj_bar, void* in_bar, int64_t dim, int64_t batch);
+/* SimplexBijector (K = rows of the simplex side): reverse sweeps of simplex.jl:47-64 / :102-120 and of the
+ * log-det terms :122-138 (the reference's adjoints: simplex.jl:145-215, :248-308, :358-470).
+ * inverse=1: in = y[K-1,batch], out_bar = x_bar[K,batch], in_bar = y_bar[K-1,batch];
+ * inverse=0: in = x[K,batch],   out_bar = y_bar[K-1,batch], in_bar = x_bar[K,batch]. */
+int bjx_simplex_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar,
+                    const void* ladj_bar, void* in_bar, int64_t K, int64_t batch);
 /* inverse(VecCholeskyBijector): y[n,batch] -> (W[K,K,batch], logJ[batch]); pullback
  * src/bijectors/corr.jl:402-451 (_inv_link_chol_lkj_rrule; ext/BijectorsChainRulesCoreExt.jl:311-320).
  * W_bar: dense K x K per sample (entries outside the stored triangle are ignored), logJ_bar: T[batch]

@@ -430,3 +430,95 @@ def chain_vjp(ops, x, y_bar, ladj_bar=None):
     for dy, dl in reversed(stages):
         g = g * dy + lb * dl
     return g
+
+
+def _simplex_terms(x_k, s_k, eps, first):
+    """t_k of logabsdetjac (simplex.jl:122-138) and its partials w.r.t. x_k and s_k (s_k = sum of the earlier rows)."""
+    if first:
+        m1, m2 = np.maximum(x_k, eps), np.maximum(1 - x_k, eps)
+        t = np.log(m1) + np.log(m2)
+        dtdx = np.where(x_k > eps, 1 / m1, 0.0) - np.where(1 - x_k > eps, 1 / m2, 0.0)
+        return t, dtdx, np.zeros_like(x_k)
+    M = np.maximum(1 - s_k, eps)
+    zl = x_k / M
+    m1, m2 = np.maximum(zl, eps), np.maximum(1 - zl, eps)
+    t = np.log(m1) + np.log(m2) + np.log(M)
+    dtdzl = np.where(zl > eps, 1 / m1, 0.0) - np.where(1 - zl > eps, 1 / m2, 0.0)
+    dtdx = dtdzl / M
+    dtdM = dtdzl * (-x_k / M**2) + 1 / M
+    dtds = -np.where(1 - s_k > eps, dtdM, 0.0)
+    return t, dtdx, dtds
+
+
+def simplex_vjp(inp, out_bar, ladj_bar=None, inverse=False):
+    """Pullback of with_logabsdet_jacobian(SimplexBijector() or its inverse, inp), (rows, batch) input, per-column
+    log-det cotangent.  Reverse sweep of the stick-breaking recurrences simplex.jl:47-64 / :102-120 and of the
+    log-det terms :122-138 (the reference's own adjoints: simplex.jl:145-215 logabsdetjac gradient, :248-308
+    link, :358-470 invlink — O(K²) loops there, O(K) here; same derivative conventions: a clamped value has
+    zero derivative, max(v, ε) has derivative 1 only where v > ε).  numpy float64, loops over rows only."""
+    a = np.asarray(inp, dtype=np.float64)
+    g = np.asarray(out_bar, dtype=np.float64)
+    eps = np.finfo(np.float64).eps
+    c, E = 1 / (1 - 2 * eps), 1 + eps
+    N = a.shape[1]
+    lb = np.zeros(N) if ladj_bar is None else np.broadcast_to(np.asarray(ladj_bar, dtype=np.float64), (N,))
+    if inverse:
+        y = a
+        K = y.shape[0] + 1
+        lk = np.log(np.arange(K - 1, 0, -1, dtype=np.float64))          # log(K-k), k = 1..K-1
+        z = 1 / (1 + np.exp(-(y - lk[:, None])))
+        x = np.zeros((K, N))
+        u = np.zeros((K - 1, N))
+        s = np.zeros((K + 1, N))                                        # s[k] = sum of x[:k]
+        for k in range(K - 1):
+            r = E - s[k]
+            u[k] = (z[k] - eps) * c if k == 0 else r * c * z[k] - eps
+            x[k] = np.clip(u[k], 0, 1)
+            s[k + 1] = s[k] + x[k]
+        last = 1 - s[K - 1]
+        x[K - 1] = np.clip(last, 0, 1)
+        yb = np.zeros_like(y)
+        sb = -np.where((last > 0) & (last < 1), g[K - 1], 0.0)          # adjoint of s[K-1]
+        for k in range(K - 2, -1, -1):
+            xb = g[k] + sb                                              # s[k+1] = s[k] + x[k]
+            _, dtdx, dtds = _simplex_terms(x[k], s[k], eps, k == 0)
+            xb = xb + lb * dtdx                                         # ladj(inverse) = + sum_k t_k
+            sb = sb + lb * dtds
+            ub = np.where((u[k] > 0) & (u[k] < 1), xb, 0.0)
+            if k == 0:
+                zb = ub * c
+            else:
+                r = E - s[k]
+                zb = ub * r * c
+                sb = sb - ub * c * z[k]
+            yb[k] = zb * z[k] * (1 - z[k])
+        return yb
+    x = a
+    K = x.shape[0]
+    s = np.zeros((K + 1, N))
+    for k in range(K):
+        s[k + 1] = s[k] + x[k]
+    xb = np.zeros_like(x)
+    sb_next = np.zeros(N)                                               # adjoint of s[k+1], carried down
+    for k in range(K - 2, -1, -1):
+        # s[k+1] = s[k] + x[k]: x[k] and s[k] both receive the adjoint of s[k+1]
+        sb = sb_next.copy()
+        xbk = sb_next.copy()
+        if k == 0:
+            zf = x[0] * (1 - 2 * eps) + eps
+            zfb = g[0] / (zf * (1 - zf))
+            xbk = xbk + zfb * (1 - 2 * eps)
+        else:
+            d = E - s[k]
+            an = (x[k] + eps) * (1 - 2 * eps)
+            zf = an / d
+            zfb = g[k] / (zf * (1 - zf))
+            xbk = xbk + zfb * (1 - 2 * eps) / d
+            sb = sb + zfb * an / d**2                                   # d = E - s[k]
+        _, dtdx, dtds = _simplex_terms(x[k], s[k], eps, k == 0)
+        xbk = xbk - lb * dtdx                                           # ladj(forward) = - sum_k t_k
+        sb = sb - lb * dtds
+        xb[k] = xbk
+        sb_next = sb
+    xb[K - 1] = 0.0                                                     # row K enters neither y nor the log-det
+    return xb

@@ -134,6 +134,12 @@ def main():
     lb2 = randn(Nc, 1, dev, 14).reshape(-1).contiguous()
     rows.append(("vjp(inverse(VecCholesky)) K=64", "f-1", lambda: bj.vjp(icb, yv, Wb, lb2), 4 * (2 * n + K * K) + 4, Nc))
 
+    gxs = randn(d, Ns, dev, 15)
+    gys = randn(d - 1, Ns, dev, 16)
+    lbs = randn(Ns, 1, dev, 17).reshape(-1).contiguous()
+    sb_ = bj.SimplexBijector()
+    rows.append(("vjp(SimplexBijector) K=64", "f-1", lambda: bj.vjp(sb_, xs, gys, lbs), 4 * (d + d - 1 + d) + 4, Ns))
+    rows.append(("vjp(inverse(SimplexBijector)) K=64", "f-1", lambda: bj.vjp(bj.inverse(sb_), ys, gxs, lbs), 4 * (d - 1 + d + d - 1) + 4, Ns))
     rows.append(("vjp(Stacked(exp|Logit|identity|exp∘Shift∘Scale)) d=64", "f-1", lambda: bj.vjp(stk, xst, gb, lbar), 3 * d * 4 + 4, N))
 
     only = [s for s in a.only.split(",") if s]

@@ -747,3 +747,22 @@ def test_columnwise_returns_the_sum_over_columns(bj, orc):
     _, lo_ref = orc.ordered(yo)
     _, lo = bj.with_logabsdet_jacobian(bj.columnwise(bj.OrderedBijector()), dev(yo))
     assert lo.dim() == 0 and abs(float(lo) - lo_ref.sum()) < 1e-9 * max(1.0, abs(lo_ref.sum()))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("K,N", [(2, 7), (5, 100), (64, 130), (33, 64)])
+def test_simplex_vjp(bj, orc, K, N, dt):
+    r = rng(54)
+    lbar = r.normal(size=N).astype(dt)
+    b = bj.SimplexBijector()
+    y = np.asfortranarray(r.normal(size=(K - 1, N)).astype(dt))
+    gx = np.asfortranarray(r.normal(size=(K, N)).astype(dt))
+    ref = orc.simplex_vjp(y.astype(np.float64), gx.astype(np.float64), lbar.astype(np.float64), inverse=True)
+    got = bj.vjp(bj.inverse(b), dev(y), dev(gx), torch.from_numpy(lbar).cuda())
+    np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())))
+    x = np.asfortranarray(r.dirichlet(np.ones(K) * 2.0, size=N).T.astype(dt))
+    gy = np.asfortranarray(r.normal(size=(K - 1, N)).astype(dt))
+    ref_f = orc.simplex_vjp(x.astype(np.float64), gy.astype(np.float64), lbar.astype(np.float64))
+    got_f = bj.vjp(b, dev(x), dev(gy), torch.from_numpy(lbar).cuda())
+    assert tuple(got_f.shape) == (K, N)
+    np.testing.assert_allclose(host(got_f), ref_f, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref_f).max())))

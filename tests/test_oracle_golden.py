@@ -447,3 +447,35 @@ def test_elementwise_chain_pullback_matches_finite_differences(orc):
             yp, ym = orc.chain(ops, np.asfortranarray(xp))[0], orc.chain(ops, np.asfortranarray(xm))[0]
             fd[i] = (yp[i] - ym[i]) / (2 * h) * ybar[i] + lbar * (lp - lm) / (2 * h)
         np.testing.assert_allclose(got, fd, rtol=2e-6, atol=2e-6, err_msg=str(ops))
+
+
+def test_simplex_pullbacks_match_finite_differences(orc):
+    """O(K) reverse sweeps of simplex.jl:47-64 / :102-120 / :122-138 (the reference's adjoints, simplex.jl:145-470,
+    are O(K²) loops over the same terms), pinned by central differences of the golden-pinned forward oracle."""
+    r = np.random.default_rng(3)
+    K, N, h = 6, 4, 1e-6
+    lb = r.normal(size=N)
+    y = np.asfortranarray(r.normal(size=(K - 1, N)))
+    gb = r.normal(size=(K, N))
+    got = orc.simplex_vjp(y, gb, lb, inverse=True)
+    fd = np.zeros_like(y)
+    for i in range(K - 1):
+        yp, ym = y.copy(), y.copy()
+        yp[i] += h
+        ym[i] -= h
+        xp, lp = orc.simplex(np.asfortranarray(yp), inverse=True)
+        xm, lm = orc.simplex(np.asfortranarray(ym), inverse=True)
+        fd[i] = ((xp - xm) * gb).sum(0) / (2 * h) + lb * (lp - lm) / (2 * h)
+    np.testing.assert_allclose(got, fd, rtol=1e-6, atol=1e-7)
+    x = np.asfortranarray(r.dirichlet(np.ones(K), size=N).T)
+    gb2 = r.normal(size=(K - 1, N))
+    got = orc.simplex_vjp(x, gb2, lb)
+    fd = np.zeros_like(x)
+    for i in range(K):
+        xp, xm = x.copy(), x.copy()
+        xp[i] += h
+        xm[i] -= h
+        yp, lp = orc.simplex(np.asfortranarray(xp))
+        ym, lm = orc.simplex(np.asfortranarray(xm))
+        fd[i] = ((yp - ym) * gb2).sum(0) / (2 * h) + lb * (lp - lm) / (2 * h)
+    np.testing.assert_allclose(got, fd, rtol=1e-6, atol=1e-6)
