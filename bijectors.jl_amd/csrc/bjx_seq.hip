@@ -1366,18 +1366,49 @@ __global__ __launch_bounds__(64) void simplex_vjp_kernel(const T* __restrict__ i
     if (INV) {
       // forward recurrence: a[k] <- x_k, s = Σ x
       T s = T(0);
-      for (int k = 0; k < K - 1; ++k) {
+      auto logistic_at = [&](int k) -> T {
         const T yk = a[k] - logk[k];
         const T ex = F::exp(yk);
-        const T z = yk < Num<T>::logistic_lo ? T(0) : (yk > Num<T>::logistic_hi ? T(1) : ex * F::rcp(T(1) + ex));
-        const T u = k == 0 ? (z - e) * c : (E - s) * c * z - e;
-        const T xk = d_clamp(u, T(0), T(1));
-        a[k] = xk;
-        s += xk;
+        return yk < Num<T>::logistic_lo ? T(0) : (yk > Num<T>::logistic_hi ? T(1) : ex * F::rcp(T(1) + ex));
+      };
+      { const T xk = d_clamp((logistic_at(0) - e) * c, T(0), T(1)); a[0] = xk; s = xk; }
+      int kf = 1;
+      for (; kf + 4 <= K - 1; kf += 4) {               // the four logistics are independent of the running sum
+        T z[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = logistic_at(kf + j) * c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const T xk = d_clamp((E - s) * z[j] - e, T(0), T(1)); a[kf + j] = xk; s += xk; }
       }
+      for (; kf < K - 1; ++kf) { const T xk = d_clamp((E - s) * c * logistic_at(kf) - e, T(0), T(1)); a[kf] = xk; s += xk; }
       const T last = T(1) - s;
       T sb = (last > T(0) && last < T(1)) ? -g[K - 1] : T(0);
-      for (int k = K - 2; k >= 0; --k) {
+      // rows K-2 .. 1 in groups of 4: everything that depends only on (x_k, s_k) — four reciprocals per row —
+      // is evaluated for the whole group first; only the short adjoint chain (sb) is sequential
+      int k = K - 2;
+      for (; k >= 4; k -= 4) {
+        T xk[4], gk[4], dtdx[4], dtds[4], rc[4], z[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xk[j] = a[k - j]; gk[j] = g[k - j]; }
+        T sk[4];
+        sk[0] = s - xk[0]; sk[1] = sk[0] - xk[1]; sk[2] = sk[1] - xk[2]; sk[3] = sk[2] - xk[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          simplex_t_partials<T>(xk[j], sk[j], false, dtdx[j], dtds[j]);
+          rc[j] = (E - sk[j]) * c;
+          z[j] = (xk[j] + e) * F::rcp(rc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const T xb = gk[j] + sb + lb * dtdx[j];
+          sb += lb * dtds[j];
+          const T ub = (xk[j] > T(0) && xk[j] < T(1)) ? xb : T(0);
+          sb -= ub * c * z[j];
+          g[k - j] = ub * rc[j] * z[j] * (T(1) - z[j]);
+        }
+        s = sk[3];
+      }
+      for (; k >= 0; --k) {
         const T xk = a[k];
         const T sk = s - xk;
         T dtdx, dtds;
@@ -1393,10 +1424,37 @@ __global__ __launch_bounds__(64) void simplex_vjp_kernel(const T* __restrict__ i
       }
     } else {
       T s = T(0);
-      for (int k = 0; k < K - 1; ++k) s += a[k];                       // s_{K-1} = Σ_{j<K-1} x_j
+      {
+        T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
+        int k = 0;
+        for (; k + 4 <= K - 1; k += 4) { s0 += a[k]; s1 += a[k + 1]; s2 += a[k + 2]; s3 += a[k + 3]; }
+        for (; k < K - 1; ++k) s0 += a[k];
+        s = (s0 + s1) + (s2 + s3);                                    // s_{K-1} = Σ_{j<K-1} x_j
+      }
       T sbn = T(0);
       g[K - 1] = T(0);                                                  // row K enters neither y nor the log-det
-      for (int k = K - 2; k >= 0; --k) {
+      int k = K - 2;
+      for (; k >= 4; k -= 4) {
+        T xk[4], gy[4], dtdx[4], dtds[4], ax[4], as_[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xk[j] = a[k - j]; gy[j] = g[k - j]; }
+        T sk[4];
+        sk[0] = s - xk[0]; sk[1] = sk[0] - xk[1]; sk[2] = sk[1] - xk[2]; sk[3] = sk[2] - xk[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          simplex_t_partials<T>(xk[j], sk[j], false, dtdx[j], dtds[j]);
+          const T rd = F::rcp(E - sk[j]);
+          const T an = (xk[j] + e) * c2;
+          const T zf = an * rd;
+          const T zfb = gy[j] * F::rcp(zf * (T(1) - zf));
+          ax[j] = zfb * c2 * rd - lb * dtdx[j];                       // what row k adds to its own cotangent
+          as_[j] = zfb * an * rd * rd - lb * dtds[j];                 // ... and to the adjoint of s_k
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { g[k - j] = sbn + ax[j]; sbn += as_[j]; }
+        s = sk[3];
+      }
+      for (; k >= 0; --k) {
         const T xk = a[k];
         const T sk = s - xk;
         const T gy = g[k];
