@@ -38,6 +38,24 @@ def test_op_struct_layout_matches_header(bj):
     assert bj._lib.BjxOp.p0.offset == 8 and bj._lib.BjxOp.v0.offset == 24
 
 
+def test_segment_struct_layout_and_stacked_ranges(bj):
+    """bjx_segment (include/bjx.h) = 3 x int64 + 2 x int32 + 4 bjx_op; Stacked's output ranges are the
+    cumulative ones of stacked.jl:50-57 and inverse swaps them (:113-118) — host logic, no GPU."""
+    import ctypes as C
+
+    assert C.sizeof(bj._lib.BjxSegment) == 24 + 8 + 4 * 40
+    assert bj._lib.BjxSegment.ops.offset == 32
+    b = bj.Stacked([bj.SimplexBijector(), bj.elementwise(bj.exp), bj.identity], [(1, 5), (6, 7), (8, 8)])
+    assert b.ranges_out == [(1, 4), (5, 6), (7, 7)] and (b.length_in, b.length_out) == (8, 7)
+    assert bj.output_size(b, (8,)) == (7,) and bj.output_size(b, (8, 3)) == (7, 3)
+    ib = bj.inverse(b)
+    assert ib.ranges_in == b.ranges_out and ib.ranges_out == b.ranges_in and (ib.length_in, ib.length_out) == (7, 8)
+    with pytest.raises(ValueError):
+        bj.Stacked([bj.identity, bj.identity], [(1, 2)])
+    cw = bj.columnwise(bj.OrderedBijector())
+    assert isinstance(bj.inverse(cw), bj.Columnwise) and isinstance(bj.inverse(cw).x, bj.Inverse)
+
+
 def test_no_cpu_fallback(bj):
     import torch
 
