@@ -134,7 +134,7 @@ def make_workload(name, bj, torch, device, rank, world, log2_batch):
                     label=f"SimplexBijector fwd+logabsdetjac Float32 K={K} batch=2^{lb}/GPU",
                     cfg={"workload": "SimplexBijector (BASELINE configs[4], first half)", "K": K, "batch_per_gpu": N})
     if name == "c5b":
-        K, lb = 64, (16 if log2_batch is None else log2_batch)
+        K, lb = 64, (20 if log2_batch is None else log2_batch)   # BASELINE configs[4]: batch 2^20 (8.5 GB of y + 17 GB of dense W per GPU)
         N = 1 << lb
         n = K * (K - 1) // 2
         yv = colmajor_empty(torch, n, N, f32, device)
