@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
 // are O(eps·‖w‖‖z‖), inside the 1e-3 / 1e-6 parity bars (tests/test_gpu_parity.py::test_planar).
 // Layers are processed in groups of NLMAX; the tile in LDS is updated between groups.
 constexpr int PLANAR_NLMAX = 8;
+constexpr int PLANAR_REG_DEFAULT_COLS = 64;
 
 template <class T>
 __global__ __launch_bounds__(256) void planar_prep2_kernel(const T* w, const T* u_hat, int64_t dim, int nl, T* G, T* wT, T* uT) {
@@ -422,17 +423,20 @@ __device__ __forceinline__ void planar_act(float arg, float c, float& th, float&
   ld = F::log1p(c * (4.0f * e * r * r));     // planar_layer.jl:107, sech² = 4e/(1+e)²
 }
 
-template <int G, int NL, bool INV>
+// COLS = columns per wave: 64 (every lane runs the recurrence) or 32 (half the register tile -> twice the waves per SIMD;
+// lanes 32..63 idle in the short recurrence)
+template <int G, int NL, bool INV, int COLS>
 __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, const float* __restrict__ x, float* __restrict__ y,
                                                          float* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate,
                                                          const BjxFin fin) {
   constexpr int CPS = 64 / G;                       // columns per wave instruction
-  constexpr int NS = G;                             // pack steps for 64 columns
+  constexpr int NS = (COLS * G) / 64;               // pack steps for COLS columns
+  static_assert(NS >= 1, "COLS too small for this G");
   constexpr bool SWAP = (G == 32) && (NL >= 2);     // fold lane i+16 onto i with a transposed halving
   constexpr int NV = SWAP ? NL / 2 : NL;            // live values per lane after the fold
   constexpr int RW = G < 16 ? G : 16;               // lanes of a row that still have to be summed
   constexpr int NP = NL >= 2 ? NL / 2 : 1;          // layer pairs (packed-FP32 math)
-  __shared__ __attribute__((aligned(16))) float st_all[4][64 * NL];
+  __shared__ __attribute__((aligned(16))) float st_all[4][COLS * NL];
   __shared__ double red[4];
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef float f2 __attribute__((ext_vector_type(2)));
@@ -441,9 +445,9 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
   const int gl = lane & (G - 1);
   const int cg = lane / G;                          // column inside a wave instruction
   const bool row_ok = 4 * gl < dim;
-  const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * COLS;
   const int64_t left = batch - col0;
-  const int nvalid = left >= 64 ? 64 : (left > 0 ? (int)left : 0);
+  const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
   const int64_t step_elems = (int64_t)CPS * dim;
 
   f4 z[NS];
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
     }
     __builtin_amdgcn_wave_barrier();
     // ---- 3: scalar recurrence, one sample per lane
-    {
+    if (COLS == 64 || lane < COLS) {
       float s[NL], t[NL];
 #pragma unroll
       for (int k = 0; k < NL; ++k) { s[k] = st[lane * NL + k]; t[k] = 0.f; }
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
       py += step_elems;
     }
   }
-  const bool ok = lane < nvalid;
+  const bool ok = lane < nvalid;   // nvalid <= COLS
   if (ok && ladj_ps) ladj_ps[col0 + lane] = accumulate ? ladj_ps[col0 + lane] + ladj : ladj;
   block_publish_partial(ok ? (double)ladj : 0.0, red, fin);
 }
@@ -750,15 +754,17 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         hipLaunchKernelGGL(planar_prep_reg_kernel, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, (const float*)w, (const float*)u_hat,
                            (const float*)wtu, (const float*)b, dim, nl, nl_pad, wp, up, Gp, cp, bp);
         BJX_CHECK_LAUNCH(ctx);
-        const int64_t grid = (batch + 255) / 256;
+        static const int cols_env = getenv("BJX_PLANAR_COLS") ? atoi(getenv("BJX_PLANAR_COLS")) : 0;
+        const int G = dim > 64 ? 32 : (dim > 32 ? 16 : 8);
+        const int cols = (G == 32 && (cols_env ? cols_env == 32 : PLANAR_REG_DEFAULT_COLS == 32)) ? 32 : 64;
+        const int64_t grid = (batch + 4 * cols - 1) / (4 * cols);
         BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar: batch too large for one launch");
         BjxFin fin;
         bool second = false;
         { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
         PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad};
         const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
-        const int G = dim > 64 ? 32 : (dim > 32 ? 16 : 8);
-#define LAUNCH_REG(G_, NL_, INV_) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
+#define LAUNCH_REG(G_, NL_, INV_) if (G_ == 32 && cols == 32) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, (G_ == 32 ? 32 : 64)>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); else hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, 64>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
 #define LAUNCH_REG_NL(G_, INV_) switch (NL) { case 1: LAUNCH_REG(G_, 1, INV_); break; case 2: LAUNCH_REG(G_, 2, INV_); break; case 4: LAUNCH_REG(G_, 4, INV_); break; default: LAUNCH_REG(G_, 8, INV_); break; }
 #define LAUNCH_REG_G(INV_) switch (G) { case 8: LAUNCH_REG_NL(8, INV_) break; case 16: LAUNCH_REG_NL(16, INV_) break; default: LAUNCH_REG_NL(32, INV_) break; }
         { BjxProf prof_(ctx); if (inverse) { LAUNCH_REG_G(true) } else { LAUNCH_REG_G(false) } }
