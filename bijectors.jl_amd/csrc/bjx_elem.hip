@@ -621,6 +621,119 @@ int bn_impl(bjx_ctx* ctx, int inverse, const T* b, const T* logs, const T* m, co
   return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0);
 }
 
+// ------------------------------------------------------------------ InvertibleBatchNorm, training mode
+// normalise.jl:51-60 (`istraining() == true`): the batch statistics of every channel (= row for a 2-D
+// input, :43-47) replace the moving ones and the moving ones are updated:
+//   m = mean(x; dims=batch);  v = sum((x .- m).^2; dims=batch) ./ n
+//   bn.m = (1-mtm) bn.m + mtm m;   bn.v = (1-mtm) bn.v + (mtm n/(n-1)) v
+// This is the one place on the hot path with a cross-batch reduction (SURVEY.md §8e "Exception"):
+//   1. bn_stats_kernel   — every block streams a slab of columns, lanes along the rows, Float64 Σx and Σx² per
+//                          row in registers, column groups of the block combined through LDS -> partial[block][row][2]
+//   2. bn_stats_reduce   — fixed-order sum over the blocks -> stats[0..dim) = Σx, [dim..2dim) = Σx², [2dim] = n
+//   3. (sharded batch)   — ONE RCCL all-reduce of those 2·dim+1 doubles (bjx_comm_init'ed context)
+//   4. bn_train_finalize — mean, biased variance (Σx²/n - mean², Float64), moving-statistics update, batch
+//                          statistics for the apply pass, Σ_c (logs_c - log(v_c+eps)/2)
+//   5. the eval-mode apply kernel with the batch statistics.
+// x is read twice (statistics, apply): 3·dim·sizeof(T) + sizeof(T) bytes per sample is the algorithmic traffic.
+template <class T, int V, int R>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t dim, int64_t batch, int G, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);            // [cols_per_block][dim][2]
+  const int gl = threadIdx.x & (G - 1), cg = threadIdx.x / G;
+  const int cols_per_block = 256 / G;
+  const int64_t nvc = dim / V;                               // packs per column; lane gl owns packs gl, gl+G, ... (R of them)
+  double sx[R][V], sxx[R][V];
+#pragma unroll
+  for (int k = 0; k < R; ++k)
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sx[k][j] = 0.0; sxx[k][j] = 0.0; }
+  constexpr int U = R == 1 ? 4 : (R == 2 ? 2 : 1);          // columns in flight per lane group
+  const int64_t stride = (int64_t)gridDim.x * cols_per_block;
+  int64_t col = (int64_t)blockIdx.x * cols_per_block + cg;
+  for (; col + (U - 1) * stride < batch; col += U * stride) {
+    Pack<T, V> p[U][R];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+        if (gl + k * G < nvc) p[u][k] = load_pack<T, V, false>(x + (col + u * stride) * dim + (int64_t)(gl + k * G) * V);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+        if (gl + k * G < nvc) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) { const double v = (double)p[u][k].v[j]; sx[k][j] += v; sxx[k][j] += v * v; }
+        }
+  }
+  for (; col < batch; col += stride) {
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+      if (gl + k * G < nvc) {
+        Pack<T, V> p = load_pack<T, V, false>(x + col * dim + (int64_t)(gl + k * G) * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { const double v = (double)p.v[j]; sx[k][j] += v; sxx[k][j] += v * v; }
+      }
+  }
+  // combine the column groups of the block in a fixed order
+#pragma unroll
+  for (int k = 0; k < R; ++k)
+    if (gl + k * G < nvc) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const size_t row = (size_t)(gl + k * G) * V + j;
+        red[((size_t)cg * dim + row) * 2] = sx[k][j];
+        red[((size_t)cg * dim + row) * 2 + 1] = sxx[k][j];
+      }
+    }
+  __syncthreads();
+  for (int64_t r = threadIdx.x; r < dim; r += 256) {
+    double a = 0.0, b = 0.0;
+    for (int c = 0; c < cols_per_block; ++c) { a += red[((size_t)c * dim + r) * 2]; b += red[((size_t)c * dim + r) * 2 + 1]; }
+    partial[((size_t)blockIdx.x * dim + r) * 2] = a;
+    partial[((size_t)blockIdx.x * dim + r) * 2 + 1] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const double* __restrict__ partial, int nblocks, int64_t dim, int64_t batch, double* __restrict__ stats) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < dim; r += (int64_t)gridDim.x * blockDim.x) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nblocks; ++k) { a += partial[((size_t)k * dim + r) * 2]; b += partial[((size_t)k * dim + r) * 2 + 1]; }
+    stats[r] = a;
+    stats[dim + r] = b;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) stats[2 * dim] = (double)batch;
+}
+
+// batch statistics, moving-statistics update (normalise.jl:56-60) and the per-sample log-det constant (:63)
+template <class T>
+__global__ __launch_bounds__(256) void bn_train_finalize_kernel(const double* __restrict__ stats, int64_t dim, const T* __restrict__ logs, T eps, T mtm,
+                                                                T* __restrict__ m_mov, T* __restrict__ v_mov, T* __restrict__ m_batch,
+                                                                T* __restrict__ v_batch, int64_t local_batch, double* __restrict__ consts) {
+  __shared__ double red[4];
+  const double n = stats[2 * dim];
+  double s = 0.0;
+  for (int64_t r = threadIdx.x; r < dim; r += blockDim.x) {
+    const double mean = stats[r] / n;
+    double var = stats[dim + r] / n - mean * mean;           // biased (÷ n), :54
+    if (var < 0.0) var = 0.0;
+    const T mT = (T)mean, vT = (T)var;
+    m_batch[r] = mT;
+    v_batch[r] = vT;
+    m_mov[r] = (T(1) - mtm) * m_mov[r] + mtm * mT;                               // :58
+    v_mov[r] = (T(1) - mtm) * v_mov[r] + (T)((double)mtm * n / (n - 1.0)) * vT;  // :59
+    s += (double)(logs[r] - d_log(vT + eps) / T(2));
+  }
+  s = group_sum<64>(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double c = (red[0] + red[1]) + (red[2] + red[3]);
+    consts[0] = c;
+    consts[1] = c * (double)local_batch;
+  }
+}
+
 int build_rowmap(bjx_ctx* ctx, const int32_t* idx1, int64_t n1, int64_t dim, int32_t** map_out) {
   BJX_REQUIRE(ctx, (size_t)dim * sizeof(int32_t) + 16 <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "coupling: dim %lld too large for the context scratch", (long long)dim);
   int32_t* map = static_cast<int32_t*>(ctx->scratch);
@@ -683,6 +796,66 @@ BJX_API int bjx_batchnorm(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* b
               bn_impl<float>(ctx, inverse, (const float*)b, (const float*)logs, (const float*)m, (const float*)v, (float)eps, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, batch, flags),
               bn_impl<double>(ctx, inverse, (const double*)b, (const double*)logs, (const double*)m, (const double*)v, eps, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, batch, flags),
               "bjx_batchnorm");
+}
+
+namespace {
+template <class T>
+int bn_train_impl(bjx_ctx* ctx, const T* b, const T* logs, T* m, T* v, T eps, T mtm, const T* in, T* out, T* ladj_ps, double* ladj_sum,
+                  int64_t dim, int64_t batch, uint32_t flags) {
+  BJX_REQUIRE(ctx, batch >= 1, BJX_ERR_SHAPE, "bjx_batchnorm_train: empty batch");
+  ColLaunch c = col_launch_cfg<T>(ctx, in, out, dim, batch);
+  const int64_t nvc = dim / c.V;
+  BJX_REQUIRE(ctx, nvc <= 256, BJX_ERR_UNSUPPORTED, "bjx_batchnorm_train: %lld channels exceed the register-accumulator kernel (max %d)", (long long)dim, 256 * c.V);
+  const int R = nvc <= c.G ? 1 : (nvc <= 2 * c.G ? 2 : 4);
+  const int cols_per_block = 256 / c.G;
+  int nblocks = (int)((batch + cols_per_block * 16 - 1) / (cols_per_block * 16));     // >= 16 columns per lane group
+  if (nblocks > 1024) nblocks = 1024;
+  if (nblocks < 1) nblocks = 1;
+  // scratch: [stats 2 dim + 1][partials nblocks*dim*2] doubles, then batch m / v (T)
+  const size_t stats_n = 2 * (size_t)dim + 1;
+  const size_t part_n = (size_t)nblocks * dim * 2;
+  const size_t bytes = (stats_n + 1 + part_n) * sizeof(double) + 2 * (size_t)dim * sizeof(T);
+  BJX_REQUIRE(ctx, bytes <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_batchnorm_train: scratch too small for %lld channels", (long long)dim);
+  double* stats = static_cast<double*>(ctx->scratch);
+  double* partial = stats + stats_n + 1;
+  T* m_batch = reinterpret_cast<T*>(partial + part_n);
+  T* v_batch = m_batch + dim;
+  const size_t smem = (size_t)cols_per_block * dim * 2 * sizeof(double);
+  BJX_REQUIRE(ctx, smem <= 64 * 1024, BJX_ERR_UNSUPPORTED, "bjx_batchnorm_train: LDS");
+  constexpr int VW = Vec16<T>::N;
+  {
+    BjxProf prof_(ctx);
+#define BN_ST(V_, R_) hipLaunchKernelGGL((bn_stats_kernel<T, V_, R_>), dim3(nblocks), dim3(256), smem, ctx->stream, in, dim, batch, c.G, partial)
+#define BN_STV(V_) do { if (R == 1) BN_ST(V_, 1); else if (R == 2) BN_ST(V_, 2); else BN_ST(V_, 4); } while (0)
+    if (c.V == VW) BN_STV(VW); else BN_STV(1);
+#undef BN_STV
+#undef BN_ST
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)((dim + 255) / 256)), dim3(256), 0, ctx->stream, partial, nblocks, dim, batch, stats);
+  BJX_CHECK_LAUNCH(ctx);
+  if (ctx->comm && ctx->nranks > 1) {      // batch sharded over GPUs: the second collective of SURVEY.md §8(e)
+    int rc = bjx_allreduce_sum_f64(ctx, stats, (int64_t)stats_n);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(bn_train_finalize_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, stats, dim, logs, eps, mtm, m, v, m_batch, v_batch, batch, ctx->consts);
+  BJX_CHECK_LAUNCH(ctx);
+  const bool lds = (size_t)dim * 4 * sizeof(T) <= 60 * 1024;
+  const size_t fsm = lds ? (size_t)dim * 4 * sizeof(T) : 0;
+  BnF<T, false> f{b, logs, m_batch, v_batch, eps, dim, lds ? 1 : 0, 0.0, ctx->consts};
+  return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0);
+}
+}  // namespace
+
+BJX_API int bjx_batchnorm_train(bjx_ctx* ctx, bjx_dtype dt, const void* b, const void* logs, void* m, void* v, double eps, double mtm,
+                                const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_batchnorm_train: bad size");
+  BJX_REQUIRE(ctx, b && logs && m && v && in && out, BJX_ERR_ARG, "bjx_batchnorm_train: null pointer");
+  DISPATCH_DT(ctx, dt,
+              bn_train_impl<float>(ctx, (const float*)b, (const float*)logs, (float*)m, (float*)v, (float)eps, (float)mtm, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, batch, flags),
+              bn_train_impl<double>(ctx, (const double*)b, (const double*)logs, (double*)m, (double*)v, eps, mtm, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, batch, flags),
+              "bjx_batchnorm_train");
 }
 
 BJX_API int bjx_permute(bjx_ctx* ctx, bjx_dtype dt, const int32_t* src, const void* in, void* out, int64_t dim, int64_t batch) {

@@ -31,7 +31,7 @@ __all__ = [
     "Transform", "Bijector", "Inverse", "ComposedFunction", "Elementwise", "elementwise", "exp", "log", "identity",
     "Shift", "Scale", "Logit", "LeakyReLU", "TruncatedBijector", "SignFlip", "OrderedBijector", "SimplexBijector",
     "VecCholeskyBijector", "Permute", "PlanarLayer", "RadialLayer", "InvertibleBatchNorm", "RationalQuadraticSpline",
-    "PartitionMask", "Coupling", "Stacked", "Columnwise", "columnwise", "vjp", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
+    "PartitionMask", "Coupling", "Stacked", "Columnwise", "columnwise", "vjp", "istraining", "training", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
     "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
     "PlanarResult",
 ]
@@ -842,8 +842,34 @@ class RadialLayer(Bijector):
         return self._run(x, True, per_sample, want_ladj)
 
 
+_TRAINING = [False]
+
+
+def istraining() -> bool:
+    """normalise.jl:7 — the reference switches modes by redefining this global function."""
+    return _TRAINING[0]
+
+
+class training:
+    """`with bj.training():` — the scope in which `istraining()` is true (normalise.jl:7,51)."""
+
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = _TRAINING[0]
+        _TRAINING[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _TRAINING[0] = self.prev
+        return False
+
+
 class InvertibleBatchNorm(Bijector):
-    """normalise.jl:9-92, eval mode (`istraining() == false`, :7)."""
+    """normalise.jl:9-92.  Eval mode (`istraining() == false`, :7) uses the moving statistics; inside
+    `with bj.training():` the batch statistics are used and `m`, `v` are updated in place (:51-60) — the
+    struct is mutable in the reference too."""
 
     def __init__(self, chs_or_b, logs=None, m=None, v=None, eps=1e-5, mtm=0.1, dtype=torch.float32):
         if isinstance(chs_or_b, int):  # normalise.jl:26-37
@@ -863,8 +889,19 @@ class InvertibleBatchNorm(Bijector):
             raise ValueError("InvertibleBatchNorm needs an input with at least 2 dimensions")
         if x.shape[-2] != self.b.numel():  # normalise.jl:43-45
             raise RuntimeError(f"InvertibleBatchNorm expected {self.b.numel()} channels, got {x.shape[-2]}")
-        ps = [_param(t, x) for t in (self.b, self.logs, self.m, self.v)]
         dim = x.shape[0]
+        if istraining():
+            if inv:
+                raise AssertionError("`with_logabsdet_jacobian(::Inverse{InvertibleBatchNorm})` is only available in test mode.")  # :71
+            if x.dim() != 2:
+                raise NotImplementedError("training mode: (channels, batch) matrices only")
+            # the moving statistics live on the device from now on and are updated in place (:58-59)
+            self.m, self.v = _param(self.m, x).clone() if not (self.m.is_cuda and self.m.dtype == x.dtype) else self.m, \
+                _param(self.v, x).clone() if not (self.v.is_cuda and self.v.dtype == x.dtype) else self.v
+            b, logs = _param(self.b, x), _param(self.logs, x)
+            return _call_struct("bjx_batchnorm_train", x, dim, True, per_sample, want_ladj,
+                                (_ptr(b), _ptr(logs), _ptr(self.m), _ptr(self.v), self.eps, self.mtm), (dim,))
+        ps = [_param(t, x) for t in (self.b, self.logs, self.m, self.v)]
         return _call_struct("bjx_batchnorm", x, dim, True, per_sample, want_ladj,
                             (int(inv), *[_ptr(p) for p in ps], self.eps), (dim,))
 

@@ -51,3 +51,28 @@ def with_logabsdet_jacobian_sharded(b, x_shard: torch.Tensor, group=None, out: O
     lps, lsum = l if per_sample else (None, l)
     allreduce_logabsdetjac(lsum, group)
     return y, lps, lsum
+
+
+def init_comm(device: Optional[torch.device] = None, group=None) -> None:
+    """Give this rank's context an RCCL communicator (bjx_comm_init) so that entry points with an
+    in-library collective — InvertibleBatchNorm in training mode: one all-reduce of the 2·dim+1 Float64
+    batch sums, SURVEY.md §8(e) — see the GLOBAL batch.  The 128-byte ncclUniqueId is made on rank 0 and
+    broadcast through torch.distributed (any backend).  No-op for a single process."""
+    import ctypes as C
+
+    import torch.distributed as dist
+
+    from . import _lib as L
+    from . import interface as I
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    ctx = I.context(device)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    buf = (C.c_ubyte * 128)()
+    if rank == 0:
+        L.check(ctx.h, L.load().bjx_comm_unique_id(buf), "bjx_comm_unique_id")
+    box = [bytes(buf)]
+    dist.broadcast_object_list(box, src=0, group=group)
+    ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+    L.check(ctx.h, L.load().bjx_comm_init(ctx.h, world, rank, ident), "bjx_comm_init")

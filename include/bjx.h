@@ -160,6 +160,17 @@ int bjx_batchnorm(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* b, const 
                   const void* m, const void* v, double eps, const void* in, void* out,
                   void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
 
+/* InvertibleBatchNorm in TRAINING mode (istraining() == true), normalise.jl:51-60: the batch mean and the
+ * biased batch variance of every channel replace m / v in the transform and the log-det, and the moving
+ * statistics `m`, `v` (device T[dim], read AND written) are updated with momentum `mtm`
+ * (bn.v with the n/(n-1) correction, :59).  When the context has a communicator (bjx_comm_init) the batch is
+ * taken to be sharded over the ranks and the 2·dim+1 Float64 sums (Σx, Σx², n) are all-reduced once
+ * (SURVEY.md §8e): every rank then normalises with the GLOBAL statistics.  The reference has no inverse in
+ * training mode (:71). */
+int bjx_batchnorm_train(bjx_ctx* ctx, bjx_dtype dt, const void* b, const void* logs, void* m, void* v,
+                        double eps, double mtm, const void* in, void* out, void* ladj_ps,
+                        double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
+
 /* ------------------------------- F4: table lookup                         */
 /* RationalQuadraticSpline with matrix parameters, rational_quadratic_spline.jl:128-367,
  * applied to every column of X[dim,batch].  widths/heights/derivs: device T[dim, n_knots]

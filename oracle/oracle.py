@@ -522,3 +522,21 @@ def simplex_vjp(inp, out_bar, ladj_bar=None, inverse=False):
         sb_next = sb
     xb[K - 1] = 0.0                                                     # row K enters neither y nor the log-det
     return xb
+
+
+def batchnorm_train(b, logs, m, v, eps, mtm, x):
+    """InvertibleBatchNorm with istraining() == true on a (channels, batch) matrix — normalise.jl:41-68, numpy:
+    -> (result, per-column logabsdetjac, updated moving mean, updated moving variance)."""
+    x = np.asarray(x)
+    T = x.dtype
+    b, logs, m, v = (np.asarray(p, dtype=T) for p in (b, logs, m, v))
+    n = x.shape[1]
+    mb = x.mean(axis=1, dtype=np.float64)                                   # :53
+    vb = ((x.astype(np.float64) - mb[:, None]) ** 2).sum(axis=1) / n        # :54
+    mbT, vbT = mb.astype(T), vb.astype(T)
+    m_new = (1 - T.type(mtm)) * m + T.type(mtm) * mbT                       # :58
+    v_new = (1 - T.type(mtm)) * v + T.type(mtm * n / (n - 1)) * vbT         # :59
+    s = np.exp(logs)
+    result = s[:, None] * (x - mbT[:, None]) / np.sqrt(vbT + T.type(eps))[:, None] + b[:, None]   # :66
+    ladj = np.full(n, (logs - np.log(vbT + T.type(eps)) / 2).sum(), dtype=T)                     # :67
+    return result, ladj, m_new, v_new

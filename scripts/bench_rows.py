@@ -103,6 +103,14 @@ def main():
     add("inverse(RadialLayer) d=128", "a17", bj.inverse(rad), z)
     bn = bj.InvertibleBatchNorm(torch.zeros(d, device=dev), torch.zeros(d, device=dev), torch.zeros(d, device=dev), torch.ones(d, device=dev))
     add("InvertibleBatchNorm (eval) d=64", "a18", bn, x)
+    bnt = bj.InvertibleBatchNorm(torch.zeros(d, device=dev), torch.zeros(d, device=dev), torch.zeros(d, device=dev), torch.ones(d, device=dev))
+
+    def bn_train_step():
+        with bj.training():
+            return bj.shard.with_logabsdet_jacobian_sharded(bnt, x, out=y_bn)
+
+    y_bn = cm(d, N, dev)
+    rows.append(("InvertibleBatchNorm (training: stats pass only) d=64", "a18", bn_train_step, 4 * d, N))
     dr, Kb = 32, 16
     raw = [randn(dr, k, dev, 100 + i) for i, k in enumerate((Kb, Kb, Kb - 1))]
     rqs = bj.RationalQuadraticSpline(raw[0], raw[1], raw[2], 3.0)

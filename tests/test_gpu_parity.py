@@ -766,3 +766,31 @@ def test_simplex_vjp(bj, orc, K, N, dt):
     got_f = bj.vjp(b, dev(x), dev(gy), torch.from_numpy(lbar).cuda())
     assert tuple(got_f.shape) == (K, N)
     np.testing.assert_allclose(host(got_f), ref_f, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref_f).max())))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,N", [(2, 20), (64, 3000), (5, 257), (130, 64)])
+def test_batchnorm_training_mode(bj, orc, dim, N, dt):
+    """normalise.jl:51-60: batch statistics in the transform and the log-det, moving statistics updated in place."""
+    r = rng(62)
+    b_, logs = r.normal(size=dim).astype(dt), (0.3 * r.normal(size=dim)).astype(dt)
+    m0, v0 = r.normal(size=dim).astype(dt), r.uniform(0.5, 2, size=dim).astype(dt)
+    X = np.asfortranarray((1.5 * r.normal(size=(dim, N)) + 0.7).astype(dt))
+    bn = bj.InvertibleBatchNorm(torch.tensor(b_), torch.tensor(logs), torch.tensor(m0), torch.tensor(v0), eps=1e-5, mtm=0.1)
+    Y_ref, l_ref, m_ref, v_ref = orc.batchnorm_train(b_, logs, m0, v0, 1e-5, 0.1, X)
+    assert not bj.istraining()
+    with bj.training():
+        assert bj.istraining()
+        Y, l = bj.with_logabsdet_jacobian(bn, dev(X))
+        with pytest.raises(AssertionError):                       # :71
+            bj.transform(bj.inverse(bn), dev(X))
+    assert tuple(l.shape) == (N,)
+    close(host(Y), Y_ref, dt, scale=10, what="bn train y")
+    close(host(l), l_ref, dt, scale=dim, what="bn train ladj")
+    close(host(bn.m), m_ref, dt, what="moving mean")
+    close(host(bn.v), v_ref, dt, what="moving variance")
+    # back in eval mode the UPDATED moving statistics are used
+    Ye_ref, le_ref = orc.batchnorm(b_, logs, m_ref, v_ref, 1e-5, X)
+    Ye, le = bj.with_logabsdet_jacobian(bn, dev(X))
+    close(host(Ye), Ye_ref, dt, scale=10, what="bn eval after train")
+    close(host(le), le_ref, dt, scale=dim)
