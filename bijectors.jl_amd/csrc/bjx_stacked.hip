@@ -217,7 +217,7 @@ struct StackedPlan { char* tab; size_t tab_bytes; bool gather; int two; int V; }
 // validates the segment list, uploads it and launches the table build; `x`/`y` only decide the pack width
 template <class T>
 int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const void* x, const void* y, int64_t dim, int64_t batch, bool inplace_check,
-                    StackedPlan* plan) {
+                    bool packs_ok, StackedPlan* plan) {
   // validate on the host: every output row and every input row exactly once (stacked.jl:156-165 checks the lengths)
   int64_t total = 0;
   int max_ops = 0;
@@ -284,7 +284,8 @@ int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const voi
   if (n_segs) BJX_HIP(ctx, hipMemcpyAsync(dseg, hseg, (size_t)n_segs * sizeof(SegDev), hipMemcpyHostToDevice, ctx->stream));
   BJX_HIP(ctx, hipEventRecord(ctx->stage_ev, ctx->stream));
   // the main kernel's pack width decides the row permutation of the table (same rule as col_launch_cfg)
-  const ColLaunch cl = col_launch_cfg<T>(ctx, x, y, dim, batch);
+  ColLaunch cl = col_launch_cfg<T>(ctx, x, y, dim, batch);
+  if (!packs_ok) cl.V = 1;                               // a third buffer of the caller is not 16-byte aligned
   hipLaunchKernelGGL(stacked_table_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, dseg, n_segs, dim, cl.V, tab, flag);
   BJX_CHECK_LAUNCH(ctx);
   plan->tab = tab; plan->tab_bytes = tab_bytes; plan->gather = gather; plan->two = max_ops > 1 ? 1 : 0; plan->V = cl.V;
@@ -299,7 +300,7 @@ int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, 
     return BJX_OK;
   }
   StackedPlan pl;
-  { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, y, dim, batch, true, &pl); if (rc) return rc; }
+  { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, y, dim, batch, true, true, &pl); if (rc) return rc; }
   char* tab = pl.tab;
   const int two = pl.two;
   const bool lds = pl.tab_bytes <= 48 * 1024;
@@ -404,8 +405,7 @@ template <class T>
 int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, const T* ybar, const T* lbar, T* xbar, int64_t dim, int64_t batch) {
   if (dim * batch == 0) return BJX_OK;
   StackedPlan pl;
-  const bool al = bjx_aligned16(x) && bjx_aligned16(ybar) && bjx_aligned16(xbar);
-  { int rc = stacked_prepare<T>(ctx, segs, n_segs, al ? (const void*)x : (const void*)(reinterpret_cast<const char*>(x) + 4), xbar, dim, batch, false, &pl); if (rc) return rc; }
+  { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, xbar, dim, batch, false, bjx_aligned16(ybar), &pl); if (rc) return rc; }
   const bool lds = pl.tab_bytes <= 48 * 1024;
   const size_t smem = lds ? pl.tab_bytes : 0;
   const int64_t packs = dim / pl.V;
