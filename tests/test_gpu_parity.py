@@ -794,3 +794,30 @@ def test_batchnorm_training_mode(bj, orc, dim, N, dt):
     Ye, le = bj.with_logabsdet_jacobian(bn, dev(X))
     close(host(Ye), Ye_ref, dt, scale=10, what="bn eval after train")
     close(host(le), le_ref, dt, scale=dim)
+
+
+def test_rccl_communicator_single_rank(bj):
+    """bjx_comm_unique_id / bjx_comm_init / bjx_allreduce_sum_f64 / bjx_comm_destroy through the dlopen'ed
+    librccl.so with a 1-rank communicator: the collective path a Julia host uses loads, runs on the
+    context stream and leaves the value unchanged."""
+    import ctypes as C
+
+    L = bj._lib
+    lib = L.load()
+    h = C.c_void_p()
+    stream = torch.cuda.Stream()
+    L.check(None, lib.bjx_create(torch.cuda.current_device(), C.c_void_p(stream.cuda_stream), C.byref(h)), "bjx_create")
+    try:
+        uid = (C.c_ubyte * 128)()
+        L.check(h, lib.bjx_comm_unique_id(uid), "bjx_comm_unique_id")
+        assert any(uid)
+        L.check(h, lib.bjx_comm_init(h, 1, 0, uid), "bjx_comm_init")
+        with torch.cuda.stream(stream):
+            v = torch.tensor([1.25, -3.5, 7.0], dtype=torch.float64, device="cuda")
+        stream.synchronize()
+        L.check(h, lib.bjx_allreduce_sum_f64(h, C.c_void_p(v.data_ptr()), 3), "bjx_allreduce_sum_f64")
+        L.check(h, lib.bjx_synchronize(h), "bjx_synchronize")
+        assert v.tolist() == [1.25, -3.5, 7.0]
+        L.check(h, lib.bjx_comm_destroy(h), "bjx_comm_destroy")
+    finally:
+        lib.bjx_destroy(h)
