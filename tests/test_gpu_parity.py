@@ -821,3 +821,29 @@ def test_rccl_communicator_single_rank(bj):
         L.check(h, lib.bjx_comm_destroy(h), "bjx_comm_destroy")
     finally:
         lib.bjx_destroy(h)
+
+
+@pytest.mark.parametrize("dt,dim", [(np.float64, 1), (np.float64, 20), (np.float32, 20), (np.float32, 3)])
+def test_planar_inverse_root_finder_on_the_reference_grid(bj, dt, dim):
+    """test/normalising_flows.jl:47-70: find_alpha must solve wt_y = α + wt_u_hat·tanh(α + b) on the reference's
+    argument grid (incl. the |wt_u_hat| ~ 0 empty-bracket cases and b = -1e8).  The device root finders are not
+    ABI entry points, so the grid is realised through a PlanarLayer with w = e_1: wᵀy = y_1, wᵀû = wt_u_hat
+    (u_1 = softplus⁻¹(wt_u_hat + 1)); the residual is checked on the inverse's output in Float64 on the host."""
+    ys = (-20.3, -3.0, -1.5, 0.0, 5.0, 7.25, 12.3)
+    tus = (-0.5, -1e-20, 0.0, 1e-20, 3.0, 11 / 3, 17.2)          # wt_u_hat = -1 needs u = -inf: not representable as a layer
+    bs = (-19.3, -8 / 3, -1.0, 0.0, 0.5, 3.0, 4.3, -1e8)
+    tol = 1e-4 if dt == np.float32 else 1e-9
+    Y = np.zeros((dim, len(ys)))
+    Y[0] = ys
+    Y[1:] = 0.3
+    for tu in tus:
+        u0 = math.log(math.expm1(tu + 1.0))                        # log1pexp(u0) - 1 == tu  (planar_layer.jl:68)
+        for b in bs:
+            w = np.zeros(dim); w[0] = 1.0
+            u = np.zeros(dim); u[0] = u0
+            layer = bj.PlanarLayer(torch.tensor(w.astype(dt)), torch.tensor(u.astype(dt)), torch.tensor(np.array([b], dtype=dt)))
+            Z = host(bj.transform(bj.inverse(layer), dev(np.asfortranarray(Y.astype(dt))))).astype(np.float64)
+            alpha = Z[0]                                            # wᵀz
+            res = alpha + tu * np.tanh(alpha + b)
+            np.testing.assert_allclose(res, np.asarray(ys), rtol=tol, atol=tol * 10, err_msg=f"wt_u_hat={tu} b={b}")
+            np.testing.assert_allclose(Z[1:], Y[1:], rtol=0, atol=1e-6)   # rows 2.. have û = 0: untouched
