@@ -847,3 +847,19 @@ def test_planar_inverse_root_finder_on_the_reference_grid(bj, dt, dim):
             res = alpha + tu * np.tanh(alpha + b)
             np.testing.assert_allclose(res, np.asarray(ys), rtol=tol, atol=tol * 10, err_msg=f"wt_u_hat={tu} b={b}")
             np.testing.assert_allclose(Z[1:], Y[1:], rtol=0, atol=1e-6)   # rows 2.. have û = 0: untouched
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_simplex_extreme_unconstrained_values_stay_finite(bj, dt):
+    """test/legacy_interface.jl:158-170 (issue #12): invlink at link(x) + randn·1e10 must not produce Inf/NaN in the
+    value or the log-det (logistic saturation + the max(·, ε) guards of simplex.jl:122-138)."""
+    r = rng(71)
+    K, N = 3, 1000
+    y = (r.normal(size=(K - 1, N)) * 1e10).astype(dt)
+    x, l = bj.with_logabsdet_jacobian(bj.inverse(bj.SimplexBijector()), dev(np.asfortranarray(y)), per_sample=True)
+    xh, lh = host(x), host(l)
+    assert np.isfinite(xh).all() and np.isfinite(lh).all()
+    assert (xh >= 0).all() and (xh <= 1).all()
+    np.testing.assert_allclose(xh.sum(axis=0), 1.0, atol=1e-6)
+    yb, lb = bj.with_logabsdet_jacobian(bj.SimplexBijector(), x, per_sample=True)     # and back: finite as well
+    assert np.isfinite(host(yb)).all() and np.isfinite(host(lb)).all()
