@@ -1260,6 +1260,74 @@ __global__ __launch_bounds__(64) void ordered_vjp_kernel(const T* __restrict__ i
   tile_stage_out<T, V>(tg, in_bar + col0 * rows, rows, P, ncols, lane);
 }
 
+// Streaming variant (no LDS tiles) when a column is at most 64 packs: G lanes own one column as 16-byte
+// packs (coalesced), 4 columns in flight per lane group.  The inverse's pullback is local (each entry needs its
+// two neighbours: one lane shuffle each way); the forward's needs the suffix sum of the output cotangent
+// along the column: a 4-element suffix per lane + a reversed inclusive scan over the G lanes.
+// (The two-tile kernel below holds 33 KiB of LDS per wave at dim = 64: 4 waves per CU, 42 % of the HBM roofline.)
+template <class T, int V, bool INV>
+__global__ __launch_bounds__(256) void ordered_vjp_stream_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
+                                                                T* __restrict__ in_bar, int64_t dim, int64_t batch, int G) {
+  constexpr int UC = 4;
+  const int gl = threadIdx.x & (G - 1);
+  const int cols_per_block = 256 / G;
+  const int nvc = (int)(dim / V);
+  const bool lane_ok = gl < nvc;
+  const bool first_lane = gl == 0, last_lane = gl == nvc - 1;
+  const int64_t col0 = (int64_t)blockIdx.x * cols_per_block * UC + threadIdx.x / G;
+  Pack<T, V> a[UC], g[UC];
+#pragma unroll
+  for (int u = 0; u < UC; ++u) {
+    const int64_t col = col0 + (int64_t)u * cols_per_block;
+    if (lane_ok && col < batch) {
+      a[u] = load_pack<T, V, true>(in + col * dim + (int64_t)gl * V);
+      g[u] = load_pack<T, V, true>(out_bar + col * dim + (int64_t)gl * V);
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) { a[u].v[j] = T(0); g[u].v[j] = T(0); }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < UC; ++u) {
+    const int64_t col = col0 + (int64_t)u * cols_per_block;
+    const bool ok = lane_ok && col < batch;
+    const T lb = (ladj_bar && col < batch) ? ladj_bar[col] : T(0);
+    Pack<T, V> o;
+    if (!INV) {
+      // suffix sums: local (descending), then add the totals of the lanes to my right inside the column group
+      T sfx[V];
+      T run = T(0);
+#pragma unroll
+      for (int j = V - 1; j >= 0; --j) { run += g[u].v[j]; sfx[j] = run; }
+      T tot = run;                                            // my lane's total; inclusive reversed scan over the group
+      for (int d = 1; d < G; d <<= 1) {
+        const T o2 = __shfl_down(tot, d, 64);
+        if (gl + d < G) tot += o2;
+      }
+      const T right = tot - run;                              // Σ of the lanes to my right
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const T s = sfx[j] + right;
+        o.v[j] = (first_lane && j == 0) ? s : s * d_exp(a[u].v[j]) + lb;
+      }
+    } else {
+      const T xprev = __shfl_up(a[u].v[V - 1], 1, 64);        // x_{i-1} of my first element (unused for the column's first row)
+      T q[V + 1];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const bool row0 = first_lane && j == 0;
+        const T xm1 = j == 0 ? xprev : a[u].v[j - 1];
+        q[j] = row0 ? g[u].v[0] : (g[u].v[j] - lb) / (a[u].v[j] - xm1);
+      }
+      const T qn = __shfl_down(q[0], 1, 64);
+      q[V] = last_lane ? T(0) : qn;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.v[j] = q[j] - q[j + 1];
+    }
+    if (ok) store_pack<T, V, true>(in_bar + col * dim + (int64_t)gl * V, o);
+  }
+}
+
 // fallback for columns too long for two LDS tiles: one thread per column, straight from global memory
 template <class T, bool INV>
 __global__ __launch_bounds__(256) void ordered_vjp_column_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
@@ -1288,6 +1356,24 @@ __global__ __launch_bounds__(256) void ordered_vjp_column_kernel(const T* __rest
 template <class T>
 int ordered_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t dim, int64_t batch) {
   if (batch == 0) return BJX_OK;
+  {
+    constexpr int VW = Vec16<T>::N;
+    static const int use_stream = getenv("BJX_ORDERED_VJP_STREAM") ? atoi(getenv("BJX_ORDERED_VJP_STREAM")) : 1;
+    if (use_stream && dim % VW == 0 && dim / VW <= 64 && in_bar != in && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar)) {
+      int G = 1;
+      while (G < dim / VW) G <<= 1;
+      const int64_t cpb = (int64_t)(256 / G) * 4;
+      const int64_t grid = (batch + cpb - 1) / cpb;
+      BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+      {
+        BjxProf prof_(ctx);
+        if (inverse) hipLaunchKernelGGL((ordered_vjp_stream_kernel<T, VW, true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out_bar, ladj_bar, in_bar, dim, batch, G);
+        else hipLaunchKernelGGL((ordered_vjp_stream_kernel<T, VW, false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out_bar, ladj_bar, in_bar, dim, batch, G);
+      }
+      BJX_CHECK_LAUNCH(ctx);
+      return BJX_OK;
+    }
+  }
   const int64_t P = dim | 1;
   const size_t smem = (size_t)2 * 64 * P * sizeof(T);
   if (smem > BJX_LDS_MAX) {
