@@ -1634,10 +1634,173 @@ BJX_API int bjx_ordered(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in,
 }
 
 namespace {
+// ------------------------------------------------------------------ SimplexBijector forward, streaming kernel
+// simplex.jl:47-64 + :122-138 without a whole-column LDS tile, for K = 16·NP <= 64 (NP packs per lane):
+// the forward map couples the rows only through s_k = Σ_{j<k} x_j, so FOUR lanes own a column, each a
+// contiguous quarter of it (NP 16-byte packs; a wave instruction covers 16 columns).  s_k is accumulated in the
+// reference's order — x_1 + x_2 + … one add after the other: the quad's lanes take turns (4 rounds of 4·NP adds,
+// the carry handed on with a quad_perm DPP broadcast), because the sum's rounding decides late rows where
+// 1 - s_k is small (a re-associated prefix scan moved 1 element in 63 000 by 2 %).  Everything else is
+// elementwise.  The K-1 = odd-length output columns of one wave instruction form ONE contiguous, 16-byte aligned
+// run (16 columns), which is re-dealt through a 4 KiB LDS strip so the stores are whole coalesced 16-byte packs.
+// (The whole-column tile kernel — 16.6 KiB of LDS per wave, 9 waves per CU — reached 52 % of the HBM roofline
+// at C5a and still serves every other K.)
+template <class T, int V, int NP, bool LADJ, int UC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UC == 1 && sizeof(T) == 4) ? 6 : 4, 8))) void simplex_fwd_stream_kernel(const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t batch,
+                                                                int accumulate, double* partials) {
+  using F = Fast<T>;
+  constexpr int RPL = NP * V;                        // rows per lane
+  constexpr int K = 4 * RPL;
+  constexpr int CPS = 16;                            // columns per wave instruction (4 lanes each)
+  constexpr int PITCH = K + V;                       // LDS pitch of an input column: one pack of padding keeps the 16-byte reads conflict-free
+  constexpr int PPC = 4 * NP;                        // packs per input column
+  __shared__ __attribute__((aligned(16))) T strip[4][CPS * PITCH];
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gl = lane & 3, cg = lane >> 2;
+  const T e = Num<T>::eps, c2 = T(1) - 2 * e, E = T(1) + e;
+  const int64_t colb = ((int64_t)blockIdx.x * 4 + wave) * (CPS * UC);
+  // coalesced loads: the 16 columns of a wave instruction are one contiguous run of 64·NP packs
+  Pack<T, V> raw[UC][NP];
+#pragma unroll
+  for (int u = 0; u < UC; ++u) {
+    const int64_t colw = colb + u * CPS;
+    const int64_t npk = colw < batch ? (batch - colw < (int64_t)CPS ? batch - colw : (int64_t)CPS) * PPC : 0;   // packs of this run inside the batch
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int pk = lane + 64 * q;
+      if (pk < npk) raw[u][q] = load_pack<T, V, true>(x + colw * K + (int64_t)pk * V);
+      else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) raw[u][q].v[j] = T(0);
+      }
+    }
+  }
+  // log(K-k) per row: one precise log per thread of the block, then everybody reads its RPL rows
+  __shared__ __attribute__((aligned(16))) T lktab[K];
+  if ((int)threadIdx.x < K) lktab[threadIdx.x] = (int)threadIdx.x < K - 1 ? d_log(T(K - 1 - (int)threadIdx.x)) : T(0);
+  __syncthreads();
+  double acc = 0.0;
+  T* st = strip[wave];
+#pragma unroll
+  for (int u = 0; u < UC; ++u) {
+    const int64_t colw = colb + u * CPS;
+    const int64_t col = colw + cg;
+    // re-deal: pack p of the run belongs to column p / PPC; lane (cg, gl) takes packs gl·NP .. gl·NP+NP-1 of column cg
+    T xv[RPL];
+    __builtin_amdgcn_wave_barrier();                                   // the previous instruction's strip reads are done
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int pk = lane + 64 * q;
+      *reinterpret_cast<typename Vec16<T>::type*>(st + (pk / PPC) * PITCH + (pk % PPC) * V) = __builtin_bit_cast(typename Vec16<T>::type, raw[u][q]);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const Pack<T, V> pq = __builtin_bit_cast(Pack<T, V>, *reinterpret_cast<const typename Vec16<T>::type*>(st + cg * PITCH + (gl * NP + q) * V));
+#pragma unroll
+      for (int j = 0; j < V; ++j) xv[q * V + j] = pq.v[j];
+    }
+    // s before each of my rows, accumulated in the reference's order.  The quad's lanes take turns without any
+    // select: every round each lane re-runs its chain from the carry it holds, and then takes its left
+    // neighbour's total as the new carry; lane t's carry is final after round t-1 and never changes again, so
+    // after 4 rounds every chain is the sequential one.
+    T sb[RPL];
+    T carry = T(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      T run = carry;
+#pragma unroll
+      for (int i = 0; i < RPL; ++i) { sb[i] = run; run += xv[i]; }
+      if (t < 3) {
+        T bc;
+        if constexpr (sizeof(T) == 4) {
+          bc = __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, run), 0x90, 0xF, 0xF, true));   // quad_perm [0,0,1,2]
+        } else {
+          bc = __shfl(run, lane > 0 ? lane - 1 : 0, 64);
+        }
+        carry = gl == 0 ? T(0) : bc;
+      }
+    }
+    T lp = T(0);
+    T o[RPL];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+      const T xk = xv[i];
+      const T s = sb[i];
+      const bool row0 = i == 0 && gl == 0;
+      const T a = row0 ? xk * c2 + e : (xk + e) * c2;                 // :53 / :58
+      const T dn = row0 ? T(1) : E - s;
+      o[i] = F::log2(a * F::rcp(dn - a)) * Num<T>::log2 + lktab[gl * RPL + i];   // logit(z) + log(K-k)
+      if (LADJ && (i < RPL - 1 || gl < 3)) {
+        const T m = d_max(T(1) - s, e);                                // :133
+        const T zl = row0 ? xk : xk * F::rcp(m);
+        lp += F::log2(d_max(zl, e) * d_max(T(1) - zl, e) * (row0 ? T(1) : m));   // :130-131, :135
+      }
+    }
+    if (LADJ) {
+      const T l = -group_sum_rt(lp, 4) * Num<T>::log2;
+      if (col < batch && gl == 0) {
+        if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + l : l;
+        acc += (double)l;
+      }
+    }
+    if (y) {
+      constexpr int RO = K - 1;
+      if (colw + CPS <= batch) {
+        __builtin_amdgcn_wave_barrier();                               // the previous instruction's strip reads are done
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) { const int r = gl * RPL + i; if (r < RO) st[cg * RO + r] = o[i]; }
+        __builtin_amdgcn_wave_barrier();
+        constexpr int NPK = CPS * RO / V;                              // packs in the contiguous output run
+#pragma unroll
+        for (int k = 0; k < (NPK + 63) / 64; ++k) {
+          const int pk = lane + 64 * k;
+          if (pk < NPK) {
+            Pack<T, V> q;
+            if (V > 1) *reinterpret_cast<typename Vec16<T>::type*>(&q) = reinterpret_cast<const typename Vec16<T>::type*>(st)[pk];
+            else q.v[0] = st[pk];
+            store_pack<T, V, true>(y + colw * RO + (int64_t)pk * V, q);
+          }
+        }
+      } else if (col < batch) {
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) { const int r = gl * RPL + i; if (r < RO) y[col * RO + r] = o[i]; }
+      }
+    }
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
 template <class T>
 int simplex_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags) {
   const bool want = ladj_ps || ladj_sum;
   const int nlk = (int)(K - 1);
+  constexpr int VWs = Vec16<T>::N;
+  static const int use_stream = getenv("BJX_SIMPLEX_STREAM") ? atoi(getenv("BJX_SIMPLEX_STREAM")) : 1;
+  const int64_t np = K / (4 * VWs);                         // packs per lane with 4 lanes per column
+  if (!inverse && use_stream && batch > 0 && K % (4 * VWs) == 0 && np >= 1 && np <= 4 && bjx_aligned16(in) && (!out || bjx_aligned16(out))) {
+    static const int uc = getenv("BJX_SIMPLEX_UC") ? atoi(getenv("BJX_SIMPLEX_UC")) : 1;
+    const int64_t cpb = 4 * 16 * (uc == 2 ? 2 : 1);         // columns per block: 4 waves x 16 columns x UC in flight
+    const int64_t grid = (batch + cpb - 1) / cpb;
+    BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+    if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
+    double* partials = ladj_sum ? ctx->partials : nullptr;
+    const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+#define SFS1(NP_, L_, UC_) hipLaunchKernelGGL((simplex_fwd_stream_kernel<T, VWs, NP_, L_, UC_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out, ladj_ps, batch, accum, partials)
+#define SFS(NP_, L_) do { if (uc == 2) SFS1(NP_, L_, 2); else SFS1(NP_, L_, 1); } while (0)
+#define SFS_L(NP_) do { if (want) SFS(NP_, true); else SFS(NP_, false); } while (0)
+    {
+      BjxProf prof_(ctx);
+      if (np == 1) SFS_L(1); else if (np == 2) SFS_L(2); else if (np == 3) SFS_L(3); else SFS_L(4);
+    }
+#undef SFS_L
+#undef SFS
+#undef SFS1
+    BJX_CHECK_LAUNCH(ctx);
+    if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+    return BJX_OK;
+  }
   if (!inverse) {
     if (want) { SimplexFwd<T, true> op; op.K = K; return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K, K - 1, batch, nlk, flags); }
     SimplexFwd<T, false> op; op.K = K;

@@ -202,7 +202,8 @@ def test_ordered(bj, orc, shape, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("K,N", [(2, 9), (3, 100), (5, 257), (64, 1000), (100, 64), (64, 1)])
+@pytest.mark.parametrize("K,N", [(2, 9), (3, 100), (5, 257), (64, 1000), (100, 64), (64, 1),
+                                 (8, 50), (16, 333), (24, 19), (32, 77), (48, 130), (64, 4099)])   # K = 16·NP / 8·NP: streaming kernel, ragged runs
 def test_simplex(bj, orc, K, N, dt):
     r = rng(4)
     X = np.asfortranarray(r.dirichlet(np.ones(K), size=N).T.astype(dt))
@@ -215,6 +216,7 @@ def test_simplex(bj, orc, K, N, dt):
     _, lps = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
     close(host(lps), l_ref, dt, scale=K * 10, what="simplex per-sample ladj")
     sum_close(host(bj.logabsdetjac(b, dev(X))), np.sum(l_ref.astype(np.float64)), dt, N * K * 10)
+    close(host(bj.transform(b, dev(X))), Y_ref, dt, scale=10, what="simplex transform only")
     # inverse on unconstrained inputs
     Yin = np.asfortranarray(r.normal(size=(K - 1, N)).astype(dt) * 1.5)
     Xb_ref, lb_ref = orc.simplex(Yin, inverse=True)
