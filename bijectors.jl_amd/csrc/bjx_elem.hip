@@ -476,21 +476,70 @@ template <class T, bool INV> struct CouplingAffineF {
   static constexpr bool kLoadInput = true;
   const int32_t* map;
   const T *scale, *shift;   // [n1, batch] or null
-  int64_t n1;
+  int64_t n1, dim;
+  int map_in_lds;           // the row map is staged in LDS (dim <= 12 Ki rows), else read from the context scratch
   double per_sample_const;
   const double* per_sample_dev;
-  __device__ void stage(char*) const {}
-  template <int V> __device__ T apply(const char*, Pack<T, V>& p, const T*, int64_t row, int64_t col) const {
-    T l = T(0);
+  // θ of one pack: fetched with the input packs (all of a lane's loads in flight together).  When the pack's
+  // rows sit at consecutive, 16-byte aligned positions of x_1 (PartitionMask over a row range — the usual
+  // mask) scale and shift are one 16-byte load each; otherwise V scalar gathers.
+  template <int V> struct AuxV { Pack<T, V> s, t; int32_t m0; uint32_t on; };
+  using Aux = AuxV<Vec16<T>::N>;
+  __device__ void stage(char* smem) const {
+    if (!map_in_lds) return;
+    int32_t* m = reinterpret_cast<int32_t*>(smem);
+    for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) m[i] = map[i];
+    __syncthreads();
+  }
+  template <int V> __device__ Aux fetch(const char* smem, int64_t row, int64_t col) const {
+    if (map_in_lds) return fetch_from<V>(reinterpret_cast<const int32_t*>(smem), row, col);   // two calls: each keeps its address space
+    return fetch_from<V>(map, row, col);
+  }
+  template <int V> __device__ __forceinline__ Aux fetch_from(const int32_t* m, int64_t row, int64_t col) const {
+    static_assert(V <= Vec16<T>::N, "pack wider than Aux");
+    Aux a;
+    a.on = 0;
+    a.m0 = m[row];
+    bool run = a.m0 >= 0 && V > 1 && (a.m0 % V) == 0 && (n1 % V) == 0 && bjx_aligned16_dev(scale) && bjx_aligned16_dev(shift);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      int32_t mi = map[row + j];
-      if (mi >= 0) {
-        T s = scale ? scale[col * n1 + mi] : T(1);
-        T t = shift ? shift[col * n1 + mi] : T(0);
-        if (!INV) { p.v[j] = t + s * p.v[j]; l += d_log(d_abs(s)); }            // Shift(t) ∘ Scale(s)
-        else { p.v[j] = (T(1) / s) * (-t + p.v[j]); l -= d_log(d_abs(s)); }     // inverse(Scale) ∘ inverse(Shift)
+      const int32_t mi = m[row + j];
+      if (mi >= 0) a.on |= 1u << j;
+      run = run && mi == a.m0 + j;
+      a.s.v[j] = T(1);
+      a.t.v[j] = T(0);
+    }
+    if (run) {
+      Pack<T, V> s1, t1;
+      if (scale) s1 = load_pack<T, V, true>(scale + col * n1 + a.m0);
+      if (shift) t1 = load_pack<T, V, true>(shift + col * n1 + a.m0);
+#pragma unroll
+      for (int j = 0; j < V; ++j) { if (scale) a.s.v[j] = s1.v[j]; if (shift) a.t.v[j] = t1.v[j]; }
+    } else if (a.on) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const int32_t mi = m[row + j];
+        if (mi >= 0) {
+          if (scale) a.s.v[j] = scale[col * n1 + mi];
+          if (shift) a.t.v[j] = shift[col * n1 + mi];
+        }
       }
+    }
+    return a;
+  }
+  template <int V> __device__ T apply(const char*, Pack<T, V>& p, const Aux& a, const T*, int64_t, int64_t) const {
+    using F = Fast<T>;
+    T l = T(0);
+    if (a.on) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const bool on = (a.on >> j) & 1u;
+        const T s = a.s.v[j], t = a.t.v[j];
+        // Shift(t) ∘ Scale(s) (coupling.jl:206-219); inverse(Scale) ∘ inverse(Shift) (:236-250)
+        const T v = !INV ? t + s * p.v[j] : F::rcp(s) * (-t + p.v[j]);
+        if (on) { p.v[j] = v; l += F::log2(d_abs(s)); }
+      }
+      l *= INV ? -Num<T>::log2 : Num<T>::log2;
     }
     return l;
   }
@@ -875,9 +924,11 @@ int coupling_affine_impl(bjx_ctx* ctx, int inverse, const int32_t* idx1, int64_t
   int32_t* map = nullptr;
   int rc = build_rowmap(ctx, idx1, n1, dim, &map);
   if (rc) return rc;
-  if (!inverse) { CouplingAffineF<T, false> f{map, scale, shift, n1, 0.0, nullptr}; return launch_colgroup<T>(ctx, f, 0, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0); }
-  CouplingAffineF<T, true> f{map, scale, shift, n1, 0.0, nullptr};
-  return launch_colgroup<T>(ctx, f, 0, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0);
+  const int in_lds = dim <= 12 * 1024 ? 1 : 0;
+  const size_t fsm = in_lds ? (size_t)dim * sizeof(int32_t) + 16 : 0;      // row map in LDS
+  if (!inverse) { CouplingAffineF<T, false> f{map, scale, shift, n1, dim, in_lds, 0.0, nullptr}; return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0); }
+  CouplingAffineF<T, true> f{map, scale, shift, n1, dim, in_lds, 0.0, nullptr};
+  return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0);
 }
 template <class T>
 int coupling_rqs_impl(bjx_ctx* ctx, int inverse, const int32_t* idx1, int64_t n1, const T* w, const T* h, const T* d, int K1,

@@ -20,6 +20,15 @@ constexpr int STREAM_U = 4;
 //   static constexpr bool kLoadInput   (false: apply() gathers from xcol itself, e.g. Permute)
 //   double per_sample_const            (host-known constant added to every ladj_ps entry)
 //   const double* per_sample_dev       (device constant added likewise, or null)
+//   optional: `using Aux = ...; template <int V> Aux fetch(const char* smem, int64_t row, int64_t col) const;`
+//       per-pack operands the functor reads from HBM (Coupling's θ arrays): fetched together with the
+//       input packs so all loads of a lane are in flight at once; apply() then takes `const Aux&` after `p`
+template <class F, class = void> struct col_has_aux { static constexpr bool value = false; };
+template <class F> struct col_has_aux<F, decltype((void)sizeof(typename F::Aux))> { static constexpr bool value = true; };
+struct ColNoAux {};
+template <class F, bool H = col_has_aux<F>::value> struct col_aux_of { using type = ColNoAux; };
+template <class F> struct col_aux_of<F, true> { using type = typename F::Aux; };
+
 constexpr int COL_UC = 4;   // columns in flight per lane group (one 16-byte pack each) when a column fits in G packs
 
 template <class T, int V, bool NT, class F>
@@ -39,18 +48,21 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
   const double psc = f.per_sample_const + (f.per_sample_dev ? *f.per_sample_dev : 0.0);
   if (nvc <= G) {
     Pack<T, V> p[COL_UC];
+    typename col_aux_of<F>::type aux[COL_UC];
     const bool lane_ok = gl < nvc;
 #pragma unroll
     for (int u = 0; u < COL_UC; ++u) {
       const int64_t col = col0 + (int64_t)u * cols_per_block;
       if (F::kLoadInput && lane_ok && col < batch) p[u] = load_pack<T, V, NT>(x + col * dim + (int64_t)gl * V);
+      if constexpr (col_has_aux<F>::value) { if (lane_ok && col < batch) aux[u] = f.template fetch<V>(fsm, (int64_t)gl * V, col); }
     }
 #pragma unroll
     for (int u = 0; u < COL_UC; ++u) {
       const int64_t col = col0 + (int64_t)u * cols_per_block;
       T l = T(0);
       if (lane_ok && col < batch) {
-        l = f.template apply<V>(fsm, p[u], x + col * dim, (int64_t)gl * V, col);
+        if constexpr (col_has_aux<F>::value) l = f.template apply<V>(fsm, p[u], aux[u], x + col * dim, (int64_t)gl * V, col);
+        else l = f.template apply<V>(fsm, p[u], x + col * dim, (int64_t)gl * V, col);
         store_pack<T, V, NT>(y + col * dim + (int64_t)gl * V, p[u]);
       }
       l = group_sum_rt(l, G);
@@ -72,16 +84,19 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
         T* yc = y + col * dim;
         for (int64_t v0 = 0; v0 < nvc; v0 += (int64_t)G * STREAM_U) {
           Pack<T, V> p[STREAM_U];
+          typename col_aux_of<F>::type aux[STREAM_U];
 #pragma unroll
           for (int u = 0; u < STREAM_U; ++u) {
             int64_t v = v0 + (int64_t)u * G + gl;
             if (F::kLoadInput && v < nvc) p[u] = load_pack<T, V, NT>(xc + v * V);
+            if constexpr (col_has_aux<F>::value) { if (v < nvc) aux[u] = f.template fetch<V>(fsm, v * V, col); }
           }
 #pragma unroll
           for (int u = 0; u < STREAM_U; ++u) {
             int64_t v = v0 + (int64_t)u * G + gl;
             if (v < nvc) {
-              l += f.template apply<V>(fsm, p[u], xc, v * V, col);
+              if constexpr (col_has_aux<F>::value) l += f.template apply<V>(fsm, p[u], aux[u], xc, v * V, col);
+              else l += f.template apply<V>(fsm, p[u], xc, v * V, col);
               store_pack<T, V, NT>(yc + v * V, p[u]);
             }
           }
