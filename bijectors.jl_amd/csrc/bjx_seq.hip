@@ -737,8 +737,9 @@ __global__ __launch_bounds__(64 * CHOL_WPB) void chol_fwd_chunk_kernel(const T* 
     unsigned wmask = 0;
     T pre = T(0);
     bool seen_wrap = false;
+    int d = c0 - i00;                                                  // entries left in my current column, this one included
     {
-      int d = c0 - i00, len = c0;
+      int len = c0;
       int addr = LOWER ? i00 * K + c0 : c0 * K + i00;
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
@@ -759,8 +760,14 @@ __global__ __launch_bounds__(64 * CHOL_WPB) void chol_fwd_chunk_kernel(const T* 
       }
     }
     const T carry_sfx = seg_suffix_excl<T>(pre, seen_wrap, T(0));
-    // ---- descending pass: suffix of w² inside the column, y
+    // ---- descending pass: suffix of w² inside the column, y, and the log-det.
+    //      -_logabsdetjac_inv_chol(y) (corr.jl:239-250) adds, per column, the running sums of logcosh(y) once per
+    //      entry and once more at the column end: entry k of a column enters (entries from k to the column end) + 1
+    //      times.  With z = w / sqrt(rem):  logcosh(asinh z) = log sqrt(1 + z²) = log(sqrt(w² + rem) · rsqrt(rem)),
+    //      both factors already at hand — one v_log per entry instead of exp + log, and no scan.
+    T lsum = T(0);
     {
+      int dd = d;
       T sfx = carry_sfx;
 #pragma unroll
       for (int k = CH - 1; k >= 0; --k) {
@@ -771,9 +778,15 @@ __global__ __launch_bounds__(64 * CHOL_WPB) void chol_fwd_chunk_kernel(const T* 
         sfx = wrap ? aux[k] * aux[k] : sfx;                            // remainder_sq starts at W[j,j]² (:318)
         const T rem = head ? T(1) - w2 : sfx;                          // first row: atanh(w) (:322)
         const T rs = F::rsqrt(rem);
-        const T q = (d_abs(w) + F::sqrt(w2 + rem)) * rs;
+        const T sq = F::sqrt(w2 + rem);
+        const T q = (d_abs(w) + sq) * rs;
         wv[k] = d_copysign(F::log(q), w);                      // asinh(w / sqrt(remainder_sq)) (:327-329)
         sfx += w2;
+        if (LADJ) {
+          dd = wrap ? 1 : dd + 1;
+          const T lc = F::log2(sq * rs) * T(dd + 1);
+          lsum += (e0 + k < nv) ? lc : T(0);
+        }
       }
     }
     // ---- store y: my chunk goes to LDS (pitch CH + V: conflict-free 16-byte accesses; the W tile is dead
@@ -808,37 +821,7 @@ __global__ __launch_bounds__(64 * CHOL_WPB) void chol_fwd_chunk_kernel(const T* 
       }
     }
     if (LADJ) {
-      // ---- log-det = -_logabsdetjac_inv_chol(y): Σ_entries incl + Σ_columns incl(last)
-      T tail = T(0);
-      bool has_head = (i00 == 0);
-      {
-        bool prev_wrap = false;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-          const T ay = d_abs(wv[k]);
-          const T t = F::exp(T(-2) * ay);
-          const T lcv = F::log2(T(1) + t) * Num<T>::log2 + (ay - Num<T>::log2);
-          aux[k] = (e0 + k < nv) ? lcv : T(0);
-          tail = (prev_wrap ? T(0) : tail) + aux[k];
-          has_head |= prev_wrap;
-          prev_wrap = (wmask >> (CH - 1 - k)) & 1u;
-        }
-      }
-      const T incl = seg_prefix_incl<T>(tail, has_head, T(0));
-      const T up = __shfl_up(incl, 1, 64);
-      T run = (i00 == 0 || lane == 0) ? T(0) : up;
-      T lj = T(0);
-      {
-        bool prev_wrap = false;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-          const bool wrap = (wmask >> (CH - 1 - k)) & 1u;
-          run = (prev_wrap ? T(0) : run) + aux[k];
-          lj += run;
-          lj += wrap ? run : T(0);
-          prev_wrap = wrap;
-        }
-      }
+      T lj = lsum * Num<T>::log2;
       lj = group_sum<64>(lj);
       if (lane == 0) {
         if (ladj_ps) ladj_ps[s] = accumulate ? ladj_ps[s] + lj : lj;
