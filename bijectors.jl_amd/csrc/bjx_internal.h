@@ -207,8 +207,12 @@ template <> struct Fast<double> {
 
 // LogExpFunctions.logistic / log1pexp on the fast units (same saturation / branch thresholds as above)
 template <class T> __device__ __forceinline__ T f_logistic(T x) {
+  // the quotient is computed before the selects: a nested ?: with the rcp in its last arm compiles to two
+  // branches per element (vjp(inverse(Simplex)): 1.53 -> 1.31 ms without them)
   const T e = Fast<T>::exp(x);
-  return x < Num<T>::logistic_lo ? T(0) : (x > Num<T>::logistic_hi ? T(1) : e * Fast<T>::rcp(T(1) + e));
+  const T q = e * Fast<T>::rcp(T(1) + e);
+  const T hi = x > Num<T>::logistic_hi ? T(1) : q;
+  return x < Num<T>::logistic_lo ? T(0) : hi;
 }
 template <class T> __device__ __forceinline__ T f_log1pexp(T x) {
   const T e = Fast<T>::exp(x < Num<T>::l1pe1 ? x : -x);

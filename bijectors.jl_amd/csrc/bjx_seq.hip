@@ -94,9 +94,7 @@ template <class T, bool LADJ> struct SimplexInv {
   T sum_tmp, lp;
   __device__ void init() { sum_tmp = T(0); lp = T(0); }
   static __device__ __forceinline__ T logistic(T v) {   // LogExpFunctions.logistic with its exact 0/1 saturation
-    using F = Fast<T>;
-    const T ex = F::exp(v);
-    return v < Num<T>::logistic_lo ? T(0) : (v > Num<T>::logistic_hi ? T(1) : ex * F::rcp(T(1) + ex));
+    return f_logistic(v);
   }
   __device__ T first(T y, const T* logk) {
     using F = Fast<T>;
@@ -1437,8 +1435,7 @@ __global__ __launch_bounds__(64) void simplex_vjp_kernel(const T* __restrict__ i
       T s = T(0);
       auto logistic_at = [&](int k) -> T {
         const T yk = a[k] - logk[k];
-        const T ex = F::exp(yk);
-        return yk < Num<T>::logistic_lo ? T(0) : (yk > Num<T>::logistic_hi ? T(1) : ex * F::rcp(T(1) + ex));
+        return f_logistic(yk);
       };
       { const T xk = d_clamp((logistic_at(0) - e) * c, T(0), T(1)); a[0] = xk; s = xk; }
       int kf = 1;
@@ -1598,84 +1595,224 @@ BJX_API int bjx_ordered_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void*
 }
 
 namespace {
-}  // namespace
-
-BJX_API int bjx_ordered(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out, void* ladj_ps, double* ladj_sum,
-                        int64_t dim, int64_t batch, uint32_t flags) {
-  if (!ctx) return BJX_ERR_ARG;
-  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_ordered: input must not be empty (ordered.jl:26)");
-  BJX_REQUIRE(ctx, (in && out) || batch == 0, BJX_ERR_ARG, "bjx_ordered: null pointer");
-  if (dt == BJX_F32) {
-    if (!inverse) return launch_seq<float>(ctx, OrderedFwd<float>{}, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, dim, batch, 0, flags);
-    return launch_seq<float>(ctx, OrderedInv<float>{}, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, dim, batch, 0, flags);
-  }
-  if (dt == BJX_F64) {
-    if (!inverse) return launch_seq<double>(ctx, OrderedFwd<double>{}, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, dim, batch, 0, flags);
-    return launch_seq<double>(ctx, OrderedInv<double>{}, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, dim, batch, 0, flags);
-  }
-  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_ordered: bad dtype %d", (int)dt);
+// ------------------------------------------------------------------ Ordered / Simplex, streaming kernels (no whole-column tile)
+// ordered.jl:36-80, simplex.jl:47-138 for columns of R = G·NP·V rows (R <= 64 Float32 / 32 Float64).  These maps
+// couple the rows of a column only through ONE running value (Σ_{j<k} x_j, the previous y), so a column does not
+// need a walker lane with the whole column in LDS (seq_wave_kernel: 16.6 KiB per wave, ~2 waves per SIMD, and
+// ~37 VALU per element of staging/addressing):
+//   * a wave instruction owns 64/G columns = ONE contiguous run of input and of output: coalesced 16-byte
+//     loads -> a padded LDS strip -> G lanes per column, each a contiguous 1/G of it in registers (loading the
+//     lane pieces directly as scattered 16-byte accesses ran at 50 %: TCP pending-stall 80 %);
+//   * the running value is still accumulated IN THE REFERENCE'S ORDER, one row after the other: the G lanes of
+//     a column take turns — G rounds, every lane re-runs its chain from the carry it holds and then takes its
+//     left neighbour's final value (quad_perm DPP); lane t's carry is final after round t-1, so no selects.
+//     (A parallel prefix scan moved 1 Simplex element in 63 000 by 2 % where 1 - Σ is small: rejected.)
+//   * outputs are re-dealt through the same strip into whole coalesced 16-byte packs (rows_out = R-1 columns
+//     of a wave instruction still form one aligned contiguous run).
+// G = 4 for maps whose chain is one add per row (4 redundant adds per element), G = 2 for the Simplex inverse
+// whose chain is the 5-op recurrence x_k = clamp(((1+ε) - Σ)·z_k/(1-2ε) - ε), Σ += x_k.
+template <int G> __device__ __forceinline__ float quad_from_left(float v) {
+  // value of the lane to the left inside the G-lane group (undefined for the group's first lane)
+  if constexpr (G == 4) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x90, 0xF, 0xF, true));   // quad_perm [0,0,1,2]
+  else return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xA0, 0xF, 0xF, true));                   // quad_perm [0,0,2,2]
+}
+template <int G> __device__ __forceinline__ double quad_from_left(double v) {
+  const int lane = threadIdx.x & 63;
+  return __shfl(v, lane > 0 ? lane - 1 : 0, 64);
 }
 
-namespace {
-// ------------------------------------------------------------------ SimplexBijector forward, streaming kernel
-// simplex.jl:47-64 + :122-138 without a whole-column LDS tile, for K = 16·NP <= 64 (NP packs per lane):
-// the forward map couples the rows only through s_k = Σ_{j<k} x_j, so FOUR lanes own a column, each a
-// contiguous quarter of it (NP 16-byte packs; a wave instruction covers 16 columns).  s_k is accumulated in the
-// reference's order — x_1 + x_2 + … one add after the other: the quad's lanes take turns (4 rounds of 4·NP adds,
-// the carry handed on with a quad_perm DPP broadcast), because the sum's rounding decides late rows where
-// 1 - s_k is small (a re-associated prefix scan moved 1 element in 63 000 by 2 %).  Everything else is
-// elementwise.  The K-1 = odd-length output columns of one wave instruction form ONE contiguous, 16-byte aligned
-// run (16 columns), which is re-dealt through a 4 KiB LDS strip so the stores are whole coalesced 16-byte packs.
-// (The whole-column tile kernel — 16.6 KiB of LDS per wave, 9 waves per CU — reached 52 % of the HBM roofline
-// at C5a and still serves every other K.)
-template <class T, int V, int NP, bool LADJ, int UC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UC == 1 && sizeof(T) == 4) ? 6 : 4, 8))) void simplex_fwd_stream_kernel(const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t batch,
-                                                                int accumulate, double* partials) {
-  using F = Fast<T>;
+template <class T, bool LADJ> struct QSimplexFwd {      // simplex.jl:47-64 + :122-138
+  static constexpr int G = 4, IN_LESS = 0, OUT_LESS = 1;
+  static constexpr bool USES_LOGK = true, HAS_LADJ = LADJ;
+  template <int RPL> __device__ __forceinline__ T run(T (&x)[RPL], int gl, const T* lk) const {
+    using F = Fast<T>;
+    const T e = Num<T>::eps, c2 = T(1) - 2 * e, E = T(1) + e;
+    T carry = T(0);
+#pragma unroll
+    for (int t = 0; t < G - 1; ++t) {                                  // rounds 0..G-2: only the running sum
+      T run = carry;
+#pragma unroll
+      for (int i = 0; i < RPL; ++i) run += x[i];
+      const T bc = quad_from_left<G>(run);
+      carry = gl == 0 ? T(0) : bc;
+    }
+    T lp = T(0), s = carry;                                            // final round: s = Σ_{j<k} x_j in the reference's order
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+      const T xk = x[i];
+      const bool row0 = i == 0 && gl == 0;
+      const T a = row0 ? xk * c2 + e : (xk + e) * c2;                 // :53 / :58
+      const T dn = row0 ? T(1) : E - s;
+      x[i] = F::log2(a * F::rcp(dn - a)) * Num<T>::log2 + lk[gl * RPL + i];   // logit(z) + log(K-k)
+      if (LADJ) {
+        const T m = d_max(T(1) - s, e);                                // :133
+        const T zl = row0 ? xk : xk * F::rcp(m);
+        const T term = F::log2(d_max(zl, e) * d_max(T(1) - zl, e) * (row0 ? T(1) : m));   // :130-131, :135
+        lp += (i < RPL - 1 || gl < G - 1) ? term : T(0);               // row K has no term
+      }
+      s += xk;
+    }
+    return -lp * Num<T>::log2;
+  }
+};
+
+template <class T, bool LADJ> struct QSimplexInv {      // simplex.jl:102-120 ; log-det = -logabsdetjac(b, x_out)
+  static constexpr int G = 2, IN_LESS = 1, OUT_LESS = 0;
+  static constexpr bool USES_LOGK = true, HAS_LADJ = LADJ;
+  template <int RPL> __device__ __forceinline__ T run(T (&x)[RPL], int gl, const T* lk) const {
+    using F = Fast<T>;
+    const T e = Num<T>::eps, E = T(1) + e;
+    const T inv12e = T(1) / (T(1) - 2 * e);
+    // z_k = logistic(y_k - log(K-k)) with LogExpFunctions' exact 0/1 saturation
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+      const T v = x[i] - lk[gl * RPL + i];
+      x[i] = f_logistic(v);
+    }
+    T carry = T(0);
+#pragma unroll
+    for (int t = 0; t < G - 1; ++t) {                                  // rounds 0..G-2: only the recurrence Σ -> x_k -> Σ
+      T s = carry;
+#pragma unroll
+      for (int i = 0; i < RPL; ++i) {
+        const bool row0 = i == 0 && gl == 0;
+        const T xi = row0 ? d_clamp((x[i] - e) * inv12e, T(0), T(1)) : d_clamp((E - s) * inv12e * x[i] - e, T(0), T(1));
+        s += xi;
+      }
+      const T bc = quad_from_left<G>(s);
+      carry = gl == 0 ? T(0) : bc;
+    }
+    T lp = T(0), s = carry;
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+      const bool row0 = i == 0 && gl == 0;
+      const bool rowK = i == RPL - 1 && gl == G - 1;
+      const T xi = row0 ? d_clamp((x[i] - e) * inv12e, T(0), T(1))               // :109
+                        : d_clamp((E - s) * inv12e * x[i] - e, T(0), T(1));     // :113
+      if (LADJ) {
+        const T m = d_max(T(1) - s, e);
+        const T zl = row0 ? xi : xi * F::rcp(m);
+        const T term = F::log2(d_max(zl, e) * d_max(T(1) - zl, e) * (row0 ? T(1) : m));
+        lp += rowK ? T(0) : term;
+      }
+      x[i] = rowK ? d_clamp(T(1) - s, T(0), T(1)) : xi;                          // :116
+      s += xi;
+    }
+    return lp * Num<T>::log2;
+  }
+};
+
+template <class T> struct QOrderedFwd {                  // ordered.jl:36-49, :80
+  static constexpr int G = 4, IN_LESS = 0, OUT_LESS = 0;
+  static constexpr bool USES_LOGK = false, HAS_LADJ = true;
+  template <int RPL> __device__ __forceinline__ T run(T (&x)[RPL], int gl, const T*) const {
+    using F = Fast<T>;
+    T l = T(0);
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+      const bool row0 = i == 0 && gl == 0;
+      l += row0 ? T(0) : x[i];                                         // logabsdetjac = Σ_{k>=2} x_k
+      x[i] = row0 ? x[i] : F::exp(x[i]);                               // y_1 = x_1 ; y_k = y_{k-1} + exp(x_k)
+    }
+    T carry = T(0);                                                    // 0 + x_1 is exact: the chain starts like y_1 = x_1
+#pragma unroll
+    for (int r = 0; r < G - 1; ++r) {
+      T run = carry;
+#pragma unroll
+      for (int i = 0; i < RPL; ++i) run += x[i];
+      const T bc = quad_from_left<G>(run);
+      carry = gl == 0 ? T(0) : bc;
+    }
+    T run = carry;
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) { run += x[i]; x[i] = run; }
+    return l;
+  }
+};
+
+template <class T> struct QOrderedInv {                  // ordered.jl:63-77 ; interface.jl:276-281
+  static constexpr int G = 4, IN_LESS = 0, OUT_LESS = 0;
+  static constexpr bool USES_LOGK = false, HAS_LADJ = true;
+  template <int RPL> __device__ __forceinline__ T run(T (&x)[RPL], int gl, const T*) const {
+    using F = Fast<T>;
+    const T left = quad_from_left<G>(x[RPL - 1]);                      // y of the row before my first one
+    T l = T(0), prev = left;
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+      const bool row0 = i == 0 && gl == 0;
+      const T y = x[i];
+      const T o = row0 ? y : F::log(y - prev);                         // x_1 = y_1 ; x_k = log(y_k - y_{k-1})
+      l -= row0 ? T(0) : o;
+      prev = y;
+      x[i] = o;
+    }
+    return l;
+  }
+};
+
+template <class T, int V, int NP, class Op, int UC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void quad_stream_kernel(const Op op, const T* __restrict__ x, T* __restrict__ y,
+                                                                                                      T* __restrict__ ladj_ps, int64_t batch,
+                                                                                                      int accumulate, double* partials) {
+  constexpr int G = Op::G;
   constexpr int RPL = NP * V;                        // rows per lane
-  constexpr int K = 4 * RPL;
-  constexpr int CPS = 16;                            // columns per wave instruction (4 lanes each)
-  constexpr int PITCH = K + V;                       // LDS pitch of an input column: one pack of padding keeps the 16-byte reads conflict-free
-  constexpr int PPC = 4 * NP;                        // packs per input column
+  constexpr int R = G * RPL;                         // rows of the column frame
+  constexpr int RI = R - Op::IN_LESS, RO = R - Op::OUT_LESS;
+  constexpr int CPS = 64 / G;                        // columns per wave instruction
+  constexpr int PITCH = R + V;                       // LDS pitch of a frame column: one pack of padding keeps the 16-byte accesses conflict-free
+  constexpr int PPC = G * NP;                        // packs per frame column
+  static_assert((CPS * RI) % V == 0 && (CPS * RO) % V == 0, "a wave instruction's run is whole packs");
+  constexpr int NPI = CPS * RI / V, NPO = CPS * RO / V;          // packs of the input / output run
+  constexpr int NLI = (NPI + 63) / 64, NLO = (NPO + 63) / 64;    // pack loads / stores per lane
   __shared__ __attribute__((aligned(16))) T strip[4][CPS * PITCH];
+  __shared__ __attribute__((aligned(16))) T lktab[Op::USES_LOGK ? R : V];
   __shared__ double red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gl = lane & 3, cg = lane >> 2;
-  const T e = Num<T>::eps, c2 = T(1) - 2 * e, E = T(1) + e;
+  const int gl = lane & (G - 1), cg = lane / G;
   const int64_t colb = ((int64_t)blockIdx.x * 4 + wave) * (CPS * UC);
-  // coalesced loads: the 16 columns of a wave instruction are one contiguous run of 64·NP packs
-  Pack<T, V> raw[UC][NP];
+  // coalesced loads: the columns of a wave instruction are one contiguous run
+  Pack<T, V> raw[UC][NLI];
 #pragma unroll
   for (int u = 0; u < UC; ++u) {
     const int64_t colw = colb + u * CPS;
-    const int64_t npk = colw < batch ? (batch - colw < (int64_t)CPS ? batch - colw : (int64_t)CPS) * PPC : 0;   // packs of this run inside the batch
+    const int64_t left = batch - colw;
+    const int64_t ne = left >= CPS ? (int64_t)CPS * RI : (left > 0 ? left * RI : 0);   // elements of this run inside the batch
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
+    for (int q = 0; q < NLI; ++q) {
       const int pk = lane + 64 * q;
-      if (pk < npk) raw[u][q] = load_pack<T, V, true>(x + colw * K + (int64_t)pk * V);
+      const T* src = x + colw * RI + (int64_t)pk * V;
+      if ((int64_t)(pk + 1) * V <= ne) raw[u][q] = load_pack<T, V, true>(src);
       else {
 #pragma unroll
-        for (int j = 0; j < V; ++j) raw[u][q].v[j] = T(0);
+        for (int j = 0; j < V; ++j) raw[u][q].v[j] = (int64_t)pk * V + j < ne ? src[j] : T(0);
       }
     }
   }
-  // log(K-k) per row: one precise log per thread of the block, then everybody reads its RPL rows
-  __shared__ __attribute__((aligned(16))) T lktab[K];
-  if ((int)threadIdx.x < K) lktab[threadIdx.x] = (int)threadIdx.x < K - 1 ? d_log(T(K - 1 - (int)threadIdx.x)) : T(0);
-  __syncthreads();
+  if (Op::USES_LOGK) {
+    // log(K-k) per row (simplex.jl:35,41): one precise log per thread of the block
+    if ((int)threadIdx.x < R) lktab[threadIdx.x] = (int)threadIdx.x < R - 1 ? d_log(T(R - 1 - (int)threadIdx.x)) : T(0);
+    __syncthreads();
+  }
   double acc = 0.0;
   T* st = strip[wave];
 #pragma unroll
   for (int u = 0; u < UC; ++u) {
     const int64_t colw = colb + u * CPS;
     const int64_t col = colw + cg;
-    // re-deal: pack p of the run belongs to column p / PPC; lane (cg, gl) takes packs gl·NP .. gl·NP+NP-1 of column cg
+    // ---- re-deal the run: lane (cg, gl) takes rows gl·RPL .. gl·RPL+RPL-1 of column cg
     T xv[RPL];
     __builtin_amdgcn_wave_barrier();                                   // the previous instruction's strip reads are done
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
+    for (int q = 0; q < NLI; ++q) {
       const int pk = lane + 64 * q;
-      *reinterpret_cast<typename Vec16<T>::type*>(st + (pk / PPC) * PITCH + (pk % PPC) * V) = __builtin_bit_cast(typename Vec16<T>::type, raw[u][q]);
+      if (NPI % 64 == 0 || pk < NPI) {
+        if constexpr (Op::IN_LESS == 0) {
+          *reinterpret_cast<typename Vec16<T>::type*>(st + (pk / PPC) * PITCH + (pk % PPC) * V) = __builtin_bit_cast(typename Vec16<T>::type, raw[u][q]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) { const int el = pk * V + j; st[(el / RI) * PITCH + el % RI] = raw[u][q].v[j]; }
+        }
+      }
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1684,105 +1821,113 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UC == 1 &&
 #pragma unroll
       for (int j = 0; j < V; ++j) xv[q * V + j] = pq.v[j];
     }
-    // s before each of my rows, accumulated in the reference's order.  The quad's lanes take turns without any
-    // select: every round each lane re-runs its chain from the carry it holds, and then takes its left
-    // neighbour's total as the new carry; lane t's carry is final after round t-1 and never changes again, so
-    // after 4 rounds every chain is the sequential one.
-    T sb[RPL];
-    T carry = T(0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      T run = carry;
-#pragma unroll
-      for (int i = 0; i < RPL; ++i) { sb[i] = run; run += xv[i]; }
-      if (t < 3) {
-        T bc;
-        if constexpr (sizeof(T) == 4) {
-          bc = __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, run), 0x90, 0xF, 0xF, true));   // quad_perm [0,0,1,2]
-        } else {
-          bc = __shfl(run, lane > 0 ? lane - 1 : 0, 64);
-        }
-        carry = gl == 0 ? T(0) : bc;
-      }
-    }
-    T lp = T(0);
-    T o[RPL];
-#pragma unroll
-    for (int i = 0; i < RPL; ++i) {
-      const T xk = xv[i];
-      const T s = sb[i];
-      const bool row0 = i == 0 && gl == 0;
-      const T a = row0 ? xk * c2 + e : (xk + e) * c2;                 // :53 / :58
-      const T dn = row0 ? T(1) : E - s;
-      o[i] = F::log2(a * F::rcp(dn - a)) * Num<T>::log2 + lktab[gl * RPL + i];   // logit(z) + log(K-k)
-      if (LADJ && (i < RPL - 1 || gl < 3)) {
-        const T m = d_max(T(1) - s, e);                                // :133
-        const T zl = row0 ? xk : xk * F::rcp(m);
-        lp += F::log2(d_max(zl, e) * d_max(T(1) - zl, e) * (row0 ? T(1) : m));   // :130-131, :135
-      }
-    }
-    if (LADJ) {
-      const T l = -group_sum_rt(lp, 4) * Num<T>::log2;
+    if (Op::IN_LESS) { if (gl == G - 1) xv[RPL - 1] = T(0); }          // the frame's last row has no input
+    const T l = op.template run<RPL>(xv, gl, lktab);
+    if (Op::HAS_LADJ) {
+      const T ls = group_sum_rt(l, G);
       if (col < batch && gl == 0) {
-        if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + l : l;
-        acc += (double)l;
+        if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + ls : ls;
+        acc += (double)ls;
       }
     }
     if (y) {
-      constexpr int RO = K - 1;
       if (colw + CPS <= batch) {
-        __builtin_amdgcn_wave_barrier();                               // the previous instruction's strip reads are done
+        __builtin_amdgcn_wave_barrier();                               // everybody has read its inputs
+        if constexpr (Op::OUT_LESS == 0) {
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) { const int r = gl * RPL + i; if (r < RO) st[cg * RO + r] = o[i]; }
+          for (int q = 0; q < NP; ++q) {
+            Pack<T, V> pq;
+#pragma unroll
+            for (int j = 0; j < V; ++j) pq.v[j] = xv[q * V + j];
+            *reinterpret_cast<typename Vec16<T>::type*>(st + cg * PITCH + (gl * NP + q) * V) = __builtin_bit_cast(typename Vec16<T>::type, pq);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < RPL; ++i) { const int r = gl * RPL + i; if (r < RO) st[cg * RO + r] = xv[i]; }
+        }
         __builtin_amdgcn_wave_barrier();
-        constexpr int NPK = CPS * RO / V;                              // packs in the contiguous output run
 #pragma unroll
-        for (int k = 0; k < (NPK + 63) / 64; ++k) {
-          const int pk = lane + 64 * k;
-          if (pk < NPK) {
-            Pack<T, V> q;
-            if (V > 1) *reinterpret_cast<typename Vec16<T>::type*>(&q) = reinterpret_cast<const typename Vec16<T>::type*>(st)[pk];
-            else q.v[0] = st[pk];
-            store_pack<T, V, true>(y + colw * RO + (int64_t)pk * V, q);
+        for (int q = 0; q < NLO; ++q) {
+          const int pk = lane + 64 * q;
+          if (NPO % 64 == 0 || pk < NPO) {
+            const T* src = Op::OUT_LESS == 0 ? st + (pk / PPC) * PITCH + (pk % PPC) * V : st + pk * V;
+            const Pack<T, V> pq = __builtin_bit_cast(Pack<T, V>, *reinterpret_cast<const typename Vec16<T>::type*>(src));
+            store_pack<T, V, true>(y + colw * RO + (int64_t)pk * V, pq);
           }
         }
       } else if (col < batch) {
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) { const int r = gl * RPL + i; if (r < RO) y[col * RO + r] = o[i]; }
+        for (int i = 0; i < RPL; ++i) { const int r = gl * RPL + i; if (r < RO) y[col * RO + r] = xv[i]; }
       }
     }
   }
   if (partials) block_publish_partial(acc, red, partials);
 }
 
+// launch for R = G·NP·V rows; returns BJX_ERR_UNSUPPORTED-free "not taken" (1) when the shape does not fit
+template <class T, class Op>
+int launch_quad_stream(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t R, int64_t batch, uint32_t flags, bool* taken) {
+  constexpr int VW = Vec16<T>::N;
+  constexpr int G = Op::G;
+  *taken = false;
+  static const int use_stream = getenv("BJX_SEQ_STREAM") ? atoi(getenv("BJX_SEQ_STREAM")) : 1;
+  const int64_t np = R / (G * VW);
+  constexpr int NPMAX = 16 / G;                              // R <= 64 (Float32) / 32 (Float64)
+  if (!use_stream || batch <= 0 || R % (G * VW) != 0 || np < 1 || np > NPMAX || !bjx_aligned16(in) || (out && !bjx_aligned16(out))) return BJX_OK;
+  if (np != 1 && np != 2 && np != 3 && np != 4 && np != 8) return BJX_OK;
+  *taken = true;
+  const int64_t cpb = 4 * (64 / G);                          // columns per block: 4 waves x 64/G columns
+  const int64_t grid = (batch + cpb - 1) / cpb;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+  const bool want = Op::HAS_LADJ && (ladj_ps || ladj_sum);
+  if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
+  double* partials = (ladj_sum && Op::HAS_LADJ) ? ctx->partials : nullptr;
+  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  (void)want;
+#define QS(NP_) hipLaunchKernelGGL((quad_stream_kernel<T, VW, NP_, Op, 1>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, op, in, out, ladj_ps, batch, accum, partials)
+  {
+    BjxProf prof_(ctx);
+    switch ((int)np) {
+      case 1: QS(1); break;
+      case 2: QS(2); break;
+      case 3: if constexpr (NPMAX >= 3) QS(3); break;
+      case 4: if constexpr (NPMAX >= 4) QS(4); break;
+      case 8: if constexpr (NPMAX >= 8) QS(8); break;
+    }
+  }
+#undef QS
+  BJX_CHECK_LAUNCH(ctx);
+  if (ladj_sum) {
+    if (Op::HAS_LADJ) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+    if (!(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
+  }
+  return BJX_OK;
+}
+
+template <class T>
+int ordered_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
+  {
+    bool taken = false;
+    const int rc = !inverse ? launch_quad_stream<T>(ctx, QOrderedFwd<T>{}, in, out, ladj_ps, ladj_sum, dim, batch, flags, &taken)
+                            : launch_quad_stream<T>(ctx, QOrderedInv<T>{}, in, out, ladj_ps, ladj_sum, dim, batch, flags, &taken);
+    if (rc || taken) return rc;
+  }
+  if (!inverse) return launch_seq<T>(ctx, OrderedFwd<T>{}, in, out, ladj_ps, ladj_sum, dim, dim, batch, 0, flags);
+  return launch_seq<T>(ctx, OrderedInv<T>{}, in, out, ladj_ps, ladj_sum, dim, dim, batch, 0, flags);
+}
+
 template <class T>
 int simplex_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags) {
   const bool want = ladj_ps || ladj_sum;
   const int nlk = (int)(K - 1);
-  constexpr int VWs = Vec16<T>::N;
-  static const int use_stream = getenv("BJX_SIMPLEX_STREAM") ? atoi(getenv("BJX_SIMPLEX_STREAM")) : 1;
-  const int64_t np = K / (4 * VWs);                         // packs per lane with 4 lanes per column
-  if (!inverse && use_stream && batch > 0 && K % (4 * VWs) == 0 && np >= 1 && np <= 4 && bjx_aligned16(in) && (!out || bjx_aligned16(out))) {
-    static const int uc = getenv("BJX_SIMPLEX_UC") ? atoi(getenv("BJX_SIMPLEX_UC")) : 1;
-    const int64_t cpb = 4 * 16 * (uc == 2 ? 2 : 1);         // columns per block: 4 waves x 16 columns x UC in flight
-    const int64_t grid = (batch + cpb - 1) / cpb;
-    BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
-    if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
-    double* partials = ladj_sum ? ctx->partials : nullptr;
-    const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
-#define SFS1(NP_, L_, UC_) hipLaunchKernelGGL((simplex_fwd_stream_kernel<T, VWs, NP_, L_, UC_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out, ladj_ps, batch, accum, partials)
-#define SFS(NP_, L_) do { if (uc == 2) SFS1(NP_, L_, 2); else SFS1(NP_, L_, 1); } while (0)
-#define SFS_L(NP_) do { if (want) SFS(NP_, true); else SFS(NP_, false); } while (0)
-    {
-      BjxProf prof_(ctx);
-      if (np == 1) SFS_L(1); else if (np == 2) SFS_L(2); else if (np == 3) SFS_L(3); else SFS_L(4);
-    }
-#undef SFS_L
-#undef SFS
-#undef SFS1
-    BJX_CHECK_LAUNCH(ctx);
-    if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
-    return BJX_OK;
+  {
+    bool taken = false;
+    int rc;
+    if (!inverse) rc = want ? launch_quad_stream<T>(ctx, QSimplexFwd<T, true>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken)
+                            : launch_quad_stream<T>(ctx, QSimplexFwd<T, false>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken);
+    else rc = want ? launch_quad_stream<T>(ctx, QSimplexInv<T, true>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken)
+                   : launch_quad_stream<T>(ctx, QSimplexInv<T, false>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken);
+    if (rc || taken) return rc;
   }
   if (!inverse) {
     if (want) { SimplexFwd<T, true> op; op.K = K; return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K, K - 1, batch, nlk, flags); }
@@ -1794,6 +1939,16 @@ int simplex_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, dou
   return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K - 1, K, batch, nlk, flags);
 }
 }  // namespace
+
+BJX_API int bjx_ordered(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out, void* ladj_ps, double* ladj_sum,
+                        int64_t dim, int64_t batch, uint32_t flags) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_ordered: input must not be empty (ordered.jl:26)");
+  BJX_REQUIRE(ctx, (in && out) || batch == 0, BJX_ERR_ARG, "bjx_ordered: null pointer");
+  if (dt == BJX_F32) return ordered_impl<float>(ctx, inverse, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, batch, flags);
+  if (dt == BJX_F64) return ordered_impl<double>(ctx, inverse, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, batch, flags);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_ordered: bad dtype %d", (int)dt);
+}
 
 BJX_API int bjx_simplex(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out, void* ladj_ps, double* ladj_sum,
                         int64_t K, int64_t batch, uint32_t flags) {

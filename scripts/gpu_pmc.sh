@@ -12,10 +12,13 @@ for set in "$@"; do
   [ -n "$f" ] && python - "$f" "$KS" <<'PY'
 import csv, sys, collections
 rows=[r for r in csv.DictReader(open(sys.argv[1])) if sys.argv[2] in r['Kernel_Name']]
-agg=collections.defaultdict(list)
-for r in rows: agg[r['Counter_Name']].append(float(r['Counter_Value']))
-if rows: print('kernel:', rows[0]['Kernel_Name'][:90], 'VGPR', rows[0]['VGPR_Count'], 'SGPR', rows[0]['SGPR_Count'], 'LDS', rows[0]['LDS_Block_Size'], 'grid', rows[0]['Grid_Size'], 'wg', rows[0]['Workgroup_Size'])
-for k,v in agg.items(): print('  %-28s %16.1f  (n=%d)' % (k, sum(v)/len(v), len(v)))
+byk=collections.defaultdict(list)
+for r in rows: byk[r['Kernel_Name']].append(r)
+for kn, rows in byk.items():
+  agg=collections.defaultdict(list)
+  for r in rows: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+  print('kernel:', rows[0]['Kernel_Name'][:150], 'VGPR', rows[0]['VGPR_Count'], 'SGPR', rows[0]['SGPR_Count'], 'LDS', rows[0]['LDS_Block_Size'], 'grid', rows[0]['Grid_Size'], 'wg', rows[0]['Workgroup_Size'])
+  for k,v in agg.items(): print('  %-28s %16.1f  (n=%d)' % (k, sum(v)/len(v), len(v)))
 PY
 done
 exit 0

@@ -181,7 +181,8 @@ def test_long_chain_is_split_into_launches(bj, orc):
 
 # ------------------------------------------------------------------ F3 sequential
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("shape", [(64, 777), (5, 4), (1, 10), (100, 300), (33, 1)])
+@pytest.mark.parametrize("shape", [(64, 777), (5, 4), (1, 10), (100, 300), (33, 1),
+                                   (8, 50), (16, 333), (24, 19), (32, 77), (48, 130), (64, 4099), (64, 1)])   # 16·NP / 8·NP rows: streaming kernel
 def test_ordered(bj, orc, shape, dt):
     y = np.asfortranarray(rng(3).normal(size=shape).astype(dt) * 0.7)
     x_ref, l_ref = orc.ordered(y)
