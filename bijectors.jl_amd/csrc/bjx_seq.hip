@@ -1656,8 +1656,8 @@ template <class T, bool LADJ> struct QSimplexFwd {      // simplex.jl:47-64 + :1
   }
 };
 
-template <class T, bool LADJ> struct QSimplexInv {      // simplex.jl:102-120 ; log-det = -logabsdetjac(b, x_out)
-  static constexpr int G = 2, IN_LESS = 1, OUT_LESS = 0;
+template <class T, bool LADJ, int G_> struct QSimplexInv {      // simplex.jl:102-120 ; log-det = -logabsdetjac(b, x_out)
+  static constexpr int G = G_, IN_LESS = 1, OUT_LESS = 0;
   static constexpr bool USES_LOGK = true, HAS_LADJ = LADJ;
   template <int RPL> __device__ __forceinline__ T run(T (&x)[RPL], int gl, const T* lk) const {
     using F = Fast<T>;
@@ -1922,11 +1922,19 @@ int simplex_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, dou
   const int nlk = (int)(K - 1);
   {
     bool taken = false;
-    int rc;
+    int rc = BJX_OK;
     if (!inverse) rc = want ? launch_quad_stream<T>(ctx, QSimplexFwd<T, true>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken)
                             : launch_quad_stream<T>(ctx, QSimplexFwd<T, false>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken);
-    else rc = want ? launch_quad_stream<T>(ctx, QSimplexInv<T, true>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken)
-                   : launch_quad_stream<T>(ctx, QSimplexInv<T, false>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken);
+    else {
+      static const int g4 = getenv("BJX_SIMPLEX_INV_G") ? atoi(getenv("BJX_SIMPLEX_INV_G")) == 4 : 0;
+      constexpr int VWq = Vec16<T>::N;
+      if (g4 || K % (2 * VWq) != 0 || K / (2 * VWq) > 8 || (K / (2 * VWq) > 4 && K / (2 * VWq) != 8))
+        rc = want ? launch_quad_stream<T>(ctx, QSimplexInv<T, true, 4>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken)
+                  : launch_quad_stream<T>(ctx, QSimplexInv<T, false, 4>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken);
+      if (!rc && !taken)
+        rc = want ? launch_quad_stream<T>(ctx, QSimplexInv<T, true, 2>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken)
+                  : launch_quad_stream<T>(ctx, QSimplexInv<T, false, 2>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken);
+    }
     if (rc || taken) return rc;
   }
   if (!inverse) {
