@@ -14,10 +14,11 @@ LIB_PATH = os.path.join(_HERE, "libbjx_hip.so")
 BJX_F32, BJX_F64 = 0, 1
 BJX_ACCUMULATE = 1 << 0
 BJX_REF_VECTOR_SCALE_LADJ = 1 << 1
+BJX_BASE_STDNORMAL = 1 << 2
 BJX_MAX_OPS = 8
 
 (OP_EXP, OP_LOG, OP_SHIFT, OP_SCALE, OP_SCALE_INV, OP_LOGIT, OP_LOGIT_INV, OP_LEAKY_RELU,
- OP_TRUNCATED, OP_TRUNCATED_INV, OP_SIGNFLIP, OP_IDENTITY) = range(1, 13)
+ OP_TRUNCATED, OP_TRUNCATED_INV, OP_SIGNFLIP, OP_IDENTITY, OP_STDNORMAL_LOGPDF) = range(1, 14)
 
 ERR_ARG, ERR_SHAPE, ERR_UNSUPPORTED, ERR_NOCOMM = -1, -2, -3, -4
 

@@ -71,21 +71,33 @@ __device__ __forceinline__ void load_params(const DevOp<T>& op, int64_t r, int64
 // One stage applied to U packs of V consecutive elements (wave-uniform `switch`); returns the
 // data-dependent log-det contribution (Scale's parameter-only term is added by finalize).
 #define BJX_FOR_UJ _Pragma("unroll") for (int u = 0; u < U; ++u) _Pragma("unroll") for (int j = 0; j < V; ++j)
-template <class T, int V, int U, int ROWMODE>
+// SAMEROW: the U packs of a lane sit at the same rows (the pack stride 256·V is a multiple of dim, or the
+// per-sample geometry): the per-row parameters are loaded ONCE instead of U times — each such load is as wide
+// as the data pack itself, and two vector-parameter stages tripled the load traffic of a density chain.
+template <class T, int V, int U, int ROWMODE, bool SAMEROW = false>
 __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim, T (&l)[U]) {
   using F = Fast<T>;
   const int kind = op.kind;
   T a[U][V], b[U][V];
-  if (kind != BJX_OP_EXP && kind != BJX_OP_LOG && kind != BJX_OP_SIGNFLIP) {
+  if (kind != BJX_OP_EXP && kind != BJX_OP_LOG && kind != BJX_OP_SIGNFLIP && kind != BJX_OP_STDNORMAL_LOGPDF) {
+    if constexpr (SAMEROW && U > 1) {
+      load_params<T, V, ROWMODE>(op, r[0], dim, a[0], b[0]);
 #pragma unroll
-    for (int u = 0; u < U; ++u) load_params<T, V, ROWMODE>(op, r[u], dim, a[u], b[u]);
+      for (int u = 1; u < U; ++u) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) { a[u][j] = a[0][j]; b[u][j] = b[0][j]; }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) load_params<T, V, ROWMODE>(op, r[u], dim, a[u], b[u]);
+    }
   }
   switch (kind) {
     case BJX_OP_EXP:  // exp_log.jl:5-6: ladj = sum(x)
-      BJX_FOR_UJ { l[u] += p[u].v[j]; p[u].v[j] = d_exp(p[u].v[j]); }
+      BJX_FOR_UJ { l[u] += p[u].v[j]; p[u].v[j] = F::exp(p[u].v[j]); }       // Float32: v_exp_f32 (the OCML expf is ~15 VALU: a read-only density chain is VALU-bound with it)
       break;
     case BJX_OP_LOG:  // exp_log.jl:8-9: ladj = -sum(log, x)
-      BJX_FOR_UJ { T t = d_log(p[u].v[j]); l[u] -= t; p[u].v[j] = t; }
+      BJX_FOR_UJ { T t = F::log(p[u].v[j]); l[u] -= t; p[u].v[j] = t; }
       break;
     case BJX_OP_SHIFT:  // shift.jl:14
       BJX_FOR_UJ p[u].v[j] = a[u][j] + p[u].v[j];
@@ -94,7 +106,7 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
       BJX_FOR_UJ p[u].v[j] = a[u][j] * p[u].v[j];
       break;
     case BJX_OP_SCALE_INV:  // scale.jl:15-16: Scale(inv(a))
-      BJX_FOR_UJ p[u].v[j] = (T(1) / a[u][j]) * p[u].v[j];
+      BJX_FOR_UJ p[u].v[j] = F::rcp(a[u][j]) * p[u].v[j];
       break;
     case BJX_OP_LOGIT:  // logit.jl:15,24.  Float32: hardware log/rcp (the OCML versions make this op VALU-bound at 50 % of the roofline)
       BJX_FOR_UJ {
@@ -117,7 +129,7 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
     case BJX_OP_LEAKY_RELU:  // leaky_relu.jl:25-29
       BJX_FOR_UJ {
         T J = p[u].v[j] < T(0) ? a[u][j] : T(1);
-        l[u] += d_log(d_abs(J));
+        l[u] += F::log(d_abs(J));
         p[u].v[j] = J * p[u].v[j];
       }
       break;
@@ -152,21 +164,24 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
     case BJX_OP_SIGNFLIP:  // ordered.jl:3
       BJX_FOR_UJ p[u].v[j] = -p[u].v[j];
       break;
+    case BJX_OP_STDNORMAL_LOGPDF:  // base density of a TransformedDistribution (transformed_distribution.jl:165-169)
+      BJX_FOR_UJ l[u] += (T(-0.5) * p[u].v[j]) * p[u].v[j] - T(0.91893853320467274178);
+      break;
     default: break;
   }
 }
 
 // per-pack log-det contributions lu[u] (the per-sample kernel reduces each pack's column separately)
-template <class T, int V, int U, int ROWMODE>
+template <class T, int V, int U, int ROWMODE, bool SAMEROW = false>
 __device__ __forceinline__ void apply_chain_u(const ChainArgs<T>& A, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim, T (&lu)[U]) {
 #pragma unroll
   for (int u = 0; u < U; ++u) lu[u] = T(0);
-  for (int k = 0; k < A.n_ops; ++k) apply_op<T, V, U, ROWMODE>(A.ops[k], p, r, dim, lu);
+  for (int k = 0; k < A.n_ops; ++k) apply_op<T, V, U, ROWMODE, SAMEROW>(A.ops[k], p, r, dim, lu);
 }
-template <class T, int V, int U, int ROWMODE>
+template <class T, int V, int U, int ROWMODE, bool SAMEROW = false>
 __device__ __forceinline__ T apply_chain(const ChainArgs<T>& A, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim) {
   T lu[U];
-  apply_chain_u<T, V, U, ROWMODE>(A, p, r, dim, lu);
+  apply_chain_u<T, V, U, ROWMODE, SAMEROW>(A, p, r, dim, lu);
   T l = lu[0];
 #pragma unroll
   for (int u = 1; u < U; ++u) l += lu[u];
@@ -192,9 +207,13 @@ __global__ __launch_bounds__(256) void chain_flat_kernel(const ChainArgs<T> A, c
       r[u] = 0;
       if constexpr (ROWMODE != 0) r[u] = dim_pow2 ? (((i0 + u * 256) * V) & (dim - 1)) : (((i0 + u * 256) * V) % dim);
     }
-    T l = apply_chain<T, V, U, ROWMODE>(A, p, r, dim);
+    T l;
+    if (ROWMODE == 1 && U > 1 && (256 * V) % dim == 0) l = apply_chain<T, V, U, ROWMODE, true>(A, p, r, dim);   // same rows in every pack
+    else l = apply_chain<T, V, U, ROWMODE>(A, p, r, dim);
+    if (y) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) store_pack<T, V, NT>(y + (i0 + u * 256) * V, p[u]);
+      for (int u = 0; u < U; ++u) store_pack<T, V, NT>(y + (i0 + u * 256) * V, p[u]);
+    }
     acc = (double)l;
   } else {
     // last block: packs one at a time, then the n % V tail elements by one lane
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(256) void chain_flat_kernel(const ChainArgs<T> A, c
         int64_t r[1] = {0};
         if constexpr (ROWMODE != 0) r[0] = (i * V) % dim;
         T l = apply_chain<T, V, 1, ROWMODE>(A, p, r, dim);
-        store_pack<T, V, NT>(y + i * V, p[0]);
+        if (y) store_pack<T, V, NT>(y + i * V, p[0]);
         acc += (double)l;
       } else if (V > 1 && i == nv) {
         for (int64_t e = nv * V; e < n; ++e) {
@@ -215,7 +234,7 @@ __global__ __launch_bounds__(256) void chain_flat_kernel(const ChainArgs<T> A, c
           q[0].v[0] = x[e];
           int64_t r[1] = {ROWMODE == 0 ? 0 : e % dim};
           T l = apply_chain<T, 1, 1, (ROWMODE == 0 ? 0 : 2)>(A, q, r, dim);
-          y[e] = q[0].v[0];
+          if (y) y[e] = q[0].v[0];
           acc += (double)l;
         }
       }
@@ -251,13 +270,13 @@ __global__ __launch_bounds__(256) void chain_flatcol_kernel(const ChainArgs<T> A
     r[u] = (int64_t)gl * V;                         // row of the pack inside its column
   }
   T lu[U];
-  apply_chain_u<T, V, U, ROWMODE>(A, p, r, dim, lu);
+  apply_chain_u<T, V, U, ROWMODE, true>(A, p, r, dim, lu);      // r[u] = gl·V for every pack
   const double c_ps = c_ps_host + (c_ps_dev ? *c_ps_dev : 0.0);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int64_t i = i0 + u * 256;
     const bool ok = full || i < nv;
-    if (ok) store_pack<T, V, NT>(y + i * V, p[u]);
+    if (ok && y) store_pack<T, V, NT>(y + i * V, p[u]);
     const T l = group_sum<G>(ok ? lu[u] : T(0));
     if (ok && gl == 0) {
       const int64_t col = i / G;
@@ -298,7 +317,7 @@ __global__ __launch_bounds__(256) void chain_colgroup_kernel(const ChainArgs<T> 
         for (int u = 0; u < CHAIN_U; ++u) { p[u] = load_pack<T, V, NT>(xc + (v + (int64_t)u * G) * V); r[u] = (v + (int64_t)u * G) * V; }
         l += apply_chain<T, V, CHAIN_U, ROWMODE>(A, p, r, dim);
 #pragma unroll
-        for (int u = 0; u < CHAIN_U; ++u) store_pack<T, V, NT>(yc + (v + (int64_t)u * G) * V, p[u]);
+        for (int u = 0; u < CHAIN_U; ++u) if (y) store_pack<T, V, NT>(yc + (v + (int64_t)u * G) * V, p[u]);
       }
     }
     for (; v < nvc; v += G) {
@@ -306,7 +325,7 @@ __global__ __launch_bounds__(256) void chain_colgroup_kernel(const ChainArgs<T> 
       int64_t r[1] = {v * V};
       p[0] = load_pack<T, V, NT>(xc + v * V);
       l += apply_chain<T, V, 1, ROWMODE>(A, p, r, dim);
-      store_pack<T, V, NT>(yc + v * V, p[0]);
+      if (y) store_pack<T, V, NT>(yc + v * V, p[0]);
     }
   }
   l = group_sum_rt(l, G);
@@ -368,7 +387,7 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
   for (int k = 0; k < n_ops; ++k) {
     const bjx_op& o = ops[k];
     DevOp<T>& d = A.ops[k];
-    BJX_REQUIRE(ctx, o.kind >= BJX_OP_EXP && o.kind <= BJX_OP_IDENTITY, BJX_ERR_ARG, "bjx_chain: op %d has unknown kind %d", k, o.kind);
+    BJX_REQUIRE(ctx, o.kind >= BJX_OP_EXP && o.kind <= BJX_OP_STDNORMAL_LOGPDF, BJX_ERR_ARG, "bjx_chain: op %d has unknown kind %d", k, o.kind);
     BJX_REQUIRE(ctx, o.param_len == 0 || o.param_len == 1 || o.param_len == dim, BJX_ERR_SHAPE,
                 "bjx_chain: op %d parameter length %d does not match dim %lld", k, o.param_len, (long long)dim);
     d.kind = o.kind;
@@ -500,7 +519,17 @@ BJX_API int bjx_chain(bjx_ctx* ctx, bjx_dtype dt, const bjx_op* ops, int n_ops, 
   if (!ctx) return BJX_ERR_ARG;
   BJX_REQUIRE(ctx, n_ops >= 0 && n_ops <= BJX_MAX_OPS && (ops || n_ops == 0), BJX_ERR_ARG, "bjx_chain: n_ops must be in [0, %d]", BJX_MAX_OPS);
   BJX_REQUIRE(ctx, dim >= 0 && batch >= 0, BJX_ERR_SHAPE, "bjx_chain: negative size");
-  BJX_REQUIRE(ctx, (x && y) || dim * batch == 0, BJX_ERR_ARG, "bjx_chain: null data pointer");
+  // y == NULL: only the log-det (and, with the density op, logpdf) is wanted — the values are not stored
+  BJX_REQUIRE(ctx, (x && (y || ladj_ps || ladj_sum)) || dim * batch == 0, BJX_ERR_ARG, "bjx_chain: null data pointer");
+  bjx_op ext[BJX_MAX_OPS];
+  if (flags & BJX_BASE_STDNORMAL) {
+    BJX_REQUIRE(ctx, n_ops < BJX_MAX_OPS, BJX_ERR_UNSUPPORTED, "bjx_chain: BJX_BASE_STDNORMAL needs a free op slot (n_ops < %d)", BJX_MAX_OPS);
+    for (int k = 0; k < n_ops; ++k) ext[k] = ops[k];
+    memset(&ext[n_ops], 0, sizeof(bjx_op));
+    ext[n_ops].kind = BJX_OP_STDNORMAL_LOGPDF;
+    ops = ext;
+    ++n_ops;
+  }
   if (dt == BJX_F32) return chain_impl<float>(ctx, ops, n_ops, (const float*)x, (float*)y, (float*)ladj_ps, ladj_sum, dim, batch, flags);
   if (dt == BJX_F64) return chain_impl<double>(ctx, ops, n_ops, (const double*)x, (double*)y, (double*)ladj_ps, ladj_sum, dim, batch, flags);
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_chain: bad dtype %d", (int)dt);

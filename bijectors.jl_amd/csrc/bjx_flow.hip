@@ -137,13 +137,26 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
         }
       }
     }
+    if (accumulate & 2) {                       // BJX_BASE_STDNORMAL: + log N(out; 0, I)
+      T q = T(0);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int64_t v = gl + (int64_t)r * G;
+        if (v < nvc) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) q += z[r].v[j] * z[r].v[j];
+        }
+      }
+      q = group_sum_rt(q, G);
+      ladj += T(-0.5) * q - (T)dim * T(0.91893853320467274178);
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       int64_t v = gl + (int64_t)r * G;
-      if (col_ok && v < nvc) store_pack<T, V, true>(yc + v * V, z[r]);
+      if (col_ok && y && v < nvc) store_pack<T, V, true>(yc + v * V, z[r]);
     }
     if (col_ok && gl == 0) {
-      if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + ladj : ladj;
+      if (ladj_ps) ladj_ps[col] = (accumulate & 1) ? ladj_ps[col] + ladj : ladj;
       acc += (double)ladj;
     }
   }
@@ -291,8 +304,15 @@ __global__ __launch_bounds__(64) void planar_tile_kernel(const PlanarTileArgs<T>
     else ladj += planar_tile_group<T, INV, false>(A, tile, dim, lane, l0, ng);
   }
   __builtin_amdgcn_wave_barrier();
+  if (accumulate & 2) {                         // BJX_BASE_STDNORMAL: + log N(out; 0, I), lane = column
+    T q0 = T(0), q1 = T(0);
+    int r = 0;
+    for (; r + 2 <= dim; r += 2) { const T a = tile[tile_addr(r, lane)], b = tile[tile_addr(r + 1, lane)]; q0 += a * a; q1 += b * b; }
+    if (r < dim) { const T a = tile[tile_addr(r, lane)]; q0 += a * a; }
+    ladj += T(-0.5) * (q0 + q1) - (T)dim * T(0.91893853320467274178);
+  }
   // ---- stage out: swizzled tile -> coalesced packs
-  {
+  if (y) {
     int c = c_first, r = r_first;
 #pragma unroll 8
     for (int q = lane; q < npk; q += 64) {
@@ -308,7 +328,7 @@ __global__ __launch_bounds__(64) void planar_tile_kernel(const PlanarTileArgs<T>
     }
   }
   const bool ok = lane < ncols;
-  if (ok && ladj_ps) ladj_ps[col0 + lane] = accumulate ? ladj_ps[col0 + lane] + ladj : ladj;
+  if (ok && ladj_ps) ladj_ps[col0 + lane] = (accumulate & 1) ? ladj_ps[col0 + lane] + ladj : ladj;
   if (partials) {
     double acc = group_sum<64>(ok ? (double)ladj : 0.0);
     if (lane == 0) partials[blockIdx.x] = acc;
@@ -554,7 +574,27 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
     }
     __builtin_amdgcn_wave_barrier();
   }
-  {
+  if (accumulate & 2) {
+    // BJX_BASE_STDNORMAL: + log N(out; 0, I).  |out|² of a column is reduced over its G lanes exactly like a
+    // one-layer dot product (fold + DPP butterflies), lands in st[column] and is picked up by lane = column.
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+      float p[2];
+      p[0] = z[r].x * z[r].x + z[r].y * z[r].y + z[r].z * z[r].z + z[r].w * z[r].w;
+      float q[1];
+      if constexpr (G == 32) { p[1] = p[0]; swap_fold<1>(p, q); }                  // lane i + lane i+16
+      else q[0] = p[0];
+      row_allsum<RW, 1>(q);
+      if ((lane & (RW - 1)) == 0) {
+        const int cl = G == 32 ? r * CPS + (lane >> 5) : r * CPS + cg;
+        if (!(G == 32 && ((lane >> 4) & 1))) st[cl] = q[0];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (COLS == 64 || lane < COLS) ladj += -0.5f * st[lane] - (float)dim * 0.91893853320467274178f;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (y) {
     float* py = y + (col0 + cg) * dim + 4 * gl;
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
@@ -563,7 +603,7 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
     }
   }
   const bool ok = lane < nvalid;   // nvalid <= COLS
-  if (ok && ladj_ps) ladj_ps[col0 + lane] = accumulate ? ladj_ps[col0 + lane] + ladj : ladj;
+  if (ok && ladj_ps) ladj_ps[col0 + lane] = (accumulate & 1) ? ladj_ps[col0 + lane] + ladj : ladj;
   block_publish_partial(ok ? (double)ladj : 0.0, red, fin);
 }
 
@@ -763,7 +803,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         bool second = false;
         { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
         PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad};
-        const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+        const int accum = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
 #define LAUNCH_REG(G_, NL_, INV_) if (G_ == 32 && cols == 32) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, (G_ == 32 ? 32 : 64)>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); else hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, 64>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
 #define LAUNCH_REG_NL(G_, INV_) switch (NL) { case 1: LAUNCH_REG(G_, 1, INV_); break; case 2: LAUNCH_REG(G_, 2, INV_); break; case 4: LAUNCH_REG(G_, 4, INV_); break; default: LAUNCH_REG(G_, 8, INV_); break; }
 #define LAUNCH_REG_G(INV_) switch (G) { case 8: LAUNCH_REG_NL(8, INV_) break; case 16: LAUNCH_REG_NL(16, INV_) break; default: LAUNCH_REG_NL(32, INV_) break; }
@@ -792,7 +832,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
     if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
     double* partials = ladj_sum ? ctx->partials : nullptr;
     PlanarTileArgs<T> TA{wT, uT, G, wtu, b, nl};
-    const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+    const int accum = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
     constexpr int VW = Vec16<T>::N;
     const bool v_ok = bjx_aligned16(in) && bjx_aligned16(out) && dim % VW == 0;
 #define LAUNCH_TILE(V_, INV_) hipLaunchKernelGGL((planar_tile_kernel<T, V_, INV_>), dim3((unsigned)grid), dim3(64), tile_bytes, ctx->stream, TA, in, out, ladj_ps, (int)dim, batch, accum, partials)
@@ -810,7 +850,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
   const bool lds = tab_bytes <= 60 * 1024;
   PlanarArgs<T> A{w, u_hat, wtu, b, nl, lds ? 1 : 0};
   const size_t smem = 32 + (lds ? tab_bytes : 0);
-  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  const int accum = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
   if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)c.grid); if (rc) return rc; }
   double* partials = ladj_sum ? ctx->partials : nullptr;
   constexpr int VW = Vec16<T>::N;
@@ -867,7 +907,8 @@ BJX_API int bjx_planar(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* w, c
                        const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
   if (!ctx) return BJX_ERR_ARG;
   BJX_REQUIRE(ctx, dim >= 1 && batch >= 0 && n_layers >= 1, BJX_ERR_SHAPE, "bjx_planar: bad size (dim=%lld, n_layers=%d)", (long long)dim, n_layers);
-  BJX_REQUIRE(ctx, w && u && b && ((in && out) || batch == 0), BJX_ERR_ARG, "bjx_planar: null pointer");
+  // out == NULL: only the log-det / log-density is wanted (BJX_BASE_STDNORMAL: logpdf(td, y) without storing the pre-image)
+  BJX_REQUIRE(ctx, w && u && b && ((in && (out || ladj_ps || ladj_sum)) || batch == 0), BJX_ERR_ARG, "bjx_planar: null pointer");
   if (dt == BJX_F32) return planar_impl<float>(ctx, inverse, (const float*)w, (const float*)u, (const float*)b, n_layers, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, batch, flags);
   if (dt == BJX_F64) return planar_impl<double>(ctx, inverse, (const double*)w, (const double*)u, (const double*)b, n_layers, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, batch, flags);
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_planar: bad dtype %d", (int)dt);

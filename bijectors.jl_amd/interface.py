@@ -33,7 +33,7 @@ __all__ = [
     "VecCholeskyBijector", "Permute", "PlanarLayer", "RadialLayer", "InvertibleBatchNorm", "RationalQuadraticSpline",
     "PartitionMask", "Coupling", "Stacked", "Columnwise", "columnwise", "vjp", "istraining", "training", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
     "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
-    "PlanarResult",
+    "PlanarResult", "MvNormal", "TransformedDistribution", "transformed", "logpdf", "rand",
 ]
 
 PlanarResult = namedtuple("PlanarResult", ["result", "logabsdetjac"])  # planar_layer.jl:109
@@ -582,8 +582,9 @@ def _stage_ops(s):
     return None
 
 
-def _run_chain(ops: Sequence, x: torch.Tensor, per_sample: bool, want_ladj: bool = True, out_y: Optional[torch.Tensor] = None):
-    """One bjx_chain launch.  ops: [(kind, p0, p1)] in application order."""
+def _run_chain(ops: Sequence, x: torch.Tensor, per_sample: bool, want_ladj: bool = True, out_y: Optional[torch.Tensor] = None, store: bool = True):
+    """One bjx_chain launch.  ops: [(kind, p0, p1)] in application order.  store=False: the values are not
+    written (log-det / log-density only: half the traffic)."""
     xc, dim, batch, vec = _prep(x)
     ctx = context(xc.device)
     arr = (L.BjxOp * max(len(ops), 1))()
@@ -605,7 +606,9 @@ def _run_chain(ops: Sequence, x: torch.Tensor, per_sample: bool, want_ladj: bool
             else:
                 o.param_len = 1
                 setattr(o, f"p{j}", float(p))
-    if out_y is None:
+    if not store:
+        y = None
+    elif out_y is None:
         y = _empty(dim, batch, xc, vec)
     else:  # transform!/with_logabsdet_jacobian!: write straight into the caller's buffer (may alias x)
         y = out_y
@@ -622,14 +625,14 @@ def _run_chain(ops: Sequence, x: torch.Tensor, per_sample: bool, want_ladj: bool
 
 
 # ------------------------------------------------------------------ structured bijectors
-def _call_struct(fn_name: str, x, rows_out: int, per_sample_ret: bool, per_sample: bool, want_ladj: bool, pre_args, post_dims):
+def _call_struct(fn_name: str, x, rows_out: int, per_sample_ret: bool, per_sample: bool, want_ladj: bool, pre_args, post_dims, flags: int = 0, store: bool = True):
     """Shared launcher: fn(ctx, dt, *pre_args, in, out, ladj_ps, ladj_sum, *post_dims, flags)."""
     xc, dim, batch, vec = _prep(x)
     ctx = context(xc.device)
-    y = _empty(rows_out, batch, xc, vec)
+    y = _empty(rows_out, batch, xc, vec) if store else None
     out = _Out(xc, batch, per_sample, want_ladj, ret_vector=per_sample_ret)
     fn = getattr(L.load(), fn_name)
-    rc = fn(ctx.h, _dt(xc), *pre_args, _ptr(xc), _ptr(y), _ptr(out.ps), _ptr(out.sum), *post_dims, batch, 0)
+    rc = fn(ctx.h, _dt(xc), *pre_args, _ptr(xc), _ptr(y), _ptr(out.ps), _ptr(out.sum), *post_dims, batch, flags)
     L.check(ctx.h, rc, fn_name)
     if not want_ladj:
         return y, None
@@ -797,7 +800,7 @@ class PlanarLayer(Bijector):
     def _key(self):
         return (_keyify(self.w), _keyify(self.u), _keyify(self.b))
 
-    def _run(self, x, inv, per_sample, want_ladj):
+    def _run(self, x, inv, per_sample, want_ladj, flags=0, store=True):
         xc, dim, batch, vec = _prep(x)
         w = _param(self.w, xc)
         u = _param(self.u, xc)
@@ -807,7 +810,7 @@ class PlanarLayer(Bijector):
             raise ValueError(f"DimensionMismatch: PlanarLayer of dimension {w.numel() // self.n_layers} applied to {dim} rows")
         b = _param(self.b, xc)
         return _call_struct("bjx_planar", x, dim, True, per_sample, want_ladj,
-                            (int(inv), _ptr(w), _ptr(u), _ptr(b), self.n_layers), (dim,))
+                            (int(inv), _ptr(w), _ptr(u), _ptr(b), self.n_layers), (dim,), flags=flags, store=store)
 
     def _wlj(self, x, per_sample, want_ladj=True):
         return self._run(x, False, per_sample, want_ladj)
@@ -1268,3 +1271,93 @@ class Columnwise(Transform):
 def columnwise(f):
     """src/interface.jl:70"""
     return Columnwise(f)
+
+
+# ------------------------------------------------------------------ SURVEY.md §8(f) f-3: TransformedDistribution
+class MvNormal:
+    """Diagonal-covariance base distribution `MvNormal(μ, Diagonal(σ.^2))`; `MvNormal(dim)` is the standard normal
+    (the base of every flow in the reference's docs/tests, e.g. test/normalising_flows.jl:74-91)."""
+
+    def __init__(self, mu, sigma=None):
+        if isinstance(mu, int) and sigma is None:
+            self.dim, self.mu, self.sigma = mu, None, None
+        else:
+            self.mu = torch.as_tensor(mu).reshape(-1)
+            self.sigma = None if sigma is None else torch.as_tensor(sigma).reshape(-1)
+            self.dim = self.mu.numel()
+
+    def _whiten_ops(self):
+        """x -> (x - μ)/σ as chain ops; SCALE_INV's log-det supplies the -Σ log σ of the density."""
+        ops = []
+        if self.mu is not None:
+            ops.append((L.OP_SHIFT, -self.mu, None))
+        if self.sigma is not None:
+            ops.append((L.OP_SCALE_INV, self.sigma, None))
+        return ops
+
+    def _color_ops(self):
+        ops = []
+        if self.sigma is not None:
+            ops.append((L.OP_SCALE, self.sigma, None))
+        if self.mu is not None:
+            ops.append((L.OP_SHIFT, self.mu, None))
+        return ops
+
+
+class TransformedDistribution:
+    """src/transformed_distribution.jl:2-12: `transformed(dist, b)`; y = b(x), x ~ dist."""
+
+    def __init__(self, dist, transform):
+        self.dist, self.transform = dist, transform
+
+
+def transformed(dist, b=None):
+    """src/transformed_distribution.jl:20-28"""
+    return TransformedDistribution(dist, Elementwise(identity) if b is None else b)
+
+
+def logpdf(td: TransformedDistribution, y, reference_shape: bool = False):
+    """`logpdf(td::MvTransformed, y::AbstractMatrix)` (src/transformed_distribution.jl:164-169):
+        x, logjac = with_logabsdet_jacobian(inverse(td.transform), y);  logpdf(td.dist, x) + logjac
+    evaluated in ONE pass over `y` where the inverse is a fused chain or a PlanarLayer stack: the base density
+    is accumulated inside the kernel that inverts the flow and the pre-image `x` is never stored (the reference
+    marks this path "TODO: implement more efficiently for flows").  Returns the per-column log-density.
+
+    reference_shape=True reproduces what the reference's `+` does literally: elementwise bijectors return ONE
+    scalar log-det for the whole matrix, which it adds to every column (SURVEY.md §8a″)."""
+    ib = inverse(td.transform)
+    d = td.dist
+    base = d._whiten_ops() + [(L.OP_STDNORMAL_LOGPDF, None, None)]
+    if reference_shape:
+        x, lj = with_logabsdet_jacobian(ib, y)
+        if isinstance(lj, PlanarResult) or hasattr(x, "result"):
+            x, lj = x.result, x.logabsdetjac
+        lp = _run_chain(base, x, True, True, store=False)[1]
+        return lp + lj
+    ops = _fused_ops(ib)
+    if ops is not None and len(ops) + len(base) <= L.BJX_MAX_OPS:
+        return _run_chain(list(ops) + base, y, True, True, store=False)[1]
+    pl = ib.orig if isinstance(ib, Inverse) else None
+    if isinstance(pl, PlanarLayer) and d.mu is None and d.sigma is None:
+        return pl._run(y, True, True, True, flags=L.BJX_BASE_STDNORMAL, store=False)[1]
+    x, lj = ib._wlj(y, per_sample=True)
+    return _run_chain(base, x, True, True, store=False)[1] + lj
+
+
+def rand(td: TransformedDistribution, n: int, seed: int = 0, device=None, dtype=torch.float32, col0: int = 0):
+    """`rand(rng, td::MvTransformed, n)` (src/transformed_distribution.jl:214-224: sample the base, push every
+    column through the transform): base samples from the counter-based generator of bjx_fill_normal (identical
+    for any shard count: keyed by seed, global column and row), colouring μ + σ·z fused into the transform's
+    chain when there is one."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    dim = td.dist.dim
+    z = torch.empty((n, dim), dtype=dtype, device=device).T
+    ctx = context(device)
+    L.check(ctx.h, L.load().bjx_fill_normal(ctx.h, _dt(z), _ptr(z), dim, n, col0, seed, 0.0, 1.0), "bjx_fill_normal")
+    color = td.dist._color_ops()
+    ops = _fused_ops(td.transform)
+    if ops is not None and len(ops) + len(color) <= L.BJX_MAX_OPS:
+        return _run_chain(color + list(ops), z, False, False, out_y=z)[0]
+    if color:
+        _run_chain(color, z, False, False, out_y=z)
+    return transform(td.transform, z)

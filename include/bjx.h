@@ -60,7 +60,13 @@ enum {
    * returns sum_i log|a_i| (NOT multiplied by N).  With this flag the chain's `ladj_sum`
    * reproduces that value; without it the mathematically consistent N * sum_i log|a_i| is
    * returned.  `ladj_ps` is always the true per-sample value. */
-  BJX_REF_VECTOR_SCALE_LADJ = 1u << 1
+  BJX_REF_VECTOR_SCALE_LADJ = 1u << 1,
+  /* SURVEY.md §8(f) f-3 — logpdf(td::MvTransformed, Y) in ONE pass (src/transformed_distribution.jl:164-169,
+   * "TODO: implement more efficiently for flows"): add the standard-normal log-density of every OUTPUT column,
+   * -1/2 |out|^2 - dim/2 log(2 pi), to ladj_ps / ladj_sum.  With the inverse flow as the bijector the call
+   * returns logpdf(td, y) per column; `out` may then be NULL (the pre-image is not stored: half the traffic).
+   * Honoured by bjx_chain (same as appending BJX_OP_STDNORMAL_LOGPDF) and bjx_planar. */
+  BJX_BASE_STDNORMAL = 1u << 2
 };
 
 /* ---------------------------------------------------------------- context */
@@ -97,7 +103,12 @@ typedef enum {
   BJX_OP_TRUNCATED = 9,      /* TruncatedBijector(lb,ub)          truncated.jl:15-31,51-67    */
   BJX_OP_TRUNCATED_INV = 10, /* Inverse{TruncatedBijector}        truncated.jl:33-49,71-91    */
   BJX_OP_SIGNFLIP = 11,      /* SignFlip                ordered.jl:3                          */
-  BJX_OP_IDENTITY = 12
+  BJX_OP_IDENTITY = 12,
+  /* not a bijector: leaves the value unchanged and adds log N(v; 0, 1) = -v^2/2 - log(2 pi)/2 to the log-det
+   * accumulator — the base density of a TransformedDistribution evaluated inside the same pass
+   * (src/transformed_distribution.jl:165-169).  A diagonal MvNormal(mu, sigma) base is
+   * SHIFT(-mu), SCALE_INV(sigma), STDNORMAL_LOGPDF (the -sum log sigma comes from SCALE_INV's log-det). */
+  BJX_OP_STDNORMAL_LOGPDF = 13
 } bjx_op_kind;
 
 typedef struct {

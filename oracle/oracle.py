@@ -540,3 +540,16 @@ def batchnorm_train(b, logs, m, v, eps, mtm, x):
     result = s[:, None] * (x - mbT[:, None]) / np.sqrt(vbT + T.type(eps))[:, None] + b[:, None]   # :66
     ladj = np.full(n, (logs - np.log(vbT + T.type(eps)) / 2).sum(), dtype=T)                     # :67
     return result, ladj, m_new, v_new
+
+
+# ------------------------------------------------------------------ SURVEY.md §8(f) f-3
+def mvnormal_diag_logpdf(x, mu=None, sigma=None):
+    """Per-column log-density of MvNormal(mu, Diagonal(sigma.^2)) — the `logpdf(td.dist, x)` term of
+    src/transformed_distribution.jl:165-169 for the diagonal-normal bases the flows use (the density itself
+    lives in Distributions.jl, un-vendored; this is its textbook formula).  numpy, float64 accumulation."""
+    x = np.asarray(x, dtype=np.float64)
+    d = x.shape[0]
+    m = np.zeros(d) if mu is None else np.asarray(mu, dtype=np.float64).reshape(-1)
+    s = np.ones(d) if sigma is None else np.asarray(sigma, dtype=np.float64).reshape(-1)
+    z = (x - m[:, None]) / s[:, None]
+    return -0.5 * np.sum(z * z, axis=0) - np.sum(np.log(s)) - 0.5 * d * np.log(2.0 * np.pi)

@@ -150,6 +150,12 @@ def main():
     rows.append(("vjp(inverse(SimplexBijector)) K=64", "f-1", lambda: bj.vjp(bj.inverse(sb_), ys, gxs, lbs), 4 * (d - 1 + d + d - 1) + 4, Ns))
     rows.append(("vjp(Stacked(exp|Logit|identity|exp∘Shift∘Scale)) d=64", "f-1", lambda: bj.vjp(stk, xst, gb, lbar), 3 * d * 4 + 4, N))
 
+    # §8(f) f-3: logpdf(td, Y) fused into the inverting kernel — Y is read once, x is never stored
+    td_pl = bj.transformed(bj.MvNormal(dp), flow)
+    rows.append(("logpdf(transformed(MvNormal(128), 8×PlanarLayer)) d=128", "f-3", lambda: bj.logpdf(td_pl, zf), 4 * dp + 4, Np))
+    td_ch = bj.transformed(bj.MvNormal(torch.zeros(d, device=dev), torch.ones(d, device=dev)), e(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5))
+    rows.append(("logpdf(transformed(MvNormal(μ,σ), exp∘Shift∘Scale)) d=64", "f-3", lambda: bj.logpdf(td_ch, xpos), 4 * d + 4, N))
+
     only = [s for s in a.only.split(",") if s]
     L, ctx = bj._lib, bj.context(dev)
     lib = L.load()

@@ -903,3 +903,76 @@ def test_simplex_extreme_unconstrained_values_stay_finite(bj, dt):
     np.testing.assert_allclose(xh.sum(axis=0), 1.0, atol=1e-6)
     yb, lb = bj.with_logabsdet_jacobian(bj.SimplexBijector(), x, per_sample=True)     # and back: finite as well
     assert np.isfinite(host(yb)).all() and np.isfinite(host(lb)).all()
+
+
+# ------------------------------------------------------------------ §8(f) f-3: logpdf / rand of a TransformedDistribution
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,N,base", [(64, 300, "std"), (64, 257, "diag"), (5, 100, "diag"), (130, 33, "std")])
+def test_logpdf_transformed_chain(bj, orc, dim, N, base, dt):
+    """logpdf(transformed(MvNormal, exp∘Shift∘Scale), Y) in one launch (src/transformed_distribution.jl:165-169)."""
+    r = rng(71)
+    mu = r.normal(size=dim).astype(dt) if base == "diag" else None
+    sg = np.exp(0.3 * r.normal(size=dim)).astype(dt) if base == "diag" else None
+    dist = bj.MvNormal(dim) if base == "std" else bj.MvNormal(torch.tensor(mu), torch.tensor(sg))
+    b = bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5)
+    td = bj.transformed(dist, b)
+    Y = np.asfortranarray(np.exp(0.5 * r.normal(size=(dim, N)) + 0.1).astype(dt))
+    inv_ops = [(orc.OP_LOG, None, None), (orc.OP_SHIFT, -0.1, None), (orc.OP_SCALE_INV, 0.5, None)]
+    ref = np.empty(N)
+    for n in range(N):
+        x, lj = orc.chain(inv_ops, Y[:, n:n + 1])
+        ref[n] = orc.mvnormal_diag_logpdf(x, mu, sg)[0] + float(lj)
+    got = host(bj.logpdf(td, dev(Y)))
+    assert got.shape == (N,)
+    np.testing.assert_allclose(got, ref, rtol=RTOL[dt], atol=ATOL[dt] * dim)
+    # the reference's literal `+`: per-column base density + ONE scalar log-det for the whole matrix
+    x_all, lj_all = orc.chain(inv_ops, Y)
+    ref_q = orc.mvnormal_diag_logpdf(x_all, mu, sg) + float(lj_all)
+    got_q = host(bj.logpdf(td, dev(Y), reference_shape=True))
+    np.testing.assert_allclose(got_q, ref_q, rtol=RTOL[dt] * 10, atol=ATOL[dt] * dim * N)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,nl,N", [(128, 8, 300), (64, 3, 129), (20, 1, 77), (7, 2, 50), (200, 2, 40)])
+def test_logpdf_transformed_planar(bj, orc, dim, nl, N, dt):
+    """Flow density on a batch: the inverse flow and the base density in one kernel, x never stored."""
+    r = rng(72)
+    w = (r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(dt)
+    u = (r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(dt)
+    b = r.normal(size=nl).astype(dt)
+    flow = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(b))
+    Y = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    x = Y.copy()
+    lj = np.zeros(N)
+    for k in range(nl - 1, -1, -1):
+        x, l = orc.planar(w[:, k], u[:, k], b[k:k + 1], x, inverse=True)
+        lj += l.astype(np.float64)
+    ref = orc.mvnormal_diag_logpdf(x) + lj
+    got = host(bj.logpdf(bj.transformed(bj.MvNormal(dim), flow), dev(Y)))
+    np.testing.assert_allclose(got, ref, rtol=RTOL[dt] * 5, atol=ATOL[dt] * dim)
+    # non-standard base: inverse flow, then the whitening + density chain on its output
+    mu, sg = r.normal(size=dim).astype(dt), np.exp(0.2 * r.normal(size=dim)).astype(dt)
+    got2 = host(bj.logpdf(bj.transformed(bj.MvNormal(torch.tensor(mu), torch.tensor(sg)), flow), dev(Y)))
+    np.testing.assert_allclose(got2, orc.mvnormal_diag_logpdf(x, mu, sg) + lj, rtol=RTOL[dt] * 5, atol=ATOL[dt] * dim)
+
+
+def test_logpdf_transformed_structured_and_rand(bj, orc):
+    dt = np.float64
+    r = rng(73)
+    dim, N = 16, 200
+    td = bj.transformed(bj.MvNormal(dim), bj.OrderedBijector())
+    Y = np.asfortranarray(np.sort(r.normal(size=(dim, N)), axis=0))
+    x, lj = orc.ordered(Y, inverse=True)
+    np.testing.assert_allclose(host(bj.logpdf(td, dev(Y))), orc.mvnormal_diag_logpdf(x) + lj, rtol=1e-9, atol=1e-9)
+    # rand: base samples from the counter-based generator, pushed through the transform
+    mu, sg = r.normal(size=dim), np.exp(0.2 * r.normal(size=dim))
+    tdc = bj.transformed(bj.MvNormal(torch.tensor(mu), torch.tensor(sg)), bj.elementwise(bj.exp) @ bj.Shift(0.25))
+    S = bj.rand(tdc, 4096, seed=5, dtype=torch.float64)
+    assert tuple(S.shape) == (dim, 4096) and bool((S > 0).all())
+    z = (np.log(host(S)) - 0.25 - mu[:, None]) / sg[:, None]        # pull back to the standard normal
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
+    S2 = bj.rand(tdc, 1024, seed=5, dtype=torch.float64, col0=1024)   # shard-count independence: columns 1024..2047
+    assert np.array_equal(host(S2), host(S)[:, 1024:2048])
+    lp = host(bj.logpdf(tdc, S))
+    ref = orc.mvnormal_diag_logpdf(np.log(host(S)) - 0.25, mu, sg) - np.log(host(S)).sum(axis=0)
+    np.testing.assert_allclose(lp, ref, rtol=1e-9, atol=1e-8)
