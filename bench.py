@@ -130,7 +130,7 @@ def make_workload(name, bj, torch, device, rank, world, log2_batch):
         def step():
             return bj.shard.with_logabsdet_jacobian_sharded(b, x)[2]
 
-        return dict(step=step, samples=N, bytes_per_sample=K * 4 + (K - 1) * 4 + 4, kernel="simplex_fwd_stream_kernel", dtype="f32",
+        return dict(step=step, samples=N, bytes_per_sample=K * 4 + (K - 1) * 4 + 4, kernel="quad_stream_kernel<QSimplexFwd>", dtype="f32",
                     label=f"SimplexBijector fwd+logabsdetjac Float32 K={K} batch=2^{lb}/GPU",
                     cfg={"workload": "SimplexBijector (BASELINE configs[4], first half)", "K": K, "batch_per_gpu": N})
     if name == "c5b":

@@ -859,9 +859,14 @@ int bn_train_impl(bjx_ctx* ctx, const T* b, const T* logs, T* m, T* v, T eps, T 
   const int cols_per_block = 256 / c.G;
   int nblocks = (int)((batch + cols_per_block * 16 - 1) / (cols_per_block * 16));     // >= 16 columns per lane group
   if (nblocks > 1024) nblocks = 1024;
-  if (nblocks < 1) nblocks = 1;
   // scratch: [stats 2 dim + 1][partials nblocks*dim*2] doubles, then batch m / v (T)
   const size_t stats_n = 2 * (size_t)dim + 1;
+  {
+    const size_t fixed = (stats_n + 1) * sizeof(double) + 2 * (size_t)dim * sizeof(T);
+    const size_t fit = fixed < BJX_SCRATCH_BYTES ? (BJX_SCRATCH_BYTES - fixed) / ((size_t)dim * 2 * sizeof(double)) : 0;
+    if ((size_t)nblocks > fit) nblocks = (int)fit;      // fewer, longer blocks: the slabs of partial sums live in the context scratch
+  }
+  if (nblocks < 1) nblocks = 1;
   const size_t part_n = (size_t)nblocks * dim * 2;
   const size_t bytes = (stats_n + 1 + part_n) * sizeof(double) + 2 * (size_t)dim * sizeof(T);
   BJX_REQUIRE(ctx, bytes <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_batchnorm_train: scratch too small for %lld channels", (long long)dim);

@@ -15,6 +15,7 @@ using Bijectors: Elementwise, Inverse, Shift, Scale, Logit, LeakyReLU, Truncated
     SimplexBijector, VecCholeskyBijector, Permute, PlanarLayer, RadialLayer, InvertibleBatchNorm,
     RationalQuadraticSpline, Stacked
 using ChainRulesCore: ChainRulesCore
+using Distributions: Distributions
 const ROCVecOrMat{T} = Union{ROCVector{T},ROCMatrix{T}}
 import Bijectors: transform, logabsdetjac, with_logabsdet_jacobian, with_logabsdet_jacobian!
 
@@ -251,6 +252,33 @@ function ChainRulesCore.rrule(::typeof(Bijectors._inv_link_chol_lkj), y::ROCMatr
         return ChainRulesCore.NoTangent(), Δy
     end
     return (W, logJ), pullback_inv_link_chol_lkj
+end
+
+# ---------------------------------------------------------------- logpdf of a TransformedDistribution (SURVEY.md §8f f-3)
+# src/transformed_distribution.jl:164-169 in ONE pass over y: the inverse chain, the whitening of the diagonal-normal
+# base and the standard-normal density are ops of the same launch; the pre-image is not stored (y pointer = C_NULL).
+const OP_STDNORMAL_LOGPDF = 13
+const BJX_BASE_STDNORMAL = UInt32(1) << 2
+function Distributions.logpdf(td::Bijectors.MvTransformed{<:Distributions.MvNormal}, y::ROCMatrix{T}) where {T<:Union{Float32,Float64}}
+    Σ = td.dist.Σ
+    Σ isa Union{Distributions.PDMats.PDiagMat,Distributions.PDMats.ScalMat} || return invoke(Distributions.logpdf, Tuple{Bijectors.MvTransformed,AbstractMatrix}, td, y)
+    keep = Any[]
+    o = ops(inverse(td.transform), T, keep)
+    d, n = dims(y)
+    lp = similar(y, n)
+    μ, σ = td.dist.μ, sqrt.(Array(Distributions.PDMats.diag(Σ)))
+    if o !== nothing && length(o) + 3 <= 8
+        o = vcat(o, param_op(OP_SHIFT, -μ, T, keep), param_op(OP_SCALE_INV, σ, T, keep),
+                 BjxOp(Int32(OP_STDNORMAL_LOGPDF), 0, 0, 0, C_NULL, C_NULL))
+        GC.@preserve keep y lp check(ccall((:bjx_chain, libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{BjxOp}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+            ctx().h, dtype(T), o, length(o), devptr(y), C_NULL, devptr(lp), C_NULL, d, n, UInt32(0)), "bjx_chain")
+        return lp
+    end
+    # PlanarLayer stacks with a standard-normal base: bjx_planar(inverse = 1, out = C_NULL, flags = BJX_BASE_STDNORMAL);
+    # anything else: x, logjac = with_logabsdet_jacobian(inverse(td.transform), y), then the 3-op density chain on x.
+    x, logjac = with_logabsdet_jacobian(inverse(td.transform), y)
+    return Distributions.logpdf(Bijectors.transformed(td.dist), x) .+ logjac
 end
 
 # ---------------------------------------------------------------- multi-GPU (one process per GPU)

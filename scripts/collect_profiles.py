@@ -14,7 +14,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOMINANT = {"c2": ["chain_flat_kernel"], "c2v": ["chain_flat_kernel"], "c3": ["rqs_lds_kernel"], "c4": ["planar_reg_kernel"],
-            "c5a": ["simplex_fwd_stream_kernel"], "c5b": ["chol_inv_chunk_kernel"]}
+            "c5a": ["quad_stream_kernel"], "c5b": ["chol_inv_chunk_kernel"]}
 
 
 def main(tag):

@@ -809,7 +809,7 @@ def test_simplex_vjp(bj, orc, K, N, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("dim,N", [(2, 20), (64, 3000), (5, 257), (130, 64)])
+@pytest.mark.parametrize("dim,N", [(2, 20), (64, 3000), (5, 257), (130, 64), (64, 300000)])   # the last: more slabs than the scratch holds
 def test_batchnorm_training_mode(bj, orc, dim, N, dt):
     """normalise.jl:51-60: batch statistics in the transform and the log-det, moving statistics updated in place."""
     r = rng(62)
