@@ -1551,9 +1551,24 @@ __global__ __launch_bounds__(64) void simplex_vjp_kernel(const T* __restrict__ i
   tile_stage_out<T, V>(tb, in_bar + col0 * rows_in, rows_in, P, ncols, lane);
 }
 
+template <class T, int G>
+int launch_simplex_vjp_stream(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch, bool* taken);
+
 template <class T>
 int simplex_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
   if (batch == 0) return BJX_OK;
+  {
+    bool taken = false;
+    static const int g_inv = getenv("BJX_SIMPLEX_VJP_G") ? atoi(getenv("BJX_SIMPLEX_VJP_G")) : 2;
+    int rc;
+    if (!inverse || g_inv == 4) rc = launch_simplex_vjp_stream<T, 4>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch, &taken);
+    else rc = launch_simplex_vjp_stream<T, 2>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch, &taken);
+    if (rc || taken) return rc;
+    if (inverse && g_inv != 4) {         // K not a multiple of 2·V·{1,2,4,8}: try four lanes per column
+      rc = launch_simplex_vjp_stream<T, 4>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch, &taken);
+      if (rc || taken) return rc;
+    }
+  }
   const int64_t P = K | 1;
   const size_t smem = ((size_t)2 * 64 * P + (size_t)K) * sizeof(T);
   BJX_REQUIRE(ctx, smem <= BJX_LDS_MAX, BJX_ERR_UNSUPPORTED, "bjx_simplex_vjp: K = %lld too large for the LDS tiles", (long long)K);
@@ -1901,6 +1916,264 @@ int launch_quad_stream(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_
     if (Op::HAS_LADJ) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
     if (!(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
   }
+  return BJX_OK;
+}
+
+// ---- the re-deal of quad_stream_kernel as reusable pieces (kernels with more than one input run)
+template <class T, int V, int NP, int G> struct QuadStrip {
+  static constexpr int RPL = NP * V, R = G * RPL, CPS = 64 / G, PITCH = R + V, PPC = G * NP;
+  static constexpr int npk(int less) { return CPS * (R - less) / V; }
+  static constexpr int nl(int less) { return (npk(less) + 63) / 64; }
+  static constexpr int NLMAX = (CPS * R / V + 63) / 64;
+  // coalesced loads of one wave instruction's run of (R - LESS)-row columns starting at column colw
+  template <int LESS> static __device__ __forceinline__ void load(Pack<T, V> (&raw)[NLMAX], const T* __restrict__ x, int64_t colw, int64_t batch, int lane) {
+    constexpr int RI = R - LESS;
+    const int64_t left = batch - colw;
+    const int64_t ne = left >= CPS ? (int64_t)CPS * RI : (left > 0 ? left * RI : 0);
+#pragma unroll
+    for (int q = 0; q < nl(LESS); ++q) {
+      const int pk = lane + 64 * q;
+      const T* src = x + colw * RI + (int64_t)pk * V;
+      if ((int64_t)(pk + 1) * V <= ne) raw[q] = load_pack<T, V, true>(src);
+      else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) raw[q].v[j] = (int64_t)pk * V + j < ne ? src[j] : T(0);
+      }
+    }
+  }
+  // run -> rows gl·RPL .. gl·RPL+RPL-1 of column cg (the frame's missing last row reads as 0)
+  template <int LESS> static __device__ __forceinline__ void deal_in(T* st, const Pack<T, V> (&raw)[NLMAX], T (&xv)[RPL], int lane) {
+    constexpr int RI = R - LESS;
+    const int gl = lane & (G - 1), cg = lane / G;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < nl(LESS); ++q) {
+      const int pk = lane + 64 * q;
+      if (npk(LESS) % 64 == 0 || pk < npk(LESS)) {
+        if constexpr (LESS == 0) {
+          *reinterpret_cast<typename Vec16<T>::type*>(st + (pk / PPC) * PITCH + (pk % PPC) * V) = __builtin_bit_cast(typename Vec16<T>::type, raw[q]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) { const int el = pk * V + j; st[(el / RI) * PITCH + el % RI] = raw[q].v[j]; }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const Pack<T, V> pq = __builtin_bit_cast(Pack<T, V>, *reinterpret_cast<const typename Vec16<T>::type*>(st + cg * PITCH + (gl * NP + q) * V));
+#pragma unroll
+      for (int j = 0; j < V; ++j) xv[q * V + j] = pq.v[j];
+    }
+    if (LESS) { if (gl == G - 1) xv[RPL - 1] = T(0); }
+  }
+  template <int LESS> static __device__ __forceinline__ void deal_out(T* st, const T (&xv)[RPL], T* __restrict__ y, int64_t colw, int64_t batch, int lane) {
+    constexpr int RO = R - LESS;
+    const int gl = lane & (G - 1), cg = lane / G;
+    if (colw + CPS <= batch) {
+      __builtin_amdgcn_wave_barrier();
+      if constexpr (LESS == 0) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          Pack<T, V> pq;
+#pragma unroll
+          for (int j = 0; j < V; ++j) pq.v[j] = xv[q * V + j];
+          *reinterpret_cast<typename Vec16<T>::type*>(st + cg * PITCH + (gl * NP + q) * V) = __builtin_bit_cast(typename Vec16<T>::type, pq);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) { const int r = gl * RPL + i; if (r < RO) st[cg * RO + r] = xv[i]; }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < nl(LESS); ++q) {
+        const int pk = lane + 64 * q;
+        if (npk(LESS) % 64 == 0 || pk < npk(LESS)) {
+          const T* src = LESS == 0 ? st + (pk / PPC) * PITCH + (pk % PPC) * V : st + pk * V;
+          const Pack<T, V> pq = __builtin_bit_cast(Pack<T, V>, *reinterpret_cast<const typename Vec16<T>::type*>(src));
+          store_pack<T, V, true>(y + colw * RO + (int64_t)pk * V, pq);
+        }
+      }
+    } else if (colw + cg < batch) {
+#pragma unroll
+      for (int i = 0; i < RPL; ++i) { const int r = gl * RPL + i; if (r < RO) y[(colw + cg) * RO + r] = xv[i]; }
+    }
+  }
+};
+template <int G> __device__ __forceinline__ float quad_from_right(float v) {
+  if constexpr (G == 4) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xF9, 0xF, 0xF, true));   // quad_perm [1,2,3,3]
+  else return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xF5, 0xF, 0xF, true));                   // quad_perm [1,1,3,3]
+}
+template <int G> __device__ __forceinline__ double quad_from_right(double v) {
+  const int lane = threadIdx.x & 63;
+  return __shfl(v, lane < 63 ? lane + 1 : 63, 64);
+}
+// exclusive scans over the G lanes of a column group (ascending / descending lane order)
+template <int G, class T> __device__ __forceinline__ T group_excl_up(T v, int gl) {
+  T inc = v;
+#pragma unroll
+  for (int d = 1; d < G; d <<= 1) { const T t = __shfl_up(inc, d, G); if (gl >= d) inc += t; }
+  return inc - v;
+}
+template <int G, class T> __device__ __forceinline__ T group_excl_down(T v, int gl) {
+  T inc = v;
+#pragma unroll
+  for (int d = 1; d < G; d <<= 1) { const T t = __shfl_down(inc, d, G); if (gl + d < G) inc += t; }
+  return inc - v;
+}
+
+// ------------------------------------------------------------------ SimplexBijector pullbacks, streaming kernel
+// Same math as simplex_vjp_kernel below/above (O(K) reverse sweeps of simplex.jl:47-64, :102-120, :122-138) in the
+// G-lanes-per-column register layout: the two whole-column LDS tiles of that kernel allow ONE wave per SIMD (30-36 %
+// of the HBM roofline).  Forward map: s_k and the suffix sums of the adjoint are plain scans (local + group scan —
+// a pullback has no reference summation order to keep).  Inverse map: the clamped recurrence is re-run in the
+// reference's order by the take-turns rounds of quad_stream_kernel, and the adjoint of Σ is the affine recurrence
+// sb <- B_k sb + A_k run the same way from the last lane down.
+template <class T, int V, int NP, int G, bool INV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void simplex_vjp_stream_kernel(const T* __restrict__ in, const T* __restrict__ out_bar,
+                                                                                                              const T* __restrict__ ladj_bar, T* __restrict__ in_bar,
+                                                                                                              int64_t batch) {
+  using F = Fast<T>;
+  using Q = QuadStrip<T, V, NP, G>;
+  constexpr int RPL = Q::RPL, R = Q::R, CPS = Q::CPS;
+  __shared__ __attribute__((aligned(16))) T strip[4][CPS * Q::PITCH];
+  __shared__ __attribute__((aligned(16))) T lktab[R];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gl = lane & (G - 1), cg = lane / G;
+  const int64_t colw = ((int64_t)blockIdx.x * 4 + wave) * CPS;
+  const int64_t col = colw + cg;
+  Pack<T, V> raw_a[Q::NLMAX], raw_g[Q::NLMAX];
+  Q::template load<INV ? 1 : 0>(raw_a, in, colw, batch, lane);
+  Q::template load<INV ? 0 : 1>(raw_g, out_bar, colw, batch, lane);
+  const T lb = (ladj_bar && col < batch) ? ladj_bar[col] : T(0);
+  if (INV) {
+    if ((int)threadIdx.x < R) lktab[threadIdx.x] = (int)threadIdx.x < R - 1 ? d_log(T(R - 1 - (int)threadIdx.x)) : T(0);
+    __syncthreads();
+  }
+  T* st = strip[wave];
+  T a[RPL], g[RPL];
+  Q::template deal_in<INV ? 1 : 0>(st, raw_a, a, lane);
+  Q::template deal_in<INV ? 0 : 1>(st, raw_g, g, lane);
+  const T e = Num<T>::eps;
+  const T c = T(1) / (T(1) - 2 * e), E = T(1) + e, c2 = T(1) - 2 * e;
+  if constexpr (!INV) {
+    // ---- pullback of x -> (y, logabsdetjac): a = x (K rows), g = ȳ (K-1 rows, frame row K-1 reads 0)
+    T tot = T(0);
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) tot += a[i];
+    T s = group_excl_up<G>(tot, gl);                                   // Σ of the rows before my first one
+    T as_[RPL];
+    T asum = T(0);
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+      const bool row0 = i == 0 && gl == 0;
+      const bool rowK = i == RPL - 1 && gl == G - 1;
+      const T xk = a[i];
+      T dtdx, dtds;
+      simplex_t_partials<T>(xk, s, false, dtdx, dtds);
+      T dtdx0, dtds0;
+      if (i == 0) { simplex_t_partials<T>(xk, s, true, dtdx0, dtds0); dtdx = row0 ? dtdx0 : dtdx; dtds = row0 ? T(0) : dtds; }
+      const T rd = row0 ? T(1) : F::rcp(E - s);
+      const T an = row0 ? xk * c2 + e : (xk + e) * c2;               // zf = an·rd
+      const T zf = an * rd;
+      const T zfb = g[i] * F::rcp(zf * (T(1) - zf));
+      const T ax = zfb * c2 * rd - lb * dtdx;
+      const T asv = row0 ? T(0) : zfb * an * rd * rd - lb * dtds;
+      a[i] = rowK ? T(0) : ax;
+      as_[i] = rowK ? T(0) : asv;
+      asum += as_[i];
+      s += xk;
+    }
+    T sfx = group_excl_down<G>(asum, gl);                              // Σ as over the rows after my last one
+#pragma unroll
+    for (int i = RPL - 1; i >= 0; --i) { a[i] += sfx; sfx += as_[i]; }
+    Q::template deal_out<0>(st, a, in_bar, colw, batch, lane);
+  } else {
+    // ---- pullback of y -> (x, logabsdetjac): a = y (K-1 rows), g = x̄ (K rows)
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) a[i] = f_logistic(a[i] - lktab[gl * RPL + i]) * c;   // c·z_k
+    T carry = T(0);
+#pragma unroll
+    for (int t = 0; t < G - 1; ++t) {
+      T s = carry;
+#pragma unroll
+      for (int i = 0; i < RPL; ++i) {
+        const bool row0 = i == 0 && gl == 0;
+        const T xi = row0 ? d_clamp(a[i] - e * c, T(0), T(1)) : d_clamp((E - s) * a[i] - e, T(0), T(1));
+        s += xi;
+      }
+      const T bc = quad_from_left<G>(s);
+      carry = gl == 0 ? T(0) : bc;
+    }
+    T xk[RPL], A[RPL], B[RPL];
+    T s = carry;
+    T sb0 = T(0);
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+      const bool row0 = i == 0 && gl == 0;
+      const bool rowK = i == RPL - 1 && gl == G - 1;
+      const T xi = row0 ? d_clamp(a[i] - e * c, T(0), T(1)) : d_clamp((E - s) * a[i] - e, T(0), T(1));
+      T dtdx, dtds;
+      simplex_t_partials<T>(xi, s, false, dtdx, dtds);
+      if (i == 0) { T d0, d1; simplex_t_partials<T>(xi, s, true, d0, d1); dtdx = row0 ? d0 : dtdx; dtds = row0 ? T(0) : dtds; }
+      const bool gate = xi > T(0) && xi < T(1);
+      const T rc = (E - s) * c;
+      const T z = row0 ? xi * c2 + e : (xi + e) * F::rcp(rc);
+      const T cz = (gate && !row0) ? c * z : T(0);
+      // sb_next = B sb + A ;  ȳ = gate (g + sb_in + lb dtdx) w,  w = rc z (1-z)  (row 0: c z (1-z))
+      B[i] = rowK ? T(1) : T(1) - cz;
+      A[i] = rowK ? T(0) : lb * dtds - cz * (g[i] + lb * dtdx);
+      xk[i] = gate ? (row0 ? c : rc) * z * (T(1) - z) : T(0);          // w_k (0 where the clamp is active)
+      if (rowK) { const T last = T(1) - s; sb0 = (last > T(0) && last < T(1)) ? -g[i] : T(0); }
+      g[i] = g[i] + lb * dtdx;                                         // g + lb dtdx
+      s += xi;
+    }
+    // adjoint of Σ, from the last row down: the lanes take turns from the right
+    T cin = gl == G - 1 ? sb0 : T(0);
+#pragma unroll
+    for (int t = 0; t < G - 1; ++t) {
+      T sb = cin;
+#pragma unroll
+      for (int i = RPL - 1; i >= 0; --i) sb = B[i] * sb + A[i];
+      const T bc = quad_from_right<G>(sb);
+      cin = gl == G - 1 ? sb0 : bc;
+    }
+    T sb = cin;
+#pragma unroll
+    for (int i = RPL - 1; i >= 0; --i) {
+      a[i] = (g[i] + sb) * xk[i];
+      sb = B[i] * sb + A[i];
+    }
+    Q::template deal_out<1>(st, a, in_bar, colw, batch, lane);
+  }
+}
+
+template <class T, int G>
+int launch_simplex_vjp_stream(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch, bool* taken) {
+  constexpr int VW = Vec16<T>::N;
+  *taken = false;
+  static const int use_stream = getenv("BJX_SIMPLEX_VJP_STREAM") ? atoi(getenv("BJX_SIMPLEX_VJP_STREAM")) : 1;
+  const int64_t np = K / (G * VW);
+  constexpr int NPMAX = 16 / G;
+  if (!use_stream || batch <= 0 || K % (G * VW) != 0 || np < 1 || np > NPMAX || (np != 1 && np != 2 && np != 4 && np != 8) || !bjx_aligned16(in) || !bjx_aligned16(out_bar) || !bjx_aligned16(in_bar)) return BJX_OK;
+  *taken = true;
+  const int64_t cpb = 4 * (64 / G);
+  const int64_t grid = (batch + cpb - 1) / cpb;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+#define SVS(NP_, I_) hipLaunchKernelGGL((simplex_vjp_stream_kernel<T, VW, NP_, G, I_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out_bar, ladj_bar, in_bar, batch)
+#define SVS_I(NP_) do { if (inverse) SVS(NP_, true); else SVS(NP_, false); } while (0)
+  {
+    BjxProf prof_(ctx);
+    switch ((int)np) {
+      case 1: SVS_I(1); break;
+      case 2: SVS_I(2); break;
+      case 4: if constexpr (NPMAX >= 4) SVS_I(4); break;
+      case 8: if constexpr (NPMAX >= 8) SVS_I(8); break;
+    }
+  }
+#undef SVS_I
+#undef SVS
+  BJX_CHECK_LAUNCH(ctx);
   return BJX_OK;
 }
 

@@ -279,7 +279,11 @@ def transform(b, x):
 
 
 def logabsdetjac(b, x):
-    """src/interface.jl:183-192"""
+    """src/interface.jl:183-192.  For ONE fusable elementwise chain the values are not stored at all
+    (bjx_chain with y = NULL: the input is read once, half the traffic of the fused pair)."""
+    ops = _fused_ops(b)
+    if ops is not None:
+        return _run_chain(ops, x, False, True, store=False)[1]
     return _shape_result(b, *b._wlj(x, per_sample=False))[1]
 
 

@@ -156,6 +156,9 @@ def main():
     td_ch = bj.transformed(bj.MvNormal(torch.zeros(d, device=dev), torch.ones(d, device=dev)), e(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5))
     rows.append(("logpdf(transformed(MvNormal(μ,σ), exp∘Shift∘Scale)) d=64", "f-3", lambda: bj.logpdf(td_ch, xpos), 4 * d + 4, N))
 
+    c2b = e(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5)
+    rows.append(("logabsdetjac(exp∘Shift∘Scale) alone (values not stored)", "a1,a5", lambda: bj.logabsdetjac(c2b, x), 4 * d, N))
+
     only = [s for s in a.only.split(",") if s]
     L, ctx = bj._lib, bj.context(dev)
     lib = L.load()

@@ -790,7 +790,7 @@ def test_columnwise_returns_the_sum_over_columns(bj, orc):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("K,N", [(2, 7), (5, 100), (64, 130), (33, 64)])
+@pytest.mark.parametrize("K,N", [(2, 7), (5, 100), (64, 130), (33, 64), (8, 50), (16, 333), (32, 77), (64, 4099)])   # 8/16/32/64: streaming kernels, ragged runs
 def test_simplex_vjp(bj, orc, K, N, dt):
     r = rng(54)
     lbar = r.normal(size=N).astype(dt)
