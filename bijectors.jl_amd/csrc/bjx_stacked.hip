@@ -166,8 +166,65 @@ template <class T> __device__ __forceinline__ T slot_eval(const Slot<T>& s, T& x
   return l;
 }
 
+// the same slot on the U elements a lane holds at one row (U columns in flight): one fetch of the slot and ONE
+// pass through the per-lane switch for U elements — lanes of a wave hold different kinds, so every kind present in
+// the wave is executed serially; amortising that over the columns in flight is what this buys.
+template <class T, int U> __device__ __forceinline__ void slot_eval_multi(const Slot<T>& s, T (&x)[U], T (&l)[U]) {
+  using F = Fast<T>;
+  T u[U], v[U];
+#pragma unroll
+  for (int i = 0; i < U; ++i) { u[i] = s.a1 * d_med3(x[i], s.clo, s.chi) + s.b1; v[i] = u[i]; l[i] += s.c; }
+  switch (s.kind) {
+    case SK_EXP:
+#pragma unroll
+      for (int i = 0; i < U; ++i) { v[i] = F::exp(u[i]); l[i] += u[i]; }
+      break;
+    case SK_LOG:
+#pragma unroll
+      for (int i = 0; i < U; ++i) { v[i] = F::log(u[i]); l[i] -= v[i]; }
+      break;
+    case SK_LOGIT:
+#pragma unroll
+      for (int i = 0; i < U; ++i) { l[i] -= F::log(u[i] * (T(1) - u[i])); v[i] = F::log(u[i] * F::rcp(T(1) - u[i])); }
+      break;
+    case SK_LOGISTIC:
+#pragma unroll
+      for (int i = 0; i < U; ++i) { const T au = d_abs(u[i]); v[i] = f_logistic(u[i]); l[i] += -au - T(2) * f_log1pexp(-au); }
+      break;
+    case SK_LEAKY:
+#pragma unroll
+      for (int i = 0; i < U; ++i) { const T J = u[i] < T(0) ? s.alpha : T(1); v[i] = J * u[i]; l[i] += d_log(d_abs(J)); }
+      break;
+    default: break;
+  }
+#pragma unroll
+  for (int i = 0; i < U; ++i) x[i] = d_med3(s.a2 * v[i] + s.b2, s.plo, s.phi);
+}
+
 template <class T, bool GATHER, bool IN_LDS> struct StackedF {
   static constexpr bool kLoadInput = !GATHER;
+  static constexpr bool kMulti = !GATHER;          // apply_multi: all columns in flight of a lane group at once
+  template <int V, int U> __device__ void apply_multi(const char* smem, Pack<T, V> (&p)[U], int64_t row, T (&l)[U]) const {
+    const char* t = IN_LDS ? smem : tab;
+    const int64_t nvc = dim / V;
+#pragma unroll
+    for (int i = 0; i < U; ++i) l[i] = T(0);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const Slot<T>* e = reinterpret_cast<const Slot<T>*>(t + (V > 1 ? j * nvc + row / V : row) * stacked_row_bytes<T>());
+      T x[U];
+#pragma unroll
+      for (int i = 0; i < U; ++i) x[i] = p[i].v[j];
+#pragma unroll 1
+      for (int q = 0; q < (two_slots ? STACKED_SLOTS : 1); ++q) {
+        const Slot<T> sq = e[q];
+        if (sq.kind == SK_END) break;
+        slot_eval_multi<T, U>(sq, x, l);
+      }
+#pragma unroll
+      for (int i = 0; i < U; ++i) p[i].v[j] = x[i];
+    }
+  }
   const char* tab;
   int64_t dim;
   int two_slots;

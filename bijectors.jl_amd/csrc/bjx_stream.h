@@ -25,6 +25,8 @@ constexpr int STREAM_U = 4;
 //       input packs so all loads of a lane are in flight at once; apply() then takes `const Aux&` after `p`
 template <class F, class = void> struct col_has_aux { static constexpr bool value = false; };
 template <class F> struct col_has_aux<F, decltype((void)sizeof(typename F::Aux))> { static constexpr bool value = true; };
+template <class F, class = void> struct col_has_multi { static constexpr bool value = false; };
+template <class F> struct col_has_multi<F, decltype((void)F::kMulti)> { static constexpr bool value = F::kMulti; };
 struct ColNoAux {};
 template <class F, bool H = col_has_aux<F>::value> struct col_aux_of { using type = ColNoAux; };
 template <class F> struct col_aux_of<F, true> { using type = typename F::Aux; };
@@ -56,12 +58,25 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
       if (F::kLoadInput && lane_ok && col < batch) p[u] = load_pack<T, V, NT>(x + col * dim + (int64_t)gl * V);
       if constexpr (col_has_aux<F>::value) { if (lane_ok && col < batch) aux[u] = f.template fetch<V>(fsm, (int64_t)gl * V, col); }
     }
+    T lm[COL_UC];
+    if constexpr (col_has_multi<F>::value) {
+      // optional `apply_multi<V,U>(smem, p[U], row, l[U])`: the COL_UC packs of a lane sit at the same rows
+      if (lane_ok) {
+        if (col0 + (int64_t)(COL_UC - 1) * cols_per_block >= batch) {      // ragged end: harmless inputs for the missing columns
+#pragma unroll
+          for (int u = 0; u < COL_UC; ++u)
+            if (col0 + (int64_t)u * cols_per_block >= batch) { p[u] = p[0]; }
+        }
+        if (col0 < batch) f.template apply_multi<V, COL_UC>(fsm, p, (int64_t)gl * V, lm);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < COL_UC; ++u) {
       const int64_t col = col0 + (int64_t)u * cols_per_block;
       T l = T(0);
       if (lane_ok && col < batch) {
-        if constexpr (col_has_aux<F>::value) l = f.template apply<V>(fsm, p[u], aux[u], x + col * dim, (int64_t)gl * V, col);
+        if constexpr (col_has_multi<F>::value) l = lm[u];
+        else if constexpr (col_has_aux<F>::value) l = f.template apply<V>(fsm, p[u], aux[u], x + col * dim, (int64_t)gl * V, col);
         else l = f.template apply<V>(fsm, p[u], x + col * dim, (int64_t)gl * V, col);
         store_pack<T, V, NT>(y + col * dim + (int64_t)gl * V, p[u]);
       }

@@ -619,6 +619,28 @@ def test_stacked_reference_examples(bj):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("N", [3, 1001, 4096])
+def test_stacked_pack_rows_ragged_batch(bj, orc, dt, N):
+    """dim = 64 (16-byte packs, four columns in flight per lane group evaluated together), batch not a multiple of the block's columns."""
+    r = rng(43)
+    segs = [
+        (bj.elementwise(bj.exp), [(orc.OP_EXP, None, None)], (1, 16)),
+        (bj.Logit(0.0, 1.0), [(orc.OP_LOGIT, 0.0, 1.0)], (17, 32)),
+        (bj.identity, [], (33, 47)),
+        (bj.inverse(bj.Logit(-1.0, 1.0)), [(orc.OP_LOGIT_INV, -1.0, 1.0)], (48, 49)),
+        (bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5), [(orc.OP_SCALE, 0.5, None), (orc.OP_SHIFT, 0.1, None), (orc.OP_EXP, None, None)], (50, 64)),
+    ]
+    X = r.normal(size=(64, N))
+    X[16:32] = r.uniform(0.05, 0.95, size=(16, N))
+    X = np.asfortranarray(X.astype(dt))
+    b = bj.Stacked([s[0] for s in segs], [s[2] for s in segs])
+    Y_ref, l_ref = _stacked_oracle(orc, [(s[1], s[2]) for s in segs], X)
+    Y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+    close(host(Y), Y_ref, dt, what="stacked d=64")
+    close(host(l), l_ref, dt, scale=64, what="stacked d=64 ladj")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("N", [1, 257])
 def test_stacked_elementwise_segments_one_launch(bj, orc, dt, N):
     r = rng(41)
