@@ -163,6 +163,88 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
   if (partials) block_publish_partial(acc, red, partials);
 }
 
+// ------------------------------------------------------------------ Planar input pullback, lanes kernel (any dtype / shape)
+// SURVEY.md §8(f) f-1.  z̄ = (∂y/∂z)ᵀ ȳ + ℓ̄ ∂logabsdetjac/∂z for the fused stack of planar_layer.jl:65-110:
+//   forward sweep:  s_k = w_kᵀz_{k-1} + b_k, t_k = tanh s_k (kept in LDS, [column][layer]), z_k = z_{k-1} + û_k t_k
+//   reverse sweep:  s̄_k = (û_kᵀz̄_k)(1 - t_k²) + ℓ̄ c_k(-2 t_k)(1 - t_k²)/(1 + c_k(1 - t_k²)),  z̄_{k-1} = z̄_k + w_k s̄_k
+// Same mapping as planar_kernel: G lanes own a column in registers; the primal column is dead once the t_k are
+// known, so ȳ is loaded into the same registers.
+template <class T, int V, int R>
+__global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, const T* __restrict__ x, const T* __restrict__ ybar,
+                                                         const T* __restrict__ lbar, T* __restrict__ xbar, int64_t dim, int64_t batch, int G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int cols_per_block = blockDim.x / G;
+  T* tsave = reinterpret_cast<T*>(smem);                                   // [cols_per_block][n_layers]
+  T* tab = tsave + (size_t)cols_per_block * A.n_layers;
+  const int64_t nld = (int64_t)A.n_layers * dim;
+  if (A.in_lds) {
+    for (int64_t i = threadIdx.x; i < nld; i += blockDim.x) { tab[i] = A.w[i]; tab[nld + i] = A.u_hat[i]; }
+    __syncthreads();
+  }
+  const T* W = A.in_lds ? tab : A.w;
+  const T* UH = A.in_lds ? tab + nld : A.u_hat;
+  const int gl = threadIdx.x & (G - 1), cl = threadIdx.x / G;
+  const int64_t nvc = dim / V;
+  const int64_t col_raw = (int64_t)blockIdx.x * cols_per_block + cl;
+  const bool col_ok = col_raw < batch;
+  const int64_t col = col_ok ? col_raw : batch - 1;
+  Pack<T, V> z[R];
+  auto load_col = [&](const T* base) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t v = gl + (int64_t)r * G;
+      if (v < nvc) z[r] = load_pack<T, V, true>(base + col * dim + v * V);
+      else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) z[r].v[j] = T(0);
+      }
+    }
+  };
+  auto dot = [&](const T* row) -> T {
+    T s = T(0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t v = gl + (int64_t)r * G;
+      if (v < nvc) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) s += row[v * V + j] * z[r].v[j];
+      }
+    }
+    return group_sum_rt(s, G);
+  };
+  auto axpy = [&](const T* row, T a) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t v = gl + (int64_t)r * G;
+      if (v < nvc) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) z[r].v[j] += row[v * V + j] * a;
+      }
+    }
+  };
+  load_col(x);
+  T* tmine = tsave + (size_t)cl * A.n_layers;
+  for (int l = 0; l < A.n_layers; ++l) {
+    const T t = d_tanh(dot(W + (int64_t)l * dim) + A.b[l]);
+    if (gl == 0) tmine[l] = t;
+    axpy(UH + (int64_t)l * dim, t);
+  }
+  __syncthreads();
+  load_col(ybar);
+  const T lb = lbar ? lbar[col] : T(0);
+  for (int l = A.n_layers - 1; l >= 0; --l) {
+    const T t = tmine[l], c = A.wtu_hat[l];
+    const T q = T(1) - t * t;
+    const T sb = dot(UH + (int64_t)l * dim) * q + lb * c * (T(-2) * t) * q / (T(1) + c * q);
+    axpy(W + (int64_t)l * dim, sb);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t v = gl + (int64_t)r * G;
+    if (col_ok && v < nvc) store_pack<T, V, true>(xbar + col * dim + v * V, z[r]);
+  }
+}
+
 // ------------------------------------------------------------------ Planar, tile kernel
 // One WAVE owns 64 columns.  The lanes-along-dim kernel above evaluates tanh/cosh/log1p for only
 // 2-4 distinct samples per wave instruction, which makes an 8-layer stack ALU-bound at 8 % of the
@@ -904,6 +986,60 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
   return BJX_OK;
 }
 
+// register-kernel fast path of the pullback (Float32, 16 < dim <= 128); returns 1 when the shape is not served
+template <class T>
+int planar_vjp_reg(bjx_ctx*, const T*, const T*, const T*, const T*, int, const T*, const T*, const T*, T*, int64_t, int64_t) { return 1; }
+
+template <class T>
+int planar_vjp_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int nl, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar,
+                    int64_t dim, int64_t batch) {
+  const size_t need = ((size_t)nl * dim + nl) * sizeof(T);
+  BJX_REQUIRE(ctx, need <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: n_layers*dim = %lld exceeds the context scratch", (long long)nl * dim);
+  T* u_hat = static_cast<T*>(ctx->scratch);
+  T* wtu = u_hat + (size_t)nl * dim;
+  hipLaunchKernelGGL(planar_prep_kernel<T>, dim3(nl), dim3(256), 0, ctx->stream, w, u, dim, u_hat, wtu);
+  BJX_CHECK_LAUNCH(ctx);
+  if (batch == 0) return BJX_OK;
+  {
+    int rc = planar_vjp_reg(ctx, w, u_hat, wtu, b, nl, in, out_bar, ladj_bar, in_bar, dim, batch);
+    if (rc != 1) return rc;                               // 1 = shape not served by the register kernel
+  }
+  FlowCfg c;
+  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, in_bar, dim, batch, &c), BJX_ERR_UNSUPPORTED,
+              "bjx_planar_vjp: dim %lld too large for the register-resident kernel", (long long)dim);
+  const int cols_per_block = 256 / c.G;
+  const size_t tsave_bytes = ((size_t)cols_per_block * nl * sizeof(T) + 15) / 16 * 16;
+  const size_t tab_bytes = (size_t)2 * nl * dim * sizeof(T);
+  const bool lds = tsave_bytes + tab_bytes <= 60 * 1024;
+  BJX_REQUIRE(ctx, tsave_bytes <= 60 * 1024, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: too many layers (%d)", nl);
+  PlanarArgs<T> A{w, u_hat, wtu, b, nl, lds ? 1 : 0};
+  const size_t smem = (size_t)cols_per_block * nl * sizeof(T) + (lds ? tab_bytes : 0);
+  constexpr int VW = Vec16<T>::N;
+  const bool v_ok = c.V == VW && bjx_aligned16(out_bar);
+  BjxProf prof_(ctx);
+#define PVJ(V_, R_) hipLaunchKernelGGL((planar_vjp_kernel<T, V_, R_>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G)
+#define PVJ_R(V_) switch (c.R) { case 1: PVJ(V_, 1); break; case 2: PVJ(V_, 2); break; case 4: PVJ(V_, 4); break; case 8: PVJ(V_, 8); break; case 16: PVJ(V_, 16); break; default: PVJ(V_, 32); break; }
+  if (v_ok) { PVJ_R(VW) } else {
+    // scalar packs: recompute the geometry for V = 1
+    int G = 1;
+    while (G < 64 && G < dim) G <<= 1;
+    int64_t need_r = (dim + G - 1) / G;
+    int R = 1;
+    while (R < need_r) R <<= 1;
+    BJX_REQUIRE(ctx, R <= 32, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: dim %lld too large for the register-resident kernel", (long long)dim);
+    c.G = G; c.R = R; c.grid = (batch + (256 / G) - 1) / (256 / G);
+    const int cpb = 256 / G;
+    const size_t smem1 = (size_t)cpb * nl * sizeof(T) + (lds ? tab_bytes : 0);
+#define PVJ1(R_) hipLaunchKernelGGL((planar_vjp_kernel<T, 1, R_>), dim3((unsigned)c.grid), dim3(256), smem1, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G)
+    switch (c.R) { case 1: PVJ1(1); break; case 2: PVJ1(2); break; case 4: PVJ1(4); break; case 8: PVJ1(8); break; case 16: PVJ1(16); break; default: PVJ1(32); break; }
+#undef PVJ1
+  }
+#undef PVJ_R
+#undef PVJ
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+
 template <class T>
 int radial_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const T* z0, const T* in, T* out, T* ladj_ps,
                 double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
@@ -949,6 +1085,16 @@ BJX_API int bjx_planar(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* w, c
   if (dt == BJX_F32) return planar_impl<float>(ctx, inverse, (const float*)w, (const float*)u, (const float*)b, n_layers, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, batch, flags);
   if (dt == BJX_F64) return planar_impl<double>(ctx, inverse, (const double*)w, (const double*)u, (const double*)b, n_layers, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, batch, flags);
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_planar: bad dtype %d", (int)dt);
+}
+
+BJX_API int bjx_planar_vjp(bjx_ctx* ctx, bjx_dtype dt, const void* w, const void* u, const void* b, int n_layers, const void* in,
+                           const void* out_bar, const void* ladj_bar, void* in_bar, int64_t dim, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0 && n_layers >= 1, BJX_ERR_SHAPE, "bjx_planar_vjp: bad size (dim=%lld, n_layers=%d)", (long long)dim, n_layers);
+  BJX_REQUIRE(ctx, w && u && b && ((in && out_bar && in_bar) || batch == 0), BJX_ERR_ARG, "bjx_planar_vjp: null pointer");
+  if (dt == BJX_F32) return planar_vjp_impl<float>(ctx, (const float*)w, (const float*)u, (const float*)b, n_layers, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, dim, batch);
+  if (dt == BJX_F64) return planar_vjp_impl<double>(ctx, (const double*)w, (const double*)u, (const double*)b, n_layers, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, dim, batch);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_planar_vjp: bad dtype %d", (int)dt);
 }
 
 BJX_API int bjx_radial(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* alpha_, const void* beta, const void* z0,

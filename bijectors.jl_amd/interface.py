@@ -1232,6 +1232,24 @@ def vjp(b, x, out_bar, ladj_bar=None):
         rc = L.load().bjx_simplex_vjp(ctx.h, _dt(xc), int(inv), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), K, batch)
         L.check(ctx.h, rc, "bjx_simplex_vjp")
         return xb
+    if isinstance(base, PlanarLayer) and not inv:
+        # fused PlanarLayer stack, forward direction (closed-form derivatives of planar_layer.jl:65-110)
+        xc, dim, batch, vec = _prep(x)
+        gc, gdim, gbatch, _ = _prep(out_bar)
+        if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:
+            raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
+        w, u = _param(base.w, xc), _param(base.u, xc)
+        if w.dim() == 2:
+            w, u = w.T.contiguous(), u.T.contiguous()
+        if w.numel() != dim * base.n_layers:
+            raise ValueError(f"DimensionMismatch: PlanarLayer of dimension {w.numel() // base.n_layers} applied to {dim} rows")
+        bb = _param(base.b, xc)
+        lb = _ladj_bar(ladj_bar, batch, xc)
+        ctx = context(xc.device)
+        xb = _empty(dim, batch, xc, vec)
+        rc = L.load().bjx_planar_vjp(ctx.h, _dt(xc), _ptr(w), _ptr(u), _ptr(bb), base.n_layers, _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
+        L.check(ctx.h, rc, "bjx_planar_vjp")
+        return xb
     if not isinstance(base, OrderedBijector):
         raise NotImplementedError(f"no device pullback for {b!r} yet (SURVEY.md §8f f-1)")
     xc, dim, batch, vec = _prep(x)

@@ -553,3 +553,35 @@ def mvnormal_diag_logpdf(x, mu=None, sigma=None):
     s = np.ones(d) if sigma is None else np.asarray(sigma, dtype=np.float64).reshape(-1)
     z = (x - m[:, None]) / s[:, None]
     return -0.5 * np.sum(z * z, axis=0) - np.sum(np.log(s)) - 0.5 * d * np.log(2.0 * np.pi)
+
+
+def planar_vjp(w, u, b, z, y_bar, ladj_bar=None):
+    """Input pullback of with_logabsdet_jacobian for a stack of PlanarLayers (planar_layer.jl:65-110; the reference
+    leaves it to the AD package — these are the closed-form derivatives of its expressions):
+        s_k = w_kᵀz_{k-1} + b_k,  t_k = tanh s_k,  z_k = z_{k-1} + û_k t_k,  ℓ_k = log1p(c_k (1 - t_k²)),  c_k = w_kᵀû_k
+        s̄_k = (û_kᵀ z̄_k)(1 - t_k²) + ℓ̄ · c_k (-2 t_k)(1 - t_k²) / (1 + c_k (1 - t_k²)),   z̄_{k-1} = z̄_k + w_k s̄_k.
+    w, u: (dim, n_layers) or (dim,); z, y_bar: (dim, N); ladj_bar: (N,) or None.  numpy, float64."""
+    z = np.asarray(z, dtype=np.float64)
+    dim, N = z.shape
+    w = np.asarray(w, dtype=np.float64).reshape(dim, -1)
+    u = np.asarray(u, dtype=np.float64).reshape(dim, -1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    nl = w.shape[1]
+    lb = np.zeros(N) if ladj_bar is None else np.broadcast_to(np.asarray(ladj_bar, dtype=np.float64), (N,))
+    u_hat, c = np.empty_like(u), np.empty(nl)
+    for k in range(nl):
+        wtu = float(w[:, k] @ u[:, k])
+        u_hat[:, k] = u[:, k] + (log1pexp(-wtu) - 1.0) / float(w[:, k] @ w[:, k]) * w[:, k]   # planar_layer.jl:65-70
+        c[k] = log1pexp(wtu) - 1.0
+    ts, cur = [], z
+    for k in range(nl):
+        t = np.tanh(w[:, k] @ cur + b[k])
+        ts.append(t)
+        cur = cur + np.outer(u_hat[:, k], t)
+    g = np.asarray(y_bar, dtype=np.float64).copy()
+    for k in range(nl - 1, -1, -1):
+        t = ts[k]
+        q = 1.0 - t * t
+        sbar = (u_hat[:, k] @ g) * q + lb * c[k] * (-2.0 * t) * q / (1.0 + c[k] * q)
+        g = g + np.outer(w[:, k], sbar)
+    return g

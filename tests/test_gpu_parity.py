@@ -998,3 +998,24 @@ def test_logpdf_transformed_structured_and_rand(bj, orc):
     lp = host(bj.logpdf(tdc, S))
     ref = orc.mvnormal_diag_logpdf(np.log(host(S)) - 0.25, mu, sg) - np.log(host(S)).sum(axis=0)
     np.testing.assert_allclose(lp, ref, rtol=1e-9, atol=1e-8)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,nl,N", [(128, 8, 300), (128, 1, 64), (64, 3, 129), (20, 2, 77), (7, 2, 50), (200, 2, 40), (128, 12, 65), (36, 16, 33)])
+def test_planar_vjp(bj, orc, dim, nl, N, dt):
+    """Input pullback of the fused PlanarLayer stack (§8f f-1) against the finite-difference-pinned oracle."""
+    r = rng(81)
+    w = (r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(dt)
+    u = (r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(dt)
+    b = r.normal(size=nl).astype(dt)
+    flow = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(b))
+    Z = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    gbar = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    lbar = r.normal(size=N).astype(dt)
+    ref = orc.planar_vjp(w, u, b, Z, gbar, lbar)
+    got = bj.vjp(flow, dev(Z), dev(gbar), torch.from_numpy(lbar).cuda())
+    assert tuple(got.shape) == (dim, N)
+    np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())))
+    ref0 = orc.planar_vjp(w, u, b, Z, gbar)
+    got0 = bj.vjp(flow, dev(Z), dev(gbar))
+    np.testing.assert_allclose(host(got0), ref0, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref0).max())))

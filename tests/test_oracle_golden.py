@@ -479,3 +479,18 @@ def test_simplex_pullbacks_match_finite_differences(orc):
         ym, lm = orc.simplex(np.asfortranarray(xm))
         fd[i] = ((yp - ym) * gb2).sum(0) / (2 * h) + lb * (lp - lm) / (2 * h)
     np.testing.assert_allclose(got, fd, rtol=1e-6, atol=1e-6)
+
+
+def test_planar_pullback_matches_finite_differences(orc):
+    """Input pullback of a PlanarLayer stack (planar_layer.jl:65-110): closed-form derivatives pinned against central
+    differences of the golden-pinned forward oracle, one layer and a fused stack, with and without ℓ̄."""
+    r = np.random.default_rng(9)
+    for dim, nl, N in ((5, 1, 3), (6, 3, 4), (12, 8, 2)):
+        w = r.normal(size=(dim, nl)) / np.sqrt(dim)
+        u = r.normal(size=(dim, nl)) / np.sqrt(dim)
+        b = r.normal(size=nl)
+        z = np.asfortranarray(r.normal(size=(dim, N)))
+        gbar, lbar = r.normal(size=(dim, N)), r.normal(size=N)
+        fwd = lambda v: orc.planar(w, u, b, np.asfortranarray(v))
+        np.testing.assert_allclose(orc.planar_vjp(w, u, b, z, gbar, lbar), _fd_vjp(fwd, z, gbar, lbar), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(orc.planar_vjp(w, u, b, z, gbar), _fd_vjp(fwd, z, gbar, np.zeros(N)), rtol=1e-6, atol=1e-7)
