@@ -726,6 +726,173 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
   block_publish_partial(ok ? (double)ladj : 0.0, red, fin);
 }
 
+// ------------------------------------------------------------------ Planar input pullback, register kernel (Float32)
+// bjx_planar_vjp for 16 < dim <= 128: the two sweeps of planar_vjp_kernel on the register tile of planar_reg_kernel.
+// The reverse sweep IS the forward structure with the roles of w and û exchanged: with s̄_k the cotangent of s_k,
+//   û_kᵀz̄_k = û_kᵀȳ + Σ_{j>k} (û_kᵀw_j) s̄_j        (the same G table, read transposed),   z̄_0 = ȳ + Σ_k w_k s̄_k
+// so it is NL dot products against û per pack, the transposed reduction, a lane = column scalar recurrence from the
+// last layer down, and a rank-NL update with w.  The primal tile is dead once tanh(s_k) of every layer sits in LDS
+// ([column][layer], 4·nl_pad bytes per column), so ȳ is loaded into the same registers: read z, read ȳ, write z̄.
+typedef float bjx_f4 __attribute__((ext_vector_type(4)));
+typedef float bjx_f2 __attribute__((ext_vector_type(2)));
+template <int G, int NL, int NS>
+__device__ __forceinline__ void reg_dots(const float* __restrict__ tab, int l0, int dim, const bjx_f4 (&z)[NS], float* st, int lane, int gl, int cg, bool row_ok) {
+  constexpr int CPS = 64 / G;
+  constexpr bool SWAP = (G == 32) && (NL >= 2);
+  constexpr int NV = SWAP ? NL / 2 : NL;
+  constexpr int RW = G < 16 ? G : 16;
+  constexpr int NP = NL >= 2 ? NL / 2 : 1;
+  bjx_f2 wq[NP][4];
+#pragma unroll
+  for (int kp = 0; kp < NP; ++kp) {
+    bjx_f4 a = bjx_f4{0.f, 0.f, 0.f, 0.f}, b = a;
+    if (row_ok) {
+      a = *reinterpret_cast<const bjx_f4*>(tab + (int64_t)(l0 + 2 * kp) * dim + 4 * gl);
+      if (NL >= 2) b = *reinterpret_cast<const bjx_f4*>(tab + (int64_t)(l0 + 2 * kp + 1) * dim + 4 * gl);
+    }
+    wq[kp][0] = bjx_f2{a.x, b.x}; wq[kp][1] = bjx_f2{a.y, b.y}; wq[kp][2] = bjx_f2{a.z, b.z}; wq[kp][3] = bjx_f2{a.w, b.w};
+  }
+#pragma unroll
+  for (int r = 0; r < NS; ++r) {
+    float p[NL >= 2 ? NL : 2];
+#pragma unroll
+    for (int kp = 0; kp < NP; ++kp) {
+      bjx_f2 acc = wq[kp][0] * z[r].x;
+      acc += wq[kp][1] * z[r].y;
+      acc += wq[kp][2] * z[r].z;
+      acc += wq[kp][3] * z[r].w;
+      p[2 * kp] = acc.x; p[2 * kp + 1] = acc.y;
+    }
+    float q[NV];
+    if constexpr (SWAP) {
+      swap_fold<NV>(p, q);
+    } else if constexpr (G == 32) {
+      p[1] = p[0];
+      swap_fold<1>(p, q);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) q[k] = p[k];
+    }
+    row_allsum<RW, NV>(q);
+    if ((lane & (RW - 1)) == 0) {
+      int cl, lo;
+      if (G == 32) { cl = r * CPS + (lane >> 5); lo = SWAP ? ((lane >> 4) & 1) * NV : 0; }
+      else { cl = r * CPS + cg; lo = 0; }
+      if (!(G == 32 && !SWAP && ((lane >> 4) & 1))) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) st[cl * NL + lo + k] = q[k];
+      }
+    }
+  }
+}
+template <int G, int NL, int NS>
+__device__ __forceinline__ void reg_update(const float* __restrict__ tab, int l0, int dim, bjx_f4 (&z)[NS], const float* st, int gl, int cg, bool row_ok) {
+  constexpr int CPS = 64 / G;
+  bjx_f4 uv[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k)
+    uv[k] = row_ok ? *reinterpret_cast<const bjx_f4*>(tab + (int64_t)(l0 + k) * dim + 4 * gl) : bjx_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < NS; ++r) {
+    const float* tc = st + (r * CPS + cg) * NL;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) { const float tk = tc[k]; z[r] += uv[k] * tk; }
+  }
+}
+
+template <int G, int NL>
+__global__ __launch_bounds__(256) void planar_vjp_reg_kernel(const PlanarRegArgs A, const float* __restrict__ x, const float* __restrict__ ybar,
+                                                             const float* __restrict__ lbar, float* __restrict__ xbar, int dim, int64_t batch) {
+  constexpr int COLS = 64;
+  constexpr int CPS = 64 / G;
+  constexpr int NS = (COLS * G) / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* st = reinterpret_cast<float*>(smem) + (size_t)wave * COLS * NL;
+  float* tsave = reinterpret_cast<float*>(smem) + (size_t)4 * COLS * NL + (size_t)wave * COLS * A.nl_pad;   // [column][layer]
+  const int gl = lane & (G - 1);
+  const int cg = lane / G;
+  const bool row_ok = 4 * gl < dim;
+  const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * COLS;
+  const int64_t left = batch - col0;
+  const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
+  const int64_t step_elems = (int64_t)CPS * dim;
+  bjx_f4 z[NS];
+  auto load_tile = [&](const float* base) {
+    const float* px = base + (col0 + cg) * dim + 4 * gl;
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+      if (row_ok && r * CPS + cg < nvalid) z[r] = __builtin_nontemporal_load(reinterpret_cast<const bjx_f4*>(px));
+      else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
+      px += step_elems;
+    }
+  };
+  const int ngroups = A.nl_pad / NL;
+  // ---- forward sweep: tanh(s_k) of every layer -> tsave
+  load_tile(x);
+  for (int gi = 0; gi < ngroups; ++gi) {
+    const int l0 = gi * NL;
+    reg_dots<G, NL, NS>(A.w, l0, dim, z, st, lane, gl, cg, row_ok);
+    __builtin_amdgcn_wave_barrier();
+    {
+      float s[NL], t[NL];
+#pragma unroll
+      for (int k = 0; k < NL; ++k) { s[k] = st[lane * NL + k]; t[k] = 0.f; }
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const float* Gk = A.G + (int64_t)(l0 + k) * A.nl_pad + l0;
+        float a = s[k];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) if (j < k) a += Gk[j] * t[j];
+        t[k] = fast_tanh(a + A.b[l0 + k]);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < NL; ++k) { st[lane * NL + k] = t[k]; tsave[lane * A.nl_pad + l0 + k] = t[k]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (gi + 1 < ngroups) reg_update<G, NL, NS>(A.u_hat, l0, dim, z, st, gl, cg, row_ok);
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- reverse sweep on the cotangent tile
+  load_tile(ybar);
+  const float lb = (lbar && lane < nvalid) ? lbar[col0 + lane] : 0.f;
+  for (int gi = ngroups - 1; gi >= 0; --gi) {
+    const int l0 = gi * NL;
+    reg_dots<G, NL, NS>(A.u_hat, l0, dim, z, st, lane, gl, cg, row_ok);
+    __builtin_amdgcn_wave_barrier();
+    {
+      float g[NL], sb[NL];
+#pragma unroll
+      for (int k = 0; k < NL; ++k) { g[k] = st[lane * NL + k]; sb[k] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < NL; ++kk) {
+        const int k = NL - 1 - kk;
+        float tb = g[k];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) if (j > k) tb += A.G[(int64_t)(l0 + j) * A.nl_pad + l0 + k] * sb[j];   // û_kᵀ w_j
+        const float t = tsave[lane * A.nl_pad + l0 + k], c = A.wtu_hat[l0 + k];
+        const float q = 1.0f - t * t;
+        sb[k] = tb * q + lb * c * (-2.0f * t) * q * Fast<float>::rcp(1.0f + c * q);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < NL; ++k) st[lane * NL + k] = sb[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    reg_update<G, NL, NS>(A.w, l0, dim, z, st, gl, cg, row_ok);
+    __builtin_amdgcn_wave_barrier();
+  }
+  {
+    float* py = xbar + (col0 + cg) * dim + 4 * gl;
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+      if (row_ok && r * CPS + cg < nvalid) __builtin_nontemporal_store(z[r], reinterpret_cast<bjx_f4*>(py));
+      py += step_elems;
+    }
+  }
+}
+
 // zero-padded parameter tables for the register kernel: w, û -> [nl_pad][dim]; b, wᵀû -> [nl_pad];
 // G[k][j] = w_k . û_j -> [nl_pad][nl_pad].  grid = nl_pad * nl_pad blocks.
 __global__ __launch_bounds__(256) void planar_prep_reg_kernel(const float* w, const float* u_hat, const float* wtu_hat, const float* b,
@@ -989,6 +1156,39 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
 // register-kernel fast path of the pullback (Float32, 16 < dim <= 128); returns 1 when the shape is not served
 template <class T>
 int planar_vjp_reg(bjx_ctx*, const T*, const T*, const T*, const T*, int, const T*, const T*, const T*, T*, int64_t, int64_t) { return 1; }
+inline int planar_vjp_reg(bjx_ctx* ctx, const float* w, const float* u_hat, const float* wtu, const float* b, int nl, const float* in,
+                          const float* out_bar, const float* ladj_bar, float* in_bar, int64_t dim, int64_t batch) {
+  static const int use_reg = getenv("BJX_PLANAR_REG") ? atoi(getenv("BJX_PLANAR_REG")) : 1;
+  if (!(use_reg && dim % 4 == 0 && dim > 16 && dim <= 128 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar))) return 1;
+  const int NL = nl >= 8 ? 8 : (nl > 2 ? 4 : nl);
+  const int nl_pad = (nl + NL - 1) / NL * NL;
+  const size_t off0 = ((size_t)nl * dim + nl + 3) / 4 * 4;
+  const size_t need_reg = (off0 + (size_t)2 * nl_pad * dim + (size_t)nl_pad * nl_pad + 2 * (size_t)nl_pad) * sizeof(float);
+  const size_t smem = (size_t)4 * 64 * (NL + nl_pad) * sizeof(float);
+  if (need_reg > BJX_SCRATCH_BYTES || smem > 64 * 1024) return 1;
+  float* base = reinterpret_cast<float*>(ctx->scratch);
+  float* wp = base + off0;
+  float* up = wp + (size_t)nl_pad * dim;
+  float* Gp = up + (size_t)nl_pad * dim;
+  float* cp = Gp + (size_t)nl_pad * nl_pad;
+  float* bp = cp + nl_pad;
+  hipLaunchKernelGGL(planar_prep_reg_kernel, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, w, u_hat, wtu, b, dim, nl, nl_pad, wp, up, Gp, cp, bp);
+  BJX_CHECK_LAUNCH(ctx);
+  const int G = dim > 64 ? 32 : (dim > 32 ? 16 : 8);
+  const int64_t grid = (batch + 4 * 64 - 1) / (4 * 64);
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: batch too large for one launch");
+  PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad};
+#define LV(G_, NL_) hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch)
+#define LV_NL(G_) switch (NL) { case 1: LV(G_, 1); break; case 2: LV(G_, 2); break; case 4: LV(G_, 4); break; default: LV(G_, 8); break; }
+  {
+    BjxProf prof_(ctx);
+    switch (G) { case 8: LV_NL(8) break; case 16: LV_NL(16) break; default: LV_NL(32) break; }
+  }
+#undef LV_NL
+#undef LV
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
 
 template <class T>
 int planar_vjp_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int nl, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar,

@@ -150,6 +150,10 @@ def main():
     rows.append(("vjp(inverse(SimplexBijector)) K=64", "f-1", lambda: bj.vjp(bj.inverse(sb_), ys, gxs, lbs), 4 * (d - 1 + d + d - 1) + 4, Ns))
     rows.append(("vjp(Stacked(exp|Logit|identity|exp∘Shift∘Scale)) d=64", "f-1", lambda: bj.vjp(stk, xst, gb, lbar), 3 * d * 4 + 4, N))
 
+    gz = randn(dp, Np, dev, 21)
+    lbz = randn(Np, 1, dev, 22).reshape(-1).contiguous()
+    rows.append(("vjp(8×PlanarLayer) d=128", "f-1", lambda: bj.vjp(flow, z, gz, lbz), 4 * 3 * dp + 4, Np))
+
     # §8(f) f-3: logpdf(td, Y) fused into the inverting kernel — Y is read once, x is never stored
     td_pl = bj.transformed(bj.MvNormal(dp), flow)
     rows.append(("logpdf(transformed(MvNormal(128), 8×PlanarLayer)) d=128", "f-3", lambda: bj.logpdf(td_pl, zf), 4 * dp + 4, Np))
