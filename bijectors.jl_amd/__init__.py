@@ -8,9 +8,9 @@ transform + log-abs-det-Jacobian hot path.
 Only the hot path lives here: csrc/ (HIP kernels + the C ABI of include/bjx.h),
 _lib.py (ctypes binding) and interface.py (host mirror of src/interface.jl + src/bijectors/*.jl).
 """
-from . import _lib, shard
+from . import _lib, shard, vector
 from .interface import *  # noqa: F401,F403
 from .interface import __all__ as _iface_all
 
-__all__ = list(_iface_all) + ["_lib", "shard"]
+__all__ = list(_iface_all) + ["_lib", "shard", "vector"]
 __version__ = "0.1.0"

@@ -1019,3 +1019,74 @@ def test_planar_vjp(bj, orc, dim, nl, N, dt):
     ref0 = orc.planar_vjp(w, u, b, Z, gbar)
     got0 = bj.vjp(flow, dev(Z), dev(gbar))
     np.testing.assert_allclose(host(got0), ref0, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref0).max())))
+
+
+# ------------------------------------------------------------------ §8(f) f-2: VectorBijectors homogeneous products, batched over chains
+def test_vector_scalar_bijector_reference_values(bj):
+    """src/vector/interface.jl:98-101,129 (doctests): Beta(2,2) links through Untruncate(0, 1) / Truncate(0, 1)."""
+    V = bj.vector
+    f64 = dict(dtype=torch.float64, device="cuda")
+    y, l = bj.with_logabsdet_jacobian(V.to_linked_vec(V.scalar_to_scalar_bijector(0.0, 1.0), ()), torch.tensor([0.5], **f64))
+    assert host(y).tolist() == [0.0] and float(l) == pytest.approx(1.3862943611198906, abs=1e-15)
+    x, l2 = bj.with_logabsdet_jacobian(V.from_linked_vec(V.scalar_to_scalar_bijector(0.0, 1.0), ()), torch.tensor([1.0], **f64))
+    assert float(x[0]) == pytest.approx(0.7310585786300049, abs=1e-15) and float(l2) == pytest.approx(-1.6265233750364456, abs=1e-14)
+    # positive.jl:11-50: Log(bound, sign) / Exp(bound, sign), both signs
+    v = torch.tensor([0.3, 2.5, 7.0], **f64)
+    for bound, sign in ((0.0, 1), (-1.5, 1), (9.0, -1)):
+        lg, ld = bj.with_logabsdet_jacobian(V.Log(bound, sign), v)
+        ref = np.log(sign * (host(v) - bound))
+        np.testing.assert_allclose(host(lg), ref, rtol=1e-14)
+        assert float(ld) == pytest.approx(-ref.sum(), rel=1e-14)
+        back, lb = bj.with_logabsdet_jacobian(V.Exp(bound, sign), lg)
+        np.testing.assert_allclose(host(back), host(v), rtol=1e-13)
+        assert float(lb) == pytest.approx(ref.sum(), rel=1e-13)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_vector_product_of_univariates_batched_over_chains(bj, orc, dt):
+    """product_distribution(fill(Beta, 3, 4)) on 257 chains: one elementwise launch, per-chain log-det (fill.jl:136-159)."""
+    V = bj.vector
+    r = rng(91)
+    size, C = (3, 4), 257
+    X = np.asfortranarray(r.uniform(0.05, 0.95, size=(12, C)).astype(dt))
+    t = V.to_linked_vec(V.scalar_to_scalar_bijector(0.0, 1.0), size)
+    Y, l = bj.with_logabsdet_jacobian(t, dev(X))
+    assert tuple(Y.shape) == (12, C) and tuple(l.shape) == (C,)
+    ops = [(orc.OP_TRUNCATED, 0.0, 1.0)]
+    Y_ref, _ = orc.chain(ops, X)
+    l_ref = np.array([float(orc.chain(ops, np.asfortranarray(X[:, [c]]))[1]) for c in range(C)])
+    close(host(Y), Y_ref, dt)
+    close(host(l), l_ref, dt, scale=12)
+    Xb, lb = bj.with_logabsdet_jacobian(V.from_linked_vec(V.scalar_to_scalar_bijector(0.0, 1.0), size), Y)
+    close(host(Xb), X, dt, scale=10)
+    close(host(lb), -l_ref, dt, scale=12)
+    # Gamma-like components: Log(0, 1)
+    P = np.asfortranarray(np.exp(r.normal(size=(12, C))).astype(dt))
+    Yp, lp = bj.with_logabsdet_jacobian(V.to_linked_vec(V.scalar_to_scalar_bijector(0.0, np.inf, positive_family=True), size), dev(P))
+    close(host(Yp), np.log(P.astype(np.float64)), dt)
+    close(host(lp), -np.log(P.astype(np.float64)).sum(axis=0), dt, scale=12)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_vector_product_of_dirichlets_batched_over_chains(bj, orc, dt):
+    """product_distribution(fill(Dirichlet(ones(5)), 7)): SimplexBijector on every length-5 slice (fill.jl:143-158 with
+    src/vector/multivariate/simplex.jl), chains as columns; the slices become extra columns without a copy."""
+    V = bj.vector
+    r = rng(92)
+    K, m, C = 5, 7, 33
+    X = np.asfortranarray(r.dirichlet(np.ones(K), size=(C, m)).reshape(C, m * K).T.astype(dt))    # (K*m, C)
+    t = V.to_linked_vec(bj.SimplexBijector(), (m,), base_size=(K,))
+    Y, l = bj.with_logabsdet_jacobian(t, dev(X))
+    assert tuple(Y.shape) == ((K - 1) * m, C) and tuple(l.shape) == (C,)
+    Y_ref = np.empty(((K - 1) * m, C))
+    l_ref = np.zeros(C)
+    for c in range(C):
+        sl = np.asfortranarray(X[:, c].reshape(m, K).T)
+        ys, ls = orc.simplex(sl)
+        Y_ref[:, c] = ys.T.reshape(-1)
+        l_ref[c] = ls.astype(np.float64).sum()
+    close(host(Y), Y_ref, dt, scale=10)
+    close(host(l), l_ref, dt, scale=K * m * 10)
+    Xb, lb = bj.with_logabsdet_jacobian(V.from_linked_vec(bj.SimplexBijector(), (m,), base_size=(K,)), Y)
+    close(host(Xb), X, dt, scale=10)
+    close(host(lb), -l_ref, dt, scale=K * m * 10)
