@@ -59,6 +59,7 @@ SIGNATURES = {
     "bjx_ordered_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_simplex_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_vec_cholesky_inv_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "bjx_vec_cholesky_fwd_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i64, _i64]),
     "bjx_stacked": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _vp, _vp, _vp, _i64, _i64, _u32]),
     "bjx_stacked_vjp": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_set_option": (_i, [_vp, _i, _i]),

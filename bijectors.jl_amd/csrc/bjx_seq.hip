@@ -2282,6 +2282,143 @@ int chol_inv_vjp_impl(bjx_ctx* ctx, int uplo, const T* y, const T* Wbar, const T
 }
 }  // namespace
 
+namespace {
+// ------------------------------------------------------------------ pullback of _link_chol_lkj_from_upper / _from_lower
+// ext/BijectorsChainRulesCoreExt.jl:199-254 / :256-311.  The rule lives on the constraint manifold (unit-norm
+// columns: the strict triangle is free, the diagonal follows), ΔW[j,j] = 0.  Per column j, descending i = j-1..2:
+//   tmp = sqrt(W[j,j]² + Σ_{i'>=i} W[i',j]²),  p = W[i,j]/tmp,  Δp = Δz/(1-p²) - Δtmp·tmp·p/sqrt(1-p²),
+//   ΔW[i,j] = Δp/tmp,  Δtmp <- -Δp·W[i,j]/tmp² + Δtmp·sqrt(1-p²);   ΔW[1,j] = Δz/(1-W[1,j]²) - Δtmp·W[1,j]/sqrt(1-W[1,j]²)
+// ONE WAVE per sample, LANE = COLUMN: W is staged into a [K][K+1] LDS tile (coalesced 16-byte loads; the odd pitch
+// makes both the :U column walk and the :L row walk conflict-free), Δz into a flat strip; every lane walks its
+// column from the diagonal up, writes ΔW in place, zeroes the diagonal and the other triangle (the reference leaves
+// them undefined), and the tile leaves as coalesced 16-byte stores.  Lanes of short columns idle (triangular work:
+// ~50 % lane utilisation); the chunk decomposition of the forward kernel with an affine segmented scan is the
+// next step if this row matters.
+template <class T, int V, bool LOWER>
+__global__ __launch_bounds__(64) void chol_fwd_vjp_kernel(const T* __restrict__ W, const T* __restrict__ ybar, T* __restrict__ Wbar, int K, int64_t batch) {
+  using F = Fast<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int P = K + 1;
+  T* tile = reinterpret_cast<T*>(smem);
+  const int nv = K * (K - 1) / 2;
+  T* dz = tile + (((size_t)K * P + 3) / 4) * 4;
+  const int lane = threadIdx.x;
+  const int64_t s = blockIdx.x;
+  const T* Ws = W + s * (int64_t)K * K;
+  const T* zs = ybar + s * (int64_t)nv;
+  const int ne = K * K;
+  {
+    int e = lane * V, c = e / K, r = e % K;
+    const int dc = (64 * V) / K, dr = (64 * V) % K;
+    constexpr int SU = 4;
+    for (; e < ne; e += SU * 64 * V) {
+      Pack<T, V> p[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) if (e + u * 64 * V < ne) p[u] = load_pack<T, V, true>(Ws + e + u * 64 * V);
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (e + u * 64 * V < ne) {
+          int cc = c, rr = r;
+#pragma unroll
+          for (int j = 0; j < V; ++j) { tile[cc * P + rr] = p[u].v[j]; if (++rr == K) { rr = 0; ++cc; } }
+        }
+        c += dc; r += dr;
+        if (r >= K) { r -= K; ++c; }
+      }
+    }
+    for (int i = lane * V; i < nv; i += 64 * V) {
+      const Pack<T, V> q = load_pack<T, V, true>(zs + i);
+#pragma unroll
+      for (int j = 0; j < V; ++j) dz[i + j] = q.v[j];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // memory index of A[i][j] (A = the upper factor; :L stores its transpose): column-major W -> tile[col*P + row]
+  auto at = [&](int i, int j) -> int { return LOWER ? i * P + j : j * P + i; };
+  for (int jb = 0; jb < K; jb += 64) {
+    const int j = jb + lane;
+    const bool live = j >= 1 && j < K;
+    const int jj = live ? j : 1;
+    const int base = jj * (jj - 1) / 2;
+    T rs = tile[at(jj, jj)];
+    rs *= rs;
+    T dtmp = T(0);
+    const int imax = (jb + 63 < K - 1 ? jb + 63 : K - 1) - 1;            // longest column of this strip
+    for (int i = imax; i >= 1; --i) {
+      const bool on = live && i < j;
+      const int a = at(on ? i : 0, jj);
+      const T w = tile[a];
+      const T dzi = dz[base + (on ? i : 0)];
+      const T rs2 = rs + w * w;
+      const T rt = F::rsqrt(rs2);                                       // 1/tmp
+      const T p = w * rt;
+      const T q = T(1) - p * p;
+      const T rf = F::rsqrt(q);                                         // 1/ftmp
+      const T dp = dzi * F::rcp(q) - dtmp * (rs2 * rt) * (p * rf);
+      const T dtn = dtmp * (q * rf) - dp * (w * rt * rt);
+      if (on) { tile[a] = dp * rt; rs = rs2; dtmp = dtn; }
+    }
+    if (live) {
+      const int a0 = at(0, j);
+      const T w0 = tile[a0];
+      const T q0 = T(1) - w0 * w0;
+      tile[a0] = dz[base] * F::rcp(q0) - dtmp * F::rsqrt(q0) * w0;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // diagonal, the other triangle and column/row 0 of it: zeros
+  for (int j = lane; j < K; j += 64)
+    for (int i = j; i < K; ++i) tile[at(i, j)] = T(0);
+  __builtin_amdgcn_wave_barrier();
+  {
+    T* Os = Wbar + s * (int64_t)K * K;
+    int e = lane * V, c = e / K, r = e % K;
+    const int dc = (64 * V) / K, dr = (64 * V) % K;
+    for (; e < ne; e += 64 * V) {
+      Pack<T, V> p;
+      int cc = c, rr = r;
+#pragma unroll
+      for (int j = 0; j < V; ++j) { p.v[j] = tile[cc * P + rr]; if (++rr == K) { rr = 0; ++cc; } }
+      store_pack<T, V, true>(Os + e, p);
+      c += dc; r += dr;
+      if (r >= K) { r -= K; ++c; }
+    }
+  }
+}
+
+template <class T>
+int chol_fwd_vjp_impl(bjx_ctx* ctx, int uplo, const T* W, const T* y_bar, T* W_bar, int64_t K, int64_t batch) {
+  if (batch == 0 || K < 1) return BJX_OK;
+  if (K == 1) { BJX_HIP(ctx, hipMemsetAsync(W_bar, 0, (size_t)batch * sizeof(T), ctx->stream)); return BJX_OK; }   // no free parameter
+  const int64_t nv = K * (K - 1) / 2;
+  const size_t smem = ((((size_t)K * (K + 1) + 3) / 4) * 4 + (size_t)nv + 4) * sizeof(T);
+  BJX_REQUIRE(ctx, smem <= BJX_LDS_MAX, BJX_ERR_UNSUPPORTED, "bjx_vec_cholesky_fwd_vjp: K = %lld too large for the LDS tile", (long long)K);
+  BJX_REQUIRE(ctx, batch < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+  constexpr int VW = Vec16<T>::N;
+  const bool v_ok = bjx_aligned16(W) && bjx_aligned16(y_bar) && bjx_aligned16(W_bar) && (K * K) % VW == 0 && nv % VW == 0;
+  const bool lower = uplo == 'L';
+  {
+    BjxProf prof_(ctx);
+#define CFV(V_, L_) do { bjx_allow_big_lds(chol_fwd_vjp_kernel<T, V_, L_>, smem); hipLaunchKernelGGL((chol_fwd_vjp_kernel<T, V_, L_>), dim3((unsigned)batch), dim3(64), smem, ctx->stream, W, y_bar, W_bar, (int)K, batch); } while (0)
+    if (v_ok) { if (lower) CFV(VW, true); else CFV(VW, false); }
+    else { if (lower) CFV(1, true); else CFV(1, false); }
+#undef CFV
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+}  // namespace
+
+BJX_API int bjx_vec_cholesky_fwd_vjp(bjx_ctx* ctx, bjx_dtype dt, int uplo, const void* W, const void* y_bar, void* W_bar, int64_t K, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, uplo == 'U' || uplo == 'L', BJX_ERR_ARG, "mode must be either :U (upper triangular) or :L (lower triangular)");
+  BJX_REQUIRE(ctx, K >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_vec_cholesky_fwd_vjp: bad size");
+  BJX_REQUIRE(ctx, (W && W_bar && (y_bar || K == 1)) || batch == 0, BJX_ERR_ARG, "bjx_vec_cholesky_fwd_vjp: null pointer");
+  if (dt == BJX_F32) return chol_fwd_vjp_impl<float>(ctx, uplo, (const float*)W, (const float*)y_bar, (float*)W_bar, K, batch);
+  if (dt == BJX_F64) return chol_fwd_vjp_impl<double>(ctx, uplo, (const double*)W, (const double*)y_bar, (double*)W_bar, K, batch);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_vec_cholesky_fwd_vjp: bad dtype %d", (int)dt);
+}
+
 BJX_API int bjx_vec_cholesky_inv_vjp(bjx_ctx* ctx, bjx_dtype dt, int uplo, const void* y, const void* W_bar, const void* logJ_bar,
                                      void* y_bar, int64_t K, int64_t batch) {
   if (!ctx) return BJX_ERR_ARG;

@@ -1218,6 +1218,28 @@ def vjp(b, x, out_bar, ladj_bar=None):
         rc = L.load().bjx_vec_cholesky_inv_vjp(ctx.h, _dt(yc), ord(base.mode), _ptr(yc), _ptr(Wc), _ptr(lb), _ptr(yb), K, batch)
         L.check(ctx.h, rc, "bjx_vec_cholesky_inv_vjp")
         return yb
+    if isinstance(b, VecCholeskyBijector):
+        # forward link W (K, K[, batch]) -> y: the rule of ext/BijectorsChainRulesCoreExt.jl:199-311 (no log-det cotangent)
+        if ladj_bar is not None:
+            raise NotImplementedError("the reference's rule for the forward LKJ link has no log-det cotangent")
+        W = x
+        vec = W.dim() == 2
+        K = W.shape[0]
+        if W.shape[1] != K:
+            raise ValueError("DimensionMismatch: W must be K x K[ x batch]")
+        batch = 1 if vec else W.shape[2]
+        n = K * (K - 1) // 2
+        Wc = W.T.contiguous().T if vec else W.permute(2, 1, 0).contiguous().permute(2, 1, 0)
+        gb = out_bar.reshape(n, 1) if vec else out_bar
+        gc = colmajor(gb)
+        if tuple(gc.shape) != (n, batch) or gc.dtype != Wc.dtype:
+            raise ValueError("DimensionMismatch: out_bar must be (K(K-1)/2[, batch]) with the dtype of W")
+        _check_dev(Wc)
+        ctx = context(Wc.device)
+        Wb = torch.empty((batch, K, K), dtype=Wc.dtype, device=Wc.device).permute(2, 1, 0)
+        rc = L.load().bjx_vec_cholesky_fwd_vjp(ctx.h, _dt(Wc), ord(b.mode), _ptr(Wc), _ptr(gc), _ptr(Wb), K, batch)
+        L.check(ctx.h, rc, "bjx_vec_cholesky_fwd_vjp")
+        return Wb[:, :, 0] if vec else Wb
     inv = isinstance(b, Inverse)
     base = b.orig if inv else b
     if isinstance(base, SimplexBijector):

@@ -269,6 +269,13 @@ int bjx_ordered_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, con
  * inverse=0: in = x[K,batch],   out_bar = y_bar[K-1,batch], in_bar = x_bar[K,batch]. */
 int bjx_simplex_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar,
                     const void* ladj_bar, void* in_bar, int64_t K, int64_t batch);
+/* VecCholeskyBijector forward link W[K,K,batch] -> y[n,batch]: the rule the reference ships for
+ * _link_chol_lkj_from_upper / _from_lower (ext/BijectorsChainRulesCoreExt.jl:199-311).  It lives on the constraint
+ * manifold of Cholesky factors of correlation matrices (unit-norm columns): W_bar[j,j] = 0 and the entries outside
+ * the strict triangle — undefined in the reference — are written as zeros.  No log-det cotangent: the reference's
+ * rule covers the link only. */
+int bjx_vec_cholesky_fwd_vjp(bjx_ctx* ctx, bjx_dtype dt, int uplo, const void* W, const void* y_bar,
+                             void* W_bar, int64_t K, int64_t batch);
 /* inverse(VecCholeskyBijector): y[n,batch] -> (W[K,K,batch], logJ[batch]); pullback
  * src/bijectors/corr.jl:402-451 (_inv_link_chol_lkj_rrule; ext/BijectorsChainRulesCoreExt.jl:311-320).
  * W_bar: dense K x K per sample (entries outside the stored triangle are ignored), logJ_bar: T[batch]

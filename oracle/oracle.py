@@ -585,3 +585,40 @@ def planar_vjp(w, u, b, z, y_bar, ladj_bar=None):
         sbar = (u_hat[:, k] @ g) * q + lb * c[k] * (-2.0 * t) * q / (1.0 + c[k] * q)
         g = g + np.outer(w[:, k], sbar)
     return g
+
+
+def vec_cholesky_fwd_vjp(W, y_bar, uplo="U"):
+    """Pullback of `_link_chol_lkj_from_upper` / `_from_lower` as the reference ships it
+    (ext/BijectorsChainRulesCoreExt.jl:199-254 / :256-311): the rule lives on the constraint manifold of Cholesky
+    factors of correlation matrices (unit-norm columns; the strict triangle is the free parameter, the diagonal is a
+    function of it), so ΔW[j,j] = 0 and the entries outside the strict triangle are left undefined there (zeros here).
+    W: (K, K) or (K, K, N) column-major per sample; y_bar: (n,) or (n, N).  numpy, float64, the reference's loops."""
+    W = np.asarray(W, dtype=np.float64)
+    single = W.ndim == 2
+    Wb = W[:, :, None] if single else W
+    K, _, N = Wb.shape
+    n = K * (K - 1) // 2
+    yb = np.asarray(y_bar, dtype=np.float64).reshape(n, -1)
+    out = np.zeros_like(Wb)
+    for s in range(N):
+        A = Wb[:, :, s] if uplo == "U" else Wb[:, :, s].T      # work on the upper factor (the :L rule is its transpose)
+        dA = np.zeros((K, K))
+        for j in range(1, K):                                     # 0-based column j has rows 0..j-1 above the diagonal
+            base = j * (j - 1) // 2
+            rs = A[j, j] ** 2
+            dtmp = 0.0
+            for i in range(j - 1, 0, -1):
+                w = A[i, j]
+                rs += w * w
+                tmp = np.sqrt(rs)                                 # remainders[...]: sqrt(W[j,j]² + Σ_{i'>=i} W[i',j]²)
+                p = w / tmp
+                ftmp = np.sqrt(1.0 - p * p)
+                d_ftmp_p = -p / ftmp
+                d_p_tmp = -w / (tmp * tmp)
+                dp = yb[base + i, s] / (1.0 - p * p) + dtmp * tmp * d_ftmp_p
+                dA[i, j] = dp / tmp
+                dtmp = dp * d_p_tmp + dtmp * ftmp
+            w0 = A[0, j]
+            dA[0, j] = yb[base, s] / (1.0 - w0 * w0) - dtmp / np.sqrt(1.0 - w0 * w0) * w0
+        out[:, :, s] = dA if uplo == "U" else dA.T
+    return out[:, :, 0] if single else out

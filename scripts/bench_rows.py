@@ -142,6 +142,9 @@ def main():
     lb2 = randn(Nc, 1, dev, 14).reshape(-1).contiguous()
     rows.append(("vjp(inverse(VecCholesky)) K=64", "f-1", lambda: bj.vjp(icb, yv, Wb, lb2), 4 * (2 * n + K * K) + 4, Nc))
 
+    gyv = randn(n, Nc, dev, 23, std=1.0)
+    rows.append(("vjp(VecCholesky forward link) K=64", "f-1", lambda: bj.vjp(cb, Wd, gyv), 4 * (n + 2 * K * K), Nc))
+
     gxs = randn(d, Ns, dev, 15)
     gys = randn(d - 1, Ns, dev, 16)
     lbs = randn(Ns, 1, dev, 17).reshape(-1).contiguous()

@@ -1090,3 +1090,24 @@ def test_vector_product_of_dirichlets_batched_over_chains(bj, orc, dt):
     Xb, lb = bj.with_logabsdet_jacobian(V.from_linked_vec(bj.SimplexBijector(), (m,), base_size=(K,)), Y)
     close(host(Xb), X, dt, scale=10)
     close(host(lb), -l_ref, dt, scale=K * m * 10)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("K,N", [(2, 5), (3, 33), (5, 100), (12, 64), (33, 21), (64, 40), (100, 3)])
+@pytest.mark.parametrize("uplo", ["U", "L"])
+def test_vec_cholesky_forward_link_vjp(bj, orc, K, N, uplo, dt):
+    """The rule the reference ships for `_link_chol_lkj_from_upper/lower` (ext/BijectorsChainRulesCoreExt.jl:199-311),
+    against the oracle's restatement of its loops (pinned on the constraint manifold in test_oracle_golden.py)."""
+    r = rng(95)
+    n = K * (K - 1) // 2
+    y = np.asfortranarray((0.4 * r.normal(size=(n, N))).astype(np.float64))
+    W, _ = orc.vec_cholesky(y, inverse=True, uplo=uplo)                    # valid factors
+    W = np.asfortranarray(W.astype(dt))
+    gbar = np.asfortranarray(r.normal(size=(n, N)).astype(dt))
+    ref = orc.vec_cholesky_fwd_vjp(W, gbar, uplo=uplo)
+    b = bj.VecCholeskyBijector(uplo)
+    got = bj.vjp(b, torch.from_numpy(W).cuda(), dev(gbar))
+    assert tuple(got.shape) == (K, K, N)
+    np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref).max())))
+    g1 = bj.vjp(b, torch.from_numpy(np.ascontiguousarray(W[:, :, 0])).cuda(), dev(gbar[:, 0].copy()))
+    np.testing.assert_allclose(host(g1), ref[:, :, 0], rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref[:, :, 0]).max())))

@@ -494,3 +494,44 @@ def test_planar_pullback_matches_finite_differences(orc):
         fwd = lambda v: orc.planar(w, u, b, np.asfortranarray(v))
         np.testing.assert_allclose(orc.planar_vjp(w, u, b, z, gbar, lbar), _fd_vjp(fwd, z, gbar, lbar), rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(orc.planar_vjp(w, u, b, z, gbar), _fd_vjp(fwd, z, gbar, np.zeros(N)), rtol=1e-6, atol=1e-7)
+
+
+def test_forward_lkj_link_pullback_on_the_constraint_manifold(orc):
+    """test/bijectors/chainrules.jl:57-150: the rule of `_link_chol_lkj_from_upper/lower` is tested by the reference
+    against finite differences taken THROUGH the free parameters (strict triangle; the diagonal follows from the
+    unit-norm constraint).  Same check for the restatement, K = 3 and 5, both triangles."""
+    r = np.random.default_rng(11)
+    for K in (3, 5):
+        n = K * (K - 1) // 2
+        y0 = 0.6 * r.normal(size=n)
+        W, _ = orc.vec_cholesky(y0, inverse=True, uplo="U")                # a valid upper factor
+        ybar = r.normal(size=n) * 3
+        iu = [(i, j) for j in range(1, K) for i in range(j)]               # free parameters in packed order
+
+        def from_free(v):
+            A = np.zeros((K, K))
+            A[0, 0] = 1.0
+            for (i, j), val in zip(iu, v):
+                A[i, j] = val
+            for j in range(1, K):
+                A[j, j] = np.sqrt(1.0 - np.sum(A[:j, j] ** 2))
+            return A
+
+        for uplo in ("U", "L"):
+            def f(v):
+                A = from_free(v)
+                y, _ = orc.vec_cholesky(np.asfortranarray(A if uplo == "U" else A.T), uplo=uplo)
+                return float(np.dot(y, ybar))
+            v0 = np.array([W[i, j] for (i, j) in iu])
+            np.testing.assert_allclose(from_free(v0), W, atol=1e-12)
+            fd = np.zeros(n)
+            h = 1e-6
+            for k in range(n):
+                vp, vm = v0.copy(), v0.copy()
+                vp[k] += h
+                vm[k] -= h
+                fd[k] = (f(vp) - f(vm)) / (2 * h)
+            got = orc.vec_cholesky_fwd_vjp(W if uplo == "U" else W.T, ybar, uplo=uplo)
+            gotU = got if uplo == "U" else got.T
+            np.testing.assert_allclose(np.array([gotU[i, j] for (i, j) in iu]), fd, rtol=1e-6, atol=1e-7)
+            assert np.all(np.diag(got) == 0) and np.all((np.tril(gotU, -1)) == 0)
