@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
 //   reverse sweep:  s̄_k = (û_kᵀz̄_k)(1 - t_k²) + ℓ̄ c_k(-2 t_k)(1 - t_k²)/(1 + c_k(1 - t_k²)),  z̄_{k-1} = z̄_k + w_k s̄_k
 // Same mapping as planar_kernel: G lanes own a column in registers; the primal column is dead once the t_k are
 // known, so ȳ is loaded into the same registers.
-template <class T, int V, int R>
+template <class T, int V, int R, bool INV>
 __global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, const T* __restrict__ x, const T* __restrict__ ybar,
                                                          const T* __restrict__ lbar, T* __restrict__ xbar, int64_t dim, int64_t batch, int G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -224,19 +224,40 @@ __global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, 
   };
   load_col(x);
   T* tmine = tsave + (size_t)cl * A.n_layers;
-  for (int l = 0; l < A.n_layers; ++l) {
-    const T t = d_tanh(dot(W + (int64_t)l * dim) + A.b[l]);
-    if (gl == 0) tmine[l] = t;
-    axpy(UH + (int64_t)l * dim, t);
+  if (!INV) {
+    for (int l = 0; l < A.n_layers; ++l) {
+      const T t = d_tanh(dot(W + (int64_t)l * dim) + A.b[l]);
+      if (gl == 0) tmine[l] = t;
+      axpy(UH + (int64_t)l * dim, t);
+    }
+  } else {
+    // the inverse primal (planar_layer.jl:112-127): last layer first, t_l = tanh(α_l + b_l)
+    for (int l = A.n_layers - 1; l >= 0; --l) {
+      const T a = find_alpha_dev<T>(dot(W + (int64_t)l * dim), A.wtu_hat[l], A.b[l]);
+      const T t = d_tanh(a + A.b[l]);
+      if (gl == 0) tmine[l] = t;
+      axpy(UH + (int64_t)l * dim, -t);
+    }
   }
   __syncthreads();
   load_col(ybar);
   const T lb = lbar ? lbar[col] : T(0);
-  for (int l = A.n_layers - 1; l >= 0; --l) {
-    const T t = tmine[l], c = A.wtu_hat[l];
-    const T q = T(1) - t * t;
-    const T sb = dot(UH + (int64_t)l * dim) * q + lb * c * (T(-2) * t) * q / (T(1) + c * q);
-    axpy(W + (int64_t)l * dim, sb);
+  if (!INV) {
+    for (int l = A.n_layers - 1; l >= 0; --l) {
+      const T t = tmine[l], c = A.wtu_hat[l];
+      const T q = T(1) - t * t;
+      const T sb = dot(UH + (int64_t)l * dim) * q + lb * c * (T(-2) * t) * q / (T(1) + c * q);
+      axpy(W + (int64_t)l * dim, sb);
+    }
+  } else {
+    // find_alpha's implicit-function rule (ext/BijectorsChainRulesCoreExt.jl:42-46): dα/d(wᵀy) = 1/(1 + c q)
+    for (int l = 0; l < A.n_layers; ++l) {
+      const T t = tmine[l], c = A.wtu_hat[l];
+      const T q = T(1) - t * t;
+      const T den = T(1) + c * q;
+      const T sb = q / den * (-dot(UH + (int64_t)l * dim) + lb * T(2) * c * t / den);
+      axpy(W + (int64_t)l * dim, sb);
+    }
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -800,7 +821,7 @@ __device__ __forceinline__ void reg_update(const float* __restrict__ tab, int l0
   }
 }
 
-template <int G, int NL>
+template <int G, int NL, bool INV>
 __global__ __launch_bounds__(256) void planar_vjp_reg_kernel(const PlanarRegArgs A, const float* __restrict__ x, const float* __restrict__ ybar,
                                                              const float* __restrict__ lbar, float* __restrict__ xbar, int dim, int64_t batch) {
   constexpr int COLS = 64;
@@ -828,10 +849,10 @@ __global__ __launch_bounds__(256) void planar_vjp_reg_kernel(const PlanarRegArgs
     }
   };
   const int ngroups = A.nl_pad / NL;
-  // ---- forward sweep: tanh(s_k) of every layer -> tsave
+  // ---- primal sweep: tanh(s_k) (forward map) / tanh(α_k + b_k) (inverse map) of every layer -> tsave
   load_tile(x);
   for (int gi = 0; gi < ngroups; ++gi) {
-    const int l0 = gi * NL;
+    const int l0 = (INV ? ngroups - 1 - gi : gi) * NL;         // the inverse undoes the LAST group first
     reg_dots<G, NL, NS>(A.w, l0, dim, z, st, lane, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
     {
@@ -839,26 +860,31 @@ __global__ __launch_bounds__(256) void planar_vjp_reg_kernel(const PlanarRegArgs
 #pragma unroll
       for (int k = 0; k < NL; ++k) { s[k] = st[lane * NL + k]; t[k] = 0.f; }
 #pragma unroll
-      for (int k = 0; k < NL; ++k) {
+      for (int kk = 0; kk < NL; ++kk) {
+        const int k = INV ? NL - 1 - kk : kk;
         const float* Gk = A.G + (int64_t)(l0 + k) * A.nl_pad + l0;
         float a = s[k];
 #pragma unroll
-        for (int j = 0; j < NL; ++j) if (j < k) a += Gk[j] * t[j];
-        t[k] = fast_tanh(a + A.b[l0 + k]);
+        for (int j = 0; j < NL; ++j) {
+          if (!INV) { if (j < k) a += Gk[j] * t[j]; }
+          else { if (j > k) a += Gk[j] * t[j]; }                 // t holds -tanh for the inverse
+        }
+        if (!INV) t[k] = fast_tanh(a + A.b[l0 + k]);
+        else { float th, ld; find_alpha_act(a, A.wtu_hat[l0 + k], A.b[l0 + k], th, ld); t[k] = -th; }
       }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int k = 0; k < NL; ++k) { st[lane * NL + k] = t[k]; tsave[lane * A.nl_pad + l0 + k] = t[k]; }
+      for (int k = 0; k < NL; ++k) { st[lane * NL + k] = t[k]; tsave[lane * A.nl_pad + l0 + k] = INV ? -t[k] : t[k]; }
     }
     __builtin_amdgcn_wave_barrier();
     if (gi + 1 < ngroups) reg_update<G, NL, NS>(A.u_hat, l0, dim, z, st, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
   }
-  // ---- reverse sweep on the cotangent tile
+  // ---- cotangent sweep, in the opposite order of the primal
   load_tile(ybar);
   const float lb = (lbar && lane < nvalid) ? lbar[col0 + lane] : 0.f;
-  for (int gi = ngroups - 1; gi >= 0; --gi) {
-    const int l0 = gi * NL;
+  for (int gi = 0; gi < ngroups; ++gi) {
+    const int l0 = (INV ? gi : ngroups - 1 - gi) * NL;
     reg_dots<G, NL, NS>(A.u_hat, l0, dim, z, st, lane, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
     {
@@ -867,13 +893,17 @@ __global__ __launch_bounds__(256) void planar_vjp_reg_kernel(const PlanarRegArgs
       for (int k = 0; k < NL; ++k) { g[k] = st[lane * NL + k]; sb[k] = 0.f; }
 #pragma unroll
       for (int kk = 0; kk < NL; ++kk) {
-        const int k = NL - 1 - kk;
+        const int k = INV ? kk : NL - 1 - kk;
         float tb = g[k];
 #pragma unroll
-        for (int j = 0; j < NL; ++j) if (j > k) tb += A.G[(int64_t)(l0 + j) * A.nl_pad + l0 + k] * sb[j];   // û_kᵀ w_j
+        for (int j = 0; j < NL; ++j) {
+          if (INV ? (j < k) : (j > k)) tb += A.G[(int64_t)(l0 + j) * A.nl_pad + l0 + k] * sb[j];   // û_kᵀ w_j
+        }
         const float t = tsave[lane * A.nl_pad + l0 + k], c = A.wtu_hat[l0 + k];
         const float q = 1.0f - t * t;
-        sb[k] = tb * q + lb * c * (-2.0f * t) * q * Fast<float>::rcp(1.0f + c * q);
+        const float rden = Fast<float>::rcp(1.0f + c * q);
+        if (!INV) sb[k] = tb * q + lb * c * (-2.0f * t) * q * rden;
+        else sb[k] = q * rden * (-tb + lb * 2.0f * c * t * rden);        // find_alpha rule: dα/d(wᵀy) = 1/(1 + c q)
       }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1155,8 +1185,8 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
 
 // register-kernel fast path of the pullback (Float32, 16 < dim <= 128); returns 1 when the shape is not served
 template <class T>
-int planar_vjp_reg(bjx_ctx*, const T*, const T*, const T*, const T*, int, const T*, const T*, const T*, T*, int64_t, int64_t) { return 1; }
-inline int planar_vjp_reg(bjx_ctx* ctx, const float* w, const float* u_hat, const float* wtu, const float* b, int nl, const float* in,
+int planar_vjp_reg(bjx_ctx*, int, const T*, const T*, const T*, const T*, int, const T*, const T*, const T*, T*, int64_t, int64_t) { return 1; }
+inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float* u_hat, const float* wtu, const float* b, int nl, const float* in,
                           const float* out_bar, const float* ladj_bar, float* in_bar, int64_t dim, int64_t batch) {
   static const int use_reg = getenv("BJX_PLANAR_REG") ? atoi(getenv("BJX_PLANAR_REG")) : 1;
   if (!(use_reg && dim % 4 == 0 && dim > 16 && dim <= 128 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar))) return 1;
@@ -1178,7 +1208,8 @@ inline int planar_vjp_reg(bjx_ctx* ctx, const float* w, const float* u_hat, cons
   const int64_t grid = (batch + 4 * 64 - 1) / (4 * 64);
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: batch too large for one launch");
   PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad};
-#define LV(G_, NL_) hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch)
+#define LV(G_, NL_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, true>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch); \
+                          else hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, false>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch); } while (0)
 #define LV_NL(G_) switch (NL) { case 1: LV(G_, 1); break; case 2: LV(G_, 2); break; case 4: LV(G_, 4); break; default: LV(G_, 8); break; }
   {
     BjxProf prof_(ctx);
@@ -1191,7 +1222,7 @@ inline int planar_vjp_reg(bjx_ctx* ctx, const float* w, const float* u_hat, cons
 }
 
 template <class T>
-int planar_vjp_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int nl, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar,
+int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, int nl, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar,
                     int64_t dim, int64_t batch) {
   const size_t need = ((size_t)nl * dim + nl) * sizeof(T);
   BJX_REQUIRE(ctx, need <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: n_layers*dim = %lld exceeds the context scratch", (long long)nl * dim);
@@ -1201,7 +1232,7 @@ int planar_vjp_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int nl, co
   BJX_CHECK_LAUNCH(ctx);
   if (batch == 0) return BJX_OK;
   {
-    int rc = planar_vjp_reg(ctx, w, u_hat, wtu, b, nl, in, out_bar, ladj_bar, in_bar, dim, batch);
+    int rc = planar_vjp_reg(ctx, inverse, w, u_hat, wtu, b, nl, in, out_bar, ladj_bar, in_bar, dim, batch);
     if (rc != 1) return rc;                               // 1 = shape not served by the register kernel
   }
   FlowCfg c;
@@ -1217,7 +1248,8 @@ int planar_vjp_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int nl, co
   constexpr int VW = Vec16<T>::N;
   const bool v_ok = c.V == VW && bjx_aligned16(out_bar);
   BjxProf prof_(ctx);
-#define PVJ(V_, R_) hipLaunchKernelGGL((planar_vjp_kernel<T, V_, R_>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G)
+#define PVJ(V_, R_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_kernel<T, V_, R_, true>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G); \
+                         else hipLaunchKernelGGL((planar_vjp_kernel<T, V_, R_, false>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G); } while (0)
 #define PVJ_R(V_) switch (c.R) { case 1: PVJ(V_, 1); break; case 2: PVJ(V_, 2); break; case 4: PVJ(V_, 4); break; case 8: PVJ(V_, 8); break; case 16: PVJ(V_, 16); break; default: PVJ(V_, 32); break; }
   if (v_ok) { PVJ_R(VW) } else {
     // scalar packs: recompute the geometry for V = 1
@@ -1230,7 +1262,8 @@ int planar_vjp_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int nl, co
     c.G = G; c.R = R; c.grid = (batch + (256 / G) - 1) / (256 / G);
     const int cpb = 256 / G;
     const size_t smem1 = (size_t)cpb * nl * sizeof(T) + (lds ? tab_bytes : 0);
-#define PVJ1(R_) hipLaunchKernelGGL((planar_vjp_kernel<T, 1, R_>), dim3((unsigned)c.grid), dim3(256), smem1, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G)
+#define PVJ1(R_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_kernel<T, 1, R_, true>), dim3((unsigned)c.grid), dim3(256), smem1, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G); \
+                      else hipLaunchKernelGGL((planar_vjp_kernel<T, 1, R_, false>), dim3((unsigned)c.grid), dim3(256), smem1, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G); } while (0)
     switch (c.R) { case 1: PVJ1(1); break; case 2: PVJ1(2); break; case 4: PVJ1(4); break; case 8: PVJ1(8); break; case 16: PVJ1(16); break; default: PVJ1(32); break; }
 #undef PVJ1
   }
@@ -1287,13 +1320,13 @@ BJX_API int bjx_planar(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* w, c
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_planar: bad dtype %d", (int)dt);
 }
 
-BJX_API int bjx_planar_vjp(bjx_ctx* ctx, bjx_dtype dt, const void* w, const void* u, const void* b, int n_layers, const void* in,
+BJX_API int bjx_planar_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* w, const void* u, const void* b, int n_layers, const void* in,
                            const void* out_bar, const void* ladj_bar, void* in_bar, int64_t dim, int64_t batch) {
   if (!ctx) return BJX_ERR_ARG;
   BJX_REQUIRE(ctx, dim >= 1 && batch >= 0 && n_layers >= 1, BJX_ERR_SHAPE, "bjx_planar_vjp: bad size (dim=%lld, n_layers=%d)", (long long)dim, n_layers);
   BJX_REQUIRE(ctx, w && u && b && ((in && out_bar && in_bar) || batch == 0), BJX_ERR_ARG, "bjx_planar_vjp: null pointer");
-  if (dt == BJX_F32) return planar_vjp_impl<float>(ctx, (const float*)w, (const float*)u, (const float*)b, n_layers, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, dim, batch);
-  if (dt == BJX_F64) return planar_vjp_impl<double>(ctx, (const double*)w, (const double*)u, (const double*)b, n_layers, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, dim, batch);
+  if (dt == BJX_F32) return planar_vjp_impl<float>(ctx, inverse, (const float*)w, (const float*)u, (const float*)b, n_layers, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, dim, batch);
+  if (dt == BJX_F64) return planar_vjp_impl<double>(ctx, inverse, (const double*)w, (const double*)u, (const double*)b, n_layers, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, dim, batch);
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_planar_vjp: bad dtype %d", (int)dt);
 }
 

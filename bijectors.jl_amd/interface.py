@@ -1254,8 +1254,9 @@ def vjp(b, x, out_bar, ladj_bar=None):
         rc = L.load().bjx_simplex_vjp(ctx.h, _dt(xc), int(inv), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), K, batch)
         L.check(ctx.h, rc, "bjx_simplex_vjp")
         return xb
-    if isinstance(base, PlanarLayer) and not inv:
-        # fused PlanarLayer stack, forward direction (closed-form derivatives of planar_layer.jl:65-110)
+    if isinstance(base, PlanarLayer):
+        # fused PlanarLayer stack, either direction (closed-form derivatives of planar_layer.jl:65-127; find_alpha's
+        # implicit-function rule ext/BijectorsChainRulesCoreExt.jl:42-46 for the inverse)
         xc, dim, batch, vec = _prep(x)
         gc, gdim, gbatch, _ = _prep(out_bar)
         if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:
@@ -1269,7 +1270,7 @@ def vjp(b, x, out_bar, ladj_bar=None):
         lb = _ladj_bar(ladj_bar, batch, xc)
         ctx = context(xc.device)
         xb = _empty(dim, batch, xc, vec)
-        rc = L.load().bjx_planar_vjp(ctx.h, _dt(xc), _ptr(w), _ptr(u), _ptr(bb), base.n_layers, _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
+        rc = L.load().bjx_planar_vjp(ctx.h, _dt(xc), int(inv), _ptr(w), _ptr(u), _ptr(bb), base.n_layers, _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
         L.check(ctx.h, rc, "bjx_planar_vjp")
         return xb
     if not isinstance(base, OrderedBijector):

@@ -161,12 +161,14 @@ int bjx_planar(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* w, const voi
                void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
 
 /* input pullback of with_logabsdet_jacobian for the fused PlanarLayer stack (the reference
- * leaves it to the AD package; closed-form derivatives of planar_layer.jl:65-110):
- *   in_bar = (dy/dz)^T out_bar + ladj_bar[n] * d logabsdetjac[n] / dz.
- * in: the primal input z [dim, batch]; out_bar: cotangent of the output [dim, batch]; ladj_bar: cotangent of the
- * per-column log-det, T[batch] or NULL.  Parameter gradients are not produced. */
-int bjx_planar_vjp(bjx_ctx* ctx, bjx_dtype dt, const void* w, const void* u, const void* b, int n_layers,
-                   const void* in, const void* out_bar, const void* ladj_bar, void* in_bar,
+ * leaves it to the AD package; closed-form derivatives of planar_layer.jl:65-127):
+ *   in_bar = (d out/d in)^T out_bar + ladj_bar[n] * d logabsdetjac[n] / d in.
+ * inverse=0: the flow itself (in = z).  inverse=1: inverse(flow) (in = y; the primal is re-solved with find_alpha and
+ * differentiated with its implicit-function rule, ext/BijectorsChainRulesCoreExt.jl:42-46).
+ * in: primal input [dim, batch]; out_bar: cotangent of the output [dim, batch]; ladj_bar: cotangent of the per-column
+ * log-det, T[batch] or NULL.  Parameter gradients are not produced. */
+int bjx_planar_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* w, const void* u, const void* b,
+                   int n_layers, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar,
                    int64_t dim, int64_t batch);
 
 /* RadialLayer, radial_layer.jl:43-129.  alpha_, beta: device T[1]; z0: device T[dim]. */

@@ -555,6 +555,41 @@ def mvnormal_diag_logpdf(x, mu=None, sigma=None):
     return -0.5 * np.sum(z * z, axis=0) - np.sum(np.log(s)) - 0.5 * d * np.log(2.0 * np.pi)
 
 
+def planar_inv_vjp(w, u, b, y, x_bar, ladj_bar=None):
+    """Input pullback of with_logabsdet_jacobian(inverse(flow), y) for a PlanarLayer stack (planar_layer.jl:112-127 with
+    the implicit-function rule of find_alpha, ext/BijectorsChainRulesCoreExt.jl:42-46: dα/d(wᵀy) = 1/(1 + c sech²(α+b))).
+    The inverse undoes the LAST layer first; per layer, with t = tanh(α + b), q = 1 - t²:
+        z = y - û t,  logabsdetjac = -log1p(c q)
+        s̄ = q/(1 + c q) · (-ûᵀz̄ + ℓ̄ · 2 c t/(1 + c q)),   ȳ = z̄ + w s̄.
+    The t of every layer are read off a forward pass over the pre-image (α_k = w_kᵀz_{k-1}).  numpy, float64."""
+    y = np.asarray(y, dtype=np.float64)
+    dim, N = y.shape
+    w = np.asarray(w, dtype=np.float64).reshape(dim, -1)
+    u = np.asarray(u, dtype=np.float64).reshape(dim, -1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    nl = w.shape[1]
+    lb = np.zeros(N) if ladj_bar is None else np.broadcast_to(np.asarray(ladj_bar, dtype=np.float64), (N,))
+    x, _ = planar(w, u, b, np.asfortranarray(y), inverse=True)
+    u_hat, c = np.empty_like(u), np.empty(nl)
+    for k in range(nl):
+        wtu = float(w[:, k] @ u[:, k])
+        u_hat[:, k] = u[:, k] + (log1pexp(-wtu) - 1.0) / float(w[:, k] @ w[:, k]) * w[:, k]
+        c[k] = log1pexp(wtu) - 1.0
+    ts, cur = [], np.asarray(x, dtype=np.float64)
+    for k in range(nl):
+        t = np.tanh(w[:, k] @ cur + b[k])
+        ts.append(t)
+        cur = cur + np.outer(u_hat[:, k], t)
+    g = np.asarray(x_bar, dtype=np.float64).copy()          # cotangent of the pre-image = output of the inverse of layer 0
+    for k in range(nl):                                       # the inverse applied layer nl-1 first: pull back in the opposite order
+        t = ts[k]
+        q = 1.0 - t * t
+        den = 1.0 + c[k] * q
+        sbar = q / den * (-(u_hat[:, k] @ g) + lb * 2.0 * c[k] * t / den)
+        g = g + np.outer(w[:, k], sbar)
+    return g
+
+
 def planar_vjp(w, u, b, z, y_bar, ladj_bar=None):
     """Input pullback of with_logabsdet_jacobian for a stack of PlanarLayers (planar_layer.jl:65-110; the reference
     leaves it to the AD package — these are the closed-form derivatives of its expressions):

@@ -157,6 +157,8 @@ def main():
     lbz = randn(Np, 1, dev, 22).reshape(-1).contiguous()
     rows.append(("vjp(8×PlanarLayer) d=128", "f-1", lambda: bj.vjp(flow, z, gz, lbz), 4 * 3 * dp + 4, Np))
 
+    rows.append(("vjp(inverse(8×PlanarLayer)) d=128", "f-1", lambda: bj.vjp(bj.inverse(flow), zf, gz, lbz), 4 * 3 * dp + 4, Np))
+
     # §8(f) f-3: logpdf(td, Y) fused into the inverting kernel — Y is read once, x is never stored
     td_pl = bj.transformed(bj.MvNormal(dp), flow)
     rows.append(("logpdf(transformed(MvNormal(128), 8×PlanarLayer)) d=128", "f-3", lambda: bj.logpdf(td_pl, zf), 4 * dp + 4, Np))

@@ -1019,6 +1019,10 @@ def test_planar_vjp(bj, orc, dim, nl, N, dt):
     ref0 = orc.planar_vjp(w, u, b, Z, gbar)
     got0 = bj.vjp(flow, dev(Z), dev(gbar))
     np.testing.assert_allclose(host(got0), ref0, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref0).max())))
+    # inverse(flow): the primal is re-solved with find_alpha and differentiated with its implicit-function rule
+    ref_i = orc.planar_inv_vjp(w, u, b, Z, gbar, lbar)
+    got_i = bj.vjp(bj.inverse(flow), dev(Z), dev(gbar), torch.from_numpy(lbar).cuda())
+    np.testing.assert_allclose(host(got_i), ref_i, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref_i).max())))
 
 
 # ------------------------------------------------------------------ §8(f) f-2: VectorBijectors homogeneous products, batched over chains

@@ -494,6 +494,8 @@ def test_planar_pullback_matches_finite_differences(orc):
         fwd = lambda v: orc.planar(w, u, b, np.asfortranarray(v))
         np.testing.assert_allclose(orc.planar_vjp(w, u, b, z, gbar, lbar), _fd_vjp(fwd, z, gbar, lbar), rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(orc.planar_vjp(w, u, b, z, gbar), _fd_vjp(fwd, z, gbar, np.zeros(N)), rtol=1e-6, atol=1e-7)
+        inv = lambda v: orc.planar(w, u, b, np.asfortranarray(v), inverse=True)
+        np.testing.assert_allclose(orc.planar_inv_vjp(w, u, b, z, gbar, lbar), _fd_vjp(inv, z, gbar, lbar), rtol=1e-6, atol=1e-7)
 
 
 def test_forward_lkj_link_pullback_on_the_constraint_manifold(orc):
