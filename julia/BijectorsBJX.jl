@@ -254,6 +254,37 @@ function ChainRulesCore.rrule(::typeof(Bijectors._inv_link_chol_lkj), y::ROCMatr
     return (W, logJ), pullback_inv_link_chol_lkj
 end
 
+# forward LKJ link on a batch of factors W[K, K, n] (ext/BijectorsChainRulesCoreExt.jl:199-311)
+for (f, uplo) in ((:_link_chol_lkj_from_upper, 'U'), (:_link_chol_lkj_from_lower, 'L'))
+    @eval function ChainRulesCore.rrule(::typeof(Bijectors.$f), W::ROCArray{T,3}) where {T}
+        K, n = size(W, 1), size(W, 3)
+        y = first(with_logabsdet_jacobian(VecCholeskyBijector(Symbol($uplo)), W))
+        function pullback_link_chol_lkj(Δz)
+            ΔW = similar(W); Δc = ROCArray{T}(ChainRulesCore.unthunk(Δz))
+            GC.@preserve W Δc ΔW check(ccall((:bjx_vec_cholesky_fwd_vjp, libbjx), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+                ctx().h, dtype(T), Cint($uplo), devptr(W), devptr(Δc), devptr(ΔW), K, n), "bjx_vec_cholesky_fwd_vjp")
+            return ChainRulesCore.NoTangent(), ΔW
+        end
+        return y, pullback_link_chol_lkj
+    end
+end
+# PlanarLayer stack and its inverse: input pullback (parameters: not implemented on the device)
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::Union{PlanarLayer,Inverse{<:PlanarLayer}}, z::ROCMatrix{T}) where {T}
+    inv = flow isa Inverse; pl = inv ? flow.orig : flow
+    out = with_logabsdet_jacobian(flow, z)
+    function pullback_planar((Δy, Δl))
+        z̄ = similar(z); Δyc = ROCArray{T}(ChainRulesCore.unthunk(Δy)); Δlc = ROCArray{T}(ChainRulesCore.unthunk(Δl))
+        w, u, b = ROCArray{T}(pl.w), ROCArray{T}(pl.u), ROCArray{T}(pl.b)
+        GC.@preserve z Δyc Δlc z̄ w u b check(ccall((:bjx_planar_vjp, libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+            ctx().h, dtype(T), Cint(inv), devptr(w), devptr(u), devptr(b), 1, devptr(z), devptr(Δyc), devptr(Δlc), devptr(z̄),
+            size(z, 1), size(z, 2)), "bjx_planar_vjp")
+        return ChainRulesCore.NoTangent(), ChainRulesCore.@not_implemented("PlanarLayer parameter gradients"), z̄
+    end
+    return out, pullback_planar
+end
+
 # ---------------------------------------------------------------- logpdf of a TransformedDistribution (SURVEY.md §8f f-3)
 # src/transformed_distribution.jl:164-169 in ONE pass over y: the inverse chain, the whitening of the diagonal-normal
 # base and the standard-normal density are ops of the same launch; the pre-image is not stored (y pointer = C_NULL).
