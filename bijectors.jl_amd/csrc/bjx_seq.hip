@@ -712,7 +712,7 @@ __global__ __launch_bounds__(64 * CHOL_WPB) void chol_fwd_chunk_kernel(const T* 
       constexpr int ZV = 16 / sizeof(T);
       const int nz = K * K / ZV;
       if (bjx_aligned16_dev(Ws)) {
-        constexpr int SU = 8;
+        constexpr int SU = 16;
         for (int i0 = lane; i0 < nz; i0 += 64 * SU) {
           typename Vec16<T>::type t[SU];
 #pragma unroll
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(64 * CHOL_WPB) void chol_inv_vjp_kernel(const T* __
     constexpr int ZV = 16 / sizeof(T);
     const int nz = K * K / ZV;
     if (bjx_aligned16_dev(Ws)) {
-      constexpr int SU = 8;
+      constexpr int SU = 16;
       for (int i0 = lane; i0 < nz; i0 += 64 * SU) {
         typename Vec16<T>::type t[SU];
 #pragma unroll
@@ -2310,7 +2310,13 @@ __global__ __launch_bounds__(64) void chol_fwd_vjp_kernel(const T* __restrict__ 
   {
     int e = lane * V, c = e / K, r = e % K;
     const int dc = (64 * V) / K, dr = (64 * V) % K;
-    constexpr int SU = 4;
+    // every load of the sample in flight before the first LDS write (K = 64: 16 + 8 packs per lane): staged in
+    // rounds of 4 the load phase was four serial HBM round trips per wave, and with ~1.5 waves per SIMD (24 KiB of LDS
+    // per sample) that latency was the whole kernel
+    constexpr int SU = 16, SZ = 8;
+    Pack<T, V> pz[SZ];
+#pragma unroll
+    for (int u = 0; u < SZ; ++u) { const int i = (lane + 64 * u) * V; if (i < nv) pz[u] = load_pack<T, V, true>(zs + i); }
     for (; e < ne; e += SU * 64 * V) {
       Pack<T, V> p[SU];
 #pragma unroll
@@ -2326,7 +2332,15 @@ __global__ __launch_bounds__(64) void chol_fwd_vjp_kernel(const T* __restrict__ 
         if (r >= K) { r -= K; ++c; }
       }
     }
-    for (int i = lane * V; i < nv; i += 64 * V) {
+#pragma unroll
+    for (int u = 0; u < SZ; ++u) {
+      const int i = (lane + 64 * u) * V;
+      if (i < nv) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) dz[i + j] = pz[u].v[j];
+      }
+    }
+    for (int i = (lane + 64 * SZ) * V; i < nv; i += 64 * V) {
       const Pack<T, V> q = load_pack<T, V, true>(zs + i);
 #pragma unroll
       for (int j = 0; j < V; ++j) dz[i + j] = q.v[j];
@@ -2344,19 +2358,42 @@ __global__ __launch_bounds__(64) void chol_fwd_vjp_kernel(const T* __restrict__ 
     rs *= rs;
     T dtmp = T(0);
     const int imax = (jb + 63 < K - 1 ? jb + 63 : K - 1) - 1;            // longest column of this strip
-    for (int i = imax; i >= 1; --i) {
-      const bool on = live && i < j;
-      const int a = at(on ? i : 0, jj);
-      const T w = tile[a];
-      const T dzi = dz[base + (on ? i : 0)];
-      const T rs2 = rs + w * w;
-      const T rt = F::rsqrt(rs2);                                       // 1/tmp
-      const T p = w * rt;
-      const T q = T(1) - p * p;
-      const T rf = F::rsqrt(q);                                         // 1/ftmp
-      const T dp = dzi * F::rcp(q) - dtmp * (rs2 * rt) * (p * rf);
-      const T dtn = dtmp * (q * rf) - dp * (w * rt * rt);
-      if (on) { tile[a] = dp * rt; rs = rs2; dtmp = dtn; }
+    // Rows in groups of 4: the LDS reads of a group are issued together, everything that does not depend on the
+    // adjoint chain (tmp, p, the coefficients of Δtmp <- B·Δtmp + A) is evaluated for the four rows side by side,
+    // and only the one-FMA chain and the in-place stores are serial.  (Row by row the loop was a chain of LDS read
+    // -> two dependent transcendentals -> LDS write that the compiler may not reorder across the stores.)
+    for (int i = imax; i >= 1; i -= 4) {
+      bool on[4];
+      int a[4];
+      T w[4], dzi[4], rs2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ii = i - u;
+        on[u] = live && ii >= 1 && ii < j;
+        a[u] = at(on[u] ? ii : 0, jj);
+        w[u] = on[u] ? tile[a[u]] : T(0);
+        dzi[u] = dz[base + (on[u] ? ii : 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { rs2[u] = rs + w[u] * w[u]; rs = rs2[u]; }      // off rows add 0
+      T rt[4], X[4], A[4], B[4], D[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        rt[u] = F::rsqrt(rs2[u]);                                        // 1/tmp
+        const T p = w[u] * rt[u];
+        const T q = T(1) - p * p;
+        const T rf = F::rsqrt(q);                                        // 1/ftmp
+        X[u] = (rs2[u] * rt[u]) * (p * rf);                              // tmp · p/ftmp
+        D[u] = dzi[u] * F::rcp(q);                                       // Δz/(1-p²)
+        const T g = w[u] * rt[u] * rt[u];                                // W/tmp²
+        B[u] = q * rf + X[u] * g;                                        // Δtmp' = B Δtmp + A
+        A[u] = -D[u] * g;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const T dp = D[u] - dtmp * X[u];
+        if (on[u]) { tile[a[u]] = dp * rt[u]; dtmp = B[u] * dtmp + A[u]; }
+      }
     }
     if (live) {
       const int a0 = at(0, j);
