@@ -15,6 +15,7 @@ BJX_F32, BJX_F64 = 0, 1
 BJX_ACCUMULATE = 1 << 0
 BJX_REF_VECTOR_SCALE_LADJ = 1 << 1
 BJX_BASE_STDNORMAL = 1 << 2
+BJX_INPUT_STDNORMAL = 1 << 3
 BJX_MAX_OPS = 8
 
 (OP_EXP, OP_LOG, OP_SHIFT, OP_SCALE, OP_SCALE_INV, OP_LOGIT, OP_LOGIT_INV, OP_LEAKY_RELU,
@@ -63,6 +64,7 @@ SIGNATURES = {
     "bjx_stacked": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _vp, _vp, _vp, _i64, _i64, _u32]),
     "bjx_stacked_vjp": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_set_option": (_i, [_vp, _i, _i]),
+    "bjx_set_rng": (_i, [_vp, _u64, _i64]),
     "bjx_chain": (_i, [_vp, _i, C.POINTER(BjxOp), _i, _vp, _vp] + _tail),
     "bjx_ordered": (_i, [_vp, _i, _i, _vp, _vp] + _tail),
     "bjx_simplex": (_i, [_vp, _i, _i, _vp, _vp] + _tail),

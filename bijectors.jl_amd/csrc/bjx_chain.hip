@@ -190,9 +190,23 @@ __device__ __forceinline__ T apply_chain(const ChainArgs<T>& A, Pack<T, V> (&p)[
 
 // U 16-byte packs per thread (the block owns U consecutive 4 KiB rows), non-persistent grid (see the
 // header comment).
-template <class T, int V, int ROWMODE, bool NT, int U>
+// GEN: the input packs are drawn instead of loaded (BJX_INPUT_STDNORMAL): pack i = elements 4i..4i+3 of the global
+// stream = one Philox counter (Float32) or half of one (Float64).
+template <class T, int V> __device__ __forceinline__ Pack<T, V> gen_pack(uint64_t seed, int64_t e_global) {
+  Pack<T, V> p;
+  T z[4];
+  philox_normal4(seed, e_global >> 2, z);
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int k = (int)((e_global + j) & 3);
+    if (j > 0 && k == 0) philox_normal4(seed, (e_global + j) >> 2, z);   // the pack straddles two counters (col0·dim not a multiple of 4)
+    p.v[j] = (T)(k == 0 ? z[0] : (k == 1 ? z[1] : (k == 2 ? z[2] : z[3])));
+  }
+  return p;
+}
+template <class T, int V, int ROWMODE, bool NT, int U, bool GEN = false>
 __global__ __launch_bounds__(256) void chain_flat_kernel(const ChainArgs<T> A, const T* x, T* y, int64_t n,
-                                                         int64_t dim, int dim_pow2, double* partials) {
+                                                         int64_t dim, int dim_pow2, double* partials, uint64_t seed = 0, int64_t e0 = 0) {
   __shared__ double red[4];
   const int64_t nv = n / V;
   const int64_t i0 = (int64_t)blockIdx.x * (256 * U) + threadIdx.x;
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(256) void chain_flat_kernel(const ChainArgs<T> A, c
     Pack<T, V> p[U];
     int64_t r[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) p[u] = load_pack<T, V, NT>(x + (i0 + u * 256) * V);
+    for (int u = 0; u < U; ++u) p[u] = GEN ? gen_pack<T, V>(seed, e0 + (i0 + u * 256) * V) : load_pack<T, V, NT>(x + (i0 + u * 256) * V);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       r[u] = 0;
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(256) void chain_flat_kernel(const ChainArgs<T> A, c
       const int64_t i = i0 + u * 256;
       if (i < nv) {
         Pack<T, V> p[1];
-        p[0] = load_pack<T, V, NT>(x + i * V);
+        p[0] = GEN ? gen_pack<T, V>(seed, e0 + i * V) : load_pack<T, V, NT>(x + i * V);
         int64_t r[1] = {0};
         if constexpr (ROWMODE != 0) r[0] = (i * V) % dim;
         T l = apply_chain<T, V, 1, ROWMODE>(A, p, r, dim);
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(256) void chain_flat_kernel(const ChainArgs<T> A, c
       } else if (V > 1 && i == nv) {
         for (int64_t e = nv * V; e < n; ++e) {
           Pack<T, 1> q[1];
-          q[0].v[0] = x[e];
+          q[0].v[0] = GEN ? gen_pack<T, 1>(seed, e0 + e).v[0] : x[e];
           int64_t r[1] = {ROWMODE == 0 ? 0 : e % dim};
           T l = apply_chain<T, 1, 1, (ROWMODE == 0 ? 0 : 2)>(A, q, r, dim);
           if (y) y[e] = q[0].v[0];
@@ -428,6 +442,32 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
   const int dim_pow2 = (dim & (dim - 1)) == 0 ? 1 : 0;
   int64_t grid = 1;
 
+  if (flags & BJX_INPUT_STDNORMAL) {
+    // on-device sampling: the input packs are drawn inside the kernel (flat geometry; sum-only log-det)
+    BJX_REQUIRE(ctx, !ladj_ps, BJX_ERR_UNSUPPORTED, "bjx_chain: BJX_INPUT_STDNORMAL returns the values and, optionally, the summed log-det only");
+    BJX_REQUIRE(ctx, y, BJX_ERR_ARG, "bjx_chain: BJX_INPUT_STDNORMAL needs an output buffer");
+    constexpr int UG = 2;
+    const int64_t e0 = ctx->rng_col0 * dim;
+    const bool yv = bjx_aligned16(y);
+#define LAUNCH_GEN(V_, RM_)                                                                                          \
+  do {                                                                                                               \
+    grid = (n / V_ + 1 + 256 * UG - 1) / (256 * UG);                                                                 \
+    BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_chain: input too large for one launch");     \
+    if (ladj_sum) { int rc_ = bjx_ensure_partials(ctx, (size_t)grid); if (rc_) return rc_; }                         \
+    double* partials = ladj_sum ? ctx->partials : nullptr;                                                           \
+    BjxProf prof_(ctx);                                                                                              \
+    hipLaunchKernelGGL((chain_flat_kernel<T, V_, RM_, true, UG, true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, (const T*)nullptr, y, n, dim, dim_pow2, partials, ctx->rng_seed, e0); \
+  } while (0)
+    if (!any_row) { if (yv) LAUNCH_GEN(VW, 0); else LAUNCH_GEN(1, 0); }
+    else if (yv && rows_vec) LAUNCH_GEN(VW, 1);
+    else if (yv) LAUNCH_GEN(VW, 2);
+    else LAUNCH_GEN(1, 2);
+#undef LAUNCH_GEN
+    BJX_CHECK_LAUNCH(ctx);
+    if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, c_sum_host, any_dev_scale ? 1 : 0, 0.0, flags);
+    return BJX_OK;
+  }
+
   // Packs per thread (measured on MI355X, profiles/r01_chain_tuning.txt): a wave lives for one memory
   // round trip, so its compute latency must be amortised over enough bytes in flight.  1 light
   // stage: 2 packs (6.3 TB/s vs 5.9 with 1 / 5.7 with 4); anything heavier: 4 packs
@@ -520,7 +560,7 @@ BJX_API int bjx_chain(bjx_ctx* ctx, bjx_dtype dt, const bjx_op* ops, int n_ops, 
   BJX_REQUIRE(ctx, n_ops >= 0 && n_ops <= BJX_MAX_OPS && (ops || n_ops == 0), BJX_ERR_ARG, "bjx_chain: n_ops must be in [0, %d]", BJX_MAX_OPS);
   BJX_REQUIRE(ctx, dim >= 0 && batch >= 0, BJX_ERR_SHAPE, "bjx_chain: negative size");
   // y == NULL: only the log-det (and, with the density op, logpdf) is wanted — the values are not stored
-  BJX_REQUIRE(ctx, (x && (y || ladj_ps || ladj_sum)) || dim * batch == 0, BJX_ERR_ARG, "bjx_chain: null data pointer");
+  BJX_REQUIRE(ctx, ((x || (flags & BJX_INPUT_STDNORMAL)) && (y || ladj_ps || ladj_sum)) || dim * batch == 0, BJX_ERR_ARG, "bjx_chain: null data pointer");
   bjx_op ext[BJX_MAX_OPS];
   if (flags & BJX_BASE_STDNORMAL) {
     BJX_REQUIRE(ctx, n_ops < BJX_MAX_OPS, BJX_ERR_UNSUPPORTED, "bjx_chain: BJX_BASE_STDNORMAL needs a free op slot (n_ops < %d)", BJX_MAX_OPS);

@@ -219,20 +219,6 @@ BJX_API int bjx_kernel_time_end(bjx_ctx* ctx, float* total_ms, int* launches) {
 // Element e of the GLOBAL array (col0*dim + local index) always gets the same value, so a batch
 // is identical for any shard count.
 namespace {
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1, uint32_t* out) {
-  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += W0; k1 += W1;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
 template <class T>
 __global__ __launch_bounds__(256) void fill_normal_kernel(T* __restrict__ out, int64_t n_local, int64_t e0,
                                                            uint64_t seed, double mean, double std) {
@@ -240,20 +226,8 @@ __global__ __launch_bounds__(256) void fill_normal_kernel(T* __restrict__ out, i
   const int64_t c_first = e0 >> 2, c_last = (e0 + n_local - 1) >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t c = c_first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c <= c_last; c += stride) {
-    uint32_t r[4];
-    philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    double z[4];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      // u1 in (0,1], u2 in [0,1)
-      double u1 = ((double)r[2 * p] + 1.0) * (1.0 / 4294967296.0);
-      double u2 = (double)r[2 * p + 1] * (1.0 / 4294967296.0);
-      double rad = sqrt(-2.0 * log(u1));
-      double s, co;
-      sincospi(2.0 * u2, &s, &co);
-      z[2 * p] = rad * co;
-      z[2 * p + 1] = rad * s;
-    }
+    T z[4];
+    bjx::philox_normal4(seed, c, z);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int64_t e = (c << 2) + j - e0;
@@ -262,6 +236,14 @@ __global__ __launch_bounds__(256) void fill_normal_kernel(T* __restrict__ out, i
   }
 }
 }  // namespace
+
+BJX_API int bjx_set_rng(bjx_ctx* ctx, uint64_t seed, int64_t col0) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, col0 >= 0, BJX_ERR_ARG, "bjx_set_rng: negative column offset");
+  ctx->rng_seed = seed;
+  ctx->rng_col0 = col0;
+  return BJX_OK;
+}
 
 BJX_API int bjx_fill_normal(bjx_ctx* ctx, bjx_dtype dt, void* out, int64_t dim, int64_t batch, int64_t col0,
                             uint64_t seed, double mean, double std) {

@@ -33,6 +33,8 @@ struct bjx_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cu = 256;
   int opt_inkernel_fin = 0;     // BJX_OPT_INKERNEL_FINALIZE
+  uint64_t rng_seed = 0;        // bjx_set_rng: stream of the fused sampling path (BJX_INPUT_STDNORMAL)
+  int64_t rng_col0 = 0;
   // per-launch timing of the DOMINANT kernel of each call (bjx_kernel_time_begin/_end): event pairs
   // recorded right around the hot kernel, so helper launches and host gaps are excluded
   static constexpr int PROF_MAX = 1024;
@@ -220,6 +222,54 @@ template <class T> __device__ __forceinline__ T f_log1pexp(T x) {
   if (x < Num<T>::l1pe1) return Fast<T>::log1p(e);
   if (x < Num<T>::l1pe2) return x + e;
   return x;
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 standard normals
+// Counter = GLOBAL element index / 4, key = seed; 4 x u32 -> 2 Box-Muller pairs -> 4 normals (Float64 math, the
+// result is rounded to T once).  Element e of the global array (col0*dim + local index) always gets the same
+// value, so a batch is identical for any shard count; bjx_fill_normal and the fused sampling path
+// of bjx_chain (BJX_INPUT_STDNORMAL) draw from the same stream.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ void philox_normal4(uint64_t seed, int64_t counter, double (&z)[4]) {
+  uint32_t r[4];
+  philox4x32_10((uint32_t)counter, (uint32_t)((uint64_t)counter >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const double u1 = ((double)r[2 * p] + 1.0) * (1.0 / 4294967296.0);    // (0, 1]
+    const double u2 = (double)r[2 * p + 1] * (1.0 / 4294967296.0);        // [0, 1)
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, co;
+    sincospi(2.0 * u2, &sn, &co);
+    z[2 * p] = rad * co;
+    z[2 * p + 1] = rad * sn;
+  }
+}
+// Float32 outputs: the Box-Muller step on the hardware units (v_log_f32, v_sqrt_f32, v_sin_f32 / v_cos_f32 take the
+// angle in revolutions) — the Float64 version above is ~150 VALU per normal and made both the fill and the fused
+// sampling kernel VALU-bound at 13 % of the HBM write rate.  Same counters, same uniforms; the stream of a dtype is
+// defined by its own routine, identical in bjx_fill_normal and in the fused path.
+__device__ __forceinline__ void philox_normal4(uint64_t seed, int64_t counter, float (&z)[4]) {
+  uint32_t r[4];
+  philox4x32_10((uint32_t)counter, (uint32_t)((uint64_t)counter >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float u1 = ((float)r[2 * p] + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
+    const float u2 = (float)r[2 * p + 1] * 2.3283064365386963e-10f;       // [0, 1]
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+    z[2 * p] = rad * __builtin_amdgcn_cosf(u2);
+    z[2 * p + 1] = rad * __builtin_amdgcn_sinf(u2);
+  }
 }
 
 // ------------------------------------------------------------------ reductions (wave = 64)

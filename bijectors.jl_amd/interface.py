@@ -586,7 +586,7 @@ def _stage_ops(s):
     return None
 
 
-def _run_chain(ops: Sequence, x: torch.Tensor, per_sample: bool, want_ladj: bool = True, out_y: Optional[torch.Tensor] = None, store: bool = True):
+def _run_chain(ops: Sequence, x: torch.Tensor, per_sample: bool, want_ladj: bool = True, out_y: Optional[torch.Tensor] = None, store: bool = True, flags: int = 0):
     """One bjx_chain launch.  ops: [(kind, p0, p1)] in application order.  store=False: the values are not
     written (log-det / log-density only: half the traffic)."""
     xc, dim, batch, vec = _prep(x)
@@ -619,8 +619,8 @@ def _run_chain(ops: Sequence, x: torch.Tensor, per_sample: bool, want_ladj: bool
         if y.shape != x.shape or y.dtype != xc.dtype or y.device != xc.device or (y.dim() == 2 and colmajor(y) is not y):
             raise ValueError("DimensionMismatch: output buffer must match the input's shape, dtype and column-major layout")
     out = _Out(xc, batch, per_sample, want_ladj)
-    flags = L.BJX_REF_VECTOR_SCALE_LADJ  # reproduce scale.jl:31-32 in the scalar the reference returns
-    rc = L.load().bjx_chain(ctx.h, _dt(xc), arr, len(ops), _ptr(xc), _ptr(y), _ptr(out.ps), _ptr(out.sum), dim, batch, flags)
+    flags |= L.BJX_REF_VECTOR_SCALE_LADJ  # reproduce scale.jl:31-32 in the scalar the reference returns
+    rc = L.load().bjx_chain(ctx.h, _dt(xc), arr, len(ops), None if flags & L.BJX_INPUT_STDNORMAL else _ptr(xc), _ptr(y), _ptr(out.ps), _ptr(out.sum), dim, batch, flags)
     L.check(ctx.h, rc, "bjx_chain")
     del keep
     if not want_ladj:
@@ -1389,18 +1389,22 @@ def logpdf(td: TransformedDistribution, y, reference_shape: bool = False):
     return _run_chain(base, x, True, True, store=False)[1] + lj
 
 
-def rand(td: TransformedDistribution, n: int, seed: int = 0, device=None, dtype=torch.float32, col0: int = 0):
+def rand(td: TransformedDistribution, n: int, seed: int = 0, device=None, dtype=torch.float32, col0: int = 0, fused: bool = True):
     """`rand(rng, td::MvTransformed, n)` (src/transformed_distribution.jl:214-224: sample the base, push every
     column through the transform): base samples from the counter-based generator of bjx_fill_normal (identical
     for any shard count: keyed by seed, global column and row), colouring μ + σ·z fused into the transform's
-    chain when there is one."""
+    chain when there is one — and then drawn INSIDE that kernel (`fused=False`: fill, then transform; same bits)."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     dim = td.dist.dim
     z = torch.empty((n, dim), dtype=dtype, device=device).T
     ctx = context(device)
-    L.check(ctx.h, L.load().bjx_fill_normal(ctx.h, _dt(z), _ptr(z), dim, n, col0, seed, 0.0, 1.0), "bjx_fill_normal")
     color = td.dist._color_ops()
     ops = _fused_ops(td.transform)
+    if ops is not None and len(ops) + len(color) <= L.BJX_MAX_OPS and fused:
+        # ONE launch: the base samples are drawn inside the chain kernel (BJX_INPUT_STDNORMAL), never written
+        L.check(ctx.h, L.load().bjx_set_rng(ctx.h, seed, col0), "bjx_set_rng")
+        return _run_chain(color + list(ops), z, False, False, out_y=z, flags=L.BJX_INPUT_STDNORMAL)[0]
+    L.check(ctx.h, L.load().bjx_fill_normal(ctx.h, _dt(z), _ptr(z), dim, n, col0, seed, 0.0, 1.0), "bjx_fill_normal")
     if ops is not None and len(ops) + len(color) <= L.BJX_MAX_OPS:
         return _run_chain(color + list(ops), z, False, False, out_y=z)[0]
     if color:

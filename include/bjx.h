@@ -66,7 +66,12 @@ enum {
    * -1/2 |out|^2 - dim/2 log(2 pi), to ladj_ps / ladj_sum.  With the inverse flow as the bijector the call
    * returns logpdf(td, y) per column; `out` may then be NULL (the pre-image is not stored: half the traffic).
    * Honoured by bjx_chain (same as appending BJX_OP_STDNORMAL_LOGPDF) and bjx_planar. */
-  BJX_BASE_STDNORMAL = 1u << 2
+  BJX_BASE_STDNORMAL = 1u << 2,
+  /* On-device sampling (rand(td, n), src/transformed_distribution.jl:214-224): the INPUT of bjx_chain is not read but
+   * drawn — standard normals from the counter-based generator of bjx_fill_normal, stream (seed, first global column)
+   * set with bjx_set_rng; `x` may be NULL.  The values are bit-identical to bjx_fill_normal followed by the chain,
+   * for any shard count. */
+  BJX_INPUT_STDNORMAL = 1u << 3
 };
 
 /* ---------------------------------------------------------------- context */
@@ -86,6 +91,8 @@ int bjx_synchronize(bjx_ctx* ctx);
  * than the ~10 us of extra launches (profiles/r01_finalize_variants.txt). */
 enum { BJX_OPT_INKERNEL_FINALIZE = 1 };
 int bjx_set_option(bjx_ctx* ctx, int option, int value);
+/* Stream of BJX_INPUT_STDNORMAL: element (row, col) of a call draws value number (col0 + col) * dim + row of `seed`. */
+int bjx_set_rng(bjx_ctx* ctx, uint64_t seed, int64_t col0);
 
 /* ------------------------------------------- F1: fused elementwise chains */
 /* One entry of a `ComposedFunction` chain (src/bijectors/composed.jl:4-25) after the host has

@@ -165,6 +165,7 @@ def main():
     td_ch = bj.transformed(bj.MvNormal(torch.zeros(d, device=dev), torch.ones(d, device=dev)), e(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5))
     rows.append(("logpdf(transformed(MvNormal(μ,σ), exp∘Shift∘Scale)) d=64", "f-3", lambda: bj.logpdf(td_ch, xpos), 4 * d + 4, N))
 
+    rows.append(("rand(transformed(MvNormal(μ,σ), exp∘Shift∘Scale), 2^22) d=64 (samples drawn in the kernel)", "f-3", lambda: bj.rand(td_ch, N, seed=1), 4 * d, N))
     c2b = e(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5)
     rows.append(("logabsdetjac(exp∘Shift∘Scale) alone (values not stored)", "a1,a5", lambda: bj.logabsdetjac(c2b, x), 4 * d, N))
 

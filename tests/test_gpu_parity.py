@@ -995,6 +995,13 @@ def test_logpdf_transformed_structured_and_rand(bj, orc):
     assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
     S2 = bj.rand(tdc, 1024, seed=5, dtype=torch.float64, col0=1024)   # shard-count independence: columns 1024..2047
     assert np.array_equal(host(S2), host(S)[:, 1024:2048])
+    S_unfused = bj.rand(tdc, 4096, seed=5, dtype=torch.float64, fused=False)   # fill, then transform: same stream, same bits
+    assert np.array_equal(host(S_unfused), host(S))
+    for dtt, dimr in ((torch.float32, 64), (torch.float32, 7), (torch.float64, 5)):   # odd dims: packs straddle Philox counters
+        tdr = bj.transformed(bj.MvNormal(dimr), bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5))
+        A = bj.rand(tdr, 1000, seed=9, dtype=dtt, col0=3)
+        B = bj.rand(tdr, 1000, seed=9, dtype=dtt, col0=3, fused=False)
+        assert torch.equal(A, B)
     lp = host(bj.logpdf(tdc, S))
     ref = orc.mvnormal_diag_logpdf(np.log(host(S)) - 0.25, mu, sg) - np.log(host(S)).sum(axis=0)
     np.testing.assert_allclose(lp, ref, rtol=1e-9, atol=1e-8)
