@@ -2237,7 +2237,7 @@ BJX_API int bjx_simplex(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in,
   BJX_REQUIRE(ctx, K > 1, BJX_ERR_SHAPE, "bjx_simplex: x needs to be of length greater than 1 (simplex.jl:30), got K=%lld", (long long)K);
   BJX_REQUIRE(ctx, batch >= 0, BJX_ERR_SHAPE, "bjx_simplex: negative batch");
   BJX_REQUIRE(ctx, in || batch == 0, BJX_ERR_ARG, "bjx_simplex: null input");
-  BJX_REQUIRE(ctx, out || !inverse, BJX_ERR_ARG, "bjx_simplex: the inverse needs an output buffer");
+  BJX_REQUIRE(ctx, out || !inverse || batch == 0, BJX_ERR_ARG, "bjx_simplex: the inverse needs an output buffer");
   if (dt == BJX_F32) return simplex_impl<float>(ctx, inverse, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, K, batch, flags);
   if (dt == BJX_F64) return simplex_impl<double>(ctx, inverse, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, K, batch, flags);
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_simplex: bad dtype %d", (int)dt);

@@ -501,7 +501,7 @@ BJX_API int bjx_stacked_vjp(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs,
   if (!ctx) return BJX_ERR_ARG;
   BJX_REQUIRE(ctx, dim >= 0 && batch >= 0 && n_segs >= 0, BJX_ERR_SHAPE, "bjx_stacked_vjp: negative size");
   BJX_REQUIRE(ctx, (segs || n_segs == 0) && ((x && y_bar && x_bar) || dim * batch == 0), BJX_ERR_ARG, "bjx_stacked_vjp: null pointer");
-  BJX_REQUIRE(ctx, x_bar != x, BJX_ERR_ARG, "bjx_stacked_vjp: x_bar may not alias x");
+  BJX_REQUIRE(ctx, x_bar != x || dim * batch == 0, BJX_ERR_ARG, "bjx_stacked_vjp: x_bar may not alias x");
   BJX_REQUIRE(ctx, dim < ((int64_t)1 << 31), BJX_ERR_UNSUPPORTED, "bjx_stacked_vjp: too many rows");
   if (dt == BJX_F32) return stacked_vjp_impl<float>(ctx, segs, n_segs, (const float*)x, (const float*)y_bar, (const float*)ladj_bar, (float*)x_bar, dim, batch);
   if (dt == BJX_F64) return stacked_vjp_impl<double>(ctx, segs, n_segs, (const double*)x, (const double*)y_bar, (const double*)ladj_bar, (double*)x_bar, dim, batch);

@@ -1122,3 +1122,40 @@ def test_vec_cholesky_forward_link_vjp(bj, orc, K, N, uplo, dt):
     np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref).max())))
     g1 = bj.vjp(b, torch.from_numpy(np.ascontiguousarray(W[:, :, 0])).cuda(), dev(gbar[:, 0].copy()))
     np.testing.assert_allclose(host(g1), ref[:, :, 0], rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref[:, :, 0]).max())))
+
+
+# ------------------------------------------------------------------ empty batches through every entry point
+def test_empty_batch_everywhere(bj):
+    """batch = 0 is a valid call for every bijector and pullback (the reference's broadcasts over an empty matrix);
+    outputs have the right shapes, log-dets are empty / zero, nothing is launched on invalid grids."""
+    def e(rows, dt=torch.float32):
+        return torch.empty((0, rows), dtype=dt, device="cuda").T
+
+    d = 16
+    for b, rows_in, rows_out in (
+        (bj.OrderedBijector(), d, d), (bj.inverse(bj.OrderedBijector()), d, d),
+        (bj.SimplexBijector(), d, d - 1), (bj.inverse(bj.SimplexBijector()), d - 1, d),
+        (bj.PlanarLayer(torch.ones(d) / 4, torch.ones(d) / 4, torch.zeros(1)), d, d),
+        (bj.RadialLayer(torch.tensor([0.3]), torch.tensor([0.5]), torch.zeros(d)), d, d),
+        (bj.Stacked([bj.elementwise(bj.exp), bj.identity], [(1, 8), (9, 16)]), d, d),
+        (bj.Permute(list(range(d, 0, -1))), d, d),
+    ):
+        y, l = bj.with_logabsdet_jacobian(b, e(rows_in), per_sample=True)
+        assert tuple(y.shape) == (rows_out, 0), b
+        assert l is None or l.numel() == 0 or float(l.sum()) == 0.0
+    ib = bj.inverse(bj.VecCholeskyBijector("U"))
+    W, l = bj.with_logabsdet_jacobian(ib, e(6), per_sample=True)
+    assert tuple(W.shape) == (4, 4, 0) and l.numel() == 0
+    # pullbacks
+    assert tuple(bj.vjp(bj.OrderedBijector(), e(d), e(d)).shape) == (d, 0)
+    assert tuple(bj.vjp(bj.SimplexBijector(), e(d), e(d - 1)).shape) == (d, 0)
+    assert tuple(bj.vjp(bj.inverse(bj.SimplexBijector()), e(d - 1), e(d)).shape) == (d - 1, 0)
+    pl = bj.PlanarLayer(torch.ones(d) / 4, torch.ones(d) / 4, torch.zeros(1))
+    assert tuple(bj.vjp(pl, e(d), e(d)).shape) == (d, 0)
+    assert tuple(bj.vjp(bj.inverse(pl), e(d), e(d)).shape) == (d, 0)
+    assert tuple(bj.vjp(bj.elementwise(bj.exp) @ bj.Shift(0.1), e(d), e(d)).shape) == (d, 0)
+    # densities and samples
+    td = bj.transformed(bj.MvNormal(d), bj.elementwise(bj.exp))
+    assert bj.logpdf(td, e(d)).numel() == 0
+    assert tuple(bj.rand(td, 0).shape) == (d, 0)
+    assert bj.logpdf(bj.transformed(bj.MvNormal(d), pl), e(d)).numel() == 0
