@@ -24,7 +24,7 @@ from . import _lib as L
 from . import interface as I
 
 __all__ = ["Exp", "Log", "Truncate", "Untruncate", "TypedIdentity", "scalar_to_scalar_bijector", "ProductVecTransform",
-           "ProductVecInvTransform", "to_linked_vec", "from_linked_vec"]
+           "ProductVecInvTransform", "to_linked_vec", "from_linked_vec", "to_linked_vec_product", "from_linked_vec_product"]
 
 
 class ScalarToScalarBijector(I.Bijector):
@@ -203,3 +203,27 @@ def from_linked_vec(trf, size: Sequence[int], base_size: Tuple[int, ...] = ()):
     """`from_linked_vec(...)`: `trf` is the component LINK; its inverse is applied (fill.jl:161-219)."""
     inv = _inverse_scalar(trf) if isinstance(trf, ScalarToScalarBijector) else I.inverse(trf)
     return ProductVecInvTransform(inv, size, base_size)
+
+
+def _stack(components, inverse_links: bool):
+    """Heterogeneous product `product_distribution((a = d1, b = d2, ...))` (src/vector/interface.jl:86-129 examples):
+    the linked vector is the concatenation of the components' linked vectors, i.e. a `Stacked` with one segment per
+    component — ONE launch of bjx_stacked over all chains when every link is elementwise.
+    components: [(link, n_rows)] with `link` a scalar link (applied to n_rows rows) in the order of the fields."""
+    bs, ranges, lo = [], [], 1
+    for link, n in components:
+        t = link
+        if inverse_links:
+            t = _inverse_scalar(link) if isinstance(link, ScalarToScalarBijector) else I.inverse(link)
+        bs.append(I.identity if isinstance(t, TypedIdentity) else t)
+        ranges.append((lo, lo + int(n) - 1))
+        lo += int(n)
+    return I.Stacked(bs, ranges)
+
+
+def to_linked_vec_product(components):
+    return _stack(components, False)
+
+
+def from_linked_vec_product(components):
+    return _stack(components, True)

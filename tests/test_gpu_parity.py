@@ -1159,3 +1159,63 @@ def test_empty_batch_everywhere(bj):
     assert bj.logpdf(td, e(d)).numel() == 0
     assert tuple(bj.rand(td, 0).shape) == (d, 0)
     assert bj.logpdf(bj.transformed(bj.MvNormal(d), pl), e(d)).numel() == 0
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_views_that_are_not_16_byte_aligned(bj, orc, dt):
+    """A column-major view that starts at column 1 of a 6-row (Float32) / 3-row (Float64) parent begins 24 bytes into
+    the allocation: every kernel must take its scalar-pack path (no 16-byte accesses) and still match the oracle."""
+    r = rng(97)
+    dim = 6 if dt == np.float32 else 3
+    N = 200
+    parent = np.asfortranarray(r.normal(size=(dim, N + 1)).astype(dt))
+    dparent = dev(parent)
+    x = dparent[:, 1:]
+    assert x.data_ptr() % 16 != 0
+    X = parent[:, 1:]
+    y, l = bj.with_logabsdet_jacobian(bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5), x, per_sample=True)
+    y_ref, _ = orc.chain([(orc.OP_SCALE, 0.5, None), (orc.OP_SHIFT, 0.1, None), (orc.OP_EXP, None, None)], np.asfortranarray(X))
+    close(host(y), y_ref, dt)
+    yo, lo = bj.with_logabsdet_jacobian(bj.OrderedBijector(), x)
+    yo_ref, lo_ref = orc.ordered(np.asfortranarray(X))
+    close(host(yo), yo_ref, dt, scale=dim)
+    close(host(lo), lo_ref, dt, scale=dim)
+    ys, ls = bj.with_logabsdet_jacobian(bj.inverse(bj.SimplexBijector()), x, per_sample=True)
+    ys_ref, ls_ref = orc.simplex(np.asfortranarray(X), inverse=True)
+    close(host(ys), ys_ref, dt)
+    close(host(ls), ls_ref, dt, scale=dim * 10)
+    w, u, b = (r.normal(size=dim) / 2).astype(dt), (r.normal(size=dim) / 2).astype(dt), np.array([0.3], dtype=dt)
+    pl = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(b))
+    yp, lp = bj.with_logabsdet_jacobian(pl, x)
+    yp_ref, lp_ref = orc.planar(w, u, b, np.asfortranarray(X))
+    close(host(yp), yp_ref, dt)
+    close(host(lp), lp_ref, dt, scale=4)
+    gb = dev(np.asfortranarray(r.normal(size=(dim, N)).astype(dt)))
+    gx = bj.vjp(pl, x, gb)
+    np.testing.assert_allclose(host(gx), orc.planar_vjp(w, u, b, X, host(gb)), rtol=RTOL[dt] * 10, atol=ATOL[dt] * 50)
+    lpdf = bj.logpdf(bj.transformed(bj.MvNormal(dim), bj.elementwise(bj.exp)), torch.exp(x))
+    np.testing.assert_allclose(host(lpdf), orc.mvnormal_diag_logpdf(X) - X.astype(np.float64).sum(axis=0), rtol=RTOL[dt] * 5, atol=ATOL[dt] * 50)
+
+
+def test_vector_heterogeneous_product_reference_values(bj, orc):
+    """src/vector/interface.jl:98-129 (doctests): product_distribution((a = Normal(), b = Beta(2, 2)));
+    the linked vector of the product is a Stacked of the component links — one launch over all chains."""
+    V = bj.vector
+    comps = [(V.scalar_to_scalar_bijector(-np.inf, np.inf), 1), (V.scalar_to_scalar_bijector(0.0, 1.0), 1)]
+    f64 = dict(dtype=torch.float64, device="cuda")
+    x, l = bj.with_logabsdet_jacobian(V.from_linked_vec_product(comps), torch.tensor([0.2, 1.0], **f64))
+    np.testing.assert_allclose(host(x), [0.2, 0.7310585786300049], rtol=1e-15)
+    assert float(l) == pytest.approx(-1.6265233750364456, abs=1e-14)
+    y, l2 = bj.with_logabsdet_jacobian(V.to_linked_vec_product(comps), torch.tensor([0.2, 0.5], **f64))
+    np.testing.assert_allclose(host(y), [0.2, 0.0], atol=1e-15)
+    assert float(l2) == pytest.approx(1.3862943611198906, abs=1e-15)
+    # batched over chains: (Normal, 3 x Gamma, 4 x Beta) on 129 chains
+    r = rng(98)
+    C = 129
+    comps = [(V.TypedIdentity(), 1), (V.Log(0.0, 1), 3), (V.Untruncate(0.0, 1.0), 4)]
+    X = np.vstack([r.normal(size=(1, C)), np.exp(r.normal(size=(3, C))), r.uniform(0.05, 0.95, size=(4, C))])
+    Y, lc = bj.with_logabsdet_jacobian(V.to_linked_vec_product(comps), dev(np.asfortranarray(X)), per_sample=True)
+    Y_ref = np.vstack([X[:1], np.log(X[1:4]), np.log(X[4:] / (1 - X[4:]))])
+    l_ref = -np.log(X[1:4]).sum(axis=0) - np.log(X[4:] * (1 - X[4:])).sum(axis=0)
+    np.testing.assert_allclose(host(Y), Y_ref, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(host(lc), l_ref, rtol=1e-12, atol=1e-12)
