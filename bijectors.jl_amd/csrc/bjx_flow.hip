@@ -1048,6 +1048,102 @@ __global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, cons
   if (partials) block_publish_partial(acc, red, partials);
 }
 
+// ------------------------------------------------------------------ Radial input pullback
+// Closed-form derivatives of radial_layer.jl:43-129.  With δ = z - z₀, r = ‖δ‖, h = 1/(α + r), a = 1 + β̂h, c = -β̂h²/r:
+//   J = a I + c δδᵀ (symmetric),  ℓ'(r) = (d-1)(-β̂h²)/a + (-2β̂h² + 2β̂h³r)/(1 + β̂h - β̂h²r)
+//   forward:  z̄ = a ȳ + c (δᵀȳ) δ + ℓ̄ ℓ'(r) δ/r
+//   inverse:  v = z̄ - ℓ̄ ℓ'(r) δ/r,  ȳ = (v - c (δᵀv) δ/(a + c r²))/a      (Sherman–Morrison; δ, r at the pre-image,
+//             which the closed-form inverse gives as δ = γ (y - z₀))
+// Same mapping as radial_kernel: G lanes own a column in registers; two group reductions (‖δ‖², δᵀḡ) per column.
+template <class T, int V, int R, bool INV>
+__global__ __launch_bounds__(256) void radial_vjp_kernel(const RadialArgs<T> A, const T* __restrict__ x, const T* __restrict__ gbar,
+                                                         const T* __restrict__ lbar, T* __restrict__ xbar, int64_t dim, int64_t batch, int G) {
+  constexpr int UC = R == 1 ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tab = reinterpret_cast<T*>(smem);
+  if (A.in_lds) {
+    for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) tab[i] = A.z0[i];
+    __syncthreads();
+  }
+  const T* Z0 = A.in_lds ? tab : A.z0;
+  const T alpha = d_log1pexp(A.alpha_[0]);
+  const T apb = d_log1pexp(A.beta[0]);
+  const T bh = -alpha + apb;
+  const int gl = threadIdx.x & (G - 1);
+  const int cols_per_block = blockDim.x / G;
+  const int64_t nvc = dim / V;
+  const int64_t col_first = (int64_t)blockIdx.x * cols_per_block * UC + threadIdx.x / G;
+  Pack<T, V> zz[UC][R], gg[UC][R];
+  T z0r[R][V];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t v = gl + (int64_t)r * G;
+#pragma unroll
+    for (int j = 0; j < V; ++j) z0r[r][j] = v < nvc ? Z0[v * V + j] : T(0);
+  }
+#pragma unroll
+  for (int u = 0; u < UC; ++u) {
+    const int64_t col_raw = col_first + (int64_t)u * cols_per_block;
+    const int64_t col = col_raw < batch ? col_raw : batch - 1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t v = gl + (int64_t)r * G;
+      if (v < nvc) { zz[u][r] = load_pack<T, V, true>(x + col * dim + v * V); gg[u][r] = load_pack<T, V, true>(gbar + col * dim + v * V); }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < UC; ++u) {
+    const int64_t col_raw = col_first + (int64_t)u * cols_per_block;
+    const bool col_ok = col_raw < batch;
+    const int64_t col = col_ok ? col_raw : batch - 1;
+    T ss = T(0), dg = T(0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t v = gl + (int64_t)r * G;
+      if (v < nvc) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) { const T dlt = zz[u][r].v[j] - z0r[r][j]; ss += dlt * dlt; dg += dlt * gg[u][r].v[j]; }
+      }
+    }
+    ss = group_sum_rt(ss, G);
+    dg = group_sum_rt(dg, G);
+    T rr, gain = T(1);                       // δ at the point where J is evaluated = gain · (input - z₀)
+    if (!INV) rr = d_sqrt(ss);
+    else {
+      const T gam = d_sqrt(ss);              // compute_r, radial_layer.jl:124-129
+      const T aa = apb - gam;
+      const T r0 = (d_sqrt(aa * aa + 4 * alpha * gam) - aa) / 2;
+      gain = (alpha + r0) / (apb + r0);
+      rr = gain * gam;
+    }
+    const T h = T(1) / (alpha + rr);
+    const T a = T(1) + bh * h;
+    const T rinv = rr > T(0) ? T(1) / rr : T(0);
+    const T c = -bh * h * h * rinv;
+    const T lr = T(dim - 1) * (-bh * h * h) / a + (T(-2) * bh * h * h + T(2) * bh * h * h * h * rr) / (T(1) + bh * h - bh * h * h * rr);
+    const T lb = lbar ? lbar[col] : T(0);
+    const T kl = lb * lr * rinv;             // coefficient of δ from the log-det term
+    T ca, cd;                                // out = ca · ḡ + cd · δ_in   (δ_in = input - z₀; δ = gain · δ_in)
+    if (!INV) { ca = a; cd = c * dg + kl; }
+    else {
+      // v = ḡ - kl δ;  δᵀv = gain·dg - kl r²;  out = v/a - c (δᵀv) δ / (a (a + c r²))
+      const T dv = gain * dg - kl * rr * rr;
+      ca = T(1) / a;
+      cd = gain * (-kl / a - c * dv / (a * (a + c * rr * rr)));
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t v = gl + (int64_t)r * G;
+      if (v < nvc) {
+        Pack<T, V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.v[j] = ca * gg[u][r].v[j] + cd * (zz[u][r].v[j] - z0r[r][j]);
+        if (col_ok) store_pack<T, V, true>(xbar + col * dim + v * V, o);
+      }
+    }
+  }
+}
+
 struct FlowCfg { int V, G, R; int64_t grid; };
 
 template <class T> bool flow_cfg(const bjx_ctx* ctx, const void* x, const void* y, int64_t dim, int64_t batch, FlowCfg* c) {
@@ -1328,6 +1424,55 @@ BJX_API int bjx_planar_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* 
   if (dt == BJX_F32) return planar_vjp_impl<float>(ctx, inverse, (const float*)w, (const float*)u, (const float*)b, n_layers, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, dim, batch);
   if (dt == BJX_F64) return planar_vjp_impl<double>(ctx, inverse, (const double*)w, (const double*)u, (const double*)b, n_layers, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, dim, batch);
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_planar_vjp: bad dtype %d", (int)dt);
+}
+
+namespace {
+template <class T>
+int radial_vjp_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const T* z0, const T* in, const T* out_bar, const T* ladj_bar,
+                    T* in_bar, int64_t dim, int64_t batch) {
+  if (batch == 0) return BJX_OK;
+  FlowCfg c;
+  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, in_bar, dim, batch, &c), BJX_ERR_UNSUPPORTED, "bjx_radial_vjp: dim %lld too large for the register-resident kernel", (long long)dim);
+  constexpr int VW = Vec16<T>::N;
+  if (c.V == VW && !bjx_aligned16(out_bar)) {           // scalar packs
+    int G = 1;
+    while (G < 64 && G < dim) G <<= 1;
+    int64_t need_r = (dim + G - 1) / G;
+    int R = 1;
+    while (R < need_r) R <<= 1;
+    BJX_REQUIRE(ctx, R <= 32, BJX_ERR_UNSUPPORTED, "bjx_radial_vjp: dim %lld too large for the register-resident kernel", (long long)dim);
+    c.V = 1; c.G = G; c.R = R;
+  }
+  {
+    const int uc = c.R == 1 ? 2 : 1;
+    const int64_t cpb = (int64_t)(256 / c.G) * uc;
+    c.grid = (batch + cpb - 1) / cpb;
+  }
+  const size_t tab_bytes = (size_t)dim * sizeof(T);
+  const bool lds = tab_bytes <= 60 * 1024;
+  RadialArgs<T> A{alpha_, beta, z0, lds ? 1 : 0};
+  const size_t smem = lds ? tab_bytes : 0;
+  BjxProf prof_(ctx);
+  if (c.V == VW) {
+    if (!inverse) { FLOW_SWITCH_R(radial_vjp_kernel, T, VW, false, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G) }
+    else { FLOW_SWITCH_R(radial_vjp_kernel, T, VW, true, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G) }
+  } else {
+    if (!inverse) { FLOW_SWITCH_R(radial_vjp_kernel, T, 1, false, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G) }
+    else { FLOW_SWITCH_R(radial_vjp_kernel, T, 1, true, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G) }
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+}  // namespace
+
+BJX_API int bjx_radial_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* alpha_, const void* beta, const void* z0, const void* in,
+                           const void* out_bar, const void* ladj_bar, void* in_bar, int64_t dim, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_radial_vjp: bad size");
+  BJX_REQUIRE(ctx, alpha_ && beta && z0 && ((in && out_bar && in_bar) || batch == 0), BJX_ERR_ARG, "bjx_radial_vjp: null pointer");
+  if (dt == BJX_F32) return radial_vjp_impl<float>(ctx, inverse, (const float*)alpha_, (const float*)beta, (const float*)z0, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, dim, batch);
+  if (dt == BJX_F64) return radial_vjp_impl<double>(ctx, inverse, (const double*)alpha_, (const double*)beta, (const double*)z0, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, dim, batch);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_radial_vjp: bad dtype %d", (int)dt);
 }
 
 BJX_API int bjx_radial(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* alpha_, const void* beta, const void* z0,

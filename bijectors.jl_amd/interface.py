@@ -1273,6 +1273,27 @@ def vjp(b, x, out_bar, ladj_bar=None):
         rc = L.load().bjx_planar_vjp(ctx.h, _dt(xc), int(inv), _ptr(w), _ptr(u), _ptr(bb), base.n_layers, _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
         L.check(ctx.h, rc, "bjx_planar_vjp")
         return xb
+    if isinstance(base, RadialLayer):
+        xc, dim, batch, vec = _prep(x)
+        gc, gdim, gbatch, _ = _prep(out_bar)
+        if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:
+            raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
+        z0 = _param(base.z_0, xc)
+        if z0.numel() != dim:
+            raise ValueError(f"DimensionMismatch: RadialLayer of dimension {z0.numel()} applied to {dim} rows")
+        a, be = _param(base.alpha_, xc), _param(base.beta, xc)
+        lb = _ladj_bar(ladj_bar, batch, xc)
+        ctx = context(xc.device)
+        xb = _empty(dim, batch, xc, vec)
+        rc = L.load().bjx_radial_vjp(ctx.h, _dt(xc), int(inv), _ptr(a), _ptr(be), _ptr(z0), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
+        L.check(ctx.h, rc, "bjx_radial_vjp")
+        return xb
+    if isinstance(base, InvertibleBatchNorm) and not istraining():
+        # eval mode is a per-row affine map (normalise.jl:62,83): its input pullback is the one of Shift ∘ Scale ∘ Shift
+        like = x
+        s_ = torch.exp(_param(base.logs, like)) / torch.sqrt(_param(base.v, like) + base.eps)
+        aff = Shift(_param(base.b, like)) @ Scale(s_) @ Shift(-_param(base.m, like))
+        return vjp(inverse(aff) if inv else aff, x, out_bar, ladj_bar)
     if not isinstance(base, OrderedBijector):
         raise NotImplementedError(f"no device pullback for {b!r} yet (SURVEY.md §8f f-1)")
     xc, dim, batch, vec = _prep(x)

@@ -183,6 +183,13 @@ int bjx_radial(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* alpha_, cons
                const void* z0, const void* in, void* out,
                void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
 
+/* input pullback of with_logabsdet_jacobian for a RadialLayer (inverse=0) and its inverse
+ * (inverse=1): closed-form derivatives of radial_layer.jl:43-129 (J = a I + c dd^T, inverted with Sherman-Morrison).
+ * in: primal input [dim, batch]; out_bar [dim, batch]; ladj_bar T[batch] or NULL. */
+int bjx_radial_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* alpha_, const void* beta, const void* z0,
+                   const void* in, const void* out_bar, const void* ladj_bar, void* in_bar,
+                   int64_t dim, int64_t batch);
+
 /* InvertibleBatchNorm in eval mode (istraining() == false), normalise.jl:41-88.
  * b, logs, m, v: device T[dim] (channels = dim for 2-D input, :43-47). */
 int bjx_batchnorm(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* b, const void* logs,

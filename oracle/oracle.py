@@ -200,7 +200,7 @@ def radial(alpha_, beta, z0, x, inverse=False):
     z0 = np.ascontiguousarray(np.asarray(z0, dtype=x.dtype))
     out = np.empty_like(x, order="F")
     ladj = np.empty(batch, dtype=x.dtype)
-    getattr(lib(), f"bjo_radial_{suf}")(C.c_int(int(inverse)), ct(float(alpha_)), ct(float(beta)), _p(z0), _p(x), _p(out), C.c_int64(dim), C.c_int64(batch), _p(ladj))
+    getattr(lib(), f"bjo_radial_{suf}")(C.c_int(int(inverse)), ct(float(np.asarray(alpha_).reshape(-1)[0])), ct(float(np.asarray(beta).reshape(-1)[0])), _p(z0), _p(x), _p(out), C.c_int64(dim), C.c_int64(batch), _p(ladj))
     return out, ladj
 
 
@@ -657,3 +657,34 @@ def vec_cholesky_fwd_vjp(W, y_bar, uplo="U"):
             dA[0, j] = yb[base, s] / (1.0 - w0 * w0) - dtmp / np.sqrt(1.0 - w0 * w0) * w0
         out[:, :, s] = dA if uplo == "U" else dA.T
     return out[:, :, 0] if single else out
+
+
+def radial_vjp(alpha_, beta, z0, x, out_bar, ladj_bar=None, inverse=False):
+    """Input pullback of with_logabsdet_jacobian for a RadialLayer and its inverse (radial_layer.jl:43-129; closed-form
+    derivatives — the reference leaves them to the AD package).  With δ = z - z₀, r = ‖δ‖, h = 1/(α + r):
+        J = ∂f/∂z = (1 + β̂h) I - (β̂h²/r) δδᵀ   (symmetric),   ℓ = (d-1) log(1 + β̂h) + log(1 + β̂h - β̂h²r)
+        forward:  z̄ = J ȳ + ℓ̄ ℓ'(r) δ/r;       inverse (y ↦ z, log-det -ℓ(z)):  ȳ = J⁻¹ (z̄ - ℓ̄ ℓ'(r) δ/r)
+    numpy, float64; x, out_bar: (dim, N)."""
+    x = np.asarray(x, dtype=np.float64)
+    d, N = x.shape
+    z0 = np.asarray(z0, dtype=np.float64).reshape(-1, 1)
+    al = float(log1pexp(float(np.asarray(alpha_).reshape(-1)[0])))
+    bh = -al + float(log1pexp(float(np.asarray(beta).reshape(-1)[0])))
+    lb = np.zeros(N) if ladj_bar is None else np.broadcast_to(np.asarray(ladj_bar, dtype=np.float64), (N,))
+    g = np.asarray(out_bar, dtype=np.float64)
+    if inverse:
+        z, _ = radial(np.asarray(alpha_, dtype=np.float64), np.asarray(beta, dtype=np.float64), z0.reshape(-1), np.asfortranarray(x), inverse=True)
+    else:
+        z = x
+    dl = z - z0
+    r = np.sqrt((dl * dl).sum(axis=0))
+    h = 1.0 / (al + r)
+    a = 1.0 + bh * h
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rinv = np.where(r > 0, 1.0 / r, 0.0)
+    c = -bh * h * h * rinv
+    lr = (d - 1) * (-bh * h * h) / a + (-2.0 * bh * h * h + 2.0 * bh * h ** 3 * r) / (1.0 + bh * h - bh * h * h * r)
+    if not inverse:
+        return a * g + c * (dl * g).sum(axis=0) * dl + lb * lr * rinv * dl
+    v = g - lb * lr * rinv * dl
+    return (v - c * (dl * v).sum(axis=0) * dl / (a + c * r * r)) / a

@@ -1219,3 +1219,37 @@ def test_vector_heterogeneous_product_reference_values(bj, orc):
     l_ref = -np.log(X[1:4]).sum(axis=0) - np.log(X[4:] * (1 - X[4:])).sum(axis=0)
     np.testing.assert_allclose(host(Y), Y_ref, rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(host(lc), l_ref, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,N", [(128, 300), (64, 129), (20, 77), (7, 50), (200, 40), (2, 33)])
+def test_radial_vjp(bj, orc, dim, N, dt):
+    """Input pullback of the RadialLayer and of its inverse (§8f f-1) against the finite-difference-pinned oracle."""
+    r = rng(83)
+    al, be = np.array([0.3], dtype=dt), np.array([0.7], dtype=dt)
+    z0 = r.normal(size=dim).astype(dt)
+    layer = bj.RadialLayer(torch.tensor(al), torch.tensor(be), torch.tensor(z0))
+    Z = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    gbar = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    lbar = r.normal(size=N).astype(dt)
+    for inv in (False, True):
+        b = bj.inverse(layer) if inv else layer
+        ref = orc.radial_vjp(al, be, z0, Z, gbar, lbar, inverse=inv)
+        got = bj.vjp(b, dev(Z), dev(gbar), torch.from_numpy(lbar).cuda())
+        np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())))
+        ref0 = orc.radial_vjp(al, be, z0, Z, gbar, inverse=inv)
+        np.testing.assert_allclose(host(bj.vjp(b, dev(Z), dev(gbar))), ref0, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref0).max())))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_batchnorm_eval_vjp(bj, orc, dt):
+    r = rng(84)
+    dim, N = 12, 70
+    b_, logs = r.normal(size=dim).astype(dt), (0.3 * r.normal(size=dim)).astype(dt)
+    m, v = r.normal(size=dim).astype(dt), r.uniform(0.5, 2, size=dim).astype(dt)
+    bn = bj.InvertibleBatchNorm(torch.tensor(b_), torch.tensor(logs), torch.tensor(m), torch.tensor(v), eps=1e-5)
+    X = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    gbar = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    scale = np.exp(logs.astype(np.float64)) / np.sqrt(v.astype(np.float64) + 1e-5)
+    np.testing.assert_allclose(host(bj.vjp(bn, dev(X), dev(gbar), 1.5)), gbar * scale[:, None], rtol=RTOL[dt] * 5, atol=ATOL[dt] * 5)
+    np.testing.assert_allclose(host(bj.vjp(bj.inverse(bn), dev(X), dev(gbar))), gbar / scale[:, None], rtol=RTOL[dt] * 5, atol=ATOL[dt] * 5)

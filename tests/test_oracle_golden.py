@@ -537,3 +537,16 @@ def test_forward_lkj_link_pullback_on_the_constraint_manifold(orc):
             gotU = got if uplo == "U" else got.T
             np.testing.assert_allclose(np.array([gotU[i, j] for (i, j) in iu]), fd, rtol=1e-6, atol=1e-7)
             assert np.all(np.diag(got) == 0) and np.all((np.tril(gotU, -1)) == 0)
+
+
+def test_radial_pullback_matches_finite_differences(orc):
+    """RadialLayer and its inverse (radial_layer.jl:43-129): closed-form pullbacks (J = a I + c δδᵀ, Sherman–Morrison for
+    the inverse) against central differences of the golden-pinned oracle."""
+    r = np.random.default_rng(13)
+    for dim, N in ((5, 3), (12, 4)):
+        al, be, z0 = np.array([0.3]), np.array([0.7]), r.normal(size=dim)
+        x = np.asfortranarray(r.normal(size=(dim, N)))
+        gbar, lbar = r.normal(size=(dim, N)), r.normal(size=N)
+        for inv in (False, True):
+            f = lambda v: orc.radial(al, be, z0, np.asfortranarray(v), inverse=inv)
+            np.testing.assert_allclose(orc.radial_vjp(al, be, z0, x, gbar, lbar, inverse=inv), _fd_vjp(f, x, gbar, lbar), rtol=1e-6, atol=1e-7)
