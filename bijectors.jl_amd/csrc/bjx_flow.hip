@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
 // known, so ȳ is loaded into the same registers.
 template <class T, int V, int R, bool INV>
 __global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, const T* __restrict__ x, const T* __restrict__ ybar,
-                                                         const T* __restrict__ lbar, T* __restrict__ xbar, int64_t dim, int64_t batch, int G) {
+                                                         const T* __restrict__ lbar, T* __restrict__ xbar, int64_t dim, int64_t batch, int G,
+                                                         T* __restrict__ t_out, T* __restrict__ s_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int cols_per_block = blockDim.x / G;
   T* tsave = reinterpret_cast<T*>(smem);                                   // [cols_per_block][n_layers]
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, 
       const T t = tmine[l], c = A.wtu_hat[l];
       const T q = T(1) - t * t;
       const T sb = dot(UH + (int64_t)l * dim) * q + lb * c * (T(-2) * t) * q / (T(1) + c * q);
+      if (s_out && col_ok && gl == 0) { s_out[col * A.n_layers + l] = sb; t_out[col * A.n_layers + l] = t; }   // for the parameter pullback
       axpy(W + (int64_t)l * dim, sb);
     }
   } else {
@@ -823,7 +825,8 @@ __device__ __forceinline__ void reg_update(const float* __restrict__ tab, int l0
 
 template <int G, int NL, bool INV>
 __global__ __launch_bounds__(256) void planar_vjp_reg_kernel(const PlanarRegArgs A, const float* __restrict__ x, const float* __restrict__ ybar,
-                                                             const float* __restrict__ lbar, float* __restrict__ xbar, int dim, int64_t batch) {
+                                                             const float* __restrict__ lbar, float* __restrict__ xbar, int dim, int64_t batch,
+                                                             float* __restrict__ t_out, float* __restrict__ s_out, int nl) {
   constexpr int COLS = 64;
   constexpr int CPS = 64 / G;
   constexpr int NS = (COLS * G) / 64;
@@ -908,6 +911,11 @@ __global__ __launch_bounds__(256) void planar_vjp_reg_kernel(const PlanarRegArgs
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int k = 0; k < NL; ++k) st[lane * NL + k] = sb[k];
+      if (s_out && lane < nvalid) {                        // s̄ and tanh of every layer, [n_layers, batch]: input of the parameter pullback
+#pragma unroll
+        for (int k = 0; k < NL; ++k)
+          if (l0 + k < nl) { s_out[(col0 + lane) * nl + l0 + k] = sb[k]; t_out[(col0 + lane) * nl + l0 + k] = tsave[lane * A.nl_pad + l0 + k]; }
+      }
     }
     __builtin_amdgcn_wave_barrier();
     reg_update<G, NL, NS>(A.w, l0, dim, z, st, gl, cg, row_ok);
@@ -1281,9 +1289,9 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
 
 // register-kernel fast path of the pullback (Float32, 16 < dim <= 128); returns 1 when the shape is not served
 template <class T>
-int planar_vjp_reg(bjx_ctx*, int, const T*, const T*, const T*, const T*, int, const T*, const T*, const T*, T*, int64_t, int64_t) { return 1; }
+int planar_vjp_reg(bjx_ctx*, int, const T*, const T*, const T*, const T*, int, const T*, const T*, const T*, T*, int64_t, int64_t, T*, T*) { return 1; }
 inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float* u_hat, const float* wtu, const float* b, int nl, const float* in,
-                          const float* out_bar, const float* ladj_bar, float* in_bar, int64_t dim, int64_t batch) {
+                          const float* out_bar, const float* ladj_bar, float* in_bar, int64_t dim, int64_t batch, float* t_out, float* s_out) {
   static const int use_reg = getenv("BJX_PLANAR_REG") ? atoi(getenv("BJX_PLANAR_REG")) : 1;
   if (!(use_reg && dim % 4 == 0 && dim > 16 && dim <= 128 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar))) return 1;
   const int NL = nl >= 8 ? 8 : (nl > 2 ? 4 : nl);
@@ -1304,8 +1312,8 @@ inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float
   const int64_t grid = (batch + 4 * 64 - 1) / (4 * 64);
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: batch too large for one launch");
   PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad};
-#define LV(G_, NL_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, true>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch); \
-                          else hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, false>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch); } while (0)
+#define LV(G_, NL_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, true>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); \
+                          else hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, false>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); } while (0)
 #define LV_NL(G_) switch (NL) { case 1: LV(G_, 1); break; case 2: LV(G_, 2); break; case 4: LV(G_, 4); break; default: LV(G_, 8); break; }
   {
     BjxProf prof_(ctx);
@@ -1319,7 +1327,7 @@ inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float
 
 template <class T>
 int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, int nl, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar,
-                    int64_t dim, int64_t batch) {
+                    int64_t dim, int64_t batch, T* t_out = nullptr, T* s_out = nullptr) {
   const size_t need = ((size_t)nl * dim + nl) * sizeof(T);
   BJX_REQUIRE(ctx, need <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: n_layers*dim = %lld exceeds the context scratch", (long long)nl * dim);
   T* u_hat = static_cast<T*>(ctx->scratch);
@@ -1328,7 +1336,7 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
   BJX_CHECK_LAUNCH(ctx);
   if (batch == 0) return BJX_OK;
   {
-    int rc = planar_vjp_reg(ctx, inverse, w, u_hat, wtu, b, nl, in, out_bar, ladj_bar, in_bar, dim, batch);
+    int rc = planar_vjp_reg(ctx, inverse, w, u_hat, wtu, b, nl, in, out_bar, ladj_bar, in_bar, dim, batch, t_out, s_out);
     if (rc != 1) return rc;                               // 1 = shape not served by the register kernel
   }
   FlowCfg c;
@@ -1344,8 +1352,8 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
   constexpr int VW = Vec16<T>::N;
   const bool v_ok = c.V == VW && bjx_aligned16(out_bar);
   BjxProf prof_(ctx);
-#define PVJ(V_, R_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_kernel<T, V_, R_, true>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G); \
-                         else hipLaunchKernelGGL((planar_vjp_kernel<T, V_, R_, false>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G); } while (0)
+#define PVJ(V_, R_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_kernel<T, V_, R_, true>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, t_out, s_out); \
+                         else hipLaunchKernelGGL((planar_vjp_kernel<T, V_, R_, false>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, t_out, s_out); } while (0)
 #define PVJ_R(V_) switch (c.R) { case 1: PVJ(V_, 1); break; case 2: PVJ(V_, 2); break; case 4: PVJ(V_, 4); break; case 8: PVJ(V_, 8); break; case 16: PVJ(V_, 16); break; default: PVJ(V_, 32); break; }
   if (v_ok) { PVJ_R(VW) } else {
     // scalar packs: recompute the geometry for V = 1
@@ -1358,8 +1366,8 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
     c.G = G; c.R = R; c.grid = (batch + (256 / G) - 1) / (256 / G);
     const int cpb = 256 / G;
     const size_t smem1 = (size_t)cpb * nl * sizeof(T) + (lds ? tab_bytes : 0);
-#define PVJ1(R_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_kernel<T, 1, R_, true>), dim3((unsigned)c.grid), dim3(256), smem1, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G); \
-                      else hipLaunchKernelGGL((planar_vjp_kernel<T, 1, R_, false>), dim3((unsigned)c.grid), dim3(256), smem1, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G); } while (0)
+#define PVJ1(R_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_kernel<T, 1, R_, true>), dim3((unsigned)c.grid), dim3(256), smem1, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, t_out, s_out); \
+                      else hipLaunchKernelGGL((planar_vjp_kernel<T, 1, R_, false>), dim3((unsigned)c.grid), dim3(256), smem1, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, t_out, s_out); } while (0)
     switch (c.R) { case 1: PVJ1(1); break; case 2: PVJ1(2); break; case 4: PVJ1(4); break; case 8: PVJ1(8); break; case 16: PVJ1(16); break; default: PVJ1(32); break; }
 #undef PVJ1
   }
@@ -1414,6 +1422,243 @@ BJX_API int bjx_planar(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* w, c
   if (dt == BJX_F32) return planar_impl<float>(ctx, inverse, (const float*)w, (const float*)u, (const float*)b, n_layers, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, batch, flags);
   if (dt == BJX_F64) return planar_impl<double>(ctx, inverse, (const double*)w, (const double*)u, (const double*)b, n_layers, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, batch, flags);
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_planar: bad dtype %d", (int)dt);
+}
+
+namespace {
+// ------------------------------------------------------------------ Planar PARAMETER pullback
+// (w̄, ū, b̄) of the fused stack, summed over the batch.  With s̄_k (cotangent of s_k) and t_k = tanh s_k of every layer
+// and column — emitted by the input-pullback kernels as [n_layers, batch] arrays — everything that couples the batch is
+//   M1 = Z₀·S̄ᵀ  [dim, nl],   M2 = Ȳ·Tᵀ  [dim, nl],   ST[j][k] = Σ_n s̄_jn t_kn,   b̄_k = Σ_n s̄_kn,
+//   c̄_k = Σ_n ℓ̄_n q_kn/(1 + c_k q_kn)
+// because z_{k-1} = z₀ + Σ_{j<k} û_j t_j and z̄_k = ȳ + Σ_{j>k} w_j s̄_j:
+//   w̄_k(direct) = M1[:,k] + Σ_{j<k} û_j ST[k][j],      û̄_k = M2[:,k] + Σ_{j>k} w_j ST[j][k].
+// planar_param_reduce_kernel streams Z₀ and Ȳ once more (G lanes per column, NLG <= 8 layers per launch, the
+// [rows of my pack] x [layers] accumulators in registers), combines the column groups of a block through LDS and
+// writes one Float64 partial per block; planar_param_finalize_kernel sums the partials in a fixed order and applies
+// the chain rule through get_u_hat (planar_layer.jl:65-70).
+constexpr int PP_NLG = 8;
+template <class T, int V, int R>
+__global__ __launch_bounds__(256) void planar_param_reduce_kernel(const T* __restrict__ z0, const T* __restrict__ ybar, const T* __restrict__ sbar,
+                                                                  const T* __restrict__ tt, const T* __restrict__ lbar, const T* __restrict__ wtu_hat,
+                                                                  int64_t dim, int64_t batch, int G, int nl, int l0, int nlg, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);
+  const int gl = threadIdx.x & (G - 1), cgp = threadIdx.x / G;
+  const int cols_per_block = 256 / G;
+  const int64_t nvc = dim / V;
+  T m1[R][V][PP_NLG], m2[R][V][PP_NLG];
+  T stg[PP_NLG];                 // lane gl < nlg: ST[l0+gl][l0 .. l0+nlg) restricted to this layer group's columns... (full row below)
+  T bsum = T(0), csum = T(0);
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+#pragma unroll
+      for (int k = 0; k < PP_NLG; ++k) { m1[r][j][k] = T(0); m2[r][j][k] = T(0); }
+#pragma unroll
+  for (int k = 0; k < PP_NLG; ++k) stg[k] = T(0);
+  const T cmine = (gl < nlg) ? wtu_hat[l0 + gl] : T(0);
+  const int64_t stride = (int64_t)gridDim.x * cols_per_block;
+  for (int64_t col = (int64_t)blockIdx.x * cols_per_block + cgp; col < batch; col += stride) {
+    Pack<T, V> pz[R], pg[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t v = gl + (int64_t)r * G;
+      if (v < nvc) { pz[r] = load_pack<T, V, false>(z0 + col * dim + v * V); pg[r] = load_pack<T, V, false>(ybar + col * dim + v * V); }
+    }
+    T sk[PP_NLG], tk[PP_NLG];
+#pragma unroll
+    for (int k = 0; k < PP_NLG; ++k) { sk[k] = k < nlg ? sbar[col * nl + l0 + k] : T(0); tk[k] = k < nlg ? tt[col * nl + l0 + k] : T(0); }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t v = gl + (int64_t)r * G;
+      if (v < nvc) {
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+#pragma unroll
+          for (int k = 0; k < PP_NLG; ++k) { m1[r][j][k] += pz[r].v[j] * sk[k]; m2[r][j][k] += pg[r].v[j] * tk[k]; }
+      }
+    }
+    // Gram row / b̄ / c̄ of layer l0 + gl (lanes gl < nlg); the row of ST spans ALL layers
+    if (gl < nlg) {
+      const T sme = sbar[col * nl + l0 + gl], tme = tt[col * nl + l0 + gl];
+      bsum += sme;
+      const T q = T(1) - tme * tme;
+      csum += (lbar ? lbar[col] : T(0)) * q / (T(1) + cmine * q);
+#pragma unroll
+      for (int k = 0; k < PP_NLG; ++k) stg[k] += sme * tk[k];
+    }
+  }
+  // ---- combine the column groups of the block in a fixed order; layout of a block partial:
+  //      [M1 dim*nlg][M2 dim*nlg][ST nlg*nlg (this group's diagonal block)][b nlg][c nlg]
+  const size_t n_m = (size_t)dim * nlg;
+  const size_t per = 2 * n_m + (size_t)nlg * nlg + 2 * (size_t)nlg;
+  for (int pass = 0; pass < cols_per_block; ++pass) {
+    if (cgp == pass) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t v = gl + (int64_t)r * G;
+        if (v < nvc) {
+#pragma unroll
+          for (int j = 0; j < V; ++j)
+            for (int k = 0; k < nlg; ++k) {
+              const size_t i1 = (size_t)(v * V + j) * nlg + k;
+              if (pass == 0) { red[i1] = (double)m1[r][j][k]; red[n_m + i1] = (double)m2[r][j][k]; }
+              else { red[i1] += (double)m1[r][j][k]; red[n_m + i1] += (double)m2[r][j][k]; }
+            }
+        }
+      }
+      if (gl < nlg) {
+        for (int k = 0; k < nlg; ++k) {
+          const size_t i2 = 2 * n_m + (size_t)gl * nlg + k;
+          if (pass == 0) red[i2] = (double)stg[k]; else red[i2] += (double)stg[k];
+        }
+        const size_t ib = 2 * n_m + (size_t)nlg * nlg + gl;
+        if (pass == 0) { red[ib] = (double)bsum; red[ib + nlg] = (double)csum; } else { red[ib] += (double)bsum; red[ib + nlg] += (double)csum; }
+      }
+    }
+    __syncthreads();
+  }
+  for (size_t i = threadIdx.x; i < per; i += blockDim.x) partial[(size_t)blockIdx.x * per + i] = red[i];
+}
+
+// cross-group Gram entries ST[j][k] with j, k in DIFFERENT layer groups are produced by a small launch of this kernel
+template <class T>
+__global__ __launch_bounds__(256) void planar_gram_kernel(const T* __restrict__ sbar, const T* __restrict__ tt, int64_t batch, int nl, double* __restrict__ st) {
+  __shared__ double red[4];
+  const int j = blockIdx.x / nl, k = blockIdx.x % nl;
+  double acc = 0.0;
+  for (int64_t n = threadIdx.x; n < batch; n += blockDim.x) acc += (double)sbar[n * nl + j] * (double)tt[n * nl + k];
+  acc = group_sum<64>(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) st[j * nl + k] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// one block per layer: fixed-order sum over the block partials, then the chain rule through get_u_hat
+template <class T>
+__global__ __launch_bounds__(256) void planar_param_finalize_kernel(const double* __restrict__ partial, int nblocks, int64_t dim, int nl, int l0, int nlg,
+                                                                   const double* st, const T* __restrict__ w, const T* __restrict__ u,
+                                                                   const T* __restrict__ u_hat, T* __restrict__ w_bar, T* __restrict__ u_bar, T* __restrict__ b_bar) {
+  __shared__ double red[12];
+  __shared__ double st_l[PP_NLG * PP_NLG];
+  const int kk = blockIdx.x;                      // layer inside the group
+  const int k = l0 + kk;
+  const size_t n_m = (size_t)dim * nlg;
+  const size_t per = 2 * n_m + (size_t)nlg * nlg + 2 * (size_t)nlg;
+  if (!st) {                                      // a single layer group: the Gram matrix is the block the reduce kernel produced
+    for (int e = threadIdx.x; e < nlg * nlg; e += blockDim.x) {
+      double acc = 0.0;
+      for (int bidx = 0; bidx < nblocks; ++bidx) acc += partial[(size_t)bidx * per + 2 * n_m + e];
+      st_l[e] = acc;
+    }
+    __syncthreads();
+    st = st_l;                                    // nl == nlg here: same [j * nl + k] indexing
+  }
+  const T* wk = w + (int64_t)k * dim;
+  const T* uk = u + (int64_t)k * dim;
+  // a = wᵀu, ‖w‖²
+  double a = 0.0, n2 = 0.0;
+  for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) { a += (double)wk[i] * (double)uk[i]; n2 += (double)wk[i] * (double)wk[i]; }
+  a = group_sum<64>(a); n2 = group_sum<64>(n2);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = n2; }
+  __syncthreads();
+  a = (red[0] + red[1]) + (red[2] + red[3]);
+  n2 = (red[4] + red[5]) + (red[6] + red[7]);
+  __syncthreads();
+  double bsum = 0.0, csum = 0.0;
+  for (int bidx = 0; bidx < nblocks; ++bidx) {
+    const double* pb = partial + (size_t)bidx * per + 2 * n_m + (size_t)nlg * nlg;
+    bsum += pb[kk]; csum += pb[nlg + kk];
+  }
+  const double sa = 1.0 / (1.0 + exp(-a));                                   // logistic(a) = d(log1pexp a)/da
+  const double kap = ((double)d_log1pexp((T)(-a)) - 1.0) / n2;
+  const double ka = -(1.0 - sa) / n2;                                        // dκ/da = -logistic(-a)/‖w‖²
+  // û̄ and w̄(direct) per row; wᵀû̄ needs a block reduction, so two sweeps over the rows
+  double wtuhb = 0.0;
+  for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) {
+    double m2 = 0.0;
+    for (int bidx = 0; bidx < nblocks; ++bidx) m2 += partial[(size_t)bidx * per + n_m + (size_t)i * nlg + kk];
+    for (int j = k + 1; j < nl; ++j) m2 += (double)w[(int64_t)j * dim + i] * st[j * nl + k];
+    u_bar[(int64_t)k * dim + i] = (T)m2;                                     // û̄ for now
+    wtuhb += (double)wk[i] * m2;
+  }
+  wtuhb = group_sum<64>(wtuhb);
+  if ((threadIdx.x & 63) == 0) red[8 + (threadIdx.x >> 6)] = wtuhb;
+  __syncthreads();
+  wtuhb = (red[8] + red[9]) + (red[10] + red[11]);
+  for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) {
+    double m1 = 0.0;
+    for (int bidx = 0; bidx < nblocks; ++bidx) m1 += partial[(size_t)bidx * per + (size_t)i * nlg + kk];
+    for (int j = 0; j < k; ++j) m1 += (double)u_hat[(int64_t)j * dim + i] * st[k * nl + j];
+    const double uhb = (double)u_bar[(int64_t)k * dim + i];
+    const double wi = (double)wk[i], ui = (double)uk[i];
+    u_bar[(int64_t)k * dim + i] = (T)(uhb + wi * (ka * wtuhb + csum * sa));
+    w_bar[(int64_t)k * dim + i] = (T)(m1 + kap * uhb + wtuhb * (ka * ui - 2.0 * kap / n2 * wi) + csum * sa * ui);
+  }
+  if (threadIdx.x == 0) b_bar[k] = (T)bsum;
+}
+
+template <class T>
+int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int nl, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar,
+                           T* w_bar, T* u_bar, T* b_bar, T* work, int64_t dim, int64_t batch) {
+  BJX_REQUIRE(ctx, batch >= 1, BJX_ERR_SHAPE, "bjx_planar_vjp_params: empty batch");
+  T* s_out = work;                                   // [nl, batch]
+  T* t_out = work + (size_t)nl * batch;
+  int rc = planar_vjp_impl<T>(ctx, 0, w, u, b, nl, in, out_bar, ladj_bar, in_bar, dim, batch, t_out, s_out);
+  if (rc) return rc;
+  // tables left in the scratch by planar_vjp_impl: û [nl][dim], wᵀû [nl]
+  const T* u_hat = static_cast<const T*>(ctx->scratch);
+  const T* wtu = u_hat + (size_t)nl * dim;
+  FlowCfg c;
+  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, out_bar, dim, batch, &c) && c.R <= 4, BJX_ERR_UNSUPPORTED,
+              "bjx_planar_vjp_params: dim %lld too large for the register accumulators", (long long)dim);
+  const int R = c.R;
+  const int cols_per_block = 256 / c.G;
+  int nblocks = (int)((batch + (int64_t)cols_per_block * 16 - 1) / ((int64_t)cols_per_block * 16));
+  if (nblocks > 1024) nblocks = 1024;
+  if (nblocks < 1) nblocks = 1;
+  const size_t per_max = 2 * (size_t)dim * PP_NLG + PP_NLG * PP_NLG + 2 * PP_NLG;
+  const size_t st_n = (size_t)nl * nl;
+  { int rc2 = bjx_ensure_partials(ctx, (size_t)nblocks * per_max + st_n); if (rc2) return rc2; }
+  double* partial = ctx->partials;
+  double* st = partial + (size_t)nblocks * per_max;
+  const bool one_group = nl <= PP_NLG;
+  if (!one_group) {                                  // cross-group Gram entries: a separate (slow, rarely needed) pass
+    hipLaunchKernelGGL(planar_gram_kernel<T>, dim3(nl * nl), dim3(256), 0, ctx->stream, s_out, t_out, batch, nl, st);
+    BJX_CHECK_LAUNCH(ctx);
+  }
+  constexpr int VW = Vec16<T>::N;
+  for (int l0 = 0; l0 < nl; l0 += PP_NLG) {
+    const int nlg = nl - l0 < PP_NLG ? nl - l0 : PP_NLG;
+    const size_t per = 2 * (size_t)dim * nlg + (size_t)nlg * nlg + 2 * (size_t)nlg;
+    const size_t smem = per * sizeof(double);
+    BJX_REQUIRE(ctx, smem <= BJX_LDS_MAX, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp_params: dim %lld too large for the block combine", (long long)dim);
+    {
+      BjxProf prof_(ctx);
+#define PPR(V_, R_) do { bjx_allow_big_lds(planar_param_reduce_kernel<T, V_, R_>, smem); hipLaunchKernelGGL((planar_param_reduce_kernel<T, V_, R_>), dim3(nblocks), dim3(256), smem, ctx->stream, in, out_bar, s_out, t_out, ladj_bar, wtu, dim, batch, c.G, nl, l0, nlg, partial); } while (0)
+#define PPR_V(V_) do { if (R == 1) PPR(V_, 1); else if (R == 2) PPR(V_, 2); else PPR(V_, 4); } while (0)
+      if (c.V == VW) PPR_V(VW); else PPR_V(1);
+#undef PPR_V
+#undef PPR
+    }
+    BJX_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(planar_param_finalize_kernel<T>, dim3(nlg), dim3(256), 0, ctx->stream, partial, nblocks, dim, nl, l0, nlg, one_group ? (const double*)nullptr : (const double*)st, w, u, u_hat, w_bar, u_bar, b_bar);
+    BJX_CHECK_LAUNCH(ctx);
+  }
+  return BJX_OK;
+}
+}  // namespace
+
+BJX_API int bjx_planar_vjp_params(bjx_ctx* ctx, bjx_dtype dt, const void* w, const void* u, const void* b, int n_layers, const void* in,
+                                  const void* out_bar, const void* ladj_bar, void* in_bar, void* w_bar, void* u_bar, void* b_bar, void* work,
+                                  int64_t dim, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0 && n_layers >= 1, BJX_ERR_SHAPE, "bjx_planar_vjp_params: bad size (dim=%lld, n_layers=%d)", (long long)dim, n_layers);
+  BJX_REQUIRE(ctx, w && u && b && in && out_bar && in_bar && w_bar && u_bar && b_bar && work, BJX_ERR_ARG, "bjx_planar_vjp_params: null pointer");
+  if (dt == BJX_F32) return planar_vjp_params_impl<float>(ctx, (const float*)w, (const float*)u, (const float*)b, n_layers, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, (float*)w_bar, (float*)u_bar, (float*)b_bar, (float*)work, dim, batch);
+  if (dt == BJX_F64) return planar_vjp_params_impl<double>(ctx, (const double*)w, (const double*)u, (const double*)b, n_layers, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, (double*)w_bar, (double*)u_bar, (double*)b_bar, (double*)work, dim, batch);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_planar_vjp_params: bad dtype %d", (int)dt);
 }
 
 BJX_API int bjx_planar_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* w, const void* u, const void* b, int n_layers, const void* in,

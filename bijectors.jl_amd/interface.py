@@ -33,7 +33,7 @@ __all__ = [
     "VecCholeskyBijector", "Permute", "PlanarLayer", "RadialLayer", "InvertibleBatchNorm", "RationalQuadraticSpline",
     "PartitionMask", "Coupling", "Stacked", "Columnwise", "columnwise", "vjp", "istraining", "training", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
     "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
-    "PlanarResult", "MvNormal", "TransformedDistribution", "transformed", "logpdf", "rand",
+    "PlanarResult", "vjp_params", "MvNormal", "TransformedDistribution", "transformed", "logpdf", "rand",
 ]
 
 PlanarResult = namedtuple("PlanarResult", ["result", "logabsdetjac"])  # planar_layer.jl:109
@@ -1306,6 +1306,36 @@ def vjp(b, x, out_bar, ladj_bar=None):
     rc = L.load().bjx_ordered_vjp(ctx.h, _dt(xc), int(inv), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
     L.check(ctx.h, rc, "bjx_ordered_vjp")
     return xb
+
+
+def vjp_params(b, x, out_bar, ladj_bar=None):
+    """Pullback of `with_logabsdet_jacobian(b, x)` onto the input AND the parameters of a PlanarLayer (stack):
+    returns (x_bar, {"w": w_bar, "u": u_bar, "b": b_bar}) with the parameter cotangents summed over the batch and the
+    shapes of b.w / b.u / b.b (bjx_planar_vjp_params; closed-form derivatives of planar_layer.jl:65-110)."""
+    if not isinstance(b, PlanarLayer):
+        raise NotImplementedError(f"no device parameter pullback for {b!r} (SURVEY.md §8f f-1)")
+    xc, dim, batch, vec = _prep(x)
+    gc, gdim, gbatch, _ = _prep(out_bar)
+    if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:
+        raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
+    w, u = _param(b.w, xc), _param(b.u, xc)
+    two_d = w.dim() == 2
+    if two_d:
+        w, u = w.T.contiguous(), u.T.contiguous()
+    if w.numel() != dim * b.n_layers:
+        raise ValueError(f"DimensionMismatch: PlanarLayer of dimension {w.numel() // b.n_layers} applied to {dim} rows")
+    bb = _param(b.b, xc)
+    lb = _ladj_bar(ladj_bar, batch, xc)
+    ctx = context(xc.device)
+    xb = _empty(dim, batch, xc, vec)
+    wb, ub, bbar = torch.empty_like(w), torch.empty_like(u), torch.empty_like(bb)
+    work = torch.empty(2 * b.n_layers * max(batch, 1), dtype=xc.dtype, device=xc.device)
+    rc = L.load().bjx_planar_vjp_params(ctx.h, _dt(xc), _ptr(w), _ptr(u), _ptr(bb), b.n_layers, _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb),
+                                        _ptr(wb), _ptr(ub), _ptr(bbar), _ptr(work), dim, batch)
+    L.check(ctx.h, rc, "bjx_planar_vjp_params")
+    if two_d:
+        wb, ub = wb.T, ub.T                       # back to (dim, n_layers)
+    return xb, {"w": wb, "u": ub, "b": bbar}
 
 
 # ------------------------------------------------------------------ columnwise (src/interface.jl:41-78)

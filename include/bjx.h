@@ -178,6 +178,14 @@ int bjx_planar_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* w, const
                    int n_layers, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar,
                    int64_t dim, int64_t batch);
 
+/* The same pullback plus the PARAMETER cotangents of the stack, summed over the batch: w_bar, u_bar: T[dim*n_layers]
+ * (layer-major like w, u), b_bar: T[n_layers] — including the chain rule through get_u_hat (planar_layer.jl:65-70).
+ * `work`: caller-owned device scratch of 2*n_layers*batch elements of T (tanh and the cotangent of w^T z + b of every
+ * layer and column).  A batch sharded over GPUs all-reduces the three outputs. */
+int bjx_planar_vjp_params(bjx_ctx* ctx, bjx_dtype dt, const void* w, const void* u, const void* b, int n_layers,
+                          const void* in, const void* out_bar, const void* ladj_bar, void* in_bar,
+                          void* w_bar, void* u_bar, void* b_bar, void* work, int64_t dim, int64_t batch);
+
 /* RadialLayer, radial_layer.jl:43-129.  alpha_, beta: device T[1]; z0: device T[dim]. */
 int bjx_radial(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* alpha_, const void* beta,
                const void* z0, const void* in, void* out,

@@ -688,3 +688,51 @@ def radial_vjp(alpha_, beta, z0, x, out_bar, ladj_bar=None, inverse=False):
         return a * g + c * (dl * g).sum(axis=0) * dl + lb * lr * rinv * dl
     v = g - lb * lr * rinv * dl
     return (v - c * (dl * v).sum(axis=0) * dl / (a + c * r * r)) / a
+
+
+def planar_param_vjp(w, u, b, z, y_bar, ladj_bar=None):
+    """Parameter pullback of with_logabsdet_jacobian for a PlanarLayer stack: (w̄, ū, b̄) summed over the batch
+    (planar_layer.jl:65-110 incl. get_u_hat :65-70; the reference leaves it to the AD package).  Per layer, with
+    s̄_k, t_k, q_k = 1 - t_k² of `planar_vjp`:
+        b̄_k = Σ_n s̄_kn,   w̄_k(direct) = Σ_n z_{k-1,n} s̄_kn,   û̄_k = Σ_n z̄_{k,n} t_kn,   c̄_k = Σ_n ℓ̄_n q_kn/(1 + c_k q_kn)
+    and through û = u + κ w, κ = (log1pexp(-a) - 1)/‖w‖², c = log1pexp(a) - 1, a = wᵀu:
+        ū = û̄ + w [κ_a (wᵀû̄) + c̄ σ(a)],   w̄ = w̄(direct) + κ û̄ + (wᵀû̄)(κ_a u - 2κ/‖w‖² w) + c̄ σ(a) u,   κ_a = -σ(-a)/‖w‖².
+    numpy, float64.  Returns (w_bar, u_bar, b_bar) with the shapes of (w, u, b)."""
+    z = np.asarray(z, dtype=np.float64)
+    dim, N = z.shape
+    w = np.asarray(w, dtype=np.float64).reshape(dim, -1)
+    u = np.asarray(u, dtype=np.float64).reshape(dim, -1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    nl = w.shape[1]
+    lb = np.zeros(N) if ladj_bar is None else np.broadcast_to(np.asarray(ladj_bar, dtype=np.float64), (N,))
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    u_hat, c, a, n2, kap = np.empty_like(u), np.empty(nl), np.empty(nl), np.empty(nl), np.empty(nl)
+    for k in range(nl):
+        a[k] = float(w[:, k] @ u[:, k])
+        n2[k] = float(w[:, k] @ w[:, k])
+        kap[k] = (log1pexp(-a[k]) - 1.0) / n2[k]
+        u_hat[:, k] = u[:, k] + kap[k] * w[:, k]
+        c[k] = log1pexp(a[k]) - 1.0
+    zs, ts, cur = [], [], z
+    for k in range(nl):
+        zs.append(cur)
+        t = np.tanh(w[:, k] @ cur + b[k])
+        ts.append(t)
+        cur = cur + np.outer(u_hat[:, k], t)
+    g = np.asarray(y_bar, dtype=np.float64).copy()
+    wb, ub, bb = np.zeros_like(w), np.zeros_like(u), np.zeros(nl)
+    for k in range(nl - 1, -1, -1):
+        t = ts[k]
+        q = 1.0 - t * t
+        den = 1.0 + c[k] * q
+        uhb = g @ t                                                    # û̄_k = Σ_n z̄_{k,n} t_kn
+        cb = float(np.sum(lb * q / den))
+        sbar = (u_hat[:, k] @ g) * q + lb * c[k] * (-2.0 * t) * q / den
+        bb[k] = sbar.sum()
+        wdir = zs[k] @ sbar
+        g = g + np.outer(w[:, k], sbar)
+        ka = -sig(-a[k]) / n2[k]
+        wtuhb = float(w[:, k] @ uhb)
+        ub[:, k] = uhb + w[:, k] * (ka * wtuhb + cb * sig(a[k]))
+        wb[:, k] = wdir + kap[k] * uhb + wtuhb * (ka * u[:, k] - 2.0 * kap[k] / n2[k] * w[:, k]) + cb * sig(a[k]) * u[:, k]
+    return wb, ub, bb

@@ -159,6 +159,8 @@ def main():
 
     rows.append(("vjp(inverse(8×PlanarLayer)) d=128", "f-1", lambda: bj.vjp(bj.inverse(flow), zf, gz, lbz), 4 * 3 * dp + 4, Np))
 
+    rows.append(("vjp_params(8×PlanarLayer) d=128 (input + w̄, ū, b̄; two passes)", "f-1", lambda: bj.vjp_params(flow, z, gz, lbz), 4 * 5 * dp + 4 + 4 * 4 * nl, Np))
+
     # §8(f) f-3: logpdf(td, Y) fused into the inverting kernel — Y is read once, x is never stored
     td_pl = bj.transformed(bj.MvNormal(dp), flow)
     rows.append(("logpdf(transformed(MvNormal(128), 8×PlanarLayer)) d=128", "f-3", lambda: bj.logpdf(td_pl, zf), 4 * dp + 4, Np))

@@ -1253,3 +1253,24 @@ def test_batchnorm_eval_vjp(bj, orc, dt):
     scale = np.exp(logs.astype(np.float64)) / np.sqrt(v.astype(np.float64) + 1e-5)
     np.testing.assert_allclose(host(bj.vjp(bn, dev(X), dev(gbar), 1.5)), gbar * scale[:, None], rtol=RTOL[dt] * 5, atol=ATOL[dt] * 5)
     np.testing.assert_allclose(host(bj.vjp(bj.inverse(bn), dev(X), dev(gbar))), gbar / scale[:, None], rtol=RTOL[dt] * 5, atol=ATOL[dt] * 5)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,nl,N", [(128, 8, 3000), (64, 3, 257), (20, 1, 77), (7, 2, 50), (36, 12, 500)])
+def test_planar_param_vjp(bj, orc, dim, nl, N, dt):
+    """Parameter pullback of the PlanarLayer stack, summed over the batch (incl. the chain rule through get_u_hat)."""
+    r = rng(85)
+    w = (r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(dt)
+    u = (r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(dt)
+    b = r.normal(size=nl).astype(dt)
+    flow = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(b))
+    Z = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    gbar = np.asfortranarray((r.normal(size=(dim, N)) / np.sqrt(N)).astype(dt))
+    lbar = (r.normal(size=N) / np.sqrt(N)).astype(dt)
+    wb_ref, ub_ref, bb_ref = orc.planar_param_vjp(w, u, b, Z, gbar, lbar)
+    xb, pb = bj.vjp_params(flow, dev(Z), dev(gbar), torch.from_numpy(lbar).cuda())
+    np.testing.assert_allclose(host(xb), orc.planar_vjp(w, u, b, Z, gbar, lbar), rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10)
+    tol = dict(rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(wb_ref).max()), float(np.abs(ub_ref).max())))
+    np.testing.assert_allclose(host(pb["w"]), wb_ref, **tol)
+    np.testing.assert_allclose(host(pb["u"]), ub_ref, **tol)
+    np.testing.assert_allclose(host(pb["b"]), bb_ref, **tol)

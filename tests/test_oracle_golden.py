@@ -550,3 +550,34 @@ def test_radial_pullback_matches_finite_differences(orc):
         for inv in (False, True):
             f = lambda v: orc.radial(al, be, z0, np.asfortranarray(v), inverse=inv)
             np.testing.assert_allclose(orc.radial_vjp(al, be, z0, x, gbar, lbar, inverse=inv), _fd_vjp(f, x, gbar, lbar), rtol=1e-6, atol=1e-7)
+
+
+def test_planar_parameter_pullback_matches_finite_differences(orc):
+    """(w̄, ū, b̄) of a PlanarLayer stack incl. the chain rule through get_u_hat (planar_layer.jl:65-70), against central
+    differences of the golden-pinned forward oracle with respect to the parameters."""
+    r = np.random.default_rng(15)
+    for dim, nl, N in ((5, 1, 3), (6, 3, 4)):
+        w = r.normal(size=(dim, nl)) / np.sqrt(dim)
+        u = r.normal(size=(dim, nl)) / np.sqrt(dim)
+        b = r.normal(size=nl)
+        z = np.asfortranarray(r.normal(size=(dim, N)))
+        yb, lb = r.normal(size=(dim, N)), r.normal(size=N)
+        wb, ub, bb = orc.planar_param_vjp(w, u, b, z, yb, lb)
+
+        def F(w_, u_, b_):
+            y, l = orc.planar(w_, u_, b_, z)
+            return float((y * yb).sum() + (l * lb).sum())
+        h = 1e-6
+        for arr, grad, which in ((w, wb, 0), (u, ub, 1)):
+            for i in range(dim):
+                for k in range(nl):
+                    ap, am = arr.copy(), arr.copy()
+                    ap[i, k] += h
+                    am[i, k] -= h
+                    fd = (F(ap, u, b) - F(am, u, b)) / (2 * h) if which == 0 else (F(w, ap, b) - F(w, am, b)) / (2 * h)
+                    assert abs(fd - grad[i, k]) < 1e-6
+        for k in range(nl):
+            bp, bm = b.copy(), b.copy()
+            bp[k] += h
+            bm[k] -= h
+            assert abs((F(w, u, bp) - F(w, u, bm)) / (2 * h) - bb[k]) < 1e-6
