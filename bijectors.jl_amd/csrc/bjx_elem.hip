@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
   for (int k = 0; k < R; ++k)
 #pragma unroll
     for (int j = 0; j < V; ++j) { sx[k][j] = 0.0; sxx[k][j] = 0.0; }
-  constexpr int U = R == 1 ? 4 : (R == 2 ? 2 : 1);          // columns in flight per lane group
+  constexpr int U = R == 1 ? 8 : (R == 2 ? 4 : 2);          // columns in flight per lane group
   const int64_t stride = (int64_t)gridDim.x * cols_per_block;
   int64_t col = (int64_t)blockIdx.x * cols_per_block + cg;
   for (; col + (U - 1) * stride < batch; col += U * stride) {
@@ -706,14 +706,19 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
       for (int k = 0; k < R; ++k)
         if (gl + k * G < nvc) p[u][k] = load_pack<T, V, false>(x + (col + u * stride) * dim + (int64_t)(gl + k * G) * V);
+    // the U columns of a trip are summed in T first (U <= 8 terms), then added to the Float64 accumulators: one
+    // conversion + two Float64 adds per row and trip instead of per element
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int k = 0; k < R; ++k)
+      if (gl + k * G < nvc) {
 #pragma unroll
-      for (int k = 0; k < R; ++k)
-        if (gl + k * G < nvc) {
+        for (int j = 0; j < V; ++j) {
+          T s1 = T(0), s2 = T(0);
 #pragma unroll
-          for (int j = 0; j < V; ++j) { const double v = (double)p[u][k].v[j]; sx[k][j] += v; sxx[k][j] += v * v; }
+          for (int u = 0; u < U; ++u) { const T v = p[u][k].v[j]; s1 += v; s2 += v * v; }
+          sx[k][j] += (double)s1; sxx[k][j] += (double)s2;
         }
+      }
   }
   for (; col < batch; col += stride) {
 #pragma unroll

@@ -110,7 +110,7 @@ def main():
             return bj.shard.with_logabsdet_jacobian_sharded(bnt, x, out=y_bn)
 
     y_bn = cm(d, N, dev)
-    rows.append(("InvertibleBatchNorm (training: stats pass only) d=64", "a18", bn_train_step, 4 * d, N))
+    rows.append(("InvertibleBatchNorm (training mode: statistics pass + apply pass) d=64", "a18", bn_train_step, 3 * 4 * d + 4, N))   # x is read twice
     dr, Kb = 32, 16
     raw = [randn(dr, k, dev, 100 + i) for i, k in enumerate((Kb, Kb, Kb - 1))]
     rqs = bj.RationalQuadraticSpline(raw[0], raw[1], raw[2], 3.0)
