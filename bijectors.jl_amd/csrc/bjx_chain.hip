@@ -154,7 +154,15 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
         T lo = a[u][j], up = b[u][j], yv = p[u].v[j];
         bool lb = d_isfinite(lo), ub = d_isfinite(up);
         T x;
-        if (lb && ub) { T ay = d_abs(yv); l[u] += F::log(up - lo) - ay - T(2) * f_log1pexp(-ay); x = (up - lo) * f_logistic(yv) + lo; }
+        if (lb && ub) {
+          // one exp serves both: t = exp(-|y|) ∈ (0, 1];  logistic(y) = 1/(1+t) or t/(1+t);  log1pexp(-|y|) = log1p(t)
+          // (LogExpFunctions' saturation thresholds are reproduced by t underflowing to 0 and by 1 + t rounding to 1)
+          const T ay = d_abs(yv);
+          const T t = F::exp(-ay);
+          const T r = F::rcp(T(1) + t);
+          l[u] += F::log(up - lo) - ay - T(2) * F::log1p(t);
+          x = (up - lo) * (yv < T(0) ? t * r : r) + lo;
+        }
         else if (lb) { l[u] += yv; x = F::exp(yv) + lo; }
         else if (ub) { l[u] += yv; x = up - F::exp(yv); }
         else x = yv;
