@@ -211,10 +211,11 @@ template <> struct Fast<double> {
 template <class T> __device__ __forceinline__ T f_logistic(T x) {
   // the quotient is computed before the selects: a nested ?: with the rcp in its last arm compiles to two
   // branches per element (vjp(inverse(Simplex)): 1.53 -> 1.31 ms without them)
+  // The lower saturation needs no select: below logistic_lo exp(x) has underflowed to 0 (or to a denormal, which
+  // gives a result below 1.5e-38 / 5e-324 instead of the reference's exact 0), and 0·rcp(1) = 0.
   const T e = Fast<T>::exp(x);
   const T q = e * Fast<T>::rcp(T(1) + e);
-  const T hi = x > Num<T>::logistic_hi ? T(1) : q;
-  return x < Num<T>::logistic_lo ? T(0) : hi;
+  return x > Num<T>::logistic_hi ? T(1) : q;
 }
 template <class T> __device__ __forceinline__ T f_log1pexp(T x) {
   const T e = Fast<T>::exp(x < Num<T>::l1pe1 ? x : -x);
