@@ -411,6 +411,93 @@ __global__ __launch_bounds__(256) void rqs_lds_kernel(const T* __restrict__ blob
   block_publish_partial(acc, red, fin);
 }
 
+// ------------------------------------------------------------------ RQS input pullback
+// x̄ = ȳ·f'(x) + ℓ̄·(log f')'(x) for the elementwise spline (rational_quadratic_spline.jl:128-357; closed-form
+// derivatives).  With the quantities rqs_eval already has (ξ, p = ξ(1-ξ), den = s + ds·p, nj = d_k + dd·ξ - ds·p):
+//   f' = s²·nj/den²,   d log f'/dx = [ (dd - ds(1-2ξ))/nj - 2 ds(1-2ξ)/den ] / w
+// Inverse map (x = f⁻¹(y), log-det -log f'(x)):  ȳ = (x̄ - ℓ̄·d log f'/dx)/f'.  Outside [-B, B]: identity.
+// Same LDS blob, search and records as rqs_lds_kernel; the search depth is a runtime loop here (one instantiation per
+// direction), one column per trip.
+template <class T, bool INV>
+__device__ __forceinline__ T rqs_eval_vjp(const Rec4<T>& A, const Rec4<T>& B, T lim, T xin, T g, T lb) {
+  using F = Fast<T>;
+  const T s = B.v[0], d_k = B.v[1], ds = B.v[2], dd = B.v[3];
+  T xi, iw;
+  if (!INV) { xi = (xin - A.v[0]) * A.v[1]; iw = A.v[1]; }
+  else {
+    const T yh = xin - A.v[0];
+    const T t = yh * ds;
+    const T a1 = A.v[1] * (s - d_k) + t;
+    const T a2 = A.v[1] * d_k - t;
+    const T q = s * yh;
+    xi = F::div(q + q, a2 + F::sqrt(a2 * a2 + 4 * (a1 * q)));
+    iw = F::rcp(A.v[3]);
+  }
+  const T p = xi - xi * xi;
+  const T den = s + ds * p;
+  const T rden = F::rcp(den);
+  const T nj = (d_k + dd * xi) - ds * p;
+  const T sr = s * rden;
+  const T J = nj * (sr * sr);                                               // f'
+  const T om = T(1) - (xi + xi);                                            // dp/dξ
+  const T dl = ((dd - ds * om) * F::rcp(nj) - T(2) * ds * om * rden) * iw;  // d log f'/dx
+  const T out = !INV ? g * J + lb * dl : (g - lb * dl) * F::rcp(J);
+  return d_abs(xin) < lim ? out : g;
+}
+
+template <class T, int V, bool INV>
+__global__ __launch_bounds__(256) void rqs_vjp_kernel(const T* __restrict__ blob, const int* __restrict__ flag, int K1, int nstep_hi, int dual,
+                                                      const T* __restrict__ x, const T* __restrict__ gbar, const T* __restrict__ lbar, T* __restrict__ xbar,
+                                                      int64_t dim, int64_t batch, int G, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* blob_l = reinterpret_cast<T*>(smem);
+  const int skip0 = dual ? flag[0] : 0;
+  const RqsGeom g = rqs_geom(K1, dim, V, skip0, nstep_hi);
+  {
+    const int n16 = (int)(rqs_blob_words(g) * sizeof(T) / 16);
+    const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(blob);
+    bjx_f32x4* dst = reinterpret_cast<bjx_f32x4*>(blob_l);
+    for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+    __syncthreads();
+  }
+  const int NS = g.nstep;
+  const int gl = threadIdx.x & (G - 1), cg = threadIdx.x / G;
+  const int cols_per_block = 256 / G;
+  const bool lane_ok = gl < g.nvc;
+  const int glc = lane_ok ? gl : 0;
+  const char* base = reinterpret_cast<const char*>(blob_l);
+  constexpr int SH = sizeof(T) == 4 ? 2 : 3;
+  T lim[V];
+  int rp[V], ra[V], rb[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    rp[j] = j * g.nvc + glc;
+    lim[j] = blob_l[rp[j]];
+    ra[j] = (int)sizeof(T) * ((g.dimp << NS) + 4 * rp[j] * g.RS);
+    rb[j] = ra[j] + (int)sizeof(T) * 4 * g.dimp * g.RS;
+  }
+  const int64_t col_base = (int64_t)blockIdx.x * iters * cols_per_block + cg;
+  for (int it = 0; it < iters; ++it) {
+    const int64_t col = col_base + (int64_t)it * cols_per_block;
+    if (col >= batch || !lane_ok) continue;
+    Pack<T, V> p = load_pack<T, V, true>(x + col * dim + (int64_t)gl * V);
+    const Pack<T, V> gp = load_pack<T, V, true>(gbar + col * dim + (int64_t)gl * V);
+    const T lb = lbar ? lbar[col] : T(0);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      int pos = 0;
+      for (int lvl = 1; lvl <= NS; ++lvl) {                                  // level l keys: [dimp·2^(l-1) + rp·2^(l-1) + pos]
+        const T key = blob_l[((size_t)(g.dimp + rp[j]) << (lvl - 1)) + pos];
+        pos = 2 * pos + (key < p.v[j] ? 1 : 0);
+      }
+      const Rec4<T> A = lds_rec<T>(reinterpret_cast<const T*>(base + ((pos << (SH + 2)) + ra[j])));
+      const Rec4<T> B = lds_rec<T>(reinterpret_cast<const T*>(base + ((pos << (SH + 2)) + rb[j])));
+      p.v[j] = rqs_eval_vjp<T, INV>(A, B, lim[j], p.v[j], gp.v[j], lb);
+    }
+    store_pack<T, V, true>(xbar + col * dim + (int64_t)gl * V, p);
+  }
+}
+
 // ------------------------------------------------------------------ BatchNorm (eval)
 // normalise.jl:41-88.  LDS rows: s = exp(logs), m, q = sqrt(v + eps), b.
 template <class T, bool INV> struct BnF {
@@ -659,6 +746,43 @@ int rqs_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int 
 }
 
 template <class T>
+int rqs_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int K1, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar,
+                 int64_t dim, int64_t batch) {
+  if (dim * batch == 0) return BJX_OK;
+  ColLaunch c = col_launch_cfg<T>(ctx, in, in_bar, dim, batch);
+  if (c.V > 1 && !bjx_aligned16(out_bar)) { c.V = 1; int G = 1; while (G < 64 && G < dim) G <<= 1; c.G = G; }
+  const int nstep_hi = ceil_log2(K1 < 2 ? 2 : K1);
+  const int dual = (K1 >= 3 && ceil_log2(K1 - 1) < nstep_hi) ? 1 : 0;
+  const RqsGeom g_hi = rqs_geom(K1, dim, c.V, 0, nstep_hi);
+  const size_t blob_bytes = rqs_blob_words(g_hi) * sizeof(T);
+  BJX_REQUIRE(ctx, nstep_hi <= 6 && dim / c.V <= 64 && dim < (1 << 20) && blob_bytes <= 64 * 1024 && blob_bytes + 64 <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED,
+              "bjx_rqs_vjp: knot tables of %lld rows x %d knots do not fit the LDS path", (long long)dim, K1);
+  int* flag = reinterpret_cast<int*>(ctx->scratch);
+  T* blob = reinterpret_cast<T*>(static_cast<char*>(ctx->scratch) + 64);
+  if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, flag, blob);
+  else hipLaunchKernelGGL((rqs_blob_kernel<T, false>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, flag, blob);
+  BJX_CHECK_LAUNCH(ctx);
+  const int cols_per_block = 256 / c.G;
+  const int64_t bytes_per_group = (int64_t)cols_per_block * dim * sizeof(T);
+  int iters = (int)((4 * (int64_t)blob_bytes + bytes_per_group - 1) / bytes_per_group);
+  if (iters < 1) iters = 1;
+  if (iters > 64) iters = 64;
+  const int64_t groups = (batch + cols_per_block - 1) / cols_per_block;
+  const int64_t grid = (groups + iters - 1) / iters;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_rqs_vjp: batch too large for one launch");
+  constexpr int VW = Vec16<T>::N;
+  {
+    BjxProf prof_(ctx);
+#define RV(V_, I_) hipLaunchKernelGGL((rqs_vjp_kernel<T, V_, I_>), dim3((unsigned)grid), dim3(256), blob_bytes, ctx->stream, blob, flag, K1, nstep_hi, dual, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, iters)
+    if (c.V == VW) { if (inverse) RV(VW, true); else RV(VW, false); }
+    else { if (inverse) RV(1, true); else RV(1, false); }
+#undef RV
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+
+template <class T>
 int bn_impl(bjx_ctx* ctx, int inverse, const T* b, const T* logs, const T* m, const T* v, T eps, const T* in, T* out,
             T* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
   hipLaunchKernelGGL(bn_const_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, logs, v, eps, dim, batch, inverse, ctx->consts);
@@ -820,6 +944,18 @@ BJX_API int bjx_rqs(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* widths,
               rqs_impl<float>(ctx, inverse, (const float*)widths, (const float*)heights, (const float*)derivs, n_knots, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, batch, flags),
               rqs_impl<double>(ctx, inverse, (const double*)widths, (const double*)heights, (const double*)derivs, n_knots, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, batch, flags),
               "bjx_rqs");
+}
+
+BJX_API int bjx_rqs_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* widths, const void* heights, const void* derivs, int n_knots,
+                        const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t dim, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 0 && batch >= 0, BJX_ERR_SHAPE, "bjx_rqs_vjp: negative size");
+  BJX_REQUIRE(ctx, n_knots >= 2, BJX_ERR_SHAPE, "bjx_rqs_vjp: need at least 2 knots");
+  BJX_REQUIRE(ctx, widths && heights && derivs && ((in && out_bar && in_bar) || dim * batch == 0), BJX_ERR_ARG, "bjx_rqs_vjp: null pointer");
+  DISPATCH_DT(ctx, dt,
+              rqs_vjp_impl<float>(ctx, inverse, (const float*)widths, (const float*)heights, (const float*)derivs, n_knots, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, dim, batch),
+              rqs_vjp_impl<double>(ctx, inverse, (const double*)widths, (const double*)heights, (const double*)derivs, n_knots, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, dim, batch),
+              "bjx_rqs_vjp");
 }
 
 BJX_API int bjx_rqs_params(bjx_ctx* ctx, bjx_dtype dt, const void* raw_w, const void* raw_h, const void* raw_d, int K,

@@ -1273,6 +1273,20 @@ def vjp(b, x, out_bar, ladj_bar=None):
         rc = L.load().bjx_planar_vjp(ctx.h, _dt(xc), int(inv), _ptr(w), _ptr(u), _ptr(bb), base.n_layers, _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
         L.check(ctx.h, rc, "bjx_planar_vjp")
         return xb
+    if isinstance(base, RationalQuadraticSpline):
+        xc, dim, batch, vec = _prep(x)
+        gc, gdim, gbatch, _ = _prep(out_bar)
+        if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:
+            raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
+        if dim != base.widths.shape[0]:
+            raise ValueError(f"DimensionMismatch: spline with {base.widths.shape[0]} rows applied to {dim} rows")
+        w, h, d = (colmajor(_param(t, xc)) for t in (base.widths, base.heights, base.derivatives))
+        lb = _ladj_bar(ladj_bar, batch, xc)
+        ctx = context(xc.device)
+        xb = _empty(dim, batch, xc, vec)
+        rc = L.load().bjx_rqs_vjp(ctx.h, _dt(xc), int(inv), _ptr(w), _ptr(h), _ptr(d), int(base.widths.shape[1]), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
+        L.check(ctx.h, rc, "bjx_rqs_vjp")
+        return xb
     if isinstance(base, RadialLayer):
         xc, dim, batch, vec = _prep(x)
         gc, gdim, gbatch, _ = _prep(out_bar)

@@ -225,6 +225,13 @@ int bjx_rqs(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* widths, const v
             const void* derivs, int n_knots, const void* in, void* out,
             void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
 
+/* input pullback of with_logabsdet_jacobian for the elementwise spline (inverse=0) and its
+ * inverse (inverse=1): in_bar = out_bar * f'(x) + ladj_bar[n] * (log f')'(x) (closed-form derivatives of
+ * rational_quadratic_spline.jl:128-357); knot parameters as for bjx_rqs.  Knot gradients are not produced. */
+int bjx_rqs_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* widths, const void* heights,
+                const void* derivs, int n_knots, const void* in, const void* out_bar, const void* ladj_bar,
+                void* in_bar, int64_t dim, int64_t batch);
+
 /* The `B` constructor, rational_quadratic_spline.jl:109-123: raw_w, raw_h: T[dim,K];
  * raw_d: T[dim,K-1]  ->  widths, heights, derivs: T[dim,K+1]. */
 int bjx_rqs_params(bjx_ctx* ctx, bjx_dtype dt, const void* raw_w, const void* raw_h,

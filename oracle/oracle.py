@@ -736,3 +736,51 @@ def planar_param_vjp(w, u, b, z, y_bar, ladj_bar=None):
         ub[:, k] = uhb + w[:, k] * (ka * wtuhb + cb * sig(a[k]))
         wb[:, k] = wdir + kap[k] * uhb + wtuhb * (ka * u[:, k] - 2.0 * kap[k] / n2[k] * w[:, k]) + cb * sig(a[k]) * u[:, k]
     return wb, ub, bb
+
+
+def rqs_vjp(widths, heights, derivs, x, out_bar, ladj_bar=None, inverse=False):
+    """Input pullback of with_logabsdet_jacobian for the elementwise RationalQuadraticSpline and its inverse
+    (rational_quadratic_spline.jl:128-357; closed-form derivatives — the reference leaves them to the AD package):
+        f'(x) = s²(d_{k+1}ξ² + 2sξ(1-ξ) + d_k(1-ξ)²)/den²,  den = s + (d_{k+1} + d_k - 2s)ξ(1-ξ),
+        x̄ = ȳ f' + ℓ̄ (log f')'          (forward);      ȳ = (x̄ - ℓ̄ (log f')'(x))/f'(x)   (inverse, x = f⁻¹(y)).
+    widths/heights/derivs: (dim, K) knot arrays as for `rqs`; x, out_bar: (dim, N).  numpy, float64."""
+    W = np.asarray(widths, dtype=np.float64)
+    H = np.asarray(heights, dtype=np.float64)
+    D = np.asarray(derivs, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    dim, N = x.shape
+    K = W.shape[1]
+    g = np.asarray(out_bar, dtype=np.float64)
+    lb = np.zeros(N) if ladj_bar is None else np.broadcast_to(np.asarray(ladj_bar, dtype=np.float64), (N,))
+    if inverse:
+        xin, _ = rqs(W, H, D, np.asfortranarray(x), inverse=True)
+        xin = np.asarray(xin, dtype=np.float64)
+    else:
+        xin = x
+    out = np.empty_like(x)
+    for i in range(dim):
+        w, h, d = W[i], H[i], D[i]
+        B = w[-1]
+        for n in range(N):
+            xv = xin[i, n]
+            if not (-B < xv < B):                       # identity outside [-B, B] (:132)
+                out[i, n] = g[i, n]
+                continue
+            k = int(np.searchsorted(w, xv, side="left")) - 1      # searchsortedfirst(widths, x) - 1 (:139)
+            wk = -B if k < 0 else w[k]
+            hk = -h[-1] if k < 0 else h[k]
+            wd = w[k + 1] - wk
+            dy = h[k + 1] - hk
+            s = dy / wd
+            dk = 1.0 if k < 0 else d[k]
+            dk1 = 1.0 if k + 1 == K - 1 else d[k + 1]
+            xi = (xv - wk) / wd
+            p = xi * (1 - xi)
+            ds = dk1 + dk - 2 * s
+            den = s + ds * p
+            nj = dk1 * xi * xi + 2 * s * p + dk * (1 - xi) ** 2
+            J = s * s * nj / (den * den)
+            dnj = 2 * dk1 * xi + 2 * s * (1 - 2 * xi) - 2 * dk * (1 - xi)
+            dl = (dnj / nj - 2 * ds * (1 - 2 * xi) / den) / wd
+            out[i, n] = g[i, n] * J + lb[n] * dl if not inverse else (g[i, n] - lb[n] * dl) / J
+    return out

@@ -118,6 +118,10 @@ def main():
     add("RQS K=16 d=32 forward", "a19", rqs, xr)
     yr = bj.transform(rqs, xr)
     add("RQS K=16 d=32 inverse", "a19", bj.inverse(rqs), yr)
+    gr = randn(dr, N, dev, 31)
+    lbr = randn(N, 1, dev, 32).reshape(-1).contiguous()
+    rows.append(("vjp(RQS K=16 d=32)", "f-1", lambda: bj.vjp(rqs, xr, gr, lbr), 4 * 3 * dr + 4, N))
+    rows.append(("vjp(inverse(RQS K=16 d=32))", "f-1", lambda: bj.vjp(bj.inverse(rqs), yr, gr, lbr), 4 * 3 * dr + 4, N))
     perm = bj.Permute(list(torch.randperm(d, generator=torch.Generator().manual_seed(0)).add(1).tolist()))
     add("Permute d=64", "a21", perm, x, per_sample=False)
     mask = bj.PartitionMask(d, list(range(1, d // 2 + 1)), list(range(d // 2 + 1, d + 1)))

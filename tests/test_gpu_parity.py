@@ -1274,3 +1274,20 @@ def test_planar_param_vjp(bj, orc, dim, nl, N, dt):
     np.testing.assert_allclose(host(pb["w"]), wb_ref, **tol)
     np.testing.assert_allclose(host(pb["u"]), ub_ref, **tol)
     np.testing.assert_allclose(host(pb["b"]), bb_ref, **tol)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,K,N", [(32, 16, 600), (8, 5, 257), (3, 8, 100), (64, 10, 129), (20, 33, 40)])
+def test_rqs_vjp(bj, orc, dim, K, N, dt):
+    """Input pullback of the RationalQuadraticSpline and of its inverse (§8f f-1) against the finite-difference-pinned oracle."""
+    r = rng(87)
+    w, h, d = orc.rqs_params(r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K - 1)).astype(dt), 3.0)
+    b = bj.RationalQuadraticSpline(dev(w), dev(h), dev(d))
+    X = np.asfortranarray((1.3 * r.normal(size=(dim, N))).astype(dt))
+    X[0, :3] = [5.0, -4.0, 3.5]                                   # outside [-B, B]: identity
+    gbar = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    lbar = r.normal(size=N).astype(dt)
+    for inv in (False, True):
+        ref = orc.rqs_vjp(w, h, d, X, gbar, lbar, inverse=inv)
+        got = bj.vjp(bj.inverse(b) if inv else b, dev(X), dev(gbar), torch.from_numpy(lbar).cuda())
+        np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref).max())))

@@ -581,3 +581,17 @@ def test_planar_parameter_pullback_matches_finite_differences(orc):
             bp[k] += h
             bm[k] -= h
             assert abs((F(w, u, bp) - F(w, u, bm)) / (2 * h) - bb[k]) < 1e-6
+
+
+def test_rqs_pullback_matches_finite_differences(orc):
+    """Elementwise spline and its inverse: closed-form f' and (log f')' against central differences of the golden-pinned
+    oracle, inside and outside [-B, B]."""
+    r = np.random.default_rng(17)
+    dim, K, N = 3, 6, 5
+    w, h, d = orc.rqs_params(r.normal(size=(dim, K)), r.normal(size=(dim, K)), r.normal(size=(dim, K - 1)), 2.5)
+    x = np.asfortranarray(r.normal(size=(dim, N)) * 1.2)
+    x[0, 0] = 4.0
+    gbar, lbar = r.normal(size=(dim, N)), r.normal(size=N)
+    for inv in (False, True):
+        f = lambda v: orc.rqs(w, h, d, np.asfortranarray(v), inverse=inv)
+        np.testing.assert_allclose(orc.rqs_vjp(w, h, d, x, gbar, lbar, inverse=inv), _fd_vjp(f, x, gbar, lbar), rtol=1e-6, atol=1e-7)
