@@ -1090,6 +1090,110 @@ int coupling_rqs_impl(bjx_ctx* ctx, int inverse, const int32_t* idx1, int64_t n1
 }
 }  // namespace
 
+namespace {
+// ------------------------------------------------------------------ Coupling (affine law) pullback
+// coupling.jl:206-259 with b = Shift(t) ∘ Scale(s), s, t = θ(x₂) per column:  y₁ = t + s x₁, logabsdetjac = Σ log|s|.
+//   forward:  x̄₁ = s ȳ₁,        s̄ = ȳ₁ x₁ + ℓ̄/s,            t̄ = ȳ₁
+//   inverse:  ȳ₁ = x̄₁/s,        s̄ = -(x̄₁/s) x₁ - ℓ̄/s,       t̄ = -x̄₁/s       (x₁ = (y₁ - t)/s)
+// rows outside x₁ pass their cotangent through.  s̄, t̄ ([n1, batch]) are what the host needs to continue through θ
+// (an arbitrary closure: its pullback stays with the AD package); the cotangent θ adds to x₂ is added there too.
+// G lanes per column, 4 columns in flight, the row map in LDS.
+template <class T, int V, bool INV>
+__global__ __launch_bounds__(256) void coupling_affine_vjp_kernel(const int32_t* __restrict__ map, const T* __restrict__ scale, const T* __restrict__ shift,
+                                                                  const T* __restrict__ x, const T* __restrict__ gbar, const T* __restrict__ lbar,
+                                                                  T* __restrict__ xbar, T* __restrict__ sbar, T* __restrict__ tbar, int64_t n1, int64_t dim,
+                                                                  int64_t batch, int G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t* m = reinterpret_cast<int32_t*>(smem);
+  for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) m[i] = map[i];
+  __syncthreads();
+  const int gl = threadIdx.x & (G - 1);
+  const int cols_per_block = 256 / G;
+  const int64_t nvc = dim / V;
+  constexpr int UC = 4;
+  const int64_t col0 = (int64_t)blockIdx.x * cols_per_block * UC + threadIdx.x / G;
+  for (int64_t v = gl; v < nvc; v += G) {
+    const int64_t row = v * V;
+    Pack<T, V> px[UC], pg[UC];
+#pragma unroll
+    for (int u = 0; u < UC; ++u) {
+      const int64_t col = col0 + (int64_t)u * cols_per_block;
+      if (col < batch) { px[u] = load_pack<T, V, true>(x + col * dim + row); pg[u] = load_pack<T, V, true>(gbar + col * dim + row); }
+    }
+#pragma unroll
+    for (int u = 0; u < UC; ++u) {
+      const int64_t col = col0 + (int64_t)u * cols_per_block;
+      if (col >= batch) continue;
+      const T lb = lbar ? lbar[col] : T(0);
+      Pack<T, V> o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const int32_t mi = m[row + j];
+        T out = pg[u].v[j];
+        if (mi >= 0) {
+          const T sc = scale ? scale[col * n1 + mi] : T(1);
+          const T tv = shift ? shift[col * n1 + mi] : T(0);
+          const T rs = T(1) / sc;
+          if (!INV) {
+            out = sc * pg[u].v[j];
+            if (sbar) sbar[col * n1 + mi] = pg[u].v[j] * px[u].v[j] + lb * rs;
+            if (tbar) tbar[col * n1 + mi] = pg[u].v[j];
+          } else {
+            const T x1 = (px[u].v[j] - tv) * rs;
+            out = pg[u].v[j] * rs;
+            if (sbar) sbar[col * n1 + mi] = -out * x1 - lb * rs;
+            if (tbar) tbar[col * n1 + mi] = -out;
+          }
+        }
+        o.v[j] = out;
+      }
+      store_pack<T, V, true>(xbar + col * dim + row, o);
+    }
+  }
+}
+
+template <class T>
+int coupling_affine_vjp_impl(bjx_ctx* ctx, int inverse, const int32_t* idx1, int64_t n1, const T* scale, const T* shift, const T* in, const T* out_bar,
+                             const T* ladj_bar, T* in_bar, T* scale_bar, T* shift_bar, int64_t dim, int64_t batch) {
+  if (dim * batch == 0) return BJX_OK;
+  int32_t* map = nullptr;
+  int rc = build_rowmap(ctx, idx1, n1, dim, &map);
+  if (rc) return rc;
+  const size_t smem = (size_t)dim * sizeof(int32_t);
+  BJX_REQUIRE(ctx, smem <= 60 * 1024, BJX_ERR_UNSUPPORTED, "bjx_coupling_affine_vjp: dim %lld too large for the LDS row map", (long long)dim);
+  constexpr int VW = Vec16<T>::N;
+  const bool v_ok = bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar) && dim % VW == 0;
+  const int V = v_ok ? VW : 1;
+  const int64_t packs = dim / V;
+  int G = 1;
+  while (G < 64 && G < packs) G <<= 1;
+  const int64_t cpb = (int64_t)(256 / G) * 4;
+  const int64_t grid = (batch + cpb - 1) / cpb;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_coupling_affine_vjp: batch too large for one launch");
+  {
+    BjxProf prof_(ctx);
+#define CAV(V_, I_) hipLaunchKernelGGL((coupling_affine_vjp_kernel<T, V_, I_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, map, scale, shift, in, out_bar, ladj_bar, in_bar, scale_bar, shift_bar, n1, dim, batch, G)
+    if (v_ok) { if (inverse) CAV(VW, true); else CAV(VW, false); }
+    else { if (inverse) CAV(1, true); else CAV(1, false); }
+#undef CAV
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+}  // namespace
+
+BJX_API int bjx_coupling_affine_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const int32_t* idx1, int64_t n1, const void* scale, const void* shift,
+                                    const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, void* scale_bar, void* shift_bar,
+                                    int64_t dim, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 0 && batch >= 0 && n1 >= 0 && n1 <= dim, BJX_ERR_SHAPE, "bjx_coupling_affine_vjp: bad size (n1=%lld, dim=%lld)", (long long)n1, (long long)dim);
+  BJX_REQUIRE(ctx, (idx1 || n1 == 0) && ((in && out_bar && in_bar) || dim * batch == 0), BJX_ERR_ARG, "bjx_coupling_affine_vjp: null pointer");
+  DISPATCH_DT(ctx, dt,
+              coupling_affine_vjp_impl<float>(ctx, inverse, idx1, n1, (const float*)scale, (const float*)shift, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, (float*)scale_bar, (float*)shift_bar, dim, batch),
+              coupling_affine_vjp_impl<double>(ctx, inverse, idx1, n1, (const double*)scale, (const double*)shift, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, (double*)scale_bar, (double*)shift_bar, dim, batch),
+              "bjx_coupling_affine_vjp");
+}
+
 BJX_API int bjx_coupling_affine(bjx_ctx* ctx, bjx_dtype dt, int inverse, const int32_t* idx1, int64_t n1, const void* scale,
                                 const void* shift, const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t dim,
                                 int64_t batch, uint32_t flags) {

@@ -1044,6 +1044,64 @@ class Coupling(Bijector):
     def _wlj_inv(self, x, per_sample, want_ladj=True):
         return self._run(x, True, per_sample, want_ladj)
 
+    def _vjp(self, x, out_bar, ladj_bar, inv):
+        """Pullback of the affine coupling (bjx_coupling_affine_vjp): x̄ with the x₁ rows scaled and the rest passed
+        through, plus — when θ is made of torch operations — the part that flows back through θ's outputs
+        (s̄, t̄ from the kernel, θ's own pullback by torch.autograd on the host: θ is an arbitrary closure)."""
+        xc, dim, batch, vec = _prep(x)
+        gc, gdim, gbatch, _ = _prep(out_bar)
+        if dim != self.mask.n or (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:
+            raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
+        i2 = torch.tensor([i - 1 for i in self.mask.indices_2], dtype=torch.long, device=xc.device)
+        x2 = xc[i2].detach().clone().requires_grad_(True) if vec else xc[i2, :].detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            law = self.theta(x2)
+            scale = shift = None
+            for st in (law._stages() if isinstance(law, ComposedFunction) else [law]):
+                if isinstance(st, Scale) and scale is None and shift is None:
+                    scale = st.a
+                elif isinstance(st, Shift) and shift is None:
+                    shift = st.a
+                else:
+                    raise NotImplementedError(f"no device pullback for the coupling law {law!r} (affine laws only)")
+            n1 = len(self.mask.indices_1)
+
+            def full(p):
+                if p is None:
+                    return None
+                t = p if isinstance(p, torch.Tensor) else torch.as_tensor(p, dtype=xc.dtype, device=xc.device)
+                t = t.to(device=xc.device, dtype=xc.dtype)
+                if t.dim() == 0:
+                    t = t.expand(n1)
+                if t.dim() == 1 and not vec:
+                    t = t[:, None].expand(n1, batch)
+                return t
+            s_f, t_f = full(scale), full(shift)
+        s_c = None if s_f is None else colmajor(s_f.detach().contiguous() if s_f.dim() == 1 else s_f.detach())
+        t_c = None if t_f is None else colmajor(t_f.detach().contiguous() if t_f.dim() == 1 else t_f.detach())
+        idx1 = torch.tensor([i - 1 for i in self.mask.indices_1], dtype=torch.int32, device=xc.device)
+        lb = _ladj_bar(ladj_bar, batch, xc)
+        ctx = context(xc.device)
+        xb = _empty(dim, batch, xc, vec)
+        sb = None if s_c is None else torch.empty((batch, n1), dtype=xc.dtype, device=xc.device).T
+        tb = None if t_c is None else torch.empty((batch, n1), dtype=xc.dtype, device=xc.device).T
+        rc = L.load().bjx_coupling_affine_vjp(ctx.h, _dt(xc), int(inv), _ptr(idx1), n1, _ptr(s_c), _ptr(t_c), _ptr(xc), _ptr(gc), _ptr(lb),
+                                              _ptr(xb), _ptr(sb), _ptr(tb), dim, batch)
+        L.check(ctx.h, rc, "bjx_coupling_affine_vjp")
+        outs, cots = [], []
+        for f_, b_ in ((s_f, sb), (t_f, tb)):
+            if f_ is not None and f_.requires_grad:
+                outs.append(f_)
+                cots.append(b_.reshape(-1) if vec else b_)
+        if outs:                                   # θ depends on x₂ through torch ops: add its pullback to the x₂ rows
+            g2, = torch.autograd.grad(outs, [x2], cots, allow_unused=True)
+            if g2 is not None:
+                if vec:
+                    xb[i2] += g2
+                else:
+                    xb[i2, :] += g2
+        return xb
+
 
 # ------------------------------------------------------------------ Stacked (SURVEY.md §8f, f-4)
 def _elementwise_ops(b):
@@ -1273,6 +1331,8 @@ def vjp(b, x, out_bar, ladj_bar=None):
         rc = L.load().bjx_planar_vjp(ctx.h, _dt(xc), int(inv), _ptr(w), _ptr(u), _ptr(bb), base.n_layers, _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
         L.check(ctx.h, rc, "bjx_planar_vjp")
         return xb
+    if isinstance(base, Coupling):
+        return base._vjp(x, out_bar, ladj_bar, inv)
     if isinstance(base, RationalQuadraticSpline):
         xc, dim, batch, vec = _prep(x)
         gc, gdim, gbatch, _ = _prep(out_bar)

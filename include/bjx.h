@@ -253,6 +253,15 @@ int bjx_coupling_affine(bjx_ctx* ctx, bjx_dtype dt, int inverse, const int32_t* 
                         const void* scale, const void* shift, const void* in, void* out,
                         void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch,
                         uint32_t flags);
+/* pullback of the affine Coupling (coupling.jl:206-259, b = Shift(t) o Scale(s)):
+ * in_bar [dim, batch] (rows outside x_1 pass out_bar through) and the cotangents of theta's outputs, scale_bar and
+ * shift_bar [n1, batch] (either may be NULL) — the host continues through the closure theta and adds its x_2
+ * cotangent.  inverse=1: in = y, the pre-image x_1 = (y_1 - t)/s is recomputed. */
+int bjx_coupling_affine_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const int32_t* idx1, int64_t n1,
+                            const void* scale, const void* shift, const void* in, const void* out_bar,
+                            const void* ladj_bar, void* in_bar, void* scale_bar, void* shift_bar,
+                            int64_t dim, int64_t batch);
+
 /* Spline law (θ ↦ RationalQuadraticSpline(w,h,d)): knots T[n1, n_knots] shared over the batch. */
 int bjx_coupling_rqs(bjx_ctx* ctx, bjx_dtype dt, int inverse, const int32_t* idx1, int64_t n1,
                      const void* widths, const void* heights, const void* derivs, int n_knots,

@@ -1291,3 +1291,52 @@ def test_rqs_vjp(bj, orc, dim, K, N, dt):
         ref = orc.rqs_vjp(w, h, d, X, gbar, lbar, inverse=inv)
         got = bj.vjp(bj.inverse(b) if inv else b, dev(X), dev(gbar), torch.from_numpy(lbar).cuda())
         np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref).max())))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_coupling_affine_vjp(bj, orc, dt):
+    """Pullback of Coupling(θ, mask) with the affine law (§8f f-1): the kernel gives x̄₁, the pass-through rows and the
+    cotangents of θ's outputs; θ(x₂) = (Scale(exp(A x₂)), Shift(B x₂)) is pulled back by torch.autograd on the host.
+    Reference: the closed form in numpy (float64)."""
+    r = rng(89)
+    dim, N = 12, 150
+    idx1, idx2 = [2, 5, 6, 11], [1, 3, 4]
+    A = (0.3 * r.normal(size=(4, 3))).astype(dt)
+    Bm = r.normal(size=(4, 3)).astype(dt)
+    m = bj.PartitionMask(dim, idx1, idx2)
+    At, Bt = dev(A), dev(Bm)
+    cl = bj.Coupling(lambda x2: bj.Shift(Bt @ x2) @ bj.Scale(torch.exp(At @ x2), batched=True), m)
+    X = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    gbar = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    lbar = r.normal(size=N).astype(dt)
+    i1, i2 = [i - 1 for i in idx1], [i - 1 for i in idx2]
+    X64, g64, l64, A64, B64 = (v.astype(np.float64) for v in (X, gbar, lbar, A, Bm))
+    sc, sh = np.exp(A64 @ X64[i2]), B64 @ X64[i2]
+    # forward
+    ref = g64.copy()
+    ref[i1] = sc * g64[i1]
+    sbar = g64[i1] * X64[i1] + l64 / sc
+    tbar = g64[i1]
+    ref[i2] += A64.T @ (sc * sbar) + B64.T @ tbar
+    got = bj.vjp(cl, dev(X), dev(gbar), torch.from_numpy(lbar).cuda())
+    np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref).max())))
+    # inverse: input y, pre-image x₁ = (y₁ - t)/s (x₂ rows are unchanged, so θ sees the same x₂)
+    x1 = (X64[i1] - sh) / sc
+    refi = g64.copy()
+    refi[i1] = g64[i1] / sc
+    sbar_i = -(g64[i1] / sc) * x1 - l64 / sc
+    tbar_i = -g64[i1] / sc
+    refi[i2] += A64.T @ (sc * sbar_i) + B64.T @ tbar_i
+    goti = bj.vjp(bj.inverse(cl), dev(X), dev(gbar), torch.from_numpy(lbar).cuda())
+    np.testing.assert_allclose(host(goti), refi, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(refi).max())))
+    # the same through finite differences of the forward oracle, θ included
+    def fwd(Xv):
+        s_, t_ = np.exp(A64 @ Xv[i2]), B64 @ Xv[i2]
+        Y, l = orc.coupling_affine(i1, np.asfortranarray(s_), np.asfortranarray(t_), np.asfortranarray(Xv))
+        return float((Y * g64).sum() + (l * l64).sum())
+    h = 1e-6
+    for (i, n) in ((1, 0), (0, 3), (5, 7), (10, 2)):
+        Xp, Xm = X64.copy(), X64.copy()
+        Xp[i, n] += h
+        Xm[i, n] -= h
+        assert abs((fwd(Xp) - fwd(Xm)) / (2 * h) - ref[i, n]) < 1e-5 * max(1.0, abs(ref[i, n]))
