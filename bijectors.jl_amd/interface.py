@@ -1249,10 +1249,12 @@ def vjp(b, x, out_bar, ladj_bar=None):
     """Pullback of `with_logabsdet_jacobian(b, x)`: returns x_bar = J(x)^T out_bar + ladj_bar * grad_x logabsdetjac.
 
     `out_bar` has the shape of b(x); `ladj_bar` is the cotangent of the PER-COLUMN log-det (a (batch,) tensor,
-    a python number broadcast over the batch, or None = 0).  Elementwise chains and `Stacked`s of them go through
-    bjx_stacked_vjp (input gradient only, not the bijectors' parameters); device kernels also exist for the bijectors whose
-    rrules the reference ships (ext/BijectorsChainRulesCoreExt.jl): OrderedBijector and its inverse (:65-197)
-    and inverse(VecCholeskyBijector) (:311-320, src/bijectors/corr.jl:402-451)."""
+    a python number broadcast over the batch, or None = 0).  Input pullbacks only (parameters: `vjp_params` for the
+    PlanarLayer stack).  Device kernels: elementwise chains / `Stacked` (bjx_stacked_vjp); the rules the reference
+    ships (ext/BijectorsChainRulesCoreExt.jl) — OrderedBijector and its inverse (:65-197), the LKJ-Cholesky link
+    (:199-311) and its inverse (:311-320); SimplexBijector, PlanarLayer, RadialLayer, RationalQuadraticSpline and the
+    affine Coupling in both directions; Permute (the inverse gather); InvertibleBatchNorm in eval mode and
+    `columnwise(f)` through the kernels above."""
     if isinstance(b, Stacked):
         return b._vjp(x, out_bar, ladj_bar)
     if _elementwise_ops(b) is not None:                 # any chain of elementwise bijectors = one segment over all rows
@@ -1331,6 +1333,11 @@ def vjp(b, x, out_bar, ladj_bar=None):
         rc = L.load().bjx_planar_vjp(ctx.h, _dt(xc), int(inv), _ptr(w), _ptr(u), _ptr(bb), base.n_layers, _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
         L.check(ctx.h, rc, "bjx_planar_vjp")
         return xb
+    if isinstance(base, Permute):
+        # y = A x with A a permutation matrix: x̄ = Aᵀȳ = the inverse permutation of ȳ (bit-exact gather; log-det 0)
+        return transform(base if inv else inverse(base), out_bar)
+    if isinstance(base, Columnwise):
+        return vjp(inverse(base.x) if inv else base.x, x, out_bar, ladj_bar)
     if isinstance(base, Coupling):
         return base._vjp(x, out_bar, ladj_bar, inv)
     if isinstance(base, RationalQuadraticSpline):

@@ -1340,3 +1340,19 @@ def test_coupling_affine_vjp(bj, orc, dt):
         Xp[i, n] += h
         Xm[i, n] -= h
         assert abs((fwd(Xp) - fwd(Xm)) / (2 * h) - ref[i, n]) < 1e-5 * max(1.0, abs(ref[i, n]))
+
+
+def test_permute_and_columnwise_vjp(bj, orc):
+    r = rng(90)
+    d, N = 9, 40
+    perm = bj.Permute(list(r.permutation(d) + 1))
+    X = dev(np.asfortranarray(r.normal(size=(d, N))))
+    G = dev(np.asfortranarray(r.normal(size=(d, N))))
+    gx = bj.vjp(perm, X, G)
+    # <P x, g> = <x, Pᵀ g>
+    assert float((bj.transform(perm, X) * G).sum()) == pytest.approx(float((X * gx).sum()), rel=1e-12)
+    assert torch.equal(bj.vjp(bj.inverse(perm), X, bj.vjp(perm, X, G)), G)
+    b = bj.columnwise(bj.SimplexBijector())
+    Xs = dev(np.asfortranarray(r.dirichlet(np.ones(6), size=N).T))
+    Gs = dev(np.asfortranarray(r.normal(size=(5, N))))
+    assert torch.equal(bj.vjp(b, Xs, Gs, 0.5), bj.vjp(bj.SimplexBijector(), Xs, Gs, 0.5))
