@@ -883,6 +883,99 @@ __global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const double* __re
   if (blockIdx.x == 0 && threadIdx.x == 0) stats[2 * dim] = (double)batch;
 }
 
+// ------------------------------------------------------------------ row moments over the batch (parameter pullbacks of per-row affine stages)
+// out[i] = Σ_n a[i,n],  out[dim + i] = Σ_n a[i,n]·b[i,n]  (b = NULL: a²), Float64, fixed order.  With a = the input
+// cotangent z̄ of a chain `tail ∘ Shift(μ) ∘ Scale(σ)` and b = its input z these are the parameter cotangents of the
+// leading per-row affine stage — the mean-field family of ADVI:  μ̄ = Σ z̄/σ,  σ̄ = (Σ z̄ z + Σ ℓ̄)/σ.
+// Same streaming shape as bn_stats_kernel (lanes along the rows, Float64 accumulators, LDS combine, one partial per block).
+template <class T, int V, int R>
+__global__ __launch_bounds__(256) void row_moments_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t dim, int64_t batch, int G,
+                                                          double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);
+  const int gl = threadIdx.x & (G - 1), cg = threadIdx.x / G;
+  const int cols_per_block = 256 / G;
+  const int64_t nvc = dim / V;
+  double s1[R][V], s2[R][V];
+#pragma unroll
+  for (int k = 0; k < R; ++k)
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s1[k][j] = 0.0; s2[k][j] = 0.0; }
+  constexpr int U = R == 1 ? 4 : (R == 2 ? 2 : 1);
+  const int64_t stride = (int64_t)gridDim.x * cols_per_block;
+  for (int64_t col = (int64_t)blockIdx.x * cols_per_block + cg; col < batch; col += U * stride) {
+    Pack<T, V> pa[U][R], pb[U][R];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const int64_t c = col + u * stride;
+        const bool ok = c < batch && gl + k * G < nvc;
+        if (ok) { pa[u][k] = load_pack<T, V, false>(a + c * dim + (int64_t)(gl + k * G) * V); pb[u][k] = b ? load_pack<T, V, false>(b + c * dim + (int64_t)(gl + k * G) * V) : pa[u][k]; }
+        else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) { pa[u][k].v[j] = T(0); pb[u][k].v[j] = T(0); }
+        }
+      }
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        T t1 = T(0), t2 = T(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) { t1 += pa[u][k].v[j]; t2 += pa[u][k].v[j] * pb[u][k].v[j]; }
+        s1[k][j] += (double)t1; s2[k][j] += (double)t2;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k)
+    if (gl + k * G < nvc) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const size_t row = (size_t)(gl + k * G) * V + j;
+        red[((size_t)cg * dim + row) * 2] = s1[k][j];
+        red[((size_t)cg * dim + row) * 2 + 1] = s2[k][j];
+      }
+    }
+  __syncthreads();
+  for (int64_t r = threadIdx.x; r < dim; r += 256) {
+    double x = 0.0, y = 0.0;
+    for (int c = 0; c < cols_per_block; ++c) { x += red[((size_t)c * dim + r) * 2]; y += red[((size_t)c * dim + r) * 2 + 1]; }
+    partial[((size_t)blockIdx.x * dim + r) * 2] = x;
+    partial[((size_t)blockIdx.x * dim + r) * 2 + 1] = y;
+  }
+}
+
+template <class T>
+int row_moments_impl(bjx_ctx* ctx, const T* a, const T* b, double* out, int64_t dim, int64_t batch) {
+  if (dim == 0) return BJX_OK;
+  if (batch == 0) { BJX_HIP(ctx, hipMemsetAsync(out, 0, (size_t)(2 * dim + 1) * sizeof(double), ctx->stream)); return BJX_OK; }
+  ColLaunch c = col_launch_cfg<T>(ctx, a, b ? (const void*)b : (const void*)a, dim, batch);
+  const int64_t nvc = dim / c.V;
+  BJX_REQUIRE(ctx, nvc <= 4 * (int64_t)c.G, BJX_ERR_UNSUPPORTED, "bjx_row_moments: %lld rows exceed the register-accumulator kernel", (long long)dim);
+  const int R = nvc <= c.G ? 1 : (nvc <= 2 * c.G ? 2 : 4);
+  const int cols_per_block = 256 / c.G;
+  int nblocks = (int)((batch + (int64_t)cols_per_block * 16 - 1) / ((int64_t)cols_per_block * 16));
+  if (nblocks > 1024) nblocks = 1024;
+  if (nblocks < 1) nblocks = 1;
+  { int rc = bjx_ensure_partials(ctx, (size_t)nblocks * dim * 2); if (rc) return rc; }
+  const size_t smem = (size_t)cols_per_block * dim * 2 * sizeof(double);
+  BJX_REQUIRE(ctx, smem <= BJX_LDS_MAX, BJX_ERR_UNSUPPORTED, "bjx_row_moments: LDS");
+  constexpr int VW = Vec16<T>::N;
+  {
+    BjxProf prof_(ctx);
+#define RM(V_, R_) do { bjx_allow_big_lds(row_moments_kernel<T, V_, R_>, smem); hipLaunchKernelGGL((row_moments_kernel<T, V_, R_>), dim3(nblocks), dim3(256), smem, ctx->stream, a, b, dim, batch, c.G, ctx->partials); } while (0)
+#define RM_V(V_) do { if (R == 1) RM(V_, 1); else if (R == 2) RM(V_, 2); else RM(V_, 4); } while (0)
+    if (c.V == VW) RM_V(VW); else RM_V(1);
+#undef RM_V
+#undef RM
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)((dim + 255) / 256)), dim3(256), 0, ctx->stream, ctx->partials, nblocks, dim, batch, out);
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+
 // batch statistics, moving-statistics update (normalise.jl:56-60) and the per-sample log-det constant (:63)
 template <class T>
 __global__ __launch_bounds__(256) void bn_train_finalize_kernel(const double* __restrict__ stats, int64_t dim, const T* __restrict__ logs, T eps, T mtm,
@@ -944,6 +1037,14 @@ BJX_API int bjx_rqs(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* widths,
               rqs_impl<float>(ctx, inverse, (const float*)widths, (const float*)heights, (const float*)derivs, n_knots, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, batch, flags),
               rqs_impl<double>(ctx, inverse, (const double*)widths, (const double*)heights, (const double*)derivs, n_knots, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, batch, flags),
               "bjx_rqs");
+}
+
+BJX_API int bjx_row_moments(bjx_ctx* ctx, bjx_dtype dt, const void* a, const void* b, double* out, int64_t dim, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 0 && batch >= 0, BJX_ERR_SHAPE, "bjx_row_moments: negative size");
+  BJX_REQUIRE(ctx, out && (a || dim * batch == 0), BJX_ERR_ARG, "bjx_row_moments: null pointer");
+  DISPATCH_DT(ctx, dt, row_moments_impl<float>(ctx, (const float*)a, (const float*)b, out, dim, batch),
+              row_moments_impl<double>(ctx, (const double*)a, (const double*)b, out, dim, batch), "bjx_row_moments");
 }
 
 BJX_API int bjx_rqs_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* widths, const void* heights, const void* derivs, int n_knots,

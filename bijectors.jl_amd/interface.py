@@ -33,7 +33,7 @@ __all__ = [
     "VecCholeskyBijector", "Permute", "PlanarLayer", "RadialLayer", "InvertibleBatchNorm", "RationalQuadraticSpline",
     "PartitionMask", "Coupling", "Stacked", "Columnwise", "columnwise", "vjp", "istraining", "training", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
     "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
-    "PlanarResult", "vjp_params", "MvNormal", "TransformedDistribution", "transformed", "logpdf", "rand",
+    "PlanarResult", "vjp_params", "row_moments", "MvNormal", "TransformedDistribution", "transformed", "logpdf", "rand",
 ]
 
 PlanarResult = namedtuple("PlanarResult", ["result", "logabsdetjac"])  # planar_layer.jl:109
@@ -1389,12 +1389,64 @@ def vjp(b, x, out_bar, ladj_bar=None):
     return xb
 
 
+def row_moments(a, b=None):
+    """(Σ_n a[:, n], Σ_n a[:, n]·b[:, n]) over the batch as two float64 (dim,) tensors (bjx_row_moments; b=None: a²)."""
+    ac, dim, batch, _ = _prep(a)
+    bc = None
+    if b is not None:
+        bc, bdim, bbatch, _ = _prep(b)
+        if (bdim, bbatch) != (dim, batch) or bc.dtype != ac.dtype:
+            raise ValueError("DimensionMismatch: a and b must have the same shape and dtype")
+    ctx = context(ac.device)
+    out = torch.empty(2 * dim + 1, dtype=torch.float64, device=ac.device)
+    L.check(ctx.h, L.load().bjx_row_moments(ctx.h, _dt(ac), _ptr(ac), _ptr(bc), _ptr(out), dim, batch), "bjx_row_moments")
+    return out[:dim], out[dim:2 * dim]
+
+
+def _vjp_params_leading_affine(b, x, out_bar, ladj_bar):
+    """Parameter pullback of a chain `tail ∘ Shift(μ) ∘ Scale(σ)` (either stage optional) — the mean-field family
+    y = tail(μ + σ ⊙ z): with z̄ the input cotangent, v̄ = z̄/σ is the cotangent behind the affine stage, so
+        μ̄ = Σ_n z̄_n / σ,      σ̄ = (Σ_n z̄_n ⊙ z_n + Σ_n ℓ̄_n) / σ          (log|σ| enters every column's log-det)
+    — two row reductions over the batch (bjx_row_moments) after the input pullback.  Scalar parameters get the sum over
+    the rows.  Returns (z_bar, {"scale": σ̄ or None, "shift": μ̄ or None})."""
+    stages = b._stages() if isinstance(b, ComposedFunction) else [b]
+    scale = shift = None
+    k = 0
+    if k < len(stages) and isinstance(stages[k], Scale):
+        scale = stages[k]
+        k += 1
+    if k < len(stages) and isinstance(stages[k], Shift):
+        shift = stages[k]
+        k += 1
+    if scale is None and shift is None:
+        raise NotImplementedError(f"no device parameter pullback for {b!r}: expected a chain that starts with Scale and/or Shift (SURVEY.md §8f f-1)")
+    zb = vjp(b, x, out_bar, ladj_bar)
+    s1, s2 = row_moments(zb, x)
+    xc, dim, batch, _ = _prep(x)
+    sig = None
+    if scale is not None:
+        sig = _param(scale.a, xc).to(torch.float64).reshape(-1)
+    inv_sig = 1.0 if sig is None else 1.0 / sig
+    lsum = 0.0
+    if ladj_bar is not None:
+        lsum = float(ladj_bar) * batch if not isinstance(ladj_bar, torch.Tensor) else ladj_bar.to(torch.float64).sum()
+    out = {"scale": None, "shift": None}
+    if shift is not None:
+        mb = s1 * inv_sig
+        out["shift"] = (mb if _is_seq(shift.a) else mb.sum()).to(xc.dtype)
+    if scale is not None:
+        sb = (s2 + lsum) * inv_sig
+        out["scale"] = (sb if _is_seq(scale.a) else sb.sum()).to(xc.dtype)
+    return zb, out
+
+
 def vjp_params(b, x, out_bar, ladj_bar=None):
     """Pullback of `with_logabsdet_jacobian(b, x)` onto the input AND the parameters of a PlanarLayer (stack):
     returns (x_bar, {"w": w_bar, "u": u_bar, "b": b_bar}) with the parameter cotangents summed over the batch and the
-    shapes of b.w / b.u / b.b (bjx_planar_vjp_params; closed-form derivatives of planar_layer.jl:65-110)."""
+    shapes of b.w / b.u / b.b (bjx_planar_vjp_params; closed-form derivatives of planar_layer.jl:65-110).
+    For a chain that starts with Scale and/or Shift: (z_bar, {"scale": σ̄, "shift": μ̄}) — see _vjp_params_leading_affine."""
     if not isinstance(b, PlanarLayer):
-        raise NotImplementedError(f"no device parameter pullback for {b!r} (SURVEY.md §8f f-1)")
+        return _vjp_params_leading_affine(b, x, out_bar, ladj_bar)
     xc, dim, batch, vec = _prep(x)
     gc, gdim, gbatch, _ = _prep(out_bar)
     if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:

@@ -204,6 +204,13 @@ int bjx_batchnorm(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* b, const 
                   const void* m, const void* v, double eps, const void* in, void* out,
                   void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
 
+/* Row moments over the batch: out[i] = sum_n a[i,n], out[dim+i] = sum_n a[i,n]*b[i,n] (b NULL: a^2), out[2 dim] = batch;
+ * out: device double[2*dim+1], Float64 accumulation in a fixed order.  With a = the input cotangent of a chain
+ * `tail o Shift(mu) o Scale(sigma)` (bjx_stacked_vjp) and b = its input these are the parameter cotangents of the
+ * leading per-row affine stage (mean-field families): mu_bar = out[i]/sigma, sigma_bar = (out[dim+i] + sum ladj_bar)/sigma.
+ * A batch sharded over GPUs all-reduces `out` (bjx_allreduce_sum_f64). */
+int bjx_row_moments(bjx_ctx* ctx, bjx_dtype dt, const void* a, const void* b, double* out, int64_t dim, int64_t batch);
+
 /* InvertibleBatchNorm in TRAINING mode (istraining() == true), normalise.jl:51-60: the batch mean and the
  * biased batch variance of every channel replace m / v in the transform and the log-det, and the moving
  * statistics `m`, `v` (device T[dim], read AND written) are updated with momentum `mtm`

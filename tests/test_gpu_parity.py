@@ -1356,3 +1356,44 @@ def test_permute_and_columnwise_vjp(bj, orc):
     Xs = dev(np.asfortranarray(r.dirichlet(np.ones(6), size=N).T))
     Gs = dev(np.asfortranarray(r.normal(size=(5, N))))
     assert torch.equal(bj.vjp(b, Xs, Gs, 0.5), bj.vjp(bj.SimplexBijector(), Xs, Gs, 0.5))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,N", [(64, 3000), (5, 257), (130, 64), (300, 40)])
+def test_mean_field_parameter_pullback(bj, orc, dim, N, dt):
+    """y = exp(μ + σ ⊙ z): (μ̄, σ̄) from two row reductions of the input cotangent (bjx_row_moments); reference: the
+    closed form in Float64 and finite differences of the chain oracle with respect to μ and σ."""
+    r = rng(93)
+    mu = r.normal(size=dim).astype(dt)
+    sg = np.exp(0.3 * r.normal(size=dim)).astype(dt)
+    Z = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    gbar = np.asfortranarray((r.normal(size=(dim, N)) / np.sqrt(N)).astype(dt))
+    lbar = (r.normal(size=N) / np.sqrt(N)).astype(dt)
+    b = bj.elementwise(bj.exp) @ bj.Shift(torch.tensor(mu)) @ bj.Scale(torch.tensor(sg))
+    zb, pb = bj.vjp_params(b, dev(Z), dev(gbar), torch.from_numpy(lbar).cuda())
+    Z64, g64, l64, mu64, sg64 = (v.astype(np.float64) for v in (Z, gbar, lbar, mu, sg))
+    y = np.exp(mu64[:, None] + sg64[:, None] * Z64)
+    vbar = g64 * y + l64[None, :]                               # cotangent at v = μ + σ z (exp: dy = y, d ladj/dv = 1)
+    mu_ref = vbar.sum(axis=1)
+    sg_ref = (vbar * Z64).sum(axis=1) + l64.sum() / sg64
+    tol = dict(rtol=RTOL[dt] * 20, atol=ATOL[dt] * 50 * max(1.0, float(np.abs(sg_ref).max())))
+    np.testing.assert_allclose(host(zb), sg64[:, None] * vbar, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 20)
+    np.testing.assert_allclose(host(pb["shift"]), mu_ref, **tol)
+    np.testing.assert_allclose(host(pb["scale"]), sg_ref, **tol)
+    if dt == np.float64 and dim <= 5:                             # finite differences through the chain oracle
+        def F(m_, s_):
+            ops = [(orc.OP_SCALE, s_, None), (orc.OP_SHIFT, m_, None), (orc.OP_EXP, None, None)]
+            tot = 0.0
+            for n in range(N):
+                yv, l = orc.chain(ops, np.asfortranarray(Z64[:, n:n + 1]))
+                tot += float((yv[:, 0] * g64[:, n]).sum() + float(l) * l64[n])
+            return tot
+        h = 1e-6
+        for i in (0, dim - 1):
+            mp, mm = mu64.copy(), mu64.copy(); mp[i] += h; mm[i] -= h
+            assert abs((F(mp, sg64) - F(mm, sg64)) / (2 * h) - mu_ref[i]) < 1e-5
+            sp, sm = sg64.copy(), sg64.copy(); sp[i] += h; sm[i] -= h
+            assert abs((F(mu64, sp) - F(mu64, sm)) / (2 * h) - sg_ref[i]) < 1e-5
+    s1, s2 = bj.row_moments(dev(gbar))
+    np.testing.assert_allclose(host(s1), g64.sum(axis=1), rtol=1e-5 if dt == np.float32 else 1e-12, atol=1e-6)
+    np.testing.assert_allclose(host(s2), (g64 * g64).sum(axis=1), rtol=1e-5 if dt == np.float32 else 1e-12, atol=1e-7)
