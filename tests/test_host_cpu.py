@@ -187,3 +187,32 @@ def test_allreduce_logabsdetjac_gloo_world2():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == res[1][2]      # every rank holds the same global scalar
+
+
+def test_vector_links_and_density_op_lists(bj):
+    """Host logic of the §8(f) wrappers, no GPU: the VectorBijectors scalar links are op lists of the chain kernel
+    (src/vector/univariate/positive.jl:11-50, truncated.jl:17-103), heterogeneous products are Stacked ranges, and a
+    diagonal-normal base whitens with SHIFT(-μ), SCALE_INV(σ) in front of the density op."""
+    import torch
+
+    V, L = bj.vector, bj._lib
+    assert V.Log(0.0, 1)._ops() == [(L.OP_LOG, None, None)]
+    assert V.Log(-1.5, -1)._ops() == [(L.OP_SHIFT, 1.5, None), (L.OP_SIGNFLIP, None, None), (L.OP_LOG, None, None)]
+    assert V.Exp(2.0, -1)._ops() == [(L.OP_EXP, None, None), (L.OP_SIGNFLIP, None, None), (L.OP_SHIFT, 2.0, None)]
+    assert V.Exp(2.0, -1)._ops(True) == V.Log(2.0, -1)._ops()
+    assert V.Untruncate(0.0, 1.0)._ops() == [(L.OP_TRUNCATED, 0.0, 1.0)] and V.Truncate(0.0, 1.0)._ops() == [(L.OP_TRUNCATED_INV, 0.0, 1.0)]
+    assert isinstance(V.scalar_to_scalar_bijector(-math.inf, math.inf), V.TypedIdentity)
+    assert isinstance(V.scalar_to_scalar_bijector(0.0, math.inf, positive_family=True), V.Log)
+    assert isinstance(V.scalar_to_scalar_bijector(0.0, 1.0), V.Untruncate)
+    st = V.to_linked_vec_product([(V.TypedIdentity(), 1), (V.Log(0.0, 1), 3), (V.Untruncate(0.0, 1.0), 4)])
+    assert isinstance(st, bj.Stacked) and st.ranges_in == [(1, 1), (2, 4), (5, 8)]
+    inv = V.from_linked_vec_product([(V.Log(0.0, 1), 2)])
+    assert isinstance(inv.bs[0], V.Exp)
+    t = V.to_linked_vec(bj.SimplexBijector(), (7,), base_size=(5,))
+    assert t._n_components() == 7 and t.base_size == (5,)
+    d = bj.MvNormal(torch.tensor([1.0, 2.0]), torch.tensor([0.5, 2.0]))
+    w = d._whiten_ops()
+    assert [k for k, _, _ in w] == [L.OP_SHIFT, L.OP_SCALE_INV] and torch.equal(w[0][1], torch.tensor([-1.0, -2.0]))
+    assert [k for k, _, _ in d._color_ops()] == [L.OP_SCALE, L.OP_SHIFT]
+    assert bj.MvNormal(3)._whiten_ops() == [] and bj.MvNormal(3).dim == 3
+    assert L.OP_STDNORMAL_LOGPDF == 13 and L.BJX_BASE_STDNORMAL == 4 and L.BJX_INPUT_STDNORMAL == 8
