@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
 typedef float bjx_f4 __attribute__((ext_vector_type(4)));
 typedef float bjx_f2 __attribute__((ext_vector_type(2)));
 template <int G, int NL, int NS>
-__device__ __forceinline__ void reg_dots(const float* __restrict__ tab, int l0, int dim, const bjx_f4 (&z)[NS], float* st, int lane, int gl, int cg, bool row_ok) {
+__device__ __forceinline__ void reg_dots(const float* __restrict__ tab, int l0, int dim, const bjx_f4 (&z)[NS], float* st, int lane, int gl, int cg, bool row_ok, int row0 = 0) {
   constexpr int CPS = 64 / G;
   constexpr bool SWAP = (G == 32) && (NL >= 2);
   constexpr int NV = SWAP ? NL / 2 : NL;
@@ -770,8 +770,8 @@ __device__ __forceinline__ void reg_dots(const float* __restrict__ tab, int l0, 
   for (int kp = 0; kp < NP; ++kp) {
     bjx_f4 a = bjx_f4{0.f, 0.f, 0.f, 0.f}, b = a;
     if (row_ok) {
-      a = *reinterpret_cast<const bjx_f4*>(tab + (int64_t)(l0 + 2 * kp) * dim + 4 * gl);
-      if (NL >= 2) b = *reinterpret_cast<const bjx_f4*>(tab + (int64_t)(l0 + 2 * kp + 1) * dim + 4 * gl);
+      a = *reinterpret_cast<const bjx_f4*>(tab + (int64_t)(l0 + 2 * kp) * dim + row0 + 4 * gl);
+      if (NL >= 2) b = *reinterpret_cast<const bjx_f4*>(tab + (int64_t)(l0 + 2 * kp + 1) * dim + row0 + 4 * gl);
     }
     wq[kp][0] = bjx_f2{a.x, b.x}; wq[kp][1] = bjx_f2{a.y, b.y}; wq[kp][2] = bjx_f2{a.z, b.z}; wq[kp][3] = bjx_f2{a.w, b.w};
   }
@@ -809,18 +809,117 @@ __device__ __forceinline__ void reg_dots(const float* __restrict__ tab, int l0, 
   }
 }
 template <int G, int NL, int NS>
-__device__ __forceinline__ void reg_update(const float* __restrict__ tab, int l0, int dim, bjx_f4 (&z)[NS], const float* st, int gl, int cg, bool row_ok) {
+__device__ __forceinline__ void reg_update(const float* __restrict__ tab, int l0, int dim, bjx_f4 (&z)[NS], const float* st, int gl, int cg, bool row_ok, int row0 = 0) {
   constexpr int CPS = 64 / G;
   bjx_f4 uv[NL];
 #pragma unroll
   for (int k = 0; k < NL; ++k)
-    uv[k] = row_ok ? *reinterpret_cast<const bjx_f4*>(tab + (int64_t)(l0 + k) * dim + 4 * gl) : bjx_f4{0.f, 0.f, 0.f, 0.f};
+    uv[k] = row_ok ? *reinterpret_cast<const bjx_f4*>(tab + (int64_t)(l0 + k) * dim + row0 + 4 * gl) : bjx_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int r = 0; r < NS; ++r) {
     const float* tc = st + (r * CPS + cg) * NL;
 #pragma unroll
     for (int k = 0; k < NL; ++k) { const float tk = tc[k]; z[r] += uv[k] * tk; }
   }
+}
+
+// ------------------------------------------------------------------ Planar, register kernel with TWO waves per tile (64 < dim <= 128)
+// planar_reg_kernel keeps a 64-column tile of a 128-row problem in 128 VGPRs of ONE wave: 2 waves per SIMD, 44 % VALU
+// busy and 38 % of the wave time waiting (PMC) — latency-bound.  Here the rows of a tile are split over two waves
+// (64 rows each: 16 lanes per column, 64 VGPRs of tile): the dot products are partial sums exchanged through LDS with
+// ONE block barrier per layer group, both waves then run the (cheap) lane = column recurrence redundantly on the
+// summed values and update their own rows.  Same bytes, half the registers per wave, twice the waves in flight.
+// The partial-sum buffers are double-buffered by group parity, so a wave that runs ahead cannot overwrite what its
+// partner is still reading.
+template <int NL, bool INV>
+__global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A, const float* __restrict__ x, float* __restrict__ y,
+                                                          float* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate, const BjxFin fin) {
+  constexpr int G = 16, COLS = 64, CPS = 4, NS = 16;
+  __shared__ __attribute__((aligned(16))) float sS[2][4][COLS * NL];     // partial dot products [parity][wave]
+  __shared__ __attribute__((aligned(16))) float sT[4][COLS * NL];        // tanh values of my tile (each wave its own copy)
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = wave >> 1, half = wave & 1, partner = wave ^ 1;
+  const int gl = lane & (G - 1), cg = lane / G;
+  const int row0 = half * 64;
+  const bool row_ok = row0 + 4 * gl < dim;
+  const int64_t col0 = ((int64_t)blockIdx.x * 2 + tile) * COLS;
+  const int64_t left = batch - col0;
+  const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
+  const int64_t step_elems = (int64_t)CPS * dim;
+  bjx_f4 z[NS];
+  {
+    const float* px = x + (col0 + cg) * dim + row0 + 4 * gl;
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+      if (row_ok && r * CPS + cg < nvalid) z[r] = __builtin_nontemporal_load(reinterpret_cast<const bjx_f4*>(px));
+      else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
+      px += step_elems;
+    }
+  }
+  float ladj = 0.f;
+  const int ngroups = A.nl_pad / NL;
+  float* stT = sT[wave];
+  for (int gi = 0; gi < ngroups; ++gi) {
+    const int l0 = (INV ? ngroups - 1 - gi : gi) * NL;
+    float* mineS = sS[gi & 1][wave];
+    const float* otherS = sS[gi & 1][partner];
+    reg_dots<G, NL, NS>(A.w, l0, dim, z, mineS, lane, gl, cg, row_ok, row0);
+    __syncthreads();                                         // both halves of every tile have published their partial sums
+    {
+      float s[NL], t[NL];
+#pragma unroll
+      for (int k = 0; k < NL; ++k) { s[k] = mineS[lane * NL + k] + otherS[lane * NL + k]; t[k] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < NL; ++kk) {
+        const int k = INV ? NL - 1 - kk : kk;
+        const float* Gk = A.G + (int64_t)(l0 + k) * A.nl_pad + l0;
+        float a = s[k];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+          if (!INV) { if (j < k) a += Gk[j] * t[j]; }
+          else { if (j > k) a += Gk[j] * t[j]; }
+        }
+        const float bl = A.b[l0 + k], c = A.wtu_hat[l0 + k];
+        float th, ld;
+        if (INV) find_alpha_act(a, c, bl, th, ld);
+        else planar_act(a + bl, c, th, ld);
+        ladj += INV ? -ld : ld;
+        t[k] = INV ? -th : th;
+      }
+      __builtin_amdgcn_wave_barrier();                       // my previous group's reads of stT are done (same wave)
+#pragma unroll
+      for (int k = 0; k < NL; ++k) stT[lane * NL + k] = t[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    reg_update<G, NL, NS>(A.u_hat, l0, dim, z, stT, gl, cg, row_ok, row0);
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (accumulate & 2) {
+    // BJX_BASE_STDNORMAL: |out|² of a column = my 64 rows + my partner's 64 rows
+    float* mineS = sS[ngroups & 1][wave];
+    const float* otherS = sS[ngroups & 1][partner];
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+      float q[1];
+      q[0] = z[r].x * z[r].x + z[r].y * z[r].y + z[r].z * z[r].z + z[r].w * z[r].w;
+      row_allsum<16, 1>(q);
+      if ((lane & 15) == 0) mineS[r * CPS + cg] = q[0];
+    }
+    __syncthreads();
+    ladj += -0.5f * (mineS[lane] + otherS[lane]) - (float)dim * 0.91893853320467274178f;
+  }
+  if (y) {
+    float* py = y + (col0 + cg) * dim + row0 + 4 * gl;
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+      if (row_ok && r * CPS + cg < nvalid) __builtin_nontemporal_store(z[r], reinterpret_cast<bjx_f4*>(py));
+      py += step_elems;
+    }
+  }
+  const bool ok = lane < nvalid && half == 0;                // the two halves hold the same log-det: one of them reports it
+  if (ok && ladj_ps) ladj_ps[col0 + lane] = (accumulate & 1) ? ladj_ps[col0 + lane] + ladj : ladj;
+  block_publish_partial(ok ? (double)ladj : 0.0, red, fin);
 }
 
 template <int G, int NL, bool INV>
@@ -1217,7 +1316,13 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         static const int cols_env = getenv("BJX_PLANAR_COLS") ? atoi(getenv("BJX_PLANAR_COLS")) : 0;
         const int G = dim > 64 ? 32 : (dim > 32 ? 16 : 8);
         const int cols = (G == 32 && (cols_env ? cols_env == 32 : PLANAR_REG_DEFAULT_COLS == 32)) ? 32 : 64;
-        const int64_t grid = (batch + 4 * cols - 1) / (4 * cols);
+        // two waves per tile for 64 < dim <= 128.  Measured (A/B in one run, 2^22 columns, d = 128): 8 layers forward
+        // 0.759 vs 0.783 ms; 1 layer 0.74 vs 0.71 ms and the inverse 0.66 vs 0.62 ms are SLOWER (the barrier and the
+        // redundant recurrence cost more than the third wave per SIMD buys: 147 VGPRs, and forcing 128 spills) —
+        // so only deep forward stacks take it.  BJX_PLANAR_SPLIT = 0 / 1 forces it off / on.
+        static const int split_env = getenv("BJX_PLANAR_SPLIT") ? atoi(getenv("BJX_PLANAR_SPLIT")) : -1;
+        const bool split = G == 32 && (split_env >= 0 ? split_env != 0 : (!inverse && nl >= 8));
+        const int64_t grid = split ? (batch + 2 * 64 - 1) / (2 * 64) : (batch + 4 * cols - 1) / (4 * cols);
         BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar: batch too large for one launch");
         BjxFin fin;
         bool second = false;
@@ -1227,7 +1332,13 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
 #define LAUNCH_REG(G_, NL_, INV_) if (G_ == 32 && cols == 32) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, (G_ == 32 ? 32 : 64)>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); else hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, 64>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
 #define LAUNCH_REG_NL(G_, INV_) switch (NL) { case 1: LAUNCH_REG(G_, 1, INV_); break; case 2: LAUNCH_REG(G_, 2, INV_); break; case 4: LAUNCH_REG(G_, 4, INV_); break; default: LAUNCH_REG(G_, 8, INV_); break; }
 #define LAUNCH_REG_G(INV_) switch (G) { case 8: LAUNCH_REG_NL(8, INV_) break; case 16: LAUNCH_REG_NL(16, INV_) break; default: LAUNCH_REG_NL(32, INV_) break; }
-        { BjxProf prof_(ctx); if (inverse) { LAUNCH_REG_G(true) } else { LAUNCH_REG_G(false) } }
+#define LAUNCH_REG2(NL_, INV_) hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
+#define LAUNCH_REG2_NL(INV_) switch (NL) { case 1: LAUNCH_REG2(1, INV_); break; case 2: LAUNCH_REG2(2, INV_); break; case 4: LAUNCH_REG2(4, INV_); break; default: LAUNCH_REG2(8, INV_); break; }
+        { BjxProf prof_(ctx);
+          if (split) { if (inverse) { LAUNCH_REG2_NL(true) } else { LAUNCH_REG2_NL(false) } }
+          else if (inverse) { LAUNCH_REG_G(true) } else { LAUNCH_REG_G(false) } }
+#undef LAUNCH_REG2_NL
+#undef LAUNCH_REG2
 #undef LAUNCH_REG_G
 #undef LAUNCH_REG_NL
 #undef LAUNCH_REG

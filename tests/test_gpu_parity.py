@@ -1397,3 +1397,40 @@ def test_mean_field_parameter_pullback(bj, orc, dim, N, dt):
     s1, s2 = bj.row_moments(dev(gbar))
     np.testing.assert_allclose(host(s1), g64.sum(axis=1), rtol=1e-5 if dt == np.float32 else 1e-12, atol=1e-6)
     np.testing.assert_allclose(host(s2), (g64 * g64).sum(axis=1), rtol=1e-5 if dt == np.float32 else 1e-12, atol=1e-7)
+
+
+def test_planar_split_tile_kernel_matches_the_single_wave_tile(bj, orc, monkeypatch):
+    """planar_reg2_kernel (two waves per 64-column tile) is taken by deep forward stacks by default; every other shape it
+    supports (1-4 layers, the inverse, the fused density, a ragged batch) is exercised here through BJX_PLANAR_SPLIT=1 in
+    a subprocess (the switch is read once per process) and compared with the default path in this process."""
+    import subprocess, sys, os, json
+    code = r"""
+import json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+import bijectors_amd as bj
+r = np.random.default_rng(5)
+out = {}
+for nl in (1, 3, 8, 12):
+    dim, N = 128, 333
+    w = torch.tensor((r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(np.float32))
+    u = torch.tensor((r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(np.float32))
+    b = torch.tensor(r.normal(size=nl).astype(np.float32))
+    z = torch.tensor(np.asfortranarray(r.normal(size=(dim, N)).astype(np.float32)).T.copy()).T.cuda()
+    fl = bj.PlanarLayer(w, u, b)
+    y, l = bj.with_logabsdet_jacobian(fl, z)
+    xi, li = bj.with_logabsdet_jacobian(bj.inverse(fl), y)
+    lp = bj.logpdf(bj.transformed(bj.MvNormal(dim), fl), y)
+    out[str(nl)] = [float(y.double().sum()), float(l.double().sum()), float((xi - z).abs().max()), float(li.double().sum()), float(lp.double().sum())]
+print(json.dumps(out))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, BJX_PLANAR_SPLIT=flag)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[flag] = json.loads(p.stdout.strip().splitlines()[-1])
+    for nl, a in res["0"].items():
+        b_ = res["1"][nl]
+        np.testing.assert_allclose(b_[0:2], a[0:2], rtol=2e-5)
+        assert b_[2] < 5e-4 and a[2] < 5e-4                      # inverse(flow(z)) == z on both paths
+        np.testing.assert_allclose(b_[3:5], a[3:5], rtol=2e-5)
