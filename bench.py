@@ -116,7 +116,7 @@ def make_workload(name, bj, torch, device, rank, world, log2_batch):
         def step():
             return bj.shard.with_logabsdet_jacobian_sharded(flow, x, out=y)[2]
 
-        return dict(step=step, samples=N, bytes_per_sample=2 * dim * 4 + 4, kernel="planar_reg_kernel", dtype="f32",
+        return dict(step=step, samples=N, bytes_per_sample=2 * dim * 4 + 4, kernel="planar_reg2_kernel", dtype="f32",
                     label=f"8-layer PlanarLayer flow fused fwd+logabsdetjac Float32 dim={dim} batch=2^{lb}/GPU",
                     cfg={"workload": "8x PlanarLayer fused (BASELINE configs[3])", "dim": dim, "layers": nl, "batch_per_gpu": N})
     if name == "c5a":

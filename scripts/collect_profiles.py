@@ -13,7 +13,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = {"c2": ["chain_flat_kernel"], "c2v": ["chain_flat_kernel"], "c3": ["rqs_lds_kernel"], "c4": ["planar_reg_kernel"],
+DOMINANT = {"c2": ["chain_flat_kernel"], "c2v": ["chain_flat_kernel"], "c3": ["rqs_lds_kernel"], "c4": ["planar_reg"],
             "c5a": ["quad_stream_kernel"], "c5b": ["chol_inv_chunk_kernel"]}
 
 
