@@ -1434,3 +1434,72 @@ print(json.dumps(out))
         np.testing.assert_allclose(b_[0:2], a[0:2], rtol=2e-5)
         assert b_[2] < 5e-4 and a[2] < 5e-4                      # inverse(flow(z)) == z on both paths
         np.testing.assert_allclose(b_[3:5], a[3:5], rtol=2e-5)
+
+
+# ------------------------------------------------------------------ randomized shape sweep (geometry selection)
+_SWEEP_DIMS = [1, 2, 3, 4, 5, 7, 8, 12, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 96, 100, 127, 128, 129, 200, 256, 257, 500]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shape_sweep(bj, orc, seed):
+    """Every launcher picks a pack width, lanes per column, columns in flight and a kernel family from (dim, batch,
+    alignment): sweep shapes around the switch points (powers of two ± 1, multiples of 4 / 16 or not, batch 1 … a few
+    blocks) for the structured and elementwise bijectors in both dtypes and compare with the oracle."""
+    r = rng(1000 + seed)
+    for trial in range(10):
+        dt = [np.float32, np.float64][int(r.integers(2))]
+        dim = int(r.choice(_SWEEP_DIMS))
+        N = int(r.choice([1, 2, 3, 5, 16, 17, 63, 64, 65, 130, 257, 1000]))
+        X = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+        tag = f"dt={dt.__name__} dim={dim} N={N}"
+        # elementwise chain, per-sample and summed log-det
+        ops = [(orc.OP_SCALE, 0.7, None), (orc.OP_SHIFT, -0.2, None), (orc.OP_EXP, None, None)]
+        b = bj.elementwise(bj.exp) @ bj.Shift(-0.2) @ bj.Scale(0.7)
+        y_ref, l_ref = orc.chain(ops, X)
+        y, lps = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+        close(host(y), y_ref, dt, what="chain " + tag)
+        sum_close(host(lps).astype(np.float64).sum(), float(l_ref), dt, dim * N, what="chain ladj " + tag)
+        sum_close(host(bj.logabsdetjac(b, dev(X))), float(l_ref), dt, dim * N, what="chain logabsdetjac " + tag)
+        # ordered both ways
+        yo_ref, lo_ref = orc.ordered(X)
+        yo, lo = bj.with_logabsdet_jacobian(bj.OrderedBijector(), dev(X))
+        close(host(yo), yo_ref, dt, scale=dim, what="ordered " + tag)
+        close(host(lo), lo_ref, dt, scale=dim, what="ordered ladj " + tag)
+        xo, _ = bj.with_logabsdet_jacobian(bj.inverse(bj.OrderedBijector()), dev(yo_ref))
+        close(host(xo), X, dt, scale=dim * 10, what="ordered inv " + tag)
+        if dim >= 2:
+            # simplex both ways
+            P = np.asfortranarray(r.dirichlet(np.ones(dim), size=N).T.astype(dt))
+            ys_ref, ls_ref = orc.simplex(P)
+            ys, ls = bj.with_logabsdet_jacobian(bj.SimplexBijector(), dev(P), per_sample=True)
+            close(host(ys), ys_ref, dt, scale=10, what="simplex " + tag)
+            close(host(ls), ls_ref, dt, scale=dim * 10, what="simplex ladj " + tag)
+            Yin = np.asfortranarray((1.5 * r.normal(size=(dim - 1, N))).astype(dt))
+            xs_ref, lsi_ref = orc.simplex(Yin, inverse=True)
+            xs, lsi = bj.with_logabsdet_jacobian(bj.inverse(bj.SimplexBijector()), dev(Yin), per_sample=True)
+            close(host(xs), xs_ref, dt, what="simplex inv " + tag)
+            close(host(lsi), lsi_ref, dt, scale=dim * 10, what="simplex inv ladj " + tag)
+        if dim <= 256:
+            nl = int(r.choice([1, 2, 5, 8]))
+            w = (r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(dt)
+            u = (r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(dt)
+            bb = r.normal(size=nl).astype(dt)
+            fl = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(bb))
+            yp_ref, lp_ref = orc.planar(w, u, bb, X)
+            yp, lp = bj.with_logabsdet_jacobian(fl, dev(X))
+            close(host(yp), yp_ref, dt, scale=10, what="planar " + tag)
+            close(host(lp), lp_ref, dt, scale=10 * nl, what="planar ladj " + tag)
+            g = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+            ref_v = orc.planar_vjp(w, u, bb, X, g)
+            np.testing.assert_allclose(host(bj.vjp(fl, dev(X), dev(g))), ref_v, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref_v).max())), err_msg="planar vjp " + tag)
+            z0 = r.normal(size=dim).astype(dt)
+            rad = bj.RadialLayer(torch.tensor(np.array([0.2], dtype=dt)), torch.tensor(np.array([0.4], dtype=dt)), torch.tensor(z0))
+            yr_ref, lr_ref = orc.radial(np.array([0.2]), np.array([0.4]), z0, X)
+            yr, lr = bj.with_logabsdet_jacobian(rad, dev(X))
+            close(host(yr), yr_ref, dt, scale=10, what="radial " + tag)
+            close(host(lr), lr_ref, dt, scale=dim, what="radial ladj " + tag)
+        # permutation: bit-exact
+        perm = r.permutation(dim)
+        pb = bj.Permute(list(perm + 1))
+        yperm = host(bj.transform(pb, dev(X)))
+        assert np.array_equal(yperm[perm], X), "permute " + tag
