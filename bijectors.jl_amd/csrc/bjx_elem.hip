@@ -745,6 +745,50 @@ int rqs_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int 
   return BJX_OK;
 }
 
+// Fallback of the spline pullback for tables the LDS kernel does not take (very wide columns, > 64 knots): one
+// element per thread, knots read from global memory with the reference's search (searchsortedfirst, rqs.jl:137) and
+// the same closed-form derivatives as rqs_eval_vjp, in plain divisions.
+template <class T, bool INV>
+__global__ __launch_bounds__(256) void rqs_vjp_generic_kernel(const T* __restrict__ w, const T* __restrict__ h, const T* __restrict__ d, int K,
+                                                              const T* __restrict__ x, const T* __restrict__ gbar, const T* __restrict__ lbar,
+                                                              T* __restrict__ xbar, int64_t dim, int64_t batch) {
+  const int64_t total = dim * batch;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx % dim, col = idx / dim, st = dim;
+    const T *w_ = w + row, *h_ = h + row, *d_ = d + row;
+    const T xin = x[idx], g = gbar[idx], lb = lbar ? lbar[col] : T(0);
+    const T wK = w_[(int64_t)(K - 1) * st], hK = h_[(int64_t)(K - 1) * st];
+    const T lim = INV ? hK : wK;
+    if (!(d_abs(xin) < lim)) { xbar[idx] = g; continue; }
+    const int k = ssf<T>(INV ? h_ : w_, st, K, xin) - 1;
+    const T w_k = (k == 0) ? -wK : w_[(int64_t)(k - 1) * st];
+    const T wd = w_[(int64_t)k * st] - w_k;
+    const T h_k = (k == 0) ? -hK : h_[(int64_t)(k - 1) * st];
+    const T dy = h_[(int64_t)k * st] - h_k;
+    const T s = dy / wd;
+    const T d_k = (k == 0) ? T(1) : d_[(int64_t)(k - 1) * st];
+    const T d_k1 = (k == K - 1) ? T(1) : d_[(int64_t)k * st];
+    const T ds = d_k1 + d_k - 2 * s, dd = d_k1 - d_k;
+    T xi;
+    if (!INV) xi = (xin - w_k) / wd;
+    else {
+      const T yh = xin - h_k;
+      const T a1 = dy * (s - d_k) + yh * ds;
+      const T a2 = dy * d_k - yh * ds;
+      const T q = s * yh;
+      xi = (q + q) / (a2 + d_sqrt(a2 * a2 + 4 * (a1 * q)));
+    }
+    const T p = xi - xi * xi;
+    const T den = s + ds * p;
+    const T nj = (d_k + dd * xi) - ds * p;
+    const T sr = s / den;
+    const T J = nj * (sr * sr);
+    const T om = T(1) - (xi + xi);
+    const T dl = ((dd - ds * om) / nj - T(2) * ds * om / den) / wd;
+    xbar[idx] = !INV ? g * J + lb * dl : (g - lb * dl) / J;
+  }
+}
+
 template <class T>
 int rqs_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int K1, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar,
                  int64_t dim, int64_t batch) {
@@ -755,8 +799,15 @@ int rqs_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, 
   const int dual = (K1 >= 3 && ceil_log2(K1 - 1) < nstep_hi) ? 1 : 0;
   const RqsGeom g_hi = rqs_geom(K1, dim, c.V, 0, nstep_hi);
   const size_t blob_bytes = rqs_blob_words(g_hi) * sizeof(T);
-  BJX_REQUIRE(ctx, nstep_hi <= 6 && dim / c.V <= 64 && dim < (1 << 20) && blob_bytes <= 64 * 1024 && blob_bytes + 64 <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED,
-              "bjx_rqs_vjp: knot tables of %lld rows x %d knots do not fit the LDS path", (long long)dim, K1);
+  if (!(nstep_hi <= 6 && dim / c.V <= 64 && dim < (1 << 20) && blob_bytes <= 64 * 1024 && blob_bytes + 64 <= BJX_SCRATCH_BYTES)) {
+    int64_t nb = (dim * batch + 255) / 256;
+    if (nb > 256 * 64) nb = 256 * 64;
+    BjxProf prof_(ctx);
+    if (inverse) hipLaunchKernelGGL((rqs_vjp_generic_kernel<T, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, w, h, d, K1, in, out_bar, ladj_bar, in_bar, dim, batch);
+    else hipLaunchKernelGGL((rqs_vjp_generic_kernel<T, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, w, h, d, K1, in, out_bar, ladj_bar, in_bar, dim, batch);
+    BJX_CHECK_LAUNCH(ctx);
+    return BJX_OK;
+  }
   int* flag = reinterpret_cast<int*>(ctx->scratch);
   T* blob = reinterpret_cast<T*>(static_cast<char*>(ctx->scratch) + 64);
   if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, flag, blob);

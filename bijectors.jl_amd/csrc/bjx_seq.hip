@@ -1410,17 +1410,18 @@ template <class T> __device__ __forceinline__ void simplex_t_partials(T xk, T sk
 
 template <class T, int V, bool INV>
 __global__ __launch_bounds__(64) void simplex_vjp_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
-                                                        T* __restrict__ in_bar, int K, int P, int64_t batch) {
+                                                        T* __restrict__ in_bar, int K, int P, int64_t batch, int C) {
+  // C = columns per block (64 when two 64-column tiles fit the LDS; fewer lanes work on longer columns otherwise)
   using F = Fast<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* ta = reinterpret_cast<T*>(smem);
-  T* tb = ta + (size_t)64 * P;
-  T* logk = tb + (size_t)64 * P;
+  T* tb = ta + (size_t)C * P;
+  T* logk = tb + (size_t)C * P;
   const int lane = threadIdx.x;
   for (int i = lane; i < K - 1; i += 64) logk[i] = d_log(T(K - 1 - i));
   const int rows_in = INV ? K - 1 : K, rows_g = INV ? K : K - 1;
-  const int64_t col0 = (int64_t)blockIdx.x * 64;
-  const int ncols = (int)((batch - col0) < 64 ? (batch - col0) : 64);
+  const int64_t col0 = (int64_t)blockIdx.x * C;
+  const int ncols = (int)((batch - col0) < C ? (batch - col0) : C);
   tile_stage_in<T, V>(ta, in + col0 * rows_in, rows_in, P, ncols, lane);
   tile_stage_in<T, V>(tb, out_bar + col0 * rows_g, rows_g, P, ncols, lane);
   tile_sync();
@@ -1570,15 +1571,17 @@ int simplex_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, c
     }
   }
   const int64_t P = K | 1;
-  const size_t smem = ((size_t)2 * 64 * P + (size_t)K) * sizeof(T);
+  int C = 64;
+  while (C > 1 && ((size_t)2 * C * P + (size_t)K) * sizeof(T) > BJX_LDS_MAX) C >>= 1;
+  const size_t smem = ((size_t)2 * C * P + (size_t)K) * sizeof(T);
   BJX_REQUIRE(ctx, smem <= BJX_LDS_MAX, BJX_ERR_UNSUPPORTED, "bjx_simplex_vjp: K = %lld too large for the LDS tiles", (long long)K);
-  const int64_t grid = (batch + 63) / 64;
+  const int64_t grid = (batch + C - 1) / C;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
   constexpr int VW = Vec16<T>::N;
   const bool v_ok = bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
   {
     BjxProf prof_(ctx);
-#define SVJPK(V_, I_) bjx_allow_big_lds(simplex_vjp_kernel<T, V_, I_>, smem); hipLaunchKernelGGL((simplex_vjp_kernel<T, V_, I_>), dim3((unsigned)grid), dim3(64), smem, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)K, (int)P, batch)
+#define SVJPK(V_, I_) bjx_allow_big_lds(simplex_vjp_kernel<T, V_, I_>, smem); hipLaunchKernelGGL((simplex_vjp_kernel<T, V_, I_>), dim3((unsigned)grid), dim3(64), smem, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)K, (int)P, batch, C)
     if (v_ok) { if (inverse) { SVJPK(VW, true); } else { SVJPK(VW, false); } }
     else { if (inverse) { SVJPK(1, true); } else { SVJPK(1, false); } }
 #undef SVJPK
@@ -2259,12 +2262,12 @@ int chol_inv_vjp_impl(bjx_ctx* ctx, int uplo, const T* y, const T* Wbar, const T
   int64_t tile_words = (K * K + 3) / 4 * 4;
   if (tile_words < (int64_t)64 * (CHn + vv)) tile_words = (int64_t)64 * (CHn + vv);
   const size_t tile_bytes = (size_t)CHOL_WPB * tile_words * sizeof(T);
-  BJX_REQUIRE(ctx, CHn <= 32 && nv <= 64 * 32 && tile_bytes <= 60 * 1024, BJX_ERR_UNSUPPORTED,
+  BJX_REQUIRE(ctx, CHn <= 32 && nv <= 64 * 32 && tile_bytes <= BJX_LDS_MAX, BJX_ERR_UNSUPPORTED,
               "bjx_vec_cholesky_inv_vjp: K = %lld is too large for the LDS tile kernel", (long long)K);
   const int64_t grid = (batch + CHOL_WPB - 1) / CHOL_WPB;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
-#define CVJP_K(V_, CHV_, L_) hipLaunchKernelGGL((chol_inv_vjp_kernel<T, V_, CHV_, L_>), dim3((unsigned)grid), dim3(64 * CHOL_WPB), tile_bytes, ctx->stream, y, Wbar, lbar, ybar, (int)K, (int)tile_words, batch)
-#define CVJP_L(V_, CHV_) do { if (lower) CVJP_K(V_, CHV_, true); else CVJP_K(V_, CHV_, false); } while (0)
+#define CVJP_K(V_, CHV_, L_) bjx_allow_big_lds(chol_inv_vjp_kernel<T, V_, CHV_, L_>, tile_bytes); hipLaunchKernelGGL((chol_inv_vjp_kernel<T, V_, CHV_, L_>), dim3((unsigned)grid), dim3(64 * CHOL_WPB), tile_bytes, ctx->stream, y, Wbar, lbar, ybar, (int)K, (int)tile_words, batch)
+#define CVJP_L(V_, CHV_) do { if (lower) { CVJP_K(V_, CHV_, true); } else { CVJP_K(V_, CHV_, false); } } while (0)
   {
     BjxProf prof_(ctx);
     if (vv == VW) {

@@ -729,8 +729,6 @@ def test_ordered_vjp(bj, orc, shape, dt):
 @pytest.mark.parametrize("K,N", [(2, 5), (3, 33), (5, 100), (12, 64), (33, 21), (64, 40)])
 @pytest.mark.parametrize("uplo", ["U", "L"])
 def test_vec_cholesky_inverse_vjp(bj, orc, K, N, uplo, dt):
-    if dt == np.float64 and K == 64:
-        pytest.skip("Float64 K = 64 needs a 64 KiB tile per wave: not covered by the LDS tile kernel")
     r = rng(52)
     n = K * (K - 1) // 2
     y = np.asfortranarray((0.5 * r.normal(size=(n, N))).astype(dt))
@@ -1503,3 +1501,120 @@ def test_random_shape_sweep(bj, orc, seed):
         pb = bj.Permute(list(perm + 1))
         yperm = host(bj.transform(pb, dev(X)))
         assert np.array_equal(yperm[perm], X), "permute " + tag
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shape_sweep_structured(bj, orc, seed):
+    """Second sweep: the LKJ-Cholesky kernels (chunked, LDS tile, lane = column), the spline (LDS table vs register
+    paths), batch norm, and the pullbacks of Ordered / Simplex / Cholesky / RQS, at random (size, batch, dtype, uplo)."""
+    r = rng(2000 + seed)
+    for trial in range(8):
+        dt = [np.float32, np.float64][int(r.integers(2))]
+        N = int(r.choice([1, 2, 5, 17, 63, 64, 65, 130, 300]))
+        # Cholesky
+        K = int(r.choice([2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 24, 31, 32, 33, 47, 50]))
+        uplo = "UL"[int(r.integers(2))]
+        n = K * (K - 1) // 2
+        tag = f"dt={dt.__name__} K={K} N={N} uplo={uplo}"
+        y = np.asfortranarray((0.5 * r.normal(size=(n, N))).astype(dt))
+        b = bj.VecCholeskyBijector(uplo)
+        W_ref, lj_ref = orc.vec_cholesky(y, inverse=True, uplo=uplo)
+        W, lj = bj.with_logabsdet_jacobian(bj.inverse(b), dev(y), per_sample=True)
+        close(host(W), W_ref, dt, what="chol inv " + tag)
+        close(host(lj), lj_ref, dt, scale=n, what="chol inv logJ " + tag)
+        y_ref, lf_ref = orc.vec_cholesky(W_ref, inverse=False, uplo=uplo)
+        yf, lf = bj.with_logabsdet_jacobian(b, dev(W_ref), per_sample=True)
+        close(host(yf), y_ref, dt, what="chol fwd " + tag)
+        close(host(lf), lf_ref, dt, scale=n, what="chol fwd ladj " + tag)
+        Wbar = r.normal(size=(K, K, N)).astype(dt)
+        lbar = r.normal(size=N).astype(dt)
+        ref = orc.vec_cholesky_inv_vjp(y.astype(np.float64), Wbar.astype(np.float64), lbar.astype(np.float64), uplo=uplo)
+        got = bj.vjp(bj.inverse(b), dev(y), dev(Wbar), torch.from_numpy(lbar).cuda())
+        np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())), err_msg="chol inv vjp " + tag)
+        gbar = np.asfortranarray(r.normal(size=(n, N)).astype(dt))
+        Wd = np.asfortranarray(W_ref.astype(dt))
+        ref = orc.vec_cholesky_fwd_vjp(Wd, gbar, uplo=uplo)
+        got = bj.vjp(b, torch.from_numpy(Wd).cuda(), dev(gbar))
+        np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref).max())), err_msg="chol fwd vjp " + tag)
+        # spline
+        dim = int(r.choice([1, 2, 3, 7, 8, 16, 31, 32, 33, 64, 100, 129, 256, 300]))
+        Kb = int(r.choice([1, 2, 3, 5, 8, 10, 16, 17, 32]))
+        tag = f"dt={dt.__name__} dim={dim} K={Kb} N={N}"
+        w_ref, h_ref, d_ref = orc.rqs_params(r.normal(size=(dim, Kb)).astype(dt), r.normal(size=(dim, Kb)).astype(dt), r.normal(size=(dim, Kb - 1)).astype(dt), 3.0)
+        sp = bj.RationalQuadraticSpline(dev(w_ref), dev(h_ref), dev(d_ref))
+        X = np.asfortranarray((r.normal(size=(dim, N)) * 1.6).astype(dt))
+        Y_ref, l_ref = orc.rqs(w_ref, h_ref, d_ref, X)
+        Y, l = bj.with_logabsdet_jacobian(sp, dev(X), per_sample=True)
+        close(host(Y), Y_ref, dt, what="rqs fwd " + tag)
+        close(host(l), l_ref, dt, scale=dim, what="rqs ladj " + tag)
+        Xb_ref, lb_ref = orc.rqs(w_ref, h_ref, d_ref, Y_ref, inverse=True)
+        Xb, lb = bj.with_logabsdet_jacobian(bj.inverse(sp), dev(Y_ref), per_sample=True)
+        close(host(Xb), Xb_ref, dt, scale=10, what="rqs inv " + tag)
+        close(host(lb), lb_ref, dt, scale=dim * 10, what="rqs inv ladj " + tag)
+        g = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+        for inv in (False, True):
+            ref = orc.rqs_vjp(w_ref, h_ref, d_ref, X, g, lbar, inverse=inv)
+            got = bj.vjp(bj.inverse(sp) if inv else sp, dev(X), dev(g), torch.from_numpy(lbar).cuda())
+            np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref).max())), err_msg=f"rqs vjp inv={inv} " + tag)
+        # batch norm (evaluation mode)
+        b_, logs, m, v = r.normal(size=dim).astype(dt), (0.3 * r.normal(size=dim)).astype(dt), r.normal(size=dim).astype(dt), r.uniform(0.5, 2, size=dim).astype(dt)
+        bn = bj.InvertibleBatchNorm(torch.tensor(b_), torch.tensor(logs), torch.tensor(m), torch.tensor(v), eps=1e-5)
+        Yb_ref, lbn_ref = orc.batchnorm(b_, logs, m, v, 1e-5, X)
+        Yb, lbn = bj.with_logabsdet_jacobian(bn, dev(X))
+        close(host(Yb), Yb_ref, dt, what="bn " + tag)
+        close(host(lbn), lbn_ref, dt, scale=dim, what="bn ladj " + tag)
+        # ordered / simplex pullbacks
+        for inv in (False, True):
+            ref = orc.ordered_vjp(X.astype(np.float64), g.astype(np.float64), inverse=inv)
+            ob = bj.inverse(bj.OrderedBijector()) if inv else bj.OrderedBijector()
+            got = bj.vjp(ob, dev(X), dev(g))
+            np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 20 * dim * max(1.0, float(np.abs(ref).max())), err_msg=f"ordered vjp inv={inv} " + tag)
+        if dim >= 2:
+            P = np.asfortranarray(r.dirichlet(5.0 * np.ones(dim), size=N).T.astype(dt))   # well inside the simplex: the stick remainder keeps its digits in Float32
+            gy = np.asfortranarray(r.normal(size=(dim - 1, N)).astype(dt))
+            ref = orc.simplex_vjp(P.astype(np.float64), gy.astype(np.float64), lbar.astype(np.float64))
+            got = bj.vjp(bj.SimplexBijector(), dev(P), dev(gy), torch.from_numpy(lbar).cuda())
+            np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 50, atol=ATOL[dt] * 50 * dim * max(1.0, float(np.abs(ref).max())), err_msg="simplex vjp " + tag)
+            Yin = np.asfortranarray((1.2 * r.normal(size=(dim - 1, N))).astype(dt))
+            ref = orc.simplex_vjp(Yin.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64), inverse=True)
+            got = bj.vjp(bj.inverse(bj.SimplexBijector()), dev(Yin), dev(g), torch.from_numpy(lbar).cuda())
+            np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 50, atol=ATOL[dt] * 50 * max(1.0, float(np.abs(ref).max())), err_msg="simplex inv vjp " + tag)
+
+
+@pytest.mark.parametrize("K,N", [(257, 70), (600, 37), (1500, 5)])
+def test_simplex_vjp_long_columns(bj, orc, K, N):
+    """Columns too long for two 64-column LDS tiles: the tile kernel runs with fewer columns per block."""
+    dt = np.float64
+    r = rng(131)
+    lbar = r.normal(size=N).astype(dt)
+    b = bj.SimplexBijector()
+    y = np.asfortranarray(r.normal(size=(K - 1, N)).astype(dt))
+    gx = np.asfortranarray(r.normal(size=(K, N)).astype(dt))
+    ref = orc.simplex_vjp(y, gx, lbar, inverse=True)
+    got = bj.vjp(bj.inverse(b), dev(y), dev(gx), torch.from_numpy(lbar).cuda())
+    np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())))
+    x = np.asfortranarray(r.dirichlet(np.ones(K) * 5.0, size=N).T.astype(dt))
+    gy = np.asfortranarray(r.normal(size=(K - 1, N)).astype(dt))
+    ref_f = orc.simplex_vjp(x, gy, lbar)
+    got_f = bj.vjp(b, dev(x), dev(gy), torch.from_numpy(lbar).cuda())
+    np.testing.assert_allclose(host(got_f), ref_f, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref_f).max())))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,K,N", [(300, 33, 40), (129, 6, 50), (4, 100, 200), (2000, 8, 9)])
+def test_rqs_vjp_tables_outside_the_lds_kernel(bj, orc, dim, K, N, dt):
+    """Wide columns / more than 64 knots: the forward takes the generic functor, the pullback the one-element-per-thread kernel."""
+    r = rng(132)
+    w, h, d = orc.rqs_params(r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K - 1)).astype(dt), 3.0)
+    b = bj.RationalQuadraticSpline(dev(w), dev(h), dev(d))
+    X = np.asfortranarray((1.4 * r.normal(size=(dim, N))).astype(dt))
+    Y_ref, l_ref = orc.rqs(w, h, d, X)
+    Y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+    close(host(Y), Y_ref, dt, what="rqs fwd")
+    close(host(l), l_ref, dt, scale=dim, what="rqs ladj")
+    gbar = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    lbar = r.normal(size=N).astype(dt)
+    for inv in (False, True):
+        ref = orc.rqs_vjp(w, h, d, X, gbar, lbar, inverse=inv)
+        got = bj.vjp(bj.inverse(b) if inv else b, dev(X), dev(gbar), torch.from_numpy(lbar).cuda())
+        np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref).max())))
