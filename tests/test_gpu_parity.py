@@ -1618,3 +1618,118 @@ def test_rqs_vjp_tables_outside_the_lds_kernel(bj, orc, dim, K, N, dt):
         ref = orc.rqs_vjp(w, h, d, X, gbar, lbar, inverse=inv)
         got = bj.vjp(bj.inverse(b) if inv else b, dev(X), dev(gbar), torch.from_numpy(lbar).cuda())
         np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref).max())))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shape_sweep_composites(bj, orc, seed):
+    """Third sweep: Stacked with random segment layouts (one launch; per-segment op lists, per-row parameters, ragged
+    boundaries), Coupling over random row ranges, wide Planar / Radial columns (1 … 32 packs per lane), the planar
+    inverse, batch norm in training mode; outputs from 16-byte-misaligned views as well."""
+    r = rng(3000 + seed)
+    for trial in range(6):
+        dt = [np.float32, np.float64][int(r.integers(2))]
+        N = int(r.choice([1, 3, 17, 64, 65, 130, 257, 515]))
+        # ---- Stacked: random cut points, random segment kinds
+        dim = int(r.choice([3, 8, 19, 41, 64, 100, 128, 257]))
+        ncut = int(r.integers(1, min(dim, 7)))
+        cuts = sorted(set(int(c) for c in r.choice(np.arange(1, dim), size=ncut, replace=False))) if dim > 1 else []
+        bounds = [0] + cuts + [dim]
+        segs, X = [], np.empty((dim, N))
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            n = hi - lo
+            kind = int(r.integers(6))
+            rows = r.normal(size=(n, N))
+            if kind == 0:
+                segs.append((bj.elementwise(bj.exp), [(orc.OP_EXP, None, None)], (lo + 1, hi)))
+            elif kind == 1:
+                rows = r.uniform(-0.9, 1.9, size=(n, N))
+                segs.append((bj.Logit(-1.0, 2.0), [(orc.OP_LOGIT, -1.0, 2.0)], (lo + 1, hi)))
+            elif kind == 2:
+                segs.append((bj.identity, [], (lo + 1, hi)))
+            elif kind == 3:
+                a = np.linspace(0.5, 2.0, n)
+                segs.append((bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(torch.tensor(a)), [(orc.OP_SCALE, a, None), (orc.OP_SHIFT, 0.1, None), (orc.OP_EXP, None, None)], (lo + 1, hi)))
+            elif kind == 4:
+                segs.append((bj.inverse(bj.TruncatedBijector(0.0, 3.0)), [(orc.OP_TRUNCATED_INV, 0.0, 3.0)], (lo + 1, hi)))
+            else:
+                rows = r.uniform(0.1, 3.0, size=(n, N))
+                segs.append((bj.elementwise(bj.log), [(orc.OP_LOG, None, None)], (lo + 1, hi)))
+            X[lo:hi] = rows
+        X = np.asfortranarray(X.astype(dt))
+        tag = f"dt={dt.__name__} dim={dim} N={N} bounds={bounds}"
+        b = bj.Stacked([s[0] for s in segs], [s[2] for s in segs])
+        Y_ref, l_ref = _stacked_oracle(orc, [(s[1], s[2]) for s in segs], X)
+        Y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+        close(host(Y), Y_ref, dt, what="stacked " + tag)
+        close(host(l), l_ref, dt, scale=dim, what="stacked ladj " + tag)
+        Xb, lb = bj.with_logabsdet_jacobian(bj.inverse(b), dev(Y_ref), per_sample=True)
+        close(host(Xb), X, dt, scale=10, what="stacked inverse " + tag)
+        close(host(lb), -l_ref, dt, scale=dim * 10, what="stacked inverse ladj " + tag)
+        # misaligned input view (element offset 1): scalar-load geometry, same values
+        flat = torch.empty(dim * N + 1, dtype=dev(X).dtype, device="cuda")
+        Xv = flat[1:].view(N, dim).t()
+        Xv.copy_(dev(X))
+        Yv, lv = bj.with_logabsdet_jacobian(b, Xv, per_sample=True)
+        close(host(Yv), Y_ref, dt, what="stacked misaligned " + tag)
+        close(host(lv), l_ref, dt, scale=dim, what="stacked misaligned ladj " + tag)
+        # ---- Coupling over a random row range
+        if dim >= 3:
+            n1 = int(r.integers(1, dim - 1))
+            lo = int(r.integers(1, dim - n1 + 1))
+            idx1 = list(range(lo, lo + n1))
+            rest = [i for i in range(1, dim + 1) if i not in idx1]
+            m = bj.PartitionMask(dim, idx1, rest[: max(1, len(rest) // 2)])
+            Xc = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+            s = np.asfortranarray((np.exp(0.3 * r.normal(size=(n1, N))) * r.choice([-1.0, 1.0], size=(n1, N))).astype(dt))
+            t = np.asfortranarray(r.normal(size=(n1, N)).astype(dt))
+            i0 = [i - 1 for i in idx1]
+            cl = bj.Coupling(lambda th: bj.Shift(dev(t)) @ bj.Scale(dev(s), batched=True), m)
+            Yc_ref, lc_ref = orc.coupling_affine(i0, s, t, Xc)
+            Yc, lc = bj.with_logabsdet_jacobian(cl, dev(Xc), per_sample=True)
+            close(host(Yc), Yc_ref, dt, what=f"coupling lo={lo} n1={n1} " + tag)
+            close(host(lc), lc_ref, dt, scale=n1, what=f"coupling ladj lo={lo} n1={n1} " + tag)
+            Xcb, lcb = bj.with_logabsdet_jacobian(bj.inverse(cl), dev(Yc_ref), per_sample=True)
+            close(host(Xcb), Xc, dt, scale=10, what="coupling inverse " + tag)
+            close(host(lcb), -lc_ref, dt, scale=n1, what="coupling inverse ladj " + tag)
+        # ---- wide planar / radial columns, planar inverse
+        D = int(r.choice([260, 512, 700, 1024, 2048]))
+        Nw = int(r.choice([1, 9, 64, 70]))
+        nl = int(r.choice([1, 3]))
+        Xw = np.asfortranarray(r.normal(size=(D, Nw)).astype(dt))
+        w = (r.normal(size=(D, nl)) / np.sqrt(D)).astype(dt)
+        u = (r.normal(size=(D, nl)) / np.sqrt(D)).astype(dt)
+        bb = r.normal(size=nl).astype(dt)
+        tag = f"dt={dt.__name__} D={D} N={Nw} nl={nl}"
+        fl = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(bb))
+        yp_ref, lp_ref = orc.planar(w, u, bb, Xw)
+        yp, lp = bj.with_logabsdet_jacobian(fl, dev(Xw))
+        close(host(yp), yp_ref, dt, scale=10, what="planar " + tag)
+        close(host(lp), lp_ref, dt, scale=10 * nl, what="planar ladj " + tag)
+        xi_ref, li_ref = orc.planar(w, u, bb, Xw, inverse=True)
+        xi, li = bj.with_logabsdet_jacobian(bj.inverse(fl), dev(Xw))
+        close(host(xi), xi_ref, dt, scale=50, what="planar inverse " + tag)
+        close(host(li), li_ref, dt, scale=50 * nl, what="planar inverse ladj " + tag)
+        z0 = r.normal(size=D).astype(dt)
+        rad = bj.RadialLayer(torch.tensor(np.array([0.2], dtype=dt)), torch.tensor(np.array([0.4], dtype=dt)), torch.tensor(z0))
+        yr_ref, lr_ref = orc.radial(np.array([0.2]), np.array([0.4]), z0, Xw)
+        yr, lr = bj.with_logabsdet_jacobian(rad, dev(Xw))
+        close(host(yr), yr_ref, dt, scale=10, what="radial " + tag)
+        close(host(lr), lr_ref, dt, scale=D, what="radial ladj " + tag)
+        g = np.asfortranarray(r.normal(size=(D, Nw)).astype(dt))
+        ref_v = orc.planar_vjp(w, u, bb, Xw, g)
+        np.testing.assert_allclose(host(bj.vjp(fl, dev(Xw), dev(g))), ref_v, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref_v).max())), err_msg="planar vjp " + tag)
+        # ---- batch norm, training mode
+        dimb = int(r.choice([1, 2, 7, 64, 100, 130, 512]))
+        Nb = int(r.choice([2, 33, 1000, 5000]))
+        b_, logs = r.normal(size=dimb).astype(dt), (0.3 * r.normal(size=dimb)).astype(dt)
+        m0, v0 = r.normal(size=dimb).astype(dt), r.uniform(0.5, 2, size=dimb).astype(dt)
+        Xn = np.asfortranarray((1.5 * r.normal(size=(dimb, Nb)) + 0.7).astype(dt))
+        bn = bj.InvertibleBatchNorm(torch.tensor(b_), torch.tensor(logs), torch.tensor(m0), torch.tensor(v0), eps=1e-5, mtm=0.1)
+        Yn_ref, ln_ref, m_ref, v_ref = orc.batchnorm_train(b_, logs, m0, v0, 1e-5, 0.1, Xn)
+        with bj.training():
+            Yn, ln = bj.with_logabsdet_jacobian(bn, dev(Xn))
+        tag = f"dt={dt.__name__} dim={dimb} N={Nb}"
+        close(host(Yn), Yn_ref, dt, scale=10, what="bn train " + tag)
+        close(host(ln), ln_ref, dt, scale=dimb, what="bn train ladj " + tag)
+        close(host(bn.m), m_ref, dt, what="bn moving mean " + tag)
+        close(host(bn.v), v_ref, dt, what="bn moving var " + tag)
