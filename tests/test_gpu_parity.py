@@ -1733,3 +1733,32 @@ def test_random_shape_sweep_composites(bj, orc, seed):
         close(host(ln), ln_ref, dt, scale=dimb, what="bn train ladj " + tag)
         close(host(bn.m), m_ref, dt, what="bn moving mean " + tag)
         close(host(bn.v), v_ref, dt, what="bn moving var " + tag)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_shape_sweep_chains(bj, orc, seed):
+    """Fourth sweep: every named elementwise chain (scalar / per-row parameters, one … three ops) at random shapes:
+    values, summed and per-sample log-dets, the pullback, and logabsdetjac alone (the store-free launch)."""
+    r = rng(4000 + seed)
+    for trial in range(12):
+        dt = [np.float32, np.float64][int(r.integers(2))]
+        dim = int(r.choice(_SWEEP_DIMS))
+        N = int(r.choice([1, 2, 5, 17, 64, 65, 130, 257, 1000]))
+        name = CHAIN_NAMES[int(r.integers(len(CHAIN_NAMES)))]
+        b, ops, gen = _chain_cases(orc, bj, dim)[name]
+        x = np.asfortranarray(gen(r, (dim, N)).astype(dt))
+        tag = f"{name} dt={dt.__name__} dim={dim} N={N}"
+        y_ref, l_ref = orc.chain(ops, x)
+        y, l = bj.with_logabsdet_jacobian(b, dev(x))
+        close(host(y), y_ref, dt, what=tag)
+        sum_close(host(l), l_ref, dt, dim * N, what=tag + " ladj")
+        sum_close(host(bj.logabsdetjac(b, dev(x))), l_ref, dt, dim * N, what=tag + " logabsdetjac")
+        _, lps = bj.with_logabsdet_jacobian(b, dev(x), per_sample=True)
+        c = int(r.integers(N))
+        _, l1 = orc.chain(ops, x[:, c].copy())
+        sum_close(host(lps)[c], l1, dt, dim, what=tag + f" per-sample col {c}")
+        g = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+        lbar = r.normal(size=N).astype(dt)
+        ref = orc.chain_vjp(ops, x.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64))
+        got = bj.vjp(b, dev(x), dev(g), torch.from_numpy(lbar).cuda())
+        np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref).max())), err_msg=tag + " vjp")
