@@ -1655,6 +1655,7 @@ template <class T, bool LADJ> struct QSimplexFwd {      // simplex.jl:47-64 + :1
       carry = gl == 0 ? T(0) : bc;
     }
     T lp = T(0), s = carry;                                            // final round: s = Σ_{j<k} x_j in the reference's order
+    T Pp = T(1), mp = T(1);
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
       const T xk = x[i];
@@ -1663,10 +1664,13 @@ template <class T, bool LADJ> struct QSimplexFwd {      // simplex.jl:47-64 + :1
       const T dn = row0 ? T(1) : E - s;
       x[i] = F::log2(a * F::rcp(dn - a)) * Num<T>::log2 + lk[gl * RPL + i];   // logit(z) + log(K-k)
       if (LADJ) {
-        const T m = d_max(T(1) - s, e);                                // :133
-        const T zl = row0 ? xk : xk * F::rcp(m);
-        const T term = F::log2(d_max(zl, e) * d_max(T(1) - zl, e) * (row0 ? T(1) : m));   // :130-131, :135
-        lp += (i < RPL - 1 || gl < G - 1) ? term : T(0);               // row K has no term
+        // term_k = max(z,ε)·max(1-z,ε)·m, z = x_k/m, m = max(1-Σ,ε) (:130-135; m = 1 on row 1 since Σ = 0)
+        //        = max(x_k, εm)·max(m - x_k, εm)/m ; two rows share one reciprocal and one logarithm (each term >= ε²)
+        const bool rowK = i == RPL - 1 && gl == G - 1;                 // row K has no term
+        const T m = d_max(T(1) - s, e), em = e * m;                    // :133
+        const T P = d_max(xk, em) * d_max(m - xk, em);
+        if (i & 1) lp += F::log2(Pp * F::rcp(mp * (rowK ? T(1) : m)) * (rowK ? T(1) : P));
+        else { Pp = P; mp = m; }
       }
       s += xk;
     }
@@ -1685,8 +1689,9 @@ template <class T, bool LADJ, int G_> struct QSimplexInv {      // simplex.jl:10
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
       const T v = x[i] - lk[gl * RPL + i];
-      x[i] = f_logistic(v);
+      x[i] = f_logistic(v) * inv12e;                                   // z_k / (1 - 2ε): the factor both :109 and :113 apply
     }
+    const T e0 = e * inv12e;
     T carry = T(0);
 #pragma unroll
     for (int t = 0; t < G - 1; ++t) {                                  // rounds 0..G-2: only the recurrence Σ -> x_k -> Σ
@@ -1694,24 +1699,27 @@ template <class T, bool LADJ, int G_> struct QSimplexInv {      // simplex.jl:10
 #pragma unroll
       for (int i = 0; i < RPL; ++i) {
         const bool row0 = i == 0 && gl == 0;
-        const T xi = row0 ? d_clamp((x[i] - e) * inv12e, T(0), T(1)) : d_clamp((E - s) * inv12e * x[i] - e, T(0), T(1));
+        const T xi = row0 ? d_clamp(x[i] - e0, T(0), T(1)) : d_clamp((E - s) * x[i] - e, T(0), T(1));
         s += xi;
       }
       const T bc = quad_from_left<G>(s);
       carry = gl == 0 ? T(0) : bc;
     }
     T lp = T(0), s = carry;
+    T Pp = T(1), mp = T(1);
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
       const bool row0 = i == 0 && gl == 0;
       const bool rowK = i == RPL - 1 && gl == G - 1;
-      const T xi = row0 ? d_clamp((x[i] - e) * inv12e, T(0), T(1))               // :109
-                        : d_clamp((E - s) * inv12e * x[i] - e, T(0), T(1));     // :113
+      const T xi = row0 ? d_clamp(x[i] - e0, T(0), T(1))                          // :109
+                        : d_clamp((E - s) * x[i] - e, T(0), T(1));               // :113
       if (LADJ) {
-        const T m = d_max(T(1) - s, e);
-        const T zl = row0 ? xi : xi * F::rcp(m);
-        const T term = F::log2(d_max(zl, e) * d_max(T(1) - zl, e) * (row0 ? T(1) : m));
-        lp += rowK ? T(0) : term;
+        // term_k = max(z,ε)·max(1-z,ε)·m, z = x_k/m, m = max(1-Σ,ε) (:130-135; m = 1 on row 1 since Σ = 0)
+        //        = max(x_k, εm)·max(m - x_k, εm)/m ; two rows share one reciprocal and one logarithm (each term >= ε²)
+        const T m = d_max(T(1) - s, e), em = e * m;
+        const T P = d_max(xi, em) * d_max(m - xi, em);
+        if (i & 1) lp += F::log2(Pp * F::rcp(mp * (rowK ? T(1) : m)) * (rowK ? T(1) : P));
+        else { Pp = P; mp = m; }
       }
       x[i] = rowK ? d_clamp(T(1) - s, T(0), T(1)) : xi;                          // :116
       s += xi;
@@ -1820,6 +1828,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     // ---- re-deal the run: lane (cg, gl) takes rows gl·RPL .. gl·RPL+RPL-1 of column cg
     T xv[RPL];
     __builtin_amdgcn_wave_barrier();                                   // the previous instruction's strip reads are done
+    int dc = (lane * V) / RI, dr = (lane * V) % RI;                      // (column, row) of this lane's first element; advanced per load, no per-element division
 #pragma unroll
     for (int q = 0; q < NLI; ++q) {
       const int pk = lane + 64 * q;
@@ -1827,9 +1836,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         if constexpr (Op::IN_LESS == 0) {
           *reinterpret_cast<typename Vec16<T>::type*>(st + (pk / PPC) * PITCH + (pk % PPC) * V) = __builtin_bit_cast(typename Vec16<T>::type, raw[u][q]);
         } else {
+          T* dst = st + dc * PITCH + dr;
 #pragma unroll
-          for (int j = 0; j < V; ++j) { const int el = pk * V + j; st[(el / RI) * PITCH + el % RI] = raw[u][q].v[j]; }
+          for (int j = 0; j < V; ++j) dst[j + (dr + j >= RI ? PITCH - RI : 0)] = raw[u][q].v[j];
         }
+      }
+      if constexpr (Op::IN_LESS != 0) {
+        dc += (64 * V) / RI; dr += (64 * V) % RI;
+        if (dr >= RI) { dr -= RI; ++dc; }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1949,6 +1963,7 @@ template <class T, int V, int NP, int G> struct QuadStrip {
     constexpr int RI = R - LESS;
     const int gl = lane & (G - 1), cg = lane / G;
     __builtin_amdgcn_wave_barrier();
+    int dc = (lane * V) / RI, dr = (lane * V) % RI;                      // advanced per load: no per-element division
 #pragma unroll
     for (int q = 0; q < nl(LESS); ++q) {
       const int pk = lane + 64 * q;
@@ -1956,9 +1971,14 @@ template <class T, int V, int NP, int G> struct QuadStrip {
         if constexpr (LESS == 0) {
           *reinterpret_cast<typename Vec16<T>::type*>(st + (pk / PPC) * PITCH + (pk % PPC) * V) = __builtin_bit_cast(typename Vec16<T>::type, raw[q]);
         } else {
+          T* dst = st + dc * PITCH + dr;
 #pragma unroll
-          for (int j = 0; j < V; ++j) { const int el = pk * V + j; st[(el / RI) * PITCH + el % RI] = raw[q].v[j]; }
+          for (int j = 0; j < V; ++j) dst[j + (dr + j >= RI ? PITCH - RI : 0)] = raw[q].v[j];
         }
+      }
+      if constexpr (LESS != 0) {
+        dc += (64 * V) / RI; dr += (64 * V) % RI;
+        if (dr >= RI) { dr -= RI; ++dc; }
       }
     }
     __builtin_amdgcn_wave_barrier();
