@@ -85,7 +85,8 @@ template <class T, bool LADJ> struct SimplexFwd {
     return o;
   }
   __device__ T last(T) { return T(0); }                                     // row K has no output
-  __device__ T result() const { return -lp * Num<T>::log2; }
+  // Julia's max(NaN, ε) is NaN (v_max drops it): a NaN among x_1..x_{K-1} makes the reference's log-det NaN
+  __device__ T result() const { return sum_tmp != sum_tmp ? sum_tmp : -lp * Num<T>::log2; }
 };
 // simplex.jl:102-120 ; log-det = -logabsdetjac(b, x_out)
 template <class T, bool LADJ> struct SimplexInv {
@@ -123,7 +124,7 @@ template <class T, bool LADJ> struct SimplexInv {
     return x;
   }
   __device__ T last(T) { return d_clamp(T(1) - sum_tmp, T(0), T(1)); }      // :116
-  __device__ T result() const { return lp * Num<T>::log2; }
+  __device__ T result() const { return sum_tmp != sum_tmp ? sum_tmp : lp * Num<T>::log2; }   // NaN rows: as above
 };
 
 template <class T, class Op>
@@ -1655,7 +1656,7 @@ template <class T, bool LADJ> struct QSimplexFwd {      // simplex.jl:47-64 + :1
       carry = gl == 0 ? T(0) : bc;
     }
     T lp = T(0), s = carry;                                            // final round: s = Σ_{j<k} x_j in the reference's order
-    T Pp = T(1), mp = T(1);
+    T Pp = T(1), mp = T(1), chk = T(0);
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
       const T xk = x[i];
@@ -1671,27 +1672,28 @@ template <class T, bool LADJ> struct QSimplexFwd {      // simplex.jl:47-64 + :1
         const T P = d_max(xk, em) * d_max(m - xk, em);
         if (i & 1) lp += F::log2(Pp * F::rcp(mp * (rowK ? T(1) : m)) * (rowK ? T(1) : P));
         else { Pp = P; mp = m; }
+        if (i == RPL - 1) chk = rowK ? s : s + xk;                     // Σ over this lane's rows < K and everything above
       }
       s += xk;
     }
-    return -lp * Num<T>::log2;
+    // Julia's max(NaN, ε) is NaN (v_max drops it): a NaN among x_1..x_{K-1} makes the reference's log-det NaN
+    return chk != chk ? chk : -lp * Num<T>::log2;
   }
 };
 
 template <class T, bool LADJ, int G_> struct QSimplexInv {      // simplex.jl:102-120 ; log-det = -logabsdetjac(b, x_out)
   static constexpr int G = G_, IN_LESS = 1, OUT_LESS = 0;
   static constexpr bool USES_LOGK = true, HAS_LADJ = LADJ;
-  template <int RPL> __device__ __forceinline__ T run(T (&x)[RPL], int gl, const T* lk) const {
+  // FAST: clamp(v, 0, 1) as one v_med3_f32.  med3 does not keep a NaN (the reference's clamp does, and the NaN then
+  // poisons Σ and every later row), so run() takes this path only for waves whose inputs are all finite.
+  template <bool FAST> static __device__ __forceinline__ T cl01(T v) {
+    if constexpr (FAST) return d_med3(v, T(0), T(1));
+    else return d_clamp(v, T(0), T(1));
+  }
+  template <bool FAST, int RPL> static __device__ __forceinline__ T rounds(T (&x)[RPL], int gl) {
     using F = Fast<T>;
     const T e = Num<T>::eps, E = T(1) + e;
-    const T inv12e = T(1) / (T(1) - 2 * e);
-    // z_k = logistic(y_k - log(K-k)) with LogExpFunctions' exact 0/1 saturation
-#pragma unroll
-    for (int i = 0; i < RPL; ++i) {
-      const T v = x[i] - lk[gl * RPL + i];
-      x[i] = f_logistic(v) * inv12e;                                   // z_k / (1 - 2ε): the factor both :109 and :113 apply
-    }
-    const T e0 = e * inv12e;
+    const T e0 = e * (T(1) / (T(1) - 2 * e));
     T carry = T(0);
 #pragma unroll
     for (int t = 0; t < G - 1; ++t) {                                  // rounds 0..G-2: only the recurrence Σ -> x_k -> Σ
@@ -1699,7 +1701,7 @@ template <class T, bool LADJ, int G_> struct QSimplexInv {      // simplex.jl:10
 #pragma unroll
       for (int i = 0; i < RPL; ++i) {
         const bool row0 = i == 0 && gl == 0;
-        const T xi = row0 ? d_clamp(x[i] - e0, T(0), T(1)) : d_clamp((E - s) * x[i] - e, T(0), T(1));
+        const T xi = row0 ? cl01<FAST>(x[i] - e0) : cl01<FAST>((E - s) * x[i] - e);
         s += xi;
       }
       const T bc = quad_from_left<G>(s);
@@ -1711,8 +1713,8 @@ template <class T, bool LADJ, int G_> struct QSimplexInv {      // simplex.jl:10
     for (int i = 0; i < RPL; ++i) {
       const bool row0 = i == 0 && gl == 0;
       const bool rowK = i == RPL - 1 && gl == G - 1;
-      const T xi = row0 ? d_clamp(x[i] - e0, T(0), T(1))                          // :109
-                        : d_clamp((E - s) * x[i] - e, T(0), T(1));               // :113
+      const T xi = row0 ? cl01<FAST>(x[i] - e0)                                   // :109
+                        : cl01<FAST>((E - s) * x[i] - e);                        // :113
       if (LADJ) {
         // term_k = max(z,ε)·max(1-z,ε)·m, z = x_k/m, m = max(1-Σ,ε) (:130-135; m = 1 on row 1 since Σ = 0)
         //        = max(x_k, εm)·max(m - x_k, εm)/m ; two rows share one reciprocal and one logarithm (each term >= ε²)
@@ -1721,10 +1723,26 @@ template <class T, bool LADJ, int G_> struct QSimplexInv {      // simplex.jl:10
         if (i & 1) lp += F::log2(Pp * F::rcp(mp * (rowK ? T(1) : m)) * (rowK ? T(1) : P));
         else { Pp = P; mp = m; }
       }
-      x[i] = rowK ? d_clamp(T(1) - s, T(0), T(1)) : xi;                          // :116
+      x[i] = rowK ? cl01<FAST>(T(1) - s) : xi;                                   // :116
       s += xi;
     }
+    if (!FAST && s != s) return s;                                     // Julia's max(NaN, ε) is NaN: the log-det of a poisoned column is NaN
     return lp * Num<T>::log2;
+  }
+  template <int RPL> __device__ __forceinline__ T run(T (&x)[RPL], int gl, const T* lk) const {
+    const T e = Num<T>::eps;
+    const T inv12e = T(1) / (T(1) - 2 * e);
+    // z_k = logistic(y_k - log(K-k)) with LogExpFunctions' exact 0/1 saturation
+    T poison = T(0);
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+      const T v = x[i] - lk[gl * RPL + i];
+      const T z = f_logistic(v);
+      poison = z * T(0) + poison;                                      // NaN iff some y_k is NaN (z is in [0, 1] otherwise)
+      x[i] = z * inv12e;                                               // z_k / (1 - 2ε): the factor both :109 and :113 apply
+    }
+    if (__builtin_amdgcn_ballot_w64(poison != poison) == 0) return rounds<true, RPL>(x, gl);
+    return rounds<false, RPL>(x, gl);
   }
 };
 
@@ -1776,10 +1794,10 @@ template <class T> struct QOrderedInv {                  // ordered.jl:63-77 ; i
   }
 };
 
-template <class T, int V, int NP, class Op, int UC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void quad_stream_kernel(const Op op, const T* __restrict__ x, T* __restrict__ y,
-                                                                                                      T* __restrict__ ladj_ps, int64_t batch,
-                                                                                                      int accumulate, double* partials) {
+template <class T, int V, int NP, class Op, int UC, int WPB = 4, int H = 1>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 8))) void quad_stream_kernel(const Op op, const T* __restrict__ x, T* __restrict__ y,
+                                                                                                           T* __restrict__ ladj_ps, int64_t batch,
+                                                                                                           int accumulate, double* partials) {
   constexpr int G = Op::G;
   constexpr int RPL = NP * V;                        // rows per lane
   constexpr int R = G * RPL;                         // rows of the column frame
@@ -1790,12 +1808,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   static_assert((CPS * RI) % V == 0 && (CPS * RO) % V == 0, "a wave instruction's run is whole packs");
   constexpr int NPI = CPS * RI / V, NPO = CPS * RO / V;          // packs of the input / output run
   constexpr int NLI = (NPI + 63) / 64, NLO = (NPO + 63) / 64;    // pack loads / stores per lane
-  __shared__ __attribute__((aligned(16))) T strip[4][CPS * PITCH];
+  // The re-deal goes through the strip in H column slices (H = 1: the whole run at once).  A slice is CS columns:
+  // its packs of the run are written, its lanes read their rows; 1/H of the LDS per wave, so long columns
+  // (one lane per column, 64 rows: 17 KiB per wave unsliced) keep 4 waves per SIMD.
+  constexpr int CS = CPS / H;
+  static_assert(CPS % H == 0 && (CS * RI) % V == 0 && (CS * RO) % V == 0, "a slice is whole columns and whole packs");
+  constexpr int NSI = CS * RI / V, NSO = CS * RO / V;            // packs per slice
+  __shared__ __attribute__((aligned(16))) T strip[WPB][CS * PITCH];
   __shared__ __attribute__((aligned(16))) T lktab[Op::USES_LOGK ? R : V];
-  __shared__ double red[4];
+  __shared__ double red[WPB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gl = lane & (G - 1), cg = lane / G;
-  const int64_t colb = ((int64_t)blockIdx.x * 4 + wave) * (CPS * UC);
+  const int cs = cg % CS, hs = cg / CS;              // column inside its slice, slice of this lane
+  const int64_t colb = ((int64_t)blockIdx.x * WPB + wave) * (CPS * UC);
   // coalesced loads: the columns of a wave instruction are one contiguous run
   Pack<T, V> raw[UC][NLI];
 #pragma unroll
@@ -1815,8 +1840,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
   }
   if (Op::USES_LOGK) {
-    // log(K-k) per row (simplex.jl:35,41): one precise log per thread of the block
-    if ((int)threadIdx.x < R) lktab[threadIdx.x] = (int)threadIdx.x < R - 1 ? d_log(T(R - 1 - (int)threadIdx.x)) : T(0);
+    // log(K-k) per row (simplex.jl:35,41): precise logs, once per block
+    for (int i = threadIdx.x; i < R; i += 64 * WPB) lktab[i] = i < R - 1 ? d_log(T(R - 1 - i)) : T(0);
     __syncthreads();
   }
   double acc = 0.0;
@@ -1827,31 +1852,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int64_t col = colw + cg;
     // ---- re-deal the run: lane (cg, gl) takes rows gl·RPL .. gl·RPL+RPL-1 of column cg
     T xv[RPL];
-    __builtin_amdgcn_wave_barrier();                                   // the previous instruction's strip reads are done
-    int dc = (lane * V) / RI, dr = (lane * V) % RI;                      // (column, row) of this lane's first element; advanced per load, no per-element division
 #pragma unroll
-    for (int q = 0; q < NLI; ++q) {
-      const int pk = lane + 64 * q;
-      if (NPI % 64 == 0 || pk < NPI) {
-        if constexpr (Op::IN_LESS == 0) {
-          *reinterpret_cast<typename Vec16<T>::type*>(st + (pk / PPC) * PITCH + (pk % PPC) * V) = __builtin_bit_cast(typename Vec16<T>::type, raw[u][q]);
-        } else {
-          T* dst = st + dc * PITCH + dr;
+    for (int h = 0; h < H; ++h) {
+      __builtin_amdgcn_wave_barrier();                                 // the previous reads of the strip are done
+      int dc = (lane * V) / RI, dr = (lane * V) % RI;                  // (column, row) of this lane's first element; advanced per load, no per-element division
 #pragma unroll
-          for (int j = 0; j < V; ++j) dst[j + (dr + j >= RI ? PITCH - RI : 0)] = raw[u][q].v[j];
+      for (int q = 0; q < NLI; ++q) {
+        const int pk = lane + 64 * q;
+        if (64 * q + 63 >= h * NSI && 64 * q < (h + 1) * NSI) {        // compile time: this load holds packs of slice h
+          if ((H == 1 || (pk >= h * NSI && pk < (h + 1) * NSI)) && (NPI % 64 == 0 || pk < NPI)) {
+            if constexpr (Op::IN_LESS == 0) {
+              *reinterpret_cast<typename Vec16<T>::type*>(st + (pk / PPC - h * CS) * PITCH + (pk % PPC) * V) = __builtin_bit_cast(typename Vec16<T>::type, raw[u][q]);
+            } else {
+              T* dst = st + (dc - h * CS) * PITCH + dr;
+#pragma unroll
+              for (int j = 0; j < V; ++j) dst[j + (dr + j >= RI ? PITCH - RI : 0)] = raw[u][q].v[j];
+            }
+          }
+        }
+        if constexpr (Op::IN_LESS != 0) {
+          dc += (64 * V) / RI; dr += (64 * V) % RI;
+          if (dr >= RI) { dr -= RI; ++dc; }
         }
       }
-      if constexpr (Op::IN_LESS != 0) {
-        dc += (64 * V) / RI; dr += (64 * V) % RI;
-        if (dr >= RI) { dr -= RI; ++dc; }
+      __builtin_amdgcn_wave_barrier();
+      if (H == 1 || hs == h) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const Pack<T, V> pq = __builtin_bit_cast(Pack<T, V>, *reinterpret_cast<const typename Vec16<T>::type*>(st + cs * PITCH + (gl * NP + q) * V));
+#pragma unroll
+          for (int j = 0; j < V; ++j) xv[q * V + j] = pq.v[j];
+        }
       }
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      const Pack<T, V> pq = __builtin_bit_cast(Pack<T, V>, *reinterpret_cast<const typename Vec16<T>::type*>(st + cg * PITCH + (gl * NP + q) * V));
-#pragma unroll
-      for (int j = 0; j < V; ++j) xv[q * V + j] = pq.v[j];
     }
     if (Op::IN_LESS) { if (gl == G - 1) xv[RPL - 1] = T(0); }          // the frame's last row has no input
     const T l = op.template run<RPL>(xv, gl, lktab);
@@ -1864,27 +1896,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
     if (y) {
       if (colw + CPS <= batch) {
-        __builtin_amdgcn_wave_barrier();                               // everybody has read its inputs
-        if constexpr (Op::OUT_LESS == 0) {
 #pragma unroll
-          for (int q = 0; q < NP; ++q) {
-            Pack<T, V> pq;
+        for (int h = 0; h < H; ++h) {
+          __builtin_amdgcn_wave_barrier();                             // everybody has read its inputs / the previous slice has left
+          if (H == 1 || hs == h) {
+            if constexpr (Op::OUT_LESS == 0) {
 #pragma unroll
-            for (int j = 0; j < V; ++j) pq.v[j] = xv[q * V + j];
-            *reinterpret_cast<typename Vec16<T>::type*>(st + cg * PITCH + (gl * NP + q) * V) = __builtin_bit_cast(typename Vec16<T>::type, pq);
+              for (int q = 0; q < NP; ++q) {
+                Pack<T, V> pq;
+#pragma unroll
+                for (int j = 0; j < V; ++j) pq.v[j] = xv[q * V + j];
+                *reinterpret_cast<typename Vec16<T>::type*>(st + cs * PITCH + (gl * NP + q) * V) = __builtin_bit_cast(typename Vec16<T>::type, pq);
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < RPL; ++i) { const int r = gl * RPL + i; if (r < RO) st[cs * RO + r] = xv[i]; }
+            }
           }
-        } else {
+          __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int i = 0; i < RPL; ++i) { const int r = gl * RPL + i; if (r < RO) st[cg * RO + r] = xv[i]; }
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < NLO; ++q) {
-          const int pk = lane + 64 * q;
-          if (NPO % 64 == 0 || pk < NPO) {
-            const T* src = Op::OUT_LESS == 0 ? st + (pk / PPC) * PITCH + (pk % PPC) * V : st + pk * V;
-            const Pack<T, V> pq = __builtin_bit_cast(Pack<T, V>, *reinterpret_cast<const typename Vec16<T>::type*>(src));
-            store_pack<T, V, true>(y + colw * RO + (int64_t)pk * V, pq);
+          for (int q = 0; q < NLO; ++q) {
+            const int pk = lane + 64 * q;
+            if (64 * q + 63 >= h * NSO && 64 * q < (h + 1) * NSO) {
+              if ((H == 1 || (pk >= h * NSO && pk < (h + 1) * NSO)) && (NPO % 64 == 0 || pk < NPO)) {
+                const T* src = Op::OUT_LESS == 0 ? st + (pk / PPC - h * CS) * PITCH + (pk % PPC) * V : st + (pk - h * NSO) * V;
+                const Pack<T, V> pq = __builtin_bit_cast(Pack<T, V>, *reinterpret_cast<const typename Vec16<T>::type*>(src));
+                store_pack<T, V, true>(y + colw * RO + (int64_t)pk * V, pq);
+              }
+            }
           }
         }
       } else if (col < batch) {
@@ -1906,7 +1945,7 @@ int launch_quad_stream(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_
   const int64_t np = R / (G * VW);
   constexpr int NPMAX = 16 / G;                              // R <= 64 (Float32) / 32 (Float64)
   if (!use_stream || batch <= 0 || R % (G * VW) != 0 || np < 1 || np > NPMAX || !bjx_aligned16(in) || (out && !bjx_aligned16(out))) return BJX_OK;
-  if (np != 1 && np != 2 && np != 3 && np != 4 && np != 8) return BJX_OK;
+  if (np != 1 && np != 2 && np != 3 && np != 4 && np != 8 && np != 16) return BJX_OK;
   *taken = true;
   const int64_t cpb = 4 * (64 / G);                          // columns per block: 4 waves x 64/G columns
   const int64_t grid = (batch + cpb - 1) / cpb;
@@ -1916,7 +1955,10 @@ int launch_quad_stream(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_
   double* partials = (ladj_sum && Op::HAS_LADJ) ? ctx->partials : nullptr;
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
   (void)want;
-#define QS(NP_) hipLaunchKernelGGL((quad_stream_kernel<T, VW, NP_, Op, 1>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, op, in, out, ladj_ps, batch, accum, partials)
+  // column slices of the re-deal: keep the wave's strip at <= ~9 KiB (4 waves per SIMD by LDS)
+#define QS(NP_) do { constexpr size_t SB_ = (size_t)(64 / G) * (size_t)(G * NP_ * VW + VW) * sizeof(T);                                                        \
+    constexpr int H_ = (SB_ > 9 * 1024 && (64 / G) % 2 == 0 && ((64 / G) / 2 * (G * NP_ * VW - Op::IN_LESS)) % VW == 0 && ((64 / G) / 2 * (G * NP_ * VW - Op::OUT_LESS)) % VW == 0) ? 2 : 1; \
+    hipLaunchKernelGGL((quad_stream_kernel<T, VW, NP_, Op, 1, 4, H_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, op, in, out, ladj_ps, batch, accum, partials); } while (0)
   {
     BjxProf prof_(ctx);
     switch ((int)np) {
@@ -1925,6 +1967,7 @@ int launch_quad_stream(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_
       case 3: if constexpr (NPMAX >= 3) QS(3); break;
       case 4: if constexpr (NPMAX >= 4) QS(4); break;
       case 8: if constexpr (NPMAX >= 8) QS(8); break;
+      case 16: if constexpr (NPMAX >= 16) QS(16); break;
     }
   }
 #undef QS
@@ -2222,8 +2265,16 @@ int simplex_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, dou
     if (!inverse) rc = want ? launch_quad_stream<T>(ctx, QSimplexFwd<T, true>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken)
                             : launch_quad_stream<T>(ctx, QSimplexFwd<T, false>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken);
     else {
-      static const int g4 = getenv("BJX_SIMPLEX_INV_G") ? atoi(getenv("BJX_SIMPLEX_INV_G")) == 4 : 0;
+      static const int g_env = getenv("BJX_SIMPLEX_INV_G") ? atoi(getenv("BJX_SIMPLEX_INV_G")) : 2;
+      const int g4 = g_env == 4;
       constexpr int VWq = Vec16<T>::N;
+      // BJX_SIMPLEX_INV_G=1: one lane per column — the clamped recurrence runs once per element (19 % fewer VALU
+      // instructions than two lanes per column), but 64 rows per lane spill next to the two clamp paths: measured
+      // equal (single path) to 25 % slower, so two lanes per column stay the default
+      if (g_env == 1)
+        rc = want ? launch_quad_stream<T>(ctx, QSimplexInv<T, true, 1>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken)
+                  : launch_quad_stream<T>(ctx, QSimplexInv<T, false, 1>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken);
+      if (rc || taken) return rc;
       if (g4 || K % (2 * VWq) != 0 || K / (2 * VWq) > 8 || (K / (2 * VWq) > 4 && K / (2 * VWq) != 8))
         rc = want ? launch_quad_stream<T>(ctx, QSimplexInv<T, true, 4>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken)
                   : launch_quad_stream<T>(ctx, QSimplexInv<T, false, 4>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken);

@@ -1762,3 +1762,54 @@ def test_random_shape_sweep_chains(bj, orc, seed):
         ref = orc.chain_vjp(ops, x.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64))
         got = bj.vjp(b, dev(x), dev(g), torch.from_numpy(lbar).cuda())
         np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref).max())), err_msg=tag + " vjp")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("K", [8, 64, 33])
+def test_simplex_inverse_nan_rows_poison_the_rest_of_their_column_only(bj, orc, K, dt):
+    """The reference's `_clamp` keeps a NaN, `sum_tmp += x[k]` then poisons every later row of THAT column
+    (simplex.jl:102-120).  The streaming kernel clamps with v_med3 (which drops NaN) only in waves whose inputs are
+    all finite and falls back to the exact clamp otherwise: columns next to a NaN column must be untouched, rows
+    above the NaN must be the finite values."""
+    r = rng(140)
+    N = 300
+    y = np.asfortranarray(r.normal(size=(K - 1, N)).astype(dt))
+    bad = {5: 0, 70: K // 2, 71: K - 2, 200: 3 % (K - 1)}
+    for c, k in bad.items():
+        y[k, c] = np.nan
+    x_ref, l_ref = orc.simplex(y, inverse=True)
+    x, l = bj.with_logabsdet_jacobian(bj.inverse(bj.SimplexBijector()), dev(y), per_sample=True)
+    x, l = host(x), host(l)
+    for c, k in bad.items():
+        assert np.all(np.isnan(x[k:, c])) and np.all(np.isnan(x_ref[k:, c])), (c, k)
+        assert np.all(np.isfinite(x[:k, c]))
+        close(x[:k, c], x_ref[:k, c], dt, what=f"rows above the NaN, column {c}")
+        assert np.isnan(l[c]) and np.isnan(l_ref[c])
+    good = [c for c in range(N) if c not in bad]
+    close(x[:, good], x_ref[:, good], dt, what="finite columns")
+    close(l[good], l_ref[good], dt, scale=K * 10, what="finite columns ladj")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("K", [8, 64, 33])
+def test_simplex_forward_nan_rows(bj, orc, K, dt):
+    """A NaN among x_1..x_{K-1} makes the reference's log-det NaN (Julia's max(NaN, ε) is NaN, simplex.jl:122-138) and
+    every y from that row on NaN; a NaN in x_K alone touches nothing (row K enters neither y nor the log-det)."""
+    r = rng(141)
+    N = 300
+    x = np.asfortranarray(r.dirichlet(3.0 * np.ones(K), size=N).T.astype(dt))
+    bad = {5: 0, 70: K // 2, 71: K - 2}
+    for c, k in bad.items():
+        x[k, c] = np.nan
+    x[K - 1, 200] = np.nan
+    y_ref, l_ref = orc.simplex(x)
+    y, l = bj.with_logabsdet_jacobian(bj.SimplexBijector(), dev(x), per_sample=True)
+    y, l = host(y), host(l)
+    for c, k in bad.items():
+        assert np.all(np.isnan(y[k:, c])) and np.all(np.isnan(y_ref[k:, c])), (c, k)
+        close(y[:k, c], y_ref[:k, c], dt, scale=10, what=f"rows above the NaN, column {c}")
+        assert np.isnan(l[c]) and np.isnan(l_ref[c])
+    good = [c for c in range(N) if c not in bad]
+    assert np.all(np.isfinite(y[:, good])) and np.all(np.isfinite(l[good]))
+    close(y[:, good], y_ref[:, good], dt, scale=10, what="finite columns")
+    close(l[good], l_ref[good], dt, scale=K * 10, what="finite columns ladj")
