@@ -278,10 +278,11 @@ __device__ __forceinline__ T rqs_eval(const Rec4<T>& A, const Rec4<T>& B, T lim,
   T lj = F::log2(nj * (sr * sr));                                           // log(s²·nj) - 2 log(den)
   if (!INV) res = A.v[2] + (A.v[3] * (xi * (d_k + (s - d_k) * xi))) * rden;
   else { res = xi * A.v[3] + A.v[2]; lj = -lj; }
-  // identity outside [-B, B] (:132, :186): (x <= -lim || x >= lim) == !(|x| < lim), NaN included
-  const bool inside = d_abs(xin) < lim;
-  x = inside ? res : xin;
-  return inside ? lj : T(0);
+  // identity outside [-B, B] (:132, :186): (x <= -lim || x >= lim) == (|x| >= lim); a NaN is NOT outside (both
+  // comparisons are false in the reference too) and leaves through the arithmetic as NaN value and NaN log-det
+  const bool outside = d_abs(xin) >= lim;
+  x = outside ? xin : res;
+  return outside ? T(0) : lj;
 }
 
 // pos = 2*pos + (key < x): one compare + one add-with-carry (the compiler's own lowering of this
@@ -442,7 +443,7 @@ __device__ __forceinline__ T rqs_eval_vjp(const Rec4<T>& A, const Rec4<T>& B, T 
   const T om = T(1) - (xi + xi);                                            // dp/dξ
   const T dl = ((dd - ds * om) * F::rcp(nj) - T(2) * ds * om * rden) * iw;  // d log f'/dx
   const T out = !INV ? g * J + lb * dl : (g - lb * dl) * F::rcp(J);
-  return d_abs(xin) < lim ? out : g;
+  return d_abs(xin) >= lim ? g : out;                                        // NaN: not outside, NaN cotangent
 }
 
 template <class T, int V, bool INV>
@@ -759,7 +760,7 @@ __global__ __launch_bounds__(256) void rqs_vjp_generic_kernel(const T* __restric
     const T xin = x[idx], g = gbar[idx], lb = lbar ? lbar[col] : T(0);
     const T wK = w_[(int64_t)(K - 1) * st], hK = h_[(int64_t)(K - 1) * st];
     const T lim = INV ? hK : wK;
-    if (!(d_abs(xin) < lim)) { xbar[idx] = g; continue; }
+    if (d_abs(xin) >= lim) { xbar[idx] = g; continue; }
     const int k = ssf<T>(INV ? h_ : w_, st, K, xin) - 1;
     const T w_k = (k == 0) ? -wK : w_[(int64_t)(k - 1) * st];
     const T wd = w_[(int64_t)k * st] - w_k;

@@ -1813,3 +1813,76 @@ def test_simplex_forward_nan_rows(bj, orc, K, dt):
     assert np.all(np.isfinite(y[:, good])) and np.all(np.isfinite(l[good]))
     close(y[:, good], y_ref[:, good], dt, scale=10, what="finite columns")
     close(l[good], l_ref[good], dt, scale=K * 10, what="finite columns ladj")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_nan_inputs_poison_exactly_what_the_reference_poisons(bj, orc, dt):
+    """One NaN per marked column: values and per-sample log-dets must be NaN exactly where the oracle's are (hardware
+    min/max/med3 drop NaNs, Julia's clamp/max keep them), every other column must be untouched."""
+    r = rng(150)
+    dim, N = 64, 200
+    bad = {3: 0, 77: 31, 78: 63, 150: 17}
+
+    def check(name, y, l, y_ref, l_ref, scale=10):
+        y, l = host(y), host(l)
+        assert np.array_equal(np.isnan(y), np.isnan(y_ref)), f"{name}: NaN pattern of the values"
+        assert np.array_equal(np.isnan(l), np.isnan(l_ref)), f"{name}: NaN pattern of the log-dets"
+        ok = ~np.isnan(y_ref)
+        close(y[ok], y_ref[ok], dt, scale=scale, what=name)
+        okl = ~np.isnan(l_ref)
+        close(l[okl], l_ref[okl], dt, scale=scale * dim, what=name + " ladj")
+
+    def poisoned(X):
+        X = X.copy()
+        for c, k in bad.items():
+            X[k % X.shape[0], c] = np.nan
+        return np.asfortranarray(X.astype(dt))
+
+    def per_sample_chain(ops, X):
+        y, _ = orc.chain(ops, X)
+        return y, np.array([float(orc.chain(ops, np.asfortranarray(X[:, [c]]))[1]) for c in range(X.shape[1])])
+
+    cases = _chain_cases(orc, bj, dim)
+    for name in ("exp", "log", "logit", "inv_logit", "leaky", "trunc", "trunc_vec", "inv_trunc", "inv_trunc_vec", "affexp_v", "logit_leaky"):
+        b, ops, gen = cases[name]
+        X = poisoned(gen(r, (dim, N)))
+        y_ref, l_ref = per_sample_chain(ops, X)
+        y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+        check("chain " + name, y, l, y_ref, l_ref)
+    X = poisoned(r.normal(size=(dim, N)))
+    for inv in (False, True):
+        y_ref, l_ref = orc.ordered(X, inverse=inv)
+        b = bj.inverse(bj.OrderedBijector()) if inv else bj.OrderedBijector()
+        y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+        check(f"ordered inv={inv}", y, l, y_ref, l_ref, scale=100)
+    w = (r.normal(size=(dim, 3)) / 8).astype(dt); u = (r.normal(size=(dim, 3)) / 8).astype(dt); bb = r.normal(size=3).astype(dt)
+    fl = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(bb))
+    y_ref, l_ref = orc.planar(w, u, bb, X)
+    y, l = bj.with_logabsdet_jacobian(fl, dev(X))
+    check("planar", y, l, y_ref, l_ref)
+    z0 = r.normal(size=dim).astype(dt)
+    rad = bj.RadialLayer(torch.tensor(np.array([0.2], dtype=dt)), torch.tensor(np.array([0.4], dtype=dt)), torch.tensor(z0))
+    y_ref, l_ref = orc.radial(np.array([0.2]), np.array([0.4]), z0, X)
+    y, l = bj.with_logabsdet_jacobian(rad, dev(X))
+    check("radial", y, l, y_ref, l_ref)
+    b_, logs, m, v = r.normal(size=dim).astype(dt), (0.3 * r.normal(size=dim)).astype(dt), r.normal(size=dim).astype(dt), r.uniform(0.5, 2, size=dim).astype(dt)
+    bn = bj.InvertibleBatchNorm(torch.tensor(b_), torch.tensor(logs), torch.tensor(m), torch.tensor(v), eps=1e-5)
+    y_ref, l_ref = orc.batchnorm(b_, logs, m, v, 1e-5, X)
+    y, l = bj.with_logabsdet_jacobian(bn, dev(X))
+    check("batchnorm", y, l, y_ref, l_ref)
+    K = 8
+    wk, hk, dk = orc.rqs_params(r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K - 1)).astype(dt), 3.0)
+    sp = bj.RationalQuadraticSpline(dev(wk), dev(hk), dev(dk))
+    for inv in (False, True):
+        y_ref, l_ref = orc.rqs(wk, hk, dk, X, inverse=inv)
+        y, l = bj.with_logabsdet_jacobian(bj.inverse(sp) if inv else sp, dev(X), per_sample=True)
+        check(f"rqs inv={inv}", y, l, y_ref, l_ref)
+    Kc = 9
+    n = Kc * (Kc - 1) // 2
+    yv = np.asfortranarray((0.5 * r.normal(size=(n, N))).astype(dt))
+    for c, k in bad.items():
+        yv[k % n, c] = np.nan
+    for uplo in "UL":
+        W_ref, lj_ref = orc.vec_cholesky(yv, inverse=True, uplo=uplo)
+        W, lj = bj.with_logabsdet_jacobian(bj.inverse(bj.VecCholeskyBijector(uplo)), dev(yv), per_sample=True)
+        check("chol inv " + uplo, W, lj, W_ref, lj_ref)
