@@ -112,10 +112,9 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
       BJX_FOR_UJ {
         const T x = p[u].v[j];
         const T inv = F::rcp(b[u][j] - a[u][j]);
-        const T xa = x - a[u][j];
-        l[u] -= F::log(xa * (b[u][j] - x) * inv);
-        const T z = xa * inv;
-        p[u].v[j] = F::log(z * F::rcp(T(1) - z));               // LogExpFunctions.logit
+        const T xa = x - a[u][j], xb = b[u][j] - x;
+        l[u] -= F::log(xa * xb * inv);
+        p[u].v[j] = F::log(xa * F::rcp(xb));                    // logit((x-a)/(b-a)) = log((x-a)/(b-x)), exact at the bounds (±Inf)
       }
       break;
     case BJX_OP_LOGIT_INV:  // logit.jl:19 ; interface.jl:276-281
@@ -139,10 +138,11 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
         T x = d_clamp(p[u].v[j], lo, up);
         bool lb = d_isfinite(lo), ub = d_isfinite(up);
         if (lb && ub) {
-          const T inv = F::rcp(up - lo), xa = x - lo;
-          l[u] -= F::log(xa * (up - x) * inv);
-          const T z = xa * inv;
-          p[u].v[j] = F::log(z * F::rcp(T(1) - z));
+          // logit((x-a)/(b-a)) = log((x-a)/(b-x)): exact at the bounds (x = b gives +Inf and x = a gives -Inf like
+          // the reference's logit(1) / logit(0); z = (x-a)·rcp(b-a) can round to 1 ± ulp there)
+          const T inv = F::rcp(up - lo), xa = x - lo, xb = up - x;
+          l[u] -= F::log(xa * xb * inv);
+          p[u].v[j] = F::log(xa * F::rcp(xb));
         }
         else if (lb) { T t = F::log(x - lo); l[u] -= t; p[u].v[j] = t; }
         else if (ub) { T t = F::log(up - x); l[u] -= t; p[u].v[j] = t; }

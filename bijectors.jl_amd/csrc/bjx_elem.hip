@@ -21,7 +21,7 @@ template <class T> __device__ __forceinline__ int ssf(const T* v, int64_t st, in
 template <class T>
 __device__ __forceinline__ void rqs_forward_dev(const T* w_, const T* h_, const T* d_, int64_t st, int K, T x, T& y, T& lj) {
   const T wK = w_[(int64_t)(K - 1) * st];
-  if ((x <= -wK) || (x >= wK)) { y = x; lj = T(0); return; }   // :324-326
+  if ((x <= -wK) || (x >= wK)) { y = x; lj = T(0) * x; return; }   // :322-324 (`zero(T) * x`: NaN for ±Inf)
   int k = ssf<T>(w_, st, K, x) - 1;
   T w_k = (k == 0) ? -wK : w_[(int64_t)(k - 1) * st];
   T w = w_[(int64_t)k * st] - w_k;
@@ -282,7 +282,7 @@ __device__ __forceinline__ T rqs_eval(const Rec4<T>& A, const Rec4<T>& B, T lim,
   // comparisons are false in the reference too) and leaves through the arithmetic as NaN value and NaN log-det
   const bool outside = d_abs(xin) >= lim;
   x = outside ? xin : res;
-  return outside ? T(0) : lj;
+  return outside ? T(0) * xin : lj;                                          // `zero(T) * x` (:272, :323): NaN for x = ±Inf, like the reference
 }
 
 // pos = 2*pos + (key < x): one compare + one add-with-carry (the compiler's own lowering of this

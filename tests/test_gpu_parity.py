@@ -1815,8 +1815,9 @@ def test_simplex_forward_nan_rows(bj, orc, K, dt):
     close(l[good], l_ref[good], dt, scale=K * 10, what="finite columns ladj")
 
 
+@pytest.mark.parametrize("val", [np.nan, np.inf, -np.inf])
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-def test_nan_inputs_poison_exactly_what_the_reference_poisons(bj, orc, dt):
+def test_nan_inputs_poison_exactly_what_the_reference_poisons(bj, orc, dt, val):
     """One NaN per marked column: values and per-sample log-dets must be NaN exactly where the oracle's are (hardware
     min/max/med3 drop NaNs, Julia's clamp/max keep them), every other column must be untouched."""
     r = rng(150)
@@ -1827,15 +1828,18 @@ def test_nan_inputs_poison_exactly_what_the_reference_poisons(bj, orc, dt):
         y, l = host(y), host(l)
         assert np.array_equal(np.isnan(y), np.isnan(y_ref)), f"{name}: NaN pattern of the values"
         assert np.array_equal(np.isnan(l), np.isnan(l_ref)), f"{name}: NaN pattern of the log-dets"
-        ok = ~np.isnan(y_ref)
+        for s_ in (np.inf, -np.inf):                                      # ±Inf results: same places, same signs
+            assert np.array_equal(y == s_, y_ref == s_), f"{name}: {s_} pattern of the values"
+            assert np.array_equal(l == s_, l_ref == s_), f"{name}: {s_} pattern of the log-dets"
+        ok = np.isfinite(y_ref)
         close(y[ok], y_ref[ok], dt, scale=scale, what=name)
-        okl = ~np.isnan(l_ref)
+        okl = np.isfinite(l_ref)
         close(l[okl], l_ref[okl], dt, scale=scale * dim, what=name + " ladj")
 
     def poisoned(X):
         X = X.copy()
         for c, k in bad.items():
-            X[k % X.shape[0], c] = np.nan
+            X[k % X.shape[0], c] = val
         return np.asfortranarray(X.astype(dt))
 
     def per_sample_chain(ops, X):
@@ -1855,16 +1859,19 @@ def test_nan_inputs_poison_exactly_what_the_reference_poisons(bj, orc, dt):
         b = bj.inverse(bj.OrderedBijector()) if inv else bj.OrderedBijector()
         y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
         check(f"ordered inv={inv}", y, l, y_ref, l_ref, scale=100)
-    w = (r.normal(size=(dim, 3)) / 8).astype(dt); u = (r.normal(size=(dim, 3)) / 8).astype(dt); bb = r.normal(size=3).astype(dt)
-    fl = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(bb))
-    y_ref, l_ref = orc.planar(w, u, bb, X)
-    y, l = bj.with_logabsdet_jacobian(fl, dev(X))
-    check("planar", y, l, y_ref, l_ref)
-    z0 = r.normal(size=dim).astype(dt)
-    rad = bj.RadialLayer(torch.tensor(np.array([0.2], dtype=dt)), torch.tensor(np.array([0.4], dtype=dt)), torch.tensor(z0))
-    y_ref, l_ref = orc.radial(np.array([0.2]), np.array([0.4]), z0, X)
-    y, l = bj.with_logabsdet_jacobian(rad, dev(X))
-    check("radial", y, l, y_ref, l_ref)
+    if np.isnan(val):
+        # ±Inf is outside the parity contract of the fused flow kernels: they reassociate the layer recurrence
+        # (w_kᵀz_{k-1} = w_kᵀz_0 + Σ_j (w_kᵀû_j)t_j, zero-padded layer groups), and 0·Inf poisons the whole column
+        w = (r.normal(size=(dim, 3)) / 8).astype(dt); u = (r.normal(size=(dim, 3)) / 8).astype(dt); bb = r.normal(size=3).astype(dt)
+        fl = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(bb))
+        y_ref, l_ref = orc.planar(w, u, bb, X)
+        y, l = bj.with_logabsdet_jacobian(fl, dev(X))
+        check("planar", y, l, y_ref, l_ref)
+        z0 = r.normal(size=dim).astype(dt)
+        rad = bj.RadialLayer(torch.tensor(np.array([0.2], dtype=dt)), torch.tensor(np.array([0.4], dtype=dt)), torch.tensor(z0))
+        y_ref, l_ref = orc.radial(np.array([0.2]), np.array([0.4]), z0, X)
+        y, l = bj.with_logabsdet_jacobian(rad, dev(X))
+        check("radial", y, l, y_ref, l_ref)
     b_, logs, m, v = r.normal(size=dim).astype(dt), (0.3 * r.normal(size=dim)).astype(dt), r.normal(size=dim).astype(dt), r.uniform(0.5, 2, size=dim).astype(dt)
     bn = bj.InvertibleBatchNorm(torch.tensor(b_), torch.tensor(logs), torch.tensor(m), torch.tensor(v), eps=1e-5)
     y_ref, l_ref = orc.batchnorm(b_, logs, m, v, 1e-5, X)
@@ -1881,8 +1888,32 @@ def test_nan_inputs_poison_exactly_what_the_reference_poisons(bj, orc, dt):
     n = Kc * (Kc - 1) // 2
     yv = np.asfortranarray((0.5 * r.normal(size=(n, N))).astype(dt))
     for c, k in bad.items():
-        yv[k % n, c] = np.nan
+        yv[k % n, c] = val
     for uplo in "UL":
         W_ref, lj_ref = orc.vec_cholesky(yv, inverse=True, uplo=uplo)
         W, lj = bj.with_logabsdet_jacobian(bj.inverse(bj.VecCholeskyBijector(uplo)), dev(yv), per_sample=True)
         check("chol inv " + uplo, W, lj, W_ref, lj_ref)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_logit_and_truncated_are_exact_at_their_bounds(bj, orc, dt):
+    """x = a / x = b map to -Inf / +Inf (LogExpFunctions.logit(0) / logit(1)) with log-det +Inf, as in the reference;
+    the kernel's log((x-a)/(b-x)) form cannot round (x-a)/(b-a) past 1."""
+    r = rng(151)
+    for lo, up in ((-1.0, 2.0), (0.0, 1.0), (0.3, 0.7000001), (-1e3, 3e3)):
+        X = r.uniform(lo, up, size=(16, 40))
+        X[3, 5], X[4, 6], X[0, 7], X[15, 8] = lo, up, up, lo
+        X = np.asfortranarray(X.astype(dt))
+        lo_t, up_t = float(dt(lo)), float(dt(up))
+        X[X < lo_t] = lo_t
+        X[X > up_t] = up_t
+        for b, ops in ((bj.Logit(lo_t, up_t), [(orc.OP_LOGIT, lo_t, up_t)]), (bj.TruncatedBijector(lo_t, up_t), [(orc.OP_TRUNCATED, lo_t, up_t)])):
+            y_ref, _ = orc.chain(ops, X)
+            y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+            y, l = host(y), host(l)
+            assert np.array_equal(y == np.inf, y_ref == np.inf) and np.array_equal(y == -np.inf, y_ref == -np.inf)
+            assert not np.any(np.isnan(y))
+            assert y[3, 5] == -np.inf and y[4, 6] == np.inf and y[0, 7] == np.inf and y[15, 8] == -np.inf
+            assert np.all(l[[5, 6, 7, 8]] == np.inf)
+            fin = np.isfinite(y_ref)
+            close(y[fin], y_ref[fin], dt, scale=10)
