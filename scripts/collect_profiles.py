@@ -73,7 +73,9 @@ def main(tag):
     json.dump(traffic, open(traffic_path, "w"), indent=1)
     pt = os.path.join(src, "pytest_gpu.txt")
     if os.path.exists(pt):
-        open(os.path.join(dst, f"{tag}_pytest_gpu_tail.txt"), "w").write("".join(open(pt).readlines()[-5:]))
+        ls = open(pt).readlines()
+        keep = [l for l in ls if " passed" in l or " failed" in l or l.startswith("FAILED")] or ls[-5:]
+        open(os.path.join(dst, f"{tag}_pytest_gpu_tail.txt"), "w").write("".join(keep))
     print(json.dumps({k: v for k, v in traffic.items() if k != "_how"}, indent=1)[:3000])
 
 
