@@ -50,6 +50,18 @@ struct SegDev {                      // device copy of one bjx_segment (pointers
   const void* v1[BJX_MAX_SEG_OPS];
 };
 
+// A few segment descriptors as one kernel argument (<= 4 KiB), stored to the device list by a 1-wave launch.
+struct SegPack {
+  static constexpr int N = (3584 / (int)sizeof(SegDev)) < 1 ? 1 : (3584 / (int)sizeof(SegDev));
+  SegDev s[N];
+};
+__global__ void stacked_seg_store_kernel(const SegPack pk, int cnt, SegDev* __restrict__ dst) {
+  const int words = cnt * (int)(sizeof(SegDev) / 8);
+  const int64_t* src = reinterpret_cast<const int64_t*>(pk.s);
+  int64_t* d = reinterpret_cast<int64_t*>(dst);
+  for (int i = threadIdx.x; i < words; i += blockDim.x) d[i] = src[i];
+}
+
 // Table layout: one entry of STACKED_SLOTS slots per OUTPUT row, padded to an ODD number of 16-byte units
 // (7 for Float32, 11 for Float64) and indexed by the PERMUTED row rp = (row % V)·nvc + row / V, so that
 // the rows one wave instruction touches (same element of consecutive packs) are adjacent: their 16-byte
@@ -315,31 +327,46 @@ int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const voi
     }
     BJX_REQUIRE(ctx, cur < STACKED_SLOTS, BJX_ERR_UNSUPPORTED, "bjx_stacked: the chain of segment %d needs more than %d nonlinear stages", sg, STACKED_SLOTS);
   }
-  // segment list -> device through the context's pinned staging buffer (asynchronous; the event guards its reuse)
-  BJX_REQUIRE(ctx, seg_bytes <= BJX_HOST_STAGE_BYTES, BJX_ERR_UNSUPPORTED, "bjx_stacked: too many segments (%d)", n_segs);
-  if (!ctx->host_stage) {
-    BJX_HIP(ctx, hipHostMalloc(&ctx->host_stage, BJX_HOST_STAGE_BYTES, hipHostMallocDefault));
-    BJX_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev, hipEventDisableTiming));
-  } else {
-    BJX_HIP(ctx, hipEventSynchronize(ctx->stage_ev));      // the previous call's copy has left the buffer
-  }
-  SegDev* hseg = static_cast<SegDev*>(ctx->host_stage);
-  for (int s = 0; s < n_segs; ++s) {
+  auto fill = [&](int sg) {
     SegDev d{};
-    d.in_lo = segs[s].in_lo; d.out_lo = segs[s].out_lo; d.len = segs[s].len; d.n_ops = segs[s].n_ops;
-    for (int k = 0; k < segs[s].n_ops; ++k) {
-      d.kind[k] = segs[s].ops[k].kind; d.plen[k] = segs[s].ops[k].param_len;
-      d.s0[k] = segs[s].ops[k].p0; d.s1[k] = segs[s].ops[k].p1; d.v0[k] = segs[s].ops[k].v0; d.v1[k] = segs[s].ops[k].v1;
+    d.in_lo = segs[sg].in_lo; d.out_lo = segs[sg].out_lo; d.len = segs[sg].len; d.n_ops = segs[sg].n_ops;
+    for (int k = 0; k < segs[sg].n_ops; ++k) {
+      d.kind[k] = segs[sg].ops[k].kind; d.plen[k] = segs[sg].ops[k].param_len;
+      d.s0[k] = segs[sg].ops[k].p0; d.s1[k] = segs[sg].ops[k].p1; d.v0[k] = segs[sg].ops[k].v0; d.v1[k] = segs[sg].ops[k].v1;
     }
-    hseg[s] = d;
-  }
+    return d;
+  };
   char* sc = static_cast<char*>(ctx->scratch);
   int* flag = reinterpret_cast<int*>(sc);
   SegDev* dseg = reinterpret_cast<SegDev*>(sc + 64);
   char* tab = sc + 64 + seg_bytes;
   BJX_HIP(ctx, hipMemsetAsync(flag, 0, 64, ctx->stream));
-  if (n_segs) BJX_HIP(ctx, hipMemcpyAsync(dseg, hseg, (size_t)n_segs * sizeof(SegDev), hipMemcpyHostToDevice, ctx->stream));
-  BJX_HIP(ctx, hipEventRecord(ctx->stage_ev, ctx->stream));
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(ctx->stream, &cap);
+  if (n_segs <= 8 * SegPack::N || cap != hipStreamCaptureStatusNone) {
+    // segment list -> device as KERNEL ARGUMENTS, SegPack::N segments per tiny launch: no pinned staging buffer, no
+    // event wait between calls, and the call can be captured into a hipGraph (the descriptors live in the graph node)
+    for (int s0 = 0; s0 < n_segs; s0 += SegPack::N) {
+      SegPack pk;
+      const int cnt = n_segs - s0 < SegPack::N ? n_segs - s0 : SegPack::N;
+      for (int i = 0; i < cnt; ++i) pk.s[i] = fill(s0 + i);
+      hipLaunchKernelGGL(stacked_seg_store_kernel, dim3(1), dim3(64), 0, ctx->stream, pk, cnt, dseg + s0);
+      BJX_CHECK_LAUNCH(ctx);
+    }
+  } else {
+    // long segment lists: through the context's pinned staging buffer (asynchronous; the event guards its reuse)
+    BJX_REQUIRE(ctx, seg_bytes <= BJX_HOST_STAGE_BYTES, BJX_ERR_UNSUPPORTED, "bjx_stacked: too many segments (%d)", n_segs);
+    if (!ctx->host_stage) {
+      BJX_HIP(ctx, hipHostMalloc(&ctx->host_stage, BJX_HOST_STAGE_BYTES, hipHostMallocDefault));
+      BJX_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev, hipEventDisableTiming));
+    } else {
+      BJX_HIP(ctx, hipEventSynchronize(ctx->stage_ev));      // the previous call's copy has left the buffer
+    }
+    SegDev* hseg = static_cast<SegDev*>(ctx->host_stage);
+    for (int sg = 0; sg < n_segs; ++sg) hseg[sg] = fill(sg);
+    BJX_HIP(ctx, hipMemcpyAsync(dseg, hseg, (size_t)n_segs * sizeof(SegDev), hipMemcpyHostToDevice, ctx->stream));
+    BJX_HIP(ctx, hipEventRecord(ctx->stage_ev, ctx->stream));
+  }
   // the main kernel's pack width decides the row permutation of the table (same rule as col_launch_cfg)
   ColLaunch cl = col_launch_cfg<T>(ctx, x, y, dim, batch);
   if (!packs_ok) cl.V = 1;                               // a third buffer of the caller is not 16-byte aligned

@@ -180,7 +180,24 @@ def _param(p, like: torch.Tensor) -> torch.Tensor:
     """device tensor for a parameter (python number / sequence / tensor)."""
     if not isinstance(p, torch.Tensor):
         p = torch.as_tensor(p, dtype=like.dtype, device=like.device)
-    p = p.to(device=like.device, dtype=like.dtype)
+    if p.device != like.device or p.dtype != like.dtype:
+        # host-resident (or other-dtype) parameters: upload / convert ONCE per (device, dtype) and parameter version,
+        # not on every call (a synchronous H2D copy per launch, and not capturable into a hipGraph)
+        cache = getattr(p, "_bjx_dev", None)
+        key = (like.device, like.dtype)
+        hit = cache.get(key) if cache is not None else None
+        if hit is not None and hit[0] == p._version:
+            p = hit[1]
+        else:
+            q = p.to(device=like.device, dtype=like.dtype)
+            try:
+                if cache is None:
+                    cache = {}
+                    p._bjx_dev = cache
+                cache[key] = (p._version, q)
+            except Exception:
+                pass
+            p = q
     if p.dim() == 2 and _colmajor_dense(p):
         return p  # already Julia-layout: no row-major round trip (2 copy kernels per call)
     return p.contiguous()

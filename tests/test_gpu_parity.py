@@ -1917,3 +1917,72 @@ def test_logit_and_truncated_are_exact_at_their_bounds(bj, orc, dt):
             assert np.all(l[[5, 6, 7, 8]] == np.inf)
             fin = np.isfinite(y_ref)
             close(y[fin], y_ref[fin], dt, scale=10)
+
+
+def _graph_cases(bj, orc, r, dt):
+    """(name, callable on device tensors -> tuple of tensors, inputs A, inputs B, oracle on numpy inputs)"""
+    dim, N = 16, 33
+    cases = []
+
+    def two(gen):
+        return gen(), gen()
+
+    a_vec = np.linspace(0.5, 1.5, dim)
+    ch = bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(torch.tensor(a_vec))
+    ops = [(orc.OP_SCALE, a_vec, None), (orc.OP_SHIFT, 0.1, None), (orc.OP_EXP, None, None)]
+    xa, xb = two(lambda: np.asfortranarray(r.normal(size=(dim, N)).astype(dt)))
+    cases.append(("chain", lambda x: bj.with_logabsdet_jacobian(ch, x), (xa,), (xb,), lambda x: orc.chain(ops, x)))
+    cases.append(("ordered", lambda x: bj.with_logabsdet_jacobian(bj.OrderedBijector(), x), (xa,), (xb,), lambda x: orc.ordered(x)))
+    pa, pb = two(lambda: np.asfortranarray(r.dirichlet(3.0 * np.ones(dim), size=N).T.astype(dt)))
+    cases.append(("simplex", lambda x: bj.with_logabsdet_jacobian(bj.SimplexBijector(), x, per_sample=True), (pa,), (pb,), lambda x: orc.simplex(x)))
+    ya, yb = two(lambda: np.asfortranarray(r.normal(size=(dim - 1, N)).astype(dt)))
+    cases.append(("simplex inverse", lambda y: bj.with_logabsdet_jacobian(bj.inverse(bj.SimplexBijector()), y, per_sample=True), (ya,), (yb,),
+                  lambda y: orc.simplex(y, inverse=True)))
+    w = (r.normal(size=(dim, 3)) / 4).astype(dt); u = (r.normal(size=(dim, 3)) / 4).astype(dt); bb = r.normal(size=3).astype(dt)
+    fl = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(bb))
+    cases.append(("planar", lambda x: bj.with_logabsdet_jacobian(fl, x), (xa,), (xb,), lambda x: orc.planar(w, u, bb, x)))
+    cases.append(("planar inverse", lambda x: bj.with_logabsdet_jacobian(bj.inverse(fl), x), (xa,), (xb,), lambda x: orc.planar(w, u, bb, x, inverse=True)))
+    K = 6
+    wk, hk, dk = orc.rqs_params(r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K - 1)).astype(dt), 3.0)
+    sp = bj.RationalQuadraticSpline(dev(wk), dev(hk), dev(dk))
+    cases.append(("rqs", lambda x: bj.with_logabsdet_jacobian(sp, x, per_sample=True), (xa,), (xb,), lambda x: orc.rqs(wk, hk, dk, x)))
+    Kc = 6
+    n = Kc * (Kc - 1) // 2
+    va, vb = two(lambda: np.asfortranarray((0.5 * r.normal(size=(n, N))).astype(dt)))
+    cases.append(("chol inverse", lambda y: bj.with_logabsdet_jacobian(bj.inverse(bj.VecCholeskyBijector("U")), y, per_sample=True), (va,), (vb,),
+                  lambda y: orc.vec_cholesky(y, inverse=True, uplo="U")))
+    st = bj.Stacked([bj.elementwise(bj.exp), bj.identity, bj.Logit(-5.0, 5.0)], [(1, 5), (6, 8), (9, 16)])
+    segs = [([(orc.OP_EXP, None, None)], (1, 5)), ([], (6, 8)), ([(orc.OP_LOGIT, -5.0, 5.0)], (9, 16))]
+    cases.append(("stacked", lambda x: bj.with_logabsdet_jacobian(st, x, per_sample=True), (xa,), (xb,), lambda x: _stacked_oracle(orc, segs, x)))
+    ga, gb = two(lambda: np.asfortranarray(r.normal(size=(dim, N)).astype(dt)))
+    cases.append(("vjp chain", lambda x, g: (bj.vjp(ch, x, g),), (xa, ga), (xb, gb), lambda x, g: (orc.chain_vjp(ops, x.astype(np.float64), g.astype(np.float64)),)))
+    return cases
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_hip_graph_capture_and_replay(bj, orc, dt):
+    """Small batches are launch-bound (a `with_logabsdet_jacobian` of a 16 x 33 matrix is a few 8 µs launches): the
+    calls are capturable into a hipGraph — no allocation, synchronisation or host read-back on the launch path once
+    the context of the stream is warm — and a replay on new data in the same buffers gives the oracle's values."""
+    r = rng(160)
+    s = torch.cuda.Stream()
+    for name, fn, ins_a, ins_b, ref in _graph_cases(bj, orc, r, dt):
+        static = [dev(a).clone() for a in ins_a]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            fn(*static)                                   # warm-up on the capture stream: context, scratch, kernels
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            outs = fn(*static)
+        for t, b_ in zip(static, ins_b):
+            t.copy_(dev(b_))
+        g.replay()
+        torch.cuda.synchronize()
+        exp = ref(*ins_b)
+        for o, e in zip(outs, exp):
+            o, e = host(o), np.asarray(e)
+            if e.ndim == 0 or o.ndim == 0:
+                sum_close(o, float(e), dt, ins_b[0].size, what=f"graph {name} (summed log-det)")
+            else:
+                np.testing.assert_allclose(o, e, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 50 * max(1.0, float(np.abs(e[np.isfinite(e)]).max())), err_msg=f"graph {name}")
