@@ -127,12 +127,14 @@ __global__ __launch_bounds__(256) void stacked_table_kernel(const SegDev* segs, 
         switch (kind) {
           case BJX_OP_EXP: s->kind = SK_EXP; break;
           case BJX_OP_LOG: s->kind = SK_LOG; break;
-          case BJX_OP_LOGIT: { const T w = hi - lo; s->a1 = s->a1 / w; s->b1 = (s->b1 - lo) / w; s->c -= d_log(w); s->kind = SK_LOGIT; } break;
+          // SK_LOGIT works on u = x' - lo in [0, w] (w kept in `alpha`): N(u) = log(u/(w-u)) is exact at both bounds
+          // (u = 0 and w - u = 0 there; (x'-lo)/w can round to 1 ± ulp), log|N'| = log w - log(u(w-u))
+          case BJX_OP_LOGIT: { const T w = hi - lo; s->b1 = s->b1 - lo; s->alpha = w; s->c += d_log(w); s->kind = SK_LOGIT; } break;
           case BJX_OP_LOGIT_INV: { const T w = hi - lo; s->a2 = w; s->b2 = lo; s->c += d_log(w); s->kind = SK_LOGISTIC; } break;
           case BJX_OP_LEAKY_RELU: s->kind = SK_LEAKY; s->alpha = a; break;
           case BJX_OP_TRUNCATED:
             s->clo = lo; s->chi = hi;
-            if (lb && ub) { const T w = hi - lo; s->a1 = T(1) / w; s->b1 = -lo / w; s->c -= d_log(w); s->kind = SK_LOGIT; }
+            if (lb && ub) { const T w = hi - lo; s->a1 = T(1); s->b1 = -lo; s->alpha = w; s->c += d_log(w); s->kind = SK_LOGIT; }
             else if (lb) { s->b1 = -lo; s->kind = SK_LOG; }
             else if (ub) { s->a1 = T(-1); s->b1 = hi; s->kind = SK_LOG; }
             else s->kind = SK_ID;
@@ -169,7 +171,7 @@ template <class T> __device__ __forceinline__ T slot_eval(const Slot<T>& s, T& x
   switch (s.kind) {
     case SK_EXP: v = F::exp(u); l += u; break;                                                        // exp_log.jl:5-6
     case SK_LOG: v = F::log(u); l -= v; break;                                                        // exp_log.jl:8-9
-    case SK_LOGIT: { l -= F::log(u * (T(1) - u)); v = F::log(u * F::rcp(T(1) - u)); } break;         // logit.jl:15,24
+    case SK_LOGIT: { const T q = s.alpha - u; l -= F::log(u * q); v = F::log(u * F::rcp(q)); } break;   // logit.jl:15,24
     case SK_LOGISTIC: { const T au = d_abs(u); v = f_logistic(u); l += -au - T(2) * f_log1pexp(-au); } break;   // logit.jl:19, truncated.jl:71-82
     case SK_LEAKY: { const T J = u < T(0) ? s.alpha : T(1); v = J * u; l += d_log(d_abs(J)); } break; // leaky_relu.jl:25-29
     default: break;
@@ -197,7 +199,7 @@ template <class T, int U> __device__ __forceinline__ void slot_eval_multi(const 
       break;
     case SK_LOGIT:
 #pragma unroll
-      for (int i = 0; i < U; ++i) { l[i] -= F::log(u[i] * (T(1) - u[i])); v[i] = F::log(u[i] * F::rcp(T(1) - u[i])); }
+      for (int i = 0; i < U; ++i) { const T q = s.alpha - u[i]; l[i] -= F::log(u[i] * q); v[i] = F::log(u[i] * F::rcp(q)); }
       break;
     case SK_LOGISTIC:
 #pragma unroll
@@ -399,7 +401,7 @@ int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, 
 // ------------------------------------------------------------------ pullback (elementwise part)
 // x_bar = (dy/dx) y_bar + ladj_bar (d ladj / dx), element by element through the same canonical slots:
 //   u = a1 clamp(x) + b1,  v = N(u),  y = clamp(a2 v + b2):   dy/dx = a2 N'(u) a1 (0 where a clamp is active),
-//   d ladj/dx = l_N'(u) a1.   N: exp (v, 1) | log (1/u, -1/u) | logit (1/(u(1-u)), -(1-2u)/(u(1-u))) |
+//   d ladj/dx = l_N'(u) a1.   N: exp (v, 1) | log (1/u, -1/u) | logit on [0, w] (w/(u(w-u)), -(w-2u)/(u(w-u))) |
 //   logistic (s(1-s), 1-2s) | leaky (J, 0) | id (1, 0).   Two slots chain: x -> x1 -> y.
 template <class T> __device__ __forceinline__ void slot_grad(const Slot<T>& s, T x, T& y, T& dy, T& dl) {
   using F = Fast<T>;
@@ -410,7 +412,7 @@ template <class T> __device__ __forceinline__ void slot_grad(const Slot<T>& s, T
   switch (s.kind) {
     case SK_EXP: v = F::exp(u); np = v; lp = T(1); break;
     case SK_LOG: { const T r = F::rcp(u); v = F::log(u); np = r; lp = -r; } break;
-    case SK_LOGIT: { const T r = F::rcp(u * (T(1) - u)); v = F::log(u * F::rcp(T(1) - u)); np = r; lp = -(T(1) - 2 * u) * r; } break;
+    case SK_LOGIT: { const T q = s.alpha - u; const T r = F::rcp(u * q); v = F::log(u * F::rcp(q)); np = s.alpha * r; lp = -(q - u) * r; } break;
     case SK_LOGISTIC: { v = f_logistic(u); np = v * (T(1) - v); lp = T(1) - 2 * v; } break;
     case SK_LEAKY: { const T J = u < T(0) ? s.alpha : T(1); v = J * u; np = J; } break;
     default: break;

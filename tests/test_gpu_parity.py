@@ -1917,6 +1917,18 @@ def test_logit_and_truncated_are_exact_at_their_bounds(bj, orc, dt):
             assert np.all(l[[5, 6, 7, 8]] == np.inf)
             fin = np.isfinite(y_ref)
             close(y[fin], y_ref[fin], dt, scale=10)
+            # the same bijector as a Stacked segment (canonical-slot kernel)
+            st = bj.Stacked([bj.identity, b], [(1, 2), (3, 16)])
+            Xs = np.asfortranarray(X.copy())
+            Xs[:2] = 0.5
+            ys_ref, _ = orc.chain(ops, np.asfortranarray(Xs[2:]))
+            ys, ls = bj.with_logabsdet_jacobian(st, dev(Xs), per_sample=True)
+            ys, ls = host(ys)[2:], host(ls)
+            assert not np.any(np.isnan(ys))
+            assert np.array_equal(ys == np.inf, ys_ref == np.inf) and np.array_equal(ys == -np.inf, ys_ref == -np.inf)
+            assert np.all(ls[[5, 6, 8]] == np.inf)
+            fin = np.isfinite(ys_ref)
+            close(ys[fin], ys_ref[fin], dt, scale=10)
 
 
 def _graph_cases(bj, orc, r, dt):
