@@ -216,3 +216,27 @@ def test_vector_links_and_density_op_lists(bj):
     assert [k for k, _, _ in d._color_ops()] == [L.OP_SCALE, L.OP_SHIFT]
     assert bj.MvNormal(3)._whiten_ops() == [] and bj.MvNormal(3).dim == 3
     assert L.OP_STDNORMAL_LOGPDF == 13 and L.BJX_BASE_STDNORMAL == 4 and L.BJX_INPUT_STDNORMAL == 8
+
+
+def test_julia_binding_argument_counts_match_the_header():
+    """julia/BijectorsBJX.jl (the binding INTEGRATION.md shows) must call every entry point with the number of
+    arguments include/bjx.h declares."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = open(os.path.join(root, "include", "bjx.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    h = re.sub(r"//.*", "", h)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|void|const char\s*\*|size_t)\s+(bjx_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", h, flags=re.S):
+        args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
+        protos[m.group(1)] = len(args)
+    assert len(protos) >= 43
+    j = open(os.path.join(root, "julia", "BijectorsBJX.jl")).read()
+    calls = list(re.finditer(r"ccall\(\(:(bjx_[a-z0-9_]+),\s*\w+\),\s*\w+,\s*\(([^)]*)\)", j))
+    assert len(calls) >= 10
+    for m in calls:
+        name, types = m.group(1), [t.strip() for t in m.group(2).split(",") if t.strip()]
+        assert name in protos, f"{name} is not declared in include/bjx.h"
+        assert protos[name] == len(types), f"{name}: header has {protos[name]} arguments, the Julia ccall passes {len(types)}"
