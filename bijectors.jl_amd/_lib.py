@@ -71,6 +71,7 @@ SIGNATURES = {
     "bjx_vec_cholesky": (_i, [_vp, _i, _i, _i, _vp, _vp] + _tail),
     "bjx_planar": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp] + _tail),
     "bjx_planar_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "bjx_radial_vjp_params": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_planar_vjp_params": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_radial": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp] + _tail),
     "bjx_radial_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),

@@ -1164,7 +1164,9 @@ __global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, cons
 // Same mapping as radial_kernel: G lanes own a column in registers; two group reductions (‖δ‖², δᵀḡ) per column.
 template <class T, int V, int R, bool INV>
 __global__ __launch_bounds__(256) void radial_vjp_kernel(const RadialArgs<T> A, const T* __restrict__ x, const T* __restrict__ gbar,
-                                                         const T* __restrict__ lbar, T* __restrict__ xbar, int64_t dim, int64_t batch, int G) {
+                                                         const T* __restrict__ lbar, T* __restrict__ xbar, int64_t dim, int64_t batch, int G,
+                                                         T* __restrict__ work = nullptr) {
+  // work (forward map only, may be null): r and δᵀȳ of every column, [2, batch] — the inputs of the parameter pullback
   constexpr int UC = R == 1 ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* tab = reinterpret_cast<T*>(smem);
@@ -1230,6 +1232,7 @@ __global__ __launch_bounds__(256) void radial_vjp_kernel(const RadialArgs<T> A, 
     const T lr = T(dim - 1) * (-bh * h * h) / a + (T(-2) * bh * h * h + T(2) * bh * h * h * h * rr) / (T(1) + bh * h - bh * h * h * rr);
     const T lb = lbar ? lbar[col] : T(0);
     const T kl = lb * lr * rinv;             // coefficient of δ from the log-det term
+    if (!INV && work && col_ok && gl == 0) { work[col] = rr; work[batch + col] = dg; }
     T ca, cd;                                // out = ca · ḡ + cd · δ_in   (δ_in = input - z₀; δ = gain · δ_in)
     if (!INV) { ca = a; cd = c * dg + kl; }
     else {
@@ -1785,7 +1788,7 @@ BJX_API int bjx_planar_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* 
 namespace {
 template <class T>
 int radial_vjp_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const T* z0, const T* in, const T* out_bar, const T* ladj_bar,
-                    T* in_bar, int64_t dim, int64_t batch) {
+                    T* in_bar, int64_t dim, int64_t batch, T* work = nullptr) {
   if (batch == 0) return BJX_OK;
   FlowCfg c;
   BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, in_bar, dim, batch, &c), BJX_ERR_UNSUPPORTED, "bjx_radial_vjp: dim %lld too large for the register-resident kernel", (long long)dim);
@@ -1810,16 +1813,96 @@ int radial_vjp_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, c
   const size_t smem = lds ? tab_bytes : 0;
   BjxProf prof_(ctx);
   if (c.V == VW) {
-    if (!inverse) { FLOW_SWITCH_R(radial_vjp_kernel, T, VW, false, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G) }
-    else { FLOW_SWITCH_R(radial_vjp_kernel, T, VW, true, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G) }
+    if (!inverse) { FLOW_SWITCH_R(radial_vjp_kernel, T, VW, false, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, work) }
+    else { FLOW_SWITCH_R(radial_vjp_kernel, T, VW, true, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, work) }
   } else {
-    if (!inverse) { FLOW_SWITCH_R(radial_vjp_kernel, T, 1, false, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G) }
-    else { FLOW_SWITCH_R(radial_vjp_kernel, T, 1, true, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G) }
+    if (!inverse) { FLOW_SWITCH_R(radial_vjp_kernel, T, 1, false, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, work) }
+    else { FLOW_SWITCH_R(radial_vjp_kernel, T, 1, true, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, work) }
   }
   BJX_CHECK_LAUNCH(ctx);
   return BJX_OK;
 }
 }  // namespace
+
+namespace {
+// ------------------------------------------------------------------ Radial parameter pullback
+// radial_layer.jl:43-60 with α̂ = softplus(α_), β̂ = -α̂ + softplus(β), h = 1/(α̂ + r), a = 1 + β̂h, D = 1 + β̂h - β̂h²r:
+//   y = z + β̂hδ,  ℓ = (d-1) log a + log D.     Per column, from r and δᵀȳ (written by radial_vjp_kernel):
+//   g_β̂ = h δᵀȳ + ℓ̄ [(d-1)h/a + (h - h²r)/D],   g_α̂ = -h² [β̂ δᵀȳ + ℓ̄ ((d-1)β̂/a + (β̂ - 2β̂hr)/D)]   (∂h/∂α̂ = -h²)
+//   ᾱ_ = σ(α_)(Σ g_α̂ - Σ g_β̂),  β̄ = σ(β) Σ g_β̂ ;   z̄₀ = Σ_n (ȳ_n - z̄_n)  (y and ℓ depend on z, z₀ through δ = z - z₀ only).
+template <class T>
+__global__ __launch_bounds__(256) void radial_param_partial_kernel(const T* __restrict__ alpha_, const T* __restrict__ beta, const T* __restrict__ work,
+                                                                   const T* __restrict__ lbar, int64_t dim, int64_t batch, double* __restrict__ partials) {
+  __shared__ double red[8];
+  const double al = (double)d_log1pexp(alpha_[0]);
+  const double bh = -al + (double)d_log1pexp(beta[0]);
+  double ga = 0.0, gb = 0.0;
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < batch; n += (int64_t)gridDim.x * blockDim.x) {
+    const double r = (double)work[n], dg = (double)work[batch + n], lb = lbar ? (double)lbar[n] : 0.0;
+    const double h = 1.0 / (al + r), a = 1.0 + bh * h, D = 1.0 + bh * h - bh * h * h * r;
+    gb += h * dg + lb * ((double)(dim - 1) * h / a + (h - h * h * r) / D);
+    ga += -h * h * (bh * dg + lb * ((double)(dim - 1) * bh / a + (bh - 2.0 * bh * h * r) / D));
+  }
+  ga = group_sum<64>(ga); gb = group_sum<64>(gb);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave] = ga; red[4 + wave] = gb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    partials[2 * blockIdx.x + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+  }
+}
+template <class T>
+__global__ __launch_bounds__(256) void radial_param_finalize_kernel(const T* __restrict__ alpha_, const T* __restrict__ beta, const double* __restrict__ partials,
+                                                                    int nblocks, const double* __restrict__ sy, const double* __restrict__ sz, int64_t dim,
+                                                                    T* __restrict__ alpha_bar, T* __restrict__ beta_bar, T* __restrict__ z0_bar) {
+  for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) z0_bar[i] = (T)(sy[i] - sz[i]);
+  if (threadIdx.x == 0) {
+    double ga = 0.0, gb = 0.0;
+    for (int b = 0; b < nblocks; ++b) { ga += partials[2 * b]; gb += partials[2 * b + 1]; }
+    const double sa = 1.0 / (1.0 + exp(-(double)alpha_[0])), sb = 1.0 / (1.0 + exp(-(double)beta[0]));
+    alpha_bar[0] = (T)(sa * (ga - gb));
+    beta_bar[0] = (T)(sb * gb);
+  }
+}
+
+template <class T>
+int radial_vjp_params_impl(bjx_ctx* ctx, bjx_dtype dt, const T* alpha_, const T* beta, const T* z0, const T* in, const T* out_bar, const T* ladj_bar,
+                           T* in_bar, T* alpha_bar, T* beta_bar, T* z0_bar, T* work, int64_t dim, int64_t batch) {
+  BJX_REQUIRE(ctx, (size_t)(2 * (2 * dim + 1)) * sizeof(double) <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_radial_vjp_params: dim %lld too large", (long long)dim);
+  double* sy = reinterpret_cast<double*>(ctx->scratch);
+  double* sz = sy + (2 * dim + 1);
+  if (batch == 0) {
+    BJX_HIP(ctx, hipMemsetAsync(z0_bar, 0, (size_t)dim * sizeof(T), ctx->stream));
+    BJX_HIP(ctx, hipMemsetAsync(alpha_bar, 0, sizeof(T), ctx->stream));
+    BJX_HIP(ctx, hipMemsetAsync(beta_bar, 0, sizeof(T), ctx->stream));
+    return BJX_OK;
+  }
+  { int rc = radial_vjp_impl<T>(ctx, 0, alpha_, beta, z0, in, out_bar, ladj_bar, in_bar, dim, batch, work); if (rc) return rc; }
+  { int rc = bjx_row_moments(ctx, dt, out_bar, nullptr, sy, dim, batch); if (rc) return rc; }      // Σ_n ȳ  (rows)
+  { int rc = bjx_row_moments(ctx, dt, in_bar, nullptr, sz, dim, batch); if (rc) return rc; }       // Σ_n z̄
+  int nblocks = (int)((batch + 255) / 256);
+  if (nblocks > 512) nblocks = 512;
+  { int rc = bjx_ensure_partials(ctx, (size_t)2 * nblocks); if (rc) return rc; }
+  hipLaunchKernelGGL(radial_param_partial_kernel<T>, dim3(nblocks), dim3(256), 0, ctx->stream, alpha_, beta, work, ladj_bar, dim, batch, ctx->partials);
+  BJX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(radial_param_finalize_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, alpha_, beta, ctx->partials, nblocks, sy, sz, dim, alpha_bar, beta_bar, z0_bar);
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+}  // namespace
+
+BJX_API int bjx_radial_vjp_params(bjx_ctx* ctx, bjx_dtype dt, const void* alpha_, const void* beta, const void* z0, const void* in,
+                                  const void* out_bar, const void* ladj_bar, void* in_bar, void* alpha_bar, void* beta_bar, void* z0_bar,
+                                  void* work, int64_t dim, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_radial_vjp_params: bad size");
+  BJX_REQUIRE(ctx, alpha_ && beta && z0 && alpha_bar && beta_bar && z0_bar && ((in && out_bar && in_bar && work) || batch == 0), BJX_ERR_ARG,
+              "bjx_radial_vjp_params: null pointer");
+  if (dt == BJX_F32) return radial_vjp_params_impl<float>(ctx, dt, (const float*)alpha_, (const float*)beta, (const float*)z0, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, (float*)alpha_bar, (float*)beta_bar, (float*)z0_bar, (float*)work, dim, batch);
+  if (dt == BJX_F64) return radial_vjp_params_impl<double>(ctx, dt, (const double*)alpha_, (const double*)beta, (const double*)z0, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, (double*)alpha_bar, (double*)beta_bar, (double*)z0_bar, (double*)work, dim, batch);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_radial_vjp_params: bad dtype %d", (int)dt);
+}
 
 BJX_API int bjx_radial_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* alpha_, const void* beta, const void* z0, const void* in,
                            const void* out_bar, const void* ladj_bar, void* in_bar, int64_t dim, int64_t batch) {

@@ -1461,7 +1461,10 @@ def vjp_params(b, x, out_bar, ladj_bar=None):
     """Pullback of `with_logabsdet_jacobian(b, x)` onto the input AND the parameters of a PlanarLayer (stack):
     returns (x_bar, {"w": w_bar, "u": u_bar, "b": b_bar}) with the parameter cotangents summed over the batch and the
     shapes of b.w / b.u / b.b (bjx_planar_vjp_params; closed-form derivatives of planar_layer.jl:65-110).
+    For a RadialLayer: (x_bar, {"alpha_", "beta", "z_0"}) — see _vjp_params_radial.
     For a chain that starts with Scale and/or Shift: (z_bar, {"scale": σ̄, "shift": μ̄}) — see _vjp_params_leading_affine."""
+    if isinstance(b, RadialLayer):
+        return _vjp_params_radial(b, x, out_bar, ladj_bar)
     if not isinstance(b, PlanarLayer):
         return _vjp_params_leading_affine(b, x, out_bar, ladj_bar)
     xc, dim, batch, vec = _prep(x)
@@ -1486,6 +1489,28 @@ def vjp_params(b, x, out_bar, ladj_bar=None):
     if two_d:
         wb, ub = wb.T, ub.T                       # back to (dim, n_layers)
     return xb, {"w": wb, "u": ub, "b": bbar}
+
+
+def _vjp_params_radial(b, x, out_bar, ladj_bar=None):
+    """(x_bar, {"alpha_": ᾱ_, "beta": β̄, "z_0": z̄₀}) for a RadialLayer — the raw parameters behind softplus
+    (radial_layer.jl:43-60), cotangents summed over the batch (bjx_radial_vjp_params)."""
+    xc, dim, batch, vec = _prep(x)
+    gc, gdim, gbatch, _ = _prep(out_bar)
+    if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:
+        raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
+    z0 = _param(b.z_0, xc)
+    if z0.numel() != dim:
+        raise ValueError(f"DimensionMismatch: RadialLayer of dimension {z0.numel()} applied to {dim} rows")
+    a, be = _param(b.alpha_, xc), _param(b.beta, xc)
+    lb = _ladj_bar(ladj_bar, batch, xc)
+    ctx = context(xc.device)
+    xb = _empty(dim, batch, xc, vec)
+    ab, bb, zb = torch.empty_like(a), torch.empty_like(be), torch.empty_like(z0)
+    work = torch.empty(2 * max(batch, 1), dtype=xc.dtype, device=xc.device)
+    rc = L.load().bjx_radial_vjp_params(ctx.h, _dt(xc), _ptr(a), _ptr(be), _ptr(z0), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb),
+                                        _ptr(ab), _ptr(bb), _ptr(zb), _ptr(work), dim, batch)
+    L.check(ctx.h, rc, "bjx_radial_vjp_params")
+    return xb, {"alpha_": ab, "beta": bb, "z_0": zb}
 
 
 # ------------------------------------------------------------------ columnwise (src/interface.jl:41-78)

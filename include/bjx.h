@@ -198,6 +198,15 @@ int bjx_radial_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* alpha_, 
                    const void* in, const void* out_bar, const void* ladj_bar, void* in_bar,
                    int64_t dim, int64_t batch);
 
+/* The forward pullback plus the PARAMETER cotangents of the RadialLayer (radial_layer.jl:43-60; alpha_, beta are the
+ * raw parameters behind softplus), summed over the batch: alpha_bar, beta_bar: T[1], z0_bar: T[dim].
+ * `work`: caller-owned device scratch of 2*batch elements of T (r and (z - z0)^T out_bar of every column).
+ * A batch sharded over GPUs all-reduces the three outputs.  dim <= 1024 (Float32) / 512 (Float64), the limit of
+ * bjx_row_moments, which produces z0_bar. */
+int bjx_radial_vjp_params(bjx_ctx* ctx, bjx_dtype dt, const void* alpha_, const void* beta, const void* z0,
+                          const void* in, const void* out_bar, const void* ladj_bar, void* in_bar,
+                          void* alpha_bar, void* beta_bar, void* z0_bar, void* work, int64_t dim, int64_t batch);
+
 /* InvertibleBatchNorm in eval mode (istraining() == false), normalise.jl:41-88.
  * b, logs, m, v: device T[dim] (channels = dim for 2-D input, :43-47). */
 int bjx_batchnorm(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* b, const void* logs,

@@ -690,6 +690,33 @@ def radial_vjp(alpha_, beta, z0, x, out_bar, ladj_bar=None, inverse=False):
     return (v - c * (dl * v).sum(axis=0) * dl / (a + c * r * r)) / a
 
 
+def radial_param_vjp(alpha_, beta, z0, z, y_bar, ladj_bar=None):
+    """Parameter pullback of with_logabsdet_jacobian for a RadialLayer: (ᾱ_, β̄, z̄₀) summed over the batch, for the RAW
+    parameters behind softplus (radial_layer.jl:43-60; the reference leaves it to the AD package).  With α̂ = softplus(α_),
+    β̂ = -α̂ + softplus(β), h = 1/(α̂ + r), a = 1 + β̂h, D = 1 + β̂h - β̂h²r:
+        g_β̂ = h δᵀȳ + ℓ̄[(d-1)h/a + (h - h²r)/D],  g_α̂ = -h²[β̂ δᵀȳ + ℓ̄((d-1)β̂/a + (β̂ - 2β̂hr)/D)],
+        ᾱ_ = σ(α_)(Σ g_α̂ - Σ g_β̂),  β̄ = σ(β) Σ g_β̂,  z̄₀ = Σ_n (ȳ_n - z̄_n).   numpy, float64."""
+    z = np.asarray(z, dtype=np.float64)
+    d, N = z.shape
+    a_raw = float(np.asarray(alpha_).reshape(-1)[0])
+    b_raw = float(np.asarray(beta).reshape(-1)[0])
+    al = float(log1pexp(a_raw))
+    bh = -al + float(log1pexp(b_raw))
+    lb = np.zeros(N) if ladj_bar is None else np.broadcast_to(np.asarray(ladj_bar, dtype=np.float64), (N,))
+    g = np.asarray(y_bar, dtype=np.float64)
+    dl = z - np.asarray(z0, dtype=np.float64).reshape(-1, 1)
+    r = np.sqrt((dl * dl).sum(axis=0))
+    dg = (dl * g).sum(axis=0)
+    h = 1.0 / (al + r)
+    a = 1.0 + bh * h
+    D = 1.0 + bh * h - bh * h * h * r
+    gb = h * dg + lb * ((d - 1) * h / a + (h - h * h * r) / D)
+    ga = -h * h * (bh * dg + lb * ((d - 1) * bh / a + (bh - 2.0 * bh * h * r) / D))
+    sa, sb = 1.0 / (1.0 + np.exp(-a_raw)), 1.0 / (1.0 + np.exp(-b_raw))
+    zb = radial_vjp(alpha_, beta, z0, z, g, lb)
+    return sa * (ga.sum() - gb.sum()), sb * gb.sum(), (g - zb).sum(axis=1)
+
+
 def planar_param_vjp(w, u, b, z, y_bar, ladj_bar=None):
     """Parameter pullback of with_logabsdet_jacobian for a PlanarLayer stack: (w̄, ū, b̄) summed over the batch
     (planar_layer.jl:65-110 incl. get_u_hat :65-70; the reference leaves it to the AD package).  Per layer, with

@@ -1998,3 +1998,27 @@ def test_hip_graph_capture_and_replay(bj, orc, dt):
                 sum_close(o, float(e), dt, ins_b[0].size, what=f"graph {name} (summed log-det)")
             else:
                 np.testing.assert_allclose(o, e, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 50 * max(1.0, float(np.abs(e[np.isfinite(e)]).max())), err_msg=f"graph {name}")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,N", [(2, 9), (5, 100), (64, 1000), (130, 33), (128, 4099), (512, 17)])
+def test_radial_parameter_pullback(bj, orc, dim, N, dt):
+    """(ᾱ_, β̄, z̄₀) of a RadialLayer next to the input pullback (§8f f-1), against the finite-difference-pinned oracle."""
+    r = rng(170)
+    a_raw, b_raw = np.array([0.3], dtype=dt), np.array([-0.4], dtype=dt)
+    z0 = r.normal(size=dim).astype(dt)
+    z = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    yb = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    lb = r.normal(size=N).astype(dt)
+    rad = bj.RadialLayer(torch.tensor(a_raw), torch.tensor(b_raw), torch.tensor(z0))
+    for lbar in (lb, None):
+        ab, bb, z0b = orc.radial_param_vjp(a_raw, b_raw, z0, z, yb, lbar)
+        zb_ref = orc.radial_vjp(a_raw, b_raw, z0, z, yb, lbar)
+        xb, g = bj.vjp_params(rad, dev(z), dev(yb), None if lbar is None else torch.from_numpy(lbar).cuda())
+        np.testing.assert_allclose(host(xb), zb_ref, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(zb_ref).max())))
+        # sums over N columns of O(1) terms: absolute floor scaled with sqrt(N)·dim
+        fl = ATOL[dt] * 50 * np.sqrt(N) * dim
+        assert abs(float(host(g["alpha_"])[0]) - ab) <= RTOL[dt] * 10 * abs(ab) + fl
+        assert abs(float(host(g["beta"])[0]) - bb) <= RTOL[dt] * 10 * abs(bb) + fl
+        np.testing.assert_allclose(host(g["z_0"]), z0b, rtol=RTOL[dt] * 10, atol=fl)
+    assert g["alpha_"].shape == (1,) and g["z_0"].shape == (dim,)

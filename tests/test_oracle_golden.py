@@ -583,6 +583,29 @@ def test_planar_parameter_pullback_matches_finite_differences(orc):
             assert abs((F(w, u, bp) - F(w, u, bm)) / (2 * h) - bb[k]) < 1e-6
 
 
+def test_radial_parameter_pullback_matches_finite_differences(orc):
+    """(ᾱ_, β̄, z̄₀) of a RadialLayer for the raw parameters behind softplus (radial_layer.jl:43-60), against central
+    differences of the golden-pinned forward oracle with respect to the parameters."""
+    r = np.random.default_rng(16)
+    for dim, N, a_raw, b_raw in ((5, 4, 0.3, -0.2), (3, 6, -1.0, 1.5), (8, 2, 2.0, 0.1)):
+        z0 = r.normal(size=dim)
+        z = np.asfortranarray(r.normal(size=(dim, N)))
+        yb, lb = r.normal(size=(dim, N)), r.normal(size=N)
+        ab, bb, z0b = orc.radial_param_vjp(np.array([a_raw]), np.array([b_raw]), z0, z, yb, lb)
+
+        def F(a_, b_, z0_):
+            y, l = orc.radial(np.array([a_]), np.array([b_]), z0_, z)
+            return float((y * yb).sum() + (l * lb).sum())
+        h = 1e-6
+        assert abs((F(a_raw + h, b_raw, z0) - F(a_raw - h, b_raw, z0)) / (2 * h) - ab) < 1e-6
+        assert abs((F(a_raw, b_raw + h, z0) - F(a_raw, b_raw - h, z0)) / (2 * h) - bb) < 1e-6
+        for i in range(dim):
+            zp, zm = z0.copy(), z0.copy()
+            zp[i] += h
+            zm[i] -= h
+            assert abs((F(a_raw, b_raw, zp) - F(a_raw, b_raw, zm)) / (2 * h) - z0b[i]) < 1e-6
+
+
 def test_rqs_pullback_matches_finite_differences(orc):
     """Elementwise spline and its inverse: closed-form f' and (log f')' against central differences of the golden-pinned
     oracle, inside and outside [-B, B]."""
