@@ -285,6 +285,22 @@ function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::Union{Pla
     return out, pullback_planar
 end
 
+# RadialLayer: input AND parameter cotangents (bjx_radial_vjp_params; raw α_, β behind softplus, radial_layer.jl:43-60)
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::RadialLayer, z::ROCMatrix{T}) where {T}
+    out = with_logabsdet_jacobian(flow, z)
+    function pullback_radial((Δy, Δl))
+        Δyc, Δlc = ROCArray{T}(ChainRulesCore.unthunk(Δy)), ROCArray{T}(ChainRulesCore.unthunk(Δl))
+        z̄, ᾱ, β̄, z̄0 = similar(z), similar(flow.α_), similar(flow.β), similar(flow.z_0)
+        work = similar(z, 2 * size(z, 2))
+        GC.@preserve z Δyc Δlc z̄ ᾱ β̄ z̄0 work check(ccall((:bjx_radial_vjp_params, libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+            ctx().h, dtype(T), devptr(flow.α_), devptr(flow.β), devptr(flow.z_0), devptr(z), devptr(Δyc), devptr(Δlc), devptr(z̄),
+            devptr(ᾱ), devptr(β̄), devptr(z̄0), devptr(work), size(z, 1), size(z, 2)), "bjx_radial_vjp_params")
+        return ChainRulesCore.NoTangent(), ChainRulesCore.Tangent{typeof(flow)}(α_ = ᾱ, β = β̄, z_0 = z̄0), z̄
+    end
+    return out, pullback_radial
+end
+
 # ---------------------------------------------------------------- logpdf of a TransformedDistribution (SURVEY.md §8f f-3)
 # src/transformed_distribution.jl:164-169 in ONE pass over y: the inverse chain, the whitening of the diagonal-normal
 # base and the standard-normal density are ops of the same launch; the pre-image is not stored (y pointer = C_NULL).
