@@ -269,9 +269,26 @@ for (f, uplo) in ((:_link_chol_lkj_from_upper, 'U'), (:_link_chol_lkj_from_lower
         return y, pullback_link_chol_lkj
     end
 end
-# PlanarLayer stack and its inverse: input pullback (parameters: not implemented on the device)
-function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::Union{PlanarLayer,Inverse{<:PlanarLayer}}, z::ROCMatrix{T}) where {T}
-    inv = flow isa Inverse; pl = inv ? flow.orig : flow
+# PlanarLayer: input pullback + parameter cotangents (w̄, ū, b̄) through get_u_hat (bjx_planar_vjp_params)
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::PlanarLayer, z::ROCMatrix{T}) where {T}
+    out = with_logabsdet_jacobian(flow, z)
+    function pullback_planar_params((Δy, Δl))
+        z̄ = similar(z); Δyc = ROCArray{T}(ChainRulesCore.unthunk(Δy)); Δlc = ROCArray{T}(ChainRulesCore.unthunk(Δl))
+        w, u, b = ROCArray{T}(flow.w), ROCArray{T}(flow.u), ROCArray{T}(flow.b)
+        w̄, ū, b̄ = similar(w), similar(u), similar(b)
+        work = similar(z, 2 * size(z, 2))                      # 2 * n_layers * batch, one layer
+        GC.@preserve z Δyc Δlc z̄ w u b w̄ ū b̄ work check(ccall((:bjx_planar_vjp_params, libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+             Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+            ctx().h, dtype(T), devptr(w), devptr(u), devptr(b), 1, devptr(z), devptr(Δyc), devptr(Δlc), devptr(z̄),
+            devptr(w̄), devptr(ū), devptr(b̄), devptr(work), size(z, 1), size(z, 2)), "bjx_planar_vjp_params")
+        return ChainRulesCore.NoTangent(), ChainRulesCore.Tangent{typeof(flow)}(w = w̄, u = ū, b = b̄), z̄
+    end
+    return out, pullback_planar_params
+end
+# inverse(PlanarLayer): input pullback (its parameter cotangents are not produced on the device)
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::Inverse{<:PlanarLayer}, z::ROCMatrix{T}) where {T}
+    inv = true; pl = flow.orig
     out = with_logabsdet_jacobian(flow, z)
     function pullback_planar((Δy, Δl))
         z̄ = similar(z); Δyc = ROCArray{T}(ChainRulesCore.unthunk(Δy)); Δlc = ROCArray{T}(ChainRulesCore.unthunk(Δl))
@@ -280,7 +297,7 @@ function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::Union{Pla
             (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
             ctx().h, dtype(T), Cint(inv), devptr(w), devptr(u), devptr(b), 1, devptr(z), devptr(Δyc), devptr(Δlc), devptr(z̄),
             size(z, 1), size(z, 2)), "bjx_planar_vjp")
-        return ChainRulesCore.NoTangent(), ChainRulesCore.@not_implemented("PlanarLayer parameter gradients"), z̄
+        return ChainRulesCore.NoTangent(), ChainRulesCore.@not_implemented("parameter gradients of inverse(PlanarLayer)"), z̄
     end
     return out, pullback_planar
 end
