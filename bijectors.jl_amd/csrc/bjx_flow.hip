@@ -1649,7 +1649,26 @@ __global__ __launch_bounds__(256) void planar_gram_kernel(const T* __restrict__ 
   if (threadIdx.x == 0) st[j * nl + k] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// one block per layer: fixed-order sum over the block partials, then the chain rule through get_u_hat
+// Fixed-order sum of the per-block partial sets into one set: thread e owns element e of the set, adjacent threads
+// read adjacent doubles of every block's set (coalesced), four independent accumulators keep loads in flight.
+// (planar_param_finalize_kernel used to walk the 1024 sets itself, 8 blocks of strided dependent-latency loads:
+// 1.1 ms at 8 layers x 128 rows — as long as the streaming reduction it finishes.)
+__global__ __launch_bounds__(256) void planar_param_colsum_kernel(const double* __restrict__ partial, int nblocks, size_t per, double* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= per) return;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int b = 0;
+  for (; b + 4 <= nblocks; b += 4) {
+    a0 += partial[(size_t)b * per + e];
+    a1 += partial[(size_t)(b + 1) * per + e];
+    a2 += partial[(size_t)(b + 2) * per + e];
+    a3 += partial[(size_t)(b + 3) * per + e];
+  }
+  for (; b < nblocks; ++b) a0 += partial[(size_t)b * per + e];
+  out[e] = (a0 + a1) + (a2 + a3);
+}
+
+// one block per layer: the chain rule through get_u_hat on the summed partial set (nblocks = 1 after the column sum)
 template <class T>
 __global__ __launch_bounds__(256) void planar_param_finalize_kernel(const double* __restrict__ partial, int nblocks, int64_t dim, int nl, int l0, int nlg,
                                                                    const double* st, const T* __restrict__ w, const T* __restrict__ u,
@@ -1734,9 +1753,10 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
   if (nblocks < 1) nblocks = 1;
   const size_t per_max = 2 * (size_t)dim * PP_NLG + PP_NLG * PP_NLG + 2 * PP_NLG;
   const size_t st_n = (size_t)nl * nl;
-  { int rc2 = bjx_ensure_partials(ctx, (size_t)nblocks * per_max + st_n); if (rc2) return rc2; }
+  { int rc2 = bjx_ensure_partials(ctx, (size_t)nblocks * per_max + st_n + per_max); if (rc2) return rc2; }
   double* partial = ctx->partials;
   double* st = partial + (size_t)nblocks * per_max;
+  double* psum = st + st_n;                          // the block partials summed into one set
   const bool one_group = nl <= PP_NLG;
   if (!one_group) {                                  // cross-group Gram entries: a separate (slow, rarely needed) pass
     hipLaunchKernelGGL(planar_gram_kernel<T>, dim3(nl * nl), dim3(256), 0, ctx->stream, s_out, t_out, batch, nl, st);
@@ -1757,7 +1777,15 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
 #undef PPR
     }
     BJX_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(planar_param_finalize_kernel<T>, dim3(nlg), dim3(256), 0, ctx->stream, partial, nblocks, dim, nl, l0, nlg, one_group ? (const double*)nullptr : (const double*)st, w, u, u_hat, w_bar, u_bar, b_bar);
+    {
+      BjxProf prof_(ctx);
+      hipLaunchKernelGGL(planar_param_colsum_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, ctx->stream, partial, nblocks, per, psum);
+    }
+    BJX_CHECK_LAUNCH(ctx);
+    {
+      BjxProf prof_(ctx);
+      hipLaunchKernelGGL(planar_param_finalize_kernel<T>, dim3(nlg), dim3(256), 0, ctx->stream, psum, 1, dim, nl, l0, nlg, one_group ? (const double*)nullptr : (const double*)st, w, u, u_hat, w_bar, u_bar, b_bar);
+    }
     BJX_CHECK_LAUNCH(ctx);
   }
   return BJX_OK;
