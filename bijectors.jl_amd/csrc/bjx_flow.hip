@@ -1884,10 +1884,16 @@ template <class T>
 __global__ __launch_bounds__(256) void radial_param_finalize_kernel(const T* __restrict__ alpha_, const T* __restrict__ beta, const double* __restrict__ partials,
                                                                     int nblocks, const double* __restrict__ sy, const double* __restrict__ sz, int64_t dim,
                                                                     T* __restrict__ alpha_bar, T* __restrict__ beta_bar, T* __restrict__ z0_bar) {
+  __shared__ double red[8];
   for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) z0_bar[i] = (T)(sy[i] - sz[i]);
+  double ga = 0.0, gb = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) { ga += partials[2 * b]; gb += partials[2 * b + 1]; }
+  ga = group_sum<64>(ga); gb = group_sum<64>(gb);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = ga; red[4 + (threadIdx.x >> 6)] = gb; }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    double ga = 0.0, gb = 0.0;
-    for (int b = 0; b < nblocks; ++b) { ga += partials[2 * b]; gb += partials[2 * b + 1]; }
+    ga = (red[0] + red[1]) + (red[2] + red[3]);
+    gb = (red[4] + red[5]) + (red[6] + red[7]);
     const double sa = 1.0 / (1.0 + exp(-(double)alpha_[0])), sb = 1.0 / (1.0 + exp(-(double)beta[0]));
     alpha_bar[0] = (T)(sa * (ga - gb));
     beta_bar[0] = (T)(sb * gb);
