@@ -1636,6 +1636,132 @@ __global__ __launch_bounds__(256) void planar_param_reduce_kernel(const T* __res
   for (size_t i = threadIdx.x; i < per; i += blockDim.x) partial[(size_t)blockIdx.x * per + i] = red[i];
 }
 
+// ---- the same reduction on the matrix cores (Float32, dim = 64·NH <= 256, 16-byte aligned inputs).
+// M1 = Z₀·S̄ᵀ and M2 = Ȳ·Tᵀ are [dim x columns]·[columns x layers] products with the COLUMN index as k.
+// v_mfma_f32_16x16x4_f32 (layout probed in scripts/probe_mfma.hip): A[i][k] on lane (i = l%16, k = l/16), B[k][n] on
+// lane (n = l%16, k = l/16), D[4(l/16)+v][l%16] in VGPR v.  One wave instruction covers 4 columns (k = l/16): lane
+// (i, k) loads the 16-byte pack rows 64h+4i..+3 of column k (16 lanes = 256 contiguous bytes per column, the natural
+// coalesced layout) — four consecutive ROWS, not one A entry; but the MFMA that takes register r of every lane computes
+// the products of the rows {64h + 4i + r}, a fixed permutation of the output rows, so 4·NH MFMAs per operand pair use
+// the packs as they are.  B = s̄ / tanh of (layer n, column k) straight from the [n_layers, batch] work arrays (lanes
+// n < nlg; zero above).  The Gram block ST = S̄·Tᵀ is one more MFMA with A = the s̄ register and B = the tanh register.
+// Accumulators: 8·NH + 1 quads of VGPRs per wave (68 at dim = 128) instead of 128 scalar accumulators per lane, and
+// 4 columns per trip with 4·NH pack loads in flight.  Block combine and partial layout as planar_param_reduce_kernel.
+typedef float bjx_mf4 __attribute__((ext_vector_type(4)));
+// HS = row slices per column: wave w owns the 64·NHW rows of slice w % HS (dim = 64·NHW·HS) of the columns of its
+// group w / HS, so a block covers 16/HS columns per trip.  One slice per wave (NHW = 1) keeps the accumulators at
+// 8 + 1 quads: ~80 VGPRs, 6 waves per SIMD instead of 2 with the whole column in one wave — the loads in flight
+// per CU, not the matrix pipe (≈ 20 % busy), are what this reduction runs on.  Only slice 0 accumulates ST / b̄ / c̄.
+template <int NHW, int HS>
+__global__ __launch_bounds__(256) void planar_param_mfma_kernel(const float* __restrict__ z0, const float* __restrict__ ybar, const float* __restrict__ sbar,
+                                                                const float* __restrict__ tt, const float* __restrict__ lbar, const float* __restrict__ wtu_hat,
+                                                                int64_t batch, int nl, int l0, int nlg, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);
+  constexpr int dim = 64 * NHW * HS;
+  constexpr int WG = 4 / HS;                        // column groups (of 4 columns) per block and trip
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hs = wave % HS, wg = wave / HS;
+  const int i = lane & 15, kq = lane >> 4;
+  bjx_mf4 m1[NHW][4], m2[NHW][4], st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < NHW; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m1[h][r] = bjx_mf4{0.f, 0.f, 0.f, 0.f}; m2[h][r] = bjx_mf4{0.f, 0.f, 0.f, 0.f}; }
+  float bsum = 0.f, csum = 0.f;
+  const bool lay = i < nlg;
+  const float cmine = lay ? wtu_hat[l0 + i] : 0.f;
+  const int row0 = 64 * NHW * hs + 4 * i;            // first row of my first pack
+  // software pipeline: the packs and scalars of the NEXT trip are in flight while this trip's MFMAs run
+  const int64_t cstep = (int64_t)gridDim.x * (4 * WG);
+  int64_t col = ((int64_t)blockIdx.x * WG + wg) * 4 + kq;
+  bjx_f4 nz[NHW], ng[NHW];
+  float nsv = 0.f, ntv = 0.f, nlb = 0.f;
+  auto fetch = [&](int64_t c) {
+    const bool okc = c < batch;
+#pragma unroll
+    for (int h = 0; h < NHW; ++h) {
+      nz[h] = bjx_f4{0.f, 0.f, 0.f, 0.f}; ng[h] = nz[h];
+      if (okc) {
+        nz[h] = __builtin_nontemporal_load(reinterpret_cast<const bjx_f4*>(z0 + c * dim + row0 + 64 * h));
+        ng[h] = __builtin_nontemporal_load(reinterpret_cast<const bjx_f4*>(ybar + c * dim + row0 + 64 * h));
+      }
+    }
+    nsv = (okc && lay) ? sbar[c * nl + l0 + i] : 0.f;
+    ntv = (okc && lay) ? tt[c * nl + l0 + i] : 0.f;
+    nlb = (okc && lay && lbar && hs == 0) ? lbar[c] : 0.f;
+  };
+  fetch(col);
+  for (; col - kq < batch; col += cstep) {
+    bjx_f4 pz[NHW], pg[NHW];
+#pragma unroll
+    for (int h = 0; h < NHW; ++h) { pz[h] = nz[h]; pg[h] = ng[h]; }
+    const float sv = nsv, tv = ntv, lb = nlb;
+    fetch(col + cstep);
+#pragma unroll
+    for (int h = 0; h < NHW; ++h) {
+      m1[h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pz[h].x, sv, m1[h][0], 0, 0, 0);
+      m1[h][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pz[h].y, sv, m1[h][1], 0, 0, 0);
+      m1[h][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pz[h].z, sv, m1[h][2], 0, 0, 0);
+      m1[h][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pz[h].w, sv, m1[h][3], 0, 0, 0);
+      m2[h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pg[h].x, tv, m2[h][0], 0, 0, 0);
+      m2[h][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pg[h].y, tv, m2[h][1], 0, 0, 0);
+      m2[h][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pg[h].z, tv, m2[h][2], 0, 0, 0);
+      m2[h][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pg[h].w, tv, m2[h][3], 0, 0, 0);
+    }
+    if (hs == 0) {
+      st = __builtin_amdgcn_mfma_f32_16x16x4f32(sv, tv, st, 0, 0, 0);          // ST[j][k] += s̄_j t_k
+      bsum += sv;
+      const float q = 1.f - tv * tv;
+      csum += lb * q / (1.f + cmine * q);
+    }
+  }
+  // ---- block combine in a fixed order (waves one after another); D element (vgpr v) of lane (n = i, mq = kq):
+  //      A-row m = 4 mq + v  ->  row 64(NHW hs + h) + 4m + r of M1 / M2 (MFMA r), layer n;  ST[j = m][k = n]
+  const size_t n_m = (size_t)dim * nlg;
+  const size_t per = 2 * n_m + (size_t)nlg * nlg + 2 * (size_t)nlg;
+  for (int pass = 0; pass < 4; ++pass) {
+    if (wave == pass) {
+      const bool first = pass < HS;                  // the first wave of every row slice initialises its rows
+      if (lay) {
+#pragma unroll
+        for (int h = 0; h < NHW; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const size_t i1 = (size_t)(64 * (NHW * hs + h) + 4 * (4 * kq + v) + r) * nlg + i;
+              if (first) { red[i1] = (double)m1[h][r][v]; red[n_m + i1] = (double)m2[h][r][v]; }
+              else { red[i1] += (double)m1[h][r][v]; red[n_m + i1] += (double)m2[h][r][v]; }
+            }
+        if (hs == 0) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int j = 4 * kq + v;
+            if (j < nlg) {
+              const size_t i2 = 2 * n_m + (size_t)j * nlg + i;
+              if (pass == 0) red[i2] = (double)st[v]; else red[i2] += (double)st[v];
+            }
+          }
+        }
+      }
+      // b̄ / c̄ of layer i: the four column quads of the wave one after another
+      if (hs == 0) {
+        const size_t ib = 2 * n_m + (size_t)nlg * nlg + i;
+        for (int kp = 0; kp < 4; ++kp) {
+          if (lay && kq == kp) {
+            if (pass == 0 && kp == 0) { red[ib] = (double)bsum; red[ib + nlg] = (double)csum; }
+            else { red[ib] += (double)bsum; red[ib + nlg] += (double)csum; }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (size_t e = threadIdx.x; e < per; e += blockDim.x) partial[(size_t)blockIdx.x * per + e] = red[e];
+}
+
 // cross-group Gram entries ST[j][k] with j, k in DIFFERENT layer groups are produced by a small launch of this kernel
 template <class T>
 __global__ __launch_bounds__(256) void planar_gram_kernel(const T* __restrict__ sbar, const T* __restrict__ tt, int64_t batch, int nl, double* __restrict__ st) {
@@ -1748,8 +1874,14 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
               "bjx_planar_vjp_params: dim %lld too large for the register accumulators", (long long)dim);
   const int R = c.R;
   const int cols_per_block = 256 / c.G;
-  int nblocks = (int)((batch + (int64_t)cols_per_block * 16 - 1) / ((int64_t)cols_per_block * 16));
-  if (nblocks > 1024) nblocks = 1024;
+  constexpr int VW = Vec16<T>::N;
+  static const int use_mfma = getenv("BJX_PLANAR_PARAM_MFMA") ? atoi(getenv("BJX_PLANAR_PARAM_MFMA")) : 1;
+  static const int mfma_blocks = getenv("BJX_PLANAR_PARAM_BLOCKS") ? atoi(getenv("BJX_PLANAR_PARAM_BLOCKS")) : 1024;
+  const bool mfma = use_mfma && std::is_same<T, float>::value && c.V == VW && dim % 64 == 0 && dim <= 256 && bjx_aligned16(out_bar);
+  // persistent grids with equal grid-stride shares: every block must be resident (a second round doubles the time)
+  const int block_cap = mfma ? mfma_blocks : 1024;
+  int nblocks = mfma ? (int)((batch + 63) / 64) : (int)((batch + (int64_t)cols_per_block * 16 - 1) / ((int64_t)cols_per_block * 16));
+  if (nblocks > block_cap) nblocks = block_cap;
   if (nblocks < 1) nblocks = 1;
   const size_t per_max = 2 * (size_t)dim * PP_NLG + PP_NLG * PP_NLG + 2 * PP_NLG;
   const size_t st_n = (size_t)nl * nl;
@@ -1762,13 +1894,20 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
     hipLaunchKernelGGL(planar_gram_kernel<T>, dim3(nl * nl), dim3(256), 0, ctx->stream, s_out, t_out, batch, nl, st);
     BJX_CHECK_LAUNCH(ctx);
   }
-  constexpr int VW = Vec16<T>::N;
   for (int l0 = 0; l0 < nl; l0 += PP_NLG) {
     const int nlg = nl - l0 < PP_NLG ? nl - l0 : PP_NLG;
     const size_t per = 2 * (size_t)dim * nlg + (size_t)nlg * nlg + 2 * (size_t)nlg;
     const size_t smem = per * sizeof(double);
     BJX_REQUIRE(ctx, smem <= BJX_LDS_MAX, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp_params: dim %lld too large for the block combine", (long long)dim);
-    {
+    if (mfma) {
+      BjxProf prof_(ctx);
+      const float* zf = reinterpret_cast<const float*>(in); const float* gf = reinterpret_cast<const float*>(out_bar);
+      const float* sf = reinterpret_cast<const float*>(s_out); const float* tf = reinterpret_cast<const float*>(t_out);
+      const float* lf = reinterpret_cast<const float*>(ladj_bar); const float* cf = reinterpret_cast<const float*>(wtu);
+#define PPM(NHW_, HS_) do { bjx_allow_big_lds(planar_param_mfma_kernel<NHW_, HS_>, smem); hipLaunchKernelGGL((planar_param_mfma_kernel<NHW_, HS_>), dim3(nblocks), dim3(256), smem, ctx->stream, zf, gf, sf, tf, lf, cf, batch, nl, l0, nlg, partial); } while (0)
+      switch ((int)(dim / 64)) { case 1: PPM(1, 1); break; case 2: PPM(1, 2); break; case 3: PPM(3, 1); break; default: PPM(1, 4); break; }
+#undef PPM
+    } else {
       BjxProf prof_(ctx);
 #define PPR(V_, R_) do { bjx_allow_big_lds(planar_param_reduce_kernel<T, V_, R_>, smem); hipLaunchKernelGGL((planar_param_reduce_kernel<T, V_, R_>), dim3(nblocks), dim3(256), smem, ctx->stream, in, out_bar, s_out, t_out, ladj_bar, wtu, dim, batch, c.G, nl, l0, nlg, partial); } while (0)
 #define PPR_V(V_) do { if (R == 1) PPR(V_, 1); else if (R == 2) PPR(V_, 2); else PPR(V_, 4); } while (0)
