@@ -922,8 +922,11 @@ __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A,
   block_publish_partial(ok ? (double)ladj : 0.0, red, fin);
 }
 
+#ifndef BJX_VJP_REG_WAVES
+#define BJX_VJP_REG_WAVES 2
+#endif
 template <int G, int NL, bool INV>
-__global__ __launch_bounds__(256) void planar_vjp_reg_kernel(const PlanarRegArgs A, const float* __restrict__ x, const float* __restrict__ ybar,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG_WAVES, 8))) void planar_vjp_reg_kernel(const PlanarRegArgs A, const float* __restrict__ x, const float* __restrict__ ybar,
                                                              const float* __restrict__ lbar, float* __restrict__ xbar, int dim, int64_t batch,
                                                              float* __restrict__ t_out, float* __restrict__ s_out, int nl) {
   constexpr int COLS = 64;
@@ -1877,7 +1880,7 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
   constexpr int VW = Vec16<T>::N;
   static const int use_mfma = getenv("BJX_PLANAR_PARAM_MFMA") ? atoi(getenv("BJX_PLANAR_PARAM_MFMA")) : 1;
   static const int mfma_blocks = getenv("BJX_PLANAR_PARAM_BLOCKS") ? atoi(getenv("BJX_PLANAR_PARAM_BLOCKS")) : 1024;
-  const bool mfma = use_mfma && std::is_same<T, float>::value && c.V == VW && dim % 64 == 0 && dim <= 256 && bjx_aligned16(out_bar);
+  const bool mfma = use_mfma && std::is_same<T, float>::value && c.V == VW && (dim == 64 || dim == 128 || dim == 256) && bjx_aligned16(out_bar);   // 192 rows: three slices do not divide the four waves, one wave per column needs 357 registers
   // persistent grids with equal grid-stride shares: every block must be resident (a second round doubles the time)
   const int block_cap = mfma ? mfma_blocks : 1024;
   int nblocks = mfma ? (int)((batch + 63) / 64) : (int)((batch + (int64_t)cols_per_block * 16 - 1) / ((int64_t)cols_per_block * 16));
@@ -1905,7 +1908,7 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
       const float* sf = reinterpret_cast<const float*>(s_out); const float* tf = reinterpret_cast<const float*>(t_out);
       const float* lf = reinterpret_cast<const float*>(ladj_bar); const float* cf = reinterpret_cast<const float*>(wtu);
 #define PPM(NHW_, HS_) do { bjx_allow_big_lds(planar_param_mfma_kernel<NHW_, HS_>, smem); hipLaunchKernelGGL((planar_param_mfma_kernel<NHW_, HS_>), dim3(nblocks), dim3(256), smem, ctx->stream, zf, gf, sf, tf, lf, cf, batch, nl, l0, nlg, partial); } while (0)
-      switch ((int)(dim / 64)) { case 1: PPM(1, 1); break; case 2: PPM(1, 2); break; case 3: PPM(3, 1); break; default: PPM(1, 4); break; }
+      switch ((int)(dim / 64)) { case 1: PPM(1, 1); break; case 2: PPM(1, 2); break; default: PPM(1, 4); break; }
 #undef PPM
     } else {
       BjxProf prof_(ctx);
