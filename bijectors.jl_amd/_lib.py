@@ -63,6 +63,7 @@ SIGNATURES = {
     "bjx_vec_cholesky_fwd_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i64, _i64]),
     "bjx_stacked": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _vp, _vp, _vp, _i64, _i64, _u32]),
     "bjx_stacked_vjp": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "bjx_stacked_vjp_moments": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_set_option": (_i, [_vp, _i, _i]),
     "bjx_set_rng": (_i, [_vp, _u64, _i64]),
     "bjx_chain": (_i, [_vp, _i, C.POINTER(BjxOp), _i, _vp, _vp] + _tail),

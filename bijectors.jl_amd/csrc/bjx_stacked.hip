@@ -425,10 +425,18 @@ template <class T> __device__ __forceinline__ void slot_grad(const Slot<T>& s, T
   dl = lp * m;
 }
 
-template <class T, int V, bool GATHER, bool IN_LDS>
+// MOM: additionally the row moments of the result over the block's columns, Σ x̄ and Σ x̄·x per row (the parameter
+// cotangents of a leading per-row affine stage, bjx_row_moments) -> mpart[blockIdx][2 dim] in Float64, so that the
+// mean-field pullback does not read x̄ and x a second time (1 284 -> 772 + ~2 % B/sample).  One pack per lane
+// (dim <= G·V), partial sums over the COL_UC columns of a lane, a fixed shuffle butterfly over the column groups of a wave, the four waves through LDS.
+template <class T, int V, bool GATHER, bool IN_LDS, bool MOM = false>
 __global__ __launch_bounds__(256) void stacked_vjp_kernel(const char* __restrict__ tab_g, int two_slots, const T* __restrict__ x, const T* __restrict__ ybar,
-                                                          const T* __restrict__ lbar, T* __restrict__ xbar, int64_t dim, int64_t batch, int G) {
+                                                          const T* __restrict__ lbar, T* __restrict__ xbar, int64_t dim, int64_t batch, int G,
+                                                          double* __restrict__ mpart = nullptr, int mom_off = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  T ms1[V], ms2[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { ms1[j] = T(0); ms2[j] = T(0); }
   if (IN_LDS) {
     const int n16 = (int)(dim * stacked_row_bytes<T>() / 16);
     const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(tab_g);
@@ -451,6 +459,7 @@ __global__ __launch_bounds__(256) void stacked_vjp_kernel(const char* __restrict
       Pack<T, V> px, pg;
       if (!GATHER) px = load_pack<T, V, true>(xc + v * V);
       pg = load_pack<T, V, true>(gc + v * V);
+      const Pack<T, V> pin = px;                      // the inputs (px is overwritten by the results row by row)
 #pragma unroll 1
       for (int j = 0; j < V; ++j) {
         const Slot<T>* e = reinterpret_cast<const Slot<T>*>(t + (V > 1 ? j * nvc + v : v) * stacked_row_bytes<T>());
@@ -482,13 +491,59 @@ __global__ __launch_bounds__(256) void stacked_vjp_kernel(const char* __restrict
           px.v[3 % V] = j == 3 ? res : px.v[3 % V];
         }
       }
+      if (MOM && !GATHER) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) { ms1[j] += px.v[j]; ms2[j] += px.v[j] * pin.v[j]; }
+      }
       if (!GATHER) store_pack<T, V, true>(oc + v * V, px);
+    }
+  }
+  if (MOM) {
+    // the column groups of a wave first (lanes gl, gl + G, ...: a fixed butterfly), then the four waves through
+    // [wave][row][2] doubles behind the slot table; lanes past the last pack hold zeros
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      for (int m = G; m < 64; m <<= 1) { ms1[j] += shfl_xor(ms1[j], m); ms2[j] += shfl_xor(ms2[j], m); }
+    }
+    double* mp = reinterpret_cast<double*>(smem + mom_off);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < G && gl < nvc) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        mp[((size_t)wv * dim + gl * V + j) * 2] = (double)ms1[j];
+        mp[((size_t)wv * dim + gl * V + j) * 2 + 1] = (double)ms2[j];
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * dim; e += blockDim.x) {
+      const int row = e % (int)dim, which = e / (int)dim;
+      double acc = 0.0;
+      for (int c = 0; c < 4; ++c) acc += mp[((size_t)c * dim + row) * 2 + which];
+      mpart[(size_t)blockIdx.x * 2 * dim + e] = acc;
     }
   }
 }
 
+// sum `chunk` consecutive partial sets of `per` doubles each: out[b][e] = Σ_{k in chunk b} in[k][e] (fixed order, coalesced)
+__global__ __launch_bounds__(256) void sets_reduce_kernel(const double* __restrict__ in, int64_t nsets, int per, int chunk, double* __restrict__ out) {
+  const int64_t k0 = (int64_t)blockIdx.x * chunk;
+  const int64_t k1 = k0 + chunk < nsets ? k0 + chunk : nsets;
+  for (int e = threadIdx.x; e < per; e += blockDim.x) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int64_t k = k0;
+    for (; k + 4 <= k1; k += 4) {
+      a0 += in[k * per + e]; a1 += in[(k + 1) * per + e]; a2 += in[(k + 2) * per + e]; a3 += in[(k + 3) * per + e];
+    }
+    for (; k < k1; ++k) a0 += in[k * per + e];
+    out[(size_t)blockIdx.x * per + e] = (a0 + a1) + (a2 + a3);
+  }
+}
+__global__ void moments_count_kernel(double* out, int64_t dim, int64_t batch) { if (threadIdx.x == 0 && blockIdx.x == 0) out[2 * dim] = (double)batch; }
+
 template <class T>
-int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, const T* ybar, const T* lbar, T* xbar, int64_t dim, int64_t batch) {
+int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, const T* ybar, const T* lbar, T* xbar, int64_t dim, int64_t batch,
+                     double* moments = nullptr, bool* moments_done = nullptr) {
+  if (moments_done) *moments_done = false;
   if (dim * batch == 0) return BJX_OK;
   StackedPlan pl;
   { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, xbar, dim, batch, false, bjx_aligned16(ybar), &pl); if (rc) return rc; }
@@ -501,6 +556,35 @@ int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T*
   const int64_t grid = (batch + cpb - 1) / cpb;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_stacked_vjp: batch too large for one launch");
   constexpr int VW = Vec16<T>::N;
+  // fused row moments: one pack per lane, rows in place (no gather), LDS for the [column group][row][2] combine
+  {
+    const size_t mom_off = (smem + 15) / 16 * 16;
+    const size_t mom_bytes = (size_t)4 * dim * 2 * sizeof(double);
+    const size_t sets = (size_t)grid, per = (size_t)2 * dim;
+    const size_t stage1 = (sets + 255) / 256;
+    if (moments && !pl.gather && packs <= G && mom_off + mom_bytes <= 96 * 1024 && stage1 <= 4096) {
+      { int rc = bjx_ensure_partials(ctx, (sets + stage1) * per); if (rc) return rc; }
+      double* mpart = ctx->partials;
+      double* st1 = mpart + sets * per;
+      const size_t smem_m = mom_off + mom_bytes;
+#define SVJM(V_, L_) do { bjx_allow_big_lds(stacked_vjp_kernel<T, V_, false, L_, true>, smem_m); hipLaunchKernelGGL((stacked_vjp_kernel<T, V_, false, L_, true>), dim3((unsigned)grid), dim3(256), smem_m, ctx->stream, pl.tab, pl.two, x, ybar, lbar, xbar, dim, batch, G, mpart, (int)mom_off); } while (0)
+      {
+        BjxProf prof_(ctx);
+        if (pl.V == VW) { if (lds) SVJM(VW, true); else SVJM(VW, false); } else { if (lds) SVJM(1, true); else SVJM(1, false); }
+      }
+#undef SVJM
+      BJX_CHECK_LAUNCH(ctx);
+      {
+        BjxProf prof_(ctx);
+        hipLaunchKernelGGL(sets_reduce_kernel, dim3((unsigned)stage1), dim3(256), 0, ctx->stream, mpart, (int64_t)sets, (int)per, 256, st1);
+        hipLaunchKernelGGL(sets_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st1, (int64_t)stage1, (int)per, (int)stage1, moments);
+        hipLaunchKernelGGL(moments_count_kernel, dim3(1), dim3(64), 0, ctx->stream, moments, dim, batch);
+      }
+      BJX_CHECK_LAUNCH(ctx);
+      *moments_done = true;
+      return BJX_OK;
+    }
+  }
 #define SVJP(V_, G_, L_) hipLaunchKernelGGL((stacked_vjp_kernel<T, V_, G_, L_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, pl.tab, pl.two, x, ybar, lbar, xbar, dim, batch, G)
 #define SVJP_V(V_) do { if (pl.gather) { if (lds) SVJP(V_, true, true); else SVJP(V_, true, false); } else { if (lds) SVJP(V_, false, true); else SVJP(V_, false, false); } } while (0)
   {
@@ -523,6 +607,22 @@ BJX_API int bjx_stacked(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int
   if (dt == BJX_F32) return stacked_impl<float>(ctx, segs, n_segs, (const float*)x, (float*)y, (float*)ladj_ps, ladj_sum, dim, batch, flags);
   if (dt == BJX_F64) return stacked_impl<double>(ctx, segs, n_segs, (const double*)x, (double*)y, (double*)ladj_ps, ladj_sum, dim, batch, flags);
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_stacked: bad dtype %d", (int)dt);
+}
+
+BJX_API int bjx_stacked_vjp_moments(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const void* x, const void* y_bar,
+                                    const void* ladj_bar, void* x_bar, double* moments, int64_t dim, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0 && n_segs >= 0, BJX_ERR_SHAPE, "bjx_stacked_vjp_moments: bad size");
+  BJX_REQUIRE(ctx, moments && (segs || n_segs == 0) && ((x && y_bar && x_bar) || batch == 0), BJX_ERR_ARG, "bjx_stacked_vjp_moments: null pointer");
+  BJX_REQUIRE(ctx, x_bar != x || batch == 0, BJX_ERR_ARG, "bjx_stacked_vjp_moments: x_bar may not alias x");
+  BJX_REQUIRE(ctx, dim < ((int64_t)1 << 31), BJX_ERR_UNSUPPORTED, "bjx_stacked_vjp_moments: too many rows");
+  bool done = false;
+  int rc;
+  if (dt == BJX_F32) rc = stacked_vjp_impl<float>(ctx, segs, n_segs, (const float*)x, (const float*)y_bar, (const float*)ladj_bar, (float*)x_bar, dim, batch, moments, &done);
+  else if (dt == BJX_F64) rc = stacked_vjp_impl<double>(ctx, segs, n_segs, (const double*)x, (const double*)y_bar, (const double*)ladj_bar, (double*)x_bar, dim, batch, moments, &done);
+  else return bjx_fail(ctx, BJX_ERR_ARG, "bjx_stacked_vjp_moments: bad dtype %d", (int)dt);
+  if (rc || done) return rc;
+  return bjx_row_moments(ctx, dt, x_bar, x, moments, dim, batch);     // shapes outside the fused kernel: a second pass
 }
 
 BJX_API int bjx_stacked_vjp(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const void* x, const void* y_bar,

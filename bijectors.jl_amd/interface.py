@@ -1189,7 +1189,8 @@ class Stacked(Transform):
                         setattr(o, f"p{j}", float(p))
         return arr, keep
 
-    def _vjp(self, x, out_bar, ladj_bar):
+    def _vjp(self, x, out_bar, ladj_bar, moments=False):
+        """moments=True: also (Σ_n x̄, Σ_n x̄·x) per row from the same pass (bjx_stacked_vjp_moments)."""
         xc, dim, batch, vec = _prep(x)
         gc, gdim, gbatch, _ = _prep(out_bar)
         if dim != self.length_in:
@@ -1203,6 +1204,12 @@ class Stacked(Transform):
         lb = _ladj_bar(ladj_bar, batch, xc)
         ctx = context(xc.device)
         xb = _empty(dim, batch, xc, vec)
+        if moments:
+            mom = torch.empty(2 * dim + 1, dtype=torch.float64, device=xc.device)
+            rc = L.load().bjx_stacked_vjp_moments(ctx.h, _dt(xc), arr, len(self.bs), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), _ptr(mom), dim, batch)
+            del keep
+            L.check(ctx.h, rc, "bjx_stacked_vjp_moments")
+            return xb, mom[:dim], mom[dim:2 * dim]
         rc = L.load().bjx_stacked_vjp(ctx.h, _dt(xc), arr, len(self.bs), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
         del keep
         L.check(ctx.h, rc, "bjx_stacked_vjp")
@@ -1437,8 +1444,12 @@ def _vjp_params_leading_affine(b, x, out_bar, ladj_bar):
         k += 1
     if scale is None and shift is None:
         raise NotImplementedError(f"no device parameter pullback for {b!r}: expected a chain that starts with Scale and/or Shift (SURVEY.md §8f f-1)")
-    zb = vjp(b, x, out_bar, ladj_bar)
-    s1, s2 = row_moments(zb, x)
+    if _elementwise_ops(b) is not None and x.dim() == 2:
+        # input pullback and both row reductions in one pass over x and ȳ (bjx_stacked_vjp_moments)
+        zb, s1, s2 = Stacked([b], [(1, x.shape[0])])._vjp(x, out_bar, ladj_bar, moments=True)
+    else:
+        zb = vjp(b, x, out_bar, ladj_bar)
+        s1, s2 = row_moments(zb, x)
     xc, dim, batch, _ = _prep(x)
     sig = None
     if scale is not None:
