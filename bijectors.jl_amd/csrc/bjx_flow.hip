@@ -1168,8 +1168,9 @@ __global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, cons
 template <class T, int V, int R, bool INV>
 __global__ __launch_bounds__(256) void radial_vjp_kernel(const RadialArgs<T> A, const T* __restrict__ x, const T* __restrict__ gbar,
                                                          const T* __restrict__ lbar, T* __restrict__ xbar, int64_t dim, int64_t batch, int G,
-                                                         T* __restrict__ work = nullptr) {
+                                                         T* __restrict__ work = nullptr, double* __restrict__ zpart = nullptr, int zoff = 0) {
   // work (forward map only, may be null): r and δᵀȳ of every column, [2, batch] — the inputs of the parameter pullback
+  // zpart (may be null): Σ over the block's columns of ȳ - z̄ per row -> zpart[blockIdx][dim] (z̄₀ without a second pass)
   constexpr int UC = R == 1 ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* tab = reinterpret_cast<T*>(smem);
@@ -1187,11 +1188,12 @@ __global__ __launch_bounds__(256) void radial_vjp_kernel(const RadialArgs<T> A, 
   const int64_t col_first = (int64_t)blockIdx.x * cols_per_block * UC + threadIdx.x / G;
   Pack<T, V> zz[UC][R], gg[UC][R];
   T z0r[R][V];
+  T zsum[R][V];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int64_t v = gl + (int64_t)r * G;
 #pragma unroll
-    for (int j = 0; j < V; ++j) z0r[r][j] = v < nvc ? Z0[v * V + j] : T(0);
+    for (int j = 0; j < V; ++j) { z0r[r][j] = v < nvc ? Z0[v * V + j] : T(0); zsum[r][j] = T(0); }
   }
 #pragma unroll
   for (int u = 0; u < UC; ++u) {
@@ -1252,8 +1254,43 @@ __global__ __launch_bounds__(256) void radial_vjp_kernel(const RadialArgs<T> A, 
 #pragma unroll
         for (int j = 0; j < V; ++j) o.v[j] = ca * gg[u][r].v[j] + cd * (zz[u][r].v[j] - z0r[r][j]);
         if (col_ok) store_pack<T, V, true>(xbar + col * dim + v * V, o);
+        if (zpart && col_ok) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) zsum[r][j] += gg[u][r].v[j] - o.v[j];
+        }
       }
     }
+  }
+  if (zpart) {
+    // the column groups of a wave (fixed butterfly over lanes gl, gl + G, ...), then the four waves through LDS
+    double* zp = reinterpret_cast<double*>(smem + zoff);
+    const int wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        T a = zsum[r][j];
+        for (int m = G; m < 64; m <<= 1) a += shfl_xor(a, m);
+        const int64_t v = gl + (int64_t)r * G;
+        if ((threadIdx.x & 63) < G && v < nvc) zp[(size_t)wv * dim + v * V + j] = (double)a;
+      }
+    }
+    __syncthreads();
+    for (int64_t e = threadIdx.x; e < dim; e += blockDim.x)
+      zpart[(size_t)blockIdx.x * dim + e] = (zp[e] + zp[dim + e]) + (zp[2 * dim + e] + zp[3 * dim + e]);
+  }
+}
+
+// out[b][e] = Σ_{k in chunk b} in[k][e]: fixed order, coalesced, four accumulators (the same reduction as in bjx_stacked.hip)
+__global__ __launch_bounds__(256) void flow_sets_reduce_kernel(const double* __restrict__ in, int64_t nsets, int per, int chunk, double* __restrict__ out) {
+  const int64_t k0 = (int64_t)blockIdx.x * chunk;
+  const int64_t k1 = k0 + chunk < nsets ? k0 + chunk : nsets;
+  for (int e = threadIdx.x; e < per; e += blockDim.x) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int64_t k = k0;
+    for (; k + 4 <= k1; k += 4) { a0 += in[k * per + e]; a1 += in[(k + 1) * per + e]; a2 += in[(k + 2) * per + e]; a3 += in[(k + 3) * per + e]; }
+    for (; k < k1; ++k) a0 += in[k * per + e];
+    out[(size_t)blockIdx.x * per + e] = (a0 + a1) + (a2 + a3);
   }
 }
 
@@ -1958,7 +1995,8 @@ BJX_API int bjx_planar_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* 
 namespace {
 template <class T>
 int radial_vjp_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const T* z0, const T* in, const T* out_bar, const T* ladj_bar,
-                    T* in_bar, int64_t dim, int64_t batch, T* work = nullptr) {
+                    T* in_bar, int64_t dim, int64_t batch, T* work = nullptr, double* zsum_out = nullptr, bool* zsum_done = nullptr) {
+  if (zsum_done) *zsum_done = false;
   if (batch == 0) return BJX_OK;
   FlowCfg c;
   BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, in_bar, dim, batch, &c), BJX_ERR_UNSUPPORTED, "bjx_radial_vjp: dim %lld too large for the register-resident kernel", (long long)dim);
@@ -1980,7 +2018,31 @@ int radial_vjp_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, c
   const size_t tab_bytes = (size_t)dim * sizeof(T);
   const bool lds = tab_bytes <= 60 * 1024;
   RadialArgs<T> A{alpha_, beta, z0, lds ? 1 : 0};
-  const size_t smem = lds ? tab_bytes : 0;
+  size_t smem = lds ? tab_bytes : 0;
+  if (zsum_out && !inverse && c.V == VW && c.R <= 4) {
+    // row sums of ȳ - z̄ from the same pass: one Float64 partial set per block, two reduction stages
+    const size_t zoff = (smem + 15) / 16 * 16;
+    const size_t sets = (size_t)c.grid, stage1 = (sets + 255) / 256;
+    if (zoff + 4 * (size_t)dim * sizeof(double) <= 64 * 1024 && stage1 <= 4096) {
+      { int rc = bjx_ensure_partials(ctx, (sets + stage1) * (size_t)dim); if (rc) return rc; }
+      double* zpart = ctx->partials;
+      double* st1 = zpart + sets * (size_t)dim;
+      smem = zoff + 4 * (size_t)dim * sizeof(double);
+      {
+        BjxProf prof_(ctx);
+        FLOW_SWITCH_R(radial_vjp_kernel, T, VW, false, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, work, zpart, (int)zoff)
+      }
+      BJX_CHECK_LAUNCH(ctx);
+      {
+        BjxProf prof_(ctx);
+        hipLaunchKernelGGL(flow_sets_reduce_kernel, dim3((unsigned)stage1), dim3(256), 0, ctx->stream, zpart, (int64_t)sets, (int)dim, 256, st1);
+        hipLaunchKernelGGL(flow_sets_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st1, (int64_t)stage1, (int)dim, (int)stage1, zsum_out);
+      }
+      BJX_CHECK_LAUNCH(ctx);
+      *zsum_done = true;
+      return BJX_OK;
+    }
+  }
   BjxProf prof_(ctx);
   if (c.V == VW) {
     if (!inverse) { FLOW_SWITCH_R(radial_vjp_kernel, T, VW, false, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, work) }
@@ -2054,9 +2116,14 @@ int radial_vjp_params_impl(bjx_ctx* ctx, bjx_dtype dt, const T* alpha_, const T*
     BJX_HIP(ctx, hipMemsetAsync(beta_bar, 0, sizeof(T), ctx->stream));
     return BJX_OK;
   }
-  { int rc = radial_vjp_impl<T>(ctx, 0, alpha_, beta, z0, in, out_bar, ladj_bar, in_bar, dim, batch, work); if (rc) return rc; }
-  { int rc = bjx_row_moments(ctx, dt, out_bar, nullptr, sy, dim, batch); if (rc) return rc; }      // Σ_n ȳ  (rows)
-  { int rc = bjx_row_moments(ctx, dt, in_bar, nullptr, sz, dim, batch); if (rc) return rc; }       // Σ_n z̄
+  bool fused = false;
+  { int rc = radial_vjp_impl<T>(ctx, 0, alpha_, beta, z0, in, out_bar, ladj_bar, in_bar, dim, batch, work, sy, &fused); if (rc) return rc; }
+  if (fused) {                                       // sy = Σ_n (ȳ - z̄) from the pullback kernel itself
+    BJX_HIP(ctx, hipMemsetAsync(sz, 0, (size_t)dim * sizeof(double), ctx->stream));
+  } else {
+    { int rc = bjx_row_moments(ctx, dt, out_bar, nullptr, sy, dim, batch); if (rc) return rc; }    // Σ_n ȳ  (rows)
+    { int rc = bjx_row_moments(ctx, dt, in_bar, nullptr, sz, dim, batch); if (rc) return rc; }     // Σ_n z̄
+  }
   int nblocks = (int)((batch + 255) / 256);
   if (nblocks > 512) nblocks = 512;
   { int rc = bjx_ensure_partials(ctx, (size_t)2 * nblocks); if (rc) return rc; }

@@ -164,7 +164,7 @@ def main():
     rows.append(("vjp(inverse(8×PlanarLayer)) d=128", "f-1", lambda: bj.vjp(bj.inverse(flow), zf, gz, lbz), 4 * 3 * dp + 4, Np))
 
     rows.append(("vjp(RadialLayer) d=128", "f-1", lambda: bj.vjp(rad, z, gz, lbz), 4 * 3 * dp + 4, Np))
-    rows.append(("vjp_params(RadialLayer) d=128 (input pullback + row sums of ȳ and z̄ for z̄₀)", "f-1", lambda: bj.vjp_params(rad, z, gz, lbz), 4 * 5 * dp + 4 + 4 * 4, Np))
+    rows.append(("vjp_params(RadialLayer) d=128 (input pullback with the row sums for z̄₀ in the same pass)", "f-1", lambda: bj.vjp_params(rad, z, gz, lbz), 4 * 3 * dp + 4 + 8 + 64, Np))
     rows.append(("vjp_params(8×PlanarLayer) d=128 (input + w̄, ū, b̄; two passes)", "f-1", lambda: bj.vjp_params(flow, z, gz, lbz), 4 * 5 * dp + 4 + 4 * 4 * nl, Np))
 
     # §8(f) f-3: logpdf(td, Y) fused into the inverting kernel — Y is read once, x is never stored
