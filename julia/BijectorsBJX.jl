@@ -225,6 +225,21 @@ function with_logabsdet_jacobian(sb::Stacked, x::ROCVecOrMat{T}) where {T<:Union
     return y, T(Array(lsum)[1])
 end
 
+# Mean-field family y = tail(μ .+ σ .* z) (ADVI): input pullback and the (μ̄, σ̄) reductions in ONE pass over z and ȳ.
+# moments[1:d] = Σ_n z̄, moments[d+1:2d] = Σ_n z̄ .* z  =>  μ̄ = moments[1:d] ./ σ,  σ̄ = (moments[d+1:2d] .+ sum(ℓ̄)) ./ σ
+function meanfield_pullback(chain, z::ROCMatrix{T}, ȳ::ROCMatrix{T}, ℓ̄::ROCVector{T}) where {T<:Union{Float32,Float64}}
+    d, n = dims(z)
+    keep = Any[]
+    o = ops(chain, T, keep)                                  # tail ∘ Shift(μ) ∘ Scale(σ) as <= 4 elementwise ops
+    seg = [BjxSegment(0, 0, d, length(o), 0, ntuple(k -> k <= length(o) ? o[k] : NOOP, 4))]
+    z̄ = similar(z)
+    moments = AMDGPU.zeros(Float64, 2d + 1)
+    GC.@preserve keep z ȳ ℓ̄ z̄ moments check(ccall((:bjx_stacked_vjp_moments, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+        ctx().h, dtype(T), seg, 1, devptr(z), devptr(ȳ), devptr(ℓ̄), devptr(z̄), devptr(moments), d, n), "bjx_stacked_vjp_moments")
+    return z̄, moments
+end
+
 # ---------------------------------------------------------------- reverse-mode pullbacks (SURVEY.md §8f f-1)
 # The reference's own rrules (ext/BijectorsChainRulesCoreExt.jl:65-197, :311-320) for ROCArray primals:
 # the pullback closure calls the `_vjp` entry with the saved primal input.
