@@ -1968,6 +1968,38 @@ def _graph_cases(bj, orc, r, dt):
     cases.append(("stacked", lambda x: bj.with_logabsdet_jacobian(st, x, per_sample=True), (xa,), (xb,), lambda x: _stacked_oracle(orc, segs, x)))
     ga, gb = two(lambda: np.asfortranarray(r.normal(size=(dim, N)).astype(dt)))
     cases.append(("vjp chain", lambda x, g: (bj.vjp(ch, x, g),), (xa, ga), (xb, gb), lambda x, g: (orc.chain_vjp(ops, x.astype(np.float64), g.astype(np.float64)),)))
+
+    def planar_params(x, g):
+        xbar, p_ = bj.vjp_params(fl, x, g)
+        return xbar, p_["w"], p_["u"], p_["b"]
+
+    def planar_params_ref(x, g):
+        wb, ub, bbar = orc.planar_param_vjp(w, u, bb, x, g)
+        return orc.planar_vjp(w, u, bb, x, g), wb, ub, bbar
+    cases.append(("vjp_params planar", planar_params, (xa, ga), (xb, gb), planar_params_ref))
+    a_raw, b_raw, z0 = np.array([0.3], dtype=dt), np.array([-0.4], dtype=dt), r.normal(size=dim).astype(dt)
+    rad = bj.RadialLayer(dev(a_raw), dev(b_raw), dev(z0))
+
+    def radial_params(x, g):
+        xbar, p_ = bj.vjp_params(rad, x, g)
+        return xbar, p_["alpha_"], p_["beta"], p_["z_0"]
+
+    def radial_params_ref(x, g):
+        ab, bb_, z0b = orc.radial_param_vjp(a_raw, b_raw, z0, x, g)
+        return orc.radial_vjp(a_raw, b_raw, z0, x, g), np.array([ab]), np.array([bb_]), z0b
+    cases.append(("vjp_params radial", radial_params, (xa, ga), (xb, gb), radial_params_ref))
+    mu = np.linspace(-0.5, 0.5, dim)
+    mf = bj.elementwise(bj.exp) @ bj.Shift(dev(mu.astype(dt))) @ bj.Scale(dev(a_vec.astype(dt)))
+
+    def mf_params(x, g):
+        xbar, p_ = bj.vjp_params(mf, x, g)
+        return xbar, p_["shift"], p_["scale"]
+
+    def mf_params_ref(x, g):
+        x64, g64 = x.astype(np.float64), g.astype(np.float64)
+        vbar = g64 * np.exp(mu[:, None] + a_vec[:, None] * x64)
+        return a_vec[:, None] * vbar, vbar.sum(axis=1), (vbar * x64).sum(axis=1)
+    cases.append(("vjp_params mean-field", mf_params, (xa, ga), (xb, gb), mf_params_ref))
     return cases
 
 
