@@ -503,6 +503,24 @@ __global__ __launch_bounds__(256) void rqs_vjp_kernel(const T* __restrict__ blob
 // normalise.jl:41-88.  LDS rows: s = exp(logs), m, q = sqrt(v + eps), b.
 template <class T, bool INV> struct BnF {
   static constexpr bool kLoadInput = true;
+  static constexpr bool kMulti = true;            // the row parameters are fetched once for the columns a lane has in flight
+  template <int V, int U> __device__ void apply_multi(const char* smem, Pack<T, V> (&p)[U], int64_t row, T (&l)[U]) const {
+    const T* t = reinterpret_cast<const T*>(smem);
+#pragma unroll
+    for (int i = 0; i < U; ++i) l[i] = T(0);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int64_t r = row + j;
+      T s, mm, q, bb;
+      if (in_lds) { s = t[r]; mm = t[dim + r]; q = t[2 * dim + r]; bb = t[3 * dim + r]; }
+      else { s = d_exp(logs[r]); mm = m[r]; q = d_sqrt(v[r] + eps); bb = b[r]; }
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        if (!INV) p[i].v[j] = s * (p[i].v[j] - mm) / q + bb;        // :62
+        else p[i].v[j] = (p[i].v[j] - bb) / s * q + mm;              // :83
+      }
+    }
+  }
   const T *b, *logs, *m, *v;
   T eps;
   int64_t dim;
