@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the batched transform + log-abs-det-Jacobian hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5a|c5b]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c3|c4|c5a|c5b] [--scaling weak|strong]
+                    [--collective torch|bjx] [--no-rows]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = ONE pass of the hot path over one batch of synthetic input that is already resident in
@@ -13,8 +14,18 @@ Prints ONE JSON line on rank 0 (contract in the task description) with `roofline
 bytes / HIP-event time of the dominant kernel vs the 8 TB/s HBM peak) and `cpu_baseline`
 (the CPU oracle = a port of the reference algorithm, timed on the host cores of the same box on a
 bounded sample of the same workload).
+
+The same line carries `rows`: one measured sub-line per OTHER BASELINE.json config — c1 (configs[0], a Float64 vector
+of 2^20 through elementwise(exp): a launch-latency case, with its CPU leg), c3, c4, c5a, c5b — each with `kernel`,
+`kernel_ms`, `roofline.frac` and (N = 1) `cpu_baseline`, measured exactly like the headline (same barriers, hipEvent
+pairs on the context stream), so every BASELINE config is witnessed by whoever runs this file.  With N > 1 ranks the
+line also carries `strong_scaling`: configs[1] and configs[3] at their FIXED global batch split into contiguous column
+blocks (`shard_columns`) — the "1 vs 8 GPUs on the sharded batch" reading of north_star — next to the weak-scaling
+headline (`--scaling strong` makes the strong form the headline).
 """
 import argparse
+import ctypes as C
+import gc
 import json
 import math
 import os
@@ -26,6 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md:35)
+METRIC = "M samples/sec for with_logabsdet_jacobian (named bijector, dim×batch); % HBM roofline"
 
 
 def parse():
@@ -33,8 +45,15 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--workload", default="c2", choices=["c2", "c2v", "copy", "c3", "c4", "c5a", "c5b"])
-    p.add_argument("--log2-batch", type=int, default=None, help="override the per-GPU batch (testing)")
+    p.add_argument("--workload", default="c2", choices=["c1", "c2", "c2v", "copy", "c3", "c4", "c5a", "c5b", "vcorr", "pdvec"])
+    p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                   help="weak: the BASELINE batch PER GPU; strong: the BASELINE batch in total, split by shard_columns")
+    p.add_argument("--collective", default="torch", choices=["torch", "bjx"],
+                   help="who all-reduces the Float64 partial Σ logabsdetjac: torch.distributed (RCCL) or the library's own "
+                        "communicator (bjx_comm_init + bjx_allreduce_sum_f64: the path a Julia host takes)")
+    p.add_argument("--no-rows", action="store_true", help="only the headline workload (no per-config sub-lines)")
+    p.add_argument("--rows", default="c1,c3,c4,c5a,c5b")
+    p.add_argument("--log2-batch", type=int, default=None, help="override the batch (testing)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-log2-batch", type=int, default=None)
     return p.parse_args()
@@ -55,15 +74,42 @@ def fill_normal(bj, torch, t, col0, seed, mean=0.0, std=1.0):
 
 
 # ---------------------------------------------------------------------------------- workloads
-def make_workload(name, bj, torch, device, rank, world, log2_batch):
-    """-> dict(step=callable, samples=int per rank, bytes_per_sample=float, label=str, kernel=str, dtype=str, cfg=dict)"""
+DEFAULT_LOG2 = {"c1": 0, "c2": 24, "c2v": 24, "copy": 24, "c3": 22, "c4": 22, "c5a": 20, "c5b": 20, "vcorr": 18, "pdvec": 18}
+
+
+def make_workload(name, bj, torch, device, rank, world, log2_batch, scaling="weak"):
+    """-> dict(step=callable, samples=int on this rank, total=int over all ranks, bytes_per_sample, label, kernel, dtype, cfg)"""
     f32 = torch.float32
+    lb = DEFAULT_LOG2[name] if log2_batch is None else log2_batch
+    NG = 1 << lb                                   # the BASELINE batch
+    if scaling == "strong":                        # fixed global batch, contiguous column blocks (SURVEY.md §8e)
+        lo, hi = bj.shard.shard_columns(NG, world, rank)
+        N, col0, total = hi - lo, lo, NG
+        where = f"batch=2^{lb} split over {world} GPU(s)"
+    else:
+        N, col0, total = NG, rank * NG, NG * world
+        where = f"batch=2^{lb}/GPU"
+    sharded = bj.shard.with_logabsdet_jacobian_sharded
+    if name == "c1":
+        # configs[0]: elementwise(exp) on ONE Float64 vector of 2^20 — the reference's everyday call shape; on the GPU it
+        # is a launch-latency case (16.8 MB of traffic), not a bandwidth one
+        n = 1 << 20
+        x = torch.empty(n, dtype=torch.float64, device=device)
+        y = torch.empty_like(x)
+        fill_normal(bj, torch, x, 0, seed=0)
+        b = bj.elementwise(bj.exp)
+
+        def step():
+            return sharded(b, x, out=y, per_sample=False)[2]
+
+        return dict(step=step, samples=1, total=world, elements=n, bytes_per_sample=16 * n, kernel="chain_flat_kernel<double>", dtype="f64",
+                    label="with_logabsdet_jacobian(elementwise(exp)) Float64 vector of 2^20 (one call = one 'sample'; BASELINE configs[0])",
+                    cfg={"workload": "elementwise(exp) + logabsdetjac on a Float64 Vector of 2^20 (BASELINE configs[0])", "length": n})
     if name in ("c2", "c2v", "copy"):
-        dim, lb = 64, (24 if log2_batch is None else log2_batch)
-        N = 1 << lb
+        dim = 64
         x = colmajor_empty(torch, dim, N, f32, device)
         y = colmajor_empty(torch, dim, N, f32, device)
-        fill_normal(bj, torch, x, rank * N, seed=0)
+        fill_normal(bj, torch, x, col0, seed=0)
         if name == "c2":
             b = bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5)
         elif name == "copy":  # streaming ceiling of the same kernel skeleton (one trivial stage)
@@ -72,19 +118,18 @@ def make_workload(name, bj, torch, device, rank, world, log2_batch):
             b = bj.elementwise(bj.exp) @ bj.Shift(torch.full((dim,), 0.1, device=device)) @ bj.Scale(torch.linspace(0.5, 1.5, dim, device=device))
 
         def step():
-            return bj.shard.with_logabsdet_jacobian_sharded(b, x, out=y, per_sample=False)[2]
+            return sharded(b, x, out=y, per_sample=False)[2]
 
-        return dict(step=step, samples=N, bytes_per_sample=2 * dim * 4, kernel="chain_flat_kernel", dtype="f32",
-                    label=f"with_logabsdet_jacobian(exp∘Shift∘Scale) Float32 dim={dim} batch=2^{lb}/GPU",
+        return dict(step=step, samples=N, total=total, bytes_per_sample=2 * dim * 4, kernel="chain_flat_kernel", dtype="f32",
+                    label=f"with_logabsdet_jacobian(exp∘Shift∘Scale) Float32 dim={dim} {where}",
                     cfg={"workload": "Composed(Shift,Scale,Exp) fused fwd+logabsdetjac (BASELINE configs[1])", "dim": dim,
                          "batch_per_gpu": N, "params": "scalar" if name == "c2" else "per-row vectors"})
     if name == "c3":
-        dim, K, lb = 32, 16, (22 if log2_batch is None else log2_batch)
-        N = 1 << lb
+        dim, K = 32, 16
         x = colmajor_empty(torch, dim, N, f32, device)
         y = colmajor_empty(torch, dim, N, f32, device)
         xb = colmajor_empty(torch, dim, N, f32, device)
-        fill_normal(bj, torch, x, rank * N, seed=0)
+        fill_normal(bj, torch, x, col0, seed=0)
         raw = [colmajor_empty(torch, dim, k, f32, device) for k in (K, K, K - 1)]
         for i, r in enumerate(raw):
             fill_normal(bj, torch, r, 0, seed=100 + i)
@@ -92,19 +137,18 @@ def make_workload(name, bj, torch, device, rank, world, log2_batch):
         ib = bj.inverse(b)
 
         def step():
-            y_, _, s1 = bj.shard.with_logabsdet_jacobian_sharded(b, x, out=y)
-            _, _, s2 = bj.shard.with_logabsdet_jacobian_sharded(ib, y_, out=xb)
+            y_, _, s1 = sharded(b, x, out=y)
+            _, _, s2 = sharded(ib, y_, out=xb)
             return s1
 
-        return dict(step=step, samples=N, bytes_per_sample=(2 * dim * 4 + 4) * 2, kernel="rqs_lds_kernel (forward + inverse launch)", dtype="f32",
-                    label=f"RationalQuadraticSpline K=16 fwd+inverse+logabsdetjac Float32 dim={dim} batch=2^{lb}/GPU",
+        return dict(step=step, samples=N, total=total, bytes_per_sample=(2 * dim * 4 + 4) * 2, kernel="rqs_lds_kernel (forward + inverse launch)", dtype="f32",
+                    label=f"RationalQuadraticSpline K=16 fwd+inverse+logabsdetjac Float32 dim={dim} {where}",
                     cfg={"workload": "RationalQuadraticSpline K=16 fwd+inv+logabsdetjac (BASELINE configs[2])", "dim": dim, "batch_per_gpu": N})
     if name == "c4":
-        dim, nl, lb = 128, 8, (22 if log2_batch is None else log2_batch)
-        N = 1 << lb
+        dim, nl = 128, 8
         x = colmajor_empty(torch, dim, N, f32, device)
         y = colmajor_empty(torch, dim, N, f32, device)
-        fill_normal(bj, torch, x, rank * N, seed=0)
+        fill_normal(bj, torch, x, col0, seed=0)
         w = colmajor_empty(torch, dim, nl, f32, device)
         u = colmajor_empty(torch, dim, nl, f32, device)
         bb = torch.empty(nl, dtype=f32, device=device)
@@ -114,44 +158,59 @@ def make_workload(name, bj, torch, device, rank, world, log2_batch):
         flow = bj.PlanarLayer(w, u, bb)
 
         def step():
-            return bj.shard.with_logabsdet_jacobian_sharded(flow, x, out=y)[2]
+            return sharded(flow, x, out=y)[2]
 
-        return dict(step=step, samples=N, bytes_per_sample=2 * dim * 4 + 4, kernel="planar_reg2_kernel", dtype="f32",
-                    label=f"8-layer PlanarLayer flow fused fwd+logabsdetjac Float32 dim={dim} batch=2^{lb}/GPU",
+        return dict(step=step, samples=N, total=total, bytes_per_sample=2 * dim * 4 + 4, kernel="planar_reg2_kernel", dtype="f32",
+                    label=f"8-layer PlanarLayer flow fused fwd+logabsdetjac Float32 dim={dim} {where}",
                     cfg={"workload": "8x PlanarLayer fused (BASELINE configs[3])", "dim": dim, "layers": nl, "batch_per_gpu": N})
     if name == "c5a":
-        K, lb = 64, (20 if log2_batch is None else log2_batch)
-        N = 1 << lb
+        K = 64
         x = colmajor_empty(torch, K, N, f32, device)
-        fill_normal(bj, torch, x, rank * N, seed=0)
+        fill_normal(bj, torch, x, col0, seed=0)
         x = torch.softmax(x.T, dim=1).T  # synthetic-input preparation (outside the timed region)
         b = bj.SimplexBijector()
 
         def step():
-            return bj.shard.with_logabsdet_jacobian_sharded(b, x)[2]
+            return sharded(b, x)[2]
 
-        return dict(step=step, samples=N, bytes_per_sample=K * 4 + (K - 1) * 4 + 4, kernel="quad_stream_kernel<QSimplexFwd>", dtype="f32",
-                    label=f"SimplexBijector fwd+logabsdetjac Float32 K={K} batch=2^{lb}/GPU",
+        return dict(step=step, samples=N, total=total, bytes_per_sample=K * 4 + (K - 1) * 4 + 4, kernel="quad_stream_kernel<QSimplexFwd>", dtype="f32",
+                    label=f"SimplexBijector fwd+logabsdetjac Float32 K={K} {where}",
                     cfg={"workload": "SimplexBijector (BASELINE configs[4], first half)", "K": K, "batch_per_gpu": N})
     if name == "c5b":
-        K, lb = 64, (20 if log2_batch is None else log2_batch)   # BASELINE configs[4]: batch 2^20 (8.5 GB of y + 17 GB of dense W per GPU)
-        N = 1 << lb
+        K = 64   # BASELINE configs[4]: batch 2^20 (8.5 GB of y + 17 GB of dense W per GPU)
         n = K * (K - 1) // 2
         yv = colmajor_empty(torch, n, N, f32, device)
-        fill_normal(bj, torch, yv, rank * N, seed=0, std=0.5)
+        fill_normal(bj, torch, yv, col0, seed=0, std=0.5)
         ib = bj.inverse(bj.VecCholeskyBijector("U"))
 
         def step():
-            return bj.shard.with_logabsdet_jacobian_sharded(ib, yv)[2]
+            return sharded(ib, yv)[2]
 
-        return dict(step=step, samples=N, bytes_per_sample=n * 4 + K * K * 4 + 4, kernel="chol_inv_chunk_kernel", dtype="f32",
-                    label=f"inverse VecCholeskyBijector (y->W dense + logJ) Float32 K={K} batch=2^{lb}/GPU",
+        return dict(step=step, samples=N, total=total, bytes_per_sample=n * 4 + K * K * 4 + 4, kernel="chol_inv_chunk_kernel", dtype="f32",
+                    label=f"inverse VecCholeskyBijector (y->W dense + logJ) Float32 K={K} {where}",
                     cfg={"workload": "VecCholeskyBijector inverse, dense W (BASELINE configs[4], second half)", "K": K, "batch_per_gpu": N})
+    if name in ("vcorr", "pdvec"):
+        # the matrix-variate constraint bijectors that need a per-sample Cholesky factorisation
+        # (corr.jl:128-162, pd.jl:34-60).  Input = K x K correlation / covariance matrices X = U'U built on the device.
+        K = 32
+        n = K * (K - 1) // 2 if name == "vcorr" else K * (K + 1) // 2
+        yv = colmajor_empty(torch, n, N, f32, device)
+        fill_normal(bj, torch, yv, col0, seed=0, std=0.3)
+        b = bj.VecCorrBijector() if name == "vcorr" else bj.PDVecBijector()
+        X = bj.transform(bj.inverse(b), yv)        # preparation, outside the timed region
+        del yv
+
+        def step():
+            return sharded(b, X)[2]
+
+        return dict(step=step, samples=N, total=total, bytes_per_sample=K * K * 4 + n * 4 + 4, kernel="chol_link_kernel", dtype="f32",
+                    label=f"{'VecCorrBijector' if name == 'vcorr' else 'PDVecBijector'} (X -> Cholesky -> y + logabsdetjac) Float32 K={K} {where}",
+                    cfg={"workload": f"{'VecCorrBijector' if name == 'vcorr' else 'PDVecBijector'} forward (SURVEY.md §8f-4)", "K": K, "batch_per_gpu": N})
     raise ValueError(name)
 
 
 # ---------------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(name, log2_batch):
+def cpu_baseline(name, log2_batch, budget=8.0, variants=True):
     """The oracle (a C++ port of the reference algorithm, reference-structured: one allocating pass
     per composed stage, single thread — the reference is single-threaded) on a bounded sample."""
     import numpy as np
@@ -161,7 +220,15 @@ def cpu_baseline(name, log2_batch):
     rng = np.random.default_rng(0)
     if name == "copy":
         name = "c2"
-    if name in ("c2", "c2v"):
+    unit = "M samples/s"
+    if name == "c1":
+        n = 1 << 20
+        N = 1
+        x = rng.standard_normal(n)
+        ops = [(orc.OP_EXP, None, None)]
+        fn = lambda: orc.chain(ops, x)
+        sample = "oracle elementwise(exp) + Σ log-det on the whole Float64 vector of 2^20 (1 thread)"
+    elif name in ("c2", "c2v"):
         lb = 20 if log2_batch is None else log2_batch
         N, dim = 1 << lb, 64
         x = np.asfortranarray(rng.standard_normal((dim, N), dtype=np.float32))
@@ -197,12 +264,22 @@ def cpu_baseline(name, log2_batch):
         x = np.asfortranarray(rng.dirichlet(np.ones(K), size=N).T.astype(np.float32))
         fn = lambda: orc.simplex(x)
         sample = f"oracle Simplex transform + logabsdetjac (2 passes, 1 thread) on Float32 64 x 2^{lb}"
+    elif name in ("vcorr", "pdvec"):
+        lb = 12 if log2_batch is None else log2_batch
+        N, K = 1 << lb, 32
+        n = K * (K - 1) // 2 if name == "vcorr" else K * (K + 1) // 2
+        y = np.asfortranarray((0.3 * rng.standard_normal((n, N))).astype(np.float32))
+        f = orc.vec_corr if name == "vcorr" else orc.pd_vec
+        X, _ = f(y, inverse=True)
+        fn = lambda: f(X)
+        sample = f"oracle {'VecCorrBijector' if name == 'vcorr' else 'PDVecBijector'} per sample (Cholesky + link, 1 thread) on Float32 {K}x{K} x 2^{lb}"
     else:
         lb = 11 if log2_batch is None else log2_batch
         N, K = 1 << lb, 64
         y = np.asfortranarray((0.5 * rng.standard_normal((K * (K - 1) // 2, N))).astype(np.float32))
         fn = lambda: orc.vec_cholesky(y, inverse=True)
         sample = f"oracle _inv_link_chol_lkj per sample (1 thread) on Float32 2016 x 2^{lb}"
+
     def best_of(f, budget):
         f()  # warm (page faults, libm init)
         best, reps, t_all = float("inf"), 0, time.perf_counter()
@@ -213,10 +290,13 @@ def cpu_baseline(name, log2_batch):
             reps += 1
         return best, reps
 
-    best, reps = best_of(fn, 8.0)
-    out = {"value": N / best / 1e6, "unit": "M samples/s", "cores": 1, "kind": "port",
+    best, reps = best_of(fn, budget)
+    out = {"value": N / best / 1e6, "unit": unit, "cores": 1, "kind": "port",
            "sample": f"{sample}; best of {reps} runs, {best * 1e3:.1f} ms each; host has {os.cpu_count()} cores"}
-    if name in ("c2", "c2v"):
+    if name == "c1":
+        out["us_per_call"] = best * 1e6
+        out["M_elements_per_s"] = (1 << 20) / best / 1e6
+    if name in ("c2", "c2v") and variants:
         # the best a CPU can do with the same arithmetic: the chain fused into ONE pass, on one
         # core and on all host cores (column blocks on a thread pool; the oracle call releases the GIL)
         from concurrent.futures import ThreadPoolExecutor
@@ -243,12 +323,79 @@ def traffic_from_profiles(workload):
         return None
 
 
+# ---------------------------------------------------------------------------------- one measured workload
+class Env:
+    pass
+
+
+def measure(env, name, steps, warmup, scaling, log2_batch=None):
+    """Warm up, then time EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks.
+    -> dict on every rank (only rank 0 uses it)."""
+    torch, bj, dist = env.torch, env.bj, env.dist
+    wl = make_workload(name, bj, torch, env.device, env.rank, env.world, log2_batch, scaling)
+    ctx = bj.context(env.device)
+    lib = bj._lib.load()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    last = None
+    for _ in range(warmup):
+        last = wl["step"]()
+    barrier()
+    lib.bjx_kernel_time_begin(ctx.h)          # one hipEvent pair around every dominant-kernel launch (context stream)
+    lib.bjx_time_begin(ctx.h)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = wl["step"]()
+    ev_ms = C.c_float(0.0)
+    lib.bjx_time_end(ctx.h, C.byref(ev_ms))   # hipEvent pair around the whole timed region (helpers + gaps included)
+    barrier()
+    dt = time.perf_counter() - t0
+    k_ms, k_n = C.c_float(0.0), C.c_int(0)
+    bj._lib.check(ctx.h, lib.bjx_kernel_time_end(ctx.h, C.byref(k_ms), C.byref(k_n)), "bjx_kernel_time_end")
+    if dist is not None:
+        tt = torch.tensor([dt, ev_ms.value, k_ms.value], dtype=torch.float64, device=env.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, ev, kern_total = float(tt[0]), float(tt[1]), float(tt[2])
+    else:
+        ev, kern_total = ev_ms.value, k_ms.value
+    ladj_total = float(last[0]) if last is not None else float("nan")
+    ms_per_step = dt / steps * 1e3
+    # dominant kernel(s) of ONE step: per-launch hipEvent pairs summed, / steps (a step of c3 has two
+    # launches, forward + inverse, and `bytes_per_sample` counts both)
+    kern_ms = kern_total / steps
+    alg_bytes = wl["samples"] * wl["bytes_per_sample"]       # per step, one GPU
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else float("nan")
+    res = {
+        "workload": name, "label": wl["label"], "value": wl["total"] / (dt / steps) / 1e6, "unit": "M samples/s", "dtype": wl["dtype"],
+        "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup, "scaling": scaling, "config": wl["cfg"],
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic_from_profiles(name), "kernel": wl["kernel"], "kernel_ms": kern_ms,
+                     "kernel_launches_per_step": k_n.value / max(steps, 1), "stream_region_ms_per_step": ev / steps,
+                     "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
+        "sum_logabsdetjac": ladj_total,
+    }
+    if name == "c1":
+        res["us_per_call"] = ms_per_step * 1e3
+        res["M_elements_per_s"] = wl["elements"] * env.world / (dt / steps) / 1e6
+    del wl, last
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     a = parse()
     import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    env = Env()
+    env.torch = torch
+    env.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+    env.rank = rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
@@ -260,80 +407,67 @@ def main():
     else:
         torch.cuda.set_device(0)
         dist = None
+    env.dist = dist
     if a.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    device = torch.device("cuda", torch.cuda.current_device())
+    env.device = torch.device("cuda", torch.cuda.current_device())
 
     import bijectors_amd as bj
 
-    wl = make_workload(a.workload, bj, torch, device, rank, world, a.log2_batch)
-    ctx = bj.context(device)
-    lib = bj._lib.load()
+    env.bj = bj
+    if a.collective == "bjx" and world > 1:
+        bj.shard.init_comm(env.device)             # ncclUniqueId broadcast through torch.distributed, then RCCL inside the library
+        bj.shard.use_library_collective(True)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    last = None
-    for _ in range(a.warmup):
-        last = wl["step"]()
-    barrier()
-    import ctypes as C
-
-    lib.bjx_kernel_time_begin(ctx.h)          # one hipEvent pair around every dominant-kernel launch (context stream)
-    lib.bjx_time_begin(ctx.h)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        last = wl["step"]()
-    ev_ms = C.c_float(0.0)
-    lib.bjx_time_end(ctx.h, C.byref(ev_ms))   # hipEvent pair around the whole timed region (helpers + gaps included)
-    barrier()
-    dt = time.perf_counter() - t0
-    k_ms, k_n = C.c_float(0.0), C.c_int(0)
-    bj._lib.check(ctx.h, lib.bjx_kernel_time_end(ctx.h, C.byref(k_ms), C.byref(k_n)), "bjx_kernel_time_end")
-    if dist is not None:
-        tt = torch.tensor([dt, ev_ms.value, k_ms.value], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, ev, kern_total = float(tt[0]), float(tt[1]), float(tt[2])
-    else:
-        ev, kern_total = ev_ms.value, k_ms.value
-    ladj_total = float(last[0]) if last is not None else float("nan")
+    head = measure(env, a.workload, a.steps, a.warmup, a.scaling, a.log2_batch)
+    rows, strong = [], []
+    want_rows = (not a.no_rows) and a.workload == "c2" and a.log2_batch is None
+    if want_rows:
+        rsteps, rwarm = max(3, min(a.steps, 10)), max(1, min(a.warmup, 3))
+        for r in [r for r in a.rows.split(",") if r]:
+            try:
+                rows.append(measure(env, r, rsteps, rwarm, a.scaling))
+            except Exception as e:                 # a sub-line must never cost the headline
+                rows.append({"workload": r, "error": repr(e)})
+        if world > 1 and a.scaling == "weak":
+            for r in ("c2", "c4"):
+                try:
+                    strong.append(measure(env, r, rsteps, rwarm, "strong"))
+                except Exception as e:
+                    strong.append({"workload": r, "error": repr(e)})
 
     if rank == 0:
-        ms_per_step = dt / a.steps * 1e3
-        total_samples = wl["samples"] * world
-        value = total_samples / (dt / a.steps) / 1e6
-        # dominant kernel(s) of ONE step: per-launch hipEvent pairs summed, / steps (a step of c3 has two
-        # launches, forward + inverse, and `bytes_per_sample` counts both)
-        kern_ms = kern_total / a.steps
-        region_ms = ev / a.steps                                 # incl. parameter-prep / finalize helpers and gaps
-        alg_bytes = wl["samples"] * wl["bytes_per_sample"]       # per step, one GPU
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = traffic_from_profiles(a.workload)
         out = {
-            "metric": "M samples/sec for with_logabsdet_jacobian (named bijector, dim×batch); % HBM roofline",
-            "value": value, "unit": "M samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": wl["dtype"], "data": "synthetic (Philox N(0,1), shard-invariant)",
-            "config": dict(wl["cfg"], parallelism=f"batch-sharded x{world}, one f64 all-reduce of Σlogabsdetjac"),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": wl["kernel"], "kernel_ms": kern_ms, "kernel_launches_per_step": k_n.value / max(a.steps, 1),
-                         "stream_region_ms_per_step": region_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
-            "sum_logabsdetjac": ladj_total,
-            "label": wl["label"],
+            "metric": METRIC, "value": head["value"], "unit": "M samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+            "dtype": head["dtype"], "data": "synthetic (Philox N(0,1), shard-invariant)",
+            "config": dict(head["config"], parallelism=f"batch-sharded x{world}, one f64 all-reduce of Σlogabsdetjac ({a.collective})"),
+            "roofline": head["roofline"], "sum_logabsdetjac": head["sum_logabsdetjac"], "label": head["label"],
         }
-        if not a.no_cpu_baseline and world == 1:
+        for k in ("us_per_call", "M_elements_per_s"):
+            if k in head:
+                out[k] = head[k]
+        cpu_ok = not a.no_cpu_baseline and world == 1
+        if cpu_ok:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_log2_batch)
             except Exception as e:  # the baseline is informational; never lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "M samples/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
         else:
             out["cpu_baseline"] = None
+        if want_rows:
+            for r in rows:
+                if cpu_ok and "error" not in r:
+                    try:
+                        r["cpu_baseline"] = cpu_baseline(r["workload"], None, budget=2.5, variants=False)
+                    except Exception as e:
+                        r["cpu_baseline"] = {"value": None, "unit": "M samples/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+            out["rows"] = rows
+            if strong:
+                out["strong_scaling"] = strong
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

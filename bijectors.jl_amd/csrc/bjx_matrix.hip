@@ -1,0 +1,399 @@
+// bjx_matrix.hip — SURVEY.md §8(f) f-4: the matrix-variate constraint bijectors that need a per-sample Cholesky
+// factorisation, batched over samples:
+//   VecCorrBijector  corr.jl:128-162   X[K,K] correlation matrix <-> y[K(K-1)/2]
+//   CorrBijector     corr.jl:64-92     X[K,K]                    <-> Y[K,K] (strict upper triangle, zeros elsewhere)
+//   PDBijector       pd.jl:1-36        X[K,K] positive definite  <-> Y[K,K] (lower factor with log diagonal)
+//   PDVecBijector    pd.jl:38-60       X[K,K]                    <-> y[K(K+1)/2]
+// and Scale with a MATRIX parameter (scale.jl:14,17,35-36): y = a*x, x = a\y, logabsdetjac = logabsdet(a).
+//
+// Mapping on gfx950 (matrix_link_kernel): ONE WAVE = ONE SAMPLE, lane i = row i of the lower Cholesky factor L kept
+// in REGISTERS (a[0..KP), fully unrolled, so every register index is a compile-time constant).
+//   load     the K*K (or packed) input of the sample with coalesced 16-byte loads into an odd-pitch LDS tile;
+//            lane i picks its row of the triangle the reference reads (cholesky(Hermitian(X)) reads the UPPER triangle,
+//            cholesky(Hermitian(X, :L)) the LOWER one: src/utils.jl:37,50)
+//   factor   right-looking: for column k: d = sqrt(A[k,k]) comes from lane k by v_readlane (a wave-uniform SGPR
+//            operand), the column is scaled, and for every later column j the multiplier L[j,k] is one more
+//            v_readlane of lane j's register k feeding one FMA: K^2/2 (readlane + FMA) per sample, no LDS traffic and
+//            no divergent lanes in the O(K^3) part.  The factor U = L' of the correlation kinds has COLUMN j in lane j.
+//   link     in-lane: the LKJ link walks a column of U top to bottom / bottom to top (corr.jl:277-297, :314-335,
+//            :345-399), which is a loop over the registers of ONE lane; log-det terms are lane sums + one wave reduction
+//   inverse  X = U'U = L L' (pd_from_upper / pd_from_lower, src/utils.jl:17-24): X[i,j] = sum_m L[i,m] L[j,m] with the
+//            rows of L exact zeros past the diagonal, again K^2/2 (readlane + FMA)
+//   store    through the same LDS tile into coalesced stores
+// Algorithmic bytes per sample: K*K*sizeof(T) on the matrix side (the reference materialises dense matrices) +
+// the packed / dense unconstrained side + 4 for the per-sample log-det.  The factorisation is O(K^3/3) flop on
+// O(K^2) bytes (K/12 flop per byte in Float32): HBM-bound on paper, but the readlane + FMA pair issues 2 wave
+// instructions per 64 useful FMA lanes only in the last columns, so the kernel is VALU-issue-bound.
+#include "bjx_internal.h"
+
+using namespace bjx;
+
+namespace {
+
+enum { MK_VEC_CORR = 0, MK_CORR = 1, MK_PD = 2, MK_PD_VEC = 3 };
+
+__device__ __forceinline__ float rdlane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ double rdlane(double v, int l) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+// asinh / atanh / tanh / logcosh of the link: Float32 on the hardware log/exp/rcp units (parity bar 1e-3), Float64 exact OCML
+template <class T> struct LinkMath;
+template <> struct LinkMath<float> {
+  using F = Fast<float>;
+  // y = asinh(w / sqrt(rem)), lc = logcosh(y) = log(sqrt(1 + z^2))
+  static __device__ __forceinline__ void asinh_lc(float w, float rem, float& y, float& lc) {
+    const float r = F::rsqrt(rem);
+    const float z = w * r;
+    const float t = F::sqrt(z * z + 1.0f);
+    const float az = fabsf(z);
+    y = __builtin_copysignf(F::log1p(az + z * z * F::rcp(1.0f + t)), z);     // log(|z| + sqrt(z^2+1)) without cancellation near 0
+    lc = F::log(t);
+  }
+  static __device__ __forceinline__ void atanh_lc(float w, float& y, float& lc) {
+    y = 0.5f * F::log((1.0f + w) * F::rcp(1.0f - w));
+    lc = -0.5f * F::log((1.0f - w) * (1.0f + w));                            // logcosh(atanh w) = -log(1 - w^2)/2
+  }
+  // z = tanh(y), lc = logcosh(y) from one exp (LogExpFunctions.logcosh: |y| + log1pexp(-2|y|) - log 2)
+  static __device__ __forceinline__ void tanh_lc(float y, float& z, float& lc) {
+    const float ay = fabsf(y);
+    const float t = F::exp(-2.0f * ay);
+    z = __builtin_copysignf((1.0f - t) * F::rcp(1.0f + t), y);
+    lc = ay + F::log1p(t) - Num<float>::log2;
+  }
+  static __device__ __forceinline__ float exp(float x) { return F::exp(x); }
+  static __device__ __forceinline__ float log(float x) { return F::log(x); }
+};
+template <> struct LinkMath<double> {
+  static __device__ __forceinline__ void asinh_lc(double w, double rem, double& y, double& lc) {
+    const double z = w / ::sqrt(rem);
+    y = ::asinh(z);
+    lc = 0.5 * ::log1p(z * z);
+  }
+  static __device__ __forceinline__ void atanh_lc(double w, double& y, double& lc) {
+    y = ::atanh(w);
+    lc = -0.5 * ::log1p(-w * w);
+  }
+  static __device__ __forceinline__ void tanh_lc(double y, double& z, double& lc) {
+    z = ::tanh(y);
+    lc = d_logcosh(y);
+  }
+  static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+  static __device__ __forceinline__ double log(double x) { return ::log(x); }
+};
+
+// Layout of the contiguous run of one sample in global memory; every layout lands in the tile as tile[c*pitch + r]:
+//   L_DENSE  K x K column-major          column c has K entries
+//   L_TRIU1  triu1_to_vec (src/utils.jl:99-108): strict upper triangle, column-major: column c has c entries (c >= 1)
+//   L_TRIU   triu_to_vec  (src/utils.jl:137-142): upper triangle with the diagonal:   column c has c + 1 entries
+enum { L_DENSE = 0, L_TRIU1 = 1, L_TRIU = 2 };
+template <int LAY> __device__ __forceinline__ int col_len(int c, int K) { return LAY == L_DENSE ? K : (LAY == L_TRIU1 ? c : c + 1); }
+template <int LAY> __device__ __forceinline__ void decode(int e, int K, int& c, int& r) {
+  if (LAY == L_DENSE) { c = e / K; r = e - c * K; return; }
+  // first column whose run contains flat index e (float estimate, corrected exactly)
+  int cc = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) + (LAY == L_TRIU1 ? 1.0f : -1.0f)) * 0.5f);
+  auto start = [](int col) { return LAY == L_TRIU1 ? col * (col - 1) / 2 : col * (col + 1) / 2; };
+  while (start(cc) > e) --cc;
+  while (start(cc + 1) <= e) ++cc;
+  c = cc; r = e - start(cc);
+}
+template <int LAY> __device__ __forceinline__ void advance(int step, int K, int& c, int& r) {
+  r += step;
+  while (r >= col_len<LAY>(c, K)) { r -= col_len<LAY>(c, K); ++c; }
+}
+// coalesced copy of the `cnt` contiguous elements of one sample between global memory and the LDS tile
+template <class T, int LAY> __device__ __forceinline__ void stage_in(const T* __restrict__ g, T* tile, int cnt, int K, int pitch, int lane, bool vec_ok) {
+  constexpr int VW = Vec16<T>::N;
+  const int W = vec_ok ? VW : 1;
+  int e = lane * W, c = 0, r = 0;
+  if (e < cnt) decode<LAY>(e, K, c, r);
+  for (; e < cnt; e += 64 * W) {
+    if (vec_ok) {
+      const Pack<T, VW> p = load_pack<T, VW, true>(g + e);
+      int cc = c, rr = r;
+#pragma unroll
+      for (int t = 0; t < VW; ++t) {
+        tile[cc * pitch + rr] = p.v[t];
+        advance<LAY>(1, K, cc, rr);
+      }
+    } else tile[c * pitch + r] = __builtin_nontemporal_load(g + e);
+    if (e + 64 * W < cnt) advance<LAY>(64 * W, K, c, r);
+  }
+}
+template <class T, int LAY> __device__ __forceinline__ void stage_out(T* __restrict__ g, const T* tile, int cnt, int K, int pitch, int lane, bool vec_ok) {
+  constexpr int VW = Vec16<T>::N;
+  const int W = vec_ok ? VW : 1;
+  int e = lane * W, c = 0, r = 0;
+  if (e < cnt) decode<LAY>(e, K, c, r);
+  for (; e < cnt; e += 64 * W) {
+    if (vec_ok) {
+      Pack<T, VW> p;
+      int cc = c, rr = r;
+#pragma unroll
+      for (int t = 0; t < VW; ++t) {
+        p.v[t] = tile[cc * pitch + rr];
+        advance<LAY>(1, K, cc, rr);
+      }
+      store_pack<T, VW, true>(g + e, p);
+    } else __builtin_nontemporal_store(tile[c * pitch + r], g + e);
+    if (e + 64 * W < cnt) advance<LAY>(64 * W, K, c, r);
+  }
+}
+
+// One wave per sample; block = 1 wave; the grid walks the batch.  KP = register rows (K <= KP).
+template <class T, int KP, int KIND, bool INV>
+__global__ __launch_bounds__(64) void matrix_link_kernel(const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps, int K0, int pitch,
+                                                         int64_t batch, int accumulate, int vec_in, int vec_out, double* partials) {
+  extern __shared__ __align__(16) unsigned char smem_[];
+  T* tile = reinterpret_cast<T*>(smem_);
+  __shared__ double red[1];
+  using M = LinkMath<T>;
+  constexpr bool CORR = KIND == MK_VEC_CORR || KIND == MK_CORR;
+  constexpr int LAY = KIND == MK_VEC_CORR ? L_TRIU1 : (KIND == MK_PD_VEC ? L_TRIU : L_DENSE);   // layout of the unconstrained side
+  const int lane0 = threadIdx.x;
+  int K = K0;
+  const int KK = K * K;
+  const int nv = KIND == MK_VEC_CORR ? K * (K - 1) / 2 : (KIND == MK_PD_VEC ? K * (K + 1) / 2 : KK);   // elements on the unconstrained side
+  double acc = 0.0;
+  for (int64_t s = blockIdx.x; s < batch; s += gridDim.x) {
+    // The lane id and K are made opaque at every phase: the several hundred compare masks of the unrolled code below
+    // (lane == k, j < K, ...) are loop-invariant; left alone they are all hoisted out of the sample loop / kept alive
+    // across phases and spilled (measured: 670 SGPR spills + the register row in scratch).
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    asm volatile("" : "+s"(K));
+    const bool live = lane < K;
+    T* myrow = tile + (live ? lane : 0) * pitch;      // tile row `lane`: column `lane` of an upper-triangular matrix
+    T a[KP];                                  // row `lane` of the lower factor L (= column `lane` of U = L')
+    T lsum = T(0);                            // this lane's log-det terms
+    if constexpr (!INV) {
+      // ---------------------------------------------------------------- X -> Cholesky -> link
+      stage_in<T, L_DENSE>(in + s * KK, tile, KK, K, pitch, lane, vec_in != 0);
+      __builtin_amdgcn_wave_barrier();
+      // A[i][j], j <= i, from the triangle the reference reads; identity padding outside K
+#pragma unroll
+      for (int j = 0; j < KP; ++j) {
+        T v = j == lane ? T(1) : T(0);
+        if (j < K && live) v = CORR ? myrow[j] : tile[j * pitch + lane];   // X[j,i] (upper) | X[i,j] (lower)
+        a[j] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // right-looking Cholesky in registers
+      asm volatile("" : "+v"(lane));
+      asm volatile("" : "+s"(K));
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        if (k < K) {
+          const T d = d_sqrt(rdlane(a[k], k));
+          const T inv = T(1) / d;
+          a[k] = lane == k ? d : a[k] * inv;
+#pragma unroll
+          for (int j = k + 1; j < KP; ++j) a[j] -= a[k] * rdlane(a[k], j);
+        }
+      }
+      asm volatile("" : "+v"(lane));
+      asm volatile("" : "+s"(K));
+      if constexpr (CORR) {
+        // column `lane` of U = my registers -> my tile row; then corr.jl:277-297 / :314-335 walks it bottom-up (a rolled
+        // loop over LDS: the per-entry asinh is too large to unroll 64 times); y overwrites w in place.
+        // log-det = -_logabsdetjac_inv_corr(y) (:92, :135-137, :453-472): weight K - i + 1 for 1-based row i.
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+          if (j < K && live) myrow[j] = a[j];
+        __builtin_amdgcn_wave_barrier();
+        const T dg = live ? myrow[lane] : T(1);
+        T rem = dg * dg;
+        for (int i = K - 2; i >= 0; --i) {
+          const bool act = i < lane && live;
+          const T w = act ? myrow[i] : T(0);
+          T y, lc;
+          if (KIND == MK_VEC_CORR && i == 0) M::atanh_lc(w, y, lc);                        // :322 atanh(W[1, j])
+          else M::asinh_lc(w, act ? rem : T(1), y, lc);
+          if (act) {
+            rem += w * w;
+            lsum += T(K - i) * lc;
+            myrow[i] = y;
+          }
+        }
+        if (KIND == MK_CORR) {                                                             // zero fill on and below the diagonal (:292-294)
+          for (int i = live ? lane : K; i < K; ++i) myrow[i] = T(0);
+        }
+      } else {
+        // pd.jl:11,27-31,41: Y = replace_diag(log, L); log-det = -(sum_i (d+2-i) log L_ii + d log 2)
+        T dg = T(1);
+#pragma unroll
+        for (int j = 0; j < KP; ++j) dg = j == lane ? a[j] : dg;
+        const T ld = M::log(dg);
+        if (live) lsum = -(T(K + 1 - lane) * ld + Num<T>::log2);
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+          if (j < K && live) {
+            const T v = j == lane ? ld : (j < lane ? a[j] : T(0));
+            if (KIND == MK_PD) tile[j * pitch + lane] = v;                                 // Y[lane, j]
+            else if (j <= lane) myrow[j] = v;                                              // triu_to_vec(Y'): (Y')[r,c] = L[c,r], r <= c
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (out) stage_out<T, LAY>(out + s * nv, tile, nv, K, pitch, lane, vec_out != 0);
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      // ---------------------------------------------------------------- inverse link -> L -> X = L L'
+      stage_in<T, LAY>(in + s * nv, tile, nv, K, pitch, lane, vec_in != 0);
+      __builtin_amdgcn_wave_barrier();
+      if constexpr (CORR) {
+        // corr.jl:345-399: column `lane` of U top-down (rolled, in place in my tile row);
+        // + sum_{j=2}^{K-1} (K-j) log U[j,j] (:77-79, :144-146), log U[j,j] = the final log_remainder of column j
+        T lr = T(0);
+        for (int i = 0; i < K - 1; ++i) {
+          const bool act = i < lane && live;
+          const T yv = act ? myrow[i] : T(0);
+          T z, lc;
+          M::tanh_lc(yv, z, lc);
+          const T e = M::exp(lr);
+          if (act) { myrow[i] = z * e; lr -= lc; lsum += lr; }
+        }
+        if (live) {
+          myrow[lane] = M::exp(lr);
+          lsum += lr + ((lane >= 1 && lane <= K - 2) ? T(K - 1 - lane) * lr : T(0));
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+          T v = j == lane ? T(1) : T(0);
+          if (j < K && live) v = j <= lane ? myrow[j] : T(0);
+          a[j] = v;
+        }
+      } else {
+        // pd.jl:13-16,44-47: L = lower_triangular(replace_diag(exp, Y)); log-det = +(sum_i (d+2-i) Y_ii + d log 2) (interface.jl:278-281)
+        T yd = T(0);
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+          T v = j == lane ? T(1) : T(0);
+          if (j < K && live) {
+            const T t = (j <= lane) ? (KIND == MK_PD ? tile[j * pitch + lane] : myrow[j]) : T(0);
+            if (j == lane) { yd = t; v = M::exp(t); } else v = t;
+          }
+          a[j] = v;
+        }
+        if (live) lsum = T(K + 1 - lane) * yd + Num<T>::log2;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // X[lane][j] = sum_{m <= j} L[lane][m] * L[j][m]   (rows are exact zeros past the diagonal)
+      asm volatile("" : "+v"(lane));
+      asm volatile("" : "+s"(K));
+      if (out) {
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+          if (j < K) {
+            T x = T(0);
+#pragma unroll
+            for (int m = 0; m <= j; ++m) {
+              x += a[m] * rdlane(a[m], j);
+              if ((m & 7) == 7) __builtin_amdgcn_sched_barrier(0);       // keep each readlane next to its FMA (64 hoisted Float64 readlanes = 128 SGPRs: spills)
+            }
+            if (lane < K) tile[j * pitch + lane] = x;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        stage_out<T, L_DENSE>(out + s * KK, tile, KK, K, pitch, lane, vec_out != 0);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (ladj_ps || partials) {
+      const double l = group_sum<64>((double)lsum);
+      if (lane == 0) {
+        const T lt = (T)l;
+        if (ladj_ps) ladj_ps[s] = accumulate ? ladj_ps[s] + lt : lt;
+        acc += (double)lt;
+      }
+    }
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
+template <class T, int KP, int KIND>
+int launch_kp(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* partials, int K, int pitch, int64_t batch, int accum, int vin, int vout,
+              int grid, size_t smem) {
+  if (inverse) {
+    bjx_allow_big_lds(matrix_link_kernel<T, KP, KIND, true>, smem);
+    hipLaunchKernelGGL((matrix_link_kernel<T, KP, KIND, true>), dim3(grid), dim3(64), smem, ctx->stream, in, out, ladj_ps, K, pitch, batch, accum, vin, vout, partials);
+  } else {
+    bjx_allow_big_lds(matrix_link_kernel<T, KP, KIND, false>, smem);
+    hipLaunchKernelGGL((matrix_link_kernel<T, KP, KIND, false>), dim3(grid), dim3(64), smem, ctx->stream, in, out, ladj_ps, K, pitch, batch, accum, vin, vout, partials);
+  }
+  return 0;
+}
+
+template <class T, int KIND>
+int matrix_impl(bjx_ctx* ctx, const char* who, int inverse, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags) {
+  if (batch == 0) {
+    if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
+    return BJX_OK;
+  }
+  BJX_REQUIRE(ctx, K <= 64, BJX_ERR_UNSUPPORTED, "%s: K = %lld; the register-resident Cholesky kernel takes K <= 64", who, (long long)K);
+  constexpr int VW = Vec16<T>::N;
+  const int64_t KK = K * K;
+  const int64_t nv = KIND == MK_VEC_CORR ? K * (K - 1) / 2 : (KIND == MK_PD_VEC ? K * (K + 1) / 2 : KK);
+  const int pitch = (int)((K & 1) ? K : K + 1);                  // odd: lane i at tile[i*pitch + j] hits 64 distinct banks
+  int64_t words = (int64_t)K * pitch;
+  if (words < nv) words = nv;
+  words = (words + VW + 3) / 4 * 4;
+  const size_t smem = (size_t)words * sizeof(T);
+  const int64_t in_n = inverse ? nv : KK, out_n = inverse ? KK : nv;
+  const int vin = bjx_aligned16(in) && in_n % VW == 0 && K >= VW;
+  const int vout = out && bjx_aligned16(out) && out_n % VW == 0 && K >= VW;
+  const int64_t cap = (int64_t)ctx->num_cu * 16;
+  const int grid = (int)(batch < cap ? batch : cap);
+  if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
+  double* partials = ladj_sum ? ctx->partials : nullptr;
+  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  {
+    BjxProf prof_(ctx);
+#define BJX_MK(KP_) launch_kp<T, KP_, KIND>(ctx, inverse, in, out, ladj_ps, partials, (int)K, pitch, batch, accum, vin, vout, grid, smem)
+    if (K <= 8) BJX_MK(8);
+    else if (K <= 16) BJX_MK(16);
+    else if (K <= 32) BJX_MK(32);
+    else BJX_MK(64);
+#undef BJX_MK
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  if (ladj_sum) return bjx_launch_finalize(ctx, grid, ladj_sum, 0.0, 0, 0.0, flags);
+  return BJX_OK;
+}
+
+template <int KIND>
+int matrix_entry(bjx_ctx* ctx, const char* who, bjx_dtype dt, int inverse, const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t K,
+                 int64_t batch, uint32_t flags) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, K >= 1 && batch >= 0, BJX_ERR_SHAPE, "%s: bad size", who);
+  BJX_REQUIRE(ctx, in || batch == 0 || (K == 1 && KIND == MK_VEC_CORR && inverse), BJX_ERR_ARG, "%s: null input", who);
+  BJX_REQUIRE(ctx, out || ladj_ps || ladj_sum || batch == 0, BJX_ERR_ARG, "%s: nothing to compute", who);
+  if (dt == BJX_F32) return matrix_impl<float, KIND>(ctx, who, inverse, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, K, batch, flags);
+  if (dt == BJX_F64) return matrix_impl<double, KIND>(ctx, who, inverse, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, K, batch, flags);
+  return bjx_fail(ctx, BJX_ERR_ARG, "%s: bad dtype %d", who, (int)dt);
+}
+
+}  // namespace
+
+BJX_API int bjx_vec_corr(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch,
+                         uint32_t flags) {
+  return matrix_entry<MK_VEC_CORR>(ctx, "bjx_vec_corr", dt, inverse, in, out, ladj_ps, ladj_sum, K, batch, flags);
+}
+BJX_API int bjx_corr(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch,
+                     uint32_t flags) {
+  return matrix_entry<MK_CORR>(ctx, "bjx_corr", dt, inverse, in, out, ladj_ps, ladj_sum, K, batch, flags);
+}
+BJX_API int bjx_pd(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch,
+                   uint32_t flags) {
+  return matrix_entry<MK_PD>(ctx, "bjx_pd", dt, inverse, in, out, ladj_ps, ladj_sum, K, batch, flags);
+}
+BJX_API int bjx_pd_vec(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch,
+                       uint32_t flags) {
+  return matrix_entry<MK_PD_VEC>(ctx, "bjx_pd_vec", dt, inverse, in, out, ladj_ps, ladj_sum, K, batch, flags);
+}

@@ -30,7 +30,7 @@ from . import _lib as L
 __all__ = [
     "Transform", "Bijector", "Inverse", "ComposedFunction", "Elementwise", "elementwise", "exp", "log", "identity",
     "Shift", "Scale", "Logit", "LeakyReLU", "TruncatedBijector", "SignFlip", "OrderedBijector", "SimplexBijector",
-    "VecCholeskyBijector", "Permute", "PlanarLayer", "RadialLayer", "InvertibleBatchNorm", "RationalQuadraticSpline",
+    "VecCholeskyBijector", "VecCorrBijector", "CorrBijector", "PDBijector", "PDVecBijector", "Permute", "PlanarLayer", "RadialLayer", "InvertibleBatchNorm", "RationalQuadraticSpline",
     "PartitionMask", "Coupling", "Stacked", "Columnwise", "columnwise", "vjp", "istraining", "training", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
     "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
     "PlanarResult", "vjp_params", "row_moments", "MvNormal", "TransformedDistribution", "transformed", "logpdf", "rand",
@@ -301,6 +301,10 @@ def logabsdetjac(b, x):
     ops = _fused_ops(b)
     if ops is not None:
         return _run_chain(ops, x, False, True, store=False)[1]
+    if isinstance(b, _MatrixBijector):                                   # corr.jl:82-92, pd.jl:22-31: no output matrix is written
+        return b._wlj(x, per_sample=False, store=False)[1]
+    if isinstance(b, Inverse) and isinstance(b.orig, _MatrixBijector):   # corr.jl:81, :150 (_logabsdetjac_inv_corr)
+        return b.orig._wlj_inv(x, per_sample=False, store=False)[1]
     return _shape_result(b, *b._wlj(x, per_sample=False))[1]
 
 
@@ -374,6 +378,13 @@ def output_size(b, sz):
         return (sz[0] - 1,) + sz[1:]
     if isinstance(b, Inverse) and isinstance(b.orig, SimplexBijector):
         return (sz[0] + 1,) + sz[1:]
+    if isinstance(b, (VecCorrBijector, PDVecBijector)):  # corr.jl:150-160, pd.jl:50-60
+        if len(sz) < 2 or sz[0] != sz[1]:
+            raise ValueError(f"sizes should be equal; received {sz}")
+        return (b._n(sz[0]),)
+    if isinstance(b, Inverse) and isinstance(b.orig, (VecCorrBijector, PDVecBijector)):
+        n = b.orig._K(sz[0])
+        return (n, n)
     if isinstance(b, VecCholeskyBijector):  # corr.jl:256-259
         n = sz[0]
         return (n * (n - 1) // 2,)
@@ -636,7 +647,12 @@ def _run_chain(ops: Sequence, x: torch.Tensor, per_sample: bool, want_ladj: bool
         if y.shape != x.shape or y.dtype != xc.dtype or y.device != xc.device or (y.dim() == 2 and colmajor(y) is not y):
             raise ValueError("DimensionMismatch: output buffer must match the input's shape, dtype and column-major layout")
     out = _Out(xc, batch, per_sample, want_ladj)
-    flags |= L.BJX_REF_VECTOR_SCALE_LADJ  # reproduce scale.jl:31-32 in the scalar the reference returns
+    if per_sample is False:
+        # reproduce scale.jl:31-32 (vector-`a` Scale on a matrix: Σ log|a_i|, NOT times batch) only in the scalar the
+        # reference itself returns.  The sharded modes ("both" / "sum64") must stay additive over column blocks: there
+        # ladj_sum is the mathematically consistent Σ_n ladj_ps[n], so the all-reduced value does not depend on the
+        # shard count and equals sum(ladj_ps).
+        flags |= L.BJX_REF_VECTOR_SCALE_LADJ
     rc = L.load().bjx_chain(ctx.h, _dt(xc), arr, len(ops), None if flags & L.BJX_INPUT_STDNORMAL else _ptr(xc), _ptr(y), _ptr(out.ps), _ptr(out.sum), dim, batch, flags)
     L.check(ctx.h, rc, "bjx_chain")
     del keep
@@ -729,6 +745,107 @@ class VecCholeskyBijector(Bijector):
         if not want_ladj:
             return W, None
         return W, out.result()
+
+
+def _triu_dim_from_length(d: int) -> int:  # src/utils.jl:135
+    return (-1 + math.isqrt(1 + 8 * d)) // 2
+
+
+def _dense3(X: torch.Tensor) -> torch.Tensor:
+    """(K, K[, batch]) -> the same logical array in Julia's column-major layout (strides (1, K, K*K))."""
+    if X.dim() == 2:
+        return X if X.T.is_contiguous() else X.T.contiguous().T
+    K = X.shape[0]
+    if X.stride() == (1, K, K * K) or X.shape[2] == 0:
+        return X
+    return X.permute(2, 1, 0).contiguous().permute(2, 1, 0)
+
+
+class _MatrixBijector(Bijector):
+    """Shared launcher of the matrix-variate constraint bijectors: the constrained side is a
+    (K, K) matrix or a (K, K, batch) stack, column-major; the unconstrained side a (n,) / (n, batch) vector
+    (`_VEC`) or a (K, K[, batch]) matrix.  The reference defines these for ONE matrix; a stack returns the
+    sum of the log-dets (per_sample=True: one value per matrix), like every other bijector here."""
+
+    _FN = ""
+    _VEC = False
+
+    @staticmethod
+    def _n(K):            # packed length for a K x K matrix
+        raise NotImplementedError
+
+    @staticmethod
+    def _K(n):
+        raise NotImplementedError
+
+    def _wlj(self, X, per_sample, want_ladj=True, store=True):
+        _check_dev(X)
+        if X.dim() not in (2, 3) or X.shape[0] != X.shape[1]:
+            raise ValueError(f"DimensionMismatch: {type(self).__name__} expects a square (K, K[, batch]) matrix")   # checksquare
+        K = X.shape[0]
+        single = X.dim() == 2
+        batch = 1 if single else X.shape[2]
+        Xc = _dense3(X)
+        ctx = context(X.device)
+        if not store:
+            y = None
+        elif self._VEC:
+            y = _empty(self._n(K), batch, X, single)
+        else:
+            y = torch.empty((K, K), dtype=X.dtype, device=X.device).T if single else torch.empty((batch, K, K), dtype=X.dtype, device=X.device).permute(2, 1, 0)
+        out = _Out(X, batch, per_sample, want_ladj)
+        rc = getattr(L.load(), self._FN)(ctx.h, _dt(X), 0, _ptr(Xc), _ptr(y), _ptr(out.ps), _ptr(out.sum), K, batch, 0)
+        L.check(ctx.h, rc, self._FN)
+        return (y, out.result(vec_scalar=single and per_sample is True)) if want_ladj else (y, None)
+
+    def _wlj_inv(self, y, per_sample, want_ladj=True, store=True):
+        _check_dev(y)
+        if self._VEC:
+            yc, n, batch, single = _prep(y)
+            K = self._K(n)
+            if self._n(K) != n:
+                raise ValueError(f"DimensionMismatch: {n} is not a valid packed length for {type(self).__name__}")
+        else:
+            if y.dim() not in (2, 3) or y.shape[0] != y.shape[1]:
+                raise ValueError(f"DimensionMismatch: inverse({type(self).__name__}) expects a square (K, K[, batch]) matrix")
+            K, single = y.shape[0], y.dim() == 2
+            batch = 1 if single else y.shape[2]
+            yc = _dense3(y)
+        ctx = context(y.device)
+        if not store:
+            X = None
+        elif single:
+            X = torch.empty((K, K), dtype=y.dtype, device=y.device).T
+        else:
+            X = torch.empty((batch, K, K), dtype=y.dtype, device=y.device).permute(2, 1, 0)
+        out = _Out(yc, batch, per_sample, want_ladj)
+        rc = getattr(L.load(), self._FN)(ctx.h, _dt(y), 1, _ptr(yc), _ptr(X), _ptr(out.ps), _ptr(out.sum), K, batch, 0)
+        L.check(ctx.h, rc, self._FN)
+        return (X, out.result(vec_scalar=single and per_sample is True)) if want_ladj else (X, None)
+
+
+class VecCorrBijector(_MatrixBijector):
+    """corr.jl:94-162 — correlation matrix <-> unconstrained vector of length K(K-1)/2 (what `bijector(::LKJ)` returns)."""
+    _FN, _VEC = "bjx_vec_corr", True
+    _n = staticmethod(lambda K: K * (K - 1) // 2)
+    _K = staticmethod(_triu1_dim_from_length)
+
+
+class CorrBijector(_MatrixBijector):
+    """corr.jl:1-92 — correlation matrix <-> strictly upper triangular unconstrained matrix."""
+    _FN, _VEC = "bjx_corr", False
+
+
+class PDBijector(_MatrixBijector):
+    """pd.jl:1-36 — positive definite matrix <-> lower triangular matrix with the log of the Cholesky diagonal."""
+    _FN, _VEC = "bjx_pd", False
+
+
+class PDVecBijector(_MatrixBijector):
+    """pd.jl:38-60 — positive definite matrix <-> unconstrained vector of length K(K+1)/2."""
+    _FN, _VEC = "bjx_pd_vec", True
+    _n = staticmethod(lambda K: K * (K + 1) // 2)
+    _K = staticmethod(_triu_dim_from_length)
 
 
 class Permute(Bijector):

@@ -18,6 +18,15 @@ def shard_columns(batch: int, world_size: int, rank: int) -> Tuple[int, int]:
     return lo, hi
 
 
+_LIBRARY_COLLECTIVE = [False]
+
+
+def use_library_collective(on: bool = True) -> None:
+    """Route the Σ logabsdetjac all-reduce through the library's own RCCL communicator (bjx_allreduce_sum_f64 on the
+    context's stream, after `init_comm`) instead of torch.distributed — the path a Julia host takes."""
+    _LIBRARY_COLLECTIVE[0] = bool(on)
+
+
 def allreduce_logabsdetjac(partial: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum all-reduce of the per-rank float64 partial log-det sum."""
     import torch.distributed as dist
@@ -25,7 +34,14 @@ def allreduce_logabsdetjac(partial: torch.Tensor, group=None) -> torch.Tensor:
     if partial.dtype != torch.float64:
         raise TypeError("the partial log-det sum is reduced in float64 so the result does not depend on the shard count")
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
+        if _LIBRARY_COLLECTIVE[0] and partial.is_cuda:
+            from . import _lib as L
+            from . import interface as I
+
+            ctx = I.context(partial.device)
+            L.check(ctx.h, L.load().bjx_allreduce_sum_f64(ctx.h, partial.data_ptr(), partial.numel()), "bjx_allreduce_sum_f64")
+        else:
+            dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
     return partial
 
 

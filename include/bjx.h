@@ -157,6 +157,35 @@ int bjx_simplex(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* o
 int bjx_vec_cholesky(bjx_ctx* ctx, bjx_dtype dt, int inverse, int uplo, const void* in, void* out,
                      void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags);
 
+/* ------------------------------- matrix-variate constraint bijectors (per-sample Cholesky) */
+/* What bijector(::LKJ) / bijector(::Wishart-family) return.  X is a dense K x K column-major matrix per sample
+ * (X[K,K,batch]); K <= 64 (one wave per sample, the factor's rows in registers; larger K -> BJX_ERR_UNSUPPORTED).
+ * The triangle of X that is READ is the one the reference's Cholesky wrapper reads (src/utils.jl:37,50):
+ * the UPPER one for the correlation bijectors (cholesky(Hermitian(X)).U), the LOWER one for the PD bijectors
+ * (cholesky(Hermitian(X, :L)).L).  The inverse writes the full symmetric matrix (pd_from_upper / pd_from_lower,
+ * src/utils.jl:17-24).  `out` may be NULL to compute only the log-det.
+ *
+ * bjx_vec_corr — VecCorrBijector, corr.jl:128-162.
+ *   inverse=0: X[K,K,N] -> y[K(K-1)/2, N] = _link_chol_lkj_from_upper(cholesky_upper(X)) (:133);
+ *              ladj = -_logabsdetjac_inv_corr(y) (:135-137, :463-472)
+ *   inverse=1: y -> X = U'U with U, logJ = _inv_link_chol_lkj(y); ladj = logJ + sum_{j=2}^{K-1} (K-j) log U[j,j] (:139-148) */
+int bjx_vec_corr(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out,
+                 void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags);
+/* bjx_corr — CorrBijector, corr.jl:64-92: the same maps with the unconstrained side a K x K matrix Y whose strict upper
+ * triangle holds the free values (zeros on and below the diagonal, :292-294); inverse reads only that triangle (:345-368). */
+int bjx_corr(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out,
+             void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags);
+/* bjx_pd — PDBijector, pd.jl:1-36.
+ *   inverse=0: X -> Y = replace_diag(log, cholesky_lower(X)) (lower triangular, zeros above);
+ *              ladj = -(sum_i (K+2-i) log L_ii + K log 2) (:27-31)
+ *   inverse=1: Y -> X = L L', L = lower_triangular(replace_diag(exp, Y)) (:13-16); ladj = -(forward ladj at X) (interface.jl:278-281) */
+int bjx_pd(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out,
+           void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags);
+/* bjx_pd_vec — PDVecBijector, pd.jl:38-60: the same with the unconstrained side packed,
+ * y[K(K+1)/2, N] = triu_to_vec(transpose(pd_link(X))) (:41; column-major upper triangle with the diagonal). */
+int bjx_pd_vec(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out,
+               void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags);
+
 /* ------------------------------- F2: per-sample reduce + broadcast        */
 /* PlanarLayer, planar_layer.jl:65-127,160-185; `n_layers` stacked layers (composition
  * layer[n_layers-1] ∘ ... ∘ layer[0]) are fused into one pass over Z.

@@ -382,6 +382,137 @@ template <class T> T logabsdetjac_inv_chol(const T* y, int64_t K) {
   return result;
 }
 
+// ---------------------------------------------------------------- matrix-variate constraint bijectors
+// src/utils.jl:37,50 — cholesky(Hermitian(X)).U reads the UPPER triangle of X, cholesky(Hermitian(X, :L)).L the LOWER one
+// (LinearAlgebra -> LAPACK potrf, not under /root/reference).  The factor of a positive definite matrix is unique, so
+// the restatement is the textbook unblocked factorisation (row by row, inner products in ascending order); it differs
+// from LAPACK's blocked order at rounding level only.  L is returned DENSE column-major with the other triangle zeroed
+// (lower_triangular / upper_triangular, src/utils.jl:14-15).
+template <class T> void cholesky_lower_from(const T* X, T* L, int64_t K, bool upper_storage) {
+  for (int64_t j = 0; j < K; ++j) for (int64_t i = 0; i < K; ++i) L[j * K + i] = T(0);
+  for (int64_t i = 0; i < K; ++i) {
+    for (int64_t j = 0; j <= i; ++j) {
+      T a = upper_storage ? X[i * K + j] : X[j * K + i];      // A[i,j], i >= j
+      T s = a;
+      for (int64_t m = 0; m < j; ++m) s -= L[m * K + i] * L[m * K + j];
+      if (i == j) L[j * K + i] = std::sqrt(s);
+      else L[j * K + i] = s / L[j * K + j];
+    }
+  }
+}
+template <class T> void cholesky_upper(const T* X, T* U, int64_t K) {   // src/utils.jl:50
+  std::vector<T> L(K * K);
+  cholesky_lower_from<T>(X, L.data(), K, true);
+  for (int64_t j = 0; j < K; ++j) for (int64_t i = 0; i < K; ++i) U[j * K + i] = L[i * K + j];
+}
+template <class T> void cholesky_lower(const T* X, T* L, int64_t K) { cholesky_lower_from<T>(X, L, K, false); }   // src/utils.jl:37
+// corr.jl:277-297 (matrix form: asinh on every row, zero fill on and below the diagonal)
+template <class T> void link_chol_lkj_mat(const T* W, T* Y, int64_t K) {
+  for (int64_t j = 1; j <= K; ++j) {
+    T remainder_sq = W[(j - 1) * K + (j - 1)] * W[(j - 1) * K + (j - 1)];
+    for (int64_t i = j - 1; i >= 1; --i) {
+      T w = W[(j - 1) * K + (i - 1)];
+      T z = w / std::sqrt(remainder_sq);
+      Y[(j - 1) * K + (i - 1)] = std::asinh(z);
+      remainder_sq += w * w;
+    }
+    for (int64_t i = j; i <= K; ++i) Y[(j - 1) * K + (i - 1)] = T(0);
+  }
+}
+// corr.jl:345-368 (matrix form of the inverse link; only the strict upper triangle of Y is read)
+template <class T> T inv_link_chol_lkj_mat(const T* Y, T* W, int64_t K) {
+  T logJ = T(0);
+  for (int64_t j = 1; j <= K; ++j) {
+    T log_remainder = T(0);
+    for (int64_t i = 1; i <= j - 1; ++i) {
+      T yv = Y[(j - 1) * K + (i - 1)];
+      T z = std::tanh(yv);
+      W[(j - 1) * K + (i - 1)] = z * std::exp(log_remainder);
+      log_remainder -= logcosh_<T>(yv);
+      logJ += log_remainder;
+    }
+    logJ += log_remainder;
+    W[(j - 1) * K + (j - 1)] = std::exp(log_remainder);
+    for (int64_t i = j + 1; i <= K; ++i) W[(j - 1) * K + (i - 1)] = T(0);
+  }
+  return logJ;
+}
+// corr.jl:453-461 / :463-472 (vec_to_triu1_row_index: src/utils.jl:123-128)
+template <class T> T logabsdetjac_inv_corr_mat(const T* Y, int64_t K) {
+  T result = T(0);
+  for (int64_t j = 2; j <= K; ++j) for (int64_t i = 1; i <= j - 1; ++i) result -= T(K - i + 1) * logcosh_<T>(Y[(j - 1) * K + (i - 1)]);
+  return result;
+}
+template <class T> T logabsdetjac_inv_corr_vec(const T* y, int64_t K) {
+  T result = T(0);
+  int64_t n = K * (K - 1) / 2;
+  for (int64_t idx = 1; idx <= n; ++idx) {
+    int64_t M = triu1_dim_from_length(idx - 1);
+    int64_t row_idx = idx - (M * (M - 1) / 2);
+    result -= T(K - row_idx + 1) * logcosh_<T>(y[idx - 1]);
+  }
+  return result;
+}
+// pd_from_upper / pd_from_lower (src/utils.jl:17-24): U'U, L L'
+template <class T> void pd_from_upper(const T* U, T* X, int64_t K) {
+  for (int64_t j = 0; j < K; ++j) for (int64_t i = 0; i < K; ++i) {
+    T s = T(0);
+    for (int64_t m = 0; m <= (i < j ? i : j); ++m) s += U[i * K + m] * U[j * K + m];
+    X[j * K + i] = s;
+  }
+}
+template <class T> void pd_from_lower(const T* L, T* X, int64_t K) {
+  for (int64_t j = 0; j < K; ++j) for (int64_t i = 0; i < K; ++i) {
+    T s = T(0);
+    for (int64_t m = 0; m <= (i < j ? i : j); ++m) s += L[m * K + i] * L[m * K + j];
+    X[j * K + i] = s;
+  }
+}
+// pd.jl:27-31
+template <class T> T logabsdetjac_pdbijector_chol(const T* L, int64_t d) {
+  T z = T(0);
+  for (int64_t i = 1; i <= d; ++i) z += T(d + 2 - i) * std::log(L[(i - 1) * d + (i - 1)]);
+  return -(z + T(d) * T(0.6931471805599453094172321214581766));
+}
+// kind 0: VecCorrBijector (corr.jl:128-162)   X[K,K] <-> y[K(K-1)/2]
+// kind 1: CorrBijector    (corr.jl:64-92)     X[K,K] <-> Y[K,K] (strict upper triangle, zeros elsewhere)
+// kind 2: PDBijector      (pd.jl:1-36)        X[K,K] <-> Y[K,K] (lower factor with log diagonal)
+// kind 3: PDVecBijector   (pd.jl:38-60)       X[K,K] <-> y[K(K+1)/2] (triu_to_vec of the transposed PD link)
+template <class T> T matrix_bijector(int kind, int inv, const T* in, T* out, int64_t K) {
+  std::vector<T> A(K * K), B(K * K);
+  if (kind == 0 || kind == 1) {
+    if (!inv) {
+      cholesky_upper<T>(in, A.data(), K);                                   // corr.jl:69, :133
+      if (kind == 0) { link_chol_lkj_from_upper<T>(A.data(), out, K); return -logabsdetjac_inv_corr_vec<T>(out, K); }   // :135-137
+      link_chol_lkj_mat<T>(A.data(), out, K);                               // :70
+      return -logabsdetjac_inv_corr_mat<T>(out, K);                         // :92
+    }
+    T logJ = kind == 0 ? inv_link_chol_lkj<T>(in, A.data(), K) : inv_link_chol_lkj_mat<T>(in, A.data(), K);   // :140, :75
+    for (int64_t j = 2; j <= K - 1; ++j) logJ += T(K - j) * std::log(A[(j - 1) * K + (j - 1)]);               // :144-146, :77-79
+    pd_from_upper<T>(A.data(), out, K);
+    return logJ;
+  }
+  if (!inv) {
+    cholesky_lower<T>(in, A.data(), K);                                     // pd.jl:34
+    T l = logabsdetjac_pdbijector_chol<T>(A.data(), K);
+    for (int64_t i = 0; i < K; ++i) A[i * K + i] = std::log(A[i * K + i]);  // replace_diag(log, L), :11
+    if (kind == 2) { std::memcpy(out, A.data(), sizeof(T) * K * K); return l; }
+    int64_t idx = 0;                                                        // triu_to_vec(transpose(Y)), :41 ; src/utils.jl:68
+    for (int64_t j = 0; j < K; ++j) for (int64_t i = 0; i <= j; ++i) out[idx++] = A[i * K + j];   // (Y')[i,j] = Y[j,i]
+    return l;
+  }
+  if (kind == 2) { for (int64_t j = 0; j < K; ++j) for (int64_t i = 0; i < K; ++i) A[j * K + i] = i >= j ? in[j * K + i] : T(0); }
+  else {                                                                    // transpose_eager(vec_to_triu(y)), pd.jl:44
+    std::fill(A.begin(), A.end(), T(0));
+    int64_t idx = 0;
+    for (int64_t j = 0; j < K; ++j) for (int64_t i = 0; i <= j; ++i) A[i * K + j] = in[idx++];
+  }
+  for (int64_t i = 0; i < K; ++i) A[i * K + i] = std::exp(A[i * K + i]);    // replace_diag(exp, Y), :14 ; pd_from_lower drops the upper part
+  pd_from_lower<T>(A.data(), out, K);
+  cholesky_lower<T>(out, B.data(), K);                                      // interface.jl:278-281: -logabsdetjac(PDBijector(), x)
+  return -logabsdetjac_pdbijector_chol<T>(B.data(), K);
+}
+
 // ---------------------------------------------------------------- F2 flows
 // planar_layer.jl:65-70
 template <class T> T get_u_hat(const T* u, const T* w, int64_t d, T* u_hat) {
@@ -664,6 +795,13 @@ template <class T> void coupling_rqs(int inverse, const int32_t* idx1, int64_t n
         if (ladj) ladj[n] = -logabsdetjac_inv_chol<T>(out + n * nv, K);   /* corr.jl:235-237 */                  \
       }                                                                                                          \
     } }                                                                                                          \
+  BJO_EXPORT void bjo_matrix_bijector_##SUF(int kind, int inv, const T* in, T* out, int64_t K, int64_t N, T* ladj) { \
+    int64_t nv = kind == 0 ? K * (K - 1) / 2 : (kind == 3 ? K * (K + 1) / 2 : K * K);                            \
+    for (int64_t n = 0; n < N; ++n) {                                                                            \
+      T l = matrix_bijector<T>(kind, inv, in + n * (inv ? nv : K * K), out + n * (inv ? K * K : nv), K);         \
+      if (ladj) ladj[n] = l; } }                                                                                 \
+  BJO_EXPORT double bjo_logabsdetjac_inv_corr_##SUF(int vec, const T* y, int64_t K) {                            \
+    return (double)(vec ? logabsdetjac_inv_corr_vec<T>(y, K) : logabsdetjac_inv_corr_mat<T>(y, K)); }            \
   BJO_EXPORT void bjo_planar_##SUF(int inv, const T* w, const T* u, const T* b, int nl, const T* in, T* out,     \
                                    int64_t d, int64_t N, T* ladj) {                                              \
     std::vector<T> cur(in, in + d * N), nxt(d * N), l(N), acc(N, T(0));                                          \

@@ -53,7 +53,7 @@ def lib():
         build()
         _lib = C.CDLL(_SO)
         for suf in ("f32", "f64"):
-            for name in ("chain", "chain_fused", "find_alpha", "logistic", "log1pexp", "logcosh"):
+            for name in ("chain", "chain_fused", "find_alpha", "logistic", "log1pexp", "logcosh", "logabsdetjac_inv_corr"):
                 getattr(_lib, f"bjo_{name}_{suf}").restype = C.c_double
         _lib.bjo_triu1_dim_from_length.restype = C.c_int64
         _lib.bjo_triu1_dim_from_length.argtypes = [C.c_int64]
@@ -171,6 +171,68 @@ def vec_cholesky(x, inverse=False, uplo="U", transform=True):
     ladj = np.empty(batch, dtype=x.dtype)
     getattr(lib(), f"bjo_vec_cholesky_{suf}")(C.c_int(int(inverse)), C.c_int(ord(uplo)), _p(x), _p(out), C.c_int64(K), C.c_int64(batch), _p(ladj))
     return out, ladj
+
+
+MATRIX_KINDS = {"vec_corr": 0, "corr": 1, "pd": 2, "pd_vec": 3}
+
+
+def matrix_bijector(kind, x, inverse=False):
+    """SURVEY.md §8(f) f-4 — VecCorrBijector / CorrBijector (corr.jl:64-162) and PDBijector / PDVecBijector (pd.jl:1-60),
+    one sample (x.ndim = 1 or 2) or a batch along the LAST axis.  forward: X[K,K(,N)] -> y[n(,N)] or Y[K,K(,N)];
+    inverse: the other way.  Returns (out, per-sample ladj) with ladj what with_logabsdet_jacobian returns."""
+    k = MATRIX_KINDS[kind]
+    x = _f(x)
+    suf, _ = _suf(x.dtype)
+    vec_side = k in (0, 3)
+    if not inverse:
+        K = x.shape[0]
+        assert x.shape[1] == K
+        batch = 1 if x.ndim == 2 else x.shape[2]
+        single = x.ndim == 2
+        nv = K * (K - 1) // 2 if k == 0 else (K * (K + 1) // 2 if k == 3 else None)
+        out = np.empty(((nv,) if vec_side else (K, K)) + (() if single else (batch,)), dtype=x.dtype, order="F")
+    else:
+        if vec_side:
+            nv = x.shape[0]
+            K = int(lib().bjo_triu1_dim_from_length(nv)) if k == 0 else (int(lib().bjo_triu1_dim_from_length(nv)) - 1)
+            if k == 3:
+                K = (int(round(np.sqrt(1 + 8 * nv))) - 1) // 2          # src/utils.jl:135 _triu_dim_from_length
+            batch = 1 if x.ndim == 1 else x.shape[1]
+            single = x.ndim == 1
+        else:
+            K = x.shape[0]
+            batch = 1 if x.ndim == 2 else x.shape[2]
+            single = x.ndim == 2
+        out = np.empty((K, K) + (() if single else (batch,)), dtype=x.dtype, order="F")
+    ladj = np.empty(batch, dtype=x.dtype)
+    getattr(lib(), f"bjo_matrix_bijector_{suf}")(C.c_int(k), C.c_int(int(inverse)), _p(x), _p(out), C.c_int64(K), C.c_int64(batch), _p(ladj))
+    return out, ladj
+
+
+def vec_corr(x, inverse=False):
+    return matrix_bijector("vec_corr", x, inverse)
+
+
+def corr(x, inverse=False):
+    return matrix_bijector("corr", x, inverse)
+
+
+def pd(x, inverse=False):
+    return matrix_bijector("pd", x, inverse)
+
+
+def pd_vec(x, inverse=False):
+    return matrix_bijector("pd_vec", x, inverse)
+
+
+def logabsdetjac_inv_corr(y):
+    """logabsdetjac(inverse(CorrBijector()), Y) (matrix, corr.jl:453-461) / (inverse(VecCorrBijector()), y) (vector, :463-472)."""
+    y = _f(y)
+    suf, _ = _suf(y.dtype)
+    if y.ndim == 1:
+        K = int(lib().bjo_triu1_dim_from_length(y.shape[0]))
+        return getattr(lib(), f"bjo_logabsdetjac_inv_corr_{suf}")(C.c_int(1), _p(y), C.c_int64(K))
+    return getattr(lib(), f"bjo_logabsdetjac_inv_corr_{suf}")(C.c_int(0), _p(y), C.c_int64(y.shape[0]))
 
 
 def planar(w, u, b, x, inverse=False):

@@ -150,3 +150,28 @@ def test_c5_simplex_and_cholesky_full_size(bj, orc):
     Ws, ljs = orc.vec_cholesky(sample_cols(yv, idx), inverse=True, uplo="U")
     np.testing.assert_allclose(W[:, :, idx].cpu().numpy(), Ws, rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(lj[idx].cpu().numpy(), ljs, rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("mode", ["sum", "both"])
+def test_shard_invariance_with_a_vector_scale(bj, mode):
+    """A per-row vector Scale in a sharded chain (bench.py's c2v): the all-reduced Σ logabsdetjac must not depend on
+    the shard count and must equal sum(ladj_ps).  The reference's un-multiplied Σ log|a_i| (scale.jl:31-32) is only the
+    value of the UNSHARDED scalar return (`with_logabsdet_jacobian`), never of the partial sums that get all-reduced."""
+    d, N = 64, (1 << 18) + 37
+    x = fill(bj, cm(d, N), 3)
+    a = torch.linspace(0.5, 1.5, d, device="cuda")
+    b = bj.elementwise(bj.exp) @ bj.Shift(torch.full((d,), 0.1, device="cuda")) @ bj.Scale(a)
+    per_sample = mode == "both"
+    _, lps, whole = bj.shard.with_logabsdet_jacobian_sharded(b, x, per_sample=per_sample)
+    ref = (x.double() * a.double()[:, None] + 0.1).sum() + N * a.double().log().sum()       # closed form, Float64
+    assert abs(float(whole) - float(ref)) <= 1e-6 * abs(float(ref))
+    if per_sample:
+        assert abs(float(whole) - float(lps.double().sum())) <= 1e-6 * abs(float(whole))
+    for G in (2, 8):
+        parts = sum(float(bj.shard.with_logabsdet_jacobian_sharded(b, x[:, lo:hi], per_sample=per_sample)[2])
+                    for lo, hi in (bj.shard.shard_columns(N, G, r) for r in range(G)))
+        assert abs(parts - float(whole)) <= 1e-9 * abs(float(whole)), (G, parts, float(whole))
+    # the unsharded reference-shaped scalar keeps the reference's value: data terms + Σ log|a_i| ONCE
+    _, l_ref_shape = bj.with_logabsdet_jacobian(b, x)
+    want = (x.double() * a.double()[:, None] + 0.1).sum() + a.double().log().sum()
+    assert abs(float(l_ref_shape) - float(want)) <= 2e-6 * abs(float(want)) + 1e-2

@@ -2054,3 +2054,91 @@ def test_radial_parameter_pullback(bj, orc, dim, N, dt):
         assert abs(float(host(g["beta"])[0]) - bb) <= RTOL[dt] * 10 * abs(bb) + fl
         np.testing.assert_allclose(host(g["z_0"]), z0b, rtol=RTOL[dt] * 10, atol=fl)
     assert g["alpha_"].shape == (1,) and g["z_0"].shape == (dim,)
+
+
+# ------------------------------------------------------------------ Corr / VecCorr / PD / PDVec
+MATRIX_KINDS = ["vec_corr", "corr", "pd", "pd_vec"]
+
+
+def _matrix_cls(bj, kind):
+    return {"vec_corr": bj.VecCorrBijector, "corr": bj.CorrBijector, "pd": bj.PDBijector, "pd_vec": bj.PDVecBijector}[kind]()
+
+
+def _matrix_free(kind, K, batch, r, dt):
+    """Random unconstrained side (the free entries; the rest zero like the reference's outputs)."""
+    if kind == "vec_corr":
+        return (0.6 * r.normal(size=(K * (K - 1) // 2, batch))).astype(dt)
+    if kind == "pd_vec":
+        return (0.5 * r.normal(size=(K * (K + 1) // 2, batch))).astype(dt)
+    Y = (0.5 * r.normal(size=(K, K, batch))).astype(dt)
+    mask = np.triu(np.ones((K, K), bool), 1) if kind == "corr" else np.tril(np.ones((K, K), bool))
+    return Y * mask[:, :, None]
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("K,batch", [(2, 33), (3, 129), (5, 64), (8, 257), (13, 65), (16, 40), (24, 31), (32, 70), (33, 9), (50, 17), (64, 21), (1, 5)])
+@pytest.mark.parametrize("kind", MATRIX_KINDS)
+def test_matrix_bijectors_match_oracle(bj, orc, kind, K, batch, dt):
+    """corr.jl:64-162, pd.jl:1-60 batched: inverse (unconstrained -> matrix) and forward (matrix -> unconstrained)
+    against the oracle; test/bijectors/corr.jl:9-40 and test/bijectors/pd.jl round trips."""
+    r = rng(zlib.crc32(f"{kind}{K}{batch}".encode()))
+    b = _matrix_cls(bj, kind)
+    y = np.asfortranarray(_matrix_free(kind, K, batch, r, dt))
+    X_ref, lj_ref = orc.matrix_bijector(kind, y.astype(np.float64), inverse=True)
+    X, lj = bj.with_logabsdet_jacobian(bj.inverse(b), dev(y), per_sample=True)
+    scale = float(np.abs(X_ref).max())
+    close(host(X), X_ref, dt, scale=max(scale, 1.0), what=f"inverse({kind}) K={K}")
+    close(host(lj), lj_ref, dt, scale=K * K, what=f"inverse({kind}) ladj K={K}")
+    # forward from the oracle's (Float64) matrix, rounded to dt
+    Xd = np.asfortranarray(X_ref.astype(dt))
+    y_ref, lf_ref = orc.matrix_bijector(kind, Xd.astype(np.float64))
+    yy, lf = bj.with_logabsdet_jacobian(b, dev(Xd), per_sample=True)
+    # conditioning: the link amplifies the rounding of X by ~1/min(diag of the factor)
+    amp = 1.0 if dt == np.float64 else 30.0
+    close(host(yy), y_ref, dt, scale=amp, what=f"{kind} K={K}")
+    close(host(lf), lf_ref, dt, scale=K * K * amp, what=f"{kind} ladj K={K}")
+    # scalar-sum shape + logabsdetjac alone (no output written)
+    _, ls = bj.with_logabsdet_jacobian(b, dev(Xd))
+    sum_close(ls, lf_ref.sum(), dt, batch * K * K, what=f"{kind} Σ ladj")
+    sum_close(bj.logabsdetjac(b, dev(Xd)), lf_ref.sum(), dt, batch * K * K, what=f"logabsdetjac({kind})")
+    sum_close(bj.logabsdetjac(bj.inverse(b), dev(y)), lj_ref.sum(), dt, batch * K * K, what=f"logabsdetjac(inverse({kind}))")
+    # round trip on the device
+    Xb = bj.transform(bj.inverse(b), yy)
+    close(host(Xb), Xd, dt, scale=max(scale, 1.0) * amp, what=f"round trip {kind} K={K}")
+
+
+@pytest.mark.parametrize("kind", MATRIX_KINDS)
+def test_matrix_bijectors_single_matrix_and_reference_values(bj, orc, kind):
+    """One matrix (the reference's only call shape): scalar log-det; VecCorrBijector reproduces the docstring value
+    corr.jl:113-122 to the 6 digits the printed input carries."""
+    b = _matrix_cls(bj, kind)
+    if kind == "vec_corr":
+        X = np.array([[1.0, -0.705273, -0.348638], [-0.705273, 1.0, 0.0534538], [-0.348638, 0.0534538, 1.0]])
+        y, l = bj.with_logabsdet_jacobian(b, dev(X))
+        np.testing.assert_allclose(host(y), [-0.8777149781928181, -0.3638927608636788, -0.29813769428942216], atol=2e-6)
+        assert y.shape == (3,) and l.dim() == 0
+        Xb, lb = bj.with_logabsdet_jacobian(bj.inverse(b), y)
+        np.testing.assert_allclose(host(Xb), X, atol=1e-12)
+        assert abs(float(lb) + float(l)) < 1e-12
+        assert bj.output_size(b, (3, 3)) == (3,) and bj.output_size(bj.inverse(b), (3,)) == (3, 3)
+    r = rng(11)
+    K = 6
+    y = np.asfortranarray(_matrix_free(kind, K, 1, r, np.float64))[..., 0]
+    X, lj = bj.with_logabsdet_jacobian(bj.inverse(b), dev(y))
+    X_ref, lj_ref = orc.matrix_bijector(kind, y, inverse=True)
+    assert X.shape == (K, K) and lj.dim() == 0
+    np.testing.assert_allclose(host(X), X_ref, rtol=1e-9, atol=1e-12)
+    assert abs(float(lj) - float(lj_ref[0])) < 1e-9
+    np.testing.assert_allclose(host(X), host(X).T, atol=1e-14)             # symmetric output
+    if kind in ("vec_corr", "corr"):
+        np.testing.assert_allclose(np.diag(host(X)), np.ones(K), atol=1e-12)    # a correlation matrix
+
+
+def test_matrix_bijectors_reject_what_the_reference_rejects(bj):
+    x = torch.zeros(3, 4, dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError):
+        bj.transform(bj.VecCorrBijector(), x)                              # checksquare
+    with pytest.raises(ValueError):
+        bj.transform(bj.inverse(bj.VecCorrBijector()), torch.zeros(4, dtype=torch.float64, device="cuda"))   # 4 != K(K-1)/2
+    with pytest.raises(NotImplementedError):
+        bj.transform(bj.inverse(bj.VecCorrBijector()), torch.zeros(65 * 64 // 2, 2, dtype=torch.float64, device="cuda"))  # K = 65

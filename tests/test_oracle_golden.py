@@ -618,3 +618,77 @@ def test_rqs_pullback_matches_finite_differences(orc):
     for inv in (False, True):
         f = lambda v: orc.rqs(w, h, d, np.asfortranarray(v), inverse=inv)
         np.testing.assert_allclose(orc.rqs_vjp(w, h, d, x, gbar, lbar, inverse=inv), _fd_vjp(f, x, gbar, lbar), rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------ Corr / VecCorr / PD / PDVec
+def _free_to_input(kind, v, K):
+    if kind == "corr":
+        Y = np.zeros((K, K)); Y[np.triu_indices(K, 1)] = v; return Y
+    if kind == "pd":
+        Y = np.zeros((K, K)); Y[np.tril_indices(K)] = v; return Y
+    return v
+
+
+def _free_of_matrix(kind, X, K):
+    return X[np.triu_indices(K, 1)] if kind in ("vec_corr", "corr") else X[np.tril_indices(K)]
+
+
+def test_vec_corr_docstring_value(orc):
+    """src/bijectors/corr.jl:113-122: the printed 3x3 correlation matrix (6 digits) -> y; round trip (:124-125)."""
+    X = np.array([[1.0, -0.705273, -0.348638], [-0.705273, 1.0, 0.0534538], [-0.348638, 0.0534538, 1.0]])
+    y, l = orc.vec_corr(X)
+    np.testing.assert_allclose(y, [-0.8777149781928181, -0.3638927608636788, -0.29813769428942216], atol=2e-6)
+    Xb, lb = orc.vec_corr(y, inverse=True)
+    np.testing.assert_allclose(Xb, X, atol=1e-14)
+    assert abs(lb[0] + l[0]) < 1e-13
+    # CorrBijector on the same matrix holds the same values in its strict upper triangle (column-major order)
+    Y, l2 = orc.corr(X)
+    np.testing.assert_allclose(Y.T[np.tril_indices(3, -1)], y, atol=1e-12)   # (1,2), (1,3), (2,3)
+    assert abs(l2[0] - l[0]) < 1e-12 and np.all(np.tril(Y) == 0)
+
+
+@pytest.mark.parametrize("kind", ["vec_corr", "corr", "pd", "pd_vec"])
+@pytest.mark.parametrize("K", [2, 3, 5, 9])
+def test_matrix_bijector_properties(orc, kind, K):
+    """test/bijectors/corr.jl:9-40, test/bijectors/pd.jl: round trip, ladj(inverse) = -ladj(forward), and the log-det
+    against log|det| of a central-difference Jacobian of free parameters -> free entries of X (what test_bijector does
+    with ForwardDiff); logabsdetjac(inverse(b), y) (_logabsdetjac_inv_corr, corr.jl:453-472) equals the fused value."""
+    r = np.random.default_rng(K * 17 + len(kind))
+    n_free = {"vec_corr": K * (K - 1) // 2, "corr": K * (K - 1) // 2, "pd": K * (K + 1) // 2, "pd_vec": K * (K + 1) // 2}[kind]
+    v0 = 0.7 * r.normal(size=n_free)
+    y0 = _free_to_input(kind, v0, K)
+    X, lj = orc.matrix_bijector(kind, y0, inverse=True)
+    np.testing.assert_allclose(X, X.T, atol=1e-14)
+    assert np.all(np.linalg.eigvalsh(X) > 0)
+    if kind in ("vec_corr", "corr"):
+        np.testing.assert_allclose(np.diag(X), 1.0, atol=1e-13)
+        assert abs(orc.logabsdetjac_inv_corr(y0) - lj[0]) < 1e-11 * max(1.0, abs(lj[0]))
+    y1, lf = orc.matrix_bijector(kind, X)
+    np.testing.assert_allclose(y1, y0, atol=1e-11)
+    assert abs(lf[0] + lj[0]) < 1e-10 * max(1.0, abs(lj[0]))
+    J = np.zeros((n_free, n_free))
+    h = 1e-6
+    for c in range(n_free):
+        vp, vm = v0.copy(), v0.copy()
+        vp[c] += h
+        vm[c] -= h
+        J[:, c] = (_free_of_matrix(kind, orc.matrix_bijector(kind, _free_to_input(kind, vp, K), inverse=True)[0], K)
+                   - _free_of_matrix(kind, orc.matrix_bijector(kind, _free_to_input(kind, vm, K), inverse=True)[0], K)) / (2 * h)
+    assert abs(np.linalg.slogdet(J)[1] - lj[0]) < 1e-6 * max(1.0, abs(lj[0]))
+
+
+def test_pd_bijector_against_numpy_cholesky(orc):
+    """pd.jl:10-31: Y = replace_diag(log, cholesky_lower(X)); logabsdetjac = -(sum((d+1):-1:2 .* log.(diag(L))) + d log 2)."""
+    r = np.random.default_rng(5)
+    A = r.normal(size=(6, 6))
+    X = A @ A.T + 6 * np.eye(6)
+    Lc = np.linalg.cholesky(X)
+    Y, l = orc.pd(X)
+    ref = Lc.copy()
+    ref[np.diag_indices(6)] = np.log(np.diag(Lc))
+    np.testing.assert_allclose(Y, ref, atol=1e-13)
+    want = -(np.sum(np.arange(7, 1, -1) * np.log(np.diag(Lc))) + 6 * np.log(2.0))
+    assert abs(l[0] - want) < 1e-12
+    yv, l2 = orc.pd_vec(X)
+    np.testing.assert_allclose(yv, np.concatenate([ref.T[:j + 1, j] for j in range(6)]), atol=1e-13)      # triu_to_vec(Y'), column-major
+    assert abs(l2[0] - want) < 1e-12
