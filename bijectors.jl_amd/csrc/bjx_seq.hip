@@ -37,7 +37,8 @@ template <class T> struct OrderedFwd {   // ordered.jl:36-49, :80
   T prev, ladj;
   __device__ void init() { prev = T(0); ladj = T(0); }
   __device__ T first(T v, const T*) { prev = v; return v; }
-  __device__ T mid(int, T v, T) { const T o = prev + d_exp(v); ladj += v; prev = o; return o; }
+  // Fast<T>::exp = the exp of every other kernel (chain, quad_stream): one input gives the same bits whatever kernel a shape selects
+  __device__ T mid(int, T v, T) { const T o = prev + Fast<T>::exp(v); ladj += v; prev = o; return o; }
   __device__ T last(T v) { return v; }
   __device__ T result() const { return ladj; }
 };
@@ -46,7 +47,7 @@ template <class T> struct OrderedInv {   // ordered.jl:63-77 ; interface.jl:276-
   T prev, ladj;
   __device__ void init() { prev = T(0); ladj = T(0); }
   __device__ T first(T v, const T*) { prev = v; return v; }
-  __device__ T mid(int, T v, T) { const T o = d_log(v - prev); ladj -= o; prev = v; return o; }
+  __device__ T mid(int, T v, T) { const T o = Fast<T>::log(v - prev); ladj -= o; prev = v; return o; }
   __device__ T last(T v) { return v; }
   __device__ T result() const { return ladj; }
 };

@@ -31,7 +31,7 @@ __all__ = [
     "Transform", "Bijector", "Inverse", "ComposedFunction", "Elementwise", "elementwise", "exp", "log", "identity",
     "Shift", "Scale", "Logit", "LeakyReLU", "TruncatedBijector", "SignFlip", "OrderedBijector", "SimplexBijector",
     "VecCholeskyBijector", "VecCorrBijector", "CorrBijector", "PDBijector", "PDVecBijector", "Permute", "PlanarLayer", "RadialLayer", "InvertibleBatchNorm", "RationalQuadraticSpline",
-    "PartitionMask", "Coupling", "Stacked", "Columnwise", "columnwise", "vjp", "istraining", "training", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
+    "PartitionMask", "Coupling", "Stacked", "NamedStacked", "Columnwise", "columnwise", "vjp", "istraining", "training", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
     "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
     "PlanarResult", "vjp_params", "row_moments", "MvNormal", "TransformedDistribution", "transformed", "logpdf", "rand",
 ]
@@ -260,7 +260,7 @@ class Inverse(Transform):
 
 def inverse(t):
     """src/interface.jl:265-266 (+ shift.jl:12, leaky_relu.jl:16, composed inverse, stacked.jl:113-118)"""
-    if type(t).__name__ == "Stacked":
+    if type(t).__name__ in ("Stacked", "NamedStacked"):
         return t._inverse()
     if type(t).__name__ == "Columnwise":                  # interface.jl:71
         return Columnwise(inverse(t.x))
@@ -473,21 +473,43 @@ class Shift(_ChainOp):
 
 
 class Scale(_ChainOp):
-    """scale.jl:1-36 (scalar and vector `a`; matrix `a` is out of scope)"""
+    """scale.jl:1-36: scalar `a`, vector `a` (one value per row) and MATRIX `a` (`a * x`, `a \\ y`, logabsdet(a); :14,17,35-36).
+    The matrix form is its own launch (bjx_scale_matrix: LDS-resident matrix, dim <= 128), not a stage of the fused chain."""
 
     def __init__(self, a, batched: bool = False):
         # `batched=True`: `a` has shape (rows, batch) and scales element-wise — only meaningful as the
-        # law returned by a Coupling's θ for a batch of columns.  A plain matrix `a` means `a * x`
-        # in the reference (scale.jl:14), which is not on the hot path.
-        if isinstance(a, torch.Tensor) and a.dim() > 1 and not batched:
-            raise NotImplementedError("Scale with a matrix parameter is not on the hot path (SURVEY.md §8f-4)")
+        # law returned by a Coupling's θ for a batch of columns.  A plain 2-D `a` is the reference's matrix Scale.
         self.a = a
+        self.matrix = isinstance(a, torch.Tensor) and a.dim() == 2 and not batched
+        if self.matrix and a.shape[0] != a.shape[1]:
+            raise ValueError("DimensionMismatch: Scale with a matrix parameter needs a square matrix")
 
     def _key(self):
         return (_keyify(self.a),)
 
     def _ops(self, inv=False):
+        if self.matrix:
+            return None
         return [(L.OP_SCALE_INV if inv else L.OP_SCALE, self.a, None)]
+
+    def _run_matrix(self, x, inv, per_sample, want_ladj):
+        xc, dim, batch, vec = _prep(x)
+        a = colmajor(_param(self.a, xc))
+        if a.shape[0] != dim:
+            raise ValueError(f"DimensionMismatch: Scale with a {tuple(a.shape)} matrix applied to {dim} rows")
+        # scale.jl:35-36: logabsdet(a) ONCE for a matrix of columns in the reference's scalar; per-column vector otherwise
+        return _call_struct("bjx_scale_matrix", x, dim, False, per_sample, want_ladj, (int(inv), _ptr(a)), (dim,),
+                            flags=L.BJX_REF_VECTOR_SCALE_LADJ if per_sample is False else 0)
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        if self.matrix:
+            return self._run_matrix(x, False, per_sample, want_ladj)
+        return super()._wlj(x, per_sample, want_ladj)
+
+    def _wlj_inv(self, x, per_sample, want_ladj=True):
+        if self.matrix:
+            return self._run_matrix(x, True, per_sample, want_ladj)
+        return super()._wlj_inv(x, per_sample, want_ladj)
 
 
 class Logit(_ChainOp):
@@ -1371,6 +1393,75 @@ class Stacked(Transform):
         if per_sample:
             return y, (ps[0] if vec else ps)
         return y, sm[0].to(xc.dtype)
+
+
+class NamedStacked(Transform):
+    """src/bijectors/named_stacked.jl:1-60 — a NamedTuple of bijectors for `ProductNamedTupleDistribution` samples.
+    `transforms` and `ranges` are dicts with the same keys (insertion order = field order); `ranges[name]` is the
+    1-based index (int) or (lo, hi) range of that field's OUTPUT in the stacked vector.  The forward direction takes a
+    dict of values (python numbers, (len,) or (len, batch) tensors) and returns ONE vector / matrix: the fields are
+    concatenated and sent through `Stacked`, so elementwise fields cost one fused launch (bjx_stacked) whatever their
+    number; the inverse takes the vector and returns a dict (:118-150)."""
+
+    def __init__(self, transforms: dict, ranges: dict, _inv: bool = False):
+        if list(transforms.keys()) != list(ranges.keys()):
+            raise ValueError("transforms and ranges need the same field names")           # NamedTuple{names} on both, :53-58
+        self.names = list(transforms.keys())
+        self.transforms = dict(transforms)
+        self.ranges = {n: ((int(r), int(r)) if isinstance(r, int) else (int(r[0]), int(r[1]))) for n, r in ranges.items()}
+        self._int_fields = {n for n, r in ranges.items() if isinstance(r, int)} if not isinstance(ranges, NamedStacked) else set()
+        self._ranges_arg = dict(ranges)
+        self._inv = _inv
+
+    def _key(self):
+        return (tuple(self.names), tuple(self.transforms[n] for n in self.names), tuple(self.ranges[n] for n in self.names), self._inv)
+
+    def _inverse(self):
+        return NamedStacked(self.transforms, self._ranges_arg, not self._inv)
+
+    def _stacked(self):
+        """The equivalent `Stacked` over the concatenated fields (input ranges are cumulative input lengths)."""
+        bs, rin, off = [], [], 0
+        for n in self.names:
+            b = self.transforms[n]
+            lo, hi = self.ranges[n]
+            n_out = hi - lo + 1
+            n_in = n_out if b is identity else output_size(inverse(b), (n_out,))[0]
+            bs.append(b)
+            rin.append((off + 1, off + n_in))
+            off += n_in
+        st = Stacked(bs, rin)
+        if [tuple(r) for r in st.ranges_out] != [self.ranges[n] for n in self.names]:
+            raise ValueError(f"ranges {self.ranges} do not match the output sizes of the transforms ({st.ranges_out})")
+        return st
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        st = self._stacked()
+        if self._inv:                                                                    # :118-150: vector -> NamedTuple
+            xs, l = st._inverse()._wlj(x, per_sample, want_ladj)
+            out = {}
+            for n, (lo, hi) in zip(self.names, st.ranges_in):
+                piece = xs[lo - 1:hi]
+                out[n] = piece[0] if n in self._int_fields else piece               # an Int range is a scalar field (:19-21)
+            return out, l
+        if not isinstance(x, dict) or list(x.keys()) != self.names:
+            raise ValueError(f"expected a dict with the fields {self.names}")             # x::NamedTuple{names}, :66
+        like = next((v for v in x.values() if isinstance(v, torch.Tensor) and v.is_cuda), None)
+        if like is None:
+            raise RuntimeError("bijectors_amd operates on ROCm device tensors only (no CPU fallback): at least one field must be a device tensor")
+        batched = any(isinstance(v, torch.Tensor) and v.dim() == 2 for v in x.values())
+        pieces = []
+        for n in self.names:
+            v = x[n]
+            t = v if isinstance(v, torch.Tensor) else torch.as_tensor(v, dtype=like.dtype)
+            t = t.to(device=like.device, dtype=like.dtype)
+            if t.dim() == 0:
+                t = t.reshape(1)
+            if batched and t.dim() == 1:                                                 # a scalar field holds one value per column
+                t = t[None, :] if n in self._int_fields and t.shape[0] != 1 else t[:, None].expand(t.shape[0], like.shape[-1])
+            pieces.append(t)
+        cat = torch.cat(pieces, dim=0)
+        return st._wlj(colmajor(cat) if batched else cat.contiguous(), per_sample, want_ladj)
 
 
 # ------------------------------------------------------------------ reverse-mode pullbacks (SURVEY.md §8f, f-1)

@@ -186,6 +186,13 @@ int bjx_pd(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out,
 int bjx_pd_vec(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out,
                void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags);
 
+/* Scale with a MATRIX parameter, scale.jl:14,17,35-36: out = a * in (inverse=1: out = a \ in), a: device T[dim, dim]
+ * column-major, dim <= 128.  logabsdetjac = logabsdet(a) (negated for the inverse): ladj_ps[n] holds it for every column;
+ * ladj_sum = batch * logabsdet(a), or logabsdet(a) ONCE with BJX_REF_VECTOR_SCALE_LADJ — the value the reference returns
+ * for a matrix of columns (:36).  The LU (partial pivoting) behind logabsdet / the inverse runs on the device per call. */
+int bjx_scale_matrix(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* a, const void* in, void* out,
+                     void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
+
 /* ------------------------------- F2: per-sample reduce + broadcast        */
 /* PlanarLayer, planar_layer.jl:65-127,160-185; `n_layers` stacked layers (composition
  * layer[n_layers-1] ∘ ... ∘ layer[0]) are fused into one pass over Z.

@@ -2065,14 +2065,21 @@ def _matrix_cls(bj, kind):
 
 
 def _matrix_free(kind, K, batch, r, dt):
-    """Random unconstrained side (the free entries; the rest zero like the reference's outputs)."""
+    """Random unconstrained side (the free entries; the rest zero like the reference's outputs).  The off-diagonal scale
+    shrinks like 1/sqrt(K) (what an LKJ / Wishart draw does): with O(1) entries the factor's diagonal decays
+    exponentially in K and the forward link of a matrix rounded to `dt` is ill-conditioned, which would test the
+    conditioning of the problem, not the kernel."""
+    off = min(0.6, 1.6 / math.sqrt(K))
     if kind == "vec_corr":
-        return (0.6 * r.normal(size=(K * (K - 1) // 2, batch))).astype(dt)
-    if kind == "pd_vec":
-        return (0.5 * r.normal(size=(K * (K + 1) // 2, batch))).astype(dt)
-    Y = (0.5 * r.normal(size=(K, K, batch))).astype(dt)
-    mask = np.triu(np.ones((K, K), bool), 1) if kind == "corr" else np.tril(np.ones((K, K), bool))
-    return Y * mask[:, :, None]
+        return (off * r.normal(size=(K * (K - 1) // 2, batch))).astype(dt)
+    if kind == "corr":
+        Y = (off * r.normal(size=(K, K, batch))).astype(dt)
+        return Y * np.triu(np.ones((K, K), bool), 1)[:, :, None]
+    L = off * r.normal(size=(K, K, batch)) * np.tril(np.ones((K, K), bool), -1)[:, :, None]
+    L[np.arange(K), np.arange(K), :] = 0.4 * r.normal(size=(K, batch))          # log of the Cholesky diagonal
+    if kind == "pd":
+        return L.astype(dt)
+    return np.stack([np.concatenate([L[j, :j + 1, n] for j in range(K)]) for n in range(batch)], axis=1).astype(dt)   # triu_to_vec(L')
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
@@ -2142,3 +2149,68 @@ def test_matrix_bijectors_reject_what_the_reference_rejects(bj):
         bj.transform(bj.inverse(bj.VecCorrBijector()), torch.zeros(4, dtype=torch.float64, device="cuda"))   # 4 != K(K-1)/2
     with pytest.raises(NotImplementedError):
         bj.transform(bj.inverse(bj.VecCorrBijector()), torch.zeros(65 * 64 // 2, 2, dtype=torch.float64, device="cuda"))  # K = 65
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,batch", [(3, 50), (16, 1000), (37, 129), (64, 4096), (100, 333), (128, 1025), (5, 1)])
+def test_scale_with_a_matrix(bj, dim, batch, dt):
+    """scale.jl:14,17,35-36: a * x, a \\ y, logabsdet(a) — against numpy (matmul / LU solve / slogdet in Float64)."""
+    r = rng(dim * 1000 + batch)
+    A = (r.normal(size=(dim, dim)) / math.sqrt(dim) + 1.5 * np.eye(dim)).astype(dt)      # well conditioned, not symmetric
+    x = np.asfortranarray(r.normal(size=(dim, batch)).astype(dt))
+    b = bj.Scale(dev(A))
+    lad = np.linalg.slogdet(A.astype(np.float64))[1]
+    y, l = bj.with_logabsdet_jacobian(b, dev(x))
+    close(host(y), A.astype(np.float64) @ x.astype(np.float64), dt, what="a * x")
+    assert l.dim() == 0
+    assert abs(float(l) - lad) <= RTOL[dt] * max(1.0, abs(lad)), "the reference returns logabsdet(a) once for a matrix of columns"
+    _, lps = bj.with_logabsdet_jacobian(b, dev(x), per_sample=True)
+    close(host(lps), np.full(batch, lad), dt, what="per-column logabsdet")
+    xb, li = bj.with_logabsdet_jacobian(bj.inverse(b), y)
+    close(host(xb), np.linalg.solve(A.astype(np.float64), host(y).astype(np.float64)), dt, scale=4.0, what="a \\\\ y")
+    assert abs(float(li) + lad) <= RTOL[dt] * max(1.0, abs(lad))
+    # a vector input (the reference's other method) and a chain with elementwise stages around the matrix
+    yv, lv = bj.with_logabsdet_jacobian(b, dev(x[:, 0].copy()))
+    close(host(yv), A.astype(np.float64) @ x[:, 0].astype(np.float64), dt, what="a * vector")
+    assert abs(float(lv) - lad) <= RTOL[dt] * max(1.0, abs(lad))
+    ch = bj.elementwise(bj.exp) @ b @ bj.Shift(0.25)
+    yc, lc = bj.with_logabsdet_jacobian(ch, dev(x), per_sample=True)
+    inner = A.astype(np.float64) @ (x.astype(np.float64) + 0.25)
+    close(host(yc), np.exp(inner), dt, scale=float(np.exp(inner).max()), what="exp ∘ Scale(A) ∘ Shift")
+    close(host(lc), inner.sum(axis=0) + lad, dt, scale=dim, what="chain ladj")
+
+
+def test_scale_matrix_permutation_and_pivoting(bj):
+    """A matrix that needs row exchanges: logabsdet through the pivoted LU, inverse exact for a signed permutation."""
+    P = np.zeros((6, 6))
+    for i, j in enumerate([3, 0, 5, 1, 4, 2]):
+        P[i, j] = (-2.0) ** (i % 3)
+    x = np.asfortranarray(rng(3).normal(size=(6, 40)))
+    b = bj.Scale(dev(P))
+    y, l = bj.with_logabsdet_jacobian(b, dev(x))
+    np.testing.assert_allclose(host(y), P @ x, rtol=1e-14)
+    assert abs(float(l) - np.linalg.slogdet(P)[1]) < 1e-12
+    np.testing.assert_allclose(host(bj.transform(bj.inverse(b), y)), x, rtol=1e-13, atol=1e-14)
+
+
+def test_named_stacked_reference_example(bj):
+    """src/bijectors/named_stacked.jl:24-36: (a = LogNormal, b = InverseGamma, c = MvNormal) -> (log, log, identity)."""
+    log = bj.elementwise(bj.log)
+    ns = bj.NamedStacked({"a": log, "b": log, "c": bj.identity}, {"a": 1, "b": 2, "c": (3, 4)})
+    x = {"a": 1.0, "b": 2.0, "c": torch.tensor([0.5, -0.5], dtype=torch.float64, device="cuda")}
+    y, lj = bj.with_logabsdet_jacobian(ns, x)
+    np.testing.assert_allclose(host(y), [0.0, 0.6931471805599453, 0.5, -0.5], atol=1e-15)
+    assert abs(float(lj) + 0.6931471805599453) < 1e-15
+    back, lb = bj.with_logabsdet_jacobian(bj.inverse(ns), y)
+    assert list(back.keys()) == ["a", "b", "c"] and back["a"].dim() == 0 and back["c"].shape == (2,)
+    np.testing.assert_allclose([float(back["a"]), float(back["b"])], [1.0, 2.0], rtol=1e-15)
+    np.testing.assert_allclose(host(back["c"]), [0.5, -0.5])
+    assert abs(float(lb) - 0.6931471805599453) < 1e-15
+    # one column per chain: the same NamedStacked over 257 parameter vectors in one launch
+    r = rng(0)
+    xa, xb_, xc = r.uniform(0.2, 3, 257), r.uniform(0.2, 3, 257), r.normal(size=(2, 257))
+    yb, lps = bj.with_logabsdet_jacobian(ns, {"a": dev(xa), "b": dev(xb_), "c": dev(np.asfortranarray(xc))}, per_sample=True)
+    np.testing.assert_allclose(host(yb), np.vstack([np.log(xa), np.log(xb_), xc]), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(host(lps), -(np.log(xa) + np.log(xb_)), rtol=1e-12, atol=1e-14)
+    with pytest.raises(ValueError):
+        bj.NamedStacked({"a": log}, {"b": 1})

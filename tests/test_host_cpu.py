@@ -124,8 +124,9 @@ def test_constructors_and_errors(bj):
 
     with pytest.raises(AssertionError):
         bj.RationalQuadraticSpline(torch.zeros(2, 3), torch.zeros(2, 3), -torch.ones(2, 3))   # derivatives > 0 (rqs.jl:94)
-    with pytest.raises(NotImplementedError):
-        bj.Scale(torch.eye(3))
+    assert bj.Scale(torch.eye(3)).matrix and not bj.Scale(torch.ones(3)).matrix       # scale.jl:14: a matrix `a` means a * x
+    with pytest.raises(ValueError):
+        bj.Scale(torch.zeros(3, 4))                                                      # logabsdet needs a square matrix
     with pytest.raises(ValueError):
         bj.Inverse(object())
 
