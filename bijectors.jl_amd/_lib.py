@@ -16,6 +16,8 @@ BJX_ACCUMULATE = 1 << 0
 BJX_REF_VECTOR_SCALE_LADJ = 1 << 1
 BJX_BASE_STDNORMAL = 1 << 2
 BJX_INPUT_STDNORMAL = 1 << 3
+BJX_COUPLING_SCALE_BCAST = 1 << 4
+BJX_COUPLING_SHIFT_BCAST = 1 << 5
 BJX_MAX_OPS = 8
 
 (OP_EXP, OP_LOG, OP_SHIFT, OP_SCALE, OP_SCALE_INV, OP_LOGIT, OP_LOGIT_INV, OP_LEAKY_RELU,
@@ -84,6 +86,8 @@ SIGNATURES = {
     "bjx_batchnorm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _d, _vp, _vp] + _tail),
     "bjx_row_moments": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _i64]),
     "bjx_batchnorm_train": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp] + _tail),
+    "bjx_batchnorm_stats": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _i64]),
+    "bjx_batchnorm_train_apply": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp] + _tail),
     "bjx_rqs": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp] + _tail),
     "bjx_rqs_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_rqs_params": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i64, _d, _vp, _vp, _vp]),

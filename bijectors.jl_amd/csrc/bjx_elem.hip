@@ -583,6 +583,7 @@ template <class T, bool INV> struct CouplingAffineF {
   const int32_t* map;
   const T *scale, *shift;   // [n1, batch] or null
   int64_t n1, dim;
+  int64_t ss, st;           // column strides of scale / shift: n1, or 0 when the array is T[n1] shared by every column
   int map_in_lds;           // the row map is staged in LDS (dim <= 12 Ki rows), else read from the context scratch
   double per_sample_const;
   const double* per_sample_dev;
@@ -617,8 +618,8 @@ template <class T, bool INV> struct CouplingAffineF {
     }
     if (run) {
       Pack<T, V> s1, t1;
-      if (scale) s1 = load_pack<T, V, true>(scale + col * n1 + a.m0);
-      if (shift) t1 = load_pack<T, V, true>(shift + col * n1 + a.m0);
+      if (scale) s1 = load_pack<T, V, true>(scale + col * ss + a.m0);
+      if (shift) t1 = load_pack<T, V, true>(shift + col * st + a.m0);
 #pragma unroll
       for (int j = 0; j < V; ++j) { if (scale) a.s.v[j] = s1.v[j]; if (shift) a.t.v[j] = t1.v[j]; }
     } else if (a.on) {
@@ -626,8 +627,8 @@ template <class T, bool INV> struct CouplingAffineF {
       for (int j = 0; j < V; ++j) {
         const int32_t mi = m[row + j];
         if (mi >= 0) {
-          if (scale) a.s.v[j] = scale[col * n1 + mi];
-          if (shift) a.t.v[j] = shift[col * n1 + mi];
+          if (scale) a.s.v[j] = scale[col * ss + mi];
+          if (shift) a.t.v[j] = shift[col * st + mi];
         }
       }
     }
@@ -879,17 +880,24 @@ int bn_impl(bjx_ctx* ctx, int inverse, const T* b, const T* logs, const T* m, co
 //   5. the eval-mode apply kernel with the batch statistics.
 // x is read twice (statistics, apply): 3·dim·sizeof(T) + sizeof(T) bytes per sample is the algorithmic traffic.
 template <class T, int V, int R>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t dim, int64_t batch, int G, double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, const T* __restrict__ shift, int64_t dim, int64_t batch, int G, double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* red = reinterpret_cast<double*>(smem);            // [cols_per_block][dim][2]
   const int gl = threadIdx.x & (G - 1), cg = threadIdx.x / G;
   const int cols_per_block = 256 / G;
   const int64_t nvc = dim / V;                               // packs per column; lane gl owns packs gl, gl+G, ... (R of them)
   double sx[R][V], sxx[R][V];
+  // Sums of x - c and (x - c)^2 with a per-row shift c that every rank holds identically (the moving mean): the
+  // variance S2/n - (S1/n)^2 then cancels on the scale of the batch spread, not of |mean| (the reference's two-pass
+  // sum((x - m)^2)/n, normalise.jl:54, has no cancellation; raw one-pass sums lose it for Float64 data with |mean| >> std)
+  T sh[R][V];
 #pragma unroll
   for (int k = 0; k < R; ++k)
 #pragma unroll
-    for (int j = 0; j < V; ++j) { sx[k][j] = 0.0; sxx[k][j] = 0.0; }
+    for (int j = 0; j < V; ++j) {
+      sx[k][j] = 0.0; sxx[k][j] = 0.0;
+      sh[k][j] = (shift && gl + k * G < nvc) ? shift[(int64_t)(gl + k * G) * V + j] : T(0);
+    }
   constexpr int U = R == 1 ? 8 : (R == 2 ? 4 : 2);          // columns in flight per lane group
   const int64_t stride = (int64_t)gridDim.x * cols_per_block;
   int64_t col = (int64_t)blockIdx.x * cols_per_block + cg;
@@ -909,7 +917,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
         for (int j = 0; j < V; ++j) {
           T s1 = T(0), s2 = T(0);
 #pragma unroll
-          for (int u = 0; u < U; ++u) { const T v = p[u][k].v[j]; s1 += v; s2 += v * v; }
+          for (int u = 0; u < U; ++u) { const T v = p[u][k].v[j] - sh[k][j]; s1 += v; s2 += v * v; }
           sx[k][j] += (double)s1; sxx[k][j] += (double)s2;
         }
       }
@@ -920,7 +928,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
       if (gl + k * G < nvc) {
         Pack<T, V> p = load_pack<T, V, false>(x + col * dim + (int64_t)(gl + k * G) * V);
 #pragma unroll
-        for (int j = 0; j < V; ++j) { const double v = (double)p.v[j]; sx[k][j] += v; sxx[k][j] += v * v; }
+        for (int j = 0; j < V; ++j) { const double v = (double)(p.v[j] - sh[k][j]); sx[k][j] += v; sxx[k][j] += v * v; }
       }
   }
   // combine the column groups of the block in a fixed order
@@ -1075,8 +1083,10 @@ __global__ __launch_bounds__(256) void bn_train_finalize_kernel(const double* __
   const double n = stats[2 * dim];
   double s = 0.0;
   for (int64_t r = threadIdx.x; r < dim; r += blockDim.x) {
-    const double mean = stats[r] / n;
-    double var = stats[dim + r] / n - mean * mean;           // biased (÷ n), :54
+    // stats hold the sums of x - c, c = the moving mean BEFORE this update (the shift of bn_stats_kernel)
+    const double dm = stats[r] / n;
+    const double mean = (double)m_mov[r] + dm;
+    double var = stats[dim + r] / n - dm * dm;               // biased (÷ n), :54
     if (var < 0.0) var = 0.0;
     const T mT = (T)mean, vT = (T)var;
     m_batch[r] = mT;
@@ -1180,38 +1190,24 @@ BJX_API int bjx_batchnorm(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* b
 }
 
 namespace {
+// statistics of this column block: stats[0..dim) = Σ (x - shift), [dim..2 dim) = Σ (x - shift)², [2 dim] = columns
 template <class T>
-int bn_train_impl(bjx_ctx* ctx, const T* b, const T* logs, T* m, T* v, T eps, T mtm, const T* in, T* out, T* ladj_ps, double* ladj_sum,
-                  int64_t dim, int64_t batch, uint32_t flags) {
-  BJX_REQUIRE(ctx, batch >= 1, BJX_ERR_SHAPE, "bjx_batchnorm_train: empty batch");
-  ColLaunch c = col_launch_cfg<T>(ctx, in, out, dim, batch);
+int bn_stats_impl(bjx_ctx* ctx, const T* shift, const T* in, double* stats, double* partial, int max_blocks, int64_t dim, int64_t batch) {
+  ColLaunch c = col_launch_cfg<T>(ctx, in, in, dim, batch);
   const int64_t nvc = dim / c.V;
   BJX_REQUIRE(ctx, nvc <= 256, BJX_ERR_UNSUPPORTED, "bjx_batchnorm_train: %lld channels exceed the register-accumulator kernel (max %d)", (long long)dim, 256 * c.V);
   const int R = nvc <= c.G ? 1 : (nvc <= 2 * c.G ? 2 : 4);
   const int cols_per_block = 256 / c.G;
   int nblocks = (int)((batch + cols_per_block * 16 - 1) / (cols_per_block * 16));     // >= 16 columns per lane group
   if (nblocks > 1024) nblocks = 1024;
-  // scratch: [stats 2 dim + 1][partials nblocks*dim*2] doubles, then batch m / v (T)
-  const size_t stats_n = 2 * (size_t)dim + 1;
-  {
-    const size_t fixed = (stats_n + 1) * sizeof(double) + 2 * (size_t)dim * sizeof(T);
-    const size_t fit = fixed < BJX_SCRATCH_BYTES ? (BJX_SCRATCH_BYTES - fixed) / ((size_t)dim * 2 * sizeof(double)) : 0;
-    if ((size_t)nblocks > fit) nblocks = (int)fit;      // fewer, longer blocks: the slabs of partial sums live in the context scratch
-  }
+  if (nblocks > max_blocks) nblocks = max_blocks;       // fewer, longer blocks: the slabs of partial sums live in the context scratch
   if (nblocks < 1) nblocks = 1;
-  const size_t part_n = (size_t)nblocks * dim * 2;
-  const size_t bytes = (stats_n + 1 + part_n) * sizeof(double) + 2 * (size_t)dim * sizeof(T);
-  BJX_REQUIRE(ctx, bytes <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_batchnorm_train: scratch too small for %lld channels", (long long)dim);
-  double* stats = static_cast<double*>(ctx->scratch);
-  double* partial = stats + stats_n + 1;
-  T* m_batch = reinterpret_cast<T*>(partial + part_n);
-  T* v_batch = m_batch + dim;
   const size_t smem = (size_t)cols_per_block * dim * 2 * sizeof(double);
   BJX_REQUIRE(ctx, smem <= 64 * 1024, BJX_ERR_UNSUPPORTED, "bjx_batchnorm_train: LDS");
   constexpr int VW = Vec16<T>::N;
   {
     BjxProf prof_(ctx);
-#define BN_ST(V_, R_) hipLaunchKernelGGL((bn_stats_kernel<T, V_, R_>), dim3(nblocks), dim3(256), smem, ctx->stream, in, dim, batch, c.G, partial)
+#define BN_ST(V_, R_) hipLaunchKernelGGL((bn_stats_kernel<T, V_, R_>), dim3(nblocks), dim3(256), smem, ctx->stream, in, shift, dim, batch, c.G, partial)
 #define BN_STV(V_) do { if (R == 1) BN_ST(V_, 1); else if (R == 2) BN_ST(V_, 2); else BN_ST(V_, 4); } while (0)
     if (c.V == VW) BN_STV(VW); else BN_STV(1);
 #undef BN_STV
@@ -1221,18 +1217,78 @@ int bn_train_impl(bjx_ctx* ctx, const T* b, const T* logs, T* m, T* v, T eps, T 
   { BjxProf prof_(ctx);
   hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)((dim + 63) / 64)), dim3(256), 0, ctx->stream, partial, nblocks, dim, batch, stats); }
   BJX_CHECK_LAUNCH(ctx);
-  if (ctx->comm && ctx->nranks > 1) {      // batch sharded over GPUs: the second collective of SURVEY.md §8(e)
-    int rc = bjx_allreduce_sum_f64(ctx, stats, (int64_t)stats_n);
-    if (rc) return rc;
+  return BJX_OK;
+}
+
+// scratch layout of the training path: [stats 2 dim + 1 (+1 pad)][partials max_blocks*dim*2] doubles, then batch m / v (T)
+template <class T> struct BnScratch {
+  double* stats; double* partial; T* m_batch; T* v_batch; int max_blocks; bool ok;
+  BnScratch(bjx_ctx* ctx, int64_t dim) {
+    const size_t stats_n = 2 * (size_t)dim + 1;
+    const size_t fixed = (stats_n + 1) * sizeof(double) + 2 * (size_t)dim * sizeof(T);
+    const size_t fit = fixed < BJX_SCRATCH_BYTES ? (BJX_SCRATCH_BYTES - fixed) / ((size_t)dim * 2 * sizeof(double)) : 0;
+    max_blocks = (int)(fit < 1024 ? fit : 1024);
+    ok = max_blocks >= 1;
+    stats = static_cast<double*>(ctx->scratch);
+    partial = stats + stats_n + 1;
+    m_batch = reinterpret_cast<T*>(partial + (size_t)(ok ? max_blocks : 0) * dim * 2);
+    v_batch = m_batch + dim;
   }
-  hipLaunchKernelGGL(bn_train_finalize_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, stats, dim, logs, eps, mtm, m, v, m_batch, v_batch, batch, ctx->consts);
+};
+
+// moving-statistics update + the eval-mode apply kernel with the batch statistics behind `stats` (GLOBAL sums)
+template <class T>
+int bn_apply_stats_impl(bjx_ctx* ctx, const T* b, const T* logs, T* m, T* v, T eps, T mtm, const double* stats, const T* in, T* out, T* ladj_ps,
+                        double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
+  BnScratch<T> sc(ctx, dim);
+  BJX_REQUIRE(ctx, sc.ok, BJX_ERR_UNSUPPORTED, "bjx_batchnorm_train: scratch too small for %lld channels", (long long)dim);
+  hipLaunchKernelGGL(bn_train_finalize_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, stats, dim, logs, eps, mtm, m, v, sc.m_batch, sc.v_batch, batch, ctx->consts);
   BJX_CHECK_LAUNCH(ctx);
   const bool lds = (size_t)dim * 4 * sizeof(T) <= 60 * 1024;
   const size_t fsm = lds ? (size_t)dim * 4 * sizeof(T) : 0;
-  BnF<T, false> f{b, logs, m_batch, v_batch, eps, dim, lds ? 1 : 0, 0.0, ctx->consts};
+  BnF<T, false> f{b, logs, sc.m_batch, sc.v_batch, eps, dim, lds ? 1 : 0, 0.0, ctx->consts};
   return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0);
 }
+
+template <class T>
+int bn_train_impl(bjx_ctx* ctx, const T* b, const T* logs, T* m, T* v, T eps, T mtm, const T* in, T* out, T* ladj_ps, double* ladj_sum,
+                  int64_t dim, int64_t batch, uint32_t flags) {
+  BJX_REQUIRE(ctx, batch >= 1, BJX_ERR_SHAPE, "bjx_batchnorm_train: empty batch");
+  BnScratch<T> sc(ctx, dim);
+  BJX_REQUIRE(ctx, sc.ok, BJX_ERR_UNSUPPORTED, "bjx_batchnorm_train: scratch too small for %lld channels", (long long)dim);
+  int rc = bn_stats_impl<T>(ctx, m, in, sc.stats, sc.partial, sc.max_blocks, dim, batch);
+  if (rc) return rc;
+  if (ctx->comm && ctx->nranks > 1) {      // batch sharded over GPUs: the second collective of SURVEY.md §8(e)
+    rc = bjx_allreduce_sum_f64(ctx, sc.stats, (int64_t)(2 * dim + 1));
+    if (rc) return rc;
+  }
+  return bn_apply_stats_impl<T>(ctx, b, logs, m, v, eps, mtm, sc.stats, in, out, ladj_ps, ladj_sum, dim, batch, flags);
+}
 }  // namespace
+
+BJX_API int bjx_batchnorm_stats(bjx_ctx* ctx, bjx_dtype dt, const void* shift, const void* in, double* stats, int64_t dim, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_batchnorm_stats: bad size");
+  BJX_REQUIRE(ctx, stats && (in || batch == 0), BJX_ERR_ARG, "bjx_batchnorm_stats: null pointer");
+  if (batch == 0) { BJX_HIP(ctx, hipMemsetAsync(stats, 0, (size_t)(2 * dim + 1) * sizeof(double), ctx->stream)); return BJX_OK; }
+  if (dt == BJX_F32) { BnScratch<float> sc(ctx, dim); BJX_REQUIRE(ctx, sc.ok, BJX_ERR_UNSUPPORTED, "bjx_batchnorm_stats: too many channels");
+    return bn_stats_impl<float>(ctx, (const float*)shift, (const float*)in, stats, sc.partial, sc.max_blocks, dim, batch); }
+  if (dt == BJX_F64) { BnScratch<double> sc(ctx, dim); BJX_REQUIRE(ctx, sc.ok, BJX_ERR_UNSUPPORTED, "bjx_batchnorm_stats: too many channels");
+    return bn_stats_impl<double>(ctx, (const double*)shift, (const double*)in, stats, sc.partial, sc.max_blocks, dim, batch); }
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_batchnorm_stats: bad dtype %d", (int)dt);
+}
+
+BJX_API int bjx_batchnorm_train_apply(bjx_ctx* ctx, bjx_dtype dt, const void* b, const void* logs, void* m, void* v, double eps, double mtm,
+                                      const double* stats, const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch,
+                                      uint32_t flags) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_batchnorm_train_apply: bad size");
+  BJX_REQUIRE(ctx, b && logs && m && v && stats && ((in && out) || batch == 0), BJX_ERR_ARG, "bjx_batchnorm_train_apply: null pointer");
+  DISPATCH_DT(ctx, dt,
+              bn_apply_stats_impl<float>(ctx, (const float*)b, (const float*)logs, (float*)m, (float*)v, (float)eps, (float)mtm, stats, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, batch, flags),
+              bn_apply_stats_impl<double>(ctx, (const double*)b, (const double*)logs, (double*)m, (double*)v, eps, mtm, stats, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, batch, flags),
+              "bjx_batchnorm_train_apply");
+}
 
 BJX_API int bjx_batchnorm_train(bjx_ctx* ctx, bjx_dtype dt, const void* b, const void* logs, void* m, void* v, double eps, double mtm,
                                 const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
@@ -1326,8 +1382,9 @@ int coupling_affine_impl(bjx_ctx* ctx, int inverse, const int32_t* idx1, int64_t
   if (rc) return rc;
   const int in_lds = dim <= 12 * 1024 ? 1 : 0;
   const size_t fsm = in_lds ? (size_t)dim * sizeof(int32_t) + 16 : 0;      // row map in LDS
-  if (!inverse) { CouplingAffineF<T, false> f{map, scale, shift, n1, dim, in_lds, 0.0, nullptr}; return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0); }
-  CouplingAffineF<T, true> f{map, scale, shift, n1, dim, in_lds, 0.0, nullptr};
+  const int64_t ss = (flags & BJX_COUPLING_SCALE_BCAST) ? 0 : n1, st = (flags & BJX_COUPLING_SHIFT_BCAST) ? 0 : n1;
+  if (!inverse) { CouplingAffineF<T, false> f{map, scale, shift, n1, dim, ss, st, in_lds, 0.0, nullptr}; return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0); }
+  CouplingAffineF<T, true> f{map, scale, shift, n1, dim, ss, st, in_lds, 0.0, nullptr};
   return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0);
 }
 template <class T>

@@ -1062,11 +1062,35 @@ class InvertibleBatchNorm(Bijector):
             self.m, self.v = _param(self.m, x).clone() if not (self.m.is_cuda and self.m.dtype == x.dtype) else self.m, \
                 _param(self.v, x).clone() if not (self.v.is_cuda and self.v.dtype == x.dtype) else self.v
             b, logs = _param(self.b, x), _param(self.logs, x)
-            return _call_struct("bjx_batchnorm_train", x, dim, True, per_sample, want_ladj,
-                                (_ptr(b), _ptr(logs), _ptr(self.m), _ptr(self.v), self.eps, self.mtm), (dim,))
+            # statistics of this rank's columns -> ONE sum all-reduce of 2·dim+1 Float64 values when the batch is sharded
+            # (SURVEY.md §8e "Exception"; torch.distributed or the library's communicator) -> update + transform
+            stats = self.batch_stats(x)
+            from . import shard as _shard
+
+            _shard.allreduce_logabsdetjac(stats)
+            return self.apply_batch_stats(x, stats, per_sample, want_ladj)
         ps = [_param(t, x) for t in (self.b, self.logs, self.m, self.v)]
         return _call_struct("bjx_batchnorm", x, dim, True, per_sample, want_ladj,
                             (int(inv), *[_ptr(p) for p in ps], self.eps), (dim,))
+
+    def batch_stats(self, x):
+        """(Σ(x − m), Σ(x − m)², n) of these columns as a float64 tensor of 2·dim+1 entries (bjx_batchnorm_stats); sums of
+        column blocks add up to the sums of the whole batch, which is all a sharded batch has to exchange."""
+        xc, dim, batch, _ = _prep(x)
+        if not (self.m.is_cuda and self.m.dtype == xc.dtype):
+            self.m, self.v = _param(self.m, xc).clone(), _param(self.v, xc).clone()
+        ctx = context(xc.device)
+        stats = torch.empty(2 * dim + 1, dtype=torch.float64, device=xc.device)
+        L.check(ctx.h, L.load().bjx_batchnorm_stats(ctx.h, _dt(xc), _ptr(self.m), _ptr(xc), _ptr(stats), dim, batch), "bjx_batchnorm_stats")
+        return stats
+
+    def apply_batch_stats(self, x, stats, per_sample=False, want_ladj=True):
+        """Training-mode transform of these columns with the statistics behind the GLOBAL sums `stats`; updates m, v in place
+        (call it once per rank: every rank holds its own replica of the moving statistics)."""
+        b, logs = _param(self.b, x), _param(self.logs, x)
+        dim = x.shape[0]
+        return _call_struct("bjx_batchnorm_train_apply", x, dim, True, per_sample, want_ladj,
+                            (_ptr(b), _ptr(logs), _ptr(self.m), _ptr(self.v), self.eps, self.mtm, _ptr(stats)), (dim,))
 
     def _wlj(self, x, per_sample, want_ladj=True):
         return self._run(x, False, per_sample, want_ladj)
@@ -1146,6 +1170,24 @@ class PartitionMask:
         idx = lambda l: torch.tensor([i - 1 for i in l], dtype=torch.long, device=x.device)
         return x[idx(self.indices_1)], x[idx(self.indices_2)], x[idx(self.indices_3)]
 
+    def rows2(self, x):
+        """x_2 = A_2' x (coupling.jl:133): a view when indices_2 is a row range, one gather otherwise."""
+        i2 = self.indices_2
+        if i2 and i2 == list(range(i2[0], i2[0] + len(i2))):
+            return x[i2[0] - 1:i2[0] - 1 + len(i2)]
+        cache = self.__dict__.setdefault("_dev2", {})
+        t = cache.get(x.device)
+        if t is None:
+            t = cache[x.device] = torch.tensor([i - 1 for i in i2], dtype=torch.long, device=x.device)
+        return x[t]
+
+    def idx1_dev(self, device):
+        cache = self.__dict__.setdefault("_dev1", {})
+        t = cache.get(device)
+        if t is None:
+            t = cache[device] = torch.tensor([i - 1 for i in self.indices_1], dtype=torch.int32, device=device)
+        return t
+
 
 class Coupling(Bijector):
     """coupling.jl:174-259.  θ maps x₂ (rows of partition 2, shape (n2[, batch])) to a bijector for x₁.
@@ -1162,9 +1204,10 @@ class Coupling(Bijector):
         xc, dim, batch, vec = _prep(x)
         if dim != self.mask.n:
             raise ValueError(f"DimensionMismatch: mask for {self.mask.n} rows applied to {dim} rows")
-        x1, x2, x3 = self.mask.partition(xc)
-        law = self.theta(x2)
-        idx1 = torch.tensor([i - 1 for i in self.mask.indices_1], dtype=torch.int32, device=xc.device)
+        # only x_2 feeds θ (coupling.jl:210, :240); x_1 and x_3 are read in place by the kernel.  A row-range partition is a
+        # strided view (no gather kernel); scattered indices cost one index gather of x_2.
+        law = self.theta(self.mask.rows2(xc))
+        idx1 = self.mask.idx1_dev(xc.device)
         n1 = idx1.numel()
         if isinstance(law, RationalQuadraticSpline):
             w, h, d = (colmajor(_param(t, xc)) for t in (law.widths, law.heights, law.derivatives))
@@ -1180,19 +1223,24 @@ class Coupling(Bijector):
             else:
                 raise NotImplementedError(f"coupling law {law!r} has no device kernel (supported: Shift, Scale, Shift∘Scale, RQS)")
 
-        def full(p):
+        def full(p, bcast_flag):
+            """-> (device array, flag): a scalar or (n1,) parameter stays T[n1] (broadcast over the columns inside the kernel)."""
             if p is None:
-                return None
+                return None, 0
             t = _param(p, xc)
             if t.dim() == 0:
-                t = t.expand(n1)
-            if t.dim() == 1 and not vec:
-                t = t[:, None].expand(n1, batch)
-            return colmajor(t.contiguous() if t.dim() == 1 else t)
+                t = t.expand(n1).contiguous()
+            if t.dim() == 1:
+                if t.numel() != n1:
+                    raise ValueError(f"DimensionMismatch: coupling parameter of length {t.numel()} for {n1} rows")
+                return t.contiguous(), (0 if vec else bcast_flag)
+            if tuple(t.shape) != (n1, batch):
+                raise ValueError(f"DimensionMismatch: coupling parameter of shape {tuple(t.shape)} for ({n1}, {batch})")
+            return colmajor(t), 0
 
-        s_t, t_t = full(scale), full(shift)
+        (s_t, f_s), (t_t, f_t) = full(scale, L.BJX_COUPLING_SCALE_BCAST), full(shift, L.BJX_COUPLING_SHIFT_BCAST)
         return _call_struct("bjx_coupling_affine", x, dim, False, per_sample, want_ladj,
-                            (int(inv), _ptr(idx1), n1, _ptr(s_t), _ptr(t_t)), (dim,))
+                            (int(inv), _ptr(idx1), n1, _ptr(s_t), _ptr(t_t)), (dim,), flags=f_s | f_t)
 
     def _wlj(self, x, per_sample, want_ladj=True):
         return self._run(x, False, per_sample, want_ladj)

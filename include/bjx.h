@@ -71,7 +71,11 @@ enum {
    * drawn — standard normals from the counter-based generator of bjx_fill_normal, stream (seed, first global column)
    * set with bjx_set_rng; `x` may be NULL.  The values are bit-identical to bjx_fill_normal followed by the chain,
    * for any shard count. */
-  BJX_INPUT_STDNORMAL = 1u << 3
+  BJX_INPUT_STDNORMAL = 1u << 3,
+  /* bjx_coupling_affine: the `scale` / `shift` array is T[n1] shared by every column instead of T[n1, batch] (a law whose
+   * parameter does not depend on x_2, e.g. Shift(0.25) or Scale(vector): nothing is expanded on the host). */
+  BJX_COUPLING_SCALE_BCAST = 1u << 4,
+  BJX_COUPLING_SHIFT_BCAST = 1u << 5
 };
 
 /* ---------------------------------------------------------------- context */
@@ -266,6 +270,20 @@ int bjx_row_moments(bjx_ctx* ctx, bjx_dtype dt, const void* a, const void* b, do
 int bjx_batchnorm_train(bjx_ctx* ctx, bjx_dtype dt, const void* b, const void* logs, void* m, void* v,
                         double eps, double mtm, const void* in, void* out, void* ladj_ps,
                         double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
+
+/* The two halves of bjx_batchnorm_train, for hosts that own the collective (and for shard emulation on one GPU):
+ *   bjx_batchnorm_stats        stats[0..dim) = sum_n (x[i,n] - shift[i]), stats[dim..2 dim) = sum_n (x[i,n] - shift[i])^2,
+ *                              stats[2 dim] = batch  — device double[2 dim + 1], Float64, fixed summation order.
+ *                              `shift` (device T[dim] or NULL = 0) must be identical on every rank: pass the moving
+ *                              mean `m`, which makes the one-pass variance as well conditioned as normalise.jl:54's two-pass form.
+ *   (host)                     sum `stats` over the ranks (bjx_allreduce_sum_f64 / MPI / torch.distributed)
+ *   bjx_batchnorm_train_apply  statistics from the GLOBAL sums (shift = the `m` passed in, read before it is updated),
+ *                              moving-statistics update (:58-59), transform and log-det of THIS rank's columns.
+ * bjx_batchnorm_train(x) == stats(m, x) -> all-reduce when the context has a communicator -> train_apply. */
+int bjx_batchnorm_stats(bjx_ctx* ctx, bjx_dtype dt, const void* shift, const void* in, double* stats, int64_t dim, int64_t batch);
+int bjx_batchnorm_train_apply(bjx_ctx* ctx, bjx_dtype dt, const void* b, const void* logs, void* m, void* v,
+                              double eps, double mtm, const double* stats, const void* in, void* out, void* ladj_ps,
+                              double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
 
 /* ------------------------------- F4: table lookup                         */
 /* RationalQuadraticSpline with matrix parameters, rational_quadratic_spline.jl:128-367,

@@ -2214,3 +2214,117 @@ def test_named_stacked_reference_example(bj):
     np.testing.assert_allclose(host(lps), -(np.log(xa) + np.log(xb_)), rtol=1e-12, atol=1e-14)
     with pytest.raises(ValueError):
         bj.NamedStacked({"a": log}, {"b": 1})
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,N", [(64, 40000), (20, 7777), (256, 4099)])
+def test_batchnorm_training_shard_emulation(bj, orc, dim, N, dt):
+    """SURVEY.md §8(e) 'Exception' on ONE GPU: G column blocks -> bjx_batchnorm_stats per block -> the 2·dim+1 Float64 sums
+    added in rank order (what the all-reduce does) -> bjx_batchnorm_train_apply per block with the GLOBAL sums.  The
+    result must be the G = 1 result: bit-equal for Float32 (the Float64 sums differ in their last bits between
+    partitions, which does not survive the rounding of mean / variance to Float32 here), 1e-12 for Float64; and both
+    must equal the monolithic bjx_batchnorm_train entry point."""
+    import ctypes as C
+
+    r = rng(dim + N)
+    b_, logs = r.normal(size=dim).astype(dt), (0.3 * r.normal(size=dim)).astype(dt)
+    m0, v0 = (3.0 + r.normal(size=dim)).astype(dt), r.uniform(0.5, 2, size=dim).astype(dt)
+    X = np.asfortranarray((1.5 * r.normal(size=(dim, N)) + 3.2).astype(dt))
+    Xd = dev(X)
+    mk = lambda: bj.InvertibleBatchNorm(torch.tensor(b_), torch.tensor(logs), torch.tensor(m0), torch.tensor(v0), eps=1e-5, mtm=0.1)
+
+    def run(G):
+        bns = [mk() for _ in range(G)]                                       # one replica of the moving statistics per rank
+        blocks = [Xd[:, lo:hi] for lo, hi in (bj.shard.shard_columns(N, G, g) for g in range(G))]
+        stats = [bn.batch_stats(xb) for bn, xb in zip(bns, blocks)]
+        total = stats[0].clone()
+        for s_ in stats[1:]:
+            total += s_                                                      # rank order, Float64
+        outs = [bn.apply_batch_stats(xb, total, per_sample=True) for bn, xb in zip(bns, blocks)]
+        Y = torch.cat([o[0] for o in outs], dim=1)
+        l = torch.cat([o[1] for o in outs])
+        for bn in bns[1:]:
+            assert torch.equal(bn.m, bns[0].m) and torch.equal(bn.v, bns[0].v)      # replicas stay identical
+        return host(Y), host(l), host(bns[0].m), host(bns[0].v)
+
+    Y1, l1, m1, v1 = run(1)
+    Y_ref, l_ref, m_ref, v_ref = orc.batchnorm_train(b_, logs, m0, v0, 1e-5, 0.1, X)
+    close(Y1, Y_ref, dt, scale=10, what="G=1 vs oracle")
+    close(l1, l_ref, dt, scale=dim)
+    close(m1, m_ref, dt)
+    close(v1, v_ref, dt)
+    for G in (2, 4, 8):
+        Yg, lg, mg, vg = run(G)
+        if dt == np.float32:
+            assert np.array_equal(Yg, Y1) and np.array_equal(lg, l1) and np.array_equal(mg, m1) and np.array_equal(vg, v1), f"G={G}"
+        else:
+            for a_, b2 in ((Yg, Y1), (lg, l1), (mg, m1), (vg, v1)):
+                np.testing.assert_allclose(a_, b2, rtol=1e-12, atol=1e-12, err_msg=f"G={G}")
+    # the monolithic entry point (no communicator: a single rank) gives the G = 1 result
+    L = bj._lib
+    ctx = bj.context(Xd.device)
+    t = lambda a: torch.tensor(a, device="cuda")
+    bd, ld, md, vd = t(b_), t(logs), t(m0), t(v0)
+    Y = torch.empty((N, dim), dtype=Xd.dtype, device="cuda").T
+    lps = torch.empty(N, dtype=Xd.dtype, device="cuda")
+    rc = L.load().bjx_batchnorm_train(ctx.h, L.BJX_F32 if dt == np.float32 else L.BJX_F64, C.c_void_p(bd.data_ptr()), C.c_void_p(ld.data_ptr()),
+                                      C.c_void_p(md.data_ptr()), C.c_void_p(vd.data_ptr()), 1e-5, 0.1, C.c_void_p(Xd.data_ptr()),
+                                      C.c_void_p(Y.data_ptr()), C.c_void_p(lps.data_ptr()), None, dim, N, 0)
+    L.check(ctx.h, rc, "bjx_batchnorm_train")
+    assert np.array_equal(host(Y), Y1) and np.array_equal(host(lps), l1) and np.array_equal(host(md), m1) and np.array_equal(host(vd), v1)
+
+
+def test_batchnorm_training_large_mean_float64(bj):
+    """one-pass Σx² - mean² cancels for Float64 data with |mean| >> std; the shifted sums (shift = moving
+    mean) keep the 1e-6 bar: mean 1e6, std 1e-2, moving mean near the data."""
+    dim, N = 8, 50000
+    r = rng(9)
+    X = np.asfortranarray(1e6 + 1e-2 * r.normal(size=(dim, N)))
+    bn = bj.InvertibleBatchNorm(torch.zeros(dim, dtype=torch.float64), torch.zeros(dim, dtype=torch.float64),
+                                torch.full((dim,), 1e6, dtype=torch.float64), torch.ones(dim, dtype=torch.float64), eps=1e-12, mtm=0.1)
+    with bj.training():
+        Y, l = bj.with_logabsdet_jacobian(bn, dev(X))
+    m = X.mean(axis=1, keepdims=True)
+    v = ((X - m) ** 2).sum(axis=1, keepdims=True) / N                          # normalise.jl:54, two passes
+    np.testing.assert_allclose(host(Y), (X - m) / np.sqrt(v + 1e-12), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(host(l), np.full(N, -0.5 * np.log(v + 1e-12).sum()), rtol=1e-8)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("ranged", [True, False])
+def test_coupling_broadcast_parameters_and_data_dependent_theta(bj, orc, dt, ranged):
+    """A law whose parameters are per-row constants (Shift(0.25) ∘ Scale(vector)) is broadcast over the columns INSIDE the
+    kernel (BJX_COUPLING_*_BCAST: no (n1, batch) expansion on the host), and θ sees x₂ as a view of x when the partition
+    is a row range (only x₂ is ever gathered, coupling.jl:132-134,210)."""
+    r = rng(77)
+    dim, N, n1 = 32, 513, 16
+    idx1 = list(range(1, n1 + 1)) if ranged else [1, 4, 5, 8, 9, 12, 14, 17, 19, 20, 22, 25, 27, 28, 30, 32]
+    idx2 = [i for i in range(1, dim + 1) if i not in idx1]
+    m = bj.PartitionMask(dim, idx1, idx2)
+    X = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    sv = np.linspace(0.5, 1.5, n1).astype(dt) * np.where(np.arange(n1) % 3 == 0, -1, 1)
+    i0 = [i - 1 for i in idx1]
+    cl = bj.Coupling(lambda x2: bj.Shift(0.25) @ bj.Scale(dev(sv)), m)
+    Y, l = bj.with_logabsdet_jacobian(cl, dev(X), per_sample=True)
+    Y_ref, l_ref = orc.coupling_affine(i0, np.repeat(sv[:, None], N, 1), np.full((n1, N), 0.25, dtype=dt), X)
+    close(host(Y), Y_ref, dt, what="broadcast law")
+    close(host(l), l_ref, dt, scale=n1)
+    Xb, lb = bj.with_logabsdet_jacobian(bj.inverse(cl), Y, per_sample=True)
+    close(host(Xb), X, dt, scale=10)
+    close(host(lb), -l_ref, dt, scale=n1)
+    # θ depends on x₂: scale = exp(0.1 x₂), shift = 2 x₂ (same number of rows here)
+    seen = {}
+
+    def theta(x2):
+        seen["shape"], seen["is_view"] = tuple(x2.shape), x2.untyped_storage().data_ptr() == theta.x.untyped_storage().data_ptr()
+        return bj.Shift(2.0 * x2) @ bj.Scale(torch.exp(0.1 * x2), batched=True)
+
+    cd = bj.Coupling(theta, m)
+    Xd = dev(X)
+    theta.x = Xd
+    Yd, ld = bj.with_logabsdet_jacobian(cd, Xd, per_sample=True)
+    x2 = X[[i - 1 for i in idx2]]
+    Yd_ref, ld_ref = orc.coupling_affine(i0, np.exp(0.1 * x2).astype(dt), (2.0 * x2).astype(dt), X)
+    close(host(Yd), Yd_ref, dt, what="data-dependent law")
+    close(host(ld), ld_ref, dt, scale=n1)
+    assert seen["shape"] == (dim - n1, N) and seen["is_view"] == ranged
