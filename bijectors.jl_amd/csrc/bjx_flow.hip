@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, 
 // Layers are processed in groups of NLMAX; the tile in LDS is updated between groups.
 constexpr int PLANAR_NLMAX = 8;
 constexpr int PLANAR_REG_DEFAULT_COLS = 64;
+constexpr int PLANAR_MFMA_DEFAULT = 0;       // BJX_PLANAR_MFMA: see planar_mfma_kernel (A/B numbers in DESIGN.md)
 
 template <class T>
 __global__ __launch_bounds__(256) void planar_prep2_kernel(const T* w, const T* u_hat, int64_t dim, int nl, T* G, T* wT, T* uT) {
@@ -745,6 +746,159 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
     }
   }
   const bool ok = lane < nvalid;   // nvalid <= COLS
+  if (ok && ladj_ps) ladj_ps[col0 + lane] = (accumulate & 1) ? ladj_ps[col0 + lane] + ladj : ladj;
+  block_publish_partial(ok ? (double)ladj : 0.0, red, fin);
+}
+
+// ------------------------------------------------------------------ Planar, MFMA kernel (Float32, forward, dim % 16 == 0)
+// north_star: "MFMA used only for PlanarLayer's u·Wᵀ contraction".  Both dense steps of a layer group go to the matrix
+// cores with the tile kept in the C/D layout of v_mfma_f32_16x16x4_f32 for its whole life:
+//   lane (n = lane % 16, q = lane / 16) holds, for row block b, the 16-byte pack rows 16b + 4q .. +3 of column n
+//   (16 columns per tile, 4 lanes per column, dim/16 packs per lane).
+//   contraction  S[layer][col] = Σ_rows W[layer][row] Z[row][col]: register r of pack b IS the B operand
+//                B[k = q][n] of the MFMA that contracts the rows {16b + 4q + r} (the order inside a dot product is
+//                free), A = W[layer = lane % 16][16b + 4(lane/16) + r] (8 layers padded to 16): dim/4 MFMAs per tile.
+//   update       Z[16b + m][col] += Σ_k Û[k][16b + m] t[k][col]: the pack is the C/D operand as it stands,
+//                A = Û[4g + lane/16][16b + lane % 16], B = t[col = lane % 16][4g + lane/16]: 2 MFMAs per pack.
+// The per-layer 32-lane butterflies (permlane swap + 4 DPP stages per layer pair) and the 4·NL FMAs per pack of
+// planar_reg_kernel disappear; the NL-step scalar recurrence still runs lane = column on S through 2 KiB of LDS.
+// LOADS: with STAGE = 0 a lane loads its packs directly (64 contiguous bytes per column and instruction, 16 columns
+// per instruction); with STAGE = 1 a tile is loaded with fully coalesced 16-byte accesses and transposed through LDS.
+typedef float mf4 __attribute__((ext_vector_type(4)));
+template <int NB, int TILES, int STAGE>
+__global__ __launch_bounds__(256) void planar_mfma_kernel(const PlanarRegArgs A, const float* __restrict__ x, float* __restrict__ y,
+                                                          float* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate,
+                                                          const BjxFin fin) {
+  constexpr int NL = 8, COLS = 16 * TILES;
+  constexpr int PK = 4 * NB;                        // packs per column
+  constexpr int PITCH = 4 * PK + 4;                 // floats per staged column (+1 pack: conflict-free column walk)
+  __shared__ __attribute__((aligned(16))) float st_all[4][COLS * NL];
+  __shared__ __attribute__((aligned(16))) float stage_all[STAGE ? 4 : 1][STAGE ? 16 * PITCH : 4];
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* st = st_all[wave];
+  float* sg = stage_all[STAGE ? wave : 0];
+  const int n = lane & 15, q = lane >> 4;
+  const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * COLS;
+  const int64_t left = batch - col0;
+  const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
+
+  mf4 z[TILES][NB];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    if constexpr (STAGE == 0) {
+      const bool ok = t * 16 + n < nvalid;
+      const float* px = x + (col0 + t * 16 + n) * dim + 4 * q;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        z[t][b] = ok ? __builtin_nontemporal_load(reinterpret_cast<const mf4*>(px + 16 * b)) : mf4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      // coalesced: the tile's 16 columns are one contiguous run of 16*PK packs
+      const float* px = x + (col0 + t * 16) * dim;
+      mf4 tmp[PK / 4];
+#pragma unroll
+      for (int it = 0; it < PK / 4; ++it) {
+        const int p = it * 64 + lane, c = p / PK;
+        tmp[it] = (t * 16 + c < nvalid) ? __builtin_nontemporal_load(reinterpret_cast<const mf4*>(px) + p) : mf4{0.f, 0.f, 0.f, 0.f};
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < PK / 4; ++it) {
+        const int p = it * 64 + lane, c = p / PK, k = p - c * PK;
+        *reinterpret_cast<mf4*>(sg + c * PITCH + 4 * k) = tmp[it];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int b = 0; b < NB; ++b) z[t][b] = *reinterpret_cast<const mf4*>(sg + n * PITCH + 4 * (4 * b + q));
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  float ladj = 0.f;
+  const int ngroups = A.nl_pad / NL;
+  for (int gi = 0; gi < ngroups; ++gi) {
+    const int l0 = gi * NL;
+    // A operands of the group: W rows (layer = n < 8, else 0) and the Û rows of the update
+    float wa[NB][4], ua[NB][2];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      mf4 wv = mf4{0.f, 0.f, 0.f, 0.f};
+      if (n < NL) wv = *reinterpret_cast<const mf4*>(A.w + (int64_t)(l0 + n) * dim + 16 * b + 4 * q);
+      wa[b][0] = wv.x; wa[b][1] = wv.y; wa[b][2] = wv.z; wa[b][3] = wv.w;
+      ua[b][0] = A.u_hat[(int64_t)(l0 + q) * dim + 16 * b + n];
+      ua[b][1] = A.u_hat[(int64_t)(l0 + 4 + q) * dim + 16 * b + n];
+    }
+    // ---- contraction: S[4q + r][column n] in acc[r]; layers 0..7 live in q = 0, 1
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      mf4 acc = mf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[b][0], z[t][b].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[b][1], z[t][b].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[b][2], z[t][b].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[b][3], z[t][b].w, acc, 0, 0, 0);
+      }
+      if (q < 2) *reinterpret_cast<mf4*>(st + (t * 16 + n) * NL + 4 * q) = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- scalar recurrence, one sample per lane (same algebra as planar_reg_kernel)
+    if (COLS == 64 || lane < COLS) {
+      float s[NL], tt[NL];
+#pragma unroll
+      for (int k = 0; k < NL; ++k) { s[k] = st[lane * NL + k]; tt[k] = 0.f; }
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const float* Gk = A.G + (int64_t)(l0 + k) * A.nl_pad + l0;
+        float a = s[k];
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+          if (j < k) a += Gk[j] * tt[j];
+        float th, ld;
+        planar_act(a + A.b[l0 + k], A.wtu_hat[l0 + k], th, ld);
+        ladj += ld;
+        tt[k] = th;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < NL; ++k) st[lane * NL + k] = tt[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- rank-8 update on the matrix cores: the pack is the accumulator
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const float t0 = st[(t * 16 + n) * NL + q], t1 = st[(t * 16 + n) * NL + 4 + q];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        z[t][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[b][0], t0, z[t][b], 0, 0, 0);
+        z[t][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[b][1], t1, z[t][b], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (y) {
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      if constexpr (STAGE == 0) {
+        const bool ok = t * 16 + n < nvalid;
+        float* py = y + (col0 + t * 16 + n) * dim + 4 * q;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          if (ok) __builtin_nontemporal_store(z[t][b], reinterpret_cast<mf4*>(py + 16 * b));
+      } else {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) *reinterpret_cast<mf4*>(sg + n * PITCH + 4 * (4 * b + q)) = z[t][b];
+        __builtin_amdgcn_wave_barrier();
+        float* py = y + (col0 + t * 16) * dim;
+#pragma unroll
+        for (int it = 0; it < PK / 4; ++it) {
+          const int p = it * 64 + lane, c = p / PK, k = p - c * PK;
+          if (t * 16 + c < nvalid) __builtin_nontemporal_store(*reinterpret_cast<const mf4*>(sg + c * PITCH + 4 * k), reinterpret_cast<mf4*>(py) + p);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  const bool ok = lane < nvalid;
   if (ok && ladj_ps) ladj_ps[col0 + lane] = (accumulate & 1) ? ladj_ps[col0 + lane] + ladj : ladj;
   block_publish_partial(ok ? (double)ladj : 0.0, red, fin);
 }
@@ -1377,6 +1531,28 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
 #define LAUNCH_REG_G(INV_) switch (G) { case 8: LAUNCH_REG_NL(8, INV_) break; case 16: LAUNCH_REG_NL(16, INV_) break; default: LAUNCH_REG_NL(32, INV_) break; }
 #define LAUNCH_REG2(NL_, INV_) hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
 #define LAUNCH_REG2_NL(INV_) switch (NL) { case 1: LAUNCH_REG2(1, INV_); break; case 2: LAUNCH_REG2(2, INV_); break; case 4: LAUNCH_REG2(4, INV_); break; default: LAUNCH_REG2(8, INV_); break; }
+        // matrix-core kernel (forward, groups of 8 layers, dim a multiple of 16, no fused base density):
+        // BJX_PLANAR_MFMA = 0 off | 1 direct loads, 64 columns per wave | 2 LDS-staged, 64 | 3 direct, 32 | 4 staged, 32 | 5 direct, 16 | 6 staged, 16
+        static const int mfma_env = getenv("BJX_PLANAR_MFMA") ? atoi(getenv("BJX_PLANAR_MFMA")) : PLANAR_MFMA_DEFAULT;
+        if (mfma_env && !inverse && NL == 8 && dim % 16 == 0 && dim >= 32 && !(flags & BJX_BASE_STDNORMAL)) {
+          const int tiles = mfma_env >= 5 ? 1 : (mfma_env >= 3 ? 2 : 4), stage = (mfma_env % 2 == 0) ? 1 : 0;
+          const int64_t gridm = (batch + 4 * 16 * tiles - 1) / (4 * 16 * tiles);
+          BJX_REQUIRE(ctx, gridm < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar: batch too large for one launch");
+          BjxFin finm;
+          bool secondm = false;
+          { int rc = bjx_make_fin(ctx, gridm, ladj_sum, 0.0, 0, flags, &finm, &secondm); if (rc) return rc; }
+#define LAUNCH_MF(NB_, T_, S_) hipLaunchKernelGGL((planar_mfma_kernel<NB_, T_, S_>), dim3((unsigned)gridm), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, finm)
+#define LAUNCH_MF_TS(NB_) do { if (tiles == 4) { if (stage) LAUNCH_MF(NB_, 4, 1); else LAUNCH_MF(NB_, 4, 0); } else if (tiles == 2) { if (stage) LAUNCH_MF(NB_, 2, 1); else LAUNCH_MF(NB_, 2, 0); } \
+                                else { if (stage) LAUNCH_MF(NB_, 1, 1); else LAUNCH_MF(NB_, 1, 0); } } while (0)
+          { BjxProf prof_(ctx);
+            switch (dim / 16) { case 2: LAUNCH_MF_TS(2); break; case 3: LAUNCH_MF_TS(3); break; case 4: LAUNCH_MF_TS(4); break; case 5: LAUNCH_MF_TS(5); break;
+                                case 6: LAUNCH_MF_TS(6); break; case 7: LAUNCH_MF_TS(7); break; default: LAUNCH_MF_TS(8); break; } }
+#undef LAUNCH_MF_TS
+#undef LAUNCH_MF
+          BJX_CHECK_LAUNCH(ctx);
+          if (secondm) return bjx_launch_finalize(ctx, (int)gridm, ladj_sum, 0.0, 0, 0.0, flags);
+          return BJX_OK;
+        }
         { BjxProf prof_(ctx);
           if (split) { if (inverse) { LAUNCH_REG2_NL(true) } else { LAUNCH_REG2_NL(false) } }
           else if (inverse) { LAUNCH_REG_G(true) } else { LAUNCH_REG_G(false) } }

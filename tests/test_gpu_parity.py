@@ -2328,3 +2328,40 @@ def test_coupling_broadcast_parameters_and_data_dependent_theta(bj, orc, dt, ran
     close(host(Yd), Yd_ref, dt, what="data-dependent law")
     close(host(ld), ld_ref, dt, scale=n1)
     assert seen["shape"] == (dim - n1, N) and seen["is_view"] == ranged
+
+
+def test_planar_mfma_kernel_matches_the_register_kernel(bj, monkeypatch):
+    """planar_mfma_kernel (north_star's matrix-core form of the Planar contraction + rank-8 update) on every geometry it
+    takes — direct / LDS-staged loads x 64 / 32 / 16 columns per wave, dim = 32 ... 128 in steps of 16, 8 / 16 / 11 layers,
+    ragged batches — through BJX_PLANAR_MFMA in a subprocess (the switch is read once per process), compared with the
+    default register kernel of this process."""
+    import subprocess, sys, os, json
+    code = r"""
+import json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+import bijectors_amd as bj
+r = np.random.default_rng(7)
+out = {}
+for dim, nl, N in ((128, 8, 333), (128, 16, 64), (96, 8, 1000), (64, 11, 257), (48, 8, 17), (32, 8, 4099), (112, 8, 130), (80, 24, 65)):
+    w = torch.tensor((r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(np.float32))
+    u = torch.tensor((r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(np.float32))
+    b = torch.tensor(r.normal(size=nl).astype(np.float32))
+    z = torch.tensor(np.asfortranarray(r.normal(size=(dim, N)).astype(np.float32)).T.copy()).T.cuda()
+    fl = bj.PlanarLayer(w, u, b)
+    y, l = bj.with_logabsdet_jacobian(fl, z)
+    _, _, ls = bj.shard.with_logabsdet_jacobian_sharded(fl, z)
+    out[f"{dim},{nl},{N}"] = [y.cpu().T.numpy().tolist(), l.cpu().numpy().tolist(), float(ls)]
+print(json.dumps(out))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("0", "1", "2", "3", "4", "5", "6"):
+        env = dict(os.environ, BJX_PLANAR_MFMA=flag)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[flag] = json.loads(p.stdout.strip().splitlines()[-1])
+    for flag in ("1", "2", "3", "4", "5", "6"):
+        for key, a in res["0"].items():
+            b_ = res[flag][key]
+            np.testing.assert_allclose(np.asarray(b_[0]), np.asarray(a[0]), rtol=1e-4, atol=2e-5, err_msg=f"MFMA={flag} {key} values")
+            np.testing.assert_allclose(np.asarray(b_[1]), np.asarray(a[1]), rtol=1e-4, atol=2e-5, err_msg=f"MFMA={flag} {key} log-det")
+            assert abs(b_[2] - a[2]) <= 1e-5 * abs(a[2]) + 1e-4, (flag, key)
