@@ -6,24 +6,12 @@
 //   PDVecBijector    pd.jl:38-60       X[K,K]                    <-> y[K(K+1)/2]
 // and Scale with a MATRIX parameter (scale.jl:14,17,35-36): y = a*x, x = a\y, logabsdetjac = logabsdet(a).
 //
-// Mapping on gfx950 (matrix_link_kernel): ONE WAVE = ONE SAMPLE, lane i = row i of the lower Cholesky factor L kept
-// in REGISTERS (a[0..KP), fully unrolled, so every register index is a compile-time constant).
-//   load     the K*K (or packed) input of the sample with coalesced 16-byte loads into an odd-pitch LDS tile;
-//            lane i picks its row of the triangle the reference reads (cholesky(Hermitian(X)) reads the UPPER triangle,
-//            cholesky(Hermitian(X, :L)) the LOWER one: src/utils.jl:37,50)
-//   factor   right-looking: for column k: d = sqrt(A[k,k]) comes from lane k by v_readlane (a wave-uniform SGPR
-//            operand), the column is scaled, and for every later column j the multiplier L[j,k] is one more
-//            v_readlane of lane j's register k feeding one FMA: K^2/2 (readlane + FMA) per sample, no LDS traffic and
-//            no divergent lanes in the O(K^3) part.  The factor U = L' of the correlation kinds has COLUMN j in lane j.
-//   link     in-lane: the LKJ link walks a column of U top to bottom / bottom to top (corr.jl:277-297, :314-335,
-//            :345-399), which is a loop over the registers of ONE lane; log-det terms are lane sums + one wave reduction
-//   inverse  X = U'U = L L' (pd_from_upper / pd_from_lower, src/utils.jl:17-24): X[i,j] = sum_m L[i,m] L[j,m] with the
-//            rows of L exact zeros past the diagonal, again K^2/2 (readlane + FMA)
-//   store    through the same LDS tile into coalesced stores
+// Mapping on gfx950 (matrix_link_kernel, documented at the kernel): GS = 16 / 32 / 64 lanes own one sample, lane i keeps
+// row i of the lower Cholesky factor in registers, the pivot column / the rows of L travel as broadcast 16-byte LDS reads,
+// the LKJ link is a per-lane loop over one LDS row, loads and stores are coalesced through the same LDS tile.
 // Algorithmic bytes per sample: K*K*sizeof(T) on the matrix side (the reference materialises dense matrices) +
-// the packed / dense unconstrained side + 4 for the per-sample log-det.  The factorisation is O(K^3/3) flop on
-// O(K^2) bytes (K/12 flop per byte in Float32): HBM-bound on paper, but the readlane + FMA pair issues 2 wave
-// instructions per 64 useful FMA lanes only in the last columns, so the kernel is VALU-issue-bound.
+// the packed / dense unconstrained side + sizeof(T) for the per-sample log-det.  The factorisation is O(K^3/3) flop on
+// O(K^2) bytes (K/12 flop per byte in Float32): HBM-bound on paper, VALU/LDS-issue-bound in practice.
 #include "bjx_internal.h"
 
 using namespace bjx;
@@ -145,71 +133,140 @@ template <class T, int LAY> __device__ __forceinline__ void stage_out(T* __restr
   }
 }
 
-// One wave per sample; block = 1 wave; the grid walks the batch.  KP = register rows (K <= KP).
-template <class T, int KP, int KIND, bool INV>
+// 16-byte LDS read of 4 consecutive T (two 16-byte reads for Float64)
+template <class T> struct Quad { T v[4]; };
+template <class T> __device__ __forceinline__ Quad<T> lds_quad(const T* p) {
+  Quad<T> r;
+  if constexpr (sizeof(T) == 4) {
+    const bjx_f32x4 t = *reinterpret_cast<const bjx_f32x4*>(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else {
+    const bjx_f64x2 t0 = *reinterpret_cast<const bjx_f64x2*>(p), t1 = *reinterpret_cast<const bjx_f64x2*>(p + 2);
+    r.v[0] = t0.x; r.v[1] = t0.y; r.v[2] = t1.x; r.v[3] = t1.y;
+  }
+  return r;
+}
+// two consecutive elements as one operand: Float32 pairs become v_pk_fma_f32 (both halves of an aligned register pair),
+// Float64 pairs are two v_fma_f64.  (SLP vectorisation is off for this file: it builds such pairs out of unrelated
+// registers and pays for them with v_mov — 600 of them in the K = 64 kernel.)
+template <class T> struct V2 { typedef T t __attribute__((ext_vector_type(2))); };
+template <class T> struct QuadP { typename V2<T>::t lo, hi; };
+template <class T> __device__ __forceinline__ QuadP<T> lds_quadp(const T* p) {
+  QuadP<T> r;
+  if constexpr (sizeof(T) == 4) {
+    const bjx_f32x4 t = *reinterpret_cast<const bjx_f32x4*>(p);
+    r.lo = __builtin_shufflevector(t, t, 0, 1);
+    r.hi = __builtin_shufflevector(t, t, 2, 3);
+  } else {
+    r.lo = *reinterpret_cast<const bjx_f64x2*>(p);
+    r.hi = *reinterpret_cast<const bjx_f64x2*>(p + 2);
+  }
+  return r;
+}
+template <class T> struct FacMath;                  // 1/d, 1/sqrt(d), sqrt(d) of a pivot: hardware units in Float32 (parity bar 1e-3)
+template <> struct FacMath<float> {
+  static __device__ __forceinline__ void pivot(float d, float& rd, float& rs, float& sq) { rs = Fast<float>::rsqrt(d); rd = rs * rs; sq = d * rs; }
+};
+template <> struct FacMath<double> {
+  static __device__ __forceinline__ void pivot(double d, double& rd, double& rs, double& sq) { sq = ::sqrt(d); rs = 1.0 / sq; rd = 1.0 / d; }
+};
+
+// GS = 8 / 16 / 32 / 64 lanes = one sample (K <= GS), 64/GS samples per wave; block = 1 wave; the grid walks the batch.
+//   lane (g = lane / GS, i = lane % GS) keeps row i of the lower factor L of sample g in REGISTERS (a[0..GS), fully
+//   unrolled: every register index is a compile-time constant); the sample's matrix is staged in an LDS tile
+//   tile[c*pitch + r] = M[r, c] (pitch a multiple of 4: rows of the tile are 16-byte aligned).
+//   factor (forward): right-looking.  Step k: every lane writes its A[i][k] to a K-entry column buffer; the pivot and
+//     the multipliers A[j][k] come back as WAVE-UNIFORM-PER-SAMPLE (broadcast) 16-byte LDS reads, four multipliers per
+//     read: K^2/8 LDS reads + K^2/2 FMAs per sample (a[j] -= (A[i][k]/d) * A[j][k]), pivot math on the hardware units.
+//     (v1 of this kernel fetched every multiplier with v_readlane: one sample per wave, 2 issue slots + hazard nops per
+//     FMA, lanes >= K idle: 10 % of the HBM roofline at K = 32.)
+//   link: rolled per-lane loops over the lane's tile row (column of U = L'), corr.jl:277-297, :314-335, :345-399.
+//   X = L L' (inverse): row j of L is read from the tile with broadcast 16-byte reads, dotted with the lane's registers.
+template <class T, int GS, int KIND, bool INV>
 __global__ __launch_bounds__(64) void matrix_link_kernel(const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps, int K0, int pitch,
                                                          int64_t batch, int accumulate, int vec_in, int vec_out, double* partials) {
   extern __shared__ __align__(16) unsigned char smem_[];
-  T* tile = reinterpret_cast<T*>(smem_);
   __shared__ double red[1];
   using M = LinkMath<T>;
+  constexpr int KP = GS, NSW = 64 / GS;
   constexpr bool CORR = KIND == MK_VEC_CORR || KIND == MK_CORR;
   constexpr int LAY = KIND == MK_VEC_CORR ? L_TRIU1 : (KIND == MK_PD_VEC ? L_TRIU : L_DENSE);   // layout of the unconstrained side
   const int lane0 = threadIdx.x;
   int K = K0;
   const int KK = K * K;
   const int nv = KIND == MK_VEC_CORR ? K * (K - 1) / 2 : (KIND == MK_PD_VEC ? K * (K + 1) / 2 : KK);   // elements on the unconstrained side
+  const int tile_words = GS * pitch;                              // GS rows: the unrolled loops touch rows >= K as scratch
+  const int sample_words = tile_words + GS + 4;                  // tile + column buffer (kept 16-byte aligned)
+  T* lds = reinterpret_cast<T*>(smem_);
   double acc = 0.0;
-  for (int64_t s = blockIdx.x; s < batch; s += gridDim.x) {
+  for (int64_t s0 = (int64_t)blockIdx.x * NSW; s0 < batch; s0 += (int64_t)gridDim.x * NSW) {
     // The lane id and K are made opaque at every phase: the several hundred compare masks of the unrolled code below
     // (lane == k, j < K, ...) are loop-invariant; left alone they are all hoisted out of the sample loop / kept alive
     // across phases and spilled (measured: 670 SGPR spills + the register row in scratch).
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     asm volatile("" : "+s"(K));
-    const bool live = lane < K;
-    T* myrow = tile + (live ? lane : 0) * pitch;      // tile row `lane`: column `lane` of an upper-triangular matrix
-    T a[KP];                                  // row `lane` of the lower factor L (= column `lane` of U = L')
-    T lsum = T(0);                            // this lane's log-det terms
+    const int g = lane / GS;
+    int li = lane - g * GS;                                      // row of my sample
+    const int nsamp = (batch - s0) < NSW ? (int)(batch - s0) : NSW;
+    const bool live = li < K && g < nsamp;
+    T* tile = lds + g * sample_words;
+    T* colbuf = tile + tile_words;
+    T* myrow = tile + (li < K ? li : 0) * pitch;                 // tile row li: column li of an upper-triangular matrix
+    typename V2<T>::t a2[KP / 2];                                // row li of the lower factor L (= column li of U = L'), as register pairs
+#define a(j_) a2[(j_) >> 1][(j_) & 1]
+    T lsum = T(0);                                               // this lane's log-det terms
     if constexpr (!INV) {
       // ---------------------------------------------------------------- X -> Cholesky -> link
-      stage_in<T, L_DENSE>(in + s * KK, tile, KK, K, pitch, lane, vec_in != 0);
+#pragma unroll
+      for (int gg = 0; gg < NSW; ++gg)
+        if (gg < nsamp) stage_in<T, L_DENSE>(in + (s0 + gg) * KK, lds + gg * sample_words, KK, K, pitch, lane, vec_in != 0);
       __builtin_amdgcn_wave_barrier();
       // A[i][j], j <= i, from the triangle the reference reads; identity padding outside K
 #pragma unroll
       for (int j = 0; j < KP; ++j) {
-        T v = j == lane ? T(1) : T(0);
-        if (j < K && live) v = CORR ? myrow[j] : tile[j * pitch + lane];   // X[j,i] (upper) | X[i,j] (lower)
-        a[j] = v;
+        T v = j == li ? T(1) : T(0);
+        if (j < K && live) v = CORR ? myrow[j] : tile[j * pitch + li];   // X[j,i] (upper) | X[i,j] (lower)
+        a(j) = v;
       }
       __builtin_amdgcn_wave_barrier();
-      // right-looking Cholesky in registers
-      asm volatile("" : "+v"(lane));
+      // right-looking Cholesky: row in registers, column k through the LDS column buffer
+      asm volatile("" : "+v"(li));
       asm volatile("" : "+s"(K));
+      // STRAIGHT-LINE code over all GS columns (the identity padding makes the steps k >= K no-ops): uniform `k < K`
+      // guards turn every a(j) into a PHI across ~100 basic blocks and the register coalescer gives up — the GS = 32
+      // kernel carried 2 250 register-to-register moves and 210 VGPRs with them
 #pragma unroll
       for (int k = 0; k < KP; ++k) {
-        if (k < K) {
-          const T d = d_sqrt(rdlane(a[k], k));
-          const T inv = T(1) / d;
-          a[k] = lane == k ? d : a[k] * inv;
+        colbuf[li] = a(k);
+        __builtin_amdgcn_wave_barrier();
+        T rd, rs, sq;
+        FacMath<T>::pivot(colbuf[k], rd, rs, sq);
+        const T c = a(k) * rd;                                   // A[i][k] / d: a(j) -= c * A[j][k]
 #pragma unroll
-          for (int j = k + 1; j < KP; ++j) a[j] -= a[k] * rdlane(a[k], j);
+        for (int j4 = (k + 1) & ~3; j4 < KP; j4 += 4) {
+          const QuadP<T> m = lds_quadp<T>(colbuf + j4);
+          // pairs entirely right of column k are updated as pairs; the pair that contains column k only in its odd half
+          if (j4 > k) a2[j4 >> 1] -= c * m.lo; else if (j4 + 1 > k) a(j4 + 1) -= c * m.lo[1];
+          if (j4 + 2 > k) a2[(j4 >> 1) + 1] -= c * m.hi; else if (j4 + 3 > k) a(j4 + 3) -= c * m.hi[1];
         }
+        a(k) = li == k ? sq : a(k) * rs;
+        __builtin_amdgcn_wave_barrier();
       }
-      asm volatile("" : "+v"(lane));
+      asm volatile("" : "+v"(li));
       asm volatile("" : "+s"(K));
       if constexpr (CORR) {
-        // column `lane` of U = my registers -> my tile row; then corr.jl:277-297 / :314-335 walks it bottom-up (a rolled
+        // column li of U = my registers -> my tile row; then corr.jl:277-297 / :314-335 walks it bottom-up (a rolled
         // loop over LDS: the per-entry asinh is too large to unroll 64 times); y overwrites w in place.
         // log-det = -_logabsdetjac_inv_corr(y) (:92, :135-137, :453-472): weight K - i + 1 for 1-based row i.
 #pragma unroll
         for (int j = 0; j < KP; ++j)
-          if (j < K && live) myrow[j] = a[j];
+          if (j < K && live) myrow[j] = a(j);
         __builtin_amdgcn_wave_barrier();
-        const T dg = live ? myrow[lane] : T(1);
+        const T dg = live ? myrow[li] : T(1);
         T rem = dg * dg;
         for (int i = K - 2; i >= 0; --i) {
-          const bool act = i < lane && live;
+          const bool act = i < li && live;
           const T w = act ? myrow[i] : T(0);
           T y, lc;
           if (KIND == MK_VEC_CORR && i == 0) M::atanh_lc(w, y, lc);                        // :322 atanh(W[1, j])
@@ -221,37 +278,43 @@ __global__ __launch_bounds__(64) void matrix_link_kernel(const T* __restrict__ i
           }
         }
         if (KIND == MK_CORR) {                                                             // zero fill on and below the diagonal (:292-294)
-          for (int i = live ? lane : K; i < K; ++i) myrow[i] = T(0);
+          for (int i = live ? li : K; i < K; ++i) myrow[i] = T(0);
         }
       } else {
         // pd.jl:11,27-31,41: Y = replace_diag(log, L); log-det = -(sum_i (d+2-i) log L_ii + d log 2)
         T dg = T(1);
 #pragma unroll
-        for (int j = 0; j < KP; ++j) dg = j == lane ? a[j] : dg;
+        for (int j = 0; j < KP; ++j) dg = j == li ? a(j) : dg;
         const T ld = M::log(dg);
-        if (live) lsum = -(T(K + 1 - lane) * ld + Num<T>::log2);
+        if (live) lsum = -(T(K + 1 - li) * ld + Num<T>::log2);
 #pragma unroll
         for (int j = 0; j < KP; ++j) {
           if (j < K && live) {
-            const T v = j == lane ? ld : (j < lane ? a[j] : T(0));
-            if (KIND == MK_PD) tile[j * pitch + lane] = v;                                 // Y[lane, j]
-            else if (j <= lane) myrow[j] = v;                                              // triu_to_vec(Y'): (Y')[r,c] = L[c,r], r <= c
+            const T v = j == li ? ld : (j < li ? a(j) : T(0));
+            if (KIND == MK_PD) tile[j * pitch + li] = v;                                   // Y[li, j]
+            else if (j <= li) myrow[j] = v;                                                // triu_to_vec(Y'): (Y')[r,c] = L[c,r], r <= c
           }
         }
       }
       __builtin_amdgcn_wave_barrier();
-      if (out) stage_out<T, LAY>(out + s * nv, tile, nv, K, pitch, lane, vec_out != 0);
+      if (out) {
+#pragma unroll
+        for (int gg = 0; gg < NSW; ++gg)
+          if (gg < nsamp) stage_out<T, LAY>(out + (s0 + gg) * nv, lds + gg * sample_words, nv, K, pitch, lane, vec_out != 0);
+      }
       __builtin_amdgcn_wave_barrier();
     } else {
       // ---------------------------------------------------------------- inverse link -> L -> X = L L'
-      stage_in<T, LAY>(in + s * nv, tile, nv, K, pitch, lane, vec_in != 0);
+#pragma unroll
+      for (int gg = 0; gg < NSW; ++gg)
+        if (gg < nsamp) stage_in<T, LAY>(in + (s0 + gg) * nv, lds + gg * sample_words, nv, K, pitch, lane, vec_in != 0);
       __builtin_amdgcn_wave_barrier();
       if constexpr (CORR) {
-        // corr.jl:345-399: column `lane` of U top-down (rolled, in place in my tile row);
+        // corr.jl:345-399: column li of U top-down (rolled, in place in my tile row);
         // + sum_{j=2}^{K-1} (K-j) log U[j,j] (:77-79, :144-146), log U[j,j] = the final log_remainder of column j
         T lr = T(0);
         for (int i = 0; i < K - 1; ++i) {
-          const bool act = i < lane && live;
+          const bool act = i < li && live;
           const T yv = act ? myrow[i] : T(0);
           T z, lc;
           M::tanh_lc(yv, z, lc);
@@ -259,73 +322,88 @@ __global__ __launch_bounds__(64) void matrix_link_kernel(const T* __restrict__ i
           if (act) { myrow[i] = z * e; lr -= lc; lsum += lr; }
         }
         if (live) {
-          myrow[lane] = M::exp(lr);
-          lsum += lr + ((lane >= 1 && lane <= K - 2) ? T(K - 1 - lane) * lr : T(0));
+          myrow[li] = M::exp(lr);
+          lsum += lr + ((li >= 1 && li <= K - 2) ? T(K - 1 - li) * lr : T(0));
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < KP; ++j) {
-          T v = j == lane ? T(1) : T(0);
-          if (j < K && live) v = j <= lane ? myrow[j] : T(0);
-          a[j] = v;
+          T v = j == li ? T(1) : T(0);
+          if (j < K && live) v = j <= li ? myrow[j] : T(0);
+          a(j) = v;
         }
       } else {
         // pd.jl:13-16,44-47: L = lower_triangular(replace_diag(exp, Y)); log-det = +(sum_i (d+2-i) Y_ii + d log 2) (interface.jl:278-281)
         T yd = T(0);
 #pragma unroll
         for (int j = 0; j < KP; ++j) {
-          T v = j == lane ? T(1) : T(0);
+          T v = j == li ? T(1) : T(0);
           if (j < K && live) {
-            const T t = (j <= lane) ? (KIND == MK_PD ? tile[j * pitch + lane] : myrow[j]) : T(0);
-            if (j == lane) { yd = t; v = M::exp(t); } else v = t;
+            const T t = (j <= li) ? (KIND == MK_PD ? tile[j * pitch + li] : myrow[j]) : T(0);
+            if (j == li) { yd = t; v = M::exp(t); } else v = t;
           }
-          a[j] = v;
+          a(j) = v;
         }
-        if (live) lsum = T(K + 1 - lane) * yd + Num<T>::log2;
+        if (live) lsum = T(K + 1 - li) * yd + Num<T>::log2;
       }
       __builtin_amdgcn_wave_barrier();
-      // X[lane][j] = sum_{m <= j} L[lane][m] * L[j][m]   (rows are exact zeros past the diagonal)
-      asm volatile("" : "+v"(lane));
+      asm volatile("" : "+v"(li));
       asm volatile("" : "+s"(K));
       if (out) {
+        // every lane's row of L into its tile row (the diagonal already exponentiated), rows are then read back as
+        // broadcast 16-byte packs:  X[li][j] = sum_{m <= j} L[li][m] * L[j][m]  (my row has exact zeros past its diagonal)
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+          if (j < K && live) myrow[j] = a(j);
+        __builtin_amdgcn_wave_barrier();
+        // straight-line over all GS rows like the factorisation (the tile has GS rows; rows >= K are never staged out)
 #pragma unroll
         for (int j = 0; j < KP; ++j) {
-          if (j < K) {
-            T x = T(0);
+          typename V2<T>::t x2 = {T(0), T(0)}, x3 = {T(0), T(0)};     // two chains: back-to-back dependent v_pk_fma_f32 cost a wait state each
+          T x = T(0);
 #pragma unroll
-            for (int m = 0; m <= j; ++m) {
-              x += a[m] * rdlane(a[m], j);
-              if ((m & 7) == 7) __builtin_amdgcn_sched_barrier(0);       // keep each readlane next to its FMA (64 hoisted Float64 readlanes = 128 SGPRs: spills)
-            }
-            if (lane < K) tile[j * pitch + lane] = x;
+          for (int m4 = 0; m4 <= j; m4 += 4) {
+            const QuadP<T> r4 = lds_quadp<T>(tile + j * pitch + m4);
+            if (m4 + 1 <= j) x2 += a2[m4 >> 1] * r4.lo; else x += a(m4) * r4.lo[0];
+            if (m4 + 3 <= j) x3 += a2[(m4 >> 1) + 1] * r4.hi; else if (m4 + 2 <= j) x += a(m4 + 2) * r4.hi[0];
           }
+          x2 += x3;
+          x += x2[0] + x2[1];
+          __builtin_amdgcn_wave_barrier();                       // every lane has read row j: it is dead now and takes column j of X
+          if (live) tile[j * pitch + li] = x;                     // (rows j >= K of the GS-row tile are scratch)
         }
         __builtin_amdgcn_wave_barrier();
-        stage_out<T, L_DENSE>(out + s * KK, tile, KK, K, pitch, lane, vec_out != 0);
+#pragma unroll
+        for (int gg = 0; gg < NSW; ++gg)
+          if (gg < nsamp) stage_out<T, L_DENSE>(out + (s0 + gg) * KK, lds + gg * sample_words, KK, K, pitch, lane, vec_out != 0);
         __builtin_amdgcn_wave_barrier();
       }
     }
     if (ladj_ps || partials) {
-      const double l = group_sum<64>((double)lsum);
-      if (lane == 0) {
+      // sum over the GS lanes of each sample (xor butterflies stay inside an aligned group of GS lanes)
+      double l = (double)lsum;
+#pragma unroll
+      for (int off = 1; off < GS; off <<= 1) l += shfl_xor(l, off);
+      if (li == 0 && g < nsamp) {
         const T lt = (T)l;
-        if (ladj_ps) ladj_ps[s] = accumulate ? ladj_ps[s] + lt : lt;
+        if (ladj_ps) ladj_ps[s0 + g] = accumulate ? ladj_ps[s0 + g] + lt : lt;
         acc += (double)lt;
       }
     }
   }
   if (partials) block_publish_partial(acc, red, partials);
 }
+#undef a
 
-template <class T, int KP, int KIND>
-int launch_kp(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* partials, int K, int pitch, int64_t batch, int accum, int vin, int vout,
+template <class T, int GS, int KIND>
+int launch_gs(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* partials, int K, int pitch, int64_t batch, int accum, int vin, int vout,
               int grid, size_t smem) {
   if (inverse) {
-    bjx_allow_big_lds(matrix_link_kernel<T, KP, KIND, true>, smem);
-    hipLaunchKernelGGL((matrix_link_kernel<T, KP, KIND, true>), dim3(grid), dim3(64), smem, ctx->stream, in, out, ladj_ps, K, pitch, batch, accum, vin, vout, partials);
+    bjx_allow_big_lds(matrix_link_kernel<T, GS, KIND, true>, smem);
+    hipLaunchKernelGGL((matrix_link_kernel<T, GS, KIND, true>), dim3(grid), dim3(64), smem, ctx->stream, in, out, ladj_ps, K, pitch, batch, accum, vin, vout, partials);
   } else {
-    bjx_allow_big_lds(matrix_link_kernel<T, KP, KIND, false>, smem);
-    hipLaunchKernelGGL((matrix_link_kernel<T, KP, KIND, false>), dim3(grid), dim3(64), smem, ctx->stream, in, out, ladj_ps, K, pitch, batch, accum, vin, vout, partials);
+    bjx_allow_big_lds(matrix_link_kernel<T, GS, KIND, false>, smem);
+    hipLaunchKernelGGL((matrix_link_kernel<T, GS, KIND, false>), dim3(grid), dim3(64), smem, ctx->stream, in, out, ladj_ps, K, pitch, batch, accum, vin, vout, partials);
   }
   return 0;
 }
@@ -340,25 +418,26 @@ int matrix_impl(bjx_ctx* ctx, const char* who, int inverse, const T* in, T* out,
   constexpr int VW = Vec16<T>::N;
   const int64_t KK = K * K;
   const int64_t nv = KIND == MK_VEC_CORR ? K * (K - 1) / 2 : (KIND == MK_PD_VEC ? K * (K + 1) / 2 : KK);
-  const int pitch = (int)((K & 1) ? K : K + 1);                  // odd: lane i at tile[i*pitch + j] hits 64 distinct banks
-  int64_t words = (int64_t)K * pitch;
-  if (words < nv) words = nv;
-  words = (words + VW + 3) / 4 * 4;
-  const size_t smem = (size_t)words * sizeof(T);
+  const int gs = K <= 8 ? 8 : (K <= 16 ? 16 : (K <= 32 ? 32 : 64));
+  const int nsw = 64 / gs;
+  const int pitch = (int)((K + 3) / 4 * 4 + 4);                  // multiple of 4 (16-byte rows), + 4: consecutive rows start 4 banks apart
+  const int64_t sample_words = (int64_t)gs * pitch + gs + 4;
+  const size_t smem = (size_t)(nsw * sample_words) * sizeof(T);
   const int64_t in_n = inverse ? nv : KK, out_n = inverse ? KK : nv;
-  const int vin = bjx_aligned16(in) && in_n % VW == 0 && K >= VW;
-  const int vout = out && bjx_aligned16(out) && out_n % VW == 0 && K >= VW;
+  const int vin = bjx_aligned16(in) && in_n % VW == 0;
+  const int vout = out && bjx_aligned16(out) && out_n % VW == 0;
+  const int64_t groups = (batch + nsw - 1) / nsw;
   const int64_t cap = (int64_t)ctx->num_cu * 16;
-  const int grid = (int)(batch < cap ? batch : cap);
+  const int grid = (int)(groups < cap ? groups : cap);
   if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
   double* partials = ladj_sum ? ctx->partials : nullptr;
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
   {
     BjxProf prof_(ctx);
-#define BJX_MK(KP_) launch_kp<T, KP_, KIND>(ctx, inverse, in, out, ladj_ps, partials, (int)K, pitch, batch, accum, vin, vout, grid, smem)
-    if (K <= 8) BJX_MK(8);
-    else if (K <= 16) BJX_MK(16);
-    else if (K <= 32) BJX_MK(32);
+#define BJX_MK(GS_) launch_gs<T, GS_, KIND>(ctx, inverse, in, out, ladj_ps, partials, (int)K, pitch, batch, accum, vin, vout, grid, smem)
+    if (gs == 8) BJX_MK(8);
+    else if (gs == 16) BJX_MK(16);
+    else if (gs == 32) BJX_MK(32);
     else BJX_MK(64);
 #undef BJX_MK
   }

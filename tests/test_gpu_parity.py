@@ -2221,9 +2221,8 @@ def test_named_stacked_reference_example(bj):
 def test_batchnorm_training_shard_emulation(bj, orc, dim, N, dt):
     """SURVEY.md §8(e) 'Exception' on ONE GPU: G column blocks -> bjx_batchnorm_stats per block -> the 2·dim+1 Float64 sums
     added in rank order (what the all-reduce does) -> bjx_batchnorm_train_apply per block with the GLOBAL sums.  The
-    result must be the G = 1 result: bit-equal for Float32 (the Float64 sums differ in their last bits between
-    partitions, which does not survive the rounding of mean / variance to Float32 here), 1e-12 for Float64; and both
-    must equal the monolithic bjx_batchnorm_train entry point."""
+    result must be the G = 1 result to a few ulp (see the comment at the comparison), and G = 1 must equal the monolithic
+    bjx_batchnorm_train entry point bit for bit."""
     import ctypes as C
 
     r = rng(dim + N)
@@ -2255,11 +2254,13 @@ def test_batchnorm_training_shard_emulation(bj, orc, dim, N, dt):
     close(v1, v_ref, dt)
     for G in (2, 4, 8):
         Yg, lg, mg, vg = run(G)
-        if dt == np.float32:
-            assert np.array_equal(Yg, Y1) and np.array_equal(lg, l1) and np.array_equal(mg, m1) and np.array_equal(vg, v1), f"G={G}"
-        else:
-            for a_, b2 in ((Yg, Y1), (lg, l1), (mg, m1), (vg, v1)):
-                np.testing.assert_allclose(a_, b2, rtol=1e-12, atol=1e-12, err_msg=f"G={G}")
+        # NOT bit-equal in general: the Float64 sums of different partitions differ in their last bits (a floating-point
+        # all-reduce has no canonical order either), which can flip the rounding of a mean / variance to Float32 —
+        # measured on the GPU: G = 2 / 4 differ from G = 1 in single elements.  The bound is one rounding of the
+        # statistics: a few ulp of the data type in the outputs.
+        tol = 4 * np.finfo(dt).eps
+        for a_, b2 in ((Yg, Y1), (lg, l1), (mg, m1), (vg, v1)):
+            np.testing.assert_allclose(a_, b2, rtol=tol, atol=tol * 10, err_msg=f"G={G}")
     # the monolithic entry point (no communicator: a single rank) gives the G = 1 result
     L = bj._lib
     ctx = bj.context(Xd.device)
@@ -2284,9 +2285,12 @@ def test_batchnorm_training_large_mean_float64(bj):
                                 torch.full((dim,), 1e6, dtype=torch.float64), torch.ones(dim, dtype=torch.float64), eps=1e-12, mtm=0.1)
     with bj.training():
         Y, l = bj.with_logabsdet_jacobian(bn, dev(X))
-    m = X.mean(axis=1, keepdims=True)
-    v = ((X - m) ** 2).sum(axis=1, keepdims=True) / N                          # normalise.jl:54, two passes
-    np.testing.assert_allclose(host(Y), (X - m) / np.sqrt(v + 1e-12), rtol=1e-6, atol=1e-6)
+    # reference in exact-shift form: X - 1e6 is exact in Float64, so mean and deviations carry no cancellation error
+    # (a plain X.mean() is itself only good to ~1e-9 absolute here, i.e. 1e-7 of the spread)
+    D = X - 1e6
+    dm = D.mean(axis=1, keepdims=True)
+    v = ((D - dm) ** 2).sum(axis=1, keepdims=True) / N                         # normalise.jl:54, two passes
+    np.testing.assert_allclose(host(Y), (D - dm) / np.sqrt(v + 1e-12), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(host(l), np.full(N, -0.5 * np.log(v + 1e-12).sum()), rtol=1e-8)
 
 
