@@ -40,11 +40,11 @@ template <class T> __device__ __forceinline__ T find_alpha_dev(T wy, T c, T b) {
   const T delta = T(2) * d_abs(c);
   T lo = wy - delta, hi = wy + delta;
   if (lo == hi) return lo;                       // :171-173
-  T a = wy - c * d_tanh(wy + b);                 // one fixed-point step as the start
+  T a = wy - c * x_tanh(wy + b);                 // one fixed-point step as the start
   a = a < lo ? lo : (a > hi ? hi : a);
   const int max_it = sizeof(T) == 4 ? 40 : 80;
   for (int it = 0; it < max_it; ++it) {
-    T t = d_tanh(a + b);
+    T t = x_tanh(a + b);
     T f = a + c * t - wy;
     if (f == T(0)) break;
     if (f < T(0)) lo = a; else hi = a;
@@ -123,9 +123,9 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
       T arg;
       if (!INV) arg = s + bl;
       else arg = find_alpha_dev<T>(s, c, bl) + bl;
-      const T t = d_tanh(arg);
-      const T sech = T(1) / d_cosh(arg);
-      const T ld = d_log1p(c * (sech * sech));  // planar_layer.jl:107
+      T t, s2;
+      x_tanh_sech2(arg, t, s2);
+      const T ld = Fast<T>::log1p(c * s2);      // planar_layer.jl:107
       ladj += INV ? -ld : ld;
       const T tt = INV ? -t : t;
 #pragma unroll
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, 
   T* tmine = tsave + (size_t)cl * A.n_layers;
   if (!INV) {
     for (int l = 0; l < A.n_layers; ++l) {
-      const T t = d_tanh(dot(W + (int64_t)l * dim) + A.b[l]);
+      const T t = x_tanh(dot(W + (int64_t)l * dim) + A.b[l]);
       if (gl == 0) tmine[l] = t;
       axpy(UH + (int64_t)l * dim, t);
     }
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, 
     // the inverse primal (planar_layer.jl:112-127): last layer first, t_l = tanh(α_l + b_l)
     for (int l = A.n_layers - 1; l >= 0; --l) {
       const T a = find_alpha_dev<T>(dot(W + (int64_t)l * dim), A.wtu_hat[l], A.b[l]);
-      const T t = d_tanh(a + A.b[l]);
+      const T t = x_tanh(a + A.b[l]);
       if (gl == 0) tmine[l] = t;
       axpy(UH + (int64_t)l * dim, -t);
     }
@@ -346,9 +346,9 @@ __device__ __forceinline__ T planar_tile_group(const PlanarTileArgs<T>& A, T* ti
       }
       const T bl = A.b[l0 + k], c = A.wtu_hat[l0 + k];
       const T arg = INV ? find_alpha_dev<T>(a, c, bl) + bl : a + bl;
-      const T th = d_tanh(arg);
-      const T sech = T(1) / d_cosh(arg);
-      const T ld = d_log1p(c * (sech * sech));            // planar_layer.jl:107
+      T th, s2;
+      x_tanh_sech2(arg, th, s2);
+      const T ld = Fast<T>::log1p(c * s2);                // planar_layer.jl:107
       ladj += INV ? -ld : ld;
       t[k] = th;
     }
@@ -903,6 +903,163 @@ __global__ __launch_bounds__(256) void planar_mfma_kernel(const PlanarRegArgs A,
   block_publish_partial(ok ? (double)ladj : 0.0, red, fin);
 }
 
+// ------------------------------------------------------------------ Planar, MFMA kernel (Float64, forward and inverse)
+// Float64 is the data type of the reference's tests and Turing's default.  The register kernel above is Float32-only and the
+// LDS-tile fallback ran 8 layers at d = 128 at 15 % of the HBM roofline.  In Float64 the matrix cores are the natural home of
+// both dense steps: v_mfma_f64_16x16x4_f64 runs at twice the vector FP64 rate.  Same scheme as planar_mfma_kernel with the
+// C/D layout of the Float64 instruction (probed: scripts/probe_mfma_f64.hip): lane (n = lane % 16, q = lane / 16), register r
+// holds row 4r + q of the 16-row block, i.e. z[b][r] = Z[16b + 4r + q][column n].
+//   contraction  MFMA (b, r) contracts the four consecutive rows 16b + 4r .. +3: B = z[b][r], A = W[layer = lane % 16][16b + 4r + q]
+//                -> acc[rr] = S[layer 4rr + q][column n] (8 layers: rr = 0, 1 on all four q)
+//   update       z[b] += MFMA(A = Û[4g + q][16b + n], B = t[column n][4g + q]), g = 0, 1
+// The tile is loaded / stored with coalesced 16-byte accesses and transposed through LDS (the rows of a lane are 4 apart);
+// W and Û of a group come from L1/L2 per use (8 KiB per group, shared by every wave).  INV: groups and layers last to
+// first, find_alpha_dev per layer (planar_layer.jl:112-127,160-185), update with -tanh.
+typedef double md4 __attribute__((ext_vector_type(4)));
+template <int NB, int TILES, bool INV>
+__global__ __launch_bounds__(256) void planar_mfma64_kernel(const double* __restrict__ Wp, const double* __restrict__ Up, const double* __restrict__ Gp,
+                                                            const double* __restrict__ cp, const double* __restrict__ bp, int nl_pad,
+                                                            const double* __restrict__ x, double* __restrict__ y, double* __restrict__ ladj_ps, int dim,
+                                                            int64_t batch, int accumulate, const BjxFin fin) {
+  constexpr int NL = 8, COLS = 16 * TILES;
+  constexpr int ROWS = 16 * NB;
+  constexpr int PITCH = ROWS + 4;                  // doubles per staged column (rows of consecutive columns start 8 banks apart)
+  extern __shared__ __attribute__((aligned(16))) char smem_[];
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* sg = reinterpret_cast<double*>(smem_) + (size_t)wave * (16 * PITCH + COLS * NL);
+  double* st = sg + 16 * PITCH;
+  const int n = lane & 15, q = lane >> 4;
+  const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * COLS;
+  const int64_t left = batch - col0;
+  const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int PK = ROWS / 2;                      // 16-byte packs per column
+  constexpr int NIT = (16 * PK + 63) / 64;          // pack loads per lane and tile
+
+  double z[TILES][NB][4];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    const double* px = x + (col0 + t * 16) * dim;
+    d2 tmp[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int p = it * 64 + lane, c = p / PK;
+      tmp[it] = (p < 16 * PK && t * 16 + c < nvalid) ? __builtin_nontemporal_load(reinterpret_cast<const d2*>(px) + p) : d2{0., 0.};
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int p = it * 64 + lane, c = p / PK, k = p - c * PK;
+      if (p < 16 * PK) *reinterpret_cast<d2*>(sg + c * PITCH + 2 * k) = tmp[it];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[t][b][r] = sg[n * PITCH + 16 * b + 4 * r + q];
+    __builtin_amdgcn_wave_barrier();
+  }
+  double ladj = 0.0;
+  const int ngroups = nl_pad / NL;
+  for (int gi = 0; gi < ngroups; ++gi) {
+    const int l0 = (INV ? ngroups - 1 - gi : gi) * NL;
+    // ---- contraction
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      md4 acc = md4{0., 0., 0., 0.};
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double wa = n < NL ? Wp[(int64_t)(l0 + n) * dim + 16 * b + 4 * r + q] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, z[t][b][r], acc, 0, 0, 0);
+        }
+      st[(t * 16 + n) * NL + q] = acc[0];
+      st[(t * 16 + n) * NL + 4 + q] = acc[1];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- scalar recurrence, one sample per lane
+    if (COLS == 64 || lane < COLS) {
+      double s[NL], tt[NL];
+#pragma unroll
+      for (int k = 0; k < NL; ++k) { s[k] = st[lane * NL + k]; tt[k] = 0.0; }
+#pragma unroll
+      for (int kk = 0; kk < NL; ++kk) {
+        const int k = INV ? NL - 1 - kk : kk;
+        const double* Gk = Gp + (int64_t)(l0 + k) * nl_pad + l0;
+        double a = s[k];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+          if (!INV) { if (j < k) a += Gk[j] * tt[j]; }
+          else { if (j > k) a += Gk[j] * tt[j]; }         // tt holds -tanh for the inverse
+        }
+        const double bl = bp[l0 + k], c = cp[l0 + k];
+        const double arg = INV ? find_alpha_dev<double>(a, c, bl) + bl : a + bl;
+        double th, s2;
+        x_tanh_sech2(arg, th, s2);
+        const double ld = Fast<double>::log1p(c * s2);      // planar_layer.jl:107
+        ladj += INV ? -ld : ld;
+        tt[k] = INV ? -th : th;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < NL; ++k) st[lane * NL + k] = tt[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- rank-8 update: the tile registers are the accumulator
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const double t0 = st[(t * 16 + n) * NL + q], t1 = st[(t * 16 + n) * NL + 4 + q];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        md4 zz = md4{z[t][b][0], z[t][b][1], z[t][b][2], z[t][b][3]};
+        zz = __builtin_amdgcn_mfma_f64_16x16x4f64(Up[(int64_t)(l0 + q) * dim + 16 * b + n], t0, zz, 0, 0, 0);
+        zz = __builtin_amdgcn_mfma_f64_16x16x4f64(Up[(int64_t)(l0 + 4 + q) * dim + 16 * b + n], t1, zz, 0, 0, 0);
+        z[t][b][0] = zz[0]; z[t][b][1] = zz[1]; z[t][b][2] = zz[2]; z[t][b][3] = zz[3];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (accumulate & 2) {
+    // BJX_BASE_STDNORMAL: + log N(out; 0, I): |out|^2 of a column = my 4*NB entries, summed over the four q lanes
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      double p = 0.0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p += z[t][b][r] * z[t][b][r];
+      p += shfl_xor(p, 16);
+      p += shfl_xor(p, 32);
+      if (q == 0) st[t * 16 + n] = p;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (COLS == 64 || lane < COLS) ladj += -0.5 * st[lane] - (double)dim * 0.91893853320467274178;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (y) {
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sg[n * PITCH + 16 * b + 4 * r + q] = z[t][b][r];
+      __builtin_amdgcn_wave_barrier();
+      double* py = y + (col0 + t * 16) * dim;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int p = it * 64 + lane, c = p / PK, k = p - c * PK;
+        if (p < 16 * PK && t * 16 + c < nvalid) __builtin_nontemporal_store(*reinterpret_cast<const d2*>(sg + c * PITCH + 2 * k), reinterpret_cast<d2*>(py) + p);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  const bool ok = lane < nvalid;
+  if (ok && ladj_ps) ladj_ps[col0 + lane] = (accumulate & 1) ? ladj_ps[col0 + lane] + ladj : ladj;
+  block_publish_partial(ok ? ladj : 0.0, red, fin);
+}
+
 // ------------------------------------------------------------------ Planar input pullback, register kernel (Float32)
 // bjx_planar_vjp for 16 < dim <= 128: the two sweeps of planar_vjp_kernel on the register tile of planar_reg_kernel.
 // The reverse sweep IS the forward structure with the roles of w and û exchanged: with s̄_k the cotangent of s_k,
@@ -1189,9 +1346,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
 
 // zero-padded parameter tables for the register kernel: w, û -> [nl_pad][dim]; b, wᵀû -> [nl_pad];
 // G[k][j] = w_k . û_j -> [nl_pad][nl_pad].  grid = nl_pad * nl_pad blocks.
-__global__ __launch_bounds__(256) void planar_prep_reg_kernel(const float* w, const float* u_hat, const float* wtu_hat, const float* b,
-                                                              int64_t dim, int nl, int nl_pad, float* wp, float* up, float* Gp,
-                                                              float* cp, float* bp) {
+template <class T>
+__global__ __launch_bounds__(256) void planar_prep_reg_kernel(const T* w, const T* u_hat, const T* wtu_hat, const T* b,
+                                                              int64_t dim, int nl, int nl_pad, T* wp, T* up, T* Gp,
+                                                              T* cp, T* bp) {
   __shared__ double red[4];
   const int k = blockIdx.x / nl_pad, j = blockIdx.x % nl_pad;
   const bool live = k < nl && j < nl;
@@ -1200,13 +1358,13 @@ __global__ __launch_bounds__(256) void planar_prep_reg_kernel(const float* w, co
   dot = group_sum<64>(dot);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
   __syncthreads();
-  if (threadIdx.x == 0) Gp[k * nl_pad + j] = live ? (float)((red[0] + red[1]) + (red[2] + red[3])) : 0.f;
+  if (threadIdx.x == 0) Gp[k * nl_pad + j] = live ? (T)((red[0] + red[1]) + (red[2] + red[3])) : T(0);
   if (j == 0) {
     for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) {
-      wp[(int64_t)k * dim + i] = k < nl ? w[(int64_t)k * dim + i] : 0.f;
-      up[(int64_t)k * dim + i] = k < nl ? u_hat[(int64_t)k * dim + i] : 0.f;
+      wp[(int64_t)k * dim + i] = k < nl ? w[(int64_t)k * dim + i] : T(0);
+      up[(int64_t)k * dim + i] = k < nl ? u_hat[(int64_t)k * dim + i] : T(0);
     }
-    if (threadIdx.x == 0) { cp[k] = k < nl ? wtu_hat[k] : 0.f; bp[k] = k < nl ? b[k] : 0.f; }
+    if (threadIdx.x == 0) { cp[k] = k < nl ? wtu_hat[k] : T(0); bp[k] = k < nl ? b[k] : T(0); }
   }
 }
 
@@ -1507,7 +1665,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         float* Gp = up + (size_t)nl_pad * dim;
         float* cp = Gp + (size_t)nl_pad * nl_pad;
         float* bp = cp + nl_pad;
-        hipLaunchKernelGGL(planar_prep_reg_kernel, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, (const float*)w, (const float*)u_hat,
+        hipLaunchKernelGGL(planar_prep_reg_kernel<float>, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, (const float*)w, (const float*)u_hat,
                            (const float*)wtu, (const float*)b, dim, nl, nl_pad, wp, up, Gp, cp, bp);
         BJX_CHECK_LAUNCH(ctx);
         static const int cols_env = getenv("BJX_PLANAR_COLS") ? atoi(getenv("BJX_PLANAR_COLS")) : 0;
@@ -1563,6 +1721,48 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
 #undef LAUNCH_REG
         BJX_CHECK_LAUNCH(ctx);
         if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+        return BJX_OK;
+      }
+    }
+  }
+  // Float64: matrix-core kernel (groups of 8 layers, dim a multiple of 16 up to 128)
+  if constexpr (sizeof(T) == 8) {
+    static const int use_mf64 = getenv("BJX_PLANAR_MFMA64") ? atoi(getenv("BJX_PLANAR_MFMA64")) : 2;    // 0 off | 1: 16 columns per wave | 2: 32
+    if (use_mf64 && dim % 16 == 0 && dim >= 16 && dim <= 128 && bjx_aligned16(in) && (!out || bjx_aligned16(out))) {
+      const int nl_pad = (nl + 7) / 8 * 8;
+      const size_t off0 = ((size_t)nl * dim + nl + 1) / 2 * 2;
+      const size_t need_reg = (off0 + (size_t)2 * nl_pad * dim + (size_t)nl_pad * nl_pad + 2 * (size_t)nl_pad) * sizeof(double);
+      if (need_reg <= BJX_SCRATCH_BYTES) {
+        double* base = reinterpret_cast<double*>(ctx->scratch);
+        double* wp = base + off0;
+        double* up = wp + (size_t)nl_pad * dim;
+        double* Gp = up + (size_t)nl_pad * dim;
+        double* cp = Gp + (size_t)nl_pad * nl_pad;
+        double* bp = cp + nl_pad;
+        hipLaunchKernelGGL(planar_prep_reg_kernel<double>, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, (const double*)w, (const double*)u_hat,
+                           (const double*)wtu, (const double*)b, dim, nl, nl_pad, wp, up, Gp, cp, bp);
+        BJX_CHECK_LAUNCH(ctx);
+        const int tiles = use_mf64 == 1 ? 1 : 2;
+        const int cols = 16 * tiles;
+        const int64_t gridm = (batch + 4 * cols - 1) / (4 * cols);
+        BJX_REQUIRE(ctx, gridm < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar: batch too large for one launch");
+        BjxFin finm;
+        bool secondm = false;
+        { int rc = bjx_make_fin(ctx, gridm, ladj_sum, 0.0, 0, flags, &finm, &secondm); if (rc) return rc; }
+        const int accum = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
+        const size_t smem = (size_t)4 * (16 * (dim + 4) + cols * 8) * sizeof(double);
+#define LAUNCH_MF64(NB_, T_, I_) do { bjx_allow_big_lds(planar_mfma64_kernel<NB_, T_, I_>, smem); \
+          hipLaunchKernelGGL((planar_mfma64_kernel<NB_, T_, I_>), dim3((unsigned)gridm), dim3(256), smem, ctx->stream, wp, up, Gp, cp, bp, nl_pad, \
+                             (const double*)in, (double*)out, (double*)ladj_ps, (int)dim, batch, accum, finm); } while (0)
+#define LAUNCH_MF64_TI(NB_) do { if (tiles == 1) { if (inverse) LAUNCH_MF64(NB_, 1, true); else LAUNCH_MF64(NB_, 1, false); } \
+                                 else { if (inverse) LAUNCH_MF64(NB_, 2, true); else LAUNCH_MF64(NB_, 2, false); } } while (0)
+        { BjxProf prof_(ctx);
+          switch (dim / 16) { case 1: LAUNCH_MF64_TI(1); break; case 2: LAUNCH_MF64_TI(2); break; case 3: LAUNCH_MF64_TI(3); break; case 4: LAUNCH_MF64_TI(4); break;
+                              case 5: LAUNCH_MF64_TI(5); break; case 6: LAUNCH_MF64_TI(6); break; case 7: LAUNCH_MF64_TI(7); break; default: LAUNCH_MF64_TI(8); break; } }
+#undef LAUNCH_MF64_TI
+#undef LAUNCH_MF64
+        BJX_CHECK_LAUNCH(ctx);
+        if (secondm) return bjx_launch_finalize(ctx, (int)gridm, ladj_sum, 0.0, 0, 0.0, flags);
         return BJX_OK;
       }
     }
@@ -1636,7 +1836,7 @@ inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float
   float* Gp = up + (size_t)nl_pad * dim;
   float* cp = Gp + (size_t)nl_pad * nl_pad;
   float* bp = cp + nl_pad;
-  hipLaunchKernelGGL(planar_prep_reg_kernel, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, w, u_hat, wtu, b, dim, nl, nl_pad, wp, up, Gp, cp, bp);
+  hipLaunchKernelGGL(planar_prep_reg_kernel<float>, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, w, u_hat, wtu, b, dim, nl, nl_pad, wp, up, Gp, cp, bp);
   BJX_CHECK_LAUNCH(ctx);
   const int G = dim > 64 ? 32 : (dim > 32 ? 16 : 8);
   const int64_t grid = (batch + 4 * 64 - 1) / (4 * 64);

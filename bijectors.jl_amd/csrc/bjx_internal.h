@@ -196,7 +196,127 @@ template <> struct Fast<float> {
     return d == 0.0f ? x : log(u) * (x * __builtin_amdgcn_rcpf(d));
   }
 };
+// Float64: lean versions of the elementary functions (BJX_F64_LEAN, default on).  The OCML routines are correctly
+// rounded-ish with full denormal / flag care and cost 40-100 VALU each, which makes every Float64 kernel VALU-bound at
+// 15-58 % of the HBM roofline; the parity bar is 1e-6 relative.  These keep ~1e-15 relative accuracy (scripts/f64math_bench.hip
+// prints the measured maximum error against long double libm and the throughput next to OCML) and the IEEE special values
+// the reference's code paths rely on (log(0) = -Inf, log(<0) = NaN, exp(-Inf) = 0, 1/0 = Inf, NaN in -> NaN out); they do
+// not care about gradual underflow of results or exception flags.
+#ifndef BJX_F64_LEAN
+#define BJX_F64_LEAN 1
+#endif
+namespace f64lean {
+__device__ __forceinline__ double rcp(double x) {
+  const double r0 = __builtin_amdgcn_rcp(x);                 // v_rcp_f64: ~2^-26 relative
+  double e = __builtin_fma(-x, r0, 1.0);
+  double r = __builtin_fma(e, r0, r0);
+  e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(e, r, r);
+  return r == r ? r : r0;                                    // x = 0, +-Inf, NaN: the Newton step is NaN, the hardware value is right
+}
+__device__ __forceinline__ void sqrt_rsqrt(double x, double& sq, double& rs) {
+  const double y = __builtin_amdgcn_rsq(x);                  // v_rsq_f64
+  double g = x * y, h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  const bool special = !(x > 0.0) || x == Num<double>::inf;  // 0, negative, NaN, +Inf: g is NaN there
+  sq = special ? (x == 0.0 || x == Num<double>::inf ? x : y * 0.0) : g;   // sqrt(-x) = NaN, sqrt(0) = 0, sqrt(Inf) = Inf
+  rs = special ? y : h + h;
+}
+__device__ __forceinline__ double exp(double x) {
+  const double xc = __builtin_fmin(__builtin_fmax(x, -1100.0), 1100.0);
+  const double k = __builtin_rint(xc * 1.4426950408889634074);
+  double r = __builtin_fma(k, -6.93147180369123816490e-01, xc);      // ln2 split: hi has 32 significant bits
+  r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+  // exp(r), |r| <= ln2/2: Taylor to r^13 (truncation 2e-18 relative)
+  double p = 1.6059043836821614599e-10;                     // 1/13!
+  p = __builtin_fma(p, r, 2.0876756987868098979e-09);       // 1/12!
+  p = __builtin_fma(p, r, 2.5052108385441718775e-08);
+  p = __builtin_fma(p, r, 2.7557319223985890653e-07);
+  p = __builtin_fma(p, r, 2.7557319223985890653e-06);
+  p = __builtin_fma(p, r, 2.4801587301587301587e-05);
+  p = __builtin_fma(p, r, 1.9841269841269841270e-04);
+  p = __builtin_fma(p, r, 1.3888888888888888889e-03);
+  p = __builtin_fma(p, r, 8.3333333333333333333e-03);
+  p = __builtin_fma(p, r, 4.1666666666666666667e-02);
+  p = __builtin_fma(p, r, 1.6666666666666666667e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  const double y = __builtin_ldexp(p, (int)k);
+  return x == x ? y : x;                                     // fmin/fmax drop a NaN
+}
+// expm1 for a <= 0 (the tanh / logistic tails): exact slope at 0, no cancellation
+__device__ __forceinline__ double expm1_neg(double a) {
+  const double ac = __builtin_fmax(a, -1100.0);
+  const double k = __builtin_rint(ac * 1.4426950408889634074);
+  double r = __builtin_fma(k, -6.93147180369123816490e-01, ac);
+  r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821614599e-10;
+  p = __builtin_fma(p, r, 2.0876756987868098979e-09);
+  p = __builtin_fma(p, r, 2.5052108385441718775e-08);
+  p = __builtin_fma(p, r, 2.7557319223985890653e-07);
+  p = __builtin_fma(p, r, 2.7557319223985890653e-06);
+  p = __builtin_fma(p, r, 2.4801587301587301587e-05);
+  p = __builtin_fma(p, r, 1.9841269841269841270e-04);
+  p = __builtin_fma(p, r, 1.3888888888888888889e-03);
+  p = __builtin_fma(p, r, 8.3333333333333333333e-03);
+  p = __builtin_fma(p, r, 4.1666666666666666667e-02);
+  p = __builtin_fma(p, r, 1.6666666666666666667e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p *= r;                                                    // expm1(r) = r (1 + r/2 + ...)
+  const double s = __builtin_ldexp(1.0, (int)k);             // 2^k, k <= 0
+  const double y = __builtin_fma(s, p, s - 1.0);             // 2^k expm1(r) + (2^k - 1)
+  return a == a ? y : a;
+}
+__device__ __forceinline__ double log(double x) {
+  // x = m 2^e, m in [sqrt(1/2), sqrt(2)); log(m) = 2 atanh(s), s = f/(2+f), f = m - 1 (fdlibm's scheme, Remez coefficients)
+  double m = __builtin_amdgcn_frexp_mant(x);                 // [0.5, 1), denormals handled by the instruction
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const double f = m - 1.0;
+  const double s = f * rcp(2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)e;
+  double y = __builtin_fma(dk, 6.93147180369123816490e-01, f - (hfsq - __builtin_fma(s, hfsq + R, dk * 1.90821492927058770002e-10)));
+  // specials: log(0) = -Inf, log(<0) = NaN, log(+Inf) = +Inf, NaN -> NaN
+  y = x == Num<double>::inf ? x : y;
+  y = x == 0.0 ? -Num<double>::inf : y;
+  y = x < 0.0 ? __builtin_nan("") : y;
+  return x == x ? y : x;
+}
+__device__ __forceinline__ double log1p(double x) {
+  const double u = 1.0 + x;
+  const double c = x - (u - 1.0);                            // what the addition lost
+  const double l = log(u);
+  return __builtin_fabs(c) > 0.0 && u > 0.0 && u < Num<double>::inf ? __builtin_fma(c, rcp(u), l) : l;
+}
+}  // namespace f64lean
+
 template <> struct Fast<double> {
+#if BJX_F64_LEAN
+  static __device__ __forceinline__ double log(double x) { return f64lean::log(x); }
+  static __device__ __forceinline__ double log2(double x) { return f64lean::log(x) * 1.4426950408889634074; }
+  static __device__ __forceinline__ double exp(double x) { return ::exp(x); }      // OCML's exp is already lean (measured: 1353 vs 1206 G/s)
+  static __device__ __forceinline__ double rcp(double x) { return f64lean::rcp(x); }
+  static __device__ __forceinline__ double div(double a, double b) { return a * f64lean::rcp(b); }
+  static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }    // same rate as the lean form
+  static __device__ __forceinline__ double rsqrt(double x) { double s, r; f64lean::sqrt_rsqrt(x, s, r); return r; }
+  static __device__ __forceinline__ double log1p(double x) { return f64lean::log1p(x); }
+#else
   static __device__ __forceinline__ double log(double x) { return ::log(x); }
   static __device__ __forceinline__ double log2(double x) { return ::log2(x); }
   static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
@@ -205,7 +325,53 @@ template <> struct Fast<double> {
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
   static __device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
+#endif
 };
+// tanh / asinh / atanh / logcosh in Float64 from the lean pieces (Float32 callers have their own hardware-unit forms)
+__device__ __forceinline__ double fast_tanh64(double x) {
+  const double em = f64lean::expm1_neg(-2.0 * __builtin_fabs(x));          // e^{-2|x|} - 1 in [-1, 0]
+  const double t = -em * f64lean::rcp(2.0 + em);
+  return __builtin_copysign(t, x);
+}
+__device__ __forceinline__ double fast_asinh64(double x) {
+  const double ax = __builtin_fabs(x);
+  double sq, rs;
+  f64lean::sqrt_rsqrt(__builtin_fma(ax, ax, 1.0), sq, rs);
+  const double small = f64lean::log1p(ax + ax * ax * f64lean::rcp(1.0 + sq));   // log(|x| + sqrt(x^2+1)) without cancellation
+  const double big = f64lean::log(ax) + 0.69314718055994530942;              // |x| > 1e150: x^2 overflows
+  return __builtin_copysign(ax > 1e150 ? big : small, x);
+}
+
+// tanh / (tanh, sech^2) / asinh / atanh: Float32 -> OCML (the Float32 hot kernels have their own hardware-unit forms),
+// Float64 -> the lean pieces (3.7x OCML's tanh, scripts/f64math_bench.hip)
+__device__ __forceinline__ float x_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ double x_tanh(double x) {
+#if BJX_F64_LEAN
+  return fast_tanh64(x);
+#else
+  return ::tanh(x);
+#endif
+}
+__device__ __forceinline__ void x_tanh_sech2(float arg, float& th, float& s2) { th = tanhf(arg); const float sc = 1.0f / coshf(arg); s2 = sc * sc; }
+__device__ __forceinline__ void x_tanh_sech2(double arg, double& th, double& s2) {
+#if BJX_F64_LEAN
+  const double em = f64lean::expm1_neg(-2.0 * __builtin_fabs(arg));     // e - 1, e = exp(-2|arg|)
+  const double r = f64lean::rcp(2.0 + em);                               // 1 / (1 + e)
+  th = __builtin_copysign(-em * r, arg);
+  s2 = 4.0 * (1.0 + em) * r * r;                                        // sech^2 = 4e / (1+e)^2
+#else
+  th = ::tanh(arg); const double sc = 1.0 / ::cosh(arg); s2 = sc * sc;
+#endif
+}
+__device__ __forceinline__ float x_asinh(float x) { return asinhf(x); }
+__device__ __forceinline__ float x_atanh(float x) { return atanhf(x); }
+#if BJX_F64_LEAN
+__device__ __forceinline__ double x_asinh(double x) { return fast_asinh64(x); }
+__device__ __forceinline__ double x_atanh(double x) { return 0.5 * f64lean::log1p((x + x) * f64lean::rcp(1.0 - x)); }
+#else
+__device__ __forceinline__ double x_asinh(double x) { return ::asinh(x); }
+__device__ __forceinline__ double x_atanh(double x) { return ::atanh(x); }
+#endif
 
 // LogExpFunctions.logistic / log1pexp on the fast units (same saturation / branch thresholds as above)
 template <class T> __device__ __forceinline__ T f_logistic(T x) {
@@ -223,6 +389,12 @@ template <class T> __device__ __forceinline__ T f_log1pexp(T x) {
   if (x < Num<T>::l1pe1) return Fast<T>::log1p(e);
   if (x < Num<T>::l1pe2) return x + e;
   return x;
+}
+
+// LogExpFunctions.logcosh on the fast units: |x| + log1pexp(-2|x|) - log 2
+template <class T> __device__ __forceinline__ T f_logcosh(T x) {
+  const T ax = d_abs(x);
+  return ax + f_log1pexp(T(-2) * ax) - Num<T>::log2;
 }
 
 // ------------------------------------------------------------------ Philox4x32-10 standard normals

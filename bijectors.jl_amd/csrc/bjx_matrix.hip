@@ -58,21 +58,22 @@ template <> struct LinkMath<float> {
   static __device__ __forceinline__ float log(float x) { return F::log(x); }
 };
 template <> struct LinkMath<double> {
+  using F = Fast<double>;
   static __device__ __forceinline__ void asinh_lc(double w, double rem, double& y, double& lc) {
-    const double z = w / ::sqrt(rem);
-    y = ::asinh(z);
-    lc = 0.5 * ::log1p(z * z);
+    const double z = w * F::rsqrt(rem);
+    y = x_asinh(z);
+    lc = 0.5 * F::log1p(z * z);
   }
   static __device__ __forceinline__ void atanh_lc(double w, double& y, double& lc) {
-    y = ::atanh(w);
-    lc = -0.5 * ::log1p(-w * w);
+    y = x_atanh(w);
+    lc = -0.5 * F::log1p(-w * w);
   }
   static __device__ __forceinline__ void tanh_lc(double y, double& z, double& lc) {
-    z = ::tanh(y);
-    lc = d_logcosh(y);
+    z = x_tanh(y);
+    lc = f_logcosh(y);
   }
-  static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
-  static __device__ __forceinline__ double log(double x) { return ::log(x); }
+  static __device__ __forceinline__ double exp(double x) { return F::exp(x); }
+  static __device__ __forceinline__ double log(double x) { return F::log(x); }
 };
 
 // Layout of the contiguous run of one sample in global memory; every layout lands in the tile as tile[c*pitch + r]:

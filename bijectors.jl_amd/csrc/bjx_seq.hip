@@ -1056,8 +1056,8 @@ __global__ __launch_bounds__(256) void chol_fwd_kernel(const T* W, T* y, T* ladj
       const T suffix = is_tail ? T(0) : (lane == 63 ? carry : nxt);   // Σ_{k>i0} w_k²
       if (valid) {
         T yv;
-        if (i0 == 0) yv = d_atanh(w);                            // :322
-        else yv = d_asinh(w / d_sqrt(dg * dg + suffix));         // :327-329
+        if (i0 == 0) yv = x_atanh(w);                            // :322
+        else yv = x_asinh(w * Fast<T>::rsqrt(dg * dg + suffix)); // :327-329
         ys[e] = yv;
       }
       // carry for the next (lower) step: the part of lane 0's column that lives in this and higher steps
@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(256) void chol_fwd_kernel(const T* W, T* y, T* ladj
         const bool valid = e < nv;
         int c = 1, i0 = 0;
         if (valid) triu1_decode(e, c, i0);
-        const T lc = valid ? d_logcosh(ys[e]) : T(0);
+        const T lc = valid ? f_logcosh(ys[e]) : T(0);
         const T incl = seg_prefix_incl<T>(lc, !valid || i0 == 0, cr);
         const bool last = valid && (i0 == c - 1);
         if (valid) lj += last ? T(-2) * incl : -incl;

@@ -173,7 +173,7 @@ template <class T> __device__ __forceinline__ T slot_eval(const Slot<T>& s, T& x
     case SK_LOG: v = F::log(u); l -= v; break;                                                        // exp_log.jl:8-9
     case SK_LOGIT: { const T q = s.alpha - u; l -= F::log(u * q); v = F::log(u * F::rcp(q)); } break;   // logit.jl:15,24
     case SK_LOGISTIC: { const T au = d_abs(u); v = f_logistic(u); l += -au - T(2) * f_log1pexp(-au); } break;   // logit.jl:19, truncated.jl:71-82
-    case SK_LEAKY: { const T J = u < T(0) ? s.alpha : T(1); v = J * u; l += d_log(d_abs(J)); } break; // leaky_relu.jl:25-29
+    case SK_LEAKY: { const T J = u < T(0) ? s.alpha : T(1); v = J * u; l += Fast<T>::log(d_abs(J)); } break; // leaky_relu.jl:25-29
     default: break;
   }
   x = d_med3(s.a2 * v + s.b2, s.plo, s.phi);
@@ -207,7 +207,7 @@ template <class T, int U> __device__ __forceinline__ void slot_eval_multi(const 
       break;
     case SK_LEAKY:
 #pragma unroll
-      for (int i = 0; i < U; ++i) { const T J = u[i] < T(0) ? s.alpha : T(1); v[i] = J * u[i]; l[i] += d_log(d_abs(J)); }
+      for (int i = 0; i < U; ++i) { const T J = u[i] < T(0) ? s.alpha : T(1); v[i] = J * u[i]; l[i] += Fast<T>::log(d_abs(J)); }
       break;
     default: break;
   }

@@ -2369,3 +2369,28 @@ print(json.dumps(out))
             np.testing.assert_allclose(np.asarray(b_[0]), np.asarray(a[0]), rtol=1e-4, atol=2e-5, err_msg=f"MFMA={flag} {key} values")
             np.testing.assert_allclose(np.asarray(b_[1]), np.asarray(a[1]), rtol=1e-4, atol=2e-5, err_msg=f"MFMA={flag} {key} log-det")
             assert abs(b_[2] - a[2]) <= 1e-5 * abs(a[2]) + 1e-4, (flag, key)
+
+
+@pytest.mark.parametrize("dim,nl,N", [(16, 1, 5), (32, 3, 100), (48, 8, 33), (64, 11, 257), (80, 16, 64), (96, 8, 31), (112, 2, 130), (128, 8, 1000), (128, 24, 17)])
+def test_planar_float64_matrix_core_kernel(bj, orc, dim, nl, N):
+    """planar_mfma64_kernel (Float64: both dense steps of a Planar layer group on v_mfma_f64_16x16x4_f64) against the oracle:
+    forward, inverse (find_alpha per layer), the fused density, ragged batches, 1 ... 24 layers (1 ... 3 groups of 8)."""
+    r = rng(dim * 31 + nl)
+    w = r.normal(size=(dim, nl)) / math.sqrt(dim)
+    u = r.normal(size=(dim, nl)) / math.sqrt(dim)
+    b = r.normal(size=nl)
+    Z = np.asfortranarray(r.normal(size=(dim, N)))
+    fl = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(b))
+    Y_ref, l_ref = orc.planar(w, u, b, Z)
+    res = bj.with_logabsdet_jacobian(fl, dev(Z))
+    close(host(res.result), Y_ref, np.float64, scale=10, what="planar f64 mfma")
+    close(host(res.logabsdetjac), l_ref, np.float64, scale=nl, what="planar f64 mfma ladj")
+    X_ref, li_ref = orc.planar(w, u, b, Y_ref, inverse=True)
+    xi, li = bj.with_logabsdet_jacobian(bj.inverse(fl), dev(Y_ref))
+    close(host(xi), X_ref, np.float64, scale=10, what="planar f64 mfma inverse")
+    close(host(li), li_ref, np.float64, scale=nl)
+    lp = bj.logpdf(bj.transformed(bj.MvNormal(dim), fl), dev(Y_ref))
+    lp_ref = orc.mvnormal_diag_logpdf(X_ref) + li_ref
+    close(host(lp), lp_ref, np.float64, scale=dim, what="fused logpdf f64")
+    _, _, ls = bj.shard.with_logabsdet_jacobian_sharded(fl, dev(Z))
+    sum_close(ls, l_ref.sum(), np.float64, N * nl)
