@@ -64,6 +64,9 @@ SIGNATURES = {
     "bjx_vec_cholesky_inv_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_vec_cholesky_fwd_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i64, _i64]),
     "bjx_stacked": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _vp, _vp, _vp, _i64, _i64, _u32]),
+    "bjx_stacked_ld": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _u32]),
+    "bjx_ordered_ld": (_i, [_vp, _i, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _u32]),
+    "bjx_simplex_ld": (_i, [_vp, _i, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _u32]),
     "bjx_stacked_vjp": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_stacked_vjp_moments": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_set_option": (_i, [_vp, _i, _i]),

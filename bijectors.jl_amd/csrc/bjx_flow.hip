@@ -506,6 +506,7 @@ struct PlanarRegArgs {
   const float *G;           // [nl_pad][nl_pad], G[k][j] = w_k . u_hat_j
   const float *wtu_hat, *b; // [nl_pad]
   int nl_pad;
+  int n_layers;             // layers beyond it are padding: their tanh is forced to 0 (a +-Inf input would make 0 * Inf = NaN of them)
 };
 
 // find_alpha for the register kernel: same safeguarded Newton on the reference's bracket
@@ -694,6 +695,7 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
         float th, ld;
         if (INV) find_alpha_act(a, c, bl, th, ld);
         else planar_act(a + bl, c, th, ld);
+        if (l0 + k >= A.n_layers) { th = 0.f; ld = 0.f; }    // padding layer (wave-uniform)
         ladj += INV ? -ld : ld;
         t[k] = INV ? -th : th;
       }
@@ -855,6 +857,7 @@ __global__ __launch_bounds__(256) void planar_mfma_kernel(const PlanarRegArgs A,
           if (j < k) a += Gk[j] * tt[j];
         float th, ld;
         planar_act(a + A.b[l0 + k], A.wtu_hat[l0 + k], th, ld);
+        if (l0 + k >= A.n_layers) { th = 0.f; ld = 0.f; }    // padding layer (wave-uniform)
         ladj += ld;
         tt[k] = th;
       }
@@ -918,7 +921,7 @@ __global__ __launch_bounds__(256) void planar_mfma_kernel(const PlanarRegArgs A,
 typedef double md4 __attribute__((ext_vector_type(4)));
 template <int NB, int TILES, bool INV>
 __global__ __launch_bounds__(256) void planar_mfma64_kernel(const double* __restrict__ Wp, const double* __restrict__ Up, const double* __restrict__ Gp,
-                                                            const double* __restrict__ cp, const double* __restrict__ bp, int nl_pad,
+                                                            const double* __restrict__ cp, const double* __restrict__ bp, int nl_pad, int n_layers,
                                                             const double* __restrict__ x, double* __restrict__ y, double* __restrict__ ladj_ps, int dim,
                                                             int64_t batch, int accumulate, const BjxFin fin) {
   constexpr int NL = 8, COLS = 16 * TILES;
@@ -998,7 +1001,8 @@ __global__ __launch_bounds__(256) void planar_mfma64_kernel(const double* __rest
         const double arg = INV ? find_alpha_dev<double>(a, c, bl) + bl : a + bl;
         double th, s2;
         x_tanh_sech2(arg, th, s2);
-        const double ld = Fast<double>::log1p(c * s2);      // planar_layer.jl:107
+        double ld = Fast<double>::log1p(c * s2);            // planar_layer.jl:107
+        if (l0 + k >= n_layers) { th = 0.0; ld = 0.0; }     // padding layer (wave-uniform)
         ladj += INV ? -ld : ld;
         tt[k] = INV ? -th : th;
       }
@@ -1195,6 +1199,7 @@ __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A,
         float th, ld;
         if (INV) find_alpha_act(a, c, bl, th, ld);
         else planar_act(a + bl, c, th, ld);
+        if (l0 + k >= A.n_layers) { th = 0.f; ld = 0.f; }    // padding layer (wave-uniform)
         ladj += INV ? -ld : ld;
         t[k] = INV ? -th : th;
       }
@@ -1682,7 +1687,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         BjxFin fin;
         bool second = false;
         { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
-        PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad};
+        PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl};
         const int accum = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
 #define LAUNCH_REG(G_, NL_, INV_) if (G_ == 32 && cols == 32) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, (G_ == 32 ? 32 : 64)>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); else hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, 64>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
 #define LAUNCH_REG_NL(G_, INV_) switch (NL) { case 1: LAUNCH_REG(G_, 1, INV_); break; case 2: LAUNCH_REG(G_, 2, INV_); break; case 4: LAUNCH_REG(G_, 4, INV_); break; default: LAUNCH_REG(G_, 8, INV_); break; }
@@ -1752,7 +1757,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         const int accum = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
         const size_t smem = (size_t)4 * (16 * (dim + 4) + cols * 8) * sizeof(double);
 #define LAUNCH_MF64(NB_, T_, I_) do { bjx_allow_big_lds(planar_mfma64_kernel<NB_, T_, I_>, smem); \
-          hipLaunchKernelGGL((planar_mfma64_kernel<NB_, T_, I_>), dim3((unsigned)gridm), dim3(256), smem, ctx->stream, wp, up, Gp, cp, bp, nl_pad, \
+          hipLaunchKernelGGL((planar_mfma64_kernel<NB_, T_, I_>), dim3((unsigned)gridm), dim3(256), smem, ctx->stream, wp, up, Gp, cp, bp, nl_pad, nl, \
                              (const double*)in, (double*)out, (double*)ladj_ps, (int)dim, batch, accum, finm); } while (0)
 #define LAUNCH_MF64_TI(NB_) do { if (tiles == 1) { if (inverse) LAUNCH_MF64(NB_, 1, true); else LAUNCH_MF64(NB_, 1, false); } \
                                  else { if (inverse) LAUNCH_MF64(NB_, 2, true); else LAUNCH_MF64(NB_, 2, false); } } while (0)
@@ -1841,7 +1846,7 @@ inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float
   const int G = dim > 64 ? 32 : (dim > 32 ? 16 : 8);
   const int64_t grid = (batch + 4 * 64 - 1) / (4 * 64);
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: batch too large for one launch");
-  PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad};
+  PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl};
 #define LV(G_, NL_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, true>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); \
                           else hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, false>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); } while (0)
 #define LV_NL(G_) switch (NL) { case 1: LV(G_, 1); break; case 2: LV(G_, 2); break; case 4: LV(G_, 4); break; default: LV(G_, 8); break; }

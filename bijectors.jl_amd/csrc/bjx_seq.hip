@@ -241,6 +241,30 @@ __device__ __forceinline__ void tile_stage_out(const T* tile, T* __restrict__ ds
     for (int e = lane; e < ne; e += 64) dst[e] = tile[(e / rows) * P + e % rows];
   }
 }
+// strided variants (leading dimension ld != rows: the columns are windows of a taller matrix — Stacked segments):
+// consecutive lanes walk the rows of a column, 4- / 8-byte accesses, runs of `rows` contiguous elements
+template <class T>
+__device__ __forceinline__ void tile_stage_in_ld(T* tile, const T* __restrict__ src, int rows, int64_t ld, int P, int ncols, int lane) {
+  const int ne = ncols * rows;
+  const int dc = 64 / rows, dr = 64 % rows;
+  int c = lane / rows, r = lane % rows;
+  for (int e = lane; e < ne; e += 64) {
+    tile[c * P + r] = src[(int64_t)c * ld + r];
+    c += dc; r += dr;
+    if (r >= rows) { r -= rows; ++c; }
+  }
+}
+template <class T>
+__device__ __forceinline__ void tile_stage_out_ld(const T* tile, T* __restrict__ dst, int rows, int64_t ld, int P, int ncols, int lane) {
+  const int ne = ncols * rows;
+  const int dc = 64 / rows, dr = 64 % rows;
+  int c = lane / rows, r = lane % rows;
+  for (int e = lane; e < ne; e += 64) {
+    dst[(int64_t)c * ld + r] = tile[c * P + r];
+    c += dc; r += dr;
+    if (r >= rows) { r -= rows; ++c; }
+  }
+}
 // single-wave block: the LDS queue is in order, only pin the compiler
 __device__ __forceinline__ void tile_sync() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 
@@ -256,7 +280,7 @@ __device__ __forceinline__ void tile_sync() { asm volatile("" ::: "memory"); __b
 template <class T, class Op, int V>
 __global__ __launch_bounds__(64) void seq_wave_kernel(Op op0, const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps,
                                                      int rows_in, int rows_out, int P, int64_t batch, int n_logk, int accumulate,
-                                                     const BjxFin fin) {
+                                                     const BjxFin fin, int64_t ld_in, int64_t ld_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double red[1];
   T* tile = reinterpret_cast<T*>(smem);
@@ -265,7 +289,8 @@ __global__ __launch_bounds__(64) void seq_wave_kernel(Op op0, const T* __restric
   for (int i = lane; i < n_logk; i += 64) logk[i] = d_log(T(n_logk - i));      // log(K-1-i), simplex.jl:35,41
   const int64_t col0 = (int64_t)blockIdx.x * 64;
   const int ncols = (int)((batch - col0) < 64 ? (batch - col0) : 64);
-  tile_stage_in<T, V>(tile, in + col0 * rows_in, rows_in, P, ncols, lane);
+  if (ld_in == rows_in) tile_stage_in<T, V>(tile, in + col0 * rows_in, rows_in, P, ncols, lane);
+  else tile_stage_in_ld<T>(tile, in + col0 * ld_in, rows_in, ld_in, P, ncols, lane);
   tile_sync();
   // ---- walk: lane = column
   T lres = T(0);
@@ -292,13 +317,19 @@ __global__ __launch_bounds__(64) void seq_wave_kernel(Op op0, const T* __restric
     if (ladj_ps) ladj_ps[col0 + lane] = accumulate ? ladj_ps[col0 + lane] + lres : lres;
   }
   tile_sync();
-  if (out) tile_stage_out<T, V>(tile, out + col0 * rows_out, rows_out, P, ncols, lane);
+  if (out) {
+    if (ld_out == rows_out) tile_stage_out<T, V>(tile, out + col0 * rows_out, rows_out, P, ncols, lane);
+    else tile_stage_out_ld<T>(tile, out + col0 * ld_out, rows_out, ld_out, P, ncols, lane);
+  }
   block_publish_partial(lane < ncols ? (double)lres : 0.0, red, fin);
 }
 
 template <class T, class Op>
 int launch_seq(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t rows_in, int64_t rows_out,
-               int64_t batch, int n_logk, uint32_t flags) {
+               int64_t batch, int n_logk, uint32_t flags, int64_t ld_in = 0, int64_t ld_out = 0) {
+  if (ld_in == 0) ld_in = rows_in;
+  if (ld_out == 0) ld_out = rows_out;
+  const bool strided = ld_in != rows_in || ld_out != rows_out;
   if (batch == 0) {
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
     return BJX_OK;
@@ -320,16 +351,17 @@ int launch_seq(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, doub
       // two-pass finalize here.
       if (fin.counter) { fin.counter = nullptr; second = true; }
       constexpr int VW = Vec16<T>::N;
-      const bool v_ok = bjx_aligned16(in) && (!out || bjx_aligned16(out));
+      const bool v_ok = bjx_aligned16(in) && (!out || bjx_aligned16(out)) && !(ld_in != rows_in && ld_out != rows_out);
       const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
       { BjxProf prof_(ctx);
-      if (v_ok) hipLaunchKernelGGL((seq_wave_kernel<T, Op, VW>), dim3((unsigned)grid), dim3(64), smem_w, ctx->stream, op, in, out, ladj_ps, (int)rows_in, (int)rows_out, (int)P, batch, n_logk, accum, fin);
-      else hipLaunchKernelGGL((seq_wave_kernel<T, Op, 1>), dim3((unsigned)grid), dim3(64), smem_w, ctx->stream, op, in, out, ladj_ps, (int)rows_in, (int)rows_out, (int)P, batch, n_logk, accum, fin); }
+      if (v_ok) hipLaunchKernelGGL((seq_wave_kernel<T, Op, VW>), dim3((unsigned)grid), dim3(64), smem_w, ctx->stream, op, in, out, ladj_ps, (int)rows_in, (int)rows_out, (int)P, batch, n_logk, accum, fin, ld_in, ld_out);
+      else hipLaunchKernelGGL((seq_wave_kernel<T, Op, 1>), dim3((unsigned)grid), dim3(64), smem_w, ctx->stream, op, in, out, ladj_ps, (int)rows_in, (int)rows_out, (int)P, batch, n_logk, accum, fin, ld_in, ld_out); }
       BJX_CHECK_LAUNCH(ctx);
       if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
       return BJX_OK;
     }
   }
+  BJX_REQUIRE(ctx, !strided, BJX_ERR_UNSUPPORTED, "columns of %lld rows with a leading dimension exceed the LDS tile kernel", (long long)(rows_in > rows_out ? rows_in : rows_out));
   constexpr int C = SeqCfg<T>::C, NT = SeqCfg<T>::NT;
   const size_t smem = 32 + ((size_t)NT * (C + 1) + (size_t)n_logk) * sizeof(T);
   BJX_REQUIRE(ctx, smem <= 64 * 1024, BJX_ERR_UNSUPPORTED, "simplex: K = %d too large for the LDS log-table", n_logk + 1);
@@ -2245,7 +2277,13 @@ int launch_simplex_vjp_stream(bjx_ctx* ctx, int inverse, const T* in, const T* o
 }
 
 template <class T>
-int ordered_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
+int ordered_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags,
+                 int64_t ld_in = 0, int64_t ld_out = 0) {
+  const bool strided = (ld_in && ld_in != dim) || (ld_out && ld_out != dim);
+  if (strided) {
+    if (!inverse) return launch_seq<T>(ctx, OrderedFwd<T>{}, in, out, ladj_ps, ladj_sum, dim, dim, batch, 0, flags, ld_in, ld_out);
+    return launch_seq<T>(ctx, OrderedInv<T>{}, in, out, ladj_ps, ladj_sum, dim, dim, batch, 0, flags, ld_in, ld_out);
+  }
   {
     bool taken = false;
     const int rc = !inverse ? launch_quad_stream<T>(ctx, QOrderedFwd<T>{}, in, out, ladj_ps, ladj_sum, dim, batch, flags, &taken)
@@ -2257,10 +2295,13 @@ int ordered_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, dou
 }
 
 template <class T>
-int simplex_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags) {
+int simplex_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags,
+                 int64_t ld_in = 0, int64_t ld_out = 0) {
   const bool want = ladj_ps || ladj_sum;
   const int nlk = (int)(K - 1);
-  {
+  const int64_t ri = inverse ? K - 1 : K, ro = inverse ? K : K - 1;
+  const bool strided = (ld_in && ld_in != ri) || (ld_out && ld_out != ro);
+  if (!strided) {
     bool taken = false;
     int rc = BJX_OK;
     if (!inverse) rc = want ? launch_quad_stream<T>(ctx, QSimplexFwd<T, true>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken)
@@ -2286,13 +2327,13 @@ int simplex_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, dou
     if (rc || taken) return rc;
   }
   if (!inverse) {
-    if (want) { SimplexFwd<T, true> op; op.K = K; return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K, K - 1, batch, nlk, flags); }
+    if (want) { SimplexFwd<T, true> op; op.K = K; return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K, K - 1, batch, nlk, flags, ld_in, ld_out); }
     SimplexFwd<T, false> op; op.K = K;
-    return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K, K - 1, batch, nlk, flags);
+    return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K, K - 1, batch, nlk, flags, ld_in, ld_out);
   }
-  if (want) { SimplexInv<T, true> op; op.K = K; return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K - 1, K, batch, nlk, flags); }
+  if (want) { SimplexInv<T, true> op; op.K = K; return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K - 1, K, batch, nlk, flags, ld_in, ld_out); }
   SimplexInv<T, false> op; op.K = K;
-  return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K - 1, K, batch, nlk, flags);
+  return launch_seq<T>(ctx, op, in, out, ladj_ps, ladj_sum, K - 1, K, batch, nlk, flags, ld_in, ld_out);
 }
 }  // namespace
 
@@ -2552,4 +2593,26 @@ BJX_API int bjx_vec_cholesky(bjx_ctx* ctx, bjx_dtype dt, int inverse, int uplo, 
   if (dt == BJX_F32) return chol_impl<float>(ctx, inverse, uplo, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, K, batch, flags);
   if (dt == BJX_F64) return chol_impl<double>(ctx, inverse, uplo, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, K, batch, flags);
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_vec_cholesky: bad dtype %d", (int)dt);
+}
+
+/* Leading-dimension variants: the columns are windows [row0, row0 + rows) of a taller matrix (segments of a Stacked,
+ * stacked.jl:142-166); in / out point at the first row of the window in column 0.  One-lane-per-column LDS tile kernel. */
+BJX_API int bjx_ordered_ld(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, int64_t ld_in, void* out, int64_t ld_out, void* ladj_ps,
+                           double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0 && ld_in >= dim && ld_out >= dim, BJX_ERR_SHAPE, "bjx_ordered_ld: bad size");
+  BJX_REQUIRE(ctx, (in && out) || batch == 0, BJX_ERR_ARG, "bjx_ordered_ld: null pointer");
+  if (dt == BJX_F32) return ordered_impl<float>(ctx, inverse, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, batch, flags, ld_in, ld_out);
+  if (dt == BJX_F64) return ordered_impl<double>(ctx, inverse, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, batch, flags, ld_in, ld_out);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_ordered_ld: bad dtype %d", (int)dt);
+}
+BJX_API int bjx_simplex_ld(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, int64_t ld_in, void* out, int64_t ld_out, void* ladj_ps,
+                           double* ladj_sum, int64_t K, int64_t batch, uint32_t flags) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, K > 1, BJX_ERR_SHAPE, "bjx_simplex_ld: x needs to be of length greater than 1 (simplex.jl:30), got K=%lld", (long long)K);
+  BJX_REQUIRE(ctx, batch >= 0 && ld_in >= (inverse ? K - 1 : K) && ld_out >= (inverse ? K : K - 1), BJX_ERR_SHAPE, "bjx_simplex_ld: bad size");
+  BJX_REQUIRE(ctx, (in && out) || batch == 0, BJX_ERR_ARG, "bjx_simplex_ld: null pointer");
+  if (dt == BJX_F32) return simplex_impl<float>(ctx, inverse, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, K, batch, flags, ld_in, ld_out);
+  if (dt == BJX_F64) return simplex_impl<double>(ctx, inverse, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, K, batch, flags, ld_in, ld_out);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_simplex_ld: bad dtype %d", (int)dt);
 }

@@ -286,16 +286,20 @@ template <class T, bool GATHER, bool IN_LDS> struct StackedF {
 struct StackedPlan { char* tab; size_t tab_bytes; bool gather; int two; int V; };
 
 // validates the segment list, uploads it and launches the table build; `x`/`y` only decide the pack width
+// `ldx` = rows of the input matrix (== dim unless the call is bjx_stacked_ld: the segments then read rows of a taller /
+// shorter matrix and every row is gathered), `ldy` = rows of the output matrix (>= dim)
 template <class T>
 int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const void* x, const void* y, int64_t dim, int64_t batch, bool inplace_check,
-                    bool packs_ok, StackedPlan* plan) {
+                    bool packs_ok, StackedPlan* plan, int64_t ldx = 0, int64_t ldy = 0) {
+  if (ldx == 0) ldx = dim;
+  if (ldy == 0) ldy = dim;
   // validate on the host: every output row and every input row exactly once (stacked.jl:156-165 checks the lengths)
   int64_t total = 0;
   int max_ops = 0;
   bool gather = false;
   for (int s = 0; s < n_segs; ++s) {
     const bjx_segment& g = segs[s];
-    BJX_REQUIRE(ctx, g.len >= 0 && g.in_lo >= 0 && g.out_lo >= 0 && g.in_lo + g.len <= dim && g.out_lo + g.len <= dim, BJX_ERR_SHAPE,
+    BJX_REQUIRE(ctx, g.len >= 0 && g.in_lo >= 0 && g.out_lo >= 0 && g.in_lo + g.len <= ldx && g.out_lo + g.len <= dim, BJX_ERR_SHAPE,
                 "bjx_stacked: segment %d [%lld, +%lld) is outside the %lld rows", s, (long long)g.in_lo, (long long)g.len, (long long)dim);
     BJX_REQUIRE(ctx, g.n_ops >= 0 && g.n_ops <= BJX_MAX_SEG_OPS, BJX_ERR_ARG, "bjx_stacked: segment %d has %d ops (max %d)", s, g.n_ops, BJX_MAX_SEG_OPS);
     for (int k = 0; k < g.n_ops; ++k)
@@ -305,6 +309,7 @@ int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const voi
     if (g.n_ops > max_ops) max_ops = g.n_ops;
     if (g.in_lo != g.out_lo) gather = true;
   }
+  if (ldx != dim || ldy != dim) gather = true;
   BJX_REQUIRE(ctx, total == dim, BJX_ERR_SHAPE, "input length mismatch (%lld != %lld)", (long long)total, (long long)dim);   // stacked.jl:157
   const size_t seg_bytes = ((size_t)n_segs * sizeof(SegDev) + 63) / 64 * 64;
   const size_t tab_bytes = (size_t)dim * stacked_row_bytes<T>();
@@ -370,7 +375,7 @@ int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const voi
     BJX_HIP(ctx, hipEventRecord(ctx->stage_ev, ctx->stream));
   }
   // the main kernel's pack width decides the row permutation of the table (same rule as col_launch_cfg)
-  ColLaunch cl = col_launch_cfg<T>(ctx, x, y, dim, batch);
+  ColLaunch cl = col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy);
   if (!packs_ok) cl.V = 1;                               // a third buffer of the caller is not 16-byte aligned
   hipLaunchKernelGGL(stacked_table_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, dseg, n_segs, dim, cl.V, tab, flag);
   BJX_CHECK_LAUNCH(ctx);
@@ -380,18 +385,18 @@ int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const voi
 
 template <class T>
 int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, T* y, T* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch,
-                 uint32_t flags) {
+                 uint32_t flags, int64_t ldx = 0, int64_t ldy = 0) {
   if (dim * batch == 0) {
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
     return BJX_OK;
   }
   StackedPlan pl;
-  { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, y, dim, batch, true, true, &pl); if (rc) return rc; }
+  { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, y, dim, batch, true, true, &pl, ldx, ldy); if (rc) return rc; }
   char* tab = pl.tab;
   const int two = pl.two;
   const bool lds = pl.tab_bytes <= 48 * 1024;
   const size_t fsm = lds ? pl.tab_bytes : 0;
-#define STK_LAUNCH(G_, L_) do { StackedF<T, G_, L_> f{tab, dim, two, 0.0, nullptr}; return launch_colgroup<T>(ctx, f, fsm, x, y, ladj_ps, ladj_sum, dim, batch, flags, 0.0); } while (0)
+#define STK_LAUNCH(G_, L_) do { StackedF<T, G_, L_> f{tab, dim, two, 0.0, nullptr}; return launch_colgroup<T>(ctx, f, fsm, x, y, ladj_ps, ladj_sum, dim, batch, flags, 0.0, ldx, ldy); } while (0)
   if (pl.gather) { if (lds) STK_LAUNCH(true, true); else STK_LAUNCH(true, false); }
   if (lds) STK_LAUNCH(false, true);
   STK_LAUNCH(false, false);
@@ -607,6 +612,22 @@ BJX_API int bjx_stacked(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int
   if (dt == BJX_F32) return stacked_impl<float>(ctx, segs, n_segs, (const float*)x, (float*)y, (float*)ladj_ps, ladj_sum, dim, batch, flags);
   if (dt == BJX_F64) return stacked_impl<double>(ctx, segs, n_segs, (const double*)x, (double*)y, (double*)ladj_ps, ladj_sum, dim, batch, flags);
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_stacked: bad dtype %d", (int)dt);
+}
+
+/* bjx_stacked with separate leading dimensions: x is [ldx, batch], y is [ldy, batch], the segments produce the first `dim`
+ * rows of y from any rows of x (every row is gathered).  What a Stacked with structured segments needs (stacked.jl:142-166):
+ * the elementwise segments in ONE launch here (the rows of the structured segments are covered by identity placeholders),
+ * then the structured entry points with a leading dimension (bjx_simplex_ld, bjx_ordered_ld) overwrite their rows in place. */
+BJX_API int bjx_stacked_ld(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const void* x, int64_t ldx, void* y, int64_t ldy,
+                           void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 0 && batch >= 0 && n_segs >= 0 && ldx >= 0 && ldy >= dim, BJX_ERR_SHAPE, "bjx_stacked_ld: bad size");
+  BJX_REQUIRE(ctx, (segs || n_segs == 0) && ((x && y) || dim * batch == 0), BJX_ERR_ARG, "bjx_stacked_ld: null pointer");
+  BJX_REQUIRE(ctx, x != y, BJX_ERR_ARG, "bjx_stacked_ld: in-place is not supported");
+  BJX_REQUIRE(ctx, dim < ((int64_t)1 << 31) && ldx < ((int64_t)1 << 31), BJX_ERR_UNSUPPORTED, "bjx_stacked_ld: too many rows");
+  if (dt == BJX_F32) return stacked_impl<float>(ctx, segs, n_segs, (const float*)x, (float*)y, (float*)ladj_ps, ladj_sum, dim, batch, flags, ldx, ldy);
+  if (dt == BJX_F64) return stacked_impl<double>(ctx, segs, n_segs, (const double*)x, (double*)y, (double*)ladj_ps, ladj_sum, dim, batch, flags, ldx, ldy);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_stacked_ld: bad dtype %d", (int)dt);
 }
 
 BJX_API int bjx_stacked_vjp_moments(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const void* x, const void* y_bar,

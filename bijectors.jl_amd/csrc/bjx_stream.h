@@ -35,7 +35,9 @@ constexpr int COL_UC = 4;   // columns in flight per lane group (one 16-byte pac
 
 template <class T, int V, bool NT, class F>
 __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T* y, T* ladj_ps, int64_t dim,
-                                                       int64_t batch, int G, int accumulate, const BjxFin fin) {
+                                                       int64_t batch, int G, int accumulate, const BjxFin fin, int64_t ldx, int64_t ldy) {
+  // ldx / ldy: leading dimensions of x / y (== dim for a dense [dim, batch] array; larger when the `dim` rows are a
+  // window of a taller matrix — Stacked segments, stacked.jl:142-166)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* red = reinterpret_cast<double*>(smem);   // first 32 bytes
   char* fsm = smem + 32;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
 #pragma unroll
     for (int u = 0; u < COL_UC; ++u) {
       const int64_t col = col0 + (int64_t)u * cols_per_block;
-      if (F::kLoadInput && lane_ok && col < batch) p[u] = load_pack<T, V, NT>(x + col * dim + (int64_t)gl * V);
+      if (F::kLoadInput && lane_ok && col < batch) p[u] = load_pack<T, V, NT>(x + col * ldx + (int64_t)gl * V);
       if constexpr (col_has_aux<F>::value) { if (lane_ok && col < batch) aux[u] = f.template fetch<V>(fsm, (int64_t)gl * V, col); }
     }
     T lm[COL_UC];
@@ -76,9 +78,9 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
       T l = T(0);
       if (lane_ok && col < batch) {
         if constexpr (col_has_multi<F>::value) l = lm[u];
-        else if constexpr (col_has_aux<F>::value) l = f.template apply<V>(fsm, p[u], aux[u], x + col * dim, (int64_t)gl * V, col);
-        else l = f.template apply<V>(fsm, p[u], x + col * dim, (int64_t)gl * V, col);
-        store_pack<T, V, NT>(y + col * dim + (int64_t)gl * V, p[u]);
+        else if constexpr (col_has_aux<F>::value) l = f.template apply<V>(fsm, p[u], aux[u], x + col * ldx, (int64_t)gl * V, col);
+        else l = f.template apply<V>(fsm, p[u], x + col * ldx, (int64_t)gl * V, col);
+        store_pack<T, V, NT>(y + col * ldy + (int64_t)gl * V, p[u]);
       }
       l = group_sum_rt(l, G);
       if (col < batch && gl == 0) {
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
       const int64_t col = col0 + (int64_t)uc * cols_per_block;
       T l = T(0);
       if (col < batch) {
-        const T* xc = x + col * dim;
-        T* yc = y + col * dim;
+        const T* xc = x + col * ldx;
+        T* yc = y + col * ldy;
         for (int64_t v0 = 0; v0 < nvc; v0 += (int64_t)G * STREAM_U) {
           Pack<T, V> p[STREAM_U];
           typename col_aux_of<F>::type aux[STREAM_U];
@@ -137,10 +139,11 @@ struct ColLaunch {
 };
 
 // choose pack width / lanes per column / grid for a [dim, batch] problem
-template <class T> inline ColLaunch col_launch_cfg(const bjx_ctx* ctx, const void* x, const void* y, int64_t dim, int64_t batch) {
+template <class T> inline ColLaunch col_launch_cfg(const bjx_ctx* ctx, const void* x, const void* y, int64_t dim, int64_t batch, int64_t ldx = 0,
+                                                   int64_t ldy = 0) {
   ColLaunch c;
   constexpr int VW = Vec16<T>::N;
-  const bool v_ok = bjx_aligned16(x) && bjx_aligned16(y) && dim % VW == 0;
+  const bool v_ok = bjx_aligned16(x) && bjx_aligned16(y) && dim % VW == 0 && ldx % VW == 0 && ldy % VW == 0;
   c.V = v_ok ? VW : 1;
   const int64_t packs = dim / c.V;
   int G = 1;
@@ -154,12 +157,15 @@ template <class T> inline ColLaunch col_launch_cfg(const bjx_ctx* ctx, const voi
 
 template <class T, class F>
 inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, T* y, T* ladj_ps, double* ladj_sum,
-                           int64_t dim, int64_t batch, uint32_t flags, double sum_const) {
+                           int64_t dim, int64_t batch, uint32_t flags, double sum_const, int64_t ldx = 0, int64_t ldy = 0, int force_v1 = 0) {
+  if (ldx == 0) ldx = dim;
+  if (ldy == 0) ldy = dim;
   if (dim * batch == 0) {
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
     return BJX_OK;
   }
-  ColLaunch c = col_launch_cfg<T>(ctx, x, y, dim, batch);
+  ColLaunch c = col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy);
+  if (force_v1 && c.V != 1) { c.V = 1; int G = 1; while (G < 64 && G < dim) G <<= 1; c.G = G; const int64_t cpb = (int64_t)(256 / G) * COL_UC; c.grid = (batch + cpb - 1) / cpb; }
   constexpr int VW = Vec16<T>::N;
   const size_t smem = 32 + f_smem;
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
@@ -170,9 +176,9 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
   {
   BjxProf prof_(ctx);
   if (c.V == VW)
-    hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin);
+    hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy);
   else
-    hipLaunchKernelGGL((colgroup_kernel<T, 1, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin);
+    hipLaunchKernelGGL((colgroup_kernel<T, 1, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy);
   }
   BJX_CHECK_LAUNCH(ctx);
   if (second) return bjx_launch_finalize(ctx, (int)c.grid, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, 0.0, flags);

@@ -1260,6 +1260,17 @@ class Coupling(Bijector):
         x2 = xc[i2].detach().clone().requires_grad_(True) if vec else xc[i2, :].detach().clone().requires_grad_(True)
         with torch.enable_grad():
             law = self.theta(x2)
+            if isinstance(law, RationalQuadraticSpline):
+                # spline law (coupling.jl:206-259 with b = RationalQuadraticSpline(w, h, d), knots shared by the batch):
+                # x̄₁ = the elementwise spline pullback on the x₁ rows (bjx_rqs_vjp), every other row passes ȳ through.
+                # (Knot cotangents are not produced, so nothing flows back through θ.)
+                i1 = self.mask.idx1_dev(xc.device).long()
+                x1 = colmajor(xc[i1] if not vec else xc[i1])
+                g1 = colmajor(gc[i1])
+                sub = vjp(inverse(law) if inv else law, x1, g1, ladj_bar)
+                xb = gc.clone() if vec else colmajor(gc.clone())
+                xb[i1] = sub
+                return xb
             scale = shift = None
             for st in (law._stages() if isinstance(law, ComposedFunction) else [law]):
                 if isinstance(st, Scale) and scale is None and shift is None:
@@ -1402,6 +1413,83 @@ class Stacked(Transform):
         L.check(ctx.h, rc, "bjx_stacked_vjp")
         return xb
 
+    def _wlj_in_place(self, xc, dim, batch, vec, y, out, segs_ops, fused, rest, per_sample, want_ladj, ctx):
+        """The copy-free path for Stacked with Simplex / Ordered segments; None when a segment has no `_ld` entry point."""
+        def struct_of(b):
+            inv = isinstance(b, Inverse)
+            base = b.orig if inv else b
+            if isinstance(base, SimplexBijector):
+                return "bjx_simplex_ld", inv
+            if isinstance(base, OrderedBijector):
+                return "bjx_ordered_ld", inv
+            return None
+        if vec or batch == 0 or any(struct_of(self.bs[i]) is None for i in rest):
+            return None
+        if any((self.ranges_in[i][1] - self.ranges_in[i][0] + 1) > 250 for i in rest):     # LDS tile of the strided kernel
+            return None
+        dout = self.length_out
+        ps = torch.zeros(batch, dtype=xc.dtype, device=xc.device) if (want_ladj and out.ps is not None) else None
+        sm = torch.zeros(1, dtype=torch.float64, device=xc.device) if (want_ladj and out.sum is not None) else None
+        lib = L.load()
+        if fused:
+            segs = []
+            for i in range(len(self.bs)):
+                (lo, hi), (olo, ohi) = self.ranges_in[i], self.ranges_out[i]
+                if i in fused:
+                    segs.append((lo - 1, olo - 1, hi - lo + 1, segs_ops[i]))
+                else:                                            # placeholder: identity from any valid rows, overwritten in step 2
+                    n_out = ohi - olo + 1
+                    if n_out > dim:
+                        return None
+                    segs.append((min(lo - 1, dim - n_out), olo - 1, n_out, []))
+            arr = (L.BjxSegment * len(segs))()
+            keep = []
+            for si, (ilo, olo0, ln, ops) in enumerate(segs):
+                sg = arr[si]
+                sg.in_lo, sg.out_lo, sg.len, sg.n_ops = ilo, olo0, ln, len(ops)
+                for k, (kind, p0, p1) in enumerate(ops):
+                    o = sg.ops[k]
+                    o.kind, o.param_len, o.p0, o.p1, o.v0, o.v1 = kind, 0, 0.0, 0.0, None, None
+                    seq = any(_is_seq(p) for p in (p0, p1) if p is not None)
+                    for j, p in enumerate((p0, p1)):
+                        if p is None:
+                            continue
+                        if seq:
+                            t = _param(p, xc).reshape(-1) if _is_seq(p) else torch.full((ln,), float(p), dtype=xc.dtype, device=xc.device)
+                            if t.numel() != ln:
+                                raise ValueError(f"DimensionMismatch: parameter of length {t.numel()} for a segment of {ln} rows")
+                            keep.append(t)
+                            o.param_len = ln
+                            setattr(o, f"v{j}", t.data_ptr())
+                        else:
+                            o.param_len = 1
+                            setattr(o, f"p{j}", float(p))
+            rc = lib.bjx_stacked_ld(ctx.h, _dt(xc), arr, len(segs), _ptr(xc), dim, _ptr(y), dout, _ptr(ps), _ptr(sm), dout, batch, 0)
+            del keep
+            if rc == L.ERR_UNSUPPORTED:
+                return None
+            L.check(ctx.h, rc, "bjx_stacked_ld")
+        es = xc.element_size()
+        for i in rest:
+            fn, inv = struct_of(self.bs[i])
+            (lo, hi), (olo, ohi) = self.ranges_in[i], self.ranges_out[i]
+            n_in, n_out = hi - lo + 1, ohi - olo + 1
+            size = (n_out if inv else n_in) if fn == "bjx_simplex_ld" else n_in          # K of the simplex side / rows of Ordered
+            rc = getattr(lib, fn)(ctx.h, _dt(xc), int(inv), C.c_void_p(xc.data_ptr() + (lo - 1) * es), dim,
+                                  C.c_void_p(y.data_ptr() + (olo - 1) * es), dout, _ptr(ps), _ptr(sm), size, batch, L.BJX_ACCUMULATE)
+            if rc == L.ERR_UNSUPPORTED:
+                return None
+            L.check(ctx.h, rc, fn)
+        if not want_ladj:
+            return y, None
+        if out.both:
+            return y, (ps, sm)
+        if out.sum64:
+            return y, sm
+        if per_sample:
+            return y, ps
+        return y, sm[0].to(xc.dtype)
+
     def _wlj(self, x, per_sample, want_ladj=True):
         xc, dim, batch, vec = _prep(x)
         if dim != self.length_in:
@@ -1419,6 +1507,12 @@ class Stacked(Transform):
             if rc != L.ERR_UNSUPPORTED:   # a chain with > 2 nonlinear stages is evaluated per segment below
                 L.check(ctx.h, rc, "bjx_stacked")
                 return (y, out.result(vec_scalar=vec and bool(per_sample) and per_sample is True)) if want_ladj else (y, None)
+        # structured segments (Simplex / Ordered blocks): no slicing copies — the elementwise segments in one
+        # bjx_stacked_ld launch (identity placeholders on the structured rows), then the structured entry points with a
+        # leading dimension overwrite their rows in place and ACCUMULATE their log-dets
+        r_ = self._wlj_in_place(xc, dim, batch, vec, y, out, segs_ops, fused, rest, per_sample, want_ladj, ctx)
+        if r_ is not None:
+            return r_
         # general case: per-segment launches on row slices (copies); log-dets are summed like :236-244
         total = None
         x2 = xc if not vec else xc[:, None]
@@ -1732,6 +1826,8 @@ def vjp_params(b, x, out_bar, ladj_bar=None):
     For a chain that starts with Scale and/or Shift: (z_bar, {"scale": σ̄, "shift": μ̄}) — see _vjp_params_leading_affine."""
     if isinstance(b, RadialLayer):
         return _vjp_params_radial(b, x, out_bar, ladj_bar)
+    if isinstance(b, InvertibleBatchNorm):
+        return _vjp_params_batchnorm(b, x, out_bar, ladj_bar)
     if not isinstance(b, PlanarLayer):
         return _vjp_params_leading_affine(b, x, out_bar, ladj_bar)
     xc, dim, batch, vec = _prep(x)
@@ -1756,6 +1852,27 @@ def vjp_params(b, x, out_bar, ladj_bar=None):
     if two_d:
         wb, ub = wb.T, ub.T                       # back to (dim, n_layers)
     return xb, {"w": wb, "u": ub, "b": bbar}
+
+
+def _vjp_params_batchnorm(bn, x, out_bar, ladj_bar=None):
+    """InvertibleBatchNorm in eval mode (normalise.jl:39 marks `b, logs` trainable): y = γ (x − m) + b, γ = exp(logs)/√(v+ε),
+    logabsdetjac[n] = Σ_c (logs_c − ½ log(v_c+ε)).  x̄ = γ ȳ;  b̄ = Σ_n ȳ;  l̄ogs_c = Σ_n ȳ_{c,n} (y_{c,n} − b_c) + Σ_n ℓ̄_n.
+    ONE pass: the input pullback of the affine chain with its row moments (bjx_stacked_vjp_moments: Σ_n x̄ and Σ_n x̄·x),
+    from which b̄ = Σx̄/γ and l̄ogs = Σx̄x − m Σx̄ + Σℓ̄.  -> (x_bar, {"b": ..., "logs": ...})."""
+    if istraining():
+        raise NotImplementedError("parameter pullback of InvertibleBatchNorm: eval mode only (the training-mode statistics are not differentiated)")
+    xc, dim, batch, vec = _prep(x)
+    if vec:
+        raise ValueError("InvertibleBatchNorm needs an input with at least 2 dimensions")
+    logs, v, m, bb = (_param(t, xc) for t in (bn.logs, bn.v, bn.m, bn.b))
+    gam = torch.exp(logs) / torch.sqrt(v + bn.eps)
+    aff = Shift(bb) @ Scale(gam) @ Shift(-m)
+    xb, m1, m2 = Stacked([aff], [(1, dim)])._vjp(x, out_bar, ladj_bar, moments=True)
+    lb = _ladj_bar(ladj_bar, batch, xc)
+    lsum = lb.double().sum() if lb is not None else 0.0
+    b_bar = (m1 / gam.double()).to(xc.dtype)
+    logs_bar = (m2 - m.double() * m1 + lsum).to(xc.dtype)
+    return xb, {"b": b_bar, "logs": logs_bar}
 
 
 def _vjp_params_radial(b, x, out_bar, ladj_bar=None):

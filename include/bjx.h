@@ -358,6 +358,20 @@ typedef struct {
 int bjx_stacked(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const void* x, void* y,
                 void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
 
+/* Stacked with STRUCTURED segments (Simplex / Ordered blocks of a Turing model) without slicing copies, stacked.jl:142-166:
+ *   1. bjx_stacked_ld — the elementwise segments in ONE launch between matrices of different heights: x is [ldx, batch],
+ *      y is [ldy, batch], the segments (row ranges of x -> row ranges of y, every one of the first `dim` rows of y exactly
+ *      once) are gathered row by row; rows that belong to a structured segment are covered by identity placeholders.
+ *   2. bjx_simplex_ld / bjx_ordered_ld — the structured bijector on a row window of the same matrices: `in` / `out` point at
+ *      the first row of the window in column 0, ld_in / ld_out are the heights of the matrices; with BJX_ACCUMULATE the
+ *      log-dets add to the ones of step 1.  (VecCholesky / Corr / PD have a matrix on one side and cannot be Stacked segments.) */
+int bjx_stacked_ld(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const void* x, int64_t ldx, void* y, int64_t ldy,
+                   void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
+int bjx_ordered_ld(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, int64_t ld_in, void* out, int64_t ld_out,
+                   void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
+int bjx_simplex_ld(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, int64_t ld_in, void* out, int64_t ld_out,
+                   void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags);
+
 /* ------------------------------- reverse-mode pullbacks (first rows)  */
 /* Pullback of with_logabsdet_jacobian for one launch over the batch:
  *     in_bar = J(in)^T * out_bar + ladj_bar * grad_in logabsdetjac

@@ -1859,14 +1859,16 @@ def test_nan_inputs_poison_exactly_what_the_reference_poisons(bj, orc, dt, val):
         b = bj.inverse(bj.OrderedBijector()) if inv else bj.OrderedBijector()
         y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
         check(f"ordered inv={inv}", y, l, y_ref, l_ref, scale=100)
-    if np.isnan(val):
-        # ±Inf is outside the parity contract of the fused flow kernels: they reassociate the layer recurrence
-        # (w_kᵀz_{k-1} = w_kᵀz_0 + Σ_j (w_kᵀû_j)t_j, zero-padded layer groups), and 0·Inf poisons the whole column
-        w = (r.normal(size=(dim, 3)) / 8).astype(dt); u = (r.normal(size=(dim, 3)) / 8).astype(dt); bb = r.normal(size=3).astype(dt)
+    # the fused flow kernels reassociate the layer recurrence (w_kᵀz_{k-1} = w_kᵀz_0 + Σ_j (w_kᵀû_j)t_j) and pad layer
+    # groups with zero layers; a padding layer's tanh is forced to 0, so a ±Inf input keeps the finite rows finite as
+    # in the reference (0·Inf of a padding layer would poison the whole column)
+    for nlay in (3, 8, 11):
+        w = (r.normal(size=(dim, nlay)) / 8).astype(dt); u = (r.normal(size=(dim, nlay)) / 8).astype(dt); bb = r.normal(size=nlay).astype(dt)
         fl = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(bb))
         y_ref, l_ref = orc.planar(w, u, bb, X)
         y, l = bj.with_logabsdet_jacobian(fl, dev(X))
-        check("planar", y, l, y_ref, l_ref)
+        check(f"planar {nlay} layers", y, l, y_ref, l_ref)
+    if np.isnan(val):
         z0 = r.normal(size=dim).astype(dt)
         rad = bj.RadialLayer(torch.tensor(np.array([0.2], dtype=dt)), torch.tensor(np.array([0.4], dtype=dt)), torch.tensor(z0))
         y_ref, l_ref = orc.radial(np.array([0.2]), np.array([0.4]), z0, X)
@@ -2394,3 +2396,99 @@ def test_planar_float64_matrix_core_kernel(bj, orc, dim, nl, N):
     close(host(lp), lp_ref, np.float64, scale=dim, what="fused logpdf f64")
     _, _, ls = bj.shard.with_logabsdet_jacobian_sharded(fl, dev(Z))
     sum_close(ls, l_ref.sum(), np.float64, N * nl)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_batchnorm_parameter_pullback(bj, dt):
+    """normalise.jl:39 (`b, logs` trainable), eval mode: closed forms in Float64 + finite differences through the oracle-free
+    formula y = exp(logs)(x − m)/√(v+ε) + b, ladj = Σ(logs − ½log(v+ε))."""
+    r = rng(41)
+    dim, N = 24, 700
+    b_, logs = r.normal(size=dim), 0.3 * r.normal(size=dim)
+    m, v = r.normal(size=dim), r.uniform(0.5, 2, size=dim)
+    X, G, lb = r.normal(size=(dim, N)), r.normal(size=(dim, N)), r.normal(size=N)
+    bn = bj.InvertibleBatchNorm(torch.tensor(b_.astype(dt)), torch.tensor(logs.astype(dt)), torch.tensor(m.astype(dt)), torch.tensor(v.astype(dt)), eps=1e-5)
+    xb, pb = bj.vjp_params(bn, dev(np.asfortranarray(X.astype(dt))), dev(np.asfortranarray(G.astype(dt))), dev(lb.astype(dt)))
+    gam = np.exp(logs) / np.sqrt(v + 1e-5)
+    Y = gam[:, None] * (X - m[:, None]) + b_[:, None]
+    close(host(xb), gam[:, None] * G, dt, scale=5, what="x_bar")
+    close(host(pb["b"]), G.sum(axis=1), dt, scale=math.sqrt(N) * 5, what="b_bar")
+    close(host(pb["logs"]), (G * (Y - b_[:, None])).sum(axis=1) + lb.sum(), dt, scale=math.sqrt(N) * 20, what="logs_bar")
+
+    def F(b2, l2):                                                  # scalar objective <y, G> + <ladj, lb>
+        g2 = np.exp(l2) / np.sqrt(v + 1e-5)
+        return float(((g2[:, None] * (X - m[:, None]) + b2[:, None]) * G).sum() + lb.sum() * (l2 - 0.5 * np.log(v + 1e-5)).sum())
+
+    if dt == np.float64:
+        h = 1e-6
+        for i in (0, dim - 1):
+            e = np.zeros(dim); e[i] = h
+            assert abs((F(b_ + e, logs) - F(b_ - e, logs)) / (2 * h) - float(host(pb["b"])[i])) < 1e-5
+            assert abs((F(b_, logs + e) - F(b_, logs - e)) / (2 * h) - float(host(pb["logs"])[i])) < 1e-4
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("inv", [False, True])
+def test_coupling_spline_law_pullback(bj, orc, dt, inv):
+    """Coupling with the spline law (coupling.jl:206-259 + rational_quadratic_spline.jl:317-357): x̄₁ from bjx_rqs_vjp on the
+    x₁ rows, pass-through elsewhere; against the elementwise spline pullback oracle."""
+    r = rng(52)
+    dim, N, K = 12, 300, 6
+    idx1 = [2, 5, 6, 11]
+    m = bj.PartitionMask(dim, idx1, [1, 3, 4])
+    X = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    G = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    lb = r.normal(size=N).astype(dt)
+    w, h, d = orc.rqs_params(r.normal(size=(4, K)).astype(dt), r.normal(size=(4, K)).astype(dt), r.normal(size=(4, K - 1)).astype(dt), 2.5)
+    cq = bj.Coupling(lambda th: bj.RationalQuadraticSpline(dev(w), dev(h), dev(d)), m)
+    b = bj.inverse(cq) if inv else cq
+    xb = bj.vjp(b, dev(X), dev(G), dev(lb))
+    i0 = [i - 1 for i in idx1]
+    ref = G.astype(np.float64).copy()
+    ref[i0] = orc.rqs_vjp(w.astype(np.float64), h.astype(np.float64), d.astype(np.float64), X[i0].astype(np.float64), G[i0].astype(np.float64),
+                          lb.astype(np.float64), inverse=inv)
+    close(host(xb), ref, dt, scale=20, what="coupling spline pullback")
+    keep = [i for i in range(dim) if i not in i0]
+    assert np.array_equal(host(xb)[keep], G[keep])
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 1000])
+def test_stacked_with_structured_segments_in_place(bj, orc, dt, N):
+    """A mixed-constraint parameter vector (what bijector(::ProductNamedTupleDistribution) / Turing's link hands over):
+    exp rows | Simplex block (6 -> 5) | Logit rows | Ordered block | identity | second Simplex (3 -> 2).  The elementwise
+    segments are ONE bjx_stacked_ld launch, the structured blocks run in place with a leading dimension and accumulate
+    their log-dets — checked against the per-segment oracle, forward and inverse, per-sample, scalar and logabsdetjac-only."""
+    r = rng(N + 7)
+    P1 = r.dirichlet(np.ones(6), size=N).T
+    P2 = r.dirichlet(np.ones(3), size=N).T
+    U = r.uniform(0.05, 0.95, size=(3, N))
+    X = np.asfortranarray(np.vstack([r.normal(size=(3, N)), P1, U, r.normal(size=(8, N)), r.normal(size=(1, N)), P2]).astype(dt))
+    exp = bj.elementwise(bj.exp)
+    b = bj.Stacked([exp @ bj.Shift(0.1) @ bj.Scale(0.5), bj.SimplexBijector(), bj.Logit(0.0, 1.0), bj.OrderedBijector(), bj.identity, bj.SimplexBijector()],
+                   [(1, 3), (4, 9), (10, 12), (13, 20), (21, 21), (22, 24)])
+    assert bj.output_size(b, (24,)) == (22,)
+    Xd = X.astype(np.float64)
+    y1, l1 = np.exp(0.5 * Xd[0:3] + 0.1), (0.5 * Xd[0:3] + 0.1).sum(axis=0) + 3 * math.log(0.5)
+    y2, l2 = orc.simplex(np.asfortranarray(Xd[3:9]))
+    y3, l3 = np.log(Xd[9:12] / (1 - Xd[9:12])), -np.log(Xd[9:12] * (1 - Xd[9:12])).sum(axis=0)
+    y4, l4 = orc.ordered(np.asfortranarray(Xd[12:20]))
+    y6, l6 = orc.simplex(np.asfortranarray(Xd[21:24]))
+    Y_ref = np.vstack([y1, y2, y3, y4, Xd[20:21], y6])
+    l_ref = l1 + l2 + l3 + l4 + l6
+    Y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+    assert tuple(Y.shape) == (22, N)
+    close(host(Y), Y_ref, dt, scale=20, what="mixed Stacked")
+    close(host(l), l_ref, dt, scale=200, what="mixed Stacked ladj")
+    _, ls = bj.with_logabsdet_jacobian(b, dev(X))
+    sum_close(ls, l_ref.sum(), dt, N * 24 * 10)
+    Xb, lb = bj.with_logabsdet_jacobian(bj.inverse(b), dev(Y_ref.astype(dt)), per_sample=True)
+    assert tuple(Xb.shape) == (24, N)
+    close(host(Xb), Xd, dt, scale=20, what="inverse mixed Stacked")
+    close(host(lb), -l_ref, dt, scale=200, what="inverse mixed Stacked ladj")
+    # only structured segments (no elementwise launch at all)
+    b3 = bj.Stacked([bj.SimplexBijector(), bj.OrderedBijector()], [(1, 6), (7, 14)])
+    X3 = np.asfortranarray(np.vstack([P1, Xd[12:20]]).astype(dt))
+    Y3, l3b = bj.with_logabsdet_jacobian(b3, dev(X3), per_sample=True)
+    close(host(Y3), np.vstack([y2, y4]), dt, scale=20)
+    close(host(l3b), l2 + l4, dt, scale=200)
