@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void rqs_blob_kernel(const T* w, const T* h, c
         const T sl = dy / wd;                                        // s = Δy/w
         const T d_k = (k == 0) ? T(1) : D(k);
         const T d_k1 = (k == K1 - 1) ? T(1) : D(k + 1);
-        if (!INV) { a[0] = w_k; a[1] = T(1) / wd; a[2] = h_k; a[3] = dy; }
+        if (!INV) { a[1] = T(1) / wd; a[0] = -w_k * a[1]; a[2] = h_k; a[3] = dy; }   // ξ = x·(1/w) − w_k/w: one FMA per element
         else { a[0] = h_k; a[1] = dy; a[2] = w_k; a[3] = wd; }
         b[0] = sl; b[1] = d_k; b[2] = d_k1 + d_k - 2 * sl; b[3] = d_k1 - d_k;
       }
@@ -261,7 +261,7 @@ __device__ __forceinline__ T rqs_eval(const Rec4<T>& A, const Rec4<T>& B, T lim,
   const T xin = x;
   T xi, res;
   if (!INV) {
-    xi = (xin - A.v[0]) * A.v[1];                                           // ξ = (x - w_k)/w
+    xi = xin * A.v[1] + A.v[0];                                             // ξ = (x - w_k)/w as one FMA (A.v[0] = -w_k/w)
   } else {
     const T yh = xin - A.v[0];
     const T t = yh * ds;
@@ -271,9 +271,15 @@ __device__ __forceinline__ T rqs_eval(const Rec4<T>& A, const Rec4<T>& B, T lim,
     xi = F::div(q + q, a2 + F::sqrt(a2 * a2 + 4 * (a1 * q)));               // Eq. (24)
   }
   const T p = xi - xi * xi;                                                 // contracts to fma(-ξ, ξ, ξ)
-  const T den = s + ds * p;
+  T den, tq;
+  if constexpr (sizeof(T) == 4) {
+    // (den, t) = (s, d_k) + (ds, dd)·(p, ξ): both operand pairs are adjacent halves of the 16-byte record read -> one v_pk_fma_f32
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 r2 = __builtin_elementwise_fma(f2{ds, dd}, f2{p, xi}, f2{s, d_k});
+    den = r2.x; tq = r2.y;
+  } else { den = s + ds * p; tq = d_k + dd * xi; }
   const T rden = F::rcp(den);
-  const T nj = (d_k + dd * xi) - ds * p;
+  const T nj = tq - ds * p;
   const T sr = s * rden;
   T lj = F::log2(nj * (sr * sr));                                           // log(s²·nj) - 2 log(den)
   if (!INV) res = A.v[2] + (A.v[3] * (xi * (d_k + (s - d_k) * xi))) * rden;
@@ -424,7 +430,7 @@ __device__ __forceinline__ T rqs_eval_vjp(const Rec4<T>& A, const Rec4<T>& B, T 
   using F = Fast<T>;
   const T s = B.v[0], d_k = B.v[1], ds = B.v[2], dd = B.v[3];
   T xi, iw;
-  if (!INV) { xi = (xin - A.v[0]) * A.v[1]; iw = A.v[1]; }
+  if (!INV) { xi = xin * A.v[1] + A.v[0]; iw = A.v[1]; }
   else {
     const T yh = xin - A.v[0];
     const T t = yh * ds;

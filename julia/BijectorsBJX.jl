@@ -13,7 +13,7 @@ using AMDGPU: AMDGPU, ROCArray, ROCVector, ROCMatrix
 using Bijectors
 using Bijectors: Elementwise, Inverse, Shift, Scale, Logit, LeakyReLU, TruncatedBijector, OrderedBijector,
     SimplexBijector, VecCholeskyBijector, Permute, PlanarLayer, RadialLayer, InvertibleBatchNorm,
-    RationalQuadraticSpline, Stacked
+    RationalQuadraticSpline, Stacked, VecCorrBijector, CorrBijector, PDBijector, PDVecBijector, NamedStacked
 using ChainRulesCore: ChainRulesCore
 using Distributions: Distributions
 const ROCVecOrMat{T} = Union{ROCVector{T},ROCMatrix{T}}
@@ -195,6 +195,87 @@ end
 # VecCholeskyBijector, Permute, Coupling and the Inverse{…} flow methods follow the same pattern
 # (bjx_vec_cholesky / bjx_permute / bjx_coupling_* / inverse = Cint(1)); see INTEGRATION.md.
 
+# ---------------------------------------------------------------- matrix-variate constraint bijectors (SURVEY.md §8f f-4)
+# corr.jl:64-162, pd.jl:1-60.  The reference defines them for ONE matrix; a K x K x N ROCArray is a batch of N samples
+# and returns the per-sample log-det vector.  (A single ROCMatrix is the N = 1 case and returns the scalar.)
+const MatrixKinds = Union{VecCorrBijector,CorrBijector,PDBijector,PDVecBijector}
+bjx_symbol(::VecCorrBijector) = :bjx_vec_corr
+bjx_symbol(::CorrBijector) = :bjx_corr
+bjx_symbol(::PDBijector) = :bjx_pd
+bjx_symbol(::PDVecBijector) = :bjx_pd_vec
+packed_length(::VecCorrBijector, K) = (K * (K - 1)) ÷ 2                      # corr.jl:150-154
+packed_length(::PDVecBijector, K) = (K * (K + 1)) ÷ 2                        # pd.jl:50-54
+function matrix_call(b::MatrixKinds, inv::Bool, inp::ROCArray{T}, out::ROCArray{T}, K, n) where {T}
+    lps = similar(inp, T, n)
+    GC.@preserve inp out lps begin
+        rc = ccall((bjx_symbol(b), libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+            ctx().h, dtype(T), Cint(inv), devptr(inp), devptr(out), devptr(lps), C_NULL, K, n, UInt32(0))
+        check(rc, String(bjx_symbol(b)))
+    end
+    return lps
+end
+function with_logabsdet_jacobian(b::Union{VecCorrBijector,PDVecBijector}, X::ROCArray{T,3}) where {T}
+    K, n = size(X, 1), size(X, 3)
+    size(X, 2) == K || throw(DimensionMismatch("sizes should be equal; received $(size(X)[1:2])"))
+    y = similar(X, packed_length(b, K), n)
+    return y, matrix_call(b, false, X, y, K, n)
+end
+function with_logabsdet_jacobian(ib::Inverse{<:Union{VecCorrBijector,PDVecBijector}}, y::ROCMatrix{T}) where {T}
+    b = ib.orig
+    K = b isa VecCorrBijector ? Bijectors._triu1_dim_from_length(size(y, 1)) : Bijectors._triu_dim_from_length(size(y, 1))
+    X = similar(y, K, K, size(y, 2))
+    return X, matrix_call(b, true, y, X, K, size(y, 2))
+end
+function with_logabsdet_jacobian(b::Union{CorrBijector,PDBijector}, X::ROCArray{T,3}) where {T}
+    Y = similar(X)
+    return Y, matrix_call(b, false, X, Y, size(X, 1), size(X, 3))
+end
+function with_logabsdet_jacobian(ib::Inverse{<:Union{CorrBijector,PDBijector}}, Y::ROCArray{T,3}) where {T}
+    X = similar(Y)
+    return X, matrix_call(ib.orig, true, Y, X, size(Y, 1), size(Y, 3))
+end
+# one matrix (the reference's call shape): the N = 1 batch, scalar log-det
+function with_logabsdet_jacobian(b::Union{MatrixKinds,Inverse{<:MatrixKinds}}, x::ROCVecOrMat{T}) where {T}
+    out, l = with_logabsdet_jacobian(b, reshape(x, size(x)..., 1))
+    return dropdims(out; dims=ndims(out)), Array(l)[1]
+end
+
+# Scale with a matrix parameter (scale.jl:14,17,35-36): a * x, a \ y, logabsdet(a) once
+function scale_matrix(a::ROCMatrix{T}, x::ROCVecOrMat{T}, inv::Bool) where {T}
+    d, n = dims(x)
+    size(a) == (d, d) || throw(DimensionMismatch("Scale with a $(size(a)) matrix applied to $d rows"))
+    y = similar(x)
+    lsum = AMDGPU.zeros(Float64, 1)
+    GC.@preserve a x y lsum begin
+        rc = ccall((:bjx_scale_matrix, libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+            ctx().h, dtype(T), Cint(inv), devptr(a), devptr(x), devptr(y), C_NULL, devptr(lsum), d, n, BJX_REF_VECTOR_SCALE_LADJ)
+        check(rc, "bjx_scale_matrix")
+    end
+    return y, T(Array(lsum)[1])
+end
+with_logabsdet_jacobian(b::Scale{<:ROCMatrix{T}}, x::ROCVecOrMat{T}) where {T} = scale_matrix(b.a, x, false)
+with_logabsdet_jacobian(ib::Inverse{<:Scale{<:ROCMatrix{T}}}, y::ROCVecOrMat{T}) where {T} = scale_matrix(ib.orig.a, y, true)
+
+# InvertibleBatchNorm in training mode on a batch sharded over ranks (normalise.jl:51-60; SURVEY.md §8e "Exception"):
+# statistics of this rank's columns -> the host's collective (MPI.Allreduce!, or bjx_allreduce_sum_f64 after bjx_comm_init)
+# -> update of the moving statistics and transform with the GLOBAL statistics.
+function batchnorm_train!(bn::InvertibleBatchNorm, x::ROCMatrix{T}; allreduce! = identity) where {T}
+    d, n = size(x)
+    stats = AMDGPU.zeros(Float64, 2d + 1)
+    GC.@preserve bn x stats check(ccall((:bjx_batchnorm_stats, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+        ctx().h, dtype(T), devptr(bn.m), devptr(x), devptr(stats), d, n), "bjx_batchnorm_stats")
+    allreduce!(stats)                                      # sum of the 2d+1 Float64 values over the ranks
+    y = similar(x); lps = similar(x, T, n)
+    GC.@preserve bn x y lps stats check(ccall((:bjx_batchnorm_train_apply, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        ctx().h, dtype(T), devptr(bn.b), devptr(bn.logs), devptr(bn.m), devptr(bn.v), Float64(bn.eps), Float64(bn.mtm),
+        devptr(stats), devptr(x), devptr(y), devptr(lps), C_NULL, d, n, UInt32(0)), "bjx_batchnorm_train_apply")
+    return y, lps
+end
+
 # ---------------------------------------------------------------- Stacked (SURVEY.md §8f f-4)
 # stacked.jl:27-252: every segment whose bijector is a fusable elementwise chain goes into ONE launch.
 struct BjxSegment
@@ -210,7 +291,7 @@ function with_logabsdet_jacobian(sb::Stacked, x::ROCVecOrMat{T}) where {T<:Union
     for (b, rin, rout) in zip(sb.bs, sb.ranges_in, sb.ranges_out)
         o = b === identity ? BjxOp[] : ops(b, T, keep)
         (o === nothing || length(o) > 4 || length(rin) != length(rout)) &&
-            return invoke(with_logabsdet_jacobian, Tuple{Stacked,AbstractVector}, sb, x)   # structured segment: generic method
+            return stacked_structured(sb, x)                                               # Simplex / Ordered blocks: in place, below
         push!(segs, BjxSegment(first(rin) - 1, first(rout) - 1, length(rin), length(o), 0,
                                ntuple(k -> k <= length(o) ? o[k] : NOOP, 4)))
     end
@@ -223,6 +304,45 @@ function with_logabsdet_jacobian(sb::Stacked, x::ROCVecOrMat{T}) where {T<:Union
         check(rc, "bjx_stacked")
     end
     return y, T(Array(lsum)[1])
+end
+
+# Stacked with Simplex / Ordered segments (stacked.jl:142-166) without slicing copies: the elementwise segments in one
+# bjx_stacked_ld launch between matrices of different heights (identity placeholders on the structured rows), then
+# bjx_simplex_ld / bjx_ordered_ld on row windows of the same matrices, accumulating their log-dets.
+structured_entry(::SimplexBijector) = (:bjx_simplex_ld, false)
+structured_entry(::Inverse{SimplexBijector}) = (:bjx_simplex_ld, true)
+structured_entry(::OrderedBijector) = (:bjx_ordered_ld, false)
+structured_entry(::Inverse{OrderedBijector}) = (:bjx_ordered_ld, true)
+structured_entry(b) = nothing
+function stacked_structured(sb::Stacked, x::ROCMatrix{T}) where {T<:Union{Float32,Float64}}
+    d, n = size(x)
+    dout = last(last(sb.ranges_out))
+    keep = Any[]; segs = BjxSegment[]; later = Any[]
+    for (b, rin, rout) in zip(sb.bs, sb.ranges_in, sb.ranges_out)
+        o = b === identity ? BjxOp[] : ops(b, T, keep)
+        if o !== nothing && length(o) <= 4 && length(rin) == length(rout)
+            push!(segs, BjxSegment(first(rin) - 1, first(rout) - 1, length(rin), length(o), 0, ntuple(k -> k <= length(o) ? o[k] : NOOP, 4)))
+        else
+            e = structured_entry(b)
+            e === nothing && return invoke(with_logabsdet_jacobian, Tuple{Stacked,AbstractMatrix}, sb, x)
+            push!(later, (e, rin, rout))
+            push!(segs, BjxSegment(min(first(rin) - 1, d - length(rout)), first(rout) - 1, length(rout), 0, 0, ntuple(_ -> NOOP, 4)))
+        end
+    end
+    y = similar(x, dout, n); lps = AMDGPU.zeros(T, n)
+    GC.@preserve keep x y lps begin
+        check(ccall((:bjx_stacked_ld, libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+            ctx().h, dtype(T), segs, length(segs), devptr(x), d, devptr(y), dout, devptr(lps), C_NULL, dout, n, UInt32(0)), "bjx_stacked_ld")
+        for ((sym, inv), rin, rout) in later
+            K = sym === :bjx_simplex_ld ? (inv ? length(rout) : length(rin)) : length(rin)
+            check(ccall((sym, libbjx), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+                ctx().h, dtype(T), Cint(inv), devptr(x) + (first(rin) - 1) * sizeof(T), d, devptr(y) + (first(rout) - 1) * sizeof(T), dout,
+                devptr(lps), C_NULL, K, n, BJX_ACCUMULATE), String(sym))
+        end
+    end
+    return y, lps
 end
 
 # Mean-field family y = tail(μ .+ σ .* z) (ADVI): input pullback and the (μ̄, σ̄) reductions in ONE pass over z and ȳ.
