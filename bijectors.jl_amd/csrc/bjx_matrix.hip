@@ -574,6 +574,117 @@ __global__ __launch_bounds__(256) void scale_matrix_kernel(const T* __restrict__
   }
 }
 
+// Y = M X on the matrix cores (the one genuinely dense product on this path: 2 dim^2 flop per 2 dim sizeof(T) bytes).
+// One wave = a tile of 16 columns.  M (padded to DP = 16 NRB rows / columns) sits in LDS in A-operand order
+// (for row block rb and k-step ks the 64 lane values M[16 rb + lane % 16][4 ks + lane / 16] are consecutive), the X tile is
+// loaded with coalesced 16-byte accesses and transposed through LDS into B operands (lane (n, q): X[4 ks + q][column n]);
+// NRB accumulators of 16 x 16 per wave; the result leaves through the same LDS tile with coalesced stores.  The next
+// tile's loads are issued before the MFMA loop of the current one.
+template <class T> struct MfmaOps;
+template <> struct MfmaOps<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int q, int r) { return 4 * q + r; }        // D register r of lane (n, q) -> row of the 16-block
+};
+template <> struct MfmaOps<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int q, int r) { return 4 * r + q; }        // probed: scripts/probe_mfma_f64.hip
+};
+template <class T, int NRB, bool AREG_OK>
+__global__ __launch_bounds__(256) void scale_matrix_mfma_kernel(const T* __restrict__ M, int ldm_row_major, const T* __restrict__ X, T* __restrict__ Y,
+                                                                T* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate, const double* logabsdet) {
+  extern __shared__ __align__(16) unsigned char smem_[];
+  constexpr int DP = 16 * NRB, NKS = DP / 4;
+  constexpr int P = DP + 4;                              // staged column pitch (16-byte aligned rows, columns 4 banks apart)
+  constexpr int VW = Vec16<T>::N;
+  using O = MfmaOps<T>;
+  T* Ms = reinterpret_cast<T*>(smem_);                   // [NRB][NKS][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* xs = Ms + NRB * NKS * 64 + wave * 16 * P;
+  for (int e = threadIdx.x; e < NRB * NKS * 64; e += 256) {
+    const int l = e & 63, blk = e >> 6, ks = blk % NKS, rb = blk / NKS;
+    const int i = 16 * rb + (l & 15), k = 4 * ks + (l >> 4);
+    T v = T(0);
+    if (i < dim && k < dim) v = ldm_row_major ? M[(size_t)i * ldm_row_major + k] : M[(size_t)k * dim + i];
+    Ms[e] = v;
+  }
+  __syncthreads();
+  const T lad = ladj_ps ? (T)*logabsdet : T(0);
+  const int n = lane & 15, q = lane >> 4;
+  const bool vec_ok = dim % VW == 0 && bjx_aligned16_dev(X) && (!Y || bjx_aligned16_dev(Y));
+  // small matrices: the A operands of a wave stay in registers (NRB*NKS <= 64 values), LDS only carries the tiles
+  constexpr bool AREG = AREG_OK && NRB * NKS * (int)sizeof(T) <= 256;
+  T areg[AREG ? NRB : 1][AREG ? NKS : 1];
+  if constexpr (AREG) {
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) areg[rb][ks] = Ms[(rb * NKS + ks) * 64 + lane];
+  }
+  const int64_t tile_stride = (int64_t)gridDim.x * 4 * 16;
+  for (int64_t c0 = ((int64_t)blockIdx.x * 4 + wave) * 16; c0 < batch; c0 += tile_stride) {
+    const int nc = (int)((batch - c0) < 16 ? (batch - c0) : 16);
+    const int ne = nc * dim;                             // contiguous elements of the tile
+    // ---- stage the tile: xs[c*P + k] = X[k, c0 + c]; rows >= dim and columns >= nc are zero
+    for (int e = lane; e < 16 * (DP - dim) ; e += 64) { const int c = e / (DP - dim), k = dim + e % (DP - dim); xs[c * P + k] = T(0); }
+    if (vec_ok) {
+      for (int e = lane * VW; e < 16 * dim; e += 64 * VW) {
+        Pack<T, VW> p;
+#pragma unroll
+        for (int t = 0; t < VW; ++t) p.v[t] = T(0);
+        if (e < ne) p = load_pack<T, VW, true>(X + c0 * dim + e);
+        const int c = e / dim, k = e - c * dim;          // VW | dim: a pack stays inside one column
+#pragma unroll
+        for (int t = 0; t < VW; ++t) xs[c * P + k + t] = p.v[t];
+      }
+    } else {
+      for (int e = lane; e < 16 * dim; e += 64) { const int c = e / dim, k = e - c * dim; xs[c * P + k] = e < ne ? X[c0 * dim + e] : T(0); }
+    }
+    __builtin_amdgcn_wave_barrier();
+    typename O::acc_t acc[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) acc[rb] = typename O::acc_t{T(0), T(0), T(0), T(0)};
+    if constexpr (AREG) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const T b = xs[n * P + 4 * ks + q];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[rb] = O::mfma(areg[rb][ks], b, acc[rb]);
+      }
+    } else {
+#pragma unroll 4
+      for (int ks = 0; ks < NKS; ++ks) {
+        const T b = xs[n * P + 4 * ks + q];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[rb] = O::mfma(Ms[(rb * NKS + ks) * 64 + lane], b, acc[rb]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- results back through the tile
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xs[n * P + 16 * rb + O::row(q, r)] = acc[rb][r];
+    __builtin_amdgcn_wave_barrier();
+    if (Y) {
+      if (vec_ok) {
+        for (int e = lane * VW; e < ne; e += 64 * VW) {
+          const int c = e / dim, k = e - c * dim;
+          Pack<T, VW> p;
+#pragma unroll
+          for (int t = 0; t < VW; ++t) p.v[t] = xs[c * P + k + t];
+          store_pack<T, VW, true>(Y + c0 * dim + e, p);
+        }
+      } else {
+        for (int e = lane; e < ne; e += 64) { const int c = e / dim, k = e - c * dim; Y[c0 * dim + e] = xs[c * P + k]; }
+      }
+    }
+    if (ladj_ps && lane < nc) ladj_ps[c0 + lane] = accumulate ? ladj_ps[c0 + lane] + lad : lad;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __global__ void scale_matrix_sum_kernel(const double* logabsdet, double mult, double* out, int accumulate) {
   const double v = *logabsdet * mult;
   *out = accumulate ? *out + v : v;
@@ -606,6 +717,26 @@ int scale_matrix_impl(bjx_ctx* ctx, int inverse, const T* a, const T* in, T* out
     const T* M = inverse ? W + dim : a;
     const int ldm = inverse ? (int)(2 * dim) : 0;
     BjxProf prof_(ctx);
+    static const int use_mfma = getenv("BJX_SCALE_MFMA") ? atoi(getenv("BJX_SCALE_MFMA")) : 1;
+    const int nrb_ = (int)((dim + 15) / 16);
+    const size_t smem_try = ((size_t)(16 * nrb_) * (16 * nrb_) + (size_t)4 * 16 * (16 * nrb_ + 4)) * sizeof(T);
+    if (use_mfma && smem_try <= BJX_LDS_MAX) {
+      if (inverse && want_ladj) hipLaunchKernelGGL(scale_matrix_sum_kernel, dim3(1), dim3(1), 0, ctx->stream, lad, -1.0, lad, 0);
+      const int nrb = (int)((dim + 15) / 16), DP = 16 * nrb;
+      const size_t smem_m = ((size_t)DP * DP + (size_t)4 * 16 * (DP + 4)) * sizeof(T);
+      const int64_t tiles = (batch + 63) / 64;
+      const int64_t capm = (int64_t)ctx->num_cu * (smem_m > 80 * 1024 ? 1 : (smem_m > 40 * 1024 ? 2 : 4));
+      const int gridm = (int)(tiles < capm ? tiles : capm);
+      static const int areg = getenv("BJX_SCALE_AREG") ? atoi(getenv("BJX_SCALE_AREG")) : 0;
+#define BJX_SMM(N_) do { if (areg) { bjx_allow_big_lds(scale_matrix_mfma_kernel<T, N_, true>, smem_m); \
+      hipLaunchKernelGGL((scale_matrix_mfma_kernel<T, N_, true>), dim3(gridm), dim3(256), smem_m, ctx->stream, M, ldm, in, out, ladj_ps, (int)dim, batch, accum, lad); } \
+      else { bjx_allow_big_lds(scale_matrix_mfma_kernel<T, N_, false>, smem_m); \
+      hipLaunchKernelGGL((scale_matrix_mfma_kernel<T, N_, false>), dim3(gridm), dim3(256), smem_m, ctx->stream, M, ldm, in, out, ladj_ps, (int)dim, batch, accum, lad); } } while (0)
+      switch (nrb) { case 1: BJX_SMM(1); break; case 2: BJX_SMM(2); break; case 3: BJX_SMM(3); break; case 4: BJX_SMM(4); break;
+                     case 5: BJX_SMM(5); break; case 6: BJX_SMM(6); break; case 7: BJX_SMM(7); break; default: BJX_SMM(8); break; }
+#undef BJX_SMM
+      BJX_CHECK_LAUNCH(ctx);
+    } else {
 #define BJX_SM(R_) do { bjx_allow_big_lds(scale_matrix_kernel<T, R_>, smem); \
     hipLaunchKernelGGL((scale_matrix_kernel<T, R_>), dim3(grid), dim3(256), smem, ctx->stream, M, ldm, in, out, ladj_ps, (int)dim, batch, TC, accum, lad); } while (0)
     if (inverse && want_ladj) {               // negate once on the device before the per-sample broadcast
@@ -614,6 +745,7 @@ int scale_matrix_impl(bjx_ctx* ctx, int inverse, const T* a, const T* in, T* out
     if (rpt == 8) BJX_SM(8); else if (rpt == 16) BJX_SM(16); else BJX_SM(32);
 #undef BJX_SM
     BJX_CHECK_LAUNCH(ctx);
+    }
   } else if (inverse && want_ladj) {
     hipLaunchKernelGGL(scale_matrix_sum_kernel, dim3(1), dim3(1), 0, ctx->stream, lad, -1.0, lad, 0);
   }

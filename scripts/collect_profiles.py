@@ -13,8 +13,8 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = {"c2": ["chain_flat_kernel"], "c2v": ["chain_flat_kernel"], "c3": ["rqs_lds_kernel"], "c4": ["planar_reg"],
-            "c5a": ["quad_stream_kernel"], "c5b": ["chol_inv_chunk_kernel"]}
+DOMINANT = {"c1": ["chain_flat"], "c2": ["chain_flat_kernel"], "c2v": ["chain_flat_kernel"], "c3": ["rqs_lds_kernel"], "c4": ["planar_reg"],
+            "c5a": ["quad_stream_kernel"], "c5b": ["chol_inv_chunk_kernel"], "vcorr": ["matrix_link_kernel"], "pdvec": ["matrix_link_kernel"]}
 
 
 def main(tag):
@@ -71,6 +71,11 @@ def main(tag):
         with open(os.path.join(dst, f"{tag}_bench_lines.jsonl"), "w") as f:
             f.write("\n".join(lines) + "\n")
     json.dump(traffic, open(traffic_path, "w"), indent=1)
+    for extra in ("bench_default.json", "rows.md", "rows_kernel_stats.csv", "f64_rows.md", "f64math_bench.txt", "planar_mfma_ab.txt"):
+        pe = os.path.join(src, extra)
+        if os.path.exists(pe) and os.path.getsize(pe) > 2:
+            with open(pe) as fi, open(os.path.join(dst, f"{tag}_{extra}"), "w") as fo:
+                fo.write(fi.read())
     pt = os.path.join(src, "pytest_gpu.txt")
     if os.path.exists(pt):
         ls = open(pt).readlines()
