@@ -338,6 +338,8 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
   const int64_t left = batch - bcol0 - cg;                 // my columns: it*cols_per_block < left
   const int my_cols = left > (int64_t)iters * cols_per_block ? iters * cols_per_block : (left > 0 ? (int)left : 0);
   const int64_t it_stride = (int64_t)cols_per_block * dim;
+  // (A/B in one run, 2^22 columns: dropping the look-ahead (load, evaluate, store) or alternating two buffer pairs to save the
+  // 16 pack-copy v_mov per trip are both 25-30 % SLOWER — 0.31 vs 0.23 ms forward — so the look-ahead with copies stays.)
   // TWO columns per trip (the per-column epilogue — G-lane butterfly behind wave-uniform branches, log-det
   // store, loop control — costs ~40 VALU, a quarter of a 4-element pack's evaluation) and one trip of
   // look-ahead: the next two loads are in flight while these are evaluated.
@@ -713,7 +715,8 @@ int rqs_launch_lds(bjx_ctx* ctx, int nstep_hi, int dual, const T* blob, const in
     case 4: RQS_L(2, false); break;  case 5: RQS_L(2, true); break;
     case 6: RQS_L(3, false); break;  case 7: RQS_L(3, true); break;
     case 8: RQS_L(4, false); break;  case 9: RQS_L(4, true); break;
-    case 10: RQS_L(5, false); break; case 11: RQS_L(5, true); break;
+    case 10: RQS_L(5, false); break;
+    case 11: RQS_L(5, true); break;
     case 12: RQS_L(6, false); break; case 13: RQS_L(6, true); break;
     default: return bjx_fail(ctx, BJX_ERR_UNSUPPORTED, "bjx_rqs: unsupported search depth %d", nstep_hi);
   }

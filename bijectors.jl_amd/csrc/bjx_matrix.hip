@@ -56,6 +56,31 @@ template <> struct LinkMath<float> {
   }
   static __device__ __forceinline__ float exp(float x) { return F::exp(x); }
   static __device__ __forceinline__ float log(float x) { return F::log(x); }
+  // One row of the bottom-up column walk (corr.jl:282-288) with the logarithm of the running remainder carried along:
+  //   asinh(w/√R) = log(|w| + √(R + w²)) − ½ log R,   logcosh(asinh(w/√R)) = ½ (log(R + w²) − log R)
+  // -> sqrt + 2 log per entry instead of rsqrt, sqrt, rcp, log1p, log.  L = log2 of the remainder.
+  static __device__ __forceinline__ void fwd_init(float dg, float& rem, float& L) { rem = dg * dg; L = F::log2(rem); }
+  static __device__ __forceinline__ void fwd_step(float w, float& rem, float& L, float& y, float& lc) {
+    const float rn = rem + w * w;
+    const float Ln = F::log2(rn);
+    const float a = F::log2(fabsf(w) + F::sqrt(rn)) - 0.5f * L;
+    y = __builtin_copysignf(a * Num<float>::log2, w);
+    lc = (0.5f * Num<float>::log2) * (Ln - L);
+    rem = rn; L = Ln;
+  }
+  // One row of the top-down walk (corr.jl:352-357): E = exp(log_remainder) is carried as a product of sech(y),
+  // tanh and sech come from one exp(-|y|) and one rcp, logcosh = -log(sech): exp + rcp + log per entry.
+  static __device__ __forceinline__ void inv_init(float& E) { E = 1.0f; }
+  static __device__ __forceinline__ void inv_step(float yv, float& E, float& w, float& lc) {
+    const float u = F::exp(-fabsf(yv));
+    const float t = u * u;
+    const float r = F::rcp(1.0f + t);
+    w = __builtin_copysignf((1.0f - t) * r, yv) * E;
+    const float sech = (u + u) * r;
+    lc = -F::log(sech);
+    E *= sech;
+  }
+  static __device__ __forceinline__ float inv_diag(float E, float) { return E; }
 };
 template <> struct LinkMath<double> {
   using F = Fast<double>;
@@ -74,6 +99,19 @@ template <> struct LinkMath<double> {
   }
   static __device__ __forceinline__ double exp(double x) { return F::exp(x); }
   static __device__ __forceinline__ double log(double x) { return F::log(x); }
+  static __device__ __forceinline__ void fwd_init(double dg, double& rem, double& L) { rem = dg * dg; L = 0.0; }
+  static __device__ __forceinline__ void fwd_step(double w, double& rem, double& L, double& y, double& lc) {
+    asinh_lc(w, rem, y, lc);
+    rem += w * w;
+  }
+  static __device__ __forceinline__ void inv_init(double& E) { E = 0.0; }           // E holds log_remainder in Float64 (no product: no underflow question)
+  static __device__ __forceinline__ void inv_step(double yv, double& E, double& w, double& lc) {
+    double z;
+    tanh_lc(yv, z, lc);
+    w = z * F::exp(E);
+    E -= lc;
+  }
+  static __device__ __forceinline__ double inv_diag(double E, double) { return F::exp(E); }
 };
 
 // Layout of the contiguous run of one sample in global memory; every layout lands in the tile as tile[c*pitch + r]:
@@ -265,18 +303,23 @@ __global__ __launch_bounds__(64) void matrix_link_kernel(const T* __restrict__ i
           if (j < K && live) myrow[j] = a(j);
         __builtin_amdgcn_wave_barrier();
         const T dg = live ? myrow[li] : T(1);
-        T rem = dg * dg;
-        for (int i = K - 2; i >= 0; --i) {
+        T rem, Lr;
+        M::fwd_init(dg, rem, Lr);
+        for (int i = K - 2; i >= (KIND == MK_VEC_CORR ? 1 : 0); --i) {
           const bool act = i < li && live;
           const T w = act ? myrow[i] : T(0);
           T y, lc;
-          if (KIND == MK_VEC_CORR && i == 0) M::atanh_lc(w, y, lc);                        // :322 atanh(W[1, j])
-          else M::asinh_lc(w, act ? rem : T(1), y, lc);
+          M::fwd_step(w, rem, Lr, y, lc);                                                  // inactive lanes: w = 0 leaves rem and L unchanged
           if (act) {
-            rem += w * w;
             lsum += T(K - i) * lc;
             myrow[i] = y;
           }
+        }
+        if (KIND == MK_VEC_CORR && K >= 2) {                                               // :322 atanh(W[1, j]) on row 1
+          const bool act = 0 < li && live;
+          T y, lc;
+          M::atanh_lc(act ? myrow[0] : T(0), y, lc);
+          if (act) { lsum += T(K) * lc; myrow[0] = y; }
         }
         if (KIND == MK_CORR) {                                                             // zero fill on and below the diagonal (:292-294)
           for (int i = live ? li : K; i < K; ++i) myrow[i] = T(0);
@@ -313,17 +356,17 @@ __global__ __launch_bounds__(64) void matrix_link_kernel(const T* __restrict__ i
       if constexpr (CORR) {
         // corr.jl:345-399: column li of U top-down (rolled, in place in my tile row);
         // + sum_{j=2}^{K-1} (K-j) log U[j,j] (:77-79, :144-146), log U[j,j] = the final log_remainder of column j
-        T lr = T(0);
+        T lr = T(0), E;
+        M::inv_init(E);
         for (int i = 0; i < K - 1; ++i) {
           const bool act = i < li && live;
           const T yv = act ? myrow[i] : T(0);
-          T z, lc;
-          M::tanh_lc(yv, z, lc);
-          const T e = M::exp(lr);
-          if (act) { myrow[i] = z * e; lr -= lc; lsum += lr; }
+          T w, lc;
+          M::inv_step(yv, E, w, lc);                                                       // inactive lanes: y = 0 -> sech = 1, lc = 0
+          if (act) { myrow[i] = w; lr -= lc; lsum += lr; }
         }
         if (live) {
-          myrow[li] = M::exp(lr);
+          myrow[li] = M::inv_diag(E, lr);
           lsum += lr + ((li >= 1 && li <= K - 2) ? T(K - 1 - li) * lr : T(0));
         }
         __builtin_amdgcn_wave_barrier();

@@ -309,7 +309,7 @@ int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const voi
     if (g.n_ops > max_ops) max_ops = g.n_ops;
     if (g.in_lo != g.out_lo) gather = true;
   }
-  if (ldx != dim || ldy != dim) gather = true;
+  // (a window of taller matrices is NOT a gather: rows keep their place inside the window, only the column stride differs)
   BJX_REQUIRE(ctx, total == dim, BJX_ERR_SHAPE, "input length mismatch (%lld != %lld)", (long long)total, (long long)dim);   // stacked.jl:157
   const size_t seg_bytes = ((size_t)n_segs * sizeof(SegDev) + 63) / 64 * 64;
   const size_t tab_bytes = (size_t)dim * stacked_row_bytes<T>();
@@ -615,7 +615,8 @@ BJX_API int bjx_stacked(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int
 }
 
 /* bjx_stacked with separate leading dimensions: x is [ldx, batch], y is [ldy, batch], the segments produce the first `dim`
- * rows of y from any rows of x (every row is gathered).  What a Stacked with structured segments needs (stacked.jl:142-166):
+ * rows of y (from `y` on) out of rows of x (from `x` on); rows that keep their offset (in_lo == out_lo for every segment: a
+ * WINDOW of the two matrices) stream as packs, otherwise every row is gathered.  What a Stacked with structured segments needs (stacked.jl:142-166):
  * the elementwise segments in ONE launch here (the rows of the structured segments are covered by identity placeholders),
  * then the structured entry points with a leading dimension (bjx_simplex_ld, bjx_ordered_ld) overwrite their rows in place. */
 BJX_API int bjx_stacked_ld(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const void* x, int64_t ldx, void* y, int64_t ldy,

@@ -1431,45 +1431,56 @@ class Stacked(Transform):
         ps = torch.zeros(batch, dtype=xc.dtype, device=xc.device) if (want_ladj and out.ps is not None) else None
         sm = torch.zeros(1, dtype=torch.float64, device=xc.device) if (want_ladj and out.sum is not None) else None
         lib = L.load()
-        if fused:
-            segs = []
-            for i in range(len(self.bs)):
-                (lo, hi), (olo, ohi) = self.ranges_in[i], self.ranges_out[i]
-                if i in fused:
-                    segs.append((lo - 1, olo - 1, hi - lo + 1, segs_ops[i]))
-                else:                                            # placeholder: identity from any valid rows, overwritten in step 2
-                    n_out = ohi - olo + 1
-                    if n_out > dim:
-                        return None
-                    segs.append((min(lo - 1, dim - n_out), olo - 1, n_out, []))
-            arr = (L.BjxSegment * len(segs))()
-            keep = []
-            for si, (ilo, olo0, ln, ops) in enumerate(segs):
-                sg = arr[si]
-                sg.in_lo, sg.out_lo, sg.len, sg.n_ops = ilo, olo0, ln, len(ops)
-                for k, (kind, p0, p1) in enumerate(ops):
-                    o = sg.ops[k]
-                    o.kind, o.param_len, o.p0, o.p1, o.v0, o.v1 = kind, 0, 0.0, 0.0, None, None
-                    seq = any(_is_seq(p) for p in (p0, p1) if p is not None)
-                    for j, p in enumerate((p0, p1)):
-                        if p is None:
-                            continue
-                        if seq:
-                            t = _param(p, xc).reshape(-1) if _is_seq(p) else torch.full((ln,), float(p), dtype=xc.dtype, device=xc.device)
-                            if t.numel() != ln:
-                                raise ValueError(f"DimensionMismatch: parameter of length {t.numel()} for a segment of {ln} rows")
-                            keep.append(t)
-                            o.param_len = ln
-                            setattr(o, f"v{j}", t.data_ptr())
-                        else:
-                            o.param_len = 1
-                            setattr(o, f"p{j}", float(p))
-            rc = lib.bjx_stacked_ld(ctx.h, _dt(xc), arr, len(segs), _ptr(xc), dim, _ptr(y), dout, _ptr(ps), _ptr(sm), dout, batch, 0)
-            del keep
-            if rc == L.ERR_UNSUPPORTED:
-                return None
-            L.check(ctx.h, rc, "bjx_stacked_ld")
         es = xc.element_size()
+        first = True
+        if fused:
+            # maximal runs of elementwise segments that are contiguous on BOTH sides keep their row offsets inside a window of
+            # x and y: one bjx_stacked_ld launch per run, streaming packs (no gather), log-dets accumulated run after run
+            order = sorted(fused, key=lambda i: self.ranges_out[i][0])
+            runs, cur = [], []
+            for i in order:
+                if cur and self.ranges_out[i][0] == self.ranges_out[cur[-1]][1] + 1 and self.ranges_in[i][0] == self.ranges_in[cur[-1]][1] + 1:
+                    cur.append(i)
+                else:
+                    if cur:
+                        runs.append(cur)
+                    cur = [i]
+            if cur:
+                runs.append(cur)
+            for run in runs:
+                x_off, y_off = self.ranges_in[run[0]][0] - 1, self.ranges_out[run[0]][0] - 1
+                rows_run = sum(self.ranges_in[i][1] - self.ranges_in[i][0] + 1 for i in run)
+                arr = (L.BjxSegment * len(run))()
+                keep = []
+                for si, i in enumerate(run):
+                    lo, hi = self.ranges_in[i]
+                    ln, ops = hi - lo + 1, segs_ops[i]
+                    sg = arr[si]
+                    sg.in_lo, sg.out_lo, sg.len, sg.n_ops = lo - 1 - x_off, self.ranges_out[i][0] - 1 - y_off, ln, len(ops)
+                    for k, (kind, p0, p1) in enumerate(ops):
+                        o = sg.ops[k]
+                        o.kind, o.param_len, o.p0, o.p1, o.v0, o.v1 = kind, 0, 0.0, 0.0, None, None
+                        seq = any(_is_seq(p) for p in (p0, p1) if p is not None)
+                        for j, p in enumerate((p0, p1)):
+                            if p is None:
+                                continue
+                            if seq:
+                                t = _param(p, xc).reshape(-1) if _is_seq(p) else torch.full((ln,), float(p), dtype=xc.dtype, device=xc.device)
+                                if t.numel() != ln:
+                                    raise ValueError(f"DimensionMismatch: parameter of length {t.numel()} for a segment of {ln} rows")
+                                keep.append(t)
+                                o.param_len = ln
+                                setattr(o, f"v{j}", t.data_ptr())
+                            else:
+                                o.param_len = 1
+                                setattr(o, f"p{j}", float(p))
+                rc = lib.bjx_stacked_ld(ctx.h, _dt(xc), arr, len(run), C.c_void_p(xc.data_ptr() + x_off * es), dim, C.c_void_p(y.data_ptr() + y_off * es), dout,
+                                        _ptr(ps), _ptr(sm), rows_run, batch, 0 if first else L.BJX_ACCUMULATE)
+                del keep
+                if rc == L.ERR_UNSUPPORTED:
+                    return None
+                L.check(ctx.h, rc, "bjx_stacked_ld")
+                first = False
         for i in rest:
             fn, inv = struct_of(self.bs[i])
             (lo, hi), (olo, ohi) = self.ranges_in[i], self.ranges_out[i]
