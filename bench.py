@@ -402,8 +402,17 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # BJX_BENCH_BACKEND=gloo BJX_BENCH_ONE_DEVICE=1: N ranks on ONE GPU over gloo — exercises the multi-rank code path
+        # (sharding, rows, strong-scaling sub-lines, max-over-ranks timing) on the single-GPU boxes this build has; the
+        # driver's multi-GPU runs use the defaults (one GPU per rank, "nccl" = RCCL over xGMI)
+        backend = os.environ.get("BJX_BENCH_BACKEND", "nccl")
+        if os.environ.get("BJX_BENCH_ONE_DEVICE"):
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
         dist = None
