@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbjx_hip.so")
+LIB_PATH = os.environ.get("BJX_LIB_PATH") or os.path.join(_HERE, "libbjx_hip.so")   # override: A/B of two builds in one GPU call
 
 BJX_F32, BJX_F64 = 0, 1
 BJX_ACCUMULATE = 1 << 0

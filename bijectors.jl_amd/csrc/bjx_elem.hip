@@ -145,12 +145,20 @@ __global__ __launch_bounds__(256) void rqs_params_kernel(const T* rw, const T* r
 //  * lets one block walk ITER column groups so the table staging is amortised.
 // Bin selection is exact (same knot values and comparisons as the oracle).
 //
-// LDS blob, in units of T (built by rqs_blob_kernel in the context scratch, copied verbatim):
+// LDS blob (built by rqs_blob_kernel in the context scratch, copied verbatim), key part in units of T:
 //   [0, dimp)                         lim[rp]          = knot K (range limit) of permuted row rp
 //   [dimp·2^(l-1), dimp·2^l)          level l keys     [rp][2^(l-1)],  l = 1..NSTEP
-//   [dimp·2^NSTEP, +4·dimp·RS)        record half A    [rp][RS] x 4    {w_k, 1/w, h_k, Δy}  (inverse: {h_k, Δy, w_k, w})
-//   [.. , +4·dimp·RS)                 record half B    [rp][RS] x 4    {s, d_k, d_k+1 + d_k - 2s, d_k+1 - d_k}
-// rp = j·nvc + v for row v·V + j (V = pack width, nvc = packs per column); RS = nslots + 1 (skew).
+// then the bin records in 256-byte LDS rows of sixteen 16-byte slots.  A lane always reads slot (lane & 15): the
+// ds_read_b128 lane groups hold one lane of every residue mod 16, so sixteen different records — whatever bins the
+// sixteen lanes landed in — come from sixteen different slots of the bank row, without conflicts.  (With the records
+// of one table row contiguous the sixteen random bins of a lane group collided ~3-way: SQ_LDS_BANK_CONFLICT was
+// 62 % of the LDS cycles and the LDS pipe as busy as the VALU.)  Row index:
+//   ((j·GH + hi)·NS + pos)·RQ + q     j = element of the pack, hi = lane-in-group / 16, pos = bin slot,
+//                                     q = quad of the record: Float32 A, B; Float64 A.lo, A.hi, B.lo, B.hi with
+//                                     A = {-w_k/w, 1/w, h_k, Δy}  (inverse: {h_k, Δy, w_k, w}),
+//                                     B = {s, d_k, d_k+1 + d_k - 2s, d_k+1 - d_k}
+// and slot s of a row holds the record of the group lane gl = hi·16 + s (groups of 16+ lanes) or gl = s mod G
+// (narrower groups: 16/G copies).  rp = j·nvc + gl for row gl·V + j (V = pack width, nvc = packs per column).
 struct RqsGeom {
   int K1;       // knots per row
   int nvc;      // packs per column (dim / V)
@@ -159,24 +167,34 @@ struct RqsGeom {
   int nstep;    // search levels
   int kbase;    // 1: bin 0 dropped
   int nslots;   // bins kept = K1 - kbase
-  int RS;       // record row stride (records)
+  int G;        // lanes per column group (power of two >= nvc)
+  int GH;       // 16-lane slices of a group: max(1, G / 16)
 };
-__host__ __device__ inline RqsGeom rqs_geom(int K1, int64_t dim, int V, int skip0, int nstep_hi) {
+__host__ __device__ inline RqsGeom rqs_geom(int K1, int64_t dim, int V, int skip0, int nstep_hi, int G) {
   RqsGeom g;
   g.K1 = K1; g.V = V; g.nvc = (int)(dim / V); g.dimp = (int)((dim + 3) / 4 * 4);
   g.kbase = skip0 ? 1 : 0;
   g.nstep = nstep_hi - g.kbase;
   g.nslots = K1 - g.kbase;
-  g.RS = g.nslots + 1;
+  g.G = G; g.GH = G > 16 ? G / 16 : 1;
   return g;
 }
-__host__ __device__ inline size_t rqs_blob_words(const RqsGeom& g) { return (size_t)g.dimp * (1u << g.nstep) + 8 * (size_t)g.dimp * g.RS; }
+template <class T> struct RqsRec { static constexpr int RQ = sizeof(T) == 4 ? 2 : 4; static constexpr int PS = sizeof(T) == 4 ? 9 : 10; };   // quads per record, log2(bytes per bin)
+template <class T> __host__ __device__ inline size_t rqs_key_bytes(const RqsGeom& g) { return (size_t)g.dimp * (1u << g.nstep) * sizeof(T); }
+template <class T> __host__ __device__ inline size_t rqs_blob_bytes(const RqsGeom& g) {
+  return rqs_key_bytes<T>(g) + (size_t)g.V * g.GH * g.nslots * RqsRec<T>::RQ * 256;
+}
+// byte offset (from the blob start) of the record of (pack element j, lane) at bin 0; bin pos adds pos << PS, quad q adds 256 q
+template <class T> __device__ __forceinline__ int rqs_rec_base(const RqsGeom& g, int j, int lane, int gl) {
+  const int hi = g.G > 16 ? gl >> 4 : 0;
+  return (int)rqs_key_bytes<T>(g) + (((j * g.GH + hi) * g.nslots) << RqsRec<T>::PS) + (lane & 15) * 16;
+}
 
 // One block: (i) flag[0] = 1 iff knot 1 <= -knot K for widths and heights of every row (bin 0
 // unreachable, only evaluated when `dual`), (ii) the LDS blob in the layout above.
 template <class T, bool INV>
 __global__ __launch_bounds__(256) void rqs_blob_kernel(const T* w, const T* h, const T* d, int K1, int64_t rows, int V, int nstep_hi,
-                                                       int dual, int* flag, T* blob) {
+                                                       int dual, int G, int* flag, T* blob) {
   __shared__ int bad;
   if (threadIdx.x == 0) bad = 0;
   __syncthreads();
@@ -187,19 +205,16 @@ __global__ __launch_bounds__(256) void rqs_blob_kernel(const T* w, const T* h, c
   __syncthreads();
   const int skip0 = (dual && !bad) ? 1 : 0;
   if (threadIdx.x == 0) flag[0] = skip0;
-  const RqsGeom g = rqs_geom(K1, rows, V, skip0, nstep_hi);
+  const RqsGeom g = rqs_geom(K1, rows, V, skip0, nstep_hi, G);
   const int nkeys = (1 << g.nstep) - 1;
-  const int per_row = nkeys > g.nslots ? nkeys : g.nslots;
+  const int per_row = nkeys > 1 ? nkeys : 1;
   const int64_t total = (int64_t)g.dimp * per_row;
-  T* recA = blob + (size_t)g.dimp * (1u << g.nstep);
-  T* recB = recA + 4 * (size_t)g.dimp * g.RS;
   for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
     const int rp = (int)(i / per_row), s = (int)(i % per_row);
     const int64_t r = (int64_t)(rp % g.nvc) * g.V + rp / g.nvc;   // actual row
     const bool live = rp < g.V * g.nvc && r < rows;
     auto W = [&](int j) { return w[(int64_t)(j - 1) * rows + r]; };   // 1-based knot j of row r
     auto H = [&](int j) { return h[(int64_t)(j - 1) * rows + r]; };
-    auto D = [&](int j) { return d[(int64_t)(j - 1) * rows + r]; };
     if (s == 0) blob[rp] = live ? (INV ? H(K1) : W(K1)) : T(0);
     if (s < nkeys) {
       // sorted searched key s (0-based) = knot kbase + s + 1, padded with +inf; tree position:
@@ -209,37 +224,55 @@ __global__ __launch_bounds__(256) void rqs_blob_kernel(const T* w, const T* h, c
       if (live && s < g.nslots - 1) kv = INV ? H(g.kbase + s + 1) : W(g.kbase + s + 1);
       blob[(size_t)g.dimp * (1u << (lvl - 1)) + (size_t)rp * (1u << (lvl - 1)) + path] = kv;
     }
-    if (s < g.nslots) {
-      T a[4] = {T(0), T(1), T(0), T(0)}, b[4] = {T(1), T(1), T(0), T(0)};
-      if (live) {
-        const int k = s + g.kbase;                                   // bin k spans knots k..k+1 (knot 0 = -knot K)
-        const T w_k = (k == 0) ? -W(K1) : W(k);                      // :140,:192
-        const T wd = W(k + 1) - w_k;
-        const T h_k = (k == 0) ? -H(K1) : H(k);
-        const T dy = H(k + 1) - h_k;
-        const T sl = dy / wd;                                        // s = Δy/w
-        const T d_k = (k == 0) ? T(1) : D(k);
-        const T d_k1 = (k == K1 - 1) ? T(1) : D(k + 1);
-        if (!INV) { a[1] = T(1) / wd; a[0] = -w_k * a[1]; a[2] = h_k; a[3] = dy; }   // ξ = x·(1/w) − w_k/w: one FMA per element
-        else { a[0] = h_k; a[1] = dy; a[2] = w_k; a[3] = wd; }
-        b[0] = sl; b[1] = d_k; b[2] = d_k1 + d_k - 2 * sl; b[3] = d_k1 - d_k;
-      }
-      T* pa = recA + 4 * ((size_t)rp * g.RS + s);
-      T* pb = recB + 4 * ((size_t)rp * g.RS + s);
+  }
+  // records: one per (pack element j, 16-lane slice hi, bin slot, slot of the LDS row)
+  char* rec = reinterpret_cast<char*>(blob) + rqs_key_bytes<T>(g);
+  constexpr int RQ = RqsRec<T>::RQ;
+  const int64_t nrec = (int64_t)g.V * g.GH * g.nslots * 16;
+  for (int64_t i = threadIdx.x; i < nrec; i += blockDim.x) {
+    const int slot = (int)(i & 15);
+    const int s = (int)((i >> 4) % g.nslots);
+    const int jh = (int)((i >> 4) / g.nslots);
+    const int j = jh / g.GH, hi = jh % g.GH;
+    const int gl = g.G > 16 ? hi * 16 + slot : (slot & (g.G - 1));
+    const int64_t r = (int64_t)gl * g.V + j;                          // actual row
+    const bool live = gl < g.nvc && r < rows;
+    auto W = [&](int q) { return w[(int64_t)(q - 1) * rows + r]; };   // 1-based knot q of row r
+    auto H = [&](int q) { return h[(int64_t)(q - 1) * rows + r]; };
+    auto D = [&](int q) { return d[(int64_t)(q - 1) * rows + r]; };
+    T a[4] = {T(0), T(1), T(0), T(0)}, b[4] = {T(1), T(1), T(0), T(0)};
+    if (live) {
+      const int k = s + g.kbase;                                   // bin k spans knots k..k+1 (knot 0 = -knot K)
+      const T w_k = (k == 0) ? -W(K1) : W(k);                      // :140,:192
+      const T wd = W(k + 1) - w_k;
+      const T h_k = (k == 0) ? -H(K1) : H(k);
+      const T dy = H(k + 1) - h_k;
+      const T sl = dy / wd;                                        // s = Δy/w
+      const T d_k = (k == 0) ? T(1) : D(k);
+      const T d_k1 = (k == K1 - 1) ? T(1) : D(k + 1);
+      if (!INV) { a[1] = T(1) / wd; a[0] = -w_k * a[1]; a[2] = h_k; a[3] = dy; }   // ξ = x·(1/w) − w_k/w: one FMA per element
+      else { a[0] = h_k; a[1] = dy; a[2] = w_k; a[3] = wd; }
+      b[0] = sl; b[1] = d_k; b[2] = d_k1 + d_k - 2 * sl; b[3] = d_k1 - d_k;
+    }
+    char* row0 = rec + ((((size_t)(j * g.GH + hi) * g.nslots + s) * RQ) << 8) + slot * 16;
+    constexpr int PER = 16 / (int)sizeof(T);                           // values per 16-byte quad
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { pa[q] = a[q]; pb[q] = b[q]; }
+    for (int q = 0; q < 4; ++q) {
+      reinterpret_cast<T*>(row0 + ((q / PER) << 8))[q % PER] = a[q];
+      reinterpret_cast<T*>(row0 + ((RQ / 2 + q / PER) << 8))[q % PER] = b[q];
     }
   }
 }
 
 template <class T> struct Rec4 { T v[4]; };
-template <class T> __device__ __forceinline__ Rec4<T> lds_rec(const T* p) {
+// record half (A: q0 = 0, B: q0 = RQ/2) from the slotted rows: quads 256 bytes apart
+template <class T> __device__ __forceinline__ Rec4<T> lds_rec(const char* p, int q0) {
   Rec4<T> r;
   if constexpr (sizeof(T) == 4) {
-    bjx_f32x4 t = *reinterpret_cast<const bjx_f32x4*>(p);
+    bjx_f32x4 t = *reinterpret_cast<const bjx_f32x4*>(p + (q0 << 8));
     r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
   } else {
-    bjx_f64x2 t0 = *reinterpret_cast<const bjx_f64x2*>(p), t1 = *reinterpret_cast<const bjx_f64x2*>(p + 2);
+    bjx_f64x2 t0 = *reinterpret_cast<const bjx_f64x2*>(p + (q0 << 8)), t1 = *reinterpret_cast<const bjx_f64x2*>(p + ((q0 + 1) << 8));
     r.v[0] = t0.x; r.v[1] = t0.y; r.v[2] = t1.x; r.v[3] = t1.y;
   }
   return r;
@@ -312,34 +345,49 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
   // per-lane constants: a lane owns rows glc*V + j of every column.  lb[l][j] / ra / rb are LDS BYTE
   // offsets so the per-element address is one v_lshl_add_u32 of the search position.
   T lim[V], k1[V], k2a[V], k2b[V];
-  int lb[NSTEP > 2 ? NSTEP - 2 : 1][V], ra[V], rb[V];
+  int lb[NSTEP > 2 ? NSTEP - 2 : 1][V], ra[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     const int rp = j * g.nvc + glc;
-    lim[j] = blob_l[rp];
+    lim[j] = lane_ok ? blob_l[rp] : T(0);          // an idle lane of the group (zeros from its out-of-range loads) is "outside": log-det 0
     k1[j] = blob_l[g.dimp + rp];
     if (NSTEP >= 2) { k2a[j] = blob_l[2 * g.dimp + 2 * rp]; k2b[j] = blob_l[2 * g.dimp + 2 * rp + 1]; }
     else { k2a[j] = k2b[j] = T(0); }
 #pragma unroll
     for (int lvl = 3; lvl <= NSTEP; ++lvl) lb[lvl - 3][j] = (int)sizeof(T) * ((g.dimp + rp) << (lvl - 1));
-    ra[j] = (int)sizeof(T) * ((g.dimp << NSTEP) + 4 * rp * g.RS);
-    rb[j] = ra[j] + (int)sizeof(T) * 4 * g.dimp * g.RS;
+    ra[j] = rqs_rec_base<T>(g, j, (int)threadIdx.x, glc);
     // opaque to the optimiser: otherwise the constants are re-read from LDS inside the column loop
     asm volatile("" : "+v"(lim[j]), "+v"(k1[j]), "+v"(k2a[j]), "+v"(k2b[j]));
   }
   constexpr int SH = sizeof(T) == 4 ? 2 : 3;
-  // uniform block base + 32-bit lane offset: the per-iteration address is one scalar add
+  // The column loop is STRAIGHT-LINE code: every global access goes through a buffer descriptor whose extent is the
+  // block's remaining columns, so a lane past the end (or an idle lane of the group) reads zeros and its stores are
+  // dropped by the range check instead of sitting behind an exec branch.  With branches around the loads and stores
+  // the compiler could not count the memory operations in flight and drained ALL of them (s_waitcnt vmcnt(0), twice
+  // per trip) — every wave waited for the acknowledgement of the stores it had just issued before it could touch the
+  // columns that had been prefetched a trip earlier (PMC: 54 % of the wave cycles in s_waitcnt).  Now the wait is
+  // "all but the newest k operations".
   const int64_t bcol0 = (int64_t)blockIdx.x * iters * cols_per_block;
-  const T* xb = x + bcol0 * dim;
-  T* yb = y + bcol0 * dim;
-  T* lb_ps = ladj_ps ? ladj_ps + bcol0 : nullptr;
   const int cg = threadIdx.x / G;
-  const int loff = cg * (int)dim + gl * V;                 // < 2^31: a block spans iters*cols_per_block*dim elements
-  const int64_t left = batch - bcol0 - cg;                 // my columns: it*cols_per_block < left
-  const int my_cols = left > (int64_t)iters * cols_per_block ? iters * cols_per_block : (left > 0 ? (int)left : 0);
-  const int64_t it_stride = (int64_t)cols_per_block * dim;
-  // (A/B in one run, 2^22 columns: dropping the look-ahead (load, evaluate, store) or alternating two buffer pairs to save the
-  // 16 pack-copy v_mov per trip are both 25-30 % SLOWER — 0.31 vs 0.23 ms forward — so the look-ahead with copies stays.)
+  const int64_t left_blk = batch - bcol0;
+  const int ncols_blk = left_blk > (int64_t)iters * cols_per_block ? iters * cols_per_block : (left_blk > 0 ? (int)left_blk : 0);
+  const int col_bytes = (int)dim * (int)sizeof(T);                     // a block spans < 2^31 bytes (dim <= 256 on this path)
+  const int trip_cols = cols_per_block;
+  constexpr int kOob = 0x7fffff00;                                     // beyond any extent: loads give 0, stores are dropped
+  const int vo0 = lane_ok ? (cg * (int)dim + gl * V) * (int)sizeof(T) : kOob;
+  const int vo1 = lane_ok ? vo0 + trip_cols * col_bytes : kOob;
+  const int lo0 = gl == 0 ? cg * (int)sizeof(T) : kOob;                // the group's first lane owns the column's log-det
+  const int lo1 = gl == 0 ? lo0 + trip_cols * (int)sizeof(T) : kOob;
+  const int my_cols = gl == 0 ? ncols_blk - cg : 0;                    // columns whose log-det this lane adds to the block partial
+  const char* xb = reinterpret_cast<const char*>(x + bcol0 * dim);
+  char* yb = reinterpret_cast<char*>(y + bcol0 * dim);
+  char* lpb = reinterpret_cast<char*>(ladj_ps ? ladj_ps + bcol0 : nullptr);
+  // descriptors of trip `it` (two column groups from block column it*trip_cols on)
+  auto extent = [&](int it, int unit) -> uint32_t { const int r = ncols_blk - it * trip_cols; return r > 0 ? (uint32_t)r * (uint32_t)unit : 0u; };
+  auto rsrc_x = [&](int it) { return bjx_make_rsrc(xb + (int64_t)it * trip_cols * col_bytes, extent(it, col_bytes)); };
+  auto rsrc_y = [&](int it) { return bjx_make_rsrc(yb + (int64_t)it * trip_cols * col_bytes, extent(it, col_bytes)); };
+  auto rsrc_l = [&](int it) { return bjx_make_rsrc(lpb + (int64_t)it * trip_cols * (int)sizeof(T), lpb ? extent(it, (int)sizeof(T)) : 0u); };
+  auto rsrc_l_in = [&](int it) { return bjx_make_rsrc(lpb + (int64_t)it * trip_cols * (int)sizeof(T), (lpb && accumulate) ? extent(it, (int)sizeof(T)) : 0u); };
   // TWO columns per trip (the per-column epilogue — G-lane butterfly behind wave-uniform branches, log-det
   // store, loop control — costs ~40 VALU, a quarter of a 4-element pack's evaluation) and one trip of
   // look-ahead: the next two loads are in flight while these are evaluated.
@@ -361,36 +409,58 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
     Rec4<T> A[V], B[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      A[j] = lds_rec<T>(reinterpret_cast<const T*>(base + ((pos[j] << (SH + 2)) + ra[j])));
-      B[j] = lds_rec<T>(reinterpret_cast<const T*>(base + ((pos[j] << (SH + 2)) + rb[j])));
+      const char* rec = base + ((pos[j] << RqsRec<T>::PS) + ra[j]);
+      A[j] = lds_rec<T>(rec, 0);
+      B[j] = lds_rec<T>(rec, RqsRec<T>::RQ / 2);
     }
     T l = T(0);
 #pragma unroll
     for (int j = 0; j < V; ++j) l += rqs_eval<T, INV>(A[j], B[j], lim[j], p.v[j]);
     return l;
   };
+  const GroupMasks gm = make_group_masks(G);
   Pack<T, V> pn0, pn1;
-  if (0 < my_cols && lane_ok) pn0 = load_pack<T, V, true>(xb + loff);
-  if (cols_per_block < my_cols && lane_ok) pn1 = load_pack<T, V, true>(xb + it_stride + loff);
+  {
+    const auto r0 = rsrc_x(0);
+    pn0 = buf_load_pack<T, V>(r0, vo0);
+    pn1 = buf_load_pack<T, V>(r0, vo1);
+    // the first columns land before the loop: otherwise the loop head inherits "wait until at most 4 operations are
+    // outstanding" from this entry edge, which on every later trip means waiting for the previous trip's stores
+#pragma unroll
+    for (int j = 0; j < V; ++j) asm volatile("" : "+v"(pn0.v[j]), "+v"(pn1.v[j]));   // a use: the wait sits here, outside the loop
+  }
   for (int it = 0; it < iters; it += 2) {
-    const bool ok0 = it * cols_per_block < my_cols && lane_ok;
-    const bool ok1 = (it + 1) * cols_per_block < my_cols && lane_ok && it + 1 < iters;
     Pack<T, V> p0 = pn0, p1 = pn1;
-    if ((it + 2) * cols_per_block < my_cols && lane_ok) pn0 = load_pack<T, V, true>(xb + 2 * it_stride + loff);
-    if ((it + 3) * cols_per_block < my_cols && lane_ok) pn1 = load_pack<T, V, true>(xb + 3 * it_stride + loff);
-    T l0 = T(0), l1 = T(0);
-    if (ok0) { l0 = eval_pack(p0); store_pack<T, V, true>(yb + loff, p0); }
-    if (ok1) { l1 = eval_pack(p1); store_pack<T, V, true>(yb + it_stride + loff, p1); }
-    group_sum2_rt(l0, l1, G);
+    // BJX_ACCUMULATE: read-modify-write of the log-det.  The reads are issued FIRST in the trip (the counter of
+    // outstanding memory operations is in-order: waiting for the newest operation waits for everything before it) and,
+    // without the flag, go through an EMPTY descriptor (zeros, no memory access) rather than around a branch — a
+    // conditional load inside the loop makes the compiler drain every outstanding operation at the loop head.
+    const auto rl_in = rsrc_l_in(it);
+    const T lin0 = buf_load_pack<T, 1>(rl_in, lo0).v[0], lin1 = buf_load_pack<T, 1>(rl_in, lo1).v[0];
+    {
+      const auto rn = rsrc_x(it + 2);
+      pn0 = buf_load_pack<T, V>(rn, vo0);
+      pn1 = buf_load_pack<T, V>(rn, vo1);
+    }
+    const auto ry = rsrc_y(it);
+    // the fences keep the loads at the head of the trip (a full trip of look-ahead) and the two evaluations apart
+    // (interleaved by the scheduler they need 130 VGPRs instead of ~100)
+    __builtin_amdgcn_sched_barrier(0);
+    T l0 = eval_pack(p0);
+    buf_store_pack<T, V>(ry, vo0, p0);
+    __builtin_amdgcn_sched_barrier(0);
+    T l1 = eval_pack(p1);
+    buf_store_pack<T, V>(ry, vo1, p1);
+    __builtin_amdgcn_sched_barrier(0);
+    group_sum2_flat(l0, l1, gm);
     l0 *= Num<T>::log2;                               // log2 -> natural log, once per column
     l1 *= Num<T>::log2;
-    if (gl == 0) {
-      if (ok0) { if (lb_ps) lb_ps[cg] = accumulate ? lb_ps[cg] + l0 : l0; acc += (double)l0; }
-      if (ok1) { if (lb_ps) lb_ps[cols_per_block + cg] = accumulate ? lb_ps[cols_per_block + cg] + l1 : l1; acc += (double)l1; }
-    }
-    xb += 2 * it_stride;
-    yb += 2 * it_stride;
-    if (lb_ps) lb_ps += 2 * cols_per_block;
+    const auto rl = rsrc_l(it);
+    const T s0 = l0 + lin0, s1 = l1 + lin1;
+    buf_store_pack<T, 1>(rl, lo0, Pack<T, 1>{{s0}});
+    buf_store_pack<T, 1>(rl, lo1, Pack<T, 1>{{s1}});
+    acc += (double)(it * trip_cols < my_cols ? l0 : T(0));
+    acc += (double)((it + 1) * trip_cols < my_cols ? l1 : T(0));
   }
 }
 
@@ -402,9 +472,9 @@ __global__ __launch_bounds__(256) void rqs_lds_kernel(const T* __restrict__ blob
   __shared__ double red[4];
   T* blob_l = reinterpret_cast<T*>(smem);
   const int skip0 = DUAL ? flag[0] : 0;
-  const RqsGeom g = rqs_geom(K1, dim, V, skip0, NSTEP_HI);
+  const RqsGeom g = rqs_geom(K1, dim, V, skip0, NSTEP_HI, G);
   {
-    const int n16 = (int)(rqs_blob_words(g) * sizeof(T) / 16);
+    const int n16 = (int)(rqs_blob_bytes<T>(g) / 16);
     const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(blob);
     bjx_f32x4* dst = reinterpret_cast<bjx_f32x4*>(blob_l);
     for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
@@ -461,9 +531,9 @@ __global__ __launch_bounds__(256) void rqs_vjp_kernel(const T* __restrict__ blob
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* blob_l = reinterpret_cast<T*>(smem);
   const int skip0 = dual ? flag[0] : 0;
-  const RqsGeom g = rqs_geom(K1, dim, V, skip0, nstep_hi);
+  const RqsGeom g = rqs_geom(K1, dim, V, skip0, nstep_hi, G);
   {
-    const int n16 = (int)(rqs_blob_words(g) * sizeof(T) / 16);
+    const int n16 = (int)(rqs_blob_bytes<T>(g) / 16);
     const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(blob);
     bjx_f32x4* dst = reinterpret_cast<bjx_f32x4*>(blob_l);
     for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
@@ -475,15 +545,13 @@ __global__ __launch_bounds__(256) void rqs_vjp_kernel(const T* __restrict__ blob
   const bool lane_ok = gl < g.nvc;
   const int glc = lane_ok ? gl : 0;
   const char* base = reinterpret_cast<const char*>(blob_l);
-  constexpr int SH = sizeof(T) == 4 ? 2 : 3;
   T lim[V];
-  int rp[V], ra[V], rb[V];
+  int rp[V], ra[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     rp[j] = j * g.nvc + glc;
     lim[j] = blob_l[rp[j]];
-    ra[j] = (int)sizeof(T) * ((g.dimp << NS) + 4 * rp[j] * g.RS);
-    rb[j] = ra[j] + (int)sizeof(T) * 4 * g.dimp * g.RS;
+    ra[j] = rqs_rec_base<T>(g, j, (int)threadIdx.x, glc);
   }
   const int64_t col_base = (int64_t)blockIdx.x * iters * cols_per_block + cg;
   for (int it = 0; it < iters; ++it) {
@@ -499,8 +567,9 @@ __global__ __launch_bounds__(256) void rqs_vjp_kernel(const T* __restrict__ blob
         const T key = blob_l[((size_t)(g.dimp + rp[j]) << (lvl - 1)) + pos];
         pos = 2 * pos + (key < p.v[j] ? 1 : 0);
       }
-      const Rec4<T> A = lds_rec<T>(reinterpret_cast<const T*>(base + ((pos << (SH + 2)) + ra[j])));
-      const Rec4<T> B = lds_rec<T>(reinterpret_cast<const T*>(base + ((pos << (SH + 2)) + rb[j])));
+      const char* rec = base + ((pos << RqsRec<T>::PS) + ra[j]);
+      const Rec4<T> A = lds_rec<T>(rec, 0);
+      const Rec4<T> B = lds_rec<T>(rec, RqsRec<T>::RQ / 2);
       p.v[j] = rqs_eval_vjp<T, INV>(A, B, lim[j], p.v[j], gp.v[j], lb);
     }
     store_pack<T, V, true>(xbar + col * dim + (int64_t)gl * V, p);
@@ -703,6 +772,17 @@ template <class T> struct PermuteF {
 
 template <class T> bool knots_fit_lds(int64_t rows, int K1) { return (size_t)rows * K1 * 3 * sizeof(T) <= 60 * 1024; }
 
+// largest knot blob the LDS kernels take (the default dynamic-LDS limit of a launch); beyond it the generic functor path runs
+constexpr size_t kRqsBlobMax = 64 * 1024;
+// Column groups per block: enough to amortise the table staging (>= ~4x the table bytes of data).
+inline int rqs_iters(const bjx_ctx* ctx, size_t blob_bytes, int64_t bytes_per_group, int64_t groups) {
+  static const int forced = [] { const char* e = getenv("BJX_RQS_ITERS"); return e ? atoi(e) : 0; }();   // tuning switch
+  if (forced > 0) return forced;
+  int64_t amort = (4 * (int64_t)blob_bytes + bytes_per_group - 1) / bytes_per_group;
+  if (amort < 1) amort = 1;
+  if (amort > 64) amort = 64;
+  return (int)amort;
+}
 inline int ceil_log2(int n) { int s = 0; while ((1 << s) < n) ++s; return s; }
 
 template <class T, int V, bool INV>
@@ -735,9 +815,9 @@ int rqs_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int 
   ColLaunch c = col_launch_cfg<T>(ctx, in, out, dim, batch);
   const int nstep_hi = ceil_log2(K1 < 2 ? 2 : K1);
   const int dual = (K1 >= 3 && ceil_log2(K1 - 1) < nstep_hi) ? 1 : 0;
-  const RqsGeom g_hi = rqs_geom(K1, dim, c.V, 0, nstep_hi);
-  const size_t blob_bytes = rqs_blob_words(g_hi) * sizeof(T);      // the no-skip layout is the larger one
-  const bool lds_path = nstep_hi <= 6 && dim / c.V <= 64 && dim < (1 << 20) && blob_bytes <= 64 * 1024 && blob_bytes + 64 <= BJX_SCRATCH_BYTES;
+  const RqsGeom g_hi = rqs_geom(K1, dim, c.V, 0, nstep_hi, c.G);
+  const size_t blob_bytes = rqs_blob_bytes<T>(g_hi);      // the no-skip layout is the larger one
+  const bool lds_path = nstep_hi <= 6 && dim / c.V <= 64 && dim < (1 << 20) && blob_bytes <= kRqsBlobMax && blob_bytes + 64 <= BJX_SCRATCH_BYTES;
   if (!lds_path) {   // huge knot tables / very wide columns: generic functor path
     const bool lds = knots_fit_lds<T>(dim, K1);
     const size_t fsm = lds ? (size_t)dim * K1 * 3 * sizeof(T) : 0;
@@ -747,16 +827,12 @@ int rqs_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int 
   }
   int* flag = reinterpret_cast<int*>(ctx->scratch);
   T* blob = reinterpret_cast<T*>(static_cast<char*>(ctx->scratch) + 64);
-  if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, flag, blob);
-  else hipLaunchKernelGGL((rqs_blob_kernel<T, false>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, flag, blob);
+  if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, c.G, flag, blob);
+  else hipLaunchKernelGGL((rqs_blob_kernel<T, false>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, c.G, flag, blob);
   BJX_CHECK_LAUNCH(ctx);
   const int cols_per_block = 256 / c.G;
-  // amortise the table staging: each block walks `iters` column groups (>= ~4x the table bytes of data)
-  const int64_t bytes_per_group = (int64_t)cols_per_block * dim * sizeof(T);
-  int iters = (int)((4 * (int64_t)blob_bytes + bytes_per_group - 1) / bytes_per_group);
-  if (iters < 1) iters = 1;
-  if (iters > 64) iters = 64;
   const int64_t groups = (batch + cols_per_block - 1) / cols_per_block;
+  const int iters = rqs_iters(ctx, blob_bytes, (int64_t)cols_per_block * dim * sizeof(T), groups);
   const int64_t grid = (groups + iters - 1) / iters;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_rqs: batch too large for one launch");
   BjxFin fin;
@@ -826,9 +902,9 @@ int rqs_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, 
   if (c.V > 1 && !bjx_aligned16(out_bar)) { c.V = 1; int G = 1; while (G < 64 && G < dim) G <<= 1; c.G = G; }
   const int nstep_hi = ceil_log2(K1 < 2 ? 2 : K1);
   const int dual = (K1 >= 3 && ceil_log2(K1 - 1) < nstep_hi) ? 1 : 0;
-  const RqsGeom g_hi = rqs_geom(K1, dim, c.V, 0, nstep_hi);
-  const size_t blob_bytes = rqs_blob_words(g_hi) * sizeof(T);
-  if (!(nstep_hi <= 6 && dim / c.V <= 64 && dim < (1 << 20) && blob_bytes <= 64 * 1024 && blob_bytes + 64 <= BJX_SCRATCH_BYTES)) {
+  const RqsGeom g_hi = rqs_geom(K1, dim, c.V, 0, nstep_hi, c.G);
+  const size_t blob_bytes = rqs_blob_bytes<T>(g_hi);
+  if (!(nstep_hi <= 6 && dim / c.V <= 64 && dim < (1 << 20) && blob_bytes <= kRqsBlobMax && blob_bytes + 64 <= BJX_SCRATCH_BYTES)) {
     int64_t nb = (dim * batch + 255) / 256;
     if (nb > 256 * 64) nb = 256 * 64;
     BjxProf prof_(ctx);
@@ -839,15 +915,12 @@ int rqs_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, 
   }
   int* flag = reinterpret_cast<int*>(ctx->scratch);
   T* blob = reinterpret_cast<T*>(static_cast<char*>(ctx->scratch) + 64);
-  if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, flag, blob);
-  else hipLaunchKernelGGL((rqs_blob_kernel<T, false>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, flag, blob);
+  if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, c.G, flag, blob);
+  else hipLaunchKernelGGL((rqs_blob_kernel<T, false>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, c.G, flag, blob);
   BJX_CHECK_LAUNCH(ctx);
   const int cols_per_block = 256 / c.G;
-  const int64_t bytes_per_group = (int64_t)cols_per_block * dim * sizeof(T);
-  int iters = (int)((4 * (int64_t)blob_bytes + bytes_per_group - 1) / bytes_per_group);
-  if (iters < 1) iters = 1;
-  if (iters > 64) iters = 64;
   const int64_t groups = (batch + cols_per_block - 1) / cols_per_block;
+  const int iters = rqs_iters(ctx, blob_bytes, (int64_t)cols_per_block * dim * sizeof(T), groups);
   const int64_t grid = (groups + iters - 1) / iters;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_rqs_vjp: batch too large for one launch");
   constexpr int VW = Vec16<T>::N;

@@ -549,6 +549,92 @@ template <> __device__ __forceinline__ void group_sum2_rt<float>(float& a, float
   if (G >= 64) { a += shfl_xor(a, 32); b += shfl_xor(b, 32); }
 }
 
+// The same sums WITHOUT control flow: each butterfly stage runs under an all-or-nothing EXEC mask (all ones when the
+// group is at least that wide, zero otherwise) instead of behind a wave-uniform branch.  A column loop whose body is
+// one basic block lets the compiler count the memory operations in flight across the back edge (s_waitcnt vmcnt(k));
+// with branches in the body it drains them all at the loop head.  Every lane of the wave must be active at the call.
+struct GroupMasks { int m2, m4, m8, m16, m32, m64; int i16, i32; };   // masks: -1 / 0, the same word for both EXEC halves
+__device__ __forceinline__ GroupMasks make_group_masks(int G) {
+  GroupMasks g;
+  // (built by scalar instructions in inline assembly: a C++ select of a uniform condition may be lowered to a
+  // v_cndmask, and the "s" operands of group_sum2_flat would then be handed a VGPR)
+  const int Gu = __builtin_amdgcn_readfirstlane(G);
+  auto mask = [&](int k) -> int {
+    int m;
+    asm volatile("s_cmp_ge_i32 %1, %2\n\ts_cselect_b32 %0, -1, 0" : "=s"(m) : "s"(Gu), "s"(k) : "scc");
+    return m;
+  };
+  g.m2 = mask(2); g.m4 = mask(4); g.m8 = mask(8); g.m16 = mask(16); g.m32 = mask(32); g.m64 = mask(64);
+  const int lane = (int)(threadIdx.x & 63);
+  g.i16 = (lane ^ 16) << 2; g.i32 = (lane ^ 32) << 2;
+  return g;
+}
+#define BJX_DPP2_(ctrl_) \
+  "v_add_f32_dpp %[a], %[a], %[a] " ctrl_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_add_f32_dpp %[b], %[b], %[b] " ctrl_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void group_sum2_flat(float& a, float& b, const GroupMasks& g) {
+  uint64_t sv;
+  float t, u;
+  // (a DPP operand needs two wait states after the VALU write of its register: the other value's add and the s_mov
+  // sit between two stages of one value; the s_nop covers the first stage)
+  asm volatile("s_mov_b64 %[sv], exec\n\t"
+               "s_mov_b32 exec_lo, %[m2]\n\ts_mov_b32 exec_hi, %[m2]\n\t"
+               "s_nop 1\n\t" BJX_DPP2_("quad_perm:[1,0,3,2]")
+               "s_mov_b32 exec_lo, %[m4]\n\ts_mov_b32 exec_hi, %[m4]\n\t" BJX_DPP2_("quad_perm:[2,3,0,1]")
+               "s_mov_b32 exec_lo, %[m8]\n\ts_mov_b32 exec_hi, %[m8]\n\t" BJX_DPP2_("row_half_mirror")
+               "s_mov_b32 exec_lo, %[m16]\n\ts_mov_b32 exec_hi, %[m16]\n\t" BJX_DPP2_("row_mirror")
+               "s_mov_b32 exec_lo, %[m32]\n\ts_mov_b32 exec_hi, %[m32]\n\t"
+               "ds_bpermute_b32 %[t], %[i16], %[a]\n\t"
+               "ds_bpermute_b32 %[u], %[i16], %[b]\n\t"
+               "s_waitcnt lgkmcnt(0)\n\t"
+               "v_add_f32 %[a], %[a], %[t]\n\t"
+               "v_add_f32 %[b], %[b], %[u]\n\t"
+               "s_mov_b32 exec_lo, %[m64]\n\ts_mov_b32 exec_hi, %[m64]\n\t"
+               "ds_bpermute_b32 %[t], %[i32], %[a]\n\t"
+               "ds_bpermute_b32 %[u], %[i32], %[b]\n\t"
+               "s_waitcnt lgkmcnt(0)\n\t"
+               "v_add_f32 %[a], %[a], %[t]\n\t"
+               "v_add_f32 %[b], %[b], %[u]\n\t"
+               "s_mov_b64 exec, %[sv]"
+               : [a] "+v"(a), [b] "+v"(b), [t] "=&v"(t), [u] "=&v"(u), [sv] "=&s"(sv)
+               : [m2] "s"(g.m2), [m4] "s"(g.m4), [m8] "s"(g.m8), [m16] "s"(g.m16), [m32] "s"(g.m32), [m64] "s"(g.m64), [i16] "v"(g.i16), [i32] "v"(g.i32)
+               : "memory");
+}
+#undef BJX_DPP2_
+// Float64: the partner's halves are fetched under the mask into zeroed registers and added outside (x + 0.0 = x).
+#define BJX_DPPMOV4_(ctrl_) \
+  "v_mov_b32_dpp %[t0], %[a0] " ctrl_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_mov_b32_dpp %[t1], %[a1] " ctrl_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_mov_b32_dpp %[u0], %[b0] " ctrl_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_mov_b32_dpp %[u1], %[b1] " ctrl_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+template <int STAGE> __device__ __forceinline__ void group_stage2_flat(double& a, double& b, int m, int idx) {
+  int a0 = __double2loint(a), a1 = __double2hiint(a), b0 = __double2loint(b), b1 = __double2hiint(b);
+  int t0 = 0, t1 = 0, u0 = 0, u1 = 0;
+  uint64_t sv;
+#define BJX_ST_(body_) \
+  asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[m]\n\ts_mov_b32 exec_hi, %[m]\n\ts_nop 1\n\t" body_ "s_mov_b64 exec, %[sv]" \
+               : [t0] "+v"(t0), [t1] "+v"(t1), [u0] "+v"(u0), [u1] "+v"(u1), [sv] "=&s"(sv) \
+               : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [m] "s"(m), [ix] "v"(idx) : "memory")
+  if constexpr (STAGE == 0) BJX_ST_(BJX_DPPMOV4_("quad_perm:[1,0,3,2]"));
+  else if constexpr (STAGE == 1) BJX_ST_(BJX_DPPMOV4_("quad_perm:[2,3,0,1]"));
+  else if constexpr (STAGE == 2) BJX_ST_(BJX_DPPMOV4_("row_half_mirror"));
+  else if constexpr (STAGE == 3) BJX_ST_(BJX_DPPMOV4_("row_mirror"));
+  else BJX_ST_("ds_bpermute_b32 %[t0], %[ix], %[a0]\n\tds_bpermute_b32 %[t1], %[ix], %[a1]\n\t"
+               "ds_bpermute_b32 %[u0], %[ix], %[b0]\n\tds_bpermute_b32 %[u1], %[ix], %[b1]\n\ts_waitcnt lgkmcnt(0)\n\t");
+#undef BJX_ST_
+  a += __hiloint2double(t1, t0);
+  b += __hiloint2double(u1, u0);
+}
+#undef BJX_DPPMOV4_
+__device__ __forceinline__ void group_sum2_flat(double& a, double& b, const GroupMasks& g) {
+  group_stage2_flat<0>(a, b, g.m2, 0);
+  group_stage2_flat<1>(a, b, g.m4, 0);
+  group_stage2_flat<2>(a, b, g.m8, 0);
+  group_stage2_flat<3>(a, b, g.m16, 0);
+  group_stage2_flat<4>(a, b, g.m32, g.i16);
+  group_stage2_flat<4>(a, b, g.m64, g.i32);
+}
+
 // 16-byte vector types per element type
 template <class T> struct Vec16;
 typedef float bjx_f32x4 __attribute__((ext_vector_type(4)));
@@ -579,6 +665,30 @@ template <class T, int V, bool NT> __device__ __forceinline__ void store_pack(T*
     __builtin_memcpy(&t, &r, sizeof(t));
     if (NT) __builtin_nontemporal_store(t, reinterpret_cast<VT*>(p)); else *reinterpret_cast<VT*>(p) = t;
   }
+}
+
+// Buffer-addressed packs (raw buffer, stride 0): address = base + voffset, and an access whose voffset + size exceeds
+// the descriptor's extent reads zeros / is dropped.  Streaming (nt) like the NT packs above.
+typedef unsigned int bjx_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int bjx_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bjx_make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+template <class T, int V> __device__ __forceinline__ Pack<T, V> buf_load_pack(__amdgpu_buffer_rsrc_t r, int voffset) {
+  Pack<T, V> p;
+  constexpr int B = V * (int)sizeof(T);
+  static_assert(B == 4 || B == 8 || B == 16, "pack bytes");
+  if constexpr (B == 16) { const bjx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voffset, 0, 2); __builtin_memcpy(&p, &t, 16); }
+  else if constexpr (B == 8) { const bjx_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voffset, 0, 2); __builtin_memcpy(&p, &t, 8); }
+  else { const unsigned int t = __builtin_amdgcn_raw_buffer_load_b32(r, voffset, 0, 2); __builtin_memcpy(&p, &t, 4); }
+  return p;
+}
+template <class T, int V> __device__ __forceinline__ void buf_store_pack(__amdgpu_buffer_rsrc_t r, int voffset, const Pack<T, V>& p) {
+  constexpr int B = V * (int)sizeof(T);
+  static_assert(B == 4 || B == 8 || B == 16, "pack bytes");
+  if constexpr (B == 16) { bjx_u32x4 t; __builtin_memcpy(&t, &p, 16); __builtin_amdgcn_raw_buffer_store_b128(t, r, voffset, 0, 2); }
+  else if constexpr (B == 8) { bjx_u32x2 t; __builtin_memcpy(&t, &p, 8); __builtin_amdgcn_raw_buffer_store_b64(t, r, voffset, 0, 2); }
+  else { unsigned int t; __builtin_memcpy(&t, &p, 4); __builtin_amdgcn_raw_buffer_store_b32(t, r, voffset, 0, 2); }
 }
 
 }  // namespace bjx
