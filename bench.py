@@ -388,6 +388,48 @@ def measure(env, name, steps, warmup, scaling, log2_batch=None):
     return res
 
 
+def measure_graph(env, name, log2_batch, steps, warmup, scaling):
+    """Launch-bound shards: the same step (kernel + finalize + the library's all-reduce) issued call by call and as ONE
+    captured hipGraph (bjx_graph_begin/_end/_launch through bj.CapturedStep), `steps` steps each, max over ranks."""
+    torch, bj, dist = env.torch, env.bj, env.dist
+    wl = make_workload(name, bj, torch, env.device, env.rank, env.world, log2_batch, scaling)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(run):
+        barrier()
+        t0 = time.perf_counter()
+        run()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=env.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt[0])
+        return dt / steps * 1e3
+
+    for _ in range(warmup):
+        wl["step"]()
+    eager = timed(lambda: [wl["step"]() for _ in range(steps)])
+    cs = bj.CapturedStep(wl["step"], env.device)
+    cs.replay(warmup)
+    graph = timed(lambda: cs.replay(steps))
+    s_graph = float(cs.result[0]) if cs.result is not None else float("nan")
+    cs.close()
+    s_eager = float(wl["step"]()[0])
+    res = {"workload": name, "label": wl["label"], "steps": steps, "eager_ms_per_step": eager, "graph_ms_per_step": graph,
+           "speedup": eager / graph if graph > 0 else None, "M_samples_per_s_graph": wl["total"] / (graph * 1e-3) / 1e6 if graph > 0 else None,
+           "sum_logabsdetjac_eager": s_eager, "sum_logabsdetjac_graph": s_graph}
+    del wl, cs
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     a = parse()
     import torch
@@ -445,6 +487,16 @@ def main():
                 except Exception as e:
                     strong.append({"workload": r, "error": repr(e)})
 
+    graph_rows = []
+    if want_rows and (world == 1 or a.collective == "bjx"):
+        # shards of 2^20 columns and below are launch-bound: the step as a captured hipGraph next to call-by-call issue.
+        # (multi-rank only with --collective bjx: the all-reduce must be recorded on the library's stream)
+        for lb in (20, 16):
+            try:
+                graph_rows.append(dict(measure_graph(env, "c2", lb, 50, 5, a.scaling), log2_batch_per_gpu=lb))
+            except Exception as e:
+                graph_rows.append({"workload": "c2", "log2_batch_per_gpu": lb, "error": repr(e)})
+
     if rank == 0:
         out = {
             "metric": METRIC, "value": head["value"], "unit": "M samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -472,6 +524,8 @@ def main():
                     except Exception as e:
                         r["cpu_baseline"] = {"value": None, "unit": "M samples/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
             out["rows"] = rows
+            if graph_rows:
+                out["graph_step"] = graph_rows
             if strong:
                 out["strong_scaling"] = strong
         print(json.dumps(out))

@@ -107,6 +107,10 @@ SIGNATURES = {
     "bjx_time_end": (_i, [_vp, C.POINTER(C.c_float)]),
     "bjx_kernel_time_begin": (_i, [_vp]),
     "bjx_kernel_time_end": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "bjx_graph_begin": (_i, [_vp]),
+    "bjx_graph_end": (_i, [_vp, C.POINTER(_vp)]),
+    "bjx_graph_launch": (_i, [_vp, _vp]),
+    "bjx_graph_destroy": (_i, [_vp]),
 }
 
 _lib = None

@@ -167,6 +167,7 @@ BJX_API int bjx_set_option(bjx_ctx* ctx, int option, int value) {
 
 BJX_API int bjx_synchronize(bjx_ctx* ctx) {
   if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, !ctx->capturing, BJX_ERR_UNSUPPORTED, "bjx_synchronize: a graph capture is open on this context");
   BJX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return BJX_OK;
 }
@@ -179,6 +180,7 @@ BJX_API int bjx_time_begin(bjx_ctx* ctx) {
 
 BJX_API int bjx_time_end(bjx_ctx* ctx, float* ms_out) {
   if (!ctx || !ms_out) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, !ctx->capturing, BJX_ERR_UNSUPPORTED, "bjx_time_end: a graph capture is open on this context");
   BJX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   BJX_HIP(ctx, hipEventSynchronize(ctx->ev1));
   BJX_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
@@ -200,6 +202,7 @@ BJX_API int bjx_kernel_time_begin(bjx_ctx* ctx) {
 
 BJX_API int bjx_kernel_time_end(bjx_ctx* ctx, float* total_ms, int* launches) {
   if (!ctx || !total_ms || !launches) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, !ctx->capturing, BJX_ERR_UNSUPPORTED, "bjx_kernel_time_end: a graph capture is open on this context");
   ctx->prof_on = 0;
   BJX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   double tot = 0.0;
@@ -211,6 +214,57 @@ BJX_API int bjx_kernel_time_end(bjx_ctx* ctx, float* total_ms, int* launches) {
   *total_ms = (float)tot;
   *launches = ctx->prof_n;
   if (ctx->prof_dropped) return bjx_fail(ctx, BJX_ERR_UNSUPPORTED, "bjx_kernel_time_end: %d launches not recorded (more than %d in the region)", ctx->prof_dropped, bjx_ctx::PROF_MAX);
+  return BJX_OK;
+}
+
+// ------------------------------------------------------------------ captured steps (hipGraph)
+struct bjx_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+BJX_API int bjx_graph_begin(bjx_ctx* ctx) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, !ctx->capturing, BJX_ERR_ARG, "bjx_graph_begin: a capture is already open on this context");
+  BJX_REQUIRE(ctx, ctx->stream != nullptr, BJX_ERR_UNSUPPORTED, "bjx_graph_begin: the NULL stream cannot be captured; give the context a stream");
+  BJX_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+  ctx->capturing = 1;
+  return BJX_OK;
+}
+
+BJX_API int bjx_graph_end(bjx_ctx* ctx, bjx_graph** out) {
+  if (!ctx || !out) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, ctx->capturing, BJX_ERR_ARG, "bjx_graph_end: no capture is open on this context");
+  ctx->capturing = 0;
+  hipGraph_t g = nullptr;
+  BJX_HIP(ctx, hipStreamEndCapture(ctx->stream, &g));
+  BJX_REQUIRE(ctx, g != nullptr, BJX_ERR_UNSUPPORTED, "bjx_graph_end: the capture was invalidated (a call inside it synchronised or used another stream)");
+  hipGraphExec_t e = nullptr;
+  hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  if (err != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    return bjx_fail(ctx, BJX_ERR_UNSUPPORTED, "hipGraphInstantiate: %s", hipGetErrorString(err));
+  }
+  bjx_graph* r = new (std::nothrow) bjx_graph();
+  if (!r) { (void)hipGraphExecDestroy(e); (void)hipGraphDestroy(g); return bjx_fail(ctx, BJX_ERR_ARG, "out of host memory"); }
+  r->graph = g;
+  r->exec = e;
+  *out = r;
+  return BJX_OK;
+}
+
+BJX_API int bjx_graph_launch(bjx_ctx* ctx, bjx_graph* graph) {
+  if (!ctx || !graph || !graph->exec) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, !ctx->capturing, BJX_ERR_ARG, "bjx_graph_launch: a capture is open on this context");
+  BJX_HIP(ctx, hipGraphLaunch(graph->exec, ctx->stream));
+  return BJX_OK;
+}
+
+BJX_API int bjx_graph_destroy(bjx_graph* graph) {
+  if (!graph) return BJX_OK;
+  if (graph->exec) (void)hipGraphExecDestroy(graph->exec);
+  if (graph->graph) (void)hipGraphDestroy(graph->graph);
+  delete graph;
   return BJX_OK;
 }
 

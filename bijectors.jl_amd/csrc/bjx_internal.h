@@ -40,6 +40,7 @@ struct bjx_ctx {
   static constexpr int PROF_MAX = 1024;
   hipEvent_t* prof_ev = nullptr;   // [2 * PROF_MAX], created lazily
   int prof_on = 0, prof_n = 0, prof_dropped = 0;
+  int capturing = 0;            // between bjx_graph_begin and bjx_graph_end
   // RCCL (lazily dlopen'ed)
   void* rccl_handle = nullptr;
   void* comm = nullptr;
@@ -71,7 +72,7 @@ struct BjxProf {
   bjx_ctx* c;
   int slot;
   explicit BjxProf(bjx_ctx* ctx) : c(ctx), slot(-1) {
-    if (c->prof_on) {
+    if (c->prof_on && !c->capturing) {
       if (c->prof_n < bjx_ctx::PROF_MAX) { slot = c->prof_n++; (void)hipEventRecord(c->prof_ev[2 * slot], c->stream); }
       else ++c->prof_dropped;
     }

@@ -363,6 +363,7 @@ int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const voi
   } else {
     // long segment lists: through the context's pinned staging buffer (asynchronous; the event guards its reuse)
     BJX_REQUIRE(ctx, seg_bytes <= BJX_HOST_STAGE_BYTES, BJX_ERR_UNSUPPORTED, "bjx_stacked: too many segments (%d)", n_segs);
+    BJX_REQUIRE(ctx, !ctx->capturing, BJX_ERR_UNSUPPORTED, "bjx_stacked: %d segments go through the pinned staging buffer, which cannot be recorded into a graph", n_segs);
     if (!ctx->host_stage) {
       BJX_HIP(ctx, hipHostMalloc(&ctx->host_stage, BJX_HOST_STAGE_BYTES, hipHostMallocDefault));
       BJX_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev, hipEventDisableTiming));

@@ -34,6 +34,7 @@ __all__ = [
     "PartitionMask", "Coupling", "Stacked", "NamedStacked", "Columnwise", "columnwise", "vjp", "istraining", "training", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
     "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
     "PlanarResult", "vjp_params", "row_moments", "MvNormal", "TransformedDistribution", "transformed", "logpdf", "rand",
+    "CapturedStep",
 ]
 
 PlanarResult = namedtuple("PlanarResult", ["result", "logabsdetjac"])  # planar_layer.jl:109
@@ -72,6 +73,55 @@ def context(device: Optional[torch.device] = None) -> _Ctx:
         c = _Ctx(dev, stream)
         _ctx_cache[key] = c
     return c
+
+
+class CapturedStep:
+    """`fn()` recorded ONCE into a hipGraph (bjx_graph_begin / bjx_graph_end, include/bjx.h) and replayed with
+    `replay()`: for small shards a step — kernel, finalize, the 8-byte all-reduce through the library's communicator —
+    costs more in per-call dispatch than on the GPU.  `fn` must read and write the same tensors on every call (their
+    addresses are baked into the graph), must not synchronise with the host, and a multi-rank step must use the library
+    collective (`shard.use_library_collective()`): a torch.distributed all-reduce runs on torch's own stream.
+
+    The step runs on a private stream (the NULL stream cannot be captured); `replay()` orders it after the work already
+    queued on the caller's current stream, and `wait()` makes the caller's stream wait for the replays."""
+
+    def __init__(self, fn, device: Optional[torch.device] = None):
+        self._h = C.c_void_p()
+        self.stream = torch.cuda.Stream(device)
+        self.stream.wait_stream(torch.cuda.current_stream(device))
+        lib = L.load()
+        with torch.cuda.stream(self.stream):
+            fn()                                  # eager run on this stream: context, staging buffers, allocator blocks
+            self.stream.synchronize()
+            self._ctx = context(device)
+            L.check(self._ctx.h, lib.bjx_graph_begin(self._ctx.h), "bjx_graph_begin")
+            try:
+                self.result = fn()                # recorded, not executed; keeps the output tensors alive
+            finally:
+                rc = lib.bjx_graph_end(self._ctx.h, C.byref(self._h))
+            L.check(self._ctx.h, rc, "bjx_graph_end")
+
+    def replay(self, n: int = 1):
+        self.stream.wait_stream(torch.cuda.current_stream(self.stream.device))
+        lib = L.load()
+        for _ in range(n):
+            L.check(self._ctx.h, lib.bjx_graph_launch(self._ctx.h, self._h), "bjx_graph_launch")
+        return self.result
+
+    def wait(self) -> None:
+        torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
+
+    def close(self) -> None:
+        if self._h:
+            self.stream.synchronize()
+            L.load().bjx_graph_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _dt(t: torch.Tensor) -> int:

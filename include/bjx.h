@@ -442,6 +442,21 @@ int bjx_time_end(bjx_ctx* ctx, float* ms_out);
 int bjx_kernel_time_begin(bjx_ctx* ctx);
 int bjx_kernel_time_end(bjx_ctx* ctx, float* total_ms, int* launches);
 
+/* ---- captured steps (hipGraph) -------------------------------------------------------------------------------------
+ * For small shards a step (kernel + finalize + the 8-byte all-reduce) is launch-bound: capture it once, replay it
+ * with one hipGraphLaunch.  Between _begin and _end every call on this context is RECORDED on the context stream
+ * (hipStreamBeginCapture, relaxed mode) instead of executed; pointers and sizes are baked into the graph, so a replay
+ * reads and writes the same buffers.  Entry points that must synchronise with the host (bjx_synchronize,
+ * bjx_time_end, bjx_kernel_time_end, bjx_stacked with more segments than the staging buffer was last used for)
+ * return BJX_ERR_UNSUPPORTED while a capture is open; per-kernel timing is off inside a capture.
+ * bjx_allreduce_sum_f64 is capturable (RCCL records into the graph).  Reference counterpart: none — the reference
+ * is a CPU library; this replaces the per-call dispatch a Julia host pays per step. */
+typedef struct bjx_graph bjx_graph;
+int bjx_graph_begin(bjx_ctx* ctx);
+int bjx_graph_end(bjx_ctx* ctx, bjx_graph** out);
+int bjx_graph_launch(bjx_ctx* ctx, bjx_graph* graph);   /* asynchronous on the context stream */
+int bjx_graph_destroy(bjx_graph* graph);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@ oracle standing in for the Julia package.
 Tolerances are north_star's: <= 1e-3 relative for Float32, <= 1e-6 relative for Float64
 (bit-exact for Permute, which is pure data movement).
 """
+import ctypes as C
 import math
 import zlib
 
@@ -2492,3 +2493,50 @@ def test_stacked_with_structured_segments_in_place(bj, orc, dt, N):
     Y3, l3b = bj.with_logabsdet_jacobian(b3, dev(X3), per_sample=True)
     close(host(Y3), np.vstack([y2, y4]), dt, scale=20)
     close(host(l3b), l2 + l4, dt, scale=200)
+
+
+def test_captured_step_replays_the_same_result(bj):
+    """bjx_graph_begin/_end/_launch (include/bjx.h): a step recorded into a hipGraph writes the same outputs as the eager call,
+    on every replay, and picks up new INPUT VALUES in the same buffers (addresses are baked in, contents are not)."""
+    torch.manual_seed(3)
+    d, n = 16, 4096
+    x = bj.colmajor(torch.randn(d, n, device="cuda"))
+    y = torch.empty_like(x)
+    b = bj.elementwise(bj.exp) @ bj.Shift(0.25) @ bj.Scale(0.5)
+    y_ref, l_ref = bj.with_logabsdet_jacobian(b, x, per_sample=True)
+
+    def step():
+        return bj.shard.with_logabsdet_jacobian_sharded(b, x, out=y)
+
+    cs = bj.CapturedStep(step)
+    y.zero_()
+    yy, lps, lsum = cs.replay()
+    cs.wait()
+    torch.cuda.synchronize()
+    assert yy.data_ptr() == y.data_ptr()
+    assert torch.equal(y, y_ref) and torch.equal(lps, l_ref)
+    assert abs(float(lsum) - float(l_ref.double().sum())) < 1e-6 * max(1.0, abs(float(lsum)))
+    x.mul_(0.5)                                     # new contents, same buffer
+    y2_ref, l2_ref = bj.with_logabsdet_jacobian(b, x, per_sample=True)
+    cs.replay(3)
+    cs.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2_ref) and torch.equal(lps, l2_ref)
+    ctx = bj.context()
+    lib = bj._lib.load()
+    assert lib.bjx_graph_begin(ctx.h) != 0          # the NULL stream cannot be captured: loud error, not a silent no-op
+    cs.close()
+
+
+def test_capture_refuses_host_synchronisation(bj):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ctx = bj.context()
+        lib = bj._lib.load()
+        assert lib.bjx_graph_begin(ctx.h) == 0
+        assert lib.bjx_synchronize(ctx.h) == bj._lib.ERR_UNSUPPORTED
+        assert b"capture" in lib.bjx_last_error(ctx.h)
+        h = C.c_void_p()
+        assert lib.bjx_graph_end(ctx.h, C.byref(h)) in (0, bj._lib.ERR_UNSUPPORTED)   # an empty capture may or may not instantiate
+        if h:
+            lib.bjx_graph_destroy(h)
