@@ -936,6 +936,182 @@ int rqs_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, 
   return BJX_OK;
 }
 
+// ------------------------------------------------------------------ RQS knot pullback
+// Cotangents of the knot arrays (widths, heights, derivatives: T[dim, K]) of with_logabsdet_jacobian for the elementwise
+// spline and its inverse, summed over the batch.  With the element in bin k (knots k, k+1; knot 0 = -knot K) and
+//   Δw, Δh, s = Δh/Δw, ξ = (x - w_k)/Δw, p = ξ(1-ξ), N = sξ² + d_k p, Dn = s + (d_k+1 + d_k - 2s) p, M = d_k+1 ξ² + 2sp + d_k(1-ξ)²
+//   y = h_k + Δh N/Dn,   ℓ = log(s² M / Dn²)                                  (rational_quadratic_spline.jl:128-164, 266-297)
+// the partials in (ξ, s, Δh, d_k, d_k+1) are
+//   y_ξ = Δh (N_ξ Dn - N Dn_ξ)/Dn²      N_ξ = 2sξ + d_k(1-2ξ), Dn_ξ = (d_k+1 + d_k - 2s)(1-2ξ)
+//   y_s = Δh (ξ² Dn - N (1-2p))/Dn²     y_Δh = N/Dn     y_dk = Δh p (Dn - N)/Dn²     y_dk+1 = -Δh N p/Dn²
+//   ℓ_ξ = M_ξ/M - 2 Dn_ξ/Dn             ℓ_s = 2/s + 2p/M - 2(1-2p)/Dn     ℓ_dk = (1-ξ)²/M - 2p/Dn     ℓ_dk+1 = ξ²/M - 2p/Dn
+// and ξ, s, Δh reach the knots through ∂ξ/∂w_k = (ξ-1)/Δw, ∂ξ/∂w_k+1 = -ξ/Δw, ∂s/∂w_k = s/Δw = -∂s/∂w_k+1,
+// ∂s/∂h_k+1 = 1/Δw = -∂s/∂h_k, ∂Δh/∂h_k+1 = 1 = -∂Δh/∂h_k, ∂y/∂h_k = 1.  The inverse map x = f⁻¹(y) with log-det -ℓ(x)
+// is the same accumulation at the point x with ȳ := -(x̄ - ℓ̄ ℓ_x)/f'(x), ℓ̄ := -ℓ̄ (implicit function theorem).
+// Elements outside [-B, B] are the identity: no contribution.  d_1 and d_K are the constant 1 of the reference (:146-147).
+//
+// Every thread owns ONE row (and one of `cpp` column lanes) and a private slice of LDS accumulators [3K][threads]
+// (bank = thread: conflict-free, no atomics, a fixed order of additions); the block sums its lanes in a fixed order and
+// adds its table to the Float64 table of the call (one atomic add per entry and block).
+template <class T, class A, bool INV>
+__global__ void rqs_knot_vjp_kernel(const T* __restrict__ w, const T* __restrict__ h, const T* __restrict__ d, int K,
+                                    const T* __restrict__ x, const T* __restrict__ gbar, const T* __restrict__ lbar,
+                                    double* __restrict__ acc, int64_t dim, int64_t batch, int cpp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nthr = (int)blockDim.x, t = (int)threadIdx.x;
+  const int64_t nk = (int64_t)K * dim;
+  T* kw = reinterpret_cast<T*>(smem);
+  T* kh = kw + nk;
+  T* kd = kh + nk;
+  A* priv = reinterpret_cast<A*>(smem + ((3 * nk * sizeof(T) + 15) / 16) * 16);       // [3K][nthr]
+  for (int64_t i = t; i < nk; i += nthr) { kw[i] = w[i]; kh[i] = h[i]; kd[i] = d[i]; }
+  for (int e = 0; e < 3 * K; ++e) priv[(size_t)e * nthr + t] = A(0);
+  __syncthreads();
+  const bool active = t < cpp * (int)dim;
+  const int row = t % (int)dim, cl = t / (int)dim;
+  const T *w_ = kw + row, *h_ = kh + row, *d_ = kd + row;
+  const int64_t st = dim;
+  const int64_t passes = (batch + cpp - 1) / cpp;
+  auto add = [&](int table, int knot0, A v) { priv[(size_t)(table * K + knot0) * nthr + t] += v; };   // knot0: 0-based knot
+  for (int64_t ps = blockIdx.x; ps < passes; ps += gridDim.x) {
+    const int64_t col = ps * cpp + cl;
+    if (!active || col >= batch) continue;
+    const int64_t idx = col * dim + row;
+    const T xin = x[idx];
+    T g = gbar[idx], lb = lbar ? lbar[col] : T(0);
+    const T wK = w_[(int64_t)(K - 1) * st], hK = h_[(int64_t)(K - 1) * st];
+    if (!(d_abs(xin) < (INV ? hK : wK))) continue;                    // identity outside (-B, B); NaN contributes nothing
+    const int k = ssf<T>(INV ? h_ : w_, st, K, xin) - 1;              // bin k: knots k, k+1 (1-based), knot 0 = -knot K
+    const T w_k = (k == 0) ? -wK : w_[(int64_t)(k - 1) * st];
+    const T wd = w_[(int64_t)k * st] - w_k;
+    const T h_k = (k == 0) ? -hK : h_[(int64_t)(k - 1) * st];
+    const T dy = h_[(int64_t)k * st] - h_k;
+    const T s = dy / wd;
+    const T d_k = (k == 0) ? T(1) : d_[(int64_t)(k - 1) * st];
+    const T d_k1 = (k == K - 1) ? T(1) : d_[(int64_t)k * st];
+    const T ds = d_k1 + d_k - 2 * s, dd = d_k1 - d_k;
+    T xi;
+    if (!INV) xi = (xin - w_k) / wd;
+    else {
+      const T yh = xin - h_k;
+      const T a1 = dy * (s - d_k) + yh * ds;
+      const T a2 = dy * d_k - yh * ds;
+      const T q = s * yh;
+      xi = (q + q) / (a2 + d_sqrt(a2 * a2 + 4 * (a1 * q)));
+    }
+    const T p = xi - xi * xi, om = T(1) - (xi + xi);
+    const T den = s + ds * p, rden = T(1) / den;
+    const T M = (d_k + dd * xi) - ds * p, rM = T(1) / M;
+    const T N = xi * (d_k + (s - d_k) * xi);
+    const T iw = T(1) / wd;
+    const T l_xi = (dd - ds * om) * rM - T(2) * ds * om * rden;
+    if (INV) {                                                        // implicit function theorem at x = f⁻¹(y)
+      const T sr = s * rden;
+      const T J = M * (sr * sr);
+      g = -(g - lb * (l_xi * iw)) / J;
+      lb = -lb;
+    }
+    const T r2 = rden * rden;
+    const T y_xi = dy * ((T(2) * s * xi + d_k * om) * den - N * (ds * om)) * r2;
+    const T y_s = dy * (xi * xi * den - N * (T(1) - 2 * p)) * r2;
+    const T y_dh = N * rden;
+    const T y_dk = dy * p * (den - N) * r2;
+    const T y_dk1 = -dy * N * p * r2;
+    const T l_s = T(2) / s + T(2) * p * rM - T(2) * (T(1) - 2 * p) * rden;
+    const T omx = T(1) - xi;
+    const T l_dk = omx * omx * rM - T(2) * p * rden;
+    const T l_dk1 = xi * xi * rM - T(2) * p * rden;
+    const T Gxi = g * y_xi + lb * l_xi, Gs = g * y_s + lb * l_s, Gdh = g * y_dh;
+    const T gw_k = (Gxi * (xi - T(1)) + Gs * s) * iw, gw_k1 = -(Gxi * xi + Gs * s) * iw;
+    const T gh_k = g - Gdh - Gs * iw, gh_k1 = Gdh + Gs * iw;
+    // knot k (1-based) lives at index k-1; knot 0 is -knot K
+    if (k == 0) { add(0, K - 1, (A)(-gw_k)); add(1, K - 1, (A)(-gh_k)); }
+    else { add(0, k - 1, (A)gw_k); add(1, k - 1, (A)gh_k); add(2, k - 1, (A)(g * y_dk + lb * l_dk)); }
+    add(0, k, (A)gw_k1);
+    add(1, k, (A)gh_k1);
+    if (k != K - 1) add(2, k, (A)(g * y_dk1 + lb * l_dk1));
+  }
+  __syncthreads();
+  for (int64_t o = t; o < 3 * nk; o += nthr) {                         // o = (table*K + knot)*dim + row
+    const int r = (int)(o % dim);
+    const int64_t e = o / dim;
+    double sum = 0.0;
+    for (int c = 0; c < cpp; ++c) sum += (double)priv[(size_t)e * nthr + c * (int)dim + r];
+    if (sum != 0.0) atomicAdd(acc + o, sum);
+  }
+}
+template <class T>
+__global__ __launch_bounds__(256) void rqs_knot_vjp_out_kernel(const double* __restrict__ acc, int K, int64_t dim, T* wb, T* hb, T* db) {
+  const int64_t nk = (int64_t)K * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += (int64_t)gridDim.x * blockDim.x) {
+    wb[i] = (T)acc[i]; hb[i] = (T)acc[nk + i]; db[i] = (T)acc[2 * nk + i];
+  }
+}
+
+template <class T>
+int rqs_knot_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int K, const T* in, const T* out_bar, const T* ladj_bar,
+                      T* wb, T* hb, T* db, int64_t dim, int64_t batch) {
+  const int64_t nk = (int64_t)K * dim;
+  BJX_REQUIRE(ctx, dim <= 256, BJX_ERR_UNSUPPORTED, "bjx_rqs_vjp_knots: at most 256 rows (got %lld)", (long long)dim);
+  BJX_REQUIRE(ctx, (size_t)(3 * nk) * sizeof(double) <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_rqs_vjp_knots: knot table too large");
+  double* acc = reinterpret_cast<double*>(ctx->scratch);
+  BJX_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)(3 * nk) * sizeof(double), ctx->stream));
+  if (batch > 0) {
+    using A = T;                                                     // accumulator type of the private slices
+    int nthr = 256;
+    auto bytes = [&](int n) { return ((size_t)(3 * nk) * sizeof(T) + 15) / 16 * 16 + (size_t)3 * K * n * sizeof(A); };
+    while (nthr > 16 && nthr / 2 >= dim && bytes(nthr) > 60 * 1024) nthr /= 2;      // a thread per row at least
+    BJX_REQUIRE(ctx, bytes(nthr) <= 64 * 1024, BJX_ERR_UNSUPPORTED, "bjx_rqs_vjp_knots: %d knots x %lld rows do not fit the LDS accumulators", K, (long long)dim);
+    const int cpp = nthr / (int)dim;
+    const int64_t passes = (batch + cpp - 1) / cpp;
+    int64_t grid = (int64_t)ctx->num_cu * 2;
+    if (grid > passes) grid = passes;
+    BjxProf prof_(ctx);
+    if (inverse) hipLaunchKernelGGL((rqs_knot_vjp_kernel<T, A, true>), dim3((unsigned)grid), dim3(nthr), bytes(nthr), ctx->stream, w, h, d, K, in, out_bar, ladj_bar, acc, dim, batch, cpp);
+    else hipLaunchKernelGGL((rqs_knot_vjp_kernel<T, A, false>), dim3((unsigned)grid), dim3(nthr), bytes(nthr), ctx->stream, w, h, d, K, in, out_bar, ladj_bar, acc, dim, batch, cpp);
+    BJX_CHECK_LAUNCH(ctx);
+  }
+  int g2 = (int)((nk + 255) / 256);
+  if (g2 > 1024) g2 = 1024;
+  if (g2 < 1) g2 = 1;
+  hipLaunchKernelGGL(rqs_knot_vjp_out_kernel<T>, dim3(g2), dim3(256), 0, ctx->stream, acc, K, dim, wb, hb, db);
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+
+// Pullback of the B-constructor (rational_quadratic_spline.jl:109-123; rqs_params_kernel above): knots
+// c_j = 2B Σ_{i<=j} softmax(raw)_i - B (c_0 = -B constant) and d_j = log1pexp(raw_d_j) for the interior knots.
+//   p̄_i = 2B Σ_{j>=i} c̄_j,   raw̄_i = p_i (p̄_i - Σ_m p_m p̄_m),   raw̄_d_j = d̄_j sigmoid(raw_d_j).
+template <class T>
+__global__ __launch_bounds__(256) void rqs_params_vjp_kernel(const T* rw, const T* rh, const T* rd, int K, int64_t dim, T B,
+                                                             const T* wb, const T* hb, const T* db, T* rwb, T* rhb, T* rdb) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int pass = 0; pass < 2; ++pass) {
+      const T* r = pass == 0 ? rw : rh;
+      const T* cb = pass == 0 ? wb : hb;                 // cotangents of the K+1 knots [dim, K+1]
+      T* o = pass == 0 ? rwb : rhb;
+      T mx = r[i];
+      for (int k = 1; k < K; ++k) mx = d_max(mx, r[(int64_t)k * dim + i]);
+      T s = T(0);
+      for (int k = 0; k < K; ++k) s += d_exp(r[(int64_t)k * dim + i] - mx);
+      T tail = T(0), dot = T(0);
+      for (int k = K - 1; k >= 0; --k) {                 // p̄_k = 2B Σ_{j>=k} c̄_{j+1}
+        tail += cb[(int64_t)(k + 1) * dim + i];
+        dot += (d_exp(r[(int64_t)k * dim + i] - mx) / s) * ((2 * B) * tail);
+      }
+      tail = T(0);
+      for (int k = K - 1; k >= 0; --k) {
+        tail += cb[(int64_t)(k + 1) * dim + i];
+        o[(int64_t)k * dim + i] = (d_exp(r[(int64_t)k * dim + i] - mx) / s) * ((2 * B) * tail - dot);
+      }
+    }
+    for (int k = 0; k < K - 1; ++k) {
+      const T v = rd[(int64_t)k * dim + i];
+      rdb[(int64_t)k * dim + i] = db[(int64_t)(k + 1) * dim + i] / (T(1) + d_exp(-v));
+    }
+  }
+}
+
 template <class T>
 int bn_impl(bjx_ctx* ctx, int inverse, const T* b, const T* logs, const T* m, const T* v, T eps, const T* in, T* out,
             T* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
@@ -1256,6 +1432,37 @@ BJX_API int bjx_rqs_params(bjx_ctx* ctx, bjx_dtype dt, const void* raw_w, const 
     hipLaunchKernelGGL(rqs_params_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)raw_w, (const double*)raw_h, (const double*)raw_d, K, dim, B, (double*)widths, (double*)heights, (double*)derivs);
   else
     return bjx_fail(ctx, BJX_ERR_ARG, "bjx_rqs_params: bad dtype %d", (int)dt);
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+
+BJX_API int bjx_rqs_vjp_knots(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* widths, const void* heights, const void* derivs, int n_knots,
+                              const void* in, const void* out_bar, const void* ladj_bar, void* widths_bar, void* heights_bar, void* derivs_bar,
+                              int64_t dim, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_rqs_vjp_knots: bad size");
+  BJX_REQUIRE(ctx, n_knots >= 2, BJX_ERR_SHAPE, "bjx_rqs_vjp_knots: need at least 2 knots");
+  BJX_REQUIRE(ctx, widths && heights && derivs && widths_bar && heights_bar && derivs_bar && ((in && out_bar) || batch == 0), BJX_ERR_ARG, "bjx_rqs_vjp_knots: null pointer");
+  DISPATCH_DT(ctx, dt,
+               rqs_knot_vjp_impl<float>(ctx, inverse, (const float*)widths, (const float*)heights, (const float*)derivs, n_knots, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)widths_bar, (float*)heights_bar, (float*)derivs_bar, dim, batch),
+               rqs_knot_vjp_impl<double>(ctx, inverse, (const double*)widths, (const double*)heights, (const double*)derivs, n_knots, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)widths_bar, (double*)heights_bar, (double*)derivs_bar, dim, batch),
+               "bjx_rqs_vjp_knots");
+}
+
+BJX_API int bjx_rqs_params_vjp(bjx_ctx* ctx, bjx_dtype dt, const void* raw_w, const void* raw_h, const void* raw_d, int K, int64_t dim, double B,
+                               const void* widths_bar, const void* heights_bar, const void* derivs_bar, void* raw_w_bar, void* raw_h_bar, void* raw_d_bar) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, K >= 1 && dim >= 0, BJX_ERR_SHAPE, "bjx_rqs_params_vjp: bad size");
+  BJX_REQUIRE(ctx, raw_w && raw_h && widths_bar && heights_bar && raw_w_bar && raw_h_bar && ((raw_d && derivs_bar && raw_d_bar) || K == 1), BJX_ERR_ARG, "bjx_rqs_params_vjp: null pointer");
+  if (dim == 0) return BJX_OK;
+  int grid = (int)((dim + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  if (dt == BJX_F32)
+    hipLaunchKernelGGL(rqs_params_vjp_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)raw_w, (const float*)raw_h, (const float*)raw_d, K, dim, (float)B, (const float*)widths_bar, (const float*)heights_bar, (const float*)derivs_bar, (float*)raw_w_bar, (float*)raw_h_bar, (float*)raw_d_bar);
+  else if (dt == BJX_F64)
+    hipLaunchKernelGGL(rqs_params_vjp_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)raw_w, (const double*)raw_h, (const double*)raw_d, K, dim, B, (const double*)widths_bar, (const double*)heights_bar, (const double*)derivs_bar, (double*)raw_w_bar, (double*)raw_h_bar, (double*)raw_d_bar);
+  else
+    return bjx_fail(ctx, BJX_ERR_ARG, "bjx_rqs_params_vjp: bad dtype %d", (int)dt);
   BJX_CHECK_LAUNCH(ctx);
   return BJX_OK;
 }

@@ -1157,6 +1157,7 @@ class RationalQuadraticSpline(Bijector):
     """
 
     def __init__(self, widths, heights, derivatives, B=None):
+        self._raw = None
         w, h, d = (torch.as_tensor(t) for t in (widths, heights, derivatives))
         if w.dim() == 1:
             w, h, d = w[None, :], h[None, :], d[None, :]
@@ -1172,6 +1173,7 @@ class RationalQuadraticSpline(Bijector):
             outs = [torch.empty((K + 1, dim), dtype=w.dtype, device=w.device).T for _ in range(3)]
             rc = L.load().bjx_rqs_params(ctx.h, _dt(w), _ptr(rw), _ptr(rh), _ptr(rd), K, dim, float(B), *[_ptr(o) for o in outs])
             L.check(ctx.h, rc, "bjx_rqs_params")
+            self._raw = (rw, rh, rd, float(B))      # for the pullback onto the unconstrained parameters (vjp_params)
             w, h, d = outs
         else:
             if not (w.shape[1] == h.shape[1] == d.shape[1]):  # :93
@@ -1884,9 +1886,12 @@ def vjp_params(b, x, out_bar, ladj_bar=None):
     returns (x_bar, {"w": w_bar, "u": u_bar, "b": b_bar}) with the parameter cotangents summed over the batch and the
     shapes of b.w / b.u / b.b (bjx_planar_vjp_params; closed-form derivatives of planar_layer.jl:65-110).
     For a RadialLayer: (x_bar, {"alpha_", "beta", "z_0"}) — see _vjp_params_radial.
+    For a RationalQuadraticSpline or its inverse: (x_bar, {"widths", "heights", "derivatives"[, "raw_widths", ...]}) — see _vjp_params_rqs.
     For a chain that starts with Scale and/or Shift: (z_bar, {"scale": σ̄, "shift": μ̄}) — see _vjp_params_leading_affine."""
     if isinstance(b, RadialLayer):
         return _vjp_params_radial(b, x, out_bar, ladj_bar)
+    if isinstance(b, RationalQuadraticSpline) or (isinstance(b, Inverse) and isinstance(b.orig, RationalQuadraticSpline)):
+        return _vjp_params_rqs(b, x, out_bar, ladj_bar)
     if isinstance(b, InvertibleBatchNorm):
         return _vjp_params_batchnorm(b, x, out_bar, ladj_bar)
     if not isinstance(b, PlanarLayer):
@@ -1913,6 +1918,39 @@ def vjp_params(b, x, out_bar, ladj_bar=None):
     if two_d:
         wb, ub = wb.T, ub.T                       # back to (dim, n_layers)
     return xb, {"w": wb, "u": ub, "b": bbar}
+
+
+def _vjp_params_rqs(b, x, out_bar, ladj_bar=None):
+    """RationalQuadraticSpline (or inverse(spline)): input pullback (bjx_rqs_vjp) + the cotangents of the knot arrays summed over
+    the batch (bjx_rqs_vjp_knots; closed-form derivatives of rational_quadratic_spline.jl:128-357 — the reference leaves them to
+    the AD package).  A spline built with the `B` constructor (:109-123) also gets the cotangents of its unconstrained
+    parameters (bjx_rqs_params_vjp: softmax/cumsum and log1pexp backwards) as "raw_widths", "raw_heights", "raw_derivatives"."""
+    inv = isinstance(b, Inverse)
+    sp = b.orig if inv else b
+    xc, dim, batch, vec = _prep(x)
+    gc, gdim, gbatch, _ = _prep(out_bar)
+    if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:
+        raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
+    if dim != sp.widths.shape[0]:
+        raise ValueError(f"DimensionMismatch: spline with {sp.widths.shape[0]} rows applied to {dim} rows")
+    xb = vjp(b, x, out_bar, ladj_bar)
+    w, h, d = (colmajor(_param(t, xc)) for t in (sp.widths, sp.heights, sp.derivatives))
+    K1 = int(sp.widths.shape[1])
+    lb = _ladj_bar(ladj_bar, batch, xc)
+    ctx = context(xc.device)
+    outs = [torch.empty((K1, dim), dtype=xc.dtype, device=xc.device).T for _ in range(3)]
+    rc = L.load().bjx_rqs_vjp_knots(ctx.h, _dt(xc), int(inv), _ptr(w), _ptr(h), _ptr(d), K1, _ptr(xc), _ptr(gc), _ptr(lb),
+                                    *[_ptr(o) for o in outs], dim, batch)
+    L.check(ctx.h, rc, "bjx_rqs_vjp_knots")
+    grads = {"widths": outs[0], "heights": outs[1], "derivatives": outs[2]}
+    if sp._raw is not None and sp._raw[0].dtype == xc.dtype:
+        rw, rh, rd, B = sp._raw
+        K = K1 - 1
+        routs = [torch.empty((k, dim), dtype=xc.dtype, device=xc.device).T for k in (K, K, max(K - 1, 1))]
+        rc = L.load().bjx_rqs_params_vjp(ctx.h, _dt(xc), _ptr(rw), _ptr(rh), _ptr(rd), K, dim, B, *[_ptr(o) for o in outs], *[_ptr(o) for o in routs])
+        L.check(ctx.h, rc, "bjx_rqs_params_vjp")
+        grads.update({"raw_widths": routs[0], "raw_heights": routs[1], "raw_derivatives": routs[2][:, :K - 1]})
+    return xb, grads
 
 
 def _vjp_params_batchnorm(bn, x, out_bar, ladj_bar=None):

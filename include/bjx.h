@@ -301,12 +301,26 @@ int bjx_rqs(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* widths, const v
 int bjx_rqs_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* widths, const void* heights,
                 const void* derivs, int n_knots, const void* in, const void* out_bar, const void* ladj_bar,
                 void* in_bar, int64_t dim, int64_t batch);
+/* the PARAMETER side of the same pullback.  widths_bar/heights_bar/derivs_bar: device T[dim, n_knots]
+ * (overwritten) = cotangents of the knot arrays summed over the batch, for the forward map (inverse=0: `in` = x,
+ * `out_bar` = ȳ) or the inverse map (inverse=1: `in` = y, `out_bar` = x̄; implicit function theorem at x = f⁻¹(y)).
+ * The derivative at the last knot is not read by the spline (constant 1, as in bjx_rqs): its cotangent is 0.
+ * dim <= 256; Float64 accumulation across blocks.  Reference counterpart: the AD package's pullback of
+ * rqs_forward / rqs_univariate_inverse (the reference has no hand-written rule). */
+int bjx_rqs_vjp_knots(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* widths, const void* heights,
+                      const void* derivs, int n_knots, const void* in, const void* out_bar, const void* ladj_bar,
+                      void* widths_bar, void* heights_bar, void* derivs_bar, int64_t dim, int64_t batch);
 
 /* The `B` constructor, rational_quadratic_spline.jl:109-123: raw_w, raw_h: T[dim,K];
  * raw_d: T[dim,K-1]  ->  widths, heights, derivs: T[dim,K+1]. */
 int bjx_rqs_params(bjx_ctx* ctx, bjx_dtype dt, const void* raw_w, const void* raw_h,
                    const void* raw_d, int K, int64_t dim, double B,
                    void* widths, void* heights, void* derivs);
+/* Pullback of bjx_rqs_params (the `B` constructor, rational_quadratic_spline.jl:109-123): knot cotangents
+ * T[dim, K+1] -> raw_w_bar, raw_h_bar T[dim, K], raw_d_bar T[dim, K-1] (softmax/cumsum and log1pexp backwards). */
+int bjx_rqs_params_vjp(bjx_ctx* ctx, bjx_dtype dt, const void* raw_w, const void* raw_h, const void* raw_d, int K,
+                       int64_t dim, double B, const void* widths_bar, const void* heights_bar, const void* derivs_bar,
+                       void* raw_w_bar, void* raw_h_bar, void* raw_d_bar);
 
 /* ------------------------------- F5: gather / scatter wrappers            */
 /* Permute, permute.jl:152-157: out[i,n] = in[src[i],n]  (src = column index of the nonzero in

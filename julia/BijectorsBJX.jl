@@ -453,6 +453,53 @@ function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::RadialLay
     return out, pullback_radial
 end
 
+# RationalQuadraticSpline with matrix parameters: input pullback (bjx_rqs_vjp) AND the cotangents of the knot arrays summed over
+# the batch (bjx_rqs_vjp_knots; rational_quadratic_spline.jl:128-357 has no hand-written rule).  For a spline made by the `B`
+# constructor (:109-123) the wrapper that owns the raw parameters chains on with `rqs_params_pullback` (bjx_rqs_params_vjp).
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), b::RationalQuadraticSpline{<:ROCMatrix{T}}, x::ROCMatrix{T}) where {T}
+    out = with_logabsdet_jacobian(b, x)
+    K1 = size(b.widths, 2)
+    function pullback_rqs((Δy, Δl))
+        Δyc, Δlc = ROCArray{T}(ChainRulesCore.unthunk(Δy)), ROCArray{T}(ChainRulesCore.unthunk(Δl))
+        x̄, w̄, h̄, d̄ = similar(x), similar(b.widths), similar(b.heights), similar(b.derivatives)
+        GC.@preserve x Δyc Δlc x̄ w̄ h̄ d̄ begin
+            check(ccall((:bjx_rqs_vjp, libbjx), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+                ctx().h, dtype(T), 0, devptr(b.widths), devptr(b.heights), devptr(b.derivatives), K1, devptr(x), devptr(Δyc), devptr(Δlc), devptr(x̄),
+                size(x, 1), size(x, 2)), "bjx_rqs_vjp")
+            check(ccall((:bjx_rqs_vjp_knots, libbjx), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+                ctx().h, dtype(T), 0, devptr(b.widths), devptr(b.heights), devptr(b.derivatives), K1, devptr(x), devptr(Δyc), devptr(Δlc),
+                devptr(w̄), devptr(h̄), devptr(d̄), size(x, 1), size(x, 2)), "bjx_rqs_vjp_knots")
+        end
+        return ChainRulesCore.NoTangent(), ChainRulesCore.Tangent{typeof(b)}(widths = w̄, heights = h̄, derivatives = d̄), x̄
+    end
+    return out, pullback_rqs
+end
+
+# pullback of the `B` constructor: knot cotangents (dim, K+1) -> cotangents of the unconstrained (dim, K), (dim, K), (dim, K-1)
+function rqs_params_pullback(raw_w::ROCMatrix{T}, raw_h::ROCMatrix{T}, raw_d::ROCMatrix{T}, B::Real, w̄, h̄, d̄) where {T}
+    r̄w, r̄h, r̄d = similar(raw_w), similar(raw_h), similar(raw_d)
+    GC.@preserve raw_w raw_h raw_d w̄ h̄ d̄ r̄w r̄h r̄d check(ccall((:bjx_rqs_params_vjp, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        ctx().h, dtype(T), devptr(raw_w), devptr(raw_h), devptr(raw_d), size(raw_w, 2), size(raw_w, 1), Float64(B),
+        devptr(w̄), devptr(h̄), devptr(d̄), devptr(r̄w), devptr(r̄h), devptr(r̄d)), "bjx_rqs_params_vjp")
+    return r̄w, r̄h, r̄d
+end
+
+# captured steps (hipGraph): record the calls of `f()` once, replay them with one launch (include/bjx.h, bjx_graph_*)
+function capture(f)
+    check(ccall((:bjx_graph_begin, libbjx), Cint, (Ptr{Cvoid},), ctx().h), "bjx_graph_begin")
+    g = Ref{Ptr{Cvoid}}(C_NULL)
+    try
+        f()
+    finally
+        check(ccall((:bjx_graph_end, libbjx), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), ctx().h, g), "bjx_graph_end")
+    end
+    return g[]
+end
+replay(g::Ptr{Cvoid}) = check(ccall((:bjx_graph_launch, libbjx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx().h, g), "bjx_graph_launch")
+
 # ---------------------------------------------------------------- logpdf of a TransformedDistribution (SURVEY.md §8f f-3)
 # src/transformed_distribution.jl:164-169 in ONE pass over y: the inverse chain, the whitening of the diagonal-normal
 # base and the standard-normal density are ops of the same launch; the pre-image is not stored (y pointer = C_NULL).

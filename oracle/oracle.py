@@ -873,3 +873,92 @@ def rqs_vjp(widths, heights, derivs, x, out_bar, ladj_bar=None, inverse=False):
             dl = (dnj / nj - 2 * ds * (1 - 2 * xi) / den) / wd
             out[i, n] = g[i, n] * J + lb[n] * dl if not inverse else (g[i, n] - lb[n] * dl) / J
     return out
+
+
+def rqs_vjp_knots(widths, heights, derivs, x, out_bar, ladj_bar=None, inverse=False):
+    """Parameter side of `rqs_vjp`: cotangents of the knot arrays (dim, K), summed over the batch, of
+    with_logabsdet_jacobian for the elementwise RationalQuadraticSpline (inverse=False: x = input, out_bar = ȳ) and its
+    inverse (inverse=True: x = y, out_bar = x̄; implicit function theorem at f⁻¹(y)).  Closed-form partials of
+    rational_quadratic_spline.jl:128-164 (value) and :266-297 (logjac); test infrastructure, pinned by finite differences of
+    `rqs` in tests/test_oracle_golden.py.  The derivative at the last knot is not read by the spline (constant 1)."""
+    W = np.asarray(widths, dtype=np.float64)
+    H = np.asarray(heights, dtype=np.float64)
+    D = np.asarray(derivs, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    dim, N = x.shape
+    K = W.shape[1]
+    g_all = np.asarray(out_bar, dtype=np.float64)
+    lb_all = np.zeros(N) if ladj_bar is None else np.broadcast_to(np.asarray(ladj_bar, dtype=np.float64), (N,))
+    if inverse:
+        xin, _ = rqs(W, H, D, np.asfortranarray(x), inverse=True)
+        xin = np.asarray(xin, dtype=np.float64)
+    else:
+        xin = x
+    Wb, Hb, Db = np.zeros_like(W), np.zeros_like(H), np.zeros_like(D)
+    for i in range(dim):
+        w, h, d = W[i], H[i], D[i]
+        B = w[-1]
+        for n in range(N):
+            xv = xin[i, n]
+            if not (-B < xv < B):
+                continue
+            k = int(np.searchsorted(w, xv, side="left")) - 1      # bin between knots k and k+1 (0-based), k = -1: knot "0" = -knot K
+            wk = -B if k < 0 else w[k]
+            hk = -h[-1] if k < 0 else h[k]
+            wd = w[k + 1] - wk
+            dy = h[k + 1] - hk
+            s = dy / wd
+            dk = 1.0 if k < 0 else d[k]
+            dk1 = 1.0 if k + 1 == K - 1 else d[k + 1]
+            xi = (xv - wk) / wd
+            p = xi * (1 - xi)
+            om = 1 - 2 * xi
+            ds = dk1 + dk - 2 * s
+            den = s + ds * p
+            M = dk1 * xi * xi + 2 * s * p + dk * (1 - xi) ** 2
+            Nn = s * xi * xi + dk * p
+            g, lb = g_all[i, n], lb_all[n]
+            l_xi = (2 * dk1 * xi + 2 * s * om - 2 * dk * (1 - xi)) / M - 2 * ds * om / den
+            if inverse:
+                J = s * s * M / (den * den)
+                g = -(g - lb * l_xi / wd) / J
+                lb = -lb
+            y_xi = dy * ((2 * s * xi + dk * om) * den - Nn * ds * om) / den ** 2
+            y_s = dy * (xi * xi * den - Nn * (1 - 2 * p)) / den ** 2
+            y_dh = Nn / den
+            y_dk = dy * p * (den - Nn) / den ** 2
+            y_dk1 = -dy * Nn * p / den ** 2
+            l_s = 2 / s + 2 * p / M - 2 * (1 - 2 * p) / den
+            l_dk = (1 - xi) ** 2 / M - 2 * p / den
+            l_dk1 = xi * xi / M - 2 * p / den
+            Gxi, Gs, Gdh = g * y_xi + lb * l_xi, g * y_s + lb * l_s, g * y_dh
+            gw_k, gw_k1 = (Gxi * (xi - 1) + Gs * s) / wd, -(Gxi * xi + Gs * s) / wd
+            gh_k, gh_k1 = g - Gdh - Gs / wd, Gdh + Gs / wd
+            if k < 0:
+                Wb[i, K - 1] -= gw_k
+                Hb[i, K - 1] -= gh_k
+            else:
+                Wb[i, k] += gw_k
+                Hb[i, k] += gh_k
+                Db[i, k] += g * y_dk + lb * l_dk
+            Wb[i, k + 1] += gw_k1
+            Hb[i, k + 1] += gh_k1
+            if k + 1 != K - 1:
+                Db[i, k + 1] += g * y_dk1 + lb * l_dk1
+    return Wb, Hb, Db
+
+
+def rqs_params_vjp(raw_w, raw_h, raw_d, B, w_bar, h_bar, d_bar):
+    """Pullback of `rqs_params` (the B constructor, rational_quadratic_spline.jl:109-123): knot cotangents (dim, K+1) ->
+    cotangents of the raw parameters (dim, K), (dim, K), (dim, K-1).  numpy, float64; pinned by finite differences."""
+    outs = []
+    for raw, cb in ((raw_w, w_bar), (raw_h, h_bar)):
+        r = np.asarray(raw, dtype=np.float64)
+        cb = np.asarray(cb, dtype=np.float64)
+        e = np.exp(r - r.max(axis=1, keepdims=True))
+        p = e / e.sum(axis=1, keepdims=True)
+        pbar = 2 * B * np.cumsum(cb[:, 1:][:, ::-1], axis=1)[:, ::-1]      # p̄_i = 2B Σ_{j>=i} c̄_{j+1}
+        outs.append(p * (pbar - (p * pbar).sum(axis=1, keepdims=True)))
+    rd = np.asarray(raw_d, dtype=np.float64)
+    outs.append(np.asarray(d_bar, dtype=np.float64)[:, 1:-1] / (1 + np.exp(-rd)))
+    return tuple(outs)

@@ -122,6 +122,8 @@ def main():
     lbr = randn(N, 1, dev, 32).reshape(-1).contiguous()
     rows.append(("vjp(RQS K=16 d=32)", "f-1", lambda: bj.vjp(rqs, xr, gr, lbr), 4 * 3 * dr + 4, N))
     rows.append(("vjp(inverse(RQS K=16 d=32))", "f-1", lambda: bj.vjp(bj.inverse(rqs), yr, gr, lbr), 4 * 3 * dr + 4, N))
+    rows.append(("vjp_params(RQS K=16 d=32): input pullback + knot and raw-parameter cotangents (two passes)", "f-1",
+                 lambda: bj.vjp_params(rqs, xr, gr, lbr), 4 * 5 * dr + 8, N))
     perm = bj.Permute(list(torch.randperm(d, generator=torch.Generator().manual_seed(0)).add(1).tolist()))
     add("Permute d=64", "a21", perm, x, per_sample=False)
     mask = bj.PartitionMask(d, list(range(1, d // 2 + 1)), list(range(d // 2 + 1, d + 1)))

@@ -1293,6 +1293,57 @@ def test_rqs_vjp(bj, orc, dim, K, N, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,K,N", [(32, 16, 700), (8, 5, 257), (3, 8, 100), (64, 10, 129), (20, 33, 40), (200, 4, 64), (1, 6, 33)])
+def test_rqs_knot_pullback(bj, orc, dim, K, N, dt):
+    """bjx_rqs_vjp_knots + bjx_rqs_params_vjp (§8f f-1): cotangents of the knot arrays and of the B-constructor's raw parameters,
+    forward and inverse, against the finite-difference-pinned oracle (float64 reference of the same inputs)."""
+    r = rng(91 + dim)
+    raw = [r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K - 1)).astype(dt)]
+    b = bj.RationalQuadraticSpline(dev(raw[0]), dev(raw[1]), dev(raw[2]), 3.0)
+    w, h, d = (host(t).astype(np.float64) for t in (b.widths, b.heights, b.derivatives))   # the device's own knots
+    X = np.asfortranarray((1.3 * r.normal(size=(dim, N))).astype(dt))
+    X[0, :3] = [5.0, -4.0, 3.5][:min(3, N)]                          # outside [-B, B]: no contribution
+    gbar = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    lbar = r.normal(size=N).astype(dt)
+    for inv in (False, True):
+        ref = orc.rqs_vjp_knots(w, h, d, X.astype(np.float64), gbar.astype(np.float64), lbar.astype(np.float64), inverse=inv)
+        xb, g = bj.vjp_params(bj.inverse(b) if inv else b, dev(X), dev(gbar), torch.from_numpy(lbar).cuda())
+        np.testing.assert_allclose(host(xb), orc.rqs_vjp(w, h, d, X, gbar, lbar, inverse=inv), rtol=RTOL[dt] * 20, atol=ATOL[dt] * 200)
+        for name, rf in zip(("widths", "heights", "derivatives"), ref):
+            scale = max(1.0, float(np.abs(rf).max()))
+            np.testing.assert_allclose(host(g[name]), rf, rtol=RTOL[dt] * 50, atol=ATOL[dt] * 50 * scale * np.sqrt(N), err_msg=f"{name} inv={inv}")
+        assert np.all(host(g["derivatives"])[:, -1] == 0)
+        rref = orc.rqs_params_vjp(*[a.astype(np.float64) for a in raw], 3.0, *ref)
+        for name, rf in zip(("raw_widths", "raw_heights", "raw_derivatives"), rref):
+            scale = max(1.0, float(np.abs(rf).max()))
+            assert host(g[name]).shape == rf.shape
+            np.testing.assert_allclose(host(g[name]), rf, rtol=RTOL[dt] * 50, atol=ATOL[dt] * 50 * scale * np.sqrt(N), err_msg=f"{name} inv={inv}")
+
+
+def test_rqs_knot_pullback_general_knots_and_empty_batch(bj, orc):
+    """Knot arrays that were NOT made by the B constructor: the first knot lies inside (-w_K, w_K), so bin 0 (between the mirrored
+    last knot and the first) is populated and its cotangents land on the LAST knot with a minus sign.  Empty batch: zeros."""
+    r = rng(97)
+    dim, K, N = 5, 7, 300
+    w = np.sort(r.uniform(-1.5, 2.0, size=(dim, K)), axis=1)
+    w[:, -1] = 2.5
+    h = np.sort(r.uniform(-1.5, 2.0, size=(dim, K)), axis=1)
+    h[:, -1] = 2.5
+    d = r.uniform(0.3, 2.0, size=(dim, K))
+    b = bj.RationalQuadraticSpline(dev(w), dev(h), dev(d))
+    X = np.asfortranarray(r.uniform(-2.4, 2.4, size=(dim, N)))
+    gbar, lbar = np.asfortranarray(r.normal(size=(dim, N))), r.normal(size=N)
+    for inv in (False, True):
+        ref = orc.rqs_vjp_knots(w, h, d, X, gbar, lbar, inverse=inv)
+        _, g = bj.vjp_params(bj.inverse(b) if inv else b, dev(X), dev(gbar), torch.from_numpy(lbar).cuda())
+        for name, rf in zip(("widths", "heights", "derivatives"), ref):
+            np.testing.assert_allclose(host(g[name]), rf, rtol=1e-9, atol=1e-9 * max(1.0, float(np.abs(rf).max())), err_msg=f"{name} inv={inv}")
+        assert "raw_widths" not in g
+    _, g0 = bj.vjp_params(b, dev(X[:, :0]), dev(gbar[:, :0]), torch.zeros(0, dtype=torch.float64, device="cuda"))
+    assert all(float(g0[k].abs().max()) == 0.0 for k in ("widths", "heights", "derivatives"))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_coupling_affine_vjp(bj, orc, dt):
     """Pullback of Coupling(θ, mask) with the affine law (§8f f-1): the kernel gives x̄₁, the pass-through rows and the
     cotangents of θ's outputs; θ(x₂) = (Scale(exp(A x₂)), Shift(B x₂)) is pulled back by torch.autograd on the host.

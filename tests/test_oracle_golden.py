@@ -620,6 +620,56 @@ def test_rqs_pullback_matches_finite_differences(orc):
         np.testing.assert_allclose(orc.rqs_vjp(w, h, d, x, gbar, lbar, inverse=inv), _fd_vjp(f, x, gbar, lbar), rtol=1e-6, atol=1e-7)
 
 
+def test_rqs_knot_pullback_matches_finite_differences(orc):
+    """Cotangents of the knot arrays (orc.rqs_vjp_knots) and of the B-constructor's raw parameters (orc.rqs_params_vjp)
+    against central differences of the golden-pinned oracle, forward and inverse, knot by knot."""
+    r = np.random.default_rng(23)
+    dim, K, N = 3, 6, 9
+    raw = [r.normal(size=(dim, K)), r.normal(size=(dim, K)), r.normal(size=(dim, K - 1))]
+    B = 2.5
+    w, h, d = orc.rqs_params(*raw, B)
+    x = np.asfortranarray(r.normal(size=(dim, N)) * 1.2)
+    x[0, 0] = 4.0                                   # outside: contributes nothing
+    gbar, lbar = r.normal(size=(dim, N)), r.normal(size=N)
+
+    def loss(W, H, D, inv):
+        y, l = orc.rqs(np.asfortranarray(W), np.asfortranarray(H), np.asfortranarray(D), x, inverse=inv)
+        return float((np.asarray(y) * gbar).sum() + (np.asarray(l) * lbar).sum())
+
+    eps = 1e-6
+    for inv in (False, True):
+        got = orc.rqs_vjp_knots(w, h, d, x, gbar, lbar, inverse=inv)
+        for which in range(3):
+            fd = np.zeros((dim, K + 1))
+            for i in range(dim):
+                for j in range(K + 1):
+                    P = [np.array(w), np.array(h), np.array(d)]
+                    M = [np.array(w), np.array(h), np.array(d)]
+                    P[which][i, j] += eps
+                    M[which][i, j] -= eps
+                    fd[i, j] = (loss(*P, inv) - loss(*M, inv)) / (2 * eps)
+            if which == 2:
+                assert np.all(fd[:, -1] == 0) and np.all(got[2][:, -1] == 0)   # the last derivative is not read
+            np.testing.assert_allclose(got[which], fd, rtol=2e-5, atol=2e-6)
+    # constructor pullback
+    wb, hb, db = r.normal(size=(dim, K + 1)), r.normal(size=(dim, K + 1)), r.normal(size=(dim, K + 1))
+
+    def closs(rw, rh, rd):
+        W, H, D = orc.rqs_params(rw, rh, rd, B)
+        return float((W * wb).sum() + (H * hb).sum() + (D * db).sum())
+
+    got = orc.rqs_params_vjp(*raw, B, wb, hb, db)
+    for which in range(3):
+        fd = np.zeros_like(raw[which])
+        for i in range(dim):
+            for j in range(raw[which].shape[1]):
+                P, M = [a.copy() for a in raw], [a.copy() for a in raw]
+                P[which][i, j] += eps
+                M[which][i, j] -= eps
+                fd[i, j] = (closs(*P) - closs(*M)) / (2 * eps)
+        np.testing.assert_allclose(got[which], fd, rtol=1e-6, atol=1e-8)
+
+
 # ------------------------------------------------------------------ SURVEY.md §8(f) f-4: Corr / VecCorr / PD / PDVec
 def _free_to_input(kind, v, K):
     if kind == "corr":
