@@ -45,6 +45,12 @@ class BjxSegment(C.Structure):
                 ("ops", BjxOp * BJX_MAX_SEG_OPS)]
 
 
+class BjxBlock(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("in_lo", C.c_int64), ("out_lo", C.c_int64), ("len_in", C.c_int64), ("len_out", C.c_int64)]
+
+
+BLOCK_SIMPLEX, BLOCK_SIMPLEX_INV, BLOCK_ORDERED, BLOCK_ORDERED_INV = 1, 2, 3, 4
+
 _vp, _i, _i64, _u32, _u64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
 _tail = [_vp, _vp, _i64, _i64, _u32]  # ladj_ps, ladj_sum, dim/K, batch, flags
 
@@ -65,6 +71,7 @@ SIGNATURES = {
     "bjx_vec_cholesky_fwd_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i64, _i64]),
     "bjx_stacked": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _vp, _vp, _vp, _i64, _i64, _u32]),
     "bjx_stacked_ld": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _u32]),
+    "bjx_stacked_mixed": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _u32]),
     "bjx_ordered_ld": (_i, [_vp, _i, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _u32]),
     "bjx_simplex_ld": (_i, [_vp, _i, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _u32]),
     "bjx_stacked_vjp": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _vp, _vp, _vp, _vp, _i64, _i64]),

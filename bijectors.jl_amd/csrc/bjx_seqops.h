@@ -1,0 +1,203 @@
+// Per-column walkers (Ordered / Simplex) and the wave-private [64][P] tile staging: shared by bjx_seq.hip (one structured
+// bijector per launch) and bjx_stacked.hip (Stacked with structured blocks in one launch).  Included INSIDE the
+// anonymous namespace of each translation unit (after `using namespace bjx;`).
+// ---- per-column walkers.  A column is walked in ascending row order: first(v) for row 0,
+// mid(i, v, log(K-1-i)) for the interior rows, last(v) for the final row when the op has a special
+// one (HAS_LAST).  The split keeps the interior loop free of row-index branches, so four rows are
+// in flight per lane (the only carried dependency is the running sum).  step() is the generic form
+// used by the chunked kernel.
+template <class T, class Op> __device__ __forceinline__ T seq_step(Op& op, int64_t i, int64_t rows, T v, const T* logk) {
+  if (i == 0) return op.first(v, logk);
+  if (Op::HAS_LAST && i == rows - 1) return op.last(v);
+  return op.mid((int)i, v, Op::USES_LOGK ? logk[i] : T(0));
+}
+template <class T> struct OrderedFwd {   // ordered.jl:36-49, :80
+  static constexpr bool HAS_LAST = false, USES_LOGK = false;
+  T prev, ladj;
+  __device__ void init() { prev = T(0); ladj = T(0); }
+  __device__ T first(T v, const T*) { prev = v; return v; }
+  // Fast<T>::exp = the exp of every other kernel (chain, quad_stream): one input gives the same bits whatever kernel a shape selects
+  __device__ T mid(int, T v, T) { const T o = prev + Fast<T>::exp(v); ladj += v; prev = o; return o; }
+  __device__ T last(T v) { return v; }
+  __device__ T result() const { return ladj; }
+};
+template <class T> struct OrderedInv {   // ordered.jl:63-77 ; interface.jl:276-281
+  static constexpr bool HAS_LAST = false, USES_LOGK = false;
+  T prev, ladj;
+  __device__ void init() { prev = T(0); ladj = T(0); }
+  __device__ T first(T v, const T*) { prev = v; return v; }
+  __device__ T mid(int, T v, T) { const T o = Fast<T>::log(v - prev); ladj -= o; prev = v; return o; }
+  __device__ T last(T v) { return v; }
+  __device__ T result() const { return ladj; }
+};
+// simplex.jl:47-64 (transform) fused with :122-138 (logabsdetjac); lk = log(T(K-1-i)).
+// The kernel is VALU-bound with exact OCML logs/divisions (118 VALU per element, PMC in
+// profiles/), so Float32 uses the hardware log/rcp units (Fast<T>), logit(z) = log(a/(d-a)) for
+// z = a/d needs one reciprocal instead of two, the three logs of one log-det term are merged into
+// the log of their product (>= eps^3, no underflow) and log2 values are summed (x ln 2 once).
+template <class T, bool LADJ> struct SimplexFwd {
+  static constexpr bool HAS_LAST = true, USES_LOGK = true;
+  int64_t K;
+  T sum_tmp, lp;   // lp accumulates log2 terms
+  __device__ void init() { sum_tmp = T(0); lp = T(0); }
+  __device__ T first(T x, const T* logk) {
+    using F = Fast<T>;
+    const T e = Num<T>::eps;
+    sum_tmp = x;                                                            // Σ_{j<1} x_j for the next row
+    if (K < 2) return T(0);
+    const T z = x * (T(1) - 2 * e) + e;                                     // :53
+    if (LADJ) lp += F::log2(d_max(x, e) * d_max(T(1) - x, e));              // :130-131
+    return F::log2(z * F::rcp(T(1) - z)) * Num<T>::log2 + logk[0];          // logit(z) + log(K-1)
+  }
+  __device__ T mid(int, T x, T lk) {
+    using F = Fast<T>;
+    const T e = Num<T>::eps;
+    const T s = sum_tmp;
+    sum_tmp = s + x;
+    const T a = (x + e) * (T(1) - 2 * e);                                   // z = a / ((1+ε) - Σ)   (:58)
+    const T dn = (T(1) + e) - s;
+    const T o = F::log2(a * F::rcp(dn - a)) * Num<T>::log2 + lk;            // logit(z) + log(K-1-i)
+    if (LADJ) {
+      const T m = d_max(T(1) - s, e);                                       // :133
+      const T zl = x * F::rcp(m);                                           // :134
+      lp += F::log2(d_max(zl, e) * d_max(T(1) - zl, e) * m);                // :135
+    }
+    return o;
+  }
+  __device__ T last(T) { return T(0); }                                     // row K has no output
+  // Julia's max(NaN, ε) is NaN (v_max drops it): a NaN among x_1..x_{K-1} makes the reference's log-det NaN
+  __device__ T result() const { return sum_tmp != sum_tmp ? sum_tmp : -lp * Num<T>::log2; }
+};
+// simplex.jl:102-120 ; log-det = -logabsdetjac(b, x_out)
+template <class T, bool LADJ> struct SimplexInv {
+  static constexpr bool HAS_LAST = true, USES_LOGK = true;
+  int64_t K;
+  T sum_tmp, lp;
+  __device__ void init() { sum_tmp = T(0); lp = T(0); }
+  static __device__ __forceinline__ T logistic(T v) {   // LogExpFunctions.logistic with its exact 0/1 saturation
+    return f_logistic(v);
+  }
+  __device__ T first(T y, const T* logk) {
+    using F = Fast<T>;
+    const T e = Num<T>::eps;
+    if (K < 2) return T(1);
+    const T inv12e = T(1) / (T(1) - 2 * e);
+    const T z = logistic(y - logk[0]);
+    const T x = d_clamp((z - e) * inv12e, T(0), T(1));                      // :109
+    if (LADJ) lp += F::log2(d_max(x, e) * d_max(T(1) - x, e));
+    sum_tmp = x;
+    return x;
+  }
+  __device__ T mid(int, T y, T lk) {
+    using F = Fast<T>;
+    const T e = Num<T>::eps;
+    const T inv12e = T(1) / (T(1) - 2 * e);
+    const T z = logistic(y - lk);
+    const T s = sum_tmp;
+    const T x = d_clamp(((T(1) + e) - s) * inv12e * z - e, T(0), T(1));     // :113
+    sum_tmp = s + x;
+    if (LADJ) {
+      const T m = d_max(T(1) - s, e);
+      const T zl = x * F::rcp(m);
+      lp += F::log2(d_max(zl, e) * d_max(T(1) - zl, e) * m);
+    }
+    return x;
+  }
+  __device__ T last(T) { return d_clamp(T(1) - sum_tmp, T(0), T(1)); }      // :116
+  __device__ T result() const { return sum_tmp != sum_tmp ? sum_tmp : lp * Num<T>::log2; }   // NaN rows: as above
+};
+
+// ---- wave-private [64][P] tile staging (single-wave blocks; shared by seq_wave_kernel and the VJP kernels)
+// A full tile (64 columns) is a whole number of 16-byte packs (64*rows*sizeof(T) % 16 == 0); the ragged
+// last wave of the batch takes the element-wise path.  SU independent 16-byte loads are in flight per lane.
+template <class T, int V>
+__device__ __forceinline__ void tile_stage_in(T* tile, const T* __restrict__ src, int rows, int P, int ncols, int lane) {
+  if (ncols == 64) {
+    constexpr int SU = 8;
+    const int ne = 64 * rows;
+    const int dc = (64 * V) / rows, dr = (64 * V) % rows;
+    int e = lane * V, c = e / rows, r = e % rows;
+    for (; e < ne; e += SU * 64 * V) {
+      Pack<T, V> p[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (e + u * 64 * V < ne) p[u] = load_pack<T, V, true>(src + e + u * 64 * V);
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (e + u * 64 * V < ne) {
+          int cc = c, rr = r;
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            tile[cc * P + rr] = p[u].v[j];
+            if (++rr == rows) { rr = 0; ++cc; }
+          }
+        }
+        c += dc; r += dr;
+        if (r >= rows) { r -= rows; ++c; }
+      }
+    }
+  } else {
+    const int ne = ncols * rows;
+    for (int e = lane; e < ne; e += 64) tile[(e / rows) * P + e % rows] = src[e];
+  }
+}
+template <class T, int V>
+__device__ __forceinline__ void tile_stage_out(const T* tile, T* __restrict__ dst, int rows, int P, int ncols, int lane) {
+  if (ncols == 64) {
+    constexpr int SU = 4;
+    const int ne = 64 * rows;
+    const int dc = (64 * V) / rows, dr = (64 * V) % rows;
+    int e = lane * V, c = e / rows, r = e % rows;
+    for (; e < ne; e += SU * 64 * V) {
+      Pack<T, V> p[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        int cc = c, rr = r;
+        if (e + u * 64 * V < ne) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            p[u].v[j] = tile[cc * P + rr];
+            if (++rr == rows) { rr = 0; ++cc; }
+          }
+        }
+        c += dc; r += dr;
+        if (r >= rows) { r -= rows; ++c; }
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (e + u * 64 * V < ne) store_pack<T, V, true>(dst + e + u * 64 * V, p[u]);
+      }
+    }
+  } else {
+    const int ne = ncols * rows;
+    for (int e = lane; e < ne; e += 64) dst[e] = tile[(e / rows) * P + e % rows];
+  }
+}
+// strided variants (leading dimension ld != rows: the columns are windows of a taller matrix — Stacked segments):
+// consecutive lanes walk the rows of a column, 4- / 8-byte accesses, runs of `rows` contiguous elements
+template <class T>
+__device__ __forceinline__ void tile_stage_in_ld(T* tile, const T* __restrict__ src, int rows, int64_t ld, int P, int ncols, int lane) {
+  const int ne = ncols * rows;
+  const int dc = 64 / rows, dr = 64 % rows;
+  int c = lane / rows, r = lane % rows;
+  for (int e = lane; e < ne; e += 64) {
+    tile[c * P + r] = src[(int64_t)c * ld + r];
+    c += dc; r += dr;
+    if (r >= rows) { r -= rows; ++c; }
+  }
+}
+template <class T>
+__device__ __forceinline__ void tile_stage_out_ld(const T* tile, T* __restrict__ dst, int rows, int64_t ld, int P, int ncols, int lane) {
+  const int ne = ncols * rows;
+  const int dc = 64 / rows, dr = 64 % rows;
+  int c = lane / rows, r = lane % rows;
+  for (int e = lane; e < ne; e += 64) {
+    dst[(int64_t)c * ld + r] = tile[c * P + r];
+    c += dc; r += dr;
+    if (r >= rows) { r -= rows; ++c; }
+  }
+}
+// single-wave block: the LDS queue is in order, only pin the compiler
+__device__ __forceinline__ void tile_sync() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+

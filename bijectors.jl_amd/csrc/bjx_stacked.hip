@@ -9,6 +9,7 @@
 // and one streaming pass on the column-group skeleton applies each row's ops (per-lane `switch`; lanes
 // of a wave that hold different kinds serialise only over the kinds present).
 #include <cstdlib>
+#include <vector>
 
 #include "bjx_stream.h"
 
@@ -404,6 +405,168 @@ int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, 
 #undef STK_LAUNCH
 }
 
+// ------------------------------------------------------------------ Stacked with structured blocks, ONE launch
+// stacked.jl:142-166 for a mixed-constraint model (what `bijector(d)` builds): elementwise chains on some row ranges, a
+// Simplex or Ordered bijector on others.  Elementwise rows and structured blocks have nothing in common as a per-lane
+// program when a lane owns a ROW (the streaming skeleton above), so here a lane owns a COLUMN: one wave stages 64
+// consecutive columns (one contiguous run of the input) through a [64][P] LDS tile with an odd pitch and every lane walks
+// its column top to bottom.  All lanes are at the same row at the same time, so the row's slots are wave-uniform (scalar
+// loads, scalar branch on the kind — none of the per-lane kind divergence of the row-owner kernel), a structured block is
+// the walker of bjx_seq.hip on a row window of the column, and the log-det of a column is one lane's running sum (no
+// cross-lane reduction).  The walk is IN PLACE: the input sits `shift` rows down the column, shift = the largest amount by
+// which an output range starts (or the output ends) above its input range, so a write never overtakes an unread input
+// (inverse Simplex blocks lengthen the column, forward ones shorten it).
+#include "bjx_seqops.h"
+
+enum { MB_SIMPLEX = 1, MB_SIMPLEX_INV = 2, MB_ORDERED = 3, MB_ORDERED_INV = 4 };
+struct MixBlock { int kind, in_lo, out_lo, len_in, len_out, pad; };
+struct MixBlocks { static constexpr int N = 64; MixBlock b[N]; };
+
+template <class T, class Op>
+__device__ __forceinline__ T mixed_run_block(Op op, const T* pin, T* pout, int len_in, int len_out, const T* logn) {
+  // logn[m] = log(m); the walkers want log(K-1-i) (simplex.jl:35,41): logn[K-1-i]
+  op.init();
+  const int rows = len_in > len_out ? len_in : len_out;
+  const int K1 = (int)(Op::USES_LOGK ? (len_in > len_out ? len_in : len_out) - 1 : 0);     // K - 1
+  const T lk0 = Op::USES_LOGK ? logn[K1] : T(0);
+  {
+    const T v = pin[0];                                   // (len_in >= 1 always)
+    const T o = op.first(v, &lk0);
+    if (len_out >= 1) pout[0] = o;
+  }
+  const int mid_end = (Op::HAS_LAST && rows > 1) ? rows - 1 : rows;
+  for (int i = 1; i < mid_end; ++i) pout[i] = op.mid(i, pin[i], Op::USES_LOGK ? logn[K1 - i] : T(0));
+  if (Op::HAS_LAST && rows > 1) {
+    const T v = (rows - 1 < len_in) ? pin[rows - 1] : T(0);
+    const T o = op.last(v);
+    if (rows - 1 < len_out) pout[rows - 1] = o;
+  }
+  return op.result();
+}
+
+template <class T, int V>
+__global__ __launch_bounds__(64) void stacked_mixed_kernel(const char* __restrict__ tab, int two_slots, const MixBlocks blocks, int n_blocks,
+                                                         const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps, int rows_in, int rows_out,
+                                                         int shift, int P, int n_logn, int64_t batch, int accumulate, const BjxFin fin) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[1];
+  T* tile = reinterpret_cast<T*>(smem);
+  T* logn = tile + (size_t)64 * P;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < n_logn; i += 64) logn[i] = d_log(T(i));
+  const int64_t col0 = (int64_t)blockIdx.x * 64;
+  const int ncols = (int)((batch - col0) < 64 ? (batch - col0) : 64);
+  tile_stage_in<T, V>(tile + shift, in + col0 * rows_in, rows_in, P, ncols, lane);
+  tile_sync();
+  T lres = T(0);
+  if (lane < ncols) {
+    T* mine = tile + lane * P;
+    const T* src = mine + shift;
+    constexpr size_t RB = stacked_row_bytes<T>();
+    int r = 0, bi = 0;
+    while (r < rows_out) {
+      const int stop = bi < n_blocks ? blocks.b[bi].out_lo : rows_out;
+      for (; r < stop; ++r) {                               // elementwise rows: the row's slots are the same for every lane
+        const Slot<T>* sl = reinterpret_cast<const Slot<T>*>(tab + (size_t)r * RB);
+        const Slot<T> s0 = sl[0];
+        T v = src[s0.src];
+        lres += slot_eval(s0, v);
+        if (two_slots) { const Slot<T> s1 = sl[1]; if (s1.kind != SK_END) lres += slot_eval(s1, v); }
+        mine[r] = v;
+      }
+      if (bi < n_blocks) {
+        const MixBlock b = blocks.b[bi];
+        const T* pin = src + b.in_lo;
+        T* pout = mine + b.out_lo;
+        switch (b.kind) {
+          case MB_SIMPLEX: { SimplexFwd<T, true> op; op.K = b.len_in; lres += mixed_run_block<T>(op, pin, pout, b.len_in, b.len_out, logn); } break;
+          case MB_SIMPLEX_INV: { SimplexInv<T, true> op; op.K = b.len_out; lres += mixed_run_block<T>(op, pin, pout, b.len_in, b.len_out, logn); } break;
+          case MB_ORDERED: { OrderedFwd<T> op; lres += mixed_run_block<T>(op, pin, pout, b.len_in, b.len_out, logn); } break;
+          default: { OrderedInv<T> op; lres += mixed_run_block<T>(op, pin, pout, b.len_in, b.len_out, logn); } break;
+        }
+        r += b.len_out;
+        ++bi;
+      }
+    }
+    if (ladj_ps) ladj_ps[col0 + lane] = accumulate ? ladj_ps[col0 + lane] + lres : lres;
+  }
+  tile_sync();
+  tile_stage_out<T, V>(tile, out + col0 * rows_out, rows_out, P, ncols, lane);
+  block_publish_partial(lane < ncols ? (double)lres : 0.0, red, fin);
+}
+
+template <class T>
+int stacked_mixed_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const bjx_block* blocks, int n_blocks, const T* x, int64_t rows_in, T* y,
+                       int64_t rows_out, T* ladj_ps, double* ladj_sum, int64_t batch, uint32_t flags) {
+  if (batch == 0 || rows_out == 0) {
+    if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
+    return BJX_OK;
+  }
+  BJX_REQUIRE(ctx, n_blocks <= MixBlocks::N, BJX_ERR_UNSUPPORTED, "bjx_stacked_mixed: %d structured blocks (max %d)", n_blocks, MixBlocks::N);
+  // blocks: ascending and disjoint in the output AND the input; the elementwise segments cover the remaining output rows
+  // (the structured rows carry identity placeholders, as for bjx_stacked_ld), with non-decreasing input ranges
+  MixBlocks mb{};
+  int64_t shift = rows_out > rows_in ? rows_out - rows_in : 0, max_len = 2, prev_out = 0, prev_in = 0;
+  for (int i = 0; i < n_blocks; ++i) {
+    const bjx_block& b = blocks[i];
+    BJX_REQUIRE(ctx, b.kind >= MB_SIMPLEX && b.kind <= MB_ORDERED_INV, BJX_ERR_ARG, "bjx_stacked_mixed: block %d: bad kind %d", i, b.kind);
+    const int64_t want_out = b.kind == MB_SIMPLEX ? b.len_in - 1 : (b.kind == MB_SIMPLEX_INV ? b.len_in + 1 : b.len_in);
+    BJX_REQUIRE(ctx, b.len_in >= 1 && b.len_out == want_out && b.len_out >= 1, BJX_ERR_SHAPE, "bjx_stacked_mixed: block %d: %lld rows in, %lld rows out", i, (long long)b.len_in, (long long)b.len_out);
+    BJX_REQUIRE(ctx, b.in_lo >= prev_in && b.out_lo >= prev_out && b.in_lo + b.len_in <= rows_in && b.out_lo + b.len_out <= rows_out, BJX_ERR_SHAPE,
+                "bjx_stacked_mixed: block %d is out of order or outside the column", i);
+    prev_in = b.in_lo + b.len_in; prev_out = b.out_lo + b.len_out;
+    if (b.out_lo - b.in_lo > shift) shift = b.out_lo - b.in_lo;
+    if (b.len_in + 1 > max_len) max_len = b.len_in + 1;
+    if (b.len_out + 1 > max_len) max_len = b.len_out + 1;
+    mb.b[i] = MixBlock{b.kind, (int)b.in_lo, (int)b.out_lo, (int)b.len_in, (int)b.len_out, 0};
+  }
+  {   // elementwise segments: ascending in the output with non-decreasing input rows (the walk is in place)
+    int64_t po = -1, pi = -1;
+    for (int s = 0; s < n_segs; ++s) {
+      if (segs[s].len == 0) continue;
+      BJX_REQUIRE(ctx, segs[s].out_lo > po && segs[s].in_lo >= pi, BJX_ERR_UNSUPPORTED, "bjx_stacked_mixed: segments must be listed in ascending row order");
+      po = segs[s].out_lo; pi = segs[s].in_lo;
+      if (segs[s].out_lo - segs[s].in_lo > shift) shift = segs[s].out_lo - segs[s].in_lo;
+    }
+  }
+  // the slot table wants every output row once: identity placeholders on the rows of the structured blocks (never evaluated)
+  std::vector<bjx_segment> full(segs, segs + n_segs);
+  for (int i = 0; i < n_blocks; ++i) {
+    bjx_segment ph{};
+    ph.len = blocks[i].len_out;
+    BJX_REQUIRE(ctx, ph.len <= rows_in, BJX_ERR_UNSUPPORTED, "bjx_stacked_mixed: block %d is longer than the input column", i);
+    ph.in_lo = blocks[i].in_lo + ph.len <= rows_in ? blocks[i].in_lo : rows_in - ph.len;
+    ph.out_lo = blocks[i].out_lo;
+    ph.n_ops = 0;
+    full.push_back(ph);
+  }
+  const int64_t rows_tile = rows_out > shift + rows_in ? rows_out : shift + rows_in;
+  const int64_t P = rows_tile | 1;
+  const size_t smem = ((size_t)64 * P + (size_t)max_len) * sizeof(T);
+  BJX_REQUIRE(ctx, smem <= 64 * 1024, BJX_ERR_UNSUPPORTED, "bjx_stacked_mixed: columns of %lld rows exceed the LDS tile", (long long)rows_tile);
+  StackedPlan pl;
+  { int rc = stacked_prepare<T>(ctx, full.data(), (int)full.size(), x, y, rows_out, batch, false, false, &pl, rows_in, rows_out); if (rc) return rc; }
+  const int64_t grid = (batch + 63) / 64;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+  BjxFin fin;
+  bool second = false;
+  { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
+  if (fin.counter) { fin.counter = nullptr; second = true; }           // single-wave blocks: two-pass finalize (see launch_seq)
+  constexpr int VW = Vec16<T>::N;
+  const bool v_ok = bjx_aligned16(x) && bjx_aligned16(y);
+  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  {
+    BjxProf prof_(ctx);
+    if (v_ok) hipLaunchKernelGGL((stacked_mixed_kernel<T, VW>), dim3((unsigned)grid), dim3(64), smem, ctx->stream, pl.tab, pl.two, mb, n_blocks, x, y, ladj_ps,
+                                 (int)rows_in, (int)rows_out, (int)shift, (int)P, (int)max_len, batch, accum, fin);
+    else hipLaunchKernelGGL((stacked_mixed_kernel<T, 1>), dim3((unsigned)grid), dim3(64), smem, ctx->stream, pl.tab, pl.two, mb, n_blocks, x, y, ladj_ps,
+                            (int)rows_in, (int)rows_out, (int)shift, (int)P, (int)max_len, batch, accum, fin);
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+  return BJX_OK;
+}
+
 // ------------------------------------------------------------------ pullback (elementwise part)
 // x_bar = (dy/dx) y_bar + ladj_bar (d ladj / dx), element by element through the same canonical slots:
 //   u = a1 clamp(x) + b1,  v = N(u),  y = clamp(a2 v + b2):   dy/dx = a2 N'(u) a1 (0 where a clamp is active),
@@ -630,6 +793,18 @@ BJX_API int bjx_stacked_ld(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, 
   if (dt == BJX_F32) return stacked_impl<float>(ctx, segs, n_segs, (const float*)x, (float*)y, (float*)ladj_ps, ladj_sum, dim, batch, flags, ldx, ldy);
   if (dt == BJX_F64) return stacked_impl<double>(ctx, segs, n_segs, (const double*)x, (double*)y, (double*)ladj_ps, ladj_sum, dim, batch, flags, ldx, ldy);
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_stacked_ld: bad dtype %d", (int)dt);
+}
+
+BJX_API int bjx_stacked_mixed(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const bjx_block* blocks, int n_blocks, const void* x,
+                              int64_t rows_in, void* y, int64_t rows_out, void* ladj_ps, double* ladj_sum, int64_t batch, uint32_t flags) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, rows_in >= 0 && rows_out >= 0 && batch >= 0 && n_segs >= 0 && n_blocks >= 0, BJX_ERR_SHAPE, "bjx_stacked_mixed: bad size");
+  BJX_REQUIRE(ctx, (segs || n_segs == 0) && (blocks || n_blocks == 0) && ((x && y) || rows_out * batch == 0), BJX_ERR_ARG, "bjx_stacked_mixed: null pointer");
+  BJX_REQUIRE(ctx, x != y, BJX_ERR_ARG, "bjx_stacked_mixed: in-place is not supported");
+  BJX_REQUIRE(ctx, rows_in < (1 << 20) && rows_out < (1 << 20), BJX_ERR_UNSUPPORTED, "bjx_stacked_mixed: too many rows");
+  if (dt == BJX_F32) return stacked_mixed_impl<float>(ctx, segs, n_segs, blocks, n_blocks, (const float*)x, rows_in, (float*)y, rows_out, (float*)ladj_ps, ladj_sum, batch, flags);
+  if (dt == BJX_F64) return stacked_mixed_impl<double>(ctx, segs, n_segs, blocks, n_blocks, (const double*)x, rows_in, (double*)y, rows_out, (double*)ladj_ps, ladj_sum, batch, flags);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_stacked_mixed: bad dtype %d", (int)dt);
 }
 
 BJX_API int bjx_stacked_vjp_moments(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const void* x, const void* y_bar,

@@ -1484,6 +1484,52 @@ class Stacked(Transform):
         sm = torch.zeros(1, dtype=torch.float64, device=xc.device) if (want_ladj and out.sum is not None) else None
         lib = L.load()
         es = xc.element_size()
+
+        def fill_segment(sg, i, x_off, y_off, keep):
+            lo, hi = self.ranges_in[i]
+            ln, ops = hi - lo + 1, segs_ops[i]
+            sg.in_lo, sg.out_lo, sg.len, sg.n_ops = lo - 1 - x_off, self.ranges_out[i][0] - 1 - y_off, ln, len(ops)
+            for k, (kind, p0, p1) in enumerate(ops):
+                o = sg.ops[k]
+                o.kind, o.param_len, o.p0, o.p1, o.v0, o.v1 = kind, 0, 0.0, 0.0, None, None
+                seq = any(_is_seq(p) for p in (p0, p1) if p is not None)
+                for j, p in enumerate((p0, p1)):
+                    if p is None:
+                        continue
+                    if seq:
+                        t = _param(p, xc).reshape(-1) if _is_seq(p) else torch.full((ln,), float(p), dtype=xc.dtype, device=xc.device)
+                        if t.numel() != ln:
+                            raise ValueError(f"DimensionMismatch: parameter of length {t.numel()} for a segment of {ln} rows")
+                        keep.append(t)
+                        o.param_len = ln
+                        setattr(o, f"v{j}", t.data_ptr())
+                    else:
+                        o.param_len = 1
+                        setattr(o, f"p{j}", float(p))
+
+        # ONE launch when a whole column fits the LDS tile of bjx_stacked_mixed (a lane walks its column: elementwise rows and
+        # structured blocks in the same pass); taller columns: the window launches below
+        order_all = sorted(range(len(self.bs)), key=lambda i: self.ranges_out[i][0])
+        in_ascending = all(self.ranges_in[a][0] < self.ranges_in[b][0] for a, b in zip(order_all, order_all[1:]))
+        if in_ascending and len(rest) <= 64:
+            el = [i for i in order_all if i in fused]
+            st = [i for i in order_all if i in rest]
+            arr = (L.BjxSegment * max(len(el), 1))()
+            keep = []
+            for si, i in enumerate(el):
+                fill_segment(arr[si], i, 0, 0, keep)
+            blk = (L.BjxBlock * max(len(st), 1))()
+            for bi, i in enumerate(st):
+                fn, inv = struct_of(self.bs[i])
+                (lo, hi), (olo, ohi) = self.ranges_in[i], self.ranges_out[i]
+                b_ = blk[bi]
+                b_.kind = (L.BLOCK_SIMPLEX_INV if inv else L.BLOCK_SIMPLEX) if fn == "bjx_simplex_ld" else (L.BLOCK_ORDERED_INV if inv else L.BLOCK_ORDERED)
+                b_.in_lo, b_.out_lo, b_.len_in, b_.len_out = lo - 1, olo - 1, hi - lo + 1, ohi - olo + 1
+            rc = lib.bjx_stacked_mixed(ctx.h, _dt(xc), arr, len(el), blk, len(st), _ptr(xc), dim, _ptr(y), dout, _ptr(ps), _ptr(sm), batch, 0)
+            del keep
+            if rc != L.ERR_UNSUPPORTED:
+                L.check(ctx.h, rc, "bjx_stacked_mixed")
+                return self._ladj_result(y, ps, sm, out, per_sample, want_ladj, xc)
         first = True
         if fused:
             # maximal runs of elementwise segments that are contiguous on BOTH sides keep their row offsets inside a window of
@@ -1505,27 +1551,7 @@ class Stacked(Transform):
                 arr = (L.BjxSegment * len(run))()
                 keep = []
                 for si, i in enumerate(run):
-                    lo, hi = self.ranges_in[i]
-                    ln, ops = hi - lo + 1, segs_ops[i]
-                    sg = arr[si]
-                    sg.in_lo, sg.out_lo, sg.len, sg.n_ops = lo - 1 - x_off, self.ranges_out[i][0] - 1 - y_off, ln, len(ops)
-                    for k, (kind, p0, p1) in enumerate(ops):
-                        o = sg.ops[k]
-                        o.kind, o.param_len, o.p0, o.p1, o.v0, o.v1 = kind, 0, 0.0, 0.0, None, None
-                        seq = any(_is_seq(p) for p in (p0, p1) if p is not None)
-                        for j, p in enumerate((p0, p1)):
-                            if p is None:
-                                continue
-                            if seq:
-                                t = _param(p, xc).reshape(-1) if _is_seq(p) else torch.full((ln,), float(p), dtype=xc.dtype, device=xc.device)
-                                if t.numel() != ln:
-                                    raise ValueError(f"DimensionMismatch: parameter of length {t.numel()} for a segment of {ln} rows")
-                                keep.append(t)
-                                o.param_len = ln
-                                setattr(o, f"v{j}", t.data_ptr())
-                            else:
-                                o.param_len = 1
-                                setattr(o, f"p{j}", float(p))
+                    fill_segment(arr[si], i, x_off, y_off, keep)
                 rc = lib.bjx_stacked_ld(ctx.h, _dt(xc), arr, len(run), C.c_void_p(xc.data_ptr() + x_off * es), dim, C.c_void_p(y.data_ptr() + y_off * es), dout,
                                         _ptr(ps), _ptr(sm), rows_run, batch, 0 if first else L.BJX_ACCUMULATE)
                 del keep
@@ -1543,6 +1569,10 @@ class Stacked(Transform):
             if rc == L.ERR_UNSUPPORTED:
                 return None
             L.check(ctx.h, rc, fn)
+        return self._ladj_result(y, ps, sm, out, per_sample, want_ladj, xc)
+
+    @staticmethod
+    def _ladj_result(y, ps, sm, out, per_sample, want_ladj, xc):
         if not want_ladj:
             return y, None
         if out.both:

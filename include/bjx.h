@@ -386,6 +386,21 @@ int bjx_ordered_ld(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, int6
 int bjx_simplex_ld(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, int64_t ld_in, void* out, int64_t ld_out,
                    void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags);
 
+/*   3. bjx_stacked_mixed — steps 1 and 2 as ONE launch when a column fits an LDS tile (64 columns x rows x sizeof(T) <= 64 KiB):
+ *      a lane owns a column and walks it top to bottom, elementwise rows through the same slots as bjx_stacked, every
+ *      structured block with the walker of bjx_simplex / bjx_ordered.  `segs`: the elementwise segments only, in ascending
+ *      row order; `blocks`: the structured ones, ascending and disjoint; together they cover every row of y once.  x is
+ *      [rows_in, batch], y is [rows_out, batch], both dense.  BJX_ERR_UNSUPPORTED when the column is too tall: fall back to steps 1 + 2. */
+typedef enum { BJX_BLOCK_SIMPLEX = 1, BJX_BLOCK_SIMPLEX_INV = 2, BJX_BLOCK_ORDERED = 3, BJX_BLOCK_ORDERED_INV = 4 } bjx_block_kind;
+typedef struct {
+  int32_t kind;      /* bjx_block_kind */
+  int32_t reserved;
+  int64_t in_lo, out_lo, len_in, len_out;   /* Simplex: len_out = len_in - 1; its inverse: len_in + 1; Ordered: equal */
+} bjx_block;
+int bjx_stacked_mixed(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const bjx_block* blocks, int n_blocks,
+                      const void* x, int64_t rows_in, void* y, int64_t rows_out, void* ladj_ps, double* ladj_sum,
+                      int64_t batch, uint32_t flags);
+
 /* ------------------------------- reverse-mode pullbacks (first rows)  */
 /* Pullback of with_logabsdet_jacobian for one launch over the batch:
  *     in_bar = J(in)^T * out_bar + ladj_bar * grad_in logabsdetjac

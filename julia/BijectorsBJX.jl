@@ -309,6 +309,9 @@ end
 # Stacked with Simplex / Ordered segments (stacked.jl:142-166) without slicing copies: the elementwise segments in one
 # bjx_stacked_ld launch between matrices of different heights (identity placeholders on the structured rows), then
 # bjx_simplex_ld / bjx_ordered_ld on row windows of the same matrices, accumulating their log-dets.
+struct BjxBlock            # include/bjx.h: bjx_block
+    kind::Cint; reserved::Cint; in_lo::Int64; out_lo::Int64; len_in::Int64; len_out::Int64
+end
 structured_entry(::SimplexBijector) = (:bjx_simplex_ld, false)
 structured_entry(::Inverse{SimplexBijector}) = (:bjx_simplex_ld, true)
 structured_entry(::OrderedBijector) = (:bjx_ordered_ld, false)
@@ -330,6 +333,15 @@ function stacked_structured(sb::Stacked, x::ROCMatrix{T}) where {T<:Union{Float3
         end
     end
     y = similar(x, dout, n); lps = AMDGPU.zeros(T, n)
+    # ONE launch when a column fits the LDS tile (bjx_stacked_mixed: a lane walks its column through every segment)
+    blocks = [BjxBlock(Cint(sym === :bjx_simplex_ld ? (inv ? 2 : 1) : (inv ? 4 : 3)), Cint(0), first(rin) - 1, first(rout) - 1, length(rin), length(rout))
+              for ((sym, inv), rin, rout) in later]
+    elem = [sg for sg in segs if !any(b -> b.out_lo == sg.out_lo, blocks)]
+    rc = GC.@preserve keep x y lps ccall((:bjx_stacked_mixed, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{BjxBlock}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, UInt32),
+        ctx().h, dtype(T), elem, length(elem), blocks, length(blocks), devptr(x), d, devptr(y), dout, devptr(lps), C_NULL, n, UInt32(0))
+    rc == 0 && return y, lps
+    rc == BJX_ERR_UNSUPPORTED || check(rc, "bjx_stacked_mixed")       # taller columns: the window launches below
     GC.@preserve keep x y lps begin
         check(ccall((:bjx_stacked_ld, libbjx), Cint,
             (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),

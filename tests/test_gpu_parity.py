@@ -2546,6 +2546,35 @@ def test_stacked_with_structured_segments_in_place(bj, orc, dt, N):
     close(host(l3b), l2 + l4, dt, scale=200)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("tall", [False, True])
+def test_stacked_mixed_one_launch_and_window_fallback(bj, orc, dt, tall):
+    """bjx_stacked_mixed (one lane per column, the whole stack in ONE launch) and its fallback for columns taller than the LDS
+    tile (bjx_stacked_ld windows + bjx_simplex_ld / bjx_ordered_ld) give the same numbers: per-row VECTOR parameters on the
+    elementwise rows, an inverse Ordered block, a Simplex block, ragged batch."""
+    r = rng(321 + tall)
+    n_e = 300 if tall else 11                      # 300 + 14 rows x 64 columns exceed 64 KiB of LDS in both types
+    N = 130
+    mu = r.normal(size=n_e)
+    sg = r.uniform(0.5, 1.5, size=n_e)
+    E = r.normal(size=(n_e, N))
+    Oy = np.sort(r.normal(size=(8, N)), axis=0) + 0.1 * np.arange(8)[:, None]     # an ordered vector: input of inverse(Ordered)
+    Pp = r.dirichlet(np.ones(6), size=N).T
+    X = np.asfortranarray(np.vstack([E, Oy, Pp]).astype(dt))
+    Xd = X.astype(np.float64)
+    exp = bj.elementwise(bj.exp)
+    b = bj.Stacked([exp @ bj.Shift(dev(mu.astype(dt))) @ bj.Scale(dev(sg.astype(dt))), bj.inverse(bj.OrderedBijector()), bj.SimplexBijector()],
+                   [(1, n_e), (n_e + 1, n_e + 8), (n_e + 9, n_e + 14)])
+    u = sg[:, None] * Xd[:n_e] + mu[:, None]
+    y1, l1 = np.exp(u), u.sum(axis=0) + np.log(sg).sum()
+    y2, l2 = orc.ordered(np.asfortranarray(Xd[n_e:n_e + 8]), inverse=True)
+    y3, l3 = orc.simplex(np.asfortranarray(Xd[n_e + 8:]))
+    Y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+    assert tuple(Y.shape) == (n_e + 13, N)
+    close(host(Y), np.vstack([y1, y2, y3]), dt, scale=50, what="mixed Stacked values")
+    close(host(l), l1 + l2 + l3, dt, scale=50 * max(1, n_e // 10), what="mixed Stacked ladj")
+
+
 def test_captured_step_replays_the_same_result(bj):
     """bjx_graph_begin/_end/_launch (include/bjx.h): a step recorded into a hipGraph writes the same outputs as the eager call,
     on every replay, and picks up new INPUT VALUES in the same buffers (addresses are baked in, contents are not)."""
