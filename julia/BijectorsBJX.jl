@@ -24,6 +24,7 @@ const libbjx = get(ENV, "BJX_LIBRARY", "libbjx_hip.so")
 # ---------------------------------------------------------------- include/bjx.h mirror
 const BJX_F32, BJX_F64 = Cint(0), Cint(1)
 const BJX_ACCUMULATE, BJX_REF_VECTOR_SCALE_LADJ = UInt32(1), UInt32(2)
+const BJX_ERR_UNSUPPORTED = Cint(-3)
 @enum OpKind::Int32 OP_EXP = 1 OP_LOG OP_SHIFT OP_SCALE OP_SCALE_INV OP_LOGIT OP_LOGIT_INV OP_LEAKY_RELU OP_TRUNCATED OP_TRUNCATED_INV OP_SIGNFLIP OP_IDENTITY
 
 struct BjxOp            # layout of `bjx_op` (40 bytes)
