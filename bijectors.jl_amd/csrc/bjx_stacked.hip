@@ -466,7 +466,31 @@ __global__ __launch_bounds__(64) void stacked_mixed_kernel(const char* __restric
     int r = 0, bi = 0;
     while (r < rows_out) {
       const int stop = bi < n_blocks ? blocks.b[bi].out_lo : rows_out;
-      for (; r < stop; ++r) {                               // elementwise rows: the row's slots are the same for every lane
+      // elementwise rows: the row's slots are the same for every lane (scalar loads).  Four rows at a time — the slot
+      // fetches, then the LDS reads they address, then the evaluations: row by row the walk is one serial chain of
+      // scalar-load -> LDS-read -> transcendental latencies per row (42 % of the roofline on an all-elementwise stack).
+      for (; r + 4 <= stop; r += 4) {
+        T v[4];
+        {
+          Slot<T> s0[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) s0[u] = reinterpret_cast<const Slot<T>*>(tab + (size_t)(r + u) * RB)[0];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = src[s0[u].src];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) lres += slot_eval(s0[u], v[u]);
+        }
+        if (two_slots) {
+          Slot<T> s1[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) s1[u] = reinterpret_cast<const Slot<T>*>(tab + (size_t)(r + u) * RB)[1];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (s1[u].kind != SK_END) lres += slot_eval(s1[u], v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mine[r + u] = v[u];
+      }
+      for (; r < stop; ++r) {
         const Slot<T>* sl = reinterpret_cast<const Slot<T>*>(tab + (size_t)r * RB);
         const Slot<T> s0 = sl[0];
         T v = src[s0.src];
