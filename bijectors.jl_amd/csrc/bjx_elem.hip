@@ -774,12 +774,12 @@ template <class T> bool knots_fit_lds(int64_t rows, int K1) { return (size_t)row
 
 // largest knot blob the LDS kernels take (the default dynamic-LDS limit of a launch); beyond it the generic functor path runs
 constexpr size_t kRqsBlobMax = 64 * 1024;
-// Column groups per block: enough to amortise the table staging (>= ~2x the table bytes of data; same-call sweep at 32 x 2^22:
-// 8 groups 0.53 ms, 16-64 groups 0.47-0.49 ms, 128 groups 0.50 ms — shorter blocks keep the CUs' phases apart).
+// Column groups per block: enough to amortise the table staging (>= ~3x the table bytes of data; same-call sweeps at 32 x 2^22,
+// forward + inverse: 8 groups 0.53 ms, 12: 0.50, 17: 0.49, 24: 0.48, 34: 0.49, 64: 0.48, 128: 0.50).
 inline int rqs_iters(const bjx_ctx* ctx, size_t blob_bytes, int64_t bytes_per_group, int64_t groups) {
   static const int forced = [] { const char* e = getenv("BJX_RQS_ITERS"); return e ? atoi(e) : 0; }();   // tuning switch
   if (forced > 0) return forced;
-  int64_t amort = (2 * (int64_t)blob_bytes + bytes_per_group - 1) / bytes_per_group;
+  int64_t amort = (3 * (int64_t)blob_bytes + bytes_per_group - 1) / bytes_per_group;
   if (amort < 1) amort = 1;
   if (amort > 64) amort = 64;
   return (int)amort;
