@@ -491,11 +491,11 @@ def main():
     if want_rows and (world == 1 or a.collective == "bjx"):
         # shards of 2^20 columns and below are launch-bound: the step as a captured hipGraph next to call-by-call issue.
         # (multi-rank only with --collective bjx: the all-reduce must be recorded on the library's stream)
-        for lb in (20, 16):
+        for wl_, lb in (("c1", None), ("c2", 20), ("c2", 16)):      # c1 = BASELINE configs[0]: one Float64 vector of 2^20, a launch-latency case
             try:
-                graph_rows.append(dict(measure_graph(env, "c2", lb, 50, 5, a.scaling), log2_batch_per_gpu=lb))
+                graph_rows.append(dict(measure_graph(env, wl_, lb, 50, 5, a.scaling), log2_batch_per_gpu=lb))
             except Exception as e:
-                graph_rows.append({"workload": "c2", "log2_batch_per_gpu": lb, "error": repr(e)})
+                graph_rows.append({"workload": wl_, "log2_batch_per_gpu": lb, "error": repr(e)})
 
     if rank == 0:
         out = {
