@@ -12,11 +12,14 @@
 // Algorithmic bytes per sample: K*K*sizeof(T) on the matrix side (the reference materialises dense matrices) +
 // the packed / dense unconstrained side + sizeof(T) for the per-sample log-det.  The factorisation is O(K^3/3) flop on
 // O(K^2) bytes (K/12 flop per byte in Float32): HBM-bound on paper, VALU/LDS-issue-bound in practice.
+#include <cstdlib>
+
 #include "bjx_internal.h"
 
 using namespace bjx;
 
 namespace {
+#include "bjx_seqops.h"
 
 enum { MK_VEC_CORR = 0, MK_CORR = 1, MK_PD = 2, MK_PD_VEC = 3 };
 
@@ -439,6 +442,180 @@ __global__ __launch_bounds__(64) void matrix_link_kernel(const T* __restrict__ i
 }
 #undef a
 
+// ------------------------------------------------------------------ small matrices: ONE LANE per sample (K <= 8)
+// The LKJ / Wishart blocks of real models are 2x2 ... 8x8.  With lanes along the rows a wave holds 8 such samples and every
+// column step is an LDS round trip for a handful of FMAs (K = 8: 11 % of the roofline).  Here a wave takes 64 consecutive
+// samples — one contiguous run of the input and of the output, moved with 16-byte accesses through a [64][P odd] LDS tile
+// — and lane t factors sample t entirely in its own registers: no cross-lane traffic, no LDS inside the arithmetic, fully
+// unrolled to KMAX rows with wave-uniform guards (K is a launch constant).  Same pivot and link arithmetic as
+// matrix_link_kernel (FacMath, LinkMath); the trailing update uses the scaled column (l_ik l_jk instead of a_ik a_jk / d).
+template <class T, int KMAX, int KIND, bool INV, int V>
+__global__ __launch_bounds__(64) void matrix_lane_kernel(const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps, int K, int P,
+                                                         int64_t batch, int accumulate, double* partials) {
+  extern __shared__ __align__(16) unsigned char smem_[];
+  __shared__ double red[1];
+  using M = LinkMath<T>;
+  constexpr bool CORR = KIND == MK_VEC_CORR || KIND == MK_CORR;
+  T* tile = reinterpret_cast<T*>(smem_);
+  const int lane = threadIdx.x;
+  const int KK = K * K;
+  const int nv = KIND == MK_VEC_CORR ? K * (K - 1) / 2 : (KIND == MK_PD_VEC ? K * (K + 1) / 2 : KK);
+  const int n_in = INV ? nv : KK, n_out = INV ? KK : nv;
+  double acc = 0.0;
+  for (int64_t s0 = (int64_t)blockIdx.x * 64; s0 < batch; s0 += (int64_t)gridDim.x * 64) {
+    const int ncols = (int)((batch - s0) < 64 ? (batch - s0) : 64);
+    if (n_in > 0) tile_stage_in<T, V>(tile, in + s0 * n_in, n_in, P, ncols, lane);
+    tile_sync();
+    T* mine = tile + lane * P;
+    T L[KMAX][KMAX];                                              // lower factor, row-major; only j <= i is used
+    T lsum = T(0);
+    if constexpr (!INV) {
+      // A[i][j], j <= i, from the triangle the reference reads (upper for the correlation bijectors, lower for PD)
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) L[i][j] = (i < K) ? (CORR ? mine[i * K + j] : mine[j * K + i]) : (i == j ? T(1) : T(0));
+      // right-looking Cholesky (the update order of matrix_link_kernel)
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+          T rd, rs, sq;
+          FacMath<T>::pivot(L[k][k], rd, rs, sq);
+          L[k][k] = sq;
+#pragma unroll
+          for (int i = k + 1; i < KMAX; ++i) if (i < K) L[i][k] *= rs;             // column k of the factor
+#pragma unroll
+          for (int i = k + 1; i < KMAX; ++i) {
+            if (i < K) {
+#pragma unroll
+              for (int j = k + 1; j <= i; ++j) L[i][j] -= L[i][k] * L[j][k];        // trailing update with the scaled column
+            }
+          }
+        }
+      }
+      tile_sync();                                                // (single wave: every lane has read its sample)
+      if constexpr (CORR) {
+        // column c of U = row c of L, bottom-up (corr.jl:277-297, :314-335); log-det weights K - i (0-based row i)
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) {
+          if (c < K) {
+            T rem, Lr;
+            M::fwd_init(L[c][c], rem, Lr);
+#pragma unroll
+            for (int i = KMAX - 2; i >= (KIND == MK_VEC_CORR ? 1 : 0); --i) {
+              if (i < c && i <= K - 2) {
+                T y, lc;
+                M::fwd_step(L[c][i], rem, Lr, y, lc);
+                lsum += T(K - i) * lc;
+                if (KIND == MK_VEC_CORR) mine[c * (c - 1) / 2 + i] = y; else mine[c * K + i] = y;
+              }
+            }
+            if (KIND == MK_VEC_CORR && c >= 1) {                  // :322 atanh(W[1, j]) on the first row
+              T y, lc;
+              M::atanh_lc(L[c][0], y, lc);
+              lsum += T(K) * lc;
+              mine[c * (c - 1) / 2] = y;
+            }
+            if (KIND == MK_CORR) {                                // zeros on and below the diagonal (:292-294)
+#pragma unroll
+              for (int i = 0; i < KMAX; ++i) if (i >= c && i < K) mine[c * K + i] = T(0);
+            }
+          }
+        }
+      } else {
+        // pd.jl:11,27-31,41: Y = replace_diag(log, L); log-det = -(sum_i (d+2-i) log L_ii + d log 2)
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+          if (i < K) {
+            const T ld = M::log(L[i][i]);
+            lsum -= T(K + 1 - i) * ld + Num<T>::log2;
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) {
+              if (j < K) {
+                const T v = j == i ? ld : (j < i ? L[i][j] : T(0));
+                if (KIND == MK_PD) mine[j * K + i] = v;                 // Y[i, j]
+                else if (j <= i) mine[i * (i + 1) / 2 + j] = v;         // triu_to_vec(Y'): (Y')[r, c] = L[c][r], r <= c
+              }
+            }
+          }
+        }
+      }
+    } else {
+      if constexpr (CORR) {
+        // corr.jl:345-399: column c of U top-down; + sum_{j=2}^{K-1} (K-j) log U[j,j] (:77-79, :144-146)
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) {
+          if (c < K) {
+            T lr = T(0), E;
+            M::inv_init(E);
+#pragma unroll
+            for (int i = 0; i < KMAX - 1; ++i) {
+              if (i < c) {
+                const T yv = KIND == MK_VEC_CORR ? mine[c * (c - 1) / 2 + i] : mine[c * K + i];
+                T w, lc;
+                M::inv_step(yv, E, w, lc);
+                L[c][i] = w;
+                lr -= lc;
+                lsum += lr;
+              }
+            }
+            L[c][c] = M::inv_diag(E, lr);
+            lsum += lr + ((c >= 1 && c <= K - 2) ? T(K - 1 - c) * lr : T(0));
+          }
+        }
+      } else {
+        // pd.jl:13-16,44-47: L = lower_triangular(replace_diag(exp, Y)); log-det = +(sum_i (d+2-i) Y_ii + d log 2)
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+          if (i < K) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+              const T t = KIND == MK_PD ? mine[j * K + i] : mine[i * (i + 1) / 2 + j];
+              if (j == i) { lsum += T(K + 1 - i) * t + Num<T>::log2; L[i][j] = M::exp(t); } else L[i][j] = t;
+            }
+          }
+        }
+      }
+      tile_sync();
+      if (out) {
+        // X = L L' (both triangles written): X[i][j] = sum_{m <= min(i,j)} L[i][m] L[j][m]
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+          if (i < K) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+              T x = T(0);
+#pragma unroll
+              for (int m = 0; m <= j; ++m) x += L[i][m] * L[j][m];
+              mine[j * K + i] = x;
+              if (j != i) mine[i * K + j] = x;
+            }
+          }
+        }
+      }
+    }
+    tile_sync();
+    if (out && n_out > 0) tile_stage_out<T, V>(tile, out + s0 * n_out, n_out, P, ncols, lane);
+    tile_sync();
+    if (lane < ncols) {
+      if (ladj_ps) ladj_ps[s0 + lane] = accumulate ? ladj_ps[s0 + lane] + lsum : lsum;
+      acc += (double)lsum;
+    }
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
+template <class T, int KMAX, int KIND>
+int launch_lane(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* partials, int K, int P, int64_t batch, int accum, bool vec, int grid,
+                size_t smem) {
+  constexpr int VW = Vec16<T>::N;
+#define BJX_ML(INV_, V_) hipLaunchKernelGGL((matrix_lane_kernel<T, KMAX, KIND, INV_, V_>), dim3(grid), dim3(64), smem, ctx->stream, in, out, ladj_ps, K, P, batch, accum, partials)
+  if (inverse) { if (vec) BJX_ML(true, VW); else BJX_ML(true, 1); }
+  else { if (vec) BJX_ML(false, VW); else BJX_ML(false, 1); }
+#undef BJX_ML
+  return 0;
+}
+
 template <class T, int GS, int KIND>
 int launch_gs(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* partials, int K, int pitch, int64_t batch, int accum, int vin, int vout,
               int grid, size_t smem) {
@@ -462,6 +639,27 @@ int matrix_impl(bjx_ctx* ctx, const char* who, int inverse, const T* in, T* out,
   constexpr int VW = Vec16<T>::N;
   const int64_t KK = K * K;
   const int64_t nv = KIND == MK_VEC_CORR ? K * (K - 1) / 2 : (KIND == MK_PD_VEC ? K * (K + 1) / 2 : KK);
+  static const int lane_max = getenv("BJX_MATRIX_LANE_MAX") ? atoi(getenv("BJX_MATRIX_LANE_MAX")) : 8;   // tuning switch (0: lanes along the rows for every K)
+  if (K <= lane_max && K <= 8) {
+    // one lane per sample (matrix_lane_kernel)
+    const int64_t rows = KK > nv ? KK : nv;
+    const int P = (int)(rows | 1);
+    const size_t smem_l = (size_t)64 * P * sizeof(T);
+    const int64_t tiles = (batch + 63) / 64;
+    const int64_t cap_l = (int64_t)ctx->num_cu * 32;
+    const int grid_l = (int)(tiles < cap_l ? tiles : cap_l);
+    if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid_l); if (rc) return rc; }
+    double* partials_l = ladj_sum ? ctx->partials : nullptr;
+    const bool vec = bjx_aligned16(in) && (!out || bjx_aligned16(out));     // a full tile of 64 samples is a whole number of 16-byte packs
+    {
+      BjxProf prof_(ctx);
+      if (K <= 4) launch_lane<T, 4, KIND>(ctx, inverse, in, out, ladj_ps, partials_l, (int)K, P, batch, (flags & BJX_ACCUMULATE) ? 1 : 0, vec, grid_l, smem_l);
+      else launch_lane<T, 8, KIND>(ctx, inverse, in, out, ladj_ps, partials_l, (int)K, P, batch, (flags & BJX_ACCUMULATE) ? 1 : 0, vec, grid_l, smem_l);
+    }
+    BJX_CHECK_LAUNCH(ctx);
+    if (ladj_sum) return bjx_launch_finalize(ctx, grid_l, ladj_sum, 0.0, 0, 0.0, flags);
+    return BJX_OK;
+  }
   const int gs = K <= 8 ? 8 : (K <= 16 ? 16 : (K <= 32 ? 32 : 64));
   const int nsw = 64 / gs;
   const int pitch = (int)((K + 3) / 4 * 4 + 4);                  // multiple of 4 (16-byte rows), + 4: consecutive rows start 4 banks apart

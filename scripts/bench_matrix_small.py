@@ -1,0 +1,34 @@
+"""Small correlation / covariance blocks (K = 2 ... 8, the sizes LKJ / Wishart priors have in practice): one lane per sample
+(matrix_lane_kernel) against lanes along the rows (BJX_MATRIX_LANE_MAX=0 in a second process).  Prints a markdown table."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import bijectors_amd as bj
+import ctypes as C
+
+dev = torch.device("cuda", 0)
+N = 1 << 20
+lib = bj._lib.load()
+ctx = bj.context(dev)
+print("| bijector | K | kernel ms | alg. B/sample | GB/s | % of 8 TB/s |")
+print("|---|---|---|---|---|---|")
+for K in (2, 3, 4, 5, 8):
+    nv = K * (K - 1) // 2
+    y = (0.4 * torch.randn(N, nv, device=dev)).T if nv else torch.zeros(0, N, device=dev)
+    for name, b, nu in (("VecCorrBijector", bj.VecCorrBijector(), nv), ("PDVecBijector", bj.PDVecBijector(), K * (K + 1) // 2)):
+        yy = (0.4 * torch.randn(N, nu, device=dev)).T
+        X = bj.transform(bj.inverse(b), yy)
+        for label, bb, xin in ((name, b, X), (f"inverse({name})", bj.inverse(b), yy)):
+            for _ in range(3):
+                bj.with_logabsdet_jacobian(bb, xin, per_sample=True)
+            torch.cuda.synchronize()
+            lib.bjx_kernel_time_begin(ctx.h)
+            reps = 10
+            for _ in range(reps):
+                bj.with_logabsdet_jacobian(bb, xin, per_sample=True)
+            ms, n = C.c_float(0), C.c_int(0)
+            lib.bjx_kernel_time_end(ctx.h, C.byref(ms), C.byref(n))
+            kms = ms.value / reps
+            bytes_ps = (K * K + nu) * 4 + 4
+            gbs = bytes_ps * N / (kms * 1e-3) / 1e9
+            print(f"| {label} | {K} | {kms:.4f} | {bytes_ps} | {gbs:.0f} | {gbs / 80:.1f} |")

@@ -182,16 +182,17 @@ def main():
     rows.append(("logabsdetjac(exp∘Shift∘Scale) alone (values not stored)", "a1,a5", lambda: bj.logabsdetjac(c2b, x), 4 * d, N))
 
     # §8(f) f-4: matrix-variate constraint bijectors (per-sample Cholesky), Scale with a matrix, Stacked with structured blocks
-    Km = 32
-    Nm = 1 << min(a.log2_batch, 18)
-    for nm, cls in (("VecCorrBijector", bj.VecCorrBijector), ("PDVecBijector", bj.PDVecBijector)):
-        bm = cls()
-        nvm = bm._n(Km)
-        ym = randn(nvm, Nm, dev, 40, std=0.3)
-        Xm = bj.transform(bj.inverse(bm), ym)
-        bpsm = 4 * (Km * Km + nvm) + 4
-        rows.append((f"{nm} K=32 (X → Cholesky → y)", "f-4", (lambda b_=bm, X_=Xm: bj.shard.with_logabsdet_jacobian_sharded(b_, X_)), bpsm, Nm))
-        rows.append((f"inverse({nm}) K=32 (y → X = U'U)", "f-4", (lambda b_=bm, y_=ym: bj.shard.with_logabsdet_jacobian_sharded(bj.inverse(b_), y_)), bpsm, Nm))
+    # K = 4 and 8: the sizes LKJ / Wishart blocks have in models (one lane per sample); K = 32: lanes along the rows
+    for Km, lbm in ((4, 22), (8, 20), (32, 18)):
+        Nm = 1 << min(a.log2_batch, lbm)
+        for nm, cls in (("VecCorrBijector", bj.VecCorrBijector), ("PDVecBijector", bj.PDVecBijector)):
+            bm = cls()
+            nvm = bm._n(Km)
+            ym = randn(nvm, Nm, dev, 40, std=0.3)
+            Xm = bj.transform(bj.inverse(bm), ym)
+            bpsm = 4 * (Km * Km + nvm) + 4
+            rows.append((f"{nm} K={Km} (X → Cholesky → y)", "f-4", (lambda b_=bm, X_=Xm: bj.shard.with_logabsdet_jacobian_sharded(b_, X_)), bpsm, Nm))
+            rows.append((f"inverse({nm}) K={Km} (y → X = U'U)", "f-4", (lambda b_=bm, y_=ym: bj.shard.with_logabsdet_jacobian_sharded(bj.inverse(b_), y_)), bpsm, Nm))
     Am = (randn(d, d, dev, 41, std=1 / math.sqrt(d)) + 1.5 * torch.eye(d, device=dev).T).T.contiguous().T
     add("Scale(64×64 matrix): a * x + logabsdet(a)", "f-4", bj.Scale(Am), x)
     add("inverse(Scale(64×64 matrix)): a \\ y", "f-4", bj.inverse(bj.Scale(Am)), x)
@@ -199,7 +200,7 @@ def main():
     xmix = x.clone()
     xmix[16:32] = torch.softmax(x[16:32].T, dim=1).T
     xmix[32:48] = xunit[32:48]
-    add("Stacked(exp∘Shift∘Scale | Simplex | Logit | Ordered) d=64 → 63: structured blocks in place", "f-4", mix, xmix, out_rows=d - 1)
+    add("Stacked(exp∘Shift∘Scale | Simplex | Logit | Ordered) d=64 → 63: structured blocks in the same launch", "f-4", mix, xmix, out_rows=d - 1)
 
     only = [s for s in a.only.split(",") if s]
     L, ctx = bj._lib, bj.context(dev)
