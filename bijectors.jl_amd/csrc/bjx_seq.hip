@@ -927,6 +927,85 @@ __global__ __launch_bounds__(256) void chol_fwd_kernel(const T* W, T* y, T* ladj
   if (partials) block_publish_partial(acc, red, partials);
 }
 
+// ------------------------------------------------------------------ VecCholesky, small K: ONE LANE per sample
+// LKJCholesky blocks in models are 2x2 ... 10x10; the wave-per-sample kernels above spend 64 lanes on a handful of entries
+// (K = 4: 3 % of the roofline).  A wave takes 64 consecutive samples — one contiguous run of the input and of the output,
+// 16-byte accesses through a [64][P odd] LDS tile — and lane t walks the columns of sample t in place: forward
+// (corr.jl:314-335) columns ascending (y lands below the column it came from), inverse (corr.jl:370-399) columns DESCENDING
+// (W lands above the y it came from); :L factors are transposed inside the lane's tile row before / after the walk.
+#include "bjx_linkmath.h"
+
+template <class T, bool INV, int V>
+__global__ __launch_bounds__(64) void chol_lane_kernel(const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps, int K, int P, int lower,
+                                                       int64_t batch, int accumulate, double* partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[1];
+  using M = LinkMath<T>;
+  T* tile = reinterpret_cast<T*>(smem);
+  const int lane = threadIdx.x;
+  const int KK = K * K, nv = K * (K - 1) / 2;
+  const int n_in = INV ? nv : KK, n_out = INV ? KK : nv;
+  double acc = 0.0;
+  for (int64_t s0 = (int64_t)blockIdx.x * 64; s0 < batch; s0 += (int64_t)gridDim.x * 64) {
+    const int ncols = (int)((batch - s0) < 64 ? (batch - s0) : 64);
+    if (n_in > 0) tile_stage_in<T, V>(tile, in + s0 * n_in, n_in, P, ncols, lane);
+    tile_sync();
+    T* mine = tile + lane * P;
+    T lsum = T(0);
+    if constexpr (!INV) {
+      if (lower)                                                   // W' is the upper factor
+        for (int j = 1; j < K; ++j)
+          for (int i = 0; i < j; ++i) mine[j * K + i] = mine[i * K + j];
+      for (int c = 1; c < K; ++c) {
+        const T* col = mine + c * K;
+        T* yo = mine + c * (c - 1) / 2;
+        T rem, Lr;
+        M::fwd_init(col[c], rem, Lr);
+        for (int i = c - 1; i >= 1; --i) {
+          T y, lc;
+          M::fwd_step(col[i], rem, Lr, y, lc);
+          lsum += T(c - i + 1) * lc;                               // -logabsdetjac_inv_chol (corr.jl:235-237, :485-501): entry i of column c counts c - i + 1 times
+          yo[i] = y;
+        }
+        T y0, lc0;
+        M::atanh_lc(col[0], y0, lc0);                              // :322
+        lsum += T(c + 1) * lc0;
+        yo[0] = y0;
+      }
+    } else {
+      for (int c = K - 1; c >= 0; --c) {
+        const T* yi = mine + c * (c - 1) / 2;
+        T* col = mine + c * K;
+        T lr = T(0), E;
+        M::inv_init(E);
+        for (int i = 0; i < c; ++i) {
+          T w, lc;
+          M::inv_step(yi[i], E, w, lc);
+          lr -= lc;
+          lsum += lr;
+          if (out) col[i] = w;
+        }
+        lsum += lr;
+        if (out) {
+          col[c] = M::inv_diag(E, lr);
+          for (int i = c + 1; i < K; ++i) col[i] = T(0);
+        }
+      }
+      if (out && lower)
+        for (int j = 1; j < K; ++j)
+          for (int i = 0; i < j; ++i) { mine[i * K + j] = mine[j * K + i]; mine[j * K + i] = T(0); }
+    }
+    tile_sync();
+    if (out && n_out > 0) tile_stage_out<T, V>(tile, out + s0 * n_out, n_out, P, ncols, lane);
+    tile_sync();
+    if (lane < ncols) {
+      if (ladj_ps) ladj_ps[s0 + lane] = accumulate ? ladj_ps[s0 + lane] + lsum : lsum;
+      acc += (double)lsum;
+    }
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
 template <class T>
 int chol_impl(bjx_ctx* ctx, int inverse, int uplo, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t K, int64_t batch,
               uint32_t flags) {
@@ -935,9 +1014,34 @@ int chol_impl(bjx_ctx* ctx, int inverse, int uplo, const T* in, T* out, T* ladj_
     return BJX_OK;
   }
   const int lower = (uplo == 'L') ? 1 : 0;
+  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  {
+    // small factors: one lane per sample (chol_lane_kernel) while 64 samples fit an LDS tile with room for 4+ waves per CU
+    static const int lane_max = getenv("BJX_CHOL_LANE_MAX") ? atoi(getenv("BJX_CHOL_LANE_MAX")) : 11;     // tuning switch (0: off)
+    const int64_t P = (K * K) | 1;
+    const size_t smem_l = (size_t)64 * P * sizeof(T);
+    if (K >= 2 && K <= lane_max && smem_l <= 36 * 1024) {
+      const int64_t tiles = (batch + 63) / 64;
+      const int64_t cap = (int64_t)ctx->num_cu * 32;
+      const int grid_l = (int)(tiles < cap ? tiles : cap);
+      if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid_l); if (rc) return rc; }
+      double* partials_l = ladj_sum ? ctx->partials : nullptr;
+      constexpr int VW = Vec16<T>::N;
+      const bool vec = bjx_aligned16(in) && (!out || bjx_aligned16(out));
+      {
+        BjxProf prof_(ctx);
+#define CHOL_LN(INV_, V_) hipLaunchKernelGGL((chol_lane_kernel<T, INV_, V_>), dim3(grid_l), dim3(64), smem_l, ctx->stream, in, out, ladj_ps, (int)K, (int)P, lower, batch, accum, partials_l)
+        if (inverse) { if (vec) CHOL_LN(true, VW); else CHOL_LN(true, 1); }
+        else { if (vec) CHOL_LN(false, VW); else CHOL_LN(false, 1); }
+#undef CHOL_LN
+      }
+      BJX_CHECK_LAUNCH(ctx);
+      if (ladj_sum) return bjx_launch_finalize(ctx, grid_l, ladj_sum, 0.0, 0, 0.0, flags);
+      return BJX_OK;
+    }
+  }
   const int64_t grid = (batch + 3) / 4;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
-  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
   if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
   double* partials = ladj_sum ? ctx->partials : nullptr;
   if (inverse) {

@@ -245,7 +245,7 @@ def test_simplex_reference_edge_cases(bj):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("K,N", [(2, 5), (3, 33), (5, 100), (12, 64), (64, 40), (100, 7), (9, 70), (33, 21), (40, 9)])
+@pytest.mark.parametrize("K,N", [(2, 5), (3, 33), (5, 100), (12, 64), (64, 40), (100, 7), (9, 70), (33, 21), (40, 9), (4, 64), (8, 130), (11, 65)])
 @pytest.mark.parametrize("uplo", ["U", "L"])
 def test_vec_cholesky(bj, orc, K, N, uplo, dt):
     r = rng(6)
