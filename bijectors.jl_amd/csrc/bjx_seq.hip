@@ -2266,12 +2266,80 @@ BJX_API int bjx_simplex(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in,
 }
 
 namespace {
+// Small K: one lane per sample (cf. chol_lane_kernel).  Two odd-pitch tiles: y (+ K words of scratch) and ΔW.  Column by
+// column: forward sweep z = tanh y (kept in y's place), logcosh (scratch), log_remainder; reverse sweep (corr.jl:437-447)
+// with (1/z − z)·W[i,j] written as (1 − z²)·exp(log_remainder) — the same value, and finite at z = 0.
+template <class T, int V>
+__global__ __launch_bounds__(64) void chol_inv_vjp_lane_kernel(const T* __restrict__ y, const T* __restrict__ Wbar, const T* __restrict__ lbar,
+                                                               T* __restrict__ ybar, int K, int Py, int Pw, int lower, int64_t batch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using M = LinkMath<T>;
+  T* ty = reinterpret_cast<T*>(smem);
+  T* tw = ty + (size_t)64 * Py;
+  const int lane = threadIdx.x;
+  const int KK = K * K, nv = K * (K - 1) / 2;
+  for (int64_t s0 = (int64_t)blockIdx.x * 64; s0 < batch; s0 += (int64_t)gridDim.x * 64) {
+    const int ncols = (int)((batch - s0) < 64 ? (batch - s0) : 64);
+    tile_stage_in<T, V>(ty, y + s0 * nv, nv, Py, ncols, lane);
+    tile_stage_in<T, V>(tw, Wbar + s0 * KK, KK, Pw, ncols, lane);
+    tile_sync();
+    if (lane < ncols) {
+      T* my = ty + lane * Py;
+      T* sc = my + nv;
+      const T* dw = tw + lane * Pw;
+      const T lb = lbar ? lbar[s0 + lane] : T(0);
+      for (int j = 1; j < K; ++j) {
+        T* yj = my + j * (j - 1) / 2;
+        T lr = T(0);
+        for (int i = 0; i < j; ++i) {
+          T z, lc;
+          M::tanh_lc(yj[i], z, lc);
+          yj[i] = z;
+          sc[i] = lc;
+          lr -= lc;
+        }
+        T dlr = M::exp(lr) * dw[j * K + j] + T(2) * lb;                    // :438
+        for (int i = j - 1; i >= 0; --i) {
+          lr += sc[i];                                                     // log_remainder BEFORE entry i
+          const T E = M::exp(lr);
+          const T z = yj[i];
+          const T d = lower ? dw[i * K + j] : dw[j * K + i];
+          const T EdW = E * d;
+          yj[i] = (T(1) - z * z) * EdW - z * dlr;                           // :441-443
+          dlr += lb + z * EdW;                                             // :444
+        }
+      }
+    }
+    tile_sync();
+    tile_stage_out<T, V>(ty, ybar + s0 * nv, nv, Py, ncols, lane);
+    tile_sync();
+  }
+}
+}  // namespace
+
+namespace {
 template <class T>
 int chol_inv_vjp_impl(bjx_ctx* ctx, int uplo, const T* y, const T* Wbar, const T* lbar, T* ybar, int64_t K, int64_t batch) {
   if (batch == 0 || K < 2) return BJX_OK;
   const int lower = (uplo == 'L') ? 1 : 0;
   const int64_t nv = K * (K - 1) / 2;
   constexpr int VW = Vec16<T>::N;
+  {
+    static const int lane_max = getenv("BJX_CHOL_LANE_MAX") ? atoi(getenv("BJX_CHOL_LANE_MAX")) : 11;
+    const int64_t Py = (nv + K) | 1, Pw = (K * K) | 1;
+    const size_t smem_l = (size_t)64 * (Py + Pw) * sizeof(T);
+    if (K <= lane_max && smem_l <= 56 * 1024) {
+      const int64_t tiles = (batch + 63) / 64;
+      const int64_t cap = (int64_t)ctx->num_cu * 32;
+      const int grid_l = (int)(tiles < cap ? tiles : cap);
+      const bool vec = bjx_aligned16(y) && bjx_aligned16(ybar) && bjx_aligned16(Wbar);
+      BjxProf prof_(ctx);
+      if (vec) hipLaunchKernelGGL((chol_inv_vjp_lane_kernel<T, VW>), dim3(grid_l), dim3(64), smem_l, ctx->stream, y, Wbar, lbar, ybar, (int)K, (int)Py, (int)Pw, lower, batch);
+      else hipLaunchKernelGGL((chol_inv_vjp_lane_kernel<T, 1>), dim3(grid_l), dim3(64), smem_l, ctx->stream, y, Wbar, lbar, ybar, (int)K, (int)Py, (int)Pw, lower, batch);
+      BJX_CHECK_LAUNCH(ctx);
+      return BJX_OK;
+    }
+  }
   const bool v_ok = bjx_aligned16(y) && bjx_aligned16(ybar) && nv % VW == 0;
   const int ch = (int)((nv + 63) / 64);
   int chv, vv;

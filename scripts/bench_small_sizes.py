@@ -35,6 +35,16 @@ for K in (3, 4, 8, 16):
         bps = (K * K + nv) * 4 + 4
         g = bps * N / (ms * 1e-3) / 1e9
         print(f"| {label} | {K} | 2^22 | {ms:.4f} | {bps} | {g:.0f} | {g / 80:.1f} |")
+for K in (3, 4, 8):
+    nv = K * (K - 1) // 2
+    y = (0.4 * torch.randn(N, nv, device=dev)).T
+    Wb = torch.randn(N, K * K, device=dev).T.reshape(K, K, N)
+    lb = torch.randn(N, device=dev)
+    b = bj.VecCholeskyBijector("U")
+    ms = timed(lambda: bj.vjp(bj.inverse(b), y, Wb, lb))
+    bps = (2 * nv + K * K) * 4 + 4
+    g = bps * N / (ms * 1e-3) / 1e9
+    print(f"| vjp(inverse(VecCholesky)) | {K} | 2^22 | {ms:.4f} | {bps} | {g:.0f} | {g / 80:.1f} |")
 for K in (3, 4, 8, 16):
     x = torch.softmax(torch.randn(N, K, device=dev), dim=1).T
     for label, bb, xin in (("SimplexBijector", bj.SimplexBijector(), x), ("OrderedBijector", bj.OrderedBijector(), (torch.randn(N, K, device=dev)).T)):

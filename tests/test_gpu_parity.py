@@ -727,7 +727,7 @@ def test_ordered_vjp(bj, orc, shape, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("K,N", [(2, 5), (3, 33), (5, 100), (12, 64), (33, 21), (64, 40)])
+@pytest.mark.parametrize("K,N", [(2, 5), (3, 33), (5, 100), (12, 64), (33, 21), (64, 40), (4, 64), (8, 130), (11, 65)])
 @pytest.mark.parametrize("uplo", ["U", "L"])
 def test_vec_cholesky_inverse_vjp(bj, orc, K, N, uplo, dt):
     r = rng(52)
