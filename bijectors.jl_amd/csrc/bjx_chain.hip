@@ -508,6 +508,23 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
   } else {
     // per-sample: G lanes per column
     const bool v_ok = vec_ok && dim % VW == 0;
+    // Columns that are not a whole number of 16-byte packs (dim = 3, 10, 13, ...: most real parameter vectors) would fall to
+    // 4-byte accesses here (dim = 10: 12 % of the roofline).  The column walker of bjx_stacked_mixed moves 64 consecutive
+    // columns as ONE contiguous run of 16-byte packs whatever the column height and gives every column to a lane, so the
+    // per-sample log-det needs no cross-lane sum either: the chain goes there as a single elementwise segment.
+    static const int use_walker = env_int("BJX_CHAIN_WALKER", 1);
+    if (use_walker && !v_ok && y && (const void*)x != (const void*)y && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0 && n_ops <= BJX_MAX_SEG_OPS && dim >= 1) {
+      bool plain = true;
+      for (int k = 0; k < n_ops; ++k) plain = plain && ops[k].kind >= BJX_OP_EXP && ops[k].kind <= BJX_OP_IDENTITY;
+      if (plain) {
+        bjx_segment sg;
+        memset(&sg, 0, sizeof(sg));
+        sg.in_lo = 0; sg.out_lo = 0; sg.len = dim; sg.n_ops = n_ops;
+        for (int k = 0; k < n_ops; ++k) sg.ops[k] = ops[k];
+        const int rc_w = bjx_stacked_mixed(ctx, sizeof(T) == 4 ? BJX_F32 : BJX_F64, &sg, 1, nullptr, 0, x, dim, y, dim, ladj_ps, ladj_sum, batch, flags);
+        if (rc_w != BJX_ERR_UNSUPPORTED) return rc_w;              // too tall for the tile / more than two nonlinear stages: the group kernels below
+      }
+    }
     const int64_t packs = v_ok ? dim / VW : dim;
     int G = 1;
     while (G < 64 && G < packs) G <<= 1;
