@@ -71,7 +71,7 @@ def main(tag):
         with open(os.path.join(dst, f"{tag}_bench_lines.jsonl"), "w") as f:
             f.write("\n".join(lines) + "\n")
     json.dump(traffic, open(traffic_path, "w"), indent=1)
-    for extra in ("bench_default.json", "rows.md", "rows_kernel_stats.csv", "f64_rows.md", "f64math_bench.txt", "planar_mfma_ab.txt"):
+    for extra in ("bench_default.json", "rows.md", "rows_kernel_stats.csv", "f64_rows.md", "f64math_bench.txt", "planar_mfma_ab.txt", "small_sizes.md"):
         pe = os.path.join(src, extra)
         if os.path.exists(pe) and os.path.getsize(pe) > 2:
             with open(pe) as fi, open(os.path.join(dst, f"{tag}_{extra}"), "w") as fo:
