@@ -2513,11 +2513,82 @@ __global__ __launch_bounds__(64) void chol_fwd_vjp_kernel(const T* __restrict__ 
   }
 }
 
+// Small K: one lane per sample (cf. chol_lane_kernel): W in an odd-pitch tile, Δz in a second one; every lane walks the columns
+// of its factor from the diagonal up with the recurrences of chol_fwd_vjp_kernel and writes ΔW over W in place.
+template <class T, int V>
+__global__ __launch_bounds__(64) void chol_fwd_vjp_lane_kernel(const T* __restrict__ W, const T* __restrict__ ybar, T* __restrict__ Wbar, int K, int Pw, int Py,
+                                                               int lower, int64_t batch) {
+  using F = Fast<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tw = reinterpret_cast<T*>(smem);
+  T* tz = tw + (size_t)64 * Pw;
+  const int lane = threadIdx.x;
+  const int KK = K * K, nv = K * (K - 1) / 2;
+  for (int64_t s0 = (int64_t)blockIdx.x * 64; s0 < batch; s0 += (int64_t)gridDim.x * 64) {
+    const int ncols = (int)((batch - s0) < 64 ? (batch - s0) : 64);
+    tile_stage_in<T, V>(tw, W + s0 * KK, KK, Pw, ncols, lane);
+    tile_stage_in<T, V>(tz, ybar + s0 * nv, nv, Py, ncols, lane);
+    tile_sync();
+    if (lane < ncols) {
+      T* w = tw + lane * Pw;
+      const T* dz = tz + lane * Py;
+      auto at = [&](int i, int j) -> int { return lower ? i * K + j : j * K + i; };     // A[i][j] of the upper factor
+      for (int j = 1; j < K; ++j) {
+        const int base = j * (j - 1) / 2;
+        T rs = w[at(j, j)];
+        rs *= rs;
+        T dtmp = T(0);
+        for (int i = j - 1; i >= 1; --i) {
+          const int a = at(i, j);
+          const T wi = w[a];
+          rs += wi * wi;
+          const T rt = F::rsqrt(rs);                                       // 1/tmp
+          const T p = wi * rt;
+          const T q = T(1) - p * p;
+          const T rf = F::rsqrt(q);                                        // 1/ftmp
+          const T X = (rs * rt) * (p * rf);                                // tmp · p/ftmp
+          const T D = dz[base + i] * F::rcp(q);                            // Δz/(1-p²)
+          const T g = wi * rt * rt;                                        // W/tmp²
+          const T dp = D - dtmp * X;
+          w[a] = dp * rt;
+          dtmp = (q * rf + X * g) * dtmp - D * g;
+        }
+        const int a0 = at(0, j);
+        const T w0 = w[a0];
+        const T q0 = T(1) - w0 * w0;
+        w[a0] = dz[base] * F::rcp(q0) - dtmp * F::rsqrt(q0) * w0;
+      }
+      for (int j = 0; j < K; ++j)                                          // diagonal and the other triangle: zeros
+        for (int i = j; i < K; ++i) w[at(i, j)] = T(0);
+    }
+    tile_sync();
+    tile_stage_out<T, V>(tw, Wbar + s0 * KK, KK, Pw, ncols, lane);
+    tile_sync();
+  }
+}
+
 template <class T>
 int chol_fwd_vjp_impl(bjx_ctx* ctx, int uplo, const T* W, const T* y_bar, T* W_bar, int64_t K, int64_t batch) {
   if (batch == 0 || K < 1) return BJX_OK;
   if (K == 1) { BJX_HIP(ctx, hipMemsetAsync(W_bar, 0, (size_t)batch * sizeof(T), ctx->stream)); return BJX_OK; }   // no free parameter
   const int64_t nv = K * (K - 1) / 2;
+  {
+    static const int lane_max = getenv("BJX_CHOL_LANE_MAX") ? atoi(getenv("BJX_CHOL_LANE_MAX")) : 11;
+    const int64_t Pw = (K * K) | 1, Py = nv | 1;
+    const size_t smem_l = (size_t)64 * (Pw + Py) * sizeof(T);
+    if (K <= lane_max && smem_l <= 56 * 1024) {
+      constexpr int VW = Vec16<T>::N;
+      const int64_t tiles = (batch + 63) / 64;
+      const int64_t cap = (int64_t)ctx->num_cu * 32;
+      const int grid_l = (int)(tiles < cap ? tiles : cap);
+      const bool vec = bjx_aligned16(W) && bjx_aligned16(y_bar) && bjx_aligned16(W_bar);
+      BjxProf prof_(ctx);
+      if (vec) hipLaunchKernelGGL((chol_fwd_vjp_lane_kernel<T, VW>), dim3(grid_l), dim3(64), smem_l, ctx->stream, W, y_bar, W_bar, (int)K, (int)Pw, (int)Py, uplo == 'L' ? 1 : 0, batch);
+      else hipLaunchKernelGGL((chol_fwd_vjp_lane_kernel<T, 1>), dim3(grid_l), dim3(64), smem_l, ctx->stream, W, y_bar, W_bar, (int)K, (int)Pw, (int)Py, uplo == 'L' ? 1 : 0, batch);
+      BJX_CHECK_LAUNCH(ctx);
+      return BJX_OK;
+    }
+  }
   const size_t smem = ((((size_t)K * (K + 1) + 3) / 4) * 4 + (size_t)nv + 4) * sizeof(T);
   BJX_REQUIRE(ctx, smem <= BJX_LDS_MAX, BJX_ERR_UNSUPPORTED, "bjx_vec_cholesky_fwd_vjp: K = %lld too large for the LDS tile", (long long)K);
   BJX_REQUIRE(ctx, batch < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
