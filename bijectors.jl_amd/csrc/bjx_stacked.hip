@@ -386,11 +386,22 @@ int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const voi
 }
 
 template <class T>
+int stacked_mixed_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const bjx_block* blocks, int n_blocks, const T* x, int64_t rows_in, T* y,
+                       int64_t rows_out, T* ladj_ps, double* ladj_sum, int64_t batch, uint32_t flags);
+
+template <class T>
 int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, T* y, T* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch,
                  uint32_t flags, int64_t ldx = 0, int64_t ldy = 0) {
   if (dim * batch == 0) {
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
     return BJX_OK;
+  }
+  // columns that are not whole 16-byte packs: the row-owner kernel below would read them 4 bytes at a time; the column walker moves
+  // 64 columns as one contiguous run of packs whatever their height (cf. bjx_chain)
+  static const int use_walker = getenv("BJX_STACKED_WALKER") ? atoi(getenv("BJX_STACKED_WALKER")) : 1;
+  if (use_walker && ldx == 0 && ldy == 0 && (const void*)x != (const void*)y && dim % Vec16<T>::N != 0 && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0) {
+    const int rc_w = stacked_mixed_impl<T>(ctx, segs, n_segs, nullptr, 0, x, dim, y, dim, ladj_ps, ladj_sum, batch, flags);
+    if (rc_w != BJX_ERR_UNSUPPORTED) return rc_w;                  // permuted ranges / taller than the tile: below
   }
   StackedPlan pl;
   { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, y, dim, batch, true, true, &pl, ldx, ldy); if (rc) return rc; }

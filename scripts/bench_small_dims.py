@@ -44,6 +44,11 @@ for d in (2, 3, 8, 10):
         m = bj.PartitionMask(d, list(range(1, d // 2 + 1)), list(range(d // 2 + 1, d + 1)))
         sc = torch.full((d // 2,), 1.5, device=dev)
         cases.append(("Coupling(Shift∘Scale)", bj.Coupling(lambda x2: bj.Shift(0.25) @ bj.Scale(sc), m), x))
+    if d >= 3:
+        a_, b_ = d // 3, 2 * (d // 3)
+        xs = x.clone()
+        xs[a_:b_] = torch.rand(N, b_ - a_, device=dev).T * 0.9 + 0.05
+        cases.append(("Stacked(exp | Logit | identity)", bj.Stacked([e(bj.exp), bj.Logit(0.0, 1.0), bj.identity], [(1, a_), (a_ + 1, b_), (b_ + 1, d)]), xs))
     for name, b, xin in cases:
         if b is None:
             continue
