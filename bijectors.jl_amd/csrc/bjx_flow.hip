@@ -10,6 +10,7 @@
 
 namespace {
 using namespace bjx;
+#include "bjx_seqops.h"
 
 // planar_layer.jl:65-70: û = u + ((log1pexp(-wᵀu) - 1)/‖w‖²) w ;  wᵀû = log1pexp(wᵀu) - 1.
 // One block per layer; writes û[l,:] and wᵀû[l] to scratch.
@@ -1611,6 +1612,145 @@ __global__ __launch_bounds__(256) void flow_sets_reduce_kernel(const double* __r
   }
 }
 
+// ------------------------------------------------------------------ low-dimensional flows: ONE LANE per column (dim <= 16)
+// Planar and radial flows are mostly used on 2 ... 10 dimensional densities.  With G lanes along a column such columns leave
+// most of a wave idle and every layer pays a cross-lane reduction for a dot product of a few terms (dim = 2, 8 layers: 6 % of the
+// roofline).  Here a wave takes 64 consecutive columns — one contiguous run, 16-byte packs through a [64][P odd] LDS tile — lane t
+// keeps column t in registers and runs the whole stack on it: dot products and rank-1 updates are plain FMAs of the lane, the
+// layer parameters are wave-uniform (scalar loads), nothing crosses lanes.
+template <class T, int DMAX, bool INV, int V>
+__global__ __launch_bounds__(64) void planar_walk_kernel(const T* __restrict__ Aw, const T* __restrict__ Auh, const T* __restrict__ Ac, const T* __restrict__ Ab, int n_layers,
+                                                         const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int dim, int P,
+                                                         int64_t batch, int accumulate, double* partials) {
+  // The layer tables go to LDS once per block, zero-padded to DMAX rows: [w | û | b, wᵀû] per layer, read back as wave-uniform
+  // (broadcast) 16-byte LDS reads.  (Read in place they were 2·dim + 2 dependent loads of one address per layer — per-lane global
+  // loads through the argument struct, one-dword scalar loads as `const __restrict__` arguments — and the walk was bound by them.)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[1];
+  T* tile = reinterpret_cast<T*>(smem);
+  constexpr int LW = 2 * DMAX + 4;
+  T* tab = tile + (((size_t)64 * P + 3) / 4) * 4;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < n_layers * LW; i += 64) {
+    const int l = i / LW, q = i - l * LW;
+    T v = T(0);
+    if (q < DMAX) { if (q < dim) v = Aw[l * dim + q]; }
+    else if (q < 2 * DMAX) { if (q - DMAX < dim) v = Auh[l * dim + q - DMAX]; }
+    else if (q == 2 * DMAX) v = Ab[l];
+    else if (q == 2 * DMAX + 1) v = Ac[l];
+    tab[i] = v;
+  }
+  tile_sync();
+  double acc = 0.0;
+  for (int64_t c0 = (int64_t)blockIdx.x * 64; c0 < batch; c0 += (int64_t)gridDim.x * 64) {
+    const int ncols = (int)((batch - c0) < 64 ? (batch - c0) : 64);
+    tile_stage_in<T, V>(tile, x + c0 * dim, dim, P, ncols, lane);
+    tile_sync();
+    T* mine = tile + lane * P;
+    T z[DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) z[r] = r < dim ? mine[r] : T(0);
+    T ladj = T(0);
+    for (int li = 0; li < n_layers; ++li) {
+      const int l = INV ? n_layers - 1 - li : li;
+      const T* tl = tab + l * LW;
+      T wv[DMAX], uv[DMAX];
+#pragma unroll
+      for (int r = 0; r < DMAX; ++r) { wv[r] = tl[r]; uv[r] = tl[DMAX + r]; }
+      const T bl = tl[2 * DMAX], c = tl[2 * DMAX + 1];
+      T s0 = T(0), s1 = T(0);
+#pragma unroll
+      for (int r = 0; r < DMAX; r += 2) { s0 += wv[r] * z[r]; s1 += wv[r + 1] * z[r + 1]; }   // padded rows: 0 · 0
+      const T s = s0 + s1;                                           // wᵀz (src/utils.jl:2)
+      T t, ld;
+      if constexpr (sizeof(T) == 4) {                                // the activation of the register kernels: tanh, sech², log1p from one exp
+        if (!INV) planar_act(s + bl, c, t, ld); else find_alpha_act(s, c, bl, t, ld);
+      } else {
+        const T arg = INV ? find_alpha_dev<T>(s, c, bl) + bl : s + bl;
+        T s2;
+        x_tanh_sech2(arg, t, s2);
+        ld = Fast<T>::log1p(c * s2);                                 // planar_layer.jl:107
+      }
+      ladj += INV ? -ld : ld;
+      const T tt = INV ? -t : t;
+#pragma unroll
+      for (int r = 0; r < DMAX; ++r) z[r] += uv[r] * tt;             // z ± û tanh(·)
+    }
+    if (accumulate & 2) {                                            // BJX_BASE_STDNORMAL: + log N(out; 0, I)
+      T q = T(0);
+#pragma unroll
+      for (int r = 0; r < DMAX; ++r) q += z[r] * z[r];
+      ladj += T(-0.5) * q - (T)dim * T(0.91893853320467274178);
+    }
+    if (y) {
+#pragma unroll
+      for (int r = 0; r < DMAX; ++r) if (r < dim) mine[r] = z[r];
+    }
+    tile_sync();
+    if (y) tile_stage_out<T, V>(tile, y + c0 * dim, dim, P, ncols, lane);
+    tile_sync();
+    if (lane < ncols) {
+      if (ladj_ps) ladj_ps[c0 + lane] = (accumulate & 1) ? ladj_ps[c0 + lane] + ladj : ladj;
+      acc += (double)ladj;
+    }
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
+// radial_layer.jl:43-72 (forward) and :88-129 (inverse), same arithmetic as radial_kernel
+template <class T, int DMAX, bool INV, int V>
+__global__ __launch_bounds__(64) void radial_walk_kernel(const T* __restrict__ Aalpha, const T* __restrict__ Abeta, const T* __restrict__ Az0, const T* __restrict__ x,
+                                                         T* __restrict__ y, T* __restrict__ ladj_ps, int dim, int P, int64_t batch, int accumulate, double* partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[1];
+  T* tile = reinterpret_cast<T*>(smem);
+  const int lane = threadIdx.x;
+  const T alpha = d_log1pexp(Aalpha[0]);          // :44
+  const T apb = d_log1pexp(Abeta[0]);              // α + β̂
+  const T beta_hat = -alpha + apb;                  // :45
+  double acc = 0.0;
+  for (int64_t c0 = (int64_t)blockIdx.x * 64; c0 < batch; c0 += (int64_t)gridDim.x * 64) {
+    const int ncols = (int)((batch - c0) < 64 ? (batch - c0) : 64);
+    tile_stage_in<T, V>(tile, x + c0 * dim, dim, P, ncols, lane);
+    tile_sync();
+    T* mine = tile + lane * P;
+    T dz[DMAX];
+    T ss = T(0);
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) { dz[r] = r < dim ? mine[r] - Az0[r] : T(0); ss += dz[r] * dz[r]; }
+    T r_fwd, gain;
+    if (!INV) {
+      r_fwd = d_sqrt(ss);
+      gain = T(1) + beta_hat / (alpha + r_fwd);
+    } else {
+      const T gam = d_sqrt(ss);                     // compute_r :124-129
+      const T a = apb - gam;
+      const T rr = (d_sqrt(a * a + 4 * alpha * gam) - a) / 2;
+      gain = (alpha + rr) / (apb + rr);             // γ :96-101
+      r_fwd = gain * gam;
+    }
+    const T h_ = T(1) / (alpha + r_fwd);
+    T ld = T(dim - 1) * d_log(T(1) + beta_hat * h_) + d_log(T(1) + beta_hat * h_ + beta_hat * (-(h_ * h_)) * r_fwd);   // :68-70
+    if (INV) ld = -ld;
+    const T fwd_gain = beta_hat / (alpha + r_fwd);
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) {
+      if (r < dim) {
+        if (!INV) mine[r] = mine[r] + fwd_gain * dz[r];             // :52
+        else mine[r] = Az0[r] + gain * dz[r];                      // :101
+      }
+    }
+    tile_sync();
+    tile_stage_out<T, V>(tile, y + c0 * dim, dim, P, ncols, lane);
+    tile_sync();
+    if (lane < ncols) {
+      if (ladj_ps) ladj_ps[c0 + lane] = accumulate ? ladj_ps[c0 + lane] + ld : ld;
+      acc += (double)ld;
+    }
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
 struct FlowCfg { int V, G, R; int64_t grid; };
 
 template <class T> bool flow_cfg(const bjx_ctx* ctx, const void* x, const void* y, int64_t dim, int64_t batch, FlowCfg* c) {
@@ -1653,6 +1793,34 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
   BJX_CHECK_LAUNCH(ctx);
   if (batch == 0) {
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
+    return BJX_OK;
+  }
+  // low-dimensional stacks: one lane per column (planar_walk_kernel)
+  static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 16;       // tuning switch (0: off)
+  if (dim <= walk_max && dim <= 16 && (size_t)nl * 36 * sizeof(T) <= 32 * 1024) {
+    constexpr int VW = Vec16<T>::N;
+    const int P = (int)(dim | 1);
+    const int dmax = dim <= 4 ? 4 : (dim <= 8 ? 8 : 16);
+    const size_t smem_w = ((((size_t)64 * P + 3) / 4) * 4 + (size_t)nl * (2 * dmax + 4)) * sizeof(T);
+    const int64_t tiles = (batch + 63) / 64;
+    const int64_t cap = (int64_t)ctx->num_cu * 32;
+    const int grid_w = (int)(tiles < cap ? tiles : cap);
+    if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid_w); if (rc) return rc; }
+    double* partials_w = ladj_sum ? ctx->partials : nullptr;
+    const bool vec = bjx_aligned16(in) && (!out || bjx_aligned16(out));
+    const int accum = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
+    {
+      BjxProf prof_(ctx);
+#define PW(D_, I_, V_) hipLaunchKernelGGL((planar_walk_kernel<T, D_, I_, V_>), dim3(grid_w), dim3(64), smem_w, ctx->stream, (const T*)w, (const T*)u_hat, (const T*)wtu, (const T*)b, nl, in, out, ladj_ps, (int)dim, P, batch, accum, partials_w)
+#define PW_V(D_, I_) do { if (vec) PW(D_, I_, VW); else PW(D_, I_, 1); } while (0)
+#define PW_D(I_) do { if (dim <= 4) PW_V(4, I_); else if (dim <= 8) PW_V(8, I_); else PW_V(16, I_); } while (0)
+      if (inverse) PW_D(true); else PW_D(false);
+#undef PW_D
+#undef PW_V
+#undef PW
+    }
+    BJX_CHECK_LAUNCH(ctx);
+    if (ladj_sum) return bjx_launch_finalize(ctx, grid_w, ladj_sum, 0.0, 0, 0.0, flags);
     return BJX_OK;
   }
   // register kernel (Float32, 16-byte packs, 20 <= dim <= 128): see planar_reg_kernel
@@ -1917,6 +2085,32 @@ int radial_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const
                 double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
   if (batch == 0) {
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
+    return BJX_OK;
+  }
+  static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 16;
+  if (dim <= walk_max && dim <= 16 && dim % Vec16<T>::N != 0) {      // whole-pack columns stream at 71 % on the group kernel already
+    constexpr int VW = Vec16<T>::N;
+    const int P = (int)(dim | 1);
+    const size_t smem_w = (size_t)64 * P * sizeof(T);
+    const int64_t tiles = (batch + 63) / 64;
+    const int64_t cap = (int64_t)ctx->num_cu * 32;
+    const int grid_w = (int)(tiles < cap ? tiles : cap);
+    if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid_w); if (rc) return rc; }
+    double* partials_w = ladj_sum ? ctx->partials : nullptr;
+    const bool vec = bjx_aligned16(in) && bjx_aligned16(out);
+    const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+    {
+      BjxProf prof_(ctx);
+#define RW(D_, I_, V_) hipLaunchKernelGGL((radial_walk_kernel<T, D_, I_, V_>), dim3(grid_w), dim3(64), smem_w, ctx->stream, alpha_, beta, z0, in, out, ladj_ps, (int)dim, P, batch, accum, partials_w)
+#define RW_V(D_, I_) do { if (vec) RW(D_, I_, VW); else RW(D_, I_, 1); } while (0)
+#define RW_D(I_) do { if (dim <= 4) RW_V(4, I_); else if (dim <= 8) RW_V(8, I_); else RW_V(16, I_); } while (0)
+      if (inverse) RW_D(true); else RW_D(false);
+#undef RW_D
+#undef RW_V
+#undef RW
+    }
+    BJX_CHECK_LAUNCH(ctx);
+    if (ladj_sum) return bjx_launch_finalize(ctx, grid_w, ladj_sum, 0.0, 0, 0.0, flags);
     return BJX_OK;
   }
   FlowCfg c;
