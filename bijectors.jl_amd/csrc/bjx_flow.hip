@@ -1796,11 +1796,13 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
     return BJX_OK;
   }
   // low-dimensional stacks: one lane per column (planar_walk_kernel)
-  static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 16;       // tuning switch (0: off)
-  if (dim <= walk_max && dim <= 16 && (size_t)nl * 36 * sizeof(T) <= 32 * 1024) {
+  static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 32;       // tuning switch (0: off)
+  // (same-call A/B, 2^22 columns, 1 / 8 layers: dim 12-32 walker 62-69 % / 43-57 % vs 29-44 % / 23-34 % on the group kernels;
+  //  dim 40-64 walker 56-60 % / 27-31 % vs 72-74 % / 55-71 %: the register tile wins once a column fills 10+ lanes)
+  if (dim <= walk_max && dim <= 32 && (size_t)nl * 68 * sizeof(T) <= 32 * 1024) {
     constexpr int VW = Vec16<T>::N;
     const int P = (int)(dim | 1);
-    const int dmax = dim <= 4 ? 4 : (dim <= 8 ? 8 : 16);
+    const int dmax = dim <= 4 ? 4 : (dim <= 8 ? 8 : (dim <= 16 ? 16 : 32));
     const size_t smem_w = ((((size_t)64 * P + 3) / 4) * 4 + (size_t)nl * (2 * dmax + 4)) * sizeof(T);
     const int64_t tiles = (batch + 63) / 64;
     const int64_t cap = (int64_t)ctx->num_cu * 32;
@@ -1813,7 +1815,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
       BjxProf prof_(ctx);
 #define PW(D_, I_, V_) hipLaunchKernelGGL((planar_walk_kernel<T, D_, I_, V_>), dim3(grid_w), dim3(64), smem_w, ctx->stream, (const T*)w, (const T*)u_hat, (const T*)wtu, (const T*)b, nl, in, out, ladj_ps, (int)dim, P, batch, accum, partials_w)
 #define PW_V(D_, I_) do { if (vec) PW(D_, I_, VW); else PW(D_, I_, 1); } while (0)
-#define PW_D(I_) do { if (dim <= 4) PW_V(4, I_); else if (dim <= 8) PW_V(8, I_); else PW_V(16, I_); } while (0)
+#define PW_D(I_) do { if (dim <= 4) PW_V(4, I_); else if (dim <= 8) PW_V(8, I_); else if (dim <= 16) PW_V(16, I_); else PW_V(32, I_); } while (0)
       if (inverse) PW_D(true); else PW_D(false);
 #undef PW_D
 #undef PW_V
