@@ -2089,8 +2089,9 @@ int radial_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
     return BJX_OK;
   }
-  static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 16;
-  if (dim <= walk_max && dim <= 16 && dim % Vec16<T>::N != 0) {      // whole-pack columns stream at 71 % on the group kernel already
+  static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 32;
+  static const int walk_all = getenv("BJX_RADIAL_WALK_ALL") ? atoi(getenv("BJX_RADIAL_WALK_ALL")) : 0;
+  if (dim <= walk_max && dim <= 32 && (dim % Vec16<T>::N != 0 || walk_all)) {      // whole-pack columns stream at 71 % on the group kernel already
     constexpr int VW = Vec16<T>::N;
     const int P = (int)(dim | 1);
     const size_t smem_w = (size_t)64 * P * sizeof(T);
@@ -2105,7 +2106,7 @@ int radial_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const
       BjxProf prof_(ctx);
 #define RW(D_, I_, V_) hipLaunchKernelGGL((radial_walk_kernel<T, D_, I_, V_>), dim3(grid_w), dim3(64), smem_w, ctx->stream, alpha_, beta, z0, in, out, ladj_ps, (int)dim, P, batch, accum, partials_w)
 #define RW_V(D_, I_) do { if (vec) RW(D_, I_, VW); else RW(D_, I_, 1); } while (0)
-#define RW_D(I_) do { if (dim <= 4) RW_V(4, I_); else if (dim <= 8) RW_V(8, I_); else RW_V(16, I_); } while (0)
+#define RW_D(I_) do { if (dim <= 4) RW_V(4, I_); else if (dim <= 8) RW_V(8, I_); else if (dim <= 16) RW_V(16, I_); else RW_V(32, I_); } while (0)
       if (inverse) RW_D(true); else RW_D(false);
 #undef RW_D
 #undef RW_V
