@@ -83,6 +83,7 @@ template <class T, bool INV> struct RqsF {
   int in_lds;
   double per_sample_const;
   const double* per_sample_dev;
+  int walk_smem_offset = 0;   // colwalk_kernel: where the column tile starts behind the functor's LDS tables (set by launch_colgroup)
   __device__ void stage(char* smem) const {
     if (in_lds) { stage3<T>(reinterpret_cast<T*>(smem), w, h, d, rows * K1); __syncthreads(); }
   }
@@ -604,6 +605,7 @@ template <class T, bool INV> struct BnF {
   int in_lds;
   double per_sample_const;
   const double* per_sample_dev;
+  int walk_smem_offset = 0;   // colwalk_kernel: where the column tile starts behind the functor's LDS tables (set by launch_colgroup)
   __device__ void stage(char* smem) const {
     if (in_lds) {
       T* t = reinterpret_cast<T*>(smem);
@@ -664,6 +666,7 @@ template <class T, bool INV> struct CouplingAffineF {
   int map_in_lds;           // the row map is staged in LDS (dim <= 12 Ki rows), else read from the context scratch
   double per_sample_const;
   const double* per_sample_dev;
+  int walk_smem_offset = 0;   // colwalk_kernel: where the column tile starts behind the functor's LDS tables (set by launch_colgroup)
   // θ of one pack: fetched with the input packs (all of a lane's loads in flight together).  When the pack's
   // rows sit at consecutive, 16-byte aligned positions of x_1 (PartitionMask over a row range — the usual
   // mask) scale and shift are one 16-byte load each; otherwise V scalar gathers.
@@ -738,6 +741,7 @@ template <class T, bool INV> struct CouplingRqsF {
   int in_lds;
   double per_sample_const;
   const double* per_sample_dev;
+  int walk_smem_offset = 0;   // colwalk_kernel: where the column tile starts behind the functor's LDS tables (set by launch_colgroup)
   __device__ void stage(char* smem) const {
     if (in_lds) { stage3<T>(reinterpret_cast<T*>(smem), w, h, d, n1 * K1); __syncthreads(); }
   }
@@ -762,6 +766,7 @@ template <class T> struct PermuteF {
   const int32_t* src;
   double per_sample_const;
   const double* per_sample_dev;
+  int walk_smem_offset = 0;   // colwalk_kernel: where the column tile starts behind the functor's LDS tables (set by launch_colgroup)
   __device__ void stage(char*) const {}
   template <int V> __device__ T apply(const char*, Pack<T, V>& p, const T* xcol, int64_t row, int64_t) const {
 #pragma unroll

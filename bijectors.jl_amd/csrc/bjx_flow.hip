@@ -7,10 +7,10 @@
 // reference's GEMV pass + rank-1 update pass + sech/log1p pass per layer become
 // in-register dot products reduced with wave shuffles inside the G-lane group.
 #include "bjx_internal.h"
+#include "bjx_tile.h"
 
 namespace {
 using namespace bjx;
-#include "bjx_seqops.h"
 
 // planar_layer.jl:65-70: û = u + ((log1pexp(-wᵀu) - 1)/‖w‖²) w ;  wᵀû = log1pexp(wᵀu) - 1.
 // One block per layer; writes û[l,:] and wᵀû[l] to scratch.

@@ -15,11 +15,11 @@
 #include <cstdlib>
 
 #include "bjx_internal.h"
+#include "bjx_tile.h"
 
 using namespace bjx;
 
 namespace {
-#include "bjx_seqops.h"
 
 enum { MK_VEC_CORR = 0, MK_CORR = 1, MK_PD = 2, MK_PD_VEC = 3 };
 

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "bjx_internal.h"
+#include "bjx_tile.h"
 
 namespace {
 using namespace bjx;

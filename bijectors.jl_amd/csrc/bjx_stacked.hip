@@ -245,6 +245,7 @@ template <class T, bool GATHER, bool IN_LDS> struct StackedF {
   int two_slots;
   double per_sample_const;
   const double* per_sample_dev;
+  int walk_smem_offset = 0;   // colwalk_kernel: where the column tile starts behind the functor's LDS tables (set by launch_colgroup)
   __device__ void stage(char* smem) const {
     if (IN_LDS) {
       const int n16 = (int)(dim * stacked_row_bytes<T>() / 16);

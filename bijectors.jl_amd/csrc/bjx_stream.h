@@ -7,7 +7,10 @@
 // log-det contribution; the G lanes are summed with a butterfly of wave shuffles, lane 0 of the
 // group writes ladj_ps[col], and the block publishes one f64 partial for the global sum.
 #pragma once
+#include <cstdlib>
+
 #include "bjx_internal.h"
+#include "bjx_tile.h"
 
 namespace bjx {
 
@@ -133,6 +136,46 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
   block_publish_partial(acc, red, fin);
 }
 
+// Column-walker form of the same skeleton, for columns that are NOT a whole number of 16-byte packs (dim = 3, 10, 13 ...): the group
+// kernel reads such columns 4 bytes at a time.  One single-wave block moves 64 consecutive columns — one contiguous run, 16-byte
+// packs — through a [64][P odd] LDS tile and lane t walks column t with the functor's one-element `apply`; the row is the same
+// in every lane, so the functor's per-row parameters are wave-uniform reads, and the column's log-det is the lane's own sum.
+template <class T, int V, class F>
+__global__ __launch_bounds__(64) void colwalk_kernel(const F f, const T* x, T* y, T* ladj_ps, int dim, int P, int64_t batch, int accumulate, const BjxFin fin) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);   // first 32 bytes
+  char* fsm = smem + 32;
+  f.stage(fsm);
+  T* tile = reinterpret_cast<T*>(smem + 32 + f.walk_smem_offset);
+  const int lane = threadIdx.x;
+  const int64_t c0 = (int64_t)blockIdx.x * 64;
+  const int ncols = (int)((batch - c0) < 64 ? (batch - c0) : 64);
+  const double psc = f.per_sample_const + (f.per_sample_dev ? *f.per_sample_dev : 0.0);
+  if (F::kLoadInput) tile_stage_in<T, V>(tile, x + c0 * dim, dim, P, ncols, lane);
+  tile_sync();
+  T l = T(0);
+  if (lane < ncols) {
+    T* mine = tile + lane * P;
+    const int64_t col = c0 + lane;
+    const T* xcol = x + col * dim;
+    for (int r = 0; r < dim; ++r) {
+      Pack<T, 1> p;
+      p.v[0] = F::kLoadInput ? mine[r] : T(0);
+      if constexpr (col_has_aux<F>::value) { const auto aux = f.template fetch<1>(fsm, (int64_t)r, col); l += f.template apply<1>(fsm, p, aux, xcol, (int64_t)r, col); }
+      else l += f.template apply<1>(fsm, p, xcol, (int64_t)r, col);
+      mine[r] = p.v[0];
+    }
+    if (ladj_ps) {
+      T out = l + (T)psc;
+      if (accumulate) out += ladj_ps[col];
+      ladj_ps[col] = out;
+    }
+  }
+  tile_sync();
+  tile_stage_out<T, V>(tile, y + c0 * dim, dim, P, ncols, lane);
+  block_publish_partial(lane < ncols ? (double)l : 0.0, red, fin);
+}
+
 struct ColLaunch {
   int V, G;
   int64_t grid;
@@ -165,6 +208,33 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
     return BJX_OK;
   }
   ColLaunch c = col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy);
+  {
+    // odd column heights of dense arrays: the column-walker form (colwalk_kernel)
+    static const int use_walk = getenv("BJX_COLWALK") ? atoi(getenv("BJX_COLWALK")) : 1;
+    constexpr int VWW = Vec16<T>::N;
+    const int64_t P = dim | 1;
+    const size_t f_pad = (f_smem + 15) / 16 * 16;
+    const size_t smem_w = 32 + f_pad + (size_t)64 * P * sizeof(T);
+    if (use_walk && !force_v1 && dim % VWW != 0 && ldx == dim && ldy == dim && (const void*)x != (const void*)y && smem_w <= 64 * 1024) {
+      const int64_t grid_w = (batch + 63) / 64;
+      BJX_REQUIRE(ctx, grid_w < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+      BjxFin fin;
+      bool second = false;
+      { int rc = bjx_make_fin(ctx, grid_w, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, flags, &fin, &second); if (rc) return rc; }
+      if (fin.counter) { fin.counter = nullptr; second = true; }        // single-wave blocks: two-pass finalize
+      F fw = f;
+      fw.walk_smem_offset = (int)f_pad;
+      const bool vec = bjx_aligned16(x) && bjx_aligned16(y);
+      {
+        BjxProf prof_(ctx);
+        if (vec) hipLaunchKernelGGL((colwalk_kernel<T, VWW, F>), dim3((unsigned)grid_w), dim3(64), smem_w, ctx->stream, fw, x, y, ladj_ps, (int)dim, (int)P, batch, (flags & BJX_ACCUMULATE) ? 1 : 0, fin);
+        else hipLaunchKernelGGL((colwalk_kernel<T, 1, F>), dim3((unsigned)grid_w), dim3(64), smem_w, ctx->stream, fw, x, y, ladj_ps, (int)dim, (int)P, batch, (flags & BJX_ACCUMULATE) ? 1 : 0, fin);
+      }
+      BJX_CHECK_LAUNCH(ctx);
+      if (second) return bjx_launch_finalize(ctx, (int)grid_w, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, 0.0, flags);
+      return BJX_OK;
+    }
+  }
   if (force_v1 && c.V != 1) { c.V = 1; int G = 1; while (G < 64 && G < dim) G <<= 1; c.G = G; const int64_t cpb = (int64_t)(256 / G) * COL_UC; c.grid = (batch + cpb - 1) / cpb; }
   constexpr int VW = Vec16<T>::N;
   const size_t smem = 32 + f_smem;

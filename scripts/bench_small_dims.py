@@ -36,7 +36,9 @@ for d in [int(v) for v in os.environ.get("BJX_BENCH_DIMS", "2,3,8,10").split(","
     U8 = torch.randn(d, 8, device=dev) / math.sqrt(d)
     cases.append(("8×PlanarLayer", bj.PlanarLayer(W8, U8, torch.randn(8, device=dev)), x))
     cases.append(("RadialLayer", bj.RadialLayer(torch.tensor([0.5], device=dev), torch.tensor([0.3], device=dev), torch.randn(d, device=dev)), x))
-    cases.append(("InvertibleBatchNorm (eval)", bj.InvertibleBatchNorm(d, device=dev) if hasattr(bj.InvertibleBatchNorm, "__call__") and False else None, x))
+    cases.append(("InvertibleBatchNorm (eval)", bj.InvertibleBatchNorm(torch.randn(d, device=dev), 0.1 * torch.randn(d, device=dev), torch.randn(d, device=dev),
+                                                                       torch.rand(d, device=dev) + 0.5), x))
+    cases.append(("Permute", bj.Permute(list(torch.randperm(d).add(1).tolist())), x))
     raw = [torch.randn(d, 8, device=dev), torch.randn(d, 8, device=dev), torch.randn(d, 7, device=dev)]
     cases.append(("RQS K=8", bj.RationalQuadraticSpline(raw[0], raw[1], raw[2], 3.0), x))
     cases.append(("exp∘Shift∘Scale (per-sample ladj)", e(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5), x))
