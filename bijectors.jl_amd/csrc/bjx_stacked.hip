@@ -745,11 +745,71 @@ __global__ __launch_bounds__(256) void sets_reduce_kernel(const double* __restri
 }
 __global__ void moments_count_kernel(double* out, int64_t dim, int64_t batch) { if (threadIdx.x == 0 && blockIdx.x == 0) out[2 * dim] = (double)batch; }
 
+// Column-walker form of the pullback for columns that are not whole 16-byte packs (cf. stacked_mixed_kernel): x and ȳ of 64
+// consecutive columns through two odd-pitch LDS tiles, lane = column, the row's slots as wave-uniform scalar loads, x̄ written
+// over x in the tile (every input row is the source of exactly one output row) and stored as one contiguous run.
+template <class T, int V>
+__global__ __launch_bounds__(64) void stacked_vjp_walk_kernel(const char* __restrict__ tab, int two_slots, const T* __restrict__ x, const T* __restrict__ ybar,
+                                                            const T* __restrict__ lbar, T* __restrict__ xbar, int dim, int P, int64_t batch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tx = reinterpret_cast<T*>(smem);
+  T* tg = tx + (size_t)64 * P;
+  const int lane = threadIdx.x;
+  const int64_t c0 = (int64_t)blockIdx.x * 64;
+  const int ncols = (int)((batch - c0) < 64 ? (batch - c0) : 64);
+  tile_stage_in<T, V>(tx, x + c0 * dim, dim, P, ncols, lane);
+  tile_stage_in<T, V>(tg, ybar + c0 * dim, dim, P, ncols, lane);
+  tile_sync();
+  if (lane < ncols) {
+    T* mx = tx + lane * P;
+    const T* mg = tg + lane * P;
+    const T lb = lbar ? lbar[c0 + lane] : T(0);
+    constexpr size_t RB = stacked_row_bytes<T>();
+    for (int r = 0; r < dim; ++r) {
+      const Slot<T>* e = reinterpret_cast<const Slot<T>*>(tab + (size_t)r * RB);
+      const Slot<T> s0 = e[0];
+      T x1, dy0, dl0;
+      slot_grad<T>(s0, mx[s0.src], x1, dy0, dl0);
+      T g = mg[r];
+      if (two_slots) {
+        const Slot<T> s1 = e[1];
+        if (s1.kind != SK_END) {
+          T y2, dy1, dl1;
+          slot_grad<T>(s1, x1, y2, dy1, dl1);
+          g = g * dy1 + lb * dl1;
+        }
+      }
+      mx[s0.src] = g * dy0 + lb * dl0;
+    }
+  }
+  tile_sync();
+  tile_stage_out<T, V>(tx, xbar + c0 * dim, dim, P, ncols, lane);
+}
+
 template <class T>
 int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, const T* ybar, const T* lbar, T* xbar, int64_t dim, int64_t batch,
                      double* moments = nullptr, bool* moments_done = nullptr) {
   if (moments_done) *moments_done = false;
   if (dim * batch == 0) return BJX_OK;
+  {
+    static const int use_walker = getenv("BJX_STACKED_WALKER") ? atoi(getenv("BJX_STACKED_WALKER")) : 1;
+    const int64_t P = dim | 1;
+    const size_t smem_w = (size_t)2 * 64 * P * sizeof(T);
+    if (use_walker && !moments && dim % Vec16<T>::N != 0 && smem_w <= 64 * 1024 && (const void*)x != (const void*)xbar) {
+      StackedPlan plw;
+      { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, xbar, dim, batch, false, false, &plw); if (rc) return rc; }   // V = 1: unpermuted table
+      const int64_t grid_w = (batch + 63) / 64;
+      BJX_REQUIRE(ctx, grid_w < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_stacked_vjp: batch too large for one launch");
+      const bool vec = bjx_aligned16(x) && bjx_aligned16(ybar) && bjx_aligned16(xbar);
+      {
+        BjxProf prof_(ctx);
+        if (vec) hipLaunchKernelGGL((stacked_vjp_walk_kernel<T, Vec16<T>::N>), dim3((unsigned)grid_w), dim3(64), smem_w, ctx->stream, plw.tab, plw.two, x, ybar, lbar, xbar, (int)dim, (int)P, batch);
+        else hipLaunchKernelGGL((stacked_vjp_walk_kernel<T, 1>), dim3((unsigned)grid_w), dim3(64), smem_w, ctx->stream, plw.tab, plw.two, x, ybar, lbar, xbar, (int)dim, (int)P, batch);
+      }
+      BJX_CHECK_LAUNCH(ctx);
+      return BJX_OK;
+    }
+  }
   StackedPlan pl;
   { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, xbar, dim, batch, false, bjx_aligned16(ybar), &pl); if (rc) return rc; }
   const bool lds = pl.tab_bytes <= 48 * 1024;
