@@ -1697,6 +1697,101 @@ __global__ __launch_bounds__(64) void planar_walk_kernel(const T* __restrict__ A
   if (partials) block_publish_partial(acc, red, partials);
 }
 
+__device__ __forceinline__ float walk_tanh(float v) { return fast_tanh(v); }      // the register kernels' one-exp tanh (parity bar 1e-3)
+__device__ __forceinline__ double walk_tanh(double v) { return x_tanh(v); }
+// Pullback of the Planar stack on low-dimensional columns, one lane per column (the arithmetic of planar_vjp_kernel): x and ȳ
+// through two odd-pitch tiles, the primal sweep leaves t_k = tanh(·) of every layer in the lane's strip of LDS scratch, the reverse
+// sweep runs on the cotangent in registers.  t_out / s_out (the per-column, per-layer values the parameter pullback reads) as in
+// planar_vjp_kernel.
+template <class T, int DMAX, bool INV, int V>
+__global__ __launch_bounds__(64) void planar_vjp_walk_kernel(const T* __restrict__ Aw, const T* __restrict__ Auh, const T* __restrict__ Ac, const T* __restrict__ Ab, int n_layers,
+                                                             const T* __restrict__ x, const T* __restrict__ ybar, const T* __restrict__ lbar, T* __restrict__ xbar, int dim, int P, int NLP,
+                                                             int64_t batch, T* __restrict__ t_out, T* __restrict__ s_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tx = reinterpret_cast<T*>(smem);
+  T* tg = tx + (size_t)64 * P;
+  T* tsave = tg + (size_t)64 * P;                                   // [64][NLP]
+  constexpr int LW = 2 * DMAX + 4;
+  T* tab = tsave + (((size_t)64 * NLP + 3) / 4) * 4;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < n_layers * LW; i += 64) {
+    const int l = i / LW, q = i - l * LW;
+    T v = T(0);
+    if (q < DMAX) { if (q < dim) v = Aw[l * dim + q]; }
+    else if (q < 2 * DMAX) { if (q - DMAX < dim) v = Auh[l * dim + q - DMAX]; }
+    else if (q == 2 * DMAX) v = Ab[l];
+    else if (q == 2 * DMAX + 1) v = Ac[l];
+    tab[i] = v;
+  }
+  tile_sync();
+  for (int64_t c0 = (int64_t)blockIdx.x * 64; c0 < batch; c0 += (int64_t)gridDim.x * 64) {
+    const int ncols = (int)((batch - c0) < 64 ? (batch - c0) : 64);
+    tile_stage_in<T, V>(tx, x + c0 * dim, dim, P, ncols, lane);
+    tile_stage_in<T, V>(tg, ybar + c0 * dim, dim, P, ncols, lane);
+    tile_sync();
+    T* mx = tx + lane * P;
+    const T* mg = tg + lane * P;
+    T* tm = tsave + lane * NLP;
+    T z[DMAX];
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) z[r] = r < dim ? mx[r] : T(0);
+    auto dot = [&](const T* row) -> T {
+      T s0 = T(0), s1 = T(0);
+#pragma unroll
+      for (int r = 0; r < DMAX; r += 2) { s0 += row[r] * z[r]; s1 += row[r + 1] * z[r + 1]; }
+      return s0 + s1;
+    };
+    auto axpy = [&](const T* row, T a) {
+#pragma unroll
+      for (int r = 0; r < DMAX; ++r) z[r] += row[r] * a;
+    };
+    if (!INV) {
+      for (int l = 0; l < n_layers; ++l) {
+        const T* tl = tab + l * LW;
+        const T t = walk_tanh(dot(tl) + tl[2 * DMAX]);
+        tm[l] = t;
+        axpy(tl + DMAX, t);
+      }
+    } else {
+      for (int l = n_layers - 1; l >= 0; --l) {
+        const T* tl = tab + l * LW;
+        const T a = find_alpha_dev<T>(dot(tl), tl[2 * DMAX + 1], tl[2 * DMAX]);
+        const T t = walk_tanh(a + tl[2 * DMAX]);
+        tm[l] = t;
+        axpy(tl + DMAX, -t);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) z[r] = r < dim ? mg[r] : T(0);
+    const int64_t col = c0 + lane;
+    const T lb = (lbar && lane < ncols) ? lbar[col] : T(0);
+    if (!INV) {
+      for (int l = n_layers - 1; l >= 0; --l) {
+        const T* tl = tab + l * LW;
+        const T t = tm[l], c = tl[2 * DMAX + 1];
+        const T q = T(1) - t * t;
+        const T sb = dot(tl + DMAX) * q + lb * c * (T(-2) * t) * q / (T(1) + c * q);
+        if (s_out && lane < ncols) { s_out[col * n_layers + l] = sb; t_out[col * n_layers + l] = t; }
+        axpy(tl, sb);
+      }
+    } else {
+      for (int l = 0; l < n_layers; ++l) {
+        const T* tl = tab + l * LW;
+        const T t = tm[l], c = tl[2 * DMAX + 1];
+        const T q = T(1) - t * t;
+        const T den = T(1) + c * q;
+        const T sb = q / den * (-dot(tl + DMAX) + lb * T(2) * c * t / den);
+        axpy(tl, sb);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) if (r < dim) mx[r] = z[r];
+    tile_sync();
+    tile_stage_out<T, V>(tx, xbar + c0 * dim, dim, P, ncols, lane);
+    tile_sync();
+  }
+}
+
 // radial_layer.jl:43-72 (forward) and :88-129 (inverse), same arithmetic as radial_kernel
 template <class T, int DMAX, bool INV, int V>
 __global__ __launch_bounds__(64) void radial_walk_kernel(const T* __restrict__ Aalpha, const T* __restrict__ Abeta, const T* __restrict__ Az0, const T* __restrict__ x,
@@ -2040,6 +2135,33 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
   hipLaunchKernelGGL(planar_prep_kernel<T>, dim3(nl), dim3(256), 0, ctx->stream, w, u, dim, u_hat, wtu);
   BJX_CHECK_LAUNCH(ctx);
   if (batch == 0) return BJX_OK;
+  {
+    // low-dimensional columns: one lane per column (planar_vjp_walk_kernel)
+    static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 32;
+    const int dmax = dim <= 4 ? 4 : (dim <= 8 ? 8 : (dim <= 16 ? 16 : 32));
+    const int64_t P = dim | 1, NLP = nl | 1;
+    const size_t smem_w = ((size_t)2 * 64 * P + (((size_t)64 * NLP + 3) / 4) * 4 + (size_t)nl * (2 * dmax + 4)) * sizeof(T);
+    if (dim <= walk_max && dim <= 32 && smem_w <= 60 * 1024 && (const void*)in != (const void*)in_bar) {
+      constexpr int VW = Vec16<T>::N;
+      const int64_t tiles = (batch + 63) / 64;
+      const int64_t cap = (int64_t)ctx->num_cu * 32;
+      const int grid_w = (int)(tiles < cap ? tiles : cap);
+      const bool vec = bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
+      {
+        BjxProf prof_(ctx);
+#define PVW(D_, I_, V_) hipLaunchKernelGGL((planar_vjp_walk_kernel<T, D_, I_, V_>), dim3(grid_w), dim3(64), smem_w, ctx->stream, (const T*)w, (const T*)u_hat, (const T*)wtu, (const T*)b, nl, \
+                                           in, out_bar, ladj_bar, in_bar, (int)dim, (int)P, (int)NLP, batch, t_out, s_out)
+#define PVW_V(D_, I_) do { if (vec) PVW(D_, I_, VW); else PVW(D_, I_, 1); } while (0)
+#define PVW_D(I_) do { if (dim <= 4) PVW_V(4, I_); else if (dim <= 8) PVW_V(8, I_); else if (dim <= 16) PVW_V(16, I_); else PVW_V(32, I_); } while (0)
+        if (inverse) PVW_D(true); else PVW_D(false);
+#undef PVW_D
+#undef PVW_V
+#undef PVW
+      }
+      BJX_CHECK_LAUNCH(ctx);
+      return BJX_OK;
+    }
+  }
   {
     int rc = planar_vjp_reg(ctx, inverse, w, u_hat, wtu, b, nl, in, out_bar, ladj_bar, in_bar, dim, batch, t_out, s_out);
     if (rc != 1) return rc;                               // 1 = shape not served by the register kernel
