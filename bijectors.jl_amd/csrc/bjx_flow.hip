@@ -1846,6 +1846,67 @@ __global__ __launch_bounds__(64) void radial_walk_kernel(const T* __restrict__ A
   if (partials) block_publish_partial(acc, red, partials);
 }
 
+// Pullback of the RadialLayer on odd column heights, one lane per column (the arithmetic of radial_vjp_kernel)
+template <class T, int DMAX, bool INV, int V>
+__global__ __launch_bounds__(64) void radial_vjp_walk_kernel(const T* __restrict__ Aalpha, const T* __restrict__ Abeta, const T* __restrict__ Az0, const T* __restrict__ x,
+                                                             const T* __restrict__ gbar, const T* __restrict__ lbar, T* __restrict__ xbar, int dim, int P, int64_t batch,
+                                                             T* __restrict__ work) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tx = reinterpret_cast<T*>(smem);
+  T* tg = tx + (size_t)64 * P;
+  const int lane = threadIdx.x;
+  const T alpha = d_log1pexp(Aalpha[0]);
+  const T apb = d_log1pexp(Abeta[0]);
+  const T bh = -alpha + apb;
+  for (int64_t c0 = (int64_t)blockIdx.x * 64; c0 < batch; c0 += (int64_t)gridDim.x * 64) {
+    const int ncols = (int)((batch - c0) < 64 ? (batch - c0) : 64);
+    tile_stage_in<T, V>(tx, x + c0 * dim, dim, P, ncols, lane);
+    tile_stage_in<T, V>(tg, gbar + c0 * dim, dim, P, ncols, lane);
+    tile_sync();
+    T* mx = tx + lane * P;
+    const T* mg = tg + lane * P;
+    T dz[DMAX], gv[DMAX];
+    T ss = T(0), dg = T(0);
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) {
+      dz[r] = r < dim ? mx[r] - Az0[r] : T(0);
+      gv[r] = r < dim ? mg[r] : T(0);
+      ss += dz[r] * dz[r];
+      dg += dz[r] * gv[r];
+    }
+    T rr, gain = T(1);
+    if (!INV) rr = d_sqrt(ss);
+    else {
+      const T gam = d_sqrt(ss);              // compute_r, radial_layer.jl:124-129
+      const T aa = apb - gam;
+      const T r0 = (d_sqrt(aa * aa + 4 * alpha * gam) - aa) / 2;
+      gain = (alpha + r0) / (apb + r0);
+      rr = gain * gam;
+    }
+    const T h = T(1) / (alpha + rr);
+    const T a = T(1) + bh * h;
+    const T rinv = rr > T(0) ? T(1) / rr : T(0);
+    const T c = -bh * h * h * rinv;
+    const T lr = T(dim - 1) * (-bh * h * h) / a + (T(-2) * bh * h * h + T(2) * bh * h * h * h * rr) / (T(1) + bh * h - bh * h * h * rr);
+    const int64_t col = c0 + lane;
+    const T lb = (lbar && lane < ncols) ? lbar[col] : T(0);
+    const T kl = lb * lr * rinv;
+    if (!INV && work && lane < ncols) { work[col] = rr; work[batch + col] = dg; }
+    T ca, cd;
+    if (!INV) { ca = a; cd = c * dg + kl; }
+    else {
+      const T dv = gain * dg - kl * rr * rr;
+      ca = T(1) / a;
+      cd = gain * (-kl / a - c * dv / (a * (a + c * rr * rr)));
+    }
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) if (r < dim) mx[r] = ca * gv[r] + cd * dz[r];
+    tile_sync();
+    tile_stage_out<T, V>(tx, xbar + c0 * dim, dim, P, ncols, lane);
+    tile_sync();
+  }
+}
+
 struct FlowCfg { int V, G, R; int64_t grid; };
 
 template <class T> bool flow_cfg(const bjx_ctx* ctx, const void* x, const void* y, int64_t dim, int64_t batch, FlowCfg* c) {
@@ -2698,6 +2759,30 @@ int radial_vjp_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, c
                     T* in_bar, int64_t dim, int64_t batch, T* work = nullptr, double* zsum_out = nullptr, bool* zsum_done = nullptr) {
   if (zsum_done) *zsum_done = false;
   if (batch == 0) return BJX_OK;
+  {
+    static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 32;
+    if (dim <= walk_max && dim <= 32 && dim % Vec16<T>::N != 0 && (const void*)in != (const void*)in_bar) {   // (zsum_out stays unset: the caller reduces ȳ - z̄ itself)
+      constexpr int VWW = Vec16<T>::N;
+      const int P = (int)(dim | 1);
+      const size_t smem_w = (size_t)2 * 64 * P * sizeof(T);
+      const int64_t tiles = (batch + 63) / 64;
+      const int64_t cap = (int64_t)ctx->num_cu * 32;
+      const int grid_w = (int)(tiles < cap ? tiles : cap);
+      const bool vec = bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
+      {
+        BjxProf prof_(ctx);
+#define RVW(D_, I_, V_) hipLaunchKernelGGL((radial_vjp_walk_kernel<T, D_, I_, V_>), dim3(grid_w), dim3(64), smem_w, ctx->stream, alpha_, beta, z0, in, out_bar, ladj_bar, in_bar, (int)dim, P, batch, work)
+#define RVW_V(D_, I_) do { if (vec) RVW(D_, I_, VWW); else RVW(D_, I_, 1); } while (0)
+#define RVW_D(I_) do { if (dim <= 4) RVW_V(4, I_); else if (dim <= 8) RVW_V(8, I_); else if (dim <= 16) RVW_V(16, I_); else RVW_V(32, I_); } while (0)
+        if (inverse) RVW_D(true); else RVW_D(false);
+#undef RVW_D
+#undef RVW_V
+#undef RVW
+      }
+      BJX_CHECK_LAUNCH(ctx);
+      return BJX_OK;
+    }
+  }
   FlowCfg c;
   BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, in_bar, dim, batch, &c), BJX_ERR_UNSUPPORTED, "bjx_radial_vjp: dim %lld too large for the register-resident kernel", (long long)dim);
   constexpr int VW = Vec16<T>::N;
