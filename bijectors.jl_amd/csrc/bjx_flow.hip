@@ -2673,6 +2673,10 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
   FlowCfg c;
   BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, out_bar, dim, batch, &c) && c.R <= 4, BJX_ERR_UNSUPPORTED,
               "bjx_planar_vjp_params: dim %lld too large for the register accumulators", (long long)dim);
+  // planar_param_reduce_kernel gives the Gram row / b̄ / c̄ of layer l0 + gl to lane gl of a column's group: the group must have at
+  // least PP_NLG lanes even when the column is only one or two packs (dim <= 4·PP_NLG: lanes without a pack only do that part).
+  // (Found with dim = 2, 4, 8: with G < 8 the rows of the upper layers were never accumulated — wrong w̄, ū, b̄.)
+  if (c.G < PP_NLG) c.G = PP_NLG;
   const int R = c.R;
   const int cols_per_block = 256 / c.G;
   constexpr int VW = Vec16<T>::N;

@@ -40,9 +40,11 @@ for d in (3, 4, 8, 10):
     U8 = torch.randn(d, 8, device=dev) / math.sqrt(d)
     cases.append(("vjp(8×PlanarLayer)", bj.PlanarLayer(W8, U8, torch.randn(8, device=dev)), x, g, 3 * d))
     cases.append(("vjp(RadialLayer)", bj.RadialLayer(torch.tensor([0.5], device=dev), torch.tensor([0.3], device=dev), torch.randn(d, device=dev)), x, g, 3 * d))
+    pl8 = bj.PlanarLayer(W8, U8, torch.randn(8, device=dev))
+    cases.append(("vjp_params(8×PlanarLayer)", pl8, x, g, 5 * d))
     for name, b, xin, gin, words in cases:
         try:
-            ms = timed(lambda: bj.vjp(b, xin, gin, lb))
+            ms = timed((lambda: bj.vjp_params(b, xin, gin, lb)) if name.startswith("vjp_params") else (lambda: bj.vjp(b, xin, gin, lb)))
         except Exception as ex:
             print(f"| {name} | {d} | error {ex!r} | | | |")
             continue

@@ -22,7 +22,7 @@ grep "^|" $O/rows_raw.txt > $O/rows.md; f=$(ls $O/prof_rows/*kernel_stats.csv 2>
 python scripts/bench_f64.py 2>/dev/null | grep "^|" > $O/f64_rows.md; wc -l $O/f64_rows.md
 [ -x scripts/f64math_bench.co ] && ./scripts/f64math_bench.co > $O/f64math_bench.txt 2>&1
 echo "== small per-sample sizes (K = 2 ... 16 matrix / Cholesky blocks, dim = 2 ... 10 columns)"
-( python scripts/bench_small_sizes.py 2>/dev/null | grep "^|"; echo; python scripts/bench_matrix_small.py 2>/dev/null | grep "^|"; echo; python scripts/bench_small_dims.py 2>/dev/null | grep "^|" ) > $O/small_sizes.md; wc -l $O/small_sizes.md
+( python scripts/bench_small_sizes.py 2>/dev/null | grep "^|"; echo; python scripts/bench_matrix_small.py 2>/dev/null | grep "^|"; echo; python scripts/bench_small_dims.py 2>/dev/null | grep "^|"; echo; python scripts/bench_small_vjp.py 2>/dev/null | grep "^|" ) > $O/small_sizes.md; wc -l $O/small_sizes.md
 ( for m in 0 2 1 4 0; do echo -n "c4 BJX_PLANAR_MFMA=$m : "; BJX_PLANAR_MFMA=$m python bench.py --workload c4 --no-rows --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('kernel_ms %.4f frac %.3f' % (d['roofline']['kernel_ms'], d['roofline']['frac']))"; done ) > $O/planar_mfma_ab.txt 2>&1; cat $O/planar_mfma_ab.txt
 for wl in $WLS; do
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o $wl -- python $R/bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-rows > $O/rocprof_$wl.log 2>&1 )

@@ -1255,7 +1255,8 @@ def test_batchnorm_eval_vjp(bj, orc, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("dim,nl,N", [(128, 8, 3000), (64, 3, 257), (20, 1, 77), (7, 2, 50), (36, 12, 500), (192, 5, 1001), (256, 12, 333), (128, 8, 70001), (64, 1, 18)])
+@pytest.mark.parametrize("dim,nl,N", [(128, 8, 3000), (64, 3, 257), (20, 1, 77), (7, 2, 50), (36, 12, 500), (192, 5, 1001), (256, 12, 333), (128, 8, 70001), (64, 1, 18),
+                                       (2, 8, 300), (4, 8, 257), (8, 8, 300), (10, 8, 129), (3, 5, 100), (16, 12, 200), (1, 8, 65)])   # few packs per column, many layers
 def test_planar_param_vjp(bj, orc, dim, nl, N, dt):
     """Parameter pullback of the PlanarLayer stack, summed over the batch (incl. the chain rule through get_u_hat)."""
     r = rng(85)
