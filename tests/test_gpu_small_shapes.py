@@ -1,0 +1,211 @@
+"""Small-shape matrix: every bijector and pullback at the column heights / block sizes real models have (1 ... 13 rows, K = 2 ... 9)
+and ragged batches (1, 63, 65, 130 columns), Float32 and Float64, against the CPU oracle.
+
+The regular parity tests use mostly "benchmark-sized" shapes; the kernels pick different geometries for small ones (one lane per
+column / per sample, narrow lane groups, one-element packs for odd heights), and a bug that only shows there — the Planar
+parameter pullback with fewer lanes per column than layers — went unnoticed until these shapes were measured.  Tolerances as in
+test_gpu_parity.py (north_star: 1e-3 relative Float32, 1e-6 Float64)."""
+import math
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+RTOL = {np.float32: 1e-3, np.float64: 1e-6}
+ATOL = {np.float32: 2e-4, np.float64: 1e-9}
+DIMS = [1, 2, 3, 5, 8, 10, 13]
+BATCHES = [1, 63, 130]
+
+
+@pytest.fixture(scope="module")
+def bj():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    import bijectors_amd
+
+    bijectors_amd._lib.load()
+    return bijectors_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+
+    return oracle
+
+
+def dev(a):
+    a = np.asarray(a)
+    if a.ndim == 1:
+        return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    if a.ndim == 2:
+        return torch.from_numpy(np.ascontiguousarray(a.T)).cuda().T
+    return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 1, 0))).cuda().permute(2, 1, 0)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def close(got, ref, dt, scale=1.0, what=""):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    s = max(1.0, float(np.abs(ref).max()) if ref.size else 1.0)
+    np.testing.assert_allclose(got, ref, rtol=RTOL[dt] * scale, atol=ATOL[dt] * scale * s, err_msg=what)
+
+
+def F(a, dt):
+    return np.asfortranarray(np.asarray(a).astype(dt))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("N", BATCHES)
+@pytest.mark.parametrize("dim", DIMS)
+def test_elementwise_chain_stacked_and_pullbacks(bj, orc, dim, N, dt):
+    r = np.random.default_rng(1000 * dim + N)
+    X = F(r.normal(size=(dim, N)), dt)
+    Xd = X.astype(np.float64)
+    b = bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5)
+    ops = [(orc.OP_SCALE, 0.5, None), (orc.OP_SHIFT, 0.1, None), (orc.OP_EXP, None, None)]
+    Y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+    u = 0.5 * Xd + 0.1
+    close(host(Y), np.exp(u), dt, what="chain values")
+    close(host(l), u.sum(axis=0) + dim * math.log(0.5), dt, scale=dim, what="chain per-sample ladj")
+    Xb, lb = bj.with_logabsdet_jacobian(bj.inverse(b), dev(np.exp(u).astype(dt)), per_sample=True)
+    close(host(Xb), Xd, dt, scale=10, what="chain inverse")
+    close(host(lb), -(u.sum(axis=0) + dim * math.log(0.5)), dt, scale=10 * dim, what="chain inverse ladj")
+    g, lbar = F(r.normal(size=(dim, N)), dt), r.normal(size=N).astype(dt)
+    ref = orc.chain_vjp(ops, Xd, g.astype(np.float64), lbar.astype(np.float64))
+    close(host(bj.vjp(b, dev(X), dev(g), torch.from_numpy(lbar).cuda())), ref, dt, scale=20, what="chain pullback")
+    if dim >= 3:                                     # Stacked: exp | Logit | identity on thirds
+        a_, b_ = dim // 3, 2 * (dim // 3)
+        Xs = X.copy()
+        Xs[a_:b_] = r.uniform(0.05, 0.95, size=(b_ - a_, N)).astype(dt)
+        st = bj.Stacked([bj.elementwise(bj.exp), bj.Logit(0.0, 1.0), bj.identity], [(1, a_), (a_ + 1, b_), (b_ + 1, dim)])
+        Ys, ls = bj.with_logabsdet_jacobian(st, dev(Xs), per_sample=True)
+        Xsd = Xs.astype(np.float64)
+        yref = np.vstack([np.exp(Xsd[:a_]), np.log(Xsd[a_:b_] / (1 - Xsd[a_:b_])), Xsd[b_:]])
+        lref = Xsd[:a_].sum(axis=0) - np.log(Xsd[a_:b_] * (1 - Xsd[a_:b_])).sum(axis=0)
+        close(host(Ys), yref, dt, scale=10, what="Stacked values")
+        close(host(ls), lref, dt, scale=10 * dim, what="Stacked ladj")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("N", BATCHES)
+@pytest.mark.parametrize("dim", DIMS)
+@pytest.mark.parametrize("nl", [1, 3, 8])
+def test_planar_all_directions_and_pullbacks(bj, orc, dim, nl, N, dt):
+    r = np.random.default_rng(77 * dim + 5 * nl + N)
+    w = (r.normal(size=(dim, nl)) / math.sqrt(dim)).astype(dt)
+    u = (r.normal(size=(dim, nl)) / math.sqrt(dim)).astype(dt)
+    b = r.normal(size=nl).astype(dt)
+    Z = F(r.normal(size=(dim, N)), dt)
+    flow = bj.PlanarLayer(dev(w), dev(u), dev(b)) if nl > 1 else bj.PlanarLayer(dev(w[:, 0]), dev(u[:, 0]), dev(b))
+    Yr, lr = orc.planar(w, u, b, Z)
+    res = bj.with_logabsdet_jacobian(flow, dev(Z))
+    close(host(res.result), Yr, dt, scale=5, what="planar forward")
+    close(host(res.logabsdetjac), lr, dt, scale=5 * nl, what="planar ladj")
+    Zb, lb = bj.with_logabsdet_jacobian(bj.inverse(flow), dev(Yr))
+    close(host(Zb), Z, dt, scale=50, what="planar inverse (round trip)")
+    close(host(lb), -lr, dt, scale=50 * nl, what="planar inverse ladj")
+    g, lbar = F(r.normal(size=(dim, N)), dt), (r.normal(size=N) / math.sqrt(N)).astype(dt)
+    w64, u64, b64 = w.astype(np.float64), u.astype(np.float64), b.astype(np.float64)
+    xb_ref = orc.planar_vjp(w64, u64, b64, Z.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64))
+    close(host(bj.vjp(flow, dev(Z), dev(g), torch.from_numpy(lbar).cuda())), xb_ref, dt, scale=20, what="planar pullback")
+    yb_ref = orc.planar_inv_vjp(w64, u64, b64, Yr.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64))
+    close(host(bj.vjp(bj.inverse(flow), dev(Yr), dev(g), torch.from_numpy(lbar).cuda())), yb_ref, dt, scale=100, what="planar inverse pullback")
+    if nl > 1:
+        wb, ub, bb = orc.planar_param_vjp(w64, u64, b64, Z.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64))
+        xb, pb = bj.vjp_params(flow, dev(Z), dev(g), torch.from_numpy(lbar).cuda())
+        close(host(xb), xb_ref, dt, scale=20, what="planar vjp_params input side")
+        for name, rf in (("w", wb), ("u", ub), ("b", bb)):
+            close(host(pb[name]), rf, dt, scale=50 * math.sqrt(N), what=f"planar parameter cotangent {name}")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("N", BATCHES)
+@pytest.mark.parametrize("dim", DIMS)
+def test_radial_batchnorm_permute_coupling(bj, orc, dim, N, dt):
+    r = np.random.default_rng(31 * dim + N)
+    Z = F(r.normal(size=(dim, N)), dt)
+    a_, b_, z0 = np.array([0.4], dtype=dt), np.array([-0.2], dtype=dt), r.normal(size=dim).astype(dt)
+    rad = bj.RadialLayer(dev(a_), dev(b_), dev(z0))
+    Yr, lr = orc.radial(a_, b_, z0, Z)
+    Y, l = bj.with_logabsdet_jacobian(rad, dev(Z))
+    close(host(Y), Yr, dt, scale=5, what="radial forward")
+    close(host(l), lr, dt, scale=5 * dim, what="radial ladj")
+    Zb, lb = bj.with_logabsdet_jacobian(bj.inverse(rad), dev(Yr))
+    close(host(Zb), Z, dt, scale=50, what="radial inverse")
+    g, lbar = F(r.normal(size=(dim, N)), dt), r.normal(size=N).astype(dt)
+    for inv, xin in ((False, Z), (True, Yr)):
+        ref = orc.radial_vjp(a_.astype(np.float64), b_.astype(np.float64), z0.astype(np.float64), np.asarray(xin, dtype=np.float64), g.astype(np.float64),
+                             lbar.astype(np.float64), inverse=inv)
+        got = bj.vjp(bj.inverse(rad) if inv else rad, dev(np.asarray(xin).astype(dt)), dev(g), torch.from_numpy(lbar).cuda())
+        close(host(got), ref, dt, scale=50, what=f"radial pullback inverse={inv}")
+    # InvertibleBatchNorm in eval mode
+    bb, logs, m, v = r.normal(size=dim).astype(dt), (0.2 * r.normal(size=dim)).astype(dt), r.normal(size=dim).astype(dt), r.uniform(0.5, 1.5, size=dim).astype(dt)
+    bn = bj.InvertibleBatchNorm(dev(bb), dev(logs), dev(m), dev(v))
+    Yb, lbn = orc.batchnorm(bb, logs, m, v, 1e-5, Z)
+    Y, l = bj.with_logabsdet_jacobian(bn, dev(Z))
+    close(host(Y), Yb, dt, scale=5, what="batchnorm eval")
+    close(host(l), lbn, dt, scale=5 * dim, what="batchnorm ladj")
+    # Permute (bit-exact)
+    perm = r.permutation(dim)
+    P = host(bj.transform(bj.Permute((perm + 1).tolist()), dev(Z)))             # y[perm[i]] = x[i] (permute.jl)
+    Pref = np.empty_like(Z)
+    Pref[perm] = Z
+    assert np.array_equal(P, Pref), "permute"
+    if dim >= 2:
+        i1 = list(range(1, dim // 2 + 1))
+        mask = bj.PartitionMask(dim, i1, list(range(dim // 2 + 1, dim + 1)))
+        sc = r.uniform(0.5, 1.5, size=len(i1)).astype(dt)
+        cp = bj.Coupling(lambda x2: bj.Shift(0.25) @ bj.Scale(dev(sc)), mask)
+        Yc, lc = bj.with_logabsdet_jacobian(cp, dev(Z), per_sample=True)
+        ref = Z.astype(np.float64).copy()
+        ref[: len(i1)] = sc[:, None].astype(np.float64) * ref[: len(i1)] + 0.25
+        close(host(Yc), ref, dt, scale=5, what="coupling values")
+        close(host(lc), np.full(N, np.log(sc.astype(np.float64)).sum()), dt, scale=5 * dim, what="coupling ladj")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("N", BATCHES)
+@pytest.mark.parametrize("K", [2, 3, 4, 5, 7, 9])
+def test_structured_blocks_and_pullbacks(bj, orc, K, N, dt):
+    r = np.random.default_rng(13 * K + N)
+    X = F(r.dirichlet(np.ones(K), size=N).T, dt)
+    Ys, ls = orc.simplex(X)
+    Y, l = bj.with_logabsdet_jacobian(bj.SimplexBijector(), dev(X), per_sample=True)
+    close(host(Y), Ys, dt, scale=10, what="simplex forward")
+    close(host(l), ls, dt, scale=20 * K, what="simplex ladj")
+    Xb, lb = bj.with_logabsdet_jacobian(bj.inverse(bj.SimplexBijector()), dev(Ys), per_sample=True)
+    close(host(Xb), X, dt, scale=20, what="simplex inverse")
+    Yo = F(r.normal(size=(K, N)), dt)
+    Xo, lo = orc.ordered(Yo)
+    Y2, l2 = bj.with_logabsdet_jacobian(bj.OrderedBijector(), dev(Yo), per_sample=True)
+    close(host(Y2), Xo, dt, scale=10, what="ordered forward")
+    close(host(l2), lo, dt, scale=10 * K, what="ordered ladj")
+    g, lbar = F(r.normal(size=(K, N)), dt), r.normal(size=N).astype(dt)
+    close(host(bj.vjp(bj.OrderedBijector(), dev(Yo), dev(g), torch.from_numpy(lbar).cuda())),
+          orc.ordered_vjp(Yo.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64)), dt, scale=20 * K, what="ordered pullback")
+    gs = F(r.normal(size=(K - 1, N)), dt)
+    close(host(bj.vjp(bj.SimplexBijector(), dev(X), dev(gs), torch.from_numpy(lbar).cuda())),
+          orc.simplex_vjp(X.astype(np.float64), gs.astype(np.float64), lbar.astype(np.float64)), dt, scale=200 * K, what="simplex pullback")
+    # LKJ blocks: VecCholesky (both triangles), VecCorr, PDVec round trips against the oracle
+    n = K * (K - 1) // 2
+    y = F(0.5 * r.normal(size=(n, N)), dt)
+    for uplo in ("U", "L"):
+        Wr, lj = orc.vec_cholesky(y, inverse=True, uplo=uplo)
+        W, lw = bj.with_logabsdet_jacobian(bj.inverse(bj.VecCholeskyBijector(uplo)), dev(y), per_sample=True)
+        close(host(W), Wr, dt, scale=10, what=f"VecCholesky inverse {uplo}")
+        close(host(lw), lj, dt, scale=10 * n, what=f"VecCholesky inverse logJ {uplo}")
+        yr, lf = orc.vec_cholesky(Wr, inverse=False, uplo=uplo)
+        yf, lff = bj.with_logabsdet_jacobian(bj.VecCholeskyBijector(uplo), dev(Wr), per_sample=True)
+        close(host(yf), yr, dt, scale=20, what=f"VecCholesky forward {uplo}")
+        close(host(lff), lf, dt, scale=20 * n, what=f"VecCholesky forward ladj {uplo}")
+    Xc, lc = orc.vec_corr(y, inverse=True)
+    Xg, lg = bj.with_logabsdet_jacobian(bj.inverse(bj.VecCorrBijector()), dev(y), per_sample=True)
+    close(host(Xg), Xc, dt, scale=20, what="VecCorr inverse")
+    close(host(lg), lc, dt, scale=20 * max(n, 1), what="VecCorr inverse ladj")
