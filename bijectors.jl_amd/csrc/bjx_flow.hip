@@ -1710,9 +1710,10 @@ __global__ __launch_bounds__(64) void planar_vjp_walk_kernel(const T* __restrict
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* tx = reinterpret_cast<T*>(smem);
   T* tg = tx + (size_t)64 * P;
-  T* tsave = tg + (size_t)64 * P;                                   // [64][NLP]
+  T* tsave = tg + (size_t)64 * P;                                   // [64][NLP]: tanh of every layer
+  T* ssave = tsave + (size_t)64 * NLP;                              // [64][NLP]: s̄ of every layer (for t_out / s_out: stored as contiguous runs)
   constexpr int LW = 2 * DMAX + 4;
-  T* tab = tsave + (((size_t)64 * NLP + 3) / 4) * 4;
+  T* tab = ssave + (((size_t)64 * NLP + 3) / 4) * 4;
   const int lane = threadIdx.x;
   for (int i = lane; i < n_layers * LW; i += 64) {
     const int l = i / LW, q = i - l * LW;
@@ -1771,7 +1772,7 @@ __global__ __launch_bounds__(64) void planar_vjp_walk_kernel(const T* __restrict
         const T t = tm[l], c = tl[2 * DMAX + 1];
         const T q = T(1) - t * t;
         const T sb = dot(tl + DMAX) * q + lb * c * (T(-2) * t) * q / (T(1) + c * q);
-        if (s_out && lane < ncols) { s_out[col * n_layers + l] = sb; t_out[col * n_layers + l] = t; }
+        if (s_out) ssave[lane * NLP + l] = sb;
         axpy(tl, sb);
       }
     } else {
@@ -1788,6 +1789,10 @@ __global__ __launch_bounds__(64) void planar_vjp_walk_kernel(const T* __restrict
     for (int r = 0; r < DMAX; ++r) if (r < dim) mx[r] = z[r];
     tile_sync();
     tile_stage_out<T, V>(tx, xbar + c0 * dim, dim, P, ncols, lane);
+    if (s_out) {
+      tile_stage_out<T, V>(ssave, s_out + c0 * n_layers, n_layers, NLP, ncols, lane);
+      tile_stage_out<T, V>(tsave, t_out + c0 * n_layers, n_layers, NLP, ncols, lane);
+    }
     tile_sync();
   }
 }
@@ -2201,7 +2206,7 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
     static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 32;
     const int dmax = dim <= 4 ? 4 : (dim <= 8 ? 8 : (dim <= 16 ? 16 : 32));
     const int64_t P = dim | 1, NLP = nl | 1;
-    const size_t smem_w = ((size_t)2 * 64 * P + (((size_t)64 * NLP + 3) / 4) * 4 + (size_t)nl * (2 * dmax + 4)) * sizeof(T);
+    const size_t smem_w = ((size_t)2 * 64 * P + (size_t)64 * NLP + (((size_t)64 * NLP + 3) / 4) * 4 + (size_t)nl * (2 * dmax + 4)) * sizeof(T);
     if (dim <= walk_max && dim <= 32 && smem_w <= 60 * 1024 && (const void*)in != (const void*)in_bar) {
       constexpr int VW = Vec16<T>::N;
       const int64_t tiles = (batch + 63) / 64;
@@ -2437,6 +2442,84 @@ __global__ __launch_bounds__(256) void planar_param_reduce_kernel(const T* __res
   for (size_t i = threadIdx.x; i < per; i += blockDim.x) partial[(size_t)blockIdx.x * per + i] = red[i];
 }
 
+// ---- the same reduction for LOW-DIMENSIONAL columns (dim <= 12), one lane per column: Z₀ and Ȳ of 64 consecutive columns through two
+// odd-pitch LDS tiles, the lane's s̄ / tanh of the layer group from the work arrays, M1 / M2 accumulated in the lane's own strip of
+// LDS ([2·dim·nlg][64]: bank = lane), the Gram block / b̄ / c̄ sums in registers; at the end the 64 strips are summed in a fixed
+// order into ONE Float64 partial per block with the layout of planar_param_reduce_kernel.  (With G lanes per column a 2 … 10 row
+// column keeps 1 - 3 lanes of every 8 busy: 2.5 - 12 % of the roofline.)
+template <class T, int V>
+__global__ __launch_bounds__(64) void planar_param_walk_kernel(const T* __restrict__ z0, const T* __restrict__ ybar, const T* __restrict__ sbar, const T* __restrict__ tt,
+                                                               const T* __restrict__ lbar, const T* __restrict__ wtu_hat, int dim, int P, int64_t batch, int nl, int l0, int nlg,
+                                                               double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tz = reinterpret_cast<T*>(smem);
+  T* tg = tz + (size_t)64 * P;
+  T* acc = tg + (((size_t)64 * P + 3) / 4) * 4;                   // [2·dim·nlg][64]
+  const int lane = threadIdx.x;
+  const int n_m = dim * nlg;
+  for (int i = 0; i < 2 * n_m; ++i) acc[i * 64 + lane] = T(0);
+  T stg[PP_NLG][PP_NLG], bs[PP_NLG], cs[PP_NLG], ck[PP_NLG];
+#pragma unroll
+  for (int j = 0; j < PP_NLG; ++j) {
+    bs[j] = T(0); cs[j] = T(0); ck[j] = j < nlg ? wtu_hat[l0 + j] : T(0);
+#pragma unroll
+    for (int k = 0; k < PP_NLG; ++k) stg[j][k] = T(0);
+  }
+  for (int64_t c0 = (int64_t)blockIdx.x * 64; c0 < batch; c0 += (int64_t)gridDim.x * 64) {
+    const int ncols = (int)((batch - c0) < 64 ? (batch - c0) : 64);
+    tile_stage_in<T, V>(tz, z0 + c0 * dim, dim, P, ncols, lane);
+    tile_stage_in<T, V>(tg, ybar + c0 * dim, dim, P, ncols, lane);
+    tile_sync();
+    if (lane < ncols) {
+      const int64_t col = c0 + lane;
+      T sk[PP_NLG], tk[PP_NLG];
+#pragma unroll
+      for (int k = 0; k < PP_NLG; ++k) { sk[k] = k < nlg ? sbar[col * nl + l0 + k] : T(0); tk[k] = k < nlg ? tt[col * nl + l0 + k] : T(0); }
+      const T lb = lbar ? lbar[col] : T(0);
+      const T* mz = tz + lane * P;
+      const T* mg = tg + lane * P;
+      for (int r = 0; r < dim; ++r) {
+        const T zr = mz[r], gr = mg[r];
+        T* a1 = acc + (size_t)(r * nlg) * 64 + lane;
+        T* a2 = acc + (size_t)(n_m + r * nlg) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < PP_NLG; ++k) {
+          if (k < nlg) { a1[k * 64] += zr * sk[k]; a2[k * 64] += gr * tk[k]; }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < PP_NLG; ++j) {
+        bs[j] += sk[j];
+        const T q = T(1) - tk[j] * tk[j];
+        cs[j] += lb * q / (T(1) + ck[j] * q);
+#pragma unroll
+        for (int k = 0; k < PP_NLG; ++k) stg[j][k] += sk[j] * tk[k];
+      }
+    }
+    tile_sync();
+  }
+  // lanes -> one partial set: M1 / M2 from the strips, the register sums through a fixed xor butterfly
+  const size_t per = 2 * (size_t)n_m + (size_t)nlg * nlg + 2 * (size_t)nlg;
+  double* out = partial + (size_t)blockIdx.x * per;
+  for (int i = lane; i < 2 * n_m; i += 64) {
+    double sum = 0.0;
+    for (int l = 0; l < 64; ++l) sum += (double)acc[i * 64 + l];
+    out[i] = sum;
+  }
+#pragma unroll
+  for (int j = 0; j < PP_NLG; ++j) {
+    double b_ = (double)bs[j], c_ = (double)cs[j];
+    for (int m = 1; m < 64; m <<= 1) { b_ += shfl_xor(b_, m); c_ += shfl_xor(c_, m); }
+    if (lane == 0 && j < nlg) { out[2 * n_m + (size_t)nlg * nlg + j] = b_; out[2 * n_m + (size_t)nlg * nlg + nlg + j] = c_; }
+#pragma unroll
+    for (int k = 0; k < PP_NLG; ++k) {
+      double s_ = (double)stg[j][k];
+      for (int m = 1; m < 64; m <<= 1) s_ += shfl_xor(s_, m);
+      if (lane == 0 && j < nlg && k < nlg) out[2 * n_m + (size_t)j * nlg + k] = s_;
+    }
+  }
+}
+
 // ---- the same reduction on the matrix cores (Float32, dim = 64·NH <= 256, 16-byte aligned inputs).
 // M1 = Z₀·S̄ᵀ and M2 = Ȳ·Tᵀ are [dim x columns]·[columns x layers] products with the COLUMN index as k.
 // v_mfma_f32_16x16x4_f32 (layout probed in scripts/probe_mfma.hip): A[i][k] on lane (i = l%16, k = l/16), B[k][n] on
@@ -2564,6 +2647,83 @@ __global__ __launch_bounds__(256) void planar_param_mfma_kernel(const float* __r
 }
 
 // cross-group Gram entries ST[j][k] with j, k in DIFFERENT layer groups are produced by a small launch of this kernel
+// ---- low-dimensional columns (dim <= 32, Float32) on the matrix cores: M1 = Z₀·S̄ᵀ and M2 = Ȳ·Tᵀ are [rows x columns]·[columns x layers]
+// products with at most 16 (or 2 x 16) rows — ONE 16x16 accumulator each, the column index as k.  A single-wave block stages 64 consecutive
+// columns of Z₀, Ȳ (odd-pitch tiles) and of the [n_layers, batch] work arrays s̄, tanh (contiguous too) through LDS; step m feeds the four
+// columns 4m … 4m+3: A = Z[row l%16][column 4m + l/16] (a conflict-free 4-byte LDS read), B = s̄[column 4m + l/16][layer l%16], and the Gram
+// block ST = S̄·Tᵀ is one more MFMA on the s̄ and tanh registers.  No per-lane accumulators, no cross-lane reduction for the matrices: the
+// accumulators ARE the block's partial (same layout as planar_param_reduce_kernel); b̄ and c̄ are two xor-butterflies at the end.
+template <int NRB, int V>
+__global__ __launch_bounds__(64) void planar_param_mfma_small_kernel(const float* __restrict__ z0, const float* __restrict__ ybar, const float* __restrict__ sbar,
+                                                                     const float* __restrict__ tt, const float* __restrict__ lbar, const float* __restrict__ wtu_hat,
+                                                                     int dim, int P, int PN, int64_t batch, int nl, int l0, int nlg, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tz = reinterpret_cast<float*>(smem);
+  float* tg = tz + (size_t)64 * P;
+  float* ts = tg + (size_t)64 * P;                                  // [64][PN]: s̄ of the tile's columns, all layers
+  float* tth = ts + (size_t)64 * PN;
+  float* tl = tth + (size_t)64 * PN;                                // ℓ̄ of the tile's columns (one coalesced load per tile, not one per step)
+  const int lane = threadIdx.x;
+  const int li = lane & 15, lk = lane >> 4;
+  bjx_mf4 m1[NRB], m2[NRB], st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < NRB; ++h) { m1[h] = bjx_mf4{0.f, 0.f, 0.f, 0.f}; m2[h] = bjx_mf4{0.f, 0.f, 0.f, 0.f}; }
+  float bsum = 0.f, csum = 0.f;
+  const bool lay_ok = li < nlg;
+  const float cme = lay_ok ? wtu_hat[l0 + li] : 0.f;
+  for (int64_t c0 = (int64_t)blockIdx.x * 64; c0 < batch; c0 += (int64_t)gridDim.x * 64) {
+    const int ncols = (int)((batch - c0) < 64 ? (batch - c0) : 64);
+    tile_stage_in<float, V>(tz, z0 + c0 * dim, dim, P, ncols, lane);
+    tile_stage_in<float, V>(tg, ybar + c0 * dim, dim, P, ncols, lane);
+    tile_stage_in<float, V>(ts, sbar + c0 * nl, nl, PN, ncols, lane);
+    tile_stage_in<float, V>(tth, tt + c0 * nl, nl, PN, ncols, lane);
+    tl[lane] = (lbar && lane < ncols) ? lbar[c0 + lane] : 0.f;
+    tile_sync();
+    for (int m = 0; m < 16; ++m) {
+      const int c = 4 * m + lk;                                      // my column of this step
+      const bool col_ok = c < ncols;
+      const float sv = (col_ok && lay_ok) ? ts[c * PN + l0 + li] : 0.f;
+      const float tv = (col_ok && lay_ok) ? tth[c * PN + l0 + li] : 0.f;
+#pragma unroll
+      for (int h = 0; h < NRB; ++h) {
+        const int row = 16 * h + li;
+        const bool ok = col_ok && row < dim;
+        const float za = ok ? tz[c * P + row] : 0.f;
+        const float ga = ok ? tg[c * P + row] : 0.f;
+        m1[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(za, sv, m1[h], 0, 0, 0);
+        m2[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, tv, m2[h], 0, 0, 0);
+      }
+      st = __builtin_amdgcn_mfma_f32_16x16x4f32(sv, tv, st, 0, 0, 0);           // ST[j][k] += s̄_j t_k
+      if (col_ok && lay_ok) {
+        bsum += sv;
+        const float q = 1.f - tv * tv;
+        csum += tl[c] * q / (1.f + cme * q);
+      }
+    }
+    tile_sync();
+  }
+  const size_t n_m = (size_t)dim * nlg;
+  const size_t per = 2 * n_m + (size_t)nlg * nlg + 2 * (size_t)nlg;
+  double* out = partial + (size_t)blockIdx.x * per;
+  // D[4 (l/16) + r][l%16] in register r: rows 4 lk + r of the block, layer li
+#pragma unroll
+  for (int h = 0; h < NRB; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * h + 4 * lk + r;
+      if (row < dim && lay_ok) { out[(size_t)row * nlg + li] = (double)m1[h][r]; out[n_m + (size_t)row * nlg + li] = (double)m2[h][r]; }
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = 4 * lk + r;
+    if (j < nlg && lay_ok) out[2 * n_m + (size_t)j * nlg + li] = (double)st[r];
+  }
+  double b_ = (double)bsum, c_ = (double)csum;
+  b_ += shfl_xor(b_, 16); c_ += shfl_xor(c_, 16);
+  b_ += shfl_xor(b_, 32); c_ += shfl_xor(c_, 32);
+  if (lk == 0 && lay_ok) { out[2 * n_m + (size_t)nlg * nlg + li] = b_; out[2 * n_m + (size_t)nlg * nlg + nlg + li] = c_; }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void planar_gram_kernel(const T* __restrict__ sbar, const T* __restrict__ tt, int64_t batch, int nl, double* __restrict__ st) {
   __shared__ double red[4];
@@ -2580,9 +2740,18 @@ __global__ __launch_bounds__(256) void planar_gram_kernel(const T* __restrict__ 
 // read adjacent doubles of every block's set (coalesced), four independent accumulators keep loads in flight.
 // (planar_param_finalize_kernel used to walk the 1024 sets itself, 8 blocks of strided dependent-latency loads:
 // 1.1 ms at 8 layers x 128 rows — as long as the streaming reduction it finishes.)
-__global__ __launch_bounds__(256) void planar_param_colsum_kernel(const double* __restrict__ partial, int nblocks, size_t per, double* __restrict__ out) {
+// gridDim.y > 1: slice y sums the sets [y·chunk, (y+1)·chunk) into out[y·per + e] (a second launch with gridDim.y = 1 sums the slices):
+// a small set (a few hundred entries, low-dimensional flows) would otherwise be summed over thousands of blocks by ONE thread block.
+__global__ __launch_bounds__(256) void planar_param_colsum_kernel(const double* __restrict__ partial, int nblocks, size_t per, double* __restrict__ out, int chunk = 0) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= per) return;
+  if (chunk > 0) {
+    const int b0 = (int)blockIdx.y * chunk;
+    partial += (size_t)b0 * per;
+    out += (size_t)blockIdx.y * per;
+    nblocks = nblocks - b0 < chunk ? nblocks - b0 : chunk;
+    if (nblocks < 0) nblocks = 0;
+  }
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   int b = 0;
   for (; b + 4 <= nblocks; b += 4) {
@@ -2684,16 +2853,18 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
   static const int mfma_blocks = getenv("BJX_PLANAR_PARAM_BLOCKS") ? atoi(getenv("BJX_PLANAR_PARAM_BLOCKS")) : 1024;
   const bool mfma = use_mfma && std::is_same<T, float>::value && c.V == VW && (dim == 64 || dim == 128 || dim == 256) && bjx_aligned16(out_bar);   // 192 rows: three slices do not divide the four waves, one wave per column needs 357 registers
   // persistent grids with equal grid-stride shares: every block must be resident (a second round doubles the time)
-  const int block_cap = mfma ? mfma_blocks : 1024;
-  int nblocks = mfma ? (int)((batch + 63) / 64) : (int)((batch + (int64_t)cols_per_block * 16 - 1) / ((int64_t)cols_per_block * 16));
+  const bool small_walk = (std::is_same<T, float>::value && dim <= 32) || dim <= 12;   // single-wave blocks of 64 columns (planar_param_mfma_small_kernel / planar_param_walk_kernel)
+  const int block_cap = mfma ? mfma_blocks : (small_walk ? 4096 : 1024);
+  int nblocks = (mfma || small_walk) ? (int)((batch + 63) / 64) : (int)((batch + (int64_t)cols_per_block * 16 - 1) / ((int64_t)cols_per_block * 16));
   if (nblocks > block_cap) nblocks = block_cap;
   if (nblocks < 1) nblocks = 1;
   const size_t per_max = 2 * (size_t)dim * PP_NLG + PP_NLG * PP_NLG + 2 * PP_NLG;
   const size_t st_n = (size_t)nl * nl;
-  { int rc2 = bjx_ensure_partials(ctx, (size_t)nblocks * per_max + st_n + per_max); if (rc2) return rc2; }
+  { int rc2 = bjx_ensure_partials(ctx, (size_t)nblocks * per_max + st_n + per_max + 32 * per_max); if (rc2) return rc2; }
   double* partial = ctx->partials;
   double* st = partial + (size_t)nblocks * per_max;
   double* psum = st + st_n;                          // the block partials summed into one set
+  double* slices = psum + per_max;                   // [32][per]: first stage of the column sum when there are many sets of few entries
   const bool one_group = nl <= PP_NLG;
   if (!one_group) {                                  // cross-group Gram entries: a separate (slow, rarely needed) pass
     hipLaunchKernelGGL(planar_gram_kernel<T>, dim3(nl * nl), dim3(256), 0, ctx->stream, s_out, t_out, batch, nl, st);
@@ -2704,7 +2875,26 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
     const size_t per = 2 * (size_t)dim * nlg + (size_t)nlg * nlg + 2 * (size_t)nlg;
     const size_t smem = per * sizeof(double);
     BJX_REQUIRE(ctx, smem <= BJX_LDS_MAX, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp_params: dim %lld too large for the block combine", (long long)dim);
-    if (mfma) {
+    static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 32;
+    const int64_t Pw = dim | 1;
+    const size_t smem_walk = ((size_t)64 * Pw + (((size_t)64 * Pw + 3) / 4) * 4 + (size_t)2 * dim * nlg * 64) * sizeof(T);
+    const int64_t PNw = nl | 1;
+    const size_t smem_ms = ((size_t)2 * 64 * Pw + (size_t)2 * 64 * PNw + 64) * sizeof(float);
+    if (std::is_same<T, float>::value && dim <= 32 && dim <= walk_max && smem_ms <= 48 * 1024) {
+      BjxProf prof_(ctx);
+      const bool vec = bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(s_out) && bjx_aligned16(t_out);
+      const float* zf = reinterpret_cast<const float*>(in); const float* gf = reinterpret_cast<const float*>(out_bar);
+      const float* sf = reinterpret_cast<const float*>(s_out); const float* tf = reinterpret_cast<const float*>(t_out);
+      const float* lf = reinterpret_cast<const float*>(ladj_bar); const float* cf = reinterpret_cast<const float*>(wtu);
+#define PPS(NRB_, V_) hipLaunchKernelGGL((planar_param_mfma_small_kernel<NRB_, V_>), dim3(nblocks), dim3(64), smem_ms, ctx->stream, zf, gf, sf, tf, lf, cf, (int)dim, (int)Pw, (int)PNw, batch, nl, l0, nlg, partial)
+      if (dim <= 16) { if (vec) PPS(1, 4); else PPS(1, 1); } else { if (vec) PPS(2, 4); else PPS(2, 1); }
+#undef PPS
+    } else if (dim <= 12 && dim <= walk_max && smem_walk <= 64 * 1024) {
+      BjxProf prof_(ctx);
+      const bool vec = bjx_aligned16(in) && bjx_aligned16(out_bar);
+      if (vec) hipLaunchKernelGGL((planar_param_walk_kernel<T, VW>), dim3(nblocks), dim3(64), smem_walk, ctx->stream, in, out_bar, s_out, t_out, ladj_bar, wtu, (int)dim, (int)Pw, batch, nl, l0, nlg, partial);
+      else hipLaunchKernelGGL((planar_param_walk_kernel<T, 1>), dim3(nblocks), dim3(64), smem_walk, ctx->stream, in, out_bar, s_out, t_out, ladj_bar, wtu, (int)dim, (int)Pw, batch, nl, l0, nlg, partial);
+    } else if (mfma) {
       BjxProf prof_(ctx);
       const float* zf = reinterpret_cast<const float*>(in); const float* gf = reinterpret_cast<const float*>(out_bar);
       const float* sf = reinterpret_cast<const float*>(s_out); const float* tf = reinterpret_cast<const float*>(t_out);
@@ -2723,7 +2913,15 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
     BJX_CHECK_LAUNCH(ctx);
     {
       BjxProf prof_(ctx);
-      hipLaunchKernelGGL(planar_param_colsum_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, ctx->stream, partial, nblocks, per, psum);
+      const unsigned gx = (unsigned)((per + 255) / 256);
+      if (nblocks > 256 && gx <= 8) {                 // few entries, many sets: 32 slices, then the slices
+        constexpr int S = 32;
+        const int chunk = (nblocks + S - 1) / S;
+        hipLaunchKernelGGL(planar_param_colsum_kernel, dim3(gx, S), dim3(256), 0, ctx->stream, partial, nblocks, per, slices, chunk);
+        hipLaunchKernelGGL(planar_param_colsum_kernel, dim3(gx), dim3(256), 0, ctx->stream, slices, S, per, psum, 0);
+      } else {
+        hipLaunchKernelGGL(planar_param_colsum_kernel, dim3(gx), dim3(256), 0, ctx->stream, partial, nblocks, per, psum, 0);
+      }
     }
     BJX_CHECK_LAUNCH(ctx);
     {
