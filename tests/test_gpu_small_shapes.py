@@ -209,3 +209,77 @@ def test_structured_blocks_and_pullbacks(bj, orc, K, N, dt):
     Xg, lg = bj.with_logabsdet_jacobian(bj.inverse(bj.VecCorrBijector()), dev(y), per_sample=True)
     close(host(Xg), Xc, dt, scale=20, what="VecCorr inverse")
     close(host(lg), lc, dt, scale=20 * max(n, 1), what="VecCorr inverse ladj")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("N", BATCHES)
+@pytest.mark.parametrize("dim", DIMS)
+def test_spline_and_parameter_pullbacks(bj, orc, dim, N, dt):
+    r = np.random.default_rng(59 * dim + N)
+    K = 5
+    raw = [r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K - 1)).astype(dt)]
+    b = bj.RationalQuadraticSpline(dev(raw[0]), dev(raw[1]), dev(raw[2]), 3.0)
+    w, h, d = (host(t).astype(np.float64) for t in (b.widths, b.heights, b.derivatives))
+    X = F(1.3 * r.normal(size=(dim, N)), dt)
+    X[0, 0] = 4.5                                                     # outside [-B, B]
+    Yr, lr = orc.rqs(w, h, d, X.astype(np.float64))
+    Y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+    close(host(Y), Yr, dt, scale=10, what="spline forward")
+    close(host(l), lr, dt, scale=20 * dim, what="spline ladj")
+    Xb, lb = bj.with_logabsdet_jacobian(bj.inverse(b), dev(Yr.astype(dt)), per_sample=True)
+    close(host(Xb), X, dt, scale=50, what="spline inverse")
+    g, lbar = F(r.normal(size=(dim, N)), dt), r.normal(size=N).astype(dt)
+    for inv, xin in ((False, X), (True, Yr.astype(dt))):
+        xin64 = np.asarray(xin, dtype=np.float64)
+        xb, gk = bj.vjp_params(bj.inverse(b) if inv else b, dev(xin), dev(g), torch.from_numpy(lbar).cuda())
+        close(host(xb), orc.rqs_vjp(w, h, d, xin64, g.astype(np.float64), lbar.astype(np.float64), inverse=inv), dt, scale=100, what=f"spline pullback inverse={inv}")
+        ref = orc.rqs_vjp_knots(w, h, d, xin64, g.astype(np.float64), lbar.astype(np.float64), inverse=inv)
+        for name, rf in zip(("widths", "heights", "derivatives"), ref):
+            close(host(gk[name]), rf, dt, scale=100 * math.sqrt(N), what=f"spline knot cotangent {name} inverse={inv}")
+    # RadialLayer parameters
+    a_raw, b_raw, z0 = np.array([0.3], dtype=dt), np.array([-0.4], dtype=dt), r.normal(size=dim).astype(dt)
+    rad = bj.RadialLayer(dev(a_raw), dev(b_raw), dev(z0))
+    Z = F(r.normal(size=(dim, N)), dt)
+    ab, bb, z0b = orc.radial_param_vjp(a_raw, b_raw, z0, Z, g, lbar)
+    xb, gp = bj.vjp_params(rad, dev(Z), dev(g), torch.from_numpy(lbar).cuda())
+    close(host(xb), orc.radial_vjp(a_raw.astype(np.float64), b_raw.astype(np.float64), z0.astype(np.float64), Z.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64)),
+          dt, scale=50, what="radial vjp_params input side")
+    fl = ATOL[dt] * 100 * math.sqrt(N) * dim
+    assert abs(float(host(gp["alpha_"])[0]) - ab) <= RTOL[dt] * 20 * abs(ab) + fl
+    assert abs(float(host(gp["beta"])[0]) - bb) <= RTOL[dt] * 20 * abs(bb) + fl
+    np.testing.assert_allclose(host(gp["z_0"]), z0b, rtol=RTOL[dt] * 20, atol=fl)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("N", BATCHES)
+@pytest.mark.parametrize("K", [2, 3, 4, 5, 7, 9])
+def test_matrix_blocks_and_scale_matrix(bj, orc, K, N, dt):
+    r = np.random.default_rng(7 * K + N)
+    for name, cls, n in (("corr", bj.CorrBijector, K * K), ("pd", bj.PDBijector, K * K), ("pd_vec", bj.PDVecBijector, K * (K + 1) // 2)):
+        free = 0.4 * r.normal(size=(K * K if name != "pd_vec" else n, N))
+        if name == "pd_vec":
+            y = F(free, dt)
+        else:
+            y = F(free.reshape(K, K, N), dt)
+            if name == "corr":                                                  # strict upper triangle, zeros elsewhere (corr.jl:64-92)
+                y = np.asfortranarray(y * np.triu(np.ones((K, K)), 1)[:, :, None].astype(dt))
+            else:                                                               # lower factor with a free diagonal (pd.jl:1-36)
+                y = np.asfortranarray(y * np.tril(np.ones((K, K)))[:, :, None].astype(dt))
+        Xr, lr = getattr(orc, name)(y, inverse=True)
+        Xg, lg = bj.with_logabsdet_jacobian(bj.inverse(cls()), dev(y), per_sample=True)
+        close(host(Xg), Xr, dt, scale=50, what=f"{name} inverse")
+        close(host(lg), lr, dt, scale=50 * K * K, what=f"{name} inverse ladj")
+        yr, lf = getattr(orc, name)(Xr, inverse=False)
+        yg, lfg = bj.with_logabsdet_jacobian(cls(), dev(np.asarray(Xr).astype(dt)), per_sample=True)
+        close(host(yg), yr, dt, scale=200, what=f"{name} forward")
+        close(host(lfg), lf, dt, scale=200 * K * K, what=f"{name} forward ladj")
+    # Scale with a K x K matrix (scale.jl:14,17,35-36)
+    A = (r.normal(size=(K, K)) / math.sqrt(K) + 1.5 * np.eye(K)).astype(dt)
+    X = F(r.normal(size=(K, N)), dt)
+    sc = bj.Scale(dev(A))
+    Y, l = bj.with_logabsdet_jacobian(sc, dev(X), per_sample=True)
+    A64 = A.astype(np.float64)
+    close(host(Y), A64 @ X.astype(np.float64), dt, scale=20, what="Scale(matrix) values")
+    close(host(l), np.full(N, np.linalg.slogdet(A64)[1]), dt, scale=20 * K, what="Scale(matrix) ladj")
+    Xb = bj.transform(bj.inverse(sc), dev((A64 @ X.astype(np.float64)).astype(dt)))
+    close(host(Xb), X, dt, scale=200, what="Scale(matrix) inverse")
