@@ -283,3 +283,49 @@ def test_matrix_blocks_and_scale_matrix(bj, orc, K, N, dt):
     close(host(l), np.full(N, np.linalg.slogdet(A64)[1]), dt, scale=20 * K, what="Scale(matrix) ladj")
     Xb = bj.transform(bj.inverse(sc), dev((A64 @ X.astype(np.float64)).astype(dt)))
     close(host(Xb), X, dt, scale=200, what="Scale(matrix) inverse")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("N", [2, 63, 130])
+@pytest.mark.parametrize("dim", DIMS)
+def test_batchnorm_training_and_fused_densities(bj, orc, dim, N, dt):
+    r = np.random.default_rng(41 * dim + N)
+    # InvertibleBatchNorm in training mode (normalise.jl:51-60): batch statistics, moving statistics updated in place
+    b_, logs = r.normal(size=dim).astype(dt), (0.3 * r.normal(size=dim)).astype(dt)
+    m0, v0 = r.normal(size=dim).astype(dt), r.uniform(0.5, 2, size=dim).astype(dt)
+    X = F(1.5 * r.normal(size=(dim, N)) + 0.7, dt)
+    bn = bj.InvertibleBatchNorm(dev(b_), dev(logs), dev(m0), dev(v0), eps=1e-5, mtm=0.1)
+    Yr, lr, mr, vr = orc.batchnorm_train(b_, logs, m0, v0, 1e-5, 0.1, X)
+    with bj.training():
+        Y, l = bj.with_logabsdet_jacobian(bn, dev(X))
+    close(host(Y), Yr, dt, scale=20, what="batchnorm training values")
+    close(host(l), lr, dt, scale=20 * dim, what="batchnorm training ladj")
+    close(host(bn.m), mr, dt, scale=5, what="moving mean")
+    close(host(bn.v), vr, dt, scale=5, what="moving variance")
+    # logpdf of a TransformedDistribution, fused into the inverting kernel (transformed_distribution.jl:164-169)
+    nl = 3
+    w = (r.normal(size=(dim, nl)) / math.sqrt(dim)).astype(dt)
+    u = (r.normal(size=(dim, nl)) / math.sqrt(dim)).astype(dt)
+    b = r.normal(size=nl).astype(dt)
+    flow = bj.PlanarLayer(dev(w), dev(u), dev(b))
+    Yq = F(r.normal(size=(dim, N)), dt)
+    x, lj = Yq.copy(), np.zeros(N)
+    for k in range(nl - 1, -1, -1):
+        x, lk = orc.planar(w[:, k], u[:, k], b[k:k + 1], x, inverse=True)
+        lj += lk.astype(np.float64)
+    close(host(bj.logpdf(bj.transformed(bj.MvNormal(dim), flow), dev(Yq))), orc.mvnormal_diag_logpdf(x) + lj, dt, scale=20 * dim, what="logpdf through a planar flow")
+    mu, sg = r.normal(size=dim).astype(dt), np.exp(0.3 * r.normal(size=dim)).astype(dt)
+    ch = bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5)
+    Yp = F(np.exp(0.5 * r.normal(size=(dim, N)) + 0.1), dt)
+    inv_ops = [(orc.OP_LOG, None, None), (orc.OP_SHIFT, -0.1, None), (orc.OP_SCALE_INV, 0.5, None)]
+    ref = np.array([orc.mvnormal_diag_logpdf(*[orc.chain(inv_ops, Yp[:, n:n + 1])[0], mu, sg])[0] + float(orc.chain(inv_ops, Yp[:, n:n + 1])[1]) for n in range(N)])
+    close(host(bj.logpdf(bj.transformed(bj.MvNormal(dev(mu), dev(sg)), ch), dev(Yp))), ref, dt, scale=20 * dim, what="logpdf through a chain, diagonal base")
+    # rand: fused sampling equals fill + transform, bit for bit, and does not depend on the shard split
+    tdr = bj.transformed(bj.MvNormal(dim), ch)
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    A = bj.rand(tdr, N, seed=3, dtype=tdt)
+    B = bj.rand(tdr, N, seed=3, dtype=tdt, fused=False)
+    assert torch.equal(A, B), "fused and unfused sampling differ"
+    if N > 2:
+        C2 = bj.rand(tdr, N - 1, seed=3, dtype=tdt, col0=1)
+        assert torch.equal(C2, A[:, 1:]), "sampling depends on the first column of the shard"
