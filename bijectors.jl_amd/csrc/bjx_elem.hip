@@ -554,13 +554,31 @@ __global__ __launch_bounds__(256) void rqs_vjp_kernel(const T* __restrict__ blob
     lim[j] = blob_l[rp[j]];
     ra[j] = rqs_rec_base<T>(g, j, (int)threadIdx.x, glc);
   }
-  const int64_t col_base = (int64_t)blockIdx.x * iters * cols_per_block + cg;
+  // Straight-line column loop on buffer descriptors with one trip of look-ahead (cf. rqs_body): the next column's x, ȳ and ℓ̄ are in
+  // flight while this one is searched and evaluated; lanes past the end read zeros and drop their stores.
+  const int64_t bcol0 = (int64_t)blockIdx.x * iters * cols_per_block;
+  const int64_t left_blk = batch - bcol0;
+  const int ncols_blk = left_blk > (int64_t)iters * cols_per_block ? iters * cols_per_block : (left_blk > 0 ? (int)left_blk : 0);
+  const int col_bytes = (int)dim * (int)sizeof(T);
+  constexpr int kOob = 0x7fffff00;
+  const int vo = lane_ok ? (cg * (int)dim + gl * V) * (int)sizeof(T) : kOob;
+  const int lo = cg * (int)sizeof(T);
+  const char* xb = reinterpret_cast<const char*>(x + bcol0 * dim);
+  const char* gb = reinterpret_cast<const char*>(gbar + bcol0 * dim);
+  char* ob = reinterpret_cast<char*>(xbar + bcol0 * dim);
+  const char* lbp = reinterpret_cast<const char*>(lbar ? lbar + bcol0 : nullptr);
+  auto extent = [&](int it, int unit) -> uint32_t { const int r = ncols_blk - it * cols_per_block; return r > 0 ? (uint32_t)r * (uint32_t)unit : 0u; };
+  auto rs = [&](const char* b, int it, int unit, bool on) { return bjx_make_rsrc(b + (int64_t)it * cols_per_block * unit, on ? extent(it, unit) : 0u); };
+  Pack<T, V> pn = buf_load_pack<T, V>(rs(xb, 0, col_bytes, true), vo);
+  Pack<T, V> gn = buf_load_pack<T, V>(rs(gb, 0, col_bytes, true), vo);
+  T ln = buf_load_pack<T, 1>(rs(lbp, 0, (int)sizeof(T), lbp != nullptr), lo).v[0];
   for (int it = 0; it < iters; ++it) {
-    const int64_t col = col_base + (int64_t)it * cols_per_block;
-    if (col >= batch || !lane_ok) continue;
-    Pack<T, V> p = load_pack<T, V, true>(x + col * dim + (int64_t)gl * V);
-    const Pack<T, V> gp = load_pack<T, V, true>(gbar + col * dim + (int64_t)gl * V);
-    const T lb = lbar ? lbar[col] : T(0);
+    Pack<T, V> p = pn;
+    const Pack<T, V> gp = gn;
+    const T lb = ln;
+    pn = buf_load_pack<T, V>(rs(xb, it + 1, col_bytes, true), vo);
+    gn = buf_load_pack<T, V>(rs(gb, it + 1, col_bytes, true), vo);
+    ln = buf_load_pack<T, 1>(rs(lbp, it + 1, (int)sizeof(T), lbp != nullptr), lo).v[0];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       int pos = 0;
@@ -573,7 +591,7 @@ __global__ __launch_bounds__(256) void rqs_vjp_kernel(const T* __restrict__ blob
       const Rec4<T> B = lds_rec<T>(rec, RqsRec<T>::RQ / 2);
       p.v[j] = rqs_eval_vjp<T, INV>(A, B, lim[j], p.v[j], gp.v[j], lb);
     }
-    store_pack<T, V, true>(xbar + col * dim + (int64_t)gl * V, p);
+    buf_store_pack<T, V>(rs(ob, it, col_bytes, true), vo, p);
   }
 }
 
