@@ -74,24 +74,10 @@ __device__ __forceinline__ void load_params(const DevOp<T>& op, int64_t r, int64
 // SAMEROW: the U packs of a lane sit at the same rows (the pack stride 256·V is a multiple of dim, or the
 // per-sample geometry): the per-row parameters are loaded ONCE instead of U times — each such load is as wide
 // as the data pack itself, and two vector-parameter stages tripled the load traffic of a density chain.
-template <class T, int V, int U, int ROWMODE, bool SAMEROW = false>
-__device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim, T (&l)[U]) {
+// The arithmetic of one stage on U packs; UA = 1: one parameter pack serves all U packs (same rows), UA = U: one per pack.
+template <class T, int V, int U, int UA>
+__device__ __forceinline__ void apply_kind(const int kind, Pack<T, V> (&p)[U], const T (&a)[UA][V], const T (&b)[UA][V], T (&l)[U]) {
   using F = Fast<T>;
-  const int kind = op.kind;
-  T a[U][V], b[U][V];
-  if (kind != BJX_OP_EXP && kind != BJX_OP_LOG && kind != BJX_OP_SIGNFLIP && kind != BJX_OP_STDNORMAL_LOGPDF) {
-    if constexpr (SAMEROW && U > 1) {
-      load_params<T, V, ROWMODE>(op, r[0], dim, a[0], b[0]);
-#pragma unroll
-      for (int u = 1; u < U; ++u) {
-#pragma unroll
-        for (int j = 0; j < V; ++j) { a[u][j] = a[0][j]; b[u][j] = b[0][j]; }
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < U; ++u) load_params<T, V, ROWMODE>(op, r[u], dim, a[u], b[u]);
-    }
-  }
   switch (kind) {
     case BJX_OP_EXP:  // exp_log.jl:5-6: ladj = sum(x)
       BJX_FOR_UJ { l[u] += p[u].v[j]; p[u].v[j] = F::exp(p[u].v[j]); }       // Float32: v_exp_f32 (the OCML expf is ~15 VALU: a read-only density chain is VALU-bound with it)
@@ -100,41 +86,41 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
       BJX_FOR_UJ { T t = F::log(p[u].v[j]); l[u] -= t; p[u].v[j] = t; }
       break;
     case BJX_OP_SHIFT:  // shift.jl:14
-      BJX_FOR_UJ p[u].v[j] = a[u][j] + p[u].v[j];
+      BJX_FOR_UJ p[u].v[j] = a[UA == 1 ? 0 : u][j] + p[u].v[j];
       break;
     case BJX_OP_SCALE:  // scale.jl:13
-      BJX_FOR_UJ p[u].v[j] = a[u][j] * p[u].v[j];
+      BJX_FOR_UJ p[u].v[j] = a[UA == 1 ? 0 : u][j] * p[u].v[j];
       break;
     case BJX_OP_SCALE_INV:  // scale.jl:15-16: Scale(inv(a))
-      BJX_FOR_UJ p[u].v[j] = F::rcp(a[u][j]) * p[u].v[j];
+      BJX_FOR_UJ p[u].v[j] = F::rcp(a[UA == 1 ? 0 : u][j]) * p[u].v[j];
       break;
     case BJX_OP_LOGIT:  // logit.jl:15,24.  Float32: hardware log/rcp (the OCML versions make this op VALU-bound at 50 % of the roofline)
       BJX_FOR_UJ {
         const T x = p[u].v[j];
-        const T inv = F::rcp(b[u][j] - a[u][j]);
-        const T xa = x - a[u][j], xb = b[u][j] - x;
+        const T inv = F::rcp(b[UA == 1 ? 0 : u][j] - a[UA == 1 ? 0 : u][j]);
+        const T xa = x - a[UA == 1 ? 0 : u][j], xb = b[UA == 1 ? 0 : u][j] - x;
         l[u] -= F::log(xa * xb * inv);
         p[u].v[j] = F::log(xa * F::rcp(xb));                    // logit((x-a)/(b-a)) = log((x-a)/(b-x)), exact at the bounds (±Inf)
       }
       break;
     case BJX_OP_LOGIT_INV:  // logit.jl:19 ; interface.jl:276-281
       BJX_FOR_UJ {
-        const T w = b[u][j] - a[u][j];
-        const T x = w * f_logistic(p[u].v[j]) + a[u][j];
-        l[u] += F::log((x - a[u][j]) * (b[u][j] - x) * F::rcp(w));
+        const T w = b[UA == 1 ? 0 : u][j] - a[UA == 1 ? 0 : u][j];
+        const T x = w * f_logistic(p[u].v[j]) + a[UA == 1 ? 0 : u][j];
+        l[u] += F::log((x - a[UA == 1 ? 0 : u][j]) * (b[UA == 1 ? 0 : u][j] - x) * F::rcp(w));
         p[u].v[j] = x;
       }
       break;
     case BJX_OP_LEAKY_RELU:  // leaky_relu.jl:25-29
       BJX_FOR_UJ {
-        T J = p[u].v[j] < T(0) ? a[u][j] : T(1);
+        T J = p[u].v[j] < T(0) ? a[UA == 1 ? 0 : u][j] : T(1);
         l[u] += F::log(d_abs(J));
         p[u].v[j] = J * p[u].v[j];
       }
       break;
     case BJX_OP_TRUNCATED:  // truncated.jl:15-31,51-67
       BJX_FOR_UJ {
-        T lo = a[u][j], up = b[u][j];
+        T lo = a[UA == 1 ? 0 : u][j], up = b[UA == 1 ? 0 : u][j];
         T x = d_clamp(p[u].v[j], lo, up);
         bool lb = d_isfinite(lo), ub = d_isfinite(up);
         if (lb && ub) {
@@ -151,7 +137,7 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
       break;
     case BJX_OP_TRUNCATED_INV:  // truncated.jl:33-49,71-91
       BJX_FOR_UJ {
-        T lo = a[u][j], up = b[u][j], yv = p[u].v[j];
+        T lo = a[UA == 1 ? 0 : u][j], up = b[UA == 1 ? 0 : u][j], yv = p[u].v[j];
         bool lb = d_isfinite(lo), ub = d_isfinite(up);
         T x;
         if (lb && ub) {
@@ -178,13 +164,73 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
     default: break;
   }
 }
+__device__ __forceinline__ bool kind_has_params(int kind) {
+  return kind != BJX_OP_EXP && kind != BJX_OP_LOG && kind != BJX_OP_SIGNFLIP && kind != BJX_OP_STDNORMAL_LOGPDF;
+}
+// SAMEROW: the U packs of a lane sit at the same rows (the pack stride 256·V is a multiple of dim, or the
+// per-sample geometry): the per-row parameters are loaded ONCE instead of U times — each such load is as wide
+// as the data pack itself, and two vector-parameter stages tripled the load traffic of a density chain.
+template <class T, int V, int U, int ROWMODE, bool SAMEROW = false>
+__device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim, T (&l)[U]) {
+  const int kind = op.kind;
+  T a[U][V], b[U][V];
+  if (kind_has_params(kind)) {
+    if constexpr (SAMEROW && U > 1) {
+      load_params<T, V, ROWMODE>(op, r[0], dim, a[0], b[0]);
+#pragma unroll
+      for (int u = 1; u < U; ++u) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) { a[u][j] = a[0][j]; b[u][j] = b[0][j]; }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) load_params<T, V, ROWMODE>(op, r[u], dim, a[u], b[u]);
+    }
+  }
+  apply_kind<T, V, U, U>(kind, p, a, b, l);
+}
 
 // per-pack log-det contributions lu[u] (the per-sample kernel reduces each pack's column separately)
-template <class T, int V, int U, int ROWMODE, bool SAMEROW = false>
-__device__ __forceinline__ void apply_chain_u(const ChainArgs<T>& A, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim, T (&lu)[U]) {
+// One parameter pack per stage (SAMEROW, or no per-row parameters at all): the descriptor and the parameters of stage
+// k + 1 are fetched BEFORE the arithmetic of stage k.  A stage is one dependent chain kernarg s_load -> branch ->
+// pointer s_load -> table load -> wait, ~0.2 us that nothing else of the wave covers; on a read-only density chain
+// of six stages those chains were a third of the wave's life (PMC: VALU 45 % busy, HBM 37 %, 4 waves/SIMD resident).
+template <class T, int V, int U, int ROWMODE>
+__device__ __forceinline__ void apply_chain_u_prefetch(const ChainArgs<T>& A, Pack<T, V> (&p)[U], int64_t r0, int64_t dim, T (&lu)[U]) {
 #pragma unroll
   for (int u = 0; u < U; ++u) lu[u] = T(0);
-  for (int k = 0; k < A.n_ops; ++k) apply_op<T, V, U, ROWMODE, SAMEROW>(A.ops[k], p, r, dim, lu);
+  const int n_ops = A.n_ops;
+  if (n_ops <= 0) return;
+  int kind = A.ops[0].kind;
+  T a[1][V], b[1][V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { a[0][j] = T(0); b[0][j] = T(0); }
+  if (kind_has_params(kind)) load_params<T, V, ROWMODE>(A.ops[0], r0, dim, a[0], b[0]);
+  for (int k = 0; k < n_ops; ++k) {
+    int kn = BJX_OP_IDENTITY;
+    T an[1][V], bn[1][V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { an[0][j] = T(0); bn[0][j] = T(0); }
+    if (k + 1 < n_ops) {
+      kn = A.ops[k + 1].kind;
+      if (kind_has_params(kn)) load_params<T, V, ROWMODE>(A.ops[k + 1], r0, dim, an[0], bn[0]);
+    }
+    apply_kind<T, V, U, 1>(kind, p, a, b, lu);
+    kind = kn;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { a[0][j] = an[0][j]; b[0][j] = bn[0][j]; }
+  }
+}
+template <class T, int V, int U, int ROWMODE, bool SAMEROW = false>
+__device__ __forceinline__ void apply_chain_u(const ChainArgs<T>& A, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim, T (&lu)[U]) {
+  // scalar-only chains keep the plain loop: nothing but one s_load to cover, and the look-ahead's copies cost 2-6 % (same-call A/B)
+  if constexpr (ROWMODE != 0 && (SAMEROW || U == 1)) {
+    apply_chain_u_prefetch<T, V, U, ROWMODE>(A, p, r[0], dim, lu);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) lu[u] = T(0);
+    for (int k = 0; k < A.n_ops; ++k) apply_op<T, V, U, ROWMODE, SAMEROW>(A.ops[k], p, r, dim, lu);
+  }
 }
 template <class T, int V, int U, int ROWMODE, bool SAMEROW = false>
 __device__ __forceinline__ T apply_chain(const ChainArgs<T>& A, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim) {

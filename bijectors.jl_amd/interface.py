@@ -310,6 +310,8 @@ class Inverse(Transform):
 
 def inverse(t):
     """src/interface.jl:265-266 (+ shift.jl:12, leaky_relu.jl:16, composed inverse, stacked.jl:113-118)"""
+    if t is identity:                                     # `identity` is its own bijector (stacked.jl:21-23, transformed_distribution.jl:20)
+        return identity
     if type(t).__name__ in ("Stacked", "NamedStacked"):
         return t._inverse()
     if type(t).__name__ == "Columnwise":                  # interface.jl:71
@@ -342,6 +344,8 @@ def inverse(t):
 
 def transform(b, x):
     """src/interface.jl:156-166"""
+    if b is identity:
+        return x
     return b._wlj(x, per_sample=False, want_ladj=False)[0]
 
 
@@ -363,6 +367,8 @@ def with_logabsdet_jacobian(b, x, per_sample: bool = False):
 
     per_sample=False reproduces the reference's return shape; per_sample=True always returns the
     per-column log-det vector."""
+    if b is identity:
+        return _run_chain(_stage_ops(b), x, per_sample, True)
     y, l = b._wlj(x, per_sample=per_sample)
     if per_sample:
         return y, l
@@ -677,6 +683,8 @@ def _add_ladj(a, b):
 
 
 def _stage_ops(s):
+    if s is identity:
+        return [(L.OP_IDENTITY, None, None)]
     if isinstance(s, Elementwise):
         return s._ops()
     if isinstance(s, _ChainOp):
@@ -2074,7 +2082,9 @@ class MvNormal:
         """x -> (x - μ)/σ as chain ops; SCALE_INV's log-det supplies the -Σ log σ of the density."""
         ops = []
         if self.mu is not None:
-            ops.append((L.OP_SHIFT, -self.mu, None))
+            if getattr(self, "_neg_mu_src", None) is not self.mu:          # negated once, not on every density call
+                self._neg_mu, self._neg_mu_src = -self.mu, self.mu
+            ops.append((L.OP_SHIFT, self._neg_mu, None))
         if self.sigma is not None:
             ops.append((L.OP_SCALE_INV, self.sigma, None))
         return ops
@@ -2097,7 +2107,7 @@ class TransformedDistribution:
 
 def transformed(dist, b=None):
     """src/transformed_distribution.jl:20-28"""
-    return TransformedDistribution(dist, Elementwise(identity) if b is None else b)
+    return TransformedDistribution(dist, identity if b is None else b)
 
 
 def logpdf(td: TransformedDistribution, y, reference_shape: bool = False):

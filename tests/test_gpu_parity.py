@@ -977,6 +977,26 @@ def test_logpdf_transformed_planar(bj, orc, dim, nl, N, dt):
     np.testing.assert_allclose(got2, orc.mvnormal_diag_logpdf(x, mu, sg) + lj, rtol=RTOL[dt] * 5, atol=ATOL[dt] * dim)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_identity_is_its_own_bijector(bj, orc, dt):
+    """`transformed(d)` of an unconstrained base uses `identity` (src/transformed_distribution.jl:20-28, stacked.jl:21-23):
+    values unchanged, zero log-det, logpdf = the base density, rand = the coloured base samples."""
+    r = rng(74)
+    dim, N = 12, 133
+    mu, sg = r.normal(size=dim).astype(dt), np.exp(0.2 * r.normal(size=dim)).astype(dt)
+    td = bj.transformed(bj.MvNormal(torch.tensor(mu), torch.tensor(sg)))
+    assert td.transform is bj.identity and bj.inverse(bj.identity) is bj.identity
+    Y = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    Yd = dev(Y)
+    assert bj.transform(bj.identity, Yd) is Yd
+    y, l = bj.with_logabsdet_jacobian(bj.identity, Yd, per_sample=True)
+    assert np.array_equal(host(y), Y) and np.array_equal(host(l), np.zeros(N, dtype=dt))
+    np.testing.assert_allclose(host(bj.logpdf(td, Yd)), orc.mvnormal_diag_logpdf(Y, mu, sg), rtol=RTOL[dt], atol=ATOL[dt] * dim)
+    S = host(bj.rand(td, 4096, seed=3, dtype=torch.float32 if dt == np.float32 else torch.float64))
+    z = (S - mu[:, None]) / sg[:, None]
+    assert S.shape == (dim, 4096) and abs(z.mean()) < 0.03 and abs(z.std() - 1.0) < 0.03
+
+
 def test_logpdf_transformed_structured_and_rand(bj, orc):
     dt = np.float64
     r = rng(73)
