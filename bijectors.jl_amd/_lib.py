@@ -101,7 +101,7 @@ SIGNATURES = {
     "bjx_rqs": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp] + _tail),
     "bjx_rqs_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_rqs_params": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i64, _d, _vp, _vp, _vp]),
-    "bjx_rqs_vjp_knots": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "bjx_rqs_vjp_knots": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_rqs_params_vjp": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i64, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bjx_permute": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _i64]),
     "bjx_coupling_affine": (_i, [_vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp] + _tail),

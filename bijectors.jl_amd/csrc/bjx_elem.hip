@@ -979,7 +979,7 @@ int rqs_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, 
 template <class T, class A, bool INV>
 __global__ void rqs_knot_vjp_kernel(const T* __restrict__ w, const T* __restrict__ h, const T* __restrict__ d, int K,
                                     const T* __restrict__ x, const T* __restrict__ gbar, const T* __restrict__ lbar,
-                                    double* __restrict__ acc, int64_t dim, int64_t batch, int cpp) {
+                                    T* __restrict__ xbar, double* __restrict__ acc, int64_t dim, int64_t batch, int cpp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nthr = (int)blockDim.x, t = (int)threadIdx.x;
   const int64_t nk = (int64_t)K * dim;
@@ -1013,8 +1013,12 @@ __global__ void rqs_knot_vjp_kernel(const T* __restrict__ w, const T* __restrict
     T g = ng, lb = nl;
     fetch(ps + gridDim.x);
     if (!ok) continue;
+    const int64_t oidx = (ps * cpp + cl) * dim + row;
     const T wK = w_[(K - 1) * st], hK = h_[(K - 1) * st];
-    if (!(d_abs(xin) < (INV ? hK : wK))) continue;                    // identity outside (-B, B); NaN contributes nothing
+    if (!(d_abs(xin) < (INV ? hK : wK))) {                            // identity outside (-B, B): x̄ = ȳ, no knot contribution (NaN: nothing)
+      if (xbar) xbar[oidx] = g;
+      continue;
+    }
     int k;                                                            // bin k: knots k, k+1 (1-based), knot 0 = -knot K
     {
       const T* sv = INV ? h_ : w_;                                    // Base.searchsortedfirst (ssf above) with 32-bit indices
@@ -1062,6 +1066,8 @@ __global__ void rqs_knot_vjp_kernel(const T* __restrict__ w, const T* __restrict
     const T l_dk = omx * omx * rM - T(2) * p * rden;
     const T l_dk1 = xi * xi * rM - T(2) * p * rden;
     const T Gxi = g * y_xi + lb * l_xi, Gs = g * y_s + lb * l_s, Gdh = g * y_dh;
+    // the input cotangent of the same element (what bjx_rqs_vjp returns): forward ȳ f' + ℓ̄ ℓ_x = Gξ/Δw; inverse (x̄ - ℓ̄ ℓ_x)/f' = -g here
+    if (xbar) xbar[oidx] = INV ? -g : Gxi * iw;
     const T gw_k = (Gxi * (xi - T(1)) + Gs * s) * iw, gw_k1 = -(Gxi * xi + Gs * s) * iw;
     const T gh_k = g - Gdh - Gs * iw, gh_k1 = Gdh + Gs * iw;
     // knot k (1-based) lives at index k-1; knot 0 is -knot K.  Six slots, always distinct (k = 0: the unread derivative of the last
@@ -1101,7 +1107,7 @@ __global__ __launch_bounds__(256) void rqs_knot_vjp_out_kernel(const double* __r
 
 template <class T>
 int rqs_knot_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int K, const T* in, const T* out_bar, const T* ladj_bar,
-                      T* wb, T* hb, T* db, int64_t dim, int64_t batch) {
+                      T* in_bar, T* wb, T* hb, T* db, int64_t dim, int64_t batch) {
   const int64_t nk = (int64_t)K * dim;
   BJX_REQUIRE(ctx, dim <= 256, BJX_ERR_UNSUPPORTED, "bjx_rqs_vjp_knots: at most 256 rows (got %lld)", (long long)dim);
   BJX_REQUIRE(ctx, (size_t)(3 * nk) * sizeof(double) <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_rqs_vjp_knots: knot table too large");
@@ -1121,8 +1127,8 @@ int rqs_knot_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T
     int64_t grid = (int64_t)ctx->num_cu * per_cu;
     if (grid > passes) grid = passes;
     BjxProf prof_(ctx);
-    if (inverse) hipLaunchKernelGGL((rqs_knot_vjp_kernel<T, A, true>), dim3((unsigned)grid), dim3(nthr), bytes(nthr), ctx->stream, w, h, d, K, in, out_bar, ladj_bar, acc, dim, batch, cpp);
-    else hipLaunchKernelGGL((rqs_knot_vjp_kernel<T, A, false>), dim3((unsigned)grid), dim3(nthr), bytes(nthr), ctx->stream, w, h, d, K, in, out_bar, ladj_bar, acc, dim, batch, cpp);
+    if (inverse) hipLaunchKernelGGL((rqs_knot_vjp_kernel<T, A, true>), dim3((unsigned)grid), dim3(nthr), bytes(nthr), ctx->stream, w, h, d, K, in, out_bar, ladj_bar, in_bar, acc, dim, batch, cpp);
+    else hipLaunchKernelGGL((rqs_knot_vjp_kernel<T, A, false>), dim3((unsigned)grid), dim3(nthr), bytes(nthr), ctx->stream, w, h, d, K, in, out_bar, ladj_bar, in_bar, acc, dim, batch, cpp);
     BJX_CHECK_LAUNCH(ctx);
   }
   int g2 = (int)((nk + 255) / 256);
@@ -1491,15 +1497,15 @@ BJX_API int bjx_rqs_params(bjx_ctx* ctx, bjx_dtype dt, const void* raw_w, const 
 }
 
 BJX_API int bjx_rqs_vjp_knots(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* widths, const void* heights, const void* derivs, int n_knots,
-                              const void* in, const void* out_bar, const void* ladj_bar, void* widths_bar, void* heights_bar, void* derivs_bar,
+                              const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, void* widths_bar, void* heights_bar, void* derivs_bar,
                               int64_t dim, int64_t batch) {
   if (!ctx) return BJX_ERR_ARG;
   BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_rqs_vjp_knots: bad size");
   BJX_REQUIRE(ctx, n_knots >= 2, BJX_ERR_SHAPE, "bjx_rqs_vjp_knots: need at least 2 knots");
   BJX_REQUIRE(ctx, widths && heights && derivs && widths_bar && heights_bar && derivs_bar && ((in && out_bar) || batch == 0), BJX_ERR_ARG, "bjx_rqs_vjp_knots: null pointer");
   DISPATCH_DT(ctx, dt,
-               rqs_knot_vjp_impl<float>(ctx, inverse, (const float*)widths, (const float*)heights, (const float*)derivs, n_knots, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)widths_bar, (float*)heights_bar, (float*)derivs_bar, dim, batch),
-               rqs_knot_vjp_impl<double>(ctx, inverse, (const double*)widths, (const double*)heights, (const double*)derivs, n_knots, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)widths_bar, (double*)heights_bar, (double*)derivs_bar, dim, batch),
+               rqs_knot_vjp_impl<float>(ctx, inverse, (const float*)widths, (const float*)heights, (const float*)derivs, n_knots, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, (float*)widths_bar, (float*)heights_bar, (float*)derivs_bar, dim, batch),
+               rqs_knot_vjp_impl<double>(ctx, inverse, (const double*)widths, (const double*)heights, (const double*)derivs, n_knots, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, (double*)widths_bar, (double*)heights_bar, (double*)derivs_bar, dim, batch),
                "bjx_rqs_vjp_knots");
 }
 

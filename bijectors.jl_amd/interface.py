@@ -1924,8 +1924,11 @@ def vjp_params(b, x, out_bar, ladj_bar=None):
     returns (x_bar, {"w": w_bar, "u": u_bar, "b": b_bar}) with the parameter cotangents summed over the batch and the
     shapes of b.w / b.u / b.b (bjx_planar_vjp_params; closed-form derivatives of planar_layer.jl:65-110).
     For a RadialLayer: (x_bar, {"alpha_", "beta", "z_0"}) — see _vjp_params_radial.
+    For inverse(PlanarLayer) / inverse(RadialLayer): the same dictionaries through the implicit function theorem — see _vjp_params_inverse.
     For a RationalQuadraticSpline or its inverse: (x_bar, {"widths", "heights", "derivatives"[, "raw_widths", ...]}) — see _vjp_params_rqs.
     For a chain that starts with Scale and/or Shift: (z_bar, {"scale": σ̄, "shift": μ̄}) — see _vjp_params_leading_affine."""
+    if isinstance(b, Inverse) and isinstance(b.orig, (PlanarLayer, RadialLayer)):
+        return _vjp_params_inverse(b, x, out_bar, ladj_bar)
     if isinstance(b, RadialLayer):
         return _vjp_params_radial(b, x, out_bar, ladj_bar)
     if isinstance(b, RationalQuadraticSpline) or (isinstance(b, Inverse) and isinstance(b.orig, RationalQuadraticSpline)):
@@ -1958,9 +1961,26 @@ def vjp_params(b, x, out_bar, ladj_bar=None):
     return xb, {"w": wb, "u": ub, "b": bbar}
 
 
+def _vjp_params_inverse(ib, y, x_bar, ladj_bar=None):
+    """Parameter pullback of the INVERSE of a flow layer (maximum-likelihood training evaluates inverse(flow) on the data;
+    the reference differentiates it through the `find_alpha` rule, ext/BijectorsChainRulesCoreExt.jl:42-46, layer by layer).
+    Implicit function theorem on the whole stack: with x = f⁻¹(y; θ) and the inverse's log-det -ℓ(x; θ),
+        ȳ = J⁻ᵀ (x̄ - ℓ̄ ∇ₓℓ)                       (the input pullback of the inverse, bjx_planar_vjp / bjx_radial_vjp)
+        θ̄ = (∂f/∂θ)ᵀ(-ȳ) + (-ℓ̄) ∂ℓ/∂θ              (the FORWARD parameter pullback at x with cotangents -ȳ, -ℓ̄)
+    so three existing launches — inverse transform, inverse input pullback, forward parameter pullback — and no new kernel;
+    Newton's root is not differentiated through.  -> (y_bar, the forward layer's parameter dictionary)."""
+    f = ib.orig
+    x = transform(ib, y)
+    y_bar = vjp(ib, y, x_bar, ladj_bar)
+    _, batch = _prep(y)[1:3]
+    lb = None if ladj_bar is None else -_ladj_bar(ladj_bar, batch, _prep(y)[0])
+    _, grads = vjp_params(f, x, -y_bar, lb)
+    return y_bar, grads
+
+
 def _vjp_params_rqs(b, x, out_bar, ladj_bar=None):
-    """RationalQuadraticSpline (or inverse(spline)): input pullback (bjx_rqs_vjp) + the cotangents of the knot arrays summed over
-    the batch (bjx_rqs_vjp_knots; closed-form derivatives of rational_quadratic_spline.jl:128-357 — the reference leaves them to
+    """RationalQuadraticSpline (or inverse(spline)): input pullback + the cotangents of the knot arrays summed over
+    the batch, ONE pass over x, ȳ, ℓ̄ (bjx_rqs_vjp_knots with in_bar; closed-form derivatives of rational_quadratic_spline.jl:128-357 — the reference leaves them to
     the AD package).  A spline built with the `B` constructor (:109-123) also gets the cotangents of its unconstrained
     parameters (bjx_rqs_params_vjp: softmax/cumsum and log1pexp backwards) as "raw_widths", "raw_heights", "raw_derivatives"."""
     inv = isinstance(b, Inverse)
@@ -1971,14 +1991,14 @@ def _vjp_params_rqs(b, x, out_bar, ladj_bar=None):
         raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
     if dim != sp.widths.shape[0]:
         raise ValueError(f"DimensionMismatch: spline with {sp.widths.shape[0]} rows applied to {dim} rows")
-    xb = vjp(b, x, out_bar, ladj_bar)
     w, h, d = (colmajor(_param(t, xc)) for t in (sp.widths, sp.heights, sp.derivatives))
     K1 = int(sp.widths.shape[1])
     lb = _ladj_bar(ladj_bar, batch, xc)
     ctx = context(xc.device)
     outs = [torch.empty((K1, dim), dtype=xc.dtype, device=xc.device).T for _ in range(3)]
+    xb = _empty(dim, batch, xc, vec)
     rc = L.load().bjx_rqs_vjp_knots(ctx.h, _dt(xc), int(inv), _ptr(w), _ptr(h), _ptr(d), K1, _ptr(xc), _ptr(gc), _ptr(lb),
-                                    *[_ptr(o) for o in outs], dim, batch)
+                                    _ptr(xb), *[_ptr(o) for o in outs], dim, batch)
     L.check(ctx.h, rc, "bjx_rqs_vjp_knots")
     grads = {"widths": outs[0], "heights": outs[1], "derivatives": outs[2]}
     if sp._raw is not None and sp._raw[0].dtype == xc.dtype:
@@ -2082,8 +2102,9 @@ class MvNormal:
         """x -> (x - μ)/σ as chain ops; SCALE_INV's log-det supplies the -Σ log σ of the density."""
         ops = []
         if self.mu is not None:
-            if getattr(self, "_neg_mu_src", None) is not self.mu:          # negated once, not on every density call
-                self._neg_mu, self._neg_mu_src = -self.mu, self.mu
+            key = (id(self.mu), self.mu._version)                           # negated once per value of μ (in-place updates bump _version)
+            if getattr(self, "_neg_mu_key", None) != key:
+                self._neg_mu, self._neg_mu_key = -self.mu, key
             ops.append((L.OP_SHIFT, self._neg_mu, None))
         if self.sigma is not None:
             ops.append((L.OP_SCALE_INV, self.sigma, None))

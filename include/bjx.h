@@ -305,11 +305,13 @@ int bjx_rqs_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* widths, con
  * (overwritten) = cotangents of the knot arrays summed over the batch, for the forward map (inverse=0: `in` = x,
  * `out_bar` = ȳ) or the inverse map (inverse=1: `in` = y, `out_bar` = x̄; implicit function theorem at x = f⁻¹(y)).
  * The derivative at the last knot is not read by the spline (constant 1, as in bjx_rqs): its cotangent is 0.
+ * in_bar: NULL, or device T[dim, batch] that receives the input cotangent of bjx_rqs_vjp in the same pass (training wants
+ * both: one read of in / out_bar / ladj_bar instead of two).
  * dim <= 256; Float64 accumulation across blocks.  Reference counterpart: the AD package's pullback of
  * rqs_forward / rqs_univariate_inverse (the reference has no hand-written rule). */
 int bjx_rqs_vjp_knots(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* widths, const void* heights,
                       const void* derivs, int n_knots, const void* in, const void* out_bar, const void* ladj_bar,
-                      void* widths_bar, void* heights_bar, void* derivs_bar, int64_t dim, int64_t batch);
+                      void* in_bar, void* widths_bar, void* heights_bar, void* derivs_bar, int64_t dim, int64_t batch);
 
 /* The `B` constructor, rational_quadratic_spline.jl:109-123: raw_w, raw_h: T[dim,K];
  * raw_d: T[dim,K-1]  ->  widths, heights, derivs: T[dim,K+1]. */

@@ -434,10 +434,14 @@ function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::PlanarLay
     end
     return out, pullback_planar_params
 end
-# inverse(PlanarLayer): input pullback (its parameter cotangents are not produced on the device)
+# inverse(PlanarLayer): input pullback AND parameter cotangents.  Implicit function theorem (the reference differentiates the
+# Newton root through its find_alpha rule, ext/BijectorsChainRulesCoreExt.jl:42-46): with x = f⁻¹(y) and the inverse's log-det
+# -ℓ(x),  ȳ = J⁻ᵀ(x̄ - ℓ̄ ∇ₓℓ)  (bjx_planar_vjp, inverse = 1)  and  θ̄ = the FORWARD parameter pullback at x with cotangents
+# (-ȳ, -ℓ̄)  (bjx_planar_vjp_params) — no new kernel, the root is not differentiated through.
 function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::Inverse{<:PlanarLayer}, z::ROCMatrix{T}) where {T}
     inv = true; pl = flow.orig
     out = with_logabsdet_jacobian(flow, z)
+    x = out[1]                                                  # the pre-image: the point where the forward rule is evaluated
     function pullback_planar((Δy, Δl))
         z̄ = similar(z); Δyc = ROCArray{T}(ChainRulesCore.unthunk(Δy)); Δlc = ROCArray{T}(ChainRulesCore.unthunk(Δl))
         w, u, b = ROCArray{T}(pl.w), ROCArray{T}(pl.u), ROCArray{T}(pl.b)
@@ -445,7 +449,16 @@ function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::Inverse{<
             (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
             ctx().h, dtype(T), Cint(inv), devptr(w), devptr(u), devptr(b), 1, devptr(z), devptr(Δyc), devptr(Δlc), devptr(z̄),
             size(z, 1), size(z, 2)), "bjx_planar_vjp")
-        return ChainRulesCore.NoTangent(), ChainRulesCore.@not_implemented("parameter gradients of inverse(PlanarLayer)"), z̄
+        g, gl = -z̄, -Δlc
+        scratch = similar(z)                                    # the forward rule's input cotangent (= -x̄): not used
+        w̄, ū, b̄ = similar(w), similar(u), similar(b)
+        work = similar(z, 2 * size(z, 2))
+        GC.@preserve x g gl scratch w u b w̄ ū b̄ work check(ccall((:bjx_planar_vjp_params, libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+             Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+            ctx().h, dtype(T), devptr(w), devptr(u), devptr(b), 1, devptr(x), devptr(g), devptr(gl), devptr(scratch),
+            devptr(w̄), devptr(ū), devptr(b̄), devptr(work), size(z, 1), size(z, 2)), "bjx_planar_vjp_params")
+        return ChainRulesCore.NoTangent(), ChainRulesCore.Tangent{typeof(flow)}(orig = ChainRulesCore.Tangent{typeof(pl)}(w = w̄, u = ū, b = b̄)), z̄
     end
     return out, pullback_planar
 end
@@ -466,8 +479,8 @@ function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::RadialLay
     return out, pullback_radial
 end
 
-# RationalQuadraticSpline with matrix parameters: input pullback (bjx_rqs_vjp) AND the cotangents of the knot arrays summed over
-# the batch (bjx_rqs_vjp_knots; rational_quadratic_spline.jl:128-357 has no hand-written rule).  For a spline made by the `B`
+# RationalQuadraticSpline with matrix parameters: input pullback AND the cotangents of the knot arrays summed over
+# the batch in one pass (bjx_rqs_vjp_knots with in_bar; rational_quadratic_spline.jl:128-357 has no hand-written rule).  For a spline made by the `B`
 # constructor (:109-123) the wrapper that owns the raw parameters chains on with `rqs_params_pullback` (bjx_rqs_params_vjp).
 function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), b::RationalQuadraticSpline{<:ROCMatrix{T}}, x::ROCMatrix{T}) where {T}
     out = with_logabsdet_jacobian(b, x)
@@ -476,13 +489,9 @@ function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), b::RationalQuad
         Δyc, Δlc = ROCArray{T}(ChainRulesCore.unthunk(Δy)), ROCArray{T}(ChainRulesCore.unthunk(Δl))
         x̄, w̄, h̄, d̄ = similar(x), similar(b.widths), similar(b.heights), similar(b.derivatives)
         GC.@preserve x Δyc Δlc x̄ w̄ h̄ d̄ begin
-            check(ccall((:bjx_rqs_vjp, libbjx), Cint,
-                (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+            check(ccall((:bjx_rqs_vjp_knots, libbjx), Cint,    # x̄ and the knot cotangents in one pass over x, Δy, Δl
+                (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
                 ctx().h, dtype(T), 0, devptr(b.widths), devptr(b.heights), devptr(b.derivatives), K1, devptr(x), devptr(Δyc), devptr(Δlc), devptr(x̄),
-                size(x, 1), size(x, 2)), "bjx_rqs_vjp")
-            check(ccall((:bjx_rqs_vjp_knots, libbjx), Cint,
-                (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-                ctx().h, dtype(T), 0, devptr(b.widths), devptr(b.heights), devptr(b.derivatives), K1, devptr(x), devptr(Δyc), devptr(Δlc),
                 devptr(w̄), devptr(h̄), devptr(d̄), size(x, 1), size(x, 2)), "bjx_rqs_vjp_knots")
         end
         return ChainRulesCore.NoTangent(), ChainRulesCore.Tangent{typeof(b)}(widths = w̄, heights = h̄, derivatives = d̄), x̄

@@ -1356,10 +1356,13 @@ def test_rqs_knot_pullback_general_knots_and_empty_batch(bj, orc):
     gbar, lbar = np.asfortranarray(r.normal(size=(dim, N))), r.normal(size=N)
     for inv in (False, True):
         ref = orc.rqs_vjp_knots(w, h, d, X, gbar, lbar, inverse=inv)
-        _, g = bj.vjp_params(bj.inverse(b) if inv else b, dev(X), dev(gbar), torch.from_numpy(lbar).cuda())
+        bb = bj.inverse(b) if inv else b
+        xb, g = bj.vjp_params(bb, dev(X), dev(gbar), torch.from_numpy(lbar).cuda())
         for name, rf in zip(("widths", "heights", "derivatives"), ref):
             np.testing.assert_allclose(host(g[name]), rf, rtol=1e-9, atol=1e-9 * max(1.0, float(np.abs(rf).max())), err_msg=f"{name} inv={inv}")
         assert "raw_widths" not in g
+        # the input cotangent written by the same pass = the one of the dedicated kernel
+        np.testing.assert_allclose(host(xb), host(bj.vjp(bb, dev(X), dev(gbar), torch.from_numpy(lbar).cuda())), rtol=1e-11, atol=1e-11)
     _, g0 = bj.vjp_params(b, dev(X[:, :0]), dev(gbar[:, :0]), torch.zeros(0, dtype=torch.float64, device="cuda"))
     assert all(float(g0[k].abs().max()) == 0.0 for k in ("widths", "heights", "derivatives"))
 
@@ -2129,6 +2132,94 @@ def test_radial_parameter_pullback(bj, orc, dim, N, dt):
         assert abs(float(host(g["beta"])[0]) - bb) <= RTOL[dt] * 10 * abs(bb) + fl
         np.testing.assert_allclose(host(g["z_0"]), z0b, rtol=RTOL[dt] * 10, atol=fl)
     assert g["alpha_"].shape == (1,) and g["z_0"].shape == (dim,)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,nl,N", [(5, 2, 40), (16, 3, 129), (128, 8, 300), (3, 1, 17)])
+def test_inverse_planar_parameter_pullback(bj, orc, dim, nl, N, dt):
+    """vjp_params(inverse(PlanarLayer stack)) (§8f f-1; the reference's find_alpha rule, BijectorsChainRulesCoreExt.jl:42-46):
+    implicit function theorem over the whole stack.  Checked two ways: against the oracle's forward parameter pullback at the
+    oracle's pre-image, and — Float64 — against central finite differences of the scalar Σ x̄·x(θ) + Σ ℓ̄·ladj(θ) through the
+    oracle's inverse (an independent statement of the claim)."""
+    r = rng(181)
+    w = (r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(dt)
+    u = (r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(dt)
+    b = r.normal(size=nl).astype(dt)
+    flow = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(b))
+    Y = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    xbar = np.asfortranarray((r.normal(size=(dim, N)) / np.sqrt(N)).astype(dt))
+    lbar = (r.normal(size=N) / np.sqrt(N)).astype(dt)
+
+    def inv64(w_, u_, b_):
+        x, lj = Y.astype(np.float64), np.zeros(N)
+        for k in range(nl - 1, -1, -1):
+            x, l = orc.planar(w_[:, k], u_[:, k], b_[k:k + 1], x, inverse=True)
+            lj = lj + l
+        return x, lj
+
+    w64, u64, b64 = w.astype(np.float64), u.astype(np.float64), b.astype(np.float64)
+    x64, _ = inv64(w64, u64, b64)
+    yb, g = bj.vjp_params(bj.inverse(flow), dev(Y), dev(xbar), torch.from_numpy(lbar).cuda())
+    yb_ref = host(bj.vjp(bj.inverse(flow), dev(Y), dev(xbar), torch.from_numpy(lbar).cuda()))
+    assert np.array_equal(host(yb), yb_ref)
+    wb, ub, bb = orc.planar_param_vjp(w64, u64, b64, x64, -yb_ref.astype(np.float64), -lbar.astype(np.float64))
+    sc = max(1.0, float(np.abs(wb).max()), float(np.abs(ub).max()))
+    tol = dict(rtol=RTOL[dt] * 50, atol=ATOL[dt] * 50 * sc)
+    np.testing.assert_allclose(host(g["w"]), wb, **tol)
+    np.testing.assert_allclose(host(g["u"]), ub, **tol)
+    np.testing.assert_allclose(host(g["b"]), bb, **tol)
+    if dt == np.float64 and dim <= 16:
+        def scalar(w_, u_, b_):
+            x, lj = inv64(w_, u_, b_)
+            return float((xbar * x).sum() + (lbar * lj).sum())
+        h = 1e-6
+        for (arr, name) in ((w64, "w"), (u64, "u"), (b64, "b")):
+            for _ in range(3):
+                idx = tuple(int(r.integers(0, n)) for n in arr.shape)
+                ap, am = arr.copy(), arr.copy()
+                ap[idx] += h
+                am[idx] -= h
+                args_p = [ap if a is arr else a for a in (w64, u64, b64)]
+                args_m = [am if a is arr else a for a in (w64, u64, b64)]
+                fd = (scalar(*args_p) - scalar(*args_m)) / (2 * h)
+                assert abs(float(host(g[name])[idx]) - fd) <= 1e-6 * max(1.0, abs(fd)), (name, idx, fd)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,N", [(5, 60), (64, 300), (130, 33)])
+def test_inverse_radial_parameter_pullback(bj, orc, dim, N, dt):
+    """vjp_params(inverse(RadialLayer)): same implicit-function composition; oracle forward parameter pullback at the oracle's
+    pre-image and (Float64) central finite differences through the oracle's inverse."""
+    r = rng(182)
+    a_raw, b_raw = np.array([0.3], dtype=dt), np.array([-0.4], dtype=dt)
+    z0 = r.normal(size=dim).astype(dt)
+    rad = bj.RadialLayer(torch.tensor(a_raw), torch.tensor(b_raw), torch.tensor(z0))
+    Y = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    xbar = np.asfortranarray((r.normal(size=(dim, N)) / np.sqrt(N)).astype(dt))
+    lbar = (r.normal(size=N) / np.sqrt(N)).astype(dt)
+    a64, b64, z64 = a_raw.astype(np.float64), b_raw.astype(np.float64), z0.astype(np.float64)
+    x64, _ = orc.radial(a64, b64, z64, Y.astype(np.float64), inverse=True)
+    yb, g = bj.vjp_params(bj.inverse(rad), dev(Y), dev(xbar), torch.from_numpy(lbar).cuda())
+    yb64 = host(yb).astype(np.float64)
+    ab, bb, z0b = orc.radial_param_vjp(a64, b64, z64, x64, -yb64, -lbar.astype(np.float64))
+    fl = ATOL[dt] * 100 * np.sqrt(N) * dim
+    assert abs(float(host(g["alpha_"])[0]) - ab) <= RTOL[dt] * 50 * abs(ab) + fl
+    assert abs(float(host(g["beta"])[0]) - bb) <= RTOL[dt] * 50 * abs(bb) + fl
+    np.testing.assert_allclose(host(g["z_0"]), z0b, rtol=RTOL[dt] * 50, atol=fl)
+    if dt == np.float64 and dim <= 64:
+        def scalar(a_, b_, z_):
+            x, lj = orc.radial(a_, b_, z_, Y, inverse=True)
+            return float((xbar * x).sum() + (lbar * lj).sum())
+        h = 1e-6
+        fd_a = (scalar(a64 + h, b64, z64) - scalar(a64 - h, b64, z64)) / (2 * h)
+        fd_b = (scalar(a64, b64 + h, z64) - scalar(a64, b64 - h, z64)) / (2 * h)
+        assert abs(float(host(g["alpha_"])[0]) - fd_a) <= 1e-6 * max(1.0, abs(fd_a))
+        assert abs(float(host(g["beta"])[0]) - fd_b) <= 1e-6 * max(1.0, abs(fd_b))
+        zp, zm = z64.copy(), z64.copy()
+        zp[1] += h
+        zm[1] -= h
+        fd_z = (scalar(a64, b64, zp) - scalar(a64, b64, zm)) / (2 * h)
+        assert abs(float(host(g["z_0"])[1]) - fd_z) <= 1e-6 * max(1.0, abs(fd_z))
 
 
 # ------------------------------------------------------------------ SURVEY.md §8(f) f-4: Corr / VecCorr / PD / PDVec
