@@ -2383,8 +2383,13 @@ namespace {
 // makes both the :U column walk and the :L row walk conflict-free), Δz into a flat strip; every lane walks its
 // column from the diagonal up, writes ΔW in place, zeroes the diagonal and the other triangle (the reference leaves
 // them undefined), and the tile leaves as coalesced 16-byte stores.  Lanes of short columns idle (triangular work:
-// ~50 % lane utilisation); the chunk decomposition of the forward kernel with an affine segmented scan is the
-// next step if this row matters.
+// ~50 % lane utilisation).  Measured alternative (round 2, removed again): TWO samples per wave, lane l of a half-wave
+// walking the column pair (K-1-l, l) — K-1 rows for every lane — on a triangle-only tile (16 KiB per sample): 0.90 ms
+// against 0.66 ms for this kernel at K = 64 x 2^16.  PMC of this kernel: 3 130 VALU instructions per sample of which only
+// ~1 500 are the walk; the rest is the element-wise LDS staging of W (odd pitch: four ds_write_b32 + index arithmetic
+// per 16-byte pack) and the way out.  Balancing the walk therefore removes at most a quarter of the instructions and
+// pays for it with occupancy (4 waves of two samples per CU instead of 6 of one).  What would help is a staging that
+// keeps 16-byte LDS accesses (a swizzled pitch-64 tile), not a different walk.
 template <class T, int V, bool LOWER>
 __global__ __launch_bounds__(64) void chol_fwd_vjp_kernel(const T* __restrict__ W, const T* __restrict__ ybar, T* __restrict__ Wbar, int K, int64_t batch) {
   using F = Fast<T>;

@@ -122,8 +122,8 @@ def main():
     lbr = randn(N, 1, dev, 32).reshape(-1).contiguous()
     rows.append(("vjp(RQS K=16 d=32)", "f-1", lambda: bj.vjp(rqs, xr, gr, lbr), 4 * 3 * dr + 4, N))
     rows.append(("vjp(inverse(RQS K=16 d=32))", "f-1", lambda: bj.vjp(bj.inverse(rqs), yr, gr, lbr), 4 * 3 * dr + 4, N))
-    rows.append(("vjp_params(RQS K=16 d=32): input pullback + knot and raw-parameter cotangents (two passes)", "f-1",
-                 lambda: bj.vjp_params(rqs, xr, gr, lbr), 4 * 5 * dr + 8, N))
+    rows.append(("vjp_params(RQS K=16 d=32): input pullback + knot and raw-parameter cotangents (one pass over x, ȳ, ℓ̄)", "f-1",
+                 lambda: bj.vjp_params(rqs, xr, gr, lbr), 4 * 3 * dr + 4, N))
     perm = bj.Permute(list(torch.randperm(d, generator=torch.Generator().manual_seed(0)).add(1).tolist()))
     add("Permute d=64", "a21", perm, x, per_sample=False)
     mask = bj.PartitionMask(d, list(range(1, d // 2 + 1)), list(range(d // 2 + 1, d + 1)))
@@ -168,6 +168,9 @@ def main():
     rows.append(("vjp(RadialLayer) d=128", "f-1", lambda: bj.vjp(rad, z, gz, lbz), 4 * 3 * dp + 4, Np))
     rows.append(("vjp_params(RadialLayer) d=128 (input pullback with the row sums for z̄₀ in the same pass)", "f-1", lambda: bj.vjp_params(rad, z, gz, lbz), 4 * 3 * dp + 4 + 8 + 64, Np))
     rows.append(("vjp_params(8×PlanarLayer) d=128 (input + w̄, ū, b̄; two passes)", "f-1", lambda: bj.vjp_params(flow, z, gz, lbz), 4 * 5 * dp + 4 + 4 * 4 * nl, Np))
+
+    rows.append(("vjp_params(inverse(8×PlanarLayer)) d=128 (inverse transform + inverse input pullback + forward parameter pullback at the pre-image)", "f-1",
+                 lambda: bj.vjp_params(bj.inverse(flow), zf, gz, lbz), 4 * 2 * dp + 4 * 3 * dp + 4 + 4 * 5 * dp + 4 + 4 * 4 * nl, Np))
 
     # §8(f) f-3: logpdf(td, Y) fused into the inverting kernel — Y is read once, x is never stored
     td_pl = bj.transformed(bj.MvNormal(dp), flow)
