@@ -2390,13 +2390,34 @@ namespace {
 // per 16-byte pack) and the way out.  Balancing the walk therefore removes at most a quarter of the instructions and
 // pays for it with occupancy (4 waves of two samples per CU instead of 6 of one).  What would help is a staging that
 // keeps 16-byte LDS accesses (a swizzled pitch-64 tile), not a different walk.
-template <class T, int V, bool LOWER>
+// SWZ (K a power of two, 16-byte packs): the tile keeps W's own pitch K and column c is XOR-swizzled by c,
+//   W[r, c] at c·K + (r ^ c):  a 16-byte pack of W stays one aligned 16-byte LDS access (its V words permuted by c mod V),
+// and both walks stay conflict-free (:U lanes = columns at a fixed row: banks (r ^ c) are distinct; :L lanes along a row of
+// the tile).  With the odd pitch every pack was V scalar LDS writes with their index arithmetic on the way in and V
+// scalar reads on the way out — PMC: half of the kernel's 3 130 VALU instructions per sample — plus a zero-fill pass
+// over the other triangle, which is now a mask on the way out.
+template <class T, int V> __device__ __forceinline__ Pack<T, V> swz_permute(Pack<T, V> a, int lo) {       // b[m] = a[m ^ lo], lo < V
+  if constexpr (V >= 2) {
+    const bool s1 = lo & 1;
+#pragma unroll
+    for (int m = 0; m < V; m += 2) { const T x = a.v[m], y = a.v[m + 1]; a.v[m] = s1 ? y : x; a.v[m + 1] = s1 ? x : y; }
+  }
+  if constexpr (V >= 4) {
+    const bool s2 = lo & 2;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { const T x = a.v[m], y = a.v[m + 2]; a.v[m] = s2 ? y : x; a.v[m + 2] = s2 ? x : y; }
+  }
+  return a;
+}
+template <class T, int V, bool LOWER, bool SWZ>
 __global__ __launch_bounds__(64) void chol_fwd_vjp_kernel(const T* __restrict__ W, const T* __restrict__ ybar, T* __restrict__ Wbar, int K, int64_t batch) {
   using F = Fast<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int P = K + 1;
+  const int P = SWZ ? K : K + 1;
   T* tile = reinterpret_cast<T*>(smem);
   const int nv = K * (K - 1) / 2;
+  // (Δz in the spare triangle of the swizzled tile — 16 KiB per sample instead of 24 — was measured: 0.60 vs 0.59 ms, the
+  // scatter costs what the occupancy gives)
   T* dz = tile + (((size_t)K * P + 3) / 4) * 4;
   const int lane = threadIdx.x;
   const int64_t s = blockIdx.x;
@@ -2420,9 +2441,14 @@ __global__ __launch_bounds__(64) void chol_fwd_vjp_kernel(const T* __restrict__ 
 #pragma unroll
       for (int u = 0; u < SU; ++u) {
         if (e + u * 64 * V < ne) {
-          int cc = c, rr = r;
+          if constexpr (SWZ) {
+            const Pack<T, V> q = swz_permute<T, V>(p[u], c & (V - 1));
+            *reinterpret_cast<typename Vec16<T>::type*>(tile + c * K + (r ^ (c & ~(V - 1)))) = *reinterpret_cast<const typename Vec16<T>::type*>(&q);
+          } else {
+            int cc = c, rr = r;
 #pragma unroll
-          for (int j = 0; j < V; ++j) { tile[cc * P + rr] = p[u].v[j]; if (++rr == K) { rr = 0; ++cc; } }
+            for (int j = 0; j < V; ++j) { tile[cc * P + rr] = p[u].v[j]; if (++rr == K) { rr = 0; ++cc; } }
+          }
         }
         c += dc; r += dr;
         if (r >= K) { r -= K; ++c; }
@@ -2432,8 +2458,11 @@ __global__ __launch_bounds__(64) void chol_fwd_vjp_kernel(const T* __restrict__ 
     for (int u = 0; u < SZ; ++u) {
       const int i = (lane + 64 * u) * V;
       if (i < nv) {
+        if constexpr (SWZ) *reinterpret_cast<typename Vec16<T>::type*>(dz + i) = *reinterpret_cast<const typename Vec16<T>::type*>(&pz[u]);
+        else {
 #pragma unroll
-        for (int j = 0; j < V; ++j) dz[i + j] = pz[u].v[j];
+          for (int j = 0; j < V; ++j) dz[i + j] = pz[u].v[j];
+        }
       }
     }
     for (int i = (lane + 64 * SZ) * V; i < nv; i += 64 * V) {
@@ -2444,7 +2473,7 @@ __global__ __launch_bounds__(64) void chol_fwd_vjp_kernel(const T* __restrict__ 
   }
   __builtin_amdgcn_wave_barrier();
   // memory index of A[i][j] (A = the upper factor; :L stores its transpose): column-major W -> tile[col*P + row]
-  auto at = [&](int i, int j) -> int { return LOWER ? i * P + j : j * P + i; };
+  auto at = [&](int i, int j) -> int { return SWZ ? (LOWER ? i * K + (j ^ i) : j * K + (i ^ j)) : (LOWER ? i * P + j : j * P + i); };
   for (int jb = 0; jb < K; jb += 64) {
     const int j = jb + lane;
     const bool live = j >= 1 && j < K;
@@ -2499,19 +2528,29 @@ __global__ __launch_bounds__(64) void chol_fwd_vjp_kernel(const T* __restrict__ 
     }
   }
   __builtin_amdgcn_wave_barrier();
-  // diagonal, the other triangle and column/row 0 of it: zeros
-  for (int j = lane; j < K; j += 64)
-    for (int i = j; i < K; ++i) tile[at(i, j)] = T(0);
-  __builtin_amdgcn_wave_barrier();
+  // diagonal, the other triangle and column/row 0 of it: zeros (SWZ: a mask on the way out)
+  if constexpr (!SWZ) {
+    for (int j = lane; j < K; j += 64)
+      for (int i = j; i < K; ++i) tile[at(i, j)] = T(0);
+    __builtin_amdgcn_wave_barrier();
+  }
   {
     T* Os = Wbar + s * (int64_t)K * K;
     int e = lane * V, c = e / K, r = e % K;
     const int dc = (64 * V) / K, dr = (64 * V) % K;
     for (; e < ne; e += 64 * V) {
       Pack<T, V> p;
-      int cc = c, rr = r;
+      if constexpr (SWZ) {
+        Pack<T, V> q;
+        *reinterpret_cast<typename Vec16<T>::type*>(&q) = *reinterpret_cast<const typename Vec16<T>::type*>(tile + c * K + (r ^ (c & ~(V - 1))));
+        p = swz_permute<T, V>(q, c & (V - 1));
 #pragma unroll
-      for (int j = 0; j < V; ++j) { p.v[j] = tile[cc * P + rr]; if (++rr == K) { rr = 0; ++cc; } }
+        for (int j = 0; j < V; ++j) p.v[j] = (LOWER ? r + j > c : r + j < c) ? p.v[j] : T(0);
+      } else {
+        int cc = c, rr = r;
+#pragma unroll
+        for (int j = 0; j < V; ++j) { p.v[j] = tile[cc * P + rr]; if (++rr == K) { rr = 0; ++cc; } }
+      }
       store_pack<T, V, true>(Os + e, p);
       c += dc; r += dr;
       if (r >= K) { r -= K; ++c; }
@@ -2595,17 +2634,20 @@ int chol_fwd_vjp_impl(bjx_ctx* ctx, int uplo, const T* W, const T* y_bar, T* W_b
       return BJX_OK;
     }
   }
+  constexpr int VW = Vec16<T>::N;
+  const bool v_ok = bjx_aligned16(W) && bjx_aligned16(y_bar) && bjx_aligned16(W_bar) && (K * K) % VW == 0 && nv % VW == 0;
+  static const int use_swz = getenv("BJX_CHOL_FWD_VJP_SWZ") ? atoi(getenv("BJX_CHOL_FWD_VJP_SWZ")) : 1;
+  const bool swz = use_swz && v_ok && (K & (K - 1)) == 0 && K >= VW;       // pitch-K tile, XOR-swizzled columns, 16-byte LDS accesses
   const size_t smem = ((((size_t)K * (K + 1) + 3) / 4) * 4 + (size_t)nv + 4) * sizeof(T);
   BJX_REQUIRE(ctx, smem <= BJX_LDS_MAX, BJX_ERR_UNSUPPORTED, "bjx_vec_cholesky_fwd_vjp: K = %lld too large for the LDS tile", (long long)K);
   BJX_REQUIRE(ctx, batch < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
-  constexpr int VW = Vec16<T>::N;
-  const bool v_ok = bjx_aligned16(W) && bjx_aligned16(y_bar) && bjx_aligned16(W_bar) && (K * K) % VW == 0 && nv % VW == 0;
   const bool lower = uplo == 'L';
   {
     BjxProf prof_(ctx);
-#define CFV(V_, L_) do { bjx_allow_big_lds(chol_fwd_vjp_kernel<T, V_, L_>, smem); hipLaunchKernelGGL((chol_fwd_vjp_kernel<T, V_, L_>), dim3((unsigned)batch), dim3(64), smem, ctx->stream, W, y_bar, W_bar, (int)K, batch); } while (0)
-    if (v_ok) { if (lower) CFV(VW, true); else CFV(VW, false); }
-    else { if (lower) CFV(1, true); else CFV(1, false); }
+#define CFV(V_, L_, S_) do { bjx_allow_big_lds(chol_fwd_vjp_kernel<T, V_, L_, S_>, smem); hipLaunchKernelGGL((chol_fwd_vjp_kernel<T, V_, L_, S_>), dim3((unsigned)batch), dim3(64), smem, ctx->stream, W, y_bar, W_bar, (int)K, batch); } while (0)
+    if (swz) { if (lower) CFV(VW, true, true); else CFV(VW, false, true); }
+    else if (v_ok) { if (lower) CFV(VW, true, false); else CFV(VW, false, false); }
+    else { if (lower) CFV(1, true, false); else CFV(1, false, false); }
 #undef CFV
   }
   BJX_CHECK_LAUNCH(ctx);

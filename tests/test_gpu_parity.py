@@ -1124,7 +1124,7 @@ def test_vector_product_of_dirichlets_batched_over_chains(bj, orc, dt):
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("K,N", [(2, 5), (3, 33), (5, 100), (12, 64), (33, 21), (64, 40), (100, 3), (4, 64), (8, 130), (11, 65),
-                                 (13, 7), (20, 9), (63, 5), (32, 1), (64, 129)])   # the column-pair kernel: odd K (a middle column), odd batches (a lone sample)
+                                 (13, 7), (20, 9), (63, 5), (32, 1), (64, 129), (16, 77), (32, 130)])   # powers of two: the swizzled 16-byte tile; others: the odd-pitch tile
 @pytest.mark.parametrize("uplo", ["U", "L"])
 def test_vec_cholesky_forward_link_vjp(bj, orc, K, N, uplo, dt):
     """The rule the reference ships for `_link_chol_lkj_from_upper/lower` (ext/BijectorsChainRulesCoreExt.jl:199-311),
