@@ -345,7 +345,9 @@ __global__ __launch_bounds__(256) void chain_flatcol_kernel(const ChainArgs<T> A
     const int64_t i = i0 + u * 256;
     const bool ok = full || i < nv;
     if (ok && y) store_pack<T, V, NT>(y + i * V, p[u]);
-    const T l = group_sum<G>(ok ? lu[u] : T(0));
+    T l;
+    if constexpr (sizeof(T) == 4) l = group_sum_f32_dpp<G>(ok ? lu[u] : T(0));     // in-row stages as DPP adds (a ds_bpermute stage is ~6 VALU + an LDS round trip)
+    else l = group_sum<G>(ok ? lu[u] : T(0));
     if (ok && gl == 0) {
       const int64_t col = i / G;
       T out = l + (T)c_ps;

@@ -468,6 +468,15 @@ template <class T> __device__ __forceinline__ T group_sum_rt(T v, int G) {
 template <int CTRL> __device__ __forceinline__ float dpp_xadd(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+template <int G> __device__ __forceinline__ float group_sum_f32_dpp(float v) {          // compile-time G: the same DPP stages
+  if constexpr (G >= 2) v = dpp_xadd<0xB1>(v);
+  if constexpr (G >= 4) v = dpp_xadd<0x4E>(v);
+  if constexpr (G >= 8) v = dpp_xadd<0x141>(v);
+  if constexpr (G >= 16) v = dpp_xadd<0x140>(v);
+  if constexpr (G >= 32) v += shfl_xor(v, 16);
+  if constexpr (G >= 64) v += shfl_xor(v, 32);
+  return v;
+}
 template <> __device__ __forceinline__ float group_sum_rt<float>(float v, int G) {
   if (G >= 2) v = dpp_xadd<0xB1>(v);     // quad_perm [1,0,3,2]
   if (G >= 4) v = dpp_xadd<0x4E>(v);     // quad_perm [2,3,0,1]
