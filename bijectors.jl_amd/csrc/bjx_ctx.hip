@@ -42,6 +42,9 @@ __global__ __launch_bounds__(256) void bjx_reduce_slices_kernel(const double* __
 
 int bjx_ensure_partials(bjx_ctx* ctx, size_t n) {
   if (n <= ctx->partials_cap) return BJX_OK;
+  // growing frees and allocates (both synchronise): not something a stream capture can record — run the step once
+  // outside the capture first (CapturedStep does), the buffer then has its size
+  BJX_REQUIRE(ctx, !ctx->capturing, BJX_ERR_UNSUPPORTED, "the per-block partials buffer must grow (%zu blocks) inside a graph capture: run the step once before capturing it", n);
   size_t cap = ctx->partials_cap ? ctx->partials_cap : (size_t)BJX_MAX_BLOCKS;
   while (cap < n) cap *= 2;
   if (ctx->partials) BJX_HIP(ctx, hipFree(ctx->partials));   // synchronises: earlier launches are done with it
@@ -80,6 +83,11 @@ int bjx_make_fin(bjx_ctx* ctx, int64_t grid, double* ladj_sum, double host_const
   if (rc) return rc;
   fin->partials = ctx->partials;
   if (ctx->opt_inkernel_fin && grid <= BJX_INKERNEL_FIN_MAX) {
+    // EXPERIMENTAL (off unless BJX_OPT_INKERNEL_FINALIZE / BJX_INKERNEL_FIN asks for it): the hand-off relies on sc1
+    // stores and loads being served at the device-coherent level on gfx950, not on the HSA memory model's guarantees.
+    // The arrival counter is zeroed by the host before every launch: a launch that faulted or was aborted must not leave
+    // a count behind that would make every later sum of this context silently wrong.
+    BJX_HIP(ctx, hipMemsetAsync(ctx->fin_counter, 0, sizeof(unsigned), ctx->stream));
     fin->counter = ctx->fin_counter;
     fin->out = ladj_sum;
     fin->host_const = host_const;
@@ -101,6 +109,10 @@ BJX_API int bjx_create(int device, void* hip_stream, bjx_ctx** out) {
   if (!ctx) return BJX_ERR_ARG;
   ctx->device = device;
   ctx->stream = static_cast<hipStream_t>(hip_stream);
+  // the caller's current device is put back before returning: the context allocates on ITS device, it does not move the
+  // process (a host runtime such as torch keeps its own notion of the current device)
+  int prev_device = -1;
+  (void)hipGetDevice(&prev_device);
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMalloc(&ctx->partials, sizeof(double) * BJX_MAX_BLOCKS);
   if (e == hipSuccess) ctx->partials_cap = BJX_MAX_BLOCKS;
@@ -117,6 +129,7 @@ BJX_API int bjx_create(int device, void* hip_stream, bjx_ctx** out) {
     e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
+  if (prev_device >= 0 && prev_device != device) (void)hipSetDevice(prev_device);
   if (e != hipSuccess) {
     int code = (int)e;
     bjx_destroy(ctx);

@@ -66,6 +66,11 @@ def context(device: Optional[torch.device] = None) -> _Ctx:
     if not torch.cuda.is_available():
         raise RuntimeError("bijectors_amd needs a ROCm GPU; there is no CPU fallback")
     dev = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+    if dev != torch.cuda.current_device():
+        # the entry points launch on the context's stream and allocate their scratch lazily: both follow the CURRENT device.
+        # One process per GPU (the design) never gets here; a multi-GPU process must select the device first.
+        raise ValueError(f"tensor on cuda:{dev} but the current device is cuda:{torch.cuda.current_device()}: "
+                         f"call torch.cuda.set_device({dev}) (one process per GPU is the supported layout)")
     stream = torch.cuda.current_stream(dev).cuda_stream
     key = (dev, stream)
     c = _ctx_cache.get(key)
