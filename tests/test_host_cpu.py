@@ -87,6 +87,14 @@ def test_chain_walk_and_inverse(bj):
     assert not bj.isclosedform(bj.inverse(bj.PlanarLayer([1.0, 2.0], [0.5, 0.1], [0.0])))   # planar_layer.jl:188
     # elementwise of a composition distributes (interface.jl:37-39)
     assert bj.elementwise(bj.identity) is bj.identity
+    # `identity` is its own bijector: the default of transformed(d) (transformed_distribution.jl:20-28), its own inverse, one no-op stage
+    assert bj.inverse(bj.identity) is bj.identity
+    assert [o[0] for o in I._fused_ops(bj.identity)] == [L.OP_IDENTITY]
+    td = bj.transformed(bj.MvNormal(3))
+    assert td.transform is bj.identity
+    # the inverse of a flow layer keeps the layer: its parameter pullback is the forward one at the pre-image (implicit function theorem)
+    pl = bj.PlanarLayer([1.0, 2.0], [0.5, 0.1], [0.0])
+    assert bj.inverse(pl).orig is pl and bj.inverse(bj.inverse(pl)) is pl
 
 
 def test_output_size(bj):
