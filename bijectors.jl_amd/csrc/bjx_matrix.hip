@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64) void matrix_link_kernel(const T* __restrict__ i
 }
 #undef a
 
-// ------------------------------------------------------------------ small matrices: ONE LANE per sample (K <= 8)
+// ------------------------------------------------------------------ small matrices: ONE LANE per sample (K <= 12)
 // The LKJ / Wishart blocks of real models are 2x2 ... 8x8.  With lanes along the rows a wave holds 8 such samples and every
 // column step is an LDS round trip for a handful of FMAs (K = 8: 11 % of the roofline).  Here a wave takes 64 consecutive
 // samples — one contiguous run of the input and of the output, moved with 16-byte accesses through a [64][P odd] LDS tile
@@ -527,7 +527,8 @@ template <class T, int KMAX, int KIND>
 int launch_lane(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* partials, int K, int P, int64_t batch, int accum, bool vec, int grid,
                 size_t smem) {
   constexpr int VW = Vec16<T>::N;
-#define BJX_ML(INV_, V_) hipLaunchKernelGGL((matrix_lane_kernel<T, KMAX, KIND, INV_, V_>), dim3(grid), dim3(64), smem, ctx->stream, in, out, ladj_ps, K, P, batch, accum, partials)
+#define BJX_ML(INV_, V_) do { bjx_allow_big_lds(matrix_lane_kernel<T, KMAX, KIND, INV_, V_>, smem); \
+  hipLaunchKernelGGL((matrix_lane_kernel<T, KMAX, KIND, INV_, V_>), dim3(grid), dim3(64), smem, ctx->stream, in, out, ladj_ps, K, P, batch, accum, partials); } while (0)
   if (inverse) { if (vec) BJX_ML(true, VW); else BJX_ML(true, 1); }
   else { if (vec) BJX_ML(false, VW); else BJX_ML(false, 1); }
 #undef BJX_ML
@@ -557,8 +558,11 @@ int matrix_impl(bjx_ctx* ctx, const char* who, int inverse, const T* in, T* out,
   constexpr int VW = Vec16<T>::N;
   const int64_t KK = K * K;
   const int64_t nv = KIND == MK_VEC_CORR ? K * (K - 1) / 2 : (KIND == MK_PD_VEC ? K * (K + 1) / 2 : KK);
-  static const int lane_max = getenv("BJX_MATRIX_LANE_MAX") ? atoi(getenv("BJX_MATRIX_LANE_MAX")) : 8;   // tuning switch (0: lanes along the rows for every K)
-  if (K <= lane_max && K <= 8) {
+  // one lane per sample up to K = 12 (78 registers for the triangle; the tile of 64 samples is 64 x (K² | 1) words, 37 KiB at
+  // K = 12).  The lanes-along-the-rows kernel pays an LDS round trip per column step: K = 9: 8 -> 36-48 % of the roofline,
+  // K = 12: 15 -> 33-45 %.  K = 16 was measured too (136 registers, 66 KiB tile, two waves per CU): 22-30 % against 27-33 % — not kept.
+  static const int lane_max = getenv("BJX_MATRIX_LANE_MAX") ? atoi(getenv("BJX_MATRIX_LANE_MAX")) : 12;   // tuning switch (0: lanes along the rows for every K)
+  if (K <= lane_max && K <= 12) {
     // one lane per sample (matrix_lane_kernel)
     const int64_t rows = KK > nv ? KK : nv;
     const int P = (int)(rows | 1);
@@ -572,7 +576,8 @@ int matrix_impl(bjx_ctx* ctx, const char* who, int inverse, const T* in, T* out,
     {
       BjxProf prof_(ctx);
       if (K <= 4) launch_lane<T, 4, KIND>(ctx, inverse, in, out, ladj_ps, partials_l, (int)K, P, batch, (flags & BJX_ACCUMULATE) ? 1 : 0, vec, grid_l, smem_l);
-      else launch_lane<T, 8, KIND>(ctx, inverse, in, out, ladj_ps, partials_l, (int)K, P, batch, (flags & BJX_ACCUMULATE) ? 1 : 0, vec, grid_l, smem_l);
+      else if (K <= 8) launch_lane<T, 8, KIND>(ctx, inverse, in, out, ladj_ps, partials_l, (int)K, P, batch, (flags & BJX_ACCUMULATE) ? 1 : 0, vec, grid_l, smem_l);
+      else launch_lane<T, 12, KIND>(ctx, inverse, in, out, ladj_ps, partials_l, (int)K, P, batch, (flags & BJX_ACCUMULATE) ? 1 : 0, vec, grid_l, smem_l);
     }
     BJX_CHECK_LAUNCH(ctx);
     if (ladj_sum) return bjx_launch_finalize(ctx, grid_l, ladj_sum, 0.0, 0, 0.0, flags);

@@ -2250,7 +2250,7 @@ def _matrix_free(kind, K, batch, r, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("K,batch", [(2, 33), (3, 129), (5, 64), (8, 257), (13, 65), (16, 40), (24, 31), (32, 70), (33, 9), (50, 17), (64, 21), (1, 5)])
+@pytest.mark.parametrize("K,batch", [(2, 33), (3, 129), (5, 64), (8, 257), (9, 130), (10, 65), (11, 64), (12, 257), (13, 65), (16, 40), (24, 31), (32, 70), (33, 9), (50, 17), (64, 21), (1, 5)])
 @pytest.mark.parametrize("kind", MATRIX_KINDS)
 def test_matrix_bijectors_match_oracle(bj, orc, kind, K, batch, dt):
     """corr.jl:64-162, pd.jl:1-60 batched: inverse (unconstrained -> matrix) and forward (matrix -> unconstrained)
