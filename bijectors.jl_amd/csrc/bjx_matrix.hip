@@ -787,20 +787,39 @@ __global__ __launch_bounds__(256) void scale_matrix_mfma_kernel(const T* __restr
       for (int ks = 0; ks < NKS; ++ks) areg[rb][ks] = Ms[(rb * NKS + ks) * 64 + lane];
   }
   const int64_t tile_stride = (int64_t)gridDim.x * 4 * 16;
+  // the packs of the NEXT tile are in flight while this one goes through LDS, the MFMA loop and out again (a tile is
+  // ~0.9 us of MFMA behind an HBM round trip: without the look-ahead every tile paid the round trip first)
+  constexpr int NPK = (16 * DP) / (64 * VW);             // packs per lane and tile
+  Pack<T, VW> nxt[NPK];
+  auto fetch = [&](int64_t c0n) {
+    if (!vec_ok || c0n >= batch) return;
+    const int nen = (int)((batch - c0n) < 16 ? (batch - c0n) : 16) * dim;
+#pragma unroll
+    for (int u = 0; u < NPK; ++u) {
+      const int e = (lane + 64 * u) * VW;
+#pragma unroll
+      for (int t = 0; t < VW; ++t) nxt[u].v[t] = T(0);
+      if (e < nen) nxt[u] = load_pack<T, VW, true>(X + c0n * dim + e);
+    }
+  };
+  fetch(((int64_t)blockIdx.x * 4 + wave) * 16);
   for (int64_t c0 = ((int64_t)blockIdx.x * 4 + wave) * 16; c0 < batch; c0 += tile_stride) {
     const int nc = (int)((batch - c0) < 16 ? (batch - c0) : 16);
     const int ne = nc * dim;                             // contiguous elements of the tile
     // ---- stage the tile: xs[c*P + k] = X[k, c0 + c]; rows >= dim and columns >= nc are zero
     for (int e = lane; e < 16 * (DP - dim) ; e += 64) { const int c = e / (DP - dim), k = dim + e % (DP - dim); xs[c * P + k] = T(0); }
     if (vec_ok) {
-      for (int e = lane * VW; e < 16 * dim; e += 64 * VW) {
-        Pack<T, VW> p;
+      Pack<T, VW> cur[NPK];
 #pragma unroll
-        for (int t = 0; t < VW; ++t) p.v[t] = T(0);
-        if (e < ne) p = load_pack<T, VW, true>(X + c0 * dim + e);
-        const int c = e / dim, k = e - c * dim;          // VW | dim: a pack stays inside one column
+      for (int u = 0; u < NPK; ++u) cur[u] = nxt[u];
+      fetch(c0 + tile_stride);
 #pragma unroll
-        for (int t = 0; t < VW; ++t) xs[c * P + k + t] = p.v[t];
+      for (int u = 0; u < NPK; ++u) {
+        const int e = (lane + 64 * u) * VW;
+        if (e < 16 * dim) {
+          const int c = e / dim, k = e - c * dim;        // VW | dim: a pack stays inside one column; P and k are multiples of VW: one 16-byte LDS write
+          *reinterpret_cast<typename Vec16<T>::type*>(xs + c * P + k) = *reinterpret_cast<const typename Vec16<T>::type*>(&cur[u]);
+        }
       }
     } else {
       for (int e = lane; e < 16 * dim; e += 64) { const int c = e / dim, k = e - c * dim; xs[c * P + k] = e < ne ? X[c0 * dim + e] : T(0); }
@@ -836,8 +855,7 @@ __global__ __launch_bounds__(256) void scale_matrix_mfma_kernel(const T* __restr
         for (int e = lane * VW; e < ne; e += 64 * VW) {
           const int c = e / dim, k = e - c * dim;
           Pack<T, VW> p;
-#pragma unroll
-          for (int t = 0; t < VW; ++t) p.v[t] = xs[c * P + k + t];
+          *reinterpret_cast<typename Vec16<T>::type*>(&p) = *reinterpret_cast<const typename Vec16<T>::type*>(xs + c * P + k);
           store_pack<T, VW, true>(Y + c0 * dim + e, p);
         }
       } else {
