@@ -1737,9 +1737,12 @@ def vjp(b, x, out_bar, ladj_bar=None):
     `columnwise(f)` through the kernels above."""
     if isinstance(b, Stacked):
         return b._vjp(x, out_bar, ladj_bar)
-    if _elementwise_ops(b) is not None:                 # any chain of elementwise bijectors = one segment over all rows
+    ops_ = _elementwise_ops(b)
+    if ops_ is not None and len(ops_) <= L.BJX_MAX_SEG_OPS:   # a chain of elementwise bijectors = one segment over all rows
         dim = x.shape[0]
         return Stacked([b], [(1, dim)])._vjp(x, out_bar, ladj_bar)
+    if isinstance(b, ComposedFunction):                  # longer chains, compositions of layers: the chain rule piece by piece
+        return _vjp_composed(b, x, out_bar, ladj_bar)
     inv = isinstance(b, Inverse)
     base = b.orig if inv else b
     if inv and isinstance(base, VecCholeskyBijector):
@@ -1869,6 +1872,67 @@ def vjp(b, x, out_bar, ladj_bar=None):
     return xb
 
 
+def _pieces(b):
+    """A composition cut into pieces that have a device pullback: runs of elementwise stages of at most BJX_MAX_SEG_OPS ops
+    (one fused launch each), every other stage alone.  Application order."""
+    pieces, run, nops = [], [], 0
+    for st in b._stages():
+        o = _stage_ops(st)
+        if o is not None and len(o) <= L.BJX_MAX_SEG_OPS:
+            if nops + len(o) > L.BJX_MAX_SEG_OPS:
+                pieces.append(_chain_of(run))
+                run, nops = [], 0
+            run.append(st)
+            nops += len(o)
+            continue
+        if run:
+            pieces.append(_chain_of(run))
+            run, nops = [], 0
+        pieces.append(st)
+    if run:
+        pieces.append(_chain_of(run))
+    return pieces
+
+
+def _vjp_composed(b, x, out_bar, ladj_bar=None):
+    """Pullback of a composition f_n ∘ … ∘ f_1 (what an AD package does with the per-stage rules): forward through the pieces to
+    get every piece's input, then x̄ = Σ-free chain rule backwards — the log-det is the SUM of the pieces' log-dets, so every
+    piece receives the same ℓ̄.  Flows composed of different layers (planar ∘ radial ∘ …) and elementwise chains longer than
+    one fused segment come here."""
+    pieces = _pieces(b)
+    inputs = [x]
+    for pc in pieces[:-1]:
+        inputs.append(transform(pc, inputs[-1]))
+    g = out_bar
+    for pc, xin in zip(reversed(pieces), reversed(inputs)):
+        g = vjp(pc, xin, g, ladj_bar)
+    return g
+
+
+def _has_own_params(st):
+    base = st.orig if isinstance(st, Inverse) else st
+    return isinstance(base, (PlanarLayer, RadialLayer, RationalQuadraticSpline, InvertibleBatchNorm))
+
+
+def _vjp_params_composed(b, x, out_bar, ladj_bar=None):
+    """Input AND parameter pullback of a composition of layers (planar ∘ radial ∘ spline ∘ affine …): the chain rule of
+    _vjp_composed with `vjp_params` at every stage that owns parameters (flow layers, splines, BatchNorm, Scale / Shift) and
+    `vjp` at the others.  Returns (x_bar, {"stages": [None | that stage's dictionary, ...]}) in application order."""
+    stages = b._stages()
+    inputs = [x]
+    for st in stages[:-1]:
+        inputs.append(transform(st, inputs[-1]))
+    g = out_bar
+    grads = [None] * len(stages)
+    for i in range(len(stages) - 1, -1, -1):
+        st = stages[i]
+        if _has_own_params(st) or (isinstance(st, (Scale, Shift)) and not getattr(st, "matrix", False)):
+            g, grads[i] = vjp_params(st, inputs[i], g, ladj_bar)
+        else:
+            g = vjp(st, inputs[i], g, ladj_bar)
+    return g, {"stages": grads}
+
+
 def row_moments(a, b=None):
     """(Σ_n a[:, n], Σ_n a[:, n]·b[:, n]) over the batch as two float64 (dim,) tensors (bjx_row_moments; b=None: a²)."""
     ac, dim, batch, _ = _prep(a)
@@ -1924,6 +1988,60 @@ def _vjp_params_leading_affine(b, x, out_bar, ladj_bar):
     return zb, out
 
 
+def _chain_of(stages):
+    """ComposedFunction of `stages` given in APPLICATION order (first applied first); one stage stays itself."""
+    out = stages[0]
+    for st in stages[1:]:
+        out = ComposedFunction(st, out)
+    return out
+
+
+def _vjp_params_affine_anywhere(b, x, out_bar, ladj_bar=None):
+    """Parameter pullback of EVERY `Scale(a)` / `Shift(b)` stage of a chain, wherever it sits (the parameter side of the Scale
+    adjoints in ext/BijectorsReverseDiffExt.jl:69-115; the reference leaves chains to the AD package).  The chain is cut at its
+    affine stages: forward through the pieces to get each stage's input z, then backwards — `vjp` of a piece, and at a stage with
+    the cotangent g of its output
+        Shift(b):  b̄ = Σ_n g_n,                     input cotangent g
+        Scale(a):  ā = Σ_n g_n ⊙ z_n + Σ_n ℓ̄_n / a,   input cotangent a ⊙ g        (log|a| is in every column's log-det)
+    (row sums: bjx_row_moments; scalar parameters get the sum over the rows).  A host composition of existing launches — a few
+    passes per affine stage; the mean-field head `tail ∘ Shift ∘ Scale` keeps its one-pass kernel (_vjp_params_leading_affine).
+    Returns (x_bar, {"stages": [None | cotangent, ...]}) aligned with the chain's stages in application order."""
+    stages = b._stages() if isinstance(b, ComposedFunction) else [b]
+    aff = [i for i, st in enumerate(stages) if isinstance(st, (Scale, Shift)) and not getattr(st, "matrix", False)]
+    if not aff:
+        raise NotImplementedError(f"no device parameter pullback for {b!r}: the chain has no Scale / Shift stage (SURVEY.md §8f f-1)")
+    xc, dim, batch, _ = _prep(x)
+    lsum = 0.0
+    if ladj_bar is not None:
+        lsum = float(ladj_bar) * batch if not isinstance(ladj_bar, torch.Tensor) else ladj_bar.to(torch.float64).sum()
+    # forward: the input of every piece / affine stage
+    cuts = []                       # (piece stages before the affine stage, input of the piece, affine stage index, input of the affine stage)
+    cur, lo = x, 0
+    for i in aff:
+        piece = stages[lo:i]
+        z = transform(_chain_of(piece), cur) if piece else cur
+        cuts.append((piece, cur, i, z))
+        cur = transform(stages[i], z)
+        lo = i + 1
+    tail = stages[lo:]
+    # backward
+    g = vjp(_chain_of(tail), cur, out_bar, ladj_bar) if tail else out_bar
+    grads = [None] * len(stages)
+    for piece, pin, i, z in reversed(cuts):
+        st = stages[i]
+        s1, s2 = row_moments(g, z)
+        if isinstance(st, Shift):
+            grads[i] = (s1 if _is_seq(st.a) else s1.sum()).to(xc.dtype)
+        else:
+            a64 = _param(st.a, xc).to(torch.float64).reshape(-1)
+            ab = s2 + lsum / a64
+            grads[i] = (ab if _is_seq(st.a) else ab.sum()).to(xc.dtype)
+            g = transform(Scale(st.a), g)
+        if piece:
+            g = vjp(_chain_of(piece), pin, g, ladj_bar)
+    return g, {"stages": grads}
+
+
 def vjp_params(b, x, out_bar, ladj_bar=None):
     """Pullback of `with_logabsdet_jacobian(b, x)` onto the input AND the parameters of a PlanarLayer (stack):
     returns (x_bar, {"w": w_bar, "u": u_bar, "b": b_bar}) with the parameter cotangents summed over the batch and the
@@ -1931,7 +2049,9 @@ def vjp_params(b, x, out_bar, ladj_bar=None):
     For a RadialLayer: (x_bar, {"alpha_", "beta", "z_0"}) — see _vjp_params_radial.
     For inverse(PlanarLayer) / inverse(RadialLayer): the same dictionaries through the implicit function theorem — see _vjp_params_inverse.
     For a RationalQuadraticSpline or its inverse: (x_bar, {"widths", "heights", "derivatives"[, "raw_widths", ...]}) — see _vjp_params_rqs.
-    For a chain that starts with Scale and/or Shift: (z_bar, {"scale": σ̄, "shift": μ̄}) — see _vjp_params_leading_affine."""
+    For a chain that starts with Scale and/or Shift: (z_bar, {"scale": σ̄, "shift": μ̄}) — see _vjp_params_leading_affine.
+    For a chain with Scale / Shift stages anywhere else: (x_bar, {"stages": [...]}) — see _vjp_params_affine_anywhere.
+    For a composition that contains flow layers / splines / BatchNorm: (x_bar, {"stages": [...]}) — see _vjp_params_composed."""
     if isinstance(b, Inverse) and isinstance(b.orig, (PlanarLayer, RadialLayer)):
         return _vjp_params_inverse(b, x, out_bar, ladj_bar)
     if isinstance(b, RadialLayer):
@@ -1940,8 +2060,18 @@ def vjp_params(b, x, out_bar, ladj_bar=None):
         return _vjp_params_rqs(b, x, out_bar, ladj_bar)
     if isinstance(b, InvertibleBatchNorm):
         return _vjp_params_batchnorm(b, x, out_bar, ladj_bar)
+    if isinstance(b, ComposedFunction) and any(_has_own_params(st) for st in b._stages()):
+        return _vjp_params_composed(b, x, out_bar, ladj_bar)
     if not isinstance(b, PlanarLayer):
-        return _vjp_params_leading_affine(b, x, out_bar, ladj_bar)
+        stages = b._stages() if isinstance(b, ComposedFunction) else [b]
+        lead = 0
+        if lead < len(stages) and isinstance(stages[lead], Scale):
+            lead += 1
+        if lead < len(stages) and isinstance(stages[lead], Shift):
+            lead += 1
+        if lead > 0 and not any(isinstance(st, (Scale, Shift)) for st in stages[lead:]):
+            return _vjp_params_leading_affine(b, x, out_bar, ladj_bar)
+        return _vjp_params_affine_anywhere(b, x, out_bar, ladj_bar)
     xc, dim, batch, vec = _prep(x)
     gc, gdim, gbatch, _ = _prep(out_bar)
     if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:

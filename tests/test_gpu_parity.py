@@ -2136,6 +2136,123 @@ def test_radial_parameter_pullback(bj, orc, dim, N, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,N", [(6, 50), (64, 257), (13, 33)])
+def test_affine_stage_parameters_anywhere_in_a_chain(bj, orc, dim, N, dt):
+    """vjp_params of exp ∘ Shift(b_vec) ∘ Scale(a_vec) ∘ LeakyReLU(0.3) ∘ Shift(0.2) ∘ Scale(1.7): cotangents of ALL four affine
+    stages (two scalar ones at the head, two per-row ones behind a nonlinear stage; ext/BijectorsReverseDiffExt.jl:69-115 is the
+    parameter side for one Scale).  Reference: central finite differences of Σ ȳ·y(θ) + Σ ℓ̄·ladj(θ) through the oracle's chain."""
+    r = rng(191)
+    av = np.exp(0.3 * r.normal(size=dim))
+    bv = r.normal(size=dim)
+    s0, t0 = 1.7, 0.2
+    X = np.asfortranarray(r.normal(size=(dim, N)))
+    ybar = np.asfortranarray(r.normal(size=(dim, N)) / np.sqrt(N))
+    lbar = r.normal(size=N) / np.sqrt(N)
+
+    def scalar(s0_, t0_, av_, bv_, x_=X):
+        ops = [(orc.OP_SCALE, s0_, None), (orc.OP_SHIFT, t0_, None), (orc.OP_LEAKY_RELU, 0.3, None),
+               (orc.OP_SCALE, av_, None), (orc.OP_SHIFT, bv_, None), (orc.OP_EXP, None, None)]
+        tot = 0.0
+        for n in range(N):
+            y, lj = orc.chain(ops, x_[:, n:n + 1])
+            tot += float((ybar[:, n:n + 1] * y).sum()) + float(lbar[n]) * float(lj)
+        return tot
+
+    b = (bj.elementwise(bj.exp) @ bj.Shift(torch.tensor(bv.astype(dt))) @ bj.Scale(torch.tensor(av.astype(dt))) @ bj.LeakyReLU(0.3)
+         @ bj.Shift(t0) @ bj.Scale(s0))
+    xb, g = bj.vjp_params(b, dev(X.astype(dt)), dev(ybar.astype(dt)), torch.from_numpy(lbar.astype(dt)).cuda())
+    st = g["stages"]
+    assert [v is not None for v in st] == [True, True, False, True, True, False]
+    h = 1e-6
+    tol = (lambda ref: 2e-6 * max(1.0, abs(ref))) if dt == np.float64 else (lambda ref: 2e-3 * max(1.0, abs(ref)))
+    fd = (scalar(s0 + h, t0, av, bv) - scalar(s0 - h, t0, av, bv)) / (2 * h)
+    assert abs(float(host(st[0])) - fd) <= tol(fd), ("scale0", float(host(st[0])), fd)
+    fd = (scalar(s0, t0 + h, av, bv) - scalar(s0, t0 - h, av, bv)) / (2 * h)
+    assert abs(float(host(st[1])) - fd) <= tol(fd), ("shift0", float(host(st[1])), fd)
+    for row in (0, dim - 1, dim // 2):
+        e = np.zeros(dim)
+        e[row] = h
+        fd = (scalar(s0, t0, av + e, bv) - scalar(s0, t0, av - e, bv)) / (2 * h)
+        assert abs(float(host(st[3])[row]) - fd) <= tol(fd), ("scale vec", row, float(host(st[3])[row]), fd)
+        fd = (scalar(s0, t0, av, bv + e) - scalar(s0, t0, av, bv - e)) / (2 * h)
+        assert abs(float(host(st[4])[row]) - fd) <= tol(fd), ("shift vec", row, float(host(st[4])[row]), fd)
+    # the input cotangent is the plain pullback of the whole chain
+    ref_xb = host(bj.vjp(b, dev(X.astype(dt)), dev(ybar.astype(dt)), torch.from_numpy(lbar.astype(dt)).cuda()))
+    np.testing.assert_allclose(host(xb), ref_xb, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 50)
+    # the mean-field head keeps its one-pass path and its dictionary
+    _, g2 = bj.vjp_params(bj.elementwise(bj.exp) @ bj.Shift(torch.tensor(bv.astype(dt))) @ bj.Scale(torch.tensor(av.astype(dt))),
+                          dev(X.astype(dt)), dev(ybar.astype(dt)))
+    assert set(g2) == {"scale", "shift"}
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_composed_flow_pullbacks(bj, orc, dt):
+    """A flow composed of different layers — exp∘Shift(c) ∘ RadialLayer ∘ PlanarLayer(2 layers) ∘ Scale(a_vec) — through `vjp`
+    (chain rule piece by piece, the same ℓ̄ to every piece) and `vjp_params` (every stage's own parameter rule).  Reference:
+    central finite differences of Σ ȳ·y + Σ ℓ̄·ladj through the oracle's forward functions, for inputs and one parameter of
+    every stage."""
+    r = rng(193)
+    dim, N, nl = 6, 48, 2
+    av = np.exp(0.2 * r.normal(size=dim))
+    w = r.normal(size=(dim, nl)) / np.sqrt(dim)
+    u = r.normal(size=(dim, nl)) / np.sqrt(dim)
+    pb = r.normal(size=nl)
+    a_raw, b_raw, z0 = np.array([0.3]), np.array([-0.4]), r.normal(size=dim)
+    c = 0.25
+    X = np.asfortranarray(r.normal(size=(dim, N)))
+    ybar = np.asfortranarray(r.normal(size=(dim, N)) / np.sqrt(N))
+    lbar = r.normal(size=N) / np.sqrt(N)
+
+    def scalar(X_, av_, w_, b_raw_, c_):
+        tot = 0.0
+        y, lj = orc.chain([(orc.OP_SCALE, av_, None)], X_)                       # one Σ over the matrix: handled per column below
+        lj_cols = np.full(N, np.log(np.abs(av_)).sum())
+        for k in range(nl):
+            y, l = orc.planar(w_[:, k], u[:, k], pb[k:k + 1], y)
+            lj_cols = lj_cols + l
+        y, l = orc.radial(a_raw, b_raw_, z0, y)
+        lj_cols = lj_cols + l
+        y = y + c_
+        lj_cols = lj_cols + y.sum(axis=0)
+        y = np.exp(y)
+        return float((ybar * y).sum() + (lbar * lj_cols).sum())
+
+    T = lambda a: torch.tensor(np.asarray(a).astype(dt))
+    flow = (bj.elementwise(bj.exp) @ bj.Shift(c)) @ bj.RadialLayer(T(a_raw), T(b_raw), T(z0)) @ bj.PlanarLayer(T(w), T(u), T(pb)) @ bj.Scale(T(av))
+    Xd, gd, ld = dev(X.astype(dt)), dev(ybar.astype(dt)), torch.from_numpy(lbar.astype(dt)).cuda()
+    # forward agrees with the oracle composition first
+    y_dev, l_dev = bj.with_logabsdet_jacobian(flow, Xd, per_sample=True)
+    base = scalar(X, av, w, b_raw, c)
+    got = float((ybar * host(y_dev)).sum() + (lbar * host(l_dev)).sum())
+    assert abs(got - base) <= (1e-9 if dt == np.float64 else 2e-3) * max(1.0, abs(base))
+    xb = host(bj.vjp(flow, Xd, gd, ld))
+    xb2, g = bj.vjp_params(flow, Xd, gd, ld)
+    np.testing.assert_allclose(host(xb2), xb, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 50)
+    st = g["stages"]
+    assert [type(s_).__name__ for s_ in flow._stages()] == ["Scale", "PlanarLayer", "RadialLayer", "Shift", "Elementwise"]
+    assert st[4] is None and set(st[1]) == {"w", "u", "b"} and set(st[2]) == {"alpha_", "beta", "z_0"}
+    h = 1e-6
+    tol = (lambda ref: 5e-6 * max(1.0, abs(ref))) if dt == np.float64 else (lambda ref: 5e-3 * max(1.0, abs(ref)))
+    for (i, n) in ((0, 0), (3, 7), (dim - 1, N - 1)):
+        E = np.zeros_like(X)
+        E[i, n] = h
+        fd = (scalar(X + E, av, w, b_raw, c) - scalar(X - E, av, w, b_raw, c)) / (2 * h)
+        assert abs(xb[i, n] - fd) <= tol(fd), ("x", i, n, xb[i, n], fd)
+    e = np.zeros(dim)
+    e[2] = h
+    fd = (scalar(X, av + e, w, b_raw, c) - scalar(X, av - e, w, b_raw, c)) / (2 * h)
+    assert abs(float(host(st[0]["scale"])[2]) - fd) <= tol(fd), ("scale", fd)
+    Ew = np.zeros_like(w)
+    Ew[1, 1] = h
+    fd = (scalar(X, av, w + Ew, b_raw, c) - scalar(X, av, w - Ew, b_raw, c)) / (2 * h)
+    assert abs(float(host(st[1]["w"])[1, 1]) - fd) <= tol(fd), ("planar w", fd)
+    fd = (scalar(X, av, w, b_raw + h, c) - scalar(X, av, w, b_raw - h, c)) / (2 * h)
+    assert abs(float(host(st[2]["beta"])[0]) - fd) <= tol(fd), ("radial beta", fd)
+    fd = (scalar(X, av, w, b_raw, c + h) - scalar(X, av, w, b_raw, c - h)) / (2 * h)
+    assert abs(float(host(st[3]["shift"])) - fd) <= tol(fd), ("shift", fd)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("dim,nl,N", [(5, 2, 40), (16, 3, 129), (128, 8, 300), (3, 1, 17)])
 def test_inverse_planar_parameter_pullback(bj, orc, dim, nl, N, dt):
     """vjp_params(inverse(PlanarLayer stack)) (§8f f-1; the reference's find_alpha rule, BijectorsChainRulesCoreExt.jl:42-46):
