@@ -1462,7 +1462,9 @@ class Stacked(Transform):
             raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
         segs_ops = [_elementwise_ops(b) for b in self.bs]
         if any(o is None or len(o) > L.BJX_MAX_SEG_OPS for o in segs_ops) or self.length_out != dim:
-            raise NotImplementedError("device pullback of Stacked needs every segment to be a chain of <= 4 elementwise bijectors")
+            if moments:
+                raise NotImplementedError("row moments of a Stacked pullback need every segment to be a chain of <= 4 elementwise bijectors")
+            return self._vjp_by_segment(xc, gc, ladj_bar, batch, vec)
         arr, keep = self._segments(segs_ops, list(range(len(self.bs))), xc)
         lb = _ladj_bar(ladj_bar, batch, xc)
         ctx = context(xc.device)
@@ -1476,6 +1478,25 @@ class Stacked(Transform):
         rc = L.load().bjx_stacked_vjp(ctx.h, _dt(xc), arr, len(self.bs), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
         del keep
         L.check(ctx.h, rc, "bjx_stacked_vjp")
+        return xb
+
+    def _vjp_by_segment(self, xc, gc, ladj_bar, batch, vec):
+        """Pullback of a Stacked with structured segments (Simplex / Ordered / LKJ blocks, long chains): the segments act on
+        disjoint row ranges and the log-det is their sum (stacked.jl:168-252), so x̄[ranges_in[i]] = vjp(bs[i], x[ranges_in[i]],
+        ȳ[ranges_out[i]], ℓ̄) with the same ℓ̄ for every segment — what HMC differentiates for a mixed-constraint model.  The
+        row ranges are gathered into dense blocks (one copy in, one out per segment)."""
+        xb = torch.empty((xc.shape[0],), dtype=xc.dtype, device=xc.device) if vec else _empty(xc.shape[0], batch, xc, False)
+        covered = torch.zeros(xc.shape[0], dtype=torch.bool)
+        for b, (ilo, ihi), (olo, ohi) in zip(self.bs, self.ranges_in, self.ranges_out):
+            xi = xc[ilo - 1:ihi] if vec else colmajor(xc[ilo - 1:ihi, :])
+            gi = gc[olo - 1:ohi] if vec else colmajor(gc[olo - 1:ohi, :])
+            if b is identity:
+                xb[ilo - 1:ihi] = gi
+            else:
+                xb[ilo - 1:ihi] = vjp(b, xi.contiguous() if vec else xi, gi.contiguous() if vec else gi, ladj_bar)
+            covered[ilo - 1:ihi] = True
+        if not bool(covered.all()):
+            raise ValueError("Stacked: the input ranges must cover every row for a pullback")
         return xb
 
     def _wlj_in_place(self, xc, dim, batch, vec, y, out, segs_ops, fused, rest, per_sample, want_ladj, ctx):

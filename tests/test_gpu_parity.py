@@ -2185,6 +2185,43 @@ def test_affine_stage_parameters_anywhere_in_a_chain(bj, orc, dim, N, dt):
     assert set(g2) == {"scale", "shift"}
 
 
+def test_stacked_pullback_with_structured_segments(bj, orc):
+    """vjp of a mixed-constraint Stacked (exp∘Shift∘Scale | Simplex | Logit | Ordered | identity: 64 → 63 rows) — what HMC
+    differentiates for a Turing model: per-segment pullbacks with the same ℓ̄ (stacked.jl:168-252: the log-det is the sum).
+    Reference: Float64 central differences of Σ ȳ·y + Σ ℓ̄·ladj through the DEVICE forward (itself oracle-checked in
+    test_stacked_mixed_one_launch_and_window_fallback), and the segments' own pullbacks."""
+    r = rng(197)
+    N = 37
+    e = bj.elementwise
+    st = bj.Stacked([e(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5), bj.SimplexBijector(), bj.Logit(0.0, 1.0), bj.OrderedBijector(), bj.identity],
+                    [(1, 16), (17, 32), (33, 44), (45, 60), (61, 64)])
+    X = r.normal(size=(64, N))
+    sm = np.exp(X[16:32])
+    X[16:32] = sm / sm.sum(axis=0, keepdims=True)
+    X[32:44] = r.uniform(0.05, 0.95, size=(12, N))
+    X[44:60] = np.sort(X[44:60], axis=0)
+    X = np.asfortranarray(X)
+    ybar = np.asfortranarray(r.normal(size=(63, N)))
+    lbar = r.normal(size=N)
+    Xd, gd, ld = dev(X), dev(ybar), torch.from_numpy(lbar).cuda()
+    xb = host(bj.vjp(st, Xd, gd, ld))
+    assert xb.shape == (64, N)
+    # segment by segment
+    np.testing.assert_allclose(xb[:16], host(bj.vjp(st.bs[0], dev(np.asfortranarray(X[:16])), dev(np.asfortranarray(ybar[:16])), ld)), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(xb[16:32], host(bj.vjp(st.bs[1], dev(np.asfortranarray(X[16:32])), dev(np.asfortranarray(ybar[16:31])), ld)), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(xb[60:], ybar[59:], rtol=0, atol=0)
+
+    def scalar(Xp):
+        y, l = bj.with_logabsdet_jacobian(st, dev(np.asfortranarray(Xp)), per_sample=True)
+        return float((ybar * host(y)).sum() + (lbar * host(l)).sum())
+    h = 1e-6
+    for (i, n) in ((3, 0), (35, 5), (50, 20), (62, 36)):      # exp∘affine, Logit, Ordered, identity rows (Simplex rows are constrained: checked above)
+        E = np.zeros_like(X)
+        E[i, n] = h
+        fd = (scalar(X + E) - scalar(X - E)) / (2 * h)
+        assert abs(xb[i, n] - fd) <= 2e-6 * max(1.0, abs(fd)), (i, n, xb[i, n], fd)
+
+
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_composed_flow_pullbacks(bj, orc, dt):
     """A flow composed of different layers — exp∘Shift(c) ∘ RadialLayer ∘ PlanarLayer(2 layers) ∘ Scale(a_vec) — through `vjp`
