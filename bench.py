@@ -474,7 +474,7 @@ def main():
     rows, strong = [], []
     want_rows = (not a.no_rows) and a.workload == "c2" and a.log2_batch is None
     if want_rows:
-        rsteps, rwarm = max(3, min(a.steps, 10)), max(1, min(a.warmup, 3))
+        rsteps, rwarm = max(3, min(a.steps, 20)), max(1, min(a.warmup, 5))      # the sub-lines run as warm as the headline
         for r in [r for r in a.rows.split(",") if r]:
             try:
                 rows.append(measure(env, r, rsteps, rwarm, a.scaling))
