@@ -409,6 +409,51 @@ __global__ __launch_bounds__(256) void chain_colgroup_kernel(const ChainArgs<T> 
   if (partials) block_publish_partial(acc, red, partials);
 }
 
+// Per-sample variant for columns of at most G packs (one pack per lane) that are NOT a power of two of them (dim = 100, 200,
+// 252 ...): the group kernel above keeps ONE pack per lane in flight for such shapes (33 % of the roofline).  Here a block
+// takes U times as many columns and every lane holds the packs of U different columns — the same rows, so the per-row
+// parameters are fetched once — before the chain runs: U loads in flight per lane like the flat kernels.
+template <class T, int V, int ROWMODE, bool NT, int U>
+__global__ __launch_bounds__(256) void chain_colbatch_kernel(const ChainArgs<T> A, const T* x, T* y, T* ladj_ps, int64_t dim, int64_t batch, int G,
+                                                             double c_ps_host, const double* c_ps_dev, int accumulate, double* partials) {
+  __shared__ double red[4];
+  const int gl = threadIdx.x & (G - 1);
+  const int cols_per_block = 256 / G;
+  const int64_t col0 = (int64_t)blockIdx.x * cols_per_block * U + threadIdx.x / G;
+  const int64_t nvc = dim / V;
+  const bool lane_ok = gl < nvc;
+  Pack<T, V> p[U];
+  int64_t r[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t col = col0 + (int64_t)u * cols_per_block;
+    r[u] = (int64_t)gl * V;
+    if (lane_ok && col < batch) p[u] = load_pack<T, V, NT>(x + col * dim + (int64_t)gl * V);
+    else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) p[u].v[j] = T(1);      // harmless input for every op; results discarded
+    }
+  }
+  T lu[U];
+  apply_chain_u<T, V, U, ROWMODE, true>(A, p, r, dim, lu);
+  const double c_ps = c_ps_host + (c_ps_dev ? *c_ps_dev : 0.0);
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t col = col0 + (int64_t)u * cols_per_block;
+    const bool ok = lane_ok && col < batch;
+    if (ok && y) store_pack<T, V, NT>(y + col * dim + (int64_t)gl * V, p[u]);
+    const T l = group_sum_rt(ok ? lu[u] : T(0), G);
+    if (col < batch && gl == 0) {
+      T out = l + (T)c_ps;
+      if (accumulate) out += ladj_ps[col];
+      ladj_ps[col] = out;
+      acc += (double)l;
+    }
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
 // Parameter-only log-det terms of Scale ops whose `a` lives on the device (scale.jl:26-32):
 //   consts[0] = per-sample constant  Σ_ops ± Σ_i log|a_i|           (scalar a: dim * log|a|)
 //   consts[1] = total added to ladj_sum: batch * consts[0], except that with
@@ -560,8 +605,13 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
     // 4-byte accesses here (dim = 10: 12 % of the roofline).  The column walker of bjx_stacked_mixed moves 64 consecutive
     // columns as ONE contiguous run of 16-byte packs whatever the column height and gives every column to a lane, so the
     // per-sample log-det needs no cross-lane sum either: the chain goes there as a single elementwise segment.
+    // The same holds for columns that ARE whole packs but not a power-of-two number of them (dim = 24, 48, 100, 200 ...): the
+    // group kernel below keeps one pack per lane in flight there (33 % of the roofline; the walker: 63-67 %).
     static const int use_walker = env_int("BJX_CHAIN_WALKER", 1);
-    if (use_walker && !v_ok && y && (const void*)x != (const void*)y && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0 && n_ops <= BJX_MAX_SEG_OPS && dim >= 1) {
+    bool pow2_packs = false;
+    if (v_ok) { const int64_t pk = dim / VW; pow2_packs = pk <= 64 && (pk & (pk - 1)) == 0; }
+    static const int walker_max = env_int("BJX_CHAIN_WALKER_MAX", 32);      // whole-pack columns taller than this: chain_colbatch_kernel (the walker's tile costs occupancy)
+    if (use_walker && !pow2_packs && (!v_ok || dim <= walker_max) && y && (const void*)x != (const void*)y && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0 && n_ops <= BJX_MAX_SEG_OPS && dim >= 1) {
       bool plain = true;
       for (int k = 0; k < n_ops; ++k) plain = plain && ops[k].kind >= BJX_OP_EXP && ops[k].kind <= BJX_OP_IDENTITY;
       if (plain) {
@@ -602,6 +652,25 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
       return BJX_OK;
     }
     const int cols_per_block = 256 / G;
+    static const int use_colbatch = env_int("BJX_CHAIN_COLBATCH", 1);
+    if (use_colbatch && v_ok && packs <= G && (!any_row || rows_vec)) {
+      // one pack per lane and column, not a power of two of them: four columns in flight per lane (chain_colbatch_kernel)
+      constexpr int UB = 4;
+      grid = (batch + (int64_t)cols_per_block * UB - 1) / ((int64_t)cols_per_block * UB);
+      BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_chain: input too large for one launch");
+      if (ladj_sum) { int rc_ = bjx_ensure_partials(ctx, (size_t)grid); if (rc_) return rc_; }
+      double* partials = ladj_sum ? ctx->partials : nullptr;
+#define LAUNCH_CB(RM_, NT_) hipLaunchKernelGGL((chain_colbatch_kernel<T, VW, RM_, NT_, UB>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, x, y, ladj_ps, dim, batch, G, c_ps_host, cdev, accum, partials)
+      {
+        BjxProf prof_(ctx);
+        if (!any_row) { if (nt) LAUNCH_CB(0, true); else LAUNCH_CB(0, false); }
+        else { if (nt) LAUNCH_CB(1, true); else LAUNCH_CB(1, false); }
+      }
+#undef LAUNCH_CB
+      BJX_CHECK_LAUNCH(ctx);
+      if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, c_sum_host, any_dev_scale ? 1 : 0, 0.0, flags);
+      return BJX_OK;
+    }
     grid = (batch + cols_per_block - 1) / cols_per_block;
     BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_chain: input too large for one launch");
     if (ladj_sum) { int rc_ = bjx_ensure_partials(ctx, (size_t)grid); if (rc_) return rc_; }

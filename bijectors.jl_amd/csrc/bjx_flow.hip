@@ -1147,7 +1147,9 @@ __device__ __forceinline__ void reg_update(const float* __restrict__ tab, int l0
 // summed values and update their own rows.  Same bytes, half the registers per wave, twice the waves in flight.
 // The partial-sum buffers are double-buffered by group parity, so a wave that runs ahead cannot overwrite what its
 // partner is still reading.
-template <int NL, bool INV>
+// NW = 4: the same with FOUR waves per tile (one tile per block) for 128 < dim <= 256 — those heights used to fall to the
+// LDS-tile kernel (one lane per column over a 64 x dim tile: 8-22 % of the roofline) or the generic group kernel.
+template <int NL, bool INV, int NW = 2>
 __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A, const float* __restrict__ x, float* __restrict__ y,
                                                           float* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate, const BjxFin fin) {
   constexpr int G = 16, COLS = 64, CPS = 4, NS = 16;
@@ -1155,11 +1157,11 @@ __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A,
   __shared__ __attribute__((aligned(16))) float sT[4][COLS * NL];        // tanh values of my tile (each wave its own copy)
   __shared__ double red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = wave >> 1, half = wave & 1, partner = wave ^ 1;
+  const int tile = wave / NW, half = wave % NW;              // half = which 64-row slice of the tile
   const int gl = lane & (G - 1), cg = lane / G;
   const int row0 = half * 64;
   const bool row_ok = row0 + 4 * gl < dim;
-  const int64_t col0 = ((int64_t)blockIdx.x * 2 + tile) * COLS;
+  const int64_t col0 = ((int64_t)blockIdx.x * (4 / NW) + tile) * COLS;
   const int64_t left = batch - col0;
   const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
   const int64_t step_elems = (int64_t)CPS * dim;
@@ -1179,13 +1181,18 @@ __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A,
   for (int gi = 0; gi < ngroups; ++gi) {
     const int l0 = (INV ? ngroups - 1 - gi : gi) * NL;
     float* mineS = sS[gi & 1][wave];
-    const float* otherS = sS[gi & 1][partner];
     reg_dots<G, NL, NS>(A.w, l0, dim, z, mineS, lane, gl, cg, row_ok, row0);
-    __syncthreads();                                         // both halves of every tile have published their partial sums
+    __syncthreads();                                         // every slice of every tile has published its partial sums
     {
       float s[NL], t[NL];
 #pragma unroll
-      for (int k = 0; k < NL; ++k) { s[k] = mineS[lane * NL + k] + otherS[lane * NL + k]; t[k] = 0.f; }
+      for (int k = 0; k < NL; ++k) {
+        float acc_ = sS[gi & 1][tile * NW][lane * NL + k];   // fixed order over the slices: every wave of the tile gets the same bits
+#pragma unroll
+        for (int pp = 1; pp < NW; ++pp) acc_ += sS[gi & 1][tile * NW + pp][lane * NL + k];
+        s[k] = acc_;
+        t[k] = 0.f;
+      }
 #pragma unroll
       for (int kk = 0; kk < NL; ++kk) {
         const int k = INV ? NL - 1 - kk : kk;
@@ -1213,9 +1220,8 @@ __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A,
     __builtin_amdgcn_wave_barrier();
   }
   if (accumulate & 2) {
-    // BJX_BASE_STDNORMAL: |out|² of a column = my 64 rows + my partner's 64 rows
+    // BJX_BASE_STDNORMAL: |out|² of a column = the 64-row slices of all the tile's waves
     float* mineS = sS[ngroups & 1][wave];
-    const float* otherS = sS[ngroups & 1][partner];
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
       float q[1];
@@ -1224,7 +1230,10 @@ __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A,
       if ((lane & 15) == 0) mineS[r * CPS + cg] = q[0];
     }
     __syncthreads();
-    ladj += -0.5f * (mineS[lane] + otherS[lane]) - (float)dim * 0.91893853320467274178f;
+    float q2 = sS[ngroups & 1][tile * NW][lane];
+#pragma unroll
+    for (int pp = 1; pp < NW; ++pp) q2 += sS[ngroups & 1][tile * NW + pp][lane];
+    ladj += -0.5f * q2 - (float)dim * 0.91893853320467274178f;
   }
   if (y) {
     float* py = y + (col0 + cg) * dim + row0 + 4 * gl;
@@ -1989,7 +1998,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
   // register kernel (Float32, 16-byte packs, 20 <= dim <= 128): see planar_reg_kernel
   static const int use_reg = getenv("BJX_PLANAR_REG") ? atoi(getenv("BJX_PLANAR_REG")) : 1;
   if constexpr (sizeof(T) == 4) {
-    if (use_reg && dim % 4 == 0 && dim > 16 && dim <= 128 && bjx_aligned16(in) && bjx_aligned16(out)) {
+    if (use_reg && dim % 4 == 0 && dim > 16 && dim <= 256 && bjx_aligned16(in) && bjx_aligned16(out)) {
       const int NL = nl >= 8 ? 8 : (nl > 2 ? 4 : nl);
       const int nl_pad = (nl + NL - 1) / NL * NL;
       const size_t off0 = ((size_t)nl * dim + nl + 3) / 4 * 4;   // floats, keeps the padded tables 16-byte aligned
@@ -2012,8 +2021,9 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         // redundant recurrence cost more than the third wave per SIMD buys: 147 VGPRs, and forcing 128 spills) —
         // so only deep forward stacks take it.  BJX_PLANAR_SPLIT = 0 / 1 forces it off / on.
         static const int split_env = getenv("BJX_PLANAR_SPLIT") ? atoi(getenv("BJX_PLANAR_SPLIT")) : -1;
-        const bool split = G == 32 && (split_env >= 0 ? split_env != 0 : (!inverse && nl >= 8));
-        const int64_t grid = split ? (batch + 2 * 64 - 1) / (2 * 64) : (batch + 4 * cols - 1) / (4 * cols);
+        const bool quad = dim > 128;                                 // four waves per tile (128 < dim <= 256)
+        const bool split = quad || (G == 32 && (split_env >= 0 ? split_env != 0 : (!inverse && nl >= 8)));
+        const int64_t grid = quad ? (batch + 63) / 64 : (split ? (batch + 2 * 64 - 1) / (2 * 64) : (batch + 4 * cols - 1) / (4 * cols));
         BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar: batch too large for one launch");
         BjxFin fin;
         bool second = false;
@@ -2023,12 +2033,13 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
 #define LAUNCH_REG(G_, NL_, INV_) if (G_ == 32 && cols == 32) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, (G_ == 32 ? 32 : 64)>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); else hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, 64>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
 #define LAUNCH_REG_NL(G_, INV_) switch (NL) { case 1: LAUNCH_REG(G_, 1, INV_); break; case 2: LAUNCH_REG(G_, 2, INV_); break; case 4: LAUNCH_REG(G_, 4, INV_); break; default: LAUNCH_REG(G_, 8, INV_); break; }
 #define LAUNCH_REG_G(INV_) switch (G) { case 8: LAUNCH_REG_NL(8, INV_) break; case 16: LAUNCH_REG_NL(16, INV_) break; default: LAUNCH_REG_NL(32, INV_) break; }
-#define LAUNCH_REG2(NL_, INV_) hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
+#define LAUNCH_REG2(NL_, INV_) do { if (quad) hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_, 4>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); \
+        else hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_, 2>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); } while (0)
 #define LAUNCH_REG2_NL(INV_) switch (NL) { case 1: LAUNCH_REG2(1, INV_); break; case 2: LAUNCH_REG2(2, INV_); break; case 4: LAUNCH_REG2(4, INV_); break; default: LAUNCH_REG2(8, INV_); break; }
         // matrix-core kernel (forward, groups of 8 layers, dim a multiple of 16, no fused base density):
         // BJX_PLANAR_MFMA = 0 off | 1 direct loads, 64 columns per wave | 2 LDS-staged, 64 | 3 direct, 32 | 4 staged, 32 | 5 direct, 16 | 6 staged, 16
         static const int mfma_env = getenv("BJX_PLANAR_MFMA") ? atoi(getenv("BJX_PLANAR_MFMA")) : PLANAR_MFMA_DEFAULT;
-        if (mfma_env && !inverse && NL == 8 && dim % 16 == 0 && dim >= 32 && !(flags & BJX_BASE_STDNORMAL)) {
+        if (mfma_env && !inverse && NL == 8 && dim % 16 == 0 && dim >= 32 && dim <= 128 && !(flags & BJX_BASE_STDNORMAL)) {
           const int tiles = mfma_env >= 5 ? 1 : (mfma_env >= 3 ? 2 : 4), stage = (mfma_env % 2 == 0) ? 1 : 0;
           const int64_t gridm = (batch + 4 * 16 * tiles - 1) / (4 * 16 * tiles);
           BJX_REQUIRE(ctx, gridm < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar: batch too large for one launch");
