@@ -26,7 +26,7 @@ print("| bijector | dim | kernel ms (2^22 columns) | alg. B/sample | GB/s | % of
 print("|---|---|---|---|---|---|")
 N = 1 << 22
 e = bj.elementwise
-for d in [int(v) for v in os.environ.get("BJX_BENCH_DIMS", "2,3,8,10").split(",")]:
+for d in [int(v) for v in os.environ.get("BJX_BENCH_DIMS", "2,3,8,10,24,100,200").split(",")]:
     x = torch.randn(N, d, device=dev).T
     cases = []
     w = torch.randn(d, device=dev) / math.sqrt(d)
