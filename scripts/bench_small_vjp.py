@@ -26,7 +26,7 @@ print("| pullback | size | kernel ms (2^22 columns) | alg. B/sample | GB/s | % o
 print("|---|---|---|---|---|---|")
 N = 1 << 22
 e = bj.elementwise
-for d in (3, 4, 8, 10):
+for d in tuple(int(v) for v in os.environ.get("BJX_BENCH_DIMS", "3,4,8,10").split(",")):
     x = torch.randn(N, d, device=dev).T
     g = torch.randn(N, d, device=dev).T
     lb = torch.randn(N, device=dev)

@@ -1,0 +1,33 @@
+"""Probe: Simplex / Ordered (forward, inverse, pullbacks) at tall columns (Dirichlet dimensions of topic models)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import bijectors_amd as bj
+dev = torch.device("cuda", 0)
+lib = bj._lib.load(); ctx = bj.context(dev)
+def timed(fn, reps=5):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    lib.bjx_kernel_time_begin(ctx.h)
+    for _ in range(reps): fn()
+    ms, n = C.c_float(0), C.c_int(0)
+    lib.bjx_kernel_time_end(ctx.h, C.byref(ms), C.byref(n))
+    return ms.value / reps
+N = 1 << int(os.environ.get("BJX_BENCH_LOG2N", "20"))
+print("| bijector | K | kernel ms (2^%d columns) | alg. B/sample | GB/s | %% of 8 TB/s |" % (N.bit_length() - 1))
+print("|---|---|---|---|---|---|")
+for K in tuple(int(v) for v in os.environ.get("BJX_BENCH_KS", "64,100,128,200,256,500").split(",")):
+    x = torch.softmax(torch.randn(N, K, device=dev), dim=1).T
+    sb = bj.SimplexBijector()
+    y = bj.transform(sb, x)
+    xo = torch.randn(N, K, device=dev).T
+    gy, gx, lb = torch.randn(N, K - 1, device=dev).T, torch.randn(N, K, device=dev).T, torch.randn(N, device=dev)
+    rows = [("SimplexBijector", lambda: bj.with_logabsdet_jacobian(sb, x, per_sample=True), (2 * K - 1) * 4 + 4),
+            ("inverse(SimplexBijector)", lambda: bj.with_logabsdet_jacobian(bj.inverse(sb), y, per_sample=True), (2 * K - 1) * 4 + 4),
+            ("OrderedBijector", lambda: bj.with_logabsdet_jacobian(bj.OrderedBijector(), xo, per_sample=True), 2 * K * 4 + 4),
+            ("vjp(SimplexBijector)", lambda: bj.vjp(sb, x, gy, lb), (3 * K - 1) * 4 + 4),
+            ("vjp(inverse(SimplexBijector))", lambda: bj.vjp(bj.inverse(sb), y, gx, lb), (3 * K - 2) * 4 + 4)]
+    for label, fn, bps in rows:
+        ms = timed(fn)
+        g = bps * N / (ms * 1e-3) / 1e9
+        print(f"| {label} | {K} | {ms:.4f} | {bps} | {g:.0f} | {g / 80:.1f} |", flush=True)
