@@ -97,6 +97,21 @@ def test_chain_walk_and_inverse(bj):
     assert bj.inverse(pl).orig is pl and bj.inverse(bj.inverse(pl)) is pl
 
 
+def test_composition_is_cut_into_pieces_with_a_device_pullback(bj):
+    """interface._pieces: runs of elementwise stages of at most BJX_MAX_SEG_OPS ops become one fused piece each, every other stage
+    stands alone, application order is kept (the chain rule of _vjp_composed walks these pieces backwards)."""
+    from bijectors_amd import interface as I
+    L = bj._lib
+    chain = bj.elementwise(bj.exp) @ bj.Shift(1.0) @ bj.Scale(2.0) @ bj.LeakyReLU(0.3) @ bj.Shift(0.2) @ bj.Scale(1.7)
+    pcs = I._pieces(chain)
+    assert [len(I._fused_ops(p_)) for p_ in pcs] == [L.BJX_MAX_SEG_OPS, 2]
+    assert [o[0] for p_ in pcs for o in I._fused_ops(p_)] == [L.OP_SCALE, L.OP_SHIFT, L.OP_LEAKY_RELU, L.OP_SCALE, L.OP_SHIFT, L.OP_EXP]
+    flow = bj.elementwise(bj.exp) @ bj.OrderedBijector() @ bj.Shift(0.5) @ bj.Scale(2.0) @ bj.PlanarLayer([1.0, 2.0], [0.5, 0.1], [0.0])
+    names = [type(p_).__name__ for p_ in I._pieces(flow)]
+    assert names == ["PlanarLayer", "ComposedFunction", "OrderedBijector", "Elementwise"]
+    assert I._has_own_params(flow._stages()[0]) and I._has_own_params(bj.inverse(flow._stages()[0])) and not I._has_own_params(bj.OrderedBijector())
+
+
 def test_output_size(bj):
     assert bj.output_size(bj.SimplexBijector(), (5,)) == (4,)                       # simplex.jl:6-12
     assert bj.output_size(bj.inverse(bj.SimplexBijector()), (4, 7)) == (5, 7)
