@@ -1883,9 +1883,9 @@ int launch_quad_stream(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_
   *taken = false;
   static const int use_stream = getenv("BJX_SEQ_STREAM") ? atoi(getenv("BJX_SEQ_STREAM")) : 1;
   const int64_t np = R / (G * VW);
-  constexpr int NPMAX = 16 / G;                              // R <= 64 (Float32) / 32 (Float64)
+  constexpr int NPMAX = G >= 4 ? 8 : 16 / G;                 // four lanes per column: R <= 128 (Float32) / 64 (Float64), 32 rows per lane; fewer lanes: R <= 64 / 32
   if (!use_stream || batch <= 0 || R % (G * VW) != 0 || np < 1 || np > NPMAX || !bjx_aligned16(in) || (out && !bjx_aligned16(out))) return BJX_OK;
-  if (np != 1 && np != 2 && np != 3 && np != 4 && np != 8 && np != 16) return BJX_OK;
+  if (np > 8 && np != 16) return BJX_OK;                     // np = 1 … 8 (every multiple of 16 rows up to 128 in Float32), 16
   *taken = true;
   const int64_t cpb = 4 * (64 / G);                          // columns per block: 4 waves x 64/G columns
   const int64_t grid = (batch + cpb - 1) / cpb;
@@ -1906,6 +1906,9 @@ int launch_quad_stream(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_
       case 2: QS(2); break;
       case 3: if constexpr (NPMAX >= 3) QS(3); break;
       case 4: if constexpr (NPMAX >= 4) QS(4); break;
+      case 5: if constexpr (NPMAX >= 8) QS(5); break;
+      case 6: if constexpr (NPMAX >= 8) QS(6); break;
+      case 7: if constexpr (NPMAX >= 8) QS(7); break;
       case 8: if constexpr (NPMAX >= 8) QS(8); break;
       case 16: if constexpr (NPMAX >= 16) QS(16); break;
     }
