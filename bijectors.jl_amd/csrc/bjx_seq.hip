@@ -2163,8 +2163,8 @@ int launch_simplex_vjp_stream(bjx_ctx* ctx, int inverse, const T* in, const T* o
   *taken = false;
   static const int use_stream = getenv("BJX_SIMPLEX_VJP_STREAM") ? atoi(getenv("BJX_SIMPLEX_VJP_STREAM")) : 1;
   const int64_t np = K / (G * VW);
-  constexpr int NPMAX = 16 / G;
-  if (!use_stream || batch <= 0 || K % (G * VW) != 0 || np < 1 || np > NPMAX || (np != 1 && np != 2 && np != 4 && np != 8) || !bjx_aligned16(in) || !bjx_aligned16(out_bar) || !bjx_aligned16(in_bar)) return BJX_OK;
+  constexpr int NPMAX = G >= 4 ? 8 : 16 / G;                  // four lanes per column: K <= 128 (Float32) / 64 (Float64)
+  if (!use_stream || batch <= 0 || K % (G * VW) != 0 || np < 1 || np > NPMAX || !bjx_aligned16(in) || !bjx_aligned16(out_bar) || !bjx_aligned16(in_bar)) return BJX_OK;
   *taken = true;
   const int64_t cpb = 4 * (64 / G);
   const int64_t grid = (batch + cpb - 1) / cpb;
@@ -2176,7 +2176,11 @@ int launch_simplex_vjp_stream(bjx_ctx* ctx, int inverse, const T* in, const T* o
     switch ((int)np) {
       case 1: SVS_I(1); break;
       case 2: SVS_I(2); break;
+      case 3: if constexpr (NPMAX >= 3) SVS_I(3); break;
       case 4: if constexpr (NPMAX >= 4) SVS_I(4); break;
+      case 5: if constexpr (NPMAX >= 5) SVS_I(5); break;
+      case 6: if constexpr (NPMAX >= 6) SVS_I(6); break;
+      case 7: if constexpr (NPMAX >= 7) SVS_I(7); break;
       case 8: if constexpr (NPMAX >= 8) SVS_I(8); break;
     }
   }

@@ -815,7 +815,8 @@ def test_columnwise_returns_the_sum_over_columns(bj, orc):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("K,N", [(2, 7), (5, 100), (64, 130), (33, 64), (8, 50), (16, 333), (32, 77), (64, 4099)])   # 8/16/32/64: streaming kernels, ragged runs
+@pytest.mark.parametrize("K,N", [(2, 7), (5, 100), (64, 130), (33, 64), (8, 50), (16, 333), (32, 77), (64, 4099),   # 8/16/32/64: streaming kernels, ragged runs
+                                 (48, 130), (80, 65), (96, 257), (112, 33), (128, 130), (100, 64)])   # 3 … 8 packs per lane in the streaming frame; 100: the column walker
 def test_simplex_vjp(bj, orc, K, N, dt):
     r = rng(54)
     lbar = r.normal(size=N).astype(dt)
