@@ -1,7 +1,8 @@
 """Batch sharding across GPUs: one process per GPU, every rank owns a contiguous
-block of columns, parameters are replicated, and the ONLY collective on the path is one sum
+block of columns, parameters are replicated, and the ONLY collective on the forward path is one sum
 all-reduce of the float64 partial Σ logabsdetjac (8 bytes, latency-bound) over RCCL/xGMI
-(`torch.distributed` backend "nccl" on ROCm; "gloo" in the CPU tests)."""
+(`torch.distributed` backend "nccl" on ROCm; "gloo" in the CPU tests).  Training adds the sum of the
+parameter cotangents over the ranks as ONE float64 bucket (`allreduce_param_cotangents`)."""
 from __future__ import annotations
 
 from typing import Optional, Tuple
@@ -67,6 +68,57 @@ def with_logabsdet_jacobian_sharded(b, x_shard: torch.Tensor, group=None, out: O
     lps, lsum = l if per_sample else (None, l)
     allreduce_logabsdetjac(lsum, group)
     return y, lps, lsum
+
+
+def _leaves(tree, out):
+    if isinstance(tree, torch.Tensor):
+        out.append(tree)
+    elif isinstance(tree, dict):
+        for k in sorted(tree):
+            _leaves(tree[k], out)
+    elif isinstance(tree, (list, tuple)):
+        for v in tree:
+            _leaves(v, out)
+    elif tree is not None:
+        raise TypeError(f"parameter cotangents must be tensors, dicts, lists or None (got {type(tree).__name__})")
+    return out
+
+
+def allreduce_param_cotangents(grads, group=None):
+    """Data-parallel training: every rank holds the parameter cotangents of ITS column block (`vjp_params` sums over the local
+    batch); the parameters are replicated, so the cotangents are summed over the ranks — the one exchange step of a training
+    step.  All leaves of `grads` (the dictionaries of `vjp_params`, nested `{"stages": [...]}` included) travel as ONE float64
+    bucket (a flow's parameters are a few KiB: one latency-bound collective instead of one per tensor; float64 so the sum does
+    not depend on the shard count beyond the ranks' own rounding) and are written back in place.  Returns `grads`."""
+    import torch.distributed as dist
+
+    leaves = _leaves(grads, [])
+    if not leaves or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return grads
+    bucket = torch.cat([t.detach().reshape(-1).to(torch.float64) for t in leaves])
+    if _LIBRARY_COLLECTIVE[0] and bucket.is_cuda:
+        from . import _lib as L
+        from . import interface as I
+
+        ctx = I.context(bucket.device)
+        L.check(ctx.h, L.load().bjx_allreduce_sum_f64(ctx.h, bucket.data_ptr(), bucket.numel()), "bjx_allreduce_sum_f64")
+    else:
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for t in leaves:
+        n = t.numel()
+        t.copy_(bucket[off:off + n].reshape(t.shape).to(t.dtype))
+        off += n
+    return grads
+
+
+def vjp_params_sharded(b, x_shard: torch.Tensor, out_bar_shard: torch.Tensor, ladj_bar_shard=None, group=None):
+    """`vjp_params` on this rank's column block + the all-reduce of the parameter cotangents: (x_bar_shard, global cotangents).
+    The input cotangent stays sharded like the data."""
+    from . import interface as I
+
+    x_bar, grads = I.vjp_params(b, x_shard, out_bar_shard, ladj_bar_shard)
+    return x_bar, allreduce_param_cotangents(grads, group)
 
 
 def init_comm(device: Optional[torch.device] = None, group=None) -> None:

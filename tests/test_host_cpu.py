@@ -213,6 +213,59 @@ def test_allreduce_logabsdetjac_gloo_world2():
     assert res[0][2] == res[1][2]      # every rank holds the same global scalar
 
 
+def _worker_params(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    import bijectors_amd as bj
+    from oracle import oracle as orc
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the CPU oracle stands in for this rank's vjp_params call: cotangents of a 2-layer PlanarLayer stack on the rank's columns
+    r = np.random.default_rng(5)
+    dim, nl, N = 6, 2, 101
+    w, u, b = r.normal(size=(dim, nl)) / np.sqrt(dim), r.normal(size=(dim, nl)) / np.sqrt(dim), r.normal(size=nl)
+    Z, G, lb = r.normal(size=(dim, N)), r.normal(size=(dim, N)), r.normal(size=N)
+    lo, hi = bj.shard.shard_columns(N, world, rank)
+    wb, ub, bb = orc.planar_param_vjp(w, u, b, Z[:, lo:hi], G[:, lo:hi], lb[lo:hi])
+    grads = {"stages": [None, {"w": torch.tensor(wb, dtype=torch.float32), "u": torch.tensor(ub), "b": torch.tensor(bb)}, {"shift": torch.tensor(float(rank + 1))}]}
+    out = bj.shard.allreduce_param_cotangents(grads)
+    wf, uf, bf = orc.planar_param_vjp(w, u, b, Z, G, lb)
+    st = out["stages"][1]
+    ok = out is grads and st["w"].dtype == torch.float32 and st["u"].dtype == torch.float64
+    ok = ok and np.allclose(st["w"].numpy(), wf, rtol=1e-5, atol=1e-6) and np.allclose(st["u"].numpy(), uf, rtol=1e-12, atol=1e-12)
+    ok = ok and np.allclose(st["b"].numpy(), bf, rtol=1e-12, atol=1e-12) and float(out["stages"][2]["shift"]) == sum(range(1, world + 1))
+    try:
+        bj.shard.allreduce_param_cotangents({"a": 3.0})
+        ok = False
+    except TypeError:
+        pass
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok), st["u"].numpy().tobytes()))
+
+
+def test_allreduce_param_cotangents_gloo_world2():
+    """Data-parallel training step on two ranks: per-rank parameter cotangents (nested dictionaries, mixed dtypes, None holes) are
+    summed in ONE float64 bucket and equal the single-process cotangents of the whole batch."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_params, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), [(r_, ok) for r_, ok, _ in res]
+    assert res[0][2] == res[1][2]      # bit-identical on every rank
+
+
 def test_vector_links_and_density_op_lists(bj):
     """Host logic of the §8(f) wrappers, no GPU: the VectorBijectors scalar links are op lists of the chain kernel
     (src/vector/univariate/positive.jl:11-50, truncated.jl:17-103), heterogeneous products are Stacked ranges, and a
