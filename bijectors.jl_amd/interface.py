@@ -1713,6 +1713,10 @@ class NamedStacked(Transform):
                 piece = xs[lo - 1:hi]
                 out[n] = piece[0] if n in self._int_fields else piece               # an Int range is a scalar field (:19-21)
             return out, l
+        return st._wlj(self._cat(x), per_sample, want_ladj)
+
+    def _cat(self, x):
+        """A dict of fields -> the concatenated (rows[, batch]) device tensor `Stacked` works on."""
         if not isinstance(x, dict) or list(x.keys()) != self.names:
             raise ValueError(f"expected a dict with the fields {self.names}")             # x::NamedTuple{names}, :66
         like = next((v for v in x.values() if isinstance(v, torch.Tensor) and v.is_cuda), None)
@@ -1730,7 +1734,23 @@ class NamedStacked(Transform):
                 t = t[None, :] if n in self._int_fields and t.shape[0] != 1 else t[:, None].expand(t.shape[0], like.shape[-1])
             pieces.append(t)
         cat = torch.cat(pieces, dim=0)
-        return st._wlj(colmajor(cat) if batched else cat.contiguous(), per_sample, want_ladj)
+        return colmajor(cat) if batched else cat.contiguous()
+
+    def _split(self, xs, ranges):
+        out = {}
+        for n, (lo, hi) in zip(self.names, ranges):
+            piece = xs[lo - 1:hi]
+            out[n] = piece[0] if n in self._int_fields else piece
+        return out
+
+    def _vjp(self, x, out_bar, ladj_bar):
+        """Pullback in the field layout of the forward value: forward (dict -> vector) takes the vector cotangent and returns a
+        dict; the inverse (vector -> dict, what a log-density evaluation of a ProductNamedTupleDistribution differentiates) takes a
+        dict of field cotangents and returns the vector's."""
+        st = self._stacked()
+        if self._inv:
+            return vjp(st._inverse(), x, self._cat(out_bar), ladj_bar)
+        return self._split(vjp(st, self._cat(x), out_bar, ladj_bar), st.ranges_in)
 
 
 # ------------------------------------------------------------------ reverse-mode pullbacks (SURVEY.md §8f, f-1)
@@ -1757,6 +1777,8 @@ def vjp(b, x, out_bar, ladj_bar=None):
     affine Coupling in both directions; Permute (the inverse gather); InvertibleBatchNorm in eval mode and
     `columnwise(f)` through the kernels above."""
     if isinstance(b, Stacked):
+        return b._vjp(x, out_bar, ladj_bar)
+    if isinstance(b, NamedStacked):
         return b._vjp(x, out_bar, ladj_bar)
     ops_ = _elementwise_ops(b)
     if ops_ is not None and len(ops_) <= L.BJX_MAX_SEG_OPS:   # a chain of elementwise bijectors = one segment over all rows
