@@ -59,8 +59,21 @@ def parse():
     return p.parse_args()
 
 
+_ARENA_MB = int(os.environ.get("BJX_BENCH_ARENA_MB", "0"))     # experiment: carve the large buffers from ONE allocation
+_arena = {}
+
+
 def colmajor_empty(torch, rows, batch, dtype, device):
-    return torch.empty((batch, rows), dtype=dtype, device=device).T
+    n = rows * batch
+    item = torch.empty((), dtype=dtype).element_size()
+    if _ARENA_MB <= 0 or n * item < (8 << 20):
+        return torch.empty((batch, rows), dtype=dtype, device=device).T
+    if "buf" not in _arena:
+        _arena["buf"] = torch.empty(_ARENA_MB << 20, dtype=torch.uint8, device=device)
+        _arena["off"] = 0
+    off = _arena["off"]
+    _arena["off"] = off + (n * item + 255) // 256 * 256
+    return _arena["buf"][off:off + n * item].view(dtype).view(batch, rows).T
 
 
 def fill_normal(bj, torch, t, col0, seed, mean=0.0, std=1.0):

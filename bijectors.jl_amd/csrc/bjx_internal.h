@@ -510,10 +510,12 @@ __device__ __forceinline__ void block_publish_partial(double acc, double* red, d
 // level, the store is waited for (vmcnt) before the arrival counter is bumped, and the last block
 // reads the partials with sc1 loads (MI355X_MICROARCH.md G16: "sc1 stores AND sc1 loads").
 // tests/test_gpu_parity.py::test_inkernel_finalize_is_bit_identical_to_two_pass stresses it.
-__device__ __forceinline__ void block_publish_partial(double acc, double* red, const BjxFin& f) {
+// `flag_lds`: one LDS int for the "I am the last block" broadcast.  Kernels that budget their LDS to the byte (rqs_lds_kernel: 5 blocks
+// of 32 KiB per CU) pass a word of their own dynamic allocation; the wrapper below keeps a static one.
+__device__ __forceinline__ void block_publish_partial_at(double acc, double* red, int* flag_lds, const BjxFin& f) {
   if (!f.partials) return;
   if (!f.counter) { block_publish_partial(acc, red, f.partials); return; }
-  __shared__ int is_last;
+  int& is_last = *flag_lds;
   acc = group_sum<64>(acc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = (blockDim.x + 63) >> 6;
@@ -546,6 +548,11 @@ __device__ __forceinline__ void block_publish_partial(double acc, double* red, c
     *f.out = f.accumulate ? (*f.out + t) : t;
     __hip_atomic_store(f.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+__device__ __forceinline__ void block_publish_partial(double acc, double* red, const BjxFin& f) {
+  __shared__ int is_last_static;
+  block_publish_partial_at(acc, red, &is_last_static, f);
 }
 
 // two values through one butterfly (shares the wave-uniform branches)

@@ -3,29 +3,43 @@
 # binding a Bijectors.jl maintainer would add as a package extension, in the same way the AD
 # extensions attach more specific methods (ext/BijectorsReverseDiffExt.jl:63-65,
 # ext/BijectorsForwardDiffExt.jl:11-15; weak-dep wiring Project.toml:26-42)).
+# tests/test_julia_binding.py checks it STATICALLY against include/bjx.h: every entry point of the
+# header is `ccall`ed here with the header's arity and C types, and every bijector of SURVEY.md
+# §8(b) x {plain, Inverse} has a launch plan and therefore the six interface methods below.
 #
 # AMDGPU.jl is used ONLY for the device pointer, the device id and the hipStream_t; no
 # KernelAbstractions, no CUDA.jl compat layer.  Every method below dispatches on `ROCArray`
 # inputs and falls through to the reference's generic CPU methods for anything else.
+#
+# Structure: `plan(b, x)` turns (bijector, input) into a `Plan` — output shape, the reference's
+# log-det return shape (SURVEY.md §8a'), and a closure holding the one `ccall`.  The six entry
+# points of src/interface.jl:156-218 are then written ONCE, for every planned bijector:
+#   with_logabsdet_jacobian, transform, logabsdetjac, transform!, logabsdetjac!, with_logabsdet_jacobian!
 module BijectorsBJX
 
 using AMDGPU: AMDGPU, ROCArray, ROCVector, ROCMatrix
 using Bijectors
 using Bijectors: Elementwise, Inverse, Shift, Scale, Logit, LeakyReLU, TruncatedBijector, OrderedBijector,
     SimplexBijector, VecCholeskyBijector, Permute, PlanarLayer, RadialLayer, InvertibleBatchNorm,
-    RationalQuadraticSpline, Stacked, VecCorrBijector, CorrBijector, PDBijector, PDVecBijector, NamedStacked
-using ChainRulesCore: ChainRulesCore
+    RationalQuadraticSpline, Stacked, VecCorrBijector, CorrBijector, PDBijector, PDVecBijector, NamedStacked,
+    Coupling, PartitionMask
+using ChainRulesCore: ChainRulesCore, NoTangent, Tangent, unthunk
 using Distributions: Distributions
+using SparseArrays: SparseArrays
 const ROCVecOrMat{T} = Union{ROCVector{T},ROCMatrix{T}}
-import Bijectors: transform, logabsdetjac, with_logabsdet_jacobian, with_logabsdet_jacobian!
+const BjxFloat = Union{Float32,Float64}
+import Bijectors: transform, transform!, logabsdetjac, logabsdetjac!, with_logabsdet_jacobian, with_logabsdet_jacobian!
 
 const libbjx = get(ENV, "BJX_LIBRARY", "libbjx_hip.so")
 
 # ---------------------------------------------------------------- include/bjx.h mirror
 const BJX_F32, BJX_F64 = Cint(0), Cint(1)
 const BJX_ACCUMULATE, BJX_REF_VECTOR_SCALE_LADJ = UInt32(1), UInt32(2)
+const BJX_BASE_STDNORMAL, BJX_INPUT_STDNORMAL = UInt32(1) << 2, UInt32(1) << 3
+const BJX_COUPLING_SCALE_BCAST, BJX_COUPLING_SHIFT_BCAST = UInt32(1) << 4, UInt32(1) << 5
 const BJX_ERR_UNSUPPORTED = Cint(-3)
-@enum OpKind::Int32 OP_EXP = 1 OP_LOG OP_SHIFT OP_SCALE OP_SCALE_INV OP_LOGIT OP_LOGIT_INV OP_LEAKY_RELU OP_TRUNCATED OP_TRUNCATED_INV OP_SIGNFLIP OP_IDENTITY
+const BJX_OPT_INKERNEL_FINALIZE = Cint(1)
+@enum OpKind::Int32 OP_EXP = 1 OP_LOG OP_SHIFT OP_SCALE OP_SCALE_INV OP_LOGIT OP_LOGIT_INV OP_LEAKY_RELU OP_TRUNCATED OP_TRUNCATED_INV OP_SIGNFLIP OP_IDENTITY OP_STDNORMAL_LOGPDF
 
 struct BjxOp            # layout of `bjx_op` (40 bytes)
     kind::Int32
@@ -36,6 +50,15 @@ struct BjxOp            # layout of `bjx_op` (40 bytes)
     v1::Ptr{Cvoid}
 end
 
+struct BjxSegment       # layout of `bjx_segment` (BJX_MAX_SEG_OPS = 4)
+    in_lo::Int64; out_lo::Int64; len::Int64; n_ops::Int32; reserved::Int32
+    ops::NTuple{4,BjxOp}
+end
+const NOOP = BjxOp(Int32(OP_IDENTITY), 0, 0, 0, C_NULL, C_NULL)
+struct BjxBlock         # layout of `bjx_block`
+    kind::Cint; reserved::Cint; in_lo::Int64; out_lo::Int64; len_in::Int64; len_out::Int64
+end
+
 dtype(::Type{Float32}) = BJX_F32
 dtype(::Type{Float64}) = BJX_F64
 
@@ -43,6 +66,7 @@ mutable struct Context
     h::Ptr{Cvoid}
 end
 function Context(dev::Integer=AMDGPU.device_id(AMDGPU.device()) - 1, stream=AMDGPU.stream())
+    ccall((:bjx_version, libbjx), Cint, ()) == 100 || error("libbjx_hip.so: unexpected ABI version")
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:bjx_create, libbjx), Cint, (Cint, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), dev, stream.stream, h)
     rc == 0 || error("bjx_create failed with status $rc")
@@ -61,24 +85,65 @@ function check(rc::Cint, what)
     error("$what: status $rc: $msg")                        # hipError_t / ncclResult_t
 end
 
+# follow a task onto another AMDGPU.jl stream; wait for the library's stream; scratch held by the context; tuning switch
+set_stream!(stream=AMDGPU.stream()) = check(ccall((:bjx_set_stream, libbjx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx().h, stream.stream), "bjx_set_stream")
+synchronize() = check(ccall((:bjx_synchronize, libbjx), Cint, (Ptr{Cvoid},), ctx().h), "bjx_synchronize")
+workspace_bytes() = Int(ccall((:bjx_workspace_bytes, libbjx), Csize_t, (Ptr{Cvoid},), ctx().h))
+inkernel_finalize!(on::Bool) = check(ccall((:bjx_set_option, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().h, BJX_OPT_INKERNEL_FINALIZE, Cint(on)), "bjx_set_option")
+
 dims(x::ROCVector) = (length(x), 1)
 dims(x::ROCMatrix) = size(x)
 devptr(x::ROCArray) = Ptr{Cvoid}(pointer(x))
+devptr(::Nothing) = C_NULL
+ondevice(::Type{T}, a::ROCArray{T}) where {T} = a
+ondevice(::Type{T}, a) where {T} = ROCArray{T}(a)           # parameters may already live on the device
+
+# ---------------------------------------------------------------- launch plans
+struct Plan
+    name::Symbol            # the C entry (error messages)
+    outsize::Dims           # size of the transformed array
+    ladj::Symbol            # the reference's log-det return shape: :column (T[batch]), :scalar (one number), :zero (Permute)
+    batch::Int
+    null_out::Bool          # the entry accepts out = C_NULL (log-det only, no store traffic)
+    alias_ok::Bool          # out may alias the input (transform!(b, x) == transform!(b, x, x), interface.jl:175)
+    flags::UInt32
+    keep::Vector{Any}       # device arrays the launch reads: alive until the call has been enqueued
+    launch::Function        # (out::Ptr{Cvoid}, lps::Ptr{Cvoid}, lsum::Ptr{Cvoid}, flags::UInt32) -> Cint
+end
+
+# run a plan.  out === nothing -> no transformed values wanted (C_NULL where the entry allows it, a scratch array otherwise);
+# lps_into -> a ROCVector the per-column log-dets are ADDED to (BJX_ACCUMULATE: the `!` forms of interface.jl:199-218).
+function run!(p::Plan, ::Type{T}, x, out; want_ladj::Bool=true, lps_into=nothing) where {T}
+    o = out === nothing ? (p.null_out ? nothing : similar(x, T, p.outsize)) : out
+    lps = !want_ladj || p.ladj !== :column ? nothing : (lps_into === nothing ? similar(x, T, p.batch) : lps_into)
+    lsum = want_ladj && p.ladj === :scalar ? AMDGPU.zeros(Float64, 1) : nothing
+    fl = p.flags | (lps_into === nothing ? UInt32(0) : BJX_ACCUMULATE)
+    keep = p.keep
+    GC.@preserve keep x o lps lsum check(p.launch(devptr(o), devptr(lps), devptr(lsum), fl), String(p.name))
+    want_ladj || return nothing
+    p.ladj === :column && return lps
+    p.ladj === :scalar && return T(Array(lsum)[1])       # the reference returns a host scalar here (§8a')
+    return zero(T)
+end
 
 # ---------------------------------------------------------------- F1: fused elementwise chains
 # Walk `outer ∘ inner` into application order; nothing => not fusable, use the generic method.
 ops(b::Elementwise{typeof(exp)}, T, keep) = [BjxOp(Int32(OP_EXP), 0, 0, 0, C_NULL, C_NULL)]
 ops(b::Elementwise{typeof(log)}, T, keep) = [BjxOp(Int32(OP_LOG), 0, 0, 0, C_NULL, C_NULL)]
+# (inverse(elementwise(exp)) IS elementwise(log), inverse(Shift(a)) IS Shift(-a), inverse(LeakyReLU(α)) IS LeakyReLU(1/α),
+#  inverse(SignFlip()) IS SignFlip() and inverse(f ∘ g) IS inverse(g) ∘ inverse(f) — shift.jl:12, leaky_relu.jl:16, ordered.jl:4,
+#  InverseFunctions — so `Inverse{…}` wrappers exist only for Scale, Logit and TruncatedBijector.)
 function param_op(kind, a, T, keep, b=nothing)
-    if a isa Real
+    if a isa Real && (b === nothing || b isa Real)
         return BjxOp(Int32(kind), 1, Float64(a), b === nothing ? 0.0 : Float64(b), C_NULL, C_NULL)
     end
-    va = ROCArray{T}(a); push!(keep, va)            # parameters may already live on the device
-    vb = b === nothing ? nothing : ROCArray{T}(b isa Real ? fill(T(b), length(va)) : b)
+    n = a isa Real ? length(b) : length(a)
+    va = ondevice(T, a isa Real ? fill(T(a), n) : a); push!(keep, va)
+    vb = b === nothing ? nothing : ondevice(T, b isa Real ? fill(T(b), n) : b)
     vb === nothing || push!(keep, vb)
-    return BjxOp(Int32(kind), length(va), 0, 0, devptr(va), vb === nothing ? C_NULL : devptr(vb))
+    return BjxOp(Int32(kind), n, 0, 0, devptr(va), devptr(vb))
 end
-ops(b::Shift, T, keep) = [param_op(OP_SHIFT, b.a, T, keep)]
+ops(b::Shift{<:Union{Real,AbstractVector}}, T, keep) = [param_op(OP_SHIFT, b.a, T, keep)]
 ops(b::Scale{<:Union{Real,AbstractVector}}, T, keep) = [param_op(OP_SCALE, b.a, T, keep)]
 ops(b::Inverse{<:Scale{<:Union{Real,AbstractVector}}}, T, keep) = [param_op(OP_SCALE_INV, b.orig.a, T, keep)]
 ops(b::Logit, T, keep) = [param_op(OP_LOGIT, b.a, T, keep, b.b)]
@@ -87,6 +152,7 @@ ops(b::LeakyReLU, T, keep) = [param_op(OP_LEAKY_RELU, b.α, T, keep)]
 ops(b::TruncatedBijector, T, keep) = [param_op(OP_TRUNCATED, b.lb, T, keep, b.ub)]
 ops(b::Inverse{<:TruncatedBijector}, T, keep) = [param_op(OP_TRUNCATED_INV, b.orig.lb, T, keep, b.orig.ub)]
 ops(b::Bijectors.SignFlip, T, keep) = [BjxOp(Int32(OP_SIGNFLIP), 0, 0, 0, C_NULL, C_NULL)]
+ops(::typeof(identity), T, keep) = BjxOp[]
 function ops(b::ComposedFunction, T, keep)            # inner first (composed.jl:4)
     i, o = ops(b.inner, T, keep), ops(b.outer, T, keep)
     (i === nothing || o === nothing) && return nothing
@@ -94,238 +160,446 @@ function ops(b::ComposedFunction, T, keep)            # inner first (composed.jl
 end
 ops(b, T, keep) = nothing
 
-const Fusable = Union{Elementwise{typeof(exp)},Elementwise{typeof(log)},Shift,Scale,Logit,LeakyReLU,
-    TruncatedBijector,Inverse{<:Scale},Inverse{<:Logit},Inverse{<:TruncatedBijector},ComposedFunction}
+const ElementwiseLeaf = Union{Elementwise{typeof(exp)},Elementwise{typeof(log)},Shift{<:Union{Real,AbstractVector}},
+    Scale{<:Union{Real,AbstractVector}},Logit,LeakyReLU,TruncatedBijector,Bijectors.SignFlip}
+const Fusable = Union{ElementwiseLeaf,Inverse{<:Scale{<:Union{Real,AbstractVector}}},Inverse{<:Logit},Inverse{<:TruncatedBijector},ComposedFunction}
 
-function chain!(y::ROCArray{T}, b, x::ROCArray{T}; per_sample=nothing) where {T<:Union{Float32,Float64}}
+function plan(b::Fusable, x::ROCArray{T}) where {T<:BjxFloat}
     keep = Any[]
     o = ops(b, T, keep)
-    o === nothing && return nothing
-    length(o) <= 8 || return nothing
-    d, n = dims(x)
-    lsum = AMDGPU.zeros(Float64, 1)
-    GC.@preserve keep x y lsum per_sample begin
-        rc = ccall((:bjx_chain, libbjx), Cint,
-            (Ptr{Cvoid}, Cint, Ptr{BjxOp}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
-            ctx().h, dtype(T), o, length(o), devptr(x), devptr(y),
-            per_sample === nothing ? C_NULL : devptr(per_sample), devptr(lsum), d, n, BJX_REF_VECTOR_SCALE_LADJ)
-        check(rc, "bjx_chain")
-    end
-    return T(Array(lsum)[1])          # the reference returns one scalar for elementwise bijectors (§8a')
-end
-
-function with_logabsdet_jacobian(b::Fusable, x::ROCArray{T}) where {T<:Union{Float32,Float64}}
-    y = similar(x)
-    l = chain!(y, b, x)
-    l === nothing && return invoke(with_logabsdet_jacobian, Tuple{typeof(b),AbstractArray}, b, x)
-    return y, l
-end
-transform(b::Fusable, x::ROCArray{<:Union{Float32,Float64}}) = first(with_logabsdet_jacobian(b, x))
-logabsdetjac(b::Fusable, x::ROCArray{<:Union{Float32,Float64}}) = last(with_logabsdet_jacobian(b, x))
-function with_logabsdet_jacobian!(b::Fusable, x::ROCArray{T}, y::ROCArray{T}, logjac) where {T}  # interface.jl:212-218
-    l = chain!(y, b, x)
-    return y, logjac + l
+    (o === nothing || length(o) > 8) && return nothing          # BJX_MAX_OPS; arbitrary Transforms inside ∘: generic path
+    d, n = x isa ROCVecOrMat ? dims(x) : (length(x), 1)          # higher-rank arrays: elementwise over everything
+    h = ctx().h; px = devptr(x); push!(keep, o)
+    launch = (out, lps, lsum, fl) -> ccall((:bjx_chain, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{BjxOp}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        h, dtype(T), o, length(o), px, out, lps, lsum, d, n, fl)
+    # the reference returns ONE scalar for elementwise bijectors (§8a'), with scale.jl:31-32's no-xN quirk
+    return Plan(:bjx_chain, size(x), :scalar, n, true, true, BJX_REF_VECTOR_SCALE_LADJ, keep, launch)
 end
 
 # ---------------------------------------------------------------- structured bijectors
-# One helper per ABI entry; `ladj_ps` is the per-column vector the reference returns for
-# Ordered / Planar / Radial / BatchNorm, `lsum` the scalar it returns for Simplex (§8a').
-function call_struct(sym, T, x, out, pre::Tuple, pretypes::Tuple, rows; per_column::Bool)
-    _, n = dims(x)
-    lps = per_column ? similar(x, T, n) : nothing
-    lsum = per_column ? nothing : AMDGPU.zeros(Float64, 1)
-    GC.@preserve x out lps lsum begin
-        rc = ccall((sym, libbjx), Cint,
-            (Ptr{Cvoid}, Cint, pretypes..., Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
-            ctx().h, dtype(T), pre..., devptr(x), devptr(out),
-            lps === nothing ? C_NULL : devptr(lps), lsum === nothing ? C_NULL : devptr(lsum), rows, n, UInt32(0))
-        check(rc, String(sym))
-    end
-    return per_column ? lps : T(Array(lsum)[1])
+# OrderedBijector, ordered.jl:22-80 (per-column log-det vector)
+function plan_ordered(inv::Bool, x::ROCVecOrMat{T}) where {T<:BjxFloat}
+    d, n = dims(x); h = ctx().h; px = devptr(x)
+    launch = (out, lps, lsum, fl) -> ccall((:bjx_ordered, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        h, dtype(T), Cint(inv), px, out, lps, lsum, d, n, fl)
+    return Plan(:bjx_ordered, size(x), x isa ROCVector ? :scalar : :column, n, false, false, UInt32(0), Any[], launch)
+end
+plan(::OrderedBijector, y::ROCVecOrMat{<:BjxFloat}) = plan_ordered(false, y)
+plan(::Inverse{OrderedBijector}, x::ROCVecOrMat{<:BjxFloat}) = plan_ordered(true, x)
+
+# SimplexBijector, simplex.jl:14,28-143 (scalar log-det summed over the columns, :141-143)
+function plan_simplex(inv::Bool, x::ROCVecOrMat{T}) where {T<:BjxFloat}
+    r, n = dims(x); K = inv ? r + 1 : r
+    h = ctx().h; px = devptr(x)
+    osz = x isa ROCVector ? (inv ? (K,) : (K - 1,)) : (inv ? (K, n) : (K - 1, n))
+    launch = (out, lps, lsum, fl) -> ccall((:bjx_simplex, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        h, dtype(T), Cint(inv), px, out, lps, lsum, K, n, fl)
+    return Plan(:bjx_simplex, osz, :scalar, n, !inv, false, UInt32(0), Any[], launch)
+end
+plan(::SimplexBijector, x::ROCVecOrMat{<:BjxFloat}) = plan_simplex(false, x)
+plan(::Inverse{<:SimplexBijector}, y::ROCVecOrMat{<:BjxFloat}) = plan_simplex(true, y)
+
+# VecCholeskyBijector, corr.jl:227-254: the reference handles ONE Cholesky factor; here a K x K x N ROCArray is a batch of N
+# dense factors (upper filled / lower zero for :U, transposed for :L) and the log-det is the per-sample vector; one
+# ROCMatrix (K x K) is the N = 1 case with a scalar log-det, like the reference.
+uplo(b::VecCholeskyBijector) = Cint(b.mode === :U ? 'U' : 'L')
+function plan(b::VecCholeskyBijector, W::ROCArray{T}) where {T<:BjxFloat}
+    ndims(W) in (2, 3) || return nothing
+    K, n = size(W, 1), size(W, 3)
+    size(W, 2) == K || throw(DimensionMismatch("VecCholeskyBijector: expected square factors, got $(size(W)[1:2])"))
+    h = ctx().h; pw = devptr(W); ul = uplo(b); m = (K * (K - 1)) ÷ 2
+    launch = (out, lps, lsum, fl) -> ccall((:bjx_vec_cholesky, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        h, dtype(T), Cint(0), ul, pw, out, lps, lsum, K, n, fl)
+    return Plan(:bjx_vec_cholesky, ndims(W) == 2 ? (m,) : (m, n), ndims(W) == 2 ? :scalar : :column, n, false, false, UInt32(0), Any[], launch)
+end
+function plan(ib::Inverse{VecCholeskyBijector}, y::ROCVecOrMat{T}) where {T<:BjxFloat}
+    m, n = dims(y); K = Bijectors._triu1_dim_from_length(m)
+    h = ctx().h; py = devptr(y); ul = uplo(ib.orig)
+    launch = (out, lps, lsum, fl) -> ccall((:bjx_vec_cholesky, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        h, dtype(T), Cint(1), ul, py, out, lps, lsum, K, n, fl)
+    return Plan(:bjx_vec_cholesky, y isa ROCVector ? (K, K) : (K, K, n), y isa ROCVector ? :scalar : :column, n, true, false, UInt32(0), Any[], launch)
 end
 
-function with_logabsdet_jacobian(b::OrderedBijector, y::ROCMatrix{T}) where {T}          # ordered.jl:22,80
-    x = similar(y)
-    return x, call_struct(:bjx_ordered, T, y, x, (Cint(0),), (Cint,), size(y, 1); per_column=true)
+# PlanarLayer, planar_layer.jl:65-127,160-185 (one layer per Julia object; stacks: `planar_stack` below)
+function plan_planar(flow::PlanarLayer, inv::Bool, z::ROCVecOrMat{T}, flags::UInt32=UInt32(0)) where {T<:BjxFloat}
+    d, n = dims(z); length(flow.w) == d || throw(DimensionMismatch("PlanarLayer of dimension $(length(flow.w)) applied to $d rows"))
+    w, u, b = ondevice(T, flow.w), ondevice(T, flow.u), ondevice(T, flow.b isa Real ? [flow.b] : flow.b)
+    h = ctx().h; pz = devptr(z); pw, pu, pb = devptr(w), devptr(u), devptr(b)
+    launch = (out, lps, lsum, fl) -> ccall((:bjx_planar, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        h, dtype(T), Cint(inv), pw, pu, pb, Cint(1), pz, out, lps, lsum, d, n, fl)
+    return Plan(:bjx_planar, size(z), :column, n, true, false, flags, Any[w, u, b], launch)
 end
-function with_logabsdet_jacobian(ib::Inverse{OrderedBijector}, x::ROCMatrix{T}) where {T}
-    y = similar(x)
-    return y, call_struct(:bjx_ordered, T, x, y, (Cint(1),), (Cint,), size(x, 1); per_column=true)
+plan(flow::PlanarLayer, z::ROCVecOrMat{<:BjxFloat}) = plan_planar(flow, false, z)
+plan(ib::Inverse{<:PlanarLayer}, y::ROCVecOrMat{<:BjxFloat}) = plan_planar(ib.orig, true, y)
+
+# RadialLayer, radial_layer.jl:43-129
+function plan_radial(flow::RadialLayer, inv::Bool, z::ROCVecOrMat{T}) where {T<:BjxFloat}
+    d, n = dims(z); length(flow.z_0) == d || throw(DimensionMismatch("RadialLayer of dimension $(length(flow.z_0)) applied to $d rows"))
+    a, be, z0 = ondevice(T, flow.α_ isa Real ? [flow.α_] : flow.α_), ondevice(T, flow.β isa Real ? [flow.β] : flow.β), ondevice(T, flow.z_0)
+    h = ctx().h; pz = devptr(z); pa, pbe, pz0 = devptr(a), devptr(be), devptr(z0)
+    launch = (out, lps, lsum, fl) -> ccall((:bjx_radial, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        h, dtype(T), Cint(inv), pa, pbe, pz0, pz, out, lps, lsum, d, n, fl)
+    return Plan(:bjx_radial, size(z), :column, n, false, false, UInt32(0), Any[a, be, z0], launch)
 end
-function with_logabsdet_jacobian(b::SimplexBijector, x::ROCMatrix{T}) where {T}           # simplex.jl:14,141-143
-    K = size(x, 1)
-    y = similar(x, K - 1, size(x, 2))
-    return y, call_struct(:bjx_simplex, T, x, y, (Cint(0),), (Cint,), K; per_column=false)
+plan(flow::RadialLayer, z::ROCVecOrMat{<:BjxFloat}) = plan_radial(flow, false, z)
+plan(ib::Inverse{<:RadialLayer}, y::ROCVecOrMat{<:BjxFloat}) = plan_radial(ib.orig, true, y)
+
+# InvertibleBatchNorm, normalise.jl:41-88.  Eval mode: bjx_batchnorm (both directions).  Training mode (istraining(), forward
+# only — the reference asserts the same, :75): bjx_batchnorm_train; bn.m / bn.v must be ROCVectors (updated on the device,
+# and when the context has a communicator the statistics are all-reduced over the ranks, SURVEY.md §8e).
+function plan_batchnorm(bn::InvertibleBatchNorm, inv::Bool, x::ROCMatrix{T}) where {T<:BjxFloat}
+    d, n = size(x)
+    d == length(bn.b) || error("InvertibleBatchNorm expected $(length(bn.b)) channels, got $d")          # normalise.jl:43-45
+    b, logs = ondevice(T, bn.b), ondevice(T, bn.logs)
+    h = ctx().h; px = devptr(x); pb, pl = devptr(b), devptr(logs); eps = Float64(bn.eps)
+    if Bijectors.istraining()
+        inv && error("`with_logabsdet_jacobian(::Inverse{InvertibleBatchNorm})` is only available in test mode.")
+        (bn.m isa ROCVector{T} && bn.v isa ROCVector{T}) || return nothing       # host statistics: the generic method updates them
+        pm, pv = devptr(bn.m), devptr(bn.v); mtm = Float64(bn.mtm)
+        launch = (out, lps, lsum, fl) -> ccall((:bjx_batchnorm_train, libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+            h, dtype(T), pb, pl, pm, pv, eps, mtm, px, out, lps, lsum, d, n, fl)
+        return Plan(:bjx_batchnorm_train, size(x), :column, n, false, false, UInt32(0), Any[b, logs, bn.m, bn.v], launch)
+    end
+    m, v = ondevice(T, bn.m), ondevice(T, bn.v); pm, pv = devptr(m), devptr(v)
+    launch = (out, lps, lsum, fl) -> ccall((:bjx_batchnorm, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        h, dtype(T), Cint(inv), pb, pl, pm, pv, eps, px, out, lps, lsum, d, n, fl)
+    return Plan(:bjx_batchnorm, size(x), :column, n, false, false, UInt32(0), Any[b, logs, m, v], launch)
 end
-function with_logabsdet_jacobian(ib::Inverse{SimplexBijector}, y::ROCMatrix{T}) where {T}
-    K = size(y, 1) + 1
-    x = similar(y, K, size(y, 2))
-    return x, call_struct(:bjx_simplex, T, y, x, (Cint(1),), (Cint,), K; per_column=false)
+plan(bn::InvertibleBatchNorm, x::ROCMatrix{<:BjxFloat}) = plan_batchnorm(bn, false, x)
+plan(ib::Inverse{<:InvertibleBatchNorm}, y::ROCMatrix{<:BjxFloat}) = plan_batchnorm(ib.orig, true, y)
+
+# RationalQuadraticSpline{<:AbstractMatrix} (rational_quadratic_spline.jl:173-178,227-233,304-309,363-367): the reference has the
+# single-column method (scalar log-det); a ROCMatrix of columns returns the per-column vector.
+function plan_rqs(b::RationalQuadraticSpline{<:AbstractMatrix}, inv::Bool, x::ROCVecOrMat{T}) where {T<:BjxFloat}
+    d, n = dims(x)
+    size(b.widths, 1) == d || throw(DimensionMismatch("RationalQuadraticSpline with $(size(b.widths, 1)) rows applied to $d rows"))
+    w, hh, dd = ondevice(T, b.widths), ondevice(T, b.heights), ondevice(T, b.derivatives)
+    h = ctx().h; px = devptr(x); pw, ph, pd = devptr(w), devptr(hh), devptr(dd); K1 = Cint(size(b.widths, 2))
+    launch = (out, lps, lsum, fl) -> ccall((:bjx_rqs, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        h, dtype(T), Cint(inv), pw, ph, pd, K1, px, out, lps, lsum, d, n, fl)
+    return Plan(:bjx_rqs, size(x), x isa ROCVector ? :scalar : :column, n, false, false, UInt32(0), Any[w, hh, dd], launch)
 end
-function with_logabsdet_jacobian(flow::PlanarLayer{<:ROCVector{T}}, z::ROCMatrix{T}) where {T}   # planar_layer.jl:102-110
-    out = similar(z)
-    l = call_struct(:bjx_planar, T, z, out,
-        (Cint(0), devptr(flow.w), devptr(flow.u), devptr(flow.b), Cint(1)), (Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
-        size(z, 1); per_column=true)
-    return (result=out, logabsdetjac=l)
+plan(b::RationalQuadraticSpline{<:AbstractMatrix}, x::ROCVecOrMat{<:BjxFloat}) = plan_rqs(b, false, x)
+plan(ib::Inverse{<:RationalQuadraticSpline{<:AbstractMatrix}}, y::ROCVecOrMat{<:BjxFloat}) = plan_rqs(ib.orig, true, y)
+
+# The `B` constructor on the device (rational_quadratic_spline.jl:109-123): raw (dim, K), (dim, K), (dim, K-1) -> knots (dim, K+1)
+function rqs_from_raw(raw_w::ROCMatrix{T}, raw_h::ROCMatrix{T}, raw_d::ROCMatrix{T}, B::Real) where {T<:BjxFloat}
+    d, K = size(raw_w)
+    w, hh, dd = similar(raw_w, d, K + 1), similar(raw_w, d, K + 1), similar(raw_w, d, K + 1)
+    GC.@preserve raw_w raw_h raw_d w hh dd check(ccall((:bjx_rqs_params, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        ctx().h, dtype(T), devptr(raw_w), devptr(raw_h), devptr(raw_d), Cint(K), d, Float64(B), devptr(w), devptr(hh), devptr(dd)), "bjx_rqs_params")
+    return RationalQuadraticSpline(w, hh, dd)
 end
-function with_logabsdet_jacobian(flow::RadialLayer, z::ROCMatrix{T}) where {T}                   # radial_layer.jl:58-72
-    out = similar(z)
-    l = call_struct(:bjx_radial, T, z, out, (Cint(0), devptr(flow.α_), devptr(flow.β), devptr(flow.z_0)),
-        (Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), size(z, 1); per_column=true)
-    return (result=out, logabsdetjac=l)
+
+# Permute, permute.jl:152-157: `A * x` for a permutation matrix = a row gather; src[i] = column of the 1 in row i (0-based).
+# inverse(::Permute) is a Permute again (:153), so one plan covers both directions.  Bit-exact; log-det zero.
+gather_list(A) = Int32[findfirst(!iszero, view(A, i, :)) - 1 for i in 1:size(A, 1)]
+function plan(b::Permute, x::ROCVecOrMat{T}) where {T<:BjxFloat}
+    d, n = dims(x); size(b.A) == (d, d) || throw(DimensionMismatch("Permute of size $(size(b.A)) applied to $d rows"))
+    src = ROCArray{Int32}(gather_list(b.A))
+    h = ctx().h; px = devptr(x); ps = Ptr{Int32}(pointer(src))
+    launch = (out, lps, lsum, fl) -> ccall((:bjx_permute, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Int32}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+        h, dtype(T), ps, px, out, d, n)
+    return Plan(:bjx_permute, size(x), :zero, n, false, false, UInt32(0), Any[src], launch)
 end
-function with_logabsdet_jacobian(bn::InvertibleBatchNorm, x::ROCMatrix{T}) where {T}             # normalise.jl:41-68 (eval)
-    Bijectors.istraining() && return invoke(with_logabsdet_jacobian, Tuple{InvertibleBatchNorm,Any}, bn, x)
-    size(x, 1) == length(bn.b) || error("InvertibleBatchNorm expected $(length(bn.b)) channels, got $(size(x, 1))")
-    out = similar(x)
-    l = call_struct(:bjx_batchnorm, T, x, out,
-        (Cint(0), devptr(bn.b), devptr(bn.logs), devptr(bn.m), devptr(bn.v), Float64(bn.eps)),
-        (Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble), size(x, 1); per_column=true)
-    return out, l
+
+# Coupling with a PartitionMask, coupling.jl:125-134,206-259.  θ is an arbitrary Julia closure: it runs HERE, on the x₂ rows
+# (gathered on the device), and must return one of the laws the ABI carries — Shift, Scale, Shift ∘ Scale (parameters Real,
+# length-n₁ vectors shared by every column, or n₁ x N matrices) or a RationalQuadraticSpline with n₁-row knot matrices.
+# Anything else falls back to the reference's generic method.
+mask_rows(A) = Int32.(SparseArrays.rowvals(SparseArrays.sparse(A)) .- 1)       # column j of A_k has its 1 in row idx[j]
+function gather_rows(x::ROCVecOrMat{T}, idx0::Vector{Int32}) where {T}      # x[idx .+ 1, :] through bjx_stacked_ld (identity segments)
+    d, n = dims(x); m = length(idx0)
+    out = x isa ROCVector ? similar(x, m) : similar(x, m, n)
+    m == 0 && return out
+    segs = BjxSegment[]; lo = 1
+    for j in 2:(m + 1)                                                         # maximal runs of consecutive source rows
+        if j > m || idx0[j] != idx0[j - 1] + 1
+            push!(segs, BjxSegment(idx0[lo], lo - 1, j - lo, 0, 0, ntuple(_ -> NOOP, 4))); lo = j
+        end
+    end
+    GC.@preserve x out check(ccall((:bjx_stacked_ld, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        ctx().h, dtype(T), segs, length(segs), devptr(x), d, devptr(out), m, C_NULL, C_NULL, m, n, UInt32(0)), "bjx_stacked_ld")
+    return out
 end
-# RationalQuadraticSpline{<:ROCMatrix} on a batch (the reference has only the single-column method,
-# rational_quadratic_spline.jl:173-178,304-309,363-367): returns the per-column log-det vector.
-function with_logabsdet_jacobian(b::RationalQuadraticSpline{<:ROCMatrix{T}}, x::ROCMatrix{T}) where {T}
-    y = similar(x)
-    l = call_struct(:bjx_rqs, T, x, y,
-        (Cint(0), devptr(b.widths), devptr(b.heights), devptr(b.derivatives), Cint(size(b.widths, 2))),
-        (Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), size(x, 1); per_column=true)
-    return y, l
+# law -> (kind, scale, shift | knots) ; nothing = not carried by the ABI
+coupling_law(l::Shift) = (:affine, nothing, l.a)
+coupling_law(l::Scale) = (:affine, l.a, nothing)
+coupling_law(l::ComposedFunction{<:Shift,<:Scale}) = (:affine, l.inner.a, l.outer.a)
+coupling_law(l::RationalQuadraticSpline{<:AbstractMatrix}) = (:rqs, l, nothing)
+coupling_law(l) = nothing
+function affine_arg(::Type{T}, a, n1, n, keep) where {T}        # -> (device pointer, one value per row shared by every column?)
+    a === nothing && return C_NULL, false
+    v = ondevice(T, a isa Real ? fill(T(a), n1) : a); push!(keep, v)
+    length(v) == n1 * n && return devptr(v), false           # T[n1, batch]
+    length(v) == n1 || throw(DimensionMismatch("coupling law parameter of length $(length(v)) for $n1 transformed rows"))
+    return devptr(v), true                                   # T[n1]: BJX_COUPLING_*_BCAST, nothing is expanded
 end
-# VecCholeskyBijector, Permute, Coupling and the Inverse{…} flow methods follow the same pattern
-# (bjx_vec_cholesky / bjx_permute / bjx_coupling_* / inverse = Cint(1)); see INTEGRATION.md.
+function plan_coupling(cl::Coupling, inv::Bool, x::ROCVecOrMat{T}) where {T<:BjxFloat}
+    d, n = dims(x)
+    idx1, idx2 = mask_rows(cl.mask.A_1), mask_rows(cl.mask.A_2)
+    law = coupling_law(cl.θ(gather_rows(x, idx2)))                               # θ(x₂): host closure, device arrays
+    law === nothing && return nothing
+    n1 = length(idx1); keep = Any[]
+    di = ROCArray{Int32}(idx1); push!(keep, di)
+    h = ctx().h; px = devptr(x); pi1 = Ptr{Int32}(pointer(di))
+    if law[1] === :affine
+        ps, sb = affine_arg(T, law[2], n1, n, keep)
+        pt, tb = affine_arg(T, law[3], n1, n, keep)
+        cf = (sb ? BJX_COUPLING_SCALE_BCAST : UInt32(0)) | (tb ? BJX_COUPLING_SHIFT_BCAST : UInt32(0))
+        launch = (out, lps, lsum, fl) -> ccall((:bjx_coupling_affine, libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Ptr{Int32}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+            h, dtype(T), Cint(inv), pi1, n1, ps, pt, px, out, lps, lsum, d, n, fl)
+        return Plan(:bjx_coupling_affine, size(x), x isa ROCVector ? :scalar : :column, n, false, false, cf, keep, launch)
+    end
+    sp = law[2]
+    size(sp.widths, 1) == n1 || throw(DimensionMismatch("spline coupling law with $(size(sp.widths, 1)) rows for $n1 transformed rows"))
+    w, hh, dd = ondevice(T, sp.widths), ondevice(T, sp.heights), ondevice(T, sp.derivatives); push!(keep, w, hh, dd)
+    pw, ph, pd = devptr(w), devptr(hh), devptr(dd); K1 = Cint(size(sp.widths, 2))
+    launch = (out, lps, lsum, fl) -> ccall((:bjx_coupling_rqs, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Int32}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        h, dtype(T), Cint(inv), pi1, n1, pw, ph, pd, K1, px, out, lps, lsum, d, n, fl)
+    return Plan(:bjx_coupling_rqs, size(x), x isa ROCVector ? :scalar : :column, n, false, false, UInt32(0), keep, launch)
+end
+plan(cl::Coupling, x::ROCVecOrMat{<:BjxFloat}) = plan_coupling(cl, false, x)
+plan(icl::Inverse{<:Coupling}, y::ROCVecOrMat{<:BjxFloat}) = plan_coupling(icl.orig, true, y)     # θ(y₂) = θ(x₂): the rows pass through
 
 # ---------------------------------------------------------------- matrix-variate constraint bijectors (SURVEY.md §8f f-4)
 # corr.jl:64-162, pd.jl:1-60.  The reference defines them for ONE matrix; a K x K x N ROCArray is a batch of N samples
 # and returns the per-sample log-det vector.  (A single ROCMatrix is the N = 1 case and returns the scalar.)
 const MatrixKinds = Union{VecCorrBijector,CorrBijector,PDBijector,PDVecBijector}
-bjx_symbol(::VecCorrBijector) = :bjx_vec_corr
-bjx_symbol(::CorrBijector) = :bjx_corr
-bjx_symbol(::PDBijector) = :bjx_pd
-bjx_symbol(::PDVecBijector) = :bjx_pd_vec
+packed(b) = b isa Union{VecCorrBijector,PDVecBijector}
 packed_length(::VecCorrBijector, K) = (K * (K - 1)) ÷ 2                      # corr.jl:150-154
 packed_length(::PDVecBijector, K) = (K * (K + 1)) ÷ 2                        # pd.jl:50-54
-function matrix_call(b::MatrixKinds, inv::Bool, inp::ROCArray{T}, out::ROCArray{T}, K, n) where {T}
-    lps = similar(inp, T, n)
-    GC.@preserve inp out lps begin
-        rc = ccall((bjx_symbol(b), libbjx), Cint,
-            (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
-            ctx().h, dtype(T), Cint(inv), devptr(inp), devptr(out), devptr(lps), C_NULL, K, n, UInt32(0))
-        check(rc, String(bjx_symbol(b)))
-    end
-    return lps
-end
-function with_logabsdet_jacobian(b::Union{VecCorrBijector,PDVecBijector}, X::ROCArray{T,3}) where {T}
-    K, n = size(X, 1), size(X, 3)
+unpacked_dim(::VecCorrBijector, m) = Bijectors._triu1_dim_from_length(m)
+unpacked_dim(::PDVecBijector, m) = Bijectors._triu_dim_from_length(m)
+# one literal ccall per entry (the static ABI check reads them)
+matrix_launch(::VecCorrBijector, h, dt, inv, pin, K, n) = (out, lps, lsum, fl) -> ccall((:bjx_vec_corr, libbjx), Cint,
+    (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32), h, dt, inv, pin, out, lps, lsum, K, n, fl)
+matrix_launch(::CorrBijector, h, dt, inv, pin, K, n) = (out, lps, lsum, fl) -> ccall((:bjx_corr, libbjx), Cint,
+    (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32), h, dt, inv, pin, out, lps, lsum, K, n, fl)
+matrix_launch(::PDBijector, h, dt, inv, pin, K, n) = (out, lps, lsum, fl) -> ccall((:bjx_pd, libbjx), Cint,
+    (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32), h, dt, inv, pin, out, lps, lsum, K, n, fl)
+matrix_launch(::PDVecBijector, h, dt, inv, pin, K, n) = (out, lps, lsum, fl) -> ccall((:bjx_pd_vec, libbjx), Cint,
+    (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32), h, dt, inv, pin, out, lps, lsum, K, n, fl)
+entry_name(::VecCorrBijector) = :bjx_vec_corr
+entry_name(::CorrBijector) = :bjx_corr
+entry_name(::PDBijector) = :bjx_pd
+entry_name(::PDVecBijector) = :bjx_pd_vec
+function plan(b::MatrixKinds, X::ROCArray{T}) where {T<:BjxFloat}
+    ndims(X) in (2, 3) || return nothing
+    K, n = size(X, 1), size(X, 3); single = ndims(X) == 2
     size(X, 2) == K || throw(DimensionMismatch("sizes should be equal; received $(size(X)[1:2])"))
-    y = similar(X, packed_length(b, K), n)
-    return y, matrix_call(b, false, X, y, K, n)
+    osz = packed(b) ? (single ? (packed_length(b, K),) : (packed_length(b, K), n)) : size(X)
+    return Plan(entry_name(b), osz, single ? :scalar : :column, n, true, false, UInt32(0), Any[],
+                matrix_launch(b, ctx().h, dtype(T), Cint(0), devptr(X), K, n))
 end
-function with_logabsdet_jacobian(ib::Inverse{<:Union{VecCorrBijector,PDVecBijector}}, y::ROCMatrix{T}) where {T}
+function plan(ib::Inverse{<:MatrixKinds}, Y::ROCArray{T}) where {T<:BjxFloat}
     b = ib.orig
-    K = b isa VecCorrBijector ? Bijectors._triu1_dim_from_length(size(y, 1)) : Bijectors._triu_dim_from_length(size(y, 1))
-    X = similar(y, K, K, size(y, 2))
-    return X, matrix_call(b, true, y, X, K, size(y, 2))
-end
-function with_logabsdet_jacobian(b::Union{CorrBijector,PDBijector}, X::ROCArray{T,3}) where {T}
-    Y = similar(X)
-    return Y, matrix_call(b, false, X, Y, size(X, 1), size(X, 3))
-end
-function with_logabsdet_jacobian(ib::Inverse{<:Union{CorrBijector,PDBijector}}, Y::ROCArray{T,3}) where {T}
-    X = similar(Y)
-    return X, matrix_call(ib.orig, true, Y, X, size(Y, 1), size(Y, 3))
-end
-# one matrix (the reference's call shape): the N = 1 batch, scalar log-det
-function with_logabsdet_jacobian(b::Union{MatrixKinds,Inverse{<:MatrixKinds}}, x::ROCVecOrMat{T}) where {T}
-    out, l = with_logabsdet_jacobian(b, reshape(x, size(x)..., 1))
-    return dropdims(out; dims=ndims(out)), Array(l)[1]
+    if packed(b)
+        ndims(Y) in (1, 2) || return nothing
+        m, n = dims(Y); K = unpacked_dim(b, m); single = Y isa ROCVector
+        osz = single ? (K, K) : (K, K, n)
+    else
+        ndims(Y) in (2, 3) || return nothing
+        K, n = size(Y, 1), size(Y, 3); single = ndims(Y) == 2; osz = size(Y)
+    end
+    return Plan(entry_name(b), osz, single ? :scalar : :column, n, true, false, UInt32(0), Any[],
+                matrix_launch(b, ctx().h, dtype(T), Cint(1), devptr(Y), K, n))
 end
 
-# Scale with a matrix parameter (scale.jl:14,17,35-36): a * x, a \ y, logabsdet(a) once
-function scale_matrix(a::ROCMatrix{T}, x::ROCVecOrMat{T}, inv::Bool) where {T}
+# Scale with a matrix parameter (scale.jl:14,17,35-36): a * x, a \ y, logabsdet(a) ONCE whatever the number of columns
+function plan_scale_matrix(a::ROCMatrix{T}, inv::Bool, x::ROCVecOrMat{T}) where {T<:BjxFloat}
     d, n = dims(x)
     size(a) == (d, d) || throw(DimensionMismatch("Scale with a $(size(a)) matrix applied to $d rows"))
-    y = similar(x)
-    lsum = AMDGPU.zeros(Float64, 1)
-    GC.@preserve a x y lsum begin
-        rc = ccall((:bjx_scale_matrix, libbjx), Cint,
-            (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
-            ctx().h, dtype(T), Cint(inv), devptr(a), devptr(x), devptr(y), C_NULL, devptr(lsum), d, n, BJX_REF_VECTOR_SCALE_LADJ)
-        check(rc, "bjx_scale_matrix")
-    end
-    return y, T(Array(lsum)[1])
+    h = ctx().h; pa = devptr(a); px = devptr(x)
+    launch = (out, lps, lsum, fl) -> ccall((:bjx_scale_matrix, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        h, dtype(T), Cint(inv), pa, px, out, lps, lsum, d, n, fl)
+    return Plan(:bjx_scale_matrix, size(x), :scalar, n, true, false, BJX_REF_VECTOR_SCALE_LADJ, Any[a], launch)
 end
-with_logabsdet_jacobian(b::Scale{<:ROCMatrix{T}}, x::ROCVecOrMat{T}) where {T} = scale_matrix(b.a, x, false)
-with_logabsdet_jacobian(ib::Inverse{<:Scale{<:ROCMatrix{T}}}, y::ROCVecOrMat{T}) where {T} = scale_matrix(ib.orig.a, y, true)
+plan(b::Scale{<:ROCMatrix{T}}, x::ROCVecOrMat{T}) where {T<:BjxFloat} = plan_scale_matrix(b.a, false, x)
+plan(ib::Inverse{<:Scale{<:ROCMatrix{T}}}, y::ROCVecOrMat{T}) where {T<:BjxFloat} = plan_scale_matrix(ib.orig.a, true, y)
 
-# InvertibleBatchNorm in training mode on a batch sharded over ranks (normalise.jl:51-60; SURVEY.md §8e "Exception"):
-# statistics of this rank's columns -> the host's collective (MPI.Allreduce!, or bjx_allreduce_sum_f64 after bjx_comm_init)
-# -> update of the moving statistics and transform with the GLOBAL statistics.
+# ---------------------------------------------------------------- the six interface methods, once (src/interface.jl:156-218)
+const Structured = Union{OrderedBijector,Inverse{OrderedBijector},SimplexBijector,Inverse{<:SimplexBijector},
+    VecCholeskyBijector,Inverse{VecCholeskyBijector},PlanarLayer,Inverse{<:PlanarLayer},RadialLayer,Inverse{<:RadialLayer},
+    InvertibleBatchNorm,Inverse{<:InvertibleBatchNorm},RationalQuadraticSpline{<:AbstractMatrix},
+    Inverse{<:RationalQuadraticSpline{<:AbstractMatrix}},Permute,Coupling,Inverse{<:Coupling},
+    MatrixKinds,Inverse{<:MatrixKinds},Scale{<:ROCMatrix},Inverse{<:Scale{<:ROCMatrix}}}
+const Planned = Union{Fusable,Structured}
+
+# the reference's return containers: NamedTuple for the flow layers (planar_layer.jl:102-110, radial_layer.jl:58-72), tuple otherwise
+wrap(::Union{PlanarLayer,RadialLayer}, y, l) = (result=y, logabsdetjac=l)
+wrap(b, y, l) = (y, l)
+
+function with_logabsdet_jacobian(b::Planned, x::ROCArray{T}) where {T<:BjxFloat}
+    p = plan(b, x)
+    p === nothing && return invoke(with_logabsdet_jacobian, Tuple{typeof(b),Any}, b, x)      # not expressible across the ABI
+    y = similar(x, T, p.outsize)
+    return wrap(b, y, run!(p, T, x, y))
+end
+function transform(b::Planned, x::ROCArray{T}) where {T<:BjxFloat}
+    p = plan(b, x)
+    p === nothing && return invoke(transform, Tuple{typeof(b),Any}, b, x)
+    y = similar(x, T, p.outsize)
+    run!(p, T, x, y; want_ladj=false)                          # ladj_ps = ladj_sum = C_NULL: no reduction, no extra launch
+    return y
+end
+function logabsdetjac(b::Planned, x::ROCArray{T}) where {T<:BjxFloat}
+    p = plan(b, x)
+    p === nothing && return invoke(logabsdetjac, Tuple{typeof(b),Any}, b, x)
+    return run!(p, T, x, nothing)                              # out = C_NULL where the entry allows it: half the traffic
+end
+# transform!(b, x, y) (interface.jl:175-176); transform!(b, x) = transform!(b, x, x) only where the kernel may run in place
+function transform!(b::Planned, x::ROCArray{T}, y::ROCArray{T}) where {T<:BjxFloat}
+    p = plan(b, x)
+    p === nothing && return invoke(transform!, Tuple{Any,Any,Any}, b, x, y)
+    size(y) == p.outsize || throw(DimensionMismatch("transform!: output of size $(size(y)), expected $(p.outsize)"))
+    if pointer(y) == pointer(x) && !p.alias_ok
+        copyto!(y, transform(b, x))
+    else
+        run!(p, T, x, y; want_ladj=false)
+    end
+    return y
+end
+transform!(b::Planned, x::ROCArray{<:BjxFloat}) = transform!(b, x, x)
+# logabsdetjac!(b, x, logjac) (interface.jl:199-200): returns logjac + logabsdetjac(b, x); a ROCVector accumulator of per-column
+# log-dets is updated IN PLACE by the kernel (BJX_ACCUMULATE)
+function logabsdetjac!(b::Planned, x::ROCArray{T}, logjac) where {T<:BjxFloat}
+    p = plan(b, x)
+    p === nothing && return invoke(logabsdetjac!, Tuple{Any,Any,Any}, b, x, logjac)
+    if logjac isa ROCVector{T} && p.ladj === :column
+        return run!(p, T, x, nothing; lps_into=logjac)
+    end
+    return logjac .+ run!(p, T, x, nothing)
+end
+logabsdetjac!(b::Planned, x::ROCArray{T}) where {T<:BjxFloat} = logabsdetjac!(b, x, zero(T))
+# with_logabsdet_jacobian!(b, x, y, logjac) -> (y, logjac + new) (interface.jl:212-218)
+function with_logabsdet_jacobian!(b::Planned, x::ROCArray{T}, y::ROCArray{T}, logjac) where {T<:BjxFloat}
+    p = plan(b, x)
+    p === nothing && return invoke(with_logabsdet_jacobian!, Tuple{Any,Any,Any,Any}, b, x, y, logjac)
+    size(y) == p.outsize || throw(DimensionMismatch("with_logabsdet_jacobian!: output of size $(size(y)), expected $(p.outsize)"))
+    if pointer(y) == pointer(x) && !p.alias_ok
+        y_, l = with_logabsdet_jacobian(b, x)                  # (a NamedTuple destructures into its two values)
+        return copyto!(y, y_), logjac .+ l
+    end
+    if logjac isa ROCVector{T} && p.ladj === :column
+        return y, run!(p, T, x, y; lps_into=logjac)
+    end
+    return y, logjac .+ run!(p, T, x, y)
+end
+with_logabsdet_jacobian!(b::Planned, x::ROCArray{T}, y::ROCArray{T}) where {T<:BjxFloat} = with_logabsdet_jacobian!(b, x, y, zero(T))
+with_logabsdet_jacobian!(b::Planned, x::ROCArray{<:BjxFloat}) = with_logabsdet_jacobian!(b, x, x)
+
+# a stack of PlanarLayers composed with ∘ is ONE launch (n_layers fused, BASELINE configs[3]); layer 1 is applied first
+function planar_stack(layers::Vector{<:PlanarLayer}, z::ROCMatrix{T}; inverse::Bool=false, base_stdnormal::Bool=false, out=similar(z)) where {T<:BjxFloat}
+    d, n = size(z); L = length(layers)
+    w = ROCArray{T}(reduce(vcat, [Array(l.w) for l in layers])); u = ROCArray{T}(reduce(vcat, [Array(l.u) for l in layers]))
+    b = ROCArray{T}([first(Array(l.b isa Real ? [l.b] : l.b)) for l in layers])
+    lps = similar(z, n)
+    fl = base_stdnormal ? BJX_BASE_STDNORMAL : UInt32(0)
+    GC.@preserve w u b z out lps check(ccall((:bjx_planar, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        ctx().h, dtype(T), Cint(inverse), devptr(w), devptr(u), devptr(b), Cint(L), devptr(z), devptr(out), devptr(lps), C_NULL, d, n, fl), "bjx_planar")
+    return out, lps
+end
+
+# InvertibleBatchNorm in training mode on a batch sharded over ranks (normalise.jl:51-60; SURVEY.md §8e "Exception"), for
+# hosts that own the collective: statistics of this rank's columns -> allreduce! (MPI.Allreduce!, or
+# allreduce_logabsdetjac! after comm_init) -> update of the moving statistics and transform with the GLOBAL statistics.
 function batchnorm_train!(bn::InvertibleBatchNorm, x::ROCMatrix{T}; allreduce! = identity) where {T}
     d, n = size(x)
     stats = AMDGPU.zeros(Float64, 2d + 1)
     GC.@preserve bn x stats check(ccall((:bjx_batchnorm_stats, libbjx), Cint,
-        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-        ctx().h, dtype(T), devptr(bn.m), devptr(x), devptr(stats), d, n), "bjx_batchnorm_stats")
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64),
+        ctx().h, dtype(T), devptr(bn.m), devptr(x), Ptr{Cdouble}(pointer(stats)), d, n), "bjx_batchnorm_stats")
     allreduce!(stats)                                      # sum of the 2d+1 Float64 values over the ranks
     y = similar(x); lps = similar(x, T, n)
     GC.@preserve bn x y lps stats check(ccall((:bjx_batchnorm_train_apply, libbjx), Cint,
-        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
         ctx().h, dtype(T), devptr(bn.b), devptr(bn.logs), devptr(bn.m), devptr(bn.v), Float64(bn.eps), Float64(bn.mtm),
-        devptr(stats), devptr(x), devptr(y), devptr(lps), C_NULL, d, n, UInt32(0)), "bjx_batchnorm_train_apply")
+        Ptr{Cdouble}(pointer(stats)), devptr(x), devptr(y), devptr(lps), C_NULL, d, n, UInt32(0)), "bjx_batchnorm_train_apply")
     return y, lps
 end
 
 # ---------------------------------------------------------------- Stacked (SURVEY.md §8f f-4)
 # stacked.jl:27-252: every segment whose bijector is a fusable elementwise chain goes into ONE launch.
-struct BjxSegment
-    in_lo::Int64; out_lo::Int64; len::Int64; n_ops::Int32; reserved::Int32
-    ops::NTuple{4,BjxOp}
+segment(rin, rout, o) = BjxSegment(first(rin) - 1, first(rout) - 1, length(rin), length(o), 0, ntuple(k -> k <= length(o) ? o[k] : NOOP, 4))
+function elementwise_segments(sb::Stacked, T, keep)           # nothing when a segment is not an elementwise chain of <= 4 ops
+    segs = BjxSegment[]
+    for (b, rin, rout) in zip(sb.bs, sb.ranges_in, sb.ranges_out)
+        o = ops(b, T, keep)
+        (o === nothing || length(o) > 4 || length(rin) != length(rout)) && return nothing
+        push!(segs, segment(rin, rout, o))
+    end
+    return segs
 end
-const NOOP = BjxOp(Int32(OP_IDENTITY), 0, 0, 0, C_NULL, C_NULL)
-function with_logabsdet_jacobian(sb::Stacked, x::ROCVecOrMat{T}) where {T<:Union{Float32,Float64}}
+function with_logabsdet_jacobian(sb::Stacked, x::ROCVecOrMat{T}) where {T<:BjxFloat}
     d, n = dims(x)
     sb.length_in == d || error("input length mismatch ($(sb.length_in) != $d)")          # stacked.jl:157
     keep = Any[]
-    segs = BjxSegment[]
-    for (b, rin, rout) in zip(sb.bs, sb.ranges_in, sb.ranges_out)
-        o = b === identity ? BjxOp[] : ops(b, T, keep)
-        (o === nothing || length(o) > 4 || length(rin) != length(rout)) &&
-            return stacked_structured(sb, x)                                               # Simplex / Ordered blocks: in place, below
-        push!(segs, BjxSegment(first(rin) - 1, first(rout) - 1, length(rin), length(o), 0,
-                               ntuple(k -> k <= length(o) ? o[k] : NOOP, 4)))
-    end
+    segs = elementwise_segments(sb, T, keep)
+    segs === nothing && return stacked_structured(sb, x)                                   # Simplex / Ordered blocks: below
     y = similar(x)
     lsum = AMDGPU.zeros(Float64, 1)
     GC.@preserve keep x y lsum begin
         rc = ccall((:bjx_stacked, libbjx), Cint,
-            (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
-            ctx().h, dtype(T), segs, length(segs), devptr(x), devptr(y), C_NULL, devptr(lsum), d, n, 0)
+            (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, UInt32),
+            ctx().h, dtype(T), segs, length(segs), devptr(x), devptr(y), C_NULL, Ptr{Cdouble}(pointer(lsum)), d, n, UInt32(0))
         check(rc, "bjx_stacked")
     end
     return y, T(Array(lsum)[1])
 end
+transform(sb::Stacked, x::ROCVecOrMat{<:BjxFloat}) = first(with_logabsdet_jacobian(sb, x))
+logabsdetjac(sb::Stacked, x::ROCVecOrMat{<:BjxFloat}) = last(with_logabsdet_jacobian(sb, x))
+transform!(sb::Stacked, x::ROCVecOrMat{T}, y::ROCVecOrMat{T}) where {T<:BjxFloat} = copyto!(y, transform(sb, x))
+logabsdetjac!(sb::Stacked, x::ROCVecOrMat{<:BjxFloat}, logjac) = logjac .+ logabsdetjac(sb, x)
+function with_logabsdet_jacobian!(sb::Stacked, x::ROCVecOrMat{T}, y::ROCVecOrMat{T}, logjac) where {T<:BjxFloat}
+    y_, l = with_logabsdet_jacobian(sb, x)
+    return copyto!(y, y_), logjac .+ l
+end
+# NamedStacked (named_stacked.jl:1-60) is Stacked over the concatenated fields: host side only, no entry of its own.
 
 # Stacked with Simplex / Ordered segments (stacked.jl:142-166) without slicing copies: the elementwise segments in one
 # bjx_stacked_ld launch between matrices of different heights (identity placeholders on the structured rows), then
 # bjx_simplex_ld / bjx_ordered_ld on row windows of the same matrices, accumulating their log-dets.
-struct BjxBlock            # include/bjx.h: bjx_block
-    kind::Cint; reserved::Cint; in_lo::Int64; out_lo::Int64; len_in::Int64; len_out::Int64
-end
-structured_entry(::SimplexBijector) = (:bjx_simplex_ld, false)
-structured_entry(::Inverse{SimplexBijector}) = (:bjx_simplex_ld, true)
-structured_entry(::OrderedBijector) = (:bjx_ordered_ld, false)
-structured_entry(::Inverse{OrderedBijector}) = (:bjx_ordered_ld, true)
+structured_entry(::SimplexBijector) = (:simplex, false)
+structured_entry(::Inverse{<:SimplexBijector}) = (:simplex, true)
+structured_entry(::OrderedBijector) = (:ordered, false)
+structured_entry(::Inverse{OrderedBijector}) = (:ordered, true)
 structured_entry(b) = nothing
-function stacked_structured(sb::Stacked, x::ROCMatrix{T}) where {T<:Union{Float32,Float64}}
+function window_call(kind::Symbol, ::Type{T}, inv::Bool, pin, ld_in, pout, ld_out, lps, K, n) where {T}
+    if kind === :simplex
+        return ccall((:bjx_simplex_ld, libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, UInt32),
+            ctx().h, dtype(T), Cint(inv), pin, ld_in, pout, ld_out, lps, C_NULL, K, n, BJX_ACCUMULATE)
+    end
+    return ccall((:bjx_ordered_ld, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, UInt32),
+        ctx().h, dtype(T), Cint(inv), pin, ld_in, pout, ld_out, lps, C_NULL, K, n, BJX_ACCUMULATE)
+end
+function stacked_structured(sb::Stacked, x::ROCMatrix{T}) where {T<:BjxFloat}
     d, n = size(x)
     dout = last(last(sb.ranges_out))
     keep = Any[]; segs = BjxSegment[]; later = Any[]
     for (b, rin, rout) in zip(sb.bs, sb.ranges_in, sb.ranges_out)
-        o = b === identity ? BjxOp[] : ops(b, T, keep)
+        o = ops(b, T, keep)
         if o !== nothing && length(o) <= 4 && length(rin) == length(rout)
-            push!(segs, BjxSegment(first(rin) - 1, first(rout) - 1, length(rin), length(o), 0, ntuple(k -> k <= length(o) ? o[k] : NOOP, 4)))
+            push!(segs, segment(rin, rout, o))
         else
             e = structured_entry(b)
             e === nothing && return invoke(with_logabsdet_jacobian, Tuple{Stacked,AbstractMatrix}, sb, x)
@@ -335,11 +609,11 @@ function stacked_structured(sb::Stacked, x::ROCMatrix{T}) where {T<:Union{Float3
     end
     y = similar(x, dout, n); lps = AMDGPU.zeros(T, n)
     # ONE launch when a column fits the LDS tile (bjx_stacked_mixed: a lane walks its column through every segment)
-    blocks = [BjxBlock(Cint(sym === :bjx_simplex_ld ? (inv ? 2 : 1) : (inv ? 4 : 3)), Cint(0), first(rin) - 1, first(rout) - 1, length(rin), length(rout))
-              for ((sym, inv), rin, rout) in later]
+    blocks = [BjxBlock(Cint(kind === :simplex ? (inv ? 2 : 1) : (inv ? 4 : 3)), Cint(0), first(rin) - 1, first(rout) - 1, length(rin), length(rout))
+              for ((kind, inv), rin, rout) in later]
     elem = [sg for sg in segs if !any(b -> b.out_lo == sg.out_lo, blocks)]
     rc = GC.@preserve keep x y lps ccall((:bjx_stacked_mixed, libbjx), Cint,
-        (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{BjxBlock}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, UInt32),
+        (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{BjxBlock}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cdouble}, Int64, UInt32),
         ctx().h, dtype(T), elem, length(elem), blocks, length(blocks), devptr(x), d, devptr(y), dout, devptr(lps), C_NULL, n, UInt32(0))
     rc == 0 && return y, lps
     rc == BJX_ERR_UNSUPPORTED || check(rc, "bjx_stacked_mixed")       # taller columns: the window launches below
@@ -347,90 +621,177 @@ function stacked_structured(sb::Stacked, x::ROCMatrix{T}) where {T<:Union{Float3
         check(ccall((:bjx_stacked_ld, libbjx), Cint,
             (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
             ctx().h, dtype(T), segs, length(segs), devptr(x), d, devptr(y), dout, devptr(lps), C_NULL, dout, n, UInt32(0)), "bjx_stacked_ld")
-        for ((sym, inv), rin, rout) in later
-            K = sym === :bjx_simplex_ld ? (inv ? length(rout) : length(rin)) : length(rin)
-            check(ccall((sym, libbjx), Cint,
-                (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
-                ctx().h, dtype(T), Cint(inv), devptr(x) + (first(rin) - 1) * sizeof(T), d, devptr(y) + (first(rout) - 1) * sizeof(T), dout,
-                devptr(lps), C_NULL, K, n, BJX_ACCUMULATE), String(sym))
+        for ((kind, inv), rin, rout) in later
+            K = kind === :simplex ? (inv ? length(rout) : length(rin)) : length(rin)
+            check(window_call(kind, T, inv, devptr(x) + (first(rin) - 1) * sizeof(T), d, devptr(y) + (first(rout) - 1) * sizeof(T), dout,
+                              devptr(lps), K, n), "bjx_$(kind)_ld")
         end
     end
     return y, lps
 end
 
+# ---------------------------------------------------------------- reverse-mode pullbacks (SURVEY.md §8f f-1)
+# The reference's own rrules (ext/BijectorsChainRulesCoreExt.jl:65-197, :199-320) for ROCArray primals, and rrules of
+# with_logabsdet_jacobian for the bijectors whose pullback the reference leaves to the AD package: the pullback closure
+# calls the `_vjp` entry with the saved primal input.  Cotangent convention of every `_vjp` entry:
+#   in_bar = J(in)ᵀ out_bar + ladj_bar ∇ logabsdetjac(in).
+cotangent(::Type{T}, Δ, like) where {T} = (d = unthunk(Δ); d isa ChainRulesCore.AbstractZero ? fill!(similar(like), zero(T)) : ondevice(T, d))
+ladj_cotangent(::Type{T}, Δ, n) where {T} = (d = unthunk(Δ); d isa ChainRulesCore.AbstractZero ? nothing : (d isa Real ? ROCArray{T}(fill(T(d), n)) : ondevice(T, d)))
+
+function ordered_vjp(inv::Bool, x::ROCMatrix{T}, Δy, Δl=nothing) where {T}
+    x̄ = similar(x)
+    GC.@preserve x Δy Δl x̄ check(ccall((:bjx_ordered_vjp, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+        ctx().h, dtype(T), Cint(inv), devptr(x), devptr(Δy), devptr(Δl), devptr(x̄), size(x, 1), size(x, 2)), "bjx_ordered_vjp")
+    return x̄
+end
+function ChainRulesCore.rrule(::typeof(Bijectors._transform_ordered), y::ROCMatrix{T}) where {T<:BjxFloat}       # ext/…CoreExt.jl:92-117
+    x = transform(OrderedBijector(), y)
+    _transform_ordered_adjoint(Δ) = (NoTangent(), ordered_vjp(false, y, cotangent(T, Δ, y)))
+    return x, _transform_ordered_adjoint
+end
+function ChainRulesCore.rrule(::typeof(Bijectors._transform_inverse_ordered), x::ROCMatrix{T}) where {T<:BjxFloat}  # :155-197
+    y = transform(inverse(OrderedBijector()), x)
+    _transform_inverse_ordered_adjoint(Δ) = (NoTangent(), ordered_vjp(true, x, cotangent(T, Δ, x)))
+    return y, _transform_inverse_ordered_adjoint
+end
+
+# SimplexBijector: simplex.jl:145-215 (simplex_logabsdetjac_gradient), :248-308 (link adjoint), :358-470 (invlink adjoint) as one
+# O(K) pullback of with_logabsdet_jacobian per direction.  The log-det is a scalar (summed over columns): its cotangent is a Real.
+function simplex_vjp(inv::Bool, x::ROCMatrix{T}, Δy, Δl) where {T}
+    K = inv ? size(x, 1) + 1 : size(x, 1); n = size(x, 2)
+    x̄ = similar(x)
+    GC.@preserve x Δy Δl x̄ check(ccall((:bjx_simplex_vjp, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+        ctx().h, dtype(T), Cint(inv), devptr(x), devptr(Δy), devptr(Δl), devptr(x̄), K, n), "bjx_simplex_vjp")
+    return x̄
+end
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), b::Union{SimplexBijector,Inverse{<:SimplexBijector}}, x::ROCMatrix{T}) where {T<:BjxFloat}
+    out = with_logabsdet_jacobian(b, x)
+    inv = b isa Inverse
+    function pullback_simplex((Δy, Δl))
+        x̄ = simplex_vjp(inv, x, cotangent(T, Δy, out[1]), ladj_cotangent(T, Δl, size(x, 2)))
+        return NoTangent(), NoTangent(), x̄
+    end
+    return out, pullback_simplex
+end
+
+# Elementwise chains and Stacked of elementwise chains: x̄ = (dy/dx) ȳ + ℓ̄ d logabsdetjac/dx, element by element
+# (bjx_stacked_vjp; same segment list as bjx_stacked).  The log-det is a scalar: ℓ̄ is a Real, broadcast to the columns.
+function stacked_vjp(segs::Vector{BjxSegment}, keep, x::ROCVecOrMat{T}, Δy, Δl) where {T}
+    d, n = dims(x)
+    x̄ = similar(x)
+    GC.@preserve keep x Δy Δl x̄ check(ccall((:bjx_stacked_vjp, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+        ctx().h, dtype(T), segs, length(segs), devptr(x), devptr(Δy), devptr(Δl), devptr(x̄), d, n), "bjx_stacked_vjp")
+    return x̄
+end
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), b::Fusable, x::ROCVecOrMat{T}) where {T<:BjxFloat}
+    keep = Any[]
+    o = ops(b, T, keep)
+    (o === nothing || length(o) > 4) && return nothing          # `nothing` = no rule: the AD package differentiates the stages
+    out = with_logabsdet_jacobian(b, x)
+    segs = [segment(1:size(x, 1), 1:size(x, 1), o)]
+    function pullback_chain((Δy, Δl))
+        x̄ = stacked_vjp(segs, keep, x, cotangent(T, Δy, out[1]), ladj_cotangent(T, Δl, dims(x)[2]))
+        return NoTangent(), NoTangent(), x̄              # parameter cotangents: meanfield_pullback / the AD package
+    end
+    return out, pullback_chain
+end
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), sb::Stacked, x::ROCVecOrMat{T}) where {T<:BjxFloat}
+    keep = Any[]
+    segs = elementwise_segments(sb, T, keep)
+    segs === nothing && return nothing
+    out = with_logabsdet_jacobian(sb, x)
+    function pullback_stacked((Δy, Δl))
+        x̄ = stacked_vjp(segs, keep, x, cotangent(T, Δy, out[1]), ladj_cotangent(T, Δl, dims(x)[2]))
+        return NoTangent(), NoTangent(), x̄
+    end
+    return out, pullback_stacked
+end
+
 # Mean-field family y = tail(μ .+ σ .* z) (ADVI): input pullback and the (μ̄, σ̄) reductions in ONE pass over z and ȳ.
 # moments[1:d] = Σ_n z̄, moments[d+1:2d] = Σ_n z̄ .* z  =>  μ̄ = moments[1:d] ./ σ,  σ̄ = (moments[d+1:2d] .+ sum(ℓ̄)) ./ σ
-function meanfield_pullback(chain, z::ROCMatrix{T}, ȳ::ROCMatrix{T}, ℓ̄::ROCVector{T}) where {T<:Union{Float32,Float64}}
+function meanfield_pullback(chain, z::ROCMatrix{T}, ȳ::ROCMatrix{T}, ℓ̄::ROCVector{T}) where {T<:BjxFloat}
     d, n = dims(z)
     keep = Any[]
     o = ops(chain, T, keep)                                  # tail ∘ Shift(μ) ∘ Scale(σ) as <= 4 elementwise ops
-    seg = [BjxSegment(0, 0, d, length(o), 0, ntuple(k -> k <= length(o) ? o[k] : NOOP, 4))]
+    seg = [segment(1:d, 1:d, o)]
     z̄ = similar(z)
     moments = AMDGPU.zeros(Float64, 2d + 1)
     GC.@preserve keep z ȳ ℓ̄ z̄ moments check(ccall((:bjx_stacked_vjp_moments, libbjx), Cint,
-        (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-        ctx().h, dtype(T), seg, 1, devptr(z), devptr(ȳ), devptr(ℓ̄), devptr(z̄), devptr(moments), d, n), "bjx_stacked_vjp_moments")
+        (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64),
+        ctx().h, dtype(T), seg, 1, devptr(z), devptr(ȳ), devptr(ℓ̄), devptr(z̄), Ptr{Cdouble}(pointer(moments)), d, n), "bjx_stacked_vjp_moments")
     return z̄, moments
 end
-
-# ---------------------------------------------------------------- reverse-mode pullbacks (SURVEY.md §8f f-1)
-# The reference's own rrules (ext/BijectorsChainRulesCoreExt.jl:65-197, :311-320) for ROCArray primals:
-# the pullback closure calls the `_vjp` entry with the saved primal input.
-function ChainRulesCore.rrule(::typeof(Bijectors._transform_ordered), y::ROCMatrix{T}) where {T}
-    x = first(with_logabsdet_jacobian(OrderedBijector(), y))
-    function _transform_ordered_adjoint(Δ)
-        ȳ = similar(y)
-        Δc = ROCArray{T}(ChainRulesCore.unthunk(Δ))
-        GC.@preserve y Δc ȳ check(ccall((:bjx_ordered_vjp, libbjx), Cint,
-            (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-            ctx().h, dtype(T), 0, devptr(y), devptr(Δc), C_NULL, devptr(ȳ), size(y, 1), size(y, 2)), "bjx_ordered_vjp")
-        return ChainRulesCore.NoTangent(), ȳ
-    end
-    return x, _transform_ordered_adjoint
+# the same sums for cotangents that already exist (shapes the fused kernel does not take): Σ_n a, Σ_n a .* b per row
+function row_moments(a::ROCMatrix{T}, b::Union{Nothing,ROCMatrix{T}}=nothing) where {T<:BjxFloat}
+    d, n = size(a)
+    out = AMDGPU.zeros(Float64, 2d + 1)
+    GC.@preserve a b out check(ccall((:bjx_row_moments, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64),
+        ctx().h, dtype(T), devptr(a), devptr(b), Ptr{Cdouble}(pointer(out)), d, n), "bjx_row_moments")
+    return out
 end
-function ChainRulesCore.rrule(::typeof(Bijectors._inv_link_chol_lkj), y::ROCMatrix{T}) where {T}   # columns = samples
+
+# VecCholeskyBijector: the rules the reference ships (ext/BijectorsChainRulesCoreExt.jl:199-320), batched over samples
+function ChainRulesCore.rrule(::typeof(Bijectors._inv_link_chol_lkj), y::ROCMatrix{T}) where {T<:BjxFloat}   # columns = samples
     K = Bijectors._triu1_dim_from_length(size(y, 1)); n = size(y, 2)
-    W = similar(y, K, K, n); logJ = similar(y, n)
-    # primal: bjx_vec_cholesky(inverse = 1, uplo = 'U'); pullback:
+    W, logJ = with_logabsdet_jacobian(inverse(VecCholeskyBijector(:U)), y)
     function pullback_inv_link_chol_lkj((ΔW, ΔlogJ))
         Δy = similar(y)
-        GC.@preserve y ΔW ΔlogJ Δy check(ccall((:bjx_vec_cholesky_inv_vjp, libbjx), Cint,
+        ΔWc = cotangent(T, ΔW, W); Δlc = ladj_cotangent(T, ΔlogJ, n)
+        GC.@preserve y ΔWc Δlc Δy check(ccall((:bjx_vec_cholesky_inv_vjp, libbjx), Cint,
             (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-            ctx().h, dtype(T), Cint('U'), devptr(y), devptr(ΔW), devptr(ΔlogJ), devptr(Δy), K, n), "bjx_vec_cholesky_inv_vjp")
-        return ChainRulesCore.NoTangent(), Δy
+            ctx().h, dtype(T), Cint('U'), devptr(y), devptr(ΔWc), devptr(Δlc), devptr(Δy), K, n), "bjx_vec_cholesky_inv_vjp")
+        return NoTangent(), Δy
     end
     return (W, logJ), pullback_inv_link_chol_lkj
 end
-
 # forward LKJ link on a batch of factors W[K, K, n] (ext/BijectorsChainRulesCoreExt.jl:199-311)
-for (f, uplo) in ((:_link_chol_lkj_from_upper, 'U'), (:_link_chol_lkj_from_lower, 'L'))
-    @eval function ChainRulesCore.rrule(::typeof(Bijectors.$f), W::ROCArray{T,3}) where {T}
+for (f, ul) in ((:_link_chol_lkj_from_upper, 'U'), (:_link_chol_lkj_from_lower, 'L'))
+    @eval function ChainRulesCore.rrule(::typeof(Bijectors.$f), W::ROCArray{T,3}) where {T<:BjxFloat}
         K, n = size(W, 1), size(W, 3)
-        y = first(with_logabsdet_jacobian(VecCholeskyBijector(Symbol($uplo)), W))
+        y = transform(VecCholeskyBijector(Symbol($ul)), W)
         function pullback_link_chol_lkj(Δz)
-            ΔW = similar(W); Δc = ROCArray{T}(ChainRulesCore.unthunk(Δz))
+            ΔW = similar(W); Δc = cotangent(T, Δz, y)
             GC.@preserve W Δc ΔW check(ccall((:bjx_vec_cholesky_fwd_vjp, libbjx), Cint,
                 (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-                ctx().h, dtype(T), Cint($uplo), devptr(W), devptr(Δc), devptr(ΔW), K, n), "bjx_vec_cholesky_fwd_vjp")
-            return ChainRulesCore.NoTangent(), ΔW
+                ctx().h, dtype(T), Cint($ul), devptr(W), devptr(Δc), devptr(ΔW), K, n), "bjx_vec_cholesky_fwd_vjp")
+            return NoTangent(), ΔW
         end
         return y, pullback_link_chol_lkj
     end
 end
-# PlanarLayer: input pullback + parameter cotangents (w̄, ū, b̄) through get_u_hat (bjx_planar_vjp_params)
-function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::PlanarLayer, z::ROCMatrix{T}) where {T}
+
+# PlanarLayer: input pullback (bjx_planar_vjp) and, for the forward flow, the parameter cotangents (w̄, ū, b̄) through
+# get_u_hat in the same pass (bjx_planar_vjp_params).
+function planar_vjp(pl::PlanarLayer, inv::Bool, z::ROCMatrix{T}, Δy, Δl) where {T}
+    z̄ = similar(z)
+    w, u, b = ondevice(T, pl.w), ondevice(T, pl.u), ondevice(T, pl.b isa Real ? [pl.b] : pl.b)
+    GC.@preserve z Δy Δl z̄ w u b check(ccall((:bjx_planar_vjp, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+        ctx().h, dtype(T), Cint(inv), devptr(w), devptr(u), devptr(b), Cint(1), devptr(z), devptr(Δy), devptr(Δl), devptr(z̄),
+        size(z, 1), size(z, 2)), "bjx_planar_vjp")
+    return z̄
+end
+function planar_vjp_params(pl::PlanarLayer, z::ROCMatrix{T}, Δy, Δl) where {T}
+    z̄ = similar(z)
+    w, u, b = ondevice(T, pl.w), ondevice(T, pl.u), ondevice(T, pl.b isa Real ? [pl.b] : pl.b)
+    w̄, ū, b̄ = similar(w), similar(u), similar(b)
+    work = similar(z, 2 * size(z, 2))                      # 2 * n_layers * batch, one layer
+    GC.@preserve z Δy Δl z̄ w u b w̄ ū b̄ work check(ccall((:bjx_planar_vjp_params, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+         Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+        ctx().h, dtype(T), devptr(w), devptr(u), devptr(b), Cint(1), devptr(z), devptr(Δy), devptr(Δl), devptr(z̄),
+        devptr(w̄), devptr(ū), devptr(b̄), devptr(work), size(z, 1), size(z, 2)), "bjx_planar_vjp_params")
+    return z̄, w̄, ū, b̄
+end
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::PlanarLayer, z::ROCMatrix{T}) where {T<:BjxFloat}
     out = with_logabsdet_jacobian(flow, z)
     function pullback_planar_params((Δy, Δl))
-        z̄ = similar(z); Δyc = ROCArray{T}(ChainRulesCore.unthunk(Δy)); Δlc = ROCArray{T}(ChainRulesCore.unthunk(Δl))
-        w, u, b = ROCArray{T}(flow.w), ROCArray{T}(flow.u), ROCArray{T}(flow.b)
-        w̄, ū, b̄ = similar(w), similar(u), similar(b)
-        work = similar(z, 2 * size(z, 2))                      # 2 * n_layers * batch, one layer
-        GC.@preserve z Δyc Δlc z̄ w u b w̄ ū b̄ work check(ccall((:bjx_planar_vjp_params, libbjx), Cint,
-            (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
-             Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-            ctx().h, dtype(T), devptr(w), devptr(u), devptr(b), 1, devptr(z), devptr(Δyc), devptr(Δlc), devptr(z̄),
-            devptr(w̄), devptr(ū), devptr(b̄), devptr(work), size(z, 1), size(z, 2)), "bjx_planar_vjp_params")
-        return ChainRulesCore.NoTangent(), ChainRulesCore.Tangent{typeof(flow)}(w = w̄, u = ū, b = b̄), z̄
+        z̄, w̄, ū, b̄ = planar_vjp_params(flow, z, cotangent(T, Δy, z), ladj_cotangent(T, Δl, size(z, 2)))
+        return NoTangent(), Tangent{typeof(flow)}(w = w̄, u = ū, b = b̄), z̄
     end
     return out, pullback_planar_params
 end
@@ -438,78 +799,157 @@ end
 # Newton root through its find_alpha rule, ext/BijectorsChainRulesCoreExt.jl:42-46): with x = f⁻¹(y) and the inverse's log-det
 # -ℓ(x),  ȳ = J⁻ᵀ(x̄ - ℓ̄ ∇ₓℓ)  (bjx_planar_vjp, inverse = 1)  and  θ̄ = the FORWARD parameter pullback at x with cotangents
 # (-ȳ, -ℓ̄)  (bjx_planar_vjp_params) — no new kernel, the root is not differentiated through.
-function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::Inverse{<:PlanarLayer}, z::ROCMatrix{T}) where {T}
-    inv = true; pl = flow.orig
-    out = with_logabsdet_jacobian(flow, z)
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::Inverse{<:PlanarLayer}, y::ROCMatrix{T}) where {T<:BjxFloat}
+    pl = flow.orig
+    out = with_logabsdet_jacobian(flow, y)
     x = out[1]                                                  # the pre-image: the point where the forward rule is evaluated
-    function pullback_planar((Δy, Δl))
-        z̄ = similar(z); Δyc = ROCArray{T}(ChainRulesCore.unthunk(Δy)); Δlc = ROCArray{T}(ChainRulesCore.unthunk(Δl))
-        w, u, b = ROCArray{T}(pl.w), ROCArray{T}(pl.u), ROCArray{T}(pl.b)
-        GC.@preserve z Δyc Δlc z̄ w u b check(ccall((:bjx_planar_vjp, libbjx), Cint,
-            (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-            ctx().h, dtype(T), Cint(inv), devptr(w), devptr(u), devptr(b), 1, devptr(z), devptr(Δyc), devptr(Δlc), devptr(z̄),
-            size(z, 1), size(z, 2)), "bjx_planar_vjp")
-        g, gl = -z̄, -Δlc
-        scratch = similar(z)                                    # the forward rule's input cotangent (= -x̄): not used
-        w̄, ū, b̄ = similar(w), similar(u), similar(b)
-        work = similar(z, 2 * size(z, 2))
-        GC.@preserve x g gl scratch w u b w̄ ū b̄ work check(ccall((:bjx_planar_vjp_params, libbjx), Cint,
-            (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
-             Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-            ctx().h, dtype(T), devptr(w), devptr(u), devptr(b), 1, devptr(x), devptr(g), devptr(gl), devptr(scratch),
-            devptr(w̄), devptr(ū), devptr(b̄), devptr(work), size(z, 1), size(z, 2)), "bjx_planar_vjp_params")
-        return ChainRulesCore.NoTangent(), ChainRulesCore.Tangent{typeof(flow)}(orig = ChainRulesCore.Tangent{typeof(pl)}(w = w̄, u = ū, b = b̄)), z̄
+    function pullback_planar((Δx, Δl))
+        Δlc = ladj_cotangent(T, Δl, size(y, 2))
+        ȳ = planar_vjp(pl, true, y, cotangent(T, Δx, x), Δlc)
+        _, w̄, ū, b̄ = planar_vjp_params(pl, x, -ȳ, Δlc === nothing ? nothing : -Δlc)
+        return NoTangent(), Tangent{typeof(flow)}(orig = Tangent{typeof(pl)}(w = w̄, u = ū, b = b̄)), ȳ
     end
     return out, pullback_planar
 end
 
-# RadialLayer: input AND parameter cotangents (bjx_radial_vjp_params; raw α_, β behind softplus, radial_layer.jl:43-60)
-function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::RadialLayer, z::ROCMatrix{T}) where {T}
+# RadialLayer: input pullback of both directions (bjx_radial_vjp) and the parameter cotangents (ᾱ_, β̄, z̄₀) of the forward
+# flow (bjx_radial_vjp_params; raw α_, β behind softplus, radial_layer.jl:43-60); inverse parameters by the same IFT as Planar.
+function radial_vjp(fl::RadialLayer, inv::Bool, z::ROCMatrix{T}, Δy, Δl) where {T}
+    z̄ = similar(z)
+    a, be, z0 = ondevice(T, fl.α_ isa Real ? [fl.α_] : fl.α_), ondevice(T, fl.β isa Real ? [fl.β] : fl.β), ondevice(T, fl.z_0)
+    GC.@preserve z Δy Δl z̄ a be z0 check(ccall((:bjx_radial_vjp, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+        ctx().h, dtype(T), Cint(inv), devptr(a), devptr(be), devptr(z0), devptr(z), devptr(Δy), devptr(Δl), devptr(z̄),
+        size(z, 1), size(z, 2)), "bjx_radial_vjp")
+    return z̄
+end
+function radial_vjp_params(fl::RadialLayer, z::ROCMatrix{T}, Δy, Δl) where {T}
+    a, be, z0 = ondevice(T, fl.α_ isa Real ? [fl.α_] : fl.α_), ondevice(T, fl.β isa Real ? [fl.β] : fl.β), ondevice(T, fl.z_0)
+    z̄, ᾱ, β̄, z̄0 = similar(z), similar(a), similar(be), similar(z0)
+    work = similar(z, 2 * size(z, 2))
+    GC.@preserve z Δy Δl z̄ a be z0 ᾱ β̄ z̄0 work check(ccall((:bjx_radial_vjp_params, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+        ctx().h, dtype(T), devptr(a), devptr(be), devptr(z0), devptr(z), devptr(Δy), devptr(Δl), devptr(z̄),
+        devptr(ᾱ), devptr(β̄), devptr(z̄0), devptr(work), size(z, 1), size(z, 2)), "bjx_radial_vjp_params")
+    return z̄, ᾱ, β̄, z̄0
+end
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::RadialLayer, z::ROCMatrix{T}) where {T<:BjxFloat}
     out = with_logabsdet_jacobian(flow, z)
     function pullback_radial((Δy, Δl))
-        Δyc, Δlc = ROCArray{T}(ChainRulesCore.unthunk(Δy)), ROCArray{T}(ChainRulesCore.unthunk(Δl))
-        z̄, ᾱ, β̄, z̄0 = similar(z), similar(flow.α_), similar(flow.β), similar(flow.z_0)
-        work = similar(z, 2 * size(z, 2))
-        GC.@preserve z Δyc Δlc z̄ ᾱ β̄ z̄0 work check(ccall((:bjx_radial_vjp_params, libbjx), Cint,
-            (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-            ctx().h, dtype(T), devptr(flow.α_), devptr(flow.β), devptr(flow.z_0), devptr(z), devptr(Δyc), devptr(Δlc), devptr(z̄),
-            devptr(ᾱ), devptr(β̄), devptr(z̄0), devptr(work), size(z, 1), size(z, 2)), "bjx_radial_vjp_params")
-        return ChainRulesCore.NoTangent(), ChainRulesCore.Tangent{typeof(flow)}(α_ = ᾱ, β = β̄, z_0 = z̄0), z̄
+        z̄, ᾱ, β̄, z̄0 = radial_vjp_params(flow, z, cotangent(T, Δy, z), ladj_cotangent(T, Δl, size(z, 2)))
+        return NoTangent(), Tangent{typeof(flow)}(α_ = ᾱ, β = β̄, z_0 = z̄0), z̄
     end
     return out, pullback_radial
 end
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::Inverse{<:RadialLayer}, y::ROCMatrix{T}) where {T<:BjxFloat}
+    rl = flow.orig
+    out = with_logabsdet_jacobian(flow, y)
+    x = out[1]
+    function pullback_radial_inverse((Δx, Δl))
+        Δlc = ladj_cotangent(T, Δl, size(y, 2))
+        ȳ = radial_vjp(rl, true, y, cotangent(T, Δx, x), Δlc)
+        _, ᾱ, β̄, z̄0 = radial_vjp_params(rl, x, -ȳ, Δlc === nothing ? nothing : -Δlc)
+        return NoTangent(), Tangent{typeof(flow)}(orig = Tangent{typeof(rl)}(α_ = ᾱ, β = β̄, z_0 = z̄0)), ȳ
+    end
+    return out, pullback_radial_inverse
+end
 
-# RationalQuadraticSpline with matrix parameters: input pullback AND the cotangents of the knot arrays summed over
-# the batch in one pass (bjx_rqs_vjp_knots with in_bar; rational_quadratic_spline.jl:128-357 has no hand-written rule).  For a spline made by the `B`
-# constructor (:109-123) the wrapper that owns the raw parameters chains on with `rqs_params_pullback` (bjx_rqs_params_vjp).
-function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), b::RationalQuadraticSpline{<:ROCMatrix{T}}, x::ROCMatrix{T}) where {T}
+# RationalQuadraticSpline with matrix parameters: input pullback AND the cotangents of the knot arrays summed over the batch in
+# one pass (bjx_rqs_vjp_knots with in_bar), both directions (inverse: implicit function theorem at x = f⁻¹(y));
+# bjx_rqs_vjp alone when only the input cotangent is wanted (rqs_input_pullback: HMC over x with fixed knots).
+# rational_quadratic_spline.jl:128-357 has no hand-written rule.  For a spline made by the `B` constructor (:109-123) the
+# wrapper that owns the raw parameters chains on with `rqs_params_pullback` (bjx_rqs_params_vjp).
+function rqs_input_pullback(b::RationalQuadraticSpline{<:ROCMatrix{T}}, inv::Bool, x::ROCMatrix{T}, Δy, Δl) where {T<:BjxFloat}
+    x̄ = similar(x)
+    GC.@preserve b x Δy Δl x̄ check(ccall((:bjx_rqs_vjp, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+        ctx().h, dtype(T), Cint(inv), devptr(b.widths), devptr(b.heights), devptr(b.derivatives), Cint(size(b.widths, 2)),
+        devptr(x), devptr(Δy), devptr(Δl), devptr(x̄), size(x, 1), size(x, 2)), "bjx_rqs_vjp")
+    return x̄
+end
+function rqs_knot_pullback(b::RationalQuadraticSpline{<:ROCMatrix{T}}, inv::Bool, x::ROCMatrix{T}, Δy, Δl) where {T<:BjxFloat}
+    x̄, w̄, h̄, d̄ = similar(x), similar(b.widths), similar(b.heights), similar(b.derivatives)
+    GC.@preserve b x Δy Δl x̄ w̄ h̄ d̄ check(ccall((:bjx_rqs_vjp_knots, libbjx), Cint,    # x̄ and the knot cotangents in one pass over x, Δy, Δl
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+        ctx().h, dtype(T), Cint(inv), devptr(b.widths), devptr(b.heights), devptr(b.derivatives), Cint(size(b.widths, 2)), devptr(x), devptr(Δy), devptr(Δl), devptr(x̄),
+        devptr(w̄), devptr(h̄), devptr(d̄), size(x, 1), size(x, 2)), "bjx_rqs_vjp_knots")
+    return x̄, w̄, h̄, d̄
+end
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), b::RationalQuadraticSpline{<:ROCMatrix{T}}, x::ROCMatrix{T}) where {T<:BjxFloat}
     out = with_logabsdet_jacobian(b, x)
-    K1 = size(b.widths, 2)
     function pullback_rqs((Δy, Δl))
-        Δyc, Δlc = ROCArray{T}(ChainRulesCore.unthunk(Δy)), ROCArray{T}(ChainRulesCore.unthunk(Δl))
-        x̄, w̄, h̄, d̄ = similar(x), similar(b.widths), similar(b.heights), similar(b.derivatives)
-        GC.@preserve x Δyc Δlc x̄ w̄ h̄ d̄ begin
-            check(ccall((:bjx_rqs_vjp_knots, libbjx), Cint,    # x̄ and the knot cotangents in one pass over x, Δy, Δl
-                (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-                ctx().h, dtype(T), 0, devptr(b.widths), devptr(b.heights), devptr(b.derivatives), K1, devptr(x), devptr(Δyc), devptr(Δlc), devptr(x̄),
-                devptr(w̄), devptr(h̄), devptr(d̄), size(x, 1), size(x, 2)), "bjx_rqs_vjp_knots")
-        end
-        return ChainRulesCore.NoTangent(), ChainRulesCore.Tangent{typeof(b)}(widths = w̄, heights = h̄, derivatives = d̄), x̄
+        x̄, w̄, h̄, d̄ = rqs_knot_pullback(b, false, x, cotangent(T, Δy, x), ladj_cotangent(T, Δl, size(x, 2)))
+        return NoTangent(), Tangent{typeof(b)}(widths = w̄, heights = h̄, derivatives = d̄), x̄
     end
     return out, pullback_rqs
 end
-
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), ib::Inverse{<:RationalQuadraticSpline{<:ROCMatrix{T}}}, y::ROCMatrix{T}) where {T<:BjxFloat}
+    b = ib.orig
+    out = with_logabsdet_jacobian(ib, y)
+    function pullback_rqs_inverse((Δx, Δl))
+        ȳ, w̄, h̄, d̄ = rqs_knot_pullback(b, true, y, cotangent(T, Δx, y), ladj_cotangent(T, Δl, size(y, 2)))
+        return NoTangent(), Tangent{typeof(ib)}(orig = Tangent{typeof(b)}(widths = w̄, heights = h̄, derivatives = d̄)), ȳ
+    end
+    return out, pullback_rqs_inverse
+end
 # pullback of the `B` constructor: knot cotangents (dim, K+1) -> cotangents of the unconstrained (dim, K), (dim, K), (dim, K-1)
 function rqs_params_pullback(raw_w::ROCMatrix{T}, raw_h::ROCMatrix{T}, raw_d::ROCMatrix{T}, B::Real, w̄, h̄, d̄) where {T}
     r̄w, r̄h, r̄d = similar(raw_w), similar(raw_h), similar(raw_d)
     GC.@preserve raw_w raw_h raw_d w̄ h̄ d̄ r̄w r̄h r̄d check(ccall((:bjx_rqs_params_vjp, libbjx), Cint,
         (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-        ctx().h, dtype(T), devptr(raw_w), devptr(raw_h), devptr(raw_d), size(raw_w, 2), size(raw_w, 1), Float64(B),
+        ctx().h, dtype(T), devptr(raw_w), devptr(raw_h), devptr(raw_d), Cint(size(raw_w, 2)), size(raw_w, 1), Float64(B),
         devptr(w̄), devptr(h̄), devptr(d̄), devptr(r̄w), devptr(r̄h), devptr(r̄d)), "bjx_rqs_params_vjp")
     return r̄w, r̄h, r̄d
 end
 
+# Coupling with the affine law (coupling.jl:206-259; together with the reference's rrule(::typeof(combine), …),
+# ext/BijectorsChainRulesCoreExt.jl:48-63): the kernel returns x̄ (x₁ rows and pass-through rows) and the cotangents (s̄, t̄) of
+# θ's outputs; θ's own pullback (an arbitrary closure: the AD package) turns them into the x₂ contribution, added on the x₂ rows.
+function ChainRulesCore.rrule(cfg::ChainRulesCore.RuleConfig{>:ChainRulesCore.HasReverseMode}, ::typeof(with_logabsdet_jacobian),
+                              cl::Union{Coupling,Inverse{<:Coupling}}, x::ROCMatrix{T}) where {T<:BjxFloat}
+    inv = cl isa Inverse; c = inv ? cl.orig : cl
+    d, n = size(x)
+    idx1, idx2 = mask_rows(c.mask.A_1), mask_rows(c.mask.A_2); n1 = length(idx1)
+    x2 = gather_rows(x, idx2)
+    law_obj, θ_back = ChainRulesCore.rrule_via_ad(cfg, c.θ, x2)
+    law = coupling_law(law_obj)
+    (law === nothing || law[1] !== :affine) && return nothing     # spline laws: bjx_rqs_vjp_knots on the x₁ rows via the stage rules
+    out = with_logabsdet_jacobian(cl, x)
+    function pullback_coupling((Δy, Δl))
+        keep = Any[]; di = ROCArray{Int32}(idx1)
+        # the pullback entry takes T[n1, batch] parameters: a per-row law is expanded here and its cotangent summed over the columns
+        full(a) = a === nothing ? nothing : (v = ondevice(T, a isa Real ? fill(T(a), n1) : a); length(v) == n1 * n ? v : repeat(reshape(v, n1, 1), 1, n))
+        reduce_like(ā, a) = (ā === nothing || a === nothing || length(a) == n1 * n) ? ā : ROCArray{T}(Array(row_moments(ā))[1:n1])
+        sv, tv = full(law[2]), full(law[3]); push!(keep, sv, tv)
+        ps, pt = devptr(sv), devptr(tv)
+        x̄ = similar(x); s̄ = sv === nothing ? nothing : similar(x, n1, n); t̄ = tv === nothing ? nothing : similar(x, n1, n)
+        Δyc = cotangent(T, Δy, x); Δlc = ladj_cotangent(T, Δl, n)
+        GC.@preserve keep di x Δyc Δlc x̄ s̄ t̄ check(ccall((:bjx_coupling_affine_vjp, libbjx), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Ptr{Int32}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+            ctx().h, dtype(T), Cint(inv), Ptr{Int32}(pointer(di)), n1, ps, pt, devptr(x), devptr(Δyc), devptr(Δlc), devptr(x̄), devptr(s̄), devptr(t̄), d, n),
+            "bjx_coupling_affine_vjp")
+        s̄, t̄ = reduce_like(s̄, law[2]), reduce_like(t̄, law[3])
+        law_bar = law_obj isa Shift ? Tangent{typeof(law_obj)}(a = t̄) :
+                  law_obj isa Scale ? Tangent{typeof(law_obj)}(a = s̄) :
+                  Tangent{typeof(law_obj)}(outer = Tangent{typeof(law_obj.outer)}(a = t̄), inner = Tangent{typeof(law_obj.inner)}(a = s̄))
+        _, x̄2 = θ_back(law_bar)
+        x̄[Int.(idx2) .+ 1, :] .+= unthunk(x̄2)                    # the x₂ rows also pass ȳ through (already in x̄)
+        return NoTangent(), NoTangent(), NoTangent(), x̄
+    end
+    return out, pullback_coupling
+end
+
+# Permute: the pullback of a gather is the gather with the inverse permutation (bit-exact data movement)
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), b::Permute, x::ROCVecOrMat{T}) where {T<:BjxFloat}
+    out = with_logabsdet_jacobian(b, x)
+    pullback_permute((Δy, Δl)) = (NoTangent(), NoTangent(), transform(inverse(b), cotangent(T, Δy, x)))
+    return out, pullback_permute
+end
+
 # captured steps (hipGraph): record the calls of `f()` once, replay them with one launch (include/bjx.h, bjx_graph_*)
+mutable struct Graph
+    h::Ptr{Cvoid}
+end
 function capture(f)
     check(ccall((:bjx_graph_begin, libbjx), Cint, (Ptr{Cvoid},), ctx().h), "bjx_graph_begin")
     g = Ref{Ptr{Cvoid}}(C_NULL)
@@ -518,23 +958,23 @@ function capture(f)
     finally
         check(ccall((:bjx_graph_end, libbjx), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), ctx().h, g), "bjx_graph_end")
     end
-    return g[]
+    gr = Graph(g[])
+    finalizer(x -> ccall((:bjx_graph_destroy, libbjx), Cint, (Ptr{Cvoid},), x.h), gr)
+    return gr
 end
-replay(g::Ptr{Cvoid}) = check(ccall((:bjx_graph_launch, libbjx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx().h, g), "bjx_graph_launch")
+replay(g::Graph) = check(ccall((:bjx_graph_launch, libbjx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx().h, g.h), "bjx_graph_launch")
 
-# ---------------------------------------------------------------- logpdf of a TransformedDistribution (SURVEY.md §8f f-3)
+# ---------------------------------------------------------------- logpdf / rand of a TransformedDistribution (SURVEY.md §8f f-3)
 # src/transformed_distribution.jl:164-169 in ONE pass over y: the inverse chain, the whitening of the diagonal-normal
 # base and the standard-normal density are ops of the same launch; the pre-image is not stored (y pointer = C_NULL).
-const OP_STDNORMAL_LOGPDF = 13
-const BJX_BASE_STDNORMAL = UInt32(1) << 2
-function Distributions.logpdf(td::Bijectors.MvTransformed{<:Distributions.MvNormal}, y::ROCMatrix{T}) where {T<:Union{Float32,Float64}}
-    Σ = td.dist.Σ
-    Σ isa Union{Distributions.PDMats.PDiagMat,Distributions.PDMats.ScalMat} || return invoke(Distributions.logpdf, Tuple{Bijectors.MvTransformed,AbstractMatrix}, td, y)
+diag_normal(d::Distributions.MvNormal) = d.Σ isa Union{Distributions.PDMats.PDiagMat,Distributions.PDMats.ScalMat}
+function Distributions.logpdf(td::Bijectors.MvTransformed{<:Distributions.MvNormal}, y::ROCMatrix{T}) where {T<:BjxFloat}
+    diag_normal(td.dist) || return invoke(Distributions.logpdf, Tuple{Bijectors.MvTransformed,AbstractMatrix}, td, y)
     keep = Any[]
     o = ops(inverse(td.transform), T, keep)
     d, n = dims(y)
     lp = similar(y, n)
-    μ, σ = td.dist.μ, sqrt.(Array(Distributions.PDMats.diag(Σ)))
+    μ, σ = td.dist.μ, sqrt.(Array(Distributions.PDMats.diag(td.dist.Σ)))
     if o !== nothing && length(o) + 3 <= 8
         o = vcat(o, param_op(OP_SHIFT, -μ, T, keep), param_op(OP_SCALE_INV, σ, T, keep),
                  BjxOp(Int32(OP_STDNORMAL_LOGPDF), 0, 0, 0, C_NULL, C_NULL))
@@ -543,15 +983,61 @@ function Distributions.logpdf(td::Bijectors.MvTransformed{<:Distributions.MvNorm
             ctx().h, dtype(T), o, length(o), devptr(y), C_NULL, devptr(lp), C_NULL, d, n, UInt32(0)), "bjx_chain")
         return lp
     end
-    # PlanarLayer stacks with a standard-normal base: bjx_planar(inverse = 1, out = C_NULL, flags = BJX_BASE_STDNORMAL);
-    # anything else: x, logjac = with_logabsdet_jacobian(inverse(td.transform), y), then the 3-op density chain on x.
+    # a PlanarLayer with a standard-normal base: the inverse flow with BJX_BASE_STDNORMAL, pre-image not stored
+    if td.transform isa PlanarLayer && all(iszero, μ) && all(isone, σ)
+        p = plan_planar(td.transform, true, y, BJX_BASE_STDNORMAL)
+        return run!(p, T, y, nothing)
+    end
+    # anything else: x, logjac = with_logabsdet_jacobian(inverse(td.transform), y), then the base density on x
     x, logjac = with_logabsdet_jacobian(inverse(td.transform), y)
-    return Distributions.logpdf(Bijectors.transformed(td.dist), x) .+ logjac
+    return Distributions.logpdf(td.dist, x) .+ logjac
+end
+# rand(td, n) on the device (src/transformed_distribution.jl:214-224): the base samples are drawn inside the transforming launch
+# (counter-based Philox stream keyed by (seed, global column): identical for any shard count) and never written.
+function rand_transformed(td::Bijectors.MvTransformed{<:Distributions.MvNormal}, ::Type{T}, n::Integer; seed::Integer=0, col0::Integer=0) where {T<:BjxFloat}
+    diag_normal(td.dist) || error("rand_transformed: diagonal-normal base only")
+    keep = Any[]
+    μ, σ = td.dist.μ, sqrt.(Array(Distributions.PDMats.diag(td.dist.Σ)))
+    o = ops(td.transform, T, keep)
+    (o === nothing || length(o) + 2 > 8) && error("rand_transformed: the transform is not a fusable elementwise chain")
+    o = vcat(param_op(OP_SCALE, σ, T, keep), param_op(OP_SHIFT, μ, T, keep), o)
+    d = length(μ)
+    y = ROCArray{T}(undef, d, n)
+    check(ccall((:bjx_set_rng, libbjx), Cint, (Ptr{Cvoid}, UInt64, Int64), ctx().h, UInt64(seed), Int64(col0)), "bjx_set_rng")
+    GC.@preserve keep y check(ccall((:bjx_chain, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{BjxOp}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        ctx().h, dtype(T), o, length(o), C_NULL, devptr(y), C_NULL, C_NULL, d, n, BJX_INPUT_STDNORMAL), "bjx_chain")
+    return y
 end
 
 # ---------------------------------------------------------------- multi-GPU (one process per GPU)
-comm_unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:bjx_comm_unique_id, libbjx), Cint, (Ptr{UInt8},), id), "bjx_comm_unique_id"); id)
-comm_init(nranks, rank, id::Vector{UInt8}) = check(ccall((:bjx_comm_init, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx().h, nranks, rank, id), "bjx_comm_init")
-allreduce_logabsdetjac!(partial::ROCVector{Float64}) = (check(ccall((:bjx_allreduce_sum_f64, libbjx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), ctx().h, devptr(partial), length(partial)), "bjx_allreduce_sum_f64"); partial)
+comm_unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:bjx_comm_unique_id, libbjx), Cint, (Ptr{Cvoid},), id), "bjx_comm_unique_id"); id)
+comm_init(nranks, rank, id::Vector{UInt8}) = check(ccall((:bjx_comm_init, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}), ctx().h, nranks, rank, id), "bjx_comm_init")
+comm_destroy() = check(ccall((:bjx_comm_destroy, libbjx), Cint, (Ptr{Cvoid},), ctx().h), "bjx_comm_destroy")
+allreduce_logabsdetjac!(partial::ROCVector{Float64}) = (check(ccall((:bjx_allreduce_sum_f64, libbjx), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64), ctx().h, Ptr{Cdouble}(pointer(partial)), length(partial)), "bjx_allreduce_sum_f64"); partial)
+
+# ---------------------------------------------------------------- measurement helpers (bench/reference_cpu.jl's GPU leg)
+function fill_normal!(out::ROCVecOrMat{T}; col0::Integer=0, seed::Integer=0, mean::Real=0, std::Real=1) where {T<:BjxFloat}
+    d, n = dims(out)
+    GC.@preserve out check(ccall((:bjx_fill_normal, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Int64, Int64, UInt64, Cdouble, Cdouble),
+        ctx().h, dtype(T), devptr(out), d, n, Int64(col0), UInt64(seed), Float64(mean), Float64(std)), "bjx_fill_normal")
+    return out
+end
+# milliseconds of the stream region `f()`; and the summed DOMINANT-kernel milliseconds + launch count of the same region
+function timed(f)
+    check(ccall((:bjx_time_begin, libbjx), Cint, (Ptr{Cvoid},), ctx().h), "bjx_time_begin")
+    f()
+    ms = Ref{Cfloat}(0)
+    check(ccall((:bjx_time_end, libbjx), Cint, (Ptr{Cvoid}, Ptr{Cfloat}), ctx().h, ms), "bjx_time_end")
+    return ms[]
+end
+function kernel_timed(f)
+    check(ccall((:bjx_kernel_time_begin, libbjx), Cint, (Ptr{Cvoid},), ctx().h), "bjx_kernel_time_begin")
+    f()
+    ms = Ref{Cfloat}(0); k = Ref{Cint}(0)
+    check(ccall((:bjx_kernel_time_end, libbjx), Cint, (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cint}), ctx().h, ms, k), "bjx_kernel_time_end")
+    return ms[], k[]
+end
 
 end # module

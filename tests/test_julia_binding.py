@@ -1,0 +1,273 @@
+"""Static completeness check of julia/BijectorsBJX.jl (the image has no `julia`): the binding is the Julia half of the drop-in
+boundary (/root/reference/src/interface.jl:156-218) and must
+
+  1. `ccall` EVERY entry point include/bjx.h declares, with the header's arity and C types;
+  2. mirror the header's structs field by field;
+  3. give every bijector of §8(b) x {plain, Inverse} a launch plan, and define the six interface methods on the planned union;
+  4. be the file INTEGRATION.md describes: every Julia function the table names exists;
+  5. at least parse as far as a keyword/bracket balance can tell.
+"""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header():
+    h = open(os.path.join(ROOT, "include", "bjx.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return re.sub(r"//.*", "", h)
+
+
+def _julia():
+    return open(os.path.join(ROOT, "julia", "BijectorsBJX.jl")).read()
+
+
+def _strip_julia(j):
+    """comments and string / char literals out (no nested interpolation with quotes is used in the file)"""
+    j = re.sub(r"#=.*?=#", "", j, flags=re.S)
+    out, i, n = [], 0, len(j)
+    while i < n:
+        c = j[i]
+        if c == '"':
+            k = i + 1
+            while k < n and j[k] != '"':
+                k += 2 if j[k] == "\\" else 1
+            out.append('""')
+            i = k + 1
+        elif c == "#":
+            while i < n and j[i] != "\n":
+                i += 1
+        elif c == "'" and i + 2 < n and j[i + 2] == "'":
+            out.append("' '")
+            i += 3
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def _c_to_julia(ctype):
+    """C parameter type (name stripped) -> set of acceptable Julia ccall types"""
+    t = re.sub(r"\s+", " ", ctype.strip())
+    t = t.replace(" *", "*")
+    table = {
+        "bjx_ctx*": {"Ptr{Cvoid}"}, "bjx_ctx**": {"Ptr{Ptr{Cvoid}}"},
+        "bjx_graph*": {"Ptr{Cvoid}"}, "bjx_graph**": {"Ptr{Ptr{Cvoid}}"},
+        "bjx_dtype": {"Cint"}, "int": {"Cint"},
+        "const bjx_op*": {"Ptr{BjxOp}"}, "const bjx_segment*": {"Ptr{BjxSegment}"}, "const bjx_block*": {"Ptr{BjxBlock}"},
+        "const void*": {"Ptr{Cvoid}"}, "void*": {"Ptr{Cvoid}", "Ptr{UInt8}"},
+        "double*": {"Ptr{Cdouble}", "Ptr{Cvoid}"}, "const double*": {"Ptr{Cdouble}", "Ptr{Cvoid}"},
+        "const int32_t*": {"Ptr{Int32}"},
+        "int64_t": {"Int64"}, "uint32_t": {"UInt32"}, "uint64_t": {"UInt64"}, "double": {"Cdouble"},
+        "float*": {"Ptr{Cfloat}"}, "int*": {"Ptr{Cint}"},
+    }
+    assert t in table, f"unmapped C type {t!r}"
+    return table[t]
+
+
+RET = {"int": "Cint", "size_t": "Csize_t", "const char*": "Cstring"}
+
+
+def _prototypes():
+    protos = {}
+    for m in re.finditer(r"\b(int|size_t|const char\s*\*)\s+(bjx_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", _header(), flags=re.S):
+        ret = re.sub(r"\s+", "", m.group(1)).replace("constchar*", "const char*")
+        args = []
+        for a in m.group(3).split(","):
+            a = a.strip()
+            if not a or a == "void":
+                continue
+            mm = re.match(r"(.*?)([A-Za-z_][A-Za-z0-9_]*)$", a)          # strip the parameter name
+            args.append(mm.group(1).strip())
+        protos[m.group(2)] = (ret, args)
+    return protos
+
+
+def _ccalls():
+    j = _strip_julia(_julia())
+    return [(m.group(1), m.group(2), [t.strip() for t in m.group(3).split(",") if t.strip()])
+            for m in re.finditer(r"ccall\(\(:(bjx_[a-z0-9_]+),\s*libbjx\),\s*(\w+),\s*\(([^()]*)\)", j)]
+
+
+def test_every_entry_point_is_ccalled_with_the_headers_types():
+    protos = _prototypes()
+    assert len(protos) == 62, sorted(protos)
+    calls = _ccalls()
+    assert len(calls) >= 62
+    seen = set()
+    for name, ret, types in calls:
+        assert name in protos, f"{name} is not declared in include/bjx.h"
+        cret, cargs = protos[name]
+        assert ret == RET[cret], f"{name}: returns {cret}, the ccall says {ret}"
+        assert len(types) == len(cargs), f"{name}: header has {len(cargs)} arguments, the Julia ccall passes {len(types)}"
+        for k, (jt, ct) in enumerate(zip(types, cargs)):
+            assert jt in _c_to_julia(ct), f"{name}: argument {k + 1} is `{ct}` in the header, `{jt}` in the ccall"
+        seen.add(name)
+    missing = sorted(set(protos) - seen)
+    assert not missing, f"entry points never ccalled from julia/BijectorsBJX.jl: {missing}"
+
+
+def test_struct_mirrors_match_the_header():
+    h, j = _header(), _strip_julia(_julia())
+    ctypes_ = {"int32_t": "Int32", "int64_t": "Int64", "double": "Float64", "const void*": "Ptr{Cvoid}"}
+
+    def cfields(name):
+        end_ = re.search(r"\}\s*" + name + r"\s*;", h).start()
+        body = h[h.rfind("typedef struct {", 0, end_) + len("typedef struct {"):end_]
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            m = re.match(r"(const void\s*\*|int32_t|int64_t|double|bjx_op)\s*(.*)$", decl)
+            ty = re.sub(r"\s+", " ", m.group(1)).replace(" *", "*")
+            for nm in m.group(2).split(","):
+                nm = nm.strip()
+                arr = re.match(r"(\w+)\[(\w+)\]", nm)
+                out.append((arr.group(1), f"NTuple{{4,BjxOp}}") if arr else (nm, ctypes_[ty]))
+        return out
+
+    def jfields(name):
+        body = re.search(r"struct " + name + r"\b(.*?)\nend", j, flags=re.S).group(1)
+        return [(m.group(1), m.group(2).replace("Cint", "Int32")) for m in re.finditer(r"(\w+)::([\w{},]+)", body)]
+
+    assert "#define BJX_MAX_SEG_OPS 4" in open(os.path.join(ROOT, "include", "bjx.h")).read()
+    for cname, jname in (("bjx_op", "BjxOp"), ("bjx_segment", "BjxSegment"), ("bjx_block", "BjxBlock")):
+        assert cfields(cname) == jfields(jname), (cname, cfields(cname), jfields(jname))
+    # enums and flags
+    kinds = re.search(r"@enum OpKind::Int32 (.*)", j).group(1).split()
+    cvals = dict(re.findall(r"BJX_(OP_[A-Z_]+)\s*=\s*(\d+)", h))
+    names = [k for k in kinds if k.startswith("OP_")]
+    assert names == sorted(cvals, key=lambda k: int(cvals[k])) and "OP_EXP = 1".replace(" ", "") in "".join(kinds[:3]).replace(" ", "")
+    for flag, shift in re.findall(r"(BJX_[A-Z_]+)\s*=\s*1u\s*<<\s*(\d+)", h):
+        assert re.search(flag + r"\b", j), f"{flag} is not mirrored"
+    m = re.search(r"const BJX_ACCUMULATE, BJX_REF_VECTOR_SCALE_LADJ = UInt32\((\d+)\), UInt32\((\d+)\)", j)
+    assert (m.group(1), m.group(2)) == ("1", "2")
+    assert "const BJX_BASE_STDNORMAL, BJX_INPUT_STDNORMAL = UInt32(1) << 2, UInt32(1) << 3" in j
+    assert "const BJX_COUPLING_SCALE_BCAST, BJX_COUPLING_SHIFT_BCAST = UInt32(1) << 4, UInt32(1) << 5" in j
+
+
+# b ∈ {Elementwise{exp/log}, Logit, Scale, Shift, LeakyReLU, TruncatedBijector, OrderedBijector, SimplexBijector,
+# VecCholeskyBijector, Permute, PlanarLayer, RadialLayer, InvertibleBatchNorm, RationalQuadraticSpline, Coupling} and Inverse{…} of each.
+# inverse(elementwise(exp)) / inverse(Shift) / inverse(LeakyReLU) / inverse(Permute) are bijectors of the same kind in the reference
+# (exp_log via InverseFunctions, shift.jl:12, leaky_relu.jl:16, permute.jl:153): no Inverse{…} wrapper exists for them.
+PLAIN = ["Elementwise{typeof(exp)}", "Elementwise{typeof(log)}", "Logit", "Scale{<:Union{Real,AbstractVector}}", "Shift{<:Union{Real,AbstractVector}}",
+         "LeakyReLU", "TruncatedBijector", "OrderedBijector", "SimplexBijector", "VecCholeskyBijector", "Permute", "PlanarLayer",
+         "RadialLayer", "InvertibleBatchNorm", "RationalQuadraticSpline{<:AbstractMatrix}", "Coupling"]
+WRAPPED = ["Inverse{<:Logit}", "Inverse{<:Scale{<:Union{Real,AbstractVector}}}", "Inverse{<:TruncatedBijector}", "Inverse{OrderedBijector}",
+           "Inverse{<:SimplexBijector}", "Inverse{VecCholeskyBijector}", "Inverse{<:PlanarLayer}", "Inverse{<:RadialLayer}",
+           "Inverse{<:InvertibleBatchNorm}", "Inverse{<:RationalQuadraticSpline{<:AbstractMatrix}}", "Inverse{<:Coupling}"]
+
+
+def _union_members(j, name):
+    m = re.search(r"const " + name + r"\s*=\s*Union\{", j)
+    i, depth, start = m.end(), 1, m.end()
+    while depth:
+        depth += {"{": 1, "}": -1}.get(j[i], 0)
+        i += 1
+    body, parts, depth, cur = j[start:i - 1], [], 0, ""
+    for c in body:
+        if c == "," and depth == 0:
+            parts.append(cur.strip())
+            cur = ""
+        else:
+            depth += {"{": 1, "}": -1}.get(c, 0)
+            cur += c
+    parts.append(cur.strip())
+    return [re.sub(r"\s+", "", p) for p in parts if p.strip()]
+
+
+def test_every_bijector_of_the_boundary_has_a_plan_and_the_six_methods():
+    j = _strip_julia(_julia())
+    members = set()
+    for u in ("ElementwiseLeaf", "Fusable", "Structured", "Planned"):
+        members |= set(_union_members(j, u))
+    for want in PLAIN + WRAPPED:
+        assert want.replace(" ", "") in members, f"{want} is in none of the planned unions"
+    # unions nest: Planned ⊇ Fusable ∪ Structured, Fusable ⊇ ElementwiseLeaf, Structured ⊇ MatrixKinds
+    assert {"Fusable", "Structured"} <= set(_union_members(j, "Planned"))
+    assert "ElementwiseLeaf" in _union_members(j, "Fusable")
+    # a plan method per structured member (by the type name that appears in the signature)
+    sigs = re.findall(r"^(?:function )?plan\(([^)]*)\)", j, flags=re.M)
+    sig_text = "\n".join(sigs).replace(" ", "")
+    for want in [w for w in PLAIN + WRAPPED if w not in PLAIN[:7] + WRAPPED[:3]] + ["Fusable", "MatrixKinds", "Inverse{<:MatrixKinds}",
+                                                                                     "Scale{<:ROCMatrix{T}}", "Inverse{<:Scale{<:ROCMatrix{T}}}"]:
+        key = want.replace(" ", "")
+        assert "::" + key + "," in sig_text, f"no plan(::{want}, x) method"
+    # the fused op walker knows every elementwise leaf and wrapper
+    ops_sigs = [re.sub(r"\s+", "", m) for m in re.findall(r"^(?:function )?ops\((?:\w+)?::(.*?),\s*T,\s*keep\)", j, flags=re.M)]
+    for want in PLAIN[:7] + WRAPPED[:3] + ["Bijectors.SignFlip", "ComposedFunction"]:
+        assert want.replace(" ", "") in ops_sigs, f"no ops(::{want}, T, keep) method; have {ops_sigs}"
+    # the six entry points of src/interface.jl:156-218, defined on the planned union, importing the reference's generic functions
+    imp = re.search(r"import Bijectors: ([^\n]*)", j).group(1)
+    for f in ("transform", "transform!", "logabsdetjac", "logabsdetjac!", "with_logabsdet_jacobian", "with_logabsdet_jacobian!"):
+        assert re.search(r"\b" + re.escape(f) + r"(,|$)", imp.strip()), f"{f} is not imported for extension"
+        assert re.search(r"^(?:function )?" + re.escape(f) + r"\(b::Planned, x::ROCArray", j, flags=re.M), f"{f}(b::Planned, x::ROCArray…) is not defined"
+        assert re.search(r"^(?:function )?" + re.escape(f) + r"\(sb::Stacked, x::ROCVecOrMat", j, flags=re.M), f"{f}(sb::Stacked, …) is not defined"
+    # the `!` forms take the accumulating arguments of interface.jl:199-218
+    assert re.search(r"function with_logabsdet_jacobian!\(b::Planned, x::ROCArray\{T\}, y::ROCArray\{T\}, logjac\)", j)
+    assert re.search(r"function logabsdetjac!\(b::Planned, x::ROCArray\{T\}, logjac\)", j)
+    assert re.search(r"function transform!\(b::Planned, x::ROCArray\{T\}, y::ROCArray\{T\}\)", j)
+    # log-det only calls do not store the transformed values where the entry allows it; transform passes no log-det pointers
+    assert "run!(p, T, x, nothing)" in j and "want_ladj=false" in j and "BJX_ACCUMULATE" in j
+
+
+RRULES = ["Bijectors._transform_ordered", "Bijectors._transform_inverse_ordered", "Bijectors._inv_link_chol_lkj", "Bijectors.$f"]
+RRULES_WLJ = ["Union{SimplexBijector,Inverse{<:SimplexBijector}}", "Fusable", "Stacked", "PlanarLayer", "Inverse{<:PlanarLayer}", "RadialLayer",
+              "Inverse{<:RadialLayer}", "RationalQuadraticSpline{<:ROCMatrix{T}}", "Inverse{<:RationalQuadraticSpline{<:ROCMatrix{T}}}",
+              "Union{Coupling,Inverse{<:Coupling}}", "Permute"]
+
+
+def test_pullback_rules_cover_every_vjp_entry():
+    j = _strip_julia(_julia())
+    for f in RRULES:
+        assert re.search(r"ChainRulesCore\.rrule\(::typeof\(" + re.escape(f) + r"\)", j), f"no rrule for {f}"
+    heads = re.findall(r"ChainRulesCore\.rrule\((?:cfg::[^,]*,\s*)?::typeof\(with_logabsdet_jacobian\),\s*\w+::(.*?),\s*\w+::ROC", j, flags=re.S)
+    heads = [re.sub(r"\s+", "", h) for h in heads]
+    for want in RRULES_WLJ:
+        assert want.replace(" ", "") in heads, f"no rrule(::typeof(with_logabsdet_jacobian), ::{want}, …); have {heads}"
+    vjp_entries = [n for n in _prototypes() if "_vjp" in n or n == "bjx_row_moments"]
+    assert len(vjp_entries) == 15, vjp_entries
+    called = {c[0] for c in _ccalls()}
+    assert set(vjp_entries) <= called
+
+
+def test_integration_table_names_functions_that_exist():
+    """INTEGRATION.md's `Julia side` column: every `BijectorsBJX.<name>` it cites is defined in the file, and every entry point of
+    the header has a row."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    j = _strip_julia(_julia())
+    cited = set(re.findall(r"BijectorsBJX\.([A-Za-z_!][A-Za-z0-9_!]*)", md)) - {"jl"}
+    assert len(cited) >= 25, sorted(cited)
+    for name in sorted(cited):
+        pat = r"^(?:function |mutable struct |struct |const )?" + re.escape(name) + r"(\(|\b)"
+        assert re.search(pat, j, flags=re.M), f"INTEGRATION.md cites BijectorsBJX.{name}, which julia/BijectorsBJX.jl does not define"
+    table = md.split("## Entry point")[1].split("\n## ")[0]
+    for entry in _prototypes():
+        assert re.search(r"`" + entry + r"\b", table) or re.search(r"\b" + entry.replace("bjx_", "") + r"\b", table) or entry in table, \
+            f"{entry} has no row in INTEGRATION.md's entry-point table"
+
+
+def test_the_file_is_balanced():
+    """keyword / bracket balance (what a parser would reject first)"""
+    j = _strip_julia(_julia())
+    depth, openers, ends = 0, 0, 0
+    stack = []
+    for m in re.finditer(r"[A-Za-z_!][A-Za-z0-9_!]*|[()\[\]{}]", j):
+        t = m.group(0)
+        if t in "([{":
+            stack.append(t)
+        elif t in ")]}":
+            assert stack and "([{".index(stack[-1]) == ")]}".index(t), f"unbalanced {t} at offset {m.start()}: ...{j[max(0, m.start() - 80):m.start() + 20]}"
+            stack.pop()
+        elif not stack:                                   # generators / comprehensions live inside brackets and take no `end`
+            prev = j[max(0, m.start() - 1):m.start()]
+            if prev in (":", "."):                        # a Symbol or a field, not a keyword
+                continue
+            if t in ("function", "if", "for", "while", "struct", "begin", "try", "let", "module", "quote", "do", "macro"):
+                openers += 1
+            elif t == "end":
+                ends += 1
+    assert not stack
+    assert openers == ends, (openers, ends)
