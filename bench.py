@@ -86,6 +86,8 @@ def fill_normal(bj, torch, t, col0, seed, mean=0.0, std=1.0):
     L.check(ctx.h, rc, "bjx_fill_normal")
 
 
+PREROLL_MS = float(os.environ.get("BJX_BENCH_PREROLL_MS", "60"))     # untimed clock-settling pre-roll before the timed steps (0 = off)
+
 # ---------------------------------------------------------------------------------- workloads
 DEFAULT_LOG2 = {"c1": 0, "c2": 24, "c2v": 24, "copy": 24, "c3": 22, "c4": 22, "c5a": 20, "c5b": 20, "vcorr": 18, "pdvec": 18}
 
@@ -336,6 +338,17 @@ def traffic_from_profiles(workload):
         return None
 
 
+def traffic_source(workload):
+    """`roofline.traffic` is NOT a quantity of this run: it is the PMC measurement stored in profiles/traffic.json by the
+    profiling recipe (scripts/collect_profiles.py) under the profile tag named there."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tag = json.load(f).get(workload, {}).get("tag")
+        return None if tag is None else f"profiles/traffic.json[{workload}], profile set {tag} (rocprofv3 PMC passes; not measured in this run)"
+    except Exception:
+        return None
+
+
 # ---------------------------------------------------------------------------------- one measured workload
 class Env:
     pass
@@ -356,9 +369,28 @@ def measure(env, name, steps, warmup, scaling, log2_batch=None):
         torch.cuda.synchronize()
 
     last = None
+    barrier()
+    t_w = time.perf_counter()
     for _ in range(warmup):
         last = wl["step"]()
     barrier()
+    # Clock-settling pre-roll (profiles/r03_warmup.md): a fresh process reaches its steady clocks only after ~20-30 ms of load;
+    # the W warm-up steps of a 0.1-0.5 ms workload are over long before that and the K timed steps then run 8-15 % below steady
+    # state (same box, same binary: C3 0.54 with 5 warm-up steps, 0.61-0.63 with 50-300; C4 0.69 -> 0.73; C2 and C5b, whose 5
+    # warm-up steps already last 7-24 ms, do not move).  So: the W untimed warm-up steps as asked, then MORE untimed steps of the
+    # same workload until PREROLL_MS of it have run; the count comes from the all-reduced warm-up time, so every rank issues
+    # the same number of steps (they contain the collective).  Nothing in the timed region changes.
+    pre = 0
+    if PREROLL_MS > 0:
+        per = (time.perf_counter() - t_w) / max(warmup, 1)
+        if dist is not None:
+            tt = torch.tensor([per], dtype=torch.float64, device=env.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            per = float(tt[0])
+        pre = 0 if per <= 0 else max(0, min(4000, int(math.ceil(PREROLL_MS * 1e-3 / per)) - warmup))
+        for _ in range(pre):
+            last = wl["step"]()
+        barrier()
     lib.bjx_kernel_time_begin(ctx.h)          # one hipEvent pair around every dominant-kernel launch (context stream)
     lib.bjx_time_begin(ctx.h)
     t0 = time.perf_counter()
@@ -385,9 +417,9 @@ def measure(env, name, steps, warmup, scaling, log2_batch=None):
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else float("nan")
     res = {
         "workload": name, "label": wl["label"], "value": wl["total"] / (dt / steps) / 1e6, "unit": "M samples/s", "dtype": wl["dtype"],
-        "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup, "scaling": scaling, "config": wl["cfg"],
+        "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup, "preroll_steps": pre, "scaling": scaling, "config": wl["cfg"],
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic_from_profiles(name), "kernel": wl["kernel"], "kernel_ms": kern_ms,
+                     "traffic": traffic_from_profiles(name), "traffic_source": traffic_source(name), "kernel": wl["kernel"], "kernel_ms": kern_ms,
                      "kernel_launches_per_step": k_n.value / max(steps, 1), "stream_region_ms_per_step": ev / steps,
                      "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
         "sum_logabsdetjac": ladj_total,
@@ -517,6 +549,8 @@ def main():
             "dtype": head["dtype"], "data": "synthetic (Philox N(0,1), shard-invariant)",
             "config": dict(head["config"], parallelism=f"batch-sharded x{world}, one f64 all-reduce of Σlogabsdetjac ({a.collective})"),
             "roofline": head["roofline"], "sum_logabsdetjac": head["sum_logabsdetjac"], "label": head["label"],
+            "preroll": {"ms": PREROLL_MS, "steps": head.get("preroll_steps", 0),
+                        "note": "untimed steps of the same workload after the W warm-up steps, until the GPU has been under load for `ms` (steady clocks); the timed region is exactly K steps"},
         }
         for k in ("us_per_call", "M_elements_per_s"):
             if k in head:

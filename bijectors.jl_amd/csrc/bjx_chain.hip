@@ -260,7 +260,7 @@ template <class T, int V> __device__ __forceinline__ Pack<T, V> gen_pack(uint64_
 }
 template <class T, int V, int ROWMODE, bool NT, int U, bool GEN = false>
 __global__ __launch_bounds__(256) void chain_flat_kernel(const ChainArgs<T> A, const T* x, T* y, int64_t n,
-                                                         int64_t dim, int dim_pow2, double* partials, uint64_t seed = 0, int64_t e0 = 0) {
+                                                         int64_t dim, int dim_pow2, const BjxFin fin, uint64_t seed = 0, int64_t e0 = 0) {
   __shared__ double red[4];
   const int64_t nv = n / V;
   const int64_t i0 = (int64_t)blockIdx.x * (256 * U) + threadIdx.x;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void chain_flat_kernel(const ChainArgs<T> A, c
       }
     }
   }
-  if (partials) block_publish_partial(acc, red, partials);
+  block_publish_partial(acc, red, fin);      // small grids: the last block to arrive finishes the sum (one launch per call)
 }
 
 // Per-sample log-det with the FLAT geometry (U packs in flight per lane, 16 KiB per block) when a
@@ -542,6 +542,8 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
   const bool nt = env_nt();
   const int dim_pow2 = (dim & (dim - 1)) == 0 ? 1 : 0;
   int64_t grid = 1;
+  BjxFin fin;                 // flat kernels: Σ log|det J| epilogue (in-kernel for small grids, bjx_make_fin)
+  bool second = false;
 
   if (flags & BJX_INPUT_STDNORMAL) {
     // on-device sampling: the input packs are drawn inside the kernel (flat geometry; sum-only log-det)
@@ -554,10 +556,9 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
   do {                                                                                                               \
     grid = (n / V_ + 1 + 256 * UG - 1) / (256 * UG);                                                                 \
     BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_chain: input too large for one launch");     \
-    if (ladj_sum) { int rc_ = bjx_ensure_partials(ctx, (size_t)grid); if (rc_) return rc_; }                         \
-    double* partials = ladj_sum ? ctx->partials : nullptr;                                                           \
+    { int rc_ = bjx_make_fin(ctx, grid, ladj_sum, c_sum_host, any_dev_scale ? 1 : 0, flags, &fin, &second); if (rc_) return rc_; } \
     BjxProf prof_(ctx);                                                                                              \
-    hipLaunchKernelGGL((chain_flat_kernel<T, V_, RM_, true, UG, true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, (const T*)nullptr, y, n, dim, dim_pow2, partials, ctx->rng_seed, e0); \
+    hipLaunchKernelGGL((chain_flat_kernel<T, V_, RM_, true, UG, true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, (const T*)nullptr, y, n, dim, dim_pow2, fin, ctx->rng_seed, e0); \
   } while (0)
     if (!any_row) { if (yv) LAUNCH_GEN(VW, 0); else LAUNCH_GEN(1, 0); }
     else if (yv && rows_vec) LAUNCH_GEN(VW, 1);
@@ -565,7 +566,7 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
     else LAUNCH_GEN(1, 2);
 #undef LAUNCH_GEN
     BJX_CHECK_LAUNCH(ctx);
-    if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, c_sum_host, any_dev_scale ? 1 : 0, 0.0, flags);
+    if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, c_sum_host, any_dev_scale ? 1 : 0, 0.0, flags);
     return BJX_OK;
   }
 
@@ -579,11 +580,10 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
   do {                                                                                                        \
     grid = (n / V_ + 1 + 256 * U_ - 1) / (256 * U_);   /* +1: the lane that owns the n % V tail */            \
     BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_chain: input too large for one launch"); \
-    if (ladj_sum) { int rc_ = bjx_ensure_partials(ctx, (size_t)grid); if (rc_) return rc_; }                  \
-    double* partials = ladj_sum ? ctx->partials : nullptr;                                                    \
+    { int rc_ = bjx_make_fin(ctx, grid, ladj_sum, c_sum_host, any_dev_scale ? 1 : 0, flags, &fin, &second); if (rc_) return rc_; } \
     BjxProf prof_(ctx);                                                                                       \
-    if (nt) hipLaunchKernelGGL((chain_flat_kernel<T, V_, RM_, true, U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, x, y, n, dim, dim_pow2, partials); \
-    else hipLaunchKernelGGL((chain_flat_kernel<T, V_, RM_, false, U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, x, y, n, dim, dim_pow2, partials);  \
+    if (nt) hipLaunchKernelGGL((chain_flat_kernel<T, V_, RM_, true, U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, x, y, n, dim, dim_pow2, fin); \
+    else hipLaunchKernelGGL((chain_flat_kernel<T, V_, RM_, false, U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, x, y, n, dim, dim_pow2, fin);  \
   } while (0)
 #define LAUNCH_FLAT(V_, RM_) LAUNCH_FLAT_UV(V_, RM_, 1)
 #define LAUNCH_FLAT_TUNED(V_, RM_)                                  \
@@ -691,6 +691,10 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
 #undef LAUNCH_FLAT_UV
 #undef LAUNCH_FLAT_TUNED
   BJX_CHECK_LAUNCH(ctx);
+  if (!ladj_ps) {             // flat kernels: bjx_make_fin decided who finishes the sum
+    if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, c_sum_host, any_dev_scale ? 1 : 0, 0.0, flags);
+    return BJX_OK;
+  }
   if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, c_sum_host, any_dev_scale ? 1 : 0, 0.0, flags);
   return BJX_OK;
 }

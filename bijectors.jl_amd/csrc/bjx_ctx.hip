@@ -55,6 +55,17 @@ int bjx_ensure_partials(bjx_ctx* ctx, size_t n) {
   return BJX_OK;
 }
 
+int bjx_ensure_big_ws(bjx_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->big_ws_bytes) return BJX_OK;
+  BJX_REQUIRE(ctx, !ctx->capturing, BJX_ERR_UNSUPPORTED, "the matrix workspace must grow (%zu bytes) inside a graph capture: run the step once before capturing it", bytes);
+  if (ctx->big_ws) BJX_HIP(ctx, hipFree(ctx->big_ws));     // synchronises: earlier launches are done with it
+  ctx->big_ws = nullptr;
+  ctx->big_ws_bytes = 0;
+  BJX_HIP(ctx, hipMalloc(&ctx->big_ws, bytes));
+  ctx->big_ws_bytes = bytes;
+  return BJX_OK;
+}
+
 int bjx_launch_finalize(bjx_ctx* ctx, int n_partials, double* ladj_sum, double host_const,
                         int use_dev_const, double /*unused*/, uint32_t flags) {
   const double* src = ctx->partials;
@@ -83,11 +94,8 @@ int bjx_make_fin(bjx_ctx* ctx, int64_t grid, double* ladj_sum, double host_const
   if (rc) return rc;
   fin->partials = ctx->partials;
   if (ctx->opt_inkernel_fin && grid <= BJX_INKERNEL_FIN_MAX) {
-    // EXPERIMENTAL (off unless BJX_OPT_INKERNEL_FINALIZE / BJX_INKERNEL_FIN asks for it): the hand-off relies on sc1
-    // stores and loads being served at the device-coherent level on gfx950, not on the HSA memory model's guarantees.
-    // The arrival counter is zeroed by the host before every launch: a launch that faulted or was aborted must not leave
-    // a count behind that would make every later sum of this context silently wrong.
-    BJX_HIP(ctx, hipMemsetAsync(ctx->fin_counter, 0, sizeof(unsigned), ctx->stream));
+    // The arrival counter is zero between launches: the block that draws the last ticket resets it (a launch that faults
+    // leaves the HIP context in a sticky error state, so no later launch can see a stale count); nothing is enqueued here.
     fin->counter = ctx->fin_counter;
     fin->out = ladj_sum;
     fin->host_const = host_const;
@@ -123,7 +131,6 @@ BJX_API int bjx_create(int device, void* hip_stream, bjx_ctx** out) {
   if (e == hipSuccess) e = hipMalloc(&ctx->scratch, BJX_SCRATCH_BYTES);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
-  if (e == hipSuccess && getenv("BJX_INKERNEL_FIN")) ctx->opt_inkernel_fin = atoi(getenv("BJX_INKERNEL_FIN")) ? 1 : 0;
   if (e == hipSuccess) {
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, device);
@@ -149,6 +156,7 @@ BJX_API int bjx_destroy(bjx_ctx* ctx) {
   if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
   if (ctx->stage_ev) (void)hipEventDestroy(ctx->stage_ev);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->big_ws) (void)hipFree(ctx->big_ws);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->prof_ev) {
@@ -169,7 +177,7 @@ BJX_API const char* bjx_last_error(bjx_ctx* ctx) { return ctx ? ctx->err : "null
 
 BJX_API size_t bjx_workspace_bytes(bjx_ctx* ctx) {
   (void)ctx;
-  return sizeof(double) * ((ctx ? ctx->partials_cap : (size_t)BJX_MAX_BLOCKS) + BJX_MAX_BLOCKS + BJX_CONSTS) + BJX_SCRATCH_BYTES;
+  return sizeof(double) * ((ctx ? ctx->partials_cap : (size_t)BJX_MAX_BLOCKS) + BJX_MAX_BLOCKS + BJX_CONSTS) + BJX_SCRATCH_BYTES + (ctx ? ctx->big_ws_bytes : 0);
 }
 
 BJX_API int bjx_set_option(bjx_ctx* ctx, int option, int value) {

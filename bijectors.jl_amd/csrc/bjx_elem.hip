@@ -493,151 +493,6 @@ __global__ __launch_bounds__(256) void rqs_lds_kernel(const T* __restrict__ blob
   block_publish_partial_at(acc, reinterpret_cast<double*>(smem), reinterpret_cast<int*>(smem + 64), fin);
 }
 
-// ------------------------------------------------------------------ RQS, SHORT-LIVED blocks (round 3)
-// Same blob, search, records and evaluation as rqs_lds_kernel, but a block owns NP column groups and then EXITS: a thread
-// issues its NP packs' loads up front (no look-ahead loop), evaluates them and stores.  Why: on this chip every streaming
-// skeleton whose waves LOOP over memory — grid-stride or contiguous runs, any unroll, any occupancy — tops out at 60-68 %
-// of the HBM peak, while kernels whose waves touch 1-4 packs and retire stream at 72-82 % (scripts/membench.hip,
-// profiles/r01_membench.txt: "A one-pack" 0.78-0.83, "D 2/4 packs no loop" 0.73/0.72, "B/C loops" 0.56-0.68), and the
-// looping rqs_lds_kernel's own load/stage/store skeleton measured 0.63.  The price is the table: the 34 KiB blob is staged
-// once per NP·4 KiB of data instead of once per ~100 KiB — L2 -> LDS traffic of the order of the HBM traffic, cheap for
-// the L2 (34 TB/s) and issued BEFORE the data loads so that it lands first (the VMEM counter retires in order).
-template <class T, int V, int NSTEP> struct RqsLane {
-  T lim[V], k1[V], k2a[V], k2b[V];
-  int lb[NSTEP > 2 ? NSTEP - 2 : 1][V], ra[V];
-};
-template <class T, int V, int NSTEP>
-__device__ __forceinline__ void rqs_lane_init(RqsLane<T, V, NSTEP>& L, const T* __restrict__ blob_l, const RqsGeom& g, int glc, bool lane_ok) {
-#pragma unroll
-  for (int j = 0; j < V; ++j) {
-    const int rp = j * g.nvc + glc;
-    L.lim[j] = lane_ok ? blob_l[rp] : T(0);
-    L.k1[j] = blob_l[g.dimp + rp];
-    if (NSTEP >= 2) { L.k2a[j] = blob_l[2 * g.dimp + 2 * rp]; L.k2b[j] = blob_l[2 * g.dimp + 2 * rp + 1]; }
-    else { L.k2a[j] = L.k2b[j] = T(0); }
-#pragma unroll
-    for (int lvl = 3; lvl <= NSTEP; ++lvl) L.lb[lvl - 3][j] = (int)sizeof(T) * ((g.dimp + rp) << (lvl - 1));
-    L.ra[j] = rqs_rec_base<T>(g, j, (int)threadIdx.x, glc);
-  }
-}
-template <class T, int V, int NSTEP, bool INV>
-__device__ __forceinline__ T rqs_eval_pack(const RqsLane<T, V, NSTEP>& L, const char* __restrict__ base, Pack<T, V>& p) {
-  constexpr int SH = sizeof(T) == 4 ? 2 : 3;
-  int pos[V];
-#pragma unroll
-  for (int j = 0; j < V; ++j) {
-    pos[j] = (L.k1[j] < p.v[j]) ? 1 : 0;
-    if (NSTEP >= 2) { const T kk = pos[j] ? L.k2b[j] : L.k2a[j]; search_step(pos[j], kk, p.v[j]); }
-  }
-#pragma unroll
-  for (int lvl = 3; lvl <= NSTEP; ++lvl) {
-    T kv[V];
-#pragma unroll
-    for (int j = 0; j < V; ++j) kv[j] = *reinterpret_cast<const T*>(base + ((pos[j] << SH) + L.lb[lvl - 3][j]));
-#pragma unroll
-    for (int j = 0; j < V; ++j) search_step(pos[j], kv[j], p.v[j]);
-  }
-  Rec4<T> A[V], B[V];
-#pragma unroll
-  for (int j = 0; j < V; ++j) {
-    const char* rec = base + ((pos[j] << RqsRec<T>::PS) + L.ra[j]);
-    A[j] = lds_rec<T>(rec, 0);
-    B[j] = lds_rec<T>(rec, RqsRec<T>::RQ / 2);
-  }
-  T l = T(0);
-#pragma unroll
-  for (int j = 0; j < V; ++j) l += rqs_eval<T, INV>(A[j], B[j], L.lim[j], p.v[j]);
-  return l;
-}
-
-template <class T, int V, int NSTEP, bool INV, int NP>
-__device__ __forceinline__ void rqs_sl_body(const T* __restrict__ blob_l, const RqsGeom g, Pack<T, V> (&p)[NP], __amdgpu_buffer_rsrc_t ry,
-                                            __amdgpu_buffer_rsrc_t rl, __amdgpu_buffer_rsrc_t rl_in, const int (&vo)[NP], const int (&lo)[NP],
-                                            int G, int ncols_blk, double& acc) {
-  const int gl = threadIdx.x & (G - 1);
-  const int cg = threadIdx.x / G;
-  const int cols_per_block = 256 / G;
-  const bool lane_ok = gl < g.nvc;
-  RqsLane<T, V, NSTEP> L;
-  rqs_lane_init<T, V, NSTEP>(L, blob_l, g, lane_ok ? gl : 0, lane_ok);
-  const char* base = reinterpret_cast<const char*>(blob_l);
-  const GroupMasks gm = make_group_masks(G);
-  static_assert(NP % 2 == 0, "packs are reduced in pairs");
-  T lin[NP];
-#pragma unroll
-  for (int k = 0; k < NP; ++k) lin[k] = buf_load_pack<T, 1>(rl_in, lo[k]).v[0];     // BJX_ACCUMULATE (empty descriptor otherwise)
-#pragma unroll
-  for (int k = 0; k < NP; k += 2) {
-    T l0 = rqs_eval_pack<T, V, NSTEP, INV>(L, base, p[k]);
-    buf_store_pack<T, V>(ry, vo[k], p[k]);
-    __builtin_amdgcn_sched_barrier(0);
-    T l1 = rqs_eval_pack<T, V, NSTEP, INV>(L, base, p[k + 1]);
-    buf_store_pack<T, V>(ry, vo[k + 1], p[k + 1]);
-    __builtin_amdgcn_sched_barrier(0);
-    group_sum2_flat(l0, l1, gm);
-    l0 *= Num<T>::log2;
-    l1 *= Num<T>::log2;
-    buf_store_pack<T, 1>(rl, lo[k], Pack<T, 1>{{l0 + lin[k]}});
-    buf_store_pack<T, 1>(rl, lo[k + 1], Pack<T, 1>{{l1 + lin[k + 1]}});
-    const bool own = gl == 0;
-    acc += (double)((own && cg + k * cols_per_block < ncols_blk) ? l0 : T(0));
-    acc += (double)((own && cg + (k + 1) * cols_per_block < ncols_blk) ? l1 : T(0));
-  }
-}
-
-template <class T, int V, int NSTEP_HI, bool DUAL, bool INV, int NP>
-__global__ __launch_bounds__(256) void rqs_sl_kernel(const T* __restrict__ blob, const int* __restrict__ flag, int K1,
-                                                     const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t dim,
-                                                     int64_t batch, int G, int accumulate, const BjxFin fin) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double red[4];
-  T* blob_l = reinterpret_cast<T*>(smem);
-  const int skip0 = DUAL ? flag[0] : 0;
-  const RqsGeom g = rqs_geom(K1, dim, V, skip0, NSTEP_HI, G);
-  const int n16 = (int)(rqs_blob_bytes<T>(g) / 16);
-  const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(blob);
-  bjx_f32x4* dst = reinterpret_cast<bjx_f32x4*>(blob_l);
-  // (1) table loads of the first chunk (<= 12 quads per lane = 48 KiB), (2) the NP data loads, (3) table -> LDS.  Waiting for the
-  // table then leaves the data loads in flight (s_waitcnt vmcnt(NP)).
-  constexpr int CH = 12;
-  bjx_f32x4 st[CH];
-#pragma unroll
-  for (int c = 0; c < CH; ++c) { const int i = (int)threadIdx.x + c * 256; st[c] = i < n16 ? src[i] : bjx_f32x4{0, 0, 0, 0}; }
-  const int gl = threadIdx.x & (G - 1), cg = threadIdx.x / G;
-  const int cols_per_block = 256 / G;
-  const bool lane_ok = gl < g.nvc;
-  const int64_t bcol0 = (int64_t)blockIdx.x * NP * cols_per_block;
-  const int64_t left_blk = batch - bcol0;
-  const int ncols_blk = left_blk > (int64_t)NP * cols_per_block ? NP * cols_per_block : (left_blk > 0 ? (int)left_blk : 0);
-  const int col_bytes = (int)dim * (int)sizeof(T);
-  constexpr int kOob = 0x7fffff00;
-  const auto rx = bjx_make_rsrc(reinterpret_cast<const char*>(x + bcol0 * dim), (uint32_t)ncols_blk * (uint32_t)col_bytes);
-  const auto ry = bjx_make_rsrc(reinterpret_cast<char*>(y + bcol0 * dim), (uint32_t)ncols_blk * (uint32_t)col_bytes);
-  char* lpb = reinterpret_cast<char*>(ladj_ps ? ladj_ps + bcol0 : nullptr);
-  const auto rl = bjx_make_rsrc(lpb, lpb ? (uint32_t)ncols_blk * (uint32_t)sizeof(T) : 0u);
-  const auto rl_in = bjx_make_rsrc(lpb, (lpb && accumulate) ? (uint32_t)ncols_blk * (uint32_t)sizeof(T) : 0u);
-  int vo[NP], lo[NP];
-  Pack<T, V> p[NP];
-#pragma unroll
-  for (int k = 0; k < NP; ++k) {
-    vo[k] = lane_ok ? ((cg + k * cols_per_block) * (int)dim + gl * V) * (int)sizeof(T) : kOob;
-    lo[k] = gl == 0 ? (cg + k * cols_per_block) * (int)sizeof(T) : kOob;
-    p[k] = buf_load_pack<T, V>(rx, vo[k]);
-  }
-#pragma unroll
-  for (int c = 0; c < CH; ++c) { const int i = (int)threadIdx.x + c * 256; if (i < n16) dst[i] = st[c]; }
-  for (int i = (int)threadIdx.x + CH * 256; i < n16; i += 256) dst[i] = src[i];      // blobs beyond 48 KiB
-  __syncthreads();
-  double acc = 0.0;
-  if constexpr (DUAL) {
-    if (skip0) rqs_sl_body<T, V, NSTEP_HI - 1, INV, NP>(blob_l, g, p, ry, rl, rl_in, vo, lo, G, ncols_blk, acc);
-    else rqs_sl_body<T, V, NSTEP_HI, INV, NP>(blob_l, g, p, ry, rl, rl_in, vo, lo, G, ncols_blk, acc);
-  } else {
-    rqs_sl_body<T, V, NSTEP_HI, INV, NP>(blob_l, g, p, ry, rl, rl_in, vo, lo, G, ncols_blk, acc);
-  }
-  block_publish_partial(acc, red, fin);
-}
-
 // ------------------------------------------------------------------ RQS input pullback
 // x̄ = ȳ·f'(x) + ℓ̄·(log f')'(x) for the elementwise spline (rational_quadratic_spline.jl:128-357; closed-form
 // derivatives).  With the quantities rqs_eval already has (ξ, p = ξ(1-ξ), den = s + ds·p, nj = d_k + dd·ξ - ds·p):
@@ -946,6 +801,10 @@ template <class T> bool knots_fit_lds(int64_t rows, int K1) { return (size_t)row
 constexpr size_t kRqsBlobMax = 64 * 1024;
 // Column groups per block: enough to amortise the table staging (>= ~3x the table bytes of data; same-call sweeps at 32 x 2^22,
 // forward + inverse: 8 groups 0.53 ms, 12: 0.50, 17: 0.49, 24: 0.48, 34: 0.49, 64: 0.48, 128: 0.50).
+// Round 3, tried and dropped (profiles/r03_c3_experiments.md, same-box A/Bs): SHORT-LIVED blocks — NP = 2 / 4 column groups per block,
+// all loads up front, table staged per block — 0.39 / 0.48 of the HBM peak against 0.56 for this looping form (the 34 KiB table per
+// 8-16 KiB of data is not free); and FIVE blocks per CU instead of four (no static LDS, the reduction scratch aliases the dead
+// table: 5 x 32 KiB = 160 KiB) — neutral, kept because it costs nothing.
 inline int rqs_iters(const bjx_ctx* ctx, size_t blob_bytes, int64_t bytes_per_group, int64_t groups) {
   static const int forced = [] { const char* e = getenv("BJX_RQS_ITERS"); return e ? atoi(e) : 0; }();   // tuning switch
   if (forced > 0) return forced;
@@ -972,26 +831,6 @@ int rqs_launch_lds(bjx_ctx* ctx, int nstep_hi, int dual, const T* blob, const in
     default: return bjx_fail(ctx, BJX_ERR_UNSUPPORTED, "bjx_rqs: unsupported search depth %d", nstep_hi);
   }
 #undef RQS_L
-  BJX_CHECK_LAUNCH(ctx);
-  return BJX_OK;
-}
-
-template <class T, int V, bool INV, int NP>
-int rqs_launch_sl(bjx_ctx* ctx, int nstep_hi, int dual, const T* blob, const int* flag, int K1, size_t smem, int64_t grid, const T* in,
-                  T* out, T* ladj_ps, int64_t dim, int64_t batch, int G, int accum, const BjxFin& fin) {
-  BjxProf prof_(ctx);
-#define RQS_S(NS_, DUAL_) hipLaunchKernelGGL((rqs_sl_kernel<T, V, NS_, DUAL_, INV, NP>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, blob, flag, K1, in, out, ladj_ps, dim, batch, G, accum, fin)
-  switch (nstep_hi * 2 + (dual ? 1 : 0)) {
-    case 2: RQS_S(1, false); break;
-    case 4: RQS_S(2, false); break;  case 5: RQS_S(2, true); break;
-    case 6: RQS_S(3, false); break;  case 7: RQS_S(3, true); break;
-    case 8: RQS_S(4, false); break;  case 9: RQS_S(4, true); break;
-    case 10: RQS_S(5, false); break;
-    case 11: RQS_S(5, true); break;
-    case 12: RQS_S(6, false); break; case 13: RQS_S(6, true); break;
-    default: return bjx_fail(ctx, BJX_ERR_UNSUPPORTED, "bjx_rqs: unsupported search depth %d", nstep_hi);
-  }
-#undef RQS_S
   BJX_CHECK_LAUNCH(ctx);
   return BJX_OK;
 }
@@ -1025,23 +864,6 @@ int rqs_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int 
   const int64_t groups = (batch + cols_per_block - 1) / cols_per_block;
   constexpr int VW = Vec16<T>::N;
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
-  static const int sl_np = [] { const char* e = getenv("BJX_RQS_SL"); return e ? atoi(e) : 0; }();   // experiment: short-lived blocks
-  if (sl_np > 0 && c.V == VW && sizeof(T) == 4) {
-    const int np = sl_np >= 4 ? 4 : 2;
-    const int64_t grid = (groups + np - 1) / np;
-    BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_rqs: batch too large for one launch");
-    BjxFin fin;
-    bool second = false;
-    { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
-    int rc;
-#define SL_(INV_, NP_) rqs_launch_sl<T, VW, INV_, NP_>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, accum, fin)
-    if (np == 4) rc = inverse ? SL_(true, 4) : SL_(false, 4);
-    else rc = inverse ? SL_(true, 2) : SL_(false, 2);
-#undef SL_
-    if (rc) return rc;
-    if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
-    return BJX_OK;
-  }
   const int iters = rqs_iters(ctx, blob_bytes, (int64_t)cols_per_block * dim * sizeof(T), groups);
   const int64_t grid = (groups + iters - 1) / iters;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_rqs: batch too large for one launch");

@@ -14,6 +14,7 @@
 #define BJX_API extern "C" __attribute__((visibility("default")))
 
 // ------------------------------------------------------------------ context
+constexpr int BJX_INKERNEL_FIN_MAX = 4096;    // partials one block reduces: in-kernel (BJX_OPT_INKERNEL_FINALIZE = 1) and in bjx_finalize_kernel
 constexpr int BJX_MAX_BLOCKS = 4096;        // persistent-grid cap AND size of the 2nd-stage partial buffer
 constexpr int BJX_CONSTS = 8;               // device doubles for parameter-only log-det terms
 constexpr size_t BJX_SCRATCH_BYTES = 1 << 20;  // û tables, small parameter staging
@@ -30,9 +31,11 @@ struct bjx_ctx {
   unsigned* fin_counter = nullptr;  // arrival counter of the in-kernel finalize (zero between launches)
   double* consts = nullptr;     // [BJX_CONSTS]
   void* scratch = nullptr;      // [BJX_SCRATCH_BYTES]
+  void* big_ws = nullptr;       // workspace of the general-size matrix kernels (K > 64, matrix Scale beyond 128 rows): grown on demand, cached
+  size_t big_ws_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cu = 256;
-  int opt_inkernel_fin = 0;     // BJX_OPT_INKERNEL_FINALIZE
+  int opt_inkernel_fin = 0;     // BJX_OPT_INKERNEL_FINALIZE: 0 (default) two follow-up launches, 1 the last block finishes the sum (<= 4096 blocks)
   uint64_t rng_seed = 0;        // bjx_set_rng: stream of the fused sampling path (BJX_INPUT_STDNORMAL)
   int64_t rng_col0 = 0;
   // per-launch timing of the DOMINANT kernel of each call (bjx_kernel_time_begin/_end): event pairs
@@ -98,11 +101,12 @@ struct BjxFin {
   const double* dev_const = nullptr;
   int accumulate = 0;
 };
-constexpr int BJX_INKERNEL_FIN_MAX = 32768;   // partials one block may reduce in-kernel
 // host side: builds the descriptor for a launch of `grid` blocks; *second_pass = launch bjx_launch_finalize afterwards
 int bjx_make_fin(bjx_ctx* ctx, int64_t grid, double* ladj_sum, double host_const, int use_dev_const, uint32_t flags,
                  BjxFin* fin, bool* second_pass);
 
+// host side: make sure ctx->big_ws holds `bytes` (cached; growing it synchronises the device and cannot be captured)
+int bjx_ensure_big_ws(bjx_ctx* ctx, size_t bytes);
 // host side: make sure ctx->partials can hold n doubles (cached; reallocation synchronises the device)
 int bjx_ensure_partials(bjx_ctx* ctx, size_t n);
 // host side: launch the fixed-order reduction of per-block partials (+ constant term)
@@ -504,12 +508,17 @@ __device__ __forceinline__ void block_publish_partial(double acc, double* red, d
 
 // Same block sum; when f.counter is set, the LAST block to arrive finishes the global reduction
 // (thread t sums partials t, t+256, ... then the fixed tree of bjx_finalize_kernel -> the result is
-// independent of the arrival order).  Hand-off without agent-scope fences (an agent-scope release
-// writes the XCD's dirty L2 lines back on EVERY block: measured +0.4..0.8 ms per launch): the partial
-// is stored and re-loaded with agent-scope (sc1) atomics, which are served at the device-coherent
-// level, the store is waited for (vmcnt) before the arrival counter is bumped, and the last block
-// reads the partials with sc1 loads (MI355X_MICROARCH.md G16: "sc1 stores AND sc1 loads").
-// tests/test_gpu_parity.py::test_inkernel_finalize_is_bit_identical_to_two_pass stresses it.
+// independent of the arrival order) and the call is ONE launch.  Hand-off: the "drained sc1 payload + flag" form of
+// MI355X_MICROARCH.md ("Workgroup dispatch ... inter-workgroup visibility", price list row handoff-flag): the partial is an
+// 8-byte agent-scope (sc1, write-through) store, `s_waitcnt vmcnt(0)` (inline assembly: the compiler may drop a fence's wait
+// when it believes the scoreboard empty) acknowledges it, then the relaxed agent-scope arrival RMW; the block that draws the
+// last ticket reads the partials with sc1 loads (served at the device-coherent level, never from its L1).
+// OFF by default, measured (profiles/r03_finalize_ab.txt, same box, 200 steps): the wait makes every block's publishing wave sit
+// through the acknowledgement of its own output stores, and the arrival + last-block reduction are a serial tail behind the
+// slowest block — C1 (1024 blocks) 8.1 -> 20.6 us of kernel, 16.6 -> 26.1 us per call; C2 at 2^16 columns 20.5 -> 26.7 us;
+// with agent-scope release / acquire FENCES around the hand-off (buffer_wbl2 / buffer_inv: tried in round 3, removed)
+// 31.3 and 33.5 us.  Two small follow-up launches cost less than that tail on this chip, for every grid size tried.
+// tests/test_gpu_parity.py::test_inkernel_finalize_is_bit_identical_to_two_pass stresses the hand-off under load.
 // `flag_lds`: one LDS int for the "I am the last block" broadcast.  Kernels that budget their LDS to the byte (rqs_lds_kernel: 5 blocks
 // of 32 KiB per CU) pass a word of their own dynamic allocation; the wrapper below keeps a static one.
 __device__ __forceinline__ void block_publish_partial_at(double acc, double* red, int* flag_lds, const BjxFin& f) {
@@ -524,17 +533,37 @@ __device__ __forceinline__ void block_publish_partial_at(double acc, double* red
   if (threadIdx.x == 0) {
     double s = 0.0;
     for (int w = 0; w < nw; ++w) s += red[w];
-    __hip_atomic_store(&f.partials[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // s_waitcnt vmcnt(0): the store is acknowledged
+    __hip_atomic_store(&f.partials[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // sc1: write-through to the device-coherent level
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               // the payload store is acknowledged before the flag goes out
     const unsigned prev = __hip_atomic_fetch_add(f.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (prev == gridDim.x - 1) ? 1 : 0;
+    const int last = (prev == gridDim.x - 1) ? 1 : 0;
+    is_last = last;
   }
   __syncthreads();
   if (!is_last) return;
+  if (blockDim.x == 64) {
+    // one-wave blocks (seq_wave / colwalk / stacked_mixed kernels): the lane plays lane `l` of each of the FOUR waves of
+    // bjx_finalize_kernel in turn, so the order of the additions — and the bits — are those of the two-pass finalize
+    double a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[k] = 0.0;
+      for (unsigned i = k * 64 + lane; i < gridDim.x; i += 256)
+        a[k] += __hip_atomic_load(&f.partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a[k] = group_sum<64>(a[k]);
+    }
+    if (threadIdx.x == 0) {
+      double t = ((a[0] + a[1]) + (a[2] + a[3])) + f.host_const;
+      if (f.dev_const) t += *f.dev_const;
+      *f.out = f.accumulate ? (*f.out + t) : t;
+      __hip_atomic_store(f.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   double s = 0.0;
   for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x)
     s += __hip_atomic_load(&f.partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // blockDim.x == 256 for every kernel that uses the in-kernel finalize (fixed tree of 4 waves)
+  // blockDim.x == 256 for every other kernel that uses the in-kernel finalize (fixed tree of 4 waves)
   s = group_sum<64>(s);
   __syncthreads();
   if (lane == 0) red[wave] = s;

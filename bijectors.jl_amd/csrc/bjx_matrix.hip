@@ -548,13 +548,183 @@ int launch_gs(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double
   return 0;
 }
 
+// ------------------------------------------------------------------ any K (round 3): one BLOCK per sample, factor in a global workspace
+// The register / LDS kernels above stop at K = 64 (a wave holds the factor).  corr.jl:64-162 and pd.jl:1-60 have no limit, so
+// beyond that a plain restatement runs: 256 threads own one sample, the K x K working matrix lives in a per-block slab of the
+// context's workspace (L2-resident at these sizes), the factorisation is the right-looking column form (the same subtractions in
+// the same order as the oracle's row form), the LKJ link / its inverse walks one column per thread with LinkMath, and
+// X = U'U / L L' is one inner product per thread and entry.  O(K^3) work on O(K^2) bytes at a fraction of the roofline: correct
+// first, a blocked MFMA trailing update is the next step if such sizes matter.
+template <class T, int KIND, bool INV>
+__global__ __launch_bounds__(256) void matrix_big_kernel(const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps, T* __restrict__ ws,
+                                                         int K, int64_t batch, int accumulate, double* __restrict__ partials) {
+  using LM = LinkMath<T>;
+  __shared__ double red[4];
+  __shared__ double colsum[256];
+  const int t = threadIdx.x;
+  const int64_t KK = (int64_t)K * K;
+  const int64_t nv = KIND == MK_VEC_CORR ? (int64_t)K * (K - 1) / 2 : (KIND == MK_PD_VEC ? (int64_t)K * (K + 1) / 2 : KK);
+  const int64_t in_n = INV ? nv : KK, out_n = INV ? KK : nv;
+  T* A = ws + (int64_t)blockIdx.x * KK;                 // column-major working matrix: A[c*K + r]
+  constexpr bool CORR = KIND == MK_VEC_CORR || KIND == MK_CORR;
+  double acc = 0.0;
+  for (int64_t n = blockIdx.x; n < batch; n += gridDim.x) {
+    const T* src = in + n * in_n;
+    T* dst = out ? out + n * out_n : nullptr;
+    double lsum = 0.0;                                   // this thread's share of the sample's log-det
+    if (!INV) {
+      // lower factor L of X (X = L L'), A[c*K + r] = L[r, c], r >= c.  Correlation kinds read the UPPER triangle of X
+      // (cholesky(Hermitian(X)).U, src/utils.jl:50: a(r, c) = X[c, r] = src[r*K + c]), PD kinds the LOWER one (:37).
+      for (int64_t e = t; e < KK; e += 256) {
+        const int c = (int)(e / K), r = (int)(e - (int64_t)c * K);
+        A[e] = r >= c ? (CORR ? src[(int64_t)r * K + c] : src[e]) : T(0);
+      }
+      __syncthreads();
+      for (int j = 0; j < K; ++j) {
+        if (t == 0) A[(int64_t)j * K + j] = (T)::sqrt((double)A[(int64_t)j * K + j]);
+        __syncthreads();
+        const T d = A[(int64_t)j * K + j];
+        for (int r = j + 1 + t; r < K; r += 256) A[(int64_t)j * K + r] = A[(int64_t)j * K + r] / d;
+        __syncthreads();
+        for (int c = j + 1 + (t >> 6); c < K; c += 4) {
+          const T lc = A[(int64_t)j * K + c];
+          for (int r = c + (t & 63); r < K; r += 64) A[(int64_t)c * K + r] -= A[(int64_t)j * K + r] * lc;
+        }
+        __syncthreads();
+      }
+      if (CORR) {
+        // U = L' (U[i, j] = A[i*K + j], i <= j).  Column j of U, bottom-up (corr.jl:282-288 / :314-337); forward log-det =
+        // sum (K - i + 1) logcosh(y_ij) over the strict upper triangle (negated :453-472), i 1-based
+        for (int j = 1 + t; j < K; j += 256) {           // 0-based column j has j entries above the diagonal
+          T rem, Lg;
+          LM::fwd_init(A[(int64_t)j * K + j], rem, Lg);
+          for (int i = j - 1; i >= 0; --i) {
+            const T w = A[(int64_t)i * K + j];
+            T y, lc;
+            if (KIND == MK_VEC_CORR && i == 0) LM::atanh_lc(w, y, lc);      // :319: the top entry is atanh(W[1, j])
+            else LM::fwd_step(w, rem, Lg, y, lc);
+            lsum += (double)(T(K - i) * lc);
+            if (dst) {
+              if (KIND == MK_VEC_CORR) dst[(int64_t)j * (j - 1) / 2 + i] = y;
+              else dst[(int64_t)j * K + i] = y;
+            }
+          }
+        }
+        if (KIND == MK_CORR && dst)                      // zeros on and below the diagonal (:292-294)
+          for (int64_t e = t; e < KK; e += 256) { const int c = (int)(e / K), r = (int)(e - (int64_t)c * K); if (r >= c) dst[e] = T(0); }
+      } else {
+        // pd.jl:11, :27-31: Y = L with log on the diagonal; log-det = -(sum (K + 2 - i) log L_ii + K log 2), i 1-based
+        for (int i = t; i < K; i += 256) lsum -= (double)(T(K + 1 - i) * LM::log(A[(int64_t)i * K + i]));
+        if (t == 0) lsum -= (double)(T(K) * Num<T>::log2);
+        if (dst) {
+          if (KIND == MK_PD) {
+            for (int64_t e = t; e < KK; e += 256) {
+              const int c = (int)(e / K), r = (int)(e - (int64_t)c * K);
+              dst[e] = r > c ? A[e] : (r == c ? LM::log(A[e]) : T(0));
+            }
+          } else {                                       // triu_to_vec(transpose(Y)): entry (i, j), i <= j, is Y[j, i] = L[j, i] = A[i*K + j]
+            for (int64_t e = t; e < nv; e += 256) {
+              int j = (int)((::sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+              while ((int64_t)(j + 1) * (j + 2) / 2 <= e) ++j;
+              while ((int64_t)j * (j + 1) / 2 > e) --j;
+              const int i = (int)(e - (int64_t)j * (j + 1) / 2);
+              const T v = A[(int64_t)i * K + j];
+              dst[e] = i == j ? LM::log(v) : v;
+            }
+          }
+        }
+      }
+    } else if (CORR) {
+      // corr.jl:345-399: column j of U top-down from the free values, logJ of the link, + (K - j) log U[j, j] for j = 2 … K-1
+      // (:77-79, :144-146); A[j*K + i] = U[i, j]
+      for (int64_t e = t; e < KK; e += 256) A[e] = T(0);
+      __syncthreads();
+      for (int j = t; j < K; j += 256) {
+        T E;
+        LM::inv_init(E);
+        double lr = 0.0, lj = 0.0;                       // log_remainder and this column's share of logJ
+        for (int i = 0; i < j; ++i) {
+          const T yv = KIND == MK_VEC_CORR ? src[(int64_t)j * (j - 1) / 2 + i] : src[(int64_t)j * K + i];
+          T w, lc;
+          LM::inv_step(yv, E, w, lc);
+          A[(int64_t)j * K + i] = w;
+          lr -= (double)lc;
+          lj += lr;
+        }
+        lj += lr;
+        A[(int64_t)j * K + j] = LM::inv_diag(E, (T)lr);
+        if (j >= 1 && j <= K - 2) lj += (double)(K - 1 - j) * lr;      // (K - j) log U[j, j], j 1-based in 2 … K-1; log U[j, j] = log_remainder
+        lsum += lj;
+      }
+      __syncthreads();
+      if (dst)                                           // pd_from_upper: X = U'U
+        for (int64_t e = t; e < KK; e += 256) {
+          const int c = (int)(e / K), r = (int)(e - (int64_t)c * K);
+          const int m1 = r < c ? r : c;
+          T s = T(0);
+          for (int m = 0; m <= m1; ++m) s += A[(int64_t)r * K + m] * A[(int64_t)c * K + m];
+          dst[e] = s;
+        }
+    } else {
+      // pd.jl:13-16: L = lower_triangular(replace_diag(exp, Y)); X = L L'; log-det = +(sum (K + 2 - i) Y_ii + K log 2)
+      for (int64_t e = t; e < KK; e += 256) {
+        const int c = (int)(e / K), r = (int)(e - (int64_t)c * K);
+        T v = T(0);
+        if (r >= c) v = KIND == MK_PD ? src[e] : src[(int64_t)r * (r + 1) / 2 + c];    // vec: entry (c, r) of triu_to_vec(Y') is Y[r, c]
+        if (r == c) { lsum += (double)(T(K + 1 - r) * v); v = LM::exp(v); }
+        A[e] = v;
+      }
+      if (t == 0) lsum += (double)(T(K) * Num<T>::log2);
+      __syncthreads();
+      if (dst)
+        for (int64_t e = t; e < KK; e += 256) {
+          const int c = (int)(e / K), r = (int)(e - (int64_t)c * K);
+          const int m1 = r < c ? r : c;
+          T s = T(0);
+          for (int m = 0; m <= m1; ++m) s += A[(int64_t)m * K + r] * A[(int64_t)m * K + c];
+          dst[e] = s;
+        }
+    }
+    // the sample's log-det: fixed-order sum of the 256 per-thread shares
+    colsum[t] = lsum;
+    __syncthreads();
+    if (t == 0) {
+      double s = 0.0;
+      for (int k = 0; k < 256; ++k) s += colsum[k];
+      if (ladj_ps) ladj_ps[n] = accumulate ? ladj_ps[n] + (T)s : (T)s;
+      acc += s;
+    }
+    __syncthreads();                                     // A and colsum are reused by the next sample
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
+template <class T, int KIND>
+int matrix_big(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags) {
+  BJX_REQUIRE(ctx, K <= 4096, BJX_ERR_UNSUPPORTED, "K = %lld: beyond the general-size kernel's index range", (long long)K);
+  int64_t grid = batch < 2 * (int64_t)ctx->num_cu ? batch : 2 * (int64_t)ctx->num_cu;
+  while (grid > 1 && (size_t)grid * K * K * sizeof(T) > ((size_t)1 << 31)) grid >>= 1;      // workspace <= 2 GiB
+  { int rc = bjx_ensure_big_ws(ctx, (size_t)grid * K * K * sizeof(T)); if (rc) return rc; }
+  if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
+  double* partials = ladj_sum ? ctx->partials : nullptr;
+  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  {
+    BjxProf prof_(ctx);
+    if (inverse) hipLaunchKernelGGL((matrix_big_kernel<T, KIND, true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out, ladj_ps, (T*)ctx->big_ws, (int)K, batch, accum, partials);
+    else hipLaunchKernelGGL((matrix_big_kernel<T, KIND, false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out, ladj_ps, (T*)ctx->big_ws, (int)K, batch, accum, partials);
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+  return BJX_OK;
+}
+
 template <class T, int KIND>
 int matrix_impl(bjx_ctx* ctx, const char* who, int inverse, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags) {
   if (batch == 0) {
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
     return BJX_OK;
   }
-  BJX_REQUIRE(ctx, K <= 64, BJX_ERR_UNSUPPORTED, "%s: K = %lld; the register-resident Cholesky kernel takes K <= 64", who, (long long)K);
+  if (K > 64) return matrix_big<T, KIND>(ctx, inverse, in, out, ladj_ps, ladj_sum, K, batch, flags);   // beyond the register-resident kernels
   constexpr int VW = Vec16<T>::N;
   const int64_t KK = K * K;
   const int64_t nv = KIND == MK_VEC_CORR ? K * (K - 1) / 2 : (KIND == MK_PD_VEC ? K * (K + 1) / 2 : KK);
@@ -872,10 +1042,55 @@ __global__ void scale_matrix_sum_kernel(const double* logabsdet, double mult, do
   *out = accumulate ? *out + v : v;
 }
 
+// Any dim (round 3; scale.jl:14-17 has no limit): Y = M X with M read from global memory (L2-resident), one thread per output
+// entry and a plain inner product — the correct-first path behind the LDS / MFMA kernels, which stop at 128 rows.
+template <class T>
+__global__ __launch_bounds__(256) void scale_matrix_big_kernel(const T* __restrict__ M, int ldm_row_major, const T* __restrict__ X, T* __restrict__ Y,
+                                                               T* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate, const double* logabsdet) {
+  const int64_t total = (int64_t)dim * batch;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t n = e / dim;
+    const int i = (int)(e - n * dim);
+    if (Y) {
+      const T* x = X + n * dim;
+      T s = T(0);
+      if (ldm_row_major) for (int k = 0; k < dim; ++k) s += M[(size_t)i * ldm_row_major + k] * x[k];
+      else for (int k = 0; k < dim; ++k) s += M[(size_t)k * dim + i] * x[k];
+      Y[e] = s;
+    }
+    if (ladj_ps && i == 0) ladj_ps[n] = accumulate ? ladj_ps[n] + (T)*logabsdet : (T)*logabsdet;
+  }
+}
+
 template <class T>
 int scale_matrix_impl(bjx_ctx* ctx, int inverse, const T* a, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
-  BJX_REQUIRE(ctx, dim <= 128, BJX_ERR_UNSUPPORTED, "bjx_scale_matrix: dim = %lld; the LDS-resident matrix kernel takes dim <= 128", (long long)dim);
-  BJX_REQUIRE(ctx, (size_t)dim * 2 * dim * sizeof(T) <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_scale_matrix: dim too large for the context scratch");
+  if (dim > 128 || (size_t)dim * 2 * dim * sizeof(T) > BJX_SCRATCH_BYTES) {
+    BJX_REQUIRE(ctx, dim <= 8192, BJX_ERR_UNSUPPORTED, "bjx_scale_matrix: dim = %lld: beyond the general-size kernel's range", (long long)dim);
+    { int rc = bjx_ensure_big_ws(ctx, (size_t)dim * 2 * dim * sizeof(T)); if (rc) return rc; }
+    T* Wb = reinterpret_cast<T*>(ctx->big_ws);
+    double* ladb = ctx->consts + 2;
+    const int want = (ladj_ps || ladj_sum) ? 1 : 0;
+    const int accb = (flags & BJX_ACCUMULATE) ? 1 : 0;
+    if (inverse || want) {
+      hipLaunchKernelGGL((scale_matrix_prep_kernel<T>), dim3(1), dim3(256), 0, ctx->stream, a, Wb, (int)dim, inverse ? 1 : 0, ladb);
+      BJX_CHECK_LAUNCH(ctx);
+      if (inverse && want) hipLaunchKernelGGL(scale_matrix_sum_kernel, dim3(1), dim3(1), 0, ctx->stream, ladb, -1.0, ladb, 0);
+    }
+    if (batch > 0 && (out || ladj_ps)) {
+      const int64_t need = (dim * batch + 255) / 256;
+      const int64_t capb = (int64_t)ctx->num_cu * 16;
+      BjxProf prof_(ctx);
+      hipLaunchKernelGGL((scale_matrix_big_kernel<T>), dim3((unsigned)(need < capb ? need : capb)), dim3(256), 0, ctx->stream,
+                         inverse ? Wb + dim : a, inverse ? (int)(2 * dim) : 0, in, out, ladj_ps, (int)dim, batch, accb, ladb);
+      BJX_CHECK_LAUNCH(ctx);
+    }
+    if (ladj_sum) {
+      const double mult = (flags & BJX_REF_VECTOR_SCALE_LADJ) ? 1.0 : (double)batch;
+      hipLaunchKernelGGL(scale_matrix_sum_kernel, dim3(1), dim3(1), 0, ctx->stream, ladb, mult, ladj_sum, accb);
+      BJX_CHECK_LAUNCH(ctx);
+    }
+    return BJX_OK;
+  }
   T* W = reinterpret_cast<T*>(ctx->scratch);
   double* lad = ctx->consts + 2;
   const int want_ladj = (ladj_ps || ladj_sum) ? 1 : 0;

@@ -127,6 +127,147 @@ __global__ __launch_bounds__(64) void seq_wave_kernel(Op op0, const T* __restric
   block_publish_partial(lane < ncols ? (double)lres : 0.0, red, fin);
 }
 
+// Chunked wave walker (round 3): ANY column height at a constant 16.6 KiB of LDS per wave.  seq_wave_kernel keeps whole
+// columns in its tile — 64 x (rows | 1) words: 25 KiB at 100 rows (6 waves per CU, 49 % of the HBM peak), 51 KiB at 200 (3 waves,
+// 31 %), nothing beyond 255 rows (seq_kernel: 256-column blocks, three barriers per 32 rows, 33 %).  Here one wave still owns 64
+// columns and a lane still walks ONE column top to bottom in the reference's order, but the tile holds a CHUNK of C = 64 (Float32)
+// / 32 (Float64) rows: load chunk -> walk (the op's running state stays in the lane's registers from chunk to chunk) -> store
+// chunk.  Chunk loads are 64 runs of C rows, one per column: with whole-pack column strides 16 lanes move one run as 16-byte
+// packs (4 columns per instruction), otherwise the 64 lanes of an instruction move one run of 64 consecutive rows with 4-byte
+// accesses — 256 contiguous bytes either way, the full TA rate.  Nine waves per CU, no block barrier, any leading dimension.
+template <class T, class Op, int V, bool TABLE>
+__global__ __launch_bounds__(64) void seq_chunk_kernel(Op op0, const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps,
+                                                       int64_t rows_in, int64_t rows_out, int64_t batch, int n_logk, int accumulate,
+                                                       double* __restrict__ partials, int64_t ld_in, int64_t ld_out) {
+  constexpr int C = 256 / (int)sizeof(T), P = C + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[1];
+  T* tile = reinterpret_cast<T*>(smem);
+  T* logk = tile + (size_t)64 * P;
+  const int lane = threadIdx.x;
+  if (TABLE) for (int i = lane; i < n_logk; i += 64) logk[i] = d_log(T(n_logk - i));      // log(K-1-i), simplex.jl:35,41
+  else if (lane == 0) logk[0] = d_log(T(n_logk > 0 ? n_logk : 1));                        // op.first reads entry 0
+  const int64_t col0 = (int64_t)blockIdx.x * 64;
+  const int ncols = (int)((batch - col0) < 64 ? (batch - col0) : 64);
+  const int64_t rows = rows_in > rows_out ? rows_in : rows_out;
+  const T* src = in + col0 * ld_in;
+  T* dst = out ? out + col0 * ld_out : nullptr;
+  Op op = op0;
+  op.init();
+  constexpr int LPR = C / V;                  // lanes per run (V > 1): C rows of one column as 16-byte packs
+  constexpr int CPI = 64 / LPR;               // columns per instruction
+  for (int64_t c0 = 0; c0 < rows; c0 += C) {
+    const int nr = (int)((rows - c0) < C ? (rows - c0) : C);
+    tile_sync();                              // the previous chunk's stores have read the tile
+    // ---- load rows [c0, c0 + nr) of the 64 columns (rows >= rows_in do not exist: zero)
+    if constexpr (V > 1) {
+      const int lr = (lane % LPR) * V, lc = lane / LPR;
+#pragma unroll 4
+      for (int cb = 0; cb < 64; cb += CPI) {
+        const int c = cb + lc;
+        Pack<T, V> p;
+#pragma unroll
+        for (int j = 0; j < V; ++j) p.v[j] = T(0);
+        if (c < ncols && c0 + lr + V <= rows_in) p = load_pack<T, V, true>(src + (int64_t)c * ld_in + c0 + lr);
+        else if (c < ncols) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) if (c0 + lr + j < rows_in) p.v[j] = src[(int64_t)c * ld_in + c0 + lr + j];
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) tile[c * P + lr + j] = p.v[j];
+      }
+    } else {
+#pragma unroll 8
+      for (int c = 0; c < 64; ++c) {
+        T v = T(0);
+        if (c < ncols && lane < nr && c0 + lane < rows_in) v = __builtin_nontemporal_load(src + (int64_t)c * ld_in + c0 + lane);
+        if (lane < C) tile[c * P + lane] = v;
+      }
+    }
+    tile_sync();
+    // ---- walk: lane = column, ascending rows (the reference's order)
+    if (lane < ncols) {
+      T* mine = tile + lane * P;
+      int i = 0;
+      if (c0 == 0) { mine[0] = op.first(mine[0], logk); i = 1; }
+      const int64_t mid_end64 = (Op::HAS_LAST && rows > 1) ? rows - 1 : rows;            // interior rows are [1, mid_end)
+      const int mid_end = (int)((mid_end64 - c0) < nr ? (mid_end64 - c0) : nr);
+      for (; i + 4 <= mid_end; i += 4) {
+        T v[4], lk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = mine[i + j];
+          lk[j] = !Op::USES_LOGK ? T(0) : (TABLE ? logk[c0 + i + j] : d_log(T(n_logk - (c0 + i + j))));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = op.mid((int)(c0 + i + j), v[j], lk[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mine[i + j] = v[j];
+      }
+      for (; i < mid_end; ++i) mine[i] = op.mid((int)(c0 + i), mine[i], !Op::USES_LOGK ? T(0) : (TABLE ? logk[c0 + i] : d_log(T(n_logk - (c0 + i)))));
+      if (Op::HAS_LAST && rows > 1 && c0 + nr == rows) mine[nr - 1] = op.last(mine[nr - 1]);
+    }
+    tile_sync();
+    // ---- store rows [c0, c0 + nr) that exist in the output
+    if (dst) {
+      if constexpr (V > 1) {
+        const int lr = (lane % LPR) * V, lc = lane / LPR;
+#pragma unroll 4
+        for (int cb = 0; cb < 64; cb += CPI) {
+          const int c = cb + lc;
+          Pack<T, V> p;
+#pragma unroll
+          for (int j = 0; j < V; ++j) p.v[j] = tile[c * P + lr + j];
+          if (c < ncols && c0 + lr + V <= rows_out) store_pack<T, V, true>(dst + (int64_t)c * ld_out + c0 + lr, p);
+          else if (c < ncols) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) if (c0 + lr + j < rows_out) dst[(int64_t)c * ld_out + c0 + lr + j] = p.v[j];
+          }
+        }
+      } else {
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) {
+          if (lane < C) {
+            const T v = tile[c * P + lane];
+            if (c < ncols && lane < nr && c0 + lane < rows_out) __builtin_nontemporal_store(v, dst + (int64_t)c * ld_out + c0 + lane);
+          }
+        }
+      }
+    }
+  }
+  T lres = T(0);
+  if (lane < ncols) {
+    lres = op.result();
+    if (ladj_ps) ladj_ps[col0 + lane] = accumulate ? ladj_ps[col0 + lane] + lres : lres;
+  }
+  if (partials) block_publish_partial(lane < ncols ? (double)lres : 0.0, red, partials);
+}
+
+template <class T, class Op>
+int launch_seq_chunk(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t rows_in, int64_t rows_out,
+                     int64_t batch, int n_logk, uint32_t flags, int64_t ld_in, int64_t ld_out) {
+  constexpr int C = 256 / (int)sizeof(T), VW = Vec16<T>::N;
+  const bool table = (size_t)n_logk * sizeof(T) <= 40 * 1024;                  // taller: log(K-1-i) on the fly
+  const size_t smem = ((size_t)64 * (C + 1) + (table ? (size_t)n_logk : 1)) * sizeof(T);
+  const int64_t grid = (batch + 63) / 64;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+  if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
+  double* partials = ladj_sum ? ctx->partials : nullptr;
+  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  // 16-byte packs need every run to start on a 16-byte boundary: whole-pack column strides and aligned bases
+  const bool v_ok = bjx_aligned16(in) && (!out || bjx_aligned16(out)) && ld_in % VW == 0 && ld_out % VW == 0;
+  {
+    BjxProf prof_(ctx);
+#define SCK(V_, TB_) hipLaunchKernelGGL((seq_chunk_kernel<T, Op, V_, TB_>), dim3((unsigned)grid), dim3(64), smem, ctx->stream, op, in, out, ladj_ps, rows_in, rows_out, batch, n_logk, accum, partials, ld_in, ld_out)
+    if (v_ok) { if (table) SCK(VW, true); else SCK(VW, false); }
+    else { if (table) SCK(1, true); else SCK(1, false); }
+#undef SCK
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+  return BJX_OK;
+}
+
 template <class T, class Op>
 int launch_seq(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t rows_in, int64_t rows_out,
                int64_t batch, int n_logk, uint32_t flags, int64_t ld_in = 0, int64_t ld_out = 0) {
@@ -143,6 +284,10 @@ int launch_seq(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, doub
     const int64_t P = rows | 1;
     const size_t smem_w = ((size_t)64 * P + (size_t)n_logk) * sizeof(T);
     static const int use_wave = getenv("BJX_SEQ_WAVE") ? atoi(getenv("BJX_SEQ_WAVE")) : 1;
+    // whole-column tiles up to `chunk_min` bytes (tuning switch for the same-box A/B): beyond, the chunked walker keeps 9 waves per CU
+    static const long chunk_min = getenv("BJX_SEQ_CHUNK_MIN") ? atol(getenv("BJX_SEQ_CHUNK_MIN")) : 20 * 1024;
+    if (smem_w > (size_t)chunk_min && rows_in >= 1 && rows_out >= 1)
+      return launch_seq_chunk<T, Op>(ctx, op, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, n_logk, flags, ld_in, ld_out);
     if (use_wave && smem_w <= 64 * 1024 && rows_in >= 1 && rows_out >= 1) {   // larger columns: the chunked block kernel below
       const int64_t grid = (batch + 63) / 64;
       BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
@@ -1493,6 +1638,145 @@ __global__ __launch_bounds__(64) void simplex_vjp_kernel(const T* __restrict__ i
   tile_stage_out<T, V>(tb, in_bar + col0 * rows_in, rows_in, P, ncols, lane);
 }
 
+// Chunked form of simplex_vjp_kernel for TALL columns (round 3).  The whole-column kernel above needs two [C][K|1] tiles per
+// wave and halves its working lanes until they fit: 28 % of the HBM peak at K = 100, 11 % at 200, 6 % at 500.  Here a wave keeps
+// its 64 columns and two CHUNK tiles of CH rows (17 KiB, nine waves per CU) and makes two passes over the column:
+//   forward map  (in = x):  pass 1 ascending: s = Σ_{j<K-1} x_j;   pass 2 descending: the reverse sweep, chunk by chunk;
+//   inverse map  (in = y):  pass 1 ascending: the recurrence x_k = clamp(…) — x_k parked in in_bar (same shape as y) — and s;
+//                           pass 2 descending: reads x_k back, sweeps, overwrites in_bar with ȳ.
+// The running values (s, the adjoint of s) stay in the lane's registers across chunks.  One extra read of the primal
+// (forward) / one extra write + read of x (inverse) against the single-pass kernel: 4/3 and 5/3 of the algorithmic bytes.
+template <class T, int CH>
+__device__ __forceinline__ void vchunk_load(T* tile, const T* __restrict__ src, int64_t ld, int64_t c0, int64_t rows_lim, int ncols, int lane) {
+  constexpr int P = CH + 1, CPI = 64 / CH;
+  const int r = lane % CH, cc = lane / CH;
+#pragma unroll 8
+  for (int cb = 0; cb < 64; cb += CPI) {
+    const int c = cb + cc;
+    T v = T(0);
+    if (c < ncols && c0 + r < rows_lim) v = src[(int64_t)c * ld + c0 + r];
+    tile[c * P + r] = v;
+  }
+}
+template <class T, int CH>
+__device__ __forceinline__ void vchunk_store(const T* tile, T* __restrict__ dst, int64_t ld, int64_t c0, int64_t rows_lim, int ncols, int lane) {
+  constexpr int P = CH + 1, CPI = 64 / CH;
+  const int r = lane % CH, cc = lane / CH;
+#pragma unroll 8
+  for (int cb = 0; cb < 64; cb += CPI) {
+    const int c = cb + cc;
+    const T v = tile[c * P + r];
+    if (c < ncols && c0 + r < rows_lim) dst[(int64_t)c * ld + c0 + r] = v;
+  }
+}
+template <class T, bool INV, bool TABLE>
+__global__ __launch_bounds__(64) void simplex_vjp_chunk_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
+                                                               T* __restrict__ in_bar, int K, int64_t batch) {
+  using F = Fast<T>;
+  constexpr int CH = 128 / (int)sizeof(T), P = CH + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* ta = reinterpret_cast<T*>(smem);
+  T* tb = ta + (size_t)64 * P;
+  T* logk = tb + (size_t)64 * P;
+  const int lane = threadIdx.x;
+  if (TABLE) for (int i = lane; i < K - 1; i += 64) logk[i] = d_log(T(K - 1 - i));
+  auto lk = [&](int k) -> T { return TABLE ? logk[k] : d_log(T(K - 1 - k)); };
+  const int rows_in = INV ? K - 1 : K, rows_g = INV ? K : K - 1;
+  const int64_t col0 = (int64_t)blockIdx.x * 64;
+  const int ncols = (int)((batch - col0) < 64 ? (batch - col0) : 64);
+  const T* src = in + col0 * rows_in;
+  const T* gsrc = out_bar + col0 * rows_g;
+  T* dst = in_bar + col0 * rows_in;
+  const T e = Num<T>::eps;
+  const T c = T(1) / (T(1) - 2 * e), E = T(1) + e, c2 = T(1) - 2 * e;
+  const T lb = (ladj_bar && lane < ncols) ? ladj_bar[col0 + lane] : T(0);
+  T* a = ta + lane * P;
+  T* g = tb + lane * P;
+  // ---- pass 1 (ascending)
+  T s = T(0);
+  T s4[4] = {T(0), T(0), T(0), T(0)};
+  for (int c0 = 0; c0 < K - 1; c0 += CH) {
+    const int nr = (K - 1 - c0) < CH ? (K - 1 - c0) : CH;
+    tile_sync();
+    vchunk_load<T, CH>(ta, src, rows_in, c0, K - 1, ncols, lane);
+    tile_sync();
+    if (lane < ncols) {
+      if (!INV) {
+        for (int i = 0; i < nr; ++i) s4[(c0 + i) & 3] += a[i];        // the whole-column kernel's four interleaved sums
+      } else {
+        for (int i = 0; i < nr; ++i) {
+          const int k = c0 + i;
+          const T z = f_logistic(a[i] - lk(k));
+          const T xk = k == 0 ? d_clamp((z - e) * c, T(0), T(1)) : d_clamp((E - s) * c * z - e, T(0), T(1));
+          a[i] = xk;
+          s += xk;
+        }
+      }
+    }
+    if (INV) { tile_sync(); vchunk_store<T, CH>(ta, dst, rows_in, c0, K - 1, ncols, lane); }    // x_k parked in in_bar
+  }
+  if (!INV) s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  if (INV) __threadfence_block();                                        // the parked x_k are read back below
+  // ---- pass 2 (descending): rows K-1 … 0 of the cotangent, K-2 … 0 of the primal
+  T sb = T(0);
+  bool top = true;
+  const int nchunks = (K + CH - 1) / CH;                                  // chunks over K rows (the longer of the two sides)
+  for (int ci = nchunks - 1; ci >= 0; --ci) {
+    const int c0 = ci * CH;
+    tile_sync();
+    vchunk_load<T, CH>(ta, INV ? (const T*)dst : src, rows_in, c0, K - 1, ncols, lane);     // x_k, k <= K-2
+    vchunk_load<T, CH>(tb, gsrc, rows_g, c0, rows_g, ncols, lane);
+    tile_sync();
+    if (lane < ncols) {
+      int khi = (c0 + CH < K ? c0 + CH : K) - 1;                          // highest row of this chunk (<= K-1)
+      if (top) {
+        if (INV) { const T last = T(1) - s; sb = (last > T(0) && last < T(1)) ? -g[K - 1 - c0] : T(0); }
+        else if (K - 1 - c0 < CH) g[K - 1 - c0] = T(0);                   // row K enters neither y nor the log-det (forward map: rows_in = K)
+        top = false;
+      }
+      if (khi > K - 2) khi = K - 2;
+#pragma unroll 2
+      for (int k = khi; k >= c0; --k) {
+        const int i = k - c0;
+        const T xk = a[i];
+        const T sk = s - xk;
+        T dtdx, dtds;
+        simplex_t_partials<T>(xk, sk, k == 0, dtdx, dtds);
+        if (INV) {
+          const T xb = g[i] + sb + lb * dtdx;
+          sb += lb * dtds;
+          const T ub = (xk > T(0) && xk < T(1)) ? xb : T(0);
+          T zb, z;
+          if (k == 0) { zb = ub * c; z = xk * c2 + e; }
+          else { const T rc = (E - sk) * c; zb = ub * rc; z = (xk + e) * F::rcp(rc); sb -= ub * c * z; }
+          g[i] = zb * z * (T(1) - z);
+        } else {
+          const T gy = g[i];
+          T xb = sb, sn = sb;
+          if (k == 0) {
+            const T zf = xk * c2 + e;
+            xb += gy * F::rcp(zf * (T(1) - zf)) * c2;
+          } else {
+            const T rd = F::rcp(E - sk);
+            const T an = (xk + e) * c2;
+            const T zf = an * rd;
+            const T zfb = gy * F::rcp(zf * (T(1) - zf));
+            xb += zfb * c2 * rd;
+            sn += zfb * an * rd * rd;
+          }
+          xb -= lb * dtdx;
+          sn -= lb * dtds;
+          g[i] = xb;
+          sb = sn;
+        }
+        s = sk;
+      }
+    }
+    tile_sync();
+    vchunk_store<T, CH>(tb, dst, rows_in, c0, rows_in, ncols, lane);
+  }
+}
+
 template <class T, int G>
 int launch_simplex_vjp_stream(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch, bool* taken);
 
@@ -1510,6 +1794,25 @@ int simplex_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, c
       rc = launch_simplex_vjp_stream<T, 4>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch, &taken);
       if (rc || taken) return rc;
     }
+  }
+  // tall columns: the chunked two-pass kernel (two whole-column tiles of 64 columns cost 2·64·K words: beyond `chunk_min` bytes
+  // the whole-column kernel runs with too few waves, then with too few lanes)
+  static const long vjp_chunk_min = getenv("BJX_SIMPLEX_VJP_CHUNK_MIN") ? atol(getenv("BJX_SIMPLEX_VJP_CHUNK_MIN")) : 40 * 1024;
+  if (((size_t)2 * 64 * (K | 1) + (size_t)K) * sizeof(T) > (size_t)vjp_chunk_min) {
+    constexpr int CH = 128 / (int)sizeof(T);
+    const bool table = (size_t)K * sizeof(T) <= 40 * 1024;
+    const size_t smem_c = ((size_t)2 * 64 * (CH + 1) + (table ? (size_t)K : 1)) * sizeof(T);
+    const int64_t grid_c = (batch + 63) / 64;
+    BJX_REQUIRE(ctx, grid_c < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+    {
+      BjxProf prof_(ctx);
+#define SVC(I_, TB_) hipLaunchKernelGGL((simplex_vjp_chunk_kernel<T, I_, TB_>), dim3((unsigned)grid_c), dim3(64), smem_c, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)K, batch)
+      if (inverse) { if (table) SVC(true, true); else SVC(true, false); }
+      else { if (table) SVC(false, true); else SVC(false, false); }
+#undef SVC
+    }
+    BJX_CHECK_LAUNCH(ctx);
+    return BJX_OK;
   }
   const int64_t P = K | 1;
   int C = 64;

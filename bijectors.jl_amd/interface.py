@@ -1097,7 +1097,11 @@ class InvertibleBatchNorm(Bijector):
     `with bj.training():` the batch statistics are used and `m`, `v` are updated in place (:51-60) — the
     struct is mutable in the reference too."""
 
-    def __init__(self, chs_or_b, logs=None, m=None, v=None, eps=1e-5, mtm=0.1, dtype=torch.float32):
+    def __init__(self, chs_or_b, logs=None, m=None, v=None, eps=1e-5, mtm=0.1, dtype=torch.float32, sync=None):
+        # sync: None -> the statistics of THIS process's batch (the reference's behaviour); True -> the batch is sharded over the
+        # default torch.distributed group; a ProcessGroup -> over that group.  Every rank of the group must then call the
+        # bijector in lockstep (one all-reduce of 2·dim+1 Float64 sums per training-mode call, SURVEY.md §8e).
+        self.sync = sync
         if isinstance(chs_or_b, int):  # normalise.jl:26-37
             c = chs_or_b
             self.b, self.logs = torch.zeros(c, dtype=dtype), torch.zeros(c, dtype=dtype)
@@ -1128,9 +1132,10 @@ class InvertibleBatchNorm(Bijector):
             # statistics of this rank's columns -> ONE sum all-reduce of 2·dim+1 Float64 values when the batch is sharded
             # (SURVEY.md §8e "Exception"; torch.distributed or the library's communicator) -> update + transform
             stats = self.batch_stats(x)
-            from . import shard as _shard
+            if self.sync is not None and self.sync is not False:
+                from . import shard as _shard
 
-            _shard.allreduce_logabsdetjac(stats)
+                _shard.allreduce_logabsdetjac(stats, None if self.sync is True else self.sync)
             return self.apply_batch_stats(x, stats, per_sample, want_ladj)
         ps = [_param(t, x) for t in (self.b, self.logs, self.m, self.v)]
         return _call_struct("bjx_batchnorm", x, dim, True, per_sample, want_ladj,
@@ -1328,13 +1333,26 @@ class Coupling(Bijector):
             if isinstance(law, RationalQuadraticSpline):
                 # spline law (coupling.jl:206-259 with b = RationalQuadraticSpline(w, h, d), knots shared by the batch):
                 # x̄₁ = the elementwise spline pullback on the x₁ rows (bjx_rqs_vjp), every other row passes ȳ through.
-                # (Knot cotangents are not produced, so nothing flows back through θ.)
+                # When θ builds the knots from x₂ with torch operations (the neural-spline coupling), the knot cotangents of
+                # the same pass (bjx_rqs_vjp_knots) go back through θ by torch.autograd and land on the x₂ rows — as the
+                # affine branch below does with (s̄, t̄).
                 i1 = self.mask.idx1_dev(xc.device).long()
                 x1 = colmajor(xc[i1] if not vec else xc[i1])
                 g1 = colmajor(gc[i1])
-                sub = vjp(inverse(law) if inv else law, x1, g1, ladj_bar)
+                knots = [t for t in (law.widths, law.heights, law.derivatives)]
+                through_theta = any(isinstance(t, torch.Tensor) and t.requires_grad for t in knots)
                 xb = gc.clone() if vec else colmajor(gc.clone())
+                if not through_theta:
+                    xb[i1] = vjp(inverse(law) if inv else law, x1, g1, ladj_bar)
+                    return xb
+                plain = RationalQuadraticSpline(*[t.detach() for t in knots])
+                sub, kb = _vjp_params_rqs(inverse(plain) if inv else plain, x1, g1, ladj_bar)
                 xb[i1] = sub
+                outs = [t for t in knots if t.requires_grad]
+                cots = [kb[n].reshape(t.shape).to(t.dtype) for n, t in zip(("widths", "heights", "derivatives"), knots) if t.requires_grad]
+                g2, = torch.autograd.grad(outs, [x2], cots, allow_unused=True)
+                if g2 is not None:
+                    xb[i2] += g2
                 return xb
             scale = shift = None
             for st in (law._stages() if isinstance(law, ComposedFunction) else [law]):
@@ -1722,7 +1740,12 @@ class NamedStacked(Transform):
         like = next((v for v in x.values() if isinstance(v, torch.Tensor) and v.is_cuda), None)
         if like is None:
             raise RuntimeError("bijectors_amd operates on ROCm device tensors only (no CPU fallback): at least one field must be a device tensor")
-        batched = any(isinstance(v, torch.Tensor) and v.dim() == 2 for v in x.values())
+        # the batch size comes from the 2-D fields (all of them must agree), never from an unbatched 1-D field
+        widths = {int(v.shape[1]) for v in x.values() if isinstance(v, torch.Tensor) and v.dim() == 2}
+        if len(widths) > 1:
+            raise ValueError(f"DimensionMismatch: fields with different batch sizes {sorted(widths)}")
+        batched = bool(widths)
+        nb = widths.pop() if widths else 1
         pieces = []
         for n in self.names:
             v = x[n]
@@ -1730,8 +1753,13 @@ class NamedStacked(Transform):
             t = t.to(device=like.device, dtype=like.dtype)
             if t.dim() == 0:
                 t = t.reshape(1)
-            if batched and t.dim() == 1:                                                 # a scalar field holds one value per column
-                t = t[None, :] if n in self._int_fields and t.shape[0] != 1 else t[:, None].expand(t.shape[0], like.shape[-1])
+            if batched and t.dim() == 1:
+                if n in self._int_fields and t.shape[0] != 1:                            # a scalar field holds one value per column
+                    if t.shape[0] != nb:
+                        raise ValueError(f"DimensionMismatch: scalar field {n!r} has {t.shape[0]} values for a batch of {nb}")
+                    t = t[None, :]
+                else:                                                                    # an unbatched vector field: the same for every column
+                    t = t[:, None].expand(t.shape[0], nb)
             pieces.append(t)
         cat = torch.cat(pieces, dim=0)
         return colmajor(cat) if batched else cat.contiguous()

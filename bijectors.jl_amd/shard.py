@@ -28,6 +28,13 @@ def use_library_collective(on: bool = True) -> None:
     _LIBRARY_COLLECTIVE[0] = bool(on)
 
 
+def _is_world(group) -> bool:
+    """True when `group` is the default (world) group — the set of ranks the library's own communicator (init_comm) spans."""
+    import torch.distributed as dist
+
+    return group is None or group is dist.group.WORLD
+
+
 def allreduce_logabsdetjac(partial: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum all-reduce of the per-rank float64 partial log-det sum."""
     import torch.distributed as dist
@@ -35,8 +42,8 @@ def allreduce_logabsdetjac(partial: torch.Tensor, group=None) -> torch.Tensor:
     if partial.dtype != torch.float64:
         raise TypeError("the partial log-det sum is reduced in float64 so the result does not depend on the shard count")
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        if _LIBRARY_COLLECTIVE[0] and partial.is_cuda:
-            from . import _lib as L
+        if _LIBRARY_COLLECTIVE[0] and partial.is_cuda and _is_world(group):      # the library communicator spans the world:
+            from . import _lib as L                                              # a sub-group goes through torch.distributed
             from . import interface as I
 
             ctx = I.context(partial.device)
@@ -96,7 +103,7 @@ def allreduce_param_cotangents(grads, group=None):
     if not leaves or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return grads
     bucket = torch.cat([t.detach().reshape(-1).to(torch.float64) for t in leaves])
-    if _LIBRARY_COLLECTIVE[0] and bucket.is_cuda:
+    if _LIBRARY_COLLECTIVE[0] and bucket.is_cuda and _is_world(group):
         from . import _lib as L
         from . import interface as I
 

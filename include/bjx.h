@@ -88,11 +88,11 @@ int bjx_version(void);
 /* bytes of scratch a context holds (informational; SURVEY.md §8b "bjx_workspace_bytes") */
 size_t bjx_workspace_bytes(bjx_ctx* ctx);
 int bjx_synchronize(bjx_ctx* ctx);
-/* Tuning switches (per context).  BJX_OPT_INKERNEL_FINALIZE: 1 = the last block to arrive finishes
- * the deterministic sum of `ladj_sum` inside the hot kernel (one launch per call) instead of the
- * default two small follow-up launches; same bits either way (tests/test_gpu_parity.py).  Default 0:
- * on MI355X the arrival atomic makes every block wait for its own output stores, which costs more
- * than the ~10 us of extra launches (profiles/r01_finalize_variants.txt). */
+/* Tuning switches (per context).  BJX_OPT_INKERNEL_FINALIZE: 1 = the last block to arrive finishes the deterministic sum of
+ * `ladj_sum` inside the hot kernel (one launch per call, grids of <= 4096 blocks) instead of the default two small follow-up
+ * launches; same bits either way (tests/test_gpu_parity.py).  Default 0: on MI355X the hand-off makes every block wait for its
+ * own output stores and adds a serial tail behind the slowest block, which costs more than the ~8 us of extra launches
+ * (profiles/r03_finalize_ab.txt: 16.6 -> 26.1 us per call of BASELINE configs[0]). */
 enum { BJX_OPT_INKERNEL_FINALIZE = 1 };
 int bjx_set_option(bjx_ctx* ctx, int option, int value);
 /* Stream of BJX_INPUT_STDNORMAL: element (row, col) of a call draws value number (col0 + col) * dim + row of `seed`. */

@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import bijectors_amd as bj  # noqa: E402
+from _timing import kernel_ms  # noqa: E402
 
 f64 = torch.float64
 
@@ -85,15 +86,7 @@ def main():
     print("|---|---|---|---|---|---|")
     for name, step, bps, ns in rows:
         try:
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            lib.bjx_kernel_time_begin(ctx.h)
-            for _ in range(a.steps):
-                step()
-            ms, cnt = C.c_float(0), C.c_int(0)
-            L.check(ctx.h, lib.bjx_kernel_time_end(ctx.h, C.byref(ms), C.byref(cnt)), "time_end")
-            k = ms.value / a.steps
+            k = kernel_ms(bj, step, steps=a.steps, device=dev)
             gbs = bps * ns / (k * 1e-3) / 1e9
             print(f"| {name} | {k:.4f} | 2^{int(math.log2(ns))} | {bps} | {gbs:.0f} | {100 * gbs / 8000:.1f} |", flush=True)
         except Exception as ex:

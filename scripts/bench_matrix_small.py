@@ -21,16 +21,8 @@ for K in tuple(int(k) for k in os.environ.get("BJX_BENCH_KS", "2,3,4,5,8,9,12").
         yy = (0.4 * torch.randn(N, nu, device=dev, dtype=DT)).T
         X = bj.transform(bj.inverse(b), yy)
         for label, bb, xin in ((name, b, X), (f"inverse({name})", bj.inverse(b), yy)):
-            for _ in range(3):
-                bj.with_logabsdet_jacobian(bb, xin, per_sample=True)
-            torch.cuda.synchronize()
-            lib.bjx_kernel_time_begin(ctx.h)
-            reps = 10
-            for _ in range(reps):
-                bj.with_logabsdet_jacobian(bb, xin, per_sample=True)
-            ms, n = C.c_float(0), C.c_int(0)
-            lib.bjx_kernel_time_end(ctx.h, C.byref(ms), C.byref(n))
-            kms = ms.value / reps
+            from _timing import kernel_ms
+            kms = kernel_ms(bj, lambda: bj.with_logabsdet_jacobian(bb, xin, per_sample=True), steps=10, device=dev)
             bytes_ps = (K * K + nu) * EB + EB
             gbs = bytes_ps * N / (kms * 1e-3) / 1e9
             print(f"| {label} | {K} | {kms:.4f} | {bytes_ps} | {gbs:.0f} | {gbs / 80:.1f} |")

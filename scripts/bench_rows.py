@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import bijectors_amd as bj  # noqa: E402
+from _timing import kernel_ms  # noqa: E402
 
 PEAK = 8000.0
 
@@ -214,15 +215,7 @@ def main():
         if only and not any(o in name for o in only):
             continue
         try:
-            for _ in range(3):
-                step()
-            torch.cuda.synchronize()
-            lib.bjx_kernel_time_begin(ctx.h)
-            for _ in range(a.steps):
-                step()
-            ms, cnt = C.c_float(0), C.c_int(0)
-            L.check(ctx.h, lib.bjx_kernel_time_end(ctx.h, C.byref(ms), C.byref(cnt)), "time_end")
-            k = ms.value / a.steps
+            k = kernel_ms(bj, step, steps=a.steps, device=dev)
             gbs = bps * n / (k * 1e-3) / 1e9
             print(f"| {name} | {ref} | {k:.4f} | 2^{int(math.log2(n))} | {bps} | {gbs:.0f} | {100 * gbs / PEAK:.1f} |", flush=True)
         except Exception as ex:  # keep the table going

@@ -11,15 +11,8 @@ ctx = bj.context(dev)
 
 
 def timed(fn, reps=10):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
-    lib.bjx_kernel_time_begin(ctx.h)
-    for _ in range(reps):
-        fn()
-    ms, n = C.c_float(0), C.c_int(0)
-    lib.bjx_kernel_time_end(ctx.h, C.byref(ms), C.byref(n))
-    return ms.value / reps
+    from _timing import kernel_ms          # clock-settling pre-roll, then the per-launch event pairs
+    return kernel_ms(bj, fn, steps=reps, device=dev)
 
 
 print("| bijector | dim | kernel ms (2^22 columns) | alg. B/sample | GB/s | % of 8 TB/s |")

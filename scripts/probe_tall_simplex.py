@@ -6,13 +6,9 @@ import bijectors_amd as bj
 dev = torch.device("cuda", 0)
 lib = bj._lib.load(); ctx = bj.context(dev)
 def timed(fn, reps=5):
-    for _ in range(2): fn()
-    torch.cuda.synchronize()
-    lib.bjx_kernel_time_begin(ctx.h)
-    for _ in range(reps): fn()
-    ms, n = C.c_float(0), C.c_int(0)
-    lib.bjx_kernel_time_end(ctx.h, C.byref(ms), C.byref(n))
-    return ms.value / reps
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _timing import kernel_ms
+    return kernel_ms(bj, fn, steps=reps, device=dev)
 N = 1 << int(os.environ.get("BJX_BENCH_LOG2N", "20"))
 print("| bijector | K | kernel ms (2^%d columns) | alg. B/sample | GB/s | %% of 8 TB/s |" % (N.bit_length() - 1))
 print("|---|---|---|---|---|---|")

@@ -132,19 +132,26 @@ def test_c5_simplex_and_cholesky_full_size(bj, orc):
     ys, ls = orc.simplex(sample_cols(x, idx))
     np.testing.assert_allclose(y[:, idx].cpu().numpy(), ys, rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(lps[idx].cpu().numpy(), ls, rtol=1e-3, atol=1e-2)
-    # Cholesky-correlation factor: K = 64, 2^17 samples (1 GB of y, 2 GB of dense W)
-    Nc = 1 << 17
+    del y, xb, lps, lps_inv, x
+    torch.cuda.empty_cache()
+    # Cholesky-correlation factor: K = 64 at the FULL batch of BASELINE configs[4], 2^20 samples (8.5 GB of y, 17 GB of dense W —
+    # what bench.py's c5b row times); invariants over every sample, the oracle on 16 sampled columns
+    Nc = 1 << 20
     n = K * (K - 1) // 2
     yv = fill(bj, cm(n, Nc), 1, std=0.5)
     ib = bj.inverse(bj.VecCholeskyBijector("U"))
     W, lj, ljsum = bj.shard.with_logabsdet_jacobian_sharded(ib, yv)
     Wm = W.permute(2, 1, 0)                                        # (Nc, col, row): contiguous samples
-    assert torch.allclose((Wm * Wm).sum(dim=2), torch.ones(Nc, K, device="cuda"), atol=2e-5)   # unit columns of a correlation factor
-    assert bool((torch.tril(W.permute(2, 0, 1), diagonal=-1) == 0).all())                       # strictly lower part is zero (corr.jl:391-395)
+    for lo in range(0, Nc, 1 << 17):                               # in slabs: the temporaries stay at 2 GB
+        sl = Wm[lo:lo + (1 << 17)]
+        assert torch.allclose((sl * sl).sum(dim=2), torch.ones(sl.shape[0], K, device="cuda"), atol=2e-5)   # unit columns of a correlation factor
+        assert bool((torch.triu(sl, diagonal=1) == 0).all())       # strictly lower part of every W[:, :, n] is zero (corr.jl:391-395); sl[n] = W[:, :, n]'
+        del sl
     # logabsdetjac(inverse(b), y) alone (corr.jl:252-254, no W written) equals the fused value
     assert abs(float(bj.logabsdetjac(ib, yv)) - float(ljsum)) <= 1e-4 * abs(float(ljsum))
     yb, lf, _ = bj.shard.with_logabsdet_jacobian_sharded(bj.VecCholeskyBijector("U"), W)
-    assert torch.allclose(yb, yv, rtol=2e-3, atol=2e-4)            # test/bijectors/corr.jl:46-64 roundtrip
+    for lo in range(0, Nc, 1 << 18):
+        assert torch.allclose(yb[:, lo:lo + (1 << 18)], yv[:, lo:lo + (1 << 18)], rtol=2e-3, atol=2e-4)      # test/bijectors/corr.jl:46-64 roundtrip
     assert torch.allclose(lf, -lj, rtol=1e-3, atol=5e-2)
     idx = torch.randint(0, Nc, (16,), generator=torch.Generator().manual_seed(6)).cuda()
     Ws, ljs = orc.vec_cholesky(sample_cols(yv, idx), inverse=True, uplo="U")
