@@ -97,6 +97,7 @@ SIGNATURES = {
     "bjx_row_moments": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _i64]),
     "bjx_batchnorm_train": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp] + _tail),
     "bjx_batchnorm_stats": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _i64]),
+    "bjx_batchnorm_train_vjp": (_i, [_vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_batchnorm_train_apply": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp] + _tail),
     "bjx_rqs": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp] + _tail),
     "bjx_rqs_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i64]),

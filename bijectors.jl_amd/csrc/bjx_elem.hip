@@ -195,13 +195,16 @@ template <class T> __device__ __forceinline__ int rqs_rec_base(const RqsGeom& g,
 // unreachable, only evaluated when `dual`), (ii) the LDS blob in the layout above.
 template <class T, bool INV>
 __global__ __launch_bounds__(256) void rqs_blob_kernel(const T* w, const T* h, const T* d, int K1, int64_t rows, int V, int nstep_hi,
-                                                       int dual, int G, int* flag, T* blob) {
+                                                       int dual, int G, int* flag, T* blob, int64_t tstride = 0) {
+  // `rows` rows of the knot tables starting at w / h / d; `tstride` = rows of the WHOLE tables when this is a row slab of a
+  // taller spline (knot j of row r is w[(j-1)*tstride + r]); 0 = the tables have exactly `rows` rows
+  const int64_t ts = tstride ? tstride : rows;
   __shared__ int bad;
   if (threadIdx.x == 0) bad = 0;
   __syncthreads();
   if (dual) {
     for (int64_t r = threadIdx.x; r < rows; r += blockDim.x)
-      if (!(w[r] <= -w[(int64_t)(K1 - 1) * rows + r]) || !(h[r] <= -h[(int64_t)(K1 - 1) * rows + r])) bad = 1;
+      if (!(w[r] <= -w[(int64_t)(K1 - 1) * ts + r]) || !(h[r] <= -h[(int64_t)(K1 - 1) * ts + r])) bad = 1;
   }
   __syncthreads();
   const int skip0 = (dual && !bad) ? 1 : 0;
@@ -214,8 +217,8 @@ __global__ __launch_bounds__(256) void rqs_blob_kernel(const T* w, const T* h, c
     const int rp = (int)(i / per_row), s = (int)(i % per_row);
     const int64_t r = (int64_t)(rp % g.nvc) * g.V + rp / g.nvc;   // actual row
     const bool live = rp < g.V * g.nvc && r < rows;
-    auto W = [&](int j) { return w[(int64_t)(j - 1) * rows + r]; };   // 1-based knot j of row r
-    auto H = [&](int j) { return h[(int64_t)(j - 1) * rows + r]; };
+    auto W = [&](int j) { return w[(int64_t)(j - 1) * ts + r]; };   // 1-based knot j of row r
+    auto H = [&](int j) { return h[(int64_t)(j - 1) * ts + r]; };
     if (s == 0) blob[rp] = live ? (INV ? H(K1) : W(K1)) : T(0);
     if (s < nkeys) {
       // sorted searched key s (0-based) = knot kbase + s + 1, padded with +inf; tree position:
@@ -238,9 +241,9 @@ __global__ __launch_bounds__(256) void rqs_blob_kernel(const T* w, const T* h, c
     const int gl = g.G > 16 ? hi * 16 + slot : (slot & (g.G - 1));
     const int64_t r = (int64_t)gl * g.V + j;                          // actual row
     const bool live = gl < g.nvc && r < rows;
-    auto W = [&](int q) { return w[(int64_t)(q - 1) * rows + r]; };   // 1-based knot q of row r
-    auto H = [&](int q) { return h[(int64_t)(q - 1) * rows + r]; };
-    auto D = [&](int q) { return d[(int64_t)(q - 1) * rows + r]; };
+    auto W = [&](int q) { return w[(int64_t)(q - 1) * ts + r]; };   // 1-based knot q of row r
+    auto H = [&](int q) { return h[(int64_t)(q - 1) * ts + r]; };
+    auto D = [&](int q) { return d[(int64_t)(q - 1) * ts + r]; };
     T a[4] = {T(0), T(1), T(0), T(0)}, b[4] = {T(1), T(1), T(0), T(0)};
     if (live) {
       const int k = s + g.kbase;                                   // bin k spans knots k..k+1 (knot 0 = -knot K)
@@ -337,7 +340,9 @@ __device__ __forceinline__ void search_step(int& pos, double key, double x) {
 template <class T, int V, int NSTEP, bool INV>
 __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const RqsGeom g, const T* __restrict__ x, T* __restrict__ y,
                                          T* __restrict__ ladj_ps, int64_t dim, int64_t batch, int G, int iters, int accumulate,
-                                         double& acc) {
+                                         double& acc, int64_t ld) {
+  // `ld`: elements between the starts of consecutive columns (== dim for dense arrays; the full column height when x / y point
+  // at a row slab of taller columns)
   const int gl = threadIdx.x & (G - 1);
   const int cols_per_block = 256 / G;
   const bool lane_ok = gl < g.nvc;
@@ -372,16 +377,16 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
   const int cg = threadIdx.x / G;
   const int64_t left_blk = batch - bcol0;
   const int ncols_blk = left_blk > (int64_t)iters * cols_per_block ? iters * cols_per_block : (left_blk > 0 ? (int)left_blk : 0);
-  const int col_bytes = (int)dim * (int)sizeof(T);                     // a block spans < 2^31 bytes (dim <= 256 on this path)
+  const int col_bytes = (int)ld * (int)sizeof(T);                      // a block spans < 2^31 bytes (<= 64 trips of <= 256 columns)
   const int trip_cols = cols_per_block;
   constexpr int kOob = 0x7fffff00;                                     // beyond any extent: loads give 0, stores are dropped
-  const int vo0 = lane_ok ? (cg * (int)dim + gl * V) * (int)sizeof(T) : kOob;
+  const int vo0 = lane_ok ? (cg * (int)ld + gl * V) * (int)sizeof(T) : kOob;
   const int vo1 = lane_ok ? vo0 + trip_cols * col_bytes : kOob;
   const int lo0 = gl == 0 ? cg * (int)sizeof(T) : kOob;                // the group's first lane owns the column's log-det
   const int lo1 = gl == 0 ? lo0 + trip_cols * (int)sizeof(T) : kOob;
   const int my_cols = gl == 0 ? ncols_blk - cg : 0;                    // columns whose log-det this lane adds to the block partial
-  const char* xb = reinterpret_cast<const char*>(x + bcol0 * dim);
-  char* yb = reinterpret_cast<char*>(y + bcol0 * dim);
+  const char* xb = reinterpret_cast<const char*>(x + bcol0 * ld);
+  char* yb = reinterpret_cast<char*>(y + bcol0 * ld);
   char* lpb = reinterpret_cast<char*>(ladj_ps ? ladj_ps + bcol0 : nullptr);
   // descriptors of trip `it` (two column groups from block column it*trip_cols on)
   auto extent = [&](int it, int unit) -> uint32_t { const int r = ncols_blk - it * trip_cols; return r > 0 ? (uint32_t)r * (uint32_t)unit : 0u; };
@@ -468,7 +473,7 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
 template <class T, int V, int NSTEP_HI, bool DUAL, bool INV>
 __global__ __launch_bounds__(256) void rqs_lds_kernel(const T* __restrict__ blob, const int* __restrict__ flag, int K1,
                                                       const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t dim,
-                                                      int64_t batch, int G, int iters, int accumulate, const BjxFin fin) {
+                                                      int64_t batch, int G, int iters, int accumulate, const BjxFin fin, int64_t ld) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // no static LDS: with the C3 table (32 768 bytes) five blocks fit the CU's 160 KiB only if the block asks for nothing else;
   // the reduction scratch aliases the table once every wave is done with it
@@ -484,10 +489,10 @@ __global__ __launch_bounds__(256) void rqs_lds_kernel(const T* __restrict__ blob
   }
   double acc = 0.0;
   if constexpr (DUAL) {
-    if (skip0) rqs_body<T, V, NSTEP_HI - 1, INV>(blob_l, g, x, y, ladj_ps, dim, batch, G, iters, accumulate, acc);
-    else rqs_body<T, V, NSTEP_HI, INV>(blob_l, g, x, y, ladj_ps, dim, batch, G, iters, accumulate, acc);
+    if (skip0) rqs_body<T, V, NSTEP_HI - 1, INV>(blob_l, g, x, y, ladj_ps, dim, batch, G, iters, accumulate, acc, ld);
+    else rqs_body<T, V, NSTEP_HI, INV>(blob_l, g, x, y, ladj_ps, dim, batch, G, iters, accumulate, acc, ld);
   } else {
-    rqs_body<T, V, NSTEP_HI, INV>(blob_l, g, x, y, ladj_ps, dim, batch, G, iters, accumulate, acc);
+    rqs_body<T, V, NSTEP_HI, INV>(blob_l, g, x, y, ladj_ps, dim, batch, G, iters, accumulate, acc, ld);
   }
   __syncthreads();                                                  // the table is dead: its first bytes become the scratch
   block_publish_partial_at(acc, reinterpret_cast<double*>(smem), reinterpret_cast<int*>(smem + 64), fin);
@@ -817,9 +822,9 @@ inline int ceil_log2(int n) { int s = 0; while ((1 << s) < n) ++s; return s; }
 
 template <class T, int V, bool INV>
 int rqs_launch_lds(bjx_ctx* ctx, int nstep_hi, int dual, const T* blob, const int* flag, int K1, size_t smem, int64_t grid, const T* in,
-                   T* out, T* ladj_ps, int64_t dim, int64_t batch, int G, int iters, int accum, const BjxFin& fin) {
+                   T* out, T* ladj_ps, int64_t dim, int64_t batch, int G, int iters, int accum, const BjxFin& fin, int64_t ld) {
   BjxProf prof_(ctx);
-#define RQS_L(NS_, DUAL_) hipLaunchKernelGGL((rqs_lds_kernel<T, V, NS_, DUAL_, INV>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, blob, flag, K1, in, out, ladj_ps, dim, batch, G, iters, accum, fin)
+#define RQS_L(NS_, DUAL_) hipLaunchKernelGGL((rqs_lds_kernel<T, V, NS_, DUAL_, INV>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, blob, flag, K1, in, out, ladj_ps, dim, batch, G, iters, accum, fin, ld)
   switch (nstep_hi * 2 + (dual ? 1 : 0)) {
     case 2: RQS_L(1, false); break;
     case 4: RQS_L(2, false); break;  case 5: RQS_L(2, true); break;
@@ -835,6 +840,46 @@ int rqs_launch_lds(bjx_ctx* ctx, int nstep_hi, int dual, const T* blob, const in
   return BJX_OK;
 }
 
+// One launch pair (blob + rqs_lds_kernel) for `rows` rows of columns that are `ld` elements apart; the knot tables have `trows`
+// rows in all (w / h / d point at the slab's first row).  -> BJX_ERR_UNSUPPORTED-free: returns 1 when the shape does not fit
+// the LDS kernel (the caller then takes another path).
+template <class T>
+int rqs_lds_slab(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int K1, int64_t trows, const T* in, T* out, T* ladj_ps,
+                 double* ladj_sum, int64_t rows, int64_t ld, int64_t batch, uint32_t flags, bool* taken) {
+  *taken = false;
+  constexpr int VW = Vec16<T>::N;
+  ColLaunch c = col_launch_cfg<T>(ctx, in, out, rows, batch, ld, ld);
+  const int nstep_hi = ceil_log2(K1 < 2 ? 2 : K1);
+  const int dual = (K1 >= 3 && ceil_log2(K1 - 1) < nstep_hi) ? 1 : 0;
+  const RqsGeom g_hi = rqs_geom(K1, rows, c.V, 0, nstep_hi, c.G);
+  const size_t blob_bytes = rqs_blob_bytes<T>(g_hi);      // the no-skip layout is the larger one
+  const bool lds_path = nstep_hi <= 6 && rows / c.V <= 64 && ld < (1 << 20) && blob_bytes <= kRqsBlobMax && blob_bytes + 64 <= BJX_SCRATCH_BYTES;
+  if (!lds_path) return BJX_OK;
+  *taken = true;
+  int* flag = reinterpret_cast<int*>(ctx->scratch);
+  T* blob = reinterpret_cast<T*>(static_cast<char*>(ctx->scratch) + 64);
+  if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, rows, c.V, nstep_hi, dual, c.G, flag, blob, trows);
+  else hipLaunchKernelGGL((rqs_blob_kernel<T, false>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, rows, c.V, nstep_hi, dual, c.G, flag, blob, trows);
+  BJX_CHECK_LAUNCH(ctx);
+  const int cols_per_block = 256 / c.G;
+  const int64_t groups = (batch + cols_per_block - 1) / cols_per_block;
+  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  const int iters = rqs_iters(ctx, blob_bytes, (int64_t)cols_per_block * rows * sizeof(T), groups);
+  const int64_t grid = (groups + iters - 1) / iters;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_rqs: batch too large for one launch");
+  BjxFin fin;
+  bool second = false;
+  { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
+  int rc;
+  if (c.V == VW) rc = inverse ? rqs_launch_lds<T, VW, true>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, rows, batch, c.G, iters, accum, fin, ld)
+                              : rqs_launch_lds<T, VW, false>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, rows, batch, c.G, iters, accum, fin, ld);
+  else rc = inverse ? rqs_launch_lds<T, 1, true>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, rows, batch, c.G, iters, accum, fin, ld)
+                    : rqs_launch_lds<T, 1, false>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, rows, batch, c.G, iters, accum, fin, ld);
+  if (rc) return rc;
+  if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+  return BJX_OK;
+}
+
 template <class T>
 int rqs_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int K1, const T* in, T* out, T* ladj_ps,
              double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
@@ -842,42 +887,35 @@ int rqs_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int 
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
     return BJX_OK;
   }
-  ColLaunch c = col_launch_cfg<T>(ctx, in, out, dim, batch);
-  const int nstep_hi = ceil_log2(K1 < 2 ? 2 : K1);
-  const int dual = (K1 >= 3 && ceil_log2(K1 - 1) < nstep_hi) ? 1 : 0;
-  const RqsGeom g_hi = rqs_geom(K1, dim, c.V, 0, nstep_hi, c.G);
-  const size_t blob_bytes = rqs_blob_bytes<T>(g_hi);      // the no-skip layout is the larger one
-  const bool lds_path = nstep_hi <= 6 && dim / c.V <= 64 && dim < (1 << 20) && blob_bytes <= kRqsBlobMax && blob_bytes + 64 <= BJX_SCRATCH_BYTES;
-  if (!lds_path) {   // huge knot tables / very wide columns: generic functor path
-    const bool lds = knots_fit_lds<T>(dim, K1);
-    const size_t fsm = lds ? (size_t)dim * K1 * 3 * sizeof(T) : 0;
-    if (!inverse) { RqsF<T, false> f{w, h, d, K1, dim, lds ? 1 : 0, 0.0, nullptr}; return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0); }
-    RqsF<T, true> f{w, h, d, K1, dim, lds ? 1 : 0, 0.0, nullptr};
-    return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0);
+  {
+    bool taken = false;
+    const int rc = rqs_lds_slab<T>(ctx, inverse, w, h, d, K1, dim, in, out, ladj_ps, ladj_sum, dim, dim, batch, flags, &taken);
+    if (rc || taken) return rc;
   }
-  int* flag = reinterpret_cast<int*>(ctx->scratch);
-  T* blob = reinterpret_cast<T*>(static_cast<char*>(ctx->scratch) + 64);
-  if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, c.G, flag, blob);
-  else hipLaunchKernelGGL((rqs_blob_kernel<T, false>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, c.G, flag, blob);
-  BJX_CHECK_LAUNCH(ctx);
-  const int cols_per_block = 256 / c.G;
-  const int64_t groups = (batch + cols_per_block - 1) / cols_per_block;
-  constexpr int VW = Vec16<T>::N;
-  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
-  const int iters = rqs_iters(ctx, blob_bytes, (int64_t)cols_per_block * dim * sizeof(T), groups);
-  const int64_t grid = (groups + iters - 1) / iters;
-  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_rqs: batch too large for one launch");
-  BjxFin fin;
-  bool second = false;
-  { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
-  int rc;
-  if (c.V == VW) rc = inverse ? rqs_launch_lds<T, VW, true>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, fin)
-                              : rqs_launch_lds<T, VW, false>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, fin);
-  else rc = inverse ? rqs_launch_lds<T, 1, true>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, fin)
-                    : rqs_launch_lds<T, 1, false>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, dim, batch, c.G, iters, accum, fin);
-  if (rc) return rc;
-  if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
-  return BJX_OK;
+  // Taller columns than one table takes (the record part of the blob grows with the lanes per column: 65 KiB at 200 rows x 9
+  // knots): ROW SLABS of 64 rows (16 lanes per column, a 20 KiB table), one launch pair per slab on a row window of the same
+  // arrays (column stride = dim), the log-dets of the slabs accumulated in launch order (BJX_ACCUMULATE from the second slab on:
+  // deterministic).  Round 2 sent these shapes to the generic functor kernel: 23 % of the HBM peak at dim = 200, 8 % at 1000.
+  constexpr int VWs = Vec16<T>::N;
+  static const int slab_rows = getenv("BJX_RQS_SLAB") ? atoi(getenv("BJX_RQS_SLAB")) : 64;      // tuning switch: 0 = the generic path as in round 2
+  if (slab_rows > 0 && dim % VWs == 0 && bjx_aligned16(in) && bjx_aligned16(out) && out) {
+    bool ok = true;
+    for (int64_t r0 = 0; r0 < dim && ok; r0 += slab_rows) {
+      const int64_t rs = dim - r0 < slab_rows ? dim - r0 : slab_rows;
+      bool taken = false;
+      const uint32_t fl = r0 == 0 ? flags : (flags | BJX_ACCUMULATE);
+      const int rc = rqs_lds_slab<T>(ctx, inverse, w + r0, h + r0, d + r0, K1, dim, in + r0, out + r0, ladj_ps, ladj_sum, rs, dim, batch, fl, &taken);
+      if (rc) return rc;
+      if (!taken) { ok = false; BJX_REQUIRE(ctx, r0 == 0, BJX_ERR_UNSUPPORTED, "bjx_rqs: row slab %lld does not fit the LDS kernel", (long long)r0); }
+    }
+    if (ok) return BJX_OK;
+  }
+  // huge knot tables / odd very wide columns: generic functor path
+  const bool lds = knots_fit_lds<T>(dim, K1);
+  const size_t fsm = lds ? (size_t)dim * K1 * 3 * sizeof(T) : 0;
+  if (!inverse) { RqsF<T, false> f{w, h, d, K1, dim, lds ? 1 : 0, 0.0, nullptr}; return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0); }
+  RqsF<T, true> f{w, h, d, K1, dim, lds ? 1 : 0, 0.0, nullptr};
+  return launch_colgroup<T>(ctx, f, fsm, in, out, ladj_ps, ladj_sum, dim, batch, flags, 0.0);
 }
 
 // Fallback of the spline pullback for tables the LDS kernel does not take (very wide columns, > 64 knots): one
@@ -1655,6 +1693,82 @@ BJX_API int bjx_batchnorm_train(bjx_ctx* ctx, bjx_dtype dt, const void* b, const
               bn_train_impl<float>(ctx, (const float*)b, (const float*)logs, (float*)m, (float*)v, (float)eps, (float)mtm, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, batch, flags),
               bn_train_impl<double>(ctx, (const double*)b, (const double*)logs, (double*)m, (double*)v, eps, mtm, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, batch, flags),
               "bjx_batchnorm_train");
+}
+
+namespace {
+// ------------------------------------------------------------------ InvertibleBatchNorm, TRAINING-mode pullback
+// normalise.jl:51-60: m = mean(x), v = Σ(x - m)²/N are functions of the batch; the reference leaves the adjoint to the AD
+// package.  With σ = sqrt(v + ε), x̂ = (x - m)/σ, γ = exp(logs), y = γ x̂ + b, logabsdetjac[n] = Σ_c (logs_c - ½ log(v_c + ε)):
+//   x̄ = (γ/σ) [ȳ - mean_n ȳ - x̂ mean_n(ȳ x̂)] - (Σ_n ℓ̄ / N) x̂ / σ        (the last term: ∂/∂x of -½ Σℓ̄ log(v + ε))
+//      = p ȳ + q x + r   per channel,  p = γ/σ,  q = -(p mean(ȳ x̂) + Σℓ̄/(N σ))/σ,  r = -p mean ȳ - q m
+//   b̄ = Σ_n ȳ,   l̄ogs = γ Σ_n ȳ x̂ + Σ_n ℓ̄,   Σ_n ȳ x̂ = (Σ ȳ x - m Σ ȳ)/σ
+// The batch sums (Σȳ, Σȳx, N) come in as `moments` (bjx_row_moments(ȳ, x), all-reduced by the host when the batch is sharded).
+template <class T>
+__global__ __launch_bounds__(256) void bn_train_vjp_coef_kernel(const T* __restrict__ logs, const T* __restrict__ mean, const T* __restrict__ var, double eps,
+                                                                const double* __restrict__ mom, const double* __restrict__ lsum, int dim,
+                                                                T* __restrict__ coef /*[3 dim]: p | q | r*/, T* __restrict__ b_bar, T* __restrict__ logs_bar) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= dim) return;
+  const double n = mom[2 * dim], Sy = mom[c], Syx = mom[dim + c], L = lsum ? *lsum : 0.0;
+  const double m = (double)mean[c], sig = ::sqrt((double)var[c] + eps), gam = ::exp((double)logs[c]);
+  const double Syxh = (Syx - m * Sy) / sig;
+  const double pp = gam / sig;
+  const double qq = -(pp * (Syxh / n) + L / (n * sig)) / sig;
+  coef[c] = (T)pp;
+  coef[dim + c] = (T)qq;
+  coef[2 * dim + c] = (T)(-pp * (Sy / n) - qq * m);
+  if (b_bar) b_bar[c] = (T)Sy;
+  if (logs_bar) logs_bar[c] = (T)(gam * Syxh + L);
+}
+template <class T, int V>
+__global__ __launch_bounds__(256) void bn_train_vjp_apply_kernel(const T* __restrict__ coef, const T* __restrict__ x, const T* __restrict__ g, T* __restrict__ xb,
+                                                                 int64_t dim, int64_t total) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
+  if (i >= total) return;
+  const int64_t row = i % dim;                           // V > 1 only when dim % V == 0: a pack stays inside one column
+  const Pack<T, V> xv = load_pack<T, V, true>(x + i), gv = load_pack<T, V, true>(g + i);
+  Pack<T, V> o;
+#pragma unroll
+  for (int j = 0; j < V; ++j) o.v[j] = coef[row + j] * gv.v[j] + (coef[dim + row + j] * xv.v[j] + coef[2 * dim + row + j]);
+  store_pack<T, V, true>(xb + i, o);
+}
+template <class T>
+int bn_train_vjp_impl(bjx_ctx* ctx, const T* logs, const T* mean, const T* var, double eps, const double* mom, const double* lsum, const T* in,
+                      const T* out_bar, T* in_bar, T* b_bar, T* logs_bar, int64_t dim, int64_t batch) {
+  BJX_REQUIRE(ctx, (size_t)3 * dim * sizeof(T) <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_batchnorm_train_vjp: too many channels");
+  T* coef = reinterpret_cast<T*>(ctx->scratch);
+  hipLaunchKernelGGL((bn_train_vjp_coef_kernel<T>), dim3((unsigned)((dim + 255) / 256)), dim3(256), 0, ctx->stream, logs, mean, var, eps, mom, lsum, (int)dim, coef, b_bar, logs_bar);
+  BJX_CHECK_LAUNCH(ctx);
+  if (batch == 0 || !in_bar) return BJX_OK;
+  constexpr int VW = Vec16<T>::N;
+  const int64_t total = dim * batch;
+  const bool vec = dim % VW == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
+  BjxProf prof_(ctx);
+  if (vec) {
+    const int64_t grid = (total / VW + 255) / 256;
+    BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_batchnorm_train_vjp: input too large for one launch");
+    hipLaunchKernelGGL((bn_train_vjp_apply_kernel<T, VW>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, coef, in, out_bar, in_bar, dim, total);
+  } else {
+    const int64_t grid = (total + 255) / 256;
+    BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_batchnorm_train_vjp: input too large for one launch");
+    hipLaunchKernelGGL((bn_train_vjp_apply_kernel<T, 1>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, coef, in, out_bar, in_bar, dim, total);
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+}  // namespace
+
+BJX_API int bjx_batchnorm_train_vjp(bjx_ctx* ctx, bjx_dtype dt, const void* logs, const void* mean, const void* var, double eps, const double* moments,
+                                    const double* ladj_bar_sum, const void* in, const void* out_bar, void* in_bar, void* b_bar, void* logs_bar,
+                                    int64_t dim, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_batchnorm_train_vjp: bad size");
+  BJX_REQUIRE(ctx, logs && mean && var && moments && ((in && out_bar) || batch == 0 || !in_bar), BJX_ERR_ARG, "bjx_batchnorm_train_vjp: null pointer");
+  BJX_REQUIRE(ctx, !in_bar || ((const void*)in_bar != in), BJX_ERR_ARG, "bjx_batchnorm_train_vjp: in_bar may not alias the primal input");
+  DISPATCH_DT(ctx, dt,
+              bn_train_vjp_impl<float>(ctx, (const float*)logs, (const float*)mean, (const float*)var, eps, moments, ladj_bar_sum, (const float*)in, (const float*)out_bar, (float*)in_bar, (float*)b_bar, (float*)logs_bar, dim, batch),
+              bn_train_vjp_impl<double>(ctx, (const double*)logs, (const double*)mean, (const double*)var, eps, moments, ladj_bar_sum, (const double*)in, (const double*)out_bar, (double*)in_bar, (double*)b_bar, (double*)logs_bar, dim, batch),
+              "bjx_batchnorm_train_vjp");
 }
 
 namespace {

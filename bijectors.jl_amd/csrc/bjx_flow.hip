@@ -63,6 +63,14 @@ template <class T> __device__ __forceinline__ T find_alpha_dev(T wy, T c, T b) {
   return a;
 }
 
+// the inverse step's root + activation: Float64 through find_alpha_act64 (Float32 pre-solve + two Float64 Newton steps, below),
+// Float32 through the safeguarded loop (the Float32 hot kernels have their own find_alpha_act)
+__device__ __forceinline__ void find_alpha_act64(double wy, double c, double b, double& th, double& s2);
+template <class T> __device__ __forceinline__ void planar_inv_act(T wy, T c, T b, T& th, T& s2) {
+  if constexpr (sizeof(T) == 8) find_alpha_act64(wy, c, b, th, s2);
+  else { const T arg = find_alpha_dev<T>(wy, c, b) + b; x_tanh_sech2(arg, th, s2); }
+}
+
 template <class T> struct PlanarArgs {
   const T *w, *u_hat, *wtu_hat, *b;
   int n_layers;
@@ -121,11 +129,9 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
       }
       s = group_sum_rt(s, G);                 // wᵀz   (src/utils.jl:2)
       const T bl = A.b[l], c = A.wtu_hat[l];
-      T arg;
-      if (!INV) arg = s + bl;
-      else arg = find_alpha_dev<T>(s, c, bl) + bl;
       T t, s2;
-      x_tanh_sech2(arg, t, s2);
+      if (!INV) x_tanh_sech2(s + bl, t, s2);
+      else planar_inv_act<T>(s, c, bl, t, s2);
       const T ld = Fast<T>::log1p(c * s2);      // planar_layer.jl:107
       ladj += INV ? -ld : ld;
       const T tt = INV ? -t : t;
@@ -346,9 +352,9 @@ __device__ __forceinline__ T planar_tile_group(const PlanarTileArgs<T>& A, T* ti
         else { if (j > k && (FULL || j < ng)) a -= Gk[j] * t[j]; }
       }
       const T bl = A.b[l0 + k], c = A.wtu_hat[l0 + k];
-      const T arg = INV ? find_alpha_dev<T>(a, c, bl) + bl : a + bl;
       T th, s2;
-      x_tanh_sech2(arg, th, s2);
+      if (INV) planar_inv_act<T>(a, c, bl, th, s2);
+      else x_tanh_sech2(a + bl, th, s2);
       const T ld = Fast<T>::log1p(c * s2);                // planar_layer.jl:107
       ladj += INV ? -ld : ld;
       t[k] = th;
@@ -586,6 +592,40 @@ __device__ __forceinline__ void find_alpha_act(float wy, float c, float b, float
   }
   th = t;
   ld = F::log1p(c * (4.0f * e * r * r));               // planar_layer.jl:107, sech² = 4e/(1+e)²
+}
+
+// Float64 find_alpha + activation of the inverse step (round 3).  find_alpha_dev<double> runs a data-dependent safeguarded loop:
+// max-over-lanes ~7-8 iterations of a Float64 tanh (expm1 + reciprocal) and a Float64 division — the inverse 8-layer flow sat at
+// 25 % of the HBM peak against 52 % for the forward one.  Here the root is first solved in FLOAT32 on the hardware exp / rcp units
+// (the fixed-point start and three Newton steps of find_alpha_act: ~1e-7 relative), which leaves Newton's quadratic convergence
+// two Float64 steps from rounding level (1e-7 -> 1e-14 -> below eps); the third Float64 evaluation is the one tanh / sech² of the
+// step need anyway and doubles as the acceptance test (residual at rounding level, root inside the reference's bracket,
+// planar_layer.jl:160-173).  Every lane does the same straight-line work; a lane that fails the test (c -> -1 with tanh ~ 0, or
+// operands outside Float32's range) falls back to the safeguarded loop.
+__device__ __forceinline__ void find_alpha_act64(double wy, double c, double b, double& th, double& s2) {
+  using F = Fast<double>;
+  const float wyf = (float)wy, cf = (float)c, bf = (float)b;
+  float af = wyf - cf * fast_tanh(wyf + bf);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const float t = fast_tanh(af + bf);
+    af -= (af + cf * t - wyf) * Fast<float>::rcp(1.0f + cf * (1.0f - t * t));
+  }
+  double a = (double)af;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    double t, q;
+    x_tanh_sech2(a + b, t, q);
+    a -= (a + c * t - wy) * F::rcp(1.0 + c * q);
+  }
+  x_tanh_sech2(a + b, th, s2);
+  const double f = a + c * th - wy;
+  const double delta = 2.0 * __builtin_fabs(c);
+  const bool ok = __builtin_fabs(f) <= 8.0 * Num<double>::eps * (__builtin_fabs(wy) + __builtin_fabs(c) + __builtin_fabs(a)) && a >= wy - delta && a <= wy + delta;
+  if (!ok) {                                           // rare, divergent
+    a = find_alpha_dev<double>(wy, c, b);
+    x_tanh_sech2(a + b, th, s2);
+  }
 }
 
 // COLS = columns per wave: 64 (every lane runs the recurrence) or 32 (half the register tile -> twice the waves per SIMD;
@@ -999,9 +1039,9 @@ __global__ __launch_bounds__(256) void planar_mfma64_kernel(const double* __rest
           else { if (j > k) a += Gk[j] * tt[j]; }         // tt holds -tanh for the inverse
         }
         const double bl = bp[l0 + k], c = cp[l0 + k];
-        const double arg = INV ? find_alpha_dev<double>(a, c, bl) + bl : a + bl;
         double th, s2;
-        x_tanh_sech2(arg, th, s2);
+        if (INV) find_alpha_act64(a, c, bl, th, s2);
+        else x_tanh_sech2(a + bl, th, s2);
         double ld = Fast<double>::log1p(c * s2);            // planar_layer.jl:107
         if (l0 + k >= n_layers) { th = 0.0; ld = 0.0; }     // padding layer (wave-uniform)
         ladj += INV ? -ld : ld;
@@ -1675,9 +1715,9 @@ __global__ __launch_bounds__(64) void planar_walk_kernel(const T* __restrict__ A
       if constexpr (sizeof(T) == 4) {                                // the activation of the register kernels: tanh, sech², log1p from one exp
         if (!INV) planar_act(s + bl, c, t, ld); else find_alpha_act(s, c, bl, t, ld);
       } else {
-        const T arg = INV ? find_alpha_dev<T>(s, c, bl) + bl : s + bl;
         T s2;
-        x_tanh_sech2(arg, t, s2);
+        if (INV) planar_inv_act<T>(s, c, bl, t, s2);
+        else x_tanh_sech2(s + bl, t, s2);
         ld = Fast<T>::log1p(c * s2);                                 // planar_layer.jl:107
       }
       ladj += INV ? -ld : ld;

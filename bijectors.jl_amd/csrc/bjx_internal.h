@@ -737,6 +737,25 @@ template <class T, int V> __device__ __forceinline__ void buf_store_pack(__amdgp
   else { unsigned int t; __builtin_memcpy(&t, &p, 4); __builtin_amdgcn_raw_buffer_store_b32(t, r, voffset, 0, 2); }
 }
 
+// the same with a wave-uniform byte offset in an SGPR (soffset): a run of loads that differ only by a uniform stride shares ONE
+// per-lane offset register instead of one 64-bit address pair per load
+template <class T, int V> __device__ __forceinline__ Pack<T, V> buf_load_pack_s(__amdgpu_buffer_rsrc_t r, int voffset, int soffset) {
+  Pack<T, V> p;
+  constexpr int B = V * (int)sizeof(T);
+  static_assert(B == 4 || B == 8 || B == 16, "pack bytes");
+  if constexpr (B == 16) { const bjx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 2); __builtin_memcpy(&p, &t, 16); }
+  else if constexpr (B == 8) { const bjx_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voffset, soffset, 2); __builtin_memcpy(&p, &t, 8); }
+  else { const unsigned int t = __builtin_amdgcn_raw_buffer_load_b32(r, voffset, soffset, 2); __builtin_memcpy(&p, &t, 4); }
+  return p;
+}
+template <class T, int V> __device__ __forceinline__ void buf_store_pack_s(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, const Pack<T, V>& p) {
+  constexpr int B = V * (int)sizeof(T);
+  static_assert(B == 4 || B == 8 || B == 16, "pack bytes");
+  if constexpr (B == 16) { bjx_u32x4 t; __builtin_memcpy(&t, &p, 16); __builtin_amdgcn_raw_buffer_store_b128(t, r, voffset, soffset, 2); }
+  else if constexpr (B == 8) { bjx_u32x2 t; __builtin_memcpy(&t, &p, 8); __builtin_amdgcn_raw_buffer_store_b64(t, r, voffset, soffset, 2); }
+  else { unsigned int t; __builtin_memcpy(&t, &p, 4); __builtin_amdgcn_raw_buffer_store_b32(t, r, voffset, soffset, 2); }
+}
+
 }  // namespace bjx
 
 // grid sizing for streaming kernels: enough blocks to fill 256 CUs x 8 resident blocks

@@ -154,35 +154,40 @@ __global__ __launch_bounds__(64) void seq_chunk_kernel(Op op0, const T* __restri
   T* dst = out ? out + col0 * ld_out : nullptr;
   Op op = op0;
   op.init();
-  constexpr int LPR = C / V;                  // lanes per run (V > 1): C rows of one column as 16-byte packs
-  constexpr int CPI = 64 / LPR;               // columns per instruction
+  // Chunk I/O: an instruction moves CPI runs of C rows (one run per column) as V-element packs, LPR lanes per run; ALL NLD
+  // instructions of a chunk are issued before the first result is used (64 VGPRs of data in flight per lane) — issued one by
+  // one behind their own waits the chunk loads cost NLD memory round trips and the kernel ran at 15 % of the HBM peak.
+  // Raw buffer accesses: the descriptor spans this wave's ncols columns (columns beyond read zeros / drop their stores), the
+  // per-lane byte offset is the same register for every instruction of a chunk and the column step is a wave-uniform SGPR
+  // offset; rows that do not exist get the out-of-range offset.
+  constexpr int LPR = C / V, CPI = 64 / LPR, NLD = 64 / CPI;
+  constexpr int kOob = 0x7fffff00;
+  const int lr = (lane % LPR) * V, lc = lane / LPR;
+  const auto r_in = bjx_make_rsrc(src, (uint32_t)((int64_t)ncols * ld_in * (int64_t)sizeof(T)));
+  const auto r_out = bjx_make_rsrc(dst, dst ? (uint32_t)((int64_t)ncols * ld_out * (int64_t)sizeof(T)) : 0u);
+  const int step_in = (int)(CPI * ld_in * (int64_t)sizeof(T)), step_out = (int)(CPI * ld_out * (int64_t)sizeof(T));
+  Pack<T, V> regs[NLD];
   for (int64_t c0 = 0; c0 < rows; c0 += C) {
     const int nr = (int)((rows - c0) < C ? (rows - c0) : C);
-    tile_sync();                              // the previous chunk's stores have read the tile
     // ---- load rows [c0, c0 + nr) of the 64 columns (rows >= rows_in do not exist: zero)
-    if constexpr (V > 1) {
-      const int lr = (lane % LPR) * V, lc = lane / LPR;
-#pragma unroll 4
-      for (int cb = 0; cb < 64; cb += CPI) {
-        const int c = cb + lc;
-        Pack<T, V> p;
+    const bool full_in = c0 + lr + V <= rows_in;
+    const int vo_in = full_in ? (int)(((int64_t)lc * ld_in + c0 + lr) * (int64_t)sizeof(T)) : kOob;
 #pragma unroll
-        for (int j = 0; j < V; ++j) p.v[j] = T(0);
-        if (c < ncols && c0 + lr + V <= rows_in) p = load_pack<T, V, true>(src + (int64_t)c * ld_in + c0 + lr);
-        else if (c < ncols) {
+    for (int u = 0; u < NLD; ++u) regs[u] = buf_load_pack_s<T, V>(r_in, vo_in, u * step_in);
+    if (V > 1 && !full_in && c0 + lr < rows_in) {          // the ragged last pack of a column (rows_in % V != 0): element by element
 #pragma unroll
-          for (int j = 0; j < V; ++j) if (c0 + lr + j < rows_in) p.v[j] = src[(int64_t)c * ld_in + c0 + lr + j];
-        }
+      for (int u = 0; u < NLD; ++u) {
+        const int c = u * CPI + lc;
 #pragma unroll
-        for (int j = 0; j < V; ++j) tile[c * P + lr + j] = p.v[j];
+        for (int j = 0; j < V; ++j) regs[u].v[j] = (c < ncols && c0 + lr + j < rows_in) ? src[(int64_t)c * ld_in + c0 + lr + j] : T(0);
       }
-    } else {
-#pragma unroll 8
-      for (int c = 0; c < 64; ++c) {
-        T v = T(0);
-        if (c < ncols && lane < nr && c0 + lane < rows_in) v = __builtin_nontemporal_load(src + (int64_t)c * ld_in + c0 + lane);
-        if (lane < C) tile[c * P + lane] = v;
-      }
+    }
+    tile_sync();                                          // the previous chunk's stores have read the tile
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int c = u * CPI + lc;
+#pragma unroll
+      for (int j = 0; j < V; ++j) tile[c * P + lr + j] = regs[u].v[j];
     }
     tile_sync();
     // ---- walk: lane = column, ascending rows (the reference's order)
@@ -210,27 +215,22 @@ __global__ __launch_bounds__(64) void seq_chunk_kernel(Op op0, const T* __restri
     tile_sync();
     // ---- store rows [c0, c0 + nr) that exist in the output
     if (dst) {
-      if constexpr (V > 1) {
-        const int lr = (lane % LPR) * V, lc = lane / LPR;
-#pragma unroll 4
-        for (int cb = 0; cb < 64; cb += CPI) {
-          const int c = cb + lc;
-          Pack<T, V> p;
 #pragma unroll
-          for (int j = 0; j < V; ++j) p.v[j] = tile[c * P + lr + j];
-          if (c < ncols && c0 + lr + V <= rows_out) store_pack<T, V, true>(dst + (int64_t)c * ld_out + c0 + lr, p);
-          else if (c < ncols) {
+      for (int u = 0; u < NLD; ++u) {
+        const int c = u * CPI + lc;
 #pragma unroll
-            for (int j = 0; j < V; ++j) if (c0 + lr + j < rows_out) dst[(int64_t)c * ld_out + c0 + lr + j] = p.v[j];
-          }
-        }
-      } else {
-#pragma unroll 8
-        for (int c = 0; c < 64; ++c) {
-          if (lane < C) {
-            const T v = tile[c * P + lane];
-            if (c < ncols && lane < nr && c0 + lane < rows_out) __builtin_nontemporal_store(v, dst + (int64_t)c * ld_out + c0 + lane);
-          }
+        for (int j = 0; j < V; ++j) regs[u].v[j] = tile[c * P + lr + j];
+      }
+      const bool full_out = c0 + lr + V <= rows_out;
+      const int vo_out = full_out ? (int)(((int64_t)lc * ld_out + c0 + lr) * (int64_t)sizeof(T)) : kOob;
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) buf_store_pack_s<T, V>(r_out, vo_out, u * step_out, regs[u]);
+      if (V > 1 && !full_out && c0 + lr < rows_out) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+          const int c = u * CPI + lc;
+#pragma unroll
+          for (int j = 0; j < V; ++j) if (c < ncols && c0 + lr + j < rows_out) dst[(int64_t)c * ld_out + c0 + lr + j] = regs[u].v[j];
         }
       }
     }
@@ -285,7 +285,10 @@ int launch_seq(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, doub
     const size_t smem_w = ((size_t)64 * P + (size_t)n_logk) * sizeof(T);
     static const int use_wave = getenv("BJX_SEQ_WAVE") ? atoi(getenv("BJX_SEQ_WAVE")) : 1;
     // whole-column tiles up to `chunk_min` bytes (tuning switch for the same-box A/B): beyond, the chunked walker keeps 9 waves per CU
-    static const long chunk_min = getenv("BJX_SEQ_CHUNK_MIN") ? atol(getenv("BJX_SEQ_CHUNK_MIN")) : 20 * 1024;
+    // (same-box A/B, profiles/r03_tall_columns.md: the chunk loads are runs of 256 bytes that straddle cache lines, so part of
+    //  every line is fetched twice — the chunked walker wins only where the whole-column tile leaves < 3 waves per CU:
+    //  K = 100: 30 % against 49 %, 200: 29-34 % against 27-31 %, 256: 39-68 % against 35-61 %, 1000: 34-41 % (no tile at all))
+    static const long chunk_min = getenv("BJX_SEQ_CHUNK_MIN") ? atol(getenv("BJX_SEQ_CHUNK_MIN")) : 50 * 1024;
     if (smem_w > (size_t)chunk_min && rows_in >= 1 && rows_out >= 1)
       return launch_seq_chunk<T, Op>(ctx, op, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, n_logk, flags, ld_in, ld_out);
     if (use_wave && smem_w <= 64 * 1024 && rows_in >= 1 && rows_out >= 1) {   // larger columns: the chunked block kernel below
@@ -1209,13 +1212,15 @@ int chol_impl(bjx_ctx* ctx, int inverse, int uplo, const T* in, T* out, T* ladj_
     if (tile_words < (int64_t)64 * (CHn + vv)) tile_words = (int64_t)64 * (CHn + vv);   // staging of the packed vector
     tile_words = (tile_words + 1 + 3) / 4 * 4;                    // + dummy word, 16-byte multiple
     const size_t tile_bytes = out ? (size_t)CHOL_WPB * tile_words * sizeof(T) : 0;
-    if (use_chunk && K >= 2 && CHn <= 32 && nv <= 64 * 32 && tile_bytes <= 60 * 1024) {
+    // (Float64 at K = 64: two 32.8 KiB tiles per block = 65.6 KiB — above the default dynamic-LDS limit, opted into per kernel;
+    //  round 2 sent that shape to the generic block kernel: 34 % of the HBM peak, the forward link 17 %)
+    if (use_chunk && K >= 2 && CHn <= 32 && nv <= 64 * 32 && tile_bytes <= 80 * 1024) {
       const int64_t grid = (batch + CHOL_WPB - 1) / CHOL_WPB;
       BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
       if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
       double* partials = ladj_sum ? ctx->partials : nullptr;
-#define CHOL_K(V_, CHV_, W_, L_) hipLaunchKernelGGL((chol_inv_chunk_kernel<T, V_, CHV_, W_, L_>), dim3((unsigned)grid), dim3(64 * CHOL_WPB), tile_bytes, ctx->stream, in, out, ladj_ps, (int)K, (int)tile_words, batch, accum, partials)
-#define CHOL_L(V_, CHV_) do { if (!out) CHOL_K(V_, CHV_, false, false); else if (lower) CHOL_K(V_, CHV_, true, true); else CHOL_K(V_, CHV_, true, false); } while (0)
+#define CHOL_K(V_, CHV_, W_, L_) bjx_allow_big_lds(chol_inv_chunk_kernel<T, V_, CHV_, W_, L_>, tile_bytes); hipLaunchKernelGGL((chol_inv_chunk_kernel<T, V_, CHV_, W_, L_>), dim3((unsigned)grid), dim3(64 * CHOL_WPB), tile_bytes, ctx->stream, in, out, ladj_ps, (int)K, (int)tile_words, batch, accum, partials)
+#define CHOL_L(V_, CHV_) do { if (!out) { CHOL_K(V_, CHV_, false, false); } else if (lower) { CHOL_K(V_, CHV_, true, true); } else { CHOL_K(V_, CHV_, true, false); } } while (0)
       { BjxProf prof_(ctx);
       if (vv == VW) {
         if (chv == 1) CHOL_L(VW, 1); else if (chv == 2) CHOL_L(VW, 2); else if (chv == 4) CHOL_L(VW, 4);
@@ -1250,13 +1255,13 @@ int chol_impl(bjx_ctx* ctx, int inverse, int uplo, const T* in, T* out, T* ladj_
       int64_t tile_words = (K * K + 3) / 4 * 4;
       if (tile_words < (int64_t)64 * (CHn + vv)) tile_words = (int64_t)64 * (CHn + vv);   // staging of the packed vector
       const size_t tile_bytes = (size_t)CHOL_WPB * tile_words * sizeof(T);
-      if (use_chunk && K >= 2 && CHn <= 32 && nv <= 64 * 32 && tile_bytes <= 60 * 1024) {
+      if (use_chunk && K >= 2 && CHn <= 32 && nv <= 64 * 32 && tile_bytes <= 80 * 1024) {
         const int64_t grid = (batch + CHOL_WPB - 1) / CHOL_WPB;
         BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
         if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
         double* partials = ladj_sum ? ctx->partials : nullptr;
-#define CHOLF_K(V_, CHV_, L_, J_) hipLaunchKernelGGL((chol_fwd_chunk_kernel<T, V_, CHV_, L_, J_>), dim3((unsigned)grid), dim3(64 * CHOL_WPB), tile_bytes, ctx->stream, in, out, ladj_ps, (int)K, (int)tile_words, batch, accum, partials)
-#define CHOLF_L(V_, CHV_) do { if (lower) { if (want) CHOLF_K(V_, CHV_, true, true); else CHOLF_K(V_, CHV_, true, false); } else { if (want) CHOLF_K(V_, CHV_, false, true); else CHOLF_K(V_, CHV_, false, false); } } while (0)
+#define CHOLF_K(V_, CHV_, L_, J_) bjx_allow_big_lds(chol_fwd_chunk_kernel<T, V_, CHV_, L_, J_>, tile_bytes); hipLaunchKernelGGL((chol_fwd_chunk_kernel<T, V_, CHV_, L_, J_>), dim3((unsigned)grid), dim3(64 * CHOL_WPB), tile_bytes, ctx->stream, in, out, ladj_ps, (int)K, (int)tile_words, batch, accum, partials)
+#define CHOLF_L(V_, CHV_) do { if (lower) { if (want) { CHOLF_K(V_, CHV_, true, true); } else { CHOLF_K(V_, CHV_, true, false); } } else { if (want) { CHOLF_K(V_, CHV_, false, true); } else { CHOLF_K(V_, CHV_, false, false); } } } while (0)
         { BjxProf prof_(ctx);
         if (vv == VW) {
           if (chv == 1) CHOLF_L(VW, 1); else if (chv == 2) CHOLF_L(VW, 2); else if (chv == 4) CHOLF_L(VW, 4);
@@ -1648,26 +1653,31 @@ __global__ __launch_bounds__(64) void simplex_vjp_kernel(const T* __restrict__ i
 // (forward) / one extra write + read of x (inverse) against the single-pass kernel: 4/3 and 5/3 of the algorithmic bytes.
 template <class T, int CH>
 __device__ __forceinline__ void vchunk_load(T* tile, const T* __restrict__ src, int64_t ld, int64_t c0, int64_t rows_lim, int ncols, int lane) {
-  constexpr int P = CH + 1, CPI = 64 / CH;
+  // every load of the chunk is issued before the first LDS write; raw buffer loads: one per-lane offset register for the whole
+  // chunk, a wave-uniform SGPR step from column pair to column pair, zeros beyond the wave's columns and beyond the rows that exist
+  constexpr int P = CH + 1, CPI = 64 / CH, NLD = 64 / CPI;
   const int r = lane % CH, cc = lane / CH;
-#pragma unroll 8
-  for (int cb = 0; cb < 64; cb += CPI) {
-    const int c = cb + cc;
-    T v = T(0);
-    if (c < ncols && c0 + r < rows_lim) v = src[(int64_t)c * ld + c0 + r];
-    tile[c * P + r] = v;
-  }
+  const auto rs = bjx_make_rsrc(src, (uint32_t)((int64_t)ncols * ld * (int64_t)sizeof(T)));
+  const int vo = c0 + r < rows_lim ? (int)(((int64_t)cc * ld + c0 + r) * (int64_t)sizeof(T)) : 0x7fffff00;
+  const int step = (int)(CPI * ld * (int64_t)sizeof(T));
+  Pack<T, 1> v[NLD];
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) v[u] = buf_load_pack_s<T, 1>(rs, vo, u * step);
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) tile[(u * CPI + cc) * P + r] = v[u].v[0];
 }
 template <class T, int CH>
 __device__ __forceinline__ void vchunk_store(const T* tile, T* __restrict__ dst, int64_t ld, int64_t c0, int64_t rows_lim, int ncols, int lane) {
-  constexpr int P = CH + 1, CPI = 64 / CH;
+  constexpr int P = CH + 1, CPI = 64 / CH, NLD = 64 / CPI;
   const int r = lane % CH, cc = lane / CH;
-#pragma unroll 8
-  for (int cb = 0; cb < 64; cb += CPI) {
-    const int c = cb + cc;
-    const T v = tile[c * P + r];
-    if (c < ncols && c0 + r < rows_lim) dst[(int64_t)c * ld + c0 + r] = v;
-  }
+  const auto rs = bjx_make_rsrc(dst, (uint32_t)((int64_t)ncols * ld * (int64_t)sizeof(T)));
+  const int vo = c0 + r < rows_lim ? (int)(((int64_t)cc * ld + c0 + r) * (int64_t)sizeof(T)) : 0x7fffff00;
+  const int step = (int)(CPI * ld * (int64_t)sizeof(T));
+  Pack<T, 1> v[NLD];
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) v[u].v[0] = tile[(u * CPI + cc) * P + r];
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) buf_store_pack_s<T, 1>(rs, vo, u * step, v[u]);
 }
 template <class T, bool INV, bool TABLE>
 __global__ __launch_bounds__(64) void simplex_vjp_chunk_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
@@ -1797,7 +1807,8 @@ int simplex_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, c
   }
   // tall columns: the chunked two-pass kernel (two whole-column tiles of 64 columns cost 2·64·K words: beyond `chunk_min` bytes
   // the whole-column kernel runs with too few waves, then with too few lanes)
-  static const long vjp_chunk_min = getenv("BJX_SIMPLEX_VJP_CHUNK_MIN") ? atol(getenv("BJX_SIMPLEX_VJP_CHUNK_MIN")) : 40 * 1024;
+  // (K = 100: 22 / 13 % against 29 / 23 % for the whole-column kernel; K = 200: 24 / 13 % against 11 / 9 %; K = 500: 24 / 14 % against 6 / 5 %)
+  static const long vjp_chunk_min = getenv("BJX_SIMPLEX_VJP_CHUNK_MIN") ? atol(getenv("BJX_SIMPLEX_VJP_CHUNK_MIN")) : 80 * 1024;
   if (((size_t)2 * 64 * (K | 1) + (size_t)K) * sizeof(T) > (size_t)vjp_chunk_min) {
     constexpr int CH = 128 / (int)sizeof(T);
     const bool table = (size_t)K * sizeof(T) <= 40 * 1024;

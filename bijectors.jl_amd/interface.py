@@ -1157,6 +1157,11 @@ class InvertibleBatchNorm(Bijector):
         (call it once per rank: every rank holds its own replica of the moving statistics)."""
         b, logs = _param(self.b, x), _param(self.logs, x)
         dim = x.shape[0]
+        # the batch statistics the launch below normalises with (shift = the moving mean BEFORE its update): kept for the
+        # training-mode pullback (bjx_batchnorm_train_vjp); dim-sized device arithmetic, Float64
+        n = stats[2 * dim]
+        s1, s2 = stats[:dim] / n, stats[dim:2 * dim] / n
+        self._batch_stats = ((self.m.double() + s1).to(x.dtype), (s2 - s1 * s1).to(x.dtype))
         return _call_struct("bjx_batchnorm_train_apply", x, dim, True, per_sample, want_ladj,
                             (_ptr(b), _ptr(logs), _ptr(self.m), _ptr(self.v), self.eps, self.mtm, _ptr(stats)), (dim,))
 
@@ -1929,6 +1934,8 @@ def vjp(b, x, out_bar, ladj_bar=None):
         s_ = torch.exp(_param(base.logs, like)) / torch.sqrt(_param(base.v, like) + base.eps)
         aff = Shift(_param(base.b, like)) @ Scale(s_) @ Shift(-_param(base.m, like))
         return vjp(inverse(aff) if inv else aff, x, out_bar, ladj_bar)
+    if isinstance(base, InvertibleBatchNorm) and not inv:
+        return _vjp_params_batchnorm_training(base, x, out_bar, ladj_bar)[0]      # training mode: the batch statistics depend on x
     if not isinstance(base, OrderedBijector):
         raise NotImplementedError(f"no device pullback for {b!r} yet (SURVEY.md §8f f-1)")
     xc, dim, batch, vec = _prep(x)
@@ -2223,7 +2230,7 @@ def _vjp_params_batchnorm(bn, x, out_bar, ladj_bar=None):
     ONE pass: the input pullback of the affine chain with its row moments (bjx_stacked_vjp_moments: Σ_n x̄ and Σ_n x̄·x),
     from which b̄ = Σx̄/γ and l̄ogs = Σx̄x − m Σx̄ + Σℓ̄.  -> (x_bar, {"b": ..., "logs": ...})."""
     if istraining():
-        raise NotImplementedError("parameter pullback of InvertibleBatchNorm: eval mode only (the training-mode statistics are not differentiated)")
+        return _vjp_params_batchnorm_training(bn, x, out_bar, ladj_bar)
     xc, dim, batch, vec = _prep(x)
     if vec:
         raise ValueError("InvertibleBatchNorm needs an input with at least 2 dimensions")
@@ -2235,6 +2242,42 @@ def _vjp_params_batchnorm(bn, x, out_bar, ladj_bar=None):
     lsum = lb.double().sum() if lb is not None else 0.0
     b_bar = (m1 / gam.double()).to(xc.dtype)
     logs_bar = (m2 - m.double() * m1 + lsum).to(xc.dtype)
+    return xb, {"b": b_bar, "logs": logs_bar}
+
+
+def _vjp_params_batchnorm_training(bn, x, out_bar, ladj_bar=None):
+    """InvertibleBatchNorm in TRAINING mode (normalise.jl:51-60): the batch mean and variance are functions of x, so the input
+    cotangent has the two centring terms of batch normalisation plus the derivative of -½ Σℓ̄ log(v + ε):
+        x̄ = γ/σ [ȳ − mean ȳ − x̂ mean(ȳ x̂)] − (Σℓ̄/N) x̂/σ,   b̄ = Σ ȳ,   l̄ogs = γ Σ ȳ x̂ + Σℓ̄
+    Two passes over (ȳ, x): bjx_row_moments (Σȳ, Σȳ·x per channel) → one all-reduce of 2·dim+2 doubles when the bijector is
+    sharded (`sync`) → bjx_batchnorm_train_vjp.  Uses the batch statistics of the LAST training-mode forward call on this
+    bijector (the pullback of that call).  -> (x_bar, {"b": ..., "logs": ...})."""
+    xc, dim, batch, vec = _prep(x)
+    if vec:
+        raise ValueError("InvertibleBatchNorm needs an input with at least 2 dimensions")
+    gc, gdim, gbatch, _ = _prep(out_bar)
+    if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:
+        raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
+    st = getattr(bn, "_batch_stats", None)
+    if st is None or st[0].numel() != dim or st[0].dtype != xc.dtype:
+        raise RuntimeError("training-mode pullback of InvertibleBatchNorm: run the training-mode forward pass on this batch first")
+    mean_b, var_b = st
+    ctx = context(xc.device)
+    lib = L.load()
+    mom = torch.empty(2 * dim + 2, dtype=torch.float64, device=xc.device)       # (Σȳ, Σȳx, N, Σℓ̄): ONE bucket for the collective
+    L.check(ctx.h, lib.bjx_row_moments(ctx.h, _dt(xc), _ptr(gc), _ptr(xc), _ptr(mom), dim, batch), "bjx_row_moments")
+    lb = _ladj_bar(ladj_bar, batch, xc)
+    mom[2 * dim + 1] = lb.double().sum() if lb is not None else 0.0
+    if bn.sync is not None and bn.sync is not False:
+        from . import shard as _shard
+
+        _shard.allreduce_logabsdetjac(mom, None if bn.sync is True else bn.sync)
+    logs = _param(bn.logs, xc)
+    xb = _empty(dim, batch, xc, vec)
+    b_bar, logs_bar = torch.empty(dim, dtype=xc.dtype, device=xc.device), torch.empty(dim, dtype=xc.dtype, device=xc.device)
+    rc = lib.bjx_batchnorm_train_vjp(ctx.h, _dt(xc), _ptr(logs), _ptr(mean_b), _ptr(var_b), float(bn.eps), _ptr(mom), mom.data_ptr() + 8 * (2 * dim + 1),
+                                     _ptr(xc), _ptr(gc), _ptr(xb), _ptr(b_bar), _ptr(logs_bar), dim, batch)
+    L.check(ctx.h, rc, "bjx_batchnorm_train_vjp")
     return xb, {"b": b_bar, "logs": logs_bar}
 
 
@@ -2293,16 +2336,36 @@ def columnwise(f):
 
 # ------------------------------------------------------------------ TransformedDistribution
 class MvNormal:
-    """Diagonal-covariance base distribution `MvNormal(μ, Diagonal(σ.^2))`; `MvNormal(dim)` is the standard normal
-    (the base of every flow in the reference's docs/tests, e.g. test/normalising_flows.jl:74-91)."""
+    """Base distribution of a `TransformedDistribution` (src/transformed_distribution.jl:159-240 takes any `MvNormal`):
+    `MvNormal(dim)` the standard normal (the base of every flow in the reference's docs/tests, e.g. test/normalising_flows.jl:74-91),
+    `MvNormal(μ, σ)` the diagonal `MvNormal(μ, Diagonal(σ.^2))`, `MvNormal(μ, cov=Σ)` / `MvNormal(μ, scale_tril=L)` a FULL
+    covariance Σ = L Lᵀ: whitening is the matrix `Scale` of scale.jl:14-36 (x ↦ L \ (x − μ), log-det −logabsdet L: bjx_scale_matrix)."""
 
-    def __init__(self, mu, sigma=None):
-        if isinstance(mu, int) and sigma is None:
+    def __init__(self, mu, sigma=None, cov=None, scale_tril=None):
+        self.scale_tril = None
+        if isinstance(mu, int) and sigma is None and cov is None and scale_tril is None:
             self.dim, self.mu, self.sigma = mu, None, None
         else:
             self.mu = torch.as_tensor(mu).reshape(-1)
             self.sigma = None if sigma is None else torch.as_tensor(sigma).reshape(-1)
             self.dim = self.mu.numel()
+            if cov is not None or scale_tril is not None:
+                if sigma is not None or (cov is not None and scale_tril is not None):
+                    raise ValueError("MvNormal: give ONE of sigma (diagonal), cov or scale_tril")
+                Lm = torch.linalg.cholesky(torch.as_tensor(cov)) if cov is not None else torch.as_tensor(scale_tril)   # dim x dim: host-side prep, once
+                if tuple(Lm.shape) != (self.dim, self.dim):
+                    raise ValueError(f"DimensionMismatch: covariance factor of shape {tuple(Lm.shape)} for a mean of length {self.dim}")
+                self.scale_tril = Lm
+
+    def _tril_on(self, like):
+        """(Scale(L) as a bijector, -L⁻¹μ) on the device / dtype of `like`, cached"""
+        key = (like.device, like.dtype, id(self.scale_tril), self.scale_tril._version, id(self.mu), self.mu._version)
+        if getattr(self, "_tril_key", None) != key:
+            Ld = self.scale_tril.to(device=like.device, dtype=like.dtype)
+            mu = self.mu.to(device=like.device, dtype=like.dtype)
+            self._tril_cache = (Scale(colmajor(Ld)), -torch.linalg.solve_triangular(Ld, mu[:, None], upper=False)[:, 0].contiguous(), mu)
+            self._tril_key = key
+        return self._tril_cache
 
     def _whiten_ops(self):
         """x -> (x - μ)/σ as chain ops; SCALE_INV's log-det supplies the -Σ log σ of the density."""
@@ -2348,6 +2411,19 @@ def logpdf(td: TransformedDistribution, y, reference_shape: bool = False):
     scalar log-det for the whole matrix, which it adds to every column (SURVEY.md §8a″)."""
     ib = inverse(td.transform)
     d = td.dist
+    if getattr(d, "scale_tril", None) is not None:
+        # full covariance: x = b⁻¹(y); z = L \ x (bjx_scale_matrix, log-det −logabsdet L per column); then the standard-normal
+        # density of z − L⁻¹μ accumulated without storing anything (one chain launch, store=False)
+        if ib is identity:
+            x, lj = y, None
+        else:
+            x, lj = ib._wlj(y, per_sample=True) if not isinstance(ib, ComposedFunction) else with_logabsdet_jacobian(ib, y, per_sample=True)
+            if hasattr(x, "result"):
+                x, lj = x.result, x.logabsdetjac
+        sc, shift, _ = d._tril_on(x)
+        z, lz = inverse(sc)._wlj(x, per_sample=True)
+        lp = _run_chain([(L.OP_SHIFT, shift, None), (L.OP_STDNORMAL_LOGPDF, None, None)], z, True, True, store=False)[1]
+        return lp + lz if lj is None else lp + lz + lj
     base = d._whiten_ops() + [(L.OP_STDNORMAL_LOGPDF, None, None)]
     if reference_shape:
         x, lj = with_logabsdet_jacobian(ib, y)
@@ -2374,6 +2450,16 @@ def rand(td: TransformedDistribution, n: int, seed: int = 0, device=None, dtype=
     dim = td.dist.dim
     z = torch.empty((n, dim), dtype=dtype, device=device).T
     ctx = context(device)
+    if getattr(td.dist, "scale_tril", None) is not None:
+        # full covariance: base samples, x = μ + L z (bjx_scale_matrix, then the shift fused into the transform's chain when it has one)
+        L.check(ctx.h, L.load().bjx_fill_normal(ctx.h, _dt(z), _ptr(z), dim, n, col0, seed, 0.0, 1.0), "bjx_fill_normal")
+        sc, _, mu = td.dist._tril_on(z)
+        xz = transform(sc, z)
+        ops = _fused_ops(td.transform) if td.transform is not identity else []
+        if ops is not None and len(ops) + 1 <= L.BJX_MAX_OPS:
+            return _run_chain([(L.OP_SHIFT, mu, None)] + list(ops), xz, False, False, out_y=xz)[0]
+        _run_chain([(L.OP_SHIFT, mu, None)], xz, False, False, out_y=xz)
+        return transform(td.transform, xz)
     color = td.dist._color_ops()
     ops = _fused_ops(td.transform)
     if ops is not None and len(ops) + len(color) <= L.BJX_MAX_OPS and fused:

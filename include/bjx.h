@@ -285,6 +285,20 @@ int bjx_batchnorm_train_apply(bjx_ctx* ctx, bjx_dtype dt, const void* b, const v
                               double eps, double mtm, const double* stats, const void* in, void* out, void* ladj_ps,
                               double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
 
+/* pullback of InvertibleBatchNorm in TRAINING mode (normalise.jl:51-60: the batch mean and the biased batch
+ * variance are functions of x; the reference leaves the adjoint to the AD package).  With sigma = sqrt(var + eps),
+ * xh = (in - mean)/sigma, gamma = exp(logs):
+ *   in_bar   = gamma/sigma [out_bar - mean_n(out_bar) - xh mean_n(out_bar xh)] - (sum_n ladj_bar / N) xh / sigma
+ *   b_bar    = sum_n out_bar,      logs_bar = gamma sum_n out_bar xh + sum_n ladj_bar
+ * mean, var: device T[dim], the batch statistics the forward pass normalised with (from the sums of bjx_batchnorm_stats).
+ * moments: device double[2 dim + 1] = (sum_n out_bar, sum_n out_bar*in, N) of the WHOLE batch: bjx_row_moments(out_bar, in) on
+ * this rank's columns, summed over the ranks by the host — the one extra all-reduce of a sharded training step.
+ * ladj_bar_sum: device double[1] = sum_n ladj_bar over the whole batch, or NULL (= 0).  in_bar (may not alias in), b_bar,
+ * logs_bar (device T[dim]) may each be NULL. */
+int bjx_batchnorm_train_vjp(bjx_ctx* ctx, bjx_dtype dt, const void* logs, const void* mean, const void* var, double eps,
+                            const double* moments, const double* ladj_bar_sum, const void* in, const void* out_bar,
+                            void* in_bar, void* b_bar, void* logs_bar, int64_t dim, int64_t batch);
+
 /* ------------------------------- F4: table lookup                         */
 /* RationalQuadraticSpline with matrix parameters, rational_quadratic_spline.jl:128-367,
  * applied to every column of X[dim,batch].  widths/heights/derivs: device T[dim, n_knots]

@@ -536,6 +536,23 @@ function batchnorm_train!(bn::InvertibleBatchNorm, x::ROCMatrix{T}; allreduce! =
     return y, lps
 end
 
+# Pullback of the training-mode InvertibleBatchNorm (normalise.jl:51-60: batch mean and biased batch variance are functions of
+# x).  (mean, var) = the batch statistics of the forward pass; moments = Σ_n ȳ, Σ_n ȳ·x, N of the WHOLE batch (row_moments on this
+# rank's columns, then the host's all-reduce); ℓ̄sum = Σ_n ℓ̄.  -> (x̄, b̄, l̄ogs)
+function batchnorm_train_pullback(bn::InvertibleBatchNorm, mean::ROCVector{T}, var::ROCVector{T}, x::ROCMatrix{T}, ȳ::ROCMatrix{T},
+                                  ℓ̄sum::Real; allreduce! = identity) where {T<:BjxFloat}
+    d, n = size(x)
+    moments = row_moments(ȳ, x)
+    allreduce!(moments)
+    ls = ROCArray{Float64}([Float64(ℓ̄sum)])
+    x̄ = similar(x); logs = ondevice(T, bn.logs); b̄ = similar(logs); l̄ogs = similar(logs)
+    GC.@preserve logs mean var moments ls x ȳ x̄ b̄ l̄ogs check(ccall((:bjx_batchnorm_train_vjp, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+        ctx().h, dtype(T), devptr(logs), devptr(mean), devptr(var), Float64(bn.eps), Ptr{Cdouble}(pointer(moments)), Ptr{Cdouble}(pointer(ls)),
+        devptr(x), devptr(ȳ), devptr(x̄), devptr(b̄), devptr(l̄ogs), d, n), "bjx_batchnorm_train_vjp")
+    return x̄, b̄, l̄ogs
+end
+
 # ---------------------------------------------------------------- Stacked (SURVEY.md §8f f-4)
 # stacked.jl:27-252: every segment whose bijector is a fusable elementwise chain goes into ONE launch.
 segment(rin, rout, o) = BjxSegment(first(rin) - 1, first(rout) - 1, length(rin), length(o), 0, ntuple(k -> k <= length(o) ? o[k] : NOOP, 4))

@@ -604,6 +604,35 @@ def batchnorm_train(b, logs, m, v, eps, mtm, x):
     return result, ladj, m_new, v_new
 
 
+def mvnormal_full_logpdf(x, mu, cov):
+    """Per-column log-density of MvNormal(mu, cov) with a FULL covariance — the `logpdf(td.dist, x)` term of
+    src/transformed_distribution.jl:165-169 (the density itself lives in Distributions.jl / PDMats.jl, un-vendored: its
+    textbook formula through the Cholesky factor).  numpy, Float64."""
+    x = np.asarray(x, dtype=np.float64)
+    mu, cov = np.asarray(mu, dtype=np.float64).reshape(-1), np.asarray(cov, dtype=np.float64)
+    Lc = np.linalg.cholesky(cov)
+    z = np.linalg.solve(Lc, x - mu[:, None])
+    return -0.5 * np.sum(z * z, axis=0) - np.sum(np.log(np.diag(Lc))) - 0.5 * x.shape[0] * np.log(2.0 * np.pi)
+
+
+def batchnorm_train_vjp(logs, eps, x, out_bar, ladj_bar):
+    """Pullback of `batchnorm_train` (normalise.jl:51-60: batch mean / biased batch variance are functions of x; the reference
+    leaves this adjoint to the AD package) — numpy Float64 restatement of the closed form, pinned by central differences of
+    `batchnorm_train` in tests/test_oracle_golden.py.  -> (x_bar, b_bar, logs_bar)."""
+    x, g = np.asarray(x, dtype=np.float64), np.asarray(out_bar, dtype=np.float64)
+    logs = np.asarray(logs, dtype=np.float64)
+    lb = np.zeros(x.shape[1]) if ladj_bar is None else np.asarray(ladj_bar, dtype=np.float64)
+    n = x.shape[1]
+    m = x.mean(axis=1)
+    v = ((x - m[:, None]) ** 2).sum(axis=1) / n
+    sig = np.sqrt(v + eps)
+    xh = (x - m[:, None]) / sig[:, None]
+    gam = np.exp(logs)
+    L = lb.sum()
+    x_bar = (gam / sig)[:, None] * (g - g.mean(axis=1)[:, None] - xh * (g * xh).mean(axis=1)[:, None]) - (L / n) * xh / sig[:, None]
+    return x_bar, g.sum(axis=1), gam * (g * xh).sum(axis=1) + L
+
+
 # ------------------------------------------------------------------ SURVEY.md §8(f) f-3
 def mvnormal_diag_logpdf(x, mu=None, sigma=None):
     """Per-column log-density of MvNormal(mu, Diagonal(sigma.^2)) — the `logpdf(td.dist, x)` term of

@@ -2789,6 +2789,66 @@ def test_batchnorm_training_shard_emulation(bj, orc, dim, N, dt):
     assert np.array_equal(host(Y), Y1) and np.array_equal(host(lps), l1) and np.array_equal(host(md), m1) and np.array_equal(host(vd), v1)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,N,flow", [(6, 1000, "chain"), (16, 4099, "planar"), (3, 50, "none"), (150, 301, "chain")])
+def test_logpdf_and_rand_with_a_full_covariance_base(bj, orc, dim, N, flow, dt):
+    """src/transformed_distribution.jl:159-240 with a FULL-covariance MvNormal base (f-3 beyond the diagonal case): the matrix
+    `Scale` whitens / colours the batch; logpdf against the oracle's density + the oracle's inverse flow; rand's first two moments."""
+    r = rng(dim * 17 + N)
+    A = r.normal(size=(dim, dim)) / math.sqrt(dim)
+    cov, mu = A @ A.T + 0.3 * np.eye(dim), r.normal(size=dim)
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    base = bj.MvNormal(torch.tensor(mu, dtype=tdt), cov=torch.tensor(cov, dtype=tdt))
+    if flow == "chain":
+        b = bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5)
+        ylog = r.normal(size=(dim, N))
+        y = np.asfortranarray(np.exp(ylog).astype(dt))
+        x_ref = (np.log(y.astype(np.float64)) - 0.1) / 0.5
+        lj_ref = -(np.log(y.astype(np.float64)).sum(axis=0) + dim * math.log(0.5))       # inverse: -(Σ log y + Σ log 0.5)
+    elif flow == "planar":
+        w, u, bb = r.normal(size=(dim, 2)) / 4, r.normal(size=(dim, 2)) / 4, r.normal(size=2)
+        b = bj.PlanarLayer(torch.tensor(w, dtype=tdt), torch.tensor(u, dtype=tdt), torch.tensor(bb, dtype=tdt))
+        y = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+        x_ref, lj_ref = orc.planar(w, u, bb, y.astype(np.float64), inverse=True)
+    else:
+        b = None
+        y = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+        x_ref, lj_ref = y.astype(np.float64), np.zeros(N)
+    td = bj.transformed(base, b)
+    lp = bj.logpdf(td, dev(y))
+    ref = orc.mvnormal_full_logpdf(x_ref, mu, cov) + lj_ref
+    close(host(lp), ref, dt, scale=dim * (20.0 if dt == np.float32 else 1.0), what="logpdf, full covariance")
+    if flow == "none":
+        smp = host(bj.rand(td, 1 << 16, seed=5, dtype=tdt)).astype(np.float64)
+        assert smp.shape == (dim, 1 << 16)
+        np.testing.assert_allclose(smp.mean(axis=1), mu, atol=0.03 * np.sqrt(np.diag(cov)).max() + 0.01)
+        np.testing.assert_allclose(np.cov(smp), cov, atol=0.05 * np.abs(cov).max())
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,N", [(5, 37), (64, 4099), (13, 1000)])
+def test_batchnorm_training_pullback(bj, orc, dim, N, dt):
+    """SURVEY.md §8(f) f-1 remainder: gradients THROUGH the batch statistics of training-mode InvertibleBatchNorm
+    (normalise.jl:51-60; bjx_row_moments + bjx_batchnorm_train_vjp) against the FD-pinned oracle."""
+    r = rng(dim * 31 + N)
+    x = np.asfortranarray((r.normal(size=(dim, N)) * 1.5 + 0.7).astype(dt))
+    b, logs = r.normal(size=dim).astype(dt), (0.2 * r.normal(size=dim)).astype(dt)
+    g, lb = np.asfortranarray(r.normal(size=(dim, N)).astype(dt)), r.normal(size=N).astype(dt)
+    bn = bj.InvertibleBatchNorm(torch.tensor(b), torch.tensor(logs), torch.zeros(dim, dtype=torch.from_numpy(b).dtype), torch.ones(dim, dtype=torch.from_numpy(b).dtype), eps=1e-5, mtm=0.1)
+    with bj.training():
+        with pytest.raises(RuntimeError):
+            bj.vjp_params(bn, dev(x), dev(g), dev(lb))                # no forward pass yet: no batch statistics to differentiate
+        bj.with_logabsdet_jacobian(bn, dev(x))
+        xb, grads = bj.vjp_params(bn, dev(x), dev(g), dev(lb))
+        xb2 = bj.vjp(bn, dev(x), dev(g), dev(lb))
+    xr, br, lr = orc.batchnorm_train_vjp(logs.astype(np.float64), 1e-5, x, g, lb)
+    scale = float(np.abs(xr).max())
+    close(host(xb), xr, dt, scale=max(scale, 1.0) * (4 if dt == np.float32 else 1), what="x_bar")
+    assert np.array_equal(host(xb2), host(xb))
+    close(host(grads["b"]), br, dt, scale=np.sqrt(N) * 4, what="b_bar")
+    close(host(grads["logs"]), lr, dt, scale=np.sqrt(N) * 8, what="logs_bar")
+
+
 def test_batchnorm_training_large_mean_float64(bj):
     """one-pass Σx² - mean² cancels for Float64 data with |mean| >> std; the shifted sums (shift = moving
     mean) keep the 1e-6 bar: mean 1e6, std 1e-2, moving mean near the data."""

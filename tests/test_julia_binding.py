@@ -92,9 +92,9 @@ def _ccalls():
 
 def test_every_entry_point_is_ccalled_with_the_headers_types():
     protos = _prototypes()
-    assert len(protos) == 62, sorted(protos)
+    assert len(protos) == 63, sorted(protos)
     calls = _ccalls()
-    assert len(calls) >= 62
+    assert len(calls) >= 63
     seen = set()
     for name, ret, types in calls:
         assert name in protos, f"{name} is not declared in include/bjx.h"
@@ -228,7 +228,7 @@ def test_pullback_rules_cover_every_vjp_entry():
     for want in RRULES_WLJ:
         assert want.replace(" ", "") in heads, f"no rrule(::typeof(with_logabsdet_jacobian), ::{want}, …); have {heads}"
     vjp_entries = [n for n in _prototypes() if "_vjp" in n or n == "bjx_row_moments"]
-    assert len(vjp_entries) == 15, vjp_entries
+    assert len(vjp_entries) == 16, vjp_entries
     called = {c[0] for c in _ccalls()}
     assert set(vjp_entries) <= called
 

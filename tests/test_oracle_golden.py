@@ -742,3 +742,42 @@ def test_pd_bijector_against_numpy_cholesky(orc):
     yv, l2 = orc.pd_vec(X)
     np.testing.assert_allclose(yv, np.concatenate([ref.T[:j + 1, j] for j in range(6)]), atol=1e-13)      # triu_to_vec(Y'), column-major
     assert abs(l2[0] - want) < 1e-12
+
+
+def test_batchnorm_training_pullback_is_the_gradient_of_the_training_forward(orc):
+    """oracle.batchnorm_train_vjp (closed form of the adjoint of normalise.jl:51-60, batch statistics differentiated) against
+    central differences of oracle.batchnorm_train: L = Σ ȳ·y + Σ ℓ̄·logabsdetjac, perturbing x, b and logs."""
+    r = np.random.default_rng(17)
+    d, n, eps = 5, 37, 1e-5
+    x = r.normal(size=(d, n)) * 1.7 + 0.4
+    b, logs = r.normal(size=d), 0.3 * r.normal(size=d)
+    g, lb = r.normal(size=(d, n)), r.normal(size=n)
+
+    def loss(x_, b_, logs_):
+        y, l, _, _ = orc.batchnorm_train(b_, logs_, np.zeros(d), np.ones(d), eps, 0.1, x_)
+        return float((g * y).sum() + (lb * l).sum())
+
+    xb, bb, lgb = orc.batchnorm_train_vjp(logs, eps, x, g, lb)
+    h = 1e-6
+    for (i, k) in [(0, 0), (2, 11), (4, 36), (1, 5)]:
+        xp, xm = x.copy(), x.copy()
+        xp[i, k] += h
+        xm[i, k] -= h
+        fd = (loss(xp, b, logs) - loss(xm, b, logs)) / (2 * h)
+        assert abs(fd - xb[i, k]) <= 2e-6 * max(1.0, abs(fd)), (i, k, fd, xb[i, k])
+    for c in range(d):
+        e = np.zeros(d)
+        e[c] = h
+        assert abs((loss(x, b + e, logs) - loss(x, b - e, logs)) / (2 * h) - bb[c]) <= 2e-6 * max(1.0, abs(bb[c]))
+        assert abs((loss(x, b, logs + e) - loss(x, b, logs - e)) / (2 * h) - lgb[c]) <= 2e-6 * max(1.0, abs(lgb[c]))
+
+
+def test_full_covariance_normal_density_against_scipy(orc):
+    from scipy.stats import multivariate_normal
+
+    r = np.random.default_rng(3)
+    d = 6
+    A = r.normal(size=(d, d))
+    cov, mu = A @ A.T + 0.5 * np.eye(d), r.normal(size=d)
+    x = r.normal(size=(d, 40)) * 2.0
+    np.testing.assert_allclose(orc.mvnormal_full_logpdf(x, mu, cov), multivariate_normal(mean=mu, cov=cov).logpdf(x.T), rtol=1e-12, atol=1e-12)
