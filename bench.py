@@ -363,6 +363,8 @@ def measure(env, name, steps, warmup, scaling, log2_batch=None):
     lib = bj._lib.load()
 
     def barrier():
+        if getattr(env, "library_collective", False):          # the library's stream first, under its watchdog
+            bj._lib.check(ctx.h, lib.bjx_synchronize(ctx.h), "bjx_synchronize")
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -512,8 +514,9 @@ def main():
 
     env.bj = bj
     if a.collective == "bjx" and world > 1:
-        bj.shard.init_comm(env.device)             # ncclUniqueId broadcast through torch.distributed, then RCCL inside the library
-        bj.shard.use_library_collective(True)
+        bj.shard.init_comm(env.device, timeout_ms=60000)   # ncclUniqueId broadcast through torch.distributed, then RCCL inside the library;
+        bj.shard.use_library_collective(True)               # watchdog: a stuck collective is an error after 60 s, not a hang
+        env.library_collective = True
 
     head = measure(env, a.workload, a.steps, a.warmup, a.scaling, a.log2_batch)
     rows, strong = [], []

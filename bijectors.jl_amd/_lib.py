@@ -55,6 +55,7 @@ _vp, _i, _i64, _u32, _u64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_
 _tail = [_vp, _vp, _i64, _i64, _u32]  # ladj_ps, ladj_sum, dim/K, batch, flags
 
 BJX_OPT_INKERNEL_FINALIZE = 1
+BJX_OPT_COLLECTIVE_TIMEOUT_MS = 2
 
 # name -> (restype, argtypes); mirrors include/bjx.h line by line
 SIGNATURES = {

@@ -3,7 +3,9 @@
 
 #include <cstdlib>
 
+#include <chrono>
 #include <new>
+#include <thread>
 
 #include "bjx_internal.h"
 
@@ -183,12 +185,39 @@ BJX_API size_t bjx_workspace_bytes(bjx_ctx* ctx) {
 BJX_API int bjx_set_option(bjx_ctx* ctx, int option, int value) {
   if (!ctx) return BJX_ERR_ARG;
   if (option == BJX_OPT_INKERNEL_FINALIZE) { ctx->opt_inkernel_fin = value ? 1 : 0; return BJX_OK; }
+  if (option == BJX_OPT_COLLECTIVE_TIMEOUT_MS) {
+    BJX_REQUIRE(ctx, value >= 0, BJX_ERR_ARG, "BJX_OPT_COLLECTIVE_TIMEOUT_MS: milliseconds >= 0 (0 = wait for ever)");
+    ctx->collective_timeout_ms = value;
+    return BJX_OK;
+  }
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_set_option: unknown option %d", option);
 }
 
 BJX_API int bjx_synchronize(bjx_ctx* ctx) {
   if (!ctx) return BJX_ERR_ARG;
   BJX_REQUIRE(ctx, !ctx->capturing, BJX_ERR_UNSUPPORTED, "bjx_synchronize: a graph capture is open on this context");
+  if (ctx->comm && ctx->collective_timeout_ms > 0) {
+    // Watchdog (BJX_OPT_COLLECTIVE_TIMEOUT_MS): a rank that never arrives leaves ncclAllReduce spinning on the stream for ever.
+    // Poll instead of blocking; on time-out abort the communicator (ncclCommAbort releases the kernel) and report an error —
+    // the caller gets a status, not a hang.  Polling costs nothing on the launch path: only this explicit wait uses it.
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t q = hipStreamQuery(ctx->stream);
+      if (q == hipSuccess) return BJX_OK;
+      if (q != hipErrorNotReady) return bjx_fail(ctx, (int)q, "bjx_synchronize: %s", hipGetErrorString(q));
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (ms > (double)ctx->collective_timeout_ms) {
+        typedef int (*fn_abort)(void*);
+        fn_abort ab = (fn_abort)dlsym(ctx->rccl_handle, "ncclCommAbort");
+        if (ab) ab(ctx->comm);
+        ctx->comm = nullptr;
+        ctx->nranks = 1;
+        return bjx_fail(ctx, 1000 + 6 /* ncclRemoteError */, "bjx_synchronize: the stream did not drain within %d ms with a communicator of %s ranks attached: a collective is stuck (a rank did not arrive); the communicator was aborted",
+                        ctx->collective_timeout_ms, "several");
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(ms < 5.0 ? 20 : 500));
+    }
+  }
   BJX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return BJX_OK;
 }

@@ -1043,19 +1043,28 @@ __global__ void rqs_knot_vjp_kernel(const T* __restrict__ w, const T* __restrict
   // (plain read-add-write of the thread's own slots below; `ds_add_f32` on the same addresses was measured 2.7x SLOWER: 4.8 vs 1.75 ms)
   // one pass of look-ahead: the next pass's x, ȳ, ℓ̄ are in flight while this one is evaluated (a pass is a few hundred dependent
   // instructions behind three loads; without the look-ahead every pass paid the full memory latency first)
-  T nx = T(0), ng = T(0), nl = T(0);
-  bool nok = false;
-  auto fetch = [&](int64_t ps) {
+  // A ring of LA prefetched (x, ȳ, ℓ̄) triples in registers, slot u refilled for pass ps + LA·grid as soon as it has been consumed.
+  // LA = 1 (round 3 tried 4: 1.10 -> 1.54 ms at K = 16, dim = 32, 2^22 columns — the four unrolled bodies, ~300 instructions each with
+  // divergent early exits, cost more than the extra loads in flight bring: the kernel is bound by its LDS read-modify-write chains).
+  constexpr int LA = 1;
+  T qx[LA], qg[LA], ql[LA];
+  bool qok[LA];
+  auto fetch = [&](int64_t ps, T& fx, T& fg, T& fl, bool& fok) {
     const int64_t col = ps * cpp + cl;
-    nok = active && ps < passes && col < batch;
-    if (nok) { const int64_t idx = col * dim + row; nx = x[idx]; ng = gbar[idx]; nl = lbar ? lbar[col] : T(0); }
+    fok = active && ps < passes && col < batch;
+    fx = T(0); fg = T(0); fl = T(0);
+    if (fok) { const int64_t idx = col * dim + row; fx = x[idx]; fg = gbar[idx]; fl = lbar ? lbar[col] : T(0); }
   };
-  fetch(blockIdx.x);
-  for (int64_t ps = blockIdx.x; ps < passes; ps += gridDim.x) {
-    const bool ok = nok;
-    const T xin = nx;
-    T g = ng, lb = nl;
-    fetch(ps + gridDim.x);
+#pragma unroll
+  for (int u = 0; u < LA; ++u) fetch((int64_t)blockIdx.x + (int64_t)u * gridDim.x, qx[u], qg[u], ql[u], qok[u]);
+  for (int64_t ps0 = blockIdx.x; ps0 < passes; ps0 += (int64_t)LA * gridDim.x) {
+#pragma unroll
+  for (int u = 0; u < LA; ++u) {
+    const int64_t ps = ps0 + (int64_t)u * gridDim.x;
+    const bool ok = qok[u];
+    const T xin = qx[u];
+    T g = qg[u], lb = ql[u];
+    fetch(ps + (int64_t)LA * gridDim.x, qx[u], qg[u], ql[u], qok[u]);
     if (!ok) continue;
     const int64_t oidx = (ps * cpp + cl) * dim + row;
     const T wK = w_[(K - 1) * st], hK = h_[(K - 1) * st];
@@ -1131,6 +1140,7 @@ __global__ void rqs_knot_vjp_kernel(const T* __restrict__ w, const T* __restrict
     *ph1 = q3 + (A)gh_k1;
     *pd0 = q4 + (A)(k == 0 ? T(0) : g * y_dk + lb * l_dk);
     *pd1 = q5 + (A)(k == K - 1 ? T(0) : g * y_dk1 + lb * l_dk1);
+  }
   }
   __syncthreads();
   for (int64_t o = t; o < 3 * nk; o += nthr) {                         // o = (table*K + knot)*dim + row

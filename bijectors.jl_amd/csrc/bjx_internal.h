@@ -48,6 +48,7 @@ struct bjx_ctx {
   void* rccl_handle = nullptr;
   void* comm = nullptr;
   int nranks = 1, rank = 0;
+  int collective_timeout_ms = 0;   // BJX_OPT_COLLECTIVE_TIMEOUT_MS: watchdog of bjx_synchronize while a communicator is attached (0 = none)
   char err[512] = {0};
 };
 

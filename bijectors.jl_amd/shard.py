@@ -128,7 +128,7 @@ def vjp_params_sharded(b, x_shard: torch.Tensor, out_bar_shard: torch.Tensor, la
     return x_bar, allreduce_param_cotangents(grads, group)
 
 
-def init_comm(device: Optional[torch.device] = None, group=None) -> None:
+def init_comm(device: Optional[torch.device] = None, group=None, timeout_ms: int = 0) -> None:
     """Give this rank's context an RCCL communicator (bjx_comm_init) so that entry points with an
     in-library collective — InvertibleBatchNorm in training mode: one all-reduce of the 2·dim+1 Float64
     batch sums, SURVEY.md §8(e) — see the GLOBAL batch.  The 128-byte ncclUniqueId is made on rank 0 and
@@ -151,3 +151,5 @@ def init_comm(device: Optional[torch.device] = None, group=None) -> None:
     dist.broadcast_object_list(box, src=0, group=group)
     ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
     L.check(ctx.h, L.load().bjx_comm_init(ctx.h, world, rank, ident), "bjx_comm_init")
+    if timeout_ms > 0:        # watchdog of bjx_synchronize: a collective some rank never joins becomes an error, not a hang
+        L.check(ctx.h, L.load().bjx_set_option(ctx.h, L.BJX_OPT_COLLECTIVE_TIMEOUT_MS, int(timeout_ms)), "bjx_set_option")

@@ -93,7 +93,13 @@ int bjx_synchronize(bjx_ctx* ctx);
  * launches; same bits either way (tests/test_gpu_parity.py).  Default 0: on MI355X the hand-off makes every block wait for its
  * own output stores and adds a serial tail behind the slowest block, which costs more than the ~8 us of extra launches
  * (profiles/r03_finalize_ab.txt: 16.6 -> 26.1 us per call of BASELINE configs[0]). */
-enum { BJX_OPT_INKERNEL_FINALIZE = 1 };
+enum {
+  BJX_OPT_INKERNEL_FINALIZE = 1,
+  /* Watchdog of the library's own collective (bjx_comm_init + bjx_allreduce_sum_f64): with a communicator attached,
+   * bjx_synchronize polls the stream for at most `value` milliseconds; on time-out it aborts the communicator (ncclCommAbort) and
+   * returns 1000 + ncclRemoteError instead of hanging on a rank that never arrived.  0 (default) = wait for ever. */
+  BJX_OPT_COLLECTIVE_TIMEOUT_MS = 2
+};
 int bjx_set_option(bjx_ctx* ctx, int option, int value);
 /* Stream of BJX_INPUT_STDNORMAL: element (row, col) of a call draws value number (col0 + col) * dim + row of `seed`. */
 int bjx_set_rng(bjx_ctx* ctx, uint64_t seed, int64_t col0);

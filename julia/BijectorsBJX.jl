@@ -89,6 +89,8 @@ end
 set_stream!(stream=AMDGPU.stream()) = check(ccall((:bjx_set_stream, libbjx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx().h, stream.stream), "bjx_set_stream")
 synchronize() = check(ccall((:bjx_synchronize, libbjx), Cint, (Ptr{Cvoid},), ctx().h), "bjx_synchronize")
 workspace_bytes() = Int(ccall((:bjx_workspace_bytes, libbjx), Csize_t, (Ptr{Cvoid},), ctx().h))
+const BJX_OPT_COLLECTIVE_TIMEOUT_MS = Cint(2)
+collective_timeout!(ms::Integer) = check(ccall((:bjx_set_option, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().h, BJX_OPT_COLLECTIVE_TIMEOUT_MS, Cint(ms)), "bjx_set_option")   # watchdog of synchronize()
 inkernel_finalize!(on::Bool) = check(ccall((:bjx_set_option, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().h, BJX_OPT_INKERNEL_FINALIZE, Cint(on)), "bjx_set_option")
 
 dims(x::ROCVector) = (length(x), 1)

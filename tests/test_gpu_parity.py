@@ -940,6 +940,20 @@ def test_rccl_communicator_single_rank(bj):
         L.check(h, lib.bjx_allreduce_sum_f64(h, C.c_void_p(v.data_ptr()), 3), "bjx_allreduce_sum_f64")
         L.check(h, lib.bjx_synchronize(h), "bjx_synchronize")
         assert v.tolist() == [1.25, -3.5, 7.0]
+        # watchdog (BJX_OPT_COLLECTIVE_TIMEOUT_MS): with a communicator attached, a stream that does not drain in time is an
+        # ERROR from bjx_synchronize (communicator aborted), not a hang — here a 1.5 s spin kernel stands in for the stuck collective
+        L.check(h, lib.bjx_set_option(h, L.BJX_OPT_COLLECTIVE_TIMEOUT_MS, 100), "bjx_set_option")
+        L.check(h, lib.bjx_synchronize(h), "bjx_synchronize")                  # an idle stream passes at once
+        with torch.cuda.stream(stream):
+            torch.cuda._sleep(int(3.6e9))
+        import time as _t
+        t0 = _t.perf_counter()
+        rc = lib.bjx_synchronize(h)
+        waited = _t.perf_counter() - t0
+        assert rc == 1006 and b"stuck" in lib.bjx_last_error(h), (rc, lib.bjx_last_error(h))
+        assert 0.09 <= waited < 10.0, waited           # (ncclCommAbort itself waits for THIS stand-in kernel; a stuck collective it releases)
+        stream.synchronize()
+        L.check(h, lib.bjx_allreduce_sum_f64(h, C.c_void_p(v.data_ptr()), 3), "bjx_allreduce_sum_f64")     # no communicator any more: single shard, a no-op
         L.check(h, lib.bjx_comm_destroy(h), "bjx_comm_destroy")
     finally:
         lib.bjx_destroy(h)
