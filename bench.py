@@ -45,14 +45,14 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--workload", default="c2", choices=["c1", "c2", "c2v", "copy", "c3", "c4", "c5a", "c5b", "vcorr", "pdvec"])
+    p.add_argument("--workload", default="c2", choices=["c1", "c2", "c2v", "copy", "c3", "c4", "c5a", "c5b", "vcorr", "pdvec", "c2_f64", "c4_f64"])
     p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                    help="weak: the BASELINE batch PER GPU; strong: the BASELINE batch in total, split by shard_columns")
     p.add_argument("--collective", default="torch", choices=["torch", "bjx"],
                    help="who all-reduces the Float64 partial Σ logabsdetjac: torch.distributed (RCCL) or the library's own "
                         "communicator (bjx_comm_init + bjx_allreduce_sum_f64: the path a Julia host takes)")
     p.add_argument("--no-rows", action="store_true", help="only the headline workload (no per-config sub-lines)")
-    p.add_argument("--rows", default="c1,c3,c4,c5a,c5b")
+    p.add_argument("--rows", default="c1,c3,c4,c5a,c5b,c2_f64,c4_f64")
     p.add_argument("--log2-batch", type=int, default=None, help="override the batch (testing)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-log2-batch", type=int, default=None)
@@ -89,7 +89,7 @@ def fill_normal(bj, torch, t, col0, seed, mean=0.0, std=1.0):
 PREROLL_MS = float(os.environ.get("BJX_BENCH_PREROLL_MS", "60"))     # untimed clock-settling pre-roll before the timed steps (0 = off)
 
 # ---------------------------------------------------------------------------------- workloads
-DEFAULT_LOG2 = {"c1": 0, "c2": 24, "c2v": 24, "copy": 24, "c3": 22, "c4": 22, "c5a": 20, "c5b": 20, "vcorr": 18, "pdvec": 18}
+DEFAULT_LOG2 = {"c1": 0, "c2": 24, "c2v": 24, "copy": 24, "c3": 22, "c4": 22, "c5a": 20, "c5b": 20, "vcorr": 18, "pdvec": 18, "c2_f64": 24, "c4_f64": 22}
 
 
 def make_workload(name, bj, torch, device, rank, world, log2_batch, scaling="weak"):
@@ -159,6 +159,41 @@ def make_workload(name, bj, torch, device, rank, world, log2_batch, scaling="wea
         return dict(step=step, samples=N, total=total, bytes_per_sample=(2 * dim * 4 + 4) * 2, kernel="rqs_lds_kernel (forward + inverse launch)", dtype="f32",
                     label=f"RationalQuadraticSpline K=16 fwd+inverse+logabsdetjac Float32 dim={dim} {where}",
                     cfg={"workload": "RationalQuadraticSpline K=16 fwd+inv+logabsdetjac (BASELINE configs[2])", "dim": dim, "batch_per_gpu": N})
+    if name in ("c2_f64", "c4_f64"):
+        # Float64 sub-lines (Float64 is Turing's default and the dtype of the reference's own tests): the C2 chain
+        # and the C4 flow in Float64 at HALF the Float32 batch (the same bytes per launch)
+        f64 = torch.float64
+        N64 = max(1, N // 2)
+        if name == "c2_f64":
+            dim = 64
+            x = colmajor_empty(torch, dim, N64, f64, device)
+            y = colmajor_empty(torch, dim, N64, f64, device)
+            fill_normal(bj, torch, x, col0 // 2, seed=0)
+            b = bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5)
+
+            def step():
+                return sharded(b, x, out=y, per_sample=False)[2]
+
+            return dict(step=step, samples=N64, total=total // 2, bytes_per_sample=2 * dim * 8, kernel="chain_flat_kernel<double>", dtype="f64",
+                        label=f"with_logabsdet_jacobian(exp∘Shift∘Scale) Float64 dim={dim} batch=2^{lb - 1}/GPU",
+                        cfg={"workload": "Composed(Shift,Scale,Exp) fused fwd+logabsdetjac, Float64 (configs[1] in the reference's test dtype)", "dim": dim, "batch_per_gpu": N64})
+        dim, nl = 128, 8
+        x = colmajor_empty(torch, dim, N64, f64, device)
+        y = colmajor_empty(torch, dim, N64, f64, device)
+        fill_normal(bj, torch, x, col0 // 2, seed=0)
+        w, u = colmajor_empty(torch, dim, nl, f64, device), colmajor_empty(torch, dim, nl, f64, device)
+        bb = torch.empty(nl, dtype=f64, device=device)
+        fill_normal(bj, torch, w, 0, seed=200, std=1.0 / math.sqrt(dim))
+        fill_normal(bj, torch, u, 0, seed=201, std=1.0 / math.sqrt(dim))
+        fill_normal(bj, torch, bb, 0, seed=202)
+        flow = bj.PlanarLayer(w, u, bb)
+
+        def step():
+            return sharded(flow, x, out=y)[2]
+
+        return dict(step=step, samples=N64, total=total // 2, bytes_per_sample=2 * dim * 8 + 8, kernel="planar_mfma64_kernel", dtype="f64",
+                    label=f"8-layer PlanarLayer flow fused fwd+logabsdetjac Float64 dim={dim} batch=2^{lb - 1}/GPU",
+                    cfg={"workload": "8x PlanarLayer fused, Float64 (configs[3] in the reference's test dtype)", "dim": dim, "layers": nl, "batch_per_gpu": N64})
     if name == "c4":
         dim, nl = 128, 8
         x = colmajor_empty(torch, dim, N, f32, device)
@@ -253,6 +288,20 @@ def cpu_baseline(name, log2_batch, budget=8.0, variants=True):
             ops = [(orc.OP_SCALE, np.linspace(0.5, 1.5, dim), None), (orc.OP_SHIFT, np.full(dim, 0.1), None), (orc.OP_EXP, None, None)]
         fn = lambda: orc.chain(ops, x)
         sample = f"oracle chain (3 allocating passes, 1 thread) on Float32 64 x 2^{lb}"
+    elif name == "c2_f64":
+        lb = 19 if log2_batch is None else log2_batch
+        N, dim = 1 << lb, 64
+        x = np.asfortranarray(rng.standard_normal((dim, N)))
+        ops = [(orc.OP_SCALE, 0.5, None), (orc.OP_SHIFT, 0.1, None), (orc.OP_EXP, None, None)]
+        fn = lambda: orc.chain(ops, x)
+        sample = f"oracle chain (3 allocating passes, 1 thread) on Float64 64 x 2^{lb}"
+    elif name == "c4_f64":
+        lb = 15 if log2_batch is None else log2_batch
+        N, dim, nl = 1 << lb, 128, 8
+        w, u, b = rng.standard_normal((dim, nl)) / math.sqrt(dim), rng.standard_normal((dim, nl)) / math.sqrt(dim), rng.standard_normal(nl)
+        x = np.asfortranarray(rng.standard_normal((dim, N)))
+        fn = lambda: orc.planar(w, u, b, x)
+        sample = f"oracle 8 Planar layers (layer-by-layer passes, 1 thread) on Float64 128 x 2^{lb}"
     elif name == "c3":
         lb = 16 if log2_batch is None else log2_batch
         N, dim, K = 1 << lb, 32, 16

@@ -95,6 +95,21 @@ __device__ __forceinline__ void apply_kind(const int kind, Pack<T, V> (&p)[U], c
       BJX_FOR_UJ p[u].v[j] = F::rcp(a[UA == 1 ? 0 : u][j]) * p[u].v[j];
       break;
     case BJX_OP_LOGIT:  // logit.jl:15,24.  Float32: hardware log/rcp (the OCML versions make this op VALU-bound at 50 % of the roofline)
+      if constexpr (sizeof(T) == 8 && UA == 1) {
+        // Float64 with one parameter pack for the lane's U packs (scalars, or the same rows): two lean logs per element instead of
+        // two logs + two reciprocals (a lean log costs ~3.8 reciprocals, scripts/f64math_bench.hip): logit = log(x-a) - log(b-x),
+        // log-det term -(log(x-a) + log(b-x) - log(b-a)) with log(b-a) once per row of the pack.  Same limits at the bounds (±Inf).
+        T lw[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) lw[j] = F::log(b[0][j] - a[0][j]);
+        BJX_FOR_UJ {
+          const T x = p[u].v[j];
+          const T la = F::log(x - a[0][j]), lb = F::log(b[0][j] - x);
+          l[u] -= (la + lb) - lw[j];
+          p[u].v[j] = la - lb;
+        }
+        break;
+      }
       BJX_FOR_UJ {
         const T x = p[u].v[j];
         const T inv = F::rcp(b[UA == 1 ? 0 : u][j] - a[UA == 1 ? 0 : u][j]);
@@ -173,6 +188,16 @@ __device__ __forceinline__ bool kind_has_params(int kind) {
 template <class T, int V, int U, int ROWMODE, bool SAMEROW = false>
 __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim, T (&l)[U]) {
   const int kind = op.kind;
+  if constexpr (ROWMODE == 0 && sizeof(T) == 8) {
+    // scalar parameters, Float64: ONE parameter pack for the U packs (UA = 1) — lets the Logit stage take its two-log form
+    // (the Float32 instantiations keep the round-2 code path: the C2 headline kernel is not touched)
+    T a1[1][V], b1[1][V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { a1[0][j] = T(0); b1[0][j] = T(0); }
+    if (kind_has_params(kind)) load_params<T, V, ROWMODE>(op, r[0], dim, a1[0], b1[0]);
+    apply_kind<T, V, U, 1>(kind, p, a1, b1, l);
+    return;
+  }
   T a[U][V], b[U][V];
   if (kind_has_params(kind)) {
     if constexpr (SAMEROW && U > 1) {

@@ -249,6 +249,8 @@ int launch_seq_chunk(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps
   constexpr int C = 256 / (int)sizeof(T), VW = Vec16<T>::N;
   const bool table = (size_t)n_logk * sizeof(T) <= 40 * 1024;                  // taller: log(K-1-i) on the fly
   const size_t smem = ((size_t)64 * (C + 1) + (table ? (size_t)n_logk : 1)) * sizeof(T);
+  BJX_REQUIRE(ctx, (int64_t)64 * (ld_in > ld_out ? ld_in : ld_out) * (int64_t)sizeof(T) < ((int64_t)1 << 31), BJX_ERR_UNSUPPORTED,
+              "columns of %lld elements: a wave's 64 columns exceed the 2 GiB range of one buffer descriptor", (long long)(ld_in > ld_out ? ld_in : ld_out));
   const int64_t grid = (batch + 63) / 64;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
   if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
@@ -1813,6 +1815,7 @@ int simplex_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, c
     constexpr int CH = 128 / (int)sizeof(T);
     const bool table = (size_t)K * sizeof(T) <= 40 * 1024;
     const size_t smem_c = ((size_t)2 * 64 * (CH + 1) + (table ? (size_t)K : 1)) * sizeof(T);
+    BJX_REQUIRE(ctx, (int64_t)64 * K * (int64_t)sizeof(T) < ((int64_t)1 << 31), BJX_ERR_UNSUPPORTED, "bjx_simplex_vjp: K = %lld too large for one buffer descriptor per wave", (long long)K);
     const int64_t grid_c = (batch + 63) / 64;
     BJX_REQUIRE(ctx, grid_c < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
     {
