@@ -114,6 +114,12 @@ int bjx_ensure_partials(bjx_ctx* ctx, size_t n);
 int bjx_launch_finalize(bjx_ctx* ctx, int n_partials, double* ladj_sum, double host_const,
                         int use_dev_const, double dev_const_mult, uint32_t flags);
 
+// bjx_tall.hip: Ordered / Simplex on columns taller than the quad frames of bjx_seq.hip (G lanes per column, any height up to
+// 64 lanes x 128 bytes); *taken = false and nothing is launched when the shape is not for that kernel
+enum { BJX_TALL_ORDERED_FWD = 0, BJX_TALL_ORDERED_INV = 1, BJX_TALL_SIMPLEX_FWD = 2, BJX_TALL_SIMPLEX_INV = 3 };
+int bjx_tall_stream(bjx_ctx* ctx, bjx_dtype dt, int which, const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t rows_in,
+                    int64_t rows_out, int64_t batch, uint32_t flags, bool* taken);
+
 // ------------------------------------------------------------------ device math
 // Same definitions as the reference's third-party scalar functions (LogExpFunctions), see
 // oracle/bjx_oracle.cpp for the citations; thresholds are identical to the CPU restatement.

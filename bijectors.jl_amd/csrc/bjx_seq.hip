@@ -2521,6 +2521,12 @@ int ordered_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, dou
                             : launch_quad_stream<T>(ctx, QOrderedInv<T>{}, in, out, ladj_ps, ladj_sum, dim, batch, flags, &taken);
     if (rc || taken) return rc;
   }
+  {
+    bool taken = false;                                                // taller than the quad frames: G lanes per column (bjx_tall.hip)
+    const int rc = bjx_tall_stream(ctx, sizeof(T) == 4 ? BJX_F32 : BJX_F64, inverse ? BJX_TALL_ORDERED_INV : BJX_TALL_ORDERED_FWD, in, out, ladj_ps,
+                                   ladj_sum, dim, dim, batch, flags, &taken);
+    if (rc || taken) return rc;
+  }
   if (!inverse) return launch_seq<T>(ctx, OrderedFwd<T>{}, in, out, ladj_ps, ladj_sum, dim, dim, batch, 0, flags);
   return launch_seq<T>(ctx, OrderedInv<T>{}, in, out, ladj_ps, ladj_sum, dim, dim, batch, 0, flags);
 }
@@ -2555,6 +2561,9 @@ int simplex_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, dou
         rc = want ? launch_quad_stream<T>(ctx, QSimplexInv<T, true, 2>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken)
                   : launch_quad_stream<T>(ctx, QSimplexInv<T, false, 2>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken);
     }
+    if (rc || taken) return rc;
+    rc = bjx_tall_stream(ctx, sizeof(T) == 4 ? BJX_F32 : BJX_F64, inverse ? BJX_TALL_SIMPLEX_INV : BJX_TALL_SIMPLEX_FWD, in, out, ladj_ps, ladj_sum,
+                         ri, ro, batch, flags, &taken);              // taller than the quad frames: G lanes per column (bjx_tall.hip)
     if (rc || taken) return rc;
   }
   if (!inverse) {

@@ -23,6 +23,7 @@ for K in tuple(int(v) for v in os.environ.get("BJX_BENCH_KS", "64,100,128,200,25
             ("OrderedBijector", lambda: bj.with_logabsdet_jacobian(bj.OrderedBijector(), xo, per_sample=True), 2 * K * 4 + 4),
             ("vjp(SimplexBijector)", lambda: bj.vjp(sb, x, gy, lb), (3 * K - 1) * 4 + 4),
             ("vjp(inverse(SimplexBijector))", lambda: bj.vjp(bj.inverse(sb), y, gx, lb), (3 * K - 2) * 4 + 4)]
+    if os.environ.get("BJX_PROBE_ROWS") == "fwd": rows = rows[:3]
     for label, fn, bps in rows:
         ms = timed(fn)
         g = bps * N / (ms * 1e-3) / 1e9

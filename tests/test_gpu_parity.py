@@ -185,7 +185,9 @@ def test_long_chain_is_split_into_launches(bj, orc):
 @pytest.mark.parametrize("shape", [(64, 777), (5, 4), (1, 10), (100, 300), (33, 1),
                                    (8, 50), (16, 333), (24, 19), (32, 77), (48, 130), (64, 4099), (64, 1),    # 16·NP / 8·NP rows: streaming kernel
                                    (96, 65), (97, 130), (128, 64), (129, 31), (200, 257), (500, 70), (1031, 9),   # tall columns, ragged batches
-                                   (40, 33), (56, 130), (80, 257), (112, 65)])   # 5 / 7 packs per lane in the streaming frame
+                                   (40, 33), (56, 130), (80, 257), (112, 65),    # 5 / 7 packs per lane in the streaming frame
+                                   (65, 131), (66, 12), (99, 77), (101, 1), (160, 33), (255, 19), (256, 70), (333, 41), (512, 9), (513, 7), (999, 5),
+                                   (1000, 6001), (1024, 3), (1025, 2), (2047, 3), (2048, 2), (2049, 2)])   # G lanes per column (bjx_tall.hip), full and ragged sets
 def test_ordered(bj, orc, shape, dt):
     y = np.asfortranarray(rng(3).normal(size=shape).astype(dt) * 0.7)
     x_ref, l_ref = orc.ordered(y)
@@ -209,7 +211,9 @@ def test_ordered(bj, orc, shape, dt):
 @pytest.mark.parametrize("K,N", [(2, 9), (3, 100), (5, 257), (64, 1000), (100, 64), (64, 1),
                                  (8, 50), (16, 333), (24, 19), (32, 77), (48, 130), (64, 4099),    # K = 16·NP / 8·NP: streaming kernel, ragged runs
                                  (96, 65), (97, 130), (128, 77), (129, 31), (200, 257), (500, 70), (1031, 9),   # tall columns (K = 128: the 32-rows-per-lane streaming frame)
-                                 (40, 33), (56, 130), (80, 257), (112, 65)])   # 5 / 7 packs per lane in the streaming frame
+                                 (40, 33), (56, 130), (80, 257), (112, 65),    # 5 / 7 packs per lane in the streaming frame
+                                 (65, 131), (66, 12), (99, 77), (101, 1), (160, 33), (255, 19), (256, 70), (333, 41), (512, 9), (513, 7), (999, 5),
+                                 (1000, 6001), (1024, 3), (1025, 2), (2047, 3), (2048, 2), (2049, 2)])   # G lanes per column (bjx_tall.hip), full and ragged sets
 def test_simplex(bj, orc, K, N, dt):
     r = rng(4)
     X = np.asfortranarray(r.dirichlet(np.ones(K), size=N).T.astype(dt))
