@@ -1484,23 +1484,6 @@ int ordered_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, c
 // Two wave-private [64][P] tiles (primal, cotangent), lane = column.  The inverse first re-runs the forward
 // recurrence (ascending) leaving x_k in the primal tile; the backward sweep recovers s_k = s_{k+1} - x_k and,
 // where x_k is not clamped, z_k = (x_k + ε)/((1+ε-s_k)/(1-2ε)) — a clamped x_k has zero derivative anyway.
-template <class T> __device__ __forceinline__ void simplex_t_partials(T xk, T sk, bool first, T& dtdx, T& dtds) {
-  using F = Fast<T>;
-  const T e = Num<T>::eps;
-  if (first) {
-    dtdx = (xk > e ? F::rcp(xk) : T(0)) - (T(1) - xk > e ? F::rcp(T(1) - xk) : T(0));
-    dtds = T(0);
-    return;
-  }
-  const T M = d_max(T(1) - sk, e);
-  const T rM = F::rcp(M);
-  const T zl = xk * rM;
-  const T dtdzl = (zl > e ? F::rcp(zl) : T(0)) - (T(1) - zl > e ? F::rcp(T(1) - zl) : T(0));
-  dtdx = dtdzl * rM;
-  const T dtdM = rM - dtdzl * zl * rM;                 // d/dM [log max(zl) + log max(1-zl) + log M], zl = x/M
-  dtds = (T(1) - sk > e) ? -dtdM : T(0);
-}
-
 template <class T, int V, bool INV>
 __global__ __launch_bounds__(64) void simplex_vjp_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
                                                         T* __restrict__ in_bar, int K, int P, int64_t batch, int C) {
@@ -1806,6 +1789,8 @@ int simplex_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, c
       rc = launch_simplex_vjp_stream<T, 4>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch, &taken);
       if (rc || taken) return rc;
     }
+    rc = bjx_tall_simplex_vjp(ctx, sizeof(T) == 4 ? BJX_F32 : BJX_F64, inverse, in, out_bar, ladj_bar, in_bar, K, batch, &taken);   // taller: G lanes per column (bjx_tall.hip)
+    if (rc || taken) return rc;
   }
   // tall columns: the chunked two-pass kernel (two whole-column tiles of 64 columns cost 2·64·K words: beyond `chunk_min` bytes
   // the whole-column kernel runs with too few waves, then with too few lanes)

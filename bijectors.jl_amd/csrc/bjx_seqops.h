@@ -107,3 +107,21 @@ template <class T, bool LADJ> struct SimplexInv {
   __device__ T result() const { return sum_tmp != sum_tmp ? sum_tmp : lp * Num<T>::log2; }   // NaN rows: as above
 };
 
+// partials of one log-det term t_k(x_k, s_k) of simplex.jl:122-138 (s_k = Σ_{j<k} x_j): used by every Simplex pullback kernel
+template <class T> __device__ __forceinline__ void simplex_t_partials(T xk, T sk, bool first, T& dtdx, T& dtds) {
+  using F = Fast<T>;
+  const T e = Num<T>::eps;
+  if (first) {
+    dtdx = (xk > e ? F::rcp(xk) : T(0)) - (T(1) - xk > e ? F::rcp(T(1) - xk) : T(0));
+    dtds = T(0);
+    return;
+  }
+  const T M = d_max(T(1) - sk, e);
+  const T rM = F::rcp(M);
+  const T zl = xk * rM;
+  const T dtdzl = (zl > e ? F::rcp(zl) : T(0)) - (T(1) - zl > e ? F::rcp(T(1) - zl) : T(0));
+  dtdx = dtdzl * rM;
+  const T dtdM = rM - dtdzl * zl * rM;                 // d/dM [log max(zl) + log max(1-zl) + log M], zl = x/M
+  dtds = (T(1) - sk > e) ? -dtdM : T(0);
+}
+

@@ -27,6 +27,8 @@
 namespace {
 using namespace bjx;
 
+#include "bjx_seqops.h"   // simplex_t_partials
+
 struct TallGeom {
   int gl;    // lane inside its column group
   int G;     // lanes per column
@@ -396,6 +398,313 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
   if (partials) block_publish_partial(acc, red, partials);
 }
 
+// ---------------------------------------------------------------- the run <-> strip moves as pieces (kernels with several runs)
+// strip position of every element of a run of CPS columns of `rows` rows; all threads of the block
+template <class T> __device__ __forceinline__ void tall_build_table(unsigned short* tab, int rows, int G, int CPS) {
+  int dc = 0, dr = 0;
+  tall_advance(dc, dr, (int)threadIdx.x, rows);
+  for (int e = threadIdx.x; e < CPS * rows; e += 256) { tab[e] = (unsigned short)tall_slot<T>(dc, dr, G); tall_advance(dc, dr, 256, rows); }
+}
+// strip positions of this lane's 16-byte packs of a run whose columns are whole packs; -1 = beyond the run
+template <class T> __device__ __forceinline__ void tall_pack_positions(int (&pos)[TallCfg<T>::NQ], int lane, int rows, int G, int CPS) {
+  constexpr int V = TallCfg<T>::V, NQ = TallCfg<T>::NQ;
+  int dc = 0, dr = 0;
+  tall_advance(dc, dr, lane * V, rows);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { pos[q] = dc < CPS ? tall_slot<T>(dc, dr, G) : -1; tall_advance(dc, dr, 64 * V, rows); }
+}
+// global run of ncol columns -> strip.  VEC: whole-pack columns (pos from tall_pack_positions); else element accesses through `tab`
+template <class T, bool VEC>
+__device__ __forceinline__ void tall_run_load(T* st, const T* __restrict__ run, int ncol, int rows, int G, int CPS, int lane,
+                                              const int (&pos)[TallCfg<T>::NQ], const unsigned short* tab) {
+  constexpr int V = TallCfg<T>::V, NQ = TallCfg<T>::NQ;
+  using VT = typename Vec16<T>::type;
+  const int nel = ncol * rows;
+  const auto rs = bjx_make_rsrc(run, (uint32_t)((size_t)nel * sizeof(T)));
+  if (VEC && ncol == CPS) {
+    Pack<T, V> raw[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) raw[q] = buf_load_pack<T, V>(rs, pos[q] >= 0 ? (lane + 64 * q) * V * (int)sizeof(T) : 0x7fffff00);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { if (pos[q] >= 0) *reinterpret_cast<VT*>(st + pos[q]) = __builtin_bit_cast(VT, raw[q]); }
+  } else if (!VEC) {
+    for (int e0 = 0; e0 < nel; e0 += 64 * 8) {
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = buf_load_pack<T, 1>(rs, (e0 + 64 * u + lane) * (int)sizeof(T)).v[0];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 64 * u + lane;
+        if (e < nel) st[tab[e]] = v[u];
+      }
+    }
+  } else {                                                             // the ragged last set of a launch with whole-pack columns
+    int dc = 0, dr = 0;
+    tall_advance(dc, dr, lane, rows);
+    for (int e0 = 0; e0 < nel; e0 += 64) {
+      const T v = buf_load_pack<T, 1>(rs, (e0 + lane) * (int)sizeof(T)).v[0];
+      if (e0 + lane < nel) st[tall_slot<T>(dc, dr, G)] = v;
+      tall_advance1(dc, dr, 64, rows);
+    }
+  }
+}
+template <class T, bool VEC>
+__device__ __forceinline__ void tall_run_store(const T* st, T* __restrict__ run, int ncol, int rows, int G, int CPS, int lane,
+                                               const int (&pos)[TallCfg<T>::NQ], const unsigned short* tab) {
+  constexpr int V = TallCfg<T>::V, NQ = TallCfg<T>::NQ;
+  using VT = typename Vec16<T>::type;
+  const int nel = ncol * rows;
+  const auto rs = bjx_make_rsrc(run, (uint32_t)((size_t)nel * sizeof(T)));
+  if (VEC && ncol == CPS) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (pos[q] >= 0) {
+        const Pack<T, V> pq = __builtin_bit_cast(Pack<T, V>, *reinterpret_cast<const VT*>(st + pos[q]));
+        buf_store_pack<T, V>(rs, (lane + 64 * q) * V * (int)sizeof(T), pq);
+      }
+    }
+  } else if (!VEC) {
+    for (int e0 = 0; e0 < nel; e0 += 64 * 4) {
+      T v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int e = e0 + 64 * u + lane; v[u] = e < nel ? st[tab[e]] : T(0); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        Pack<T, 1> p1;
+        p1.v[0] = v[u];
+        buf_store_pack<T, 1>(rs, (e0 + 64 * u + lane) * (int)sizeof(T), p1);            // beyond the run: outside the descriptor, dropped
+      }
+    }
+  } else {
+    int dc = 0, dr = 0;
+    tall_advance(dc, dr, lane, rows);
+    for (int e0 = 0; e0 < nel; e0 += 64) {
+      if (e0 + lane < nel) {
+        Pack<T, 1> p1;
+        p1.v[0] = st[tall_slot<T>(dc, dr, G)];
+        buf_store_pack<T, 1>(rs, (e0 + lane) * (int)sizeof(T), p1);
+      }
+      tall_advance1(dc, dr, 64, rows);
+    }
+  }
+}
+// this lane's slot -> registers; rows >= n read as zero (the strip is shared by runs of different heights)
+template <class T> __device__ __forceinline__ void tall_slot_read(const T* st, int lane, T (&xv)[TallCfg<T>::RPL], int n) {
+  constexpr int V = TallCfg<T>::V, NQ = TallCfg<T>::NQ, SLOT = TallCfg<T>::SLOT;
+  using VT = typename Vec16<T>::type;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const Pack<T, V> pq = __builtin_bit_cast(Pack<T, V>, *reinterpret_cast<const VT*>(st + lane * SLOT + q * V));
+#pragma unroll
+    for (int j = 0; j < V; ++j) xv[q * V + j] = q * V + j < n ? pq.v[j] : T(0);
+  }
+}
+template <class T> __device__ __forceinline__ void tall_slot_write(T* st, int lane, const T (&xv)[TallCfg<T>::RPL]) {
+  constexpr int V = TallCfg<T>::V, NQ = TallCfg<T>::NQ, SLOT = TallCfg<T>::SLOT;
+  using VT = typename Vec16<T>::type;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    Pack<T, V> pq;
+#pragma unroll
+    for (int j = 0; j < V; ++j) pq.v[j] = xv[q * V + j];
+    *reinterpret_cast<VT*>(st + lane * SLOT + q * V) = __builtin_bit_cast(VT, pq);
+  }
+}
+// exclusive sums over the G lanes of a column group, ascending / descending lane order (G any value: guarded shuffles)
+template <class T> __device__ __forceinline__ T tall_excl_up(T v, int gl, int G) {
+  T inc = v;
+  for (int d = 1; d < G; d <<= 1) { const T t = __shfl_up(inc, d, 64); if (gl >= d) inc += t; }
+  return inc - v;
+}
+template <class T> __device__ __forceinline__ T tall_excl_down(T v, int gl, int G) {
+  T inc = v;
+  for (int d = 1; d < G; d <<= 1) { const T t = __shfl_down(inc, d, 64); if (gl + d < G) inc += t; }
+  return inc - v;
+}
+
+// ---------------------------------------------------------------- SimplexBijector pullbacks on tall columns
+// The math of simplex_vjp_stream_kernel (bjx_seq.hip: O(K) reverse sweeps of simplex.jl:47-64, :102-120, :122-138) in the G-lane
+// layout above.  in: K rows (forward map) / K-1 rows (inverse), out_bar: K-1 / K rows, in_bar like in.  Forward map: Σ_{j<k} x_j and
+// the suffix sums of the adjoint are plain scans (a pullback has no reference summation order to keep).  Inverse map: the clamped
+// recurrence is re-run in the reference's order by take-turns rounds and the adjoint of Σ, sb <- B_k sb + A_k, the same way from
+// the last lane down.
+template <class T, bool INV, bool VK, bool VK1>     // VK: the K-row runs are whole 16-byte packs; VK1: the (K-1)-row runs
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void tall_simplex_vjp_kernel(const T* __restrict__ in, const T* __restrict__ out_bar,
+                                                                                                           const T* __restrict__ ladj_bar, T* __restrict__ in_bar,
+                                                                                                           int K, int64_t batch, int G, int nsteps) {
+  using F = Fast<T>;
+  using C = TallCfg<T>;
+  constexpr int V = C::V, RPL = C::RPL, SLOT = C::SLOT, NQ = C::NQ, WPB = C::WPB;
+  constexpr bool VA = INV ? VK1 : VK, VG = INV ? VK : VK1;            // in / in_bar ; out_bar
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* strips = reinterpret_cast<T*>(smem);
+  T* lktab = strips + WPB * 64 * SLOT;                                 // [G slots], inverse only
+  const int CPS = 64 / G;
+  const int rows_a = INV ? K - 1 : K, rows_g = INV ? K : K - 1;
+  unsigned short* tab_a = reinterpret_cast<unsigned short*>(lktab + (INV ? G * SLOT : 0));
+  unsigned short* tab_g = tab_a + (VA ? 0 : (CPS * rows_a + 1) / 2 * 2);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = lane / G, gl = lane - cg * G;
+  const bool idle = cg >= CPS;
+  T* st = strips + wave * 64 * SLOT;
+  if (INV) {
+    for (int r = threadIdx.x; r < G * RPL; r += 64 * WPB) lktab[(r / RPL) * SLOT + (r & (RPL - 1))] = r < K - 1 ? d_log(T(K - 1 - r)) : T(0);
+  }
+  if (!VA) tall_build_table<T>(tab_a, rows_a, G, CPS);
+  if (!VG) tall_build_table<T>(tab_g, rows_g, G, CPS);
+  __syncthreads();
+  int pos_a[NQ], pos_g[NQ];
+  if (VA) tall_pack_positions<T>(pos_a, lane, rows_a, G, CPS);
+  if (VG) tall_pack_positions<T>(pos_g, lane, rows_g, G, CPS);
+  const int iK = idle ? -1 : K - 1 - gl * RPL;                         // index of row K-1 inside this lane
+  const int na = idle ? 0 : (rows_a - gl * RPL < 0 ? 0 : (rows_a - gl * RPL > RPL ? RPL : rows_a - gl * RPL));
+  const int ng = idle ? 0 : (rows_g - gl * RPL < 0 ? 0 : (rows_g - gl * RPL > RPL ? RPL : rows_g - gl * RPL));
+  const T e = Num<T>::eps;
+  const T c = T(1) / (T(1) - 2 * e), E = T(1) + e, c2 = T(1) - 2 * e;
+  const T* lk = lktab + gl * SLOT;
+  const int64_t set0 = ((int64_t)blockIdx.x * WPB + wave) * nsteps;
+  for (int sidx = 0; sidx < nsteps; ++sidx) {
+    const int64_t colw = (set0 + sidx) * CPS;
+    if (colw >= batch) break;
+    const int ncol = (int)((batch - colw) < CPS ? (batch - colw) : CPS);
+    const int64_t col = colw + cg;
+    T a[RPL], g[RPL];
+    __builtin_amdgcn_wave_barrier();
+    tall_run_load<T, VA>(st, in + colw * rows_a, ncol, rows_a, G, CPS, lane, pos_a, tab_a);
+    __builtin_amdgcn_wave_barrier();
+    tall_slot_read<T>(st, lane, a, na);
+    __builtin_amdgcn_wave_barrier();
+    tall_run_load<T, VG>(st, out_bar + colw * rows_g, ncol, rows_g, G, CPS, lane, pos_g, tab_g);
+    __builtin_amdgcn_wave_barrier();
+    tall_slot_read<T>(st, lane, g, ng);
+    const T lb = (ladj_bar && !idle && cg < ncol) ? ladj_bar[col] : T(0);
+    if constexpr (!INV) {
+      // ---- pullback of x -> (y, logabsdetjac): a = x (K rows), g = ȳ (K-1 rows)
+      T tot = T(0);
+#pragma unroll
+      for (int i = 0; i < RPL; ++i) tot += a[i];
+      T s = tall_excl_up(tot, gl, G);                                  // Σ of the rows before my first one
+      T as_[RPL];
+      T asum = T(0);
+#pragma unroll
+      for (int i = 0; i < RPL; ++i) {
+        const bool row0 = i == 0 && gl == 0;
+        const bool dead = i >= iK;                                     // x_K and the padding: no gradient
+        const T xk = a[i];
+        T dtdx, dtds;
+        simplex_t_partials<T>(xk, s, false, dtdx, dtds);
+        if (i == 0) { T d0, d1; simplex_t_partials<T>(xk, s, true, d0, d1); dtdx = row0 ? d0 : dtdx; dtds = row0 ? T(0) : dtds; }
+        const T rd = row0 ? T(1) : F::rcp(E - s);
+        const T an = row0 ? xk * c2 + e : (xk + e) * c2;               // zf = an·rd
+        const T zf = an * rd;
+        const T zfb = g[i] * F::rcp(zf * (T(1) - zf));
+        const T ax = zfb * c2 * rd - lb * dtdx;
+        const T asv = row0 ? T(0) : zfb * an * rd * rd - lb * dtds;
+        a[i] = dead ? T(0) : ax;
+        as_[i] = dead ? T(0) : asv;
+        asum += as_[i];
+        s += xk;
+      }
+      T sfx = tall_excl_down(asum, gl, G);                             // Σ as over the rows after my last one
+#pragma unroll
+      for (int i = RPL - 1; i >= 0; --i) { a[i] = i < na ? a[i] + sfx : T(0); sfx += as_[i]; }
+    } else {
+      // ---- pullback of y -> (x, logabsdetjac): a = y (K-1 rows), g = x̄ (K rows)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const Pack<T, V> lkq = __builtin_bit_cast(Pack<T, V>, *reinterpret_cast<const typename Vec16<T>::type*>(lk + q * V));
+#pragma unroll
+        for (int j = 0; j < V; ++j) { const int i = q * V + j; a[i] = i < iK ? f_logistic(a[i] - lkq.v[j]) * c : T(0); }   // c·z_k
+      }
+      T carry = T(0);
+      for (int t = 1; t < G; ++t) {
+        T s = carry;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+          const bool row0 = i == 0 && gl == 0;
+          const T xi = row0 ? d_clamp(a[i] - e * c, T(0), T(1)) : d_clamp((E - s) * a[i] - e, T(0), T(1));
+          s += xi;
+        }
+        const T bc = __shfl_up(s, 1, 64);
+        carry = gl == 0 ? T(0) : bc;
+      }
+      T xk[RPL], A[RPL], B[RPL];
+      T s = carry;
+      T sb0 = T(0);
+#pragma unroll
+      for (int i = 0; i < RPL; ++i) {
+        const bool row0 = i == 0 && gl == 0;
+        const bool rowK = i == iK, dead = i >= iK;
+        const T xi = row0 ? d_clamp(a[i] - e * c, T(0), T(1)) : d_clamp((E - s) * a[i] - e, T(0), T(1));
+        T dtdx, dtds;
+        simplex_t_partials<T>(xi, s, false, dtdx, dtds);
+        if (i == 0) { T d0, d1; simplex_t_partials<T>(xi, s, true, d0, d1); dtdx = row0 ? d0 : dtdx; dtds = row0 ? T(0) : dtds; }
+        const bool gate = xi > T(0) && xi < T(1);
+        const T rc = (E - s) * c;
+        const T z = row0 ? xi * c2 + e : (xi + e) * F::rcp(rc);
+        const T cz = (gate && !row0) ? c * z : T(0);
+        // sb_next = B sb + A ;  ȳ = gate (g + sb_in + lb dtdx) w,  w = rc z (1-z)  (row 0: c z (1-z))
+        B[i] = dead ? T(1) : T(1) - cz;
+        A[i] = dead ? T(0) : lb * dtds - cz * (g[i] + lb * dtdx);
+        xk[i] = (gate && !dead) ? (row0 ? c : rc) * z * (T(1) - z) : T(0);   // w_k (0 where the clamp is active)
+        if (rowK) { const T last = T(1) - s; sb0 = (last > T(0) && last < T(1)) ? -g[i] : T(0); }
+        g[i] = dead ? T(0) : g[i] + lb * dtdx;                         // g + lb dtdx
+        s += xi;
+      }
+      // adjoint of Σ, from the last row down: the lanes take turns from the right
+      const bool lastlane = iK >= 0 && iK < RPL;
+      T cin = lastlane ? sb0 : T(0);
+      for (int t = 1; t < G; ++t) {
+        T sb = cin;
+#pragma unroll
+        for (int i = RPL - 1; i >= 0; --i) sb = B[i] * sb + A[i];
+        const T bc = __shfl_down(sb, 1, 64);
+        cin = lastlane ? sb0 : bc;
+      }
+      T sb = cin;
+#pragma unroll
+      for (int i = RPL - 1; i >= 0; --i) {
+        a[i] = (g[i] + sb) * xk[i];
+        sb = B[i] * sb + A[i];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    tall_slot_write<T>(st, lane, a);
+    __builtin_amdgcn_wave_barrier();
+    tall_run_store<T, VA>(st, in_bar + colw * rows_a, ncol, rows_a, G, CPS, lane, pos_a, tab_a);
+  }
+}
+
+template <class T>
+int launch_tall_simplex_vjp(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
+  using C = TallCfg<T>;
+  const int G = (int)((K + C::RPL - 1) / C::RPL), CPS = 64 / G;
+  const int64_t sets = (batch + CPS - 1) / CPS;
+  int nsteps = (int)(sets / 4096);
+  nsteps = nsteps < 1 ? 1 : (nsteps > 8 ? 8 : nsteps);
+  const int64_t waves = (sets + nsteps - 1) / nsteps;
+  const int64_t grid = (waves + C::WPB - 1) / C::WPB;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+  const int64_t rows_a = inverse ? K - 1 : K, rows_g = inverse ? K : K - 1;
+  const bool al = bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
+  const bool vk = al && K % C::V == 0, vk1 = al && (K - 1) % C::V == 0;
+  const bool va = inverse ? vk1 : vk, vg = inverse ? vk : vk1;
+  const size_t smem = ((size_t)C::WPB * 64 * C::SLOT + (inverse ? (size_t)G * C::SLOT : 0)) * sizeof(T) +
+                      (va ? 0 : ((size_t)CPS * rows_a + 1) / 2 * 2 * sizeof(unsigned short)) + (vg ? 0 : ((size_t)CPS * rows_g + 1) / 2 * 2 * sizeof(unsigned short));
+  {
+    BjxProf prof_(ctx);
+#define TSV(I_, A_, B_) hipLaunchKernelGGL((tall_simplex_vjp_kernel<T, I_, A_, B_>), dim3((unsigned)grid), dim3(64 * C::WPB), smem, ctx->stream, in, out_bar, ladj_bar, \
+                                           in_bar, (int)K, batch, G, nsteps)
+#define TSV2(I_) do { if (vk) { if (vk1) TSV(I_, true, true); else TSV(I_, true, false); } else { if (vk1) TSV(I_, false, true); else TSV(I_, false, false); } } while (0)
+    if (inverse) TSV2(true); else TSV2(false);
+#undef TSV2
+#undef TSV
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+
 template <class T, class Op>
 int launch_tall(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t rows_in, int64_t rows_out,
                 int64_t batch, uint32_t flags) {
@@ -455,11 +764,11 @@ int bjx_tall_stream(bjx_ctx* ctx, bjx_dtype dt, int which, const void* in, void*
   static const int use_tall = getenv("BJX_SEQ_TALL") ? atoi(getenv("BJX_SEQ_TALL")) : 1;
   // the Simplex inverse pays four chain operations per row and round: beyond `inv_max` rows the chunked walker is ahead (same-box A/B)
   static const long inv_max = getenv("BJX_SEQ_TALL_INV_MAX") ? atol(getenv("BJX_SEQ_TALL_INV_MAX")) : 512;
-  static const long min_rows = getenv("BJX_SEQ_TALL_MIN") ? atol(getenv("BJX_SEQ_TALL_MIN")) : 129;
+  static const long min_rows = getenv("BJX_SEQ_TALL_MIN") ? atol(getenv("BJX_SEQ_TALL_MIN")) : 65;
   const int rpl = dt == BJX_F32 ? 32 : 16;
   const int64_t rows = rows_in > rows_out ? rows_in : rows_out;
   if (!use_tall || batch <= 0 || rows < min_rows || rows > 64 * rpl) return BJX_OK;
-  if (which == BJX_TALL_SIMPLEX_INV && rows > inv_max) return BJX_OK;
+  if (which == BJX_TALL_SIMPLEX_INV && (rows > inv_max || rows < 129)) return BJX_OK;   // 65-128 rows: the whole-column tile is ahead (45 against 43 % at K = 100)
   const int G = (int)((rows + rpl - 1) / rpl), CPS = 64 / G;
   // lanes that hold rows of a column / lanes of the wave: K just above a multiple of RPL wastes most of the last lane
   const double eff = (double)rows * CPS / (64.0 * rpl);
@@ -468,4 +777,22 @@ int bjx_tall_stream(bjx_ctx* ctx, bjx_dtype dt, int which, const void* in, void*
   *taken = true;
   if (dt == BJX_F32) return tall_dispatch<float>(ctx, which, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, rows_in, rows_out, batch, flags);
   return tall_dispatch<double>(ctx, which, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, rows_in, rows_out, batch, flags);
+}
+
+// Pullback of the Simplex maps on tall columns; same contract as bjx_tall_stream
+int bjx_tall_simplex_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K,
+                         int64_t batch, bool* taken) {
+  *taken = false;
+  static const int use_tall = getenv("BJX_SIMPLEX_VJP_TALL") ? atoi(getenv("BJX_SIMPLEX_VJP_TALL")) : 1;
+  static const long min_rows = getenv("BJX_SIMPLEX_VJP_TALL_MIN") ? atol(getenv("BJX_SIMPLEX_VJP_TALL_MIN")) : 65;
+  static const long inv_max = getenv("BJX_SIMPLEX_VJP_TALL_INV_MAX") ? atol(getenv("BJX_SIMPLEX_VJP_TALL_INV_MAX")) : 512;
+  const int rpl = dt == BJX_F32 ? 32 : 16;
+  if (!use_tall || batch <= 0 || K < min_rows || K > 64 * rpl) return BJX_OK;
+  if (inverse && K > inv_max) return BJX_OK;
+  const int G = (int)((K + rpl - 1) / rpl), CPS = 64 / G;
+  static const double min_eff = getenv("BJX_SEQ_TALL_EFF") ? atof(getenv("BJX_SEQ_TALL_EFF")) : 0.6;
+  if ((double)K * CPS / (64.0 * rpl) < min_eff) return BJX_OK;
+  *taken = true;
+  if (dt == BJX_F32) return launch_tall_simplex_vjp<float>(ctx, inverse, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, K, batch);
+  return launch_tall_simplex_vjp<double>(ctx, inverse, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, K, batch);
 }
