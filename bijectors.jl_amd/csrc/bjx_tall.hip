@@ -63,7 +63,7 @@ template <class T> struct TOrderedFwd {                  // ordered.jl:36-49, :8
     }
     T run = carry;
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) { run += x[i]; x[i] = i < g.nin ? run : T(0); }
+    for (int i = 0; i < RPL; ++i) { run += x[i]; x[i] = run; }         // rows beyond the column: not stored, and masked when the strip is read again
     return l;
   }
 };
@@ -81,7 +81,7 @@ template <class T> struct TOrderedInv {                  // ordered.jl:63-77 ; i
       const T o = first ? y : F::log(y - prev);                        // x_1 = y_1 ; x_k = log(y_k - y_{k-1})
       l -= (live && !first) ? o : T(0);
       prev = y;
-      x[i] = live ? o : T(0);
+      x[i] = o;
     }
     return l;
   }
@@ -126,7 +126,7 @@ template <class T, bool LADJ> struct TSimplexFwd {       // simplex.jl:47-64 + :
           if (i & 1) lp += F::log2(Pp * F::rcp(mp * mm) * PP);
           else { Pp = PP; mp = mm; }
         }
-        x[i] = dead ? T(0) : o;
+        x[i] = o;
         s += xk;
       }
       __builtin_amdgcn_sched_barrier(0);                               // V rows in flight, not 32: the scheduler otherwise spills under the 128-VGPR target
@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
   const int cg = lane / G, gl = lane - cg * G;
   const bool idle = cg >= CPS;                                         // 64 - CPS·G lanes have no column
   T* st = strips + wave * 64 * SLOT;
-  // The strip is zeroed once: positions no run element maps to (rows beyond the column, idle lanes) stay zero — the maps write
-  // zeros back there.
+  // The strip is zeroed once so that the first step reads no uninitialised LDS in the positions no run element maps to (rows beyond
+  // the column, idle lanes); later steps find the previous step's values there, and every map masks the rows that do not exist.
   for (int i = lane; i < 64 * SLOT; i += 64) st[i] = T(0);
   if (Op::USES_LOGK) {
     for (int r = threadIdx.x; r < G * RPL; r += 64 * WPB)              // log(K-1-r), simplex.jl:35,41 (precise logs, once per block)
@@ -769,6 +769,10 @@ int bjx_tall_stream(bjx_ctx* ctx, bjx_dtype dt, int which, const void* in, void*
   const int64_t rows = rows_in > rows_out ? rows_in : rows_out;
   if (!use_tall || batch <= 0 || rows < min_rows || rows > 64 * rpl) return BJX_OK;
   if (which == BJX_TALL_SIMPLEX_INV && (rows > inv_max || rows < 129)) return BJX_OK;   // 65-128 rows: the whole-column tile is ahead (45 against 43 % at K = 100)
+  // Float64 (same-box A/B, profiles/r03_tall_columns.md): the rounds of the Simplex inverse are four Float64 operations per row — the
+  // walkers stay ahead at every height (39 / 35 % against 31 / 27 % at K = 200 / 500); beyond 32 lanes per column (512 rows) the
+  // walkers are level or ahead for the other maps too (Ordered at K = 1000: 54 against 45 %)
+  if (dt == BJX_F64 && (which == BJX_TALL_SIMPLEX_INV || rows > 512)) return BJX_OK;
   const int G = (int)((rows + rpl - 1) / rpl), CPS = 64 / G;
   // lanes that hold rows of a column / lanes of the wave: K just above a multiple of RPL wastes most of the last lane
   const double eff = (double)rows * CPS / (64.0 * rpl);

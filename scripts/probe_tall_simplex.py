@@ -10,19 +10,21 @@ def timed(fn, reps=5):
     from _timing import kernel_ms
     return kernel_ms(bj, fn, steps=reps, device=dev)
 N = 1 << int(os.environ.get("BJX_BENCH_LOG2N", "20"))
+TD = torch.float64 if os.environ.get("BJX_PROBE_DTYPE") == "f64" else torch.float32
+ES = 8 if TD == torch.float64 else 4
 print("| bijector | K | kernel ms (2^%d columns) | alg. B/sample | GB/s | %% of 8 TB/s |" % (N.bit_length() - 1))
 print("|---|---|---|---|---|---|")
 for K in tuple(int(v) for v in os.environ.get("BJX_BENCH_KS", "64,100,128,200,256,500").split(",")):
-    x = torch.softmax(torch.randn(N, K, device=dev), dim=1).T
+    x = torch.softmax(torch.randn(N, K, device=dev, dtype=TD), dim=1).T
     sb = bj.SimplexBijector()
     y = bj.transform(sb, x)
-    xo = torch.randn(N, K, device=dev).T
-    gy, gx, lb = torch.randn(N, K - 1, device=dev).T, torch.randn(N, K, device=dev).T, torch.randn(N, device=dev)
-    rows = [("SimplexBijector", lambda: bj.with_logabsdet_jacobian(sb, x, per_sample=True), (2 * K - 1) * 4 + 4),
-            ("inverse(SimplexBijector)", lambda: bj.with_logabsdet_jacobian(bj.inverse(sb), y, per_sample=True), (2 * K - 1) * 4 + 4),
-            ("OrderedBijector", lambda: bj.with_logabsdet_jacobian(bj.OrderedBijector(), xo, per_sample=True), 2 * K * 4 + 4),
-            ("vjp(SimplexBijector)", lambda: bj.vjp(sb, x, gy, lb), (3 * K - 1) * 4 + 4),
-            ("vjp(inverse(SimplexBijector))", lambda: bj.vjp(bj.inverse(sb), y, gx, lb), (3 * K - 2) * 4 + 4)]
+    xo = torch.randn(N, K, device=dev, dtype=TD).T
+    gy, gx, lb = torch.randn(N, K - 1, device=dev, dtype=TD).T, torch.randn(N, K, device=dev, dtype=TD).T, torch.randn(N, device=dev, dtype=TD)
+    rows = [("SimplexBijector", lambda: bj.with_logabsdet_jacobian(sb, x, per_sample=True), (2 * K - 1) * ES + ES),
+            ("inverse(SimplexBijector)", lambda: bj.with_logabsdet_jacobian(bj.inverse(sb), y, per_sample=True), (2 * K - 1) * ES + ES),
+            ("OrderedBijector", lambda: bj.with_logabsdet_jacobian(bj.OrderedBijector(), xo, per_sample=True), 2 * K * ES + ES),
+            ("vjp(SimplexBijector)", lambda: bj.vjp(sb, x, gy, lb), (3 * K - 1) * ES + ES),
+            ("vjp(inverse(SimplexBijector))", lambda: bj.vjp(bj.inverse(sb), y, gx, lb), (3 * K - 2) * ES + ES)]
     if os.environ.get("BJX_PROBE_ROWS") == "fwd": rows = rows[:3]
     for label, fn, bps in rows:
         ms = timed(fn)
