@@ -35,7 +35,24 @@ struct TallGeom {
   int nin;   // rows of this lane that exist in the input (0..RPL)
   int nout;  // rows of this lane that exist in the output
   int iK;    // index, inside this lane, of the column's final row (rows-1); >= RPL on the lanes to its left, < 0 to its right
+  int scan;  // Simplex inverse: carry by an affine scan (1) or by take-turns rounds in the reference's order (0)
 };
+
+// s -> A s + B maps composed over the G lanes of a column group: on return (A, B) of lane gl is the composition of the maps of
+// lanes 0 .. gl (lane 0 applied first).  Guarded shuffles: G is any value.
+template <class T> __device__ __forceinline__ void tall_affine_scan_up(T& A, T& B, int gl, int G) {
+  for (int d = 1; d < G; d <<= 1) {
+    const T Al = __shfl_up(A, d, 64), Bl = __shfl_up(B, d, 64);
+    if (gl >= d) { B = A * Bl + B; A = A * Al; }
+  }
+}
+// the same from the last lane down: (A, B) of lane gl = composition of the maps of lanes G-1 .. gl (lane G-1 applied first)
+template <class T> __device__ __forceinline__ void tall_affine_scan_down(T& A, T& B, int gl, int G) {
+  for (int d = 1; d < G; d <<= 1) {
+    const T Ar = __shfl_down(A, d, 64), Br = __shfl_down(B, d, 64);
+    if (gl + d < G) { B = A * Br + B; A = A * Ar; }
+  }
+}
 
 template <class T> __device__ __forceinline__ T lane_left(T v) { return __shfl_up(v, 1, 64); }
 
@@ -148,16 +165,37 @@ template <class T, bool LADJ> struct TSimplexInv {       // simplex.jl:102-120 ;
     const T e = Num<T>::eps, E = T(1) + e;
     const T e0 = e * (T(1) / (T(1) - 2 * e));
     T carry = T(0);
-    for (int t = 1; t < g.G; ++t) {                                    // rounds: only the recurrence Σ -> x_k -> Σ
-      T s = carry;
+    if (g.scan) {
+      // Σ entering this lane by an AFFINE SCAN: without its clamp a row is Σ' = (1 - a_k) Σ + ((1+ε) a_k - ε), a_k = z_k/(1-2ε) — one
+      // composition per lane (4 operations per row, the price of ONE round) and log2 G shuffle steps instead of G-1 rounds of the
+      // four-operation recurrence.  Not the reference's association, and a clamped row moves the carry by <= ε; both are harmless
+      // HERE (unlike in the transform): the recurrence contracts — an error δ in Σ becomes (1 - a_k) δ after the row — the outputs
+      // carry it as a_k δ.  The log-det terms see it relative to 1 - Σ, which is why Float32 does NOT take this path by default (see
+      // bjx_tall_stream below); Float64 does.
+      T A = T(1), B = T(0);
 #pragma unroll
       for (int i = 0; i < RPL; ++i) {
         const bool first = i == 0 && g.gl == 0;
-        const T xi = first ? cl01<FAST>(x[i] - e0) : cl01<FAST>((E - s) * x[i] - e);
-        s += xi;
+        const T Ar = first ? T(1) : T(1) - x[i];
+        const T Br = first ? x[i] - e0 : E * x[i] - e;
+        B = Ar * B + Br;
+        A = Ar * A;
       }
-      const T bc = lane_left(s);
+      tall_affine_scan_up(A, B, g.gl, g.G);
+      const T bc = lane_left(B);                                       // the composition of the lanes to my left, applied to Σ = 0
       carry = g.gl == 0 ? T(0) : bc;
+    } else {
+      for (int t = 1; t < g.G; ++t) {                                  // rounds: only the recurrence Σ -> x_k -> Σ
+        T s = carry;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+          const bool first = i == 0 && g.gl == 0;
+          const T xi = first ? cl01<FAST>(x[i] - e0) : cl01<FAST>((E - s) * x[i] - e);
+          s += xi;
+        }
+        const T bc = lane_left(s);
+        carry = g.gl == 0 ? T(0) : bc;
+      }
     }
     T lp = T(0), s = carry;
     T Pp = T(1), mp = T(1);
@@ -231,7 +269,7 @@ __device__ __forceinline__ void tall_advance1(int& dc, int& dr, int step, int ro
 template <class T, class Op, bool VIN, bool VOUT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void tall_stream_kernel(const Op op, const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps,
                                                           int rows_in, int rows_out, int64_t batch, int G, int nsteps,
-                                                          int accumulate, double* __restrict__ partials) {
+                                                          int accumulate, double* __restrict__ partials, int inv_scan) {
   using C = TallCfg<T>;
   constexpr int V = C::V, RPL = C::RPL, SLOT = C::SLOT, NQ = C::NQ, WPB = C::WPB;
   using VT = typename Vec16<T>::type;
@@ -269,7 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
   }
   __syncthreads();
   TallGeom g;
-  g.gl = gl; g.G = G;
+  g.gl = gl; g.G = G; g.scan = inv_scan;
   { const int a = rows_in - gl * RPL; g.nin = idle ? 0 : (a < 0 ? 0 : (a > RPL ? RPL : a)); }
   { const int a = rows_out - gl * RPL; g.nout = idle ? 0 : (a < 0 ? 0 : (a > RPL ? RPL : a)); }
   g.iK = idle ? -1 : rows - 1 - gl * RPL;
@@ -531,7 +569,7 @@ template <class T> __device__ __forceinline__ T tall_excl_down(T v, int gl, int 
 template <class T, bool INV, bool VK, bool VK1>     // VK: the K-row runs are whole 16-byte packs; VK1: the (K-1)-row runs
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void tall_simplex_vjp_kernel(const T* __restrict__ in, const T* __restrict__ out_bar,
                                                                                                            const T* __restrict__ ladj_bar, T* __restrict__ in_bar,
-                                                                                                           int K, int64_t batch, int G, int nsteps) {
+                                                                                                           int K, int64_t batch, int G, int nsteps, int scan) {
   using F = Fast<T>;
   using C = TallCfg<T>;
   constexpr int V = C::V, RPL = C::RPL, SLOT = C::SLOT, NQ = C::NQ, WPB = C::WPB;
@@ -618,16 +656,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         for (int j = 0; j < V; ++j) { const int i = q * V + j; a[i] = i < iK ? f_logistic(a[i] - lkq.v[j]) * c : T(0); }   // c·z_k
       }
       T carry = T(0);
-      for (int t = 1; t < G; ++t) {
-        T s = carry;
+      if (scan) {                                                      // Σ entering this lane by the affine scan of TSimplexInv (see there)
+        T As = T(1), Bs = T(0);
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
           const bool row0 = i == 0 && gl == 0;
-          const T xi = row0 ? d_clamp(a[i] - e * c, T(0), T(1)) : d_clamp((E - s) * a[i] - e, T(0), T(1));
-          s += xi;
+          const T Ar = row0 ? T(1) : T(1) - a[i];
+          const T Br = row0 ? a[i] - e * c : E * a[i] - e;
+          Bs = Ar * Bs + Br;
+          As = Ar * As;
         }
-        const T bc = __shfl_up(s, 1, 64);
+        tall_affine_scan_up(As, Bs, gl, G);
+        const T bc = __shfl_up(Bs, 1, 64);
         carry = gl == 0 ? T(0) : bc;
+      } else {
+        for (int t = 1; t < G; ++t) {
+          T s = carry;
+#pragma unroll
+          for (int i = 0; i < RPL; ++i) {
+            const bool row0 = i == 0 && gl == 0;
+            const T xi = row0 ? d_clamp(a[i] - e * c, T(0), T(1)) : d_clamp((E - s) * a[i] - e, T(0), T(1));
+            s += xi;
+          }
+          const T bc = __shfl_up(s, 1, 64);
+          carry = gl == 0 ? T(0) : bc;
+        }
       }
       T xk[RPL], A[RPL], B[RPL];
       T s = carry;
@@ -655,12 +708,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
       // adjoint of Σ, from the last row down: the lanes take turns from the right
       const bool lastlane = iK >= 0 && iK < RPL;
       T cin = lastlane ? sb0 : T(0);
-      for (int t = 1; t < G; ++t) {
-        T sb = cin;
+      if (scan) {
+        // sb <- B_k sb + A_k is affine in sb: compose this lane's rows (last row first), scan the compositions from the last lane down,
+        // apply the composition of the lanes to my right to the value the last row starts from
+        T P = T(1), Q = T(0);
 #pragma unroll
-        for (int i = RPL - 1; i >= 0; --i) sb = B[i] * sb + A[i];
-        const T bc = __shfl_down(sb, 1, 64);
-        cin = lastlane ? sb0 : bc;
+        for (int i = RPL - 1; i >= 0; --i) { Q = B[i] * Q + A[i]; P = B[i] * P; }
+        tall_affine_scan_down(P, Q, gl, G);
+        const T sbK = __shfl(sb0, lane - gl + (G - 1), 64);            // the column's last lane holds row K-1
+        const T Pr = __shfl_down(P, 1, 64), Qr = __shfl_down(Q, 1, 64);
+        cin = lastlane ? sb0 : Pr * sbK + Qr;
+      } else {
+        for (int t = 1; t < G; ++t) {
+          T sb = cin;
+#pragma unroll
+          for (int i = RPL - 1; i >= 0; --i) sb = B[i] * sb + A[i];
+          const T bc = __shfl_down(sb, 1, 64);
+          cin = lastlane ? sb0 : bc;
+        }
       }
       T sb = cin;
 #pragma unroll
@@ -687,6 +752,7 @@ int launch_tall_simplex_vjp(bjx_ctx* ctx, int inverse, const T* in, const T* out
   const int64_t grid = (waves + C::WPB - 1) / C::WPB;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
   const int64_t rows_a = inverse ? K - 1 : K, rows_g = inverse ? K : K - 1;
+  static const int vjp_scan = getenv("BJX_SIMPLEX_VJP_TALL_SCAN") ? atoi(getenv("BJX_SIMPLEX_VJP_TALL_SCAN")) : 1;   // 0: take-turns rounds in the pullback of the inverse
   const bool al = bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
   const bool vk = al && K % C::V == 0, vk1 = al && (K - 1) % C::V == 0;
   const bool va = inverse ? vk1 : vk, vg = inverse ? vk : vk1;
@@ -695,7 +761,7 @@ int launch_tall_simplex_vjp(bjx_ctx* ctx, int inverse, const T* in, const T* out
   {
     BjxProf prof_(ctx);
 #define TSV(I_, A_, B_) hipLaunchKernelGGL((tall_simplex_vjp_kernel<T, I_, A_, B_>), dim3((unsigned)grid), dim3(64 * C::WPB), smem, ctx->stream, in, out_bar, ladj_bar, \
-                                           in_bar, (int)K, batch, G, nsteps)
+                                           in_bar, (int)K, batch, G, nsteps, vjp_scan)
 #define TSV2(I_) do { if (vk) { if (vk1) TSV(I_, true, true); else TSV(I_, true, false); } else { if (vk1) TSV(I_, false, true); else TSV(I_, false, false); } } while (0)
     if (inverse) TSV2(true); else TSV2(false);
 #undef TSV2
@@ -707,7 +773,7 @@ int launch_tall_simplex_vjp(bjx_ctx* ctx, int inverse, const T* in, const T* out
 
 template <class T, class Op>
 int launch_tall(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t rows_in, int64_t rows_out,
-                int64_t batch, uint32_t flags) {
+                int64_t batch, uint32_t flags, int inv_scan) {
   using C = TallCfg<T>;
   const int64_t rows = rows_in > rows_out ? rows_in : rows_out;
   const int G = (int)((rows + C::RPL - 1) / C::RPL), CPS = 64 / G;
@@ -728,7 +794,7 @@ int launch_tall(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, dou
   {
     BjxProf prof_(ctx);
 #define TSK(VI_, VO_) hipLaunchKernelGGL((tall_stream_kernel<T, Op, VI_, VO_>), dim3((unsigned)grid), dim3(64 * C::WPB), smem, ctx->stream, op, in, out, \
-                                         ladj_ps, (int)rows_in, (int)rows_out, batch, G, nsteps, (flags & BJX_ACCUMULATE) ? 1 : 0, partials)
+                                         ladj_ps, (int)rows_in, (int)rows_out, batch, G, nsteps, (flags & BJX_ACCUMULATE) ? 1 : 0, partials, inv_scan)
     if (vin) { if (vout) TSK(true, true); else TSK(true, false); }
     else { if (vout) TSK(false, true); else TSK(false, false); }
 #undef TSK
@@ -740,17 +806,17 @@ int launch_tall(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, dou
 
 template <class T>
 int tall_dispatch(bjx_ctx* ctx, int which, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t rows_in, int64_t rows_out, int64_t batch,
-                  uint32_t flags) {
+                  uint32_t flags, int inv_scan) {
   const bool want = ladj_ps || ladj_sum;
   switch (which) {
-    case BJX_TALL_ORDERED_FWD: return launch_tall<T>(ctx, TOrderedFwd<T>{}, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, flags);
-    case BJX_TALL_ORDERED_INV: return launch_tall<T>(ctx, TOrderedInv<T>{}, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, flags);
+    case BJX_TALL_ORDERED_FWD: return launch_tall<T>(ctx, TOrderedFwd<T>{}, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, flags, inv_scan);
+    case BJX_TALL_ORDERED_INV: return launch_tall<T>(ctx, TOrderedInv<T>{}, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, flags, inv_scan);
     case BJX_TALL_SIMPLEX_FWD:
-      return want ? launch_tall<T>(ctx, TSimplexFwd<T, true>{}, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, flags)
-                  : launch_tall<T>(ctx, TSimplexFwd<T, false>{}, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, flags);
+      return want ? launch_tall<T>(ctx, TSimplexFwd<T, true>{}, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, flags, inv_scan)
+                  : launch_tall<T>(ctx, TSimplexFwd<T, false>{}, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, flags, inv_scan);
     case BJX_TALL_SIMPLEX_INV:
-      return want ? launch_tall<T>(ctx, TSimplexInv<T, true>{}, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, flags)
-                  : launch_tall<T>(ctx, TSimplexInv<T, false>{}, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, flags);
+      return want ? launch_tall<T>(ctx, TSimplexInv<T, true>{}, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, flags, inv_scan)
+                  : launch_tall<T>(ctx, TSimplexInv<T, false>{}, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, flags, inv_scan);
   }
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_tall_stream: bad map %d", which);
 }
@@ -768,19 +834,26 @@ int bjx_tall_stream(bjx_ctx* ctx, bjx_dtype dt, int which, const void* in, void*
   const int rpl = dt == BJX_F32 ? 32 : 16;
   const int64_t rows = rows_in > rows_out ? rows_in : rows_out;
   if (!use_tall || batch <= 0 || rows < min_rows || rows > 64 * rpl) return BJX_OK;
-  if (which == BJX_TALL_SIMPLEX_INV && (rows > inv_max || rows < 129)) return BJX_OK;   // 65-128 rows: the whole-column tile is ahead (45 against 43 % at K = 100)
+  // Carry of the Simplex inverse: take-turns rounds in the reference's order (0) or the affine scan (1).  Float32 keeps the rounds: on
+  // a long simplex the stick is used up before the last rows (1 - Σ falls to ε), the log-det terms divide by what is left, and a
+  // re-associated Σ moves the per-column log-det by up to 0.7 % there (K = 1000, y ~ N(0, 1.5²): 7 % of the columns beyond the 1e-3 bar
+  // against the Float32 oracle).  Float64 has the digits (all parity cases hold at 1e-6) and takes the scan.
+  static const int scan_env = getenv("BJX_SEQ_TALL_INV_SCAN") ? atoi(getenv("BJX_SEQ_TALL_INV_SCAN")) : -1;
+  const int inv_scan = scan_env >= 0 ? scan_env : (dt == BJX_F64 ? 1 : 0);
+  // with rounds the chunked walker is ahead beyond 512 rows (four chain operations per row and round)
+  if (which == BJX_TALL_SIMPLEX_INV && (rows > (inv_scan ? 2048 : inv_max) || rows < 129)) return BJX_OK;   // 65-128 rows: the whole-column tile is ahead (45 against 43 % at K = 100)
   // Float64 (same-box A/B, profiles/r03_tall_columns.md): the rounds of the Simplex inverse are four Float64 operations per row — the
   // walkers stay ahead at every height (39 / 35 % against 31 / 27 % at K = 200 / 500); beyond 32 lanes per column (512 rows) the
   // walkers are level or ahead for the other maps too (Ordered at K = 1000: 54 against 45 %)
-  if (dt == BJX_F64 && (which == BJX_TALL_SIMPLEX_INV || rows > 512)) return BJX_OK;
+  if (dt == BJX_F64 && rows > 512) return BJX_OK;
   const int G = (int)((rows + rpl - 1) / rpl), CPS = 64 / G;
   // lanes that hold rows of a column / lanes of the wave: K just above a multiple of RPL wastes most of the last lane
   const double eff = (double)rows * CPS / (64.0 * rpl);
   static const double min_eff = getenv("BJX_SEQ_TALL_EFF") ? atof(getenv("BJX_SEQ_TALL_EFF")) : 0.6;
   if (eff < min_eff) return BJX_OK;
   *taken = true;
-  if (dt == BJX_F32) return tall_dispatch<float>(ctx, which, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, rows_in, rows_out, batch, flags);
-  return tall_dispatch<double>(ctx, which, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, rows_in, rows_out, batch, flags);
+  if (dt == BJX_F32) return tall_dispatch<float>(ctx, which, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, rows_in, rows_out, batch, flags, inv_scan);
+  return tall_dispatch<double>(ctx, which, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, rows_in, rows_out, batch, flags, inv_scan);
 }
 
 // Pullback of the Simplex maps on tall columns; same contract as bjx_tall_stream
@@ -789,7 +862,7 @@ int bjx_tall_simplex_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in
   *taken = false;
   static const int use_tall = getenv("BJX_SIMPLEX_VJP_TALL") ? atoi(getenv("BJX_SIMPLEX_VJP_TALL")) : 1;
   static const long min_rows = getenv("BJX_SIMPLEX_VJP_TALL_MIN") ? atol(getenv("BJX_SIMPLEX_VJP_TALL_MIN")) : 65;
-  static const long inv_max = getenv("BJX_SIMPLEX_VJP_TALL_INV_MAX") ? atol(getenv("BJX_SIMPLEX_VJP_TALL_INV_MAX")) : 512;
+  static const long inv_max = getenv("BJX_SIMPLEX_VJP_TALL_INV_MAX") ? atol(getenv("BJX_SIMPLEX_VJP_TALL_INV_MAX")) : 2048;
   const int rpl = dt == BJX_F32 ? 32 : 16;
   if (!use_tall || batch <= 0 || K < min_rows || K > 64 * rpl) return BJX_OK;
   if (inverse && K > inv_max) return BJX_OK;
