@@ -434,6 +434,52 @@ __global__ __launch_bounds__(256) void chain_colgroup_kernel(const ChainArgs<T> 
   if (partials) block_publish_partial(acc, red, partials);
 }
 
+// Per-sample variant for SHORT columns that are not whole 16-byte packs (dim = 1 ... 13 except 4, 8, 12; same-box A/B: 43-67 % against 20-53 % for the walker, level at 14, behind at 15): lane = column, the column in
+// registers, no LDS and no cross-lane sum.  A wave instruction reads 64 consecutive columns = one contiguous run (dim·256 bytes), row
+// as one or two multi-dword accesses per lane (element-aligned: dwordx2 / x3 / x4 pieces).  UC columns per thread in flight.  (The mixed walker these
+// shapes took before spends ~150 VALU per row on slot decoding and tile addressing: 18-35 % of the HBM peak at dim = 2 ... 5, where
+// the whole-pack dim = 4 runs at 63-68 % — profiles/r03_small_sizes.md.  With one 4-byte load per row and lane instead of the
+// multi-dword pieces the same kernel ran at 37-43 % for dim <= 3 and BEHIND the walker from dim = 6.)
+template <class T, int DIM> struct __attribute__((aligned(sizeof(T)))) TinyCol { T v[DIM]; };   // element-aligned: the compiler moves it as dwordx2/x3/x4 pieces
+template <class T, int DIM, int ROWMODE, bool NT, int UC>
+__global__ __launch_bounds__(256) void chain_tiny_kernel(const ChainArgs<T> A, const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t batch,
+                                                         double c_ps_host, const double* c_ps_dev, int accumulate, double* partials) {
+  __shared__ double red[4];
+  const int64_t col0 = (int64_t)blockIdx.x * (256 * UC) + threadIdx.x;
+  Pack<T, 1> p[UC][DIM];
+#pragma unroll
+  for (int k = 0; k < UC; ++k) {
+    const int64_t col = col0 + (int64_t)k * 256;
+    TinyCol<T, DIM> t{};
+    if (col < batch) t = *reinterpret_cast<const TinyCol<T, DIM>*>(x + col * DIM);
+#pragma unroll
+    for (int u = 0; u < DIM; ++u) p[k][u].v[0] = t.v[u];
+  }
+  const double c_ps = c_ps_host + (c_ps_dev ? *c_ps_dev : 0.0);
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < UC; ++k) {
+    const int64_t col = col0 + (int64_t)k * 256;
+    int64_t r[DIM];
+#pragma unroll
+    for (int u = 0; u < DIM; ++u) r[u] = u;
+    const T l = apply_chain<T, 1, DIM, ROWMODE>(A, p[k], r, DIM);
+    if (col < batch) {
+      if (y) {
+        TinyCol<T, DIM> t;
+#pragma unroll
+        for (int u = 0; u < DIM; ++u) t.v[u] = p[k][u].v[0];
+        *reinterpret_cast<TinyCol<T, DIM>*>(y + col * DIM) = t;
+      }
+      T out = l + (T)c_ps;
+      if (accumulate) out += ladj_ps[col];
+      ladj_ps[col] = out;
+      acc += (double)l;
+    }
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
 // Per-sample variant for columns of at most G packs (one pack per lane) that are NOT a power of two of them (dim = 100, 200,
 // 252 ...): the group kernel above keeps ONE pack per lane in flight for such shapes (33 % of the roofline).  Here a block
 // takes U times as many columns and every lane holds the packs of U different columns — the same rows, so the per-row
@@ -632,6 +678,43 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
     // per-sample log-det needs no cross-lane sum either: the chain goes there as a single elementwise segment.
     // The same holds for columns that ARE whole packs but not a power-of-two number of them (dim = 24, 48, 100, 200 ...): the
     // group kernel below keeps one pack per lane in flight there (33 % of the roofline; the walker: 63-67 %).
+    static const int use_tiny = env_int("BJX_CHAIN_TINY", 1);
+    if (use_tiny && !v_ok && dim >= 1 && dim <= 13 && x && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0) {
+      // short columns that are not whole packs: lane = column, the column in registers (chain_tiny_kernel)
+      const int UCt = dim <= 7 ? 4 : 2;
+      const double* cdev_t = any_dev_scale ? ctx->consts : nullptr;
+      const int accum_t = (flags & BJX_ACCUMULATE) ? 1 : 0;
+      grid = (batch + 256 * UCt - 1) / (256 * UCt);
+      BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_chain: input too large for one launch");
+      if (ladj_sum) { int rc_ = bjx_ensure_partials(ctx, (size_t)grid); if (rc_) return rc_; }
+      double* partials_t = ladj_sum ? ctx->partials : nullptr;
+#define LAUNCH_TINY2(D_, RM_, UC_) hipLaunchKernelGGL((chain_tiny_kernel<T, D_, RM_, false, UC_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, x, y, ladj_ps, batch, c_ps_host, cdev_t, accum_t, partials_t)
+#define LAUNCH_TINY(D_, UC_) do { if (any_row) LAUNCH_TINY2(D_, 2, UC_); else LAUNCH_TINY2(D_, 0, UC_); } while (0)
+      bool launched = true;
+      {
+        BjxProf prof_(ctx);
+        switch ((int)dim) {
+          case 1: LAUNCH_TINY(1, 4); break;
+          case 2: LAUNCH_TINY(2, 4); break;
+          case 3: LAUNCH_TINY(3, 4); break;
+          case 5: LAUNCH_TINY(5, 4); break;
+          case 6: LAUNCH_TINY(6, 4); break;
+          case 7: LAUNCH_TINY(7, 4); break;
+          case 9: LAUNCH_TINY(9, 2); break;
+          case 10: LAUNCH_TINY(10, 2); break;
+          case 11: LAUNCH_TINY(11, 2); break;
+          case 13: LAUNCH_TINY(13, 2); break;
+          default: launched = false; break;      // Float64 even heights are whole packs (v_ok) and never get here; kept for safety
+        }
+      }
+#undef LAUNCH_TINY
+#undef LAUNCH_TINY2
+      if (launched) {
+        BJX_CHECK_LAUNCH(ctx);
+        if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, c_sum_host, any_dev_scale ? 1 : 0, 0.0, flags);
+        return BJX_OK;
+      }
+    }
     static const int use_walker = env_int("BJX_CHAIN_WALKER", 1);
     bool pow2_packs = false;
     if (v_ok) { const int64_t pk = dim / VW; pow2_packs = pk <= 64 && (pk & (pk - 1)) == 0; }

@@ -459,15 +459,20 @@ __device__ __forceinline__ T mixed_run_block(Op op, const T* pin, T* pout, int l
 template <class T, int V>
 __global__ __launch_bounds__(64) void stacked_mixed_kernel(const char* __restrict__ tab, int two_slots, const MixBlocks blocks, int n_blocks,
                                                          const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps, int rows_in, int rows_out,
-                                                         int shift, int P, int n_logn, int64_t batch, int accumulate, const BjxFin fin) {
+                                                         int shift, int P, int n_logn, int64_t batch, int accumulate, const BjxFin fin, int gpb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double red[1];
   T* tile = reinterpret_cast<T*>(smem);
   T* logn = tile + (size_t)64 * P;
   const int lane = threadIdx.x;
   for (int i = lane; i < n_logn; i += 64) logn[i] = d_log(T(i));
-  const int64_t col0 = (int64_t)blockIdx.x * 64;
+  double acc = 0.0;
+  // gpb groups of 64 columns per block (short columns: a group is a few hundred bytes)
+  for (int gi = 0; gi < gpb; ++gi) {
+  const int64_t col0 = ((int64_t)blockIdx.x * gpb + gi) * 64;
+  if (col0 >= batch) break;
   const int ncols = (int)((batch - col0) < 64 ? (batch - col0) : 64);
+  if (gi) tile_sync();                                                 // the previous group's stores have read the tile
   tile_stage_in<T, V>(tile + shift, in + col0 * rows_in, rows_in, P, ncols, lane);
   tile_sync();
   T lres = T(0);
@@ -528,7 +533,9 @@ __global__ __launch_bounds__(64) void stacked_mixed_kernel(const char* __restric
   }
   tile_sync();
   tile_stage_out<T, V>(tile, out + col0 * rows_out, rows_out, P, ncols, lane);
-  block_publish_partial(lane < ncols ? (double)lres : 0.0, red, fin);
+  acc += lane < ncols ? (double)lres : 0.0;
+  }
+  block_publish_partial(acc, red, fin);
 }
 
 template <class T>
@@ -582,7 +589,15 @@ int stacked_mixed_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const 
   BJX_REQUIRE(ctx, smem <= 64 * 1024, BJX_ERR_UNSUPPORTED, "bjx_stacked_mixed: columns of %lld rows exceed the LDS tile", (long long)rows_tile);
   StackedPlan pl;
   { int rc = stacked_prepare<T>(ctx, full.data(), (int)full.size(), x, y, rows_out, batch, false, false, &pl, rows_in, rows_out); if (rc) return rc; }
-  const int64_t grid = (batch + 63) / 64;
+  // groups of 64 columns per block: up to three when a group is under ~4 KiB, while the grid keeps >= 16 384 blocks (same-box sweep
+  // of BJX_MIXED_GPB = 1 / 2 / 3 / 4 / 6 / 8 at dim = 2, 3, 5, 10: +5-14 % at 2-3, nothing beyond — a wave that lives for more groups
+  // leaves too few waves per CU)
+  const int64_t groups = (batch + 63) / 64;
+  static const int gpb_env = getenv("BJX_MIXED_GPB") ? atoi(getenv("BJX_MIXED_GPB")) : 0;
+  int64_t gpb = gpb_env > 0 ? gpb_env : 8192 / (64 * (rows_in > rows_out ? rows_in : rows_out) * (int64_t)sizeof(T));
+  if (gpb_env <= 0) { if (gpb > 3) gpb = 3; if (gpb > groups / 16384) gpb = groups / 16384; }
+  gpb = gpb < 1 ? 1 : (gpb > 16 ? 16 : gpb);
+  const int64_t grid = (groups + gpb - 1) / gpb;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
   BjxFin fin;
   bool second = false;
@@ -594,9 +609,9 @@ int stacked_mixed_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const 
   {
     BjxProf prof_(ctx);
     if (v_ok) hipLaunchKernelGGL((stacked_mixed_kernel<T, VW>), dim3((unsigned)grid), dim3(64), smem, ctx->stream, pl.tab, pl.two, mb, n_blocks, x, y, ladj_ps,
-                                 (int)rows_in, (int)rows_out, (int)shift, (int)P, (int)max_len, batch, accum, fin);
+                                 (int)rows_in, (int)rows_out, (int)shift, (int)P, (int)max_len, batch, accum, fin, (int)gpb);
     else hipLaunchKernelGGL((stacked_mixed_kernel<T, 1>), dim3((unsigned)grid), dim3(64), smem, ctx->stream, pl.tab, pl.two, mb, n_blocks, x, y, ladj_ps,
-                            (int)rows_in, (int)rows_out, (int)shift, (int)P, (int)max_len, batch, accum, fin);
+                            (int)rows_in, (int)rows_out, (int)shift, (int)P, (int)max_len, batch, accum, fin, (int)gpb);
   }
   BJX_CHECK_LAUNCH(ctx);
   if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
