@@ -440,7 +440,6 @@ __global__ __launch_bounds__(256) void chain_colgroup_kernel(const ChainArgs<T> 
 // shapes took before spends ~150 VALU per row on slot decoding and tile addressing: 18-35 % of the HBM peak at dim = 2 ... 5, where
 // the whole-pack dim = 4 runs at 63-68 % — profiles/r03_small_sizes.md.  With one 4-byte load per row and lane instead of the
 // multi-dword pieces the same kernel ran at 37-43 % for dim <= 3 and BEHIND the walker from dim = 6.)
-template <class T, int DIM> struct __attribute__((aligned(sizeof(T)))) TinyCol { T v[DIM]; };   // element-aligned: the compiler moves it as dwordx2/x3/x4 pieces
 template <class T, int DIM, int ROWMODE, bool NT, int UC>
 __global__ __launch_bounds__(256) void chain_tiny_kernel(const ChainArgs<T> A, const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t batch,
                                                          double c_ps_host, const double* c_ps_dev, int accumulate, double* partials) {

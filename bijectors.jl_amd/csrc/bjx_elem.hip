@@ -887,6 +887,8 @@ int rqs_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int 
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
     return BJX_OK;
   }
+  // (Short odd columns, dim <= 7: the generic functor on the lane-per-column kernel of bjx_stream.h was tried in round 3 — 29-34 %
+  //  against 29-37 % for the LDS-blob kernel with one-element packs: the functor's search, not the access width, is the cost there.)
   {
     bool taken = false;
     const int rc = rqs_lds_slab<T>(ctx, inverse, w, h, d, K1, dim, in, out, ladj_ps, ladj_sum, dim, dim, batch, flags, &taken);

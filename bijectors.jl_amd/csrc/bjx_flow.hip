@@ -1667,7 +1667,9 @@ __global__ __launch_bounds__(256) void flow_sets_reduce_kernel(const double* __r
 // roofline).  Here a wave takes 64 consecutive columns — one contiguous run, 16-byte packs through a [64][P odd] LDS tile — lane t
 // keeps column t in registers and runs the whole stack on it: dot products and rank-1 updates are plain FMAs of the lane, the
 // layer parameters are wave-uniform (scalar loads), nothing crosses lanes.
-template <class T, int DMAX, bool INV, int V>
+// DX > 0: columns of exactly DX <= 8 rows are read and written by their lane directly (TinyCol: one or two
+// multi-dword accesses), no tile: at dim = 2 ... 7 the staging, not the stack, was the cost (1 layer, dim = 2 / 3 / 5: 24 / 34 / 43 %).
+template <class T, int DMAX, bool INV, int V, int DX = 0>
 __global__ __launch_bounds__(64) void planar_walk_kernel(const T* __restrict__ Aw, const T* __restrict__ Auh, const T* __restrict__ Ac, const T* __restrict__ Ab, int n_layers,
                                                          const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int dim, int P,
                                                          int64_t batch, int accumulate, double* partials) {
@@ -1693,12 +1695,19 @@ __global__ __launch_bounds__(64) void planar_walk_kernel(const T* __restrict__ A
   double acc = 0.0;
   for (int64_t c0 = (int64_t)blockIdx.x * 64; c0 < batch; c0 += (int64_t)gridDim.x * 64) {
     const int ncols = (int)((batch - c0) < 64 ? (batch - c0) : 64);
-    tile_stage_in<T, V>(tile, x + c0 * dim, dim, P, ncols, lane);
-    tile_sync();
     T* mine = tile + lane * P;
     T z[DMAX];
+    if constexpr (DX > 0) {
+      TinyCol<T, DX> t{};
+      if (lane < ncols) t = *reinterpret_cast<const TinyCol<T, DX>*>(x + (c0 + lane) * DX);
 #pragma unroll
-    for (int r = 0; r < DMAX; ++r) z[r] = r < dim ? mine[r] : T(0);
+      for (int r = 0; r < DMAX; ++r) z[r] = r < DX ? t.v[r < DX ? r : 0] : T(0);
+    } else {
+      tile_stage_in<T, V>(tile, x + c0 * dim, dim, P, ncols, lane);
+      tile_sync();
+#pragma unroll
+      for (int r = 0; r < DMAX; ++r) z[r] = r < dim ? mine[r] : T(0);
+    }
     T ladj = T(0);
     for (int li = 0; li < n_layers; ++li) {
       const int l = INV ? n_layers - 1 - li : li;
@@ -1731,13 +1740,22 @@ __global__ __launch_bounds__(64) void planar_walk_kernel(const T* __restrict__ A
       for (int r = 0; r < DMAX; ++r) q += z[r] * z[r];
       ladj += T(-0.5) * q - (T)dim * T(0.91893853320467274178);
     }
-    if (y) {
+    if constexpr (DX > 0) {
+      if (y && lane < ncols) {
+        TinyCol<T, DX> t;
 #pragma unroll
-      for (int r = 0; r < DMAX; ++r) if (r < dim) mine[r] = z[r];
+        for (int r = 0; r < DX; ++r) t.v[r] = z[r];
+        *reinterpret_cast<TinyCol<T, DX>*>(y + (c0 + lane) * DX) = t;
+      }
+    } else {
+      if (y) {
+#pragma unroll
+        for (int r = 0; r < DMAX; ++r) if (r < dim) mine[r] = z[r];
+      }
+      tile_sync();
+      if (y) tile_stage_out<T, V>(tile, y + c0 * dim, dim, P, ncols, lane);
+      tile_sync();
     }
-    tile_sync();
-    if (y) tile_stage_out<T, V>(tile, y + c0 * dim, dim, P, ncols, lane);
-    tile_sync();
     if (lane < ncols) {
       if (ladj_ps) ladj_ps[c0 + lane] = (accumulate & 1) ? ladj_ps[c0 + lane] + ladj : ladj;
       acc += (double)ladj;
@@ -1847,7 +1865,7 @@ __global__ __launch_bounds__(64) void planar_vjp_walk_kernel(const T* __restrict
 }
 
 // radial_layer.jl:43-72 (forward) and :88-129 (inverse), same arithmetic as radial_kernel
-template <class T, int DMAX, bool INV, int V>
+template <class T, int DMAX, bool INV, int V, int DX = 0>     // DX > 0: see planar_walk_kernel
 __global__ __launch_bounds__(64) void radial_walk_kernel(const T* __restrict__ Aalpha, const T* __restrict__ Abeta, const T* __restrict__ Az0, const T* __restrict__ x,
                                                          T* __restrict__ y, T* __restrict__ ladj_ps, int dim, int P, int64_t batch, int accumulate, double* partials) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1860,13 +1878,23 @@ __global__ __launch_bounds__(64) void radial_walk_kernel(const T* __restrict__ A
   double acc = 0.0;
   for (int64_t c0 = (int64_t)blockIdx.x * 64; c0 < batch; c0 += (int64_t)gridDim.x * 64) {
     const int ncols = (int)((batch - c0) < 64 ? (batch - c0) : 64);
-    tile_stage_in<T, V>(tile, x + c0 * dim, dim, P, ncols, lane);
-    tile_sync();
     T* mine = tile + lane * P;
+    T xin[DX > 0 ? DX : 1];
     T dz[DMAX];
     T ss = T(0);
+    if constexpr (DX > 0) {
+      TinyCol<T, DX> t{};
+      if (lane < ncols) t = *reinterpret_cast<const TinyCol<T, DX>*>(x + (c0 + lane) * DX);
 #pragma unroll
-    for (int r = 0; r < DMAX; ++r) { dz[r] = r < dim ? mine[r] - Az0[r] : T(0); ss += dz[r] * dz[r]; }
+      for (int r = 0; r < DX; ++r) xin[r] = t.v[r];
+#pragma unroll
+      for (int r = 0; r < DMAX; ++r) { dz[r] = r < DX ? xin[r < DX ? r : 0] - Az0[r < DX ? r : 0] : T(0); ss += dz[r] * dz[r]; }
+    } else {
+      tile_stage_in<T, V>(tile, x + c0 * dim, dim, P, ncols, lane);
+      tile_sync();
+#pragma unroll
+      for (int r = 0; r < DMAX; ++r) { dz[r] = r < dim ? mine[r] - Az0[r] : T(0); ss += dz[r] * dz[r]; }
+    }
     T r_fwd, gain;
     if (!INV) {
       r_fwd = d_sqrt(ss);
@@ -1882,16 +1910,25 @@ __global__ __launch_bounds__(64) void radial_walk_kernel(const T* __restrict__ A
     T ld = T(dim - 1) * d_log(T(1) + beta_hat * h_) + d_log(T(1) + beta_hat * h_ + beta_hat * (-(h_ * h_)) * r_fwd);   // :68-70
     if (INV) ld = -ld;
     const T fwd_gain = beta_hat / (alpha + r_fwd);
+    if constexpr (DX > 0) {
+      if (lane < ncols) {
+        TinyCol<T, DX> t;
 #pragma unroll
-    for (int r = 0; r < DMAX; ++r) {
-      if (r < dim) {
-        if (!INV) mine[r] = mine[r] + fwd_gain * dz[r];             // :52
-        else mine[r] = Az0[r] + gain * dz[r];                      // :101
+        for (int r = 0; r < DX; ++r) t.v[r] = !INV ? xin[r] + fwd_gain * dz[r] : Az0[r] + gain * dz[r];   // :52 / :101
+        *reinterpret_cast<TinyCol<T, DX>*>(y + (c0 + lane) * DX) = t;
       }
+    } else {
+#pragma unroll
+      for (int r = 0; r < DMAX; ++r) {
+        if (r < dim) {
+          if (!INV) mine[r] = mine[r] + fwd_gain * dz[r];             // :52
+          else mine[r] = Az0[r] + gain * dz[r];                      // :101
+        }
+      }
+      tile_sync();
+      tile_stage_out<T, V>(tile, y + c0 * dim, dim, P, ncols, lane);
+      tile_sync();
     }
-    tile_sync();
-    tile_stage_out<T, V>(tile, y + c0 * dim, dim, P, ncols, lane);
-    tile_sync();
     if (lane < ncols) {
       if (ladj_ps) ladj_ps[c0 + lane] = accumulate ? ladj_ps[c0 + lane] + ld : ld;
       acc += (double)ld;
@@ -2011,7 +2048,9 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
   //  dim 40-64 walker 56-60 % / 27-31 % vs 72-74 % / 55-71 %: the register tile wins once a column fills 10+ lanes)
   if (dim <= walk_max && dim <= 32 && (size_t)nl * 68 * sizeof(T) <= 32 * 1024) {
     constexpr int VW = Vec16<T>::N;
-    const int P = (int)(dim | 1);
+    static const int use_direct = getenv("BJX_PLANAR_WALK_DIRECT") ? atoi(getenv("BJX_PLANAR_WALK_DIRECT")) : 1;
+    const bool direct = use_direct && dim <= 8;                      // short columns: no tile (DX = dim)
+    const int P = direct ? 0 : (int)(dim | 1);
     const int dmax = dim <= 4 ? 4 : (dim <= 8 ? 8 : (dim <= 16 ? 16 : 32));
     const size_t smem_w = ((((size_t)64 * P + 3) / 4) * 4 + (size_t)nl * (2 * dmax + 4)) * sizeof(T);
     const int64_t tiles = (batch + 63) / 64;
@@ -2026,7 +2065,22 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
 #define PW(D_, I_, V_) hipLaunchKernelGGL((planar_walk_kernel<T, D_, I_, V_>), dim3(grid_w), dim3(64), smem_w, ctx->stream, (const T*)w, (const T*)u_hat, (const T*)wtu, (const T*)b, nl, in, out, ladj_ps, (int)dim, P, batch, accum, partials_w)
 #define PW_V(D_, I_) do { if (vec) PW(D_, I_, VW); else PW(D_, I_, 1); } while (0)
 #define PW_D(I_) do { if (dim <= 4) PW_V(4, I_); else if (dim <= 8) PW_V(8, I_); else if (dim <= 16) PW_V(16, I_); else PW_V(32, I_); } while (0)
-      if (inverse) PW_D(true); else PW_D(false);
+#define PWX(D_, X_) do { if (inverse) hipLaunchKernelGGL((planar_walk_kernel<T, D_, true, 1, X_>), dim3(grid_w), dim3(64), smem_w, ctx->stream, (const T*)w, (const T*)u_hat, (const T*)wtu, (const T*)b, nl, in, out, ladj_ps, (int)dim, P, batch, accum, partials_w); \
+                          else hipLaunchKernelGGL((planar_walk_kernel<T, D_, false, 1, X_>), dim3(grid_w), dim3(64), smem_w, ctx->stream, (const T*)w, (const T*)u_hat, (const T*)wtu, (const T*)b, nl, in, out, ladj_ps, (int)dim, P, batch, accum, partials_w); } while (0)
+      if (direct) {
+        switch ((int)dim) {
+          case 1: PWX(4, 1); break;
+          case 2: PWX(4, 2); break;
+          case 3: PWX(4, 3); break;
+          case 4: PWX(4, 4); break;
+          case 5: PWX(8, 5); break;
+          case 6: PWX(8, 6); break;
+          case 7: PWX(8, 7); break;
+          default: PWX(8, 8); break;
+        }
+      }
+      else if (inverse) PW_D(true); else PW_D(false);
+#undef PWX
 #undef PW_D
 #undef PW_V
 #undef PW
@@ -2330,9 +2384,11 @@ int radial_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const
   }
   static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 32;
   static const int walk_all = getenv("BJX_RADIAL_WALK_ALL") ? atoi(getenv("BJX_RADIAL_WALK_ALL")) : 0;
+  static const int use_direct = getenv("BJX_PLANAR_WALK_DIRECT") ? atoi(getenv("BJX_PLANAR_WALK_DIRECT")) : 1;
   if (dim <= walk_max && dim <= 32 && (dim % Vec16<T>::N != 0 || walk_all)) {      // whole-pack columns stream at 71 % on the group kernel already
     constexpr int VW = Vec16<T>::N;
-    const int P = (int)(dim | 1);
+    const bool direct = use_direct && dim <= 7;                      // short columns: no tile (DX = dim)
+    const int P = direct ? 0 : (int)(dim | 1);
     const size_t smem_w = (size_t)64 * P * sizeof(T);
     const int64_t tiles = (batch + 63) / 64;
     const int64_t cap = (int64_t)ctx->num_cu * 32;
@@ -2346,7 +2402,21 @@ int radial_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const
 #define RW(D_, I_, V_) hipLaunchKernelGGL((radial_walk_kernel<T, D_, I_, V_>), dim3(grid_w), dim3(64), smem_w, ctx->stream, alpha_, beta, z0, in, out, ladj_ps, (int)dim, P, batch, accum, partials_w)
 #define RW_V(D_, I_) do { if (vec) RW(D_, I_, VW); else RW(D_, I_, 1); } while (0)
 #define RW_D(I_) do { if (dim <= 4) RW_V(4, I_); else if (dim <= 8) RW_V(8, I_); else if (dim <= 16) RW_V(16, I_); else RW_V(32, I_); } while (0)
-      if (inverse) RW_D(true); else RW_D(false);
+#define RWX(D_, X_) do { if (inverse) hipLaunchKernelGGL((radial_walk_kernel<T, D_, true, 1, X_>), dim3(grid_w), dim3(64), smem_w, ctx->stream, alpha_, beta, z0, in, out, ladj_ps, (int)dim, P, batch, accum, partials_w); \
+                          else hipLaunchKernelGGL((radial_walk_kernel<T, D_, false, 1, X_>), dim3(grid_w), dim3(64), smem_w, ctx->stream, alpha_, beta, z0, in, out, ladj_ps, (int)dim, P, batch, accum, partials_w); } while (0)
+      if (direct) {
+        switch ((int)dim) {
+          case 1: RWX(4, 1); break;
+          case 2: RWX(4, 2); break;
+          case 3: RWX(4, 3); break;
+          case 4: RWX(4, 4); break;
+          case 5: RWX(8, 5); break;
+          case 6: RWX(8, 6); break;
+          default: RWX(8, 7); break;
+        }
+      }
+      else if (inverse) RW_D(true); else RW_D(false);
+#undef RWX
 #undef RW_D
 #undef RW_V
 #undef RW

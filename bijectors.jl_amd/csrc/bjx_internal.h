@@ -722,6 +722,10 @@ template <class T, int V, bool NT> __device__ __forceinline__ void store_pack(T*
   }
 }
 
+// A whole short column as one object, element-aligned: the compiler moves it as dwordx2 / x3 / x4 pieces (global accesses need
+// only element alignment), so a lane reads its column of 2 ... 13 rows in one to four instructions
+template <class T, int DIM> struct __attribute__((aligned(sizeof(T)))) TinyCol { T v[DIM]; };
+
 // Buffer-addressed packs (raw buffer, stride 0): address = base + voffset, and an access whose voffset + size exceeds
 // the descriptor's extent reads zeros / is dropped.  Streaming (nt) like the NT packs above.
 typedef unsigned int bjx_u32x4 __attribute__((ext_vector_type(4)));

@@ -176,6 +176,41 @@ __global__ __launch_bounds__(64) void colwalk_kernel(const F f, const T* x, T* y
   block_publish_partial(lane < ncols ? (double)l : 0.0, red, fin);
 }
 
+// The same for SHORT columns (DX = dim <= 7 rows, not whole packs): lane = column, the column read and written by its lane as one
+// or two multi-dword accesses (TinyCol) — no tile, no staging; 256-thread blocks, the functor's tables staged once per block.  At
+// dim = 2 ... 5 the walker above spends its time on the tile, not on the map (profiles/r03_small_sizes.md: 22-42 % whatever the functor).
+template <class T, int DX, class F>
+__global__ __launch_bounds__(256) void coldirect_kernel(const F f, const T* x, T* y, T* ladj_ps, int64_t batch, int accumulate, const BjxFin fin) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);   // first 32 bytes
+  char* fsm = smem + 32;
+  f.stage(fsm);
+  __syncthreads();
+  const double psc = f.per_sample_const + (f.per_sample_dev ? *f.per_sample_dev : 0.0);
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  T l = T(0);
+  if (col < batch) {
+    const T* xcol = x + col * DX;
+    TinyCol<T, DX> t{};
+    if (F::kLoadInput) t = *reinterpret_cast<const TinyCol<T, DX>*>(xcol);
+#pragma unroll
+    for (int r = 0; r < DX; ++r) {
+      Pack<T, 1> p;
+      p.v[0] = t.v[r];
+      if constexpr (col_has_aux<F>::value) { const auto aux = f.template fetch<1>(fsm, (int64_t)r, col); l += f.template apply<1>(fsm, p, aux, xcol, (int64_t)r, col); }
+      else l += f.template apply<1>(fsm, p, xcol, (int64_t)r, col);
+      t.v[r] = p.v[0];
+    }
+    *reinterpret_cast<TinyCol<T, DX>*>(y + col * DX) = t;
+    if (ladj_ps) {
+      T out = l + (T)psc;
+      if (accumulate) out += ladj_ps[col];
+      ladj_ps[col] = out;
+    }
+  }
+  block_publish_partial(col < batch ? (double)l : 0.0, red, fin);
+}
+
 struct ColLaunch {
   int V, G;
   int64_t grid;
@@ -215,6 +250,31 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
     const int64_t P = dim | 1;
     const size_t f_pad = (f_smem + 15) / 16 * 16;
     const size_t smem_w = 32 + f_pad + (size_t)64 * P * sizeof(T);
+    static const int use_direct = getenv("BJX_COLDIRECT") ? atoi(getenv("BJX_COLDIRECT")) : 1;
+    if (use_direct && !force_v1 && dim % VWW != 0 && dim <= 7 && ldx == dim && ldy == dim && 32 + f_smem <= 64 * 1024) {
+      const int64_t grid_d = (batch + 255) / 256;
+      BJX_REQUIRE(ctx, grid_d < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+      BjxFin fin;
+      bool second = false;
+      { int rc = bjx_make_fin(ctx, grid_d, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, flags, &fin, &second); if (rc) return rc; }
+      const int accum_d = (flags & BJX_ACCUMULATE) ? 1 : 0;
+#define BJX_CD(X_) hipLaunchKernelGGL((coldirect_kernel<T, X_, F>), dim3((unsigned)grid_d), dim3(256), 32 + f_smem, ctx->stream, f, x, y, ladj_ps, batch, accum_d, fin)
+      {
+        BjxProf prof_(ctx);
+        switch ((int)dim) {
+          case 1: BJX_CD(1); break;
+          case 2: BJX_CD(2); break;
+          case 3: BJX_CD(3); break;
+          case 5: BJX_CD(5); break;
+          case 6: BJX_CD(6); break;
+          default: BJX_CD(7); break;
+        }
+      }
+#undef BJX_CD
+      BJX_CHECK_LAUNCH(ctx);
+      if (second) return bjx_launch_finalize(ctx, (int)grid_d, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, 0.0, flags);
+      return BJX_OK;
+    }
     if (use_walk && !force_v1 && dim % VWW != 0 && ldx == dim && ldy == dim && (const void*)x != (const void*)y && smem_w <= 64 * 1024) {
       const int64_t grid_w = (batch + 63) / 64;
       BJX_REQUIRE(ctx, grid_w < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
