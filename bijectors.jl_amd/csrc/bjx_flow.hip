@@ -1770,7 +1770,7 @@ __device__ __forceinline__ double walk_tanh(double v) { return x_tanh(v); }
 // through two odd-pitch tiles, the primal sweep leaves t_k = tanh(·) of every layer in the lane's strip of LDS scratch, the reverse
 // sweep runs on the cotangent in registers.  t_out / s_out (the per-column, per-layer values the parameter pullback reads) as in
 // planar_vjp_kernel.
-template <class T, int DMAX, bool INV, int V>
+template <class T, int DMAX, bool INV, int V, int DX = 0>     // DX > 0: x, ȳ and x̄ move per lane as whole columns (see planar_walk_kernel)
 __global__ __launch_bounds__(64) void planar_vjp_walk_kernel(const T* __restrict__ Aw, const T* __restrict__ Auh, const T* __restrict__ Ac, const T* __restrict__ Ab, int n_layers,
                                                              const T* __restrict__ x, const T* __restrict__ ybar, const T* __restrict__ lbar, T* __restrict__ xbar, int dim, int P, int NLP,
                                                              int64_t batch, T* __restrict__ t_out, T* __restrict__ s_out) {
@@ -1794,15 +1794,25 @@ __global__ __launch_bounds__(64) void planar_vjp_walk_kernel(const T* __restrict
   tile_sync();
   for (int64_t c0 = (int64_t)blockIdx.x * 64; c0 < batch; c0 += (int64_t)gridDim.x * 64) {
     const int ncols = (int)((batch - c0) < 64 ? (batch - c0) : 64);
-    tile_stage_in<T, V>(tx, x + c0 * dim, dim, P, ncols, lane);
-    tile_stage_in<T, V>(tg, ybar + c0 * dim, dim, P, ncols, lane);
-    tile_sync();
     T* mx = tx + lane * P;
     const T* mg = tg + lane * P;
     T* tm = tsave + lane * NLP;
     T z[DMAX];
+    T gin[DX > 0 ? DX : 1];
+    if constexpr (DX > 0) {
+      TinyCol<T, DX> t{}, g{};
+      if (lane < ncols) { t = *reinterpret_cast<const TinyCol<T, DX>*>(x + (c0 + lane) * DX); g = *reinterpret_cast<const TinyCol<T, DX>*>(ybar + (c0 + lane) * DX); }
 #pragma unroll
-    for (int r = 0; r < DMAX; ++r) z[r] = r < dim ? mx[r] : T(0);
+      for (int r = 0; r < DMAX; ++r) z[r] = r < DX ? t.v[r < DX ? r : 0] : T(0);
+#pragma unroll
+      for (int r = 0; r < DX; ++r) gin[r] = g.v[r];
+    } else {
+      tile_stage_in<T, V>(tx, x + c0 * dim, dim, P, ncols, lane);
+      tile_stage_in<T, V>(tg, ybar + c0 * dim, dim, P, ncols, lane);
+      tile_sync();
+#pragma unroll
+      for (int r = 0; r < DMAX; ++r) z[r] = r < dim ? mx[r] : T(0);
+    }
     auto dot = [&](const T* row) -> T {
       T s0 = T(0), s1 = T(0);
 #pragma unroll
@@ -1829,8 +1839,13 @@ __global__ __launch_bounds__(64) void planar_vjp_walk_kernel(const T* __restrict
         axpy(tl + DMAX, -t);
       }
     }
+    if constexpr (DX > 0) {
 #pragma unroll
-    for (int r = 0; r < DMAX; ++r) z[r] = r < dim ? mg[r] : T(0);
+      for (int r = 0; r < DMAX; ++r) z[r] = r < DX ? gin[r < DX ? r : 0] : T(0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < DMAX; ++r) z[r] = r < dim ? mg[r] : T(0);
+    }
     const int64_t col = c0 + lane;
     const T lb = (lbar && lane < ncols) ? lbar[col] : T(0);
     if (!INV) {
@@ -1852,10 +1867,20 @@ __global__ __launch_bounds__(64) void planar_vjp_walk_kernel(const T* __restrict
         axpy(tl, sb);
       }
     }
+    if constexpr (DX > 0) {
+      if (lane < ncols) {
+        TinyCol<T, DX> t;
 #pragma unroll
-    for (int r = 0; r < DMAX; ++r) if (r < dim) mx[r] = z[r];
-    tile_sync();
-    tile_stage_out<T, V>(tx, xbar + c0 * dim, dim, P, ncols, lane);
+        for (int r = 0; r < DX; ++r) t.v[r] = z[r];
+        *reinterpret_cast<TinyCol<T, DX>*>(xbar + (c0 + lane) * DX) = t;
+      }
+      tile_sync();
+    } else {
+#pragma unroll
+      for (int r = 0; r < DMAX; ++r) if (r < dim) mx[r] = z[r];
+      tile_sync();
+      tile_stage_out<T, V>(tx, xbar + c0 * dim, dim, P, ncols, lane);
+    }
     if (s_out) {
       tile_stage_out<T, V>(ssave, s_out + c0 * n_layers, n_layers, NLP, ncols, lane);
       tile_stage_out<T, V>(tsave, t_out + c0 * n_layers, n_layers, NLP, ncols, lane);
@@ -2310,7 +2335,9 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
     // low-dimensional columns: one lane per column (planar_vjp_walk_kernel)
     static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 32;
     const int dmax = dim <= 4 ? 4 : (dim <= 8 ? 8 : (dim <= 16 ? 16 : 32));
-    const int64_t P = dim | 1, NLP = nl | 1;
+    static const int use_direct = getenv("BJX_PLANAR_WALK_DIRECT") ? atoi(getenv("BJX_PLANAR_WALK_DIRECT")) : 1;
+    const bool direct = use_direct && dim <= 8;                      // short columns: no data tiles (DX = dim)
+    const int64_t P = direct ? 0 : (dim | 1), NLP = nl | 1;
     const size_t smem_w = ((size_t)2 * 64 * P + (size_t)64 * NLP + (((size_t)64 * NLP + 3) / 4) * 4 + (size_t)nl * (2 * dmax + 4)) * sizeof(T);
     if (dim <= walk_max && dim <= 32 && smem_w <= 60 * 1024 && (const void*)in != (const void*)in_bar) {
       constexpr int VW = Vec16<T>::N;
@@ -2324,7 +2351,25 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
                                            in, out_bar, ladj_bar, in_bar, (int)dim, (int)P, (int)NLP, batch, t_out, s_out)
 #define PVW_V(D_, I_) do { if (vec) PVW(D_, I_, VW); else PVW(D_, I_, 1); } while (0)
 #define PVW_D(I_) do { if (dim <= 4) PVW_V(4, I_); else if (dim <= 8) PVW_V(8, I_); else if (dim <= 16) PVW_V(16, I_); else PVW_V(32, I_); } while (0)
-        if (inverse) PVW_D(true); else PVW_D(false);
+#define PVWX2(D_, X_, I_, V_) hipLaunchKernelGGL((planar_vjp_walk_kernel<T, D_, I_, V_, X_>), dim3(grid_w), dim3(64), smem_w, ctx->stream, (const T*)w, (const T*)u_hat, (const T*)wtu, (const T*)b, nl, \
+                                                 in, out_bar, ladj_bar, in_bar, (int)dim, (int)P, (int)NLP, batch, t_out, s_out)
+        const bool vec_ts = !t_out || (bjx_aligned16(t_out) && bjx_aligned16(s_out));   // V only moves the per-layer t / s̄ tiles in this mode
+#define PVWX(D_, X_) do { if (inverse) { if (vec_ts) PVWX2(D_, X_, true, VW); else PVWX2(D_, X_, true, 1); } else { if (vec_ts) PVWX2(D_, X_, false, VW); else PVWX2(D_, X_, false, 1); } } while (0)
+        if (direct) {
+          switch ((int)dim) {
+            case 1: PVWX(4, 1); break;
+            case 2: PVWX(4, 2); break;
+            case 3: PVWX(4, 3); break;
+            case 4: PVWX(4, 4); break;
+            case 5: PVWX(8, 5); break;
+            case 6: PVWX(8, 6); break;
+            case 7: PVWX(8, 7); break;
+            default: PVWX(8, 8); break;
+          }
+        }
+        else if (inverse) PVW_D(true); else PVW_D(false);
+#undef PVWX
+#undef PVWX2
 #undef PVW_D
 #undef PVW_V
 #undef PVW
