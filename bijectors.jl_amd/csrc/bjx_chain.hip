@@ -678,6 +678,21 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
     // The same holds for columns that ARE whole packs but not a power-of-two number of them (dim = 24, 48, 100, 200 ...): the
     // group kernel below keeps one pack per lane in flight there (33 % of the roofline; the walker: 63-67 %).
     static const int use_tiny = env_int("BJX_CHAIN_TINY", 1);
+    // dim <= 7: the one-segment Stacked route below reaches stacked_tiny_kernel, which is ahead there (68-73 % against 48-67 %); this
+    // kernel then serves what that route does not take (in-place calls, chains with more than two nonlinear stages) and dim = 9 ... 13
+    bool via_stacked = false;
+    if (dim <= 7 && !v_ok && y && (const void*)x != (const void*)y && n_ops <= BJX_MAX_SEG_OPS && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0 && env_int("BJX_CHAIN_WALKER", 1)) {
+      via_stacked = true;
+      for (int k = 0; k < n_ops; ++k) via_stacked = via_stacked && ops[k].kind >= BJX_OP_EXP && ops[k].kind <= BJX_OP_IDENTITY;
+    }
+    if (via_stacked) {
+      bjx_segment sg;
+      memset(&sg, 0, sizeof(sg));
+      sg.in_lo = 0; sg.out_lo = 0; sg.len = dim; sg.n_ops = n_ops;
+      for (int k = 0; k < n_ops; ++k) sg.ops[k] = ops[k];
+      const int rc_w = bjx_stacked_mixed(ctx, sizeof(T) == 4 ? BJX_F32 : BJX_F64, &sg, 1, nullptr, 0, x, dim, y, dim, ladj_ps, ladj_sum, batch, flags);
+      if (rc_w != BJX_ERR_UNSUPPORTED) return rc_w;
+    }
     if (use_tiny && !v_ok && dim >= 1 && dim <= 13 && x && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0) {
       // short columns that are not whole packs: lane = column, the column in registers (chain_tiny_kernel)
       const int UCt = dim <= 7 ? 4 : 2;

@@ -538,6 +538,37 @@ __global__ __launch_bounds__(64) void stacked_mixed_kernel(const char* __restric
   block_publish_partial(acc, red, fin);
 }
 
+// SHORT columns without structured blocks (a model's joint link: Stacked(exp | Logit | identity ...) on 2 ... 10 parameters; same-box A/B: 68-73 % at 3 ... 7 rows, 56 % at 9 ... 10, level at 11, behind at 13): lane =
+// column, the column read and written by its lane as multi-dword accesses (TinyCol), the slots of a row wave-uniform scalar loads, the
+// gather `src` a select chain over the lane's DX registers.  No tile: at dim = 3 ... 7 the walker above spends ~150 VALU per row on
+// staging and slot fetches (27-45 % of the HBM peak, profiles/r03_small_sizes.md).
+template <class T, int DX>
+__global__ __launch_bounds__(256) void stacked_tiny_kernel(const char* __restrict__ tab, int two_slots, const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps,
+                                                           int64_t batch, int accumulate, const BjxFin fin) {
+  __shared__ double red[4];
+  constexpr size_t RB = stacked_row_bytes<T>();
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  T lres = T(0);
+  if (col < batch) {
+    const TinyCol<T, DX> t = *reinterpret_cast<const TinyCol<T, DX>*>(in + col * DX);
+    TinyCol<T, DX> o;
+#pragma unroll
+    for (int r = 0; r < DX; ++r) {
+      const Slot<T>* sl = reinterpret_cast<const Slot<T>*>(tab + (size_t)r * RB);
+      const Slot<T> s0 = sl[0];
+      T v = t.v[0];
+#pragma unroll
+      for (int k = 1; k < DX; ++k) v = s0.src == k ? t.v[k] : v;       // the source row is the same in every lane
+      lres += slot_eval(s0, v);
+      if (two_slots) { const Slot<T> s1 = sl[1]; if (s1.kind != SK_END) lres += slot_eval(s1, v); }
+      o.v[r] = v;
+    }
+    *reinterpret_cast<TinyCol<T, DX>*>(out + col * DX) = o;
+    if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + lres : lres;
+  }
+  block_publish_partial(col < batch ? (double)lres : 0.0, red, fin);
+}
+
 template <class T>
 int stacked_mixed_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const bjx_block* blocks, int n_blocks, const T* x, int64_t rows_in, T* y,
                        int64_t rows_out, T* ladj_ps, double* ladj_sum, int64_t batch, uint32_t flags) {
@@ -589,6 +620,37 @@ int stacked_mixed_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const 
   BJX_REQUIRE(ctx, smem <= 64 * 1024, BJX_ERR_UNSUPPORTED, "bjx_stacked_mixed: columns of %lld rows exceed the LDS tile", (long long)rows_tile);
   StackedPlan pl;
   { int rc = stacked_prepare<T>(ctx, full.data(), (int)full.size(), x, y, rows_out, batch, false, false, &pl, rows_in, rows_out); if (rc) return rc; }
+  static const int use_tiny = getenv("BJX_STACKED_TINY") ? atoi(getenv("BJX_STACKED_TINY")) : 1;
+  if (use_tiny && n_blocks == 0 && rows_in == rows_out && shift == 0 && rows_out <= 10 && rows_out % Vec16<T>::N != 0) {
+    const int64_t grid_t = (batch + 255) / 256;
+    BJX_REQUIRE(ctx, grid_t < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+    BjxFin fin_t;
+    bool second_t = false;
+    { int rc = bjx_make_fin(ctx, grid_t, ladj_sum, 0.0, 0, flags, &fin_t, &second_t); if (rc) return rc; }
+    const int accum_t = (flags & BJX_ACCUMULATE) ? 1 : 0;
+#define BJX_ST(X_) hipLaunchKernelGGL((stacked_tiny_kernel<T, X_>), dim3((unsigned)grid_t), dim3(256), 0, ctx->stream, pl.tab, pl.two, x, y, ladj_ps, batch, accum_t, fin_t)
+    bool launched = true;
+    {
+      BjxProf prof_(ctx);
+      switch ((int)rows_out) {
+        case 1: BJX_ST(1); break;
+        case 2: BJX_ST(2); break;
+        case 3: BJX_ST(3); break;
+        case 5: BJX_ST(5); break;
+        case 6: BJX_ST(6); break;
+        case 7: BJX_ST(7); break;
+        case 9: BJX_ST(9); break;
+        case 10: BJX_ST(10); break;
+        default: launched = false; break;
+      }
+    }
+#undef BJX_ST
+    if (launched) {
+      BJX_CHECK_LAUNCH(ctx);
+      if (second_t) return bjx_launch_finalize(ctx, (int)grid_t, ladj_sum, 0.0, 0, 0.0, flags);
+      return BJX_OK;
+    }
+  }
   // groups of 64 columns per block: up to three when a group is under ~4 KiB, while the grid keeps >= 16 384 blocks (same-box sweep
   // of BJX_MIXED_GPB = 1 / 2 / 3 / 4 / 6 / 8 at dim = 2, 3, 5, 10: +5-14 % at 2-3, nothing beyond — a wave that lives for more groups
   // leaves too few waves per CU)
