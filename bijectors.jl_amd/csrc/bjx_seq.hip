@@ -2501,6 +2501,12 @@ int ordered_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, dou
     return launch_seq<T>(ctx, OrderedInv<T>{}, in, out, ladj_ps, ladj_sum, dim, dim, batch, 0, flags, ld_in, ld_out);
   }
   {
+    bool taken = false;                                                // 1 ... 7 rows: lane = column in registers (bjx_tiny.hip)
+    const int rc = bjx_seq_tiny(ctx, sizeof(T) == 4 ? BJX_F32 : BJX_F64, inverse ? BJX_TALL_ORDERED_INV : BJX_TALL_ORDERED_FWD, in, out, ladj_ps, ladj_sum, dim,
+                                batch, flags, &taken);
+    if (rc || taken) return rc;
+  }
+  {
     bool taken = false;
     const int rc = !inverse ? launch_quad_stream<T>(ctx, QOrderedFwd<T>{}, in, out, ladj_ps, ladj_sum, dim, batch, flags, &taken)
                             : launch_quad_stream<T>(ctx, QOrderedInv<T>{}, in, out, ladj_ps, ladj_sum, dim, batch, flags, &taken);
@@ -2525,7 +2531,9 @@ int simplex_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, dou
   const bool strided = (ld_in && ld_in != ri) || (ld_out && ld_out != ro);
   if (!strided) {
     bool taken = false;
-    int rc = BJX_OK;
+    int rc = bjx_seq_tiny(ctx, sizeof(T) == 4 ? BJX_F32 : BJX_F64, inverse ? BJX_TALL_SIMPLEX_INV : BJX_TALL_SIMPLEX_FWD, in, out, ladj_ps, ladj_sum, K, batch,
+                          flags, &taken);                              // 2 ... 7 rows: lane = column in registers (bjx_tiny.hip)
+    if (rc || taken) return rc;
     if (!inverse) rc = want ? launch_quad_stream<T>(ctx, QSimplexFwd<T, true>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken)
                             : launch_quad_stream<T>(ctx, QSimplexFwd<T, false>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken);
     else {
