@@ -122,6 +122,8 @@ int bjx_tall_stream(bjx_ctx* ctx, bjx_dtype dt, int which, const void* in, void*
 // bjx_tiny.hip: the same maps on columns of 1 ... 7 rows (lane = column in registers); same contract
 int bjx_seq_tiny(bjx_ctx* ctx, bjx_dtype dt, int which, const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags,
                  bool* taken);
+int bjx_seq_tiny_vjp(bjx_ctx* ctx, bjx_dtype dt, int simplex, int inverse, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K,
+                     int64_t batch, bool* taken);
 int bjx_tall_simplex_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K,
                          int64_t batch, bool* taken);
 

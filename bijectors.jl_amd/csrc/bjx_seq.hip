@@ -1431,6 +1431,11 @@ template <class T>
 int ordered_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t dim, int64_t batch) {
   if (batch == 0) return BJX_OK;
   {
+    bool taken = false;                                                // 1 ... 8 rows: lane = column in registers (bjx_tiny.hip)
+    const int rc = bjx_seq_tiny_vjp(ctx, sizeof(T) == 4 ? BJX_F32 : BJX_F64, 0, inverse, in, out_bar, ladj_bar, in_bar, dim, batch, &taken);
+    if (rc || taken) return rc;
+  }
+  {
     constexpr int VW = Vec16<T>::N;
     static const int use_stream = getenv("BJX_ORDERED_VJP_STREAM") ? atoi(getenv("BJX_ORDERED_VJP_STREAM")) : 1;
     if (use_stream && dim % VW == 0 && dim / VW <= 64 && in_bar != in && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar)) {
@@ -1778,6 +1783,11 @@ int launch_simplex_vjp_stream(bjx_ctx* ctx, int inverse, const T* in, const T* o
 template <class T>
 int simplex_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
   if (batch == 0) return BJX_OK;
+  {
+    bool taken = false;                                                // 2 ... 8 rows: lane = column in registers (bjx_tiny.hip)
+    const int rc = bjx_seq_tiny_vjp(ctx, sizeof(T) == 4 ? BJX_F32 : BJX_F64, 1, inverse, in, out_bar, ladj_bar, in_bar, K, batch, &taken);
+    if (rc || taken) return rc;
+  }
   {
     bool taken = false;
     static const int g_inv = getenv("BJX_SIMPLEX_VJP_G") ? atoi(getenv("BJX_SIMPLEX_VJP_G")) : 2;

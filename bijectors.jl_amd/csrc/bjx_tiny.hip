@@ -102,7 +102,156 @@ int tiny_dispatch(bjx_ctx* ctx, int which, int K, const T* in, T* out, T* ladj_p
     default: return tiny_k<T, 8>(ctx, which, in, out, ladj_ps, ladj_sum, batch, flags);
   }
 }
+// ---------------------------------------------------------------- pullbacks (the per-row sweeps of simplex_vjp_kernel / ordered_vjp_kernel
+// in bjx_seq.hip, on registers with the row count a template parameter)
+template <class T, bool INV, int K>
+__global__ __launch_bounds__(256) void simplex_vjp_tiny_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
+                                                               T* __restrict__ in_bar, int64_t batch) {
+  using F = Fast<T>;
+  constexpr int KA = INV ? K - 1 : K, KG = INV ? K : K - 1;          // rows of in / in_bar ; of out_bar
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= batch) return;
+  const TinyCol<T, KA> ta = *reinterpret_cast<const TinyCol<T, KA>*>(in + col * KA);
+  const TinyCol<T, KG> tg = *reinterpret_cast<const TinyCol<T, KG>*>(out_bar + col * KG);
+  T a[K], g[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) { a[i] = i < KA ? ta.v[i < KA ? i : 0] : T(0); g[i] = i < KG ? tg.v[i < KG ? i : 0] : T(0); }
+  const T e = Num<T>::eps;
+  const T c = T(1) / (T(1) - 2 * e), E = T(1) + e, c2 = T(1) - 2 * e;
+  const T lb = ladj_bar ? ladj_bar[col] : T(0);
+  if (INV) {
+    // forward recurrence: a[k] <- x_k, s = Σ x
+    T s = T(0);
+    { const T xk = d_clamp((f_logistic(a[0] - (T)kLogN[K - 1]) - e) * c, T(0), T(1)); a[0] = xk; s = xk; }
+#pragma unroll
+    for (int k = 1; k < K - 1; ++k) { const T xk = d_clamp((E - s) * c * f_logistic(a[k] - (T)kLogN[K - 1 - k]) - e, T(0), T(1)); a[k] = xk; s += xk; }
+    const T last = T(1) - s;
+    T sb = (last > T(0) && last < T(1)) ? -g[K - 1] : T(0);
+#pragma unroll
+    for (int k = K - 2; k >= 0; --k) {
+      const T xk = a[k];
+      const T sk = s - xk;
+      T dtdx, dtds;
+      simplex_t_partials<T>(xk, sk, k == 0, dtdx, dtds);
+      const T xb = g[k] + sb + lb * dtdx;
+      sb += lb * dtds;
+      const T ub = (xk > T(0) && xk < T(1)) ? xb : T(0);
+      T zb, z;
+      if (k == 0) { zb = ub * c; z = xk * c2 + e; }
+      else { const T rc = (E - sk) * c; zb = ub * rc; z = (xk + e) * F::rcp(rc); sb -= ub * c * z; }
+      g[k] = zb * z * (T(1) - z);
+      s = sk;
+    }
+  } else {
+    T s = T(0);
+#pragma unroll
+    for (int k = 0; k < K - 1; ++k) s += a[k];                         // s_{K-1} = Σ_{j<K-1} x_j
+    T sbn = T(0);
+    g[K - 1] = T(0);                                                   // row K enters neither y nor the log-det
+#pragma unroll
+    for (int k = K - 2; k >= 0; --k) {
+      const T xk = a[k];
+      const T sk = s - xk;
+      const T gy = g[k];
+      T xb = sbn, sb = sbn;
+      if (k == 0) {
+        const T zf = xk * c2 + e;
+        const T zfb = gy * F::rcp(zf * (T(1) - zf));
+        xb += zfb * c2;
+      } else {
+        const T rd = F::rcp(E - sk);
+        const T an = (xk + e) * c2;
+        const T zf = an * rd;
+        const T zfb = gy * F::rcp(zf * (T(1) - zf));
+        xb += zfb * c2 * rd;
+        sb += zfb * an * rd * rd;
+      }
+      T dtdx, dtds;
+      simplex_t_partials<T>(xk, sk, k == 0, dtdx, dtds);
+      xb -= lb * dtdx;
+      sb -= lb * dtds;
+      g[k] = xb;
+      sbn = sb;
+      s = sk;
+    }
+  }
+  TinyCol<T, KA> o;
+#pragma unroll
+  for (int i = 0; i < KA; ++i) o.v[i] = g[i];
+  *reinterpret_cast<TinyCol<T, KA>*>(in_bar + col * KA) = o;
+}
+
+template <class T, bool INV, int K>
+__global__ __launch_bounds__(256) void ordered_vjp_tiny_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
+                                                               T* __restrict__ in_bar, int64_t batch) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= batch) return;
+  const TinyCol<T, K> a = *reinterpret_cast<const TinyCol<T, K>*>(in + col * K);
+  TinyCol<T, K> g = *reinterpret_cast<const TinyCol<T, K>*>(out_bar + col * K);
+  const T lb = ladj_bar ? ladj_bar[col] : T(0);
+  if (!INV) {
+    T sfx = T(0);
+#pragma unroll
+    for (int i = K - 1; i >= 1; --i) { sfx += g.v[i]; g.v[i] = sfx * d_exp(a.v[i]) + lb; }
+    g.v[0] = sfx + g.v[0];
+  } else {
+    T nxt = T(0);                                                      // Δ_{i+1}/r_{i+1} of the row above
+#pragma unroll
+    for (int i = K - 1; i >= 1; --i) {
+      const T q = (g.v[i] - lb) / (a.v[i] - a.v[i - 1]);
+      g.v[i] = q - nxt;
+      nxt = q;
+    }
+    g.v[0] = g.v[0] - nxt;
+  }
+  *reinterpret_cast<TinyCol<T, K>*>(in_bar + col * K) = g;
+}
+
+template <class T, int K>
+int tiny_vjp_k(bjx_ctx* ctx, int simplex, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t batch) {
+  const int64_t grid = (batch + 255) / 256;
+  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
+  {
+    BjxProf prof_(ctx);
+    if (simplex) {
+      if constexpr (K >= 2) {
+        if (inverse) hipLaunchKernelGGL((simplex_vjp_tiny_kernel<T, true, K>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out_bar, ladj_bar, in_bar, batch);
+        else hipLaunchKernelGGL((simplex_vjp_tiny_kernel<T, false, K>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out_bar, ladj_bar, in_bar, batch);
+      }
+    } else {
+      if (inverse) hipLaunchKernelGGL((ordered_vjp_tiny_kernel<T, true, K>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out_bar, ladj_bar, in_bar, batch);
+      else hipLaunchKernelGGL((ordered_vjp_tiny_kernel<T, false, K>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out_bar, ladj_bar, in_bar, batch);
+    }
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+template <class T>
+int tiny_vjp_dispatch(bjx_ctx* ctx, int simplex, int inverse, int K, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t batch) {
+  switch (K) {
+    case 1: return tiny_vjp_k<T, 1>(ctx, simplex, inverse, in, out_bar, ladj_bar, in_bar, batch);
+    case 2: return tiny_vjp_k<T, 2>(ctx, simplex, inverse, in, out_bar, ladj_bar, in_bar, batch);
+    case 3: return tiny_vjp_k<T, 3>(ctx, simplex, inverse, in, out_bar, ladj_bar, in_bar, batch);
+    case 4: return tiny_vjp_k<T, 4>(ctx, simplex, inverse, in, out_bar, ladj_bar, in_bar, batch);
+    case 5: return tiny_vjp_k<T, 5>(ctx, simplex, inverse, in, out_bar, ladj_bar, in_bar, batch);
+    case 6: return tiny_vjp_k<T, 6>(ctx, simplex, inverse, in, out_bar, ladj_bar, in_bar, batch);
+    case 7: return tiny_vjp_k<T, 7>(ctx, simplex, inverse, in, out_bar, ladj_bar, in_bar, batch);
+    default: return tiny_vjp_k<T, 8>(ctx, simplex, inverse, in, out_bar, ladj_bar, in_bar, batch);
+  }
+}
 }  // namespace
+
+// Pullbacks of the Ordered (simplex = 0) / Simplex (simplex = 1) maps on columns of K <= 8 rows; *taken as above
+int bjx_seq_tiny_vjp(bjx_ctx* ctx, bjx_dtype dt, int simplex, int inverse, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K,
+                     int64_t batch, bool* taken) {
+  *taken = false;
+  static const int use_tiny = getenv("BJX_SEQ_TINY") ? atoi(getenv("BJX_SEQ_TINY")) : 1;
+  static const int kmax = getenv("BJX_SEQ_TINY_MAX") ? atoi(getenv("BJX_SEQ_TINY_MAX")) : 8;
+  if (!use_tiny || batch <= 0 || K < (simplex ? 2 : 1) || K > kmax || K > 8 || (const void*)in == (const void*)in_bar) return BJX_OK;
+  *taken = true;
+  if (dt == BJX_F32) return tiny_vjp_dispatch<float>(ctx, simplex, inverse, (int)K, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, batch);
+  return tiny_vjp_dispatch<double>(ctx, simplex, inverse, (int)K, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, batch);
+}
 
 // Columns of K rows (K = the larger of the input and output heights), contiguous.  Same contract as bjx_tall_stream.
 int bjx_seq_tiny(bjx_ctx* ctx, bjx_dtype dt, int which, const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags,
