@@ -863,12 +863,72 @@ __global__ __launch_bounds__(64) void stacked_vjp_walk_kernel(const char* __rest
   tile_stage_out<T, V>(tx, xbar + c0 * dim, dim, P, ncols, lane);
 }
 
+// The same on SHORT columns (cf. stacked_tiny_kernel): lane = column, x and ȳ read and x̄ written as whole columns, the scatter to
+// the source row a select chain over the lane's registers.
+template <class T, int DX>
+__global__ __launch_bounds__(256) void stacked_vjp_tiny_kernel(const char* __restrict__ tab, int two_slots, const T* __restrict__ x, const T* __restrict__ ybar,
+                                                               const T* __restrict__ lbar, T* __restrict__ xbar, int64_t batch) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= batch) return;
+  const TinyCol<T, DX> tx = *reinterpret_cast<const TinyCol<T, DX>*>(x + col * DX);
+  const TinyCol<T, DX> tg = *reinterpret_cast<const TinyCol<T, DX>*>(ybar + col * DX);
+  TinyCol<T, DX> o = tx;
+  const T lb = lbar ? lbar[col] : T(0);
+  constexpr size_t RB = stacked_row_bytes<T>();
+#pragma unroll
+  for (int r = 0; r < DX; ++r) {
+    const Slot<T>* e = reinterpret_cast<const Slot<T>*>(tab + (size_t)r * RB);
+    const Slot<T> s0 = e[0];
+    T xin = tx.v[0];
+#pragma unroll
+    for (int k = 1; k < DX; ++k) xin = s0.src == k ? tx.v[k] : xin;    // the source row is the same in every lane
+    T x1, dy0, dl0;
+    slot_grad<T>(s0, xin, x1, dy0, dl0);
+    T g = tg.v[r];
+    if (two_slots) {
+      const Slot<T> s1 = e[1];
+      if (s1.kind != SK_END) {
+        T y2, dy1, dl1;
+        slot_grad<T>(s1, x1, y2, dy1, dl1);
+        g = g * dy1 + lb * dl1;
+      }
+    }
+    const T res = g * dy0 + lb * dl0;
+#pragma unroll
+    for (int k = 0; k < DX; ++k) o.v[k] = s0.src == k ? res : o.v[k];
+  }
+  *reinterpret_cast<TinyCol<T, DX>*>(xbar + col * DX) = o;
+}
+
 template <class T>
 int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, const T* ybar, const T* lbar, T* xbar, int64_t dim, int64_t batch,
                      double* moments = nullptr, bool* moments_done = nullptr) {
   if (moments_done) *moments_done = false;
   if (dim * batch == 0) return BJX_OK;
   {
+    static const int use_tiny = getenv("BJX_STACKED_TINY") ? atoi(getenv("BJX_STACKED_TINY")) : 1;
+    if (use_tiny && !moments && dim <= 7 && dim % Vec16<T>::N != 0) {     // same-box A/B: 61-78 % against 28-51 % at 2-5 rows, level from 7
+      StackedPlan plt;
+      { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, xbar, dim, batch, false, false, &plt); if (rc) return rc; }   // V = 1: unpermuted table
+      const int64_t grid_t = (batch + 255) / 256;
+      BJX_REQUIRE(ctx, grid_t < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_stacked_vjp: batch too large for one launch");
+#define BJX_SVT(X_) hipLaunchKernelGGL((stacked_vjp_tiny_kernel<T, X_>), dim3((unsigned)grid_t), dim3(256), 0, ctx->stream, plt.tab, plt.two, x, ybar, lbar, xbar, batch)
+      bool launched = true;
+      {
+        BjxProf prof_(ctx);
+        switch ((int)dim) {
+          case 1: BJX_SVT(1); break;
+          case 2: BJX_SVT(2); break;
+          case 3: BJX_SVT(3); break;
+          case 5: BJX_SVT(5); break;
+          case 6: BJX_SVT(6); break;
+          case 7: BJX_SVT(7); break;
+          default: launched = false; break;
+        }
+      }
+#undef BJX_SVT
+      if (launched) { BJX_CHECK_LAUNCH(ctx); return BJX_OK; }
+    }
     static const int use_walker = getenv("BJX_STACKED_WALKER") ? atoi(getenv("BJX_STACKED_WALKER")) : 1;
     const int64_t P = dim | 1;
     const size_t smem_w = (size_t)2 * 64 * P * sizeof(T);
