@@ -367,8 +367,10 @@ __global__ __launch_bounds__(64) void matrix_link_kernel(const T* __restrict__ i
 // — and lane t factors sample t entirely in its own registers: no cross-lane traffic, no LDS inside the arithmetic, fully
 // unrolled to KMAX rows with wave-uniform guards (K is a launch constant).  Same pivot and link arithmetic as
 // matrix_link_kernel (FacMath, LinkMath); the trailing update uses the scaled column (l_ik l_jk instead of a_ik a_jk / d).
-template <class T, int KMAX, int KIND, bool INV, int V>
-__global__ __launch_bounds__(64) void matrix_lane_kernel(const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps, int K, int P,
+// KX > 0 (= K, 2 ... 4): the sample is read and written by its lane as one TinyCol object (multi-dword accesses), no tile — a 2x2 or
+// 3x3 block is 16-36 bytes and the staging, not the factorisation, was the cost (K = 2 / 3: 22-46 % of the HBM peak).
+template <class T, int KMAX, int KIND, bool INV, int V, int KX = 0>
+__global__ __launch_bounds__(64) void matrix_lane_kernel(const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps, int Krt, int P,
                                                          int64_t batch, int accumulate, double* partials) {
   extern __shared__ __align__(16) unsigned char smem_[];
   __shared__ double red[1];
@@ -376,15 +378,27 @@ __global__ __launch_bounds__(64) void matrix_lane_kernel(const T* __restrict__ i
   constexpr bool CORR = KIND == MK_VEC_CORR || KIND == MK_CORR;
   T* tile = reinterpret_cast<T*>(smem_);
   const int lane = threadIdx.x;
+  const int K = KX > 0 ? KX : Krt;
   const int KK = K * K;
   const int nv = KIND == MK_VEC_CORR ? K * (K - 1) / 2 : (KIND == MK_PD_VEC ? K * (K + 1) / 2 : KK);
   const int n_in = INV ? nv : KK, n_out = INV ? KK : nv;
+  constexpr int KKX = KX * KX, NVX = KIND == MK_VEC_CORR ? KX * (KX - 1) / 2 : (KIND == MK_PD_VEC ? KX * (KX + 1) / 2 : KKX);
+  constexpr int NIN = KX > 0 ? (INV ? NVX : KKX) : 1, NOUT = KX > 0 ? (INV ? KKX : NVX) : 1, NBUF = KX > 0 ? (KKX > NVX ? KKX : NVX) : 1;
   double acc = 0.0;
   for (int64_t s0 = (int64_t)blockIdx.x * 64; s0 < batch; s0 += (int64_t)gridDim.x * 64) {
     const int ncols = (int)((batch - s0) < 64 ? (batch - s0) : 64);
-    if (n_in > 0) tile_stage_in<T, V>(tile, in + s0 * n_in, n_in, P, ncols, lane);
-    tile_sync();
+    T buf[NBUF];
     T* mine = tile + lane * P;
+    if constexpr (KX > 0) {
+      TinyCol<T, NIN> t{};
+      if (lane < ncols) t = *reinterpret_cast<const TinyCol<T, NIN>*>(in + (s0 + lane) * NIN);
+#pragma unroll
+      for (int i = 0; i < NBUF; ++i) buf[i] = i < NIN ? t.v[i < NIN ? i : 0] : T(0);
+      mine = buf;
+    } else {
+      if (n_in > 0) tile_stage_in<T, V>(tile, in + s0 * n_in, n_in, P, ncols, lane);
+      tile_sync();
+    }
     T L[KMAX][KMAX];                                              // lower factor, row-major; only j <= i is used
     T lsum = T(0);
     if constexpr (!INV) {
@@ -512,15 +526,31 @@ __global__ __launch_bounds__(64) void matrix_lane_kernel(const T* __restrict__ i
         }
       }
     }
-    tile_sync();
-    if (out && n_out > 0) tile_stage_out<T, V>(tile, out + s0 * n_out, n_out, P, ncols, lane);
-    tile_sync();
+    if constexpr (KX > 0) {
+      if (out && lane < ncols) {
+        TinyCol<T, NOUT> o;
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) o.v[i] = buf[i];
+        *reinterpret_cast<TinyCol<T, NOUT>*>(out + (s0 + lane) * NOUT) = o;
+      }
+    } else {
+      tile_sync();
+      if (out && n_out > 0) tile_stage_out<T, V>(tile, out + s0 * n_out, n_out, P, ncols, lane);
+      tile_sync();
+    }
     if (lane < ncols) {
       if (ladj_ps) ladj_ps[s0 + lane] = accumulate ? ladj_ps[s0 + lane] + lsum : lsum;
       acc += (double)lsum;
     }
   }
   if (partials) block_publish_partial(acc, red, partials);
+}
+
+template <class T, int KX, int KIND>
+int launch_lane_direct(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* partials, int64_t batch, int accum, int grid) {
+  if (inverse) hipLaunchKernelGGL((matrix_lane_kernel<T, 4, KIND, true, 1, KX>), dim3(grid), dim3(64), 0, ctx->stream, in, out, ladj_ps, KX, 0, batch, accum, partials);
+  else hipLaunchKernelGGL((matrix_lane_kernel<T, 4, KIND, false, 1, KX>), dim3(grid), dim3(64), 0, ctx->stream, in, out, ladj_ps, KX, 0, batch, accum, partials);
+  return 0;
 }
 
 template <class T, int KMAX, int KIND>
@@ -745,7 +775,16 @@ int matrix_impl(bjx_ctx* ctx, const char* who, int inverse, const T* in, T* out,
     const bool vec = bjx_aligned16(in) && (!out || bjx_aligned16(out));     // a full tile of 64 samples is a whole number of 16-byte packs
     {
       BjxProf prof_(ctx);
-      if (K <= 4) launch_lane<T, 4, KIND>(ctx, inverse, in, out, ladj_ps, partials_l, (int)K, P, batch, (flags & BJX_ACCUMULATE) ? 1 : 0, vec, grid_l, smem_l);
+      static const int lane_direct = getenv("BJX_MATRIX_LANE_DIRECT") ? atoi(getenv("BJX_MATRIX_LANE_DIRECT")) : 1;
+      // 2x2 ... 4x4: no tile (matrix_lane_kernel, KX = K).  Same-box A/B: K = 2 / 3 forward 24 / 34-42 -> 42-55 / 65-66 %, inverse
+      // 19-26 / 36-43 -> 30-46 / 46-55 %; K = 4 forward 61-64 -> 69-71 %, inverse 50-59 against 48-55 % (stays on the tile)
+      if (lane_direct && K >= 2 && (K <= 3 || (K == 4 && !inverse)) && nv >= 1) {
+        const int accum_d = (flags & BJX_ACCUMULATE) ? 1 : 0;
+        if (K == 2) launch_lane_direct<T, 2, KIND>(ctx, inverse, in, out, ladj_ps, partials_l, batch, accum_d, grid_l);
+        else if (K == 3) launch_lane_direct<T, 3, KIND>(ctx, inverse, in, out, ladj_ps, partials_l, batch, accum_d, grid_l);
+        else launch_lane_direct<T, 4, KIND>(ctx, inverse, in, out, ladj_ps, partials_l, batch, accum_d, grid_l);
+      }
+      else if (K <= 4) launch_lane<T, 4, KIND>(ctx, inverse, in, out, ladj_ps, partials_l, (int)K, P, batch, (flags & BJX_ACCUMULATE) ? 1 : 0, vec, grid_l, smem_l);
       else if (K <= 8) launch_lane<T, 8, KIND>(ctx, inverse, in, out, ladj_ps, partials_l, (int)K, P, batch, (flags & BJX_ACCUMULATE) ? 1 : 0, vec, grid_l, smem_l);
       else launch_lane<T, 12, KIND>(ctx, inverse, in, out, ladj_ps, partials_l, (int)K, P, batch, (flags & BJX_ACCUMULATE) ? 1 : 0, vec, grid_l, smem_l);
     }
