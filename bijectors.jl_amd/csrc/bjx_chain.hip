@@ -681,7 +681,7 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
     // dim <= 7: the one-segment Stacked route below reaches stacked_tiny_kernel, which is ahead there (68-73 % against 48-67 %); this
     // kernel then serves what that route does not take (in-place calls, chains with more than two nonlinear stages) and dim = 9 ... 13
     bool via_stacked = false;
-    if (dim <= 7 && !v_ok && y && (const void*)x != (const void*)y && n_ops <= BJX_MAX_SEG_OPS && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0 && env_int("BJX_CHAIN_WALKER", 1)) {
+    if (dim <= 7 && (!v_ok || dim * sizeof(T) <= 16) && y && (const void*)x != (const void*)y && n_ops <= BJX_MAX_SEG_OPS && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0 && env_int("BJX_CHAIN_WALKER", 1)) {
       via_stacked = true;
       for (int k = 0; k < n_ops; ++k) via_stacked = via_stacked && ops[k].kind >= BJX_OP_EXP && ops[k].kind <= BJX_OP_IDENTITY;
     }

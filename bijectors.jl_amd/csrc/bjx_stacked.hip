@@ -400,7 +400,7 @@ int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, 
   // columns that are not whole 16-byte packs: the row-owner kernel below would read them 4 bytes at a time; the column walker moves
   // 64 columns as one contiguous run of packs whatever their height (cf. bjx_chain)
   static const int use_walker = getenv("BJX_STACKED_WALKER") ? atoi(getenv("BJX_STACKED_WALKER")) : 1;
-  if (use_walker && ldx == 0 && ldy == 0 && (const void*)x != (const void*)y && dim % Vec16<T>::N != 0 && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0) {
+  if (use_walker && ldx == 0 && ldy == 0 && (const void*)x != (const void*)y && (dim % Vec16<T>::N != 0 || dim * sizeof(T) <= 16) && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0) {   // one pack per column: stacked_tiny_kernel (69-71 % against 63-68 %; two packs: 65 against 72-74 %)
     const int rc_w = stacked_mixed_impl<T>(ctx, segs, n_segs, nullptr, 0, x, dim, y, dim, ladj_ps, ladj_sum, batch, flags);
     if (rc_w != BJX_ERR_UNSUPPORTED) return rc_w;                  // permuted ranges / taller than the tile: below
   }
@@ -621,7 +621,7 @@ int stacked_mixed_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const 
   StackedPlan pl;
   { int rc = stacked_prepare<T>(ctx, full.data(), (int)full.size(), x, y, rows_out, batch, false, false, &pl, rows_in, rows_out); if (rc) return rc; }
   static const int use_tiny = getenv("BJX_STACKED_TINY") ? atoi(getenv("BJX_STACKED_TINY")) : 1;
-  if (use_tiny && n_blocks == 0 && rows_in == rows_out && shift == 0 && rows_out <= 10 && rows_out % Vec16<T>::N != 0) {
+  if (use_tiny && n_blocks == 0 && rows_in == rows_out && shift == 0 && rows_out <= 10 && (rows_out % Vec16<T>::N != 0 || rows_out * sizeof(T) <= 16)) {
     const int64_t grid_t = (batch + 255) / 256;
     BJX_REQUIRE(ctx, grid_t < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
     BjxFin fin_t;
@@ -636,6 +636,7 @@ int stacked_mixed_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const 
         case 1: BJX_ST(1); break;
         case 2: BJX_ST(2); break;
         case 3: BJX_ST(3); break;
+        case 4: BJX_ST(4); break;
         case 5: BJX_ST(5); break;
         case 6: BJX_ST(6); break;
         case 7: BJX_ST(7); break;
