@@ -130,23 +130,28 @@ template <class T, bool LADJ> struct TSimplexFwd {       // simplex.jl:47-64 + :
       for (int j = 0; j < V; ++j) {
         const int i = q * V + j;
         const T xk = x[i];
-        const bool first = i == 0 && g.gl == 0, dead = i >= g.iK;
+        const bool first = i == 0 && g.gl == 0;
         const T a = first ? xk * c2 + e : (xk + e) * c2;               // :53 / :58
         const T dn = first ? T(1) : E - s;
         const T o = F::log2(a * F::rcp(dn - a)) * Num<T>::log2 + lkq.v[j];   // logit(z) + log(K-k)
         if (LADJ) {
           // term_k = max(z,ε)·max(1-z,ε)·m, z = x_k/m, m = max(1-Σ,ε) (:130-135) = max(x_k, εm)·max(m - x_k, εm)/m ;
-          // two rows share one reciprocal and one logarithm (each term >= ε²); rows without a term contribute a factor 1
+          // two rows share one reciprocal and one logarithm (each term >= ε²)
           const T m = d_max(T(1) - s, e), em = e * m;
           const T P = d_max(xk, em) * d_max(m - xk, em);
-          const T mm = dead ? T(1) : m, PP = dead ? T(1) : P;
-          if (i & 1) lp += F::log2(Pp * F::rcp(mp * mm) * PP);
-          else { Pp = PP; mp = mm; }
+          if (i & 1) lp += F::log2(Pp * F::rcp(mp * m) * P);
+          else { Pp = P; mp = m; }
         }
         x[i] = o;
         s += xk;
       }
       __builtin_amdgcn_sched_barrier(0);                               // V rows in flight, not 32: the scheduler otherwise spills under the 128-VGPR target
+    }
+    if (LADJ) {
+      // The rows without a term (x_K and the padding; x = 0 there, Σ no longer moves) each put the factor ε·m_end into the products
+      // above, m_end = max(1 - Σ_end, ε): taken out here in one step instead of three selects per row
+      const int nd = g.iK >= RPL ? 0 : (g.iK < 0 ? RPL : RPL - g.iK);
+      lp -= T(nd) * F::log2(e * d_max(T(1) - s, e));
     }
     // Julia's max(NaN, ε) is NaN (v_max drops it): a NaN among x_1..x_{K-1} makes the reference's log-det NaN
     return s != s ? s : -lp * Num<T>::log2;
@@ -202,19 +207,22 @@ template <class T, bool LADJ> struct TSimplexInv {       // simplex.jl:102-120 ;
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
       const bool first = i == 0 && g.gl == 0;
-      const bool rowK = i == g.iK, dead = i >= g.iK;
+      const bool rowK = i == g.iK;
       const T xi = first ? cl01<FAST>(x[i] - e0)                       // :109
                          : cl01<FAST>((E - s) * x[i] - e);             // :113   (x[i] = 0 on the rows without input: xi = 0)
       if (LADJ) {
         const T m = d_max(T(1) - s, e), em = e * m;
         const T P = d_max(xi, em) * d_max(m - xi, em);
-        const T mm = dead ? T(1) : m, PP = dead ? T(1) : P;
-        if (i & 1) lp += F::log2(Pp * F::rcp(mp * mm) * PP);
-        else { Pp = PP; mp = mm; }
+        if (i & 1) lp += F::log2(Pp * F::rcp(mp * m) * P);
+        else { Pp = P; mp = m; }
       }
       x[i] = rowK ? cl01<FAST>(T(1) - s) : xi;                         // :116
       s += xi;
       if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (LADJ) {                                                        // rows without a term (x_i = 0, Σ fixed): the factor ε·m_end each, taken out here (see TSimplexFwd)
+      const int nd = g.iK >= RPL ? 0 : (g.iK < 0 ? RPL : RPL - g.iK);
+      lp -= T(nd) * F::log2(e * d_max(T(1) - s, e));
     }
     if (!FAST && s != s) return s;                                     // Julia's max(NaN, ε) is NaN: the log-det of a poisoned column is NaN
     return lp * Num<T>::log2;
