@@ -237,6 +237,42 @@ def test_simplex(bj, orc, K, N, dt):
     np.testing.assert_allclose(host(Xb).sum(axis=0), 1.0, atol=K * 4 * np.finfo(dt).eps)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("K,N", [(3, 1000), (8, 70), (100, 257), (200, 130), (1000, 9), (3000, 5)])
+def test_ordered_simplex_flags_through_the_c_abi(bj, orc, K, N, dt):
+    """BJX_ACCUMULATE on the per-column and on the summed log-det, and calls without an output buffer, for every kernel family behind
+    bjx_ordered / bjx_simplex (lane-per-column up to 8 rows, quad frames, G lanes per column, the chunked walker beyond 2048 rows)."""
+    import ctypes as C
+    import bijectors_amd._lib as L
+    lib = L.load()
+    ctx = bj.context(torch.device("cuda", 0))
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    code = L.BJX_F32 if dt == np.float32 else L.BJX_F64
+    r = rng(K * 31 + N)
+    cases = [("bjx_ordered", 0, K, K, np.asfortranarray((0.7 * r.normal(size=(K, N))).astype(dt)), lambda a: orc.ordered(a)),
+             ("bjx_simplex", 0, K, K - 1, np.asfortranarray(r.dirichlet(np.ones(K), size=N).T.astype(dt)), lambda a: orc.simplex(a)),
+             ("bjx_simplex", 1, K - 1, K, np.asfortranarray((1.2 * r.normal(size=(K - 1, N))).astype(dt)), lambda a: orc.simplex(a, inverse=True))]
+    for name, inv, rows_in, rows_out, a, ref in cases:
+        y_ref, l_ref = ref(a)
+        x = torch.from_numpy(a.T.copy()).cuda()                        # [N, rows]: row-major = the column-major [rows, N] the library reads
+        y = torch.empty(N, rows_out, dtype=tdt, device="cuda")
+        base = torch.from_numpy(r.normal(size=N).astype(dt)).cuda()
+        lps = base.clone()
+        lsum = torch.full((1,), 2.5, dtype=torch.float64, device="cuda")
+        fn = getattr(lib, name)
+        L.check(ctx.h, fn(ctx.h, code, inv, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(lps.data_ptr()), C.c_void_p(lsum.data_ptr()),
+                          K, N, L.BJX_ACCUMULATE), name)
+        torch.cuda.synchronize()
+        close(y.cpu().numpy().T, y_ref, dt, scale=10 if name == "bjx_simplex" and not inv else max(K, 1), what=name)
+        close((lps - base).cpu().numpy(), l_ref, dt, scale=K * 10, what=name + " accumulated per-column log-det")
+        sum_close(float(lsum) - 2.5, float(np.sum(l_ref.astype(np.float64))), dt, N * K * 10, what=name + " accumulated sum")
+        if name == "bjx_simplex" and not inv:                          # the transform may be asked for its log-det alone (out = NULL)
+            lps2 = torch.zeros(N, dtype=tdt, device="cuda")
+            L.check(ctx.h, fn(ctx.h, code, inv, C.c_void_p(x.data_ptr()), None, C.c_void_p(lps2.data_ptr()), None, K, N, 0), name + " (no output)")
+            torch.cuda.synchronize()
+            close(lps2.cpu().numpy(), l_ref, dt, scale=K * 10, what=name + " log-det only")
+
+
 def test_simplex_reference_edge_cases(bj):
     # test/legacy_interface.jl:275-289
     ib = bj.inverse(bj.SimplexBijector())
