@@ -175,8 +175,8 @@ template <class T, bool LADJ> struct TSimplexInv {       // simplex.jl:102-120 ;
       // composition per lane (4 operations per row, the price of ONE round) and log2 G shuffle steps instead of G-1 rounds of the
       // four-operation recurrence.  Not the reference's association, and a clamped row moves the carry by <= ε; both are harmless
       // HERE (unlike in the transform): the recurrence contracts — an error δ in Σ becomes (1 - a_k) δ after the row — the outputs
-      // carry it as a_k δ.  The log-det terms see it relative to 1 - Σ, which is why Float32 does NOT take this path by default (see
-      // bjx_tall_stream below); Float64 does.
+      // carry it as a_k δ.  The log-det terms see it relative to 1 - Σ, and a clamped row breaks the affine model: not the default
+      // (see bjx_tall_stream below).
       T A = T(1), B = T(0);
 #pragma unroll
       for (int i = 0; i < RPL; ++i) {
@@ -664,7 +664,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         for (int j = 0; j < V; ++j) { const int i = q * V + j; a[i] = i < iK ? f_logistic(a[i] - lkq.v[j]) * c : T(0); }   // c·z_k
       }
       T carry = T(0);
-      if (scan) {                                                      // Σ entering this lane by the affine scan of TSimplexInv (see there)
+      bool use_scan = scan != 0;
+      if (use_scan) {                                                  // Σ entering this lane by the affine scan of TSimplexInv (see there)
         T As = T(1), Bs = T(0);
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
@@ -677,7 +678,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         tall_affine_scan_up(As, Bs, gl, G);
         const T bc = __shfl_up(Bs, 1, 64);
         carry = gl == 0 ? T(0) : bc;
-      } else {
+        // The scan models the recurrence WITHOUT its clamp: exact (up to association) as long as no clamp changes a value.  Where one
+        // does — a saturated row hands over the rest of the stick and every later row is pinned at 0 with a closed gate — the
+        // unclamped Σ drifts and would open those gates again.  One clamped trip from the scan's carry finds out (the first lane a
+        // clamp binds in starts from an uncontaminated carry); if any row of the wave was clamped the rounds below take over.
+        bool viol = false;
+        T sc = carry;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+          const bool row0 = i == 0 && gl == 0;
+          const T raw = row0 ? a[i] - e * c : (E - sc) * a[i] - e;
+          const T xi = d_clamp(raw, T(0), T(1));
+          viol = viol || (raw != xi && i < iK);                        // (a NaN counts)
+          sc += xi;
+        }
+        if (__builtin_amdgcn_ballot_w64(viol && !idle && cg < ncol) != 0) use_scan = false;   // wave-uniform
+      }
+      if (!use_scan) {
+        carry = T(0);
         for (int t = 1; t < G; ++t) {
           T s = carry;
 #pragma unroll
@@ -716,7 +734,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
       // adjoint of Σ, from the last row down: the lanes take turns from the right
       const bool lastlane = iK >= 0 && iK < RPL;
       T cin = lastlane ? sb0 : T(0);
-      if (scan) {
+      if (use_scan) {
         // sb <- B_k sb + A_k is affine in sb: compose this lane's rows (last row first), scan the compositions from the last lane down,
         // apply the composition of the lanes to my right to the value the last row starts from
         T P = T(1), Q = T(0);
@@ -842,18 +860,20 @@ int bjx_tall_stream(bjx_ctx* ctx, bjx_dtype dt, int which, const void* in, void*
   const int rpl = dt == BJX_F32 ? 32 : 16;
   const int64_t rows = rows_in > rows_out ? rows_in : rows_out;
   if (!use_tall || batch <= 0 || rows < min_rows || rows > 64 * rpl) return BJX_OK;
-  // Carry of the Simplex inverse: take-turns rounds in the reference's order (0) or the affine scan (1).  Float32 keeps the rounds: on
-  // a long simplex the stick is used up before the last rows (1 - Σ falls to ε), the log-det terms divide by what is left, and a
-  // re-associated Σ moves the per-column log-det by up to 0.7 % there (K = 1000, y ~ N(0, 1.5²): 7 % of the columns beyond the 1e-3 bar
-  // against the Float32 oracle).  Float64 has the digits (all parity cases hold at 1e-6) and takes the scan.
+  // Carry of the Simplex inverse: take-turns rounds in the reference's order (default) or the affine scan (BJX_SEQ_TALL_INV_SCAN=1, an
+  // experiment).  The scan is NOT parity-safe for the transform: on a long simplex the stick is used up before the last rows (1 - Σ
+  // falls to ε), the log-det terms divide by what is left, and a re-associated Σ moves the per-column log-det by up to 0.7 % there
+  // (Float32, K = 1000, y ~ N(0, 1.5²): 7 % of the columns beyond the 1e-3 bar); and it ignores the clamp — after a saturated row
+  // (z_k = 1: the rest of the stick at once) the reference pins Σ at 1 and every later term at log ε, the unclamped Σ drifts back by ε
+  // per row and the terms with it (tests/test_gpu_parity.py::test_simplex_inverse_tall_columns_with_clamped_rows, either dtype).
   static const int scan_env = getenv("BJX_SEQ_TALL_INV_SCAN") ? atoi(getenv("BJX_SEQ_TALL_INV_SCAN")) : -1;
-  const int inv_scan = scan_env >= 0 ? scan_env : (dt == BJX_F64 ? 1 : 0);
+  const int inv_scan = scan_env > 0 ? 1 : 0;
   // with rounds the chunked walker is ahead beyond 512 rows (four chain operations per row and round)
   if (which == BJX_TALL_SIMPLEX_INV && (rows > (inv_scan ? 2048 : inv_max) || rows < 129)) return BJX_OK;   // 65-128 rows: the whole-column tile is ahead (45 against 43 % at K = 100)
   // Float64 (same-box A/B, profiles/r03_tall_columns.md): the rounds of the Simplex inverse are four Float64 operations per row — the
-  // walkers stay ahead at every height (39 / 35 % against 31 / 27 % at K = 200 / 500); beyond 32 lanes per column (512 rows) the
-  // walkers are level or ahead for the other maps too (Ordered at K = 1000: 54 against 45 %)
-  if (dt == BJX_F64 && rows > 512) return BJX_OK;
+  // walkers stay ahead at every height (39 / 35 % against 31 / 27 % at K = 200 / 500), so the Float64 inverse is not taken here; beyond
+  // 32 lanes per column (512 rows) the walkers are level or ahead for the other maps too (Ordered at K = 1000: 54 against 45 %)
+  if (dt == BJX_F64 && (rows > 512 || (which == BJX_TALL_SIMPLEX_INV && !inv_scan))) return BJX_OK;
   const int G = (int)((rows + rpl - 1) / rpl), CPS = 64 / G;
   // lanes that hold rows of a column / lanes of the wave: K just above a multiple of RPL wastes most of the last lane
   const double eff = (double)rows * CPS / (64.0 * rpl);

@@ -273,6 +273,33 @@ def test_ordered_simplex_flags_through_the_c_abi(bj, orc, K, N, dt):
             close(lps2.cpu().numpy(), l_ref, dt, scale=K * 10, what=name + " log-det only")
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("K,N", [(160, 70), (200, 1031), (500, 9)])
+def test_simplex_inverse_tall_columns_with_clamped_rows(bj, orc, K, N, dt):
+    """Rows whose stick fraction underflows against ε (y_k - log(K-k) << -16) are clamped to 0 by simplex.jl:113: the G-lane kernel's
+    unclamped rounds must notice and fall back to the exact ones (every second column has such rows, some columns start with them)."""
+    r = rng(K + N)
+    y = (1.2 * r.normal(size=(K - 1, N))).astype(dt)
+    y[r.integers(0, K - 1, size=40), ::2] = -60.0
+    y[0, ::5] = -200.0
+    y[K // 2:K // 2 + 3, 1::7] = 80.0                                   # z = 1: the rest of the stick goes at once, later rows clamp
+    y = np.asfortranarray(y)
+    X_ref, l_ref = orc.simplex(y, inverse=True)
+    X, l = bj.with_logabsdet_jacobian(bj.inverse(bj.SimplexBijector()), dev(y), per_sample=True)
+    close(host(X), X_ref, dt, what="simplex inv with clamped rows")
+    close(host(l), l_ref, dt, scale=K * 10, what="simplex inv ladj with clamped rows")
+    if dt == np.float64:
+        # the pullback's scan carry must give way to the exact rounds where a clamp binds (closed gates stay closed); without the
+        # saturated rows, whose log-det terms sit on the 1/ε pole of max(·, ε) and have no meaningful derivative in any implementation
+        yu = y.copy()
+        yu[yu > 40] = 0.3
+        gx = np.asfortranarray(r.normal(size=(K, N)))
+        lbar = r.normal(size=N)
+        ref = orc.simplex_vjp(yu, gx, lbar, inverse=True)
+        got = bj.vjp(bj.inverse(bj.SimplexBijector()), dev(yu), dev(gx), torch.from_numpy(lbar).cuda())
+        np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())), err_msg="simplex inv vjp with clamped rows")
+
+
 def test_simplex_reference_edge_cases(bj):
     # test/legacy_interface.jl:275-289
     ib = bj.inverse(bj.SimplexBijector())
