@@ -415,12 +415,47 @@ __global__ __launch_bounds__(256) void chain_colgroup_kernel(const ChainArgs<T> 
         for (int u = 0; u < CHAIN_U; ++u) if (y) store_pack<T, V, NT>(yc + (v + (int64_t)u * G) * V, p[u]);
       }
     }
-    for (; v < nvc; v += G) {
-      Pack<T, V> p[1];
-      int64_t r[1] = {v * V};
-      p[0] = load_pack<T, V, NT>(xc + v * V);
-      l += apply_chain<T, V, 1, ROWMODE>(A, p, r, dim);
-      if (y) store_pack<T, V, NT>(yc + v * V, p[0]);
+    if (v < nvc) {
+      // the last (up to CHAIN_U - 1) packs of every lane: requested together, not one round trip each (64 < packs < 4·G per column:
+      // dim = 333 ran at 25 % with one pack per lane in flight)
+      constexpr int UR = CHAIN_U - 1;
+      Pack<T, V> p[UR];
+      int64_t r[UR];
+      bool ok[UR];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const int64_t vu = v + (int64_t)u * G;
+        ok[u] = vu < nvc;
+        r[u] = ok[u] ? vu * V : 0;
+        if (ok[u]) p[u] = load_pack<T, V, NT>(xc + vu * V);
+        else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) p[u].v[j] = T(1);
+        }
+      }
+      T lu[UR];
+      apply_chain_u<T, V, UR, ROWMODE, false>(A, p, r, dim, lu);
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        if (ok[u]) {
+          l += lu[u];
+          if (y) store_pack<T, V, NT>(yc + (v + (int64_t)u * G) * V, p[u]);
+        }
+      }
+    }
+    // column heights that are not whole packs (dim = 127, 333, 1001 ...): the packs above are then only ELEMENT-aligned — global
+    // accesses take that — and the last dim % V rows go one by one on the lane after the last pack's
+    if (V > 1) {
+      const int tail = (int)(dim - nvc * V);
+      if (tail && gl == (int)(nvc % G)) {
+        for (int t = 0; t < tail; ++t) {
+          Pack<T, 1> p1[1];
+          int64_t r1[1] = {nvc * V + t};
+          p1[0].v[0] = xc[r1[0]];
+          l += apply_chain<T, 1, 1, (ROWMODE == 0 ? 0 : 2)>(A, p1, r1, dim);
+          if (y) yc[r1[0]] = p1[0].v[0];
+        }
+      }
     }
   }
   l = group_sum_rt(l, G);
@@ -506,6 +541,37 @@ __global__ __launch_bounds__(256) void chain_colbatch_kernel(const ChainArgs<T> 
   }
   T lu[U];
   apply_chain_u<T, V, U, ROWMODE, true>(A, p, r, dim, lu);
+  // column heights that are not whole packs: the packs above are then only element-aligned, and the last dim % V rows go to the
+  // lanes after the last pack's, ONE row each (all U columns at once: the same loads-in-flight as the packs; one lane walking the
+  // three tail rows of four columns one after the other held dim = 63 / 127 / 255 at 26 %)
+  T ltail[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) ltail[u] = T(0);
+  if (V > 1) {
+    const int tail = (int)(dim - nvc * V);
+    if (tail) {                                                        // wave-uniform
+      const int tt = (gl - (int)(nvc & (G - 1))) & (G - 1);
+      const bool has_tail = tt < tail;
+      Pack<T, 1> pt[U];
+      int64_t rt[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t col = col0 + (int64_t)u * cols_per_block;
+        rt[u] = nvc * V + (has_tail ? tt : 0);
+        pt[u].v[0] = (has_tail && col < batch) ? x[col * dim + rt[u]] : T(1);
+      }
+      T lt[U];
+      apply_chain_u<T, 1, U, (ROWMODE == 0 ? 0 : 2), true>(A, pt, rt, dim, lt);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t col = col0 + (int64_t)u * cols_per_block;
+        if (has_tail && col < batch) {
+          if (y) y[col * dim + rt[u]] = pt[u].v[0];
+          ltail[u] = lt[u];
+        }
+      }
+    }
+  }
   const double c_ps = c_ps_host + (c_ps_dev ? *c_ps_dev : 0.0);
   double acc = 0.0;
 #pragma unroll
@@ -513,7 +579,7 @@ __global__ __launch_bounds__(256) void chain_colbatch_kernel(const ChainArgs<T> 
     const int64_t col = col0 + (int64_t)u * cols_per_block;
     const bool ok = lane_ok && col < batch;
     if (ok && y) store_pack<T, V, NT>(y + col * dim + (int64_t)gl * V, p[u]);
-    const T l = group_sum_rt(ok ? lu[u] : T(0), G);
+    const T l = group_sum_rt((ok ? lu[u] : T(0)) + ltail[u], G);
     if (col < batch && gl == 0) {
       T out = l + (T)c_ps;
       if (accumulate) out += ladj_ps[col];
@@ -728,6 +794,45 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
         if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, c_sum_host, any_dev_scale ? 1 : 0, 0.0, flags);
         return BJX_OK;
       }
+    }
+    static const int use_unal = env_int("BJX_CHAIN_UNALIGNED", 1);
+    static const int unal_min = env_int("BJX_CHAIN_UNALIGNED_MIN", 48);
+    // (same-box A/B, 2^22 columns: 63 ... 257 rows 56-67 % against 12-46 %; 1001 / 2049 rows 56 / 64 % against 41 / 54 %; between 65
+    //  and ~250 packs per column the lanes of a 64-lane group hold one to three packs each and the group kernel runs its three-pack
+    //  remainder for all of them: 26-47 % against 37-52 % for the 4-byte path, which keeps those heights)
+    if (use_unal && !v_ok && dim >= unal_min && (dim / VW <= 64 || dim / VW >= 250) && x && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0) {
+      // taller columns that are not whole packs: G lanes per column with ELEMENT-aligned 16-byte packs + a tail (chain_colgroup_kernel).
+      // The tile walker below loses its occupancy with the height (dim = 127: 24 %, 255: 12 %, 1001 on 4-byte accesses: 39 %).
+      const int64_t packs_u = dim / VW;
+      int Gu = 1;
+      while (Gu < 64 && Gu < packs_u) Gu <<= 1;
+      const double* cdev_u = any_dev_scale ? ctx->consts : nullptr;
+      const int accum_u = (flags & BJX_ACCUMULATE) ? 1 : 0;
+      const int cpb_u = 256 / Gu;
+      grid = (batch + cpb_u - 1) / cpb_u;
+      BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_chain: input too large for one launch");
+      if (ladj_sum) { int rc_ = bjx_ensure_partials(ctx, (size_t)grid); if (rc_) return rc_; }
+      double* partials_u = ladj_sum ? ctx->partials : nullptr;
+      if (packs_u <= 64) {                                             // one pack per lane: four columns in flight per lane (chain_colbatch_kernel)
+        constexpr int UBu = 4;
+        grid = (batch + (int64_t)cpb_u * UBu - 1) / ((int64_t)cpb_u * UBu);
+        if (ladj_sum) { int rc_ = bjx_ensure_partials(ctx, (size_t)grid); if (rc_) return rc_; }
+        partials_u = ladj_sum ? ctx->partials : nullptr;
+        BjxProf prof_(ctx);
+#define LAUNCH_CBU(RM_) hipLaunchKernelGGL((chain_colbatch_kernel<T, VW, RM_, false, UBu>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, x, y, ladj_ps, dim, batch, Gu, c_ps_host, cdev_u, accum_u, partials_u)
+        if (!any_row) LAUNCH_CBU(0);
+        else LAUNCH_CBU(2);
+#undef LAUNCH_CBU
+      } else {
+        BjxProf prof_(ctx);
+#define LAUNCH_CGU(RM_) hipLaunchKernelGGL((chain_colgroup_kernel<T, VW, RM_, false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, A, x, y, ladj_ps, dim, batch, Gu, c_ps_host, cdev_u, accum_u, partials_u)
+        if (!any_row) LAUNCH_CGU(0);
+        else LAUNCH_CGU(2);
+#undef LAUNCH_CGU
+      }
+      BJX_CHECK_LAUNCH(ctx);
+      if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, c_sum_host, any_dev_scale ? 1 : 0, 0.0, flags);
+      return BJX_OK;
     }
     static const int use_walker = env_int("BJX_CHAIN_WALKER", 1);
     bool pow2_packs = false;
