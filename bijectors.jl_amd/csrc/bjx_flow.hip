@@ -514,7 +514,32 @@ struct PlanarRegArgs {
   const float *wtu_hat, *b; // [nl_pad]
   int nl_pad;
   int n_layers;             // layers beyond it are padding: their tanh is forced to 0 (a +-Inf input would make 0 * Inf = NaN of them)
+  int ldw;                  // row pitch of w / u_hat: dim rounded up to whole 16-byte packs (the padding rows are zero)
+  int unal;                 // columns are not made of whole ALIGNED packs (dim % 4 != 0 or a 4-byte aligned base): see reg_load_pack
 };
+
+// Column heights that are not a multiple of four (round 3).  A lane still owns rows 4gl .. 4gl+3 of its column, but the packs are
+// only element-aligned (global_load_dwordx4 takes any 4-byte address) and the last pack of a column holds nrow = 1..3 live rows.
+// That pack is LOADED as the last four rows of the column (which stay inside it: dim >= 4) and shifted down, the dead rows read as
+// zero so that the zero-padded parameter tables need no masks; it is STORED row by row.
+typedef float bjx_pk4 __attribute__((ext_vector_type(4)));
+typedef bjx_pk4 bjx_pk4u __attribute__((aligned(4)));
+__device__ __forceinline__ bjx_pk4 reg_load_pack(const float* px, int nrow) {
+  const int sh = 4 - nrow;
+  bjx_pk4 v = __builtin_nontemporal_load(reinterpret_cast<const bjx_pk4u*>(px - sh));
+  if (sh == 1) v = bjx_pk4{v.y, v.z, v.w, 0.f};
+  else if (sh == 2) v = bjx_pk4{v.z, v.w, 0.f, 0.f};
+  else if (sh == 3) v = bjx_pk4{v.w, 0.f, 0.f, 0.f};
+  return v;
+}
+__device__ __forceinline__ void reg_store_pack(float* py, const bjx_pk4 v, int nrow) {
+  if (nrow == 4) __builtin_nontemporal_store(v, reinterpret_cast<bjx_pk4u*>(py));
+  else {
+    py[0] = v.x;
+    if (nrow > 1) py[1] = v.y;
+    if (nrow > 2) py[2] = v.z;
+  }
+}
 
 // find_alpha for the register kernel: same safeguarded Newton on the reference's bracket
 // (planar_layer.jl:160-185) with tanh from one hardware exp (the OCML tanhf made the inverse flow
@@ -650,6 +675,7 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
   const int gl = lane & (G - 1);
   const int cg = lane / G;                          // column inside a wave instruction
   const bool row_ok = 4 * gl < dim;
+  const int nrow = dim - 4 * gl >= 4 ? 4 : dim - 4 * gl;   // live rows of my pack (<= 0: none)
   const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * COLS;
   const int64_t left = batch - col0;
   const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
@@ -658,11 +684,20 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
   f4 z[NS];
   {
     const float* px = x + (col0 + cg) * dim + 4 * gl;
+    if (A.unal) {
 #pragma unroll
-    for (int r = 0; r < NS; ++r) {
-      if (row_ok && r * CPS + cg < nvalid) z[r] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(px));
-      else z[r] = f4{0.f, 0.f, 0.f, 0.f};
-      px += step_elems;
+      for (int r = 0; r < NS; ++r) {
+        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, nrow);
+        else z[r] = f4{0.f, 0.f, 0.f, 0.f};
+        px += step_elems;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        if (row_ok && r * CPS + cg < nvalid) z[r] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(px));
+        else z[r] = f4{0.f, 0.f, 0.f, 0.f};
+        px += step_elems;
+      }
     }
   }
   float ladj = 0.f;
@@ -677,8 +712,8 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
       for (int kp = 0; kp < NP; ++kp) {
         f4 a = f4{0.f, 0.f, 0.f, 0.f}, b = a;
         if (row_ok) {
-          a = *reinterpret_cast<const f4*>(A.w + (int64_t)(l0 + 2 * kp) * dim + 4 * gl);
-          if (NL >= 2) b = *reinterpret_cast<const f4*>(A.w + (int64_t)(l0 + 2 * kp + 1) * dim + 4 * gl);
+          a = *reinterpret_cast<const f4*>(A.w + (int64_t)(l0 + 2 * kp) * A.ldw + 4 * gl);
+          if (NL >= 2) b = *reinterpret_cast<const f4*>(A.w + (int64_t)(l0 + 2 * kp + 1) * A.ldw + 4 * gl);
         }
         wq[kp][0] = f2{a.x, b.x}; wq[kp][1] = f2{a.y, b.y}; wq[kp][2] = f2{a.z, b.z}; wq[kp][3] = f2{a.w, b.w};
       }
@@ -750,7 +785,7 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
       f4 uv[NL];
 #pragma unroll
       for (int k = 0; k < NL; ++k)
-        uv[k] = row_ok ? *reinterpret_cast<const f4*>(A.u_hat + (int64_t)(l0 + k) * dim + 4 * gl) : f4{0.f, 0.f, 0.f, 0.f};
+        uv[k] = row_ok ? *reinterpret_cast<const f4*>(A.u_hat + (int64_t)(l0 + k) * A.ldw + 4 * gl) : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
         const float* tc = st + (r * CPS + cg) * NL;
@@ -782,10 +817,18 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
   }
   if (y) {
     float* py = y + (col0 + cg) * dim + 4 * gl;
+    if (A.unal) {
 #pragma unroll
-    for (int r = 0; r < NS; ++r) {
-      if (row_ok && r * CPS + cg < nvalid) __builtin_nontemporal_store(z[r], reinterpret_cast<f4*>(py));
-      py += step_elems;
+      for (int r = 0; r < NS; ++r) {
+        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow);
+        py += step_elems;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        if (row_ok && r * CPS + cg < nvalid) __builtin_nontemporal_store(z[r], reinterpret_cast<f4*>(py));
+        py += step_elems;
+      }
     }
   }
   const bool ok = lane < nvalid;   // nvalid <= COLS
@@ -1201,6 +1244,7 @@ __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A,
   const int gl = lane & (G - 1), cg = lane / G;
   const int row0 = half * 64;
   const bool row_ok = row0 + 4 * gl < dim;
+  const int nrow = dim - row0 - 4 * gl >= 4 ? 4 : dim - row0 - 4 * gl;
   const int64_t col0 = ((int64_t)blockIdx.x * (4 / NW) + tile) * COLS;
   const int64_t left = batch - col0;
   const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
@@ -1208,11 +1252,20 @@ __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A,
   bjx_f4 z[NS];
   {
     const float* px = x + (col0 + cg) * dim + row0 + 4 * gl;
+    if (A.unal) {
 #pragma unroll
-    for (int r = 0; r < NS; ++r) {
-      if (row_ok && r * CPS + cg < nvalid) z[r] = __builtin_nontemporal_load(reinterpret_cast<const bjx_f4*>(px));
-      else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
-      px += step_elems;
+      for (int r = 0; r < NS; ++r) {
+        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, nrow);
+        else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
+        px += step_elems;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        if (row_ok && r * CPS + cg < nvalid) z[r] = __builtin_nontemporal_load(reinterpret_cast<const bjx_f4*>(px));
+        else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
+        px += step_elems;
+      }
     }
   }
   float ladj = 0.f;
@@ -1221,7 +1274,7 @@ __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A,
   for (int gi = 0; gi < ngroups; ++gi) {
     const int l0 = (INV ? ngroups - 1 - gi : gi) * NL;
     float* mineS = sS[gi & 1][wave];
-    reg_dots<G, NL, NS>(A.w, l0, dim, z, mineS, lane, gl, cg, row_ok, row0);
+    reg_dots<G, NL, NS>(A.w, l0, A.ldw, z, mineS, lane, gl, cg, row_ok, row0);
     __syncthreads();                                         // every slice of every tile has published its partial sums
     {
       float s[NL], t[NL];
@@ -1256,7 +1309,7 @@ __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A,
       for (int k = 0; k < NL; ++k) stT[lane * NL + k] = t[k];
     }
     __builtin_amdgcn_wave_barrier();
-    reg_update<G, NL, NS>(A.u_hat, l0, dim, z, stT, gl, cg, row_ok, row0);
+    reg_update<G, NL, NS>(A.u_hat, l0, A.ldw, z, stT, gl, cg, row_ok, row0);
     __builtin_amdgcn_wave_barrier();
   }
   if (accumulate & 2) {
@@ -1277,10 +1330,18 @@ __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A,
   }
   if (y) {
     float* py = y + (col0 + cg) * dim + row0 + 4 * gl;
+    if (A.unal) {
 #pragma unroll
-    for (int r = 0; r < NS; ++r) {
-      if (row_ok && r * CPS + cg < nvalid) __builtin_nontemporal_store(z[r], reinterpret_cast<bjx_f4*>(py));
-      py += step_elems;
+      for (int r = 0; r < NS; ++r) {
+        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow);
+        py += step_elems;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        if (row_ok && r * CPS + cg < nvalid) __builtin_nontemporal_store(z[r], reinterpret_cast<bjx_f4*>(py));
+        py += step_elems;
+      }
     }
   }
   const bool ok = lane < nvalid && half == 0;                // the two halves hold the same log-det: one of them reports it
@@ -1305,6 +1366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
   const int gl = lane & (G - 1);
   const int cg = lane / G;
   const bool row_ok = 4 * gl < dim;
+  const int nrow = dim - 4 * gl >= 4 ? 4 : dim - 4 * gl;
   const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * COLS;
   const int64_t left = batch - col0;
   const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
@@ -1312,11 +1374,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
   bjx_f4 z[NS];
   auto load_tile = [&](const float* base) {
     const float* px = base + (col0 + cg) * dim + 4 * gl;
+    if (A.unal) {
 #pragma unroll
-    for (int r = 0; r < NS; ++r) {
-      if (row_ok && r * CPS + cg < nvalid) z[r] = __builtin_nontemporal_load(reinterpret_cast<const bjx_f4*>(px));
-      else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
-      px += step_elems;
+      for (int r = 0; r < NS; ++r) {
+        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, nrow);
+        else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
+        px += step_elems;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        if (row_ok && r * CPS + cg < nvalid) z[r] = __builtin_nontemporal_load(reinterpret_cast<const bjx_f4*>(px));
+        else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
+        px += step_elems;
+      }
     }
   };
   const int ngroups = A.nl_pad / NL;
@@ -1324,7 +1395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
   load_tile(x);
   for (int gi = 0; gi < ngroups; ++gi) {
     const int l0 = (INV ? ngroups - 1 - gi : gi) * NL;         // the inverse undoes the LAST group first
-    reg_dots<G, NL, NS>(A.w, l0, dim, z, st, lane, gl, cg, row_ok);
+    reg_dots<G, NL, NS>(A.w, l0, A.ldw, z, st, lane, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
     {
       float s[NL], t[NL];
@@ -1348,7 +1419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
       for (int k = 0; k < NL; ++k) { st[lane * NL + k] = t[k]; tsave[lane * A.nl_pad + l0 + k] = INV ? -t[k] : t[k]; }
     }
     __builtin_amdgcn_wave_barrier();
-    if (gi + 1 < ngroups) reg_update<G, NL, NS>(A.u_hat, l0, dim, z, st, gl, cg, row_ok);
+    if (gi + 1 < ngroups) reg_update<G, NL, NS>(A.u_hat, l0, A.ldw, z, st, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
   }
   // ---- cotangent sweep, in the opposite order of the primal
@@ -1356,7 +1427,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
   const float lb = (lbar && lane < nvalid) ? lbar[col0 + lane] : 0.f;
   for (int gi = 0; gi < ngroups; ++gi) {
     const int l0 = (INV ? gi : ngroups - 1 - gi) * NL;
-    reg_dots<G, NL, NS>(A.u_hat, l0, dim, z, st, lane, gl, cg, row_ok);
+    reg_dots<G, NL, NS>(A.u_hat, l0, A.ldw, z, st, lane, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
     {
       float g[NL], sb[NL];
@@ -1386,15 +1457,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
       }
     }
     __builtin_amdgcn_wave_barrier();
-    reg_update<G, NL, NS>(A.w, l0, dim, z, st, gl, cg, row_ok);
+    reg_update<G, NL, NS>(A.w, l0, A.ldw, z, st, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
   }
   {
     float* py = xbar + (col0 + cg) * dim + 4 * gl;
+    if (A.unal) {
 #pragma unroll
-    for (int r = 0; r < NS; ++r) {
-      if (row_ok && r * CPS + cg < nvalid) __builtin_nontemporal_store(z[r], reinterpret_cast<bjx_f4*>(py));
-      py += step_elems;
+      for (int r = 0; r < NS; ++r) {
+        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow);
+        py += step_elems;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        if (row_ok && r * CPS + cg < nvalid) __builtin_nontemporal_store(z[r], reinterpret_cast<bjx_f4*>(py));
+        py += step_elems;
+      }
     }
   }
 }
@@ -1404,7 +1483,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
 template <class T>
 __global__ __launch_bounds__(256) void planar_prep_reg_kernel(const T* w, const T* u_hat, const T* wtu_hat, const T* b,
                                                               int64_t dim, int nl, int nl_pad, T* wp, T* up, T* Gp,
-                                                              T* cp, T* bp) {
+                                                              T* cp, T* bp, int64_t ldw = 0) {
+  if (ldw == 0) ldw = dim;                                      // row pitch of wp / up (rows dim .. ldw-1 are written as zeros)
   __shared__ double red[4];
   const int k = blockIdx.x / nl_pad, j = blockIdx.x % nl_pad;
   const bool live = k < nl && j < nl;
@@ -1415,9 +1495,10 @@ __global__ __launch_bounds__(256) void planar_prep_reg_kernel(const T* w, const 
   __syncthreads();
   if (threadIdx.x == 0) Gp[k * nl_pad + j] = live ? (T)((red[0] + red[1]) + (red[2] + red[3])) : T(0);
   if (j == 0) {
-    for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) {
-      wp[(int64_t)k * dim + i] = k < nl ? w[(int64_t)k * dim + i] : T(0);
-      up[(int64_t)k * dim + i] = k < nl ? u_hat[(int64_t)k * dim + i] : T(0);
+    for (int64_t i = threadIdx.x; i < ldw; i += blockDim.x) {
+      const bool in = k < nl && i < dim;
+      wp[(int64_t)k * ldw + i] = in ? w[(int64_t)k * dim + i] : T(0);
+      up[(int64_t)k * ldw + i] = in ? u_hat[(int64_t)k * dim + i] : T(0);
     }
     if (threadIdx.x == 0) { cp[k] = k < nl ? wtu_hat[k] : T(0); bp[k] = k < nl ? b[k] : T(0); }
   }
@@ -2117,20 +2198,25 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
   // register kernel (Float32, 16-byte packs, 20 <= dim <= 128): see planar_reg_kernel
   static const int use_reg = getenv("BJX_PLANAR_REG") ? atoi(getenv("BJX_PLANAR_REG")) : 1;
   if constexpr (sizeof(T) == 4) {
-    if (use_reg && dim % 4 == 0 && dim > 16 && dim <= 256 && bjx_aligned16(in) && bjx_aligned16(out)) {
+    // columns that are not whole aligned packs (odd heights, or a base that is only 4-byte aligned) run the same kernels on
+    // element-aligned packs (reg_load_pack).  They used to fall to the LDS-tile kernel: 4-28 % of the HBM peak at 33-255 rows.
+    static const int use_unal = getenv("BJX_PLANAR_REG_UNALIGNED") ? atoi(getenv("BJX_PLANAR_REG_UNALIGNED")) : 1;
+    const bool packs_ok = dim % 4 == 0 && bjx_aligned16(in) && bjx_aligned16(out);
+    if (use_reg && (packs_ok || use_unal) && dim > 16 && dim <= 256) {
       const int NL = nl >= 8 ? 8 : (nl > 2 ? 4 : nl);
       const int nl_pad = (nl + NL - 1) / NL * NL;
+      const int64_t ldw = (dim + 3) / 4 * 4;
       const size_t off0 = ((size_t)nl * dim + nl + 3) / 4 * 4;   // floats, keeps the padded tables 16-byte aligned
-      const size_t need_reg = (off0 + (size_t)2 * nl_pad * dim + (size_t)nl_pad * nl_pad + 2 * (size_t)nl_pad) * sizeof(float);
+      const size_t need_reg = (off0 + (size_t)2 * nl_pad * ldw + (size_t)nl_pad * nl_pad + 2 * (size_t)nl_pad) * sizeof(float);
       if (need_reg <= BJX_SCRATCH_BYTES) {
         float* base = reinterpret_cast<float*>(ctx->scratch);
         float* wp = base + off0;
-        float* up = wp + (size_t)nl_pad * dim;
-        float* Gp = up + (size_t)nl_pad * dim;
+        float* up = wp + (size_t)nl_pad * ldw;
+        float* Gp = up + (size_t)nl_pad * ldw;
         float* cp = Gp + (size_t)nl_pad * nl_pad;
         float* bp = cp + nl_pad;
         hipLaunchKernelGGL(planar_prep_reg_kernel<float>, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, (const float*)w, (const float*)u_hat,
-                           (const float*)wtu, (const float*)b, dim, nl, nl_pad, wp, up, Gp, cp, bp);
+                           (const float*)wtu, (const float*)b, dim, nl, nl_pad, wp, up, Gp, cp, bp, ldw);
         BJX_CHECK_LAUNCH(ctx);
         static const int cols_env = getenv("BJX_PLANAR_COLS") ? atoi(getenv("BJX_PLANAR_COLS")) : 0;
         const int G = dim > 64 ? 32 : (dim > 32 ? 16 : 8);
@@ -2147,7 +2233,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         BjxFin fin;
         bool second = false;
         { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
-        PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl};
+        PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : 1};
         const int accum = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
 #define LAUNCH_REG(G_, NL_, INV_) if (G_ == 32 && cols == 32) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, (G_ == 32 ? 32 : 64)>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); else hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, 64>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
 #define LAUNCH_REG_NL(G_, INV_) switch (NL) { case 1: LAUNCH_REG(G_, 1, INV_); break; case 2: LAUNCH_REG(G_, 2, INV_); break; case 4: LAUNCH_REG(G_, 4, INV_); break; default: LAUNCH_REG(G_, 8, INV_); break; }
@@ -2289,25 +2375,28 @@ int planar_vjp_reg(bjx_ctx*, int, const T*, const T*, const T*, const T*, int, c
 inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float* u_hat, const float* wtu, const float* b, int nl, const float* in,
                           const float* out_bar, const float* ladj_bar, float* in_bar, int64_t dim, int64_t batch, float* t_out, float* s_out) {
   static const int use_reg = getenv("BJX_PLANAR_REG") ? atoi(getenv("BJX_PLANAR_REG")) : 1;
-  if (!(use_reg && dim % 4 == 0 && dim > 16 && dim <= 128 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar))) return 1;
+  static const int use_unal = getenv("BJX_PLANAR_REG_UNALIGNED") ? atoi(getenv("BJX_PLANAR_REG_UNALIGNED")) : 1;
+  const bool packs_ok = dim % 4 == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
+  if (!(use_reg && (packs_ok || use_unal) && dim > 16 && dim <= 128)) return 1;
   const int NL = nl >= 8 ? 8 : (nl > 2 ? 4 : nl);
   const int nl_pad = (nl + NL - 1) / NL * NL;
+  const int64_t ldw = (dim + 3) / 4 * 4;
   const size_t off0 = ((size_t)nl * dim + nl + 3) / 4 * 4;
-  const size_t need_reg = (off0 + (size_t)2 * nl_pad * dim + (size_t)nl_pad * nl_pad + 2 * (size_t)nl_pad) * sizeof(float);
+  const size_t need_reg = (off0 + (size_t)2 * nl_pad * ldw + (size_t)nl_pad * nl_pad + 2 * (size_t)nl_pad) * sizeof(float);
   const size_t smem = (size_t)4 * 64 * (NL + nl_pad) * sizeof(float);
   if (need_reg > BJX_SCRATCH_BYTES || smem > 64 * 1024) return 1;
   float* base = reinterpret_cast<float*>(ctx->scratch);
   float* wp = base + off0;
-  float* up = wp + (size_t)nl_pad * dim;
-  float* Gp = up + (size_t)nl_pad * dim;
+  float* up = wp + (size_t)nl_pad * ldw;
+  float* Gp = up + (size_t)nl_pad * ldw;
   float* cp = Gp + (size_t)nl_pad * nl_pad;
   float* bp = cp + nl_pad;
-  hipLaunchKernelGGL(planar_prep_reg_kernel<float>, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, w, u_hat, wtu, b, dim, nl, nl_pad, wp, up, Gp, cp, bp);
+  hipLaunchKernelGGL(planar_prep_reg_kernel<float>, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, w, u_hat, wtu, b, dim, nl, nl_pad, wp, up, Gp, cp, bp, ldw);
   BJX_CHECK_LAUNCH(ctx);
   const int G = dim > 64 ? 32 : (dim > 32 ? 16 : 8);
   const int64_t grid = (batch + 4 * 64 - 1) / (4 * 64);
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: batch too large for one launch");
-  PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl};
+  PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : 1};
 #define LV(G_, NL_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, true>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); \
                           else hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, false>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); } while (0)
 #define LV_NL(G_) switch (NL) { case 1: LV(G_, 1); break; case 2: LV(G_, 2); break; case 4: LV(G_, 4); break; default: LV(G_, 8); break; }

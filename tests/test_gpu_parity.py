@@ -349,7 +349,9 @@ def test_vec_cholesky_mode_check(bj):
 # ------------------------------------------------------------------ F2 flows
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("dim,N,nl", [(2, 20, 1), (10, 100, 1), (128, 500, 8), (130, 33, 3), (7, 1, 2), (600, 9, 2),
-                                       (128, 67, 1), (100, 300, 2), (64, 257, 5), (32, 1000, 4), (24, 65, 16), (128, 129, 11), (60, 64, 8)])
+                                       (128, 67, 1), (100, 300, 2), (64, 257, 5), (32, 1000, 4), (24, 65, 16), (128, 129, 11), (60, 64, 8),
+                                       # heights that are not whole 16-byte packs: element-aligned packs in the register kernels
+                                       (33, 300, 1), (63, 129, 8), (65, 257, 3), (127, 200, 8), (129, 70, 2), (255, 131, 8), (254, 65, 5), (130, 300, 9), (37, 64, 12)])
 def test_planar(bj, orc, dim, N, nl, dt):
     r = rng(7)
     w = (r.normal(size=(dim, nl)) / math.sqrt(dim)).astype(dt)
@@ -1169,7 +1171,8 @@ def test_logpdf_transformed_structured_and_rand(bj, orc):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("dim,nl,N", [(128, 8, 300), (128, 1, 64), (64, 3, 129), (20, 2, 77), (7, 2, 50), (200, 2, 40), (128, 12, 65), (36, 16, 33)])
+@pytest.mark.parametrize("dim,nl,N", [(128, 8, 300), (128, 1, 64), (64, 3, 129), (20, 2, 77), (7, 2, 50), (200, 2, 40), (128, 12, 65), (36, 16, 33),
+                                      (33, 1, 300), (63, 8, 129), (65, 3, 257), (127, 8, 70), (126, 2, 64), (37, 12, 65)])
 def test_planar_vjp(bj, orc, dim, nl, N, dt):
     """Input pullback of the fused PlanarLayer stack (§8f f-1) against the finite-difference-pinned oracle."""
     r = rng(81)
