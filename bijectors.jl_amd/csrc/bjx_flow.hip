@@ -77,6 +77,21 @@ template <class T> struct PlanarArgs {
   int in_lds;
 };
 
+// The last pack of a column whose height is not a whole number of packs (the group kernels on element-aligned packs, round 3):
+// nrow < V live rows, read / written one by one, the dead rows read as zero.
+template <class T, int V> __device__ __forceinline__ Pack<T, V> load_pack_part(const T* p, int nrow) {
+  if (nrow >= V) return load_pack<T, V, true>(p);
+  Pack<T, V> r;
+#pragma unroll
+  for (int j = 0; j < V; ++j) r.v[j] = j < nrow ? p[j] : T(0);
+  return r;
+}
+template <class T, int V> __device__ __forceinline__ void store_pack_part(T* p, const Pack<T, V>& r, int nrow) {
+  if (nrow >= V) { store_pack<T, V, true>(p, r); return; }
+#pragma unroll
+  for (int j = 0; j < V; ++j) if (j < nrow) p[j] = r.v[j];
+}
+
 template <class T, int V, int R, bool INV>
 __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, const T* x, T* y, T* ladj_ps, int64_t dim,
                                                      int64_t batch, int G, int accumulate, double* partials) {
@@ -93,7 +108,7 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
 
   const int gl = threadIdx.x & (G - 1);
   const int cols_per_block = blockDim.x / G;
-  const int64_t nvc = dim / V;
+  const int64_t nvc = (dim + V - 1) / V;         // the last pack may be partial (odd heights: element-aligned packs, load_pack_part)
   double acc = 0.0;
   // non-persistent grid: one column per G-lane group.  Lanes of a group past the batch keep
   // running (on column batch-1, results discarded) so the group shuffles stay convergent.
@@ -107,7 +122,7 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       int64_t v = gl + (int64_t)r * G;
-      if (v < nvc) z[r] = load_pack<T, V, true>(xc + v * V);
+      if (v < nvc) z[r] = load_pack_part<T, V>(xc + v * V, (int)(dim - v * V < V ? dim - v * V : V));
       else {
 #pragma unroll
         for (int j = 0; j < V; ++j) z[r].v[j] = T(0);
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
         int64_t v = gl + (int64_t)r * G;
         if (v < nvc) {
 #pragma unroll
-          for (int j = 0; j < V; ++j) s += wl[v * V + j] * z[r].v[j];
+          for (int j = 0; j < V; ++j) s += (v * V + j < dim ? wl[v * V + j] : T(0)) * z[r].v[j];
         }
       }
       s = group_sum_rt(s, G);                 // wᵀz   (src/utils.jl:2)
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
         int64_t v = gl + (int64_t)r * G;
         if (v < nvc) {
 #pragma unroll
-          for (int j = 0; j < V; ++j) z[r].v[j] += ul[v * V + j] * tt;   // z ± û tanh(·)
+          for (int j = 0; j < V; ++j) z[r].v[j] += (v * V + j < dim ? ul[v * V + j] : T(0)) * tt;   // z ± û tanh(·)
         }
       }
     }
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       int64_t v = gl + (int64_t)r * G;
-      if (col_ok && y && v < nvc) store_pack<T, V, true>(yc + v * V, z[r]);
+      if (col_ok && y && v < nvc) store_pack_part<T, V>(yc + v * V, z[r], (int)(dim - v * V < V ? dim - v * V : V));
     }
     if (col_ok && gl == 0) {
       if (ladj_ps) ladj_ps[col] = (accumulate & 1) ? ladj_ps[col] + ladj : ladj;
@@ -1232,20 +1247,27 @@ __device__ __forceinline__ void reg_update(const float* __restrict__ tab, int l0
 // partner is still reading.
 // NW = 4: the same with FOUR waves per tile (one tile per block) for 128 < dim <= 256 — those heights used to fall to the
 // LDS-tile kernel (one lane per column over a 64 x dim tile: 8-22 % of the roofline) or the generic group kernel.
+// NW = 8 / 16 (round 3): 512- / 1024-thread blocks, one tile of 64 columns per block, for 256 < dim <= 512 / 1024 — stacks of layers
+// at those heights ran on the group kernel, where every layer costs a 64-lane reduction and a tanh / log1p on all 64 lanes of a
+// column (8 layers: 18 % of the HBM peak at 500 rows, 28 % at 1000).
 template <int NL, bool INV, int NW = 2>
-__global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A, const float* __restrict__ x, float* __restrict__ y,
+__global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 1, 8))) void planar_reg2_kernel(const PlanarRegArgs A, const float* __restrict__ x, float* __restrict__ y,
                                                           float* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate, const BjxFin fin) {
-  constexpr int G = 16, COLS = 64, CPS = 4, NS = 16;
-  __shared__ __attribute__((aligned(16))) float sS[2][4][COLS * NL];     // partial dot products [parity][wave]
-  __shared__ __attribute__((aligned(16))) float sT[4][COLS * NL];        // tanh values of my tile (each wave its own copy)
-  __shared__ double red[4];
+  constexpr int NWB = NW <= 4 ? 4 : NW;                      // waves per block
+  // (a tile of 32 columns — NS = 8 packs, 32 floats — is merged by the compiler into ONE 32-register value that it copies whole at
+  //  every conditional load: 211+ VGPRs, thousands of spills under the 128-register budget of a 1024-thread block.  Keep NS = 16.)
+  constexpr int G = 16, COLS = 64, CPS = 4, NS = COLS / CPS;
+  __shared__ __attribute__((aligned(16))) float sS[2][NWB][COLS * NL];   // partial dot products [parity][wave]
+  __shared__ __attribute__((aligned(16))) float sT[NWB][COLS * NL];      // tanh values of my tile (each wave its own copy)
+  __shared__ double red[NWB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = wave / NW, half = wave % NW;              // half = which 64-row slice of the tile
   const int gl = lane & (G - 1), cg = lane / G;
+  const int lc = lane & (COLS - 1);                          // my column in the lane = column steps
   const int row0 = half * 64;
   const bool row_ok = row0 + 4 * gl < dim;
   const int nrow = dim - row0 - 4 * gl >= 4 ? 4 : dim - row0 - 4 * gl;
-  const int64_t col0 = ((int64_t)blockIdx.x * (4 / NW) + tile) * COLS;
+  const int64_t col0 = ((int64_t)blockIdx.x * (NWB / NW) + tile) * COLS;
   const int64_t left = batch - col0;
   const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
   const int64_t step_elems = (int64_t)CPS * dim;
@@ -1277,14 +1299,17 @@ __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A,
     reg_dots<G, NL, NS>(A.w, l0, A.ldw, z, mineS, lane, gl, cg, row_ok, row0);
     __syncthreads();                                         // every slice of every tile has published its partial sums
     {
+      // (COLS = 32: lanes 32..63 run the recurrence of column lane - 32 along — same values, same stores; a divergent region
+      //  around it made the compiler copy the register tile at every merge)
       float s[NL], t[NL];
 #pragma unroll
-      for (int k = 0; k < NL; ++k) {
-        float acc_ = sS[gi & 1][tile * NW][lane * NL + k];   // fixed order over the slices: every wave of the tile gets the same bits
+      for (int k = 0; k < NL; ++k) { s[k] = sS[gi & 1][tile * NW][lc * NL + k]; t[k] = 0.f; }
+      // fixed order over the slices: every wave of the tile gets the same bits (four slices at a time: all sixteen in flight
+      // cost the 1024-thread variant its 128-register budget)
+#pragma unroll 4
+      for (int pp = 1; pp < NW; ++pp) {
 #pragma unroll
-        for (int pp = 1; pp < NW; ++pp) acc_ += sS[gi & 1][tile * NW + pp][lane * NL + k];
-        s[k] = acc_;
-        t[k] = 0.f;
+        for (int k = 0; k < NL; ++k) s[k] += sS[gi & 1][tile * NW + pp][lc * NL + k];
       }
 #pragma unroll
       for (int kk = 0; kk < NL; ++kk) {
@@ -1306,7 +1331,7 @@ __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A,
       }
       __builtin_amdgcn_wave_barrier();                       // my previous group's reads of stT are done (same wave)
 #pragma unroll
-      for (int k = 0; k < NL; ++k) stT[lane * NL + k] = t[k];
+      for (int k = 0; k < NL; ++k) stT[lc * NL + k] = t[k];
     }
     __builtin_amdgcn_wave_barrier();
     reg_update<G, NL, NS>(A.u_hat, l0, A.ldw, z, stT, gl, cg, row_ok, row0);
@@ -1323,9 +1348,9 @@ __global__ __launch_bounds__(256) void planar_reg2_kernel(const PlanarRegArgs A,
       if ((lane & 15) == 0) mineS[r * CPS + cg] = q[0];
     }
     __syncthreads();
-    float q2 = sS[ngroups & 1][tile * NW][lane];
+    float q2 = sS[ngroups & 1][tile * NW][lane & (COLS - 1)];
 #pragma unroll
-    for (int pp = 1; pp < NW; ++pp) q2 += sS[ngroups & 1][tile * NW + pp][lane];
+    for (int pp = 1; pp < NW; ++pp) q2 += sS[ngroups & 1][tile * NW + pp][lane & (COLS - 1)];
     ladj += -0.5f * q2 - (float)dim * 0.91893853320467274178f;
   }
   if (y) {
@@ -1530,7 +1555,7 @@ __global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, cons
 
   const int gl = threadIdx.x & (G - 1);
   const int cols_per_block = blockDim.x / G;
-  const int64_t nvc = dim / V;
+  const int64_t nvc = (dim + V - 1) / V;         // the last pack may be partial (odd heights: element-aligned packs, load_pack_part)
   double acc = 0.0;
   // non-persistent grid: UC columns per G-lane group.  Lanes of a group past the batch keep
   // running (on column batch-1, results discarded) so the group shuffles stay convergent.
@@ -1541,7 +1566,7 @@ __global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, cons
   for (int r = 0; r < R; ++r) {
     const int64_t v = gl + (int64_t)r * G;
 #pragma unroll
-    for (int j = 0; j < V; ++j) z0r[r][j] = v < nvc ? Z0[v * V + j] : T(0);
+    for (int j = 0; j < V; ++j) z0r[r][j] = v * V + j < dim ? Z0[v * V + j] : T(0);
   }
 #pragma unroll
   for (int u = 0; u < UC; ++u) {
@@ -1550,7 +1575,7 @@ __global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, cons
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t v = gl + (int64_t)r * G;
-      if (v < nvc) zz[u][r] = load_pack<T, V, true>(x + col * dim + v * V);
+      if (v < nvc) zz[u][r] = load_pack_part<T, V>(x + col * dim + v * V, (int)(dim - v * V < V ? dim - v * V : V));
     }
   }
 #pragma unroll
@@ -1595,7 +1620,7 @@ __global__ __launch_bounds__(256) void radial_kernel(const RadialArgs<T> A, cons
           if (!INV) o.v[j] = zz[u][r].v[j] + fwd_gain * dlt;                  // :52
           else o.v[j] = z0r[r][j] + gain * dlt;                              // :101
         }
-        if (col_ok) store_pack<T, V, true>(yc + v * V, o);
+        if (col_ok) store_pack_part<T, V>(yc + v * V, o, (int)(dim - v * V < V ? dim - v * V : V));
       }
     }
     if (col_ok && gl == 0) {
@@ -2106,11 +2131,14 @@ __global__ __launch_bounds__(64) void radial_vjp_walk_kernel(const T* __restrict
 
 struct FlowCfg { int V, G, R; int64_t grid; };
 
-template <class T> bool flow_cfg(const bjx_ctx* ctx, const void* x, const void* y, int64_t dim, int64_t batch, FlowCfg* c) {
+template <class T> bool flow_cfg(const bjx_ctx* ctx, const void* x, const void* y, int64_t dim, int64_t batch, FlowCfg* c, bool allow_unal = false) {
   constexpr int VW = Vec16<T>::N;
   const bool v_ok = bjx_aligned16(x) && bjx_aligned16(y) && dim % VW == 0;
   c->V = v_ok ? VW : 1;
-  const int64_t packs = dim / c->V;
+  int64_t packs = dim / c->V;
+  // odd heights / element-aligned bases (kernels that take a partial last pack): 16-byte packs all the same
+  static const int use_unal = getenv("BJX_FLOW_UNALIGNED") ? atoi(getenv("BJX_FLOW_UNALIGNED")) : 1;
+  if (allow_unal && use_unal && !v_ok && dim >= 32) { c->V = VW; packs = (dim + VW - 1) / VW; }
   int G = 1;
   while (G < 64 && G < packs) G <<= 1;
   // prefer fewer lanes per column with 2 packs each when that keeps >= 16-lane groups (more ILP)
@@ -2202,8 +2230,11 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
     // element-aligned packs (reg_load_pack).  They used to fall to the LDS-tile kernel: 4-28 % of the HBM peak at 33-255 rows.
     static const int use_unal = getenv("BJX_PLANAR_REG_UNALIGNED") ? atoi(getenv("BJX_PLANAR_REG_UNALIGNED")) : 1;
     const bool packs_ok = dim % 4 == 0 && bjx_aligned16(in) && bjx_aligned16(out);
-    if (use_reg && (packs_ok || use_unal) && dim > 16 && dim <= 256) {
-      const int NL = nl >= 8 ? 8 : (nl > 2 ? 4 : nl);
+    // 256 < dim <= 1024, two layers or more: the tile split over 8 / 16 waves of one block (planar_reg2_kernel, NW = 8 / 16)
+    static const int use_big = getenv("BJX_PLANAR_REG_BIG") ? atoi(getenv("BJX_PLANAR_REG_BIG")) : 1;
+    const bool big = use_big && dim > 256 && dim <= 1024 && nl >= 2;
+    if (use_reg && (packs_ok || use_unal) && dim > 16 && (dim <= 256 || big)) {
+      const int NL = (nl >= 8 && !big) ? 8 : (nl > 2 ? 4 : nl);           // 8 / 16 waves a block: groups of four layers (118 VGPRs: two 512-thread blocks a CU)
       const int nl_pad = (nl + NL - 1) / NL * NL;
       const int64_t ldw = (dim + 3) / 4 * 4;
       const size_t off0 = ((size_t)nl * dim + nl + 3) / 4 * 4;   // floats, keeps the padded tables 16-byte aligned
@@ -2227,6 +2258,26 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         // so only deep forward stacks take it.  BJX_PLANAR_SPLIT = 0 / 1 forces it off / on.
         static const int split_env = getenv("BJX_PLANAR_SPLIT") ? atoi(getenv("BJX_PLANAR_SPLIT")) : -1;
         const bool quad = dim > 128;                                 // four waves per tile (128 < dim <= 256)
+        if (big) {
+          const int64_t gridb = (batch + 63) / 64;
+          BJX_REQUIRE(ctx, gridb < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar: batch too large for one launch");
+          BjxFin finb;
+          bool secondb = false;
+          { int rc = bjx_make_fin(ctx, gridb, ladj_sum, 0.0, 0, flags, &finb, &secondb); if (rc) return rc; }
+          if (finb.counter) { finb.counter = nullptr; secondb = true; }        // blocks of 8 / 16 waves: two-pass finalize
+          PlanarRegArgs RB{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : 1};
+          const int accumb = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
+#define LAUNCH_BIG(NL_, INV_, NW_) hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_, NW_>), dim3((unsigned)gridb), dim3(NW_ * 64), 0, ctx->stream, RB, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accumb, finb)
+#define LAUNCH_BIG_I(NL_, NW_) do { if (inverse) LAUNCH_BIG(NL_, true, NW_); else LAUNCH_BIG(NL_, false, NW_); } while (0)
+          { BjxProf prof_(ctx);
+            if (dim <= 512) { if (NL == 4) LAUNCH_BIG_I(4, 8); else LAUNCH_BIG_I(2, 8); }
+            else { if (NL == 4) LAUNCH_BIG_I(4, 16); else LAUNCH_BIG_I(2, 16); } }
+#undef LAUNCH_BIG_I
+#undef LAUNCH_BIG
+          BJX_CHECK_LAUNCH(ctx);
+          if (secondb) return bjx_launch_finalize(ctx, (int)gridb, ladj_sum, 0.0, 0, 0.0, flags);
+          return BJX_OK;
+        }
         const bool split = quad || (G == 32 && (split_env >= 0 ? split_env != 0 : (!inverse && nl >= 8)));
         const int64_t grid = quad ? (batch + 63) / 64 : (split ? (batch + 2 * 64 - 1) / (2 * 64) : (batch + 4 * cols - 1) / (4 * cols));
         BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar: batch too large for one launch");
@@ -2347,7 +2398,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
     return BJX_OK;
   }
   FlowCfg c;
-  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, out, dim, batch, &c), BJX_ERR_UNSUPPORTED, "bjx_planar: dim %lld too large for the register-resident kernel", (long long)dim);
+  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, out, dim, batch, &c, true), BJX_ERR_UNSUPPORTED, "bjx_planar: dim %lld too large for the register-resident kernel", (long long)dim);
   const size_t tab_bytes = (size_t)2 * nl * dim * sizeof(T);
   const bool lds = tab_bytes <= 60 * 1024;
   PlanarArgs<T> A{w, u_hat, wtu, b, nl, lds ? 1 : 0};
@@ -2560,7 +2611,7 @@ int radial_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const
     return BJX_OK;
   }
   FlowCfg c;
-  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, out, dim, batch, &c), BJX_ERR_UNSUPPORTED, "bjx_radial: dim %lld too large for the register-resident kernel", (long long)dim);
+  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, out, dim, batch, &c, true), BJX_ERR_UNSUPPORTED, "bjx_radial: dim %lld too large for the register-resident kernel", (long long)dim);
   {
     const int uc = c.R == 1 ? 4 : (c.R == 2 ? 2 : 1);          // RadialUC<R>
     const int64_t cpb = (int64_t)(256 / c.G) * uc;

@@ -72,7 +72,8 @@ template <class T> __host__ __device__ constexpr size_t stacked_row_bytes() {
   return ((STACKED_SLOTS * sizeof(Slot<T>) + 15) / 16) % 2 == 1 ? (STACKED_SLOTS * sizeof(Slot<T>) + 15) / 16 * 16
                                                                 : (STACKED_SLOTS * sizeof(Slot<T>) + 15) / 16 * 16 + 16;
 }
-__host__ __device__ inline int64_t stacked_row_index(int64_t row, int V, int64_t nvc) { return V > 1 ? (row % V) * nvc + row / V : row; }
+// (rows past the last whole pack — odd heights on element-aligned packs — keep their natural place behind the permuted block)
+__host__ __device__ inline int64_t stacked_row_index(int64_t row, int V, int64_t nvc) { return (V > 1 && row < nvc * V) ? (row % V) * nvc + row / V : row; }
 
 template <class T> __device__ __forceinline__ void slot_reset(Slot<T>& s) {
   s.clo = -Num<T>::inf; s.chi = Num<T>::inf; s.a1 = T(1); s.b1 = T(0); s.a2 = T(1); s.b2 = T(0);
@@ -292,7 +293,7 @@ struct StackedPlan { char* tab; size_t tab_bytes; bool gather; int two; int V; }
 // shorter matrix and every row is gathered), `ldy` = rows of the output matrix (>= dim)
 template <class T>
 int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const void* x, const void* y, int64_t dim, int64_t batch, bool inplace_check,
-                    bool packs_ok, StackedPlan* plan, int64_t ldx = 0, int64_t ldy = 0) {
+                    bool packs_ok, StackedPlan* plan, int64_t ldx = 0, int64_t ldy = 0, bool allow_unal = false) {
   if (ldx == 0) ldx = dim;
   if (ldy == 0) ldy = dim;
   // validate on the host: every output row and every input row exactly once (stacked.jl:156-165 checks the lengths)
@@ -378,7 +379,7 @@ int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const voi
     BJX_HIP(ctx, hipEventRecord(ctx->stage_ev, ctx->stream));
   }
   // the main kernel's pack width decides the row permutation of the table (same rule as col_launch_cfg)
-  ColLaunch cl = col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy);
+  ColLaunch cl = col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy, allow_unal);
   if (!packs_ok) cl.V = 1;                               // a third buffer of the caller is not 16-byte aligned
   hipLaunchKernelGGL(stacked_table_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, dseg, n_segs, dim, cl.V, tab, flag);
   BJX_CHECK_LAUNCH(ctx);
@@ -400,12 +401,57 @@ int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, 
   // columns that are not whole 16-byte packs: the row-owner kernel below would read them 4 bytes at a time; the column walker moves
   // 64 columns as one contiguous run of packs whatever their height (cf. bjx_chain)
   static const int use_walker = getenv("BJX_STACKED_WALKER") ? atoi(getenv("BJX_STACKED_WALKER")) : 1;
-  if (use_walker && ldx == 0 && ldy == 0 && (const void*)x != (const void*)y && (dim % Vec16<T>::N != 0 || dim * sizeof(T) <= 16) && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0) {   // one pack per column: stacked_tiny_kernel (69-71 % against 63-68 %; two packs: 65 against 72-74 %)
+  const bool unal = col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy, true).unal != 0;     // odd heights from 48 rows: the group kernel on element-aligned packs
+  if (use_walker && !unal && ldx == 0 && ldy == 0 && (const void*)x != (const void*)y && (dim % Vec16<T>::N != 0 || dim * sizeof(T) <= 16) && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0) {   // one pack per column: stacked_tiny_kernel (69-71 % against 63-68 %; two packs: 65 against 72-74 %)
     const int rc_w = stacked_mixed_impl<T>(ctx, segs, n_segs, nullptr, 0, x, dim, y, dim, ladj_ps, ladj_sum, batch, flags);
     if (rc_w != BJX_ERR_UNSUPPORTED) return rc_w;                  // permuted ranges / taller than the tile: below
   }
+  // Tall columns: ROW SLABS.  The slot table is 2 x 48 bytes a row (Float32): past ~250 rows a block of the group kernel stages more
+  // table than it moves data (500 rows: 48 KiB of table for 64 KiB of columns, three blocks a CU: 24 % of the HBM peak) and past 512
+  // rows the table no longer fits the LDS at all (1000 rows: every element reads its slots from L2, 22 %).  A slab is a window of
+  // `slab` rows of the same arrays (column pitch = dim) with the segments clipped to it — one launch pair per slab, the log-dets of
+  // the slabs accumulated in launch order (BJX_ACCUMULATE from the second slab on: deterministic), as for the spline tables.
+  static const int slab = getenv("BJX_STACKED_SLAB") ? atoi(getenv("BJX_STACKED_SLAB")) : 256;
+  if (slab >= 16 && ldx == 0 && ldy == 0 && dim > slab + slab / 2 && n_segs > 0) {
+    bool keep = true;
+    int64_t total = 0;
+    for (int s = 0; s < n_segs && keep; ++s) {
+      const bjx_segment& g = segs[s];
+      keep = g.in_lo == g.out_lo && g.len >= 0 && g.in_lo >= 0 && g.in_lo + g.len <= dim && g.n_ops >= 0 && g.n_ops <= BJX_MAX_SEG_OPS;
+      for (int k = 0; keep && k < g.n_ops; ++k) keep = g.ops[k].param_len == 0 || g.ops[k].param_len == 1 || g.ops[k].param_len == g.len;
+      total += g.len;
+    }
+    if (keep && total == dim) {                        // (anything else: the one-launch path below reports it)
+      std::vector<bjx_segment> clip;
+      for (int64_t r0 = 0; r0 < dim; r0 += slab) {
+        const int64_t rs = dim - r0 < slab ? dim - r0 : slab;
+        clip.clear();
+        for (int s = 0; s < n_segs; ++s) {
+          const bjx_segment& g = segs[s];
+          const int64_t lo = g.in_lo > r0 ? g.in_lo : r0, hi = g.in_lo + g.len < r0 + rs ? g.in_lo + g.len : r0 + rs;
+          if (hi <= lo) continue;
+          bjx_segment c = g;
+          c.in_lo = c.out_lo = lo - r0;
+          c.len = hi - lo;
+          for (int k = 0; k < g.n_ops; ++k) {
+            if (g.ops[k].param_len > 1) {              // one value per row of the segment: the window's part of it
+              const size_t off = (size_t)(lo - g.in_lo) * sizeof(T);
+              if (c.ops[k].v0) c.ops[k].v0 = static_cast<const char*>(g.ops[k].v0) + off;
+              if (c.ops[k].v1) c.ops[k].v1 = static_cast<const char*>(g.ops[k].v1) + off;
+              c.ops[k].param_len = (int32_t)(hi - lo);
+            }
+          }
+          clip.push_back(c);
+        }
+        const uint32_t fl = r0 == 0 ? flags : (flags | BJX_ACCUMULATE);
+        const int rc = stacked_impl<T>(ctx, clip.data(), (int)clip.size(), x + r0, y + r0, ladj_ps, ladj_sum, rs, batch, fl, dim, dim);
+        if (rc) return rc;
+      }
+      return BJX_OK;
+    }
+  }
   StackedPlan pl;
-  { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, y, dim, batch, true, true, &pl, ldx, ldy); if (rc) return rc; }
+  { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, y, dim, batch, true, true, &pl, ldx, ldy, true); if (rc) return rc; }
   char* tab = pl.tab;
   const int two = pl.two;
   const bool lds = pl.tab_bytes <= 48 * 1024;

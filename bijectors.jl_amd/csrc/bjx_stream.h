@@ -53,17 +53,51 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
   // ~30 % faster than grid-stride loops on MI355X; one pack per lane in flight is latency-bound)
   const int64_t col0 = (int64_t)blockIdx.x * cols_per_block * COL_UC + threadIdx.x / G;
   const double psc = f.per_sample_const + (f.per_sample_dev ? *f.per_sample_dev : 0.0);
-  if (nvc <= G) {
+  // Column heights that are not whole packs (dim = 101, 201, 1001 ...; V > 1 only): the packs are then ELEMENT-aligned — global
+  // accesses take that — and the last tail = dim % V rows go one row per lane on the lanes after the last pack's (the launcher
+  // sizes G for nvc + tail lanes when the column fits one pack per lane).
+  const int tail = V > 1 ? (int)(dim - nvc * V) : 0;
+  if (nvc + tail <= G) {
     Pack<T, V> p[COL_UC];
     typename col_aux_of<F>::type aux[COL_UC];
     const bool lane_ok = gl < nvc;
+    const bool tail_ok = V > 1 && gl >= nvc && gl < nvc + tail;
+    const int64_t trow = nvc * V + (gl - nvc);                   // the tail lane's row
 #pragma unroll
     for (int u = 0; u < COL_UC; ++u) {
       const int64_t col = col0 + (int64_t)u * cols_per_block;
       if (F::kLoadInput && lane_ok && col < batch) p[u] = load_pack<T, V, NT>(x + col * ldx + (int64_t)gl * V);
       if constexpr (col_has_aux<F>::value) { if (lane_ok && col < batch) aux[u] = f.template fetch<V>(fsm, (int64_t)gl * V, col); }
+      if constexpr (V > 1) {
+        if (tail_ok && col < batch) {
+          if (F::kLoadInput) p[u].v[0] = x[col * ldx + trow];
+          if constexpr (col_has_aux<F>::value) aux[u] = f.template fetch<1>(fsm, trow, col);
+        }
+      }
     }
     T lm[COL_UC];
+    if constexpr (V > 1) {
+      if (tail_ok) {
+        Pack<T, 1> q[COL_UC];
+#pragma unroll
+        for (int u = 0; u < COL_UC; ++u) q[u].v[0] = (col0 + (int64_t)u * cols_per_block < batch) ? p[u].v[0] : p[0].v[0];
+        if constexpr (col_has_multi<F>::value) {
+          if (col0 < batch) f.template apply_multi<1, COL_UC>(fsm, q, trow, lm);
+        } else {
+#pragma unroll
+          for (int u = 0; u < COL_UC; ++u) {
+            const int64_t col = col0 + (int64_t)u * cols_per_block;
+            lm[u] = T(0);
+            if (col < batch) {
+              if constexpr (col_has_aux<F>::value) lm[u] = f.template apply<1>(fsm, q[u], aux[u], x + col * ldx, trow, col);
+              else lm[u] = f.template apply<1>(fsm, q[u], x + col * ldx, trow, col);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < COL_UC; ++u) p[u].v[0] = q[u].v[0];
+      }
+    }
     if constexpr (col_has_multi<F>::value) {
       // optional `apply_multi<V,U>(smem, p[U], row, l[U])`: the COL_UC packs of a lane sit at the same rows
       if (lane_ok) {
@@ -84,6 +118,9 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
         else if constexpr (col_has_aux<F>::value) l = f.template apply<V>(fsm, p[u], aux[u], x + col * ldx, (int64_t)gl * V, col);
         else l = f.template apply<V>(fsm, p[u], x + col * ldx, (int64_t)gl * V, col);
         store_pack<T, V, NT>(y + col * ldy + (int64_t)gl * V, p[u]);
+      }
+      if constexpr (V > 1) {
+        if (tail_ok && col < batch) { l = lm[u]; y[col * ldy + trow] = p[u].v[0]; }
       }
       l = group_sum_rt(l, G);
       if (col < batch && gl == 0) {
@@ -119,6 +156,17 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
               else l += f.template apply<V>(fsm, p[u], xc, v * V, col);
               store_pack<T, V, NT>(yc + v * V, p[u]);
             }
+          }
+        }
+        if constexpr (V > 1) {
+          const int tl = (int)((gl - nvc) & (G - 1));              // tail row t goes to lane (nvc + t) % G
+          if (tl < tail) {
+            const int64_t trow = nvc * V + tl;
+            Pack<T, 1> q;
+            if (F::kLoadInput) q.v[0] = xc[trow];
+            if constexpr (col_has_aux<F>::value) { const typename col_aux_of<F>::type a1 = f.template fetch<1>(fsm, trow, col); l += f.template apply<1>(fsm, q, a1, xc, trow, col); }
+            else l += f.template apply<1>(fsm, q, xc, trow, col);
+            yc[trow] = q.v[0];
           }
         }
       }
@@ -214,16 +262,28 @@ __global__ __launch_bounds__(256) void coldirect_kernel(const F f, const T* x, T
 struct ColLaunch {
   int V, G;
   int64_t grid;
+  int unal;       // V-wide packs on columns that are only ELEMENT-aligned (odd heights): tail rows one per lane, see colgroup_kernel
 };
 
 // choose pack width / lanes per column / grid for a [dim, batch] problem
 template <class T> inline ColLaunch col_launch_cfg(const bjx_ctx* ctx, const void* x, const void* y, int64_t dim, int64_t batch, int64_t ldx = 0,
-                                                   int64_t ldy = 0) {
+                                                   int64_t ldy = 0, bool allow_unal = false) {
   ColLaunch c;
   constexpr int VW = Vec16<T>::N;
   const bool v_ok = bjx_aligned16(x) && bjx_aligned16(y) && dim % VW == 0 && ldx % VW == 0 && ldy % VW == 0;
   c.V = v_ok ? VW : 1;
-  const int64_t packs = dim / c.V;
+  c.unal = 0;
+  int64_t packs = dim / c.V;
+  // Columns that are not whole aligned packs and too tall for the tile walker to keep its occupancy (same-box A/B at 101 / 201
+  // rows, % of the HBM peak: BatchNorm 32 / 15, Coupling 36 / 21, Stacked 36 / 20 on the walker): 16-byte packs on element-aligned
+  // addresses, the dim % V tail rows on one lane each.  Callers that build V-permuted tables must ask with the same flag.
+  static const int use_unal = getenv("BJX_COL_UNALIGNED") ? atoi(getenv("BJX_COL_UNALIGNED")) : 1;
+  static const int unal_min = getenv("BJX_COL_UNALIGNED_MIN") ? atoi(getenv("BJX_COL_UNALIGNED_MIN")) : 48;
+  if (allow_unal && use_unal && !v_ok && dim >= unal_min && dim >= VW) {
+    c.V = VW;
+    c.unal = 1;
+    packs = dim / VW + dim % VW;                       // lanes a column needs at one pack (or one tail row) per lane
+  }
   int G = 1;
   while (G < 64 && G < packs) G <<= 1;
   c.G = G;
@@ -242,7 +302,7 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
     return BJX_OK;
   }
-  ColLaunch c = col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy);
+  ColLaunch c = col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy, !force_v1);
   {
     // odd column heights of dense arrays: the column-walker form (colwalk_kernel)
     static const int use_walk = getenv("BJX_COLWALK") ? atoi(getenv("BJX_COLWALK")) : 1;
@@ -275,7 +335,7 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
       if (second) return bjx_launch_finalize(ctx, (int)grid_d, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, 0.0, flags);
       return BJX_OK;
     }
-    if (use_walk && !force_v1 && dim % VWW != 0 && ldx == dim && ldy == dim && (const void*)x != (const void*)y && smem_w <= 64 * 1024) {
+    if (use_walk && !force_v1 && !c.unal && dim % VWW != 0 && ldx == dim && ldy == dim && (const void*)x != (const void*)y && smem_w <= 64 * 1024) {
       const int64_t grid_w = (batch + 63) / 64;
       BJX_REQUIRE(ctx, grid_w < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
       BjxFin fin;
@@ -295,7 +355,7 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
       return BJX_OK;
     }
   }
-  if (force_v1 && c.V != 1) { c.V = 1; int G = 1; while (G < 64 && G < dim) G <<= 1; c.G = G; const int64_t cpb = (int64_t)(256 / G) * COL_UC; c.grid = (batch + cpb - 1) / cpb; }
+  if (force_v1 && c.V != 1) { c.V = 1; c.unal = 0; int G = 1; while (G < 64 && G < dim) G <<= 1; c.G = G; const int64_t cpb = (int64_t)(256 / G) * COL_UC; c.grid = (batch + cpb - 1) / cpb; }
   constexpr int VW = Vec16<T>::N;
   const size_t smem = 32 + f_smem;
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;

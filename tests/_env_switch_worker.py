@@ -74,6 +74,24 @@ def main(path):
                 put(f"stacked.{tg}", bj.with_logabsdet_jacobian(st, dev(np.asfortranarray(xm.astype(dt))), per_sample=True))
                 A = (r.normal(size=(dim, dim)) / np.sqrt(dim) + 1.5 * np.eye(dim)).astype(dt)
                 put(f"scale_matrix.{tg}", bj.with_logabsdet_jacobian(bj.Scale(dev(A)), dev(x), per_sample=True), bj.with_logabsdet_jacobian(bj.inverse(bj.Scale(dev(A))), dev(x), per_sample=True))
+        # heights that are not whole 16-byte packs, past the tile walkers (element-aligned packs, row slabs, the 8 / 16-wave Planar tile)
+        for dim, N in ((101, 90), (601, 40)):
+            x = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+            nl = 3
+            w, u, b = r.normal(size=(dim, nl)) / np.sqrt(dim), r.normal(size=(dim, nl)) / np.sqrt(dim), r.normal(size=nl)
+            fl = bj.PlanarLayer(torch.tensor(w, dtype=tdt), torch.tensor(u, dtype=tdt), torch.tensor(b, dtype=tdt))
+            put(f"planar_odd.{tg}.{dim}", bj.with_logabsdet_jacobian(fl, dev(x)))
+            rd = bj.RadialLayer(torch.tensor([0.3], dtype=tdt), torch.tensor([0.2], dtype=tdt), torch.tensor(r.normal(size=dim), dtype=tdt))
+            put(f"radial_odd.{tg}.{dim}", bj.with_logabsdet_jacobian(rd, dev(x)))
+            bn = bj.InvertibleBatchNorm(torch.tensor(r.normal(size=dim), dtype=tdt), torch.tensor(0.3 * r.normal(size=dim), dtype=tdt),
+                                        torch.tensor(r.normal(size=dim), dtype=tdt), torch.tensor(r.uniform(0.5, 2, size=dim), dtype=tdt), eps=1e-5)
+            put(f"bn_odd.{tg}.{dim}", bj.with_logabsdet_jacobian(bn, dev(x)))
+            a_, b_ = dim // 3, 2 * (dim // 3)
+            xs = x.copy()
+            xs[a_:b_] = r.uniform(0.05, 0.95, size=(b_ - a_, N))
+            av = torch.linspace(0.5, 1.5, a_, dtype=tdt).cuda()
+            st = bj.Stacked([e(bj.exp) @ bj.Scale(av), bj.Logit(0.0, 1.0), bj.identity], [(1, a_), (a_ + 1, b_), (b_ + 1, dim)])
+            put(f"stacked_odd.{tg}.{dim}", bj.with_logabsdet_jacobian(st, dev(np.asfortranarray(xs.astype(dt))), per_sample=True))
         for K, N in ((4, 300), (9, 130), (16, 70), (64, 9)):
             nv = K * (K - 1) // 2
             y = np.asfortranarray((r.normal(size=(nv, N)) * min(0.6, 1.6 / np.sqrt(K))).astype(dt))

@@ -351,7 +351,9 @@ def test_vec_cholesky_mode_check(bj):
 @pytest.mark.parametrize("dim,N,nl", [(2, 20, 1), (10, 100, 1), (128, 500, 8), (130, 33, 3), (7, 1, 2), (600, 9, 2),
                                        (128, 67, 1), (100, 300, 2), (64, 257, 5), (32, 1000, 4), (24, 65, 16), (128, 129, 11), (60, 64, 8),
                                        # heights that are not whole 16-byte packs: element-aligned packs in the register kernels
-                                       (33, 300, 1), (63, 129, 8), (65, 257, 3), (127, 200, 8), (129, 70, 2), (255, 131, 8), (254, 65, 5), (130, 300, 9), (37, 64, 12)])
+                                       (33, 300, 1), (63, 129, 8), (65, 257, 3), (127, 200, 8), (129, 70, 2), (255, 131, 8), (254, 65, 5), (130, 300, 9), (37, 64, 12),
+                                       # two layers or more at 257 ... 1024 rows: the tile split over the 8 / 16 waves of one block
+                                       (500, 130, 8), (1000, 70, 8), (1001, 65, 3), (513, 64, 2), (300, 100, 5), (1024, 33, 12), (257, 64, 1), (1001, 33, 1), (1025, 20, 2)])
 def test_planar(bj, orc, dim, N, nl, dt):
     r = rng(7)
     w = (r.normal(size=(dim, nl)) / math.sqrt(dim)).astype(dt)
@@ -386,7 +388,8 @@ def test_planar_stack_equals_composition(bj):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("dim,N", [(2, 20), (10, 100), (128, 300), (131, 17)])
+@pytest.mark.parametrize("dim,N", [(2, 20), (10, 100), (128, 300), (131, 17),
+                                   (33, 70), (101, 130), (201, 65), (255, 40), (257, 9), (1001, 17)])    # odd heights: element-aligned packs, partial last pack
 def test_radial(bj, orc, dim, N, dt):
     r = rng(9)
     a_, be, z0 = float(r.normal()), float(r.normal()), r.normal(size=dim).astype(dt)
@@ -404,7 +407,7 @@ def test_radial(bj, orc, dim, N, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("dim,N", [(2, 20), (64, 300), (5, 3)])
+@pytest.mark.parametrize("dim,N", [(2, 20), (64, 300), (5, 3), (49, 77), (63, 100), (101, 300), (201, 65), (255, 33), (1001, 33)])
 def test_batchnorm_eval(bj, orc, dim, N, dt):
     r = rng(10)
     b_, logs, m, v = r.normal(size=dim).astype(dt), (0.3 * r.normal(size=dim)).astype(dt), r.normal(size=dim).astype(dt), r.uniform(0.5, 2, size=dim).astype(dt)
@@ -425,7 +428,7 @@ def test_batchnorm_eval(bj, orc, dim, N, dt):
 # ------------------------------------------------------------------ F4 RQS
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("dim,K,N", [(32, 16, 500), (3, 8, 50), (1, 4, 10), (130, 5, 20), (64, 16, 300), (32, 7, 200), (256, 4, 70),
-                                     (40, 32, 100), (8, 1, 33), (12, 2, 40), (300, 3, 9)])
+                                     (40, 32, 100), (8, 1, 33), (12, 2, 40), (300, 3, 9), (101, 8, 70), (201, 8, 33), (255, 5, 20), (1001, 4, 9)])
 def test_rqs(bj, orc, dim, K, N, dt):
     r = rng(12)
     raw = [r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K)).astype(dt), r.normal(size=(dim, K - 1)).astype(dt)]
@@ -491,7 +494,7 @@ def test_permute_exact(bj, orc):
         bj.Permute(2, ([1, 2, 3], [2, 1]))
     r = rng(13)
     for dt in (np.float32, np.float64):
-        for dim, N in ((64, 1000), (7, 33), (257, 5)):
+        for dim, N in ((64, 1000), (7, 33), (257, 5), (101, 50), (255, 20)):
             perm = r.permutation(dim)
             X = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
             b = bj.Permute((perm + 1).tolist())             # y[perm[i]] = x[i]
@@ -521,7 +524,8 @@ def test_coupling_reference_cases(bj):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("dim,lo,n1,N", [(64, 1, 32, 1000), (64, 33, 32, 257), (64, 3, 10, 100), (24, 9, 8, 77), (200, 41, 80, 33), (7, 2, 3, 19)])
+@pytest.mark.parametrize("dim,lo,n1,N", [(64, 1, 32, 1000), (64, 33, 32, 257), (64, 3, 10, 100), (24, 9, 8, 77), (200, 41, 80, 33), (7, 2, 3, 19),
+                                         (101, 7, 40, 77), (201, 50, 99, 65), (255, 1, 128, 20), (1001, 100, 500, 9)])
 def test_coupling_row_ranges(bj, orc, dim, lo, n1, N, dt):
     """PartitionMask over a row range lo:lo+n1-1 (1-based): θ packs are read as whole 16-byte loads when aligned."""
     r = rng(15)
@@ -796,6 +800,41 @@ def test_stacked_elementwise_segments_one_launch(bj, orc, dt, N):
     _, lsum = bj.with_logabsdet_jacobian(b, dev(X))
     sum_close(host(lsum), l_ref.sum(), dt, dim * N)
     # inverse(Stacked) undoes it and negates the log-det (stacked.jl:113-118)
+    Xb, lb = bj.with_logabsdet_jacobian(bj.inverse(b), dev(Y_ref), per_sample=True)
+    close(host(Xb), X, dt, scale=10, what="stacked inverse")
+    close(host(lb), -l_ref, dt, scale=dim * 10, what="stacked inverse ladj")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim", [101, 201, 255, 385, 500, 771, 1000, 1001])
+def test_stacked_tall_columns(bj, orc, dt, dim):
+    """Heights past the tile walker: the group kernel on element-aligned packs (odd heights from 48 rows) and, from 385 rows,
+    row slabs of 256 rows with the segments — and their per-row parameters — clipped to each slab (stacked.jl:142-166)."""
+    r = rng(43)
+    N = 131
+    n1, n3, n4 = dim // 5, dim // 3, dim // 4
+    b1, b2, b3, b4 = n1, n1 + 1, n1 + 1 + n3, n1 + 1 + n3 + n4
+    a_vec = np.linspace(0.5, 2.0, n4)
+    c_vec = r.normal(size=n4)
+    segs = [
+        (bj.elementwise(bj.exp), [(orc.OP_EXP, None, None)], (1, b1)),
+        (bj.identity, [], (b1 + 1, b2)),
+        (bj.Logit(-1.0, 2.0), [(orc.OP_LOGIT, -1.0, 2.0)], (b2 + 1, b3)),
+        (bj.elementwise(bj.exp) @ bj.Shift(torch.tensor(c_vec)) @ bj.Scale(torch.tensor(a_vec)), [(orc.OP_SCALE, a_vec, None), (orc.OP_SHIFT, c_vec, None), (orc.OP_EXP, None, None)], (b3 + 1, b4)),
+        (bj.inverse(bj.TruncatedBijector(0.0, 3.0)), [(orc.OP_TRUNCATED_INV, 0.0, 3.0)], (b4 + 1, dim - 1)),
+        (bj.elementwise(bj.log), [(orc.OP_LOG, None, None)], (dim, dim)),
+    ]
+    X = r.normal(size=(dim, N))
+    X[b2:b3] = r.uniform(-0.9, 1.9, size=(b3 - b2, N))
+    X[dim - 1] = r.uniform(0.1, 3.0, size=N)
+    X = np.asfortranarray(X.astype(dt))
+    b = bj.Stacked([s[0] for s in segs], [s[2] for s in segs])
+    Y_ref, l_ref = _stacked_oracle(orc, [(s[1], s[2]) for s in segs], X)
+    Y, l = bj.with_logabsdet_jacobian(b, dev(X), per_sample=True)
+    close(host(Y), Y_ref, dt, what="stacked y")
+    close(host(l), l_ref, dt, scale=dim, what="stacked ladj")
+    _, lsum = bj.with_logabsdet_jacobian(b, dev(X))
+    sum_close(host(lsum), l_ref.sum(), dt, dim * N)
     Xb, lb = bj.with_logabsdet_jacobian(bj.inverse(b), dev(Y_ref), per_sample=True)
     close(host(Xb), X, dt, scale=10, what="stacked inverse")
     close(host(lb), -l_ref, dt, scale=dim * 10, what="stacked inverse ladj")
