@@ -412,7 +412,7 @@ int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, 
   // `slab` rows of the same arrays (column pitch = dim) with the segments clipped to it — one launch pair per slab, the log-dets of
   // the slabs accumulated in launch order (BJX_ACCUMULATE from the second slab on: deterministic), as for the spline tables.
   static const int slab = getenv("BJX_STACKED_SLAB") ? atoi(getenv("BJX_STACKED_SLAB")) : 256;
-  if (slab >= 16 && ldx == 0 && ldy == 0 && dim > slab + slab / 2 && n_segs > 0) {
+  if (slab >= 16 && ldx == 0 && ldy == 0 && dim > slab && n_segs > 0) {
     bool keep = true;
     int64_t total = 0;
     for (int s = 0; s < n_segs && keep; ++s) {
@@ -423,8 +423,8 @@ int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, 
     }
     if (keep && total == dim) {                        // (anything else: the one-launch path below reports it)
       std::vector<bjx_segment> clip;
-      for (int64_t r0 = 0; r0 < dim; r0 += slab) {
-        const int64_t rs = dim - r0 < slab ? dim - r0 : slab;
+      for (int64_t r0 = 0, rs = 0; r0 < dim; r0 += rs) {
+        rs = dim - r0 <= slab + slab / 2 ? dim - r0 : slab;      // (no sliver at the end: the last slab takes up to half a slab more)
         clip.clear();
         for (int s = 0; s < n_segs; ++s) {
           const bjx_segment& g = segs[s];

@@ -36,7 +36,7 @@ template <class F> struct col_aux_of<F, true> { using type = typename F::Aux; };
 
 constexpr int COL_UC = 4;   // columns in flight per lane group (one 16-byte pack each) when a column fits in G packs
 
-template <class T, int V, bool NT, class F>
+template <class T, int V, bool NT, class F, bool TAIL = false>
 __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T* y, T* ladj_ps, int64_t dim,
                                                        int64_t batch, int G, int accumulate, const BjxFin fin, int64_t ldx, int64_t ldy) {
   // ldx / ldy: leading dimensions of x / y (== dim for a dense [dim, batch] array; larger when the `dim` rows are a
@@ -56,19 +56,21 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
   // Column heights that are not whole packs (dim = 101, 201, 1001 ...; V > 1 only): the packs are then ELEMENT-aligned — global
   // accesses take that — and the last tail = dim % V rows go one row per lane on the lanes after the last pack's (the launcher
   // sizes G for nvc + tail lanes when the column fits one pack per lane).
-  const int tail = V > 1 ? (int)(dim - nvc * V) : 0;
+  // TAIL is a template flag: with the tail code compiled into the whole-pack instantiation, Coupling and Stacked at 252 rows lost a
+  // fifth of their rate (56 -> 46 %, 63 -> 51 %) to the second functor call's registers.
+  const int tail = (V > 1 && TAIL) ? (int)(dim - nvc * V) : 0;
   if (nvc + tail <= G) {
     Pack<T, V> p[COL_UC];
     typename col_aux_of<F>::type aux[COL_UC];
     const bool lane_ok = gl < nvc;
-    const bool tail_ok = V > 1 && gl >= nvc && gl < nvc + tail;
+    const bool tail_ok = V > 1 && TAIL && gl >= nvc && gl < nvc + tail;
     const int64_t trow = nvc * V + (gl - nvc);                   // the tail lane's row
 #pragma unroll
     for (int u = 0; u < COL_UC; ++u) {
       const int64_t col = col0 + (int64_t)u * cols_per_block;
       if (F::kLoadInput && lane_ok && col < batch) p[u] = load_pack<T, V, NT>(x + col * ldx + (int64_t)gl * V);
       if constexpr (col_has_aux<F>::value) { if (lane_ok && col < batch) aux[u] = f.template fetch<V>(fsm, (int64_t)gl * V, col); }
-      if constexpr (V > 1) {
+      if constexpr (V > 1 && TAIL) {
         if (tail_ok && col < batch) {
           if (F::kLoadInput) p[u].v[0] = x[col * ldx + trow];
           if constexpr (col_has_aux<F>::value) aux[u] = f.template fetch<1>(fsm, trow, col);
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
       }
     }
     T lm[COL_UC];
-    if constexpr (V > 1) {
+    if constexpr (V > 1 && TAIL) {
       if (tail_ok) {
         Pack<T, 1> q[COL_UC];
 #pragma unroll
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
         else l = f.template apply<V>(fsm, p[u], x + col * ldx, (int64_t)gl * V, col);
         store_pack<T, V, NT>(y + col * ldy + (int64_t)gl * V, p[u]);
       }
-      if constexpr (V > 1) {
+      if constexpr (V > 1 && TAIL) {
         if (tail_ok && col < batch) { l = lm[u]; y[col * ldy + trow] = p[u].v[0]; }
       }
       l = group_sum_rt(l, G);
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
             }
           }
         }
-        if constexpr (V > 1) {
+        if constexpr (V > 1 && TAIL) {
           const int tl = (int)((gl - nvc) & (G - 1));              // tail row t goes to lane (nvc + t) % G
           if (tl < tail) {
             const int64_t trow = nvc * V + tl;
@@ -275,10 +277,11 @@ template <class T> inline ColLaunch col_launch_cfg(const bjx_ctx* ctx, const voi
   c.unal = 0;
   int64_t packs = dim / c.V;
   // Columns that are not whole aligned packs and too tall for the tile walker to keep its occupancy (same-box A/B at 101 / 201
-  // rows, % of the HBM peak: BatchNorm 32 / 15, Coupling 36 / 21, Stacked 36 / 20 on the walker): 16-byte packs on element-aligned
-  // addresses, the dim % V tail rows on one lane each.  Callers that build V-permuted tables must ask with the same flag.
+  // rows, % of the HBM peak: BatchNorm 32 / 15 -> 44 / 45, Stacked 36 / 20 -> 43 / 41, Coupling 36 / 21 -> 29 / 31; at 63 rows the
+  // walker still wins, 54 / 49 against 31 / 31): 16-byte packs on element-aligned addresses, the dim % V tail rows on one lane each.
+  // Callers that build V-permuted tables must ask with the same flag.
   static const int use_unal = getenv("BJX_COL_UNALIGNED") ? atoi(getenv("BJX_COL_UNALIGNED")) : 1;
-  static const int unal_min = getenv("BJX_COL_UNALIGNED_MIN") ? atoi(getenv("BJX_COL_UNALIGNED_MIN")) : 48;
+  static const int unal_min = getenv("BJX_COL_UNALIGNED_MIN") ? atoi(getenv("BJX_COL_UNALIGNED_MIN")) : 96;
   if (allow_unal && use_unal && !v_ok && dim >= unal_min && dim >= VW) {
     c.V = VW;
     c.unal = 1;
@@ -365,7 +368,9 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
   { int rc = bjx_make_fin(ctx, c.grid, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, flags, &fin, &second); if (rc) return rc; }
   {
   BjxProf prof_(ctx);
-  if (c.V == VW)
+  if (c.V == VW && c.unal && dim % VW != 0)
+    hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F, true>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy);
+  else if (c.V == VW)
     hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy);
   else
     hipLaunchKernelGGL((colgroup_kernel<T, 1, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy);
