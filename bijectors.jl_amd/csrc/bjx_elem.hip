@@ -607,6 +607,9 @@ __global__ __launch_bounds__(256) void rqs_vjp_kernel(const T* __restrict__ blob
 template <class T, bool INV> struct BnF {
   static constexpr bool kLoadInput = true;
   static constexpr bool kMulti = true;            // the row parameters are fetched once for the columns a lane has in flight
+  static constexpr bool kMasked = true;           // any first row; the per-element log-det is a per-column constant (no mask needed)
+  template <int V, int U> __device__ void apply_multi_masked(const char* smem, Pack<T, V> (&p)[U], int64_t row, T (&l)[U], uint32_t) const { apply_multi<V, U>(smem, p, row, l); }
+  template <int V> __device__ T apply_masked(const char* smem, Pack<T, V>& p, const T* xc, int64_t row, int64_t col, uint32_t) const { return apply<V>(smem, p, xc, row, col); }
   template <int V, int U> __device__ void apply_multi(const char* smem, Pack<T, V> (&p)[U], int64_t row, T (&l)[U]) const {
     const T* t = reinterpret_cast<const T*>(smem);
 #pragma unroll
@@ -684,6 +687,7 @@ __global__ void rowmap_kernel(const int32_t* idx1, int64_t n1, int64_t dim, int3
 
 template <class T, bool INV> struct CouplingAffineF {
   static constexpr bool kLoadInput = true;
+  static constexpr bool kMasked = true;           // fetch() takes any first row; apply_masked drops the log-det terms of rows outside the mask
   const int32_t* map;
   const T *scale, *shift;   // [n1, batch] or null
   int64_t n1, dim;
@@ -739,13 +743,16 @@ template <class T, bool INV> struct CouplingAffineF {
     }
     return a;
   }
-  template <int V> __device__ T apply(const char*, Pack<T, V>& p, const Aux& a, const T*, int64_t, int64_t) const {
+  template <int V> __device__ T apply(const char* sm, Pack<T, V>& p, const Aux& a, const T* xc, int64_t row, int64_t col) const {
+    return apply_masked<V>(sm, p, a, xc, row, col, ~0u);
+  }
+  template <int V> __device__ T apply_masked(const char*, Pack<T, V>& p, const Aux& a, const T*, int64_t, int64_t, uint32_t mask) const {
     using F = Fast<T>;
     T l = T(0);
     if (a.on) {
 #pragma unroll
       for (int j = 0; j < V; ++j) {
-        const bool on = (a.on >> j) & 1u;
+        const bool on = (a.on >> j) & (mask >> j) & 1u;
         const T s = a.s.v[j], t = a.t.v[j];
         // Shift(t) ∘ Scale(s) (coupling.jl:206-219); inverse(Scale) ∘ inverse(Shift) (:236-250)
         const T v = !INV ? t + s * p.v[j] : F::rcp(s) * (-t + p.v[j]);

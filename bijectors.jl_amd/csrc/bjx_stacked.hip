@@ -220,6 +220,36 @@ template <class T, int U> __device__ __forceinline__ void slot_eval_multi(const 
 template <class T, bool GATHER, bool IN_LDS> struct StackedF {
   static constexpr bool kLoadInput = !GATHER;
   static constexpr bool kMulti = !GATHER;          // apply_multi: all columns in flight of a lane group at once
+  static constexpr bool kMasked = !GATHER;         // the masked forms take any first row (every element looks up its own table place)
+  template <int V, int U> __device__ void apply_multi_masked(const char* smem, Pack<T, V> (&p)[U], int64_t row, T (&l)[U], uint32_t mask) const {
+    const char* t = IN_LDS ? smem : tab;
+    const int64_t nvc = dim / V;
+#pragma unroll
+    for (int i = 0; i < U; ++i) l[i] = T(0);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const Slot<T>* e = reinterpret_cast<const Slot<T>*>(t + stacked_row_index(row + j, V, nvc) * stacked_row_bytes<T>());
+      T x[U], lj[U];
+#pragma unroll
+      for (int i = 0; i < U; ++i) { x[i] = p[i].v[j]; lj[i] = T(0); }
+#pragma unroll 1
+      for (int q = 0; q < (two_slots ? STACKED_SLOTS : 1); ++q) {
+        const Slot<T> sq = e[q];
+        if (sq.kind == SK_END) break;
+        slot_eval_multi<T, U>(sq, x, lj);
+      }
+      const bool on = (mask >> j) & 1u;
+#pragma unroll
+      for (int i = 0; i < U; ++i) { p[i].v[j] = x[i]; l[i] += on ? lj[i] : T(0); }
+    }
+  }
+  template <int V> __device__ T apply_masked(const char* smem, Pack<T, V>& p, const T*, int64_t row, int64_t, uint32_t mask) const {
+    Pack<T, V> pp[1] = {p};
+    T l1[1];
+    apply_multi_masked<V, 1>(smem, pp, row, l1, mask);
+    p = pp[0];
+    return l1[0];
+  }
   template <int V, int U> __device__ void apply_multi(const char* smem, Pack<T, V> (&p)[U], int64_t row, T (&l)[U]) const {
     const char* t = IN_LDS ? smem : tab;
     const int64_t nvc = dim / V;

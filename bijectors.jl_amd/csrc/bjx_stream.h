@@ -30,6 +30,8 @@ template <class F, class = void> struct col_has_aux { static constexpr bool valu
 template <class F> struct col_has_aux<F, decltype((void)sizeof(typename F::Aux))> { static constexpr bool value = true; };
 template <class F, class = void> struct col_has_multi { static constexpr bool value = false; };
 template <class F> struct col_has_multi<F, decltype((void)F::kMulti)> { static constexpr bool value = F::kMulti; };
+template <class F, class = void> struct col_has_masked { static constexpr bool value = false; };
+template <class F> struct col_has_masked<F, decltype((void)F::kMasked)> { static constexpr bool value = F::kMasked; };
 struct ColNoAux {};
 template <class F, bool H = col_has_aux<F>::value> struct col_aux_of { using type = ColNoAux; };
 template <class F> struct col_aux_of<F, true> { using type = typename F::Aux; };
@@ -169,6 +171,129 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
             if constexpr (col_has_aux<F>::value) { const typename col_aux_of<F>::type a1 = f.template fetch<1>(fsm, trow, col); l += f.template apply<1>(fsm, q, a1, xc, trow, col); }
             else l += f.template apply<1>(fsm, q, xc, trow, col);
             yc[trow] = q.v[0];
+          }
+        }
+      }
+      l = group_sum_rt(l, G);
+      if (col < batch && gl == 0) {
+        if (ladj_ps) {
+          T out = l + (T)psc;
+          if (accumulate) out += ladj_ps[col];
+          ladj_ps[col] = out;
+        }
+        acc += (double)l;
+      }
+    }
+  }
+  block_publish_partial(acc, red, fin);
+}
+
+
+// Odd column heights for functors that take ANY first row and a row mask (`kMasked`: apply_masked / apply_multi_masked): the dim % V
+// tail rows are one more unit of the SAME code path — the lane after the last whole pack reads the LAST V rows of the column
+// (element-aligned, overlapping the pack before it), evaluates all V of them, and keeps only its own: the mask drops the overlap's
+// log-det terms and the store writes the tail rows alone.  No second functor call (colgroup_kernel<..., TAIL = true> runs the tail
+// through a one-row call behind a divergent branch: BatchNorm / Stacked 43-46 % of the HBM peak at 101 / 201 rows against 62-67 %
+// at 252).  In place: the overlap may already hold outputs when the tail unit runs in a later trip; those values are never used.
+template <class T, int V, class F>
+__global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* x, T* y, T* ladj_ps, int64_t dim,
+                                                            int64_t batch, int G, int accumulate, const BjxFin fin, int64_t ldx, int64_t ldy) {
+  static_assert(V > 1, "whole packs only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* red = reinterpret_cast<double*>(smem);
+  char* fsm = smem + 32;
+  f.stage(fsm);
+  const int gl = threadIdx.x & (G - 1);
+  const int cols_per_block = blockDim.x / G;
+  const int64_t nvc = dim / V;
+  const int tail = (int)(dim - nvc * V);                          // 1 .. V-1
+  const int64_t nun = nvc + 1;                                    // units of a column: the whole packs and the tail
+  constexpr uint32_t full = (1u << V) - 1u;
+  const uint32_t tmask = (full << (V - tail)) & full;             // the tail unit's own rows are the LAST `tail` of its pack
+  double acc = 0.0;
+  const int64_t col0 = (int64_t)blockIdx.x * cols_per_block * COL_UC + threadIdx.x / G;
+  const double psc = f.per_sample_const + (f.per_sample_dev ? *f.per_sample_dev : 0.0);
+  if (nun <= G) {
+    Pack<T, V> p[COL_UC];
+    typename col_aux_of<F>::type aux[COL_UC];
+    const bool lane_ok = gl < nun;
+    const bool is_tail = gl == nvc;
+    const int64_t prow = is_tail ? dim - V : (int64_t)gl * V;
+    const uint32_t mask = is_tail ? tmask : full;
+#pragma unroll
+    for (int u = 0; u < COL_UC; ++u) {
+      const int64_t col = col0 + (int64_t)u * cols_per_block;
+      if (F::kLoadInput && lane_ok && col < batch) p[u] = load_pack<T, V, true>(x + col * ldx + prow);
+      if constexpr (col_has_aux<F>::value) { if (lane_ok && col < batch) aux[u] = f.template fetch<V>(fsm, prow, col); }
+    }
+    T lm[COL_UC];
+    if constexpr (col_has_multi<F>::value) {
+      if (lane_ok) {
+        if (col0 + (int64_t)(COL_UC - 1) * cols_per_block >= batch) {
+#pragma unroll
+          for (int u = 0; u < COL_UC; ++u)
+            if (col0 + (int64_t)u * cols_per_block >= batch) { p[u] = p[0]; }
+        }
+        if (col0 < batch) f.template apply_multi_masked<V, COL_UC>(fsm, p, prow, lm, mask);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < COL_UC; ++u) {
+      const int64_t col = col0 + (int64_t)u * cols_per_block;
+      T l = T(0);
+      if (lane_ok && col < batch) {
+        if constexpr (col_has_multi<F>::value) l = lm[u];
+        else if constexpr (col_has_aux<F>::value) l = f.template apply_masked<V>(fsm, p[u], aux[u], x + col * ldx, prow, col, mask);
+        else l = f.template apply_masked<V>(fsm, p[u], x + col * ldx, prow, col, mask);
+        T* yp = y + col * ldy + prow;
+        if (!is_tail) store_pack<T, V, true>(yp, p[u]);
+        else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) if ((mask >> j) & 1u) yp[j] = p[u].v[j];
+        }
+      }
+      l = group_sum_rt(l, G);
+      if (col < batch && gl == 0) {
+        if (ladj_ps) {
+          T out = l + (T)psc;
+          if (accumulate) out += ladj_ps[col];
+          ladj_ps[col] = out;
+        }
+        acc += (double)l;
+      }
+    }
+  } else {
+    for (int uc = 0; uc < COL_UC; ++uc) {
+      const int64_t col = col0 + (int64_t)uc * cols_per_block;
+      T l = T(0);
+      if (col < batch) {
+        const T* xc = x + col * ldx;
+        T* yc = y + col * ldy;
+        for (int64_t v0 = 0; v0 < nun; v0 += (int64_t)G * STREAM_U) {
+          Pack<T, V> p[STREAM_U];
+          typename col_aux_of<F>::type aux[STREAM_U];
+#pragma unroll
+          for (int u = 0; u < STREAM_U; ++u) {
+            const int64_t v = v0 + (int64_t)u * G + gl;
+            const int64_t prow = v == nvc ? dim - V : v * V;
+            if (F::kLoadInput && v < nun) p[u] = load_pack<T, V, true>(xc + prow);
+            if constexpr (col_has_aux<F>::value) { if (v < nun) aux[u] = f.template fetch<V>(fsm, prow, col); }
+          }
+#pragma unroll
+          for (int u = 0; u < STREAM_U; ++u) {
+            const int64_t v = v0 + (int64_t)u * G + gl;
+            if (v < nun) {
+              const bool is_tail = v == nvc;
+              const int64_t prow = is_tail ? dim - V : v * V;
+              const uint32_t mask = is_tail ? tmask : full;
+              if constexpr (col_has_aux<F>::value) l += f.template apply_masked<V>(fsm, p[u], aux[u], xc, prow, col, mask);
+              else l += f.template apply_masked<V>(fsm, p[u], xc, prow, col, mask);
+              if (!is_tail) store_pack<T, V, true>(yc + prow, p[u]);
+              else {
+#pragma unroll
+                for (int j = 0; j < V; ++j) if ((mask >> j) & 1u) yc[prow + j] = p[u].v[j];
+              }
+            }
           }
         }
       }
@@ -368,9 +493,12 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
   { int rc = bjx_make_fin(ctx, c.grid, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, flags, &fin, &second); if (rc) return rc; }
   {
   BjxProf prof_(ctx);
-  if (c.V == VW && c.unal && dim % VW != 0)
-    hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F, true>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy);
-  else if (c.V == VW)
+  if (c.V == VW && c.unal && dim % VW != 0) {
+    if constexpr (col_has_masked<F>::value && Vec16<T>::N > 1)
+      hipLaunchKernelGGL((colgroup_tail_kernel<T, VW, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy);
+    else
+      hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F, true>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy);
+  } else if (c.V == VW)
     hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy);
   else
     hipLaunchKernelGGL((colgroup_kernel<T, 1, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy);
