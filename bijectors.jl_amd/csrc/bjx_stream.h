@@ -136,6 +136,49 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
         acc += (double)l;
       }
     }
+  } else if (!TAIL && nvc <= 2 * (int64_t)G) {
+    // up to two packs per lane: TWO columns in flight (see colgroup_tail_kernel)
+    for (int uc = 0; uc < COL_UC; uc += 2) {
+      Pack<T, V> p[2][2];
+      typename col_aux_of<F>::type aux[2][2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int64_t col = col0 + (int64_t)(uc + c) * cols_per_block;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int64_t v = (int64_t)r * G + gl;
+          if (F::kLoadInput && col < batch && v < nvc) p[c][r] = load_pack<T, V, NT>(x + col * ldx + v * V);
+          if constexpr (col_has_aux<F>::value) { if (col < batch && v < nvc) aux[c][r] = f.template fetch<V>(fsm, v * V, col); }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int64_t col = col0 + (int64_t)(uc + c) * cols_per_block;
+        T l = T(0);
+        if (col < batch) {
+          const T* xc = x + col * ldx;
+          T* yc = y + col * ldy;
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int64_t v = (int64_t)r * G + gl;
+            if (v < nvc) {
+              if constexpr (col_has_aux<F>::value) l += f.template apply<V>(fsm, p[c][r], aux[c][r], xc, v * V, col);
+              else l += f.template apply<V>(fsm, p[c][r], xc, v * V, col);
+              store_pack<T, V, NT>(yc + v * V, p[c][r]);
+            }
+          }
+        }
+        l = group_sum_rt(l, G);
+        if (col < batch && gl == 0) {
+          if (ladj_ps) {
+            T out = l + (T)psc;
+            if (accumulate) out += ladj_ps[col];
+            ladj_ps[col] = out;
+          }
+          acc += (double)l;
+        }
+      }
+    }
   } else {
     for (int uc = 0; uc < COL_UC; ++uc) {
       const int64_t col = col0 + (int64_t)uc * cols_per_block;
@@ -260,6 +303,58 @@ __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* 
           ladj_ps[col] = out;
         }
         acc += (double)l;
+      }
+    }
+  } else if (nun <= 2 * (int64_t)G) {
+    // up to two units per lane: TWO columns in flight (one column alone is a single round trip of 1-2 KiB per wave: 333 rows ran at
+    // 24-38 % of the HBM peak, two thirds of what 500 rows get from the loop below)
+    for (int uc = 0; uc < COL_UC; uc += 2) {
+      Pack<T, V> p[2][2];
+      typename col_aux_of<F>::type aux[2][2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int64_t col = col0 + (int64_t)(uc + c) * cols_per_block;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int64_t v = (int64_t)r * G + gl;
+          const int64_t prow = v == nvc ? dim - V : v * V;
+          if (F::kLoadInput && col < batch && v < nun) p[c][r] = load_pack<T, V, true>(x + col * ldx + prow);
+          if constexpr (col_has_aux<F>::value) { if (col < batch && v < nun) aux[c][r] = f.template fetch<V>(fsm, prow, col); }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int64_t col = col0 + (int64_t)(uc + c) * cols_per_block;
+        T l = T(0);
+        if (col < batch) {
+          const T* xc = x + col * ldx;
+          T* yc = y + col * ldy;
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int64_t v = (int64_t)r * G + gl;
+            if (v < nun) {
+              const bool is_tail = v == nvc;
+              const int64_t prow = is_tail ? dim - V : v * V;
+              const uint32_t mask = is_tail ? tmask : full;
+              if constexpr (col_has_aux<F>::value) l += f.template apply_masked<V>(fsm, p[c][r], aux[c][r], xc, prow, col, mask);
+              else l += f.template apply_masked<V>(fsm, p[c][r], xc, prow, col, mask);
+              if (!is_tail) store_pack<T, V, true>(yc + prow, p[c][r]);
+              else {
+#pragma unroll
+                for (int j = 0; j < V; ++j) if ((mask >> j) & 1u) yc[prow + j] = p[c][r].v[j];
+              }
+            }
+          }
+        }
+        l = group_sum_rt(l, G);
+        if (col < batch && gl == 0) {
+          if (ladj_ps) {
+            T out = l + (T)psc;
+            if (accumulate) out += ladj_ps[col];
+            ladj_ps[col] = out;
+          }
+          acc += (double)l;
+        }
       }
     }
   } else {
@@ -402,11 +497,11 @@ template <class T> inline ColLaunch col_launch_cfg(const bjx_ctx* ctx, const voi
   c.unal = 0;
   int64_t packs = dim / c.V;
   // Columns that are not whole aligned packs and too tall for the tile walker to keep its occupancy (same-box A/B at 101 / 201
-  // rows, % of the HBM peak: BatchNorm 32 / 15 -> 44 / 45, Stacked 36 / 20 -> 43 / 41, Coupling 36 / 21 -> 29 / 31; at 63 rows the
-  // walker still wins, 54 / 49 against 31 / 31): 16-byte packs on element-aligned addresses, the dim % V tail rows on one lane each.
+  // rows, % of the HBM peak: BatchNorm 32 / 15 -> 44 / 45, Stacked 36 / 20 -> 43 / 41, Coupling 36 / 21 -> 29 / 31; at 49 / 63 rows the
+  // walker still wins, 58 / 54 and 54 / 49 against 56 / 46 and 40 / 42; at 77 rows it is 43 / 46 against 50 / 50): 16-byte packs on element-aligned addresses, the dim % V tail rows on one lane each.
   // Callers that build V-permuted tables must ask with the same flag.
   static const int use_unal = getenv("BJX_COL_UNALIGNED") ? atoi(getenv("BJX_COL_UNALIGNED")) : 1;
-  static const int unal_min = getenv("BJX_COL_UNALIGNED_MIN") ? atoi(getenv("BJX_COL_UNALIGNED_MIN")) : 96;
+  static const int unal_min = getenv("BJX_COL_UNALIGNED_MIN") ? atoi(getenv("BJX_COL_UNALIGNED_MIN")) : 80;
   if (allow_unal && use_unal && !v_ok && dim >= unal_min && dim >= VW) {
     c.V = VW;
     c.unal = 1;
