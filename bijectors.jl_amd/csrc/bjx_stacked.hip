@@ -436,12 +436,15 @@ int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, 
     const int rc_w = stacked_mixed_impl<T>(ctx, segs, n_segs, nullptr, 0, x, dim, y, dim, ladj_ps, ladj_sum, batch, flags);
     if (rc_w != BJX_ERR_UNSUPPORTED) return rc_w;                  // permuted ranges / taller than the tile: below
   }
-  // Tall columns: ROW SLABS.  The slot table is 2 x 48 bytes a row (Float32): past ~250 rows a block of the group kernel stages more
-  // table than it moves data (500 rows: 48 KiB of table for 64 KiB of columns, three blocks a CU: 24 % of the HBM peak) and past 512
-  // rows the table no longer fits the LDS at all (1000 rows: every element reads its slots from L2, 22 %).  A slab is a window of
-  // `slab` rows of the same arrays (column pitch = dim) with the segments clipped to it — one launch pair per slab, the log-dets of
-  // the slabs accumulated in launch order (BJX_ACCUMULATE from the second slab on: deterministic), as for the spline tables.
-  static const int slab = getenv("BJX_STACKED_SLAB") ? atoi(getenv("BJX_STACKED_SLAB")) : 256;
+  // Tall columns: ROW SLABS of 64 packs (256 rows Float32, 128 Float64).  Up to 64 packs a column is one pack per lane, and the
+  // group kernel then keeps four columns in flight per lane and evaluates a row's slots once for the four (apply_multi); past that it
+  // walks a column pack by pack through the one-element form (300 rows: 24 % of the HBM peak against 62 % at 252), its blocks stage
+  // more table than they move data (2 x 48 bytes a row) and past 512 rows the table no longer fits the LDS at all (1000 rows: every
+  // element reads its slots from L2, 22 %).  A slab is a window of rows of the same arrays (column pitch = dim) with the segments —
+  // and their per-row parameters — clipped to it: one launch pair per slab, the log-dets of the slabs accumulated in launch order
+  // (BJX_ACCUMULATE from the second slab on: deterministic), as for the spline tables.  BJX_STACKED_SLAB = rows per slab (0: off).
+  static const int slab_env = getenv("BJX_STACKED_SLAB") ? atoi(getenv("BJX_STACKED_SLAB")) : -1;
+  const int slab = slab_env >= 0 ? slab_env : 64 * Vec16<T>::N;
   if (slab >= 16 && ldx == 0 && ldy == 0 && dim > slab && n_segs > 0) {
     bool keep = true;
     int64_t total = 0;
@@ -454,7 +457,7 @@ int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, 
     if (keep && total == dim) {                        // (anything else: the one-launch path below reports it)
       std::vector<bjx_segment> clip;
       for (int64_t r0 = 0, rs = 0; r0 < dim; r0 += rs) {
-        rs = dim - r0 <= slab + slab / 2 ? dim - r0 : slab;      // (no sliver at the end: the last slab takes up to half a slab more)
+        rs = dim - r0 < slab ? dim - r0 : slab;
         clip.clear();
         for (int s = 0; s < n_segs; ++s) {
           const bjx_segment& g = segs[s];

@@ -502,7 +502,8 @@ template <class T> inline ColLaunch col_launch_cfg(const bjx_ctx* ctx, const voi
   // Callers that build V-permuted tables must ask with the same flag.
   static const int use_unal = getenv("BJX_COL_UNALIGNED") ? atoi(getenv("BJX_COL_UNALIGNED")) : 1;
   static const int unal_min = getenv("BJX_COL_UNALIGNED_MIN") ? atoi(getenv("BJX_COL_UNALIGNED_MIN")) : 80;
-  if (allow_unal && use_unal && !v_ok && dim >= unal_min && dim >= VW) {
+  const bool window = ldx > dim && ldy > dim;             // a row window of taller arrays (slabs): no tile walker to fall back on
+  if (allow_unal && use_unal && !v_ok && dim >= (window ? 2 * VW : unal_min) && dim >= VW) {
     c.V = VW;
     c.unal = 1;
     packs = dim / VW + dim % VW;                       // lanes a column needs at one pack (or one tail row) per lane
