@@ -40,7 +40,8 @@ constexpr int COL_UC = 4;   // columns in flight per lane group (one 16-byte pac
 
 template <class T, int V, bool NT, class F, bool TAIL = false>
 __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T* y, T* ladj_ps, int64_t dim,
-                                                       int64_t batch, int G, int accumulate, const BjxFin fin, int64_t ldx, int64_t ldy) {
+                                                       int64_t batch, int G, int accumulate, const BjxFin fin, int64_t ldx, int64_t ldy, int64_t row0) {
+  // row0: first row of a row window (x and y already point at it; the functor and its gathers see the rows of the whole column)
   // ldx / ldy: leading dimensions of x / y (== dim for a dense [dim, batch] array; larger when the `dim` rows are a
   // window of a taller matrix — Stacked segments, stacked.jl:142-166)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -71,11 +72,11 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
     for (int u = 0; u < COL_UC; ++u) {
       const int64_t col = col0 + (int64_t)u * cols_per_block;
       if (F::kLoadInput && lane_ok && col < batch) p[u] = load_pack<T, V, NT>(x + col * ldx + (int64_t)gl * V);
-      if constexpr (col_has_aux<F>::value) { if (lane_ok && col < batch) aux[u] = f.template fetch<V>(fsm, (int64_t)gl * V, col); }
+      if constexpr (col_has_aux<F>::value) { if (lane_ok && col < batch) aux[u] = f.template fetch<V>(fsm, row0 + (int64_t)gl * V, col); }
       if constexpr (V > 1 && TAIL) {
         if (tail_ok && col < batch) {
           if (F::kLoadInput) p[u].v[0] = x[col * ldx + trow];
-          if constexpr (col_has_aux<F>::value) aux[u] = f.template fetch<1>(fsm, trow, col);
+          if constexpr (col_has_aux<F>::value) aux[u] = f.template fetch<1>(fsm, row0 + trow, col);
         }
       }
     }
@@ -86,15 +87,15 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
 #pragma unroll
         for (int u = 0; u < COL_UC; ++u) q[u].v[0] = (col0 + (int64_t)u * cols_per_block < batch) ? p[u].v[0] : p[0].v[0];
         if constexpr (col_has_multi<F>::value) {
-          if (col0 < batch) f.template apply_multi<1, COL_UC>(fsm, q, trow, lm);
+          if (col0 < batch) f.template apply_multi<1, COL_UC>(fsm, q, row0 + trow, lm);
         } else {
 #pragma unroll
           for (int u = 0; u < COL_UC; ++u) {
             const int64_t col = col0 + (int64_t)u * cols_per_block;
             lm[u] = T(0);
             if (col < batch) {
-              if constexpr (col_has_aux<F>::value) lm[u] = f.template apply<1>(fsm, q[u], aux[u], x + col * ldx, trow, col);
-              else lm[u] = f.template apply<1>(fsm, q[u], x + col * ldx, trow, col);
+              if constexpr (col_has_aux<F>::value) lm[u] = f.template apply<1>(fsm, q[u], aux[u], x + col * ldx - row0, row0 + trow, col);
+              else lm[u] = f.template apply<1>(fsm, q[u], x + col * ldx - row0, row0 + trow, col);
             }
           }
         }
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
           for (int u = 0; u < COL_UC; ++u)
             if (col0 + (int64_t)u * cols_per_block >= batch) { p[u] = p[0]; }
         }
-        if (col0 < batch) f.template apply_multi<V, COL_UC>(fsm, p, (int64_t)gl * V, lm);
+        if (col0 < batch) f.template apply_multi<V, COL_UC>(fsm, p, row0 + (int64_t)gl * V, lm);
       }
     }
 #pragma unroll
@@ -119,8 +120,8 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
       T l = T(0);
       if (lane_ok && col < batch) {
         if constexpr (col_has_multi<F>::value) l = lm[u];
-        else if constexpr (col_has_aux<F>::value) l = f.template apply<V>(fsm, p[u], aux[u], x + col * ldx, (int64_t)gl * V, col);
-        else l = f.template apply<V>(fsm, p[u], x + col * ldx, (int64_t)gl * V, col);
+        else if constexpr (col_has_aux<F>::value) l = f.template apply<V>(fsm, p[u], aux[u], x + col * ldx - row0, row0 + (int64_t)gl * V, col);
+        else l = f.template apply<V>(fsm, p[u], x + col * ldx - row0, row0 + (int64_t)gl * V, col);
         store_pack<T, V, NT>(y + col * ldy + (int64_t)gl * V, p[u]);
       }
       if constexpr (V > 1 && TAIL) {
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
         for (int r = 0; r < 2; ++r) {
           const int64_t v = (int64_t)r * G + gl;
           if (F::kLoadInput && col < batch && v < nvc) p[c][r] = load_pack<T, V, NT>(x + col * ldx + v * V);
-          if constexpr (col_has_aux<F>::value) { if (col < batch && v < nvc) aux[c][r] = f.template fetch<V>(fsm, v * V, col); }
+          if constexpr (col_has_aux<F>::value) { if (col < batch && v < nvc) aux[c][r] = f.template fetch<V>(fsm, row0 + v * V, col); }
         }
       }
 #pragma unroll
@@ -162,8 +163,8 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
           for (int r = 0; r < 2; ++r) {
             const int64_t v = (int64_t)r * G + gl;
             if (v < nvc) {
-              if constexpr (col_has_aux<F>::value) l += f.template apply<V>(fsm, p[c][r], aux[c][r], xc, v * V, col);
-              else l += f.template apply<V>(fsm, p[c][r], xc, v * V, col);
+              if constexpr (col_has_aux<F>::value) l += f.template apply<V>(fsm, p[c][r], aux[c][r], xc - row0, row0 + v * V, col);
+              else l += f.template apply<V>(fsm, p[c][r], xc - row0, row0 + v * V, col);
               store_pack<T, V, NT>(yc + v * V, p[c][r]);
             }
           }
@@ -193,14 +194,14 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
           for (int u = 0; u < STREAM_U; ++u) {
             int64_t v = v0 + (int64_t)u * G + gl;
             if (F::kLoadInput && v < nvc) p[u] = load_pack<T, V, NT>(xc + v * V);
-            if constexpr (col_has_aux<F>::value) { if (v < nvc) aux[u] = f.template fetch<V>(fsm, v * V, col); }
+            if constexpr (col_has_aux<F>::value) { if (v < nvc) aux[u] = f.template fetch<V>(fsm, row0 + v * V, col); }
           }
 #pragma unroll
           for (int u = 0; u < STREAM_U; ++u) {
             int64_t v = v0 + (int64_t)u * G + gl;
             if (v < nvc) {
-              if constexpr (col_has_aux<F>::value) l += f.template apply<V>(fsm, p[u], aux[u], xc, v * V, col);
-              else l += f.template apply<V>(fsm, p[u], xc, v * V, col);
+              if constexpr (col_has_aux<F>::value) l += f.template apply<V>(fsm, p[u], aux[u], xc - row0, row0 + v * V, col);
+              else l += f.template apply<V>(fsm, p[u], xc - row0, row0 + v * V, col);
               store_pack<T, V, NT>(yc + v * V, p[u]);
             }
           }
@@ -211,8 +212,8 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
             const int64_t trow = nvc * V + tl;
             Pack<T, 1> q;
             if (F::kLoadInput) q.v[0] = xc[trow];
-            if constexpr (col_has_aux<F>::value) { const typename col_aux_of<F>::type a1 = f.template fetch<1>(fsm, trow, col); l += f.template apply<1>(fsm, q, a1, xc, trow, col); }
-            else l += f.template apply<1>(fsm, q, xc, trow, col);
+            if constexpr (col_has_aux<F>::value) { const typename col_aux_of<F>::type a1 = f.template fetch<1>(fsm, row0 + trow, col); l += f.template apply<1>(fsm, q, a1, xc - row0, row0 + trow, col); }
+            else l += f.template apply<1>(fsm, q, xc - row0, row0 + trow, col);
             yc[trow] = q.v[0];
           }
         }
@@ -240,7 +241,8 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
 // at 252).  In place: the overlap may already hold outputs when the tail unit runs in a later trip; those values are never used.
 template <class T, int V, class F>
 __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* x, T* y, T* ladj_ps, int64_t dim,
-                                                            int64_t batch, int G, int accumulate, const BjxFin fin, int64_t ldx, int64_t ldy) {
+                                                            int64_t batch, int G, int accumulate, const BjxFin fin, int64_t ldx, int64_t ldy, int64_t row0) {
+  // row0: first row of a row window (x and y already point at it; the functor and its gathers see the rows of the whole column)
   static_assert(V > 1, "whole packs only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* red = reinterpret_cast<double*>(smem);
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* 
     for (int u = 0; u < COL_UC; ++u) {
       const int64_t col = col0 + (int64_t)u * cols_per_block;
       if (F::kLoadInput && lane_ok && col < batch) p[u] = load_pack<T, V, true>(x + col * ldx + prow);
-      if constexpr (col_has_aux<F>::value) { if (lane_ok && col < batch) aux[u] = f.template fetch<V>(fsm, prow, col); }
+      if constexpr (col_has_aux<F>::value) { if (lane_ok && col < batch) aux[u] = f.template fetch<V>(fsm, row0 + prow, col); }
     }
     T lm[COL_UC];
     if constexpr (col_has_multi<F>::value) {
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* 
           for (int u = 0; u < COL_UC; ++u)
             if (col0 + (int64_t)u * cols_per_block >= batch) { p[u] = p[0]; }
         }
-        if (col0 < batch) f.template apply_multi_masked<V, COL_UC>(fsm, p, prow, lm, mask);
+        if (col0 < batch) f.template apply_multi_masked<V, COL_UC>(fsm, p, row0 + prow, lm, mask);
       }
     }
 #pragma unroll
@@ -286,8 +288,8 @@ __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* 
       T l = T(0);
       if (lane_ok && col < batch) {
         if constexpr (col_has_multi<F>::value) l = lm[u];
-        else if constexpr (col_has_aux<F>::value) l = f.template apply_masked<V>(fsm, p[u], aux[u], x + col * ldx, prow, col, mask);
-        else l = f.template apply_masked<V>(fsm, p[u], x + col * ldx, prow, col, mask);
+        else if constexpr (col_has_aux<F>::value) l = f.template apply_masked<V>(fsm, p[u], aux[u], x + col * ldx - row0, row0 + prow, col, mask);
+        else l = f.template apply_masked<V>(fsm, p[u], x + col * ldx - row0, row0 + prow, col, mask);
         T* yp = y + col * ldy + prow;
         if (!is_tail) store_pack<T, V, true>(yp, p[u]);
         else {
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* 
           const int64_t v = (int64_t)r * G + gl;
           const int64_t prow = v == nvc ? dim - V : v * V;
           if (F::kLoadInput && col < batch && v < nun) p[c][r] = load_pack<T, V, true>(x + col * ldx + prow);
-          if constexpr (col_has_aux<F>::value) { if (col < batch && v < nun) aux[c][r] = f.template fetch<V>(fsm, prow, col); }
+          if constexpr (col_has_aux<F>::value) { if (col < batch && v < nun) aux[c][r] = f.template fetch<V>(fsm, row0 + prow, col); }
         }
       }
 #pragma unroll
@@ -336,8 +338,8 @@ __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* 
               const bool is_tail = v == nvc;
               const int64_t prow = is_tail ? dim - V : v * V;
               const uint32_t mask = is_tail ? tmask : full;
-              if constexpr (col_has_aux<F>::value) l += f.template apply_masked<V>(fsm, p[c][r], aux[c][r], xc, prow, col, mask);
-              else l += f.template apply_masked<V>(fsm, p[c][r], xc, prow, col, mask);
+              if constexpr (col_has_aux<F>::value) l += f.template apply_masked<V>(fsm, p[c][r], aux[c][r], xc - row0, row0 + prow, col, mask);
+              else l += f.template apply_masked<V>(fsm, p[c][r], xc - row0, row0 + prow, col, mask);
               if (!is_tail) store_pack<T, V, true>(yc + prow, p[c][r]);
               else {
 #pragma unroll
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* 
             const int64_t v = v0 + (int64_t)u * G + gl;
             const int64_t prow = v == nvc ? dim - V : v * V;
             if (F::kLoadInput && v < nun) p[u] = load_pack<T, V, true>(xc + prow);
-            if constexpr (col_has_aux<F>::value) { if (v < nun) aux[u] = f.template fetch<V>(fsm, prow, col); }
+            if constexpr (col_has_aux<F>::value) { if (v < nun) aux[u] = f.template fetch<V>(fsm, row0 + prow, col); }
           }
 #pragma unroll
           for (int u = 0; u < STREAM_U; ++u) {
@@ -381,8 +383,8 @@ __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* 
               const bool is_tail = v == nvc;
               const int64_t prow = is_tail ? dim - V : v * V;
               const uint32_t mask = is_tail ? tmask : full;
-              if constexpr (col_has_aux<F>::value) l += f.template apply_masked<V>(fsm, p[u], aux[u], xc, prow, col, mask);
-              else l += f.template apply_masked<V>(fsm, p[u], xc, prow, col, mask);
+              if constexpr (col_has_aux<F>::value) l += f.template apply_masked<V>(fsm, p[u], aux[u], xc - row0, row0 + prow, col, mask);
+              else l += f.template apply_masked<V>(fsm, p[u], xc - row0, row0 + prow, col, mask);
               if (!is_tail) store_pack<T, V, true>(yc + prow, p[u]);
               else {
 #pragma unroll
@@ -519,13 +521,42 @@ template <class T> inline ColLaunch col_launch_cfg(const bjx_ctx* ctx, const voi
 
 template <class T, class F>
 inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, T* y, T* ladj_ps, double* ladj_sum,
-                           int64_t dim, int64_t batch, uint32_t flags, double sum_const, int64_t ldx = 0, int64_t ldy = 0, int force_v1 = 0) {
+                           int64_t dim, int64_t batch, uint32_t flags, double sum_const, int64_t ldx = 0, int64_t ldy = 0, int force_v1 = 0,
+                           int64_t row0 = 0) {
+  // row0 > 0: `dim` rows starting at row row0 of columns that are ldx / ldy apart (x and y point at row 0; see the slabs below)
+  const bool dense = ldx == 0 && ldy == 0;
   if (ldx == 0) ldx = dim;
   if (ldy == 0) ldy = dim;
   if (dim * batch == 0) {
     if (ladj_sum && !(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
     return BJX_OK;
   }
+  {
+    // Columns of more than 64 packs: ROW SLABS of 64 packs.  One pack per lane is the form that keeps four columns in flight per lane
+    // and shares a row's parameters between them (apply_multi); beyond it a lane walks its column's packs one latency round trip at
+    // a time (BatchNorm 39 % of the HBM peak at 257 rows, 46 % at 333; `Stacked`, which slices its table as well, went 24 -> 51 % at
+    // 300 rows with the same step).  A slab is a launch on a row window of the same arrays; the functor keeps seeing the rows of the
+    // whole column (row0), the log-dets of the slabs accumulate in launch order (deterministic).
+    static const int use_slab = getenv("BJX_COL_SLAB") ? atoi(getenv("BJX_COL_SLAB")) : 1;
+    constexpr int VWs = Vec16<T>::N;
+    const int64_t slab = (int64_t)64 * VWs;
+    // (up to 128 packs only: every block stages the functor's whole table, which the slabs of a taller column would repeat four times
+    //  and more per byte moved, and from two packs per lane on the column loop runs at 57-63 % anyway)
+    if (use_slab && dense && row0 == 0 && !force_v1 && dim > slab && dim <= 2 * slab && col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy, true).V == VWs) {
+      for (int64_t r0 = 0; r0 < dim; r0 += slab) {
+        const int64_t rs = dim - r0 < slab ? dim - r0 : slab;
+        F fw = f;
+        if (r0 > 0) { fw.per_sample_const = 0.0; fw.per_sample_dev = nullptr; }
+        const uint32_t fl = r0 == 0 ? flags : (flags | BJX_ACCUMULATE);
+        const int rc = launch_colgroup<T, F>(ctx, fw, f_smem, x, y, ladj_ps, ladj_sum, rs, batch, fl, r0 == 0 ? sum_const : 0.0, dim, dim, 0, r0 == 0 ? -1 : r0);
+        if (rc) return rc;
+      }
+      return BJX_OK;
+    }
+    if (row0 < 0) row0 = 0;                              // (-1: the first slab — row 0, but a window all the same)
+  }
+  x += row0;
+  y += row0;
   ColLaunch c = col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy, !force_v1);
   {
     // odd column heights of dense arrays: the column-walker form (colwalk_kernel)
@@ -591,13 +622,13 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
   BjxProf prof_(ctx);
   if (c.V == VW && c.unal && dim % VW != 0) {
     if constexpr (col_has_masked<F>::value && Vec16<T>::N > 1)
-      hipLaunchKernelGGL((colgroup_tail_kernel<T, VW, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy);
+      hipLaunchKernelGGL((colgroup_tail_kernel<T, VW, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy, row0);
     else
-      hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F, true>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy);
+      hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F, true>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy, row0);
   } else if (c.V == VW)
-    hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy);
+    hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy, row0);
   else
-    hipLaunchKernelGGL((colgroup_kernel<T, 1, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy);
+    hipLaunchKernelGGL((colgroup_kernel<T, 1, true, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy, row0);
   }
   BJX_CHECK_LAUNCH(ctx);
   if (second) return bjx_launch_finalize(ctx, (int)c.grid, ladj_sum, sum_const, f.per_sample_dev ? 1 : 0, 0.0, flags);

@@ -75,7 +75,7 @@ def main(path):
                 A = (r.normal(size=(dim, dim)) / np.sqrt(dim) + 1.5 * np.eye(dim)).astype(dt)
                 put(f"scale_matrix.{tg}", bj.with_logabsdet_jacobian(bj.Scale(dev(A)), dev(x), per_sample=True), bj.with_logabsdet_jacobian(bj.inverse(bj.Scale(dev(A))), dev(x), per_sample=True))
         # heights that are not whole 16-byte packs, past the tile walkers (element-aligned packs, row slabs, the 8 / 16-wave Planar tile)
-        for dim, N in ((101, 90), (601, 40)):
+        for dim, N in ((101, 90), (333, 50), (601, 40)):
             x = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
             nl = 3
             w, u, b = r.normal(size=(dim, nl)) / np.sqrt(dim), r.normal(size=(dim, nl)) / np.sqrt(dim), r.normal(size=nl)

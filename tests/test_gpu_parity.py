@@ -407,7 +407,8 @@ def test_radial(bj, orc, dim, N, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("dim,N", [(2, 20), (64, 300), (5, 3), (49, 77), (63, 100), (101, 300), (201, 65), (255, 33), (1001, 33)])
+@pytest.mark.parametrize("dim,N", [(2, 20), (64, 300), (5, 3), (49, 77), (63, 100), (101, 300), (201, 65), (255, 33), (1001, 33),
+                                   (257, 70), (300, 131), (333, 40), (512, 9)])      # 65 ... 128 packs: two row slabs of the same launch pair
 def test_batchnorm_eval(bj, orc, dim, N, dt):
     r = rng(10)
     b_, logs, m, v = r.normal(size=dim).astype(dt), (0.3 * r.normal(size=dim)).astype(dt), r.normal(size=dim).astype(dt), r.uniform(0.5, 2, size=dim).astype(dt)
@@ -494,7 +495,7 @@ def test_permute_exact(bj, orc):
         bj.Permute(2, ([1, 2, 3], [2, 1]))
     r = rng(13)
     for dt in (np.float32, np.float64):
-        for dim, N in ((64, 1000), (7, 33), (257, 5), (101, 50), (255, 20)):
+        for dim, N in ((64, 1000), (7, 33), (257, 5), (101, 50), (255, 20), (300, 33), (333, 9), (5000, 3)):
             perm = r.permutation(dim)
             X = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
             b = bj.Permute((perm + 1).tolist())             # y[perm[i]] = x[i]
@@ -525,7 +526,8 @@ def test_coupling_reference_cases(bj):
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("dim,lo,n1,N", [(64, 1, 32, 1000), (64, 33, 32, 257), (64, 3, 10, 100), (24, 9, 8, 77), (200, 41, 80, 33), (7, 2, 3, 19),
-                                         (101, 7, 40, 77), (201, 50, 99, 65), (255, 1, 128, 20), (1001, 100, 500, 9)])
+                                         (101, 7, 40, 77), (201, 50, 99, 65), (255, 1, 128, 20), (1001, 100, 500, 9),
+                                         (333, 20, 150, 33), (300, 200, 100, 40), (512, 250, 12, 17)])
 def test_coupling_row_ranges(bj, orc, dim, lo, n1, N, dt):
     """PartitionMask over a row range lo:lo+n1-1 (1-based): θ packs are read as whole 16-byte loads when aligned."""
     r = rng(15)
