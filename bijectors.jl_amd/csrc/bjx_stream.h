@@ -540,9 +540,10 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
     static const int use_slab = getenv("BJX_COL_SLAB") ? atoi(getenv("BJX_COL_SLAB")) : 1;
     constexpr int VWs = Vec16<T>::N;
     const int64_t slab = (int64_t)64 * VWs;
-    // (up to 128 packs only: every block stages the functor's whole table, which the slabs of a taller column would repeat four times
-    //  and more per byte moved, and from two packs per lane on the column loop runs at 57-63 % anyway)
-    if (use_slab && dense && row0 == 0 && !force_v1 && dim > slab && dim <= 2 * slab && col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy, true).V == VWs) {
+    // (up to 96 packs only — same-box A/B, % of the HBM peak, slabs / column loop: BatchNorm 257 rows 53 / 39, 300 rows 53 / 52,
+    //  500 rows 57 / 61; Coupling 300 rows 47 / 35, 500 rows 49 / 50: every block stages the functor's whole table, and from two
+    //  packs per lane on the column loop has two columns in flight anyway)
+    if (use_slab && dense && row0 == 0 && !force_v1 && dim > slab && dim <= slab + slab / 2 && col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy, true).V == VWs) {
       for (int64_t r0 = 0; r0 < dim; r0 += slab) {
         const int64_t rs = dim - r0 < slab ? dim - r0 : slab;
         F fw = f;
