@@ -88,8 +88,7 @@ template <class T, int V> __device__ __forceinline__ Pack<T, V> load_pack_part(c
 }
 template <class T, int V> __device__ __forceinline__ void store_pack_part(T* p, const Pack<T, V>& r, int nrow) {
   if (nrow >= V) { store_pack<T, V, true>(p, r); return; }
-#pragma unroll
-  for (int j = 0; j < V; ++j) if (j < nrow) p[j] = r.v[j];
+  store_pack_run<T, V>(p, r, 0, nrow);
 }
 
 template <class T, int V, int R, bool INV>
@@ -549,11 +548,9 @@ __device__ __forceinline__ bjx_pk4 reg_load_pack(const float* px, int nrow) {
 }
 __device__ __forceinline__ void reg_store_pack(float* py, const bjx_pk4 v, int nrow) {
   if (nrow == 4) __builtin_nontemporal_store(v, reinterpret_cast<bjx_pk4u*>(py));
-  else {
-    py[0] = v.x;
-    if (nrow > 1) py[1] = v.y;
-    if (nrow > 2) py[2] = v.z;
-  }
+  else if (nrow == 3) { TinyCol<float, 3> t; t.v[0] = v.x; t.v[1] = v.y; t.v[2] = v.z; *reinterpret_cast<TinyCol<float, 3>*>(py) = t; }   // one dwordx3 / x2 store
+  else if (nrow == 2) { TinyCol<float, 2> t; t.v[0] = v.x; t.v[1] = v.y; *reinterpret_cast<TinyCol<float, 2>*>(py) = t; }
+  else py[0] = v.x;
 }
 
 // find_alpha for the register kernel: same safeguarded Newton on the reference's bracket

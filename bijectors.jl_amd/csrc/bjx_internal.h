@@ -731,6 +731,19 @@ template <class T, int V, bool NT> __device__ __forceinline__ void store_pack(T*
 // only element alignment), so a lane reads its column of 2 ... 13 rows in one to four instructions
 template <class T, int DIM> struct __attribute__((aligned(sizeof(T)))) TinyCol { T v[DIM]; };
 
+// elements [j0, j0 + n) of a pack to p[j0 ...] as ONE multi-dword store (n = 1 ... V-1; the tail rows of an odd column: n is the
+// same for every column, so each case is one instruction for the wave instead of n one-dword stores)
+template <class T, int V> __device__ __forceinline__ void store_pack_run(T* p, const Pack<T, V>& r, int j0, int n) {
+  if constexpr (V == 4) {
+    if (n == 3) { TinyCol<T, 3> t; if (j0 == 0) { t.v[0] = r.v[0]; t.v[1] = r.v[1]; t.v[2] = r.v[2]; } else { t.v[0] = r.v[1]; t.v[1] = r.v[2]; t.v[2] = r.v[3]; } *reinterpret_cast<TinyCol<T, 3>*>(p + j0) = t; }
+    else if (n == 2) { TinyCol<T, 2> t; t.v[0] = j0 == 0 ? r.v[0] : r.v[2]; t.v[1] = j0 == 0 ? r.v[1] : r.v[3]; *reinterpret_cast<TinyCol<T, 2>*>(p + j0) = t; }
+    else if (n == 1) p[j0] = j0 == 0 ? r.v[0] : r.v[3];
+  } else {
+#pragma unroll
+    for (int j = 0; j < V; ++j) if (j >= j0 && j < j0 + n) p[j] = r.v[j];
+  }
+}
+
 // Buffer-addressed packs (raw buffer, stride 0): address = base + voffset, and an access whose voffset + size exceeds
 // the descriptor's extent reads zeros / is dropped.  Streaming (nt) like the NT packs above.
 typedef unsigned int bjx_u32x4 __attribute__((ext_vector_type(4)));

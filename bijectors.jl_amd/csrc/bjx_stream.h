@@ -292,10 +292,7 @@ __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* 
         else l = f.template apply_masked<V>(fsm, p[u], x + col * ldx - row0, row0 + prow, col, mask);
         T* yp = y + col * ldy + prow;
         if (!is_tail) store_pack<T, V, true>(yp, p[u]);
-        else {
-#pragma unroll
-          for (int j = 0; j < V; ++j) if ((mask >> j) & 1u) yp[j] = p[u].v[j];
-        }
+        else store_pack_run<T, V>(yp, p[u], V - tail, tail);
       }
       l = group_sum_rt(l, G);
       if (col < batch && gl == 0) {
@@ -341,10 +338,7 @@ __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* 
               if constexpr (col_has_aux<F>::value) l += f.template apply_masked<V>(fsm, p[c][r], aux[c][r], xc - row0, row0 + prow, col, mask);
               else l += f.template apply_masked<V>(fsm, p[c][r], xc - row0, row0 + prow, col, mask);
               if (!is_tail) store_pack<T, V, true>(yc + prow, p[c][r]);
-              else {
-#pragma unroll
-                for (int j = 0; j < V; ++j) if ((mask >> j) & 1u) yc[prow + j] = p[c][r].v[j];
-              }
+              else store_pack_run<T, V>(yc + prow, p[c][r], V - tail, tail);
             }
           }
         }
@@ -386,10 +380,7 @@ __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* 
               if constexpr (col_has_aux<F>::value) l += f.template apply_masked<V>(fsm, p[u], aux[u], xc - row0, row0 + prow, col, mask);
               else l += f.template apply_masked<V>(fsm, p[u], xc - row0, row0 + prow, col, mask);
               if (!is_tail) store_pack<T, V, true>(yc + prow, p[u]);
-              else {
-#pragma unroll
-                for (int j = 0; j < V; ++j) if ((mask >> j) & 1u) yc[prow + j] = p[u].v[j];
-              }
+              else store_pack_run<T, V>(yc + prow, p[u], V - tail, tail);
             }
           }
         }
