@@ -902,11 +902,12 @@ int rqs_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int 
     if (rc || taken) return rc;
   }
   // Taller columns than one table takes (the record part of the blob grows with the lanes per column: 65 KiB at 200 rows x 9
-  // knots): ROW SLABS of 64 rows (16 lanes per column, a 20 KiB table), one launch pair per slab on a row window of the same
+  // knots): ROW SLABS of 128 rows (32 lanes per column; same-box A/B at 200 / 500 / 1000 rows, K = 8, % of the HBM peak: slabs of 64
+  // rows 34 / 34 / 40, 96 rows 39 / 39 / 45, 128 rows 45 / 44 / 49 — fewer launches, 512-byte runs), one launch pair per slab on a row window of the same
   // arrays (column stride = dim), the log-dets of the slabs accumulated in launch order (BJX_ACCUMULATE from the second slab on:
   // deterministic).  Round 2 sent these shapes to the generic functor kernel: 23 % of the HBM peak at dim = 200, 8 % at 1000.
   constexpr int VWs = Vec16<T>::N;
-  static const int slab_rows = getenv("BJX_RQS_SLAB") ? atoi(getenv("BJX_RQS_SLAB")) : 64;      // tuning switch: 0 = the generic path as in round 2
+  static const int slab_rows = getenv("BJX_RQS_SLAB") ? atoi(getenv("BJX_RQS_SLAB")) : 128;     // tuning switch: 0 = the generic path as in round 2
   // (heights that are not whole aligned packs take the same slabs on 4-byte accesses, 64 lanes per column: the generic functor path
   //  ran them at 8-18 % of the HBM peak, its knots read from L2)
   (void)VWs;

@@ -667,7 +667,9 @@ __device__ __forceinline__ void find_alpha_act64(double wy, double c, double b, 
 
 // COLS = columns per wave: 64 (every lane runs the recurrence) or 32 (half the register tile -> twice the waves per SIMD;
 // lanes 32..63 idle in the short recurrence)
-template <int G, int NL, bool INV, int COLS>
+// UNAL (template flag, like the tail rows of the group skeleton): the element-aligned / partial-pack accesses compiled into the
+// whole-pack instantiation cost C4 6 % in a same-box A/B (0.66 against 0.70-0.71 of the HBM peak) — they are separate kernels.
+template <int G, int NL, bool INV, int COLS, bool UNAL = false>
 __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, const float* __restrict__ x, float* __restrict__ y,
                                                          float* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate,
                                                          const BjxFin fin) {
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
   f4 z[NS];
   {
     const float* px = x + (col0 + cg) * dim + 4 * gl;
-    if (A.unal) {
+    if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
         if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, nrow);
@@ -724,8 +726,8 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
       for (int kp = 0; kp < NP; ++kp) {
         f4 a = f4{0.f, 0.f, 0.f, 0.f}, b = a;
         if (row_ok) {
-          a = *reinterpret_cast<const f4*>(A.w + (int64_t)(l0 + 2 * kp) * A.ldw + 4 * gl);
-          if (NL >= 2) b = *reinterpret_cast<const f4*>(A.w + (int64_t)(l0 + 2 * kp + 1) * A.ldw + 4 * gl);
+          a = *reinterpret_cast<const f4*>(A.w + (int64_t)(l0 + 2 * kp) * (UNAL ? A.ldw : dim) + 4 * gl);
+          if (NL >= 2) b = *reinterpret_cast<const f4*>(A.w + (int64_t)(l0 + 2 * kp + 1) * (UNAL ? A.ldw : dim) + 4 * gl);
         }
         wq[kp][0] = f2{a.x, b.x}; wq[kp][1] = f2{a.y, b.y}; wq[kp][2] = f2{a.z, b.z}; wq[kp][3] = f2{a.w, b.w};
       }
@@ -797,7 +799,7 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
       f4 uv[NL];
 #pragma unroll
       for (int k = 0; k < NL; ++k)
-        uv[k] = row_ok ? *reinterpret_cast<const f4*>(A.u_hat + (int64_t)(l0 + k) * A.ldw + 4 * gl) : f4{0.f, 0.f, 0.f, 0.f};
+        uv[k] = row_ok ? *reinterpret_cast<const f4*>(A.u_hat + (int64_t)(l0 + k) * (UNAL ? A.ldw : dim) + 4 * gl) : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
         const float* tc = st + (r * CPS + cg) * NL;
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
   }
   if (y) {
     float* py = y + (col0 + cg) * dim + 4 * gl;
-    if (A.unal) {
+    if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
         if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow);
@@ -1247,7 +1249,7 @@ __device__ __forceinline__ void reg_update(const float* __restrict__ tab, int l0
 // NW = 8 / 16 (round 3): 512- / 1024-thread blocks, one tile of 64 columns per block, for 256 < dim <= 512 / 1024 — stacks of layers
 // at those heights ran on the group kernel, where every layer costs a 64-lane reduction and a tanh / log1p on all 64 lanes of a
 // column (8 layers: 18 % of the HBM peak at 500 rows, 28 % at 1000).
-template <int NL, bool INV, int NW = 2>
+template <int NL, bool INV, int NW = 2, bool UNAL = false>
 __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 1, 8))) void planar_reg2_kernel(const PlanarRegArgs A, const float* __restrict__ x, float* __restrict__ y,
                                                           float* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate, const BjxFin fin) {
   constexpr int NWB = NW <= 4 ? 4 : NW;                      // waves per block
@@ -1271,7 +1273,7 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
   bjx_f4 z[NS];
   {
     const float* px = x + (col0 + cg) * dim + row0 + 4 * gl;
-    if (A.unal) {
+    if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
         if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, nrow);
@@ -1293,7 +1295,7 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
   for (int gi = 0; gi < ngroups; ++gi) {
     const int l0 = (INV ? ngroups - 1 - gi : gi) * NL;
     float* mineS = sS[gi & 1][wave];
-    reg_dots<G, NL, NS>(A.w, l0, A.ldw, z, mineS, lane, gl, cg, row_ok, row0);
+    reg_dots<G, NL, NS>(A.w, l0, (UNAL ? A.ldw : dim), z, mineS, lane, gl, cg, row_ok, row0);
     __syncthreads();                                         // every slice of every tile has published its partial sums
     {
       // (COLS = 32: lanes 32..63 run the recurrence of column lane - 32 along — same values, same stores; a divergent region
@@ -1331,7 +1333,7 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
       for (int k = 0; k < NL; ++k) stT[lc * NL + k] = t[k];
     }
     __builtin_amdgcn_wave_barrier();
-    reg_update<G, NL, NS>(A.u_hat, l0, A.ldw, z, stT, gl, cg, row_ok, row0);
+    reg_update<G, NL, NS>(A.u_hat, l0, (UNAL ? A.ldw : dim), z, stT, gl, cg, row_ok, row0);
     __builtin_amdgcn_wave_barrier();
   }
   if (accumulate & 2) {
@@ -1352,7 +1354,7 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
   }
   if (y) {
     float* py = y + (col0 + cg) * dim + row0 + 4 * gl;
-    if (A.unal) {
+    if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
         if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow);
@@ -1374,7 +1376,7 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
 #ifndef BJX_VJP_REG_WAVES
 #define BJX_VJP_REG_WAVES 2
 #endif
-template <int G, int NL, bool INV>
+template <int G, int NL, bool INV, bool UNAL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG_WAVES, 8))) void planar_vjp_reg_kernel(const PlanarRegArgs A, const float* __restrict__ x, const float* __restrict__ ybar,
                                                              const float* __restrict__ lbar, float* __restrict__ xbar, int dim, int64_t batch,
                                                              float* __restrict__ t_out, float* __restrict__ s_out, int nl) {
@@ -1396,7 +1398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
   bjx_f4 z[NS];
   auto load_tile = [&](const float* base) {
     const float* px = base + (col0 + cg) * dim + 4 * gl;
-    if (A.unal) {
+    if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
         if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, nrow);
@@ -1417,7 +1419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
   load_tile(x);
   for (int gi = 0; gi < ngroups; ++gi) {
     const int l0 = (INV ? ngroups - 1 - gi : gi) * NL;         // the inverse undoes the LAST group first
-    reg_dots<G, NL, NS>(A.w, l0, A.ldw, z, st, lane, gl, cg, row_ok);
+    reg_dots<G, NL, NS>(A.w, l0, (UNAL ? A.ldw : dim), z, st, lane, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
     {
       float s[NL], t[NL];
@@ -1441,7 +1443,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
       for (int k = 0; k < NL; ++k) { st[lane * NL + k] = t[k]; tsave[lane * A.nl_pad + l0 + k] = INV ? -t[k] : t[k]; }
     }
     __builtin_amdgcn_wave_barrier();
-    if (gi + 1 < ngroups) reg_update<G, NL, NS>(A.u_hat, l0, A.ldw, z, st, gl, cg, row_ok);
+    if (gi + 1 < ngroups) reg_update<G, NL, NS>(A.u_hat, l0, (UNAL ? A.ldw : dim), z, st, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
   }
   // ---- cotangent sweep, in the opposite order of the primal
@@ -1449,7 +1451,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
   const float lb = (lbar && lane < nvalid) ? lbar[col0 + lane] : 0.f;
   for (int gi = 0; gi < ngroups; ++gi) {
     const int l0 = (INV ? gi : ngroups - 1 - gi) * NL;
-    reg_dots<G, NL, NS>(A.u_hat, l0, A.ldw, z, st, lane, gl, cg, row_ok);
+    reg_dots<G, NL, NS>(A.u_hat, l0, (UNAL ? A.ldw : dim), z, st, lane, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
     {
       float g[NL], sb[NL];
@@ -1479,12 +1481,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
       }
     }
     __builtin_amdgcn_wave_barrier();
-    reg_update<G, NL, NS>(A.w, l0, A.ldw, z, st, gl, cg, row_ok);
+    reg_update<G, NL, NS>(A.w, l0, (UNAL ? A.ldw : dim), z, st, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
   }
   {
     float* py = xbar + (col0 + cg) * dim + 4 * gl;
-    if (A.unal) {
+    if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
         if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow);
@@ -2230,7 +2232,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
     // 256 < dim <= 1024, two layers or more: the tile split over 8 / 16 waves of one block (planar_reg2_kernel, NW = 8 / 16)
     static const int use_big = getenv("BJX_PLANAR_REG_BIG") ? atoi(getenv("BJX_PLANAR_REG_BIG")) : 1;
     const bool big = use_big && dim > 256 && dim <= 1024 && nl >= 2;
-    if (use_reg && (packs_ok || use_unal) && dim > 16 && (dim <= 256 || big)) {
+    if (use_reg && (packs_ok || (use_unal && dim > 32)) && dim > 16 && (dim <= 256 || big)) {
       const int NL = (nl >= 8 && !big) ? 8 : (nl > 2 ? 4 : nl);           // 8 / 16 waves a block: groups of four layers (118 VGPRs: two 512-thread blocks a CU)
       const int nl_pad = (nl + NL - 1) / NL * NL;
       const int64_t ldw = (dim + 3) / 4 * 4;
@@ -2264,13 +2266,15 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
           if (finb.counter) { finb.counter = nullptr; secondb = true; }        // blocks of 8 / 16 waves: two-pass finalize
           PlanarRegArgs RB{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : 1};
           const int accumb = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
-#define LAUNCH_BIG(NL_, INV_, NW_) hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_, NW_>), dim3((unsigned)gridb), dim3(NW_ * 64), 0, ctx->stream, RB, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accumb, finb)
+#define LAUNCH_BIG_U(NL_, INV_, NW_, U_) hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_, NW_, U_>), dim3((unsigned)gridb), dim3(NW_ * 64), 0, ctx->stream, RB, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accumb, finb)
+#define LAUNCH_BIG(NL_, INV_, NW_) do { if (packs_ok) LAUNCH_BIG_U(NL_, INV_, NW_, false); else LAUNCH_BIG_U(NL_, INV_, NW_, true); } while (0)
 #define LAUNCH_BIG_I(NL_, NW_) do { if (inverse) LAUNCH_BIG(NL_, true, NW_); else LAUNCH_BIG(NL_, false, NW_); } while (0)
           { BjxProf prof_(ctx);
             if (dim <= 512) { if (NL == 4) LAUNCH_BIG_I(4, 8); else LAUNCH_BIG_I(2, 8); }
             else { if (NL == 4) LAUNCH_BIG_I(4, 16); else LAUNCH_BIG_I(2, 16); } }
 #undef LAUNCH_BIG_I
 #undef LAUNCH_BIG
+#undef LAUNCH_BIG_U
           BJX_CHECK_LAUNCH(ctx);
           if (secondb) return bjx_launch_finalize(ctx, (int)gridb, ladj_sum, 0.0, 0, 0.0, flags);
           return BJX_OK;
@@ -2283,11 +2287,13 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
         PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : 1};
         const int accum = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
-#define LAUNCH_REG(G_, NL_, INV_) if (G_ == 32 && cols == 32) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, (G_ == 32 ? 32 : 64)>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); else hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, 64>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
+#define LAUNCH_REG_U(G_, NL_, INV_, U_) if (G_ == 32 && cols == 32) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, (G_ == 32 ? 32 : 64), (G_ != 8) && U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); else hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, 64, (G_ != 8) && U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
+#define LAUNCH_REG(G_, NL_, INV_) do { if (packs_ok) { LAUNCH_REG_U(G_, NL_, INV_, false); } else { LAUNCH_REG_U(G_, NL_, INV_, true); } } while (0)
 #define LAUNCH_REG_NL(G_, INV_) switch (NL) { case 1: LAUNCH_REG(G_, 1, INV_); break; case 2: LAUNCH_REG(G_, 2, INV_); break; case 4: LAUNCH_REG(G_, 4, INV_); break; default: LAUNCH_REG(G_, 8, INV_); break; }
 #define LAUNCH_REG_G(INV_) switch (G) { case 8: LAUNCH_REG_NL(8, INV_) break; case 16: LAUNCH_REG_NL(16, INV_) break; default: LAUNCH_REG_NL(32, INV_) break; }
-#define LAUNCH_REG2(NL_, INV_) do { if (quad) hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_, 4>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); \
-        else hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_, 2>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); } while (0)
+#define LAUNCH_REG2_U(NL_, INV_, U_) do { if (quad) hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_, 4, U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); \
+        else hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_, 2, U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); } while (0)
+#define LAUNCH_REG2(NL_, INV_) do { if (packs_ok) LAUNCH_REG2_U(NL_, INV_, false); else LAUNCH_REG2_U(NL_, INV_, true); } while (0)
 #define LAUNCH_REG2_NL(INV_) switch (NL) { case 1: LAUNCH_REG2(1, INV_); break; case 2: LAUNCH_REG2(2, INV_); break; case 4: LAUNCH_REG2(4, INV_); break; default: LAUNCH_REG2(8, INV_); break; }
         // matrix-core kernel (forward, groups of 8 layers, dim a multiple of 16, no fused base density):
         // BJX_PLANAR_MFMA = 0 off | 1 direct loads, 64 columns per wave | 2 LDS-staged, 64 | 3 direct, 32 | 4 staged, 32 | 5 direct, 16 | 6 staged, 16
@@ -2316,9 +2322,11 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
           else if (inverse) { LAUNCH_REG_G(true) } else { LAUNCH_REG_G(false) } }
 #undef LAUNCH_REG2_NL
 #undef LAUNCH_REG2
+#undef LAUNCH_REG2_U
 #undef LAUNCH_REG_G
 #undef LAUNCH_REG_NL
 #undef LAUNCH_REG
+#undef LAUNCH_REG_U
         BJX_CHECK_LAUNCH(ctx);
         if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
         return BJX_OK;
@@ -2425,7 +2433,7 @@ inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float
   static const int use_reg = getenv("BJX_PLANAR_REG") ? atoi(getenv("BJX_PLANAR_REG")) : 1;
   static const int use_unal = getenv("BJX_PLANAR_REG_UNALIGNED") ? atoi(getenv("BJX_PLANAR_REG_UNALIGNED")) : 1;
   const bool packs_ok = dim % 4 == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
-  if (!(use_reg && (packs_ok || use_unal) && dim > 16 && dim <= 128)) return 1;
+  if (!(use_reg && (packs_ok || (use_unal && dim > 32)) && dim > 16 && dim <= 128)) return 1;
   const int NL = nl >= 8 ? 8 : (nl > 2 ? 4 : nl);
   const int nl_pad = (nl + NL - 1) / NL * NL;
   const int64_t ldw = (dim + 3) / 4 * 4;
@@ -2445,8 +2453,9 @@ inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float
   const int64_t grid = (batch + 4 * 64 - 1) / (4 * 64);
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: batch too large for one launch");
   PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : 1};
-#define LV(G_, NL_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, true>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); \
-                          else hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, false>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); } while (0)
+#define LVU(G_, NL_, U_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, true, (G_ != 8) && U_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); \
+                          else hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, false, (G_ != 8) && U_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); } while (0)
+#define LV(G_, NL_) do { if (packs_ok) LVU(G_, NL_, false); else LVU(G_, NL_, true); } while (0)
 #define LV_NL(G_) switch (NL) { case 1: LV(G_, 1); break; case 2: LV(G_, 2); break; case 4: LV(G_, 4); break; default: LV(G_, 8); break; }
   {
     BjxProf prof_(ctx);
@@ -2454,6 +2463,7 @@ inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float
   }
 #undef LV_NL
 #undef LV
+#undef LVU
   BJX_CHECK_LAUNCH(ctx);
   return BJX_OK;
 }
