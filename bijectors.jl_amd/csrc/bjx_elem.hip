@@ -910,11 +910,12 @@ int rqs_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, int 
   static const int slab_rows = getenv("BJX_RQS_SLAB") ? atoi(getenv("BJX_RQS_SLAB")) : 128;     // tuning switch: 0 = the generic path as in round 2
   // (heights that are not whole aligned packs take the same slabs on 4-byte accesses, 64 lanes per column: the generic functor path
   //  ran them at 8-18 % of the HBM peak, its knots read from L2)
-  (void)VWs;
-  if (slab_rows > 0 && out) {
+  const bool whole_packs = dim % VWs == 0 && bjx_aligned16(in) && bjx_aligned16(out);
+  const int64_t slab = (whole_packs || slab_rows < 64) ? slab_rows : 64;       // one-element packs: 64 lanes per column take 64 rows
+  if (slab > 0 && out) {
     bool ok = true;
-    for (int64_t r0 = 0; r0 < dim && ok; r0 += slab_rows) {
-      const int64_t rs = dim - r0 < slab_rows ? dim - r0 : slab_rows;
+    for (int64_t r0 = 0; r0 < dim && ok; r0 += slab) {
+      const int64_t rs = dim - r0 < slab ? dim - r0 : slab;
       bool taken = false;
       const uint32_t fl = r0 == 0 ? flags : (flags | BJX_ACCUMULATE);
       const int rc = rqs_lds_slab<T>(ctx, inverse, w + r0, h + r0, d + r0, K1, dim, in + r0, out + r0, ladj_ps, ladj_sum, rs, dim, batch, fl, &taken);
