@@ -546,8 +546,10 @@ __device__ __forceinline__ bjx_pk4 reg_load_pack(const float* px, int nrow) {
   else if (sh == 3) v = bjx_pk4{v.w, 0.f, 0.f, 0.f};
   return v;
 }
-__device__ __forceinline__ void reg_store_pack(float* py, const bjx_pk4 v, int nrow) {
-  if (nrow == 4) __builtin_nontemporal_store(v, reinterpret_cast<bjx_pk4u*>(py));
+// nt: streaming stores (A.unal == 2, BJX_UNAL_NT = 1).  Off by default — the halves of a 64-byte sector that two columns of an odd
+// height share are written at different times, and streamed they reach HBM as partial writes (WRITE_SIZE 1.15-1.35 x the output).
+__device__ __forceinline__ void reg_store_pack(float* py, const bjx_pk4 v, int nrow, bool nt) {
+  if (nrow == 4) { if (nt) __builtin_nontemporal_store(v, reinterpret_cast<bjx_pk4u*>(py)); else *reinterpret_cast<bjx_pk4u*>(py) = v; }
   else if (nrow == 3) { TinyCol<float, 3> t; t.v[0] = v.x; t.v[1] = v.y; t.v[2] = v.z; *reinterpret_cast<TinyCol<float, 3>*>(py) = t; }   // one dwordx3 / x2 store
   else if (nrow == 2) { TinyCol<float, 2> t; t.v[0] = v.x; t.v[1] = v.y; *reinterpret_cast<TinyCol<float, 2>*>(py) = t; }
   else py[0] = v.x;
@@ -834,7 +836,7 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow);
+        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow, A.unal == 2);
         py += step_elems;
       }
     } else {
@@ -1357,7 +1359,7 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow);
+        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow, A.unal == 2);
         py += step_elems;
       }
     } else {
@@ -1489,7 +1491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow);
+        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow, A.unal == 2);
         py += step_elems;
       }
     } else {
@@ -2228,6 +2230,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
     // columns that are not whole aligned packs (odd heights, or a base that is only 4-byte aligned) run the same kernels on
     // element-aligned packs (reg_load_pack).  They used to fall to the LDS-tile kernel: 4-28 % of the HBM peak at 33-255 rows.
     static const int use_unal = getenv("BJX_PLANAR_REG_UNALIGNED") ? atoi(getenv("BJX_PLANAR_REG_UNALIGNED")) : 1;
+    static const int unal_nt = getenv("BJX_UNAL_NT") ? atoi(getenv("BJX_UNAL_NT")) : 0;
     const bool packs_ok = dim % 4 == 0 && bjx_aligned16(in) && bjx_aligned16(out);
     // 256 < dim <= 1024, two layers or more: the tile split over 8 / 16 waves of one block (planar_reg2_kernel, NW = 8 / 16)
     static const int use_big = getenv("BJX_PLANAR_REG_BIG") ? atoi(getenv("BJX_PLANAR_REG_BIG")) : 1;
@@ -2264,7 +2267,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
           bool secondb = false;
           { int rc = bjx_make_fin(ctx, gridb, ladj_sum, 0.0, 0, flags, &finb, &secondb); if (rc) return rc; }
           if (finb.counter) { finb.counter = nullptr; secondb = true; }        // blocks of 8 / 16 waves: two-pass finalize
-          PlanarRegArgs RB{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : 1};
+          PlanarRegArgs RB{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : (unal_nt ? 2 : 1)};
           const int accumb = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
 #define LAUNCH_BIG_U(NL_, INV_, NW_, U_) hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_, NW_, U_>), dim3((unsigned)gridb), dim3(NW_ * 64), 0, ctx->stream, RB, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accumb, finb)
 #define LAUNCH_BIG(NL_, INV_, NW_) do { if (packs_ok) LAUNCH_BIG_U(NL_, INV_, NW_, false); else LAUNCH_BIG_U(NL_, INV_, NW_, true); } while (0)
@@ -2285,7 +2288,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         BjxFin fin;
         bool second = false;
         { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
-        PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : 1};
+        PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : (unal_nt ? 2 : 1)};
         const int accum = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
 #define LAUNCH_REG_U(G_, NL_, INV_, U_) if (G_ == 32 && cols == 32) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, (G_ == 32 ? 32 : 64), (G_ != 8) && U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); else hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, 64, (G_ != 8) && U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
 #define LAUNCH_REG(G_, NL_, INV_) do { if (packs_ok) { LAUNCH_REG_U(G_, NL_, INV_, false); } else { LAUNCH_REG_U(G_, NL_, INV_, true); } } while (0)
@@ -2432,6 +2435,7 @@ inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float
                           const float* out_bar, const float* ladj_bar, float* in_bar, int64_t dim, int64_t batch, float* t_out, float* s_out) {
   static const int use_reg = getenv("BJX_PLANAR_REG") ? atoi(getenv("BJX_PLANAR_REG")) : 1;
   static const int use_unal = getenv("BJX_PLANAR_REG_UNALIGNED") ? atoi(getenv("BJX_PLANAR_REG_UNALIGNED")) : 1;
+  static const int unal_nt = getenv("BJX_UNAL_NT") ? atoi(getenv("BJX_UNAL_NT")) : 0;
   const bool packs_ok = dim % 4 == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
   if (!(use_reg && (packs_ok || (use_unal && dim > 32)) && dim > 16 && dim <= 128)) return 1;
   const int NL = nl >= 8 ? 8 : (nl > 2 ? 4 : nl);
@@ -2452,7 +2456,7 @@ inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float
   const int G = dim > 64 ? 32 : (dim > 32 ? 16 : 8);
   const int64_t grid = (batch + 4 * 64 - 1) / (4 * 64);
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: batch too large for one launch");
-  PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : 1};
+  PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : (unal_nt ? 2 : 1)};
 #define LVU(G_, NL_, U_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, true, (G_ != 8) && U_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); \
                           else hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, false, (G_ != 8) && U_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); } while (0)
 #define LV(G_, NL_) do { if (packs_ok) LVU(G_, NL_, false); else LVU(G_, NL_, true); } while (0)

@@ -241,8 +241,11 @@ __global__ __launch_bounds__(256) void colgroup_kernel(const F f, const T* x, T*
 // at 252).  In place: the overlap may already hold outputs when the tail unit runs in a later trip; those values are never used.
 template <class T, int V, class F>
 __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* x, T* y, T* ladj_ps, int64_t dim,
-                                                            int64_t batch, int G, int accumulate, const BjxFin fin, int64_t ldx, int64_t ldy, int64_t row0) {
+                                                            int64_t batch, int G, int accumulate, const BjxFin fin, int64_t ldx, int64_t ldy, int64_t row0, int nt) {
   // row0: first row of a row window (x and y already point at it; the functor and its gathers see the rows of the whole column)
+  // nt: streaming (nontemporal) stores.  OFF by default: columns of an odd height end and begin inside a 64-byte sector, and the two
+  // halves are written by different instructions at different times — with streaming stores each half goes to HBM as a partial write
+  // (WRITE_SIZE 1.15 x the output at 101 rows, `profiles/r03_odd_counters.md`); ordinary stores let the L2 merge them.
   static_assert(V > 1, "whole packs only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* red = reinterpret_cast<double*>(smem);
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* 
         else if constexpr (col_has_aux<F>::value) l = f.template apply_masked<V>(fsm, p[u], aux[u], x + col * ldx - row0, row0 + prow, col, mask);
         else l = f.template apply_masked<V>(fsm, p[u], x + col * ldx - row0, row0 + prow, col, mask);
         T* yp = y + col * ldy + prow;
-        if (!is_tail) store_pack<T, V, true>(yp, p[u]);
+        if (!is_tail) { if (nt) store_pack<T, V, true>(yp, p[u]); else store_pack<T, V, false>(yp, p[u]); }
         else store_pack_run<T, V>(yp, p[u], V - tail, tail);
       }
       l = group_sum_rt(l, G);
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* 
               const uint32_t mask = is_tail ? tmask : full;
               if constexpr (col_has_aux<F>::value) l += f.template apply_masked<V>(fsm, p[c][r], aux[c][r], xc - row0, row0 + prow, col, mask);
               else l += f.template apply_masked<V>(fsm, p[c][r], xc - row0, row0 + prow, col, mask);
-              if (!is_tail) store_pack<T, V, true>(yc + prow, p[c][r]);
+              if (!is_tail) { if (nt) store_pack<T, V, true>(yc + prow, p[c][r]); else store_pack<T, V, false>(yc + prow, p[c][r]); }
               else store_pack_run<T, V>(yc + prow, p[c][r], V - tail, tail);
             }
           }
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(256) void colgroup_tail_kernel(const F f, const T* 
               const uint32_t mask = is_tail ? tmask : full;
               if constexpr (col_has_aux<F>::value) l += f.template apply_masked<V>(fsm, p[u], aux[u], xc - row0, row0 + prow, col, mask);
               else l += f.template apply_masked<V>(fsm, p[u], xc - row0, row0 + prow, col, mask);
-              if (!is_tail) store_pack<T, V, true>(yc + prow, p[u]);
+              if (!is_tail) { if (nt) store_pack<T, V, true>(yc + prow, p[u]); else store_pack<T, V, false>(yc + prow, p[u]); }
               else store_pack_run<T, V>(yc + prow, p[u], V - tail, tail);
             }
           }
@@ -613,8 +616,9 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
   {
   BjxProf prof_(ctx);
   if (c.V == VW && c.unal && dim % VW != 0) {
+    static const int unal_nt = getenv("BJX_UNAL_NT") ? atoi(getenv("BJX_UNAL_NT")) : 0;
     if constexpr (col_has_masked<F>::value && Vec16<T>::N > 1)
-      hipLaunchKernelGGL((colgroup_tail_kernel<T, VW, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy, row0);
+      hipLaunchKernelGGL((colgroup_tail_kernel<T, VW, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy, row0, unal_nt);
     else
       hipLaunchKernelGGL((colgroup_kernel<T, VW, true, F, true>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy, row0);
   } else if (c.V == VW)
