@@ -791,7 +791,12 @@ template <class T> __device__ __forceinline__ void slot_grad(const Slot<T>& s, T
 // cotangents of a leading per-row affine stage, bjx_row_moments) -> mpart[blockIdx][2 dim] in Float64, so that the
 // mean-field pullback does not read x̄ and x a second time (1 284 -> 772 + ~2 % B/sample).  One pack per lane
 // (dim <= G·V), partial sums over the COL_UC columns of a lane, a fixed shuffle butterfly over the column groups of a wave, the four waves through LDS.
-template <class T, int V, bool GATHER, bool IN_LDS, bool MOM = false>
+// UNAL (round 3, odd column heights from 80 rows; whole-segment rows in place, no fused moments): 16-byte packs on element-aligned
+// addresses, and the dim mod V tail rows as one more unit of the same loop — the LAST V rows of the column (overlapping the pack
+// before them), every element looking up its own place in the row-permuted table; the pullback is elementwise, so the overlap is
+// simply recomputed and only the tail rows are stored.  The tile walker these heights used ran the chain pullback at 18 / 32 % of the
+// HBM peak at 101 / 201 rows (70 % at 100 rows on this kernel).
+template <class T, int V, bool GATHER, bool IN_LDS, bool MOM = false, bool UNAL = false>
 __global__ __launch_bounds__(256) void stacked_vjp_kernel(const char* __restrict__ tab_g, int two_slots, const T* __restrict__ x, const T* __restrict__ ybar,
                                                           const T* __restrict__ lbar, T* __restrict__ xbar, int64_t dim, int64_t batch, int G,
                                                           double* __restrict__ mpart = nullptr, int mom_off = 0) {
@@ -810,6 +815,8 @@ __global__ __launch_bounds__(256) void stacked_vjp_kernel(const char* __restrict
   const int gl = threadIdx.x & (G - 1);
   const int cols_per_block = blockDim.x / G;
   const int64_t nvc = dim / V;
+  const int tail = UNAL ? (int)(dim - nvc * V) : 0;
+  const int64_t nun = nvc + (tail ? 1 : 0);           // units of a column: the whole packs and (UNAL) the tail
   for (int uc = 0; uc < COL_UC; ++uc) {
     const int64_t col = ((int64_t)blockIdx.x * COL_UC + uc) * cols_per_block + threadIdx.x / G;
     if (col >= batch) continue;
@@ -817,14 +824,16 @@ __global__ __launch_bounds__(256) void stacked_vjp_kernel(const char* __restrict
     const T* xc = x + col * dim;
     const T* gc = ybar + col * dim;
     T* oc = xbar + col * dim;
-    for (int64_t v = gl; v < nvc; v += G) {
+    for (int64_t v = gl; v < nun; v += G) {
+      const bool is_tail = UNAL && v == nvc;
+      const int64_t prow = is_tail ? dim - V : v * V;
       Pack<T, V> px, pg;
-      if (!GATHER) px = load_pack<T, V, true>(xc + v * V);
-      pg = load_pack<T, V, true>(gc + v * V);
+      if (!GATHER) px = load_pack<T, V, true>(xc + prow);
+      pg = load_pack<T, V, true>(gc + prow);
       const Pack<T, V> pin = px;                      // the inputs (px is overwritten by the results row by row)
 #pragma unroll 1
       for (int j = 0; j < V; ++j) {
-        const Slot<T>* e = reinterpret_cast<const Slot<T>*>(t + (V > 1 ? j * nvc + v : v) * stacked_row_bytes<T>());
+        const Slot<T>* e = reinterpret_cast<const Slot<T>*>(t + (is_tail ? stacked_row_index(prow + j, V, nvc) : (V > 1 ? j * nvc + v : v)) * stacked_row_bytes<T>());
         const Slot<T> s0 = e[0];
         T xv = px.v[0], gv = pg.v[0];
         if (V > 1) {
@@ -857,7 +866,10 @@ __global__ __launch_bounds__(256) void stacked_vjp_kernel(const char* __restrict
 #pragma unroll
         for (int j = 0; j < V; ++j) { ms1[j] += px.v[j]; ms2[j] += px.v[j] * pin.v[j]; }
       }
-      if (!GATHER) store_pack<T, V, true>(oc + v * V, px);
+      if (!GATHER) {
+        if (!is_tail) store_pack<T, V, true>(oc + prow, px);
+        else store_pack_run<T, V>(oc + prow, px, V - tail, tail);
+      }
     }
   }
   if (MOM) {
@@ -1008,6 +1020,34 @@ int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T*
       }
 #undef BJX_SVT
       if (launched) { BJX_CHECK_LAUNCH(ctx); return BJX_OK; }
+    }
+    // odd heights from 80 rows (BJX_COL_UNALIGNED_MIN), rows in place: the group kernel on element-aligned packs (UNAL)
+    static const int use_unal_vjp = getenv("BJX_STACKED_VJP_UNALIGNED") ? atoi(getenv("BJX_STACKED_VJP_UNALIGNED")) : 1;
+    if constexpr (Vec16<T>::N > 1) {
+      bool in_place_rows = true;
+      for (int sgi = 0; sgi < n_segs; ++sgi) in_place_rows = in_place_rows && segs[sgi].in_lo == segs[sgi].out_lo;
+      if (use_unal_vjp && !moments && in_place_rows && dim % Vec16<T>::N != 0 && col_launch_cfg<T>(ctx, x, xbar, dim, batch, 0, 0, true).unal) {
+        constexpr int VWu = Vec16<T>::N;
+        StackedPlan plu;
+        { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, xbar, dim, batch, false, true, &plu, 0, 0, true); if (rc) return rc; }
+        if (plu.V == VWu && !plu.gather) {
+          const bool ldsu = plu.tab_bytes <= 48 * 1024;
+          const size_t smemu = ldsu ? plu.tab_bytes : 0;
+          const int64_t units = dim / VWu + 1;
+          int Gu = 1;
+          while (Gu < 64 && Gu < units) Gu <<= 1;
+          const int64_t cpbu = (int64_t)(256 / Gu) * COL_UC;
+          const int64_t gridu = (batch + cpbu - 1) / cpbu;
+          BJX_REQUIRE(ctx, gridu < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_stacked_vjp: batch too large for one launch");
+          {
+            BjxProf prof_(ctx);
+            if (ldsu) hipLaunchKernelGGL((stacked_vjp_kernel<T, VWu, false, true, false, true>), dim3((unsigned)gridu), dim3(256), smemu, ctx->stream, plu.tab, plu.two, x, ybar, lbar, xbar, dim, batch, Gu);
+            else hipLaunchKernelGGL((stacked_vjp_kernel<T, VWu, false, false, false, true>), dim3((unsigned)gridu), dim3(256), smemu, ctx->stream, plu.tab, plu.two, x, ybar, lbar, xbar, dim, batch, Gu);
+          }
+          BJX_CHECK_LAUNCH(ctx);
+          return BJX_OK;
+        }
+      }
     }
     static const int use_walker = getenv("BJX_STACKED_WALKER") ? atoi(getenv("BJX_STACKED_WALKER")) : 1;
     const int64_t P = dim | 1;

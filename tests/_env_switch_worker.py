@@ -92,6 +92,8 @@ def main(path):
             av = torch.linspace(0.5, 1.5, a_, dtype=tdt).cuda()
             st = bj.Stacked([e(bj.exp) @ bj.Scale(av), bj.Logit(0.0, 1.0), bj.identity], [(1, a_), (a_ + 1, b_), (b_ + 1, dim)])
             put(f"stacked_odd.{tg}.{dim}", bj.with_logabsdet_jacobian(st, dev(np.asfortranarray(xs.astype(dt))), per_sample=True))
+            g_, lb_ = np.asfortranarray(r.normal(size=(dim, N)).astype(dt)), r.normal(size=N).astype(dt)
+            put(f"stacked_odd_vjp.{tg}.{dim}", bj.vjp(st, dev(np.asfortranarray(xs.astype(dt))), dev(g_), dev(lb_)))
         for K, N in ((4, 300), (9, 130), (16, 70), (64, 9)):
             nv = K * (K - 1) // 2
             y = np.asfortranarray((r.normal(size=(nv, N)) * min(0.6, 1.6 / np.sqrt(K))).astype(dt))

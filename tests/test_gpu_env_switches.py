@@ -23,7 +23,7 @@ SETTINGS = [
     "BJX_ORDERED_VJP_STREAM=0", "BJX_SIMPLEX_VJP_STREAM=0", "BJX_SIMPLEX_VJP_G=4", "BJX_SIMPLEX_VJP_CHUNK_MIN=1000", "BJX_SIMPLEX_VJP_CHUNK_MIN=100000000",
     "BJX_SEQ_TINY=0", "BJX_SEQ_TINY_MAX=3", "BJX_SEQ_TALL=0", "BJX_SEQ_TALL_MIN=250", "BJX_SEQ_TALL_INV_MAX=100", "BJX_SEQ_TALL_EFF=0.95", "BJX_SIMPLEX_VJP_TALL=0", "BJX_SIMPLEX_VJP_TALL_MIN=250",
     "BJX_SIMPLEX_VJP_TALL_INV_MAX=100", "BJX_SEQ_TALL_INV_SCAN=0", "BJX_SEQ_TALL_INV_SCAN=1", "BJX_SIMPLEX_VJP_TALL_SCAN=0",
-    "BJX_MIXED_GPB=1", "BJX_MIXED_GPB=5", "BJX_CHAIN_TINY=0", "BJX_PLANAR_REG_UNALIGNED=0", "BJX_PLANAR_REG_BIG=0", "BJX_FLOW_UNALIGNED=0", "BJX_COL_UNALIGNED=0", "BJX_UNAL_NT=1", "BJX_COL_SLAB=0", "BJX_COL_UNALIGNED_MIN=17", "BJX_STACKED_SLAB=0", "BJX_STACKED_SLAB=64", "BJX_CHAIN_UNALIGNED=0", "BJX_CHAIN_UNALIGNED_MIN=17", "BJX_PLANAR_WALK_DIRECT=0", "BJX_COLDIRECT=0", "BJX_STACKED_TINY=0",
+    "BJX_MIXED_GPB=1", "BJX_MIXED_GPB=5", "BJX_CHAIN_TINY=0", "BJX_PLANAR_REG_UNALIGNED=0", "BJX_PLANAR_REG_BIG=0", "BJX_FLOW_UNALIGNED=0", "BJX_COL_UNALIGNED=0", "BJX_STACKED_VJP_UNALIGNED=0", "BJX_UNAL_NT=1", "BJX_COL_SLAB=0", "BJX_COL_UNALIGNED_MIN=17", "BJX_STACKED_SLAB=0", "BJX_STACKED_SLAB=64", "BJX_CHAIN_UNALIGNED=0", "BJX_CHAIN_UNALIGNED_MIN=17", "BJX_PLANAR_WALK_DIRECT=0", "BJX_COLDIRECT=0", "BJX_STACKED_TINY=0",
     "BJX_CHOL_CHUNK=0", "BJX_CHOL_LANE_MAX=0", "BJX_CHOL_FWD_VJP_SWZ=0", "BJX_STACKED_WALKER=0", "BJX_RQS_ITERS=7", "BJX_RQS_SLAB=0", "BJX_RQS_SLAB=32",
 ]
 

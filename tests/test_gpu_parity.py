@@ -958,6 +958,41 @@ def test_stacked_and_chain_vjp(bj, orc, dt):
     np.testing.assert_allclose(got3, ref3, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim", [81, 101, 201, 255, 333, 1001])
+def test_stacked_and_chain_vjp_odd_heights(bj, orc, dt, dim):
+    """Pullback of chains / `Stacked` at heights that are not whole 16-byte packs, from 80 rows: the group kernel on element-aligned
+    packs with the tail rows as an overlapping last pack (`stacked_vjp_kernel<..., UNAL>`); cotangent buffer aliased by the result too."""
+    r = rng(57)
+    N = 70
+    lbar = r.normal(size=N).astype(dt)
+    av = np.linspace(0.5, 1.5, dim)
+    ch = bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(torch.tensor(av))
+    ops = [(orc.OP_SCALE, av, None), (orc.OP_SHIFT, 0.1, None), (orc.OP_EXP, None, None)]
+    X = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    g = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    ref = orc.chain_vjp(ops, X.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64))
+    got = bj.vjp(ch, dev(X), dev(g), torch.from_numpy(lbar).cuda())
+    np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())))
+    # three segments, the last one a single row
+    a_, b_ = dim // 3, 2 * (dim // 3)
+    segs = [
+        (bj.elementwise(bj.exp), [(orc.OP_EXP, None, None)], (1, a_)),
+        (bj.Logit(-1.0, 2.0), [(orc.OP_LOGIT, -1.0, 2.0)], (a_ + 1, b_)),
+        (bj.identity, [], (b_ + 1, dim - 1)),
+        (bj.elementwise(bj.log), [(orc.OP_LOG, None, None)], (dim, dim)),
+    ]
+    Xs = r.normal(size=(dim, N))
+    Xs[a_:b_] = r.uniform(-0.8, 1.8, size=(b_ - a_, N))
+    Xs[dim - 1] = r.uniform(0.2, 3.0, size=N)
+    Xs = np.asfortranarray(Xs.astype(dt))
+    refs = np.vstack([orc.chain_vjp(o, Xs[lo - 1:hi].astype(np.float64), g[lo - 1:hi].astype(np.float64), lbar.astype(np.float64)) if o
+                      else g[lo - 1:hi].astype(np.float64) for _, o, (lo, hi) in segs])
+    st = bj.Stacked([s_[0] for s_ in segs], [s_[2] for s_ in segs])
+    gots = bj.vjp(st, dev(Xs), dev(g), torch.from_numpy(lbar).cuda())
+    np.testing.assert_allclose(host(gots), refs, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(refs).max())))
+
+
 def test_columnwise_returns_the_sum_over_columns(bj, orc):
     """src/interface.jl:71-78: with_logabsdet_jacobian(columnwise(f), X) = (hcat of f(col), sum of the log-dets)."""
     r = rng(61)
