@@ -89,6 +89,7 @@ SIGNATURES = {
     "bjx_pd_vec": (_i, [_vp, _i, _i, _vp, _vp] + _tail),
     "bjx_scale_matrix": (_i, [_vp, _i, _i, _vp, _vp, _vp] + _tail),
     "bjx_planar": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp] + _tail),
+    "bjx_pack_vectors": (_i, [_vp, _i, _i, C.POINTER(_vp), _i64, _vp]),
     "bjx_planar_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_radial_vjp_params": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_planar_vjp_params": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),

@@ -366,6 +366,45 @@ BJX_API int bjx_fill_normal(bjx_ctx* ctx, bjx_dtype dt, void* out, int64_t dim, 
   return BJX_OK;
 }
 
+// ------------------------------------------------------------------ parameter gather for composed flows
+// The reference writes a flow as `l8 ∘ … ∘ l1` (docs/src/flows.md:115, composed.jl:4): one PlanarLayer object, i.e. one (w, u, b)
+// triple of separate device vectors, per layer.  The host walks the composition and hands the RUN of layers to the fused kernel;
+// this entry copies the n vectors into the layer-major table bjx_planar takes, in one launch (pointer table in the kernel
+// arguments, 64 vectors per launch).
+namespace {
+struct BjxPtrTable { const void* p[64]; };
+template <class T>
+__global__ __launch_bounds__(256) void bjx_pack_vectors_kernel(BjxPtrTable tab, int64_t len, T* __restrict__ dst) {
+  const T* __restrict__ src = static_cast<const T*>(tab.p[blockIdx.y]);
+  T* __restrict__ out = dst + (int64_t)blockIdx.y * len;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) out[i] = src[i];
+}
+}  // namespace
+
+BJX_API int bjx_pack_vectors(bjx_ctx* ctx, bjx_dtype dt, int n, const void* const* src, int64_t len, void* dst) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, n >= 0 && len >= 0, BJX_ERR_SHAPE, "bjx_pack_vectors: bad size (n=%d, len=%lld)", n, (long long)len);
+  BJX_REQUIRE(ctx, dt == BJX_F32 || dt == BJX_F64, BJX_ERR_ARG, "bjx_pack_vectors: bad dtype %d", (int)dt);
+  if (n == 0 || len == 0) return BJX_OK;
+  BJX_REQUIRE(ctx, src && dst, BJX_ERR_ARG, "bjx_pack_vectors: null pointer");
+  for (int i = 0; i < n; ++i) BJX_REQUIRE(ctx, src[i], BJX_ERR_ARG, "bjx_pack_vectors: vector %d is a null pointer", i);
+  const size_t esz = dt == BJX_F32 ? 4 : 8;
+  int64_t gx = (len + 255) / 256;
+  if (gx > 1024) gx = 1024;
+  for (int lo = 0; lo < n; lo += 64) {
+    const int cnt = n - lo < 64 ? n - lo : 64;
+    BjxPtrTable tab;
+    for (int i = 0; i < 64; ++i) tab.p[i] = i < cnt ? src[lo + i] : nullptr;
+    char* d = static_cast<char*>(dst) + (size_t)lo * (size_t)len * esz;
+    if (dt == BJX_F32)
+      hipLaunchKernelGGL(bjx_pack_vectors_kernel<float>, dim3((unsigned)gx, (unsigned)cnt), dim3(256), 0, ctx->stream, tab, len, reinterpret_cast<float*>(d));
+    else
+      hipLaunchKernelGGL(bjx_pack_vectors_kernel<double>, dim3((unsigned)gx, (unsigned)cnt), dim3(256), 0, ctx->stream, tab, len, reinterpret_cast<double*>(d));
+    BJX_CHECK_LAUNCH(ctx);
+  }
+  return BJX_OK;
+}
+
 // ------------------------------------------------------------------ RCCL (lazy)
 // RCCL is dlopen'ed on first use so the library loads (and single-GPU use works) in processes
 // that never touch a communicator, and so it shares the RCCL already mapped by the host

@@ -34,7 +34,7 @@ __all__ = [
     "PartitionMask", "Coupling", "Stacked", "NamedStacked", "Columnwise", "columnwise", "vjp", "istraining", "training", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
     "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
     "PlanarResult", "vjp_params", "row_moments", "MvNormal", "TransformedDistribution", "transformed", "logpdf", "rand",
-    "CapturedStep",
+    "CapturedStep", "kernel_timed",
 ]
 
 PlanarResult = namedtuple("PlanarResult", ["result", "logabsdetjac"])  # planar_layer.jl:109
@@ -127,6 +127,22 @@ class CapturedStep:
             self.close()
         except Exception:
             pass
+
+
+def kernel_timed(fn, device: Optional[torch.device] = None):
+    """-> (fn(), summed milliseconds of the DOMINANT kernels fn launched on the context stream, how many of them): the library
+    brackets every hot kernel (not the parameter-prep / finalize helpers) with its own hipEvent pair between
+    bjx_kernel_time_begin and _end.  The launch count is how the tests assert that a composition ran as ONE fused launch."""
+    ctx = context(device)
+    lib = L.load()
+    L.check(ctx.h, lib.bjx_kernel_time_begin(ctx.h), "bjx_kernel_time_begin")
+    try:
+        out = fn()
+    finally:
+        ms, n = C.c_float(0), C.c_int(0)
+        rc = lib.bjx_kernel_time_end(ctx.h, C.byref(ms), C.byref(n))
+    L.check(ctx.h, rc, "bjx_kernel_time_end")
+    return out, float(ms.value), int(n.value)
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -648,9 +664,20 @@ class ComposedFunction(Transform):
                 out.append(part)
         return out
 
-    def _wlj(self, x, per_sample, want_ladj=True):
-        # Walk the chain; maximal runs of fusable elementwise stages become ONE kernel launch.
+    def _plan(self):
+        """(planned stages, spans) of `_planned`, kept while the chain's stage objects are the same (the `_PlanarRun`s carry the
+        gathered parameter tables)."""
         stages = self._stages()
+        key = tuple(id(st) for st in stages)
+        hit = getattr(self, "_plan_cache", None)
+        if hit is None or hit[0] != key:
+            hit = (key, _planned(stages), stages)
+            self._plan_cache = hit
+        return hit[1]
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        # Walk the chain; maximal runs of fusable elementwise stages become ONE kernel launch, and so do runs of PlanarLayers.
+        stages = self._plan()[0]
         y = x
         total = None
         run: list = []
@@ -1004,34 +1031,46 @@ class Permute(Bijector):
 
 class PlanarLayer(Bijector):
     """planar_layer.jl:12-188.  `w`, `u`: (dim,) tensors, `b`: 1-element tensor.
-    Several layers may be stacked into one fused launch with `PlanarLayer.stack([...])`."""
+    A composition of layers written the reference's way, `l8 @ ... @ l1` (docs/src/flows.md:115), is ONE launch: the
+    composition planner (`_planned`) merges the run into a `_PlanarRun`.  `PlanarLayer.stack([...])` builds the same object."""
 
     def __init__(self, w, u, b):
         self.w = torch.as_tensor(w)
         self.u = torch.as_tensor(u)
         self.b = torch.as_tensor(b).reshape(-1)
         self.n_layers = 1 if self.w.dim() == 1 else self.w.shape[1]
+        self._tab = None
 
     @classmethod
     def stack(cls, layers):
         """layer[-1] ∘ ... ∘ layer[0] evaluated by ONE kernel."""
-        w = torch.stack([l.w.reshape(-1) for l in layers], dim=1)
-        u = torch.stack([l.u.reshape(-1) for l in layers], dim=1)
-        b = torch.cat([l.b.reshape(-1)[:1] for l in layers])
-        return cls(w, u, b)
+        return _PlanarRun(layers)
 
     def _key(self):
         return (_keyify(self.w), _keyify(self.u), _keyify(self.b))
 
+    def _single_layers(self):
+        """The stack as one-layer PlanarLayers in application order."""
+        if self.n_layers == 1 and self.w.dim() == 1:
+            return [self]
+        return [PlanarLayer(self.w[:, k], self.u[:, k], self.b[k:k + 1]) for k in range(self.n_layers)]
+
+    def _tables(self, xc, dim):
+        """(w, u, b) on xc's device as the layer-major tables bjx_planar takes.  A (dim, n_layers) parameter matrix is transposed
+        once per parameter version, not per call."""
+        w, u, b = _param(self.w, xc), _param(self.u, xc), _param(self.b, xc)
+        if w.numel() != dim * self.n_layers or u.numel() != w.numel():
+            raise ValueError(f"DimensionMismatch: PlanarLayer of dimension {w.numel() // self.n_layers} applied to {dim} rows")
+        if w.dim() != 2:
+            return w, u, b
+        key = (w.data_ptr(), w._version, u.data_ptr(), u._version)
+        if self._tab is None or self._tab[0] != key:
+            self._tab = (key, w.T.contiguous(), u.T.contiguous(), (w, u))
+        return self._tab[1], self._tab[2], b
+
     def _run(self, x, inv, per_sample, want_ladj, flags=0, store=True):
         xc, dim, batch, vec = _prep(x)
-        w = _param(self.w, xc)
-        u = _param(self.u, xc)
-        if w.dim() == 2:  # (dim, n_layers) -> layer-major contiguous
-            w, u = w.T.contiguous(), u.T.contiguous()
-        if w.numel() != dim * self.n_layers:
-            raise ValueError(f"DimensionMismatch: PlanarLayer of dimension {w.numel() // self.n_layers} applied to {dim} rows")
-        b = _param(self.b, xc)
+        w, u, b = self._tables(xc, dim)
         return _call_struct("bjx_planar", x, dim, True, per_sample, want_ladj,
                             (int(inv), _ptr(w), _ptr(u), _ptr(b), self.n_layers), (dim,), flags=flags, store=store)
 
@@ -1040,6 +1079,95 @@ class PlanarLayer(Bijector):
 
     def _wlj_inv(self, x, per_sample, want_ladj=True):
         return self._run(x, True, per_sample, want_ladj)
+
+
+class _PlanarRun(PlanarLayer):
+    """A maximal run of PlanarLayer stages of a composition, in APPLICATION order (layers[0] first) — what the composition
+    planner hands to one bjx_planar / bjx_planar_vjp / bjx_planar_vjp_params launch.  The layers keep their own parameter tensors
+    (they are what a training loop updates); the layer-major tables the kernel reads are gathered on the device by
+    bjx_pack_vectors and rebuilt only when a parameter tensor changed (`_version`) or moved."""
+
+    def __init__(self, layers):
+        flat = []
+        for l in layers:
+            if not isinstance(l, PlanarLayer):
+                raise TypeError(f"PlanarLayer.stack: {l!r} is not a PlanarLayer")
+            flat.extend(l._single_layers())
+        if not flat:
+            raise ValueError("PlanarLayer.stack: no layers")
+        self.layers = flat
+        self.n_layers = len(flat)
+        self._tab = None
+
+    # (dim, n_layers) views of the parameters, for code that treats the run as one stacked layer (oracle comparisons, _key)
+    @property
+    def w(self):
+        return torch.stack([l.w.reshape(-1) for l in self.layers], dim=1)
+
+    @property
+    def u(self):
+        return torch.stack([l.u.reshape(-1) for l in self.layers], dim=1)
+
+    @property
+    def b(self):
+        return torch.cat([l.b.reshape(-1)[:1] for l in self.layers])
+
+    def _single_layers(self):
+        return list(self.layers)
+
+    def _tables(self, xc, dim):
+        ws = [_param(l.w, xc).reshape(-1) for l in self.layers]
+        us = [_param(l.u, xc).reshape(-1) for l in self.layers]
+        bs = [_param(l.b, xc).reshape(-1) for l in self.layers]
+        for t in ws + us:
+            if t.numel() != dim:
+                raise ValueError(f"DimensionMismatch: PlanarLayer of dimension {t.numel()} applied to {dim} rows")
+        key = (xc.device, xc.dtype, dim, tuple((t.data_ptr(), t._version) for t in ws + us + bs))
+        if self._tab is not None and self._tab[0] == key:
+            return self._tab[1]
+        n = self.n_layers
+        ctx = context(xc.device)
+        w = torch.empty(n * dim, dtype=xc.dtype, device=xc.device)
+        u = torch.empty(n * dim, dtype=xc.dtype, device=xc.device)
+        b = torch.empty(n, dtype=xc.dtype, device=xc.device)
+        for src, ln, dst in ((ws, dim, w), (us, dim, u), (bs, 1, b)):
+            arr = (C.c_void_p * n)(*[t.data_ptr() for t in src])
+            L.check(ctx.h, L.load().bjx_pack_vectors(ctx.h, _dt(xc), n, arr, ln, _ptr(dst)), "bjx_pack_vectors")
+        self._tab = (key, (w, u, b), (ws, us, bs))      # the sources stay alive: their addresses are part of the key
+        return self._tab[1]
+
+
+def _planar_kind(s) -> int:
+    """+1: a PlanarLayer stage, -1: inverse(PlanarLayer), 0: anything else."""
+    if isinstance(s, PlanarLayer):
+        return 1
+    if isinstance(s, Inverse) and isinstance(s.orig, PlanarLayer):
+        return -1
+    return 0
+
+
+def _planned(stages):
+    """The composition planner (src/bijectors/composed.jl:4-25 applies a chain stage by stage; docs/src/flows.md:115 is how the
+    reference writes a flow).  `stages` in application order -> (planned stages, spans): every maximal run of PlanarLayer stages
+    becomes one `_PlanarRun` (ONE bjx_planar launch over the batch instead of one per layer: 1 028 instead of 8 224 B/sample for
+    eight layers at dim 128), a run of inverse(PlanarLayer) stages the inverse of the reversed run; everything else stays.
+    spans[i] = (lo, hi): planned stage i covers stages[lo:hi]."""
+    out, spans, i = [], [], 0
+    while i < len(stages):
+        kind = _planar_kind(stages[i])
+        j = i + 1
+        if kind:
+            while j < len(stages) and _planar_kind(stages[j]) == kind:
+                j += 1
+        if j - i == 1:
+            out.append(stages[i])
+        elif kind == 1:
+            out.append(_PlanarRun(stages[i:j]))
+        else:       # inv(l_a) applied first, then inv(l_b), ... = inverse(l_a ∘ l_b ∘ ...): the forward run applies the LAST stage's layer first
+            out.append(Inverse(_PlanarRun([st.orig for st in reversed(stages[i:j])])))
+        spans.append((i, j))
+        i = j
+    return out, spans
 
 
 class RadialLayer(Bijector):
@@ -1880,12 +2008,7 @@ def vjp(b, x, out_bar, ladj_bar=None):
         gc, gdim, gbatch, _ = _prep(out_bar)
         if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:
             raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
-        w, u = _param(base.w, xc), _param(base.u, xc)
-        if w.dim() == 2:
-            w, u = w.T.contiguous(), u.T.contiguous()
-        if w.numel() != dim * base.n_layers:
-            raise ValueError(f"DimensionMismatch: PlanarLayer of dimension {w.numel() // base.n_layers} applied to {dim} rows")
-        bb = _param(base.b, xc)
+        w, u, bb = base._tables(xc, dim)
         lb = _ladj_bar(ladj_bar, batch, xc)
         ctx = context(xc.device)
         xb = _empty(dim, batch, xc, vec)
@@ -1954,7 +2077,7 @@ def _pieces(b):
     """A composition cut into pieces that have a device pullback: runs of elementwise stages of at most BJX_MAX_SEG_OPS ops
     (one fused launch each), every other stage alone.  Application order."""
     pieces, run, nops = [], [], 0
-    for st in b._stages():
+    for st in b._plan()[0]:
         o = _stage_ops(st)
         if o is not None and len(o) <= L.BJX_MAX_SEG_OPS:
             if nops + len(o) > L.BJX_MAX_SEG_OPS:
@@ -1995,17 +2118,26 @@ def _has_own_params(st):
 def _vjp_params_composed(b, x, out_bar, ladj_bar=None):
     """Input AND parameter pullback of a composition of layers (planar ∘ radial ∘ spline ∘ affine …): the chain rule of
     _vjp_composed with `vjp_params` at every stage that owns parameters (flow layers, splines, BatchNorm, Scale / Shift) and
-    `vjp` at the others.  Returns (x_bar, {"stages": [None | that stage's dictionary, ...]}) in application order."""
-    stages = b._stages()
+    `vjp` at the others, on the PLANNED stages — a run of PlanarLayers is one bjx_planar_vjp_params launch, and its (w̄, ū, b̄)
+    tables are handed back layer by layer.  Returns (x_bar, {"stages": [None | that stage's dictionary, ...]}) aligned with
+    `b._stages()` (application order)."""
+    stages, spans = b._plan()
     inputs = [x]
     for st in stages[:-1]:
         inputs.append(transform(st, inputs[-1]))
     g = out_bar
-    grads = [None] * len(stages)
+    grads = [None] * spans[-1][1]
     for i in range(len(stages) - 1, -1, -1):
         st = stages[i]
+        lo, hi = spans[i]
         if _has_own_params(st) or (isinstance(st, (Scale, Shift)) and not getattr(st, "matrix", False)):
-            g, grads[i] = vjp_params(st, inputs[i], g, ladj_bar)
+            g, gr = vjp_params(st, inputs[i], g, ladj_bar)
+            if hi - lo == 1:
+                grads[lo] = gr
+            else:     # a merged run: column k of the tables is layer k of the forward run = stage lo+k (reversed for an inverse run)
+                order = range(lo, hi) if _planar_kind(st) == 1 else range(hi - 1, lo - 1, -1)
+                for k, j in enumerate(order):
+                    grads[j] = {"w": gr["w"][:, k], "u": gr["u"][:, k], "b": gr["b"][k:k + 1]}
         else:
             g = vjp(st, inputs[i], g, ladj_bar)
     return g, {"stages": grads}
@@ -2154,13 +2286,8 @@ def vjp_params(b, x, out_bar, ladj_bar=None):
     gc, gdim, gbatch, _ = _prep(out_bar)
     if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:
         raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
-    w, u = _param(b.w, xc), _param(b.u, xc)
-    two_d = w.dim() == 2
-    if two_d:
-        w, u = w.T.contiguous(), u.T.contiguous()
-    if w.numel() != dim * b.n_layers:
-        raise ValueError(f"DimensionMismatch: PlanarLayer of dimension {w.numel() // b.n_layers} applied to {dim} rows")
-    bb = _param(b.b, xc)
+    w, u, bb = b._tables(xc, dim)
+    two_d = b.n_layers > 1 or isinstance(b, _PlanarRun) or b.w.dim() == 2
     lb = _ladj_bar(ladj_bar, batch, xc)
     ctx = context(xc.device)
     xb = _empty(dim, batch, xc, vec)
@@ -2170,7 +2297,7 @@ def vjp_params(b, x, out_bar, ladj_bar=None):
                                         _ptr(wb), _ptr(ub), _ptr(bbar), _ptr(work), dim, batch)
     L.check(ctx.h, rc, "bjx_planar_vjp_params")
     if two_d:
-        wb, ub = wb.T, ub.T                       # back to (dim, n_layers)
+        wb, ub = wb.reshape(b.n_layers, dim).T, ub.reshape(b.n_layers, dim).T                       # back to (dim, n_layers)
     return xb, {"w": wb, "u": ub, "b": bbar}
 
 
@@ -2434,6 +2561,8 @@ def logpdf(td: TransformedDistribution, y, reference_shape: bool = False):
     ops = _fused_ops(ib)
     if ops is not None and len(ops) + len(base) <= L.BJX_MAX_OPS:
         return _run_chain(list(ops) + base, y, True, True, store=False)[1]
+    if isinstance(ib, ComposedFunction) and len(ib._plan()[0]) == 1:       # inverse(l8 ∘ … ∘ l1): the planner's single inverse run
+        ib = ib._plan()[0][0]
     pl = ib.orig if isinstance(ib, Inverse) else None
     if isinstance(pl, PlanarLayer) and d.mu is None and d.sigma is None:
         return pl._run(y, True, True, True, flags=L.BJX_BASE_STDNORMAL, store=False)[1]

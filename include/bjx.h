@@ -213,6 +213,14 @@ int bjx_planar(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* w, const voi
                const void* b, int n_layers, const void* in, void* out,
                void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
 
+/* A flow written the reference's way — `l8 ∘ … ∘ l1` (docs/src/flows.md:115, src/bijectors/composed.jl:4-25) — is one
+ * PlanarLayer object per layer, each with its own w, u, b device vectors.  The host's composition planner hands a maximal RUN
+ * of PlanarLayer stages to ONE bjx_planar call; this entry builds the layer-major tables that call takes:
+ *   dst[i*len + k] = src[i][k],  i < n, k < len       (src: HOST array of n device pointers to T[len]; dst: device T[n*len])
+ * in one launch per 64 vectors (the pointers travel in the kernel arguments).  Used for w and u (len = dim) and b (len = 1);
+ * the cotangent tables of bjx_planar_vjp_params are layer-major too, so layer i's w̄ is the slice [i*dim, (i+1)*dim). */
+int bjx_pack_vectors(bjx_ctx* ctx, bjx_dtype dt, int n, const void* const* src, int64_t len, void* dst);
+
 /* input pullback of with_logabsdet_jacobian for the fused PlanarLayer stack (the reference
  * leaves it to the AD package; closed-form derivatives of planar_layer.jl:65-127):
  *   in_bar = (d out/d in)^T out_bar + ladj_bar[n] * d logabsdetjac[n] / d in.

@@ -97,9 +97,20 @@ def test_c4_planar_flow_full_size(bj, orc):
     w = fill(bj, cm(d, nl), 200, std=1 / math.sqrt(d))
     u = fill(bj, cm(d, nl), 201, std=1 / math.sqrt(d))
     bb = fill(bj, cm(nl, 1), 202).reshape(-1).contiguous()
-    flow = bj.PlanarLayer(w, u, bb)
-    zf, lps, lsum = bj.shard.with_logabsdet_jacobian_sharded(flow, z)
-    zb, lps_inv, _ = bj.shard.with_logabsdet_jacobian_sharded(bj.inverse(flow), zf)
+    # the flow the way the reference writes it (docs/src/flows.md:115): l8 ∘ … ∘ l1, one PlanarLayer object per layer; the
+    # composition planner must hand the run to ONE fused launch (1 028 B/sample, not 8 224)
+    layers = [bj.PlanarLayer(w[:, l].contiguous(), u[:, l].contiguous(), bb[l:l + 1].contiguous()) for l in range(nl)]
+    flow = layers[0]
+    for l in layers[1:]:
+        flow = l @ flow
+    bj.transform(flow, z[:, :64])
+    (zf, lps, lsum), _, launches = bj.kernel_timed(lambda: bj.shard.with_logabsdet_jacobian_sharded(flow, z))
+    assert launches == 1
+    stacked = bj.with_logabsdet_jacobian(bj.PlanarLayer(w, u, bb), z)
+    assert torch.equal(zf, stacked.result) and torch.equal(lps, stacked.logabsdetjac)      # bit-equal with the stacked constructor
+    del stacked
+    (zb, lps_inv, _), _, launches = bj.kernel_timed(lambda: bj.shard.with_logabsdet_jacobian_sharded(bj.inverse(flow), zf))
+    assert launches == 1
     assert torch.allclose(zb, z, rtol=1e-3, atol=2e-3)            # test/normalising_flows.jl:37-42
     assert torch.allclose(lps_inv, -lps, rtol=1e-3, atol=2e-3)
     assert abs(float(lsum) - float(lps.double().sum())) <= 1e-6 * abs(float(lsum)) + 1e-3
