@@ -22,7 +22,8 @@ using Bijectors
 using Bijectors: Elementwise, Inverse, Shift, Scale, Logit, LeakyReLU, TruncatedBijector, OrderedBijector,
     SimplexBijector, VecCholeskyBijector, Permute, PlanarLayer, RadialLayer, InvertibleBatchNorm,
     RationalQuadraticSpline, Stacked, VecCorrBijector, CorrBijector, PDBijector, PDVecBijector, NamedStacked,
-    Coupling, PartitionMask
+    Coupling, PartitionMask, Columnwise
+const VB = Bijectors.VectorBijectors
 using ChainRulesCore: ChainRulesCore, NoTangent, Tangent, unthunk
 using Distributions: Distributions
 using SparseArrays: SparseArrays
@@ -164,7 +165,8 @@ ops(b, T, keep) = nothing
 
 const ElementwiseLeaf = Union{Elementwise{typeof(exp)},Elementwise{typeof(log)},Shift{<:Union{Real,AbstractVector}},
     Scale{<:Union{Real,AbstractVector}},Logit,LeakyReLU,TruncatedBijector,Bijectors.SignFlip}
-const Fusable = Union{ElementwiseLeaf,Inverse{<:Scale{<:Union{Real,AbstractVector}}},Inverse{<:Logit},Inverse{<:TruncatedBijector},ComposedFunction}
+const FusableLeaf = Union{ElementwiseLeaf,Inverse{<:Scale{<:Union{Real,AbstractVector}}},Inverse{<:Logit},Inverse{<:TruncatedBijector}}   # one op each
+const Fusable = Union{FusableLeaf,ComposedFunction}
 
 function plan(b::Fusable, x::ROCArray{T}) where {T<:BjxFloat}
     keep = Any[]
@@ -227,18 +229,50 @@ function plan(ib::Inverse{VecCholeskyBijector}, y::ROCVecOrMat{T}) where {T<:Bjx
     return Plan(:bjx_vec_cholesky, y isa ROCVector ? (K, K) : (K, K, n), y isa ROCVector ? :scalar : :column, n, true, false, UInt32(0), Any[], launch)
 end
 
-# PlanarLayer, planar_layer.jl:65-127,160-185 (one layer per Julia object; stacks: `planar_stack` below)
-function plan_planar(flow::PlanarLayer, inv::Bool, z::ROCVecOrMat{T}, flags::UInt32=UInt32(0)) where {T<:BjxFloat}
-    d, n = dims(z); length(flow.w) == d || throw(DimensionMismatch("PlanarLayer of dimension $(length(flow.w)) applied to $d rows"))
-    w, u, b = ondevice(T, flow.w), ondevice(T, flow.u), ondevice(T, flow.b isa Real ? [flow.b] : flow.b)
-    h = ctx().h; pz = devptr(z); pw, pu, pb = devptr(w), devptr(u), devptr(b)
+# PlanarLayer, planar_layer.jl:65-127,160-185.  One Julia object per layer; a RUN of layers of a composition (`l8 ∘ … ∘ l1`,
+# docs/src/flows.md:115) is the planner's `PlanarRun` below: ONE bjx_planar launch with n_layers = the run.
+# n device vectors of length `len` -> the layer-major table the entry takes, in one launch (bjx_pack_vectors)
+function pack(::Type{T}, vs::Vector, len::Integer) where {T}
+    n = length(vs)
+    dst = ROCArray{T}(undef, n * len)
+    ptrs = Ptr{Cvoid}[devptr(v) for v in vs]
+    GC.@preserve vs dst ptrs check(ccall((:bjx_pack_vectors, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}, Int64, Ptr{Cvoid}),
+        ctx().h, dtype(T), Cint(n), ptrs, Int64(len), devptr(dst)), "bjx_pack_vectors")
+    return dst
+end
+planar_b(::Type{T}, l::PlanarLayer) where {T} = ondevice(T, l.b isa Real ? [l.b] : l.b)
+function planar_tables(::Type{T}, layers, d::Integer) where {T}       # layers in application order -> (w, u, b) tables
+    for l in layers
+        length(l.w) == d || throw(DimensionMismatch("PlanarLayer of dimension $(length(l.w)) applied to $d rows"))
+    end
+    if length(layers) == 1
+        l = layers[1]
+        return ondevice(T, l.w), ondevice(T, l.u), planar_b(T, l)
+    end
+    return pack(T, [ondevice(T, l.w) for l in layers], d), pack(T, [ondevice(T, l.u) for l in layers], d),
+           pack(T, [planar_b(T, l) for l in layers], 1)
+end
+function plan_planar(layers, inv::Bool, z::ROCVecOrMat{T}, flags::UInt32=UInt32(0)) where {T<:BjxFloat}
+    d, n = dims(z)
+    w, u, b = planar_tables(T, layers, d)
+    h = ctx().h; pz = devptr(z); pw, pu, pb = devptr(w), devptr(u), devptr(b); nl = Cint(length(layers))
     launch = (out, lps, lsum, fl) -> ccall((:bjx_planar, libbjx), Cint,
         (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
-        h, dtype(T), Cint(inv), pw, pu, pb, Cint(1), pz, out, lps, lsum, d, n, fl)
+        h, dtype(T), Cint(inv), pw, pu, pb, nl, pz, out, lps, lsum, d, n, fl)
     return Plan(:bjx_planar, size(z), :column, n, true, false, flags, Any[w, u, b], launch)
 end
-plan(flow::PlanarLayer, z::ROCVecOrMat{<:BjxFloat}) = plan_planar(flow, false, z)
-plan(ib::Inverse{<:PlanarLayer}, y::ROCVecOrMat{<:BjxFloat}) = plan_planar(ib.orig, true, y)
+plan(flow::PlanarLayer, z::ROCVecOrMat{<:BjxFloat}) = plan_planar(PlanarLayer[flow], false, z)
+plan(ib::Inverse{<:PlanarLayer}, y::ROCVecOrMat{<:BjxFloat}) = plan_planar(PlanarLayer[ib.orig], true, y)
+
+# A maximal run of PlanarLayer stages of a composition.  `layers` is the FORWARD application order of the underlying flow;
+# inv = true: the run is inverse(l_a), inverse(l_b), … applied in that order = inverse(l_a ∘ l_b ∘ …), whose forward flow applies
+# … , l_b, l_a — so `layers` holds the stages' layers REVERSED and bjx_planar (inverse = 1) undoes them last to first.
+struct PlanarRun
+    layers::Vector{PlanarLayer}
+    inv::Bool
+end
+plan(r::PlanarRun, z::ROCVecOrMat{<:BjxFloat}) = plan_planar(r.layers, r.inv, z)
 
 # RadialLayer, radial_layer.jl:43-129
 function plan_radial(flow::RadialLayer, inv::Bool, z::ROCVecOrMat{T}) where {T<:BjxFloat}
@@ -441,7 +475,7 @@ const Structured = Union{OrderedBijector,Inverse{OrderedBijector},SimplexBijecto
     VecCholeskyBijector,Inverse{VecCholeskyBijector},PlanarLayer,Inverse{<:PlanarLayer},RadialLayer,Inverse{<:RadialLayer},
     InvertibleBatchNorm,Inverse{<:InvertibleBatchNorm},RationalQuadraticSpline{<:AbstractMatrix},
     Inverse{<:RationalQuadraticSpline{<:AbstractMatrix}},Permute,Coupling,Inverse{<:Coupling},
-    MatrixKinds,Inverse{<:MatrixKinds},Scale{<:ROCMatrix},Inverse{<:Scale{<:ROCMatrix}}}
+    MatrixKinds,Inverse{<:MatrixKinds},Scale{<:ROCMatrix},Inverse{<:Scale{<:ROCMatrix}},PlanarRun}
 const Planned = Union{Fusable,Structured}
 
 # the reference's return containers: NamedTuple for the flow layers (planar_layer.jl:102-110, radial_layer.jl:58-72), tuple otherwise
@@ -507,17 +541,126 @@ end
 with_logabsdet_jacobian!(b::Planned, x::ROCArray{T}, y::ROCArray{T}) where {T<:BjxFloat} = with_logabsdet_jacobian!(b, x, y, zero(T))
 with_logabsdet_jacobian!(b::Planned, x::ROCArray{<:BjxFloat}) = with_logabsdet_jacobian!(b, x, x)
 
-# a stack of PlanarLayers composed with ∘ is ONE launch (n_layers fused, BASELINE configs[3]); layer 1 is applied first
+# ---------------------------------------------------------------- composition planner (composed.jl:4-25; docs/src/flows.md:115)
+# `l8 ∘ … ∘ l1` is a nest of ComposedFunctions; the reference applies it stage by stage: one pass over the batch per layer
+# (8 224 B/sample for eight layers at dim 128).  Here the chain is flattened into application order and cut into PIECES, one launch each:
+#   * a maximal run of fusable elementwise stages (<= 8 ops)                   -> bjx_chain       (a ComposedFunction of the run)
+#   * a maximal run of PlanarLayers / of Inverse{<:PlanarLayer}s               -> bjx_planar, n_layers = the run  (PlanarRun; 1 028 B/sample)
+#   * any other planned bijector                                               -> its own entry
+#   * anything else (arbitrary Transforms)                                     -> the reference's generic method for that stage
+stages(b::ComposedFunction) = vcat(stages(b.inner), stages(b.outer))          # inner first (composed.jl:4)
+stages(::typeof(identity)) = Any[]
+stages(b) = Any[b]
+chain_of(run) = foldl((acc, st) -> st ∘ acc, run)                              # application order -> `last ∘ … ∘ first`
+planar_kind(st) = st isa PlanarLayer ? 1 : (st isa Inverse{<:PlanarLayer} ? -1 : 0)
+function pieces(b::ComposedFunction)
+    st = stages(b); out = Any[]; run = Any[]; i = 1
+    while i <= length(st)
+        cur = st[i]
+        if cur isa FusableLeaf                                                 # one op each: a run of at most 8 (BJX_MAX_OPS)
+            length(run) == 8 && (push!(out, chain_of(run)); run = Any[])
+            push!(run, cur); i += 1
+            continue
+        end
+        isempty(run) || (push!(out, chain_of(run)); run = Any[])
+        k = planar_kind(cur); j = i
+        while k != 0 && j < length(st) && planar_kind(st[j + 1]) == k
+            j += 1
+        end
+        if j > i
+            push!(out, k == 1 ? PlanarRun(PlanarLayer[st[m] for m in i:j], false) : PlanarRun(PlanarLayer[st[m].orig for m in j:-1:i], true))
+        else
+            push!(out, cur)
+        end
+        i = j + 1
+    end
+    isempty(run) || push!(out, chain_of(run))
+    return out
+end
+piece_wlj(pc, x) = (r = with_logabsdet_jacobian(pc, x); (r[1], r[2]))          # the flow layers return NamedTuples: by position
+
+# the six interface methods for a composition that is NOT one fused elementwise chain: piece by piece
+function with_logabsdet_jacobian(b::ComposedFunction, x::ROCArray{T}) where {T<:BjxFloat}
+    p = plan(b, x)
+    if p !== nothing                                                           # ONE fused elementwise chain
+        y = similar(x, T, p.outsize)
+        return y, run!(p, T, x, y)
+    end
+    cur = x; total = nothing
+    for pc in pieces(b)
+        cur, l = piece_wlj(pc, cur)
+        total = total === nothing ? l : total + l                              # ChangesOfVariables' rule for ∘: ladj_inner + ladj_outer
+    end
+    return cur, total
+end
+function transform(b::ComposedFunction, x::ROCArray{T}) where {T<:BjxFloat}
+    p = plan(b, x)
+    if p !== nothing
+        y = similar(x, T, p.outsize)
+        run!(p, T, x, y; want_ladj=false)
+        return y
+    end
+    return foldl((cur, pc) -> transform(pc, cur), pieces(b); init=x)           # composed.jl:4
+end
+function logabsdetjac(b::ComposedFunction, x::ROCArray{T}) where {T<:BjxFloat}
+    p = plan(b, x)
+    p === nothing || return run!(p, T, x, nothing)
+    pcs = pieces(b); cur = x; total = nothing
+    for pc in pcs[1:(end - 1)]                                                 # composed.jl:12-15: values of every piece but the last
+        cur, l = piece_wlj(pc, cur)
+        total = total === nothing ? l : total + l
+    end
+    l = logabsdetjac(pcs[end], cur)
+    return total === nothing ? l : total + l
+end
+function transform!(b::ComposedFunction, x::ROCArray{T}, y::ROCArray{T}) where {T<:BjxFloat}
+    p = plan(b, x)
+    if p !== nothing
+        size(y) == p.outsize || throw(DimensionMismatch("transform!: output of size $(size(y)), expected $(p.outsize)"))
+        run!(p, T, x, y; want_ladj=false)
+        return y
+    end
+    pcs = pieces(b)
+    transform!(pcs[1], x, y)                                                   # composed.jl:7-10
+    for pc in pcs[2:end]
+        transform!(pc, y, y)
+    end
+    return y
+end
+transform!(b::ComposedFunction, x::ROCArray{<:BjxFloat}) = transform!(b, x, x)
+function with_logabsdet_jacobian!(b::ComposedFunction, x::ROCArray{T}, y::ROCArray{T}, logjac) where {T<:BjxFloat}
+    p = plan(b, x)
+    if p !== nothing
+        size(y) == p.outsize || throw(DimensionMismatch("with_logabsdet_jacobian!: output of size $(size(y)), expected $(p.outsize)"))
+        return y, logjac .+ run!(p, T, x, y)
+    end
+    pcs = pieces(b)
+    _, logjac = with_logabsdet_jacobian!(pcs[1], x, y, logjac)                 # composed.jl:22-25
+    for pc in pcs[2:end]
+        _, logjac = with_logabsdet_jacobian!(pc, y, y, logjac)
+    end
+    return y, logjac
+end
+with_logabsdet_jacobian!(b::ComposedFunction, x::ROCArray{T}, y::ROCArray{T}) where {T<:BjxFloat} = with_logabsdet_jacobian!(b, x, y, zero(T))
+with_logabsdet_jacobian!(b::ComposedFunction, x::ROCArray{<:BjxFloat}) = with_logabsdet_jacobian!(b, x, x)
+logabsdetjac!(b::ComposedFunction, x::ROCArray{T}, logjac) where {T<:BjxFloat} = logjac .+ logabsdetjac(b, x)
+logabsdetjac!(b::ComposedFunction, x::ROCArray{T}) where {T<:BjxFloat} = logabsdetjac(b, x)
+
+# `planar_stack(layers, z)`: the same single launch for code that already holds the layers as a vector (layer 1 applied first)
 function planar_stack(layers::Vector{<:PlanarLayer}, z::ROCMatrix{T}; inverse::Bool=false, base_stdnormal::Bool=false, out=similar(z)) where {T<:BjxFloat}
-    d, n = size(z); L = length(layers)
-    w = ROCArray{T}(reduce(vcat, [Array(l.w) for l in layers])); u = ROCArray{T}(reduce(vcat, [Array(l.u) for l in layers]))
-    b = ROCArray{T}([first(Array(l.b isa Real ? [l.b] : l.b)) for l in layers])
-    lps = similar(z, n)
-    fl = base_stdnormal ? BJX_BASE_STDNORMAL : UInt32(0)
-    GC.@preserve w u b z out lps check(ccall((:bjx_planar, libbjx), Cint,
-        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
-        ctx().h, dtype(T), Cint(inverse), devptr(w), devptr(u), devptr(b), Cint(L), devptr(z), devptr(out), devptr(lps), C_NULL, d, n, fl), "bjx_planar")
-    return out, lps
+    p = plan_planar(PlanarLayer[l for l in layers], inverse, z, base_stdnormal ? BJX_BASE_STDNORMAL : UInt32(0))
+    return out, run!(p, T, z, out)
+end
+
+# Columnwise (interface.jl:41-78): `columnwise(f)` maps f over the columns and SUMS the log-dets — on a ROCMatrix of columns that
+# is the batched kernel of f itself.  `f(x)` goes through eachcolmaphcat (Bijectors.jl:118): route that to the kernel too.
+Bijectors.eachcolmaphcat(f::Planned, x::ROCMatrix{<:BjxFloat}) = transform(f, x)
+transform(f::Columnwise{<:Planned}, x::ROCMatrix{<:BjxFloat}) = transform(f.x, x)
+column_sum(l) = l isa ROCVector ? sum(l) : l                                   # per-column vector -> the scalar of interface.jl:75-77
+logabsdetjac(f::Columnwise{<:Planned}, x::ROCMatrix{<:BjxFloat}) = column_sum(logabsdetjac(f.x, x))
+function with_logabsdet_jacobian(f::Columnwise{<:Planned}, x::ROCMatrix{<:BjxFloat})
+    y, l = piece_wlj(f.x, x)
+    return y, column_sum(l)
 end
 
 # InvertibleBatchNorm in training mode on a batch sharded over ranks (normalise.jl:51-60; SURVEY.md §8e "Exception"), for
@@ -591,7 +734,100 @@ function with_logabsdet_jacobian!(sb::Stacked, x::ROCVecOrMat{T}, y::ROCVecOrMat
     y_, l = with_logabsdet_jacobian(sb, x)
     return copyto!(y, y_), logjac .+ l
 end
-# NamedStacked (named_stacked.jl:1-60) is Stacked over the concatenated fields: host side only, no entry of its own.
+# NamedStacked (named_stacked.jl:42-199): a NamedTuple of bijectors for ProductNamedTupleDistribution samples.  Forward takes a
+# NamedTuple of fields and returns ONE stacked array (:118-145): the fields are concatenated and sent through the equivalent
+# `Stacked`, so elementwise fields cost one bjx_stacked launch whatever their number; the inverse takes the stacked array and
+# returns the NamedTuple (:147-199).  Device batches: a field is a ROCMatrix (rows x batch), or a ROCVector holding one value per
+# column for a scalar field (an Int range) / one unbatched vector otherwise; at least one field must be a ROCArray, else the
+# reference's method runs.
+field_rows(r::Integer) = 1
+field_rows(r::AbstractUnitRange) = length(r)
+as_range(r::Integer) = r:r
+as_range(r::AbstractUnitRange) = r
+function named_as_stacked(ns::NamedStacked{names}) where {names}               # input ranges = cumulative input lengths
+    bs = Any[]; rin = UnitRange{Int}[]; off = 0
+    for nm in names
+        b = getfield(ns.transforms, nm); n_out = field_rows(getfield(ns.ranges, nm))
+        n_in = b === identity ? n_out : first(Bijectors.output_size(inverse(b), (n_out,)))
+        push!(bs, b); push!(rin, (off + 1):(off + n_in)); off += n_in
+    end
+    st = Stacked(Tuple(bs), rin)
+    collect(st.ranges_out) == [as_range(getfield(ns.ranges, nm)) for nm in names] ||
+        throw(ArgumentError("NamedStacked: ranges $(ns.ranges) do not match the output sizes of the transforms"))
+    return st
+end
+function named_cat(ns::NamedStacked{names}, x::NamedTuple{names}) where {names}
+    like = first(v for v in values(x) if v isa ROCArray); T = eltype(like)
+    nb = maximum(v isa ROCMatrix ? size(v, 2) : 0 for v in values(x)); batched = nb > 0
+    rows = Any[]
+    for nm in names
+        v = getfield(x, nm); scalar_field = getfield(ns.ranges, nm) isa Integer
+        v = v isa Real ? ROCArray{T}(fill(T(v), 1)) : ondevice(T, v)
+        if batched && v isa ROCVector
+            v = scalar_field && length(v) != 1 ? reshape(v, 1, :) : repeat(reshape(v, :, 1), 1, nb)
+        end
+        batched && size(v, 2) != nb && throw(DimensionMismatch("NamedStacked: fields with different batch sizes"))
+        push!(rows, v)
+    end
+    return reduce(vcat, rows)
+end
+const DeviceFields{names} = NamedTuple{names,<:Tuple{Vararg{Union{Real,AbstractVector,ROCArray}}}}
+function with_logabsdet_jacobian(ns::NamedStacked{names}, x::DeviceFields{names}) where {names}
+    any(v -> v isa ROCArray, values(x)) || return invoke(with_logabsdet_jacobian, Tuple{NamedStacked{names},NamedTuple{names}}, ns, x)
+    return with_logabsdet_jacobian(named_as_stacked(ns), named_cat(ns, x))
+end
+function transform(ns::NamedStacked{names}, x::DeviceFields{names}) where {names}
+    any(v -> v isa ROCArray, values(x)) || return invoke(transform, Tuple{NamedStacked{names},NamedTuple{names}}, ns, x)
+    return transform(named_as_stacked(ns), named_cat(ns, x))
+end
+function named_split(ns::NamedStacked{names}, st::Stacked, xs::ROCVecOrMat) where {names}
+    vals = map(names, Tuple(st.ranges_in)) do nm, r
+        piece = xs isa ROCVector ? xs[r] : xs[r, :]
+        getfield(ns.ranges, nm) isa Integer ? (xs isa ROCVector ? Array(piece)[1] : vec(piece)) : piece     # an Int range is a scalar field (:19-21)
+    end
+    return NamedTuple{names}(vals)
+end
+function with_logabsdet_jacobian(nsi::Inverse{<:NamedStacked{names}}, y::ROCVecOrMat{<:BjxFloat}) where {names}
+    st = named_as_stacked(nsi.orig)
+    xs, l = with_logabsdet_jacobian(inverse(st), y)
+    return named_split(nsi.orig, st, xs), l
+end
+transform(nsi::Inverse{<:NamedStacked}, y::ROCVecOrMat{<:BjxFloat}) = first(with_logabsdet_jacobian(nsi, y))
+logabsdetjac(nsi::Inverse{<:NamedStacked}, y::ROCVecOrMat{<:BjxFloat}) = last(with_logabsdet_jacobian(nsi, y))
+
+# ---------------------------------------------------------------- VectorBijectors products batched over chains (SURVEY.md §8f f-2)
+# src/vector/product/fill.jl:111-219: `product_distribution(fill(d, size...))` links every component with the SAME scalar map
+# (positive.jl:11-50 Exp / Log, truncated.jl:17-103 Truncate / Untruncate, common.jl:27 TypedIdentity); DynamicPPL calls it on every
+# log-density evaluation.  With one COLUMN per chain a (prod(size), n_chains) ROCMatrix is one bjx_chain launch; the log-det of a
+# chain is its column's entry of the returned ROCVector (the reference's scalar, per chain).
+const ScalarLink = Union{VB.Exp,VB.Log,VB.Truncate,VB.Untruncate,VB.TypedIdentity}
+op0(kind) = BjxOp(Int32(kind), 0, 0, 0, C_NULL, C_NULL)
+op2(kind, a, b=0.0) = BjxOp(Int32(kind), 1, Float64(a), Float64(b), C_NULL, C_NULL)
+scalar_ops(e::VB.Exp) = vcat(op0(OP_EXP), e.sign < 0 ? [op0(OP_SIGNFLIP)] : BjxOp[], iszero(e.bound) ? BjxOp[] : [op2(OP_SHIFT, e.bound)])        # sign * exp(y) + bound
+scalar_ops(l::VB.Log) = vcat(iszero(l.bound) ? BjxOp[] : [op2(OP_SHIFT, -l.bound)], l.sign < 0 ? [op0(OP_SIGNFLIP)] : BjxOp[], op0(OP_LOG))       # log(sign * (x - bound))
+scalar_ops(t::VB.Truncate) = [op2(OP_TRUNCATED_INV, t.lower, t.upper)]         # (-Inf, Inf) -> (a, b): the four branches of truncated.jl:28-48
+scalar_ops(u::VB.Untruncate) = [op2(OP_TRUNCATED, u.lower, u.upper)]           # (a, b) -> (-Inf, Inf), :79-99
+scalar_ops(::VB.TypedIdentity) = [op0(OP_IDENTITY)]
+function chains_launch(o::Vector{BjxOp}, x::ROCMatrix{T}, osz::Dims) where {T<:BjxFloat}
+    d, n = size(x); y = similar(x, T, osz); lps = similar(x, T, n)
+    GC.@preserve o x y lps check(ccall((:bjx_chain, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{BjxOp}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        ctx().h, dtype(T), o, length(o), devptr(x), devptr(y), devptr(lps), C_NULL, d, n, UInt32(0)), "bjx_chain")
+    return y, lps
+end
+# to_linked_vec / to_vec of the product: columns = chains, rows = vec of the components (fill.jl:111-159)
+function with_logabsdet_jacobian(t::VB.ProductVecTransform{<:VB.Elementwise{<:ScalarLink,Dims{M}},Nothing,Dims{0}}, x::ROCMatrix{T}) where {M,T<:BjxFloat}
+    size(x, 1) == prod(t.transforms.size) || throw(DimensionMismatch("expected $(prod(t.transforms.size)) rows (one column per chain), got $(size(x, 1))"))
+    return chains_launch(scalar_ops(t.transforms.value), x, size(x))
+end
+(t::VB.ProductVecTransform{<:VB.Elementwise{<:ScalarLink,Dims{M}},Nothing,Dims{0}})(x::ROCMatrix{<:BjxFloat}) where {M} = first(with_logabsdet_jacobian(t, x))
+# from_linked_vec / from_vec (fill.jl:161-219): a (prod(size), n_chains) matrix of linked vectors -> size... x n_chains components
+function with_logabsdet_jacobian(t::VB.ProductVecInvTransform{<:VB.Elementwise{<:ScalarLink,Dims{M}},Nothing,Dims{0}}, y::ROCMatrix{T}) where {M,T<:BjxFloat}
+    size(y, 1) == prod(t.transforms.size) || throw(DimensionMismatch("expected $(prod(t.transforms.size)) rows (one column per chain), got $(size(y, 1))"))
+    x, lps = chains_launch(scalar_ops(t.transforms.value), y, size(y))
+    return reshape(x, t.transforms.size..., size(y, 2)), lps
+end
+(t::VB.ProductVecInvTransform{<:VB.Elementwise{<:ScalarLink,Dims{M}},Nothing,Dims{0}})(y::ROCMatrix{<:BjxFloat}) where {M} = first(with_logabsdet_jacobian(t, y))
 
 # Stacked with Simplex / Ordered segments (stacked.jl:142-166) without slicing copies: the elementwise segments in one
 # bjx_stacked_ld launch between matrices of different heights (identity placeholders on the structured rows), then
@@ -753,17 +989,30 @@ function row_moments(a::ROCMatrix{T}, b::Union{Nothing,ROCMatrix{T}}=nothing) wh
     return out
 end
 
-# VecCholeskyBijector: the rules the reference ships (ext/BijectorsChainRulesCoreExt.jl:199-320), batched over samples
-function ChainRulesCore.rrule(::typeof(Bijectors._inv_link_chol_lkj), y::ROCMatrix{T}) where {T<:BjxFloat}   # columns = samples
-    K = Bijectors._triu1_dim_from_length(size(y, 1)); n = size(y, 2)
+# VecCholeskyBijector: the rule the reference ships for ONE packed vector (`_inv_link_chol_lkj(y::AbstractVector)`, corr.jl:370-451;
+# ext/BijectorsChainRulesCoreExt.jl:311-320) on a ROCVector, and the batched form — columns = samples — on the PUBLIC call
+# with_logabsdet_jacobian(inverse(VecCholeskyBijector), y::ROCMatrix).  (Not on `_inv_link_chol_lkj(::ROCMatrix)`: in the
+# reference that method takes ONE K x K matrix of free parameters, corr.jl:344-368, a different meaning of the argument.)
+function vec_cholesky_inv_pullback(ul::Cint, y::ROCVecOrMat{T}, ΔW, Δl) where {T}
+    m, n = dims(y); K = Bijectors._triu1_dim_from_length(m)
+    Δy = similar(y)
+    GC.@preserve y ΔW Δl Δy check(ccall((:bjx_vec_cholesky_inv_vjp, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+        ctx().h, dtype(T), ul, devptr(y), devptr(ΔW), devptr(Δl), devptr(Δy), K, n), "bjx_vec_cholesky_inv_vjp")
+    return Δy
+end
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), ib::Inverse{VecCholeskyBijector}, y::ROCVecOrMat{T}) where {T<:BjxFloat}
+    out = with_logabsdet_jacobian(ib, y)
+    function pullback_inverse_vec_cholesky((ΔW, ΔlogJ))
+        Δy = vec_cholesky_inv_pullback(uplo(ib.orig), y, cotangent(T, ΔW, out[1]), ladj_cotangent(T, ΔlogJ, dims(y)[2]))
+        return NoTangent(), NoTangent(), Δy
+    end
+    return out, pullback_inverse_vec_cholesky
+end
+function ChainRulesCore.rrule(::typeof(Bijectors._inv_link_chol_lkj), y::ROCVector{T}) where {T<:BjxFloat}       # one sample, the reference's meaning
     W, logJ = with_logabsdet_jacobian(inverse(VecCholeskyBijector(:U)), y)
     function pullback_inv_link_chol_lkj((ΔW, ΔlogJ))
-        Δy = similar(y)
-        ΔWc = cotangent(T, ΔW, W); Δlc = ladj_cotangent(T, ΔlogJ, n)
-        GC.@preserve y ΔWc Δlc Δy check(ccall((:bjx_vec_cholesky_inv_vjp, libbjx), Cint,
-            (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-            ctx().h, dtype(T), Cint('U'), devptr(y), devptr(ΔWc), devptr(Δlc), devptr(Δy), K, n), "bjx_vec_cholesky_inv_vjp")
-        return NoTangent(), Δy
+        return NoTangent(), vec_cholesky_inv_pullback(Cint('U'), y, cotangent(T, ΔW, W), ladj_cotangent(T, ΔlogJ, 1))
     end
     return (W, logJ), pullback_inv_link_chol_lkj
 end
@@ -783,52 +1032,100 @@ for (f, ul) in ((:_link_chol_lkj_from_upper, 'U'), (:_link_chol_lkj_from_lower, 
     end
 end
 
-# PlanarLayer: input pullback (bjx_planar_vjp) and, for the forward flow, the parameter cotangents (w̄, ū, b̄) through
-# get_u_hat in the same pass (bjx_planar_vjp_params).
-function planar_vjp(pl::PlanarLayer, inv::Bool, z::ROCMatrix{T}, Δy, Δl) where {T}
+# PlanarLayer (one layer or a planner run): input pullback (bjx_planar_vjp) and, for the forward flow, the parameter cotangents
+# (w̄, ū, b̄) through get_u_hat in the same pass (bjx_planar_vjp_params), on the layer-major tables of `planar_tables`.
+function planar_vjp(w, u, b, nl::Integer, inv::Bool, z::ROCMatrix{T}, Δy, Δl) where {T}
     z̄ = similar(z)
-    w, u, b = ondevice(T, pl.w), ondevice(T, pl.u), ondevice(T, pl.b isa Real ? [pl.b] : pl.b)
     GC.@preserve z Δy Δl z̄ w u b check(ccall((:bjx_planar_vjp, libbjx), Cint,
         (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-        ctx().h, dtype(T), Cint(inv), devptr(w), devptr(u), devptr(b), Cint(1), devptr(z), devptr(Δy), devptr(Δl), devptr(z̄),
+        ctx().h, dtype(T), Cint(inv), devptr(w), devptr(u), devptr(b), Cint(nl), devptr(z), devptr(Δy), devptr(Δl), devptr(z̄),
         size(z, 1), size(z, 2)), "bjx_planar_vjp")
     return z̄
 end
-function planar_vjp_params(pl::PlanarLayer, z::ROCMatrix{T}, Δy, Δl) where {T}
+function planar_vjp_params(w, u, b, nl::Integer, z::ROCMatrix{T}, Δy, Δl) where {T}
     z̄ = similar(z)
-    w, u, b = ondevice(T, pl.w), ondevice(T, pl.u), ondevice(T, pl.b isa Real ? [pl.b] : pl.b)
     w̄, ū, b̄ = similar(w), similar(u), similar(b)
-    work = similar(z, 2 * size(z, 2))                      # 2 * n_layers * batch, one layer
+    work = similar(z, 2 * nl * size(z, 2))                 # 2 * n_layers * batch
     GC.@preserve z Δy Δl z̄ w u b w̄ ū b̄ work check(ccall((:bjx_planar_vjp_params, libbjx), Cint,
         (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
          Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-        ctx().h, dtype(T), devptr(w), devptr(u), devptr(b), Cint(1), devptr(z), devptr(Δy), devptr(Δl), devptr(z̄),
+        ctx().h, dtype(T), devptr(w), devptr(u), devptr(b), Cint(nl), devptr(z), devptr(Δy), devptr(Δl), devptr(z̄),
         devptr(w̄), devptr(ū), devptr(b̄), devptr(work), size(z, 1), size(z, 2)), "bjx_planar_vjp_params")
     return z̄, w̄, ū, b̄
+end
+# (z̄, per-layer tangents in the order of `layers`) of a run; inv: implicit function theorem (the reference differentiates the
+# Newton root through its find_alpha rule, ext/BijectorsChainRulesCoreExt.jl:42-46): with x = f⁻¹(y) and the inverse's log-det
+# -ℓ(x),  ȳ = J⁻ᵀ(x̄ - ℓ̄ ∇ₓℓ)  (bjx_planar_vjp, inverse = 1)  and  θ̄ = the FORWARD parameter pullback at x with cotangents
+# (-ȳ, -ℓ̄)  (bjx_planar_vjp_params) — no new kernel, the root is not differentiated through.
+function planar_run_pullback(layers, inv::Bool, z::ROCMatrix{T}, x, Δy, Δl) where {T}
+    d = size(z, 1); nl = length(layers)
+    w, u, b = planar_tables(T, layers, d)
+    if inv
+        z̄ = planar_vjp(w, u, b, nl, true, z, Δy, Δl)
+        _, w̄, ū, b̄ = planar_vjp_params(w, u, b, nl, x, -z̄, Δl === nothing ? nothing : -Δl)
+    else
+        z̄, w̄, ū, b̄ = planar_vjp_params(w, u, b, nl, z, Δy, Δl)
+    end
+    ts = [Tangent{typeof(layers[k])}(w = w̄[((k - 1) * d + 1):(k * d)], u = ū[((k - 1) * d + 1):(k * d)], b = b̄[k:k]) for k in 1:nl]
+    return z̄, ts
 end
 function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::PlanarLayer, z::ROCMatrix{T}) where {T<:BjxFloat}
     out = with_logabsdet_jacobian(flow, z)
     function pullback_planar_params((Δy, Δl))
-        z̄, w̄, ū, b̄ = planar_vjp_params(flow, z, cotangent(T, Δy, z), ladj_cotangent(T, Δl, size(z, 2)))
-        return NoTangent(), Tangent{typeof(flow)}(w = w̄, u = ū, b = b̄), z̄
+        z̄, ts = planar_run_pullback(PlanarLayer[flow], false, z, nothing, cotangent(T, Δy, z), ladj_cotangent(T, Δl, size(z, 2)))
+        return NoTangent(), ts[1], z̄
     end
     return out, pullback_planar_params
 end
-# inverse(PlanarLayer): input pullback AND parameter cotangents.  Implicit function theorem (the reference differentiates the
-# Newton root through its find_alpha rule, ext/BijectorsChainRulesCoreExt.jl:42-46): with x = f⁻¹(y) and the inverse's log-det
-# -ℓ(x),  ȳ = J⁻ᵀ(x̄ - ℓ̄ ∇ₓℓ)  (bjx_planar_vjp, inverse = 1)  and  θ̄ = the FORWARD parameter pullback at x with cotangents
-# (-ȳ, -ℓ̄)  (bjx_planar_vjp_params) — no new kernel, the root is not differentiated through.
 function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), flow::Inverse{<:PlanarLayer}, y::ROCMatrix{T}) where {T<:BjxFloat}
-    pl = flow.orig
     out = with_logabsdet_jacobian(flow, y)
-    x = out[1]                                                  # the pre-image: the point where the forward rule is evaluated
     function pullback_planar((Δx, Δl))
-        Δlc = ladj_cotangent(T, Δl, size(y, 2))
-        ȳ = planar_vjp(pl, true, y, cotangent(T, Δx, x), Δlc)
-        _, w̄, ū, b̄ = planar_vjp_params(pl, x, -ȳ, Δlc === nothing ? nothing : -Δlc)
-        return NoTangent(), Tangent{typeof(flow)}(orig = Tangent{typeof(pl)}(w = w̄, u = ū, b = b̄)), ȳ
+        ȳ, ts = planar_run_pullback(PlanarLayer[flow.orig], true, y, out[1], cotangent(T, Δx, y), ladj_cotangent(T, Δl, size(y, 2)))
+        return NoTangent(), Tangent{typeof(flow)}(orig = ts[1]), ȳ
     end
     return out, pullback_planar
+end
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), r::PlanarRun, z::ROCMatrix{T}) where {T<:BjxFloat}
+    out = with_logabsdet_jacobian(r, z)
+    function pullback_planar_run((Δy, Δl))
+        z̄, ts = planar_run_pullback(r.layers, r.inv, z, out[1], cotangent(T, Δy, z), ladj_cotangent(T, Δl, size(z, 2)))
+        return NoTangent(), Tangent{PlanarRun}(layers = ts), z̄
+    end
+    return out, pullback_planar_run
+end
+
+# A composition on a ROCArray: the chain rule over the planner's pieces, every piece through its own rule (PlanarRun, RadialLayer,
+# splines, elementwise chains …) or, for stages the ABI does not carry, the AD package.  The log-det is the SUM of the pieces'
+# log-dets, so every piece receives the same ℓ̄.  The piece tangents are folded back onto the nest of ComposedFunctions.
+stage_tangents(pc::PlanarRun, t) = (ts = unthunk(t).layers; pc.inv ? Any[Tangent{Inverse{typeof(l)}}(orig = tl) for (l, tl) in zip(reverse(pc.layers), reverse(ts))] : Any[ts...])
+stage_tangents(pc::ComposedFunction, t) = Any[NoTangent() for _ in stages(pc)]      # an elementwise run: parameters via meanfield_pullback
+stage_tangents(pc, t) = Any[t]
+fold_tangent(::typeof(identity), ts, i) = (NoTangent(), i)
+fold_tangent(b, ts, i) = (ts[i], i + 1)
+function fold_tangent(b::ComposedFunction, ts, i)                                   # stages are numbered inner first
+    ti, i = fold_tangent(b.inner, ts, i)
+    to, i = fold_tangent(b.outer, ts, i)
+    return Tangent{typeof(b)}(outer = to, inner = ti), i
+end
+function ChainRulesCore.rrule(cfg::ChainRulesCore.RuleConfig{>:ChainRulesCore.HasReverseMode}, ::typeof(with_logabsdet_jacobian),
+                              b::ComposedFunction, x::ROCVecOrMat{T}) where {T<:BjxFloat}
+    fused = ChainRulesCore.rrule(with_logabsdet_jacobian, b, x)                     # ONE elementwise segment (<= 4 ops): its own rule
+    fused === nothing || return fused
+    pcs = pieces(b); cur = x; total = nothing; backs = Any[]
+    for pc in pcs
+        out, back = ChainRulesCore.rrule_via_ad(cfg, with_logabsdet_jacobian, pc, cur)
+        push!(backs, back)
+        cur = out[1]; total = total === nothing ? out[2] : total + out[2]
+    end
+    function pullback_composed((Δy, Δl))
+        g = Δy; ts = Any[]
+        for k in length(pcs):-1:1
+            _, t, g = backs[k]((g, Δl))
+            prepend!(ts, stage_tangents(pcs[k], t))
+        end
+        return NoTangent(), first(fold_tangent(b, ts, 1)), g
+    end
+    return (cur, total), pullback_composed
 end
 
 # RadialLayer: input pullback of both directions (bjx_radial_vjp) and the parameter cotangents (ᾱ_, β̄, z̄₀) of the forward
@@ -1003,9 +1300,14 @@ function Distributions.logpdf(td::Bijectors.MvTransformed{<:Distributions.MvNorm
         return lp
     end
     # a PlanarLayer with a standard-normal base: the inverse flow with BJX_BASE_STDNORMAL, pre-image not stored
-    if td.transform isa PlanarLayer && all(iszero, μ) && all(isone, σ)
-        p = plan_planar(td.transform, true, y, BJX_BASE_STDNORMAL)
-        return run!(p, T, y, nothing)
+    if all(iszero, μ) && all(isone, σ)
+        tr = td.transform
+        pcs = tr isa ComposedFunction ? pieces(tr) : Any[tr]                         # l8 ∘ … ∘ l1: the planner's single forward run
+        layers = length(pcs) != 1 ? nothing : pcs[1] isa PlanarLayer ? PlanarLayer[pcs[1]] : (pcs[1] isa PlanarRun && !pcs[1].inv ? pcs[1].layers : nothing)
+        if layers !== nothing
+            p = plan_planar(layers, true, y, BJX_BASE_STDNORMAL)
+            return run!(p, T, y, nothing)
+        end
     end
     # anything else: x, logjac = with_logabsdet_jacobian(inverse(td.transform), y), then the base density on x
     x, logjac = with_logabsdet_jacobian(inverse(td.transform), y)
