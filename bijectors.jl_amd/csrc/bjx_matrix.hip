@@ -731,7 +731,8 @@ __global__ __launch_bounds__(256) void matrix_big_kernel(const T* __restrict__ i
 
 template <class T, int KIND>
 int matrix_big(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags) {
-  BJX_REQUIRE(ctx, K <= 4096, BJX_ERR_UNSUPPORTED, "K = %lld: beyond the general-size kernel's index range", (long long)K);
+  // one block per sample, serial pivots: O(K^3) per sample — K = 1024 is ~0.2 s per wave of samples, 4096 would run for minutes
+  BJX_REQUIRE(ctx, K <= 1024, BJX_ERR_UNSUPPORTED, "K = %lld: the general-size matrix kernel stops at 1024 (serial O(K^3) pivots per sample)", (long long)K);
   int64_t grid = batch < 2 * (int64_t)ctx->num_cu ? batch : 2 * (int64_t)ctx->num_cu;
   while (grid > 1 && (size_t)grid * K * K * sizeof(T) > ((size_t)1 << 31)) grid >>= 1;      // workspace <= 2 GiB
   { int rc = bjx_ensure_big_ws(ctx, (size_t)grid * K * K * sizeof(T)); if (rc) return rc; }
@@ -1104,7 +1105,9 @@ __global__ __launch_bounds__(256) void scale_matrix_big_kernel(const T* __restri
 template <class T>
 int scale_matrix_impl(bjx_ctx* ctx, int inverse, const T* a, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
   if (dim > 128 || (size_t)dim * 2 * dim * sizeof(T) > BJX_SCRATCH_BYTES) {
-    BJX_REQUIRE(ctx, dim <= 8192, BJX_ERR_UNSUPPORTED, "bjx_scale_matrix: dim = %lld: beyond the general-size kernel's range", (long long)dim);
+    // the factorisation behind logabsdet / the inverse is ONE block's Gauss-Jordan sweep, O(dim^3) serial pivots, redone on every
+    // call: ~0.2 s at 1024, minutes at 8192 (a launch that long looks like a hang).  Larger systems belong to a blocked LU (rocSOLVER).
+    BJX_REQUIRE(ctx, dim <= 1024, BJX_ERR_UNSUPPORTED, "bjx_scale_matrix: dim = %lld: the general-size path stops at 1024 (single-block O(dim^3) factorisation per call)", (long long)dim);
     { int rc = bjx_ensure_big_ws(ctx, (size_t)dim * 2 * dim * sizeof(T)); if (rc) return rc; }
     T* Wb = reinterpret_cast<T*>(ctx->big_ws);
     double* ladb = ctx->consts + 2;

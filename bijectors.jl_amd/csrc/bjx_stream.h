@@ -537,7 +537,17 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
     // (up to 96 packs only — same-box A/B, % of the HBM peak, slabs / column loop: BatchNorm 257 rows 53 / 39, 300 rows 53 / 52,
     //  500 rows 57 / 61; Coupling 300 rows 47 / 35, 500 rows 49 / 50: every block stages the functor's whole table, and from two
     //  packs per lane on the column loop has two columns in flight anyway)
-    if (use_slab && dense && row0 == 0 && !force_v1 && dim > slab && dim <= slab + slab / 2 && col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy, true).V == VWs) {
+    // Every slab window must resolve to the pack width of the whole-column call: functors with a V-permuted table (StackedF) were
+    // built for THAT width, and a short last slab (fewer than two packs of rows: Float32 dim 261-263, Float64 dim 131) would fall
+    // to V = 1 and read the table at the wrong slots.  Such heights take the single launch.
+    auto slabs_keep_v = [&]() {
+      for (int64_t r0 = 0; r0 < dim; r0 += slab) {
+        const int64_t rs = dim - r0 < slab ? dim - r0 : slab;
+        if (col_launch_cfg<T>(ctx, x + r0, y + r0, rs, batch, dim, dim, true).V != VWs) return false;
+      }
+      return true;
+    };
+    if (use_slab && dense && row0 == 0 && !force_v1 && dim > slab && dim <= slab + slab / 2 && col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy, true).V == VWs && slabs_keep_v()) {
       for (int64_t r0 = 0; r0 < dim; r0 += slab) {
         const int64_t rs = dim - r0 < slab ? dim - r0 : slab;
         F fw = f;

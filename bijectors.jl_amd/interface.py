@@ -1196,6 +1196,10 @@ class RadialLayer(Bijector):
         return self._run(x, True, per_sample, want_ladj)
 
 
+def _batch_tag(x):
+    return (x.data_ptr(), x._version, tuple(x.shape), x.dtype)
+
+
 _TRAINING = [False]
 
 
@@ -1260,14 +1264,36 @@ class InvertibleBatchNorm(Bijector):
             # statistics of this rank's columns -> ONE sum all-reduce of 2·dim+1 Float64 values when the batch is sharded
             # (SURVEY.md §8e "Exception"; torch.distributed or the library's communicator) -> update + transform
             stats = self.batch_stats(x)
-            if self.sync is not None and self.sync is not False:
+            grp = self._sync_group()
+            if grp is not False:
                 from . import shard as _shard
 
-                _shard.allreduce_logabsdetjac(stats, None if self.sync is True else self.sync)
+                _shard.allreduce_logabsdetjac(stats, grp)
             return self.apply_batch_stats(x, stats, per_sample, want_ladj)
         ps = [_param(t, x) for t in (self.b, self.logs, self.m, self.v)]
         return _call_struct("bjx_batchnorm", x, dim, True, per_sample, want_ladj,
                             (int(inv), *[_ptr(p) for p in ps], self.eps), (dim,))
+
+    _warned_unsynced = [False]
+
+    def _sync_group(self):
+        """False: statistics of this process's columns only; None: all-reduce over the default group; a ProcessGroup: over it.
+        `sync=None` (unspecified) inside a multi-process job is almost always a sharded batch whose ranks would silently
+        normalise with different statistics and let their m / v replicas drift apart: warn once and say how to choose."""
+        if self.sync is None:
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not InvertibleBatchNorm._warned_unsynced[0]:
+                import warnings
+
+                InvertibleBatchNorm._warned_unsynced[0] = True
+                warnings.warn("InvertibleBatchNorm(sync=None) in a multi-process job: training mode normalises with THIS rank's batch statistics "
+                              "and every rank updates its own m / v.  Pass sync=True (batch sharded over the default group: one all-reduce of the "
+                              "2·dim+1 sums per call), a ProcessGroup, or sync=False to keep per-rank statistics on purpose.", RuntimeWarning, stacklevel=4)
+            return False
+        if self.sync is False:
+            return False
+        return None if self.sync is True else self.sync
 
     def batch_stats(self, x):
         """(Σ(x − m), Σ(x − m)², n) of these columns as a float64 tensor of 2·dim+1 entries (bjx_batchnorm_stats); sums of
@@ -1289,7 +1315,9 @@ class InvertibleBatchNorm(Bijector):
         # training-mode pullback (bjx_batchnorm_train_vjp); dim-sized device arithmetic, Float64
         n = stats[2 * dim]
         s1, s2 = stats[:dim] / n, stats[dim:2 * dim] / n
-        self._batch_stats = ((self.m.double() + s1).to(x.dtype), (s2 - s1 * s1).to(x.dtype))
+        # … tagged with the batch they belong to: the pullback refuses any other (two forward calls before one backward — micro-batches,
+        # a validation batch, the layer used twice in a flow — would otherwise give wrong gradients without an error)
+        self._batch_stats = ((self.m.double() + s1).to(x.dtype), (s2 - s1 * s1).to(x.dtype), _batch_tag(x))
         return _call_struct("bjx_batchnorm_train_apply", x, dim, True, per_sample, want_ladj,
                             (_ptr(b), _ptr(logs), _ptr(self.m), _ptr(self.v), self.eps, self.mtm, _ptr(stats)), (dim,))
 
@@ -2388,17 +2416,21 @@ def _vjp_params_batchnorm_training(bn, x, out_bar, ladj_bar=None):
     st = getattr(bn, "_batch_stats", None)
     if st is None or st[0].numel() != dim or st[0].dtype != xc.dtype:
         raise RuntimeError("training-mode pullback of InvertibleBatchNorm: run the training-mode forward pass on this batch first")
-    mean_b, var_b = st
+    if st[2] != _batch_tag(x):
+        raise RuntimeError("training-mode pullback of InvertibleBatchNorm: the saved batch statistics belong to a different forward call "
+                           "(another batch went through this bijector in between, or x was modified): run the forward pass on THIS batch right before its pullback")
+    mean_b, var_b = st[0], st[1]
     ctx = context(xc.device)
     lib = L.load()
     mom = torch.empty(2 * dim + 2, dtype=torch.float64, device=xc.device)       # (Σȳ, Σȳx, N, Σℓ̄): ONE bucket for the collective
     L.check(ctx.h, lib.bjx_row_moments(ctx.h, _dt(xc), _ptr(gc), _ptr(xc), _ptr(mom), dim, batch), "bjx_row_moments")
     lb = _ladj_bar(ladj_bar, batch, xc)
     mom[2 * dim + 1] = lb.double().sum() if lb is not None else 0.0
-    if bn.sync is not None and bn.sync is not False:
+    grp = bn._sync_group()
+    if grp is not False:
         from . import shard as _shard
 
-        _shard.allreduce_logabsdetjac(mom, None if bn.sync is True else bn.sync)
+        _shard.allreduce_logabsdetjac(mom, grp)
     logs = _param(bn.logs, xc)
     xb = _empty(dim, batch, xc, vec)
     b_bar, logs_bar = torch.empty(dim, dtype=xc.dtype, device=xc.device), torch.empty(dim, dtype=xc.dtype, device=xc.device)
@@ -2466,7 +2498,7 @@ class MvNormal:
     """Base distribution of a `TransformedDistribution` (src/transformed_distribution.jl:159-240 takes any `MvNormal`):
     `MvNormal(dim)` the standard normal (the base of every flow in the reference's docs/tests, e.g. test/normalising_flows.jl:74-91),
     `MvNormal(μ, σ)` the diagonal `MvNormal(μ, Diagonal(σ.^2))`, `MvNormal(μ, cov=Σ)` / `MvNormal(μ, scale_tril=L)` a FULL
-    covariance Σ = L Lᵀ: whitening is the matrix `Scale` of scale.jl:14-36 (x ↦ L \ (x − μ), log-det −logabsdet L: bjx_scale_matrix)."""
+    covariance Σ = L Lᵀ: whitening is the matrix `Scale` of scale.jl:14-36 (x ↦ L⁻¹ (x − μ), log-det −logabsdet L: bjx_scale_matrix)."""
 
     def __init__(self, mu, sigma=None, cov=None, scale_tril=None):
         self.scale_tril = None

@@ -124,15 +124,25 @@ def vjp_params_sharded(b, x_shard: torch.Tensor, out_bar_shard: torch.Tensor, la
     The input cotangent stays sharded like the data."""
     from . import interface as I
 
+    # a sharded training step must not normalise with per-rank batch statistics by accident: every InvertibleBatchNorm of the chain
+    # has to say how its batch is sharded (sync=True / a group) or that per-rank statistics are intended (sync=False)
+    if I.istraining():
+        for st in (b._stages() if isinstance(b, I.ComposedFunction) else [b]):
+            base = st.orig if isinstance(st, I.Inverse) else st
+            if isinstance(base, I.InvertibleBatchNorm) and base.sync is None:
+                raise ValueError("vjp_params_sharded: InvertibleBatchNorm(sync=None) in training mode — pass sync=True (statistics of the "
+                                 "whole sharded batch) or sync=False (per-rank statistics on purpose)")
     x_bar, grads = I.vjp_params(b, x_shard, out_bar_shard, ladj_bar_shard)
     return x_bar, allreduce_param_cotangents(grads, group)
 
 
 def init_comm(device: Optional[torch.device] = None, group=None, timeout_ms: int = 0) -> None:
-    """Give this rank's context an RCCL communicator (bjx_comm_init) so that entry points with an
-    in-library collective — InvertibleBatchNorm in training mode: one all-reduce of the 2·dim+1 Float64
-    batch sums, SURVEY.md §8(e) — see the GLOBAL batch.  The 128-byte ncclUniqueId is made on rank 0 and
-    broadcast through torch.distributed (any backend).  No-op for a single process."""
+    """Give this rank's context an RCCL communicator (bjx_comm_init): `use_library_collective()` then routes the Σ logabsdetjac
+    all-reduce (and the parameter-cotangent bucket) through bjx_allreduce_sum_f64 on the context's stream, and the C entry
+    bjx_batchnorm_train — what a Julia host calls — sees the GLOBAL batch (one all-reduce of the 2·dim+1 Float64 sums,
+    SURVEY.md §8e).  The Python `InvertibleBatchNorm` does NOT go through that entry: it all-reduces its statistics itself and
+    only when constructed with `sync=True` / a group (sync=None warns once in a multi-process job, `vjp_params_sharded` refuses
+    it).  The 128-byte ncclUniqueId is made on rank 0 and broadcast through torch.distributed (any backend).  No-op for a single process."""
     import ctypes as C
 
     import torch.distributed as dist

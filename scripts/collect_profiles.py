@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/<TAG>/ (written by scripts/gpu_profile.sh on the GPU box) into the tracked
+"""Turns gpurun_out/<TAG>/ (written by `scripts/gpu_run.sh profile <TAG>` on the GPU box) into the tracked
 evidence under profiles/: <TAG>_bench_lines.jsonl, <TAG>_<wl>_kernel_stats.csv (top rows),
 <TAG>_<wl>_pmc_{FETCH,WRITE}_SIZE.csv (dominant-kernel rows) and profiles/traffic.json.
 
@@ -71,7 +71,13 @@ def main(tag):
         with open(os.path.join(dst, f"{tag}_bench_lines.jsonl"), "w") as f:
             f.write("\n".join(lines) + "\n")
     json.dump(traffic, open(traffic_path, "w"), indent=1)
-    for extra in ("bench_default.json", "rows.md", "rows_kernel_stats.csv", "f64_rows.md", "f64math_bench.txt", "planar_mfma_ab.txt", "small_sizes.md"):
+    # which binary the evidence belongs to (tests/test_profiles_fresh.py: the kernel names of these files must exist in the .so of the tree)
+    sha = os.path.join(src, "lib_sha16.txt")
+    if os.path.exists(sha):
+        traffic["_lib_sha16"] = open(sha).read().strip()
+        traffic["_tag"] = tag
+    for extra in ("bench_default.json", "bench_default_detail.json", "rows.md", "rows_kernel_stats.csv", "f64_rows.md", "f64math_bench.txt", "planar_mfma_ab.txt", "small_sizes.md",
+                  "lib_sha16.txt", "lib_bytes.txt", "first_call.txt"):
         pe = os.path.join(src, extra)
         if os.path.exists(pe) and os.path.getsize(pe) > 2:
             with open(pe) as fi, open(os.path.join(dst, f"{tag}_{extra}"), "w") as fo:

@@ -243,6 +243,26 @@ def _worker_params(rank, world, port, q):
         ok = False
     except TypeError:
         pass
+    # InvertibleBatchNorm in a multi-process job: sync unspecified = per-rank statistics WITH a warning (once);
+    # sync=False the same on purpose, silently; sync=True the default group; a sharded training step refuses sync=None
+    import warnings
+
+    bj.InvertibleBatchNorm._warned_unsynced[0] = False
+    with warnings.catch_warnings(record=True) as wrec:
+        warnings.simplefilter("always")
+        g0 = bj.InvertibleBatchNorm(3)._sync_group()
+        g0b = bj.InvertibleBatchNorm(3)._sync_group()
+    ok = ok and g0 is False and g0b is False and len([w_ for w_ in wrec if issubclass(w_.category, RuntimeWarning)]) == 1
+    with warnings.catch_warnings(record=True) as wrec:
+        warnings.simplefilter("always")
+        ok = ok and bj.InvertibleBatchNorm(3, sync=False)._sync_group() is False and bj.InvertibleBatchNorm(3, sync=True)._sync_group() is None
+    ok = ok and not wrec
+    with bj.training():
+        try:
+            bj.shard.vjp_params_sharded(bj.InvertibleBatchNorm(3) @ bj.Shift(1.0), None, None)
+            ok = False
+        except ValueError as e:
+            ok = ok and "sync" in str(e)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, bool(ok), st["u"].numpy().tobytes()))
@@ -317,3 +337,29 @@ def test_julia_binding_argument_counts_match_the_header():
         name, types = m.group(1), [t.strip() for t in m.group(2).split(",") if t.strip()]
         assert name in protos, f"{name} is not declared in include/bjx.h"
         assert protos[name] == len(types), f"{name}: header has {protos[name]} arguments, the Julia ccall passes {len(types)}"
+
+
+def test_composition_planner_merges_planar_runs(bj):
+    """Host logic of the planner (no GPU): maximal runs of PlanarLayer stages become one `_PlanarRun`, inverse runs the inverse of
+    the REVERSED run; other stages are untouched and the spans map the planned stages back onto `_stages()`."""
+    import torch
+
+    I = bj.interface
+    ls = [bj.PlanarLayer(torch.full((3,), float(k)), torch.ones(3), torch.zeros(1)) for k in range(5)]
+    rad = bj.RadialLayer(torch.zeros(1), torch.zeros(1), torch.zeros(3))
+    flow = ls[4] @ ls[3] @ bj.Shift(1.0) @ ls[2] @ ls[1] @ ls[0] @ rad                  # application order: rad, l0, l1, l2, Shift, l3, l4
+    st, spans = flow._plan()
+    assert [type(x).__name__ for x in st] == ["RadialLayer", "_PlanarRun", "Shift", "_PlanarRun"] and spans == [(0, 1), (1, 4), (4, 5), (5, 7)]
+    assert st[1].layers == ls[0:3] and st[3].layers == ls[3:5] and st[1].n_layers == 3
+    assert flow._plan() is flow._plan()                                                   # cached while the stage objects are the same
+    inv = bj.inverse(flow)                                                                # inv(l4), inv(l3), Shift(-1), inv(l2), inv(l1), inv(l0), inv(rad)
+    sti, spi = inv._plan()
+    assert [type(x).__name__ for x in sti] == ["Inverse", "Shift", "Inverse", "Inverse"] and spi == [(0, 2), (2, 3), (3, 6), (6, 7)]
+    assert isinstance(sti[0].orig, I._PlanarRun) and sti[0].orig.layers == [ls[3], ls[4]]  # the forward flow of the run applies l3 then l4
+    assert sti[2].orig.layers == ls[0:3] and isinstance(sti[3].orig, bj.RadialLayer)
+    single = ls[1] @ bj.Shift(0.5)
+    assert single._plan()[0][1] is ls[1]                                                  # a lone layer stays itself
+    run = bj.PlanarLayer.stack(ls[:2])
+    assert isinstance(run, I._PlanarRun) and tuple(run.w.shape) == (3, 2) and torch.equal(run.w[:, 1], ls[1].w)
+    stacked2d = bj.PlanarLayer(torch.zeros(3, 2), torch.zeros(3, 2), torch.zeros(2))
+    assert (ls[0] @ stacked2d)._plan()[0][0].n_layers == 3                                # a (dim, n_layers) layer joins a run column by column
