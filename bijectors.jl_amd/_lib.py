@@ -87,6 +87,10 @@ SIGNATURES = {
     "bjx_corr": (_i, [_vp, _i, _i, _vp, _vp] + _tail),
     "bjx_pd": (_i, [_vp, _i, _i, _vp, _vp] + _tail),
     "bjx_pd_vec": (_i, [_vp, _i, _i, _vp, _vp] + _tail),
+    "bjx_vec_corr_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "bjx_corr_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "bjx_pd_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "bjx_pd_vec_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_scale_matrix": (_i, [_vp, _i, _i, _vp, _vp, _vp] + _tail),
     "bjx_planar": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp] + _tail),
     "bjx_pack_vectors": (_i, [_vp, _i, _i, C.POINTER(_vp), _i64, _vp]),

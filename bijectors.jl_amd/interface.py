@@ -2017,6 +2017,13 @@ def vjp(b, x, out_bar, ladj_bar=None):
         return Wb[:, :, 0] if vec else Wb
     inv = isinstance(b, Inverse)
     base = b.orig if inv else b
+    if isinstance(base, _MatrixBijector):
+        return _vjp_matrix(base, inv, x, out_bar, ladj_bar)
+    if isinstance(base, Scale) and base.matrix:
+        # y = a x: x̄ = aᵀ ȳ; x = a \ y: ȳ = a⁻ᵀ x̄ (the input side of ext/BijectorsReverseDiffExt.jl:72-115; the log-det does not
+        # depend on the input) — the same entry with the transposed matrix
+        at = colmajor(_param(base.a, out_bar)).T
+        return transform(inverse(Scale(at)) if inv else Scale(at), out_bar)
     if isinstance(base, SimplexBijector):
         xc, rows, batch, vec = _prep(x)
         gc, grows, gbatch, _ = _prep(out_bar)
@@ -2099,6 +2106,78 @@ def vjp(b, x, out_bar, ladj_bar=None):
     rc = L.load().bjx_ordered_vjp(ctx.h, _dt(xc), int(inv), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), dim, batch)
     L.check(ctx.h, rc, "bjx_ordered_vjp")
     return xb
+
+
+def _vjp_matrix(base, inv, x, out_bar, ladj_bar):
+    """Pullback of VecCorrBijector / CorrBijector / PDBijector / PDVecBijector and their inverses (bjx_*_vjp): the rules the
+    reference ships, chained per sample — pd_from_upper / pd_from_lower (ext/BijectorsChainRulesCoreExt.jl:324-331,
+    ext/BijectorsReverseDiffExt.jl:143-193), _inv_link_chol_lkj (corr.jl:402-451), replace_diag — and, for the forward direction, the
+    cotangent of the link through the reverse of cholesky(Hermitian(X)), on the triangle the reference reads.  `out_bar` has the
+    shape of the output: a (K, K[, batch]) matrix for the inverse direction (any matrix, not assumed symmetric)."""
+    _check_dev(x)
+    fn = base._FN + "_vjp"
+    if inv:
+        if base._VEC:
+            xc, n, batch, single = _prep(x)
+            K = base._K(n)
+            if base._n(K) != n:
+                raise ValueError(f"DimensionMismatch: {n} is not a valid packed length for {type(base).__name__}")
+        else:
+            if x.dim() not in (2, 3) or x.shape[0] != x.shape[1]:
+                raise ValueError(f"DimensionMismatch: inverse({type(base).__name__}) expects a square (K, K[, batch]) matrix")
+            K, single = x.shape[0], x.dim() == 2
+            batch = 1 if single else x.shape[2]
+            xc = _dense3(x)
+        want = (K, K) if single else (K, K, batch)
+        if tuple(out_bar.shape) != want or out_bar.dtype != x.dtype:
+            raise ValueError(f"DimensionMismatch: out_bar must be {want} with the dtype of the input")
+        gc = _dense3(out_bar)
+    else:
+        if x.dim() not in (2, 3) or x.shape[0] != x.shape[1]:
+            raise ValueError(f"DimensionMismatch: {type(base).__name__} expects a square (K, K[, batch]) matrix")
+        K, single = x.shape[0], x.dim() == 2
+        batch = 1 if single else x.shape[2]
+        xc = _dense3(x)
+        if base._VEC:
+            gc, gn, gbatch, _ = _prep(out_bar)
+            if (gn, gbatch) != (base._n(K), batch) or gc.dtype != x.dtype:
+                raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
+        else:
+            if tuple(out_bar.shape) != tuple(x.shape) or out_bar.dtype != x.dtype:
+                raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
+            gc = _dense3(out_bar)
+    lb = _ladj_bar(ladj_bar, batch, xc)
+    ctx = context(x.device)
+    if inv and base._VEC:
+        xb = _empty(xc.shape[0], batch, xc, single)
+    elif single:
+        xb = torch.empty((K, K), dtype=x.dtype, device=x.device).T
+    else:
+        xb = torch.empty((batch, K, K), dtype=x.dtype, device=x.device).permute(2, 1, 0)
+    rc = getattr(L.load(), fn)(ctx.h, _dt(x), int(inv), _ptr(xc), _ptr(gc), _ptr(lb), _ptr(xb), K, batch)
+    L.check(ctx.h, rc, fn)
+    return xb
+
+
+def _vjp_params_scale_matrix(b, x, out_bar, ladj_bar=None):
+    """Scale with a MATRIX parameter (scale.jl:14,17,35-36; the rules of ext/BijectorsReverseDiffExt.jl:72-115): for y = a x with the
+    per-column log-det logabsdet(a):  x̄ = aᵀȳ,  ā = ȳ xᵀ + (Σ_n ℓ̄_n) a⁻ᵀ; for the inverse x = a⁻¹y (log-det -logabsdet(a)):
+    ȳ = a⁻ᵀx̄,  ā = -ȳ xᵀ - (Σ ℓ̄) a⁻ᵀ.  The input side is the library's own entry with the transposed matrix; the batch
+    reduction ȳ xᵀ is a plain dense GEMM (the library GEMM of the host runtime: rocBLAS / hipBLASLt), a⁻ᵀ the library solve.
+    -> (in_bar, {"a": ā})."""
+    inv = isinstance(b, Inverse)
+    base = b.orig if inv else b
+    in_bar = vjp(b, x, out_bar, ladj_bar)
+    a = colmajor(_param(base.a, x))
+    batch = 1 if x.dim() == 1 else x.shape[1]
+    lsum = 0.0 if ladj_bar is None else (float(ladj_bar) * batch if not isinstance(ladj_bar, torch.Tensor) else ladj_bar.to(a.dtype).sum())
+    ainv_t = torch.linalg.inv(a).T
+    X2, G2 = x.reshape(x.shape[0], -1), out_bar.reshape(out_bar.shape[0], -1)
+    if not inv:
+        a_bar = G2 @ X2.T + lsum * ainv_t
+    else:
+        a_bar = -(in_bar.reshape(in_bar.shape[0], -1) @ transform(b, x).reshape(x.shape[0], -1).T) - lsum * ainv_t
+    return in_bar, {"a": a_bar}
 
 
 def _pieces(b):
@@ -2298,6 +2377,8 @@ def vjp_params(b, x, out_bar, ladj_bar=None):
         return _vjp_params_rqs(b, x, out_bar, ladj_bar)
     if isinstance(b, InvertibleBatchNorm):
         return _vjp_params_batchnorm(b, x, out_bar, ladj_bar)
+    if (isinstance(b, Scale) and b.matrix) or (isinstance(b, Inverse) and isinstance(b.orig, Scale) and b.orig.matrix):
+        return _vjp_params_scale_matrix(b, x, out_bar, ladj_bar)
     if isinstance(b, ComposedFunction) and any(_has_own_params(st) for st in b._stages()):
         return _vjp_params_composed(b, x, out_bar, ladj_bar)
     if not isinstance(b, PlanarLayer):

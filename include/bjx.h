@@ -196,6 +196,28 @@ int bjx_pd(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out,
 int bjx_pd_vec(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, void* out,
                void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags);
 
+/* SURVEY.md §8(f) f-1 x f-4: pullbacks of the four matrix-variate bijectors above, either direction:
+ *   in_bar = J(in)' out_bar + ladj_bar[n] * grad logabsdetjac(in)       (ladj_bar: T[batch] or NULL = 0)
+ * inverse=1 (unconstrained -> matrix, what HMC on an LKJ / Wishart / covariance prior differentiates every leapfrog step):
+ *   in = y (packed T[n, batch] or dense T[K, K, batch], the layouts of the forward entries), out_bar = X̄ dense T[K, K, batch]
+ *   (any matrix, not assumed symmetric), in_bar = ȳ in the layout of y.  The rules the reference ships, chained per sample:
+ *   pd_from_upper / pd_from_lower (ext/BijectorsChainRulesCoreExt.jl:324-331, ext/BijectorsReverseDiffExt.jl:160-168), then
+ *   _inv_link_chol_lkj's reverse sweep (corr.jl:402-451) + the (K-j) log U[j,j] terms of corr.jl:77-79, or replace_diag(exp)
+ *   (ext/BijectorsReverseDiffExt.jl:153-158) + the weights of pd.jl:27-31.
+ * inverse=0 (matrix -> unconstrained): in = X dense, out_bar = ȳ in the layout of the forward output, in_bar = X̄ dense; the
+ *   cotangent of the link (corr.jl:299-335, pd.jl:11) goes through the reverse of cholesky(Hermitian(X)) and lands on the
+ *   triangle the reference READS (upper for the correlation bijectors, src/utils.jl:50; lower for PD, :37) — the other
+ *   triangle of X̄ is zero.  in_bar may alias in.  K <= 12: one lane per sample, factor and cotangent in registers; larger K:
+ *   the same code on a global workspace (correct, not fast). */
+int bjx_vec_corr_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar, const void* ladj_bar,
+                     void* in_bar, int64_t K, int64_t batch);
+int bjx_corr_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar, const void* ladj_bar,
+                 void* in_bar, int64_t K, int64_t batch);
+int bjx_pd_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar, const void* ladj_bar,
+               void* in_bar, int64_t K, int64_t batch);
+int bjx_pd_vec_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar, const void* ladj_bar,
+                   void* in_bar, int64_t K, int64_t batch);
+
 /* Scale with a MATRIX parameter, scale.jl:14,17,35-36: out = a * in (inverse=1: out = a \ in), a: device T[dim, dim]
  * column-major, dim <= 128.  logabsdetjac = logabsdet(a) (negated for the inverse): ladj_ps[n] holds it for every column;
  * ladj_sum = batch * logabsdet(a), or logabsdet(a) ONCE with BJX_REF_VECTOR_SCALE_LADJ — the value the reference returns

@@ -1032,6 +1032,57 @@ for (f, ul) in ((:_link_chol_lkj_from_upper, 'U'), (:_link_chol_lkj_from_lower, 
     end
 end
 
+# Matrix-variate constraint bijectors (SURVEY.md §8f f-1 x f-4): the rules the reference ships piecewise — pd_from_upper
+# (ext/BijectorsChainRulesCoreExt.jl:324-331), replace_diag / pd_from_lower / lower_ / upper_triangular (ext/BijectorsReverseDiffExt.jl:
+# 143-193), cholesky_lower / _upper (ext/BijectorsReverseDiffChainRulesExt.jl:11-40), _inv_link_chol_lkj (corr.jl:402-461) — chained
+# per sample in ONE launch, attached to the PUBLIC call on device arrays.  Forward direction: the cotangent of X lands on the
+# triangle the reference reads (upper for the correlation bijectors, lower for PD).  One literal ccall per entry.
+matrix_vjp_launch(::VecCorrBijector, h, dt, inv, pin, pg, pl, pout, K, n) = ccall((:bjx_vec_corr_vjp, libbjx), Cint,
+    (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64), h, dt, inv, pin, pg, pl, pout, K, n)
+matrix_vjp_launch(::CorrBijector, h, dt, inv, pin, pg, pl, pout, K, n) = ccall((:bjx_corr_vjp, libbjx), Cint,
+    (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64), h, dt, inv, pin, pg, pl, pout, K, n)
+matrix_vjp_launch(::PDBijector, h, dt, inv, pin, pg, pl, pout, K, n) = ccall((:bjx_pd_vjp, libbjx), Cint,
+    (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64), h, dt, inv, pin, pg, pl, pout, K, n)
+matrix_vjp_launch(::PDVecBijector, h, dt, inv, pin, pg, pl, pout, K, n) = ccall((:bjx_pd_vec_vjp, libbjx), Cint,
+    (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64), h, dt, inv, pin, pg, pl, pout, K, n)
+function matrix_pullback(b::MatrixKinds, inv::Bool, x::ROCArray{T}, Δout, Δl, K::Integer, n::Integer) where {T}
+    x̄ = similar(x)
+    GC.@preserve x Δout Δl x̄ check(matrix_vjp_launch(b, ctx().h, dtype(T), Cint(inv), devptr(x), devptr(Δout), devptr(Δl), devptr(x̄), Int64(K), Int64(n)),
+                                  String(entry_name(b)) * "_vjp")
+    return x̄
+end
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), b::MatrixKinds, X::ROCArray{T}) where {T<:BjxFloat}
+    ndims(X) in (2, 3) || return nothing
+    out = with_logabsdet_jacobian(b, X)
+    K, n = size(X, 1), size(X, 3)
+    function pullback_matrix_link((Δy, Δl))
+        return NoTangent(), NoTangent(), matrix_pullback(b, false, X, cotangent(T, Δy, out[1]), ladj_cotangent(T, Δl, n), K, n)
+    end
+    return out, pullback_matrix_link
+end
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), ib::Inverse{<:MatrixKinds}, Y::ROCArray{T}) where {T<:BjxFloat}
+    out = with_logabsdet_jacobian(ib, Y)                       # X (K, K[, n]) and the log-det
+    K, n = size(out[1], 1), size(out[1], 3)
+    function pullback_matrix_invlink((ΔX, Δl))
+        return NoTangent(), NoTangent(), matrix_pullback(ib.orig, true, Y, cotangent(T, ΔX, out[1]), ladj_cotangent(T, Δl, n), K, n)
+    end
+    return out, pullback_matrix_invlink
+end
+# Scale with a matrix (scale.jl:14,17,35-36; ext/BijectorsReverseDiffExt.jl:72-115): x̄ = a'ȳ through the same entry with the transposed
+# matrix; ā = ȳ x' + (Σ ℓ̄) a⁻ᵀ is a dense GEMM over the batch and a solve — the host's library calls (rocBLAS / rocSOLVER via AMDGPU.jl).
+function ChainRulesCore.rrule(::typeof(with_logabsdet_jacobian), b::Scale{<:ROCMatrix{T}}, x::ROCVecOrMat{T}) where {T<:BjxFloat}
+    out = with_logabsdet_jacobian(b, x)
+    function pullback_scale_matrix((Δy, Δl))
+        ȳ = cotangent(T, Δy, x)
+        x̄ = transform(Scale(ROCArray(permutedims(b.a))), ȳ)
+        dl = unthunk(Δl)
+        ā = reshape(ȳ, size(b.a, 1), :) * reshape(x, size(b.a, 1), :)'
+        dl isa ChainRulesCore.AbstractZero || (ā = ā .+ T(dl) .* permutedims(inv(b.a)))      # the reference's scalar log-det: logabsdet(a) ONCE (:36)
+        return NoTangent(), Tangent{typeof(b)}(a = ā), x̄
+    end
+    return out, pullback_scale_matrix
+end
+
 # PlanarLayer (one layer or a planner run): input pullback (bjx_planar_vjp) and, for the forward flow, the parameter cotangents
 # (w̄, ū, b̄) through get_u_hat in the same pass (bjx_planar_vjp_params), on the layer-major tables of `planar_tables`.
 function planar_vjp(w, u, b, nl::Integer, inv::Bool, z::ROCMatrix{T}, Δy, Δl) where {T}

@@ -991,3 +991,155 @@ def rqs_params_vjp(raw_w, raw_h, raw_d, B, w_bar, h_bar, d_bar):
     rd = np.asarray(raw_d, dtype=np.float64)
     outs.append(np.asarray(d_bar, dtype=np.float64)[:, 1:-1] / (1 + np.exp(-rd)))
     return tuple(outs)
+
+
+# ------------------------------------------------------------------ pullbacks of the matrix-variate bijectors (SURVEY.md §8f f-1 x f-4)
+def _free_matrix(kind, y, K):
+    """Unconstrained side -> (K, K, N) matrix of free parameters: corr kinds: strict upper triangle Y[i, j], i < j (VecCorr packing:
+    column-major strict upper, src/utils.jl:99-108); pd kinds: lower triangle with the log-diagonal (PDVec packing:
+    triu_to_vec(Y'), pd.jl:41)."""
+    y = np.asarray(y)
+    if kind in ("corr", "pd"):
+        return np.array(y, copy=True)
+    N = y.shape[1]
+    Y = np.zeros((K, K, N), dtype=y.dtype)
+    idx = 0
+    for j in range(K):
+        for i in range(j if kind == "vec_corr" else j + 1):
+            if kind == "vec_corr":
+                Y[i, j] = y[idx]
+            else:
+                Y[j, i] = y[idx]          # (Y')[i, j] = Y[j, i]
+            idx += 1
+    return Y
+
+
+def _pack_free(kind, G, K):
+    if kind == "corr":
+        return G * np.triu(np.ones((K, K), bool), 1)[:, :, None]
+    if kind == "pd":
+        return G * np.tril(np.ones((K, K), bool))[:, :, None]
+    rows = []
+    for j in range(K):
+        for i in range(j if kind == "vec_corr" else j + 1):
+            rows.append(G[i, j] if kind == "vec_corr" else G[j, i])
+    return np.stack(rows, axis=0) if rows else np.zeros((0, G.shape[2]), dtype=G.dtype)
+
+
+def _chol_lower_batch(A):
+    """lower Cholesky factor of the (K, K, N) symmetric matrices"""
+    return np.transpose(np.linalg.cholesky(np.transpose(A, (2, 0, 1))), (1, 2, 0))
+
+
+def _chol_reverse(L, Lb):
+    """Reverse mode of the lower Cholesky factorisation A = L L' READ FROM ONE TRIANGLE (entries A[i][j], j <= i, each read once —
+    cholesky(Hermitian(X, uplo)), src/utils.jl:37,50): cotangent of those entries given the cotangent Lb of the factor.  Unblocked,
+    column by column from the last (forward: s_jj = A_jj - Σ_m L_jm², L_jj = √s_jj; s_ij = A_ij - Σ_m L_im L_jm, L_ij = s_ij / L_jj)."""
+    K = L.shape[0]
+    Lb = np.array(Lb, copy=True)
+    Ab = np.zeros_like(L)
+    for j in range(K - 1, -1, -1):
+        for i in range(j + 1, K):
+            Lb[j, j] = Lb[j, j] - Lb[i, j] * L[i, j] / L[j, j]
+        sjj = Lb[j, j] / (2 * L[j, j])
+        Ab[j, j] = sjj
+        for m in range(j):
+            Lb[j, m] = Lb[j, m] - 2 * sjj * L[j, m]
+        for i in range(j + 1, K):
+            sij = Lb[i, j] / L[j, j]
+            Ab[i, j] = sij
+            for m in range(j):
+                Lb[i, m] = Lb[i, m] - sij * L[j, m]
+                Lb[j, m] = Lb[j, m] - sij * L[i, m]
+    return Ab
+
+
+def matrix_bijector_vjp(kind, inp, out_bar, ladj_bar=None, inverse=False):
+    """Pullback of with_logabsdet_jacobian for VecCorrBijector / CorrBijector / PDBijector / PDVecBijector (forward) and their
+    inverses, a batch along the LAST axis: in_bar = J(inp)' out_bar + ladj_bar ∇ logabsdetjac(inp).
+
+    inverse=True (unconstrained -> matrix, what a log-density evaluation differentiates): the rules the reference ships, chained —
+    pd_from_upper / pd_from_lower (ext/BijectorsChainRulesCoreExt.jl:324-331, ext/BijectorsReverseDiffExt.jl:160-168: the factor's
+    cotangent is the triangle of (X̄ + X̄') L), then replace_diag(exp) (ext/BijectorsReverseDiffExt.jl:153-158) + the log-det
+    weights of pd.jl:27-31, or the reverse sweep of _inv_link_chol_lkj (corr.jl:402-451, with (1 - z²)·exp(log_remainder) for its
+    (inv(z) - z)·W) + the (K - j) log U[j,j] terms of corr.jl:77-79.
+    inverse=False (matrix -> unconstrained): cotangent of the factor from the link (corr.jl:299-335 differentiated: asinh(w/√R),
+    logcosh = ½ log(1 + w²/R), R the running remainder; atanh on the first row of the vector form, :322; pd.jl:11: replace_diag(log)
+    and the weights of :27-31), then the reverse of cholesky(Hermitian(X)) — the cotangent lands on the triangle the reference
+    READS (upper for the correlation bijectors, src/utils.jl:50; lower for PD, :37), the other triangle gets zeros."""
+    inp = np.asarray(inp)
+    dt = inp.dtype
+    corr_kind = kind in ("vec_corr", "corr")
+    if inverse:
+        K = out_bar.shape[0]
+        N = out_bar.shape[2]
+        Y = _free_matrix(kind, inp, K)
+    else:
+        K, N = inp.shape[0], inp.shape[2]
+    dl = np.zeros(N, dtype=dt) if ladj_bar is None else np.broadcast_to(np.asarray(ladj_bar, dtype=dt), (N,))
+    if inverse:
+        Xb = np.asarray(out_bar, dtype=dt)
+        S = Xb + np.transpose(Xb, (1, 0, 2))
+        L = np.zeros((K, K, N), dtype=dt)
+        if corr_kind:
+            z, lc = np.tanh(Y), np.abs(Y) + np.log1p(np.exp(-2 * np.abs(Y))) - np.log(2.0)
+            E = np.zeros((K, K, N), dtype=dt)
+            for c in range(K):
+                lr = np.zeros(N, dtype=dt)
+                for i in range(c):
+                    E[i, c] = np.exp(lr)
+                    L[c, i] = z[i, c] * E[i, c]
+                    lr = lr - lc[i, c]
+                L[c, c] = np.exp(lr)
+        else:
+            L = Y * np.tril(np.ones((K, K), bool), -1)[:, :, None]
+            for i in range(K):
+                L[i, i] = np.exp(Y[i, i])
+        Lb = np.einsum("imn,mjn->ijn", S, L) * np.tril(np.ones((K, K), bool))[:, :, None]
+        G = np.zeros((K, K, N), dtype=dt)
+        if corr_kind:
+            for c in range(K):
+                dlr = L[c, c] * Lb[c, c] + 2 * dl + ((K - 1 - c) * dl if 1 <= c <= K - 2 else 0.0)
+                for i in range(c - 1, -1, -1):
+                    G[i, c] = (1 - z[i, c] ** 2) * E[i, c] * Lb[c, i] - z[i, c] * dlr
+                    dlr = dlr + dl + L[c, i] * Lb[c, i]
+        else:
+            G = Lb * np.tril(np.ones((K, K), bool), -1)[:, :, None]
+            for i in range(K):
+                G[i, i] = Lb[i, i] * L[i, i] + dl * (K + 1 - i)
+        return _pack_free(kind, G, K)
+    X = inp
+    Gy = _free_matrix(kind, np.asarray(out_bar, dtype=dt), K)           # cotangent of the free parameters, same arrangement
+    if corr_kind:
+        A = np.triu(np.ones((K, K), bool))[:, :, None] * X
+        A = A + np.transpose(A, (1, 0, 2)) - np.eye(K)[:, :, None] * X     # Hermitian(X): the upper triangle mirrored
+    else:
+        A = np.tril(np.ones((K, K), bool))[:, :, None] * X
+        A = A + np.transpose(A, (1, 0, 2)) - np.eye(K)[:, :, None] * X
+    L = _chol_lower_batch(A)
+    Lb = np.zeros((K, K, N), dtype=dt)
+    if corr_kind:
+        for c in range(K):
+            # row c of L = column c of U: w_i = L[c, i] (i < c), d = L[c, c]; R_i = d² + Σ_{m > i} w_m²
+            R = np.zeros((max(c, 1), N), dtype=dt)
+            rem = L[c, c] ** 2
+            for i in range(c - 1, -1, -1):
+                R[i] = rem
+                rem = rem + L[c, i] ** 2
+            Gsum = np.zeros(N, dtype=dt)                                  # Σ_{i < m} ∂F/∂R_i
+            for m in range(c):
+                w, yb, wt = L[c, m], Gy[m, c], (K - m) * dl
+                if kind == "vec_corr" and m == 0:                        # y = atanh(w), logcosh = -½ log(1 - w²): no remainder
+                    Lb[c, m] = (yb + wt * w) / (1 - w * w)
+                    continue
+                S2 = R[m] + w * w
+                Sq = np.sqrt(S2)
+                Lb[c, m] = yb / Sq + wt * w / S2 + 2 * w * Gsum
+                Gsum = Gsum + yb * (-w / (2 * R[m] * Sq)) + wt * (-(w * w) / (2 * R[m] * S2))
+            Lb[c, c] = 2 * L[c, c] * Gsum
+    else:
+        Lb = Gy * np.tril(np.ones((K, K), bool), -1)[:, :, None]
+        for i in range(K):
+            Lb[i, i] = (Gy[i, i] - dl * (K + 1 - i)) / L[i, i]
+    Ab = _chol_reverse(L, Lb)                                             # cotangent of A[i][j], j <= i
+    return np.transpose(Ab, (1, 0, 2)) if corr_kind else Ab               # corr kinds read X[j, i] (upper); PD reads X[i, j] (lower)

@@ -67,7 +67,7 @@ def _c_to_julia(ctype):
 
 
 RET = {"int": "Cint", "size_t": "Csize_t", "const char*": "Cstring"}
-N_ENTRIES = 64          # include/bjx.h (63 at the end of round 3 + bjx_pack_vectors)
+N_ENTRIES = 68          # include/bjx.h (63 at the end of round 3 + bjx_pack_vectors + the four bjx_{vec_corr,corr,pd,pd_vec}_vjp)
 
 
 def _prototypes():
@@ -216,7 +216,7 @@ def test_every_bijector_of_the_boundary_has_a_plan_and_the_six_methods():
 
 RRULES = ["Bijectors._transform_ordered", "Bijectors._transform_inverse_ordered", "Bijectors._inv_link_chol_lkj", "Bijectors.$f"]
 RRULES_WLJ = ["Union{SimplexBijector,Inverse{<:SimplexBijector}}", "Fusable", "Stacked", "PlanarLayer", "Inverse{<:PlanarLayer}", "PlanarRun", "ComposedFunction",
-              "Inverse{VecCholeskyBijector}", "RadialLayer",
+              "Inverse{VecCholeskyBijector}", "MatrixKinds", "Inverse{<:MatrixKinds}", "Scale{<:ROCMatrix{T}}", "RadialLayer",
               "Inverse{<:RadialLayer}", "RationalQuadraticSpline{<:ROCMatrix{T}}", "Inverse{<:RationalQuadraticSpline{<:ROCMatrix{T}}}",
               "Union{Coupling,Inverse{<:Coupling}}", "Permute"]
 
@@ -230,7 +230,7 @@ def test_pullback_rules_cover_every_vjp_entry():
     for want in RRULES_WLJ:
         assert want.replace(" ", "") in heads, f"no rrule(::typeof(with_logabsdet_jacobian), ::{want}, …); have {heads}"
     vjp_entries = [n for n in _prototypes() if "_vjp" in n or n == "bjx_row_moments"]
-    assert len(vjp_entries) == 16, vjp_entries
+    assert len(vjp_entries) == 20, vjp_entries
     called = {c[0] for c in _ccalls()}
     assert set(vjp_entries) <= called
 

@@ -781,3 +781,40 @@ def test_full_covariance_normal_density_against_scipy(orc):
     cov, mu = A @ A.T + 0.5 * np.eye(d), r.normal(size=d)
     x = r.normal(size=(d, 40)) * 2.0
     np.testing.assert_allclose(orc.mvnormal_full_logpdf(x, mu, cov), multivariate_normal(mean=mu, cov=cov).logpdf(x.T), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("inverse", [True, False])
+@pytest.mark.parametrize("K", [1, 2, 3, 5, 7])
+@pytest.mark.parametrize("kind", ["vec_corr", "corr", "pd", "pd_vec"])
+def test_matrix_bijector_pullbacks_against_central_differences(orc, kind, K, inverse):
+    """oracle.matrix_bijector_vjp (the reference's rules chained: pd_from_upper ext/BijectorsChainRulesCoreExt.jl:324-331,
+    pd_from_lower / replace_diag ext/BijectorsReverseDiffExt.jl:143-168, _inv_link_chol_lkj corr.jl:402-451; the forward links and
+    the Cholesky reverse derived) is the gradient of Σ out_bar·out + Σ ladj_bar·logabsdetjac of oracle.matrix_bijector.  The
+    forward direction is differentiated entry by entry of X: only the triangle the reference reads carries a gradient."""
+    r = np.random.default_rng(1000 * K + 10 * len(kind) + int(inverse))
+    N = 3
+    n_free = K * (K - 1) // 2 if kind in ("vec_corr", "corr") else K * (K + 1) // 2
+    v0 = 0.6 * r.normal(size=(n_free, N))
+    y0 = np.asfortranarray(np.stack([_free_to_input(kind, v0[:, n], K) for n in range(N)], axis=-1))
+    X0, _ = orc.matrix_bijector(kind, y0, inverse=True)
+    inp = y0 if inverse else np.asfortranarray(X0)
+    out0, l0 = orc.matrix_bijector(kind, inp, inverse=inverse)
+    gbar, lbar = r.normal(size=out0.shape), r.normal(size=N)
+
+    def loss(a):
+        o, l = orc.matrix_bijector(kind, np.asfortranarray(a), inverse=inverse)
+        return (gbar * o).sum(axis=tuple(range(o.ndim - 1))) + lbar * l
+
+    got = orc.matrix_bijector_vjp(kind, inp, gbar, lbar, inverse=inverse)
+    assert got.shape == inp.shape
+    want = np.zeros_like(inp)
+    h = 1e-6
+    for idx in np.ndindex(*inp.shape[:-1]):
+        ap, am = inp.copy(), inp.copy()
+        ap[idx] += h
+        am[idx] -= h
+        want[idx] = (loss(ap) - loss(am)) / (2 * h)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-7 * max(1.0, float(np.abs(want).max()) if want.size else 1.0))
+    if not inverse and K > 1:       # the other triangle is never read (cholesky(Hermitian(X)) / Hermitian(X, :L), src/utils.jl:37,50)
+        other = np.tril_indices(K, -1) if kind in ("vec_corr", "corr") else np.triu_indices(K, 1)
+        assert np.all(got[other] == 0) and np.all(np.abs(want[other]) < 1e-9)
