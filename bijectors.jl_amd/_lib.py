@@ -56,6 +56,7 @@ _tail = [_vp, _vp, _i64, _i64, _u32]  # ladj_ps, ladj_sum, dim/K, batch, flags
 
 BJX_OPT_INKERNEL_FINALIZE = 1
 BJX_OPT_COLLECTIVE_TIMEOUT_MS = 2
+BJX_OPT_PARAM_EPOCH = 3
 
 # name -> (restype, argtypes); mirrors include/bjx.h line by line
 SIGNATURES = {

@@ -28,6 +28,27 @@ __global__ __launch_bounds__(256) void bjx_finalize_kernel(const double* __restr
   }
 }
 
+// 4 097 ... 65 536 partials (C3: 5 462 blocks; C5a): ONE launch of one 1024-thread block instead of the reduce-slices + finalize
+// pair — a step then carries one tail launch, not two (4.8 + 4.7 µs of helper kernels per call next
+// to a 100 - 220 µs hot kernel).  Fixed order: thread t takes t, t+1024, ...; wave trees; the 16 wave sums in index order.
+__global__ __launch_bounds__(1024) void bjx_finalize_wide_kernel(const double* __restrict__ partials, int n, double* __restrict__ out, double host_const,
+                                                                  const double* __restrict__ dev_const, int accumulate) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += partials[i];
+  s = bjx::group_sum<64>(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    t += host_const;
+    if (dev_const) t += *dev_const;
+    *out = accumulate ? (*out + t) : t;
+  }
+}
+
 // Stage 1 for large grids (one-pack-per-thread kernels publish up to millions of partials): block b
 // sums the contiguous slice [b*per, (b+1)*per) in a fixed order -> out[b].
 __global__ __launch_bounds__(256) void bjx_reduce_slices_kernel(const double* __restrict__ partials, long n, long per,
@@ -72,6 +93,12 @@ int bjx_launch_finalize(bjx_ctx* ctx, int n_partials, double* ladj_sum, double h
                         int use_dev_const, double /*unused*/, uint32_t flags) {
   const double* src = ctx->partials;
   int n = n_partials;
+  if (n > BJX_MAX_BLOCKS && n <= BJX_FIN_WIDE_MAX) {
+    hipLaunchKernelGGL(bjx_finalize_wide_kernel, dim3(1), dim3(1024), 0, ctx->stream, src, n, ladj_sum, host_const,
+                       use_dev_const ? ctx->consts + 1 : nullptr, (flags & BJX_ACCUMULATE) ? 1 : 0);
+    BJX_CHECK_LAUNCH(ctx);
+    return BJX_OK;
+  }
   if (n > BJX_MAX_BLOCKS) {
     const long per = ((long)n + BJX_MAX_BLOCKS - 1) / BJX_MAX_BLOCKS;
     const int nb = (int)(((long)n + per - 1) / per);
@@ -159,6 +186,7 @@ BJX_API int bjx_destroy(bjx_ctx* ctx) {
   if (ctx->stage_ev) (void)hipEventDestroy(ctx->stage_ev);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->big_ws) (void)hipFree(ctx->big_ws);
+  for (auto& sl : ctx->rqs_slots) if (sl.buf) (void)hipFree(sl.buf);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->prof_ev) {
@@ -172,6 +200,7 @@ BJX_API int bjx_destroy(bjx_ctx* ctx) {
 BJX_API int bjx_set_stream(bjx_ctx* ctx, void* hip_stream) {
   if (!ctx) return BJX_ERR_ARG;
   ctx->stream = static_cast<hipStream_t>(hip_stream);
+  for (auto& sl : ctx->rqs_slots) sl.epoch = 0;          // cached parameter tables were built on the old stream: rebuild on first use
   return BJX_OK;
 }
 
@@ -185,6 +214,11 @@ BJX_API size_t bjx_workspace_bytes(bjx_ctx* ctx) {
 BJX_API int bjx_set_option(bjx_ctx* ctx, int option, int value) {
   if (!ctx) return BJX_ERR_ARG;
   if (option == BJX_OPT_INKERNEL_FINALIZE) { ctx->opt_inkernel_fin = value ? 1 : 0; return BJX_OK; }
+  if (option == BJX_OPT_PARAM_EPOCH) {
+    BJX_REQUIRE(ctx, value >= 0, BJX_ERR_ARG, "BJX_OPT_PARAM_EPOCH: an epoch >= 0 (0 = no reuse of parameter-derived tables)");
+    ctx->param_epoch = value;
+    return BJX_OK;
+  }
   if (option == BJX_OPT_COLLECTIVE_TIMEOUT_MS) {
     BJX_REQUIRE(ctx, value >= 0, BJX_ERR_ARG, "BJX_OPT_COLLECTIVE_TIMEOUT_MS: milliseconds >= 0 (0 = wait for ever)");
     ctx->collective_timeout_ms = value;

@@ -865,9 +865,30 @@ int rqs_lds_slab(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, 
   *taken = true;
   int* flag = reinterpret_cast<int*>(ctx->scratch);
   T* blob = reinterpret_cast<T*>(static_cast<char*>(ctx->scratch) + 64);
-  if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, rows, c.V, nstep_hi, dual, c.G, flag, blob, trows);
-  else hipLaunchKernelGGL((rqs_blob_kernel<T, false>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, rows, c.V, nstep_hi, dual, c.G, flag, blob, trows);
-  BJX_CHECK_LAUNCH(ctx);
+  // BJX_OPT_PARAM_EPOCH != 0: the blob of an unchanged spline is kept (4 slots: forward and inverse tables of two splines) and the
+  // helper launch is skipped — per C3 step two launches of 7.4 us next to two hot kernels of ~220 us.
+  bool build = true;
+  if (ctx->param_epoch != 0 && !ctx->capturing) {          // (a captured step bakes pointers into the graph: it keeps the per-call build in the scratch)
+    bjx_ctx::RqsBlobSlot* hit = nullptr;
+    for (auto& sl : ctx->rqs_slots)
+      if (sl.buf && sl.epoch == ctx->param_epoch && sl.w == w && sl.h == h && sl.d == d && sl.K1 == K1 && sl.rows == rows && sl.trows == trows && sl.V == c.V &&
+          sl.nstep_hi == nstep_hi && sl.dual == dual && sl.G == c.G && sl.inverse == inverse && sl.dt == (int)sizeof(T)) { hit = &sl; break; }
+    if (hit) build = false;
+    else {
+      hit = &ctx->rqs_slots[ctx->rqs_next];
+      if (!hit->buf) { if (hipMalloc(&hit->buf, kRqsBlobMax + 64) != hipSuccess) hit->buf = nullptr; }
+      if (hit->buf) {
+        ctx->rqs_next = (ctx->rqs_next + 1) % 4;
+        *hit = bjx_ctx::RqsBlobSlot{w, h, d, K1, c.V, nstep_hi, dual, c.G, inverse, (int)sizeof(T), ctx->param_epoch, rows, trows, hit->buf};
+      } else hit = nullptr;                                   // (no buffer: the shared scratch, rebuilt every call)
+    }
+    if (hit) { flag = reinterpret_cast<int*>(hit->buf); blob = reinterpret_cast<T*>(static_cast<char*>(hit->buf) + 64); }
+  }
+  if (build) {
+    if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, rows, c.V, nstep_hi, dual, c.G, flag, blob, trows);
+    else hipLaunchKernelGGL((rqs_blob_kernel<T, false>), dim3(1), dim3(256), 0, ctx->stream, w, h, d, K1, rows, c.V, nstep_hi, dual, c.G, flag, blob, trows);
+    BJX_CHECK_LAUNCH(ctx);
+  }
   const int cols_per_block = 256 / c.G;
   const int64_t groups = (batch + cols_per_block - 1) / cols_per_block;
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
@@ -1165,6 +1186,11 @@ __global__ void rqs_knot_vjp_kernel(const T* __restrict__ w, const T* __restrict
     if (sum != 0.0) atomicAdd(acc + o, sum);
   }
 }
+// (Round 4 tried the pack / LDS-blob skeleton of rqs_vjp_kernel with ONE table per block: profiles/r04_rqs_knots.md.  The front end
+//  alone runs at 0.54 ms against this kernel's 1.12 ms, but the accumulation has no cheap race-free form there: LDS Float32 atomics run
+//  at 0.33 lane-adds per clock per CU on gfx950 — 28x slower than ds_add_u32 (scripts/probe_lds_atomics.hip) — which made that kernel
+//  4.2 ms; fixed-point integer atomics cost 6-10 VALU per contribution in a VALU-bound kernel; private accumulators are what this
+//  kernel already has.)
 template <class T>
 __global__ __launch_bounds__(256) void rqs_knot_vjp_out_kernel(const double* __restrict__ acc, int K, int64_t dim, T* wb, T* hb, T* db) {
   const int64_t nk = (int64_t)K * dim;

@@ -16,6 +16,7 @@
 // ------------------------------------------------------------------ context
 constexpr int BJX_INKERNEL_FIN_MAX = 4096;    // partials one block reduces: in-kernel (BJX_OPT_INKERNEL_FINALIZE = 1) and in bjx_finalize_kernel
 constexpr int BJX_MAX_BLOCKS = 4096;        // persistent-grid cap AND size of the 2nd-stage partial buffer
+constexpr int BJX_FIN_WIDE_MAX = 65536;     // partials ONE 1024-thread block still sums in a single launch (bjx_finalize_wide_kernel)
 constexpr int BJX_CONSTS = 8;               // device doubles for parameter-only log-det terms
 constexpr size_t BJX_SCRATCH_BYTES = 1 << 20;  // û tables, small parameter staging
 constexpr size_t BJX_HOST_STAGE_BYTES = 256 << 10;  // pinned host staging for descriptor lists (bjx_stacked)
@@ -35,6 +36,16 @@ struct bjx_ctx {
   size_t big_ws_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cu = 256;
+  // BJX_OPT_PARAM_EPOCH (0 = off): while the host keeps the epoch unchanged, tables DERIVED from parameter arrays (the spline's LDS
+  // blob) are reused when the same device pointers come back, instead of being rebuilt by a helper launch on every call.
+  int param_epoch = 0;
+  struct RqsBlobSlot {
+    const void *w = nullptr, *h = nullptr, *d = nullptr;
+    int K1 = 0, V = 0, nstep_hi = 0, dual = 0, G = 0, inverse = 0, dt = 0, epoch = 0;
+    int64_t rows = 0, trows = 0;
+    void* buf = nullptr;          // [64 bytes flag][blob], kRqsBlobMax + 64, allocated on first use
+  } rqs_slots[4];
+  int rqs_next = 0;
   int opt_inkernel_fin = 0;     // BJX_OPT_INKERNEL_FINALIZE: 0 (default) two follow-up launches, 1 the last block finishes the sum (<= 4096 blocks)
   uint64_t rng_seed = 0;        // bjx_set_rng: stream of the fused sampling path (BJX_INPUT_STDNORMAL)
   int64_t rng_col0 = 0;

@@ -145,6 +145,35 @@ def kernel_timed(fn, device: Optional[torch.device] = None):
     return out, float(ms.value), int(n.value)
 
 
+_PARAM_WATCH: dict = {}     # id(ctx) -> [epoch, last epoch handed to the library, {data_ptr: (weakref to the tensor, _version)}]
+
+
+def _note_params(ctx: "_Ctx", *tensors) -> None:
+    """BJX_OPT_PARAM_EPOCH bookkeeping (include/bjx.h): the library may keep tables it derives from parameter arrays (the spline's
+    LDS blob) while the epoch is unchanged.  torch knows when a tensor was written (`_version`) and a weak reference tells a live
+    tensor from a new one at a recycled address — so the epoch moves exactly when a parameter array that is about to be passed is
+    not the same, unwritten tensor that was passed at that address before.  Conversions that make a fresh tensor on every call
+    (a host parameter uploaded anew, a layout copy) change the epoch every time: no reuse, never a stale table."""
+    import weakref
+
+    st = _PARAM_WATCH.setdefault(id(ctx), [1, 0, {}])
+    changed = False
+    for t in tensors:
+        key = t.data_ptr()
+        seen = st[2].get(key)
+        if seen is None or seen[0]() is not t or seen[1] != t._version:
+            st[2][key] = (weakref.ref(t), t._version)
+            changed = seen is not None or changed           # a new address does not invalidate what is cached for the others
+    if changed:
+        st[0] = st[0] + 1 if st[0] < (1 << 30) else 1
+    if len(st[2]) > 4096:                                   # bound the table; forgetting entries only costs a rebuild
+        st[2].clear()
+        st[0] = st[0] + 1 if st[0] < (1 << 30) else 1
+    if st[1] != st[0]:
+        L.check(ctx.h, L.load().bjx_set_option(ctx.h, L.BJX_OPT_PARAM_EPOCH, st[0]), "bjx_set_option")
+        st[1] = st[0]
+
+
 def _dt(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
         return L.BJX_F32
@@ -1369,6 +1398,7 @@ class RationalQuadraticSpline(Bijector):
         if dim != self.widths.shape[0]:
             raise ValueError(f"DimensionMismatch: spline with {self.widths.shape[0]} rows applied to {dim} rows")
         w, h, d = (colmajor(_param(t, xc)) for t in (self.widths, self.heights, self.derivatives))
+        _note_params(context(xc.device), w, h, d)           # an unchanged spline keeps its LDS blob (BJX_OPT_PARAM_EPOCH)
         return _call_struct("bjx_rqs", x, dim, False, per_sample, want_ladj,
                             (int(inv), _ptr(w), _ptr(h), _ptr(d), int(self.widths.shape[1])), (dim,))
 

@@ -98,7 +98,14 @@ enum {
   /* Watchdog of the library's own collective (bjx_comm_init + bjx_allreduce_sum_f64): with a communicator attached,
    * bjx_synchronize polls the stream for at most `value` milliseconds; on time-out it aborts the communicator (ncclCommAbort) and
    * returns 1000 + ncclRemoteError instead of hanging on a rank that never arrived.  0 (default) = wait for ever. */
-  BJX_OPT_COLLECTIVE_TIMEOUT_MS = 2
+  BJX_OPT_COLLECTIVE_TIMEOUT_MS = 2,
+  /* Parameter epoch.  Some entries derive a table from their parameter arrays with a helper launch before the hot kernel (bjx_rqs:
+   * the spline's 17 - 64 KiB LDS blob of search keys and per-bin records, 2 x 7.4 us per C3 step).  With value != 0 the library
+   * keeps such tables, keyed by the parameter POINTERS and shapes, and reuses them while the epoch is unchanged: the host promises
+   * that the memory behind a pointer it passes again has not been written since the epoch was set, and sets a different non-zero
+   * epoch (or 0) whenever it may have been (an optimiser step, a new array at a recycled address).  0 (default) = rebuild on
+   * every call — the safe setting for hosts that cannot track writes (arrays mutated in place without a version counter). */
+  BJX_OPT_PARAM_EPOCH = 3
 };
 int bjx_set_option(bjx_ctx* ctx, int option, int value);
 /* Stream of BJX_INPUT_STDNORMAL: element (row, col) of a call draws value number (col0 + col) * dim + row of `seed`. */

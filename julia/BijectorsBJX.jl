@@ -92,6 +92,12 @@ synchronize() = check(ccall((:bjx_synchronize, libbjx), Cint, (Ptr{Cvoid},), ctx
 workspace_bytes() = Int(ccall((:bjx_workspace_bytes, libbjx), Csize_t, (Ptr{Cvoid},), ctx().h))
 const BJX_OPT_COLLECTIVE_TIMEOUT_MS = Cint(2)
 collective_timeout!(ms::Integer) = check(ccall((:bjx_set_option, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().h, BJX_OPT_COLLECTIVE_TIMEOUT_MS, Cint(ms)), "bjx_set_option")   # watchdog of synchronize()
+# BJX_OPT_PARAM_EPOCH (include/bjx.h): a non-zero epoch lets the library keep tables derived from parameter arrays (the spline's LDS
+# blob) while it is unchanged.  ROCArrays carry no write counter, so the default stays 0 (rebuild every call); a training loop that
+# knows when it updates its parameters calls `param_epoch!(step)` after each update (any different non-zero value) to skip the
+# per-call helper launch in between.
+const BJX_OPT_PARAM_EPOCH = Cint(3)
+param_epoch!(n::Integer) = check(ccall((:bjx_set_option, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().h, BJX_OPT_PARAM_EPOCH, Cint(n)), "bjx_set_option")
 inkernel_finalize!(on::Bool) = check(ccall((:bjx_set_option, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().h, BJX_OPT_INKERNEL_FINALIZE, Cint(on)), "bjx_set_option")
 
 dims(x::ROCVector) = (length(x), 1)

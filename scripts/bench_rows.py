@@ -197,6 +197,20 @@ def main():
             bpsm = 4 * (Km * Km + nvm) + 4
             rows.append((f"{nm} K={Km} (X → Cholesky → y)", "f-4", (lambda b_=bm, X_=Xm: bj.shard.with_logabsdet_jacobian_sharded(b_, X_)), bpsm, Nm))
             rows.append((f"inverse({nm}) K={Km} (y → X = U'U)", "f-4", (lambda b_=bm, y_=ym: bj.shard.with_logabsdet_jacobian_sharded(bj.inverse(b_), y_)), bpsm, Nm))
+    # §8(f) f-1 x f-4: pullbacks of the matrix bijectors (bjx_*_vjp).  Algorithmic bytes: primal input + output cotangent read, input
+    # cotangent written, + the log-det cotangent
+    for Km, lbm in ((3, 22), (4, 22), (8, 20), (12, 19), (32, 14)):
+        Nm = 1 << min(a.log2_batch, lbm)
+        for nm, cls in (("VecCorrBijector", bj.VecCorrBijector), ("PDVecBijector", bj.PDVecBijector)):
+            bm = cls()
+            nvm = bm._n(Km)
+            ym = randn(nvm, Nm, dev, 40, std=0.3)
+            Xm = bj.transform(bj.inverse(bm), ym)
+            Xbar = randn(Km * Km, Nm, dev, 42).T.reshape(Nm, Km, Km).permute(2, 1, 0)      # column-major (K, K, batch): strides (1, K, K²)
+            ybar = randn(nvm, Nm, dev, 43)
+            lbm_ = randn(Nm, 1, dev, 44).reshape(-1).contiguous()
+            rows.append((f"vjp(inverse({nm})) K={Km} (ȳ from X̄, ℓ̄)", "f-1", (lambda b_=bm, y_=ym, g_=Xbar, l_=lbm_: bj.vjp(bj.inverse(b_), y_, g_, l_)), 4 * (2 * nvm + Km * Km) + 4, Nm))
+            rows.append((f"vjp({nm}) K={Km} (X̄ from ȳ, ℓ̄)", "f-1", (lambda b_=bm, X_=Xm, g_=ybar, l_=lbm_: bj.vjp(b_, X_, g_, l_)), 4 * (2 * Km * Km + nvm) + 4, Nm))
     Am = (randn(d, d, dev, 41, std=1 / math.sqrt(d)) + 1.5 * torch.eye(d, device=dev).T).T.contiguous().T
     add("Scale(64×64 matrix): a * x + logabsdet(a)", "f-4", bj.Scale(Am), x)
     add("inverse(Scale(64×64 matrix)): a \\ y", "f-4", bj.inverse(bj.Scale(Am)), x)

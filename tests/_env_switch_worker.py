@@ -66,6 +66,9 @@ def main(path):
                 raw = [dev(r.normal(size=(dim, k)).astype(dt)) for k in (K, K, K - 1)]
                 sp = bj.RationalQuadraticSpline(raw[0], raw[1], raw[2], 3.0)
                 put(f"rqs.{tg}.{dim}", bj.with_logabsdet_jacobian(sp, dev(x), per_sample=True))
+                if dim == 24:        # knot / raw-parameter cotangents
+                    xbk, grk = bj.vjp_params(sp, dev(x), dev(g), dev(lb))
+                    put(f"rqs_vjp_knots.{tg}.{dim}", xbk, grk["widths"], grk["heights"], grk["derivatives"])
             if dim == 64:
                 st = bj.Stacked([ch_seg(bj, av), bj.SimplexBijector(), bj.Logit(0.0, 1.0), bj.OrderedBijector()], [(1, 16), (17, 32), (33, 48), (49, 64)])
                 xm = x.copy()
