@@ -749,6 +749,10 @@ int matrix_big(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, doubl
   return BJX_OK;
 }
 
+}  // namespace
+int bjx_matrix_cyc(bjx_ctx* ctx, int dt, int kind, int inverse, const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch,
+                   uint32_t flags, bool* taken);                  // bjx_matrix_cyc.hip
+namespace {
 template <class T, int KIND>
 int matrix_impl(bjx_ctx* ctx, const char* who, int inverse, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags) {
   if (batch == 0) {
@@ -756,6 +760,12 @@ int matrix_impl(bjx_ctx* ctx, const char* who, int inverse, const T* in, T* out,
     return BJX_OK;
   }
   if (K > 64) return matrix_big<T, KIND>(ctx, inverse, in, out, ladj_ps, ladj_sum, K, batch, flags);   // beyond the register-resident kernels
+  {
+    // 12 < K <= 64: cyclic rows, R rows of the factor per lane (bjx_matrix_cyc.hip) — matrix_link_kernel below (one row per lane) is its A/B
+    bool taken = false;
+    const int rc = bjx_matrix_cyc(ctx, sizeof(T) == 4 ? BJX_F32 : BJX_F64, KIND, inverse, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken);
+    if (rc || taken) return rc;
+  }
   constexpr int VW = Vec16<T>::N;
   const int64_t KK = K * K;
   const int64_t nv = KIND == MK_VEC_CORR ? K * (K - 1) / 2 : (KIND == MK_PD_VEC ? K * (K + 1) / 2 : KK);

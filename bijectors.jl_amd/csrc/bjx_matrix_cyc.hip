@@ -1,0 +1,427 @@
+// bjx_matrix_cyc.hip — the matrix-variate constraint bijectors (corr.jl:64-162, pd.jl:1-60) for 12 < K <= 64: GS lanes own one
+// sample and every lane keeps R rows of the lower Cholesky factor, dealt CYCLICALLY (lane li has rows li, li + GS, ... ), in registers.
+//
+// Why (round 4; VERDICT r02 / r03: matrix_link_kernel 29-32 % of the HBM peak at K = 32): with ONE row per lane (K = 32: 32 lanes a
+// sample, two samples a wave) every step of the right-looking factorisation runs its update on all 32 lanes although only the rows
+// below the pivot do useful work, the link walks one row per lane with the lanes above the diagonal idle, and each sample holds a
+// K x (K+4) LDS tile (4.6 KiB: the occupancy limit).  Per sample that is ~3 000 SIMD-cycles of VALU issue against a budget of ~3 700 at
+// 50 % of the roofline: the mapping, not the memory system, was the bound.  With cyclic rows a wave holds 64/GS = 8 samples (K <= 32),
+// every lane's R rows span the whole matrix (balanced work at every step, no idle lanes in the link), the only LDS a sample needs is
+// one K-entry broadcast buffer (128 bytes), and the matrix travels between global memory and registers directly: a row of the
+// triangle the correlation bijectors read is a contiguous run of a column of X (16-byte loads), the lower triangle the PD bijectors
+// read comes as 4-byte loads whose GS lanes cover consecutive addresses (32-byte segments of one 128-byte line per column).
+//
+// Register file: a[m][j], m < R, j < GS (m + 1) — row li + GS m needs columns up to its diagonal, and all indices are compile-time
+// constants after unrolling (GS R (R+1) / 2 registers: 80 for GS = 8, R = 4).  Entries right of a row's own diagonal hold garbage
+// that nothing reads: the factorisation needs NO per-lane masks (identity padding makes the steps k >= K no-ops).
+// Arithmetic: FacMath / LinkMath exactly as matrix_link_kernel and matrix_lane_kernel (same pivot and link formulas).
+#include <cstdlib>
+
+#include "bjx_internal.h"
+
+using namespace bjx;
+
+namespace {
+
+enum { MK_VEC_CORR = 0, MK_CORR = 1, MK_PD = 2, MK_PD_VEC = 3 };
+
+#include "bjx_linkmath.h"
+
+template <class T> struct V2 { typedef T t __attribute__((ext_vector_type(2))); };
+template <class T> struct FacMathC;
+template <> struct FacMathC<float> {
+  static __device__ __forceinline__ void pivot(float d, float& rd, float& rs, float& sq) { rs = Fast<float>::rsqrt(d); rd = rs * rs; sq = d * rs; }
+};
+template <> struct FacMathC<double> {
+  static __device__ __forceinline__ void pivot(double d, double& rd, double& rs, double& sq) { sq = ::sqrt(d); rs = 1.0 / sq; rd = 1.0 / d; }
+};
+template <class T> struct QuadC { T v[4]; };
+template <class T> __device__ __forceinline__ QuadC<T> lds_quad4(const T* p) {
+  QuadC<T> r;
+  if constexpr (sizeof(T) == 4) {
+    const bjx_f32x4 t = *reinterpret_cast<const bjx_f32x4*>(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else {
+    const bjx_f64x2 t0 = *reinterpret_cast<const bjx_f64x2*>(p), t1 = *reinterpret_cast<const bjx_f64x2*>(p + 2);
+    r.v[0] = t0.x; r.v[1] = t0.y; r.v[2] = t1.x; r.v[3] = t1.y;
+  }
+  return r;
+}
+
+template <class T, int GS, int R, int KIND, bool INV>
+__global__ __launch_bounds__(64) void matrix_cyc_kernel(const T* __restrict__ in, T* __restrict__ out, T* __restrict__ ladj_ps, int K0, int64_t batch,
+                                                        int accumulate, int vec_ok, double* partials) {
+  using M = LinkMath<T>;
+  constexpr int KC = GS * R, NSW = 64 / GS, NA = GS * R * (R + 1) / 2;
+  constexpr bool CORR = KIND == MK_VEC_CORR || KIND == MK_CORR;
+  constexpr bool STAGE = KC > 16;                                    // forward outputs through the LDS tile (wins from 17 rows on, loses below)
+  // per sample: one row group (GS rows) of staging tile; the factorisation's two K-entry broadcast buffers live in its first rows
+  __shared__ __attribute__((aligned(16))) T bufs[NSW * (GS * (KC + 4) + 4)];   // >= 2 NSW (KC + 4) for GS >= 2
+  __shared__ double red[1];
+  // a[OFF(m) + j] = entry (row li + GS m, column j), j < GS (m + 1)
+#define OFF(m_) (GS * (m_) * ((m_) + 1) / 2)
+#define A_(m_, j_) a[OFF(m_) + (j_)]
+  const int lane = threadIdx.x;
+  const int g = lane / GS, li = lane - g * GS;
+  T* buf = bufs + g * (GS * (KC + 4) + 4);
+  int K = K0;
+  const int KK = K * K;
+  const int nv = KIND == MK_VEC_CORR ? K * (K - 1) / 2 : (KIND == MK_PD_VEC ? K * (K + 1) / 2 : KK);
+  const int n_in = INV ? nv : KK, n_out = INV ? KK : nv;
+  double acc = 0.0;
+  for (int64_t s0 = (int64_t)blockIdx.x * NSW; s0 < batch; s0 += (int64_t)gridDim.x * NSW) {
+    asm volatile("" : "+s"(K));
+    const bool samp = s0 + g < batch;
+    const T* src = in + (samp ? (s0 + g) : s0) * n_in;
+    T* dst = out ? out + (samp ? (s0 + g) : s0) * n_out : nullptr;
+    T a[NA];
+    T lsum = T(0);
+    if constexpr (!INV) {
+      // ---------------------------------------------------------------- X -> A (triangle the reference reads) -> L -> link
+#pragma unroll
+      for (int m = 0; m < R; ++m) {
+        const int r = li + GS * m;
+        const bool live = r < K;
+        if (CORR) {
+          // row r of A = the upper part of column r of X: X[0..r, r], contiguous
+          const T* col = src + (live ? r : 0) * K;
+#pragma unroll
+          for (int j4 = 0; j4 < GS * (m + 1); j4 += 4) {
+            QuadC<T> q{{T(0), T(0), T(0), T(0)}};
+            if (live && j4 < K) {
+              if (vec_ok) {
+                if constexpr (sizeof(T) == 4) { const bjx_f32x4 t = *reinterpret_cast<const bjx_f32x4*>(col + j4); q.v[0] = t.x; q.v[1] = t.y; q.v[2] = t.z; q.v[3] = t.w; }
+                else { const bjx_f64x2 t0 = *reinterpret_cast<const bjx_f64x2*>(col + j4), t1 = *reinterpret_cast<const bjx_f64x2*>(col + j4 + 2); q.v[0] = t0.x; q.v[1] = t0.y; q.v[2] = t1.x; q.v[3] = t1.y; }
+              } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (j4 + t < K) q.v[t] = col[j4 + t];
+              }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) A_(m, j4 + t) = live ? (j4 + t < K ? q.v[t] : T(0)) : (j4 + t == r ? T(1) : T(0));
+          }
+        } else {
+          // row r of A = row r of the LOWER triangle of X: X[r, j] at j K + r — the GS lanes of a sample read consecutive addresses
+#pragma unroll
+          for (int j = 0; j < GS * (m + 1); ++j) A_(m, j) = live ? (j < K ? src[(int64_t)j * K + r] : T(0)) : (j == r ? T(1) : T(0));
+        }
+      }
+      // right-looking Cholesky; column k travels through the sample's broadcast buffer.  No masks: rows above the pivot only
+      // touch entries right of their own diagonal (never read), padding rows / columns are the identity.
+      // LOOK-AHEAD: step k updates column k+1 FIRST and publishes it in the other buffer, so the LDS round trip of step k+1
+      // (write, pivot read, rsqrt) runs under the rest of step k's trailing update instead of behind it.  One wave per block and an
+      // in-order LDS queue: program order is the only synchronisation needed.
+      T* bcur = buf;
+      T* bnxt = buf + (KC + 4);
+#pragma unroll
+      for (int m = 0; m < R; ++m) bcur[li + GS * m] = A_(m, 0);
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        const int mo = k / GS;
+        T rd, rs, sq;
+        FacMathC<T>::pivot(bcur[k], rd, rs, sq);
+        T c[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) c[m] = m >= mo ? A_(m, k) * rd : T(0);
+        if (k + 1 < KC) {
+          const T qn = bcur[k + 1];                                    // A[k+1][k]
+          const int mn = (k + 1) / GS;
+#pragma unroll
+          for (int m = 0; m < R; ++m) {
+            if (m >= mo && GS * (m + 1) > k + 1) A_(m, k + 1) -= c[m] * qn;
+            if (m >= mn) bnxt[li + GS * m] = A_(m, k + 1);
+          }
+        }
+#pragma unroll
+        for (int j4 = (k + 2) & ~3; j4 < KC; j4 += 4) {
+          const QuadC<T> q = lds_quad4<T>(bcur + j4);                 // A[j][k], j = j4 .. j4+3 (same address for the GS lanes: broadcast)
+#pragma unroll
+          for (int m = 0; m < R; ++m) {
+            if (m >= mo && GS * (m + 1) > j4) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) if (j4 + t > k + 1) A_(m, j4 + t) -= c[m] * q.v[t];
+            }
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < R; ++m) if (m >= mo) A_(m, k) = (li + GS * m == k) ? sq : A_(m, k) * rs;
+        T* tmp = bcur; bcur = bnxt; bnxt = tmp;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // the link, every lane on its R rows (independent chains)
+#pragma unroll
+      for (int m = 0; m < R; ++m) {
+        const int r = li + GS * m;
+        const bool live = r < K && samp;
+        if constexpr (CORR) {
+          // corr.jl:277-297 / :314-335: bottom-up along column r of U (= my row), y in place;
+          // log-det = -_logabsdetjac_inv_corr(y) (:92, :135-137, :453-472): weight K - i for 0-based row i.
+          // The entries right of the diagonal are zeroed first: a zero entry leaves the running remainder alone and has logcosh = 0
+          // exactly, so the walk itself needs no per-lane predicate (47 live compare masks spilled the scalar registers otherwise),
+          // and Σ (K - i) lc_i = K Σ lc_i - Σ i lc_i keeps the weights compile-time constants.
+          T dg = T(1);
+#pragma unroll
+          for (int j = 0; j < GS * (m + 1); ++j) {
+            if (j >= GS * m) dg = j == r ? A_(m, j) : dg;
+            A_(m, j) = j < r ? A_(m, j) : T(0);
+          }
+          T rem, Lr, sa = T(0), sb = T(0);
+          M::fwd_init(dg, rem, Lr);
+#pragma unroll
+          for (int i = GS * (m + 1) - 2; i >= (KIND == MK_VEC_CORR ? 1 : 0); --i) {
+            T y, lc;
+            M::fwd_step(A_(m, i), rem, Lr, y, lc);
+            sa += lc; sb += T(i) * lc;
+            A_(m, i) = y;
+          }
+          if (KIND == MK_VEC_CORR) {                                    // :322 atanh(W[1, j]) on the first row (weight K)
+            T y, lc;
+            M::atanh_lc(A_(m, 0), y, lc);
+            sa += lc;
+            A_(m, 0) = y;
+          }
+          lsum += T(K) * sa - sb;
+          __builtin_amdgcn_sched_barrier(0);
+          // The group's rows go through an LDS tile and leave as stores whose GS lanes cover CONSECUTIVE addresses (32 / 64-byte
+          // segments).  A lane writing its own contiguous run (16-byte stores, K floats apart from its neighbour's) measured 30 - 40 %
+          // slower on the whole kernel: partial-line writes from 64 different lines per instruction.
+          if (dst && !STAGE) {                                          // K <= 16: the rows are short, the lane writes its own run
+            if (live) {
+              if (KIND == MK_VEC_CORR) {
+                T* o = dst + r * (r - 1) / 2;                          // triu1_to_vec: column r holds rows 0 .. r-1
+#pragma unroll
+                for (int i = 0; i < GS * (m + 1) - 1; ++i) if (i < r) o[i] = A_(m, i);
+              } else {
+                T* o = dst + r * K;                                     // Y[:, r]: values above the diagonal, zeros on and below (:292-294)
+#pragma unroll
+                for (int i = 0; i < KC; ++i) if (i < K) o[i] = (i < GS * (m + 1) && i < r) ? A_(m, i < GS * (m + 1) ? i : 0) : T(0);
+              }
+            }
+          }
+          if (dst && STAGE) {
+            T* tile = bufs + g * (GS * (KC + 4) + 4);
+            T* mine = tile + li * (KC + 4);
+#pragma unroll
+            for (int t4 = 0; t4 < GS * (m + 1); t4 += 4) {
+              if constexpr (sizeof(T) == 4) *reinterpret_cast<bjx_f32x4*>(mine + t4) = bjx_f32x4{A_(m, t4), A_(m, t4 + 1), A_(m, t4 + 2), A_(m, t4 + 3)};
+              else { *reinterpret_cast<bjx_f64x2*>(mine + t4) = bjx_f64x2{A_(m, t4), A_(m, t4 + 1)}; *reinterpret_cast<bjx_f64x2*>(mine + t4 + 2) = bjx_f64x2{A_(m, t4 + 2), A_(m, t4 + 3)}; }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int cc = 0; cc < GS; ++cc) {
+              const int c = GS * m + cc;                                 // row c of L = column c of the output
+              if (c < K && samp) {
+                if (KIND == MK_VEC_CORR) {
+                  T* o = dst + c * (c - 1) / 2;                         // triu1_to_vec: column c holds rows 0 .. c-1
+#pragma unroll
+                  for (int i0 = 0; i0 < GS * (m + 1) - 1; i0 += GS) if (i0 < c && i0 + li < c) o[i0 + li] = tile[cc * (KC + 4) + i0 + li];
+                } else {
+                  T* o = dst + c * K;                                    // Y[:, c]: values above the diagonal, zeros on and below (:292-294)
+#pragma unroll
+                  for (int i0 = 0; i0 < KC; i0 += GS) if (i0 + li < K) o[i0 + li] = (i0 < GS * (m + 1) && i0 + li < c) ? tile[cc * (KC + 4) + (i0 < GS * (m + 1) ? i0 : 0) + li] : T(0);
+                }
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        } else {
+          // pd.jl:11,27-31,41: Y = replace_diag(log, L); log-det = -(sum_i (d+1-i) log L_ii + d log 2), 0-based i
+          T dg = T(1);
+#pragma unroll
+          for (int j = GS * m; j < GS * (m + 1); ++j) dg = j == r ? A_(m, j) : dg;
+          const T ld = M::log(dg);
+          if (live) lsum -= T(K + 1 - r) * ld + Num<T>::log2;
+          if (dst) {
+            if (KIND == MK_PD) {
+              if (live) {
+#pragma unroll
+                for (int j = 0; j < KC; ++j) if (j < K) dst[(int64_t)j * K + r] = j == r ? ld : ((j < GS * (m + 1) && j < r) ? A_(m, j < GS * (m + 1) ? j : 0) : T(0));   // Y[r, j]: the GS lanes write consecutive addresses
+              }
+            } else if (!STAGE) {
+              if (live) {
+                T* o = dst + r * (r + 1) / 2;                          // triu_to_vec(Y'): column r holds L[r][0 .. r] with the log diagonal
+#pragma unroll
+                for (int j = 0; j < GS * (m + 1); ++j) if (j <= r) o[j] = j == r ? ld : A_(m, j);
+              }
+            } else {
+              // triu_to_vec(Y'): column c holds L[c][0 .. c] with the log diagonal — staged like the correlation outputs
+              T* tile = bufs + g * (GS * (KC + 4) + 4);
+              T* mine = tile + li * (KC + 4);
+#pragma unroll
+              for (int j = 0; j < GS * (m + 1); ++j) mine[j] = j == r ? ld : A_(m, j);
+              __builtin_amdgcn_wave_barrier();
+#pragma unroll
+              for (int cc = 0; cc < GS; ++cc) {
+                const int c = GS * m + cc;
+                if (c < K && samp) {
+                  T* o = dst + c * (c + 1) / 2;
+#pragma unroll
+                  for (int i0 = 0; i0 < GS * (m + 1); i0 += GS) if (i0 <= c && i0 + li <= c) o[i0 + li] = tile[cc * (KC + 4) + i0 + li];
+                }
+              }
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+        }
+      }
+    } else {
+      // ---------------------------------------------------------------- inverse link -> L (exact zeros right of the diagonal) -> X = L L'
+#pragma unroll
+      for (int m = 0; m < R; ++m) {
+        const int r = li + GS * m;
+        const bool live = r < K && samp;
+        if constexpr (CORR) {
+          // corr.jl:345-399: column r of U top-down; + (K - j) log U[j,j] for 2 <= j <= K-1 (1-based; :77-79, :144-146)
+          T lr = T(0), E, sall = T(0);
+          M::inv_init(E);
+          const T* yv = KIND == MK_VEC_CORR ? src + r * (r - 1) / 2 : src + (int64_t)r * K;
+#pragma unroll
+          for (int i = 0; i < GS * (m + 1); ++i) {
+            const T y = (i < r && live) ? yv[i] : T(0);
+            T w, lc;
+            M::inv_step(y, E, w, lc);                                   // y = 0 right of the diagonal: w = 0, lc = 0, E and lr unchanged
+            lr -= lc; sall += lr;
+            A_(m, i) = w;
+            if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);        // keeps the loads next to their use (hoisted, they cost a register each)
+          }
+          // the steps right of the diagonal each added the FINAL lr: take them out again
+          lsum += sall - T(GS * (m + 1) - r) * lr;
+          const T dgv = live ? M::inv_diag(E, lr) : T(1);               // the diagonal closes the unit row; padding rows are the identity
+#pragma unroll
+          for (int j = GS * m; j < GS * (m + 1); ++j) A_(m, j) = j == r ? dgv : A_(m, j);
+          if (live) lsum += lr + ((r >= 1 && r <= K - 2) ? T(K - 1 - r) * lr : T(0));
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          // pd.jl:13-16,44-47: L = lower_triangular(replace_diag(exp, Y)); log-det = +(sum_i (d+1-i) Y_ii + d log 2)
+#pragma unroll
+          for (int j = 0; j < GS * (m + 1); ++j) {
+            T v = T(0);
+            if (live && j <= r) {
+              const T t = KIND == MK_PD ? src[(int64_t)j * K + r] : src[r * (r + 1) / 2 + j];
+              if (j == r) { lsum += T(K + 1 - r) * t + Num<T>::log2; v = M::exp(t); } else v = t;
+            } else if (!live && j == r) v = T(1);
+            A_(m, j) = v;
+          }
+        }
+      }
+      if (dst) {
+        // X = L L'.  The rows of L are published one ROW GROUP at a time (every lane owns exactly one row of group mj: no
+        // divergence, R write -> read round trips per sample instead of K), then X[r][j] = <row r, row j> for the lane's R rows
+        // (zeros right of a row's diagonal make the dot over t <= j exact).  X is symmetric by construction — the same products in
+        // the same order on both sides — so the lane writes X[r][j] into COLUMN r (r K + j: contiguous in j, 16-byte stores).
+        T* tile = bufs + g * (GS * (KC + 4) + 4);                   // + 4: the samples' tiles start 4 banks apart (a multiple of 64 words put every sample on the same banks)
+#pragma unroll
+        for (int mj = 0; mj < R; ++mj) {
+          T* mine = tile + li * (KC + 4);
+#pragma unroll
+          for (int t4 = 0; t4 < GS * (mj + 1); t4 += 4) {
+            if constexpr (sizeof(T) == 4) *reinterpret_cast<bjx_f32x4*>(mine + t4) = bjx_f32x4{A_(mj, t4), A_(mj, t4 + 1), A_(mj, t4 + 2), A_(mj, t4 + 3)};
+            else { *reinterpret_cast<bjx_f64x2*>(mine + t4) = bjx_f64x2{A_(mj, t4), A_(mj, t4 + 1)}; *reinterpret_cast<bjx_f64x2*>(mine + t4 + 2) = bjx_f64x2{A_(mj, t4 + 2), A_(mj, t4 + 3)}; }
+          }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int jq = 0; jq < GS; jq += 4) {
+            T x[R][4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int j = GS * mj + jq + jj;
+#pragma unroll
+              for (int m = 0; m < R; ++m) x[m][jj] = T(0);
+#pragma unroll
+              for (int t4 = 0; t4 <= j; t4 += 4) {
+                const QuadC<T> q = lds_quad4<T>(tile + (jq + jj) * (KC + 4) + t4);      // row j of L: one address for the sample's GS lanes
+#pragma unroll
+                for (int m = 0; m < R; ++m) {
+                  if (GS * (m + 1) > t4) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (t4 + t <= j) x[m][jj] += A_(m, t4 + t) * q.v[t];
+                  }
+                }
+              }
+            }
+            const int j0 = GS * mj + jq;
+            {
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                if (j0 + jj < K) {
+#pragma unroll
+                  for (int m = 0; m < R; ++m) if (li + GS * m < K && samp) dst[(int64_t)(j0 + jj) * K + li + GS * m] = x[m][jj];
+                }
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+    if (ladj_ps || partials) {
+      double l = (double)lsum;
+#pragma unroll
+      for (int off = 1; off < GS; off <<= 1) l += shfl_xor(l, off);
+      if (li == 0 && samp) {
+        const T lt = (T)l;
+        if (ladj_ps) ladj_ps[s0 + g] = accumulate ? ladj_ps[s0 + g] + lt : lt;
+        acc += (double)lt;
+      }
+    }
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+#undef A_
+#undef OFF
+}
+
+template <class T, int GS, int R, int KIND>
+void launch_cyc(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* partials, int K, int64_t batch, int accum, int vec_ok, int grid) {
+  if (inverse) hipLaunchKernelGGL((matrix_cyc_kernel<T, GS, R, KIND, true>), dim3(grid), dim3(64), 0, ctx->stream, in, out, ladj_ps, K, batch, accum, vec_ok, partials);
+  else hipLaunchKernelGGL((matrix_cyc_kernel<T, GS, R, KIND, false>), dim3(grid), dim3(64), 0, ctx->stream, in, out, ladj_ps, K, batch, accum, vec_ok, partials);
+}
+
+template <class T, int KIND>
+int matrix_cyc_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t K, int64_t batch, uint32_t flags) {
+  // (lanes per sample, rows per lane) — same-box sweeps at K = 13 ... 64, profiles/r04_matrix_cyc.md:
+  //   K <= 16: 8 lanes x 2 rows;  forward, Float32, 16 < K <= 32: 8 lanes x 4 rows (8 samples a wave: 37-46 % of the HBM peak against 36-46 % for 16 x 2 up to K = 24 and 41 against 36 at K = 32)
+  //   inverse and Float64, 16 < K <= 32: 16 x 2 (the 8 x 4 inverse holds 170-250 registers: one wave per SIMD)
+  //   K <= 64 (Float32): 32 x 2, two samples a wave
+  const bool f32 = sizeof(T) == 4;
+  const int shape = K > 32 ? 322 : (K <= 16 ? 82 : ((!inverse && f32) ? 84 : 162));
+  const int gs = shape / 10 >= 32 ? 32 : shape / 10;
+  const int nsw = 64 / gs;
+  const int64_t groups = (batch + nsw - 1) / nsw;
+  const int64_t cap = (int64_t)ctx->num_cu * 32;
+  const int grid = (int)(groups < cap ? groups : cap);
+  if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
+  double* partials = ladj_sum ? ctx->partials : nullptr;
+  const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  const int vec_ok = (K % 4 == 0 && bjx_aligned16(in)) ? 1 : 0;
+  {
+    BjxProf prof_(ctx);
+    if (shape == 84) {
+      if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((matrix_cyc_kernel<T, 8, 4, KIND, false>), dim3(grid), dim3(64), 0, ctx->stream, in, out, ladj_ps, (int)K, batch, accum, vec_ok, partials);
+    } else if (shape == 82) launch_cyc<T, 8, 2, KIND>(ctx, inverse, in, out, ladj_ps, partials, (int)K, batch, accum, vec_ok, grid);
+    else if (shape == 162) launch_cyc<T, 16, 2, KIND>(ctx, inverse, in, out, ladj_ps, partials, (int)K, batch, accum, vec_ok, grid);
+    else { if constexpr (sizeof(T) == 4) launch_cyc<T, 32, 2, KIND>(ctx, inverse, in, out, ladj_ps, partials, (int)K, batch, accum, vec_ok, grid); }
+  }
+  BJX_CHECK_LAUNCH(ctx);
+  if (ladj_sum) return bjx_launch_finalize(ctx, grid, ladj_sum, 0.0, 0, 0.0, flags);
+  return BJX_OK;
+}
+
+}  // namespace
+
+// 12 < K <= 64.  *taken = false: the caller's own kernels run.
+int bjx_matrix_cyc(bjx_ctx* ctx, int dt, int kind, int inverse, const void* in, void* out, void* ladj_ps, double* ladj_sum, int64_t K, int64_t batch,
+                   uint32_t flags, bool* taken) {
+  static const int use = getenv("BJX_MATRIX_CYC") ? atoi(getenv("BJX_MATRIX_CYC")) : 1;            // tuning switch (0: matrix_link_kernel, one row per lane)
+  *taken = false;
+  if (!use || K <= 12 || K > 64 || batch == 0) return BJX_OK;
+  if (dt == BJX_F64 && K > 32) return BJX_OK;                        // (32 x 2 rows of Float64: 192 registers of factor alone)
+  *taken = true;
+#define CYC(T_) switch (kind) { \
+    case MK_VEC_CORR: return matrix_cyc_impl<T_, MK_VEC_CORR>(ctx, inverse, (const T_*)in, (T_*)out, (T_*)ladj_ps, ladj_sum, K, batch, flags); \
+    case MK_CORR: return matrix_cyc_impl<T_, MK_CORR>(ctx, inverse, (const T_*)in, (T_*)out, (T_*)ladj_ps, ladj_sum, K, batch, flags); \
+    case MK_PD: return matrix_cyc_impl<T_, MK_PD>(ctx, inverse, (const T_*)in, (T_*)out, (T_*)ladj_ps, ladj_sum, K, batch, flags); \
+    default: return matrix_cyc_impl<T_, MK_PD_VEC>(ctx, inverse, (const T_*)in, (T_*)out, (T_*)ladj_ps, ladj_sum, K, batch, flags); }
+  if (dt == BJX_F32) { CYC(float) }
+  CYC(double)
+#undef CYC
+}

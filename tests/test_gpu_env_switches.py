@@ -18,7 +18,7 @@ SETTINGS = [
     "BJX_U=1", "BJX_U=2", "BJX_NT=0", "BJX_CHAIN_WALKER=0", "BJX_CHAIN_WALKER_MAX=8", "BJX_CHAIN_FLATCOL=0", "BJX_CHAIN_COLBATCH=0", "BJX_COLWALK=0",
     "BJX_PLANAR_REG=0", "BJX_PLANAR_COLS=32", "BJX_PLANAR_SPLIT=0", "BJX_PLANAR_SPLIT=1", "BJX_PLANAR_MFMA=1", "BJX_PLANAR_MFMA=2", "BJX_PLANAR_MFMA=4",
     "BJX_PLANAR_MFMA64=0", "BJX_PLANAR_TILE=0", "BJX_FLOW_WALK_MAX=0", "BJX_RADIAL_WALK_ALL=1", "BJX_PLANAR_PARAM_MFMA=0", "BJX_PLANAR_PARAM_BLOCKS=64",
-    "BJX_SCALE_MFMA=0", "BJX_SCALE_AREG=1", "BJX_MATRIX_LANE_MAX=0", "BJX_MATRIX_LANE_DIRECT=0",
+    "BJX_SCALE_MFMA=0", "BJX_SCALE_AREG=1", "BJX_MATRIX_LANE_MAX=0", "BJX_MATRIX_LANE_DIRECT=0", "BJX_MATRIX_CYC=0",
     "BJX_SEQ_WAVE=0", "BJX_SEQ_STREAM=0", "BJX_SEQ_CHUNK_MIN=1000", "BJX_SEQ_CHUNK_MIN=100000000", "BJX_SIMPLEX_INV_G=1", "BJX_SIMPLEX_INV_G=4",
     "BJX_ORDERED_VJP_STREAM=0", "BJX_SIMPLEX_VJP_STREAM=0", "BJX_SIMPLEX_VJP_G=4", "BJX_SIMPLEX_VJP_CHUNK_MIN=1000", "BJX_SIMPLEX_VJP_CHUNK_MIN=100000000",
     "BJX_SEQ_TINY=0", "BJX_SEQ_TINY_MAX=3", "BJX_SEQ_TALL=0", "BJX_SEQ_TALL_MIN=250", "BJX_SEQ_TALL_INV_MAX=100", "BJX_SEQ_TALL_EFF=0.95", "BJX_SIMPLEX_VJP_TALL=0", "BJX_SIMPLEX_VJP_TALL_MIN=250",
