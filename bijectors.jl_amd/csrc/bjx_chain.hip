@@ -710,7 +710,7 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
   // round trip, so its compute latency must be amortised over enough bytes in flight.  1 light
   // stage: 2 packs (6.3 TB/s vs 5.9 with 1 / 5.7 with 4); anything heavier: 4 packs
   // (C2 6.1 TB/s, C2 with per-row vectors 5.8 vs 5.0 with 2).
-  static const int tune_u = env_int("BJX_U", 0);
+  static const int tune_u = 0;
   const int upt = tune_u ? tune_u : ((n_ops <= 1 && !any_row) ? 2 : 4);
 #define LAUNCH_FLAT_UV(V_, RM_, U_)                                                                           \
   do {                                                                                                        \
@@ -796,7 +796,7 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
       }
     }
     static const int use_unal = env_int("BJX_CHAIN_UNALIGNED", 1);
-    static const int unal_min = env_int("BJX_CHAIN_UNALIGNED_MIN", 48);
+    static const int unal_min = 48;
     // (same-box A/B, 2^22 columns: 63 ... 257 rows 56-67 % against 12-46 %; 1001 / 2049 rows 56 / 64 % against 41 / 54 %; between 65
     //  and ~250 packs per column the lanes of a 64-lane group hold one to three packs each and the group kernel runs its three-pack
     //  remainder for all of them: 26-47 % against 37-52 % for the 4-byte path, which keeps those heights)
@@ -837,7 +837,7 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
     static const int use_walker = env_int("BJX_CHAIN_WALKER", 1);
     bool pow2_packs = false;
     if (v_ok) { const int64_t pk = dim / VW; pow2_packs = pk <= 64 && (pk & (pk - 1)) == 0; }
-    static const int walker_max = env_int("BJX_CHAIN_WALKER_MAX", 32);      // whole-pack columns taller than this: chain_colbatch_kernel (the walker's tile costs occupancy)
+    static const int walker_max = 32;      // whole-pack columns taller than this: chain_colbatch_kernel (the walker's tile costs occupancy)
     if (use_walker && !pow2_packs && (!v_ok || dim <= walker_max) && y && (const void*)x != (const void*)y && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0 && n_ops <= BJX_MAX_SEG_OPS && dim >= 1) {
       bool plain = true;
       for (int k = 0; k < n_ops; ++k) plain = plain && ops[k].kind >= BJX_OP_EXP && ops[k].kind <= BJX_OP_IDENTITY;

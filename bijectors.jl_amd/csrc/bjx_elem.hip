@@ -818,7 +818,7 @@ constexpr size_t kRqsBlobMax = 64 * 1024;
 // 8-16 KiB of data is not free); and FIVE blocks per CU instead of four (no static LDS, the reduction scratch aliases the dead
 // table: 5 x 32 KiB = 160 KiB) — neutral, kept because it costs nothing.
 inline int rqs_iters(const bjx_ctx* ctx, size_t blob_bytes, int64_t bytes_per_group, int64_t groups) {
-  static const int forced = [] { const char* e = getenv("BJX_RQS_ITERS"); return e ? atoi(e) : 0; }();   // tuning switch
+  static const int forced = 0;   // tuning switch
   if (forced > 0) return forced;
   int64_t amort = (3 * (int64_t)blob_bytes + bytes_per_group - 1) / bytes_per_group;
   if (amort < 1) amort = 1;

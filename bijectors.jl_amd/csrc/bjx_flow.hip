@@ -2230,7 +2230,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
     // columns that are not whole aligned packs (odd heights, or a base that is only 4-byte aligned) run the same kernels on
     // element-aligned packs (reg_load_pack).  They used to fall to the LDS-tile kernel: 4-28 % of the HBM peak at 33-255 rows.
     static const int use_unal = getenv("BJX_PLANAR_REG_UNALIGNED") ? atoi(getenv("BJX_PLANAR_REG_UNALIGNED")) : 1;
-    static const int unal_nt = getenv("BJX_UNAL_NT") ? atoi(getenv("BJX_UNAL_NT")) : 0;
+    static const int unal_nt = 0;
     const bool packs_ok = dim % 4 == 0 && bjx_aligned16(in) && bjx_aligned16(out);
     // 256 < dim <= 1024, two layers or more: the tile split over 8 / 16 waves of one block (planar_reg2_kernel, NW = 8 / 16)
     static const int use_big = getenv("BJX_PLANAR_REG_BIG") ? atoi(getenv("BJX_PLANAR_REG_BIG")) : 1;
@@ -2251,7 +2251,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         hipLaunchKernelGGL(planar_prep_reg_kernel<float>, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, (const float*)w, (const float*)u_hat,
                            (const float*)wtu, (const float*)b, dim, nl, nl_pad, wp, up, Gp, cp, bp, ldw);
         BJX_CHECK_LAUNCH(ctx);
-        static const int cols_env = getenv("BJX_PLANAR_COLS") ? atoi(getenv("BJX_PLANAR_COLS")) : 0;
+        static const int cols_env = 0;
         const int G = dim > 64 ? 32 : (dim > 32 ? 16 : 8);
         const int cols = (G == 32 && (cols_env ? cols_env == 32 : PLANAR_REG_DEFAULT_COLS == 32)) ? 32 : 64;
         // two waves per tile for 64 < dim <= 128.  Measured (A/B in one run, 2^22 columns, d = 128): 8 layers forward
@@ -2435,7 +2435,7 @@ inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float
                           const float* out_bar, const float* ladj_bar, float* in_bar, int64_t dim, int64_t batch, float* t_out, float* s_out) {
   static const int use_reg = getenv("BJX_PLANAR_REG") ? atoi(getenv("BJX_PLANAR_REG")) : 1;
   static const int use_unal = getenv("BJX_PLANAR_REG_UNALIGNED") ? atoi(getenv("BJX_PLANAR_REG_UNALIGNED")) : 1;
-  static const int unal_nt = getenv("BJX_UNAL_NT") ? atoi(getenv("BJX_UNAL_NT")) : 0;
+  static const int unal_nt = 0;
   const bool packs_ok = dim % 4 == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
   if (!(use_reg && (packs_ok || (use_unal && dim > 32)) && dim > 16 && dim <= 128)) return 1;
   const int NL = nl >= 8 ? 8 : (nl > 2 ? 4 : nl);
@@ -3167,7 +3167,7 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
   const int cols_per_block = 256 / c.G;
   constexpr int VW = Vec16<T>::N;
   static const int use_mfma = getenv("BJX_PLANAR_PARAM_MFMA") ? atoi(getenv("BJX_PLANAR_PARAM_MFMA")) : 1;
-  static const int mfma_blocks = getenv("BJX_PLANAR_PARAM_BLOCKS") ? atoi(getenv("BJX_PLANAR_PARAM_BLOCKS")) : 1024;
+  static const int mfma_blocks = 1024;
   const bool mfma = use_mfma && std::is_same<T, float>::value && c.V == VW && (dim == 64 || dim == 128 || dim == 256) && bjx_aligned16(out_bar);   // 192 rows: three slices do not divide the four waves, one wave per column needs 357 registers
   // persistent grids with equal grid-stride shares: every block must be resident (a second round doubles the time)
   const bool small_walk = (std::is_same<T, float>::value && dim <= 32) || dim <= 12;   // single-wave blocks of 64 columns (planar_param_mfma_small_kernel / planar_param_walk_kernel)

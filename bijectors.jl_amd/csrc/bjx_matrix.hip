@@ -1176,7 +1176,7 @@ int scale_matrix_impl(bjx_ctx* ctx, int inverse, const T* a, const T* in, T* out
       const int64_t tiles = (batch + 63) / 64;
       const int64_t capm = (int64_t)ctx->num_cu * (smem_m > 80 * 1024 ? 1 : (smem_m > 40 * 1024 ? 2 : 4));
       const int gridm = (int)(tiles < capm ? tiles : capm);
-      static const int areg = getenv("BJX_SCALE_AREG") ? atoi(getenv("BJX_SCALE_AREG")) : 0;
+      static const int areg = 0;
 #define BJX_SMM(N_) do { if (areg) { bjx_allow_big_lds(scale_matrix_mfma_kernel<T, N_, true>, smem_m); \
       hipLaunchKernelGGL((scale_matrix_mfma_kernel<T, N_, true>), dim3(gridm), dim3(256), smem_m, ctx->stream, M, ldm, in, out, ladj_ps, (int)dim, batch, accum, lad); } \
       else { bjx_allow_big_lds(scale_matrix_mfma_kernel<T, N_, false>, smem_m); \

@@ -290,7 +290,7 @@ int launch_seq(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_ps, doub
     // (same-box A/B, profiles/r03_tall_columns.md: the chunk loads are runs of 256 bytes that straddle cache lines, so part of
     //  every line is fetched twice — the chunked walker wins only where the whole-column tile leaves < 3 waves per CU:
     //  K = 100: 30 % against 49 %, 200: 29-34 % against 27-31 %, 256: 39-68 % against 35-61 %, 1000: 34-41 % (no tile at all))
-    static const long chunk_min = getenv("BJX_SEQ_CHUNK_MIN") ? atol(getenv("BJX_SEQ_CHUNK_MIN")) : 50 * 1024;
+    static const long chunk_min = 50 * 1024;
     if (smem_w > (size_t)chunk_min && rows_in >= 1 && rows_out >= 1)
       return launch_seq_chunk<T, Op>(ctx, op, in, out, ladj_ps, ladj_sum, rows_in, rows_out, batch, n_logk, flags, ld_in, ld_out);
     if (use_wave && smem_w <= 64 * 1024 && rows_in >= 1 && rows_out >= 1) {   // larger columns: the chunked block kernel below
@@ -1790,7 +1790,7 @@ int simplex_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, c
   }
   {
     bool taken = false;
-    static const int g_inv = getenv("BJX_SIMPLEX_VJP_G") ? atoi(getenv("BJX_SIMPLEX_VJP_G")) : 2;
+    static const int g_inv = 2;
     int rc;
     if (!inverse || g_inv == 4) rc = launch_simplex_vjp_stream<T, 4>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch, &taken);
     else rc = launch_simplex_vjp_stream<T, 2>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch, &taken);
@@ -1805,7 +1805,7 @@ int simplex_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, c
   // tall columns: the chunked two-pass kernel (two whole-column tiles of 64 columns cost 2·64·K words: beyond `chunk_min` bytes
   // the whole-column kernel runs with too few waves, then with too few lanes)
   // (K = 100: 22 / 13 % against 29 / 23 % for the whole-column kernel; K = 200: 24 / 13 % against 11 / 9 %; K = 500: 24 / 14 % against 6 / 5 %)
-  static const long vjp_chunk_min = getenv("BJX_SIMPLEX_VJP_CHUNK_MIN") ? atol(getenv("BJX_SIMPLEX_VJP_CHUNK_MIN")) : 80 * 1024;
+  static const long vjp_chunk_min = 80 * 1024;
   if (((size_t)2 * 64 * (K | 1) + (size_t)K) * sizeof(T) > (size_t)vjp_chunk_min) {
     constexpr int CH = 128 / (int)sizeof(T);
     const bool table = (size_t)K * sizeof(T) <= 40 * 1024;
@@ -2547,7 +2547,7 @@ int simplex_impl(bjx_ctx* ctx, int inverse, const T* in, T* out, T* ladj_ps, dou
     if (!inverse) rc = want ? launch_quad_stream<T>(ctx, QSimplexFwd<T, true>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken)
                             : launch_quad_stream<T>(ctx, QSimplexFwd<T, false>{}, in, out, ladj_ps, ladj_sum, K, batch, flags, &taken);
     else {
-      static const int g_env = getenv("BJX_SIMPLEX_INV_G") ? atoi(getenv("BJX_SIMPLEX_INV_G")) : 2;
+      static const int g_env = 2;
       const int g4 = g_env == 4;
       constexpr int VWq = Vec16<T>::N;
       // BJX_SIMPLEX_INV_G=1: one lane per column — the clamped recurrence runs once per element (19 % fewer VALU

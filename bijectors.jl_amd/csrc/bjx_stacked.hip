@@ -735,7 +735,7 @@ int stacked_mixed_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const 
   // of BJX_MIXED_GPB = 1 / 2 / 3 / 4 / 6 / 8 at dim = 2, 3, 5, 10: +5-14 % at 2-3, nothing beyond — a wave that lives for more groups
   // leaves too few waves per CU)
   const int64_t groups = (batch + 63) / 64;
-  static const int gpb_env = getenv("BJX_MIXED_GPB") ? atoi(getenv("BJX_MIXED_GPB")) : 0;
+  static const int gpb_env = 0;
   int64_t gpb = gpb_env > 0 ? gpb_env : 8192 / (64 * (rows_in > rows_out ? rows_in : rows_out) * (int64_t)sizeof(T));
   if (gpb_env <= 0) { if (gpb > 3) gpb = 3; if (gpb > groups / 16384) gpb = groups / 16384; }
   gpb = gpb < 1 ? 1 : (gpb > 16 ? 16 : gpb);

@@ -497,7 +497,7 @@ template <class T> inline ColLaunch col_launch_cfg(const bjx_ctx* ctx, const voi
   // walker still wins, 58 / 54 and 54 / 49 against 56 / 46 and 40 / 42; at 77 rows it is 43 / 46 against 50 / 50): 16-byte packs on element-aligned addresses, the dim % V tail rows on one lane each.
   // Callers that build V-permuted tables must ask with the same flag.
   static const int use_unal = getenv("BJX_COL_UNALIGNED") ? atoi(getenv("BJX_COL_UNALIGNED")) : 1;
-  static const int unal_min = getenv("BJX_COL_UNALIGNED_MIN") ? atoi(getenv("BJX_COL_UNALIGNED_MIN")) : 80;
+  static const int unal_min = 80;
   const bool window = ldx > dim && ldy > dim;             // a row window of taller arrays (slabs): no tile walker to fall back on
   if (allow_unal && use_unal && !v_ok && dim >= (window ? 2 * VW : unal_min) && dim >= VW) {
     c.V = VW;
@@ -626,7 +626,7 @@ inline int launch_colgroup(bjx_ctx* ctx, const F& f, size_t f_smem, const T* x, 
   {
   BjxProf prof_(ctx);
   if (c.V == VW && c.unal && dim % VW != 0) {
-    static const int unal_nt = getenv("BJX_UNAL_NT") ? atoi(getenv("BJX_UNAL_NT")) : 0;
+    static const int unal_nt = 0;
     if constexpr (col_has_masked<F>::value && Vec16<T>::N > 1)
       hipLaunchKernelGGL((colgroup_tail_kernel<T, VW, F>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, f, x, y, ladj_ps, dim, batch, c.G, accum, fin, ldx, ldy, row0, unal_nt);
     else

@@ -778,7 +778,7 @@ int launch_tall_simplex_vjp(bjx_ctx* ctx, int inverse, const T* in, const T* out
   const int64_t grid = (waves + C::WPB - 1) / C::WPB;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
   const int64_t rows_a = inverse ? K - 1 : K, rows_g = inverse ? K : K - 1;
-  static const int vjp_scan = getenv("BJX_SIMPLEX_VJP_TALL_SCAN") ? atoi(getenv("BJX_SIMPLEX_VJP_TALL_SCAN")) : 1;   // 0: take-turns rounds in the pullback of the inverse
+  static const int vjp_scan = 1;   // 0: take-turns rounds in the pullback of the inverse
   const bool al = bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
   const bool vk = al && K % C::V == 0, vk1 = al && (K - 1) % C::V == 0;
   const bool va = inverse ? vk1 : vk, vg = inverse ? vk : vk1;
@@ -855,8 +855,8 @@ int bjx_tall_stream(bjx_ctx* ctx, bjx_dtype dt, int which, const void* in, void*
   *taken = false;
   static const int use_tall = getenv("BJX_SEQ_TALL") ? atoi(getenv("BJX_SEQ_TALL")) : 1;
   // the Simplex inverse pays four chain operations per row and round: beyond `inv_max` rows the chunked walker is ahead (same-box A/B)
-  static const long inv_max = getenv("BJX_SEQ_TALL_INV_MAX") ? atol(getenv("BJX_SEQ_TALL_INV_MAX")) : 512;
-  static const long min_rows = getenv("BJX_SEQ_TALL_MIN") ? atol(getenv("BJX_SEQ_TALL_MIN")) : 65;
+  static const long inv_max = 512;
+  static const long min_rows = 65;
   const int rpl = dt == BJX_F32 ? 32 : 16;
   const int64_t rows = rows_in > rows_out ? rows_in : rows_out;
   if (!use_tall || batch <= 0 || rows < min_rows || rows > 64 * rpl) return BJX_OK;
@@ -866,7 +866,7 @@ int bjx_tall_stream(bjx_ctx* ctx, bjx_dtype dt, int which, const void* in, void*
   // (Float32, K = 1000, y ~ N(0, 1.5²): 7 % of the columns beyond the 1e-3 bar); and it ignores the clamp — after a saturated row
   // (z_k = 1: the rest of the stick at once) the reference pins Σ at 1 and every later term at log ε, the unclamped Σ drifts back by ε
   // per row and the terms with it (tests/test_gpu_parity.py::test_simplex_inverse_tall_columns_with_clamped_rows, either dtype).
-  static const int scan_env = getenv("BJX_SEQ_TALL_INV_SCAN") ? atoi(getenv("BJX_SEQ_TALL_INV_SCAN")) : -1;
+  static const int scan_env = -1;
   const int inv_scan = scan_env > 0 ? 1 : 0;
   // with rounds the chunked walker is ahead beyond 512 rows (four chain operations per row and round)
   if (which == BJX_TALL_SIMPLEX_INV && (rows > (inv_scan ? 2048 : inv_max) || rows < 129)) return BJX_OK;   // 65-128 rows: the whole-column tile is ahead (45 against 43 % at K = 100)
@@ -877,7 +877,7 @@ int bjx_tall_stream(bjx_ctx* ctx, bjx_dtype dt, int which, const void* in, void*
   const int G = (int)((rows + rpl - 1) / rpl), CPS = 64 / G;
   // lanes that hold rows of a column / lanes of the wave: K just above a multiple of RPL wastes most of the last lane
   const double eff = (double)rows * CPS / (64.0 * rpl);
-  static const double min_eff = getenv("BJX_SEQ_TALL_EFF") ? atof(getenv("BJX_SEQ_TALL_EFF")) : 0.6;
+  static const double min_eff = 0.6;
   if (eff < min_eff) return BJX_OK;
   *taken = true;
   if (dt == BJX_F32) return tall_dispatch<float>(ctx, which, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, rows_in, rows_out, batch, flags, inv_scan);
@@ -889,13 +889,13 @@ int bjx_tall_simplex_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in
                          int64_t batch, bool* taken) {
   *taken = false;
   static const int use_tall = getenv("BJX_SIMPLEX_VJP_TALL") ? atoi(getenv("BJX_SIMPLEX_VJP_TALL")) : 1;
-  static const long min_rows = getenv("BJX_SIMPLEX_VJP_TALL_MIN") ? atol(getenv("BJX_SIMPLEX_VJP_TALL_MIN")) : 65;
-  static const long inv_max = getenv("BJX_SIMPLEX_VJP_TALL_INV_MAX") ? atol(getenv("BJX_SIMPLEX_VJP_TALL_INV_MAX")) : 2048;
+  static const long min_rows = 65;
+  static const long inv_max = 2048;
   const int rpl = dt == BJX_F32 ? 32 : 16;
   if (!use_tall || batch <= 0 || K < min_rows || K > 64 * rpl) return BJX_OK;
   if (inverse && K > inv_max) return BJX_OK;
   const int G = (int)((K + rpl - 1) / rpl), CPS = 64 / G;
-  static const double min_eff = getenv("BJX_SEQ_TALL_EFF") ? atof(getenv("BJX_SEQ_TALL_EFF")) : 0.6;
+  static const double min_eff = 0.6;
   if ((double)K * CPS / (64.0 * rpl) < min_eff) return BJX_OK;
   *taken = true;
   if (dt == BJX_F32) return launch_tall_simplex_vjp<float>(ctx, inverse, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, K, batch);

@@ -246,7 +246,7 @@ int bjx_seq_tiny_vjp(bjx_ctx* ctx, bjx_dtype dt, int simplex, int inverse, const
                      int64_t batch, bool* taken) {
   *taken = false;
   static const int use_tiny = getenv("BJX_SEQ_TINY") ? atoi(getenv("BJX_SEQ_TINY")) : 1;
-  static const int kmax = getenv("BJX_SEQ_TINY_MAX") ? atoi(getenv("BJX_SEQ_TINY_MAX")) : 8;
+  static const int kmax = 8;
   if (!use_tiny || batch <= 0 || K < (simplex ? 2 : 1) || K > kmax || K > 8 || (const void*)in == (const void*)in_bar) return BJX_OK;
   *taken = true;
   if (dt == BJX_F32) return tiny_vjp_dispatch<float>(ctx, simplex, inverse, (int)K, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, batch);
@@ -258,7 +258,7 @@ int bjx_seq_tiny(bjx_ctx* ctx, bjx_dtype dt, int which, const void* in, void* ou
                  bool* taken) {
   *taken = false;
   static const int use_tiny = getenv("BJX_SEQ_TINY") ? atoi(getenv("BJX_SEQ_TINY")) : 1;
-  static const int kmax = getenv("BJX_SEQ_TINY_MAX") ? atoi(getenv("BJX_SEQ_TINY_MAX")) : 8;
+  static const int kmax = 8;
   const bool simplex = which == BJX_TALL_SIMPLEX_FWD || which == BJX_TALL_SIMPLEX_INV;
   if (!use_tiny || batch <= 0 || K < (simplex ? 2 : 1) || K > kmax || K > 8 || !in) return BJX_OK;
   if (which == BJX_TALL_SIMPLEX_INV && !out) return BJX_OK;

@@ -15,16 +15,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SETTINGS = [
-    "BJX_U=1", "BJX_U=2", "BJX_NT=0", "BJX_CHAIN_WALKER=0", "BJX_CHAIN_WALKER_MAX=8", "BJX_CHAIN_FLATCOL=0", "BJX_CHAIN_COLBATCH=0", "BJX_COLWALK=0",
-    "BJX_PLANAR_REG=0", "BJX_PLANAR_COLS=32", "BJX_PLANAR_SPLIT=0", "BJX_PLANAR_SPLIT=1", "BJX_PLANAR_MFMA=1", "BJX_PLANAR_MFMA=2", "BJX_PLANAR_MFMA=4",
-    "BJX_PLANAR_MFMA64=0", "BJX_PLANAR_TILE=0", "BJX_FLOW_WALK_MAX=0", "BJX_RADIAL_WALK_ALL=1", "BJX_PLANAR_PARAM_MFMA=0", "BJX_PLANAR_PARAM_BLOCKS=64",
-    "BJX_SCALE_MFMA=0", "BJX_SCALE_AREG=1", "BJX_MATRIX_LANE_MAX=0", "BJX_MATRIX_LANE_DIRECT=0", "BJX_MATRIX_CYC=0",
-    "BJX_SEQ_WAVE=0", "BJX_SEQ_STREAM=0", "BJX_SEQ_CHUNK_MIN=1000", "BJX_SEQ_CHUNK_MIN=100000000", "BJX_SIMPLEX_INV_G=1", "BJX_SIMPLEX_INV_G=4",
-    "BJX_ORDERED_VJP_STREAM=0", "BJX_SIMPLEX_VJP_STREAM=0", "BJX_SIMPLEX_VJP_G=4", "BJX_SIMPLEX_VJP_CHUNK_MIN=1000", "BJX_SIMPLEX_VJP_CHUNK_MIN=100000000",
-    "BJX_SEQ_TINY=0", "BJX_SEQ_TINY_MAX=3", "BJX_SEQ_TALL=0", "BJX_SEQ_TALL_MIN=250", "BJX_SEQ_TALL_INV_MAX=100", "BJX_SEQ_TALL_EFF=0.95", "BJX_SIMPLEX_VJP_TALL=0", "BJX_SIMPLEX_VJP_TALL_MIN=250",
-    "BJX_SIMPLEX_VJP_TALL_INV_MAX=100", "BJX_SEQ_TALL_INV_SCAN=0", "BJX_SEQ_TALL_INV_SCAN=1", "BJX_SIMPLEX_VJP_TALL_SCAN=0",
-    "BJX_MIXED_GPB=1", "BJX_MIXED_GPB=5", "BJX_CHAIN_TINY=0", "BJX_PLANAR_REG_UNALIGNED=0", "BJX_PLANAR_REG_BIG=0", "BJX_FLOW_UNALIGNED=0", "BJX_COL_UNALIGNED=0", "BJX_STACKED_VJP_UNALIGNED=0", "BJX_UNAL_NT=1", "BJX_COL_SLAB=0", "BJX_COL_UNALIGNED_MIN=17", "BJX_STACKED_SLAB=0", "BJX_STACKED_SLAB=64", "BJX_CHAIN_UNALIGNED=0", "BJX_CHAIN_UNALIGNED_MIN=17", "BJX_PLANAR_WALK_DIRECT=0", "BJX_COLDIRECT=0", "BJX_STACKED_TINY=0",
-    "BJX_CHOL_CHUNK=0", "BJX_CHOL_LANE_MAX=0", "BJX_CHOL_FWD_VJP_SWZ=0", "BJX_STACKED_WALKER=0", "BJX_RQS_ITERS=7", "BJX_RQS_SLAB=0", "BJX_RQS_SLAB=32",
+    "BJX_NT=0", "BJX_CHAIN_WALKER=0", "BJX_CHAIN_FLATCOL=0", "BJX_CHAIN_COLBATCH=0", "BJX_COLWALK=0", "BJX_PLANAR_REG=0", "BJX_PLANAR_SPLIT=0",
+    "BJX_PLANAR_SPLIT=1", "BJX_PLANAR_MFMA=1", "BJX_PLANAR_MFMA=2", "BJX_PLANAR_MFMA=4", "BJX_PLANAR_MFMA64=0", "BJX_PLANAR_TILE=0",
+    "BJX_FLOW_WALK_MAX=0", "BJX_RADIAL_WALK_ALL=1", "BJX_PLANAR_PARAM_MFMA=0", "BJX_SCALE_MFMA=0", "BJX_MATRIX_LANE_MAX=0",
+    "BJX_MATRIX_LANE_DIRECT=0", "BJX_MATRIX_CYC=0", "BJX_SEQ_WAVE=0", "BJX_SEQ_STREAM=0", "BJX_ORDERED_VJP_STREAM=0", "BJX_SIMPLEX_VJP_STREAM=0",
+    "BJX_SEQ_TINY=0", "BJX_SEQ_TALL=0", "BJX_SIMPLEX_VJP_TALL=0", "BJX_CHAIN_TINY=0", "BJX_PLANAR_REG_UNALIGNED=0", "BJX_PLANAR_REG_BIG=0",
+    "BJX_FLOW_UNALIGNED=0", "BJX_COL_UNALIGNED=0", "BJX_STACKED_VJP_UNALIGNED=0", "BJX_COL_SLAB=0", "BJX_STACKED_SLAB=0", "BJX_STACKED_SLAB=64",
+    "BJX_CHAIN_UNALIGNED=0", "BJX_PLANAR_WALK_DIRECT=0", "BJX_COLDIRECT=0", "BJX_STACKED_TINY=0", "BJX_CHOL_CHUNK=0", "BJX_CHOL_LANE_MAX=0",
+    "BJX_CHOL_FWD_VJP_SWZ=0", "BJX_STACKED_WALKER=0", "BJX_RQS_SLAB=0", "BJX_RQS_SLAB=32",
 ]
 
 
