@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, 
   const T* W = A.in_lds ? tab : A.w;
   const T* UH = A.in_lds ? tab + nld : A.u_hat;
   const int gl = threadIdx.x & (G - 1), cl = threadIdx.x / G;
-  const int64_t nvc = dim / V;
+  const int64_t nvc = (dim + V - 1) / V;                 // the last pack may be partial (odd heights: element-aligned packs, load_pack_part)
   const int64_t col_raw = (int64_t)blockIdx.x * cols_per_block + cl;
   const bool col_ok = col_raw < batch;
   const int64_t col = col_ok ? col_raw : batch - 1;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t v = gl + (int64_t)r * G;
-      if (v < nvc) z[r] = load_pack<T, V, true>(base + col * dim + v * V);
+      if (v < nvc) z[r] = load_pack_part<T, V>(base + col * dim + v * V, (int)(dim - v * V < V ? dim - v * V : V));
       else {
 #pragma unroll
         for (int j = 0; j < V; ++j) z[r].v[j] = T(0);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, 
       const int64_t v = gl + (int64_t)r * G;
       if (v < nvc) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) s += row[v * V + j] * z[r].v[j];
+        for (int j = 0; j < V; ++j) s += (v * V + j < dim ? row[v * V + j] : T(0)) * z[r].v[j];
       }
     }
     return group_sum_rt(s, G);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, 
       const int64_t v = gl + (int64_t)r * G;
       if (v < nvc) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) z[r].v[j] += row[v * V + j] * a;
+        for (int j = 0; j < V; ++j) z[r].v[j] += (v * V + j < dim ? row[v * V + j] : T(0)) * a;
       }
     }
   };
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, 
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int64_t v = gl + (int64_t)r * G;
-    if (col_ok && v < nvc) store_pack<T, V, true>(xbar + col * dim + v * V, z[r]);
+    if (col_ok && v < nvc) store_pack_part<T, V>(xbar + col * dim + v * V, z[r], (int)(dim - v * V < V ? dim - v * V : V));
   }
 }
 
@@ -1658,7 +1658,7 @@ __global__ __launch_bounds__(256) void radial_vjp_kernel(const RadialArgs<T> A, 
   const T bh = -alpha + apb;
   const int gl = threadIdx.x & (G - 1);
   const int cols_per_block = blockDim.x / G;
-  const int64_t nvc = dim / V;
+  const int64_t nvc = (dim + V - 1) / V;                 // the last pack may be partial (odd heights: element-aligned packs)
   const int64_t col_first = (int64_t)blockIdx.x * cols_per_block * UC + threadIdx.x / G;
   Pack<T, V> zz[UC][R], gg[UC][R];
   T z0r[R][V];
@@ -1667,7 +1667,7 @@ __global__ __launch_bounds__(256) void radial_vjp_kernel(const RadialArgs<T> A, 
   for (int r = 0; r < R; ++r) {
     const int64_t v = gl + (int64_t)r * G;
 #pragma unroll
-    for (int j = 0; j < V; ++j) { z0r[r][j] = v < nvc ? Z0[v * V + j] : T(0); zsum[r][j] = T(0); }
+    for (int j = 0; j < V; ++j) { z0r[r][j] = v * V + j < dim ? Z0[v * V + j] : T(0); zsum[r][j] = T(0); }
   }
 #pragma unroll
   for (int u = 0; u < UC; ++u) {
@@ -1676,7 +1676,10 @@ __global__ __launch_bounds__(256) void radial_vjp_kernel(const RadialArgs<T> A, 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t v = gl + (int64_t)r * G;
-      if (v < nvc) { zz[u][r] = load_pack<T, V, true>(x + col * dim + v * V); gg[u][r] = load_pack<T, V, true>(gbar + col * dim + v * V); }
+      if (v < nvc) {
+        const int nrow = (int)(dim - v * V < V ? dim - v * V : V);
+        zz[u][r] = load_pack_part<T, V>(x + col * dim + v * V, nrow); gg[u][r] = load_pack_part<T, V>(gbar + col * dim + v * V, nrow);
+      }
     }
   }
 #pragma unroll
@@ -1727,7 +1730,7 @@ __global__ __launch_bounds__(256) void radial_vjp_kernel(const RadialArgs<T> A, 
         Pack<T, V> o;
 #pragma unroll
         for (int j = 0; j < V; ++j) o.v[j] = ca * gg[u][r].v[j] + cd * (zz[u][r].v[j] - z0r[r][j]);
-        if (col_ok) store_pack<T, V, true>(xbar + col * dim + v * V, o);
+        if (col_ok) store_pack_part<T, V>(xbar + col * dim + v * V, o, (int)(dim - v * V < V ? dim - v * V : V));
         if (zpart && col_ok) {
 #pragma unroll
           for (int j = 0; j < V; ++j) zsum[r][j] += gg[u][r].v[j] - o.v[j];
@@ -1746,7 +1749,7 @@ __global__ __launch_bounds__(256) void radial_vjp_kernel(const RadialArgs<T> A, 
         T a = zsum[r][j];
         for (int m = G; m < 64; m <<= 1) a += shfl_xor(a, m);
         const int64_t v = gl + (int64_t)r * G;
-        if ((threadIdx.x & 63) < G && v < nvc) zp[(size_t)wv * dim + v * V + j] = (double)a;
+        if ((threadIdx.x & 63) < G && v * V + j < dim) zp[(size_t)wv * dim + v * V + j] = (double)a;
       }
     }
     __syncthreads();
@@ -2534,7 +2537,9 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
     if (rc != 1) return rc;                               // 1 = shape not served by the register kernel
   }
   FlowCfg c;
-  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, in_bar, dim, batch, &c), BJX_ERR_UNSUPPORTED,
+  // (odd heights / element-aligned bases take 16-byte packs with a partial last pack, like the forward group kernel: the 4-byte
+  //  form ran the pullback of eight layers at 201 rows at 16 % of the HBM peak)
+  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, in_bar, dim, batch, &c, true), BJX_ERR_UNSUPPORTED,
               "bjx_planar_vjp: dim %lld too large for the register-resident kernel", (long long)dim);
   const int cols_per_block = 256 / c.G;
   const size_t tsave_bytes = ((size_t)cols_per_block * nl * sizeof(T) + 15) / 16 * 16;
@@ -2544,7 +2549,8 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
   PlanarArgs<T> A{w, u_hat, wtu, b, nl, lds ? 1 : 0};
   const size_t smem = (size_t)cols_per_block * nl * sizeof(T) + (lds ? tab_bytes : 0);
   constexpr int VW = Vec16<T>::N;
-  const bool v_ok = c.V == VW && bjx_aligned16(out_bar);
+  const bool whole = dim % VW == 0 && bjx_aligned16(in) && bjx_aligned16(in_bar);
+  const bool v_ok = c.V == VW && (!whole || bjx_aligned16(out_bar));      // element-aligned packs do not need an aligned cotangent either
   BjxProf prof_(ctx);
 #define PVJ(V_, R_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_kernel<T, V_, R_, true>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, t_out, s_out); \
                          else hipLaunchKernelGGL((planar_vjp_kernel<T, V_, R_, false>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, t_out, s_out); } while (0)
@@ -2682,7 +2688,7 @@ __global__ __launch_bounds__(256) void planar_param_reduce_kernel(const T* __res
   double* red = reinterpret_cast<double*>(smem);
   const int gl = threadIdx.x & (G - 1), cgp = threadIdx.x / G;
   const int cols_per_block = 256 / G;
-  const int64_t nvc = dim / V;
+  const int64_t nvc = (dim + V - 1) / V;                 // the last pack may be partial (odd heights: element-aligned packs; its dead rows read as zero)
   T m1[R][V][PP_NLG], m2[R][V][PP_NLG];
   T stg[PP_NLG];                 // lane gl < nlg: ST[l0+gl][l0 .. l0+nlg) restricted to this layer group's columns... (full row below)
   T bsum = T(0), csum = T(0);
@@ -2701,7 +2707,10 @@ __global__ __launch_bounds__(256) void planar_param_reduce_kernel(const T* __res
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t v = gl + (int64_t)r * G;
-      if (v < nvc) { pz[r] = load_pack<T, V, false>(z0 + col * dim + v * V); pg[r] = load_pack<T, V, false>(ybar + col * dim + v * V); }
+      if (v < nvc) {
+        const int nrow = (int)(dim - v * V < V ? dim - v * V : V);
+        pz[r] = load_pack_part<T, V>(z0 + col * dim + v * V, nrow); pg[r] = load_pack_part<T, V>(ybar + col * dim + v * V, nrow);
+      }
     }
     T sk[PP_NLG], tk[PP_NLG];
 #pragma unroll
@@ -2738,7 +2747,7 @@ __global__ __launch_bounds__(256) void planar_param_reduce_kernel(const T* __res
         if (v < nvc) {
 #pragma unroll
           for (int j = 0; j < V; ++j)
-            for (int k = 0; k < nlg; ++k) {
+            for (int k = 0; k < nlg && v * V + j < dim; ++k) {
               const size_t i1 = (size_t)(v * V + j) * nlg + k;
               if (pass == 0) { red[i1] = (double)m1[r][j][k]; red[n_m + i1] = (double)m2[r][j][k]; }
               else { red[i1] += (double)m1[r][j][k]; red[n_m + i1] += (double)m2[r][j][k]; }
@@ -3157,7 +3166,7 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
   const T* u_hat = static_cast<const T*>(ctx->scratch);
   const T* wtu = u_hat + (size_t)nl * dim;
   FlowCfg c;
-  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, out_bar, dim, batch, &c) && c.R <= 4, BJX_ERR_UNSUPPORTED,
+  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, out_bar, dim, batch, &c, true) && c.R <= 4, BJX_ERR_UNSUPPORTED,
               "bjx_planar_vjp_params: dim %lld too large for the register accumulators", (long long)dim);
   // planar_param_reduce_kernel gives the Gram row / b̄ / c̄ of layer l0 + gl to lane gl of a column's group: the group must have at
   // least PP_NLG lanes even when the column is only one or two packs (dim <= 4·PP_NLG: lanes without a pack only do that part).
@@ -3303,9 +3312,10 @@ int radial_vjp_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, c
     }
   }
   FlowCfg c;
-  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, in_bar, dim, batch, &c), BJX_ERR_UNSUPPORTED, "bjx_radial_vjp: dim %lld too large for the register-resident kernel", (long long)dim);
+  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, in_bar, dim, batch, &c, true), BJX_ERR_UNSUPPORTED, "bjx_radial_vjp: dim %lld too large for the register-resident kernel", (long long)dim);
   constexpr int VW = Vec16<T>::N;
-  if (c.V == VW && !bjx_aligned16(out_bar)) {           // scalar packs
+  const bool whole = dim % VW == 0 && bjx_aligned16(in) && bjx_aligned16(in_bar);   // otherwise: element-aligned packs, partial last pack (any alignment)
+  if (c.V == VW && whole && !bjx_aligned16(out_bar)) {           // scalar packs
     int G = 1;
     while (G < 64 && G < dim) G <<= 1;
     int64_t need_r = (dim + G - 1) / G;

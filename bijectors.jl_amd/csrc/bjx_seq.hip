@@ -1334,71 +1334,113 @@ __global__ __launch_bounds__(64) void ordered_vjp_kernel(const T* __restrict__ i
   tile_stage_out<T, V>(tg, in_bar + col0 * rows, rows, P, ncols, lane);
 }
 
+// last pack of a column whose height is not a whole number of packs: nrow < V live rows one by one, dead rows read as zero
+template <class T, int V> __device__ __forceinline__ Pack<T, V> seq_load_pack_part(const T* p, int nrow) {
+  if (nrow >= V) return load_pack<T, V, true>(p);
+  Pack<T, V> r;
+#pragma unroll
+  for (int j = 0; j < V; ++j) r.v[j] = j < nrow ? p[j] : T(0);
+  return r;
+}
+template <class T, int V> __device__ __forceinline__ void seq_store_pack_part(T* p, const Pack<T, V>& r, int nrow) {
+  if (nrow >= V) { store_pack<T, V, true>(p, r); return; }
+#pragma unroll
+  for (int j = 0; j < V; ++j) if (j < nrow) p[j] = r.v[j];
+}
 // Streaming variant (no LDS tiles) when a column is at most 64 packs: G lanes own one column as 16-byte
 // packs (coalesced), 4 columns in flight per lane group.  The inverse's pullback is local (each entry needs its
 // two neighbours: one lane shuffle each way); the forward's needs the suffix sum of the output cotangent
 // along the column: a 4-element suffix per lane + a reversed inclusive scan over the G lanes.
 // (The two-tile kernel below holds 33 KiB of LDS per wave at dim = 64: 4 waves per CU, 42 % of the HBM roofline.)
-template <class T, int V, bool INV>
+// Round 4: R packs per lane (pack v = r G + gl: every load / store instruction of a column group is one contiguous run) and a PARTIAL
+// last pack on element-aligned addresses — any height up to 64 R packs (2 048 rows in Float32).  Odd heights and columns taller than
+// 64 packs used to fall to the two-tile walker (103 KiB of LDS per wave at 201 rows: 12 % of the HBM peak) or, past the LDS, to one
+// thread per column (333 rows: 3.5 %).
+template <class T, int V, int R, bool INV>
 __global__ __launch_bounds__(256) void ordered_vjp_stream_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
                                                                 T* __restrict__ in_bar, int64_t dim, int64_t batch, int G) {
-  constexpr int UC = 4;
+  constexpr int UC = R == 1 ? 4 : (R == 2 ? 2 : 1);
   const int gl = threadIdx.x & (G - 1);
   const int cols_per_block = 256 / G;
-  const int nvc = (int)(dim / V);
-  const bool lane_ok = gl < nvc;
-  const bool first_lane = gl == 0, last_lane = gl == nvc - 1;
+  const int nvc = (int)((dim + V - 1) / V);
   const int64_t col0 = (int64_t)blockIdx.x * cols_per_block * UC + threadIdx.x / G;
-  Pack<T, V> a[UC], g[UC];
+  Pack<T, V> a[UC][R], g[UC][R];
 #pragma unroll
   for (int u = 0; u < UC; ++u) {
     const int64_t col = col0 + (int64_t)u * cols_per_block;
-    if (lane_ok && col < batch) {
-      a[u] = load_pack<T, V, true>(in + col * dim + (int64_t)gl * V);
-      g[u] = load_pack<T, V, true>(out_bar + col * dim + (int64_t)gl * V);
-    } else {
 #pragma unroll
-      for (int j = 0; j < V; ++j) { a[u].v[j] = T(0); g[u].v[j] = T(0); }
+    for (int r = 0; r < R; ++r) {
+      const int v = r * G + gl;
+      if (v < nvc && col < batch) {
+        const int nrow = (int)(dim - (int64_t)v * V < V ? dim - (int64_t)v * V : V);
+        a[u][r] = seq_load_pack_part<T, V>(in + col * dim + (int64_t)v * V, nrow);
+        g[u][r] = seq_load_pack_part<T, V>(out_bar + col * dim + (int64_t)v * V, nrow);
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) { a[u][r].v[j] = T(0); g[u][r].v[j] = T(0); }
+      }
     }
   }
 #pragma unroll
   for (int u = 0; u < UC; ++u) {
     const int64_t col = col0 + (int64_t)u * cols_per_block;
-    const bool ok = lane_ok && col < batch;
     const T lb = (ladj_bar && col < batch) ? ladj_bar[col] : T(0);
-    Pack<T, V> o;
+    Pack<T, V> o[R];
     if (!INV) {
-      // suffix sums: local (descending), then add the totals of the lanes to my right inside the column group
-      T sfx[V];
-      T run = T(0);
+      // suffix sums of the output cotangent along the column (dead rows of the last pack and dead packs hold zeros): inside a
+      // pack, then over the G lanes of pack round r (reversed inclusive scan), then the totals of the rounds above
+      T above = T(0);
 #pragma unroll
-      for (int j = V - 1; j >= 0; --j) { run += g[u].v[j]; sfx[j] = run; }
-      T tot = run;                                            // my lane's total; inclusive reversed scan over the group
-      for (int d = 1; d < G; d <<= 1) {
-        const T o2 = __shfl_down(tot, d, 64);
-        if (gl + d < G) tot += o2;
-      }
-      const T right = tot - run;                              // Σ of the lanes to my right
+      for (int r = R - 1; r >= 0; --r) {
+        T sfx[V];
+        T run = T(0);
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        const T s = sfx[j] + right;
-        o.v[j] = (first_lane && j == 0) ? s : s * d_exp(a[u].v[j]) + lb;
+        for (int j = V - 1; j >= 0; --j) { run += g[u][r].v[j]; sfx[j] = run; }
+        T tot = run;
+        for (int d = 1; d < G; d <<= 1) {
+          const T o2 = __shfl_down(tot, d, 64);
+          if (gl + d < G) tot += o2;
+        }
+        const T right = tot - run + above;                      // Σ of everything below my pack in the column
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const T sv = sfx[j] + right;
+          o[r].v[j] = (r == 0 && gl == 0 && j == 0) ? sv : sv * d_exp(a[u][r].v[j]) + lb;
+        }
+        above += __shfl(tot, (threadIdx.x & 63) & ~(G - 1), 64);  // the round's total sits in the group's first lane
       }
     } else {
-      const T xprev = __shfl_up(a[u].v[V - 1], 1, 64);        // x_{i-1} of my first element (unused for the column's first row)
-      T q[V + 1];
+      // q_i = (ȳ_i - ℓ̄)/(x_i - x_{i-1}) (q_0 = ȳ_0), x̄_i = q_i - q_{i+1}; rows past the column's end have q = 0
+      T q[R][V + 1];
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        const bool row0 = first_lane && j == 0;
-        const T xm1 = j == 0 ? xprev : a[u].v[j - 1];
-        q[j] = row0 ? g[u].v[0] : (g[u].v[j] - lb) / (a[u].v[j] - xm1);
+      for (int r = 0; r < R; ++r) {
+        T xprev = __shfl_up(a[u][r].v[V - 1], 1, 64);             // x_{i-1} of my first element: the lane to my left in this round ...
+        if (r > 0) { const T wrap = __shfl(a[u][r - 1].v[V - 1], ((threadIdx.x & 63) & ~(G - 1)) + G - 1, 64); if (gl == 0) xprev = wrap; }   // ... or the last lane of the round before
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const int64_t row = ((int64_t)r * G + gl) * V + j;
+          const T xm1 = j == 0 ? xprev : a[u][r].v[j - 1];
+          q[r][j] = row == 0 ? g[u][r].v[0] : (row < dim ? (g[u][r].v[j] - lb) / (a[u][r].v[j] - xm1) : T(0));
+        }
       }
-      const T qn = __shfl_down(q[0], 1, 64);
-      q[V] = last_lane ? T(0) : qn;
 #pragma unroll
-      for (int j = 0; j < V; ++j) o.v[j] = q[j] - q[j + 1];
+      for (int r = 0; r < R; ++r) {
+        T qn = __shfl_down(q[r][0], 1, 64);                      // q of the next pack: my right neighbour, or the first lane of the next round
+        if (gl == G - 1) qn = T(0);
+        if (r + 1 < R) { const T wrap = __shfl(q[r + 1][0], (threadIdx.x & 63) & ~(G - 1), 64); if (gl == G - 1) qn = wrap; }
+        q[r][V] = qn;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[r].v[j] = q[r][j] - q[r][j + 1];
+      }
     }
-    if (ok) store_pack<T, V, true>(in_bar + col * dim + (int64_t)gl * V, o);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int v = r * G + gl;
+      if (v < nvc && col < batch) {
+        const int nrow = (int)(dim - (int64_t)v * V < V ? dim - (int64_t)v * V : V);
+        seq_store_pack_part<T, V>(in_bar + col * dim + (int64_t)v * V, o[r], nrow);
+      }
+    }
   }
 }
 
@@ -1438,16 +1480,23 @@ int ordered_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, c
   {
     constexpr int VW = Vec16<T>::N;
     static const int use_stream = getenv("BJX_ORDERED_VJP_STREAM") ? atoi(getenv("BJX_ORDERED_VJP_STREAM")) : 1;
-    if (use_stream && dim % VW == 0 && dim / VW <= 64 && in_bar != in && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar)) {
+    const int64_t packs = (dim + VW - 1) / VW;
+    if (use_stream && dim >= 2 * VW && packs <= 64 * 8) {
+      // whole aligned packs or not: 16-byte packs on element-aligned addresses, a partial last pack, R packs per lane beyond 64
       int G = 1;
-      while (G < dim / VW) G <<= 1;
-      const int64_t cpb = (int64_t)(256 / G) * 4;
+      while (G < 64 && G < packs) G <<= 1;
+      int R = 1;
+      while ((int64_t)R * G < packs) R <<= 1;
+      const int uc = R == 1 ? 4 : (R == 2 ? 2 : 1);
+      const int64_t cpb = (int64_t)(256 / G) * uc;
       const int64_t grid = (batch + cpb - 1) / cpb;
       BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
       {
         BjxProf prof_(ctx);
-        if (inverse) hipLaunchKernelGGL((ordered_vjp_stream_kernel<T, VW, true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out_bar, ladj_bar, in_bar, dim, batch, G);
-        else hipLaunchKernelGGL((ordered_vjp_stream_kernel<T, VW, false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out_bar, ladj_bar, in_bar, dim, batch, G);
+#define OVS(R_) do { if (inverse) hipLaunchKernelGGL((ordered_vjp_stream_kernel<T, VW, R_, true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out_bar, ladj_bar, in_bar, dim, batch, G); \
+                     else hipLaunchKernelGGL((ordered_vjp_stream_kernel<T, VW, R_, false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out_bar, ladj_bar, in_bar, dim, batch, G); } while (0)
+        switch (R) { case 1: OVS(1); break; case 2: OVS(2); break; case 4: OVS(4); break; default: OVS(8); break; }
+#undef OVS
       }
       BJX_CHECK_LAUNCH(ctx);
       return BJX_OK;
