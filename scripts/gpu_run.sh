@@ -33,7 +33,8 @@ PY
 
 case $MODE in
 tests)
-  ( time timeout 1500 python -m pytest ${@:-tests} -m gpu -q --maxfail=25 -p no:cacheprovider ) > gpurun_out/pytest_gpu.txt 2>&1; tail -8 gpurun_out/pytest_gpu.txt ;;
+  [ $# -eq 0 ] && set -- tests
+  ( time timeout 1500 python -m pytest "$@" -m gpu -q --maxfail=25 -p no:cacheprovider ) > gpurun_out/pytest_gpu.txt 2>&1; tail -8 gpurun_out/pytest_gpu.txt ;;
 bench)
   timeout 900 python bench.py "$@" > gpurun_out/bench.json 2> gpurun_out/bench.err; wc -c gpurun_out/bench.json; cut -c1-600 gpurun_out/bench.json ;;
 rows)

@@ -875,7 +875,9 @@ def test_stacked_permuted_ranges_and_structured_segments(bj, orc):
 
 # ------------------------------------------------------------------ §8(f) f-1: pullbacks
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("shape", [(1, 5), (2, 64), (7, 300), (64, 129), (100, 33)])
+@pytest.mark.parametrize("shape", [(1, 5), (2, 64), (7, 300), (64, 129), (100, 33),
+                                   # round 4: partial last pack / R packs per lane in the streaming pullback, and past its 512 packs
+                                   (9, 70), (13, 257), (101, 37), (201, 19), (257, 11), (333, 9), (1000, 5), (2048, 3), (2049, 2), (1025, 3)])
 def test_ordered_vjp(bj, orc, shape, dt):
     r = rng(51)
     n, N = shape
