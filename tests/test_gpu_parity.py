@@ -1250,7 +1250,10 @@ def test_logpdf_transformed_structured_and_rand(bj, orc):
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("dim,nl,N", [(128, 8, 300), (128, 1, 64), (64, 3, 129), (20, 2, 77), (7, 2, 50), (200, 2, 40), (128, 12, 65), (36, 16, 33),
-                                      (33, 1, 300), (63, 8, 129), (65, 3, 257), (127, 8, 70), (126, 2, 64), (37, 12, 65)])
+                                      (33, 1, 300), (63, 8, 129), (65, 3, 257), (127, 8, 70), (126, 2, 64), (37, 12, 65),
+                                      # round 4: the tile split over 2 / 4 / 8 / 16 waves (planar_vjp_reg2_kernel), whole packs and odd heights
+                                      (101, 8, 130), (129, 5, 70), (201, 8, 129), (256, 8, 65), (255, 1, 64), (333, 8, 70), (512, 3, 65), (500, 2, 130),
+                                      (1000, 8, 67), (1024, 5, 64), (1001, 1, 30), (777, 12, 33)])
 def test_planar_vjp(bj, orc, dim, nl, N, dt):
     """Input pullback of the fused PlanarLayer stack (§8f f-1) against the finite-difference-pinned oracle."""
     r = rng(81)
@@ -1500,7 +1503,8 @@ def test_batchnorm_eval_vjp(bj, orc, dt):
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("dim,nl,N", [(128, 8, 3000), (64, 3, 257), (20, 1, 77), (7, 2, 50), (36, 12, 500), (192, 5, 1001), (256, 12, 333), (128, 8, 70001), (64, 1, 18),
-                                       (2, 8, 300), (4, 8, 257), (8, 8, 300), (10, 8, 129), (3, 5, 100), (16, 12, 200), (1, 8, 65)])   # few packs per column, many layers
+                                       (2, 8, 300), (4, 8, 257), (8, 8, 300), (10, 8, 129), (3, 5, 100), (16, 12, 200), (1, 8, 65),   # few packs per column, many layers
+                                       (101, 8, 300), (201, 8, 257), (333, 3, 129), (512, 8, 130), (1000, 5, 70)])     # input pullback on the split tile
 def test_planar_param_vjp(bj, orc, dim, nl, N, dt):
     """Parameter pullback of the PlanarLayer stack, summed over the batch (incl. the chain rule through get_u_hat)."""
     r = rng(85)
@@ -1508,6 +1512,11 @@ def test_planar_param_vjp(bj, orc, dim, nl, N, dt):
     u = (r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(dt)
     b = r.normal(size=nl).astype(dt)
     flow = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(b))
+    if dt == np.float64 and dim > 512:
+        # the register accumulators of the parameter reduction hold 512 Float64 rows: a loud error, not a slow path (include/bjx.h)
+        with pytest.raises(NotImplementedError):
+            bj.vjp_params(flow, dev(np.zeros((dim, N), dt)), dev(np.zeros((dim, N), dt)))
+        return
     Z = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
     gbar = np.asfortranarray((r.normal(size=(dim, N)) / np.sqrt(N)).astype(dt))
     lbar = (r.normal(size=N) / np.sqrt(N)).astype(dt)
