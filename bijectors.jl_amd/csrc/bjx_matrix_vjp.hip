@@ -26,38 +26,11 @@
 
 #include "bjx_internal.h"
 #include "bjx_tile.h"
+#include "bjx_matrix_vjp.h"
 
 using namespace bjx;
 
 namespace {
-
-enum { MK_VEC_CORR = 0, MK_CORR = 1, MK_PD = 2, MK_PD_VEC = 3 };
-
-// tanh(y), sech²(y) and the pivot / remainder math: Float32 on the hardware units (parity bar 1e-3), Float64 on the lean pieces
-template <class T> struct VjpMath;
-template <> struct VjpMath<float> {
-  using F = Fast<float>;
-  static __device__ __forceinline__ void tanh_sech2(float y, float& z, float& s2) {
-    const float u = F::exp(-fabsf(y));
-    const float t = u * u;
-    const float r = F::rcp(1.0f + t);
-    z = __builtin_copysignf((1.0f - t) * r, y);
-    const float sech = (u + u) * r;
-    s2 = sech * sech;
-  }
-  static __device__ __forceinline__ float exp(float x) { return F::exp(x); }
-  static __device__ __forceinline__ float sqrt(float x) { return F::sqrt(x); }
-  static __device__ __forceinline__ float rcp(float x) { return F::rcp(x); }
-  static __device__ __forceinline__ void pivot(float d, float& rs, float& sq) { rs = F::rsqrt(d); sq = d * rs; }
-};
-template <> struct VjpMath<double> {
-  using F = Fast<double>;
-  static __device__ __forceinline__ void tanh_sech2(double y, double& z, double& s2) { x_tanh_sech2(y, z, s2); }
-  static __device__ __forceinline__ double exp(double x) { return F::exp(x); }
-  static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
-  static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
-  static __device__ __forceinline__ void pivot(double d, double& rs, double& sq) { sq = ::sqrt(d); rs = 1.0 / sq; }
-};
 
 // storage of a K x K triangle per lane: registers (KMAX > 0, every index a compile-time constant after unrolling) or a
 // lane-strided slice of a global workspace (KMAX = 0)
@@ -240,10 +213,6 @@ __device__ __forceinline__ void matrix_vjp_sample(const Elems<T> xin, const Elem
   }
 }
 
-template <int KIND> __host__ __device__ inline int64_t free_len(int64_t K) {
-  return KIND == MK_VEC_CORR ? K * (K - 1) / 2 : (KIND == MK_PD_VEC ? K * (K + 1) / 2 : K * K);
-}
-
 // K <= 12: registers + two wave-private LDS tiles
 template <class T, int KMAX, int KIND, bool INV, int V>
 __global__ __launch_bounds__(64) void matrix_lane_vjp_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
@@ -312,6 +281,10 @@ int matrix_vjp_impl(bjx_ctx* ctx, const char* who, int inverse, const T* in, con
     }
     BJX_CHECK_LAUNCH(ctx);
     return BJX_OK;
+  }
+  {
+    const int rc = bjx_matrix_vjp_grp(ctx, sizeof(T) == 4 ? BJX_F32 : BJX_F64, KIND, inverse, in, out_bar, ladj_bar, in_bar, K, batch);
+    if (rc != 1) return rc;                                       // 1 = shape not served by the group kernel
   }
   BJX_REQUIRE(ctx, K <= 1024, BJX_ERR_UNSUPPORTED, "%s: K = %lld: the general-size pullback stops at 1024", who, (long long)K);
   // lanes in flight: as many as a 512 MiB workspace holds (two K x K triangles per lane), at most the batch

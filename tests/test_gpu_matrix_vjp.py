@@ -22,7 +22,8 @@ def orc():
     return oracle
 
 
-KB = [(2, 33), (3, 129), (5, 64), (8, 257), (9, 130), (10, 65), (11, 64), (12, 257), (13, 65), (16, 40), (24, 31), (32, 70), (33, 9), (50, 17), (64, 21), (1, 5)]
+KB = [(2, 33), (3, 129), (5, 64), (8, 257), (9, 130), (10, 65), (11, 64), (12, 257), (13, 65), (16, 40), (24, 31), (32, 70), (33, 9), (50, 17), (64, 21), (1, 5),
+      (14, 3), (15, 129), (17, 66), (20, 131), (31, 17), (32, 257)]      # round 4: one group of 16 / 32 lanes per sample (bjx_matrix_vjp_grp.hip)
 
 
 def _close_per_sample(got, ref, dt, K, what, loose=1.0):
