@@ -4,17 +4,18 @@
 // bjx_matrix_vjp.hip gives a sample to ONE lane; past 12 rows its triangles no longer fit the lane's registers and the same code
 // ran on a lane-strided global workspace: 0.4 % of the HBM peak at K = 32.  Here a GROUP of GS = 16 / 32 lanes owns a sample
 // (4 / 2 samples per wave, the group never leaves its wave: LDS traffic is ordered by the wave's queue, no block barrier), the
-// factor L and a second K x K buffer B live in LDS at an odd pitch (lane = row and lane = column accesses are both conflict-free),
-// and every phase is either "lane = row, sequential along the row" or "lane = column with wave-wide broadcast reads of L":
+// factor L and a second K x K buffer B live in LDS (rows on 16-byte boundaries: see GrpLds), and every phase is either "lane = row,
+// sequential along the row", "lane = column with 16-byte broadcast reads of a row of L", or elementwise over the triangle:
 //
 // inverse (unconstrained y -> X = L L'; what a leapfrog step differentiates):
-//   I1  y -> B (coalesced)                                I2  lane c builds row c of L (the LKJ sweep / replace_diag(exp));
-//       the correlation kinds park z = tanh(y) in the dead upper triangle of L for the way back
+//   I1  y -> B (coalesced)                                I2  tanh / sech of every entry (rows p and K - p together fill the group),
+//       then lane c builds row c of L from them (the LKJ sweep) / replace_diag(exp); z = tanh(y) stays parked in the dead upper
+//       triangle of L for the way back
 //   I3  X̄ -> B                                            I4  lane i: row i of L̄ = tril((X̄ + X̄') L) in registers
 //   I5  lane c: reverse sweep of its row, with sech² · E recovered as Σ_{m>i} L[c][m]² / √(Σ_{m>=i} L[c][m]²) (sums of
 //       squares only — the same number as (1 - z²) exp(log_remainder), no second tanh) -> B      I6  B -> in_bar (coalesced)
 // forward (X -> y):
-//   F1  X -> B     F2  right-looking Cholesky, lane i keeps row i in registers, column k published to L for the broadcast reads
+//   F1  X -> B     F2  right-looking Cholesky, lane i keeps row i in registers, column k published for the broadcast reads
 //   F3  ȳ -> B     F4  lane c: cotangent of row c of the factor from the link (two sweeps along the row) -> B as L̄
 //   F5-F8  the reverse of the factorisation in its level-3 form:  S = L⁻ᵀ Φ(LᵀL̄) L⁻¹ (Φ: lower triangle, half the diagonal),
 //       Ā[i][j] = S[i][j] + S[j][i] on the triangle the reference reads, S[j][j] on the diagonal — lane = column of LᵀL̄ and of
@@ -33,23 +34,53 @@ using namespace bjx;
 namespace {
 
 #define GRP_UNROLL _Pragma("unroll")
+// Left alone, the compiler SINKS the whole FMA chain of a fully unrolled phase below all of its LDS reads (nothing uses the
+// accumulators until the next phase) and hoists the reads as far as the register file lets it: 512 registers and scratch.  A fence
+// every GRP_FENCE_EVERY rows of L pins the accumulators (an empty asm that "modifies" each of them: the FMAs before it must be
+// done) and stops the scheduler there; a few rows stay in flight.
+#ifndef GRP_FENCE_EVERY
+#define GRP_FENCE_EVERY 2
+#endif
+template <class T, int KMAX> __device__ __forceinline__ void grp_pin(T (&v)[KMAX]) {
+  GRP_UNROLL for (int j = 0; j < KMAX; ++j) asm volatile("" : "+v"(v[j]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+// phase boundary: the wave's LDS queue is in order (the group never leaves its wave); pin the compiler and the scheduler
+__device__ __forceinline__ void grp_sync() { tile_sync(); __builtin_amdgcn_sched_barrier(0); }
+#define GRP_FENCE4(i_) do { if (((i_) % 4) == 3) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define GRP_FENCE(i_, arr_) do { if (((i_) % GRP_FENCE_EVERY) == GRP_FENCE_EVERY - 1) grp_pin(arr_); } while (0)
 
-// bank padding between the samples of a wave (in elements): neighbouring groups start GS banks apart (Float64: half-waves are
-// served separately, only GS = 16 needs it)
-template <class T, int GS> struct GrpPad { static constexpr int value = sizeof(T) == 4 ? (GS == 32 ? 32 : 48) : (GS == 32 ? 0 : 16); };
+// 16-byte broadcast reads of a row of L: every lane of the group reads the same address
+template <class T> struct Row16;
+template <> struct Row16<float> { static constexpr int N = 4; typedef float V __attribute__((ext_vector_type(4))); };
+template <> struct Row16<double> { static constexpr int N = 2; typedef double V __attribute__((ext_vector_type(2))); };
+
+// LDS of one sample, in elements: L [KMAX][P] | B [KMAX][P] | column vector [KMAX] | bank padding.  P = KMAX + one 16-byte pack:
+// rows start on 16-byte boundaries (broadcast reads of row segments as one ds_read_b128), lane = row accesses are conflict-free at
+// KMAX = 16 and two-way at 32.  The padding puts the groups of a wave (Float32) / of a half-wave (Float64) GS banks apart.
+template <class T, int KMAX> struct GrpLds {
+  static constexpr int N = Row16<T>::N;
+  static constexpr int P = KMAX + N;
+  static constexpr int BASE = 2 * KMAX * P + KMAX;
+  static constexpr int W = sizeof(T) / 4;
+  static constexpr int TARGET = sizeof(T) == 4 ? KMAX : (KMAX == 32 ? 0 : 32);
+  static constexpr int pad() { int q = 0; while (((BASE + q) * W) % 64 != TARGET) q += N; return q; }
+  static constexpr int SS = BASE + pad();
+};
 
 template <class T, int KMAX, int KIND, bool INV>
 __global__ __launch_bounds__(256) void matrix_grp_vjp_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
                                                             T* __restrict__ in_bar, int K, int64_t batch) {
   using M = VjpMath<T>;
-  constexpr int GS = KMAX, P = KMAX + 1, SPB = 256 / GS;
-  constexpr int SS = 2 * KMAX * P + GrpPad<T, GS>::value;
+  using RV = typename Row16<T>::V;
+  constexpr int GS = KMAX, N = Row16<T>::N, P = GrpLds<T, KMAX>::P, SPB = 256 / GS, SS = GrpLds<T, KMAX>::SS;
   constexpr bool CORR = KIND == MK_VEC_CORR || KIND == MK_CORR;
   constexpr bool VECK = KIND == MK_VEC_CORR || KIND == MK_PD_VEC;
   extern __shared__ __align__(16) unsigned char smem_[];
   const int t = threadIdx.x & (GS - 1), sl = threadIdx.x / GS;
   T* Lb = reinterpret_cast<T*>(smem_) + (size_t)sl * SS;
   T* B = Lb + KMAX * P;
+  T* colv = B + KMAX * P;
   const int64_t s_raw = (int64_t)blockIdx.x * SPB + sl;
   const bool live = s_raw < batch;                       // uniform over the group; a dead group computes on the last sample and stores nothing
   const int64_t s = live ? s_raw : batch - 1;
@@ -58,235 +89,258 @@ __global__ __launch_bounds__(256) void matrix_grp_vjp_kernel(const T* __restrict
   const bool act = t < K;
   const int gbase = (threadIdx.x & 63) & ~(GS - 1);      // first lane of my group inside the wave
 
-  auto stage_lin = [&](const T* src, int64_t n) { for (int64_t e = t; e < n; e += GS) B[e] = src[e]; };
-  auto unstage_lin = [&](T* dst, int64_t n) { for (int64_t e = t; e < n; e += GS) dst[e] = B[e]; };
-  auto stage_mat = [&](const T* src) {                   // K x K row-major -> pitch P, consecutive lanes on consecutive addresses
+  // global <-> B.  Every load of a sample is issued before the first LDS store (at most KMAX per lane: a rolled loop waits for each
+  // load in turn — 32 round trips to HBM per phase; dead slots read element 0); consecutive lanes on consecutive addresses.
+  auto stage_lin = [&](const T* src, int64_t n) {
+    T v[KMAX];
+    GRP_UNROLL for (int it = 0; it < KMAX; ++it) { const int e = t + it * GS; v[it] = src[e < n ? e : 0]; }
+    GRP_UNROLL for (int it = 0; it < KMAX; ++it) { const int e = t + it * GS; if (e < n) B[e] = v[it]; }
+  };
+  auto unstage_lin = [&](T* dst, int64_t n) {
+    GRP_UNROLL for (int it = 0; it < KMAX; ++it) { const int e = t + it * GS; if (e < n) dst[e] = B[e]; }
+  };
+  auto stage_mat = [&](const T* src) {                   // K x K row-major -> pitch P
+    T v[KMAX];
+    GRP_UNROLL for (int it = 0; it < KMAX; ++it) { const int e = t + it * GS; v[it] = src[e < KK ? e : 0]; }
     int r = 0, c = t;
-    while (c >= K) { c -= K; ++r; }
-    while (r < K) {
-      B[r * P + c] = src[r * K + c];
-      c += GS;
+    GRP_UNROLL for (int it = 0; it < KMAX; ++it) {
       while (c >= K) { c -= K; ++r; }
+      if (r < K) B[r * P + c] = v[it];
+      c += GS;
     }
   };
   auto unstage_mat = [&](T* dst) {
     int r = 0, c = t;
-    while (c >= K) { c -= K; ++r; }
-    while (r < K) {
-      dst[r * K + c] = B[r * P + c];
-      c += GS;
+    GRP_UNROLL for (int it = 0; it < KMAX; ++it) {
       while (c >= K) { c -= K; ++r; }
+      if (r < K) dst[r * K + c] = B[r * P + c];
+      c += GS;
     }
   };
-  // where the free parameter of (factor row c, column i) sits in B (the unconstrained side staged as above)
+  // where the free parameter of (factor row c, column i) sits in B (the unconstrained side staged as above); in bounds for any c, i < KMAX
   auto pos = [&](int c, int i) -> int {
     if (KIND == MK_VEC_CORR) return c * (c - 1) / 2 + i;
     if (KIND == MK_PD_VEC) return c * (c + 1) / 2 + i;
     if (KIND == MK_CORR) return c * P + i;               // memory index c K + i
     return i * P + c;                                    // MK_PD: memory index i K + c
   };
-  // rows K .. KMAX-1 of L read as zero: the unrolled inner loops need no guards
-  for (int e = K * P + t; e < KMAX * P; e += GS) Lb[e] = T(0);
+  // Style of everything below: NO branch around an update of a register array or of a loop-carried scalar — selects only, branches
+  // around plain stores.  (With `if (k < K) { ... a[j] -= ... }` the compiler merged the arrays at every join: 3 700 v_mov_b64,
+  // 1 200 AGPR moves and 1 100 lane spills in the 16 600 instructions of the forward kernel.)  The problem is padded to KMAX rows
+  // instead: the matrix with an identity block, the cotangents with zeros — every loop runs its full compile-time length.
 
   if constexpr (INV) {
+    // rows K .. KMAX-1 of L read as zero
+    for (int e = K * P + t; e < KMAX * P; e += GS) Lb[e] = T(0);
     // ---- I1 / I2
     if (VECK) stage_lin(in + s * nfree, nfree); else stage_mat(in + s * KK);
-    tile_sync();
+    grp_sync();
     T dcc = T(0);
-    if (act) {
-      if constexpr (CORR) {
-        T E = T(1);
-        GRP_UNROLL for (int i = 0; i < KMAX; ++i) {
-          if (i < t) {
-            T z, s2;
-            M::tanh_sech2(B[pos(t, i)], z, s2);
-            Lb[t * P + i] = z * E;
-            Lb[i * P + t] = z;                            // upper triangle: dead storage, read back in I5
-            E *= M::sqrt(s2);
-          }
-        }
-        Lb[t * P + t] = E;
-        dcc = E;
-      } else {
-        GRP_UNROLL for (int i = 0; i < KMAX; ++i) {
-          if (i <= t) {
-            T v = B[pos(t, i)];
-            if (i == t) { v = M::exp(v); dcc = v; }
-            Lb[t * P + i] = v;
-          }
+    if constexpr (CORR) {
+      // tanh / sech of every free parameter, all lanes busy: rows p and K - p of the strict lower triangle hold K entries together.
+      // z -> upper triangle (dead storage of L, read back in I5), sech -> lower
+      for (int p = 1; 2 * p <= K; ++p) {
+        int c, i;
+        if (t < p) { c = p; i = t; } else { c = K - p; i = t - p; }
+        if (act && i < c && (2 * p < K || t < p)) {
+          T z, s2;
+          M::tanh_sech2(B[pos(c, i)], z, s2);
+          Lb[i * P + c] = z;
+          Lb[c * P + i] = M::sqrt(s2);
         }
       }
+      grp_sync();
+      T E = T(1);
+      GRP_UNROLL for (int i = 0; i < KMAX; ++i) {
+        const bool on = act && i < t;
+        const T z = Lb[i * P + t], sech = Lb[t * P + i];
+        if (on) Lb[t * P + i] = z * E;
+        E = on ? E * sech : E;
+        GRP_FENCE4(i);
+      }
+      if (act) Lb[t * P + t] = E;
+      dcc = E;
+    } else {
+      GRP_UNROLL for (int i = 0; i < KMAX; ++i) {
+        const T raw = B[pos(t, i)];
+        const T ex = M::exp(raw);
+        const T v = i == t ? ex : raw;
+        dcc = i == t ? ex : dcc;
+        if (act && i <= t) Lb[t * P + i] = v;
+      }
     }
-    tile_sync();
+    grp_sync();
     // ---- I3 / I4
     stage_mat(out_bar + s * KK);
-    tile_sync();
+    grp_sync();
     T acc[KMAX];
     GRP_UNROLL for (int j = 0; j < KMAX; ++j) acc[j] = T(0);
     GRP_UNROLL for (int m = 0; m < KMAX; ++m) {
-      if (m < K) {
-        const T sv = act ? B[m * P + t] + B[t * P + m] : T(0);
-        GRP_UNROLL for (int j = 0; j <= m; ++j) acc[j] += sv * Lb[m * P + j];
+      const T raw = B[m * P + t] + B[t * P + m];
+      const T sv = (act && m < K) ? raw : T(0);
+      GRP_UNROLL for (int j0 = 0; j0 <= m; j0 += N) {                   // row m of L: 16-byte broadcast reads
+        const RV x = *reinterpret_cast<const RV*>(Lb + m * P + j0);
+        GRP_UNROLL for (int u = 0; u < N; ++u) if (j0 + u <= m) acc[j0 + u] += sv * x[u];
       }
+      GRP_FENCE(m, acc);
     }
-    tile_sync();
+    grp_sync();
     // ---- I5
-    if (act) {
-      T gcc = T(0);
-      GRP_UNROLL for (int j = 0; j < KMAX; ++j) if (j == t) gcc = acc[j];
-      if constexpr (CORR) {
-        T dlr = dcc * gcc + (dl + dl) + ((t >= 1 && t <= K - 2) ? T(K - 1 - t) * dl : T(0));
-        T rem = dcc * dcc;
-        GRP_UNROLL for (int i = KMAX - 1; i >= 0; --i) {
-          if (i < t) {
-            const T z = Lb[i * P + t], w = Lb[t * P + i], gw = acc[i];
-            const T prev = rem;
-            rem += w * w;
-            T rs, sq;
-            M::pivot(rem, rs, sq);
-            const T f = rem > T(0) ? prev * rs : T(0);     // sech²(y) exp(log_remainder before entry i)
-            B[pos(t, i)] = f * gw - z * dlr;
-            dlr += dl + w * gw;
-          }
-        }
-        if (KIND == MK_CORR) {
-          GRP_UNROLL for (int i = 0; i < KMAX; ++i) if (i >= t && i < K) B[t * P + i] = T(0);
-        }
-      } else {
-        GRP_UNROLL for (int i = 0; i < KMAX; ++i) {
-          if (i < K) {
-            if (i < t) B[pos(t, i)] = acc[i];
-            else if (i == t) B[pos(t, t)] = gcc * dcc + dl * T(K + 1 - t);
-            else if (KIND == MK_PD) B[i * P + t] = T(0);
-          }
-        }
+    T gcc = T(0);
+    GRP_UNROLL for (int j = 0; j < KMAX; ++j) gcc = j == t ? acc[j] : gcc;
+    if constexpr (CORR) {
+      T dlr = dcc * gcc + (dl + dl) + ((t >= 1 && t <= K - 2) ? T(K - 1 - t) * dl : T(0));
+      T rem = dcc * dcc;
+      GRP_UNROLL for (int i = KMAX - 1; i >= 0; --i) {
+        const bool on = act && i < t;
+        const T z = Lb[i * P + t], w = Lb[t * P + i], gw = acc[i];
+        const T rem2 = rem + w * w;
+        T rs, sq;
+        M::pivot(rem2, rs, sq);
+        const T f = rem2 > T(0) ? rem * rs : T(0);             // sech²(y) exp(log_remainder before entry i)
+        if (on) B[pos(t, i)] = f * gw - z * dlr;
+        rem = on ? rem2 : rem;
+        dlr = on ? dlr + dl + w * gw : dlr;
+        GRP_FENCE4(i);
+      }
+      if (KIND == MK_CORR) {
+        GRP_UNROLL for (int i = 0; i < KMAX; ++i) if (act && i >= t && i < K) B[t * P + i] = T(0);
+      }
+    } else {
+      GRP_UNROLL for (int i = 0; i < KMAX; ++i) {
+        const T v = i < t ? acc[i] : (i == t ? gcc * dcc + dl * T(K + 1 - t) : T(0));
+        if (act && i < K && (i <= t || KIND == MK_PD)) B[pos(t, i)] = v;
       }
     }
-    tile_sync();
+    grp_sync();
     if (live) { if (VECK) unstage_lin(in_bar + s * nfree, nfree); else unstage_mat(in_bar + s * KK); }
   } else {
-    // ---- F1 / F2
+    // ---- F1 / F2: rows and columns K .. KMAX-1 are an identity block
     stage_mat(in + s * KK);
-    tile_sync();
+    grp_sync();
     T a[KMAX];
-    GRP_UNROLL for (int j = 0; j < KMAX; ++j) a[j] = (act && j <= t) ? (CORR ? B[t * P + j] : B[j * P + t]) : T(0);
-    tile_sync();
+    GRP_UNROLL for (int j = 0; j < KMAX; ++j) {
+      const T raw = CORR ? B[t * P + j] : B[j * P + t];
+      a[j] = (act && j <= t) ? raw : ((!act && j == t) ? T(1) : T(0));
+    }
+    grp_sync();
     GRP_UNROLL for (int k = 0; k < KMAX; ++k) {
-      if (k < K) {
-        const T d = __shfl(a[k], gbase + k, 64);
-        T rs, sq;
-        M::pivot(d, rs, sq);
-        if (t == k) a[k] = sq; else if (t > k) a[k] *= rs;
-        if (act && t >= k) Lb[t * P + k] = a[k];
-        tile_sync();
-        GRP_UNROLL for (int j = k + 1; j < KMAX; ++j) {
-          const T ljk = Lb[j * P + k];
-          if (j <= t) a[j] -= a[k] * ljk;
-        }
+      const T d = __shfl(a[k], gbase + k, 64);
+      T rs, sq;
+      M::pivot(d, rs, sq);
+      a[k] = t == k ? sq : (t > k ? a[k] * rs : a[k]);
+      Lb[t * P + k] = a[k];                                   // (lanes t < k write dead storage above the diagonal)
+      colv[t] = t > k ? a[k] : T(0);                          // column k of L below the pivot, for the broadcast reads
+      grp_sync();
+      // a[j] -= L[t][k] L[j][k], j > k (entries j > t of a are never used: no mask)
+      GRP_UNROLL for (int j0 = ((k + 1) / N) * N; j0 < KMAX; j0 += N) {
+        const RV x = *reinterpret_cast<const RV*>(colv + j0);
+        GRP_UNROLL for (int u = 0; u < N; ++u) if (j0 + u > k) a[j0 + u] -= a[k] * x[u];
       }
+      GRP_FENCE(k, a);
     }
     // ---- F3 / F4
     if (nfree > 0) { if (VECK) stage_lin(out_bar + s * nfree, nfree); else stage_mat(out_bar + s * KK); }
-    tile_sync();
+    grp_sync();
     T g[KMAX];
-    GRP_UNROLL for (int j = 0; j < KMAX; ++j) g[j] = T(0);
-    if (act) {
-      T dcc = T(0);
-      GRP_UNROLL for (int j = 0; j < KMAX; ++j) if (j == t) dcc = a[j];
+    {
+      T dcc = T(1);
+      GRP_UNROLL for (int j = 0; j < KMAX; ++j) dcc = j == t ? a[j] : dcc;
       if constexpr (CORR) {
         T rem = dcc * dcc;
         GRP_UNROLL for (int i = KMAX - 1; i >= 0; --i) {
-          if (i < t) { g[i] = rem; rem += a[i] * a[i]; }
+          g[i] = rem;
+          rem = i < t ? rem + a[i] * a[i] : rem;
         }
         T gsum = T(0);
         GRP_UNROLL for (int m = 0; m < KMAX; ++m) {
-          if (m < t) {
-            const T w = a[m], yb = B[pos(t, m)], wt = T(K - m) * dl;
-            if (KIND == MK_VEC_CORR && m == 0) {
-              g[m] = (yb + wt * w) * M::rcp(T(1) - w * w);
-            } else {
-              const T R = g[m];
-              const T S2 = R + w * w;
-              const T rS = M::rcp(M::sqrt(S2)), rS2 = M::rcp(S2), rR = M::rcp(R);
-              const T tt = yb * rS + wt * w * rS2;
-              g[m] = tt + (w + w) * gsum;
-              gsum -= T(0.5) * rR * w * tt;
-            }
+          const bool on = m < t;
+          const T w = a[m], yb = B[pos(t, m)], wt = T(K - m) * dl;
+          T gm, dsum;
+          if (KIND == MK_VEC_CORR && m == 0) {
+            gm = (yb + wt * w) * M::rcp(T(1) - w * w);
+            dsum = T(0);
+          } else {
+            const T R = g[m];
+            const T S2 = R + w * w;
+            const T rS = M::rcp(M::sqrt(S2)), rS2 = M::rcp(S2), rR = M::rcp(R);
+            const T tt = yb * rS + wt * w * rS2;
+            gm = tt + (w + w) * gsum;
+            dsum = T(0.5) * rR * w * tt;
           }
+          g[m] = on ? gm : T(0);
+          gsum = on ? gsum - dsum : gsum;
+          GRP_FENCE4(m);
         }
         const T gd = (dcc + dcc) * gsum;
-        GRP_UNROLL for (int j = 0; j < KMAX; ++j) if (j == t) g[j] = gd;
+        GRP_UNROLL for (int j = 0; j < KMAX; ++j) g[j] = j == t ? gd : g[j];
       } else {
         const T rd = M::rcp(dcc);
         GRP_UNROLL for (int i = 0; i < KMAX; ++i) {
-          if (i < t) g[i] = B[pos(t, i)];
-          else if (i == t) g[i] = (B[pos(t, t)] - dl * T(K + 1 - t)) * rd;
+          const T raw = B[pos(t, i)];
+          g[i] = i < t ? raw : (i == t ? (raw - dl * T(K + 1 - t)) * rd : T(0));
         }
       }
     }
-    tile_sync();
-    if (act) {
-      GRP_UNROLL for (int i = 0; i < KMAX; ++i) if (i < K) B[t * P + i] = i <= t ? g[i] : T(0);
-    }
-    tile_sync();
+    grp_sync();
+    GRP_UNROLL for (int i = 0; i < KMAX; ++i) B[t * P + i] = (act && i <= t) ? g[i] : T(0);   // L̄, zero outside the K x K triangle
+    grp_sync();
     // ---- F5: column t of Φ(L' L̄)
     T z[KMAX];
     GRP_UNROLL for (int j = 0; j < KMAX; ++j) z[j] = T(0);
     GRP_UNROLL for (int i = 0; i < KMAX; ++i) {
-      if (i < K) {
-        const T gv = act ? B[i * P + t] : T(0);
-        GRP_UNROLL for (int r = 0; r <= i; ++r) z[r] += Lb[i * P + r] * gv;
+      const T gv = B[i * P + t];
+      GRP_UNROLL for (int j0 = 0; j0 <= i; j0 += N) {
+        const RV x = *reinterpret_cast<const RV*>(Lb + i * P + j0);
+        GRP_UNROLL for (int u = 0; u < N; ++u) if (j0 + u <= i) z[j0 + u] += gv * x[u];
       }
+      GRP_FENCE(i, z);
     }
     GRP_UNROLL for (int r = 0; r < KMAX; ++r) z[r] = r > t ? z[r] : (r == t ? T(0.5) * z[r] : T(0));
-    // ---- F6: L' Z = Φ, column t
-    GRP_UNROLL for (int r = KMAX - 1; r >= 0; --r) {
-      if (r < K) {
-        T sum = z[r];
-        GRP_UNROLL for (int q = r + 1; q < KMAX; ++q) sum -= Lb[q * P + r] * z[q];
-        z[r] = sum * M::rcp(Lb[r * P + r]);
-      } else z[r] = T(0);
-    }
+    // ---- F6: L' Z = Φ, column t — from the last row up, each solved entry eliminated with ONE row of L
+    auto solve_lt = [&](T (&v)[KMAX]) {
+      GRP_UNROLL for (int r = KMAX - 1; r >= 0; --r) {
+        v[r] *= M::rcp(Lb[r * P + r]);
+        const T mv = -v[r];
+        GRP_UNROLL for (int j0 = 0; j0 < r; j0 += N) {
+          const RV x = *reinterpret_cast<const RV*>(Lb + r * P + j0);
+          GRP_UNROLL for (int u = 0; u < N; ++u) if (j0 + u < r) v[j0 + u] += mv * x[u];
+        }
+        GRP_FENCE(r, v);
+      }
+    };
+    solve_lt(z);
     // ---- F7: transpose
-    tile_sync();
-    if (act) { GRP_UNROLL for (int r = 0; r < KMAX; ++r) if (r < K) B[r * P + t] = z[r]; }
-    tile_sync();
-    GRP_UNROLL for (int b = 0; b < KMAX; ++b) z[b] = (act && b < K) ? B[t * P + b] : T(0);
-    // ---- F8: S L = Z, row t
-    GRP_UNROLL for (int b = KMAX - 1; b >= 0; --b) {
-      if (b < K) {
-        T sum = z[b];
-        GRP_UNROLL for (int c = b + 1; c < KMAX; ++c) sum -= z[c] * Lb[c * P + b];
-        z[b] = sum * M::rcp(Lb[b * P + b]);
-      } else z[b] = T(0);
-    }
+    grp_sync();
+    GRP_UNROLL for (int r = 0; r < KMAX; ++r) B[r * P + t] = z[r];
+    grp_sync();
+    GRP_UNROLL for (int b = 0; b < KMAX; ++b) z[b] = B[t * P + b];
+    // ---- F8: S L = Z, row t: the same elimination
+    solve_lt(z);
     // ---- F9: Ā on the triangle the reference reads
-    tile_sync();
-    if (act) { GRP_UNROLL for (int b = 0; b < KMAX; ++b) if (b < K) B[t * P + b] = z[b]; }
-    tile_sync();
+    grp_sync();
+    GRP_UNROLL for (int b = 0; b < KMAX; ++b) B[t * P + b] = z[b];
+    grp_sync();
     T diag = T(0);
     GRP_UNROLL for (int j = 0; j < KMAX; ++j) {
-      if (j == t) diag = z[j];
-      if (j < t) z[j] += B[j * P + t];
+      diag = j == t ? z[j] : diag;
+      const T other = B[j * P + t];
+      z[j] = j < t ? z[j] + other : z[j];
     }
-    tile_sync();
-    if (act) {
-      GRP_UNROLL for (int j = 0; j < KMAX; ++j) {
-        if (j < K) {
-          const T v = j < t ? z[j] : (j == t ? diag : T(0));
-          if (CORR) B[t * P + j] = v; else B[j * P + t] = v;
-        }
-      }
+    grp_sync();
+    GRP_UNROLL for (int j = 0; j < KMAX; ++j) {
+      const T v = j < t ? z[j] : (j == t ? diag : T(0));
+      if (CORR) B[t * P + j] = v; else B[j * P + t] = v;
     }
-    tile_sync();
+    grp_sync();
     if (live) unstage_mat(in_bar + s * KK);
   }
 }
 
 template <class T, int KMAX, int KIND>
 int grp_launch(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
-  constexpr int GS = KMAX, P = KMAX + 1, SPB = 256 / GS;
-  const size_t smem = (size_t)SPB * (2 * KMAX * P + GrpPad<T, GS>::value) * sizeof(T);
+  constexpr int GS = KMAX, SPB = 256 / GS;
+  const size_t smem = (size_t)SPB * GrpLds<T, KMAX>::SS * sizeof(T);
   const int64_t grid = (batch + SPB - 1) / SPB;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "matrix pullback: batch too large for one launch");
   {
