@@ -58,26 +58,30 @@ template <> struct Row16<double> { static constexpr int N = 2; typedef double V 
 // LDS of one sample, in elements: L [KMAX][P] | B [KMAX][P] | column vector [KMAX] | bank padding.  P = KMAX + one 16-byte pack:
 // rows start on 16-byte boundaries (broadcast reads of row segments as one ds_read_b128), lane = row accesses are conflict-free at
 // KMAX = 16 and two-way at 32.  The padding puts the groups of a wave (Float32) / of a half-wave (Float64) GS banks apart.
-template <class T, int KMAX> struct GrpLds {
+template <class T, int GS, int KMAX> struct GrpLds {
   static constexpr int N = Row16<T>::N;
   static constexpr int P = KMAX + N;
   static constexpr int BASE = 2 * KMAX * P + KMAX;
   static constexpr int W = sizeof(T) / 4;
-  static constexpr int TARGET = sizeof(T) == 4 ? KMAX : (KMAX == 32 ? 0 : 32);
+  static constexpr int TARGET = sizeof(T) == 4 ? GS : (GS == 32 ? 0 : 32);
   static constexpr int pad() { int q = 0; while (((BASE + q) * W) % 64 != TARGET) q += N; return q; }
   static constexpr int SS = BASE + pad();
 };
 
-template <class T, int KMAX, int KIND, bool INV>
+template <class T, int GS, int KMAX, int KIND, bool INV>
 __global__ __launch_bounds__(256) void matrix_grp_vjp_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
                                                             T* __restrict__ in_bar, int K, int64_t batch) {
   using M = VjpMath<T>;
   using RV = typename Row16<T>::V;
-  constexpr int GS = KMAX, N = Row16<T>::N, P = GrpLds<T, KMAX>::P, SPB = 256 / GS, SS = GrpLds<T, KMAX>::SS;
+  constexpr int N = Row16<T>::N, P = GrpLds<T, GS, KMAX>::P, SPB = 256 / GS, SS = GrpLds<T, GS, KMAX>::SS;
+  constexpr int NIT = (KMAX * KMAX + GS - 1) / GS;           // staging rounds of the group over a K x K array
   constexpr bool CORR = KIND == MK_VEC_CORR || KIND == MK_CORR;
   constexpr bool VECK = KIND == MK_VEC_CORR || KIND == MK_PD_VEC;
   extern __shared__ __align__(16) unsigned char smem_[];
-  const int t = threadIdx.x & (GS - 1), sl = threadIdx.x / GS;
+  // tl: my lane in the group (staging: every lane moves its own elements).  t: the row / column I compute — lanes past KMAX (a
+  // 24-row problem on a 32-lane group) repeat the last one: same values to the same addresses.
+  const int tl = threadIdx.x & (GS - 1), sl = threadIdx.x / GS;
+  const int t = tl < KMAX ? tl : KMAX - 1;
   T* Lb = reinterpret_cast<T*>(smem_) + (size_t)sl * SS;
   T* B = Lb + KMAX * P;
   T* colv = B + KMAX * P;
@@ -92,26 +96,26 @@ __global__ __launch_bounds__(256) void matrix_grp_vjp_kernel(const T* __restrict
   // global <-> B.  Every load of a sample is issued before the first LDS store (at most KMAX per lane: a rolled loop waits for each
   // load in turn — 32 round trips to HBM per phase; dead slots read element 0); consecutive lanes on consecutive addresses.
   auto stage_lin = [&](const T* src, int64_t n) {
-    T v[KMAX];
-    GRP_UNROLL for (int it = 0; it < KMAX; ++it) { const int e = t + it * GS; v[it] = src[e < n ? e : 0]; }
-    GRP_UNROLL for (int it = 0; it < KMAX; ++it) { const int e = t + it * GS; if (e < n) B[e] = v[it]; }
+    T v[NIT];
+    GRP_UNROLL for (int it = 0; it < NIT; ++it) { const int e = tl + it * GS; v[it] = src[e < n ? e : 0]; }
+    GRP_UNROLL for (int it = 0; it < NIT; ++it) { const int e = tl + it * GS; if (e < n) B[e] = v[it]; }
   };
   auto unstage_lin = [&](T* dst, int64_t n) {
-    GRP_UNROLL for (int it = 0; it < KMAX; ++it) { const int e = t + it * GS; if (e < n) dst[e] = B[e]; }
+    GRP_UNROLL for (int it = 0; it < NIT; ++it) { const int e = tl + it * GS; if (e < n) dst[e] = B[e]; }
   };
   auto stage_mat = [&](const T* src) {                   // K x K row-major -> pitch P
-    T v[KMAX];
-    GRP_UNROLL for (int it = 0; it < KMAX; ++it) { const int e = t + it * GS; v[it] = src[e < KK ? e : 0]; }
-    int r = 0, c = t;
-    GRP_UNROLL for (int it = 0; it < KMAX; ++it) {
+    T v[NIT];
+    GRP_UNROLL for (int it = 0; it < NIT; ++it) { const int e = tl + it * GS; v[it] = src[e < KK ? e : 0]; }
+    int r = 0, c = tl;
+    GRP_UNROLL for (int it = 0; it < NIT; ++it) {
       while (c >= K) { c -= K; ++r; }
       if (r < K) B[r * P + c] = v[it];
       c += GS;
     }
   };
   auto unstage_mat = [&](T* dst) {
-    int r = 0, c = t;
-    GRP_UNROLL for (int it = 0; it < KMAX; ++it) {
+    int r = 0, c = tl;
+    GRP_UNROLL for (int it = 0; it < NIT; ++it) {
       while (c >= K) { c -= K; ++r; }
       if (r < K) dst[r * K + c] = B[r * P + c];
       c += GS;
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void matrix_grp_vjp_kernel(const T* __restrict
 
   if constexpr (INV) {
     // rows K .. KMAX-1 of L read as zero
-    for (int e = K * P + t; e < KMAX * P; e += GS) Lb[e] = T(0);
+    for (int e = K * P + tl; e < KMAX * P; e += GS) Lb[e] = T(0);
     // ---- I1 / I2
     if (VECK) stage_lin(in + s * nfree, nfree); else stage_mat(in + s * KK);
     grp_sync();
@@ -337,20 +341,20 @@ __global__ __launch_bounds__(256) void matrix_grp_vjp_kernel(const T* __restrict
   }
 }
 
-template <class T, int KMAX, int KIND>
+template <class T, int GS, int KMAX, int KIND>
 int grp_launch(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
-  constexpr int GS = KMAX, SPB = 256 / GS;
-  const size_t smem = (size_t)SPB * GrpLds<T, KMAX>::SS * sizeof(T);
+  constexpr int SPB = 256 / GS;
+  const size_t smem = (size_t)SPB * GrpLds<T, GS, KMAX>::SS * sizeof(T);
   const int64_t grid = (batch + SPB - 1) / SPB;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "matrix pullback: batch too large for one launch");
   {
     BjxProf prof_(ctx);
     if (inverse) {
-      bjx_allow_big_lds(matrix_grp_vjp_kernel<T, KMAX, KIND, true>, smem);
-      hipLaunchKernelGGL((matrix_grp_vjp_kernel<T, KMAX, KIND, true>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)K, batch);
+      bjx_allow_big_lds(matrix_grp_vjp_kernel<T, GS, KMAX, KIND, true>, smem);
+      hipLaunchKernelGGL((matrix_grp_vjp_kernel<T, GS, KMAX, KIND, true>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)K, batch);
     } else {
-      bjx_allow_big_lds(matrix_grp_vjp_kernel<T, KMAX, KIND, false>, smem);
-      hipLaunchKernelGGL((matrix_grp_vjp_kernel<T, KMAX, KIND, false>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)K, batch);
+      bjx_allow_big_lds(matrix_grp_vjp_kernel<T, GS, KMAX, KIND, false>, smem);
+      hipLaunchKernelGGL((matrix_grp_vjp_kernel<T, GS, KMAX, KIND, false>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)K, batch);
     }
   }
   BJX_CHECK_LAUNCH(ctx);
@@ -359,7 +363,10 @@ int grp_launch(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T
 
 template <class T>
 int grp_kind(bjx_ctx* ctx, int kind, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
-#define GRP_K(KIND_) (K <= 16 ? grp_launch<T, 16, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch) : grp_launch<T, 32, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch))
+  // the unrolled phases cost ~KMAX² instructions whatever K is: 16, 24 and 32 rows
+#define GRP_K(KIND_) (K <= 16 ? grp_launch<T, 16, 16, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch) \
+                    : K <= 24 ? grp_launch<T, 32, 24, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch) \
+                              : grp_launch<T, 32, 32, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch))
   switch (kind) {
     case MK_VEC_CORR: return GRP_K(MK_VEC_CORR);
     case MK_CORR: return GRP_K(MK_CORR);
