@@ -15,11 +15,15 @@
 // pd.jl:27-31 — then the reverse of cholesky(Hermitian(X)), unblocked, column by column from the last.  The cotangent lands on
 // the triangle the reference READS (upper for the correlation bijectors, src/utils.jl:50; lower for PD, :37); the other is zero.
 //
-// Mapping on gfx950: ONE LANE per sample, like matrix_lane_kernel.  K <= 12: the factor and its cotangent live in the lane's
-// registers (fully unrolled, wave-uniform guards), the primal input and the output cotangent of 64 consecutive samples travel
-// through two [64][odd pitch] LDS tiles with 16-byte global accesses, the input cotangent leaves through the first tile.
-// K > 12 (the LKJ / Wishart blocks of real models are 2x2 ... 8x8): the same code on a lane-strided global workspace
-// (entry e of lane l at ws[e * lanes + l]: coalesced), plain per-lane global accesses for the arrays — correct, not fast.
+// Mapping on gfx950, three ranges of K:
+//   K <= 8   ONE LANE per sample, like matrix_lane_kernel: the factor and its cotangent live in the lane's registers (fully
+//            unrolled, wave-uniform guards), the primal input and the output cotangent of 64 consecutive samples travel through
+//            two [64][odd pitch] LDS tiles with 16-byte global accesses, the input cotangent leaves through the first tile.
+//            (The 12-row instantiation stays as the A/B of the next range: BJX_MATRIX_VJP_GRP = 0.)
+//   9 ... 32 one GROUP of 16 / 32 lanes per sample with the factor in LDS: bjx_matrix_vjp_grp.hip.
+//   > 32     the one-lane code on a lane-strided global workspace (entry e of lane l at ws[e * lanes + l]: coalesced), plain
+//            per-lane global accesses for the arrays — correct, not fast (0.4 % of the HBM peak at K = 32 before the group kernel;
+//            the LKJ / Wishart blocks of real models are 2x2 ... 8x8).
 // Algorithmic bytes per sample: 2 x (unconstrained side) + K² (matrix side: one of in / out_bar is the matrix) + K² when the
 // matrix is the input (its cotangent is written) — e.g. inverse(VecCorr): (K(K-1) + K²)·sizeof(T) + ladj_bar.
 #include <cstdlib>
@@ -260,6 +264,10 @@ int matrix_vjp_impl(bjx_ctx* ctx, const char* who, int inverse, const T* in, con
   const int64_t KK = K * K, nv = free_len<KIND>(K);
   const int64_t n_in = inverse ? nv : KK, n_out = inverse ? KK : nv;
   if (n_in == 0) return BJX_OK;                                   // VecCorr with K = 1: nothing to differentiate
+  if (K > 8) {
+    const int rc = bjx_matrix_vjp_grp(ctx, sizeof(T) == 4 ? BJX_F32 : BJX_F64, KIND, inverse, in, out_bar, ladj_bar, in_bar, K, batch);
+    if (rc != 1) return rc;                                       // 1 = shape not served by the group kernel
+  }
   if (K <= 12) {
     const int P_in = (int)(n_in | 1), P_out = (int)((n_out > 0 ? n_out : 1) | 1);
     const size_t smem = ((((size_t)64 * P_in + 3) / 4) * 4 + (size_t)64 * P_out) * sizeof(T);
@@ -281,10 +289,6 @@ int matrix_vjp_impl(bjx_ctx* ctx, const char* who, int inverse, const T* in, con
     }
     BJX_CHECK_LAUNCH(ctx);
     return BJX_OK;
-  }
-  {
-    const int rc = bjx_matrix_vjp_grp(ctx, sizeof(T) == 4 ? BJX_F32 : BJX_F64, KIND, inverse, in, out_bar, ladj_bar, in_bar, K, batch);
-    if (rc != 1) return rc;                                       // 1 = shape not served by the group kernel
   }
   BJX_REQUIRE(ctx, K <= 1024, BJX_ERR_UNSUPPORTED, "%s: K = %lld: the general-size pullback stops at 1024", who, (long long)K);
   // lanes in flight: as many as a 512 MiB workspace holds (two K x K triangles per lane), at most the batch

@@ -1,8 +1,8 @@
 // bjx_matrix_vjp_grp.hip — pullbacks of VecCorrBijector / CorrBijector / PDBijector / PDVecBijector and their inverses
-// (SURVEY.md §8(f) f-1 x f-4; the rules and their reference lines: bjx_matrix_vjp.hip) for 12 < K <= 32.
+// (SURVEY.md §8(f) f-1 x f-4; the rules and their reference lines: bjx_matrix_vjp.hip) for 8 < K <= 32.
 //
 // bjx_matrix_vjp.hip gives a sample to ONE lane; past 12 rows its triangles no longer fit the lane's registers and the same code
-// ran on a lane-strided global workspace: 0.4 % of the HBM peak at K = 32.  Here a GROUP of GS = 16 / 32 lanes owns a sample
+// ran on a lane-strided global workspace: 0.4 % of the HBM peak at K = 32 (and 19-27 % at K = 12, on 150 registers of triangle).  Here a GROUP of GS = 16 / 32 lanes owns a sample
 // (4 / 2 samples per wave, the group never leaves its wave: LDS traffic is ordered by the wave's queue, no block barrier), the
 // factor L and a second K x K buffer B live in LDS (rows on 16-byte boundaries: see GrpLds), and every phase is either "lane = row,
 // sequential along the row", "lane = column with 16-byte broadcast reads of a row of L", or elementwise over the triangle:
@@ -364,7 +364,8 @@ int grp_launch(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T
 template <class T>
 int grp_kind(bjx_ctx* ctx, int kind, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
   // the unrolled phases cost ~KMAX² instructions whatever K is: 16, 24 and 32 rows
-#define GRP_K(KIND_) (K <= 16 ? grp_launch<T, 16, 16, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch) \
+#define GRP_K(KIND_) (K <= 12 ? grp_launch<T, 16, 12, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch) \
+                    : K <= 16 ? grp_launch<T, 16, 16, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch) \
                     : K <= 24 ? grp_launch<T, 32, 24, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch) \
                               : grp_launch<T, 32, 32, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch))
   switch (kind) {
@@ -382,7 +383,8 @@ namespace bjx {
 
 int bjx_matrix_vjp_grp(bjx_ctx* ctx, bjx_dtype dt, int kind, int inverse, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K, int64_t batch) {
   static const int use_grp = getenv("BJX_MATRIX_VJP_GRP") ? atoi(getenv("BJX_MATRIX_VJP_GRP")) : 1;      // 0: the one-lane-per-sample workspace kernel (its A/B)
-  if (!use_grp || K <= 12 || K > 32) return 1;
+  // K = 9 ... 12 too: same call, 2^19 samples, K = 12: 24-48 % of the HBM peak here against 19-27 % for the twelve-row register kernel
+  if (!use_grp || K < 9 || K > 32) return 1;
   if (dt == BJX_F32) return grp_kind<float>(ctx, kind, inverse, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, K, batch);
   return grp_kind<double>(ctx, kind, inverse, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, K, batch);
 }
