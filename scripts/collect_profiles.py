@@ -14,7 +14,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOMINANT = {"c1": ["chain_flat"], "c2": ["chain_flat_kernel"], "c2v": ["chain_flat_kernel"], "c3": ["rqs_lds_kernel"], "c4": ["planar_reg"],
-            "c5a": ["quad_stream_kernel"], "c5b": ["chol_inv_chunk_kernel"], "vcorr": ["matrix_link_kernel<float, 32, 0, false>"], "pdvec": ["matrix_link_kernel<float, 32, 3, false>"]}   # the forward kernel is the timed one (the inverse builds the input)
+            "c5a": ["quad_stream_kernel"], "c5b": ["chol_inv_chunk_kernel"], "vcorr": ["matrix_cyc_kernel<float, 8, 4, 0, false>"], "pdvec": ["matrix_cyc_kernel<float, 8, 4, 3, false>"]}   # the forward kernel is the timed one (the inverse builds the input)
 
 
 def main(tag):
@@ -70,12 +70,12 @@ def main(tag):
     if lines:
         with open(os.path.join(dst, f"{tag}_bench_lines.jsonl"), "w") as f:
             f.write("\n".join(lines) + "\n")
-    json.dump(traffic, open(traffic_path, "w"), indent=1)
     # which binary the evidence belongs to (tests/test_profiles_fresh.py: the kernel names of these files must exist in the .so of the tree)
     sha = os.path.join(src, "lib_sha16.txt")
     if os.path.exists(sha):
         traffic["_lib_sha16"] = open(sha).read().strip()
-        traffic["_tag"] = tag
+    traffic["_tag"] = tag
+    json.dump(traffic, open(traffic_path, "w"), indent=1)
     for extra in ("bench_default.json", "bench_default_detail.json", "rows.md", "rows_kernel_stats.csv", "f64_rows.md", "f64math_bench.txt", "planar_mfma_ab.txt", "small_sizes.md",
                   "lib_sha16.txt", "lib_bytes.txt", "first_call.txt"):
         pe = os.path.join(src, extra)
