@@ -529,30 +529,52 @@ struct PlanarRegArgs {
   int nl_pad;
   int n_layers;             // layers beyond it are padding: their tanh is forced to 0 (a +-Inf input would make 0 * Inf = NaN of them)
   int ldw;                  // row pitch of w / u_hat: dim rounded up to whole 16-byte packs (the padding rows are zero)
-  int unal;                 // columns are not made of whole ALIGNED packs (dim % 4 != 0 or a 4-byte aligned base): see reg_load_pack
+  int unal;                 // column heights that are not a multiple of four: see reg_load_pack (2: streaming stores)
+  int lead;                 // zero rows in front of every row of w / u_hat (4 in that case, 0 otherwise)
 };
 
-// Column heights that are not a multiple of four (round 3).  A lane still owns rows 4gl .. 4gl+3 of its column, but the packs are
-// only element-aligned (global_load_dwordx4 takes any 4-byte address) and the last pack of a column holds nrow = 1..3 live rows.
-// That pack is LOADED as the last four rows of the column (which stay inside it: dim >= 4) and shifted down, the dead rows read as
-// zero so that the zero-padded parameter tables need no masks; it is STORED row by row.
+// Column heights that are not a multiple of four (UNAL instantiations; bases 16-byte aligned).  Round 3 kept "lane gl owns rows
+// 4gl .. 4gl+3 of its column" and read them with 16-byte loads on element-aligned addresses: every 256-byte slice of a column then
+// straddles three 128-byte lines instead of two, and eight layers at 101 / 201 rows ran at 36-41 % of the HBM peak against 74 % at
+// 128.  Round 4 keeps the ADDRESSES on the 16-byte grid instead: a column that starts phi elements past a 16-byte boundary is cut
+// into the aligned packs of memory, lane gl owns rows rel .. rel+3 with rel = row0 + 4gl - phi — the first pack of a column and
+// the last one also hold rows of the neighbouring columns, which are read as zeros (live elements [lo, hi)) and never stored.
+// phi is the same for every column a lane touches: a 16-lane group steps through columns cg, cg+4, cg+8, … and
+// (c + 4) dim = c dim (mod 4).  The parameter tables are read at the matching offset (their rows carry `lead` zeros in front and
+// at least four behind), so the zero-padded products need no masks.
 typedef float bjx_pk4 __attribute__((ext_vector_type(4)));
 typedef bjx_pk4 bjx_pk4u __attribute__((aligned(4)));
-__device__ __forceinline__ bjx_pk4 reg_load_pack(const float* px, int nrow) {
-  const int sh = 4 - nrow;
-  bjx_pk4 v = __builtin_nontemporal_load(reinterpret_cast<const bjx_pk4u*>(px - sh));
-  if (sh == 1) v = bjx_pk4{v.y, v.z, v.w, 0.f};
-  else if (sh == 2) v = bjx_pk4{v.z, v.w, 0.f, 0.f};
-  else if (sh == 3) v = bjx_pk4{v.w, 0.f, 0.f, 0.f};
+__device__ __forceinline__ bjx_pk4 reg_load_pack(const float* px, int lo, int hi) {
+  bjx_pk4 v = __builtin_nontemporal_load(reinterpret_cast<const bjx_pk4*>(px));
+  if (lo > 0 || hi < 4) {
+    v.x = (lo <= 0 && hi > 0) ? v.x : 0.f;
+    v.y = (lo <= 1 && hi > 1) ? v.y : 0.f;
+    v.z = (lo <= 2 && hi > 2) ? v.z : 0.f;
+    v.w = (lo <= 3 && hi > 3) ? v.w : 0.f;
+  }
   return v;
 }
-// nt: streaming stores (A.unal == 2, BJX_UNAL_NT = 1).  Off by default — the halves of a 64-byte sector that two columns of an odd
-// height share are written at different times, and streamed they reach HBM as partial writes (WRITE_SIZE 1.15-1.35 x the output).
-__device__ __forceinline__ void reg_store_pack(float* py, const bjx_pk4 v, int nrow, bool nt) {
-  if (nrow == 4) { if (nt) __builtin_nontemporal_store(v, reinterpret_cast<bjx_pk4u*>(py)); else *reinterpret_cast<bjx_pk4u*>(py) = v; }
-  else if (nrow == 3) { TinyCol<float, 3> t; t.v[0] = v.x; t.v[1] = v.y; t.v[2] = v.z; *reinterpret_cast<TinyCol<float, 3>*>(py) = t; }   // one dwordx3 / x2 store
-  else if (nrow == 2) { TinyCol<float, 2> t; t.v[0] = v.x; t.v[1] = v.y; *reinterpret_cast<TinyCol<float, 2>*>(py) = t; }
-  else py[0] = v.x;
+// nt: streaming stores (A.unal == 2).  Off by default — the 64-byte sector that two columns share is written at different times,
+// and streamed it reached HBM as partial writes (WRITE_SIZE 1.15-1.35 x the output).
+__device__ __forceinline__ void reg_store_pack(float* py, const bjx_pk4 v, int lo, int hi, bool nt) {
+  if (lo <= 0 && hi >= 4) { if (nt) __builtin_nontemporal_store(v, reinterpret_cast<bjx_pk4*>(py)); else *reinterpret_cast<bjx_pk4*>(py) = v; }
+  else {
+    if (lo <= 0 && hi > 0) py[0] = v.x;
+    if (lo <= 1 && hi > 1) py[1] = v.y;
+    if (lo <= 2 && hi > 2) py[2] = v.z;
+    if (lo <= 3 && hi > 3) py[3] = v.w;
+  }
+}
+// my pack on the aligned grid: rel = first row (may be -3 .. -1 at the head of a column), live elements [lo, hi)
+struct RegGrid { int phi, rel, lo, hi; bool ok; };
+template <bool UNAL> __device__ __forceinline__ RegGrid reg_grid(int64_t col, int dim, int row) {
+  RegGrid g;
+  g.phi = UNAL ? (int)((col * (int64_t)dim) & 3) : 0;
+  g.rel = row - g.phi;
+  g.lo = g.rel < 0 ? -g.rel : 0;
+  g.hi = dim - g.rel < 4 ? dim - g.rel : 4;
+  g.ok = g.hi > g.lo;
+  return g;
 }
 
 // find_alpha for the register kernel: same safeguarded Newton on the reference's bracket
@@ -690,20 +712,22 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
   float* st = st_all[wave];
   const int gl = lane & (G - 1);
   const int cg = lane / G;                          // column inside a wave instruction
-  const bool row_ok = 4 * gl < dim;
-  const int nrow = dim - 4 * gl >= 4 ? 4 : dim - 4 * gl;   // live rows of my pack (<= 0: none)
   const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * COLS;
+  const RegGrid gr = reg_grid<UNAL>(col0 + cg, dim, 4 * gl);      // UNAL: see reg_load_pack
+  const bool row_ok = gr.ok;
+  const float* Aw = A.w + (UNAL ? A.lead - gr.phi : 0);
+  const float* Au = A.u_hat + (UNAL ? A.lead - gr.phi : 0);
   const int64_t left = batch - col0;
   const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
   const int64_t step_elems = (int64_t)CPS * dim;
 
   f4 z[NS];
   {
-    const float* px = x + (col0 + cg) * dim + 4 * gl;
+    const float* px = x + (col0 + cg) * dim + gr.rel;
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, nrow);
+        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, gr.lo, gr.hi);
         else z[r] = f4{0.f, 0.f, 0.f, 0.f};
         px += step_elems;
       }
@@ -728,8 +752,8 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
       for (int kp = 0; kp < NP; ++kp) {
         f4 a = f4{0.f, 0.f, 0.f, 0.f}, b = a;
         if (row_ok) {
-          a = *reinterpret_cast<const f4*>(A.w + (int64_t)(l0 + 2 * kp) * (UNAL ? A.ldw : dim) + 4 * gl);
-          if (NL >= 2) b = *reinterpret_cast<const f4*>(A.w + (int64_t)(l0 + 2 * kp + 1) * (UNAL ? A.ldw : dim) + 4 * gl);
+          a = *reinterpret_cast<const bjx_pk4u*>(Aw + (int64_t)(l0 + 2 * kp) * (UNAL ? A.ldw : dim) + 4 * gl);
+          if (NL >= 2) b = *reinterpret_cast<const bjx_pk4u*>(Aw + (int64_t)(l0 + 2 * kp + 1) * (UNAL ? A.ldw : dim) + 4 * gl);
         }
         wq[kp][0] = f2{a.x, b.x}; wq[kp][1] = f2{a.y, b.y}; wq[kp][2] = f2{a.z, b.z}; wq[kp][3] = f2{a.w, b.w};
       }
@@ -801,7 +825,7 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
       f4 uv[NL];
 #pragma unroll
       for (int k = 0; k < NL; ++k)
-        uv[k] = row_ok ? *reinterpret_cast<const f4*>(A.u_hat + (int64_t)(l0 + k) * (UNAL ? A.ldw : dim) + 4 * gl) : f4{0.f, 0.f, 0.f, 0.f};
+        uv[k] = row_ok ? (f4)*reinterpret_cast<const bjx_pk4u*>(Au + (int64_t)(l0 + k) * (UNAL ? A.ldw : dim) + 4 * gl) : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
         const float* tc = st + (r * CPS + cg) * NL;
@@ -832,11 +856,11 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
     __builtin_amdgcn_wave_barrier();
   }
   if (y) {
-    float* py = y + (col0 + cg) * dim + 4 * gl;
+    float* py = y + (col0 + cg) * dim + gr.rel;
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow, A.unal == 2);
+        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], gr.lo, gr.hi, A.unal == 2);
         py += step_elems;
       }
     } else {
@@ -1185,8 +1209,8 @@ __device__ __forceinline__ void reg_dots(const float* __restrict__ tab, int l0, 
   for (int kp = 0; kp < NP; ++kp) {
     bjx_f4 a = bjx_f4{0.f, 0.f, 0.f, 0.f}, b = a;
     if (row_ok) {
-      a = *reinterpret_cast<const bjx_f4*>(tab + (int64_t)(l0 + 2 * kp) * dim + row0 + 4 * gl);
-      if (NL >= 2) b = *reinterpret_cast<const bjx_f4*>(tab + (int64_t)(l0 + 2 * kp + 1) * dim + row0 + 4 * gl);
+      a = *reinterpret_cast<const bjx_pk4u*>(tab + (int64_t)(l0 + 2 * kp) * dim + row0 + 4 * gl);
+      if (NL >= 2) b = *reinterpret_cast<const bjx_pk4u*>(tab + (int64_t)(l0 + 2 * kp + 1) * dim + row0 + 4 * gl);
     }
     wq[kp][0] = bjx_f2{a.x, b.x}; wq[kp][1] = bjx_f2{a.y, b.y}; wq[kp][2] = bjx_f2{a.z, b.z}; wq[kp][3] = bjx_f2{a.w, b.w};
   }
@@ -1229,7 +1253,7 @@ __device__ __forceinline__ void reg_update(const float* __restrict__ tab, int l0
   bjx_f4 uv[NL];
 #pragma unroll
   for (int k = 0; k < NL; ++k)
-    uv[k] = row_ok ? *reinterpret_cast<const bjx_f4*>(tab + (int64_t)(l0 + k) * dim + row0 + 4 * gl) : bjx_f4{0.f, 0.f, 0.f, 0.f};
+    uv[k] = row_ok ? (bjx_f4)*reinterpret_cast<const bjx_pk4u*>(tab + (int64_t)(l0 + k) * dim + row0 + 4 * gl) : bjx_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int r = 0; r < NS; ++r) {
     const float* tc = st + (r * CPS + cg) * NL;
@@ -1266,19 +1290,21 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
   const int gl = lane & (G - 1), cg = lane / G;
   const int lc = lane & (COLS - 1);                          // my column in the lane = column steps
   const int row0 = half * 64;
-  const bool row_ok = row0 + 4 * gl < dim;
-  const int nrow = dim - row0 - 4 * gl >= 4 ? 4 : dim - row0 - 4 * gl;
   const int64_t col0 = ((int64_t)blockIdx.x * (NWB / NW) + tile) * COLS;
+  const RegGrid gr = reg_grid<UNAL>(col0 + cg, dim, row0 + 4 * gl);      // UNAL: see reg_load_pack
+  const bool row_ok = gr.ok;
+  const float* Aw = A.w + (UNAL ? A.lead - gr.phi : 0);
+  const float* Au = A.u_hat + (UNAL ? A.lead - gr.phi : 0);
   const int64_t left = batch - col0;
   const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
   const int64_t step_elems = (int64_t)CPS * dim;
   bjx_f4 z[NS];
   {
-    const float* px = x + (col0 + cg) * dim + row0 + 4 * gl;
+    const float* px = x + (col0 + cg) * dim + gr.rel;
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, nrow);
+        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, gr.lo, gr.hi);
         else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
         px += step_elems;
       }
@@ -1297,7 +1323,7 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
   for (int gi = 0; gi < ngroups; ++gi) {
     const int l0 = (INV ? ngroups - 1 - gi : gi) * NL;
     float* mineS = sS[gi & 1][wave];
-    reg_dots<G, NL, NS>(A.w, l0, (UNAL ? A.ldw : dim), z, mineS, lane, gl, cg, row_ok, row0);
+    reg_dots<G, NL, NS>(Aw, l0, (UNAL ? A.ldw : dim), z, mineS, lane, gl, cg, row_ok, row0);
     __syncthreads();                                         // every slice of every tile has published its partial sums
     {
       // (COLS = 32: lanes 32..63 run the recurrence of column lane - 32 along — same values, same stores; a divergent region
@@ -1335,7 +1361,7 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
       for (int k = 0; k < NL; ++k) stT[lc * NL + k] = t[k];
     }
     __builtin_amdgcn_wave_barrier();
-    reg_update<G, NL, NS>(A.u_hat, l0, (UNAL ? A.ldw : dim), z, stT, gl, cg, row_ok, row0);
+    reg_update<G, NL, NS>(Au, l0, (UNAL ? A.ldw : dim), z, stT, gl, cg, row_ok, row0);
     __builtin_amdgcn_wave_barrier();
   }
   if (accumulate & 2) {
@@ -1355,11 +1381,11 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
     ladj += -0.5f * q2 - (float)dim * 0.91893853320467274178f;
   }
   if (y) {
-    float* py = y + (col0 + cg) * dim + row0 + 4 * gl;
+    float* py = y + (col0 + cg) * dim + gr.rel;
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow, A.unal == 2);
+        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], gr.lo, gr.hi, A.unal == 2);
         py += step_elems;
       }
     } else {
@@ -1391,19 +1417,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
   float* tsave = reinterpret_cast<float*>(smem) + (size_t)4 * COLS * NL + (size_t)wave * COLS * A.nl_pad;   // [column][layer]
   const int gl = lane & (G - 1);
   const int cg = lane / G;
-  const bool row_ok = 4 * gl < dim;
-  const int nrow = dim - 4 * gl >= 4 ? 4 : dim - 4 * gl;
   const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * COLS;
+  const RegGrid gr = reg_grid<UNAL>(col0 + cg, dim, 4 * gl);      // UNAL: see reg_load_pack
+  const bool row_ok = gr.ok;
+  const float* Aw = A.w + (UNAL ? A.lead - gr.phi : 0);
+  const float* Au = A.u_hat + (UNAL ? A.lead - gr.phi : 0);
   const int64_t left = batch - col0;
   const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
   const int64_t step_elems = (int64_t)CPS * dim;
   bjx_f4 z[NS];
   auto load_tile = [&](const float* base) {
-    const float* px = base + (col0 + cg) * dim + 4 * gl;
+    const float* px = base + (col0 + cg) * dim + gr.rel;
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, nrow);
+        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, gr.lo, gr.hi);
         else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
         px += step_elems;
       }
@@ -1421,7 +1449,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
   load_tile(x);
   for (int gi = 0; gi < ngroups; ++gi) {
     const int l0 = (INV ? ngroups - 1 - gi : gi) * NL;         // the inverse undoes the LAST group first
-    reg_dots<G, NL, NS>(A.w, l0, (UNAL ? A.ldw : dim), z, st, lane, gl, cg, row_ok);
+    reg_dots<G, NL, NS>(Aw, l0, (UNAL ? A.ldw : dim), z, st, lane, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
     {
       float s[NL], t[NL];
@@ -1445,7 +1473,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
       for (int k = 0; k < NL; ++k) { st[lane * NL + k] = t[k]; tsave[lane * A.nl_pad + l0 + k] = INV ? -t[k] : t[k]; }
     }
     __builtin_amdgcn_wave_barrier();
-    if (gi + 1 < ngroups) reg_update<G, NL, NS>(A.u_hat, l0, (UNAL ? A.ldw : dim), z, st, gl, cg, row_ok);
+    if (gi + 1 < ngroups) reg_update<G, NL, NS>(Au, l0, (UNAL ? A.ldw : dim), z, st, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
   }
   // ---- cotangent sweep, in the opposite order of the primal
@@ -1453,7 +1481,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
   const float lb = (lbar && lane < nvalid) ? lbar[col0 + lane] : 0.f;
   for (int gi = 0; gi < ngroups; ++gi) {
     const int l0 = (INV ? gi : ngroups - 1 - gi) * NL;
-    reg_dots<G, NL, NS>(A.u_hat, l0, (UNAL ? A.ldw : dim), z, st, lane, gl, cg, row_ok);
+    reg_dots<G, NL, NS>(Au, l0, (UNAL ? A.ldw : dim), z, st, lane, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
     {
       float g[NL], sb[NL];
@@ -1483,15 +1511,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
       }
     }
     __builtin_amdgcn_wave_barrier();
-    reg_update<G, NL, NS>(A.w, l0, (UNAL ? A.ldw : dim), z, st, gl, cg, row_ok);
+    reg_update<G, NL, NS>(Aw, l0, (UNAL ? A.ldw : dim), z, st, gl, cg, row_ok);
     __builtin_amdgcn_wave_barrier();
   }
   {
-    float* py = xbar + (col0 + cg) * dim + 4 * gl;
+    float* py = xbar + (col0 + cg) * dim + gr.rel;
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow, A.unal == 2);
+        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], gr.lo, gr.hi, A.unal == 2);
         py += step_elems;
       }
     } else {
@@ -1525,9 +1553,11 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
   const int tile = wave / NW, half = wave % NW;
   const int gl = lane & (G - 1), cg = lane / G;
   const int row0 = half * 64;
-  const bool row_ok = row0 + 4 * gl < dim;
-  const int nrow = dim - row0 - 4 * gl >= 4 ? 4 : dim - row0 - 4 * gl;
   const int64_t col0 = ((int64_t)blockIdx.x * TILES + tile) * COLS;
+  const RegGrid gr = reg_grid<UNAL>(col0 + cg, dim, row0 + 4 * gl);      // UNAL: see reg_load_pack
+  const bool row_ok = gr.ok;
+  const float* Aw = A.w + (UNAL ? A.lead - gr.phi : 0);
+  const float* Au = A.u_hat + (UNAL ? A.lead - gr.phi : 0);
   const int64_t left = batch - col0;
   const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
   const int64_t step_elems = (int64_t)CPS * dim;
@@ -1536,11 +1566,11 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
   float* tsave = sV + (size_t)tile * COLS * A.nl_pad;
   bjx_f4 z[NS];
   auto load_tile = [&](const float* base) {
-    const float* px = base + (col0 + cg) * dim + row0 + 4 * gl;
+    const float* px = base + (col0 + cg) * dim + gr.rel;
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, nrow);
+        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, gr.lo, gr.hi);
         else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
         px += step_elems;
       }
@@ -1570,7 +1600,7 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
   load_tile(x);
   for (int gi = 0; gi < ngroups; ++gi, ++gc) {
     const int l0 = (INV ? ngroups - 1 - gi : gi) * NL;
-    reg_dots<G, NL, NS>(A.w, l0, ldt, z, sS + ((size_t)(gc & 1) * NWB + wave) * COLS * NL, lane, gl, cg, row_ok, row0);
+    reg_dots<G, NL, NS>(Aw, l0, ldt, z, sS + ((size_t)(gc & 1) * NWB + wave) * COLS * NL, lane, gl, cg, row_ok, row0);
     __syncthreads();
     {
       float s[NL], t[NL];
@@ -1599,7 +1629,7 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (gi + 1 < ngroups) reg_update<G, NL, NS>(A.u_hat, l0, ldt, z, stT, gl, cg, row_ok, row0);
+    if (gi + 1 < ngroups) reg_update<G, NL, NS>(Au, l0, ldt, z, stT, gl, cg, row_ok, row0);
     __builtin_amdgcn_wave_barrier();
   }
   // ---- cotangent sweep, in the opposite order of the primal (tsave of the first slice is visible after the first barrier below)
@@ -1607,7 +1637,7 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
   const float lb = (lbar && lane < nvalid) ? lbar[col0 + lane] : 0.f;
   for (int gi = 0; gi < ngroups; ++gi, ++gc) {
     const int l0 = (INV ? gi : ngroups - 1 - gi) * NL;
-    reg_dots<G, NL, NS>(A.u_hat, l0, ldt, z, sS + ((size_t)(gc & 1) * NWB + wave) * COLS * NL, lane, gl, cg, row_ok, row0);
+    reg_dots<G, NL, NS>(Au, l0, ldt, z, sS + ((size_t)(gc & 1) * NWB + wave) * COLS * NL, lane, gl, cg, row_ok, row0);
     __syncthreads();
     {
       float g[NL], sb[NL], tk[NL];
@@ -1638,15 +1668,15 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
       }
     }
     __builtin_amdgcn_wave_barrier();
-    reg_update<G, NL, NS>(A.w, l0, ldt, z, stT, gl, cg, row_ok, row0);
+    reg_update<G, NL, NS>(Aw, l0, ldt, z, stT, gl, cg, row_ok, row0);
     __builtin_amdgcn_wave_barrier();
   }
   {
-    float* py = xbar + (col0 + cg) * dim + row0 + 4 * gl;
+    float* py = xbar + (col0 + cg) * dim + gr.rel;
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], nrow, A.unal == 2);
+        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], gr.lo, gr.hi, A.unal == 2);
         py += step_elems;
       }
     } else {
@@ -1664,8 +1694,8 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
 template <class T>
 __global__ __launch_bounds__(256) void planar_prep_reg_kernel(const T* w, const T* u_hat, const T* wtu_hat, const T* b,
                                                               int64_t dim, int nl, int nl_pad, T* wp, T* up, T* Gp,
-                                                              T* cp, T* bp, int64_t ldw = 0) {
-  if (ldw == 0) ldw = dim;                                      // row pitch of wp / up (rows dim .. ldw-1 are written as zeros)
+                                                              T* cp, T* bp, int64_t ldw = 0, int lead = 0) {
+  if (ldw == 0) ldw = dim;                                      // row pitch of wp / up: `lead` zeros, the dim values, zeros to the pitch
   __shared__ double red[4];
   const int k = blockIdx.x / nl_pad, j = blockIdx.x % nl_pad;
   const bool live = k < nl && j < nl;
@@ -1677,9 +1707,9 @@ __global__ __launch_bounds__(256) void planar_prep_reg_kernel(const T* w, const 
   if (threadIdx.x == 0) Gp[k * nl_pad + j] = live ? (T)((red[0] + red[1]) + (red[2] + red[3])) : T(0);
   if (j == 0) {
     for (int64_t i = threadIdx.x; i < ldw; i += blockDim.x) {
-      const bool in = k < nl && i < dim;
-      wp[(int64_t)k * ldw + i] = in ? w[(int64_t)k * dim + i] : T(0);
-      up[(int64_t)k * ldw + i] = in ? u_hat[(int64_t)k * dim + i] : T(0);
+      const bool in = k < nl && i >= lead && i - lead < dim;
+      wp[(int64_t)k * ldw + i] = in ? w[(int64_t)k * dim + i - lead] : T(0);
+      up[(int64_t)k * ldw + i] = in ? u_hat[(int64_t)k * dim + i - lead] : T(0);
     }
     if (threadIdx.x == 0) { cp[k] = k < nl ? wtu_hat[k] : T(0); bp[k] = k < nl ? b[k] : T(0); }
   }
@@ -2390,13 +2420,17 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
     static const int use_unal = getenv("BJX_PLANAR_REG_UNALIGNED") ? atoi(getenv("BJX_PLANAR_REG_UNALIGNED")) : 1;
     static const int unal_nt = 0;
     const bool packs_ok = dim % 4 == 0 && bjx_aligned16(in) && bjx_aligned16(out);
+    // heights that are not a multiple of four, on the 16-byte grid of memory (reg_load_pack): the lanes cover up to dim + 3 rows
+    const bool grid_ok = use_unal && dim > 32 && dim % 4 != 0 && bjx_aligned16(in) && bjx_aligned16(out);
+    const int64_t de = packs_ok ? dim : dim + 3;
     // 256 < dim <= 1024, two layers or more: the tile split over 8 / 16 waves of one block (planar_reg2_kernel, NW = 8 / 16)
     static const int use_big = getenv("BJX_PLANAR_REG_BIG") ? atoi(getenv("BJX_PLANAR_REG_BIG")) : 1;
-    const bool big = use_big && dim > 256 && dim <= 1024 && nl >= 2;
-    if (use_reg && (packs_ok || (use_unal && dim > 32)) && dim > 16 && (dim <= 256 || big)) {
+    const bool big = use_big && de > 256 && de <= 1024 && nl >= 2;
+    if (use_reg && (packs_ok || grid_ok) && dim > 16 && (de <= 256 || big)) {
       const int NL = (nl >= 8 && !big) ? 8 : (nl > 2 ? 4 : nl);           // 8 / 16 waves a block: groups of four layers (118 VGPRs: two 512-thread blocks a CU)
       const int nl_pad = (nl + NL - 1) / NL * NL;
-      const int64_t ldw = (dim + 3) / 4 * 4;
+      const int lead = packs_ok ? 0 : 4;
+      const int64_t ldw = (dim + 3) / 4 * 4 + 2 * lead;
       const size_t off0 = ((size_t)nl * dim + nl + 3) / 4 * 4;   // floats, keeps the padded tables 16-byte aligned
       const size_t need_reg = (off0 + (size_t)2 * nl_pad * ldw + (size_t)nl_pad * nl_pad + 2 * (size_t)nl_pad) * sizeof(float);
       if (need_reg <= BJX_SCRATCH_BYTES) {
@@ -2407,17 +2441,17 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         float* cp = Gp + (size_t)nl_pad * nl_pad;
         float* bp = cp + nl_pad;
         hipLaunchKernelGGL(planar_prep_reg_kernel<float>, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, (const float*)w, (const float*)u_hat,
-                           (const float*)wtu, (const float*)b, dim, nl, nl_pad, wp, up, Gp, cp, bp, ldw);
+                           (const float*)wtu, (const float*)b, dim, nl, nl_pad, wp, up, Gp, cp, bp, ldw, lead);
         BJX_CHECK_LAUNCH(ctx);
         static const int cols_env = 0;
-        const int G = dim > 64 ? 32 : (dim > 32 ? 16 : 8);
+        const int G = de > 64 ? 32 : (de > 32 ? 16 : 8);
         const int cols = (G == 32 && (cols_env ? cols_env == 32 : PLANAR_REG_DEFAULT_COLS == 32)) ? 32 : 64;
         // two waves per tile for 64 < dim <= 128.  Measured (A/B in one run, 2^22 columns, d = 128): 8 layers forward
         // 0.759 vs 0.783 ms; 1 layer 0.74 vs 0.71 ms and the inverse 0.66 vs 0.62 ms are SLOWER (the barrier and the
         // redundant recurrence cost more than the third wave per SIMD buys: 147 VGPRs, and forcing 128 spills) —
         // so only deep forward stacks take it.  BJX_PLANAR_SPLIT = 0 / 1 forces it off / on.
         static const int split_env = getenv("BJX_PLANAR_SPLIT") ? atoi(getenv("BJX_PLANAR_SPLIT")) : -1;
-        const bool quad = dim > 128;                                 // four waves per tile (128 < dim <= 256)
+        const bool quad = de > 128;                                  // four waves per tile (128 < dim <= 256)
         if (big) {
           const int64_t gridb = (batch + 63) / 64;
           BJX_REQUIRE(ctx, gridb < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar: batch too large for one launch");
@@ -2425,13 +2459,13 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
           bool secondb = false;
           { int rc = bjx_make_fin(ctx, gridb, ladj_sum, 0.0, 0, flags, &finb, &secondb); if (rc) return rc; }
           if (finb.counter) { finb.counter = nullptr; secondb = true; }        // blocks of 8 / 16 waves: two-pass finalize
-          PlanarRegArgs RB{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : (unal_nt ? 2 : 1)};
+          PlanarRegArgs RB{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : (unal_nt ? 2 : 1), lead};
           const int accumb = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
 #define LAUNCH_BIG_U(NL_, INV_, NW_, U_) hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_, NW_, U_>), dim3((unsigned)gridb), dim3(NW_ * 64), 0, ctx->stream, RB, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accumb, finb)
 #define LAUNCH_BIG(NL_, INV_, NW_) do { if (packs_ok) LAUNCH_BIG_U(NL_, INV_, NW_, false); else LAUNCH_BIG_U(NL_, INV_, NW_, true); } while (0)
 #define LAUNCH_BIG_I(NL_, NW_) do { if (inverse) LAUNCH_BIG(NL_, true, NW_); else LAUNCH_BIG(NL_, false, NW_); } while (0)
           { BjxProf prof_(ctx);
-            if (dim <= 512) { if (NL == 4) LAUNCH_BIG_I(4, 8); else LAUNCH_BIG_I(2, 8); }
+            if (de <= 512) { if (NL == 4) LAUNCH_BIG_I(4, 8); else LAUNCH_BIG_I(2, 8); }
             else { if (NL == 4) LAUNCH_BIG_I(4, 16); else LAUNCH_BIG_I(2, 16); } }
 #undef LAUNCH_BIG_I
 #undef LAUNCH_BIG
@@ -2440,15 +2474,16 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
           if (secondb) return bjx_launch_finalize(ctx, (int)gridb, ladj_sum, 0.0, 0, 0.0, flags);
           return BJX_OK;
         }
-        const bool split = quad || (G == 32 && (split_env >= 0 ? split_env != 0 : (!inverse && nl >= 8)));
+        // (the aligned grid needs 16-lane groups — four columns per wave instruction: past 64 rows always the split tile)
+        const bool split = quad || (G == 32 && (!packs_ok || (split_env >= 0 ? split_env != 0 : (!inverse && nl >= 8))));
         const int64_t grid = quad ? (batch + 63) / 64 : (split ? (batch + 2 * 64 - 1) / (2 * 64) : (batch + 4 * cols - 1) / (4 * cols));
         BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar: batch too large for one launch");
         BjxFin fin;
         bool second = false;
         { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
-        PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : (unal_nt ? 2 : 1)};
+        PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : (unal_nt ? 2 : 1), lead};
         const int accum = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
-#define LAUNCH_REG_U(G_, NL_, INV_, U_) if (G_ == 32 && cols == 32) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, (G_ == 32 ? 32 : 64), (G_ != 8) && U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); else hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, 64, (G_ != 8) && U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
+#define LAUNCH_REG_U(G_, NL_, INV_, U_) if (G_ == 32 && cols == 32) hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, (G_ == 32 ? 32 : 64), (G_ == 16) && U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin); else hipLaunchKernelGGL((planar_reg_kernel<G_, NL_, INV_, 64, (G_ == 16) && U_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, RA, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accum, fin)
 #define LAUNCH_REG(G_, NL_, INV_) do { if (packs_ok) { LAUNCH_REG_U(G_, NL_, INV_, false); } else { LAUNCH_REG_U(G_, NL_, INV_, true); } } while (0)
 #define LAUNCH_REG_NL(G_, INV_) switch (NL) { case 1: LAUNCH_REG(G_, 1, INV_); break; case 2: LAUNCH_REG(G_, 2, INV_); break; case 4: LAUNCH_REG(G_, 4, INV_); break; default: LAUNCH_REG(G_, 8, INV_); break; }
 #define LAUNCH_REG_G(INV_) switch (G) { case 8: LAUNCH_REG_NL(8, INV_) break; case 16: LAUNCH_REG_NL(16, INV_) break; default: LAUNCH_REG_NL(32, INV_) break; }
@@ -2595,16 +2630,18 @@ inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float
   static const int use_unal = getenv("BJX_PLANAR_REG_UNALIGNED") ? atoi(getenv("BJX_PLANAR_REG_UNALIGNED")) : 1;
   static const int unal_nt = 0;
   const bool packs_ok = dim % 4 == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
+  const bool grid_ok = use_unal && dim > 32 && dim % 4 != 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);   // reg_load_pack
+  const int64_t de = packs_ok ? dim : dim + 3;
   // the tile split over NW waves (planar_vjp_reg2_kernel): 2 for 64 < dim <= 128, 4 to 256, 8 to 512, 16 to 1024.  (Same call, 2^22
   // columns, 8 layers, two waves against the one-wave tile: 72 rows 45.5 / 43.4 %, 101 rows 37.9 / 31.5 %, 128 rows 73.0 / 67.7 %.)
   constexpr int split_env = 1;
-  const bool big = dim > 256 && dim <= 1024 && nl >= 2;
-  if (!(use_reg && (packs_ok || (use_unal && dim > 32)) && dim > 16 && (dim <= 256 || big))) return 1;
-  const int NW = dim > 512 ? 16 : (dim > 256 ? 8 : (dim > 128 ? 4 : ((dim > 64 && split_env) ? 2 : 1)));
-  if (NW == 1 && dim > 128) return 1;
+  const bool big = de > 256 && de <= 1024 && nl >= 2;
+  if (!(use_reg && (packs_ok || grid_ok) && dim > 16 && (de <= 256 || big))) return 1;
+  const int NW = de > 512 ? 16 : (de > 256 ? 8 : (de > 128 ? 4 : ((de > 64 && split_env) ? 2 : 1)));
   const int NL = (nl >= 8 && !big) ? 8 : (nl > 2 ? 4 : nl);
   const int nl_pad = (nl + NL - 1) / NL * NL;
-  const int64_t ldw = (dim + 3) / 4 * 4;
+  const int lead = packs_ok ? 0 : 4;
+  const int64_t ldw = (dim + 3) / 4 * 4 + 2 * lead;
   const size_t off0 = ((size_t)nl * dim + nl + 3) / 4 * 4;
   const size_t need_reg = (off0 + (size_t)2 * nl_pad * ldw + (size_t)nl_pad * nl_pad + 2 * (size_t)nl_pad) * sizeof(float);
   const int NWB = NW <= 4 ? 4 : NW;
@@ -2617,12 +2654,12 @@ inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float
   float* Gp = up + (size_t)nl_pad * ldw;
   float* cp = Gp + (size_t)nl_pad * nl_pad;
   float* bp = cp + nl_pad;
-  hipLaunchKernelGGL(planar_prep_reg_kernel<float>, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, w, u_hat, wtu, b, dim, nl, nl_pad, wp, up, Gp, cp, bp, ldw);
+  hipLaunchKernelGGL(planar_prep_reg_kernel<float>, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, w, u_hat, wtu, b, dim, nl, nl_pad, wp, up, Gp, cp, bp, ldw, lead);
   BJX_CHECK_LAUNCH(ctx);
-  const int G = dim > 64 ? 32 : (dim > 32 ? 16 : 8);
+  const int G = de > 64 ? 32 : (de > 32 ? 16 : 8);
   const int64_t grid = (batch + 4 * 64 - 1) / (4 * 64);
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: batch too large for one launch");
-  PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : (unal_nt ? 2 : 1)};
+  PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : (unal_nt ? 2 : 1), lead};
   if (NW > 1) {
     const int64_t grid2 = (batch + (int64_t)(NWB / NW) * 64 - 1) / ((int64_t)(NWB / NW) * 64);
     BJX_REQUIRE(ctx, grid2 < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: batch too large for one launch");
@@ -2643,8 +2680,8 @@ inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float
     BJX_CHECK_LAUNCH(ctx);
     return BJX_OK;
   }
-#define LVU(G_, NL_, U_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, true, (G_ != 8) && U_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); \
-                          else hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, false, (G_ != 8) && U_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); } while (0)
+#define LVU(G_, NL_, U_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, true, (G_ == 16) && U_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); \
+                          else hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, false, (G_ == 16) && U_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); } while (0)
 #define LV(G_, NL_) do { if (packs_ok) LVU(G_, NL_, false); else LVU(G_, NL_, true); } while (0)
 #define LV_NL(G_) switch (NL) { case 1: LV(G_, 1); break; case 2: LV(G_, 2); break; case 4: LV(G_, 4); break; default: LV(G_, 8); break; }
   {
