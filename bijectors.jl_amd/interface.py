@@ -33,7 +33,7 @@ __all__ = [
     "VecCholeskyBijector", "VecCorrBijector", "CorrBijector", "PDBijector", "PDVecBijector", "Permute", "PlanarLayer", "RadialLayer", "InvertibleBatchNorm", "RationalQuadraticSpline",
     "PartitionMask", "Coupling", "Stacked", "NamedStacked", "Columnwise", "columnwise", "vjp", "istraining", "training", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
     "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
-    "PlanarResult", "vjp_params", "row_moments", "MvNormal", "TransformedDistribution", "transformed", "logpdf", "rand",
+    "PlanarResult", "vjp_params", "row_moments", "MvNormal", "TorchBase", "TransformedDistribution", "transformed", "logpdf", "rand",
     "CapturedStep", "kernel_timed",
 ]
 
@@ -2658,6 +2658,39 @@ class MvNormal:
         return ops
 
 
+class TorchBase:
+    """Any other base distribution (src/transformed_distribution.jl:159-240 is generic in `td.dist`; VERDICT r03 missing #6): an adapter
+    around a `torch.distributions.Distribution` whose event is the column of `dim` rows — e.g. `Independent(Laplace(loc, scale), 1)`,
+    `MultivariateNormal`, `StudentT` factors, a mixture.  The protocol `logpdf` / `rand` use is duck-typed, any object with
+        logpdf(x[dim, N]) -> [N]      and      rand(n, device, dtype, seed) -> x[dim, n] (column-major)
+    can be the `dist` of `transformed`.  Nothing is fused for such a base: the flow's kernel writes the pre-image, the base reads it."""
+
+    def __init__(self, dist, dim=None):
+        self.dist = dist
+        es = tuple(dist.event_shape) if len(dist.event_shape) else tuple(dist.batch_shape)
+        self.dim = int(dim if dim is not None else (es[-1] if es else 1))
+
+    def logpdf(self, x):
+        lp = self.dist.log_prob(x.T)                     # rows of x.T are samples
+        return lp.reshape(lp.shape[0], -1).sum(dim=1) if lp.dim() > 1 else lp     # independent factors given as a batch shape
+
+    def rand(self, n, device, dtype, seed=0):
+        with torch.random.fork_rng(devices=[device] if torch.device(device).type == "cuda" else []):
+            torch.manual_seed(seed)
+            smp = self.dist.sample((n,)).reshape(n, -1).to(device=device, dtype=dtype)
+        return colmajor(smp.T)
+
+
+def _preimage(ib, y):
+    """(x, per-column log-det) of the inverse transform, materialised"""
+    if ib is identity:
+        return y, None
+    x, lj = with_logabsdet_jacobian(ib, y, per_sample=True) if isinstance(ib, ComposedFunction) else ib._wlj(y, per_sample=True)
+    if hasattr(x, "result"):
+        x, lj = x.result, x.logabsdetjac
+    return x, lj
+
+
 class TransformedDistribution:
     """src/transformed_distribution.jl:2-12: `transformed(dist, b)`; y = b(x), x ~ dist."""
 
@@ -2681,6 +2714,11 @@ def logpdf(td: TransformedDistribution, y, reference_shape: bool = False):
     scalar log-det for the whole matrix, which it adds to every column (SURVEY.md §8a″)."""
     ib = inverse(td.transform)
     d = td.dist
+    if not isinstance(d, MvNormal):
+        # any base with logpdf(x[dim, N]) -> [N] (TorchBase): transformed_distribution.jl:164-169 literally
+        x, lj = _preimage(ib, y)
+        lp = d.logpdf(x)
+        return lp if lj is None else lp + lj
     if getattr(d, "scale_tril", None) is not None:
         # full covariance: x = b⁻¹(y); z = L \ x (bjx_scale_matrix, log-det −logabsdet L per column); then the standard-normal
         # density of z − L⁻¹μ accumulated without storing anything (one chain launch, store=False)
@@ -2719,6 +2757,9 @@ def rand(td: TransformedDistribution, n: int, seed: int = 0, device=None, dtype=
     for any shard count: keyed by seed, global column and row), colouring μ + σ·z fused into the transform's
     chain when there is one — and then drawn INSIDE that kernel (`fused=False`: fill, then transform; same bits)."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if not isinstance(td.dist, MvNormal):
+        x = td.dist.rand(n, device, dtype, seed)             # any base (TorchBase protocol), then the transform over all columns
+        return x if td.transform is identity else transform(td.transform, x)
     dim = td.dist.dim
     z = torch.empty((n, dim), dtype=dtype, device=device).T
     ctx = context(device)
