@@ -544,15 +544,19 @@ struct PlanarRegArgs {
 // at least four behind), so the zero-padded products need no masks.
 typedef float bjx_pk4 __attribute__((ext_vector_type(4)));
 typedef bjx_pk4 bjx_pk4u __attribute__((aligned(4)));
-__device__ __forceinline__ bjx_pk4 reg_load_pack(const float* px, int lo, int hi) {
-  bjx_pk4 v = __builtin_nontemporal_load(reinterpret_cast<const bjx_pk4*>(px));
-  if (lo > 0 || hi < 4) {
-    v.x = (lo <= 0 && hi > 0) ? v.x : 0.f;
-    v.y = (lo <= 1 && hi > 1) ? v.y : 0.f;
-    v.z = (lo <= 2 && hi > 2) ? v.z : 0.f;
-    v.w = (lo <= 3 && hi > 3) ? v.w : 0.f;
+// (the loads of a tile are all issued BEFORE the first mask is applied — reg_mask_tile below: masked one by one, every load was
+//  followed by an s_waitcnt and the sixteen loads of a lane went to memory one after the other; with eight layers of work per tile that
+//  halved the bytes in flight per CU: 42 % of the HBM peak at 201 rows against 60 % at 200)
+__device__ __forceinline__ bjx_pk4 reg_load_pack(const float* px) { return __builtin_nontemporal_load(reinterpret_cast<const bjx_pk4*>(px)); }
+template <int NS> __device__ __forceinline__ void reg_mask_tile(bjx_pk4 (&z)[NS], int lo, int hi) {
+  const bool k0 = lo <= 0 && hi > 0, k1 = lo <= 1 && hi > 1, k2 = lo <= 2 && hi > 2, k3 = lo <= 3 && hi > 3;   // selects, no branch around the tile
+#pragma unroll
+  for (int r = 0; r < NS; ++r) {
+    z[r].x = k0 ? z[r].x : 0.f;
+    z[r].y = k1 ? z[r].y : 0.f;
+    z[r].z = k2 ? z[r].z : 0.f;
+    z[r].w = k3 ? z[r].w : 0.f;
   }
-  return v;
 }
 // nt: streaming stores (A.unal == 2).  Off by default — the 64-byte sector that two columns share is written at different times,
 // and streamed it reached HBM as partial writes (WRITE_SIZE 1.15-1.35 x the output).
@@ -727,10 +731,11 @@ __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, 
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, gr.lo, gr.hi);
+        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px);
         else z[r] = f4{0.f, 0.f, 0.f, 0.f};
         px += step_elems;
       }
+      reg_mask_tile(z, gr.lo, gr.hi);
     } else {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
@@ -1304,10 +1309,11 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, gr.lo, gr.hi);
+        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px);
         else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
         px += step_elems;
       }
+      reg_mask_tile(z, gr.lo, gr.hi);
     } else {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
@@ -1431,10 +1437,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, gr.lo, gr.hi);
+        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px);
         else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
         px += step_elems;
       }
+      reg_mask_tile(z, gr.lo, gr.hi);
     } else {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
@@ -1570,10 +1577,11 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
     if constexpr (UNAL) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px, gr.lo, gr.hi);
+        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px);
         else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
         px += step_elems;
       }
+      reg_mask_tile(z, gr.lo, gr.hi);
     } else {
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
