@@ -38,7 +38,7 @@ template <int KIND> __host__ __device__ inline int64_t free_len(int64_t K) {
 }
 
 
-// 8 < K <= 32: one group of 16 / 32 lanes per sample, the factor and its cotangent in LDS (bjx_matrix_vjp_grp.hip).
+// 8 < K <= 64 (Float64: <= 32): one group of 16 / 32 / 64 lanes per sample, the factor and its cotangent in LDS (bjx_matrix_vjp_grp.hip).
 // Returns 1 when the shape is not served.
 int bjx_matrix_vjp_grp(bjx_ctx* ctx, bjx_dtype dt, int kind, int inverse, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K, int64_t batch);
 

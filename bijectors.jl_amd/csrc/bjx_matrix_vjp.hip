@@ -20,8 +20,8 @@
 //            unrolled, wave-uniform guards), the primal input and the output cotangent of 64 consecutive samples travel through
 //            two [64][odd pitch] LDS tiles with 16-byte global accesses, the input cotangent leaves through the first tile.
 //            (The 12-row instantiation stays as the A/B of the next range: BJX_MATRIX_VJP_GRP = 0.)
-//   9 ... 32 one GROUP of 16 / 32 lanes per sample with the factor in LDS: bjx_matrix_vjp_grp.hip.
-//   > 32     the one-lane code on a lane-strided global workspace (entry e of lane l at ws[e * lanes + l]: coalesced), plain
+//   9 ... 64 one GROUP of 16 / 32 / 64 lanes per sample with the factor in LDS: bjx_matrix_vjp_grp.hip (Float64: to 32).
+//   beyond   the one-lane code on a lane-strided global workspace (entry e of lane l at ws[e * lanes + l]: coalesced), plain
 //            per-lane global accesses for the arrays — correct, not fast (0.4 % of the HBM peak at K = 32 before the group kernel;
 //            the LKJ / Wishart blocks of real models are 2x2 ... 8x8).
 // Algorithmic bytes per sample: 2 x (unconstrained side) + K² (matrix side: one of in / out_bar is the matrix) + K² when the

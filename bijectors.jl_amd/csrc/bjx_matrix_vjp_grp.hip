@@ -1,9 +1,9 @@
 // bjx_matrix_vjp_grp.hip — pullbacks of VecCorrBijector / CorrBijector / PDBijector / PDVecBijector and their inverses
-// (SURVEY.md §8(f) f-1 x f-4; the rules and their reference lines: bjx_matrix_vjp.hip) for 8 < K <= 32.
+// (SURVEY.md §8(f) f-1 x f-4; the rules and their reference lines: bjx_matrix_vjp.hip) for 8 < K <= 64 (Float64: <= 32).
 //
 // bjx_matrix_vjp.hip gives a sample to ONE lane; past 12 rows its triangles no longer fit the lane's registers and the same code
-// ran on a lane-strided global workspace: 0.4 % of the HBM peak at K = 32 (and 19-27 % at K = 12, on 150 registers of triangle).  Here a GROUP of GS = 16 / 32 lanes owns a sample
-// (4 / 2 samples per wave, the group never leaves its wave: LDS traffic is ordered by the wave's queue, no block barrier), the
+// ran on a lane-strided global workspace: 0.4 % of the HBM peak at K = 32 (and 19-27 % at K = 12, on 150 registers of triangle).  Here a GROUP of GS = 16 / 32 / 64 lanes owns a sample
+// (4 / 2 / 1 samples per wave, the group never leaves its wave: LDS traffic is ordered by the wave's queue, no block barrier), the
 // factor L and a second K x K buffer B live in LDS (rows on 16-byte boundaries: see GrpLds), and every phase is either "lane = row,
 // sequential along the row", "lane = column with 16-byte broadcast reads of a row of L", or elementwise over the triangle:
 //
@@ -63,7 +63,7 @@ template <class T, int GS, int KMAX> struct GrpLds {
   static constexpr int P = KMAX + N;
   static constexpr int BASE = 2 * KMAX * P + KMAX;
   static constexpr int W = sizeof(T) / 4;
-  static constexpr int TARGET = sizeof(T) == 4 ? GS : (GS == 32 ? 0 : 32);
+  static constexpr int TARGET = sizeof(T) == 4 ? GS % 64 : (GS >= 32 ? 0 : 32);
   static constexpr int pad() { int q = 0; while (((BASE + q) * W) % 64 != TARGET) q += N; return q; }
   static constexpr int SS = BASE + pad();
 };
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void matrix_grp_vjp_kernel(const T* __restrict
     }
     GRP_UNROLL for (int r = 0; r < KMAX; ++r) z[r] = r > t ? z[r] : (r == t ? T(0.5) * z[r] : T(0));
     // ---- F6: L' Z = Φ, column t — from the last row up, each solved entry eliminated with ONE row of L
-    auto solve_lt = [&](T (&v)[KMAX]) {
+    auto solve_lt = [&](T (&v)[KMAX]) __attribute__((always_inline)) {     // (left to the inliner, the 64-row instantiation calls it: the arrays go to scratch, 0.5 % of the HBM peak)
       GRP_UNROLL for (int r = KMAX - 1; r >= 0; --r) {
         v[r] *= M::rcp(Lb[r * P + r]);
         const T mv = -v[r];
@@ -364,6 +364,21 @@ int grp_launch(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T
 template <class T>
 int grp_kind(bjx_ctx* ctx, int kind, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
   // the unrolled phases cost ~KMAX² instructions whatever K is: 16, 24 and 32 rows
+  if constexpr (sizeof(T) == 4) {
+    // 32 < K <= 64 (Float32): the whole wave on one sample (the Float64 arrays would not fit the register file: those sizes stay on
+    // the one-lane workspace kernel)
+    if (K > 32) {
+#define GRP_W(KIND_) (K <= 48 ? grp_launch<T, 64, 48, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch) \
+                              : grp_launch<T, 64, 64, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch))
+      switch (kind) {
+        case MK_VEC_CORR: return GRP_W(MK_VEC_CORR);
+        case MK_CORR: return GRP_W(MK_CORR);
+        case MK_PD: return GRP_W(MK_PD);
+        default: return GRP_W(MK_PD_VEC);
+      }
+#undef GRP_W
+    }
+  }
 #define GRP_K(KIND_) (K <= 12 ? grp_launch<T, 16, 12, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch) \
                     : K <= 16 ? grp_launch<T, 16, 16, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch) \
                     : K <= 24 ? grp_launch<T, 32, 24, KIND_>(ctx, inverse, in, out_bar, ladj_bar, in_bar, K, batch) \
@@ -384,7 +399,7 @@ namespace bjx {
 int bjx_matrix_vjp_grp(bjx_ctx* ctx, bjx_dtype dt, int kind, int inverse, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K, int64_t batch) {
   static const int use_grp = getenv("BJX_MATRIX_VJP_GRP") ? atoi(getenv("BJX_MATRIX_VJP_GRP")) : 1;      // 0: the one-lane-per-sample workspace kernel (its A/B)
   // K = 9 ... 12 too: same call, 2^19 samples, K = 12: 24-48 % of the HBM peak here against 19-27 % for the twelve-row register kernel
-  if (!use_grp || K < 9 || K > 32) return 1;
+  if (!use_grp || K < 9 || K > 64 || (K > 32 && dt != BJX_F32)) return 1;
   if (dt == BJX_F32) return grp_kind<float>(ctx, kind, inverse, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, K, batch);
   return grp_kind<double>(ctx, kind, inverse, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, K, batch);
 }

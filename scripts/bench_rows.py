@@ -199,7 +199,7 @@ def main():
             rows.append((f"inverse({nm}) K={Km} (y → X = U'U)", "f-4", (lambda b_=bm, y_=ym: bj.shard.with_logabsdet_jacobian_sharded(bj.inverse(b_), y_)), bpsm, Nm))
     # §8(f) f-1 x f-4: pullbacks of the matrix bijectors (bjx_*_vjp).  Algorithmic bytes: primal input + output cotangent read, input
     # cotangent written, + the log-det cotangent
-    for Km, lbm in ((3, 22), (4, 22), (8, 20), (12, 19), (16, 18), (24, 16), (32, 16)):
+    for Km, lbm in ((3, 22), (4, 22), (8, 20), (12, 19), (16, 18), (24, 16), (32, 16), (48, 14), (64, 14)):
         Nm = 1 << min(a.log2_batch, lbm)
         for nm, cls in (("VecCorrBijector", bj.VecCorrBijector), ("PDVecBijector", bj.PDVecBijector)):
             bm = cls()
