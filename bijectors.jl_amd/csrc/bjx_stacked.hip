@@ -799,8 +799,10 @@ template <class T> __device__ __forceinline__ void slot_grad(const Slot<T>& s, T
 template <class T, int V, bool GATHER, bool IN_LDS, bool MOM = false, bool UNAL = false>
 __global__ __launch_bounds__(256) void stacked_vjp_kernel(const char* __restrict__ tab_g, int two_slots, const T* __restrict__ x, const T* __restrict__ ybar,
                                                           const T* __restrict__ lbar, T* __restrict__ xbar, int64_t dim, int64_t batch, int G,
-                                                          double* __restrict__ mpart = nullptr, int mom_off = 0) {
+                                                          double* __restrict__ mpart = nullptr, int mom_off = 0, int64_t ld = 0) {
+  // ld: elements between the starts of consecutive columns when x / ȳ / x̄ point at a ROW WINDOW of taller columns (0: dense, = dim)
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t cs = ld ? ld : dim;
   T ms1[V], ms2[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) { ms1[j] = T(0); ms2[j] = T(0); }
@@ -821,9 +823,9 @@ __global__ __launch_bounds__(256) void stacked_vjp_kernel(const char* __restrict
     const int64_t col = ((int64_t)blockIdx.x * COL_UC + uc) * cols_per_block + threadIdx.x / G;
     if (col >= batch) continue;
     const T lb = lbar ? lbar[col] : T(0);
-    const T* xc = x + col * dim;
-    const T* gc = ybar + col * dim;
-    T* oc = xbar + col * dim;
+    const T* xc = x + col * cs;
+    const T* gc = ybar + col * cs;
+    T* oc = xbar + col * cs;
     for (int64_t v = gl; v < nun; v += G) {
       const bool is_tail = UNAL && v == nvc;
       const int64_t prow = is_tail ? dim - V : v * V;
@@ -994,12 +996,58 @@ __global__ __launch_bounds__(256) void stacked_vjp_tiny_kernel(const char* __res
 
 template <class T>
 int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, const T* ybar, const T* lbar, T* xbar, int64_t dim, int64_t batch,
-                     double* moments = nullptr, bool* moments_done = nullptr) {
+                     double* moments = nullptr, bool* moments_done = nullptr, int64_t ld = 0) {
+  // ld != 0: `dim` rows of columns that are ld apart (a row slab of the loop below)
   if (moments_done) *moments_done = false;
   if (dim * batch == 0) return BJX_OK;
   {
+    // Columns of more than 64 packs: ROW SLABS, like the forward map (stacked_impl) — one launch per 64 packs on a window of the same
+    // arrays with the segments and their per-row parameters clipped to it.  One pack per lane is the form that keeps four columns in
+    // flight; beyond it a lane walked its column one memory round trip per pack (the chain pullback at 509 / 1 001 rows: 25 / 19 % of
+    // the HBM peak).  The pullback is elementwise: the slabs are independent, nothing accumulates.
+    static const int slab_env = getenv("BJX_STACKED_SLAB") ? atoi(getenv("BJX_STACKED_SLAB")) : -1;
+    const int slab = slab_env >= 0 ? slab_env : 64 * Vec16<T>::N;
+    if (slab >= 16 && ld == 0 && !moments && dim > slab && n_segs > 0) {
+      bool keep = true;
+      int64_t total = 0;
+      for (int s = 0; s < n_segs && keep; ++s) {
+        const bjx_segment& g = segs[s];
+        keep = g.in_lo == g.out_lo && g.len >= 0 && g.in_lo >= 0 && g.in_lo + g.len <= dim && g.n_ops >= 0 && g.n_ops <= BJX_MAX_SEG_OPS;
+        for (int k = 0; keep && k < g.n_ops; ++k) keep = g.ops[k].param_len == 0 || g.ops[k].param_len == 1 || g.ops[k].param_len == g.len;
+        total += g.len;
+      }
+      if (keep && total == dim) {
+        std::vector<bjx_segment> clip;
+        for (int64_t r0 = 0, rs = 0; r0 < dim; r0 += rs) {
+          rs = dim - r0 < slab ? dim - r0 : slab;
+          clip.clear();
+          for (int s = 0; s < n_segs; ++s) {
+            const bjx_segment& g = segs[s];
+            const int64_t lo = g.in_lo > r0 ? g.in_lo : r0, hi = g.in_lo + g.len < r0 + rs ? g.in_lo + g.len : r0 + rs;
+            if (hi <= lo) continue;
+            bjx_segment c = g;
+            c.in_lo = c.out_lo = lo - r0;
+            c.len = hi - lo;
+            for (int k = 0; k < g.n_ops; ++k) {
+              if (g.ops[k].param_len > 1) {
+                const size_t off = (size_t)(lo - g.in_lo) * sizeof(T);
+                if (c.ops[k].v0) c.ops[k].v0 = static_cast<const char*>(g.ops[k].v0) + off;
+                if (c.ops[k].v1) c.ops[k].v1 = static_cast<const char*>(g.ops[k].v1) + off;
+                c.ops[k].param_len = (int32_t)(hi - lo);
+              }
+            }
+            clip.push_back(c);
+          }
+          const int rc = stacked_vjp_impl<T>(ctx, clip.data(), (int)clip.size(), x + r0, ybar + r0, lbar, xbar + r0, rs, batch, nullptr, nullptr, dim);
+          if (rc) return rc;
+        }
+        return BJX_OK;
+      }
+    }
+  }
+  {
     static const int use_tiny = getenv("BJX_STACKED_TINY") ? atoi(getenv("BJX_STACKED_TINY")) : 1;
-    if (use_tiny && !moments && dim <= 7 && dim % Vec16<T>::N != 0) {     // same-box A/B: 61-78 % against 28-51 % at 2-5 rows, level from 7
+    if (use_tiny && !moments && ld == 0 && dim <= 7 && dim % Vec16<T>::N != 0) {     // same-box A/B: 61-78 % against 28-51 % at 2-5 rows, level from 7
       StackedPlan plt;
       { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, xbar, dim, batch, false, false, &plt); if (rc) return rc; }   // V = 1: unpermuted table
       const int64_t grid_t = (batch + 255) / 256;
@@ -1026,10 +1074,11 @@ int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T*
     if constexpr (Vec16<T>::N > 1) {
       bool in_place_rows = true;
       for (int sgi = 0; sgi < n_segs; ++sgi) in_place_rows = in_place_rows && segs[sgi].in_lo == segs[sgi].out_lo;
-      if (use_unal_vjp && !moments && in_place_rows && dim % Vec16<T>::N != 0 && col_launch_cfg<T>(ctx, x, xbar, dim, batch, 0, 0, true).unal) {
+      // (a slab of columns whose pitch is not a whole number of packs is element-aligned whatever its own height is)
+      if (use_unal_vjp && !moments && in_place_rows && (dim % Vec16<T>::N != 0 || ld % Vec16<T>::N != 0) && col_launch_cfg<T>(ctx, x, xbar, dim, batch, ld, ld, true).unal) {
         constexpr int VWu = Vec16<T>::N;
         StackedPlan plu;
-        { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, xbar, dim, batch, false, true, &plu, 0, 0, true); if (rc) return rc; }
+        { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, xbar, dim, batch, false, true, &plu, ld, ld, true); if (rc) return rc; }
         if (plu.V == VWu && !plu.gather) {
           const bool ldsu = plu.tab_bytes <= 48 * 1024;
           const size_t smemu = ldsu ? plu.tab_bytes : 0;
@@ -1041,8 +1090,8 @@ int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T*
           BJX_REQUIRE(ctx, gridu < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_stacked_vjp: batch too large for one launch");
           {
             BjxProf prof_(ctx);
-            if (ldsu) hipLaunchKernelGGL((stacked_vjp_kernel<T, VWu, false, true, false, true>), dim3((unsigned)gridu), dim3(256), smemu, ctx->stream, plu.tab, plu.two, x, ybar, lbar, xbar, dim, batch, Gu);
-            else hipLaunchKernelGGL((stacked_vjp_kernel<T, VWu, false, false, false, true>), dim3((unsigned)gridu), dim3(256), smemu, ctx->stream, plu.tab, plu.two, x, ybar, lbar, xbar, dim, batch, Gu);
+            if (ldsu) hipLaunchKernelGGL((stacked_vjp_kernel<T, VWu, false, true, false, true>), dim3((unsigned)gridu), dim3(256), smemu, ctx->stream, plu.tab, plu.two, x, ybar, lbar, xbar, dim, batch, Gu, (double*)nullptr, 0, ld);
+            else hipLaunchKernelGGL((stacked_vjp_kernel<T, VWu, false, false, false, true>), dim3((unsigned)gridu), dim3(256), smemu, ctx->stream, plu.tab, plu.two, x, ybar, lbar, xbar, dim, batch, Gu, (double*)nullptr, 0, ld);
           }
           BJX_CHECK_LAUNCH(ctx);
           return BJX_OK;
@@ -1052,7 +1101,7 @@ int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T*
     static const int use_walker = getenv("BJX_STACKED_WALKER") ? atoi(getenv("BJX_STACKED_WALKER")) : 1;
     const int64_t P = dim | 1;
     const size_t smem_w = (size_t)2 * 64 * P * sizeof(T);
-    if (use_walker && !moments && dim % Vec16<T>::N != 0 && smem_w <= 64 * 1024 && (const void*)x != (const void*)xbar) {
+    if (use_walker && !moments && ld == 0 && dim % Vec16<T>::N != 0 && smem_w <= 64 * 1024 && (const void*)x != (const void*)xbar) {
       StackedPlan plw;
       { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, xbar, dim, batch, false, false, &plw); if (rc) return rc; }   // V = 1: unpermuted table
       const int64_t grid_w = (batch + 63) / 64;
@@ -1068,7 +1117,7 @@ int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T*
     }
   }
   StackedPlan pl;
-  { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, xbar, dim, batch, false, bjx_aligned16(ybar), &pl); if (rc) return rc; }
+  { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, xbar, dim, batch, false, bjx_aligned16(ybar), &pl, ld, ld); if (rc) return rc; }
   const bool lds = pl.tab_bytes <= 48 * 1024;
   const size_t smem = lds ? pl.tab_bytes : 0;
   const int64_t packs = dim / pl.V;
@@ -1107,7 +1156,7 @@ int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T*
       return BJX_OK;
     }
   }
-#define SVJP(V_, G_, L_) hipLaunchKernelGGL((stacked_vjp_kernel<T, V_, G_, L_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, pl.tab, pl.two, x, ybar, lbar, xbar, dim, batch, G)
+#define SVJP(V_, G_, L_) hipLaunchKernelGGL((stacked_vjp_kernel<T, V_, G_, L_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, pl.tab, pl.two, x, ybar, lbar, xbar, dim, batch, G, (double*)nullptr, 0, ld)
 #define SVJP_V(V_) do { if (pl.gather) { if (lds) SVJP(V_, true, true); else SVJP(V_, true, false); } else { if (lds) SVJP(V_, false, true); else SVJP(V_, false, false); } } while (0)
   {
     BjxProf prof_(ctx);
