@@ -323,7 +323,7 @@ struct StackedPlan { char* tab; size_t tab_bytes; bool gather; int two; int V; }
 // shorter matrix and every row is gathered), `ldy` = rows of the output matrix (>= dim)
 template <class T>
 int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const void* x, const void* y, int64_t dim, int64_t batch, bool inplace_check,
-                    bool packs_ok, StackedPlan* plan, int64_t ldx = 0, int64_t ldy = 0, bool allow_unal = false) {
+                    bool packs_ok, StackedPlan* plan, int64_t ldx = 0, int64_t ldy = 0, bool allow_unal = false, int unal_from = 0) {
   if (ldx == 0) ldx = dim;
   if (ldy == 0) ldy = dim;
   // validate on the host: every output row and every input row exactly once (stacked.jl:156-165 checks the lengths)
@@ -409,7 +409,7 @@ int stacked_prepare(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const voi
     BJX_HIP(ctx, hipEventRecord(ctx->stage_ev, ctx->stream));
   }
   // the main kernel's pack width decides the row permutation of the table (same rule as col_launch_cfg)
-  ColLaunch cl = col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy, allow_unal);
+  ColLaunch cl = col_launch_cfg<T>(ctx, x, y, dim, batch, ldx, ldy, allow_unal, unal_from);
   if (!packs_ok) cl.V = 1;                               // a third buffer of the caller is not 16-byte aligned
   hipLaunchKernelGGL(stacked_table_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, dseg, n_segs, dim, cl.V, tab, flag);
   BJX_CHECK_LAUNCH(ctx);
@@ -1069,16 +1069,19 @@ int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T*
 #undef BJX_SVT
       if (launched) { BJX_CHECK_LAUNCH(ctx); return BJX_OK; }
     }
-    // odd heights from 80 rows (BJX_COL_UNALIGNED_MIN), rows in place: the group kernel on element-aligned packs (UNAL)
+    // odd heights, rows in place: the group kernel on element-aligned packs (UNAL)
     static const int use_unal_vjp = getenv("BJX_STACKED_VJP_UNALIGNED") ? atoi(getenv("BJX_STACKED_VJP_UNALIGNED")) : 1;
+    // from 24 rows (the forward maps switch at 80): same call, 2^22 columns, walker / group kernel — 17 rows 60 / 48 %, 21 rows 56 / 56,
+    // 25 rows 53 / 62, 29 rows 49 / 64, 45 rows 37 / 59, 61 rows 29 / 65, 77 rows 24 / 52 % of the HBM peak
+    constexpr int vjp_unal_from = 24;
     if constexpr (Vec16<T>::N > 1) {
       bool in_place_rows = true;
       for (int sgi = 0; sgi < n_segs; ++sgi) in_place_rows = in_place_rows && segs[sgi].in_lo == segs[sgi].out_lo;
       // (a slab of columns whose pitch is not a whole number of packs is element-aligned whatever its own height is)
-      if (use_unal_vjp && !moments && in_place_rows && (dim % Vec16<T>::N != 0 || ld % Vec16<T>::N != 0) && col_launch_cfg<T>(ctx, x, xbar, dim, batch, ld, ld, true).unal) {
+      if (use_unal_vjp && !moments && in_place_rows && (dim % Vec16<T>::N != 0 || ld % Vec16<T>::N != 0) && col_launch_cfg<T>(ctx, x, xbar, dim, batch, ld, ld, true, vjp_unal_from).unal) {
         constexpr int VWu = Vec16<T>::N;
         StackedPlan plu;
-        { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, xbar, dim, batch, false, true, &plu, ld, ld, true); if (rc) return rc; }
+        { int rc = stacked_prepare<T>(ctx, segs, n_segs, x, xbar, dim, batch, false, true, &plu, ld, ld, true, vjp_unal_from); if (rc) return rc; }
         if (plu.V == VWu && !plu.gather) {
           const bool ldsu = plu.tab_bytes <= 48 * 1024;
           const size_t smemu = ldsu ? plu.tab_bytes : 0;

@@ -485,7 +485,7 @@ struct ColLaunch {
 
 // choose pack width / lanes per column / grid for a [dim, batch] problem
 template <class T> inline ColLaunch col_launch_cfg(const bjx_ctx* ctx, const void* x, const void* y, int64_t dim, int64_t batch, int64_t ldx = 0,
-                                                   int64_t ldy = 0, bool allow_unal = false) {
+                                                   int64_t ldy = 0, bool allow_unal = false, int unal_from = 0) {
   ColLaunch c;
   constexpr int VW = Vec16<T>::N;
   const bool v_ok = bjx_aligned16(x) && bjx_aligned16(y) && dim % VW == 0 && ldx % VW == 0 && ldy % VW == 0;
@@ -497,7 +497,7 @@ template <class T> inline ColLaunch col_launch_cfg(const bjx_ctx* ctx, const voi
   // walker still wins, 58 / 54 and 54 / 49 against 56 / 46 and 40 / 42; at 77 rows it is 43 / 46 against 50 / 50): 16-byte packs on element-aligned addresses, the dim % V tail rows on one lane each.
   // Callers that build V-permuted tables must ask with the same flag.
   static const int use_unal = getenv("BJX_COL_UNALIGNED") ? atoi(getenv("BJX_COL_UNALIGNED")) : 1;
-  static const int unal_min = 80;
+  const int unal_min = unal_from > 0 ? unal_from : 80;      // (the pullback of chains asks from fewer rows: see stacked_vjp_impl)
   const bool window = ldx > dim && ldy > dim;             // a row window of taller arrays (slabs): no tile walker to fall back on
   if (allow_unal && use_unal && !v_ok && dim >= (window ? 2 * VW : unal_min) && dim >= VW) {
     c.V = VW;

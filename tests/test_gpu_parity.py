@@ -961,10 +961,11 @@ def test_stacked_and_chain_vjp(bj, orc, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("dim", [81, 101, 201, 255, 333, 1001])
+@pytest.mark.parametrize("dim", [81, 101, 201, 255, 333, 1001, 512, 1000, 2049])
 def test_stacked_and_chain_vjp_odd_heights(bj, orc, dt, dim):
     """Pullback of chains / `Stacked` at heights that are not whole 16-byte packs, from 80 rows: the group kernel on element-aligned
-    packs with the tail rows as an overlapping last pack (`stacked_vjp_kernel<..., UNAL>`); cotangent buffer aliased by the result too."""
+    packs with the tail rows as an overlapping last pack (`stacked_vjp_kernel<..., UNAL>`); cotangent buffer aliased by the result too.
+    Past 64 packs per column (round 4): row slabs — windows of the same arrays, segments and per-row parameters clipped per slab."""
     r = rng(57)
     N = 70
     lbar = r.normal(size=N).astype(dt)
