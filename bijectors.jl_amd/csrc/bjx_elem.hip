@@ -1368,7 +1368,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 // sets each, every thread with four independent accumulator pairs (8 loads in flight), combined through LDS in a
 // fixed order.  (One thread per row walking all sets — 2048 dependent-latency loads — took 250 µs next to a 365 µs
 // streaming pass; launch with grid = ceil(dim / 64), 256 threads.)
-__global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const double* __restrict__ partial, int nblocks, int64_t dim, int64_t batch, double* __restrict__ stats) {
+__global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const double* __restrict__ partial, int nblocks, int64_t dim, int64_t batch, double* __restrict__ stats,
+                                                              double* __restrict__ stats2 = nullptr, double* __restrict__ statn = nullptr) {
+  // stats2 / statn: where the second sums and the count go when `dim` rows are a WINDOW of a taller problem (default: stats + dim, stats + 2 dim)
+  if (!stats2) stats2 = stats + dim;
+  if (!statn) statn = stats + 2 * dim;
   __shared__ double red[2][4][64];
   const int rl = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t r = (int64_t)blockIdx.x * 64 + rl;
@@ -1388,9 +1392,9 @@ __global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const double* __re
   __syncthreads();
   if (q == 0 && r < dim) {
     stats[r] = (red[0][0][rl] + red[0][1][rl]) + (red[0][2][rl] + red[0][3][rl]);
-    stats[dim + r] = (red[1][0][rl] + red[1][1][rl]) + (red[1][2][rl] + red[1][3][rl]);
+    stats2[r] = (red[1][0][rl] + red[1][1][rl]) + (red[1][2][rl] + red[1][3][rl]);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) stats[2 * dim] = (double)batch;
+  if (blockIdx.x == 0 && threadIdx.x == 0) statn[0] = (double)batch;
 }
 
 // ------------------------------------------------------------------ row moments over the batch (parameter pullbacks of per-row affine stages)
@@ -1400,7 +1404,8 @@ __global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const double* __re
 // Same streaming shape as bn_stats_kernel (lanes along the rows, Float64 accumulators, LDS combine, one partial per block).
 template <class T, int V, int R>
 __global__ __launch_bounds__(256) void row_moments_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t dim, int64_t batch, int G,
-                                                          double* __restrict__ partial) {
+                                                          double* __restrict__ partial, int64_t ld) {
+  // dim rows of columns that are ld elements apart (a and b point at the first row of the window)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* red = reinterpret_cast<double*>(smem);
   const int gl = threadIdx.x & (G - 1), cg = threadIdx.x / G;
@@ -1421,7 +1426,7 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const T* __restrict__ 
       for (int k = 0; k < R; ++k) {
         const int64_t c = col + u * stride;
         const bool ok = c < batch && gl + k * G < nvc;
-        if (ok) { pa[u][k] = load_pack<T, V, false>(a + c * dim + (int64_t)(gl + k * G) * V); pb[u][k] = b ? load_pack<T, V, false>(b + c * dim + (int64_t)(gl + k * G) * V) : pa[u][k]; }
+        if (ok) { pa[u][k] = load_pack<T, V, false>(a + c * ld + (int64_t)(gl + k * G) * V); pb[u][k] = b ? load_pack<T, V, false>(b + c * ld + (int64_t)(gl + k * G) * V) : pa[u][k]; }
         else {
 #pragma unroll
           for (int j = 0; j < V; ++j) { pa[u][k].v[j] = T(0); pb[u][k].v[j] = T(0); }
@@ -1456,34 +1461,48 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const T* __restrict__ 
   }
 }
 
-template <class T>
-int row_moments_impl(bjx_ctx* ctx, const T* a, const T* b, double* out, int64_t dim, int64_t batch) {
-  if (dim == 0) return BJX_OK;
-  if (batch == 0) { BJX_HIP(ctx, hipMemsetAsync(out, 0, (size_t)(2 * dim + 1) * sizeof(double), ctx->stream)); return BJX_OK; }
-  ColLaunch c = col_launch_cfg<T>(ctx, a, b ? (const void*)b : (const void*)a, dim, batch);
-  const int64_t nvc = dim / c.V;
-  BJX_REQUIRE(ctx, nvc <= 4 * (int64_t)c.G, BJX_ERR_UNSUPPORTED, "bjx_row_moments: %lld rows exceed the register-accumulator kernel", (long long)dim);
-  const int R = nvc <= c.G ? 1 : (nvc <= 2 * c.G ? 2 : 4);
-  const int cols_per_block = 256 / c.G;
+// One window of rows [r0, r0 + rs) with V-element packs (element-aligned addresses are fine: the packs are plain 16-byte loads).
+template <class T, int V>
+int row_moments_window(bjx_ctx* ctx, const T* a, const T* b, double* out, int64_t dim, int64_t batch, int64_t r0, int64_t rs) {
+  const int64_t nvc = rs / V;                                    // rs is a multiple of V here
+  int G = 1;
+  while (G < 64 && G < nvc) G <<= 1;
+  const int R = nvc <= G ? 1 : (nvc <= 2 * (int64_t)G ? 2 : 4);
+  const int cols_per_block = 256 / G;
   int nblocks = (int)((batch + (int64_t)cols_per_block * 16 - 1) / ((int64_t)cols_per_block * 16));
   if (nblocks > 1024) nblocks = 1024;
   if (nblocks < 1) nblocks = 1;
-  { int rc = bjx_ensure_partials(ctx, (size_t)nblocks * dim * 2); if (rc) return rc; }
-  const size_t smem = (size_t)cols_per_block * dim * 2 * sizeof(double);
+  { int rc = bjx_ensure_partials(ctx, (size_t)nblocks * rs * 2); if (rc) return rc; }
+  const size_t smem = (size_t)cols_per_block * rs * 2 * sizeof(double);
   BJX_REQUIRE(ctx, smem <= BJX_LDS_MAX, BJX_ERR_UNSUPPORTED, "bjx_row_moments: LDS");
-  constexpr int VW = Vec16<T>::N;
   {
     BjxProf prof_(ctx);
-#define RM(V_, R_) do { bjx_allow_big_lds(row_moments_kernel<T, V_, R_>, smem); hipLaunchKernelGGL((row_moments_kernel<T, V_, R_>), dim3(nblocks), dim3(256), smem, ctx->stream, a, b, dim, batch, c.G, ctx->partials); } while (0)
-#define RM_V(V_) do { if (R == 1) RM(V_, 1); else if (R == 2) RM(V_, 2); else RM(V_, 4); } while (0)
-    if (c.V == VW) RM_V(VW); else RM_V(1);
-#undef RM_V
+#define RM(R_) do { bjx_allow_big_lds(row_moments_kernel<T, V, R_>, smem); hipLaunchKernelGGL((row_moments_kernel<T, V, R_>), dim3(nblocks), dim3(256), smem, ctx->stream, a + r0, b ? b + r0 : nullptr, rs, batch, G, ctx->partials, dim); } while (0)
+    if (R == 1) RM(1); else if (R == 2) RM(2); else RM(4);
 #undef RM
   }
   BJX_CHECK_LAUNCH(ctx);
   { BjxProf prof_(ctx);
-  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)((dim + 63) / 64)), dim3(256), 0, ctx->stream, ctx->partials, nblocks, dim, batch, out); }
+  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)((rs + 63) / 64)), dim3(256), 0, ctx->stream, ctx->partials, nblocks, rs, batch, out + r0, out + dim + r0, out + 2 * dim); }
   BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+
+template <class T>
+int row_moments_impl(bjx_ctx* ctx, const T* a, const T* b, double* out, int64_t dim, int64_t batch) {
+  if (dim == 0) return BJX_OK;
+  if (batch == 0) { BJX_HIP(ctx, hipMemsetAsync(out, 0, (size_t)(2 * dim + 1) * sizeof(double), ctx->stream)); return BJX_OK; }
+  // Any number of rows (round 4; the register accumulators hold 256 packs per column, and columns that were not whole aligned packs
+  // fell to one-element packs: 256 rows — a mean-field family of 333 parameters was refused): windows of 64 packs of 16 bytes on
+  // element-aligned addresses, the dim mod V rows that are left as a last window of one-element packs.
+  constexpr int VW = Vec16<T>::N;
+  const int64_t whole = dim / VW * VW;
+  const int64_t win = (int64_t)64 * VW;      // one pack per lane: four columns in flight (windows of 256 packs ran 1 001 rows at a fifth of the rate)
+  for (int64_t r0 = 0; r0 < whole; r0 += win) {
+    const int rc = row_moments_window<T, VW>(ctx, a, b, out, dim, batch, r0, whole - r0 < win ? whole - r0 : win);
+    if (rc) return rc;
+  }
+  if (whole < dim) { const int rc = row_moments_window<T, 1>(ctx, a, b, out, dim, batch, whole, dim - whole); if (rc) return rc; }
   return BJX_OK;
 }
 
@@ -1659,7 +1678,7 @@ int bn_stats_impl(bjx_ctx* ctx, const T* shift, const T* in, double* stats, doub
   }
   BJX_CHECK_LAUNCH(ctx);
   { BjxProf prof_(ctx);
-  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)((dim + 63) / 64)), dim3(256), 0, ctx->stream, partial, nblocks, dim, batch, stats); }
+  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)((dim + 63) / 64)), dim3(256), 0, ctx->stream, partial, nblocks, dim, batch, stats, (double*)nullptr, (double*)nullptr); }
   BJX_CHECK_LAUNCH(ctx);
   return BJX_OK;
 }

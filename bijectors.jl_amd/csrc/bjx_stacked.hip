@@ -1000,6 +1000,15 @@ int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T*
   // ld != 0: `dim` rows of columns that are ld apart (a row slab of the loop below)
   if (moments_done) *moments_done = false;
   if (dim * batch == 0) return BJX_OK;
+  if (moments) {
+    // The row moments ride along only in the one-pack-per-lane form on whole aligned packs (below).  Every other shape — odd heights,
+    // more than 64 packs per column — takes the best plain pullback (element-aligned packs, row slabs) and leaves the moments to the
+    // caller's second pass (bjx_row_moments): asked WITH moments those shapes used to fall to the column loop (the mean-field
+    // parameter pullback at 1 001 rows: 15.6 ms, of which 2.9 for the pullback proper and 1.7 for the moments).
+    constexpr int VWm = Vec16<T>::N;
+    const bool fusable = dim % VWm == 0 && dim / VWm <= 64 && bjx_aligned16(x) && bjx_aligned16(ybar) && bjx_aligned16(xbar);
+    if (!fusable) return stacked_vjp_impl<T>(ctx, segs, n_segs, x, ybar, lbar, xbar, dim, batch, nullptr, nullptr, ld);
+  }
   {
     // Columns of more than 64 packs: ROW SLABS, like the forward map (stacked_impl) — one launch per 64 packs on a window of the same
     // arrays with the segments and their per-row parameters clipped to it.  One pack per lane is the form that keeps four columns in

@@ -477,7 +477,8 @@ int bjx_stacked_vjp(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_s
 /* bjx_stacked_vjp plus the row moments of its result in the same pass: moments[i] = sum_n x_bar[i,n],
  * moments[dim+i] = sum_n x_bar[i,n]*x[i,n], moments[2 dim] = batch (the layout of bjx_row_moments, device double[2*dim+1]):
  * the parameter cotangents of a leading per-row Shift(mu) / Scale(sigma) stage (mean-field ADVI) without reading x_bar and
- * x a second time.  Shapes the fused kernel does not take (gathered rows, > 64 packs per column) run bjx_row_moments. */
+ * x a second time.  Shapes the fused kernel does not take (gathered rows, heights that are not whole aligned packs, > 64 packs per
+ * column) run the plain pullback (row slabs on tall columns) and then bjx_row_moments, which takes any number of rows. */
 int bjx_stacked_vjp_moments(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, const void* x,
                             const void* y_bar, const void* ladj_bar, void* x_bar, double* moments,
                             int64_t dim, int64_t batch);

@@ -1667,7 +1667,9 @@ def test_permute_and_columnwise_vjp(bj, orc):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("dim,N", [(64, 3000), (5, 257), (130, 64), (300, 40), (64, 70001), (256, 999), (1, 50), (2, 1)])
+@pytest.mark.parametrize("dim,N", [(64, 3000), (5, 257), (130, 64), (300, 40), (64, 70001), (256, 999), (1, 50), (2, 1),
+                                   # round 4: any number of parameters (row windows; 333 rows used to be refused: NotImplementedError)
+                                   (333, 70), (1001, 33), (1024, 40), (1500, 21), (2051, 9)])
 def test_mean_field_parameter_pullback(bj, orc, dim, N, dt):
     """y = exp(μ + σ ⊙ z): (μ̄, σ̄) from two row reductions of the input cotangent (bjx_row_moments); reference: the
     closed form in Float64 and finite differences of the chain oracle with respect to μ and σ."""
