@@ -796,7 +796,12 @@ template <class T> __device__ __forceinline__ void slot_grad(const Slot<T>& s, T
 // before them), every element looking up its own place in the row-permuted table; the pullback is elementwise, so the overlap is
 // simply recomputed and only the tail rows are stored.  The tile walker these heights used ran the chain pullback at 18 / 32 % of the
 // HBM peak at 101 / 201 rows (70 % at 100 rows on this kernel).
-template <class T, int V, bool GATHER, bool IN_LDS, bool MOM = false, bool UNAL = false>
+// SLAB (round 4): columns of more than G units in ONE launch — blockIdx.y picks a slab of G units, the block stages only that slab's
+// part of the row-permuted table (V runs of G entries -> [V][G] in LDS; the whole table of a tall column does not fit) and every
+// lane owns one unit.  The pullback is elementwise: slabs need nothing from each other, so they are blocks of one grid instead of the
+// launches of a host loop (which is what the forward maps use, because their log-dets accumulate in launch order) — at 16 columns of
+// 5 000 rows the host loop was 20 launch / table-build pairs, 375 µs a call.
+template <class T, int V, bool GATHER, bool IN_LDS, bool MOM = false, bool UNAL = false, bool SLAB = false>
 __global__ __launch_bounds__(256) void stacked_vjp_kernel(const char* __restrict__ tab_g, int two_slots, const T* __restrict__ x, const T* __restrict__ ybar,
                                                           const T* __restrict__ lbar, T* __restrict__ xbar, int64_t dim, int64_t batch, int G,
                                                           double* __restrict__ mpart = nullptr, int mom_off = 0, int64_t ld = 0) {
@@ -806,27 +811,49 @@ __global__ __launch_bounds__(256) void stacked_vjp_kernel(const char* __restrict
   T ms1[V], ms2[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) { ms1[j] = T(0); ms2[j] = T(0); }
-  if (IN_LDS) {
+  const int64_t nvc = dim / V;
+  // SLAB: `mom_off` carries the number of slabs; the slab index runs FASTEST over the grid (neighbouring blocks work on the same columns)
+  const int64_t v0 = SLAB ? (int64_t)(blockIdx.x % (unsigned)mom_off) * G : 0;          // first unit of my slab
+  const int64_t cblk = SLAB ? blockIdx.x / (unsigned)mom_off : blockIdx.x;               // my block of columns
+  if (IN_LDS && !SLAB) {
     const int n16 = (int)(dim * stacked_row_bytes<T>() / 16);
     const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(tab_g);
     bjx_f32x4* dst = reinterpret_cast<bjx_f32x4*>(smem);
     for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
   }
+  if (IN_LDS && SLAB) {
+    constexpr int RB16 = (int)(stacked_row_bytes<T>() / 16);
+    const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(tab_g);
+    bjx_f32x4* dst = reinterpret_cast<bjx_f32x4*>(smem);
+    for (int i = threadIdx.x; i < V * G * RB16; i += blockDim.x) {
+      const int q = i % RB16, en = i / RB16, vv = en & (G - 1), j = en / G;
+      if (v0 + vv < nvc) dst[i] = src[((int64_t)j * nvc + v0 + vv) * RB16 + q];
+    }
+    if (UNAL && v0 <= nvc && nvc < v0 + G) {
+      // the tail unit lives in this slab: its V rows (the last V of the column; they overlap the pack before it, which may belong to
+      // the previous slab) behind the slab's entries — every slot read of this kernel stays an LDS read (a pointer chosen between
+      // the global table and LDS compiles to flat loads: 56 -> 40 % of the HBM peak at 1 001 rows)
+      for (int i = threadIdx.x; i < V * RB16; i += blockDim.x) {
+        const int q = i % RB16, j = i / RB16;
+        dst[V * G * RB16 + i] = src[stacked_row_index(dim - V + j, V, nvc) * RB16 + q];
+      }
+    }
+    __syncthreads();
+  }
   const char* t = IN_LDS ? smem : tab_g;
   const int gl = threadIdx.x & (G - 1);
   const int cols_per_block = blockDim.x / G;
-  const int64_t nvc = dim / V;
   const int tail = UNAL ? (int)(dim - nvc * V) : 0;
   const int64_t nun = nvc + (tail ? 1 : 0);           // units of a column: the whole packs and (UNAL) the tail
   for (int uc = 0; uc < COL_UC; ++uc) {
-    const int64_t col = ((int64_t)blockIdx.x * COL_UC + uc) * cols_per_block + threadIdx.x / G;
+    const int64_t col = (cblk * COL_UC + uc) * cols_per_block + threadIdx.x / G;
     if (col >= batch) continue;
     const T lb = lbar ? lbar[col] : T(0);
     const T* xc = x + col * cs;
     const T* gc = ybar + col * cs;
     T* oc = xbar + col * cs;
-    for (int64_t v = gl; v < nun; v += G) {
+    for (int64_t v = v0 + gl; v < (SLAB && v0 + G < nun ? v0 + G : nun); v += G) {
       const bool is_tail = UNAL && v == nvc;
       const int64_t prow = is_tail ? dim - V : v * V;
       Pack<T, V> px, pg;
@@ -835,7 +862,9 @@ __global__ __launch_bounds__(256) void stacked_vjp_kernel(const char* __restrict
       const Pack<T, V> pin = px;                      // the inputs (px is overwritten by the results row by row)
 #pragma unroll 1
       for (int j = 0; j < V; ++j) {
-        const Slot<T>* e = reinterpret_cast<const Slot<T>*>(t + (is_tail ? stacked_row_index(prow + j, V, nvc) : (V > 1 ? j * nvc + v : v)) * stacked_row_bytes<T>());
+                const Slot<T>* e = (SLAB && IN_LDS)
+            ? reinterpret_cast<const Slot<T>*>(t + (size_t)(is_tail ? V * G + j : j * G + gl) * stacked_row_bytes<T>())
+            : reinterpret_cast<const Slot<T>*>(t + (is_tail ? stacked_row_index(prow + j, V, nvc) : (V > 1 ? j * nvc + v : v)) * stacked_row_bytes<T>());
         const Slot<T> s0 = e[0];
         T xv = px.v[0], gv = pg.v[0];
         if (V > 1) {
@@ -1010,51 +1039,6 @@ int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T*
     if (!fusable) return stacked_vjp_impl<T>(ctx, segs, n_segs, x, ybar, lbar, xbar, dim, batch, nullptr, nullptr, ld);
   }
   {
-    // Columns of more than 64 packs: ROW SLABS, like the forward map (stacked_impl) — one launch per 64 packs on a window of the same
-    // arrays with the segments and their per-row parameters clipped to it.  One pack per lane is the form that keeps four columns in
-    // flight; beyond it a lane walked its column one memory round trip per pack (the chain pullback at 509 / 1 001 rows: 25 / 19 % of
-    // the HBM peak).  The pullback is elementwise: the slabs are independent, nothing accumulates.
-    static const int slab_env = getenv("BJX_STACKED_SLAB") ? atoi(getenv("BJX_STACKED_SLAB")) : -1;
-    const int slab = slab_env >= 0 ? slab_env : 64 * Vec16<T>::N;
-    if (slab >= 16 && ld == 0 && !moments && dim > slab && n_segs > 0) {
-      bool keep = true;
-      int64_t total = 0;
-      for (int s = 0; s < n_segs && keep; ++s) {
-        const bjx_segment& g = segs[s];
-        keep = g.in_lo == g.out_lo && g.len >= 0 && g.in_lo >= 0 && g.in_lo + g.len <= dim && g.n_ops >= 0 && g.n_ops <= BJX_MAX_SEG_OPS;
-        for (int k = 0; keep && k < g.n_ops; ++k) keep = g.ops[k].param_len == 0 || g.ops[k].param_len == 1 || g.ops[k].param_len == g.len;
-        total += g.len;
-      }
-      if (keep && total == dim) {
-        std::vector<bjx_segment> clip;
-        for (int64_t r0 = 0, rs = 0; r0 < dim; r0 += rs) {
-          rs = dim - r0 < slab ? dim - r0 : slab;
-          clip.clear();
-          for (int s = 0; s < n_segs; ++s) {
-            const bjx_segment& g = segs[s];
-            const int64_t lo = g.in_lo > r0 ? g.in_lo : r0, hi = g.in_lo + g.len < r0 + rs ? g.in_lo + g.len : r0 + rs;
-            if (hi <= lo) continue;
-            bjx_segment c = g;
-            c.in_lo = c.out_lo = lo - r0;
-            c.len = hi - lo;
-            for (int k = 0; k < g.n_ops; ++k) {
-              if (g.ops[k].param_len > 1) {
-                const size_t off = (size_t)(lo - g.in_lo) * sizeof(T);
-                if (c.ops[k].v0) c.ops[k].v0 = static_cast<const char*>(g.ops[k].v0) + off;
-                if (c.ops[k].v1) c.ops[k].v1 = static_cast<const char*>(g.ops[k].v1) + off;
-                c.ops[k].param_len = (int32_t)(hi - lo);
-              }
-            }
-            clip.push_back(c);
-          }
-          const int rc = stacked_vjp_impl<T>(ctx, clip.data(), (int)clip.size(), x + r0, ybar + r0, lbar, xbar + r0, rs, batch, nullptr, nullptr, dim);
-          if (rc) return rc;
-        }
-        return BJX_OK;
-      }
-    }
-  }
-  {
     static const int use_tiny = getenv("BJX_STACKED_TINY") ? atoi(getenv("BJX_STACKED_TINY")) : 1;
     if (use_tiny && !moments && ld == 0 && dim <= 7 && dim % Vec16<T>::N != 0) {     // same-box A/B: 61-78 % against 28-51 % at 2-5 rows, level from 7
       StackedPlan plt;
@@ -1100,9 +1084,12 @@ int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T*
           const int64_t cpbu = (int64_t)(256 / Gu) * COL_UC;
           const int64_t gridu = (batch + cpbu - 1) / cpbu;
           BJX_REQUIRE(ctx, gridu < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_stacked_vjp: batch too large for one launch");
+          const int64_t nslab = (units + Gu - 1) / Gu;               // > 1: more than 64 units per column — slabs of one grid (SLAB)
+          BJX_REQUIRE(ctx, gridu * nslab < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_stacked_vjp: too many rows for one launch");
           {
             BjxProf prof_(ctx);
-            if (ldsu) hipLaunchKernelGGL((stacked_vjp_kernel<T, VWu, false, true, false, true>), dim3((unsigned)gridu), dim3(256), smemu, ctx->stream, plu.tab, plu.two, x, ybar, lbar, xbar, dim, batch, Gu, (double*)nullptr, 0, ld);
+            if (nslab > 1) hipLaunchKernelGGL((stacked_vjp_kernel<T, VWu, false, true, false, true, true>), dim3((unsigned)(gridu * nslab)), dim3(256), (size_t)VWu * (Gu + 1) * stacked_row_bytes<T>(), ctx->stream, plu.tab, plu.two, x, ybar, lbar, xbar, dim, batch, Gu, (double*)nullptr, (int)nslab, ld);
+            else if (ldsu) hipLaunchKernelGGL((stacked_vjp_kernel<T, VWu, false, true, false, true>), dim3((unsigned)gridu), dim3(256), smemu, ctx->stream, plu.tab, plu.two, x, ybar, lbar, xbar, dim, batch, Gu, (double*)nullptr, 0, ld);
             else hipLaunchKernelGGL((stacked_vjp_kernel<T, VWu, false, false, false, true>), dim3((unsigned)gridu), dim3(256), smemu, ctx->stream, plu.tab, plu.two, x, ybar, lbar, xbar, dim, batch, Gu, (double*)nullptr, 0, ld);
           }
           BJX_CHECK_LAUNCH(ctx);
@@ -1172,7 +1159,13 @@ int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T*
 #define SVJP_V(V_) do { if (pl.gather) { if (lds) SVJP(V_, true, true); else SVJP(V_, true, false); } else { if (lds) SVJP(V_, false, true); else SVJP(V_, false, false); } } while (0)
   {
     BjxProf prof_(ctx);
-    if (pl.V == VW) SVJP_V(VW); else SVJP_V(1);
+    const int64_t nslab = (packs + G - 1) / G;
+    if (nslab > 1 && !pl.gather && grid * nslab < (int64_t)1 << 31) {              // rows in place, more than 64 packs per column: slabs of one grid (SLAB)
+      const size_t smem_s = (size_t)pl.V * G * stacked_row_bytes<T>();
+      if (pl.V == VW) hipLaunchKernelGGL((stacked_vjp_kernel<T, VW, false, true, false, false, true>), dim3((unsigned)(grid * nslab)), dim3(256), smem_s, ctx->stream, pl.tab, pl.two, x, ybar, lbar, xbar, dim, batch, G, (double*)nullptr, (int)nslab, ld);
+      else hipLaunchKernelGGL((stacked_vjp_kernel<T, 1, false, true, false, false, true>), dim3((unsigned)(grid * nslab)), dim3(256), smem_s, ctx->stream, pl.tab, pl.two, x, ybar, lbar, xbar, dim, batch, G, (double*)nullptr, (int)nslab, ld);
+    }
+    else if (pl.V == VW) SVJP_V(VW); else SVJP_V(1);
   }
 #undef SVJP_V
 #undef SVJP
