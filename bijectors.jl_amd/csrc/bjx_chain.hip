@@ -832,6 +832,29 @@ int chain_impl(bjx_ctx* ctx, const bjx_op* ops, int n_ops, const T* x, T* y, T* 
         return BJX_OK;
       }
     }
+    // Per-row parameters (Shift(mu), Scale(sigma) with vectors: the mean-field family) with a per-sample log-det on columns that
+    // are not whole packs, or taller than 64 packs: as ONE segment of `Stacked`, whose kernels keep a row's parameters in an LDS table
+    // shared by the columns in flight (row slabs on tall columns).  Same call, 256 MiB of input, this route against the group kernels
+    // below (which fetch mu and sigma again for every pack): 101 rows 56 / 50 %, 333 rows 49 / 28 %, 1 001 rows 42 / 29 %, 1 000 rows
+    // 44 / 41 %; whole-pack heights up to 64 packs stay here (64 / 100 rows: 67 / 75 %).
+    if (any_row && y && n_ops <= BJX_MAX_SEG_OPS && (flags & ~(uint32_t)BJX_ACCUMULATE) == 0 && ((!v_ok && dim >= 96) || dim / VW > 64)) {
+      // (a row of the Stacked table holds two nonlinear stages: chains with at most two non-affine stages and no Truncated stage,
+      //  whose slot rules are its own — everything else stays on the kernels below)
+      bool plain = true;
+      int nonlin = 0;
+      for (int k = 0; k < n_ops; ++k) {
+        const int kd = ops[k].kind;
+        plain = plain && kd >= BJX_OP_EXP && kd <= BJX_OP_IDENTITY && kd != BJX_OP_TRUNCATED && kd != BJX_OP_TRUNCATED_INV;
+        if (!(kd == BJX_OP_SHIFT || kd == BJX_OP_SCALE || kd == BJX_OP_SCALE_INV || kd == BJX_OP_SIGNFLIP || kd == BJX_OP_IDENTITY)) ++nonlin;
+      }
+      if (plain && nonlin <= 2) {
+        bjx_segment sg;
+        memset(&sg, 0, sizeof(sg));
+        sg.in_lo = 0; sg.out_lo = 0; sg.len = dim; sg.n_ops = n_ops;
+        for (int k = 0; k < n_ops; ++k) sg.ops[k] = ops[k];
+        return bjx_stacked(ctx, sizeof(T) == 4 ? BJX_F32 : BJX_F64, &sg, 1, x, y, ladj_ps, ladj_sum, dim, batch, flags);
+      }
+    }
     static const int use_unal = env_int("BJX_CHAIN_UNALIGNED", 1);
     static const int unal_min = 48;
     // (same-box A/B, 2^22 columns: 63 ... 257 rows 56-67 % against 12-46 %; 1001 / 2049 rows 56 / 64 % against 41 / 54 %; between 65

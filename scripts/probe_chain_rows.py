@@ -17,3 +17,6 @@ for d in [int(v) for v in sys.argv[1:]]:
         ms = kernel_ms(bj, lambda: bj.with_logabsdet_jacobian(b, x), steps=10, device=dev)
         ms2 = kernel_ms(bj, lambda: bj.with_logabsdet_jacobian(b, x, per_sample=True), steps=10, device=dev)
         print(f"d={d:5d} N={N:8d} {name}: sum {ms:.4f} ms {N*d*8/ms/1e6/8000*100:5.1f} %   per-sample {ms2:.4f} ms {N*(d*8+4)/ms2/1e6/8000*100:5.1f} %")
+    st = bj.Stacked([ch], [(1, d)])
+    ms3 = kernel_ms(bj, lambda: bj.with_logabsdet_jacobian(st, x, per_sample=True), steps=10, device=dev)
+    print(f"        Stacked([chain]) per-sample {ms3:.4f} ms {N*(d*8+4)/ms3/1e6/8000*100:5.1f} %")
