@@ -1,10 +1,11 @@
 import sys, os, math
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/scripts')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import bijectors_amd as bj
 from _timing import kernel_ms
 dev = torch.device("cuda", 0)
-d, N = 64, 1 << 22
+d = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+N = (1 << 28) // (4 * d) // 64 * 64
 e = bj.elementwise
 y = torch.rand(N, d, device=dev).T + 0.1
 mu = torch.randn(d, device=dev); sg = torch.rand(d, device=dev) + 0.5
