@@ -318,6 +318,13 @@ template <class T, bool GATHER, bool IN_LDS> struct StackedF {
 
 struct StackedPlan { char* tab; size_t tab_bytes; bool gather; int two; int V; };
 
+// lanes per column of the slab kernels: 64 or 32, whichever leaves fewer idle lanes in the last slab (84 units — 333 rows — are
+// 64 + 20 on 64-lane slabs, a third of the lanes idle, and 32 + 32 + 20 on 32-lane slabs)
+inline int stacked_slab_lanes(int64_t units) {
+  const int64_t w64 = (units + 63) / 64 * 64 - units, w32 = (units + 31) / 32 * 32 - units;
+  return w32 < w64 ? 32 : 64;
+}
+
 // validates the segment list, uploads it and launches the table build; `x`/`y` only decide the pack width
 // `ldx` = rows of the input matrix (== dim unless the call is bjx_stacked_ld: the segments then read rows of a taller /
 // shorter matrix and every row is gathered), `ldy` = rows of the output matrix (>= dim)
@@ -421,6 +428,108 @@ template <class T>
 int stacked_mixed_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const bjx_block* blocks, int n_blocks, const T* x, int64_t rows_in, T* y,
                        int64_t rows_out, T* ladj_ps, double* ladj_sum, int64_t batch, uint32_t flags);
 
+// ------------------------------------------------------------------ tall columns in ONE launch (round 4)
+// Columns of more than 64 packs with every segment on its own rows: the blocks of one grid are (block of columns) x (ROW SLAB of
+// G units) — the slab index runs fastest — each staging its slab's part of the row-permuted table in LDS ([V][G] entries + the
+// tail unit's rows), four columns in flight per lane sharing a row's slots (slot_eval_multi).  A block leaves one partial log-det
+// per column and slab in a [slab][column] scratch; stacked_slab_combine_kernel adds the slabs of a column in slab order (fixed:
+// deterministic), writes the per-sample log-det and the block partials of the sum.  The host loop this replaces launched a table
+// build and a kernel per slab and accumulated in launch order: 16 columns x 5 000 rows took 358 us a call.
+template <class T, int V, bool UNAL>
+__global__ __launch_bounds__(256) void stacked_fwd_slab_kernel(const char* __restrict__ tab_g, int two_slots, const T* __restrict__ x, T* __restrict__ y,
+                                                               T* __restrict__ lpart, int64_t dim, int64_t batch, int G, int nslab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int U = COL_UC;
+  constexpr int RB16 = (int)(stacked_row_bytes<T>() / 16);
+  const int64_t nvc = dim / V;
+  const int tail = UNAL ? (int)(dim - nvc * V) : 0;
+  const int64_t nun = nvc + (tail ? 1 : 0);
+  const int slab = (int)(blockIdx.x % (unsigned)nslab);
+  const int64_t cblk = blockIdx.x / (unsigned)nslab;
+  const int64_t v0 = (int64_t)slab * G;
+  {
+    const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(tab_g);
+    bjx_f32x4* dst = reinterpret_cast<bjx_f32x4*>(smem);
+    for (int i = threadIdx.x; i < V * G * RB16; i += blockDim.x) {
+      const int q = i % RB16, en = i / RB16, vv = en & (G - 1), j = en / G;
+      if (v0 + vv < nvc) dst[i] = src[((int64_t)j * nvc + v0 + vv) * RB16 + q];
+    }
+    if (UNAL && v0 <= nvc && nvc < v0 + G) {
+      for (int i = threadIdx.x; i < V * RB16; i += blockDim.x) {
+        const int q = i % RB16, j = i / RB16;
+        dst[V * G * RB16 + i] = src[stacked_row_index(dim - V + j, V, nvc) * RB16 + q];
+      }
+    }
+    __syncthreads();
+  }
+  const int gl = threadIdx.x & (G - 1);
+  const int cols_per_block = blockDim.x / G;
+  const int64_t col0 = cblk * cols_per_block * U + threadIdx.x / G;
+  const int64_t v = v0 + gl;
+  const bool lane_ok = v < nun;
+  const bool is_tail = UNAL && v == nvc;
+  const int64_t prow = is_tail ? dim - V : v * V;
+  constexpr uint32_t full = (1u << V) - 1u;
+  const uint32_t mask = is_tail ? ((full << (V - tail)) & full) : full;     // the tail unit owns the LAST `tail` rows of its pack
+  Pack<T, V> p[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t col = col0 + (int64_t)u * cols_per_block;
+    if (lane_ok && col < batch) p[u] = load_pack<T, V, true>(x + col * dim + prow);
+    else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) p[u].v[j] = T(1);          // harmless input for every slot kind; nothing of it is kept
+    }
+  }
+  T l[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) l[u] = T(0);
+  if (lane_ok) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const Slot<T>* e = reinterpret_cast<const Slot<T>*>(smem + (size_t)(is_tail ? V * G + j : j * G + gl) * stacked_row_bytes<T>());
+      T xv[U], lj[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { xv[u] = p[u].v[j]; lj[u] = T(0); }
+#pragma unroll 1
+      for (int q = 0; q < (two_slots ? STACKED_SLOTS : 1); ++q) {
+        const Slot<T> sq = e[q];
+        if (sq.kind == SK_END) break;
+        slot_eval_multi<T, U>(sq, xv, lj);
+      }
+      const bool on = (mask >> j) & 1u;
+#pragma unroll
+      for (int u = 0; u < U; ++u) { p[u].v[j] = xv[u]; l[u] += on ? lj[u] : T(0); }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t col = col0 + (int64_t)u * cols_per_block;
+    if (y && lane_ok && col < batch) {
+      T* yp = y + col * dim + prow;
+      if (!is_tail) store_pack<T, V, false>(yp, p[u]);
+      else store_pack_run<T, V>(yp, p[u], V - tail, tail);
+    }
+    const T ls = group_sum_rt(lane_ok ? l[u] : T(0), G);
+    if (gl == 0 && col < batch) lpart[(int64_t)slab * batch + col] = ls;
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void stacked_slab_combine_kernel(const T* __restrict__ lpart, int nslab, int64_t batch, T* __restrict__ ladj_ps, int accumulate,
+                                                                   double* __restrict__ partials) {
+  __shared__ double red[4];
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double acc = 0.0;
+  if (col < batch) {
+    T l = T(0);
+    for (int sidx = 0; sidx < nslab; ++sidx) l += lpart[(int64_t)sidx * batch + col];      // slab order: fixed
+    if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + l : l;
+    acc = (double)l;
+  }
+  if (partials) block_publish_partial(acc, red, partials);
+}
+
 template <class T>
 int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, T* y, T* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch,
                  uint32_t flags, int64_t ldx = 0, int64_t ldy = 0) {
@@ -455,6 +564,49 @@ int stacked_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T* x, 
       total += g.len;
     }
     if (keep && total == dim) {                        // (anything else: the one-launch path below reports it)
+      {
+        // one launch for all slabs (stacked_fwd_slab_kernel) when the column is made of 16-byte packs, aligned or element-aligned
+        constexpr int VWo = Vec16<T>::N;
+        StackedPlan po;
+        po.V = 0; po.gather = true;
+        if ((double)batch * (double)dim * sizeof(T) <= 256.0 * 1024 * 1024) {
+          int rc = stacked_prepare<T>(ctx, segs, n_segs, x, y ? (const void*)y : (const void*)x, dim, batch, true, true, &po, 0, 0, true);
+          if (rc) return rc;
+        }
+        // ... for inputs up to 256 MiB, where the launches of the loop below are what a call costs (16 columns x 5 000 rows: 358 -> 81 us,
+        // x 1 001 rows: 88 -> 45 us); on the large batches of the throughput tables the loop's whole-table-in-LDS kernels are 5-15 %
+        // ahead (2^22 columns x 333 / 1 001 rows: 47 / 49 % of the HBM peak against 40 / 45 %) and keep the job
+        const bool small_job = (double)batch * (double)dim * sizeof(T) <= 256.0 * 1024 * 1024;
+        if (small_job && po.V == VWo && !po.gather && VWo > 1) {
+          const bool whole = dim % VWo == 0;
+          const int64_t units = dim / VWo + (whole ? 0 : 1);
+          const int Go = stacked_slab_lanes(units);
+          const int64_t nslab = (units + Go - 1) / Go;
+          const int64_t cpb = (int64_t)(256 / Go) * COL_UC;
+          const int64_t gridc = (batch + cpb - 1) / cpb;
+          const int64_t gridk = (batch + 255) / 256;
+          if (gridc * nslab < (int64_t)1 << 31) {
+            { int rc = bjx_ensure_big_ws(ctx, (size_t)nslab * batch * sizeof(T)); if (rc) return rc; }
+            if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)gridk); if (rc) return rc; }
+            T* lpart = static_cast<T*>(ctx->big_ws);
+            const size_t smem_o = (size_t)VWo * (Go + 1) * stacked_row_bytes<T>();
+            {
+              BjxProf prof_(ctx);
+              if (whole) hipLaunchKernelGGL((stacked_fwd_slab_kernel<T, VWo, false>), dim3((unsigned)(gridc * nslab)), dim3(256), smem_o, ctx->stream, po.tab, po.two, x, y, lpart, dim, batch, Go, (int)nslab);
+              else hipLaunchKernelGGL((stacked_fwd_slab_kernel<T, VWo, true>), dim3((unsigned)(gridc * nslab)), dim3(256), smem_o, ctx->stream, po.tab, po.two, x, y, lpart, dim, batch, Go, (int)nslab);
+            }
+            BJX_CHECK_LAUNCH(ctx);
+            {
+              BjxProf prof_(ctx);
+              hipLaunchKernelGGL(stacked_slab_combine_kernel<T>, dim3((unsigned)gridk), dim3(256), 0, ctx->stream, (const T*)lpart, (int)nslab, batch, ladj_ps, (flags & BJX_ACCUMULATE) ? 1 : 0,
+                                 ladj_sum ? ctx->partials : (double*)nullptr);
+            }
+            BJX_CHECK_LAUNCH(ctx);
+            if (ladj_sum) return bjx_launch_finalize(ctx, (int)gridk, ladj_sum, 0.0, 0, 0.0, flags);
+            return BJX_OK;
+          }
+        }
+      }
       std::vector<bjx_segment> clip;
       for (int64_t r0 = 0, rs = 0; r0 < dim; r0 += rs) {
         rs = dim - r0 < slab ? dim - r0 : slab;
@@ -1081,6 +1233,7 @@ int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T*
           const int64_t units = dim / VWu + 1;
           int Gu = 1;
           while (Gu < 64 && Gu < units) Gu <<= 1;
+          if (units > 64) Gu = stacked_slab_lanes(units);
           const int64_t cpbu = (int64_t)(256 / Gu) * COL_UC;
           const int64_t gridu = (batch + cpbu - 1) / cpbu;
           BJX_REQUIRE(ctx, gridu < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_stacked_vjp: batch too large for one launch");
@@ -1122,6 +1275,7 @@ int stacked_vjp_impl(bjx_ctx* ctx, const bjx_segment* segs, int n_segs, const T*
   const int64_t packs = dim / pl.V;
   int G = 1;
   while (G < 64 && G < packs) G <<= 1;
+  if (packs > 64 && !pl.gather && !moments) G = stacked_slab_lanes(packs);
   const int64_t cpb = (int64_t)(256 / G) * COL_UC;
   const int64_t grid = (batch + cpb - 1) / cpb;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_stacked_vjp: batch too large for one launch");

@@ -842,6 +842,27 @@ def test_stacked_tall_columns(bj, orc, dt, dim):
     close(host(lb), -l_ref, dt, scale=dim * 10, what="stacked inverse ladj")
 
 
+def test_stacked_tall_columns_small_and_large_jobs_agree(bj):
+    """Tall `Stacked` columns run as ONE launch (row slabs as blocks of a grid) for inputs up to 256 MiB and as a loop of slab launches
+    beyond: the same batch evaluated whole (280 MB: the loop) and in two halves (the single launch) gives the same values, per-sample
+    log-dets and sum."""
+    dim, N = 1001, 70000
+    g = torch.Generator(device="cuda").manual_seed(7)
+    X = torch.rand(N, dim, device="cuda", generator=g).T * 0.8 + 0.1
+    a_ = dim // 3
+    sg = torch.linspace(0.5, 1.5, a_, device="cuda")
+    b = bj.Stacked([bj.elementwise(bj.exp) @ bj.Scale(sg), bj.Logit(0.0, 1.0), bj.elementwise(bj.log)], [(1, a_), (a_ + 1, 2 * a_), (2 * a_ + 1, dim)])
+    Y, l = bj.with_logabsdet_jacobian(b, X, per_sample=True)
+    h = N // 2
+    Y1, l1 = bj.with_logabsdet_jacobian(b, X[:, :h], per_sample=True)
+    Y2, l2 = bj.with_logabsdet_jacobian(b, X[:, h:], per_sample=True)
+    torch.testing.assert_close(Y[:, :h], Y1, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(Y[:, h:], Y2, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(l, torch.cat([l1, l2]), rtol=1e-5, atol=1e-3)
+    _, ls = bj.with_logabsdet_jacobian(b, X)
+    assert abs(float(ls) - float(l.double().sum())) <= 1e-6 * abs(float(ls)) + 1.0
+
+
 def test_stacked_chain_with_three_nonlinear_stages_falls_back(bj, orc):
     """exp ∘ log ∘ exp needs three canonical slots: bjx_stacked refuses, the wrapper evaluates per segment."""
     r = rng(43)
