@@ -1404,8 +1404,12 @@ __global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const double* __re
 // Same streaming shape as bn_stats_kernel (lanes along the rows, Float64 accumulators, LDS combine, one partial per block).
 template <class T, int V, int R>
 __global__ __launch_bounds__(256) void row_moments_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t dim, int64_t batch, int G,
-                                                          double* __restrict__ partial, int64_t ld) {
-  // dim rows of columns that are ld elements apart (a and b point at the first row of the window)
+                                                          double* __restrict__ partial, int64_t ld, int64_t prow) {
+  // dim rows per WINDOW of columns that are ld elements apart; blockIdx.y picks the window (rows blockIdx.y * dim ... of the `prow`
+  // rows this launch covers: the last window may be shorter); the partials form one [block][prow][2] array
+  const int64_t w0 = (int64_t)blockIdx.y * dim;
+  a += w0; if (b) b += w0;
+  if (w0 + dim > prow) dim = prow - w0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* red = reinterpret_cast<double*>(smem);
   const int gl = threadIdx.x & (G - 1), cg = threadIdx.x / G;
@@ -1456,34 +1460,37 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const T* __restrict__ 
   for (int64_t r = threadIdx.x; r < dim; r += 256) {
     double x = 0.0, y = 0.0;
     for (int c = 0; c < cols_per_block; ++c) { x += red[((size_t)c * dim + r) * 2]; y += red[((size_t)c * dim + r) * 2 + 1]; }
-    partial[((size_t)blockIdx.x * dim + r) * 2] = x;
-    partial[((size_t)blockIdx.x * dim + r) * 2 + 1] = y;
+    partial[((size_t)blockIdx.x * prow + w0 + r) * 2] = x;
+    partial[((size_t)blockIdx.x * prow + w0 + r) * 2 + 1] = y;
   }
 }
 
-// One window of rows [r0, r0 + rs) with V-element packs (element-aligned addresses are fine: the packs are plain 16-byte loads).
+// Rows [r0, r0 + rows) in windows of `win` rows (a multiple of V; one pack per lane: four columns in flight), the windows as
+// blockIdx.y of ONE launch, then one fixed-order reduction of the block partials over all of them.
 template <class T, int V>
-int row_moments_window(bjx_ctx* ctx, const T* a, const T* b, double* out, int64_t dim, int64_t batch, int64_t r0, int64_t rs) {
-  const int64_t nvc = rs / V;                                    // rs is a multiple of V here
+int row_moments_windows(bjx_ctx* ctx, const T* a, const T* b, double* out, int64_t dim, int64_t batch, int64_t r0, int64_t rows, int64_t win) {
+  if (win > rows) win = rows;
+  const int64_t nwin = (rows + win - 1) / win;
+  BJX_REQUIRE(ctx, nwin < 65536, BJX_ERR_UNSUPPORTED, "bjx_row_moments: too many rows");
+  const int64_t nvc = win / V;
   int G = 1;
   while (G < 64 && G < nvc) G <<= 1;
-  const int R = nvc <= G ? 1 : (nvc <= 2 * (int64_t)G ? 2 : 4);
   const int cols_per_block = 256 / G;
   int nblocks = (int)((batch + (int64_t)cols_per_block * 16 - 1) / ((int64_t)cols_per_block * 16));
-  if (nblocks > 1024) nblocks = 1024;
+  const int cap = nwin > 1 ? (int)(1024 / (nwin < 8 ? nwin : 8) < 64 ? 64 : 1024 / (nwin < 8 ? nwin : 8)) : 1024;   // ~1 024 blocks in all
+  if (nblocks > cap) nblocks = cap;
   if (nblocks < 1) nblocks = 1;
-  { int rc = bjx_ensure_partials(ctx, (size_t)nblocks * rs * 2); if (rc) return rc; }
-  const size_t smem = (size_t)cols_per_block * rs * 2 * sizeof(double);
+  { int rc = bjx_ensure_partials(ctx, (size_t)nblocks * rows * 2); if (rc) return rc; }
+  const size_t smem = (size_t)cols_per_block * win * 2 * sizeof(double);
   BJX_REQUIRE(ctx, smem <= BJX_LDS_MAX, BJX_ERR_UNSUPPORTED, "bjx_row_moments: LDS");
   {
     BjxProf prof_(ctx);
-#define RM(R_) do { bjx_allow_big_lds(row_moments_kernel<T, V, R_>, smem); hipLaunchKernelGGL((row_moments_kernel<T, V, R_>), dim3(nblocks), dim3(256), smem, ctx->stream, a + r0, b ? b + r0 : nullptr, rs, batch, G, ctx->partials, dim); } while (0)
-    if (R == 1) RM(1); else if (R == 2) RM(2); else RM(4);
-#undef RM
+    bjx_allow_big_lds(row_moments_kernel<T, V, 1>, smem);
+    hipLaunchKernelGGL((row_moments_kernel<T, V, 1>), dim3(nblocks, (unsigned)nwin), dim3(256), smem, ctx->stream, a + r0, b ? b + r0 : nullptr, win, batch, G, ctx->partials, dim, rows);
   }
   BJX_CHECK_LAUNCH(ctx);
   { BjxProf prof_(ctx);
-  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)((rs + 63) / 64)), dim3(256), 0, ctx->stream, ctx->partials, nblocks, rs, batch, out + r0, out + dim + r0, out + 2 * dim); }
+  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, ctx->stream, ctx->partials, nblocks, rows, batch, out + r0, out + dim + r0, out + 2 * dim); }
   BJX_CHECK_LAUNCH(ctx);
   return BJX_OK;
 }
@@ -1494,15 +1501,11 @@ int row_moments_impl(bjx_ctx* ctx, const T* a, const T* b, double* out, int64_t 
   if (batch == 0) { BJX_HIP(ctx, hipMemsetAsync(out, 0, (size_t)(2 * dim + 1) * sizeof(double), ctx->stream)); return BJX_OK; }
   // Any number of rows (round 4; the register accumulators hold 256 packs per column, and columns that were not whole aligned packs
   // fell to one-element packs: 256 rows — a mean-field family of 333 parameters was refused): windows of 64 packs of 16 bytes on
-  // element-aligned addresses, the dim mod V rows that are left as a last window of one-element packs.
+  // element-aligned addresses — the blocks of one grid —, the dim mod V rows that are left as a last launch of one-element packs.
   constexpr int VW = Vec16<T>::N;
   const int64_t whole = dim / VW * VW;
-  const int64_t win = (int64_t)64 * VW;      // one pack per lane: four columns in flight (windows of 256 packs ran 1 001 rows at a fifth of the rate)
-  for (int64_t r0 = 0; r0 < whole; r0 += win) {
-    const int rc = row_moments_window<T, VW>(ctx, a, b, out, dim, batch, r0, whole - r0 < win ? whole - r0 : win);
-    if (rc) return rc;
-  }
-  if (whole < dim) { const int rc = row_moments_window<T, 1>(ctx, a, b, out, dim, batch, whole, dim - whole); if (rc) return rc; }
+  if (whole > 0) { const int rc = row_moments_windows<T, VW>(ctx, a, b, out, dim, batch, 0, whole, (int64_t)64 * VW); if (rc) return rc; }
+  if (whole < dim) { const int rc = row_moments_windows<T, 1>(ctx, a, b, out, dim, batch, whole, dim - whole, 64); if (rc) return rc; }
   return BJX_OK;
 }
 
