@@ -808,7 +808,7 @@ def test_stacked_elementwise_segments_one_launch(bj, orc, dt, N):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("dim", [101, 201, 255, 385, 500, 771, 1000, 1001])
+@pytest.mark.parametrize("dim", [101, 201, 255, 385, 500, 771, 1000, 1001, 257, 513, 1024, 2051])
 def test_stacked_tall_columns(bj, orc, dt, dim):
     """Heights past the tile walker: the group kernel on element-aligned packs (odd heights from 48 rows) and, from 385 rows,
     row slabs of 256 rows with the segments — and their per-row parameters — clipped to each slab (stacked.jl:142-166)."""
@@ -840,6 +840,30 @@ def test_stacked_tall_columns(bj, orc, dt, dim):
     Xb, lb = bj.with_logabsdet_jacobian(bj.inverse(b), dev(Y_ref), per_sample=True)
     close(host(Xb), X, dt, scale=10, what="stacked inverse")
     close(host(lb), -l_ref, dt, scale=dim * 10, what="stacked inverse ladj")
+
+
+@pytest.mark.parametrize("N", [1, 3, 17])
+@pytest.mark.parametrize("dim", [257, 1001, 1024])
+def test_tall_columns_tiny_batches(bj, orc, dim, N):
+    """One, three and seventeen columns through the slab kernels (forward, pullback, mean-field parameter pullback): what a sampler
+    calls; against the chain oracle."""
+    r = rng(dim + N)
+    mu, sg = r.normal(size=dim), np.exp(0.3 * r.normal(size=dim))
+    ops = [(orc.OP_SCALE, sg, None), (orc.OP_SHIFT, mu, None), (orc.OP_EXP, None, None)]
+    ch = bj.elementwise(bj.exp) @ bj.Shift(torch.tensor(mu)) @ bj.Scale(torch.tensor(sg))
+    X = np.asfortranarray(r.normal(size=(dim, N)))
+    g = np.asfortranarray(r.normal(size=(dim, N)))
+    lbar = r.normal(size=N)
+    Y, l = bj.with_logabsdet_jacobian(ch, dev(X), per_sample=True)
+    np.testing.assert_allclose(host(Y), np.exp(mu[:, None] + sg[:, None] * X), rtol=1e-12)
+    np.testing.assert_allclose(host(l), (mu[:, None] + sg[:, None] * X).sum(axis=0) + np.log(sg).sum(), rtol=1e-11)
+    ref = orc.chain_vjp(ops, X, g, lbar)
+    np.testing.assert_allclose(host(bj.vjp(ch, dev(X), dev(g), torch.from_numpy(lbar).cuda())), ref, rtol=1e-11, atol=1e-11)
+    zb, pb = bj.vjp_params(ch, dev(X), dev(g), torch.from_numpy(lbar).cuda())
+    vbar = g * np.exp(mu[:, None] + sg[:, None] * X) + lbar[None, :]
+    np.testing.assert_allclose(host(zb), sg[:, None] * vbar, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(host(pb["shift"]), vbar.sum(axis=1), rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(host(pb["scale"]), (vbar * X).sum(axis=1) + lbar.sum() / sg, rtol=1e-10, atol=1e-9)
 
 
 def test_stacked_tall_columns_small_and_large_jobs_agree(bj):
@@ -982,7 +1006,7 @@ def test_stacked_and_chain_vjp(bj, orc, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("dim", [81, 101, 201, 255, 333, 1001, 512, 1000, 2049])
+@pytest.mark.parametrize("dim", [81, 101, 201, 255, 333, 1001, 512, 1000, 2049, 257, 513, 1024, 129])     # 257 / 513: the tail unit alone in the last slab
 def test_stacked_and_chain_vjp_odd_heights(bj, orc, dt, dim):
     """Pullback of chains / `Stacked` at heights that are not whole 16-byte packs, from 80 rows: the group kernel on element-aligned
     packs with the tail rows as an overlapping last pack (`stacked_vjp_kernel<..., UNAL>`); cotangent buffer aliased by the result too.
