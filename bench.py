@@ -437,20 +437,30 @@ def measure(env, name, steps, warmup, scaling, log2_batch=None, want_cold=True):
     barrier()
     per_warm = (time.perf_counter() - t_w) / max(warmup, 1)
 
-    def timed_pass():
-        """EXACTLY `steps` steps between barrier + synchronize on both sides -> (wall s, stream-region ms, Σ dominant-kernel ms, launches), max over ranks"""
+    def timed_pass(instrument):
+        """EXACTLY `steps` steps between barrier + synchronize on both sides, max over ranks.  THREE kinds of pass, never mixed
+        (the per-launch hipEvent pairs cost 30-55 % on launch-bound steps and must not sit inside the region
+        whose wall clock becomes `value`):
+          "wall"   — nothing of ours on the stream: -> wall seconds                     (`value`, `ms_per_step`, `cold`)
+          "region" — ONE hipEvent pair around the whole region: -> stream-region ms     (`stream_region_ms_per_step`)
+          "kernel" — one hipEvent pair around every dominant-kernel launch: -> Σ ms, n  (`kernel_ms`, `roofline`)
+        -> (wall s, stream-region ms, Σ dominant-kernel ms, launches)"""
         nonlocal last
-        lib.bjx_kernel_time_begin(ctx.h)          # one hipEvent pair around every dominant-kernel launch (context stream)
-        lib.bjx_time_begin(ctx.h)
+        if instrument == "kernel":
+            lib.bjx_kernel_time_begin(ctx.h)      # prof_on = 1 (context stream)
+        if instrument == "region":
+            lib.bjx_time_begin(ctx.h)
         t0 = time.perf_counter()
         for _ in range(steps):
             last = wl["step"]()
         ev_ms = C.c_float(0.0)
-        lib.bjx_time_end(ctx.h, C.byref(ev_ms))   # hipEvent pair around the whole timed region (helpers + gaps included)
+        if instrument == "region":
+            lib.bjx_time_end(ctx.h, C.byref(ev_ms))
         barrier()
         dt = time.perf_counter() - t0
         k_ms, k_n = C.c_float(0.0), C.c_int(0)
-        bj._lib.check(ctx.h, lib.bjx_kernel_time_end(ctx.h, C.byref(k_ms), C.byref(k_n)), "bjx_kernel_time_end")
+        if instrument == "kernel":
+            bj._lib.check(ctx.h, lib.bjx_kernel_time_end(ctx.h, C.byref(k_ms), C.byref(k_n)), "bjx_kernel_time_end")
         if dist is not None:
             tt = torch.tensor([dt, ev_ms.value, k_ms.value], dtype=torch.float64, device=env.device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -459,25 +469,41 @@ def measure(env, name, steps, warmup, scaling, log2_batch=None, want_cold=True):
 
     # COLD pass: the W warm-up steps as asked, then K timed steps — what a sampler's first calls or any burst shorter than ~30 ms
     # see (profiles/r03_warmup.md: a fresh process reaches its steady clocks only after 20-30 ms of load; C3 reads 0.54 of the
-    # peak like this, 0.61-0.63 after 50-300 steps).  Reported as `cold`.
+    # peak like this, 0.61-0.63 after 50-300 steps).  Reported as `cold` (wall clock only, no events on the stream).
     cold = None
     if PREROLL_MS > 0 and want_cold:
-        cdt, _, ck, _ = timed_pass()
-        cold = {"value": wl["total"] / (cdt / steps) / 1e6, "ms_per_step": cdt / steps * 1e3, "kernel_ms": ck / steps}
-    # STEADY pass: MORE untimed steps of the same workload until PREROLL_MS of it have run, then the K timed steps.  The count comes
-    # from the all-reduced warm-up time, so every rank issues the same number of steps (they contain the collective).
+        cdt, _, _, _ = timed_pass("wall")
+        cold = {"value": wl["total"] / (cdt / steps) / 1e6, "ms_per_step": cdt / steps * 1e3}
+    # STEADY passes: MORE untimed steps of the same workload until PREROLL_MS of it have run, then K timed steps three times over
+    # (wall, region, kernel).  The count comes from the all-reduced warm-up time, so every rank issues the same number of steps
+    # (they contain the collective).
     pre = 0
     if PREROLL_MS > 0:
-        per = per_warm
+        # per-step time for the count: K more steps timed AFTER the warm-up (the warm-up's own clock contains one-time costs — code
+        # objects, allocator growth — and under-counted the pre-roll by 10x for short steps: C5a's "steady" pass of round 4 started
+        # 5 ms into the load, inside the clock transient it was meant to skip, and read 113 µs where 93 µs is the steady state)
+        barrier()
+        t_p = time.perf_counter()
+        for _ in range(steps):
+            last = wl["step"]()
+        barrier()
+        per = (time.perf_counter() - t_p) / steps
         if dist is not None:
             tt = torch.tensor([per], dtype=torch.float64, device=env.device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             per = float(tt[0])
-        pre = 0 if per <= 0 else max(0, min(4000, int(math.ceil(PREROLL_MS * 1e-3 / per)) - warmup - (steps if cold else 0)))
-        for _ in range(pre):
-            last = wl["step"]()
+        pre = 0 if per <= 0 else max(0, min(4000, int(math.ceil(PREROLL_MS * 1e-3 / per))))
+        done = 0
+        while done < pre:                        # in bursts of <= 256 steps: the host never runs far ahead of the stream
+            nb = min(256, pre - done)
+            for _ in range(nb):
+                last = wl["step"]()
+            done += nb
+            torch.cuda.synchronize()
         barrier()
-    dt, ev, kern_total, k_launches = timed_pass()
+    dt, _, _, _ = timed_pass("wall")
+    _, ev, _, _ = timed_pass("region")
+    dt_k, _, kern_total, k_launches = timed_pass("kernel")
     ladj_total = float(last[0]) if last is not None else float("nan")
     ms_per_step = dt / steps * 1e3
     # dominant kernel(s) of ONE step: per-launch hipEvent pairs summed, / steps (a step of c3 has two
@@ -493,6 +519,8 @@ def measure(env, name, steps, warmup, scaling, log2_batch=None, want_cold=True):
                      "kernel_launches_per_step": k_launches / max(steps, 1), "stream_region_ms_per_step": ev / steps,
                      "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
         "sum_logabsdetjac": ladj_total, "cold": cold,
+        "passes": {"wall_ms_per_step": ms_per_step, "kernel_pass_wall_ms_per_step": dt_k / steps * 1e3,
+                   "note": "value / ms_per_step / cold: pass without any event on the stream; kernel_ms: a separate pass with one hipEvent pair per launch"},
     }
     if name == "c1":
         res["us_per_call"] = ms_per_step * 1e3
@@ -559,6 +587,8 @@ def compact_row(r):
            "value": _sig(r["value"]), "ms_per_step": _sig(r["ms_per_step"], 5), "frac": round(rf["frac"], 4),
            "kernel_ms": _sig(rf["kernel_ms"], 5), "stream_ms": _sig(rf["stream_region_ms_per_step"], 5), "kernel": rf["kernel"],
            "launches": rf["kernel_launches_per_step"], "scaling": r["scaling"]}
+    if r.get("passes"):        # wall ms/step of the separate pass that carried the per-launch events (NOT what `value` comes from)
+        out["ms_with_events"] = _sig(r["passes"]["kernel_pass_wall_ms_per_step"], 5)
     if r.get("cold"):
         out["cold"] = {"value": _sig(r["cold"]["value"]), "ms_per_step": _sig(r["cold"]["ms_per_step"], 5)}
     cb = r.get("cpu_baseline")
@@ -583,6 +613,7 @@ def build_line(a, world, head, rows, graph_rows, strong, cpu):
                                         "kernel_launches_per_step", "stream_region_ms_per_step", "algorithmic_bytes_per_launch")},
         "cpu_baseline": cpu,
         "preroll": {"ms": PREROLL_MS, "steps": head.get("preroll_steps", 0)},
+        "passes": head.get("passes"),
         "cold": head.get("cold"),
         "sum_logabsdetjac": head["sum_logabsdetjac"],
     }

@@ -122,7 +122,15 @@ int bjx_make_fin(bjx_ctx* ctx, int64_t grid, double* ladj_sum, double host_const
   int rc = bjx_ensure_partials(ctx, (size_t)grid);
   if (rc) return rc;
   fin->partials = ctx->partials;
-  if (ctx->opt_inkernel_fin && grid <= BJX_INKERNEL_FIN_MAX) {
+  if (ctx->opt_inkernel_fin == 2 && grid <= BJX_FIN_WIDE_MAX && ctx->sent_l1) {
+    // sentinel hand-off: the slots hold BJX_FIN_SENT between launches (set at bjx_create, put back by the polling blocks)
+    fin->partials = ctx->sent_l1;
+    fin->l2 = ctx->sent_l2;
+    fin->out = ladj_sum;
+    fin->host_const = host_const;
+    fin->dev_const = use_dev_const ? ctx->consts + 1 : nullptr;
+    fin->accumulate = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  } else if (ctx->opt_inkernel_fin == 1 && grid <= BJX_INKERNEL_FIN_MAX) {
     // The arrival counter is zero between launches: the block that draws the last ticket resets it (a launch that faults
     // leaves the HIP context in a sticky error state, so no later launch can see a stale count); nothing is enqueued here.
     fin->counter = ctx->fin_counter;
@@ -157,6 +165,10 @@ BJX_API int bjx_create(int device, void* hip_stream, bjx_ctx** out) {
   if (e == hipSuccess) e = hipMalloc(&ctx->consts, sizeof(double) * BJX_CONSTS);
   if (e == hipSuccess) e = hipMalloc(&ctx->fin_counter, 64);
   if (e == hipSuccess) e = hipMemset(ctx->fin_counter, 0, 64);
+  if (e == hipSuccess) e = hipMalloc(&ctx->sent_l1, sizeof(double) * BJX_FIN_SENT_GROUPS * 64);
+  if (e == hipSuccess) e = hipMalloc(&ctx->sent_l2, sizeof(double) * BJX_FIN_SENT_GROUPS);
+  if (e == hipSuccess) e = hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(ctx->sent_l1), (int)0xFFFFDEAD, (size_t)BJX_FIN_SENT_GROUPS * 64 * 2);
+  if (e == hipSuccess) e = hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(ctx->sent_l2), (int)0xFFFFDEAD, (size_t)BJX_FIN_SENT_GROUPS * 2);
   if (e == hipSuccess) e = hipMalloc(&ctx->scratch, BJX_SCRATCH_BYTES);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
@@ -182,11 +194,13 @@ BJX_API int bjx_destroy(bjx_ctx* ctx) {
   if (ctx->partials2) (void)hipFree(ctx->partials2);
   if (ctx->consts) (void)hipFree(ctx->consts);
   if (ctx->fin_counter) (void)hipFree(ctx->fin_counter);
+  if (ctx->sent_l1) (void)hipFree(ctx->sent_l1);
+  if (ctx->sent_l2) (void)hipFree(ctx->sent_l2);
   if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
   if (ctx->stage_ev) (void)hipEventDestroy(ctx->stage_ev);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->big_ws) (void)hipFree(ctx->big_ws);
-  for (auto& sl : ctx->rqs_slots) if (sl.buf) (void)hipFree(sl.buf);
+  if (ctx->scale_slot.buf) (void)hipFree(ctx->scale_slot.buf);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->prof_ev) {
@@ -200,7 +214,7 @@ BJX_API int bjx_destroy(bjx_ctx* ctx) {
 BJX_API int bjx_set_stream(bjx_ctx* ctx, void* hip_stream) {
   if (!ctx) return BJX_ERR_ARG;
   ctx->stream = static_cast<hipStream_t>(hip_stream);
-  for (auto& sl : ctx->rqs_slots) sl.epoch = 0;          // cached parameter tables were built on the old stream: rebuild on first use
+  ctx->scale_slot.epoch = 0;          // cached parameter tables were built on the old stream: rebuild on first use
   return BJX_OK;
 }
 
@@ -213,7 +227,11 @@ BJX_API size_t bjx_workspace_bytes(bjx_ctx* ctx) {
 
 BJX_API int bjx_set_option(bjx_ctx* ctx, int option, int value) {
   if (!ctx) return BJX_ERR_ARG;
-  if (option == BJX_OPT_INKERNEL_FINALIZE) { ctx->opt_inkernel_fin = value ? 1 : 0; return BJX_OK; }
+  if (option == BJX_OPT_INKERNEL_FINALIZE) {
+    BJX_REQUIRE(ctx, value >= 0 && value <= 2, BJX_ERR_ARG, "BJX_OPT_INKERNEL_FINALIZE: 0 (two-pass), 1 (arrival ticket) or 2 (sentinel hand-off), got %d", value);
+    ctx->opt_inkernel_fin = value;
+    return BJX_OK;
+  }
   if (option == BJX_OPT_PARAM_EPOCH) {
     BJX_REQUIRE(ctx, value >= 0, BJX_ERR_ARG, "BJX_OPT_PARAM_EPOCH: an epoch >= 0 (0 = no reuse of parameter-derived tables)");
     ctx->param_epoch = value;

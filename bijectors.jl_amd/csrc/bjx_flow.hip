@@ -1048,14 +1048,20 @@ __global__ __launch_bounds__(256) void planar_mfma_kernel(const PlanarRegArgs A,
 // W and Û of a group come from L1/L2 per use (8 KiB per group, shared by every wave).  INV: groups and layers last to
 // first, find_alpha_dev per layer (planar_layer.jl:112-127,160-185), update with -tanh.
 typedef double md4 __attribute__((ext_vector_type(4)));
-template <int NB, int TILES, bool INV>
+// SPLIT: the tile goes through the LDS transpose in SPLIT row chunks (the staging tile of a wave is 16 columns x ROWS / SPLIT rows).
+// Round 5 (profiles/r05_c4f64_pmc.md): with TILES = 2, SPLIT = 1 a wave holds 128 VGPRs of tile and 18.9 KiB of LDS — two waves
+// per SIMD, 48 % of the wave cycles parked in s_waitcnt and nothing to switch to.  TILES = 1, SPLIT = 2 halves both: four waves
+// per SIMD on the same bytes in flight per CU.
+template <int NB, int TILES, bool INV, int SPLIT = 1>
 __global__ __launch_bounds__(256) void planar_mfma64_kernel(const double* __restrict__ Wp, const double* __restrict__ Up, const double* __restrict__ Gp,
                                                             const double* __restrict__ cp, const double* __restrict__ bp, int nl_pad, int n_layers,
                                                             const double* __restrict__ x, double* __restrict__ y, double* __restrict__ ladj_ps, int dim,
                                                             int64_t batch, int accumulate, const BjxFin fin) {
   constexpr int NL = 8, COLS = 16 * TILES;
   constexpr int ROWS = 16 * NB;
-  constexpr int PITCH = ROWS + 4;                  // doubles per staged column (rows of consecutive columns start 8 banks apart)
+  static_assert(NB % SPLIT == 0, "a staging chunk is whole 16-row blocks");
+  constexpr int NBC = NB / SPLIT, RC = 16 * NBC;   // 16-row blocks / rows per staging chunk
+  constexpr int PITCH = RC + 4;                    // doubles per staged column (rows of consecutive columns start 8 banks apart)
   extern __shared__ __attribute__((aligned(16))) char smem_[];
   __shared__ double red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1066,31 +1072,34 @@ __global__ __launch_bounds__(256) void planar_mfma64_kernel(const double* __rest
   const int64_t left = batch - col0;
   const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
   typedef double d2 __attribute__((ext_vector_type(2)));
-  constexpr int PK = ROWS / 2;                      // 16-byte packs per column
-  constexpr int NIT = (16 * PK + 63) / 64;          // pack loads per lane and tile
+  constexpr int PK = RC / 2;                        // 16-byte packs per column and chunk
+  constexpr int NIT = (16 * PK + 63) / 64;          // pack loads per lane, tile and chunk
 
   double z[TILES][NB][4];
 #pragma unroll
   for (int t = 0; t < TILES; ++t) {
-    const double* px = x + (col0 + t * 16) * dim;
-    d2 tmp[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int p = it * 64 + lane, c = p / PK;
-      tmp[it] = (p < 16 * PK && t * 16 + c < nvalid) ? __builtin_nontemporal_load(reinterpret_cast<const d2*>(px) + p) : d2{0., 0.};
+    for (int h = 0; h < SPLIT; ++h) {
+      const double* px = x + (col0 + t * 16) * dim + h * RC;
+      d2 tmp[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int p = it * 64 + lane, c = p / PK, k = p - c * PK;
+        tmp[it] = (p < 16 * PK && t * 16 + c < nvalid) ? __builtin_nontemporal_load(reinterpret_cast<const d2*>(px + (int64_t)c * dim) + k) : d2{0., 0.};
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int p = it * 64 + lane, c = p / PK, k = p - c * PK;
+        if (p < 16 * PK) *reinterpret_cast<d2*>(sg + c * PITCH + 2 * k) = tmp[it];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int b = 0; b < NBC; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[t][h * NBC + b][r] = sg[n * PITCH + 16 * b + 4 * r + q];
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int p = it * 64 + lane, c = p / PK, k = p - c * PK;
-      if (p < 16 * PK) *reinterpret_cast<d2*>(sg + c * PITCH + 2 * k) = tmp[it];
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) z[t][b][r] = sg[n * PITCH + 16 * b + 4 * r + q];
-    __builtin_amdgcn_wave_barrier();
   }
   double ladj = 0.0;
   const int ngroups = nl_pad / NL;
@@ -1099,16 +1108,17 @@ __global__ __launch_bounds__(256) void planar_mfma64_kernel(const double* __rest
     // ---- contraction
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-      md4 acc = md4{0., 0., 0., 0.};
+      md4 acc = md4{0., 0., 0., 0.}, acc2 = md4{0., 0., 0., 0.};      // two chains: a dependent MFMA waits for the whole pass of its predecessor
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const double wa = n < NL ? Wp[(int64_t)(l0 + n) * dim + 16 * b + 4 * r + q] : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, z[t][b][r], acc, 0, 0, 0);
+          if (r & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, z[t][b][r], acc2, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, z[t][b][r], acc, 0, 0, 0);
         }
-      st[(t * 16 + n) * NL + q] = acc[0];
-      st[(t * 16 + n) * NL + 4 + q] = acc[1];
+      st[(t * 16 + n) * NL + q] = acc[0] + acc2[0];
+      st[(t * 16 + n) * NL + 4 + q] = acc[1] + acc2[1];
     }
     __builtin_amdgcn_wave_barrier();
     // ---- scalar recurrence, one sample per lane
@@ -1175,17 +1185,20 @@ __global__ __launch_bounds__(256) void planar_mfma64_kernel(const double* __rest
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
+      for (int h = 0; h < SPLIT; ++h) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sg[n * PITCH + 16 * b + 4 * r + q] = z[t][b][r];
-      __builtin_amdgcn_wave_barrier();
-      double* py = y + (col0 + t * 16) * dim;
+        for (int b = 0; b < NBC; ++b)
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int p = it * 64 + lane, c = p / PK, k = p - c * PK;
-        if (p < 16 * PK && t * 16 + c < nvalid) __builtin_nontemporal_store(*reinterpret_cast<const d2*>(sg + c * PITCH + 2 * k), reinterpret_cast<d2*>(py) + p);
+          for (int r = 0; r < 4; ++r) sg[n * PITCH + 16 * b + 4 * r + q] = z[t][h * NBC + b][r];
+        __builtin_amdgcn_wave_barrier();
+        double* py = y + (col0 + t * 16) * dim + h * RC;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int p = it * 64 + lane, c = p / PK, k = p - c * PK;
+          if (p < 16 * PK && t * 16 + c < nvalid) __builtin_nontemporal_store(*reinterpret_cast<const d2*>(sg + c * PITCH + 2 * k), reinterpret_cast<d2*>(py + (int64_t)c * dim) + k);
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
     }
   }
   const bool ok = lane < nvalid;
@@ -2554,6 +2567,9 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         hipLaunchKernelGGL(planar_prep_reg_kernel<double>, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, (const double*)w, (const double*)u_hat,
                            (const double*)wtu, (const double*)b, dim, nl, nl_pad, wp, up, Gp, cp, bp);
         BJX_CHECK_LAUNCH(ctx);
+        // (round 5: 16 columns per wave staged in two 64-row chunks — SPLIT = 2, four waves per SIMD — measured 0.478 of the HBM peak
+        //  against 0.542 for this form and 0.498 for TILES = 1 unsplit, profiles/r05_c4f64_modes.md: not dispatched)
+        constexpr bool split2 = false;
         const int tiles = use_mf64 == 1 ? 1 : 2;
         const int cols = 16 * tiles;
         const int64_t gridm = (batch + 4 * cols - 1) / (4 * cols);
@@ -2562,10 +2578,11 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         bool secondm = false;
         { int rc = bjx_make_fin(ctx, gridm, ladj_sum, 0.0, 0, flags, &finm, &secondm); if (rc) return rc; }
         const int accum = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
-        const size_t smem = (size_t)4 * (16 * (dim + 4) + cols * 8) * sizeof(double);
-#define LAUNCH_MF64(NB_, T_, I_) do { bjx_allow_big_lds(planar_mfma64_kernel<NB_, T_, I_>, smem); \
-          hipLaunchKernelGGL((planar_mfma64_kernel<NB_, T_, I_>), dim3((unsigned)gridm), dim3(256), smem, ctx->stream, wp, up, Gp, cp, bp, nl_pad, nl, \
+        const size_t smem = (size_t)4 * (16 * (dim / (split2 ? 2 : 1) + 4) + cols * 8) * sizeof(double);
+#define LAUNCH_MF64_S(NB_, T_, I_, S_) do { bjx_allow_big_lds(planar_mfma64_kernel<NB_, T_, I_, S_>, smem); \
+          hipLaunchKernelGGL((planar_mfma64_kernel<NB_, T_, I_, S_>), dim3((unsigned)gridm), dim3(256), smem, ctx->stream, wp, up, Gp, cp, bp, nl_pad, nl, \
                              (const double*)in, (double*)out, (double*)ladj_ps, (int)dim, batch, accum, finm); } while (0)
+#define LAUNCH_MF64(NB_, T_, I_) LAUNCH_MF64_S(NB_, T_, I_, 1)
 #define LAUNCH_MF64_TI(NB_) do { if (tiles == 1) { if (inverse) LAUNCH_MF64(NB_, 1, true); else LAUNCH_MF64(NB_, 1, false); } \
                                  else { if (inverse) LAUNCH_MF64(NB_, 2, true); else LAUNCH_MF64(NB_, 2, false); } } while (0)
         { BjxProf prof_(ctx);
@@ -2573,6 +2590,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
                               case 5: LAUNCH_MF64_TI(5); break; case 6: LAUNCH_MF64_TI(6); break; case 7: LAUNCH_MF64_TI(7); break; default: LAUNCH_MF64_TI(8); break; } }
 #undef LAUNCH_MF64_TI
 #undef LAUNCH_MF64
+#undef LAUNCH_MF64_S
         BJX_CHECK_LAUNCH(ctx);
         if (secondm) return bjx_launch_finalize(ctx, (int)gridm, ladj_sum, 0.0, 0, 0.0, flags);
         return BJX_OK;

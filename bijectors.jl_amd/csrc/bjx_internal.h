@@ -16,6 +16,7 @@
 // ------------------------------------------------------------------ context
 constexpr int BJX_INKERNEL_FIN_MAX = 4096;    // partials one block reduces: in-kernel (BJX_OPT_INKERNEL_FINALIZE = 1) and in bjx_finalize_kernel
 constexpr int BJX_MAX_BLOCKS = 4096;        // persistent-grid cap AND size of the 2nd-stage partial buffer
+constexpr int BJX_FIN_SENT_GROUPS = 1040;   // sentinel hand-off: 8 residue classes x ceil(8192 / 64) groups of 64 blocks (+ slack)
 constexpr int BJX_FIN_WIDE_MAX = 65536;     // partials ONE 1024-thread block still sums in a single launch (bjx_finalize_wide_kernel)
 constexpr int BJX_CONSTS = 8;               // device doubles for parameter-only log-det terms
 constexpr size_t BJX_SCRATCH_BYTES = 1 << 20;  // û tables, small parameter staging
@@ -30,23 +31,26 @@ struct bjx_ctx {
   void* host_stage = nullptr;      // pinned, BJX_HOST_STAGE_BYTES, created on first use
   hipEvent_t stage_ev = nullptr;   // recorded after the last copy out of host_stage
   unsigned* fin_counter = nullptr;  // arrival counter of the in-kernel finalize (zero between launches)
+  double* sent_l1 = nullptr;    // [BJX_FIN_SENT_GROUPS * 64] block partials of the sentinel hand-off (BJX_FIN_SENT between launches)
+  double* sent_l2 = nullptr;    // [BJX_FIN_SENT_GROUPS] group sums of the sentinel hand-off (BJX_FIN_SENT between launches)
   double* consts = nullptr;     // [BJX_CONSTS]
   void* scratch = nullptr;      // [BJX_SCRATCH_BYTES]
   void* big_ws = nullptr;       // workspace of the general-size matrix kernels (K > 64, matrix Scale beyond 128 rows): grown on demand, cached
   size_t big_ws_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cu = 256;
-  // BJX_OPT_PARAM_EPOCH (0 = off): while the host keeps the epoch unchanged, tables DERIVED from parameter arrays (the spline's LDS
-  // blob) are reused when the same device pointers come back, instead of being rebuilt by a helper launch on every call.
+  // BJX_OPT_PARAM_EPOCH (0 = off): while the host keeps the epoch unchanged, tables DERIVED from parameter arrays (the factorisation
+  // behind a matrix `Scale`) are reused when the same device pointers come back, instead of being rebuilt by a helper launch on every call.
   int param_epoch = 0;
-  struct RqsBlobSlot {
-    const void *w = nullptr, *h = nullptr, *d = nullptr;
-    int K1 = 0, V = 0, nstep_hi = 0, dual = 0, G = 0, inverse = 0, dt = 0, epoch = 0;
-    int64_t rows = 0, trows = 0;
-    void* buf = nullptr;          // [64 bytes flag][blob], kRqsBlobMax + 64, allocated on first use
-  } rqs_slots[4];
-  int rqs_next = 0;
-  int opt_inkernel_fin = 0;     // BJX_OPT_INKERNEL_FINALIZE: 0 (default) two follow-up launches, 1 the last block finishes the sum (<= 4096 blocks)
+  // the factorisation behind a matrix `Scale` ([A^-1 | logabsdet], bjx_scale_matrix) under the same epoch contract
+  struct ScaleSlot {
+    const void* a = nullptr;
+    int64_t dim = 0;
+    int dt = 0, has_inverse = 0, epoch = 0;
+    void* buf = nullptr;          // [dim][2 dim] of T, then one double (logabsdet); allocated on first use
+    size_t cap = 0;
+  } scale_slot;
+  int opt_inkernel_fin = 2;     // BJX_OPT_INKERNEL_FINALIZE: 0 two follow-up launches, 1 arrival ticket (<= 4096 blocks), 2 (default) sentinel hand-off (<= 65536 blocks)
   uint64_t rng_seed = 0;        // bjx_set_rng: stream of the fused sampling path (BJX_INPUT_STDNORMAL)
   int64_t rng_col0 = 0;
   // per-launch timing of the DOMINANT kernel of each call (bjx_kernel_time_begin/_end): event pairs
@@ -107,7 +111,8 @@ struct BjxProf {
 // launch (no extra dispatch, ~5 us each on MI355X); otherwise the host launches the two-pass finalize.
 struct BjxFin {
   double* partials = nullptr;       // null: no sum requested
-  unsigned* counter = nullptr;      // null: host-launched finalize
+  unsigned* counter = nullptr;      // null: host-launched finalize (or the sentinel hand-off, `l2` set)
+  double* l2 = nullptr;             // sentinel hand-off: the group sums; `partials` then points at the sentinel-initialised block slots
   double* out = nullptr;
   double host_const = 0.0;
   const double* dev_const = nullptr;
@@ -546,8 +551,84 @@ __device__ __forceinline__ void block_publish_partial(double acc, double* red, d
 // tests/test_gpu_parity.py::test_inkernel_finalize_is_bit_identical_to_two_pass stresses the hand-off under load.
 // `flag_lds`: one LDS int for the "I am the last block" broadcast.  Kernels that budget their LDS to the byte (rqs_lds_kernel: 5 blocks
 // of 32 KiB per CU) pass a word of their own dynamic allocation; the wrapper below keeps a static one.
+// ---- sentinel hand-off (BJX_OPT_INKERNEL_FINALIZE = 2, the default since round 5): ONE launch per call without any wait in the
+// publishing blocks.  Every slot of `f.partials` / `f.l2` holds BJX_FIN_SENT (a NaN pattern no sum can produce: sums of NaNs are
+// canonicalised before they are published) between launches.  A block publishes its partial with ONE relaxed agent-scope 8-byte
+// store — atomic, so no flag and no ordering against its other stores is needed, the wave retires with its output stores still in
+// flight.  The block that closes a group of 64 consecutive blocks (index ≡ 63 mod 64, or the last block) polls the 64 slots of
+// its group with its first wave (one slot per lane), puts the sentinel back, and publishes the group sum the same way; the LAST
+// block polls the group sums (<= 1024: four per thread) and writes the result.  A block only ever waits for blocks with LOWER
+// indices, which the dispatcher started before it — they never need the slot the waiting wave occupies, so the wait cannot
+// deadlock; a poll gives up after BJX_FIN_SPIN_MAX rounds and lets the sentinel (a NaN) through, so a broken invariant shows as
+// a NaN sum instead of a hung GPU.  Fixed order (lanes of a group by butterfly, groups t, t+256, ... per thread, wave trees,
+// (r0+r1)+(r2+r3)): run-to-run identical, within 1e-15 relative of the two-pass order.
+constexpr unsigned long long BJX_FIN_SENT = 0xFFFFDEADFFFFDEADull;
+constexpr int BJX_FIN_SPIN_MAX = 1 << 21;
+__device__ __forceinline__ void fin_publish(double* slot, double v) {
+  unsigned long long b = (v != v) ? 0x7FF8000000000000ull : (unsigned long long)__double_as_longlong(v);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double fin_poll(double* slot) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(slot);
+  unsigned long long v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int spins = 0;
+  while (v == BJX_FIN_SENT && ++spins < BJX_FIN_SPIN_MAX) {
+    __builtin_amdgcn_s_sleep(2);
+    v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __hip_atomic_store(q, BJX_FIN_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the slot is ready for the next launch
+  return __longlong_as_double((long long)v);
+}
+// Groups are XCD-LOCAL: block b runs on XCD b % 8 (observed placement, used for speed only — the protocol is correct under any
+// placement), and the XCDs work through their shares of the grid at their own pace.  A group of 64 CONSECUTIVE blocks spans all
+// eight XCDs, and its closing block then waits for the slowest of them while it holds a CU slot of a faster one: measured
+// (round 5, same-process A/B) +5 % on C4, +1 % on C5a instead of the gain.  So a group is 64 blocks of ONE residue class:
+// x = b % 8, j = b / 8, group (x, q = j / 64), member l = j % 64; its closing block is the member with l = 63 or the last block
+// of the residue class.  Slot of block b: (q * 8 + x) * 64 + l (contiguous per group: one 512-byte run per poll).
+__device__ __forceinline__ void block_publish_sentinel(double acc, double* red, const BjxFin& f) {
+  acc = group_sum<64>(acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  if (nw > 1) {
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+  }
+  if (wave != 0) return;
+  const unsigned n = gridDim.x, b = blockIdx.x;
+  const unsigned x = b & 7u, j = b >> 3;
+  const unsigned cnt_x = (n - x + 7u) >> 3;              // blocks of this residue class (>= 1: b is one of them)
+  const unsigned q = j >> 6, l = j & 63u, g = q * 8u + x;
+  if (lane == 0) {
+    double s = acc;
+    if (nw > 1) { s = 0.0; for (int w = 0; w < nw; ++w) s += red[w]; }
+    fin_publish(&f.partials[g * 64u + l], s);
+  }
+  if (!(l == 63u || j == cnt_x - 1)) return;
+  const unsigned members = cnt_x - q * 64u < 64u ? cnt_x - q * 64u : 64u;
+  double v = (unsigned)lane < members ? fin_poll(&f.partials[g * 64u + lane]) : 0.0;
+  v = group_sum<64>(v);
+  if (lane == 0) fin_publish(&f.l2[g], v);
+  if (b != n - 1) return;
+  // the last block: every (x, q) that has members, in the fixed order k = q * 8 + x
+  const unsigned cnt_0 = (n + 7u) >> 3;                   // the largest residue class
+  const unsigned nk = ((cnt_0 + 63u) >> 6) * 8u;          // <= 1032 for 65 536 blocks
+  double t = 0.0;
+  for (unsigned k = lane; k < nk; k += 64) {
+    const unsigned xk = k & 7u, qk = k >> 3;
+    const unsigned ck = n > xk ? (n - xk + 7u) >> 3 : 0u;
+    if (qk * 64u < ck) t += fin_poll(&f.l2[k]);
+  }
+  t = group_sum<64>(t);
+  if (lane == 0) {
+    t += f.host_const;
+    if (f.dev_const) t += *f.dev_const;
+    *f.out = f.accumulate ? (*f.out + t) : t;
+  }
+}
+
 __device__ __forceinline__ void block_publish_partial_at(double acc, double* red, int* flag_lds, const BjxFin& f) {
   if (!f.partials) return;
+  if (f.l2) { block_publish_sentinel(acc, red, f); return; }
   if (!f.counter) { block_publish_partial(acc, red, f.partials); return; }
   int& is_last = *flag_lds;
   acc = group_sum<64>(acc);

@@ -2098,7 +2098,7 @@ template <class T> struct QOrderedInv {                  // ordered.jl:63-77 ; i
 template <class T, int V, int NP, class Op, int UC, int WPB = 4, int H = 1>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 8))) void quad_stream_kernel(const Op op, const T* __restrict__ x, T* __restrict__ y,
                                                                                                            T* __restrict__ ladj_ps, int64_t batch,
-                                                                                                           int accumulate, double* partials) {
+                                                                                                           int accumulate, const BjxFin fin) {
   constexpr int G = Op::G;
   constexpr int RPL = NP * V;                        // rows per lane
   constexpr int R = G * RPL;                         // rows of the column frame
@@ -2233,7 +2233,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 8))
       }
     }
   }
-  if (partials) block_publish_partial(acc, red, partials);
+  block_publish_partial(acc, red, fin);      // the sentinel hand-off (one launch per call) or the two-pass partials
 }
 
 // launch for R = G·NP·V rows; returns BJX_ERR_UNSUPPORTED-free "not taken" (1) when the shape does not fit
@@ -2251,15 +2251,15 @@ int launch_quad_stream(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_
   const int64_t cpb = 4 * (64 / G);                          // columns per block: 4 waves x 64/G columns
   const int64_t grid = (batch + cpb - 1) / cpb;
   BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
-  const bool want = Op::HAS_LADJ && (ladj_ps || ladj_sum);
-  if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)grid); if (rc) return rc; }
-  double* partials = (ladj_sum && Op::HAS_LADJ) ? ctx->partials : nullptr;
+  BjxFin fin;
+  bool second = false;
+  if (Op::HAS_LADJ) { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
+  if (fin.counter) { fin.counter = nullptr; second = true; }      // short-lived blocks: the arrival-ticket form makes every wave wait for its own stores
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
-  (void)want;
   // column slices of the re-deal: keep the wave's strip at <= ~9 KiB (4 waves per SIMD by LDS)
 #define QS(NP_) do { constexpr size_t SB_ = (size_t)(64 / G) * (size_t)(G * NP_ * VW + VW) * sizeof(T);                                                        \
     constexpr int H_ = (SB_ > 9 * 1024 && (64 / G) % 2 == 0 && ((64 / G) / 2 * (G * NP_ * VW - Op::IN_LESS)) % VW == 0 && ((64 / G) / 2 * (G * NP_ * VW - Op::OUT_LESS)) % VW == 0) ? 2 : 1; \
-    hipLaunchKernelGGL((quad_stream_kernel<T, VW, NP_, Op, 1, 4, H_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, op, in, out, ladj_ps, batch, accum, partials); } while (0)
+    hipLaunchKernelGGL((quad_stream_kernel<T, VW, NP_, Op, 1, 4, H_>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, op, in, out, ladj_ps, batch, accum, fin); } while (0)
   {
     BjxProf prof_(ctx);
     switch ((int)np) {
@@ -2277,7 +2277,7 @@ int launch_quad_stream(bjx_ctx* ctx, const Op& op, const T* in, T* out, T* ladj_
 #undef QS
   BJX_CHECK_LAUNCH(ctx);
   if (ladj_sum) {
-    if (Op::HAS_LADJ) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
+    if (Op::HAS_LADJ) return second ? bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags) : BJX_OK;
     if (!(flags & BJX_ACCUMULATE)) BJX_HIP(ctx, hipMemsetAsync(ladj_sum, 0, sizeof(double), ctx->stream));
   }
   return BJX_OK;

@@ -34,7 +34,7 @@ __all__ = [
     "PartitionMask", "Coupling", "Stacked", "NamedStacked", "Columnwise", "columnwise", "vjp", "istraining", "training", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
     "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
     "PlanarResult", "vjp_params", "row_moments", "MvNormal", "TorchBase", "TransformedDistribution", "transformed", "logpdf", "rand",
-    "CapturedStep", "kernel_timed",
+    "CapturedStep", "kernel_timed", "cache_params", "invalidate_params",
 ]
 
 PlanarResult = namedtuple("PlanarResult", ["result", "logabsdetjac"])  # planar_layer.jl:109
@@ -146,17 +146,64 @@ def kernel_timed(fn, device: Optional[torch.device] = None):
 
 
 _PARAM_WATCH: dict = {}     # id(ctx) -> [epoch, last epoch handed to the library, {data_ptr: (weakref to the tensor, _version)}]
+_PARAM_CACHE = {"on": False, "gen": 0}
+
+
+class cache_params:
+    """Opt in to the REUSE of tables derived from parameter tensors between calls: the layer-major (w, u, b) tables
+    of a PlanarLayer run, the device copy of a host-resident parameter, and — through BJX_OPT_PARAM_EPOCH (include/bjx.h) — whatever
+    the library keeps per parameter epoch.  OFF by default: a table is then rebuilt from the parameter arrays on every call, so a
+    write the host cannot see is never missed.
+
+    With the reuse on, staleness is decided from `tensor._version`, which torch bumps for every in-place operation on THAT tensor
+    object (what `torch.optim` steps and `p.add_()` / `p.copy_()` under `no_grad` do).  It does NOT see `p.data.add_(...)` (`.data`
+    is a second tensor object with its own counter), writes by other frameworks through DLPack, or raw-pointer writes — after any of
+    those call `invalidate_params()`.
+
+        bj.cache_params(True)              # process-wide
+        with bj.cache_params():            # or for a region (a sampler loop whose parameters are frozen)
+            ...
+    """
+
+    def __init__(self, enabled: bool = True):
+        self._prev = _PARAM_CACHE["on"]
+        _PARAM_CACHE["on"] = bool(enabled)
+        if not enabled:
+            invalidate_params()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        _PARAM_CACHE["on"] = self._prev
+        if not self._prev:
+            invalidate_params()
+        return False
+
+
+def invalidate_params() -> None:
+    """Forget every table derived from parameter tensors (see `cache_params`): the next call rebuilds them from the arrays."""
+    _PARAM_CACHE["gen"] += 1
+    for st in _PARAM_WATCH.values():
+        st[0] = st[0] + 1 if st[0] < (1 << 30) else 1
+        st[2].clear()
 
 
 def _note_params(ctx: "_Ctx", *tensors) -> None:
-    """BJX_OPT_PARAM_EPOCH bookkeeping (include/bjx.h): the library may keep tables it derives from parameter arrays (the spline's
-    LDS blob) while the epoch is unchanged.  torch knows when a tensor was written (`_version`) and a weak reference tells a live
-    tensor from a new one at a recycled address — so the epoch moves exactly when a parameter array that is about to be passed is
-    not the same, unwritten tensor that was passed at that address before.  Conversions that make a fresh tensor on every call
-    (a host parameter uploaded anew, a layout copy) change the epoch every time: no reuse, never a stale table."""
+    """BJX_OPT_PARAM_EPOCH bookkeeping (include/bjx.h): the library may keep tables it derives from parameter arrays while the
+    epoch is unchanged; epoch 0 (the library's default, and what this sends while `cache_params` is off) = never reuse.  With the
+    reuse on: torch knows when a tensor was written (`_version`) and a weak reference tells a live tensor from a new one at a
+    recycled address — so the epoch moves exactly when a parameter array that is about to be passed is not the same, unwritten
+    tensor that was passed at that address before.  Conversions that make a fresh tensor on every call (a host parameter uploaded
+    anew, a layout copy) change the epoch every time: no reuse, never a stale table."""
     import weakref
 
     st = _PARAM_WATCH.setdefault(id(ctx), [1, 0, {}])
+    if not _PARAM_CACHE["on"]:
+        if st[1] != 0:
+            L.check(ctx.h, L.load().bjx_set_option(ctx.h, L.BJX_OPT_PARAM_EPOCH, 0), "bjx_set_option")
+            st[1] = 0
+        return
     changed = False
     for t in tensors:
         key = t.data_ptr()
@@ -172,6 +219,18 @@ def _note_params(ctx: "_Ctx", *tensors) -> None:
     if st[1] != st[0]:
         L.check(ctx.h, L.load().bjx_set_option(ctx.h, L.BJX_OPT_PARAM_EPOCH, st[0]), "bjx_set_option")
         st[1] = st[0]
+
+
+def _mark_written(t: Optional[torch.Tensor]) -> None:
+    """The library writes through raw pointers, which torch's version counter does not see: bump it by hand for every tensor an
+    entry point was asked to write IN PLACE, so that anything keyed on `_version` (torch's own autograd checks, the parameter
+    tables above, the batch tag of InvertibleBatchNorm) notices."""
+    if t is None:
+        return
+    try:
+        torch._C._autograd._unsafe_set_version_counter([t], [t._version + 1])
+    except Exception:
+        pass
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -239,6 +298,7 @@ def _empty(rows: int, batch: int, like: torch.Tensor, vec: bool) -> torch.Tensor
         want = (rows,) if vec else (rows, batch)
         if tuple(h.shape) == want and h.dtype == like.dtype and h.device == like.device and _colmajor_dense(h):
             _OUT_HINT[-1] = None  # one use per scope
+            _mark_written(h)      # a caller-owned tensor written through its raw pointer
             return h
     if vec:
         return torch.empty(rows, dtype=like.dtype, device=like.device)
@@ -282,11 +342,12 @@ def _param(p, like: torch.Tensor) -> torch.Tensor:
         p = torch.as_tensor(p, dtype=like.dtype, device=like.device)
     if p.device != like.device or p.dtype != like.dtype:
         # host-resident (or other-dtype) parameters: upload / convert ONCE per (device, dtype) and parameter version,
-        # not on every call (a synchronous H2D copy per launch, and not capturable into a hipGraph)
+        # not on every call (a synchronous H2D copy per launch, and not capturable into a hipGraph); `invalidate_params()`
+        # drops the copy (writes through `.data` do not move `_version`)
         cache = getattr(p, "_bjx_dev", None)
         key = (like.device, like.dtype)
         hit = cache.get(key) if cache is not None else None
-        if hit is not None and hit[0] == p._version:
+        if hit is not None and hit[0] == (p._version, _PARAM_CACHE["gen"]):
             p = hit[1]
         else:
             q = p.to(device=like.device, dtype=like.dtype)
@@ -294,7 +355,7 @@ def _param(p, like: torch.Tensor) -> torch.Tensor:
                 if cache is None:
                     cache = {}
                     p._bjx_dev = cache
-                cache[key] = (p._version, q)
+                cache[key] = ((p._version, _PARAM_CACHE["gen"]), q)
             except Exception:
                 pass
             p = q
@@ -450,6 +511,7 @@ def transform_(b, x, y=None):
     ops = _fused_ops(b)
     if ops is not None:
         _run_chain(ops, x, False, False, out_y=tgt)
+        _mark_written(tgt)
         return tgt
     with _into(tgt if tgt is not x else None):
         out = transform(b, x)
@@ -465,6 +527,7 @@ def with_logabsdet_jacobian_(b, x, y=None, logjac=0.0):
     ops = _fused_ops(b)
     if ops is not None:
         _, l = _run_chain(ops, x, False, True, out_y=tgt)
+        _mark_written(tgt)
         return tgt, (l if isinstance(logjac, float) and logjac == 0.0 else logjac + l)
     with _into(tgt if tgt is not x else None):
         out, l = with_logabsdet_jacobian(b, x)
@@ -603,6 +666,7 @@ class Scale(_ChainOp):
         a = colmajor(_param(self.a, xc))
         if a.shape[0] != dim:
             raise ValueError(f"DimensionMismatch: Scale with a {tuple(a.shape)} matrix applied to {dim} rows")
+        _note_params(context(xc.device), a)      # an unchanged matrix keeps its factorisation under `cache_params` (BJX_OPT_PARAM_EPOCH)
         # scale.jl:35-36: logabsdet(a) ONCE for a matrix of columns in the reference's scalar; per-column vector otherwise
         return _call_struct("bjx_scale_matrix", x, dim, False, per_sample, want_ladj, (int(inv), _ptr(a)), (dim,),
                             flags=L.BJX_REF_VECTOR_SCALE_LADJ if per_sample is False else 0)
@@ -1092,8 +1156,8 @@ class PlanarLayer(Bijector):
             raise ValueError(f"DimensionMismatch: PlanarLayer of dimension {w.numel() // self.n_layers} applied to {dim} rows")
         if w.dim() != 2:
             return w, u, b
-        key = (w.data_ptr(), w._version, u.data_ptr(), u._version)
-        if self._tab is None or self._tab[0] != key:
+        key = (w.data_ptr(), w._version, u.data_ptr(), u._version, _PARAM_CACHE["gen"])
+        if not _PARAM_CACHE["on"] or self._tab is None or self._tab[0] != key:
             self._tab = (key, w.T.contiguous(), u.T.contiguous(), (w, u))
         return self._tab[1], self._tab[2], b
 
@@ -1151,8 +1215,8 @@ class _PlanarRun(PlanarLayer):
         for t in ws + us:
             if t.numel() != dim:
                 raise ValueError(f"DimensionMismatch: PlanarLayer of dimension {t.numel()} applied to {dim} rows")
-        key = (xc.device, xc.dtype, dim, tuple((t.data_ptr(), t._version) for t in ws + us + bs))
-        if self._tab is not None and self._tab[0] == key:
+        key = (xc.device, xc.dtype, dim, _PARAM_CACHE["gen"], tuple((t.data_ptr(), t._version) for t in ws + us + bs))
+        if _PARAM_CACHE["on"] and self._tab is not None and self._tab[0] == key:
             return self._tab[1]
         n = self.n_layers
         ctx = context(xc.device)
@@ -1225,11 +1289,29 @@ class RadialLayer(Bijector):
         return self._run(x, True, per_sample, want_ladj)
 
 
+class _BatchTag:
+    """Identity of the batch a training-mode forward call of InvertibleBatchNorm saw: the tensor OBJECT (weak reference — an address
+    is recycled by the allocator, an object is not) and its version counter (in-place writes, including the library's own, which
+    `_mark_written` reports).  `matches(x)` is False for any other tensor, for the same tensor after a write, and once the
+    forward call's tensor is gone — the pullback then RECOMPUTES the batch statistics from the x it was given (one more pass
+    over x; exact, since the statistics are a function of x alone) instead of trusting, or refusing, the saved ones."""
+    __slots__ = ("ref", "version", "shape", "dtype")
+
+    def __init__(self, x):
+        import weakref
+
+        self.ref, self.version, self.shape, self.dtype = weakref.ref(x), x._version, tuple(x.shape), x.dtype
+
+    def matches(self, x) -> bool:
+        return self.ref() is x and self.version == x._version and self.shape == tuple(x.shape) and self.dtype == x.dtype
+
+
 def _batch_tag(x):
-    return (x.data_ptr(), x._version, tuple(x.shape), x.dtype)
+    return _BatchTag(x)
 
 
 _TRAINING = [False]
+_BN_RECOMPUTE = [False]      # True while a pullback re-runs forward stages: training-mode BatchNorm keeps its moving statistics
 
 
 def istraining() -> bool:
@@ -1347,8 +1429,11 @@ class InvertibleBatchNorm(Bijector):
         # … tagged with the batch they belong to: the pullback refuses any other (two forward calls before one backward — micro-batches,
         # a validation batch, the layer used twice in a flow — would otherwise give wrong gradients without an error)
         self._batch_stats = ((self.m.double() + s1).to(x.dtype), (s2 - s1 * s1).to(x.dtype), _batch_tag(x))
+        # (a RECOMPUTATION of a forward pass — the stage inputs a composition's pullback needs — must not move m / v a second time:
+        #  momentum 0 leaves them as they are)
+        mtm = 0.0 if _BN_RECOMPUTE[0] else self.mtm
         return _call_struct("bjx_batchnorm_train_apply", x, dim, True, per_sample, want_ladj,
-                            (_ptr(b), _ptr(logs), _ptr(self.m), _ptr(self.v), self.eps, self.mtm, _ptr(stats)), (dim,))
+                            (_ptr(b), _ptr(logs), _ptr(self.m), _ptr(self.v), self.eps, mtm, _ptr(stats)), (dim,))
 
     def _wlj(self, x, per_sample, want_ladj=True):
         return self._run(x, False, per_sample, want_ladj)
@@ -2260,8 +2345,12 @@ def _vjp_params_composed(b, x, out_bar, ladj_bar=None):
     `b._stages()` (application order)."""
     stages, spans = b._plan()
     inputs = [x]
-    for st in stages[:-1]:
-        inputs.append(transform(st, inputs[-1]))
+    _BN_RECOMPUTE[0] = True
+    try:
+        for st in stages[:-1]:
+            inputs.append(transform(st, inputs[-1]))
+    finally:
+        _BN_RECOMPUTE[0] = False
     g = out_bar
     grads = [None] * spans[-1][1]
     for i in range(len(stages) - 1, -1, -1):
@@ -2516,8 +2605,8 @@ def _vjp_params_batchnorm_training(bn, x, out_bar, ladj_bar=None):
     cotangent has the two centring terms of batch normalisation plus the derivative of -½ Σℓ̄ log(v + ε):
         x̄ = γ/σ [ȳ − mean ȳ − x̂ mean(ȳ x̂)] − (Σℓ̄/N) x̂/σ,   b̄ = Σ ȳ,   l̄ogs = γ Σ ȳ x̂ + Σℓ̄
     Two passes over (ȳ, x): bjx_row_moments (Σȳ, Σȳ·x per channel) → one all-reduce of 2·dim+2 doubles when the bijector is
-    sharded (`sync`) → bjx_batchnorm_train_vjp.  Uses the batch statistics of the LAST training-mode forward call on this
-    bijector (the pullback of that call).  -> (x_bar, {"b": ..., "logs": ...})."""
+    sharded (`sync`) → bjx_batchnorm_train_vjp.  Uses the batch statistics saved by the training-mode forward call
+    when that call saw this very tensor (object identity + version), and recomputes them from x otherwise.  -> (x_bar, {"b": ..., "logs": ...})."""
     xc, dim, batch, vec = _prep(x)
     if vec:
         raise ValueError("InvertibleBatchNorm needs an input with at least 2 dimensions")
@@ -2525,12 +2614,22 @@ def _vjp_params_batchnorm_training(bn, x, out_bar, ladj_bar=None):
     if (gdim, gbatch) != (dim, batch) or gc.dtype != xc.dtype:
         raise ValueError("DimensionMismatch: out_bar must have the shape and dtype of the output")
     st = getattr(bn, "_batch_stats", None)
-    if st is None or st[0].numel() != dim or st[0].dtype != xc.dtype:
-        raise RuntimeError("training-mode pullback of InvertibleBatchNorm: run the training-mode forward pass on this batch first")
-    if st[2] != _batch_tag(x):
-        raise RuntimeError("training-mode pullback of InvertibleBatchNorm: the saved batch statistics belong to a different forward call "
-                           "(another batch went through this bijector in between, or x was modified): run the forward pass on THIS batch right before its pullback")
-    mean_b, var_b = st[0], st[1]
+    if st is not None and st[0].numel() == dim and st[0].dtype == xc.dtype and st[2].matches(x):
+        mean_b, var_b = st[0], st[1]                # the statistics of the forward call on this very tensor
+    else:
+        # another batch went through the bijector since (micro-batches, a validation batch, the layer used twice in a flow), x is
+        # a different tensor object with the same values, or it was written: the batch mean and variance are functions of x alone
+        # — recompute them from the x of THIS pullback (storage identity is not a batch identity).  The shift of the
+        # sums is the current moving mean; mean = m + Σ(x − m)/N and var = Σ(x − m)²/N − (Σ(x − m)/N)² do not depend on it.
+        stats = bn.batch_stats(x)
+        grp0 = bn._sync_group()
+        if grp0 is not False:
+            from . import shard as _shard
+
+            _shard.allreduce_logabsdetjac(stats, grp0)
+        n = stats[2 * dim]
+        s1, s2 = stats[:dim] / n, stats[dim:2 * dim] / n
+        mean_b, var_b = (_param(bn.m, xc).double() + s1).to(xc.dtype), (s2 - s1 * s1).to(xc.dtype)
     ctx = context(xc.device)
     lib = L.load()
     mom = torch.empty(2 * dim + 2, dtype=torch.float64, device=xc.device)       # (Σȳ, Σȳx, N, Σℓ̄): ONE bucket for the collective

@@ -88,23 +88,28 @@ int bjx_version(void);
 /* bytes of scratch a context holds (informational; SURVEY.md §8b "bjx_workspace_bytes") */
 size_t bjx_workspace_bytes(bjx_ctx* ctx);
 int bjx_synchronize(bjx_ctx* ctx);
-/* Tuning switches (per context).  BJX_OPT_INKERNEL_FINALIZE: 1 = the last block to arrive finishes the deterministic sum of
- * `ladj_sum` inside the hot kernel (one launch per call, grids of <= 4096 blocks) instead of the default two small follow-up
- * launches; same bits either way (tests/test_gpu_parity.py).  Default 0: on MI355X the hand-off makes every block wait for its
- * own output stores and adds a serial tail behind the slowest block, which costs more than the ~8 us of extra launches
- * (profiles/r03_finalize_ab.txt: 16.6 -> 26.1 us per call of BASELINE configs[0]). */
+/* Tuning switches (per context).  BJX_OPT_INKERNEL_FINALIZE: who finishes the deterministic sum `ladj_sum` of a call.
+ *   2 (default since round 5) = sentinel hand-off inside the hot kernel: ONE launch per call (grids of <= 65 536 blocks; larger
+ *       grids and the kernels that do not carry the epilogue fall back to 0).  Blocks publish their partial with one atomic
+ *       8-byte store and never wait; group-closing blocks and the last block poll slots that hold a sentinel between launches
+ *       (csrc/bjx_internal.h, block_publish_sentinel).  Fixed order: run-to-run identical bits.
+ *   1 = arrival ticket (round 3): the last block to ARRIVE sums (<= 4 096 blocks); every block waits for its own output stores
+ *       before it draws the ticket, which costs short kernels more than the launches it saves (profiles/r03_finalize_ab.txt).
+ *   0 = two small follow-up launches (the partials reduced by bjx_finalize*_kernel).
+ * 0 and 1 give the same bits; 2 sums in a different (fixed) order: equal to <= 1e-15 relative. */
 enum {
   BJX_OPT_INKERNEL_FINALIZE = 1,
   /* Watchdog of the library's own collective (bjx_comm_init + bjx_allreduce_sum_f64): with a communicator attached,
    * bjx_synchronize polls the stream for at most `value` milliseconds; on time-out it aborts the communicator (ncclCommAbort) and
    * returns 1000 + ncclRemoteError instead of hanging on a rank that never arrived.  0 (default) = wait for ever. */
   BJX_OPT_COLLECTIVE_TIMEOUT_MS = 2,
-  /* Parameter epoch.  Some entries derive a table from their parameter arrays with a helper launch before the hot kernel (bjx_rqs:
-   * the spline's 17 - 64 KiB LDS blob of search keys and per-bin records, 2 x 7.4 us per C3 step).  With value != 0 the library
-   * keeps such tables, keyed by the parameter POINTERS and shapes, and reuses them while the epoch is unchanged: the host promises
-   * that the memory behind a pointer it passes again has not been written since the epoch was set, and sets a different non-zero
-   * epoch (or 0) whenever it may have been (an optimiser step, a new array at a recycled address).  0 (default) = rebuild on
-   * every call — the safe setting for hosts that cannot track writes (arrays mutated in place without a version counter). */
+  /* Parameter epoch.  bjx_scale_matrix derives [A^-1 | logabsdet A] from its matrix with a helper launch before the hot kernel.
+   * With value != 0 the library keeps that factorisation, keyed by the parameter POINTER, size and dtype, and reuses it while the
+   * epoch is unchanged: the host promises that the memory behind a pointer it passes again has not been written since the epoch
+   * was set, and sets a different non-zero epoch (or 0) whenever it may have been (an optimiser step, a new array at a recycled
+   * address).  0 (default) = rebuild on every call — the safe setting for hosts that cannot track writes (arrays mutated in place
+   * without a version counter).  (Rounds 3-4 kept the spline's LDS table under this option too; since round 5 bjx_rqs builds it
+   * inside the hot kernel and needs no epoch.) */
   BJX_OPT_PARAM_EPOCH = 3
 };
 int bjx_set_option(bjx_ctx* ctx, int option, int value);

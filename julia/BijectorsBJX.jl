@@ -27,6 +27,7 @@ const VB = Bijectors.VectorBijectors
 using ChainRulesCore: ChainRulesCore, NoTangent, Tangent, unthunk
 using Distributions: Distributions
 using SparseArrays: SparseArrays
+using Random: Random
 const ROCVecOrMat{T} = Union{ROCVector{T},ROCMatrix{T}}
 const BjxFloat = Union{Float32,Float64}
 import Bijectors: transform, transform!, logabsdetjac, logabsdetjac!, with_logabsdet_jacobian, with_logabsdet_jacobian!
@@ -92,13 +93,15 @@ synchronize() = check(ccall((:bjx_synchronize, libbjx), Cint, (Ptr{Cvoid},), ctx
 workspace_bytes() = Int(ccall((:bjx_workspace_bytes, libbjx), Csize_t, (Ptr{Cvoid},), ctx().h))
 const BJX_OPT_COLLECTIVE_TIMEOUT_MS = Cint(2)
 collective_timeout!(ms::Integer) = check(ccall((:bjx_set_option, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().h, BJX_OPT_COLLECTIVE_TIMEOUT_MS, Cint(ms)), "bjx_set_option")   # watchdog of synchronize()
-# BJX_OPT_PARAM_EPOCH (include/bjx.h): a non-zero epoch lets the library keep tables derived from parameter arrays (the spline's LDS
-# blob) while it is unchanged.  ROCArrays carry no write counter, so the default stays 0 (rebuild every call); a training loop that
-# knows when it updates its parameters calls `param_epoch!(step)` after each update (any different non-zero value) to skip the
-# per-call helper launch in between.
+# BJX_OPT_PARAM_EPOCH (include/bjx.h): a non-zero epoch lets the library keep what it derives from parameter arrays with a helper
+# launch — since round 5 only the [A⁻¹ | logabsdet] factorisation behind a matrix `Scale` (the spline builds its table inside the hot
+# kernel: nothing to keep, the C3 rate of the bench line is what every caller gets).  ROCArrays carry no write counter, so the default
+# stays 0 (refactorise on every call); a loop that knows when it updates the matrix calls `param_epoch!(step)` after each update
+# (any different non-zero value).
 const BJX_OPT_PARAM_EPOCH = Cint(3)
 param_epoch!(n::Integer) = check(ccall((:bjx_set_option, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().h, BJX_OPT_PARAM_EPOCH, Cint(n)), "bjx_set_option")
-inkernel_finalize!(on::Bool) = check(ccall((:bjx_set_option, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().h, BJX_OPT_INKERNEL_FINALIZE, Cint(on)), "bjx_set_option")
+# who finishes Σ logabsdetjac: 2 (default) the sentinel hand-off inside the hot kernel, 1 the arrival ticket, 0 two follow-up launches
+inkernel_finalize!(mode::Integer) = check(ccall((:bjx_set_option, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().h, BJX_OPT_INKERNEL_FINALIZE, Cint(mode)), "bjx_set_option")
 
 dims(x::ROCVector) = (length(x), 1)
 dims(x::ROCMatrix) = size(x)
@@ -134,6 +137,9 @@ function run!(p::Plan, ::Type{T}, x, out; want_ladj::Bool=true, lps_into=nothing
     p.ladj === :scalar && return T(Array(lsum)[1])       # the reference returns a host scalar here (§8a')
     return zero(T)
 end
+
+# the same launch with the per-column log-det vector instead of the reference's scalar (what a composition with flow layers adds up)
+column_plan(p::Plan) = p.ladj === :scalar ? Plan(p.name, p.outsize, :column, p.batch, p.null_out, p.alias_ok, p.flags & ~BJX_REF_VECTOR_SCALE_LADJ, p.keep, p.launch) : p
 
 # ---------------------------------------------------------------- F1: fused elementwise chains
 # Walk `outer ∘ inner` into application order; nothing => not fusable, use the generic method.
@@ -584,6 +590,25 @@ function pieces(b::ComposedFunction)
     return out
 end
 piece_wlj(pc, x) = (r = with_logabsdet_jacobian(pc, x); (r[1], r[2]))          # the flow layers return NamedTuples: by position
+# Mixed shapes (ADVICE r04): a fused elementwise run returns ONE scalar for a matrix (the sum over all columns, §8a'), the flow
+# layers / Ordered / BatchNorm a per-column vector — `scalar + vector` is a MethodError (in the reference too: composed.jl:12-15
+# adds whatever the stages return), and broadcasting it would add the TOTAL to every column.  When any piece of a composition on a
+# matrix is of the per-column kind, every planned piece is run with its per-column plan (`column_plan`), so the sum is the
+# per-column log-det of the whole composition.
+const PerColumnKind = Union{PlanarRun,PlanarLayer,Inverse{<:PlanarLayer},RadialLayer,Inverse{<:RadialLayer},InvertibleBatchNorm,Inverse{<:InvertibleBatchNorm},
+    OrderedBijector,Inverse{OrderedBijector}}
+wants_columns(pcs, x) = x isa ROCMatrix && any(pc -> pc isa PerColumnKind, pcs)
+function piece_wlj_columns(pc, x::ROCMatrix{T}) where {T}
+    p = pc isa Planned ? plan(pc, x) : nothing
+    (p === nothing || p.ladj !== :scalar) && return piece_wlj(pc, x)
+    y = similar(x, T, p.outsize)
+    return y, run!(column_plan(p), T, x, y)
+end
+add_ladj(::Nothing, l) = l
+add_ladj(a::Number, b::Number) = a + b
+add_ladj(a::AbstractVector, b::AbstractVector) = a .+ b
+add_ladj(a::Number, b::AbstractVector) = iszero(a) ? b : throw(ArgumentError("composition on a matrix: a stage returned the scalar log-det $(a) next to per-column log-dets; plan that stage per column"))
+add_ladj(a::AbstractVector, b::Number) = add_ladj(b, a)
 
 # the six interface methods for a composition that is NOT one fused elementwise chain: piece by piece
 function with_logabsdet_jacobian(b::ComposedFunction, x::ROCArray{T}) where {T<:BjxFloat}
@@ -592,10 +617,11 @@ function with_logabsdet_jacobian(b::ComposedFunction, x::ROCArray{T}) where {T<:
         y = similar(x, T, p.outsize)
         return y, run!(p, T, x, y)
     end
-    cur = x; total = nothing
-    for pc in pieces(b)
-        cur, l = piece_wlj(pc, cur)
-        total = total === nothing ? l : total + l                              # ChangesOfVariables' rule for ∘: ladj_inner + ladj_outer
+    pcs = pieces(b); cur = x; total = nothing
+    col = wants_columns(pcs, x)
+    for pc in pcs
+        cur, l = col ? piece_wlj_columns(pc, cur) : piece_wlj(pc, cur)
+        total = add_ladj(total, l)                                             # ChangesOfVariables' rule for ∘: ladj_inner + ladj_outer
     end
     return cur, total
 end
@@ -612,12 +638,13 @@ function logabsdetjac(b::ComposedFunction, x::ROCArray{T}) where {T<:BjxFloat}
     p = plan(b, x)
     p === nothing || return run!(p, T, x, nothing)
     pcs = pieces(b); cur = x; total = nothing
+    col = wants_columns(pcs, x)
     for pc in pcs[1:(end - 1)]                                                 # composed.jl:12-15: values of every piece but the last
-        cur, l = piece_wlj(pc, cur)
-        total = total === nothing ? l : total + l
+        cur, l = col ? piece_wlj_columns(pc, cur) : piece_wlj(pc, cur)
+        total = add_ladj(total, l)
     end
-    l = logabsdetjac(pcs[end], cur)
-    return total === nothing ? l : total + l
+    l = col ? last(piece_wlj_columns(pcs[end], cur)) : logabsdetjac(pcs[end], cur)
+    return add_ladj(total, l)
 end
 function transform!(b::ComposedFunction, x::ROCArray{T}, y::ROCArray{T}) where {T<:BjxFloat}
     p = plan(b, x)
@@ -834,6 +861,46 @@ function with_logabsdet_jacobian(t::VB.ProductVecInvTransform{<:VB.Elementwise{<
     return reshape(x, t.transforms.size..., size(y, 2)), lps
 end
 (t::VB.ProductVecInvTransform{<:VB.Elementwise{<:ScalarLink,Dims{M}},Nothing,Dims{0}})(y::ROCMatrix{<:BjxFloat}) where {M} = first(with_logabsdet_jacobian(t, y))
+
+# HETEROGENEOUS products of univariate components (src/vector/product/product.jl:95-131, 381-395: `product_distribution((d1, d2, …))`
+# / a NamedTuple of univariate distributions whose links differ): component i owns row i of the (P, n_chains) matrix and its own
+# scalar link (wrapped in VectWrap on the way to the linked vector, OnlyWrap on the way back, univariate.jl:7-30).  One bjx_stacked
+# launch over all chains: one segment per run of consecutive components with the same link (<= 4 ops each); the log-det of a
+# chain is its column's entry (the reference's scalar, per chain).
+const WrappedLink = Union{VB.VectWrap{<:ScalarLink},VB.OnlyWrap{<:ScalarLink}}
+function product_segments(links)
+    segs = BjxSegment[]; lo = 0
+    while lo < length(links)
+        hi = lo + 1
+        while hi < length(links) && links[hi + 1] == links[lo + 1]
+            hi += 1
+        end
+        o = scalar_ops(links[lo + 1].bijector)
+        length(o) <= 4 || return nothing
+        push!(segs, BjxSegment(lo, lo, hi - lo, Int32(length(o)), 0, ntuple(k -> k <= length(o) ? o[k] : NOOP, 4)))
+        lo = hi
+    end
+    return segs
+end
+function product_launch(links, x::ROCMatrix{T}) where {T<:BjxFloat}
+    P, n = size(x)
+    P == length(links) || throw(DimensionMismatch("expected $(length(links)) rows (one per component, one column per chain), got $P"))
+    segs = product_segments(links)
+    segs === nothing && throw(ArgumentError("a component link needs more than 4 fused ops"))
+    y = similar(x); lps = similar(x, T, n)
+    GC.@preserve segs x y lps check(ccall((:bjx_stacked, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, UInt32),
+        ctx().h, dtype(T), segs, length(segs), devptr(x), devptr(y), devptr(lps), C_NULL, P, n, UInt32(0)), "bjx_stacked")
+    return y, lps
+end
+const LinkTuple{P} = Union{NTuple{P,WrappedLink},NamedTuple{<:Any,<:NTuple{P,WrappedLink}}}
+with_logabsdet_jacobian(t::VB.ProductVecTransform{<:LinkTuple{P},<:Any,Tuple{}}, x::ROCMatrix{<:BjxFloat}) where {P} = product_launch(collect(values(t.transforms)), x)
+with_logabsdet_jacobian(t::VB.ProductVecInvTransform{<:LinkTuple{P},<:Any,Tuple{}}, y::ROCMatrix{<:BjxFloat}) where {P} = product_launch(collect(values(t.transforms)), y)
+(t::VB.ProductVecTransform{<:LinkTuple{P},<:Any,Tuple{}})(x::ROCMatrix{<:BjxFloat}) where {P} = first(with_logabsdet_jacobian(t, x))
+(t::VB.ProductVecInvTransform{<:LinkTuple{P},<:Any,Tuple{}})(y::ROCMatrix{<:BjxFloat}) where {P} = first(with_logabsdet_jacobian(t, y))
+# arrays of univariate components with differing links (`product_distribution([d1, d2, …])` → AbstractArray of wrapped links)
+with_logabsdet_jacobian(t::VB.ProductVecTransform{<:AbstractArray{<:WrappedLink},<:Any,Tuple{}}, x::ROCMatrix{<:BjxFloat}) = product_launch(vec(collect(t.transforms)), x)
+with_logabsdet_jacobian(t::VB.ProductVecInvTransform{<:AbstractArray{<:WrappedLink},<:Any,Tuple{}}, y::ROCMatrix{<:BjxFloat}) = product_launch(vec(collect(t.transforms)), y)
 
 # Stacked with Simplex / Ordered segments (stacked.jl:142-166) without slicing copies: the elementwise segments in one
 # bjx_stacked_ld launch between matrices of different heights (identity placeholders on the structured rows), then
@@ -1341,52 +1408,125 @@ replay(g::Graph) = check(ccall((:bjx_graph_launch, libbjx), Cint, (Ptr{Cvoid}, P
 # src/transformed_distribution.jl:164-169 in ONE pass over y: the inverse chain, the whitening of the diagonal-normal
 # base and the standard-normal density are ops of the same launch; the pre-image is not stored (y pointer = C_NULL).
 diag_normal(d::Distributions.MvNormal) = d.Σ isa Union{Distributions.PDMats.PDiagMat,Distributions.PDMats.ScalMat}
-function Distributions.logpdf(td::Bijectors.MvTransformed{<:Distributions.MvNormal}, y::ROCMatrix{T}) where {T<:BjxFloat}
-    diag_normal(td.dist) || return invoke(Distributions.logpdf, Tuple{Bijectors.MvTransformed,AbstractMatrix}, td, y)
+
+# ---- the base density on device columns: the extension point for ANY base (the Python mirror's `TorchBase`).
+# `base_logpdf(d, x::ROCMatrix) -> ROCVector` (one value per column).  Methods here: a diagonal MvNormal (one fused launch: whitening
+# + standard-normal density as ops of bjx_chain), a full-covariance MvNormal (whitening = the matrix Scale of scale.jl:14-36 with
+# L⁻¹, then the same density op), and the fall-back: Distributions' own `logpdf(d, x)` on the device array (generic array code of
+# the base — correct for every distribution whose logpdf is written with array operations; define a method for yours otherwise).
+function stdnormal_chain(x::ROCMatrix{T}, pre::Vector{BjxOp}, keep) where {T<:BjxFloat}
+    d, n = size(x); lp = similar(x, T, n)
+    o = vcat(pre, BjxOp(Int32(OP_STDNORMAL_LOGPDF), 0, 0, 0, C_NULL, C_NULL))
+    GC.@preserve keep x lp o check(ccall((:bjx_chain, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{BjxOp}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        ctx().h, dtype(T), o, length(o), devptr(x), C_NULL, devptr(lp), C_NULL, d, n, UInt32(0)), "bjx_chain")
+    return lp
+end
+function base_logpdf(d::Distributions.MvNormal, x::ROCMatrix{T}) where {T<:BjxFloat}
     keep = Any[]
-    o = ops(inverse(td.transform), T, keep)
-    d, n = dims(y)
-    lp = similar(y, n)
-    μ, σ = td.dist.μ, sqrt.(Array(Distributions.PDMats.diag(td.dist.Σ)))
-    if o !== nothing && length(o) + 3 <= 8
-        o = vcat(o, param_op(OP_SHIFT, -μ, T, keep), param_op(OP_SCALE_INV, σ, T, keep),
-                 BjxOp(Int32(OP_STDNORMAL_LOGPDF), 0, 0, 0, C_NULL, C_NULL))
-        GC.@preserve keep y lp check(ccall((:bjx_chain, libbjx), Cint,
-            (Ptr{Cvoid}, Cint, Ptr{BjxOp}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
-            ctx().h, dtype(T), o, length(o), devptr(y), C_NULL, devptr(lp), C_NULL, d, n, UInt32(0)), "bjx_chain")
-        return lp
+    if diag_normal(d)
+        σ = sqrt.(Array(Distributions.PDMats.diag(d.Σ)))
+        return stdnormal_chain(x, [param_op(OP_SHIFT, -d.μ, T, keep), param_op(OP_SCALE_INV, σ, T, keep)], keep)
     end
-    # a PlanarLayer with a standard-normal base: the inverse flow with BJX_BASE_STDNORMAL, pre-image not stored
-    if all(iszero, μ) && all(isone, σ)
-        tr = td.transform
-        pcs = tr isa ComposedFunction ? pieces(tr) : Any[tr]                         # l8 ∘ … ∘ l1: the planner's single forward run
-        layers = length(pcs) != 1 ? nothing : pcs[1] isa PlanarLayer ? PlanarLayer[pcs[1]] : (pcs[1] isa PlanarRun && !pcs[1].inv ? pcs[1].layers : nothing)
-        if layers !== nothing
-            p = plan_planar(layers, true, y, BJX_BASE_STDNORMAL)
-            return run!(p, T, y, nothing)
+    # Σ = L Lᵀ: z = L⁻¹ (x − μ), log N(x; μ, Σ) = log N(z; 0, I) − logabsdet L
+    Lc = ROCArray{T}(Matrix(Distributions.PDMats.cholesky(d.Σ).L)); push!(keep, Lc)
+    xc = similar(x)
+    o = [param_op(OP_SHIFT, -d.μ, T, keep)]
+    GC.@preserve keep x xc o check(ccall((:bjx_chain, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{BjxOp}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        ctx().h, dtype(T), o, length(o), devptr(x), devptr(xc), C_NULL, C_NULL, size(x, 1), size(x, 2), UInt32(0)), "bjx_chain")
+    p = plan_scale_matrix(Lc, true, xc)
+    lj = run!(column_plan(p), T, xc, xc)                         # z in place; per-column −logabsdet L
+    return stdnormal_chain(xc, BjxOp[], keep) .+ lj
+end
+base_logpdf(d::Distributions.Distribution, x::ROCMatrix) = Distributions.logpdf(d, x)
+
+function Distributions.logpdf(td::Bijectors.MvTransformed, y::ROCMatrix{T}) where {T<:BjxFloat}
+    if td.dist isa Distributions.MvNormal && diag_normal(td.dist)
+        keep = Any[]
+        o = ops(inverse(td.transform), T, keep)
+        d, n = dims(y)
+        μ, σ = td.dist.μ, sqrt.(Array(Distributions.PDMats.diag(td.dist.Σ)))
+        if o !== nothing && length(o) + 3 <= 8
+            # ONE pass over y: the inverse chain, the whitening and the standard-normal density are ops of the same launch;
+            # the pre-image is not stored (src/transformed_distribution.jl:164-169 without its two intermediate arrays)
+            return stdnormal_chain(y, vcat(o, param_op(OP_SHIFT, -μ, T, keep), param_op(OP_SCALE_INV, σ, T, keep)), keep)
+        end
+        # a PlanarLayer flow with a standard-normal base: the inverse flow with BJX_BASE_STDNORMAL, pre-image not stored
+        if all(iszero, μ) && all(isone, σ)
+            tr = td.transform
+            pcs = tr isa ComposedFunction ? pieces(tr) : Any[tr]                         # l8 ∘ … ∘ l1: the planner's single forward run
+            layers = length(pcs) != 1 ? nothing : pcs[1] isa PlanarLayer ? PlanarLayer[pcs[1]] : (pcs[1] isa PlanarRun && !pcs[1].inv ? pcs[1].layers : nothing)
+            if layers !== nothing
+                p = plan_planar(layers, true, y, BJX_BASE_STDNORMAL)
+                return run!(p, T, y, nothing)
+            end
         end
     end
-    # anything else: x, logjac = with_logabsdet_jacobian(inverse(td.transform), y), then the base density on x
-    x, logjac = with_logabsdet_jacobian(inverse(td.transform), y)
-    return Distributions.logpdf(td.dist, x) .+ logjac
+    # any base, any planned transform: x, logjac = with_logabsdet_jacobian(inverse(td.transform), y), per COLUMN (a scalar log-det
+    # — the reference's return shape for elementwise transforms, :165-169 and its TODO — would be added to every column), then the
+    # base density on the device columns
+    itr = inverse(td.transform)
+    pcs = itr isa ComposedFunction ? pieces(itr) : Any[itr]
+    cur = y; total = nothing
+    for pc in pcs
+        cur, l = piece_wlj_columns(pc, cur)
+        total = add_ladj(total, l)
+    end
+    total isa Number && !iszero(total) && throw(ArgumentError("logpdf(td, y::ROCMatrix): the transform $(typeof(td.transform)) has no per-column log-det on the device"))
+    lp = base_logpdf(td.dist, cur)
+    return total isa Number ? lp : lp .+ total
 end
-# rand(td, n) on the device (src/transformed_distribution.jl:214-224): the base samples are drawn inside the transforming launch
-# (counter-based Philox stream keyed by (seed, global column): identical for any shard count) and never written.
-function rand_transformed(td::Bijectors.MvTransformed{<:Distributions.MvNormal}, ::Type{T}, n::Integer; seed::Integer=0, col0::Integer=0) where {T<:BjxFloat}
-    diag_normal(td.dist) || error("rand_transformed: diagonal-normal base only")
+# rand(rng, td, n) on the device (src/transformed_distribution.jl:214-224; the reference's own signature).  `BjxRNG` is the device
+# generator: the counter-based Philox stream of the library keyed by (seed, GLOBAL column, row) — identical for any shard count;
+# `col0` is this rank's first global column.  A fusable transform on a diagonal-normal base draws its samples INSIDE the
+# transforming launch (never written); every other planned transform (flows, splines, Stacked, …) and a full covariance:
+# bjx_fill_normal, colouring, then the transform over all columns (what the Python mirror's `rand` does).
+struct BjxRNG <: Random.AbstractRNG
+    seed::UInt64
+    col0::Int64
+end
+BjxRNG(seed::Integer=0; col0::Integer=0) = BjxRNG(UInt64(seed), Int64(col0))
+function base_rand(rng::BjxRNG, d::Distributions.MvNormal, ::Type{T}, n::Integer) where {T<:BjxFloat}
+    z = fill_normal!(ROCArray{T}(undef, length(d), n); col0=rng.col0, seed=rng.seed)
     keep = Any[]
-    μ, σ = td.dist.μ, sqrt.(Array(Distributions.PDMats.diag(td.dist.Σ)))
-    o = ops(td.transform, T, keep)
-    (o === nothing || length(o) + 2 > 8) && error("rand_transformed: the transform is not a fusable elementwise chain")
-    o = vcat(param_op(OP_SCALE, σ, T, keep), param_op(OP_SHIFT, μ, T, keep), o)
-    d = length(μ)
-    y = ROCArray{T}(undef, d, n)
-    check(ccall((:bjx_set_rng, libbjx), Cint, (Ptr{Cvoid}, UInt64, Int64), ctx().h, UInt64(seed), Int64(col0)), "bjx_set_rng")
-    GC.@preserve keep y check(ccall((:bjx_chain, libbjx), Cint,
+    if diag_normal(d)
+        σ = sqrt.(Array(Distributions.PDMats.diag(d.Σ)))
+        o = [param_op(OP_SCALE, σ, T, keep), param_op(OP_SHIFT, d.μ, T, keep)]
+    else
+        Lc = ROCArray{T}(Matrix(Distributions.PDMats.cholesky(d.Σ).L)); push!(keep, Lc)
+        run!(plan_scale_matrix(Lc, false, z), T, z, z; want_ladj=false)          # x = L z in place
+        o = [param_op(OP_SHIFT, d.μ, T, keep)]
+    end
+    GC.@preserve keep z o check(ccall((:bjx_chain, libbjx), Cint,
         (Ptr{Cvoid}, Cint, Ptr{BjxOp}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
-        ctx().h, dtype(T), o, length(o), C_NULL, devptr(y), C_NULL, C_NULL, d, n, BJX_INPUT_STDNORMAL), "bjx_chain")
-    return y
+        ctx().h, dtype(T), o, length(o), devptr(z), devptr(z), C_NULL, C_NULL, size(z, 1), n, UInt32(0)), "bjx_chain")
+    return z
 end
+# any other base: its own sampler on the host generator seeded from the stream's seed, uploaded (define `base_rand` for yours to stay on the device)
+base_rand(rng::BjxRNG, d::Distributions.Distribution, ::Type{T}, n::Integer) where {T<:BjxFloat} =
+    ROCArray{T}(rand(Random.Xoshiro(rng.seed + UInt64(rng.col0)), d, n))
+function Base.rand(rng::BjxRNG, td::Bijectors.MvTransformed, n::Int; eltype::Type{T}=Float32) where {T<:BjxFloat}
+    d = td.dist
+    if d isa Distributions.MvNormal && diag_normal(d)
+        keep = Any[]
+        o = ops(td.transform, T, keep)
+        if o !== nothing && length(o) + 2 <= 8
+            μ, σ = d.μ, sqrt.(Array(Distributions.PDMats.diag(d.Σ)))
+            o = vcat(param_op(OP_SCALE, σ, T, keep), param_op(OP_SHIFT, μ, T, keep), o)
+            y = ROCArray{T}(undef, length(μ), n)
+            check(ccall((:bjx_set_rng, libbjx), Cint, (Ptr{Cvoid}, UInt64, Int64), ctx().h, rng.seed, rng.col0), "bjx_set_rng")
+            GC.@preserve keep y o check(ccall((:bjx_chain, libbjx), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{BjxOp}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+                ctx().h, dtype(T), o, length(o), C_NULL, devptr(y), C_NULL, C_NULL, length(μ), n, BJX_INPUT_STDNORMAL), "bjx_chain")
+            return y
+        end
+    end
+    x = base_rand(rng, d, T, n)
+    return td.transform === identity ? x : transform(td.transform, x)               # a planned flow: ONE launch over all columns (:215-224 loops over columns)
+end
+# round-4 spelling, kept for callers of that round
+rand_transformed(td::Bijectors.MvTransformed, ::Type{T}, n::Integer; seed::Integer=0, col0::Integer=0) where {T<:BjxFloat} = rand(BjxRNG(seed; col0=col0), td, Int(n); eltype=T)
 
 # ---------------------------------------------------------------- multi-GPU (one process per GPU)
 comm_unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:bjx_comm_unique_id, libbjx), Cint, (Ptr{Cvoid},), id), "bjx_comm_unique_id"); id)

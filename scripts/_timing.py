@@ -31,3 +31,21 @@ def kernel_ms(bj, fn, steps=10, warm=3, device=None):
     ms, n = C.c_float(0), C.c_int(0)
     bj._lib.check(ctx.h, lib.bjx_kernel_time_end(ctx.h, C.byref(ms), C.byref(n)), "bjx_kernel_time_end")
     return ms.value / steps
+
+
+def kernel_and_region_ms(bj, fn, steps=10, warm=3, device=None):
+    """-> (average summed dominant-kernel ms, average STREAM-REGION ms) of one fn() call, from two separate passes after ONE
+    pre-roll: the region pass has a single hipEvent pair around all `steps` calls, so it contains every helper launch (parameter
+    preparation, finalize) and every gap — the cost a caller sees on the stream (a row whose helper launch
+    costs as much as its hot kernel must say so)."""
+    k = kernel_ms(bj, fn, steps=steps, warm=warm, device=device)
+    lib = bj._lib.load()
+    ctx = bj.context(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    torch.cuda.synchronize()
+    lib.bjx_time_begin(ctx.h)
+    for _ in range(steps):
+        fn()
+    ms = C.c_float(0)
+    lib.bjx_time_end(ctx.h, C.byref(ms))
+    torch.cuda.synchronize()
+    return k, ms.value / steps

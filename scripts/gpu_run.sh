@@ -41,12 +41,12 @@ rows)
   F=$1; shift
   [ $# -eq 0 ] && set -- "BJX_NOOP=0"
   for e in "$@"; do
-    echo "== [$e]"; env $e python scripts/bench_rows.py --only "$F" --steps 10 2>/dev/null | grep "^| " | grep -v "^| row\|^|---" | cut -d'|' -f2,4,8
+    echo "== [$e]"; env $e python scripts/bench_rows.py --only "$F" --steps 10 2>/dev/null | grep "^| " | grep -v "^| row\|^|---" | cut -d'|' -f2,4,8,10
   done ;;
 ab)
   F=$1; OLD=$2; NEW=$3
   for so in $OLD $NEW; do
-    echo "== $so"; BJX_LIB_PATH=$R/$so python scripts/bench_rows.py --only "$F" --steps 10 2>/dev/null | grep "^| " | grep -v "^| row\|^|---" | cut -d'|' -f2,4,8
+    echo "== $so"; BJX_LIB_PATH=$R/$so python scripts/bench_rows.py --only "$F" --steps 10 2>/dev/null | grep "^| " | grep -v "^| row\|^|---" | cut -d'|' -f2,4,8,10
   done ;;
 pmc)
   WL=$1; KS=$2; shift 2; i=0

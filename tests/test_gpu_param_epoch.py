@@ -12,6 +12,13 @@ pytestmark = pytest.mark.gpu
 from test_gpu_parity import bj, dev, host, rng  # noqa: E402,F401
 
 
+@pytest.fixture(autouse=True)
+def _reuse_on(bj):
+    """The reuse of parameter tables is opt-in since round 5: these tests are about the opted-in behaviour."""
+    with bj.cache_params():
+        yield
+
+
 def _spline(bj, r, dim=32, K=16):
     raw = [torch.tensor(r.normal(size=(dim, k)).astype(np.float32)).cuda() for k in (K, K, K - 1)]
     return bj.RationalQuadraticSpline(raw[0], raw[1], raw[2], 3.0)

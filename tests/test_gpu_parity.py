@@ -3118,11 +3118,12 @@ def test_batchnorm_training_pullback(bj, orc, dim, N, dt):
     g, lb = np.asfortranarray(r.normal(size=(dim, N)).astype(dt)), r.normal(size=N).astype(dt)
     bn = bj.InvertibleBatchNorm(torch.tensor(b), torch.tensor(logs), torch.zeros(dim, dtype=torch.from_numpy(b).dtype), torch.ones(dim, dtype=torch.from_numpy(b).dtype), eps=1e-5, mtm=0.1)
     with bj.training():
-        with pytest.raises(RuntimeError):
-            bj.vjp_params(bn, dev(x), dev(g), dev(lb))                # no forward pass yet: no batch statistics to differentiate
-        bj.with_logabsdet_jacobian(bn, dev(x))
-        xb, grads = bj.vjp_params(bn, dev(x), dev(g), dev(lb))
-        xb2 = bj.vjp(bn, dev(x), dev(g), dev(lb))
+        xb0, _ = bj.vjp_params(bn, dev(x), dev(g), dev(lb))           # no forward pass yet: the batch statistics are recomputed from x
+        xd = dev(x)
+        bj.with_logabsdet_jacobian(bn, xd)
+        xb, grads = bj.vjp_params(bn, xd, dev(g), dev(lb))            # the statistics saved by the forward call on this very tensor
+        xb2 = bj.vjp(bn, xd, dev(g), dev(lb))
+    close(host(xb0), host(xb).astype(np.float64), dt, scale=max(float(np.abs(host(xb)).max()), 1.0) * (4 if dt == np.float32 else 1), what="x_bar, recomputed statistics")
     xr, br, lr = orc.batchnorm_train_vjp(logs.astype(np.float64), 1e-5, x, g, lb)
     scale = float(np.abs(xr).max())
     close(host(xb), xr, dt, scale=max(scale, 1.0) * (4 if dt == np.float32 else 1), what="x_bar")

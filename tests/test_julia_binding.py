@@ -318,3 +318,96 @@ def test_the_composition_planner_exists_in_the_binding():
         assert re.search(pat, j), pat
     for link in ("VB.Exp", "VB.Log", "VB.Truncate", "VB.Untruncate", "VB.TypedIdentity"):
         assert re.search(r"^scalar_ops\(\w*::" + re.escape(link) + r"\)", j, flags=re.M), link
+
+
+# ---------------------------------------------------------------- dispatch table (round 5)
+_BASE_NAMES = {
+    "Any", "Nothing", "Bool", "Integer", "Int", "Int32", "Int64", "UInt8", "UInt32", "UInt64", "Real", "Number", "Float32", "Float64", "Type", "Symbol", "String", "Function",
+    "Tuple", "NTuple", "NamedTuple", "Vararg", "Union", "Vector", "Matrix", "Array", "AbstractVector", "AbstractMatrix", "AbstractArray", "AbstractUnitRange", "UnitRange",
+    "Dims", "Ptr", "Cvoid", "Cint", "Cdouble", "Cfloat", "Csize_t", "Ref", "typeof", "ComposedFunction", "Base", "T", "M", "N", "P", "names", "AbstractRNG",
+}
+
+
+def _method_heads(j):
+    """(function name, [argument type expressions]) of every method definition at top level whose name is one of the reference's generic functions"""
+    names = r"(?:Distributions\.logpdf|Base\.rand|with_logabsdet_jacobian!?|transform!?|logabsdetjac!?|plan)"
+    heads = []
+    for m in re.finditer(r"^(?:function\s+)?(" + names + r")\(", j, flags=re.M):
+        i, depth = m.end(), 1
+        while depth and i < len(j):
+            depth += {"(": 1, ")": -1}.get(j[i], 0)
+            i += 1
+        args, cur, d2 = [], "", 0
+        for c in j[m.end():i - 1].split(";")[0]:
+            if c == "," and d2 == 0:
+                args.append(cur)
+                cur = ""
+            else:
+                d2 += {"{": 1, "(": 1, "}": -1, ")": -1}.get(c, 0)
+                cur += c
+        args.append(cur)
+        types = [re.sub(r"\s+", "", a.split("::", 1)[1].split("=")[0]) if "::" in a else "Any" for a in args if a.strip()]
+        heads.append((m.group(1), types, j.count("\n", 0, m.start()) + 1))
+    return heads
+
+
+def test_every_type_in_a_method_signature_resolves():
+    """Every type name in the signature of a method that extends one of the reference's generic functions is a Base name, a name the
+    file defines (struct / const), a name it imports (`using X: a, b`), or qualified by a module it imports — a typo there is a
+    method that silently never matches (or an UndefVarError at load)."""
+    j = _strip_julia(_julia())
+    defined = set(re.findall(r"^(?:mutable\s+)?struct\s+(\w+)", j, flags=re.M)) | set(re.findall(r"^const\s+(\w+)", j, flags=re.M))
+    imported, modules = set(), set()
+    for m in re.finditer(r"^using\s+(\w+)\s*(?::\s*((?:[^\n]|\n\s{4,})*))?", j, flags=re.M):
+        modules.add(m.group(1))
+        if m.group(2):
+            imported |= {t.strip() for t in re.split(r"[,\s]+", m.group(2)) if t.strip()}
+    modules |= set(re.findall(r"^const\s+(\w+)\s*=\s*\w+(?:\.\w+)+\s*$", j, flags=re.M))          # module aliases (const VB = Bijectors.VectorBijectors)
+    known = _BASE_NAMES | defined | imported | modules
+    bad = []
+    for name, types, line in _method_heads(j):
+        for t in types:
+            for tok in re.findall(r"(?<![\w.])([A-Z]\w*(?:\.\w+)*)", t):
+                head = tok.split(".")[0]
+                if head not in known:
+                    bad.append((line, name, tok))
+    assert not bad, f"unresolved type names in method signatures: {bad[:12]}"
+    # the names taken from Bijectors exist in the reference (a renamed type upstream would make the method dead code)
+    ref_src = "/root/reference/src"
+    if os.path.isdir(ref_src):
+        text = ""
+        for dp, _, fs in os.walk(ref_src):
+            for f in fs:
+                if f.endswith(".jl"):
+                    text += open(os.path.join(dp, f)).read()
+        first_using = re.search(r"^using Bijectors:\s*((?:[^\n]|\n\s{4,})*)", j, flags=re.M).group(1)
+        for nm in {t.strip() for t in re.split(r"[,\s]+", first_using) if t.strip()}:
+            assert re.search(r"\b" + re.escape(nm) + r"\b", text), f"`using Bijectors: {nm}`: no such name in the reference"
+        for nm in set(re.findall(r"\bVB\.(\w+)", j)):
+            assert re.search(r"\b(?:struct|function|const|abstract type)\s+" + re.escape(nm) + r"\b|^" + re.escape(nm) + r"\(", text, flags=re.M), f"VB.{nm}: no such name in src/vector"
+
+
+def test_no_two_methods_share_a_signature():
+    """Two definitions of one function with the same argument types: the second silently replaces the first."""
+    j = _strip_julia(_julia())
+    seen = {}
+    for name, types, line in _method_heads(j):
+        key = (name, tuple(types))
+        assert key not in seen, f"{name}({', '.join(types)}) is defined at lines {seen[key]} and {line}"
+        seen[key] = line
+
+
+def test_rand_and_logpdf_use_the_references_spellings():
+    """src/transformed_distribution.jl:159-224: `logpdf(td::MvTransformed, y::AbstractMatrix)` for ANY base and
+    `rand(rng::AbstractRNG, td::MvTransformed, n::Int)` — the binding extends exactly those (a device RNG type carries seed and
+    first global column), with `base_logpdf` / `base_rand` as the extension points for other bases."""
+    j = _strip_julia(_julia())
+    assert re.search(r"struct BjxRNG <: Random\.AbstractRNG", j)
+    assert re.search(r"function Base\.rand\(rng::BjxRNG, td::Bijectors\.MvTransformed, n::Int", j)
+    assert re.search(r"function Distributions\.logpdf\(td::Bijectors\.MvTransformed, y::ROCMatrix\{T\}\)", j)
+    assert re.search(r"^base_logpdf\(d::Distributions\.Distribution, x::ROCMatrix\)", j, flags=re.M) and "function base_logpdf(d::Distributions.MvNormal" in j
+    assert "base_rand(rng::BjxRNG, d::Distributions.Distribution" in j and "function base_rand(rng::BjxRNG, d::Distributions.MvNormal" in j
+    # mixed scalar / per-column log-dets of a composition are resolved per column, never by adding a scalar to a vector
+    assert "column_plan(p::Plan)" in j and "piece_wlj_columns" in j and "add_ladj(a::Number, b::AbstractVector)" in j
+    # heterogeneous VectorBijectors products: one bjx_stacked launch
+    assert "function product_launch(links, x::ROCMatrix{T})" in j and "VB.VectWrap{<:ScalarLink}" in j
