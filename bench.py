@@ -52,7 +52,9 @@ def parse():
                    help="who all-reduces the Float64 partial Σ logabsdetjac: torch.distributed (RCCL) or the library's own "
                         "communicator (bjx_comm_init + bjx_allreduce_sum_f64: the path a Julia host takes)")
     p.add_argument("--no-rows", action="store_true", help="only the headline workload (no per-config sub-lines)")
-    p.add_argument("--rows", default="c1,c3,c4,c5a,c5b,c2_f64,c4_f64")
+    p.add_argument("--rows", default="c1,c3,c3_uncached,c4,c5a,c5b,c2_f64,c4_f64")
+    p.add_argument("--no-cache-params", action="store_true",
+                   help="do not opt into bj.cache_params: tables derived from parameters (the spline's LDS blob, the layer-major Planar tables) are rebuilt on every call")
     p.add_argument("--log2-batch", type=int, default=None, help="override the batch (testing)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-log2-batch", type=int, default=None)
@@ -608,7 +610,8 @@ def build_line(a, world, head, rows, graph_rows, strong, cpu):
         "metric": METRIC, "value": head["value"], "unit": "M samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
         "dtype": head["dtype"], "data": "synthetic (Philox N(0,1), shard-invariant)",
-        "config": dict(head["config"], parallelism=f"batch-sharded x{world}, one f64 all-reduce of Σlogabsdetjac ({a.collective})"),
+        "config": dict(head["config"], parallelism=f"batch-sharded x{world}, one f64 all-reduce of Σlogabsdetjac ({a.collective})",
+                       cache_params=not a.no_cache_params),
         "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
                                         "kernel_launches_per_step", "stream_region_ms_per_step", "algorithmic_bytes_per_launch")},
         "cpu_baseline": cpu,
@@ -698,6 +701,13 @@ def main():
     import bijectors_amd as bj
 
     env.bj = bj
+    # The workloads call their bijectors with FROZEN parameters, step after step: the case `bj.cache_params` (Julia: `param_epoch!`)
+    # exists for — tables derived from parameter arrays are kept while torch's version counters stand still.  The library's default is
+    # OFF (a write the host cannot see must never meet a kept table), so the line says `cache_params: true`, and the row
+    # `c3_uncached` is the spline with the default setting (its table rebuilt by a helper launch on every call).
+    env.cache_params = not a.no_cache_params
+    if env.cache_params:
+        bj.cache_params(True)
     if a.collective == "bjx" and world > 1:
         bj.shard.init_comm(env.device, timeout_ms=60000)   # ncclUniqueId broadcast through torch.distributed, then RCCL inside the library;
         bj.shard.use_library_collective(True)               # watchdog: a stuck collective is an error after 60 s, not a hang
@@ -710,7 +720,14 @@ def main():
         rsteps, rwarm = max(3, min(a.steps, 20)), max(1, min(a.warmup, 5))      # the sub-lines run as warm as the headline
         for r in [r for r in a.rows.split(",") if r]:
             try:
-                rows.append(measure(env, r, rsteps, rwarm, a.scaling))
+                if r.endswith("_uncached"):        # the same workload with the library's default: no reuse of parameter tables
+                    with bj.cache_params(False):
+                        row = measure(env, r[:-len("_uncached")], rsteps, rwarm, a.scaling)
+                    row["workload"] = r
+                    row["config"] = dict(row["config"], workload=row["config"]["workload"] + " — cache_params OFF (library default)")
+                    rows.append(row)
+                else:
+                    rows.append(measure(env, r, rsteps, rwarm, a.scaling))
             except Exception as e:                 # a sub-line must never cost the headline
                 rows.append({"workload": r, "error": repr(e)})
         if world > 1 and a.scaling == "weak":
@@ -739,7 +756,7 @@ def main():
             except Exception as e:  # the baseline is informational; never lose the GPU number
                 cpu = {"value": None, "unit": "M samples/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
             for r in rows:
-                if "error" not in r:
+                if "error" not in r and not r["workload"].endswith("_uncached"):       # (the same CPU leg as the cached row)
                     try:
                         r["cpu_baseline"] = cpu_baseline(r["workload"], None, budget=2.5, variants=False)
                     except Exception as e:

@@ -201,6 +201,7 @@ BJX_API int bjx_destroy(bjx_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->big_ws) (void)hipFree(ctx->big_ws);
   if (ctx->scale_slot.buf) (void)hipFree(ctx->scale_slot.buf);
+  for (auto& sl : ctx->rqs_slots) if (sl.buf) (void)hipFree(sl.buf);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->prof_ev) {
@@ -215,6 +216,7 @@ BJX_API int bjx_set_stream(bjx_ctx* ctx, void* hip_stream) {
   if (!ctx) return BJX_ERR_ARG;
   ctx->stream = static_cast<hipStream_t>(hip_stream);
   ctx->scale_slot.epoch = 0;          // cached parameter tables were built on the old stream: rebuild on first use
+  for (auto& sl : ctx->rqs_slots) sl.epoch = 0;
   return BJX_OK;
 }
 

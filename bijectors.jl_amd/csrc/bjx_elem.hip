@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void rqs_params_kernel(const T* rw, const T* r
 //  * lets one block walk ITER column groups so the table staging is amortised.
 // Bin selection is exact (same knot values and comparisons as the oracle).
 //
-// LDS blob (built by every block for itself: rqs_build_blob_lds), key part in units of T:
+// LDS blob (built by rqs_blob_kernel in the context scratch, copied verbatim), key part in units of T:
 //   [0, dimp)                         lim[rp]          = knot K (range limit) of permuted row rp
 //   [dimp·2^(l-1), dimp·2^l)          level l keys     [rp][2^(l-1)],  l = 1..NSTEP
 // then the bin records in 256-byte LDS rows of sixteen 16-byte slots.  A lane always reads slot (lane & 15): the
@@ -191,48 +191,54 @@ template <class T> __device__ __forceinline__ int rqs_rec_base(const RqsGeom& g,
   return (int)rqs_key_bytes<T>(g) + (((j * g.GH + hi) * g.nslots) << RqsRec<T>::PS) + (lane & 15) * 16;
 }
 
-// The table is built by EVERY block straight into its LDS (round 5; rounds 2-4 built it once per call with a one-block helper launch
-// into the context scratch, copied it per block, and in round 4 kept it per parameter epoch): no helper launch, no blob in global
-// memory, nothing to keep between calls — a caller that cannot track parameter writes (Julia arrays, `p.data` updates: ADVICE r04)
-// gets the same call as one that can.  Per C3 block: 1 632 knot values from L2 instead of the 34 KiB blob, two records per thread
-// (one division and one reciprocal each) against 256 elements per thread of evaluation.
-//   skip0 = 1 iff knot 1 <= -knot K for widths and heights of every row (bin 0 unreachable, only evaluated when `dual`).
-// Returns skip0; ends with a barrier.
+// One block: (i) flag[0] = 1 iff knot 1 <= -knot K for widths and heights of every row (bin 0
+// unreachable, only evaluated when `dual`), (ii) the LDS blob in the layout above.
 template <class T, bool INV>
-__device__ __forceinline__ int rqs_build_blob_lds(const T* __restrict__ w, const T* __restrict__ h, const T* __restrict__ d, int K1, int64_t rows, int V,
-                                                  int nstep_hi, int dual, int G, int64_t tstride, T* __restrict__ blob) {
+__global__ __launch_bounds__(256) void rqs_blob_kernel(const T* w, const T* h, const T* d, int K1, int64_t rows, int V, int nstep_hi,
+                                                       int dual, int G, int* flag, T* blob, int64_t tstride = 0) {
+  // `rows` rows of the knot tables starting at w / h / d; `tstride` = rows of the WHOLE tables when this is a row slab of a
+  // taller spline (knot j of row r is w[(j-1)*tstride + r]); 0 = the tables have exactly `rows` rows
   const int64_t ts = tstride ? tstride : rows;
-  int bad = 0;
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
   if (dual) {
     for (int64_t r = threadIdx.x; r < rows; r += blockDim.x)
       if (!(w[r] <= -w[(int64_t)(K1 - 1) * ts + r]) || !(h[r] <= -h[(int64_t)(K1 - 1) * ts + r])) bad = 1;
-    bad = __syncthreads_or(bad);
   }
+  __syncthreads();
   const int skip0 = (dual && !bad) ? 1 : 0;
+  if (threadIdx.x == 0 && blockIdx.x == 0) flag[0] = skip0;
   const RqsGeom g = rqs_geom(K1, rows, V, skip0, nstep_hi, G);
   const int nkeys = (1 << g.nstep) - 1;
   const int per_row = nkeys > 1 ? nkeys : 1;
-  const int total = g.dimp * per_row;
-  for (int i = threadIdx.x; i < total; i += blockDim.x) {
-    const int rp = i / per_row, s = i - rp * per_row;
+  const int64_t total = (int64_t)g.dimp * per_row;
+  // (round 5: the items are dealt over the blocks of the launch — one block took 7.4 us, four dependent global reads per thread)
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, tstep = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = t0; i < total; i += tstep) {
+    const int rp = (int)(i / per_row), s = (int)(i % per_row);
     const int64_t r = (int64_t)(rp % g.nvc) * g.V + rp / g.nvc;   // actual row
     const bool live = rp < g.V * g.nvc && r < rows;
-    if (s == 0) blob[rp] = live ? (INV ? h[(int64_t)(K1 - 1) * ts + r] : w[(int64_t)(K1 - 1) * ts + r]) : T(0);
+    auto W = [&](int j) { return w[(int64_t)(j - 1) * ts + r]; };   // 1-based knot j of row r
+    auto H = [&](int j) { return h[(int64_t)(j - 1) * ts + r]; };
+    if (s == 0) blob[rp] = live ? (INV ? H(K1) : W(K1)) : T(0);
     if (s < nkeys) {
+      // sorted searched key s (0-based) = knot kbase + s + 1, padded with +inf; tree position:
       const int t = __builtin_ctz(s + 1);
       const int lvl = g.nstep - t, path = (s + 1) >> (t + 1);
       T kv = Num<T>::inf;
-      if (live && s < g.nslots - 1) kv = INV ? h[(int64_t)(g.kbase + s) * ts + r] : w[(int64_t)(g.kbase + s) * ts + r];
+      if (live && s < g.nslots - 1) kv = INV ? H(g.kbase + s + 1) : W(g.kbase + s + 1);
       blob[(size_t)g.dimp * (1u << (lvl - 1)) + (size_t)rp * (1u << (lvl - 1)) + path] = kv;
     }
   }
+  // records: one per (pack element j, 16-lane slice hi, bin slot, slot of the LDS row)
   char* rec = reinterpret_cast<char*>(blob) + rqs_key_bytes<T>(g);
   constexpr int RQ = RqsRec<T>::RQ;
-  const int nrec = g.V * g.GH * g.nslots * 16;
-  for (int i = threadIdx.x; i < nrec; i += blockDim.x) {
-    const int slot = i & 15;
-    const int s = (i >> 4) % g.nslots;
-    const int jh = (i >> 4) / g.nslots;
+  const int64_t nrec = (int64_t)g.V * g.GH * g.nslots * 16;
+  for (int64_t i = t0; i < nrec; i += tstep) {
+    const int slot = (int)(i & 15);
+    const int s = (int)((i >> 4) % g.nslots);
+    const int jh = (int)((i >> 4) / g.nslots);
     const int j = jh / g.GH, hi = jh % g.GH;
     const int gl = g.G > 16 ? hi * 16 + slot : (slot & (g.G - 1));
     const int64_t r = (int64_t)gl * g.V + j;                          // actual row
@@ -242,28 +248,26 @@ __device__ __forceinline__ int rqs_build_blob_lds(const T* __restrict__ w, const
     auto D = [&](int q) { return d[(int64_t)(q - 1) * ts + r]; };
     T a[4] = {T(0), T(1), T(0), T(0)}, b[4] = {T(1), T(1), T(0), T(0)};
     if (live) {
-      const int k = s + g.kbase;
-      const T w_k = (k == 0) ? -W(K1) : W(k);
+      const int k = s + g.kbase;                                   // bin k spans knots k..k+1 (knot 0 = -knot K)
+      const T w_k = (k == 0) ? -W(K1) : W(k);                      // :140,:192
       const T wd = W(k + 1) - w_k;
       const T h_k = (k == 0) ? -H(K1) : H(k);
       const T dy = H(k + 1) - h_k;
-      const T sl = dy / wd;
+      const T sl = dy / wd;                                        // s = Δy/w
       const T d_k = (k == 0) ? T(1) : D(k);
       const T d_k1 = (k == K1 - 1) ? T(1) : D(k + 1);
-      if (!INV) { a[1] = T(1) / wd; a[0] = -w_k * a[1]; a[2] = h_k; a[3] = dy; }
+      if (!INV) { a[1] = T(1) / wd; a[0] = -w_k * a[1]; a[2] = h_k; a[3] = dy; }   // ξ = x·(1/w) − w_k/w: one FMA per element
       else { a[0] = h_k; a[1] = dy; a[2] = w_k; a[3] = wd; }
       b[0] = sl; b[1] = d_k; b[2] = d_k1 + d_k - 2 * sl; b[3] = d_k1 - d_k;
     }
     char* row0 = rec + ((((size_t)(j * g.GH + hi) * g.nslots + s) * RQ) << 8) + slot * 16;
-    constexpr int PER = 16 / (int)sizeof(T);
+    constexpr int PER = 16 / (int)sizeof(T);                           // values per 16-byte quad
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       reinterpret_cast<T*>(row0 + ((q / PER) << 8))[q % PER] = a[q];
       reinterpret_cast<T*>(row0 + ((RQ / 2 + q / PER) << 8))[q % PER] = b[q];
     }
   }
-  __syncthreads();
-  return skip0;
 }
 
 template <class T> struct Rec4 { T v[4]; };
@@ -469,14 +473,22 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
 }
 
 template <class T, int V, int NSTEP_HI, bool DUAL, bool INV>
-__global__ __launch_bounds__(256) void rqs_lds_kernel(const T* __restrict__ kw, const T* __restrict__ kh, const T* __restrict__ kd, int64_t tstride, int K1,
+__global__ __launch_bounds__(256) void rqs_lds_kernel(const T* __restrict__ blob, const int* __restrict__ flag, int K1,
                                                       const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t dim,
                                                       int64_t batch, int G, int iters, int accumulate, const BjxFin fin, int64_t ld) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // no static LDS: the reduction scratch aliases the table once every wave is done with it
+  // no static LDS: with the C3 table (32 768 bytes) five blocks fit the CU's 160 KiB only if the block asks for nothing else;
+  // the reduction scratch aliases the table once every wave is done with it
   T* blob_l = reinterpret_cast<T*>(smem);
-  const int skip0 = rqs_build_blob_lds<T, INV>(kw, kh, kd, K1, dim, V, NSTEP_HI, DUAL ? 1 : 0, G, tstride, blob_l);
+  const int skip0 = DUAL ? flag[0] : 0;
   const RqsGeom g = rqs_geom(K1, dim, V, skip0, NSTEP_HI, G);
+  {
+    const int n16 = (int)(rqs_blob_bytes<T>(g) / 16);
+    const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(blob);
+    bjx_f32x4* dst = reinterpret_cast<bjx_f32x4*>(blob_l);
+    for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+    __syncthreads();
+  }
   double acc = 0.0;
   if constexpr (DUAL) {
     if (skip0) rqs_body<T, V, NSTEP_HI - 1, INV>(blob_l, g, x, y, ladj_ps, dim, batch, G, iters, accumulate, acc, ld);
@@ -523,13 +535,20 @@ __device__ __forceinline__ T rqs_eval_vjp(const Rec4<T>& A, const Rec4<T>& B, T 
 }
 
 template <class T, int V, bool INV>
-__global__ __launch_bounds__(256) void rqs_vjp_kernel(const T* __restrict__ kw, const T* __restrict__ kh, const T* __restrict__ kd, int K1, int nstep_hi, int dual,
+__global__ __launch_bounds__(256) void rqs_vjp_kernel(const T* __restrict__ blob, const int* __restrict__ flag, int K1, int nstep_hi, int dual,
                                                       const T* __restrict__ x, const T* __restrict__ gbar, const T* __restrict__ lbar, T* __restrict__ xbar,
                                                       int64_t dim, int64_t batch, int G, int iters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* blob_l = reinterpret_cast<T*>(smem);
-  const int skip0 = rqs_build_blob_lds<T, INV>(kw, kh, kd, K1, dim, V, nstep_hi, dual, G, 0, blob_l);
+  const int skip0 = dual ? flag[0] : 0;
   const RqsGeom g = rqs_geom(K1, dim, V, skip0, nstep_hi, G);
+  {
+    const int n16 = (int)(rqs_blob_bytes<T>(g) / 16);
+    const bjx_f32x4* src = reinterpret_cast<const bjx_f32x4*>(blob);
+    bjx_f32x4* dst = reinterpret_cast<bjx_f32x4*>(blob_l);
+    for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+    __syncthreads();
+  }
   const int NS = g.nstep;
   const int gl = threadIdx.x & (G - 1), cg = threadIdx.x / G;
   const int cols_per_block = 256 / G;
@@ -794,6 +813,7 @@ template <class T> bool knots_fit_lds(int64_t rows, int K1) { return (size_t)row
 
 // largest knot blob the LDS kernels take (the default dynamic-LDS limit of a launch); beyond it the generic functor path runs
 constexpr size_t kRqsBlobMax = 64 * 1024;
+constexpr int kRqsBlobGrid = 8;           // blocks of the table-building helper launch (every block recomputes the skip flag for itself)
 // Column groups per block: enough to amortise the table staging (>= ~3x the table bytes of data; same-call sweeps at 32 x 2^22,
 // forward + inverse: 8 groups 0.53 ms, 12: 0.50, 17: 0.49, 24: 0.48, 34: 0.49, 64: 0.48, 128: 0.50).
 // Round 3, tried and dropped (profiles/r03_c3_experiments.md, same-box A/Bs): SHORT-LIVED blocks — NP = 2 / 4 column groups per block,
@@ -811,10 +831,10 @@ inline int rqs_iters(const bjx_ctx* ctx, size_t blob_bytes, int64_t bytes_per_gr
 inline int ceil_log2(int n) { int s = 0; while ((1 << s) < n) ++s; return s; }
 
 template <class T, int V, bool INV>
-int rqs_launch_lds(bjx_ctx* ctx, int nstep_hi, int dual, const T* kw, const T* kh, const T* kd, int64_t tstride, int K1, size_t smem, int64_t grid, const T* in,
+int rqs_launch_lds(bjx_ctx* ctx, int nstep_hi, int dual, const T* blob, const int* flag, int K1, size_t smem, int64_t grid, const T* in,
                    T* out, T* ladj_ps, int64_t dim, int64_t batch, int G, int iters, int accum, const BjxFin& fin, int64_t ld) {
   BjxProf prof_(ctx);
-#define RQS_L(NS_, DUAL_) hipLaunchKernelGGL((rqs_lds_kernel<T, V, NS_, DUAL_, INV>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, kw, kh, kd, tstride, K1, in, out, ladj_ps, dim, batch, G, iters, accum, fin, ld)
+#define RQS_L(NS_, DUAL_) hipLaunchKernelGGL((rqs_lds_kernel<T, V, NS_, DUAL_, INV>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, blob, flag, K1, in, out, ladj_ps, dim, batch, G, iters, accum, fin, ld)
   switch (nstep_hi * 2 + (dual ? 1 : 0)) {
     case 2: RQS_L(1, false); break;
     case 4: RQS_L(2, false); break;  case 5: RQS_L(2, true); break;
@@ -846,8 +866,32 @@ int rqs_lds_slab(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, 
   const bool lds_path = nstep_hi <= 6 && rows / c.V <= 64 && ld < (1 << 20) && blob_bytes <= kRqsBlobMax && blob_bytes + 64 <= BJX_SCRATCH_BYTES;
   if (!lds_path) return BJX_OK;
   *taken = true;
-  // (rounds 3-4 built the table with a helper launch into the context scratch and kept it per parameter epoch; since round 5
-  //  every block builds it in its own LDS: rqs_build_blob_lds)
+  int* flag = reinterpret_cast<int*>(ctx->scratch);
+  T* blob = reinterpret_cast<T*>(static_cast<char*>(ctx->scratch) + 64);
+  // BJX_OPT_PARAM_EPOCH != 0: the blob of an unchanged spline is kept (4 slots: forward and inverse tables of two splines) and the
+  // helper launch is skipped — per C3 step two launches of 7.4 us next to two hot kernels of ~220 us.
+  bool build = true;
+  if (ctx->param_epoch != 0 && !ctx->capturing) {          // (a captured step bakes pointers into the graph: it keeps the per-call build in the scratch)
+    bjx_ctx::RqsBlobSlot* hit = nullptr;
+    for (auto& sl : ctx->rqs_slots)
+      if (sl.buf && sl.epoch == ctx->param_epoch && sl.w == w && sl.h == h && sl.d == d && sl.K1 == K1 && sl.rows == rows && sl.trows == trows && sl.V == c.V &&
+          sl.nstep_hi == nstep_hi && sl.dual == dual && sl.G == c.G && sl.inverse == inverse && sl.dt == (int)sizeof(T)) { hit = &sl; break; }
+    if (hit) build = false;
+    else {
+      hit = &ctx->rqs_slots[ctx->rqs_next];
+      if (!hit->buf) { if (hipMalloc(&hit->buf, kRqsBlobMax + 64) != hipSuccess) hit->buf = nullptr; }
+      if (hit->buf) {
+        ctx->rqs_next = (ctx->rqs_next + 1) % 4;
+        *hit = bjx_ctx::RqsBlobSlot{w, h, d, K1, c.V, nstep_hi, dual, c.G, inverse, (int)sizeof(T), ctx->param_epoch, rows, trows, hit->buf};
+      } else hit = nullptr;                                   // (no buffer: the shared scratch, rebuilt every call)
+    }
+    if (hit) { flag = reinterpret_cast<int*>(hit->buf); blob = reinterpret_cast<T*>(static_cast<char*>(hit->buf) + 64); }
+  }
+  if (build) {
+    if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(kRqsBlobGrid), dim3(256), 0, ctx->stream, w, h, d, K1, rows, c.V, nstep_hi, dual, c.G, flag, blob, trows);
+    else hipLaunchKernelGGL((rqs_blob_kernel<T, false>), dim3(kRqsBlobGrid), dim3(256), 0, ctx->stream, w, h, d, K1, rows, c.V, nstep_hi, dual, c.G, flag, blob, trows);
+    BJX_CHECK_LAUNCH(ctx);
+  }
   const int cols_per_block = 256 / c.G;
   const int64_t groups = (batch + cols_per_block - 1) / cols_per_block;
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
@@ -858,10 +902,10 @@ int rqs_lds_slab(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, 
   bool second = false;
   { int rc = bjx_make_fin(ctx, grid, ladj_sum, 0.0, 0, flags, &fin, &second); if (rc) return rc; }
   int rc;
-  if (c.V == VW) rc = inverse ? rqs_launch_lds<T, VW, true>(ctx, nstep_hi, dual, w, h, d, trows, K1, blob_bytes, grid, in, out, ladj_ps, rows, batch, c.G, iters, accum, fin, ld)
-                              : rqs_launch_lds<T, VW, false>(ctx, nstep_hi, dual, w, h, d, trows, K1, blob_bytes, grid, in, out, ladj_ps, rows, batch, c.G, iters, accum, fin, ld);
-  else rc = inverse ? rqs_launch_lds<T, 1, true>(ctx, nstep_hi, dual, w, h, d, trows, K1, blob_bytes, grid, in, out, ladj_ps, rows, batch, c.G, iters, accum, fin, ld)
-                    : rqs_launch_lds<T, 1, false>(ctx, nstep_hi, dual, w, h, d, trows, K1, blob_bytes, grid, in, out, ladj_ps, rows, batch, c.G, iters, accum, fin, ld);
+  if (c.V == VW) rc = inverse ? rqs_launch_lds<T, VW, true>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, rows, batch, c.G, iters, accum, fin, ld)
+                              : rqs_launch_lds<T, VW, false>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, rows, batch, c.G, iters, accum, fin, ld);
+  else rc = inverse ? rqs_launch_lds<T, 1, true>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, rows, batch, c.G, iters, accum, fin, ld)
+                    : rqs_launch_lds<T, 1, false>(ctx, nstep_hi, dual, blob, flag, K1, blob_bytes, grid, in, out, ladj_ps, rows, batch, c.G, iters, accum, fin, ld);
   if (rc) return rc;
   if (second) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
   return BJX_OK;
@@ -975,6 +1019,11 @@ int rqs_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, 
     BJX_CHECK_LAUNCH(ctx);
     return BJX_OK;
   }
+  int* flag = reinterpret_cast<int*>(ctx->scratch);
+  T* blob = reinterpret_cast<T*>(static_cast<char*>(ctx->scratch) + 64);
+  if (inverse) hipLaunchKernelGGL((rqs_blob_kernel<T, true>), dim3(kRqsBlobGrid), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, c.G, flag, blob);
+  else hipLaunchKernelGGL((rqs_blob_kernel<T, false>), dim3(kRqsBlobGrid), dim3(256), 0, ctx->stream, w, h, d, K1, dim, c.V, nstep_hi, dual, c.G, flag, blob);
+  BJX_CHECK_LAUNCH(ctx);
   const int cols_per_block = 256 / c.G;
   const int64_t groups = (batch + cols_per_block - 1) / cols_per_block;
   const int iters = rqs_iters(ctx, blob_bytes, (int64_t)cols_per_block * dim * sizeof(T), groups);
@@ -983,7 +1032,7 @@ int rqs_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, 
   constexpr int VW = Vec16<T>::N;
   {
     BjxProf prof_(ctx);
-#define RV(V_, I_) hipLaunchKernelGGL((rqs_vjp_kernel<T, V_, I_>), dim3((unsigned)grid), dim3(256), blob_bytes, ctx->stream, w, h, d, K1, nstep_hi, dual, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, iters)
+#define RV(V_, I_) hipLaunchKernelGGL((rqs_vjp_kernel<T, V_, I_>), dim3((unsigned)grid), dim3(256), blob_bytes, ctx->stream, blob, flag, K1, nstep_hi, dual, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, iters)
     if (c.V == VW) { if (inverse) RV(VW, true); else RV(VW, false); }
     else { if (inverse) RV(1, true); else RV(1, false); }
 #undef RV

@@ -2341,6 +2341,137 @@ __global__ __launch_bounds__(64) void radial_vjp_walk_kernel(const T* __restrict
 
 struct FlowCfg { int V, G, R; int64_t grid; };
 
+// ------------------------------------------------------------------ Planar / Radial on columns of ANY height (round 5)
+// The register kernels stop at 64 lanes x 32 packs (8 192 rows Float32, 4 096 Float64) and bjx_planar / bjx_radial refused taller
+// columns (the reference has no limit: planar_layer.jl:73-80, radial_layer.jl:43-53).  Here ONE BLOCK owns a column and walks it
+// in passes of 16-byte packs (element accesses when the height or a base is not pack-aligned); between passes the column lives in
+// the OUTPUT array (a workspace when only the log-det is asked for) — a column of this height is a few hundred KiB, it stays in the
+// XCD's L2 between the passes, so the HBM traffic is still one read and one write.
+//   Planar: n_layers + 1 passes — pass l applies layer l-1's update (z += û tanh(·)) and accumulates w_lᵀz for layer l in the same walk.
+//   Radial: 2 passes — ‖z - z₀‖², then the update.
+// Blocks take columns blockIdx.x, + gridDim.x, ...; the block sums are reduced through LDS (two barriers per pass).
+template <class T> __device__ __forceinline__ T block_sum_256(T v, T* red /*[5]*/) {
+  v = group_sum<64>(v);
+  __syncthreads();                                     // the previous use of red[] is over
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+template <class T, int V, bool INV>
+__global__ __launch_bounds__(256) void planar_tall_kernel(const PlanarArgs<T> A, const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ws, T* __restrict__ ladj_ps,
+                                                          int64_t dim, int64_t batch, int accumulate, double* partials) {
+  __shared__ T red[5];
+  __shared__ double redd[4];
+  const int64_t nv = dim / V;                          // V = 1 when the height or a base is not pack-aligned
+  double acc = 0.0;
+  for (int64_t col = blockIdx.x; col < batch; col += gridDim.x) {
+    const T* xc = x + col * dim;
+    T* zc = y ? y + col * dim : ws + (int64_t)blockIdx.x * dim;
+    T ladj = T(0);
+    T tt = T(0);                                       // ± tanh of the layer applied in this pass
+    for (int li = 0; li <= A.n_layers; ++li) {
+      const int l = INV ? A.n_layers - 1 - li : li;          // the layer whose wᵀz this pass accumulates
+      const int lp = INV ? l + 1 : l - 1;                     // the layer whose update this pass applies
+      const T* wl = li < A.n_layers ? A.w + (int64_t)l * dim : nullptr;
+      const T* ul = li > 0 ? A.u_hat + (int64_t)lp * dim : nullptr;
+      const T* src = li == 0 ? xc : zc;
+      T s = T(0), q = T(0);
+      for (int64_t v = threadIdx.x; v < nv; v += 256) {
+        Pack<T, V> z = load_pack<T, V, false>(src + v * V);
+        if (ul) {
+          const Pack<T, V> u = load_pack<T, V, false>(ul + v * V);
+#pragma unroll
+          for (int j = 0; j < V; ++j) z.v[j] += u.v[j] * tt;
+        }
+        if (wl) {
+          const Pack<T, V> w = load_pack<T, V, false>(wl + v * V);
+#pragma unroll
+          for (int j = 0; j < V; ++j) s += w.v[j] * z.v[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) q += z.v[j] * z.v[j];
+        }
+        if (ul || li == 0) store_pack<T, V, false>(zc + v * V, z);
+      }
+      if (li < A.n_layers) {
+        s = block_sum_256(s, red);                     // wᵀz (src/utils.jl:2); the barriers also order this pass's stores before the next pass's loads
+        const T bl = A.b[l], c = A.wtu_hat[l];
+        T t, s2;
+        if (!INV) x_tanh_sech2(s + bl, t, s2);
+        else planar_inv_act<T>(s, c, bl, t, s2);
+        const T ld = Fast<T>::log1p(c * s2);           // planar_layer.jl:107
+        ladj += INV ? -ld : ld;
+        tt = INV ? -t : t;
+      } else if (accumulate & 2) {                     // BJX_BASE_STDNORMAL: + log N(out; 0, I)
+        q = block_sum_256(q, red);
+        ladj += T(-0.5) * q - (T)dim * T(0.91893853320467274178);
+      }
+    }
+    if (threadIdx.x == 0) {
+      if (ladj_ps) ladj_ps[col] = (accumulate & 1) ? ladj_ps[col] + ladj : ladj;
+      acc += (double)ladj;
+    }
+    __syncthreads();                                   // the workspace column is reused by the block's next column
+  }
+  if (partials) block_publish_partial(acc, redd, partials);
+}
+
+template <class T, int V, bool INV>
+__global__ __launch_bounds__(256) void radial_tall_kernel(const RadialArgs<T> A, const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t dim,
+                                                          int64_t batch, int accumulate, double* partials) {
+  __shared__ T red[5];
+  __shared__ double redd[4];
+  const T alpha = d_log1pexp(A.alpha_[0]);          // radial_layer.jl:44
+  const T apb = d_log1pexp(A.beta[0]);              // α + β̂
+  const T beta_hat = -alpha + apb;                  // :45
+  const int64_t nv = dim / V;
+  double acc = 0.0;
+  for (int64_t col = blockIdx.x; col < batch; col += gridDim.x) {
+    const T* xc = x + col * dim;
+    T ss = T(0);
+    for (int64_t v = threadIdx.x; v < nv; v += 256) {
+      const Pack<T, V> z = load_pack<T, V, false>(xc + v * V), z0 = load_pack<T, V, false>(A.z0 + v * V);
+#pragma unroll
+      for (int j = 0; j < V; ++j) { const T dlt = z.v[j] - z0.v[j]; ss += dlt * dlt; }
+    }
+    ss = block_sum_256(ss, red);
+    T r_fwd, gain;
+    if (!INV) {
+      r_fwd = d_sqrt(ss);
+      gain = T(1) + beta_hat / (alpha + r_fwd);
+    } else {
+      const T gam = d_sqrt(ss);                     // compute_r :124-129
+      const T a = apb - gam;
+      const T rr = (d_sqrt(a * a + 4 * alpha * gam) - a) / 2;
+      gain = (alpha + rr) / (apb + rr);             // γ :96-101
+      r_fwd = gain * gam;
+    }
+    const T h_ = T(1) / (alpha + r_fwd);
+    T ld = T(dim - 1) * d_log(T(1) + beta_hat * h_) + d_log(T(1) + beta_hat * h_ + beta_hat * (-(h_ * h_)) * r_fwd);   // :68-70
+    if (INV) ld = -ld;
+    const T fwd_gain = beta_hat / (alpha + r_fwd);
+    if (y) {
+      T* yc = y + col * dim;
+      for (int64_t v = threadIdx.x; v < nv; v += 256) {
+        const Pack<T, V> z = load_pack<T, V, false>(xc + v * V), z0 = load_pack<T, V, false>(A.z0 + v * V);
+        Pack<T, V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const T dlt = z.v[j] - z0.v[j];
+          if (!INV) o.v[j] = z.v[j] + fwd_gain * dlt;                        // :52
+          else o.v[j] = z0.v[j] + gain * dlt;                                // :101
+        }
+        store_pack<T, V, false>(yc + v * V, o);
+      }
+    }
+    if (threadIdx.x == 0) {
+      if (ladj_ps) ladj_ps[col] = accumulate ? ladj_ps[col] + ld : ld;
+      acc += (double)ld;
+    }
+  }
+  if (partials) block_publish_partial(acc, redd, partials);
+}
+
 template <class T> bool flow_cfg(const bjx_ctx* ctx, const void* x, const void* y, int64_t dim, int64_t batch, FlowCfg* c, bool allow_unal = false) {
   constexpr int VW = Vec16<T>::N;
   const bool v_ok = bjx_aligned16(x) && bjx_aligned16(y) && dim % VW == 0;
@@ -2376,9 +2507,17 @@ template <class T> bool flow_cfg(const bjx_ctx* ctx, const void* x, const void* 
 template <class T>
 int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, int nl, const T* in, T* out, T* ladj_ps,
                 double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
-  const size_t need = ((size_t)nl * dim + nl) * sizeof(T);
-  BJX_REQUIRE(ctx, need <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_planar: n_layers*dim = %lld exceeds the context scratch", (long long)nl * dim);
+  const size_t need = (((size_t)nl * dim + nl) * sizeof(T) + 255) / 256 * 256;
   T* u_hat = static_cast<T*>(ctx->scratch);
+  size_t ws_off = 0;                                          // (tall columns, log-det only) where the column workspace starts in big_ws
+  if (need > BJX_SCRATCH_BYTES) {
+    // û of a stack this large (only the tall-column kernel gets here: 8 layers x 16 384 Float64 rows) lives in the grown workspace,
+    // in front of the column workspace of a log-det-only call
+    const size_t ws_cols = out ? 0 : (size_t)ctx->num_cu * 8 * dim * sizeof(T);
+    { int rc = bjx_ensure_big_ws(ctx, need + ws_cols); if (rc) return rc; }
+    u_hat = static_cast<T*>(ctx->big_ws);
+    ws_off = need;
+  }
   T* wtu = u_hat + (size_t)nl * dim;
   hipLaunchKernelGGL(planar_prep_kernel<T>, dim3(nl), dim3(256), 0, ctx->stream, w, u, dim, u_hat, wtu);
   BJX_CHECK_LAUNCH(ctx);
@@ -2625,7 +2764,33 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
     return BJX_OK;
   }
   FlowCfg c;
-  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, out, dim, batch, &c, true), BJX_ERR_UNSUPPORTED, "bjx_planar: dim %lld too large for the register-resident kernel", (long long)dim);
+  if (!flow_cfg<T>(ctx, in, out, dim, batch, &c, true)) {
+    // columns taller than the register kernels hold: one block per column, n_layers + 1 passes (planar_tall_kernel)
+    BJX_REQUIRE(ctx, batch < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar: batch too large for one launch");
+    const int64_t capt = (int64_t)ctx->num_cu * 8;
+    const int gridt = (int)(batch < capt ? batch : capt);
+    T* ws = nullptr;
+    if (!out) {
+      if (ws_off == 0) { int rc = bjx_ensure_big_ws(ctx, (size_t)gridt * dim * sizeof(T)); if (rc) return rc; }
+      ws = reinterpret_cast<T*>(static_cast<char*>(ctx->big_ws) + ws_off);
+    }
+    if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)gridt); if (rc) return rc; }
+    double* partials_t = ladj_sum ? ctx->partials : nullptr;
+    PlanarArgs<T> At{w, u_hat, wtu, b, nl, 0};
+    const int accum_t = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
+    constexpr int VWt = Vec16<T>::N;
+    const bool v_ok = dim % VWt == 0 && bjx_aligned16(in) && (!out || bjx_aligned16(out)) && bjx_aligned16(u_hat) && bjx_aligned16(w) && ((size_t)dim * sizeof(T)) % 16 == 0;
+    {
+      BjxProf prof_(ctx);
+#define LAUNCH_PT(V_, INV_) hipLaunchKernelGGL((planar_tall_kernel<T, V_, INV_>), dim3(gridt), dim3(256), 0, ctx->stream, At, in, out, ws, ladj_ps, dim, batch, accum_t, partials_t)
+      if (v_ok) { if (inverse) LAUNCH_PT(VWt, true); else LAUNCH_PT(VWt, false); }
+      else { if (inverse) LAUNCH_PT(1, true); else LAUNCH_PT(1, false); }
+#undef LAUNCH_PT
+    }
+    BJX_CHECK_LAUNCH(ctx);
+    if (ladj_sum) return bjx_launch_finalize(ctx, gridt, ladj_sum, 0.0, 0, 0.0, flags);
+    return BJX_OK;
+  }
   const size_t tab_bytes = (size_t)2 * nl * dim * sizeof(T);
   const bool lds = tab_bytes <= 60 * 1024;
   PlanarArgs<T> A{w, u_hat, wtu, b, nl, lds ? 1 : 0};
@@ -2874,7 +3039,27 @@ int radial_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const
     return BJX_OK;
   }
   FlowCfg c;
-  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, out, dim, batch, &c, true), BJX_ERR_UNSUPPORTED, "bjx_radial: dim %lld too large for the register-resident kernel", (long long)dim);
+  if (!flow_cfg<T>(ctx, in, out, dim, batch, &c, true)) {
+    // columns taller than the register kernels hold: one block per column, two passes (radial_tall_kernel)
+    BJX_REQUIRE(ctx, batch < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_radial: batch too large for one launch");
+    const int64_t capt = (int64_t)ctx->num_cu * 8;
+    const int gridt = (int)(batch < capt ? batch : capt);
+    if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)gridt); if (rc) return rc; }
+    double* partials_t = ladj_sum ? ctx->partials : nullptr;
+    RadialArgs<T> At{alpha_, beta, z0, 0};
+    constexpr int VWt = Vec16<T>::N;
+    const bool v_ok = dim % VWt == 0 && bjx_aligned16(in) && (!out || bjx_aligned16(out)) && bjx_aligned16(z0);
+    {
+      BjxProf prof_(ctx);
+#define LAUNCH_RT(V_, INV_) hipLaunchKernelGGL((radial_tall_kernel<T, V_, INV_>), dim3(gridt), dim3(256), 0, ctx->stream, At, in, out, ladj_ps, dim, batch, (flags & BJX_ACCUMULATE) ? 1 : 0, partials_t)
+      if (v_ok) { if (inverse) LAUNCH_RT(VWt, true); else LAUNCH_RT(VWt, false); }
+      else { if (inverse) LAUNCH_RT(1, true); else LAUNCH_RT(1, false); }
+#undef LAUNCH_RT
+    }
+    BJX_CHECK_LAUNCH(ctx);
+    if (ladj_sum) return bjx_launch_finalize(ctx, gridt, ladj_sum, 0.0, 0, 0.0, flags);
+    return BJX_OK;
+  }
   {
     const int uc = c.R == 1 ? 4 : (c.R == 2 ? 2 : 1);          // RadialUC<R>
     const int64_t cpb = (int64_t)(256 / c.G) * uc;

@@ -39,10 +39,19 @@ struct bjx_ctx {
   size_t big_ws_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cu = 256;
-  // BJX_OPT_PARAM_EPOCH (0 = off): while the host keeps the epoch unchanged, tables DERIVED from parameter arrays (the factorisation
-  // behind a matrix `Scale`) are reused when the same device pointers come back, instead of being rebuilt by a helper launch on every call.
+  // BJX_OPT_PARAM_EPOCH (0 = off): while the host keeps the epoch unchanged, tables DERIVED from parameter arrays (the spline's LDS blob,
+  // the factorisation behind a matrix `Scale`) are reused when the same device pointers come back, instead of being rebuilt by a helper
+  // launch on every call.
   int param_epoch = 0;
-  // the factorisation behind a matrix `Scale` ([A^-1 | logabsdet], bjx_scale_matrix) under the same epoch contract
+  // BJX_OPT_PARAM_EPOCH: the spline's LDS blob (built by a one-block helper launch) is kept per slot while the epoch stands
+  struct RqsBlobSlot {
+    const void *w = nullptr, *h = nullptr, *d = nullptr;
+    int K1 = 0, V = 0, nstep_hi = 0, dual = 0, G = 0, inverse = 0, dt = 0, epoch = 0;
+    int64_t rows = 0, trows = 0;
+    void* buf = nullptr;          // [64 bytes flag][blob], kRqsBlobMax + 64, allocated on first use
+  } rqs_slots[4];
+  int rqs_next = 0;
+  // the factorisation behind a matrix `Scale` ([A^-1 | logabsdet], bjx_scale_matrix) under the epoch contract
   struct ScaleSlot {
     const void* a = nullptr;
     int64_t dim = 0;

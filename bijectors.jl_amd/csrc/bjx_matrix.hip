@@ -913,17 +913,20 @@ __global__ __launch_bounds__(512) void scale_matrix_prep_lds_kernel(const T* __r
   extern __shared__ __align__(16) unsigned char smem_p_[];
   __shared__ int piv_row;
   __shared__ T piv_val;
-  __shared__ double lad;
   const int t = threadIdx.x, nt = blockDim.x;
   const int W2 = want_inverse ? 2 * dim : dim;
   const int P = W2 | 1;                                  // odd pitch: a column walk (pivot search, multipliers) is conflict-free
   T* Ws = reinterpret_cast<T*>(smem_p_);                 // [dim][P]
   T* fl = Ws + (size_t)dim * P;                          // [dim] multipliers of the current pivot
+  T* pivs = fl + dim;                                    // [dim] the pivots: their logarithms are taken once, in parallel, at the end
+  int CT = 32;                                           // column threads: the power of two >= min(W2, blockDim) (lanes of a wave walk a row)
+  while (CT < W2 && CT < nt) CT <<= 1;
+  const int RT = nt / CT;                                // row threads
+  const int tx = t & (CT - 1), ty = t / CT;
   for (int e = t; e < dim * W2; e += nt) {
     const int i = e / W2, j = e - i * W2;
     Ws[i * P + j] = j < dim ? A[(size_t)j * dim + i] : (j - dim == i ? T(1) : T(0));
   }
-  if (t == 0) lad = 0.0;
   __syncthreads();
   for (int k = 0; k < dim; ++k) {
     if (t < 64) {
@@ -938,7 +941,7 @@ __global__ __launch_bounds__(512) void scale_matrix_prep_lds_kernel(const T* __r
         const int oi = __shfl_down(bi, off, 64);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
       }
-      if (t == 0) { piv_row = bi; piv_val = Ws[bi * P + k]; lad += ::log((double)d_abs(Ws[bi * P + k])); }
+      if (t == 0) { piv_row = bi; piv_val = Ws[bi * P + k]; pivs[k] = Ws[bi * P + k]; }
     }
     __syncthreads();
     const int p = piv_row;
@@ -956,12 +959,12 @@ __global__ __launch_bounds__(512) void scale_matrix_prep_lds_kernel(const T* __r
       Ws[k * P + j] = want_inverse ? rp * rpv : rp;
     }
     __syncthreads();
-    // (3) W[i][j] -= fl[i] * W[k][j], i != k, j > k
-    const int ncol = W2 - (k + 1);
-    const int nrow = dim - ilo;
-    for (int e = t; e < nrow * ncol; e += nt) {
-      const int i = ilo + e / ncol, j = k + 1 + e % ncol;
-      if (i != k) Ws[i * P + j] -= fl[i] * Ws[k * P + j];
+    // (3) W[i][j] -= fl[i] * W[k][j], i != k, j > k.  Thread (tx, ty): column k + 1 + tx (+ CT, ...), rows ilo + ty, + RT, ...
+    // (CT a power of two: no integer division in the loop; the first form used e / ncol, e % ncol and took 2.5 us per pivot)
+    for (int j = k + 1 + tx; j < W2; j += CT) {
+      const T rkj = Ws[k * P + j];
+#pragma unroll 8
+      for (int i = ilo + ty; i < dim; i += RT) Ws[i * P + j] -= fl[i] * rkj;          // fl[k] = 0: row k is left alone (independent rows: the loads pipeline)
     }
     __syncthreads();
   }
@@ -970,12 +973,17 @@ __global__ __launch_bounds__(512) void scale_matrix_prep_lds_kernel(const T* __r
       const int i = e / dim, j = e - i * dim;
       W[(size_t)i * (2 * dim) + dim + j] = Ws[i * P + dim + j];
     }
-  if (t == 0) *logabsdet = lad;
+  if (t < 64) {                                          // sum log|pivot| in Float64, fixed order
+    double a = 0.0;
+    for (int k = t; k < dim; k += 64) a += ::log((double)d_abs(pivs[k]));
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+    if (t == 0) *logabsdet = a;
+  }
 }
 // dynamic LDS of the kernel above (0: does not fit, take the global-memory sweep)
 template <class T> inline size_t scale_prep_lds_bytes(int64_t dim, int want_inverse) {
   const size_t W2 = want_inverse ? 2 * (size_t)dim : (size_t)dim;
-  const size_t b = ((size_t)dim * (W2 | 1) + (size_t)dim) * sizeof(T);
+  const size_t b = ((size_t)dim * (W2 | 1) + 2 * (size_t)dim) * sizeof(T);
   return b <= 150 * 1024 ? b : 0;
 }
 

@@ -1483,7 +1483,7 @@ class RationalQuadraticSpline(Bijector):
         if dim != self.widths.shape[0]:
             raise ValueError(f"DimensionMismatch: spline with {self.widths.shape[0]} rows applied to {dim} rows")
         w, h, d = (colmajor(_param(t, xc)) for t in (self.widths, self.heights, self.derivatives))
-        _note_params(context(xc.device), w, h, d)           # an unchanged spline keeps its LDS blob (BJX_OPT_PARAM_EPOCH)
+        _note_params(context(xc.device), w, h, d)           # under `cache_params` an unchanged spline keeps its LDS blob (BJX_OPT_PARAM_EPOCH)
         return _call_struct("bjx_rqs", x, dim, False, per_sample, want_ladj,
                             (int(inv), _ptr(w), _ptr(h), _ptr(d), int(self.widths.shape[1])), (dim,))
 

@@ -103,13 +103,12 @@ enum {
    * bjx_synchronize polls the stream for at most `value` milliseconds; on time-out it aborts the communicator (ncclCommAbort) and
    * returns 1000 + ncclRemoteError instead of hanging on a rank that never arrived.  0 (default) = wait for ever. */
   BJX_OPT_COLLECTIVE_TIMEOUT_MS = 2,
-  /* Parameter epoch.  bjx_scale_matrix derives [A^-1 | logabsdet A] from its matrix with a helper launch before the hot kernel.
-   * With value != 0 the library keeps that factorisation, keyed by the parameter POINTER, size and dtype, and reuses it while the
-   * epoch is unchanged: the host promises that the memory behind a pointer it passes again has not been written since the epoch
-   * was set, and sets a different non-zero epoch (or 0) whenever it may have been (an optimiser step, a new array at a recycled
-   * address).  0 (default) = rebuild on every call — the safe setting for hosts that cannot track writes (arrays mutated in place
-   * without a version counter).  (Rounds 3-4 kept the spline's LDS table under this option too; since round 5 bjx_rqs builds it
-   * inside the hot kernel and needs no epoch.) */
+  /* Parameter epoch.  Some entries derive a table from their parameter arrays with a helper launch before the hot kernel (bjx_rqs:
+   * the spline's 17 - 64 KiB LDS blob of search keys and per-bin records; bjx_scale_matrix: [A^-1 | logabsdet A]).  With value != 0
+   * the library keeps such tables, keyed by the parameter POINTERS and shapes, and reuses them while the epoch is unchanged: the
+   * host promises that the memory behind a pointer it passes again has not been written since the epoch was set, and sets a
+   * different non-zero epoch (or 0) whenever it may have been (an optimiser step, a new array at a recycled address).  0 (default) =
+   * rebuild on every call — the safe setting for hosts that cannot track writes (arrays mutated in place without a version counter). */
   BJX_OPT_PARAM_EPOCH = 3
 };
 int bjx_set_option(bjx_ctx* ctx, int option, int value);

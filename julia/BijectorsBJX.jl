@@ -94,10 +94,11 @@ workspace_bytes() = Int(ccall((:bjx_workspace_bytes, libbjx), Csize_t, (Ptr{Cvoi
 const BJX_OPT_COLLECTIVE_TIMEOUT_MS = Cint(2)
 collective_timeout!(ms::Integer) = check(ccall((:bjx_set_option, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().h, BJX_OPT_COLLECTIVE_TIMEOUT_MS, Cint(ms)), "bjx_set_option")   # watchdog of synchronize()
 # BJX_OPT_PARAM_EPOCH (include/bjx.h): a non-zero epoch lets the library keep what it derives from parameter arrays with a helper
-# launch — since round 5 only the [A⁻¹ | logabsdet] factorisation behind a matrix `Scale` (the spline builds its table inside the hot
-# kernel: nothing to keep, the C3 rate of the bench line is what every caller gets).  ROCArrays carry no write counter, so the default
-# stays 0 (refactorise on every call); a loop that knows when it updates the matrix calls `param_epoch!(step)` after each update
-# (any different non-zero value).
+# launch (the spline's LDS blob, the [A⁻¹ | logabsdet] factorisation behind a matrix `Scale`) while it is unchanged.  ROCArrays carry
+# no write counter, so the default stays 0 (rebuild on every call: always correct — the same default as the Python mirror since
+# round 5, so the default numbers of bench.py are what a Julia caller gets); code that knows when it updates its parameters calls
+# `param_epoch!(step)` after each update (any different non-zero value) and keeps the tables in between — what bench.py's
+# `cache_params` rows measure.
 const BJX_OPT_PARAM_EPOCH = Cint(3)
 param_epoch!(n::Integer) = check(ccall((:bjx_set_option, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().h, BJX_OPT_PARAM_EPOCH, Cint(n)), "bjx_set_option")
 # who finishes Σ logabsdetjac: 2 (default) the sentinel hand-off inside the hot kernel, 1 the arrival ticket, 0 two follow-up launches

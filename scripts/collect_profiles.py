@@ -87,7 +87,37 @@ def main(tag):
         ls = open(pt).readlines()
         keep = [l for l in ls if " passed" in l or " failed" in l or l.startswith("FAILED")] or ls[-5:]
         open(os.path.join(dst, f"{tag}_pytest_gpu_tail.txt"), "w").write("".join(keep))
+    mv = os.path.join(src, "matrix_vjp_errors.jsonl")
+    if os.path.exists(mv):
+        write_matrix_vjp_table(mv, os.path.join(dst, f"{tag}_matrix_vjp_errors.md"), tag)
     print(json.dumps({k: v for k, v in traffic.items() if k != "_how"}, indent=1)[:3000])
+
+
+def write_matrix_vjp_table(jsonl, out_md, tag):
+    """tests/test_gpu_matrix_vjp.py records the worst relative error it measured per check: one row per (pullback, K, dtype)."""
+    from collections import OrderedDict
+
+    rows = [json.loads(l) for l in open(jsonl) if l.strip()]
+    agg = OrderedDict()
+    for r in rows:
+        kind = r["what"].split(" K=")[0].replace(" no ladj", "").replace(" single", "")
+        a = agg.setdefault((kind, r["K"], r["dtype"]), {"err": 0.0, "cond": 0.0, "condw": 0.0})
+        if r["worst_rel_err"] >= a["err"]:
+            a["err"], a["condw"] = r["worst_rel_err"], r["cond_L_at_worst"]
+        a["cond"] = max(a["cond"], r["cond_L_max"])
+    out = ["# Measured errors of the matrix-bijector pullbacks (`tests/test_gpu_matrix_vjp.py`, GPU vs the FD-pinned oracle)", "",
+           "Worst relative error of a sample's cotangent on that sample's scale, per (kind, direction, K, dtype), over the test's batches; `cond(L)` = condition",
+           "number of the triangular factor of the sample (sqrt(cond(X))): of the worst sample and the largest in the batch.  The bar is north_star's FLAT 1e-3",
+           f"(Float32) / 1e-6 (Float64).  Source: the pytest run of `profiles/{tag}_pytest_gpu_tail.txt`.", "",
+           "| pullback | K | dtype | worst rel. error | cond(L) of that sample | largest cond(L) in the batch |", "|---|---|---|---|---|---|"]
+    for (kind, K, dt), a in sorted(agg.items(), key=lambda kv: (kv[0][0], kv[0][2], kv[0][1])):
+        out.append(f"| {kind} | {K} | {dt} | {a['err']:.2e} | {a['condw']:.3g} | {a['cond']:.3g} |")
+    for dt, bar in (("float32", "1e-3"), ("float64", "1e-6")):
+        vals = [a["err"] for (k, K, d), a in agg.items() if d == dt]
+        if vals:
+            out.append("")
+            out.append(f"Worst {dt}: {max(vals):.2e} (bar {bar}).")
+    open(out_md, "w").write("\n".join(out) + "\n")
 
 
 if __name__ == "__main__":

@@ -60,22 +60,16 @@ stats)
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$WL -o $WL -- python $R/bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline --no-rows > $R/gpurun_out/rocprof_$WL.log 2>&1 )
   f=$(ls gpurun_out/prof_$WL/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && { cp "$f" gpurun_out/${WL}_kernel_stats.csv; head -8 "$f" | cut -c1-200; }; rm -rf gpurun_out/prof_$WL ;;
 profile)
-  TAG=${1:-r04}; shift
+  TAG=${1:-r05}; shift
   WLS=${@:-c2 c2v c3 c4 c5a c5b vcorr pdvec}
   O=$R/gpurun_out/$TAG; mkdir -p $O
   # the binary this evidence belongs to (tests/test_profiles_fresh.py compares kernel names with the .so in the tree)
   sha256sum bijectors.jl_amd/libbjx_hip.so | cut -c1-16 > $O/lib_sha16.txt; stat -c %s bijectors.jl_amd/libbjx_hip.so > $O/lib_bytes.txt
-  python - > $O/first_call.txt 2>&1 <<'PY'
-import time, torch
-t0 = time.perf_counter(); import bijectors_amd as bj; bj._lib.load(); t1 = time.perf_counter()
-x = torch.randn(64, 1024, device="cuda").T.contiguous().T; torch.cuda.synchronize(); t2 = time.perf_counter()
-b = bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5)
-bj.with_logabsdet_jacobian(b, x); torch.cuda.synchronize(); t3 = time.perf_counter()
-bj.with_logabsdet_jacobian(b, x); torch.cuda.synchronize(); t4 = time.perf_counter()
-print(f"dlopen of libbjx_hip.so {1e3*(t1-t0):.1f} ms; first call (context + code-object load of the kernel) {1e3*(t3-t2):.1f} ms; second call {1e3*(t4-t3):.3f} ms")
-PY
+  python scripts/probe_first_call.py > $O/first_call.txt 2>&1
   cat $O/first_call.txt
+  rm -f gpurun_out/matrix_vjp_errors.jsonl
   echo "== pytest -m gpu"; ( time timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 -p no:cacheprovider ) > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt
+  cp gpurun_out/matrix_vjp_errors.jsonl $O/ 2>/dev/null
   echo "== default bench line (what the driver runs)"; timeout 900 python bench.py > $O/bench_default.json 2>$O/bench_default.err; wc -c $O/bench_default.json; cp gpurun_out/bench_detail.json $O/bench_default_detail.json 2>/dev/null
   for wl in $WLS; do
     timeout 600 python bench.py --workload $wl --no-rows --steps 20 --warmup 5 2>$O/bench_$wl.err | tail -1 > $O/bench_$wl.json; echo "== bench $wl: $(cut -c1-120 $O/bench_$wl.json)"

@@ -28,8 +28,8 @@ def _fake_row(name, bench):
 def test_the_line_fits_the_drivers_window_with_every_row():
     import bench
 
-    a = argparse.Namespace(steps=20, warmup=5, scaling="weak", collective="torch")
-    names = ["c1", "c3", "c4", "c5a", "c5b", "c2_f64", "c4_f64"]
+    a = argparse.Namespace(steps=20, warmup=5, scaling="weak", collective="torch", no_cache_params=False)
+    names = ["c1", "c3", "c3_uncached", "c4", "c5a", "c5b", "c2_f64", "c4_f64"]
     head = _fake_row("c2", bench)
     cpu = dict(head["cpu_baseline"], variants={"fused_single_pass_1_core": {"value": 210.123456, "cores": 1}, "fused_single_pass_threads": {"value": 5210.123456, "cores": 64}})
     graph = [{"workload": w, "log2_batch_per_gpu": lb, "label": "q" * 100, "steps": 50, "eager_ms_per_step": 0.0176123, "graph_ms_per_step": 0.0140123,

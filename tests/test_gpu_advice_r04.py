@@ -134,3 +134,34 @@ def test_scale_matrix_factorisation_in_lds_and_kept_per_epoch(bj, dt, dim):
             a.mul_(1.25)                     # in place: `_version` moves, the epoch moves, the factorisation is rebuilt
         check(1.25 * A64)
     assert abs(lad) < 1e3
+
+
+def test_spline_never_uses_a_stale_table_by_default(bj):
+    """Default (no `cache_params`): the spline's table is rebuilt from the knots on every call, so a write the host cannot see
+    (`.data`, another framework, a raw pointer) is seen by the next call — forward, inverse and the input pullback, over 300 calls
+    with in-place updates in between, against a fresh spline object with cloned knots."""
+    r = rng(31)
+    d, K, N = 32, 16, 2049
+    x = dev(np.asfortranarray(r.normal(size=(d, N)).astype(np.float32)))
+    raw = [torch.tensor(r.normal(size=(d, k)).astype(np.float32), device="cuda") for k in (K, K, K - 1)]
+    sp = bj.RationalQuadraticSpline(raw[0], raw[1], raw[2], 3.0)
+    g, lb = torch.ones_like(x), torch.zeros(N, device="cuda")
+
+    def fresh():
+        f = bj.RationalQuadraticSpline(sp.widths.clone(), sp.heights.clone(), sp.derivatives.clone())
+        y, l = bj.with_logabsdet_jacobian(f, x)
+        xb, li = bj.with_logabsdet_jacobian(bj.inverse(f), y)
+        return y, l, xb, li, bj.vjp(f, x, g, lb)
+
+    for it in range(300):
+        if it in (3, 4, 150, 257, 258):
+            sp.derivatives.data[:, 1:-1].mul_(1.0 + 0.01 * (it % 7 + 1))       # invisible to `_version`; same pointers
+            sp.heights.data[:, 5].add_(1e-3)
+        y, l = bj.with_logabsdet_jacobian(sp, x)
+        if it in (0, 2, 3, 4, 5, 150, 151, 256, 257, 258, 259, 299):
+            xb, li = bj.with_logabsdet_jacobian(bj.inverse(sp), y)
+            gx = bj.vjp(sp, x, g, lb)
+            ref = fresh()
+            assert torch.equal(y, ref[0]) and torch.equal(l, ref[1]), f"call {it}: forward used a stale table"
+            assert torch.equal(xb, ref[2]) and torch.equal(li, ref[3]), f"call {it}: inverse used a stale table"
+            assert torch.equal(gx, ref[4]), f"call {it}: pullback used a stale table"
