@@ -57,3 +57,25 @@ def test_cited_profile_files_exist():
         cited |= set(re.findall(r"`(profiles/[A-Za-z0-9_./\-]+?\.(?:md|json|csv|txt|jsonl))`", _read(doc)))
     missing = sorted(c for c in cited if not os.path.exists(os.path.join(ROOT, c)))
     assert not missing, f"documents cite profile files that are not in the tree: {missing}"
+
+
+def test_readme_batch_exponents_match_the_bench_defaults():
+    """the README's results table said 64 × 2²² for the headline that bench.py runs at 2²⁴.  Every BASELINE row of
+    the table names its batch as a superscript power of two; it must be bench.DEFAULT_LOG2's."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_for_docs", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sup = str.maketrans("⁰¹²³⁴⁵⁶⁷⁸⁹", "0123456789")
+    rows = [l for l in _read("README.md").splitlines() if re.match(r"\| C[1-5][ab]? ", l)]
+    seen = {}
+    for l in rows:
+        name = re.match(r"\| (C[1-5][ab]?) ", l).group(1).lower()
+        m = re.search(r"2([⁰¹²³⁴⁵⁶⁷⁸⁹]+)", l.split("|")[1])
+        if m:
+            seen[name] = int(m.group(1).translate(sup))
+    assert {"c2", "c3", "c4", "c5a", "c5b"} <= set(seen), seen
+    for name, lb in seen.items():
+        want = 20 if name == "c1" else bench.DEFAULT_LOG2[name]      # c1: ONE vector of 2^20 elements
+        assert lb == want, f"README row {name.upper()} says 2^{lb}, bench.py runs 2^{want}"
