@@ -819,14 +819,47 @@ def _stage_ops(s):
     return None
 
 
+_CHAIN_OPS: dict = {}
+
+
+def _chain_key(ops, xc, dim):
+    """Hashable identity of a marshalled op list, or None when it holds a temporary (a host parameter, a scalar broadcast next to a
+    vector, another dtype / device / layout): kinds, scalar values, and (address, length) of device-resident vector parameters."""
+    key = [dim, xc.dtype, xc.device.index]
+    for kind, p0, p1 in ops:
+        key.append(kind)
+        seq = False
+        for p in (p0, p1):
+            if p is None:
+                key.append(None)
+            elif isinstance(p, torch.Tensor) and p.dim() > 0 and p.numel() != 1:
+                if p.dtype != xc.dtype or p.device != xc.device or not p.is_contiguous() or p.numel() != dim:
+                    return None
+                key.append((p.data_ptr(), p.numel()))
+                seq = True
+            elif isinstance(p, (int, float)):
+                key.append(float(p))
+            else:
+                return None
+        if seq and any(isinstance(p, (int, float)) for p in (p0, p1)):
+            return None                                   # a scalar broadcast to a temporary vector next to a vector parameter
+    return tuple(key)
+
+
 def _run_chain(ops: Sequence, x: torch.Tensor, per_sample: bool, want_ladj: bool = True, out_y: Optional[torch.Tensor] = None, store: bool = True, flags: int = 0):
     """One bjx_chain launch.  ops: [(kind, p0, p1)] in application order.  store=False: the values are not
     written (log-det / log-density only: half the traffic)."""
     xc, dim, batch, vec = _prep(x)
     ctx = context(xc.device)
-    arr = (L.BjxOp * max(len(ops), 1))()
+    # The marshalled op list (a ctypes array of kinds, scalars and parameter POINTERS — no parameter values) is kept per (ops, dim,
+    # dtype, device): building it costs 10-29 us of a 35-48 us call (profiles/r05_host_overhead.txt).  Only op lists whose vector
+    # parameters are device tensors of the input's dtype are kept (no temporaries to keep alive); the key holds their addresses, so a
+    # parameter that moved is a different key, and a pointer is all the kept array holds — nothing that could go stale.
+    ckey = _chain_key(ops, xc, dim)
+    hit = _CHAIN_OPS.get(ckey) if ckey is not None else None
+    arr = hit if hit is not None else (L.BjxOp * max(len(ops), 1))()
     keep = []
-    for i, (kind, p0, p1) in enumerate(ops):
+    for i, (kind, p0, p1) in enumerate(() if hit is not None else ops):
         o = arr[i]
         o.kind, o.param_len, o.p0, o.p1, o.v0, o.v1 = kind, 0, 0.0, 0.0, None, None
         seq = any(_is_seq(p) for p in (p0, p1) if p is not None)
@@ -843,6 +876,10 @@ def _run_chain(ops: Sequence, x: torch.Tensor, per_sample: bool, want_ladj: bool
             else:
                 o.param_len = 1
                 setattr(o, f"p{j}", float(p))
+    if hit is None and ckey is not None:
+        if len(_CHAIN_OPS) >= 512:
+            _CHAIN_OPS.clear()
+        _CHAIN_OPS[ckey] = arr
     if not store:
         y = None
     elif out_y is None:
@@ -1191,6 +1228,8 @@ class _PlanarRun(PlanarLayer):
         self.layers = flat
         self.n_layers = len(flat)
         self._tab = None
+        self._srcs = None
+        self._bufs = {}
 
     # (dim, n_layers) views of the parameters, for code that treats the run as one stacked layer (oracle comparisons, _key)
     @property
@@ -1209,25 +1248,63 @@ class _PlanarRun(PlanarLayer):
         return list(self.layers)
 
     def _tables(self, xc, dim):
-        ws = [_param(l.w, xc).reshape(-1) for l in self.layers]
-        us = [_param(l.u, xc).reshape(-1) for l in self.layers]
-        bs = [_param(l.b, xc).reshape(-1) for l in self.layers]
-        for t in ws + us:
-            if t.numel() != dim:
-                raise ValueError(f"DimensionMismatch: PlanarLayer of dimension {t.numel()} applied to {dim} rows")
-        key = (xc.device, xc.dtype, dim, _PARAM_CACHE["gen"], tuple((t.data_ptr(), t._version) for t in ws + us + bs))
-        if _PARAM_CACHE["on"] and self._tab is not None and self._tab[0] == key:
-            return self._tab[1]
+        """Layer-major (w, u, b) tables of the run.  Two things are kept on the run object, neither of which can go stale: the
+        POINTER ARRAYS of the layers' parameter tensors (re-read when a layer's attribute is another tensor object or its storage
+        moved) and the destination buffers per (stream, dtype, dim).  The VALUES are gathered on the device on every call — two
+        launches (w and u together, then b) — unless `cache_params` is on and torch's version counters stand still."""
+        srcs = self._srcs
+        fresh = srcs is None or srcs[0] != xc.device or srcs[1] != xc.dtype
+        if not fresh:
+            for l, (tw, tu, tb) in zip(self.layers, srcs[2]):
+                if l.w is not tw[0] or l.u is not tu[0] or l.b is not tb[0] or tw[0].data_ptr() != tw[2] or tu[0].data_ptr() != tu[2] or tb[0].data_ptr() != tb[2]:
+                    fresh = True
+                    break
+        if fresh:
+            per = []
+            for l in self.layers:
+                ent = []
+                for t in (l.w, l.u, l.b):
+                    c = _param(t, xc).reshape(-1)
+                    ent.append((t, c, t.data_ptr() if isinstance(t, torch.Tensor) else None, c.data_ptr()))
+                per.append(tuple(ent))
+            for tw, tu, _ in per:
+                if tw[1].numel() != dim or tu[1].numel() != dim:
+                    raise ValueError(f"DimensionMismatch: PlanarLayer of dimension {tw[1].numel()} applied to {dim} rows")
+            n = self.n_layers
+            wu_ptrs = (C.c_void_p * (2 * n))(*([e[0][3] for e in per] + [e[1][3] for e in per]))
+            b_ptrs = (C.c_void_p * n)(*[e[2][3] for e in per])
+            # a host-resident / other-dtype parameter is converted by `_param` on every sighting: its device copy is a temporary, so such
+            # runs are re-read on every call (never kept)
+            stable = all(isinstance(e[k][0], torch.Tensor) and e[k][1].data_ptr() == e[k][2] for e in per for k in range(3))
+            srcs = (xc.device, xc.dtype, per, wu_ptrs, b_ptrs, dim)
+            self._srcs = srcs if stable else None
+        per, wu_ptrs, b_ptrs = srcs[2], srcs[3], srcs[4]
+        if srcs[5] != dim:
+            raise ValueError(f"DimensionMismatch: PlanarLayer of dimension {srcs[5]} applied to {dim} rows")
         n = self.n_layers
+        if _PARAM_CACHE["on"]:
+            key = (xc.device, xc.dtype, dim, _PARAM_CACHE["gen"], tuple((e[k][3], e[k][1]._version, e[k][0]._version if isinstance(e[k][0], torch.Tensor) else 0) for e in per for k in range(3)))
+            if self._tab is not None and self._tab[0] == key:
+                return self._tab[1]
         ctx = context(xc.device)
-        w = torch.empty(n * dim, dtype=xc.dtype, device=xc.device)
-        u = torch.empty(n * dim, dtype=xc.dtype, device=xc.device)
-        b = torch.empty(n, dtype=xc.dtype, device=xc.device)
-        for src, ln, dst in ((ws, dim, w), (us, dim, u), (bs, 1, b)):
-            arr = (C.c_void_p * n)(*[t.data_ptr() for t in src])
-            L.check(ctx.h, L.load().bjx_pack_vectors(ctx.h, _dt(xc), n, arr, ln, _ptr(dst)), "bjx_pack_vectors")
-        self._tab = (key, (w, u, b), (ws, us, bs))      # the sources stay alive: their addresses are part of the key
-        return self._tab[1]
+        bkey = (id(ctx), xc.dtype, dim)
+        buf = self._bufs.get(bkey)
+        if buf is None or _PARAM_CACHE["on"]:          # (a kept table must not be overwritten by the next gather: fresh buffers under cache_params)
+            buf = (torch.empty(2 * n * dim, dtype=xc.dtype, device=xc.device), torch.empty(n, dtype=xc.dtype, device=xc.device))
+            if not _PARAM_CACHE["on"]:
+                self._bufs = {bkey: buf}                # one (stream, dtype, dim) at a time: launches on a stream are ordered, so the next gather cannot overtake a reader
+        wu, b = buf
+        lib = L.load()
+        L.check(ctx.h, lib.bjx_pack_vectors(ctx.h, _dt(xc), 2 * n, wu_ptrs, dim, _ptr(wu)), "bjx_pack_vectors")
+        L.check(ctx.h, lib.bjx_pack_vectors(ctx.h, _dt(xc), n, b_ptrs, 1, _ptr(b)), "bjx_pack_vectors")
+        tabs = (wu[:n * dim], wu[n * dim:], b)
+        if (n * dim * xc.element_size()) % 16:          # the û table would start off a 16-byte boundary (the kernels' vector paths ask for one): its own buffer
+            u2 = torch.empty(n * dim, dtype=xc.dtype, device=xc.device)
+            u2.copy_(tabs[1])
+            tabs = (tabs[0], u2, b)
+        if _PARAM_CACHE["on"]:
+            self._tab = (key, tabs, per)
+        return tabs
 
 
 def _planar_kind(s) -> int:
@@ -1720,7 +1797,21 @@ class Stacked(Transform):
         return inv
 
     def _segments(self, segs_ops, fused, xc):
-        """bjx_segment[] for the fusable segments (+ the parameter tensors that must stay alive)"""
+        """bjx_segment[] for the fusable segments (+ the parameter tensors that must stay alive).  Kept per (segments, ranges, dtype,
+        device) like the op list of a chain (`_chain_key`): pointers and scalars only, nothing that could go stale."""
+        skey = [len(self.bs)]
+        for i in fused:
+            (lo, hi), (olo, _) = self.ranges_in[i], self.ranges_out[i]
+            k = _chain_key(segs_ops[i], xc, hi - lo + 1)
+            if k is None:
+                skey = None
+                break
+            skey.append((i, lo, hi, olo, k))
+        if skey is not None:
+            skey = ("seg",) + tuple(skey)
+            hit = _CHAIN_OPS.get(skey)
+            if hit is not None:
+                return hit, []
         arr = (L.BjxSegment * max(len(self.bs), 1))()
         keep = []
         for si, i in enumerate(fused):
@@ -1744,6 +1835,10 @@ class Stacked(Transform):
                     else:
                         o.param_len = 1
                         setattr(o, f"p{j}", float(p))
+        if skey is not None:
+            if len(_CHAIN_OPS) >= 512:
+                _CHAIN_OPS.clear()
+            _CHAIN_OPS[skey] = arr
         return arr, keep
 
     def _vjp(self, x, out_bar, ladj_bar, moments=False):

@@ -1478,6 +1478,19 @@ function Distributions.logpdf(td::Bijectors.MvTransformed, y::ROCMatrix{T}) wher
     lp = base_logpdf(td.dist, cur)
     return total isa Number ? lp : lp .+ total
 end
+# the reference's Dirichlet method (:171-177: the base density at x + ε) would be ambiguous with the method above on a ROCMatrix
+function Distributions.logpdf(td::Bijectors.MvTransformed{<:Distributions.Dirichlet}, y::ROCMatrix{T}) where {T<:BjxFloat}
+    itr = inverse(td.transform)                                                 # per-column log-dets of the planned pieces
+    pcs = itr isa ComposedFunction ? pieces(itr) : Any[itr]
+    cur = y; total = nothing
+    for pc in pcs
+        cur, l = piece_wlj_columns(pc, cur)
+        total = add_ladj(total, l)
+    end
+    lp = base_logpdf(td.dist, cur .+ Bijectors._eps(T))
+    return total isa Number ? lp : lp .+ total
+end
+
 # rand(rng, td, n) on the device (src/transformed_distribution.jl:214-224; the reference's own signature).  `BjxRNG` is the device
 # generator: the counter-based Philox stream of the library keyed by (seed, GLOBAL column, row) — identical for any shard count;
 # `col0` is this rank's first global column.  A fusable transform on a diagonal-normal base draws its samples INSIDE the
@@ -1507,7 +1520,8 @@ end
 # any other base: its own sampler on the host generator seeded from the stream's seed, uploaded (define `base_rand` for yours to stay on the device)
 base_rand(rng::BjxRNG, d::Distributions.Distribution, ::Type{T}, n::Integer) where {T<:BjxFloat} =
     ROCArray{T}(rand(Random.Xoshiro(rng.seed + UInt64(rng.col0)), d, n))
-function Base.rand(rng::BjxRNG, td::Bijectors.MvTransformed, n::Int; eltype::Type{T}=Float32) where {T<:BjxFloat}
+Base.rand(rng::BjxRNG, td::Bijectors.MvTransformed, n::Int) = rand(rng, td, n, Float32)       # the reference's signature (:215); Float32 columns
+function Base.rand(rng::BjxRNG, td::Bijectors.MvTransformed, n::Int, ::Type{T}) where {T<:BjxFloat}
     d = td.dist
     if d isa Distributions.MvNormal && diag_normal(d)
         keep = Any[]
@@ -1527,7 +1541,7 @@ function Base.rand(rng::BjxRNG, td::Bijectors.MvTransformed, n::Int; eltype::Typ
     return td.transform === identity ? x : transform(td.transform, x)               # a planned flow: ONE launch over all columns (:215-224 loops over columns)
 end
 # round-4 spelling, kept for callers of that round
-rand_transformed(td::Bijectors.MvTransformed, ::Type{T}, n::Integer; seed::Integer=0, col0::Integer=0) where {T<:BjxFloat} = rand(BjxRNG(seed; col0=col0), td, Int(n); eltype=T)
+rand_transformed(td::Bijectors.MvTransformed, ::Type{T}, n::Integer; seed::Integer=0, col0::Integer=0) where {T<:BjxFloat} = rand(BjxRNG(seed; col0=col0), td, Int(n), T)
 
 # ---------------------------------------------------------------- multi-GPU (one process per GPU)
 comm_unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:bjx_comm_unique_id, libbjx), Cint, (Ptr{Cvoid},), id), "bjx_comm_unique_id"); id)

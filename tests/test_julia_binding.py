@@ -403,7 +403,8 @@ def test_rand_and_logpdf_use_the_references_spellings():
     first global column), with `base_logpdf` / `base_rand` as the extension points for other bases."""
     j = _strip_julia(_julia())
     assert re.search(r"struct BjxRNG <: Random\.AbstractRNG", j)
-    assert re.search(r"function Base\.rand\(rng::BjxRNG, td::Bijectors\.MvTransformed, n::Int", j)
+    assert re.search(r"^Base\.rand\(rng::BjxRNG, td::Bijectors\.MvTransformed, n::Int\) =", j, flags=re.M)
+    assert re.search(r"function Base\.rand\(rng::BjxRNG, td::Bijectors\.MvTransformed, n::Int, ::Type\{T\}\)", j)
     assert re.search(r"function Distributions\.logpdf\(td::Bijectors\.MvTransformed, y::ROCMatrix\{T\}\)", j)
     assert re.search(r"^base_logpdf\(d::Distributions\.Distribution, x::ROCMatrix\)", j, flags=re.M) and "function base_logpdf(d::Distributions.MvNormal" in j
     assert "base_rand(rng::BjxRNG, d::Distributions.Distribution" in j and "function base_rand(rng::BjxRNG, d::Distributions.MvNormal" in j
