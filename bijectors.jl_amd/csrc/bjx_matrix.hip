@@ -1168,7 +1168,15 @@ __global__ __launch_bounds__(256) void scale_matrix_mfma_kernel(const T* __restr
         for (int e = lane; e < ne; e += 64) { const int c = e / dim, k = e - c * dim; Y[c0 * dim + e] = xs[c * P + k]; }
       }
     }
-    if (ladj_ps && lane < nc) ladj_ps[c0 + lane] = accumulate ? ladj_ps[c0 + lane] + lad : lad;
+    if (ladj_ps && lane < nc) {
+      T extra = T(0);
+      if (accumulate & 2) {                                // BJX_BASE_STDNORMAL: + log N(out; 0, I) of this column, the values still in the tile
+        T ss = T(0);
+        for (int k = 0; k < dim; ++k) { const T v = xs[lane * P + k]; ss += v * v; }
+        extra = T(-0.5) * ss - (T)dim * T(0.91893853320467274178);
+      }
+      ladj_ps[c0 + lane] = ((accumulate & 1) ? ladj_ps[c0 + lane] + lad : lad) + extra;
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -1204,6 +1212,7 @@ int scale_matrix_impl(bjx_ctx* ctx, int inverse, const T* a, const T* in, T* out
     // the factorisation behind logabsdet / the inverse is ONE block's Gauss-Jordan sweep, O(dim^3) serial pivots, redone on every
     // call: ~0.2 s at 1024, minutes at 8192 (a launch that long looks like a hang).  Larger systems belong to a blocked LU (rocSOLVER).
     BJX_REQUIRE(ctx, dim <= 1024, BJX_ERR_UNSUPPORTED, "bjx_scale_matrix: dim = %lld: the general-size path stops at 1024 (single-block O(dim^3) factorisation per call)", (long long)dim);
+    BJX_REQUIRE(ctx, !(flags & BJX_BASE_STDNORMAL), BJX_ERR_UNSUPPORTED, "bjx_scale_matrix: BJX_BASE_STDNORMAL is served by the matrix-core kernel only (dim <= 128)");
     { int rc = bjx_ensure_big_ws(ctx, (size_t)dim * 2 * dim * sizeof(T)); if (rc) return rc; }
     T* Wb = reinterpret_cast<T*>(ctx->big_ws);
     double* ladb = ctx->consts + 2;
@@ -1267,6 +1276,8 @@ int scale_matrix_impl(bjx_ctx* ctx, int inverse, const T* a, const T* in, T* out
     }
   }
   const int accum = (flags & BJX_ACCUMULATE) ? 1 : 0;
+  const bool want_density = (flags & BJX_BASE_STDNORMAL) != 0;      // + log N(out; 0, I) per column in ladj_ps: the matrix-core kernel only
+  if (want_density) BJX_REQUIRE(ctx, ladj_ps && !ladj_sum, BJX_ERR_ARG, "bjx_scale_matrix: BJX_BASE_STDNORMAL writes the per-column vector (ladj_ps), not the sum");
   if (batch > 0 && (out || ladj_ps)) {
     const int rpt = dim <= 32 ? 8 : dim <= 64 ? 16 : 32;
     const int RP = 4 * rpt;
@@ -1294,14 +1305,15 @@ int scale_matrix_impl(bjx_ctx* ctx, int inverse, const T* a, const T* in, T* out
       const int gridm = (int)(tiles < capm ? tiles : capm);
       static const int areg = 0;
 #define BJX_SMM(N_) do { if (areg) { bjx_allow_big_lds(scale_matrix_mfma_kernel<T, N_, true>, smem_m); \
-      hipLaunchKernelGGL((scale_matrix_mfma_kernel<T, N_, true>), dim3(gridm), dim3(256), smem_m, ctx->stream, M, ldm, in, out, ladj_ps, (int)dim, batch, accum, lad); } \
+      hipLaunchKernelGGL((scale_matrix_mfma_kernel<T, N_, true>), dim3(gridm), dim3(256), smem_m, ctx->stream, M, ldm, in, out, ladj_ps, (int)dim, batch, accum | (want_density ? 2 : 0), lad); } \
       else { bjx_allow_big_lds(scale_matrix_mfma_kernel<T, N_, false>, smem_m); \
-      hipLaunchKernelGGL((scale_matrix_mfma_kernel<T, N_, false>), dim3(gridm), dim3(256), smem_m, ctx->stream, M, ldm, in, out, ladj_ps, (int)dim, batch, accum, lad); } } while (0)
+      hipLaunchKernelGGL((scale_matrix_mfma_kernel<T, N_, false>), dim3(gridm), dim3(256), smem_m, ctx->stream, M, ldm, in, out, ladj_ps, (int)dim, batch, accum | (want_density ? 2 : 0), lad); } } while (0)
       switch (nrb) { case 1: BJX_SMM(1); break; case 2: BJX_SMM(2); break; case 3: BJX_SMM(3); break; case 4: BJX_SMM(4); break;
                      case 5: BJX_SMM(5); break; case 6: BJX_SMM(6); break; case 7: BJX_SMM(7); break; default: BJX_SMM(8); break; }
 #undef BJX_SMM
       BJX_CHECK_LAUNCH(ctx);
     } else {
+      BJX_REQUIRE(ctx, !want_density, BJX_ERR_UNSUPPORTED, "bjx_scale_matrix: BJX_BASE_STDNORMAL is served by the matrix-core kernel only (dim <= 128)");
 #define BJX_SM(R_) do { bjx_allow_big_lds(scale_matrix_kernel<T, R_>, smem); \
     hipLaunchKernelGGL((scale_matrix_kernel<T, R_>), dim3(grid), dim3(256), smem, ctx->stream, M, ldm, in, out, ladj_ps, (int)dim, batch, TC, accum, lad); } while (0)
     if (inverse && want_ladj) {               // negate once on the device before the per-sample broadcast

@@ -1469,6 +1469,80 @@ __global__ __launch_bounds__(256) void ordered_vjp_column_kernel(const T* __rest
   }
 }
 
+// Columns beyond the stream kernel's 64 lanes x 8 packs (2 048 rows Float32): ONE BLOCK per column (round 5; the one-thread-per-column
+// kernel above reads a column with one lane: 4-8 % of the HBM peak).  The column is walked in tiles of 256 packs FROM ITS END, every
+// access a coalesced 16-byte pack (element accesses when the height or a base is not pack-aligned):
+//   forward  ȳ_i = (Σ_{k>=i} x̄_k) exp(y_i) + ℓ̄  (i >= 2), ȳ_1 = Σ_k x̄_k: a suffix sum — in-pack suffix, wave scan (shuffles), the
+//            four wave totals through LDS, plus the carry of the tiles already done;
+//   inverse  x̄_j = q_j - q_{j+1}, q_j = (ȳ_j - ℓ̄)/(x_j - x_{j-1}) (q_1 := ȳ_1 ... see ordered_vjp_column_kernel): neighbours only —
+//            the pack's own rows plus one row on either side.
+template <class T, int V, bool INV>
+__global__ __launch_bounds__(256) void ordered_vjp_tall_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
+                                                               T* __restrict__ in_bar, int64_t rows, int64_t batch) {
+  __shared__ T wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t npk = (rows + V - 1) / V;                       // the last pack may be partial (V = 1 when nothing is pack-aligned)
+  const int64_t ntile = (npk + 255) / 256;
+  for (int64_t col = blockIdx.x; col < batch; col += gridDim.x) {
+    const T lb = ladj_bar ? ladj_bar[col] : T(0);
+    const T* a = in + col * rows;
+    const T* g = out_bar + col * rows;
+    T* o = in_bar + col * rows;
+    T carry = T(0);                                              // forward: Σ x̄ of the tiles behind this one
+    for (int64_t tl = ntile - 1; tl >= 0; --tl) {
+      const int64_t pk = tl * 256 + threadIdx.x;
+      const int64_t r0 = pk * V;
+      const bool live = pk < npk;
+      T gv[V], av[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) { const bool ok = live && r0 + j < rows; gv[j] = ok ? g[r0 + j] : T(0); av[j] = ok ? a[r0 + j] : T(0); }
+      if (!INV) {
+        // suffix sums inside the pack, then over the lanes behind this one, the waves behind this one, the tiles behind this one
+        T sfx[V];
+        T run = T(0);
+#pragma unroll
+        for (int j = V - 1; j >= 0; --j) { run += gv[j]; sfx[j] = run; }
+        T inc = run;                                             // inclusive suffix scan of the pack totals across the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const T v = __shfl_down(inc, off, 64); if (lane + off < 64) inc += v; }
+        const T wave_total = __shfl(inc, 0, 64);
+        __syncthreads();                                         // wsum of the previous tile has been read
+        if (lane == 0) wsum[wave] = wave_total;
+        __syncthreads();
+        T behind = carry;
+#pragma unroll
+        for (int w = 3; w >= 0; --w) if (w > wave) behind += wsum[w];
+        const T after = behind + (inc - run);                    // Σ x̄ of every row behind this pack
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const int64_t r = r0 + j;
+          if (live && r < rows) o[r] = r == 0 ? (sfx[j] + after) : (sfx[j] + after) * d_exp(av[j]) + lb;
+        }
+        carry += (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+      } else {
+        // q of the pack's rows and of the row behind it; row r needs x_{r-1}
+        const T a_prev = (live && r0 >= 1 && r0 < rows) ? a[r0 - 1] : T(0);
+        const int64_t rn = r0 + V;                               // the row behind the pack
+        const T q_next = (live && rn < rows) ? (g[rn] - lb) / (a[rn] - a[rn - 1]) : T(0);
+        T q[V + 1];
+        q[V] = q_next;
+#pragma unroll
+        for (int j = V - 1; j >= 0; --j) {
+          const int64_t r = r0 + j;
+          const T below = j == 0 ? a_prev : av[j - 1];
+          q[j] = (live && r >= 1 && r < rows) ? (gv[j] - lb) / (av[j] - below) : T(0);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const int64_t r = r0 + j;
+          if (live && r < rows) o[r] = r == 0 ? gv[j] - q[j + 1] : q[j] - q[j + 1];
+        }
+      }
+    }
+    if (!INV) __syncthreads();                                   // the next column's first tile rewrites wsum
+  }
+}
+
 template <class T>
 int ordered_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t dim, int64_t batch) {
   if (batch == 0) return BJX_OK;
@@ -1506,6 +1580,20 @@ int ordered_vjp_impl(bjx_ctx* ctx, int inverse, const T* in, const T* out_bar, c
   const size_t smem = (size_t)2 * 64 * P * sizeof(T);
   if (smem > BJX_LDS_MAX) {
     BJX_REQUIRE(ctx, in_bar != out_bar, BJX_ERR_ARG, "bjx_ordered_vjp: in_bar may not alias out_bar for dim = %lld", (long long)dim);
+    static const int use_tall = getenv("BJX_ORDERED_VJP_TALL") ? atoi(getenv("BJX_ORDERED_VJP_TALL")) : 1;
+    if (use_tall && dim >= 1024 && in_bar != in) {
+      const int64_t capt = (int64_t)ctx->num_cu * 8;
+      const int gridt = (int)(batch < capt ? batch : capt);
+      constexpr int VWt = Vec16<T>::N;
+      const bool v_ok = dim % VWt == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
+      BjxProf prof_(ctx);
+#define OVT(V_, I_) hipLaunchKernelGGL((ordered_vjp_tall_kernel<T, V_, I_>), dim3(gridt), dim3(256), 0, ctx->stream, in, out_bar, ladj_bar, in_bar, dim, batch)
+      if (v_ok) { if (inverse) OVT(VWt, true); else OVT(VWt, false); }
+      else { if (inverse) OVT(1, true); else OVT(1, false); }
+#undef OVT
+      BJX_CHECK_LAUNCH(ctx);
+      return BJX_OK;
+    }
     const int64_t g2 = (batch + 255) / 256;
     BJX_REQUIRE(ctx, g2 < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "batch too large for one launch");
     BjxProf prof_(ctx);

@@ -2897,6 +2897,32 @@ def transformed(dist, b=None):
     return TransformedDistribution(dist, identity if b is None else b)
 
 
+def _logpdf_full_cov_fused(d, ib, y):
+    """Full-covariance base, fusable inverse transform, dim <= 128 (round 5): TWO launches and three array passes instead of four
+    launches and five passes — the inverse chain with the shift −μ appended writes x − μ and its per-column log-det, then the matrix
+    `Scale` kernel whitens with L⁻¹ and accumulates log N(z; 0, I) − logabsdet L per column while the whitened tile is still in LDS
+    (BJX_BASE_STDNORMAL on bjx_scale_matrix: nothing is stored).  None when the shape is not served (the caller takes the general path)."""
+    yc, dim, batch, vec = _prep(y)
+    if vec or dim > 128 or batch == 0:
+        return None
+    ops = [] if ib is identity else _fused_ops(ib)
+    if ops is None or len(ops) + 1 > L.BJX_MAX_OPS:
+        return None
+    sc, _, mu = d._tril_on(yc)
+    key = (id(mu), mu._version)
+    if getattr(d, "_neg_mu_full_key", None) != key:
+        d._neg_mu_full, d._neg_mu_full_key = (-mu).contiguous(), key
+    xm, lj = _run_chain(list(ops) + [(L.OP_SHIFT, d._neg_mu_full, None)], yc, True, True)
+    a = colmajor(_param(sc.a, xm))
+    ctx = context(xm.device)
+    _note_params(ctx, a)
+    rc = L.load().bjx_scale_matrix(ctx.h, _dt(xm), 1, _ptr(a), _ptr(xm), None, _ptr(lj), None, dim, batch, L.BJX_ACCUMULATE | L.BJX_BASE_STDNORMAL)
+    if rc == L.ERR_UNSUPPORTED:
+        return None
+    L.check(ctx.h, rc, "bjx_scale_matrix")
+    return lj
+
+
 def logpdf(td: TransformedDistribution, y, reference_shape: bool = False):
     """`logpdf(td::MvTransformed, y::AbstractMatrix)` (src/transformed_distribution.jl:164-169):
         x, logjac = with_logabsdet_jacobian(inverse(td.transform), y);  logpdf(td.dist, x) + logjac
@@ -2916,6 +2942,9 @@ def logpdf(td: TransformedDistribution, y, reference_shape: bool = False):
     if getattr(d, "scale_tril", None) is not None:
         # full covariance: x = b⁻¹(y); z = L \ x (bjx_scale_matrix, log-det −logabsdet L per column); then the standard-normal
         # density of z − L⁻¹μ accumulated without storing anything (one chain launch, store=False)
+        fused = _logpdf_full_cov_fused(d, ib, y)
+        if fused is not None:
+            return fused
         if ib is identity:
             x, lj = y, None
         else:

@@ -232,7 +232,10 @@ int bjx_pd_vec_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, cons
 /* Scale with a MATRIX parameter, scale.jl:14,17,35-36: out = a * in (inverse=1: out = a \ in), a: device T[dim, dim]
  * column-major, dim <= 128.  logabsdetjac = logabsdet(a) (negated for the inverse): ladj_ps[n] holds it for every column;
  * ladj_sum = batch * logabsdet(a), or logabsdet(a) ONCE with BJX_REF_VECTOR_SCALE_LADJ — the value the reference returns
- * for a matrix of columns (:36).  The LU (partial pivoting) behind logabsdet / the inverse runs on the device per call. */
+ * for a matrix of columns (:36).  The LU (partial pivoting) behind logabsdet / the inverse runs on the device per call (kept per
+ * BJX_OPT_PARAM_EPOCH).  BJX_BASE_STDNORMAL (dim <= 128, ladj_ps only, out may be NULL): ladj_ps[n] additionally receives
+ * log N(out[:, n]; 0, I) — with inverse = 1 and a = the Cholesky factor L of a covariance, one launch turns x - mu into the
+ * full-covariance normal log-density without storing the whitened values (src/transformed_distribution.jl:164-169). */
 int bjx_scale_matrix(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* a, const void* in, void* out,
                      void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
 

@@ -1437,6 +1437,13 @@ function base_logpdf(d::Distributions.MvNormal, x::ROCMatrix{T}) where {T<:BjxFl
         (Ptr{Cvoid}, Cint, Ptr{BjxOp}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
         ctx().h, dtype(T), o, length(o), devptr(x), devptr(xc), C_NULL, C_NULL, size(x, 1), size(x, 2), UInt32(0)), "bjx_chain")
     p = plan_scale_matrix(Lc, true, xc)
+    if size(x, 1) <= 128
+        # ONE launch: whitening on the matrix cores, log N(z; 0, I) − logabsdet L accumulated per column while the tile is in LDS,
+        # nothing stored (BJX_BASE_STDNORMAL on bjx_scale_matrix, include/bjx.h)
+        lp = similar(x, T, size(x, 2))
+        GC.@preserve keep xc lp check(p.launch(C_NULL, devptr(lp), C_NULL, BJX_BASE_STDNORMAL), "bjx_scale_matrix")
+        return lp
+    end
     lj = run!(column_plan(p), T, xc, xc)                         # z in place; per-column −logabsdet L
     return stdnormal_chain(xc, BjxOp[], keep) .+ lj
 end

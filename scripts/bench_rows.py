@@ -145,7 +145,7 @@ def main():
     rows.append(("vjp(OrderedBijector) d=64", "f-1", lambda: bj.vjp(ob, x, gb, lbar), 3 * d * 4 + 4, N))
     rows.append(("vjp(inverse(OrderedBijector)) d=64", "f-1", lambda: bj.vjp(bj.inverse(ob), xo, gb, lbar), 3 * d * 4 + 4, N))
 
-    Wb = randn(K * K, Nc, dev, 13).reshape(K, K, Nc)
+    Wb = randn(K * K, Nc, dev, 13).T.reshape(Nc, K, K).permute(2, 1, 0)      # column-major (K, K, batch): strides (1, K, K²) — a plain reshape gives (K, 1, K²) and the call a layout copy (0.8 ms)
     lb2 = randn(Nc, 1, dev, 14).reshape(-1).contiguous()
     rows.append(("vjp(inverse(VecCholesky)) K=64", "f-1", lambda: bj.vjp(icb, yv, Wb, lb2), 4 * (2 * n + K * K) + 4, Nc))
 

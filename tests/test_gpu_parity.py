@@ -922,7 +922,9 @@ def test_stacked_permuted_ranges_and_structured_segments(bj, orc):
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("shape", [(1, 5), (2, 64), (7, 300), (64, 129), (100, 33),
                                    # round 4: partial last pack / R packs per lane in the streaming pullback, and past its 512 packs
-                                   (9, 70), (13, 257), (101, 37), (201, 19), (257, 11), (333, 9), (1000, 5), (2048, 3), (2049, 2), (1025, 3)])
+                                   (9, 70), (13, 257), (101, 37), (201, 19), (257, 11), (333, 9), (1000, 5), (2048, 3), (2049, 2), (1025, 3),
+                                   # round 5: one block per column beyond the stream kernel (ordered_vjp_tall_kernel): whole packs, odd heights, more columns than blocks
+                                   (4096, 5), (4100, 3), (5003, 2), (2052, 2300)])
 def test_ordered_vjp(bj, orc, shape, dt):
     r = rng(51)
     n, N = shape
@@ -3072,7 +3074,8 @@ def test_logpdf_and_rand_with_any_base(bj, orc, flow, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("dim,N,flow", [(6, 1000, "chain"), (16, 4099, "planar"), (3, 50, "none"), (150, 301, "chain")])
+@pytest.mark.parametrize("dim,N,flow", [(6, 1000, "chain"), (16, 4099, "planar"), (3, 50, "none"), (150, 301, "chain"),
+                                        (64, 4099, "chain"), (128, 513, "none"), (50, 77, "chain")])      # round 5: density fused into the whitening launch (dim <= 128)
 def test_logpdf_and_rand_with_a_full_covariance_base(bj, orc, dim, N, flow, dt):
     """src/transformed_distribution.jl:159-240 with a FULL-covariance MvNormal base (f-3 beyond the diagonal case): the matrix
     `Scale` whitens / colours the batch; logpdf against the oracle's density + the oracle's inverse flow; rand's first two moments."""
