@@ -144,6 +144,17 @@ int bjx_make_fin(bjx_ctx* ctx, int64_t grid, double* ladj_sum, double host_const
   return BJX_OK;
 }
 
+int bjx_fin_two_pass(bjx_ctx* ctx, int64_t grid, BjxFin* fin, bool* second_pass) {
+  if (!fin->partials) return BJX_OK;                     // no sum requested
+  if (!fin->l2 && !fin->counter) return BJX_OK;          // already two-pass
+  int rc = bjx_ensure_partials(ctx, (size_t)grid);
+  if (rc) return rc;
+  *fin = BjxFin{};
+  fin->partials = ctx->partials;
+  *second_pass = true;
+  return BJX_OK;
+}
+
 // ------------------------------------------------------------------ context
 BJX_API int bjx_version(void) { return BJX_VERSION; }
 

@@ -2716,6 +2716,9 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
         BjxFin finm;
         bool secondm = false;
         { int rc = bjx_make_fin(ctx, gridm, ladj_sum, 0.0, 0, flags, &finm, &secondm); if (rc) return rc; }
+        // 28 us blocks at two per CU: a group-closing block that waits holds half a CU — the sentinel hand-off measured +0.9 % here
+        // (LAB_NOTEBOOK.md "Round 5"): the follow-up launch stays
+        { int rc = bjx_fin_two_pass(ctx, gridm, &finm, &secondm); if (rc) return rc; }
         const int accum = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
         const size_t smem = (size_t)4 * (16 * (dim / (split2 ? 2 : 1) + 4) + cols * 8) * sizeof(double);
 #define LAUNCH_MF64_S(NB_, T_, I_, S_) do { bjx_allow_big_lds(planar_mfma64_kernel<NB_, T_, I_, S_>, smem); \

@@ -131,6 +131,10 @@ struct BjxFin {
 int bjx_make_fin(bjx_ctx* ctx, int64_t grid, double* ladj_sum, double host_const, int use_dev_const, uint32_t flags,
                  BjxFin* fin, bool* second_pass);
 
+// host side: turn a descriptor built by bjx_make_fin back into the two-pass form (per-block partials + bjx_launch_finalize) — for kernels
+// whose long-lived blocks at low occupancy lose more to a closing block's wait than the follow-up launch costs
+int bjx_fin_two_pass(bjx_ctx* ctx, int64_t grid, BjxFin* fin, bool* second_pass);
+
 // host side: make sure ctx->big_ws holds `bytes` (cached; growing it synchronises the device and cannot be captured)
 int bjx_ensure_big_ws(bjx_ctx* ctx, size_t bytes);
 // host side: make sure ctx->partials can hold n doubles (cached; reallocation synchronises the device)

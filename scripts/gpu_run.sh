@@ -78,6 +78,10 @@ profile)
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_rows -o rows -- python $R/scripts/bench_rows.py > $O/rows_raw.txt 2>&1 )
   grep "^|" $O/rows_raw.txt > $O/rows.md; f=$(ls $O/prof_rows/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -60 "$f" > $O/rows_kernel_stats.csv; rm -rf $O/prof_rows; wc -l $O/rows.md
   timeout 600 python scripts/bench_f64.py 2>/dev/null | grep "^|" > $O/f64_rows.md; wc -l $O/f64_rows.md
+  timeout 300 python scripts/probe_ordered_tall.py 2>/dev/null | grep "^|" > $O/ordered_tall.md
+  { echo; echo "With \`BJX_ORDERED_VJP_TALL=0\` (one thread per column, rounds 2-4), same call:"; echo; BJX_ORDERED_VJP_TALL=0 timeout 300 python scripts/probe_ordered_tall.py 2>/dev/null | grep "^|" | sed -n '1,2p;7,10p'; } >> $O/ordered_tall.md
+  timeout 300 python scripts/probe_host_overhead.py --calls 2000 --top 8 2>/dev/null | grep -v amdgpu.ids > $O/host_overhead.txt
+  bash scripts/ab_c3.sh 2>/dev/null > $O/c3_table_policy.txt
   for wl in $WLS; do
     ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o $wl -- python $R/bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-rows > $O/rocprof_$wl.log 2>&1 )
     f=$(ls $O/prof_$wl/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && { cp "$f" $O/${wl}_kernel_stats.csv; echo "-- kernel stats $wl"; head -3 "$f" | cut -c1-160; }
