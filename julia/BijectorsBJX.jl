@@ -903,6 +903,32 @@ with_logabsdet_jacobian(t::VB.ProductVecInvTransform{<:LinkTuple{P},<:Any,Tuple{
 with_logabsdet_jacobian(t::VB.ProductVecTransform{<:AbstractArray{<:WrappedLink},<:Any,Tuple{}}, x::ROCMatrix{<:BjxFloat}) = product_launch(vec(collect(t.transforms)), x)
 with_logabsdet_jacobian(t::VB.ProductVecInvTransform{<:AbstractArray{<:WrappedLink},<:Any,Tuple{}}, y::ROCMatrix{<:BjxFloat}) = product_launch(vec(collect(t.transforms)), y)
 
+# MvLogNormal links (src/vector/multivariate/mvlognormal.jl:1-15) over a matrix of chains: one bjx_chain launch, per-chain log-det
+with_logabsdet_jacobian(::VB.MapLog, x::ROCMatrix{<:BjxFloat}) = chains_launch([op0(OP_LOG)], x, size(x))
+with_logabsdet_jacobian(::VB.MapExp, x::ROCMatrix{<:BjxFloat}) = chains_launch([op0(OP_EXP)], x, size(x))
+(t::VB.MapLog)(x::ROCMatrix{<:BjxFloat}) = first(with_logabsdet_jacobian(t, x))
+(t::VB.MapExp)(x::ROCMatrix{<:BjxFloat}) = first(with_logabsdet_jacobian(t, x))
+# JointOrderStatistics (src/vector/order/order.jl:14-76): the scalar link of the parent distribution over every element (sign flipped
+# back when the link is decreasing), then the ordered vector to an unordered one — which IS inverse(OrderedBijector) (y₁, log(yᵢ − yᵢ₋₁)
+# with log-det −Σ log(yᵢ − yᵢ₋₁), ordered.jl:50-80): one bjx_chain launch + one bjx_ordered launch over all chains, per-chain log-dets
+function with_logabsdet_jacobian(m::VB.JointOrderWrap{<:ScalarLink}, x::ROCMatrix{T}) where {T<:BjxFloat}
+    o = copy(scalar_ops(m.bijector))
+    Bijectors.is_monotonically_decreasing(m.bijector) && push!(o, op0(OP_SIGNFLIP))
+    y, l1 = chains_launch(o, x, size(x))
+    z = similar(y)
+    l2 = run!(plan_ordered(true, y), T, y, z)
+    return z, l1 .+ l2
+end
+function with_logabsdet_jacobian(m::VB.InverseJointOrderWrap{<:ScalarLink}, y::ROCMatrix{T}) where {T<:BjxFloat}
+    x = similar(y)
+    l1 = run!(plan_ordered(false, y), T, y, x)                                  # xᵢ = exp(yᵢ) + xᵢ₋₁
+    o = vcat(Bijectors.is_monotonically_decreasing(m.bijector) ? [op0(OP_SIGNFLIP)] : BjxOp[], scalar_ops(m.bijector))
+    z, l2 = chains_launch(o, x, size(x))
+    return z, l1 .+ l2
+end
+(m::VB.JointOrderWrap{<:ScalarLink})(x::ROCMatrix{<:BjxFloat}) = first(with_logabsdet_jacobian(m, x))
+(m::VB.InverseJointOrderWrap{<:ScalarLink})(y::ROCMatrix{<:BjxFloat}) = first(with_logabsdet_jacobian(m, y))
+
 # Stacked with Simplex / Ordered segments (stacked.jl:142-166) without slicing copies: the elementwise segments in one
 # bjx_stacked_ld launch between matrices of different heights (identity placeholders on the structured rows), then
 # bjx_simplex_ld / bjx_ordered_ld on row windows of the same matrices, accumulating their log-dets.
