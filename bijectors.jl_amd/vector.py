@@ -24,7 +24,8 @@ from . import _lib as L
 from . import interface as I
 
 __all__ = ["Exp", "Log", "Truncate", "Untruncate", "TypedIdentity", "scalar_to_scalar_bijector", "ProductVecTransform",
-           "ProductVecInvTransform", "to_linked_vec", "from_linked_vec", "to_linked_vec_product", "from_linked_vec_product"]
+           "ProductVecInvTransform", "to_linked_vec", "from_linked_vec", "to_linked_vec_product", "from_linked_vec_product",
+           "MapLog", "MapExp", "JointOrderWrap", "InverseJointOrderWrap", "is_monotonically_decreasing"]
 
 
 class ScalarToScalarBijector(I.Bijector):
@@ -115,6 +116,82 @@ class Untruncate(ScalarToScalarBijector):
 
     def _ops(self, inv=False):
         return [(L.OP_TRUNCATED_INV if inv else L.OP_TRUNCATED, self.lower, self.upper)]
+
+
+class MapLog(ScalarToScalarBijector):
+    """src/vector/multivariate/mvlognormal.jl:1-8 (to_linked_vec of an MvLogNormal): log of every element, log-det −Σ log x."""
+
+    def _key(self):
+        return ()
+
+    def _ops(self, inv=False):
+        return [(L.OP_EXP if inv else L.OP_LOG, None, None)]
+
+
+class MapExp(ScalarToScalarBijector):
+    """mvlognormal.jl:9-15 (from_linked_vec): exp of every element, log-det Σ x."""
+
+    def _key(self):
+        return ()
+
+    def _ops(self, inv=False):
+        return [(L.OP_LOG if inv else L.OP_EXP, None, None)]
+
+
+def is_monotonically_decreasing(t) -> bool:
+    """Bijectors.is_monotonically_decreasing for the scalar links (truncated.jl:21-22, 72-73; positive.jl: sign = -1; common.jl:29)."""
+    if isinstance(t, (Truncate, Untruncate)):
+        return math.isinf(t.lower) and not math.isinf(t.upper)
+    if isinstance(t, (Exp, Log)):
+        return t.sign < 0
+    return False
+
+
+class JointOrderWrap(I.Bijector):
+    """src/vector/order/order.jl:14-46 (to_linked_vec of JointOrderStatistics): the parent's scalar link over every element of the
+    ORDERED sample (the sign flipped back when the link is decreasing), then ordered -> unordered: y₁, log(yᵢ − yᵢ₋₁) — which is
+    inverse(OrderedBijector) (ordered.jl:50-80).  One bjx_chain launch + one bjx_ordered launch; per-column log-det for a matrix of chains."""
+
+    def __init__(self, bijector):
+        self.bijector = bijector
+
+    def _key(self):
+        return (self.bijector,)
+
+    def _wlj(self, x, per_sample, want_ladj=True):
+        ops = list(self.bijector._ops(False)) + ([(L.OP_SIGNFLIP, None, None)] if is_monotonically_decreasing(self.bijector) else [])
+        y, l1 = I._run_chain(ops, x, True if want_ladj else False, want_ladj)
+        z, l2 = I.inverse(I.OrderedBijector())._wlj(y, per_sample=True, want_ladj=want_ladj)
+        if not want_ladj:
+            return z, None
+        l = l1 + l2
+        return z, (l if (per_sample or x.dim() == 2) else l.reshape(()))
+
+    def _wlj_inv(self, y, per_sample, want_ladj=True):
+        return InverseJointOrderWrap(_inverse_scalar(self.bijector))._wlj(y, per_sample, want_ladj)
+
+
+class InverseJointOrderWrap(I.Bijector):
+    """order.jl:48-76 (from_linked_vec): unordered -> ordered (xᵢ = exp(yᵢ) + xᵢ₋₁ = OrderedBijector), the sign flip, then the
+    inverse link over every element."""
+
+    def __init__(self, bijector):
+        self.bijector = bijector
+
+    def _key(self):
+        return (self.bijector,)
+
+    def _wlj(self, y, per_sample, want_ladj=True):
+        x, l1 = I.OrderedBijector()._wlj(y, per_sample=True, want_ladj=want_ladj)
+        ops = ([(L.OP_SIGNFLIP, None, None)] if is_monotonically_decreasing(self.bijector) else []) + list(self.bijector._ops(False))
+        z, l2 = I._run_chain(ops, x, True if want_ladj else False, want_ladj)
+        if not want_ladj:
+            return z, None
+        l = l1 + l2
+        return z, (l if (per_sample or y.dim() == 2) else l.reshape(()))
+
+    def _wlj_inv(self, x, per_sample, want_ladj=True):
+        return JointOrderWrap(_inverse_scalar(self.bijector))._wlj(x, per_sample, want_ladj)
 
 
 def _inverse_scalar(t):

@@ -371,3 +371,60 @@ def test_radial_columns_taller_than_the_register_kernels(bj, orc, dim, N, dt):
     Zb, lb = bj.with_logabsdet_jacobian(bj.inverse(layer), dev(Y_ref))
     close(host(Zb), Z.astype(np.float64), dt, scale=40, what="tall radial inv")
     close(host(lb), -l_ref, dt, scale=dim, what="tall radial inv ladj")
+
+
+# ---------------------------------------------------------------- round 5: VectorBijectors links of JointOrderStatistics / MvLogNormal
+def _link_np(kind, x):
+    """(y, per-element log-det) of the scalar links used below, restated from src/vector/univariate/{positive,truncated}.jl"""
+    if kind == "log":                      # Log(0, +1): positive.jl:27-50
+        return np.log(x), -np.log(x)
+    if kind == "unit":                     # Untruncate(0, 1): logit, truncated.jl:79-99
+        return np.log(x) - np.log1p(-x), -(np.log(x) + np.log1p(-x))
+    if kind == "upper":                    # Untruncate(-Inf, 2): log(2 - x), decreasing
+        return np.log(2.0 - x), -np.log(2.0 - x)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["log", "unit", "upper"])
+@pytest.mark.parametrize("K,N", [(1, 5), (2, 64), (7, 131), (64, 300)])
+def test_joint_order_wrap_matches_the_reference_loop(bj, kind, K, N, dt):
+    """src/vector/order/order.jl:14-76 restated as its two loops (scalar link with the sign flipped back for a decreasing link, then
+    y₁, log(yᵢ − yᵢ₋₁)); the device path is one bjx_chain launch + bjx_ordered; the inverse wrap undoes it."""
+    V = bj.vector
+    r = np.random.default_rng(K * 100 + N)
+    if kind == "log":
+        x = np.sort(r.gamma(2.0, size=(K, N)), axis=0)
+        link = V.Log(0.0, 1)
+    elif kind == "unit":
+        x = np.sort(r.uniform(0.02, 0.98, size=(K, N)), axis=0)
+        link = V.Untruncate(0.0, 1.0)
+    else:
+        x = np.sort(2.0 - r.gamma(2.0, size=(K, N)), axis=0)
+        link = V.Untruncate(-math.inf, 2.0)
+    x = F(x, dt)
+    x64 = x.astype(np.float64)
+    s = -1.0 if V.is_monotonically_decreasing(link) else 1.0
+    assert (s < 0) == (kind == "upper")
+    yl, lj = _link_np(kind, x64)
+    y = s * yl
+    ref = y.copy()
+    ladj = lj.sum(axis=0)
+    for i in range(1, K):
+        ref[i] = np.log(y[i] - y[i - 1])
+        ladj -= ref[i]
+    w = V.JointOrderWrap(link)
+    got, l = bj.with_logabsdet_jacobian(w, dev(x), per_sample=True)
+    sc = 200 if dt == np.float32 else 1e4
+    close(host(got), ref, dt, scale=sc, what=f"JointOrderWrap({kind})")
+    close(host(l), ladj, dt, scale=sc * K, what="JointOrderWrap ladj")
+    back, lb = bj.with_logabsdet_jacobian(bj.inverse(w), got, per_sample=True)
+    close(host(back), x64, dt, scale=sc, what="InverseJointOrderWrap")
+    close(host(lb), -ladj, dt, scale=sc * K, what="InverseJointOrderWrap ladj")
+    # MvLogNormal's links over the same columns
+    pos = F(np.exp(r.normal(size=(K, N))), dt)
+    yl2, l2 = bj.with_logabsdet_jacobian(V.MapLog(), dev(pos), per_sample=True)
+    close(host(yl2), np.log(pos.astype(np.float64)), dt, what="MapLog")
+    close(host(l2), -np.log(pos.astype(np.float64)).sum(axis=0), dt, scale=K, what="MapLog ladj")
+    ye, le = bj.with_logabsdet_jacobian(V.MapExp(), yl2, per_sample=True)
+    close(host(ye), pos.astype(np.float64), dt, scale=10, what="MapExp")
