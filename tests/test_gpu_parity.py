@@ -675,10 +675,26 @@ def test_inkernel_finalize_is_bit_identical_to_two_pass(bj):
             if it % 8 == 0 or it > 9990:                      # (a host read per launch would serialise the stream and hide races)
                 assert torch.equal(lsum, two_pass[k]), f"launch {it}: {float(lsum)!r} != {float(two_pass[k])!r}"
         torch.cuda.synchronize()
+        # mode 2 (the default since round 5: sentinel hand-off, no arrival counter, group-closing blocks poll): another FIXED order —
+        # run-to-run identical bits, within 1e-13 of the two-pass sum — under the same load; a slot that was not put back to the
+        # sentinel, or a poll that gave up, would show as a difference or a NaN
+        _set_fin_mode(bj, 2)
+        sent = [bj.shard.with_logabsdet_jacobian_sharded(layer, xs[k], out=y)[2].clone() for k in (0, 1)]
+        for k in (0, 1):
+            assert abs(float(sent[k]) - float(two_pass[k])) <= 1e-13 * max(1.0, abs(float(two_pass[k])))
+        for it in range(10000):
+            if it % 50 == 0:
+                with torch.cuda.stream(side):
+                    big_b.copy_(big_a, non_blocking=True)
+            k = it & 1
+            _, lps, lsum = bj.shard.with_logabsdet_jacobian_sharded(layer, xs[k], out=y)
+            if it % 8 == 0 or it > 9990:
+                assert torch.equal(lsum, sent[k]), f"sentinel launch {it}: {float(lsum)!r} != {float(sent[k])!r}"
+        torch.cuda.synchronize()
     finally:
-        _set_fin_mode(bj, 0)
+        _set_fin_mode(bj, 2)                                                                 # the library's default
     _, lps0, lsum0 = bj.shard.with_logabsdet_jacobian_sharded(layer, xs[0], out=y)      # back on the default
-    assert torch.equal(lsum0, two_pass[0])
+    assert torch.equal(lsum0, sent[0])
     assert abs(float(two_pass[0]) - float(lps0.double().sum())) <= 1e-9 * max(1.0, abs(float(two_pass[0])))
     assert not torch.equal(two_pass[0], two_pass[1])
 
@@ -686,7 +702,8 @@ def test_inkernel_finalize_is_bit_identical_to_two_pass(bj):
 @pytest.mark.parametrize("case", ["chain_f64_vector", "chain_f32_matrix", "ordered_one_wave_blocks", "rqs", "stacked_mixed"])
 def test_finalize_modes_give_the_same_bits(bj, case):
     """Every kernel family that takes the in-kernel epilogue — 256-thread blocks (chains, Planar, RQS) and one-wave blocks (the
-    column walkers) — returns the SAME Float64 sum in mode 0 (two follow-up launches, the default) and 1 (in-kernel)."""
+    column walkers) — returns the SAME Float64 sum in mode 0 (two follow-up launches) and 1 (arrival ticket), and a deterministic
+    sum equal to rounding in mode 2 (sentinel hand-off, the default)."""
     r = rng(77)
     if case == "chain_f64_vector":            # BASELINE configs[0]
         x = torch.from_numpy(r.normal(size=1 << 20)).cuda()
@@ -712,16 +729,19 @@ def test_finalize_modes_give_the_same_bits(bj, case):
         run = lambda: bj.shard.with_logabsdet_jacobian_sharded(st, x)[2]
     got = {}
     try:
-        for mode in (0, 1, 1, 0):
+        for mode in (0, 1, 2, 1, 0, 2):
             _set_fin_mode(bj, mode)
             got.setdefault(mode, []).append(run().clone())
     finally:
-        _set_fin_mode(bj, 0)
+        _set_fin_mode(bj, 2)                     # the library's default
     ref = got[0][0]
     assert math.isfinite(float(ref)) and float(ref) != 0.0
-    for mode, vals in got.items():
-        for v in vals:
+    for mode in (0, 1):
+        for v in got[mode]:
             assert torch.equal(v, ref), f"{case}: mode {mode} gives {float(v)!r}, two-pass {float(ref)!r}"
+    # mode 2 sums in another fixed order: identical from run to run, equal to the two-pass sum to rounding
+    assert torch.equal(got[2][0], got[2][1]), f"{case}: the sentinel hand-off is not deterministic"
+    assert abs(float(got[2][0]) - float(ref)) <= 1e-13 * max(1.0, abs(float(ref))), f"{case}: mode 2 {float(got[2][0])!r} vs two-pass {float(ref)!r}"
 
 
 # ------------------------------------------------------------------ §8(f) f-4: Stacked
