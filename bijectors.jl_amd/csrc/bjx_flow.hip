@@ -2472,6 +2472,148 @@ __global__ __launch_bounds__(256) void radial_tall_kernel(const RadialArgs<T> A,
   if (partials) block_publish_partial(acc, redd, partials);
 }
 
+// The input pullbacks on columns of any height (same mapping: one block per column, passes of 16-byte packs).
+//   Planar: the primal sweep walks the column n_layers times (pass l applies layer l-1's update and accumulates w_lᵀz; the column
+//   between passes lives in the block's workspace column, t_l in LDS), the reverse sweep n_layers + 1 times (pass i adds
+//   w s̄ of the layer before and accumulates ûᵀz̄ of the next; between passes z̄ lives in the OUTPUT column).  Formulas as in
+//   planar_vjp_kernel above.
+template <class T, int V, bool INV>
+__global__ __launch_bounds__(256) void planar_vjp_tall_kernel(const PlanarArgs<T> A, const T* x, const T* ybar, const T* lbar, T* xbar, T* ws,
+                                                              int64_t dim, int64_t batch, T* t_out, T* s_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tsave = reinterpret_cast<T*>(smem);               // [n_layers]
+  __shared__ T red[5];
+  const int64_t nv = dim / V;
+  const int nl = A.n_layers;
+  for (int64_t col = blockIdx.x; col < batch; col += gridDim.x) {
+    const T* xc = x + col * dim;
+    T* zc = ws + (int64_t)blockIdx.x * dim;
+    T tt = T(0);
+    for (int li = 0; li < nl; ++li) {
+      const int l = INV ? nl - 1 - li : li;
+      const int lp = INV ? l + 1 : l - 1;
+      const T* wl = A.w + (int64_t)l * dim;
+      const T* ul = li > 0 ? A.u_hat + (int64_t)lp * dim : nullptr;
+      const T* src = li <= 1 ? xc : zc;                // pass 0 only reads; pass 1 reads x again and writes the workspace
+      const bool keep = li + 1 < nl;                   // the column after the last layer is not needed: only the t_l are
+      T s = T(0);
+      for (int64_t v = threadIdx.x; v < nv; v += 256) {
+        Pack<T, V> z = load_pack<T, V, false>(src + v * V);
+        if (ul) {
+          const Pack<T, V> u = load_pack<T, V, false>(ul + v * V);
+#pragma unroll
+          for (int j = 0; j < V; ++j) z.v[j] += u.v[j] * tt;
+        }
+        const Pack<T, V> w = load_pack<T, V, false>(wl + v * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) s += w.v[j] * z.v[j];
+        if (ul && keep) store_pack<T, V, false>(zc + v * V, z);
+      }
+      s = block_sum_256(s, red);
+      T t;
+      if (!INV) { t = x_tanh(s + A.b[l]); tt = t; }
+      else { t = x_tanh(find_alpha_dev<T>(s, A.wtu_hat[l], A.b[l]) + A.b[l]); tt = -t; }
+      if (threadIdx.x == 0) tsave[l] = t;
+    }
+    __syncthreads();
+    const T lb = lbar ? lbar[col] : T(0);
+    const T* gc = ybar + col * dim;
+    T* oc = xbar + col * dim;
+    T sbp = T(0);
+    int lprev = 0;
+    for (int li = 0; li <= nl; ++li) {
+      const int l = INV ? li : nl - 1 - li;
+      const T* ul = li < nl ? A.u_hat + (int64_t)l * dim : nullptr;
+      const T* wp = li > 0 ? A.w + (int64_t)lprev * dim : nullptr;
+      const T* src = li <= 1 ? gc : oc;
+      T d = T(0);
+      for (int64_t v = threadIdx.x; v < nv; v += 256) {
+        Pack<T, V> z = load_pack<T, V, false>(src + v * V);
+        if (wp) {
+          const Pack<T, V> w = load_pack<T, V, false>(wp + v * V);
+#pragma unroll
+          for (int j = 0; j < V; ++j) z.v[j] += w.v[j] * sbp;
+        }
+        if (ul) {
+          const Pack<T, V> u = load_pack<T, V, false>(ul + v * V);
+#pragma unroll
+          for (int j = 0; j < V; ++j) d += u.v[j] * z.v[j];
+        }
+        if (wp) store_pack<T, V, false>(oc + v * V, z);
+      }
+      if (li < nl) {
+        d = block_sum_256(d, red);
+        const T t = tsave[l], c = A.wtu_hat[l];
+        const T q = T(1) - t * t;
+        if (!INV) {
+          sbp = d * q + lb * c * (T(-2) * t) * q / (T(1) + c * q);
+          if (s_out && threadIdx.x == 0) { s_out[col * nl + l] = sbp; t_out[col * nl + l] = t; }
+        } else {
+          const T den = T(1) + c * q;
+          sbp = q / den * (-d + lb * T(2) * c * t / den);
+        }
+        lprev = l;
+      }
+    }
+    __syncthreads();                                   // tsave and the workspace column are reused by the block's next column
+  }
+}
+
+//   Radial: two passes — (‖δ‖², δᵀȳ), then z̄ = ca ȳ + cd δ (coefficients as in radial_vjp_kernel above).
+template <class T, int V, bool INV>
+__global__ __launch_bounds__(256) void radial_vjp_tall_kernel(const RadialArgs<T> A, const T* x, const T* gbar, const T* lbar, T* xbar, int64_t dim,
+                                                              int64_t batch, T* work) {
+  __shared__ T red[5];
+  const T alpha = d_log1pexp(A.alpha_[0]);
+  const T apb = d_log1pexp(A.beta[0]);
+  const T bh = -alpha + apb;
+  const int64_t nv = dim / V;
+  for (int64_t col = blockIdx.x; col < batch; col += gridDim.x) {
+    const T* xc = x + col * dim;
+    const T* gc = gbar + col * dim;
+    T ss = T(0), dg = T(0);
+    for (int64_t v = threadIdx.x; v < nv; v += 256) {
+      const Pack<T, V> z = load_pack<T, V, false>(xc + v * V), z0 = load_pack<T, V, false>(A.z0 + v * V), g = load_pack<T, V, false>(gc + v * V);
+#pragma unroll
+      for (int j = 0; j < V; ++j) { const T dlt = z.v[j] - z0.v[j]; ss += dlt * dlt; dg += dlt * g.v[j]; }
+    }
+    ss = block_sum_256(ss, red);
+    dg = block_sum_256(dg, red);
+    T rr, gain = T(1);
+    if (!INV) rr = d_sqrt(ss);
+    else {
+      const T gam = d_sqrt(ss);
+      const T aa = apb - gam;
+      const T r0 = (d_sqrt(aa * aa + 4 * alpha * gam) - aa) / 2;
+      gain = (alpha + r0) / (apb + r0);
+      rr = gain * gam;
+    }
+    const T h = T(1) / (alpha + rr);
+    const T a = T(1) + bh * h;
+    const T rinv = rr > T(0) ? T(1) / rr : T(0);
+    const T c = -bh * h * h * rinv;
+    const T lr = T(dim - 1) * (-bh * h * h) / a + (T(-2) * bh * h * h + T(2) * bh * h * h * h * rr) / (T(1) + bh * h - bh * h * h * rr);
+    const T lb = lbar ? lbar[col] : T(0);
+    const T kl = lb * lr * rinv;
+    if (!INV && work && threadIdx.x == 0) { work[col] = rr; work[batch + col] = dg; }
+    T ca, cd;
+    if (!INV) { ca = a; cd = c * dg + kl; }
+    else {
+      const T dv = gain * dg - kl * rr * rr;
+      ca = T(1) / a;
+      cd = gain * (-kl / a - c * dv / (a * (a + c * rr * rr)));
+    }
+    T* oc = xbar + col * dim;
+    for (int64_t v = threadIdx.x; v < nv; v += 256) {
+      const Pack<T, V> z = load_pack<T, V, false>(xc + v * V), z0 = load_pack<T, V, false>(A.z0 + v * V), g = load_pack<T, V, false>(gc + v * V);
+      Pack<T, V> o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.v[j] = ca * g.v[j] + cd * (z.v[j] - z0.v[j]);
+      store_pack<T, V, false>(oc + v * V, o);
+    }
+  }
+}
+
 template <class T> bool flow_cfg(const bjx_ctx* ctx, const void* x, const void* y, int64_t dim, int64_t batch, FlowCfg* c, bool allow_unal = false) {
   constexpr int VW = Vec16<T>::N;
   const bool v_ok = bjx_aligned16(x) && bjx_aligned16(y) && dim % VW == 0;
@@ -2892,13 +3034,41 @@ inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float
 template <class T>
 int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, int nl, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar,
                     int64_t dim, int64_t batch, T* t_out = nullptr, T* s_out = nullptr) {
-  const size_t need = ((size_t)nl * dim + nl) * sizeof(T);
-  BJX_REQUIRE(ctx, need <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: n_layers*dim = %lld exceeds the context scratch", (long long)nl * dim);
+  const size_t need = (((size_t)nl * dim + nl) * sizeof(T) + 255) / 256 * 256;
   T* u_hat = static_cast<T*>(ctx->scratch);
+  const int64_t capt = (int64_t)ctx->num_cu * 8;                       // blocks (= workspace columns) of the tall-column kernel
+  const int gridt = (int)(batch < capt ? batch : capt);
+  size_t ws_off = 0;
+  if (need > BJX_SCRATCH_BYTES) {
+    // û of a stack this large (only the tall-column kernel gets here) lives in the grown workspace, in front of the column workspace
+    { int rc = bjx_ensure_big_ws(ctx, need + (size_t)gridt * dim * sizeof(T)); if (rc) return rc; }
+    u_hat = static_cast<T*>(ctx->big_ws);
+    ws_off = need;
+  }
   T* wtu = u_hat + (size_t)nl * dim;
   hipLaunchKernelGGL(planar_prep_kernel<T>, dim3(nl), dim3(256), 0, ctx->stream, w, u, dim, u_hat, wtu);
   BJX_CHECK_LAUNCH(ctx);
   if (batch == 0) return BJX_OK;
+  auto launch_tall = [&]() -> int {
+    // columns taller than the register kernels hold: one block per column (planar_vjp_tall_kernel)
+    BJX_REQUIRE(ctx, batch < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: batch too large for one launch");
+    BJX_REQUIRE(ctx, (size_t)nl * sizeof(T) <= 32 * 1024, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: too many layers (%d)", nl);
+    if (ws_off == 0) { int rc = bjx_ensure_big_ws(ctx, (size_t)gridt * dim * sizeof(T)); if (rc) return rc; }
+    T* ws = reinterpret_cast<T*>(static_cast<char*>(ctx->big_ws) + ws_off);
+    PlanarArgs<T> At{w, u_hat, wtu, b, nl, 0};
+    constexpr int VWt = Vec16<T>::N;
+    const bool v_ok = dim % VWt == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar) && bjx_aligned16(u_hat) && bjx_aligned16(w);
+    const size_t smem_t = (size_t)nl * sizeof(T);
+    {
+      BjxProf prof_(ctx);
+#define LAUNCH_PVT(V_, INV_) hipLaunchKernelGGL((planar_vjp_tall_kernel<T, V_, INV_>), dim3(gridt), dim3(256), smem_t, ctx->stream, At, in, out_bar, ladj_bar, in_bar, ws, dim, batch, t_out, s_out)
+      if (v_ok) { if (inverse) LAUNCH_PVT(VWt, true); else LAUNCH_PVT(VWt, false); }
+      else { if (inverse) LAUNCH_PVT(1, true); else LAUNCH_PVT(1, false); }
+#undef LAUNCH_PVT
+    }
+    BJX_CHECK_LAUNCH(ctx);
+    return BJX_OK;
+  };
   {
     // low-dimensional columns: one lane per column (planar_vjp_walk_kernel)
     static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 32;
@@ -2953,8 +3123,7 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
   FlowCfg c;
   // (odd heights / element-aligned bases take 16-byte packs with a partial last pack, like the forward group kernel: the 4-byte
   //  form ran the pullback of eight layers at 201 rows at 16 % of the HBM peak)
-  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, in_bar, dim, batch, &c, true), BJX_ERR_UNSUPPORTED,
-              "bjx_planar_vjp: dim %lld too large for the register-resident kernel", (long long)dim);
+  if (!flow_cfg<T>(ctx, in, in_bar, dim, batch, &c, true)) return launch_tall();
   const int cols_per_block = 256 / c.G;
   const size_t tsave_bytes = ((size_t)cols_per_block * nl * sizeof(T) + 15) / 16 * 16;
   const size_t tab_bytes = (size_t)2 * nl * dim * sizeof(T);
@@ -2976,7 +3145,7 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
     int64_t need_r = (dim + G - 1) / G;
     int R = 1;
     while (R < need_r) R <<= 1;
-    BJX_REQUIRE(ctx, R <= 32, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: dim %lld too large for the register-resident kernel", (long long)dim);
+    if (R > 32) return launch_tall();
     c.G = G; c.R = R; c.grid = (batch + (256 / G) - 1) / (256 / G);
     const int cpb = 256 / G;
     const size_t smem1 = (size_t)cpb * nl * sizeof(T) + (lds ? tab_bytes : 0);
@@ -3484,6 +3653,76 @@ __global__ __launch_bounds__(64) void planar_param_mfma_small_kernel(const float
   if (lk == 0 && lay_ok) { out[2 * n_m + (size_t)nlg * nlg + li] = b_; out[2 * n_m + (size_t)nlg * nlg + nlg + li] = c_; }
 }
 
+// ---- the same sums for columns beyond the register accumulators (more than 64 lanes x 4 packs, or a partial set beyond the LDS):
+// a block owns 256·V ROWS (blockIdx.x) and a slice of the batch (columns blockIdx.y, + gridDim.y, ...); a thread keeps the
+// [V rows] x [layer group] accumulators of M1 and M2 and writes them into the slice's Float64 set.  The Gram block, b̄ and c̄ do not
+// depend on the rows: planar_param_sums_kernel writes them into the summed set.
+template <class T, int V>
+__global__ __launch_bounds__(256) void planar_param_rows_kernel(const T* __restrict__ z0, const T* __restrict__ ybar, const T* __restrict__ sbar,
+                                                                const T* __restrict__ tt, int64_t dim, int64_t batch, int nl, int l0, int nlg,
+                                                                double* __restrict__ partial) {
+  const int64_t row0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
+  const bool ok = row0 < dim;                            // V = 1 unless the height is a whole number of packs
+  T m1[V][PP_NLG], m2[V][PP_NLG];
+#pragma unroll
+  for (int j = 0; j < V; ++j)
+#pragma unroll
+    for (int k = 0; k < PP_NLG; ++k) { m1[j][k] = T(0); m2[j][k] = T(0); }
+  for (int64_t col = blockIdx.y; col < batch; col += gridDim.y) {
+    T sk[PP_NLG], tk[PP_NLG];
+#pragma unroll
+    for (int k = 0; k < PP_NLG; ++k) { sk[k] = k < nlg ? sbar[col * nl + l0 + k] : T(0); tk[k] = k < nlg ? tt[col * nl + l0 + k] : T(0); }
+    if (ok) {
+      const Pack<T, V> pz = load_pack<T, V, false>(z0 + col * dim + row0), pg = load_pack<T, V, false>(ybar + col * dim + row0);
+#pragma unroll
+      for (int j = 0; j < V; ++j)
+#pragma unroll
+        for (int k = 0; k < PP_NLG; ++k) { m1[j][k] += pz.v[j] * sk[k]; m2[j][k] += pg.v[j] * tk[k]; }
+    }
+  }
+  const size_t n_m = (size_t)dim * nlg;
+  const size_t per = 2 * n_m + (size_t)nlg * nlg + 2 * (size_t)nlg;
+  double* out = partial + (size_t)blockIdx.y * per;
+  if (ok) {
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+      for (int k = 0; k < nlg; ++k) {
+        out[(size_t)(row0 + j) * nlg + k] = (double)m1[j][k];
+        out[n_m + (size_t)(row0 + j) * nlg + k] = (double)m2[j][k];
+      }
+  }
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nlg * nlg + 2 * nlg; i += 256) out[2 * n_m + i] = 0.0;
+}
+
+// one block per entry of [ST nlg*nlg][b̄ nlg][c̄ nlg] of a layer group, summed over the whole batch in Float64
+template <class T>
+__global__ __launch_bounds__(256) void planar_param_sums_kernel(const T* __restrict__ sbar, const T* __restrict__ tt, const T* __restrict__ lbar,
+                                                                const T* __restrict__ wtu_hat, int64_t batch, int nl, int l0, int nlg, double* __restrict__ out) {
+  __shared__ double red[4];
+  const int e = blockIdx.x;
+  double acc = 0.0;
+  if (e < nlg * nlg) {
+    const int j = l0 + e / nlg, k = l0 + e % nlg;
+    for (int64_t n = threadIdx.x; n < batch; n += 256) acc += (double)sbar[n * nl + j] * (double)tt[n * nl + k];
+  } else if (e < nlg * nlg + nlg) {
+    const int k = l0 + e - nlg * nlg;
+    for (int64_t n = threadIdx.x; n < batch; n += 256) acc += (double)sbar[n * nl + k];
+  } else {
+    const int k = l0 + e - nlg * nlg - nlg;
+    const double c = (double)wtu_hat[k];
+    if (lbar)
+      for (int64_t n = threadIdx.x; n < batch; n += 256) {
+        const double t = (double)tt[n * nl + k], q = 1.0 - t * t;
+        acc += (double)lbar[n] * q / (1.0 + c * q);
+      }
+  }
+  acc = group_sum<64>(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[e] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void planar_gram_kernel(const T* __restrict__ sbar, const T* __restrict__ tt, int64_t batch, int nl, double* __restrict__ st) {
   __shared__ double red[4];
@@ -3596,12 +3835,49 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
   T* t_out = work + (size_t)nl * batch;
   int rc = planar_vjp_impl<T>(ctx, 0, w, u, b, nl, in, out_bar, ladj_bar, in_bar, dim, batch, t_out, s_out);
   if (rc) return rc;
-  // tables left in the scratch by planar_vjp_impl: û [nl][dim], wᵀû [nl]
-  const T* u_hat = static_cast<const T*>(ctx->scratch);
+  // tables left by planar_vjp_impl: û [nl][dim], wᵀû [nl] — in the scratch, or (a stack too large for it) at the head of the grown workspace
+  const T* u_hat = (((size_t)nl * dim + nl) * sizeof(T) + 255) / 256 * 256 > BJX_SCRATCH_BYTES ? static_cast<const T*>(ctx->big_ws) : static_cast<const T*>(ctx->scratch);
   const T* wtu = u_hat + (size_t)nl * dim;
   FlowCfg c;
-  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, out_bar, dim, batch, &c, true) && c.R <= 4, BJX_ERR_UNSUPPORTED,
-              "bjx_planar_vjp_params: dim %lld too large for the register accumulators", (long long)dim);
+  const size_t nlg_max = nl < PP_NLG ? nl : PP_NLG;
+  // beyond 64 lanes x 4 packs (1 024 rows Float32, 512 Float64), or a partial set beyond the LDS: rows owned by threads (planar_param_rows_kernel)
+  const bool rows_path = !(flow_cfg<T>(ctx, in, out_bar, dim, batch, &c, true) && c.R <= 4) ||
+                         (2 * (size_t)dim * nlg_max + nlg_max * nlg_max + 2 * nlg_max) * sizeof(double) > BJX_LDS_MAX;
+  if (rows_path) {
+    constexpr int VWr = Vec16<T>::N;
+    const bool v_ok = dim % VWr == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar);
+    const int Vr = v_ok ? VWr : 1;
+    const int64_t chunks = (dim + 256 * (int64_t)Vr - 1) / (256 * (int64_t)Vr);
+    BJX_REQUIRE(ctx, chunks < 65536, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp_params: dim %lld too large", (long long)dim);
+    const size_t per_max_r = 2 * (size_t)dim * nlg_max + nlg_max * nlg_max + 2 * nlg_max;
+    int64_t S = 2048 / chunks;
+    const int64_t s_mem = (int64_t)(((size_t)64 << 20) / (per_max_r * sizeof(double)));
+    if (S > s_mem) S = s_mem;
+    if (S > batch) S = batch;
+    if (S < 1) S = 1;
+    const size_t st_n = (size_t)nl * nl;
+    { int rc2 = bjx_ensure_partials(ctx, (size_t)S * per_max_r + st_n + per_max_r); if (rc2) return rc2; }
+    double* partial = ctx->partials;
+    double* st = partial + (size_t)S * per_max_r;
+    double* psum = st + st_n;
+    const bool one_group = nl <= PP_NLG;
+    if (!one_group) {
+      hipLaunchKernelGGL(planar_gram_kernel<T>, dim3(nl * nl), dim3(256), 0, ctx->stream, s_out, t_out, batch, nl, st);
+      BJX_CHECK_LAUNCH(ctx);
+    }
+    for (int l0 = 0; l0 < nl; l0 += PP_NLG) {
+      const int nlg = nl - l0 < PP_NLG ? nl - l0 : PP_NLG;
+      const size_t per = 2 * (size_t)dim * nlg + (size_t)nlg * nlg + 2 * (size_t)nlg;
+      BjxProf prof_(ctx);
+      if (v_ok) hipLaunchKernelGGL((planar_param_rows_kernel<T, VWr>), dim3((unsigned)chunks, (unsigned)S), dim3(256), 0, ctx->stream, in, out_bar, s_out, t_out, dim, batch, nl, l0, nlg, partial);
+      else hipLaunchKernelGGL((planar_param_rows_kernel<T, 1>), dim3((unsigned)chunks, (unsigned)S), dim3(256), 0, ctx->stream, in, out_bar, s_out, t_out, dim, batch, nl, l0, nlg, partial);
+      hipLaunchKernelGGL(planar_param_colsum_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, ctx->stream, partial, (int)S, per, psum, 0);
+      hipLaunchKernelGGL(planar_param_sums_kernel<T>, dim3(nlg * nlg + 2 * nlg), dim3(256), 0, ctx->stream, s_out, t_out, ladj_bar, wtu, batch, nl, l0, nlg, psum + 2 * (size_t)dim * nlg);
+      hipLaunchKernelGGL(planar_param_finalize_kernel<T>, dim3(nlg), dim3(256), 0, ctx->stream, psum, 1, dim, nl, l0, nlg, one_group ? (const double*)nullptr : (const double*)st, w, u, u_hat, w_bar, u_bar, b_bar);
+      BJX_CHECK_LAUNCH(ctx);
+    }
+    return BJX_OK;
+  }
   // planar_param_reduce_kernel gives the Gram row / b̄ / c̄ of layer l0 + gl to lane gl of a column's group: the group must have at
   // least PP_NLG lanes even when the column is only one or two packs (dim <= 4·PP_NLG: lanes without a pack only do that part).
   // (Found with dim = 2, 4, 8: with G < 8 the rows of the upper layers were never accumulated — wrong w̄, ū, b̄.)
@@ -3746,8 +4022,25 @@ int radial_vjp_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, c
     }
   }
   FlowCfg c;
-  BJX_REQUIRE(ctx, flow_cfg<T>(ctx, in, in_bar, dim, batch, &c, true), BJX_ERR_UNSUPPORTED, "bjx_radial_vjp: dim %lld too large for the register-resident kernel", (long long)dim);
   constexpr int VW = Vec16<T>::N;
+  auto launch_tall = [&]() -> int {
+    // columns taller than the register kernels hold: one block per column, two passes (radial_vjp_tall_kernel)
+    BJX_REQUIRE(ctx, batch < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_radial_vjp: batch too large for one launch");
+    const int64_t capt = (int64_t)ctx->num_cu * 8;
+    const int gridt = (int)(batch < capt ? batch : capt);
+    RadialArgs<T> At{alpha_, beta, z0, 0};
+    const bool v_ok = dim % VW == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar) && bjx_aligned16(z0);
+    {
+      BjxProf prof_(ctx);
+#define LAUNCH_RVT(V_, INV_) hipLaunchKernelGGL((radial_vjp_tall_kernel<T, V_, INV_>), dim3(gridt), dim3(256), 0, ctx->stream, At, in, out_bar, ladj_bar, in_bar, dim, batch, work)
+      if (v_ok) { if (inverse) LAUNCH_RVT(VW, true); else LAUNCH_RVT(VW, false); }
+      else { if (inverse) LAUNCH_RVT(1, true); else LAUNCH_RVT(1, false); }
+#undef LAUNCH_RVT
+    }
+    BJX_CHECK_LAUNCH(ctx);
+    return BJX_OK;
+  };
+  if (!flow_cfg<T>(ctx, in, in_bar, dim, batch, &c, true)) return launch_tall();
   const bool whole = dim % VW == 0 && bjx_aligned16(in) && bjx_aligned16(in_bar);   // otherwise: element-aligned packs, partial last pack (any alignment)
   if (c.V == VW && whole && !bjx_aligned16(out_bar)) {           // scalar packs
     int G = 1;
@@ -3755,7 +4048,7 @@ int radial_vjp_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, c
     int64_t need_r = (dim + G - 1) / G;
     int R = 1;
     while (R < need_r) R <<= 1;
-    BJX_REQUIRE(ctx, R <= 32, BJX_ERR_UNSUPPORTED, "bjx_radial_vjp: dim %lld too large for the register-resident kernel", (long long)dim);
+    if (R > 32) return launch_tall();
     c.V = 1; c.G = G; c.R = R;
   }
   {

@@ -373,6 +373,78 @@ def test_radial_columns_taller_than_the_register_kernels(bj, orc, dim, N, dt):
     close(host(lb), -l_ref, dt, scale=dim, what="tall radial inv ladj")
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,N,nl", [(8196, 5, 3), (8193, 3, 2), (16384, 4, 8), (4100, 7, 1), (4099, 2, 2), (20000, 2, 2), (4104, 1500, 2)])
+def test_planar_pullback_on_columns_taller_than_the_register_kernels(bj, orc, dim, N, nl, dt):
+    """bjx_planar_vjp refused these heights until round 5 ('dim too large for the register-resident kernel').  planar_vjp_tall_kernel:
+    one block per column, the primal sweep through a workspace column, the reverse sweep through the output column; the layer and
+    its inverse, with and without the log-det cotangent, against the finite-difference-pinned oracle."""
+    if dt == np.float32 and dim < 8193:
+        pytest.skip("the register kernels still serve this height in Float32")
+    r = np.random.default_rng(dim + 7 * nl)
+    w = (r.normal(size=(dim, nl)) / math.sqrt(dim)).astype(dt)
+    u = (r.normal(size=(dim, nl)) / math.sqrt(dim)).astype(dt)
+    bb = r.normal(size=nl).astype(dt)
+    Z = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    g = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    lb = r.normal(size=N).astype(dt)
+    layer = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(bb))
+    ref = orc.planar_vjp(w, u, bb, Z, g, lb)
+    got = bj.vjp(layer, dev(Z), dev(g), torch.from_numpy(lb).cuda())
+    np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())))
+    ref0 = orc.planar_vjp(w, u, bb, Z, g)
+    np.testing.assert_allclose(host(bj.vjp(layer, dev(Z), dev(g))), ref0, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref0).max())))
+    ref_i = orc.planar_inv_vjp(w, u, bb, Z, g, lb)
+    got_i = bj.vjp(bj.inverse(layer), dev(Z), dev(g), torch.from_numpy(lb).cuda())
+    np.testing.assert_allclose(host(got_i), ref_i, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref_i).max())))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,N", [(8196, 5), (8193, 3), (16384, 3), (4100, 6), (4099, 2), (4104, 1500)])
+def test_radial_pullback_on_columns_taller_than_the_register_kernels(bj, orc, dim, N, dt):
+    if dt == np.float32 and dim < 8193:
+        pytest.skip("the register kernels still serve this height in Float32")
+    r = np.random.default_rng(dim + 1)
+    al, be = np.array([0.3], dtype=dt), np.array([0.7], dtype=dt)
+    z0 = r.normal(size=dim).astype(dt)
+    layer = bj.RadialLayer(torch.tensor(al), torch.tensor(be), torch.tensor(z0))
+    Z = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    g = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    lb = r.normal(size=N).astype(dt)
+    for inv in (False, True):
+        b = bj.inverse(layer) if inv else layer
+        ref = orc.radial_vjp(al, be, z0, Z, g, lb, inverse=inv)
+        got = bj.vjp(b, dev(Z), dev(g), torch.from_numpy(lb).cuda())
+        np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())))
+        ref0 = orc.radial_vjp(al, be, z0, Z, g, inverse=inv)
+        np.testing.assert_allclose(host(bj.vjp(b, dev(Z), dev(g))), ref0, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref0).max())))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,N,nl", [(1028, 300, 3), (1025, 70, 2), (2048, 129, 8), (600, 257, 12), (8196, 40, 3), (16384, 9, 8), (4099, 33, 10), (1500, 3000, 1)])
+def test_planar_parameter_pullback_beyond_the_register_accumulators(bj, orc, dim, N, nl, dt):
+    """bjx_planar_vjp_params refused more than 1 024 Float32 / 512 Float64 rows until round 5.  planar_param_rows_kernel: threads own
+    rows, blocks own a slice of the batch; the Gram block, b̄ and c̄ by planar_param_sums_kernel; more than one layer group (nl > 8)
+    takes the cross-group Gram pass."""
+    if dt == np.float32 and dim <= 1024:
+        pytest.skip("the register accumulators still serve this height in Float32")
+    r = np.random.default_rng(dim + 3 * nl)
+    w = (r.normal(size=(dim, nl)) / math.sqrt(dim)).astype(dt)
+    u = (r.normal(size=(dim, nl)) / math.sqrt(dim)).astype(dt)
+    bb = r.normal(size=nl).astype(dt)
+    Z = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    g = np.asfortranarray((r.normal(size=(dim, N)) / math.sqrt(N)).astype(dt))
+    lb = (r.normal(size=N) / math.sqrt(N)).astype(dt)
+    layer = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(bb))
+    wb_ref, ub_ref, bb_ref = orc.planar_param_vjp(w, u, bb, Z, g, lb)
+    xb, pb = bj.vjp_params(layer, dev(Z), dev(g), torch.from_numpy(lb).cuda())
+    np.testing.assert_allclose(host(xb), orc.planar_vjp(w, u, bb, Z, g, lb), rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10)
+    tol = dict(rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(wb_ref).max()), float(np.abs(ub_ref).max())))
+    np.testing.assert_allclose(host(pb["w"]).reshape(dim, nl), wb_ref.reshape(dim, nl), **tol)
+    np.testing.assert_allclose(host(pb["u"]).reshape(dim, nl), ub_ref.reshape(dim, nl), **tol)
+    np.testing.assert_allclose(host(pb["b"]).reshape(-1), bb_ref.reshape(-1), **tol)
+
+
 # ---------------------------------------------------------------- round 5: VectorBijectors links of JointOrderStatistics / MvLogNormal
 def _link_np(kind, x):
     """(y, per-element log-det) of the scalar links used below, restated from src/vector/univariate/{positive,truncated}.jl"""
