@@ -2559,6 +2559,209 @@ __global__ __launch_bounds__(256) void planar_vjp_tall_kernel(const PlanarArgs<T
   }
 }
 
+// Between the register tiles (Float32 to 1 024 rows) and the kernel above: a BLOCK owns C columns at a time, thread t holds the packs
+// t, t + 256, ... (R of them) of each of the C columns in registers.  planar_vjp_kernel gives a column to 64 lanes: every wave loads the
+// w / û rows of every layer for ONE column (2·n_layers·dim per column through the L2: 4–5 TB/s of parameter traffic, 5 % of the HBM
+// roofline at 1 500 … 8 192 rows) and evaluates ONE tanh on 64 lanes; here a parameter pack is loaded once for C columns and the
+// C dot products of a layer are reduced together (one butterfly each, one barrier per layer: the LDS slots alternate by layer parity).
+// Packs on element-aligned addresses, the last one partial.  C·R = 16 (8 at R = 1): 64 data registers.  (Blocks of 512 / 1 024 threads that keep
+// R small and C large beyond 4 096 rows: no faster at 512 — 153–179 registers — and spilled at 1 024.)
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <int G> __device__ __forceinline__ float group_sum_fast(float v) { return group_sum_f32_dpp<G>(v); }
+template <int G> __device__ __forceinline__ double group_sum_fast(double v) { return group_sum<G>(v); }
+// C values per lane -> lane L holds the wave sum of value L / (64 / C): log2(C) halving exchanges (C/2 + C/4 + ... shuffles in all)
+// and one butterfly over the 64 / C lanes that are left, instead of C full butterflies (6·C shuffles).
+template <class T, int C> __device__ __forceinline__ T wave_sum_scatter(const T (&s)[C], int lane) {
+  static_assert(C == 1 || C == 2 || C == 4 || C == 8, "C");
+  if constexpr (C == 1) return group_sum_fast<64>(s[0]);
+  else if constexpr (C == 2) {
+    const bool hi = lane & 32;
+    const T a = (hi ? s[1] : s[0]) + shfl_xor(hi ? s[0] : s[1], 32);
+    return group_sum_fast<32>(a);
+  } else if constexpr (C == 4) {
+    const bool hi = lane & 32;
+    T a[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = (hi ? s[2 + i] : s[i]) + shfl_xor(hi ? s[i] : s[2 + i], 32);
+    const bool hi2 = lane & 16;
+    const T b = (hi2 ? a[1] : a[0]) + shfl_xor(hi2 ? a[0] : a[1], 16);
+    return group_sum_fast<16>(b);
+  } else {
+    const bool hi = lane & 32;
+    T a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (hi ? s[4 + i] : s[i]) + shfl_xor(hi ? s[i] : s[4 + i], 32);
+    const bool hi2 = lane & 16;
+    T b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i] = (hi2 ? a[2 + i] : a[i]) + shfl_xor(hi2 ? a[i] : a[2 + i], 16);
+    const bool hi3 = lane & 8;
+    const T c = (hi3 ? b[1] : b[0]) + shfl_xor(hi3 ? b[0] : b[1], 8);
+    return group_sum_fast<8>(c);
+  }
+}
+
+template <class T, int V, int R, int C, bool INV, int NT>
+__global__ __launch_bounds__(NT) void planar_vjp_cols_kernel(const PlanarArgs<T> A, const T* __restrict__ x, const T* __restrict__ ybar, const T* __restrict__ lbar,
+                                                             T* __restrict__ xbar, int64_t dim, int64_t batch, T* __restrict__ t_out, T* __restrict__ s_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NWV = NT / 64;
+  constexpr bool PF = R <= 4;                          // request parameter rows ahead of the barrier (three row buffers: not at 8+ packs per thread)
+  T* red = reinterpret_cast<T*>(smem);                 // [2][NWV][C]
+  T* tsave = red + 2 * NWV * C;                        // [C][n_layers]
+  const int nl = A.n_layers;
+  const int64_t nvc = (dim + V - 1) / V;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int cme = lane & (C - 1);                      // the column whose scalar recurrence this lane evaluates (every wave redundantly, once)
+  int nrow[R];
+  int64_t off[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t v = threadIdx.x + (int64_t)r * NT;
+    off[r] = v * V;
+    nrow[r] = v < nvc ? (int)(dim - v * V < V ? dim - v * V : V) : 0;
+  }
+  int par = 0;
+  // block sums of C values: lane L of every wave gets the sum of value L & (C - 1)
+  auto reduce = [&](const T (&s)[C]) -> T {
+    const T v = wave_sum_scatter<T, C>(s, lane);
+    T* rp = red + par * NWV * C;
+    if ((lane & (64 / C - 1)) == 0) rp[wv * C + lane / (64 / C)] = v;
+    __syncthreads();
+    T a = T(0);
+#pragma unroll
+    for (int q = 0; q < NWV; ++q) a += rp[q * C + cme];
+    par ^= 1;
+    return a;
+  };
+  auto load_row = [&](const T* row, Pack<T, V> (&p)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (nrow[r] > 0) p[r] = load_pack_part<T, V>(row + off[r], nrow[r]);
+      else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) p[r].v[j] = T(0);
+      }
+    }
+  };
+  const int64_t tiles = (batch + C - 1) / C;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t col0 = tile * C;
+    Pack<T, V> z[C][R];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int64_t col = col0 + c < batch ? col0 + c : batch - 1;
+      load_row(x + col * dim, z[c]);
+    }
+    const bool me_ok = col0 + cme < batch;
+    const T lbme = (lbar && me_ok) ? lbar[col0 + cme] : T(0);
+    // ---- primal sweep: t_l of every layer and column.  The parameter rows do not depend on the data: with PF the row a step needs
+    //      AFTER its reduction (û_l) and the next step's w are requested before the barrier
+    Pack<T, V> pw[R], pu[R], pnx[R];
+    if (PF) load_row(A.w + (int64_t)(INV ? nl - 1 : 0) * dim, pw);
+    for (int li = 0; li < nl; ++li) {
+      const int l = INV ? nl - 1 - li : li;
+      const bool more = li + 1 < nl;
+      if constexpr (PF) { if (more) load_row(A.u_hat + (int64_t)l * dim, pu); }
+      else load_row(A.w + (int64_t)l * dim, pw);
+      T s[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        s[c] = T(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int j = 0; j < V; ++j) s[c] += pw[r].v[j] * z[c][r].v[j];
+      }
+      if constexpr (PF) { if (more) load_row(A.w + (int64_t)(INV ? l - 1 : l + 1) * dim, pnx); }
+      const T sme = reduce(s);
+      T tme;
+      if (!INV) tme = x_tanh(sme + A.b[l]);
+      else tme = x_tanh(find_alpha_dev<T>(sme, A.wtu_hat[l], A.b[l]) + A.b[l]);
+      if (threadIdx.x < C) tsave[threadIdx.x * nl + l] = tme;
+      if (more) {
+        if constexpr (!PF) load_row(A.u_hat + (int64_t)l * dim, pu);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const T tc = lane_bcast(tme, c);
+          const T a = INV ? -tc : tc;
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < V; ++j) z[c][r].v[j] += pu[r].v[j] * a;
+        }
+        if constexpr (PF) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) pw[r] = pnx[r];
+        }
+      }
+    }
+    __syncthreads();                                   // tsave complete
+    // ---- reverse sweep on the cotangent
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int64_t col = col0 + c < batch ? col0 + c : batch - 1;
+      load_row(ybar + col * dim, z[c]);
+    }
+    if (PF) load_row(A.u_hat + (int64_t)(INV ? 0 : nl - 1) * dim, pu);
+    for (int li = 0; li < nl; ++li) {
+      const int l = INV ? li : nl - 1 - li;
+      const bool more = li + 1 < nl;
+      if constexpr (PF) load_row(A.w + (int64_t)l * dim, pw);            // for the update after the reduction
+      else load_row(A.u_hat + (int64_t)l * dim, pu);
+      T d[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        d[c] = T(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int j = 0; j < V; ++j) d[c] += pu[r].v[j] * z[c][r].v[j];
+      }
+      if constexpr (PF) { if (more) load_row(A.u_hat + (int64_t)(INV ? l + 1 : l - 1) * dim, pnx); }
+      const T dme = reduce(d);
+      const T cw = A.wtu_hat[l];
+      const T t = tsave[cme * nl + l];
+      const T q = T(1) - t * t;
+      T sbme;
+      if (!INV) {
+        sbme = dme * q + lbme * cw * (T(-2) * t) * q / (T(1) + cw * q);
+        if (s_out && threadIdx.x < C && me_ok) { s_out[(col0 + cme) * nl + l] = sbme; t_out[(col0 + cme) * nl + l] = t; }
+      } else {
+        const T den = T(1) + cw * q;
+        sbme = q / den * (-dme + lbme * T(2) * cw * t / den);
+      }
+      if constexpr (!PF) load_row(A.w + (int64_t)l * dim, pw);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const T sb = lane_bcast(sbme, c);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int j = 0; j < V; ++j) z[c][r].v[j] += pw[r].v[j] * sb;
+      }
+      if constexpr (PF) {
+        if (more) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) pu[r] = pnx[r];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (col0 + c < batch) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (nrow[r] > 0) store_pack_part<T, V>(xbar + (col0 + c) * dim + off[r], z[c][r], nrow[r]);
+      }
+    }
+    __syncthreads();                                   // tsave is rewritten by the next tile
+  }
+}
+
 //   Radial: two passes — (‖δ‖², δᵀȳ), then z̄ = ca ȳ + cd δ (coefficients as in radial_vjp_kernel above).
 template <class T, int V, bool INV>
 __global__ __launch_bounds__(256) void radial_vjp_tall_kernel(const RadialArgs<T> A, const T* x, const T* gbar, const T* lbar, T* xbar, int64_t dim,
@@ -3120,6 +3323,37 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
     int rc = planar_vjp_reg(ctx, inverse, w, u_hat, wtu, b, nl, in, out_bar, ladj_bar, in_bar, dim, batch, t_out, s_out);
     if (rc != 1) return rc;                               // 1 = shape not served by the register kernel
   }
+  {
+    // a block per C columns, the columns in registers (planar_vjp_cols_kernel): beyond the Float32 register tiles, and Float64
+    constexpr int VWc = Vec16<T>::N;
+    static const int cols_min_f32 = getenv("BJX_PLANAR_VJP_COLS_MIN_F32") ? atoi(getenv("BJX_PLANAR_VJP_COLS_MIN_F32")) : 1025;
+    static const int cols_min_f64 = getenv("BJX_PLANAR_VJP_COLS_MIN_F64") ? atoi(getenv("BJX_PLANAR_VJP_COLS_MIN_F64")) : 33;
+    const int64_t cols_min = std::is_same<T, float>::value ? cols_min_f32 : cols_min_f64;
+    const int64_t packs_c = (dim + VWc - 1) / VWc;
+    if (cols_min > 0 && dim >= cols_min && packs_c <= 256 * 32 && (size_t)nl * 8 * sizeof(T) <= 32 * 1024 && batch < ((int64_t)1 << 40)) {
+      // threads per block x packs per thread: the smallest NT·R that covers the column (NT = 64 … 256 in waves, R a power of two)
+      int NTc = 256, Rc = 32;
+      for (int r = 32; r >= 1; r >>= 1)
+        for (int nt = 256; nt >= (r == 1 ? 64 : (r <= 4 ? 192 : 256)); nt -= 64)
+          if ((int64_t)nt * r >= packs_c && nt * r <= NTc * Rc) { NTc = nt; Rc = r; }
+      const int Cc = Rc == 1 ? 8 : (Rc >= 16 ? 1 : 16 / Rc);
+      const int64_t tiles = (batch + Cc - 1) / Cc;
+      const int64_t capc = (int64_t)ctx->num_cu * (2048 / NTc);
+      const int gridc = (int)(tiles < capc ? tiles : capc);
+      PlanarArgs<T> Ac{w, u_hat, wtu, b, nl, 0};
+      const size_t smem_c = ((size_t)2 * (NTc / 64) * Cc + (size_t)Cc * nl) * sizeof(T);
+      BjxProf prof_(ctx);
+#define PVC(R_, C_, NT_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_cols_kernel<T, VWc, R_, C_, true, NT_>), dim3(gridc), dim3(NT_), smem_c, ctx->stream, Ac, in, out_bar, ladj_bar, in_bar, dim, batch, t_out, s_out); \
+                              else hipLaunchKernelGGL((planar_vjp_cols_kernel<T, VWc, R_, C_, false, NT_>), dim3(gridc), dim3(NT_), smem_c, ctx->stream, Ac, in, out_bar, ladj_bar, in_bar, dim, batch, t_out, s_out); } while (0)
+      if (NTc == 64) PVC(1, 8, 64);
+      else if (NTc == 128) PVC(1, 8, 128);
+      else if (NTc == 192) { switch (Rc) { case 1: PVC(1, 8, 192); break; case 2: PVC(2, 8, 192); break; default: PVC(4, 4, 192); break; } }
+      else switch (Rc) { case 1: PVC(1, 8, 256); break; case 2: PVC(2, 8, 256); break; case 4: PVC(4, 4, 256); break; case 8: PVC(8, 2, 256); break; case 16: PVC(16, 1, 256); break; default: PVC(32, 1, 256); break; }
+#undef PVC
+      BJX_CHECK_LAUNCH(ctx);
+      return BJX_OK;
+    }
+  }
   FlowCfg c;
   // (odd heights / element-aligned bases take 16-byte packs with a partial last pack, like the forward group kernel: the 4-byte
   //  form ran the pullback of eight layers at 201 rows at 16 % of the HBM peak)
@@ -3653,46 +3887,71 @@ __global__ __launch_bounds__(64) void planar_param_mfma_small_kernel(const float
   if (lk == 0 && lay_ok) { out[2 * n_m + (size_t)nlg * nlg + li] = b_; out[2 * n_m + (size_t)nlg * nlg + nlg + li] = c_; }
 }
 
-// ---- the same sums for columns beyond the register accumulators (more than 64 lanes x 4 packs, or a partial set beyond the LDS):
-// a block owns 256·V ROWS (blockIdx.x) and a slice of the batch (columns blockIdx.y, + gridDim.y, ...); a thread keeps the
-// [V rows] x [layer group] accumulators of M1 and M2 and writes them into the slice's Float64 set.  The Gram block, b̄ and c̄ do not
-// depend on the rows: planar_param_sums_kernel writes them into the summed set.
+// ---- the same sums with ROWS owned by threads (round 5): columns beyond one pack per lane of a 64-lane group.
+// planar_param_reduce_kernel keeps [R packs] x [V rows] x [8 layers] x 2 accumulators per lane — 128 registers at R = 2, 256 at R = 4
+// (10–14 % of the roofline at 333 / 509 rows) and stops at R = 4 (1 024 rows Float32, 512 Float64: a loud error until round 5).  Here a
+// thread owns ONE pack of rows (2·V·8 accumulators) and walks columns: TP = 64 / 128 / 256 threads span a chunk of TP packs
+// (blockIdx.x), the CG = 256 / TP thread groups of a block and the blockIdx.y take different columns, and every (blockIdx.y, group)
+// writes its own Float64 set — the existing column sum adds the sets in a fixed order.  Packs on element-aligned addresses, the last
+// one partial; the s̄ / tanh rows of a column are wave-uniform (scalar loads).  The Gram block, b̄ and c̄ do not depend on the rows:
+// planar_param_sums_kernel writes them into the summed set.
 template <class T, int V>
 __global__ __launch_bounds__(256) void planar_param_rows_kernel(const T* __restrict__ z0, const T* __restrict__ ybar, const T* __restrict__ sbar,
-                                                                const T* __restrict__ tt, int64_t dim, int64_t batch, int nl, int l0, int nlg,
+                                                                const T* __restrict__ tt, int64_t dim, int64_t batch, int nl, int l0, int nlg, int TP,
                                                                 double* __restrict__ partial) {
-  const int64_t row0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
-  const bool ok = row0 < dim;                            // V = 1 unless the height is a whole number of packs
+  const int tp = threadIdx.x & (TP - 1);
+  const int cg = __builtin_amdgcn_readfirstlane((int)threadIdx.x / TP);       // TP >= 64: a wave lies in one group
+  const int CG = 256 / TP;
+  const int64_t row0 = ((int64_t)blockIdx.x * TP + tp) * V;
+  const bool ok = row0 < dim;
+  const int nrow = ok ? (int)(dim - row0 < V ? dim - row0 : V) : 0;
   T m1[V][PP_NLG], m2[V][PP_NLG];
 #pragma unroll
   for (int j = 0; j < V; ++j)
 #pragma unroll
     for (int k = 0; k < PP_NLG; ++k) { m1[j][k] = T(0); m2[j][k] = T(0); }
-  for (int64_t col = blockIdx.y; col < batch; col += gridDim.y) {
-    T sk[PP_NLG], tk[PP_NLG];
-#pragma unroll
-    for (int k = 0; k < PP_NLG; ++k) { sk[k] = k < nlg ? sbar[col * nl + l0 + k] : T(0); tk[k] = k < nlg ? tt[col * nl + l0 + k] : T(0); }
+  const int64_t set = (int64_t)blockIdx.y * CG + cg, nsets = (int64_t)gridDim.y * CG;
+  for (int64_t col = set; col < batch; col += 2 * nsets) {
+    const int64_t colb = col + nsets;
+    const bool twob = colb < batch;
+    Pack<T, V> pz, pg, pzb, pgb;
     if (ok) {
-      const Pack<T, V> pz = load_pack<T, V, false>(z0 + col * dim + row0), pg = load_pack<T, V, false>(ybar + col * dim + row0);
+      pz = load_pack_part<T, V>(z0 + col * dim + row0, nrow); pg = load_pack_part<T, V>(ybar + col * dim + row0, nrow);
+      if (twob) { pzb = load_pack_part<T, V>(z0 + colb * dim + row0, nrow); pgb = load_pack_part<T, V>(ybar + colb * dim + row0, nrow); }
+    }
+    T sk[PP_NLG], tk[PP_NLG], skb[PP_NLG], tkb[PP_NLG];
+#pragma unroll
+    for (int k = 0; k < PP_NLG; ++k) {
+      sk[k] = k < nlg ? sbar[col * nl + l0 + k] : T(0); tk[k] = k < nlg ? tt[col * nl + l0 + k] : T(0);
+      skb[k] = (k < nlg && twob) ? sbar[colb * nl + l0 + k] : T(0); tkb[k] = (k < nlg && twob) ? tt[colb * nl + l0 + k] : T(0);
+    }
+    if (ok) {
 #pragma unroll
       for (int j = 0; j < V; ++j)
 #pragma unroll
         for (int k = 0; k < PP_NLG; ++k) { m1[j][k] += pz.v[j] * sk[k]; m2[j][k] += pg.v[j] * tk[k]; }
+      if (twob) {
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+#pragma unroll
+          for (int k = 0; k < PP_NLG; ++k) { m1[j][k] += pzb.v[j] * skb[k]; m2[j][k] += pgb.v[j] * tkb[k]; }
+      }
     }
   }
   const size_t n_m = (size_t)dim * nlg;
   const size_t per = 2 * n_m + (size_t)nlg * nlg + 2 * (size_t)nlg;
-  double* out = partial + (size_t)blockIdx.y * per;
+  double* out = partial + (size_t)set * per;
   if (ok) {
 #pragma unroll
     for (int j = 0; j < V; ++j)
-      for (int k = 0; k < nlg; ++k) {
-        out[(size_t)(row0 + j) * nlg + k] = (double)m1[j][k];
-        out[n_m + (size_t)(row0 + j) * nlg + k] = (double)m2[j][k];
-      }
+      if (j < nrow)
+        for (int k = 0; k < nlg; ++k) {
+          out[(size_t)(row0 + j) * nlg + k] = (double)m1[j][k];
+          out[n_m + (size_t)(row0 + j) * nlg + k] = (double)m2[j][k];
+        }
   }
   if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < nlg * nlg + 2 * nlg; i += 256) out[2 * n_m + i] = 0.0;
+    for (int i = tp; i < nlg * nlg + 2 * nlg; i += TP) out[2 * n_m + i] = 0.0;
 }
 
 // one block per entry of [ST nlg*nlg][b̄ nlg][c̄ nlg] of a layer group, summed over the whole batch in Float64
@@ -3840,26 +4099,38 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
   const T* wtu = u_hat + (size_t)nl * dim;
   FlowCfg c;
   const size_t nlg_max = nl < PP_NLG ? nl : PP_NLG;
-  // beyond 64 lanes x 4 packs (1 024 rows Float32, 512 Float64), or a partial set beyond the LDS: rows owned by threads (planar_param_rows_kernel)
-  const bool rows_path = !(flow_cfg<T>(ctx, in, out_bar, dim, batch, &c, true) && c.R <= 4) ||
-                         (2 * (size_t)dim * nlg_max + nlg_max * nlg_max + 2 * nlg_max) * sizeof(double) > BJX_LDS_MAX;
+  constexpr int VWr = Vec16<T>::N;
+  const bool cfg_ok = flow_cfg<T>(ctx, in, out_bar, dim, batch, &c, true);
+  // more than one pack per lane of a 64-lane group (256 rows Float32, 128 Float64): rows owned by threads (planar_param_rows_kernel);
+  // the register accumulators stop at four packs, the block combine at the LDS
+  static const int use_rows = getenv("BJX_PLANAR_PARAM_ROWS") ? atoi(getenv("BJX_PLANAR_PARAM_ROWS")) : 1;
+  const bool must_rows = !(cfg_ok && c.R <= 4) || (2 * (size_t)dim * nlg_max + nlg_max * nlg_max + 2 * nlg_max) * sizeof(double) > BJX_LDS_MAX;
+  const bool rows_path = must_rows || (use_rows && dim > 64 * VWr && !(std::is_same<T, float>::value && dim == 256 && c.V == VWr && bjx_aligned16(out_bar)));
   if (rows_path) {
-    constexpr int VWr = Vec16<T>::N;
-    const bool v_ok = dim % VWr == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar);
-    const int Vr = v_ok ? VWr : 1;
-    const int64_t chunks = (dim + 256 * (int64_t)Vr - 1) / (256 * (int64_t)Vr);
+    const int64_t packs = (dim + VWr - 1) / VWr;
+    const int TP = packs > 128 ? 256 : (packs > 64 ? 128 : 64);
+    const int CG = 256 / TP;
+    const int64_t chunks = (packs + TP - 1) / TP;
     BJX_REQUIRE(ctx, chunks < 65536, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp_params: dim %lld too large", (long long)dim);
     const size_t per_max_r = 2 * (size_t)dim * nlg_max + nlg_max * nlg_max + 2 * nlg_max;
-    int64_t S = 2048 / chunks;
-    const int64_t s_mem = (int64_t)(((size_t)64 << 20) / (per_max_r * sizeof(double)));
+    // sets = (blockIdx.y, thread group): four resident blocks per CU (two — 512 blocks — left the loads of two waves per SIMD in
+    // flight: 20 % of the roofline), at least 256 columns per set (a set is written and read once in Float64: 128·dim bytes against
+    // 2 048·dim bytes of input), at most 192 MiB of sets
+    int64_t S = ((int64_t)ctx->num_cu * 4 + chunks - 1) / chunks;
+    const int64_t s_mem = (int64_t)(((size_t)192 << 20) / (per_max_r * sizeof(double))) / CG;
+    const int64_t s_cols = batch / (256 * (int64_t)CG);
     if (S > s_mem) S = s_mem;
-    if (S > batch) S = batch;
+    if (S > s_cols) S = s_cols;
+    if (S > 65535) S = 65535;
     if (S < 1) S = 1;
+    const int nsets = (int)(S * CG);
     const size_t st_n = (size_t)nl * nl;
-    { int rc2 = bjx_ensure_partials(ctx, (size_t)S * per_max_r + st_n + per_max_r); if (rc2) return rc2; }
+    constexpr int SL = 32;                             // slices of the first column-sum stage
+    { int rc2 = bjx_ensure_partials(ctx, (size_t)nsets * per_max_r + st_n + per_max_r + (size_t)SL * per_max_r); if (rc2) return rc2; }
     double* partial = ctx->partials;
-    double* st = partial + (size_t)S * per_max_r;
+    double* st = partial + (size_t)nsets * per_max_r;
     double* psum = st + st_n;
+    double* slices = psum + per_max_r;
     const bool one_group = nl <= PP_NLG;
     if (!one_group) {
       hipLaunchKernelGGL(planar_gram_kernel<T>, dim3(nl * nl), dim3(256), 0, ctx->stream, s_out, t_out, batch, nl, st);
@@ -3868,10 +4139,16 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
     for (int l0 = 0; l0 < nl; l0 += PP_NLG) {
       const int nlg = nl - l0 < PP_NLG ? nl - l0 : PP_NLG;
       const size_t per = 2 * (size_t)dim * nlg + (size_t)nlg * nlg + 2 * (size_t)nlg;
+      const unsigned gx = (unsigned)((per + 255) / 256);
       BjxProf prof_(ctx);
-      if (v_ok) hipLaunchKernelGGL((planar_param_rows_kernel<T, VWr>), dim3((unsigned)chunks, (unsigned)S), dim3(256), 0, ctx->stream, in, out_bar, s_out, t_out, dim, batch, nl, l0, nlg, partial);
-      else hipLaunchKernelGGL((planar_param_rows_kernel<T, 1>), dim3((unsigned)chunks, (unsigned)S), dim3(256), 0, ctx->stream, in, out_bar, s_out, t_out, dim, batch, nl, l0, nlg, partial);
-      hipLaunchKernelGGL(planar_param_colsum_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, ctx->stream, partial, (int)S, per, psum, 0);
+      hipLaunchKernelGGL((planar_param_rows_kernel<T, VWr>), dim3((unsigned)chunks, (unsigned)S), dim3(256), 0, ctx->stream, in, out_bar, s_out, t_out, dim, batch, nl, l0, nlg, TP, partial);
+      if (nsets > 64) {
+        const int chunk = (nsets + SL - 1) / SL;
+        hipLaunchKernelGGL(planar_param_colsum_kernel, dim3(gx, SL), dim3(256), 0, ctx->stream, partial, nsets, per, slices, chunk);
+        hipLaunchKernelGGL(planar_param_colsum_kernel, dim3(gx), dim3(256), 0, ctx->stream, slices, SL, per, psum, 0);
+      } else {
+        hipLaunchKernelGGL(planar_param_colsum_kernel, dim3(gx), dim3(256), 0, ctx->stream, partial, nsets, per, psum, 0);
+      }
       hipLaunchKernelGGL(planar_param_sums_kernel<T>, dim3(nlg * nlg + 2 * nlg), dim3(256), 0, ctx->stream, s_out, t_out, ladj_bar, wtu, batch, nl, l0, nlg, psum + 2 * (size_t)dim * nlg);
       hipLaunchKernelGGL(planar_param_finalize_kernel<T>, dim3(nlg), dim3(256), 0, ctx->stream, psum, 1, dim, nl, l0, nlg, one_group ? (const double*)nullptr : (const double*)st, w, u, u_hat, w_bar, u_bar, b_bar);
       BJX_CHECK_LAUNCH(ctx);

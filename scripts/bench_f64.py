@@ -76,6 +76,12 @@ def main():
     rows.append(("8×PlanarLayer d=128", lambda: sh(flow, z, out=yz), 16 * dp + 8, Np))
     zf = bj.transform(flow, z)
     rows.append(("inverse(8×PlanarLayer) d=128", lambda: sh(bj.inverse(flow), zf, out=yz), 16 * dp + 8, Np))
+    # the pullbacks (round 5: planar_vjp_cols_kernel / planar_param_rows_kernel serve Float64 — the lanes-per-column kernel ran them at 14 %)
+    gz = randn(dp, Np, 11)
+    lbz = randn(Np, 1, 12).reshape(-1).contiguous()
+    rows.append(("vjp(8×PlanarLayer) d=128", lambda: bj.vjp(flow, z, gz, lbz), 24 * dp + 8, Np))
+    rows.append(("vjp(inverse(8×PlanarLayer)) d=128", lambda: bj.vjp(bj.inverse(flow), zf, gz, lbz), 24 * dp + 8, Np))
+    rows.append(("vjp_params(8×PlanarLayer) d=128 (two passes)", lambda: bj.vjp_params(flow, z, gz, lbz), 40 * dp + 8 + 16 * nl, Np))
     dr, Kb = 32, 16
     raw = [randn(dr, k, 100 + i) for i, k in enumerate((Kb, Kb, Kb - 1))]
     rqs = bj.RationalQuadraticSpline(raw[0], raw[1], raw[2], 3.0)
