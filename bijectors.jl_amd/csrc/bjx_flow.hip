@@ -2762,6 +2762,133 @@ __global__ __launch_bounds__(NT) void planar_vjp_cols_kernel(const PlanarArgs<T>
   }
 }
 
+// The forward / inverse map on the same mapping (round 5): planar_kernel gives a column to 64 lanes — one tanh / log1p per wave and
+// layer, the w / û rows of every layer loaded per column: 7 % of the roofline beyond 1 024 rows Float32, 8–19 % in Float64 beyond 128.
+template <class T, int V, int R, int C, bool INV, int NT>
+__global__ __launch_bounds__(NT) void planar_cols_kernel(const PlanarArgs<T> A, const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t dim,
+                                                         int64_t batch, int accumulate, double* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NWV = NT / 64;
+  constexpr bool PF = R <= 4;
+  T* red = reinterpret_cast<T*>(smem);                 // [2][NWV][C]
+  double* redd = reinterpret_cast<double*>(red + 2 * NWV * C + (2 * NWV * C) % 2);
+  const int nl = A.n_layers;
+  const int64_t nvc = (dim + V - 1) / V;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int cme = lane & (C - 1);
+  int nrow[R];
+  int64_t off[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t v = threadIdx.x + (int64_t)r * NT;
+    off[r] = v * V;
+    nrow[r] = v < nvc ? (int)(dim - v * V < V ? dim - v * V : V) : 0;
+  }
+  int par = 0;
+  auto reduce = [&](const T (&s)[C]) -> T {
+    const T v = wave_sum_scatter<T, C>(s, lane);
+    T* rp = red + par * NWV * C;
+    if ((lane & (64 / C - 1)) == 0) rp[wv * C + lane / (64 / C)] = v;
+    __syncthreads();
+    T a = T(0);
+#pragma unroll
+    for (int q = 0; q < NWV; ++q) a += rp[q * C + cme];
+    par ^= 1;
+    return a;
+  };
+  auto load_row = [&](const T* row, Pack<T, V> (&p)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (nrow[r] > 0) p[r] = load_pack_part<T, V>(row + off[r], nrow[r]);
+      else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) p[r].v[j] = T(0);
+      }
+    }
+  };
+  double acc = 0.0;
+  const int64_t tiles = (batch + C - 1) / C;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t col0 = tile * C;
+    Pack<T, V> z[C][R];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int64_t col = col0 + c < batch ? col0 + c : batch - 1;
+      load_row(x + col * dim, z[c]);
+    }
+    const bool me_ok = col0 + cme < batch;
+    T ladj = T(0);
+    Pack<T, V> pw[R], pu[R], pnx[R];
+    if (PF) load_row(A.w + (int64_t)(INV ? nl - 1 : 0) * dim, pw);
+    for (int li = 0; li < nl; ++li) {
+      const int l = INV ? nl - 1 - li : li;
+      const bool more = li + 1 < nl;
+      if constexpr (PF) load_row(A.u_hat + (int64_t)l * dim, pu);
+      else load_row(A.w + (int64_t)l * dim, pw);
+      T s[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        s[c] = T(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int j = 0; j < V; ++j) s[c] += pw[r].v[j] * z[c][r].v[j];
+      }
+      if constexpr (PF) { if (more) load_row(A.w + (int64_t)(INV ? l - 1 : l + 1) * dim, pnx); }
+      const T sme = reduce(s);
+      const T bl = A.b[l], cw = A.wtu_hat[l];
+      T t, s2;
+      if (!INV) x_tanh_sech2(sme + bl, t, s2);
+      else planar_inv_act<T>(sme, cw, bl, t, s2);
+      const T ld = Fast<T>::log1p(cw * s2);            // planar_layer.jl:107
+      ladj += INV ? -ld : ld;
+      const T tme = INV ? -t : t;
+      if constexpr (!PF) load_row(A.u_hat + (int64_t)l * dim, pu);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const T a = lane_bcast(tme, c);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int j = 0; j < V; ++j) z[c][r].v[j] += pu[r].v[j] * a;
+      }
+      if constexpr (PF) {
+        if (more) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) pw[r] = pnx[r];
+        }
+      }
+    }
+    if (accumulate & 2) {                              // BJX_BASE_STDNORMAL: + log N(out; 0, I)
+      T q[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        q[c] = T(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int j = 0; j < V; ++j) q[c] += z[c][r].v[j] * z[c][r].v[j];     // rows that do not exist hold zeros
+      }
+      ladj += T(-0.5) * reduce(q) - (T)dim * T(0.91893853320467274178);
+    }
+    if (y) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        if (col0 + c < batch) {
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            if (nrow[r] > 0) store_pack_part<T, V>(y + (col0 + c) * dim + off[r], z[c][r], nrow[r]);
+        }
+      }
+    }
+    if (threadIdx.x < C && me_ok) {
+      if (ladj_ps) ladj_ps[col0 + cme] = (accumulate & 1) ? ladj_ps[col0 + cme] + ladj : ladj;
+      acc += (double)ladj;
+    }
+  }
+  if (partials) block_publish_partial(acc, redd, partials);
+}
+
 //   Radial: two passes — (‖δ‖², δᵀȳ), then z̄ = ca ȳ + cd δ (coefficients as in radial_vjp_kernel above).
 template <class T, int V, bool INV>
 __global__ __launch_bounds__(256) void radial_vjp_tall_kernel(const RadialArgs<T> A, const T* x, const T* gbar, const T* lbar, T* xbar, int64_t dim,
@@ -3110,6 +3237,42 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
     BJX_CHECK_LAUNCH(ctx);
     if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
     return BJX_OK;
+  }
+  {
+    // a block per C columns, the columns in registers (planar_cols_kernel): beyond the Float32 register tiles, and Float64
+    constexpr int VWc = Vec16<T>::N;
+    static const int cols_min_f32 = getenv("BJX_PLANAR_COLS_MIN_F32") ? atoi(getenv("BJX_PLANAR_COLS_MIN_F32")) : 1025;
+    static const int cols_min_f64 = getenv("BJX_PLANAR_COLS_MIN_F64") ? atoi(getenv("BJX_PLANAR_COLS_MIN_F64")) : 33;
+    const int64_t cols_min = std::is_same<T, float>::value ? cols_min_f32 : cols_min_f64;
+    const int64_t packs_c = (dim + VWc - 1) / VWc;
+    if (cols_min > 0 && dim >= cols_min && packs_c <= 256 * 32 && batch < ((int64_t)1 << 40)) {
+      int NTc = 256, Rc = 32;
+      for (int r = 32; r >= 1; r >>= 1)
+        for (int nt = 256; nt >= (r == 1 ? 64 : (r <= 4 ? 192 : 256)); nt -= 64)
+          if ((int64_t)nt * r >= packs_c && nt * r <= NTc * Rc) { NTc = nt; Rc = r; }
+      const int Cc = Rc == 1 ? 8 : (Rc >= 16 ? 1 : 16 / Rc);
+      const int64_t tiles = (batch + Cc - 1) / Cc;
+      const int64_t capc = (int64_t)ctx->num_cu * (2048 / NTc);
+      const int gridc = (int)(tiles < capc ? tiles : capc);
+      if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)gridc); if (rc) return rc; }
+      double* partials_c = ladj_sum ? ctx->partials : nullptr;
+      PlanarArgs<T> Ac{w, u_hat, wtu, b, nl, 0};
+      const int accum_c = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
+      const size_t smem_c = ((size_t)2 * (NTc / 64) * Cc + 2) * sizeof(T) + 8 * sizeof(double);
+      {
+        BjxProf prof_(ctx);
+#define PFC(R_, C_, NT_) do { if (inverse) hipLaunchKernelGGL((planar_cols_kernel<T, VWc, R_, C_, true, NT_>), dim3(gridc), dim3(NT_), smem_c, ctx->stream, Ac, in, out, ladj_ps, dim, batch, accum_c, partials_c); \
+                              else hipLaunchKernelGGL((planar_cols_kernel<T, VWc, R_, C_, false, NT_>), dim3(gridc), dim3(NT_), smem_c, ctx->stream, Ac, in, out, ladj_ps, dim, batch, accum_c, partials_c); } while (0)
+        if (NTc == 64) PFC(1, 8, 64);
+        else if (NTc == 128) PFC(1, 8, 128);
+        else if (NTc == 192) { switch (Rc) { case 1: PFC(1, 8, 192); break; case 2: PFC(2, 8, 192); break; default: PFC(4, 4, 192); break; } }
+        else switch (Rc) { case 1: PFC(1, 8, 256); break; case 2: PFC(2, 8, 256); break; case 4: PFC(4, 4, 256); break; case 8: PFC(8, 2, 256); break; case 16: PFC(16, 1, 256); break; default: PFC(32, 1, 256); break; }
+#undef PFC
+      }
+      BJX_CHECK_LAUNCH(ctx);
+      if (ladj_sum) return bjx_launch_finalize(ctx, gridc, ladj_sum, 0.0, 0, 0.0, flags);
+      return BJX_OK;
+    }
   }
   FlowCfg c;
   if (!flow_cfg<T>(ctx, in, out, dim, batch, &c, true)) {

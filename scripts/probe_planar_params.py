@@ -28,8 +28,8 @@ def main():
     a = ap.parse_args()
     torch.manual_seed(0)
     print(f"BJX_PLANAR_PARAM_ROWS={os.environ.get('BJX_PLANAR_PARAM_ROWS', '(default 1)')}")
-    print("| dtype | rows | columns | ms / call | GB/s (5 passes) | % of 8 TB/s | input pullback alone, ms | its % (3 passes) |")
-    print("|---|---|---|---|---|---|---|---|")
+    print("| dtype | rows | columns | ms / call | GB/s (5 passes) | % of 8 TB/s | input pullback alone, ms | its % (3 passes) | forward ms | % (2 passes) | inverse ms | % (2 passes) |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
     for dt in (torch.float32, torch.float64):
         es = 4 if dt == torch.float32 else 8
         for dim in [int(v) for v in a.dims.split(",")]:
@@ -50,9 +50,13 @@ def main():
                 continue
             k_ms, ms = kernel_and_region_ms(bj, lambda: bj.vjp_params(layer, x, g, lb), steps=a.steps, warm=2)
             _, ms_in = kernel_and_region_ms(bj, lambda: bj.vjp(layer, x, g, lb), steps=a.steps, warm=2)
+            _, ms_f = kernel_and_region_ms(bj, lambda: bj.with_logabsdet_jacobian(layer, x), steps=a.steps, warm=2)
+            y = bj.transform(layer, x)
+            _, ms_i = kernel_and_region_ms(bj, lambda: bj.with_logabsdet_jacobian(bj.inverse(layer), y), steps=a.steps, warm=2)
+            del y
             byts = (5 * dim + 4 * nl + 1) * es * N
             gbs = byts / ms / 1e6
-            print(f"| {str(dt)[6:]} | {dim} | {N} | {ms:.3f} | {gbs:.0f} | {gbs / 80:.1f} | {ms_in:.3f} | {3 * dim * es * N / ms_in / 1e6 / 80:.1f} |")
+            print(f"| {str(dt)[6:]} | {dim} | {N} | {ms:.3f} | {gbs:.0f} | {gbs / 80:.1f} | {ms_in:.3f} | {3 * dim * es * N / ms_in / 1e6 / 80:.1f} | {ms_f:.3f} | {2 * dim * es * N / ms_f / 1e6 / 80:.1f} | {ms_i:.3f} | {2 * dim * es * N / ms_i / 1e6 / 80:.1f} |")
             del x, g, lb
 
 
