@@ -2574,34 +2574,20 @@ template <int G> __device__ __forceinline__ float group_sum_fast(float v) { retu
 template <int G> __device__ __forceinline__ double group_sum_fast(double v) { return group_sum<G>(v); }
 // C values per lane -> lane L holds the wave sum of value L / (64 / C): log2(C) halving exchanges (C/2 + C/4 + ... shuffles in all)
 // and one butterfly over the 64 / C lanes that are left, instead of C full butterflies (6·C shuffles).
-template <class T, int C> __device__ __forceinline__ T wave_sum_scatter(const T (&s)[C], int lane) {
-  static_assert(C == 1 || C == 2 || C == 4 || C == 8, "C");
-  if constexpr (C == 1) return group_sum_fast<64>(s[0]);
-  else if constexpr (C == 2) {
-    const bool hi = lane & 32;
-    const T a = (hi ? s[1] : s[0]) + shfl_xor(hi ? s[0] : s[1], 32);
-    return group_sum_fast<32>(a);
-  } else if constexpr (C == 4) {
-    const bool hi = lane & 32;
-    T a[2];
+template <class T, int C, int G> __device__ __forceinline__ T wave_sum_scatter_rec(const T (&s)[C], int lane) {
+  if constexpr (C == 1) return group_sum_fast<G>(s[0]);
+  else {
+    constexpr int H = G / 2;
+    const bool hi = lane & H;
+    T a[C / 2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a[i] = (hi ? s[2 + i] : s[i]) + shfl_xor(hi ? s[i] : s[2 + i], 32);
-    const bool hi2 = lane & 16;
-    const T b = (hi2 ? a[1] : a[0]) + shfl_xor(hi2 ? a[0] : a[1], 16);
-    return group_sum_fast<16>(b);
-  } else {
-    const bool hi = lane & 32;
-    T a[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = (hi ? s[4 + i] : s[i]) + shfl_xor(hi ? s[i] : s[4 + i], 32);
-    const bool hi2 = lane & 16;
-    T b[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) b[i] = (hi2 ? a[2 + i] : a[i]) + shfl_xor(hi2 ? a[i] : a[2 + i], 16);
-    const bool hi3 = lane & 8;
-    const T c = (hi3 ? b[1] : b[0]) + shfl_xor(hi3 ? b[0] : b[1], 8);
-    return group_sum_fast<8>(c);
+    for (int i = 0; i < C / 2; ++i) a[i] = (hi ? s[C / 2 + i] : s[i]) + shfl_xor(hi ? s[i] : s[C / 2 + i], H);
+    return wave_sum_scatter_rec<T, C / 2, H>(a, lane);
   }
+}
+template <class T, int C> __device__ __forceinline__ T wave_sum_scatter(const T (&s)[C], int lane) {
+  static_assert(C == 1 || C == 2 || C == 4 || C == 8 || C == 16, "C");
+  return wave_sum_scatter_rec<T, C, 64>(s, lane);
 }
 
 template <class T, int V, int R, int C, bool INV, int NT>
@@ -3211,6 +3197,51 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
       }
     }
   }
+  auto try_cols = [&]() -> int {
+    // a block per C columns, the columns in registers (planar_cols_kernel): beyond the Float32 register tiles, and Float64
+    constexpr int VWc = Vec16<T>::N;
+    static const int cols_min_f32 = getenv("BJX_PLANAR_COLS_MIN_F32") ? atoi(getenv("BJX_PLANAR_COLS_MIN_F32")) : 1025;
+    static const int cols_min_f64 = getenv("BJX_PLANAR_COLS_MIN_F64") ? atoi(getenv("BJX_PLANAR_COLS_MIN_F64")) : 33;
+    const int64_t cols_min = std::is_same<T, float>::value ? cols_min_f32 : cols_min_f64;
+    const int64_t packs_c = (dim + VWc - 1) / VWc;
+    if (cols_min > 0 && dim >= cols_min && packs_c <= 256 * 32 && batch < ((int64_t)1 << 40)) {
+      int NTc = 256, Rc = 32;
+      for (int r = 32; r >= 1; r >>= 1)
+        for (int nt = 256; nt >= (r == 1 ? 64 : (r <= 4 ? 192 : 256)); nt -= 64)
+          if ((int64_t)nt * r >= packs_c && nt * r <= NTc * Rc) { NTc = nt; Rc = r; }
+      constexpr bool is_f64 = std::is_same<T, double>::value;
+      const int Cc = Rc == 1 ? (is_f64 ? 16 : 8) : (Rc >= 16 ? 1 : 16 / Rc);        // (Float64: the scalar recurrence of a layer, evaluated once per wave, costs as much as the products of 8 columns)
+      const int64_t tiles = (batch + Cc - 1) / Cc;
+      const int64_t capc = (int64_t)ctx->num_cu * (2048 / NTc);
+      const int gridc = (int)(tiles < capc ? tiles : capc);
+      if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)gridc); if (rc) return rc; }
+      double* partials_c = ladj_sum ? ctx->partials : nullptr;
+      PlanarArgs<T> Ac{w, u_hat, wtu, b, nl, 0};
+      const int accum_c = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
+      const size_t smem_c = ((size_t)2 * (NTc / 64) * Cc + 2) * sizeof(T) + 8 * sizeof(double);
+      {
+        BjxProf prof_(ctx);
+#define PFC(R_, C_, NT_) do { if (inverse) hipLaunchKernelGGL((planar_cols_kernel<T, VWc, R_, C_, true, NT_>), dim3(gridc), dim3(NT_), smem_c, ctx->stream, Ac, in, out, ladj_ps, dim, batch, accum_c, partials_c); \
+                              else hipLaunchKernelGGL((planar_cols_kernel<T, VWc, R_, C_, false, NT_>), dim3(gridc), dim3(NT_), smem_c, ctx->stream, Ac, in, out, ladj_ps, dim, batch, accum_c, partials_c); } while (0)
+      if constexpr (is_f64) {
+        if (Rc == 1) { switch (NTc) { case 64: PFC(1, 16, 64); break; case 128: PFC(1, 16, 128); break; case 192: PFC(1, 16, 192); break; default: PFC(1, 16, 256); break; } }
+      }
+      if (is_f64 && Rc == 1) {}
+      else if (NTc == 64) PFC(1, 8, 64);
+      else if (NTc == 128) PFC(1, 8, 128);
+      else if (NTc == 192) { switch (Rc) { case 1: PFC(1, 8, 192); break; case 2: PFC(2, 8, 192); break; default: PFC(4, 4, 192); break; } }
+        else switch (Rc) { case 1: PFC(1, 8, 256); break; case 2: PFC(2, 8, 256); break; case 4: PFC(4, 4, 256); break; case 8: PFC(8, 2, 256); break; case 16: PFC(16, 1, 256); break; default: PFC(32, 1, 256); break; }
+#undef PFC
+      }
+      BJX_CHECK_LAUNCH(ctx);
+      if (ladj_sum) return bjx_launch_finalize(ctx, gridc, ladj_sum, 0.0, 0, 0.0, flags);
+      return BJX_OK;
+    }
+    return 1;                                          // 1 = not served
+  };
+  // Float64 beyond 64 rows: the column-tile kernel before the LDS tile kernel (100 rows: 20 % on the tile kernel)
+  static const int tile_max_f64 = getenv("BJX_PLANAR_TILE_MAX_F64") ? atoi(getenv("BJX_PLANAR_TILE_MAX_F64")) : 64;
+  if (sizeof(T) == 8 && dim > tile_max_f64) { const int rc_cols = try_cols(); if (rc_cols != 1) return rc_cols; }
   // tile kernel: lane = column (full-lane scalar recurrence); needs the 64 x dim tile in LDS
   static const int use_tile = getenv("BJX_PLANAR_TILE") ? atoi(getenv("BJX_PLANAR_TILE")) : 1;
   const size_t tile_bytes = (size_t)64 * dim * sizeof(T);
@@ -3238,42 +3269,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
     if (ladj_sum) return bjx_launch_finalize(ctx, (int)grid, ladj_sum, 0.0, 0, 0.0, flags);
     return BJX_OK;
   }
-  {
-    // a block per C columns, the columns in registers (planar_cols_kernel): beyond the Float32 register tiles, and Float64
-    constexpr int VWc = Vec16<T>::N;
-    static const int cols_min_f32 = getenv("BJX_PLANAR_COLS_MIN_F32") ? atoi(getenv("BJX_PLANAR_COLS_MIN_F32")) : 1025;
-    static const int cols_min_f64 = getenv("BJX_PLANAR_COLS_MIN_F64") ? atoi(getenv("BJX_PLANAR_COLS_MIN_F64")) : 33;
-    const int64_t cols_min = std::is_same<T, float>::value ? cols_min_f32 : cols_min_f64;
-    const int64_t packs_c = (dim + VWc - 1) / VWc;
-    if (cols_min > 0 && dim >= cols_min && packs_c <= 256 * 32 && batch < ((int64_t)1 << 40)) {
-      int NTc = 256, Rc = 32;
-      for (int r = 32; r >= 1; r >>= 1)
-        for (int nt = 256; nt >= (r == 1 ? 64 : (r <= 4 ? 192 : 256)); nt -= 64)
-          if ((int64_t)nt * r >= packs_c && nt * r <= NTc * Rc) { NTc = nt; Rc = r; }
-      const int Cc = Rc == 1 ? 8 : (Rc >= 16 ? 1 : 16 / Rc);
-      const int64_t tiles = (batch + Cc - 1) / Cc;
-      const int64_t capc = (int64_t)ctx->num_cu * (2048 / NTc);
-      const int gridc = (int)(tiles < capc ? tiles : capc);
-      if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)gridc); if (rc) return rc; }
-      double* partials_c = ladj_sum ? ctx->partials : nullptr;
-      PlanarArgs<T> Ac{w, u_hat, wtu, b, nl, 0};
-      const int accum_c = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
-      const size_t smem_c = ((size_t)2 * (NTc / 64) * Cc + 2) * sizeof(T) + 8 * sizeof(double);
-      {
-        BjxProf prof_(ctx);
-#define PFC(R_, C_, NT_) do { if (inverse) hipLaunchKernelGGL((planar_cols_kernel<T, VWc, R_, C_, true, NT_>), dim3(gridc), dim3(NT_), smem_c, ctx->stream, Ac, in, out, ladj_ps, dim, batch, accum_c, partials_c); \
-                              else hipLaunchKernelGGL((planar_cols_kernel<T, VWc, R_, C_, false, NT_>), dim3(gridc), dim3(NT_), smem_c, ctx->stream, Ac, in, out, ladj_ps, dim, batch, accum_c, partials_c); } while (0)
-        if (NTc == 64) PFC(1, 8, 64);
-        else if (NTc == 128) PFC(1, 8, 128);
-        else if (NTc == 192) { switch (Rc) { case 1: PFC(1, 8, 192); break; case 2: PFC(2, 8, 192); break; default: PFC(4, 4, 192); break; } }
-        else switch (Rc) { case 1: PFC(1, 8, 256); break; case 2: PFC(2, 8, 256); break; case 4: PFC(4, 4, 256); break; case 8: PFC(8, 2, 256); break; case 16: PFC(16, 1, 256); break; default: PFC(32, 1, 256); break; }
-#undef PFC
-      }
-      BJX_CHECK_LAUNCH(ctx);
-      if (ladj_sum) return bjx_launch_finalize(ctx, gridc, ladj_sum, 0.0, 0, 0.0, flags);
-      return BJX_OK;
-    }
-  }
+  { const int rc_cols = try_cols(); if (rc_cols != 1) return rc_cols; }
   FlowCfg c;
   if (!flow_cfg<T>(ctx, in, out, dim, batch, &c, true)) {
     // columns taller than the register kernels hold: one block per column, n_layers + 1 passes (planar_tall_kernel)
@@ -3499,7 +3495,8 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
       for (int r = 32; r >= 1; r >>= 1)
         for (int nt = 256; nt >= (r == 1 ? 64 : (r <= 4 ? 192 : 256)); nt -= 64)
           if ((int64_t)nt * r >= packs_c && nt * r <= NTc * Rc) { NTc = nt; Rc = r; }
-      const int Cc = Rc == 1 ? 8 : (Rc >= 16 ? 1 : 16 / Rc);
+      constexpr bool is_f64 = std::is_same<T, double>::value;
+      const int Cc = Rc == 1 ? (is_f64 ? 16 : 8) : (Rc >= 16 ? 1 : 16 / Rc);        // (Float64: the scalar recurrence of a layer, evaluated once per wave, costs as much as the products of 8 columns)
       const int64_t tiles = (batch + Cc - 1) / Cc;
       const int64_t capc = (int64_t)ctx->num_cu * (2048 / NTc);
       const int gridc = (int)(tiles < capc ? tiles : capc);
@@ -3508,7 +3505,11 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
       BjxProf prof_(ctx);
 #define PVC(R_, C_, NT_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_cols_kernel<T, VWc, R_, C_, true, NT_>), dim3(gridc), dim3(NT_), smem_c, ctx->stream, Ac, in, out_bar, ladj_bar, in_bar, dim, batch, t_out, s_out); \
                               else hipLaunchKernelGGL((planar_vjp_cols_kernel<T, VWc, R_, C_, false, NT_>), dim3(gridc), dim3(NT_), smem_c, ctx->stream, Ac, in, out_bar, ladj_bar, in_bar, dim, batch, t_out, s_out); } while (0)
-      if (NTc == 64) PVC(1, 8, 64);
+      if constexpr (is_f64) {
+        if (Rc == 1) { switch (NTc) { case 64: PVC(1, 16, 64); break; case 128: PVC(1, 16, 128); break; case 192: PVC(1, 16, 192); break; default: PVC(1, 16, 256); break; } }
+      }
+      if (is_f64 && Rc == 1) {}
+      else if (NTc == 64) PVC(1, 8, 64);
       else if (NTc == 128) PVC(1, 8, 128);
       else if (NTc == 192) { switch (Rc) { case 1: PVC(1, 8, 192); break; case 2: PVC(2, 8, 192); break; default: PVC(4, 4, 192); break; } }
       else switch (Rc) { case 1: PVC(1, 8, 256); break; case 2: PVC(2, 8, 256); break; case 4: PVC(4, 4, 256); break; case 8: PVC(8, 2, 256); break; case 16: PVC(16, 1, 256); break; default: PVC(32, 1, 256); break; }

@@ -84,6 +84,8 @@ def main(path):
             w, u, b = r.normal(size=(dim, nl)) / np.sqrt(dim), r.normal(size=(dim, nl)) / np.sqrt(dim), r.normal(size=nl)
             fl = bj.PlanarLayer(torch.tensor(w, dtype=tdt), torch.tensor(u, dtype=tdt), torch.tensor(b, dtype=tdt))
             put(f"planar_odd.{tg}.{dim}", bj.with_logabsdet_jacobian(fl, dev(x)))
+            g, lb = np.asfortranarray(r.normal(size=(dim, N)).astype(dt)), r.normal(size=N).astype(dt)
+            put(f"planar_odd_vjp.{tg}.{dim}", bj.vjp(fl, dev(x), dev(g), dev(lb)), bj.vjp_params(fl, dev(x), dev(g), dev(lb)))
             rd = bj.RadialLayer(torch.tensor([0.3], dtype=tdt), torch.tensor([0.2], dtype=tdt), torch.tensor(r.normal(size=dim), dtype=tdt))
             put(f"radial_odd.{tg}.{dim}", bj.with_logabsdet_jacobian(rd, dev(x)))
             bn = bj.InvertibleBatchNorm(torch.tensor(r.normal(size=dim), dtype=tdt), torch.tensor(0.3 * r.normal(size=dim), dtype=tdt),
