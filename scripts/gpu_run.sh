@@ -83,7 +83,7 @@ profile)
   { echo "# r05 — 8 × PlanarLayer over column heights (scripts/probe_planar_params.py, 2^29 bytes-ish per array, stream-region time per call)"; echo;
     echo "Shipped paths (column-tile kernels \`planar_cols_kernel\` / \`planar_vjp_cols_kernel\`, parameter reduction with rows owned by threads):"; echo;
     BJX_BENCH_PREROLL_MS=20 timeout 400 python scripts/probe_planar_params.py 2>/dev/null | grep "^|";
-    echo; echo "The same call with the five switches of the round off (\`BJX_PLANAR_COLS_MIN_F32/F64=0 BJX_PLANAR_VJP_COLS_MIN_F32/F64=0 BJX_PLANAR_PARAM_ROWS=0\`: the lanes-per-column kernels of rounds 1-4; heights they refuse are marked):"; echo;
+    echo; echo "The same call with the five switches of the round off (\`BJX_PLANAR_COLS_MIN_F32/F64=0 BJX_PLANAR_VJP_COLS_MIN_F32/F64=0 BJX_PLANAR_PARAM_ROWS=0\`: the lanes-per-column kernels of rounds 1-4; what they refused — the input pullback beyond 8 192 / 4 096 rows, the parameter reduction beyond 1 024 / 512 — is served by the tall-column kernels of the same round):"; echo;
     BJX_PLANAR_COLS_MIN_F32=0 BJX_PLANAR_COLS_MIN_F64=0 BJX_PLANAR_VJP_COLS_MIN_F32=0 BJX_PLANAR_VJP_COLS_MIN_F64=0 BJX_PLANAR_PARAM_ROWS=0 BJX_BENCH_PREROLL_MS=20 timeout 600 python scripts/probe_planar_params.py 2>/dev/null | grep "^|"; } > $O/planar_heights.md
   timeout 300 python scripts/probe_host_overhead.py --calls 2000 --top 8 2>/dev/null | grep -v amdgpu.ids > $O/host_overhead.txt
   bash scripts/ab_c3.sh 2>/dev/null > $O/c3_table_policy.txt
