@@ -86,6 +86,14 @@ template <class T, int V> __device__ __forceinline__ Pack<T, V> load_pack_part(c
   for (int j = 0; j < V; ++j) r.v[j] = j < nrow ? p[j] : T(0);
   return r;
 }
+// the same through the caches (parameter rows that every block reads: load_pack_part's loads are nontemporal)
+template <class T, int V> __device__ __forceinline__ Pack<T, V> load_pack_part_cached(const T* p, int nrow) {
+  if (nrow >= V) return load_pack<T, V, false>(p);
+  Pack<T, V> r;
+#pragma unroll
+  for (int j = 0; j < V; ++j) r.v[j] = j < nrow ? p[j] : T(0);
+  return r;
+}
 template <class T, int V> __device__ __forceinline__ void store_pack_part(T* p, const Pack<T, V>& r, int nrow) {
   if (nrow >= V) { store_pack<T, V, true>(p, r); return; }
   store_pack_run<T, V>(p, r, 0, nrow);
@@ -2591,7 +2599,7 @@ template <class T, int C> __device__ __forceinline__ T wave_sum_scatter(const T 
 }
 
 template <class T, int V, int R, int C, bool INV, int NT>
-__global__ __launch_bounds__(NT) void planar_vjp_cols_kernel(const PlanarArgs<T> A, const T* __restrict__ x, const T* __restrict__ ybar, const T* __restrict__ lbar,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((R <= 4 && sizeof(T) == 4) ? 4 : 1, 8))) void planar_vjp_cols_kernel(const PlanarArgs<T> A, const T* __restrict__ x, const T* __restrict__ ybar, const T* __restrict__ lbar,
                                                              T* __restrict__ xbar, int64_t dim, int64_t batch, T* __restrict__ t_out, T* __restrict__ s_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NWV = NT / 64;
@@ -2633,6 +2641,16 @@ __global__ __launch_bounds__(NT) void planar_vjp_cols_kernel(const PlanarArgs<T>
       }
     }
   };
+  auto load_par = [&](const T* row, Pack<T, V> (&p)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (nrow[r] > 0) p[r] = load_pack_part_cached<T, V>(row + off[r], nrow[r]);
+      else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) p[r].v[j] = T(0);
+      }
+    }
+  };
   const int64_t tiles = (batch + C - 1) / C;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t col0 = tile * C;
@@ -2647,12 +2665,12 @@ __global__ __launch_bounds__(NT) void planar_vjp_cols_kernel(const PlanarArgs<T>
     // ---- primal sweep: t_l of every layer and column.  The parameter rows do not depend on the data: with PF the row a step needs
     //      AFTER its reduction (û_l) and the next step's w are requested before the barrier
     Pack<T, V> pw[R], pu[R], pnx[R];
-    if (PF) load_row(A.w + (int64_t)(INV ? nl - 1 : 0) * dim, pw);
+    if (PF) load_par(A.w + (int64_t)(INV ? nl - 1 : 0) * dim, pw);
     for (int li = 0; li < nl; ++li) {
       const int l = INV ? nl - 1 - li : li;
       const bool more = li + 1 < nl;
-      if constexpr (PF) { if (more) load_row(A.u_hat + (int64_t)l * dim, pu); }
-      else load_row(A.w + (int64_t)l * dim, pw);
+      if constexpr (PF) { if (more) load_par(A.u_hat + (int64_t)l * dim, pu); }
+      else load_par(A.w + (int64_t)l * dim, pw);
       T s[C];
 #pragma unroll
       for (int c = 0; c < C; ++c) {
@@ -2662,14 +2680,14 @@ __global__ __launch_bounds__(NT) void planar_vjp_cols_kernel(const PlanarArgs<T>
 #pragma unroll
           for (int j = 0; j < V; ++j) s[c] += pw[r].v[j] * z[c][r].v[j];
       }
-      if constexpr (PF) { if (more) load_row(A.w + (int64_t)(INV ? l - 1 : l + 1) * dim, pnx); }
+      if constexpr (PF) { if (more) load_par(A.w + (int64_t)(INV ? l - 1 : l + 1) * dim, pnx); }
       const T sme = reduce(s);
       T tme;
       if (!INV) tme = x_tanh(sme + A.b[l]);
       else tme = x_tanh(find_alpha_dev<T>(sme, A.wtu_hat[l], A.b[l]) + A.b[l]);
       if (threadIdx.x < C) tsave[threadIdx.x * nl + l] = tme;
       if (more) {
-        if constexpr (!PF) load_row(A.u_hat + (int64_t)l * dim, pu);
+        if constexpr (!PF) load_par(A.u_hat + (int64_t)l * dim, pu);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           const T tc = lane_bcast(tme, c);
@@ -2692,12 +2710,12 @@ __global__ __launch_bounds__(NT) void planar_vjp_cols_kernel(const PlanarArgs<T>
       const int64_t col = col0 + c < batch ? col0 + c : batch - 1;
       load_row(ybar + col * dim, z[c]);
     }
-    if (PF) load_row(A.u_hat + (int64_t)(INV ? 0 : nl - 1) * dim, pu);
+    if (PF) load_par(A.u_hat + (int64_t)(INV ? 0 : nl - 1) * dim, pu);
     for (int li = 0; li < nl; ++li) {
       const int l = INV ? li : nl - 1 - li;
       const bool more = li + 1 < nl;
-      if constexpr (PF) load_row(A.w + (int64_t)l * dim, pw);            // for the update after the reduction
-      else load_row(A.u_hat + (int64_t)l * dim, pu);
+      if constexpr (PF) load_par(A.w + (int64_t)l * dim, pw);            // for the update after the reduction
+      else load_par(A.u_hat + (int64_t)l * dim, pu);
       T d[C];
 #pragma unroll
       for (int c = 0; c < C; ++c) {
@@ -2707,7 +2725,7 @@ __global__ __launch_bounds__(NT) void planar_vjp_cols_kernel(const PlanarArgs<T>
 #pragma unroll
           for (int j = 0; j < V; ++j) d[c] += pu[r].v[j] * z[c][r].v[j];
       }
-      if constexpr (PF) { if (more) load_row(A.u_hat + (int64_t)(INV ? l + 1 : l - 1) * dim, pnx); }
+      if constexpr (PF) { if (more) load_par(A.u_hat + (int64_t)(INV ? l + 1 : l - 1) * dim, pnx); }
       const T dme = reduce(d);
       const T cw = A.wtu_hat[l];
       const T t = tsave[cme * nl + l];
@@ -2720,7 +2738,7 @@ __global__ __launch_bounds__(NT) void planar_vjp_cols_kernel(const PlanarArgs<T>
         const T den = T(1) + cw * q;
         sbme = q / den * (-dme + lbme * T(2) * cw * t / den);
       }
-      if constexpr (!PF) load_row(A.w + (int64_t)l * dim, pw);
+      if constexpr (!PF) load_par(A.w + (int64_t)l * dim, pw);
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const T sb = lane_bcast(sbme, c);
@@ -2751,7 +2769,7 @@ __global__ __launch_bounds__(NT) void planar_vjp_cols_kernel(const PlanarArgs<T>
 // The forward / inverse map on the same mapping (round 5): planar_kernel gives a column to 64 lanes — one tanh / log1p per wave and
 // layer, the w / û rows of every layer loaded per column: 7 % of the roofline beyond 1 024 rows Float32, 8–19 % in Float64 beyond 128.
 template <class T, int V, int R, int C, bool INV, int NT>
-__global__ __launch_bounds__(NT) void planar_cols_kernel(const PlanarArgs<T> A, const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t dim,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((R <= 4 && sizeof(T) == 4) ? 4 : 1, 8))) void planar_cols_kernel(const PlanarArgs<T> A, const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t dim,
                                                          int64_t batch, int accumulate, double* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NWV = NT / 64;
@@ -2792,6 +2810,16 @@ __global__ __launch_bounds__(NT) void planar_cols_kernel(const PlanarArgs<T> A, 
       }
     }
   };
+  auto load_par = [&](const T* row, Pack<T, V> (&p)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (nrow[r] > 0) p[r] = load_pack_part_cached<T, V>(row + off[r], nrow[r]);
+      else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) p[r].v[j] = T(0);
+      }
+    }
+  };
   double acc = 0.0;
   const int64_t tiles = (batch + C - 1) / C;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -2805,12 +2833,12 @@ __global__ __launch_bounds__(NT) void planar_cols_kernel(const PlanarArgs<T> A, 
     const bool me_ok = col0 + cme < batch;
     T ladj = T(0);
     Pack<T, V> pw[R], pu[R], pnx[R];
-    if (PF) load_row(A.w + (int64_t)(INV ? nl - 1 : 0) * dim, pw);
+    if (PF) load_par(A.w + (int64_t)(INV ? nl - 1 : 0) * dim, pw);
     for (int li = 0; li < nl; ++li) {
       const int l = INV ? nl - 1 - li : li;
       const bool more = li + 1 < nl;
-      if constexpr (PF) load_row(A.u_hat + (int64_t)l * dim, pu);
-      else load_row(A.w + (int64_t)l * dim, pw);
+      if constexpr (PF) load_par(A.u_hat + (int64_t)l * dim, pu);
+      else load_par(A.w + (int64_t)l * dim, pw);
       T s[C];
 #pragma unroll
       for (int c = 0; c < C; ++c) {
@@ -2820,7 +2848,7 @@ __global__ __launch_bounds__(NT) void planar_cols_kernel(const PlanarArgs<T> A, 
 #pragma unroll
           for (int j = 0; j < V; ++j) s[c] += pw[r].v[j] * z[c][r].v[j];
       }
-      if constexpr (PF) { if (more) load_row(A.w + (int64_t)(INV ? l - 1 : l + 1) * dim, pnx); }
+      if constexpr (PF) { if (more) load_par(A.w + (int64_t)(INV ? l - 1 : l + 1) * dim, pnx); }
       const T sme = reduce(s);
       const T bl = A.b[l], cw = A.wtu_hat[l];
       T t, s2;
@@ -2829,7 +2857,7 @@ __global__ __launch_bounds__(NT) void planar_cols_kernel(const PlanarArgs<T> A, 
       const T ld = Fast<T>::log1p(cw * s2);            // planar_layer.jl:107
       ladj += INV ? -ld : ld;
       const T tme = INV ? -t : t;
-      if constexpr (!PF) load_row(A.u_hat + (int64_t)l * dim, pu);
+      if constexpr (!PF) load_par(A.u_hat + (int64_t)l * dim, pu);
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const T a = lane_bcast(tme, c);
@@ -3204,7 +3232,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
     static const int cols_min_f64 = getenv("BJX_PLANAR_COLS_MIN_F64") ? atoi(getenv("BJX_PLANAR_COLS_MIN_F64")) : 33;
     const int64_t cols_min = std::is_same<T, float>::value ? cols_min_f32 : cols_min_f64;
     const int64_t packs_c = (dim + VWc - 1) / VWc;
-    if (cols_min > 0 && dim >= cols_min && packs_c <= 256 * 32 && batch < ((int64_t)1 << 40)) {
+    if (cols_min > 0 && dim >= cols_min && dim >= 2 * VWc && packs_c <= 256 * 32 && batch < ((int64_t)1 << 40)) {
       int NTc = 256, Rc = 32;
       for (int r = 32; r >= 1; r >>= 1)
         for (int nt = 256; nt >= (r == 1 ? 64 : (r <= 4 ? 192 : 256)); nt -= 64)
@@ -3489,7 +3517,7 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
     static const int cols_min_f64 = getenv("BJX_PLANAR_VJP_COLS_MIN_F64") ? atoi(getenv("BJX_PLANAR_VJP_COLS_MIN_F64")) : 33;
     const int64_t cols_min = std::is_same<T, float>::value ? cols_min_f32 : cols_min_f64;
     const int64_t packs_c = (dim + VWc - 1) / VWc;
-    if (cols_min > 0 && dim >= cols_min && packs_c <= 256 * 32 && (size_t)nl * 8 * sizeof(T) <= 32 * 1024 && batch < ((int64_t)1 << 40)) {
+    if (cols_min > 0 && dim >= cols_min && dim >= 2 * VWc && packs_c <= 256 * 32 && (size_t)nl * 16 * sizeof(T) <= 32 * 1024 && batch < ((int64_t)1 << 40)) {
       // threads per block x packs per thread: the smallest NT·R that covers the column (NT = 64 … 256 in waves, R a power of two)
       int NTc = 256, Rc = 32;
       for (int r = 32; r >= 1; r >>= 1)
