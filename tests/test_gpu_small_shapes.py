@@ -445,6 +445,37 @@ def test_planar_parameter_pullback_beyond_the_register_accumulators(bj, orc, dim
     np.testing.assert_allclose(host(pb["b"]).reshape(-1), bb_ref.reshape(-1), **tol)
 
 
+@pytest.mark.parametrize("dt,dim,N,nl", [(np.float64, 72, 133, 3), (np.float64, 200, 70, 8), (np.float64, 333, 41, 2), (np.float32, 1500, 37, 3),
+                                          (np.float32, 4100, 9, 2), (np.float32, 9000, 5, 2), (np.float64, 20000, 3, 2)])
+def test_planar_column_tile_kernels_in_place(bj, orc, dt, dim, N, nl):
+    """The column-tile kernels (and the block-per-column ones beyond them) read a tile's columns before they write them: the map into its
+    own input (`transform!(b, x)`), and — through the C ABI, which allows it — the pullback into the cotangent's buffer."""
+    r = np.random.default_rng(dim + nl)
+    w = (r.normal(size=(dim, nl)) / math.sqrt(dim)).astype(dt)
+    u = (r.normal(size=(dim, nl)) / math.sqrt(dim)).astype(dt)
+    bb = r.normal(size=nl).astype(dt)
+    Z = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    g = np.asfortranarray(r.normal(size=(dim, N)).astype(dt))
+    lb = r.normal(size=N).astype(dt)
+    layer = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(bb))
+    Y_ref, _ = orc.planar(w, u, bb, Z)
+    x = dev(Z).clone()
+    bj.transform_(layer, x)
+    close(host(x), Y_ref, dt, scale=4, what="transform!(b, x) in place")
+    bj.transform_(bj.inverse(layer), x)
+    close(host(x), Z.astype(np.float64), dt, scale=40, what="inverse in place")
+    # the pullback with in_bar == out_bar
+    L = bj._lib
+    ctx = bj.context(torch.device("cuda", torch.cuda.current_device()))
+    wd, ud, bd = torch.tensor(np.ascontiguousarray(w.T)).cuda(), torch.tensor(np.ascontiguousarray(u.T)).cuda(), torch.tensor(bb).cuda()    # layer-major [nl][dim]
+    xd, gd, lbd = dev(Z), dev(g).clone(), torch.from_numpy(lb).cuda()
+    code = L.BJX_F32 if dt == np.float32 else L.BJX_F64
+    rc = L.load().bjx_planar_vjp(ctx.h, code, 0, wd.data_ptr(), ud.data_ptr(), bd.data_ptr(), nl, xd.data_ptr(), gd.data_ptr(), lbd.data_ptr(), gd.data_ptr(), dim, N)
+    L.check(ctx.h, rc, "bjx_planar_vjp")
+    ref = orc.planar_vjp(w, u, bb, Z, g, lb)
+    np.testing.assert_allclose(host(gd), ref, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())))
+
+
 # ---------------------------------------------------------------- round 5: VectorBijectors links of JointOrderStatistics / MvLogNormal
 def _link_np(kind, x):
     """(y, per-element log-det) of the scalar links used below, restated from src/vector/univariate/{positive,truncated}.jl"""
