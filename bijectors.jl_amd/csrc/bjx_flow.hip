@@ -4087,6 +4087,58 @@ __global__ __launch_bounds__(64) void planar_param_mfma_small_kernel(const float
 // writes its own Float64 set — the existing column sum adds the sets in a fixed order.  Packs on element-aligned addresses, the last
 // one partial; the s̄ / tanh rows of a column are wave-uniform (scalar loads).  The Gram block, b̄ and c̄ do not depend on the rows:
 // planar_param_sums_kernel writes them into the summed set.
+// (the column walk: FULL = the layer group has all PP_NLG layers — the s̄ / tanh rows are then read without per-layer guards and the
+//  scalar loads merge; two columns per trip in Float32, one in Float64 (the scalars of two columns did not fit the SGPR file: 117
+//  v_readlane / 99 v_writelane per trip); whole packs take ONE branch around all their loads, not one per load)
+template <class T, int V, bool FULL>
+__device__ __forceinline__ void planar_param_rows_walk(const T* __restrict__ z0, const T* __restrict__ ybar, const T* __restrict__ sbar, const T* __restrict__ tt,
+                                                       int64_t dim, int64_t batch, int nl, int l0, int nlg, int64_t set, int64_t nsets, int64_t row0, int nrow,
+                                                       T (&m1)[V][PP_NLG], T (&m2)[V][PP_NLG]) {
+  constexpr int U = sizeof(T) == 4 ? 2 : 1;
+  Pack<T, V> pz[U], pg[U], nz[U], ng[U];
+  auto fetch = [&](int64_t col, Pack<T, V> (&az)[U], Pack<T, V> (&ag)[U]) {
+    if (nrow == V) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const int64_t cq = col + q * nsets;
+        if (cq < batch) { az[q] = load_pack<T, V, true>(z0 + cq * dim + row0); ag[q] = load_pack<T, V, true>(ybar + cq * dim + row0); }
+      }
+    } else if (nrow > 0) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const int64_t cq = col + q * nsets;
+        if (cq < batch) { az[q] = load_pack_part<T, V>(z0 + cq * dim + row0, nrow); ag[q] = load_pack_part<T, V>(ybar + cq * dim + row0, nrow); }
+      }
+    }
+  };
+  if (set < batch) fetch(set, pz, pg);
+  for (int64_t col = set; col < batch; col += U * nsets) {
+    if (col + U * nsets < batch) fetch(col + U * nsets, nz, ng);          // the next trip's packs are in flight during this trip's products
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int64_t cq = col + q * nsets;
+      if (cq < batch) {
+        T sk[PP_NLG], tk[PP_NLG];
+        const T* sp = sbar + cq * nl + l0;
+        const T* tp = tt + cq * nl + l0;
+#pragma unroll
+        for (int k = 0; k < PP_NLG; ++k) {
+          if constexpr (FULL) { sk[k] = sp[k]; tk[k] = tp[k]; }
+          else { sk[k] = k < nlg ? sp[k] : T(0); tk[k] = k < nlg ? tp[k] : T(0); }
+        }
+        if (nrow > 0) {
+#pragma unroll
+          for (int j = 0; j < V; ++j)
+#pragma unroll
+            for (int k = 0; k < PP_NLG; ++k) { m1[j][k] += pz[q].v[j] * sk[k]; m2[j][k] += pg[q].v[j] * tk[k]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) { pz[q] = nz[q]; pg[q] = ng[q]; }
+  }
+}
+
 template <class T, int V>
 __global__ __launch_bounds__(256) void planar_param_rows_kernel(const T* __restrict__ z0, const T* __restrict__ ybar, const T* __restrict__ sbar,
                                                                 const T* __restrict__ tt, int64_t dim, int64_t batch, int nl, int l0, int nlg, int TP,
@@ -4103,33 +4155,8 @@ __global__ __launch_bounds__(256) void planar_param_rows_kernel(const T* __restr
 #pragma unroll
     for (int k = 0; k < PP_NLG; ++k) { m1[j][k] = T(0); m2[j][k] = T(0); }
   const int64_t set = (int64_t)blockIdx.y * CG + cg, nsets = (int64_t)gridDim.y * CG;
-  for (int64_t col = set; col < batch; col += 2 * nsets) {
-    const int64_t colb = col + nsets;
-    const bool twob = colb < batch;
-    Pack<T, V> pz, pg, pzb, pgb;
-    if (ok) {
-      pz = load_pack_part<T, V>(z0 + col * dim + row0, nrow); pg = load_pack_part<T, V>(ybar + col * dim + row0, nrow);
-      if (twob) { pzb = load_pack_part<T, V>(z0 + colb * dim + row0, nrow); pgb = load_pack_part<T, V>(ybar + colb * dim + row0, nrow); }
-    }
-    T sk[PP_NLG], tk[PP_NLG], skb[PP_NLG], tkb[PP_NLG];
-#pragma unroll
-    for (int k = 0; k < PP_NLG; ++k) {
-      sk[k] = k < nlg ? sbar[col * nl + l0 + k] : T(0); tk[k] = k < nlg ? tt[col * nl + l0 + k] : T(0);
-      skb[k] = (k < nlg && twob) ? sbar[colb * nl + l0 + k] : T(0); tkb[k] = (k < nlg && twob) ? tt[colb * nl + l0 + k] : T(0);
-    }
-    if (ok) {
-#pragma unroll
-      for (int j = 0; j < V; ++j)
-#pragma unroll
-        for (int k = 0; k < PP_NLG; ++k) { m1[j][k] += pz.v[j] * sk[k]; m2[j][k] += pg.v[j] * tk[k]; }
-      if (twob) {
-#pragma unroll
-        for (int j = 0; j < V; ++j)
-#pragma unroll
-          for (int k = 0; k < PP_NLG; ++k) { m1[j][k] += pzb.v[j] * skb[k]; m2[j][k] += pgb.v[j] * tkb[k]; }
-      }
-    }
-  }
+  if (nlg == PP_NLG) planar_param_rows_walk<T, V, true>(z0, ybar, sbar, tt, dim, batch, nl, l0, nlg, set, nsets, row0, nrow, m1, m2);
+  else planar_param_rows_walk<T, V, false>(z0, ybar, sbar, tt, dim, batch, nl, l0, nlg, set, nsets, row0, nrow, m1, m2);
   const size_t n_m = (size_t)dim * nlg;
   const size_t per = 2 * n_m + (size_t)nlg * nlg + 2 * (size_t)nlg;
   double* out = partial + (size_t)set * per;
@@ -4146,32 +4173,49 @@ __global__ __launch_bounds__(256) void planar_param_rows_kernel(const T* __restr
     for (int i = tp; i < nlg * nlg + 2 * nlg; i += TP) out[2 * n_m + i] = 0.0;
 }
 
-// one block per entry of [ST nlg*nlg][b̄ nlg][c̄ nlg] of a layer group, summed over the whole batch in Float64
+// [ST nlg*nlg][b̄ nlg][c̄ nlg] of a layer group over the whole batch: a thread owns columns (the [batch][n_layers] rows of s̄ and tanh
+// are contiguous: coalesced), keeps the nlg² + 2·nlg sums in registers, the block combines them in Float64 and writes one set; the
+// column sum adds the sets.  (First form: one block per ENTRY walking the whole batch with a stride of n_layers elements — 80 blocks,
+// 0.5 ms at 2¹⁹ columns, as long as the row reduction it completes.)
 template <class T>
 __global__ __launch_bounds__(256) void planar_param_sums_kernel(const T* __restrict__ sbar, const T* __restrict__ tt, const T* __restrict__ lbar,
-                                                                const T* __restrict__ wtu_hat, int64_t batch, int nl, int l0, int nlg, double* __restrict__ out) {
-  __shared__ double red[4];
-  const int e = blockIdx.x;
-  double acc = 0.0;
-  if (e < nlg * nlg) {
-    const int j = l0 + e / nlg, k = l0 + e % nlg;
-    for (int64_t n = threadIdx.x; n < batch; n += 256) acc += (double)sbar[n * nl + j] * (double)tt[n * nl + k];
-  } else if (e < nlg * nlg + nlg) {
-    const int k = l0 + e - nlg * nlg;
-    for (int64_t n = threadIdx.x; n < batch; n += 256) acc += (double)sbar[n * nl + k];
-  } else {
-    const int k = l0 + e - nlg * nlg - nlg;
-    const double c = (double)wtu_hat[k];
-    if (lbar)
-      for (int64_t n = threadIdx.x; n < batch; n += 256) {
-        const double t = (double)tt[n * nl + k], q = 1.0 - t * t;
-        acc += (double)lbar[n] * q / (1.0 + c * q);
-      }
+                                                                const T* __restrict__ wtu_hat, int64_t batch, int nl, int l0, int nlg, double* __restrict__ part) {
+  __shared__ double red[4][PP_NLG * PP_NLG + 2 * PP_NLG];
+  T g[PP_NLG][PP_NLG], bs[PP_NLG], cs[PP_NLG], cw[PP_NLG];
+#pragma unroll
+  for (int j = 0; j < PP_NLG; ++j) {
+    bs[j] = T(0); cs[j] = T(0); cw[j] = j < nlg ? wtu_hat[l0 + j] : T(0);
+#pragma unroll
+    for (int k = 0; k < PP_NLG; ++k) g[j][k] = T(0);
   }
-  acc = group_sum<64>(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < batch; n += (int64_t)gridDim.x * 256) {
+    T sk[PP_NLG], tk[PP_NLG];
+#pragma unroll
+    for (int k = 0; k < PP_NLG; ++k) { sk[k] = k < nlg ? sbar[n * nl + l0 + k] : T(0); tk[k] = k < nlg ? tt[n * nl + l0 + k] : T(0); }
+    const T lb = lbar ? lbar[n] : T(0);
+#pragma unroll
+    for (int j = 0; j < PP_NLG; ++j) {
+      bs[j] += sk[j];
+      const T q = T(1) - tk[j] * tk[j];
+      cs[j] += lb * q / (T(1) + cw[j] * q);
+#pragma unroll
+      for (int k = 0; k < PP_NLG; ++k) g[j][k] += sk[j] * tk[k];
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int E = nlg * nlg + 2 * nlg;
+#pragma unroll
+  for (int j = 0; j < PP_NLG; ++j) {
+#pragma unroll
+    for (int k = 0; k < PP_NLG; ++k) {
+      const double v = group_sum<64>((double)g[j][k]);
+      if (lane == 0 && j < nlg && k < nlg) red[wv][j * nlg + k] = v;
+    }
+    const double vb = group_sum<64>((double)bs[j]), vc = group_sum<64>((double)cs[j]);
+    if (lane == 0 && j < nlg) { red[wv][nlg * nlg + j] = vb; red[wv][nlg * nlg + nlg + j] = vc; }
+  }
   __syncthreads();
-  if (threadIdx.x == 0) out[e] = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int e = threadIdx.x; e < E; e += 256) part[(size_t)blockIdx.x * E + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 template <class T>
@@ -4341,7 +4385,16 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
       } else {
         hipLaunchKernelGGL(planar_param_colsum_kernel, dim3(gx), dim3(256), 0, ctx->stream, partial, nsets, per, psum, 0);
       }
-      hipLaunchKernelGGL(planar_param_sums_kernel<T>, dim3(nlg * nlg + 2 * nlg), dim3(256), 0, ctx->stream, s_out, t_out, ladj_bar, wtu, batch, nl, l0, nlg, psum + 2 * (size_t)dim * nlg);
+      {
+        // Gram block / b̄ / c̄: one set per block into the (now free) head of the row sets, summed into the tail of the summed set
+        const int E = nlg * nlg + 2 * nlg;
+        int sb = (int)((batch + 511) / 512);
+        if (sb > 1024) sb = 1024;
+        if ((size_t)sb * E > (size_t)nsets * per) sb = (int)((size_t)nsets * per / E);
+        if (sb < 1) sb = 1;
+        hipLaunchKernelGGL(planar_param_sums_kernel<T>, dim3(sb), dim3(256), 0, ctx->stream, s_out, t_out, ladj_bar, wtu, batch, nl, l0, nlg, partial);
+        hipLaunchKernelGGL(planar_param_colsum_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, sb, (size_t)E, psum + 2 * (size_t)dim * nlg, 0);
+      }
       hipLaunchKernelGGL(planar_param_finalize_kernel<T>, dim3(nlg), dim3(256), 0, ctx->stream, psum, 1, dim, nl, l0, nlg, one_group ? (const double*)nullptr : (const double*)st, w, u, u_hat, w_bar, u_bar, b_bar);
       BJX_CHECK_LAUNCH(ctx);
     }
