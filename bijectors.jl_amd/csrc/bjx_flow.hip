@@ -4218,16 +4218,62 @@ __global__ __launch_bounds__(256) void planar_param_sums_kernel(const T* __restr
   for (int e = threadIdx.x; e < E; e += 256) part[(size_t)blockIdx.x * E + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
+// The cross-group Gram matrix ST[j][k] = Σ_n s̄_jn t_kn of a stack of more than PP_NLG layers, in 8 x 8 tiles: blockIdx.y = tile,
+// blockIdx.x = slice of the batch, a thread owns columns (coalesced rows of the [batch][n_layers] arrays) and the tile's 64 sums;
+// planar_gram_final_kernel adds the slices.  (First form: one block per ENTRY walking the whole batch with a stride of n_layers
+// elements: 8 ms at 2²² columns and 12 layers — vjp_params of 12 / 16 layers ran at 11 / 10 % where 8 layers reach 61 %.)
 template <class T>
-__global__ __launch_bounds__(256) void planar_gram_kernel(const T* __restrict__ sbar, const T* __restrict__ tt, int64_t batch, int nl, double* __restrict__ st) {
-  __shared__ double red[4];
-  const int j = blockIdx.x / nl, k = blockIdx.x % nl;
-  double acc = 0.0;
-  for (int64_t n = threadIdx.x; n < batch; n += blockDim.x) acc += (double)sbar[n * nl + j] * (double)tt[n * nl + k];
-  acc = group_sum<64>(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+__global__ __launch_bounds__(256) void planar_gram_tiles_kernel(const T* __restrict__ sbar, const T* __restrict__ tt, int64_t batch, int nl, int nt,
+                                                                double* __restrict__ part) {
+  __shared__ double red[4][64];
+  const int j0 = ((int)blockIdx.y / nt) * 8, k0 = ((int)blockIdx.y % nt) * 8;
+  T g[8][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[j][k] = T(0);
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < batch; n += (int64_t)gridDim.x * 256) {
+    T sk[8], tk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sk[k] = j0 + k < nl ? sbar[n * nl + j0 + k] : T(0); tk[k] = k0 + k < nl ? tt[n * nl + k0 + k] : T(0); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[j][k] += sk[j] * tk[k];
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double v = group_sum<64>((double)g[j][k]);
+      if (lane == 0) red[wv][j * 8 + k] = v;
+    }
   __syncthreads();
-  if (threadIdx.x == 0) st[j * nl + k] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x < 64) part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void planar_gram_final_kernel(const double* __restrict__ part, int slices, int nl, int nt, double* __restrict__ st) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= nl * nl) return;
+  const int j = e / nl, k = e % nl;
+  const size_t tile = (size_t)(j / 8) * nt + k / 8;
+  const int in = (j % 8) * 8 + k % 8;
+  double a = 0.0;
+  for (int b = 0; b < slices; ++b) a += part[(tile * slices + b) * 64 + in];
+  st[e] = a;
+}
+constexpr int PP_GRAM_SLICES = 256;
+template <class T>
+int planar_gram_launch(bjx_ctx* ctx, const T* s_out, const T* t_out, int64_t batch, int nl, double* work, double* st) {
+  const int nt = (nl + 7) / 8;
+  int slices = (int)((batch + 1023) / 1024);
+  if (slices > PP_GRAM_SLICES) slices = PP_GRAM_SLICES;
+  if (slices < 1) slices = 1;
+  BjxProf prof_(ctx);
+  hipLaunchKernelGGL(planar_gram_tiles_kernel<T>, dim3(slices, nt * nt), dim3(256), 0, ctx->stream, s_out, t_out, batch, nl, nt, work);
+  hipLaunchKernelGGL(planar_gram_final_kernel, dim3((nl * nl + 255) / 256), dim3(256), 0, ctx->stream, work, slices, nl, nt, st);
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
 }
 
 // Fixed-order sum of the per-block partial sets into one set: thread e owns element e of the set, adjacent threads
@@ -4341,7 +4387,11 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
   // the register accumulators stop at four packs, the block combine at the LDS
   static const int use_rows = getenv("BJX_PLANAR_PARAM_ROWS") ? atoi(getenv("BJX_PLANAR_PARAM_ROWS")) : 1;
   const bool must_rows = !(cfg_ok && c.R <= 4) || (2 * (size_t)dim * nlg_max + nlg_max * nlg_max + 2 * nlg_max) * sizeof(double) > BJX_LDS_MAX;
-  const bool rows_path = must_rows || (use_rows && dim > 64 * VWr && !(std::is_same<T, float>::value && dim == 256 && c.V == VWr && bjx_aligned16(out_bar)));
+  // (a value above 1 = the first height that takes the rows path; Float64 from 33 rows: 40 / 72 / 100 rows 14.8 / 19.2 / 25.7 → 16.9 / 28.8 / 38.1 %
+  //  of the whole call; Float32 below 257 rows: 72 / 100 / 250 rows lose, 192 / 200 win — the register accumulators stay)
+  const int64_t rows_min = use_rows > 1 ? use_rows : (std::is_same<T, double>::value ? 33 : 64 * VWr + 1);
+  const bool mfma_shape = std::is_same<T, float>::value && (dim == 64 || dim == 128 || dim == 256) && c.V == VWr && bjx_aligned16(out_bar);
+  const bool rows_path = must_rows || (use_rows && dim >= rows_min && dim > 32 && !mfma_shape);
   if (rows_path) {
     const int64_t packs = (dim + VWr - 1) / VWr;
     const int TP = packs > 128 ? 256 : (packs > 64 ? 128 : 64);
@@ -4362,16 +4412,14 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
     const int nsets = (int)(S * CG);
     const size_t st_n = (size_t)nl * nl;
     constexpr int SL = 32;                             // slices of the first column-sum stage
-    { int rc2 = bjx_ensure_partials(ctx, (size_t)nsets * per_max_r + st_n + per_max_r + (size_t)SL * per_max_r); if (rc2) return rc2; }
+    const bool one_group = nl <= PP_NLG;
+    const size_t gram_n = one_group ? 0 : (size_t)((nl + 7) / 8) * ((nl + 7) / 8) * 64 * PP_GRAM_SLICES;
+    { int rc2 = bjx_ensure_partials(ctx, (size_t)nsets * per_max_r + st_n + per_max_r + (size_t)SL * per_max_r + gram_n); if (rc2) return rc2; }
     double* partial = ctx->partials;
     double* st = partial + (size_t)nsets * per_max_r;
     double* psum = st + st_n;
     double* slices = psum + per_max_r;
-    const bool one_group = nl <= PP_NLG;
-    if (!one_group) {
-      hipLaunchKernelGGL(planar_gram_kernel<T>, dim3(nl * nl), dim3(256), 0, ctx->stream, s_out, t_out, batch, nl, st);
-      BJX_CHECK_LAUNCH(ctx);
-    }
+    if (!one_group) { int rcg = planar_gram_launch<T>(ctx, s_out, t_out, batch, nl, slices + (size_t)SL * per_max_r, st); if (rcg) return rcg; }
     for (int l0 = 0; l0 < nl; l0 += PP_NLG) {
       const int nlg = nl - l0 < PP_NLG ? nl - l0 : PP_NLG;
       const size_t per = 2 * (size_t)dim * nlg + (size_t)nlg * nlg + 2 * (size_t)nlg;
@@ -4418,16 +4466,14 @@ int planar_vjp_params_impl(bjx_ctx* ctx, const T* w, const T* u, const T* b, int
   if (nblocks < 1) nblocks = 1;
   const size_t per_max = 2 * (size_t)dim * PP_NLG + PP_NLG * PP_NLG + 2 * PP_NLG;
   const size_t st_n = (size_t)nl * nl;
-  { int rc2 = bjx_ensure_partials(ctx, (size_t)nblocks * per_max + st_n + per_max + 32 * per_max); if (rc2) return rc2; }
+  const bool one_group = nl <= PP_NLG;
+  const size_t gram_n = one_group ? 0 : (size_t)((nl + 7) / 8) * ((nl + 7) / 8) * 64 * PP_GRAM_SLICES;
+  { int rc2 = bjx_ensure_partials(ctx, (size_t)nblocks * per_max + st_n + per_max + 32 * per_max + gram_n); if (rc2) return rc2; }
   double* partial = ctx->partials;
   double* st = partial + (size_t)nblocks * per_max;
   double* psum = st + st_n;                          // the block partials summed into one set
   double* slices = psum + per_max;                   // [32][per]: first stage of the column sum when there are many sets of few entries
-  const bool one_group = nl <= PP_NLG;
-  if (!one_group) {                                  // cross-group Gram entries: a separate (slow, rarely needed) pass
-    hipLaunchKernelGGL(planar_gram_kernel<T>, dim3(nl * nl), dim3(256), 0, ctx->stream, s_out, t_out, batch, nl, st);
-    BJX_CHECK_LAUNCH(ctx);
-  }
+  if (!one_group) { int rcg = planar_gram_launch<T>(ctx, s_out, t_out, batch, nl, slices + 32 * per_max, st); if (rcg) return rcg; }   // cross-group Gram entries
   for (int l0 = 0; l0 < nl; l0 += PP_NLG) {
     const int nlg = nl - l0 < PP_NLG ? nl - l0 : PP_NLG;
     const size_t per = 2 * (size_t)dim * nlg + (size_t)nlg * nlg + 2 * (size_t)nlg;
