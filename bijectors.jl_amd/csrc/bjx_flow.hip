@@ -33,71 +33,7 @@ __global__ __launch_bounds__(256) void planar_prep_kernel(const T* w, const T* u
   if (threadIdx.x == 0) wtu_hat[l] = d_log1pexp(wT_u) - T(1);
 }
 
-// planar_layer.jl:160-185 (find_alpha): solve α + c·tanh(α+b) = wy inside [wy-2|c|, wy+2|c|].
-// Roots.A42 is replaced by a safeguarded Newton iteration on the same bracket (the function is
-// strictly increasing because c = wᵀû > -1); terminates when the step is below 1 ulp or the
-// bracket collapses.  Parity with the reference is residual-pinned (test/normalising_flows.jl:47-70).
-template <class T> __device__ __forceinline__ T find_alpha_dev(T wy, T c, T b) {
-  const T delta = T(2) * d_abs(c);
-  T lo = wy - delta, hi = wy + delta;
-  if (lo == hi) return lo;                       // :171-173
-  T a = wy - c * x_tanh(wy + b);                 // one fixed-point step as the start
-  a = a < lo ? lo : (a > hi ? hi : a);
-  const int max_it = sizeof(T) == 4 ? 40 : 80;
-  for (int it = 0; it < max_it; ++it) {
-    T t = x_tanh(a + b);
-    T f = a + c * t - wy;
-    if (f == T(0)) break;
-    if (f < T(0)) lo = a; else hi = a;
-    T fp = T(1) + c * (T(1) - t * t);
-    T an = a - f / fp;
-    if (!(an > lo && an < hi)) an = lo + (hi - lo) / T(2);     // safeguard: bisect
-    if (an == a || !(an > lo && an < hi)) break;               // bracket is adjacent floats
-    T step = d_abs(an - a);
-    a = an;
-    if (step <= Num<T>::eps * d_abs(a)) {
-      // one more residual check would not change the float; done
-      break;
-    }
-  }
-  return a;
-}
-
-// the inverse step's root + activation: Float64 through find_alpha_act64 (Float32 pre-solve + two Float64 Newton steps, below),
-// Float32 through the safeguarded loop (the Float32 hot kernels have their own find_alpha_act)
-__device__ __forceinline__ void find_alpha_act64(double wy, double c, double b, double& th, double& s2);
-template <class T> __device__ __forceinline__ void planar_inv_act(T wy, T c, T b, T& th, T& s2) {
-  if constexpr (sizeof(T) == 8) find_alpha_act64(wy, c, b, th, s2);
-  else { const T arg = find_alpha_dev<T>(wy, c, b) + b; x_tanh_sech2(arg, th, s2); }
-}
-
-template <class T> struct PlanarArgs {
-  const T *w, *u_hat, *wtu_hat, *b;
-  int n_layers;
-  int in_lds;
-};
-
-// The last pack of a column whose height is not a whole number of packs (the group kernels on element-aligned packs, round 3):
-// nrow < V live rows, read / written one by one, the dead rows read as zero.
-template <class T, int V> __device__ __forceinline__ Pack<T, V> load_pack_part(const T* p, int nrow) {
-  if (nrow >= V) return load_pack<T, V, true>(p);
-  Pack<T, V> r;
-#pragma unroll
-  for (int j = 0; j < V; ++j) r.v[j] = j < nrow ? p[j] : T(0);
-  return r;
-}
-// the same through the caches (parameter rows that every block reads: load_pack_part's loads are nontemporal)
-template <class T, int V> __device__ __forceinline__ Pack<T, V> load_pack_part_cached(const T* p, int nrow) {
-  if (nrow >= V) return load_pack<T, V, false>(p);
-  Pack<T, V> r;
-#pragma unroll
-  for (int j = 0; j < V; ++j) r.v[j] = j < nrow ? p[j] : T(0);
-  return r;
-}
-template <class T, int V> __device__ __forceinline__ void store_pack_part(T* p, const Pack<T, V>& r, int nrow) {
-  if (nrow >= V) { store_pack<T, V, true>(p, r); return; }
-  store_pack_run<T, V>(p, r, 0, nrow);
-}
+#include "bjx_flow_common.inc"
 
 template <class T, int V, int R, bool INV>
 __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, const T* x, T* y, T* ladj_ps, int64_t dim,
@@ -487,224 +423,8 @@ __global__ __launch_bounds__(64) void planar_tile_kernel(const PlanarTileArgs<T>
 //      registers.
 // 128 + 32 VGPRs at dim = 128 -> 2 waves per SIMD, every load of a wave in flight at once.
 
-__device__ __forceinline__ void permlane16_swap(float& a, float& b) {
-  // a' rows = [a0, b0, a2, b2], b' rows = [a1, b1, a3, b3] (row = 16 lanes; scripts/probe_lane_ops.hip).
-  // inline asm: __builtin_amdgcn_permlane16_swap miscompiles in this ROCm (both results read vdst).
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-}
-// One butterfly stage (v += v[partner]) on NV independent values with the DPP modifier fused into
-// the add.  GFX9 hazard: a VALU write needs 2 wait states before a DPP read of the same VGPR.  The
-// NV adds of a stage are independent, so from the second stage on NV >= 4 needs no padding; the
-// first stage (inputs written by compiler-scheduled VALU code) and short stages get an s_nop 1.
-#define BJX_DPP1(i, CTRL) "v_add_f32_dpp %" #i ", %" #i ", %" #i " " CTRL " row_mask:0xf bank_mask:0xf\n\t"
-#define BJX_DPP_STAGE(NOP, CTRL)                                                                                       \
-  if constexpr (NV == 1) asm volatile("s_nop 1\n\t" BJX_DPP1(0, CTRL) : "+v"(q[0]));                                    \
-  else if constexpr (NV == 2) asm volatile("s_nop 1\n\t" BJX_DPP1(0, CTRL) BJX_DPP1(1, CTRL) : "+v"(q[0]), "+v"(q[1])); \
-  else if constexpr (NV == 4) asm volatile(NOP BJX_DPP1(0, CTRL) BJX_DPP1(1, CTRL) BJX_DPP1(2, CTRL) BJX_DPP1(3, CTRL) \
-                                           : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));                           \
-  else asm volatile(NOP BJX_DPP1(0, CTRL) BJX_DPP1(1, CTRL) BJX_DPP1(2, CTRL) BJX_DPP1(3, CTRL)                         \
-                    BJX_DPP1(4, CTRL) BJX_DPP1(5, CTRL) BJX_DPP1(6, CTRL) BJX_DPP1(7, CTRL)                             \
-                    : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]));
-// all-lanes sum over aligned groups of W <= 16 consecutive lanes, NV values at once
-template <int W, int NV> __device__ __forceinline__ void row_allsum(float (&q)[NV]) {
-  static_assert(NV == 1 || NV == 2 || NV == 4 || NV == 8, "NV");
-  if constexpr (W >= 2) { BJX_DPP_STAGE("s_nop 1\n\t", "quad_perm:[1,0,3,2]") }
-  if constexpr (W >= 4) { BJX_DPP_STAGE("", "quad_perm:[2,3,0,1]") }
-  if constexpr (W >= 8) { BJX_DPP_STAGE("", "row_half_mirror") }
-  if constexpr (W >= 16) { BJX_DPP_STAGE("", "row_mirror") }
-}
-#undef BJX_DPP_STAGE
-// q[k] = fold(p[k], p[k+NV]) for k < NV: v_permlane16_swap puts lanes i / i+16 of p[k] side by side
-// in the even rows and those of p[k+NV] in the odd rows (see permlane16_swap), then one add.
-template <int NV> __device__ __forceinline__ void swap_fold(float* p, float (&q)[NV]) {
-  if constexpr (NV == 4)
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
-                 "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
-                 : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
-  else if constexpr (NV == 2)
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1"
-                 : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));
-  else
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(p[0]), "+v"(p[1]));
-#pragma unroll
-  for (int k = 0; k < NV; ++k) q[k] = p[k] + p[k + NV];
-}
+#include "bjx_flow_reg.inc"
 
-struct PlanarRegArgs {
-  const float *w, *u_hat;   // [nl_pad][dim] (layers beyond n_layers are zero)
-  const float *G;           // [nl_pad][nl_pad], G[k][j] = w_k . u_hat_j
-  const float *wtu_hat, *b; // [nl_pad]
-  int nl_pad;
-  int n_layers;             // layers beyond it are padding: their tanh is forced to 0 (a +-Inf input would make 0 * Inf = NaN of them)
-  int ldw;                  // row pitch of w / u_hat: dim rounded up to whole 16-byte packs (the padding rows are zero)
-  int unal;                 // column heights that are not a multiple of four: see reg_load_pack (2: streaming stores)
-  int lead;                 // zero rows in front of every row of w / u_hat (4 in that case, 0 otherwise)
-};
-
-// Column heights that are not a multiple of four (UNAL instantiations; bases 16-byte aligned).  Round 3 kept "lane gl owns rows
-// 4gl .. 4gl+3 of its column" and read them with 16-byte loads on element-aligned addresses: every 256-byte slice of a column then
-// straddles three 128-byte lines instead of two, and eight layers at 101 / 201 rows ran at 36-41 % of the HBM peak against 74 % at
-// 128.  Round 4 keeps the ADDRESSES on the 16-byte grid instead: a column that starts phi elements past a 16-byte boundary is cut
-// into the aligned packs of memory, lane gl owns rows rel .. rel+3 with rel = row0 + 4gl - phi — the first pack of a column and
-// the last one also hold rows of the neighbouring columns, which are read as zeros (live elements [lo, hi)) and never stored.
-// phi is the same for every column a lane touches: a 16-lane group steps through columns cg, cg+4, cg+8, … and
-// (c + 4) dim = c dim (mod 4).  The parameter tables are read at the matching offset (their rows carry `lead` zeros in front and
-// at least four behind), so the zero-padded products need no masks.
-typedef float bjx_pk4 __attribute__((ext_vector_type(4)));
-typedef bjx_pk4 bjx_pk4u __attribute__((aligned(4)));
-// (the loads of a tile are all issued BEFORE the first mask is applied — reg_mask_tile below: masked one by one, every load was
-//  followed by an s_waitcnt and the sixteen loads of a lane went to memory one after the other; with eight layers of work per tile that
-//  halved the bytes in flight per CU: 42 % of the HBM peak at 201 rows against 60 % at 200)
-__device__ __forceinline__ bjx_pk4 reg_load_pack(const float* px) { return __builtin_nontemporal_load(reinterpret_cast<const bjx_pk4*>(px)); }
-template <int NS> __device__ __forceinline__ void reg_mask_tile(bjx_pk4 (&z)[NS], int lo, int hi) {
-  const bool k0 = lo <= 0 && hi > 0, k1 = lo <= 1 && hi > 1, k2 = lo <= 2 && hi > 2, k3 = lo <= 3 && hi > 3;   // selects, no branch around the tile
-#pragma unroll
-  for (int r = 0; r < NS; ++r) {
-    z[r].x = k0 ? z[r].x : 0.f;
-    z[r].y = k1 ? z[r].y : 0.f;
-    z[r].z = k2 ? z[r].z : 0.f;
-    z[r].w = k3 ? z[r].w : 0.f;
-  }
-}
-// nt: streaming stores (A.unal == 2).  Off by default — the 64-byte sector that two columns share is written at different times,
-// and streamed it reached HBM as partial writes (WRITE_SIZE 1.15-1.35 x the output).
-__device__ __forceinline__ void reg_store_pack(float* py, const bjx_pk4 v, int lo, int hi, bool nt) {
-  if (lo <= 0 && hi >= 4) { if (nt) __builtin_nontemporal_store(v, reinterpret_cast<bjx_pk4*>(py)); else *reinterpret_cast<bjx_pk4*>(py) = v; }
-  else {
-    if (lo <= 0 && hi > 0) py[0] = v.x;
-    if (lo <= 1 && hi > 1) py[1] = v.y;
-    if (lo <= 2 && hi > 2) py[2] = v.z;
-    if (lo <= 3 && hi > 3) py[3] = v.w;
-  }
-}
-// my pack on the aligned grid: rel = first row (may be -3 .. -1 at the head of a column), live elements [lo, hi)
-struct RegGrid { int phi, rel, lo, hi; bool ok; };
-template <bool UNAL> __device__ __forceinline__ RegGrid reg_grid(int64_t col, int dim, int row) {
-  RegGrid g;
-  g.phi = UNAL ? (int)((col * (int64_t)dim) & 3) : 0;
-  g.rel = row - g.phi;
-  g.lo = g.rel < 0 ? -g.rel : 0;
-  g.hi = dim - g.rel < 4 ? dim - g.rel : 4;
-  g.ok = g.hi > g.lo;
-  return g;
-}
-
-// find_alpha for the register kernel: same safeguarded Newton on the reference's bracket
-// (planar_layer.jl:160-185) with tanh from one hardware exp (the OCML tanhf made the inverse flow
-// VALU-bound at 39 % of the HBM roofline); lanes leave the loop individually, the wave runs
-// max-over-lanes iterations (typically 3-5).
-__device__ __forceinline__ float fast_tanh(float x) {
-  const float e = Fast<float>::exp(-2.0f * fabsf(x));
-  const float t = (1.0f - e) * Fast<float>::rcp(1.0f + e);
-  return x < 0.0f ? -t : t;
-}
-__device__ __noinline__ float find_alpha_safe(float wy, float c, float b) {
-  const float delta = 2.0f * fabsf(c);
-  float lo = wy - delta, hi = wy + delta;
-  if (lo == hi) return lo;                       // :171-173
-  float a = wy - c * fast_tanh(wy + b);          // one fixed-point step as the start
-  a = a < lo ? lo : (a > hi ? hi : a);
-  for (int it = 0; it < 40; ++it) {
-    const float t = fast_tanh(a + b);
-    const float f = a + c * t - wy;
-    if (f == 0.0f) break;
-    if (f < 0.0f) lo = a; else hi = a;
-    const float fp = 1.0f + c * (1.0f - t * t);
-    float an = a - f * Fast<float>::rcp(fp);
-    if (!(an > lo && an < hi)) an = lo + (hi - lo) * 0.5f;     // safeguard: bisect
-    if (an == a || !(an > lo && an < hi)) break;               // bracket is adjacent floats
-    const float step = fabsf(an - a);
-    a = an;
-    if (step <= Num<float>::eps * fabsf(a)) break;
-  }
-  return a;
-}
-
-// tanh / sech^2 / log1p from one exp (|rel err| ~ 1e-6, Float32 parity bar 1e-3)
-__device__ __forceinline__ void planar_act(float arg, float c, float& th, float& ld) {
-  using F = Fast<float>;
-  const float e = F::exp(-2.0f * fabsf(arg));
-  const float r = F::rcp(1.0f + e);
-  const float t = (1.0f - e) * r;
-  th = arg < 0.0f ? -t : t;
-  ld = F::log1p(c * (4.0f * e * r * r));     // planar_layer.jl:107, sech² = 4e/(1+e)²
-}
-
-// find_alpha + the activation of the inverse step in one go.  Three UNGUARDED Newton steps from the fixed-point
-// start α₀ = wᵀy − c·tanh(wᵀy + b) (inside the reference's bracket, planar_layer.jl:160-173), no data-dependent
-// loop: every lane of the wave does the same ~80 instructions.  The residual is then checked at rounding level and
-// against the bracket; only a lane that fails (c → −1 with tanh ≈ 0, where f′ → 0) falls back to the safeguarded
-// bracketing loop above.  (The loop alone ran max-over-lanes ≈ 6 iterations of ≈ 42 issue slots per layer: the
-// inverse flow was 62 % VALU-busy at 50 % of the HBM roofline.)  The exp/rcp of the acceptance test are the ones
-// tanh, sech² and log1p of the step need.
-__device__ __forceinline__ void find_alpha_act(float wy, float c, float b, float& th, float& ld) {
-  using F = Fast<float>;
-  const float delta = 2.0f * fabsf(c);
-  float a = wy - c * fast_tanh(wy + b);
-#pragma unroll
-  for (int it = 0; it < 3; ++it) {
-    const float t = fast_tanh(a + b);
-    const float f = a + c * t - wy;
-    const float fp = 1.0f + c * (1.0f - t * t);
-    a -= f * F::rcp(fp);
-  }
-  float arg = a + b;
-  float e = F::exp(-2.0f * fabsf(arg));
-  float r = F::rcp(1.0f + e);
-  float t = (1.0f - e) * r;
-  t = arg < 0.0f ? -t : t;
-  const float f = a + c * t - wy;
-  const bool ok = fabsf(f) <= 8.0f * Num<float>::eps * (fabsf(wy) + fabsf(c) + fabsf(a)) && a >= wy - delta && a <= wy + delta;
-  if (!ok) {                                           // rare, divergent
-    a = find_alpha_safe(wy, c, b);
-    arg = a + b;
-    e = F::exp(-2.0f * fabsf(arg));
-    r = F::rcp(1.0f + e);
-    t = (1.0f - e) * r;
-    t = arg < 0.0f ? -t : t;
-  }
-  th = t;
-  ld = F::log1p(c * (4.0f * e * r * r));               // planar_layer.jl:107, sech² = 4e/(1+e)²
-}
-
-// Float64 find_alpha + activation of the inverse step (round 3).  find_alpha_dev<double> runs a data-dependent safeguarded loop:
-// max-over-lanes ~7-8 iterations of a Float64 tanh (expm1 + reciprocal) and a Float64 division — the inverse 8-layer flow sat at
-// 25 % of the HBM peak against 52 % for the forward one.  Here the root is first solved in FLOAT32 on the hardware exp / rcp units
-// (the fixed-point start and three Newton steps of find_alpha_act: ~1e-7 relative), which leaves Newton's quadratic convergence
-// two Float64 steps from rounding level (1e-7 -> 1e-14 -> below eps); the third Float64 evaluation is the one tanh / sech² of the
-// step need anyway and doubles as the acceptance test (residual at rounding level, root inside the reference's bracket,
-// planar_layer.jl:160-173).  Every lane does the same straight-line work; a lane that fails the test (c -> -1 with tanh ~ 0, or
-// operands outside Float32's range) falls back to the safeguarded loop.
-__device__ __forceinline__ void find_alpha_act64(double wy, double c, double b, double& th, double& s2) {
-  using F = Fast<double>;
-  const float wyf = (float)wy, cf = (float)c, bf = (float)b;
-  float af = wyf - cf * fast_tanh(wyf + bf);
-#pragma unroll
-  for (int it = 0; it < 3; ++it) {
-    const float t = fast_tanh(af + bf);
-    af -= (af + cf * t - wyf) * Fast<float>::rcp(1.0f + cf * (1.0f - t * t));
-  }
-  double a = (double)af;
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    double t, q;
-    x_tanh_sech2(a + b, t, q);
-    a -= (a + c * t - wy) * F::rcp(1.0 + c * q);
-  }
-  x_tanh_sech2(a + b, th, s2);
-  const double f = a + c * th - wy;
-  const double delta = 2.0 * __builtin_fabs(c);
-  const bool ok = __builtin_fabs(f) <= 8.0 * Num<double>::eps * (__builtin_fabs(wy) + __builtin_fabs(c) + __builtin_fabs(a)) && a >= wy - delta && a <= wy + delta;
-  if (!ok) {                                           // rare, divergent
-    a = find_alpha_dev<double>(wy, c, b);
-    x_tanh_sech2(a + b, th, s2);
-  }
-}
-
-// COLS = columns per wave: 64 (every lane runs the recurrence) or 32 (half the register tile -> twice the waves per SIMD;
-// lanes 32..63 idle in the short recurrence)
-// UNAL (template flag, like the tail rows of the group skeleton): the element-aligned / partial-pack accesses compiled into the
-// whole-pack instantiation cost C4 6 % in a same-box A/B (0.66 against 0.70-0.71 of the HBM peak) — they are separate kernels.
 template <int G, int NL, bool INV, int COLS, bool UNAL = false>
 __global__ __launch_bounds__(256) void planar_reg_kernel(const PlanarRegArgs A, const float* __restrict__ x, float* __restrict__ y,
                                                          float* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate,
@@ -1221,86 +941,6 @@ __global__ __launch_bounds__(256) void planar_mfma64_kernel(const double* __rest
 // so it is NL dot products against û per pack, the transposed reduction, a lane = column scalar recurrence from the
 // last layer down, and a rank-NL update with w.  The primal tile is dead once tanh(s_k) of every layer sits in LDS
 // ([column][layer], 4·nl_pad bytes per column), so ȳ is loaded into the same registers: read z, read ȳ, write z̄.
-typedef float bjx_f4 __attribute__((ext_vector_type(4)));
-typedef float bjx_f2 __attribute__((ext_vector_type(2)));
-template <int G, int NL, int NS>
-__device__ __forceinline__ void reg_dots(const float* __restrict__ tab, int l0, int dim, const bjx_f4 (&z)[NS], float* st, int lane, int gl, int cg, bool row_ok, int row0 = 0) {
-  constexpr int CPS = 64 / G;
-  constexpr bool SWAP = (G == 32) && (NL >= 2);
-  constexpr int NV = SWAP ? NL / 2 : NL;
-  constexpr int RW = G < 16 ? G : 16;
-  constexpr int NP = NL >= 2 ? NL / 2 : 1;
-  bjx_f2 wq[NP][4];
-#pragma unroll
-  for (int kp = 0; kp < NP; ++kp) {
-    bjx_f4 a = bjx_f4{0.f, 0.f, 0.f, 0.f}, b = a;
-    if (row_ok) {
-      a = *reinterpret_cast<const bjx_pk4u*>(tab + (int64_t)(l0 + 2 * kp) * dim + row0 + 4 * gl);
-      if (NL >= 2) b = *reinterpret_cast<const bjx_pk4u*>(tab + (int64_t)(l0 + 2 * kp + 1) * dim + row0 + 4 * gl);
-    }
-    wq[kp][0] = bjx_f2{a.x, b.x}; wq[kp][1] = bjx_f2{a.y, b.y}; wq[kp][2] = bjx_f2{a.z, b.z}; wq[kp][3] = bjx_f2{a.w, b.w};
-  }
-#pragma unroll
-  for (int r = 0; r < NS; ++r) {
-    float p[NL >= 2 ? NL : 2];
-#pragma unroll
-    for (int kp = 0; kp < NP; ++kp) {
-      bjx_f2 acc = wq[kp][0] * z[r].x;
-      acc += wq[kp][1] * z[r].y;
-      acc += wq[kp][2] * z[r].z;
-      acc += wq[kp][3] * z[r].w;
-      p[2 * kp] = acc.x; p[2 * kp + 1] = acc.y;
-    }
-    float q[NV];
-    if constexpr (SWAP) {
-      swap_fold<NV>(p, q);
-    } else if constexpr (G == 32) {
-      p[1] = p[0];
-      swap_fold<1>(p, q);
-    } else {
-#pragma unroll
-      for (int k = 0; k < NV; ++k) q[k] = p[k];
-    }
-    row_allsum<RW, NV>(q);
-    if ((lane & (RW - 1)) == 0) {
-      int cl, lo;
-      if (G == 32) { cl = r * CPS + (lane >> 5); lo = SWAP ? ((lane >> 4) & 1) * NV : 0; }
-      else { cl = r * CPS + cg; lo = 0; }
-      if (!(G == 32 && !SWAP && ((lane >> 4) & 1))) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) st[cl * NL + lo + k] = q[k];
-      }
-    }
-  }
-}
-template <int G, int NL, int NS>
-__device__ __forceinline__ void reg_update(const float* __restrict__ tab, int l0, int dim, bjx_f4 (&z)[NS], const float* st, int gl, int cg, bool row_ok, int row0 = 0) {
-  constexpr int CPS = 64 / G;
-  bjx_f4 uv[NL];
-#pragma unroll
-  for (int k = 0; k < NL; ++k)
-    uv[k] = row_ok ? (bjx_f4)*reinterpret_cast<const bjx_pk4u*>(tab + (int64_t)(l0 + k) * dim + row0 + 4 * gl) : bjx_f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int r = 0; r < NS; ++r) {
-    const float* tc = st + (r * CPS + cg) * NL;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) { const float tk = tc[k]; z[r] += uv[k] * tk; }
-  }
-}
-
-// ------------------------------------------------------------------ Planar, register kernel with TWO waves per tile (64 < dim <= 128)
-// planar_reg_kernel keeps a 64-column tile of a 128-row problem in 128 VGPRs of ONE wave: 2 waves per SIMD, 44 % VALU
-// busy and 38 % of the wave time waiting (PMC) — latency-bound.  Here the rows of a tile are split over two waves
-// (64 rows each: 16 lanes per column, 64 VGPRs of tile): the dot products are partial sums exchanged through LDS with
-// ONE block barrier per layer group, both waves then run the (cheap) lane = column recurrence redundantly on the
-// summed values and update their own rows.  Same bytes, half the registers per wave, twice the waves in flight.
-// The partial-sum buffers are double-buffered by group parity, so a wave that runs ahead cannot overwrite what its
-// partner is still reading.
-// NW = 4: the same with FOUR waves per tile (one tile per block) for 128 < dim <= 256 — those heights used to fall to the
-// LDS-tile kernel (one lane per column over a 64 x dim tile: 8-22 % of the roofline) or the generic group kernel.
-// NW = 8 / 16 (round 3): 512- / 1024-thread blocks, one tile of 64 columns per block, for 256 < dim <= 512 / 1024 — stacks of layers
-// at those heights ran on the group kernel, where every layer costs a 64-lane reduction and a tanh / log1p on all 64 lanes of a
-// column (8 layers: 18 % of the HBM peak at 500 rows, 28 % at 1000).
 template <int NL, bool INV, int NW = 2, bool UNAL = false>
 __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 1, 8))) void planar_reg2_kernel(const PlanarRegArgs A, const float* __restrict__ x, float* __restrict__ y,
                                                           float* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate, const BjxFin fin) {
@@ -1426,322 +1066,6 @@ __global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_wave
   const bool ok = lane < nvalid && half == 0;                // the two halves hold the same log-det: one of them reports it
   if (ok && ladj_ps) ladj_ps[col0 + lane] = (accumulate & 1) ? ladj_ps[col0 + lane] + ladj : ladj;
   block_publish_partial(ok ? (double)ladj : 0.0, red, fin);
-}
-
-#ifndef BJX_VJP_REG_WAVES
-#define BJX_VJP_REG_WAVES 2
-#endif
-template <int G, int NL, bool INV, bool UNAL = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BJX_VJP_REG_WAVES, 8))) void planar_vjp_reg_kernel(const PlanarRegArgs A, const float* __restrict__ x, const float* __restrict__ ybar,
-                                                             const float* __restrict__ lbar, float* __restrict__ xbar, int dim, int64_t batch,
-                                                             float* __restrict__ t_out, float* __restrict__ s_out, int nl) {
-  constexpr int COLS = 64;
-  constexpr int CPS = 64 / G;
-  constexpr int NS = (COLS * G) / 64;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* st = reinterpret_cast<float*>(smem) + (size_t)wave * COLS * NL;
-  float* tsave = reinterpret_cast<float*>(smem) + (size_t)4 * COLS * NL + (size_t)wave * COLS * A.nl_pad;   // [column][layer]
-  const int gl = lane & (G - 1);
-  const int cg = lane / G;
-  const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * COLS;
-  const RegGrid gr = reg_grid<UNAL>(col0 + cg, dim, 4 * gl);      // UNAL: see reg_load_pack
-  const bool row_ok = gr.ok;
-  const float* Aw = A.w + (UNAL ? A.lead - gr.phi : 0);
-  const float* Au = A.u_hat + (UNAL ? A.lead - gr.phi : 0);
-  const int64_t left = batch - col0;
-  const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
-  const int64_t step_elems = (int64_t)CPS * dim;
-  bjx_f4 z[NS];
-  auto load_tile = [&](const float* base) {
-    const float* px = base + (col0 + cg) * dim + gr.rel;
-    if constexpr (UNAL) {
-#pragma unroll
-      for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px);
-        else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
-        px += step_elems;
-      }
-      reg_mask_tile(z, gr.lo, gr.hi);
-    } else {
-#pragma unroll
-      for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) z[r] = __builtin_nontemporal_load(reinterpret_cast<const bjx_f4*>(px));
-        else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
-        px += step_elems;
-      }
-    }
-  };
-  const int ngroups = A.nl_pad / NL;
-  // ---- primal sweep: tanh(s_k) (forward map) / tanh(α_k + b_k) (inverse map) of every layer -> tsave
-  load_tile(x);
-  for (int gi = 0; gi < ngroups; ++gi) {
-    const int l0 = (INV ? ngroups - 1 - gi : gi) * NL;         // the inverse undoes the LAST group first
-    reg_dots<G, NL, NS>(Aw, l0, (UNAL ? A.ldw : dim), z, st, lane, gl, cg, row_ok);
-    __builtin_amdgcn_wave_barrier();
-    {
-      float s[NL], t[NL];
-#pragma unroll
-      for (int k = 0; k < NL; ++k) { s[k] = st[lane * NL + k]; t[k] = 0.f; }
-#pragma unroll
-      for (int kk = 0; kk < NL; ++kk) {
-        const int k = INV ? NL - 1 - kk : kk;
-        const float* Gk = A.G + (int64_t)(l0 + k) * A.nl_pad + l0;
-        float a = s[k];
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-          if (!INV) { if (j < k) a += Gk[j] * t[j]; }
-          else { if (j > k) a += Gk[j] * t[j]; }                 // t holds -tanh for the inverse
-        }
-        if (!INV) t[k] = fast_tanh(a + A.b[l0 + k]);
-        else { float th, ld; find_alpha_act(a, A.wtu_hat[l0 + k], A.b[l0 + k], th, ld); t[k] = -th; }
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int k = 0; k < NL; ++k) { st[lane * NL + k] = t[k]; tsave[lane * A.nl_pad + l0 + k] = INV ? -t[k] : t[k]; }
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (gi + 1 < ngroups) reg_update<G, NL, NS>(Au, l0, (UNAL ? A.ldw : dim), z, st, gl, cg, row_ok);
-    __builtin_amdgcn_wave_barrier();
-  }
-  // ---- cotangent sweep, in the opposite order of the primal
-  load_tile(ybar);
-  const float lb = (lbar && lane < nvalid) ? lbar[col0 + lane] : 0.f;
-  for (int gi = 0; gi < ngroups; ++gi) {
-    const int l0 = (INV ? gi : ngroups - 1 - gi) * NL;
-    reg_dots<G, NL, NS>(Au, l0, (UNAL ? A.ldw : dim), z, st, lane, gl, cg, row_ok);
-    __builtin_amdgcn_wave_barrier();
-    {
-      float g[NL], sb[NL];
-#pragma unroll
-      for (int k = 0; k < NL; ++k) { g[k] = st[lane * NL + k]; sb[k] = 0.f; }
-#pragma unroll
-      for (int kk = 0; kk < NL; ++kk) {
-        const int k = INV ? kk : NL - 1 - kk;
-        float tb = g[k];
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-          if (INV ? (j < k) : (j > k)) tb += A.G[(int64_t)(l0 + j) * A.nl_pad + l0 + k] * sb[j];   // û_kᵀ w_j
-        }
-        const float t = tsave[lane * A.nl_pad + l0 + k], c = A.wtu_hat[l0 + k];
-        const float q = 1.0f - t * t;
-        const float rden = Fast<float>::rcp(1.0f + c * q);
-        if (!INV) sb[k] = tb * q + lb * c * (-2.0f * t) * q * rden;
-        else sb[k] = q * rden * (-tb + lb * 2.0f * c * t * rden);        // find_alpha rule: dα/d(wᵀy) = 1/(1 + c q)
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int k = 0; k < NL; ++k) st[lane * NL + k] = sb[k];
-      if (s_out && lane < nvalid) {                        // s̄ and tanh of every layer, [n_layers, batch]: input of the parameter pullback
-#pragma unroll
-        for (int k = 0; k < NL; ++k)
-          if (l0 + k < nl) { s_out[(col0 + lane) * nl + l0 + k] = sb[k]; t_out[(col0 + lane) * nl + l0 + k] = tsave[lane * A.nl_pad + l0 + k]; }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    reg_update<G, NL, NS>(Aw, l0, (UNAL ? A.ldw : dim), z, st, gl, cg, row_ok);
-    __builtin_amdgcn_wave_barrier();
-  }
-  {
-    float* py = xbar + (col0 + cg) * dim + gr.rel;
-    if constexpr (UNAL) {
-#pragma unroll
-      for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], gr.lo, gr.hi, A.unal == 2);
-        py += step_elems;
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) __builtin_nontemporal_store(z[r], reinterpret_cast<bjx_f4*>(py));
-        py += step_elems;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------ Planar input pullback, NW waves per tile (64 < dim <= 1024, Float32)
-// planar_vjp_reg_kernel on the tile split of planar_reg2_kernel: the rows of a 64-column tile over NW waves (64 rows each, 16 lanes per
-// column, 64 VGPRs of tile), partial dot products exchanged through LDS with one block barrier per layer group, the lane = column
-// recurrence run redundantly by every wave of the tile on the summed values.  Until round 4 the pullback had the one-wave tile only
-// (dim <= 128: 128 VGPRs of tile, 31 % of the HBM peak at 101 rows) and the group kernel beyond (a 64-lane reduction and a tanh per
-// layer and column: 15 % at 201 rows).  The partial-sum buffers alternate by a group counter that runs through BOTH sweeps.
-// Dynamic LDS: sS [2][NWB][64 NL] | sT [NWB][64 NL] | tsave [tiles][64 nl_pad] (written by the first slice of a tile).
-template <int NL, bool INV, int NW, bool UNAL>
-__global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 1, 8))) void planar_vjp_reg2_kernel(const PlanarRegArgs A, const float* __restrict__ x, const float* __restrict__ ybar,
-                                                             const float* __restrict__ lbar, float* __restrict__ xbar, int dim, int64_t batch,
-                                                             float* __restrict__ t_out, float* __restrict__ s_out, int nl) {
-  constexpr int NWB = NW <= 4 ? 4 : NW;
-  constexpr int G = 16, COLS = 64, CPS = 4, NS = COLS / CPS, TILES = NWB / NW;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sS = reinterpret_cast<float*>(smem);                          // [2][NWB][COLS * NL]
-  float* sT = sS + (size_t)2 * NWB * COLS * NL;                        // [NWB][COLS * NL]
-  float* sV = sT + (size_t)NWB * COLS * NL;                            // [TILES][COLS * nl_pad]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = wave / NW, half = wave % NW;
-  const int gl = lane & (G - 1), cg = lane / G;
-  const int row0 = half * 64;
-  const int64_t col0 = ((int64_t)blockIdx.x * TILES + tile) * COLS;
-  const RegGrid gr = reg_grid<UNAL>(col0 + cg, dim, row0 + 4 * gl);      // UNAL: see reg_load_pack
-  const bool row_ok = gr.ok;
-  const float* Aw = A.w + (UNAL ? A.lead - gr.phi : 0);
-  const float* Au = A.u_hat + (UNAL ? A.lead - gr.phi : 0);
-  const int64_t left = batch - col0;
-  const int nvalid = left >= COLS ? COLS : (left > 0 ? (int)left : 0);
-  const int64_t step_elems = (int64_t)CPS * dim;
-  const int ldt = UNAL ? A.ldw : dim;
-  float* stT = sT + (size_t)wave * COLS * NL;
-  float* tsave = sV + (size_t)tile * COLS * A.nl_pad;
-  bjx_f4 z[NS];
-  auto load_tile = [&](const float* base) {
-    const float* px = base + (col0 + cg) * dim + gr.rel;
-    if constexpr (UNAL) {
-#pragma unroll
-      for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) z[r] = reg_load_pack(px);
-        else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
-        px += step_elems;
-      }
-      reg_mask_tile(z, gr.lo, gr.hi);
-    } else {
-#pragma unroll
-      for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) z[r] = __builtin_nontemporal_load(reinterpret_cast<const bjx_f4*>(px));
-        else z[r] = bjx_f4{0.f, 0.f, 0.f, 0.f};
-        px += step_elems;
-      }
-    }
-  };
-  // Σ over the tile's slices, in a fixed order: every wave of the tile gets the same bits
-  auto gather = [&](int par, float (&s)[NL]) {
-    const float* p0 = sS + ((size_t)par * NWB + tile * NW) * COLS * NL + lane * NL;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) s[k] = p0[k];
-#pragma unroll 4
-    for (int pp = 1; pp < NW; ++pp) {
-#pragma unroll
-      for (int k = 0; k < NL; ++k) s[k] += p0[(size_t)pp * COLS * NL + k];
-    }
-  };
-  const int ngroups = A.nl_pad / NL;
-  int gc = 0;                                                          // group counter through both sweeps: parity of the partial-sum buffer
-  // ---- primal sweep: tanh(s_k) (forward map) / tanh(α_k + b_k) (inverse map) of every layer -> tsave
-  load_tile(x);
-  for (int gi = 0; gi < ngroups; ++gi, ++gc) {
-    const int l0 = (INV ? ngroups - 1 - gi : gi) * NL;
-    reg_dots<G, NL, NS>(Aw, l0, ldt, z, sS + ((size_t)(gc & 1) * NWB + wave) * COLS * NL, lane, gl, cg, row_ok, row0);
-    __syncthreads();
-    {
-      float s[NL], t[NL];
-      gather(gc & 1, s);
-#pragma unroll
-      for (int k = 0; k < NL; ++k) t[k] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < NL; ++kk) {
-        const int k = INV ? NL - 1 - kk : kk;
-        const float* Gk = A.G + (int64_t)(l0 + k) * A.nl_pad + l0;
-        float a = s[k];
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-          if (!INV) { if (j < k) a += Gk[j] * t[j]; }
-          else { if (j > k) a += Gk[j] * t[j]; }                 // t holds -tanh for the inverse
-        }
-        if (!INV) t[k] = fast_tanh(a + A.b[l0 + k]);
-        else { float th, ld; find_alpha_act(a, A.wtu_hat[l0 + k], A.b[l0 + k], th, ld); t[k] = -th; }
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int k = 0; k < NL; ++k) stT[lane * NL + k] = t[k];
-      if (half == 0) {
-#pragma unroll
-        for (int k = 0; k < NL; ++k) tsave[lane * A.nl_pad + l0 + k] = INV ? -t[k] : t[k];
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (gi + 1 < ngroups) reg_update<G, NL, NS>(Au, l0, ldt, z, stT, gl, cg, row_ok, row0);
-    __builtin_amdgcn_wave_barrier();
-  }
-  // ---- cotangent sweep, in the opposite order of the primal (tsave of the first slice is visible after the first barrier below)
-  load_tile(ybar);
-  const float lb = (lbar && lane < nvalid) ? lbar[col0 + lane] : 0.f;
-  for (int gi = 0; gi < ngroups; ++gi, ++gc) {
-    const int l0 = (INV ? gi : ngroups - 1 - gi) * NL;
-    reg_dots<G, NL, NS>(Au, l0, ldt, z, sS + ((size_t)(gc & 1) * NWB + wave) * COLS * NL, lane, gl, cg, row_ok, row0);
-    __syncthreads();
-    {
-      float g[NL], sb[NL], tk[NL];
-      gather(gc & 1, g);
-#pragma unroll
-      for (int k = 0; k < NL; ++k) { sb[k] = 0.f; tk[k] = tsave[lane * A.nl_pad + l0 + k]; }
-#pragma unroll
-      for (int kk = 0; kk < NL; ++kk) {
-        const int k = INV ? kk : NL - 1 - kk;
-        float tb = g[k];
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-          if (INV ? (j < k) : (j > k)) tb += A.G[(int64_t)(l0 + j) * A.nl_pad + l0 + k] * sb[j];   // û_kᵀ w_j
-        }
-        const float t = tk[k], c = A.wtu_hat[l0 + k];
-        const float q = 1.0f - t * t;
-        const float rden = Fast<float>::rcp(1.0f + c * q);
-        if (!INV) sb[k] = tb * q + lb * c * (-2.0f * t) * q * rden;
-        else sb[k] = q * rden * (-tb + lb * 2.0f * c * t * rden);
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int k = 0; k < NL; ++k) stT[lane * NL + k] = sb[k];
-      if (s_out && half == 0 && lane < nvalid) {
-#pragma unroll
-        for (int k = 0; k < NL; ++k)
-          if (l0 + k < nl) { s_out[(col0 + lane) * nl + l0 + k] = sb[k]; t_out[(col0 + lane) * nl + l0 + k] = tk[k]; }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    reg_update<G, NL, NS>(Aw, l0, ldt, z, stT, gl, cg, row_ok, row0);
-    __builtin_amdgcn_wave_barrier();
-  }
-  {
-    float* py = xbar + (col0 + cg) * dim + gr.rel;
-    if constexpr (UNAL) {
-#pragma unroll
-      for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) reg_store_pack(py, z[r], gr.lo, gr.hi, A.unal == 2);
-        py += step_elems;
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < NS; ++r) {
-        if (row_ok && r * CPS + cg < nvalid) __builtin_nontemporal_store(z[r], reinterpret_cast<bjx_f4*>(py));
-        py += step_elems;
-      }
-    }
-  }
-}
-
-// zero-padded parameter tables for the register kernel: w, û -> [nl_pad][dim]; b, wᵀû -> [nl_pad];
-// G[k][j] = w_k . û_j -> [nl_pad][nl_pad].  grid = nl_pad * nl_pad blocks.
-template <class T>
-__global__ __launch_bounds__(256) void planar_prep_reg_kernel(const T* w, const T* u_hat, const T* wtu_hat, const T* b,
-                                                              int64_t dim, int nl, int nl_pad, T* wp, T* up, T* Gp,
-                                                              T* cp, T* bp, int64_t ldw = 0, int lead = 0) {
-  if (ldw == 0) ldw = dim;                                      // row pitch of wp / up: `lead` zeros, the dim values, zeros to the pitch
-  __shared__ double red[4];
-  const int k = blockIdx.x / nl_pad, j = blockIdx.x % nl_pad;
-  const bool live = k < nl && j < nl;
-  double dot = 0.0;
-  if (live) for (int64_t i = threadIdx.x; i < dim; i += blockDim.x) dot += (double)w[(int64_t)k * dim + i] * (double)u_hat[(int64_t)j * dim + i];
-  dot = group_sum<64>(dot);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
-  __syncthreads();
-  if (threadIdx.x == 0) Gp[k * nl_pad + j] = live ? (T)((red[0] + red[1]) + (red[2] + red[3])) : T(0);
-  if (j == 0) {
-    for (int64_t i = threadIdx.x; i < ldw; i += blockDim.x) {
-      const bool in = k < nl && i >= lead && i - lead < dim;
-      wp[(int64_t)k * ldw + i] = in ? w[(int64_t)k * dim + i - lead] : T(0);
-      up[(int64_t)k * ldw + i] = in ? u_hat[(int64_t)k * dim + i - lead] : T(0);
-    }
-    if (threadIdx.x == 0) { cp[k] = k < nl ? wtu_hat[k] : T(0); bp[k] = k < nl ? b[k] : T(0); }
-  }
 }
 
 template <class T> struct RadialArgs {
@@ -2348,6 +1672,10 @@ __global__ __launch_bounds__(64) void radial_vjp_walk_kernel(const T* __restrict
 }
 
 struct FlowCfg { int V, G, R; int64_t grid; };
+// packs per lane the lanes-per-column kernels are instantiated for (64 lanes x 8 packs: 2 048 rows Float32, 1 024 Float64).  Until
+// round 5 they went to 32 packs — 48 of the 63 unrolled packs of every kernel family, most of this file's compile time — for heights
+// the column-tile and block-per-column kernels now serve better.
+constexpr int FLOW_R_MAX = 8;
 
 // ------------------------------------------------------------------ Planar / Radial on columns of ANY height (round 5)
 // The register kernels stop at 64 lanes x 32 packs (8 192 rows Float32, 4 096 Float64) and bjx_planar / bjx_radial refused taller
@@ -2567,342 +1895,6 @@ __global__ __launch_bounds__(256) void planar_vjp_tall_kernel(const PlanarArgs<T
   }
 }
 
-// Between the register tiles (Float32 to 1 024 rows) and the kernel above: a BLOCK owns C columns at a time, thread t holds the packs
-// t, t + 256, ... (R of them) of each of the C columns in registers.  planar_vjp_kernel gives a column to 64 lanes: every wave loads the
-// w / û rows of every layer for ONE column (2·n_layers·dim per column through the L2: 4–5 TB/s of parameter traffic, 5 % of the HBM
-// roofline at 1 500 … 8 192 rows) and evaluates ONE tanh on 64 lanes; here a parameter pack is loaded once for C columns and the
-// C dot products of a layer are reduced together (one butterfly each, one barrier per layer: the LDS slots alternate by layer parity).
-// Packs on element-aligned addresses, the last one partial.  C·R = 16 (8 at R = 1): 64 data registers.  (Blocks of 512 / 1 024 threads that keep
-// R small and C large beyond 4 096 rows: no faster at 512 — 153–179 registers — and spilled at 1 024.)
-__device__ __forceinline__ float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-__device__ __forceinline__ double lane_bcast(double v, int l) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-template <int G> __device__ __forceinline__ float group_sum_fast(float v) { return group_sum_f32_dpp<G>(v); }
-template <int G> __device__ __forceinline__ double group_sum_fast(double v) { return group_sum<G>(v); }
-// C values per lane -> lane L holds the wave sum of value L / (64 / C): log2(C) halving exchanges (C/2 + C/4 + ... shuffles in all)
-// and one butterfly over the 64 / C lanes that are left, instead of C full butterflies (6·C shuffles).
-template <class T, int C, int G> __device__ __forceinline__ T wave_sum_scatter_rec(const T (&s)[C], int lane) {
-  if constexpr (C == 1) return group_sum_fast<G>(s[0]);
-  else {
-    constexpr int H = G / 2;
-    const bool hi = lane & H;
-    T a[C / 2];
-#pragma unroll
-    for (int i = 0; i < C / 2; ++i) a[i] = (hi ? s[C / 2 + i] : s[i]) + shfl_xor(hi ? s[i] : s[C / 2 + i], H);
-    return wave_sum_scatter_rec<T, C / 2, H>(a, lane);
-  }
-}
-template <class T, int C> __device__ __forceinline__ T wave_sum_scatter(const T (&s)[C], int lane) {
-  static_assert(C == 1 || C == 2 || C == 4 || C == 8 || C == 16, "C");
-  return wave_sum_scatter_rec<T, C, 64>(s, lane);
-}
-
-template <class T, int V, int R, int C, bool INV, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((R <= 4 && sizeof(T) == 4) ? 4 : 1, 8))) void planar_vjp_cols_kernel(const PlanarArgs<T> A, const T* __restrict__ x, const T* __restrict__ ybar, const T* __restrict__ lbar,
-                                                             T* __restrict__ xbar, int64_t dim, int64_t batch, T* __restrict__ t_out, T* __restrict__ s_out) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NWV = NT / 64;
-  constexpr bool PF = R <= 4;                          // request parameter rows ahead of the barrier (three row buffers: not at 8+ packs per thread)
-  T* red = reinterpret_cast<T*>(smem);                 // [2][NWV][C]
-  T* tsave = red + 2 * NWV * C;                        // [C][n_layers]
-  const int nl = A.n_layers;
-  const int64_t nvc = (dim + V - 1) / V;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int cme = lane & (C - 1);                      // the column whose scalar recurrence this lane evaluates (every wave redundantly, once)
-  int nrow[R];
-  int64_t off[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int64_t v = threadIdx.x + (int64_t)r * NT;
-    off[r] = v * V;
-    nrow[r] = v < nvc ? (int)(dim - v * V < V ? dim - v * V : V) : 0;
-  }
-  int par = 0;
-  // block sums of C values: lane L of every wave gets the sum of value L & (C - 1)
-  auto reduce = [&](const T (&s)[C]) -> T {
-    const T v = wave_sum_scatter<T, C>(s, lane);
-    T* rp = red + par * NWV * C;
-    if ((lane & (64 / C - 1)) == 0) rp[wv * C + lane / (64 / C)] = v;
-    __syncthreads();
-    T a = T(0);
-#pragma unroll
-    for (int q = 0; q < NWV; ++q) a += rp[q * C + cme];
-    par ^= 1;
-    return a;
-  };
-  auto load_row = [&](const T* row, Pack<T, V> (&p)[R]) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (nrow[r] > 0) p[r] = load_pack_part<T, V>(row + off[r], nrow[r]);
-      else {
-#pragma unroll
-        for (int j = 0; j < V; ++j) p[r].v[j] = T(0);
-      }
-    }
-  };
-  auto load_par = [&](const T* row, Pack<T, V> (&p)[R]) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (nrow[r] > 0) p[r] = load_pack_part_cached<T, V>(row + off[r], nrow[r]);
-      else {
-#pragma unroll
-        for (int j = 0; j < V; ++j) p[r].v[j] = T(0);
-      }
-    }
-  };
-  const int64_t tiles = (batch + C - 1) / C;
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int64_t col0 = tile * C;
-    Pack<T, V> z[C][R];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int64_t col = col0 + c < batch ? col0 + c : batch - 1;
-      load_row(x + col * dim, z[c]);
-    }
-    const bool me_ok = col0 + cme < batch;
-    const T lbme = (lbar && me_ok) ? lbar[col0 + cme] : T(0);
-    // ---- primal sweep: t_l of every layer and column.  The parameter rows do not depend on the data: with PF the row a step needs
-    //      AFTER its reduction (û_l) and the next step's w are requested before the barrier
-    Pack<T, V> pw[R], pu[R], pnx[R];
-    if (PF) load_par(A.w + (int64_t)(INV ? nl - 1 : 0) * dim, pw);
-    for (int li = 0; li < nl; ++li) {
-      const int l = INV ? nl - 1 - li : li;
-      const bool more = li + 1 < nl;
-      if constexpr (PF) { if (more) load_par(A.u_hat + (int64_t)l * dim, pu); }
-      else load_par(A.w + (int64_t)l * dim, pw);
-      T s[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        s[c] = T(0);
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-          for (int j = 0; j < V; ++j) s[c] += pw[r].v[j] * z[c][r].v[j];
-      }
-      if constexpr (PF) { if (more) load_par(A.w + (int64_t)(INV ? l - 1 : l + 1) * dim, pnx); }
-      const T sme = reduce(s);
-      T tme;
-      if (!INV) tme = x_tanh(sme + A.b[l]);
-      else tme = x_tanh(find_alpha_dev<T>(sme, A.wtu_hat[l], A.b[l]) + A.b[l]);
-      if (threadIdx.x < C) tsave[threadIdx.x * nl + l] = tme;
-      if (more) {
-        if constexpr (!PF) load_par(A.u_hat + (int64_t)l * dim, pu);
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const T tc = lane_bcast(tme, c);
-          const T a = INV ? -tc : tc;
-#pragma unroll
-          for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int j = 0; j < V; ++j) z[c][r].v[j] += pu[r].v[j] * a;
-        }
-        if constexpr (PF) {
-#pragma unroll
-          for (int r = 0; r < R; ++r) pw[r] = pnx[r];
-        }
-      }
-    }
-    __syncthreads();                                   // tsave complete
-    // ---- reverse sweep on the cotangent
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int64_t col = col0 + c < batch ? col0 + c : batch - 1;
-      load_row(ybar + col * dim, z[c]);
-    }
-    if (PF) load_par(A.u_hat + (int64_t)(INV ? 0 : nl - 1) * dim, pu);
-    for (int li = 0; li < nl; ++li) {
-      const int l = INV ? li : nl - 1 - li;
-      const bool more = li + 1 < nl;
-      if constexpr (PF) load_par(A.w + (int64_t)l * dim, pw);            // for the update after the reduction
-      else load_par(A.u_hat + (int64_t)l * dim, pu);
-      T d[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        d[c] = T(0);
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-          for (int j = 0; j < V; ++j) d[c] += pu[r].v[j] * z[c][r].v[j];
-      }
-      if constexpr (PF) { if (more) load_par(A.u_hat + (int64_t)(INV ? l + 1 : l - 1) * dim, pnx); }
-      const T dme = reduce(d);
-      const T cw = A.wtu_hat[l];
-      const T t = tsave[cme * nl + l];
-      const T q = T(1) - t * t;
-      T sbme;
-      if (!INV) {
-        sbme = dme * q + lbme * cw * (T(-2) * t) * q / (T(1) + cw * q);
-        if (s_out && threadIdx.x < C && me_ok) { s_out[(col0 + cme) * nl + l] = sbme; t_out[(col0 + cme) * nl + l] = t; }
-      } else {
-        const T den = T(1) + cw * q;
-        sbme = q / den * (-dme + lbme * T(2) * cw * t / den);
-      }
-      if constexpr (!PF) load_par(A.w + (int64_t)l * dim, pw);
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const T sb = lane_bcast(sbme, c);
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-          for (int j = 0; j < V; ++j) z[c][r].v[j] += pw[r].v[j] * sb;
-      }
-      if constexpr (PF) {
-        if (more) {
-#pragma unroll
-          for (int r = 0; r < R; ++r) pu[r] = pnx[r];
-        }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      if (col0 + c < batch) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-          if (nrow[r] > 0) store_pack_part<T, V>(xbar + (col0 + c) * dim + off[r], z[c][r], nrow[r]);
-      }
-    }
-    __syncthreads();                                   // tsave is rewritten by the next tile
-  }
-}
-
-// The forward / inverse map on the same mapping (round 5): planar_kernel gives a column to 64 lanes — one tanh / log1p per wave and
-// layer, the w / û rows of every layer loaded per column: 7 % of the roofline beyond 1 024 rows Float32, 8–19 % in Float64 beyond 128.
-template <class T, int V, int R, int C, bool INV, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((R <= 4 && sizeof(T) == 4) ? 4 : 1, 8))) void planar_cols_kernel(const PlanarArgs<T> A, const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t dim,
-                                                         int64_t batch, int accumulate, double* __restrict__ partials) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NWV = NT / 64;
-  constexpr bool PF = R <= 4;
-  T* red = reinterpret_cast<T*>(smem);                 // [2][NWV][C]
-  double* redd = reinterpret_cast<double*>(red + 2 * NWV * C + (2 * NWV * C) % 2);
-  const int nl = A.n_layers;
-  const int64_t nvc = (dim + V - 1) / V;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int cme = lane & (C - 1);
-  int nrow[R];
-  int64_t off[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int64_t v = threadIdx.x + (int64_t)r * NT;
-    off[r] = v * V;
-    nrow[r] = v < nvc ? (int)(dim - v * V < V ? dim - v * V : V) : 0;
-  }
-  int par = 0;
-  auto reduce = [&](const T (&s)[C]) -> T {
-    const T v = wave_sum_scatter<T, C>(s, lane);
-    T* rp = red + par * NWV * C;
-    if ((lane & (64 / C - 1)) == 0) rp[wv * C + lane / (64 / C)] = v;
-    __syncthreads();
-    T a = T(0);
-#pragma unroll
-    for (int q = 0; q < NWV; ++q) a += rp[q * C + cme];
-    par ^= 1;
-    return a;
-  };
-  auto load_row = [&](const T* row, Pack<T, V> (&p)[R]) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (nrow[r] > 0) p[r] = load_pack_part<T, V>(row + off[r], nrow[r]);
-      else {
-#pragma unroll
-        for (int j = 0; j < V; ++j) p[r].v[j] = T(0);
-      }
-    }
-  };
-  auto load_par = [&](const T* row, Pack<T, V> (&p)[R]) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (nrow[r] > 0) p[r] = load_pack_part_cached<T, V>(row + off[r], nrow[r]);
-      else {
-#pragma unroll
-        for (int j = 0; j < V; ++j) p[r].v[j] = T(0);
-      }
-    }
-  };
-  double acc = 0.0;
-  const int64_t tiles = (batch + C - 1) / C;
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int64_t col0 = tile * C;
-    Pack<T, V> z[C][R];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int64_t col = col0 + c < batch ? col0 + c : batch - 1;
-      load_row(x + col * dim, z[c]);
-    }
-    const bool me_ok = col0 + cme < batch;
-    T ladj = T(0);
-    Pack<T, V> pw[R], pu[R], pnx[R];
-    if (PF) load_par(A.w + (int64_t)(INV ? nl - 1 : 0) * dim, pw);
-    for (int li = 0; li < nl; ++li) {
-      const int l = INV ? nl - 1 - li : li;
-      const bool more = li + 1 < nl;
-      if constexpr (PF) load_par(A.u_hat + (int64_t)l * dim, pu);
-      else load_par(A.w + (int64_t)l * dim, pw);
-      T s[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        s[c] = T(0);
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-          for (int j = 0; j < V; ++j) s[c] += pw[r].v[j] * z[c][r].v[j];
-      }
-      if constexpr (PF) { if (more) load_par(A.w + (int64_t)(INV ? l - 1 : l + 1) * dim, pnx); }
-      const T sme = reduce(s);
-      const T bl = A.b[l], cw = A.wtu_hat[l];
-      T t, s2;
-      if (!INV) x_tanh_sech2(sme + bl, t, s2);
-      else planar_inv_act<T>(sme, cw, bl, t, s2);
-      const T ld = Fast<T>::log1p(cw * s2);            // planar_layer.jl:107
-      ladj += INV ? -ld : ld;
-      const T tme = INV ? -t : t;
-      if constexpr (!PF) load_par(A.u_hat + (int64_t)l * dim, pu);
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const T a = lane_bcast(tme, c);
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-          for (int j = 0; j < V; ++j) z[c][r].v[j] += pu[r].v[j] * a;
-      }
-      if constexpr (PF) {
-        if (more) {
-#pragma unroll
-          for (int r = 0; r < R; ++r) pw[r] = pnx[r];
-        }
-      }
-    }
-    if (accumulate & 2) {                              // BJX_BASE_STDNORMAL: + log N(out; 0, I)
-      T q[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        q[c] = T(0);
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-          for (int j = 0; j < V; ++j) q[c] += z[c][r].v[j] * z[c][r].v[j];     // rows that do not exist hold zeros
-      }
-      ladj += T(-0.5) * reduce(q) - (T)dim * T(0.91893853320467274178);
-    }
-    if (y) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        if (col0 + c < batch) {
-#pragma unroll
-          for (int r = 0; r < R; ++r)
-            if (nrow[r] > 0) store_pack_part<T, V>(y + (col0 + c) * dim + off[r], z[c][r], nrow[r]);
-        }
-      }
-    }
-    if (threadIdx.x < C && me_ok) {
-      if (ladj_ps) ladj_ps[col0 + cme] = (accumulate & 1) ? ladj_ps[col0 + cme] + ladj : ladj;
-      acc += (double)ladj;
-    }
-  }
-  if (partials) block_publish_partial(acc, redd, partials);
-}
-
 //   Radial: two passes — (‖δ‖², δᵀȳ), then z̄ = ca ȳ + cd δ (coefficients as in radial_vjp_kernel above).
 template <class T, int V, bool INV>
 __global__ __launch_bounds__(256) void radial_vjp_tall_kernel(const RadialArgs<T> A, const T* x, const T* gbar, const T* lbar, T* xbar, int64_t dim,
@@ -2972,7 +1964,7 @@ template <class T> bool flow_cfg(const bjx_ctx* ctx, const void* x, const void* 
   int64_t need = (packs + G - 1) / G;
   int R = 1;
   while (R < need) R <<= 1;
-  if (R > 32) return false;
+  if (R > FLOW_R_MAX) return false;             // beyond: the column-tile kernels (bjx_flow_cols.hip) and the block-per-column ones
   c->G = G;
   c->R = R;
   (void)ctx;
@@ -2985,9 +1977,7 @@ template <class T> bool flow_cfg(const bjx_ctx* ctx, const void* x, const void* 
     case 1: hipLaunchKernelGGL((KERNEL<TT, VV, 1, INVV>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
     case 2: hipLaunchKernelGGL((KERNEL<TT, VV, 2, INVV>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
     case 4: hipLaunchKernelGGL((KERNEL<TT, VV, 4, INVV>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
-    case 8: hipLaunchKernelGGL((KERNEL<TT, VV, 8, INVV>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
-    case 16: hipLaunchKernelGGL((KERNEL<TT, VV, 16, INVV>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break; \
-    default: hipLaunchKernelGGL((KERNEL<TT, VV, 32, INVV>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL((KERNEL<TT, VV, 8, INVV>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, __VA_ARGS__); break;  \
   }
 
 template <class T>
@@ -3225,48 +2215,7 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
       }
     }
   }
-  auto try_cols = [&]() -> int {
-    // a block per C columns, the columns in registers (planar_cols_kernel): beyond the Float32 register tiles, and Float64
-    constexpr int VWc = Vec16<T>::N;
-    static const int cols_min_f32 = getenv("BJX_PLANAR_COLS_MIN_F32") ? atoi(getenv("BJX_PLANAR_COLS_MIN_F32")) : 1025;
-    static const int cols_min_f64 = getenv("BJX_PLANAR_COLS_MIN_F64") ? atoi(getenv("BJX_PLANAR_COLS_MIN_F64")) : 33;
-    const int64_t cols_min = std::is_same<T, float>::value ? cols_min_f32 : cols_min_f64;
-    const int64_t packs_c = (dim + VWc - 1) / VWc;
-    if (cols_min > 0 && dim >= cols_min && dim >= 2 * VWc && packs_c <= 256 * 32 && batch < ((int64_t)1 << 40)) {
-      int NTc = 256, Rc = 32;
-      for (int r = 32; r >= 1; r >>= 1)
-        for (int nt = 256; nt >= (r == 1 ? 64 : (r <= 4 ? 192 : 256)); nt -= 64)
-          if ((int64_t)nt * r >= packs_c && nt * r <= NTc * Rc) { NTc = nt; Rc = r; }
-      constexpr bool is_f64 = std::is_same<T, double>::value;
-      const int Cc = Rc == 1 ? (is_f64 ? 16 : 8) : (Rc >= 16 ? 1 : 16 / Rc);        // (Float64: the scalar recurrence of a layer, evaluated once per wave, costs as much as the products of 8 columns)
-      const int64_t tiles = (batch + Cc - 1) / Cc;
-      const int64_t capc = (int64_t)ctx->num_cu * (2048 / NTc);
-      const int gridc = (int)(tiles < capc ? tiles : capc);
-      if (ladj_sum) { int rc = bjx_ensure_partials(ctx, (size_t)gridc); if (rc) return rc; }
-      double* partials_c = ladj_sum ? ctx->partials : nullptr;
-      PlanarArgs<T> Ac{w, u_hat, wtu, b, nl, 0};
-      const int accum_c = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
-      const size_t smem_c = ((size_t)2 * (NTc / 64) * Cc + 2) * sizeof(T) + 8 * sizeof(double);
-      {
-        BjxProf prof_(ctx);
-#define PFC(R_, C_, NT_) do { if (inverse) hipLaunchKernelGGL((planar_cols_kernel<T, VWc, R_, C_, true, NT_>), dim3(gridc), dim3(NT_), smem_c, ctx->stream, Ac, in, out, ladj_ps, dim, batch, accum_c, partials_c); \
-                              else hipLaunchKernelGGL((planar_cols_kernel<T, VWc, R_, C_, false, NT_>), dim3(gridc), dim3(NT_), smem_c, ctx->stream, Ac, in, out, ladj_ps, dim, batch, accum_c, partials_c); } while (0)
-      if constexpr (is_f64) {
-        if (Rc == 1) { switch (NTc) { case 64: PFC(1, 16, 64); break; case 128: PFC(1, 16, 128); break; case 192: PFC(1, 16, 192); break; default: PFC(1, 16, 256); break; } }
-      }
-      if (is_f64 && Rc == 1) {}
-      else if (NTc == 64) PFC(1, 8, 64);
-      else if (NTc == 128) PFC(1, 8, 128);
-      else if (NTc == 192) { switch (Rc) { case 1: PFC(1, 8, 192); break; case 2: PFC(2, 8, 192); break; default: PFC(4, 4, 192); break; } }
-        else switch (Rc) { case 1: PFC(1, 8, 256); break; case 2: PFC(2, 8, 256); break; case 4: PFC(4, 4, 256); break; case 8: PFC(8, 2, 256); break; case 16: PFC(16, 1, 256); break; default: PFC(32, 1, 256); break; }
-#undef PFC
-      }
-      BJX_CHECK_LAUNCH(ctx);
-      if (ladj_sum) return bjx_launch_finalize(ctx, gridc, ladj_sum, 0.0, 0, 0.0, flags);
-      return BJX_OK;
-    }
-    return 1;                                          // 1 = not served
-  };
+  auto try_cols = [&]() -> int { return bjx::planar_cols_launch<T>(ctx, inverse, w, u_hat, wtu, b, nl, in, out, ladj_ps, ladj_sum, dim, batch, flags); };   // 1 = not served (bjx_flow_cols.hip)
   // Float64 beyond 64 rows: the column-tile kernel before the LDS tile kernel (100 rows: 20 % on the tile kernel)
   static const int tile_max_f64 = getenv("BJX_PLANAR_TILE_MAX_F64") ? atoi(getenv("BJX_PLANAR_TILE_MAX_F64")) : 64;
   if (sizeof(T) == 8 && dim > tile_max_f64) { const int rc_cols = try_cols(); if (rc_cols != 1) return rc_cols; }
@@ -3352,73 +2301,7 @@ template <class T>
 int planar_vjp_reg(bjx_ctx*, int, const T*, const T*, const T*, const T*, int, const T*, const T*, const T*, T*, int64_t, int64_t, T*, T*) { return 1; }
 inline int planar_vjp_reg(bjx_ctx* ctx, int inverse, const float* w, const float* u_hat, const float* wtu, const float* b, int nl, const float* in,
                           const float* out_bar, const float* ladj_bar, float* in_bar, int64_t dim, int64_t batch, float* t_out, float* s_out) {
-  static const int use_reg = getenv("BJX_PLANAR_REG") ? atoi(getenv("BJX_PLANAR_REG")) : 1;
-  static const int use_unal = getenv("BJX_PLANAR_REG_UNALIGNED") ? atoi(getenv("BJX_PLANAR_REG_UNALIGNED")) : 1;
-  static const int unal_nt = 0;
-  const bool packs_ok = dim % 4 == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
-  const bool grid_ok = use_unal && dim > 32 && dim % 4 != 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);   // reg_load_pack
-  const int64_t de = packs_ok ? dim : dim + 3;
-  // the tile split over NW waves (planar_vjp_reg2_kernel): 2 for 64 < dim <= 128, 4 to 256, 8 to 512, 16 to 1024.  (Same call, 2^22
-  // columns, 8 layers, two waves against the one-wave tile: 72 rows 45.5 / 43.4 %, 101 rows 37.9 / 31.5 %, 128 rows 73.0 / 67.7 %.)
-  constexpr int split_env = 1;
-  const bool big = de > 256 && de <= 1024 && nl >= 2;
-  if (!(use_reg && (packs_ok || grid_ok) && dim > 16 && (de <= 256 || big))) return 1;
-  const int NW = de > 512 ? 16 : (de > 256 ? 8 : (de > 128 ? 4 : ((de > 64 && split_env) ? 2 : 1)));
-  const int NL = (nl >= 8 && !big) ? 8 : (nl > 2 ? 4 : nl);
-  const int nl_pad = (nl + NL - 1) / NL * NL;
-  const int lead = packs_ok ? 0 : 4;
-  const int64_t ldw = (dim + 3) / 4 * 4 + 2 * lead;
-  const size_t off0 = ((size_t)nl * dim + nl + 3) / 4 * 4;
-  const size_t need_reg = (off0 + (size_t)2 * nl_pad * ldw + (size_t)nl_pad * nl_pad + 2 * (size_t)nl_pad) * sizeof(float);
-  const int NWB = NW <= 4 ? 4 : NW;
-  const size_t smem = NW == 1 ? (size_t)4 * 64 * (NL + nl_pad) * sizeof(float)
-                              : ((size_t)3 * NWB * 64 * NL + (size_t)(NWB / NW) * 64 * nl_pad) * sizeof(float);
-  if (need_reg > BJX_SCRATCH_BYTES || smem > 64 * 1024) return 1;
-  float* base = reinterpret_cast<float*>(ctx->scratch);
-  float* wp = base + off0;
-  float* up = wp + (size_t)nl_pad * ldw;
-  float* Gp = up + (size_t)nl_pad * ldw;
-  float* cp = Gp + (size_t)nl_pad * nl_pad;
-  float* bp = cp + nl_pad;
-  hipLaunchKernelGGL(planar_prep_reg_kernel<float>, dim3(nl_pad * nl_pad), dim3(256), 0, ctx->stream, w, u_hat, wtu, b, dim, nl, nl_pad, wp, up, Gp, cp, bp, ldw, lead);
-  BJX_CHECK_LAUNCH(ctx);
-  const int G = de > 64 ? 32 : (de > 32 ? 16 : 8);
-  const int64_t grid = (batch + 4 * 64 - 1) / (4 * 64);
-  BJX_REQUIRE(ctx, grid < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: batch too large for one launch");
-  PlanarRegArgs RA{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : (unal_nt ? 2 : 1), lead};
-  if (NW > 1) {
-    const int64_t grid2 = (batch + (int64_t)(NWB / NW) * 64 - 1) / ((int64_t)(NWB / NW) * 64);
-    BJX_REQUIRE(ctx, grid2 < (int64_t)1 << 31, BJX_ERR_UNSUPPORTED, "bjx_planar_vjp: batch too large for one launch");
-#define LV2(NL_, I_, NW_, U_) hipLaunchKernelGGL((planar_vjp_reg2_kernel<NL_, I_, NW_, U_>), dim3((unsigned)grid2), dim3(NW_ <= 4 ? 256 : NW_ * 64), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl)
-#define LV2_U(NL_, I_, NW_) do { if (packs_ok) LV2(NL_, I_, NW_, false); else LV2(NL_, I_, NW_, true); } while (0)
-#define LV2_I(NL_, NW_) do { if (inverse) LV2_U(NL_, true, NW_); else LV2_U(NL_, false, NW_); } while (0)
-#define LV2_SMALL(NW_) switch (NL) { case 1: LV2_I(1, NW_); break; case 2: LV2_I(2, NW_); break; case 4: LV2_I(4, NW_); break; default: LV2_I(8, NW_); break; }
-#define LV2_BIG(NW_) do { if (NL == 4) LV2_I(4, NW_); else LV2_I(2, NW_); } while (0)
-    {
-      BjxProf prof_(ctx);
-      if (NW == 2) { LV2_SMALL(2) } else if (NW == 4) { LV2_SMALL(4) } else if (NW == 8) LV2_BIG(8); else LV2_BIG(16);
-    }
-#undef LV2_BIG
-#undef LV2_SMALL
-#undef LV2_I
-#undef LV2_U
-#undef LV2
-    BJX_CHECK_LAUNCH(ctx);
-    return BJX_OK;
-  }
-#define LVU(G_, NL_, U_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, true, (G_ == 16) && U_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); \
-                          else hipLaunchKernelGGL((planar_vjp_reg_kernel<G_, NL_, false, (G_ == 16) && U_>), dim3((unsigned)grid), dim3(256), smem, ctx->stream, RA, in, out_bar, ladj_bar, in_bar, (int)dim, batch, t_out, s_out, nl); } while (0)
-#define LV(G_, NL_) do { if (packs_ok) LVU(G_, NL_, false); else LVU(G_, NL_, true); } while (0)
-#define LV_NL(G_) switch (NL) { case 1: LV(G_, 1); break; case 2: LV(G_, 2); break; case 4: LV(G_, 4); break; default: LV(G_, 8); break; }
-  {
-    BjxProf prof_(ctx);
-    switch (G) { case 8: LV_NL(8) break; case 16: LV_NL(16) break; default: LV_NL(32) break; }
-  }
-#undef LV_NL
-#undef LV
-#undef LVU
-  BJX_CHECK_LAUNCH(ctx);
-  return BJX_OK;
+  return bjx::planar_vjp_reg_launch(ctx, inverse, w, u_hat, wtu, b, nl, in, out_bar, ladj_bar, in_bar, dim, batch, t_out, s_out);   // bjx_flow_vjp_reg.hip
 }
 
 template <class T>
@@ -3511,40 +2394,9 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
     if (rc != 1) return rc;                               // 1 = shape not served by the register kernel
   }
   {
-    // a block per C columns, the columns in registers (planar_vjp_cols_kernel): beyond the Float32 register tiles, and Float64
-    constexpr int VWc = Vec16<T>::N;
-    static const int cols_min_f32 = getenv("BJX_PLANAR_VJP_COLS_MIN_F32") ? atoi(getenv("BJX_PLANAR_VJP_COLS_MIN_F32")) : 1025;
-    static const int cols_min_f64 = getenv("BJX_PLANAR_VJP_COLS_MIN_F64") ? atoi(getenv("BJX_PLANAR_VJP_COLS_MIN_F64")) : 33;
-    const int64_t cols_min = std::is_same<T, float>::value ? cols_min_f32 : cols_min_f64;
-    const int64_t packs_c = (dim + VWc - 1) / VWc;
-    if (cols_min > 0 && dim >= cols_min && dim >= 2 * VWc && packs_c <= 256 * 32 && (size_t)nl * 16 * sizeof(T) <= 32 * 1024 && batch < ((int64_t)1 << 40)) {
-      // threads per block x packs per thread: the smallest NT·R that covers the column (NT = 64 … 256 in waves, R a power of two)
-      int NTc = 256, Rc = 32;
-      for (int r = 32; r >= 1; r >>= 1)
-        for (int nt = 256; nt >= (r == 1 ? 64 : (r <= 4 ? 192 : 256)); nt -= 64)
-          if ((int64_t)nt * r >= packs_c && nt * r <= NTc * Rc) { NTc = nt; Rc = r; }
-      constexpr bool is_f64 = std::is_same<T, double>::value;
-      const int Cc = Rc == 1 ? (is_f64 ? 16 : 8) : (Rc >= 16 ? 1 : 16 / Rc);        // (Float64: the scalar recurrence of a layer, evaluated once per wave, costs as much as the products of 8 columns)
-      const int64_t tiles = (batch + Cc - 1) / Cc;
-      const int64_t capc = (int64_t)ctx->num_cu * (2048 / NTc);
-      const int gridc = (int)(tiles < capc ? tiles : capc);
-      PlanarArgs<T> Ac{w, u_hat, wtu, b, nl, 0};
-      const size_t smem_c = ((size_t)2 * (NTc / 64) * Cc + (size_t)Cc * nl) * sizeof(T);
-      BjxProf prof_(ctx);
-#define PVC(R_, C_, NT_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_cols_kernel<T, VWc, R_, C_, true, NT_>), dim3(gridc), dim3(NT_), smem_c, ctx->stream, Ac, in, out_bar, ladj_bar, in_bar, dim, batch, t_out, s_out); \
-                              else hipLaunchKernelGGL((planar_vjp_cols_kernel<T, VWc, R_, C_, false, NT_>), dim3(gridc), dim3(NT_), smem_c, ctx->stream, Ac, in, out_bar, ladj_bar, in_bar, dim, batch, t_out, s_out); } while (0)
-      if constexpr (is_f64) {
-        if (Rc == 1) { switch (NTc) { case 64: PVC(1, 16, 64); break; case 128: PVC(1, 16, 128); break; case 192: PVC(1, 16, 192); break; default: PVC(1, 16, 256); break; } }
-      }
-      if (is_f64 && Rc == 1) {}
-      else if (NTc == 64) PVC(1, 8, 64);
-      else if (NTc == 128) PVC(1, 8, 128);
-      else if (NTc == 192) { switch (Rc) { case 1: PVC(1, 8, 192); break; case 2: PVC(2, 8, 192); break; default: PVC(4, 4, 192); break; } }
-      else switch (Rc) { case 1: PVC(1, 8, 256); break; case 2: PVC(2, 8, 256); break; case 4: PVC(4, 4, 256); break; case 8: PVC(8, 2, 256); break; case 16: PVC(16, 1, 256); break; default: PVC(32, 1, 256); break; }
-#undef PVC
-      BJX_CHECK_LAUNCH(ctx);
-      return BJX_OK;
-    }
+    // a block per C columns, the columns in registers (planar_vjp_cols_kernel, bjx_flow_cols.hip): beyond the Float32 register tiles, and Float64
+    const int rc_cols = bjx::planar_vjp_cols_launch<T>(ctx, inverse, w, u_hat, wtu, b, nl, in, out_bar, ladj_bar, in_bar, dim, batch, t_out, s_out);
+    if (rc_cols != 1) return rc_cols;
   }
   FlowCfg c;
   // (odd heights / element-aligned bases take 16-byte packs with a partial last pack, like the forward group kernel: the 4-byte
@@ -3563,7 +2415,7 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
   BjxProf prof_(ctx);
 #define PVJ(V_, R_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_kernel<T, V_, R_, true>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, t_out, s_out); \
                          else hipLaunchKernelGGL((planar_vjp_kernel<T, V_, R_, false>), dim3((unsigned)c.grid), dim3(256), smem, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, t_out, s_out); } while (0)
-#define PVJ_R(V_) switch (c.R) { case 1: PVJ(V_, 1); break; case 2: PVJ(V_, 2); break; case 4: PVJ(V_, 4); break; case 8: PVJ(V_, 8); break; case 16: PVJ(V_, 16); break; default: PVJ(V_, 32); break; }
+#define PVJ_R(V_) switch (c.R) { case 1: PVJ(V_, 1); break; case 2: PVJ(V_, 2); break; case 4: PVJ(V_, 4); break; default: PVJ(V_, 8); break; }
   if (v_ok) { PVJ_R(VW) } else {
     // scalar packs: recompute the geometry for V = 1
     int G = 1;
@@ -3571,13 +2423,13 @@ int planar_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* 
     int64_t need_r = (dim + G - 1) / G;
     int R = 1;
     while (R < need_r) R <<= 1;
-    if (R > 32) return launch_tall();
+    if (R > FLOW_R_MAX) return launch_tall();
     c.G = G; c.R = R; c.grid = (batch + (256 / G) - 1) / (256 / G);
     const int cpb = 256 / G;
     const size_t smem1 = (size_t)cpb * nl * sizeof(T) + (lds ? tab_bytes : 0);
 #define PVJ1(R_) do { if (inverse) hipLaunchKernelGGL((planar_vjp_kernel<T, 1, R_, true>), dim3((unsigned)c.grid), dim3(256), smem1, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, t_out, s_out); \
                       else hipLaunchKernelGGL((planar_vjp_kernel<T, 1, R_, false>), dim3((unsigned)c.grid), dim3(256), smem1, ctx->stream, A, in, out_bar, ladj_bar, in_bar, dim, batch, c.G, t_out, s_out); } while (0)
-    switch (c.R) { case 1: PVJ1(1); break; case 2: PVJ1(2); break; case 4: PVJ1(4); break; case 8: PVJ1(8); break; case 16: PVJ1(16); break; default: PVJ1(32); break; }
+    switch (c.R) { case 1: PVJ1(1); break; case 2: PVJ1(2); break; case 4: PVJ1(4); break; default: PVJ1(8); break; }
 #undef PVJ1
   }
 #undef PVJ_R
@@ -4616,7 +3468,7 @@ int radial_vjp_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, c
     int64_t need_r = (dim + G - 1) / G;
     int R = 1;
     while (R < need_r) R <<= 1;
-    if (R > 32) return launch_tall();
+    if (R > FLOW_R_MAX) return launch_tall();
     c.V = 1; c.G = G; c.R = R;
   }
   {

@@ -156,6 +156,20 @@ int bjx_seq_tiny_vjp(bjx_ctx* ctx, bjx_dtype dt, int simplex, int inverse, const
 int bjx_tall_simplex_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K,
                          int64_t batch, bool* taken);
 
+// Planar on the column-tile mapping (bjx_flow_cols.hip), called from planar_impl / planar_vjp_impl (bjx_flow.hip) with the prepared
+// û / wᵀû tables; 1 = the shape is not theirs.
+namespace bjx {
+template <class T>
+int planar_cols_launch(bjx_ctx* ctx, int inverse, const T* w, const T* u_hat, const T* wtu, const T* b, int nl, const T* in, T* out, T* ladj_ps,
+                       double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
+template <class T>
+int planar_vjp_cols_launch(bjx_ctx* ctx, int inverse, const T* w, const T* u_hat, const T* wtu, const T* b, int nl, const T* in, const T* out_bar,
+                           const T* ladj_bar, T* in_bar, int64_t dim, int64_t batch, T* t_out, T* s_out);
+// the Float32 register-tile input pullback (bjx_flow_vjp_reg.hip); 1 = shape not served
+int planar_vjp_reg_launch(bjx_ctx* ctx, int inverse, const float* w, const float* u_hat, const float* wtu, const float* b, int nl, const float* in,
+                          const float* out_bar, const float* ladj_bar, float* in_bar, int64_t dim, int64_t batch, float* t_out, float* s_out);
+}  // namespace bjx
+
 // ------------------------------------------------------------------ device math
 // Same definitions as the reference's third-party scalar functions (LogExpFunctions), see
 // oracle/bjx_oracle.cpp for the citations; thresholds are identical to the CPU restatement.
