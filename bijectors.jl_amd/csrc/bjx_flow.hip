@@ -1848,7 +1848,7 @@ __global__ __launch_bounds__(256) void planar_vjp_tall_kernel(const PlanarArgs<T
       s = block_sum_256(s, red);
       T t;
       if (!INV) { t = x_tanh(s + A.b[l]); tt = t; }
-      else { t = x_tanh(find_alpha_dev<T>(s, A.wtu_hat[l], A.b[l]) + A.b[l]); tt = -t; }
+      else { T s2u; planar_inv_act<T>(s, A.wtu_hat[l], A.b[l], t, s2u); tt = -t; }
       if (threadIdx.x == 0) tsave[l] = t;
     }
     __syncthreads();

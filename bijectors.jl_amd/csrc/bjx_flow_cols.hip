@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((R <= 4 && s
       const T sme = reduce(s);
       T tme;
       if (!INV) tme = x_tanh(sme + A.b[l]);
-      else tme = x_tanh(find_alpha_dev<T>(sme, A.wtu_hat[l], A.b[l]) + A.b[l]);
+      else { T s2u; planar_inv_act<T>(sme, A.wtu_hat[l], A.b[l], tme, s2u); }      // Float64: Float32 pre-solve + two Newton steps (find_alpha_act64), not the safeguarded loop
       if (threadIdx.x < C) tsave[threadIdx.x * nl + l] = tme;
       if (more) {
         if constexpr (!PF) load_par(A.u_hat + (int64_t)l * dim, pu);
