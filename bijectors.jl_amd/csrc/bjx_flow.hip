@@ -199,8 +199,8 @@ __global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, 
   } else {
     // the inverse primal (planar_layer.jl:112-127): last layer first, t_l = tanh(α_l + b_l)
     for (int l = A.n_layers - 1; l >= 0; --l) {
-      const T a = find_alpha_dev<T>(dot(W + (int64_t)l * dim), A.wtu_hat[l], A.b[l]);
-      const T t = x_tanh(a + A.b[l]);
+      T t, s2u;
+      planar_inv_act<T>(dot(W + (int64_t)l * dim), A.wtu_hat[l], A.b[l], t, s2u);
       if (gl == 0) tmine[l] = t;
       axpy(UH + (int64_t)l * dim, -t);
     }
@@ -1481,8 +1481,9 @@ __global__ __launch_bounds__(64) void planar_vjp_walk_kernel(const T* __restrict
     } else {
       for (int l = n_layers - 1; l >= 0; --l) {
         const T* tl = tab + l * LW;
-        const T a = find_alpha_dev<T>(dot(tl), tl[2 * DMAX + 1], tl[2 * DMAX]);
-        const T t = walk_tanh(a + tl[2 * DMAX]);
+        T t;
+        if constexpr (sizeof(T) == 8) { T s2u; planar_inv_act<T>(dot(tl), tl[2 * DMAX + 1], tl[2 * DMAX], t, s2u); }      // find_alpha_act64, not the safeguarded Float64 loop
+        else { const T a = find_alpha_dev<T>(dot(tl), tl[2 * DMAX + 1], tl[2 * DMAX]); t = walk_tanh(a + tl[2 * DMAX]); }
         tm[l] = t;
         axpy(tl + DMAX, -t);
       }

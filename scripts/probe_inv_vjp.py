@@ -6,7 +6,7 @@ import torch, bijectors_amd as bj
 from _timing import kernel_and_region_ms
 for dt in (torch.float32, torch.float64):
     es = 4 if dt == torch.float32 else 8
-    for dim in (128, 200, 512, 1500):
+    for dim in (4, 8, 16, 32, 128, 200, 512, 1500):
         N = (1 << 29) // (dim * (es // 4)); nl = 8
         w = torch.randn(dim, nl, device="cuda", dtype=dt) / dim ** 0.5; u = torch.randn(dim, nl, device="cuda", dtype=dt) / dim ** 0.5
         b = torch.randn(nl, device="cuda", dtype=dt)
