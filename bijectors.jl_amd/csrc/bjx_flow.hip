@@ -1483,7 +1483,7 @@ __global__ __launch_bounds__(64) void planar_vjp_walk_kernel(const T* __restrict
         const T* tl = tab + l * LW;
         T t;
         if constexpr (sizeof(T) == 8) { T s2u; planar_inv_act<T>(dot(tl), tl[2 * DMAX + 1], tl[2 * DMAX], t, s2u); }      // find_alpha_act64, not the safeguarded Float64 loop
-        else { const T a = find_alpha_dev<T>(dot(tl), tl[2 * DMAX + 1], tl[2 * DMAX]); t = walk_tanh(a + tl[2 * DMAX]); }
+        else { T ldu; find_alpha_act(dot(tl), tl[2 * DMAX + 1], tl[2 * DMAX], t, ldu); }
         tm[l] = t;
         axpy(tl + DMAX, -t);
       }
