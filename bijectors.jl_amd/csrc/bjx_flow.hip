@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void planar_kernel(const PlanarArgs<T> A, cons
       s = group_sum_rt(s, G);                 // wᵀz   (src/utils.jl:2)
       const T bl = A.b[l], c = A.wtu_hat[l];
       T t, s2;
-      if (!INV) x_tanh_sech2(s + bl, t, s2);
+      if (!INV) flow_tanh_sech2(s + bl, t, s2);
       else planar_inv_act<T>(s, c, bl, t, s2);
       const T ld = Fast<T>::log1p(c * s2);      // planar_layer.jl:107
       ladj += INV ? -ld : ld;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void planar_vjp_kernel(const PlanarArgs<T> A, 
   T* tmine = tsave + (size_t)cl * A.n_layers;
   if (!INV) {
     for (int l = 0; l < A.n_layers; ++l) {
-      const T t = x_tanh(dot(W + (int64_t)l * dim) + A.b[l]);
+      const T t = flow_tanh(dot(W + (int64_t)l * dim) + A.b[l]);
       if (gl == 0) tmine[l] = t;
       axpy(UH + (int64_t)l * dim, t);
     }
@@ -312,7 +312,7 @@ __device__ __forceinline__ T planar_tile_group(const PlanarTileArgs<T>& A, T* ti
       const T bl = A.b[l0 + k], c = A.wtu_hat[l0 + k];
       T th, s2;
       if (INV) planar_inv_act<T>(a, c, bl, th, s2);
-      else x_tanh_sech2(a + bl, th, s2);
+      else flow_tanh_sech2(a + bl, th, s2);
       const T ld = Fast<T>::log1p(c * s2);                // planar_layer.jl:107
       ladj += INV ? -ld : ld;
       t[k] = th;
@@ -867,7 +867,7 @@ __global__ __launch_bounds__(256) void planar_mfma64_kernel(const double* __rest
         const double bl = bp[l0 + k], c = cp[l0 + k];
         double th, s2;
         if (INV) find_alpha_act64(a, c, bl, th, s2);
-        else x_tanh_sech2(a + bl, th, s2);
+        else flow_tanh_sech2(a + bl, th, s2);
         double ld = Fast<double>::log1p(c * s2);            // planar_layer.jl:107
         if (l0 + k >= n_layers) { th = 0.0; ld = 0.0; }     // padding layer (wave-uniform)
         ladj += INV ? -ld : ld;
@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(64) void planar_walk_kernel(const T* __restrict__ A
       } else {
         T s2;
         if (INV) planar_inv_act<T>(s, c, bl, t, s2);
-        else x_tanh_sech2(s + bl, t, s2);
+        else flow_tanh_sech2(s + bl, t, s2);
         ld = Fast<T>::log1p(c * s2);                                 // planar_layer.jl:107
       }
       ladj += INV ? -ld : ld;
@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(64) void planar_walk_kernel(const T* __restrict__ A
 }
 
 __device__ __forceinline__ float walk_tanh(float v) { return fast_tanh(v); }      // the register kernels' one-exp tanh (parity bar 1e-3)
-__device__ __forceinline__ double walk_tanh(double v) { return x_tanh(v); }
+__device__ __forceinline__ double walk_tanh(double v) { return flow_tanh(v); }
 // Pullback of the Planar stack on low-dimensional columns, one lane per column (the arithmetic of planar_vjp_kernel): x and ȳ
 // through two odd-pitch tiles, the primal sweep leaves t_k = tanh(·) of every layer in the lane's strip of LDS scratch, the reverse
 // sweep runs on the cotangent in registers.  t_out / s_out (the per-column, per-layer values the parameter pullback reads) as in
@@ -1734,7 +1734,7 @@ __global__ __launch_bounds__(256) void planar_tall_kernel(const PlanarArgs<T> A,
         s = block_sum_256(s, red);                     // wᵀz (src/utils.jl:2); the barriers also order this pass's stores before the next pass's loads
         const T bl = A.b[l], c = A.wtu_hat[l];
         T t, s2;
-        if (!INV) x_tanh_sech2(s + bl, t, s2);
+        if (!INV) flow_tanh_sech2(s + bl, t, s2);
         else planar_inv_act<T>(s, c, bl, t, s2);
         const T ld = Fast<T>::log1p(c * s2);           // planar_layer.jl:107
         ladj += INV ? -ld : ld;
@@ -1848,7 +1848,7 @@ __global__ __launch_bounds__(256) void planar_vjp_tall_kernel(const PlanarArgs<T
       }
       s = block_sum_256(s, red);
       T t;
-      if (!INV) { t = x_tanh(s + A.b[l]); tt = t; }
+      if (!INV) { t = flow_tanh(s + A.b[l]); tt = t; }
       else { T s2u; planar_inv_act<T>(s, A.wtu_hat[l], A.b[l], t, s2u); tt = -t; }
       if (threadIdx.x == 0) tsave[l] = t;
     }

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((R <= 4 && s
       if constexpr (PF) { if (more) load_par(A.w + (int64_t)(INV ? l - 1 : l + 1) * dim, pnx); }
       const T sme = reduce(s);
       T tme;
-      if (!INV) tme = x_tanh(sme + A.b[l]);
+      if (!INV) tme = flow_tanh(sme + A.b[l]);
       else { T s2u; planar_inv_act<T>(sme, A.wtu_hat[l], A.b[l], tme, s2u); }      // Float64: Float32 pre-solve + two Newton steps (find_alpha_act64), not the safeguarded loop
       if (threadIdx.x < C) tsave[threadIdx.x * nl + l] = tme;
       if (more) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((R <= 4 && s
       const T sme = reduce(s);
       const T bl = A.b[l], cw = A.wtu_hat[l];
       T t, s2;
-      if (!INV) x_tanh_sech2(sme + bl, t, s2);
+      if (!INV) flow_tanh_sech2(sme + bl, t, s2);
       else planar_inv_act<T>(sme, cw, bl, t, s2);
       const T ld = Fast<T>::log1p(cw * s2);            // planar_layer.jl:107
       ladj += INV ? -ld : ld;
