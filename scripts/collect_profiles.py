@@ -77,7 +77,7 @@ def main(tag):
     traffic["_tag"] = tag
     json.dump(traffic, open(traffic_path, "w"), indent=1)
     for extra in ("bench_default.json", "bench_default_detail.json", "rows.md", "rows_kernel_stats.csv", "f64_rows.md", "f64math_bench.txt", "planar_mfma_ab.txt", "small_sizes.md",
-                  "lib_sha16.txt", "lib_bytes.txt", "first_call.txt", "ordered_tall.md", "planar_heights.md", "host_overhead.txt", "c3_table_policy.txt"):
+                  "lib_sha16.txt", "lib_bytes.txt", "first_call.txt", "ordered_tall.md", "planar_heights.md", "small_dims.md", "host_overhead.txt", "c3_table_policy.txt"):
         pe = os.path.join(src, extra)
         if os.path.exists(pe) and os.path.getsize(pe) > 2:
             with open(pe) as fi, open(os.path.join(dst, f"{tag}_{extra}"), "w") as fo:

@@ -85,6 +85,9 @@ profile)
     BJX_BENCH_PREROLL_MS=20 timeout 400 python scripts/probe_planar_params.py 2>/dev/null | grep "^|";
     echo; echo "The same call with the five switches of the round off (\`BJX_PLANAR_COLS_MIN_F32/F64=0 BJX_PLANAR_VJP_COLS_MIN_F32/F64=0 BJX_PLANAR_PARAM_ROWS=0\`: the lanes-per-column kernels of rounds 1-4; what they refused — the input pullback beyond 8 192 / 4 096 rows, the parameter reduction beyond 1 024 / 512 — is served by the tall-column kernels of the same round):"; echo;
     BJX_PLANAR_COLS_MIN_F32=0 BJX_PLANAR_COLS_MIN_F64=0 BJX_PLANAR_VJP_COLS_MIN_F32=0 BJX_PLANAR_VJP_COLS_MIN_F64=0 BJX_PLANAR_PARAM_ROWS=0 BJX_BENCH_PREROLL_MS=20 timeout 600 python scripts/probe_planar_params.py 2>/dev/null | grep "^|"; } > $O/planar_heights.md
+  { echo "# r05 — low-dimensional columns (2 ... 50 rows), Float32 and Float64: stream-region time of one call, algorithmic array passes as a fraction of 8 TB/s (scripts/probe_small_dims.py; 2^27 elements per array)"; echo;
+    echo "(An 8-layer Planar stack on 2 ... 10 rows is bound by the VALU, not by HBM: 8 tanh / log1p — inverse: 8 root solves of ~80 instructions — per column of 8 ... 40 bytes.)"; echo;
+    BJX_BENCH_PREROLL_MS=10 timeout 600 python scripts/probe_small_dims.py 2>/dev/null | grep "^|"; } > $O/small_dims.md
   timeout 300 python scripts/probe_host_overhead.py --calls 2000 --top 8 2>/dev/null | grep -v amdgpu.ids > $O/host_overhead.txt
   bash scripts/ab_c3.sh 2>/dev/null > $O/c3_table_policy.txt
   for wl in $WLS; do
