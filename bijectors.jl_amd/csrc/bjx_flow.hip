@@ -2449,7 +2449,9 @@ int radial_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, const
   static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 32;
   static const int walk_all = getenv("BJX_RADIAL_WALK_ALL") ? atoi(getenv("BJX_RADIAL_WALK_ALL")) : 0;
   static const int use_direct = getenv("BJX_PLANAR_WALK_DIRECT") ? atoi(getenv("BJX_PLANAR_WALK_DIRECT")) : 1;
-  if (dim <= walk_max && dim <= 32 && (dim % Vec16<T>::N != 0 || walk_all)) {      // whole-pack columns stream at 71 % on the group kernel already
+  // (Float32 whole-pack columns stream at 56–73 % on the group kernel already; Float64 ones did not: 4 / 10 / 20 / 32 rows 38 / 27 / 26 / 41 %
+  //  against 54 / 66 / 64 / 68 % one lane per column — round 5)
+  if (dim <= walk_max && dim <= 32 && (dim % Vec16<T>::N != 0 || walk_all || sizeof(T) == 8)) {
     constexpr int VW = Vec16<T>::N;
     const bool direct = use_direct && dim <= 7;                      // short columns: no tile (DX = dim)
     const int P = direct ? 0 : (int)(dim | 1);
@@ -3420,7 +3422,7 @@ int radial_vjp_impl(bjx_ctx* ctx, int inverse, const T* alpha_, const T* beta, c
   if (batch == 0) return BJX_OK;
   {
     static const int walk_max = getenv("BJX_FLOW_WALK_MAX") ? atoi(getenv("BJX_FLOW_WALK_MAX")) : 32;
-    if (dim <= walk_max && dim <= 32 && dim % Vec16<T>::N != 0 && (const void*)in != (const void*)in_bar) {   // (zsum_out stays unset: the caller reduces ȳ - z̄ itself)
+    if (dim <= walk_max && dim <= 32 && (dim % Vec16<T>::N != 0 || (sizeof(T) == 8 && dim > 2)) && (const void*)in != (const void*)in_bar) {   // (zsum_out stays unset: the caller reduces ȳ - z̄ itself)
       constexpr int VWW = Vec16<T>::N;
       const int P = (int)(dim | 1);
       const size_t smem_w = (size_t)2 * 64 * P * sizeof(T);
