@@ -244,7 +244,10 @@ int bjx_scale_matrix(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* a, con
  * layer[n_layers-1] ∘ ... ∘ layer[0]) are fused into one pass over Z.
  * w,u: device T[dim*n_layers] (layer-major), b: device T[n_layers].
  * inverse=0: z' = z + û tanh(wᵀz+b), ladj[n] = Σ_layers log1p(wᵀû sech²(wᵀz+b)).
- * inverse=1: layers are undone last-to-first with find_alpha; ladj = -(forward ladj at the result). */
+ * inverse=1: layers are undone last-to-first with find_alpha; ladj = -(forward ladj at the result).
+ * Any column height and any alignment (like the reference, which has no limit): since round 5 this also holds for
+ * bjx_planar_vjp, bjx_planar_vjp_params, bjx_radial_vjp and bjx_radial_vjp_params (which used to return BJX_ERR_UNSUPPORTED
+ * beyond 8 192 / 4 096 rows, the parameter pullback beyond 1 024 / 512).  `out`, `in_bar` may alias `in` / `out_bar`. */
 int bjx_planar(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* w, const void* u,
                const void* b, int n_layers, const void* in, void* out,
                void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
