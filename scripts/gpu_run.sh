@@ -68,9 +68,9 @@ profile)
   python scripts/probe_first_call.py > $O/first_call.txt 2>&1
   cat $O/first_call.txt
   rm -f gpurun_out/matrix_vjp_errors.jsonl
+  echo "== default bench line (what the driver runs: first on a fresh box — after the 2.5 min of the test suite the same line reads C3 1-3 % lower, profiles/r05_bench_repeats.md)"; timeout 900 python bench.py > $O/bench_default.json 2>$O/bench_default.err; wc -c $O/bench_default.json; cp gpurun_out/bench_detail.json $O/bench_default_detail.json 2>/dev/null
   echo "== pytest -m gpu"; ( time timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 -p no:cacheprovider ) > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt
   cp gpurun_out/matrix_vjp_errors.jsonl $O/ 2>/dev/null
-  echo "== default bench line (what the driver runs)"; timeout 900 python bench.py > $O/bench_default.json 2>$O/bench_default.err; wc -c $O/bench_default.json; cp gpurun_out/bench_detail.json $O/bench_default_detail.json 2>/dev/null
   for wl in $WLS; do
     timeout 600 python bench.py --workload $wl --no-rows --steps 20 --warmup 5 2>$O/bench_$wl.err | tail -1 > $O/bench_$wl.json; echo "== bench $wl: $(cut -c1-120 $O/bench_$wl.json)"
   done
