@@ -23,7 +23,7 @@ BJX_MAX_OPS = 8
 (OP_EXP, OP_LOG, OP_SHIFT, OP_SCALE, OP_SCALE_INV, OP_LOGIT, OP_LOGIT_INV, OP_LEAKY_RELU,
  OP_TRUNCATED, OP_TRUNCATED_INV, OP_SIGNFLIP, OP_IDENTITY, OP_STDNORMAL_LOGPDF) = range(1, 14)
 
-ERR_ARG, ERR_SHAPE, ERR_UNSUPPORTED, ERR_NOCOMM = -1, -2, -3, -4
+ERR_ARG, ERR_SHAPE, ERR_UNSUPPORTED, ERR_NOCOMM, ERR_FINALIZE = -1, -2, -3, -4, -5
 
 
 class BjxOp(C.Structure):
@@ -57,6 +57,8 @@ _tail = [_vp, _vp, _i64, _i64, _u32]  # ladj_ps, ladj_sum, dim/K, batch, flags
 BJX_OPT_INKERNEL_FINALIZE = 1
 BJX_OPT_COLLECTIVE_TIMEOUT_MS = 2
 BJX_OPT_PARAM_EPOCH = 3
+BJX_OPT_DEBUG_FIN_DROP_BLOCK = 4      # fault injection, tests only
+BJX_OPT_DEBUG_FIN_POISON_SLOT = 5
 
 # name -> (restype, argtypes); mirrors include/bjx.h line by line
 SIGNATURES = {
@@ -67,6 +69,7 @@ SIGNATURES = {
     "bjx_version": (_i, []),
     "bjx_workspace_bytes": (C.c_size_t, [_vp]),
     "bjx_synchronize": (_i, [_vp]),
+    "bjx_check_state": (_i, [_vp]),
     "bjx_ordered_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_simplex_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_vec_cholesky_inv_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
@@ -159,6 +162,11 @@ class BjxError(RuntimeError):
     """hipError_t / ncclResult_t surfaced by the library (Julia: ErrorException)."""
 
 
+class BjxFinalizeError(BjxError):
+    """BJX_ERR_FINALIZE: the in-kernel finalize of an EARLIER launch timed out (its Σ logabsdetjac is NaN); the context has re-armed
+    and switched to the two-pass finalize — repeat the call."""
+
+
 def check(ctx, code: int, what: str):
     """Map ABI status codes onto the exception classes the reference raises."""
     if code == 0:
@@ -171,4 +179,6 @@ def check(ctx, code: int, what: str):
         raise ValueError(f"{what}: DimensionMismatch: {msg}")
     if code == ERR_UNSUPPORTED:
         raise NotImplementedError(f"{what}: {msg}")
+    if code == ERR_FINALIZE:
+        raise BjxFinalizeError(f"{what}: {msg}")
     raise BjxError(f"{what}: status {code}: {msg}")

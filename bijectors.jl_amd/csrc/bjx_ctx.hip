@@ -114,11 +114,71 @@ int bjx_launch_finalize(bjx_ctx* ctx, int n_partials, double* ladj_sum, double h
   return BJX_OK;
 }
 
+// ------------------------------------------------------------------ failure channel of the sentinel hand-off
+// Every slot back to the sentinel and the device error word to zero, IN STREAM ORDER (after whatever launch faulted, before the
+// next one); the host word is cleared here and now — it is only ever set by a kernel that precedes these memsets on the stream.
+static hipError_t bjx_fin_rearm(bjx_ctx* ctx) {
+  hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->sent_l1), (int)0xFFFFDEAD, (size_t)BJX_FIN_SENT_GROUPS * 64 * 2, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->sent_l2), (int)0xFFFFDEAD, (size_t)BJX_FIN_SENT_GROUPS * 2, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->fin_counter, 0, 64, ctx->stream);
+  if (ctx->fin_err_host) *ctx->fin_err_host = 0u;
+  return e;
+}
+
+// Called by every entry that asks for a sum (bjx_make_fin) and by bjx_synchronize / bjx_check_state: has a hand-off of an EARLIER
+// launch on this context timed out?  Reading pinned host memory costs nothing; the report is asynchronous like a hipError_t
+// (the faulted launch itself returned BJX_OK and wrote NaN; this call reports it, repairs the context and launches nothing).
+int bjx_fin_fault_check(bjx_ctx* ctx) {
+  if (!ctx->fin_err_host || !*ctx->fin_err_host) return BJX_OK;
+  ctx->fin_faults++;
+  ctx->opt_inkernel_fin = 0;            // after one fault the context finishes its sums with the two follow-up launches
+  if (ctx->capturing) return bjx_fail(ctx, BJX_ERR_FINALIZE, "the sentinel hand-off of an earlier launch timed out while a graph capture is open: end the capture, the context re-arms at the next call");
+  const hipError_t e = bjx_fin_rearm(ctx);
+  if (e != hipSuccess) return bjx_fail(ctx, (int)e, "re-arming the hand-off slots failed: %s", hipGetErrorString(e));
+  return bjx_fail(ctx, BJX_ERR_FINALIZE,
+                  "the in-kernel finalize (sentinel hand-off) of an earlier launch on this context timed out: a block waited %d poll rounds for a lower-indexed "
+                  "block of its own grid (dispatch-order assumption, include/bjx.h). The Σ logabsdetjac of that launch — and of every launch enqueued "
+                  "after it until now — is NaN. The slots were re-armed in stream order and the context now uses the two-pass finalize (fault %d).",
+                  bjx::BJX_FIN_SPIN_MAX, ctx->fin_faults);
+}
+
+// bjx_check_state: every slot must hold the sentinel between launches.  One small launch that reads them all (diagnostics / tests /
+// after a hipError_t of the caller's own: not on the hot path).
+__global__ __launch_bounds__(256) void bjx_fin_verify_kernel(const unsigned long long* __restrict__ l1, long n1, const unsigned long long* __restrict__ l2, long n2,
+                                                              const unsigned* __restrict__ counter, unsigned* err, unsigned* err_host) {
+  bool bad = false;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2; i += (long)gridDim.x * 256) {
+    const unsigned long long v = i < n1 ? l1[i] : l2[i - n1];
+    bad |= (v != bjx::BJX_FIN_SENT);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) bad |= (*counter != 0u);
+  if (bad) {
+    __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(err_host, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+BJX_API int bjx_check_state(bjx_ctx* ctx) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, !ctx->capturing, BJX_ERR_UNSUPPORTED, "bjx_check_state: a graph capture is open on this context");
+  hipLaunchKernelGGL(bjx_fin_verify_kernel, dim3(64), dim3(256), 0, ctx->stream, reinterpret_cast<const unsigned long long*>(ctx->sent_l1), (long)BJX_FIN_SENT_GROUPS * 64,
+                     reinterpret_cast<const unsigned long long*>(ctx->sent_l2), (long)BJX_FIN_SENT_GROUPS, ctx->fin_counter, ctx->fin_err, ctx->fin_err_host_dev);
+  BJX_CHECK_LAUNCH(ctx);
+  BJX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const unsigned code = *ctx->fin_err_host;
+  const int rc = bjx_fin_fault_check(ctx);
+  if (rc == BJX_ERR_FINALIZE && code == 2u)
+    return bjx_fail(ctx, BJX_ERR_FINALIZE, "bjx_check_state: a hand-off slot did not hold the sentinel between launches (a launch was aborted mid-flight, or the memory was written by "
+                    "someone else). The slots were re-armed in stream order and the context now uses the two-pass finalize (fault %d).", ctx->fin_faults);
+  return rc;
+}
+
 int bjx_make_fin(bjx_ctx* ctx, int64_t grid, double* ladj_sum, double host_const, int use_dev_const, uint32_t flags,
                  BjxFin* fin, bool* second_pass) {
   *fin = BjxFin{};
   *second_pass = false;
   if (!ladj_sum) return BJX_OK;
+  { const int rc_f = bjx_fin_fault_check(ctx); if (rc_f) return rc_f; }
   int rc = bjx_ensure_partials(ctx, (size_t)grid);
   if (rc) return rc;
   fin->partials = ctx->partials;
@@ -130,6 +190,9 @@ int bjx_make_fin(bjx_ctx* ctx, int64_t grid, double* ladj_sum, double host_const
     fin->host_const = host_const;
     fin->dev_const = use_dev_const ? ctx->consts + 1 : nullptr;
     fin->accumulate = (flags & BJX_ACCUMULATE) ? 1 : 0;
+    fin->err = ctx->fin_err;
+    fin->err_host = ctx->fin_err_host_dev;
+    fin->drop_block = ctx->dbg_fin_drop;
   } else if (ctx->opt_inkernel_fin == 1 && grid <= BJX_INKERNEL_FIN_MAX) {
     // The arrival counter is zero between launches: the block that draws the last ticket resets it (a launch that faults
     // leaves the HIP context in a sticky error state, so no later launch can see a stale count); nothing is enqueued here.
@@ -175,11 +238,24 @@ BJX_API int bjx_create(int device, void* hip_stream, bjx_ctx** out) {
   if (e == hipSuccess) e = hipMalloc(&ctx->partials2, sizeof(double) * BJX_MAX_BLOCKS);
   if (e == hipSuccess) e = hipMalloc(&ctx->consts, sizeof(double) * BJX_CONSTS);
   if (e == hipSuccess) e = hipMalloc(&ctx->fin_counter, 64);
-  if (e == hipSuccess) e = hipMemset(ctx->fin_counter, 0, 64);
+  if (e == hipSuccess) ctx->fin_err = ctx->fin_counter + 4;
   if (e == hipSuccess) e = hipMalloc(&ctx->sent_l1, sizeof(double) * BJX_FIN_SENT_GROUPS * 64);
   if (e == hipSuccess) e = hipMalloc(&ctx->sent_l2, sizeof(double) * BJX_FIN_SENT_GROUPS);
-  if (e == hipSuccess) e = hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(ctx->sent_l1), (int)0xFFFFDEAD, (size_t)BJX_FIN_SENT_GROUPS * 64 * 2);
-  if (e == hipSuccess) e = hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(ctx->sent_l2), (int)0xFFFFDEAD, (size_t)BJX_FIN_SENT_GROUPS * 2);
+  if (e == hipSuccess) {
+    void* hp = nullptr;
+    e = hipHostMalloc(&hp, 64, hipHostMallocMapped);
+    if (e == hipSuccess) {
+      ctx->fin_err_host = static_cast<volatile unsigned*>(hp);
+      *ctx->fin_err_host = 0u;
+      void* dp = nullptr;
+      e = hipHostGetDevicePointer(&dp, hp, 0);
+      ctx->fin_err_host_dev = static_cast<unsigned*>(dp);
+    }
+  }
+  // the slots get their sentinel ON THE CONTEXT'S STREAM (a null-stream memset is not ordered before the first launch on a
+  // non-blocking stream); bjx_set_stream keeps the order when the stream changes
+  if (e == hipSuccess) e = bjx_fin_rearm(ctx);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->stream_ev, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc(&ctx->scratch, BJX_SCRATCH_BYTES);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
@@ -205,6 +281,8 @@ BJX_API int bjx_destroy(bjx_ctx* ctx) {
   if (ctx->partials2) (void)hipFree(ctx->partials2);
   if (ctx->consts) (void)hipFree(ctx->consts);
   if (ctx->fin_counter) (void)hipFree(ctx->fin_counter);
+  if (ctx->fin_err_host) (void)hipHostFree(const_cast<unsigned*>(ctx->fin_err_host));
+  if (ctx->stream_ev) (void)hipEventDestroy(ctx->stream_ev);
   if (ctx->sent_l1) (void)hipFree(ctx->sent_l1);
   if (ctx->sent_l2) (void)hipFree(ctx->sent_l2);
   if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
@@ -225,7 +303,15 @@ BJX_API int bjx_destroy(bjx_ctx* ctx) {
 
 BJX_API int bjx_set_stream(bjx_ctx* ctx, void* hip_stream) {
   if (!ctx) return BJX_ERR_ARG;
-  ctx->stream = static_cast<hipStream_t>(hip_stream);
+  BJX_REQUIRE(ctx, !ctx->capturing, BJX_ERR_UNSUPPORTED, "bjx_set_stream: a graph capture is open on this context");
+  hipStream_t next = static_cast<hipStream_t>(hip_stream);
+  if (next != ctx->stream) {
+    // The context's scratch (partials, hand-off slots, parameter tables) is shared by everything it launches: work already enqueued
+    // on the old stream must be finished before a launch on the new one touches it.  An event, not a host wait.
+    BJX_HIP(ctx, hipEventRecord(ctx->stream_ev, ctx->stream));
+    BJX_HIP(ctx, hipStreamWaitEvent(next, ctx->stream_ev, 0));
+  }
+  ctx->stream = next;
   ctx->scale_slot.epoch = 0;          // cached parameter tables were built on the old stream: rebuild on first use
   for (auto& sl : ctx->rqs_slots) sl.epoch = 0;
   return BJX_OK;
@@ -250,6 +336,17 @@ BJX_API int bjx_set_option(bjx_ctx* ctx, int option, int value) {
     ctx->param_epoch = value;
     return BJX_OK;
   }
+  if (option == BJX_OPT_DEBUG_FIN_DROP_BLOCK) {
+    ctx->dbg_fin_drop = value;          // < 0: off
+    return BJX_OK;
+  }
+  if (option == BJX_OPT_DEBUG_FIN_POISON_SLOT) {
+    BJX_REQUIRE(ctx, value >= 0 && value < BJX_FIN_SENT_GROUPS * 64, BJX_ERR_ARG, "BJX_OPT_DEBUG_FIN_POISON_SLOT: slot index out of range");
+    const double one = 1.0;
+    BJX_HIP(ctx, hipMemcpyAsync(ctx->sent_l1 + value, &one, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    BJX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BJX_OK;
+  }
   if (option == BJX_OPT_COLLECTIVE_TIMEOUT_MS) {
     BJX_REQUIRE(ctx, value >= 0, BJX_ERR_ARG, "BJX_OPT_COLLECTIVE_TIMEOUT_MS: milliseconds >= 0 (0 = wait for ever)");
     ctx->collective_timeout_ms = value;
@@ -268,7 +365,7 @@ BJX_API int bjx_synchronize(bjx_ctx* ctx) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
       const hipError_t q = hipStreamQuery(ctx->stream);
-      if (q == hipSuccess) return BJX_OK;
+      if (q == hipSuccess) return bjx_fin_fault_check(ctx);
       if (q != hipErrorNotReady) return bjx_fail(ctx, (int)q, "bjx_synchronize: %s", hipGetErrorString(q));
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (ms > (double)ctx->collective_timeout_ms) {
@@ -284,7 +381,7 @@ BJX_API int bjx_synchronize(bjx_ctx* ctx) {
     }
   }
   BJX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return BJX_OK;
+  return bjx_fin_fault_check(ctx);
 }
 
 BJX_API int bjx_time_begin(bjx_ctx* ctx) {

@@ -292,9 +292,14 @@ template <class T> __device__ __forceinline__ Rec4<T> lds_rec(const char* p, int
 //   numerator of y   s ξ² + d_k ξ(1-ξ)                                     = ξ (d_k + (s - d_k) ξ)
 //   numerator of J   d_{k+1} ξ² + 2s ξ(1-ξ) + d_k (1-ξ)²                   = d_k + (d_{k+1} - d_k) ξ - ds·p
 // (the last is a convex interpolation minus a term of at most the same size: cancellation <= ~2x).
-// Returns log2|J| (the caller multiplies the per-column sum by ln 2 once).
+// Returns the FACTORS of |J| (round 6), not its logarithm: the log-det of a column is a sum over its rows, so the caller multiplies the
+// factors of the V elements of a pack and takes ONE hardware log per pack instead of one per element (a transcendental holds the
+// VALU for four issue slots: profiles/r05_pmc_notes.md counted 54 slots per inverse element, 16 of them four transcendentals).
+//   forward:  jn = nj·(s/den)²                      (1/den is needed for the value anyway), jd unused
+//   inverse:  jn = nj·s², jd = den                  log2|J⁻¹| of the pack = 2·log2(Π jd) − log2(Π jn): the reciprocal of den is gone too
+// Outside [-B, B]: jn = 1 + 0·x (1, or NaN for x = ±Inf like the reference's `zero(T) * x`, :272, :323), jd = 1.
 template <class T, bool INV>
-__device__ __forceinline__ T rqs_eval(const Rec4<T>& A, const Rec4<T>& B, T lim, T& x) {
+__device__ __forceinline__ void rqs_eval(const Rec4<T>& A, const Rec4<T>& B, T lim, T& x, T& jn, T& jd) {
   using F = Fast<T>;
   const T s = B.v[0], d_k = B.v[1], ds = B.v[2], dd = B.v[3];
   const T xin = x;
@@ -317,17 +322,40 @@ __device__ __forceinline__ T rqs_eval(const Rec4<T>& A, const Rec4<T>& B, T lim,
     const f2 r2 = __builtin_elementwise_fma(f2{ds, dd}, f2{p, xi}, f2{s, d_k});
     den = r2.x; tq = r2.y;
   } else { den = s + ds * p; tq = d_k + dd * xi; }
-  const T rden = F::rcp(den);
   const T nj = tq - ds * p;
-  const T sr = s * rden;
-  T lj = F::log2(nj * (sr * sr));                                           // log(s²·nj) - 2 log(den)
-  if (!INV) res = A.v[2] + (A.v[3] * (xi * (d_k + (s - d_k) * xi))) * rden;
-  else { res = xi * A.v[3] + A.v[2]; lj = -lj; }
+  T jn_in;
+  if (!INV) {
+    const T rden = F::rcp(den);
+    const T sr = s * rden;
+    jn_in = nj * (sr * sr);                                                 // s²·nj / den²
+    res = A.v[2] + (A.v[3] * (xi * (d_k + (s - d_k) * xi))) * rden;
+  } else {
+    jn_in = nj * (s * s);
+    res = xi * A.v[3] + A.v[2];
+  }
   // identity outside [-B, B] (:132, :186): (x <= -lim || x >= lim) == (|x| >= lim); a NaN is NOT outside (both
   // comparisons are false in the reference too) and leaves through the arithmetic as NaN value and NaN log-det
   const bool outside = d_abs(xin) >= lim;
   x = outside ? xin : res;
-  return outside ? T(0) * xin : lj;                                          // `zero(T) * x` (:272, :323): NaN for x = ±Inf, like the reference
+  jn = outside ? __builtin_fma(T(0), xin, T(1)) : jn_in;
+  if (INV) jd = outside ? T(1) : den;
+}
+
+// log2 of a product of Jacobian factors with the range of the SUM of the logs: the product of V factors can leave the Float32 range
+// (|J| of one element up to ~1e9 is fine, four of them 1e36 is not) or reach 0 / NaN / a negative value where a single factor would
+// decide; then the logs are taken one by one — the rare branch, so the common one pays one compare pair for three saved logs.
+template <class T> struct ProdRange;
+template <> struct ProdRange<float> { static constexpr float lo = 1e-30f, hi = 1e30f; };
+template <> struct ProdRange<double> { static constexpr double lo = 1e-280, hi = 1e280; };
+template <class T, int V> __device__ __forceinline__ T log2_of_product(const T (&f)[V]) {
+  T pr = f[0];
+#pragma unroll
+  for (int j = 1; j < V; ++j) pr *= f[j];
+  if (__builtin_expect(pr > ProdRange<T>::lo && pr < ProdRange<T>::hi, 1)) return Fast<T>::log2(pr);
+  T l = T(0);
+#pragma unroll
+  for (int j = 0; j < V; ++j) l += Fast<T>::log2(f[j]);
+  return l;
 }
 
 // pos = 2*pos + (key < x): one compare + one add-with-carry (the compiler's own lowering of this
@@ -421,10 +449,11 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
       A[j] = lds_rec<T>(rec, 0);
       B[j] = lds_rec<T>(rec, RqsRec<T>::RQ / 2);
     }
-    T l = T(0);
+    T jn[V], jd[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) l += rqs_eval<T, INV>(A[j], B[j], lim[j], p.v[j]);
-    return l;
+    for (int j = 0; j < V; ++j) rqs_eval<T, INV>(A[j], B[j], lim[j], p.v[j], jn[j], jd[j]);
+    if constexpr (!INV) return log2_of_product<T, V>(jn);
+    else return T(2) * log2_of_product<T, V>(jd) - log2_of_product<T, V>(jn);
   };
   const GroupMasks gm = make_group_masks(G);
   Pack<T, V> pn0, pn1;

@@ -31,6 +31,16 @@ struct bjx_ctx {
   void* host_stage = nullptr;      // pinned, BJX_HOST_STAGE_BYTES, created on first use
   hipEvent_t stage_ev = nullptr;   // recorded after the last copy out of host_stage
   unsigned* fin_counter = nullptr;  // arrival counter of the in-kernel finalize (zero between launches)
+  // Failure channel of the sentinel hand-off (round 6): word [4] of the fin_counter allocation is a sticky DEVICE error word (a poll
+  // that timed out sets it; the last block of every later launch reads it and writes NaN instead of a sum built on a slot the
+  // faulted launch may have left dirty); `fin_err_host` is the same fact in pinned, device-mapped host memory, which the host reads
+  // for free at the next entry and in bjx_synchronize -> BJX_ERR_FINALIZE, re-arm, two-pass from then on.
+  unsigned* fin_err = nullptr;            // = fin_counter + 4
+  volatile unsigned* fin_err_host = nullptr;   // hipHostMalloc(mapped), 64 bytes
+  unsigned* fin_err_host_dev = nullptr;   // the device's address of the same word
+  int fin_faults = 0;                     // hand-off faults seen by this context (after the first the context stays on the two-pass finalize)
+  int dbg_fin_drop = -1;                  // BJX_OPT_DEBUG_FIN_DROP_BLOCK: fault injection — this block index does not publish (tests)
+  hipEvent_t stream_ev = nullptr;         // bjx_set_stream: the new stream waits for the work in flight on the old one
   double* sent_l1 = nullptr;    // [BJX_FIN_SENT_GROUPS * 64] block partials of the sentinel hand-off (BJX_FIN_SENT between launches)
   double* sent_l2 = nullptr;    // [BJX_FIN_SENT_GROUPS] group sums of the sentinel hand-off (BJX_FIN_SENT between launches)
   double* consts = nullptr;     // [BJX_CONSTS]
@@ -126,10 +136,15 @@ struct BjxFin {
   double host_const = 0.0;
   const double* dev_const = nullptr;
   int accumulate = 0;
+  int drop_block = -1;              // fault injection (BJX_OPT_DEBUG_FIN_DROP_BLOCK): the block that does not publish
+  unsigned* err = nullptr;          // sentinel hand-off: sticky device error word (ctx->fin_err)
+  unsigned* err_host = nullptr;     // ... and its host-visible twin (ctx->fin_err_host_dev)
 };
 // host side: builds the descriptor for a launch of `grid` blocks; *second_pass = launch bjx_launch_finalize afterwards
 int bjx_make_fin(bjx_ctx* ctx, int64_t grid, double* ladj_sum, double host_const, int use_dev_const, uint32_t flags,
                  BjxFin* fin, bool* second_pass);
+// host side: BJX_ERR_FINALIZE (after re-arming the slots and switching the context to the two-pass finalize) when a hand-off of an earlier launch timed out
+int bjx_fin_fault_check(bjx_ctx* ctx);
 
 // host side: turn a descriptor built by bjx_make_fin back into the two-pass form (per-block partials + bjx_launch_finalize) — for kernels
 // whose long-lived blocks at low occupancy lose more to a closing block's wait than the follow-up launch costs
@@ -586,8 +601,10 @@ __device__ __forceinline__ void block_publish_partial(double acc, double* red, d
 // its group with its first wave (one slot per lane), puts the sentinel back, and publishes the group sum the same way; the LAST
 // block polls the group sums (<= 1024: four per thread) and writes the result.  A block only ever waits for blocks with LOWER
 // indices, which the dispatcher started before it — they never need the slot the waiting wave occupies, so the wait cannot
-// deadlock; a poll gives up after BJX_FIN_SPIN_MAX rounds and lets the sentinel (a NaN) through, so a broken invariant shows as
-// a NaN sum instead of a hung GPU.  Fixed order (lanes of a group by butterfly, groups t, t+256, ... per thread, wave trees,
+// deadlock — an ASSUMPTION about the dispatcher (lower block indices of a grid start first), true on today's queues and stated in
+// include/bjx.h, not a guarantee (CU masking, priority pre-emption).  If it breaks, a poll gives up after BJX_FIN_SPIN_MAX rounds: the sum of that
+// launch is NaN AND the failure channel is raised (fin_raise): the next entry / bjx_synchronize return BJX_ERR_FINALIZE, the slots are
+// re-armed in stream order and the context finishes its sums with the two-pass finalize from then on — never a hung GPU, never a NaN with BJX_OK.  Fixed order (lanes of a group by butterfly, groups t, t+256, ... per thread, wave trees,
 // (r0+r1)+(r2+r3)): run-to-run identical, within 1e-15 relative of the two-pass order.
 constexpr unsigned long long BJX_FIN_SENT = 0xFFFFDEADFFFFDEADull;
 constexpr int BJX_FIN_SPIN_MAX = 1 << 21;
@@ -595,7 +612,14 @@ __device__ __forceinline__ void fin_publish(double* slot, double v) {
   unsigned long long b = (v != v) ? 0x7FF8000000000000ull : (unsigned long long)__double_as_longlong(v);
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double fin_poll(double* slot) {
+// A poll that gives up (BJX_FIN_SPIN_MAX rounds: ~0.3 s) raises the failure channel: the sticky device word `f.err` (every later
+// launch on this context then writes NaN, never a sum that may contain what the late block leaves in the slot) and its twin in
+// host memory, which the next entry point and bjx_synchronize turn into BJX_ERR_FINALIZE (bjx_ctx.hip: bjx_fin_fault_check).
+__device__ __forceinline__ void fin_raise(const BjxFin& f) {      // (inlined: a real call in the epilogue would put every kernel on the callable-function ABI)
+  if (f.err) __hip_atomic_store(f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (f.err_host) __hip_atomic_store(f.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double fin_poll(double* slot, const BjxFin& f) {
   unsigned long long* q = reinterpret_cast<unsigned long long*>(slot);
   unsigned long long v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int spins = 0;
@@ -603,6 +627,7 @@ __device__ __forceinline__ double fin_poll(double* slot) {
     __builtin_amdgcn_s_sleep(2);
     v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (v == BJX_FIN_SENT) fin_raise(f);
   __hip_atomic_store(q, BJX_FIN_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the slot is ready for the next launch
   return __longlong_as_double((long long)v);
 }
@@ -628,11 +653,11 @@ __device__ __forceinline__ void block_publish_sentinel(double acc, double* red, 
   if (lane == 0) {
     double s = acc;
     if (nw > 1) { s = 0.0; for (int w = 0; w < nw; ++w) s += red[w]; }
-    fin_publish(&f.partials[g * 64u + l], s);
+    if ((int)b != f.drop_block) fin_publish(&f.partials[g * 64u + l], s);
   }
   if (!(l == 63u || j == cnt_x - 1)) return;
   const unsigned members = cnt_x - q * 64u < 64u ? cnt_x - q * 64u : 64u;
-  double v = (unsigned)lane < members ? fin_poll(&f.partials[g * 64u + lane]) : 0.0;
+  double v = (unsigned)lane < members ? fin_poll(&f.partials[g * 64u + lane], f) : 0.0;
   v = group_sum<64>(v);
   if (lane == 0) fin_publish(&f.l2[g], v);
   if (b != n - 1) return;
@@ -643,12 +668,14 @@ __device__ __forceinline__ void block_publish_sentinel(double acc, double* red, 
   for (unsigned k = lane; k < nk; k += 64) {
     const unsigned xk = k & 7u, qk = k >> 3;
     const unsigned ck = n > xk ? (n - xk + 7u) >> 3 : 0u;
-    if (qk * 64u < ck) t += fin_poll(&f.l2[k]);
+    if (qk * 64u < ck) t += fin_poll(&f.l2[k], f);
   }
   t = group_sum<64>(t);
   if (lane == 0) {
     t += f.host_const;
     if (f.dev_const) t += *f.dev_const;
+    // sticky: a hand-off of THIS or of an EARLIER launch on the context timed out -> no number (the host sees BJX_ERR_FINALIZE)
+    if (f.err && __hip_atomic_load(f.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) t = __longlong_as_double(0x7FF8000000000000ll);
     *f.out = f.accumulate ? (*f.out + t) : t;
   }
 }

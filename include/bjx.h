@@ -50,7 +50,13 @@ enum {
   BJX_ERR_ARG = -1,       /* NULL / negative size / bad enum  (Julia: ArgumentError)      */
   BJX_ERR_SHAPE = -2,     /* size mismatch                    (Julia: DimensionMismatch)  */
   BJX_ERR_UNSUPPORTED = -3,
-  BJX_ERR_NOCOMM = -4     /* collective requested without bjx_comm_init                  */
+  BJX_ERR_NOCOMM = -4,    /* collective requested without bjx_comm_init                  */
+  /* ASYNCHRONOUS, reported like a hipError_t by the first entry point (or bjx_synchronize / bjx_check_state) that runs after the
+   * fact: the in-kernel finalize of an EARLIER launch on this context gave up waiting (see BJX_OPT_INKERNEL_FINALIZE), or a hand-off
+   * slot was found dirty.  The `ladj_sum` of that launch, and of the launches enqueued after it on the context until the report, is
+   * NaN — never a plausible number.  The reporting call launches nothing, re-arms the slots in stream order and switches the
+   * context to the two-pass finalize for good; the caller repeats its call.  (Julia: ErrorException) */
+  BJX_ERR_FINALIZE = -5
 };
 
 /* flags */
@@ -96,7 +102,13 @@ int bjx_synchronize(bjx_ctx* ctx);
  *   1 = arrival ticket (round 3): the last block to ARRIVE sums (<= 4 096 blocks); every block waits for its own output stores
  *       before it draws the ticket, which costs short kernels more than the launches it saves (profiles/r03_finalize_ab.txt).
  *   0 = two small follow-up launches (the partials reduced by bjx_finalize*_kernel).
- * 0 and 1 give the same bits; 2 sums in a different (fixed) order: equal to <= 1e-15 relative. */
+ * 0 and 1 give the same bits; 2 sums in a different (fixed) order: equal to <= 1e-15 relative.
+ * ASSUMPTION of mode 2, stated here because nothing in HIP guarantees it: within one grid the dispatcher starts blocks of lower index
+ * no later than blocks of higher index, so a block that waits for lower-indexed blocks never holds a slot they need.  True on every
+ * queue configuration of this pool; CU masking, priority pre-emption or a debugger could break it.  If it breaks the wait times out
+ * (~1 s), that launch's sum is NaN and the context reports BJX_ERR_FINALIZE at the next call, re-arms and stays on mode 0.
+ * A context must not have launches in flight on two streams at once (its scratch is shared): bjx_set_stream orders the new stream
+ * after the work already enqueued on the old one. */
 enum {
   BJX_OPT_INKERNEL_FINALIZE = 1,
   /* Watchdog of the library's own collective (bjx_comm_init + bjx_allreduce_sum_f64): with a communicator attached,
@@ -109,9 +121,18 @@ enum {
    * host promises that the memory behind a pointer it passes again has not been written since the epoch was set, and sets a
    * different non-zero epoch (or 0) whenever it may have been (an optimiser step, a new array at a recycled address).  0 (default) =
    * rebuild on every call — the safe setting for hosts that cannot track writes (arrays mutated in place without a version counter). */
-  BJX_OPT_PARAM_EPOCH = 3
+  BJX_OPT_PARAM_EPOCH = 3,
+  /* Fault injection for the tests of the failure channel (tests/test_gpu_fin_faults.py), never set by a host binding:
+   * DROP_BLOCK: the block with this index does not publish its partial in sentinel-mode launches (value < 0: off) — the closing block
+   * of its group times out; POISON_SLOT: writes 1.0 into hand-off slot `value` now (what an aborted launch would leave behind). */
+  BJX_OPT_DEBUG_FIN_DROP_BLOCK = 4,
+  BJX_OPT_DEBUG_FIN_POISON_SLOT = 5
 };
 int bjx_set_option(bjx_ctx* ctx, int option, int value);
+/* Diagnostics: synchronises the stream and verifies that the context's hand-off state is clean (every slot holds its sentinel, the
+ * arrival counter is zero, no time-out is pending).  BJX_OK, or BJX_ERR_FINALIZE after repairing the state (see the error code).  For
+ * hosts that caught a hipError_t of their own, and for tests; bjx_synchronize reports time-outs without the extra launch. */
+int bjx_check_state(bjx_ctx* ctx);
 /* Stream of BJX_INPUT_STDNORMAL: element (row, col) of a call draws value number (col0 + col) * dim + row of `seed`. */
 int bjx_set_rng(bjx_ctx* ctx, uint64_t seed, int64_t col0);
 

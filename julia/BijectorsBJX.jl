@@ -64,32 +64,81 @@ end
 dtype(::Type{Float32}) = BJX_F32
 dtype(::Type{Float64}) = BJX_F64
 
+# One context per (device, hipStream_t) — the boundary is RE-ENTRANT (VERDICT r05 "do this" #3; SURVEY.md §8b "Threading": a context
+# is not thread-safe, distinct contexts are).  The reference's entry points are pure functions callable from any task
+# (src/interface.jl:156-218) and Turing's default multi-chain mode is MCMCThreads; AMDGPU.jl gives every Task its own HIPStream,
+# so every task gets its own context: its own stream, its own scratch (reduction partials, hand-off slots, parameter tables), its
+# own 8-byte result slot.  The library's launches of a task are therefore ordered against that task's own ROCArray work, and two
+# tasks never share scratch.  Same scheme as the Python mirror (bijectors.jl_amd/interface.py `_ctx_for`: contexts keyed by
+# (device, stream)).  Nothing at module level holds "the" context: the registry below is only ever touched under its lock, and the
+# per-task cache lives in task_local_storage.
 mutable struct Context
     h::Ptr{Cvoid}
+    device::Int
+    stream::Ptr{Cvoid}
+    lsum::ROCVector{Float64}      # the Σ logabsdetjac of a scalar-log-det call lands here (one slot, reused: run! reads it back before it returns)
+    hsum::Vector{Float64}         # its host copy (one copyto! per scalar result, no allocation per call)
 end
-function Context(dev::Integer=AMDGPU.device_id(AMDGPU.device()) - 1, stream=AMDGPU.stream())
+function Context(dev::Integer, stream)
     ccall((:bjx_version, libbjx), Cint, ()) == 100 || error("libbjx_hip.so: unexpected ABI version")
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    rc = ccall((:bjx_create, libbjx), Cint, (Cint, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), dev, stream.stream, h)
+    sp = Ptr{Cvoid}(stream.stream)
+    rc = ccall((:bjx_create, libbjx), Cint, (Cint, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), dev, sp, h)
     rc == 0 || error("bjx_create failed with status $rc")
-    ctx = Context(h[])
-    finalizer(c -> ccall((:bjx_destroy, libbjx), Cint, (Ptr{Cvoid},), c.h), ctx)
-    return ctx
+    c = Context(h[], Int(dev), sp, AMDGPU.zeros(Float64, 1), zeros(Float64, 1))
+    finalizer(x -> ccall((:bjx_destroy, libbjx), Cint, (Ptr{Cvoid},), x.h), c)
+    return c
 end
-const CTX = Ref{Union{Nothing,Context}}(nothing)
-ctx() = something(CTX[], (CTX[] = Context()))
+const CONTEXTS_LOCK = ReentrantLock()
+const CONTEXTS = Dict{Tuple{Int,Ptr{Cvoid}},Context}()      # guarded by CONTEXTS_LOCK; values are never shared between streams
+function ctx()
+    dev = AMDGPU.device_id(AMDGPU.device()) - 1
+    st = AMDGPU.stream()                                    # task-local in AMDGPU.jl
+    key = (Int(dev), Ptr{Cvoid}(st.stream))
+    tls = task_local_storage()
+    c = get(tls, :bjx_context, nothing)
+    (c isa Context && c.device == key[1] && c.stream == key[2]) && return c      # fast path: no lock, no lookup
+    c = lock(CONTEXTS_LOCK) do
+        get!(() -> Context(dev, st), CONTEXTS, key)
+    end
+    tls[:bjx_context] = c
+    return c
+end
+# a task that is done with the GPU hands its context back (the registry otherwise keeps one per stream ever seen)
+function release_context!()
+    c = get(task_local_storage(), :bjx_context, nothing)
+    c isa Context || return nothing
+    lock(CONTEXTS_LOCK) do
+        delete!(CONTEXTS, (c.device, c.stream))
+    end
+    delete!(task_local_storage(), :bjx_context)
+    return nothing
+end
 
 function check(rc::Cint, what)
     rc == 0 && return nothing
     msg = unsafe_string(ccall((:bjx_last_error, libbjx), Cstring, (Ptr{Cvoid},), ctx().h))
     rc == -1 && throw(ArgumentError("$what: $msg"))         # BJX_ERR_ARG
     rc == -2 && throw(DimensionMismatch("$what: $msg"))     # BJX_ERR_SHAPE
-    error("$what: status $rc: $msg")                        # hipError_t / ncclResult_t
+    error("$what: status $rc: $msg")                        # hipError_t / ncclResult_t / BJX_ERR_FINALIZE (asynchronous: repeat the call)
 end
 
-# follow a task onto another AMDGPU.jl stream; wait for the library's stream; scratch held by the context; tuning switch
-set_stream!(stream=AMDGPU.stream()) = check(ccall((:bjx_set_stream, libbjx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx().h, stream.stream), "bjx_set_stream")
+# Move THIS task's context onto another stream (rarely needed: `ctx()` already follows `AMDGPU.stream()`); the library orders the new
+# stream after the work in flight on the old one (bjx_set_stream records an event).  Wait for the library's stream; verify the
+# hand-off state (diagnostics); scratch held by the context; tuning switches.
+function set_stream!(stream=AMDGPU.stream())
+    c = ctx()
+    sp = Ptr{Cvoid}(stream.stream)
+    sp == c.stream && return nothing
+    lock(CONTEXTS_LOCK) do
+        haskey(CONTEXTS, (c.device, sp)) && error("set_stream!: another context already serves that stream")
+        check(ccall((:bjx_set_stream, libbjx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), c.h, sp), "bjx_set_stream")
+        delete!(CONTEXTS, (c.device, c.stream)); c.stream = sp; CONTEXTS[(c.device, sp)] = c
+    end
+    return nothing
+end
 synchronize() = check(ccall((:bjx_synchronize, libbjx), Cint, (Ptr{Cvoid},), ctx().h), "bjx_synchronize")
+check_state() = check(ccall((:bjx_check_state, libbjx), Cint, (Ptr{Cvoid},), ctx().h), "bjx_check_state")
 workspace_bytes() = Int(ccall((:bjx_workspace_bytes, libbjx), Csize_t, (Ptr{Cvoid},), ctx().h))
 const BJX_OPT_COLLECTIVE_TIMEOUT_MS = Cint(2)
 collective_timeout!(ms::Integer) = check(ccall((:bjx_set_option, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().h, BJX_OPT_COLLECTIVE_TIMEOUT_MS, Cint(ms)), "bjx_set_option")   # watchdog of synchronize()
@@ -129,13 +178,17 @@ end
 function run!(p::Plan, ::Type{T}, x, out; want_ladj::Bool=true, lps_into=nothing) where {T}
     o = out === nothing ? (p.null_out ? nothing : similar(x, T, p.outsize)) : out
     lps = !want_ladj || p.ladj !== :column ? nothing : (lps_into === nothing ? similar(x, T, p.batch) : lps_into)
-    lsum = want_ladj && p.ladj === :scalar ? AMDGPU.zeros(Float64, 1) : nothing
+    c = ctx()
+    lsum = want_ladj && p.ladj === :scalar ? c.lsum : nothing        # the context's reused 8-byte slot: nothing allocated per call
     fl = p.flags | (lps_into === nothing ? UInt32(0) : BJX_ACCUMULATE)
     keep = p.keep
     GC.@preserve keep x o lps lsum check(p.launch(devptr(o), devptr(lps), devptr(lsum), fl), String(p.name))
     want_ladj || return nothing
     p.ladj === :column && return lps
-    p.ladj === :scalar && return T(Array(lsum)[1])       # the reference returns a host scalar here (§8a')
+    if p.ladj === :scalar                                  # the reference returns a host scalar here (§8a'): ONE copy, stream-ordered
+        copyto!(c.hsum, c.lsum)
+        return T(c.hsum[1])
+    end
     return zero(T)
 end
 
@@ -1465,10 +1518,13 @@ function base_logpdf(d::Distributions.MvNormal, x::ROCMatrix{T}) where {T<:BjxFl
     p = plan_scale_matrix(Lc, true, xc)
     if size(x, 1) <= 128
         # ONE launch: whitening on the matrix cores, log N(z; 0, I) − logabsdet L accumulated per column while the tile is in LDS,
-        # nothing stored (BJX_BASE_STDNORMAL on bjx_scale_matrix, include/bjx.h)
+        # nothing stored (BJX_BASE_STDNORMAL on bjx_scale_matrix, include/bjx.h).  The flag is served by the matrix-core kernel only:
+        # Float64 beyond 112 rows (its tile would need 194 KiB of LDS) and any run with BJX_SCALE_MFMA=0 answer BJX_ERR_UNSUPPORTED —
+        # then fall through to the two-launch path below, as the Python mirror does (`_logpdf_full_cov_fused`; ADVICE r05).
         lp = similar(x, T, size(x, 2))
-        GC.@preserve keep xc lp check(p.launch(C_NULL, devptr(lp), C_NULL, BJX_BASE_STDNORMAL), "bjx_scale_matrix")
-        return lp
+        rc = GC.@preserve keep xc lp p.launch(C_NULL, devptr(lp), C_NULL, BJX_BASE_STDNORMAL)
+        rc == 0 && return lp
+        rc == BJX_ERR_UNSUPPORTED || check(rc, "bjx_scale_matrix")
     end
     lj = run!(column_plan(p), T, xc, xc)                         # z in place; per-column −logabsdet L
     return stdnormal_chain(xc, BjxOp[], keep) .+ lj

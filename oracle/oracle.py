@@ -512,15 +512,23 @@ def _simplex_terms(x_k, s_k, eps, first):
     return t, dtdx, dtds
 
 
-def simplex_vjp(inp, out_bar, ladj_bar=None, inverse=False):
+def simplex_vjp(inp, out_bar, ladj_bar=None, inverse=False, eps=None):
     """Pullback of with_logabsdet_jacobian(SimplexBijector() or its inverse, inp), (rows, batch) input, per-column
     log-det cotangent.  Reverse sweep of the stick-breaking recurrences simplex.jl:47-64 / :102-120 and of the
     log-det terms :122-138 (the reference's own adjoints: simplex.jl:145-215 logabsdetjac gradient, :248-308
     link, :358-470 invlink — O(K²) loops there, O(K) here; same derivative conventions: a clamped value has
-    zero derivative, max(v, ε) has derivative 1 only where v > ε).  numpy float64, loops over rows only."""
+    zero derivative, max(v, ε) has derivative 1 only where v > ε).  numpy float64, loops over rows only.
+
+    `eps`: the reference's ε is `eps(T)` of the ELEMENT TYPE it is called with (src/Bijectors.jl:91-93, simplex.jl:32,88,126) — part of the
+    function, not of the arithmetic: max(z, ε) switches its derivative off below ε, and the ε-shifted sticks differ by ε/remainder.
+    Default: ε of `inp`'s dtype (Float32 input -> Float32 ε, evaluated here in Float64 arithmetic); round 5 used the Float64 ε for
+    Float32 inputs too, which is a different function wherever a stick is within ~1e-7 of a kink (round 6: the flat-tolerance pullback
+    tests found it — up to 2.5 % of a column's cotangent scale at K = 64)."""
+    if eps is None:
+        in_dt = np.asarray(inp).dtype
+        eps = float(np.finfo(in_dt if in_dt in (np.float32, np.float64) else np.float64).eps)
     a = np.asarray(inp, dtype=np.float64)
     g = np.asarray(out_bar, dtype=np.float64)
-    eps = np.finfo(np.float64).eps
     c, E = 1 / (1 - 2 * eps), 1 + eps
     N = a.shape[1]
     lb = np.zeros(N) if ladj_bar is None else np.broadcast_to(np.asarray(ladj_bar, dtype=np.float64), (N,))

@@ -34,7 +34,8 @@ PY
 case $MODE in
 tests)
   [ $# -eq 0 ] && set -- tests
-  ( time timeout 1500 python -m pytest "$@" -m gpu -q --maxfail=25 -p no:cacheprovider ) > gpurun_out/pytest_gpu.txt 2>&1; tail -8 gpurun_out/pytest_gpu.txt ;;
+  rm -f gpurun_out/vjp_errors.jsonl gpurun_out/matrix_vjp_errors.jsonl
+  ( time timeout 1500 python -m pytest --maxfail=25 "$@" -m gpu -q -p no:cacheprovider ) > gpurun_out/pytest_gpu.txt 2>&1; tail -8 gpurun_out/pytest_gpu.txt ;;
 bench)
   timeout 900 python bench.py "$@" > gpurun_out/bench.json 2> gpurun_out/bench.err; wc -c gpurun_out/bench.json; cut -c1-600 gpurun_out/bench.json ;;
 rows)

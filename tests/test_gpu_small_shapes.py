@@ -14,6 +14,8 @@ torch = pytest.importorskip("torch")
 
 pytestmark = pytest.mark.gpu
 
+from _tol import flat_close, planar_inverse_amp, simplex_amp  # noqa: E402  (north_star's flat 1e-3 / 1e-6 on a stated scale, measured error recorded)
+
 RTOL = {np.float32: 1e-3, np.float64: 1e-6}
 ATOL = {np.float32: 2e-4, np.float64: 1e-9}
 DIMS = [1, 2, 3, 5, 8, 10, 13]
@@ -79,7 +81,7 @@ def test_elementwise_chain_stacked_and_pullbacks(bj, orc, dim, N, dt):
     close(host(lb), -(u.sum(axis=0) + dim * math.log(0.5)), dt, scale=10 * dim, what="chain inverse ladj")
     g, lbar = F(r.normal(size=(dim, N)), dt), r.normal(size=N).astype(dt)
     ref = orc.chain_vjp(ops, Xd, g.astype(np.float64), lbar.astype(np.float64))
-    close(host(bj.vjp(b, dev(X), dev(g), torch.from_numpy(lbar).cuda())), ref, dt, scale=20, what="chain pullback")
+    flat_close(host(bj.vjp(b, dev(X), dev(g), torch.from_numpy(lbar).cuda())), ref, dt, "chain pullback")
     if dim >= 3:                                     # Stacked: exp | Logit | identity on thirds
         a_, b_ = dim // 3, 2 * (dim // 3)
         Xs = X.copy()
@@ -114,15 +116,18 @@ def test_planar_all_directions_and_pullbacks(bj, orc, dim, nl, N, dt):
     g, lbar = F(r.normal(size=(dim, N)), dt), (r.normal(size=N) / math.sqrt(N)).astype(dt)
     w64, u64, b64 = w.astype(np.float64), u.astype(np.float64), b.astype(np.float64)
     xb_ref = orc.planar_vjp(w64, u64, b64, Z.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64))
-    close(host(bj.vjp(flow, dev(Z), dev(g), torch.from_numpy(lbar).cuda())), xb_ref, dt, scale=20, what="planar pullback")
+    flat_close(host(bj.vjp(flow, dev(Z), dev(g), torch.from_numpy(lbar).cuda())), xb_ref, dt, "planar pullback")
     yb_ref = orc.planar_inv_vjp(w64, u64, b64, Yr.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64))
-    close(host(bj.vjp(bj.inverse(flow), dev(Yr), dev(g), torch.from_numpy(lbar).cuda())), yb_ref, dt, scale=100, what="planar inverse pullback")
+    # inverse pullback: J⁻ᵀ and ∇ logabsdetjac both divide by the layers' determinants 1 + wᵀû·sech² (> 0 only because wᵀû > −1): the
+    # amplification eps·(Π max(1, 1/d_l))² is computed per column from the oracle's forward and enters the bar where it exceeds it
+    flat_close(host(bj.vjp(bj.inverse(flow), dev(Yr), dev(g), torch.from_numpy(lbar).cuda())), yb_ref, dt, f"planar inverse pullback dim={dim} layers={nl} N={N}",
+               cond=planar_inverse_amp(orc, w64, u64, b64, Z.astype(np.float64), dt))
     if nl > 1:
         wb, ub, bb = orc.planar_param_vjp(w64, u64, b64, Z.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64))
         xb, pb = bj.vjp_params(flow, dev(Z), dev(g), torch.from_numpy(lbar).cuda())
-        close(host(xb), xb_ref, dt, scale=20, what="planar vjp_params input side")
+        flat_close(host(xb), xb_ref, dt, "planar vjp_params input side")
         for name, rf in (("w", wb), ("u", ub), ("b", bb)):
-            close(host(pb[name]), rf, dt, scale=50 * math.sqrt(N), what=f"planar parameter cotangent {name}")
+            flat_close(host(pb[name]), rf, dt, f"planar parameter cotangent {name}", per="tensor")
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
@@ -144,7 +149,7 @@ def test_radial_batchnorm_permute_coupling(bj, orc, dim, N, dt):
         ref = orc.radial_vjp(a_.astype(np.float64), b_.astype(np.float64), z0.astype(np.float64), np.asarray(xin, dtype=np.float64), g.astype(np.float64),
                              lbar.astype(np.float64), inverse=inv)
         got = bj.vjp(bj.inverse(rad) if inv else rad, dev(np.asarray(xin).astype(dt)), dev(g), torch.from_numpy(lbar).cuda())
-        close(host(got), ref, dt, scale=50, what=f"radial pullback inverse={inv}")
+        flat_close(host(got), ref, dt, f"radial pullback inverse={inv}")
     # InvertibleBatchNorm in eval mode
     bb, logs, m, v = r.normal(size=dim).astype(dt), (0.2 * r.normal(size=dim)).astype(dt), r.normal(size=dim).astype(dt), r.uniform(0.5, 1.5, size=dim).astype(dt)
     bn = bj.InvertibleBatchNorm(dev(bb), dev(logs), dev(m), dev(v))
@@ -188,11 +193,12 @@ def test_structured_blocks_and_pullbacks(bj, orc, K, N, dt):
     close(host(Y2), Xo, dt, scale=10, what="ordered forward")
     close(host(l2), lo, dt, scale=10 * K, what="ordered ladj")
     g, lbar = F(r.normal(size=(K, N)), dt), r.normal(size=N).astype(dt)
-    close(host(bj.vjp(bj.OrderedBijector(), dev(Yo), dev(g), torch.from_numpy(lbar).cuda())),
-          orc.ordered_vjp(Yo.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64)), dt, scale=20 * K, what="ordered pullback")
+    flat_close(host(bj.vjp(bj.OrderedBijector(), dev(Yo), dev(g), torch.from_numpy(lbar).cuda())),
+               orc.ordered_vjp(Yo.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64)), dt, f"ordered pullback K={K} N={N}")
     gs = F(r.normal(size=(K - 1, N)), dt)
-    close(host(bj.vjp(bj.SimplexBijector(), dev(X), dev(gs), torch.from_numpy(lbar).cuda())),
-          orc.simplex_vjp(X.astype(np.float64), gs.astype(np.float64), lbar.astype(np.float64)), dt, scale=200 * K, what="simplex pullback")
+    flat_close(host(bj.vjp(bj.SimplexBijector(), dev(X), dev(gs), torch.from_numpy(lbar).cuda())),
+               orc.simplex_vjp(X.astype(np.float64), gs.astype(np.float64), lbar.astype(np.float64), eps=float(np.finfo(dt).eps)), dt, f"simplex pullback K={K} N={N}",
+               cond=simplex_amp(X, dt))
     # LKJ blocks: VecCholesky (both triangles), VecCorr, PDVec round trips against the oracle
     n = K * (K - 1) // 2
     y = F(0.5 * r.normal(size=(n, N)), dt)
@@ -232,10 +238,10 @@ def test_spline_and_parameter_pullbacks(bj, orc, dim, N, dt):
     for inv, xin in ((False, X), (True, Yr.astype(dt))):
         xin64 = np.asarray(xin, dtype=np.float64)
         xb, gk = bj.vjp_params(bj.inverse(b) if inv else b, dev(xin), dev(g), torch.from_numpy(lbar).cuda())
-        close(host(xb), orc.rqs_vjp(w, h, d, xin64, g.astype(np.float64), lbar.astype(np.float64), inverse=inv), dt, scale=100, what=f"spline pullback inverse={inv}")
+        flat_close(host(xb), orc.rqs_vjp(w, h, d, xin64, g.astype(np.float64), lbar.astype(np.float64), inverse=inv), dt, f"spline pullback inverse={inv}")
         ref = orc.rqs_vjp_knots(w, h, d, xin64, g.astype(np.float64), lbar.astype(np.float64), inverse=inv)
         for name, rf in zip(("widths", "heights", "derivatives"), ref):
-            close(host(gk[name]), rf, dt, scale=100 * math.sqrt(N), what=f"spline knot cotangent {name} inverse={inv}")
+            flat_close(host(gk[name]), rf, dt, f"spline knot cotangent {name} inverse={inv}", per="tensor")
     # RadialLayer parameters
     a_raw, b_raw, z0 = np.array([0.3], dtype=dt), np.array([-0.4], dtype=dt), r.normal(size=dim).astype(dt)
     rad = bj.RadialLayer(dev(a_raw), dev(b_raw), dev(z0))
@@ -244,10 +250,10 @@ def test_spline_and_parameter_pullbacks(bj, orc, dim, N, dt):
     xb, gp = bj.vjp_params(rad, dev(Z), dev(g), torch.from_numpy(lbar).cuda())
     close(host(xb), orc.radial_vjp(a_raw.astype(np.float64), b_raw.astype(np.float64), z0.astype(np.float64), Z.astype(np.float64), g.astype(np.float64), lbar.astype(np.float64)),
           dt, scale=50, what="radial vjp_params input side")
-    fl = ATOL[dt] * 100 * math.sqrt(N) * dim
-    assert abs(float(host(gp["alpha_"])[0]) - ab) <= RTOL[dt] * 20 * abs(ab) + fl
-    assert abs(float(host(gp["beta"])[0]) - bb) <= RTOL[dt] * 20 * abs(bb) + fl
-    np.testing.assert_allclose(host(gp["z_0"]), z0b, rtol=RTOL[dt] * 20, atol=fl)
+    tag = f"small shapes radial vjp_params dim={dim} N={N}"
+    flat_close(host(gp["alpha_"])[0], ab, dt, tag + ": ᾱ_", per="tensor")
+    flat_close(host(gp["beta"])[0], bb, dt, tag + ": β̄", per="tensor")
+    flat_close(host(gp["z_0"]), z0b, dt, tag + ": z̄₀", per="tensor")
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
@@ -391,12 +397,12 @@ def test_planar_pullback_on_columns_taller_than_the_register_kernels(bj, orc, di
     layer = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(bb))
     ref = orc.planar_vjp(w, u, bb, Z, g, lb)
     got = bj.vjp(layer, dev(Z), dev(g), torch.from_numpy(lb).cuda())
-    np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())))
+    flat_close(host(got), ref, dt, "planar_pullback_on_columns_taller_than_the_register_kernels: ref")
     ref0 = orc.planar_vjp(w, u, bb, Z, g)
-    np.testing.assert_allclose(host(bj.vjp(layer, dev(Z), dev(g))), ref0, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref0).max())))
+    flat_close(host(bj.vjp(layer, dev(Z), dev(g))), ref0, dt, "planar_pullback_on_columns_taller_than_the_register_kernels: ref0")
     ref_i = orc.planar_inv_vjp(w, u, bb, Z, g, lb)
     got_i = bj.vjp(bj.inverse(layer), dev(Z), dev(g), torch.from_numpy(lb).cuda())
-    np.testing.assert_allclose(host(got_i), ref_i, rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(ref_i).max())))
+    flat_close(host(got_i), ref_i, dt, "planar_pullback_on_columns_taller_than_the_register_kernels: ref_i")
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
@@ -415,9 +421,9 @@ def test_radial_pullback_on_columns_taller_than_the_register_kernels(bj, orc, di
         b = bj.inverse(layer) if inv else layer
         ref = orc.radial_vjp(al, be, z0, Z, g, lb, inverse=inv)
         got = bj.vjp(b, dev(Z), dev(g), torch.from_numpy(lb).cuda())
-        np.testing.assert_allclose(host(got), ref, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())))
+        flat_close(host(got), ref, dt, "radial_pullback_on_columns_taller_than_the_register_kernels: ref")
         ref0 = orc.radial_vjp(al, be, z0, Z, g, inverse=inv)
-        np.testing.assert_allclose(host(bj.vjp(b, dev(Z), dev(g))), ref0, rtol=RTOL[dt] * 10, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref0).max())))
+        flat_close(host(bj.vjp(b, dev(Z), dev(g))), ref0, dt, "radial_pullback_on_columns_taller_than_the_register_kernels: ref0")
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
@@ -438,11 +444,11 @@ def test_planar_parameter_pullback_beyond_the_register_accumulators(bj, orc, dim
     layer = bj.PlanarLayer(torch.tensor(w), torch.tensor(u), torch.tensor(bb))
     wb_ref, ub_ref, bb_ref = orc.planar_param_vjp(w, u, bb, Z, g, lb)
     xb, pb = bj.vjp_params(layer, dev(Z), dev(g), torch.from_numpy(lb).cuda())
-    np.testing.assert_allclose(host(xb), orc.planar_vjp(w, u, bb, Z, g, lb), rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10)
-    tol = dict(rtol=RTOL[dt] * 20, atol=ATOL[dt] * 20 * max(1.0, float(np.abs(wb_ref).max()), float(np.abs(ub_ref).max())))
-    np.testing.assert_allclose(host(pb["w"]).reshape(dim, nl), wb_ref.reshape(dim, nl), **tol)
-    np.testing.assert_allclose(host(pb["u"]).reshape(dim, nl), ub_ref.reshape(dim, nl), **tol)
-    np.testing.assert_allclose(host(pb["b"]).reshape(-1), bb_ref.reshape(-1), **tol)
+    tag = f"tall planar vjp_params dim={dim} layers={nl} N={N}"
+    flat_close(host(xb), orc.planar_vjp(w, u, bb, Z, g, lb), dt, tag + ": x̄")
+    flat_close(host(pb["w"]).reshape(dim, nl), wb_ref.reshape(dim, nl), dt, tag + ": w̄", per="tensor")
+    flat_close(host(pb["u"]).reshape(dim, nl), ub_ref.reshape(dim, nl), dt, tag + ": ū", per="tensor")
+    flat_close(host(pb["b"]).reshape(-1), bb_ref.reshape(-1), dt, tag + ": b̄", per="tensor")
 
 
 @pytest.mark.parametrize("dt,dim,N,nl", [(np.float64, 72, 133, 3), (np.float64, 200, 70, 8), (np.float64, 333, 41, 2), (np.float32, 1500, 37, 3),
@@ -473,7 +479,7 @@ def test_planar_column_tile_kernels_in_place(bj, orc, dt, dim, N, nl):
     rc = L.load().bjx_planar_vjp(ctx.h, code, 0, wd.data_ptr(), ud.data_ptr(), bd.data_ptr(), nl, xd.data_ptr(), gd.data_ptr(), lbd.data_ptr(), gd.data_ptr(), dim, N)
     L.check(ctx.h, rc, "bjx_planar_vjp")
     ref = orc.planar_vjp(w, u, bb, Z, g, lb)
-    np.testing.assert_allclose(host(gd), ref, rtol=RTOL[dt] * 5, atol=ATOL[dt] * 10 * max(1.0, float(np.abs(ref).max())))
+    flat_close(host(gd), ref, dt, "planar_column_tile_kernels_in_place: ref")
 
 
 # ---------------------------------------------------------------- round 5: VectorBijectors links of JointOrderStatistics / MvLogNormal
