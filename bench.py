@@ -439,6 +439,8 @@ def measure(env, name, steps, warmup, scaling, log2_batch=None, want_cold=True):
     barrier()
     per_warm = (time.perf_counter() - t_w) / max(warmup, 1)
 
+    launches_all = [None]
+
     def timed_pass(instrument):
         """EXACTLY `steps` steps between barrier + synchronize on both sides, max over ranks.  THREE kinds of pass, never mixed
         (the per-launch hipEvent pairs cost 30-55 % on launch-bound steps and must not sit inside the region
@@ -452,9 +454,11 @@ def measure(env, name, steps, warmup, scaling, log2_batch=None, want_cold=True):
             lib.bjx_kernel_time_begin(ctx.h)      # prof_on = 1 (context stream)
         if instrument == "region":
             lib.bjx_time_begin(ctx.h)
+        n_launch0 = lib.bjx_launch_count()
         t0 = time.perf_counter()
         for _ in range(steps):
             last = wl["step"]()
+        launches_all[0] = (lib.bjx_launch_count() - n_launch0) / max(steps, 1)      # EVERY kernel launch of the library in the region (helpers included)
         ev_ms = C.c_float(0.0)
         if instrument == "region":
             lib.bjx_time_end(ctx.h, C.byref(ev_ms))
@@ -518,7 +522,7 @@ def measure(env, name, steps, warmup, scaling, log2_batch=None, want_cold=True):
         "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup, "preroll_steps": pre, "scaling": scaling, "config": wl["cfg"],
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic_from_profiles(name), "traffic_source": traffic_source(name), "kernel": wl["kernel"], "kernel_ms": kern_ms,
-                     "kernel_launches_per_step": k_launches / max(steps, 1), "stream_region_ms_per_step": ev / steps,
+                     "kernel_launches_per_step": k_launches / max(steps, 1), "launches_per_step_all": launches_all[0], "stream_region_ms_per_step": ev / steps,
                      "algorithmic_bytes_per_launch": alg_bytes, "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
         "sum_logabsdetjac": ladj_total, "cold": cold,
         "passes": {"wall_ms_per_step": ms_per_step, "kernel_pass_wall_ms_per_step": dt_k / steps * 1e3,
@@ -612,8 +616,8 @@ def build_line(a, world, head, rows, graph_rows, strong, cpu):
         "dtype": head["dtype"], "data": "synthetic (Philox N(0,1), shard-invariant)",
         "config": dict(head["config"], parallelism=f"batch-sharded x{world}, one f64 all-reduce of Σlogabsdetjac ({a.collective})",
                        cache_params=not a.no_cache_params),
-        "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
-                                        "kernel_launches_per_step", "stream_region_ms_per_step", "algorithmic_bytes_per_launch")},
+        "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms",
+                                            "kernel_launches_per_step", "launches_per_step_all", "stream_region_ms_per_step", "algorithmic_bytes_per_launch")},
         "cpu_baseline": cpu,
         "preroll": {"ms": PREROLL_MS, "steps": head.get("preroll_steps", 0)},
         "passes": head.get("passes"),

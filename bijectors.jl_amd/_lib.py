@@ -59,6 +59,7 @@ BJX_OPT_COLLECTIVE_TIMEOUT_MS = 2
 BJX_OPT_PARAM_EPOCH = 3
 BJX_OPT_DEBUG_FIN_DROP_BLOCK = 4      # fault injection, tests only
 BJX_OPT_DEBUG_FIN_POISON_SLOT = 5
+BJX_PLAN_CHAIN, BJX_PLAN_SIMPLEX, BJX_PLAN_ORDERED = 1, 2, 3
 
 # name -> (restype, argtypes); mirrors include/bjx.h line by line
 SIGNATURES = {
@@ -127,6 +128,11 @@ SIGNATURES = {
     "bjx_time_end": (_i, [_vp, C.POINTER(C.c_float)]),
     "bjx_kernel_time_begin": (_i, [_vp]),
     "bjx_kernel_time_end": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "bjx_launch_count": (_u64, []),
+    "bjx_plan_chain": (_i, [_vp, _i, C.POINTER(BjxOp), _i, _i64, _u32, C.POINTER(_vp)]),
+    "bjx_plan_structured": (_i, [_vp, _i, _i, _i, _i64, _u32, C.POINTER(_vp)]),
+    "bjx_plan_run": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "bjx_plan_destroy": (_i, [_vp]),
     "bjx_graph_begin": (_i, [_vp]),
     "bjx_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "bjx_graph_launch": (_i, [_vp, _vp]),

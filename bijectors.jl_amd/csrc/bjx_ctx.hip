@@ -14,7 +14,7 @@
 // t, t+256, ...; then a fixed tree) so the result does not depend on dispatch order.
 __global__ __launch_bounds__(256) void bjx_finalize_kernel(const double* __restrict__ partials, int n,
                                                             double* __restrict__ out, double host_const,
-                                                            const double* __restrict__ dev_const, int accumulate) {
+                                                            const double* __restrict__ dev_const, int accumulate, float* __restrict__ out32) {
   __shared__ double red[4];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
@@ -24,7 +24,9 @@ __global__ __launch_bounds__(256) void bjx_finalize_kernel(const double* __restr
   if (threadIdx.x == 0) {
     double t = ((red[0] + red[1]) + (red[2] + red[3])) + host_const;
     if (dev_const) t += *dev_const;
-    *out = accumulate ? (*out + t) : t;
+    const double r_ = accumulate ? (*out + t) : t;
+    *out = r_;
+    if (out32) *out32 = (float)r_;
   }
 }
 
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(256) void bjx_finalize_kernel(const double* __restr
 // pair — a step then carries one tail launch, not two (4.8 + 4.7 µs of helper kernels per call next
 // to a 100 - 220 µs hot kernel).  Fixed order: thread t takes t, t+1024, ...; wave trees; the 16 wave sums in index order.
 __global__ __launch_bounds__(1024) void bjx_finalize_wide_kernel(const double* __restrict__ partials, int n, double* __restrict__ out, double host_const,
-                                                                  const double* __restrict__ dev_const, int accumulate) {
+                                                                  const double* __restrict__ dev_const, int accumulate, float* __restrict__ out32) {
   __shared__ double red[16];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 1024) s += partials[i];
@@ -45,7 +47,9 @@ __global__ __launch_bounds__(1024) void bjx_finalize_wide_kernel(const double* _
     for (int w = 0; w < 16; ++w) t += red[w];
     t += host_const;
     if (dev_const) t += *dev_const;
-    *out = accumulate ? (*out + t) : t;
+    const double r_ = accumulate ? (*out + t) : t;
+    *out = r_;
+    if (out32) *out32 = (float)r_;
   }
 }
 
@@ -95,7 +99,8 @@ int bjx_launch_finalize(bjx_ctx* ctx, int n_partials, double* ladj_sum, double h
   int n = n_partials;
   if (n > BJX_MAX_BLOCKS && n <= BJX_FIN_WIDE_MAX) {
     hipLaunchKernelGGL(bjx_finalize_wide_kernel, dim3(1), dim3(1024), 0, ctx->stream, src, n, ladj_sum, host_const,
-                       use_dev_const ? ctx->consts + 1 : nullptr, (flags & BJX_ACCUMULATE) ? 1 : 0);
+                       use_dev_const ? ctx->consts + 1 : nullptr, (flags & BJX_ACCUMULATE) ? 1 : 0, ctx->fin_out32);
+    ctx->fin_out32_taken = ctx->fin_out32 ? 1 : 0;
     BJX_CHECK_LAUNCH(ctx);
     return BJX_OK;
   }
@@ -109,7 +114,8 @@ int bjx_launch_finalize(bjx_ctx* ctx, int n_partials, double* ladj_sum, double h
   }
   hipLaunchKernelGGL(bjx_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, src, n,
                      ladj_sum, host_const, use_dev_const ? ctx->consts + 1 : nullptr,
-                     (flags & BJX_ACCUMULATE) ? 1 : 0);
+                     (flags & BJX_ACCUMULATE) ? 1 : 0, ctx->fin_out32);
+  ctx->fin_out32_taken = ctx->fin_out32 ? 1 : 0;
   BJX_CHECK_LAUNCH(ctx);
   return BJX_OK;
 }
@@ -193,6 +199,8 @@ int bjx_make_fin(bjx_ctx* ctx, int64_t grid, double* ladj_sum, double host_const
     fin->err = ctx->fin_err;
     fin->err_host = ctx->fin_err_host_dev;
     fin->drop_block = ctx->dbg_fin_drop;
+    fin->out32 = ctx->fin_out32;
+    ctx->fin_out32_taken = ctx->fin_out32 ? 1 : 0;
   } else if (ctx->opt_inkernel_fin == 1 && grid <= BJX_INKERNEL_FIN_MAX) {
     // The arrival counter is zero between launches: the block that draws the last ticket resets it (a launch that faults
     // leaves the HIP context in a sticky error state, so no later launch can see a stale count); nothing is enqueued here.
@@ -201,6 +209,8 @@ int bjx_make_fin(bjx_ctx* ctx, int64_t grid, double* ladj_sum, double host_const
     fin->host_const = host_const;
     fin->dev_const = use_dev_const ? ctx->consts + 1 : nullptr;
     fin->accumulate = (flags & BJX_ACCUMULATE) ? 1 : 0;
+    fin->out32 = ctx->fin_out32;
+    ctx->fin_out32_taken = ctx->fin_out32 ? 1 : 0;
   } else {
     *second_pass = true;
   }
@@ -215,11 +225,14 @@ int bjx_fin_two_pass(bjx_ctx* ctx, int64_t grid, BjxFin* fin, bool* second_pass)
   *fin = BjxFin{};
   fin->partials = ctx->partials;
   *second_pass = true;
+  ctx->fin_out32_taken = 0;          // bjx_launch_finalize will take it
   return BJX_OK;
 }
 
 // ------------------------------------------------------------------ context
+std::atomic<unsigned long long> bjx_g_launches{0};
 BJX_API int bjx_version(void) { return BJX_VERSION; }
+BJX_API uint64_t bjx_launch_count(void) { return (uint64_t)bjx_g_launches.load(std::memory_order_relaxed); }
 
 BJX_API int bjx_create(int device, void* hip_stream, bjx_ctx** out) {
   if (!out) return BJX_ERR_ARG;
@@ -299,6 +312,85 @@ BJX_API int bjx_destroy(bjx_ctx* ctx) {
   }
   delete ctx;
   return BJX_OK;
+}
+
+// ------------------------------------------------------------------ launch plans (include/bjx.h "plans")
+__global__ void bjx_cast_sum_kernel(const double* __restrict__ src, float* __restrict__ dst) { *dst = (float)*src; }
+
+static int bjx_plan_new(bjx_ctx* ctx, bjx_plan** out, bjx_plan** p) {
+  if (!ctx || !out) return BJX_ERR_ARG;
+  *out = nullptr;
+  *p = new (std::nothrow) bjx_plan();
+  if (!*p) return bjx_fail(ctx, BJX_ERR_ARG, "out of host memory");
+  (*p)->ctx = ctx;
+  return BJX_OK;
+}
+
+BJX_API int bjx_plan_chain(bjx_ctx* ctx, bjx_dtype dt, const bjx_op* ops, int n_ops, int64_t dim, uint32_t flags, bjx_plan** out) {
+  if (!ctx || !out) return BJX_ERR_ARG;
+  *out = nullptr;
+  BJX_REQUIRE(ctx, n_ops >= 0 && n_ops <= BJX_MAX_OPS && (ops || n_ops == 0), BJX_ERR_ARG, "bjx_plan_chain: n_ops must be in [0, %d]", BJX_MAX_OPS);
+  BJX_REQUIRE(ctx, dt == BJX_F32 || dt == BJX_F64, BJX_ERR_ARG, "bjx_plan_chain: bad dtype %d", (int)dt);
+  BJX_REQUIRE(ctx, dim >= 0, BJX_ERR_SHAPE, "bjx_plan_chain: negative size");
+  for (int k = 0; k < n_ops; ++k) {
+    BJX_REQUIRE(ctx, ops[k].kind >= BJX_OP_EXP && ops[k].kind <= BJX_OP_STDNORMAL_LOGPDF, BJX_ERR_ARG, "bjx_plan_chain: op %d has unknown kind %d", k, (int)ops[k].kind);
+    BJX_REQUIRE(ctx, ops[k].param_len == 0 || ops[k].param_len == 1 || ops[k].param_len == dim, BJX_ERR_SHAPE,
+                "bjx_plan_chain: op %d has a parameter of length %d for %lld rows", k, (int)ops[k].param_len, (long long)dim);
+  }
+  bjx_plan* p;
+  { const int rc = bjx_plan_new(ctx, out, &p); if (rc) return rc; }
+  p->kind = BJX_PLAN_CHAIN; p->dt = dt; p->n_ops = n_ops; p->dim = dim; p->flags = flags;
+  for (int k = 0; k < n_ops; ++k) p->ops[k] = ops[k];
+  *out = p;
+  return BJX_OK;
+}
+
+BJX_API int bjx_plan_structured(bjx_ctx* ctx, bjx_dtype dt, int kind, int inverse, int64_t dim, uint32_t flags, bjx_plan** out) {
+  if (!ctx || !out) return BJX_ERR_ARG;
+  *out = nullptr;
+  BJX_REQUIRE(ctx, kind == BJX_PLAN_SIMPLEX || kind == BJX_PLAN_ORDERED, BJX_ERR_ARG, "bjx_plan_structured: kind must be BJX_PLAN_SIMPLEX or BJX_PLAN_ORDERED, got %d", kind);
+  BJX_REQUIRE(ctx, dt == BJX_F32 || dt == BJX_F64, BJX_ERR_ARG, "bjx_plan_structured: bad dtype %d", (int)dt);
+  BJX_REQUIRE(ctx, dim >= 0, BJX_ERR_SHAPE, "bjx_plan_structured: negative size");
+  bjx_plan* p;
+  { const int rc = bjx_plan_new(ctx, out, &p); if (rc) return rc; }
+  p->kind = kind; p->dt = dt; p->inverse = inverse ? 1 : 0; p->dim = dim; p->flags = flags;
+  *out = p;
+  return BJX_OK;
+}
+
+BJX_API int bjx_plan_destroy(bjx_plan* plan) {
+  delete plan;
+  return BJX_OK;
+}
+
+BJX_API int bjx_plan_run(bjx_plan* plan, const void* in, void* out, void* ladj_ps, double* ladj_sum, void* ladj_sum_t, int64_t batch) {
+  if (!plan || !plan->ctx) return BJX_ERR_ARG;
+  bjx_ctx* ctx = plan->ctx;
+  double* sum = ladj_sum;
+  if (ladj_sum_t) {
+    BJX_REQUIRE(ctx, plan->dt == BJX_F32, BJX_ERR_ARG, "bjx_plan_run: ladj_sum_t is the Float32 copy of the sum; a Float64 plan returns it in ladj_sum");
+    if (!sum) {
+      BJX_REQUIRE(ctx, !(plan->flags & BJX_ACCUMULATE), BJX_ERR_ARG, "bjx_plan_run: BJX_ACCUMULATE needs the Float64 accumulator ladj_sum");
+      sum = reinterpret_cast<double*>(ctx->fin_counter + 8);          // the context's own 8-byte slot (stream-ordered reuse)
+    }
+    ctx->fin_out32 = static_cast<float*>(ladj_sum_t);
+    ctx->fin_out32_taken = 0;
+  }
+  int rc;
+  if (plan->kind == BJX_PLAN_CHAIN) rc = bjx_chain(ctx, plan->dt, plan->ops, plan->n_ops, in, out, ladj_ps, sum, plan->dim, batch, plan->flags);
+  else if (plan->kind == BJX_PLAN_SIMPLEX) rc = bjx_simplex(ctx, plan->dt, plan->inverse, in, out, ladj_ps, sum, plan->inverse ? plan->dim + 1 : plan->dim, batch, plan->flags);
+  else rc = bjx_ordered(ctx, plan->dt, plan->inverse, in, out, ladj_ps, sum, plan->dim, batch, plan->flags);
+  if (ladj_sum_t) {
+    float* dst = ctx->fin_out32;
+    const int taken = ctx->fin_out32_taken;
+    ctx->fin_out32 = nullptr;
+    ctx->fin_out32_taken = 0;
+    if (rc == BJX_OK && !taken) {          // a path that finished its sum without the shared epilogue (constant log-dets, empty inputs)
+      hipLaunchKernelGGL(bjx_cast_sum_kernel, dim3(1), dim3(1), 0, ctx->stream, sum, dst);
+      BJX_CHECK_LAUNCH(ctx);
+    }
+  }
+  return rc;
 }
 
 BJX_API int bjx_set_stream(bjx_ctx* ctx, void* hip_stream) {

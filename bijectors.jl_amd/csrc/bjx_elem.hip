@@ -292,14 +292,9 @@ template <class T> __device__ __forceinline__ Rec4<T> lds_rec(const char* p, int
 //   numerator of y   s ξ² + d_k ξ(1-ξ)                                     = ξ (d_k + (s - d_k) ξ)
 //   numerator of J   d_{k+1} ξ² + 2s ξ(1-ξ) + d_k (1-ξ)²                   = d_k + (d_{k+1} - d_k) ξ - ds·p
 // (the last is a convex interpolation minus a term of at most the same size: cancellation <= ~2x).
-// Returns the FACTORS of |J| (round 6), not its logarithm: the log-det of a column is a sum over its rows, so the caller multiplies the
-// factors of the V elements of a pack and takes ONE hardware log per pack instead of one per element (a transcendental holds the
-// VALU for four issue slots: profiles/r05_pmc_notes.md counted 54 slots per inverse element, 16 of them four transcendentals).
-//   forward:  jn = nj·(s/den)²                      (1/den is needed for the value anyway), jd unused
-//   inverse:  jn = nj·s², jd = den                  log2|J⁻¹| of the pack = 2·log2(Π jd) − log2(Π jn): the reciprocal of den is gone too
-// Outside [-B, B]: jn = 1 + 0·x (1, or NaN for x = ±Inf like the reference's `zero(T) * x`, :272, :323), jd = 1.
+// Returns log2|J| (the caller multiplies the per-column sum by ln 2 once).
 template <class T, bool INV>
-__device__ __forceinline__ void rqs_eval(const Rec4<T>& A, const Rec4<T>& B, T lim, T& x, T& jn, T& jd) {
+__device__ __forceinline__ T rqs_eval(const Rec4<T>& A, const Rec4<T>& B, T lim, T& x) {
   using F = Fast<T>;
   const T s = B.v[0], d_k = B.v[1], ds = B.v[2], dd = B.v[3];
   const T xin = x;
@@ -322,39 +317,77 @@ __device__ __forceinline__ void rqs_eval(const Rec4<T>& A, const Rec4<T>& B, T l
     const f2 r2 = __builtin_elementwise_fma(f2{ds, dd}, f2{p, xi}, f2{s, d_k});
     den = r2.x; tq = r2.y;
   } else { den = s + ds * p; tq = d_k + dd * xi; }
+  const T rden = F::rcp(den);
+  const T nj = tq - ds * p;
+  const T sr = s * rden;
+  T lj = F::log2(nj * (sr * sr));                                           // log(s²·nj) - 2 log(den)
+  if (!INV) res = A.v[2] + (A.v[3] * (xi * (d_k + (s - d_k) * xi))) * rden;
+  else { res = xi * A.v[3] + A.v[2]; lj = -lj; }
+  // identity outside [-B, B] (:132, :186): (x <= -lim || x >= lim) == (|x| >= lim); a NaN is NOT outside (both
+  // comparisons are false in the reference too) and leaves through the arithmetic as NaN value and NaN log-det
+  const bool outside = d_abs(xin) >= lim;
+  x = outside ? xin : res;
+  return outside ? T(0) * xin : lj;                                          // `zero(T) * x` (:272, :323): NaN for x = ±Inf, like the reference
+}
+
+// Float64 (round 6): the FACTORS of |J| instead of its logarithm.  The log-det of a column is a sum over its rows, so the caller
+// multiplies the factors of the V elements of a pack and takes ONE lean log (≈ 40 Float64 VALU operations, scripts/f64math_bench.hip)
+// per pack instead of one per element; the inverse does not need 1/den per element either (one reciprocal of the product of the
+// dens per pack).  In Float32 the same change was measured and reverted (profiles/r06_c3_experiments.md: a hardware log is 4 issue
+// slots, the range guard of the product costs what it saves).
+//   forward:  jn = nj·(s/den)²;   inverse:  jn = nj·s², jd = den  ->  log2|J⁻¹| of the pack = −log2(Π jn · (1/Π jd)²)
+// Outside [-B, B]: jn = 1 + 0·x (1, or NaN for x = ±Inf like the reference's `zero(T) * x`, :272, :323), jd = 1.
+template <class T, bool INV>
+__device__ __forceinline__ void rqs_eval_factors(const Rec4<T>& A, const Rec4<T>& B, T lim, T& x, T& jn, T& jd) {
+  using F = Fast<T>;
+  const T s = B.v[0], d_k = B.v[1], ds = B.v[2], dd = B.v[3];
+  const T xin = x;
+  T xi, res;
+  if (!INV) {
+    xi = xin * A.v[1] + A.v[0];
+  } else {
+    const T yh = xin - A.v[0];
+    const T t = yh * ds;
+    const T a1 = A.v[1] * (s - d_k) + t;                                    // Eq. (25)
+    const T a2 = A.v[1] * d_k - t;                                          // Eq. (26)
+    const T q = s * yh;                                                     // -a3, Eq. (27)
+    xi = F::div(q + q, a2 + F::sqrt(a2 * a2 + 4 * (a1 * q)));               // Eq. (24)
+  }
+  const T p = xi - xi * xi;
+  const T den = s + ds * p, tq = d_k + dd * xi;
   const T nj = tq - ds * p;
   T jn_in;
   if (!INV) {
     const T rden = F::rcp(den);
     const T sr = s * rden;
-    jn_in = nj * (sr * sr);                                                 // s²·nj / den²
+    jn_in = nj * (sr * sr);
     res = A.v[2] + (A.v[3] * (xi * (d_k + (s - d_k) * xi))) * rden;
   } else {
     jn_in = nj * (s * s);
     res = xi * A.v[3] + A.v[2];
   }
-  // identity outside [-B, B] (:132, :186): (x <= -lim || x >= lim) == (|x| >= lim); a NaN is NOT outside (both
-  // comparisons are false in the reference too) and leaves through the arithmetic as NaN value and NaN log-det
   const bool outside = d_abs(xin) >= lim;
   x = outside ? xin : res;
   jn = outside ? __builtin_fma(T(0), xin, T(1)) : jn_in;
-  if (INV) jd = outside ? T(1) : den;
+  jd = (INV && !outside) ? den : T(1);
 }
-
-// log2 of a product of Jacobian factors with the range of the SUM of the logs: the product of V factors can leave the Float32 range
-// (|J| of one element up to ~1e9 is fine, four of them 1e36 is not) or reach 0 / NaN / a negative value where a single factor would
-// decide; then the logs are taken one by one — the rare branch, so the common one pays one compare pair for three saved logs.
-template <class T> struct ProdRange;
-template <> struct ProdRange<float> { static constexpr float lo = 1e-30f, hi = 1e30f; };
-template <> struct ProdRange<double> { static constexpr double lo = 1e-280, hi = 1e280; };
-template <class T, int V> __device__ __forceinline__ T log2_of_product(const T (&f)[V]) {
-  T pr = f[0];
+// log2 of the pack's Jacobian from the factors.  The product of V factors can leave the range where no single factor does (or reach 0 /
+// a negative value / NaN where one factor would decide): then the logs are taken one by one — the rare branch.
+template <class T, int V, bool INV> __device__ __forceinline__ T rqs_log2_of_factors(const T (&jn)[V], const T (&jd)[V]) {
+  using F = Fast<T>;
+  constexpr T lo = T(1e-140), hi = T(1e140);
+  T pn = jn[0], pd = jd[0];
 #pragma unroll
-  for (int j = 1; j < V; ++j) pr *= f[j];
-  if (__builtin_expect(pr > ProdRange<T>::lo && pr < ProdRange<T>::hi, 1)) return Fast<T>::log2(pr);
+  for (int j = 1; j < V; ++j) { pn *= jn[j]; pd *= jd[j]; }
+  const bool ok = pn > lo && pn < hi && (!INV || (pd > lo && pd < hi));
+  if (__builtin_expect(ok, 1)) {
+    if (!INV) return F::log2(pn);
+    const T r = F::rcp(pd);
+    return -F::log2(pn * (r * r));
+  }
   T l = T(0);
 #pragma unroll
-  for (int j = 0; j < V; ++j) l += Fast<T>::log2(f[j]);
+  for (int j = 0; j < V; ++j) l += INV ? T(2) * F::log2(jd[j]) - F::log2(jn[j]) : F::log2(jn[j]);
   return l;
 }
 
@@ -449,11 +482,17 @@ __device__ __forceinline__ void rqs_body(const T* __restrict__ blob_l, const Rqs
       A[j] = lds_rec<T>(rec, 0);
       B[j] = lds_rec<T>(rec, RqsRec<T>::RQ / 2);
     }
-    T jn[V], jd[V];
+    if constexpr (sizeof(T) == 8 && V > 1) {
+      T jn[V], jd[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) rqs_eval<T, INV>(A[j], B[j], lim[j], p.v[j], jn[j], jd[j]);
-    if constexpr (!INV) return log2_of_product<T, V>(jn);
-    else return T(2) * log2_of_product<T, V>(jd) - log2_of_product<T, V>(jn);
+      for (int j = 0; j < V; ++j) rqs_eval_factors<T, INV>(A[j], B[j], lim[j], p.v[j], jn[j], jd[j]);
+      return rqs_log2_of_factors<T, V, INV>(jn, jd);
+    } else {
+      T l = T(0);
+#pragma unroll
+      for (int j = 0; j < V; ++j) l += rqs_eval<T, INV>(A[j], B[j], lim[j], p.v[j]);
+      return l;
+    }
   };
   const GroupMasks gm = make_group_masks(G);
   Pack<T, V> pn0, pn1;
@@ -506,8 +545,9 @@ __global__ __launch_bounds__(256) void rqs_lds_kernel(const T* __restrict__ blob
                                                       const T* __restrict__ x, T* __restrict__ y, T* __restrict__ ladj_ps, int64_t dim,
                                                       int64_t batch, int G, int iters, int accumulate, const BjxFin fin, int64_t ld) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // no static LDS: with the C3 table (32 768 bytes) five blocks fit the CU's 160 KiB only if the block asks for nothing else;
-  // the reduction scratch aliases the table once every wave is done with it
+  // no static LDS (the reduction scratch aliases the table once every wave is done with it).  The launch asks for the NO-SKIP layout
+  // (C3: 38 912 bytes — whether bin 0 can be dropped is decided on the device, after the launch was sized): FOUR blocks per CU.  Five
+  // (97 -> 96 VGPRs and a 32 KiB request) were built and measured in round 6: no gain (profiles/r06_c3_experiments.md).
   T* blob_l = reinterpret_cast<T*>(smem);
   const int skip0 = DUAL ? flag[0] : 0;
   const RqsGeom g = rqs_geom(K1, dim, V, skip0, NSTEP_HI, G);
@@ -850,7 +890,7 @@ constexpr int kRqsBlobGrid = 8;           // blocks of the table-building helper
 // 8-16 KiB of data is not free); and FIVE blocks per CU instead of four (no static LDS, the reduction scratch aliases the dead
 // table: 5 x 32 KiB = 160 KiB) — neutral, kept because it costs nothing.
 inline int rqs_iters(const bjx_ctx* ctx, size_t blob_bytes, int64_t bytes_per_group, int64_t groups) {
-  static const int forced = 0;   // tuning switch
+  static const int forced = 0;   // (round 6 swept 16 ... 64 trips per block through a temporary switch: all within the run-to-run spread, profiles/r06_c3_experiments.md)
   if (forced > 0) return forced;
   int64_t amort = (3 * (int64_t)blob_bytes + bytes_per_group - 1) / bytes_per_group;
   if (amort < 1) amort = 1;

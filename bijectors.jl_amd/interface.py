@@ -32,7 +32,7 @@ __all__ = [
     "Shift", "Scale", "Logit", "LeakyReLU", "TruncatedBijector", "SignFlip", "OrderedBijector", "SimplexBijector",
     "VecCholeskyBijector", "VecCorrBijector", "CorrBijector", "PDBijector", "PDVecBijector", "Permute", "PlanarLayer", "RadialLayer", "InvertibleBatchNorm", "RationalQuadraticSpline",
     "PartitionMask", "Coupling", "Stacked", "NamedStacked", "Columnwise", "columnwise", "vjp", "istraining", "training", "transform", "inverse", "logabsdetjac", "with_logabsdet_jacobian",
-    "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context",
+    "with_logabsdet_jacobian_", "transform_", "output_size", "isinvertible", "isclosedform", "colmajor", "context", "_fast_plans",
     "PlanarResult", "vjp_params", "row_moments", "MvNormal", "TorchBase", "TransformedDistribution", "transformed", "logpdf", "rand",
     "CapturedStep", "kernel_timed", "cache_params", "invalidate_params",
 ]
@@ -365,8 +365,16 @@ def _param(p, like: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ interface (src/interface.jl)
+_BIJ_EPOCH = [0]      # bumped when a public attribute of an existing Transform is re-assigned: cached launch plans (`_fast_chain`) die with it
+
+
 class Transform:
     """src/interface.jl:133-135"""
+
+    def __setattr__(self, name, value):
+        if name[0] != "_" and name in self.__dict__:      # a parameter replaced after construction (b.a = new_tensor)
+            _BIJ_EPOCH[0] += 1
+        object.__setattr__(self, name, value)
 
     def __call__(self, x):
         return transform(self, x)
@@ -473,11 +481,128 @@ def logabsdetjac(b, x):
     return _shape_result(b, *b._wlj(x, per_sample=False))[1]
 
 
+# ------------------------------------------------------------------ launch plans: the small-call fast path
+# What a sampler calls on every log-density evaluation is the SAME chain on a small (param_dim x n_chains) array
+# (src/vector/product/fill.jl:146-165, 192-213).  The general path walks the composition, builds the op list, hashes it, allocates
+# three tensors and converts the Float64 sum with a torch launch: 31-41 us of host time for a 5-15 us kernel
+# (profiles/r05_host_overhead.txt).  Here the op list of (bijector object, dtype, rows, device, stream, return shape) is validated
+# ONCE into a `bjx_plan` (include/bjx.h "plans") kept on the bijector object; a call is then: shape / layout checks, two
+# `torch.empty`, one ctypes call.  The plan holds parameter POINTERS (the tensors are kept alive next to it): values rewritten in
+# place are seen by the next call; a parameter ATTRIBUTE that is re-assigned bumps `_BIJ_EPOCH` and the plan is rebuilt.
+class _FastPlan:
+    __slots__ = ("h", "epoch", "keep", "ctx", "f32")
+
+    def __init__(self, h, epoch, keep, ctx, f32):
+        self.h, self.epoch, self.keep, self.ctx, self.f32 = h, epoch, keep, ctx, f32
+
+    def __del__(self):
+        try:
+            if self.h is not None:
+                L.load().bjx_plan_destroy(self.h)
+        except Exception:
+            pass
+
+
+_FAST_OFF = [False]       # tests / A-B: `bj._fast_plans(False)` takes every call through the general path
+
+
+def _fast_plans(on: bool = True) -> None:
+    _FAST_OFF[0] = not on
+
+
+def _fast_build(owner, get_ops, x, dim, per_sample, key):
+    def not_applicable():                              # remembered too: the next call of this shape goes straight to the general path
+        fp = _FastPlan(None, _BIJ_EPOCH[0], None, None, False)
+        owner.__dict__.setdefault("_fast", {})[key] = fp
+        return fp
+
+    ops = get_ops()
+    if ops is None or len(ops) > L.BJX_MAX_OPS:
+        return not_applicable()
+    ops2 = get_ops()                                   # a parameter that is a TEMPORARY (e.g. the negated shift of an inverse) is a new tensor every time
+    for (k1, a0, a1), (k2, b0, b1) in zip(ops, ops2):
+        for p, q in ((a0, b0), (a1, b1)):
+            if isinstance(p, torch.Tensor) and p is not q:
+                return not_applicable()
+    if _chain_key(ops, x, dim) is None:                # host / other-dtype / broadcast parameters: the general path converts them per call
+        return not_applicable()
+    ctx = context(x.device)
+    arr = (L.BjxOp * max(len(ops), 1))()
+    keep = []
+    for i, (kind, p0, p1) in enumerate(ops):
+        o = arr[i]
+        o.kind, o.param_len, o.p0, o.p1, o.v0, o.v1 = kind, 0, 0.0, 0.0, None, None
+        for j, p in enumerate((p0, p1)):
+            if p is None:
+                continue
+            if isinstance(p, torch.Tensor) and p.dim() > 0 and p.numel() != 1:
+                keep.append(p)
+                o.param_len = dim
+                setattr(o, f"v{j}", p.data_ptr())
+            else:
+                o.param_len = max(o.param_len, 1)
+                setattr(o, f"p{j}", float(p))
+    flags = L.BJX_REF_VECTOR_SCALE_LADJ if per_sample is False else 0
+    h = C.c_void_p()
+    L.check(ctx.h, L.load().bjx_plan_chain(ctx.h, _dt(x), arr, len(ops), dim, flags, C.byref(h)), "bjx_plan_chain")
+    fp = _FastPlan(h, _BIJ_EPOCH[0], keep, ctx, x.dtype == torch.float32)
+    owner.__dict__.setdefault("_fast", {})[key] = fp
+    return fp
+
+
+def _fast_chain(owner, get_ops, x, per_sample):
+    """-> (y, ladj) through a cached bjx_plan, or None when this call does not qualify (then the general path runs)."""
+    if _FAST_OFF[0] or not isinstance(x, torch.Tensor) or not x.is_cuda or _OUT_HINT:
+        return None
+    nd = x.dim()
+    if nd == 2:
+        dim, batch = x.shape
+        if x.stride(0) != 1 or (batch > 1 and x.stride(1) != dim) or dim == 0 or batch == 0:
+            return None
+    elif nd == 1:
+        dim, batch = x.shape[0], 1
+        if x.stride(0) != 1 or dim == 0:
+            return None
+    else:
+        return None
+    dt = x.dtype
+    if dt is not torch.float32 and dt is not torch.float64:
+        return None
+    dev = x.device.index
+    if dev != torch._C._cuda_getDevice():
+        return None
+    key = (dt, dim, per_sample, dev, torch._C._cuda_getCurrentRawStream(dev))
+    cache = owner.__dict__.get("_fast")
+    fp = cache.get(key) if cache is not None else None
+    if fp is None or fp.epoch != _BIJ_EPOCH[0]:
+        fp = _fast_build(owner, get_ops, x, dim, per_sample, key)
+    if fp.h is None:
+        return None
+    y = torch.empty(dim, dtype=dt, device=x.device) if nd == 1 else torch.empty((batch, dim), dtype=dt, device=x.device).T
+    run = L.load().bjx_plan_run
+    if per_sample:
+        l = torch.empty(batch, dtype=dt, device=x.device)
+        rc = run(fp.h, x.data_ptr(), y.data_ptr(), l.data_ptr(), None, None, batch)
+    else:
+        l = torch.empty((), dtype=dt, device=x.device)
+        if fp.f32:
+            rc = run(fp.h, x.data_ptr(), y.data_ptr(), None, None, l.data_ptr(), batch)       # the library writes the sum as Float32 too
+        else:
+            rc = run(fp.h, x.data_ptr(), y.data_ptr(), None, l.data_ptr(), None, batch)
+    if rc != 0:
+        L.check(fp.ctx.h, rc, "bjx_plan_run")
+    return y, l
+
+
 def with_logabsdet_jacobian(b, x, per_sample: bool = False):
     """ChangesOfVariables.with_logabsdet_jacobian for the hot-path bijectors.
 
     per_sample=False reproduces the reference's return shape; per_sample=True always returns the
     per-column log-det vector."""
+    if (per_sample is False or per_sample is True) and isinstance(b, (ComposedFunction, _ChainOp, Elementwise, Inverse)):
+        r = _fast_chain(b, lambda: _fused_ops(b), x, per_sample)
+        if r is not None:
+            return r
     if b is identity:
         return _run_chain(_stage_ops(b), x, per_sample, True)
     y, l = b._wlj(x, per_sample=per_sample)

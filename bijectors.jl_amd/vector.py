@@ -250,7 +250,8 @@ def _product_apply(trf, t: ProductVecTransform, x, per_sample, want_ladj):
     if not t.base_size:                                   # univariate components: one elementwise launch
         if X.shape[0] != m:
             raise ValueError(f"DimensionMismatch: expected {m} rows, got {X.shape[0]}")
-        y, l = I._run_chain(trf._ops(False), X, True if want_ladj else False, want_ladj)
+        r = I._fast_chain(t, lambda: trf._ops(False), X, True) if want_ladj else None      # cached launch plan (include/bjx.h "plans")
+        y, l = r if r is not None else I._run_chain(trf._ops(False), X, True if want_ladj else False, want_ladj)
     else:                                                 # vector components: slices become extra columns (zero-copy)
         k_in = X.shape[0] // m
         if k_in * m != X.shape[0]:

@@ -561,6 +561,10 @@ int bjx_time_end(bjx_ctx* ctx, float* ms_out);
  * (at most 1024 per region).  bench.py's roofline.achieved is computed from this. */
 int bjx_kernel_time_begin(bjx_ctx* ctx);
 int bjx_kernel_time_end(bjx_ctx* ctx, float* total_ms, int* launches);
+/* Kernel launches issued by the library in this process so far, all contexts, helpers included (table builders, finalize passes,
+ * packers; memsets and copies are not kernels).  A difference of two readings around a region = the launches of that region: what
+ * bench.py reports as `launches_per_step_all` next to the dominant-kernel count of bjx_kernel_time_end. */
+uint64_t bjx_launch_count(void);
 
 /* ---- captured steps (hipGraph) -------------------------------------------------------------------------------------
  * For small shards a step (kernel + finalize + the 8-byte all-reduce) is launch-bound: capture it once, replay it
@@ -576,6 +580,26 @@ int bjx_graph_begin(bjx_ctx* ctx);
 int bjx_graph_end(bjx_ctx* ctx, bjx_graph** out);
 int bjx_graph_launch(bjx_ctx* ctx, bjx_graph* graph);   /* asynchronous on the context stream */
 int bjx_graph_destroy(bjx_graph* graph);
+
+/* ---------------------------------------------------------------- plans
+ * What a sampler calls thousands of times per second is the SAME bijector on a small (param_dim x n_chains) array
+ * (src/vector/product/fill.jl:146-165, 192-213: one `from_linked_vec` / `to_linked_vec` per log-density evaluation): the kernel takes
+ * 5-15 us, and a host that walks the bijector, marshals the op list and checks the shapes on every call spends 3-8x that
+ * (profiles/r05_host_overhead.txt).  A plan holds everything of the call that does not change — validated once — so that a call is
+ * the data pointers and the batch.  A plan belongs to the context it was made for (same stream, same thread rules) and holds parameter
+ * POINTERS, never values: the caller keeps the parameter arrays alive and may rewrite them in place between runs.
+ *   bjx_plan_chain        an elementwise chain (bjx_chain's ops / dim / flags)
+ *   bjx_plan_structured   BJX_PLAN_SIMPLEX / BJX_PLAN_ORDERED (bjx_simplex / bjx_ordered; `dim` = rows of the INPUT)
+ *   bjx_plan_run          in / out / ladj_ps / ladj_sum as in the planned entry.  `ladj_sum_t` (Float32 plans only, may be NULL): the
+ *                         sum once more as T[1] = Float32, written by the same epilogue that finishes ladj_sum — the reference returns
+ *                         the scalar in the element type, and a host-side conversion is another launch.  With ladj_sum_t given,
+ *                         ladj_sum may be NULL (the Float64 accumulator then lives in the context). */
+typedef struct bjx_plan bjx_plan;
+enum { BJX_PLAN_CHAIN = 1, BJX_PLAN_SIMPLEX = 2, BJX_PLAN_ORDERED = 3 };
+int bjx_plan_chain(bjx_ctx* ctx, bjx_dtype dt, const bjx_op* ops, int n_ops, int64_t dim, uint32_t flags, bjx_plan** out);
+int bjx_plan_structured(bjx_ctx* ctx, bjx_dtype dt, int kind, int inverse, int64_t dim, uint32_t flags, bjx_plan** out);
+int bjx_plan_run(bjx_plan* plan, const void* in, void* out, void* ladj_ps, double* ladj_sum, void* ladj_sum_t, int64_t batch);
+int bjx_plan_destroy(bjx_plan* plan);
 
 #ifdef __cplusplus
 }

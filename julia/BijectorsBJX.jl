@@ -139,6 +139,7 @@ function set_stream!(stream=AMDGPU.stream())
 end
 synchronize() = check(ccall((:bjx_synchronize, libbjx), Cint, (Ptr{Cvoid},), ctx().h), "bjx_synchronize")
 check_state() = check(ccall((:bjx_check_state, libbjx), Cint, (Ptr{Cvoid},), ctx().h), "bjx_check_state")
+launch_count() = Int(ccall((:bjx_launch_count, libbjx), UInt64, ()))      # kernel launches of the library so far (helpers included): launches of a region = a difference
 workspace_bytes() = Int(ccall((:bjx_workspace_bytes, libbjx), Csize_t, (Ptr{Cvoid},), ctx().h))
 const BJX_OPT_COLLECTIVE_TIMEOUT_MS = Cint(2)
 collective_timeout!(ms::Integer) = check(ccall((:bjx_set_option, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint), ctx().h, BJX_OPT_COLLECTIVE_TIMEOUT_MS, Cint(ms)), "bjx_set_option")   # watchdog of synchronize()
@@ -234,24 +235,73 @@ const ElementwiseLeaf = Union{Elementwise{typeof(exp)},Elementwise{typeof(log)},
 const FusableLeaf = Union{ElementwiseLeaf,Inverse{<:Scale{<:Union{Real,AbstractVector}}},Inverse{<:Logit},Inverse{<:TruncatedBijector}}   # one op each
 const Fusable = Union{FusableLeaf,ComposedFunction}
 
+# C-level launch plans (include/bjx.h "plans"; VERDICT r05 "do this" #6): what a sampler calls on every log-density evaluation is the
+# SAME chain on a small (param_dim x n_chains) array (src/vector/product/fill.jl:146-165, 192-213) — walking `outer ∘ inner`, uploading
+# nothing but still allocating the op vector and re-validating it costs more than the 5-15 us kernel.  The op list of a (bijector,
+# element type, height, flags) is marshalled ONCE into a `bjx_plan` kept by the CONTEXT of the calling task (a plan belongs to its
+# context); a call is then bjx_plan_run(plan, x, y, lps, lsum, C_NULL, batch).  The plan holds parameter POINTERS (`keep` keeps the
+# arrays alive), never values: parameters rewritten in place are seen by the next run.
+mutable struct CPlan
+    h::Ptr{Cvoid}
+    keep::Vector{Any}
+end
+const CPLANS_LOCK = ReentrantLock()
+const CPLANS = Dict{Tuple{Ptr{Cvoid},UInt,DataType,Int,UInt32},CPlan}()         # (context, objectid(bijector), T, rows, flags); guarded by CPLANS_LOCK
+function chain_cplan(b, ::Type{T}, o::Vector{BjxOp}, keep, d::Int, flags::UInt32) where {T}
+    c = ctx()
+    key = (c.h, objectid(b), T, d, flags)
+    lock(CPLANS_LOCK) do
+        get!(CPLANS, key) do
+            hp = Ref{Ptr{Cvoid}}(C_NULL)
+            GC.@preserve o keep check(ccall((:bjx_plan_chain, libbjx), Cint, (Ptr{Cvoid}, Cint, Ptr{BjxOp}, Cint, Int64, UInt32, Ptr{Ptr{Cvoid}}),
+                                            c.h, dtype(T), o, length(o), d, flags, hp), "bjx_plan_chain")
+            cp = CPlan(hp[], copy(keep))
+            finalizer(x -> ccall((:bjx_plan_destroy, libbjx), Cint, (Ptr{Cvoid},), x.h), cp)
+            cp
+        end
+    end
+end
+# the two structured bijectors a Dirichlet / ordered model variable uses on every evaluation
+function structured_cplan(kind::Cint, inv::Bool, ::Type{T}, d::Int, flags::UInt32) where {T}
+    c = ctx()
+    key = (c.h, UInt(kind) * UInt(2) + UInt(inv), T, d, flags)
+    lock(CPLANS_LOCK) do
+        get!(CPLANS, key) do
+            hp = Ref{Ptr{Cvoid}}(C_NULL)
+            check(ccall((:bjx_plan_structured, libbjx), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Int64, UInt32, Ptr{Ptr{Cvoid}}),
+                        c.h, dtype(T), kind, Cint(inv), d, flags, hp), "bjx_plan_structured")
+            cp = CPlan(hp[], Any[])
+            finalizer(x -> ccall((:bjx_plan_destroy, libbjx), Cint, (Ptr{Cvoid},), x.h), cp)
+            cp
+        end
+    end
+end
+const BJX_PLAN_SIMPLEX, BJX_PLAN_ORDERED = Cint(2), Cint(3)
+plan_run(cp::CPlan, px, out, lps, lsum, n) = ccall((:bjx_plan_run, libbjx), Cint,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64), cp.h, px, out, lps, lsum, C_NULL, n)
+
 function plan(b::Fusable, x::ROCArray{T}) where {T<:BjxFloat}
     keep = Any[]
     o = ops(b, T, keep)
     (o === nothing || length(o) > 8) && return nothing          # BJX_MAX_OPS; arbitrary Transforms inside ∘: generic path
     d, n = x isa ROCVecOrMat ? dims(x) : (length(x), 1)          # higher-rank arrays: elementwise over everything
     h = ctx().h; px = devptr(x); push!(keep, o)
-    launch = (out, lps, lsum, fl) -> ccall((:bjx_chain, libbjx), Cint,
+    base = BJX_REF_VECTOR_SCALE_LADJ
+    cp = chain_cplan(b, T, o, keep, Int(d), base); push!(keep, cp)
+    launch = (out, lps, lsum, fl) -> fl == base ? plan_run(cp, px, out, lps, lsum, n) :          # the plan's flags; anything else (BJX_ACCUMULATE, per-column shape) marshals per call
+        ccall((:bjx_chain, libbjx), Cint,
         (Ptr{Cvoid}, Cint, Ptr{BjxOp}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
         h, dtype(T), o, length(o), px, out, lps, lsum, d, n, fl)
     # the reference returns ONE scalar for elementwise bijectors (§8a'), with scale.jl:31-32's no-xN quirk
-    return Plan(:bjx_chain, size(x), :scalar, n, true, true, BJX_REF_VECTOR_SCALE_LADJ, keep, launch)
+    return Plan(:bjx_chain, size(x), :scalar, n, true, true, base, keep, launch)
 end
 
 # ---------------------------------------------------------------- structured bijectors
 # OrderedBijector, ordered.jl:22-80 (per-column log-det vector)
 function plan_ordered(inv::Bool, x::ROCVecOrMat{T}) where {T<:BjxFloat}
     d, n = dims(x); h = ctx().h; px = devptr(x)
-    launch = (out, lps, lsum, fl) -> ccall((:bjx_ordered, libbjx), Cint,
+    cp = structured_cplan(BJX_PLAN_ORDERED, inv, T, Int(d), UInt32(0))
+    launch = (out, lps, lsum, fl) -> fl == UInt32(0) ? plan_run(cp, px, out, lps, lsum, n) : ccall((:bjx_ordered, libbjx), Cint,
         (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
         h, dtype(T), Cint(inv), px, out, lps, lsum, d, n, fl)
     return Plan(:bjx_ordered, size(x), x isa ROCVector ? :scalar : :column, n, false, false, UInt32(0), Any[], launch)
@@ -264,7 +314,8 @@ function plan_simplex(inv::Bool, x::ROCVecOrMat{T}) where {T<:BjxFloat}
     r, n = dims(x); K = inv ? r + 1 : r
     h = ctx().h; px = devptr(x)
     osz = x isa ROCVector ? (inv ? (K,) : (K - 1,)) : (inv ? (K, n) : (K - 1, n))
-    launch = (out, lps, lsum, fl) -> ccall((:bjx_simplex, libbjx), Cint,
+    cp = structured_cplan(BJX_PLAN_SIMPLEX, inv, T, Int(r), UInt32(0))           # `dim` of a structured plan = rows of the INPUT
+    launch = (out, lps, lsum, fl) -> fl == UInt32(0) ? plan_run(cp, px, out, lps, lsum, n) : ccall((:bjx_simplex, libbjx), Cint,
         (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
         h, dtype(T), Cint(inv), px, out, lps, lsum, K, n, fl)
     return Plan(:bjx_simplex, osz, :scalar, n, !inv, false, UInt32(0), Any[], launch)

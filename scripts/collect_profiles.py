@@ -77,7 +77,7 @@ def main(tag):
     traffic["_tag"] = tag
     json.dump(traffic, open(traffic_path, "w"), indent=1)
     for extra in ("bench_default.json", "bench_default_detail.json", "rows.md", "rows_kernel_stats.csv", "f64_rows.md", "f64math_bench.txt", "planar_mfma_ab.txt", "small_sizes.md",
-                  "lib_sha16.txt", "lib_bytes.txt", "first_call.txt", "ordered_tall.md", "planar_heights.md", "small_dims.md", "host_overhead.txt", "c3_table_policy.txt"):
+                  "kernel_trace_timed.jsonl", "lib_sha16.txt", "lib_bytes.txt", "first_call.txt", "ordered_tall.md", "planar_heights.md", "small_dims.md", "host_overhead.txt", "c3_table_policy.txt"):
         pe = os.path.join(src, extra)
         if os.path.exists(pe) and os.path.getsize(pe) > 2:
             with open(pe) as fi, open(os.path.join(dst, f"{tag}_{extra}"), "w") as fo:
@@ -90,7 +90,49 @@ def main(tag):
     mv = os.path.join(src, "matrix_vjp_errors.jsonl")
     if os.path.exists(mv):
         write_matrix_vjp_table(mv, os.path.join(dst, f"{tag}_matrix_vjp_errors.md"), tag)
+    ve = os.path.join(src, "vjp_errors.jsonl")
+    if os.path.exists(ve):
+        write_vjp_error_table(ve, os.path.join(dst, f"{tag}_vjp_errors.md"), tag)
     print(json.dumps({k: v for k, v in traffic.items() if k != "_how"}, indent=1)[:3000])
+
+
+def write_vjp_error_table(jsonl, out_md, tag):
+    """tests/_tol.py (flat_close) records the worst error of every pullback / density comparison of the GPU suites: one row per
+    (family, dtype), the family being the record's label with its shape numbers taken out."""
+    import re
+    from collections import OrderedDict
+
+    rows = [json.loads(l) for l in open(jsonl) if l.strip()]
+    agg = OrderedDict()
+    for r in rows:
+        fam = re.sub(r"\b(dim|K|N|layers|dt|seed|uplo|lbar|inv|inverse)=[^ :,]+", "", r["what"])
+        fam = re.sub(r"\s+", " ", fam).strip(" :,")
+        a = agg.setdefault((fam, r["dtype"], r["per"], bool(r.get("conditioned"))), {"n": 0, "worst": 0.0, "what": "", "over": 0.0, "amp": None, "frac": 0.0, "flatcol": 0.0})
+        a["n"] += 1
+        if r["worst"] >= a["worst"]:
+            a["worst"], a["what"] = r["worst"], r["what"]
+            a["amp"] = r.get("amp_at_worst")
+        a["over"] = max(a["over"], r.get("worst_over_allowed", r["worst_over_rtol"]))
+        a["frac"] = max(a["frac"], r.get("frac_over_flat", 0.0))
+        if r.get("worst_flat_column") is not None:
+            a["flatcol"] = max(a["flatcol"], r["worst_flat_column"])
+    out = [f"# {tag} — measured errors of every pullback / density comparison of the GPU suites (`tests/_tol.py`, GPU vs the FD-pinned oracle)", "",
+           "Bar: north_star's FLAT relative tolerance, 1e-3 Float32 / 1e-6 Float64, on the stated scale — `sample`: max-norm of the reference cotangent of that column;",
+           "`tensor`: max-norm of the (small) parameter-cotangent tensor; `element`: |ref| + 1 (log-densities).  No multiplier anywhere (`grep -c \"RTOL\\[dt\\] \\* [0-9]\" tests/test_gpu_*.py` = 0).",
+           "Rows marked *conditioned* add, per column, `max(rtol, 4·a)` with a first-order amplification `a` computed by the test from the data and printed:",
+           "Simplex in Float32: `a = sqrt(K)·eps/(2·min remainder)` (the running stick sum every Float32 evaluation carries, the reference's included);",
+           "inverse PlanarLayer: `a = eps·(Π_l max(1, 1/d_l))²`, `d_l = 1 + wᵀû·sech²` the layer's determinant.  For those rows `worst / bar` is against the conditioned bar, the",
+           "share of columns over the FLAT bar and the worst column that had no allowance are listed too.",
+           f"Source: the pytest run of `profiles/{tag}_pytest_gpu_tail.txt` ({len(rows)} comparisons).", "",
+           "| comparison | dtype | scale | checks | worst error | worst / bar | conditioned: amplification at worst, columns over flat, worst un-allowanced column |", "|---|---|---|---|---|---|---|"]
+    for (fam, dt, per, cond), a in sorted(agg.items(), key=lambda kv: (kv[0][1], -kv[1]["over"])):
+        extra = f"a = {a['amp']:.2e}, {100 * a['frac']:.1f} %, {a['flatcol']:.2e}" if cond and a["amp"] is not None else ""
+        out.append(f"| {fam} | {dt} | {per} | {a['n']} | {a['worst']:.2e} | {a['over']:.3f} | {extra} |")
+    for dt, bar in (("float32", 1e-3), ("float64", 1e-6)):
+        flat = [a["worst"] for (f, d, p, c), a in agg.items() if d == dt and not c]
+        if flat:
+            out += ["", f"Worst {dt} on the flat bar: {max(flat):.2e} (bar {bar:.0e}); {sum(a['n'] for (f, d, p, c), a in agg.items() if d == dt)} comparisons."]
+    open(out_md, "w").write("\n".join(out) + "\n")
 
 
 def write_matrix_vjp_table(jsonl, out_md, tag):

@@ -61,17 +61,17 @@ stats)
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$WL -o $WL -- python $R/bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline --no-rows > $R/gpurun_out/rocprof_$WL.log 2>&1 )
   f=$(ls gpurun_out/prof_$WL/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && { cp "$f" gpurun_out/${WL}_kernel_stats.csv; head -8 "$f" | cut -c1-200; }; rm -rf gpurun_out/prof_$WL ;;
 profile)
-  TAG=${1:-r05}; shift
+  TAG=${1:-r06}; shift
   WLS=${@:-c2 c2v c3 c4 c5a c5b vcorr pdvec}
   O=$R/gpurun_out/$TAG; mkdir -p $O
   # the binary this evidence belongs to (tests/test_profiles_fresh.py compares kernel names with the .so in the tree)
   sha256sum bijectors.jl_amd/libbjx_hip.so | cut -c1-16 > $O/lib_sha16.txt; stat -c %s bijectors.jl_amd/libbjx_hip.so > $O/lib_bytes.txt
   python scripts/probe_first_call.py > $O/first_call.txt 2>&1
   cat $O/first_call.txt
-  rm -f gpurun_out/matrix_vjp_errors.jsonl
+  rm -f gpurun_out/matrix_vjp_errors.jsonl gpurun_out/vjp_errors.jsonl $O/kernel_trace_timed.jsonl
   echo "== default bench line (what the driver runs: first on a fresh box — after the 2.5 min of the test suite the same line reads C3 1-3 % lower, profiles/r05_bench_repeats.md)"; timeout 900 python bench.py > $O/bench_default.json 2>$O/bench_default.err; wc -c $O/bench_default.json; cp gpurun_out/bench_detail.json $O/bench_default_detail.json 2>/dev/null
   echo "== pytest -m gpu"; ( time timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 -p no:cacheprovider ) > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt
-  cp gpurun_out/matrix_vjp_errors.jsonl $O/ 2>/dev/null
+  cp gpurun_out/matrix_vjp_errors.jsonl gpurun_out/vjp_errors.jsonl $O/ 2>/dev/null
   for wl in $WLS; do
     timeout 600 python bench.py --workload $wl --no-rows --steps 20 --warmup 5 2>$O/bench_$wl.err | tail -1 > $O/bench_$wl.json; echo "== bench $wl: $(cut -c1-120 $O/bench_$wl.json)"
   done
@@ -94,6 +94,8 @@ profile)
   for wl in $WLS; do
     ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o $wl -- python $R/bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-rows > $O/rocprof_$wl.log 2>&1 )
     f=$(ls $O/prof_$wl/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && { cp "$f" $O/${wl}_kernel_stats.csv; echo "-- kernel stats $wl"; head -3 "$f" | cut -c1-160; }
+    # the same trace, timed launches only (after bench.py's pre-roll): median / min / mean — what the line's kernel_ms must agree with
+    f=$(ls $O/prof_$wl/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$f" ] && python scripts/trace_stats.py "$f" $wl 60 >> $O/kernel_trace_timed.jsonl
     for c in FETCH_SIZE WRITE_SIZE; do
       ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${wl}_$c -o $wl -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-rows > $O/rocprof_pmc_${wl}_$c.log 2>&1 )
       f=$(ls $O/pmc_${wl}_$c/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $O/${wl}_pmc_$c.csv

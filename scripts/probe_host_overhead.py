@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--calls", type=int, default=3000)
     ap.add_argument("--top", type=int, default=18)
     ap.add_argument("--only", default="")
+    ap.add_argument("--no-plans", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     d, n = 1001, 16
@@ -34,13 +35,25 @@ def main():
     flow = layers[0]
     for l in layers[1:]:
         flow = l @ flow
+    # f-2 shapes (src/vector/product/fill.jl:146-165, 192-213): what a sampler calls per log-density evaluation — the linked vector of a
+    # product distribution, one column per chain
+    V = bj.vector
+    x64 = torch.randn(256, 64, device=dev).T                                   # 64 parameters x 256 chains
+    link64 = V.from_linked_vec(V.scalar_to_scalar_bijector(0.0, float("inf")), (64,))
+    link1000 = V.from_linked_vec(V.scalar_to_scalar_bijector(0.0, 1.0), (1000,))
+    x1000 = torch.randn(n, 1000, device=dev).T                                 # 1 000 parameters x 16 chains
     cases = {
         "chain fwd (scalar params) 1001 x 16": lambda: bj.with_logabsdet_jacobian(chain, x),
         "chain fwd per_sample (vector params)": lambda: bj.with_logabsdet_jacobian(mf, x, per_sample=True),
+        "f-2 from_linked_vec(positive) 64 x 256 chains": lambda: bj.with_logabsdet_jacobian(link64, x64, per_sample=True),
+        "f-2 from_linked_vec(unit interval) 1000 x 16 chains": lambda: bj.with_logabsdet_jacobian(link1000, x1000, per_sample=True),
         "chain vjp": lambda: bj.vjp(chain, x, g, lb),
         "vjp_params(mean-field chain)": lambda: bj.vjp_params(mf, x, g, lb),
         "8 x PlanarLayer composition 128 x 16": lambda: bj.with_logabsdet_jacobian(flow, x128),
     }
+    if a.no_plans:
+        bj._fast_plans(False)               # the general path of rounds 1-5 (op list walked, marshalled and hashed per call)
+        print("(launch plans OFF: general path)")
     for name, fn in cases.items():
         if a.only and a.only not in name:
             continue

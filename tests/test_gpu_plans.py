@@ -1,0 +1,237 @@
+"""Launch plans (include/bjx.h "plans"; VERDICT r05 "do this" #6): `bjx_plan_chain / _structured / _run / _destroy` through the C ABI, and the
+host mirror's small-call fast path built on them — results bit-identical to the general path (same kernels, same arguments), parameter
+updates seen, host time per call measured and recorded (profiles/r06_host_overhead.txt is the full profile).
+Reference call shape: src/vector/product/fill.jl:146-165, 192-213 (one `from_linked_vec` per log-density evaluation)."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bj():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    import bijectors_amd
+
+    bijectors_amd._lib.load()
+    return bijectors_amd
+
+
+def _cm(a):
+    return torch.from_numpy(np.ascontiguousarray(a.T)).cuda().T
+
+
+def _chains(bj, dim, dt):
+    r = np.random.default_rng(3)
+    av = torch.from_numpy(np.linspace(0.5, 1.5, dim).astype(dt)).cuda()
+    bv = torch.from_numpy(r.normal(size=dim).astype(dt)).cuda()
+    return {
+        "affexp_s": bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5),
+        "affexp_v": bj.elementwise(bj.exp) @ bj.Shift(bv) @ bj.Scale(av),
+        "scale_only": bj.Scale(-1.7),                           # constant log-det: no shared epilogue, the cast launch serves ladj_sum_t
+        "exp": bj.elementwise(bj.exp),
+        "inv_logit": bj.inverse(bj.Logit(-1.0, 2.0)),
+        "leaky_logit": bj.LeakyReLU(0.3) @ bj.Logit(-3.0, 3.0),
+        "inv_shift_v": bj.inverse(bj.Shift(bv)),                # its op holds a TEMPORARY (-bv): must take the general path, and still be right
+    }
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(64, 256), (1000, 16), (7, 1), (33,)])
+def test_fast_path_equals_general_path_bit_for_bit(bj, shape, dt):
+    r = np.random.default_rng(8)
+    dim = shape[0]
+    x = r.uniform(-0.9, 0.9, size=shape).astype(dt)
+    xd = _cm(x) if x.ndim == 2 else torch.from_numpy(x).cuda()
+    for name, b in _chains(bj, dim, dt).items():
+        for ps in (False, True):
+            bj._fast_plans(False)
+            try:
+                y0, l0 = bj.with_logabsdet_jacobian(b, xd, per_sample=ps)
+            finally:
+                bj._fast_plans(True)
+            y1, l1 = bj.with_logabsdet_jacobian(b, xd, per_sample=ps)          # builds the plan
+            y2, l2 = bj.with_logabsdet_jacobian(b, xd, per_sample=ps)          # runs it
+            for y, l in ((y1, l1), (y2, l2)):
+                assert y.shape == y0.shape and l.shape == l0.shape and l.dtype == l0.dtype, (name, ps)
+                assert torch.equal(y, y0), (name, ps)
+                assert torch.equal(l, l0), (name, ps, float(l.reshape(-1)[0]), float(l0.reshape(-1)[0]))
+    fast = _chains(bj, dim, dt)["affexp_v"]
+    bj.with_logabsdet_jacobian(fast, xd)
+    assert any(fp.h is not None for fp in fast.__dict__["_fast"].values()), "the vector-parameter chain did not get a plan"
+    tmp = _chains(bj, dim, dt)["inv_shift_v"]
+    bj.with_logabsdet_jacobian(tmp, xd)
+    assert all(fp.h is None for fp in tmp.__dict__["_fast"].values()), "a chain with a temporary parameter must not be planned"
+
+
+def test_plans_see_in_place_updates_and_reassigned_parameters(bj):
+    dim, n = 40, 64
+    x = _cm(np.random.default_rng(1).normal(size=(dim, n)))
+    a = torch.full((dim,), 2.0, dtype=torch.float64, device="cuda")
+    b = bj.elementwise(bj.exp) @ bj.Scale(a)
+    y1, _ = bj.with_logabsdet_jacobian(b, x)
+    y1b, _ = bj.with_logabsdet_jacobian(b, x)
+    assert torch.equal(y1, torch.exp(2.0 * x)) and torch.equal(y1b, y1)
+    a.mul_(0.5)                                                   # in place: the plan holds the pointer
+    y2, l2 = bj.with_logabsdet_jacobian(b, x)
+    assert torch.equal(y2, torch.exp(1.0 * x))
+    sc = b._stages()[0]
+    sc.a = torch.full((dim,), 3.0, dtype=torch.float64, device="cuda")          # re-assigned: epoch bump, plan rebuilt
+    y3, _ = bj.with_logabsdet_jacobian(b, x)
+    assert torch.equal(y3, torch.exp(3.0 * x))
+    # another stream = another context = another plan
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        y4, _ = bj.with_logabsdet_jacobian(b, x)
+    s.synchronize()
+    assert torch.equal(y4, y3) and len(b.__dict__["_fast"]) >= 2
+
+
+def test_f2_product_transform_uses_a_plan_and_matches(bj):
+    V = bj.vector
+    r = np.random.default_rng(2)
+    t = V.from_linked_vec(V.scalar_to_scalar_bijector(0.0, 1.0), (1000,))
+    x = _cm(r.normal(size=(1000, 16)).astype(np.float32))
+    bj._fast_plans(False)
+    try:
+        y0, l0 = bj.with_logabsdet_jacobian(t, x, per_sample=True)
+    finally:
+        bj._fast_plans(True)
+    y1, l1 = bj.with_logabsdet_jacobian(t, x, per_sample=True)
+    y2, l2 = bj.with_logabsdet_jacobian(t, x, per_sample=True)
+    assert torch.equal(y1, y0) and torch.equal(l1, l0) and torch.equal(y2, y0) and torch.equal(l2, l0)
+    assert any(fp.h is not None for fp in t.__dict__["_fast"].values())
+
+
+def test_plan_entries_through_the_c_abi(bj):
+    L = bj._lib
+    lib = L.load()
+    ctx = bj.context()
+    r = np.random.default_rng(4)
+    dim, n = 64, 300
+    x = _cm(r.normal(size=(dim, n)).astype(np.float32))
+    y, y_ref = torch.empty_like(x), torch.empty_like(x)
+    ops = (L.BjxOp * 3)(L.BjxOp(L.OP_SCALE, 1, 0.5, 0.0, None, None), L.BjxOp(L.OP_SHIFT, 1, 0.1, 0.0, None, None), L.BjxOp(L.OP_EXP, 0, 0.0, 0.0, None, None))
+    s_ref = torch.zeros(1, dtype=torch.float64, device="cuda")
+    L.check(ctx.h, lib.bjx_chain(ctx.h, L.BJX_F32, ops, 3, C.c_void_p(x.data_ptr()), C.c_void_p(y_ref.data_ptr()), None, C.c_void_p(s_ref.data_ptr()), dim, n, 0), "bjx_chain")
+    h = C.c_void_p()
+    L.check(ctx.h, lib.bjx_plan_chain(ctx.h, L.BJX_F32, ops, 3, dim, 0, C.byref(h)), "bjx_plan_chain")
+    try:
+        s64 = torch.zeros(1, dtype=torch.float64, device="cuda")
+        s32 = torch.zeros(1, dtype=torch.float32, device="cuda")
+        n0 = lib.bjx_launch_count()
+        L.check(ctx.h, lib.bjx_plan_run(h, x.data_ptr(), y.data_ptr(), None, s64.data_ptr(), s32.data_ptr(), n), "bjx_plan_run")
+        assert lib.bjx_launch_count() - n0 == 1, "a planned chain call with both sums is ONE launch"
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_ref) and torch.equal(s64, s_ref)
+        assert float(s32) == float(np.float32(float(s64)))
+        # the Float32 sum alone (the Float64 accumulator then lives in the context)
+        s32.zero_()
+        L.check(ctx.h, lib.bjx_plan_run(h, x.data_ptr(), y.data_ptr(), None, None, s32.data_ptr(), n), "bjx_plan_run")
+        torch.cuda.synchronize()
+        assert float(s32) == float(np.float32(float(s_ref)))
+        # per-column log-dets through the plan
+        lps, lps_ref = torch.empty(n, dtype=torch.float32, device="cuda"), torch.empty(n, dtype=torch.float32, device="cuda")
+        L.check(ctx.h, lib.bjx_chain(ctx.h, L.BJX_F32, ops, 3, C.c_void_p(x.data_ptr()), C.c_void_p(y_ref.data_ptr()), C.c_void_p(lps_ref.data_ptr()), None, dim, n, 0), "bjx_chain")
+        L.check(ctx.h, lib.bjx_plan_run(h, x.data_ptr(), y.data_ptr(), lps.data_ptr(), None, None, n), "bjx_plan_run")
+        torch.cuda.synchronize()
+        assert torch.equal(lps, lps_ref)
+    finally:
+        lib.bjx_plan_destroy(h)
+    # argument checks happen at plan time
+    bad = (L.BjxOp * 1)(L.BjxOp(99, 0, 0.0, 0.0, None, None))
+    assert lib.bjx_plan_chain(ctx.h, L.BJX_F32, bad, 1, dim, 0, C.byref(h)) == L.ERR_ARG
+    badlen = (L.BjxOp * 1)(L.BjxOp(L.OP_SCALE, dim + 1, 0.0, 0.0, x.data_ptr(), None))
+    assert lib.bjx_plan_chain(ctx.h, L.BJX_F32, badlen, 1, dim, 0, C.byref(h)) == L.ERR_SHAPE
+    # a Float64 plan has no Float32 sum
+    L.check(ctx.h, lib.bjx_plan_chain(ctx.h, L.BJX_F64, ops, 3, dim, 0, C.byref(h)), "bjx_plan_chain")
+    try:
+        xd = x.double()
+        xd = _cm(xd.cpu().numpy())
+        yd = torch.empty_like(xd)
+        s32 = torch.zeros(1, dtype=torch.float32, device="cuda")
+        assert lib.bjx_plan_run(h, xd.data_ptr(), yd.data_ptr(), None, None, s32.data_ptr(), n) == L.ERR_ARG
+    finally:
+        lib.bjx_plan_destroy(h)
+    assert lib.bjx_plan_structured(ctx.h, L.BJX_F32, 7, 0, dim, 0, C.byref(h)) == L.ERR_ARG
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["simplex", "inv_simplex", "ordered", "inv_ordered"])
+def test_structured_plans_equal_the_direct_entries(bj, kind, dt):
+    L = bj._lib
+    lib = L.load()
+    ctx = bj.context()
+    r = np.random.default_rng(5)
+    K, n = 12, 130
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    bdt = L.BJX_F32 if dt == np.float32 else L.BJX_F64
+    inv = kind.startswith("inv_")
+    if kind == "simplex":
+        x, rows_out, fn, pk = _cm(r.dirichlet(np.ones(K), size=n).T.astype(dt)), K - 1, lib.bjx_simplex, L.BJX_PLAN_SIMPLEX
+    elif kind == "inv_simplex":
+        x, rows_out, fn, pk = _cm(r.normal(size=(K - 1, n)).astype(dt)), K, lib.bjx_simplex, L.BJX_PLAN_SIMPLEX
+    else:
+        xs = r.normal(size=(K, n)).astype(dt)
+        x, rows_out, fn, pk = _cm(np.sort(xs, axis=0) if inv else xs), K, lib.bjx_ordered, L.BJX_PLAN_ORDERED
+    rows_in = x.shape[0]
+    y0 = torch.empty((n, rows_out), dtype=tdt, device="cuda").T
+    y1 = torch.empty_like(y0)
+    l0, l1 = torch.empty(n, dtype=tdt, device="cuda"), torch.empty(n, dtype=tdt, device="cuda")
+    s0, s1 = torch.zeros(1, dtype=torch.float64, device="cuda"), torch.zeros(1, dtype=torch.float64, device="cuda")
+    Kside = K
+    L.check(ctx.h, fn(ctx.h, bdt, int(inv), C.c_void_p(x.data_ptr()), C.c_void_p(y0.data_ptr()), C.c_void_p(l0.data_ptr()), C.c_void_p(s0.data_ptr()), Kside, n, 0), kind)
+    h = C.c_void_p()
+    L.check(ctx.h, lib.bjx_plan_structured(ctx.h, bdt, pk, int(inv), rows_in, 0, C.byref(h)), "bjx_plan_structured")
+    try:
+        L.check(ctx.h, lib.bjx_plan_run(h, x.data_ptr(), y1.data_ptr(), l1.data_ptr(), s1.data_ptr(), None, n), "bjx_plan_run")
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y0) and torch.equal(l1, l0) and torch.equal(s1, s0)
+    finally:
+        lib.bjx_plan_destroy(h)
+
+
+def test_host_time_of_a_small_planned_call(bj):
+    """Host issue time per call of the f-2 shapes with and without plans, printed and recorded (the bar of VERDICT r05 #6 is 12 us from Python;
+    the assertion is the weaker, load-independent one: planned calls cost at most 60 % of the general path's)."""
+    import json
+    import os
+
+    V = bj.vector
+    out = {}
+    for label, t, x in (("from_linked_vec 64 x 256", V.from_linked_vec(V.scalar_to_scalar_bijector(0.0, float("inf")), (64,)), torch.randn(256, 64, device="cuda").T),
+                        ("from_linked_vec 1000 x 16", V.from_linked_vec(V.scalar_to_scalar_bijector(0.0, 1.0), (1000,)), torch.randn(16, 1000, device="cuda").T),
+                        ("exp∘Shift∘Scale 1001 x 16 (scalar log-det)", bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5), torch.randn(16, 1001, device="cuda").T)):
+        ps = "linked" in label
+        res = {}
+        for mode in ("general", "planned"):
+            bj._fast_plans(mode == "planned")
+            try:
+                for _ in range(50):
+                    bj.with_logabsdet_jacobian(t, x, per_sample=ps)
+                torch.cuda.synchronize()
+                best = 1e9
+                for _rep in range(5):
+                    t0 = time.perf_counter()
+                    for _ in range(400):
+                        bj.with_logabsdet_jacobian(t, x, per_sample=ps)
+                    best = min(best, (time.perf_counter() - t0) / 400 * 1e6)
+                    torch.cuda.synchronize()
+                res[mode] = best
+            finally:
+                bj._fast_plans(True)
+        out[label] = res
+        print(f"{label}: general {res['general']:.1f} us/call, planned {res['planned']:.1f} us/call (host issue, best of 5 x 400)")
+        assert res["planned"] <= 0.6 * res["general"], (label, res)
+    try:
+        root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(root, exist_ok=True)
+        json.dump(out, open(os.path.join(root, "plan_host_us.json"), "w"), indent=1)
+    except Exception:
+        pass

@@ -326,7 +326,7 @@ def test_julia_binding_argument_counts_match_the_header():
     h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
     h = re.sub(r"//.*", "", h)
     protos = {}
-    for m in re.finditer(r"\b(?:int|void|const char\s*\*|size_t)\s+(bjx_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", h, flags=re.S):
+    for m in re.finditer(r"\b(?:int|void|const char\s*\*|size_t|uint64_t)\s+(bjx_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", h, flags=re.S):
         args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
         protos[m.group(1)] = len(args)
     assert len(protos) >= 43

@@ -54,6 +54,7 @@ def _c_to_julia(ctype):
     table = {
         "bjx_ctx*": {"Ptr{Cvoid}"}, "bjx_ctx**": {"Ptr{Ptr{Cvoid}}"},
         "bjx_graph*": {"Ptr{Cvoid}"}, "bjx_graph**": {"Ptr{Ptr{Cvoid}}"},
+        "bjx_plan*": {"Ptr{Cvoid}"}, "bjx_plan**": {"Ptr{Ptr{Cvoid}}"},
         "bjx_dtype": {"Cint"}, "int": {"Cint"},
         "const bjx_op*": {"Ptr{BjxOp}"}, "const bjx_segment*": {"Ptr{BjxSegment}"}, "const bjx_block*": {"Ptr{BjxBlock}"},
         "const void*": {"Ptr{Cvoid}"}, "void*": {"Ptr{Cvoid}", "Ptr{UInt8}"}, "const void* const*": {"Ptr{Ptr{Cvoid}}"},
@@ -66,13 +67,13 @@ def _c_to_julia(ctype):
     return table[t]
 
 
-RET = {"int": "Cint", "size_t": "Csize_t", "const char*": "Cstring"}
-N_ENTRIES = 69          # include/bjx.h (63 at the end of round 3 + bjx_pack_vectors + the four bjx_{vec_corr,corr,pd,pd_vec}_vjp + bjx_check_state in round 6)
+RET = {"int": "Cint", "size_t": "Csize_t", "const char*": "Cstring", "uint64_t": "UInt64"}
+N_ENTRIES = 74          # include/bjx.h (63 at the end of round 3 + bjx_pack_vectors + the four bjx_{vec_corr,corr,pd,pd_vec}_vjp + bjx_check_state, bjx_launch_count and the four bjx_plan_* in round 6)
 
 
 def _prototypes():
     protos = {}
-    for m in re.finditer(r"\b(int|size_t|const char\s*\*)\s+(bjx_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", _header(), flags=re.S):
+    for m in re.finditer(r"\b(int|size_t|uint64_t|const char\s*\*)\s+(bjx_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", _header(), flags=re.S):
         ret = re.sub(r"\s+", "", m.group(1)).replace("constchar*", "const char*")
         args = []
         for a in m.group(3).split(","):
