@@ -1127,7 +1127,11 @@ int rqs_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T* d, 
 // Every thread owns ONE row (and one of `cpp` column lanes) and a private slice of LDS accumulators [3K][threads]
 // (bank = thread: conflict-free, no atomics, a fixed order of additions); the block sums its lanes in a fixed order and
 // adds its table to the Float64 table of the call (one atomic add per entry and block).
-template <class T, class A, bool INV>
+// SHARED (round 6): ONE Float64 table [3][K][dim] per block, filled with `ds_add_f64` — the Float64 LDS atomic runs at 3.0 lane-adds
+// per clock per CU on gfx950, nine times the Float32 one (0.33; scripts/probe_lds_atomics.hip, profiles/r06_lds_atomics.txt) — instead
+// of 3·K private Float32 slots per thread (49 KiB per block, 3 blocks per CU, read-add-write chains of LDS latency and a 12 288-read
+// fold at the end): 18 KiB per block, 8 blocks per CU, fire-and-forget adds, sums exact to Float64.
+template <class T, class A, bool INV, bool SHARED>
 __global__ void rqs_knot_vjp_kernel(const T* __restrict__ w, const T* __restrict__ h, const T* __restrict__ d, int K,
                                     const T* __restrict__ x, const T* __restrict__ gbar, const T* __restrict__ lbar,
                                     T* __restrict__ xbar, double* __restrict__ acc, int64_t dim, int64_t batch, int cpp) {
@@ -1138,8 +1142,10 @@ __global__ void rqs_knot_vjp_kernel(const T* __restrict__ w, const T* __restrict
   T* kh = kw + nk;
   T* kd = kh + nk;
   A* priv = reinterpret_cast<A*>(smem + ((3 * nk * sizeof(T) + 15) / 16) * 16);       // [3K][nthr]
+  double* tab = reinterpret_cast<double*>(smem + ((3 * nk * sizeof(T) + 15) / 16) * 16);   // SHARED: [3K][dim]
   for (int64_t i = t; i < nk; i += nthr) { kw[i] = w[i]; kh[i] = h[i]; kd[i] = d[i]; }
-  for (int e = 0; e < 3 * K; ++e) priv[(size_t)e * nthr + t] = A(0);
+  if constexpr (SHARED) { for (int64_t i = t; i < 3 * nk; i += nthr) tab[i] = 0.0; }
+  else { for (int e = 0; e < 3 * K; ++e) priv[(size_t)e * nthr + t] = A(0); }
   __syncthreads();
   const bool active = t < cpp * (int)dim;
   const int row = t % (int)dim, cl = t / (int)dim;
@@ -1234,6 +1240,17 @@ __global__ void rqs_knot_vjp_kernel(const T* __restrict__ w, const T* __restrict
     // knot takes the +0): all six reads, then the adds, then the writes — one LDS round trip instead of six dependent ones.
     const int lo_i = k == 0 ? K - 1 : k - 1;
     const T sgn = k == 0 ? T(-1) : T(1);
+    if constexpr (SHARED) {
+      double* const c0 = tab + lo_i * st + row;                        // knot k (index lo_i) and knot k+1 (index k) of this row, three tables nk apart
+      double* const c1 = tab + k * st + row;
+      atomicAdd(c0, (double)(sgn * gw_k));
+      atomicAdd(c1, (double)gw_k1);
+      atomicAdd(c0 + nk, (double)(sgn * gh_k));
+      atomicAdd(c1 + nk, (double)gh_k1);
+      if (k != 0) atomicAdd(c0 + 2 * nk, (double)(g * y_dk + lb * l_dk));
+      if (k != K - 1) atomicAdd(c1 + 2 * nk, (double)(g * y_dk1 + lb * l_dk1));
+      continue;
+    }
     A* const pw0 = priv + (0 * K + lo_i) * nthr + t;
     A* const pw1 = priv + (0 * K + k) * nthr + t;
     A* const ph0 = priv + (1 * K + lo_i) * nthr + t;
@@ -1250,6 +1267,13 @@ __global__ void rqs_knot_vjp_kernel(const T* __restrict__ w, const T* __restrict
   }
   }
   __syncthreads();
+  if constexpr (SHARED) {
+    // the block's table, as it is, to ITS slice of the partials array (plain coalesced stores: 2 048 blocks x 1 536 Float64 global
+    // atomics on the same 96 cache lines were a serial tail of ~0.1 ms); rqs_knot_fold_kernel sums the slices in block order
+    double* mine = acc + (int64_t)blockIdx.x * 3 * nk;
+    for (int64_t o = t; o < 3 * nk; o += nthr) mine[o] = tab[o];
+    return;
+  }
   for (int64_t o = t; o < 3 * nk; o += nthr) {                         // o = (table*K + knot)*dim + row
     const int r = (int)(o % dim);
     const int64_t e = o / dim;
@@ -1263,6 +1287,32 @@ __global__ void rqs_knot_vjp_kernel(const T* __restrict__ w, const T* __restrict
 //  at 0.33 lane-adds per clock per CU on gfx950 — 28x slower than ds_add_u32 (scripts/probe_lds_atomics.hip) — which made that kernel
 //  4.2 ms; fixed-point integer atomics cost 6-10 VALU per contribution in a VALU-bound kernel; private accumulators are what this
 //  kernel already has.)
+// Σ over the blocks' tables, fixed order: thread (o, c) sums the slices [c·per, (c+1)·per) of entry o -> stage[c][o]; the out kernel
+// adds the C stage rows in order.  Deterministic (no floating-point atomics anywhere on this path).
+__global__ __launch_bounds__(256) void rqs_knot_fold_kernel(const double* __restrict__ parts, int nb, int64_t n3, int per, double* __restrict__ stage) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= n3) return;
+  const int c = blockIdx.y;
+  const int lo = c * per, hi = lo + per < nb ? lo + per : nb;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = lo;
+  for (; b + 3 < hi; b += 4) {
+    s0 += parts[(int64_t)b * n3 + o]; s1 += parts[(int64_t)(b + 1) * n3 + o];
+    s2 += parts[(int64_t)(b + 2) * n3 + o]; s3 += parts[(int64_t)(b + 3) * n3 + o];
+  }
+  for (; b < hi; ++b) s0 += parts[(int64_t)b * n3 + o];
+  stage[(int64_t)c * n3 + o] = (s0 + s1) + (s2 + s3);
+}
+template <class T>
+__global__ __launch_bounds__(256) void rqs_knot_vjp_out_stage_kernel(const double* __restrict__ stage, int C_, int K, int64_t dim, T* wb, T* hb, T* db) {
+  const int64_t nk = (int64_t)K * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += (int64_t)gridDim.x * blockDim.x) {
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int q = 0; q < C_; ++q) { const double* st = stage + (int64_t)q * 3 * nk; a += st[i]; b += st[nk + i]; c += st[2 * nk + i]; }
+    wb[i] = (T)a; hb[i] = (T)b; db[i] = (T)c;
+  }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void rqs_knot_vjp_out_kernel(const double* __restrict__ acc, int K, int64_t dim, T* wb, T* hb, T* db) {
   const int64_t nk = (int64_t)K * dim;
@@ -1278,6 +1328,41 @@ int rqs_knot_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T
   BJX_REQUIRE(ctx, dim <= 256, BJX_ERR_UNSUPPORTED, "bjx_rqs_vjp_knots: at most 256 rows (got %lld)", (long long)dim);
   BJX_REQUIRE(ctx, (size_t)(3 * nk) * sizeof(double) <= BJX_SCRATCH_BYTES, BJX_ERR_UNSUPPORTED, "bjx_rqs_vjp_knots: knot table too large");
   double* acc = reinterpret_cast<double*>(ctx->scratch);
+  // tuning switch: 0 = the private Float32 slices of rounds 2-5; n > 0 = the shared Float64 table with at most n blocks per CU
+  static const int shared_tab = getenv("BJX_RQS_KNOTS_SHARED") ? atoi(getenv("BJX_RQS_KNOTS_SHARED")) : 8;
+  const size_t shared_bytes = ((size_t)(3 * nk) * sizeof(T) + 15) / 16 * 16 + (size_t)(3 * nk) * sizeof(double);
+  if (batch > 0 && shared_tab && shared_bytes <= 60 * 1024) {
+    using A = T;
+    const int nthr = 256;
+    const int cpp = nthr / (int)dim;                                   // whole columns per pass (threads past cpp·dim idle)
+    const int64_t passes = (batch + cpp - 1) / cpp;
+    int per_cu = (int)((BJX_LDS_MAX - 2048) / shared_bytes);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu * nthr > 2048) per_cu = 2048 / nthr;
+    if (per_cu > shared_tab) per_cu = shared_tab;        // (every block ends with one Float64 global atomic per table entry)
+    int64_t grid = (int64_t)ctx->num_cu * per_cu;
+    if (grid > passes) grid = passes;
+    // partials: one [3][K][dim] Float64 table per block, then C stage rows (workspace of the context, grown on demand)
+    constexpr int C_ = 32;
+    const int64_t n3 = 3 * nk;
+    { const int rc = bjx_ensure_big_ws(ctx, (size_t)(grid + C_) * n3 * sizeof(double)); if (rc) return rc; }
+    double* parts = reinterpret_cast<double*>(ctx->big_ws);
+    double* stage = parts + grid * n3;
+    {
+      BjxProf prof_(ctx);
+      if (inverse) hipLaunchKernelGGL((rqs_knot_vjp_kernel<T, A, true, true>), dim3((unsigned)grid), dim3(nthr), shared_bytes, ctx->stream, w, h, d, K, in, out_bar, ladj_bar, in_bar, parts, dim, batch, cpp);
+      else hipLaunchKernelGGL((rqs_knot_vjp_kernel<T, A, false, true>), dim3((unsigned)grid), dim3(nthr), shared_bytes, ctx->stream, w, h, d, K, in, out_bar, ladj_bar, in_bar, parts, dim, batch, cpp);
+      BJX_CHECK_LAUNCH(ctx);
+    }
+    const int per = (int)((grid + C_ - 1) / C_);
+    hipLaunchKernelGGL(rqs_knot_fold_kernel, dim3((unsigned)((n3 + 255) / 256), C_), dim3(256), 0, ctx->stream, parts, (int)grid, n3, per, stage);
+    BJX_CHECK_LAUNCH(ctx);
+    int g3 = (int)((nk + 255) / 256);
+    if (g3 > 1024) g3 = 1024;
+    hipLaunchKernelGGL(rqs_knot_vjp_out_stage_kernel<T>, dim3(g3), dim3(256), 0, ctx->stream, stage, C_, K, dim, wb, hb, db);
+    BJX_CHECK_LAUNCH(ctx);
+    return BJX_OK;
+  }
   BJX_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)(3 * nk) * sizeof(double), ctx->stream));
   if (batch > 0) {
     using A = T;                                                     // accumulator type of the private slices
@@ -1293,8 +1378,8 @@ int rqs_knot_vjp_impl(bjx_ctx* ctx, int inverse, const T* w, const T* h, const T
     int64_t grid = (int64_t)ctx->num_cu * per_cu;
     if (grid > passes) grid = passes;
     BjxProf prof_(ctx);
-    if (inverse) hipLaunchKernelGGL((rqs_knot_vjp_kernel<T, A, true>), dim3((unsigned)grid), dim3(nthr), bytes(nthr), ctx->stream, w, h, d, K, in, out_bar, ladj_bar, in_bar, acc, dim, batch, cpp);
-    else hipLaunchKernelGGL((rqs_knot_vjp_kernel<T, A, false>), dim3((unsigned)grid), dim3(nthr), bytes(nthr), ctx->stream, w, h, d, K, in, out_bar, ladj_bar, in_bar, acc, dim, batch, cpp);
+    if (inverse) hipLaunchKernelGGL((rqs_knot_vjp_kernel<T, A, true, false>), dim3((unsigned)grid), dim3(nthr), bytes(nthr), ctx->stream, w, h, d, K, in, out_bar, ladj_bar, in_bar, acc, dim, batch, cpp);
+    else hipLaunchKernelGGL((rqs_knot_vjp_kernel<T, A, false, false>), dim3((unsigned)grid), dim3(nthr), bytes(nthr), ctx->stream, w, h, d, K, in, out_bar, ladj_bar, in_bar, acc, dim, batch, cpp);
     BJX_CHECK_LAUNCH(ctx);
   }
   int g2 = (int)((nk + 255) / 256);

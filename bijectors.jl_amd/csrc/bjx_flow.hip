@@ -789,7 +789,12 @@ __global__ __launch_bounds__(256) void planar_mfma64_kernel(const double* __rest
   constexpr int ROWS = 16 * NB;
   static_assert(NB % SPLIT == 0, "a staging chunk is whole 16-row blocks");
   constexpr int NBC = NB / SPLIT, RC = 16 * NBC;   // 16-row blocks / rows per staging chunk
-  constexpr int PITCH = RC + 4;                    // doubles per staged column (rows of consecutive columns start 8 banks apart)
+  // doubles per staged column.  Round 6: + 2, not + 4.  The tile leaves the staging area with ds_read_b64 (lane groups {0-31}, {32-63}, 64 banks
+  // of 4 bytes: MI355X_MICROARCH.md, LDS): lane (n, q) reads dword 2·(n·PITCH + 16b + 4r + q), so columns n and n + 8 met on the same banks
+  // with PITCH = RC + 4 (264 n mod 64 = 8 n: 2-way on every read; the transposing ds_write_b64 of the way out 4-way, its groups are 16 lanes on 32
+  // banks) — profiles/r05_pmc_notes.md: LDS 32 % busy, 64 % of it conflicts.  With RC + 2 the 32 lanes of a read group cover the 64 banks once
+  // (260 n mod 64 = 4 n, + 2q + {0, 1}); the write is 2-way.  Columns stay 16-byte aligned for the d2 accesses of the coalesced side.
+  constexpr int PITCH = RC + 2;
   extern __shared__ __attribute__((aligned(16))) char smem_[];
   __shared__ double red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -849,7 +854,12 @@ __global__ __launch_bounds__(256) void planar_mfma64_kernel(const double* __rest
       st[(t * 16 + n) * NL + 4 + q] = acc[1] + acc2[1];
     }
     __builtin_amdgcn_wave_barrier();
-    // ---- scalar recurrence, one sample per lane
+    // ---- scalar recurrence, one sample per lane.  Only tanh feeds the next layer; the log-det term log1p(wᵀû·sech²) of a layer (a lean
+    // Float64 log1p: ~50 of the ~120 dependent operations per layer) does not, so it leaves the serial chain (round 6): the lanes
+    // that run the recurrence park the eight arguments c·sech² in the idle staging area, and ALL 64 lanes take the logs afterwards —
+    // NL·COLS / 64 each (four at 32 columns per wave, where half the lanes used to idle through the whole recurrence).
+    constexpr int LG = 64 / COLS;                             // lane groups per column set
+    static_assert(NL % LG == 0, "the layers of a group split evenly over the lane groups");
     if (COLS == 64 || lane < COLS) {
       double s[NL], tt[NL];
 #pragma unroll
@@ -868,14 +878,24 @@ __global__ __launch_bounds__(256) void planar_mfma64_kernel(const double* __rest
         double th, s2;
         if (INV) find_alpha_act64(a, c, bl, th, s2);
         else flow_tanh_sech2(a + bl, th, s2);
-        double ld = Fast<double>::log1p(c * s2);            // planar_layer.jl:107
-        if (l0 + k >= n_layers) { th = 0.0; ld = 0.0; }     // padding layer (wave-uniform)
-        ladj += INV ? -ld : ld;
+        double arg = c * s2;                                // planar_layer.jl:107: logdet term = log1p(wᵀû·sech²)
+        if (l0 + k >= n_layers) { th = 0.0; arg = 0.0; }    // padding layer (wave-uniform): log1p(0) = 0
+        sg[lane * NL + k] = arg;
         tt[k] = INV ? -th : th;
       }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int k = 0; k < NL; ++k) st[lane * NL + k] = tt[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int colL = lane & (COLS - 1), grp = lane / COLS;
+      double ld = 0.0;
+#pragma unroll
+      for (int k = 0; k < NL / LG; ++k) ld += Fast<double>::log1p(sg[colL * NL + grp * (NL / LG) + k]);
+#pragma unroll
+      for (int m = COLS; m < 64; m <<= 1) ld += shfl_xor(ld, m);          // the lane groups of a column (every lane of it gets the sum)
+      ladj += INV ? -ld : ld;
     }
     __builtin_amdgcn_wave_barrier();
     // ---- rank-8 update: the tile registers are the accumulator

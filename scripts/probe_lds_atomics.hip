@@ -28,6 +28,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
         else if (MODE == 3) { const float o = tf[a]; tf[a] = o + v; }         // racy plain RMW
         else if (MODE == 4) __hip_atomic_fetch_add(tf + a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else if (MODE == 5) (void)__builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)(tf + a), v, 0, 0, false);
+        else if (MODE == 6) atomicAdd(reinterpret_cast<double*>(tab64) + a, (double)v);                       // ds_add_f64 (round 6: is the Float64 form slow too?)
+        else if (MODE == 7) __hip_atomic_fetch_add(reinterpret_cast<double*>(tab64) + a, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
@@ -46,6 +48,7 @@ template <int MODE> void run(const char* name, float* out) {
 int main() {
   float* out; hipMalloc(&out, 1024 * 64 * 4);
   run<0>("atomicAdd float (ds_add_f32)", out); run<4>("hip_atomic_fetch_add wg f32", out); run<5>("ds_faddf builtin", out);
+  run<6>("atomicAdd double (ds_add_f64)", out); run<7>("hip_atomic_fetch_add wg f64", out);
   run<1>("atomicAdd u32 (ds_add_u32)", out); run<2>("atomicAdd u64 (ds_add_u64)", out); run<3>("plain read-add-write (racy)", out);
   return 0;
 }
