@@ -1159,7 +1159,7 @@ __global__ void rqs_knot_vjp_kernel(const T* __restrict__ w, const T* __restrict
   // A ring of LA prefetched (x, ȳ, ℓ̄) triples in registers, slot u refilled for pass ps + LA·grid as soon as it has been consumed.
   // LA = 1 (round 3 tried 4: 1.10 -> 1.54 ms at K = 16, dim = 32, 2^22 columns — the four unrolled bodies, ~300 instructions each with
   // divergent early exits, cost more than the extra loads in flight bring: the kernel is bound by its LDS read-modify-write chains).
-  constexpr int LA = 1;
+  constexpr int LA = 1;                    // (round 6, SHARED: two columns in flight per thread measured too — 0.682 vs 0.689 ms, nothing)
   T qx[LA], qg[LA], ql[LA];
   bool qok[LA];
   auto fetch = [&](int64_t ps, T& fx, T& fg, T& fl, bool& fok) {

@@ -2115,7 +2115,10 @@ int planar_impl(bjx_ctx* ctx, int inverse, const T* w, const T* u, const T* b, i
           BjxFin finb;
           bool secondb = false;
           { int rc = bjx_make_fin(ctx, gridb, ladj_sum, 0.0, 0, flags, &finb, &secondb); if (rc) return rc; }
-          if (finb.counter) { finb.counter = nullptr; secondb = true; }        // blocks of 8 / 16 waves: two-pass finalize
+          // blocks of 8 / 16 waves: the ARRIVAL-TICKET epilogue (mode 1) is written for 64- and 256-thread blocks -> two-pass there.  Under the default
+          // (mode 2) these 512 / 1024-thread blocks DO take the sentinel hand-off: block_publish_sentinel folds any number of waves through red[NWB]
+          // (covered by test_finalize_modes_give_the_same_bits[planar_big_blocks])
+          if (finb.counter) { finb.counter = nullptr; secondb = true; }
           PlanarRegArgs RB{wp, up, Gp, cp, bp, nl_pad, nl, (int)ldw, packs_ok ? 0 : (unal_nt ? 2 : 1), lead};
           const int accumb = ((flags & BJX_ACCUMULATE) ? 1 : 0) | ((flags & BJX_BASE_STDNORMAL) ? 2 : 0);
 #define LAUNCH_BIG_U(NL_, INV_, NW_, U_) hipLaunchKernelGGL((planar_reg2_kernel<NL_, INV_, NW_, U_>), dim3((unsigned)gridb), dim3(NW_ * 64), 0, ctx->stream, RB, (const float*)in, (float*)out, (float*)ladj_ps, (int)dim, batch, accumb, finb)

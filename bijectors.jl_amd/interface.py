@@ -199,7 +199,7 @@ def _note_params(ctx: "_Ctx", *tensors) -> None:
     import weakref
 
     st = _PARAM_WATCH.setdefault(id(ctx), [1, 0, {}])
-    if not _PARAM_CACHE["on"]:
+    if not _PARAM_CACHE["on"] or not _VERSION_BUMP_OK:       # (no way to mark tensors the library wrote: never promise the library an unchanged parameter)
         if st[1] != 0:
             L.check(ctx.h, L.load().bjx_set_option(ctx.h, L.BJX_OPT_PARAM_EPOCH, 0), "bjx_set_option")
             st[1] = 0
@@ -227,10 +227,47 @@ def _mark_written(t: Optional[torch.Tensor]) -> None:
     tables above, the batch tag of InvertibleBatchNorm) notices."""
     if t is None:
         return
-    try:
+    _bump_version(t)
+
+
+def _probe_version_bump():
+    """The private torch call that bumps a tensor's version counter takes ([tensors], [versions]) in current builds and (tensor, int) in
+    older ones (swallowing the TypeError of the wrong form made the bump a silent no-op there, and everything keyed on
+    `_version` — the batch tag of InvertibleBatchNorm, the parameter tables of `cache_params` — would trust a tensor the library had
+    rewritten).  Probed ONCE on a scratch CPU tensor; when neither form works the callers are told (`_VERSION_BUMP_OK` False): the
+    saved-statistics shortcut and the parameter-table reuse then never trust a version."""
+    fn = getattr(getattr(torch._C, "_autograd", None), "_unsafe_set_version_counter", None)
+    if fn is None:
+        return None
+    probe = torch.zeros(1)
+    for form in ("list", "scalar"):
+        try:
+            v0 = probe._version
+            if form == "list":
+                fn([probe], [v0 + 1])
+            else:
+                fn(probe, v0 + 1)
+            if probe._version == v0 + 1:
+                return form
+        except Exception:
+            continue
+    return None
+
+
+_VERSION_BUMP_FORM = _probe_version_bump()
+_VERSION_BUMP_OK = _VERSION_BUMP_FORM is not None
+if not _VERSION_BUMP_OK:
+    import warnings
+
+    warnings.warn("bijectors_amd: this torch build offers no way to bump a tensor's version counter; tensors written in place by the library keep their "
+                  "version, so cache_params() and the saved batch statistics of InvertibleBatchNorm are disabled (always recomputed)")
+
+
+def _bump_version(t: torch.Tensor) -> None:
+    if _VERSION_BUMP_FORM == "list":
         torch._C._autograd._unsafe_set_version_counter([t], [t._version + 1])
-    except Exception:
-        pass
+    elif _VERSION_BUMP_FORM == "scalar":
+        torch._C._autograd._unsafe_set_version_counter(t, t._version + 1)
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -1505,7 +1542,7 @@ class _BatchTag:
         self.ref, self.version, self.shape, self.dtype = weakref.ref(x), x._version, tuple(x.shape), x.dtype
 
     def matches(self, x) -> bool:
-        return self.ref() is x and self.version == x._version and self.shape == tuple(x.shape) and self.dtype == x.dtype
+        return _VERSION_BUMP_OK and self.ref() is x and self.version == x._version and self.shape == tuple(x.shape) and self.dtype == x.dtype
 
 
 def _batch_tag(x):

@@ -13,7 +13,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = {"c1": ["chain_flat"], "c2": ["chain_flat_kernel"], "c2v": ["chain_flat_kernel"], "c3": ["rqs_lds_kernel"], "c4": ["planar_reg"],
+DOMINANT = {"c1": ["chain_flat"], "c2": ["chain_flat_kernel"], "c2v": ["chain_flat_kernel"], "c2_f64": ["chain_flat_kernel"], "c4_f64": ["planar_mfma64_kernel"], "c3": ["rqs_lds_kernel"], "c4": ["planar_reg"],
             "c5a": ["quad_stream_kernel"], "c5b": ["chol_inv_chunk_kernel"], "vcorr": ["matrix_cyc_kernel<float, 8, 4, 0, false>"], "pdvec": ["matrix_cyc_kernel<float, 8, 4, 3, false>"]}   # the forward kernel is the timed one (the inverse builds the input)
 
 
@@ -77,7 +77,7 @@ def main(tag):
     traffic["_tag"] = tag
     json.dump(traffic, open(traffic_path, "w"), indent=1)
     for extra in ("bench_default.json", "bench_default_detail.json", "rows.md", "rows_kernel_stats.csv", "f64_rows.md", "f64math_bench.txt", "planar_mfma_ab.txt", "small_sizes.md",
-                  "kernel_trace_timed.jsonl", "lib_sha16.txt", "lib_bytes.txt", "first_call.txt", "ordered_tall.md", "planar_heights.md", "small_dims.md", "host_overhead.txt", "c3_table_policy.txt"):
+                  "kernel_trace_timed.jsonl", "small_calls.md", "lds_atomics.txt", "c3_sq_pmc_1.txt", "c3_sq_pmc_2.txt", "c3_sq_pmc_3.txt", "c4_f64_sq_pmc_1.txt", "c4_f64_sq_pmc_2.txt", "c4_f64_sq_pmc_3.txt", "lib_sha16.txt", "lib_bytes.txt", "first_call.txt", "ordered_tall.md", "planar_heights.md", "small_dims.md", "host_overhead.txt", "c3_table_policy.txt"):
         pe = os.path.join(src, extra)
         if os.path.exists(pe) and os.path.getsize(pe) > 2:
             with open(pe) as fi, open(os.path.join(dst, f"{tag}_{extra}"), "w") as fo:

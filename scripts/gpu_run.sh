@@ -62,14 +62,14 @@ stats)
   f=$(ls gpurun_out/prof_$WL/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && { cp "$f" gpurun_out/${WL}_kernel_stats.csv; head -8 "$f" | cut -c1-200; }; rm -rf gpurun_out/prof_$WL ;;
 profile)
   TAG=${1:-r06}; shift
-  WLS=${@:-c2 c2v c3 c4 c5a c5b vcorr pdvec}
+  WLS=${@:-c2 c2v c3 c4 c5a c5b vcorr pdvec c2_f64 c4_f64}
   O=$R/gpurun_out/$TAG; mkdir -p $O
   # the binary this evidence belongs to (tests/test_profiles_fresh.py compares kernel names with the .so in the tree)
   sha256sum bijectors.jl_amd/libbjx_hip.so | cut -c1-16 > $O/lib_sha16.txt; stat -c %s bijectors.jl_amd/libbjx_hip.so > $O/lib_bytes.txt
   python scripts/probe_first_call.py > $O/first_call.txt 2>&1
   cat $O/first_call.txt
   rm -f gpurun_out/matrix_vjp_errors.jsonl gpurun_out/vjp_errors.jsonl $O/kernel_trace_timed.jsonl
-  echo "== default bench line (what the driver runs: first on a fresh box — after the 2.5 min of the test suite the same line reads C3 1-3 % lower, profiles/r05_bench_repeats.md)"; timeout 900 python bench.py > $O/bench_default.json 2>$O/bench_default.err; wc -c $O/bench_default.json; cp gpurun_out/bench_detail.json $O/bench_default_detail.json 2>/dev/null
+  echo "== default bench line (what the driver runs: first on a fresh box)"; timeout 900 python bench.py > $O/bench_default.json 2>$O/bench_default.err; wc -c $O/bench_default.json; cp gpurun_out/bench_detail.json $O/bench_default_detail.json 2>/dev/null
   echo "== pytest -m gpu"; ( time timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 -p no:cacheprovider ) > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt
   cp gpurun_out/matrix_vjp_errors.jsonl gpurun_out/vjp_errors.jsonl $O/ 2>/dev/null
   for wl in $WLS; do
@@ -79,18 +79,23 @@ profile)
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_rows -o rows -- python $R/scripts/bench_rows.py > $O/rows_raw.txt 2>&1 )
   grep "^|" $O/rows_raw.txt > $O/rows.md; f=$(ls $O/prof_rows/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -60 "$f" > $O/rows_kernel_stats.csv; rm -rf $O/prof_rows; wc -l $O/rows.md
   timeout 600 python scripts/bench_f64.py 2>/dev/null | grep "^|" > $O/f64_rows.md; wc -l $O/f64_rows.md
-  timeout 300 python scripts/probe_ordered_tall.py 2>/dev/null | grep "^|" > $O/ordered_tall.md
-  { echo; echo "With \`BJX_ORDERED_VJP_TALL=0\` (one thread per column, rounds 2-4), same call:"; echo; BJX_ORDERED_VJP_TALL=0 timeout 300 python scripts/probe_ordered_tall.py 2>/dev/null | grep "^|" | sed -n '1,2p;7,10p'; } >> $O/ordered_tall.md
-  { echo "# r05 — 8 × PlanarLayer over column heights (scripts/probe_planar_params.py, 2^29 bytes-ish per array, stream-region time per call)"; echo;
-    echo "Shipped paths (column-tile kernels \`planar_cols_kernel\` / \`planar_vjp_cols_kernel\`, parameter reduction with rows owned by threads):"; echo;
-    BJX_BENCH_PREROLL_MS=20 timeout 400 python scripts/probe_planar_params.py 2>/dev/null | grep "^|";
-    echo; echo "The same call with the five switches of the round off (\`BJX_PLANAR_COLS_MIN_F32/F64=0 BJX_PLANAR_VJP_COLS_MIN_F32/F64=0 BJX_PLANAR_PARAM_ROWS=0\`: the lanes-per-column kernels of rounds 1-4; what they refused — the input pullback beyond 8 192 / 4 096 rows, the parameter reduction beyond 1 024 / 512 — is served by the tall-column kernels of the same round):"; echo;
-    BJX_PLANAR_COLS_MIN_F32=0 BJX_PLANAR_COLS_MIN_F64=0 BJX_PLANAR_VJP_COLS_MIN_F32=0 BJX_PLANAR_VJP_COLS_MIN_F64=0 BJX_PLANAR_PARAM_ROWS=0 BJX_BENCH_PREROLL_MS=20 timeout 600 python scripts/probe_planar_params.py 2>/dev/null | grep "^|"; } > $O/planar_heights.md
-  { echo "# r05 — low-dimensional columns (2 ... 50 rows), Float32 and Float64: stream-region time of one call, algorithmic array passes as a fraction of 8 TB/s (scripts/probe_small_dims.py; 2^27 elements per array)"; echo;
-    echo "(An 8-layer Planar stack on 2 ... 10 rows is bound by the VALU, not by HBM: 8 tanh / log1p — inverse: 8 root solves of ~80 instructions — per column of 8 ... 40 bytes.)"; echo;
-    BJX_BENCH_PREROLL_MS=10 timeout 600 python scripts/probe_small_dims.py 2>/dev/null | grep "^|"; } > $O/small_dims.md
-  timeout 300 python scripts/probe_host_overhead.py --calls 2000 --top 8 2>/dev/null | grep -v amdgpu.ids > $O/host_overhead.txt
-  bash scripts/ab_c3.sh 2>/dev/null > $O/c3_table_policy.txt
+  # (round 5's height sweeps — ordered_tall, planar_heights, small_dims — stay in profiles/ as r05_*: those kernels did not change in round 6)
+  { echo "# host time per call, launch plans ON (default)"; timeout 300 python scripts/probe_host_overhead.py --calls 2000 --top 8 2>/dev/null | grep -v amdgpu.ids;
+    echo; echo "# the same with the plans OFF (--no-plans: the general path of rounds 1-5)"; timeout 300 python scripts/probe_host_overhead.py --calls 2000 --top 4 --no-plans 2>/dev/null | grep -v amdgpu.ids; } > $O/host_overhead.txt
+  timeout 300 python scripts/probe_small_calls.py 2>/dev/null | grep "^|" > $O/small_calls.md
+  { hipcc --offload-arch=gfx950 -O3 -o /tmp/probe_lds scripts/probe_lds_atomics.hip 2>/dev/null && /tmp/probe_lds; } > $O/lds_atomics.txt 2>&1
+  bash scripts/ab_c3.sh c3 2 2>/dev/null > $O/c3_table_policy.txt
+  # issue-side counters of the two BASELINE kernels under their roofline, ON THE SHIPPED LIBRARY (VERDICT r05 missing #7): three passes each
+  for wl in c3 c4_f64; do
+    ks=rqs_lds_kernel; [ $wl = c4_f64 ] && ks=planar_mfma64_kernel
+    i=0
+    for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_LDS_IDX_ACTIVE"; do
+      i=$((i+1))
+      ( cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmcq_${wl}_$i -o p -- python $R/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-rows > $O/rocprof_pmcq_${wl}_$i.log 2>&1 )
+      f=$(ls $O/pmcq_${wl}_$i/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && pmc_summary "$f" "$ks" > $O/${wl}_sq_pmc_$i.txt
+      rm -rf $O/pmcq_${wl}_$i
+    done
+  done
   for wl in $WLS; do
     ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o $wl -- python $R/bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-rows > $O/rocprof_$wl.log 2>&1 )
     f=$(ls $O/prof_$wl/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && { cp "$f" $O/${wl}_kernel_stats.csv; echo "-- kernel stats $wl"; head -3 "$f" | cut -c1-160; }
