@@ -415,6 +415,34 @@ class Env:
     pass
 
 
+def measure_small_calls(env, calls=400, reps=5):
+    torch, bj = env.torch, env.bj
+    V = bj.vector
+    out = []
+    for label, t, shape in (("from_linked_vec(positive reals)", V.from_linked_vec(V.scalar_to_scalar_bijector(0.0, float("inf")), (64,)), (64, 256)),
+                            ("from_linked_vec(unit interval)", V.from_linked_vec(V.scalar_to_scalar_bijector(0.0, 1.0), (1000,)), (1000, 16))):
+        x = torch.randn(shape[1], shape[0], device=env.device).T
+        res = {"bijector": label, "rows_x_chains": f"{shape[0]} x {shape[1]}", "dtype": "f32", "log_det": "per chain"}
+        for key, on in (("us_per_call", True), ("us_per_call_general_path", False)):
+            bj._fast_plans(on)
+            try:
+                for _ in range(50):
+                    bj.with_logabsdet_jacobian(t, x, per_sample=True)
+                torch.cuda.synchronize()
+                best = float("inf")
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    for _ in range(calls):
+                        bj.with_logabsdet_jacobian(t, x, per_sample=True)
+                    torch.cuda.synchronize()
+                    best = min(best, (time.perf_counter() - t0) / calls * 1e6)
+                res[key] = round(best, 2)
+            finally:
+                bj._fast_plans(True)
+        out.append(res)
+    return out
+
+
 def measure(env, name, steps, warmup, scaling, log2_batch=None, want_cold=True):
     """Warm up, then time EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks.
     -> dict on every rank (only rank 0 uses it)."""
@@ -741,6 +769,16 @@ def main():
                 except Exception as e:
                     strong.append({"workload": r, "error": repr(e)})
 
+    small_rows = []
+    if want_rows and world == 1:
+        # f-2 shapes (src/vector/product/fill.jl:146-165, 192-213): what a sampler calls on every log-density evaluation — the linked vector of a
+        # product distribution, one column per chain.  Wall time per call of a burst of 400 calls (host issue + stream, drained at the end), through
+        # the cached launch plan (include/bjx.h "plans") and through the general path of rounds 1-5.
+        try:
+            small_rows = measure_small_calls(env)
+        except Exception as e:
+            small_rows = [{"error": repr(e)}]
+
     graph_rows = []
     if want_rows and (world == 1 or a.collective == "bjx"):
         # shards of 2^20 columns and below are launch-bound: the step as a captured hipGraph next to call-by-call issue.
@@ -766,6 +804,8 @@ def main():
                     except Exception as e:
                         r["cpu_baseline"] = {"value": None, "unit": "M samples/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
         out = build_line(a, world, head, rows if want_rows else [], graph_rows, strong, cpu)
+        if small_rows:
+            out["small_calls"] = small_rows
         # the full record (labels, CPU sample descriptions, traffic sources, graph-step sums): a side file, best effort
         detail = {"line": out, "head": head, "rows": rows, "graph_step": graph_rows, "strong_scaling": strong,
                   "notes": {"preroll": "untimed steps of the same workload after the W warm-up steps, until the GPU has been under load for `ms` (steady clocks); the timed region is exactly K steps",
