@@ -358,6 +358,29 @@ BJX_API int bjx_plan_structured(bjx_ctx* ctx, bjx_dtype dt, int kind, int invers
   return BJX_OK;
 }
 
+BJX_API int bjx_plan_stacked_vjp(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, int64_t dim, bjx_plan** out) {
+  if (!ctx || !out) return BJX_ERR_ARG;
+  *out = nullptr;
+  BJX_REQUIRE(ctx, dt == BJX_F32 || dt == BJX_F64, BJX_ERR_ARG, "bjx_plan_stacked_vjp: bad dtype %d", (int)dt);
+  BJX_REQUIRE(ctx, segs && n_segs >= 1 && n_segs <= 4096 && dim >= 0, BJX_ERR_ARG, "bjx_plan_stacked_vjp: 1 ... 4096 segments");
+  for (int k = 0; k < n_segs; ++k)
+    BJX_REQUIRE(ctx, segs[k].n_ops >= 0 && segs[k].n_ops <= BJX_MAX_SEG_OPS && segs[k].len >= 0, BJX_ERR_ARG, "bjx_plan_stacked_vjp: segment %d is malformed", k);
+  bjx_plan* p;
+  { const int rc = bjx_plan_new(ctx, out, &p); if (rc) return rc; }
+  p->segs = new (std::nothrow) bjx_segment[n_segs];
+  if (!p->segs) { delete p; return bjx_fail(ctx, BJX_ERR_ARG, "out of host memory"); }
+  for (int k = 0; k < n_segs; ++k) p->segs[k] = segs[k];
+  p->kind = BJX_PLAN_STACKED_VJP; p->dt = dt; p->n_segs = n_segs; p->dim = dim;
+  *out = p;
+  return BJX_OK;
+}
+
+BJX_API int bjx_plan_run_vjp(bjx_plan* plan, const void* x, const void* y_bar, const void* ladj_bar, void* x_bar, int64_t batch) {
+  if (!plan || !plan->ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(plan->ctx, plan->kind == BJX_PLAN_STACKED_VJP, BJX_ERR_ARG, "bjx_plan_run_vjp: not a pullback plan (kind %d)", plan->kind);
+  return bjx_stacked_vjp(plan->ctx, plan->dt, plan->segs, plan->n_segs, x, y_bar, ladj_bar, x_bar, plan->dim, batch);
+}
+
 BJX_API int bjx_plan_destroy(bjx_plan* plan) {
   delete plan;
   return BJX_OK;
@@ -366,6 +389,7 @@ BJX_API int bjx_plan_destroy(bjx_plan* plan) {
 BJX_API int bjx_plan_run(bjx_plan* plan, const void* in, void* out, void* ladj_ps, double* ladj_sum, void* ladj_sum_t, int64_t batch) {
   if (!plan || !plan->ctx) return BJX_ERR_ARG;
   bjx_ctx* ctx = plan->ctx;
+  BJX_REQUIRE(ctx, plan->kind != BJX_PLAN_STACKED_VJP, BJX_ERR_ARG, "bjx_plan_run: a pullback plan runs through bjx_plan_run_vjp");
   double* sum = ladj_sum;
   if (ladj_sum_t) {
     BJX_REQUIRE(ctx, plan->dt == BJX_F32, BJX_ERR_ARG, "bjx_plan_run: ladj_sum_t is the Float32 copy of the sum; a Float64 plan returns it in ladj_sum");

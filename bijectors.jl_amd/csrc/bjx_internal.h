@@ -114,6 +114,9 @@ struct bjx_plan {
   int inverse = 0;
   int64_t dim = 0;              // rows of the INPUT
   uint32_t flags = 0;
+  int n_segs = 0;               // BJX_PLAN_STACKED_VJP: the segment list of bjx_stacked_vjp
+  bjx_segment* segs = nullptr;
+  ~bjx_plan() { delete[] segs; }
 };
 
 inline int bjx_fail(bjx_ctx* ctx, int code, const char* fmt, ...) {

@@ -631,6 +631,86 @@ def _fast_chain(owner, get_ops, x, per_sample):
     return y, l
 
 
+def _fast_vjp_build(owner, get_ops, x, dim, key):
+    def not_applicable():
+        fp = _FastPlan(None, _BIJ_EPOCH[0], None, None, False)
+        owner.__dict__.setdefault("_fast", {})[key] = fp
+        return fp
+
+    ops = get_ops()
+    if ops is None or len(ops) > L.BJX_MAX_SEG_OPS:
+        return not_applicable()
+    ops2 = get_ops()
+    for (k1, a0, a1), (k2, b0, b1) in zip(ops, ops2):
+        for p, q in ((a0, b0), (a1, b1)):
+            if isinstance(p, torch.Tensor) and p is not q:
+                return not_applicable()
+    if _chain_key(ops, x, dim) is None:
+        return not_applicable()
+    ctx = context(x.device)
+    seg = (L.BjxSegment * 1)()
+    sg = seg[0]
+    sg.in_lo, sg.out_lo, sg.len, sg.n_ops = 0, 0, dim, len(ops)
+    keep = []
+    for k, (kind, p0, p1) in enumerate(ops):
+        o = sg.ops[k]
+        o.kind, o.param_len, o.p0, o.p1, o.v0, o.v1 = kind, 0, 0.0, 0.0, None, None
+        for j, p in enumerate((p0, p1)):
+            if p is None:
+                continue
+            if isinstance(p, torch.Tensor) and p.dim() > 0 and p.numel() != 1:
+                keep.append(p)
+                o.param_len = dim
+                setattr(o, f"v{j}", p.data_ptr())
+            else:
+                o.param_len = max(o.param_len, 1)
+                setattr(o, f"p{j}", float(p))
+    h = C.c_void_p()
+    L.check(ctx.h, L.load().bjx_plan_stacked_vjp(ctx.h, _dt(x), seg, 1, dim, C.byref(h)), "bjx_plan_stacked_vjp")
+    fp = _FastPlan(h, _BIJ_EPOCH[0], keep, ctx, x.dtype == torch.float32)
+    owner.__dict__.setdefault("_fast", {})[key] = fp
+    return fp
+
+
+def _fast_chain_vjp(owner, get_ops, x, out_bar, ladj_bar):
+    """Input pullback of an elementwise chain through a cached pullback plan (bjx_plan_stacked_vjp); None when the call does not qualify."""
+    if _FAST_OFF[0] or not isinstance(x, torch.Tensor) or not x.is_cuda or _OUT_HINT or not isinstance(out_bar, torch.Tensor):
+        return None
+    if ladj_bar is not None and not isinstance(ladj_bar, torch.Tensor):
+        return None                                     # a python number: the general path broadcasts it
+    nd = x.dim()
+    if nd == 2:
+        dim, batch = x.shape
+        if x.stride(0) != 1 or (batch > 1 and x.stride(1) != dim) or dim == 0 or batch == 0:
+            return None
+    elif nd == 1:
+        dim, batch = x.shape[0], 1
+        if x.stride(0) != 1 or dim == 0:
+            return None
+    else:
+        return None
+    dt = x.dtype
+    if (dt is not torch.float32 and dt is not torch.float64) or out_bar.dtype is not dt or out_bar.shape != x.shape or out_bar.stride() != x.stride() or out_bar.device != x.device:
+        return None
+    if ladj_bar is not None and (ladj_bar.dtype is not dt or ladj_bar.dim() != 1 or ladj_bar.shape[0] != batch or ladj_bar.stride(0) != 1 or ladj_bar.device != x.device):
+        return None
+    dev = x.device.index
+    if dev != torch._C._cuda_getDevice():
+        return None
+    key = ("vjp", dt, dim, dev, torch._C._cuda_getCurrentRawStream(dev))
+    cache = owner.__dict__.get("_fast")
+    fp = cache.get(key) if cache is not None else None
+    if fp is None or fp.epoch != _BIJ_EPOCH[0]:
+        fp = _fast_vjp_build(owner, get_ops, x, dim, key)
+    if fp.h is None:
+        return None
+    xb = torch.empty(dim, dtype=dt, device=x.device) if nd == 1 else torch.empty((batch, dim), dtype=dt, device=x.device).T
+    rc = L.load().bjx_plan_run_vjp(fp.h, x.data_ptr(), out_bar.data_ptr(), None if ladj_bar is None else ladj_bar.data_ptr(), xb.data_ptr(), batch)
+    if rc != 0:
+        L.check(fp.ctx.h, rc, "bjx_plan_run_vjp")
+    return xb
+
+
 def with_logabsdet_jacobian(b, x, per_sample: bool = False):
     """ChangesOfVariables.with_logabsdet_jacobian for the hot-path bijectors.
 
@@ -2341,6 +2421,10 @@ def vjp(b, x, out_bar, ladj_bar=None):
         return b._vjp(x, out_bar, ladj_bar)
     if isinstance(b, NamedStacked):
         return b._vjp(x, out_bar, ladj_bar)
+    if isinstance(b, (ComposedFunction, _ChainOp, Elementwise, Inverse)):
+        r = _fast_chain_vjp(b, lambda: _elementwise_ops(b), x, out_bar, ladj_bar)       # cached pullback plan (include/bjx.h "plans")
+        if r is not None:
+            return r
     ops_ = _elementwise_ops(b)
     if ops_ is not None and len(ops_) <= L.BJX_MAX_SEG_OPS:   # a chain of elementwise bijectors = one segment over all rows
         dim = x.shape[0]

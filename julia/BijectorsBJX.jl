@@ -1137,7 +1137,34 @@ end
 
 # Elementwise chains and Stacked of elementwise chains: x̄ = (dy/dx) ȳ + ℓ̄ d logabsdetjac/dx, element by element
 # (bjx_stacked_vjp; same segment list as bjx_stacked).  The log-det is a scalar: ℓ̄ is a Real, broadcast to the columns.
+# The pullback a gradient-based sampler repeats on every leapfrog step goes through a pullback PLAN (bjx_plan_stacked_vjp: the segment list
+# validated once, kept by the calling task's context; CPLANS is keyed by the segments' CONTENT — they hold pointers and scalars only).
+const VJP_PLANS = Dict{Tuple{Ptr{Cvoid},UInt,DataType,Int},CPlan}()          # guarded by CPLANS_LOCK
+function stacked_vjp_cplan(segs::Vector{BjxSegment}, keep, ::Type{T}, d::Int) where {T}
+    c = ctx()
+    key = (c.h, hash(segs), T, d)
+    lock(CPLANS_LOCK) do
+        get!(VJP_PLANS, key) do
+            hp = Ref{Ptr{Cvoid}}(C_NULL)
+            GC.@preserve segs keep check(ccall((:bjx_plan_stacked_vjp, libbjx), Cint, (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Int64, Ptr{Ptr{Cvoid}}),
+                                               c.h, dtype(T), segs, length(segs), d, hp), "bjx_plan_stacked_vjp")
+            cp = CPlan(hp[], copy(keep))
+            finalizer(x -> ccall((:bjx_plan_destroy, libbjx), Cint, (Ptr{Cvoid},), x.h), cp)
+            cp
+        end
+    end
+end
 function stacked_vjp(segs::Vector{BjxSegment}, keep, x::ROCVecOrMat{T}, Δy, Δl) where {T}
+    d, n = dims(x)
+    x̄ = similar(x)
+    cp = stacked_vjp_cplan(segs, keep, T, Int(d))
+    GC.@preserve keep cp x Δy Δl x̄ check(ccall((:bjx_plan_run_vjp, libbjx), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
+        cp.h, devptr(x), devptr(Δy), devptr(Δl), devptr(x̄), n), "bjx_plan_run_vjp")
+    return x̄
+end
+# (the unplanned entry, for segment lists that are built once and thrown away)
+function stacked_vjp_once(segs::Vector{BjxSegment}, keep, x::ROCVecOrMat{T}, Δy, Δl) where {T}
     d, n = dims(x)
     x̄ = similar(x)
     GC.@preserve keep x Δy Δl x̄ check(ccall((:bjx_stacked_vjp, libbjx), Cint,

@@ -701,7 +701,7 @@ def test_inkernel_finalize_is_bit_identical_to_two_pass(bj):
     assert not torch.equal(two_pass[0], two_pass[1])
 
 
-@pytest.mark.parametrize("case", ["chain_f64_vector", "chain_f32_matrix", "ordered_one_wave_blocks", "rqs", "stacked_mixed"])
+@pytest.mark.parametrize("case", ["chain_f64_vector", "chain_f32_matrix", "ordered_one_wave_blocks", "rqs", "stacked_mixed", "planar_big_blocks"])
 def test_finalize_modes_give_the_same_bits(bj, case):
     """Every kernel family that takes the in-kernel epilogue — 256-thread blocks (chains, Planar, RQS) and one-wave blocks (the
     column walkers) — returns the SAME Float64 sum in mode 0 (two follow-up launches) and 1 (arrival ticket), and a deterministic
@@ -717,6 +717,13 @@ def test_finalize_modes_give_the_same_bits(bj, case):
     elif case == "ordered_one_wave_blocks":
         x = dev(r.normal(size=(13, 5003)))
         run = lambda: bj.shard.with_logabsdet_jacobian_sharded(bj.OrderedBijector(), x)[2]
+    elif case == "planar_big_blocks":         # 512 rows: planar_reg2_kernel in 512-thread blocks (8 waves) — the sentinel hand-off folds them through red[NWB]
+        dim, nl = 512, 8
+        w = dev((r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(np.float32))
+        u = dev((r.normal(size=(dim, nl)) / np.sqrt(dim)).astype(np.float32))
+        fl = bj.PlanarLayer(w, u, dev(r.normal(size=nl).astype(np.float32)))
+        x = dev(r.normal(size=(dim, 4099)).astype(np.float32))
+        run = lambda: bj.shard.with_logabsdet_jacobian_sharded(fl, x)[2]
     elif case == "rqs":
         K, dim = 8, 16
         raw = [dev(r.normal(size=(dim, k)).astype(np.float32)) for k in (K, K, K - 1)]

@@ -73,6 +73,37 @@ def test_fast_path_equals_general_path_bit_for_bit(bj, shape, dt):
         assert all(fp.h is None for fp in mixed.__dict__["_fast"].values()), "a composition with a flow layer must not be planned as a chain"
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(64, 256), (1000, 16), (7, 1), (33,)])
+def test_pullback_plan_equals_general_path_bit_for_bit(bj, shape, dt):
+    """vjp(chain, x, ȳ, ℓ̄) through bjx_plan_stacked_vjp / bjx_plan_run_vjp: the same kernel with the same arguments as bjx_stacked_vjp."""
+    r = np.random.default_rng(18)
+    dim = shape[0]
+    x = r.uniform(-0.9, 0.9, size=shape).astype(dt)
+    g = r.normal(size=shape).astype(dt)
+    xd, gd = (_cm(a) if a.ndim == 2 else torch.from_numpy(a).cuda() for a in (x, g))
+    batch = shape[1] if len(shape) == 2 else 1
+    lb = torch.from_numpy(r.normal(size=batch).astype(dt)).cuda()
+    for name, b in _chains(bj, dim, dt).items():
+        for lbar in (lb, None):
+            bj._fast_plans(False)
+            try:
+                ref = bj.vjp(b, xd, gd, lbar)
+            finally:
+                bj._fast_plans(True)
+            got1 = bj.vjp(b, xd, gd, lbar)
+            got2 = bj.vjp(b, xd, gd, lbar)
+            assert got1.shape == ref.shape and torch.equal(got1, ref) and torch.equal(got2, ref), (name, lbar is not None)
+    planned = _chains(bj, dim, dt)["affexp_v"]
+    bj.vjp(planned, xd, gd, lb)
+    assert any(k[0] == "vjp" and fp.h is not None for k, fp in planned.__dict__["_fast"].items())
+    # a python number as the log-det cotangent takes the general path (it is broadcast there) and agrees
+    assert torch.equal(bj.vjp(planned, xd, gd, 0.0), bj.vjp(planned, xd, gd, None))
+    L = bj._lib
+    h = C.c_void_p()
+    assert L.load().bjx_plan_stacked_vjp(bj.context().h, L.BJX_F32, None, 0, dim, C.byref(h)) == L.ERR_ARG
+
+
 def test_plans_see_in_place_updates_and_reassigned_parameters(bj):
     dim, n = 40, 64
     x = _cm(np.random.default_rng(1).normal(size=(dim, n)))
@@ -229,6 +260,27 @@ def test_host_time_of_a_small_planned_call(bj):
                 res[mode] = best
             finally:
                 bj._fast_plans(True)
+        if not ps:                                   # the pullback of the same chain (what a gradient-based sampler repeats per leapfrog step)
+            g = torch.randn_like(x.T).T.contiguous() if False else torch.randn(x.shape[1], x.shape[0], device="cuda").T
+            lbv = torch.randn(x.shape[1], device="cuda")
+            for mode in ("general", "planned"):
+                bj._fast_plans(mode == "planned")
+                try:
+                    for _ in range(50):
+                        bj.vjp(t, x, g, lbv)
+                    torch.cuda.synchronize()
+                    best = 1e9
+                    for _rep in range(5):
+                        t0 = time.perf_counter()
+                        for _ in range(400):
+                            bj.vjp(t, x, g, lbv)
+                        best = min(best, (time.perf_counter() - t0) / 400 * 1e6)
+                        torch.cuda.synchronize()
+                    res["vjp_" + mode] = best
+                finally:
+                    bj._fast_plans(True)
+            print(f"{label}, pullback: general {res['vjp_general']:.1f} us/call, planned {res['vjp_planned']:.1f} us/call")
+            assert res["vjp_planned"] <= 0.8 * res["vjp_general"] and res["vjp_planned"] <= 20.0, (label, res)
         out[label] = res
         print(f"{label}: general {res['general']:.1f} us/call, planned {res['planned']:.1f} us/call (host issue, best of 5 x 400)")
         # measured on the round's boxes: 9.3-9.8 us planned against 14.4-47.6 us general (profiles/r06_host_overhead.txt); the assertion leaves room for a loaded host
