@@ -1356,6 +1356,185 @@ BJX_API int bjx_pd_vec(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, 
 }
 
 /* Scale{<:AbstractMatrix}, scale.jl:14,17,35-36 */
+// ------------------------------------------------------------------ parameter pullback of the matrix Scale (round 6)
+// ā = sign·(G Xᵀ + (Σ_n ℓ̄_n) a⁻ᵀ)  (ext/BijectorsReverseDiffExt.jl:72-115; forward: G = ȳ, X = x, sign = +1; inverse: G = the input cotangent a⁻ᵀx̄,
+// X = a⁻¹y, sign = −1).  G Xᵀ is a sum of `batch` outer products: the one dense contraction of the path with K = batch — on the matrix cores.
+// A wave owns a 64 x 64 tile of the output (4 x 4 accumulators of v_mfma_*_16x16x4) and a slice of the batch.  Both operands of the
+// instruction are indexed (lane % 16, lane / 16) = (row of the 16-block, column k of the 4-step), so a lane loads ONE element of G and
+// one of X per MFMA operand straight from the column-major arrays (16 consecutive rows = 64 / 128 contiguous bytes per column): no
+// staging, every byte of the two arrays read once per tile row / column (dim <= 64: once).  The next step's eight loads are in
+// flight during the sixteen MFMAs of this one.  Partial tiles go to the context's workspace and are folded in a fixed order
+// (no floating-point atomics: deterministic); the fold adds the log-det term from [A⁻¹] of the same factorisation kernel bjx_scale_matrix uses.
+template <class T>
+__global__ __launch_bounds__(256) void outer_sum_mfma_kernel(const T* __restrict__ G, const T* __restrict__ X, const T* __restrict__ lbar, int dim, int64_t batch,
+                                                             int64_t cols_per_wave, int tiles_1d, T* __restrict__ parts, double* __restrict__ lparts) {
+  using O = MfmaOps<T>;
+  using acc_t = typename O::acc_t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  const int ti = blockIdx.y / tiles_1d, tj = blockIdx.y % tiles_1d;
+  const int64_t wg = (int64_t)blockIdx.x * 4 + wave;                 // this wave's slice of the batch
+  const int64_t k_lo = wg * cols_per_wave;
+  int64_t k_hi = k_lo + cols_per_wave;
+  if (k_hi > batch) k_hi = batch;
+  acc_t acc[4][4];
+#pragma unroll
+  for (int I = 0; I < 4; ++I)
+#pragma unroll
+    for (int J = 0; J < 4; ++J) acc[I][J] = acc_t{0, 0, 0, 0};
+  bool rg[4], rx[4];
+#pragma unroll
+  for (int I = 0; I < 4; ++I) { rg[I] = 64 * ti + 16 * I + m < dim; rx[I] = 64 * tj + 16 * I + m < dim; }
+  const T* gp = G + 64 * ti + m;
+  const T* xp = X + 64 * tj + m;
+  // S = 4 k-steps (16 columns) per trip, double-buffered: the 32 element loads of the NEXT trip are in flight during the 64 MFMAs of this one
+  // (one step of look-ahead — 2 KiB per wave — left the kernel latency-bound at 37 % of the HBM peak; 8 KiB per wave and trip: see the row in profiles/).
+  constexpr int S = 4;
+  auto load = [&](int64_t k0, T (&a)[S][4], T (&b)[S][4]) {
+#pragma unroll
+    for (int s_ = 0; s_ < S; ++s_) {
+      const int64_t k = k0 + 4 * s_ + q;
+      const bool kok = k < k_hi;
+      const int64_t off = k * dim;
+#pragma unroll
+      for (int I = 0; I < 4; ++I) {
+        a[s_][I] = (kok && rg[I]) ? gp[off + 16 * I] : T(0);
+        b[s_][I] = (kok && rx[I]) ? xp[off + 16 * I] : T(0);
+      }
+    }
+  };
+  auto run = [&](const T (&a)[S][4], const T (&b)[S][4]) {
+#pragma unroll
+    for (int s_ = 0; s_ < S; ++s_)
+#pragma unroll
+      for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int J = 0; J < 4; ++J) acc[I][J] = O::mfma(a[s_][I], b[s_][J], acc[I][J]);
+  };
+  double lsum = 0.0;
+  T a0[S][4], b0[S][4], a1[S][4], b1[S][4];
+  if (k_lo < k_hi) load(k_lo, a0, b0);
+  for (int64_t k0 = k_lo; k0 < k_hi; k0 += 8 * S) {
+    load(k0 + 4 * S, a1, b1);                                         // (past the slice: zeros, no access)
+    run(a0, b0);
+    load(k0 + 8 * S, a0, b0);
+    run(a1, b1);
+    if (lbar && blockIdx.y == 0 && m == 0) {
+#pragma unroll
+      for (int s_ = 0; s_ < 2 * S; ++s_)
+        if (k0 + 4 * s_ + q < k_hi) lsum += (double)lbar[k0 + 4 * s_ + q];
+    }
+  }
+  // partial tile of this wave: parts[(tile * nwaves + wg)][i_local][j_local], 64 x 64, j contiguous
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  T* out = parts + ((int64_t)blockIdx.y * nwaves + wg) * 4096;
+#pragma unroll
+  for (int I = 0; I < 4; ++I)
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(16 * I + O::row(q, r)) * 64 + 16 * J + m] = acc[I][J][r];
+  if (lparts && blockIdx.y == 0) {
+    lsum = group_sum<64>(lsum);
+    if (lane == 0) lparts[wg] = lsum;
+  }
+}
+
+// stage 1: thread (o, c) sums the waves [c·per, (c+1)·per) of entry o of a tile; stage 2 adds the C chunk sums, the log-det term and writes ā (column-major)
+template <class T>
+__global__ __launch_bounds__(256) void outer_sum_fold1_kernel(const T* __restrict__ parts, int64_t nwaves, int per, double* __restrict__ stage) {
+  const int o = blockIdx.x * 256 + threadIdx.x;                      // 0 .. 4095 within the tile blockIdx.z
+  const int c = blockIdx.y;
+  const int64_t lo = (int64_t)c * per, hi = lo + per < nwaves ? lo + per : nwaves;
+  const T* p = parts + (int64_t)blockIdx.z * nwaves * 4096 + o;
+  double s0 = 0.0, s1 = 0.0;
+  int64_t w = lo;
+  for (; w + 1 < hi; w += 2) { s0 += (double)p[w * 4096]; s1 += (double)p[(w + 1) * 4096]; }
+  if (w < hi) s0 += (double)p[w * 4096];
+  stage[((int64_t)blockIdx.z * gridDim.y + c) * 4096 + o] = s0 + s1;
+}
+template <class T>
+__global__ __launch_bounds__(256) void outer_sum_fold2_kernel(const double* __restrict__ stage, int C_, const double* __restrict__ lparts, int64_t nwaves, const T* __restrict__ W /*[dim][2 dim]: right half A⁻¹*/,
+                                                              int dim, int tiles_1d, double sign, T* __restrict__ a_bar) {
+  __shared__ double lred[4];
+  double lsum_s = 0.0;
+  if (lparts) {                                                         // Σ ℓ̄ from the waves' partial sums, fixed order (every block recomputes it: <= 16 KiB)
+    double l = 0.0;
+    for (int64_t w = threadIdx.x; w < nwaves; w += 256) l += lparts[w];
+    l = group_sum<64>(l);
+    if ((threadIdx.x & 63) == 0) lred[threadIdx.x >> 6] = l;
+    __syncthreads();
+    lsum_s = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+  }
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  const int tile = blockIdx.y, ti = tile / tiles_1d, tj = tile % tiles_1d;
+  const int i = 64 * ti + o / 64, j = 64 * tj + o % 64;
+  if (i >= dim || j >= dim) return;
+  double s = 0.0;
+  for (int c = 0; c < C_; ++c) s += stage[((int64_t)tile * C_ + c) * 4096 + o];
+  if (lparts) s += lsum_s * (double)W[(int64_t)j * 2 * dim + dim + i];          // a⁻ᵀ[i][j] = A⁻¹[j][i]
+  a_bar[(int64_t)j * dim + i] = (T)(sign * s);
+}
+
+template <class T>
+int scale_matrix_vjp_params_impl(bjx_ctx* ctx, const T* a, const T* g, const T* x, const T* ladj_bar, double sign, T* a_bar, int64_t dim, int64_t batch) {
+  const int tiles_1d = (int)((dim + 63) / 64), ntiles = tiles_1d * tiles_1d;
+  // slices of the batch: enough waves to fill the chip twice over all tiles, at least 64 columns each
+  int64_t blocks = ((int64_t)ctx->num_cu * 2 + ntiles - 1) / ntiles;
+  if (blocks < 1) blocks = 1;
+  int64_t cpw = (batch + blocks * 4 - 1) / (blocks * 4);
+  if (cpw < 64) cpw = 64;
+  cpw = (cpw + 31) / 32 * 32;
+  blocks = (batch + cpw * 4 - 1) / (cpw * 4);
+  if (blocks < 1) blocks = 1;
+  const int64_t nwaves = blocks * 4;
+  constexpr int C_ = 16;
+  const size_t mat_bytes = ((size_t)dim * 2 * dim * sizeof(T) + 15) / 16 * 16;
+  const size_t parts_bytes = (size_t)ntiles * nwaves * 4096 * sizeof(T);
+  const size_t stage_bytes = (size_t)ntiles * C_ * 4096 * sizeof(double);
+  const size_t lp_bytes = ((size_t)nwaves * sizeof(double) + 15) / 16 * 16;
+  { const int rc = bjx_ensure_big_ws(ctx, mat_bytes + 16 + parts_bytes + stage_bytes + lp_bytes); if (rc) return rc; }
+  char* ws = static_cast<char*>(ctx->big_ws);
+  T* W = reinterpret_cast<T*>(ws);
+  double* lad = reinterpret_cast<double*>(ws + mat_bytes);
+  T* parts = reinterpret_cast<T*>(ws + mat_bytes + 16);
+  double* stage = reinterpret_cast<double*>(ws + mat_bytes + 16 + parts_bytes);
+  double* lparts = reinterpret_cast<double*>(ws + mat_bytes + 16 + parts_bytes + stage_bytes);
+  if (ladj_bar) {                  // [A | I] -> [· | A⁻¹]: the factorisation of bjx_scale_matrix (LDS form where it fits)
+    const size_t lds_p = dim <= 128 ? scale_prep_lds_bytes<T>(dim, 1) : 0;
+    if (lds_p) {
+      bjx_allow_big_lds(scale_matrix_prep_lds_kernel<T>, lds_p);
+      hipLaunchKernelGGL((scale_matrix_prep_lds_kernel<T>), dim3(1), dim3(512), lds_p, ctx->stream, a, W, (int)dim, 1, lad);
+    } else {
+      hipLaunchKernelGGL((scale_matrix_prep_kernel<T>), dim3(1), dim3(256), 0, ctx->stream, a, W, (int)dim, 1, lad);
+    }
+    BJX_CHECK_LAUNCH(ctx);
+  }
+  {
+    BjxProf prof_(ctx);
+    hipLaunchKernelGGL((outer_sum_mfma_kernel<T>), dim3((unsigned)blocks, (unsigned)ntiles), dim3(256), 0, ctx->stream, g, x, ladj_bar, (int)dim, batch, cpw, tiles_1d, parts,
+                       ladj_bar ? lparts : nullptr);
+    BJX_CHECK_LAUNCH(ctx);
+  }
+  const int per = (int)((nwaves + C_ - 1) / C_);
+  hipLaunchKernelGGL((outer_sum_fold1_kernel<T>), dim3(16, C_, (unsigned)ntiles), dim3(256), 0, ctx->stream, parts, nwaves, per, stage);
+  BJX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL((outer_sum_fold2_kernel<T>), dim3(16, (unsigned)ntiles), dim3(256), 0, ctx->stream, stage, C_, ladj_bar ? lparts : nullptr, nwaves, W, (int)dim, tiles_1d, sign, a_bar);
+  BJX_CHECK_LAUNCH(ctx);
+  return BJX_OK;
+}
+
+BJX_API int bjx_scale_matrix_vjp_params(bjx_ctx* ctx, bjx_dtype dt, const void* a, const void* g, const void* x, const void* ladj_bar, double sign, void* a_bar,
+                                        int64_t dim, int64_t batch) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_scale_matrix_vjp_params: bad size");
+  BJX_REQUIRE(ctx, dim <= 1024, BJX_ERR_UNSUPPORTED, "bjx_scale_matrix_vjp_params: dim = %lld: the factorisation behind a⁻ᵀ stops at 1024 rows", (long long)dim);
+  BJX_REQUIRE(ctx, a && a_bar && ((g && x) || batch == 0), BJX_ERR_ARG, "bjx_scale_matrix_vjp_params: null pointer");
+  if (dt == BJX_F32) return scale_matrix_vjp_params_impl<float>(ctx, (const float*)a, (const float*)g, (const float*)x, (const float*)ladj_bar, sign, (float*)a_bar, dim, batch);
+  if (dt == BJX_F64) return scale_matrix_vjp_params_impl<double>(ctx, (const double*)a, (const double*)g, (const double*)x, (const double*)ladj_bar, sign, (double*)a_bar, dim, batch);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_scale_matrix_vjp_params: bad dtype %d", (int)dt);
+}
+
 BJX_API int bjx_scale_matrix(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* a, const void* in, void* out, void* ladj_ps, double* ladj_sum,
                              int64_t dim, int64_t batch, uint32_t flags) {
   if (!ctx) return BJX_ERR_ARG;

@@ -2618,21 +2618,23 @@ def _vjp_matrix(base, inv, x, out_bar, ladj_bar):
 def _vjp_params_scale_matrix(b, x, out_bar, ladj_bar=None):
     """Scale with a MATRIX parameter (scale.jl:14,17,35-36; the rules of ext/BijectorsReverseDiffExt.jl:72-115): for y = a x with the
     per-column log-det logabsdet(a):  x̄ = aᵀȳ,  ā = ȳ xᵀ + (Σ_n ℓ̄_n) a⁻ᵀ; for the inverse x = a⁻¹y (log-det -logabsdet(a)):
-    ȳ = a⁻ᵀx̄,  ā = -ȳ xᵀ - (Σ ℓ̄) a⁻ᵀ.  The input side is the library's own entry with the transposed matrix; the batch
-    reduction ȳ xᵀ is a plain dense GEMM (the library GEMM of the host runtime: rocBLAS / hipBLASLt), a⁻ᵀ the library solve.
+    ȳ = a⁻ᵀx̄,  ā = -ȳ xᵀ - (Σ ℓ̄) a⁻ᵀ.  The input side is the library's own entry with the transposed matrix; the batch reduction
+    ȳ xᵀ (a sum of `batch` outer products) and the log-det term are ONE library entry since round 6 (bjx_scale_matrix_vjp_params: matrix cores,
+    deterministic fold, a⁻ᵀ from the library's own factorisation) — rounds 4-5 used the host runtime's GEMM and `torch.linalg.inv` here.
     -> (in_bar, {"a": ā})."""
     inv = isinstance(b, Inverse)
     base = b.orig if inv else b
     in_bar = vjp(b, x, out_bar, ladj_bar)
     a = colmajor(_param(base.a, x))
+    dim = x.shape[0]
     batch = 1 if x.dim() == 1 else x.shape[1]
-    lsum = 0.0 if ladj_bar is None else (float(ladj_bar) * batch if not isinstance(ladj_bar, torch.Tensor) else ladj_bar.to(a.dtype).sum())
-    ainv_t = torch.linalg.inv(a).T
-    X2, G2 = x.reshape(x.shape[0], -1), out_bar.reshape(out_bar.shape[0], -1)
-    if not inv:
-        a_bar = G2 @ X2.T + lsum * ainv_t
-    else:
-        a_bar = -(in_bar.reshape(in_bar.shape[0], -1) @ transform(b, x).reshape(x.shape[0], -1).T) - lsum * ainv_t
+    lb = None if ladj_bar is None else _ladj_bar(ladj_bar, batch, a)
+    G2 = colmajor((in_bar if inv else out_bar).reshape(dim, -1))
+    X2 = colmajor((transform(b, x) if inv else x).reshape(dim, -1))
+    a_bar = torch.empty((dim, dim), dtype=a.dtype, device=a.device).T             # column-major like `a`
+    ctx = context(a.device)
+    rc = L.load().bjx_scale_matrix_vjp_params(ctx.h, _dt(a), _ptr(a), _ptr(G2), _ptr(X2), _ptr(lb), -1.0 if inv else 1.0, _ptr(a_bar), dim, batch)
+    L.check(ctx.h, rc, "bjx_scale_matrix_vjp_params")
     return in_bar, {"a": a_bar}
 
 

@@ -259,6 +259,15 @@ int bjx_pd_vec_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, cons
  * full-covariance normal log-density without storing the whitened values (src/transformed_distribution.jl:164-169). */
 int bjx_scale_matrix(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* a, const void* in, void* out,
                      void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
+/* Parameter pullback of the matrix Scale (ext/BijectorsReverseDiffExt.jl:72-115; scale.jl:14,17,35-36):
+ *     a_bar = sign * ( g x^T + (sum_n ladj_bar[n]) a^-T )        a_bar, a: T[dim, dim] column-major; g, x: T[dim, batch]
+ * forward  y = a x     : g = y_bar, x = the input,            sign = +1   (the input cotangent is bjx_scale_matrix with a^T)
+ * inverse  x = a \ y   : g = the INPUT cotangent a^-T x_bar,  x = a \ y, sign = -1
+ * g x^T — a sum of `batch` outer products — runs on the matrix cores (v_mfma_{f32,f64}_16x16x4, 64 x 64 tiles, operands read straight from the
+ * column-major arrays), the partial tiles are folded in a fixed order (deterministic); a^-T comes from the factorisation of bjx_scale_matrix.
+ * ladj_bar may be NULL (no log-det cotangent: no factorisation).  dim <= 1024. */
+int bjx_scale_matrix_vjp_params(bjx_ctx* ctx, bjx_dtype dt, const void* a, const void* g, const void* x, const void* ladj_bar, double sign, void* a_bar,
+                                int64_t dim, int64_t batch);
 
 /* ------------------------------- F2: per-sample reduce + broadcast        */
 /* PlanarLayer, planar_layer.jl:65-127,160-185; `n_layers` stacked layers (composition

@@ -585,6 +585,18 @@ function plan_scale_matrix(a::ROCMatrix{T}, inv::Bool, x::ROCVecOrMat{T}) where 
     return Plan(:bjx_scale_matrix, size(x), :scalar, n, true, false, BJX_REF_VECTOR_SCALE_LADJ, Any[a], launch)
 end
 plan(b::Scale{<:ROCMatrix{T}}, x::ROCVecOrMat{T}) where {T<:BjxFloat} = plan_scale_matrix(b.a, false, x)
+# parameter pullback of the matrix Scale (ext/BijectorsReverseDiffExt.jl:72-115): ā = sign·(g xᵀ + Σℓ̄ · a⁻ᵀ) in one library entry — the batch-summed outer
+# product on the matrix cores, a⁻ᵀ from the library's own factorisation.  forward: g = ȳ, x = the input, sign = +1; inverse (x = a \ y): g = the input
+# cotangent a⁻ᵀx̄, x = a \ y, sign = −1.  ℓ̄ = nothing: no log-det cotangent.
+function scale_matrix_vjp_params(a::ROCMatrix{T}, g::ROCMatrix{T}, x::ROCMatrix{T}, ℓ̄::Union{Nothing,ROCVector{T}}, sign::Real) where {T<:BjxFloat}
+    d, n = size(x)
+    (size(a) == (d, d) && size(g) == (d, n)) || throw(DimensionMismatch("scale_matrix_vjp_params: a $(size(a)), g $(size(g)), x $(size(x))"))
+    ā = similar(a)
+    GC.@preserve a g x ℓ̄ ā check(ccall((:bjx_scale_matrix_vjp_params, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Ptr{Cvoid}, Int64, Int64),
+        ctx().h, dtype(T), devptr(a), devptr(g), devptr(x), devptr(ℓ̄), Cdouble(sign), devptr(ā), d, n), "bjx_scale_matrix_vjp_params")
+    return ā
+end
 plan(ib::Inverse{<:Scale{<:ROCMatrix{T}}}, y::ROCVecOrMat{T}) where {T<:BjxFloat} = plan_scale_matrix(ib.orig.a, true, y)
 
 # ---------------------------------------------------------------- the six interface methods, once (src/interface.jl:156-218)

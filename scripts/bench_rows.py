@@ -214,6 +214,11 @@ def main():
     Am = (randn(d, d, dev, 41, std=1 / math.sqrt(d)) + 1.5 * torch.eye(d, device=dev).T).T.contiguous().T
     add("Scale(64×64 matrix): a * x + logabsdet(a)", "f-4", bj.Scale(Am), x)
     add("inverse(Scale(64×64 matrix)): a \\ y", "f-4", bj.inverse(bj.Scale(Am)), x)
+    # the parameter pullback of the matrix Scale (round 6): input pullback (x̄ = aᵀȳ: x, ȳ read, x̄ written) + ā = ȳxᵀ + Σℓ̄·a⁻ᵀ (x, ȳ read again by the
+    # matrix-core outer-product kernel): 5 array passes + ℓ̄
+    gsm = randn(d, N, dev, 45)
+    lsm = randn(N, 1, dev, 46).reshape(-1).contiguous()
+    rows.append(("vjp_params(Scale(64×64 matrix)): x̄ = aᵀȳ and ā = ȳxᵀ + Σℓ̄·a⁻ᵀ (outer-product sum on the matrix cores)", "f-1", lambda: bj.vjp_params(bj.Scale(Am), x, gsm, lsm), 4 * 5 * d + 4, N))
     # the same two calls with the reuse of parameter tables opted into (bj.cache_params: the factorisation of an unchanged matrix
     # is kept — no prep kernel in the steady state), and logpdf / rand with a FULL covariance (whitening = the matrix Scale)
     cached_rows = set()

@@ -161,3 +161,40 @@ def test_scale_matrix_pullbacks(bj, dim, batch, dt):
     xin = np.linalg.solve(a64, x64)
     np.testing.assert_allclose(host(yb), ybar_ref, **{k: v * 4 for k, v in tol.items()})
     np.testing.assert_allclose(host(gri["a"]), -(ybar_ref @ xin.T) - lb64.sum() * np.linalg.inv(a64).T, **{k: v * 4 * batch ** 0.5 for k, v in tol.items()})
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dim,batch", [(64, 100003), (1, 7), (17, 4096), (128, 5000), (200, 1031), (64, 3)])
+def test_scale_matrix_parameter_pullback_entry(bj, dim, batch, dt):
+    """bjx_scale_matrix_vjp_params through the C ABI (round 6: the batch-summed outer product ȳxᵀ on the matrix cores + Σℓ̄·a⁻ᵀ, one entry): against
+    numpy in Float64 — FLAT bar on the scale of the result (the entries are sums over `batch` columns of either sign: error relative to the
+    largest entry); with and without a log-det cotangent, both signs, batches that are not multiples of the 8-column step, deterministic."""
+    import ctypes as C
+
+    L = bj._lib
+    lib = L.load()
+    ctx = bj.context()
+    r = rng(dim * 7 + batch)
+    a = (r.normal(size=(dim, dim)) / np.sqrt(dim) + 1.5 * np.eye(dim)).astype(dt)
+    g = np.asfortranarray(r.normal(size=(dim, batch)).astype(dt))
+    x = np.asfortranarray(r.normal(size=(dim, batch)).astype(dt))
+    lb = r.normal(size=batch).astype(dt)
+    ad, gd, xd, ld = dev(np.asfortranarray(a)), dev(g), dev(x), dev(lb)
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    out = torch.empty((dim, dim), dtype=tdt, device="cuda").T
+    bdt = L.BJX_F32 if dt == np.float32 else L.BJX_F64
+    rtol = 1e-3 if dt == np.float32 else 1e-6
+    gx = g.astype(np.float64) @ x.astype(np.float64).T
+    ainv_t = np.linalg.inv(a.astype(np.float64)).T
+    for lbar, sign in ((ld, 1.0), (None, 1.0), (ld, -1.0)):
+        L.check(ctx.h, lib.bjx_scale_matrix_vjp_params(ctx.h, bdt, C.c_void_p(ad.data_ptr()), C.c_void_p(gd.data_ptr()), C.c_void_p(xd.data_ptr()),
+                                                        None if lbar is None else C.c_void_p(lbar.data_ptr()), sign, C.c_void_p(out.data_ptr()), dim, batch), "bjx_scale_matrix_vjp_params")
+        ref = sign * (gx + (lb.astype(np.float64).sum() * ainv_t if lbar is not None else 0.0))
+        got = host(out).astype(np.float64)
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        assert err <= rtol, (dim, batch, sign, lbar is not None, err)
+        first = out.clone()
+        L.check(ctx.h, lib.bjx_scale_matrix_vjp_params(ctx.h, bdt, C.c_void_p(ad.data_ptr()), C.c_void_p(gd.data_ptr()), C.c_void_p(xd.data_ptr()),
+                                                        None if lbar is None else C.c_void_p(lbar.data_ptr()), sign, C.c_void_p(out.data_ptr()), dim, batch), "bjx_scale_matrix_vjp_params")
+        assert torch.equal(out, first), "the fold is not deterministic"
+    assert lib.bjx_scale_matrix_vjp_params(ctx.h, bdt, None, C.c_void_p(gd.data_ptr()), C.c_void_p(xd.data_ptr()), None, 1.0, C.c_void_p(out.data_ptr()), dim, batch) == L.ERR_ARG

@@ -68,7 +68,7 @@ def _c_to_julia(ctype):
 
 
 RET = {"int": "Cint", "size_t": "Csize_t", "const char*": "Cstring", "uint64_t": "UInt64"}
-N_ENTRIES = 76          # include/bjx.h (63 at the end of round 3 + bjx_pack_vectors + the four bjx_{vec_corr,corr,pd,pd_vec}_vjp + bjx_check_state, bjx_launch_count and the six bjx_plan_* in round 6)
+N_ENTRIES = 77          # include/bjx.h (63 at the end of round 3 + bjx_pack_vectors + the four bjx_{vec_corr,corr,pd,pd_vec}_vjp + bjx_check_state, bjx_launch_count the six bjx_plan_* and bjx_scale_matrix_vjp_params in round 6)
 
 
 def _prototypes():
@@ -231,7 +231,7 @@ def test_pullback_rules_cover_every_vjp_entry():
     for want in RRULES_WLJ:
         assert want.replace(" ", "") in heads, f"no rrule(::typeof(with_logabsdet_jacobian), ::{want}, …); have {heads}"
     vjp_entries = [n for n in _prototypes() if "_vjp" in n or n == "bjx_row_moments"]
-    assert len(vjp_entries) == 22, vjp_entries          # 20 `*_vjp*` entries + bjx_plan_stacked_vjp, bjx_plan_run_vjp (round 6)
+    assert len(vjp_entries) == 23, vjp_entries          # 20 `*_vjp*` entries + bjx_plan_stacked_vjp, bjx_plan_run_vjp, bjx_scale_matrix_vjp_params (round 6)
     called = {c[0] for c in _ccalls()}
     assert set(vjp_entries) <= called
 
