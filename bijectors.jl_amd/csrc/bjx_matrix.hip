@@ -980,6 +980,95 @@ __global__ __launch_bounds__(512) void scale_matrix_prep_lds_kernel(const T* __r
     if (t == 0) *logabsdet = a;
   }
 }
+// Round 6: the factorisation of a matrix of at most 64 rows by ONE WAVE with the matrix in REGISTERS (the block version above spends
+// 130 us at 64 x 64 — 192 block barriers — in front of a 0.4 ms hot kernel).  Lane i owns ROW i of the augmented [A | I]: registers
+// r[0 .. NC).  Gauss-Jordan WITHOUT row exchange: the pivot of step k is the largest |entry| of column k among the rows not used yet (the
+// same pivots as partial pivoting picks), the pivot row is scaled, every other row eliminated; at the end row p_k of the right block is row
+// k of A^-1.  What makes it a rolled loop of straight-line code: the update writes its result ONE REGISTER TO THE LEFT,
+//     r[j-1] = r[j] - m * pivot_row[j],      m = c_i / pivot  (own lane: m = 1 - 1/pivot, which scales the row),
+// so the current pivot column is always r[0] (no dynamic register index, nothing unrolled over k), the dead columns of the left block fall
+// off the array and after `dim` steps A^-1 sits in r[0 .. dim).  The pivot row reaches the other lanes by v_readlane (one per column).
+// No LDS, no barrier.  Float64: the same with 64-bit readlanes.  logabsdet = sum log|pivot| as before.
+template <class T> __device__ __forceinline__ T wave_readlane(T v, int l);
+template <> __device__ __forceinline__ float wave_readlane<float>(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+template <> __device__ __forceinline__ double wave_readlane<double>(double v, int l) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// maximum over the 64 lanes without LDS: four DPP butterflies inside each row of 16 lanes, then the four row maxima through SGPRs
+template <int CTRL> __device__ __forceinline__ float dpp_get(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_get(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <class T> __device__ __forceinline__ T wave_max_nolds(T v) {
+  v = d_max(v, dpp_get<0xB1>(v));      // quad_perm [1,0,3,2]
+  v = d_max(v, dpp_get<0x4E>(v));      // quad_perm [2,3,0,1]
+  v = d_max(v, dpp_get<0x141>(v));     // row_half_mirror
+  v = d_max(v, dpp_get<0x140>(v));     // row_mirror: every lane of a row of 16 holds the row's maximum
+  const T a = wave_readlane<T>(v, 0), b = wave_readlane<T>(v, 16), c = wave_readlane<T>(v, 32), d = wave_readlane<T>(v, 48);
+  return d_max(d_max(a, b), d_max(c, d));
+}
+template <class T, bool WI>
+__global__ __launch_bounds__(64) void scale_matrix_prep_wave_kernel(const T* __restrict__ A, T* __restrict__ W /*[dim][2 dim] row-major*/, int dim, double* logabsdet) {
+  constexpr int DP = 64, NC = WI ? 2 * DP : DP;
+  const int lane = threadIdx.x;
+  const bool live = lane < dim;
+  T r[NC];
+#pragma unroll
+  for (int j = 0; j < DP; ++j) r[j] = (live && j < dim) ? A[(size_t)j * dim + lane] : T(0);        // A is column-major: lanes on consecutive addresses
+  if (WI) {
+#pragma unroll
+    for (int j = 0; j < DP; ++j) r[DP + j] = T(0);
+    // the identity block starts at column `dim` of the augmented matrix: [A | I] occupies r[0 .. 2 dim); move it there
+#pragma unroll
+    for (int j = 0; j < NC; ++j) r[j] = (j >= dim && j - dim == lane && live) ? T(1) : (j < dim ? r[j] : T(0));
+  }
+  bool used = !live;
+  int my_step = -1;                                        // the step at which my row was the pivot row
+  T my_piv = T(1);                                         // ... and its pivot (the logarithms are taken once, in parallel, after the loop)
+  for (int k = 0; k < dim; ++k) {
+    const T c = r[0];
+    // largest |c| among the unused rows, lowest lane on ties — no LDS: the maximum by butterflies inside the rows of 16 lanes (DPP) and four
+    // readlanes across them, the lane by a ballot (a single wave has nothing to hide an LDS round trip behind: the ds_bpermute form of this
+    // search was half of the kernel's 83 us)
+    const T cand = used ? T(-1) : d_abs(c);
+    const T wmax = wave_max_nolds(cand);
+    const unsigned long long hit = __ballot(cand == wmax);
+    const int p = hit ? (int)__builtin_ctzll(hit) : 0;     // (all NaN: no lane compares equal — the factorisation is NaN either way)
+    const T pv = wave_readlane<T>(c, p);
+    const T rpv = T(1) / pv;
+    const T m = lane == p ? T(1) - rpv : c * rpv;
+    if (lane == p) { used = true; my_step = k; my_piv = pv; }
+    // the pivot row in chunks of 16 columns: sixteen readlanes (SGPR results), then sixteen FMAs — back to back, a VALU instruction that reads the
+    // SGPR a readlane has just written waits for it (the one-by-one form ran at ~11 cycles per column)
+#pragma unroll
+    for (int j0 = 1; j0 < NC; j0 += 16) {
+      T wp[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) wp[u] = j0 + u < NC ? wave_readlane<T>(r[j0 + u], p) : T(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) if (j0 + u < NC) r[j0 + u - 1] = r[j0 + u] - m * wp[u];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    r[NC - 1] = T(0);
+  }
+  if (WI && my_step >= 0) {                                // my row of the reduced right block is row my_step of A^-1
+    T* dst = W + (size_t)my_step * (2 * dim) + dim;
+#pragma unroll
+    for (int j = 0; j < DP; ++j) if (j < dim) dst[j] = r[j];
+  }
+  double lad = my_step >= 0 ? ::log((double)d_abs(my_piv)) : 0.0;        // one logarithm per lane, then a fixed-order wave sum
+  lad = group_sum<64>(lad);
+  if (lane == 0) *logabsdet = lad;
+}
+
 // dynamic LDS of the kernel above (0: does not fit, take the global-memory sweep)
 template <class T> inline size_t scale_prep_lds_bytes(int64_t dim, int want_inverse) {
   const size_t W2 = want_inverse ? 2 * (size_t)dim : (size_t)dim;
@@ -1262,7 +1351,11 @@ int scale_matrix_impl(bjx_ctx* ctx, int inverse, const T* a, const T* in, T* out
     }
     if (build) {
       const size_t lds_p = scale_prep_lds_bytes<T>(dim, inverse ? 1 : 0);
-      if (lds_p) {
+      static const int use_wave = getenv("BJX_SCALE_PREP_WAVE") ? atoi(getenv("BJX_SCALE_PREP_WAVE")) : 1;       // 0: the block-wide LDS factorisation of round 5
+      if (use_wave && dim <= 64) {
+        if (inverse) hipLaunchKernelGGL((scale_matrix_prep_wave_kernel<T, true>), dim3(1), dim3(64), 0, ctx->stream, a, W, (int)dim, lad_build);
+        else hipLaunchKernelGGL((scale_matrix_prep_wave_kernel<T, false>), dim3(1), dim3(64), 0, ctx->stream, a, W, (int)dim, lad_build);
+      } else if (lds_p) {
         bjx_allow_big_lds(scale_matrix_prep_lds_kernel<T>, lds_p);
         hipLaunchKernelGGL((scale_matrix_prep_lds_kernel<T>), dim3(1), dim3(512), lds_p, ctx->stream, a, W, (int)dim, inverse ? 1 : 0, lad_build);
       } else {
@@ -1502,7 +1595,10 @@ int scale_matrix_vjp_params_impl(bjx_ctx* ctx, const T* a, const T* g, const T* 
   double* lparts = reinterpret_cast<double*>(ws + mat_bytes + 16 + parts_bytes + stage_bytes);
   if (ladj_bar) {                  // [A | I] -> [· | A⁻¹]: the factorisation of bjx_scale_matrix (LDS form where it fits)
     const size_t lds_p = dim <= 128 ? scale_prep_lds_bytes<T>(dim, 1) : 0;
-    if (lds_p) {
+    static const int use_wave2 = getenv("BJX_SCALE_PREP_WAVE") ? atoi(getenv("BJX_SCALE_PREP_WAVE")) : 1;
+    if (use_wave2 && dim <= 64) {
+      hipLaunchKernelGGL((scale_matrix_prep_wave_kernel<T, true>), dim3(1), dim3(64), 0, ctx->stream, a, W, (int)dim, lad);
+    } else if (lds_p) {
       bjx_allow_big_lds(scale_matrix_prep_lds_kernel<T>, lds_p);
       hipLaunchKernelGGL((scale_matrix_prep_lds_kernel<T>), dim3(1), dim3(512), lds_p, ctx->stream, a, W, (int)dim, 1, lad);
     } else {

@@ -22,7 +22,7 @@ SETTINGS = [
     "BJX_SEQ_TINY=0", "BJX_SEQ_TALL=0", "BJX_SIMPLEX_VJP_TALL=0", "BJX_CHAIN_TINY=0", "BJX_PLANAR_REG_UNALIGNED=0", "BJX_PLANAR_REG_BIG=0",
     "BJX_FLOW_UNALIGNED=0", "BJX_COL_UNALIGNED=0", "BJX_STACKED_VJP_UNALIGNED=0", "BJX_COL_SLAB=0", "BJX_STACKED_SLAB=0", "BJX_STACKED_SLAB=64",
     "BJX_CHAIN_UNALIGNED=0", "BJX_PLANAR_WALK_DIRECT=0", "BJX_COLDIRECT=0", "BJX_STACKED_TINY=0", "BJX_CHOL_CHUNK=0", "BJX_CHOL_LANE_MAX=0",
-    "BJX_CHOL_FWD_VJP_SWZ=0", "BJX_STACKED_WALKER=0", "BJX_RQS_SLAB=0", "BJX_RQS_SLAB=32", "BJX_RQS_KNOTS_SHARED=0", "BJX_RQS_KNOTS_SHARED=2", "BJX_ORDERED_VJP_TALL=0",
+    "BJX_CHOL_FWD_VJP_SWZ=0", "BJX_STACKED_WALKER=0", "BJX_RQS_SLAB=0", "BJX_RQS_SLAB=32", "BJX_RQS_KNOTS_SHARED=0", "BJX_RQS_KNOTS_SHARED=2", "BJX_SCALE_PREP_WAVE=0", "BJX_ORDERED_VJP_TALL=0",
     "BJX_PLANAR_COLS_MIN_F32=0", "BJX_PLANAR_COLS_MIN_F64=0", "BJX_PLANAR_VJP_COLS_MIN_F32=0", "BJX_PLANAR_VJP_COLS_MIN_F64=0", "BJX_PLANAR_PARAM_ROWS=0", "BJX_PLANAR_PARAM_ROWS=33", "BJX_PLANAR_TILE_MAX_F64=128", "BJX_PLANAR_TILE_MAX_F64=32",
 ]
 
