@@ -133,6 +133,7 @@ SIGNATURES = {
     "bjx_plan_chain": (_i, [_vp, _i, C.POINTER(BjxOp), _i, _i64, _u32, C.POINTER(_vp)]),
     "bjx_plan_structured": (_i, [_vp, _i, _i, _i, _i64, _u32, C.POINTER(_vp)]),
     "bjx_plan_run": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "bjx_plan_stacked": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _i64, _u32, C.POINTER(_vp)]),
     "bjx_plan_stacked_vjp": (_i, [_vp, _i, C.POINTER(BjxSegment), _i, _i64, C.POINTER(_vp)]),
     "bjx_plan_run_vjp": (_i, [_vp, _vp, _vp, _vp, _vp, _i64]),
     "bjx_plan_destroy": (_i, [_vp]),

@@ -375,6 +375,15 @@ BJX_API int bjx_plan_stacked_vjp(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* 
   return BJX_OK;
 }
 
+BJX_API int bjx_plan_stacked(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, int64_t dim, uint32_t flags, bjx_plan** out) {
+  // same record as the pullback plan, run by bjx_plan_run through bjx_stacked
+  const int rc = bjx_plan_stacked_vjp(ctx, dt, segs, n_segs, dim, out);
+  if (rc) return rc;
+  (*out)->kind = BJX_PLAN_STACKED;
+  (*out)->flags = flags;
+  return BJX_OK;
+}
+
 BJX_API int bjx_plan_run_vjp(bjx_plan* plan, const void* x, const void* y_bar, const void* ladj_bar, void* x_bar, int64_t batch) {
   if (!plan || !plan->ctx) return BJX_ERR_ARG;
   BJX_REQUIRE(plan->ctx, plan->kind == BJX_PLAN_STACKED_VJP, BJX_ERR_ARG, "bjx_plan_run_vjp: not a pullback plan (kind %d)", plan->kind);
@@ -402,6 +411,7 @@ BJX_API int bjx_plan_run(bjx_plan* plan, const void* in, void* out, void* ladj_p
   }
   int rc;
   if (plan->kind == BJX_PLAN_CHAIN) rc = bjx_chain(ctx, plan->dt, plan->ops, plan->n_ops, in, out, ladj_ps, sum, plan->dim, batch, plan->flags);
+  else if (plan->kind == BJX_PLAN_STACKED) rc = bjx_stacked(ctx, plan->dt, plan->segs, plan->n_segs, in, out, ladj_ps, sum, plan->dim, batch, plan->flags);
   else if (plan->kind == BJX_PLAN_SIMPLEX) rc = bjx_simplex(ctx, plan->dt, plan->inverse, in, out, ladj_ps, sum, plan->inverse ? plan->dim + 1 : plan->dim, batch, plan->flags);
   else rc = bjx_ordered(ctx, plan->dt, plan->inverse, in, out, ladj_ps, sum, plan->dim, batch, plan->flags);
   if (ladj_sum_t) {

@@ -587,7 +587,38 @@ def _fast_build(owner, get_ops, x, dim, per_sample, key):
     return fp
 
 
-def _fast_chain(owner, get_ops, x, per_sample):
+def _fast_build_stacked(owner, get_ops, x, dim, per_sample, key):
+    """A `Stacked` whose segments are all elementwise chains of <= 4 ops, same height in and out: one bjx_stacked launch (bjx_plan_stacked)."""
+    def not_applicable():
+        fp = _FastPlan(None, _BIJ_EPOCH[0], None, None, False)
+        owner.__dict__.setdefault("_fast", {})[key] = fp
+        return fp
+
+    if dim != owner.length_in or owner.length_out != dim:
+        return not_applicable()
+    segs_ops = [_elementwise_ops(b) for b in owner.bs]
+    if any(o is None or len(o) > L.BJX_MAX_SEG_OPS for o in segs_ops):
+        return not_applicable()
+    segs2 = [_elementwise_ops(b) for b in owner.bs]                    # parameters that are temporaries are new tensors every time
+    for o1, o2 in zip(segs_ops, segs2):
+        for (k1, a0, a1), (k2, b0, b1) in zip(o1, o2):
+            for p_, q_ in ((a0, b0), (a1, b1)):
+                if isinstance(p_, torch.Tensor) and p_ is not q_:
+                    return not_applicable()
+    arr, keep = owner._segments(segs_ops, list(range(len(owner.bs))), x)
+    if keep:                                                           # converted / broadcast parameters: the general path makes them per call
+        return not_applicable()
+    params = [p_ for o in segs_ops for (_, a0, a1) in o for p_ in (a0, a1) if isinstance(p_, torch.Tensor)]
+    ctx = context(x.device)
+    h = C.c_void_p()
+    rc = L.load().bjx_plan_stacked(ctx.h, _dt(x), arr, len(owner.bs), dim, 0, C.byref(h))
+    L.check(ctx.h, rc, "bjx_plan_stacked")
+    fp = _FastPlan(h, _BIJ_EPOCH[0], params + [arr], ctx, x.dtype == torch.float32)
+    owner.__dict__.setdefault("_fast", {})[key] = fp
+    return fp
+
+
+def _fast_chain(owner, get_ops, x, per_sample, build=None):
     """-> (y, ladj) through a cached bjx_plan, or None when this call does not qualify (then the general path runs)."""
     if _FAST_OFF[0] or not isinstance(x, torch.Tensor) or not x.is_cuda or _OUT_HINT:
         return None
@@ -612,7 +643,7 @@ def _fast_chain(owner, get_ops, x, per_sample):
     cache = owner.__dict__.get("_fast")
     fp = cache.get(key) if cache is not None else None
     if fp is None or fp.epoch != _BIJ_EPOCH[0]:
-        fp = _fast_build(owner, get_ops, x, dim, per_sample, key)
+        fp = (build or _fast_build)(owner, get_ops, x, dim, per_sample, key)
     if fp.h is None:
         return None
     y = torch.empty(dim, dtype=dt, device=x.device) if nd == 1 else torch.empty((batch, dim), dtype=dt, device=x.device).T
@@ -626,6 +657,12 @@ def _fast_chain(owner, get_ops, x, per_sample):
             rc = run(fp.h, x.data_ptr(), y.data_ptr(), None, None, l.data_ptr(), batch)       # the library writes the sum as Float32 too
         else:
             rc = run(fp.h, x.data_ptr(), y.data_ptr(), None, l.data_ptr(), None, batch)
+    if rc == L.ERR_UNSUPPORTED:                         # a shape the planned entry does not take (bjx_stacked: > 2 nonlinear stages in a segment): remember, general path
+        try:
+            L.load().bjx_plan_destroy(fp.h)
+        finally:
+            fp.h = None
+        return None
     if rc != 0:
         L.check(fp.ctx.h, rc, "bjx_plan_run")
     return y, l
@@ -718,6 +755,10 @@ def with_logabsdet_jacobian(b, x, per_sample: bool = False):
     per-column log-det vector."""
     if (per_sample is False or per_sample is True) and isinstance(b, (ComposedFunction, _ChainOp, Elementwise, Inverse)):
         r = _fast_chain(b, lambda: _fused_ops(b), x, per_sample)
+        if r is not None:
+            return r
+    if (per_sample is False or per_sample is True) and isinstance(b, Stacked) and isinstance(x, torch.Tensor) and x.dim() == 2:
+        r = _fast_chain(b, None, x, per_sample, build=_fast_build_stacked)       # heterogeneous products: one bjx_stacked launch through a plan
         if r is not None:
             return r
     if b is identity:
@@ -1057,6 +1098,10 @@ def _stage_ops(s):
     if isinstance(s, _ChainOp):
         return s._ops(False)
     if isinstance(s, Inverse) and isinstance(s.orig, _ChainOp):
+        return s.orig._ops(True)
+    if getattr(s, "_elementwise_stage", False):          # the scalar links of src/vector/ (vector.py: ScalarToScalarBijector)
+        return s._ops(False)
+    if isinstance(s, Inverse) and getattr(s.orig, "_elementwise_stage", False):
         return s.orig._ops(True)
     return None
 

@@ -29,7 +29,10 @@ __all__ = ["Exp", "Log", "Truncate", "Untruncate", "TypedIdentity", "scalar_to_s
 
 
 class ScalarToScalarBijector(I.Bijector):
-    """A scalar map applied to every element; evaluated by the fused chain kernel."""
+    """A scalar map applied to every element; evaluated by the fused chain kernel (alone, inside a composition, or as a segment of a
+    `Stacked`: interface._stage_ops reads `_elementwise_stage`)."""
+
+    _elementwise_stage = True
 
     def _ops(self, inv=False):
         raise NotImplementedError

@@ -605,12 +605,14 @@ int bjx_graph_destroy(bjx_graph* graph);
  *                         the scalar in the element type, and a host-side conversion is another launch.  With ladj_sum_t given,
  *                         ladj_sum may be NULL (the Float64 accumulator then lives in the context). */
 typedef struct bjx_plan bjx_plan;
-enum { BJX_PLAN_CHAIN = 1, BJX_PLAN_SIMPLEX = 2, BJX_PLAN_ORDERED = 3, BJX_PLAN_STACKED_VJP = 4 };
+enum { BJX_PLAN_CHAIN = 1, BJX_PLAN_SIMPLEX = 2, BJX_PLAN_ORDERED = 3, BJX_PLAN_STACKED_VJP = 4, BJX_PLAN_STACKED = 5 };
 int bjx_plan_chain(bjx_ctx* ctx, bjx_dtype dt, const bjx_op* ops, int n_ops, int64_t dim, uint32_t flags, bjx_plan** out);
 int bjx_plan_structured(bjx_ctx* ctx, bjx_dtype dt, int kind, int inverse, int64_t dim, uint32_t flags, bjx_plan** out);
 int bjx_plan_run(bjx_plan* plan, const void* in, void* out, void* ladj_ps, double* ladj_sum, void* ladj_sum_t, int64_t batch);
 /* The pullback a gradient-based sampler repeats on every leapfrog step: bjx_stacked_vjp's segment list (an elementwise chain = one segment over all
  * rows) validated once; bjx_plan_run_vjp(plan, x, y_bar, ladj_bar, x_bar, batch) has bjx_stacked_vjp's meaning. */
+/* A `Stacked` of elementwise chains (bjx_stacked: the linked vector of a heterogeneous product distribution, src/vector/interface.jl:86-129), run by bjx_plan_run. */
+int bjx_plan_stacked(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, int64_t dim, uint32_t flags, bjx_plan** out);
 int bjx_plan_stacked_vjp(bjx_ctx* ctx, bjx_dtype dt, const bjx_segment* segs, int n_segs, int64_t dim, bjx_plan** out);
 int bjx_plan_run_vjp(bjx_plan* plan, const void* x, const void* y_bar, const void* ladj_bar, void* x_bar, int64_t batch);
 int bjx_plan_destroy(bjx_plan* plan);

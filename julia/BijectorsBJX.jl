@@ -867,14 +867,16 @@ function with_logabsdet_jacobian(sb::Stacked, x::ROCVecOrMat{T}) where {T<:BjxFl
     segs = elementwise_segments(sb, T, keep)
     segs === nothing && return stacked_structured(sb, x)                                   # Simplex / Ordered blocks: below
     y = similar(x)
-    lsum = AMDGPU.zeros(Float64, 1)
+    c = ctx()
+    lsum = c.lsum                                              # the context's reused result slot (no device allocation per call)
     GC.@preserve keep x y lsum begin
         rc = ccall((:bjx_stacked, libbjx), Cint,
             (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, UInt32),
-            ctx().h, dtype(T), segs, length(segs), devptr(x), devptr(y), C_NULL, Ptr{Cdouble}(pointer(lsum)), d, n, UInt32(0))
+            c.h, dtype(T), segs, length(segs), devptr(x), devptr(y), C_NULL, Ptr{Cdouble}(pointer(lsum)), d, n, UInt32(0))
         check(rc, "bjx_stacked")
     end
-    return y, T(Array(lsum)[1])
+    copyto!(c.hsum, c.lsum)
+    return y, T(c.hsum[1])
 end
 transform(sb::Stacked, x::ROCVecOrMat{<:BjxFloat}) = first(with_logabsdet_jacobian(sb, x))
 logabsdetjac(sb::Stacked, x::ROCVecOrMat{<:BjxFloat}) = last(with_logabsdet_jacobian(sb, x))
@@ -1005,9 +1007,9 @@ function product_launch(links, x::ROCMatrix{T}) where {T<:BjxFloat}
     segs = product_segments(links)
     segs === nothing && throw(ArgumentError("a component link needs more than 4 fused ops"))
     y = similar(x); lps = similar(x, T, n)
-    GC.@preserve segs x y lps check(ccall((:bjx_stacked, libbjx), Cint,
-        (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, UInt32),
-        ctx().h, dtype(T), segs, length(segs), devptr(x), devptr(y), devptr(lps), C_NULL, P, n, UInt32(0)), "bjx_stacked")
+    # what DynamicPPL repeats on every log-density evaluation: the segment list goes through a launch plan (validated once per context)
+    cp = stacked_cplan(segs, Any[], T, Int(P), UInt32(0))
+    GC.@preserve segs cp x y lps check(plan_run(cp, devptr(x), devptr(y), devptr(lps), C_NULL, n), "bjx_plan_run")
     return y, lps
 end
 const LinkTuple{P} = Union{NTuple{P,WrappedLink},NamedTuple{<:Any,<:NTuple{P,WrappedLink}}}
@@ -1160,6 +1162,21 @@ function stacked_vjp_cplan(segs::Vector{BjxSegment}, keep, ::Type{T}, d::Int) wh
             hp = Ref{Ptr{Cvoid}}(C_NULL)
             GC.@preserve segs keep check(ccall((:bjx_plan_stacked_vjp, libbjx), Cint, (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Int64, Ptr{Ptr{Cvoid}}),
                                                c.h, dtype(T), segs, length(segs), d, hp), "bjx_plan_stacked_vjp")
+            cp = CPlan(hp[], copy(keep))
+            finalizer(x -> ccall((:bjx_plan_destroy, libbjx), Cint, (Ptr{Cvoid},), x.h), cp)
+            cp
+        end
+    end
+end
+# the forward `Stacked` of elementwise segments through a plan (bjx_plan_stacked, run by plan_run): the linked vector of a heterogeneous product
+function stacked_cplan(segs::Vector{BjxSegment}, keep, ::Type{T}, d::Int, flags::UInt32) where {T}
+    c = ctx()
+    key = (c.h, hash(segs) ⊻ UInt(flags) ⊻ UInt(0x5), T, d)
+    lock(CPLANS_LOCK) do
+        get!(VJP_PLANS, key) do
+            hp = Ref{Ptr{Cvoid}}(C_NULL)
+            GC.@preserve segs keep check(ccall((:bjx_plan_stacked, libbjx), Cint, (Ptr{Cvoid}, Cint, Ptr{BjxSegment}, Cint, Int64, UInt32, Ptr{Ptr{Cvoid}}),
+                                               c.h, dtype(T), segs, length(segs), d, flags, hp), "bjx_plan_stacked")
             cp = CPlan(hp[], copy(keep))
             finalizer(x -> ccall((:bjx_plan_destroy, libbjx), Cint, (Ptr{Cvoid},), x.h), cp)
             cp

@@ -143,6 +143,35 @@ def test_f2_product_transform_uses_a_plan_and_matches(bj):
     assert any(fp.h is not None for fp in t.__dict__["_fast"].values())
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_stacked_of_elementwise_segments_through_a_plan(bj, dt):
+    """The linked vector of a heterogeneous product distribution (src/vector/interface.jl:86-129) is a `Stacked` of elementwise links: one
+    bjx_stacked launch through bjx_plan_stacked; results and return shapes of the general path, bit for bit."""
+    r = np.random.default_rng(21)
+    V = bj.vector
+    comps = [(V.scalar_to_scalar_bijector(-np.inf, np.inf), 3), (V.scalar_to_scalar_bijector(0.0, 1.0), 5), (V.scalar_to_scalar_bijector(0.0, np.inf), 2), (V.scalar_to_scalar_bijector(-1.0, 2.0), 30)]
+    st = V.from_linked_vec_product(comps)
+    assert isinstance(st, bj.Stacked)
+    x = _cm(r.normal(size=(40, 77)).astype(dt))
+    for ps in (False, True):
+        bj._fast_plans(False)
+        try:
+            y0, l0 = bj.with_logabsdet_jacobian(st, x, per_sample=ps)
+        finally:
+            bj._fast_plans(True)
+        y1, l1 = bj.with_logabsdet_jacobian(st, x, per_sample=ps)
+        y2, l2 = bj.with_logabsdet_jacobian(st, x, per_sample=ps)
+        for y, l in ((y1, l1), (y2, l2)):
+            assert l.shape == l0.shape and l.dtype == l0.dtype and torch.equal(y, y0) and torch.equal(l, l0), ps
+    assert any(fp.h is not None for fp in st.__dict__["_fast"].values()), "the elementwise Stacked did not get a plan"
+    # a Stacked with a structured segment is not planned (the general path slices it)
+    P = r.dirichlet(np.ones(5), size=77).T
+    X2 = _cm(np.vstack([P, r.normal(size=(2, 77))]).astype(dt))
+    b2 = bj.Stacked([bj.SimplexBijector(), bj.elementwise(bj.exp)], [(1, 5), (6, 7)])
+    bj.with_logabsdet_jacobian(b2, X2, per_sample=True)
+    assert all(fp.h is None for fp in b2.__dict__["_fast"].values())
+
+
 def test_plan_entries_through_the_c_abi(bj):
     L = bj._lib
     lib = L.load()
