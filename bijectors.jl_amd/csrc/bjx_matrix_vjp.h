@@ -42,4 +42,7 @@ template <int KIND> __host__ __device__ inline int64_t free_len(int64_t K) {
 // Returns 1 when the shape is not served.
 int bjx_matrix_vjp_grp(bjx_ctx* ctx, bjx_dtype dt, int kind, int inverse, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K, int64_t batch);
 
+// The inverse direction (y -> X) of the same shapes with the cubic step as MFMA blocks (bjx_matrix_vjp_mfma.hip).  Returns 1 when not served.
+int bjx_matrix_inv_vjp_mfma(bjx_ctx* ctx, bjx_dtype dt, int kind, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K, int64_t batch);
+
 }  // namespace bjx

@@ -399,6 +399,10 @@ namespace bjx {
 int bjx_matrix_vjp_grp(bjx_ctx* ctx, bjx_dtype dt, int kind, int inverse, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K, int64_t batch) {
   static const int use_grp = getenv("BJX_MATRIX_VJP_GRP") ? atoi(getenv("BJX_MATRIX_VJP_GRP")) : 1;      // 0: the one-lane-per-sample workspace kernel (its A/B)
   // K = 9 ... 12 too: same call, 2^19 samples, K = 12: 24-48 % of the HBM peak here against 19-27 % for the twelve-row register kernel
+  if (inverse && use_grp) {                               // the product on the matrix cores, odd pitch, in-place reverse sweep (bjx_matrix_vjp_mfma.hip)
+    const int rc = bjx_matrix_inv_vjp_mfma(ctx, dt, kind, in, out_bar, ladj_bar, in_bar, K, batch);
+    if (rc != 1) return rc;
+  }
   if (!use_grp || K < 9 || K > 64 || (K > 32 && dt != BJX_F32)) return 1;
   if (dt == BJX_F32) return grp_kind<float>(ctx, kind, inverse, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, K, batch);
   return grp_kind<double>(ctx, kind, inverse, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, K, batch);
