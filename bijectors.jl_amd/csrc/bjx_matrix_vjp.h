@@ -38,9 +38,29 @@ template <int KIND> __host__ __device__ inline int64_t free_len(int64_t K) {
 }
 
 
+// 16 x 16 x 4 MFMA of the element type, and where register r of lane (n, q) of its result sits (bjx_matrix_vjp_mfma*.hip)
+template <class T> struct VjpMfma;
+template <> struct VjpMfma<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static constexpr int N = 4;
+  typedef float V __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int q, int r) { return 4 * q + r; }        // D register r of lane (n, q) -> row of the 16-block
+};
+template <> struct VjpMfma<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static constexpr int N = 2;
+  typedef double V __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int q, int r) { return 4 * r + q; }        // probed: scripts/probe_mfma_f64.hip
+};
+
 // 8 < K <= 64 (Float64: <= 32): one group of 16 / 32 / 64 lanes per sample, the factor and its cotangent in LDS (bjx_matrix_vjp_grp.hip).
 // Returns 1 when the shape is not served.
 int bjx_matrix_vjp_grp(bjx_ctx* ctx, bjx_dtype dt, int kind, int inverse, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K, int64_t batch);
+
+// The forward direction (X -> y): Cholesky reverse as S = W' Φ(L' L̄) W with W = L⁻¹ by blocks, every product on MFMA (bjx_matrix_vjp_mfma_fwd.hip).  Returns 1 when not served.
+int bjx_matrix_fwd_vjp_mfma(bjx_ctx* ctx, bjx_dtype dt, int kind, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K, int64_t batch);
 
 // The inverse direction (y -> X) of the same shapes with the cubic step as MFMA blocks (bjx_matrix_vjp_mfma.hip).  Returns 1 when not served.
 int bjx_matrix_inv_vjp_mfma(bjx_ctx* ctx, bjx_dtype dt, int kind, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K, int64_t batch);

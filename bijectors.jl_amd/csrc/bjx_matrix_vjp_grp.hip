@@ -403,6 +403,10 @@ int bjx_matrix_vjp_grp(bjx_ctx* ctx, bjx_dtype dt, int kind, int inverse, const 
     const int rc = bjx_matrix_inv_vjp_mfma(ctx, dt, kind, in, out_bar, ladj_bar, in_bar, K, batch);
     if (rc != 1) return rc;
   }
+  if (!inverse && use_grp) {                              // W = L⁻¹ by blocks, the reverse of the factorisation as MFMA products (bjx_matrix_vjp_mfma_fwd.hip)
+    const int rc = bjx_matrix_fwd_vjp_mfma(ctx, dt, kind, in, out_bar, ladj_bar, in_bar, K, batch);
+    if (rc != 1) return rc;
+  }
   if (!use_grp || K < 9 || K > 64 || (K > 32 && dt != BJX_F32)) return 1;
   if (dt == BJX_F32) return grp_kind<float>(ctx, kind, inverse, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, K, batch);
   return grp_kind<double>(ctx, kind, inverse, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, K, batch);

@@ -35,22 +35,6 @@ namespace {
 __device__ __forceinline__ void mf_sync() { tile_sync(); __builtin_amdgcn_sched_barrier(0); }
 #define MF_FENCE4(i_) do { if (((i_) % 4) == 3) __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <class T> struct VjpMfma;
-template <> struct VjpMfma<float> {
-  typedef float acc_t __attribute__((ext_vector_type(4)));
-  static constexpr int N = 4;
-  typedef float V __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ int row(int q, int r) { return 4 * q + r; }        // D register r of lane (n, q) -> row of the 16-block
-};
-template <> struct VjpMfma<double> {
-  typedef double acc_t __attribute__((ext_vector_type(4)));
-  static constexpr int N = 2;
-  typedef double V __attribute__((ext_vector_type(2)));
-  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ int row(int q, int r) { return 4 * r + q; }        // probed: scripts/probe_mfma_f64.hip
-};
-
 // LDS of one sample, in elements: L [KMAX][P] | B [KMAX][P], P odd.  The groups of a wave sit GS banks apart (Float32; Float64 moves
 // half a wave per pass), so the "lane = row" accesses of a whole wave cover the 64 banks once.
 template <class T, int GS, int KMAX> struct MfLds {
@@ -79,13 +63,15 @@ __global__ __launch_bounds__(256) void matrix_inv_vjp_mfma_kernel(const T* __res
   constexpr bool CORR = KIND == MK_VEC_CORR || KIND == MK_CORR;
   constexpr bool VECK = KIND == MK_VEC_CORR || KIND == MK_PD_VEC;
   extern __shared__ __align__(16) unsigned char smem_[];
-  const int tl = threadIdx.x & (GS - 1), sl = threadIdx.x / GS;
-  const int t = tl < KMAX ? tl : KMAX - 1;                   // lanes past KMAX repeat the last row: same values to the same addresses
-  T* Lb = reinterpret_cast<T*>(smem_) + (size_t)sl * SS;
+  // (not const: the persistent loop below launders the lane-derived values once per sample — see there)
+  int tl = threadIdx.x & (GS - 1), sl = threadIdx.x / GS;
+  int t = tl < KMAX ? tl : KMAX - 1;                         // lanes past KMAX repeat the last row: same values to the same addresses
+  int loff = sl * SS;
+  T* Lb = reinterpret_cast<T*>(smem_) + loff;
   T* B = Lb + KMAX * P;
   unsigned short* tab = reinterpret_cast<unsigned short*>(reinterpret_cast<T*>(smem_) + (size_t)SPB * SS);
   const int64_t KK = (int64_t)K * K, nfree = free_len<KIND>(K);
-  const bool act = t < K;
+  bool act = t < K;
 
   // where the free parameter of (factor row c, column i) sits in B after I1 (the unconstrained side as staged) ...
   auto pos = [&](int c, int i) -> int {
@@ -124,7 +110,8 @@ __global__ __launch_bounds__(256) void matrix_inv_vjp_mfma_kernel(const T* __res
 
   // Staging never branches: a slot past the end of the array re-reads element 0 and re-writes it — the same value to the same word.
   // (r, c) of my first element in a K x K array, and the step of one round of the group
-  const int e0 = tl * VW, r0 = e0 / K, c0 = e0 - r0 * K;
+  const int e0 = tl * VW;
+  int r0 = e0 / K, c0 = e0 - r0 * K;
   const int dr = (GS * VW) / K, dc = (GS * VW) - dr * K;
   auto issue = [&](const T* src, int64_t n, T (&v)[NREG], auto nv_) {
     constexpr int NV_ = decltype(nv_)::value;
@@ -218,11 +205,22 @@ __global__ __launch_bounds__(256) void matrix_inv_vjp_mfma_kernel(const T* __res
     dl_next = ladj_bar ? ladj_bar[s0] : T(0);
   }
   // MFMA lane coordinates and the LDS of the wave's first group
-  const int lane = threadIdx.x & 63, mn = lane & 15, mq = lane >> 4;
-  T* Lw = reinterpret_cast<T*>(smem_) + (size_t)(threadIdx.x / 64) * SPW * SS;
-  const unsigned te = act ? (unsigned)t : 0u;              // "column i is left of my diagonal": i < te (never, for a lane without a row)
+  int lane = threadIdx.x & 63, mn = lane & 15, mq = lane >> 4;
+  int woff = (threadIdx.x / 64) * SPW * SS;
+  T* Lw = reinterpret_cast<T*>(smem_) + woff;
+  unsigned te = act ? (unsigned)t : 0u;                    // "column i is left of my diagonal": i < te (never, for a lane without a row)
 
   for (; w_raw < batch; w_raw += stride, s_raw += stride) {
+    // Everything below that depends only on the lane — LDS addresses, masks, the (row, column) pairs of the staging rounds — is loop-
+    // invariant: the compiler hoists it out of the persistent loop and keeps it in registers for the whole kernel.  Laundering the
+    // seeds once per sample makes it recompute them where they are used.
+    // (From 24 rows on: K = 48 17 % faster, K = 12 18 % slower — four small samples a wave, the recomputation is what it then measures.)
+    if constexpr (KMAX >= 24) asm volatile("" : "+v"(tl), "+v"(t), "+v"(loff), "+v"(woff), "+v"(r0), "+v"(c0), "+v"(mn), "+v"(mq));
+    Lb = reinterpret_cast<T*>(smem_) + loff;
+    B = Lb + KMAX * P;
+    Lw = reinterpret_cast<T*>(smem_) + woff;
+    act = t < K;
+    te = act ? (unsigned)t : 0u;
     const bool live = s_raw < batch;                     // uniform over the group; a dead group computes on the last sample and stores nothing
     const int64_t s = live ? s_raw : batch - 1;
     const int64_t sn = s_raw + stride < batch ? s_raw + stride : batch - 1;

@@ -110,11 +110,13 @@ def main(path):
             vc = bj.VecCorrBijector()
             X = bj.with_logabsdet_jacobian(bj.inverse(vc), dev(y), per_sample=True)
             put(f"vcorr.{tg}.{K}", X, bj.with_logabsdet_jacobian(vc, X[0], per_sample=True))
-            if K <= 16:          # pullbacks of the matrix bijectors (one lane / one group of lanes per sample)
+            if K <= 16 or K == 64:          # pullbacks of the matrix bijectors (one lane / one group of lanes per sample / MFMA blocks)
                 yb = np.asfortranarray(r.normal(size=(nv, N)).astype(dt))
                 put(f"vcorr_vjp.{tg}.{K}", bj.vjp(bj.inverse(vc), dev(y), dev(gw), dev(lb)), bj.vjp(vc, X[0], dev(yb), dev(lb)))
                 pv = bj.PDVecBijector()
-                ypd = np.asfortranarray((0.4 * r.normal(size=(K * (K + 1) // 2, N))).astype(dt))
+                # (a random triangular factor is exponentially ill-conditioned in K: 0.4 N(0,1) below the diagonal gives cotangents of 2e6 at K = 64, where
+                # every kernel — and every switch — is one rounding pattern of a problem conditioned 1e5: scripts/probe_matrix_vjp_cond.py)
+                ypd = np.asfortranarray(((0.4 if K <= 16 else 1.6 / K) * r.normal(size=(K * (K + 1) // 2, N))).astype(dt))
                 Xpd = bj.transform(bj.inverse(pv), dev(ypd))
                 put(f"pdvec_vjp.{tg}.{K}", bj.vjp(bj.inverse(pv), dev(ypd), dev(gw), dev(lb)), bj.vjp(pv, Xpd, dev(ypd), dev(lb)))
     np.savez(path, **out)

@@ -18,7 +18,7 @@ SETTINGS = [
     "BJX_NT=0", "BJX_CHAIN_WALKER=0", "BJX_CHAIN_FLATCOL=0", "BJX_CHAIN_COLBATCH=0", "BJX_COLWALK=0", "BJX_PLANAR_REG=0", "BJX_PLANAR_SPLIT=0",
     "BJX_PLANAR_SPLIT=1", "BJX_PLANAR_MFMA=1", "BJX_PLANAR_MFMA=2", "BJX_PLANAR_MFMA=4", "BJX_PLANAR_MFMA64=0", "BJX_PLANAR_TILE=0",
     "BJX_FLOW_WALK_MAX=0", "BJX_RADIAL_WALK_ALL=1", "BJX_PLANAR_PARAM_MFMA=0", "BJX_SCALE_MFMA=0", "BJX_MATRIX_LANE_MAX=0",
-    "BJX_MATRIX_LANE_DIRECT=0", "BJX_MATRIX_CYC=0", "BJX_MATRIX_VJP_GRP=0", "BJX_MATRIX_VJP_MFMA=0", "BJX_SEQ_WAVE=0", "BJX_SEQ_STREAM=0", "BJX_ORDERED_VJP_STREAM=0", "BJX_SIMPLEX_VJP_STREAM=0",
+    "BJX_MATRIX_LANE_DIRECT=0", "BJX_MATRIX_CYC=0", "BJX_MATRIX_VJP_GRP=0", "BJX_MATRIX_VJP_MFMA=0", "BJX_MATRIX_VJP_MFMA=2", "BJX_SEQ_WAVE=0", "BJX_SEQ_STREAM=0", "BJX_ORDERED_VJP_STREAM=0", "BJX_SIMPLEX_VJP_STREAM=0",
     "BJX_SEQ_TINY=0", "BJX_SEQ_TALL=0", "BJX_SIMPLEX_VJP_TALL=0", "BJX_CHAIN_TINY=0", "BJX_PLANAR_REG_UNALIGNED=0", "BJX_PLANAR_REG_BIG=0",
     "BJX_FLOW_UNALIGNED=0", "BJX_COL_UNALIGNED=0", "BJX_STACKED_VJP_UNALIGNED=0", "BJX_COL_SLAB=0", "BJX_STACKED_SLAB=0", "BJX_STACKED_SLAB=64",
     "BJX_CHAIN_UNALIGNED=0", "BJX_PLANAR_WALK_DIRECT=0", "BJX_COLDIRECT=0", "BJX_STACKED_TINY=0", "BJX_CHOL_CHUNK=0", "BJX_CHOL_LANE_MAX=0",
