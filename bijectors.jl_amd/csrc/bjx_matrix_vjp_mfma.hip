@@ -1,6 +1,6 @@
 // bjx_matrix_vjp_mfma.hip — pullback of the INVERSE VecCorrBijector / CorrBijector / PDBijector / PDVecBijector (unconstrained y -> X = L L',
 // what a leapfrog step differentiates; SURVEY.md §8(f) f-1 x f-4; the rules and their reference lines: bjx_matrix_vjp.hip) for 8 < K <= 64
-// (Float64: <= 32), with the one cubic step on the matrix cores.
+// (both element types; Float64 at 49 .. 64 rows in blocks of two waves: 66 KiB of LDS a sample), with the one cubic step on the matrix cores.
 //
 // bjx_matrix_vjp_grp.hip does L̄ = tril((X̄ + X̄') L) with "lane = row": K²/2 FMAs per lane fed by 16-byte broadcast reads of L out of LDS,
 // a K-register accumulator row per lane, and a row pitch that has to stay a multiple of 16 bytes for those reads — which puts every
@@ -46,14 +46,14 @@ template <class T, int GS, int KMAX> struct MfLds {
   static constexpr int SS = BASE + pad();
 };
 
-template <class T, int GS, int KMAX, int KIND, bool VEC>
-__global__ __launch_bounds__(256) void matrix_inv_vjp_mfma_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
+template <class T, int GS, int KMAX, int KIND, bool VEC, int NT>
+__global__ __launch_bounds__(NT) void matrix_inv_vjp_mfma_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
                                                                  T* __restrict__ in_bar, int K, int64_t batch) {
   using M = VjpMath<T>;
   using O = VjpMfma<T>;
   using RV = typename O::V;
   using ACC = typename O::acc_t;
-  constexpr int N = O::N, P = MfLds<T, GS, KMAX>::P, SPB = 256 / GS, SPW = 64 / GS, SS = MfLds<T, GS, KMAX>::SS;
+  constexpr int N = O::N, P = MfLds<T, GS, KMAX>::P, SPB = NT / GS, SPW = 64 / GS, SS = MfLds<T, GS, KMAX>::SS;
   constexpr int NIT = (KMAX * KMAX + GS - 1) / GS;           // staging rounds of the group over a K x K array, one element per lane
   constexpr int NITV = (NIT + N - 1) / N;                    // ... one 16-byte pack per lane (VEC: K and the free length whole packs, arrays on 16-byte boundaries)
   constexpr int NREG = VEC ? NITV * N : NIT;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void matrix_inv_vjp_mfma_kernel(const T* __res
   constexpr int NVA = (NFMAX + GS * VW - 1) / (GS * VW);   // ... per array of free parameters (half as many for the packed layouts)
   if constexpr (VECK) {
     // packed index e -> (c << 8) | i, once per block (the block is persistent)
-    for (int e = threadIdx.x; e < (int)nfree; e += 256) {
+    for (int e = threadIdx.x; e < (int)nfree; e += NT) {
       int c;
       if (KIND == MK_VEC_CORR) {                          // e = c (c - 1) / 2 + i, i < c
         c = (int)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);
@@ -365,50 +365,50 @@ __global__ __launch_bounds__(256) void matrix_inv_vjp_mfma_kernel(const T* __res
   }
 }
 
-template <class T, int GS, int KMAX, int KIND, bool VEC>
+template <class T, int GS, int KMAX, int KIND, bool VEC, int NT>
 void mf_launch_one(bjx_ctx* ctx, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
-  constexpr int SPB = 256 / GS;
+  constexpr int SPB = NT / GS;
   const size_t smem = (size_t)SPB * MfLds<T, GS, KMAX>::SS * sizeof(T) + ((size_t)KMAX * (KMAX + 1) / 2) * sizeof(unsigned short) + 16;
-  auto kern = matrix_inv_vjp_mfma_kernel<T, GS, KMAX, KIND, VEC>;
+  auto kern = matrix_inv_vjp_mfma_kernel<T, GS, KMAX, KIND, VEC, NT>;
   // persistent blocks: as many as are resident at once (LDS decides), each walks its share of the samples
   static int per_cu = 0;                                  // (one value per instantiation; the same on every device of a node)
   if (per_cu == 0) {
     bjx_allow_big_lds(kern, smem);
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, smem) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), NT, smem) != hipSuccess || nb < 1) nb = 1;
     per_cu = nb;
   }
   const int64_t need = (batch + SPB - 1) / SPB, cap = (int64_t)ctx->num_cu * per_cu;
   const int64_t grid = need < cap ? need : cap;
   BjxProf prof_(ctx);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)K, batch);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)K, batch);
 }
 
-template <class T, int GS, int KMAX, int KIND>
+template <class T, int GS, int KMAX, int KIND, int NT = 256>
 int mf_launch(bjx_ctx* ctx, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
   constexpr int N = VjpMfma<T>::N;
   // 16-byte staging: rows and free lengths in whole packs, the arrays on 16-byte boundaries (every sample then starts on one)
   const bool vec = K % N == 0 && free_len<KIND>(K) % N == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
-  if (vec) mf_launch_one<T, GS, KMAX, KIND, true>(ctx, in, out_bar, ladj_bar, in_bar, K, batch);
-  else mf_launch_one<T, GS, KMAX, KIND, false>(ctx, in, out_bar, ladj_bar, in_bar, K, batch);
+  if (vec) mf_launch_one<T, GS, KMAX, KIND, true, NT>(ctx, in, out_bar, ladj_bar, in_bar, K, batch);
+  else mf_launch_one<T, GS, KMAX, KIND, false, NT>(ctx, in, out_bar, ladj_bar, in_bar, K, batch);
   BJX_CHECK_LAUNCH(ctx);
   return BJX_OK;
 }
 
 template <class T>
 int mf_kind(bjx_ctx* ctx, int kind, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
-  if constexpr (sizeof(T) == 4) {
-    if (K > 32) {
+  if (K > 32) {
+    // 33 .. 64 rows: the whole wave on one sample.  Float64 at 49 .. 64 rows: 66 KiB of LDS a sample — blocks of two waves (two samples a CU)
+    constexpr int NT64 = sizeof(T) == 4 ? 256 : 128;
 #define MF_W(KIND_) (K <= 48 ? mf_launch<T, 64, 48, KIND_>(ctx, in, out_bar, ladj_bar, in_bar, K, batch) \
-                             : mf_launch<T, 64, 64, KIND_>(ctx, in, out_bar, ladj_bar, in_bar, K, batch))
-      switch (kind) {
-        case MK_VEC_CORR: return MF_W(MK_VEC_CORR);
-        case MK_CORR: return MF_W(MK_CORR);
-        case MK_PD: return MF_W(MK_PD);
-        default: return MF_W(MK_PD_VEC);
-      }
-#undef MF_W
+                             : mf_launch<T, 64, 64, KIND_, NT64>(ctx, in, out_bar, ladj_bar, in_bar, K, batch))
+    switch (kind) {
+      case MK_VEC_CORR: return MF_W(MK_VEC_CORR);
+      case MK_CORR: return MF_W(MK_CORR);
+      case MK_PD: return MF_W(MK_PD);
+      default: return MF_W(MK_PD_VEC);
     }
+#undef MF_W
   }
 #define MF_K(KIND_) (K <= 12 ? mf_launch<T, 16, 12, KIND_>(ctx, in, out_bar, ladj_bar, in_bar, K, batch) \
                    : K <= 16 ? mf_launch<T, 16, 16, KIND_>(ctx, in, out_bar, ladj_bar, in_bar, K, batch) \
@@ -430,7 +430,7 @@ namespace bjx {
 // 1: not served (the caller goes on to the lane = row group kernel)
 int bjx_matrix_inv_vjp_mfma(bjx_ctx* ctx, bjx_dtype dt, int kind, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K, int64_t batch) {
   static const int use = getenv("BJX_MATRIX_VJP_MFMA") ? atoi(getenv("BJX_MATRIX_VJP_MFMA")) : 1;      // 0: the lane = row group kernel (its A/B)
-  if (!use || K < 9 || K > 64 || (K > 32 && dt != BJX_F32)) return 1;
+  if (!use || K < 9 || K > 64) return 1;
   if (dt == BJX_F32) return mf_kind<float>(ctx, kind, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, K, batch);
   return mf_kind<double>(ctx, kind, (const double*)in, (const double*)out_bar, (const double*)ladj_bar, (double*)in_bar, K, batch);
 }

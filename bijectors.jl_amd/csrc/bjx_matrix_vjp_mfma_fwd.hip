@@ -1,5 +1,5 @@
 // bjx_matrix_vjp_mfma_fwd.hip — pullback of the FORWARD VecCorrBijector / CorrBijector / PDBijector / PDVecBijector (X -> unconstrained y;
-// SURVEY.md §8(f) f-1 x f-4; the rules and their reference lines: bjx_matrix_vjp.hip) for 8 < K <= 64 (Float64: <= 32), with every cubic
+// SURVEY.md §8(f) f-1 x f-4; the rules and their reference lines: bjx_matrix_vjp.hip) for 8 < K <= 64 (both element types), with every cubic
 // step after the factorisation on the matrix cores.
 //
 // bjx_matrix_vjp_grp.hip reverses the Cholesky factorisation as S = L⁻ᵀ Φ(LᵀL̄) L⁻¹ with a triangular product and two triangular SOLVES,
@@ -51,19 +51,20 @@ template <class T, int GS, int KMAX> struct FwLds {
   static constexpr int SS = BASE + pad();
 };
 
-template <class T, int GS, int KMAX, int KIND, bool VEC>
-__global__ __launch_bounds__(256) void matrix_fwd_vjp_mfma_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
+template <class T, int GS, int KMAX, int KIND, bool VEC, int NT>
+__global__ __launch_bounds__(NT) void matrix_fwd_vjp_mfma_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
                                                                  T* __restrict__ in_bar, int K, int64_t batch) {
   using M = VjpMath<T>;
   using O = VjpMfma<T>;
   using RV = typename O::V;
   using ACC = typename O::acc_t;
-  constexpr int N = O::N, P = FwLds<T, GS, KMAX>::P, SPB = 256 / GS, SPW = 64 / GS, SS = FwLds<T, GS, KMAX>::SS;
+  constexpr int N = O::N, P = FwLds<T, GS, KMAX>::P, SPB = NT / GS, SPW = 64 / GS, SS = FwLds<T, GS, KMAX>::SS;
   constexpr int NIT = (KMAX * KMAX + GS - 1) / GS;
   constexpr int NITV = (NIT + N - 1) / N;
   constexpr int NREG = VEC ? NITV * N : NIT;
   constexpr int NB = (KMAX + 15) / 16;
   constexpr bool RAGGED = KMAX % 16 != 0;
+  constexpr int LA = NB <= 2 ? 4 : 1, RB = LA + 1;           // operand sets of a block product in flight ahead of the MFMAs (one K-block of the contraction at up to 32 rows)
   constexpr bool CORR = KIND == MK_VEC_CORR || KIND == MK_CORR;
   constexpr bool VECK = KIND == MK_VEC_CORR || KIND == MK_PD_VEC;
   constexpr int VW = VEC ? N : 1, NV = VEC ? NITV : NIT;
@@ -81,10 +82,9 @@ __global__ __launch_bounds__(256) void matrix_fwd_vjp_mfma_kernel(const T* __res
   unsigned short* tab = reinterpret_cast<unsigned short*>(reinterpret_cast<T*>(smem_) + (size_t)SPB * SS);
   const int64_t KK = (int64_t)K * K, nfree = free_len<KIND>(K);
   bool act = t < K;
-  int gbase = (threadIdx.x & 63) & ~(GS - 1);
 
   if constexpr (VECK) {
-    for (int e = threadIdx.x; e < (int)nfree; e += 256) {
+    for (int e = threadIdx.x; e < (int)nfree; e += NT) {
       int c;
       if (KIND == MK_VEC_CORR) {
         c = (int)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);
@@ -197,7 +197,6 @@ __global__ __launch_bounds__(256) void matrix_fwd_vjp_mfma_kernel(const T* __res
     Uw = reinterpret_cast<T*>(smem_) + woff;
     act = t < K;
     te = act ? (unsigned)t : 0u;
-    gbase = lane & ~(GS - 1);
     const bool live = s_raw < batch;
     const int64_t s = live ? s_raw : batch - 1;
     const int64_t sn = s_raw + stride < batch ? s_raw + stride : batch - 1;
@@ -322,19 +321,19 @@ __global__ __launch_bounds__(256) void matrix_fwd_vjp_mfma_kernel(const T* __res
       T* Vj = const_cast<T*>(Uj) + KMAX * P;
       ACC d[NB][NB];
       FW_UNROLL for (int bi = 0; bi < NB; ++bi) FW_UNROLL for (int bj = 0; bj <= bi; ++bj) d[bi][bj] = zero;
-      T a[2][NB], b[2][NB];
+      T a[RB][NB], b[RB][NB];
       auto ld = [&](int st, T (&aa)[NB], T (&bb)[NB]) {
         const int m = st / 4, ks = st % 4;
         FW_UNROLL for (int bi = 0; bi < NB; ++bi) if (bi <= m) aa[bi] = Lel(Uj, m, bi, 4 * ks + mq, mn);              // A[i][k] = L[16 m + k][16 bi + i]
         FW_UNROLL for (int bj = 0; bj < NB; ++bj) if (bj <= m) bb[bj] = Pel(Vj, m, bj, 4 * ks + mq, mn, true);        // B[k][j] = L̄[16 m + k][16 bj + j]
       };
-      ld(0, a[0], b[0]);
+      FW_UNROLL for (int p0 = 0; p0 < LA; ++p0) if (p0 < 4 * NB) ld(p0, a[p0 % RB], b[p0 % RB]);
       FW_UNROLL for (int st = 0; st < 4 * NB; ++st) {
-        if (st + 1 < 4 * NB) ld(st + 1, a[(st + 1) & 1], b[(st + 1) & 1]);
+        if (st + LA < 4 * NB) ld(st + LA, a[(st + LA) % RB], b[(st + LA) % RB]);
         fw_fence(mn);
         const int m = st / 4;
         FW_UNROLL for (int bi = 0; bi < NB; ++bi) FW_UNROLL for (int bj = 0; bj < NB; ++bj)
-          if (bi <= m && bj <= bi) d[bi][bj] = O::mfma(a[st & 1][bi], b[st & 1][bj], d[bi][bj]);
+          if (bi <= m && bj <= bi) d[bi][bj] = O::mfma(a[st % RB][bi], b[st % RB][bj], d[bi][bj]);
         fw_fence(mn);
       }
       fw_sync();
@@ -359,8 +358,9 @@ __global__ __launch_bounds__(256) void matrix_fwd_vjp_mfma_kernel(const T* __res
       T* Uj = Uw + (size_t)js * SS;
       T w[16];
       FW_UNROLL for (int r = 0; r < 16; ++r) {
-        // (row r is read when w[r-1] exists: without the tie all 120 reads of the block are issued up front, on 120 registers)
-        if (r > 0) asm volatile("" : "+v"(b16) : "v"(w[r - 1]));
+        // (row r is read when w[r-4] exists: without a tie all 120 reads of the block are issued up front, on 120 registers; tied to
+        // w[r-1] every row waits out a whole LDS round trip)
+        if (r >= 4) asm volatile("" : "+v"(b16) : "v"(w[r - 4]));   // (four rows of look-ahead)
         const bool rin = !RAGGED || b16 + r < KMAX;
         const int rr = rin ? b16 + r : 0;
         T acc = r == mn ? T(1) : T(0);
@@ -384,18 +384,18 @@ __global__ __launch_bounds__(256) void matrix_fwd_vjp_mfma_kernel(const T* __res
         ACC q[NB];
         FW_UNROLL for (int bj = 0; bj < NB; ++bj) q[bj] = zero;
         {
-          T a[2], b[2][NB];
+          T a[RB], b[RB][NB];
           auto ld = [&](int st, T& aa, T (&bb)[NB]) {
             const int m = st / 4, ks = st % 4;
             aa = Lel(Uj, bi, m, mn, 4 * ks + mq);                                                                    // A[i][k] = L[16 bi + i][16 m + k]
             FW_UNROLL for (int bj = 0; bj < NB; ++bj) if (bj <= m) bb[bj] = Wel(Uj, m, bj, 4 * ks + mq, mn);           // B[k][j] = W[16 m + k][16 bj + j]
           };
-          ld(0, a[0], b[0]);
+          FW_UNROLL for (int p0 = 0; p0 < LA; ++p0) if (p0 < 4 * bi) ld(p0, a[p0 % RB], b[p0 % RB]);
           FW_UNROLL for (int st = 0; st < 4 * bi; ++st) {
-            if (st + 1 < 4 * bi) ld(st + 1, a[(st + 1) & 1], b[(st + 1) & 1]);
+            if (st + LA < 4 * bi) ld(st + LA, a[(st + LA) % RB], b[(st + LA) % RB]);
             fw_fence(mn);
             const int m = st / 4;
-            FW_UNROLL for (int bj = 0; bj < NB; ++bj) if (bj <= m) q[bj] = O::mfma(a[st & 1], b[st & 1][bj], q[bj]);
+            FW_UNROLL for (int bj = 0; bj < NB; ++bj) if (bj <= m) q[bj] = O::mfma(a[st % RB], b[st % RB][bj], q[bj]);
             fw_fence(mn);
           }
         }
@@ -415,19 +415,19 @@ __global__ __launch_bounds__(256) void matrix_fwd_vjp_mfma_kernel(const T* __res
       {
         ACC d[NB][NB];
         FW_UNROLL for (int bi = 0; bi < NB; ++bi) FW_UNROLL for (int bj = 0; bj <= bi; ++bj) d[bi][bj] = zero;
-        T a[2][NB], b[2][NB];
+        T a[RB][NB], b[RB][NB];
         auto ld = [&](int st, T (&aa)[NB], T (&bb)[NB]) {
           const int m = st / 4, ks = st % 4;
           FW_UNROLL for (int bi = 0; bi < NB; ++bi) if (bi >= m) aa[bi] = Pel(Vj, bi, m, mn, 4 * ks + mq, false);      // A[i][k] = Φ[16 bi + i][16 m + k]
           FW_UNROLL for (int bj = 0; bj < NB; ++bj) if (bj <= m) bb[bj] = Wel(Uj, m, bj, 4 * ks + mq, mn);             // B[k][j] = W[16 m + k][16 bj + j]
         };
-        ld(0, a[0], b[0]);
+        FW_UNROLL for (int p0 = 0; p0 < LA; ++p0) if (p0 < 4 * NB) ld(p0, a[p0 % RB], b[p0 % RB]);
         FW_UNROLL for (int st = 0; st < 4 * NB; ++st) {
-          if (st + 1 < 4 * NB) ld(st + 1, a[(st + 1) & 1], b[(st + 1) & 1]);
+          if (st + LA < 4 * NB) ld(st + LA, a[(st + LA) % RB], b[(st + LA) % RB]);
           fw_fence(mn);
           const int m = st / 4;
           FW_UNROLL for (int bi = 0; bi < NB; ++bi) FW_UNROLL for (int bj = 0; bj < NB; ++bj)
-            if (bi >= m && bj <= m) d[bi][bj] = O::mfma(a[st & 1][bi], b[st & 1][bj], d[bi][bj]);
+            if (bi >= m && bj <= m) d[bi][bj] = O::mfma(a[st % RB][bi], b[st % RB][bj], d[bi][bj]);
           fw_fence(mn);
         }
         fw_sync();
@@ -438,19 +438,19 @@ __global__ __launch_bounds__(256) void matrix_fwd_vjp_mfma_kernel(const T* __res
       {
         ACC d[NB][NB];
         FW_UNROLL for (int bi = 0; bi < NB; ++bi) FW_UNROLL for (int bj = 0; bj < NB; ++bj) d[bi][bj] = zero;
-        T a[2][NB], b[2][NB];
+        T a[RB][NB], b[RB][NB];
         auto ld = [&](int st, T (&aa)[NB], T (&bb)[NB]) {
           const int m = st / 4, ks = st % 4;
           FW_UNROLL for (int bi = 0; bi < NB; ++bi) if (bi <= m) aa[bi] = Wel(Uj, m, bi, 4 * ks + mq, mn);             // A[i][k] = W[16 m + k][16 bi + i]
           FW_UNROLL for (int bj = 0; bj < NB; ++bj) if (bj <= m) bb[bj] = Pel(Vj, m, bj, 4 * ks + mq, mn, false);      // B[k][j] = T[16 m + k][16 bj + j]
         };
-        ld(0, a[0], b[0]);
+        FW_UNROLL for (int p0 = 0; p0 < LA; ++p0) if (p0 < 4 * NB) ld(p0, a[p0 % RB], b[p0 % RB]);
         FW_UNROLL for (int st = 0; st < 4 * NB; ++st) {
-          if (st + 1 < 4 * NB) ld(st + 1, a[(st + 1) & 1], b[(st + 1) & 1]);
+          if (st + LA < 4 * NB) ld(st + LA, a[(st + LA) % RB], b[(st + LA) % RB]);
           fw_fence(mn);
           const int m = st / 4;
           FW_UNROLL for (int bi = 0; bi < NB; ++bi) FW_UNROLL for (int bj = 0; bj < NB; ++bj)
-            if (bi <= m && bj <= m) d[bi][bj] = O::mfma(a[st & 1][bi], b[st & 1][bj], d[bi][bj]);
+            if (bi <= m && bj <= m) d[bi][bj] = O::mfma(a[st % RB][bi], b[st % RB][bj], d[bi][bj]);
           fw_fence(mn);
         }
         fw_sync();
@@ -465,50 +465,50 @@ __global__ __launch_bounds__(256) void matrix_fwd_vjp_mfma_kernel(const T* __res
   }
 }
 
-template <class T, int GS, int KMAX, int KIND, bool VEC>
+template <class T, int GS, int KMAX, int KIND, bool VEC, int NT>
 void fw_launch_one(bjx_ctx* ctx, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
-  constexpr int SPB = 256 / GS;
+  constexpr int SPB = NT / GS;
   const size_t smem = (size_t)SPB * FwLds<T, GS, KMAX>::SS * sizeof(T) + ((size_t)KMAX * (KMAX + 1) / 2) * sizeof(unsigned short) + 16;
-  auto kern = matrix_fwd_vjp_mfma_kernel<T, GS, KMAX, KIND, VEC>;
+  auto kern = matrix_fwd_vjp_mfma_kernel<T, GS, KMAX, KIND, VEC, NT>;
   static int per_cu = 0;                                  // persistent blocks: as many as are resident at once
   if (per_cu == 0) {
     bjx_allow_big_lds(kern, smem);
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, smem) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), NT, smem) != hipSuccess || nb < 1) nb = 1;
     per_cu = nb;
   }
   const int64_t need = (batch + SPB - 1) / SPB, cap = (int64_t)ctx->num_cu * per_cu;
   const int64_t grid = need < cap ? need : cap;
   BjxProf prof_(ctx);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)K, batch);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, ctx->stream, in, out_bar, ladj_bar, in_bar, (int)K, batch);
 }
 
-template <class T, int GS, int KMAX, int KIND>
+template <class T, int GS, int KMAX, int KIND, int NT = 256>
 int fw_launch(bjx_ctx* ctx, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
   constexpr int N = VjpMfma<T>::N;
   const bool vec = K % N == 0 && free_len<KIND>(K) % N == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
-  if (vec) fw_launch_one<T, GS, KMAX, KIND, true>(ctx, in, out_bar, ladj_bar, in_bar, K, batch);
-  else fw_launch_one<T, GS, KMAX, KIND, false>(ctx, in, out_bar, ladj_bar, in_bar, K, batch);
+  if (vec) fw_launch_one<T, GS, KMAX, KIND, true, NT>(ctx, in, out_bar, ladj_bar, in_bar, K, batch);
+  else fw_launch_one<T, GS, KMAX, KIND, false, NT>(ctx, in, out_bar, ladj_bar, in_bar, K, batch);
   BJX_CHECK_LAUNCH(ctx);
   return BJX_OK;
 }
 
 template <class T>
 int fw_kind(bjx_ctx* ctx, int kind, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
-  if constexpr (sizeof(T) == 4) {
-    if (K > 32) {
+  if (K > 32) {
+    // 33 .. 64 rows: the whole wave on one sample.  Float64 at 49 .. 64 rows: 68 KiB of LDS a sample — blocks of two waves (two samples a CU)
+    constexpr int NT64 = sizeof(T) == 4 ? 256 : 128;
 #define FW_W(KIND_) (K <= 48 ? fw_launch<T, 64, 48, KIND_>(ctx, in, out_bar, ladj_bar, in_bar, K, batch) \
-                             : fw_launch<T, 64, 64, KIND_>(ctx, in, out_bar, ladj_bar, in_bar, K, batch))
-      switch (kind) {
-        case MK_VEC_CORR: return FW_W(MK_VEC_CORR);
+                             : fw_launch<T, 64, 64, KIND_, NT64>(ctx, in, out_bar, ladj_bar, in_bar, K, batch))
+    switch (kind) {
+      case MK_VEC_CORR: return FW_W(MK_VEC_CORR);
 #ifndef FW_DEV
-        case MK_CORR: return FW_W(MK_CORR);
-        case MK_PD: return FW_W(MK_PD);
+      case MK_CORR: return FW_W(MK_CORR);
+      case MK_PD: return FW_W(MK_PD);
 #endif
-        default: return FW_W(MK_PD_VEC);
-      }
-#undef FW_W
+      default: return FW_W(MK_PD_VEC);
     }
+#undef FW_W
   }
 #define FW_K(KIND_) (K <= 12 ? fw_launch<T, 16, 12, KIND_>(ctx, in, out_bar, ladj_bar, in_bar, K, batch) \
                    : K <= 16 ? fw_launch<T, 16, 16, KIND_>(ctx, in, out_bar, ladj_bar, in_bar, K, batch) \
@@ -532,14 +532,14 @@ namespace bjx {
 // 1: not served (the caller goes on to the lane = row group kernel).  Served where it is the faster one on the same box (2^14 .. 2^19
 // samples, Float32, percent of the HBM peak, group kernel -> this one, VecCorr / PDVec): K = 16: 31 / 33 -> 32 / 36, 32: 19 / 20 -> 25 / 28,
 // 48: 12 / 13 -> 13 / 23, 64: 7 / 7 -> 14 / 16; NOT at K <= 12 (30 / 33 -> 16 / 18: a 16 x 16 block algebra on a 12 x 12 problem, four
-// samples a wave one after the other) nor at 17 .. 24 (22 / 24 -> 15 / 21).  Float64 (call times of scripts/probe_matrix_vjp.py, group -> this): K = 32 0.71 / 0.61 -> 0.50 / 0.42 ms, K = 16 the same, 12 and 24 slower: from 25 rows.
+// samples a wave one after the other) nor at 17 .. 24 (22 / 24 -> 15 / 21).  Float64 (call times of scripts/probe_matrix_vjp.py, group -> this): K = 32 0.71 / 0.61 -> 0.50 / 0.42 ms, K = 16 the same, 12 and 24 slower: from 25 rows.  Float64 at 33 .. 64 rows had only the one-lane workspace kernel: 18.6 / 47.7 ms -> 0.43 / 2.0 ms at K = 48 / 64, 2^13 samples.
 int bjx_matrix_fwd_vjp_mfma(bjx_ctx* ctx, bjx_dtype dt, int kind, const void* in, const void* out_bar, const void* ladj_bar, void* in_bar, int64_t K, int64_t batch) {
   static const int use = getenv("BJX_MATRIX_VJP_MFMA") ? atoi(getenv("BJX_MATRIX_VJP_MFMA")) : 1;      // 0: the lane = row group kernel (its A/B); 2: every shape this kernel can do
 #ifdef FW_DEV
   if (kind == MK_CORR || kind == MK_PD) return 1;
 #endif
-  if (!use || K < 9 || K > 64 || (K > 32 && dt != BJX_F32)) return 1;
-  if (use != 2 && (K < 13 || (K > 16 && K < 25) || (dt != BJX_F32 && K < 25))) return 1;
+  if (!use || K < 9 || K > 64) return 1;
+  if (use != 2 && (K < 13 || (K > 16 && K < 25) || (dt != BJX_F32 && K < 25))) return 1;      // (K > 32 in Float64: nothing else but the workspace kernel)
   if (dt == BJX_F32) return fw_kind<float>(ctx, kind, (const float*)in, (const float*)out_bar, (const float*)ladj_bar, (float*)in_bar, K, batch);
 #ifdef FW_DEV
   return 1;

@@ -7,6 +7,7 @@
 #   gpu_run.sh rows <filter> [ENV=V ...]      scripts/bench_rows.py --only <filter>, once per env setting (same box, same call: an A/B)
 #   gpu_run.sh ab <filter> <old.so> <new.so>  the same rows with two builds of the library (BJX_LIB_PATH)
 #   gpu_run.sh pmc <workload> <kernel-substring> "<counters>" ["<counters>" ...]   rocprofv3 --pmc passes (kernel-trace only), per-kernel means
+#   gpu_run.sh rowprof <filter> ["<counters>" ...]  rocprofv3 kernel stats (+ --pmc passes, kernel-trace only) of scripts/bench_rows.py --only <filter>
 #   gpu_run.sh stats <workload>               rocprofv3 --kernel-trace --stats of one bench workload      -> gpurun_out/<wl>_kernel_stats.csv
 #   gpu_run.sh profile <TAG> [workloads...]   the round's evidence, everything under gpurun_out/<TAG>/ (scripts/collect_profiles.py <TAG>
 #                                             turns it into profiles/): pytest -m gpu, the default bench line, one bench line + kernel
@@ -55,6 +56,16 @@ pmc)
     i=$((i+1))
     ( cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${WL}_$i -o p -- python $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-rows > $R/gpurun_out/pmc_${WL}_$i.log 2>&1 )
     f=$(ls gpurun_out/pmc_${WL}_$i/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && pmc_summary "$f" "$KS"
+  done ;;
+rowprof)
+  F=$1; shift; i=0
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/rowprof_0 -o p -- python $R/scripts/bench_rows.py --only "$F" --steps 10 > $R/gpurun_out/rowprof_0.txt 2>&1 )
+  grep "^| " gpurun_out/rowprof_0.txt | grep -v "^| row\|^|---" | cut -d'|' -f2,4,8,10
+  f=$(ls gpurun_out/rowprof_0/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -8 "$f" | cut -c1-260
+  for set in "$@"; do
+    i=$((i+1))
+    ( cd /tmp && timeout 900 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/rowprof_$i -o p -- python $R/scripts/bench_rows.py --only "$F" --steps 3 > /dev/null 2>&1 )
+    f=$(ls gpurun_out/rowprof_$i/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && pmc_summary "$f" "kernel"
   done ;;
 stats)
   WL=$1
