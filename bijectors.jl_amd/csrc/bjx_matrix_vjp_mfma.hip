@@ -46,14 +46,17 @@ template <class T, int GS, int KMAX> struct MfLds {
   static constexpr int SS = BASE + pad();
 };
 
-template <class T, int GS, int KMAX, int KIND, bool VEC, int NT>
+template <class T, int GS, int KMAX, int KIND, int VWT, int NT>
 __global__ __launch_bounds__(NT) void matrix_inv_vjp_mfma_kernel(const T* __restrict__ in, const T* __restrict__ out_bar, const T* __restrict__ ladj_bar,
                                                                  T* __restrict__ in_bar, int K, int64_t batch) {
   using M = VjpMath<T>;
   using O = VjpMfma<T>;
-  using RV = typename O::V;
+  // VWT: elements per global access — 1, a 16-byte pack, or (Float32) an 8-byte pair for the sizes whose rows and free lengths are even
+  // but not whole packs (K = 12, 20, 28, ...)
+  typedef T RV __attribute__((ext_vector_type(VWT == 1 ? 2 : VWT)));
   using ACC = typename O::acc_t;
-  constexpr int N = O::N, P = MfLds<T, GS, KMAX>::P, SPB = NT / GS, SPW = 64 / GS, SS = MfLds<T, GS, KMAX>::SS;
+  constexpr bool VEC = VWT > 1;
+  constexpr int N = VWT, P = MfLds<T, GS, KMAX>::P, SPB = NT / GS, SPW = 64 / GS, SS = MfLds<T, GS, KMAX>::SS;
   constexpr int NIT = (KMAX * KMAX + GS - 1) / GS;           // staging rounds of the group over a K x K array, one element per lane
   constexpr int NITV = (NIT + N - 1) / N;                    // ... one 16-byte pack per lane (VEC: K and the free length whole packs, arrays on 16-byte boundaries)
   constexpr int NREG = VEC ? NITV * N : NIT;
@@ -365,11 +368,11 @@ __global__ __launch_bounds__(NT) void matrix_inv_vjp_mfma_kernel(const T* __rest
   }
 }
 
-template <class T, int GS, int KMAX, int KIND, bool VEC, int NT>
+template <class T, int GS, int KMAX, int KIND, int VWT, int NT>
 void mf_launch_one(bjx_ctx* ctx, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
   constexpr int SPB = NT / GS;
   const size_t smem = (size_t)SPB * MfLds<T, GS, KMAX>::SS * sizeof(T) + ((size_t)KMAX * (KMAX + 1) / 2) * sizeof(unsigned short) + 16;
-  auto kern = matrix_inv_vjp_mfma_kernel<T, GS, KMAX, KIND, VEC, NT>;
+  auto kern = matrix_inv_vjp_mfma_kernel<T, GS, KMAX, KIND, VWT, NT>;
   // persistent blocks: as many as are resident at once (LDS decides), each walks its share of the samples
   static int per_cu = 0;                                  // (one value per instantiation; the same on every device of a node)
   if (per_cu == 0) {
@@ -387,10 +390,13 @@ void mf_launch_one(bjx_ctx* ctx, const T* in, const T* out_bar, const T* ladj_ba
 template <class T, int GS, int KMAX, int KIND, int NT = 256>
 int mf_launch(bjx_ctx* ctx, const T* in, const T* out_bar, const T* ladj_bar, T* in_bar, int64_t K, int64_t batch) {
   constexpr int N = VjpMfma<T>::N;
-  // 16-byte staging: rows and free lengths in whole packs, the arrays on 16-byte boundaries (every sample then starts on one)
-  const bool vec = K % N == 0 && free_len<KIND>(K) % N == 0 && bjx_aligned16(in) && bjx_aligned16(out_bar) && bjx_aligned16(in_bar);
-  if (vec) mf_launch_one<T, GS, KMAX, KIND, true, NT>(ctx, in, out_bar, ladj_bar, in_bar, K, batch);
-  else mf_launch_one<T, GS, KMAX, KIND, false, NT>(ctx, in, out_bar, ladj_bar, in_bar, K, batch);
+  // 16-byte staging: rows and free lengths in whole packs, the arrays on 16-byte boundaries (every sample then starts on one); Float32
+  // with even rows and free lengths: 8-byte pairs
+  const int64_t nf = free_len<KIND>(K);
+  const auto al = [&](unsigned m) { return ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out_bar) | reinterpret_cast<uintptr_t>(in_bar)) & m) == 0; };
+  if (K % N == 0 && nf % N == 0 && al(15)) mf_launch_one<T, GS, KMAX, KIND, N, NT>(ctx, in, out_bar, ladj_bar, in_bar, K, batch);
+  else if (sizeof(T) == 4 && K % 2 == 0 && nf % 2 == 0 && al(7)) mf_launch_one<T, GS, KMAX, KIND, 2, NT>(ctx, in, out_bar, ladj_bar, in_bar, K, batch);
+  else mf_launch_one<T, GS, KMAX, KIND, 1, NT>(ctx, in, out_bar, ladj_bar, in_bar, K, batch);
   BJX_CHECK_LAUNCH(ctx);
   return BJX_OK;
 }
