@@ -96,6 +96,31 @@ __device__ __forceinline__ void load_params(const DevOp<T>& op, int64_t r, int64
   }
 }
 
+// log(a / b) for a, b >= 0 at the price of ONE lean logarithm: with a = ma 2^ea, b = mb 2^eb the atanh argument of fdlibm's scheme is
+// s = (m - 1) / (m + 1) = (ma - mb) / (ma + mb) for m = ma / mb — no quotient is ever formed; log(m) = 2 atanh(s) = 2 s + s R(s²) with the
+// coefficients of f64lean::log (the rounding of s costs 2e-16 |s| absolutely: two orders inside the 1e-6 bar).
+__device__ __forceinline__ double lean_log_ratio(double a, double b) {
+  double ma = __builtin_amdgcn_frexp_mant(a), mb = __builtin_amdgcn_frexp_mant(b);      // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(a) - __builtin_amdgcn_frexp_exp(b);
+  const bool lo = ma < 0.70710678118654752440 * mb;                                       // m in (0.5, 2) -> [sqrt(1/2), sqrt(2))
+  ma = lo ? ma + ma : ma;
+  e = lo ? e - 1 : e;
+  const bool hi = ma > 1.41421356237309504880 * mb;
+  ma = hi ? 0.5 * ma : ma;
+  e = hi ? e + 1 : e;
+  const double s = (ma - mb) * f64lean::rcp(ma + mb);
+  const double z = s * s, w = z * z;
+  const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double dk = (double)e;
+  double y = __builtin_fma(dk, 6.93147180369123816490e-01, (s + s) + __builtin_fma(s, t2 + t1, dk * 1.90821492927058770002e-10));
+  // a = 0: -Inf, b = 0: +Inf (the bounds of the support); anything negative, infinite or NaN: NaN (log of a negative number)
+  y = a == 0.0 ? -Num<double>::inf : y;
+  y = b == 0.0 ? Num<double>::inf : y;
+  const bool bad = !(a >= 0.0) || !(b >= 0.0) || a == Num<double>::inf || b == Num<double>::inf || (a == 0.0 && b == 0.0);
+  return bad ? __builtin_nan("") : y;
+}
+
 // One stage applied to U packs of V consecutive elements (wave-uniform `switch`); returns the
 // data-dependent log-det contribution (Scale's parameter-only term is added by finalize).
 #define BJX_FOR_UJ _Pragma("unroll") for (int u = 0; u < U; ++u) _Pragma("unroll") for (int j = 0; j < V; ++j)
@@ -103,7 +128,8 @@ __device__ __forceinline__ void load_params(const DevOp<T>& op, int64_t r, int64
 // per-sample geometry): the per-row parameters are loaded ONCE instead of U times — each such load is as wide
 // as the data pack itself, and two vector-parameter stages tripled the load traffic of a density chain.
 // The arithmetic of one stage on U packs; UA = 1: one parameter pack serves all U packs (same rows), UA = U: one per pack.
-template <class T, int V, int U, int UA>
+// LSUM: the caller adds the U log-det terms up (the summed log-det of a flat pass) — a stage may then return their sum in l[0] alone.
+template <class T, int V, int U, int UA, bool LSUM = false>
 __device__ __forceinline__ void apply_kind(const int kind, Pack<T, V> (&p)[U], const T (&a)[UA][V], const T (&b)[UA][V], T (&l)[U]) {
   using F = Fast<T>;
   switch (kind) {
@@ -124,17 +150,45 @@ __device__ __forceinline__ void apply_kind(const int kind, Pack<T, V> (&p)[U], c
       break;
     case BJX_OP_LOGIT:  // logit.jl:15,24.  Float32: hardware log/rcp (the OCML versions make this op VALU-bound at 50 % of the roofline)
       if constexpr (sizeof(T) == 8 && UA == 1) {
-        // Float64 with one parameter pack for the lane's U packs (scalars, or the same rows): two lean logs per element instead of
-        // two logs + two reciprocals (a lean log costs ~3.8 reciprocals, scripts/f64math_bench.hip): logit = log(x-a) - log(b-x),
-        // log-det term -(log(x-a) + log(b-x) - log(b-a)) with log(b-a) once per row of the pack.  Same limits at the bounds (±Inf).
-        T lw[V];
+        // Float64 with one parameter pack for the lane's U packs (scalars, or the same rows).  A lean logarithm is ~40 Float64 operations
+        // (~3.8 reciprocals, scripts/f64math_bench.hip) and this stage was two of them per element (44 % of the roofline, VALU-bound):
+        //   value    log((x-a)/(b-x)) as ONE logarithm of the ratio (lean_log_ratio: no quotient formed);
+        //   log-det  -log g, g = (x-a)(b-x)/(b-a): the log-det of a column is a SUM over its rows, so the g of the V rows of a pack are
+        //            multiplied and ONE logarithm is taken per pack — per U packs when the caller only wants the sum (g <= (b-a)/4 and one of its two factors is >= (b-a)/2: the product
+        //            of a pack cannot vanish before a factor does, except past 1e-300 — then the logarithms are taken one by one).
+        // Same limits at the bounds: value ±Inf, log-det +Inf; outside the support NaN (a negative g must not cancel another one).
+        T iw[V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) lw[j] = F::log(b[0][j] - a[0][j]);
-        BJX_FOR_UJ {
-          const T x = p[u].v[j];
-          const T la = F::log(x - a[0][j]), lb = F::log(b[0][j] - x);
-          l[u] -= (la + lb) - lw[j];
-          p[u].v[j] = la - lb;
+        for (int j = 0; j < V; ++j) iw[j] = F::rcp(b[0][j] - a[0][j]);
+        constexpr int UG = LSUM ? U : 1;                           // packs whose g share one logarithm (all of the lane's when only the sum is wanted)
+#pragma unroll
+        for (int u0 = 0; u0 < U; u0 += UG) {
+          T prod = T(1), gmin = Num<T>::inf;
+          T g[UG][V];
+#pragma unroll
+          for (int uu = 0; uu < UG; ++uu) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+              const T x = p[u0 + uu].v[j];
+              const T xa = x - a[0][j], xb = b[0][j] - x;
+              g[uu][j] = (xa * iw[j]) * xb;
+              prod *= g[uu][j];
+              gmin = g[uu][j] < gmin ? g[uu][j] : gmin;
+              p[u0 + uu].v[j] = (T)lean_log_ratio((double)xa, (double)xb);
+            }
+          }
+          T lp = F::log(prod);
+          if (prod == T(0) && gmin > T(0)) {                     // underflow of the product, not a zero factor
+            lp = T(0);
+#pragma unroll
+            for (int uu = 0; uu < UG; ++uu) {
+#pragma unroll
+              for (int j = 0; j < V; ++j) lp += F::log(g[uu][j]);
+            }
+          }
+          lp = gmin < T(0) ? (T)__builtin_nan("") : lp;
+          lp = prod != prod ? prod : lp;
+          l[u0] -= lp;
         }
         break;
       }
@@ -213,7 +267,7 @@ __device__ __forceinline__ bool kind_has_params(int kind) {
 // SAMEROW: the U packs of a lane sit at the same rows (the pack stride 256·V is a multiple of dim, or the
 // per-sample geometry): the per-row parameters are loaded ONCE instead of U times — each such load is as wide
 // as the data pack itself, and two vector-parameter stages tripled the load traffic of a density chain.
-template <class T, int V, int U, int ROWMODE, bool SAMEROW = false>
+template <class T, int V, int U, int ROWMODE, bool SAMEROW = false, bool LSUM = false>
 __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim, T (&l)[U]) {
   const int kind = op.kind;
   if constexpr (ROWMODE == 0 && sizeof(T) == 8) {
@@ -223,7 +277,7 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
 #pragma unroll
     for (int j = 0; j < V; ++j) { a1[0][j] = T(0); b1[0][j] = T(0); }
     if (kind_has_params(kind)) load_params<T, V, ROWMODE>(op, r[0], dim, a1[0], b1[0]);
-    apply_kind<T, V, U, 1>(kind, p, a1, b1, l);
+    apply_kind<T, V, U, 1, LSUM>(kind, p, a1, b1, l);
     return;
   }
   T a[U][V], b[U][V];
@@ -240,7 +294,7 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
       for (int u = 0; u < U; ++u) load_params<T, V, ROWMODE>(op, r[u], dim, a[u], b[u]);
     }
   }
-  apply_kind<T, V, U, U>(kind, p, a, b, l);
+  apply_kind<T, V, U, U, LSUM>(kind, p, a, b, l);
 }
 
 // per-pack log-det contributions lu[u] (the per-sample kernel reduces each pack's column separately)
@@ -248,7 +302,7 @@ __device__ __forceinline__ void apply_op(const DevOp<T>& op, Pack<T, V> (&p)[U],
 // k + 1 are fetched BEFORE the arithmetic of stage k.  A stage is one dependent chain kernarg s_load -> branch ->
 // pointer s_load -> table load -> wait, ~0.2 us that nothing else of the wave covers; on a read-only density chain
 // of six stages those chains were a third of the wave's life (PMC: VALU 45 % busy, HBM 37 %, 4 waves/SIMD resident).
-template <class T, int V, int U, int ROWMODE>
+template <class T, int V, int U, int ROWMODE, bool LSUM = false>
 __device__ __forceinline__ void apply_chain_u_prefetch(const ChainArgs<T>& A, Pack<T, V> (&p)[U], int64_t r0, int64_t dim, T (&lu)[U]) {
 #pragma unroll
   for (int u = 0; u < U; ++u) lu[u] = T(0);
@@ -268,27 +322,27 @@ __device__ __forceinline__ void apply_chain_u_prefetch(const ChainArgs<T>& A, Pa
       kn = A.ops[k + 1].kind;
       if (kind_has_params(kn)) load_params<T, V, ROWMODE>(A.ops[k + 1], r0, dim, an[0], bn[0]);
     }
-    apply_kind<T, V, U, 1>(kind, p, a, b, lu);
+    apply_kind<T, V, U, 1, LSUM>(kind, p, a, b, lu);
     kind = kn;
 #pragma unroll
     for (int j = 0; j < V; ++j) { a[0][j] = an[0][j]; b[0][j] = bn[0][j]; }
   }
 }
-template <class T, int V, int U, int ROWMODE, bool SAMEROW = false>
+template <class T, int V, int U, int ROWMODE, bool SAMEROW = false, bool LSUM = false>
 __device__ __forceinline__ void apply_chain_u(const ChainArgs<T>& A, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim, T (&lu)[U]) {
   // scalar-only chains keep the plain loop: nothing but one s_load to cover, and the look-ahead's copies cost 2-6 % (same-call A/B)
   if constexpr (ROWMODE != 0 && (SAMEROW || U == 1)) {
-    apply_chain_u_prefetch<T, V, U, ROWMODE>(A, p, r[0], dim, lu);
+    apply_chain_u_prefetch<T, V, U, ROWMODE, LSUM>(A, p, r[0], dim, lu);
   } else {
 #pragma unroll
     for (int u = 0; u < U; ++u) lu[u] = T(0);
-    for (int k = 0; k < A.n_ops; ++k) apply_op<T, V, U, ROWMODE, SAMEROW>(A.ops[k], p, r, dim, lu);
+    for (int k = 0; k < A.n_ops; ++k) apply_op<T, V, U, ROWMODE, SAMEROW, LSUM>(A.ops[k], p, r, dim, lu);
   }
 }
 template <class T, int V, int U, int ROWMODE, bool SAMEROW = false>
 __device__ __forceinline__ T apply_chain(const ChainArgs<T>& A, Pack<T, V> (&p)[U], const int64_t (&r)[U], int64_t dim) {
   T lu[U];
-  apply_chain_u<T, V, U, ROWMODE, SAMEROW>(A, p, r, dim, lu);
+  apply_chain_u<T, V, U, ROWMODE, SAMEROW, true>(A, p, r, dim, lu);
   T l = lu[0];
 #pragma unroll
   for (int u = 1; u < U; ++u) l += lu[u];

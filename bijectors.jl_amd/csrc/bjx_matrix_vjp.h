@@ -19,6 +19,14 @@ template <> struct VjpMath<float> {
     const float sech = (u + u) * r;
     s2 = sech * sech;
   }
+  // tanh and sech themselves (the LKJ sweep multiplies by sech: no square, no root)
+  static __device__ __forceinline__ void tanh_sech(float y, float& z, float& sech) {
+    const float u = F::exp(-fabsf(y));
+    const float t = u * u;
+    const float r = F::rcp(1.0f + t);
+    z = __builtin_copysignf((1.0f - t) * r, y);
+    sech = (u + u) * r;
+  }
   static __device__ __forceinline__ float exp(float x) { return F::exp(x); }
   static __device__ __forceinline__ float sqrt(float x) { return F::sqrt(x); }
   static __device__ __forceinline__ float rcp(float x) { return F::rcp(x); }
@@ -27,6 +35,7 @@ template <> struct VjpMath<float> {
 template <> struct VjpMath<double> {
   using F = Fast<double>;
   static __device__ __forceinline__ void tanh_sech2(double y, double& z, double& s2) { x_tanh_sech2(y, z, s2); }
+  static __device__ __forceinline__ void tanh_sech(double y, double& z, double& sech) { double s2; x_tanh_sech2(y, z, s2); sech = ::sqrt(s2); }
   static __device__ __forceinline__ double exp(double x) { return F::exp(x); }
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }

@@ -137,10 +137,10 @@ __global__ __launch_bounds__(NT) void matrix_inv_vjp_mfma_kernel(const T* __rest
         const int ci = tab[ee + u], c = ci >> 8, i = ci & 255;
         const T raw = v[it * VW + u];
         if constexpr (CORR) {
-          T z, s2;
-          M::tanh_sech2(raw, z, s2);
+          T z, sech;
+          M::tanh_sech(raw, z, sech);
           Lb[i * P + c] = z;                                 // z -> upper triangle (dead storage of L, read back in I5), sech -> lower
-          Lb[c * P + i] = M::sqrt(s2);
+          Lb[c * P + i] = sech;
         } else {
           Lb[c * P + i] = raw;
         }
