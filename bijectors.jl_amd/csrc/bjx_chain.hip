@@ -171,7 +171,7 @@ __device__ __forceinline__ void apply_kind(const int kind, Pack<T, V> (&p)[U], c
             for (int j = 0; j < V; ++j) {
               const T x = p[u0 + uu].v[j];
               const T xa = x - a[0][j], xb = b[0][j] - x;
-              g[uu][j] = (xa * iw[j]) * xb;
+              g[uu][j] = (xa < xb ? xa : xb) * ((xa < xb ? xb : xa) * iw[j]);       // (the larger factor over b - a is in [1/2, 1]: g vanishes only with x - a or b - x)
               prod *= g[uu][j];
               gmin = g[uu][j] < gmin ? g[uu][j] : gmin;
               p[u0 + uu].v[j] = (T)lean_log_ratio((double)xa, (double)xb);

@@ -2059,8 +2059,15 @@ template <class T, bool LADJ> struct QSimplexFwd {      // simplex.jl:47-64 + :1
         const bool rowK = i == RPL - 1 && gl == G - 1;                 // row K has no term
         const T m = d_max(T(1) - s, e), em = e * m;                    // :133
         const T P = d_max(xk, em) * d_max(m - xk, em);
-        if (i & 1) lp += F::log2(Pp * F::rcp(mp * (rowK ? T(1) : m)) * (rowK ? T(1) : P));
-        else { Pp = P; mp = m; }
+        if constexpr (sizeof(T) == 8) {
+          // Float64: a lean logarithm is ~40 operations — FOUR rows share one reciprocal and one logarithm (each term >= ε³ = 1e-47)
+          Pp *= rowK ? T(1) : P;
+          mp *= rowK ? T(1) : m;
+          if ((i & 3) == 3 || i == RPL - 1) { lp += F::log2(Pp * F::rcp(mp)); Pp = T(1); mp = T(1); }
+        } else {
+          if (i & 1) lp += F::log2(Pp * F::rcp(mp * (rowK ? T(1) : m)) * (rowK ? T(1) : P));
+          else { Pp = P; mp = m; }
+        }
         if (i == RPL - 1) chk = rowK ? s : s + xk;                     // Σ over this lane's rows < K and everything above
       }
       s += xk;
@@ -2109,8 +2116,14 @@ template <class T, bool LADJ, int G_> struct QSimplexInv {      // simplex.jl:10
         //        = max(x_k, εm)·max(m - x_k, εm)/m ; two rows share one reciprocal and one logarithm (each term >= ε²)
         const T m = d_max(T(1) - s, e), em = e * m;
         const T P = d_max(xi, em) * d_max(m - xi, em);
-        if (i & 1) lp += F::log2(Pp * F::rcp(mp * (rowK ? T(1) : m)) * (rowK ? T(1) : P));
-        else { Pp = P; mp = m; }
+        if constexpr (sizeof(T) == 8) {                                  // Float64: four rows per reciprocal and logarithm, as in QSimplexFwd
+          Pp *= rowK ? T(1) : P;
+          mp *= rowK ? T(1) : m;
+          if ((i & 3) == 3 || i == RPL - 1) { lp += F::log2(Pp * F::rcp(mp)); Pp = T(1); mp = T(1); }
+        } else {
+          if (i & 1) lp += F::log2(Pp * F::rcp(mp * (rowK ? T(1) : m)) * (rowK ? T(1) : P));
+          else { Pp = P; mp = m; }
+        }
       }
       x[i] = rowK ? cl01<FAST>(T(1) - s) : xi;                                   // :116
       s += xi;

@@ -39,14 +39,27 @@ template <class T, bool LADJ> struct SimplexFwd {
   static constexpr bool HAS_LAST = true, USES_LOGK = true;
   int64_t K;
   T sum_tmp, lp;   // lp accumulates log2 terms
-  __device__ void init() { sum_tmp = T(0); lp = T(0); }
+  // Float64: a lean logarithm is ~40 operations and the log-det term of a row was one of the two per element.  The terms of a column are
+  // SUMMED, so four of them (each >= eps³ = 1e-47: their product cannot underflow) are multiplied before ONE logarithm is taken.
+  static constexpr bool PROD = sizeof(T) == 8;
+  T pr;
+  int np;
+  __device__ void term(T v) {
+    if constexpr (PROD) {
+      pr *= v;
+      if (++np == 4) { lp += Fast<T>::log2(pr); pr = T(1); np = 0; }
+    } else {
+      lp += Fast<T>::log2(v);
+    }
+  }
+  __device__ void init() { sum_tmp = T(0); lp = T(0); pr = T(1); np = 0; }
   __device__ T first(T x, const T* logk) {
     using F = Fast<T>;
     const T e = Num<T>::eps;
     sum_tmp = x;                                                            // Σ_{j<1} x_j for the next row
     if (K < 2) return T(0);
     const T z = x * (T(1) - 2 * e) + e;                                     // :53
-    if (LADJ) lp += F::log2(d_max(x, e) * d_max(T(1) - x, e));              // :130-131
+    if (LADJ) term(d_max(x, e) * d_max(T(1) - x, e));                       // :130-131
     return F::log2(z * F::rcp(T(1) - z)) * Num<T>::log2 + logk[0];          // logit(z) + log(K-1)
   }
   __device__ T mid(int, T x, T lk) {
@@ -60,20 +73,35 @@ template <class T, bool LADJ> struct SimplexFwd {
     if (LADJ) {
       const T m = d_max(T(1) - s, e);                                       // :133
       const T zl = x * F::rcp(m);                                           // :134
-      lp += F::log2(d_max(zl, e) * d_max(T(1) - zl, e) * m);                // :135
+      term(d_max(zl, e) * d_max(T(1) - zl, e) * m);                         // :135
     }
     return o;
   }
   __device__ T last(T) { return T(0); }                                     // row K has no output
   // Julia's max(NaN, ε) is NaN (v_max drops it): a NaN among x_1..x_{K-1} makes the reference's log-det NaN
-  __device__ T result() const { return sum_tmp != sum_tmp ? sum_tmp : -lp * Num<T>::log2; }
+  __device__ T result() const {
+    T l = lp;
+    if constexpr (PROD) l += Fast<T>::log2(pr);                             // (log2(1) = 0 when nothing is pending)
+    return sum_tmp != sum_tmp ? sum_tmp : -l * Num<T>::log2;
+  }
 };
 // simplex.jl:102-120 ; log-det = -logabsdetjac(b, x_out)
 template <class T, bool LADJ> struct SimplexInv {
   static constexpr bool HAS_LAST = true, USES_LOGK = true;
   int64_t K;
   T sum_tmp, lp;
-  __device__ void init() { sum_tmp = T(0); lp = T(0); }
+  static constexpr bool PROD = sizeof(T) == 8;          // as in SimplexFwd: four log-det terms per logarithm in Float64
+  T pr;
+  int np;
+  __device__ void term(T v) {
+    if constexpr (PROD) {
+      pr *= v;
+      if (++np == 4) { lp += Fast<T>::log2(pr); pr = T(1); np = 0; }
+    } else {
+      lp += Fast<T>::log2(v);
+    }
+  }
+  __device__ void init() { sum_tmp = T(0); lp = T(0); pr = T(1); np = 0; }
   static __device__ __forceinline__ T logistic(T v) {   // LogExpFunctions.logistic with its exact 0/1 saturation
     return f_logistic(v);
   }
@@ -84,7 +112,7 @@ template <class T, bool LADJ> struct SimplexInv {
     const T inv12e = T(1) / (T(1) - 2 * e);
     const T z = logistic(y - logk[0]);
     const T x = d_clamp((z - e) * inv12e, T(0), T(1));                      // :109
-    if (LADJ) lp += F::log2(d_max(x, e) * d_max(T(1) - x, e));
+    if (LADJ) term(d_max(x, e) * d_max(T(1) - x, e));
     sum_tmp = x;
     return x;
   }
@@ -99,12 +127,16 @@ template <class T, bool LADJ> struct SimplexInv {
     if (LADJ) {
       const T m = d_max(T(1) - s, e);
       const T zl = x * F::rcp(m);
-      lp += F::log2(d_max(zl, e) * d_max(T(1) - zl, e) * m);
+      term(d_max(zl, e) * d_max(T(1) - zl, e) * m);
     }
     return x;
   }
   __device__ T last(T) { return d_clamp(T(1) - sum_tmp, T(0), T(1)); }      // :116
-  __device__ T result() const { return sum_tmp != sum_tmp ? sum_tmp : lp * Num<T>::log2; }   // NaN rows: as above
+  __device__ T result() const {                                             // NaN rows: as above
+    T l = lp;
+    if constexpr (PROD) l += Fast<T>::log2(pr);
+    return sum_tmp != sum_tmp ? sum_tmp : l * Num<T>::log2;
+  }
 };
 
 // partials of one log-det term t_k(x_k, s_k) of simplex.jl:122-138 (s_k = Σ_{j<k} x_j): used by every Simplex pullback kernel

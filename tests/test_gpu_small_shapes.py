@@ -537,3 +537,40 @@ def test_joint_order_wrap_matches_the_reference_loop(bj, kind, K, N, dt):
     close(host(l2), -np.log(pos.astype(np.float64)).sum(axis=0), dt, scale=K, what="MapLog ladj")
     ye, le = bj.with_logabsdet_jacobian(V.MapExp(), yl2, per_sample=True)
     close(host(ye), pos.astype(np.float64), dt, scale=10, what="MapExp")
+
+
+def test_float64_logit_at_and_next_to_the_bounds(bj, orc):
+    """Round 6: the Float64 Logit stage takes its value as ONE logarithm of the ratio (x-a)/(b-x) built from the two mantissas, and its
+    log-det as one logarithm of the PRODUCT of a pack's terms (of all of a lane's packs in a summed pass) — logit.jl:15-30.  The limits
+    must stay the reference's: ±Inf at the bounds (log-det +Inf), NaN outside the support and for NaN, finite next to the bounds (a
+    product of tiny terms must not vanish before a factor does), summed and per-sample results consistent."""
+    a, b = 0.0, 3.0                                                        # (a bound at 0: the only place Float64 has values 1e-300 away from it)
+    t = bj.Logit(a, b)
+    r = np.random.default_rng(77)
+    dim, N = 64, 96
+    x = r.uniform(a, b, size=(dim, N))
+    x[0, 0], x[1, 1] = a, b                                                # the bounds themselves
+    x[2, 2], x[3, 2] = 1e-300, np.nextafter(b, a)                          # next to each bound, both in one column (not a denormal: the reference's
+    #                                                                        own (x-a)/(b-a) rounds 5e-324/3 to zero)
+    x[:, 3] = a + 3.0 * 10.0 ** r.uniform(-300, -200, size=dim)            # a whole column whose terms multiply to far below 1e-308
+    x[4, 4], x[5, 4] = a - 0.5, b + 0.5                                    # two points outside the support in one pack: the signs must not cancel
+    x[6, 5] = np.nan
+    X = np.asfortranarray(x)
+    xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda().T
+    y, lps = bj.with_logabsdet_jacobian(t, xd, per_sample=True)
+    y, lps = y.cpu().numpy(), lps.cpu().numpy()
+    with np.errstate(all="ignore"):
+        yr = np.log(X - a) - np.log(b - X)
+        lr = -(np.log(X - a) + np.log(b - X) - np.log(b - a)).sum(axis=0)
+    fin = np.isfinite(yr)
+    assert np.array_equal(np.isnan(y), np.isnan(yr)) and np.array_equal(np.isposinf(y), np.isposinf(yr)) and np.array_equal(np.isneginf(y), np.isneginf(yr))
+    assert np.abs(y[fin] - yr[fin]).max() <= 1e-6 * (1.0 + np.abs(yr[fin]).max()) and (np.abs(y[fin] - yr[fin]) <= 1e-12 * (1.0 + np.abs(yr[fin]))).all()
+    finl = np.isfinite(lr)
+    assert np.array_equal(np.isnan(lps), np.isnan(lr)) and np.array_equal(np.isposinf(lps), np.isposinf(lr))
+    assert finl[3] and np.isfinite(lps[3]), "a column of terms near 1e-250 each: the product underflows, the log-det does not"
+    assert (np.abs(lps[finl] - lr[finl]) <= 1e-10 * np.abs(lr[finl]) + 1e-9).all()
+    # the summed pass (one logarithm per lane) on the columns that are finite
+    cols = np.where(finl)[0]
+    xs = xd[:, torch.from_numpy(cols).cuda()].T.contiguous().T
+    _, ls = bj.with_logabsdet_jacobian(t, xs)
+    assert abs(float(ls) - lr[cols].sum()) <= 1e-9 * abs(lr[cols].sum())
