@@ -97,6 +97,7 @@ SIGNATURES = {
     "bjx_pd_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_pd_vec_vjp": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64]),
     "bjx_scale_matrix": (_i, [_vp, _i, _i, _vp, _vp, _vp] + _tail),
+    "bjx_scale_matrix_chain": (_i, [_vp, _i, _i, _vp, C.POINTER(BjxOp), _i, _vp, _vp, _vp, _i64, _i64, _u32]),
     "bjx_scale_matrix_vjp_params": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _d, _vp, _i64, _i64]),
     "bjx_planar": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp] + _tail),
     "bjx_pack_vectors": (_i, [_vp, _i, _i, C.POINTER(_vp), _i64, _vp]),

