@@ -3217,6 +3217,59 @@ def _marshal_ops(ops, xc, dim):
 _MATRIX_CHAIN_KINDS = (L.OP_EXP, L.OP_LOG, L.OP_SHIFT, L.OP_SCALE, L.OP_SCALE_INV)
 
 
+_AFFINE_KINDS = (L.OP_SHIFT, L.OP_SCALE, L.OP_SCALE_INV)
+
+
+def _merge_affine_tail(d, ops, y):
+    """The runs of three or more affine stages of a density / sampling chain — the tail of the inverse transform (Shift / Scale with scalars)
+    followed by the whitening (x − μ)/σ, (any run of them in the list) — each collapsed into ONE Scale and
+    ONE Shift with per-row parameters: ((x + s)·c − μ)/σ = x·(c/σ) + (s·c − μ)/σ.  The chain kernel is issue-bound on such passes (six stages,
+    nothing stored: 50 % of the HBM peak; four: 59 %), the log-det is unchanged (Σ log|c/σ| is what the Scale stages add up to).  The merged
+    vectors are kept on the distribution object, keyed by the scalars and the (id, version) of the tensors."""
+    if not isinstance(y, torch.Tensor) or y.dim() != 2:
+        return ops
+    dim = y.shape[0]
+    out, i, n, run_no = [], 0, len(ops), 0
+    while i < n:
+        j = i
+        while j < n and ops[j][0] in _AFFINE_KINDS and ops[j][2] is None and isinstance(ops[j][1], (int, float, torch.Tensor)):
+            j += 1
+        if j - i < 3:
+            out.extend(ops[i:max(j, i + 1)])
+            i = max(j, i + 1)
+            continue
+        run = ops[i:j]
+        key = (y.dtype, y.device.index, dim, run_no) + tuple((k, id(p), p._version) if isinstance(p, torch.Tensor) else (k, float(p)) for k, p, _ in run)
+        cache = d.__dict__.setdefault("_affine_runs", {})
+        hit = cache.get(run_no)
+        if hit is None or hit[0] != key:
+            A = torch.ones(dim, dtype=torch.float64, device=y.device)
+            B = torch.zeros(dim, dtype=torch.float64, device=y.device)
+            ok = True
+            for kind, p, _ in run:
+                pv = p.to(device=y.device, dtype=torch.float64).reshape(-1) if isinstance(p, torch.Tensor) else float(p)
+                if isinstance(pv, torch.Tensor) and pv.numel() not in (1, dim):
+                    ok = False
+                    break
+                if kind == L.OP_SHIFT:
+                    B = B + pv
+                elif kind == L.OP_SCALE:
+                    A, B = A * pv, B * pv
+                else:
+                    A, B = A / pv, B / pv
+            if not ok:
+                out.extend(run)
+                i = j
+                run_no += 1
+                continue
+            hit = (key, A.to(y.dtype).contiguous(), B.to(y.dtype).contiguous())
+            cache[run_no] = hit
+        out.extend([(L.OP_SCALE, hit[1], None), (L.OP_SHIFT, hit[2], None)])
+        i = j
+        run_no += 1
+    return out
+
+
 def _logpdf_full_cov_fused(d, ib, y):
     """Full-covariance base, fusable inverse transform, dim <= 128: ONE launch when the inverse is at most three stages of exp / log / Shift /
     Scale / Scale⁻¹ (bjx_scale_matrix_chain, round 6); else (round 5) TWO launches and three array passes instead of four
@@ -3300,7 +3353,7 @@ def logpdf(td: TransformedDistribution, y, reference_shape: bool = False):
         return lp + lj
     ops = _fused_ops(ib)
     if ops is not None and len(ops) + len(base) <= L.BJX_MAX_OPS:
-        return _run_chain(list(ops) + base, y, True, True, store=False)[1]
+        return _run_chain(_merge_affine_tail(d, list(ops) + base[:-1], y) + base[-1:], y, True, True, store=False)[1]
     if isinstance(ib, ComposedFunction) and len(ib._plan()[0]) == 1:       # inverse(l8 ∘ … ∘ l1): the planner's single inverse run
         ib = ib._plan()[0][0]
     pl = ib.orig if isinstance(ib, Inverse) else None

@@ -71,3 +71,31 @@ def test_a_new_tensor_at_a_recycled_address_is_not_mistaken_for_the_old_one(bj):
         outs.append(w.data_ptr())
         del sp, w, h, d                                           # the caching allocator hands the same blocks to the next round
     assert len(set(outs)) < len(outs), "the allocator did not recycle an address: the test did not exercise what it is for"
+
+
+def test_merged_affine_tail_of_a_density_chain_follows_in_place_updates(bj):
+    """logpdf(transformed(MvNormal(μ, σ), exp ∘ Shift ∘ Scale)) collapses the affine stages at the end of its chain (tail of the inverse
+    transform + the whitening) into one Scale and one Shift with per-row vectors kept on the distribution (`_merge_affine_tail`,
+    src/transformed_distribution.jl:164-169): the kept vectors must follow an IN-PLACE update of μ or σ, and the value must be the density."""
+    import numpy as np
+    torch.manual_seed(3)
+    dim, N = 64, 1000
+    mu = torch.randn(dim, device="cuda")
+    sigma = torch.rand(dim, device="cuda") + 0.5
+    b = bj.elementwise(bj.exp) @ bj.Shift(0.1) @ bj.Scale(0.5)
+    td = bj.transformed(bj.MvNormal(mu, sigma), b)
+    y = torch.exp(0.3 * torch.randn(N, dim, device="cuda")).T
+
+    def ref():
+        x = (torch.log(y.double()) - 0.1) / 0.5
+        z = (x - mu.double()[:, None]) / sigma.double()[:, None]
+        return (-0.5 * z * z - 0.5 * np.log(2 * np.pi) - torch.log(sigma.double())[:, None]).sum(0) - (torch.log(y.double()).sum(0) + dim * np.log(0.5))
+
+    lp0 = bj.logpdf(td, y)
+    assert "_affine_runs" in td.dist.__dict__, "the density chain did not take the merged form"
+    assert torch.allclose(lp0.double(), ref(), rtol=1e-4, atol=1e-3 * dim)
+    mu.add_(0.7)                                            # in place: same tensor object, new version
+    sigma.mul_(1.3)
+    lp1 = bj.logpdf(td, y)
+    assert torch.allclose(lp1.double(), ref(), rtol=1e-4, atol=1e-3 * dim)
+    assert not torch.allclose(lp1, lp0)
