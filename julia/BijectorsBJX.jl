@@ -1654,6 +1654,31 @@ function base_logpdf(d::Distributions.MvNormal, x::ROCMatrix{T}) where {T<:BjxFl
 end
 base_logpdf(d::Distributions.Distribution, x::ROCMatrix) = Distributions.logpdf(d, x)
 
+# The affine stages at the END of a density chain — the tail of the inverse transform (Shift / Scale / Scale⁻¹ with host scalars) followed by the
+# whitening (x − μ)/σ — as ONE Scale and ONE Shift with per-row vectors: ((x + s)·c − μ)/σ = x·(c/σ) + (s·c − μ)/σ.  The chain kernel is
+# issue-bound on read-only passes (six stages 50 % of the HBM peak, four 64 %: profiles/r06_rows.md; `_merge_affine_tail` of the Python mirror);
+# the log-det is unchanged (Σ log|c/σ| is what the Scale stages add up to).
+function merge_affine_tail(o::Vector{BjxOp}, μ::AbstractVector, σ::AbstractVector, ::Type{T}, keep) where {T}
+    affine = (Int32(OP_SHIFT), Int32(OP_SCALE), Int32(OP_SCALE_INV))
+    k = length(o)
+    while k > 0 && o[k].kind in affine && o[k].param_len == 1 && o[k].v0 == C_NULL
+        k -= 1
+    end
+    A = ones(Float64, length(μ)); B = zeros(Float64, length(μ))
+    for j in (k + 1):length(o)
+        p = o[j].p0
+        if o[j].kind == Int32(OP_SHIFT)
+            B .+= p
+        elseif o[j].kind == Int32(OP_SCALE)
+            A .*= p; B .*= p
+        else
+            A ./= p; B ./= p
+        end
+    end
+    B .-= μ; A ./= σ; B ./= σ
+    return vcat(o[1:k], param_op(OP_SCALE, A, T, keep), param_op(OP_SHIFT, B, T, keep))
+end
+
 function Distributions.logpdf(td::Bijectors.MvTransformed, y::ROCMatrix{T}) where {T<:BjxFloat}
     if td.dist isa Distributions.MvNormal && diag_normal(td.dist)
         keep = Any[]
@@ -1663,7 +1688,7 @@ function Distributions.logpdf(td::Bijectors.MvTransformed, y::ROCMatrix{T}) wher
         if o !== nothing && length(o) + 3 <= 8
             # ONE pass over y: the inverse chain, the whitening and the standard-normal density are ops of the same launch;
             # the pre-image is not stored (src/transformed_distribution.jl:164-169 without its two intermediate arrays)
-            return stdnormal_chain(y, vcat(o, param_op(OP_SHIFT, -μ, T, keep), param_op(OP_SCALE_INV, σ, T, keep)), keep)
+            return stdnormal_chain(y, merge_affine_tail(o, μ, σ, T, keep), keep)
         end
         # a PlanarLayer flow with a standard-normal base: the inverse flow with BJX_BASE_STDNORMAL, pre-image not stored
         if all(iszero, μ) && all(isone, σ)
